@@ -1,0 +1,96 @@
+"""ctypes binding of libbssm_amd.so (include/bssm_amd.h).  The library is the product: if it is
+missing or no HIP device is usable the compute entry points fail loudly -- there is no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbssm_amd.so")
+
+BSSM_OK, BSSM_WARN_DEGENERATE = 0, 1
+PLAN_KEEP_HISTORY, PLAN_FORCE_GRID, PLAN_FORCE_WG = 1, 2, 4
+
+c_double_p = C.POINTER(C.c_double)
+c_u32_p = C.POINTER(C.c_uint32)
+
+
+class UngModel(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n", "m", "k", "Ztv", "Ttv", "Rtv", "Dtv", "Ctv", "Htv", "distribution",
+                                          "n_xreg", "max_iter", "local_approx")] + \
+               [("conv_tol", C.c_double), ("phi", C.c_double)] + \
+               [(k, c_double_p) for k in ("y", "Z", "T", "R", "a1", "P1", "D", "C", "xreg", "beta", "u", "H",
+                                          "initial_mode")]
+
+
+class FilterOut(C.Structure):
+    _fields_ = [(k, c_double_p) for k in ("at", "att", "Pt", "Ptt", "alphahat", "Vt", "weights", "alpha")] + \
+               [("indices", c_u32_p), ("logLik", C.c_double)]
+
+
+class IsJob(C.Structure):
+    _fields_ = [("n_stored", C.c_int32), ("first", C.c_int32), ("count", C.c_int32),
+                ("models", C.POINTER(UngModel)), ("modes", c_double_p), ("approx_loglik", c_double_p),
+                ("counts", c_u32_p), ("sampling_method", C.c_int32), ("is_type", C.c_int32),
+                ("output_type", C.c_int32), ("nsim", C.c_uint32), ("seed", C.c_uint32), ("n_threads", C.c_int32)]
+
+
+class BssmAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BssmAmdError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(bssm_amd has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.bssm_amd_last_error.restype = C.c_char_p
+        L.bssm_amd_version.restype = C.c_char_p
+        L.bssm_plan_create.restype = C.c_void_p
+        L.bssm_plan_create.argtypes = [C.POINTER(UngModel), C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.bssm_plan_destroy.argtypes = [C.c_void_p]
+        L.bssm_plan_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.bssm_plan_loglik.argtypes = [C.c_void_p, C.c_void_p, c_double_p]
+        L.bssm_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32), c_double_p]
+        L.bssm_plan_device_outputs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.bssm_plan_time.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, c_double_p]
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise BssmAmdError(f"bssm_amd error {rc}: {lib().bssm_amd_last_error().decode()}")
+    return rc
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def pack_model(arr: dict):
+    """dict from models.model_arrays -> (UngModel, keepalive list)"""
+    s = UngModel()
+    for k in ("n", "m", "k", "Ztv", "Ttv", "Rtv", "Dtv", "Ctv", "Htv", "distribution", "n_xreg", "max_iter",
+              "local_approx"):
+        setattr(s, k, int(arr[k]))
+    s.conv_tol = float(arr["conv_tol"])
+    s.phi = float(arr["phi"])
+    keep = []
+    for k in ("y", "Z", "T", "R", "a1", "P1", "D", "C", "xreg", "beta", "u", "H", "initial_mode"):
+        a = arr.get(k)
+        if a is not None and a.size == 0:
+            a = None
+        if a is not None:
+            a = np.asfortranarray(a, dtype=np.float64)
+            keep.append(a)
+        setattr(s, k, dptr(a))
+    return s, keep

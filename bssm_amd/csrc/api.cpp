@@ -1,0 +1,655 @@
+// api.cpp -- the C ABI (include/bssm_amd.h): host orchestration around the HIP kernels.
+// There is no CPU compute path in this library: every filter runs on the HIP device or fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/bssm_amd.h"
+#include "host_model.h"
+#include "pf_device.h"
+#include "pf_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                               \
+      return BSSM_ERR_HIP;                                                                     \
+    }                                                                                          \
+  } while (0)
+
+bool have_device() {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return false;
+  return cnt > 0;
+}
+int no_device() {
+  return fail(BSSM_ERR_NO_DEVICE,
+              "no HIP device available: bssm_amd has no CPU fallback (the particle filters run only on the GPU)");
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t b) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = b;
+    if (b == 0) return hipSuccess;
+    return hipMalloc(&p, b);
+  }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+template <class F>
+void parallel_for(int count, int threads, F fn) {
+  threads = std::max(1, std::min(threads, count));
+  if (threads == 1) { for (int i = 0; i < count; i++) fn(i); return; }
+  std::atomic<int> next(0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; t++)
+    pool.emplace_back([&]() { for (int i = next++; i < count; i = next++) fn(i); });
+  for (auto& th : pool) th.join();
+}
+
+// ------------------------------------------------------------------ a batch of filters on the device
+struct DeviceBatch {
+  bssm::FilterBatch fb{};
+  DevBuf mats, obs, init, phi, hist, indices, weights, loglik, ws;
+  bssm::GridWorkspace gws{};
+  bool use_grid = false;
+  std::vector<double> const_terms;  // per filter, added to the device log-likelihood on the host
+
+  // tables: one per filter (all with the same MP/KP/mats_tstride)
+  int upload(const std::vector<bssm::FilterTables>& tabs, const std::vector<double>& phis, int n, int m, int k, int N,
+             int dist, int psi, bool keep_hist, unsigned path_flags) {
+    const int F = (int)tabs.size();
+    const int MP = tabs[0].MP, KP = tabs[0].KP;
+    fb.n = n; fb.m = m; fb.k = k; fb.MP = MP; fb.KP = KP; fb.N = N; fb.F = F; fb.dist = dist; fb.psi = psi;
+    const size_t ms = tabs[0].mats.size(), os = tabs[0].obs.size(), is = tabs[0].init.size();
+    std::vector<double> hm(ms * F), ho(os * F), hi(is * F);
+    for (int f = 0; f < F; f++) {
+      if (tabs[f].mats.size() != ms || tabs[f].MP != MP || tabs[f].KP != KP) return fail(BSSM_ERR_INVALID, "filters of a batch must share padding and time-variation");
+      std::memcpy(hm.data() + ms * f, tabs[f].mats.data(), ms * sizeof(double));
+      std::memcpy(ho.data() + os * f, tabs[f].obs.data(), os * sizeof(double));
+      std::memcpy(hi.data() + is * f, tabs[f].init.data(), is * sizeof(double));
+    }
+    HIP_TRY(mats.alloc(hm.size() * sizeof(double)));
+    HIP_TRY(obs.alloc(ho.size() * sizeof(double)));
+    HIP_TRY(init.alloc(hi.size() * sizeof(double)));
+    HIP_TRY(phi.alloc(F * sizeof(double)));
+    HIP_TRY(hipMemcpy(mats.p, hm.data(), mats.bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(obs.p, ho.data(), obs.bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(init.p, hi.data(), init.bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(phi.p, phis.data(), phi.bytes, hipMemcpyHostToDevice));
+    fb.mats = mats.as<double>(); fb.mats_fstride = ms; fb.mats_tstride = tabs[0].mats_tstride;
+    fb.obs = obs.as<double>(); fb.obs_fstride = os;
+    fb.init = init.as<double>(); fb.init_fstride = is;
+    fb.phi = phi.as<double>();
+    HIP_TRY(loglik.alloc(F * sizeof(double)));
+    fb.loglik = loglik.as<double>();
+    if (keep_hist) {
+      HIP_TRY(hist.alloc((size_t)F * (n + 1) * m * N * sizeof(double)));
+      HIP_TRY(indices.alloc((size_t)F * n * N * sizeof(uint32_t)));
+      HIP_TRY(weights.alloc((size_t)F * (n + 1) * N * sizeof(double)));
+      fb.alpha_hist = hist.as<double>(); fb.indices = indices.as<uint32_t>(); fb.weights = weights.as<double>();
+    }
+    // kernel shape: workgroup-resident when the particle system fits one CU's LDS and there are
+    // enough filters to fill the chip (or the filter is small); otherwise one launch per time step.
+    const int cap = bssm::wg_filter_capacity(MP);
+    use_grid = !(N <= cap && (F >= 32 || N <= 2048));
+    if (const char* env = std::getenv("BSSM_AMD_FORCE_PATH")) {
+      if (!std::strcmp(env, "grid")) use_grid = true;
+      if (!std::strcmp(env, "wg")) use_grid = false;
+    }
+    if (path_flags & BSSM_PLAN_FORCE_GRID) use_grid = true;
+    if (path_flags & BSSM_PLAN_FORCE_WG) use_grid = false;
+    if (!use_grid && N > cap) return fail(BSSM_ERR_INVALID, "nsim exceeds the workgroup-resident capacity");
+    if (use_grid) {
+      int B, chunk;
+      const size_t bytes = bssm::grid_workspace_bytes(fb, &B, &chunk);
+      if (B > 256) return fail(BSSM_ERR_UNSUPPORTED, "nsim too large for the grid filter (max 524288)");
+      HIP_TRY(ws.alloc(bytes));
+      bssm::grid_workspace_carve(fb, ws.p, &gws);
+    }
+    return BSSM_OK;
+  }
+
+  int run(uint32_t seed, uint32_t stream0, hipStream_t st) {
+    fb.seed = seed; fb.stream0 = stream0;
+    if (fb.alpha_hist) {  // the reference zero-fills its outputs (src/R_bootstrap_filter.cpp:136-138)
+      HIP_TRY(hipMemsetAsync(hist.p, 0, hist.bytes, st));
+      HIP_TRY(hipMemsetAsync(indices.p, 0, indices.bytes, st));
+      HIP_TRY(hipMemsetAsync(weights.p, 0, weights.bytes, st));
+    }
+    HIP_TRY(use_grid ? bssm::launch_grid_filter(fb, gws, st) : bssm::launch_wg_filter(fb, st));
+    return BSSM_OK;
+  }
+
+  int fetch_loglik(hipStream_t st, double* out) {
+    HIP_TRY(hipMemcpyAsync(out, loglik.p, fb.F * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int f = 0; f < fb.F; f++) out[f] += const_terms.empty() ? 0.0 : const_terms[f];
+    return BSSM_OK;
+  }
+};
+
+bool is_gaussian_type_ok(int gaussian, int model_type) {
+  if (gaussian) return model_type >= 1 && model_type <= 3;  // ssm_ulg, bsm_lg, ar1_lg (R/model_type.R:2-8)
+  return model_type >= 1 && model_type <= 4;                // ssm_ung, bsm_ng, svm, ar1_ng
+}
+
+void transpose_to(const std::vector<double>& src, int rows, int cols, double* dst) {  // src rows x cols col-major -> cols x rows
+  for (int j = 0; j < cols; j++) for (int i = 0; i < rows; i++) dst[j + (size_t)cols * i] = src[i + (size_t)rows * j];
+}
+
+// one filter, full outputs: shared by bsf / bsf_smoother / psi_smoother
+int run_single_filter(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, bool psi, bool smoother,
+                      bssm_filter_out* out) {
+  if (!out) return fail(BSSM_ERR_INVALID, "out is NULL");
+  if (nsim < 1) return fail(BSSM_ERR_INVALID, "nsim must be positive");
+  bssm::HostModel hm;
+  const std::string err = bssm::ingest_model(model, psi, &hm);
+  if (!err.empty()) return fail(BSSM_ERR_INVALID, err);
+  if (!have_device()) return no_device();
+  const int n = hm.n, m = hm.m, N = (int)nsim;
+  std::vector<bssm::FilterTables> tabs(1);
+  double base_ll = 0.0;
+  const int MP = bssm::pad_dim(m);
+  if (psi) {
+    bssm::PsiSetup su;
+    if (!bssm::psi_setup(hm, nullptr, &su)) {  // non-finite Vt/Ct: the reference returns -Inf (model_ssm_nlg.cpp:988-990 analogue)
+      out->logLik = -INFINITY;
+      return BSSM_WARN_DEGENERATE;
+    }
+    bssm::build_psi_tables(hm, su, MP, &tabs[0]);
+    base_ll = su.approx_loglik;  // src/model_ssm_ung.cpp:561
+  } else {
+    bssm::build_bsf_tables(hm, MP, bssm::pad_dim(hm.k), &tabs[0]);
+    base_ll = bssm::const_term(hm);  // src/model_ssm_ung.cpp:690-710
+  }
+  DeviceBatch db;
+  int rc = db.upload(tabs, {hm.phi}, n, m, hm.k, N, hm.distribution, psi ? 1 : 0, true, 0);
+  if (rc) return rc;
+  hipStream_t st = nullptr;
+  if ((rc = db.run(seed, 0, st))) return rc;
+  double ll = 0;
+  HIP_TRY(hipMemcpy(&ll, db.loglik.p, sizeof(double), hipMemcpyDeviceToHost));
+  const bool degenerate = !std::isfinite(ll);
+  out->logLik = degenerate ? -INFINITY : ll + base_ll;
+
+  const size_t hist_elems = (size_t)(n + 1) * m * N;
+  DevBuf cube, smooth, d_mean, d_cov, d_att, d_Ptt;
+  const double* final_hist = db.hist.as<double>();
+  if (smoother) {  // filter_smoother + summary (src/R_bootstrap_filter.cpp:368-369, src/R_psi.cpp:94-95)
+    HIP_TRY(smooth.alloc(hist_elems * sizeof(double)));
+    HIP_TRY(bssm::launch_backtrace(db.hist.as<double>(), db.indices.as<uint32_t>(), smooth.as<double>(), 1, n, m, N, st));
+    final_hist = smooth.as<double>();
+    if (out->alphahat || out->Vt) {
+      HIP_TRY(d_mean.alloc((size_t)(n + 1) * m * sizeof(double)));
+      HIP_TRY(d_cov.alloc((size_t)(n + 1) * m * m * sizeof(double)));
+      HIP_TRY(bssm::launch_summary(final_hist, d_mean.as<double>(), d_cov.as<double>(), 1, n + 1, m, N, st));
+      std::vector<double> hmean((size_t)(n + 1) * m);
+      HIP_TRY(hipMemcpy(hmean.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost));
+      if (out->alphahat) transpose_to(hmean, m, n + 1, out->alphahat);  // arma::inplace_trans(alphahat)
+      if (out->Vt) HIP_TRY(hipMemcpy(out->Vt, d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost));
+    }
+  } else if (out->at || out->att || out->Pt || out->Ptt) {  // filter_summary (src/R_bootstrap_filter.cpp:143-147)
+    HIP_TRY(d_mean.alloc((size_t)(n + 1) * m * sizeof(double)));
+    HIP_TRY(d_att.alloc((size_t)n * m * sizeof(double)));
+    HIP_TRY(d_cov.alloc((size_t)(n + 1) * m * m * sizeof(double)));
+    HIP_TRY(d_Ptt.alloc((size_t)n * m * m * sizeof(double)));
+    HIP_TRY(bssm::launch_filter_summary(final_hist, db.weights.as<double>(), d_mean.as<double>(), d_att.as<double>(),
+                                        d_cov.as<double>(), d_Ptt.as<double>(), 1, n, m, N, st));
+    std::vector<double> h1((size_t)(n + 1) * m), h2((size_t)n * m);
+    HIP_TRY(hipMemcpy(h1.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h2.data(), d_att.p, d_att.bytes, hipMemcpyDeviceToHost));
+    if (out->at) transpose_to(h1, m, n + 1, out->at);
+    if (out->att) transpose_to(h2, m, n, out->att);
+    if (out->Pt) HIP_TRY(hipMemcpy(out->Pt, d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost));
+    if (out->Ptt) HIP_TRY(hipMemcpy(out->Ptt, d_Ptt.p, d_Ptt.bytes, hipMemcpyDeviceToHost));
+  }
+  if (out->alpha) {
+    HIP_TRY(cube.alloc(hist_elems * sizeof(double)));
+    HIP_TRY(bssm::launch_to_cube(final_hist, cube.as<double>(), 1, n + 1, m, N, st));
+    HIP_TRY(hipMemcpy(out->alpha, cube.p, cube.bytes, hipMemcpyDeviceToHost));
+  }
+  if (out->weights) HIP_TRY(hipMemcpy(out->weights, db.weights.p, db.weights.bytes, hipMemcpyDeviceToHost));
+  if (out->indices) HIP_TRY(hipMemcpy(out->indices, db.indices.p, db.indices.bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipDeviceSynchronize());
+  return degenerate ? BSSM_WARN_DEGENERATE : BSSM_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+int bssm_amd_device_count(void) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  return cnt;
+}
+const char* bssm_amd_last_error(void) { return g_err.c_str(); }
+const char* bssm_amd_version(void) { return "bssm_amd 0.1 (gfx950)"; }
+
+void bssm_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  const bssm::u32x4 r = bssm::philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+  out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+int bssm_bsf(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int gaussian, int model_type,
+             bssm_filter_out* out) {
+  if (gaussian && model_type == 0)
+    return fail(BSSM_ERR_UNSUPPORTED, "Bootstrap particle filtering for multivariate gaussian model is not yet supported. ");
+  if (!is_gaussian_type_ok(gaussian, model_type)) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
+  if (model && (gaussian != 0) != (model->distribution == BSSM_GAUSSIAN))
+    return fail(BSSM_ERR_INVALID, "gaussian flag and model->distribution disagree");
+  return run_single_filter(model, nsim, seed, false, false, out);
+}
+
+int bssm_bsf_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int gaussian, int model_type,
+                      bssm_filter_out* out) {
+  if (gaussian && model_type == 0)
+    return fail(BSSM_ERR_UNSUPPORTED, "Bootstrap particle smoothing for multivariate gaussian model is not yet supported. ");
+  if (!is_gaussian_type_ok(gaussian, model_type)) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
+  if (model && (gaussian != 0) != (model->distribution == BSSM_GAUSSIAN))
+    return fail(BSSM_ERR_INVALID, "gaussian flag and model->distribution disagree");
+  return run_single_filter(model, nsim, seed, false, true, out);
+}
+
+int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int model_type, bssm_filter_out* out) {
+  if (!is_gaussian_type_ok(0, model_type)) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
+  return run_single_filter(model, nsim, seed, true, true, out);
+}
+
+int bssm_psi_setup(const bssm_ung_model* model, const double* is_mode, double* approx_y, double* approx_H, double* mode,
+                   double* scales, double* approx_loglik, double* alphahat, double* Vt, double* Ct) {
+  bssm::HostModel hm;
+  const std::string err = bssm::ingest_model(model, is_mode == nullptr, &hm);
+  if (!err.empty()) return fail(BSSM_ERR_INVALID, err);
+  bssm::PsiSetup su;
+  const bool ok = bssm::psi_setup(hm, is_mode, &su);
+  auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
+  cp(approx_y, su.approx_y); cp(approx_H, su.approx_H); cp(mode, su.mode); cp(scales, su.scales);
+  cp(alphahat, su.alphahat); cp(Vt, su.Vt); cp(Ct, su.Ct);
+  if (approx_loglik) *approx_loglik = su.approx_loglik;
+  return ok ? BSSM_OK : BSSM_ERR_NUMERIC;
+}
+
+int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed,
+                                  uint32_t stream0, uint32_t n_rep, double* loglik) {
+  if (!loglik || n_rep < 1) return fail(BSSM_ERR_INVALID, "loglik NULL or n_rep < 1");
+  if (sampling_method != BSSM_PSI && sampling_method != BSSM_BSF)
+    return fail(BSSM_ERR_UNSUPPORTED, "sampling_method must be 1 (psi) or 2 (bsf); SPDK is not a particle filter path");
+  const bool psi = sampling_method == BSSM_PSI;
+  bssm::HostModel hm;
+  const std::string err = bssm::ingest_model(model, psi || nsim == 0, &hm);
+  if (!err.empty()) return fail(BSSM_ERR_INVALID, err);
+  if (nsim == 0) {  // src/model_ssm_ung.cpp:214-234
+    const double a = bssm::approx_loglik_only(hm);
+    for (uint32_t r = 0; r < n_rep; r++) loglik[r] = a;
+    return BSSM_OK;
+  }
+  if (!have_device()) return no_device();
+  std::vector<bssm::FilterTables> tabs(1);
+  double base = 0;
+  const int MP = bssm::pad_dim(hm.m);
+  if (psi) {
+    bssm::PsiSetup su;
+    if (!bssm::psi_setup(hm, nullptr, &su)) { for (uint32_t r = 0; r < n_rep; r++) loglik[r] = -INFINITY; return BSSM_WARN_DEGENERATE; }
+    bssm::build_psi_tables(hm, su, MP, &tabs[0]);
+    base = su.approx_loglik;
+  } else {
+    bssm::build_bsf_tables(hm, MP, bssm::pad_dim(hm.k), &tabs[0]);
+    base = bssm::const_term(hm);
+  }
+  // replicas share one table: stride 0 between filters
+  DeviceBatch db;
+  int rc = db.upload(tabs, {hm.phi}, hm.n, hm.m, hm.k, (int)nsim, hm.distribution, psi, false, 0);
+  if (rc) return rc;
+  db.fb.F = (int)n_rep;
+  db.fb.mats_fstride = 0; db.fb.obs_fstride = 0; db.fb.init_fstride = 0;
+  std::vector<double> phis(n_rep, hm.phi);
+  HIP_TRY(db.phi.alloc(n_rep * sizeof(double)));
+  HIP_TRY(hipMemcpy(db.phi.p, phis.data(), db.phi.bytes, hipMemcpyHostToDevice));
+  db.fb.phi = db.phi.as<double>();
+  HIP_TRY(db.loglik.alloc(n_rep * sizeof(double)));
+  db.fb.loglik = db.loglik.as<double>();
+  const int cap = bssm::wg_filter_capacity(MP);
+  db.use_grid = !((int)nsim <= cap && (n_rep >= 32 || nsim <= 2048));
+  if (const char* env = std::getenv("BSSM_AMD_FORCE_PATH")) {
+    if (!std::strcmp(env, "grid")) db.use_grid = true;
+    if (!std::strcmp(env, "wg") && (int)nsim <= cap) db.use_grid = false;
+  }
+  if (db.use_grid) {
+    int B, chunk;
+    const size_t bytes = bssm::grid_workspace_bytes(db.fb, &B, &chunk);
+    if (B > 256) return fail(BSSM_ERR_UNSUPPORTED, "nsim too large for the grid filter");
+    HIP_TRY(db.ws.alloc(bytes));
+    bssm::grid_workspace_carve(db.fb, db.ws.p, &db.gws);
+  }
+  db.const_terms.assign(n_rep, base);
+  if ((rc = db.run(seed, stream0, nullptr))) return rc;
+  if ((rc = db.fetch_loglik(nullptr, loglik))) return rc;
+  bool deg = false;
+  for (uint32_t r = 0; r < n_rep; r++) if (!std::isfinite(loglik[r])) { loglik[r] = -INFINITY; deg = true; }
+  return deg ? BSSM_WARN_DEGENERATE : BSSM_OK;
+}
+
+int bssm_nongaussian_loglik(const bssm_ung_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed,
+                            int model_type, double* loglik) {
+  if (!is_gaussian_type_ok(0, model_type)) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
+  return bssm_nongaussian_loglik_batch(model, nsim, sampling_method, seed, 0, 1, loglik);
+}
+
+int bssm_update_model_builtin(int model_type, const int32_t* flags, const double* theta, int32_t n_par,
+                              bssm_ung_model* model, double* T, double* R, double* P1, double* a1, double* C,
+                              double* beta) {
+  if (!flags || !theta || !model) return fail(BSSM_ERR_INVALID, "NULL argument");
+  const std::string err = bssm::update_model_builtin(model_type, flags, theta, n_par, model, T, R, P1, a1, C, beta);
+  if (!err.empty()) return fail(BSSM_ERR_UNSUPPORTED, err);
+  return BSSM_OK;
+}
+
+// ------------------------------------------------------------------ IS post-correction
+int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, double* alpha, double* alphahat_i,
+                       double* Vt_i) {
+  if (!job || !weights) return fail(BSSM_ERR_INVALID, "job/weights NULL");
+  const int cnt = job->count;
+  if (cnt <= 0) return BSSM_OK;
+  if (job->sampling_method != BSSM_PSI && job->sampling_method != BSSM_BSF)
+    return fail(BSSM_ERR_UNSUPPORTED, "sampling_method must be psi or bsf");
+  if (job->output_type < 1 || job->output_type > 3) return fail(BSSM_ERR_INVALID, "output_type must be 1..3");
+  if (job->output_type == 1 && !alpha) return fail(BSSM_ERR_INVALID, "alpha buffer required for output_type 1");
+  if (job->output_type == 2 && (!alphahat_i || !Vt_i)) return fail(BSSM_ERR_INVALID, "summary buffers required for output_type 2");
+  const bool psi = job->sampling_method == BSSM_PSI;
+  if (psi && !job->modes) return fail(BSSM_ERR_INVALID, "modes required for psi");
+  if (!psi && !job->approx_loglik) return fail(BSSM_ERR_INVALID, "approx_loglik required for bsf");
+  if (!job->counts) return fail(BSSM_ERR_INVALID, "counts NULL");
+
+  // per-draw host set-up (the reference does this inside its OpenMP region, src/approx_mcmc.cpp:372-373)
+  std::vector<bssm::HostModel> hms(cnt);
+  std::vector<bssm::FilterTables> tabs(cnt);
+  std::vector<std::string> errs(cnt);
+  std::vector<char> bad(cnt, 0);
+  const int n = job->models[0].n, m = job->models[0].m, k = job->models[0].k;
+  const int MP = bssm::pad_dim(m), KP = psi ? MP : bssm::pad_dim(k);
+  // a batch shares one table layout: force time-varying rows when any draw needs them
+  parallel_for(cnt, job->n_threads, [&](int i) {
+    errs[i] = bssm::ingest_model(&job->models[i], false, &hms[i]);
+    if (!errs[i].empty()) return;
+    if (hms[i].n != n || hms[i].m != m || hms[i].k != k) { errs[i] = "all draws must share n, m, k"; return; }
+    if (psi) {
+      bssm::PsiSetup su;
+      if (!bssm::psi_setup(hms[i], job->modes + (size_t)n * i, &su)) bad[i] = 1;
+      bssm::build_psi_tables(hms[i], su, MP, &tabs[i]);
+    } else {
+      bssm::build_bsf_tables(hms[i], MP, KP, &tabs[i]);
+    }
+  });
+  for (int i = 0; i < cnt; i++) if (!errs[i].empty()) return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]);
+  if (!have_device()) return no_device();
+  if (!psi) {  // equalise mats rows (time-invariant draws replicate to n rows if any draw is time-varying)
+    int ts = 0;
+    for (auto& t : tabs) ts = std::max(ts, t.mats_tstride);
+    for (auto& t : tabs) if (t.mats_tstride != ts) {
+      std::vector<double> rep((size_t)n * ts);
+      for (int tt = 0; tt < n; tt++) std::memcpy(rep.data() + (size_t)tt * ts, t.mats.data(), ts * sizeof(double));
+      t.mats.swap(rep);
+      t.mats_tstride = ts;
+    }
+  }
+  const int dist = hms[0].distribution;
+  const bool need_hist = job->output_type != 3;
+
+  // group draws by particle count (is1 multiplies nsim by count_i, src/approx_mcmc.cpp:376-378)
+  std::vector<int> order(cnt);
+  for (int i = 0; i < cnt; i++) order[i] = i;
+  auto nsim_of = [&](int i) { return (int)(job->is_type == 1 ? job->nsim * job->counts[i] : job->nsim); };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nsim_of(a) < nsim_of(b); });
+  bool any_degenerate = false;
+  size_t pos = 0;
+  while (pos < order.size()) {
+    const int N = nsim_of(order[pos]);
+    size_t end = pos;
+    while (end < order.size() && nsim_of(order[end]) == N) end++;
+    // cap the batch so the kept history fits comfortably in HBM (<= 64 GiB per batch)
+    const size_t per_filter = need_hist ? (size_t)(n + 1) * N * (m * 8 * 2 + 8 + 4) : 0;
+    size_t maxF = per_filter ? std::max<size_t>(1, ((size_t)64 << 30) / per_filter) : (size_t)1 << 20;
+    while (pos < end) {
+      const size_t F = std::min(maxF, end - pos);
+      std::vector<bssm::FilterTables> bt(F);
+      std::vector<double> phis(F);
+      for (size_t f = 0; f < F; f++) { bt[f] = tabs[order[pos + f]]; phis[f] = hms[order[pos + f]].phi; }
+      DeviceBatch db;
+      int rc = db.upload(bt, phis, n, m, k, N, dist, psi, need_hist, 0);
+      if (rc) return rc;
+      // Philox stream = global draw index: filters of this batch are not contiguous in draw order, so
+      // launch per contiguous run when needed.  Simplest exact approach: a per-filter stream table is
+      // emulated by running contiguous runs separately.
+      size_t f0 = 0;
+      std::vector<double> ll(F);
+      while (f0 < F) {
+        size_t f1 = f0 + 1;
+        while (f1 < F && order[pos + f1] == order[pos + f1 - 1] + 1) f1++;
+        bssm::FilterBatch sub = db.fb;
+        sub.F = (int)(f1 - f0);
+        sub.mats += db.fb.mats_fstride * f0; sub.obs += db.fb.obs_fstride * f0; sub.init += db.fb.init_fstride * f0;
+        sub.phi += f0; sub.loglik += f0;
+        if (need_hist) {
+          sub.alpha_hist += (size_t)f0 * (n + 1) * m * N; sub.indices += (size_t)f0 * n * N; sub.weights += (size_t)f0 * (n + 1) * N;
+        }
+        sub.seed = job->seed;
+        sub.stream0 = (uint32_t)(job->first + order[pos + f0]);
+        if (need_hist && f0 == 0) {
+          HIP_TRY(hipMemsetAsync(db.hist.p, 0, db.hist.bytes, nullptr));
+          HIP_TRY(hipMemsetAsync(db.indices.p, 0, db.indices.bytes, nullptr));
+        }
+        if (db.use_grid) {
+          DevBuf wsb;  // workspace sized for the sub-batch
+          int B, chunk;
+          HIP_TRY(wsb.alloc(bssm::grid_workspace_bytes(sub, &B, &chunk)));
+          bssm::GridWorkspace gw;
+          bssm::grid_workspace_carve(sub, wsb.p, &gw);
+          HIP_TRY(bssm::launch_grid_filter(sub, gw, nullptr));
+          HIP_TRY(hipDeviceSynchronize());
+        } else {
+          HIP_TRY(bssm::launch_wg_filter(sub, nullptr));
+        }
+        f0 = f1;
+      }
+      HIP_TRY(hipMemcpy(ll.data(), db.loglik.p, F * sizeof(double), hipMemcpyDeviceToHost));
+      // smoothing outputs
+      DevBuf smooth, d_mean, d_cov;
+      std::vector<double> hmean, hcov, htraj;
+      if (need_hist) {
+        HIP_TRY(smooth.alloc((size_t)F * (n + 1) * m * N * sizeof(double)));
+        HIP_TRY(bssm::launch_backtrace(db.hist.as<double>(), db.indices.as<uint32_t>(), smooth.as<double>(), (int)F, n, m, N, nullptr));
+        if (job->output_type == 2) {
+          HIP_TRY(d_mean.alloc((size_t)F * (n + 1) * m * sizeof(double)));
+          HIP_TRY(d_cov.alloc((size_t)F * (n + 1) * m * m * sizeof(double)));
+          HIP_TRY(bssm::launch_summary(smooth.as<double>(), d_mean.as<double>(), d_cov.as<double>(), (int)F, n + 1, m, N, nullptr));
+          hmean.resize((size_t)F * (n + 1) * m);
+          hcov.resize((size_t)F * (n + 1) * m * m);
+          HIP_TRY(hipMemcpy(hmean.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost));
+          HIP_TRY(hipMemcpy(hcov.data(), d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost));
+        }
+      }
+      for (size_t f = 0; f < F; f++) {
+        const int i = order[pos + f];
+        double l = ll[f];
+        if (bad[i] || !std::isfinite(l)) { l = -INFINITY; any_degenerate = true; }
+        double full = l;
+        if (psi) { weights[i] = std::exp(l); }                            // src/approx_mcmc.cpp:385 (approx_loglik = 0)
+        else { full = l + bssm::const_term(hms[i]); weights[i] = std::exp(full - job->approx_loglik[i]); }  // :479
+        if (loglik) loglik[i] = full;
+        if (job->output_type == 1) {  // one uniformly chosen back-traced trajectory, stored (n+1) x m (:391-392)
+          const bssm::u32x4 w = bssm::philox4x32_10(0, 0, 0, bssm::RNG_PICK, job->seed, (uint32_t)(job->first + i));
+          const double u = (double)bssm::bits53(w.x, w.y) * 0x1.0p-53;
+          int pick = (int)(u * N);
+          if (pick >= N) pick = N - 1;
+          htraj.resize((size_t)(n + 1) * m);
+          // strided gather of one particle: [t][c][pick]
+          HIP_TRY(hipMemcpy2D(htraj.data(), sizeof(double), smooth.as<double>() + (size_t)f * (n + 1) * m * N + pick,
+                              (size_t)N * sizeof(double), sizeof(double), (size_t)(n + 1) * m, hipMemcpyDeviceToHost));
+          for (int t = 0; t <= n; t++) for (int c = 0; c < m; c++)
+            alpha[t + (size_t)(n + 1) * (c + (size_t)m * i)] = htraj[(size_t)t * m + c];
+        } else if (job->output_type == 2) {
+          std::memcpy(alphahat_i + (size_t)i * (n + 1) * m, hmean.data() + f * (size_t)(n + 1) * m, (size_t)(n + 1) * m * sizeof(double));
+          std::memcpy(Vt_i + (size_t)i * (n + 1) * m * m, hcov.data() + f * (size_t)(n + 1) * m * m, (size_t)(n + 1) * m * m * sizeof(double));
+        }
+      }
+      pos += F;
+    }
+  }
+  return any_degenerate ? BSSM_WARN_DEGENERATE : BSSM_OK;
+}
+
+int bssm_is_merge(int32_t n, int32_t m, int32_t n_stored, const double* weights, const uint32_t* counts,
+                  const double* alphahat_i, const double* Vt_i, double* alphahat, double* Vt) {
+  if (!weights || !counts || !alphahat_i || !Vt_i || !alphahat || !Vt) return fail(BSSM_ERR_INVALID, "NULL argument");
+  const size_t mt = (size_t)m * (n + 1), mmt = mt * m;
+  std::vector<double> Valpha(mmt, 0.0), diff(mt);
+  std::fill(alphahat, alphahat + mt, 0.0);
+  std::fill(Vt, Vt + mmt, 0.0);
+  double sum_w = 0.0;
+  for (int i = 0; i < n_stored; i++) {  // src/approx_mcmc.cpp:401-411, in draw order
+    const double* ah = alphahat_i + mt * i;
+    const double* vt = Vt_i + mmt * i;
+    const double wnew = weights[i] * counts[i];
+    sum_w += wnew;
+    for (size_t q = 0; q < mt; q++) { diff[q] = ah[q] - alphahat[q]; alphahat[q] += wnew / sum_w * diff[q]; }
+    for (int t = 0; t <= n; t++)
+      for (int c = 0; c < m; c++) for (int j = 0; j < m; j++)
+        Valpha[j + m * (c + (size_t)m * t)] += wnew * diff[j + (size_t)m * t] * (ah[c + (size_t)m * t] - alphahat[c + (size_t)m * t]);
+    for (size_t q = 0; q < mmt; q++) Vt[q] += wnew / sum_w * (vt[q] - Vt[q]);
+  }
+  for (size_t q = 0; q < mmt; q++) Vt[q] += Valpha[q] / sum_w;  // :422-424
+  return BSSM_OK;
+}
+
+// ------------------------------------------------------------------ device-resident plan
+struct bssm_plan {
+  DeviceBatch db;
+  int n_models = 0, n_rep = 0;
+  bool psi = false;
+  double bytes_per_pstep = 0;
+};
+
+bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int32_t n_rep, uint32_t nsim,
+                            uint32_t sampling_method, uint32_t flags) {
+  if (!models || n_models < 1 || n_rep < 1 || nsim < 1) { fail(BSSM_ERR_INVALID, "bad plan arguments"); return nullptr; }
+  if (sampling_method != BSSM_PSI && sampling_method != BSSM_BSF) { fail(BSSM_ERR_UNSUPPORTED, "sampling_method must be psi or bsf"); return nullptr; }
+  if (!have_device()) { no_device(); return nullptr; }
+  const bool psi = sampling_method == BSSM_PSI;
+  std::vector<bssm::FilterTables> tabs;
+  std::vector<double> phis, consts;
+  int n = 0, m = 0, k = 0, dist = 0;
+  for (int i = 0; i < n_models; i++) {
+    bssm::HostModel hm;
+    const std::string err = bssm::ingest_model(&models[i], psi, &hm);
+    if (!err.empty()) { fail(BSSM_ERR_INVALID, err); return nullptr; }
+    if (i == 0) { n = hm.n; m = hm.m; k = hm.k; dist = hm.distribution; }
+    else if (hm.n != n || hm.m != m || hm.k != k || hm.distribution != dist) { fail(BSSM_ERR_INVALID, "models of a plan must share n, m, k, distribution"); return nullptr; }
+    bssm::FilterTables ft;
+    double base;
+    const int MP = bssm::pad_dim(m);
+    if (psi) {
+      bssm::PsiSetup su;
+      if (!bssm::psi_setup(hm, nullptr, &su)) { fail(BSSM_ERR_NUMERIC, "psi set-up produced non-finite values"); return nullptr; }
+      bssm::build_psi_tables(hm, su, MP, &ft);
+      base = su.approx_loglik;
+    } else {
+      bssm::build_bsf_tables(hm, MP, bssm::pad_dim(k), &ft);
+      base = bssm::const_term(hm);
+    }
+    for (int r = 0; r < n_rep; r++) { tabs.push_back(ft); phis.push_back(hm.phi); consts.push_back(base); }
+  }
+  std::unique_ptr<bssm_plan> p(new bssm_plan);
+  p->n_models = n_models; p->n_rep = n_rep; p->psi = psi;
+  const bool keep = flags & BSSM_PLAN_KEEP_HISTORY;
+  if (p->db.upload(tabs, phis, n, m, k, (int)nsim, dist, psi, keep, flags) != BSSM_OK) return nullptr;
+  p->db.const_terms = consts;
+  // full-output filter 16m + 24 bytes per particle-step; log-likelihood only 16m + 16
+  p->bytes_per_pstep = keep ? 16.0 * m + 24.0 : 16.0 * m + 16.0;
+  return p.release();
+}
+
+void bssm_plan_destroy(bssm_plan* plan) { delete plan; }
+
+int bssm_plan_run(bssm_plan* plan, uint32_t seed, uint32_t stream0, void* hip_stream) {
+  if (!plan) return fail(BSSM_ERR_INVALID, "plan NULL");
+  return plan->db.run(seed, stream0, (hipStream_t)hip_stream);
+}
+
+int bssm_plan_loglik(bssm_plan* plan, void* hip_stream, double* loglik) {
+  if (!plan || !loglik) return fail(BSSM_ERR_INVALID, "NULL argument");
+  return plan->db.fetch_loglik((hipStream_t)hip_stream, loglik);
+}
+
+int bssm_plan_info(const bssm_plan* plan, int32_t* path, int32_t* n_filters, int32_t* blocks, int32_t* threads,
+                   double* bytes_per_particle_step) {
+  if (!plan) return fail(BSSM_ERR_INVALID, "plan NULL");
+  const auto& db = plan->db;
+  if (path) *path = db.use_grid ? 1 : 0;
+  if (n_filters) *n_filters = db.fb.F;
+  if (db.use_grid) {
+    if (blocks) *blocks = db.gws.B * db.fb.F;
+    if (threads) *threads = 256;
+  } else {
+    if (blocks) *blocks = db.fb.F;
+    const int N = db.fb.N;
+    if (threads) *threads = N <= 1024 ? (N + 63) / 64 * 64 : 1024;
+  }
+  if (bytes_per_particle_step) *bytes_per_particle_step = plan->bytes_per_pstep;
+  return BSSM_OK;
+}
+
+int bssm_plan_device_outputs(const bssm_plan* plan, void** alpha_hist, void** indices, void** weights) {
+  if (!plan) return fail(BSSM_ERR_INVALID, "plan NULL");
+  if (alpha_hist) *alpha_hist = plan->db.hist.p;
+  if (indices) *indices = plan->db.indices.p;
+  if (weights) *weights = plan->db.weights.p;
+  return BSSM_OK;
+}
+
+int bssm_plan_time(bssm_plan* plan, uint32_t seed, int32_t reps, void* hip_stream, double* ms_per_run) {
+  if (!plan || !ms_per_run || reps < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, st));
+  for (int r = 0; r < reps; r++) {
+    const int rc = plan->db.run(seed + (uint32_t)r, 0, st);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_run = (double)ms / reps;
+  return BSSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// pf_device.h -- device-side building blocks of the particle-filter kernels (gfx950, wave64).
+//
+// Counter-based random stream, wavefront reductions/scans, observation
+// log-densities.  The reference draws from a sequential sitmo engine
+// (src/model_ssm_ung.h:67; call sites src/model_ssm_ung.cpp:624,652,666); a
+// sequential stream cannot be consumed by 65 536 lanes, so every draw here is
+// a pure function of (seed, filter stream, purpose, time, particle, draw#).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bssm {
+
+// ---------------------------------------------------------------- layout of the per-filter tables
+// obs row (one per time point t in [0, n)), OBS_HDR header doubles followed by Z_t[MP]
+enum { OB_Y = 0, OB_U = 1, OB_D = 2, OB_PSIY = 3, OB_PSIIH = 4, OB_SCALE = 5, OB_FLAG = 6, OB_AUX = 7, OBS_HDR = 8 };
+// distribution codes = R/bootstrap_filter.R:106-109 ; 5 = gaussian (ssm_ulg path)
+enum { DIST_SVM = 0, DIST_POISSON = 1, DIST_BINOMIAL = 2, DIST_NEGBIN = 3, DIST_GAMMA = 4, DIST_GAUSSIAN = 5 };
+// RNG purposes
+enum { RNG_INIT = 0, RNG_RESAMPLE = 1, RNG_TRANSITION = 2, RNG_PICK = 3, RNG_SDE = 4 };
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct u32x4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                         uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return u32x4{c0, c1, c2, c3};
+}
+
+__host__ __device__ __forceinline__ uint64_t bits53(uint32_t a, uint32_t b) {
+  return ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6);
+}
+
+struct RngKey { uint32_t seed, stream; };
+
+// U[0,1) with 53 random bits
+__device__ __forceinline__ double rng_uniform(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d) {
+  const u32x4 w = philox4x32_10(i, t, d, purpose, k.seed, k.stream);
+  return (double)bits53(w.x, w.y) * 0x1.0p-53;
+}
+
+// Box-Muller pair from one Philox block
+__device__ __forceinline__ void rng_normal_pair(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d,
+                                                double& z0, double& z1) {
+  const u32x4 w = philox4x32_10(i, t, d, purpose, k.seed, k.stream);
+  const double u1 = (double)(bits53(w.x, w.y) + 1) * 0x1.0p-53;  // (0,1]
+  const double u2 = (double)bits53(w.z, w.w) * 0x1.0p-53;        // [0,1)
+  const double rad = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincos(2.0 * 3.14159265358979323846 * u2, &sn, &cs);
+  z0 = rad * cs;
+  z1 = rad * sn;
+}
+
+template <int CNT>
+__device__ __forceinline__ void rng_normals(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, double (&out)[CNT]) {
+#pragma unroll
+  for (int j = 0; j < CNT; j += 2) {
+    double z0, z1;
+    rng_normal_pair(k, purpose, t, i, (uint32_t)(j / 2), z0, z1);
+    out[j] = z0;
+    if (j + 1 < CNT) out[j + 1] = z1;
+  }
+}
+
+// ---------------------------------------------------------------- wavefront primitives (64 lanes)
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// fixed-shape butterfly: every lane ends with the same bits
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// inclusive Hillis-Steele scan over the 64 lanes
+__device__ __forceinline__ double wave_scan_incl(double v) {
+  const int l = lane_id();
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(v, off, 64);
+    if (l >= off) v += o;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------- observation log-densities
+// Unnormalised log g(y_t | signal s), src/model_ssm_ung.cpp:447-493; gaussian:
+// src/model_ssm_ulg.cpp:582-586.  `ob` points at the obs-row header; state-
+// independent quotients are precomputed on the host into OB_AUX:
+//   svm (y/phi)^2, negbin y+phi, gamma y/u, gaussian 1/H^2.
+__device__ __forceinline__ double log_obs_density(int dist, const double* __restrict__ ob, double phi, double s) {
+  const double y = ob[OB_Y];
+  switch (dist) {
+    case DIST_SVM: return -0.5 * (s + ob[OB_AUX] * exp(-s));
+    case DIST_POISSON: return y * s - ob[OB_U] * exp(s);
+    case DIST_BINOMIAL: return y * s - ob[OB_U] * log1p(exp(s));
+    case DIST_NEGBIN: return y * s - ob[OB_AUX] * log(phi + ob[OB_U] * exp(s));
+    case DIST_GAMMA: return -phi * (s + ob[OB_AUX] * exp(-s));
+    case DIST_GAUSSIAN: { const double r = y - s; return -0.5 * r * r * ob[OB_AUX]; }
+  }
+  return 0.0;
+}
+
+// psi-APF weight, src/model_ssm_ung.cpp:385-439 and the `- scales(t)` of :550,590
+__device__ __forceinline__ double log_psi_weight(int dist, const double* __restrict__ ob, double phi, double s) {
+  const double q = (ob[OB_PSIY] - s) * ob[OB_PSIIH];
+  return log_obs_density(dist, ob, phi, s) + 0.5 * q * q - ob[OB_SCALE];
+}
+
+}  // namespace bssm

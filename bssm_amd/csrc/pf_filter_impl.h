@@ -1,0 +1,432 @@
+// pf_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the bssm particle-filter hot path.
+//
+// Two execution shapes for the same recursion (src/model_ssm_ung.cpp:611-712 bootstrap,
+// :536-609 psi-APF, src/model_ssm_ulg.cpp:557-643 gaussian):
+//
+//  * pf_wg_kernel    one WORKGROUP per filter, particle system resident in LDS, the whole
+//                    time loop inside one launch (4 workgroup barriers per time step, no
+//                    grid-wide synchronisation).  This is the shape of IS post-correction:
+//                    thousands of independent filters (src/approx_mcmc.cpp:370-417).
+//  * pf_grid_step    one filter spread over many workgroups (N up to 1e5), one launch per
+//                    time step; the kernel boundary is the only grid-wide synchronisation.
+//                    Blocks exchange (max, sum) partials and block-local inclusive scans so
+//                    that the global CDF never has to be materialised.
+//
+// Both draw every random number from the counter-based stream in pf_device.h and use
+// fixed-shape reductions/scans only (no floating-point atomics): results are bit-reproducible
+// run to run and independent of the number of GPUs a batch is sharded over.
+#pragma once
+#include "pf_device.h"
+#include "pf_kernels.h"
+
+namespace bssm {
+
+__global__ void weights_finalize_kernel(double* __restrict__ weights, const double* __restrict__ maxhist,
+                                        const int* __restrict__ dead_at, int n1, int N);
+
+
+// ------------------------------------------------------------------------------------------
+// shared per-particle pieces
+// ------------------------------------------------------------------------------------------
+template <int MP>
+__device__ __forceinline__ double signal_of(const double* __restrict__ ob, const double (&x)[MP]) {
+  // D(t) + Z_t' alpha + xbeta(t)   (src/model_ssm_ung.cpp:462-463); D + xbeta pre-added on the host
+  double za = 0.0;
+#pragma unroll
+  for (int c = 0; c < MP; c++) za += ob[OBS_HDR + c] * x[c];
+  return ob[OB_D] + za;
+}
+
+template <int MP>
+__device__ __forceinline__ double log_weight_of(const FilterBatch& b, const double* __restrict__ ob, double phi,
+                                                const double (&x)[MP]) {
+  if (ob[OB_FLAG] == 0.0) return 0.0;  // missing y_t: weights are ones (src/model_ssm_ung.cpp:644-647)
+  const double s = signal_of<MP>(ob, x);
+  return b.psi ? log_psi_weight(b.dist, ob, phi, s) : log_obs_density(b.dist, ob, phi, s);
+}
+
+// alpha_{t+1} = C_t + T_t a + R_t eta   (src/model_ssm_ung.cpp:663-670); for the psi-APF the host
+// folds alphahat/Ct/Vt into the same three operands (src/model_ssm_ung.cpp:585-586).
+template <int MP, int KP>
+__device__ __forceinline__ void propagate(const double* __restrict__ mt, const double (&a)[MP], const double (&z)[KP],
+                                          double (&x)[MP]) {
+  const double* __restrict__ Tm = mt;
+  const double* __restrict__ Rm = mt + MP * MP;
+  const double* __restrict__ Cv = mt + MP * MP + MP * KP;
+#pragma unroll
+  for (int j = 0; j < MP; j++) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int c = 0; c < MP; c++) s += Tm[j + MP * c] * a[c];
+#pragma unroll
+    for (int c = 0; c < KP; c++) q += Rm[j + MP * c] * z[c];
+    x[j] = Cv[j] + s + q;
+  }
+}
+
+template <int MP>
+__device__ __forceinline__ void initial_state(const double* __restrict__ ini, const double (&z)[MP], double (&x)[MP]) {
+  // a1 + L u   (src/model_ssm_ung.cpp:626; psi: alphahat_0 + V_0 u, :543)
+#pragma unroll
+  for (int j = 0; j < MP; j++) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < MP; c++) s += ini[MP + j + MP * c] * z[c];
+    x[j] = ini[j] + s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Workgroup-resident filter
+// ------------------------------------------------------------------------------------------
+// Particle i = r * NT + tid (r < PPT): consecutive lanes own consecutive particles, so LDS
+// accesses to the own slot are conflict-free and history stores are coalesced.
+template <int MP, int KP, int PPT>
+__global__ void __launch_bounds__(1024) pf_wg_kernel(const FilterBatch b) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
+  const int Ncap = NT * PPT, N = b.N, n = b.n, f = blockIdx.x;
+  double* __restrict__ s_alpha = smem;            // [MP][Ncap]
+  double* __restrict__ s_cdf = smem + MP * Ncap;  // [Ncap]
+  double* __restrict__ s_max = s_cdf + Ncap;      // [16]
+  double* __restrict__ s_tot = s_max + 16;        // [PPT*16] wave totals in particle order
+
+  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
+  const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
+  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
+  const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
+  const double phi = b.phi[f];
+  const int obs_stride = OBS_HDR + MP, m = b.m;
+  const double dN = (double)N;
+
+  double w[PPT];  // log-weights of my particles at the current time
+  double loglik = 0.0;
+
+  // ---- initial particles and their weights
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int i = r * NT + tid;
+    double z[MP], x[MP];
+    rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)i, z);
+    initial_state<MP>(ini, z, x);
+    if (i < N) {
+#pragma unroll
+      for (int c = 0; c < MP; c++) {
+        s_alpha[c * Ncap + i] = x[c];
+        if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1)) * m + c) * N + i] = x[c];
+      }
+    }
+    w[r] = (i < N) ? log_weight_of<MP>(b, obs, phi, x) : -INFINITY;
+  }
+
+  for (int t = 0; t <= n; t++) {
+    // ---- normalise the time-t weights: block max (src/model_ssm_ung.cpp:675) ...
+    double mx = w[0];
+#pragma unroll
+    for (int r = 1; r < PPT; r++) mx = fmax(mx, w[r]);
+    mx = wave_max(mx);
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();  // (1)
+    double M = s_max[0];
+    for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
+    // ... exp(w - max) and its inclusive scan in particle order (:676-679, stratified_sample.cpp:12)
+    double sc[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      const int i = r * NT + tid;
+      const double e = (i < N) ? exp(w[r] - M) : 0.0;
+      sc[r] = wave_scan_incl(e);
+      if (lane == 63) s_tot[r * nw + wave] = sc[r];
+      if (b.weights && i < N) b.weights[((size_t)f * (n + 1) + t) * N + i] = e;
+    }
+    __syncthreads();  // (2)
+    // every wave scans the <= 128 chunk totals redundantly (saves a barrier)
+    const int Q = PPT * nw;
+    const double t0 = (lane < Q) ? s_tot[lane] : 0.0;
+    const double t1 = (lane + 64 < Q) ? s_tot[lane + 64] : 0.0;
+    const double i0 = wave_scan_incl(t0);
+    const double half = __shfl(i0, 63, 64);
+    const double i1 = wave_scan_incl(t1) + half;
+    const double S = __shfl(i1, 63, 64);
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      const int q = r * nw + wave;  // my chunk; exclusive offset = inclusive prefix of chunk q-1
+      const double p0 = __shfl(i0, (q - 1) & 63, 64), p1 = __shfl(i1, (q - 65) & 63, 64);
+      const double off = (q == 0) ? 0.0 : (q <= 64 ? p0 : p1);
+      const int i = r * NT + tid;
+      if (i < N) s_cdf[i] = off + sc[r];
+    }
+    if (!(S > 0.0)) { loglik = -INFINITY; break; }  // :678-682 (uniform across the block)
+    loglik += M + log(S / dN);                       // :683
+    if (t == n) break;
+    __syncthreads();  // (3) cdf visible
+
+    // ---- stratified resampling (stratified_sample.cpp:15-26) + ancestor gather (:657-661)
+    const double c_scale = S / dN;
+    double a[PPT][MP];
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      const int i = r * NT + tid;
+      const double u = rng_uniform(key, RNG_RESAMPLE, (uint32_t)t, (uint32_t)i, 0);
+      const double v = (u + (double)i) * c_scale;
+      int lo = 0, hi = N - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v <= s_cdf[mid]) hi = mid; else lo = mid + 1;
+      }
+#pragma unroll
+      for (int c = 0; c < MP; c++) a[r][c] = s_alpha[c * Ncap + lo];
+      if (b.indices && i < N) b.indices[((size_t)f * n + t) * N + i] = (uint32_t)lo;
+    }
+    __syncthreads();  // (4) all ancestors read before the slots are overwritten
+
+    // ---- transition to t+1 and the weights there
+    const double* __restrict__ mt = mats + (size_t)t * b.mats_tstride;
+    const double* __restrict__ ob = obs + (size_t)(t + 1 < n ? t + 1 : 0) * obs_stride;
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      const int i = r * NT + tid;
+      double z[KP], x[MP];
+      rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
+      propagate<MP, KP>(mt, a[r], z, x);
+      if (i < N) {
+#pragma unroll
+        for (int c = 0; c < MP; c++) {
+          s_alpha[c * Ncap + i] = x[c];
+          if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1) + (t + 1)) * m + c) * N + i] = x[c];
+        }
+      }
+      w[r] = (i < N) ? (t + 1 < n ? log_weight_of<MP>(b, ob, phi, x) : 0.0) : -INFINITY;
+    }
+  }
+  if (tid == 0 && b.loglik) b.loglik[f] = loglik;
+}
+
+template <int MP, int KP>
+hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
+  const int N = b.N;
+  int ppt, nt;
+  if (N <= 1024) { ppt = 1; nt = (N + 63) / 64 * 64; }
+  else if (N <= 2048) { ppt = 2; nt = 1024; }
+  else if (N <= 4096) { ppt = 4; nt = 1024; }
+  else { ppt = 8; nt = 1024; }
+  const size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16) * sizeof(double);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  void (*kern)(const FilterBatch) = nullptr;
+  switch (ppt) {
+    case 1: kern = pf_wg_kernel<MP, KP, 1>; break;
+    case 2: kern = pf_wg_kernel<MP, KP, 2>; break;
+    case 4: kern = pf_wg_kernel<MP, KP, 4>; break;
+    default: kern = pf_wg_kernel<MP, KP, 8>; break;
+  }
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(b.F), dim3(nt), lds, stream, b);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-workgroup filter: one launch per time step
+// ------------------------------------------------------------------------------------------
+constexpr int GRID_NT = 256;
+
+// block-wide inclusive scan of PPT strided values per thread; returns the block total.
+// s_tot must hold PPT * 4 doubles.  One barrier.
+template <int PPT>
+__device__ __forceinline__ double block_scan_strided(const double (&e)[PPT], double (&out)[PPT], double* s_tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = GRID_NT / 64;
+  double sc[PPT];
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    sc[r] = wave_scan_incl(e[r]);
+    if (lane == 63) s_tot[r * NW + wave] = sc[r];
+  }
+  __syncthreads();
+  constexpr int Q = PPT * NW;  // <= 32
+  const double tq = (lane < Q) ? s_tot[lane] : 0.0;
+  const double incl = wave_scan_incl(tq);
+  const double total = __shfl(incl, 63, 64);
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int q = r * NW + wave;
+    const double prev = __shfl(incl, (q - 1) & 63, 64);
+    out[r] = (q == 0 ? 0.0 : prev) + sc[r];
+  }
+  return total;
+}
+
+// t = -1: initial particles + weights at time 0.  t in [0, n): resample on the time-t
+// weights, propagate to t+1, weigh at t+1 (ones when t+1 == n or y_{t+1} is missing).
+template <int MP, int KP, int PPT>
+__global__ void __launch_bounds__(GRID_NT) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
+  __shared__ double s_Q[GRID_NT];      // inclusive prefix of scaled block sums
+  __shared__ double s_scale[GRID_NT];  // exp(max_b - M)
+  __shared__ double s_red[8];
+  __shared__ double s_tot[PPT * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pb = blockIdx.x, f = blockIdx.y, B = ws.B, chunk = ws.chunk;
+  const int N = b.N, n = b.n, m = b.m;
+  if (ws.dead[f]) return;  // degenerate filter: later slots stay zero (src/model_ssm_ung.cpp:678-682)
+
+  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
+  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
+  const double phi = b.phi[f];
+  const int obs_stride = OBS_HDR + MP;
+  const int base = pb * chunk;
+  const int len = min(chunk, N - base);
+  const int tn = t + 1;  // time index of the particles produced by this launch
+
+  double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N
+                                             : ws.state[tn & 1] + (size_t)f * m * N;
+  double x[PPT][MP];
+
+  if (t < 0) {
+    const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      const int li = r * GRID_NT + tid, j = base + li;
+      double z[MP];
+      rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)j, z);
+      initial_state<MP>(ini, z, x[r]);
+      if (li < len) {
+#pragma unroll
+        for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[r][c];
+      }
+    }
+  } else {
+    // ---- combine the partials of the time-t weights (every block redundantly, same order)
+    const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
+    const double pmax = (tid < B) ? part[2 * tid] : -INFINITY;
+    const double psum = (tid < B) ? part[2 * tid + 1] : 0.0;
+    double mx = wave_max(pmax);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    const double M = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    const double scale = (tid < B) ? exp(pmax - M) : 0.0;
+    const double ss = psum * scale;
+    double qi = wave_scan_incl(ss);
+    if (lane == 63) s_red[4 + wave] = qi;
+    __syncthreads();
+    double off = 0.0;
+    for (int q = 0; q < wave; q++) off += s_red[4 + q];
+    qi += off;
+    s_Q[tid] = qi;
+    s_scale[tid] = scale;
+    const double S = ((s_red[4] + s_red[5]) + s_red[6]) + s_red[7];
+    __syncthreads();
+    if (!(S > 0.0)) {
+      if (pb == 0 && tid == 0) { ws.dead[f] = t + 1; b.loglik[f] = -INFINITY; }
+      return;
+    }
+    if (pb == 0 && tid == 0) {
+      b.loglik[f] += M + log(S / (double)N);  // src/model_ssm_ung.cpp:683 (single writer)
+      if (ws.maxhist) ws.maxhist[(size_t)f * (n + 1) + t] = M;
+    }
+    // ---- resample + gather + propagate
+    const double c_scale = S / (double)N;
+    const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
+    const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N
+                                                     : ws.state[t & 1] + (size_t)f * m * N;
+    const double* __restrict__ mt = b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride;
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      const int li = r * GRID_NT + tid, j = base + li;
+      if (li >= len) { for (int c = 0; c < MP; c++) x[r][c] = 0.0; continue; }
+      const double u = rng_uniform(key, RNG_RESAMPLE, (uint32_t)t, (uint32_t)j, 0);
+      const double v = (u + (double)j) * c_scale;
+      // level 1: source block
+      int lo = 0, hi = B - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v <= s_Q[mid]) hi = mid; else lo = mid + 1;
+      }
+      const int sb = lo;
+      const double P = sb > 0 ? s_Q[sb - 1] : 0.0;
+      const double sc = s_scale[sb];
+      const double* __restrict__ lc = lcdf + (size_t)sb * chunk;
+      // level 2: inside the source block's local scan
+      lo = 0; hi = min(chunk, N - sb * chunk) - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v <= P + lc[mid] * sc) hi = mid; else lo = mid + 1;
+      }
+      const int anc = sb * chunk + lo;
+      if (b.indices) b.indices[((size_t)f * n + t) * N + j] = (uint32_t)anc;
+      double a[MP], z[KP];
+#pragma unroll
+      for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
+      rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+      propagate<MP, KP>(mt, a, z, x[r]);
+#pragma unroll
+      for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[r][c];
+    }
+  }
+
+  // ---- weights at time tn, block-local max / scan, partials
+  double w[PPT], e[PPT], sc[PPT];
+  const bool have_obs = tn < n;
+  const double* __restrict__ ob = obs + (size_t)(have_obs ? tn : 0) * obs_stride;
+  double mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int li = r * GRID_NT + tid;
+    w[r] = (li < len) ? (have_obs ? log_weight_of<MP>(b, ob, phi, x[r]) : 0.0) : -INFINITY;
+    mx = fmax(mx, w[r]);
+  }
+  __syncthreads();  // s_red reuse
+  mx = wave_max(mx);
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  const double Mb = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int li = r * GRID_NT + tid;
+    e[r] = (li < len) ? exp(w[r] - Mb) : 0.0;
+    if (b.weights && li < len) b.weights[((size_t)f * (n + 1) + tn) * N + base + li] = w[r];  // raw; finalised later
+  }
+  const double tot = block_scan_strided<PPT>(e, sc, s_tot);
+  double* __restrict__ lcdf_new = ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N;
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int li = r * GRID_NT + tid;
+    if (li < len) lcdf_new[base + li] = sc[r];
+  }
+  if (tid == 0) {
+    double* __restrict__ part = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
+    part[2 * pb] = Mb;
+    part[2 * pb + 1] = tot;
+  }
+}
+
+template <int MP, int KP>
+hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+  const int ppt = ws.chunk / GRID_NT;
+  void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
+  switch (ppt) {
+    case 1: kern = pf_grid_step<MP, KP, 1>; break;
+    case 2: kern = pf_grid_step<MP, KP, 2>; break;
+    case 4: kern = pf_grid_step<MP, KP, 4>; break;
+    default: kern = pf_grid_step<MP, KP, 8>; break;
+  }
+  hipError_t e;
+  if ((e = hipMemsetAsync(ws.dead, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(b.loglik, 0, sizeof(double) * b.F, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(ws.maxhist, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
+  const dim3 grid(ws.B, b.F), block(GRID_NT);
+  for (int t = -1; t < b.n; t++) hipLaunchKernelGGL(kern, grid, block, 0, stream, b, ws, t);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (b.weights) {
+    const int gx = (b.N + 255) / 256 < 64 ? (b.N + 255) / 256 : 64;
+    hipLaunchKernelGGL(weights_finalize_kernel, dim3(gx, b.n + 1, b.F), dim3(256), 0, stream, b.weights, ws.maxhist,
+                       ws.dead, b.n + 1, b.N);
+  }
+  return hipGetLastError();
+}
+
+
+// per-MP entry points, one translation unit each (pf_inst_mp*.hip) so the build parallelises
+template <int MP> hipError_t launch_wg_mp(const FilterBatch& b, hipStream_t stream);
+template <int MP> hipError_t launch_grid_mp(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream);
+
+}  // namespace bssm

@@ -1,0 +1,19 @@
+// pf_inst_mp1.hip -- instantiations of the filter kernels for padded state dimension 1
+#include "pf_filter_impl.h"
+
+namespace bssm {
+
+template <> hipError_t launch_wg_mp<1>(const FilterBatch& b, hipStream_t stream) {
+  switch (b.KP) {
+    case 1: return launch_wg_mk<1, 1>(b, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+template <> hipError_t launch_grid_mp<1>(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+  switch (b.KP) {
+    case 1: return launch_grid_mk<1, 1>(b, ws, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace bssm

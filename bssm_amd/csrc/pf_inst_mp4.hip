@@ -1,0 +1,23 @@
+// pf_inst_mp4.hip -- instantiations of the filter kernels for padded state dimension 4
+#include "pf_filter_impl.h"
+
+namespace bssm {
+
+template <> hipError_t launch_wg_mp<4>(const FilterBatch& b, hipStream_t stream) {
+  switch (b.KP) {
+    case 1: return launch_wg_mk<4, 1>(b, stream);
+    case 2: return launch_wg_mk<4, 2>(b, stream);
+    case 4: return launch_wg_mk<4, 4>(b, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+template <> hipError_t launch_grid_mp<4>(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+  switch (b.KP) {
+    case 1: return launch_grid_mk<4, 1>(b, ws, stream);
+    case 2: return launch_grid_mk<4, 2>(b, ws, stream);
+    case 4: return launch_grid_mk<4, 4>(b, ws, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace bssm

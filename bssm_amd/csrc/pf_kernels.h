@@ -1,0 +1,72 @@
+// pf_kernels.h -- launch interface between the host library and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace bssm {
+
+// Device-resident description of a batch of F independent filters that share
+// (n, m, k, N, distribution) but may differ in every matrix / observation row
+// (one per retained theta-draw in post-correction, src/approx_mcmc.cpp:370-417).
+// All strides are in doubles.  A stride of 0 shares one table among filters.
+struct FilterBatch {
+  int n;         // time points
+  int m, k;      // real state / disturbance dimensions
+  int MP, KP;    // padded dimensions the kernels are instantiated for
+  int N;         // particles per filter
+  int F;         // filters in the batch
+  int dist;      // DIST_*
+  int psi;       // 0 bootstrap weights, 1 psi-APF weights
+  uint32_t seed;
+  uint32_t stream0;  // filter f uses Philox key (seed, stream0 + f)
+  // [f][tt][MP*MP + MP*KP + MP] : T_tt, R_tt, C_tt (column-major, zero padded)
+  const double* mats; size_t mats_fstride; int mats_tstride;
+  // [f][t][OBS_HDR + MP] for t in [0, n)
+  const double* obs; size_t obs_fstride;
+  // [f][MP + MP*MP] : a1 then L (initial mean and lower factor)
+  const double* init; size_t init_fstride;
+  // [f] dispersion
+  const double* phi;
+  // outputs (any may be null)
+  double* alpha_hist;   // [f][n+1][m][N]   particle-minor
+  uint32_t* indices;    // [f][n][N]
+  double* weights;      // [f][n+1][N]      exp(w - max_t), ones where unobserved
+  double* loglik;       // [f]              sum_t (max_t + log mean exp), no constants
+};
+
+// Largest N the workgroup-resident kernel can hold for a given padded state size
+int wg_filter_capacity(int MP);
+// One workgroup per filter, whole time loop inside the kernel.
+hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream);
+
+// Multi-workgroup filter for large N: workspace + per-time-step launches.
+struct GridWorkspace {
+  double* state[2];    // [F][m][N] ping-pong when no history is kept
+  double* lcdf;        // [F][N] block-local inclusive scans of exp(w - max_b)
+  double* partials;    // [2][F][B][2]  (max_b, sum_b)
+  double* logw;        // [F][N] raw log-weights when weights output is wanted
+  double* maxhist;     // [F][n+1] global max per time point (weights finalisation)
+  int* dead;           // [F]
+  int B;               // particle blocks per filter
+  int chunk;           // particles per block
+};
+size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out);
+void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
+hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream);
+
+// Ancestor back-trace (src/filter_smoother.cpp:5-18) on the particle-minor history, in place is not
+// possible in parallel, so it writes `out` [f][n+1][m][N].
+hipError_t launch_backtrace(const double* hist, const uint32_t* indices, double* out, int F, int n, int m, int N,
+                            hipStream_t stream);
+// summary() (src/summary.cpp:4-17): mean [f][n+1][m] and cov [f][n+1][m][m] over particles
+hipError_t launch_summary(const double* hist, double* mean, double* cov, int F, int n1, int m, int N,
+                          hipStream_t stream);
+// filter_summary() (src/summary.cpp:42-79): at [f][n+1][m], att [f][n][m], Pt [f][n+1][m*m], Ptt [f][n][m*m]
+hipError_t launch_filter_summary(const double* hist, const double* weights, double* at, double* att, double* Pt,
+                                 double* Ptt, int F, int n, int m, int N, hipStream_t stream);
+// [f][t][c][i] -> Armadillo cube m x (n+1) x N (index c + m*(t + (n+1)*i)) per filter
+hipError_t launch_to_cube(const double* hist, double* cube, int F, int n1, int m, int N, hipStream_t stream);
+// [f][t][i] u32 -> N x n column-major is already [t][i]; weights likewise. (no kernel needed)
+
+}  // namespace bssm

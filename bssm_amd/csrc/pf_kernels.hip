@@ -1,0 +1,241 @@
+// pf_kernels.hip -- launch dispatch plus the smoothing / summary / layout kernels.
+// The filter kernels themselves are templates in pf_filter_impl.h, instantiated per padded
+// state dimension in pf_inst_mp*.hip.
+#include "pf_filter_impl.h"
+
+namespace bssm {
+
+int wg_filter_capacity(int MP) {
+  // 160 KiB LDS per CU: (MP + 1) doubles per particle + 16 + 8*16 reduction slots
+  const size_t avail = 160 * 1024 - (16 + 8 * 16) * sizeof(double);
+  const size_t cap = avail / ((size_t)(MP + 1) * sizeof(double));
+  for (int c = 8192; c >= 1024; c >>= 1) if ((size_t)c <= cap) return c;
+  return (int)(cap / 64 * 64);
+}
+
+// weights[f][tt][i] <- exp(w - M_tt); zero after a degenerate step (reference leaves zeros)
+__global__ void weights_finalize_kernel(double* __restrict__ weights, const double* __restrict__ maxhist,
+                                        const int* __restrict__ dead_at, int n1, int N) {
+  const int tt = blockIdx.y, f = blockIdx.z;
+  const double M = maxhist[(size_t)f * n1 + tt];
+  double* __restrict__ col = weights + ((size_t)f * n1 + tt) * N;
+  const int da = dead_at[f];  // 0 = alive, else (time of degeneracy) + 1
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    if (da && tt > da - 1) col[i] = 0.0;
+    else col[i] = exp(col[i] - M);
+  }
+}
+
+size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
+  // one particle per thread until the chip is full, then more particles per thread
+  int ppt = 1;
+  while ((b.N + GRID_NT * ppt - 1) / (GRID_NT * ppt) > GRID_NT && ppt < 8) ppt *= 2;
+  const int chunk = GRID_NT * ppt;
+  const int B = (b.N + chunk - 1) / chunk;
+  if (B_out) *B_out = B;
+  if (chunk_out) *chunk_out = chunk;
+  size_t bytes = 0;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  bytes += 2 * al((size_t)b.F * b.m * b.N * sizeof(double));  // state ping-pong
+  bytes += al((size_t)2 * b.F * b.N * sizeof(double));        // lcdf
+  bytes += al((size_t)2 * b.F * B * 2 * sizeof(double));      // partials
+  bytes += al((size_t)b.F * (b.n + 1) * sizeof(double));      // maxhist
+  bytes += al((size_t)b.F * sizeof(int));                     // dead
+  return bytes;
+}
+
+void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
+  int B, chunk;
+  grid_workspace_bytes(b, &B, &chunk);
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  char* p = (char*)base;
+  ws->state[0] = (double*)p; p += al((size_t)b.F * b.m * b.N * sizeof(double));
+  ws->state[1] = (double*)p; p += al((size_t)b.F * b.m * b.N * sizeof(double));
+  ws->lcdf = (double*)p; p += al((size_t)2 * b.F * b.N * sizeof(double));
+  ws->partials = (double*)p; p += al((size_t)2 * b.F * B * 2 * sizeof(double));
+  ws->maxhist = (double*)p; p += al((size_t)b.F * (b.n + 1) * sizeof(double));
+  ws->dead = (int*)p;
+  ws->logw = nullptr;
+  ws->B = B;
+  ws->chunk = chunk;
+}
+
+
+hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream) {
+  switch (b.MP) {
+    case 1: return launch_wg_mp<1>(b, stream);
+    case 2: return launch_wg_mp<2>(b, stream);
+    case 4: return launch_wg_mp<4>(b, stream);
+    case 8: return launch_wg_mp<8>(b, stream);
+    case 16: return launch_wg_mp<16>(b, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+  switch (b.MP) {
+    case 1: return launch_grid_mp<1>(b, ws, stream);
+    case 2: return launch_grid_mp<2>(b, ws, stream);
+    case 4: return launch_grid_mp<4>(b, ws, stream);
+    case 8: return launch_grid_mp<8>(b, ws, stream);
+    case 16: return launch_grid_mp<16>(b, ws, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// smoothing and summaries
+// ------------------------------------------------------------------------------------------
+// src/filter_smoother.cpp:5-18: every trajectory is an independent pointer chase through the
+// ancestor table, so it parallelises over particles with no synchronisation at all.
+__global__ void backtrace_kernel(const double* __restrict__ hist, const uint32_t* __restrict__ indices,
+                                 double* __restrict__ out, int n, int m, int N) {
+  const int f = blockIdx.y;
+  const double* __restrict__ h = hist + (size_t)f * (n + 1) * m * N;
+  const uint32_t* __restrict__ idx = indices + (size_t)f * n * N;
+  double* __restrict__ o = out + (size_t)f * (n + 1) * m * N;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    for (int c = 0; c < m; c++) o[((size_t)n * m + c) * N + i] = h[((size_t)n * m + c) * N + i];
+    uint32_t bi = (uint32_t)i;
+    for (int t = n - 1; t >= 0; t--) {
+      bi = idx[(size_t)t * N + bi];
+      for (int c = 0; c < m; c++) o[((size_t)t * m + c) * N + i] = h[((size_t)t * m + c) * N + bi];
+    }
+  }
+}
+
+hipError_t launch_backtrace(const double* hist, const uint32_t* indices, double* out, int F, int n, int m, int N,
+                            hipStream_t stream) {
+  const int bx = (N + 255) / 256;
+  hipLaunchKernelGGL(backtrace_kernel, dim3(bx, F), dim3(256), 0, stream, hist, indices, out, n, m, N);
+  return hipGetLastError();
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double* s_red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  return ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+}
+
+// summary(): mean and population covariance over particles, two-pass (the reference's Welford
+// recursion, src/summary.cpp:4-17, is a serial formulation of the same quantities).
+__global__ void __launch_bounds__(256) summary_kernel(const double* __restrict__ hist, double* __restrict__ mean,
+                                                      double* __restrict__ cov, int n1, int m, int N) {
+  __shared__ double s_red[4];
+  __shared__ double s_mean[16];
+  const int t = blockIdx.x, f = blockIdx.y;
+  const double* __restrict__ h = hist + ((size_t)f * n1 + t) * m * N;
+  for (int j = 0; j < m; j++) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) acc += h[(size_t)j * N + i];
+    const double tot = block_sum_256(acc, s_red);
+    if (threadIdx.x == 0) { s_mean[j] = tot / N; mean[((size_t)f * n1 + t) * m + j] = tot / N; }
+  }
+  __syncthreads();
+  for (int c = 0; c < m; c++)
+    for (int j = 0; j < m; j++) {
+      const double mj = s_mean[j], mc = s_mean[c];
+      double acc = 0.0;
+      for (int i = threadIdx.x; i < N; i += 256) acc += (h[(size_t)j * N + i] - mj) * (h[(size_t)c * N + i] - mc);
+      const double tot = block_sum_256(acc, s_red);
+      if (threadIdx.x == 0) cov[(((size_t)f * n1 + t) * m + c) * m + j] = tot / N;
+    }
+}
+
+hipError_t launch_summary(const double* hist, double* mean, double* cov, int F, int n1, int m, int N,
+                          hipStream_t stream) {
+  if (m > 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(summary_kernel, dim3(n1, F), dim3(256), 0, stream, hist, mean, cov, n1, m, N);
+  return hipGetLastError();
+}
+
+// filter_summary(): src/summary.cpp:42-79
+__global__ void __launch_bounds__(256) filter_summary_kernel(const double* __restrict__ hist,
+                                                             const double* __restrict__ weights,
+                                                             double* __restrict__ at, double* __restrict__ att,
+                                                             double* __restrict__ Pt, double* __restrict__ Ptt, int n,
+                                                             int m, int N) {
+  __shared__ double s_red[4];
+  __shared__ double s_at[16], s_att[16];
+  const int t = blockIdx.x, f = blockIdx.y, n1 = n + 1;
+  const double* __restrict__ h = hist + ((size_t)f * n1 + t) * m * N;
+  const double* __restrict__ w = weights + ((size_t)f * n1 + t) * N;
+  const bool filt = t < n;
+  double wsum = 1.0;
+  if (filt) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) acc += w[i];
+    wsum = block_sum_256(acc, s_red);
+  }
+  for (int j = 0; j < m; j++) {
+    double acc = 0.0, accw = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+      const double xv = h[(size_t)j * N + i];
+      acc += xv;
+      if (filt) accw += xv * (w[i] / wsum);
+    }
+    const double tot = block_sum_256(acc, s_red);
+    const double totw = filt ? block_sum_256(accw, s_red) : 0.0;
+    if (threadIdx.x == 0) {
+      s_at[j] = tot / N;
+      at[((size_t)f * n1 + t) * m + j] = tot / N;
+      if (filt) { s_att[j] = totw; att[((size_t)f * n + t) * m + j] = totw; }
+    }
+  }
+  __syncthreads();
+  for (int c = 0; c < m; c++)
+    for (int j = 0; j < m; j++) {
+      double acc = 0.0, accw = 0.0;
+      for (int i = threadIdx.x; i < N; i += 256) {
+        const double xj = h[(size_t)j * N + i], xc = h[(size_t)c * N + i];
+        acc += (xj - s_at[j]) * (xc - s_at[c]);
+        if (filt) accw += (w[i] / wsum) * (xj - s_att[j]) * (xc - s_att[c]);
+      }
+      const double tot = block_sum_256(acc, s_red);
+      const double totw = filt ? block_sum_256(accw, s_red) : 0.0;
+      if (threadIdx.x == 0) {
+        Pt[(((size_t)f * n1 + t) * m + c) * m + j] = tot / N;
+        if (filt) Ptt[(((size_t)f * n + t) * m + c) * m + j] = totw;
+      }
+    }
+}
+
+hipError_t launch_filter_summary(const double* hist, const double* weights, double* at, double* att, double* Pt,
+                                 double* Ptt, int F, int n, int m, int N, hipStream_t stream) {
+  if (m > 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(filter_summary_kernel, dim3(n + 1, F), dim3(256), 0, stream, hist, weights, at, att, Pt, Ptt, n, m,
+                     N);
+  return hipGetLastError();
+}
+
+// particle-minor history -> Armadillo cube m x (n+1) x N.  LDS-tiled transpose of the
+// [(t,c)][i] matrix so both the reads and the writes are coalesced.
+__global__ void __launch_bounds__(256) to_cube_kernel(const double* __restrict__ hist, double* __restrict__ cube,
+                                                      int rows /* (n+1)*m */, int N) {
+  __shared__ double tile[32][33];
+  const int f = blockIdx.z;
+  const double* __restrict__ h = hist + (size_t)f * rows * N;
+  double* __restrict__ o = cube + (size_t)f * rows * N;
+  const int i0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, i = i0 + tx;
+    if (r < rows && i < N) tile[k][tx] = h[(size_t)r * N + i];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int i = i0 + k, r = r0 + tx;
+    if (r < rows && i < N) o[(size_t)i * rows + r] = tile[tx][k];
+  }
+}
+
+hipError_t launch_to_cube(const double* hist, double* cube, int F, int n1, int m, int N, hipStream_t stream) {
+  const int rows = n1 * m;
+  hipLaunchKernelGGL(to_cube_kernel, dim3((N + 31) / 32, (rows + 31) / 32, F), dim3(256), 0, stream, hist, cube, rows,
+                     N);
+  return hipGetLastError();
+}
+
+}  // namespace bssm

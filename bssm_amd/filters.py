@@ -1,0 +1,168 @@
+"""Python mirror of bssm's R front-ends for the particle-filter path.  Same names, argument
+meaning, output fields and error behaviour as
+
+* ``bootstrap_filter``  R/bootstrap_filter.R:24-202
+* ``particle_smoother`` R/particle_smoother.R:1-291
+* ``logLik``            R/loglik.R:1-161
+
+Each call goes through the C ABI of libbssm_amd.so (HIP kernels); nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .models import BssmModel, model_arrays, model_type
+
+_INT_MAX = 2 ** 31 - 1
+
+
+def check_intmax(x, name="particles", positive=True, max=1e5):
+    """R/check_arguments.R:407-418"""
+    if not (isinstance(x, (int, np.integer)) or (isinstance(x, float) and x == int(x))) or x < 0 or (positive and x <= 0):
+        raise ValueError(f"Argument '{name}' should be a {'positive' if positive else 'non-negative'} integer. ")
+    if x > max:
+        raise ValueError(f"You probably do not want '{name}' > {max:g}. If you really do, please file an issue at Github. ")
+    return int(x)
+
+
+def _default_seed():
+    return int(np.random.default_rng().integers(0, _INT_MAX))
+
+
+def _alloc(shape):
+    return np.zeros(shape, dtype=np.float64, order="F")
+
+
+def _prep(model: BssmModel, need_mode: bool):
+    arr = model_arrays(model)
+    if not need_mode:
+        arr = dict(arr)
+    smod, keep = _lib.pack_model(arr)
+    return arr, smod, keep
+
+
+def _warn_if_degenerate(rc):
+    if rc == _lib.BSSM_WARN_DEGENERATE:
+        warnings.warn("Particle filtering stopped prematurely due to nonfinite log-likelihood.")
+
+
+def bootstrap_filter(model: BssmModel, particles: int, seed: int | None = None, return_indices: bool = False):
+    """R/bootstrap_filter.R:48-120 (lineargaussian :48-79, nongaussian :85-120).
+
+    Returns dict(at (n+1) x m, att n x m, Pt, Ptt, weights N x (n+1), logLik, alpha (n+1) x m x N)."""
+    particles = check_intmax(particles, "particles")
+    seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
+    gaussian = model.inherits("lineargaussian")
+    if not (gaussian or model.inherits("nongaussian")):
+        raise TypeError("bootstrap_filter is implemented for lineargaussian and nongaussian (ssm_ung family) models")
+    n, m = model.n, model.m
+    if n * m * particles > 1e10:  # R/bootstrap_filter.R:100-105
+        warnings.warn("Trying to sample states 1e10 times; consider smaller number of particles.")
+    arr, smod, keep = _prep(model, False)
+    out = _lib.FilterOut()
+    at, att = _alloc((n + 1, m)), _alloc((n, m))
+    Pt, Ptt = _alloc((m, m, n + 1)), _alloc((m, m, n))
+    weights, alpha = _alloc((particles, n + 1)), _alloc((m, n + 1, particles))
+    indices = np.zeros((particles, n), dtype=np.uint32, order="F") if return_indices else None
+    out.at, out.att, out.Pt, out.Ptt = map(_lib.dptr, (at, att, Pt, Ptt))
+    out.weights, out.alpha = _lib.dptr(weights), _lib.dptr(alpha)
+    if indices is not None:
+        out.indices = indices.ctypes.data_as(_lib.c_u32_p)
+    rc = _lib.check(_lib.lib().bssm_bsf(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed), int(gaussian),
+                                         model_type(model), C.byref(out)))
+    _warn_if_degenerate(rc)
+    res = dict(at=at, att=att, Pt=Pt, Ptt=Ptt, weights=weights, logLik=out.logLik,
+               alpha=np.transpose(alpha, (1, 0, 2)))  # aperm(out$alpha, c(2, 1, 3)), R/bootstrap_filter.R:118
+    if indices is not None:
+        res["indices"] = indices
+    return res
+
+
+def particle_smoother(model: BssmModel, particles: int, method: str = "psi", seed: int | None = None,
+                      return_indices: bool = False):
+    """R/particle_smoother.R:140-186 (nongaussian) and :84-133 (lineargaussian, bsf only here).
+
+    Returns dict(alphahat n x m, Vt m x m x n, weights, logLik, alpha n x m x N): the extra (n+1)-th
+    time point is dropped exactly as R/particle_smoother.R:178-184 does."""
+    particles = check_intmax(particles, "particles")
+    seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
+    if method not in ("psi", "bsf", "ekf"):
+        raise ValueError("'arg' should be one of 'psi', 'bsf', 'ekf'")
+    if method == "ekf":
+        raise ValueError("Method 'ekf' is only applicable to ssm_nlg models (out of scope for this build).")
+    gaussian = model.inherits("lineargaussian")
+    if gaussian and method == "psi":
+        raise NotImplementedError("psi-APF for linear-Gaussian models is exact simulation smoothing "
+                                  "(gaussian_psi_smoother); use method='bsf'.")
+    n, m = model.n, model.m
+    arr, smod, keep = _prep(model, method == "psi")
+    out = _lib.FilterOut()
+    alphahat, Vt = _alloc((n + 1, m)), _alloc((m, m, n + 1))
+    weights, alpha = _alloc((particles, n + 1)), _alloc((m, n + 1, particles))
+    indices = np.zeros((particles, n), dtype=np.uint32, order="F") if return_indices else None
+    out.alphahat, out.Vt, out.weights, out.alpha = map(_lib.dptr, (alphahat, Vt, weights, alpha))
+    if indices is not None:
+        out.indices = indices.ctypes.data_as(_lib.c_u32_p)
+    L = _lib.lib()
+    if method == "psi":
+        rc = L.bssm_psi_smoother(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed), model_type(model), C.byref(out))
+    else:
+        rc = L.bssm_bsf_smoother(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed), int(gaussian),
+                                 model_type(model), C.byref(out))
+    _warn_if_degenerate(_lib.check(rc))
+    res = dict(alphahat=alphahat[:n, :], Vt=Vt[:, :, :n], weights=weights, logLik=out.logLik,
+               alpha=np.transpose(alpha[:, :n, :], (1, 0, 2)))
+    if indices is not None:
+        res["indices"] = indices
+    return res
+
+
+def logLik(model: BssmModel, particles: int, method: str = "psi", seed: int | None = None) -> float:
+    """R/loglik.R:73-100 (nongaussian): method 'psi' or 'bsf'; particles = 0 gives the
+    Gaussian-approximation log-likelihood."""
+    particles = check_intmax(particles, "particles", positive=False)
+    seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
+    if method not in ("psi", "bsf", "spdk"):
+        raise ValueError("'arg' should be one of 'psi', 'bsf', 'spdk'")
+    if method == "spdk":
+        raise NotImplementedError("SPDK importance sampling is not a particle-filter path (SURVEY.md 2a N23).")
+    if not model.inherits("nongaussian"):
+        raise TypeError("logLik(particles, method) is for nongaussian models")
+    arr, smod, keep = _prep(model, True)
+    ll = C.c_double(0.0)
+    rc = _lib.check(_lib.lib().bssm_nongaussian_loglik(C.byref(smod), C.c_uint32(particles),
+                                                        C.c_uint32(1 if method == "psi" else 2), C.c_uint32(seed),
+                                                        model_type(model), C.byref(ll)))
+    _warn_if_degenerate(rc)
+    return ll.value
+
+
+def logLik_batch(model: BssmModel, particles: int, n_rep: int, method: str = "bsf", seed: int = 1, stream0: int = 0):
+    """n_rep independent log-likelihood estimates in one device batch (streams stream0..stream0+n_rep-1)."""
+    arr, smod, keep = _prep(model, True)
+    out = np.zeros(n_rep)
+    rc = _lib.check(_lib.lib().bssm_nongaussian_loglik_batch(
+        C.byref(smod), C.c_uint32(particles), C.c_uint32(1 if method == "psi" else 2), C.c_uint32(seed),
+        C.c_uint32(stream0), C.c_uint32(n_rep), _lib.dptr(out)))
+    _warn_if_degenerate(rc)
+    return out
+
+
+def psi_setup(model: BssmModel, is_mode=None):
+    """Gaussian approximation + conditional factors used by the psi-APF (host side of the library)."""
+    arr, smod, keep = _prep(model, True)
+    n, m = arr["n"], arr["m"]
+    res = dict(approx_y=np.zeros(n), approx_H=np.zeros(n), mode=np.zeros(n), scales=np.zeros(n),
+               alphahat=_alloc((m, n + 1)), Vt=_alloc((m, m, n + 1)), Ct=_alloc((m, m, n + 1)))
+    al = C.c_double(0.0)
+    mode_in = None if is_mode is None else np.ascontiguousarray(is_mode, dtype=np.float64)
+    _lib.check(_lib.lib().bssm_psi_setup(C.byref(smod), _lib.dptr(mode_in), _lib.dptr(res["approx_y"]),
+                                          _lib.dptr(res["approx_H"]), _lib.dptr(res["mode"]), _lib.dptr(res["scales"]),
+                                          C.byref(al), _lib.dptr(res["alphahat"]), _lib.dptr(res["Vt"]),
+                                          _lib.dptr(res["Ct"])))
+    res["approx_loglik"] = al.value
+    return res

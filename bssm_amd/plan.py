@@ -1,0 +1,67 @@
+"""Device-resident filter plan (bssm_plan_* in include/bssm_amd.h): fixed models, only the seed changes.
+Used by benchmarks and by callers that filter the same model repeatedly (pseudo-marginal MCMC)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .models import model_arrays
+
+
+class FilterPlan:
+    def __init__(self, models, particles: int, method: str = "bsf", n_rep: int = 1, keep_history: bool = False,
+                 force: str | None = None):
+        if not isinstance(models, (list, tuple)):
+            models = [models]
+        self._keep = []
+        packed = []
+        for mdl in models:
+            s, keep = _lib.pack_model(model_arrays(mdl))
+            packed.append(s)
+            self._keep.append(keep)
+        arr_t = _lib.UngModel * len(packed)
+        self._models = arr_t(*packed)
+        flags = (_lib.PLAN_KEEP_HISTORY if keep_history else 0)
+        flags |= {"grid": _lib.PLAN_FORCE_GRID, "wg": _lib.PLAN_FORCE_WG, None: 0}[force]
+        L = _lib.lib()
+        self._h = L.bssm_plan_create(self._models, len(packed), n_rep, particles, 1 if method == "psi" else 2, flags)
+        if not self._h:
+            raise _lib.BssmAmdError(L.bssm_amd_last_error().decode())
+        self.n_filters = len(packed) * n_rep
+        self.particles = particles
+        self.n = models[0].n
+        self.m = models[0].m
+
+    def info(self):
+        path, nf, blocks, threads = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        bps = C.c_double()
+        _lib.check(_lib.lib().bssm_plan_info(self._h, C.byref(path), C.byref(nf), C.byref(blocks), C.byref(threads),
+                                              C.byref(bps)))
+        return dict(path="grid" if path.value else "wg", n_filters=nf.value, blocks=blocks.value,
+                    threads=threads.value, bytes_per_particle_step=bps.value)
+
+    def run(self, seed: int, stream0: int = 0, hip_stream: int = 0):
+        _lib.check(_lib.lib().bssm_plan_run(self._h, seed, stream0, C.c_void_p(hip_stream)))
+
+    def loglik(self, hip_stream: int = 0):
+        out = np.zeros(self.n_filters)
+        _lib.check(_lib.lib().bssm_plan_loglik(self._h, C.c_void_p(hip_stream), _lib.dptr(out)))
+        return out
+
+    def time(self, seed: int, reps: int, hip_stream: int = 0) -> float:
+        ms = C.c_double()
+        _lib.check(_lib.lib().bssm_plan_time(self._h, seed, reps, C.c_void_p(hip_stream), C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            _lib.lib().bssm_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,213 @@
+/*
+ * bssm_amd.h -- C ABI of the MI355X particle-filter engine that stands in for the
+ * particle-filter / IS post-correction entry points of helske/bssm's shared library.
+ *
+ * Every entry point names the reference interface it replaces (file:line under the
+ * reference tree).  The reference boundary is R's .Call into Rcpp-generated
+ * `extern "C" SEXP _bssm_<name>(SEXP...)` stubs (src/RcppExports.cpp:57-69,1287-1351);
+ * the stubs only unpack the R list into the C++ model constructor
+ * (src/model_ssm_ung.cpp:9-32).  `bssm_ung_model` below is that constructor's field list
+ * as plain pointers, so an R-side shim is a field-by-field REAL()/INTEGER() unpack
+ * (INTEGRATION.md shows it).
+ *
+ * Conventions
+ *  - All arrays are column-major doubles exactly as R / Armadillo hold them.
+ *  - Inputs are read during the call only; outputs are caller-allocated; a NULL
+ *    output pointer skips that output (and the work behind it where possible).
+ *  - Return value: 0 = ok, BSSM_WARN_DEGENERATE = filter stopped on a non-finite
+ *    log-likelihood (the reference issues Rcpp::warning and returns -Inf,
+ *    src/R_bootstrap_filter.cpp:140-141), negative = error (message via
+ *    bssm_amd_last_error()).  There is NO CPU fallback: without a usable HIP device
+ *    every compute entry point returns BSSM_ERR_NO_DEVICE.
+ *  - Random numbers: counter-based Philox4x32-10 keyed by (seed, filter index); see
+ *    DESIGN.md.  Same (model, nsim, seed) => bit-identical output on every call,
+ *    for any number of GPUs (reference property: tests/testthat/test_bootstrap_filter.R:5-17).
+ */
+#ifndef BSSM_AMD_H
+#define BSSM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSSM_OK 0
+#define BSSM_WARN_DEGENERATE 1
+#define BSSM_ERR_NO_DEVICE (-1)
+#define BSSM_ERR_INVALID (-2)
+#define BSSM_ERR_UNSUPPORTED (-3)
+#define BSSM_ERR_HIP (-4)
+#define BSSM_ERR_NUMERIC (-5)
+
+/* distribution codes after `pmatch(...) - 1`, R/bootstrap_filter.R:106-109;
+ * 5 = gaussian observation (ssm_ulg / bsm_lg / ar1_lg with `gaussian = TRUE`). */
+enum { BSSM_SVM = 0, BSSM_POISSON = 1, BSSM_BINOMIAL = 2, BSSM_NEGBIN = 3, BSSM_GAMMA = 4, BSSM_GAUSSIAN = 5 };
+/* model_type(): R/model_type.R:1-16 (non-gaussian branch; gaussian branch uses 1..3 too) */
+enum { BSSM_SSM_MNG = 0, BSSM_SSM_UNG = 1, BSSM_BSM_NG = 2, BSSM_SVM_MODEL = 3, BSSM_AR1_NG = 4 };
+/* sampling_method: src/model_ssm_ung.cpp:163 */
+enum { BSSM_PSI = 1, BSSM_BSF = 2 };
+
+/* Fields read by ssm_ung::ssm_ung (src/model_ssm_ung.cpp:9-32) and, for gaussian = TRUE,
+ * ssm_ulg::ssm_ulg (src/model_ssm_ulg.cpp:8-38).  "(1|n)": 1 when time-invariant, n
+ * otherwise -- the *_tv flags carry what the reference infers from trailing extents
+ * (src/model_ssm_ung.cpp:15-16). */
+typedef struct bssm_ung_model {
+  int32_t n, m, k;
+  int32_t Ztv, Ttv, Rtv, Dtv, Ctv, Htv;
+  int32_t distribution;
+  int32_t n_xreg;           /* columns of xreg (0 = none) */
+  int32_t max_iter;         /* Laplace approximation: model_ssm_ung.cpp:21 */
+  int32_t local_approx;
+  double conv_tol;
+  double phi;
+  const double* y;            /* n, NaN = missing */
+  const double* Z;            /* m x (1|n) */
+  const double* T;            /* m x m x (1|n) */
+  const double* R;            /* m x k x (1|n) */
+  const double* a1;           /* m */
+  const double* P1;           /* m x m */
+  const double* D;            /* (1|n) */
+  const double* C;            /* m x (1|n) */
+  const double* xreg;         /* n x n_xreg or NULL */
+  const double* beta;         /* n_xreg or NULL */
+  const double* u;            /* n */
+  const double* H;            /* (1|n) observation sd; gaussian only */
+  const double* initial_mode; /* n; psi-APF only */
+} bssm_ung_model;
+
+/* Outputs of the filter / smoother wrappers, shaped as the reference returns them to R:
+ *   bsf           (src/R_bootstrap_filter.cpp:151-155): at (n+1) x m, att n x m, Pt m x m x (n+1),
+ *                 Ptt m x m x n, weights N x (n+1), logLik, alpha m x (n+1) x N
+ *   bsf_smoother / psi_smoother (src/R_bootstrap_filter.cpp:374-377, src/R_psi.cpp:97-101):
+ *                 alphahat (n+1) x m, Vt m x m x (n+1), weights, logLik, alpha (back-traced)
+ * `indices` (N x n ancestor table, uint32) is an extension for testing; the reference keeps
+ * it internal. */
+typedef struct bssm_filter_out {
+  double* at;
+  double* att;
+  double* Pt;
+  double* Ptt;
+  double* alphahat;
+  double* Vt;
+  double* weights;
+  double* alpha;
+  uint32_t* indices;
+  double logLik;
+} bssm_filter_out;
+
+/* ---- library / device ---- */
+int bssm_amd_device_count(void);
+const char* bssm_amd_last_error(void);
+const char* bssm_amd_version(void);
+
+/* ---- drop-in entry points (host buffers in, host buffers out) ---- */
+
+/* replaces _bssm_bsf: `Rcpp::List bsf(model_, nsim, seed, gaussian, model_type)`
+ * src/R_bootstrap_filter.cpp:15-241, registered src/RcppExports.cpp:57-69 */
+int bssm_bsf(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int gaussian, int model_type,
+             bssm_filter_out* out);
+
+/* replaces _bssm_bsf_smoother: src/R_bootstrap_filter.cpp:245-457 */
+int bssm_bsf_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int gaussian, int model_type,
+                      bssm_filter_out* out);
+
+/* replaces _bssm_psi_smoother: `psi_smoother(model_, nsim, seed, model_type)` src/R_psi.cpp:52-171 */
+int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int model_type,
+                      bssm_filter_out* out);
+
+/* replaces _bssm_nongaussian_loglik: `double nongaussian_loglik(model_, nsim, sampling_method, seed,
+ * model_type)` src/R_loglik.cpp:41-87.  nsim = 0 returns the Gaussian-approximation log-likelihood
+ * (src/model_ssm_ung.cpp:214-234). */
+int bssm_nongaussian_loglik(const bssm_ung_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed,
+                            int model_type, double* loglik);
+
+/* Batched log-likelihoods: `n_rep` independent filters of the same model with Philox streams
+ * stream0 .. stream0+n_rep-1 (what suggest_N / repeated logLik calls do one at a time,
+ * src/R_postcorrection.cpp:24-35).  loglik has n_rep entries. */
+int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, uint32_t sampling_method,
+                                  uint32_t seed, uint32_t stream0, uint32_t n_rep, double* loglik);
+
+/* ---- IS post-correction ----
+ * replaces _bssm_postcorrection_nongaussian: `postcorrection_nongaussian(model_, model_type, output_type,
+ * nsim, seed, n_threads, is_type, counts, theta, modes)` src/R_postcorrection.cpp:150-248 and the drivers
+ * approx_mcmc::is_correction_psi / _bsf (src/approx_mcmc.cpp:353-427, 447-518, 685-921).
+ *
+ * The theta-dependent model components are supplied pre-expanded, one bssm_ung_model per retained
+ * draw -- exactly what parset_ung materialises before the parallel region (src/parset_ng.cpp:5-111);
+ * bssm_update_model_builtin() below reproduces the built-in update_model() maps for
+ * bsm_ng / svm / ar1_ng.  `first`/`count` select the contiguous block of draws this process owns
+ * (theta-sharding across GPUs); random streams are keyed by the GLOBAL draw index, so the result
+ * does not depend on how the draws are sharded. */
+typedef struct bssm_is_job {
+  int32_t n_stored;              /* global number of retained draws */
+  int32_t first, count;          /* this process handles draws [first, first+count) */
+  const bssm_ung_model* models;  /* `count` models (local) */
+  const double* modes;           /* n x count signal modes (psi) or NULL */
+  const double* approx_loglik;   /* count (bsf: src/approx_mcmc.cpp:479) or NULL */
+  const uint32_t* counts;        /* count jump-chain multiplicities */
+  int32_t sampling_method;       /* BSSM_PSI / BSSM_BSF */
+  int32_t is_type;               /* 1..3 (is3 = caller pre-expanded, src/approx_mcmc.cpp:49-88) */
+  int32_t output_type;           /* 1 full, 2 summary, 3 theta */
+  uint32_t nsim;
+  uint32_t seed;
+  int32_t n_threads;             /* host threads for the per-draw psi set-up */
+} bssm_is_job;
+
+/* outputs (local block): weights[count], loglik[count] (log of the filter estimate),
+ * output 1: alpha (n+1) x m x count; output 2: per-draw alphahat_i m x (n+1) x count and
+ * Vt_i m x m x (n+1) x count -- the caller (or bssm_is_merge) folds them with weights*counts. */
+int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, double* alpha,
+                       double* alphahat_i, double* Vt_i);
+
+/* West/Chan merge of per-draw summaries in draw order (src/approx_mcmc.cpp:397-414, 422-424):
+ * alphahat m x (n+1), Vt m x m x (n+1). Host-side, O(n_stored * n * m^2). */
+int bssm_is_merge(int32_t n, int32_t m, int32_t n_stored, const double* weights, const uint32_t* counts,
+                  const double* alphahat_i, const double* Vt_i, double* alphahat, double* Vt);
+
+/* Built-in parameter maps: bsm_ng::update_model (src/model_bsm_ng.cpp:17-51), svm::update_model
+ * (src/model_svm.cpp:12-29), ar1_ng::update_model (src/model_ar1_ng.cpp:12-36).  Writes into the
+ * caller-owned (mutable) arrays the model points at. `flags` carries the model-type specific
+ * switches: bsm_ng {slope, seasonal, noise, fixed[0..2], phi_est}, svm {svm_type},
+ * ar1_ng {mu_est, phi_est}. */
+int bssm_update_model_builtin(int model_type, const int32_t* flags, const double* theta, int32_t n_par,
+                              bssm_ung_model* model, double* T, double* R, double* P1, double* a1, double* C,
+                              double* beta);
+
+/* ---- psi-APF set-up on its own (host): approximate() + smoother_ccov + conditional_cov,
+ * src/model_ssm_ung.cpp:87-161, 514-534.  is_mode NULL = iterate from initial_mode.
+ * Outputs: approx_y[n], approx_H[n], mode[n], scales[n], approx_loglik, alphahat m x (n+1),
+ * Vt / Ct m x m x (n+1). Any may be NULL. */
+int bssm_psi_setup(const bssm_ung_model* model, const double* is_mode, double* approx_y, double* approx_H,
+                   double* mode, double* scales, double* approx_loglik, double* alphahat, double* Vt, double* Ct);
+
+/* ---- device-resident plan: repeated filtering of fixed models with nothing but the seed
+ * changing (pseudo-marginal MCMC inner loop, benchmarks).  Outputs stay in HBM. ---- */
+typedef struct bssm_plan bssm_plan;
+#define BSSM_PLAN_KEEP_HISTORY 1u  /* alpha, indices, weights kept (full-output filter) */
+#define BSSM_PLAN_FORCE_GRID 2u
+#define BSSM_PLAN_FORCE_WG 4u
+/* n_models filters x n_rep replicas each; model i, replica r uses stream stream0 + i*n_rep + r */
+bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int32_t n_rep, uint32_t nsim,
+                            uint32_t sampling_method, uint32_t flags);
+void bssm_plan_destroy(bssm_plan* plan);
+/* enqueue one pass on `hip_stream` (a hipStream_t, may be NULL for the default stream); async */
+int bssm_plan_run(bssm_plan* plan, uint32_t seed, uint32_t stream0, void* hip_stream);
+/* wait for the stream and copy the n_models*n_rep log-likelihoods (constants included) */
+int bssm_plan_loglik(bssm_plan* plan, void* hip_stream, double* loglik);
+/* introspection for benchmarks: which kernel shape, its grid, algorithmic bytes per particle-step */
+int bssm_plan_info(const bssm_plan* plan, int32_t* path /*0 wg, 1 grid*/, int32_t* n_filters, int32_t* blocks,
+                   int32_t* threads, double* bytes_per_particle_step);
+/* device pointers of the kept outputs (NULL when not kept): alpha_hist [f][n+1][m][N],
+ * indices [f][n][N], weights [f][n+1][N] */
+int bssm_plan_device_outputs(const bssm_plan* plan, void** alpha_hist, void** indices, void** weights);
+/* average device time per bssm_plan_run over `reps` runs, measured with HIP events on `hip_stream` */
+int bssm_plan_time(bssm_plan* plan, uint32_t seed, int32_t reps, void* hip_stream, double* ms_per_run);
+
+/* exposed for tests: the exact Philox block and uniform / normal pair the kernels use */
+void bssm_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

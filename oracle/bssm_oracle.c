@@ -1,0 +1,928 @@
+/*
+ * bssm_oracle.c -- CPU restatement of the helske/bssm particle-filter hot path.
+ * TEST INFRASTRUCTURE ONLY; see bssm_oracle.h for the parity status ("parity
+ * unpinned" at bit level; pinned by analytic / closed-form checks).
+ *
+ * Citations are file:line under the reference tree (src/ unless stated).
+ */
+#include "bssm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_PI 3.14159265358979323846
+#define ORC_ZERO_TOL 1e-12 /* model_ssm_ung.h:21, model_ssm_ulg.h:19 */
+#define ORC_EPS 2.220446049250313e-16
+
+/* ------------------------------------------------------------------ */
+/* Random stream                                                       */
+/* ------------------------------------------------------------------ */
+
+/* Philox4x32-10 (Salmon et al., SC'11), Random123 constants. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline uint64_t bits53(uint32_t a, uint32_t b) {
+  return ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6);
+}
+
+static void draw(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d, uint32_t w[4]) {
+  uint32_t ctr[4] = { i, t, d, purpose };
+  uint32_t key[2] = { r->seed, r->stream };
+  orc_philox4x32_10(ctr, key, w);
+}
+
+/* purpose: 0 initial-state normals, 1 resampling uniform, 2 transition normals,
+ * 3 trajectory pick, 4 SDE increments. */
+double orc_rng_uniform(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d) {
+  if (r->mode == 1 && purpose == 1) return r->unif[(size_t)t * r->N + i];
+  uint32_t w[4];
+  draw(r, purpose, t, i, d, w);
+  return (double)bits53(w[0], w[1]) * 0x1.0p-53;
+}
+
+void orc_rng_normal_pair(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d,
+                         double *z0, double *z1) {
+  uint32_t w[4];
+  draw(r, purpose, t, i, d, w);
+  double u1 = (double)(bits53(w[0], w[1]) + 1) * 0x1.0p-53; /* (0,1] */
+  double u2 = (double)bits53(w[2], w[3]) * 0x1.0p-53;       /* [0,1) */
+  double rad = sqrt(-2.0 * log(u1));
+  double ang = 2.0 * ORC_PI * u2;
+  *z0 = rad * cos(ang);
+  *z1 = rad * sin(ang);
+}
+
+/* cnt standard normals for particle i at step t */
+static void rng_normals(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, int cnt, double *out) {
+  if (r->mode == 1) {
+    if (purpose == 0) {
+      for (int j = 0; j < cnt; j++) out[j] = r->init_normals[(size_t)i * cnt + j];
+    } else {
+      for (int j = 0; j < cnt; j++) out[j] = r->normals[((size_t)t * r->N + i) * r->kk + j];
+    }
+    return;
+  }
+  for (int j = 0; j < cnt; j += 2) {
+    double z0, z1;
+    orc_rng_normal_pair(r, purpose, t, i, (uint32_t)(j / 2), &z0, &z1);
+    out[j] = z0;
+    if (j + 1 < cnt) out[j + 1] = z1;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* Small dense helpers (m <= ORC_MAXM)                                 */
+/* ------------------------------------------------------------------ */
+#define ORC_MAXM 16
+
+/* lower Cholesky of the sub-matrix selected by idx (count entries); arma::chol(.,"lower") */
+static int chol_lower_sub(const double *P, int m, const int *idx, int cnt, double *L /* m x m, zeroed */) {
+  for (int a = 0; a < cnt; a++) {
+    for (int b = 0; b <= a; b++) {
+      double s = P[idx[a] + m * idx[b]];
+      for (int c = 0; c < b; c++) s -= L[idx[a] + m * idx[c]] * L[idx[b] + m * idx[c]];
+      if (a == b) {
+        if (!(s > 0.0)) return -1;
+        L[idx[a] + m * idx[a]] = sqrt(s);
+      } else {
+        L[idx[a] + m * idx[b]] = s / L[idx[b] + m * idx[b]];
+      }
+    }
+  }
+  return 0;
+}
+
+/* model_ssm_ung.cpp:614-619 */
+static void ung_initial_chol(const double *P1, int m, double *L) {
+  int idx[ORC_MAXM], cnt = 0;
+  memset(L, 0, sizeof(double) * m * m);
+  for (int j = 0; j < m; j++) if (P1[j + m * j] > 0) idx[cnt++] = j;
+  if (cnt > 0) chol_lower_sub(P1, m, idx, cnt, L);
+}
+
+/* psd_chol.cpp:5-18 */
+void orc_psd_chol(const double *x, int m, double *L) {
+  int idx[ORC_MAXM], cnt = 0;
+  double dmax = x[0];
+  for (int j = 1; j < m; j++) if (x[j + m * j] > dmax) dmax = x[j + m * j];
+  double thr = fmax(ORC_EPS, ORC_EPS * m * dmax);
+  memset(L, 0, sizeof(double) * m * m);
+  for (int j = 0; j < m; j++) if (x[j + m * j] > thr) idx[cnt++] = j;
+  if (cnt > 0) chol_lower_sub(x, m, idx, cnt, L);
+}
+
+/* ------------------------------------------------------------------ */
+/* distribution constants: distr_consts.cpp:7-31                       */
+/* ------------------------------------------------------------------ */
+static double orc_lchoose(double n, double k) { /* distr_consts.cpp:7-9 */
+  return -log(n + 1) - lgamma(n - k + 1) - lgamma(k + 1) + lgamma(n + 2);
+}
+static double norm_log_const(double sd) { return -0.5 * log(2.0 * ORC_PI) - log(sd); }
+
+/* model_ssm_ung.cpp:690-710 (bsf) and :351-368 (first part of compute_const_term) */
+double orc_ung_const_term(const orc_ung_model *mod) {
+  double res = 0.0;
+  int nfin = 0;
+  for (int t = 0; t < mod->n; t++) {
+    double y = mod->y[t];
+    if (!isfinite(y)) continue;
+    nfin++;
+    double u = mod->u ? mod->u[t] : 1.0;
+    switch (mod->distribution) {
+    case ORC_POISSON: res += y * log(u) - lgamma(y + 1); break;                 /* distr_consts.cpp:38-44 */
+    case ORC_BINOMIAL: res += orc_lchoose(u, y); break;                          /* :46-52 */
+    case ORC_NEGBIN: res += orc_lchoose(y + mod->phi - 1, y) + mod->phi * log(mod->phi) + y * log(u); break; /* :54-60 */
+    case ORC_GAMMA: res += mod->phi * log(mod->phi) - lgamma(mod->phi) + (mod->phi - 1) * log(y) - mod->phi * log(u); break; /* :62-67 */
+    default: break;
+    }
+  }
+  if (mod->distribution == ORC_SVM) res = nfin * norm_log_const(mod->phi); /* model_ssm_ung.cpp:692 */
+  return res;
+}
+
+/* ------------------------------------------------------------------ */
+/* observation densities                                               */
+/* ------------------------------------------------------------------ */
+static inline double ung_signal(const orc_ung_model *mod, int t, const double *a) {
+  /* model_ssm_ung.cpp:462-463: D(t*Dtv) + Z.col(t*Ztv).t() * alpha + xbeta(t) */
+  const double *Zt = mod->Z + (size_t)mod->m * (t * mod->Ztv);
+  double za = 0.0;
+  for (int j = 0; j < mod->m; j++) za += Zt[j] * a[j];
+  return mod->D[t * mod->Dtv] + za + mod->xbeta[t];
+}
+
+/* model_ssm_ung.cpp:447-493, one particle; gaussian: model_ssm_ulg.cpp:582-586 */
+static inline double ung_log_obs_density(const orc_ung_model *mod, int t, const double *a) {
+  double y = mod->y[t], phi = mod->phi;
+  switch (mod->distribution) {
+  case ORC_SVM: {
+    double s = a[0]; /* :456 */
+    return -0.5 * (s + pow(y / phi, 2.0) * exp(-s));
+  }
+  case ORC_POISSON: { double s = ung_signal(mod, t, a); return y * s - mod->u[t] * exp(s); }
+  case ORC_BINOMIAL: { double s = ung_signal(mod, t, a); return y * s - mod->u[t] * log1p(exp(s)); }
+  case ORC_NEGBIN: { double s = ung_signal(mod, t, a); return y * s - (y + phi) * log(phi + mod->u[t] * exp(s)); }
+  case ORC_GAMMA: { double s = ung_signal(mod, t, a); return -phi * (s + (y * exp(-s) / mod->u[t])); }
+  case ORC_GAUSSIAN: {
+    const double *Zt = mod->Z + (size_t)mod->m * (t * mod->Ztv);
+    double za = 0.0;
+    for (int j = 0; j < mod->m; j++) za += Zt[j] * a[j];
+    double mu = mod->D[t * mod->Dtv] + za; /* ulg bsf ignores xbeta: model_ssm_ulg.cpp:583-584 */
+    double H = mod->H[t * mod->Htv];
+    return -0.5 * pow(y - mu, 2.0) / (H * H);
+  }
+  }
+  return 0.0;
+}
+
+/* model_ssm_ung.cpp:385-439, one particle */
+static inline double ung_log_weight(const orc_ung_model *mod, const orc_psi_setup *su, int t, const double *a) {
+  double s = (mod->distribution == ORC_SVM) ? a[0] : ung_signal(mod, t, a);
+  return ung_log_obs_density(mod, t, a) + 0.5 * pow((su->approx_y[t] - s) / su->approx_H[t], 2.0);
+}
+
+/* ------------------------------------------------------------------ */
+/* stratified resampling: stratified_sample.cpp:9-28                   */
+/* ------------------------------------------------------------------ */
+void orc_stratified_sample(double *p, const double *r, unsigned N, unsigned *out) {
+  for (unsigned k = 1; k < N; k++) p[k] += p[k - 1]; /* arma::cumsum */
+  p[N - 1] = 1;
+  unsigned j = 0;
+  double alpha = 1.0 / N;
+  for (unsigned k = 0; k < N && j < N; k++) {
+    while (j < N && (r[j] + j) * alpha <= p[k]) { out[j] = k; j++; }
+  }
+  while (j < N) { out[j] = N - 1; j++; }
+}
+
+/* shared tail of every filter step: model_ssm_ung.cpp:634-647 / 672-687.
+ * logw holds N log-weights; on return wcol = exp(logw - max), nw = normalised.
+ * returns 0 on degeneracy. */
+static int normalise_step(const double *logw, unsigned N, double *wcol, size_t wstride, double *nw, double *ll_inc) {
+  double maxw = logw[0];
+  for (unsigned i = 1; i < N; i++) if (logw[i] > maxw) maxw = logw[i];
+  double sumw = 0.0;
+  for (unsigned i = 0; i < N; i++) { wcol[i * wstride] = exp(logw[i] - maxw); }
+  for (unsigned i = 0; i < N; i++) sumw += wcol[i * wstride];
+  if (!(sumw > 0.0)) return 0;
+  for (unsigned i = 0; i < N; i++) nw[i] = wcol[i * wstride] / sumw;
+  *ll_inc = maxw + log(sumw / N);
+  return 1;
+}
+
+#define A_(j, t, i) alpha[(size_t)(j) + (size_t)m * ((size_t)(t) + (size_t)(n + 1) * (size_t)(i))]
+
+/* ------------------------------------------------------------------ */
+/* bootstrap filter: model_ssm_ung.cpp:611-712 (+ model_ssm_ulg.cpp:557-643) */
+/* ------------------------------------------------------------------ */
+double orc_ung_bsf_filter(const orc_ung_model *mod, unsigned N, const orc_rng *rng,
+                          double *alpha, double *weights, unsigned *indices) {
+  const int n = mod->n, m = mod->m, k = mod->k;
+  const int gauss = mod->distribution == ORC_GAUSSIAN;
+  double L[ORC_MAXM * ORC_MAXM];
+  if (gauss) orc_psd_chol(mod->P1, m, L); else ung_initial_chol(mod->P1, m, L);
+
+  double *nw = (double *)malloc(sizeof(double) * N);
+  double *lw = (double *)malloc(sizeof(double) * N);
+  double *r = (double *)malloc(sizeof(double) * N);
+  double *atmp = (double *)malloc(sizeof(double) * N * m);
+  double um[ORC_MAXM];
+
+  for (unsigned i = 0; i < N; i++) { /* :621-627 */
+    rng_normals(rng, 0, 0, i, m, um);
+    for (int j = 0; j < m; j++) {
+      double s = 0.0;
+      for (int c = 0; c < m; c++) s += L[j + m * c] * um[c];
+      A_(j, 0, i) = mod->a1[j] + s;
+    }
+  }
+  double loglik = 0.0, inc;
+  if (isfinite(mod->y[0])) { /* :633-643 */
+    for (unsigned i = 0; i < N; i++) lw[i] = ung_log_obs_density(mod, 0, &A_(0, 0, i));
+    if (!normalise_step(lw, N, weights, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+    loglik = inc + (gauss ? norm_log_const(mod->H[0]) : 0.0);
+  } else {
+    for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
+  }
+  for (int t = 0; t < n; t++) {
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0); /* :650-653 */
+    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);                 /* :655 */
+    for (unsigned i = 0; i < N; i++)                                          /* :659-661 */
+      for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
+    const double *Tt = mod->T + (size_t)m * m * (t * mod->Ttv);
+    const double *Rt = mod->R + (size_t)m * k * (t * mod->Rtv);
+    const double *Ct = mod->C + (size_t)m * (t * mod->Ctv);
+    for (unsigned i = 0; i < N; i++) { /* :663-670 */
+      rng_normals(rng, 2, t, i, k, um);
+      for (int j = 0; j < m; j++) {
+        double s = 0.0, q = 0.0;
+        for (int c = 0; c < m; c++) s += Tt[j + m * c] * atmp[c + (size_t)m * i];
+        for (int c = 0; c < k; c++) q += Rt[j + m * c] * um[c];
+        A_(j, t + 1, i) = Ct[j] + s + q;
+      }
+    }
+    double *wcol = weights + (size_t)N * (t + 1);
+    if ((t < n - 1) && isfinite(mod->y[t + 1])) { /* :672-683 */
+      for (unsigned i = 0; i < N; i++) lw[i] = ung_log_obs_density(mod, t + 1, &A_(0, t + 1, i));
+      if (!normalise_step(lw, N, wcol, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+      loglik += inc + (gauss ? norm_log_const(mod->H[(t + 1) * mod->Htv]) : 0.0);
+    } else {
+      for (unsigned i = 0; i < N; i++) { wcol[i] = 1.0; nw[i] = 1.0 / N; }
+    }
+  }
+  if (!gauss) loglik += orc_ung_const_term(mod); /* :690-710 */
+done:
+  free(nw); free(lw); free(r); free(atmp);
+  return loglik;
+}
+
+/* ------------------------------------------------------------------ */
+/* Linear-Gaussian machinery (ssm_ulg)                                 */
+/* ------------------------------------------------------------------ */
+static void mat_mul(const double *A, const double *B, int r, int inner, int c, double *out) {
+  for (int j = 0; j < c; j++)
+    for (int i = 0; i < r; i++) {
+      double s = 0.0;
+      for (int q = 0; q < inner; q++) s += A[i + r * q] * B[q + inner * j];
+      out[i + r * j] = s;
+    }
+}
+static void mat_mul_bt(const double *A, const double *B, int r, int inner, int c, double *out) { /* A * B' ; B is c x inner */
+  for (int j = 0; j < c; j++)
+    for (int i = 0; i < r; i++) {
+      double s = 0.0;
+      for (int q = 0; q < inner; q++) s += A[i + r * q] * B[j + c * q];
+      out[i + r * j] = s;
+    }
+}
+static void mat_mul_at(const double *A, const double *B, int r, int inner, int c, double *out) { /* A' * B ; A is inner x r */
+  for (int j = 0; j < c; j++)
+    for (int i = 0; i < r; i++) {
+      double s = 0.0;
+      for (int q = 0; q < inner; q++) s += A[q + inner * i] * B[q + inner * j];
+      out[i + r * j] = s;
+    }
+}
+static void symmatu(double *A, int m) { /* arma::symmatu: copy upper to lower */
+  for (int j = 0; j < m; j++) for (int i = j + 1; i < m; i++) A[i + m * j] = A[j + m * i];
+}
+static void compute_RR(const double *R, int m, int k, double *RR) { mat_mul_bt(R, R, m, k, m, RR); }
+
+#define G_Z(t) (g->Z + (size_t)m * ((t) * g->Ztv))
+#define G_T(t) (g->T + (size_t)m * m * ((t) * g->Ttv))
+#define G_R(t) (g->R + (size_t)m * g->k * ((t) * g->Rtv))
+#define G_C(t) (g->C + (size_t)m * ((t) * g->Ctv))
+#define G_HH(t) (g->H[(t) * g->Htv] * g->H[(t) * g->Htv])
+
+static double dotv(const double *a, const double *b, int m) { double s = 0; for (int j = 0; j < m; j++) s += a[j] * b[j]; return s; }
+static double quad(const double *z, const double *P, int m) { /* z' P z */
+  double s = 0; for (int j = 0; j < m; j++) { double q = 0; for (int i = 0; i < m; i++) q += z[i] * P[i + m * j]; s += q * z[j]; } return s;
+}
+
+/* one prediction step shared by the three Kalman routines. joseph=0: Pt - K K' F form
+ * (model_ssm_ulg.cpp:129), joseph=1: (I-KZ')P(I-KZ')' + K HH K' (:276-277, :442-443) */
+static void kf_step(const orc_ulg_model *g, int t, const double *at, const double *Pt, int joseph,
+                    double *at1, double *Pt1, double *F_out, double *v_out, double *K_out, int *observed) {
+  const int m = g->m;
+  const double *Zt = G_Z(t), *Tt = G_T(t);
+  double RR[ORC_MAXM * ORC_MAXM], tmp[ORC_MAXM * ORC_MAXM], tmp2[ORC_MAXM * ORC_MAXM], M[ORC_MAXM * ORC_MAXM];
+  compute_RR(G_R(t), m, g->k, RR);
+  double HH = G_HH(t);
+  double F = quad(Zt, Pt, m) + HH;
+  double ytmp = g->y[t] - g->xbeta[t];
+  *F_out = F;
+  if (isfinite(ytmp) && F > ORC_ZERO_TOL) {
+    *observed = 1;
+    double v = ytmp - g->D[t * g->Dtv] - dotv(Zt, at, m);
+    *v_out = v;
+    double K[ORC_MAXM], af[ORC_MAXM];
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Pt[i + m * j] * Zt[j]; K[i] = s / F; }
+    if (K_out) memcpy(K_out, K, sizeof(double) * m);
+    for (int i = 0; i < m; i++) af[i] = at[i] + K[i] * v;
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Tt[i + m * j] * af[j]; at1[i] = G_C(t)[i] + s; }
+    if (!joseph) {
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) M[i + m * j] = Pt[i + m * j] - K[i] * K[j] * F;
+    } else {
+      double IKZ[ORC_MAXM * ORC_MAXM];
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zt[j];
+      mat_mul(IKZ, Pt, m, m, m, tmp);
+      mat_mul_bt(tmp, IKZ, m, m, m, M);
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) M[i + m * j] += K[i] * HH * K[j];
+    }
+    mat_mul(Tt, M, m, m, m, tmp);
+    mat_mul_bt(tmp, Tt, m, m, m, tmp2);
+  } else {
+    *observed = 0;
+    *v_out = 0.0;
+    if (K_out) memset(K_out, 0, sizeof(double) * m);
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Tt[i + m * j] * at[j]; at1[i] = G_C(t)[i] + s; }
+    mat_mul(Tt, Pt, m, m, m, tmp);
+    mat_mul_bt(tmp, Tt, m, m, m, tmp2);
+  }
+  for (int q = 0; q < m * m; q++) Pt1[q] = tmp2[q] + RR[q];
+  symmatu(Pt1, m);
+}
+
+/* model_ssm_ulg.cpp:106-138 */
+double orc_ulg_loglik(const orc_ulg_model *g) {
+  const int n = g->n, m = g->m;
+  double accH = 0, accR = 0;
+  for (int t = 0; t < (g->Htv ? n : 1); t++) accH += g->H[t];
+  for (int q = 0; q < m * g->k * (g->Rtv ? n : 1); q++) accR += g->R[q];
+  if (accH + accR < ORC_ZERO_TOL) return -INFINITY;
+  double at[ORC_MAXM], Pt[ORC_MAXM * ORC_MAXM], at1[ORC_MAXM], Pt1[ORC_MAXM * ORC_MAXM];
+  memcpy(at, g->a1, sizeof(double) * m);
+  memcpy(Pt, g->P1, sizeof(double) * m * m);
+  const double LOG2PI = log(2.0 * ORC_PI);
+  double ll = 0.0;
+  for (int t = 0; t < n; t++) {
+    double F, v; int obs;
+    kf_step(g, t, at, Pt, 0, at1, Pt1, &F, &v, NULL, &obs);
+    if (obs) ll -= 0.5 * (LOG2PI + log(F) + v * v / F);
+    memcpy(at, at1, sizeof(double) * m);
+    memcpy(Pt, Pt1, sizeof(double) * m * m);
+  }
+  return ll;
+}
+
+/* model_ssm_ulg.cpp:252-305 */
+void orc_ulg_fast_smoother(const orc_ulg_model *g, double *at) {
+  const int n = g->n, m = g->m;
+  double *vt = (double *)calloc(n, sizeof(double)), *Ft = (double *)calloc(n, sizeof(double));
+  double *Kt = (double *)calloc((size_t)m * n, sizeof(double));
+  int *ob = (int *)calloc(n, sizeof(int));
+  double *rt = (double *)calloc((size_t)m * n, sizeof(double));
+  double Pt[ORC_MAXM * ORC_MAXM], Pt1[ORC_MAXM * ORC_MAXM];
+  memcpy(at, g->a1, sizeof(double) * m);
+  memcpy(Pt, g->P1, sizeof(double) * m * m);
+  for (int t = 0; t < n; t++) {
+    kf_step(g, t, at + (size_t)m * t, Pt, 1, at + (size_t)m * (t + 1), Pt1, &Ft[t], &vt[t], Kt + (size_t)m * t, &ob[t]);
+    memcpy(Pt, Pt1, sizeof(double) * m * m);
+  }
+  double L[ORC_MAXM * ORC_MAXM];
+  for (int t = n - 1; t > 0; t--) { /* :284-291 */
+    const double *Zt = G_Z(t), *Tt = G_T(t), *r1 = rt + (size_t)m * t;
+    double *r0 = rt + (size_t)m * (t - 1);
+    if (ob[t]) {
+      double IKZ[ORC_MAXM * ORC_MAXM];
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - Kt[i + (size_t)m * t] * Zt[j];
+      mat_mul(Tt, IKZ, m, m, m, L);
+      for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += L[j + m * i] * r1[j]; r0[i] = Zt[i] / Ft[t] * vt[t] + s; }
+    } else {
+      for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Tt[j + m * i] * r1[j]; r0[i] = s; }
+    }
+  }
+  { /* :292-297 */
+    const double *Z0 = g->Z, *T0 = g->T, *r0 = rt;
+    double tmpv[ORC_MAXM];
+    if (isfinite(g->y[0]) && Ft[0] > ORC_ZERO_TOL) {
+      double IKZ[ORC_MAXM * ORC_MAXM];
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - Kt[i] * Z0[j];
+      mat_mul(T0, IKZ, m, m, m, L);
+      for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += L[j + m * i] * r0[j]; tmpv[i] = Z0[i] / Ft[0] * vt[0] + s; }
+    } else {
+      for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += T0[j + m * i] * r0[j]; tmpv[i] = s; }
+    }
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += g->P1[i + m * j] * tmpv[j]; at[i] = g->a1[i] + s; }
+  }
+  for (int t = 0; t < n - 1; t++) { /* :299-301 */
+    double RR[ORC_MAXM * ORC_MAXM];
+    compute_RR(G_R(t), m, g->k, RR);
+    const double *Tt = G_T(t), *a0 = at + (size_t)m * t, *r0 = rt + (size_t)m * t;
+    double *a1v = at + (size_t)m * (t + 1);
+    for (int i = 0; i < m; i++) {
+      double s = 0, q = 0;
+      for (int j = 0; j < m; j++) { s += Tt[i + m * j] * a0[j]; q += RR[i + m * j] * r0[j]; }
+      a1v[i] = G_C(t)[i] + s + q;
+    }
+  }
+  free(vt); free(Ft); free(Kt); free(ob); free(rt);
+}
+
+/* model_ssm_ulg.cpp:419-473 */
+void orc_ulg_smoother_ccov(const orc_ulg_model *g, double *at, double *Pt, double *ccov) {
+  const int n = g->n, m = g->m, mm = m * m;
+  double *vt = (double *)calloc(n, sizeof(double)), *Ft = (double *)calloc(n, sizeof(double));
+  double *Kt = (double *)calloc((size_t)m * n, sizeof(double));
+  int *ob = (int *)calloc(n, sizeof(int));
+  memcpy(at, g->a1, sizeof(double) * m);
+  memcpy(Pt, g->P1, sizeof(double) * mm);
+  for (int t = 0; t < n; t++) {
+    kf_step(g, t, at + (size_t)m * t, Pt + (size_t)mm * t, 1, at + (size_t)m * (t + 1), Pt + (size_t)mm * (t + 1),
+            &Ft[t], &vt[t], Kt + (size_t)m * t, &ob[t]);
+    memcpy(ccov + (size_t)mm * t, Pt + (size_t)mm * (t + 1), sizeof(double) * mm); /* :449 */
+  }
+  double rt[ORC_MAXM] = {0}, Nt[ORC_MAXM * ORC_MAXM] = {0};
+  double L[ORC_MAXM * ORC_MAXM], A[ORC_MAXM * ORC_MAXM], B[ORC_MAXM * ORC_MAXM], Cm[ORC_MAXM * ORC_MAXM], rn[ORC_MAXM];
+  for (int t = n - 1; t >= 0; t--) {
+    const double *Zt = G_Z(t), *Tt = G_T(t);
+    double *Ptt = Pt + (size_t)mm * t, *cc = ccov + (size_t)mm * t;
+    if (ob[t]) {
+      double IKZ[ORC_MAXM * ORC_MAXM];
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - Kt[i + (size_t)m * t] * Zt[j];
+      mat_mul(Tt, IKZ, m, m, m, L);
+      /* ccov = Pt * L' * (I - Nt * ccov) */
+      mat_mul(Nt, cc, m, m, m, A);
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) A[i + m * j] = (i == j ? 1.0 : 0.0) - A[i + m * j];
+      mat_mul_bt(Ptt, L, m, m, m, B);
+      mat_mul(B, A, m, m, m, Cm);
+      memcpy(cc, Cm, sizeof(double) * mm);
+      for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += L[j + m * i] * rt[j]; rn[i] = Zt[i] / Ft[t] * vt[t] + s; }
+      memcpy(rt, rn, sizeof(double) * m);
+      mat_mul_at(L, Nt, m, m, m, A); /* L' Nt */
+      mat_mul(A, L, m, m, m, B);     /* L' Nt L */
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Nt[i + m * j] = Zt[i] * Zt[j] / Ft[t] + B[i + m * j];
+      symmatu(Nt, m);
+    } else {
+      mat_mul(Nt, cc, m, m, m, A);
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) A[i + m * j] = (i == j ? 1.0 : 0.0) - A[i + m * j];
+      mat_mul_bt(Ptt, Tt, m, m, m, B);
+      mat_mul(B, A, m, m, m, Cm);
+      memcpy(cc, Cm, sizeof(double) * mm);
+      for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Tt[j + m * i] * rt[j]; rn[i] = s; }
+      memcpy(rt, rn, sizeof(double) * m);
+      mat_mul_at(Tt, Nt, m, m, m, A);
+      mat_mul(A, Tt, m, m, m, B);
+      memcpy(Nt, B, sizeof(double) * mm);
+      symmatu(Nt, m);
+    }
+    /* :469-470 */
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Ptt[i + m * j] * rt[j]; at[i + (size_t)m * t] += s; }
+    mat_mul(Ptt, Nt, m, m, m, A);
+    mat_mul(A, Ptt, m, m, m, B);
+    symmatu(B, m);
+    for (int q = 0; q < mm; q++) Ptt[q] -= B[q];
+  }
+  memset(ccov + (size_t)mm * n, 0, sizeof(double) * mm); /* :472 */
+  free(vt); free(Ft); free(Kt); free(ob);
+}
+
+/* Left singular vectors / singular values of a (numerically) symmetric PSD
+ * matrix, standing in for arma::svd_econ(U, s, V, A, "left") in
+ * conditional_dist.cpp:14,21,29.  Cyclic Jacobi on the symmetrised matrix;
+ * s sorted descending; column sign fixed so the largest-magnitude entry of each
+ * column is positive (LAPACK's sign is unspecified; any sign gives a valid
+ * square-root factor U diag(sqrt(s))). */
+static void sym_svd(const double *Ain, int m, double *U, double *s) {
+  double A[ORC_MAXM * ORC_MAXM];
+  for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) A[i + m * j] = 0.5 * (Ain[i + m * j] + Ain[j + m * i]);
+  for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) U[i + m * j] = (i == j);
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0;
+    for (int j = 0; j < m; j++) for (int i = 0; i < j; i++) off += A[i + m * j] * A[i + m * j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < m - 1; p++) for (int q = p + 1; q < m; q++) {
+      double apq = A[p + m * q];
+      if (apq == 0.0) continue;
+      double app = A[p + m * p], aqq = A[q + m * q];
+      double tau = (aqq - app) / (2.0 * apq);
+      double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+      double c = 1.0 / sqrt(1.0 + tt * tt), sn = tt * c;
+      for (int r = 0; r < m; r++) { double arp = A[r + m * p], arq = A[r + m * q]; A[r + m * p] = c * arp - sn * arq; A[r + m * q] = sn * arp + c * arq; }
+      for (int r = 0; r < m; r++) { double apr = A[p + m * r], aqr = A[q + m * r]; A[p + m * r] = c * apr - sn * aqr; A[q + m * r] = sn * apr + c * aqr; }
+      for (int r = 0; r < m; r++) { double urp = U[r + m * p], urq = U[r + m * q]; U[r + m * p] = c * urp - sn * urq; U[r + m * q] = sn * urp + c * urq; }
+    }
+  }
+  for (int j = 0; j < m; j++) s[j] = fabs(A[j + m * j]);
+  for (int a = 0; a < m - 1; a++) { /* selection sort, descending */
+    int best = a;
+    for (int b = a + 1; b < m; b++) if (s[b] > s[best]) best = b;
+    if (best != a) {
+      double ts = s[a]; s[a] = s[best]; s[best] = ts;
+      for (int r = 0; r < m; r++) { double tu = U[r + m * a]; U[r + m * a] = U[r + m * best]; U[r + m * best] = tu; }
+    }
+  }
+  for (int j = 0; j < m; j++) {
+    int big = 0;
+    for (int r = 1; r < m; r++) if (fabs(U[r + m * j]) > fabs(U[big + m * j])) big = r;
+    if (U[big + m * j] < 0) for (int r = 0; r < m; r++) U[r + m * j] = -U[r + m * j];
+  }
+}
+
+/* conditional_dist.cpp:4-31 */
+void orc_conditional_cov(double *Vt, double *Ct, int m, int n1) {
+  const int mm = m * m;
+  double U[ORC_MAXM * ORC_MAXM], s[ORC_MAXM], W[ORC_MAXM * ORC_MAXM], tmp[ORC_MAXM * ORC_MAXM], A[ORC_MAXM * ORC_MAXM];
+  for (int t = n1 - 1; t > 0; t--) {
+    double *Vp = Vt + (size_t)mm * (t - 1), *Vc = Vt + (size_t)mm * t;
+    double *Cp = Ct + (size_t)mm * (t - 1), *Cc = Ct + (size_t)mm * t;
+    sym_svd(Vp, m, U, s);
+    /* W = U[:,nz] diag(1/s) U[:,nz]' */
+    memset(W, 0, sizeof(W));
+    for (int c = 0; c < m; c++) {
+      if (!(s[c] > ORC_EPS * m * s[0])) continue;
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) W[i + m * j] += U[i + m * c] * U[j + m * c] / s[c];
+    }
+    mat_mul_at(Cp, W, m, m, m, tmp); /* Ct(t-1)' * W */
+    mat_mul(tmp, Cp, m, m, m, A);
+    for (int q = 0; q < mm; q++) Vc[q] -= A[q];
+    memcpy(Cc, tmp, sizeof(double) * mm);
+    sym_svd(Vc, m, U, s);
+    for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) Vc[i + m * c] = U[i + m * c] * sqrt(s[c]);
+  }
+  sym_svd(Vt, m, U, s);
+  for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) Vt[i + m * c] = U[i + m * c] * sqrt(s[c]);
+}
+
+/* ------------------------------------------------------------------ */
+/* psi-APF set-up                                                      */
+/* ------------------------------------------------------------------ */
+orc_psi_setup *orc_psi_setup_alloc(int n, int m) {
+  orc_psi_setup *s = (orc_psi_setup *)calloc(1, sizeof(orc_psi_setup));
+  s->n = n; s->m = m;
+  s->approx_y = (double *)calloc(n, sizeof(double));
+  s->approx_H = (double *)calloc(n, sizeof(double));
+  s->mode = (double *)calloc(n, sizeof(double));
+  s->scales = (double *)calloc(n, sizeof(double));
+  s->alphahat = (double *)calloc((size_t)m * (n + 1), sizeof(double));
+  s->Vt = (double *)calloc((size_t)m * m * (n + 1), sizeof(double));
+  s->Ct = (double *)calloc((size_t)m * m * (n + 1), sizeof(double));
+  return s;
+}
+void orc_psi_setup_free(orc_psi_setup *s) {
+  if (!s) return;
+  free(s->approx_y); free(s->approx_H); free(s->mode); free(s->scales);
+  free(s->alphahat); free(s->Vt); free(s->Ct); free(s);
+}
+
+/* model_ssm_ung.cpp:302-342 */
+static void laplace_iter(const orc_ung_model *mod, const double *signal, double *ay, double *aH) {
+  const double phi = mod->phi;
+  for (int t = 0; t < mod->n; t++) {
+    double y = mod->y[t], HH = 0, yy = 0, sg = signal[t];
+    switch (mod->distribution) {
+    case ORC_SVM: {
+      double tmp = y;
+      if (fabs(tmp) < 1e-4) tmp = 1e-4;
+      HH = 2.0 * exp(sg) / ((tmp / phi) * (tmp / phi));
+      yy = sg + 1.0 - 0.5 * HH;
+    } break;
+    case ORC_POISSON: HH = 1.0 / (exp(sg) * mod->u[t]); yy = y * HH + sg - 1.0; break;
+    case ORC_BINOMIAL: { double e = exp(sg); HH = (1.0 + e) * (1.0 + e) / (mod->u[t] * e); yy = y * HH + sg - 1.0 - e; } break;
+    case ORC_NEGBIN: { double e = exp(sg) * mod->u[t]; HH = (phi + e) * (phi + e) / (phi * e * (y + phi)); yy = sg + (phi + e) * (y - e) / ((y + phi) * e); } break;
+    case ORC_GAMMA: { double e = exp(sg) * mod->u[t]; HH = e / (y * phi); yy = sg - e / y + 1; } break;
+    }
+    ay[t] = yy;
+    aH[t] = sqrt(HH);
+  }
+}
+
+/* model_ssm_ung.cpp:241-292 */
+static void update_scales(const orc_ung_model *mod, orc_psi_setup *su) {
+  const double phi = mod->phi;
+  for (int t = 0; t < mod->n; t++) {
+    su->scales[t] = 0.0;
+    double y = mod->y[t];
+    if (!isfinite(y)) continue;
+    double md = su->mode[t];
+    double g = 0.5 * pow((su->approx_y[t] - md) / su->approx_H[t], 2.0);
+    switch (mod->distribution) {
+    case ORC_SVM: su->scales[t] = -0.5 * (md + pow(y / phi, 2.0) * exp(-md)) + g; break;
+    case ORC_POISSON: su->scales[t] = y * md - mod->u[t] * exp(md) + g; break;
+    case ORC_BINOMIAL: su->scales[t] = y * md - mod->u[t] * log1p(exp(md)) + g; break;
+    case ORC_NEGBIN: su->scales[t] = y * md - (y + phi) * log(phi + mod->u[t] * exp(md)) + g; break;
+    case ORC_GAMMA: su->scales[t] = -phi * (md + (y * exp(-md) / mod->u[t])) + g; break;
+    }
+  }
+}
+
+static void make_approx_model(const orc_ung_model *mod, const orc_psi_setup *su, orc_ulg_model *g) {
+  g->n = mod->n; g->m = mod->m; g->k = mod->k;
+  g->Ztv = mod->Ztv; g->Ttv = mod->Ttv; g->Rtv = mod->Rtv; g->Dtv = mod->Dtv; g->Ctv = mod->Ctv; g->Htv = 1;
+  g->y = su->approx_y; g->H = su->approx_H;
+  g->Z = mod->Z; g->T = mod->T; g->R = mod->R; g->a1 = mod->a1; g->P1 = mod->P1;
+  g->D = mod->D; g->C = mod->C; g->xbeta = mod->xbeta;
+}
+
+int orc_ung_psi_setup(const orc_ung_model *mod, const double *is_mode, orc_psi_setup *su) {
+  const int n = mod->n, m = mod->m;
+  orc_ulg_model g;
+  make_approx_model(mod, su, &g);
+  double *sm = (double *)malloc(sizeof(double) * m * (n + 1));
+  if (is_mode) { /* approximate_for_is: model_ssm_ung.cpp:143-161 */
+    memcpy(su->mode, is_mode, sizeof(double) * n);
+    laplace_iter(mod, su->mode, su->approx_y, su->approx_H);
+    update_scales(mod, su);
+    su->approx_loglik = 0.0;
+    su->laplace_iters = 0;
+  } else { /* approximate(): :87-140, first call (approx_state == -1) */
+    memcpy(su->mode, mod->initial_mode, sizeof(double) * n);
+    int it = 0;
+    double diff = mod->conv_tol + 1;
+    double *newmode = (double *)malloc(sizeof(double) * n);
+    while (it < mod->max_iter && diff > mod->conv_tol) {
+      it++;
+      laplace_iter(mod, su->mode, su->approx_y, su->approx_H);
+      orc_ulg_fast_smoother(&g, sm);
+      for (int t = 0; t < n; t++) {
+        if (mod->distribution == ORC_SVM) newmode[t] = sm[(size_t)m * t];
+        else {
+          const double *Zt = mod->Z + (size_t)m * (t * mod->Ztv);
+          newmode[t] = mod->xbeta[t] + mod->D[t * mod->Dtv] + dotv(Zt, sm + (size_t)m * t, m);
+        }
+      }
+      diff = 0.0;
+      for (int t = 0; t < n; t++) diff += (newmode[t] - su->mode[t]) * (newmode[t] - su->mode[t]);
+      diff /= n;
+      memcpy(su->mode, newmode, sizeof(double) * n);
+    }
+    free(newmode);
+    su->laplace_iters = it;
+    /* psi_filter :519-527 */
+    double gll = orc_ulg_loglik(&g);
+    update_scales(mod, su);
+    double cterm = orc_ung_const_term(mod);
+    { /* compute_const_term :369: minus norm_log_const(approx y, H) over finite y */
+      int nf = 0; double sl = 0;
+      for (int t = 0; t < n; t++) if (isfinite(mod->y[t])) { nf++; sl += log(su->approx_H[t]); }
+      cterm -= (-0.5 * nf * log(2 * ORC_PI) - sl);
+    }
+    double ssc = 0; for (int t = 0; t < n; t++) ssc += su->scales[t];
+    su->approx_loglik = gll + cterm + ssc;
+  }
+  orc_ulg_smoother_ccov(&g, su->alphahat, su->Vt, su->Ct); /* :533 */
+  orc_conditional_cov(su->Vt, su->Ct, m, n + 1);            /* :534 */
+  free(sm);
+  return 0;
+}
+
+/* model_ssm_ung.cpp:536-609 */
+double orc_ung_psi_filter(const orc_ung_model *mod, const orc_psi_setup *su, unsigned N,
+                          const orc_rng *rng, double *alpha, double *weights, unsigned *indices) {
+  const int n = mod->n, m = mod->m, mm = m * m;
+  double *nw = (double *)malloc(sizeof(double) * N);
+  double *lw = (double *)malloc(sizeof(double) * N);
+  double *r = (double *)malloc(sizeof(double) * N);
+  double *atmp = (double *)malloc(sizeof(double) * N * m);
+  double um[ORC_MAXM];
+  for (unsigned i = 0; i < N; i++) { /* :538-544 */
+    rng_normals(rng, 0, 0, i, m, um);
+    for (int j = 0; j < m; j++) {
+      double s = 0.0;
+      for (int c = 0; c < m; c++) s += su->Vt[j + m * c] * um[c];
+      A_(j, 0, i) = su->alphahat[j] + s;
+    }
+  }
+  double loglik = 0.0, inc;
+  if (isfinite(mod->y[0])) { /* :549-561 */
+    for (unsigned i = 0; i < N; i++) lw[i] = ung_log_weight(mod, su, 0, &A_(0, 0, i)) - su->scales[0];
+    if (!normalise_step(lw, N, weights, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+    loglik = inc + su->approx_loglik; /* max + approx_loglik + log(sum/N) */
+  } else {
+    for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
+    loglik = su->approx_loglik;
+  }
+  for (int t = 0; t < n; t++) {
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    for (unsigned i = 0; i < N; i++)
+      for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
+    const double *ah0 = su->alphahat + (size_t)m * t, *ah1 = su->alphahat + (size_t)m * (t + 1);
+    const double *Ct1 = su->Ct + (size_t)mm * (t + 1), *Vt1 = su->Vt + (size_t)mm * (t + 1);
+    for (unsigned i = 0; i < N; i++) { /* :580-587 */
+      rng_normals(rng, 2, t, i, m, um);
+      for (int j = 0; j < m; j++) {
+        double s = 0.0, q = 0.0;
+        for (int c = 0; c < m; c++) s += Ct1[j + m * c] * (atmp[c + (size_t)m * i] - ah0[c]);
+        for (int c = 0; c < m; c++) q += Vt1[j + m * c] * um[c];
+        A_(j, t + 1, i) = ah1[j] + s + q;
+      }
+    }
+    double *wcol = weights + (size_t)N * (t + 1);
+    if ((t < n - 1) && isfinite(mod->y[t + 1])) { /* :589-601 */
+      for (unsigned i = 0; i < N; i++) lw[i] = ung_log_weight(mod, su, t + 1, &A_(0, t + 1, i)) - su->scales[t + 1];
+      if (!normalise_step(lw, N, wcol, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+      loglik += inc;
+    } else {
+      for (unsigned i = 0; i < N; i++) { wcol[i] = 1.0; nw[i] = 1.0 / N; }
+    }
+  }
+done:
+  free(nw); free(lw); free(r); free(atmp);
+  return loglik;
+}
+
+/* ------------------------------------------------------------------ */
+/* smoothing + summaries                                               */
+/* ------------------------------------------------------------------ */
+/* filter_smoother.cpp:5-18 */
+void orc_filter_smoother(double *alpha, const unsigned *indices, int m, int n, unsigned N) {
+  unsigned *b = (unsigned *)malloc(sizeof(unsigned) * N);
+  double *tube = (double *)malloc(sizeof(double) * m * N);
+  for (unsigned i = 0; i < N; i++) b[i] = i;
+  for (int t = n - 1; t >= 0; t--) {
+    for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) tube[j + (size_t)m * i] = A_(j, t, i);
+    for (unsigned i = 0; i < N; i++) {
+      unsigned src = indices[b[i] + (size_t)N * t];
+      for (int j = 0; j < m; j++) A_(j, t, i) = tube[j + (size_t)m * src];
+    }
+    for (unsigned i = 0; i < N; i++) b[i] = indices[b[i] + (size_t)N * t];
+  }
+  free(b); free(tube);
+}
+
+/* summary.cpp:4-17 ; alpha m x n1 x N */
+void orc_summary(const double *alpha, int m, int n1, unsigned N, double *mean, double *cov) {
+  const int n = n1 - 1;
+  size_t mt = (size_t)m * n1;
+  double *diff = (double *)malloc(sizeof(double) * mt);
+  memset(mean, 0, sizeof(double) * mt);
+  memset(cov, 0, sizeof(double) * mt * m);
+  for (unsigned i = 0; i < N; i++) {
+    for (int t = 0; t < n1; t++) for (int j = 0; j < m; j++) {
+      double d = A_(j, t, i) - mean[j + (size_t)m * t];
+      diff[j + (size_t)m * t] = d;
+      mean[j + (size_t)m * t] += d / (i + 1);
+    }
+    for (int t = 0; t < n1; t++)
+      for (int c = 0; c < m; c++) for (int j = 0; j < m; j++)
+        cov[j + m * (c + (size_t)m * t)] += diff[j + (size_t)m * t] * (A_(c, t, i) - mean[c + (size_t)m * t]);
+  }
+  for (size_t q = 0; q < mt * m; q++) cov[q] /= N;
+  free(diff);
+}
+
+/* summary.cpp:19-39 */
+void orc_weighted_summary(const double *alpha, int m, int n1, unsigned N, const double *w, double *mean, double *cov) {
+  const int n = n1 - 1;
+  size_t mt = (size_t)m * n1;
+  double *diff = (double *)malloc(sizeof(double) * mt);
+  memset(mean, 0, sizeof(double) * mt);
+  memset(cov, 0, sizeof(double) * mt * m);
+  double cum = 0;
+  for (unsigned i = 0; i < N; i++) {
+    if (!(w[i] > 0)) continue;
+    double tmp = w[i] + cum;
+    for (int t = 0; t < n1; t++) for (int j = 0; j < m; j++) {
+      double d = A_(j, t, i) - mean[j + (size_t)m * t];
+      diff[j + (size_t)m * t] = d;
+      mean[j + (size_t)m * t] += d * w[i] / tmp;
+    }
+    for (int t = 0; t < n1; t++)
+      for (int c = 0; c < m; c++) for (int j = 0; j < m; j++)
+        cov[j + m * (c + (size_t)m * t)] += w[i] * diff[j + (size_t)m * t] * (A_(c, t, i) - mean[c + (size_t)m * t]);
+    cum = tmp;
+  }
+  for (size_t q = 0; q < mt * m; q++) cov[q] /= cum;
+  free(diff);
+}
+
+/* summary.cpp:42-79 ; at m x (n+1), att m x n, Pt m x m x (n+1), Ptt m x m x n */
+void orc_filter_summary(const double *alpha, int m, int n, unsigned N, const double *weights,
+                        double *at, double *att, double *Pt, double *Ptt) {
+  double *w = (double *)malloc(sizeof(double) * N);
+  memset(at, 0, sizeof(double) * m * (n + 1));
+  memset(att, 0, sizeof(double) * m * n);
+  memset(Pt, 0, sizeof(double) * m * m * (n + 1));
+  memset(Ptt, 0, sizeof(double) * m * m * n);
+  for (int t = 0; t <= n; t++) {
+    double acc = 0;
+    if (t < n) {
+      for (unsigned i = 0; i < N; i++) acc += weights[i + (size_t)N * t];
+      for (unsigned i = 0; i < N; i++) w[i] = weights[i + (size_t)N * t] / acc;
+    }
+    for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) {
+      if (t < n) att[j + (size_t)m * t] += A_(j, t, i) * w[i];
+      at[j + (size_t)m * t] += A_(j, t, i);
+    }
+    for (int j = 0; j < m; j++) at[j + (size_t)m * t] /= N;
+    for (unsigned i = 0; i < N; i++)
+      for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) {
+        Pt[j + m * (c + (size_t)m * t)] += (A_(j, t, i) - at[j + (size_t)m * t]) * (A_(c, t, i) - at[c + (size_t)m * t]);
+        if (t < n)
+          Ptt[j + m * (c + (size_t)m * t)] += w[i] * (A_(j, t, i) - att[j + (size_t)m * t]) * (A_(c, t, i) - att[c + (size_t)m * t]);
+      }
+    for (int q = 0; q < m * m; q++) Pt[q + (size_t)m * m * t] /= N;
+  }
+  free(w);
+}
+
+/* ------------------------------------------------------------------ */
+/* IS post-correction: approx_mcmc.cpp:353-427 (psi), :447-518 (bsf)   */
+/* ------------------------------------------------------------------ */
+int orc_is_correction(const orc_is_job *job, double *weights, double *loglik_out,
+                      double *alpha_out, double *alphahat, double *Vt) {
+  const int ns = job->n_stored;
+  if (ns <= 0) return 0;
+  const int n = job->models[0].n, m = job->models[0].m;
+  const size_t mt = (size_t)m * (n + 1);
+  double *ah_all = NULL, *vt_all = NULL;
+  if (job->output_type == 2) {
+    ah_all = (double *)malloc(sizeof(double) * mt * ns);
+    vt_all = (double *)malloc(sizeof(double) * mt * m * ns);
+  }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(job->n_threads > 0 ? job->n_threads : 1)
+#endif
+  for (int i = 0; i < ns; i++) {
+    const orc_ung_model *mod = &job->models[i];
+    unsigned nsimc = job->nsim;
+    if (job->is_type == 1) nsimc *= job->counts[i]; /* :376-378 */
+    double *alpha = (double *)calloc((size_t)m * (n + 1) * nsimc, sizeof(double));
+    double *w = (double *)calloc((size_t)nsimc * (n + 1), sizeof(double));
+    unsigned *idx = (unsigned *)calloc((size_t)nsimc * n, sizeof(unsigned));
+    orc_rng rng = { 0, job->seed, (uint32_t)i, NULL, NULL, NULL, 0, 0 };
+    double ll;
+    if (job->method == 1) {
+      orc_psi_setup *su = orc_psi_setup_alloc(n, m);
+      orc_ung_psi_setup(mod, job->modes + (size_t)n * i, su); /* :372-373 */
+      ll = orc_ung_psi_filter(mod, su, nsimc, &rng, alpha, w, idx);
+      weights[i] = exp(ll); /* :385 */
+      orc_psi_setup_free(su);
+    } else {
+      ll = orc_ung_bsf_filter(mod, nsimc, &rng, alpha, w, idx);
+      weights[i] = exp(ll - job->approx_loglik[i]); /* :479 */
+    }
+    if (loglik_out) loglik_out[i] = ll;
+    if (job->output_type != 3) {
+      orc_filter_smoother(alpha, idx, m, n, nsimc); /* :388 */
+      if (job->output_type == 1) { /* :390-392: uniform pick, stored transposed (n+1) x m */
+        unsigned pick = (unsigned)(orc_rng_uniform(&rng, 3, 0, 0, 0) * nsimc);
+        if (pick >= nsimc) pick = nsimc - 1;
+        for (int t = 0; t <= n; t++) for (int j = 0; j < m; j++)
+          alpha_out[t + (size_t)(n + 1) * (j + (size_t)m * i)] = A_(j, t, pick);
+      } else {
+        orc_summary(alpha, m, n + 1, nsimc, ah_all + mt * i, vt_all + mt * m * i); /* :396 */
+      }
+    }
+    free(alpha); free(w); free(idx);
+  }
+  if (job->output_type == 2) { /* :397-414 merge (in theta order), :422-424 */
+    double *Valpha = (double *)calloc(mt * m, sizeof(double));
+    double *diff = (double *)malloc(sizeof(double) * mt);
+    memset(alphahat, 0, sizeof(double) * mt);
+    memset(Vt, 0, sizeof(double) * mt * m);
+    double sum_w = 0.0;
+    for (int i = 0; i < ns; i++) {
+      const double *ahi = ah_all + mt * i, *vti = vt_all + mt * m * i;
+      double wnew = weights[i] * job->counts[i];
+      sum_w += wnew;
+      for (size_t q = 0; q < mt; q++) { diff[q] = ahi[q] - alphahat[q]; alphahat[q] += wnew / sum_w * diff[q]; }
+      for (int t = 0; t <= n; t++)
+        for (int c = 0; c < m; c++) for (int j = 0; j < m; j++)
+          Valpha[j + m * (c + (size_t)m * t)] += wnew * diff[j + (size_t)m * t] * (ahi[c + (size_t)m * t] - alphahat[c + (size_t)m * t]);
+      for (size_t q = 0; q < mt * m; q++) Vt[q] += wnew / sum_w * (vti[q] - Vt[q]);
+    }
+    for (size_t q = 0; q < mt * m; q++) Vt[q] += Valpha[q] / sum_w;
+    free(Valpha); free(diff); free(ah_all); free(vt_all);
+  }
+  return 0;
+}

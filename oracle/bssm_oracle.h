@@ -1,0 +1,171 @@
+/*
+ * bssm_oracle.h -- CPU restatement of the helske/bssm particle-filter hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under bssm_amd/ (the product) may include,
+ * link or call this.  It is used by tests/, by __graft_entry__.smoke() and by
+ * the cpu_baseline leg of bench.py, always as the checker / reported baseline.
+ *
+ * PARITY STATUS: "parity unpinned" at the bit level.  The reference (C++ on
+ * Rcpp/RcppArmadillo/sitmo, R front-end) cannot be built or run in this image
+ * (no R, Rcpp, Armadillo, sitmo, ramcmc; no network) and its own tests hold no
+ * golden vectors for any particle filter.  The
+ * restatement is pinned instead by (1) the analytic pins the reference's tests
+ * use (particle filter == exact Kalman answer on linear-Gaussian models,
+ * psi-APF == bootstrap filter, tests/testthat/test_particle_smoother.R:25-45),
+ * (2) closed-form unit values (distribution constants, dnorm), (3) invariants.
+ *
+ * Every function cites the reference file:line it follows.  Loop order,
+ * summation order and the use of libm follow the reference; the only
+ * deliberate departure is the random stream (see rng below): bssm draws from a
+ * sequential sitmo engine through libstdc++ distributions, which is neither
+ * available here nor reproducible on a GPU.  The oracle therefore takes its
+ * random numbers either from caller-injected arrays or from the counter-based
+ * Philox4x32-10 stream that the HIP kernels also implement (independently).
+ *
+ * All matrices are column-major exactly as Armadillo / R store them.
+ */
+#ifndef BSSM_ORACLE_H
+#define BSSM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* distribution codes: R/bootstrap_filter.R:106-109 (pmatch(...) - 1); 5 = gaussian
+ * (ssm_ulg path, src/model_ssm_ulg.cpp:557-643, kept as the analytic pin). */
+enum { ORC_SVM = 0, ORC_POISSON = 1, ORC_BINOMIAL = 2, ORC_NEGBIN = 3, ORC_GAMMA = 4, ORC_GAUSSIAN = 5 };
+
+/* Fields read by ssm_ung::ssm_ung, src/model_ssm_ung.cpp:9-32. "(1|n)" extents
+ * are selected by the *tv flags exactly as model_ssm_ung.cpp:15-16. */
+typedef struct {
+  int n, m, k;
+  int Ztv, Ttv, Rtv, Dtv, Ctv, Htv;
+  int distribution;
+  const double *y;     /* n, NaN = missing */
+  const double *Z;     /* m x (1|n) */
+  const double *T;     /* m x m x (1|n) */
+  const double *R;     /* m x k x (1|n) */
+  const double *a1;    /* m */
+  const double *P1;    /* m x m */
+  const double *D;     /* (1|n) */
+  const double *C;     /* m x (1|n) */
+  const double *xbeta; /* n (zeros when there are no regressors) */
+  const double *u;     /* n */
+  const double *H;     /* (1|n) observation sd, gaussian only */
+  double phi;
+  /* Laplace approximation controls, model_ssm_ung.cpp:21-23 */
+  const double *initial_mode; /* n */
+  int max_iter;
+  double conv_tol;
+  int local_approx;
+} orc_ung_model;
+
+/* Random source.  mode 0: Philox4x32-10 counter stream keyed (seed, stream).
+ * mode 1: injected arrays in the reference's consumption order
+ * (model_ssm_ung.cpp:621-627, 650-653, 663-667):
+ *   init_normals[i*m + j], unif[t*N + i], normals[(t*N + i)*kk + j]. */
+typedef struct {
+  int mode;
+  uint32_t seed, stream;
+  const double *init_normals, *unif, *normals;
+  int N, kk; /* kk = normals per particle per step in the injected array */
+} orc_rng;
+
+/* ---- RNG primitives (exported so tests can pin them bit-for-bit) ---- */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double orc_rng_uniform(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d);
+void orc_rng_normal_pair(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d,
+                         double *z0, double *z1);
+
+/* ---- helpers ---- */
+/* src/stratified_sample.cpp:9-28. p is overwritten by its cumsum. */
+void orc_stratified_sample(double *p, const double *r, unsigned N, unsigned *out);
+/* src/filter_smoother.cpp:5-18 */
+void orc_filter_smoother(double *alpha, const unsigned *indices, int m, int n, unsigned N);
+/* src/summary.cpp:4-17 */
+void orc_summary(const double *alpha, int m, int n1, unsigned N, double *mean, double *cov);
+/* src/summary.cpp:19-39 */
+void orc_weighted_summary(const double *alpha, int m, int n1, unsigned N, const double *w,
+                          double *mean, double *cov);
+/* src/summary.cpp:42-79 */
+void orc_filter_summary(const double *alpha, int m, int n, unsigned N, const double *weights,
+                        double *at, double *att, double *Pt, double *Ptt);
+/* src/distr_consts.cpp:7-31, summed over finite y as model_ssm_ung.cpp:690-710 */
+double orc_ung_const_term(const orc_ung_model *mod);
+/* src/psd_chol.cpp:5-18 */
+void orc_psd_chol(const double *x, int m, double *L);
+
+/* ---- filters ---- */
+/* src/model_ssm_ung.cpp:611-712 (distribution 0-4) and src/model_ssm_ulg.cpp:557-643
+ * (distribution 5).  alpha m x (n+1) x N, weights N x (n+1), indices N x n; the
+ * caller zero-fills them (R_bootstrap_filter.cpp:136-138). */
+double orc_ung_bsf_filter(const orc_ung_model *mod, unsigned N, const orc_rng *rng,
+                          double *alpha, double *weights, unsigned *indices);
+
+/* psi-APF set-up state = the approximating Gaussian model and what psi_filter
+ * derives from it (model_ssm_ung.cpp:87-161, 241-370, 514-534). */
+typedef struct {
+  int n, m;
+  double *approx_y, *approx_H; /* n each: pseudo-observations and their sd */
+  double *mode;                /* n: signal mode estimate */
+  double *scales;              /* n */
+  double approx_loglik;
+  double *alphahat;            /* m x (n+1) smoothed mean of approximating model */
+  double *Vt;                  /* m x m x (n+1) sqrt factors after conditional_cov */
+  double *Ct;                  /* m x m x (n+1) */
+  int laplace_iters;
+} orc_psi_setup;
+
+orc_psi_setup *orc_psi_setup_alloc(int n, int m);
+void orc_psi_setup_free(orc_psi_setup *s);
+/* approximate() + gaussian loglik + scales + const term + smoother_ccov + conditional_cov;
+ * is_mode != NULL selects approximate_for_is(mode) (model_ssm_ung.cpp:143-161). */
+int orc_ung_psi_setup(const orc_ung_model *mod, const double *is_mode, orc_psi_setup *out);
+/* src/model_ssm_ung.cpp:511-609 (the loop from :536 on; set-up done above) */
+double orc_ung_psi_filter(const orc_ung_model *mod, const orc_psi_setup *su, unsigned N,
+                          const orc_rng *rng, double *alpha, double *weights, unsigned *indices);
+
+/* ---- exact linear-Gaussian machinery (ssm_ulg), used for psi set-up and as analytic pins ---- */
+typedef struct {
+  int n, m, k;
+  int Ztv, Ttv, Rtv, Dtv, Ctv, Htv;
+  const double *y, *Z, *T, *R, *a1, *P1, *D, *C, *xbeta, *H;
+} orc_ulg_model;
+/* src/model_ssm_ulg.cpp:106-138 */
+double orc_ulg_loglik(const orc_ulg_model *g);
+/* src/model_ssm_ulg.cpp:252-305 ; at m x (n+1) */
+void orc_ulg_fast_smoother(const orc_ulg_model *g, double *at);
+/* src/model_ssm_ulg.cpp:419-473 ; at m x (n+1), Pt/ccov m x m x (n+1) */
+void orc_ulg_smoother_ccov(const orc_ulg_model *g, double *at, double *Pt, double *ccov);
+/* src/conditional_dist.cpp:4-31 (use_svd = true branch) */
+void orc_conditional_cov(double *Vt, double *Ct, int m, int n1);
+
+/* ---- IS post-correction (src/approx_mcmc.cpp:353-427 psi, :447-518 bsf) ----
+ * Per-theta model deltas are supplied pre-expanded as a full model per draw
+ * (what parset_ung does, src/parset_ng.cpp:5-111).  The random stream is keyed
+ * by the theta index (not the OpenMP thread id as approx_mcmc.cpp:367), so the
+ * result does not depend on the thread count. */
+typedef struct {
+  int n_stored;
+  const orc_ung_model *models; /* n_stored */
+  const double *modes;         /* n x n_stored (psi) or NULL */
+  const double *approx_loglik; /* n_stored (bsf) or NULL */
+  const unsigned *counts;      /* n_stored */
+  int method;                  /* 1 = psi, 2 = bsf */
+  int is_type;                 /* 1..3, approx_mcmc.cpp:376-378 */
+  int output_type;             /* 1 full, 2 summary, 3 theta */
+  unsigned nsim;
+  uint32_t seed;
+  int n_threads;
+} orc_is_job;
+/* weights n_stored; alpha_out (n+1) x m x n_stored (output 1); alphahat m x (n+1),
+ * Vt m x m x (n+1) (output 2).  Merge order = theta index order (deterministic). */
+int orc_is_correction(const orc_is_job *job, double *weights, double *loglik_out,
+                      double *alpha_out, double *alphahat, double *Vt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

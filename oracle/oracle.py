@@ -1,0 +1,272 @@
+"""ctypes wrapper of the CPU oracle (oracle/bssm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg
+of bench.py.  Nothing in bssm_amd/ imports this module.  Parity status: see bssm_oracle.h
+("parity unpinned" at the bit level; pinned by analytic and closed-form checks).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbssm_oracle.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_uint_p = C.POINTER(C.c_uint)
+
+
+class OrcModel(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("n", "m", "k", "Ztv", "Ttv", "Rtv", "Dtv", "Ctv", "Htv", "distribution")] + \
+               [(k, c_double_p) for k in ("y", "Z", "T", "R", "a1", "P1", "D", "C", "xbeta", "u", "H")] + \
+               [("phi", C.c_double), ("initial_mode", c_double_p), ("max_iter", C.c_int), ("conv_tol", C.c_double),
+                ("local_approx", C.c_int)]
+
+
+class OrcRng(C.Structure):
+    _fields_ = [("mode", C.c_int), ("seed", C.c_uint32), ("stream", C.c_uint32), ("init_normals", c_double_p),
+                ("unif", c_double_p), ("normals", c_double_p), ("N", C.c_int), ("kk", C.c_int)]
+
+
+class OrcPsiSetup(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("approx_y", c_double_p), ("approx_H", c_double_p),
+                ("mode", c_double_p), ("scales", c_double_p), ("approx_loglik", C.c_double),
+                ("alphahat", c_double_p), ("Vt", c_double_p), ("Ct", c_double_p), ("laplace_iters", C.c_int)]
+
+
+class OrcUlg(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("n", "m", "k", "Ztv", "Ttv", "Rtv", "Dtv", "Ctv", "Htv")] + \
+               [(k, c_double_p) for k in ("y", "Z", "T", "R", "a1", "P1", "D", "C", "xbeta", "H")]
+
+
+class OrcIsJob(C.Structure):
+    _fields_ = [("n_stored", C.c_int), ("models", C.POINTER(OrcModel)), ("modes", c_double_p),
+                ("approx_loglik", c_double_p), ("counts", c_uint_p), ("method", C.c_int), ("is_type", C.c_int),
+                ("output_type", C.c_int), ("nsim", C.c_uint), ("seed", C.c_uint32), ("n_threads", C.c_int)]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "bssm_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "bssm_oracle.h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_ung_bsf_filter.restype = C.c_double
+        L.orc_ung_psi_filter.restype = C.c_double
+        L.orc_ulg_loglik.restype = C.c_double
+        L.orc_ung_const_term.restype = C.c_double
+        L.orc_rng_uniform.restype = C.c_double
+        L.orc_psi_setup_alloc.restype = C.POINTER(OrcPsiSetup)
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def pack_model(arr: dict):
+    """dict from bssm_amd.models.model_arrays -> (OrcModel, keepalive)"""
+    s = OrcModel()
+    for k in ("n", "m", "k", "Ztv", "Ttv", "Rtv", "Dtv", "Ctv", "Htv", "distribution", "max_iter", "local_approx"):
+        setattr(s, k, int(arr[k]))
+    s.phi = float(arr["phi"])
+    s.conv_tol = float(arr["conv_tol"])
+    keep = []
+    for k in ("y", "Z", "T", "R", "a1", "P1", "D", "C", "xbeta", "u", "H", "initial_mode"):
+        a = arr.get(k)
+        if a is not None:
+            a = np.asfortranarray(a, dtype=np.float64)
+            keep.append(a)
+        setattr(s, k, _p(a))
+    return s, keep
+
+
+def make_rng(seed=1, stream=0, injected=None):
+    r = OrcRng()
+    keep = []
+    if injected is None:
+        r.mode, r.seed, r.stream = 0, seed, stream
+    else:
+        init_normals, unif, normals = (np.ascontiguousarray(a, dtype=np.float64) for a in injected)
+        keep = [init_normals, unif, normals]
+        r.mode = 1
+        r.init_normals, r.unif, r.normals = _p(init_normals), _p(unif), _p(normals)
+        r.N = unif.shape[1]
+        r.kk = normals.shape[2]
+    return r, keep
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def bsf_filter(arr: dict, nsim: int, seed=1, stream=0, injected=None):
+    """orc_ung_bsf_filter -> dict(logLik, alpha m x (n+1) x N, weights N x (n+1), indices N x n)"""
+    L = lib()
+    mod, keep = pack_model(arr)
+    rng, keep2 = make_rng(seed, stream, injected)
+    n, m = arr["n"], arr["m"]
+    alpha = np.zeros((m, n + 1, nsim), order="F")
+    weights = np.zeros((nsim, n + 1), order="F")
+    indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+    ll = L.orc_ung_bsf_filter(C.byref(mod), C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights),
+                              indices.ctypes.data_as(c_uint_p))
+    return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices)
+
+
+def psi_setup(arr: dict, is_mode=None):
+    L = lib()
+    mod, keep = pack_model(arr)
+    n, m = arr["n"], arr["m"]
+    su = L.orc_psi_setup_alloc(n, m)
+    mode = None if is_mode is None else np.ascontiguousarray(is_mode, dtype=np.float64)
+    L.orc_ung_psi_setup(C.byref(mod), _p(mode), su)
+    s = su.contents
+    out = dict(
+        approx_y=np.ctypeslib.as_array(s.approx_y, (n,)).copy(), approx_H=np.ctypeslib.as_array(s.approx_H, (n,)).copy(),
+        mode=np.ctypeslib.as_array(s.mode, (n,)).copy(), scales=np.ctypeslib.as_array(s.scales, (n,)).copy(),
+        approx_loglik=s.approx_loglik,
+        alphahat=np.ctypeslib.as_array(s.alphahat, ((n + 1) * m,)).copy().reshape((m, n + 1), order="F"),
+        Vt=np.ctypeslib.as_array(s.Vt, ((n + 1) * m * m,)).copy().reshape((m, m, n + 1), order="F"),
+        Ct=np.ctypeslib.as_array(s.Ct, ((n + 1) * m * m,)).copy().reshape((m, m, n + 1), order="F"),
+        iterations=s.laplace_iters, _handle=su)
+    return out
+
+
+def psi_filter(arr: dict, nsim: int, seed=1, stream=0, is_mode=None, setup=None):
+    L = lib()
+    mod, keep = pack_model(arr)
+    su = setup if setup is not None else psi_setup(arr, is_mode)
+    rng, keep2 = make_rng(seed, stream)
+    n, m = arr["n"], arr["m"]
+    alpha = np.zeros((m, n + 1, nsim), order="F")
+    weights = np.zeros((nsim, n + 1), order="F")
+    indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+    ll = L.orc_ung_psi_filter(C.byref(mod), su["_handle"], C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights),
+                              indices.ctypes.data_as(c_uint_p))
+    return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices, setup=su)
+
+
+def filter_smoother(alpha, indices):
+    L = lib()
+    m, n1, N = alpha.shape
+    a = np.asfortranarray(alpha.copy())
+    idx = np.asfortranarray(indices, dtype=np.uint32)
+    L.orc_filter_smoother(_p(a), idx.ctypes.data_as(c_uint_p), m, n1 - 1, C.c_uint(N))
+    return a
+
+
+def summary(alpha):
+    L = lib()
+    m, n1, N = alpha.shape
+    a = np.asfortranarray(alpha)
+    mean = np.zeros((m, n1), order="F")
+    cov = np.zeros((m, m, n1), order="F")
+    L.orc_summary(_p(a), m, n1, C.c_uint(N), _p(mean), _p(cov))
+    return mean, cov
+
+
+def filter_summary(alpha, weights):
+    L = lib()
+    m, n1, N = alpha.shape
+    n = n1 - 1
+    a = np.asfortranarray(alpha)
+    w = np.asfortranarray(weights)
+    at = np.zeros((m, n + 1), order="F"); att = np.zeros((m, n), order="F")
+    Pt = np.zeros((m, m, n + 1), order="F"); Ptt = np.zeros((m, m, n), order="F")
+    L.orc_filter_summary(_p(a), m, n, C.c_uint(N), _p(w), _p(at), _p(att), _p(Pt), _p(Ptt))
+    return at, att, Pt, Ptt
+
+
+def stratified_sample(p, r):
+    L = lib()
+    p = np.array(p, dtype=np.float64)
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    out = np.zeros(p.size, dtype=np.uint32)
+    L.orc_stratified_sample(_p(p), _p(r), C.c_uint(p.size), out.ctypes.data_as(c_uint_p))
+    return out, p
+
+
+def _pack_ulg(arr: dict, y=None, H=None):
+    g = OrcUlg()
+    for k in ("n", "m", "k", "Ztv", "Ttv", "Rtv", "Dtv", "Ctv"):
+        setattr(g, k, int(arr[k]))
+    yy = np.ascontiguousarray(arr["y"] if y is None else y, dtype=np.float64)
+    HH = np.ascontiguousarray(arr["H"] if H is None else H, dtype=np.float64)
+    g.Htv = int(HH.size > 1)
+    keep = [yy, HH]
+    g.y, g.H = _p(yy), _p(HH)
+    for k in ("Z", "T", "R", "a1", "P1", "D", "C", "xbeta"):
+        a = np.asfortranarray(arr[k], dtype=np.float64)
+        keep.append(a)
+        setattr(g, k, _p(a))
+    return g, keep
+
+
+def ulg_loglik(arr: dict):
+    g, keep = _pack_ulg(arr)
+    return lib().orc_ulg_loglik(C.byref(g))
+
+
+def ulg_smoother(arr: dict):
+    """Exact Kalman smoother of a linear-Gaussian model: (alphahat m x (n+1), Vt m x m x (n+1), ccov)."""
+    g, keep = _pack_ulg(arr)
+    n, m = arr["n"], arr["m"]
+    at = np.zeros((m, n + 1), order="F")
+    Pt = np.zeros((m, m, n + 1), order="F")
+    cc = np.zeros((m, m, n + 1), order="F")
+    lib().orc_ulg_smoother_ccov(C.byref(g), _p(at), _p(Pt), _p(cc))
+    return at, Pt, cc
+
+
+def const_term(arr: dict):
+    mod, keep = pack_model(arr)
+    return lib().orc_ung_const_term(C.byref(mod))
+
+
+def is_correction(arrs, nsim, seed, method, counts, modes=None, approx_loglik=None, is_type=2, output_type=3,
+                  n_threads=1):
+    """orc_is_correction over a list of per-draw model dicts."""
+    L = lib()
+    ns = len(arrs)
+    Models = OrcModel * ns
+    packed, keep = [], []
+    for a in arrs:
+        s, k = pack_model(a)
+        packed.append(s); keep.append(k)
+    models = Models(*packed)
+    n, m = arrs[0]["n"], arrs[0]["m"]
+    job = OrcIsJob()
+    job.n_stored = ns
+    job.models = models
+    mo = None if modes is None else np.asfortranarray(modes, dtype=np.float64)
+    al = None if approx_loglik is None else np.ascontiguousarray(approx_loglik, dtype=np.float64)
+    cn = np.ascontiguousarray(counts, dtype=np.uint32)
+    job.modes, job.approx_loglik, job.counts = _p(mo), _p(al), cn.ctypes.data_as(c_uint_p)
+    job.method, job.is_type, job.output_type = method, is_type, output_type
+    job.nsim, job.seed, job.n_threads = nsim, seed, n_threads
+    weights = np.zeros(ns)
+    ll = np.zeros(ns)
+    alpha = np.zeros((n + 1, m, ns), order="F") if output_type == 1 else None
+    alphahat = np.zeros((m, n + 1), order="F") if output_type == 2 else None
+    Vt = np.zeros((m, m, n + 1), order="F") if output_type == 2 else None
+    L.orc_is_correction(C.byref(job), _p(weights), _p(ll), _p(alpha), _p(alphahat), _p(Vt))
+    return dict(weights=weights, loglik=ll, alpha=alpha, alphahat=alphahat, Vt=Vt)

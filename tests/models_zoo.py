@@ -1,0 +1,77 @@
+"""Seeded synthetic models shared by the CPU and GPU tests (numpy Generator(PCG64(seed)))."""
+import numpy as np
+
+from bssm_amd import models as M
+
+
+def poisson_local_level(n=200, seed=101, sd_level=0.1):
+    """BASELINE configs[0] / SURVEY 8d C1: bsm_ng Poisson local level."""
+    rng = np.random.default_rng(seed)
+    level = np.log(5.0) + np.cumsum(rng.normal(0, sd_level, n))
+    y = rng.poisson(np.exp(level)).astype(float)
+    return M.bsm_ng(y, sd_level=sd_level, distribution="poisson")
+
+
+def negbin_ar1(n=1000, seed=102, rho=0.95, sigma=0.3, mu=1.0, phi=5.0):
+    """ssm_ung negbin AR(1), m = k = 1."""
+    rng = np.random.default_rng(seed)
+    a = np.zeros(n)
+    a[0] = mu + rng.normal(0, sigma / np.sqrt(1 - rho ** 2))
+    for t in range(1, n):
+        a[t] = mu * (1 - rho) + rho * a[t - 1] + rng.normal(0, sigma)
+    lam = np.exp(a)
+    y = rng.negative_binomial(phi, phi / (phi + lam)).astype(float)
+    return M.ssm_ung(y, Z=1.0, T=rho, R=sigma, a1=mu, P1=sigma ** 2 / (1 - rho ** 2), C=np.array([[mu * (1 - rho)]]),
+                     distribution="negative binomial", phi=phi)
+
+
+def negbin_m4(n=1000, seed=103, phi=5.0):
+    """SURVEY 8d C2-m4 (the metric config): m = k = 4."""
+    rng = np.random.default_rng(seed)
+    T = np.array([[1, 1, 0, 0], [0, 1, 0, 0], [0, 0, 0.9, 0], [0, 0, 0, 0.5]], dtype=float)
+    R = np.diag([0.05, 0.005, 0.2, 0.3])
+    Z = np.array([1.0, 0, 1, 1])
+    a1 = np.array([1.0, 0, 0, 0])
+    P1 = np.diag([1, 0.01, 0.21, 0.12])
+    a = a1 + np.sqrt(np.diag(P1)) * rng.normal(size=4)
+    y = np.zeros(n)
+    for t in range(n):
+        lam = np.exp(np.clip(Z @ a, -20, 8))
+        y[t] = rng.negative_binomial(phi, phi / (phi + lam))
+        a = T @ a + R @ rng.normal(size=4)
+    return M.ssm_ung(y, Z=Z, T=T, R=R, a1=a1, P1=P1, distribution="negative binomial", phi=phi)
+
+
+def small_zoo():
+    """Small models covering every distribution, missing values, time-varying matrices, xreg."""
+    rng = np.random.default_rng(7)
+    zoo = {}
+    zoo["poisson_ll"] = poisson_local_level(40, seed=5)
+    y = rng.poisson(4, 30).astype(float); y[[3, 4, 17]] = np.nan
+    zoo["poisson_slope_missing"] = M.bsm_ng(y, sd_level=0.3, sd_slope=0.05, distribution="poisson",
+                                            P1=np.diag([1.0, 0.1]), a1=[1.0, 0.0])
+    yb = np.array([1, 0, 1, 1, 1, 0, 0, 0] * 3, dtype=float)
+    zoo["binomial_ar1_xreg"] = M.ar1_ng(yb, rho=M.uniform(0.5, -1, 1), sigma=M.halfnormal(0.4, 2), mu=0.3,
+                                        distribution="binomial", u=np.full(24, 2.0), xreg=np.arange(1, 25) / 10.0,
+                                        beta=M.normal(0.1, 0, 1))
+    zoo["negbin_ar1"] = negbin_ar1(35, seed=9)
+    yg = rng.gamma(2.0, 1.5, 25)
+    zoo["gamma_ll"] = M.bsm_ng(yg, sd_level=0.2, distribution="gamma", phi=2.0, u=np.full(25, 1.5), P1=np.array([[1.0]]))
+    ysv = rng.normal(0, 1.0, 45) * np.exp(0.5 * np.cumsum(rng.normal(0, 0.2, 45)))
+    zoo["svm"] = M.svm(ysv, rho=M.uniform(0.95, -1, 1), sd_ar=M.halfnormal(0.2, 5), sigma=M.halfnormal(1.0, 2))
+    n = 20  # fully time-varying m = 3, k = 2
+    Tt = np.zeros((3, 3, n)); Rt = np.zeros((3, 2, n)); Zt = np.zeros((3, n)); Ct = np.zeros((3, n))
+    for t in range(n):
+        Tt[:, :, t] = 0.8 * np.eye(3) + 0.05 * rng.normal(size=(3, 3))
+        Rt[:, :, t] = 0.2 * rng.normal(size=(3, 2))
+        Zt[:, t] = rng.normal(size=3) * 0.5
+        Ct[:, t] = 0.05 * rng.normal(size=3)
+    zoo["poisson_tv_m3"] = M.ssm_ung(rng.poisson(3, n).astype(float), Z=Zt, T=Tt, R=Rt, a1=[0.5, 0, 0],
+                                     P1=np.diag([0.3, 0.2, 0.0]), D=0.1 * rng.normal(size=n), C=Ct,
+                                     distribution="poisson", u=rng.uniform(0.5, 2, n))
+    zoo["negbin_m4"] = negbin_m4(25, seed=11)
+    zoo["gaussian_bsm"] = M.bsm_lg(np.ones(5), sd_level=0.05, sd_slope=0.01, sd_y=0.01, a1=[1, 0],
+                                   P1=np.diag([0.01, 0.01]))
+    yl = np.cumsum(rng.normal(0, 0.3, 30)) + rng.normal(0, 0.5, 30); yl[10] = np.nan
+    zoo["gaussian_ar1"] = M.ar1_lg(yl, rho=0.9, sigma=0.3, mu=0.2, sd_y=0.5)
+    return zoo

@@ -1,0 +1,147 @@
+"""GPU parity: HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (fp64): |logLik_gpu - logLik_oracle| <= 1e-9 * n; states / weights relative 1e-9; ancestor
+indices identical.  The two sides share the integer Philox stream exactly; they differ only in libm vs
+device math (ulp level) and in reduction shape, which is why the bound is 1e-9 and not 0.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from bssm_amd import filters as F
+from bssm_amd import models as M
+from models_zoo import negbin_ar1, negbin_m4, small_zoo
+
+pytestmark = pytest.mark.gpu
+
+ZOO = small_zoo()
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / (1e-300 + np.maximum(1.0, np.abs(b))))
+
+
+def _check_filter(out, ref, n, tol=1e-9):
+    assert np.array_equal(out["indices"], ref["indices"]), "ancestor tables differ"
+    assert abs(out["logLik"] - ref["logLik"]) <= tol * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= tol
+    assert _rel(out["weights"], ref["weights"]) <= tol
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+@pytest.mark.parametrize("name", sorted(ZOO))
+@pytest.mark.parametrize("N", [16, 100, 1500])
+def test_bootstrap_filter_matches_oracle(oracle, monkeypatch, name, N, path):
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    model = ZOO[name]
+    out = F.bootstrap_filter(model, N, seed=11, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), N, seed=11)
+    _check_filter(out, ref, model.n)
+    at, att, Pt, Ptt = oracle.filter_summary(ref["alpha"], ref["weights"])
+    assert _rel(out["at"], at.T) <= 1e-9 and _rel(out["att"], att.T) <= 1e-9
+    assert _rel(out["Pt"], Pt) <= 1e-8 and _rel(out["Ptt"], Ptt) <= 1e-8
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+@pytest.mark.parametrize("name", [k for k in sorted(ZOO) if not k.startswith("gaussian")])
+@pytest.mark.parametrize("N", [10, 300])
+def test_psi_smoother_matches_oracle(oracle, monkeypatch, name, N, path):
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    model = ZOO[name]
+    out = F.particle_smoother(model, N, method="psi", seed=5, return_indices=True)
+    ref = oracle.psi_filter(M.model_arrays(model), N, seed=5)
+    n = model.n
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
+    mean, cov = oracle.summary(sm)
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), sm[:, :n, :]) <= 1e-8
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8
+    assert _rel(out["Vt"], cov[:, :, :n]) <= 1e-7
+
+
+@pytest.mark.parametrize("name", ["poisson_slope_missing", "negbin_m4", "gaussian_ar1"])
+def test_bsf_smoother_matches_oracle(oracle, name):
+    model = ZOO[name]
+    out = F.particle_smoother(model, 200, method="bsf", seed=3, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), 200, seed=3)
+    n = model.n
+    sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
+    mean, cov = oracle.summary(sm)
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), sm[:, :n, :]) <= 1e-9
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-9
+    assert _rel(out["Vt"], cov[:, :, :n]) <= 1e-8
+
+
+def test_determinism_same_seed_identical():
+    """tests/testthat/test_bootstrap_filter.R:5-17: same (model, N, seed) => identical output."""
+    model = ZOO["negbin_ar1"]
+    a = F.bootstrap_filter(model, 500, seed=42)
+    b = F.bootstrap_filter(model, 500, seed=42)
+    for k in ("at", "att", "Pt", "Ptt", "weights", "alpha"):
+        assert np.array_equal(a[k], b[k])
+    assert a["logLik"] == b["logLik"]
+    c = F.bootstrap_filter(model, 500, seed=43)
+    assert c["logLik"] != a["logLik"]
+
+
+def test_loglik_entry_matches_filter(oracle):
+    model = ZOO["poisson_ll"]
+    arr = M.model_arrays(model)
+    for method, fn in (("bsf", oracle.bsf_filter), ("psi", oracle.psi_filter)):
+        ll = F.logLik(model, 64, method=method, seed=9)
+        ref = fn(arr, 64, seed=9)["logLik"]
+        assert abs(ll - ref) <= 1e-9 * model.n
+    # particles = 0: Gaussian approximation only (src/model_ssm_ung.cpp:214-234)
+    assert abs(F.logLik(model, 0, method="psi", seed=1) - oracle.psi_setup(arr)["approx_loglik"]) < 1e-10
+
+
+def test_loglik_batch_streams(oracle):
+    model = ZOO["negbin_ar1"]
+    arr = M.model_arrays(model)
+    lls = F.logLik_batch(model, 128, 40, method="bsf", seed=4, stream0=3)
+    for r in (0, 7, 39):
+        ref = oracle.bsf_filter(arr, 128, seed=4, stream=3 + r)["logLik"]
+        assert abs(lls[r] - ref) <= 1e-9 * model.n
+
+
+def test_degenerate_filter_returns_minus_inf_and_warns():
+    """src/model_ssm_ung.cpp:678-682 + src/R_bootstrap_filter.cpp:140-141"""
+    y = np.array([1.0, 2.0, 1e6, 3.0, 1.0])
+    model = M.ssm_ung(y, Z=1.0, T=1.0, R=1e-3, a1=0.0, P1=1e-6, distribution="poisson", D=800.0)
+    for path in ("wg", "grid"):
+        os.environ["BSSM_AMD_FORCE_PATH"] = path
+        try:
+            with pytest.warns(UserWarning, match="stopped prematurely"):
+                out = F.bootstrap_filter(model, 64, seed=1)
+        finally:
+            del os.environ["BSSM_AMD_FORCE_PATH"]
+        assert out["logLik"] == -np.inf
+
+
+def test_large_filter_grid_vs_wg_agree():
+    """The two kernel shapes implement the same recursion: identical ancestors, logLik to 1e-9 n."""
+    model = negbin_ar1(120, seed=21)
+    outs = {}
+    for path in ("wg", "grid"):
+        os.environ["BSSM_AMD_FORCE_PATH"] = path
+        try:
+            outs[path] = F.bootstrap_filter(model, 8192, seed=2, return_indices=True)
+        finally:
+            del os.environ["BSSM_AMD_FORCE_PATH"]
+    assert np.array_equal(outs["wg"]["indices"], outs["grid"]["indices"])
+    assert abs(outs["wg"]["logLik"] - outs["grid"]["logLik"]) <= 1e-9 * 120
+
+
+def test_full_size_c2_m4_against_oracle(oracle):
+    """BASELINE metric config at reduced T: ssm_ung negbin m=4, N=65536 (grid kernel), T=60."""
+    model = negbin_m4(60, seed=103)
+    out = F.bootstrap_filter(model, 65536, seed=1, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), 65536, seed=1)
+    same = np.array_equal(out["indices"], ref["indices"])
+    frac = np.mean(out["indices"] != ref["indices"])
+    assert same or frac < 1e-6, f"ancestor mismatch fraction {frac}"
+    assert abs(out["logLik"] - ref["logLik"]) <= (1e-9 if same else 1e-4) * 60
