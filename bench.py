@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""bench.py -- particle-steps/s of the bootstrap particle filter on MI355X.
+
+Workload (BASELINE.json metric config, SURVEY.md 8d "C2-m4"): ssm_ung, negative-binomial observations,
+m = k = 4 states, T = 1000 time points, N = 65 536 particles, full-output bootstrap filter (particle
+history, ancestor table and weights all kept in HBM, as bootstrap_filter() returns them).  One "step" =
+one complete filter pass (N*T = 65.5 M particle-steps) with the model tables already resident in HBM.
+
+A single filter does not shard (resampling is a global exchange every time step):
+--gpus N runs N independent replicas ("replicas only"), one process per GPU, and reports the aggregate.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel (pf_grid_step): algorithmic bytes per launch = N * (16 m + 24) B
+                 / its average launch duration measured with HIP events on the launch stream
+  cpu_baseline  the CPU oracle (single-threaded per filter, like the reference) timed on a bounded sample
+  regime_b      the batched regime SURVEY.md 8d asks to report separately: 512 independent N=2048 filters,
+                one workgroup each (the shape IS post-correction uses)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles", type=int, default=65536)
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-regime-b", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the particle filters have no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bssm_amd.plan import FilterPlan
+    from models_zoo import negbin_m4
+
+    N, T, m = args.particles, args.T, 4
+    model = negbin_m4(T, seed=103)
+    plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid")
+    info = plan.info()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        plan.run(1000 + w, stream0=rank, hip_stream=stream)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        plan.run(1 + s, stream0=rank, hip_stream=stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ll = plan.loglik(stream)
+    assert np.all(np.isfinite(ll)), ll
+
+    psteps_per_pass = float(N) * T
+    value = world * psteps_per_pass * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    out = {
+        "metric": "particle-steps/sec (N*T), bootstrap filter, ssm_ung negbin T=1000 m=4 N=65536",
+        "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C2-m4: ssm_ung negative binomial, m=k=4, T=%d, N=%d, full-output bootstrap filter "
+                               "(alpha, indices, weights kept in HBM); --gpus N = N independent replicas" % (T, N),
+                   "kernel_shape": info["path"], "blocks_per_launch": info["blocks"], "threads": info["threads"],
+                   "launches_per_step": T + 2, "parallelism": "replicas only x%d" % world},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events around sampled pf_grid_step launches
+        k_ms, k_n = plan.time_kernel(77, sample_every=16, hip_stream=stream)
+        bytes_per_launch = N * info["bytes_per_particle_step"]
+        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "pf_grid_step<4,4,1>", "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
+                           "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "frac_of_measured_copy_6290GBs": achieved / 6290.0}
+    plan.close()
+
+    if rank == 0 and not args.no_regime_b:
+        # ---- regime B: many independent filters, one workgroup each (post-correction shape)
+        nb, fb = 2048, 512
+        pb = FilterPlan(model, nb, method="bsf", n_rep=fb, keep_history=False, force="wg")
+        pb.run(5, hip_stream=stream); torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for s in range(reps):
+            pb.run(6 + s, hip_stream=stream)
+        torch.cuda.synchronize()
+        eb = (time.perf_counter() - t0) / reps
+        kb_ms, _ = pb.time_kernel(9, hip_stream=stream)
+        ib = pb.info()
+        ps = float(nb) * fb * T
+        out["regime_b"] = {"workload": "%d independent bootstrap filters, N=%d, T=%d, m=4, log-likelihood only "
+                                       "(one workgroup per filter, state in LDS)" % (fb, nb, T),
+                           "value": ps / eb, "unit": "particle-steps/s", "ms_per_pass": eb * 1e3,
+                           "kernel": "pf_wg_kernel<4,4,2>", "kernel_ms": kb_ms,
+                           "algorithmic_GBs": ps * ib["bytes_per_particle_step"] / (kb_ms * 1e-3) / 1e9,
+                           "note": "state never leaves LDS: HBM traffic ~0, bound by fp64 VALU/transcendentals"}
+        pb.close()
+
+    if rank == 0 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the oracle (reference loop structure, one thread per filter) on a bounded sample
+        from bssm_amd import models as M
+        from oracle import oracle as O
+        Ts = 150
+        sample = negbin_m4(Ts, seed=103)
+        arr = M.model_arrays(sample)
+        O.bsf_filter(arr, 1024, seed=1)  # warm
+        t0 = time.perf_counter()
+        O.bsf_filter(arr, N, seed=1)
+        ec = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": float(N) * Ts / ec, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+                               "sample": "same model and N=%d, first T=%d time points, 1 thread (the reference has no "
+                                         "intra-filter parallelism), gcc -O2, %.1f s" % (N, Ts, ec)}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

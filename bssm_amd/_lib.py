@@ -62,6 +62,7 @@ def lib():
                                      C.POINTER(C.c_int32), c_double_p]
         L.bssm_plan_device_outputs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.bssm_plan_time.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, c_double_p]
+        L.bssm_plan_time_kernel.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, c_double_p, C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 

@@ -132,14 +132,32 @@ struct DeviceBatch {
     return BSSM_OK;
   }
 
-  int run(uint32_t seed, uint32_t stream0, hipStream_t st) {
+  int run(uint32_t seed, uint32_t stream0, hipStream_t st, bssm::StepTiming* timing = nullptr) {
     fb.seed = seed; fb.stream0 = stream0;
     if (fb.alpha_hist) {  // the reference zero-fills its outputs (src/R_bootstrap_filter.cpp:136-138)
       HIP_TRY(hipMemsetAsync(hist.p, 0, hist.bytes, st));
       HIP_TRY(hipMemsetAsync(indices.p, 0, indices.bytes, st));
       HIP_TRY(hipMemsetAsync(weights.p, 0, weights.bytes, st));
     }
-    HIP_TRY(use_grid ? bssm::launch_grid_filter(fb, gws, st) : bssm::launch_wg_filter(fb, st));
+    if (use_grid) {
+      HIP_TRY(bssm::launch_grid_filter(fb, gws, st, timing));
+    } else if (timing && timing->every > 0) {  // one launch holds the whole filter: time that launch
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, st));
+      HIP_TRY(bssm::launch_wg_filter(fb, st));
+      HIP_TRY(hipEventRecord(e1, st));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      timing->total_ms += ms;
+      timing->count++;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    } else {
+      HIP_TRY(bssm::launch_wg_filter(fb, st));
+    }
     return BSSM_OK;
   }
 
@@ -617,7 +635,7 @@ int bssm_plan_info(const bssm_plan* plan, int32_t* path, int32_t* n_filters, int
   } else {
     if (blocks) *blocks = db.fb.F;
     const int N = db.fb.N;
-    if (threads) *threads = N <= 1024 ? (N + 63) / 64 * 64 : 1024;
+    if (threads) *threads = N <= 512 ? (N + 63) / 64 * 64 : 512;
   }
   if (bytes_per_particle_step) *bytes_per_particle_step = plan->bytes_per_pstep;
   return BSSM_OK;
@@ -649,6 +667,59 @@ int bssm_plan_time(bssm_plan* plan, uint32_t seed, int32_t reps, void* hip_strea
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *ms_per_run = (double)ms / reps;
+  return BSSM_OK;
+}
+
+// test hook: the device elementary functions (0 exp, 1 log, 2 sincos(2 pi x) -> 2n outputs, 3 Box-Muller pairs)
+int bssm_debug_math(int fn, const double* in, double* out, int32_t n) {
+  if (!have_device()) return no_device();
+  if (!in || !out || n < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  const int mult = fn >= 2 ? 2 : 1;
+  DevBuf di, dout;
+  HIP_TRY(di.alloc((size_t)n * sizeof(double)));
+  HIP_TRY(dout.alloc((size_t)n * mult * sizeof(double)));
+  HIP_TRY(hipMemcpy(di.p, in, di.bytes, hipMemcpyHostToDevice));
+  HIP_TRY(bssm::launch_debug_math(fn, di.as<double>(), dout.as<double>(), n, nullptr));
+  HIP_TRY(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
+  return BSSM_OK;
+}
+
+// debug: cycle stamps of the grid step kernel (block 0, thread 0), averaged over time steps
+int bssm_plan_debug_timeline(bssm_plan* plan, uint32_t seed, double* avg_delta_cycles /*[12]*/) {
+  if (!plan || !plan->db.use_grid) return fail(BSSM_ERR_INVALID, "grid plan required");
+  const int n = plan->db.fb.n;
+  DevBuf dbg;
+  HIP_TRY(dbg.alloc((size_t)n * 16 * sizeof(long long)));
+  HIP_TRY(hipMemset(dbg.p, 0, dbg.bytes));
+  plan->db.gws.dbg = dbg.as<long long>();
+  const int rc = plan->db.run(seed, 0, nullptr);
+  plan->db.gws.dbg = nullptr;
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<long long> h((size_t)n * 16);
+  HIP_TRY(hipMemcpy(h.data(), dbg.p, dbg.bytes, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 12; k++) avg_delta_cycles[k] = 0;
+  int cnt = 0;
+  for (int t = 1; t < n; t++) {
+    if (!h[(size_t)t * 16 + 11]) continue;
+    for (int k = 1; k < 12; k++) avg_delta_cycles[k] += (double)(h[(size_t)t * 16 + k] - h[(size_t)t * 16 + k - 1]);
+    cnt++;
+  }
+  for (int k = 1; k < 12; k++) avg_delta_cycles[k] /= cnt ? cnt : 1;
+  avg_delta_cycles[0] = cnt;
+  return BSSM_OK;
+}
+
+int bssm_plan_time_kernel(bssm_plan* plan, uint32_t seed, int32_t sample_every, void* hip_stream,
+                          double* avg_kernel_ms, int32_t* n_samples) {
+  if (!plan || !avg_kernel_ms) return fail(BSSM_ERR_INVALID, "bad arguments");
+  bssm::StepTiming tm;
+  tm.every = sample_every > 0 ? sample_every : 16;
+  const int rc = plan->db.run(seed, 0, (hipStream_t)hip_stream, &tm);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  *avg_kernel_ms = tm.count ? tm.total_ms / tm.count : 0.0;
+  if (n_samples) *n_samples = tm.count;
   return BSSM_OK;
 }
 

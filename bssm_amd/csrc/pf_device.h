@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pf_math.h"
+
 namespace bssm {
 
 // ---------------------------------------------------------------- layout of the per-filter tables
@@ -45,20 +47,21 @@ struct RngKey { uint32_t seed, stream; };
 // U[0,1) with 53 random bits
 __device__ __forceinline__ double rng_uniform(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d) {
   const u32x4 w = philox4x32_10(i, t, d, purpose, k.seed, k.stream);
-  return (double)bits53(w.x, w.y) * 0x1.0p-53;
+  return u53_to_double(w.x >> 5, w.y >> 6) * 0x1.0p-53;
 }
 
 // Box-Muller pair from one Philox block
-__device__ __forceinline__ void rng_normal_pair(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d,
-                                                double& z0, double& z1) {
-  const u32x4 w = philox4x32_10(i, t, d, purpose, k.seed, k.stream);
-  const double u1 = (double)(bits53(w.x, w.y) + 1) * 0x1.0p-53;  // (0,1]
-  const double u2 = (double)bits53(w.z, w.w) * 0x1.0p-53;        // [0,1)
-  const double rad = sqrt(-2.0 * log(u1));
+__device__ __forceinline__ void box_muller(const u32x4& w, double& z0, double& z1) {
+  const double u1 = (u53_to_double(w.x >> 5, w.y >> 6) + 1.0) * 0x1.0p-53;  // (0,1]
+  const double rad = sqrt(-2.0 * fast_log(u1));
   double sn, cs;
-  sincos(2.0 * 3.14159265358979323846 * u2, &sn, &cs);
+  fast_sincos_2pi(w.z >> 5, w.w >> 6, sn, cs);  // angle 2*pi*u2, u2 in [0,1)
   z0 = rad * cs;
   z1 = rad * sn;
+}
+__device__ __forceinline__ void rng_normal_pair(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d,
+                                                double& z0, double& z1) {
+  box_muller(philox4x32_10(i, t, d, purpose, k.seed, k.stream), z0, z1);
 }
 
 template <int CNT>
@@ -75,27 +78,48 @@ __device__ __forceinline__ void rng_normals(RngKey k, uint32_t purpose, uint32_t
 // ---------------------------------------------------------------- wavefront primitives (64 lanes)
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
+// Cross-lane moves on the DPP data path (no LDS crossbar, no address VGPR): a double travels as two
+// 32-bit halves.  `old` supplies the value for lanes without a valid source (bound_ctrl = 0) and for
+// rows masked out by row_mask, so an identity element there makes every step branch-free.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double identity, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(identity), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
-// fixed-shape butterfly: every lane ends with the same bits
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+__device__ __forceinline__ double lane_broadcast(double v, int src_lane) {  // src_lane wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
 }
-// inclusive Hillis-Steele scan over the 64 lanes
+
+// inclusive prefix sum over the 64 lanes, fixed shape: 4 steps inside each row of 16, then row 0->1 and
+// 2->3 (bcast15), then rows 0-1 -> 2-3 (bcast31).  Same association on every call => reproducible bits.
 __device__ __forceinline__ double wave_scan_incl(double v) {
-  const int l = lane_id();
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const double o = __shfl_up(v, off, 64);
-    if (l >= off) v += o;
-  }
+  v += dpp_move<DPP_ROW_SHR1, 0xf>(0.0, v);
+  v += dpp_move<DPP_ROW_SHR2, 0xf>(0.0, v);
+  v += dpp_move<DPP_ROW_SHR4, 0xf>(0.0, v);
+  v += dpp_move<DPP_ROW_SHR8, 0xf>(0.0, v);
+  v += dpp_move<DPP_ROW_BCAST15, 0xa>(0.0, v);
+  v += dpp_move<DPP_ROW_BCAST31, 0xc>(0.0, v);
   return v;
 }
+// maximum over the wave, returned in every lane
+__device__ __forceinline__ double wave_max(double v) {
+  const double ninf = -__builtin_huge_val();
+  v = fmax(v, dpp_move<DPP_ROW_SHR1, 0xf>(ninf, v));
+  v = fmax(v, dpp_move<DPP_ROW_SHR2, 0xf>(ninf, v));
+  v = fmax(v, dpp_move<DPP_ROW_SHR4, 0xf>(ninf, v));
+  v = fmax(v, dpp_move<DPP_ROW_SHR8, 0xf>(ninf, v));
+  v = fmax(v, dpp_move<DPP_ROW_BCAST15, 0xa>(ninf, v));
+  v = fmax(v, dpp_move<DPP_ROW_BCAST31, 0xc>(ninf, v));
+  return lane_broadcast(v, 63);
+}
+// sum over the wave in every lane (the last lane of the scan holds the total)
+__device__ __forceinline__ double wave_sum(double v) { return lane_broadcast(wave_scan_incl(v), 63); }
 
 // ---------------------------------------------------------------- observation log-densities
 // Unnormalised log g(y_t | signal s), src/model_ssm_ung.cpp:447-493; gaussian:
@@ -105,11 +129,11 @@ __device__ __forceinline__ double wave_scan_incl(double v) {
 __device__ __forceinline__ double log_obs_density(int dist, const double* __restrict__ ob, double phi, double s) {
   const double y = ob[OB_Y];
   switch (dist) {
-    case DIST_SVM: return -0.5 * (s + ob[OB_AUX] * exp(-s));
-    case DIST_POISSON: return y * s - ob[OB_U] * exp(s);
-    case DIST_BINOMIAL: return y * s - ob[OB_U] * log1p(exp(s));
-    case DIST_NEGBIN: return y * s - ob[OB_AUX] * log(phi + ob[OB_U] * exp(s));
-    case DIST_GAMMA: return -phi * (s + ob[OB_AUX] * exp(-s));
+    case DIST_SVM: return -0.5 * (s + ob[OB_AUX] * fast_exp(-s));
+    case DIST_POISSON: return y * s - ob[OB_U] * fast_exp(s);
+    case DIST_BINOMIAL: return y * s - ob[OB_U] * log1p(fast_exp(s));
+    case DIST_NEGBIN: return y * s - ob[OB_AUX] * fast_log(phi + ob[OB_U] * fast_exp(s));
+    case DIST_GAMMA: return -phi * (s + ob[OB_AUX] * fast_exp(-s));
     case DIST_GAUSSIAN: { const double r = y - s; return -0.5 * r * r * ob[OB_AUX]; }
   }
   return 0.0;

@@ -23,6 +23,8 @@ namespace bssm {
 
 __global__ void weights_finalize_kernel(double* __restrict__ weights, const double* __restrict__ maxhist,
                                         const int* __restrict__ dead_at, int n1, int N);
+__global__ void loglik_finalize_kernel(double* __restrict__ loglik, const double* __restrict__ llinc,
+                                       const int* __restrict__ dead_at, int n, int F);
 
 
 // ------------------------------------------------------------------------------------------
@@ -48,11 +50,11 @@ __device__ __forceinline__ double log_weight_of(const FilterBatch& b, const doub
 // alpha_{t+1} = C_t + T_t a + R_t eta   (src/model_ssm_ung.cpp:663-670); for the psi-APF the host
 // folds alphahat/Ct/Vt into the same three operands (src/model_ssm_ung.cpp:585-586).
 template <int MP, int KP>
-__device__ __forceinline__ void propagate(const double* __restrict__ mt, const double (&a)[MP], const double (&z)[KP],
+__device__ __forceinline__ void propagate(const double* mt, const double (&a)[MP], const double (&z)[KP],
                                           double (&x)[MP]) {
-  const double* __restrict__ Tm = mt;
-  const double* __restrict__ Rm = mt + MP * MP;
-  const double* __restrict__ Cv = mt + MP * MP + MP * KP;
+  const double* Tm = mt;
+  const double* Rm = mt + MP * MP;
+  const double* Cv = mt + MP * MP + MP * KP;
 #pragma unroll
   for (int j = 0; j < MP; j++) {
     double s = 0.0, q = 0.0;
@@ -79,17 +81,21 @@ __device__ __forceinline__ void initial_state(const double* __restrict__ ini, co
 // ------------------------------------------------------------------------------------------
 // Workgroup-resident filter
 // ------------------------------------------------------------------------------------------
+constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the fp64 transcendental code
 // Particle i = r * NT + tid (r < PPT): consecutive lanes own consecutive particles, so LDS
 // accesses to the own slot are conflict-free and history stores are coalesced.
 template <int MP, int KP, int PPT>
-__global__ void __launch_bounds__(1024) pf_wg_kernel(const FilterBatch b) {
+__global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
+  const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = NT >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Ncap = NT * PPT, N = b.N, n = b.n, f = blockIdx.x;
   double* __restrict__ s_alpha = smem;            // [MP][Ncap]
   double* __restrict__ s_cdf = smem + MP * Ncap;  // [Ncap]
   double* __restrict__ s_max = s_cdf + Ncap;      // [16]
   double* __restrict__ s_tot = s_max + 16;        // [PPT*16] wave totals in particle order
+  double* __restrict__ s_mats = s_tot + PPT * 16; // [MP*MP + MP*KP + MP] T_t, R_t, C_t of the current step
+  constexpr int MS = MP * MP + MP * KP + MP;
 
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
   const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
@@ -117,6 +123,7 @@ __global__ void __launch_bounds__(1024) pf_wg_kernel(const FilterBatch b) {
       }
     }
     w[r] = (i < N) ? log_weight_of<MP>(b, obs, phi, x) : -INFINITY;
+    __builtin_amdgcn_sched_barrier(0);  // keep the unrolled particles sequential: bounds live registers
   }
 
   for (int t = 0; t <= n; t++) {
@@ -129,12 +136,18 @@ __global__ void __launch_bounds__(1024) pf_wg_kernel(const FilterBatch b) {
     __syncthreads();  // (1)
     double M = s_max[0];
     for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
+    // stage this step's transition operands in LDS (every wave is past the previous transition here;
+    // they become visible at barrier (2)/(3), before the transition after barrier (4))
+    if (t < n && (t == 0 || b.mats_tstride != 0)) {
+      const double* __restrict__ src = mats + (size_t)t * b.mats_tstride;
+      for (int q = tid; q < MS; q += NT) s_mats[q] = src[q];
+    }
     // ... exp(w - max) and its inclusive scan in particle order (:676-679, stratified_sample.cpp:12)
     double sc[PPT];
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
-      const double e = (i < N) ? exp(w[r] - M) : 0.0;
+      const double e = (i < N) ? fast_exp(w[r] - M) : 0.0;
       sc[r] = wave_scan_incl(e);
       if (lane == 63) s_tot[r * nw + wave] = sc[r];
       if (b.weights && i < N) b.weights[((size_t)f * (n + 1) + t) * N + i] = e;
@@ -145,19 +158,19 @@ __global__ void __launch_bounds__(1024) pf_wg_kernel(const FilterBatch b) {
     const double t0 = (lane < Q) ? s_tot[lane] : 0.0;
     const double t1 = (lane + 64 < Q) ? s_tot[lane + 64] : 0.0;
     const double i0 = wave_scan_incl(t0);
-    const double half = __shfl(i0, 63, 64);
+    const double half = lane_broadcast(i0, 63);
     const double i1 = wave_scan_incl(t1) + half;
-    const double S = __shfl(i1, 63, 64);
+    const double S = lane_broadcast(i1, 63);
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int q = r * nw + wave;  // my chunk; exclusive offset = inclusive prefix of chunk q-1
-      const double p0 = __shfl(i0, (q - 1) & 63, 64), p1 = __shfl(i1, (q - 65) & 63, 64);
+      const double p0 = lane_broadcast(i0, (q - 1) & 63), p1 = lane_broadcast(i1, (q - 65) & 63);
       const double off = (q == 0) ? 0.0 : (q <= 64 ? p0 : p1);
       const int i = r * NT + tid;
       if (i < N) s_cdf[i] = off + sc[r];
     }
     if (!(S > 0.0)) { loglik = -INFINITY; break; }  // :678-682 (uniform across the block)
-    loglik += M + log(S / dN);                       // :683
+    loglik += M + fast_log(S / dN);                       // :683
     if (t == n) break;
     __syncthreads();  // (3) cdf visible
 
@@ -177,11 +190,12 @@ __global__ void __launch_bounds__(1024) pf_wg_kernel(const FilterBatch b) {
 #pragma unroll
       for (int c = 0; c < MP; c++) a[r][c] = s_alpha[c * Ncap + lo];
       if (b.indices && i < N) b.indices[((size_t)f * n + t) * N + i] = (uint32_t)lo;
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // (4) all ancestors read before the slots are overwritten
 
     // ---- transition to t+1 and the weights there
-    const double* __restrict__ mt = mats + (size_t)t * b.mats_tstride;
+    const double* mt = s_mats;
     const double* __restrict__ ob = obs + (size_t)(t + 1 < n ? t + 1 : 0) * obs_stride;
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
@@ -197,6 +211,7 @@ __global__ void __launch_bounds__(1024) pf_wg_kernel(const FilterBatch b) {
         }
       }
       w[r] = (i < N) ? (t + 1 < n ? log_weight_of<MP>(b, ob, phi, x) : 0.0) : -INFINITY;
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (tid == 0 && b.loglik) b.loglik[f] = loglik;
@@ -205,19 +220,19 @@ __global__ void __launch_bounds__(1024) pf_wg_kernel(const FilterBatch b) {
 template <int MP, int KP>
 hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   const int N = b.N;
-  int ppt, nt;
-  if (N <= 1024) { ppt = 1; nt = (N + 63) / 64 * 64; }
-  else if (N <= 2048) { ppt = 2; nt = 1024; }
-  else if (N <= 4096) { ppt = 4; nt = 1024; }
-  else { ppt = 8; nt = 1024; }
-  const size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16) * sizeof(double);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  int ppt = 1;
+  while (ppt < 16 && N > WG_NT_MAX * ppt) ppt *= 2;
+  const int nt = ppt == 1 ? (N + 63) / 64 * 64 : WG_NT_MAX;
+  const size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16 + (MP * MP + MP * KP + MP)) * sizeof(double);
+  if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch) = nullptr;
   switch (ppt) {
     case 1: kern = pf_wg_kernel<MP, KP, 1>; break;
     case 2: kern = pf_wg_kernel<MP, KP, 2>; break;
     case 4: kern = pf_wg_kernel<MP, KP, 4>; break;
-    default: kern = pf_wg_kernel<MP, KP, 8>; break;
+    case 8: kern = pf_wg_kernel<MP, KP, 8>; break;
+    default:
+      if constexpr (MP <= 2) kern = pf_wg_kernel<MP, KP, 16>; else return hipErrorInvalidValue;
   }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -234,7 +249,7 @@ constexpr int GRID_NT = 256;
 // s_tot must hold PPT * 4 doubles.  One barrier.
 template <int PPT>
 __device__ __forceinline__ double block_scan_strided(const double (&e)[PPT], double (&out)[PPT], double* s_tot) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NW = GRID_NT / 64;
   double sc[PPT];
 #pragma unroll
@@ -246,28 +261,73 @@ __device__ __forceinline__ double block_scan_strided(const double (&e)[PPT], dou
   constexpr int Q = PPT * NW;  // <= 32
   const double tq = (lane < Q) ? s_tot[lane] : 0.0;
   const double incl = wave_scan_incl(tq);
-  const double total = __shfl(incl, 63, 64);
+  const double total = lane_broadcast(incl, 63);
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int q = r * NW + wave;
-    const double prev = __shfl(incl, (q - 1) & 63, 64);
+    const double prev = lane_broadcast(incl, (q - 1) & 63);
     out[r] = (q == 0 ? 0.0 : prev) + sc[r];
   }
   return total;
 }
 
+// First index i in [0, len) with v <= a[i] for a non-decreasing array of at most 16 entries,
+// loaded in ONE round of independent loads (a 16-ary search step instead of 4 dependent binary steps);
+// len - 1 when no entry qualifies (the reference forces the last CDF entry to 1, stratified_sample.cpp:13).
+__device__ __forceinline__ int search16_global(const double* __restrict__ a, int len, double v) {
+  double c[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) c[q] = a[q < len ? q : len - 1];
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) cnt += (q < len && c[q] < v) ? 1 : 0;
+  return cnt < len ? cnt : len - 1;
+}
+__device__ __forceinline__ void load16_global(const double* __restrict__ a, int len, double (&c)[16]) {
+#pragma unroll
+  for (int q = 0; q < 16; q++) c[q] = a[q < len ? q : len - 1];
+}
+__device__ __forceinline__ int count16(const double (&c)[16], int len, double v) {
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) cnt += (q < len && c[q] < v) ? 1 : 0;
+  return cnt < len ? cnt : len - 1;
+}
+__device__ __forceinline__ int search16_lds(const double* a, int stride, int len, double v) {
+  double c[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) c[q] = a[(q < len ? q : len - 1) * stride];
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) cnt += (q < len && c[q] < v) ? 1 : 0;
+  return cnt < len ? cnt : len - 1;
+}
+
 // t = -1: initial particles + weights at time 0.  t in [0, n): resample on the time-t
 // weights, propagate to t+1, weigh at t+1 (ones when t+1 == n or y_{t+1} is missing).
-template <int MP, int KP, int PPT>
+//
+// Dependent-latency budget of one launch (one wave per SIMD at N = 65 536, so nothing hides latency):
+//   partials load  ||  Philox + Box-Muller for this step (independent of the exchange)
+//   -> block combine (2 barriers) -> 16-ary search over block prefixes in LDS (2 rounds)
+//   -> coarse row of the source block (1 global round) -> 16 fine entries (1 global round)
+//   -> ancestor state gather (1 global round) -> transition, density, block max/scan, stores.
+#define BSSM_STAMP(k)                                                                         \
+  if constexpr (DBG) {                                                                        \
+    asm volatile("" ::: "memory");                                                            \
+    if (ws.dbg && blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 64 && t >= 1)          \
+      ws.dbg[(size_t)t * 16 + (k)] = (long long)__builtin_readcyclecounter();                 \
+  }
+
+template <int MP, int KP, int PPT, bool DBG = false>
 __global__ void __launch_bounds__(GRID_NT) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   __shared__ double s_Q[GRID_NT];      // inclusive prefix of scaled block sums
-  __shared__ double s_scale[GRID_NT];  // exp(max_b - M)
+  __shared__ double s_iscale[GRID_NT];  // 1 / exp(max_b - M)
   __shared__ double s_red[8];
   __shared__ double s_tot[PPT * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pb = blockIdx.x, f = blockIdx.y, B = ws.B, chunk = ws.chunk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pb = blockIdx.x, f = blockIdx.y, B = ws.B, chunk = ws.chunk, crow = chunk >> 4;
   const int N = b.N, n = b.n, m = b.m;
-  if (ws.dead[f]) return;  // degenerate filter: later slots stay zero (src/model_ssm_ung.cpp:678-682)
+  BSSM_STAMP(0)
 
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
@@ -295,15 +355,28 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_step(const FilterBatch b, con
       }
     }
   } else {
-    // ---- combine the partials of the time-t weights (every block redundantly, same order)
+    // ---- issue the exchange loads first ...
     const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
     const double pmax = (tid < B) ? part[2 * tid] : -INFINITY;
     const double psum = (tid < B) ? part[2 * tid + 1] : 0.0;
+    // ... and draw this step's random numbers while they are in flight (PPT <= 2 keeps them in registers)
+    constexpr bool kEarlyRng = PPT <= 2;
+    double u_pre[kEarlyRng ? PPT : 1], z_pre[kEarlyRng ? PPT : 1][KP];
+    if constexpr (kEarlyRng) {
+#pragma unroll
+      for (int r = 0; r < PPT; r++) {
+        const uint32_t j = (uint32_t)(base + r * GRID_NT + tid);
+        u_pre[r] = rng_uniform(key, RNG_RESAMPLE, (uint32_t)t, j, 0);
+        rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, j, z_pre[r]);
+      }
+    }
+    BSSM_STAMP(1)
+    // ---- combine the partials of the time-t weights (every block redundantly, same order)
     double mx = wave_max(pmax);
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
     const double M = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-    const double scale = (tid < B) ? exp(pmax - M) : 0.0;
+    const double scale = (tid < B) ? fast_exp(pmax - M) : 0.0;
     const double ss = psum * scale;
     double qi = wave_scan_incl(ss);
     if (lane == 63) s_red[4 + wave] = qi;
@@ -312,57 +385,90 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_step(const FilterBatch b, con
     for (int q = 0; q < wave; q++) off += s_red[4 + q];
     qi += off;
     s_Q[tid] = qi;
-    s_scale[tid] = scale;
+    s_iscale[tid] = 1.0 / scale;
     const double S = ((s_red[4] + s_red[5]) + s_red[6]) + s_red[7];
     __syncthreads();
     if (!(S > 0.0)) {
-      if (pb == 0 && tid == 0) { ws.dead[f] = t + 1; b.loglik[f] = -INFINITY; }
+      // Degenerate weights (src/model_ssm_ung.cpp:678-682): stop here and poison this block's slot of the
+      // next parity so that every later launch sees a non-finite S as well and returns too (no flag load
+      // on the critical path of healthy steps); later output slots stay zero like the reference's.
+      if (tid == 0) {
+        double* __restrict__ pn = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
+        pn[2 * pb] = __builtin_nan("");
+        pn[2 * pb + 1] = __builtin_nan("");
+        if (pb == 0) { atomicCAS(&ws.dead[f], 0, t + 1); ws.maxhist[(size_t)f * (n + 1) + t] = M; }
+      }
       return;
     }
-    if (pb == 0 && tid == 0) {
-      b.loglik[f] += M + log(S / (double)N);  // src/model_ssm_ung.cpp:683 (single writer)
-      if (ws.maxhist) ws.maxhist[(size_t)f * (n + 1) + t] = M;
+    if (pb == B - 1 && tid == GRID_NT - 1) {  // single writer, store-only: summed in time order afterwards
+      ws.llinc[(size_t)f * (n + 1) + t] = M + fast_log(S / (double)N);  // src/model_ssm_ung.cpp:683
+      ws.maxhist[(size_t)f * (n + 1) + t] = M;
     }
+    BSSM_STAMP(2)
     // ---- resample + gather + propagate
     const double c_scale = S / (double)N;
     const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
+    const double* __restrict__ coarse = ws.coarse + ((size_t)(t & 1) * b.F + f) * B * crow;
     const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N
                                                      : ws.state[t & 1] + (size_t)f * m * N;
     const double* __restrict__ mt = b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride;
-#pragma unroll
-    for (int r = 0; r < PPT; r++) {
-      const int li = r * GRID_NT + tid, j = base + li;
-      if (li >= len) { for (int c = 0; c < MP; c++) x[r][c] = 0.0; continue; }
-      const double u = rng_uniform(key, RNG_RESAMPLE, (uint32_t)t, (uint32_t)j, 0);
-      const double v = (u + (double)j) * c_scale;
-      // level 1: source block
-      int lo = 0, hi = B - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (v <= s_Q[mid]) hi = mid; else lo = mid + 1;
+    {
+    #pragma unroll
+      for (int r = 0; r < PPT; r++) {
+        const int li = r * GRID_NT + tid, j = base + li;
+        if (li >= len) { for (int c = 0; c < MP; c++) x[r][c] = 0.0; continue; }
+        double u;
+        if constexpr (kEarlyRng) u = u_pre[r]; else u = rng_uniform(key, RNG_RESAMPLE, (uint32_t)t, (uint32_t)j, 0);
+        const double v = (u + (double)j) * c_scale;
+        // level 1: source block, two 16-ary rounds over the block prefixes in LDS
+        const int nrow = (B + 15) >> 4;
+        int row = 0;
+        if (nrow > 1) {  // pivots = last entry of each row of 16 (the final row may be short)
+          int cnt = 0;
+  #pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const int e = min(16 * q + 15, B - 1);
+            cnt += (q < nrow && s_Q[e] < v) ? 1 : 0;
+          }
+          row = cnt < nrow ? cnt : nrow - 1;
+        }
+        const int sb = 16 * row + search16_lds(s_Q + 16 * row, 1, min(16, B - 16 * row), v);
+        // target inside the source block's own (unscaled) local scan: (v - P_b) / exp(max_b - M)
+        const double vp = (v - (sb > 0 ? s_Q[sb - 1] : 0.0)) * s_iscale[sb];
+        BSSM_STAMP(3)
+        // level 2: inside the source block: coarse entries (every 16th of its local scan), then 16 fine ones
+        const int slen = min(chunk, N - sb * chunk);
+        const int ncr = (slen + 15) >> 4;
+        const double* __restrict__ cr = coarse + (size_t)sb * crow;
+        int lo = 0, hi = ncr - 1;
+        while (hi - lo >= 16) {  // only for chunk > 256 (N > 65 536)
+          const int mid = (lo + hi) >> 1;
+          if (vp <= cr[mid]) hi = mid; else lo = mid + 1;
+        }
+        const int crw = lo + search16_global(cr + lo, hi - lo + 1, vp);
+        BSSM_STAMP(4)
+        const int fine = search16_global(lcdf + (size_t)sb * chunk + 16 * crw, min(16, slen - 16 * crw), vp);
+        const int anc = sb * chunk + 16 * crw + fine;
+        BSSM_STAMP(5)
+        if (b.indices) b.indices[((size_t)f * n + t) * N + j] = (uint32_t)anc;
+        double a[MP];
+  #pragma unroll
+        for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
+        BSSM_STAMP(6)
+        if constexpr (kEarlyRng) {
+          propagate<MP, KP>(mt, a, z_pre[r], x[r]);
+        } else {
+          double z[KP];
+          rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+          propagate<MP, KP>(mt, a, z, x[r]);
+        }
+  #pragma unroll
+        for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[r][c];
       }
-      const int sb = lo;
-      const double P = sb > 0 ? s_Q[sb - 1] : 0.0;
-      const double sc = s_scale[sb];
-      const double* __restrict__ lc = lcdf + (size_t)sb * chunk;
-      // level 2: inside the source block's local scan
-      lo = 0; hi = min(chunk, N - sb * chunk) - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (v <= P + lc[mid] * sc) hi = mid; else lo = mid + 1;
-      }
-      const int anc = sb * chunk + lo;
-      if (b.indices) b.indices[((size_t)f * n + t) * N + j] = (uint32_t)anc;
-      double a[MP], z[KP];
-#pragma unroll
-      for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
-      rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
-      propagate<MP, KP>(mt, a, z, x[r]);
-#pragma unroll
-      for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[r][c];
     }
   }
 
+  BSSM_STAMP(7)
   // ---- weights at time tn, block-local max / scan, partials
   double w[PPT], e[PPT], sc[PPT];
   const bool have_obs = tn < n;
@@ -374,6 +480,7 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_step(const FilterBatch b, con
     w[r] = (li < len) ? (have_obs ? log_weight_of<MP>(b, ob, phi, x[r]) : 0.0) : -INFINITY;
     mx = fmax(mx, w[r]);
   }
+  BSSM_STAMP(8)
   __syncthreads();  // s_red reuse
   mx = wave_max(mx);
   if (lane == 0) s_red[wave] = mx;
@@ -382,25 +489,32 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_step(const FilterBatch b, con
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
-    e[r] = (li < len) ? exp(w[r] - Mb) : 0.0;
+    e[r] = (li < len) ? fast_exp(w[r] - Mb) : 0.0;
     if (b.weights && li < len) b.weights[((size_t)f * (n + 1) + tn) * N + base + li] = w[r];  // raw; finalised later
   }
+  BSSM_STAMP(9)
   const double tot = block_scan_strided<PPT>(e, sc, s_tot);
+  BSSM_STAMP(10)
   double* __restrict__ lcdf_new = ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N;
+  double* __restrict__ coarse_new = ws.coarse + (((size_t)(tn & 1) * b.F + f) * B + pb) * crow;
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
-    if (li < len) lcdf_new[base + li] = sc[r];
+    if (li < len) {
+      lcdf_new[base + li] = sc[r];
+      if ((li & 15) == 15 || li == len - 1) coarse_new[li >> 4] = sc[r];  // last entry of each row of 16
+    }
   }
   if (tid == 0) {
     double* __restrict__ part = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
     part[2 * pb] = Mb;
     part[2 * pb + 1] = tot;
   }
+  BSSM_STAMP(11)
 }
 
 template <int MP, int KP>
-hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   const int ppt = ws.chunk / GRID_NT;
   void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
   switch (ppt) {
@@ -409,13 +523,35 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     case 4: kern = pf_grid_step<MP, KP, 4>; break;
     default: kern = pf_grid_step<MP, KP, 8>; break;
   }
+  if constexpr (MP == 4 && KP == 4) { if (ws.dbg && ppt == 1) kern = pf_grid_step<MP, KP, 1, true>; }
   hipError_t e;
   if ((e = hipMemsetAsync(ws.dead, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(b.loglik, 0, sizeof(double) * b.F, stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(ws.maxhist, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(ws.maxhist, 0, sizeof(double) * 2 * b.F * (b.n + 1), stream)) != hipSuccess) return e;  // maxhist + llinc
   const dim3 grid(ws.B, b.F), block(GRID_NT);
-  for (int t = -1; t < b.n; t++) hipLaunchKernelGGL(kern, grid, block, 0, stream, b, ws, t);
+  if (!timing || timing->every <= 0) {
+    for (int t = -1; t < b.n; t++) hipLaunchKernelGGL(kern, grid, block, 0, stream, b, ws, t);
+  } else {
+    constexpr int kMaxSamples = 64;
+    hipEvent_t ev[2 * kMaxSamples];
+    int ns = 0;
+    for (int t = -1; t < b.n; t++) {
+      const bool sample = t >= 0 && (t % timing->every) == timing->every / 2 && ns < kMaxSamples;
+      if (sample) { (void)hipEventCreate(&ev[2 * ns]); (void)hipEventCreate(&ev[2 * ns + 1]); (void)hipEventRecord(ev[2 * ns], stream); }
+      hipLaunchKernelGGL(kern, grid, block, 0, stream, b, ws, t);
+      if (sample) { (void)hipEventRecord(ev[2 * ns + 1], stream); ns++; }
+    }
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    for (int i = 0; i < ns; i++) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+      timing->total_ms += ms;
+      timing->count++;
+      (void)hipEventDestroy(ev[2 * i]);
+      (void)hipEventDestroy(ev[2 * i + 1]);
+    }
+  }
   if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(loglik_finalize_kernel, dim3((b.F + 63) / 64), dim3(64), 0, stream, b.loglik, ws.llinc, ws.dead, b.n, b.F);
   if (b.weights) {
     const int gx = (b.N + 255) / 256 < 64 ? (b.N + 255) / 256 : 64;
     hipLaunchKernelGGL(weights_finalize_kernel, dim3(gx, b.n + 1, b.F), dim3(256), 0, stream, b.weights, ws.maxhist,
@@ -427,6 +563,6 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
 
 // per-MP entry points, one translation unit each (pf_inst_mp*.hip) so the build parallelises
 template <int MP> hipError_t launch_wg_mp(const FilterBatch& b, hipStream_t stream);
-template <int MP> hipError_t launch_grid_mp(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream);
+template <int MP> hipError_t launch_grid_mp(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing);
 
 }  // namespace bssm

@@ -10,10 +10,10 @@ template <> hipError_t launch_wg_mp<16>(const FilterBatch& b, hipStream_t stream
     default: return hipErrorInvalidValue;
   }
 }
-template <> hipError_t launch_grid_mp<16>(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+template <> hipError_t launch_grid_mp<16>(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   switch (b.KP) {
-    case 4: return launch_grid_mk<16, 4>(b, ws, stream);
-    case 16: return launch_grid_mk<16, 16>(b, ws, stream);
+    case 4: return launch_grid_mk<16, 4>(b, ws, stream, timing);
+    case 16: return launch_grid_mk<16, 16>(b, ws, stream, timing);
     default: return hipErrorInvalidValue;
   }
 }

@@ -10,10 +10,10 @@ template <> hipError_t launch_wg_mp<2>(const FilterBatch& b, hipStream_t stream)
     default: return hipErrorInvalidValue;
   }
 }
-template <> hipError_t launch_grid_mp<2>(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+template <> hipError_t launch_grid_mp<2>(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   switch (b.KP) {
-    case 1: return launch_grid_mk<2, 1>(b, ws, stream);
-    case 2: return launch_grid_mk<2, 2>(b, ws, stream);
+    case 1: return launch_grid_mk<2, 1>(b, ws, stream, timing);
+    case 2: return launch_grid_mk<2, 2>(b, ws, stream, timing);
     default: return hipErrorInvalidValue;
   }
 }

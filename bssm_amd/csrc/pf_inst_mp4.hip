@@ -11,11 +11,11 @@ template <> hipError_t launch_wg_mp<4>(const FilterBatch& b, hipStream_t stream)
     default: return hipErrorInvalidValue;
   }
 }
-template <> hipError_t launch_grid_mp<4>(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+template <> hipError_t launch_grid_mp<4>(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   switch (b.KP) {
-    case 1: return launch_grid_mk<4, 1>(b, ws, stream);
-    case 2: return launch_grid_mk<4, 2>(b, ws, stream);
-    case 4: return launch_grid_mk<4, 4>(b, ws, stream);
+    case 1: return launch_grid_mk<4, 1>(b, ws, stream, timing);
+    case 2: return launch_grid_mk<4, 2>(b, ws, stream, timing);
+    case 4: return launch_grid_mk<4, 4>(b, ws, stream, timing);
     default: return hipErrorInvalidValue;
   }
 }

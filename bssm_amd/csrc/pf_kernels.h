@@ -43,17 +43,24 @@ hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream);
 // Multi-workgroup filter for large N: workspace + per-time-step launches.
 struct GridWorkspace {
   double* state[2];    // [F][m][N] ping-pong when no history is kept
-  double* lcdf;        // [F][N] block-local inclusive scans of exp(w - max_b)
+  double* lcdf;        // [2][F][N] block-local inclusive scans of exp(w - max_b)
+  double* coarse;      // [2][F][B][chunk/16] last entry of every row of 16 of lcdf
   double* partials;    // [2][F][B][2]  (max_b, sum_b)
   double* logw;        // [F][N] raw log-weights when weights output is wanted
   double* maxhist;     // [F][n+1] global max per time point (weights finalisation)
+  double* llinc;       // [F][n+1] log-likelihood increment per time point (summed in time order at the end)
   int* dead;           // [F]
+  long long* dbg;      // optional [n][16] cycle stamps of block 0 / thread 0 (debug builds of the step kernel)
   int B;               // particle blocks per filter
   int chunk;           // particles per block
 };
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out);
 void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
-hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream);
+// Optional per-launch timing of the step kernel: every `every`-th step launch is bracketed by HIP
+// events on `stream`; the caller reads total_ms / count after the stream has drained.
+struct StepTiming { int every = 0; int count = 0; double total_ms = 0.0; };
+hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream,
+                              StepTiming* timing = nullptr);
 
 // Ancestor back-trace (src/filter_smoother.cpp:5-18) on the particle-minor history, in place is not
 // possible in parallel, so it writes `out` [f][n+1][m][N].
@@ -68,5 +75,7 @@ hipError_t launch_filter_summary(const double* hist, const double* weights, doub
 // [f][t][c][i] -> Armadillo cube m x (n+1) x N (index c + m*(t + (n+1)*i)) per filter
 hipError_t launch_to_cube(const double* hist, double* cube, int F, int n1, int m, int N, hipStream_t stream);
 // [f][t][i] u32 -> N x n column-major is already [t][i]; weights likewise. (no kernel needed)
+
+hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream);
 
 }  // namespace bssm

@@ -6,10 +6,11 @@
 namespace bssm {
 
 int wg_filter_capacity(int MP) {
-  // 160 KiB LDS per CU: (MP + 1) doubles per particle + 16 + 8*16 reduction slots
-  const size_t avail = 160 * 1024 - (16 + 8 * 16) * sizeof(double);
+  // 160 KiB LDS per CU: (MP + 1) doubles per particle + reduction slots; 512 threads x up to 16 particles
+  // (8 for padded state dimensions above 2)
+  const size_t avail = 160 * 1024 - (16 + 16 * 16 + MP * MP * 2 + MP) * sizeof(double);
   const size_t cap = avail / ((size_t)(MP + 1) * sizeof(double));
-  for (int c = 8192; c >= 1024; c >>= 1) if ((size_t)c <= cap) return c;
+  for (int c = (MP <= 2 ? 8192 : 4096); c >= 512; c >>= 1) if ((size_t)c <= cap) return c;
   return (int)(cap / 64 * 64);
 }
 
@@ -22,8 +23,18 @@ __global__ void weights_finalize_kernel(double* __restrict__ weights, const doub
   const int da = dead_at[f];  // 0 = alive, else (time of degeneracy) + 1
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     if (da && tt > da - 1) col[i] = 0.0;
-    else col[i] = exp(col[i] - M);
+    else col[i] = fast_exp(col[i] - M);
   }
+}
+
+// loglik[f] = sum_t llinc[f][t] in time order (the reference's accumulation order), -inf after a degenerate step
+__global__ void loglik_finalize_kernel(double* __restrict__ loglik, const double* __restrict__ llinc,
+                                       const int* __restrict__ dead_at, int n, int F) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double acc = 0.0;
+  for (int t = 0; t < n; t++) acc += llinc[(size_t)f * (n + 1) + t];
+  loglik[f] = dead_at[f] ? -INFINITY : acc;
 }
 
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
@@ -38,8 +49,9 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   bytes += 2 * al((size_t)b.F * b.m * b.N * sizeof(double));  // state ping-pong
   bytes += al((size_t)2 * b.F * b.N * sizeof(double));        // lcdf
+  bytes += al((size_t)2 * b.F * B * (chunk / 16) * sizeof(double));  // coarse
   bytes += al((size_t)2 * b.F * B * 2 * sizeof(double));      // partials
-  bytes += al((size_t)b.F * (b.n + 1) * sizeof(double));      // maxhist
+  bytes += al((size_t)2 * b.F * (b.n + 1) * sizeof(double));  // maxhist + llinc (contiguous)
   bytes += al((size_t)b.F * sizeof(int));                     // dead
   return bytes;
 }
@@ -52,14 +64,40 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   ws->state[0] = (double*)p; p += al((size_t)b.F * b.m * b.N * sizeof(double));
   ws->state[1] = (double*)p; p += al((size_t)b.F * b.m * b.N * sizeof(double));
   ws->lcdf = (double*)p; p += al((size_t)2 * b.F * b.N * sizeof(double));
+  ws->coarse = (double*)p; p += al((size_t)2 * b.F * B * (chunk / 16) * sizeof(double));
   ws->partials = (double*)p; p += al((size_t)2 * b.F * B * 2 * sizeof(double));
-  ws->maxhist = (double*)p; p += al((size_t)b.F * (b.n + 1) * sizeof(double));
+  ws->maxhist = (double*)p; ws->llinc = ws->maxhist + (size_t)b.F * (b.n + 1);
+  p += al((size_t)2 * b.F * (b.n + 1) * sizeof(double));
   ws->dead = (int*)p;
   ws->logw = nullptr;
+  ws->dbg = nullptr;
   ws->B = B;
   ws->chunk = chunk;
 }
 
+
+// test hook: evaluate the kernels' elementary functions on an array (see tests/test_gpu_math.py)
+__global__ void debug_math_kernel(int fn, const double* __restrict__ in, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = in[i];
+  if (fn == 0) out[i] = fast_exp(x);
+  else if (fn == 1) out[i] = fast_log(x);
+  else if (fn == 2) {
+    const uint64_t bits = (uint64_t)(x * 0x1.0p53);  // x in [0,1)
+    double sn, cs;
+    fast_sincos_2pi((uint32_t)(bits >> 26), (uint32_t)(bits & 0x3FFFFFFu), sn, cs);
+    out[2 * i] = sn; out[2 * i + 1] = cs;
+  } else if (fn == 3) {  // Box-Muller pair for Philox key (seed = 1, stream = 0), counter (i, 0, 0, purpose 2)
+    double z0, z1;
+    rng_normal_pair(RngKey{1u, 0u}, RNG_TRANSITION, 0u, (uint32_t)i, 0u, z0, z1);
+    out[2 * i] = z0; out[2 * i + 1] = z1;
+  }
+}
+hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, in, out, n);
+  return hipGetLastError();
+}
 
 hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream) {
   switch (b.MP) {
@@ -71,13 +109,13 @@ hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream) {
     default: return hipErrorInvalidValue;
   }
 }
-hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   switch (b.MP) {
-    case 1: return launch_grid_mp<1>(b, ws, stream);
-    case 2: return launch_grid_mp<2>(b, ws, stream);
-    case 4: return launch_grid_mp<4>(b, ws, stream);
-    case 8: return launch_grid_mp<8>(b, ws, stream);
-    case 16: return launch_grid_mp<16>(b, ws, stream);
+    case 1: return launch_grid_mp<1>(b, ws, stream, timing);
+    case 2: return launch_grid_mp<2>(b, ws, stream, timing);
+    case 4: return launch_grid_mp<4>(b, ws, stream, timing);
+    case 8: return launch_grid_mp<8>(b, ws, stream, timing);
+    case 16: return launch_grid_mp<16>(b, ws, stream, timing);
     default: return hipErrorInvalidValue;
   }
 }

@@ -25,7 +25,8 @@ def check_intmax(x, name="particles", positive=True, max=1e5):
     if not (isinstance(x, (int, np.integer)) or (isinstance(x, float) and x == int(x))) or x < 0 or (positive and x <= 0):
         raise ValueError(f"Argument '{name}' should be a {'positive' if positive else 'non-negative'} integer. ")
     if x > max:
-        raise ValueError(f"You probably do not want '{name}' > {max:g}. If you really do, please file an issue at Github. ")
+        shown = f"{max:.0e}" if max >= 1e5 and float(f"{max:.0e}") == max else f"{max:g}"  # R prints 1e5 as 1e+05
+        raise ValueError(f"You probably do not want '{name}' > {shown}. If you really do, please file an issue at Github. ")
     return int(x)
 
 

@@ -55,6 +55,13 @@ class FilterPlan:
         _lib.check(_lib.lib().bssm_plan_time(self._h, seed, reps, C.c_void_p(hip_stream), C.byref(ms)))
         return ms.value
 
+    def time_kernel(self, seed: int, sample_every: int = 16, hip_stream: int = 0):
+        """(average duration in ms of the dominant kernel's launches, number of sampled launches)"""
+        ms, cnt = C.c_double(), C.c_int32()
+        _lib.check(_lib.lib().bssm_plan_time_kernel(self._h, seed, sample_every, C.c_void_p(hip_stream), C.byref(ms),
+                                                     C.byref(cnt)))
+        return ms.value, cnt.value
+
     def close(self):
         if self._h:
             _lib.lib().bssm_plan_destroy(self._h)

@@ -204,6 +204,18 @@ int bssm_plan_device_outputs(const bssm_plan* plan, void** alpha_hist, void** in
 /* average device time per bssm_plan_run over `reps` runs, measured with HIP events on `hip_stream` */
 int bssm_plan_time(bssm_plan* plan, uint32_t seed, int32_t reps, void* hip_stream, double* ms_per_run);
 
+/* average duration of the DOMINANT kernel's launches during one run, measured with HIP events on
+ * `hip_stream` around sampled launches (grid shape: every `sample_every`-th time-step launch;
+ * workgroup shape: the single launch).  Used for the roofline line of bench.py. */
+int bssm_plan_time_kernel(bssm_plan* plan, uint32_t seed, int32_t sample_every, void* hip_stream,
+                          double* avg_kernel_ms, int32_t* n_samples);
+
+/* test / diagnostic hooks: device elementary functions (fn 0 exp, 1 log, 2 sincos(2*pi*x) -> 2n outputs,
+ * 3 Box-Muller pairs of the stream (seed 1, stream 0, purpose 2, t 0, particle i) -> 2n outputs) and the
+ * cycle-stamp timeline of the grid step kernel (12 averaged phase durations). */
+int bssm_debug_math(int fn, const double* in, double* out, int32_t n);
+int bssm_plan_debug_timeline(bssm_plan* plan, uint32_t seed, double* avg_delta_cycles);
+
 /* exposed for tests: the exact Philox block and uniform / normal pair the kernels use */
 void bssm_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

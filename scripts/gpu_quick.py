@@ -22,6 +22,8 @@ for name, mdl, N, kw in (("C2-m1 grid", negbin_ar1(1000), 65536, dict(force="gri
                          ("C2-m4 grid hist", negbin_m4(1000), 65536, dict(force="grid", keep_history=True)),
                          ("m4 wg N=2048 x512", negbin_m4(1000), 2048, dict(force="wg", n_rep=512)),
                          ("m1 wg N=4096 x512", negbin_ar1(1000), 4096, dict(force="wg", n_rep=512)),
+                         ("C2-m4 grid hist x8", negbin_m4(1000), 65536, dict(force="grid", keep_history=True, n_rep=8)),
+                         ("C2-m4 grid x8", negbin_m4(1000), 65536, dict(force="grid", n_rep=8)),
                          ("m4 wg N=1024 x1024", negbin_m4(200), 1024, dict(force="wg", n_rep=1024)),
                          ("m4 wg N=64 x8192", negbin_m4(200), 64, dict(force="wg", n_rep=8192))):
     t0 = time.time()

@@ -1,0 +1,151 @@
+"""CPU-side checks of the product's host logic and C ABI surface (no compute on a GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from bssm_amd import _lib
+from bssm_amd import filters as F
+from bssm_amd import models as M
+from models_zoo import small_zoo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bssm_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(bssm_[a-z0-9_]+)\s*\(", hdr))
+    names -= {"bssm_plan"}
+    assert len(names) >= 18
+    L = _lib.lib()
+    for nm in sorted(names):
+        assert hasattr(L, nm), f"{nm} declared in include/bssm_amd.h but not exported"
+    assert b"gfx950" in L.bssm_amd_version()
+
+
+def test_philox_in_library_matches_known_answers(oracle):
+    L = _lib.lib()
+    for ctr, key in (([0, 0, 0, 0], [0, 0]), ([0xffffffff] * 4, [0xffffffff] * 2), ([1, 2, 3, 4], [5, 6])):
+        o = (C.c_uint32 * 4)()
+        L.bssm_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), o)
+        assert list(o) == oracle.philox(ctr, key)
+
+
+def test_no_device_is_a_loud_error():
+    if _lib.lib().bssm_amd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    model = small_zoo()["poisson_ll"]
+    with pytest.raises(_lib.BssmAmdError, match="no CPU fallback"):
+        F.bootstrap_filter(model, 10, seed=1)
+    with pytest.raises(_lib.BssmAmdError, match="no CPU fallback"):
+        F.logLik(model, 10, method="psi", seed=1)
+
+
+def test_argument_checks_mirror_reference():
+    model = small_zoo()["poisson_ll"]
+    with pytest.raises(ValueError, match="positive integer"):
+        F.bootstrap_filter(model, 0, seed=1)
+    with pytest.raises(ValueError, match="You probably do not want 'particles' > 1e\\+05"):
+        F.bootstrap_filter(model, 100001, seed=1)   # R/check_arguments.R:407-418
+    with pytest.raises(ValueError):
+        F.particle_smoother(model, 10, method="nope")
+    with pytest.raises(ValueError, match="phi"):
+        M.ssm_ung([1.0, 2.0], Z=1, T=1, R=1, P1=1, distribution="negative binomial", phi=-1)
+    with pytest.raises(ValueError, match="should be one of"):
+        M.ssm_ung([1.0, 2.0], Z=1, T=1, R=1, P1=1, distribution="weibull")
+
+
+def test_model_constructors_shapes():
+    m = M.bsm_ng(np.arange(1.0, 25), sd_level=0.1, sd_slope=0.01, sd_seasonal=0.05, period=4, distribution="poisson")
+    assert m["Z"].shape == (5, 1) and m["T"].shape == (5, 5, 1) and m["R"].shape == (5, 3, 1)
+    assert np.allclose(m["T"][2, 2:5, 0], -1) and m["T"][3, 2, 0] == 1 and m["T"][4, 3, 0] == 1
+    assert np.allclose(np.diag(m["P1"]), 100)   # R/models.R:1001-1002
+    assert M.model_type(m) == 2
+    s = M.svm(np.array([0.1, -0.2, 0.3]), rho=M.uniform(0.9, -1, 1), sd_ar=M.halfnormal(0.2, 5), sigma=M.halfnormal(1.5, 2))
+    assert s["distribution"] == "svm" and s["phi"] == 1.5 and M.model_type(s) == 3
+    assert np.allclose(s["initial_mode"][:, 0], np.log(np.maximum(1e-4, s["y"] ** 2)) - 2 * np.log(1.5))
+    a = M.ar1_ng([1.0, 2.0, 0.0], rho=M.uniform(0.5, -1, 1), sigma=M.halfnormal(0.3, 1), mu=1.0, distribution="poisson")
+    assert np.isclose(a["P1"][0, 0], 0.09 / 0.75) and np.isclose(a["C"][0, 0], 0.5) and M.model_type(a) == 4
+    assert np.allclose(M.init_mode(np.array([0.0, 3.0, np.nan]), np.ones(3), "poisson"), np.log([0.1, 3, 0.1]))
+
+
+def test_host_psi_setup_matches_oracle(oracle):
+    zoo = small_zoo()
+    for name in sorted(zoo):
+        if name.startswith("gaussian"):
+            continue
+        model = zoo[name]
+        so = oracle.psi_setup(M.model_arrays(model))
+        sp = F.psi_setup(model)
+        for k in ("approx_y", "approx_H", "mode", "scales", "alphahat", "Vt", "Ct"):
+            a, b = so[k], sp[k]
+            ok = np.isfinite(a)
+            assert np.array_equal(np.isfinite(b), ok), (name, k)
+            assert np.allclose(a[ok], b[ok], rtol=1e-10, atol=1e-12), (name, k)
+        assert np.isclose(so["approx_loglik"], sp["approx_loglik"], rtol=1e-12)
+        # importance-sampling variant with a supplied mode (src/model_ssm_ung.cpp:143-161)
+        so2 = oracle.psi_setup(M.model_arrays(model), is_mode=so["mode"])
+        sp2 = F.psi_setup(model, is_mode=so["mode"])
+        assert sp2["approx_loglik"] == 0.0
+        assert np.allclose(so2["scales"], sp2["scales"], rtol=1e-10, atol=1e-12)
+
+
+def test_loglik_with_zero_particles_is_gaussian_approximation(oracle):
+    model = small_zoo()["negbin_ar1"]
+    ll = F.logLik(model, 0, method="psi", seed=1)      # host only: no device needed
+    assert np.isclose(ll, oracle.psi_setup(M.model_arrays(model))["approx_loglik"], rtol=1e-12)
+
+
+def test_update_model_builtin_maps():
+    """src/model_ar1_ng.cpp:12-36, src/model_svm.cpp:12-29, src/model_bsm_ng.cpp:17-51"""
+    L = _lib.lib()
+    model = M.ar1_ng([1.0, 2.0, 0.0, 1.0], rho=M.uniform(0.5, -1, 1), sigma=M.halfnormal(0.3, 1), mu=M.normal(1.0, 0, 1),
+                     distribution="negative binomial", phi=M.gamma(2.0, 1, 1))
+    arr = M.model_arrays(model)
+    s, keep = _lib.pack_model(arr)
+    T, R, P1, a1, Cc = (np.array(arr[k], dtype=float, order="F", copy=True) for k in ("T", "R", "P1", "a1", "C"))
+    theta = np.array([0.8, np.log(0.2), 1.5, np.log(3.0)])
+    flags = (C.c_int32 * 2)(1, 1)
+    rc = L.bssm_update_model_builtin(4, flags, _lib.dptr(theta), 4, C.byref(s), _lib.dptr(T), _lib.dptr(R), _lib.dptr(P1),
+                                     _lib.dptr(a1), _lib.dptr(Cc), None)
+    assert rc == 0
+    assert T[0, 0, 0] == 0.8 and np.isclose(R[0, 0, 0], 0.2) and a1[0] == 1.5
+    assert np.isclose(Cc[0, 0], 1.5 * 0.2) and np.isclose(P1[0, 0], 0.04 / (1 - 0.64)) and np.isclose(s.phi, 3.0)
+    sv = M.svm(np.array([0.1, -0.2, 0.3]), rho=M.uniform(0.9, -1, 1), sd_ar=M.halfnormal(0.2, 5), sigma=M.halfnormal(1.5, 2))
+    arr = M.model_arrays(sv)
+    s, keep = _lib.pack_model(arr)
+    T, R, P1, a1, Cc = (np.array(arr[k], dtype=float, order="F", copy=True) for k in ("T", "R", "P1", "a1", "C"))
+    theta = np.array([0.95, 0.3, 2.0])
+    rc = L.bssm_update_model_builtin(3, (C.c_int32 * 1)(0), _lib.dptr(theta), 3, C.byref(s), _lib.dptr(T), _lib.dptr(R),
+                                     _lib.dptr(P1), _lib.dptr(a1), _lib.dptr(Cc), None)
+    assert rc == 0 and s.phi == 2.0 and T[0, 0, 0] == 0.95 and R[0, 0, 0] == 0.3
+    assert np.isclose(P1[0, 0], 0.09 / (1 - 0.95 ** 2))
+
+
+def test_is_merge_matches_oracle_merge(oracle):
+    rng = np.random.default_rng(1)
+    n, m, ns = 6, 2, 5
+    w = rng.uniform(0.1, 2, ns); counts = rng.integers(1, 4, ns).astype(np.uint32)
+    ah = np.asfortranarray(rng.normal(size=(m, n + 1, ns)))
+    vt = np.zeros((m, m, n + 1, ns), order="F")
+    for i in range(ns):
+        for t in range(n + 1):
+            A = rng.normal(size=(m, m)); vt[:, :, t, i] = A @ A.T
+    alphahat = np.zeros((m, n + 1), order="F"); Vt = np.zeros((m, m, n + 1), order="F")
+    rc = _lib.lib().bssm_is_merge(n, m, ns, _lib.dptr(w), counts.ctypes.data_as(_lib.c_u32_p), _lib.dptr(ah), _lib.dptr(vt),
+                                  _lib.dptr(alphahat), _lib.dptr(Vt))
+    assert rc == 0
+    wc = w * counts
+    mean = np.tensordot(ah, wc, axes=([2], [0])) / wc.sum()
+    assert np.allclose(alphahat, mean, rtol=1e-12)
+    # law of total variance: E[Var] + Var[E]
+    ev = np.tensordot(vt, wc, axes=([3], [0])) / wc.sum()
+    ve = np.zeros_like(ev)
+    for i in range(ns):
+        d = ah[:, :, i] - mean
+        for t in range(n + 1):
+            ve[:, :, t] += wc[i] * np.outer(d[:, t], d[:, t])
+    assert np.allclose(Vt, ev + ve / wc.sum(), rtol=1e-10, atol=1e-12)
