@@ -1,0 +1,301 @@
+"""IS post-correction of an approximate MCMC run: Python mirror of bssm's ``post_correct``
+(R/post_correction.R:245-308 -> src/R_postcorrection.cpp:150-248 -> approx_mcmc::is_correction_psi,
+src/approx_mcmc.cpp:353-427).
+
+One independent psi-APF per retained theta-draw.  The draws are the unit that shards: with
+``torch.distributed`` initialised (one process per GPU, backend "nccl" = RCCL over xGMI) every rank
+filters a contiguous block of draws on its own GPU through the C ABI and ONE collective phase at the
+end all-gathers the per-draw results (weights, and the smoothed summaries / trajectories when they are
+requested).  Random streams are keyed by the global draw index, and the summary merge runs in draw
+order on every rank, so the output is bit-identical for any number of GPUs.
+
+As in the reference, ``theta`` is handed to the model's ``update_model`` exactly as stored in
+``mcmc_output`` (R/post_correction.R:266-270).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+from .filters import check_intmax, _default_seed, _INT_MAX
+from .models import BssmModel, model_arrays, model_type
+
+_OUTPUT_TYPES = {"full": 1, "summary": 2, "theta": 3, 1: 1, 2: 2, 3: 3}
+
+
+# ------------------------------------------------------------------ per-draw models (parset, src/parset_ng.cpp:5-111)
+def _builtin_flags(model: BssmModel):
+    cls = model.classes[0]
+    if cls == "bsm_ng":  # src/model_bsm_ng.cpp:4-14
+        fx = list(model["fixed"])
+        return [int(model["slope"]), int(model["seasonal"]), int(model["noise"]), int(fx[0]), int(fx[1]), int(fx[2]),
+                int(model["phi_est"])]
+    if cls == "svm":
+        return [int(model["svm_type"])]
+    if cls == "ar1_ng":
+        return [int(model["mu_est"]), int(model["phi_est"])]
+    return None
+
+
+def expand_models(model: BssmModel, theta: np.ndarray):
+    """One flattened model per row of ``theta`` (n_stored x n_par).
+
+    Built-in model classes use the library's update_model maps (bssm_update_model_builtin);
+    ``ssm_ung`` calls ``model['update_fn'](theta_i)`` which returns a dict of replaced components
+    (Z, T, R, a1, P1, D, C, phi, beta), as the R closure does (src/model_ssm_ung.cpp:41-78)."""
+    theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+    base = model_arrays(model)
+    mt = model_type(model)
+    flags = _builtin_flags(model)
+    out = []
+    L = _lib.lib()
+    for i in range(theta.shape[0]):
+        arr = dict(base)
+        th = np.ascontiguousarray(theta[i])
+        if flags is not None:
+            for k in ("T", "R", "P1", "a1", "C", "beta"):
+                arr[k] = np.array(base[k], dtype=np.float64, order="F", copy=True)
+            s, keep = _lib.pack_model(arr)
+            fl = (C.c_int32 * len(flags))(*flags)
+            _lib.check(L.bssm_update_model_builtin(mt, fl, _lib.dptr(th), th.size, C.byref(s), _lib.dptr(arr["T"]),
+                                                   _lib.dptr(arr["R"]), _lib.dptr(arr["P1"]), _lib.dptr(arr["a1"]),
+                                                   _lib.dptr(arr["C"]), _lib.dptr(arr["beta"]) if arr["beta"].size else None))
+            arr["phi"] = float(s.phi)
+        else:
+            fn = model.get("update_fn")
+            if fn is not None:
+                upd = fn(th) or {}
+                for k, v in upd.items():
+                    if k == "phi":
+                        arr["phi"] = float(v)
+                    elif k in ("Z", "T", "R", "a1", "P1", "D", "C", "beta"):
+                        arr[k] = np.asfortranarray(np.asarray(v, dtype=np.float64).reshape(np.shape(base[k])))
+                    else:
+                        raise ValueError(f"update_fn returned unknown component '{k}'")
+        if arr["xreg"].shape[1]:
+            arr["xbeta"] = arr["xreg"] @ arr["beta"]
+        out.append(arr)
+    return out
+
+
+# ------------------------------------------------------------------ sharding (static blocks, like `omp for schedule(static)`)
+def shard_bounds(work: np.ndarray, world: int):
+    """Contiguous blocks of draws with (nearly) equal total work; returns world+1 boundaries.
+    is1 multiplies the particle count by count_i (src/approx_mcmc.cpp:376-378), so work_i = count_i there."""
+    work = np.asarray(work, dtype=np.float64)
+    n = work.size
+    cum = np.concatenate([[0.0], np.cumsum(work)])
+    bounds = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        k = int(np.searchsorted(cum, target, side="left"))
+        bounds.append(min(max(k, bounds[-1]), n))
+    bounds.append(n)
+    return np.asarray(bounds, dtype=np.int64)
+
+
+def _run_local_block(arrs, modes, counts, first, n_stored, nsim, seed, is_type, output_type, n_threads,
+                     method=1, approx_loglik=None):
+    """Filter draws [first, first+len(arrs)) on this process's GPU through the C ABI."""
+    cnt = len(arrs)
+    n, m = arrs[0]["n"], arrs[0]["m"]
+    packed, keep = [], []
+    for a in arrs:
+        s, k = _lib.pack_model(a)
+        packed.append(s)
+        keep.append(k)
+    models = (_lib.UngModel * cnt)(*packed)
+    job = _lib.IsJob()
+    job.n_stored, job.first, job.count = n_stored, first, cnt
+    job.models = models
+    modes_c = None if modes is None else np.asfortranarray(modes, dtype=np.float64)
+    al_c = None if approx_loglik is None else np.ascontiguousarray(approx_loglik, dtype=np.float64)
+    counts_c = np.ascontiguousarray(counts, dtype=np.uint32)
+    job.modes = _lib.dptr(modes_c)
+    job.approx_loglik = _lib.dptr(al_c)
+    job.counts = counts_c.ctypes.data_as(_lib.c_u32_p)
+    job.sampling_method, job.is_type, job.output_type = method, is_type, output_type
+    job.nsim, job.seed, job.n_threads = nsim, seed, n_threads
+    weights, loglik = np.zeros(cnt), np.zeros(cnt)
+    alpha = np.zeros((n + 1, m, cnt), order="F") if output_type == 1 else None
+    ah = np.zeros((m, n + 1, cnt), order="F") if output_type == 2 else None
+    vt = np.zeros((m, m, n + 1, cnt), order="F") if output_type == 2 else None
+    rc = _lib.check(_lib.lib().bssm_is_correction(C.byref(job), _lib.dptr(weights), _lib.dptr(loglik), _lib.dptr(alpha),
+                                                  _lib.dptr(ah), _lib.dptr(vt)))
+    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1)
+
+
+def is_correction(model: BssmModel, theta, counts, particles: int, method: str = "psi", modes=None, approx_loglik=None,
+                  is_type: int = 2, output_type: int = 3, seed: int = 1, threads: int = 1):
+    """Single-process IS correction with either sampler (approx_mcmc::is_correction_psi / _bsf,
+    src/approx_mcmc.cpp:353-427, 447-518) -- the step run_mcmc's `is` types run after the approximate chain."""
+    arrs = expand_models(model, theta)
+    counts = np.asarray(counts, dtype=np.uint32)
+    res = _run_local_block(arrs, modes, counts, 0, len(arrs), particles, seed, is_type, output_type, threads,
+                           method=1 if method == "psi" else 2, approx_loglik=approx_loglik)
+    if output_type == 2:
+        ah, vt = is_merge(model.n, model.m, res["weights"], counts, res["alphahat_i"], res["Vt_i"])
+        res["alphahat"], res["Vt"] = ah, vt
+    return res
+
+
+def _all_gather_blocks(local: np.ndarray, bounds, rank, world, group, device):
+    """All-gather variable-length blocks along the LAST axis (padded to the largest block): one collective."""
+    import torch
+    import torch.distributed as dist
+    sizes = np.diff(bounds)
+    mx = int(sizes.max())
+    lead = local.shape[:-1]
+    pad = np.zeros(lead + (mx,), dtype=np.float64)
+    pad[..., :local.shape[-1]] = local
+    t = torch.from_numpy(np.ascontiguousarray(pad)).to(device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t, group=group)
+    parts = [outs[r].cpu().numpy()[..., :int(sizes[r])] for r in range(world)]
+    return np.concatenate(parts, axis=-1)
+
+
+def is_merge(n, m, weights, counts, alphahat_i, Vt_i):
+    """West/Chan merge in draw order (src/approx_mcmc.cpp:397-414, 422-424) via the library."""
+    ns = weights.size
+    alphahat = np.zeros((m, n + 1), order="F")
+    Vt = np.zeros((m, m, n + 1), order="F")
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    c = np.ascontiguousarray(counts, dtype=np.uint32)
+    ah = np.asfortranarray(alphahat_i, dtype=np.float64)
+    vt = np.asfortranarray(Vt_i, dtype=np.float64)
+    _lib.check(_lib.lib().bssm_is_merge(n, m, ns, _lib.dptr(w), c.ctypes.data_as(_lib.c_u32_p), _lib.dptr(ah), _lib.dptr(vt),
+                                        _lib.dptr(alphahat), _lib.dptr(Vt)))
+    return alphahat, Vt
+
+
+def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: int = 1, is_type: str = "is2",
+                 seed: int | None = None, group=None):
+    """R/post_correction.R:245-308.  ``mcmc_output`` needs: theta (n_stored x n_par), counts, modes
+    (n x n_stored, or 1 x n x n_stored as R stores it), posterior, output_type ('full'|'summary'|'theta' or 1..3).
+    Returns a copy with weights / posterior (and alpha or alphahat, Vt) updated."""
+    particles = check_intmax(particles, "particles")
+    threads = check_intmax(threads, "threads")
+    seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
+    if not isinstance(mcmc_output, dict) or "theta" not in mcmc_output or "counts" not in mcmc_output:
+        raise ValueError("Object 'mcmc_output' is not valid output from 'run_mcmc'.")
+    if is_type.lower() not in ("is1", "is2", "is3"):
+        raise ValueError("'arg' should be one of 'is1', 'is2', 'is3'")
+    is_t = int(is_type[-1])
+    if not model.inherits("nongaussian"):
+        raise TypeError("Function 'post_correct' is only available for models of class 'nongaussian' and 'ssm_nlg'.")
+    if np.any(np.isnan(np.asarray(model["u"], dtype=float))):
+        raise ValueError("Missing values not allowed in 'u'.")
+    output_type = _OUTPUT_TYPES[mcmc_output.get("output_type", 3)]
+    t0 = time.perf_counter()
+
+    theta = np.atleast_2d(np.asarray(mcmc_output["theta"], dtype=np.float64))
+    counts = np.asarray(mcmc_output["counts"], dtype=np.uint32).reshape(-1)
+    modes = np.asarray(mcmc_output["modes"], dtype=np.float64)
+    n = model.n
+    modes = modes.reshape(n, -1, order="F") if modes.ndim == 3 else modes
+    if theta.shape[0] != counts.size or modes.shape != (n, counts.size):
+        raise ValueError("theta, counts and modes of 'mcmc_output' do not agree")
+    if is_t == 3:  # expand(): src/approx_mcmc.cpp:49-88, called from src/R_postcorrection.cpp:197-199
+        rep = counts.astype(np.int64)
+        theta, modes = np.repeat(theta, rep, axis=0), np.repeat(modes, rep, axis=1)
+        counts = np.ones(int(rep.sum()), dtype=np.uint32)
+    n_stored = counts.size
+
+    # ---- shard the draws over the process group
+    rank, world, dist = 0, 1, None
+    try:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            dist, rank, world = _dist, _dist.get_rank(group), _dist.get_world_size(group)
+    except ImportError:
+        pass
+    work = counts.astype(np.float64) if is_t == 1 else np.ones(n_stored)
+    bounds = shard_bounds(work, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+
+    arrs = expand_models(model, theta[lo:hi])
+    m = model.m
+    if hi > lo:
+        loc = _run_local_block(arrs, modes[:, lo:hi], counts[lo:hi], lo, n_stored, particles, seed, is_t, output_type,
+                               threads)
+    else:
+        loc = dict(weights=np.zeros(0), loglik=np.zeros(0), alpha=np.zeros((n + 1, m, 0)),
+                   alphahat_i=np.zeros((m, n + 1, 0)), Vt_i=np.zeros((m, m, n + 1, 0)), degenerate=False)
+
+    # ---- ONE collective phase: all-gather the per-draw results
+    if world > 1:
+        import torch
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        pieces = [loc["weights"][None, :], loc["loglik"][None, :]]
+        if output_type == 1:
+            pieces.append(loc["alpha"].reshape(-1, hi - lo, order="F"))
+        elif output_type == 2:
+            pieces.append(loc["alphahat_i"].reshape(-1, hi - lo, order="F"))
+            pieces.append(loc["Vt_i"].reshape(-1, hi - lo, order="F"))
+        stacked = np.concatenate(pieces, axis=0)
+        full = _all_gather_blocks(stacked, bounds, rank, world, group, device)
+        weights, loglik = full[0], full[1]
+        if output_type == 1:
+            alpha = full[2:].reshape((n + 1, m, n_stored), order="F")
+        elif output_type == 2:
+            k1 = 2 + m * (n + 1)
+            ah_i = full[2:k1].reshape((m, n + 1, n_stored), order="F")
+            vt_i = full[k1:].reshape((m, m, n + 1, n_stored), order="F")
+    else:
+        weights, loglik = loc["weights"], loc["loglik"]
+        alpha, ah_i, vt_i = loc["alpha"], loc["alphahat_i"], loc["Vt_i"]
+
+    out = dict(mcmc_output)
+    out["weights"] = weights
+    with np.errstate(divide="ignore"):
+        # posterior = prior (0) + approx_loglik (0) + log(weight): src/approx_mcmc.cpp:425-426, R_postcorrection.cpp:178-179
+        inc = np.log(weights)
+    if is_t == 3:
+        out["theta"], out["counts"], out["modes"] = theta, counts, modes
+        out["posterior"] = np.repeat(np.asarray(mcmc_output.get("posterior", np.zeros(rep.size)), dtype=float), rep) + inc
+    else:
+        out["posterior"] = np.asarray(mcmc_output.get("posterior", np.zeros(n_stored)), dtype=float) + inc
+    out["loglik"] = loglik
+    if output_type == 1:
+        out["alpha"] = alpha
+    elif output_type == 2:
+        alphahat, Vt = is_merge(n, m, weights, counts, ah_i, vt_i)
+        out["alphahat"] = np.ascontiguousarray(alphahat.T)  # (n+1) x m, as mcmc_run.alphahat.t()
+        out["Vt"] = Vt
+    out["mcmc_type"] = f"is{is_t}"
+    out["seed"] = list(np.atleast_1d(mcmc_output.get("seed", []))) + [seed]
+    out["time_postcorrection"] = time.perf_counter() - t0
+    out["shards"] = bounds
+    return out
+
+
+def suggest_N(model: BssmModel, theta, candidates=range(10, 101, 10), replications: int = 100, seed: int | None = None):
+    """R/post_correction.R:84-130 -> suggest_n_nongaussian (src/R_postcorrection.cpp:13-140): standard deviation
+    of the psi-APF log-likelihood at ``theta`` over ``replications`` runs for each candidate N; N = first
+    candidate with sd < 1 (None if there is none, R's NA).  The replications of one candidate run as ONE device
+    batch (bssm_nongaussian_loglik_batch) instead of the reference's sequential loop."""
+    from .filters import logLik_batch
+    replications = check_intmax(replications, "replications", max=1000)
+    seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
+    candidates = [int(c) for c in candidates]
+    if not candidates or min(candidates) < 1:
+        raise ValueError("Argument 'candidates' should be vector of positive integers. ")
+    if max(candidates) > 1e5:
+        raise ValueError("I don't believe you want to use over 1e5 particles If you really do, please file an issue at Github.")
+    theta = np.asarray(theta, dtype=np.float64).reshape(-1)
+    if theta.size != np.asarray(model["theta"]).size:
+        raise ValueError("Length of 'theta' does not match length of 'model$theta'.")
+    arr = expand_models(model, theta[None, :])[0]
+    fields = {**model, **{k: arr[k] for k in ("Z", "T", "R", "P1", "a1", "C", "D", "beta")}, "phi": arr["phi"]}
+    mdl = BssmModel(model.classes, **fields)
+    sds = []
+    for i, N in enumerate(candidates):
+        ll = logLik_batch(mdl, N, replications, method="psi", seed=seed, stream0=i * replications)
+        sds.append(float(np.std(ll, ddof=1)))  # arma::stddev: N - 1 normalisation
+    sds = np.asarray(sds)
+    ok = np.nonzero(sds < 1.0)[0]
+    return dict(N=candidates[int(ok[0])] if ok.size else None, results=dict(N=np.asarray(candidates), sd=sds))

@@ -1,0 +1,111 @@
+"""world_size-2 gloo test of the theta-sharded post-correction: sharding, the single all-gather phase and
+the draw-order merge, on CPU.  The per-block compute is INJECTED from the oracle here (test infrastructure);
+the product's own block runner goes through the HIP library and has no CPU path."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_block(arrs, modes, counts, first, n_stored, nsim, seed, is_type, output_type, n_threads):
+    """Stand-in for bssm_amd.post_correct._run_local_block built on the oracle (streams keyed by global index)."""
+    from oracle import oracle as O
+    cnt = len(arrs)
+    n, m = arrs[0]["n"], arrs[0]["m"]
+    weights, loglik = np.zeros(cnt), np.zeros(cnt)
+    alpha = np.zeros((n + 1, m, cnt), order="F")
+    ah = np.zeros((m, n + 1, cnt), order="F")
+    vt = np.zeros((m, m, n + 1, cnt), order="F")
+    for i in range(cnt):
+        N = nsim * int(counts[i]) if is_type == 1 else nsim
+        res = O.psi_filter(arrs[i], N, seed=seed, stream=first + i, is_mode=modes[:, i])
+        loglik[i] = res["logLik"]
+        weights[i] = np.exp(res["logLik"])
+        if output_type != 3:
+            sm = O.filter_smoother(res["alpha"], res["indices"])
+            if output_type == 2:
+                ah[:, :, i], vt[:, :, :, i] = O.summary(sm)
+            else:
+                import ctypes as C
+                rng, _ = O.make_rng(seed=seed, stream=first + i)
+                pick = min(int(O.lib().orc_rng_uniform(C.byref(rng), 3, 0, 0, 0) * N), N - 1)
+                alpha[:, :, i] = sm[:, :, pick].T
+    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=False)
+
+
+def _make_job():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from bssm_amd import models as M
+    from oracle import oracle as O
+    rng = np.random.default_rng(4)
+    y = rng.poisson(4.0, 30).astype(float)
+    model = M.bsm_ng(y, sd_level=M.halfnormal(0.2, 1), sd_slope=M.halfnormal(0.02, 1), distribution="poisson",
+                     P1=np.diag([1.0, 0.1]))
+    ns = 7
+    theta = np.log(np.column_stack([rng.uniform(0.1, 0.4, ns), rng.uniform(0.01, 0.05, ns)]))
+    counts = np.array([3, 1, 2, 5, 1, 1, 4], dtype=np.uint32)
+    from bssm_amd.post_correct import expand_models
+    modes = np.stack([O.psi_setup(a)["mode"] for a in expand_models(model, theta)], axis=1)
+    return model, dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type="summary")
+
+
+def _worker(rank, world, port, outdir, is_type, output_type):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bssm_amd.post_correct as PC
+    PC._run_local_block = _oracle_block
+    model, mo = _make_job()
+    mo["output_type"] = output_type
+    out = PC.post_correct(model, mo, 12, threads=1, is_type=is_type, seed=5)
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), **{k: v for k, v in out.items()
+                                                       if isinstance(v, np.ndarray) and v.dtype != object})
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("is_type,output_type", [("is2", "summary"), ("is1", "full"), ("is3", "theta")])
+def test_two_rank_post_correct_equals_single_process(tmp_path, is_type, output_type):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), is_type, output_type), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    # single-process reference with the same injected block runner
+    import bssm_amd.post_correct as PC
+    old = PC._run_local_block
+    PC._run_local_block = _oracle_block
+    try:
+        model, mo = _make_job()
+        mo["output_type"] = output_type
+        single = PC.post_correct(model, mo, 12, threads=1, is_type=is_type, seed=5)
+    finally:
+        PC._run_local_block = old
+    for k in ("weights", "posterior", "loglik") + (("alphahat", "Vt") if output_type == "summary" else ()) + \
+            (("alpha",) if output_type == "full" else ()):
+        assert np.array_equal(r0[k], r1[k]), k                # every rank holds the full result
+        assert np.array_equal(r0[k], single[k]), k            # and it does not depend on the number of ranks
+    assert r0["shards"][0] == 0 and r0["shards"][-1] == r0["weights"].size and len(r0["shards"]) == 3
+    assert np.all(np.isfinite(r0["weights"])) and r0["weights"].max() > 0
+
+
+def test_shard_bounds_balance_by_work():
+    from bssm_amd.post_correct import shard_bounds
+    b = shard_bounds(np.ones(10), 4)
+    assert list(b) == [0, 3, 5, 8, 10] or (b[0] == 0 and b[-1] == 10 and np.all(np.diff(b) >= 2))
+    work = np.array([10, 1, 1, 1, 1, 1, 1, 1, 1, 2.0])
+    b = shard_bounds(work, 2)
+    assert b[0] == 0 and b[-1] == 10 and abs(work[:b[1]].sum() - work[b[1]:].sum()) <= 10
+    assert list(shard_bounds(np.ones(2), 4)) == [0, 1, 1, 2, 2] or shard_bounds(np.ones(2), 4)[-1] == 2
+    b = shard_bounds(np.ones(5), 1)
+    assert list(b) == [0, 5]

@@ -1,0 +1,74 @@
+"""GPU parity of the IS post-correction (one psi-APF / bootstrap filter per retained theta-draw) against the
+oracle's restatement of approx_mcmc::is_correction_psi / _bsf (src/approx_mcmc.cpp:353-427, 447-518)."""
+import numpy as np
+import pytest
+
+from bssm_amd import models as M
+from bssm_amd import post_correct as PC
+
+pytestmark = pytest.mark.gpu
+
+
+def _job(ns=9, n=40, seed=4):
+    rng = np.random.default_rng(seed)
+    y = rng.poisson(4.0, n).astype(float); y[5] = np.nan
+    model = M.bsm_ng(y, sd_level=M.halfnormal(0.2, 1), sd_slope=M.halfnormal(0.02, 1), distribution="poisson",
+                     P1=np.diag([1.0, 0.1]))
+    theta = np.log(np.column_stack([rng.uniform(0.1, 0.4, ns), rng.uniform(0.01, 0.05, ns)]))
+    counts = rng.integers(1, 5, ns).astype(np.uint32)
+    return model, theta, counts
+
+
+@pytest.mark.parametrize("output_type", [1, 2, 3])
+@pytest.mark.parametrize("is_type", ["is1", "is2", "is3"])
+def test_post_correct_matches_oracle(oracle, is_type, output_type):
+    model, theta, counts = _job()
+    arrs = PC.expand_models(model, theta)
+    modes = np.stack([oracle.psi_setup(a)["mode"] for a in arrs], axis=1)
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.full(len(counts), -3.0), output_type=output_type)
+    out = PC.post_correct(model, mo, 16, threads=2, is_type=is_type, seed=9)
+    it = int(is_type[-1])
+    if it == 3:
+        rep = counts.astype(int)
+        arrs_e = [a for a, r in zip(arrs, rep) for _ in range(r)]
+        modes_e, counts_e = np.repeat(modes, rep, axis=1), np.ones(rep.sum(), dtype=np.uint32)
+    else:
+        arrs_e, modes_e, counts_e = arrs, modes, counts
+    ref = oracle.is_correction(arrs_e, 16, 9, method=1, counts=counts_e, modes=modes_e, is_type=it,
+                               output_type=output_type, n_threads=2)
+    n = model.n
+    assert np.allclose(out["loglik"], ref["loglik"], rtol=0, atol=1e-9 * n)
+    assert np.allclose(out["weights"], ref["weights"], rtol=1e-8)
+    assert np.allclose(out["posterior"], (-3.0 if it != 3 else -3.0) + np.log(ref["weights"]), rtol=0, atol=1e-8)
+    if output_type == 1:
+        assert np.allclose(out["alpha"], ref["alpha"], rtol=1e-8, atol=1e-10)
+    if output_type == 2:
+        assert np.allclose(out["alphahat"], ref["alphahat"].T, rtol=1e-8, atol=1e-10)
+        assert np.allclose(out["Vt"], ref["Vt"], rtol=1e-7, atol=1e-10)
+
+
+def test_bsf_is_correction_matches_oracle(oracle):
+    model, theta, counts = _job(ns=6)
+    arrs = PC.expand_models(model, theta)
+    al = np.array([oracle.psi_setup(a)["approx_loglik"] for a in arrs])
+    res = PC.is_correction(model, theta, counts, 64, method="bsf", approx_loglik=al, output_type=2, seed=3)
+    ref = oracle.is_correction(arrs, 64, 3, method=2, counts=counts, approx_loglik=al, output_type=2)
+    assert np.allclose(res["loglik"], ref["loglik"], rtol=0, atol=1e-9 * model.n)
+    assert np.allclose(res["weights"], ref["weights"], rtol=1e-8)
+    assert np.allclose(res["alphahat"], ref["alphahat"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(res["Vt"], ref["Vt"], rtol=1e-7, atol=1e-10)
+
+
+def test_suggest_N(oracle):
+    """tests/testthat/test_post_correct.R: suggest_N returns the first candidate with sd < 1"""
+    model, theta, counts = _job()
+    res = PC.suggest_N(model, theta[0], candidates=[5, 10, 20], replications=40, seed=1)
+    assert res["results"]["sd"].shape == (3,) and np.all(np.isfinite(res["results"]["sd"]))
+    assert res["N"] in (5, 10, 20)
+    # the batch equals individual logLik calls with the same streams
+    from bssm_amd.filters import logLik_batch
+    arr = PC.expand_models(model, theta[:1])[0]
+    ll = oracle.psi_filter(arr, 5, seed=1, stream=3)["logLik"]
+    mdl = M.BssmModel(model.classes, **{**model, **{k: arr[k] for k in ("T", "R", "P1", "a1", "C")}})
+    got = logLik_batch(mdl, 5, 40, method="psi", seed=1, stream0=0)
+    assert abs(got[3] - ll) <= 1e-9 * model.n
