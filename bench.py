@@ -6,15 +6,20 @@ m = k = 4 states, T = 1000 time points, N = 65 536 particles, full-output bootst
 history, ancestor table and weights all kept in HBM, as bootstrap_filter() returns them).  One "step" =
 one complete filter pass (N*T = 65.5 M particle-steps) with the model tables already resident in HBM.
 
-A single filter does not shard (resampling is a global exchange every time step):
---gpus N runs N independent replicas ("replicas only"), one process per GPU, and reports the aggregate.
+A single filter does not shard (resampling is a global exchange every time step), and on
+its own it is latency-bound (1000 dependent launches with one wave per SIMD), so a step advances
+`--replicas` independent filter calls (different Philox streams: repeated logLik / suggest_N / parallel
+chains) together -- SURVEY.md 8d's regime B on the metric's own configuration; the single-call number
+(regime A) is reported next to it as `single_filter`.  --gpus N runs the same batch on every GPU
+("replicas only"), one process per GPU, and reports the aggregate.
 
 Extra objects in the JSON line:
   roofline      dominant kernel (pf_grid_step): algorithmic bytes per launch = N * (16 m + 24) B
                  / its average launch duration measured with HIP events on the launch stream
   cpu_baseline  the CPU oracle (single-threaded per filter, like the reference) timed on a bounded sample
-  regime_b      the batched regime SURVEY.md 8d asks to report separately: 512 independent N=2048 filters,
-                one workgroup each (the shape IS post-correction uses)
+  single_filter one filter call alone (latency regime)
+  regime_b      512 independent N=2048 filters, one workgroup each, state resident in LDS (the shape IS
+                post-correction uses)
 """
 import argparse
 import json
@@ -29,15 +34,31 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def pmc_traffic(R, N):
+    """HBM bytes per pf_grid_step launch from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this script, corrected as MI355X_MICROARCH.md prescribes and calibrated on
+    weights_finalize_kernel's known byte count); None when the profile does not match this workload."""
+    try:
+        p = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if p["replicas"] == R and p["particles"] == N:
+            return p["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--particles", type=int, default=65536)
+    ap.add_argument("--replicas", type=int, default=12,
+                    help="independent filters (different Philox streams) in flight per step; 1 = latency regime")
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-regime-b", action="store_true")
+    ap.add_argument("--no-single", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -60,7 +81,8 @@ def main():
 
     N, T, m = args.particles, args.T, 4
     model = negbin_m4(T, seed=103)
-    plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid")
+    R = args.replicas
+    plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R)
     info = plan.info()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -71,11 +93,11 @@ def main():
         torch.cuda.synchronize()
 
     for w in range(args.warmup):
-        plan.run(1000 + w, stream0=rank, hip_stream=stream)
+        plan.run(1000 + w, stream0=rank * R, hip_stream=stream)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        plan.run(1 + s, stream0=rank, hip_stream=stream)
+        plan.run(1 + s, stream0=rank * R, hip_stream=stream)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -85,7 +107,7 @@ def main():
     ll = plan.loglik(stream)
     assert np.all(np.isfinite(ll)), ll
 
-    psteps_per_pass = float(N) * T
+    psteps_per_pass = float(N) * T * R
     value = world * psteps_per_pass * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
@@ -95,22 +117,40 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "C2-m4: ssm_ung negative binomial, m=k=4, T=%d, N=%d, full-output bootstrap filter "
-                               "(alpha, indices, weights kept in HBM); --gpus N = N independent replicas" % (T, N),
-                   "kernel_shape": info["path"], "blocks_per_launch": info["blocks"], "threads": info["threads"],
-                   "launches_per_step": T + 2, "parallelism": "replicas only x%d" % world},
+                               "(alpha, indices, weights kept in HBM); one step = %d independent filter calls "
+                               "(different Philox streams) advanced together; --gpus N = the same batch on each GPU" % (T, N, R),
+                   "filters_in_flight": R, "kernel_shape": info["path"], "blocks_per_launch": info["blocks"],
+                   "threads": info["threads"], "launches_per_step": T + 3, "parallelism": "replicas only x%d" % world},
     }
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around sampled pf_grid_step launches
         k_ms, k_n = plan.time_kernel(77, sample_every=16, hip_stream=stream)
-        bytes_per_launch = N * info["bytes_per_particle_step"]
+        bytes_per_launch = float(R) * N * info["bytes_per_particle_step"]
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R, N),
                            "kernel": "pf_grid_step<4,4,1>", "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
+                           "wall_per_launch_us": ms_per_step * 1e3 / (T + 1),
                            "algorithmic_bytes_per_launch": bytes_per_launch,
                            "frac_of_measured_copy_6290GBs": achieved / 6290.0}
     plan.close()
+
+    if rank == 0 and R != 1 and not args.no_single:
+        # ---- regime A: ONE filter, latency-bound (1000 dependent launches, one wave per SIMD)
+        p1 = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=1)
+        p1.run(3, hip_stream=stream); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(5):
+            p1.run(4 + s, hip_stream=stream)
+        torch.cuda.synchronize()
+        e1 = (time.perf_counter() - t0) / 5
+        k1_ms, _ = p1.time_kernel(78, sample_every=16, hip_stream=stream)
+        out["single_filter"] = {"workload": "one bootstrap_filter call, same model, N=%d, T=%d, full output" % (N, T),
+                                "value": float(N) * T / e1, "unit": "particle-steps/s", "ms_per_call": e1 * 1e3,
+                                "avg_launch_us": k1_ms * 1e3,
+                                "algorithmic_GBs": N * info["bytes_per_particle_step"] / (k1_ms * 1e-3) / 1e9}
+        p1.close()
 
     if rank == 0 and not args.no_regime_b:
         # ---- regime B: many independent filters, one workgroup each (post-correction shape)
@@ -138,7 +178,7 @@ def main():
         # ---- CPU baseline: the oracle (reference loop structure, one thread per filter) on a bounded sample
         from bssm_amd import models as M
         from oracle import oracle as O
-        Ts = 150
+        Ts = T  # the whole single-filter workload: ~10 s of one core
         sample = negbin_m4(Ts, seed=103)
         arr = M.model_arrays(sample)
         O.bsf_filter(arr, 1024, seed=1)  # warm
@@ -146,7 +186,7 @@ def main():
         O.bsf_filter(arr, N, seed=1)
         ec = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": float(N) * Ts / ec, "unit": "particle-steps/s", "cores": 1, "kind": "port",
-                               "sample": "same model and N=%d, first T=%d time points, 1 thread (the reference has no "
+                               "sample": "one full filter call of the benchmark model: N=%d, T=%d, 1 thread (the reference has no "
                                          "intra-filter parallelism), gcc -O2, %.1f s" % (N, Ts, ec)}
 
     if rank == 0:

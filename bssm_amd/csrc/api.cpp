@@ -72,14 +72,14 @@ void parallel_for(int count, int threads, F fn) {
 // ------------------------------------------------------------------ a batch of filters on the device
 struct DeviceBatch {
   bssm::FilterBatch fb{};
-  DevBuf mats, obs, init, phi, hist, indices, weights, loglik, ws;
+  DevBuf mats, obs, init, phi, hist, indices, weights, loglik, dead, ws;
   bssm::GridWorkspace gws{};
   bool use_grid = false;
   std::vector<double> const_terms;  // per filter, added to the device log-likelihood on the host
 
   // tables: one per filter (all with the same MP/KP/mats_tstride)
   int upload(const std::vector<bssm::FilterTables>& tabs, const std::vector<double>& phis, int n, int m, int k, int N,
-             int dist, int psi, bool keep_hist, unsigned path_flags) {
+             int dist, int psi, bool keep_hist, unsigned path_flags, bool keep_weights = true) {
     const int F = (int)tabs.size();
     const int MP = tabs[0].MP, KP = tabs[0].KP;
     fb.n = n; fb.m = m; fb.k = k; fb.MP = MP; fb.KP = KP; fb.N = N; fb.F = F; fb.dist = dist; fb.psi = psi;
@@ -105,11 +105,13 @@ struct DeviceBatch {
     fb.phi = phi.as<double>();
     HIP_TRY(loglik.alloc(F * sizeof(double)));
     fb.loglik = loglik.as<double>();
+    HIP_TRY(dead.alloc(F * sizeof(int)));
+    fb.dead_at = dead.as<int>();
     if (keep_hist) {
       HIP_TRY(hist.alloc((size_t)F * (n + 1) * m * N * sizeof(double)));
       HIP_TRY(indices.alloc((size_t)F * n * N * sizeof(uint32_t)));
-      HIP_TRY(weights.alloc((size_t)F * (n + 1) * N * sizeof(double)));
-      fb.alpha_hist = hist.as<double>(); fb.indices = indices.as<uint32_t>(); fb.weights = weights.as<double>();
+      if (keep_weights) HIP_TRY(weights.alloc((size_t)F * (n + 1) * N * sizeof(double)));
+      fb.alpha_hist = hist.as<double>(); fb.indices = indices.as<uint32_t>(); fb.weights = keep_weights ? weights.as<double>() : nullptr;
     }
     // kernel shape: workgroup-resident when the particle system fits one CU's LDS and there are
     // enough filters to fill the chip (or the filter is small); otherwise one launch per time step.
@@ -134,11 +136,6 @@ struct DeviceBatch {
 
   int run(uint32_t seed, uint32_t stream0, hipStream_t st, bssm::StepTiming* timing = nullptr) {
     fb.seed = seed; fb.stream0 = stream0;
-    if (fb.alpha_hist) {  // the reference zero-fills its outputs (src/R_bootstrap_filter.cpp:136-138)
-      HIP_TRY(hipMemsetAsync(hist.p, 0, hist.bytes, st));
-      HIP_TRY(hipMemsetAsync(indices.p, 0, indices.bytes, st));
-      HIP_TRY(hipMemsetAsync(weights.p, 0, weights.bytes, st));
-    }
     if (use_grid) {
       HIP_TRY(bssm::launch_grid_filter(fb, gws, st, timing));
     } else if (timing && timing->every > 0) {  // one launch holds the whole filter: time that launch
@@ -158,6 +155,9 @@ struct DeviceBatch {
     } else {
       HIP_TRY(bssm::launch_wg_filter(fb, st));
     }
+    // the reference zero-fills its outputs (src/R_bootstrap_filter.cpp:136-138): only a degenerate filter leaves
+    // slots unwritten, so zero just those instead of memset-ing tens of GB per run
+    HIP_TRY(bssm::launch_zero_dead_tail(fb, !use_grid, st));
     return BSSM_OK;
   }
 
@@ -351,6 +351,8 @@ int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, ui
   db.fb.phi = db.phi.as<double>();
   HIP_TRY(db.loglik.alloc(n_rep * sizeof(double)));
   db.fb.loglik = db.loglik.as<double>();
+  HIP_TRY(db.dead.alloc(n_rep * sizeof(int)));
+  db.fb.dead_at = db.dead.as<int>();
   const int cap = bssm::wg_filter_capacity(MP);
   db.use_grid = !((int)nsim <= cap && (n_rep >= 32 || nsim <= 2048));
   if (const char* env = std::getenv("BSSM_AMD_FORCE_PATH")) {
@@ -458,7 +460,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       std::vector<double> phis(F);
       for (size_t f = 0; f < F; f++) { bt[f] = tabs[order[pos + f]]; phis[f] = hms[order[pos + f]].phi; }
       DeviceBatch db;
-      int rc = db.upload(bt, phis, n, m, k, N, dist, psi, need_hist, 0);
+      int rc = db.upload(bt, phis, n, m, k, N, dist, psi, need_hist, 0, false);
       if (rc) return rc;
       // Philox stream = global draw index: filters of this batch are not contiguous in draw order, so
       // launch per contiguous run when needed.  Simplest exact approach: a per-filter stream table is
@@ -471,16 +473,12 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
         bssm::FilterBatch sub = db.fb;
         sub.F = (int)(f1 - f0);
         sub.mats += db.fb.mats_fstride * f0; sub.obs += db.fb.obs_fstride * f0; sub.init += db.fb.init_fstride * f0;
-        sub.phi += f0; sub.loglik += f0;
+        sub.phi += f0; sub.loglik += f0; sub.dead_at += f0;
         if (need_hist) {
-          sub.alpha_hist += (size_t)f0 * (n + 1) * m * N; sub.indices += (size_t)f0 * n * N; sub.weights += (size_t)f0 * (n + 1) * N;
+          sub.alpha_hist += (size_t)f0 * (n + 1) * m * N; sub.indices += (size_t)f0 * n * N;
         }
         sub.seed = job->seed;
         sub.stream0 = (uint32_t)(job->first + order[pos + f0]);
-        if (need_hist && f0 == 0) {
-          HIP_TRY(hipMemsetAsync(db.hist.p, 0, db.hist.bytes, nullptr));
-          HIP_TRY(hipMemsetAsync(db.indices.p, 0, db.indices.bytes, nullptr));
-        }
         if (db.use_grid) {
           DevBuf wsb;  // workspace sized for the sub-batch
           int B, chunk;
@@ -492,6 +490,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
         } else {
           HIP_TRY(bssm::launch_wg_filter(sub, nullptr));
         }
+        HIP_TRY(bssm::launch_zero_dead_tail(sub, !db.use_grid, nullptr));
         f0 = f1;
       }
       HIP_TRY(hipMemcpy(ll.data(), db.loglik.p, F * sizeof(double), hipMemcpyDeviceToHost));

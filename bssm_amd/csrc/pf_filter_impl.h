@@ -169,7 +169,11 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
       const int i = r * NT + tid;
       if (i < N) s_cdf[i] = off + sc[r];
     }
-    if (!(S > 0.0)) { loglik = -INFINITY; break; }  // :678-682 (uniform across the block)
+    if (!(S > 0.0)) {  // :678-682 (uniform across the block)
+      loglik = -INFINITY;
+      if (tid == 0) b.dead_at[f] = t + 1;
+      break;
+    }
     loglik += M + fast_log(S / dN);                       // :683
     if (t == n) break;
     __syncthreads();  // (3) cdf visible
@@ -236,6 +240,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(b.F), dim3(nt), lds, stream, b);
   return hipGetLastError();
 }
@@ -319,7 +324,7 @@ __device__ __forceinline__ int search16_lds(const double* a, int stride, int len
   }
 
 template <int MP, int KP, int PPT, bool DBG = false>
-__global__ void __launch_bounds__(GRID_NT) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
+__global__ void __launch_bounds__(GRID_NT, 6) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   __shared__ double s_Q[GRID_NT];      // inclusive prefix of scaled block sums
   __shared__ double s_iscale[GRID_NT];  // 1 / exp(max_b - M)
   __shared__ double s_red[8];
@@ -396,7 +401,7 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_step(const FilterBatch b, con
         double* __restrict__ pn = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
         pn[2 * pb] = __builtin_nan("");
         pn[2 * pb + 1] = __builtin_nan("");
-        if (pb == 0) { atomicCAS(&ws.dead[f], 0, t + 1); ws.maxhist[(size_t)f * (n + 1) + t] = M; }
+        if (pb == 0) { atomicCAS(&b.dead_at[f], 0, t + 1); ws.maxhist[(size_t)f * (n + 1) + t] = M; }
       }
       return;
     }
@@ -525,37 +530,49 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   }
   if constexpr (MP == 4 && KP == 4) { if (ws.dbg && ppt == 1) kern = pf_grid_step<MP, KP, 1, true>; }
   hipError_t e;
-  if ((e = hipMemsetAsync(ws.dead, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.maxhist, 0, sizeof(double) * 2 * b.F * (b.n + 1), stream)) != hipSuccess) return e;  // maxhist + llinc
   const dim3 grid(ws.B, b.F), block(GRID_NT);
   if (!timing || timing->every <= 0) {
     for (int t = -1; t < b.n; t++) hipLaunchKernelGGL(kern, grid, block, 0, stream, b, ws, t);
   } else {
-    constexpr int kMaxSamples = 64;
+    // windows of kWin consecutive step launches bracketed by one event pair each: the event overhead
+    // (a few us) is amortised over the window, so total/count is the per-launch kernel cadence
+    constexpr int kMaxSamples = 64, kWin = 8;
     hipEvent_t ev[2 * kMaxSamples];
     int ns = 0;
+    const int period = timing->every > kWin ? timing->every : kWin + 1;
+    int open_t = -1;  // first launch of the window being timed, -1 = none
     for (int t = -1; t < b.n; t++) {
-      const bool sample = t >= 0 && (t % timing->every) == timing->every / 2 && ns < kMaxSamples;
-      if (sample) { (void)hipEventCreate(&ev[2 * ns]); (void)hipEventCreate(&ev[2 * ns + 1]); (void)hipEventRecord(ev[2 * ns], stream); }
+      if (open_t < 0 && t >= 0 && t % period == 0 && t + kWin <= b.n && ns < kMaxSamples) {
+        (void)hipEventCreate(&ev[2 * ns]);
+        (void)hipEventCreate(&ev[2 * ns + 1]);
+        (void)hipEventRecord(ev[2 * ns], stream);
+        open_t = t;
+      }
       hipLaunchKernelGGL(kern, grid, block, 0, stream, b, ws, t);
-      if (sample) { (void)hipEventRecord(ev[2 * ns + 1], stream); ns++; }
+      if (open_t >= 0 && t == open_t + kWin - 1) {
+        (void)hipEventRecord(ev[2 * ns + 1], stream);
+        ns++;
+        open_t = -1;
+      }
     }
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     for (int i = 0; i < ns; i++) {
       float ms = 0;
       (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
       timing->total_ms += ms;
-      timing->count++;
+      timing->count += kWin;
       (void)hipEventDestroy(ev[2 * i]);
       (void)hipEventDestroy(ev[2 * i + 1]);
     }
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  hipLaunchKernelGGL(loglik_finalize_kernel, dim3((b.F + 63) / 64), dim3(64), 0, stream, b.loglik, ws.llinc, ws.dead, b.n, b.F);
+  hipLaunchKernelGGL(loglik_finalize_kernel, dim3((b.F + 63) / 64), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);
   if (b.weights) {
     const int gx = (b.N + 255) / 256 < 64 ? (b.N + 255) / 256 : 64;
     hipLaunchKernelGGL(weights_finalize_kernel, dim3(gx, b.n + 1, b.F), dim3(256), 0, stream, b.weights, ws.maxhist,
-                       ws.dead, b.n + 1, b.N);
+                       b.dead_at, b.n + 1, b.N);
   }
   return hipGetLastError();
 }

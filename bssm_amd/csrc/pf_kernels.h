@@ -33,6 +33,7 @@ struct FilterBatch {
   uint32_t* indices;    // [f][n][N]
   double* weights;      // [f][n+1][N]      exp(w - max_t), ones where unobserved
   double* loglik;       // [f]              sum_t (max_t + log mean exp), no constants
+  int* dead_at;         // [f] 0 = alive, else (time whose weights were degenerate) + 1; zeroed by the launcher
 };
 
 // Largest N the workgroup-resident kernel can hold for a given padded state size
@@ -49,7 +50,6 @@ struct GridWorkspace {
   double* logw;        // [F][N] raw log-weights when weights output is wanted
   double* maxhist;     // [F][n+1] global max per time point (weights finalisation)
   double* llinc;       // [F][n+1] log-likelihood increment per time point (summed in time order at the end)
-  int* dead;           // [F]
   long long* dbg;      // optional [n][16] cycle stamps of block 0 / thread 0 (debug builds of the step kernel)
   int B;               // particle blocks per filter
   int chunk;           // particles per block
@@ -76,6 +76,9 @@ hipError_t launch_filter_summary(const double* hist, const double* weights, doub
 hipError_t launch_to_cube(const double* hist, double* cube, int F, int n1, int m, int N, hipStream_t stream);
 // [f][t][i] u32 -> N x n column-major is already [t][i]; weights likewise. (no kernel needed)
 
+// zero the output slots a degenerate filter never wrote (the reference hands back zero-filled buffers,
+// src/R_bootstrap_filter.cpp:136-138); a no-op for healthy filters, so outputs need no memset per run
+hipError_t launch_zero_dead_tail(const FilterBatch& b, bool weights_too, hipStream_t stream);
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream);
 
 }  // namespace bssm

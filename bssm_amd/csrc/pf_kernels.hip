@@ -52,7 +52,6 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   bytes += al((size_t)2 * b.F * B * (chunk / 16) * sizeof(double));  // coarse
   bytes += al((size_t)2 * b.F * B * 2 * sizeof(double));      // partials
   bytes += al((size_t)2 * b.F * (b.n + 1) * sizeof(double));  // maxhist + llinc (contiguous)
-  bytes += al((size_t)b.F * sizeof(int));                     // dead
   return bytes;
 }
 
@@ -68,13 +67,37 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   ws->partials = (double*)p; p += al((size_t)2 * b.F * B * 2 * sizeof(double));
   ws->maxhist = (double*)p; ws->llinc = ws->maxhist + (size_t)b.F * (b.n + 1);
   p += al((size_t)2 * b.F * (b.n + 1) * sizeof(double));
-  ws->dead = (int*)p;
   ws->logw = nullptr;
   ws->dbg = nullptr;
   ws->B = B;
   ws->chunk = chunk;
 }
 
+
+__global__ void zero_dead_tail_kernel(const FilterBatch b, const bool weights_too) {
+  const int f = blockIdx.y;
+  const int da = b.dead_at[f];
+  if (da == 0) return;
+  const int td = da - 1, n = b.n, m = b.m, N = b.N;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b.alpha_hist) {  // slots td+1 .. n were never produced
+    double* __restrict__ a = b.alpha_hist + ((size_t)f * (n + 1) + (td + 1)) * m * N;
+    for (size_t i = i0; i < (size_t)(n - td) * m * N; i += stride) a[i] = 0.0;
+  }
+  if (b.indices) {     // columns td .. n-1
+    uint32_t* __restrict__ x = b.indices + ((size_t)f * n + td) * N;
+    for (size_t i = i0; i < (size_t)(n - td) * N; i += stride) x[i] = 0u;
+  }
+  if (weights_too && b.weights) {  // columns td+1 .. n
+    double* __restrict__ w = b.weights + ((size_t)f * (n + 1) + (td + 1)) * N;
+    for (size_t i = i0; i < (size_t)(n - td) * N; i += stride) w[i] = 0.0;
+  }
+}
+hipError_t launch_zero_dead_tail(const FilterBatch& b, bool weights_too, hipStream_t stream) {
+  if (!b.alpha_hist && !b.indices && !b.weights) return hipSuccess;
+  hipLaunchKernelGGL(zero_dead_tail_kernel, dim3(256, b.F), dim3(256), 0, stream, b, weights_too);
+  return hipGetLastError();
+}
 
 // test hook: evaluate the kernels' elementary functions on an array (see tests/test_gpu_math.py)
 __global__ void debug_math_kernel(int fn, const double* __restrict__ in, double* __restrict__ out, int n) {
