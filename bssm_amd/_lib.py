@@ -22,7 +22,8 @@ class UngModel(C.Structure):
                                           "n_xreg", "max_iter", "local_approx")] + \
                [("conv_tol", C.c_double), ("phi", C.c_double)] + \
                [(k, c_double_p) for k in ("y", "Z", "T", "R", "a1", "P1", "D", "C", "xreg", "beta", "u", "H",
-                                          "initial_mode")]
+                                          "initial_mode")] + \
+               [("p", C.c_int32), ("distribution_p", C.POINTER(C.c_int32)), ("phi_p", c_double_p)]
 
 
 class FilterOut(C.Structure):
@@ -94,4 +95,11 @@ def pack_model(arr: dict):
             a = np.asfortranarray(a, dtype=np.float64)
             keep.append(a)
         setattr(s, k, dptr(a))
+    s.p = int(arr.get("p", 1))
+    if s.p > 1:
+        dp = np.ascontiguousarray(arr["distribution_p"], dtype=np.int32)
+        pp = np.ascontiguousarray(arr["phi_p"], dtype=np.float64)
+        keep += [dp, pp]
+        s.distribution_p = dp.ctypes.data_as(C.POINTER(C.c_int32))
+        s.phi_p = dptr(pp)
     return s, keep

@@ -72,17 +72,17 @@ void parallel_for(int count, int threads, F fn) {
 // ------------------------------------------------------------------ a batch of filters on the device
 struct DeviceBatch {
   bssm::FilterBatch fb{};
-  DevBuf mats, obs, init, phi, hist, indices, weights, loglik, dead, ws;
+  DevBuf mats, obs, init, hist, indices, weights, loglik, dead, ws;
   bssm::GridWorkspace gws{};
   bool use_grid = false;
   std::vector<double> const_terms;  // per filter, added to the device log-likelihood on the host
 
   // tables: one per filter (all with the same MP/KP/mats_tstride)
-  int upload(const std::vector<bssm::FilterTables>& tabs, const std::vector<double>& phis, int n, int m, int k, int N,
-             int dist, int psi, bool keep_hist, unsigned path_flags, bool keep_weights = true) {
+  int upload(const std::vector<bssm::FilterTables>& tabs, int n, int m, int k, int p, int N, int psi, bool keep_hist,
+             unsigned path_flags, bool keep_weights = true) {
     const int F = (int)tabs.size();
     const int MP = tabs[0].MP, KP = tabs[0].KP;
-    fb.n = n; fb.m = m; fb.k = k; fb.MP = MP; fb.KP = KP; fb.N = N; fb.F = F; fb.dist = dist; fb.psi = psi;
+    fb.n = n; fb.m = m; fb.k = k; fb.p = p; fb.MP = MP; fb.KP = KP; fb.N = N; fb.F = F; fb.psi = psi;
     const size_t ms = tabs[0].mats.size(), os = tabs[0].obs.size(), is = tabs[0].init.size();
     std::vector<double> hm(ms * F), ho(os * F), hi(is * F);
     for (int f = 0; f < F; f++) {
@@ -94,15 +94,12 @@ struct DeviceBatch {
     HIP_TRY(mats.alloc(hm.size() * sizeof(double)));
     HIP_TRY(obs.alloc(ho.size() * sizeof(double)));
     HIP_TRY(init.alloc(hi.size() * sizeof(double)));
-    HIP_TRY(phi.alloc(F * sizeof(double)));
     HIP_TRY(hipMemcpy(mats.p, hm.data(), mats.bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(obs.p, ho.data(), obs.bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(init.p, hi.data(), init.bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(phi.p, phis.data(), phi.bytes, hipMemcpyHostToDevice));
     fb.mats = mats.as<double>(); fb.mats_fstride = ms; fb.mats_tstride = tabs[0].mats_tstride;
     fb.obs = obs.as<double>(); fb.obs_fstride = os;
     fb.init = init.as<double>(); fb.init_fstride = is;
-    fb.phi = phi.as<double>();
     HIP_TRY(loglik.alloc(F * sizeof(double)));
     fb.loglik = loglik.as<double>();
     HIP_TRY(dead.alloc(F * sizeof(int)));
@@ -171,7 +168,7 @@ struct DeviceBatch {
 
 bool is_gaussian_type_ok(int gaussian, int model_type) {
   if (gaussian) return model_type >= 1 && model_type <= 3;  // ssm_ulg, bsm_lg, ar1_lg (R/model_type.R:2-8)
-  return model_type >= 1 && model_type <= 4;                // ssm_ung, bsm_ng, svm, ar1_ng
+  return model_type >= 0 && model_type <= 4;                // ssm_mng, ssm_ung, bsm_ng, svm, ar1_ng
 }
 
 void transpose_to(const std::vector<double>& src, int rows, int cols, double* dst) {  // src rows x cols col-major -> cols x rows
@@ -204,7 +201,7 @@ int run_single_filter(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
     base_ll = bssm::const_term(hm);  // src/model_ssm_ung.cpp:690-710
   }
   DeviceBatch db;
-  int rc = db.upload(tabs, {hm.phi}, n, m, hm.k, N, hm.distribution, psi ? 1 : 0, true, 0);
+  int rc = db.upload(tabs, n, m, hm.k, hm.p, N, psi ? 1 : 0, true, 0);
   if (rc) return rc;
   hipStream_t st = nullptr;
   if ((rc = db.run(seed, 0, st))) return rc;
@@ -341,14 +338,10 @@ int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, ui
   }
   // replicas share one table: stride 0 between filters
   DeviceBatch db;
-  int rc = db.upload(tabs, {hm.phi}, hm.n, hm.m, hm.k, (int)nsim, hm.distribution, psi, false, 0);
+  int rc = db.upload(tabs, hm.n, hm.m, hm.k, hm.p, (int)nsim, psi, false, 0);
   if (rc) return rc;
   db.fb.F = (int)n_rep;
   db.fb.mats_fstride = 0; db.fb.obs_fstride = 0; db.fb.init_fstride = 0;
-  std::vector<double> phis(n_rep, hm.phi);
-  HIP_TRY(db.phi.alloc(n_rep * sizeof(double)));
-  HIP_TRY(hipMemcpy(db.phi.p, phis.data(), db.phi.bytes, hipMemcpyHostToDevice));
-  db.fb.phi = db.phi.as<double>();
   HIP_TRY(db.loglik.alloc(n_rep * sizeof(double)));
   db.fb.loglik = db.loglik.as<double>();
   HIP_TRY(db.dead.alloc(n_rep * sizeof(int)));
@@ -416,10 +409,10 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   parallel_for(cnt, job->n_threads, [&](int i) {
     errs[i] = bssm::ingest_model(&job->models[i], false, &hms[i]);
     if (!errs[i].empty()) return;
-    if (hms[i].n != n || hms[i].m != m || hms[i].k != k) { errs[i] = "all draws must share n, m, k"; return; }
+    if (hms[i].n != n || hms[i].m != m || hms[i].k != k || hms[i].p != (job->models[0].p > 1 ? job->models[0].p : 1)) { errs[i] = "all draws must share n, m, k, p"; return; }
     if (psi) {
       bssm::PsiSetup su;
-      if (!bssm::psi_setup(hms[i], job->modes + (size_t)n * i, &su)) bad[i] = 1;
+      if (!bssm::psi_setup(hms[i], job->modes + (size_t)n * hms[i].p * i, &su)) bad[i] = 1;
       bssm::build_psi_tables(hms[i], su, MP, &tabs[i]);
     } else {
       bssm::build_bsf_tables(hms[i], MP, KP, &tabs[i]);
@@ -437,7 +430,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       t.mats_tstride = ts;
     }
   }
-  const int dist = hms[0].distribution;
+  const int pp = hms[0].p;
   const bool need_hist = job->output_type != 3;
 
   // group draws by particle count (is1 multiplies nsim by count_i, src/approx_mcmc.cpp:376-378)
@@ -457,10 +450,9 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
     while (pos < end) {
       const size_t F = std::min(maxF, end - pos);
       std::vector<bssm::FilterTables> bt(F);
-      std::vector<double> phis(F);
-      for (size_t f = 0; f < F; f++) { bt[f] = tabs[order[pos + f]]; phis[f] = hms[order[pos + f]].phi; }
+      for (size_t f = 0; f < F; f++) bt[f] = tabs[order[pos + f]];
       DeviceBatch db;
-      int rc = db.upload(bt, phis, n, m, k, N, dist, psi, need_hist, 0, false);
+      int rc = db.upload(bt, n, m, k, pp, N, psi, need_hist, 0, false);
       if (rc) return rc;
       // Philox stream = global draw index: filters of this batch are not contiguous in draw order, so
       // launch per contiguous run when needed.  Simplest exact approach: a per-filter stream table is
@@ -473,7 +465,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
         bssm::FilterBatch sub = db.fb;
         sub.F = (int)(f1 - f0);
         sub.mats += db.fb.mats_fstride * f0; sub.obs += db.fb.obs_fstride * f0; sub.init += db.fb.init_fstride * f0;
-        sub.phi += f0; sub.loglik += f0; sub.dead_at += f0;
+        sub.loglik += f0; sub.dead_at += f0;
         if (need_hist) {
           sub.alpha_hist += (size_t)f0 * (n + 1) * m * N; sub.indices += (size_t)f0 * n * N;
         }
@@ -578,14 +570,14 @@ bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int3
   if (!have_device()) { no_device(); return nullptr; }
   const bool psi = sampling_method == BSSM_PSI;
   std::vector<bssm::FilterTables> tabs;
-  std::vector<double> phis, consts;
-  int n = 0, m = 0, k = 0, dist = 0;
+  std::vector<double> consts;
+  int n = 0, m = 0, k = 0, pp = 1;
   for (int i = 0; i < n_models; i++) {
     bssm::HostModel hm;
     const std::string err = bssm::ingest_model(&models[i], psi, &hm);
     if (!err.empty()) { fail(BSSM_ERR_INVALID, err); return nullptr; }
-    if (i == 0) { n = hm.n; m = hm.m; k = hm.k; dist = hm.distribution; }
-    else if (hm.n != n || hm.m != m || hm.k != k || hm.distribution != dist) { fail(BSSM_ERR_INVALID, "models of a plan must share n, m, k, distribution"); return nullptr; }
+    if (i == 0) { n = hm.n; m = hm.m; k = hm.k; pp = hm.p; }
+    else if (hm.n != n || hm.m != m || hm.k != k || hm.p != pp) { fail(BSSM_ERR_INVALID, "models of a plan must share n, m, k, p"); return nullptr; }
     bssm::FilterTables ft;
     double base;
     const int MP = bssm::pad_dim(m);
@@ -598,12 +590,12 @@ bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int3
       bssm::build_bsf_tables(hm, MP, bssm::pad_dim(k), &ft);
       base = bssm::const_term(hm);
     }
-    for (int r = 0; r < n_rep; r++) { tabs.push_back(ft); phis.push_back(hm.phi); consts.push_back(base); }
+    for (int r = 0; r < n_rep; r++) { tabs.push_back(ft); consts.push_back(base); }
   }
   std::unique_ptr<bssm_plan> p(new bssm_plan);
   p->n_models = n_models; p->n_rep = n_rep; p->psi = psi;
   const bool keep = flags & BSSM_PLAN_KEEP_HISTORY;
-  if (p->db.upload(tabs, phis, n, m, k, (int)nsim, dist, psi, keep, flags) != BSSM_OK) return nullptr;
+  if (p->db.upload(tabs, n, m, k, pp, (int)nsim, psi, keep, flags) != BSSM_OK) return nullptr;
   p->db.const_terms = consts;
   // full-output filter 16m + 24 bytes per particle-step; log-likelihood only 16m + 16
   p->bytes_per_pstep = keep ? 16.0 * m + 24.0 : 16.0 * m + 16.0;

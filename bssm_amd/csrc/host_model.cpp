@@ -103,57 +103,104 @@ double lchoose_ts(double nn, double kk) {  // src/distr_consts.cpp:7-9
 }
 double norm_log_const(double sd) { return -0.5 * std::log(2.0 * kPi) - std::log(sd); }
 
-// views into a HostModel at time t
+// views into a HostModel at time t (observation arrays are p-major: Z is p x m)
 struct Sys {
   const HostModel& h;
   explicit Sys(const HostModel& hm) : h(hm) {}
-  Mat Zc(int t) const { return Mat(h.m, 1, h.Z.data() + (size_t)h.m * (t * h.Ztv)); }
+  Mat Zm(int t) const { return Mat(h.p, h.m, h.Z.data() + (size_t)h.p * h.m * (t * h.Ztv)); }
   Mat Tm(int t) const { return Mat(h.m, h.m, h.T.data() + (size_t)h.m * h.m * (t * h.Ttv)); }
   Mat Rm(int t) const { return Mat(h.m, h.k, h.R.data() + (size_t)h.m * h.k * (t * h.Rtv)); }
   Mat Cc(int t) const { return Mat(h.m, 1, h.C.data() + (size_t)h.m * (t * h.Ctv)); }
-  double Dv(int t) const { return h.D[t * h.Dtv]; }
+  double Dv(int j, int t) const { return h.D[j + (size_t)h.p * (t * h.Dtv)]; }
 };
 
 // ------------------------------------------------------------------ Kalman machinery of the approximating model
-struct Approx {  // pseudo-observations of the Gaussian approximation
-  std::vector<double> y, H;  // n each (H = sd)
+struct Approx {  // pseudo-observations of the Gaussian approximation, p x n (H = diagonal sd)
+  std::vector<double> y, H;
 };
 
-struct KfStep { double F = 0, v = 0; bool obs = false; Mat K; };
+// one prediction step.  Univariate: src/model_ssm_ulg.cpp:122-136 / :268-283; multivariate with missing
+// series zeroed out of Z and given unit variance: src/model_ssm_mlg.cpp:259-291, 318-356.
+struct KfStep {
+  int nobs = 0;       // observed series at t (0 = pure prediction)
+  bool ok = true;     // F finite and positive definite
+  double logdetF = 0, quad = 0;  // log|F|, v' F^-1 v over the observed series
+  double Fs = 0;                 // the scalar F when p == 1
+  Mat v, ZF, K, Zz;   // innovations (p), Z' F^-1 (m x p), gain (m x p), Z with missing rows zeroed (p x m)
+};
 
-// prediction step; joseph = numerically better covariance form (src/model_ssm_ulg.cpp:276-277)
 KfStep kf_predict(const Sys& S, const Approx& ap, int t, const Mat& at, const Mat& Pt, bool joseph, Mat* at1, Mat* Pt1) {
-  const int m = S.h.m;
-  const Mat Z = S.Zc(t), T = S.Tm(t), R = S.Rm(t);
+  const HostModel& h = S.h;
+  const int m = h.m, p = h.p;
+  const Mat T = S.Tm(t), R = S.Rm(t);
   const Mat RR = R * tr(R);
-  const double HH = ap.H[t] * ap.H[t];
   KfStep st;
-  st.K = Mat(m, 1);
-  st.F = (tr(Z) * Pt * Z)(0, 0) + HH;
-  const double ytmp = ap.y[t] - S.h.xbeta[t];
-  if (std::isfinite(ytmp) && st.F > kZeroTol) {
-    st.obs = true;
-    st.v = ytmp - S.Dv(t) - (tr(Z) * at)(0, 0);
-    const Mat PZ = Pt * Z;
-    for (int i = 0; i < m; i++) st.K(i, 0) = PZ(i, 0) / st.F;
-    *at1 = S.Cc(t) + T * (at + st.K * st.v);
-    Mat inner;
-    if (joseph) {
-      const Mat IKZ = Mat::eye(m) - st.K * tr(Z);
-      inner = IKZ * Pt * tr(IKZ) + (st.K * HH) * tr(st.K);
-    } else {
-      inner = Pt - (st.K * tr(st.K)) * st.F;
-    }
-    *Pt1 = T * inner * tr(T) + RR;
-  } else {
+  st.v = Mat(p, 1); st.ZF = Mat(m, p); st.K = Mat(m, p); st.Zz = S.Zm(t);
+  Mat HH(p, p);
+  std::vector<char> na(p);
+  for (int j = 0; j < p; j++) {
+    const double yt = ap.y[j + (size_t)p * t] - (p == 1 ? h.xbeta[t] : 0.0);
+    na[j] = !std::isfinite(yt);
+    if (na[j]) { for (int c = 0; c < m; c++) st.Zz(j, c) = 0.0; HH(j, j) = 1.0; }
+    else { HH(j, j) = ap.H[j + (size_t)p * t] * ap.H[j + (size_t)p * t]; st.nobs++; }
+  }
+  Mat F = st.Zz * Pt * tr(st.Zz) + HH;
+  if (p == 1 && st.nobs == 1 && !(F(0, 0) > kZeroTol)) st.nobs = 0;  // univariate guard F > zero_tol (:123)
+  if (st.nobs == 0) {
     *at1 = S.Cc(t) + T * at;
     *Pt1 = T * Pt * tr(T) + RR;
+    symmatu(*Pt1);
+    return st;
   }
+  if (p == 1) {  // scalar form of src/model_ssm_ulg.cpp:124-127: K = P Z / F, no factorisation
+    const double Fs = F(0, 0);
+    st.Fs = Fs;
+    double za = 0;
+    for (int c = 0; c < m; c++) za += st.Zz(0, c) * at(c, 0);
+    st.v(0, 0) = ap.y[t] - h.xbeta[t] - S.Dv(0, t) - za;
+    const Mat PZ = Pt * tr(st.Zz);
+    for (int i = 0; i < m; i++) { st.K(i, 0) = PZ(i, 0) / Fs; st.ZF(i, 0) = st.Zz(0, i) / Fs; }
+    st.logdetF = std::log(Fs);
+    st.quad = st.v(0, 0) * st.v(0, 0) / Fs;
+  } else {
+    for (double f : F.a) if (!std::isfinite(f)) { st.ok = false; return st; }
+    for (int j = 0; j < p; j++) if (!(F(j, j) > 0)) { st.ok = false; return st; }
+    std::vector<int> all(p);
+    for (int j = 0; j < p; j++) all[j] = j;
+    Mat L;
+    if (!chol_lower_on(F, all, &L)) { st.ok = false; return st; }
+    Mat Li(p, p);  // inverse of the lower factor
+    for (int j = 0; j < p; j++) {
+      Li(j, j) = 1.0 / L(j, j);
+      for (int i = j + 1; i < p; i++) { double sacc = 0; for (int q = j; q < i; q++) sacc += L(i, q) * Li(q, j); Li(i, j) = -sacc / L(i, i); }
+    }
+    const Mat Fi = tr(Li) * Li;
+    for (int j = 0; j < p; j++) {
+      st.logdetF += 2.0 * std::log(L(j, j));
+      if (na[j]) continue;
+      double za = 0;
+      for (int c = 0; c < m; c++) za += st.Zz(j, c) * at(c, 0);
+      st.v(j, 0) = ap.y[j + (size_t)p * t] - S.Dv(j, t) - za;
+    }
+    const Mat w = Li * st.v;
+    for (int j = 0; j < p; j++) st.quad += w(j, 0) * w(j, 0);
+    st.ZF = tr(st.Zz) * Fi;
+    st.K = Pt * st.ZF;
+  }
+  *at1 = S.Cc(t) + T * (at + st.K * st.v);
+  Mat inner;
+  if (joseph) {
+    const Mat IKZ = Mat::eye(m) - st.K * st.Zz;
+    inner = IKZ * Pt * tr(IKZ) + st.K * HH * tr(st.K);
+  } else {  // univariate log_likelihood() uses P - K K' F (src/model_ssm_ulg.cpp:129)
+    inner = Pt - (st.K * F) * tr(st.K);
+  }
+  *Pt1 = T * inner * tr(T) + RR;
   symmatu(*Pt1);
   return st;
 }
 
-// src/model_ssm_ulg.cpp:106-138
+// src/model_ssm_ulg.cpp:106-138, src/model_ssm_mlg.cpp:90-137
 double gaussian_loglik(const Sys& S, const Approx& ap) {
   const HostModel& h = S.h;
   double accH = 0, accR = 0;
@@ -164,52 +211,50 @@ double gaussian_loglik(const Sys& S, const Approx& ap) {
   const double LOG2PI = std::log(2.0 * kPi);
   double ll = 0.0;
   for (int t = 0; t < h.n; t++) {
-    const KfStep st = kf_predict(S, ap, t, at, Pt, false, &at1, &Pt1);
-    if (st.obs) ll -= 0.5 * (LOG2PI + std::log(st.F) + st.v * st.v / st.F);
+    const KfStep st = kf_predict(S, ap, t, at, Pt, h.p > 1, &at1, &Pt1);
+    if (!st.ok) return -INFINITY;
+    if (st.nobs > 0) ll -= 0.5 * (st.nobs * LOG2PI + st.logdetF + st.quad);
     at = at1; Pt = Pt1;
   }
   return ll;
 }
 
-// src/model_ssm_ulg.cpp:252-305 -> smoothed state means, m x (n+1)
-std::vector<Mat> fast_smoother(const Sys& S, const Approx& ap) {
+// src/model_ssm_ulg.cpp:252-305, src/model_ssm_mlg.cpp fast_smoother -> smoothed state means, m x (n+1)
+bool fast_smoother(const Sys& S, const Approx& ap, std::vector<Mat>* atp) {
   const HostModel& h = S.h;
   const int n = h.n, m = h.m;
-  std::vector<Mat> at(n + 1);
+  std::vector<Mat>& at = *atp;
+  at.assign(n + 1, Mat(m, 1));
   std::vector<KfStep> st(n);
   at[0] = Mat(m, 1, h.a1.data());
   Mat Pt(m, m, h.P1.data()), Pt1;
-  for (int t = 0; t < n; t++) { st[t] = kf_predict(S, ap, t, at[t], Pt, true, &at[t + 1], &Pt1); Pt = Pt1; }
+  for (int t = 0; t < n; t++) {
+    st[t] = kf_predict(S, ap, t, at[t], Pt, true, &at[t + 1], &Pt1);
+    if (!st[t].ok) return false;
+    Pt = Pt1;
+  }
   std::vector<Mat> rt(n, Mat(m, 1));
-  for (int t = n - 1; t > 0; t--) {
-    if (st[t].obs) {
-      const Mat Z = S.Zc(t);
-      const Mat L = S.Tm(t) * (Mat::eye(m) - st[t].K * tr(Z));
-      const Mat Lr = tr(L) * rt[t];
-      for (int i = 0; i < m; i++) rt[t - 1](i, 0) = Z(i, 0) / st[t].F * st[t].v + Lr(i, 0);
+  Mat rprev(m, 1);
+  for (int t = n - 1; t >= 0; t--) {
+    Mat r0;
+    if (st[t].nobs > 0) {
+      const Mat L = S.Tm(t) * (Mat::eye(m) - st[t].K * st[t].Zz);
+      r0 = st[t].ZF * st[t].v + tr(L) * rt[t];
     } else {
-      rt[t - 1] = tr(S.Tm(t)) * rt[t];
+      r0 = tr(S.Tm(t)) * rt[t];
     }
+    if (t > 0) rt[t - 1] = r0; else rprev = r0;
   }
-  const Mat a1(m, 1, h.a1.data()), P1(m, m, h.P1.data());
-  if (std::isfinite(h.y[0]) && st[0].F > kZeroTol) {  // :292 tests the ORIGINAL y(0)
-    const Mat Z = S.Zc(0);
-    const Mat L = S.Tm(0) * (Mat::eye(m) - st[0].K * tr(Z));
-    Mat tmp = tr(L) * rt[0];
-    for (int i = 0; i < m; i++) tmp(i, 0) = Z(i, 0) / st[0].F * st[0].v + tmp(i, 0);
-    at[0] = a1 + P1 * tmp;
-  } else {
-    at[0] = a1 + P1 * (tr(S.Tm(0)) * rt[0]);
-  }
+  at[0] = Mat(m, 1, h.a1.data()) + Mat(m, m, h.P1.data()) * rprev;
   for (int t = 0; t < n - 1; t++) {
     const Mat R = S.Rm(t);
     at[t + 1] = S.Cc(t) + S.Tm(t) * at[t] + (R * tr(R)) * rt[t];
   }
-  return at;
+  return true;
 }
 
-// src/model_ssm_ulg.cpp:419-473
-void smoother_ccov(const Sys& S, const Approx& ap, std::vector<Mat>* at, std::vector<Mat>* Pt, std::vector<Mat>* cc) {
+// src/model_ssm_ulg.cpp:419-473, src/model_ssm_mlg.cpp:310-396
+bool smoother_ccov(const Sys& S, const Approx& ap, std::vector<Mat>* at, std::vector<Mat>* Pt, std::vector<Mat>* cc) {
   const HostModel& h = S.h;
   const int n = h.n, m = h.m;
   at->assign(n + 1, Mat(m, 1));
@@ -220,21 +265,23 @@ void smoother_ccov(const Sys& S, const Approx& ap, std::vector<Mat>* at, std::ve
   (*Pt)[0] = Mat(m, m, h.P1.data());
   for (int t = 0; t < n; t++) {
     st[t] = kf_predict(S, ap, t, (*at)[t], (*Pt)[t], true, &(*at)[t + 1], &(*Pt)[t + 1]);
+    if (!st[t].ok) return false;
     (*cc)[t] = (*Pt)[t + 1];
   }
   Mat rt(m, 1), Nt(m, m);
   const Mat I = Mat::eye(m);
   for (int t = n - 1; t >= 0; t--) {
     const Mat T = S.Tm(t);
-    if (st[t].obs) {
-      const Mat Z = S.Zc(t);
-      const Mat L = T * (I - st[t].K * tr(Z));
+    if (st[t].nobs > 0) {
+      const Mat L = T * (I - st[t].K * st[t].Zz);
       (*cc)[t] = (*Pt)[t] * tr(L) * (I - Nt * (*cc)[t]);
-      Mat r2 = tr(L) * rt;
-      for (int i = 0; i < m; i++) r2(i, 0) = Z(i, 0) / st[t].F * st[t].v + r2(i, 0);
-      rt = r2;
+      rt = st[t].ZF * st[t].v + tr(L) * rt;
       Mat N2 = tr(L) * Nt * L;
-      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) N2(i, j) = Z(i, 0) * Z(j, 0) / st[t].F + N2(i, j);
+      if (h.p == 1) {  // Z Z' / F in the reference's operation order (src/model_ssm_ulg.cpp:462)
+        for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) N2(i, j) = st[t].Zz(0, i) * st[t].Zz(0, j) / st[t].Fs + N2(i, j);
+      } else {
+        N2 = st[t].ZF * st[t].Zz + N2;
+      }
       Nt = N2;
     } else {
       (*cc)[t] = (*Pt)[t] * tr(T) * (I - Nt * (*cc)[t]);
@@ -248,6 +295,7 @@ void smoother_ccov(const Sys& S, const Approx& ap, std::vector<Mat>* at, std::ve
     (*Pt)[t] = (*Pt)[t] - dP;
   }
   (*cc)[n] = Mat(m, m);
+  return true;
 }
 
 // src/conditional_dist.cpp:4-31 (use_svd = true)
@@ -272,80 +320,98 @@ void conditional_cov(std::vector<Mat>* Vt, std::vector<Mat>* Ct) {
   for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) (*Vt)[0](i, c) = U(i, c) * std::sqrt(s[c]);
 }
 
-// src/model_ssm_ung.cpp:302-342
+// src/model_ssm_ung.cpp:302-342, src/model_ssm_mng.cpp:269-315
 void laplace_iter(const HostModel& h, const std::vector<double>& signal, Approx* ap) {
-  const double phi = h.phi;
-  for (int t = 0; t < h.n; t++) {
-    const double y = h.y[t], sg = signal[t];
-    double HH = 0, yy = 0;
-    switch (h.distribution) {
-      case BSSM_SVM: {
-        double tmp = y;
-        if (std::fabs(tmp) < 1e-4) tmp = 1e-4;
-        HH = 2.0 * std::exp(sg) / ((tmp / phi) * (tmp / phi));
-        yy = sg + 1.0 - 0.5 * HH;
-      } break;
-      case BSSM_POISSON: HH = 1.0 / (std::exp(sg) * h.u[t]); yy = y * HH + sg - 1.0; break;
-      case BSSM_BINOMIAL: { const double e = std::exp(sg); HH = (1.0 + e) * (1.0 + e) / (h.u[t] * e); yy = y * HH + sg - 1.0 - e; } break;
-      case BSSM_NEGBIN: { const double e = std::exp(sg) * h.u[t]; HH = (phi + e) * (phi + e) / (phi * e * (y + phi)); yy = sg + (phi + e) * (y - e) / ((y + phi) * e); } break;
-      case BSSM_GAMMA: { const double e = std::exp(sg) * h.u[t]; HH = e / (y * phi); yy = sg - e / y + 1; } break;
-      default: break;
+  const int p = h.p;
+  for (int t = 0; t < h.n; t++)
+    for (int j = 0; j < p; j++) {
+      const size_t q = j + (size_t)p * t;
+      const double y = h.y[q], sg = signal[q], u = h.u[q], phi = h.phis[j];
+      double HH = 0, yy = 0;
+      switch (h.dist[j]) {
+        case BSSM_SVM: {
+          double tmp = y;
+          if (std::fabs(tmp) < 1e-4) tmp = 1e-4;
+          HH = 2.0 * std::exp(sg) / ((tmp / phi) * (tmp / phi));
+          yy = sg + 1.0 - 0.5 * HH;
+        } break;
+        case BSSM_POISSON: HH = 1.0 / (std::exp(sg) * u); yy = y * HH + sg - 1.0; break;
+        case BSSM_BINOMIAL: { const double e = std::exp(sg); HH = (1.0 + e) * (1.0 + e) / (u * e); yy = y * HH + sg - 1.0 - e; } break;
+        case BSSM_NEGBIN: { const double e = std::exp(sg) * u; HH = (phi + e) * (phi + e) / (phi * e * (y + phi)); yy = sg + (phi + e) * (y - e) / ((y + phi) * e); } break;
+        case BSSM_GAMMA: { const double e = std::exp(sg) * u; HH = e / (y * phi); yy = sg - e / y + 1; } break;
+        case BSSM_GAUSSIAN: HH = phi * phi; yy = y; break;  // mng only (src/model_ssm_mng.cpp:307-311)
+        default: break;
+      }
+      ap->y[q] = yy;
+      ap->H[q] = std::sqrt(HH);
     }
-    ap->y[t] = yy;
-    ap->H[t] = std::sqrt(HH);
-  }
 }
 
-// src/model_ssm_ung.cpp:241-292
+// src/model_ssm_ung.cpp:241-292, src/model_ssm_mng.cpp:218-255
 void update_scales(const HostModel& h, const Approx& ap, const std::vector<double>& mode, std::vector<double>* scales) {
-  const double phi = h.phi;
+  const int p = h.p;
   scales->assign(h.n, 0.0);
-  for (int t = 0; t < h.n; t++) {
-    const double y = h.y[t];
-    if (!std::isfinite(y)) continue;
-    const double md = mode[t];
-    const double g = 0.5 * std::pow((ap.y[t] - md) / ap.H[t], 2.0);
-    double v = 0;
-    switch (h.distribution) {
-      case BSSM_SVM: v = -0.5 * (md + std::pow(y / phi, 2.0) * std::exp(-md)); break;
-      case BSSM_POISSON: v = y * md - h.u[t] * std::exp(md); break;
-      case BSSM_BINOMIAL: v = y * md - h.u[t] * std::log1p(std::exp(md)); break;
-      case BSSM_NEGBIN: v = y * md - (y + phi) * std::log(phi + h.u[t] * std::exp(md)); break;
-      case BSSM_GAMMA: v = -phi * (md + (y * std::exp(-md) / h.u[t])); break;
-      default: break;
+  for (int t = 0; t < h.n; t++)
+    for (int j = 0; j < p; j++) {
+      const size_t q = j + (size_t)p * t;
+      const double y = h.y[q];
+      if (!std::isfinite(y)) continue;
+      const double md = mode[q], u = h.u[q], phi = h.phis[j];
+      double v = 0;
+      switch (h.dist[j]) {
+        case BSSM_SVM: v = -0.5 * (md + std::pow(y / phi, 2.0) * std::exp(-md)); break;
+        case BSSM_POISSON: v = y * md - u * std::exp(md); break;
+        case BSSM_BINOMIAL: v = y * md - u * std::log1p(std::exp(md)); break;
+        case BSSM_NEGBIN: v = y * md - (y + phi) * std::log(phi + u * std::exp(md)); break;
+        case BSSM_GAMMA: v = p == 1 ? -phi * (md + (y * std::exp(-md) / u)) : -phi * md - (y * phi * std::exp(-md) / u); break;
+        case BSSM_GAUSSIAN: v = -0.5 * std::pow((y - md) / phi, 2.0); break;
+        default: break;
+      }
+      (*scales)[t] += v + 0.5 * std::pow((ap.y[q] - md) / ap.H[q], 2.0);
     }
-    (*scales)[t] = v + g;
+}
+
+// signal mode from smoothed states: src/model_ssm_ung.cpp:124-131, src/model_ssm_mng.cpp:101-105
+void signal_from_states(const HostModel& h, const Sys& S, const std::vector<Mat>& sm, std::vector<double>* out) {
+  const int p = h.p, m = h.m;
+  out->resize((size_t)p * h.n);
+  for (int t = 0; t < h.n; t++) {
+    if (p == 1 && h.dist[0] == BSSM_SVM) { (*out)[t] = sm[t](0, 0); continue; }
+    const Mat Z = S.Zm(t);
+    for (int j = 0; j < p; j++) {
+      double za = 0;
+      for (int c = 0; c < m; c++) za += Z(j, c) * sm[t](c, 0);
+      (*out)[j + (size_t)p * t] = (p == 1 ? h.xbeta[t] : 0.0) + S.Dv(j, t) + za;
+    }
   }
 }
 
-// approximate(): src/model_ssm_ung.cpp:87-140 (first call, approx_state == -1)
-int run_laplace(const HostModel& h, const Sys& S, Approx* ap, std::vector<double>* mode) {
+// approximate(): src/model_ssm_ung.cpp:87-140, src/model_ssm_mng.cpp:73-114 (first call, approx_state == -1)
+int run_laplace(const HostModel& h, const Sys& S, Approx* ap, std::vector<double>* mode, bool* ok) {
   *mode = h.initial_mode;
   int it = 0;
   double diff = h.conv_tol + 1;
-  std::vector<double> nm(h.n);
+  std::vector<double> nm;
+  std::vector<Mat> sm;
+  *ok = true;
   while (it < h.max_iter && diff > h.conv_tol) {
     it++;
     laplace_iter(h, *mode, ap);
-    const std::vector<Mat> sm = fast_smoother(S, *ap);
-    for (int t = 0; t < h.n; t++) {
-      if (h.distribution == BSSM_SVM) nm[t] = sm[t](0, 0);
-      else nm[t] = h.xbeta[t] + S.Dv(t) + (tr(S.Zc(t)) * sm[t])(0, 0);
-    }
+    if (!fast_smoother(S, *ap, &sm)) { *ok = false; break; }
+    signal_from_states(h, S, sm, &nm);
     diff = 0.0;
-    for (int t = 0; t < h.n; t++) diff += (nm[t] - (*mode)[t]) * (nm[t] - (*mode)[t]);
-    diff /= h.n;
+    for (size_t q = 0; q < nm.size(); q++) diff += (nm[q] - (*mode)[q]) * (nm[q] - (*mode)[q]);
+    diff /= (double)h.n * h.p;
     *mode = nm;
   }
   return it;
 }
 
-double approx_const_term(const HostModel& h, const Approx& ap) {  // src/model_ssm_ung.cpp:347-370
+double approx_const_term(const HostModel& h, const Approx& ap) {  // src/model_ssm_ung.cpp:347-370, model_ssm_mng.cpp:318-355
   double c = const_term(h);
-  int nf = 0;
-  double sl = 0;
-  for (int t = 0; t < h.n; t++) if (std::isfinite(h.y[t])) { nf++; sl += std::log(ap.H[t]); }
-  return c - (-0.5 * nf * std::log(2 * kPi) - sl);
+  for (size_t q = 0; q < h.y.size(); q++)
+    if (std::isfinite(h.y[q])) c -= norm_log_const(ap.H[q]);
+  return c;
 }
 
 }  // namespace
@@ -358,27 +424,42 @@ std::string ingest_model(const bssm_ung_model* s, bool need_mode, HostModel* o) 
   if (s->n < 1 || s->m < 1 || s->k < 1) return "n, m, k must be positive";
   if (s->m > 16) return "state dimension m > 16 is not supported by the kernels";
   if (s->k > s->m) return "k (columns of R) must not exceed m";
-  if (s->distribution < 0 || s->distribution > 5) return "unknown distribution code";
   if (!s->y || !s->Z || !s->T || !s->R || !s->a1 || !s->P1) return "y, Z, T, R, a1, P1 must be non-NULL";
-  const int n = s->n, m = s->m, k = s->k;
-  o->n = n; o->m = m; o->k = k;
+  const int n = s->n, m = s->m, k = s->k, p = s->p > 1 ? s->p : 1;
+  if (p > 8) return "more than 8 observation series is not supported";
+  o->n = n; o->m = m; o->k = k; o->p = p;
   o->Ztv = s->Ztv != 0; o->Ttv = s->Ttv != 0; o->Rtv = s->Rtv != 0; o->Dtv = s->Dtv != 0; o->Ctv = s->Ctv != 0; o->Htv = s->Htv != 0;
-  o->distribution = s->distribution;
   o->max_iter = s->max_iter > 0 ? s->max_iter : 100;
   o->local_approx = s->local_approx;
   o->conv_tol = s->conv_tol > 0 ? s->conv_tol : 1e-8;
-  o->phi = s->phi;
-  o->y.assign(s->y, s->y + n);
-  o->Z.assign(s->Z, s->Z + (size_t)m * (o->Ztv ? n : 1));
+  if (p == 1) {
+    if (s->distribution < 0 || s->distribution > 5) return "unknown distribution code";
+    o->dist.assign(1, s->distribution);
+    o->phis.assign(1, s->phi);
+  } else {
+    if (!s->distribution_p || !s->phi_p) return "multivariate model needs distribution_p and phi_p";
+    o->dist.assign(s->distribution_p, s->distribution_p + p);
+    o->phis.assign(s->phi_p, s->phi_p + p);
+    for (int j = 0; j < p; j++) if (o->dist[j] < 1 || o->dist[j] > 5) return "multivariate distribution codes must be 1..5";
+  }
+  o->distribution = o->dist[0];
+  o->phi = o->phis[0];
+  // observation arrays -> p-major (the reference transposes y and u on entry, src/model_ssm_mng.cpp:8,17)
+  o->y.resize((size_t)p * n); o->u.assign((size_t)p * n, 1.0);
+  for (int t = 0; t < n; t++) for (int j = 0; j < p; j++) {
+    o->y[j + (size_t)p * t] = s->y[t + (size_t)n * j];
+    if (s->u) o->u[j + (size_t)p * t] = s->u[t + (size_t)n * j];
+  }
+  o->Z.assign(s->Z, s->Z + (size_t)p * m * (o->Ztv ? n : 1));
   o->T.assign(s->T, s->T + (size_t)m * m * (o->Ttv ? n : 1));
   o->R.assign(s->R, s->R + (size_t)m * k * (o->Rtv ? n : 1));
   o->a1.assign(s->a1, s->a1 + m);
   o->P1.assign(s->P1, s->P1 + (size_t)m * m);
-  if (s->D) o->D.assign(s->D, s->D + (o->Dtv ? n : 1)); else { o->D.assign(1, 0.0); o->Dtv = 0; }
+  if (s->D) o->D.assign(s->D, s->D + (size_t)p * (o->Dtv ? n : 1)); else { o->D.assign(p, 0.0); o->Dtv = 0; }
   if (s->C) o->C.assign(s->C, s->C + (size_t)m * (o->Ctv ? n : 1)); else { o->C.assign(m, 0.0); o->Ctv = 0; }
-  if (s->u) o->u.assign(s->u, s->u + n); else o->u.assign(n, 1.0);
   o->xbeta.assign(n, 0.0);
-  if (s->n_xreg > 0) {  // xbeta = xreg * beta (src/model_ssm_ung.h:84)
+  if (s->n_xreg > 0) {  // xbeta = xreg * beta (src/model_ssm_ung.h:84); univariate models only
+    if (p > 1) return "regression part is not available for multivariate models";
     if (!s->xreg || !s->beta) return "xreg/beta NULL with n_xreg > 0";
     for (int q = 0; q < s->n_xreg; q++)
       for (int t = 0; t < n; t++) o->xbeta[t] += s->xreg[t + (size_t)n * q] * s->beta[q];
@@ -390,48 +471,55 @@ std::string ingest_model(const bssm_ung_model* s, bool need_mode, HostModel* o) 
   if (need_mode) {
     if (o->gaussian()) return "psi-APF of a gaussian model is exact simulation; not routed through this entry";
     if (!s->initial_mode) return "initial_mode is required for the psi-APF";
-    o->initial_mode.assign(s->initial_mode, s->initial_mode + n);
+    o->initial_mode.resize((size_t)p * n);
+    for (int t = 0; t < n; t++) for (int j = 0; j < p; j++) o->initial_mode[j + (size_t)p * t] = s->initial_mode[t + (size_t)n * j];
   }
-  if ((o->distribution == BSSM_NEGBIN || o->distribution == BSSM_GAMMA || o->distribution == BSSM_SVM) && !(o->phi > 0))
-    return "phi must be positive";
+  for (int j = 0; j < p; j++)
+    if ((o->dist[j] == BSSM_NEGBIN || o->dist[j] == BSSM_GAMMA || o->dist[j] == BSSM_SVM || (p > 1 && o->dist[j] == BSSM_GAUSSIAN)) &&
+        !(o->phis[j] > 0))
+      return "phi must be positive";
   return "";
 }
 
 double const_term(const HostModel& h) {
   double res = 0.0;
+  const int p = h.p;
   int nfin = 0;
-  for (int t = 0; t < h.n; t++) {
-    const double y = h.y[t];
-    if (!std::isfinite(y)) continue;
-    nfin++;
-    const double u = h.u[t], phi = h.phi;
-    switch (h.distribution) {
-      case BSSM_POISSON: res += y * std::log(u) - std::lgamma(y + 1); break;
-      case BSSM_BINOMIAL: res += lchoose_ts(u, y); break;
-      case BSSM_NEGBIN: res += lchoose_ts(y + phi - 1, y) + phi * std::log(phi) + y * std::log(u); break;
-      case BSSM_GAMMA: res += phi * std::log(phi) - std::lgamma(phi) + (phi - 1) * std::log(y) - phi * std::log(u); break;
-      case BSSM_GAUSSIAN: res += norm_log_const(h.H[t * h.Htv]); break;
-      default: break;
+  for (int j = 0; j < p; j++)
+    for (int t = 0; t < h.n; t++) {
+      const size_t q = j + (size_t)p * t;
+      const double y = h.y[q];
+      if (!std::isfinite(y)) continue;
+      nfin++;
+      const double u = h.u[q], phi = h.phis[j];
+      switch (h.dist[j]) {
+        case BSSM_POISSON: res += y * std::log(u) - std::lgamma(y + 1); break;
+        case BSSM_BINOMIAL: res += lchoose_ts(u, y); break;
+        case BSSM_NEGBIN: res += lchoose_ts(y + phi - 1, y) + phi * std::log(phi) + y * std::log(u); break;
+        case BSSM_GAMMA: res += phi * std::log(phi) - std::lgamma(phi) + (phi - 1) * std::log(y) - phi * std::log(u); break;
+        case BSSM_GAUSSIAN: res += norm_log_const(h.gaussian() ? h.H[t * h.Htv] : phi); break;
+        default: break;
+      }
     }
-  }
-  if (h.distribution == BSSM_SVM) res = nfin * norm_log_const(h.phi);
+  if (p == 1 && h.dist[0] == BSSM_SVM) res = nfin * norm_log_const(h.phi);
   return res;
 }
 
 bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out) {
-  const int n = h.n, m = h.m;
+  const int n = h.n, m = h.m, p = h.p;
   const Sys S(h);
   Approx ap;
-  ap.y.assign(n, 0.0);
-  ap.H.assign(n, 0.0);
-  if (is_mode) {  // approximate_for_is: src/model_ssm_ung.cpp:143-161
-    out->mode.assign(is_mode, is_mode + n);
+  ap.y.assign((size_t)p * n, 0.0);
+  ap.H.assign((size_t)p * n, 0.0);
+  bool ok = true;
+  if (is_mode) {  // approximate_for_is: src/model_ssm_ung.cpp:143-161, src/model_ssm_mng.cpp:117-133 (mode p x n, as mode_storage)
+    out->mode.assign(is_mode, is_mode + (size_t)p * n);
     laplace_iter(h, out->mode, &ap);
     update_scales(h, ap, out->mode, &out->scales);
     out->approx_loglik = 0.0;
     out->iterations = 0;
   } else {  // psi_filter set-up: src/model_ssm_ung.cpp:514-528
-    out->iterations = run_laplace(h, S, &ap, &out->mode);
+    out->iterations = run_laplace(h, S, &ap, &out->mode, &ok);
     const double gll = gaussian_loglik(S, ap);
     update_scales(h, ap, out->mode, &out->scales);
     double ssc = 0;
@@ -441,12 +529,12 @@ bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out) {
   out->approx_y = ap.y;
   out->approx_H = ap.H;
   std::vector<Mat> at, Vt, Ct;
-  smoother_ccov(S, ap, &at, &Vt, &Ct);  // :533
-  conditional_cov(&Vt, &Ct);            // :534
-  out->alphahat.resize((size_t)m * (n + 1));
-  out->Vt.resize((size_t)m * m * (n + 1));
-  out->Ct.resize((size_t)m * m * (n + 1));
-  bool ok = true;
+  ok = ok && smoother_ccov(S, ap, &at, &Vt, &Ct);  // :533
+  out->alphahat.assign((size_t)m * (n + 1), 0.0);
+  out->Vt.assign((size_t)m * m * (n + 1), 0.0);
+  out->Ct.assign((size_t)m * m * (n + 1), 0.0);
+  if (!ok) return false;
+  conditional_cov(&Vt, &Ct);                       // :534
   for (int t = 0; t <= n; t++) {
     for (int i = 0; i < m; i++) { out->alphahat[i + (size_t)m * t] = at[t](i, 0); ok &= std::isfinite(at[t](i, 0)); }
     for (int q = 0; q < m * m; q++) {
@@ -461,10 +549,12 @@ bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out) {
 double approx_loglik_only(const HostModel& h) {
   const Sys S(h);
   Approx ap;
-  ap.y.assign(h.n, 0.0);
-  ap.H.assign(h.n, 0.0);
+  ap.y.assign((size_t)h.p * h.n, 0.0);
+  ap.H.assign((size_t)h.p * h.n, 0.0);
   std::vector<double> mode, scales;
-  run_laplace(h, S, &ap, &mode);
+  bool ok = true;
+  run_laplace(h, S, &ap, &mode, &ok);
+  if (!ok) return -INFINITY;
   const double gll = gaussian_loglik(S, ap);
   update_scales(h, ap, mode, &scales);
   double ssc = 0;
@@ -474,38 +564,49 @@ double approx_loglik_only(const HostModel& h) {
 
 namespace {
 void fill_obs_rows(const HostModel& h, int MP, const PsiSetup* su, std::vector<double>* obs) {
-  const int n = h.n, m = h.m, stride = OBS_HDR + MP;
+  const int n = h.n, m = h.m, p = h.p, sstride = SER_HDR + MP, stride = ROW_HDR + p * sstride;
   obs->assign((size_t)n * stride, 0.0);
   for (int t = 0; t < n; t++) {
-    double* ob = obs->data() + (size_t)t * stride;
-    const double y = h.y[t], u = h.u[t];
-    ob[OB_Y] = y;
-    ob[OB_U] = u;
-    ob[OB_FLAG] = std::isfinite(y) ? 1.0 : 0.0;
-    switch (h.distribution) {
-      case BSSM_SVM:  // signal is the first state; Z, D, xbeta are ignored (src/model_ssm_ung.cpp:456)
-        ob[OB_D] = 0.0;
-        ob[OBS_HDR] = 1.0;
-        ob[OB_AUX] = (y / h.phi) * (y / h.phi);
-        break;
-      case BSSM_GAUSSIAN:  // mu = D + Z'alpha, no xbeta (src/model_ssm_ulg.cpp:583-584)
-        ob[OB_D] = h.D[t * h.Dtv];
-        for (int c = 0; c < m; c++) ob[OBS_HDR + c] = h.Z[c + (size_t)m * (t * h.Ztv)];
-        ob[OB_AUX] = 1.0 / (h.H[t * h.Htv] * h.H[t * h.Htv]);
-        break;
-      default:
-        ob[OB_D] = h.D[t * h.Dtv] + h.xbeta[t];
-        for (int c = 0; c < m; c++) ob[OBS_HDR + c] = h.Z[c + (size_t)m * (t * h.Ztv)];
-        ob[OB_AUX] = h.distribution == BSSM_NEGBIN ? y + h.phi : (h.distribution == BSSM_GAMMA ? y / u : 0.0);
+    double* row = obs->data() + (size_t)t * stride;
+    bool any = false;
+    for (int j = 0; j < p; j++) {
+      double* ob = row + ROW_HDR + j * sstride;
+      const size_t q = j + (size_t)p * t;
+      const double y = h.y[q], u = h.u[q], phi = h.phis[j];
+      const int dist = h.dist[j];
+      ob[OB_DIST] = (double)dist;
+      ob[OB_PHI] = phi;
+      if (!std::isfinite(y)) continue;  // flag stays 0: the series is skipped (src/model_ssm_mng.cpp:414)
+      any = true;
+      ob[OB_FLAG] = 1.0;
+      ob[OB_Y] = y;
+      ob[OB_U] = u;
+      const double* Zt = h.Z.data() + (size_t)p * m * (t * h.Ztv);
+      switch (dist) {
+        case BSSM_SVM:  // signal is the first state; Z, D, xbeta are ignored (src/model_ssm_ung.cpp:456)
+          ob[OB_D] = 0.0;
+          ob[SER_HDR] = 1.0;
+          ob[OB_AUX] = (y / phi) * (y / phi);
+          break;
+        case BSSM_GAUSSIAN:
+          // ssm_ulg: mu = D + Z'alpha (no xbeta, src/model_ssm_ulg.cpp:583-584), variance H_t^2;
+          // ssm_mng series: -0.5 ((y - s) / phi)^2 (src/model_ssm_mng.cpp:435-437)
+          ob[OB_D] = h.D[j + (size_t)p * (t * h.Dtv)];
+          for (int c = 0; c < m; c++) ob[SER_HDR + c] = Zt[j + p * c];
+          ob[OB_AUX] = h.gaussian() ? 1.0 / (h.H[t * h.Htv] * h.H[t * h.Htv]) : 1.0 / (phi * phi);
+          break;
+        default:
+          ob[OB_D] = h.D[j + (size_t)p * (t * h.Dtv)] + (p == 1 ? h.xbeta[t] : 0.0);
+          for (int c = 0; c < m; c++) ob[SER_HDR + c] = Zt[j + p * c];
+          ob[OB_AUX] = dist == BSSM_NEGBIN ? y + phi : (dist == BSSM_GAMMA ? y / u : 0.0);
+      }
+      if (su) {
+        ob[OB_PSIY] = su->approx_y[q];
+        ob[OB_PSIIH] = 1.0 / su->approx_H[q];
+      }
     }
-    if (su) {
-      ob[OB_PSIY] = su->approx_y[t];
-      ob[OB_PSIIH] = 1.0 / su->approx_H[t];
-      ob[OB_SCALE] = su->scales[t];
-    }
-    if (!std::isfinite(y)) {  // keep NaN out of the arithmetic of skipped rows
-      ob[OB_Y] = 0.0; ob[OB_AUX] = 0.0; ob[OB_PSIY] = 0.0; ob[OB_PSIIH] = 0.0; ob[OB_SCALE] = 0.0;
-    }
+    row[RH_FLAG] = any ? 1.0 : 0.0;
+    row[RH_SCALE] = (su && any) ? su->scales[t] : 0.0;
   }
 }
 }  // namespace

@@ -10,13 +10,16 @@ namespace bssm {
 
 // owning copy of a bssm_ung_model (the reference's constructor also copies: SURVEY 8b "ownership")
 struct HostModel {
-  int n = 0, m = 0, k = 0;
+  int n = 0, m = 0, k = 0, p = 1;     // p observation series; arrays below are held p-major:
+                                      // y, u, initial_mode p x n; Z p x m x (1|n); D p x (1|n)
+  std::vector<int> dist;              // per-series distribution code
+  std::vector<double> phis;           // per-series dispersion
   int Ztv = 0, Ttv = 0, Rtv = 0, Dtv = 0, Ctv = 0, Htv = 0;
   int distribution = 0;
   int max_iter = 100, local_approx = 1;
   double conv_tol = 1e-8, phi = 1.0;
   std::vector<double> y, Z, T, R, a1, P1, D, C, xbeta, u, H, initial_mode;
-  bool gaussian() const { return distribution == BSSM_GAUSSIAN; }
+  bool gaussian() const { return p == 1 && distribution == BSSM_GAUSSIAN; }  // ssm_ulg family (sd = H_t)
 };
 
 // returns empty string on success, otherwise the validation error
@@ -30,7 +33,8 @@ double const_term(const HostModel& hm);
 // Result of approximate()/approximate_for_is() + smoother_ccov + conditional_cov
 // (src/model_ssm_ung.cpp:87-161, 514-534; src/model_ssm_ulg.cpp:419-473; src/conditional_dist.cpp:4-31)
 struct PsiSetup {
-  std::vector<double> approx_y, approx_H, mode, scales;
+  std::vector<double> approx_y, approx_H, mode;  // p x n
+  std::vector<double> scales;                     // n
   double approx_loglik = 0.0;
   std::vector<double> alphahat;  // m x (n+1)
   std::vector<double> Vt, Ct;    // m x m x (n+1)

@@ -14,8 +14,12 @@
 namespace bssm {
 
 // ---------------------------------------------------------------- layout of the per-filter tables
-// obs row (one per time point t in [0, n)), OBS_HDR header doubles followed by Z_t[MP]
-enum { OB_Y = 0, OB_U = 1, OB_D = 2, OB_PSIY = 3, OB_PSIIH = 4, OB_SCALE = 5, OB_FLAG = 6, OB_AUX = 7, OBS_HDR = 8 };
+// obs row (one per time point t in [0, n)): ROW_HDR doubles, then p series blocks of SER_HDR + MP doubles
+//   row:    RH_FLAG (any series observed), RH_SCALE (psi: scales_t)
+//   series: y, u, D_j + xbeta, psi pseudo-observation, 1 / psi sd, host-precomputed quotient, observed flag,
+//           distribution code, phi_j, pad; then Z_t[j, 0..MP)
+enum { RH_FLAG = 0, RH_SCALE = 1, ROW_HDR = 2 };
+enum { OB_Y = 0, OB_U = 1, OB_D = 2, OB_PSIY = 3, OB_PSIIH = 4, OB_AUX = 5, OB_FLAG = 6, OB_DIST = 7, OB_PHI = 8, SER_HDR = 10 };
 // distribution codes = R/bootstrap_filter.R:106-109 ; 5 = gaussian (ssm_ulg path)
 enum { DIST_SVM = 0, DIST_POISSON = 1, DIST_BINOMIAL = 2, DIST_NEGBIN = 3, DIST_GAMMA = 4, DIST_GAUSSIAN = 5 };
 // RNG purposes
@@ -142,7 +146,7 @@ __device__ __forceinline__ double log_obs_density(int dist, const double* __rest
 // psi-APF weight, src/model_ssm_ung.cpp:385-439 and the `- scales(t)` of :550,590
 __device__ __forceinline__ double log_psi_weight(int dist, const double* __restrict__ ob, double phi, double s) {
   const double q = (ob[OB_PSIY] - s) * ob[OB_PSIIH];
-  return log_obs_density(dist, ob, phi, s) + 0.5 * q * q - ob[OB_SCALE];
+  return log_obs_density(dist, ob, phi, s) + 0.5 * q * q;   // the caller subtracts scales_t once per row
 }
 
 }  // namespace bssm

@@ -35,16 +35,24 @@ __device__ __forceinline__ double signal_of(const double* __restrict__ ob, const
   // D(t) + Z_t' alpha + xbeta(t)   (src/model_ssm_ung.cpp:462-463); D + xbeta pre-added on the host
   double za = 0.0;
 #pragma unroll
-  for (int c = 0; c < MP; c++) za += ob[OBS_HDR + c] * x[c];
+  for (int c = 0; c < MP; c++) za += ob[SER_HDR + c] * x[c];
   return ob[OB_D] + za;
 }
 
+// log-weight of one particle at one time point: sum over the observed series of the row
+// (univariate: src/model_ssm_ung.cpp:447-493 / :385-439; multivariate: src/model_ssm_mng.cpp:407-442 / :357-393)
 template <int MP>
-__device__ __forceinline__ double log_weight_of(const FilterBatch& b, const double* __restrict__ ob, double phi,
-                                                const double (&x)[MP]) {
-  if (ob[OB_FLAG] == 0.0) return 0.0;  // missing y_t: weights are ones (src/model_ssm_ung.cpp:644-647)
-  const double s = signal_of<MP>(ob, x);
-  return b.psi ? log_psi_weight(b.dist, ob, phi, s) : log_obs_density(b.dist, ob, phi, s);
+__device__ __forceinline__ double log_weight_of(const FilterBatch& b, const double* __restrict__ row, const double (&x)[MP]) {
+  if (row[RH_FLAG] == 0.0) return 0.0;  // nothing observed at t: weights are ones (src/model_ssm_ung.cpp:644-647)
+  double w = 0.0;
+  for (int j = 0; j < b.p; j++) {
+    const double* __restrict__ ob = row + ROW_HDR + j * (SER_HDR + MP);
+    if (ob[OB_FLAG] == 0.0) continue;
+    const double s = signal_of<MP>(ob, x);
+    const int dist = (int)ob[OB_DIST];
+    w += b.psi ? log_psi_weight(dist, ob, ob[OB_PHI], s) : log_obs_density(dist, ob, ob[OB_PHI], s);
+  }
+  return b.psi ? w - row[RH_SCALE] : w;
 }
 
 // alpha_{t+1} = C_t + T_t a + R_t eta   (src/model_ssm_ung.cpp:663-670); for the psi-APF the host
@@ -101,8 +109,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
   const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
   const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
-  const double phi = b.phi[f];
-  const int obs_stride = OBS_HDR + MP, m = b.m;
+  const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP), m = b.m;
   const double dN = (double)N;
 
   double w[PPT];  // log-weights of my particles at the current time
@@ -122,7 +129,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
         if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1)) * m + c) * N + i] = x[c];
       }
     }
-    w[r] = (i < N) ? log_weight_of<MP>(b, obs, phi, x) : -INFINITY;
+    w[r] = (i < N) ? log_weight_of<MP>(b, obs, x) : -INFINITY;
     __builtin_amdgcn_sched_barrier(0);  // keep the unrolled particles sequential: bounds live registers
   }
 
@@ -214,7 +221,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
           if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1) + (t + 1)) * m + c) * N + i] = x[c];
         }
       }
-      w[r] = (i < N) ? (t + 1 < n ? log_weight_of<MP>(b, ob, phi, x) : 0.0) : -INFINITY;
+      w[r] = (i < N) ? (t + 1 < n ? log_weight_of<MP>(b, ob, x) : 0.0) : -INFINITY;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -324,7 +331,7 @@ __device__ __forceinline__ int search16_lds(const double* a, int stride, int len
   }
 
 template <int MP, int KP, int PPT, bool DBG = false>
-__global__ void __launch_bounds__(GRID_NT, 6) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
+__global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   __shared__ double s_Q[GRID_NT];      // inclusive prefix of scaled block sums
   __shared__ double s_iscale[GRID_NT];  // 1 / exp(max_b - M)
   __shared__ double s_red[8];
@@ -336,8 +343,7 @@ __global__ void __launch_bounds__(GRID_NT, 6) pf_grid_step(const FilterBatch b, 
 
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
-  const double phi = b.phi[f];
-  const int obs_stride = OBS_HDR + MP;
+  const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
   const int base = pb * chunk;
   const int len = min(chunk, N - base);
   const int tn = t + 1;  // time index of the particles produced by this launch
@@ -482,7 +488,7 @@ __global__ void __launch_bounds__(GRID_NT, 6) pf_grid_step(const FilterBatch b, 
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
-    w[r] = (li < len) ? (have_obs ? log_weight_of<MP>(b, ob, phi, x[r]) : 0.0) : -INFINITY;
+    w[r] = (li < len) ? (have_obs ? log_weight_of<MP>(b, ob, x[r]) : 0.0) : -INFINITY;
     mx = fmax(mx, w[r]);
   }
   BSSM_STAMP(8)

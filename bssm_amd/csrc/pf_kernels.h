@@ -13,21 +13,19 @@ namespace bssm {
 struct FilterBatch {
   int n;         // time points
   int m, k;      // real state / disturbance dimensions
+  int p;         // observation series per time point (1 = univariate)
   int MP, KP;    // padded dimensions the kernels are instantiated for
   int N;         // particles per filter
   int F;         // filters in the batch
-  int dist;      // DIST_*
   int psi;       // 0 bootstrap weights, 1 psi-APF weights
   uint32_t seed;
   uint32_t stream0;  // filter f uses Philox key (seed, stream0 + f)
   // [f][tt][MP*MP + MP*KP + MP] : T_tt, R_tt, C_tt (column-major, zero padded)
   const double* mats; size_t mats_fstride; int mats_tstride;
-  // [f][t][OBS_HDR + MP] for t in [0, n)
+  // [f][t][ROW_HDR + p * (SER_HDR + MP)] for t in [0, n)
   const double* obs; size_t obs_fstride;
   // [f][MP + MP*MP] : a1 then L (initial mean and lower factor)
   const double* init; size_t init_fstride;
-  // [f] dispersion
-  const double* phi;
   // outputs (any may be null)
   double* alpha_hist;   // [f][n+1][m][N]   particle-minor
   uint32_t* indices;    // [f][n][N]

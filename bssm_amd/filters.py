@@ -156,8 +156,8 @@ def logLik_batch(model: BssmModel, particles: int, n_rep: int, method: str = "bs
 def psi_setup(model: BssmModel, is_mode=None):
     """Gaussian approximation + conditional factors used by the psi-APF (host side of the library)."""
     arr, smod, keep = _prep(model, True)
-    n, m = arr["n"], arr["m"]
-    res = dict(approx_y=np.zeros(n), approx_H=np.zeros(n), mode=np.zeros(n), scales=np.zeros(n),
+    n, m, p = arr["n"], arr["m"], arr.get("p", 1)
+    res = dict(approx_y=np.zeros(n * p), approx_H=np.zeros(n * p), mode=np.zeros(n * p), scales=np.zeros(n),
                alphahat=_alloc((m, n + 1)), Vt=_alloc((m, m, n + 1)), Ct=_alloc((m, m, n + 1)))
     al = C.c_double(0.0)
     mode_in = None if is_mode is None else np.ascontiguousarray(is_mode, dtype=np.float64)
@@ -166,4 +166,7 @@ def psi_setup(model: BssmModel, is_mode=None):
                                           C.byref(al), _lib.dptr(res["alphahat"]), _lib.dptr(res["Vt"]),
                                           _lib.dptr(res["Ct"])))
     res["approx_loglik"] = al.value
+    if p > 1:  # the library holds these p x n
+        for k in ("approx_y", "approx_H", "mode"):
+            res[k] = res[k].reshape((p, n), order="F")
     return res

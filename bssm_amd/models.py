@@ -64,6 +64,9 @@ class BssmModel(dict):
     def n(self): return int(np.asarray(self["y"]).shape[0])
 
     @property
+    def p(self): return int(np.asarray(self["y"]).shape[1]) if np.asarray(self["y"]).ndim == 2 else 1
+
+    @property
     def m(self): return int(np.asarray(self["a1"]).shape[0])
 
 
@@ -357,6 +360,46 @@ def ar1_ng(y, rho, sigma, mu, distribution, phi=None, u=None, beta=None, xreg=No
         mu_est=_is_prior(mu), phi_est=phi_est, theta=np.asarray(theta, dtype=float))))
 
 
+def ssm_mng(y, Z, T, R, a1=None, P1=None, distribution="poisson", phi=1.0, u=None, init_theta=(), D=None, C=None,
+            update_fn=None, prior_fn=None):
+    """R/models.R:538-597: multivariate non-Gaussian model; y n x p, Z p x m x (1|n), D p x (1|n), u n x p."""
+    y = np.asarray(y, dtype=float)
+    if y.ndim != 2:
+        raise ValueError("Argument 'y' must be a matrix or multivariate ts object for a multivariate model")
+    n, p = y.shape
+    u = np.ones((n, p)) if u is None else np.asarray(u, dtype=float).reshape(n, p)
+    dists = [distribution] * p if isinstance(distribution, str) else list(distribution)
+    if len(dists) != p:
+        raise ValueError("'distribution' must have one entry per series")
+    dists = [d.lower() for d in dists]
+    for d in dists:
+        if d not in ("poisson", "binomial", "negative binomial", "gamma", "gaussian"):
+            raise ValueError("'arg' should be one of 'poisson', 'binomial', 'negative binomial', 'gamma', 'gaussian'")
+    phi = np.repeat(float(phi), p) if np.ndim(phi) == 0 else np.asarray(phi, dtype=float).reshape(p)
+    if np.any(phi <= 0):
+        raise ValueError("Parameter 'phi' must be positive.")
+    Z = np.asarray(Z, dtype=float)
+    if Z.ndim == 2:
+        Z = Z.reshape(Z.shape[0], Z.shape[1], 1)
+    if Z.shape[0] != p or Z.shape[2] not in (1, n):
+        raise ValueError("'Z' must be p x m or p x m x n")
+    m = Z.shape[1]
+    T = _check_cube(T, m, m, n, "T")
+    R = _check_cube(R, m, np.asarray(R).shape[1] if np.asarray(R).ndim >= 2 else 1, n, "R")
+    a1, P1 = _check_a1P1(a1, P1, m)
+    if D is None:
+        D = np.zeros((p, 1))
+    D = np.asarray(D, dtype=float)
+    D = D.reshape(p, -1) if D.ndim <= 1 else D
+    if D.shape[0] != p or D.shape[1] not in (1, n):
+        raise ValueError("'D' must be p x 1 or p x n")
+    initial_mode = np.column_stack([init_mode(y[:, i], u[:, i], dists[i]) for i in range(p)])
+    return BssmModel(("ssm_mng", "nongaussian", "bssm_model"), **_common_tail(dict(
+        y=_f(y), Z=_f(Z), T=T, R=R, a1=a1, P1=P1, phi=_f(phi), u=_f(u), D=_f(D), C=_check_C(C, m, n),
+        distribution=dists, initial_mode=_f(initial_mode), update_fn=update_fn, prior_fn=prior_fn,
+        theta=np.asarray(init_theta, dtype=float))))
+
+
 # ---- linear-Gaussian models: bootstrap_filter(gaussian=TRUE) path and the analytic pins ----
 def ssm_ulg(y, Z, H, T, R, a1=None, P1=None, D=None, C=None):
     """R/models.R ssm_ulg: y_t = D_t + Z_t' alpha_t + H_t eps_t"""
@@ -403,6 +446,8 @@ def ar1_lg(y, rho, sigma, mu, sd_y):
 def model_arrays(model: BssmModel) -> dict:
     """Flatten a model into the plain column-major arrays + flags the C ABI struct carries
     (the field list of src/model_ssm_ung.cpp:9-32)."""
+    if model.inherits("ssm_mng"):
+        return _mng_arrays(model)
     y = np.ascontiguousarray(np.asarray(model["y"], dtype=np.float64).reshape(-1))
     n = y.shape[0]
     Z = np.asfortranarray(model["Z"], dtype=np.float64)
@@ -433,3 +478,27 @@ def model_arrays(model: BssmModel) -> dict:
         out["initial_mode"] = np.ascontiguousarray(np.asarray(model["initial_mode"], dtype=np.float64).reshape(-1))
     out["xbeta"] = (xreg @ beta) if xreg.shape[1] else np.zeros(n)
     return out
+
+
+def _mng_arrays(model: BssmModel) -> dict:
+    """Multivariate counterpart of model_arrays (fields of src/model_ssm_mng.cpp:7-31); y, u, initial_mode stay
+    n x p as R holds them -- the library transposes on entry like the reference."""
+    y = np.asfortranarray(model["y"], dtype=np.float64)
+    n, p = y.shape
+    Z = np.asfortranarray(model["Z"], dtype=np.float64)
+    T = np.asfortranarray(model["T"], dtype=np.float64)
+    R = np.asfortranarray(model["R"], dtype=np.float64)
+    D = np.asfortranarray(model["D"], dtype=np.float64)
+    C = np.asfortranarray(model["C"], dtype=np.float64)
+    m, k = Z.shape[1], R.shape[1]
+    dist = np.array([DISTRIBUTIONS.index(d) for d in model["distribution"]], dtype=np.int32)
+    return dict(
+        n=n, m=m, k=k, p=p, Ztv=int(Z.shape[2] > 1), Ttv=int(T.shape[2] > 1), Rtv=int(R.shape[2] > 1),
+        Dtv=int(D.shape[1] > 1), Ctv=int(C.shape[1] > 1), Htv=0, distribution=int(dist[0]), n_xreg=0,
+        max_iter=int(model.get("max_iter", 100)), local_approx=int(bool(model.get("local_approx", True))),
+        conv_tol=float(model.get("conv_tol", 1e-8)), phi=float(np.asarray(model["phi"]).reshape(-1)[0]),
+        y=y, Z=Z, T=T, R=R, a1=np.ascontiguousarray(model["a1"], dtype=np.float64),
+        P1=np.asfortranarray(model["P1"], dtype=np.float64), D=D, C=C, xreg=np.zeros((n, 0)), beta=np.zeros(0),
+        u=np.asfortranarray(model["u"], dtype=np.float64), H=None,
+        initial_mode=np.asfortranarray(model["initial_mode"], dtype=np.float64), xbeta=np.zeros(n),
+        distribution_p=dist, phi_p=np.ascontiguousarray(model["phi"], dtype=np.float64))

@@ -74,6 +74,13 @@ typedef struct bssm_ung_model {
   const double* u;            /* n */
   const double* H;            /* (1|n) observation sd; gaussian only */
   const double* initial_mode; /* n; psi-APF only */
+  /* ---- multivariate observations: ssm_mng (model_type 0), fields of src/model_ssm_mng.cpp:7-31.
+   * p <= 1 means univariate and the three fields below are ignored.  With p > 1: y is n x p and u is n x p as R
+   * holds them (the reference transposes on entry, :8,:17), Z is p x m x (1|n), D is p x (1|n), initial_mode is
+   * n x p; `distribution` / `phi` above are ignored in favour of the per-series vectors. */
+  int32_t p;
+  const int32_t* distribution_p; /* p codes in 1..5 */
+  const double* phi_p;           /* p */
 } bssm_ung_model;
 
 /* Outputs of the filter / smoother wrappers, shaped as the reference returns them to R:
@@ -143,7 +150,7 @@ typedef struct bssm_is_job {
   int32_t n_stored;              /* global number of retained draws */
   int32_t first, count;          /* this process handles draws [first, first+count) */
   const bssm_ung_model* models;  /* `count` models (local) */
-  const double* modes;           /* n x count signal modes (psi) or NULL */
+  const double* modes;           /* p x n x count signal modes (psi; the `modes` cube of R_postcorrection.cpp:158) or NULL */
   const double* approx_loglik;   /* count (bsf: src/approx_mcmc.cpp:479) or NULL */
   const uint32_t* counts;        /* count jump-chain multiplicities */
   int32_t sampling_method;       /* BSSM_PSI / BSSM_BSF */
@@ -175,8 +182,8 @@ int bssm_update_model_builtin(int model_type, const int32_t* flags, const double
                               double* beta);
 
 /* ---- psi-APF set-up on its own (host): approximate() + smoother_ccov + conditional_cov,
- * src/model_ssm_ung.cpp:87-161, 514-534.  is_mode NULL = iterate from initial_mode.
- * Outputs: approx_y[n], approx_H[n], mode[n], scales[n], approx_loglik, alphahat m x (n+1),
+ * src/model_ssm_ung.cpp:87-161, 514-534.  is_mode (p x n) NULL = iterate from initial_mode.
+ * Outputs: approx_y, approx_H, mode (p x n each), scales[n], approx_loglik, alphahat m x (n+1),
  * Vt / Ct m x m x (n+1). Any may be NULL. */
 int bssm_psi_setup(const bssm_ung_model* model, const double* is_mode, double* approx_y, double* approx_H,
                    double* mode, double* scales, double* approx_loglik, double* alphahat, double* Vt, double* Ct);

@@ -926,3 +926,418 @@ int orc_is_correction(const orc_is_job *job, double *weights, double *loglik_out
   }
   return 0;
 }
+
+
+/* ================================================================== */
+/* ssm_mng: multivariate observations                                  */
+/* ================================================================== */
+#define ORC_MAXP 8
+#define MZ(t) (mod->Z + (size_t)mod->p * mod->m * ((t) * mod->Ztv))
+#define MD(t) (mod->D + (size_t)mod->p * ((t) * mod->Dtv))
+
+double orc_mng_const_term(const orc_mng_model *mod) { /* model_ssm_mng.cpp:632-666 */
+  double res = 0.0;
+  for (int i = 0; i < mod->p; i++)
+    for (int t = 0; t < mod->n; t++) {
+      double y = mod->y[i + (size_t)mod->p * t], u = mod->u[i + (size_t)mod->p * t], phi = mod->phi[i];
+      if (!isfinite(y)) continue;
+      switch (mod->distribution[i]) {
+      case ORC_POISSON: res += y * log(u) - lgamma(y + 1); break;
+      case ORC_BINOMIAL: res += orc_lchoose(u, y); break;
+      case ORC_NEGBIN: res += orc_lchoose(y + phi - 1, y) + phi * log(phi) + y * log(u); break;
+      case ORC_GAMMA: res += phi * log(phi) - lgamma(phi) + (phi - 1) * log(y) - phi * log(u); break;
+      case ORC_GAUSSIAN: res += norm_log_const(phi); break;
+      }
+    }
+  return res;
+}
+
+static int mng_observed(const orc_mng_model *mod, int t) { /* na_y.n_elem < p */
+  for (int i = 0; i < mod->p; i++) if (isfinite(mod->y[i + (size_t)mod->p * t])) return 1;
+  return 0;
+}
+
+/* model_ssm_mng.cpp:407-442 (su == NULL) and :357-393 (psi weights, su != NULL), one particle */
+static double mng_log_weight(const orc_mng_model *mod, const orc_mng_setup *su, int t, const double *a) {
+  const int p = mod->p, m = mod->m;
+  const double *Zt = MZ(t), *Dt = MD(t);
+  double w = 0.0;
+  for (int j = 0; j < p; j++) {
+    double y = mod->y[j + (size_t)p * t];
+    if (!isfinite(y)) continue;
+    double s = 0.0;
+    for (int c = 0; c < m; c++) s += Zt[j + p * c] * a[c];
+    s = Dt[j] + s;
+    double u = mod->u[j + (size_t)p * t], phi = mod->phi[j];
+    switch (mod->distribution[j]) {
+    case ORC_POISSON: w += y * s - u * exp(s); break;
+    case ORC_BINOMIAL: w += y * s - u * log1p(exp(s)); break;
+    case ORC_NEGBIN: w += y * s - (y + phi) * log(phi + u * exp(s)); break;
+    case ORC_GAMMA: w += -phi * (s + (y * exp(-s) / u)); break;
+    case ORC_GAUSSIAN: w += -0.5 * pow((y - s) / phi, 2.0); break;
+    }
+    if (su) w += 0.5 * pow((su->approx_y[j + (size_t)p * t] - s) / su->approx_H[j + (size_t)p * t], 2.0);
+  }
+  return w;
+}
+
+static double mng_filter_core(const orc_mng_model *mod, const orc_mng_setup *su, unsigned N, const orc_rng *rng,
+                              double *alpha, double *weights, unsigned *indices) {
+  const int n = mod->n, m = mod->m, k = su ? m : mod->k, mm = m * m;
+  double L[ORC_MAXM * ORC_MAXM];
+  if (!su) ung_initial_chol(mod->P1, m, L); /* :565-570 */
+  double *nw = (double *)malloc(sizeof(double) * N), *lw = (double *)malloc(sizeof(double) * N);
+  double *r = (double *)malloc(sizeof(double) * N), *atmp = (double *)malloc(sizeof(double) * N * m);
+  double um[ORC_MAXM];
+  for (unsigned i = 0; i < N; i++) {
+    rng_normals(rng, 0, 0, i, m, um);
+    for (int j = 0; j < m; j++) {
+      double s = 0.0;
+      for (int c = 0; c < m; c++) s += (su ? su->Vt[j + m * c] : L[j + m * c]) * um[c];
+      A_(j, 0, i) = (su ? su->alphahat[j] : mod->a1[j]) + s;
+    }
+  }
+  double loglik = su ? su->approx_loglik : 0.0, inc;
+  if (mng_observed(mod, 0)) {
+    for (unsigned i = 0; i < N; i++) lw[i] = mng_log_weight(mod, su, 0, &A_(0, 0, i)) - (su ? su->scales[0] : 0.0);
+    if (!normalise_step(lw, N, weights, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+    loglik += inc;
+  } else {
+    for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
+  }
+  for (int t = 0; t < n; t++) {
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    for (unsigned i = 0; i < N; i++)
+      for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
+    const double *Tt = mod->T + (size_t)mm * (t * mod->Ttv), *Rt = mod->R + (size_t)m * mod->k * (t * mod->Rtv);
+    const double *Cv = mod->C + (size_t)m * (t * mod->Ctv);
+    for (unsigned i = 0; i < N; i++) {
+      rng_normals(rng, 2, t, i, k, um);
+      for (int j = 0; j < m; j++) {
+        double s = 0.0, q = 0.0;
+        if (su) { /* :527-534 */
+          const double *ah0 = su->alphahat + (size_t)m * t, *Ct1 = su->Ct + (size_t)mm * (t + 1), *Vt1 = su->Vt + (size_t)mm * (t + 1);
+          for (int c = 0; c < m; c++) s += Ct1[j + m * c] * (atmp[c + (size_t)m * i] - ah0[c]);
+          for (int c = 0; c < m; c++) q += Vt1[j + m * c] * um[c];
+          A_(j, t + 1, i) = su->alphahat[j + (size_t)m * (t + 1)] + s + q;
+        } else { /* :611-618 */
+          for (int c = 0; c < m; c++) s += Tt[j + m * c] * atmp[c + (size_t)m * i];
+          for (int c = 0; c < k; c++) q += Rt[j + m * c] * um[c];
+          A_(j, t + 1, i) = Cv[j] + s + q;
+        }
+      }
+    }
+    double *wcol = weights + (size_t)N * (t + 1);
+    if ((t < n - 1) && mng_observed(mod, t + 1)) {
+      for (unsigned i = 0; i < N; i++) lw[i] = mng_log_weight(mod, su, t + 1, &A_(0, t + 1, i)) - (su ? su->scales[t + 1] : 0.0);
+      if (!normalise_step(lw, N, wcol, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+      loglik += inc;
+    } else {
+      for (unsigned i = 0; i < N; i++) { wcol[i] = 1.0; nw[i] = 1.0 / N; }
+    }
+  }
+  if (!su) loglik += orc_mng_const_term(mod); /* :632-666 */
+done:
+  free(nw); free(lw); free(r); free(atmp);
+  return loglik;
+}
+
+double orc_mng_bsf_filter(const orc_mng_model *mod, unsigned N, const orc_rng *rng, double *alpha, double *weights, unsigned *indices) {
+  return mng_filter_core(mod, NULL, N, rng, alpha, weights, indices);
+}
+double orc_mng_psi_filter(const orc_mng_model *mod, const orc_mng_setup *su, unsigned N, const orc_rng *rng,
+                          double *alpha, double *weights, unsigned *indices) {
+  return mng_filter_core(mod, su, N, rng, alpha, weights, indices);
+}
+
+orc_mng_setup *orc_mng_setup_alloc(int n, int m, int p) {
+  orc_mng_setup *s = (orc_mng_setup *)calloc(1, sizeof(orc_mng_setup));
+  s->n = n; s->m = m; s->p = p;
+  s->approx_y = (double *)calloc((size_t)p * n, sizeof(double));
+  s->approx_H = (double *)calloc((size_t)p * n, sizeof(double));
+  s->mode = (double *)calloc((size_t)p * n, sizeof(double));
+  s->scales = (double *)calloc(n, sizeof(double));
+  s->alphahat = (double *)calloc((size_t)m * (n + 1), sizeof(double));
+  s->Vt = (double *)calloc((size_t)m * m * (n + 1), sizeof(double));
+  s->Ct = (double *)calloc((size_t)m * m * (n + 1), sizeof(double));
+  return s;
+}
+void orc_mng_setup_free(orc_mng_setup *s) {
+  if (!s) return;
+  free(s->approx_y); free(s->approx_H); free(s->mode); free(s->scales); free(s->alphahat); free(s->Vt); free(s->Ct); free(s);
+}
+
+/* one multivariate Kalman prediction step, the "zeroed rows" form of src/model_ssm_mlg.cpp:259-291,318-356
+ * (numerically the same update as the observed-rows form of :103-128: missing rows decouple exactly).
+ * gy, gH: p x n pseudo-observations and their sd.  ZFinv (m x p) = Z' F^-1, K = P ZFinv. */
+static int mlg_step(const orc_mng_model *mod, const double *gy, const double *gH, int t, const double *at, const double *Pt,
+                    double *at1, double *Pt1, double *v, double *ZFinv, double *K, double *Zz, int *nobs, double *logdetF) {
+  const int m = mod->m, p = mod->p;
+  const double *Zt = MZ(t), *Dt = MD(t);
+  const double *Tt = mod->T + (size_t)m * m * (t * mod->Ttv), *Rt = mod->R + (size_t)m * mod->k * (t * mod->Rtv);
+  const double *Cv = mod->C + (size_t)m * (t * mod->Ctv);
+  double RR[ORC_MAXM * ORC_MAXM], tmp[ORC_MAXM * ORC_MAXM], tmp2[ORC_MAXM * ORC_MAXM];
+  compute_RR(Rt, m, mod->k, RR);
+  int na[ORC_MAXP], cnt = 0;
+  for (int i = 0; i < p; i++) { na[i] = !isfinite(gy[i + (size_t)p * t]); cnt += !na[i]; }
+  *nobs = cnt;
+  if (cnt == 0) {
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Tt[i + m * j] * at[j]; at1[i] = Cv[i] + s; }
+    mat_mul(Tt, Pt, m, m, m, tmp); mat_mul_bt(tmp, Tt, m, m, m, tmp2);
+    for (int q = 0; q < m * m; q++) Pt1[q] = tmp2[q] + RR[q];
+    symmatu(Pt1, m);
+    return 1;
+  }
+  double HH[ORC_MAXP * ORC_MAXP] = {0}, F[ORC_MAXP * ORC_MAXP], Lf[ORC_MAXP * ORC_MAXP] = {0}, Fi[ORC_MAXP * ORC_MAXP];
+  for (int c = 0; c < m; c++) for (int i = 0; i < p; i++) Zz[i + p * c] = na[i] ? 0.0 : Zt[i + p * c];
+  for (int i = 0; i < p; i++) HH[i + p * i] = na[i] ? 1.0 : gH[i + (size_t)p * t] * gH[i + (size_t)p * t];
+  double ZP[ORC_MAXP * ORC_MAXM];
+  mat_mul(Zz, Pt, p, m, m, ZP);
+  mat_mul_bt(ZP, Zz, p, m, p, F);
+  for (int q = 0; q < p * p; q++) F[q] += HH[q];
+  for (int q = 0; q < p * p; q++) if (!isfinite(F[q])) return 0;
+  for (int i = 0; i < p; i++) if (!(F[i + p * i] > 0)) return 0;
+  int idx[ORC_MAXP]; for (int i = 0; i < p; i++) idx[i] = i;
+  if (chol_lower_sub(F, p, idx, p, Lf) != 0) return 0;
+  *logdetF = 0; for (int i = 0; i < p; i++) *logdetF += 2.0 * log(Lf[i + p * i]);
+  /* F^-1 = L^-T L^-1 */
+  double Li[ORC_MAXP * ORC_MAXP] = {0};
+  for (int j = 0; j < p; j++) { /* invert lower triangular */
+    Li[j + p * j] = 1.0 / Lf[j + p * j];
+    for (int i = j + 1; i < p; i++) { double s = 0; for (int q = j; q < i; q++) s += Lf[i + p * q] * Li[q + p * j]; Li[i + p * j] = -s / Lf[i + p * i]; }
+  }
+  mat_mul_at(Li, Li, p, p, p, Fi);
+  for (int i = 0; i < p; i++) {
+    double za = 0; for (int c = 0; c < m; c++) za += Zz[i + p * c] * at[c];
+    v[i] = na[i] ? 0.0 : gy[i + (size_t)p * t] - Dt[i] - za;
+  }
+  mat_mul_at(Zz, Fi, m, p, p, ZFinv);      /* Z' F^-1 : m x p */
+  mat_mul(Pt, ZFinv, m, m, p, K);          /* m x p */
+  double af[ORC_MAXM];
+  for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < p; j++) s += K[i + m * j] * v[j]; af[i] = at[i] + s; }
+  for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Tt[i + m * j] * af[j]; at1[i] = Cv[i] + s; }
+  double IKZ[ORC_MAXM * ORC_MAXM], KH[ORC_MAXM * ORC_MAXP], M[ORC_MAXM * ORC_MAXM];
+  mat_mul(K, Zz, m, p, m, IKZ);
+  for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - IKZ[i + m * j];
+  mat_mul(IKZ, Pt, m, m, m, tmp); mat_mul_bt(tmp, IKZ, m, m, m, M);
+  mat_mul(K, HH, m, p, p, KH); mat_mul_bt(KH, K, m, p, m, tmp);
+  for (int q = 0; q < m * m; q++) M[q] += tmp[q];
+  mat_mul(Tt, M, m, m, m, tmp); mat_mul_bt(tmp, Tt, m, m, m, tmp2);
+  for (int q = 0; q < m * m; q++) Pt1[q] = tmp2[q] + RR[q];
+  symmatu(Pt1, m);
+  return 1;
+}
+
+double orc_mlg_loglik(const orc_mng_model *mod, const double *gy, const double *gH) { /* model_ssm_mlg.cpp:90-137 */
+  const int n = mod->n, m = mod->m, p = mod->p;
+  double at[ORC_MAXM], Pt[ORC_MAXM * ORC_MAXM], at1[ORC_MAXM], Pt1[ORC_MAXM * ORC_MAXM];
+  double v[ORC_MAXP], ZF[ORC_MAXM * ORC_MAXP], K[ORC_MAXM * ORC_MAXP], Zz[ORC_MAXP * ORC_MAXM];
+  memcpy(at, mod->a1, sizeof(double) * m); memcpy(Pt, mod->P1, sizeof(double) * m * m);
+  const double LOG2PI = log(2.0 * ORC_PI);
+  double ll = 0.0;
+  for (int t = 0; t < n; t++) {
+    int nobs; double ld = 0;
+    if (!mlg_step(mod, gy, gH, t, at, Pt, at1, Pt1, v, ZF, K, Zz, &nobs, &ld)) return -INFINITY;
+    if (nobs > 0) {
+      /* v' F^-1 v = |L^-1 v|^2 with F = L L' (the reference forms inv(chol(F))' v, :125-127) */
+      double q = 0;
+      double F[ORC_MAXP * ORC_MAXP], HH, ZP[ORC_MAXP * ORC_MAXM], Lf[ORC_MAXP * ORC_MAXP] = {0}, w[ORC_MAXP];
+      mat_mul(Zz, Pt, p, m, m, ZP); mat_mul_bt(ZP, Zz, p, m, p, F);
+      for (int i = 0; i < p; i++) { HH = isfinite(gy[i + (size_t)p * t]) ? gH[i + (size_t)p * t] * gH[i + (size_t)p * t] : 1.0; F[i + p * i] += HH; }
+      int idx[ORC_MAXP]; for (int i = 0; i < p; i++) idx[i] = i;
+      chol_lower_sub(F, p, idx, p, Lf);
+      for (int i = 0; i < p; i++) { double s = v[i]; for (int c = 0; c < i; c++) s -= Lf[i + p * c] * w[c]; w[i] = s / Lf[i + p * i]; q += w[i] * w[i]; }
+      ll -= 0.5 * (nobs * LOG2PI + ld + q);
+    }
+    memcpy(at, at1, sizeof(double) * m); memcpy(Pt, Pt1, sizeof(double) * m * m);
+  }
+  return ll;
+}
+
+/* model_ssm_mlg.cpp fast_smoother (:225-308 region) */
+static int mlg_fast_smoother(const orc_mng_model *mod, const double *gy, const double *gH, double *at) {
+  const int n = mod->n, m = mod->m, p = mod->p;
+  double *vt = (double *)calloc((size_t)p * n, sizeof(double)), *ZF = (double *)calloc((size_t)m * p * n, sizeof(double));
+  double *Kt = (double *)calloc((size_t)m * p * n, sizeof(double)), *Zz = (double *)calloc((size_t)p * m * n, sizeof(double));
+  int *nob = (int *)calloc(n, sizeof(int));
+  double *rt = (double *)calloc((size_t)m * n, sizeof(double));
+  double Pt[ORC_MAXM * ORC_MAXM], Pt1[ORC_MAXM * ORC_MAXM], ld;
+  int ok = 1;
+  memcpy(at, mod->a1, sizeof(double) * m); memcpy(Pt, mod->P1, sizeof(double) * m * m);
+  for (int t = 0; t < n && ok; t++) {
+    ok = mlg_step(mod, gy, gH, t, at + (size_t)m * t, Pt, at + (size_t)m * (t + 1), Pt1, vt + (size_t)p * t, ZF + (size_t)m * p * t,
+                  Kt + (size_t)m * p * t, Zz + (size_t)p * m * t, &nob[t], &ld);
+    memcpy(Pt, Pt1, sizeof(double) * m * m);
+  }
+  if (ok) {
+    double L[ORC_MAXM * ORC_MAXM], KZ[ORC_MAXM * ORC_MAXM];
+    for (int t = n - 1; t >= 0; t--) {
+      const double *Tt = mod->T + (size_t)m * m * (t * mod->Ttv);
+      double rnew[ORC_MAXM];
+      const double *r1 = rt + (size_t)m * t; /* r_t (r_{n-1} = 0) */
+      if (nob[t] > 0) {
+        mat_mul(Kt + (size_t)m * p * t, Zz + (size_t)p * m * t, m, p, m, KZ);
+        for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) KZ[i + m * j] = (i == j ? 1.0 : 0.0) - KZ[i + m * j];
+        mat_mul(Tt, KZ, m, m, m, L);
+        for (int i = 0; i < m; i++) {
+          double s = 0, q = 0;
+          for (int j = 0; j < p; j++) s += ZF[i + m * j + (size_t)m * p * t] * vt[j + (size_t)p * t];
+          for (int j = 0; j < m; j++) q += L[j + m * i] * r1[j];
+          rnew[i] = s + q;
+        }
+      } else {
+        for (int i = 0; i < m; i++) { double q = 0; for (int j = 0; j < m; j++) q += Tt[j + m * i] * r1[j]; rnew[i] = q; }
+      }
+      if (t > 0) memcpy(rt + (size_t)m * (t - 1), rnew, sizeof(double) * m);
+      else { /* :292-299: a_0 = a1 + P1 * r_{-1} */
+        for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += mod->P1[i + m * j] * rnew[j]; at[i] = mod->a1[i] + s; }
+      }
+    }
+    for (int t = 0; t < n - 1; t++) {
+      double RR[ORC_MAXM * ORC_MAXM];
+      compute_RR(mod->R + (size_t)m * mod->k * (t * mod->Rtv), m, mod->k, RR);
+      const double *Tt = mod->T + (size_t)m * m * (t * mod->Ttv), *Cv = mod->C + (size_t)m * (t * mod->Ctv);
+      for (int i = 0; i < m; i++) {
+        double s = 0, q = 0;
+        for (int j = 0; j < m; j++) { s += Tt[i + m * j] * at[j + (size_t)m * t]; q += RR[i + m * j] * rt[j + (size_t)m * t]; }
+        at[i + (size_t)m * (t + 1)] = Cv[i] + s + q;
+      }
+    }
+  }
+  free(vt); free(ZF); free(Kt); free(Zz); free(nob); free(rt);
+  return ok;
+}
+
+/* model_ssm_mlg.cpp:310-396 */
+static int mlg_smoother_ccov(const orc_mng_model *mod, const double *gy, const double *gH, double *at, double *Pt, double *ccov) {
+  const int n = mod->n, m = mod->m, p = mod->p, mm = m * m;
+  double *vt = (double *)calloc((size_t)p * n, sizeof(double)), *ZF = (double *)calloc((size_t)m * p * n, sizeof(double));
+  double *Kt = (double *)calloc((size_t)m * p * n, sizeof(double)), *Zz = (double *)calloc((size_t)p * m * n, sizeof(double));
+  int *nob = (int *)calloc(n, sizeof(int));
+  double ld;
+  int ok = 1;
+  memcpy(at, mod->a1, sizeof(double) * m); memcpy(Pt, mod->P1, sizeof(double) * mm);
+  for (int t = 0; t < n && ok; t++) {
+    ok = mlg_step(mod, gy, gH, t, at + (size_t)m * t, Pt + (size_t)mm * t, at + (size_t)m * (t + 1), Pt + (size_t)mm * (t + 1),
+                  vt + (size_t)p * t, ZF + (size_t)m * p * t, Kt + (size_t)m * p * t, Zz + (size_t)p * m * t, &nob[t], &ld);
+    memcpy(ccov + (size_t)mm * t, Pt + (size_t)mm * (t + 1), sizeof(double) * mm);
+  }
+  if (ok) {
+    double rt[ORC_MAXM] = {0}, Nt[ORC_MAXM * ORC_MAXM] = {0};
+    double L[ORC_MAXM * ORC_MAXM], A[ORC_MAXM * ORC_MAXM], B[ORC_MAXM * ORC_MAXM], Cm[ORC_MAXM * ORC_MAXM], rn[ORC_MAXM];
+    for (int t = n - 1; t >= 0; t--) {
+      const double *Tt = mod->T + (size_t)mm * (t * mod->Ttv);
+      double *Ptt = Pt + (size_t)mm * t, *cc = ccov + (size_t)mm * t;
+      mat_mul(Nt, cc, m, m, m, A);
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) A[i + m * j] = (i == j ? 1.0 : 0.0) - A[i + m * j];
+      if (nob[t] > 0) {
+        mat_mul(Kt + (size_t)m * p * t, Zz + (size_t)p * m * t, m, p, m, B);
+        for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) B[i + m * j] = (i == j ? 1.0 : 0.0) - B[i + m * j];
+        mat_mul(Tt, B, m, m, m, L);
+        mat_mul_bt(Ptt, L, m, m, m, B); mat_mul(B, A, m, m, m, Cm); memcpy(cc, Cm, sizeof(double) * mm);
+        for (int i = 0; i < m; i++) {
+          double s = 0, q = 0;
+          for (int j = 0; j < p; j++) s += ZF[i + m * j + (size_t)m * p * t] * vt[j + (size_t)p * t];
+          for (int j = 0; j < m; j++) q += L[j + m * i] * rt[j];
+          rn[i] = s + q;
+        }
+        memcpy(rt, rn, sizeof(double) * m);
+        mat_mul_at(L, Nt, m, m, m, A); mat_mul(A, L, m, m, m, B);
+        mat_mul(ZF + (size_t)m * p * t, Zz + (size_t)p * m * t, m, p, m, A); /* ZFinv * Zt */
+        for (int q = 0; q < mm; q++) Nt[q] = A[q] + B[q];
+      } else {
+        mat_mul_bt(Ptt, Tt, m, m, m, B); mat_mul(B, A, m, m, m, Cm); memcpy(cc, Cm, sizeof(double) * mm);
+        for (int i = 0; i < m; i++) { double q = 0; for (int j = 0; j < m; j++) q += Tt[j + m * i] * rt[j]; rn[i] = q; }
+        memcpy(rt, rn, sizeof(double) * m);
+        mat_mul_at(Tt, Nt, m, m, m, A); mat_mul(A, Tt, m, m, m, B); memcpy(Nt, B, sizeof(double) * mm);
+      }
+      symmatu(Nt, m);
+      for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Ptt[i + m * j] * rt[j]; at[i + (size_t)m * t] += s; }
+      mat_mul(Ptt, Nt, m, m, m, A); mat_mul(A, Ptt, m, m, m, B); symmatu(B, m);
+      for (int q = 0; q < mm; q++) Ptt[q] -= B[q];
+    }
+    memset(ccov + (size_t)mm * n, 0, sizeof(double) * mm);
+  }
+  free(vt); free(ZF); free(Kt); free(Zz); free(nob);
+  return ok;
+}
+
+static void mng_laplace_iter(const orc_mng_model *mod, const double *signal, double *ay, double *aH) { /* :269-315 */
+  const int p = mod->p;
+  for (int t = 0; t < mod->n; t++)
+    for (int i = 0; i < p; i++) {
+      size_t q = i + (size_t)p * t;
+      double y = mod->y[q], sg = signal[q], u = mod->u[q], phi = mod->phi[i], HH = 0, yy = 0;
+      switch (mod->distribution[i]) {
+      case ORC_POISSON: HH = 1.0 / (exp(sg) * u); yy = y * HH + sg - 1.0; break;
+      case ORC_BINOMIAL: { double e = exp(sg); HH = (1.0 + e) * (1.0 + e) / (u * e); yy = y * HH + sg - 1.0 - e; } break;
+      case ORC_NEGBIN: { double e = exp(sg) * u; HH = (phi + e) * (phi + e) / (phi * e * (y + phi)); yy = sg + (phi + e) * (y - e) / ((y + phi) * e); } break;
+      case ORC_GAMMA: { double e = exp(sg) * u; HH = e / (y * phi); yy = sg - e / y + 1; } break;
+      case ORC_GAUSSIAN: HH = phi * phi; yy = y; break;
+      }
+      ay[q] = yy; aH[q] = sqrt(HH);
+    }
+}
+
+static void mng_update_scales(const orc_mng_model *mod, orc_mng_setup *su) { /* :218-255 */
+  const int p = mod->p;
+  for (int t = 0; t < mod->n; t++) {
+    su->scales[t] = 0.0;
+    for (int i = 0; i < p; i++) {
+      size_t q = i + (size_t)p * t;
+      double y = mod->y[q];
+      if (!isfinite(y)) continue;
+      double md = su->mode[q], u = mod->u[q], phi = mod->phi[i];
+      switch (mod->distribution[i]) {
+      case ORC_POISSON: su->scales[t] += y * md - u * exp(md); break;
+      case ORC_BINOMIAL: su->scales[t] += y * md - u * log1p(exp(md)); break;
+      case ORC_NEGBIN: su->scales[t] += y * md - (y + phi) * log(phi + u * exp(md)); break;
+      case ORC_GAMMA: su->scales[t] += -phi * md - (y * phi * exp(-md) / u); break;
+      case ORC_GAUSSIAN: su->scales[t] += -0.5 * pow((y - md) / phi, 2.0); break;
+      }
+      su->scales[t] += 0.5 * pow((su->approx_y[q] - md) / su->approx_H[q], 2.0);
+    }
+  }
+}
+
+int orc_mng_psi_setup(const orc_mng_model *mod, const double *is_mode, orc_mng_setup *su) {
+  const int n = mod->n, m = mod->m, p = mod->p;
+  double *sm = (double *)malloc(sizeof(double) * m * (n + 1));
+  int ok = 1;
+  if (is_mode) { /* approximate_for_is :117-133 */
+    memcpy(su->mode, is_mode, sizeof(double) * p * n);
+    mng_laplace_iter(mod, su->mode, su->approx_y, su->approx_H);
+    mng_update_scales(mod, su);
+    su->approx_loglik = 0.0; su->laplace_iters = 0;
+  } else { /* approximate() :73-114 */
+    memcpy(su->mode, mod->initial_mode, sizeof(double) * p * n);
+    int it = 0; double diff = mod->conv_tol + 1;
+    double *nm = (double *)malloc(sizeof(double) * p * n);
+    while (it < mod->max_iter && diff > mod->conv_tol) {
+      it++;
+      mng_laplace_iter(mod, su->mode, su->approx_y, su->approx_H);
+      ok = mlg_fast_smoother(mod, su->approx_y, su->approx_H, sm);
+      if (!ok) break;
+      for (int t = 0; t < n; t++) {
+        const double *Zt = MZ(t), *Dt = MD(t);
+        for (int j = 0; j < p; j++) { double s = 0; for (int c = 0; c < m; c++) s += Zt[j + p * c] * sm[c + (size_t)m * t]; nm[j + (size_t)p * t] = Dt[j] + s; }
+      }
+      diff = 0; for (size_t q = 0; q < (size_t)p * n; q++) diff += (nm[q] - su->mode[q]) * (nm[q] - su->mode[q]);
+      diff /= (double)n * p;
+      memcpy(su->mode, nm, sizeof(double) * p * n);
+    }
+    free(nm);
+    su->laplace_iters = it;
+    double gll = orc_mlg_loglik(mod, su->approx_y, su->approx_H);
+    mng_update_scales(mod, su);
+    double ct = orc_mng_const_term(mod); /* compute_const_term :318-355 */
+    for (int i = 0; i < p; i++) for (int t = 0; t < n; t++) if (isfinite(mod->y[i + (size_t)p * t])) ct -= norm_log_const(su->approx_H[i + (size_t)p * t]);
+    double ssc = 0; for (int t = 0; t < n; t++) ssc += su->scales[t];
+    su->approx_loglik = gll + ct + ssc;
+  }
+  if (ok) ok = mlg_smoother_ccov(mod, su->approx_y, su->approx_H, su->alphahat, su->Vt, su->Ct);
+  if (ok) orc_conditional_cov(su->Vt, su->Ct, m, n + 1);
+  free(sm);
+  return ok ? 0 : -1;
+}

@@ -165,6 +165,43 @@ typedef struct {
 int orc_is_correction(const orc_is_job *job, double *weights, double *loglik_out,
                       double *alpha_out, double *alphahat, double *Vt);
 
+/* ---- multivariate non-Gaussian models (ssm_mng, src/model_ssm_mng.cpp) ----
+ * y p x n (the reference transposes the R n x p matrix on entry, model_ssm_mng.cpp:8), Z p x m x (1|n),
+ * D p x (1|n), u p x n, phi[p], distribution[p] in 1..5, initial_mode p x n. */
+typedef struct {
+  int n, m, k, p;
+  int Ztv, Ttv, Rtv, Dtv, Ctv;
+  const int *distribution;
+  const double *y, *Z, *T, *R, *a1, *P1, *D, *C, *u, *phi, *initial_mode;
+  int max_iter;
+  double conv_tol;
+} orc_mng_model;
+
+typedef struct {
+  int n, m, p;
+  double *approx_y, *approx_H; /* p x n each (H = diagonal sd) */
+  double *mode;                /* p x n */
+  double *scales;              /* n */
+  double approx_loglik;
+  double *alphahat, *Vt, *Ct;
+  int laplace_iters;
+} orc_mng_setup;
+
+orc_mng_setup *orc_mng_setup_alloc(int n, int m, int p);
+void orc_mng_setup_free(orc_mng_setup *s);
+/* src/model_ssm_mng.cpp:562-668 */
+double orc_mng_bsf_filter(const orc_mng_model *mod, unsigned N, const orc_rng *rng,
+                          double *alpha, double *weights, unsigned *indices);
+/* approximate() :73-114 / approximate_for_is :117-133 + :158-170 + mlg smoother_ccov + conditional_cov */
+int orc_mng_psi_setup(const orc_mng_model *mod, const double *is_mode, orc_mng_setup *out);
+/* src/model_ssm_mng.cpp:461-559 */
+double orc_mng_psi_filter(const orc_mng_model *mod, const orc_mng_setup *su, unsigned N, const orc_rng *rng,
+                          double *alpha, double *weights, unsigned *indices);
+/* multivariate Kalman log-likelihood of the approximating model: src/model_ssm_mlg.cpp:90-137 */
+double orc_mlg_loglik(const orc_mng_model *mod, const double *gy, const double *gH);
+/* state-independent constants over finite y: model_ssm_mng.cpp:632-666 */
+double orc_mng_const_term(const orc_mng_model *mod);
+
 #ifdef __cplusplus
 }
 #endif

@@ -270,3 +270,87 @@ def is_correction(arrs, nsim, seed, method, counts, modes=None, approx_loglik=No
     Vt = np.zeros((m, m, n + 1), order="F") if output_type == 2 else None
     L.orc_is_correction(C.byref(job), _p(weights), _p(ll), _p(alpha), _p(alphahat), _p(Vt))
     return dict(weights=weights, loglik=ll, alpha=alpha, alphahat=alphahat, Vt=Vt)
+
+
+# ------------------------------------------------------------------ ssm_mng
+class OrcMng(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("n", "m", "k", "p", "Ztv", "Ttv", "Rtv", "Dtv", "Ctv")] + \
+               [("distribution", C.POINTER(C.c_int))] + \
+               [(k, c_double_p) for k in ("y", "Z", "T", "R", "a1", "P1", "D", "C", "u", "phi", "initial_mode")] + \
+               [("max_iter", C.c_int), ("conv_tol", C.c_double)]
+
+
+class OrcMngSetup(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("p", C.c_int), ("approx_y", c_double_p), ("approx_H", c_double_p),
+                ("mode", c_double_p), ("scales", c_double_p), ("approx_loglik", C.c_double), ("alphahat", c_double_p),
+                ("Vt", c_double_p), ("Ct", c_double_p), ("laplace_iters", C.c_int)]
+
+
+def pack_mng(arr: dict):
+    """dict from bssm_amd.models.model_arrays (ssm_mng) -> OrcMng with the p-major arrays the reference works on"""
+    s = OrcMng()
+    for k in ("n", "m", "k", "p", "Ztv", "Ttv", "Rtv", "Dtv", "Ctv", "max_iter"):
+        setattr(s, k, int(arr[k]))
+    s.conv_tol = float(arr["conv_tol"])
+    keep = []
+    dist = np.ascontiguousarray(arr["distribution_p"], dtype=np.int32)
+    keep.append(dist)
+    s.distribution = dist.ctypes.data_as(C.POINTER(C.c_int))
+    conv = dict(y=np.asfortranarray(arr["y"].T), u=np.asfortranarray(arr["u"].T),
+                initial_mode=np.asfortranarray(arr["initial_mode"].T), phi=np.ascontiguousarray(arr["phi_p"]))
+    for k in ("Z", "T", "R", "a1", "P1", "D", "C"):
+        conv[k] = np.asfortranarray(arr[k], dtype=np.float64)
+    for k, a in conv.items():
+        a = np.asfortranarray(a, dtype=np.float64)
+        keep.append(a)
+        setattr(s, k, _p(a))
+    return s, keep
+
+
+def _mng_lib():
+    L = lib()
+    L.orc_mng_bsf_filter.restype = C.c_double
+    L.orc_mng_psi_filter.restype = C.c_double
+    L.orc_mng_const_term.restype = C.c_double
+    L.orc_mlg_loglik.restype = C.c_double
+    L.orc_mng_setup_alloc.restype = C.POINTER(OrcMngSetup)
+    return L
+
+
+def mng_bsf_filter(arr: dict, nsim: int, seed=1, stream=0):
+    L = _mng_lib()
+    mod, keep = pack_mng(arr)
+    rng, _ = make_rng(seed, stream)
+    n, m = arr["n"], arr["m"]
+    alpha = np.zeros((m, n + 1, nsim), order="F"); weights = np.zeros((nsim, n + 1), order="F")
+    indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+    ll = L.orc_mng_bsf_filter(C.byref(mod), C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights), indices.ctypes.data_as(c_uint_p))
+    return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices)
+
+
+def mng_psi_setup(arr: dict, is_mode=None):
+    """is_mode: p x n (mode_storage layout) or None"""
+    L = _mng_lib()
+    mod, keep = pack_mng(arr)
+    n, m, p = arr["n"], arr["m"], arr["p"]
+    su = L.orc_mng_setup_alloc(n, m, p)
+    mode = None if is_mode is None else np.asfortranarray(np.asarray(is_mode, dtype=np.float64).reshape((p, n), order="F"))
+    rc = L.orc_mng_psi_setup(C.byref(mod), _p(mode), su)
+    s = su.contents
+    g = lambda ptr, shape: np.ctypeslib.as_array(ptr, (int(np.prod(shape)),)).copy().reshape(shape, order="F")
+    return dict(approx_y=g(s.approx_y, (p, n)), approx_H=g(s.approx_H, (p, n)), mode=g(s.mode, (p, n)), scales=g(s.scales, (n,)),
+                approx_loglik=s.approx_loglik, alphahat=g(s.alphahat, (m, n + 1)), Vt=g(s.Vt, (m, m, n + 1)),
+                Ct=g(s.Ct, (m, m, n + 1)), iterations=s.laplace_iters, rc=rc, _handle=su)
+
+
+def mng_psi_filter(arr: dict, nsim: int, seed=1, stream=0, is_mode=None, setup=None):
+    L = _mng_lib()
+    mod, keep = pack_mng(arr)
+    su = setup if setup is not None else mng_psi_setup(arr, is_mode)
+    rng, _ = make_rng(seed, stream)
+    n, m = arr["n"], arr["m"]
+    alpha = np.zeros((m, n + 1, nsim), order="F"); weights = np.zeros((nsim, n + 1), order="F")
+    indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+    ll = L.orc_mng_psi_filter(C.byref(mod), su["_handle"], C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights),
+                              indices.ctypes.data_as(c_uint_p))
+    return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices, setup=su)

@@ -75,3 +75,29 @@ def small_zoo():
     yl = np.cumsum(rng.normal(0, 0.3, 30)) + rng.normal(0, 0.5, 30); yl[10] = np.nan
     zoo["gaussian_ar1"] = M.ar1_lg(yl, rho=0.9, sigma=0.3, mu=0.2, sd_y=0.5)
     return zoo
+
+
+def mng_zoo():
+    """ssm_mng models: mixed distributions, missing values (single series and whole rows), time-varying Z/D."""
+    rng = np.random.default_rng(8)
+    zoo = {}
+    n, p, m = 30, 3, 4
+    Z = rng.normal(0, 0.5, (p, m)); T = 0.9 * np.linalg.qr(rng.normal(size=(m, m)))[0]; R = 0.2 * np.eye(m)[:, :3]
+    y = np.column_stack([rng.poisson(3, n), rng.negative_binomial(5, 0.5, n), rng.normal(0, 1, n)]).astype(float)
+    y[4, 0] = np.nan; y[7, :2] = np.nan
+    zoo["mixed_m4_p3"] = M.ssm_mng(y, Z, T, R, a1=np.zeros(m), P1=0.3 * np.eye(m),
+                                   distribution=["poisson", "negative binomial", "gaussian"], phi=[1, 5, 0.7],
+                                   u=np.abs(rng.normal(1, 0.1, (n, p))) + 0.5)
+    n, p, m = 24, 2, 2
+    Zt = rng.normal(0, 0.6, (p, m, n)); Dt = 0.2 * rng.normal(size=(p, n))
+    y = np.column_stack([rng.binomial(5, 0.4, n), rng.gamma(2.0, 1.0, n)]).astype(float); y[10, :] = np.nan
+    zoo["tv_binom_gamma"] = M.ssm_mng(y, Zt, np.array([[0.9, 0.1], [0.0, 0.7]]), np.diag([0.3, 0.2]), a1=[0.2, 0.1],
+                                      P1=np.diag([0.4, 0.3]), distribution=["binomial", "gamma"], phi=[1, 2.5],
+                                      u=np.column_stack([np.full(n, 5.0), np.full(n, 1.3)]), D=Dt)
+    n, p, m = 20, 4, 8   # the BASELINE config shape (m = 8, p = 4) at small T
+    Q = np.linalg.qr(rng.normal(size=(m, m)))[0]
+    Z = rng.normal(0, 0.5, (p, m))
+    y = np.column_stack([rng.poisson(2, n), rng.poisson(4, n), rng.negative_binomial(5, 0.6, n), rng.normal(0, 0.8, n)]).astype(float)
+    zoo["c4_m8_p4"] = M.ssm_mng(y, Z, 0.95 * Q, 0.1 * np.eye(m), a1=np.zeros(m), P1=0.05 * np.eye(m),
+                                distribution=["poisson", "poisson", "negative binomial", "gaussian"], phi=[1, 1, 5, 0.5])
+    return zoo

@@ -1,0 +1,57 @@
+"""GPU parity of the multivariate non-Gaussian model path (ssm_mng, src/model_ssm_mng.cpp) against the oracle."""
+import numpy as np
+import pytest
+
+from bssm_amd import filters as F
+from bssm_amd import models as M
+from models_zoo import mng_zoo
+
+pytestmark = pytest.mark.gpu
+ZOO = mng_zoo()
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+@pytest.mark.parametrize("name", sorted(ZOO))
+@pytest.mark.parametrize("N", [20, 700])
+def test_mng_bootstrap_filter(oracle, monkeypatch, name, N, path):
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    model = ZOO[name]
+    out = F.bootstrap_filter(model, N, seed=6, return_indices=True)
+    ref = oracle.mng_bsf_filter(M.model_arrays(model), N, seed=6)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-9
+    at, att, Pt, Ptt = oracle.filter_summary(ref["alpha"], ref["weights"])
+    assert _rel(out["att"], att.T) <= 1e-9 and _rel(out["Ptt"], Ptt) <= 1e-8
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+@pytest.mark.parametrize("name", sorted(ZOO))
+def test_mng_psi_smoother(oracle, monkeypatch, name, path):
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    model = ZOO[name]
+    n = model.n
+    out = F.particle_smoother(model, 64, method="psi", seed=2, return_indices=True)
+    ref = oracle.mng_psi_filter(M.model_arrays(model), 64, seed=2)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
+    mean, cov = oracle.summary(sm)
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8 and _rel(out["Vt"], cov[:, :, :n]) <= 1e-7
+
+
+def test_mng_loglik_and_setup(oracle):
+    model = ZOO["mixed_m4_p3"]
+    arr = M.model_arrays(model)
+    so, sp = oracle.mng_psi_setup(arr), F.psi_setup(model)
+    for k in ("approx_y", "approx_H", "mode", "scales", "alphahat", "Vt", "Ct"):
+        ok = np.isfinite(so[k])
+        assert np.allclose(so[k][ok], sp[k][ok], rtol=1e-10, atol=1e-12), k
+    assert np.isclose(so["approx_loglik"], sp["approx_loglik"], rtol=1e-12)
+    assert abs(F.logLik(model, 50, method="bsf", seed=4) - oracle.mng_bsf_filter(arr, 50, seed=4)["logLik"]) <= 1e-9 * model.n
+    assert abs(F.logLik(model, 50, method="psi", seed=4) - oracle.mng_psi_filter(arr, 50, seed=4)["logLik"]) <= 1e-9 * model.n
