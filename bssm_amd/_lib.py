@@ -26,6 +26,24 @@ class UngModel(C.Structure):
                [("p", C.c_int32), ("distribution_p", C.POINTER(C.c_int32)), ("phi_p", c_double_p)]
 
 
+class FnModel(C.Structure):
+    _fields_ = [("model_id", C.c_int32), ("n", C.c_int32), ("y", c_double_p), ("theta", c_double_p), ("n_theta", C.c_int32),
+                ("known_params", c_double_p), ("n_known", C.c_int32), ("x0", C.c_double), ("positive", C.c_int32),
+                ("L", C.c_int32)]
+
+
+def pack_fn_model(model, L=None):
+    s = FnModel()
+    y = np.ascontiguousarray(model["y"], dtype=np.float64)
+    th = np.ascontiguousarray(model["theta"], dtype=np.float64)
+    kp = np.ascontiguousarray(model.get("known_params", np.zeros(0)), dtype=np.float64)
+    s.model_id, s.n, s.y, s.theta, s.n_theta = int(model["model_id"]), y.size, dptr(y), dptr(th), th.size
+    s.known_params, s.n_known = (dptr(kp) if kp.size else None), kp.size
+    s.x0, s.positive = float(model.get("x0", 0.0)), int(bool(model.get("positive", False)))
+    s.L = int(model.get("L", 0) if L is None else L)
+    return s, [y, th, kp]
+
+
 class FilterOut(C.Structure):
     _fields_ = [(k, c_double_p) for k in ("at", "att", "Pt", "Ptt", "alphahat", "Vt", "weights", "alpha")] + \
                [("indices", c_u32_p), ("logLik", C.c_double)]

@@ -15,6 +15,7 @@
 #include "../../include/bssm_amd.h"
 #include "host_model.h"
 #include "pf_device.h"
+#include "pf_functors.h"
 #include "pf_kernels.h"
 
 namespace {
@@ -72,7 +73,7 @@ void parallel_for(int count, int threads, F fn) {
 // ------------------------------------------------------------------ a batch of filters on the device
 struct DeviceBatch {
   bssm::FilterBatch fb{};
-  DevBuf mats, obs, init, hist, indices, weights, loglik, dead, ws;
+  DevBuf mats, obs, init, hist, indices, weights, loglik, dead, ws, fparbuf;
   bssm::GridWorkspace gws{};
   bool use_grid = false;
   std::vector<double> const_terms;  // per filter, added to the device log-likelihood on the host
@@ -131,6 +132,15 @@ struct DeviceBatch {
     return BSSM_OK;
   }
 
+  // built-in functor parameter blocks, one FP_SIZE block per filter (or one shared block: stride 0)
+  int set_fpar(const std::vector<double>& fp) {
+    HIP_TRY(fparbuf.alloc(fp.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(fparbuf.p, fp.data(), fparbuf.bytes, hipMemcpyHostToDevice));
+    fb.fpar = fparbuf.as<double>();
+    fb.fpar_fstride = fp.size() > (size_t)bssm::FP_SIZE ? bssm::FP_SIZE : 0;
+    return BSSM_OK;
+  }
+
   int run(uint32_t seed, uint32_t stream0, hipStream_t st, bssm::StepTiming* timing = nullptr) {
     fb.seed = seed; fb.stream0 = stream0;
     if (use_grid) {
@@ -175,6 +185,9 @@ void transpose_to(const std::vector<double>& src, int rows, int cols, double* ds
   for (int j = 0; j < cols; j++) for (int i = 0; i < rows; i++) dst[j + (size_t)cols * i] = src[i + (size_t)rows * j];
 }
 
+int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<double>* fpar, int n, int m, int k, int p, int N,
+               bool psi, bool smoother, uint32_t seed, double base_ll, bssm_filter_out* out);
+
 // one filter, full outputs: shared by bsf / bsf_smoother / psi_smoother
 int run_single_filter(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, bool psi, bool smoother,
                       bssm_filter_out* out) {
@@ -200,9 +213,16 @@ int run_single_filter(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
     bssm::build_bsf_tables(hm, MP, bssm::pad_dim(hm.k), &tabs[0]);
     base_ll = bssm::const_term(hm);  // src/model_ssm_ung.cpp:690-710
   }
+  return run_tables(tabs, nullptr, n, m, hm.k, hm.p, N, psi, smoother, seed, base_ll, out);
+}
+
+// one filter from prepared tables, full outputs (+ optional built-in functor parameters)
+int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<double>* fpar, int n, int m, int k, int p, int N,
+               bool psi, bool smoother, uint32_t seed, double base_ll, bssm_filter_out* out) {
   DeviceBatch db;
-  int rc = db.upload(tabs, n, m, hm.k, hm.p, N, psi ? 1 : 0, true, 0);
+  int rc = db.upload(tabs, n, m, k, p, N, psi ? 1 : 0, true, 0);
   if (rc) return rc;
+  if (fpar) { if ((rc = db.set_fpar(*fpar))) return rc; }
   hipStream_t st = nullptr;
   if ((rc = db.run(seed, 0, st))) return rc;
   double ll = 0;
@@ -293,6 +313,115 @@ int bssm_bsf_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
 int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int model_type, bssm_filter_out* out) {
   if (!is_gaussian_type_ok(0, model_type)) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
   return run_single_filter(model, nsim, seed, true, true, out);
+}
+
+// ---------------------------------------------------------------- built-in non-linear / SDE models
+namespace {
+int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector<double>* fpar, int* m_out, int* k_out) {
+  if (!mod || !mod->y || !mod->theta) return fail(BSSM_ERR_INVALID, "model, y, theta must be non-NULL");
+  const int id = mod->model_id, n = mod->n;
+  if (id < bssm::FN_NLG_GROWTH || id > bssm::FN_SDE_POISSON_OU)
+    return fail(BSSM_ERR_UNSUPPORTED, "unknown built-in model id: arbitrary user snippets need a device JIT (SURVEY.md 8f rank 4)");
+  if (n < 1) return fail(BSSM_ERR_INVALID, "n must be positive");
+  const int need_theta[] = {0, 3, 4, 2, 1, 3, 3}, need_known[] = {0, 6, 0, 0, 0, 0, 0};
+  if (mod->n_theta < need_theta[id] || mod->n_known < need_known[id]) return fail(BSSM_ERR_INVALID, "theta / known_params too short for this model");
+  if (mod->n_theta > 8 || mod->n_known > 8) return fail(BSSM_ERR_INVALID, "at most 8 theta / known_params");
+  const int m = id == bssm::FN_NLG_GROWTH ? 2 : 1, MP = m;
+  *m_out = m; *k_out = m;
+  const double* th = mod->theta;
+  const double* kp = mod->known_params;
+  fpar->assign(bssm::FP_SIZE, 0.0);
+  double* fp = fpar->data();
+  fp[bssm::FP_ID] = id; fp[bssm::FP_L] = mod->L; fp[bssm::FP_POS] = mod->positive ? 1.0 : 0.0; fp[bssm::FP_X0] = mod->x0;
+  for (int q = 0; q < mod->n_theta; q++) fp[bssm::FP_THETA + q] = th[q];
+  for (int q = 0; q < mod->n_known; q++) fp[bssm::FP_KNOWN + q] = kp[q];
+  double a1[2] = {0, 0}, P1[4] = {0, 0, 0, 0}, H = 1.0;
+  switch (id) {  // R/cpp_example_models.R: a1_fn, P1_fn, H_fn, R_fn of each snippet
+    case bssm::FN_NLG_GROWTH: a1[0] = kp[2]; a1[1] = kp[3]; P1[0] = kp[4]; P1[3] = kp[5]; H = std::exp(th[0]);
+      fp[bssm::FP_R] = std::exp(th[1]); fp[bssm::FP_R + 1] = std::exp(th[2]); break;
+    case bssm::FN_NLG_AR_EXP: a1[0] = th[0]; P1[0] = std::pow(std::exp(th[2]), 2) / (1 - std::pow(th[1], 2)); H = std::exp(th[3]);
+      fp[bssm::FP_R] = std::exp(th[2]); break;
+    case bssm::FN_NLG_SIN_EXP: a1[0] = 0; P1[0] = 1; H = std::exp(th[0]); fp[bssm::FP_R] = std::exp(th[1]); break;
+    case bssm::FN_NLG_LINEAR_GAUSSIAN: a1[0] = 0; P1[0] = 1; H = std::exp(th[0]); fp[bssm::FP_R] = 1.0; break;
+    case bssm::FN_SDE_GBM: H = th[2]; if (mod->L < 0 || mod->L > 20) return fail(BSSM_ERR_INVALID, "L must be in 0..20"); break;
+    case bssm::FN_SDE_POISSON_OU: fp[bssm::FP_R] = std::exp(th[2]); if (mod->L < 0 || mod->L > 20) return fail(BSSM_ERR_INVALID, "L must be in 0..20"); break;
+  }
+  fp[bssm::FP_H] = H;
+  fp[bssm::FP_LOGC] = -0.5 * (std::log(2.0 * 3.14159265358979323846) + 2.0 * std::log(H));
+  // tables: no linear transition operands; one observation series carrying y (and lgamma(y + 1) for the Poisson model)
+  ft->MP = MP; ft->KP = MP; ft->mats_tstride = 0;
+  ft->mats.assign((size_t)MP * MP * 2 + MP, 0.0);
+  const int stride = bssm::ROW_HDR + bssm::SER_HDR + MP;
+  ft->obs.assign((size_t)n * stride, 0.0);
+  for (int t = 0; t < n; t++) {
+    double* row = ft->obs.data() + (size_t)t * stride;
+    const double y = mod->y[t];
+    if (!std::isfinite(y)) continue;
+    row[bssm::RH_FLAG] = 1.0;
+    double* ob = row + bssm::ROW_HDR;
+    ob[bssm::OB_FLAG] = 1.0; ob[bssm::OB_Y] = y;
+    ob[bssm::OB_AUX] = id == bssm::FN_SDE_POISSON_OU ? std::lgamma(y + 1.0) : 0.0;
+  }
+  // initial factor: psd_chol(P1) (src/model_ssm_nlg.cpp:1072); the shipped P1 are diagonal
+  ft->init.assign((size_t)MP + (size_t)MP * MP, 0.0);
+  for (int j = 0; j < m; j++) {
+    ft->init[j] = a1[j];
+    const double d = P1[j + m * j];
+    double dmax = P1[0];
+    for (int q = 1; q < m; q++) dmax = std::max(dmax, P1[q + m * q]);
+    const double thr = std::max(2.220446049250313e-16, 2.220446049250313e-16 * m * dmax);
+    ft->init[MP + j + MP * j] = d > thr ? std::sqrt(d) : 0.0;
+  }
+  return BSSM_OK;
+}
+
+int run_functor(const bssm_fn_model* mod, uint32_t nsim, uint32_t seed, bool smoother, bssm_filter_out* out) {
+  if (!out) return fail(BSSM_ERR_INVALID, "out is NULL");
+  if (nsim < 1) return fail(BSSM_ERR_INVALID, "nsim must be positive");
+  std::vector<bssm::FilterTables> tabs(1);
+  std::vector<double> fpar;
+  int m = 1, k = 1;
+  const int rc = functor_tables(mod, &tabs[0], &fpar, &m, &k);
+  if (rc) return rc;
+  if (!have_device()) return no_device();
+  return run_tables(tabs, &fpar, mod->n, m, k, 1, (int)nsim, false, smoother, seed, 0.0, out);
+}
+}  // namespace
+
+int bssm_bsf_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
+  if (model && model->model_id >= bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_nlg model id");
+  return run_functor(model, nsim, seed, false, out);
+}
+int bssm_bsf_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
+  if (model && model->model_id >= bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_nlg model id");
+  return run_functor(model, nsim, seed, true, out);
+}
+int bssm_bsf_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
+  if (model && model->model_id < bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");
+  return run_functor(model, nsim, seed, false, out);
+}
+int bssm_bsf_smoother_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
+  if (model && model->model_id < bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");
+  return run_functor(model, nsim, seed, true, out);
+}
+int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, uint32_t stream0, uint32_t n_rep, double* loglik) {
+  if (!loglik || n_rep < 1 || nsim < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  std::vector<bssm::FilterTables> tabs(1);
+  std::vector<double> fpar;
+  int m = 1, k = 1;
+  int rc = functor_tables(model, &tabs[0], &fpar, &m, &k);
+  if (rc) return rc;
+  if (!have_device()) return no_device();
+  std::vector<bssm::FilterTables> all(n_rep, tabs[0]);
+  DeviceBatch db;
+  if ((rc = db.upload(all, model->n, m, k, 1, (int)nsim, 0, false, 0))) return rc;
+  if ((rc = db.set_fpar(fpar))) return rc;
+  db.const_terms.assign(n_rep, 0.0);
+  if ((rc = db.run(seed, stream0, nullptr))) return rc;
+  if ((rc = db.fetch_loglik(nullptr, loglik))) return rc;
+  bool deg = false;
+  for (uint32_t r = 0; r < n_rep; r++) if (!std::isfinite(loglik[r])) { loglik[r] = -INFINITY; deg = true; }
+  return deg ? BSSM_WARN_DEGENERATE : BSSM_OK;
 }
 
 int bssm_psi_setup(const bssm_ung_model* model, const double* is_mode, double* approx_y, double* approx_H, double* mode,

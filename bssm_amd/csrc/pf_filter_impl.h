@@ -17,6 +17,7 @@
 // run to run and independent of the number of GPUs a batch is sharded over.
 #pragma once
 #include "pf_device.h"
+#include "pf_functors.h"
 #include "pf_kernels.h"
 
 namespace bssm {
@@ -92,7 +93,7 @@ __device__ __forceinline__ void initial_state(const double* __restrict__ ini, co
 constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the fp64 transcendental code
 // Particle i = r * NT + tid (r < PPT): consecutive lanes own consecutive particles, so LDS
 // accesses to the own slot are conflict-free and history stores are coalesced.
-template <int MP, int KP, int PPT>
+template <int MP, int KP, int PPT, bool FN = false>
 __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = NT >> 6;
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
   const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
   const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
+  const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
   const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP), m = b.m;
   const double dN = (double)N;
 
@@ -119,9 +121,14 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int i = r * NT + tid;
-    double z[MP], x[MP];
-    rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)i, z);
-    initial_state<MP>(ini, z, x);
+    double x[MP];
+    if constexpr (FN) {
+      functor_initial<MP>(fpar, ini, key, (uint32_t)i, x);
+    } else {
+      double z[MP];
+      rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)i, z);
+      initial_state<MP>(ini, z, x);
+    }
     if (i < N) {
 #pragma unroll
       for (int c = 0; c < MP; c++) {
@@ -129,7 +136,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
         if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1)) * m + c) * N + i] = x[c];
       }
     }
-    w[r] = (i < N) ? log_weight_of<MP>(b, obs, x) : -INFINITY;
+    w[r] = (i < N) ? (FN ? functor_log_weight<MP>(fpar, obs, x) : log_weight_of<MP>(b, obs, x)) : -INFINITY;
     __builtin_amdgcn_sched_barrier(0);  // keep the unrolled particles sequential: bounds live registers
   }
 
@@ -145,7 +152,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
     for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
     // stage this step's transition operands in LDS (every wave is past the previous transition here;
     // they become visible at barrier (2)/(3), before the transition after barrier (4))
-    if (t < n && (t == 0 || b.mats_tstride != 0)) {
+    if (!FN && t < n && (t == 0 || b.mats_tstride != 0)) {
       const double* __restrict__ src = mats + (size_t)t * b.mats_tstride;
       for (int q = tid; q < MS; q += NT) s_mats[q] = src[q];
     }
@@ -211,9 +218,14 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
-      double z[KP], x[MP];
-      rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
-      propagate<MP, KP>(mt, a[r], z, x);
+      double x[MP];
+      if constexpr (FN) {
+        functor_propagate<MP, KP>(fpar, key, (uint32_t)t, (uint32_t)i, a[r], x);
+      } else {
+        double z[KP];
+        rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
+        propagate<MP, KP>(mt, a[r], z, x);
+      }
       if (i < N) {
 #pragma unroll
         for (int c = 0; c < MP; c++) {
@@ -221,7 +233,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
           if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1) + (t + 1)) * m + c) * N + i] = x[c];
         }
       }
-      w[r] = (i < N) ? (t + 1 < n ? log_weight_of<MP>(b, ob, x) : 0.0) : -INFINITY;
+      w[r] = (i < N) ? (t + 1 < n ? (FN ? functor_log_weight<MP>(fpar, ob, x) : log_weight_of<MP>(b, ob, x)) : 0.0) : -INFINITY;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -244,6 +256,19 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
     case 8: kern = pf_wg_kernel<MP, KP, 8>; break;
     default:
       if constexpr (MP <= 2) kern = pf_wg_kernel<MP, KP, 16>; else return hipErrorInvalidValue;
+  }
+  if (b.fpar) {  // built-in non-linear / SDE functors: instantiated for the shapes the shipped models have
+    if constexpr (MP == KP && MP <= 2) {
+      switch (ppt) {
+        case 1: kern = pf_wg_kernel<MP, KP, 1, true>; break;
+        case 2: kern = pf_wg_kernel<MP, KP, 2, true>; break;
+        case 4: kern = pf_wg_kernel<MP, KP, 4, true>; break;
+        case 8: kern = pf_wg_kernel<MP, KP, 8, true>; break;
+        default: kern = pf_wg_kernel<MP, KP, 16, true>; break;
+      }
+    } else {
+      return hipErrorInvalidValue;
+    }
   }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -330,7 +355,7 @@ __device__ __forceinline__ int search16_lds(const double* a, int stride, int len
       ws.dbg[(size_t)t * 16 + (k)] = (long long)__builtin_readcyclecounter();                 \
   }
 
-template <int MP, int KP, int PPT, bool DBG = false>
+template <int MP, int KP, int PPT, bool DBG = false, bool FN = false>
 __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   __shared__ double s_Q[GRID_NT];      // inclusive prefix of scaled block sums
   __shared__ double s_iscale[GRID_NT];  // 1 / exp(max_b - M)
@@ -344,6 +369,7 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
   const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
+  const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
   const int base = pb * chunk;
   const int len = min(chunk, N - base);
   const int tn = t + 1;  // time index of the particles produced by this launch
@@ -357,9 +383,13 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int li = r * GRID_NT + tid, j = base + li;
-      double z[MP];
-      rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)j, z);
-      initial_state<MP>(ini, z, x[r]);
+      if constexpr (FN) {
+        functor_initial<MP>(fpar, ini, key, (uint32_t)j, x[r]);
+      } else {
+        double z[MP];
+        rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)j, z);
+        initial_state<MP>(ini, z, x[r]);
+      }
       if (li < len) {
 #pragma unroll
         for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[r][c];
@@ -371,7 +401,7 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
     const double pmax = (tid < B) ? part[2 * tid] : -INFINITY;
     const double psum = (tid < B) ? part[2 * tid + 1] : 0.0;
     // ... and draw this step's random numbers while they are in flight (PPT <= 2 keeps them in registers)
-    constexpr bool kEarlyRng = PPT <= 2;
+    constexpr bool kEarlyRng = PPT <= 2 && !FN;
     double u_pre[kEarlyRng ? PPT : 1], z_pre[kEarlyRng ? PPT : 1][KP];
     if constexpr (kEarlyRng) {
 #pragma unroll
@@ -466,7 +496,9 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
   #pragma unroll
         for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
         BSSM_STAMP(6)
-        if constexpr (kEarlyRng) {
+        if constexpr (FN) {
+          functor_propagate<MP, KP>(fpar, key, (uint32_t)t, (uint32_t)j, a, x[r]);
+        } else if constexpr (kEarlyRng) {
           propagate<MP, KP>(mt, a, z_pre[r], x[r]);
         } else {
           double z[KP];
@@ -488,7 +520,7 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
-    w[r] = (li < len) ? (have_obs ? log_weight_of<MP>(b, ob, x[r]) : 0.0) : -INFINITY;
+    w[r] = (li < len) ? (have_obs ? (FN ? functor_log_weight<MP>(fpar, ob, x[r]) : log_weight_of<MP>(b, ob, x[r])) : 0.0) : -INFINITY;
     mx = fmax(mx, w[r]);
   }
   BSSM_STAMP(8)
@@ -535,6 +567,18 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     default: kern = pf_grid_step<MP, KP, 8>; break;
   }
   if constexpr (MP == 4 && KP == 4) { if (ws.dbg && ppt == 1) kern = pf_grid_step<MP, KP, 1, true>; }
+  if (b.fpar) {
+    if constexpr (MP == KP && MP <= 2) {
+      switch (ppt) {
+        case 1: kern = pf_grid_step<MP, KP, 1, false, true>; break;
+        case 2: kern = pf_grid_step<MP, KP, 2, false, true>; break;
+        case 4: kern = pf_grid_step<MP, KP, 4, false, true>; break;
+        default: kern = pf_grid_step<MP, KP, 8, false, true>; break;
+      }
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.maxhist, 0, sizeof(double) * 2 * b.F * (b.n + 1), stream)) != hipSuccess) return e;  // maxhist + llinc

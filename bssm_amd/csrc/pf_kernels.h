@@ -26,6 +26,8 @@ struct FilterBatch {
   const double* obs; size_t obs_fstride;
   // [f][MP + MP*MP] : a1 then L (initial mean and lower factor)
   const double* init; size_t init_fstride;
+  // built-in non-linear / SDE functor parameters (pf_functors.h), [f][FP_SIZE]; null for the linear-state models
+  const double* fpar; size_t fpar_fstride;
   // outputs (any may be null)
   double* alpha_hist;   // [f][n+1][m][N]   particle-minor
   uint32_t* indices;    // [f][n][N]

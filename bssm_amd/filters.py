@@ -51,15 +51,53 @@ def _warn_if_degenerate(rc):
         warnings.warn("Particle filtering stopped prematurely due to nonfinite log-likelihood.")
 
 
-def bootstrap_filter(model: BssmModel, particles: int, seed: int | None = None, return_indices: bool = False):
+def _functor_filter(model: BssmModel, particles: int, seed: int, smoother: bool, L, return_indices: bool):
+    """ssm_nlg / ssm_sde bootstrap filter (R/bootstrap_filter.R:126-202) and bsf smoother (R/particle_smoother.R:193-291)."""
+    sde = model.inherits("ssm_sde")
+    if sde:
+        if L is None:
+            raise ValueError("argument 'L' is missing")
+        L = check_intmax(L, "L", max=20)
+    smod, keep = _lib.pack_fn_model(model, L)
+    n = model.n
+    m = 2 if int(model["model_id"]) == 1 else 1
+    out = _lib.FilterOut()
+    at, att = _alloc((n + 1, m)), _alloc((n, m))
+    Pt, Ptt = _alloc((m, m, n + 1)), _alloc((m, m, n))
+    weights, alpha = _alloc((particles, n + 1)), _alloc((m, n + 1, particles))
+    indices = np.zeros((particles, n), dtype=np.uint32, order="F") if return_indices else None
+    if smoother:
+        out.alphahat, out.Vt = _lib.dptr(at), _lib.dptr(Pt)
+    else:
+        out.at, out.att, out.Pt, out.Ptt = map(_lib.dptr, (at, att, Pt, Ptt))
+    out.weights, out.alpha = _lib.dptr(weights), _lib.dptr(alpha)
+    if indices is not None:
+        out.indices = indices.ctypes.data_as(_lib.c_u32_p)
+    L_ = _lib.lib()
+    fn = {(False, False): L_.bssm_bsf_nlg, (False, True): L_.bssm_bsf_smoother_nlg,
+          (True, False): L_.bssm_bsf_sde, (True, True): L_.bssm_bsf_smoother_sde}[(sde, smoother)]
+    _warn_if_degenerate(_lib.check(fn(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed), C.byref(out))))
+    if smoother:
+        res = dict(alphahat=at[:n, :], Vt=Pt[:, :, :n], weights=weights, logLik=out.logLik,
+                   alpha=np.transpose(alpha[:, :n, :], (1, 0, 2)))
+    else:
+        res = dict(at=at, att=att, Pt=Pt, Ptt=Ptt, weights=weights, logLik=out.logLik, alpha=np.transpose(alpha, (1, 0, 2)))
+    if indices is not None:
+        res["indices"] = indices
+    return res
+
+
+def bootstrap_filter(model: BssmModel, particles: int, seed: int | None = None, return_indices: bool = False, L=None):
     """R/bootstrap_filter.R:48-120 (lineargaussian :48-79, nongaussian :85-120).
 
     Returns dict(at (n+1) x m, att n x m, Pt, Ptt, weights N x (n+1), logLik, alpha (n+1) x m x N)."""
     particles = check_intmax(particles, "particles")
     seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
+    if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
+        return _functor_filter(model, particles, seed, False, L, return_indices)
     gaussian = model.inherits("lineargaussian")
     if not (gaussian or model.inherits("nongaussian")):
-        raise TypeError("bootstrap_filter is implemented for lineargaussian and nongaussian (ssm_ung family) models")
+        raise TypeError("bootstrap_filter is implemented for lineargaussian, nongaussian, ssm_nlg and ssm_sde models")
     n, m = model.n, model.m
     if n * m * particles > 1e10:  # R/bootstrap_filter.R:100-105
         warnings.warn("Trying to sample states 1e10 times; consider smaller number of particles.")
@@ -84,7 +122,7 @@ def bootstrap_filter(model: BssmModel, particles: int, seed: int | None = None, 
 
 
 def particle_smoother(model: BssmModel, particles: int, method: str = "psi", seed: int | None = None,
-                      return_indices: bool = False):
+                      return_indices: bool = False, L=None):
     """R/particle_smoother.R:140-186 (nongaussian) and :84-133 (lineargaussian, bsf only here).
 
     Returns dict(alphahat n x m, Vt m x m x n, weights, logLik, alpha n x m x N): the extra (n+1)-th
@@ -93,8 +131,13 @@ def particle_smoother(model: BssmModel, particles: int, method: str = "psi", see
     seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
     if method not in ("psi", "bsf", "ekf"):
         raise ValueError("'arg' should be one of 'psi', 'bsf', 'ekf'")
+    if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
+        if method != "bsf" and not model.inherits("ssm_sde"):
+            raise NotImplementedError("only method = 'bsf' is built for ssm_nlg models in this version "
+                                      "(psi-APF and EKPF of ssm_nlg: DESIGN.md section 7)")
+        return _functor_filter(model, particles, seed, True, L, return_indices)
     if method == "ekf":
-        raise ValueError("Method 'ekf' is only applicable to ssm_nlg models (out of scope for this build).")
+        raise ValueError("Method 'ekf' is only applicable to ssm_nlg models.")
     gaussian = model.inherits("lineargaussian")
     if gaussian and method == "psi":
         raise NotImplementedError("psi-APF for linear-Gaussian models is exact simulation smoothing "

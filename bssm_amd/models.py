@@ -443,6 +443,33 @@ def ar1_lg(y, rho, sigma, mu, sd_y):
                      theta=np.zeros(0))
 
 
+FN_IDS = {"nlg_growth": 1, "nlg_ar_exp": 2, "nlg_sin_exp": 3, "nlg_linear_gaussian": 4, "sde_gbm": 5, "sde_poisson_ou": 6}
+
+
+def ssm_nlg(y, example: str, theta, known_params=(), n_states=None, n_etas=None):
+    """R/models.R:1472-1570 with the function pointers of `cpp_example_model(example)` (R/cpp_example_models.R):
+    only the shipped example models are available on the device (nlg_growth, nlg_ar_exp, nlg_sin_exp,
+    nlg_linear_gaussian); theta / known_params keep the snippets' meaning."""
+    if example not in ("nlg_growth", "nlg_ar_exp", "nlg_sin_exp", "nlg_linear_gaussian"):
+        raise ValueError("only the example models of cpp_example_model() are built in: nlg_growth, nlg_ar_exp, "
+                         "nlg_sin_exp, nlg_linear_gaussian")
+    y = _f(np.asarray(y, dtype=float).reshape(-1))
+    m = 2 if example == "nlg_growth" else 1
+    return BssmModel(("ssm_nlg", "bssm_model"), y=y, model_id=FN_IDS[example], example=example,
+                     theta=np.asarray(theta, dtype=float), known_params=np.asarray(known_params, dtype=float),
+                     n_states=m, n_etas=m, a1=np.zeros(m), x0=0.0, positive=False, L=0)
+
+
+def ssm_sde(y, example: str, theta, x0, positive: bool):
+    """R/models.R:1600-1647 with the pointers of cpp_example_model('sde_gbm' | 'sde_poisson_ou')."""
+    if example not in ("sde_gbm", "sde_poisson_ou"):
+        raise ValueError("only the example models of cpp_example_model() are built in: sde_gbm, sde_poisson_ou")
+    y = _f(np.asarray(y, dtype=float).reshape(-1))
+    return BssmModel(("ssm_sde", "bssm_model"), y=y, model_id=FN_IDS[example], example=example,
+                     theta=np.asarray(theta, dtype=float), known_params=np.zeros(0), x0=float(x0),
+                     positive=bool(positive), a1=np.zeros(1), L=0)
+
+
 def model_arrays(model: BssmModel) -> dict:
     """Flatten a model into the plain column-major arrays + flags the C ABI struct carries
     (the field list of src/model_ssm_ung.cpp:9-32)."""

@@ -135,6 +135,35 @@ int bssm_nongaussian_loglik(const bssm_ung_model* model, uint32_t nsim, uint32_t
 int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, uint32_t sampling_method,
                                   uint32_t seed, uint32_t stream0, uint32_t n_rep, double* loglik);
 
+/* ---- non-linear Gaussian (ssm_nlg) and SDE (ssm_sde) models ----
+ * The reference takes user C++ compiled at run time behind function pointers (src/model_ssm_nlg.h:10-21,
+ * src/model_ssm_sde.h:8-11); device code cannot call those, so the examples shipped in
+ * R/cpp_example_models.R are built in and selected by id (theta / known_params keep the snippets' meaning).
+ * Only the bootstrap filter is provided for them in this version (psi-APF / EKPF of ssm_nlg: DESIGN.md section 7). */
+enum { BSSM_FN_NLG_GROWTH = 1, BSSM_FN_NLG_AR_EXP = 2, BSSM_FN_NLG_SIN_EXP = 3, BSSM_FN_NLG_LINEAR_GAUSSIAN = 4,
+       BSSM_FN_SDE_GBM = 5, BSSM_FN_SDE_POISSON_OU = 6 };
+typedef struct bssm_fn_model {
+  int32_t model_id;
+  int32_t n;                  /* time points */
+  const double* y;            /* n (every built-in model is univariate), NaN = missing */
+  const double* theta;   int32_t n_theta;
+  const double* known_params; int32_t n_known;   /* nlg_growth: (dT, K, a11, a12, P11, P12) */
+  double x0;                  /* ssm_sde: initial value */
+  int32_t positive;           /* ssm_sde: reflect to stay positive (milstein.cpp:44) */
+  int32_t L;                  /* ssm_sde: 2^L Milstein sub-steps per unit time */
+} bssm_fn_model;
+/* replaces _bssm_bsf_nlg (18 args, src/R_bootstrap_filter.cpp:461-504) / _bssm_bsf_smoother_nlg (:508-551):
+ * outputs as bssm_bsf / bssm_bsf_smoother */
+int bssm_bsf_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);
+int bssm_bsf_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);
+/* replaces _bssm_bsf_sde / _bssm_bsf_smoother_sde (12 args, src/R_sde.cpp:35-130) */
+int bssm_bsf_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);
+int bssm_bsf_smoother_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);
+/* replaces _bssm_nonlinear_loglik (method = 2, bsf) and _bssm_loglik_sde (src/R_loglik.cpp:91-124, src/R_sde.cpp:11-31),
+ * batched over n_rep Philox streams */
+int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, uint32_t stream0, uint32_t n_rep,
+                         double* loglik);
+
 /* ---- IS post-correction ----
  * replaces _bssm_postcorrection_nongaussian: `postcorrection_nongaussian(model_, model_type, output_type,
  * nsim, seed, n_threads, is_type, counts, theta, modes)` src/R_postcorrection.cpp:150-248 and the drivers

@@ -1341,3 +1341,110 @@ int orc_mng_psi_setup(const orc_mng_model *mod, const double *is_mode, orc_mng_s
   free(sm);
   return ok ? 0 : -1;
 }
+
+
+/* ================================================================== */
+/* ssm_nlg / ssm_sde bootstrap filters on the shipped model functors   */
+/* ================================================================== */
+static void fn_a1P1(const orc_fn_model *mod, double *a1, double *P1) { /* a1_fn / P1_fn of each snippet */
+  const double *th = mod->theta, *kp = mod->known;
+  a1[0] = a1[1] = 0; P1[0] = P1[1] = P1[2] = P1[3] = 0;
+  switch (mod->id) {
+  case 1: a1[0] = kp[2]; a1[1] = kp[3]; P1[0] = kp[4]; P1[3] = kp[5]; break;          /* R/cpp_example_models.R:351-366 */
+  case 2: a1[0] = th[0]; P1[0] = pow(exp(th[2]), 2) / (1 - pow(th[1], 2)); break;     /* :210-225 */
+  default: a1[0] = 0; P1[0] = 1; break;                                               /* :528-541, :651-664 */
+  }
+}
+static double fn_H(const orc_fn_model *mod) { /* H_fn */
+  switch (mod->id) { case 1: return exp(mod->theta[0]); case 2: return exp(mod->theta[3]); default: return exp(mod->theta[0]); }
+}
+static void fn_T(const orc_fn_model *mod, const double *a, double *x) { /* T_fn */
+  const double *th = mod->theta, *kp = mod->known;
+  switch (mod->id) {
+  case 1: { /* :415-428 */
+    double dT = kp[0], K = kp[1];
+    x[0] = a[0];
+    double r = exp(a[0]) / (1.0 + exp(a[0]));
+    x[1] = K * a[1] * exp(r * dT) / (K + a[1] * (exp(r * dT) - 1));
+  } break;
+  case 2: x[0] = th[0] * (1 - th[1]) + th[1] * a[0]; break;
+  case 3: x[0] = sin(a[0]); break;
+  default: x[0] = a[0]; break;
+  }
+}
+static void fn_Rdiag(const orc_fn_model *mod, double *r) { /* R_fn (diagonal in every shipped model) */
+  const double *th = mod->theta;
+  r[0] = r[1] = 0;
+  switch (mod->id) { case 1: r[0] = exp(th[1]); r[1] = exp(th[2]); break; case 2: r[0] = exp(th[2]); break;
+                     case 3: r[0] = exp(th[1]); break; default: r[0] = 1.0; break; }
+}
+static double fn_Z(const orc_fn_model *mod, const double *x) { /* Z_fn */
+  switch (mod->id) { case 1: return x[1]; case 2: case 3: return exp(x[0]); default: return x[0]; }
+}
+static double sde_drift(const orc_fn_model *mod, double x) { return mod->id == 5 ? mod->theta[0] * x : exp(mod->theta[0]) * (mod->theta[1] - x); }
+static double sde_diff(const orc_fn_model *mod, double x) { return mod->id == 5 ? fmax(0.0, mod->theta[1] * x) : exp(mod->theta[2]); }
+static double sde_ddiff(const orc_fn_model *mod, double x) { return mod->id == 5 ? mod->theta[1] * (x > 0.0) : 0.0; }
+/* milstein.cpp:18-48; increments N(0, sqrt(dt)) from Box-Muller pairs d = 0.. of (purpose, t, particle) */
+static double fn_milstein(const orc_fn_model *mod, const orc_rng *rng, uint32_t purpose, uint32_t t, uint32_t i, double x) {
+  unsigned nsub = 1u << mod->L;
+  double dt = 1.0 / nsub, sdt = sqrt(dt);
+  for (unsigned k = 0; k < nsub; k++) {
+    double z0, z1;
+    orc_rng_normal_pair(rng, purpose, t, i, k / 2, &z0, &z1);
+    double dB = ((k & 1) ? z1 : z0) * sdt;
+    x += sde_drift(mod, x) * dt + sde_diff(mod, x) * dB + 0.5 * sde_diff(mod, x) * sde_ddiff(mod, x) * (dB * dB - dt);
+    if (mod->positive) x = fabs(x);
+  }
+  return x;
+}
+static double fn_log_obs(const orc_fn_model *mod, int t, const double *x) {
+  double y = mod->y[t];
+  if (mod->id == 6) return y * x[0] - exp(x[0]) - lgamma(y + 1.0); /* R::dpois(y, exp(x), log) */
+  double mu = mod->id == 5 ? log(x[0]) : fn_Z(mod, x), sd = mod->id == 5 ? mod->theta[2] : fn_H(mod);
+  return -0.5 * (log(2.0 * ORC_PI) + 2.0 * log(sd) + pow((y - mu) / sd, 2)); /* dmvnorm.cpp:10-13 (lwr) = R::dnorm log */
+}
+
+double orc_fn_bsf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rng, double *alpha, double *weights, unsigned *indices) {
+  const int n = mod->n, m = mod->id == 1 ? 2 : 1, sde = mod->id >= 5;
+  double a1[2], P1[4], L[4], rdiag[2], um[2];
+  double *nw = (double *)malloc(sizeof(double) * N), *lw = (double *)malloc(sizeof(double) * N);
+  double *r = (double *)malloc(sizeof(double) * N), *atmp = (double *)malloc(sizeof(double) * N * m);
+  fn_a1P1(mod, a1, P1);
+  if (!sde) { double Pm[4] = {P1[0], 0, 0, P1[3]}; if (m == 1) Pm[0] = P1[0]; orc_psd_chol(m == 1 ? P1 : Pm, m, L); fn_Rdiag(mod, rdiag); }
+  for (unsigned i = 0; i < N; i++) {
+    if (sde) A_(0, 0, i) = fn_milstein(mod, rng, 0, 0, i, mod->x0); /* model_ssm_sde.cpp:25-28 */
+    else {
+      rng_normals(rng, 0, 0, i, m, um);
+      for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += L[j + m * c] * um[c]; A_(j, 0, i) = a1[j] + s; }
+    }
+  }
+  double loglik = 0.0, inc;
+  if (isfinite(mod->y[0])) {
+    for (unsigned i = 0; i < N; i++) lw[i] = fn_log_obs(mod, 0, &A_(0, 0, i));
+    if (!normalise_step(lw, N, weights, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+    loglik = inc;
+  } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
+  for (int t = 0; t < n; t++) {
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
+    for (unsigned i = 0; i < N; i++) {
+      if (sde) A_(0, t + 1, i) = fn_milstein(mod, rng, 4, t, i, atmp[i]); /* :59-62 */
+      else {
+        double x[2];
+        rng_normals(rng, 2, t, i, m, um);
+        fn_T(mod, atmp + (size_t)m * i, x);
+        for (int j = 0; j < m; j++) A_(j, t + 1, i) = x[j] + rdiag[j] * um[j]; /* model_ssm_nlg.cpp:1118-1126 */
+      }
+    }
+    double *wcol = weights + (size_t)N * (t + 1);
+    if ((t < n - 1) && isfinite(mod->y[t + 1])) {
+      for (unsigned i = 0; i < N; i++) lw[i] = fn_log_obs(mod, t + 1, &A_(0, t + 1, i));
+      if (!normalise_step(lw, N, wcol, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+      loglik += inc;
+    } else for (unsigned i = 0; i < N; i++) { wcol[i] = 1.0; nw[i] = 1.0 / N; }
+  }
+done:
+  free(nw); free(lw); free(r); free(atmp);
+  return loglik;
+}

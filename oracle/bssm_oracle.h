@@ -202,6 +202,21 @@ double orc_mlg_loglik(const orc_mng_model *mod, const double *gy, const double *
 /* state-independent constants over finite y: model_ssm_mng.cpp:632-666 */
 double orc_mng_const_term(const orc_mng_model *mod);
 
+/* ---- ssm_nlg / ssm_sde bootstrap filters on the model functors shipped in R/cpp_example_models.R ----
+ * ids: 1 nlg_growth (:336-511), 2 nlg_ar_exp (:194-335), 3 nlg_sin_exp (:635-760), 4 nlg_linear_gaussian (:512-634),
+ *      5 sde_gbm (:109-193), 6 sde_poisson_ou (:24-108). */
+typedef struct {
+  int id, n;
+  const double *y;
+  double theta[8], known[8];
+  double x0;
+  int positive, L;
+} orc_fn_model;
+/* src/model_ssm_nlg.cpp:1066-1146 (ids 1-4) and src/model_ssm_sde.cpp:21-82 + src/milstein.cpp:18-48 (ids 5-6);
+ * alpha m x (n+1) x N with m = 2 for nlg_growth, 1 otherwise */
+double orc_fn_bsf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rng, double *alpha, double *weights,
+                         unsigned *indices);
+
 #ifdef __cplusplus
 }
 #endif

@@ -354,3 +354,27 @@ def mng_psi_filter(arr: dict, nsim: int, seed=1, stream=0, is_mode=None, setup=N
     ll = L.orc_mng_psi_filter(C.byref(mod), su["_handle"], C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights),
                               indices.ctypes.data_as(c_uint_p))
     return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices, setup=su)
+
+
+# ------------------------------------------------------------------ ssm_nlg / ssm_sde built-in functors
+class OrcFn(C.Structure):
+    _fields_ = [("id", C.c_int), ("n", C.c_int), ("y", c_double_p), ("theta", C.c_double * 8), ("known", C.c_double * 8),
+                ("x0", C.c_double), ("positive", C.c_int), ("L", C.c_int)]
+
+
+def fn_bsf_filter(model: dict, nsim: int, seed=1, stream=0):
+    """model: dict(id, y, theta, known_params, x0, positive, L) as bssm_amd.models.ssm_nlg / ssm_sde produce"""
+    L = lib()
+    L.orc_fn_bsf_filter.restype = C.c_double
+    s = OrcFn()
+    y = np.ascontiguousarray(model["y"], dtype=np.float64)
+    s.id, s.n, s.y = int(model["model_id"]), y.size, _p(y)
+    for i, v in enumerate(np.asarray(model["theta"], dtype=float)): s.theta[i] = v
+    for i, v in enumerate(np.asarray(model.get("known_params", []), dtype=float)): s.known[i] = v
+    s.x0, s.positive, s.L = float(model.get("x0", 0.0)), int(bool(model.get("positive", False))), int(model.get("L", 0))
+    rng, _ = make_rng(seed, stream)
+    n, m = y.size, 2 if s.id == 1 else 1
+    alpha = np.zeros((m, n + 1, nsim), order="F"); weights = np.zeros((nsim, n + 1), order="F")
+    indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+    ll = L.orc_fn_bsf_filter(C.byref(s), C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights), indices.ctypes.data_as(c_uint_p))
+    return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices)

@@ -1,0 +1,81 @@
+"""GPU parity of the ssm_nlg / ssm_sde bootstrap filters (built-in model functors) against the oracle
+(src/model_ssm_nlg.cpp:1066-1146, src/model_ssm_sde.cpp:21-82, src/milstein.cpp:18-48)."""
+import numpy as np
+import pytest
+
+from bssm_amd import filters as F
+from bssm_amd import models as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _models():
+    rng = np.random.default_rng(12)
+    out = {}
+    # growth model of vignettes/growth_model.Rmd:51-75: K=500, p1=50, H=1, R1=.05, R2=1, dT=.1
+    n, K, dT = 60, 500.0, 0.1
+    r = np.zeros(n); p = np.zeros(n); r[0] = 0.0; p[0] = 50.0
+    for t in range(1, n):
+        r[t] = r[t - 1] + rng.normal(0, 0.05)
+        rr = np.exp(r[t - 1]) / (1 + np.exp(r[t - 1]))
+        p[t] = K * p[t - 1] * np.exp(rr * dT) / (K + p[t - 1] * (np.exp(rr * dT) - 1)) + rng.normal(0, 1)
+    y = p + rng.normal(0, 1, n); y[[7, 8]] = np.nan
+    out["nlg_growth"] = (M.ssm_nlg(y, "nlg_growth", theta=[0.0, np.log(0.05), 0.0], known_params=[dT, K, 0.0, 50.0, 1.0, 100.0]), None)
+    a = np.zeros(40); a[0] = 0.3
+    for t in range(1, 40):
+        a[t] = 0.2 * (1 - 0.9) + 0.9 * a[t - 1] + rng.normal(0, 0.3)
+    out["nlg_ar_exp"] = (M.ssm_nlg(np.exp(a) + rng.normal(0, 0.4, 40), "nlg_ar_exp", theta=[0.2, 0.9, np.log(0.3), np.log(0.4)]), None)
+    out["nlg_sin_exp"] = (M.ssm_nlg(rng.normal(1.0, 0.5, 30), "nlg_sin_exp", theta=[np.log(0.6), np.log(0.4)]), None)
+    out["nlg_linear_gaussian"] = (M.ssm_nlg(np.cumsum(rng.normal(0, 1, 30)) + rng.normal(0, 0.5, 30), "nlg_linear_gaussian",
+                                            theta=[np.log(0.5)]), None)
+    x = np.exp(np.cumsum(rng.normal(0.01, 0.1, 25)))
+    out["sde_gbm"] = (M.ssm_sde(np.log(x) + rng.normal(0, 0.5, 25), "sde_gbm", theta=[0.05, 0.3, 1.0], x0=1.0, positive=True), 3)
+    yp = rng.poisson(np.exp(0.7), 25).astype(float); yp[5] = np.nan
+    out["sde_poisson_ou"] = (M.ssm_sde(yp, "sde_poisson_ou", theta=[np.log(0.5), 0.7, np.log(0.4)], x0=0.5, positive=False), 2)
+    return out
+
+
+MODELS = _models()
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+@pytest.mark.parametrize("name", sorted(MODELS))
+@pytest.mark.parametrize("N", [30, 600])
+def test_functor_bootstrap_filter(oracle, monkeypatch, name, N, path):
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    model, L = MODELS[name]
+    out = F.bootstrap_filter(model, N, seed=8, return_indices=True, L=L)
+    ref = oracle.fn_bsf_filter({**model, "L": L or 0}, N, seed=8)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-9
+
+
+@pytest.mark.parametrize("name", ["nlg_growth", "sde_poisson_ou"])
+def test_functor_bsf_smoother(oracle, name):
+    model, L = MODELS[name]
+    n = model.n
+    out = F.particle_smoother(model, 200, method="bsf", seed=4, L=L)
+    ref = oracle.fn_bsf_filter({**model, "L": L or 0}, 200, seed=4)
+    mean, cov = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8 and _rel(out["Vt"], cov[:, :, :n]) <= 1e-7
+
+
+def test_nlg_linear_gaussian_equals_kalman(oracle):
+    """Analytic pin: the nlg_linear_gaussian example is an exact LGSSM (a1=0, P1=1, T=Z=1, R=1, H=e^theta0)."""
+    model, _ = MODELS["nlg_linear_gaussian"]
+    lg = M.ssm_ulg(model["y"], Z=1.0, H=0.5, T=1.0, R=1.0, a1=0.0, P1=1.0)
+    kal = oracle.ulg_loglik(M.model_arrays(lg))
+    lls = [F.bootstrap_filter(model, 20000, seed=s)["logLik"] for s in range(8)]
+    assert abs(np.mean(lls) - kal) < 4 * np.std(lls) / np.sqrt(8) + 0.02
+
+
+def test_unknown_example_is_rejected():
+    with pytest.raises(ValueError, match="built in"):
+        M.ssm_nlg([1.0, 2.0], "my_snippet", theta=[0.0])
