@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from bssm_amd import models as M  # noqa: E402
-from models_zoo import small_zoo  # noqa: E402
+from models_zoo import mng_zoo, small_zoo  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -41,6 +41,14 @@ def main():
             for k in ("approx_y", "approx_H", "mode", "scales", "alphahat", "Vt", "Ct"):
                 pack[f"{name}/setup/{k}"] = su[k]
             pack[f"{name}/setup/approx_loglik"] = np.array(su["approx_loglik"])
+    for name, mdl in sorted(mng_zoo().items()):
+        arr = M.model_arrays(mdl)
+        bsf = O.mng_bsf_filter(arr, 24, seed=17)
+        psi = O.mng_psi_filter(arr, 24, seed=17)
+        for tag, res in (("bsf", bsf), ("psi", psi)):
+            pack[f"mng/{name}/{tag}/logLik"] = np.array(res["logLik"])
+            pack[f"mng/{name}/{tag}/alpha"] = res["alpha"]
+            pack[f"mng/{name}/{tag}/indices"] = res["indices"]
     np.savez_compressed(os.path.join(OUT, "golden_filters.npz"), **pack)
     print("wrote", len(pack), "arrays;", os.path.getsize(os.path.join(OUT, "golden_filters.npz")), "bytes")
 

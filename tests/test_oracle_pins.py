@@ -233,6 +233,13 @@ def test_golden_vectors_regression(oracle):
             psi = oracle.psi_filter(arr, 24, seed=17)
             assert np.array_equal(psi["indices"], gold[f"{name}/psi/indices"])
             assert np.isclose(psi["logLik"], float(gold[f"{name}/psi/logLik"]), rtol=1e-12)
+    from models_zoo import mng_zoo
+    for name, mdl in sorted(mng_zoo().items()):
+        arr = M.model_arrays(mdl)
+        for tag, fn in (("bsf", oracle.mng_bsf_filter), ("psi", oracle.mng_psi_filter)):
+            res = fn(arr, 24, seed=17)
+            assert np.array_equal(res["indices"], gold[f"mng/{name}/{tag}/indices"])
+            assert np.isclose(res["logLik"], float(gold[f"mng/{name}/{tag}/logLik"]), rtol=1e-12)
 
 
 def test_is_correction_weights_and_merge(oracle):
@@ -263,3 +270,80 @@ def test_is_correction_weights_and_merge(oracle):
     res2 = oracle.is_correction(arrs, 20, 7, method=1, counts=counts, modes=modes, output_type=1)
     assert np.all(np.isfinite(res2["weights"])) and res2["weights"].max() > 0
     assert res2["alpha"].shape == (base.n + 1, 1, 4) and np.all(np.isfinite(res2["alpha"]))
+
+
+# ---------------------------------------------------------------- ssm_mng / functor-model parts of the oracle
+def test_mlg_loglik_equals_dense_mvn(oracle):
+    """multivariate Kalman likelihood (src/model_ssm_mlg.cpp:90-137) vs a dense MVN evaluation"""
+    import ctypes as C
+    from models_zoo import mng_zoo
+    rng = np.random.default_rng(3)
+    n, p, m = 6, 2, 2
+    Z = rng.normal(size=(p, m)); T = np.array([[0.8, 0.1], [0.0, 0.6]]); R = np.diag([0.4, 0.3])
+    y = rng.normal(size=(n, p))
+    model = M.ssm_mng(y, Z, T, R, a1=[0.1, -0.2], P1=np.diag([0.5, 0.3]), distribution="gaussian", phi=[0.7, 0.9],
+                      D=np.array([[0.2], [-0.1]]), C=np.array([[0.05], [0.0]]))
+    arr = M.model_arrays(model)
+    mod, keep = oracle.pack_mng(arr)
+    gy = np.asfortranarray(y.T); gH = np.asfortranarray(np.tile(np.array([[0.7], [0.9]]), (1, n)))
+    L = oracle._mng_lib()
+    ll = L.orc_mlg_loglik(C.byref(mod), oracle._p(gy), oracle._p(gH))
+    # dense: stack observations
+    a, P = arr["a1"].copy(), arr["P1"].copy()
+    means, blocks = [], []
+    for t in range(n):
+        means.append(a.copy()); blocks.append(P.copy())
+        a = arr["C"][:, 0] + T @ a; P = T @ P @ T.T + R @ R.T
+    cov = np.zeros((n * m, n * m))
+    for t in range(n):
+        cov[t*m:(t+1)*m, t*m:(t+1)*m] = blocks[t]
+        A = np.eye(m)
+        for s in range(t + 1, n):
+            A = T @ A
+            cov[s*m:(s+1)*m, t*m:(t+1)*m] = A @ blocks[t]; cov[t*m:(t+1)*m, s*m:(s+1)*m] = (A @ blocks[t]).T
+    Zb = np.kron(np.eye(n), Z)
+    mu = Zb @ np.concatenate(means) + np.tile(arr["D"][:, 0], n)
+    S = Zb @ cov @ Zb.T + np.kron(np.eye(n), np.diag([0.49, 0.81]))
+    assert np.isclose(ll, stats.multivariate_normal.logpdf(y.reshape(-1), mu, S), rtol=1e-11)
+
+
+def test_mng_gaussian_pf_equals_kalman_and_psi_equals_bsf(oracle):
+    """an all-gaussian ssm_mng is an LGSSM: bootstrap log-likelihood = Kalman (analytic pin), and for a mixed
+    model the psi-APF and the bootstrap filter estimate the same likelihood (psi with far lower variance)."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    n, p, m = 12, 2, 2
+    Z = rng.normal(size=(p, m)); T = np.array([[0.8, 0.1], [0.0, 0.6]]); R = np.diag([0.4, 0.3])
+    y = rng.normal(size=(n, p)); y[3, 1] = np.nan
+    model = M.ssm_mng(y, Z, T, R, a1=[0.0, 0.0], P1=np.diag([0.5, 0.3]), distribution="gaussian", phi=[0.7, 0.9])
+    arr = M.model_arrays(model)
+    mod, keep = oracle.pack_mng(arr)
+    gH = np.asfortranarray(np.tile(np.array([[0.7], [0.9]]), (1, n)))
+    kal = oracle._mng_lib().orc_mlg_loglik(C.byref(mod), oracle._p(np.asfortranarray(y.T)), oracle._p(gH))
+    lls = [oracle.mng_bsf_filter(arr, 20000, seed=s)["logLik"] for s in range(6)]
+    assert abs(np.mean(lls) - kal) < 4 * np.std(lls) / np.sqrt(6) + 0.02
+    from models_zoo import mng_zoo
+    arr2 = M.model_arrays(mng_zoo()["mixed_m4_p3"])
+    su = oracle.mng_psi_setup(arr2)
+    lp = [oracle.mng_psi_filter(arr2, 50, seed=s, setup=su)["logLik"] for s in range(16)]
+    lb = [oracle.mng_bsf_filter(arr2, 4000, seed=s)["logLik"] for s in range(16)]
+    assert abs(np.mean(lp) - np.mean(lb)) < 4 * (np.std(lp) + np.std(lb)) / 4 + 0.05
+    assert np.std(lp) < np.std(lb) * 1.5
+
+
+def test_functor_models_analytic_pins(oracle):
+    """nlg_linear_gaussian is an exact LGSSM (PF = Kalman); sde_poisson_ou with tiny diffusion follows the ODE."""
+    rng = np.random.default_rng(12)
+    y = np.cumsum(rng.normal(0, 1, 30)) + rng.normal(0, 0.5, 30)
+    mdl = M.ssm_nlg(y, "nlg_linear_gaussian", theta=[np.log(0.5)])
+    kal = oracle.ulg_loglik(M.model_arrays(M.ssm_ulg(y, Z=1.0, H=0.5, T=1.0, R=1.0, a1=0.0, P1=1.0)))
+    lls = [oracle.fn_bsf_filter(mdl, 20000, seed=s)["logLik"] for s in range(6)]
+    assert abs(np.mean(lls) - kal) < 4 * np.std(lls) / np.sqrt(6) + 0.02
+    # OU mean reversion: dx = e^{th0}(th1 - x) dt with sigma -> 0: x(t) = th1 + (x0 - th1) e^{-kappa t}
+    ou = M.ssm_sde(np.full(5, np.nan), "sde_poisson_ou", theta=[np.log(0.5), 2.0, np.log(1e-9)], x0=0.0, positive=False)
+    out = oracle.fn_bsf_filter({**ou, "L": 10}, 4, seed=1)
+    exact = 2.0 + (0.0 - 2.0) * np.exp(-0.5 * np.arange(1, 7))
+    assert np.allclose(out["alpha"][0, :, 0], exact, atol=2e-3)   # Euler/Milstein bias O(dt) at 2^-10
+    # GBM with positive = True stays positive
+    g = M.ssm_sde(rng.normal(0, 1, 10), "sde_gbm", theta=[0.05, 0.3, 1.0], x0=1.0, positive=True)
+    assert np.all(oracle.fn_bsf_filter({**g, "L": 3}, 50, seed=2)["alpha"] > 0)
