@@ -73,6 +73,8 @@ def lib():
         L.bssm_amd_last_error.restype = C.c_char_p
         L.bssm_amd_version.restype = C.c_char_p
         L.bssm_plan_create.restype = C.c_void_p
+        L.bssm_psi_smoother_nlg.argtypes = [C.POINTER(FnModel), C.c_uint32, C.c_uint32, C.c_int32, C.c_double, C.POINTER(FilterOut)]
+        L.bssm_fn_psi_setup.argtypes = [C.POINTER(FnModel), c_double_p, C.c_int32, C.c_double] + [c_double_p] * 2 + [C.POINTER(C.c_double)] + [c_double_p] * 7
         L.bssm_plan_create.argtypes = [C.POINTER(UngModel), C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.bssm_plan_destroy.argtypes = [C.c_void_p]
         L.bssm_plan_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]

@@ -73,7 +73,7 @@ void parallel_for(int count, int threads, F fn) {
 // ------------------------------------------------------------------ a batch of filters on the device
 struct DeviceBatch {
   bssm::FilterBatch fb{};
-  DevBuf mats, obs, init, hist, indices, weights, loglik, dead, ws, fparbuf;
+  DevBuf mats, obs, init, hist, indices, weights, loglik, dead, ws, fparbuf, amatbuf;
   bssm::GridWorkspace gws{};
   bool use_grid = false;
   std::vector<double> const_terms;  // per filter, added to the device log-likelihood on the host
@@ -138,6 +138,14 @@ struct DeviceBatch {
     HIP_TRY(hipMemcpy(fparbuf.p, fp.data(), fparbuf.bytes, hipMemcpyHostToDevice));
     fb.fpar = fparbuf.as<double>();
     fb.fpar_fstride = fp.size() > (size_t)bssm::FP_SIZE ? bssm::FP_SIZE : 0;
+    return BSSM_OK;
+  }
+
+  int set_amats(const std::vector<double>& am) {  // shared by every filter of the batch (stride 0)
+    HIP_TRY(amatbuf.alloc(am.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(amatbuf.p, am.data(), amatbuf.bytes, hipMemcpyHostToDevice));
+    fb.amats = amatbuf.as<double>();
+    fb.amats_fstride = 0;
     return BSSM_OK;
   }
 
@@ -222,7 +230,11 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
   DeviceBatch db;
   int rc = db.upload(tabs, n, m, k, p, N, psi ? 1 : 0, true, 0);
   if (rc) return rc;
-  if (fpar) { if ((rc = db.set_fpar(*fpar))) return rc; }
+  if (fpar) {  // functor parameters, optionally followed by the approximating (T_t, C_t) rows of the psi-APF
+    std::vector<double> fp(fpar->begin(), fpar->begin() + bssm::FP_SIZE), am(fpar->begin() + bssm::FP_SIZE, fpar->end());
+    if ((rc = db.set_fpar(fp))) return rc;
+    if (!am.empty() && (rc = db.set_amats(am))) return rc;
+  }
   hipStream_t st = nullptr;
   if ((rc = db.run(seed, 0, st))) return rc;
   double ll = 0;
@@ -375,6 +387,35 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   return BSSM_OK;
 }
 
+int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f) {
+  if (!mod || !mod->y || !mod->theta) return fail(BSSM_ERR_INVALID, "model, y, theta must be non-NULL");
+  if (mod->model_id < bssm::FN_NLG_GROWTH || mod->model_id > bssm::FN_NLG_LINEAR_GAUSSIAN)
+    return fail(BSSM_ERR_UNSUPPORTED, "the psi-APF is available for the built-in ssm_nlg models only");
+  if (mod->n_theta > 8 || mod->n_known > 8) return fail(BSSM_ERR_INVALID, "at most 8 theta / known_params");
+  f->id = mod->model_id; f->n = mod->n; f->m = mod->model_id == bssm::FN_NLG_GROWTH ? 2 : 1;
+  f->y.assign(mod->y, mod->y + mod->n);
+  for (int q = 0; q < mod->n_theta; q++) f->theta[q] = mod->theta[q];
+  for (int q = 0; q < mod->n_known; q++) f->known[q] = mod->known_params[q];
+  return BSSM_OK;
+}
+
+// psi-APF of a built-in ssm_nlg model: tables + functor parameters + approximating (T_t, C_t)
+int functor_psi_tables(const bssm_fn_model* mod, const double* is_mode, int max_iter, double conv_tol, bssm::FilterTables* ft,
+                       std::vector<double>* fpar, std::vector<double>* amats, double* approx_loglik, bool* ok, int* m_out) {
+  bssm::FnModel f;
+  int rc = to_fn_model(mod, &f);
+  if (rc) return rc;
+  bssm::FilterTables dummy;
+  int m = 1, k = 1;
+  if ((rc = functor_tables(mod, &dummy, fpar, &m, &k))) return rc;  // fpar block (id, theta, H, R ...)
+  bssm::FnSetup su;
+  *ok = bssm::fn_psi_setup(f, is_mode, max_iter, conv_tol, &su);
+  *approx_loglik = su.approx_loglik;
+  *m_out = m;
+  if (*ok) bssm::build_fn_psi_tables(f, su, ft, amats);
+  return BSSM_OK;
+}
+
 int run_functor(const bssm_fn_model* mod, uint32_t nsim, uint32_t seed, bool smoother, bssm_filter_out* out) {
   if (!out) return fail(BSSM_ERR_INVALID, "out is NULL");
   if (nsim < 1) return fail(BSSM_ERR_INVALID, "nsim must be positive");
@@ -404,19 +445,59 @@ int bssm_bsf_smoother_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t se
   if (model && model->model_id < bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");
   return run_functor(model, nsim, seed, true, out);
 }
-int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, uint32_t stream0, uint32_t n_rep, double* loglik) {
-  if (!loglik || n_rep < 1 || nsim < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+int bssm_psi_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, int32_t max_iter, double conv_tol,
+                          bssm_filter_out* out) {
+  if (!out || nsim < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
   std::vector<bssm::FilterTables> tabs(1);
-  std::vector<double> fpar;
-  int m = 1, k = 1;
-  int rc = functor_tables(model, &tabs[0], &fpar, &m, &k);
+  std::vector<double> fpar, amats;
+  double al = 0; bool ok = true; int m = 1;
+  const int rc = functor_psi_tables(model, nullptr, max_iter, conv_tol > 0 ? conv_tol : 1e-8, &tabs[0], &fpar, &amats, &al, &ok, &m);
   if (rc) return rc;
+  if (!ok) { out->logLik = -INFINITY; return BSSM_WARN_DEGENERATE; }  // src/model_ssm_nlg.cpp:988-990
+  if (!have_device()) return no_device();
+  fpar.insert(fpar.end(), amats.begin(), amats.end());  // run_tables splits them again
+  return run_tables(tabs, &fpar, model->n, m, m, 1, (int)nsim, true, true, seed, al, out);
+}
+
+int bssm_fn_psi_setup(const bssm_fn_model* model, const double* is_mode, int32_t max_iter, double conv_tol, double* mode,
+                      double* scales, double* approx_loglik, double* alphahat, double* Vt, double* Ct, double* Zt, double* Tt,
+                      double* Dt, double* Cc) {
+  bssm::FnModel f;
+  const int rc = to_fn_model(model, &f);
+  if (rc) return rc;
+  bssm::FnSetup su;
+  const bool ok = bssm::fn_psi_setup(f, is_mode, max_iter, conv_tol > 0 ? conv_tol : 1e-8, &su);
+  auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
+  cp(mode, su.mode); cp(scales, su.scales); cp(alphahat, su.alphahat); cp(Vt, su.Vt); cp(Ct, su.Ct);
+  cp(Zt, su.Z); cp(Tt, su.T); cp(Dt, su.D); cp(Cc, su.C);
+  if (approx_loglik) *approx_loglik = su.approx_loglik;
+  return ok ? BSSM_OK : BSSM_ERR_NUMERIC;
+}
+
+int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed, uint32_t stream0,
+                         uint32_t n_rep, double* loglik) {
+  if (!loglik || n_rep < 1 || nsim < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  if (sampling_method != BSSM_PSI && sampling_method != BSSM_BSF) return fail(BSSM_ERR_UNSUPPORTED, "sampling_method must be psi or bsf");
+  std::vector<bssm::FilterTables> tabs(1);
+  std::vector<double> fpar, amats;
+  int m = 1, k = 1, rc;
+  double base = 0.0;
+  const bool psi = sampling_method == BSSM_PSI;
+  if (psi) {
+    bool ok = true;
+    if ((rc = functor_psi_tables(model, nullptr, 100, 1e-8, &tabs[0], &fpar, &amats, &base, &ok, &m))) return rc;
+    k = m;
+    if (!ok) { for (uint32_t r = 0; r < n_rep; r++) loglik[r] = -INFINITY; return BSSM_WARN_DEGENERATE; }
+  } else {
+    if ((rc = functor_tables(model, &tabs[0], &fpar, &m, &k))) return rc;
+  }
   if (!have_device()) return no_device();
   std::vector<bssm::FilterTables> all(n_rep, tabs[0]);
   DeviceBatch db;
-  if ((rc = db.upload(all, model->n, m, k, 1, (int)nsim, 0, false, 0))) return rc;
+  if ((rc = db.upload(all, model->n, m, k, 1, (int)nsim, psi ? 1 : 0, false, 0))) return rc;
   if ((rc = db.set_fpar(fpar))) return rc;
-  db.const_terms.assign(n_rep, 0.0);
+  if (psi && (rc = db.set_amats(amats))) return rc;
+  db.const_terms.assign(n_rep, base);
   if ((rc = db.run(seed, stream0, nullptr))) return rc;
   if ((rc = db.fetch_loglik(nullptr, loglik))) return rc;
   bool deg = false;
@@ -512,6 +593,149 @@ int bssm_update_model_builtin(int model_type, const int32_t* flags, const double
 }
 
 // ------------------------------------------------------------------ IS post-correction
+namespace {
+// Shared core of the IS post-correction drivers: filter `cnt` prepared draws (tables already built), then
+// back-trace / summarise as output_type asks.  const_add[i] is added to the device log-likelihood
+// (bootstrap: state-independent constants); weight_i = exp(loglik_i - sub[i]) (src/approx_mcmc.cpp:385, 479).
+struct IsCore {
+  int n = 0, m = 0, k = 0, pp = 1;
+  bool psi = false;
+  int first = 0, is_type = 2, output_type = 3;
+  uint32_t nsim = 0, seed = 0;
+  const uint32_t* counts = nullptr;
+  std::vector<bssm::FilterTables> tabs;
+  std::vector<double> fpar;    // FP_SIZE per draw, or empty
+  std::vector<double> amats;   // per draw n * (m*m + m), or empty
+  std::vector<double> const_add, sub;
+  std::vector<char> bad;
+};
+
+int run_is_core(IsCore& J, double* weights, double* loglik, double* alpha, double* alphahat_i, double* Vt_i) {
+  const int cnt = (int)J.tabs.size(), n = J.n, m = J.m, k = J.k, pp = J.pp;
+  const bool psi = J.psi;
+  std::vector<bssm::FilterTables>& tabs = J.tabs;
+  const std::vector<char>& bad = J.bad;
+  struct { int first, is_type, output_type; uint32_t nsim, seed; const uint32_t* counts; } jobv{J.first, J.is_type, J.output_type, J.nsim, J.seed, J.counts};
+  const auto* job = &jobv;
+  const bool need_hist = job->output_type != 3;
+
+  // group draws by particle count (is1 multiplies nsim by count_i, src/approx_mcmc.cpp:376-378)
+  std::vector<int> order(cnt);
+  for (int i = 0; i < cnt; i++) order[i] = i;
+  auto nsim_of = [&](int i) { return (int)(job->is_type == 1 ? job->nsim * job->counts[i] : job->nsim); };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nsim_of(a) < nsim_of(b); });
+  bool any_degenerate = false;
+  size_t pos = 0;
+  while (pos < order.size()) {
+    const int N = nsim_of(order[pos]);
+    size_t end = pos;
+    while (end < order.size() && nsim_of(order[end]) == N) end++;
+    // cap the batch so the kept history fits comfortably in HBM (<= 64 GiB per batch)
+    const size_t per_filter = need_hist ? (size_t)(n + 1) * N * (m * 8 * 2 + 8 + 4) : 0;
+    size_t maxF = per_filter ? std::max<size_t>(1, ((size_t)64 << 30) / per_filter) : (size_t)1 << 20;
+    while (pos < end) {
+      const size_t F = std::min(maxF, end - pos);
+      std::vector<bssm::FilterTables> bt(F);
+      for (size_t f = 0; f < F; f++) bt[f] = tabs[order[pos + f]];
+      DeviceBatch db;
+      int rc = db.upload(bt, n, m, k, pp, N, psi, need_hist, 0, false);
+      if (rc) return rc;
+      DevBuf fparb, amatb;  // per-draw functor parameters / approximating (T_t, C_t), in batch order
+      if (!J.fpar.empty()) {
+        std::vector<double> hb(F * bssm::FP_SIZE);
+        for (size_t f = 0; f < F; f++) std::memcpy(hb.data() + f * bssm::FP_SIZE, J.fpar.data() + (size_t)order[pos + f] * bssm::FP_SIZE, bssm::FP_SIZE * sizeof(double));
+        HIP_TRY(fparb.alloc(hb.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(fparb.p, hb.data(), fparb.bytes, hipMemcpyHostToDevice));
+        db.fb.fpar = fparb.as<double>(); db.fb.fpar_fstride = bssm::FP_SIZE;
+      }
+      if (!J.amats.empty()) {
+        const size_t as = (size_t)n * (m * m + m);
+        std::vector<double> hb(F * as);
+        for (size_t f = 0; f < F; f++) std::memcpy(hb.data() + f * as, J.amats.data() + (size_t)order[pos + f] * as, as * sizeof(double));
+        HIP_TRY(amatb.alloc(hb.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(amatb.p, hb.data(), amatb.bytes, hipMemcpyHostToDevice));
+        db.fb.amats = amatb.as<double>(); db.fb.amats_fstride = as;
+      }
+      // Philox stream = global draw index: filters of this batch are not contiguous in draw order, so
+      // launch per contiguous run when needed.  Simplest exact approach: a per-filter stream table is
+      // emulated by running contiguous runs separately.
+      size_t f0 = 0;
+      std::vector<double> ll(F);
+      while (f0 < F) {
+        size_t f1 = f0 + 1;
+        while (f1 < F && order[pos + f1] == order[pos + f1 - 1] + 1) f1++;
+        bssm::FilterBatch sub = db.fb;
+        sub.F = (int)(f1 - f0);
+        sub.mats += db.fb.mats_fstride * f0; sub.obs += db.fb.obs_fstride * f0; sub.init += db.fb.init_fstride * f0;
+        sub.loglik += f0; sub.dead_at += f0;
+        if (sub.fpar) sub.fpar += sub.fpar_fstride * f0;
+        if (sub.amats) sub.amats += sub.amats_fstride * f0;
+        if (need_hist) {
+          sub.alpha_hist += (size_t)f0 * (n + 1) * m * N; sub.indices += (size_t)f0 * n * N;
+        }
+        sub.seed = job->seed;
+        sub.stream0 = (uint32_t)(job->first + order[pos + f0]);
+        if (db.use_grid) {
+          DevBuf wsb;  // workspace sized for the sub-batch
+          int B, chunk;
+          HIP_TRY(wsb.alloc(bssm::grid_workspace_bytes(sub, &B, &chunk)));
+          bssm::GridWorkspace gw;
+          bssm::grid_workspace_carve(sub, wsb.p, &gw);
+          HIP_TRY(bssm::launch_grid_filter(sub, gw, nullptr));
+          HIP_TRY(hipDeviceSynchronize());
+        } else {
+          HIP_TRY(bssm::launch_wg_filter(sub, nullptr));
+        }
+        HIP_TRY(bssm::launch_zero_dead_tail(sub, !db.use_grid, nullptr));
+        f0 = f1;
+      }
+      HIP_TRY(hipMemcpy(ll.data(), db.loglik.p, F * sizeof(double), hipMemcpyDeviceToHost));
+      // smoothing outputs
+      DevBuf smooth, d_mean, d_cov;
+      std::vector<double> hmean, hcov, htraj;
+      if (need_hist) {
+        HIP_TRY(smooth.alloc((size_t)F * (n + 1) * m * N * sizeof(double)));
+        HIP_TRY(bssm::launch_backtrace(db.hist.as<double>(), db.indices.as<uint32_t>(), smooth.as<double>(), (int)F, n, m, N, nullptr));
+        if (job->output_type == 2) {
+          HIP_TRY(d_mean.alloc((size_t)F * (n + 1) * m * sizeof(double)));
+          HIP_TRY(d_cov.alloc((size_t)F * (n + 1) * m * m * sizeof(double)));
+          HIP_TRY(bssm::launch_summary(smooth.as<double>(), d_mean.as<double>(), d_cov.as<double>(), (int)F, n + 1, m, N, nullptr));
+          hmean.resize((size_t)F * (n + 1) * m);
+          hcov.resize((size_t)F * (n + 1) * m * m);
+          HIP_TRY(hipMemcpy(hmean.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost));
+          HIP_TRY(hipMemcpy(hcov.data(), d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost));
+        }
+      }
+      for (size_t f = 0; f < F; f++) {
+        const int i = order[pos + f];
+        double l = ll[f];
+        if (bad[i] || !std::isfinite(l)) { l = -INFINITY; any_degenerate = true; }
+        const double full = l + J.const_add[i];
+        weights[i] = std::exp(full - J.sub[i]);  // src/approx_mcmc.cpp:385 (psi: approx_loglik = 0), :479 (bsf)
+        if (loglik) loglik[i] = full;
+        if (job->output_type == 1) {  // one uniformly chosen back-traced trajectory, stored (n+1) x m (:391-392)
+          const bssm::u32x4 w = bssm::philox4x32_10(0, 0, 0, bssm::RNG_PICK, job->seed, (uint32_t)(job->first + i));
+          const double u = (double)bssm::bits53(w.x, w.y) * 0x1.0p-53;
+          int pick = (int)(u * N);
+          if (pick >= N) pick = N - 1;
+          htraj.resize((size_t)(n + 1) * m);
+          // strided gather of one particle: [t][c][pick]
+          HIP_TRY(hipMemcpy2D(htraj.data(), sizeof(double), smooth.as<double>() + (size_t)f * (n + 1) * m * N + pick,
+                              (size_t)N * sizeof(double), sizeof(double), (size_t)(n + 1) * m, hipMemcpyDeviceToHost));
+          for (int t = 0; t <= n; t++) for (int c = 0; c < m; c++)
+            alpha[t + (size_t)(n + 1) * (c + (size_t)m * i)] = htraj[(size_t)t * m + c];
+        } else if (job->output_type == 2) {
+          std::memcpy(alphahat_i + (size_t)i * (n + 1) * m, hmean.data() + f * (size_t)(n + 1) * m, (size_t)(n + 1) * m * sizeof(double));
+          std::memcpy(Vt_i + (size_t)i * (n + 1) * m * m, hcov.data() + f * (size_t)(n + 1) * m * m, (size_t)(n + 1) * m * m * sizeof(double));
+        }
+      }
+      pos += F;
+    }
+  }
+  return any_degenerate ? BSSM_WARN_DEGENERATE : BSSM_OK;
+}
+}  // namespace
+
 int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, double* alpha, double* alphahat_i,
                        double* Vt_i) {
   if (!job || !weights) return fail(BSSM_ERR_INVALID, "job/weights NULL");
@@ -559,106 +783,68 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       t.mats_tstride = ts;
     }
   }
-  const int pp = hms[0].p;
-  const bool need_hist = job->output_type != 3;
+  IsCore J;
+  J.n = n; J.m = m; J.k = k; J.pp = hms[0].p; J.psi = psi;
+  J.first = job->first; J.is_type = job->is_type; J.output_type = job->output_type; J.nsim = job->nsim; J.seed = job->seed;
+  J.counts = job->counts;
+  J.tabs.swap(tabs);
+  J.bad = bad;
+  J.const_add.assign(cnt, 0.0); J.sub.assign(cnt, 0.0);
+  for (int i = 0; i < cnt; i++) if (!psi) { J.const_add[i] = bssm::const_term(hms[i]); J.sub[i] = job->approx_loglik[i]; }
+  return run_is_core(J, weights, loglik, alpha, alphahat_i, Vt_i);
+}
 
-  // group draws by particle count (is1 multiplies nsim by count_i, src/approx_mcmc.cpp:376-378)
-  std::vector<int> order(cnt);
-  for (int i = 0; i < cnt; i++) order[i] = i;
-  auto nsim_of = [&](int i) { return (int)(job->is_type == 1 ? job->nsim * job->counts[i] : job->nsim); };
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nsim_of(a) < nsim_of(b); });
-  bool any_degenerate = false;
-  size_t pos = 0;
-  while (pos < order.size()) {
-    const int N = nsim_of(order[pos]);
-    size_t end = pos;
-    while (end < order.size() && nsim_of(order[end]) == N) end++;
-    // cap the batch so the kept history fits comfortably in HBM (<= 64 GiB per batch)
-    const size_t per_filter = need_hist ? (size_t)(n + 1) * N * (m * 8 * 2 + 8 + 4) : 0;
-    size_t maxF = per_filter ? std::max<size_t>(1, ((size_t)64 << 30) / per_filter) : (size_t)1 << 20;
-    while (pos < end) {
-      const size_t F = std::min(maxF, end - pos);
-      std::vector<bssm::FilterTables> bt(F);
-      for (size_t f = 0; f < F; f++) bt[f] = tabs[order[pos + f]];
-      DeviceBatch db;
-      int rc = db.upload(bt, n, m, k, pp, N, psi, need_hist, 0, false);
-      if (rc) return rc;
-      // Philox stream = global draw index: filters of this batch are not contiguous in draw order, so
-      // launch per contiguous run when needed.  Simplest exact approach: a per-filter stream table is
-      // emulated by running contiguous runs separately.
-      size_t f0 = 0;
-      std::vector<double> ll(F);
-      while (f0 < F) {
-        size_t f1 = f0 + 1;
-        while (f1 < F && order[pos + f1] == order[pos + f1 - 1] + 1) f1++;
-        bssm::FilterBatch sub = db.fb;
-        sub.F = (int)(f1 - f0);
-        sub.mats += db.fb.mats_fstride * f0; sub.obs += db.fb.obs_fstride * f0; sub.init += db.fb.init_fstride * f0;
-        sub.loglik += f0; sub.dead_at += f0;
-        if (need_hist) {
-          sub.alpha_hist += (size_t)f0 * (n + 1) * m * N; sub.indices += (size_t)f0 * n * N;
-        }
-        sub.seed = job->seed;
-        sub.stream0 = (uint32_t)(job->first + order[pos + f0]);
-        if (db.use_grid) {
-          DevBuf wsb;  // workspace sized for the sub-batch
-          int B, chunk;
-          HIP_TRY(wsb.alloc(bssm::grid_workspace_bytes(sub, &B, &chunk)));
-          bssm::GridWorkspace gw;
-          bssm::grid_workspace_carve(sub, wsb.p, &gw);
-          HIP_TRY(bssm::launch_grid_filter(sub, gw, nullptr));
-          HIP_TRY(hipDeviceSynchronize());
-        } else {
-          HIP_TRY(bssm::launch_wg_filter(sub, nullptr));
-        }
-        HIP_TRY(bssm::launch_zero_dead_tail(sub, !db.use_grid, nullptr));
-        f0 = f1;
+// postcorrection_nonlinear (src/R_postcorrection.cpp:252-317) / is_correction_psi<ssm_nlg>, is_correction_bsf<ssm_nlg>
+int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t count, const double* modes,
+                           const double* approx_loglik, const uint32_t* counts, int32_t sampling_method, int32_t is_type,
+                           int32_t output_type, uint32_t nsim, uint32_t seed, int32_t n_threads, double* weights,
+                           double* loglik, double* alpha, double* alphahat_i, double* Vt_i) {
+  if (!models || !weights || !counts) return fail(BSSM_ERR_INVALID, "models/weights/counts NULL");
+  if (count <= 0) return BSSM_OK;
+  if (sampling_method != BSSM_PSI && sampling_method != BSSM_BSF) return fail(BSSM_ERR_UNSUPPORTED, "sampling_method must be psi or bsf");
+  if (output_type < 1 || output_type > 3) return fail(BSSM_ERR_INVALID, "output_type must be 1..3");
+  if (output_type == 1 && !alpha) return fail(BSSM_ERR_INVALID, "alpha buffer required for output_type 1");
+  if (output_type == 2 && (!alphahat_i || !Vt_i)) return fail(BSSM_ERR_INVALID, "summary buffers required for output_type 2");
+  const bool psi = sampling_method == BSSM_PSI;
+  if (psi && !modes) return fail(BSSM_ERR_INVALID, "modes required for psi");
+  if (!psi && !approx_loglik) return fail(BSSM_ERR_INVALID, "approx_loglik required for bsf");
+  const int n = models[0].n, id = models[0].model_id, m = id == bssm::FN_NLG_GROWTH ? 2 : 1;
+  IsCore J;
+  J.n = n; J.m = m; J.k = m; J.pp = 1; J.psi = psi;
+  J.first = first; J.is_type = is_type; J.output_type = output_type; J.nsim = nsim; J.seed = seed; J.counts = counts;
+  J.tabs.resize(count);
+  J.bad.assign(count, 0);
+  J.const_add.assign(count, 0.0); J.sub.assign(count, 0.0);
+  J.fpar.assign((size_t)count * bssm::FP_SIZE, 0.0);
+  if (psi) J.amats.assign((size_t)count * n * (m * m + m), 0.0);
+  std::vector<int> rcs(count, 0);
+  std::vector<std::string> errs(count);
+  parallel_for(count, n_threads, [&](int i) {
+    if (models[i].n != n || models[i].model_id != id) { rcs[i] = BSSM_ERR_INVALID; errs[i] = "all draws must share n and model id"; return; }
+    std::vector<double> fp, am;
+    int mm_ = 1, kk_ = 1;
+    if (psi) {
+      double al = 0; bool ok = true;
+      // approximate_for_is(mode_i): scales 0, approx_loglik 0 (src/approx_mcmc.cpp:372-373)
+      rcs[i] = functor_psi_tables(&models[i], modes + (size_t)m * n * i, 0, 1e-8, &J.tabs[i], &fp, &am, &al, &ok, &mm_);
+      if (rcs[i]) { errs[i] = g_err; return; }
+      if (!ok) {  // non-finite Vt/Ct: the filter returns -Inf (:988-990); run a harmless bootstrap table in its place
+        J.bad[i] = 1;
+        rcs[i] = functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_);
+        J.tabs[i].mats.assign((size_t)n * (m * m * 2 + m), 0.0); J.tabs[i].mats_tstride = m * m * 2 + m;
+        am.assign((size_t)n * (m * m + m), 0.0);
       }
-      HIP_TRY(hipMemcpy(ll.data(), db.loglik.p, F * sizeof(double), hipMemcpyDeviceToHost));
-      // smoothing outputs
-      DevBuf smooth, d_mean, d_cov;
-      std::vector<double> hmean, hcov, htraj;
-      if (need_hist) {
-        HIP_TRY(smooth.alloc((size_t)F * (n + 1) * m * N * sizeof(double)));
-        HIP_TRY(bssm::launch_backtrace(db.hist.as<double>(), db.indices.as<uint32_t>(), smooth.as<double>(), (int)F, n, m, N, nullptr));
-        if (job->output_type == 2) {
-          HIP_TRY(d_mean.alloc((size_t)F * (n + 1) * m * sizeof(double)));
-          HIP_TRY(d_cov.alloc((size_t)F * (n + 1) * m * m * sizeof(double)));
-          HIP_TRY(bssm::launch_summary(smooth.as<double>(), d_mean.as<double>(), d_cov.as<double>(), (int)F, n + 1, m, N, nullptr));
-          hmean.resize((size_t)F * (n + 1) * m);
-          hcov.resize((size_t)F * (n + 1) * m * m);
-          HIP_TRY(hipMemcpy(hmean.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost));
-          HIP_TRY(hipMemcpy(hcov.data(), d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost));
-        }
-      }
-      for (size_t f = 0; f < F; f++) {
-        const int i = order[pos + f];
-        double l = ll[f];
-        if (bad[i] || !std::isfinite(l)) { l = -INFINITY; any_degenerate = true; }
-        double full = l;
-        if (psi) { weights[i] = std::exp(l); }                            // src/approx_mcmc.cpp:385 (approx_loglik = 0)
-        else { full = l + bssm::const_term(hms[i]); weights[i] = std::exp(full - job->approx_loglik[i]); }  // :479
-        if (loglik) loglik[i] = full;
-        if (job->output_type == 1) {  // one uniformly chosen back-traced trajectory, stored (n+1) x m (:391-392)
-          const bssm::u32x4 w = bssm::philox4x32_10(0, 0, 0, bssm::RNG_PICK, job->seed, (uint32_t)(job->first + i));
-          const double u = (double)bssm::bits53(w.x, w.y) * 0x1.0p-53;
-          int pick = (int)(u * N);
-          if (pick >= N) pick = N - 1;
-          htraj.resize((size_t)(n + 1) * m);
-          // strided gather of one particle: [t][c][pick]
-          HIP_TRY(hipMemcpy2D(htraj.data(), sizeof(double), smooth.as<double>() + (size_t)f * (n + 1) * m * N + pick,
-                              (size_t)N * sizeof(double), sizeof(double), (size_t)(n + 1) * m, hipMemcpyDeviceToHost));
-          for (int t = 0; t <= n; t++) for (int c = 0; c < m; c++)
-            alpha[t + (size_t)(n + 1) * (c + (size_t)m * i)] = htraj[(size_t)t * m + c];
-        } else if (job->output_type == 2) {
-          std::memcpy(alphahat_i + (size_t)i * (n + 1) * m, hmean.data() + f * (size_t)(n + 1) * m, (size_t)(n + 1) * m * sizeof(double));
-          std::memcpy(Vt_i + (size_t)i * (n + 1) * m * m, hcov.data() + f * (size_t)(n + 1) * m * m, (size_t)(n + 1) * m * m * sizeof(double));
-        }
-      }
-      pos += F;
+      std::memcpy(J.amats.data() + (size_t)i * am.size(), am.data(), am.size() * sizeof(double));
+    } else {
+      rcs[i] = functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_);
+      if (rcs[i]) { errs[i] = g_err; return; }
+      J.sub[i] = approx_loglik[i];
     }
-  }
-  return any_degenerate ? BSSM_WARN_DEGENERATE : BSSM_OK;
+    std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
+  });
+  for (int i = 0; i < count; i++) if (rcs[i]) return fail(rcs[i], "draw " + std::to_string(i) + ": " + errs[i]);
+  if (!have_device()) return no_device();
+  return run_is_core(J, weights, loglik, alpha, alphahat_i, Vt_i);
 }
 
 int bssm_is_merge(int32_t n, int32_t m, int32_t n_stored, const double* weights, const uint32_t* counts,

@@ -672,6 +672,256 @@ void build_psi_tables(const HostModel& h, const PsiSetup& su, int MP, FilterTabl
   for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) out->init[MP + j + MP * c] = su.Vt[j + m * c];
 }
 
+// ------------------------------------------------------------------ built-in ssm_nlg functors (host side)
+namespace {
+double fnH(const FnModel& f) { return f.id == 1 ? std::exp(f.theta[0]) : (f.id == 2 ? std::exp(f.theta[3]) : std::exp(f.theta[0])); }
+void fnRdiag(const FnModel& f, double* r) {
+  r[0] = r[1] = 0;
+  switch (f.id) { case 1: r[0] = std::exp(f.theta[1]); r[1] = std::exp(f.theta[2]); break; case 2: r[0] = std::exp(f.theta[2]); break;
+                  case 3: r[0] = std::exp(f.theta[1]); break; default: r[0] = 1.0; }
+}
+void fnT(const FnModel& f, const double* a, double* x) {  // T_fn, R/cpp_example_models.R:415-428 etc.
+  switch (f.id) {
+    case 1: { const double dT = f.known[0], K = f.known[1]; x[0] = a[0]; const double r = std::exp(a[0]) / (1.0 + std::exp(a[0]));
+              x[1] = K * a[1] * std::exp(r * dT) / (K + a[1] * (std::exp(r * dT) - 1)); } break;
+    case 2: x[0] = f.theta[0] * (1 - f.theta[1]) + f.theta[1] * a[0]; break;
+    case 3: x[0] = std::sin(a[0]); break;
+    default: x[0] = a[0];
+  }
+}
+void fnTg(const FnModel& f, const double* a, double* Tg) {  // T_gn, :432-450
+  switch (f.id) {
+    case 1: { const double dT = f.known[0], K = f.known[1]; const double r = std::exp(a[0]) / (1 + std::exp(a[0]));
+              const double tmp = std::exp(r * dT) / std::pow(K + a[1] * (std::exp(r * dT) - 1), 2);
+              Tg[0] = 1.0; Tg[2] = 0; Tg[1] = dT * K * a[1] * (K - a[1]) * tmp * r / (1 + std::exp(a[0])); Tg[3] = K * K * tmp; } break;
+    case 2: Tg[0] = f.theta[1]; break;
+    case 3: Tg[0] = std::cos(a[0]); break;
+    default: Tg[0] = 1.0;
+  }
+}
+double fnZ(const FnModel& f, const double* x) { return f.id == 1 ? x[1] : ((f.id == 2 || f.id == 3) ? std::exp(x[0]) : x[0]); }
+void fnZg(const FnModel& f, const double* a, double* Zg) {
+  switch (f.id) { case 1: Zg[0] = 0.0; Zg[1] = 1.0; break; case 2: case 3: Zg[0] = std::exp(a[0]); break; default: Zg[0] = 1.0; }
+}
+// dmvnorm(x, mean, cov, lwr = false, logd = true) for a DIAGONAL covariance (all shipped P1 / RR are diagonal)
+double dmvnorm_diag(const double* x, const double* mean, const double* var, int d) {
+  if (d == 1) return -0.5 * (std::log(2.0 * kPi) + std::log(var[0]) + std::pow(x[0] - mean[0], 2) / var[0]);
+  double out = 0.0; int cnt = 0;
+  for (int j = 0; j < d; j++) {
+    if (!(var[j] > kEps)) continue;
+    cnt++;
+    const double l = std::sqrt(var[j]), z = (x[j] - mean[j]) / l;
+    out += -std::log(l) - 0.5 * z * z;
+  }
+  return out - 0.5 * cnt * std::log(2.0 * kPi);
+}
+double dnorm_sd(double y, double mean, double sd) { return -0.5 * (std::log(2.0 * kPi) + 2.0 * std::log(sd) + std::pow((y - mean) / sd, 2)); }
+
+void fn_linearise(const FnModel& f, const double* zpts, const double* tpts, FnSetup* su) {
+  const int n = f.n, m = f.m;
+  for (int t = 0; t < n; t++) {
+    const double* zp = zpts + (size_t)m * t; const double* tp = tpts + (size_t)m * t;
+    double* Zt = su->Z.data() + (size_t)m * t; double* Tt = su->T.data() + (size_t)m * m * t; double Tf[2];
+    fnZg(f, zp, Zt); fnTg(f, tp, Tt);
+    double za = 0; for (int j = 0; j < m; j++) za += Zt[j] * zp[j];
+    su->D[t] = fnZ(f, zp) - za;
+    fnT(f, tp, Tf);
+    for (int i = 0; i < m; i++) { double sacc = 0; for (int j = 0; j < m; j++) sacc += Tt[i + m * j] * tp[j]; su->C[i + (size_t)m * t] = Tf[i] - sacc; }
+  }
+  su->H = fnH(f);
+  double rd[2]; fnRdiag(f, rd);
+  std::memset(su->R, 0, sizeof(su->R));
+  for (int i = 0; i < m; i++) su->R[i + m * i] = rd[i];
+}
+// the approximating Gaussian model as a HostModel the Kalman routines understand
+void fn_gaussian_model(const FnModel& f, const FnSetup& su, HostModel* g) {
+  const int n = f.n, m = f.m;
+  g->n = n; g->m = m; g->k = m; g->p = 1;
+  g->dist.assign(1, BSSM_GAUSSIAN); g->phis.assign(1, 1.0); g->distribution = BSSM_GAUSSIAN;
+  g->Ztv = 1; g->Ttv = 1; g->Rtv = 0; g->Dtv = 1; g->Ctv = 1; g->Htv = 0;
+  g->y = f.y; g->Z = su.Z; g->T = su.T; g->R.assign(su.R, su.R + m * m); g->D = su.D; g->C = su.C;
+  g->a1.assign(m, 0.0); g->P1.assign((size_t)m * m, 0.0);
+  fn_a1P1(f, g->a1.data(), g->P1.data());
+  g->xbeta.assign(n, 0.0); g->u.assign(n, 1.0); g->H.assign(1, su.H);
+}
+double fn_log_signal_pdf(const FnModel& f, const double* al) {  // src/model_ssm_nlg.cpp:1295-1319
+  const int n = f.n, m = f.m;
+  double a1[2], P1[4], rd[2], pv[2], rv[2];
+  fn_a1P1(f, a1, P1); fnRdiag(f, rd);
+  for (int j = 0; j < m; j++) { pv[j] = P1[j + m * j]; rv[j] = rd[j] * rd[j]; }
+  double ll = dmvnorm_diag(al, a1, pv, m);
+  if (std::isfinite(f.y[0])) ll += dnorm_sd(f.y[0], fnZ(f, al), fnH(f));
+  for (int t = 0; t < n - 1; t++) {
+    double mean[2];
+    fnT(f, al + (size_t)m * t, mean);
+    ll += dmvnorm_diag(al + (size_t)m * (t + 1), mean, rv, m);
+    if (std::isfinite(f.y[t + 1])) ll += dnorm_sd(f.y[t + 1], fnZ(f, al + (size_t)m * (t + 1)), fnH(f));
+  }
+  return ll;
+}
+bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att) {  // :284-381 with iekf_iter = 0
+  const int n = f.n, m = f.m, mm = m * m;
+  std::vector<double> Pt((size_t)mm * (n + 1), 0.0), Ptt((size_t)mm * n, 0.0);
+  at->assign((size_t)m * (n + 1), 0.0); att->assign((size_t)m * n, 0.0);
+  double rd[2]; const double H = fnH(f);
+  fnRdiag(f, rd);
+  fn_a1P1(f, at->data(), Pt.data());
+  for (int t = 0; t < n; t++) {
+    const double* a = at->data() + (size_t)m * t; const double* P = Pt.data() + (size_t)mm * t;
+    double* af = att->data() + (size_t)m * t; double* Pf = Ptt.data() + (size_t)mm * t;
+    if (std::isfinite(f.y[t])) {
+      double Zg[2], PZ[2] = {0, 0}, K[2], F = H * H;
+      fnZg(f, a, Zg);
+      for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += P[i + m * j] * Zg[j];
+      for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
+      if (!std::isfinite(F) || !(F > 0)) return false;
+      const double cF = std::sqrt(F), v = f.y[t] - fnZ(f, a);
+      for (int i = 0; i < m; i++) K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF);
+      for (int i = 0; i < m; i++) af[i] = a[i] + K[i] * v;
+      Mat IKZ(m, m), Pm(m, m, P);
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ(i, j) = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
+      const Mat J = IKZ * Pm * tr(IKZ);
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pf[i + m * j] = J(i, j) + K[i] * H * H * K[j];
+    } else { std::memcpy(af, a, sizeof(double) * m); std::memcpy(Pf, P, sizeof(double) * mm); }
+    double Tg[4];
+    fnT(f, af, at->data() + (size_t)m * (t + 1));
+    fnTg(f, af, Tg);
+    const Mat TgM(m, m, Tg), PfM(m, m, Pf);
+    const Mat Pn = TgM * PfM * tr(TgM);
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = Pn(i, j) + (i == j ? rd[i] * rd[i] : 0.0);
+  }
+  return true;
+}
+}  // namespace
+
+void fn_a1P1(const FnModel& f, double* a1, double* P1) {
+  const int m = f.m;
+  for (int j = 0; j < m; j++) a1[j] = 0;
+  for (int q = 0; q < m * m; q++) P1[q] = 0;
+  switch (f.id) {
+    case 1: a1[0] = f.known[2]; a1[1] = f.known[3]; P1[0] = f.known[4]; P1[3] = f.known[5]; break;
+    case 2: a1[0] = f.theta[0]; P1[0] = std::pow(std::exp(f.theta[2]), 2) / (1 - std::pow(f.theta[1], 2)); break;
+    default: a1[0] = 0; P1[0] = 1;
+  }
+}
+
+bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double conv_tol, FnSetup* su) {
+  const int n = f.n, m = f.m, mm = m * m;
+  su->Z.assign((size_t)m * n, 0.0); su->T.assign((size_t)mm * n, 0.0); su->D.assign(n, 0.0); su->C.assign((size_t)m * n, 0.0);
+  su->mode.assign((size_t)m * n, 0.0); su->scales.assign(n, 0.0);
+  su->alphahat.assign((size_t)m * (n + 1), 0.0); su->Vt.assign((size_t)mm * (n + 1), 0.0); su->Ct.assign((size_t)mm * (n + 1), 0.0);
+  su->approx_loglik = 0; su->iters = 0; su->ok = true;
+  HostModel g;
+  Approx ap;
+  ap.y = f.y;
+  std::vector<Mat> sm;
+  auto smooth_mode = [&](std::vector<double>* out) {
+    fn_gaussian_model(f, *su, &g);
+    ap.H.assign(n, su->H);
+    const Sys S(g);
+    if (!fast_smoother(S, ap, &sm)) return false;
+    out->resize((size_t)m * n);
+    for (int t = 0; t < n; t++) for (int j = 0; j < m; j++) (*out)[j + (size_t)m * t] = sm[t](j, 0);
+    for (double v : *out) if (!std::isfinite(v)) return false;
+    return true;
+  };
+  if (is_mode) {  // approximate_for_is (:146-176): scales stay 0, approx_loglik 0
+    su->mode.assign(is_mode, is_mode + (size_t)m * n);
+    fn_linearise(f, su->mode.data(), su->mode.data(), su);
+  } else {        // approximate() (:62-143)
+    std::vector<double> at, att, nm;
+    if (!fn_ekf(f, &at, &att)) { su->ok = false; return false; }
+    fn_linearise(f, at.data(), att.data(), su);  // approximate_by_ekf (:179-215)
+    if (!smooth_mode(&su->mode)) { su->ok = false; return false; }
+    if (max_iter > 0) {
+      double ll = fn_log_signal_pdf(f, su->mode.data()), rel = 1.0e300, ad = 1;
+      int i = 0;
+      while (i < max_iter && rel > conv_tol && ad > 1e-4) {
+        i++;
+        fn_linearise(f, su->mode.data(), su->mode.data(), su);
+        if (!smooth_mode(&nm)) { su->ok = false; return false; }
+        const double lln = fn_log_signal_pdf(f, nm.data());
+        ad = lln - ll; rel = ad / std::fabs(ll);
+        if (!std::isfinite(lln)) { su->ok = false; return false; }
+        // the reference's back-tracking branch (:118-138) needs rel < -conv_tol and ad > 1e-4 at once: unreachable
+        su->mode = nm; ll = lln;
+      }
+      su->iters = i;
+    }
+    fn_gaussian_model(f, *su, &g);
+    ap.H.assign(n, su->H);
+    const Sys S(g);
+    const double gll = gaussian_loglik(S, ap);
+    // update_scales (:854-879)
+    double rd[2], rv[2];
+    fnRdiag(f, rd);
+    for (int j = 0; j < m; j++) rv[j] = rd[j] * rd[j];
+    const double HH = su->H * su->H;
+    for (int t = 0; t < n; t++) {
+      const double* md = su->mode.data() + (size_t)m * t;
+      if (std::isfinite(f.y[t])) {
+        double am = su->D[t];
+        for (int j = 0; j < m; j++) am += su->Z[j + (size_t)m * t] * md[j];
+        su->scales[t] = dnorm_sd(f.y[t], fnZ(f, md), fnH(f)) - dmvnorm_diag(&f.y[t], &am, &HH, 1);
+      }
+    }
+    for (int t = 1; t < n; t++) {
+      const double* mp = su->mode.data() + (size_t)m * (t - 1); const double* md = su->mode.data() + (size_t)m * t;
+      double mean[2], amean[2];
+      fnT(f, mp, mean);
+      for (int i = 0; i < m; i++) { double sacc = 0; for (int j = 0; j < m; j++) sacc += su->T[i + m * j + (size_t)mm * (t - 1)] * mp[j]; amean[i] = su->C[i + (size_t)m * (t - 1)] + sacc; }
+      su->scales[t] += dmvnorm_diag(md, mean, rv, m) - dmvnorm_diag(md, amean, rv, m);
+    }
+    double ssc = 0; for (double v : su->scales) ssc += v;
+    su->approx_loglik = gll + ssc;
+  }
+  fn_gaussian_model(f, *su, &g);
+  ap.H.assign(n, su->H);
+  const Sys S(g);
+  std::vector<Mat> at, Vt, Ct;
+  if (!smoother_ccov(S, ap, &at, &Vt, &Ct)) { su->ok = false; return false; }
+  for (int t = 0; t <= n; t++) for (int q = 0; q < mm; q++) if (!std::isfinite(Vt[t].a[q]) || !std::isfinite(Ct[t].a[q])) { su->ok = false; return false; }
+  conditional_cov(&Vt, &Ct);
+  for (int t = 0; t <= n; t++) {
+    for (int i = 0; i < m; i++) su->alphahat[i + (size_t)m * t] = at[t](i, 0);
+    for (int q = 0; q < mm; q++) { su->Vt[q + (size_t)mm * t] = Vt[t].a[q]; su->Ct[q + (size_t)mm * t] = Ct[t].a[q]; }
+  }
+  return true;
+}
+
+void build_fn_psi_tables(const FnModel& f, const FnSetup& su, FilterTables* ft, std::vector<double>* amats) {
+  const int n = f.n, m = f.m, MP = m, KP = m, mm = m * m;
+  const int MS = MP * MP + MP * KP + MP;
+  ft->MP = MP; ft->KP = KP; ft->mats_tstride = MS;
+  ft->mats.assign((size_t)n * MS, 0.0);
+  for (int t = 0; t < n; t++) {  // proposal alphahat(t+1) + Ct(t+1)(a - alphahat(t)) + Vt(t+1) u  (:1032-1033)
+    double* mt = ft->mats.data() + (size_t)t * MS;
+    const double* Ct1 = su.Ct.data() + (size_t)mm * (t + 1); const double* Vt1 = su.Vt.data() + (size_t)mm * (t + 1);
+    const double* ah0 = su.alphahat.data() + (size_t)m * t; const double* ah1 = su.alphahat.data() + (size_t)m * (t + 1);
+    for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) { mt[j + MP * c] = Ct1[j + m * c]; mt[MP * MP + j + MP * c] = Vt1[j + m * c]; }
+    for (int j = 0; j < m; j++) { double sacc = 0; for (int c = 0; c < m; c++) sacc += Ct1[j + m * c] * ah0[c]; mt[MP * MP + MP * KP + j] = ah1[j] - sacc; }
+  }
+  const int stride = ROW_HDR + SER_HDR + MP;
+  ft->obs.assign((size_t)n * stride, 0.0);
+  for (int t = 0; t < n; t++) {
+    double* row = ft->obs.data() + (size_t)t * stride;
+    if (!std::isfinite(f.y[t])) continue;
+    row[RH_FLAG] = 1.0; row[RH_SCALE] = su.scales[t];
+    double* ob = row + ROW_HDR;
+    ob[OB_FLAG] = 1.0; ob[OB_Y] = f.y[t]; ob[OB_D] = su.D[t]; ob[OB_PSIIH] = 1.0 / su.H;
+    for (int c = 0; c < m; c++) ob[SER_HDR + c] = su.Z[c + (size_t)m * t];
+  }
+  ft->init.assign((size_t)MP + (size_t)MP * MP, 0.0);
+  for (int j = 0; j < m; j++) ft->init[j] = su.alphahat[j];
+  for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) ft->init[MP + j + MP * c] = su.Vt[j + m * c];
+  amats->assign((size_t)n * (MP * MP + MP), 0.0);
+  for (int t = 0; t < n; t++) {
+    double* am = amats->data() + (size_t)t * (MP * MP + MP);
+    for (int q = 0; q < mm; q++) am[q] = su.T[q + (size_t)mm * t];
+    for (int j = 0; j < m; j++) am[MP * MP + j] = su.C[j + (size_t)m * t];
+  }
+}
+
 std::string update_model_builtin(int model_type, const int32_t* fl, const double* th, int n_par, bssm_ung_model* mod,
                                  double* T, double* R, double* P1, double* a1, double* C, double* beta) {
   const int m = mod->m, k = mod->k;

@@ -60,6 +60,30 @@ void build_bsf_tables(const HostModel& hm, int MP, int KP, FilterTables* out);
 // psi-APF tables: T' = Ct(t+1), R' = Vt(t+1), C' = ahat(t+1) - Ct(t+1) ahat(t)
 void build_psi_tables(const HostModel& hm, const PsiSetup& su, int MP, FilterTables* out);
 
+// ---- built-in ssm_nlg model functors on the host: psi-APF set-up (EKF, mode search, linearised model,
+// smoother_ccov + conditional_cov), src/model_ssm_nlg.cpp:62-222, 284-381, 854-879, 974-991, 1295-1319
+struct FnModel {
+  int id = 0, n = 0, m = 1;
+  std::vector<double> y;
+  double theta[8] = {0}, known[8] = {0};
+  double x0 = 0;
+  int positive = 0, L = 0;
+};
+struct FnSetup {
+  std::vector<double> Z, T, D, C;   // m x n, m x m x n, n, m x n : the mode-linearised model
+  double H = 1, R[4] = {0, 0, 0, 0};
+  std::vector<double> mode, scales;
+  double approx_loglik = 0;
+  std::vector<double> alphahat, Vt, Ct;
+  int iters = 0;
+  bool ok = false;
+};
+bool fn_psi_setup(const FnModel& mod, const double* is_mode, int max_iter, double conv_tol, FnSetup* out);
+// psi proposal operands (as build_psi_tables), observation rows carrying the approximating D_t / Z_t / 1/H / scales,
+// and the approximating (T_t, C_t) rows used by the transition-density ratio
+void build_fn_psi_tables(const FnModel& mod, const FnSetup& su, FilterTables* ft, std::vector<double>* amats);
+void fn_a1P1(const FnModel& mod, double* a1, double* P1 /* m x m */);
+
 // built-in update_model maps (see bssm_update_model_builtin in bssm_amd.h)
 std::string update_model_builtin(int model_type, const int32_t* flags, const double* theta, int n_par,
                                  bssm_ung_model* model, double* T, double* R, double* P1, double* a1, double* C,

@@ -90,6 +90,18 @@ __device__ __forceinline__ void initial_state(const double* __restrict__ ini, co
 // ------------------------------------------------------------------------------------------
 // Workgroup-resident filter
 // ------------------------------------------------------------------------------------------
+// one particle's log-weight for whichever model family the kernel was instantiated for
+template <int MP, bool FN>
+__device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const double* __restrict__ fpar,
+                                                  const double* __restrict__ row, const double* __restrict__ amat, int t,
+                                                  const double (&x)[MP], const double (&aprev)[MP]) {
+  if constexpr (FN) {
+    return b.psi ? functor_psi_weight<MP>(fpar, row, amat, t, x, aprev) : functor_log_weight<MP>(fpar, row, x);
+  } else {
+    return log_weight_of<MP>(b, row, x);
+  }
+}
+
 constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the fp64 transcendental code
 // Particle i = r * NT + tid (r < PPT): consecutive lanes own consecutive particles, so LDS
 // accesses to the own slot are conflict-free and history stores are coalesced.
@@ -111,6 +123,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
   const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
   const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
+  const double* __restrict__ amats = (FN && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
   const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP), m = b.m;
   const double dN = (double)N;
 
@@ -122,8 +135,8 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
   for (int r = 0; r < PPT; r++) {
     const int i = r * NT + tid;
     double x[MP];
-    if constexpr (FN) {
-      functor_initial<MP>(fpar, ini, key, (uint32_t)i, x);
+    if (FN && !b.psi) {
+      if constexpr (FN) functor_initial<MP>(fpar, ini, key, (uint32_t)i, x);
     } else {
       double z[MP];
       rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)i, z);
@@ -136,7 +149,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
         if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1)) * m + c) * N + i] = x[c];
       }
     }
-    w[r] = (i < N) ? (FN ? functor_log_weight<MP>(fpar, obs, x) : log_weight_of<MP>(b, obs, x)) : -INFINITY;
+    w[r] = (i < N) ? weight_dispatch<MP, FN>(b, fpar, obs, amats, 0, x, x) : -INFINITY;
     __builtin_amdgcn_sched_barrier(0);  // keep the unrolled particles sequential: bounds live registers
   }
 
@@ -152,7 +165,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
     for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
     // stage this step's transition operands in LDS (every wave is past the previous transition here;
     // they become visible at barrier (2)/(3), before the transition after barrier (4))
-    if (!FN && t < n && (t == 0 || b.mats_tstride != 0)) {
+    if ((!FN || b.psi) && t < n && (t == 0 || b.mats_tstride != 0)) {
       const double* __restrict__ src = mats + (size_t)t * b.mats_tstride;
       for (int q = tid; q < MS; q += NT) s_mats[q] = src[q];
     }
@@ -219,8 +232,8 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
       double x[MP];
-      if constexpr (FN) {
-        functor_propagate<MP, KP>(fpar, key, (uint32_t)t, (uint32_t)i, a[r], x);
+      if (FN && !b.psi) {
+        if constexpr (FN) functor_propagate<MP, KP>(fpar, key, (uint32_t)t, (uint32_t)i, a[r], x);
       } else {
         double z[KP];
         rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
@@ -233,7 +246,7 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
           if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1) + (t + 1)) * m + c) * N + i] = x[c];
         }
       }
-      w[r] = (i < N) ? (t + 1 < n ? (FN ? functor_log_weight<MP>(fpar, ob, x) : log_weight_of<MP>(b, ob, x)) : 0.0) : -INFINITY;
+      w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN>(b, fpar, ob, amats + (size_t)t * (MP * MP + MP), t + 1, x, a[r]) : 0.0) : -INFINITY;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -370,6 +383,7 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
   const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
   const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
+  const double* __restrict__ amats = (FN && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
   const int base = pb * chunk;
   const int len = min(chunk, N - base);
   const int tn = t + 1;  // time index of the particles produced by this launch
@@ -377,14 +391,15 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
   double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N
                                              : ws.state[tn & 1] + (size_t)f * m * N;
   double x[PPT][MP];
+  double aprev[FN ? PPT : 1][MP];  // ancestors, needed by the ssm_nlg psi weights
 
   if (t < 0) {
     const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int li = r * GRID_NT + tid, j = base + li;
-      if constexpr (FN) {
-        functor_initial<MP>(fpar, ini, key, (uint32_t)j, x[r]);
+      if (FN && !b.psi) {
+        if constexpr (FN) functor_initial<MP>(fpar, ini, key, (uint32_t)j, x[r]);
       } else {
         double z[MP];
         rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)j, z);
@@ -497,7 +512,15 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
         for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
         BSSM_STAMP(6)
         if constexpr (FN) {
-          functor_propagate<MP, KP>(fpar, key, (uint32_t)t, (uint32_t)j, a, x[r]);
+          if (b.psi) {
+            double z[KP];
+            rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+            propagate<MP, KP>(mt, a, z, x[r]);
+          } else {
+            functor_propagate<MP, KP>(fpar, key, (uint32_t)t, (uint32_t)j, a, x[r]);
+          }
+#pragma unroll
+          for (int c = 0; c < MP; c++) aprev[r][c] = a[c];
         } else if constexpr (kEarlyRng) {
           propagate<MP, KP>(mt, a, z_pre[r], x[r]);
         } else {
@@ -520,7 +543,7 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
-    w[r] = (li < len) ? (have_obs ? (FN ? functor_log_weight<MP>(fpar, ob, x[r]) : log_weight_of<MP>(b, ob, x[r])) : 0.0) : -INFINITY;
+    w[r] = (li < len) ? (have_obs ? weight_dispatch<MP, FN>(b, fpar, ob, amats + (size_t)(t < 0 ? 0 : t) * (MP * MP + MP), tn, x[r], aprev[FN ? r : 0]) : 0.0) : -INFINITY;
     mx = fmax(mx, w[r]);
   }
   BSSM_STAMP(8)

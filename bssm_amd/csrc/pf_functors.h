@@ -126,4 +126,42 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
   return fp[FP_LOGC] - 0.5 * q * q;
 }
 
+// psi-APF weight of ssm_nlg (src/model_ssm_nlg.cpp:880-935 minus scales_t): observation-density ratio between
+// the model and its mode-linearised Gaussian approximation, and for t > 0 the transition-density ratio evaluated
+// at the ANCESTOR.  H and R are constant in every shipped model, so the Gaussian normalisers cancel exactly.
+//   row  : observation row of time t (y, approximating D_t in OB_D, approximating Z_t after the header, 1/H in OB_PSIIH)
+//   amat : approximating T_{t-1} (MP x MP) and C_{t-1} (MP) -- only read when t > 0
+template <int MP>
+__device__ __forceinline__ double functor_psi_weight(const double* __restrict__ fp, const double* __restrict__ row,
+                                                     const double* __restrict__ amat, int t, const double (&x)[MP],
+                                                     const double (&aprev)[MP]) {
+  if (row[RH_FLAG] == 0.0) return 0.0;  // y_t missing: weights are ones, transition ratio included (:1040-1056)
+  const int id = (int)fp[FP_ID];
+  double w = 0.0;
+  {
+    const double* __restrict__ ob = row + ROW_HDR;
+    const double y = ob[OB_Y], ih = ob[OB_PSIIH];
+    const double q1 = (y - nlg_Z_fn<MP>(id, x)) * ih;
+    double lin = ob[OB_D];
+#pragma unroll
+    for (int c = 0; c < MP; c++) lin += ob[SER_HDR + c] * x[c];
+    const double q2 = (y - lin) * ih;
+    w = 0.5 * (q2 * q2 - q1 * q1);
+  }
+  if (t > 0) {
+    double mean[MP];
+    nlg_T_fn<MP>(id, fp, aprev, mean);
+#pragma unroll
+    for (int j = 0; j < MP; j++) {
+      double am = amat[MP * MP + j];
+#pragma unroll
+      for (int c = 0; c < MP; c++) am += amat[j + MP * c] * aprev[c];
+      const double ir = 1.0 / fp[FP_R + j];
+      const double da = (x[j] - am) * ir, dm = (x[j] - mean[j]) * ir;
+      w += 0.5 * (da * da - dm * dm);
+    }
+  }
+  return w - row[RH_SCALE];
+}
+
 }  // namespace bssm

@@ -28,6 +28,8 @@ struct FilterBatch {
   const double* init; size_t init_fstride;
   // built-in non-linear / SDE functor parameters (pf_functors.h), [f][FP_SIZE]; null for the linear-state models
   const double* fpar; size_t fpar_fstride;
+  // psi-APF of ssm_nlg: approximating T_t (MP x MP), C_t (MP) per time point, [f][n][MP*MP + MP]
+  const double* amats; size_t amats_fstride;
   // outputs (any may be null)
   double* alpha_hist;   // [f][n+1][m][N]   particle-minor
   uint32_t* indices;    // [f][n][N]

@@ -51,7 +51,7 @@ def _warn_if_degenerate(rc):
         warnings.warn("Particle filtering stopped prematurely due to nonfinite log-likelihood.")
 
 
-def _functor_filter(model: BssmModel, particles: int, seed: int, smoother: bool, L, return_indices: bool):
+def _functor_filter(model: BssmModel, particles: int, seed: int, smoother: bool, L, return_indices: bool, psi: bool = False):
     """ssm_nlg / ssm_sde bootstrap filter (R/bootstrap_filter.R:126-202) and bsf smoother (R/particle_smoother.R:193-291)."""
     sde = model.inherits("ssm_sde")
     if sde:
@@ -74,9 +74,15 @@ def _functor_filter(model: BssmModel, particles: int, seed: int, smoother: bool,
     if indices is not None:
         out.indices = indices.ctypes.data_as(_lib.c_u32_p)
     L_ = _lib.lib()
-    fn = {(False, False): L_.bssm_bsf_nlg, (False, True): L_.bssm_bsf_smoother_nlg,
-          (True, False): L_.bssm_bsf_sde, (True, True): L_.bssm_bsf_smoother_sde}[(sde, smoother)]
-    _warn_if_degenerate(_lib.check(fn(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed), C.byref(out))))
+    if psi:
+        rc = L_.bssm_psi_smoother_nlg(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed),
+                                      C.c_int32(int(model.get("max_iter", 100))), C.c_double(float(model.get("conv_tol", 1e-8))),
+                                      C.byref(out))
+    else:
+        fn = {(False, False): L_.bssm_bsf_nlg, (False, True): L_.bssm_bsf_smoother_nlg,
+              (True, False): L_.bssm_bsf_sde, (True, True): L_.bssm_bsf_smoother_sde}[(sde, smoother)]
+        rc = fn(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed), C.byref(out))
+    _warn_if_degenerate(_lib.check(rc))
     if smoother:
         res = dict(alphahat=at[:n, :], Vt=Pt[:, :, :n], weights=weights, logLik=out.logLik,
                    alpha=np.transpose(alpha[:, :n, :], (1, 0, 2)))
@@ -132,10 +138,10 @@ def particle_smoother(model: BssmModel, particles: int, method: str = "psi", see
     if method not in ("psi", "bsf", "ekf"):
         raise ValueError("'arg' should be one of 'psi', 'bsf', 'ekf'")
     if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
-        if method != "bsf" and not model.inherits("ssm_sde"):
-            raise NotImplementedError("only method = 'bsf' is built for ssm_nlg models in this version "
-                                      "(psi-APF and EKPF of ssm_nlg: DESIGN.md section 7)")
-        return _functor_filter(model, particles, seed, True, L, return_indices)
+        if method == "ekf":
+            raise NotImplementedError("the EKF particle filter of ssm_nlg is not built (SURVEY.md 2a N22)")
+        psi = method == "psi" and model.inherits("ssm_nlg")
+        return _functor_filter(model, particles, seed, True, L, return_indices, psi=psi)
     if method == "ekf":
         raise ValueError("Method 'ekf' is only applicable to ssm_nlg models.")
     gaussian = model.inherits("lineargaussian")
@@ -165,7 +171,7 @@ def particle_smoother(model: BssmModel, particles: int, method: str = "psi", see
     return res
 
 
-def logLik(model: BssmModel, particles: int, method: str = "psi", seed: int | None = None) -> float:
+def logLik(model: BssmModel, particles: int, method: str = "psi", seed: int | None = None, L=None) -> float:
     """R/loglik.R:73-100 (nongaussian): method 'psi' or 'bsf'; particles = 0 gives the
     Gaussian-approximation log-likelihood."""
     particles = check_intmax(particles, "particles", positive=False)
@@ -174,8 +180,10 @@ def logLik(model: BssmModel, particles: int, method: str = "psi", seed: int | No
         raise ValueError("'arg' should be one of 'psi', 'bsf', 'spdk'")
     if method == "spdk":
         raise NotImplementedError("SPDK importance sampling is not a particle-filter path (SURVEY.md 2a N23).")
+    if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
+        return float(logLik_batch(model, particles, 1, method=method, seed=seed, L=L)[0])
     if not model.inherits("nongaussian"):
-        raise TypeError("logLik(particles, method) is for nongaussian models")
+        raise TypeError("logLik(particles, method) is for nongaussian, ssm_nlg and ssm_sde models")
     arr, smod, keep = _prep(model, True)
     ll = C.c_double(0.0)
     rc = _lib.check(_lib.lib().bssm_nongaussian_loglik(C.byref(smod), C.c_uint32(particles),
@@ -185,8 +193,16 @@ def logLik(model: BssmModel, particles: int, method: str = "psi", seed: int | No
     return ll.value
 
 
-def logLik_batch(model: BssmModel, particles: int, n_rep: int, method: str = "bsf", seed: int = 1, stream0: int = 0):
+def logLik_batch(model: BssmModel, particles: int, n_rep: int, method: str = "bsf", seed: int = 1, stream0: int = 0, L=None):
     """n_rep independent log-likelihood estimates in one device batch (streams stream0..stream0+n_rep-1)."""
+    if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
+        smod, keep = _lib.pack_fn_model(model, L)
+        out = np.zeros(n_rep)
+        meth = 1 if (method == "psi" and model.inherits("ssm_nlg")) else 2
+        rc = _lib.check(_lib.lib().bssm_fn_loglik_batch(C.byref(smod), C.c_uint32(particles), C.c_uint32(meth), C.c_uint32(seed),
+                                                        C.c_uint32(stream0), C.c_uint32(n_rep), _lib.dptr(out)))
+        _warn_if_degenerate(rc)
+        return out
     arr, smod, keep = _prep(model, True)
     out = np.zeros(n_rep)
     rc = _lib.check(_lib.lib().bssm_nongaussian_loglik_batch(
@@ -198,6 +214,19 @@ def logLik_batch(model: BssmModel, particles: int, n_rep: int, method: str = "bs
 
 def psi_setup(model: BssmModel, is_mode=None):
     """Gaussian approximation + conditional factors used by the psi-APF (host side of the library)."""
+    if model.inherits("ssm_nlg"):
+        smod, keep = _lib.pack_fn_model(model)
+        n, m = model.n, 2 if int(model["model_id"]) == 1 else 1
+        res = dict(mode=_alloc((m, n)), scales=np.zeros(n), alphahat=_alloc((m, n + 1)), Vt=_alloc((m, m, n + 1)),
+                   Ct=_alloc((m, m, n + 1)), Z=_alloc((m, n)), T=_alloc((m, m, n)), D=np.zeros(n), C=_alloc((m, n)))
+        al = C.c_double(0.0)
+        mode_in = None if is_mode is None else np.asfortranarray(is_mode, dtype=np.float64)
+        _lib.check(_lib.lib().bssm_fn_psi_setup(
+            C.byref(smod), _lib.dptr(mode_in), C.c_int32(int(model.get("max_iter", 100))), C.c_double(float(model.get("conv_tol", 1e-8))),
+            _lib.dptr(res["mode"]), _lib.dptr(res["scales"]), C.byref(al), _lib.dptr(res["alphahat"]), _lib.dptr(res["Vt"]),
+            _lib.dptr(res["Ct"]), _lib.dptr(res["Z"]), _lib.dptr(res["T"]), _lib.dptr(res["D"]), _lib.dptr(res["C"])))
+        res["approx_loglik"] = al.value
+        return res
     arr, smod, keep = _prep(model, True)
     n, m, p = arr["n"], arr["m"], arr.get("p", 1)
     res = dict(approx_y=np.zeros(n * p), approx_H=np.zeros(n * p), mode=np.zeros(n * p), scales=np.zeros(n),

@@ -142,6 +142,31 @@ def is_correction(model: BssmModel, theta, counts, particles: int, method: str =
     return res
 
 
+def _run_local_block_nlg(model, theta, modes, counts, first, n_stored, nsim, seed, is_type, output_type, n_threads,
+                         method=1, approx_loglik=None):
+    """ssm_nlg draws [first, first + len(theta)) through bssm_is_correction_nlg (only theta differs between draws)."""
+    cnt = theta.shape[0]
+    n = model.n
+    m = 2 if int(model["model_id"]) == 1 else 1
+    packed, keep = [], []
+    for i in range(cnt):
+        s, k = _lib.pack_fn_model({**model, "theta": theta[i]})
+        packed.append(s); keep.append(k)
+    models = (_lib.FnModel * cnt)(*packed)
+    modes_c = None if modes is None else np.asfortranarray(modes, dtype=np.float64)
+    al_c = None if approx_loglik is None else np.ascontiguousarray(approx_loglik, dtype=np.float64)
+    counts_c = np.ascontiguousarray(counts, dtype=np.uint32)
+    weights, loglik = np.zeros(cnt), np.zeros(cnt)
+    alpha = np.zeros((n + 1, m, cnt), order="F") if output_type == 1 else None
+    ah = np.zeros((m, n + 1, cnt), order="F") if output_type == 2 else None
+    vt = np.zeros((m, m, n + 1, cnt), order="F") if output_type == 2 else None
+    rc = _lib.check(_lib.lib().bssm_is_correction_nlg(
+        models, C.c_int32(first), C.c_int32(cnt), _lib.dptr(modes_c), _lib.dptr(al_c), counts_c.ctypes.data_as(_lib.c_u32_p),
+        C.c_int32(method), C.c_int32(is_type), C.c_int32(output_type), C.c_uint32(nsim), C.c_uint32(seed), C.c_int32(n_threads),
+        _lib.dptr(weights), _lib.dptr(loglik), _lib.dptr(alpha), _lib.dptr(ah), _lib.dptr(vt)))
+    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1)
+
+
 def _all_gather_blocks(local: np.ndarray, bounds, rank, world, group, device):
     """All-gather variable-length blocks along the LAST axis (padded to the largest block): one collective."""
     import torch
@@ -185,9 +210,10 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     if is_type.lower() not in ("is1", "is2", "is3"):
         raise ValueError("'arg' should be one of 'is1', 'is2', 'is3'")
     is_t = int(is_type[-1])
-    if not model.inherits("nongaussian"):
+    nlg = model.inherits("ssm_nlg")
+    if not (model.inherits("nongaussian") or nlg):
         raise TypeError("Function 'post_correct' is only available for models of class 'nongaussian' and 'ssm_nlg'.")
-    if np.any(np.isnan(np.asarray(model["u"], dtype=float))):
+    if not nlg and np.any(np.isnan(np.asarray(model["u"], dtype=float))):
         raise ValueError("Missing values not allowed in 'u'.")
     output_type = _OUTPUT_TYPES[mcmc_output.get("output_type", 3)]
     t0 = time.perf_counter()
@@ -196,8 +222,9 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     counts = np.asarray(mcmc_output["counts"], dtype=np.uint32).reshape(-1)
     modes = np.asarray(mcmc_output["modes"], dtype=np.float64)
     n = model.n
-    modes = modes.reshape(n, -1, order="F") if modes.ndim == 3 else modes
-    if theta.shape[0] != counts.size or modes.shape != (n, counts.size):
+    p_dim = (2 if int(model["model_id"]) == 1 else 1) if nlg else model.p   # rows of one draw's mode: states (nlg) / series
+    modes = modes.reshape(p_dim * n, -1, order="F")
+    if theta.shape[0] != counts.size or modes.shape != (p_dim * n, counts.size):
         raise ValueError("theta, counts and modes of 'mcmc_output' do not agree")
     if is_t == 3:  # expand(): src/approx_mcmc.cpp:49-88, called from src/R_postcorrection.cpp:197-199
         rep = counts.astype(np.int64)
@@ -217,9 +244,12 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     bounds = shard_bounds(work, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
 
-    arrs = expand_models(model, theta[lo:hi])
-    m = model.m
-    if hi > lo:
+    m = (2 if int(model["model_id"]) == 1 else 1) if nlg else model.m
+    if hi > lo and nlg:
+        loc = _run_local_block_nlg(model, theta[lo:hi], modes[:, lo:hi], counts[lo:hi], lo, n_stored, particles, seed, is_t,
+                                   output_type, threads)
+    elif hi > lo:
+        arrs = expand_models(model, theta[lo:hi])
         loc = _run_local_block(arrs, modes[:, lo:hi], counts[lo:hi], lo, n_stored, particles, seed, is_t, output_type,
                                threads)
     else:

@@ -161,8 +161,25 @@ int bssm_bsf_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_
 int bssm_bsf_smoother_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);
 /* replaces _bssm_nonlinear_loglik (method = 2, bsf) and _bssm_loglik_sde (src/R_loglik.cpp:91-124, src/R_sde.cpp:11-31),
  * batched over n_rep Philox streams */
-int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, uint32_t stream0, uint32_t n_rep,
-                         double* loglik);
+int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed, uint32_t stream0,
+                         uint32_t n_rep, double* loglik);
+/* replaces _bssm_psi_smoother_nlg (21 args, src/R_psi.cpp:175-222): psi-APF + back-trace + summary of a built-in
+ * ssm_nlg model.  max_iter / conv_tol are the mode-search controls of ssm_nlg (src/model_ssm_nlg.cpp:19-20). */
+int bssm_psi_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, int32_t max_iter, double conv_tol,
+                          bssm_filter_out* out);
+/* host-side psi set-up of ssm_nlg on its own (EKF, mode search, linearised model, conditional factors); is_mode m x n
+ * selects approximate_for_is.  Outputs (any may be NULL): mode m x n, scales n, approx_loglik, alphahat m x (n+1),
+ * Vt / Ct m x m x (n+1), linearised Z_t m x n, T_t m x m x n, D_t n, C_t m x n. */
+int bssm_fn_psi_setup(const bssm_fn_model* model, const double* is_mode, int32_t max_iter, double conv_tol, double* mode,
+                      double* scales, double* approx_loglik, double* alphahat, double* Vt, double* Ct, double* Zt, double* Tt,
+                      double* Dt, double* Cc);
+/* replaces _bssm_postcorrection_nonlinear (24 args, src/R_postcorrection.cpp:252-317): one model per retained draw
+ * (only theta differs), modes m x n x count (psi) or approx_loglik[count] (bsf); other arguments and outputs as
+ * bssm_is_correction.  Draws [first, first + count) of the global job. */
+int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t count, const double* modes,
+                           const double* approx_loglik, const uint32_t* counts, int32_t sampling_method, int32_t is_type,
+                           int32_t output_type, uint32_t nsim, uint32_t seed, int32_t n_threads, double* weights,
+                           double* loglik, double* alpha, double* alphahat_i, double* Vt_i);
 
 /* ---- IS post-correction ----
  * replaces _bssm_postcorrection_nongaussian: `postcorrection_nongaussian(model_, model_type, output_type,

@@ -1448,3 +1448,280 @@ done:
   free(nw); free(lw); free(r); free(atmp);
   return loglik;
 }
+
+
+/* ================================================================== */
+/* ssm_nlg psi-APF                                                     */
+/* ================================================================== */
+static void fn_Tg(const orc_fn_model *mod, const double *a, double *Tg /* m x m */) { /* T_gn */
+  const double *th = mod->theta, *kp = mod->known;
+  switch (mod->id) {
+  case 1: { /* R/cpp_example_models.R:432-450 */
+    double dT = kp[0], K = kp[1];
+    double r = exp(a[0]) / (1 + exp(a[0]));
+    double tmp = exp(r * dT) / pow(K + a[1] * (exp(r * dT) - 1), 2);
+    Tg[0] = 1.0; Tg[2] = 0;
+    Tg[1] = dT * K * a[1] * (K - a[1]) * tmp * r / (1 + exp(a[0]));
+    Tg[3] = K * K * tmp;
+  } break;
+  case 2: Tg[0] = th[1]; break;
+  case 3: Tg[0] = cos(a[0]); break;
+  default: Tg[0] = 1.0; break;
+  }
+}
+static void fn_Zg(const orc_fn_model *mod, const double *a, double *Zg /* 1 x m */) { /* Z_gn */
+  switch (mod->id) { case 1: Zg[0] = 0.0; Zg[1] = 1.0; break; case 2: case 3: Zg[0] = exp(a[0]); break; default: Zg[0] = 1.0; break; }
+}
+
+/* dmvnorm(x, mean, sigma, lwr = false, logd = true) for a covariance matrix (src/dmvnorm.cpp:4-58) */
+static double dmvnorm_cov(const double *x, const double *mean, const double *S, int d) {
+  if (d == 1) return -0.5 * (log(2.0 * ORC_PI) + log(S[0]) + pow(x[0] - mean[0], 2) / S[0]);
+  int idx[ORC_MAXM], cnt = 0;
+  for (int j = 0; j < d; j++) if (S[j + d * j] > ORC_EPS) idx[cnt++] = j;
+  double L[ORC_MAXM * ORC_MAXM] = {0};
+  chol_lower_sub(S, d, idx, cnt, L);
+  double out = -0.5 * cnt * log(2.0 * ORC_PI), z2[ORC_MAXM];
+  for (int a = 0; a < cnt; a++) { /* z2 = L^-1 z by forward substitution; log(rooti.diag) = -log(L.diag) */
+    double s = x[idx[a]] - mean[idx[a]];
+    for (int b = 0; b < a; b++) s -= L[idx[a] + d * idx[b]] * z2[b];
+    z2[a] = s / L[idx[a] + d * idx[a]];
+    out += -log(L[idx[a] + d * idx[a]]) - 0.5 * z2[a] * z2[a];
+  }
+  return out;
+}
+static double dnorm_sd(double y, double mean, double sd) { /* dmvnorm(..., lwr = true) with one element, dmvnorm.cpp:10-11 */
+  return -0.5 * (log(2.0 * ORC_PI) + 2.0 * log(sd) + pow((y - mean) / sd, 2));
+}
+
+orc_fn_setup *orc_fn_setup_alloc(int n, int m) {
+  orc_fn_setup *s = (orc_fn_setup *)calloc(1, sizeof(orc_fn_setup));
+  s->n = n; s->m = m;
+  s->Z = (double *)calloc((size_t)m * n, sizeof(double)); s->T = (double *)calloc((size_t)m * m * n, sizeof(double));
+  s->D = (double *)calloc(n, sizeof(double)); s->C = (double *)calloc((size_t)m * n, sizeof(double));
+  s->mode = (double *)calloc((size_t)m * n, sizeof(double)); s->scales = (double *)calloc(n, sizeof(double));
+  s->alphahat = (double *)calloc((size_t)m * (n + 1), sizeof(double));
+  s->Vt = (double *)calloc((size_t)m * m * (n + 1), sizeof(double)); s->Ct = (double *)calloc((size_t)m * m * (n + 1), sizeof(double));
+  return s;
+}
+void orc_fn_setup_free(orc_fn_setup *s) {
+  if (!s) return;
+  free(s->Z); free(s->T); free(s->D); free(s->C); free(s->mode); free(s->scales); free(s->alphahat); free(s->Vt); free(s->Ct); free(s);
+}
+
+/* extended Kalman filter with iekf_iter = 0: src/model_ssm_nlg.cpp:284-381 (p = 1) */
+static int fn_ekf(const orc_fn_model *mod, double *at, double *att, double *Pt, double *Ptt) {
+  const int n = mod->n, m = mod->id == 1 ? 2 : 1, mm = m * m;
+  double a1[2], P1[4], H = fn_H(mod), rd[2];
+  fn_a1P1(mod, a1, P1); fn_Rdiag(mod, rd);
+  memcpy(at, a1, sizeof(double) * m);
+  for (int q = 0; q < mm; q++) Pt[q] = (m == 1) ? P1[0] : P1[q];
+  if (m == 2) { Pt[0] = P1[0]; Pt[1] = 0; Pt[2] = 0; Pt[3] = P1[3]; }
+  for (int t = 0; t < n; t++) {
+    const double *a = at + (size_t)m * t, *P = Pt + (size_t)mm * t;
+    double *af = att + (size_t)m * t, *Pf = Ptt + (size_t)mm * t;
+    if (isfinite(mod->y[t])) {
+      double Zg[2], PZ[2] = {0, 0}, K[2], F = H * H;
+      fn_Zg(mod, a, Zg);
+      for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += P[i + m * j] * Zg[j];
+      for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
+      if (!isfinite(F) || !(F > 0)) return 0;
+      double cF = sqrt(F), v = mod->y[t] - fn_Z(mod, a);
+      for (int i = 0; i < m; i++) K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF);
+      for (int i = 0; i < m; i++) af[i] = a[i] + K[i] * v;
+      double IKZ[4], tmp[4], tmp2[4];
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
+      mat_mul(IKZ, P, m, m, m, tmp); mat_mul_bt(tmp, IKZ, m, m, m, tmp2);
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pf[i + m * j] = tmp2[i + m * j] + K[i] * H * H * K[j];
+    } else { memcpy(af, a, sizeof(double) * m); memcpy(Pf, P, sizeof(double) * mm); }
+    double Tg[4], tmp[4], tmp2[4];
+    fn_T(mod, af, at + (size_t)m * (t + 1));
+    fn_Tg(mod, af, Tg);
+    mat_mul(Tg, Pf, m, m, m, tmp); mat_mul_bt(tmp, Tg, m, m, m, tmp2);
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = tmp2[i + m * j] + (i == j ? rd[i] * rd[i] : 0.0);
+  }
+  return 1;
+}
+
+static void fn_linearise(const orc_fn_model *mod, const double *zpts /* m x n: where Z is linearised */,
+                         const double *tpts /* m x n: where T is linearised */, orc_fn_setup *su) {
+  const int n = mod->n, m = su->m;
+  for (int t = 0; t < n; t++) { /* :81-101 / :156-170 / :196-215 */
+    const double *zp = zpts + (size_t)m * t, *tp = tpts + (size_t)m * t;
+    double *Zt = su->Z + (size_t)m * t, *Tt = su->T + (size_t)m * m * t, Tf[2];
+    fn_Zg(mod, zp, Zt); fn_Tg(mod, tp, Tt);
+    su->D[t] = fn_Z(mod, zp) - dotv(Zt, zp, m);
+    fn_T(mod, tp, Tf);
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Tt[i + m * j] * tp[j]; su->C[i + (size_t)m * t] = Tf[i] - s; }
+  }
+  su->H = fn_H(mod);
+  double rd[2]; fn_Rdiag(mod, rd);
+  memset(su->R, 0, sizeof(su->R));
+  for (int i = 0; i < m; i++) su->R[i + m * i] = rd[i];
+}
+
+static void fn_approx_ulg(const orc_fn_model *mod, const orc_fn_setup *su, double *a1, double *P1, double *xb, orc_ulg_model *g) {
+  const int m = su->m;
+  double p1[4];
+  fn_a1P1(mod, a1, p1);
+  if (m == 1) P1[0] = p1[0]; else { P1[0] = p1[0]; P1[1] = 0; P1[2] = 0; P1[3] = p1[3]; }
+  memset(xb, 0, sizeof(double) * mod->n);
+  g->n = mod->n; g->m = m; g->k = m;
+  g->Ztv = 1; g->Ttv = 1; g->Rtv = 0; g->Dtv = 1; g->Ctv = 1; g->Htv = 0;
+  g->y = mod->y; g->Z = su->Z; g->T = su->T; g->R = su->R; g->a1 = a1; g->P1 = P1; g->D = su->D; g->C = su->C; g->xbeta = xb; g->H = &su->H;
+}
+
+/* src/model_ssm_nlg.cpp:1295-1319 */
+static double fn_log_signal_pdf(const orc_fn_model *mod, const double *al, int m) {
+  const int n = mod->n;
+  double a1[2], p1[4], P1[4] = {0}, rd[2], RR[4] = {0};
+  fn_a1P1(mod, a1, p1); fn_Rdiag(mod, rd);
+  if (m == 1) { P1[0] = p1[0]; RR[0] = rd[0] * rd[0]; } else { P1[0] = p1[0]; P1[3] = p1[3]; RR[0] = rd[0] * rd[0]; RR[3] = rd[1] * rd[1]; }
+  double ll = dmvnorm_cov(al, a1, P1, m);
+  if (isfinite(mod->y[0])) ll += dnorm_sd(mod->y[0], fn_Z(mod, al), fn_H(mod));
+  for (int t = 0; t < n - 1; t++) {
+    double mean[2];
+    fn_T(mod, al + (size_t)m * t, mean);
+    ll += dmvnorm_cov(al + (size_t)m * (t + 1), mean, RR, m);
+    if (isfinite(mod->y[t + 1])) ll += dnorm_sd(mod->y[t + 1], fn_Z(mod, al + (size_t)m * (t + 1)), fn_H(mod));
+  }
+  return ll;
+}
+
+int orc_fn_psi_setup(const orc_fn_model *mod, const double *is_mode, int max_iter, double conv_tol, orc_fn_setup *su) {
+  const int n = mod->n, m = su->m, mm = m * m;
+  double a1[2], P1[4];
+  double *xb = (double *)calloc(n, sizeof(double));
+  orc_ulg_model g;
+  su->ok = 1; su->iters = 0;
+  if (is_mode) { /* approximate_for_is: :146-176; scales stay 0 and approx_loglik 0 */
+    memcpy(su->mode, is_mode, sizeof(double) * m * n);
+    fn_linearise(mod, su->mode, su->mode, su);
+    memset(su->scales, 0, sizeof(double) * n);
+    su->approx_loglik = 0.0;
+    fn_approx_ulg(mod, su, a1, P1, xb, &g);
+  } else { /* approximate(): :62-143 */
+    double *at = (double *)calloc((size_t)m * (n + 1), sizeof(double)), *att = (double *)calloc((size_t)m * n, sizeof(double));
+    double *Pt = (double *)calloc((size_t)mm * (n + 1), sizeof(double)), *Ptt = (double *)calloc((size_t)mm * n, sizeof(double));
+    double *sm = (double *)calloc((size_t)m * (n + 1), sizeof(double)), *newmode = (double *)calloc((size_t)m * n, sizeof(double));
+    su->ok = fn_ekf(mod, at, att, Pt, Ptt);
+    if (su->ok) {
+      fn_linearise(mod, at, att, su); /* approximate_by_ekf :179-215: Z at a_t, T at a_t|t */
+      fn_approx_ulg(mod, su, a1, P1, xb, &g);
+      orc_ulg_fast_smoother(&g, sm);
+      memcpy(su->mode, sm, sizeof(double) * m * n);
+      for (size_t q = 0; q < (size_t)m * n; q++) if (!isfinite(su->mode[q])) su->ok = 0;
+    }
+    if (su->ok && max_iter > 0) {
+      double ll = fn_log_signal_pdf(mod, su->mode, m), rel = 1.0e300, ad = 1;
+      int i = 0;
+      while (i < max_iter && rel > conv_tol && ad > 1e-4) {
+        i++;
+        fn_linearise(mod, su->mode, su->mode, su);
+        orc_ulg_fast_smoother(&g, sm);
+        memcpy(newmode, sm, sizeof(double) * m * n);
+        double lln = fn_log_signal_pdf(mod, newmode, m);
+        ad = lln - ll; rel = ad / fabs(ll);
+        if (!isfinite(lln)) { su->ok = 0; break; }
+        /* the reference's back-tracking branch (:118-138) needs rel < -conv_tol AND ad > 1e-4 at once: unreachable */
+        memcpy(su->mode, newmode, sizeof(double) * m * n);
+        ll = lln;
+      }
+      su->iters = i;
+    }
+    if (su->ok) { /* psi_filter :974-982 */
+      double gll = orc_ulg_loglik(&g);
+      /* update_scales :854-879 */
+      double rd[2], RR[4] = {0}, HH = su->H * su->H;
+      fn_Rdiag(mod, rd);
+      if (m == 1) RR[0] = rd[0] * rd[0]; else { RR[0] = rd[0] * rd[0]; RR[3] = rd[1] * rd[1]; }
+      for (int t = 0; t < n; t++) {
+        su->scales[t] = 0.0;
+        const double *md = su->mode + (size_t)m * t;
+        if (isfinite(mod->y[t])) {
+          double am = su->D[t] + dotv(su->Z + (size_t)m * t, md, m);
+          su->scales[t] = dnorm_sd(mod->y[t], fn_Z(mod, md), fn_H(mod)) - dmvnorm_cov(&mod->y[t], &am, &HH, 1);
+        }
+      }
+      for (int t = 1; t < n; t++) {
+        const double *mp = su->mode + (size_t)m * (t - 1), *md = su->mode + (size_t)m * t;
+        double mean[2], amean[2];
+        fn_T(mod, mp, mean);
+        for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += su->T[i + m * j + (size_t)mm * (t - 1)] * mp[j]; amean[i] = su->C[i + (size_t)m * (t - 1)] + s; }
+        su->scales[t] += dmvnorm_cov(md, mean, RR, m) - dmvnorm_cov(md, amean, RR, m);
+      }
+      double ssc = 0; for (int t = 0; t < n; t++) ssc += su->scales[t];
+      su->approx_loglik = gll + ssc;
+    }
+    free(at); free(att); free(Pt); free(Ptt); free(sm); free(newmode);
+  }
+  if (su->ok) {
+    orc_ulg_smoother_ccov(&g, su->alphahat, su->Vt, su->Ct); /* :984-991 */
+    for (size_t q = 0; q < (size_t)mm * (n + 1); q++) if (!isfinite(su->Vt[q]) || !isfinite(su->Ct[q])) su->ok = 0;
+    if (su->ok) orc_conditional_cov(su->Vt, su->Ct, m, n + 1);
+  }
+  free(xb);
+  return su->ok ? 0 : -1;
+}
+
+/* src/model_ssm_nlg.cpp:880-935, one particle; aprev = ancestor (used for t > 0) */
+static double fn_psi_log_weight(const orc_fn_model *mod, const orc_fn_setup *su, int t, const double *x, const double *aprev) {
+  const int m = su->m, mm = m * m;
+  double w = 0.0, HH = su->H * su->H;
+  if (isfinite(mod->y[t])) {
+    double am = su->D[t] + dotv(su->Z + (size_t)m * t, x, m);
+    w = dnorm_sd(mod->y[t], fn_Z(mod, x), fn_H(mod)) - dmvnorm_cov(&mod->y[t], &am, &HH, 1);
+  }
+  if (t > 0) {
+    double mean[2], amean[2], rd[2], RR[4] = {0};
+    fn_T(mod, aprev, mean); fn_Rdiag(mod, rd);
+    if (m == 1) RR[0] = rd[0] * rd[0]; else { RR[0] = rd[0] * rd[0]; RR[3] = rd[1] * rd[1]; }
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += su->T[i + m * j + (size_t)mm * (t - 1)] * aprev[j]; amean[i] = su->C[i + (size_t)m * (t - 1)] + s; }
+    w -= dmvnorm_cov(x, amean, RR, m) - dmvnorm_cov(x, mean, RR, m);
+  }
+  return w;
+}
+
+/* src/model_ssm_nlg.cpp:993-1063 */
+double orc_fn_psi_filter(const orc_fn_model *mod, const orc_fn_setup *su, unsigned N, const orc_rng *rng,
+                         double *alpha, double *weights, unsigned *indices) {
+  const int n = mod->n, m = su->m, mm = m * m;
+  if (!su->ok) return -INFINITY;
+  double *nw = (double *)malloc(sizeof(double) * N), *lw = (double *)malloc(sizeof(double) * N);
+  double *r = (double *)malloc(sizeof(double) * N), *atmp = (double *)calloc((size_t)N * m, sizeof(double));
+  double um[2];
+  for (unsigned i = 0; i < N; i++) {
+    rng_normals(rng, 0, 0, i, m, um);
+    for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += su->Vt[j + m * c] * um[c]; A_(j, 0, i) = su->alphahat[j] + s; }
+  }
+  double loglik = su->approx_loglik, inc;
+  if (isfinite(mod->y[0])) {
+    for (unsigned i = 0; i < N; i++) lw[i] = fn_psi_log_weight(mod, su, 0, &A_(0, 0, i), atmp) - su->scales[0];
+    if (!normalise_step(lw, N, weights, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+    loglik += inc;
+  } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
+  for (int t = 0; t < n; t++) {
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
+    const double *ah0 = su->alphahat + (size_t)m * t, *ah1 = su->alphahat + (size_t)m * (t + 1);
+    const double *Ct1 = su->Ct + (size_t)mm * (t + 1), *Vt1 = su->Vt + (size_t)mm * (t + 1);
+    for (unsigned i = 0; i < N; i++) {
+      rng_normals(rng, 2, t, i, m, um);
+      for (int j = 0; j < m; j++) {
+        double s = 0, q = 0;
+        for (int c = 0; c < m; c++) s += Ct1[j + m * c] * (atmp[c + (size_t)m * i] - ah0[c]);
+        for (int c = 0; c < m; c++) q += Vt1[j + m * c] * um[c];
+        A_(j, t + 1, i) = ah1[j] + s + q;
+      }
+    }
+    double *wcol = weights + (size_t)N * (t + 1);
+    if ((t < n - 1) && isfinite(mod->y[t + 1])) {
+      for (unsigned i = 0; i < N; i++) lw[i] = fn_psi_log_weight(mod, su, t + 1, &A_(0, t + 1, i), atmp + (size_t)m * i) - su->scales[t + 1];
+      if (!normalise_step(lw, N, wcol, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+      loglik += inc;
+    } else for (unsigned i = 0; i < N; i++) { wcol[i] = 1.0; nw[i] = 1.0 / N; }
+  }
+done:
+  free(nw); free(lw); free(r); free(atmp);
+  return loglik;
+}

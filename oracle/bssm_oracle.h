@@ -217,6 +217,25 @@ typedef struct {
 double orc_fn_bsf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rng, double *alpha, double *weights,
                          unsigned *indices);
 
+/* psi-APF of ssm_nlg (ids 1-4): approximate() / approximate_for_is() + psi_filter, src/model_ssm_nlg.cpp:62-222,
+ * 284-381 (ekf), 854-935 (update_scales, log_weights), 971-1063, 1295-1319 (log_signal_pdf).  The approximating
+ * model is the mode-linearised Gaussian model (time-varying Z_t, T_t, D_t, C_t). */
+typedef struct {
+  int n, m;
+  double *Z, *T, *D, *C;       /* m x n, m x m x n, n, m x n */
+  double H, R[4];              /* observation sd and R (m x m, diagonal) at the mode: constant in every shipped model */
+  double *mode;                /* m x n state mode */
+  double *scales;              /* n */
+  double approx_loglik;
+  double *alphahat, *Vt, *Ct;  /* m x (n+1), m x m x (n+1) */
+  int iters, ok;
+} orc_fn_setup;
+orc_fn_setup *orc_fn_setup_alloc(int n, int m);
+void orc_fn_setup_free(orc_fn_setup *s);
+int orc_fn_psi_setup(const orc_fn_model *mod, const double *is_mode, int max_iter, double conv_tol, orc_fn_setup *out);
+double orc_fn_psi_filter(const orc_fn_model *mod, const orc_fn_setup *su, unsigned N, const orc_rng *rng,
+                         double *alpha, double *weights, unsigned *indices);
+
 #ifdef __cplusplus
 }
 #endif

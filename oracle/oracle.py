@@ -378,3 +378,50 @@ def fn_bsf_filter(model: dict, nsim: int, seed=1, stream=0):
     indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
     ll = L.orc_fn_bsf_filter(C.byref(s), C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights), indices.ctypes.data_as(c_uint_p))
     return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices)
+
+
+class OrcFnSetup(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("Z", c_double_p), ("T", c_double_p), ("D", c_double_p), ("C", c_double_p),
+                ("H", C.c_double), ("R", C.c_double * 4), ("mode", c_double_p), ("scales", c_double_p),
+                ("approx_loglik", C.c_double), ("alphahat", c_double_p), ("Vt", c_double_p), ("Ct", c_double_p),
+                ("iters", C.c_int), ("ok", C.c_int)]
+
+
+def _pack_fn(model):
+    s = OrcFn()
+    y = np.ascontiguousarray(model["y"], dtype=np.float64)
+    s.id, s.n, s.y = int(model["model_id"]), y.size, _p(y)
+    for i, v in enumerate(np.asarray(model["theta"], dtype=float)): s.theta[i] = v
+    for i, v in enumerate(np.asarray(model.get("known_params", []), dtype=float)): s.known[i] = v
+    s.x0, s.positive, s.L = float(model.get("x0", 0.0)), int(bool(model.get("positive", False))), int(model.get("L", 0))
+    return s, [y]
+
+
+def fn_psi_setup(model: dict, is_mode=None, max_iter=100, conv_tol=1e-8):
+    """is_mode: m x n state mode (mode_storage of the approximate chain) or None"""
+    L = lib()
+    L.orc_fn_setup_alloc.restype = C.POINTER(OrcFnSetup)
+    s, keep = _pack_fn(model)
+    n, m = s.n, 2 if s.id == 1 else 1
+    su = L.orc_fn_setup_alloc(n, m)
+    mode = None if is_mode is None else np.asfortranarray(np.asarray(is_mode, dtype=np.float64).reshape((m, n), order="F"))
+    rc = L.orc_fn_psi_setup(C.byref(s), _p(mode), C.c_int(max_iter), C.c_double(conv_tol), su)
+    c = su.contents
+    g = lambda ptr, shape: np.ctypeslib.as_array(ptr, (int(np.prod(shape)),)).copy().reshape(shape, order="F")
+    return dict(rc=rc, ok=c.ok, iters=c.iters, approx_loglik=c.approx_loglik, mode=g(c.mode, (m, n)), scales=g(c.scales, (n,)),
+                Z=g(c.Z, (m, n)), T=g(c.T, (m, m, n)), D=g(c.D, (n,)), C=g(c.C, (m, n)), H=c.H,
+                alphahat=g(c.alphahat, (m, n + 1)), Vt=g(c.Vt, (m, m, n + 1)), Ct=g(c.Ct, (m, m, n + 1)), _handle=su)
+
+
+def fn_psi_filter(model: dict, nsim: int, seed=1, stream=0, is_mode=None, setup=None):
+    L = lib()
+    L.orc_fn_psi_filter.restype = C.c_double
+    s, keep = _pack_fn(model)
+    su = setup if setup is not None else fn_psi_setup(model, is_mode)
+    rng, _ = make_rng(seed, stream)
+    n, m = s.n, 2 if s.id == 1 else 1
+    alpha = np.zeros((m, n + 1, nsim), order="F"); weights = np.zeros((nsim, n + 1), order="F")
+    indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+    ll = L.orc_fn_psi_filter(C.byref(s), su["_handle"], C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights),
+                             indices.ctypes.data_as(c_uint_p))
+    return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices, setup=su)

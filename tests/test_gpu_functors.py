@@ -79,3 +79,57 @@ def test_nlg_linear_gaussian_equals_kalman(oracle):
 def test_unknown_example_is_rejected():
     with pytest.raises(ValueError, match="built in"):
         M.ssm_nlg([1.0, 2.0], "my_snippet", theta=[0.0])
+
+
+# ---------------------------------------------------------------- psi-APF of ssm_nlg
+@pytest.mark.parametrize("name", ["nlg_growth", "nlg_ar_exp", "nlg_sin_exp", "nlg_linear_gaussian"])
+def test_nlg_psi_setup_matches_oracle(oracle, name):
+    model, _ = MODELS[name]
+    so, sp = oracle.fn_psi_setup(model), F.psi_setup(model)
+    assert so["ok"] == 1
+    for k in ("mode", "scales", "alphahat", "Vt", "Ct", "Z", "T", "D", "C"):
+        assert np.allclose(so[k], sp[k], rtol=1e-9, atol=1e-10), k
+    assert np.isclose(so["approx_loglik"], sp["approx_loglik"], rtol=1e-11)
+    so2, sp2 = oracle.fn_psi_setup(model, is_mode=so["mode"]), F.psi_setup(model, is_mode=so["mode"])
+    assert sp2["approx_loglik"] == 0.0 and np.all(sp2["scales"] == 0.0)
+    assert np.allclose(so2["Vt"], sp2["Vt"], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+@pytest.mark.parametrize("name", ["nlg_growth", "nlg_ar_exp", "nlg_sin_exp", "nlg_linear_gaussian"])
+def test_nlg_psi_smoother(oracle, monkeypatch, name, path):
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    model, _ = MODELS[name]
+    n = model.n
+    out = F.particle_smoother(model, 80, method="psi", seed=3, return_indices=True)
+    ref = oracle.fn_psi_filter(model, 80, seed=3)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(out["weights"], ref["weights"]) <= 1e-7
+    mean, cov = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8 and _rel(out["Vt"], cov[:, :, :n]) <= 1e-7
+    assert abs(F.logLik(model, 80, method="psi", seed=3) - ref["logLik"]) <= 1e-9 * n
+
+
+def test_nlg_post_correct(oracle):
+    """postcorrection_nonlinear (src/R_postcorrection.cpp:252-317): is_correction_psi over theta-draws of the growth model"""
+    from bssm_amd import post_correct as PC
+    model, _ = MODELS["nlg_growth"]
+    rng = np.random.default_rng(2)
+    ns = 6
+    theta = np.array([0.0, np.log(0.05), 0.0]) + 0.05 * rng.normal(size=(ns, 3))
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    modes = np.stack([oracle.fn_psi_setup({**model, "theta": th})["mode"].reshape(-1, order="F") for th in theta], axis=1)
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type=2)
+    out = PC.post_correct(model, mo, 32, threads=2, is_type="is2", seed=11)
+    m, n = 2, model.n
+    ah = np.zeros((m, n + 1, ns)); vt = np.zeros((m, m, n + 1, ns)); w = np.zeros(ns)
+    for i, th in enumerate(theta):
+        mi = {**model, "theta": th}
+        ref = oracle.fn_psi_filter(mi, 32, seed=11, stream=i, is_mode=modes[:, i].reshape((m, n), order="F"))
+        assert abs(out["loglik"][i] - ref["logLik"]) <= 1e-9 * n
+        w[i] = np.exp(ref["logLik"])
+        ah[:, :, i], vt[:, :, :, i] = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert np.allclose(out["weights"], w, rtol=1e-8)
+    wc = w * counts
+    assert np.allclose(out["alphahat"], (np.tensordot(ah, wc, axes=([2], [0])) / wc.sum()).T, rtol=1e-7, atol=1e-9)
