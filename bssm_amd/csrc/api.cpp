@@ -505,6 +505,39 @@ int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t sam
   return deg ? BSSM_WARN_DEGENERATE : BSSM_OK;
 }
 
+// replaces _bssm_gaussian_psi_smoother (src/R_psi.cpp:14-50) for the ssm_ulg family (model_type 1..3)
+int bssm_gaussian_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int model_type, double* alpha) {
+  if (!alpha || nsim < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  if (model_type == 0) return fail(BSSM_ERR_UNSUPPORTED, "ssm_mlg (multivariate gaussian) is outside the particle-filter scope of this build");
+  if (model_type < 1 || model_type > 3) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
+  bssm::HostModel hm;
+  const std::string err = bssm::ingest_model(model, false, &hm);
+  if (!err.empty()) return fail(BSSM_ERR_INVALID, err);
+  if (!hm.gaussian()) return fail(BSSM_ERR_INVALID, "gaussian_psi_smoother needs a linear-Gaussian model");
+  bssm::PsiSetup su;
+  if (!bssm::gaussian_smoothing_setup(hm, &su)) return fail(BSSM_ERR_NUMERIC, "smoother produced non-finite values");
+  if (!have_device()) return no_device();
+  const int n = hm.n, m = hm.m, N = (int)nsim, MS = 2 * m * m + m;
+  std::vector<double> mats((size_t)n * MS), init((size_t)m + m * m);
+  for (int t = 0; t < n; t++) {
+    double* mt = mats.data() + (size_t)t * MS;
+    const double* Ct1 = su.Ct.data() + (size_t)m * m * (t + 1); const double* Vt1 = su.Vt.data() + (size_t)m * m * (t + 1);
+    for (int q = 0; q < m * m; q++) { mt[q] = Ct1[q]; mt[m * m + q] = Vt1[q]; }
+    for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += Ct1[j + m * c] * su.alphahat[c + (size_t)m * t]; mt[2 * m * m + j] = su.alphahat[j + (size_t)m * (t + 1)] - s; }
+  }
+  for (int j = 0; j < m; j++) init[j] = su.alphahat[j];
+  for (int q = 0; q < m * m; q++) init[m + q] = su.Vt[q];
+  DevBuf dm, di, hist, cube;
+  HIP_TRY(dm.alloc(mats.size() * sizeof(double))); HIP_TRY(di.alloc(init.size() * sizeof(double)));
+  HIP_TRY(hist.alloc((size_t)(n + 1) * m * N * sizeof(double))); HIP_TRY(cube.alloc(hist.bytes));
+  HIP_TRY(hipMemcpy(dm.p, mats.data(), dm.bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(di.p, init.data(), di.bytes, hipMemcpyHostToDevice));
+  HIP_TRY(bssm::launch_sim_smoother(dm.as<double>(), di.as<double>(), hist.as<double>(), n, m, N, seed, nullptr));
+  HIP_TRY(bssm::launch_to_cube(hist.as<double>(), cube.as<double>(), 1, n + 1, m, N, nullptr));
+  HIP_TRY(hipMemcpy(alpha, cube.p, cube.bytes, hipMemcpyDeviceToHost));
+  return BSSM_OK;
+}
+
 int bssm_psi_setup(const bssm_ung_model* model, const double* is_mode, double* approx_y, double* approx_H, double* mode,
                    double* scales, double* approx_loglik, double* alphahat, double* Vt, double* Ct) {
   bssm::HostModel hm;

@@ -546,6 +546,30 @@ bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out) {
   return ok;
 }
 
+bool gaussian_smoothing_setup(const HostModel& h, PsiSetup* out) {
+  if (!h.gaussian()) return false;
+  const int n = h.n, m = h.m;
+  const Sys S(h);
+  Approx ap;
+  ap.y = h.y;
+  ap.H.resize(n);
+  for (int t = 0; t < n; t++) ap.H[t] = h.H[t * h.Htv];
+  std::vector<Mat> at, Vt, Ct;
+  if (!smoother_ccov(S, ap, &at, &Vt, &Ct)) return false;
+  conditional_cov(&Vt, &Ct);
+  out->scales.assign(n, 0.0);
+  out->approx_y = ap.y; out->approx_H = ap.H; out->mode.assign(n, 0.0);
+  out->alphahat.assign((size_t)m * (n + 1), 0.0);
+  out->Vt.assign((size_t)m * m * (n + 1), 0.0);
+  out->Ct.assign((size_t)m * m * (n + 1), 0.0);
+  bool ok = true;
+  for (int t = 0; t <= n; t++) {
+    for (int i = 0; i < m; i++) { out->alphahat[i + (size_t)m * t] = at[t](i, 0); ok &= std::isfinite(at[t](i, 0)); }
+    for (int q = 0; q < m * m; q++) { out->Vt[q + (size_t)m * m * t] = Vt[t].a[q]; out->Ct[q + (size_t)m * m * t] = Ct[t].a[q]; ok &= std::isfinite(Vt[t].a[q]) && std::isfinite(Ct[t].a[q]); }
+  }
+  return ok;
+}
+
 double approx_loglik_only(const HostModel& h) {
   const Sys S(h);
   Approx ap;

@@ -42,6 +42,9 @@ struct PsiSetup {
 };
 // is_mode == nullptr: iterate from hm.initial_mode.  Returns false on a numerical failure.
 bool psi_setup(const HostModel& hm, const double* is_mode, PsiSetup* out);
+// exact smoothing factors of a linear-Gaussian (ssm_ulg family) model for gaussian_psi_smoother:
+// smoother_ccov + conditional_cov on the model itself (src/model_ssm_ulg.cpp:646-652)
+bool gaussian_smoothing_setup(const HostModel& hm, PsiSetup* out);
 // log-likelihood of the Gaussian approximation only (nsim = 0 path, src/model_ssm_ung.cpp:214-234)
 double approx_loglik_only(const HostModel& hm);
 

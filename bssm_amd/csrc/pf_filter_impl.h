@@ -90,6 +90,49 @@ __device__ __forceinline__ void initial_state(const double* __restrict__ ini, co
 // ------------------------------------------------------------------------------------------
 // Workgroup-resident filter
 // ------------------------------------------------------------------------------------------
+// Transition of 64 particles (one wave) for an 8-dimensional state on the matrix cores:
+//   X' (8 x 64) = C + [T R] (8 x 16) . [A ; Z] (16 x 64)     with v_mfma_f64_16x16x4_f64
+// (ssm_mng's m = 8, k <= 8 case -- the one place on this path where the transition is a real dense contraction;
+// src/model_ssm_mng.cpp:611-618).  Operand staging goes through a per-wave LDS tile: lanes hold "my particle, all
+// components", the MFMA wants B[k = lane>>4 (+4kk)][j = lane&15] and returns D[row = (lane>>4) + 4 reg][col = lane&15]
+// (f64 fragment layout, cdna_hip_programming.md section 3).  Rows 8..15 of [T R] are zero padding.
+template <int KP>
+__device__ __forceinline__ void propagate_mfma8(const double* __restrict__ mt, const double (&a)[8], const double (&z)[KP],
+                                                double (&x)[8], double* tile /* 16 x 64 doubles, this wave's */, int lane) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int c = 0; c < 8; c++) tile[c * 64 + lane] = a[c];
+#pragma unroll
+  for (int c = 0; c < 8; c++) tile[(8 + c) * 64 + lane] = c < KP ? z[c < KP ? c : 0] : 0.0;
+  const int i = lane & 15, kq = lane >> 4;
+  double afr[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    const int k = 4 * kk + kq;  // column of [T R]
+    afr[kk] = (i < 8) ? (k < 8 ? mt[i + 8 * k] : ((k - 8) < KP ? mt[64 + i + 8 * (k - 8)] : 0.0)) : 0.0;
+  }
+  const double* __restrict__ Cv = mt + 64 + 8 * KP;
+  const double c0 = Cv[kq], c1 = Cv[kq + 4];
+  __builtin_amdgcn_wave_barrier();
+  d4 acc[4];
+#pragma unroll
+  for (int blk = 0; blk < 4; blk++) {
+    acc[blk] = d4{c0, c1, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+      acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], tile[(4 * kk + kq) * 64 + 16 * blk + i], acc[blk], 0, 0, 0);
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int blk = 0; blk < 4; blk++) {  // rows kq and kq + 4 of the result are state components
+    tile[kq * 64 + 16 * blk + i] = acc[blk][0];
+    tile[(kq + 4) * 64 + 16 * blk + i] = acc[blk][1];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int c = 0; c < 8; c++) x[c] = tile[c * 64 + lane];
+}
+
 // one particle's log-weight for whichever model family the kernel was instantiated for
 template <int MP, bool FN>
 __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const double* __restrict__ fpar,
@@ -374,6 +417,8 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
   __shared__ double s_iscale[GRID_NT];  // 1 / exp(max_b - M)
   __shared__ double s_red[8];
   __shared__ double s_tot[PPT * 4];
+  constexpr bool kMfma = MP == 8 && PPT == 1 && !FN;  // fp64 MFMA transition (ssm_mng m = 8)
+  __shared__ double s_tile[kMfma ? 4 * 16 * 64 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pb = blockIdx.x, f = blockIdx.y, B = ws.B, chunk = ws.chunk, crow = chunk >> 4;
   const int N = b.N, n = b.n, m = b.m;
@@ -472,7 +517,7 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
     #pragma unroll
       for (int r = 0; r < PPT; r++) {
         const int li = r * GRID_NT + tid, j = base + li;
-        if (li >= len) { for (int c = 0; c < MP; c++) x[r][c] = 0.0; continue; }
+        if (!kMfma && li >= len) { for (int c = 0; c < MP; c++) x[r][c] = 0.0; continue; }  // (MFMA needs the whole wave)
         double u;
         if constexpr (kEarlyRng) u = u_pre[r]; else u = rng_uniform(key, RNG_RESAMPLE, (uint32_t)t, (uint32_t)j, 0);
         const double v = (u + (double)j) * c_scale;
@@ -506,7 +551,7 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
         const int fine = search16_global(lcdf + (size_t)sb * chunk + 16 * crw, min(16, slen - 16 * crw), vp);
         const int anc = sb * chunk + 16 * crw + fine;
         BSSM_STAMP(5)
-        if (b.indices) b.indices[((size_t)f * n + t) * N + j] = (uint32_t)anc;
+        if (b.indices && li < len) b.indices[((size_t)f * n + t) * N + j] = (uint32_t)anc;
         double a[MP];
   #pragma unroll
         for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
@@ -521,6 +566,8 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
           }
 #pragma unroll
           for (int c = 0; c < MP; c++) aprev[r][c] = a[c];
+        } else if constexpr (kMfma) {
+          if constexpr (MP == 8) propagate_mfma8<KP>(mt, a, z_pre[r], x[r], s_tile + wave * (16 * 64), lane);
         } else if constexpr (kEarlyRng) {
           propagate<MP, KP>(mt, a, z_pre[r], x[r]);
         } else {
@@ -528,8 +575,10 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
           rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
           propagate<MP, KP>(mt, a, z, x[r]);
         }
+        if (li < len) {
   #pragma unroll
-        for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[r][c];
+          for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[r][c];
+        }
       }
     }
   }

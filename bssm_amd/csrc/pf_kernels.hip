@@ -99,6 +99,41 @@ hipError_t launch_zero_dead_tail(const FilterBatch& b, bool weights_too, hipStre
   return hipGetLastError();
 }
 
+// gaussian_psi_smoother (src/model_ssm_ulg.cpp:644-672): every particle is an independent draw from the joint
+// smoothing distribution, alpha_{t+1} = alphahat_{t+1} + C_{t+1}(alpha_t - alphahat_t) + V_{t+1} u: no weights, no
+// resampling, so one lane walks one trajectory.  `mats` rows hold (C_{t+1}, V_{t+1}, alphahat_{t+1} - C_{t+1} alphahat_t).
+__global__ void __launch_bounds__(256) sim_smoother_kernel(const double* __restrict__ mats, const double* __restrict__ init,
+                                                           double* __restrict__ hist, int n, int m, int N, uint32_t seed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const RngKey key{seed, 0u};
+  const int MS = 2 * m * m + m;
+  double x[16], z[16], xn[16];
+  for (int d = 0; d < m; d += 2) rng_normal_pair(key, RNG_INIT, 0u, (uint32_t)i, (uint32_t)(d >> 1), z[d], z[d + 1]);
+  for (int j = 0; j < m; j++) {
+    double s = init[j];
+    for (int c = 0; c < m; c++) s += init[m + j + m * c] * z[c];
+    x[j] = s;
+    hist[(size_t)j * N + i] = s;
+  }
+  for (int t = 0; t < n; t++) {
+    const double* __restrict__ mt = mats + (size_t)t * MS;
+    for (int d = 0; d < m; d += 2) rng_normal_pair(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, (uint32_t)(d >> 1), z[d], z[d + 1]);
+    for (int j = 0; j < m; j++) {
+      double s = 0.0, q = 0.0;
+      for (int c = 0; c < m; c++) { s += mt[j + m * c] * x[c]; q += mt[m * m + j + m * c] * z[c]; }
+      xn[j] = mt[2 * m * m + j] + s + q;
+    }
+    for (int j = 0; j < m; j++) { x[j] = xn[j]; hist[((size_t)(t + 1) * m + j) * N + i] = xn[j]; }
+  }
+}
+hipError_t launch_sim_smoother(const double* mats, const double* init, double* hist, int n, int m, int N, uint32_t seed,
+                               hipStream_t stream) {
+  if (m > 14) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sim_smoother_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, mats, init, hist, n, m, N, seed);
+  return hipGetLastError();
+}
+
 // test hook: evaluate the kernels' elementary functions on an array (see tests/test_gpu_math.py)
 __global__ void debug_math_kernel(int fn, const double* __restrict__ in, double* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

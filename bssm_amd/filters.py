@@ -145,10 +145,15 @@ def particle_smoother(model: BssmModel, particles: int, method: str = "psi", see
     if method == "ekf":
         raise ValueError("Method 'ekf' is only applicable to ssm_nlg models.")
     gaussian = model.inherits("lineargaussian")
-    if gaussian and method == "psi":
-        raise NotImplementedError("psi-APF for linear-Gaussian models is exact simulation smoothing "
-                                  "(gaussian_psi_smoother); use method='bsf'.")
     n, m = model.n, model.m
+    if gaussian and method == "psi":  # R/particle_smoother.R:107-122: exact simulation smoother, moments taken over the draws
+        arr, smod, keep = _prep(model, False)
+        alpha = _alloc((m, n + 1, particles))
+        _lib.check(_lib.lib().bssm_gaussian_psi_smoother(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed),
+                                                         model_type(model), _lib.dptr(alpha)))
+        alphahat = alpha.mean(axis=2).T
+        Vt = np.stack([np.atleast_2d(np.cov(alpha[:, t, :], ddof=1)) for t in range(n + 1)], axis=2)
+        return dict(alphahat=alphahat[:n, :], Vt=Vt[:, :, :n], alpha=np.transpose(alpha, (1, 0, 2)))
     arr, smod, keep = _prep(model, method == "psi")
     out = _lib.FilterOut()
     alphahat, Vt = _alloc((n + 1, m)), _alloc((m, m, n + 1))

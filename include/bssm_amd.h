@@ -123,6 +123,11 @@ int bssm_bsf_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
 int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int model_type,
                       bssm_filter_out* out);
 
+/* replaces _bssm_gaussian_psi_smoother: `arma::cube gaussian_psi_smoother(model_, nsim, seed, model_type)`
+ * src/R_psi.cpp:14-50 -> ssm_ulg::psi_filter src/model_ssm_ulg.cpp:644-672 (exact draws from the joint smoothing
+ * distribution; model_type 1..3).  alpha: m x (n+1) x N. */
+int bssm_gaussian_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int model_type, double* alpha);
+
 /* replaces _bssm_nongaussian_loglik: `double nongaussian_loglik(model_, nsim, sampling_method, seed,
  * model_type)` src/R_loglik.cpp:41-87.  nsim = 0 returns the Gaussian-approximation log-likelihood
  * (src/model_ssm_ung.cpp:214-234). */

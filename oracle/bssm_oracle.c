@@ -1725,3 +1725,29 @@ done:
   free(nw); free(lw); free(r); free(atmp);
   return loglik;
 }
+
+
+/* ssm_ulg::psi_filter, src/model_ssm_ulg.cpp:644-672: exact draws from the joint smoothing distribution */
+void orc_ulg_psi_filter(const orc_ulg_model *g, unsigned N, const orc_rng *rng, double *alpha) {
+  const int n = g->n, m = g->m, mm = m * m;
+  double *ah = (double *)calloc((size_t)m * (n + 1), sizeof(double));
+  double *Vt = (double *)calloc((size_t)mm * (n + 1), sizeof(double)), *Ct = (double *)calloc((size_t)mm * (n + 1), sizeof(double));
+  double um[ORC_MAXM];
+  orc_ulg_smoother_ccov(g, ah, Vt, Ct);
+  orc_conditional_cov(Vt, Ct, m, n + 1);
+  for (unsigned i = 0; i < N; i++) {
+    rng_normals(rng, 0, 0, i, m, um);
+    for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += Vt[j + m * c] * um[c]; A_(j, 0, i) = ah[j] + s; }
+  }
+  for (int t = 0; t < n; t++)
+    for (unsigned i = 0; i < N; i++) {
+      rng_normals(rng, 2, t, i, m, um);
+      for (int j = 0; j < m; j++) {
+        double s = 0, q = 0;
+        for (int c = 0; c < m; c++) s += Ct[j + m * c + (size_t)mm * (t + 1)] * (A_(c, t, i) - ah[c + (size_t)m * t]);
+        for (int c = 0; c < m; c++) q += Vt[j + m * c + (size_t)mm * (t + 1)] * um[c];
+        A_(j, t + 1, i) = ah[j + (size_t)m * (t + 1)] + s + q;
+      }
+    }
+  free(ah); free(Vt); free(Ct);
+}

@@ -139,6 +139,8 @@ double orc_ulg_loglik(const orc_ulg_model *g);
 void orc_ulg_fast_smoother(const orc_ulg_model *g, double *at);
 /* src/model_ssm_ulg.cpp:419-473 ; at m x (n+1), Pt/ccov m x m x (n+1) */
 void orc_ulg_smoother_ccov(const orc_ulg_model *g, double *at, double *Pt, double *ccov);
+/* src/model_ssm_ulg.cpp:644-672 (gaussian_psi_smoother): alpha m x (n+1) x N */
+void orc_ulg_psi_filter(const orc_ulg_model *g, unsigned N, const orc_rng *rng, double *alpha);
 /* src/conditional_dist.cpp:4-31 (use_svd = true branch) */
 void orc_conditional_cov(double *Vt, double *Ct, int m, int n1);
 

@@ -425,3 +425,13 @@ def fn_psi_filter(model: dict, nsim: int, seed=1, stream=0, is_mode=None, setup=
     ll = L.orc_fn_psi_filter(C.byref(s), su["_handle"], C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights),
                              indices.ctypes.data_as(c_uint_p))
     return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices, setup=su)
+
+
+def ulg_psi_filter(arr: dict, nsim: int, seed=1):
+    """ssm_ulg::psi_filter (gaussian_psi_smoother): alpha m x (n+1) x N"""
+    g, keep = _pack_ulg(arr)
+    rng, _ = make_rng(seed, 0)
+    n, m = arr["n"], arr["m"]
+    alpha = np.zeros((m, n + 1, nsim), order="F")
+    lib().orc_ulg_psi_filter(C.byref(g), C.c_uint(nsim), C.byref(rng), _p(alpha))
+    return alpha

@@ -101,3 +101,21 @@ def mng_zoo():
     zoo["c4_m8_p4"] = M.ssm_mng(y, Z, 0.95 * Q, 0.1 * np.eye(m), a1=np.zeros(m), P1=0.05 * np.eye(m),
                                 distribution=["poisson", "poisson", "negative binomial", "gaussian"], phi=[1, 1, 5, 0.5])
     return zoo
+
+
+def mng_c4(n=2000, seed=104):
+    """ssm_mng m = 8, k = 8, p = 4; T = 0.95 Q (Q random orthogonal), R = 0.1 I, Z ~ N(0, 0.25),
+    distributions (poisson, poisson, negbin phi = 5, gaussian sd 0.5)."""
+    rng = np.random.default_rng(seed)
+    m, p = 8, 4
+    Q = np.linalg.qr(rng.normal(size=(m, m)))[0]
+    T, R, Z = 0.95 * Q, 0.1 * np.eye(m), rng.normal(0, 0.5, (p, m))
+    a = np.zeros(m)
+    y = np.zeros((n, p))
+    for t in range(n):
+        s = Z @ a
+        y[t] = [rng.poisson(np.exp(s[0])), rng.poisson(np.exp(s[1])), rng.negative_binomial(5, 5 / (5 + np.exp(s[2]))),
+                s[3] + 0.5 * rng.normal()]
+        a = T @ a + R @ rng.normal(size=m)
+    return M.ssm_mng(y, Z, T, R, a1=np.zeros(m), P1=0.1 * np.eye(m),
+                     distribution=["poisson", "poisson", "negative binomial", "gaussian"], phi=[1, 1, 5, 0.5])

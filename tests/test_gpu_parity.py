@@ -145,3 +145,17 @@ def test_full_size_c2_m4_against_oracle(oracle):
     frac = np.mean(out["indices"] != ref["indices"])
     assert same or frac < 1e-6, f"ancestor mismatch fraction {frac}"
     assert abs(out["logLik"] - ref["logLik"]) <= (1e-9 if same else 1e-4) * 60
+
+
+def test_gaussian_psi_smoother(oracle):
+    """gaussian_psi_smoother (src/R_psi.cpp:14-50): exact draws from the joint smoothing distribution; parity with
+    the oracle on the same stream and agreement with the exact Kalman smoother (tests/testthat/test_particle_smoother.R:33-45)."""
+    model = M.bsm_lg(np.ones(5), sd_level=0.05, sd_slope=0.01, sd_y=0.01, a1=[1, 0], P1=np.diag([0.01, 0.01]))
+    arr = M.model_arrays(model)
+    out = F.particle_smoother(model, 4000, method="psi", seed=1)
+    ref = oracle.ulg_psi_filter(arr, 4000, seed=1)
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref) <= 1e-8
+    at, Pt, _ = oracle.ulg_smoother(arr)
+    assert np.allclose(out["alphahat"], at.T[:5], atol=1e-2) and np.allclose(out["Vt"], Pt[:, :, :5], atol=1e-2)
+    bsf = F.particle_smoother(model, 10000, method="bsf", seed=1)
+    assert np.allclose(out["alphahat"], bsf["alphahat"], atol=1e-2) and np.allclose(out["Vt"], bsf["Vt"], atol=1e-2)
