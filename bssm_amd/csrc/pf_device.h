@@ -22,7 +22,7 @@ enum { RH_FLAG = 0, RH_SCALE = 1, ROW_HDR = 2 };
 enum { OB_Y = 0, OB_U = 1, OB_D = 2, OB_PSIY = 3, OB_PSIIH = 4, OB_AUX = 5, OB_FLAG = 6, OB_DIST = 7, OB_PHI = 8, SER_HDR = 10 };
 // distribution codes = R/bootstrap_filter.R:106-109 ; 5 = gaussian (ssm_ulg path)
 enum { DIST_SVM = 0, DIST_POISSON = 1, DIST_BINOMIAL = 2, DIST_NEGBIN = 3, DIST_GAMMA = 4, DIST_GAUSSIAN = 5 };
-// RNG purposes
+// RNG purposes (1 is retired: the resampling uniform rides in the step block, see rng_step_block)
 enum { RNG_INIT = 0, RNG_RESAMPLE = 1, RNG_TRANSITION = 2, RNG_PICK = 3, RNG_SDE = 4 };
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -48,18 +48,48 @@ __host__ __device__ __forceinline__ uint64_t bits53(uint32_t a, uint32_t b) {
 
 struct RngKey { uint32_t seed, stream; };
 
-// U[0,1) with 53 random bits
+// U[0,1) with 53 random bits (trajectory picks; not on the per-step path)
 __device__ __forceinline__ double rng_uniform(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d) {
   const u32x4 w = philox4x32_10(i, t, d, purpose, k.seed, k.stream);
   return u53_to_double(w.x >> 5, w.y >> 6) * 0x1.0p-53;
 }
 
+// One Philox block serves a Box-Muller pair and leaves one word over:
+//   words 0,1 -> 53-bit radius uniform in (0,1];  word 2 -> 32-bit angle;  word 3 -> spare 32-bit uniform.
+// The block (particle i, step t, draw 0, RNG_TRANSITION) is the "step block": its spare word is the stratified
+// resampling uniform of output slot i at step t, its pair the first two transition normals of the same slot, so
+// a particle-step of a model with <= 2 noise terms costs a single Philox call.
+__device__ __forceinline__ u32x4 rng_step_block(RngKey k, uint32_t t, uint32_t i) {
+  return philox4x32_10(i, t, 0u, RNG_TRANSITION, k.seed, k.stream);
+}
+__device__ __forceinline__ double block_uniform(const u32x4& w) { return (double)w.w * 0x1.0p-32; }  // [0,1)
+__device__ __forceinline__ double rng_resample_uniform(RngKey k, uint32_t t, uint32_t i) {
+  return block_uniform(rng_step_block(k, t, i));
+}
+
+// sqrt for the Box-Muller radius argument x = -2 log(u) in [0, 74]: v_rsq_f64 seed, one coupled
+// Newton step and two residual corrections; no range scaling needed on this interval.  <= 1 ulp.
+__device__ __forceinline__ double sqrt_small(double x) {
+#if BSSM_FAST_MATH
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return x > 0.0 ? g : 0.0;
+#else
+  return sqrt(x);
+#endif
+}
+
 // Box-Muller pair from one Philox block
 __device__ __forceinline__ void box_muller(const u32x4& w, double& z0, double& z1) {
   const double u1 = (u53_to_double(w.x >> 5, w.y >> 6) + 1.0) * 0x1.0p-53;  // (0,1]
-  const double rad = sqrt(-2.0 * fast_log(u1));
+  const double rad = sqrt_small(-2.0 * fast_log(u1));
   double sn, cs;
-  fast_sincos_2pi(w.z >> 5, w.w >> 6, sn, cs);  // angle 2*pi*u2, u2 in [0,1)
+  fast_sincos_2pi(w.z, sn, cs);  // angle 2*pi*w2*2^-32
   z0 = rad * cs;
   z1 = rad * sn;
 }
@@ -68,15 +98,22 @@ __device__ __forceinline__ void rng_normal_pair(RngKey k, uint32_t purpose, uint
   box_muller(philox4x32_10(i, t, d, purpose, k.seed, k.stream), z0, z1);
 }
 
+// CNT normals for (purpose, t, i): pair d comes from block (i, t, d, purpose); blk0 is block d = 0, already drawn
 template <int CNT>
-__device__ __forceinline__ void rng_normals(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, double (&out)[CNT]) {
+__device__ __forceinline__ void rng_normals_blk(const u32x4& blk0, RngKey k, uint32_t purpose, uint32_t t, uint32_t i,
+                                                double (&out)[CNT]) {
 #pragma unroll
   for (int j = 0; j < CNT; j += 2) {
     double z0, z1;
-    rng_normal_pair(k, purpose, t, i, (uint32_t)(j / 2), z0, z1);
+    if (j == 0) box_muller(blk0, z0, z1);
+    else rng_normal_pair(k, purpose, t, i, (uint32_t)(j / 2), z0, z1);
     out[j] = z0;
     if (j + 1 < CNT) out[j + 1] = z1;
   }
+}
+template <int CNT>
+__device__ __forceinline__ void rng_normals(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, double (&out)[CNT]) {
+  rng_normals_blk<CNT>(philox4x32_10(i, t, 0u, purpose, k.seed, k.stream), k, purpose, t, i, out);
 }
 
 // ---------------------------------------------------------------- wavefront primitives (64 lanes)

@@ -251,10 +251,12 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
     // ---- stratified resampling (stratified_sample.cpp:15-26) + ancestor gather (:657-661)
     const double c_scale = S / dN;
     double a[PPT][MP];
+    u32x4 blk[PPT];  // step blocks: spare word -> resampling uniform now, words 0-2 -> transition normals below
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
-      const double u = rng_uniform(key, RNG_RESAMPLE, (uint32_t)t, (uint32_t)i, 0);
+      blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)i);
+      const double u = block_uniform(blk[r]);
       const double v = (u + (double)i) * c_scale;
       int lo = 0, hi = N - 1;
       while (lo < hi) {
@@ -276,10 +278,10 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
       const int i = r * NT + tid;
       double x[MP];
       if (FN && !b.psi) {
-        if constexpr (FN) functor_propagate<MP, KP>(fpar, key, (uint32_t)t, (uint32_t)i, a[r], x);
+        if constexpr (FN) functor_propagate<MP, KP>(fpar, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
       } else {
         double z[KP];
-        rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
+        rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
         propagate<MP, KP>(mt, a[r], z, x);
       }
       if (i < N) {
@@ -337,6 +339,14 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
 // Multi-workgroup filter: one launch per time step
 // ------------------------------------------------------------------------------------------
 constexpr int GRID_NT = 256;
+// Waves per SIMD the register budget of a step-kernel variant is sized for.  The kernel is bound by a mix of
+// fp64 VALU issue and dependent latency, so occupancy matters, but scratch reloads on the dependent chain cost
+// more: 6 waves (80 VGPRs) spilt 22 registers and ran 14% slower than 5 waves (96 VGPRs, 2 spilt) on C2-m4.
+constexpr int grid_occupancy(int mp, int ppt, bool fn) {
+  const int live = mp * ppt * (fn ? 2 : 1);  // state doubles held per lane (functor psi weights keep the ancestors too)
+  const int occ = live <= 4 ? 5 : (live <= 8 ? 4 : (live < 16 ? 3 : (live <= 32 ? 2 : 1)));
+  return fn && occ > 4 ? 4 : occ;
+}
 
 // block-wide inclusive scan of PPT strided values per thread; returns the block total.
 // s_tot must hold PPT * 4 doubles.  One barrier.
@@ -412,7 +422,7 @@ __device__ __forceinline__ int search16_lds(const double* a, int stride, int len
   }
 
 template <int MP, int KP, int PPT, bool DBG = false, bool FN = false>
-__global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
+__global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   __shared__ double s_Q[GRID_NT];      // inclusive prefix of scaled block sums
   __shared__ double s_iscale[GRID_NT];  // 1 / exp(max_b - M)
   __shared__ double s_red[8];
@@ -467,8 +477,9 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
 #pragma unroll
       for (int r = 0; r < PPT; r++) {
         const uint32_t j = (uint32_t)(base + r * GRID_NT + tid);
-        u_pre[r] = rng_uniform(key, RNG_RESAMPLE, (uint32_t)t, j, 0);
-        rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, j, z_pre[r]);
+        const u32x4 blk = rng_step_block(key, (uint32_t)t, j);
+        u_pre[r] = block_uniform(blk);
+        rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, j, z_pre[r]);
       }
     }
     BSSM_STAMP(1)
@@ -519,7 +530,9 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
         const int li = r * GRID_NT + tid, j = base + li;
         if (!kMfma && li >= len) { for (int c = 0; c < MP; c++) x[r][c] = 0.0; continue; }  // (MFMA needs the whole wave)
         double u;
-        if constexpr (kEarlyRng) u = u_pre[r]; else u = rng_uniform(key, RNG_RESAMPLE, (uint32_t)t, (uint32_t)j, 0);
+        u32x4 blk{0u, 0u, 0u, 0u};
+        if constexpr (kEarlyRng) u = u_pre[r];
+        else { blk = rng_step_block(key, (uint32_t)t, (uint32_t)j); u = block_uniform(blk); }
         const double v = (u + (double)j) * c_scale;
         // level 1: source block, two 16-ary rounds over the block prefixes in LDS
         const int nrow = (B + 15) >> 4;
@@ -559,10 +572,10 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
         if constexpr (FN) {
           if (b.psi) {
             double z[KP];
-            rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+            rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
             propagate<MP, KP>(mt, a, z, x[r]);
           } else {
-            functor_propagate<MP, KP>(fpar, key, (uint32_t)t, (uint32_t)j, a, x[r]);
+            functor_propagate<MP, KP>(fpar, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
           }
 #pragma unroll
           for (int c = 0; c < MP; c++) aprev[r][c] = a[c];
@@ -572,7 +585,7 @@ __global__ void __launch_bounds__(GRID_NT, (MP <= 4 ? 6 : (MP <= 8 ? 2 : 1))) pf
           propagate<MP, KP>(mt, a, z_pre[r], x[r]);
         } else {
           double z[KP];
-          rng_normals<KP>(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+          rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
           propagate<MP, KP>(mt, a, z, x[r]);
         }
         if (li < len) {

@@ -94,8 +94,8 @@ __device__ __forceinline__ void functor_initial(const double* __restrict__ fp, c
 }
 
 template <int MP, int KP>
-__device__ __forceinline__ void functor_propagate(const double* __restrict__ fp, RngKey key, uint32_t t, uint32_t i,
-                                                  const double (&a)[MP], double (&x)[MP]) {
+__device__ __forceinline__ void functor_propagate(const double* __restrict__ fp, RngKey key, const u32x4& blk0, uint32_t t,
+                                                  uint32_t i, const double (&a)[MP], double (&x)[MP]) {
   const int id = (int)fp[FP_ID];
   if (id >= FN_SDE_GBM) {
     x[0] = milstein(id, fp, key, RNG_SDE, t, i, a[0]);
@@ -103,7 +103,7 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
     for (int c = 1; c < MP; c++) x[c] = 0.0;
   } else {
     double z[KP];
-    rng_normals<KP>(key, RNG_TRANSITION, t, i, z);
+    rng_normals_blk<KP>(blk0, key, RNG_TRANSITION, t, i, z);  // blk0 = the step block
     nlg_T_fn<MP>(id, fp, a, x);
 #pragma unroll
     for (int j = 0; j < MP; j++) if (j < KP) x[j] += fp[FP_R + j] * z[j];  // R is diagonal in every shipped model

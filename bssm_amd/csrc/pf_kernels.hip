@@ -142,9 +142,8 @@ __global__ void debug_math_kernel(int fn, const double* __restrict__ in, double*
   if (fn == 0) out[i] = fast_exp(x);
   else if (fn == 1) out[i] = fast_log(x);
   else if (fn == 2) {
-    const uint64_t bits = (uint64_t)(x * 0x1.0p53);  // x in [0,1)
     double sn, cs;
-    fast_sincos_2pi((uint32_t)(bits >> 26), (uint32_t)(bits & 0x3FFFFFFu), sn, cs);
+    fast_sincos_2pi((uint32_t)(x * 0x1.0p32), sn, cs);  // x in [0,1), a multiple of 2^-32
     out[2 * i] = sn; out[2 * i + 1] = cs;
   } else if (fn == 3) {  // Box-Muller pair for Philox key (seed = 1, stream = 0), counter (i, 0, 0, purpose 2)
     double z0, z1;

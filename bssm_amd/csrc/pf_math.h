@@ -5,7 +5,7 @@
 // (Box-Muller pairs, observation density, weight normalisation), and at one wave per SIMD their
 // dependent chains ARE the kernel time.  These versions keep ~1 ulp accuracy with 20-35
 // instructions by exploiting what the kernels know about their arguments:
-//   * sincos only ever sees 2*pi*u with u a 53-bit fixed-point fraction, so the octant and the
+//   * sincos only ever sees 2*pi*u with u a 32-bit fixed-point fraction, so the octant and the
 //     reduced argument come straight from the integer bits (no Payne-Hanek, no Cody-Waite);
 //   * log uses the hardware frexp instructions and the fdlibm minimax polynomial;
 //   * exp uses a two-constant ln2 reduction and a degree-13 polynomial + v_ldexp_f64.
@@ -81,19 +81,14 @@ __device__ __forceinline__ double fast_exp(double x) {
 #endif
 }
 
-// sin and cos of 2*pi*u for u = x53 * 2^-53 given as its integer bits (hi27:lo26)
-__device__ __forceinline__ void fast_sincos_2pi(uint32_t hi27, uint32_t lo26, double& sn, double& cs) {
+// sin and cos of 2*pi*u for u = a * 2^-32 given as its integer bits
+__device__ __forceinline__ void fast_sincos_2pi(uint32_t a, double& sn, double& cs) {
 #if BSSM_FAST_MATH
-  const uint32_t q = hi27 >> 24;                    // octant 0..7 (top 3 of the 53 bits)
-  uint32_t fh = hi27 & 0x00FFFFFFu, fl = lo26;      // 50-bit fraction inside the octant
-  if (q & 1u) {                                     // reflect: 2^50 - frac  (exact in integers)
-    const uint32_t nl = (0x04000000u - fl) & 0x03FFFFFFu;
-    const uint32_t borrow = fl != 0u ? 1u : 0u;
-    fh = 0x01000000u - fh - borrow;
-    fl = nl;
-  }
-  // theta = 2*pi * frac * 2^-53  in [0, pi/4]
-  const double th = u53_to_double(fh, fl) * (6.283185307179586476925 * 0x1.0p-53);
+  const uint32_t q = a >> 29;                       // octant 0..7
+  uint32_t fr = a & 0x1FFFFFFFu;                    // 29-bit fraction inside the octant
+  if (q & 1u) fr = 0x20000000u - fr;                // reflect (exact in integers)
+  // theta = 2*pi * frac * 2^-32  in [0, pi/4]
+  const double th = (double)fr * (6.283185307179586476925 * 0x1.0p-32);
   const double z = th * th;
   // fdlibm k_sin.c / k_cos.c on [-pi/4, pi/4]
   const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
@@ -110,7 +105,7 @@ __device__ __forceinline__ void fast_sincos_2pi(uint32_t hi27, uint32_t lo26, do
   sn = (q >= 4u) ? -sa : sa;
   cs = ((q + 2u) & 4u) ? -ca : ca;                  // octants 2,3,4,5: cos negative
 #else
-  sincos(2.0 * 3.14159265358979323846 * (u53_to_double(hi27, lo26) * 0x1.0p-53), &sn, &cs);
+  sincos(2.0 * 3.14159265358979323846 * ((double)a * 0x1.0p-32), &sn, &cs);
 #endif
 }
 

@@ -50,10 +50,17 @@ static void draw(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uin
 }
 
 /* purpose: 0 initial-state normals, 1 resampling uniform, 2 transition normals,
- * 3 trajectory pick, 4 SDE increments. */
+ * 3 trajectory pick, 4 SDE increments.
+ * A block feeds one Box-Muller pair from words 0-2 (53-bit radius uniform, 32-bit angle) and leaves word 3
+ * over.  The resampling uniform of slot i at step t is that spare word of the "step block"
+ * (i, t, draw 0, purpose 2), i.e. of the block that also carries the slot's first two transition normals. */
 double orc_rng_uniform(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d) {
   if (r->mode == 1 && purpose == 1) return r->unif[(size_t)t * r->N + i];
   uint32_t w[4];
+  if (purpose == 1) {
+    draw(r, 2, t, i, 0, w);
+    return (double)w[3] * 0x1.0p-32;
+  }
   draw(r, purpose, t, i, d, w);
   return (double)bits53(w[0], w[1]) * 0x1.0p-53;
 }
@@ -63,7 +70,7 @@ void orc_rng_normal_pair(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_
   uint32_t w[4];
   draw(r, purpose, t, i, d, w);
   double u1 = (double)(bits53(w[0], w[1]) + 1) * 0x1.0p-53; /* (0,1] */
-  double u2 = (double)bits53(w[2], w[3]) * 0x1.0p-53;       /* [0,1) */
+  double u2 = (double)w[2] * 0x1.0p-32;                      /* [0,1) */
   double rad = sqrt(-2.0 * log(u1));
   double ang = 2.0 * ORC_PI * u2;
   *z0 = rad * cos(ang);

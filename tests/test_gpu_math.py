@@ -48,9 +48,9 @@ def test_fast_log():
 
 def test_fast_sincos_2pi():
     rng = np.random.default_rng(2)
-    bits = np.concatenate([rng.integers(0, 2 ** 53, 400000), np.arange(8) * 2 ** 50, np.arange(1, 9) * 2 ** 50 - 1,
-                           np.arange(8) * 2 ** 50 + 1, [0, 1, 2 ** 53 - 1]]).astype(np.uint64)
-    u = bits.astype(np.float64) * 2.0 ** -53
+    bits = np.concatenate([rng.integers(0, 2 ** 32, 400000), np.arange(8) * 2 ** 29, np.arange(1, 9) * 2 ** 29 - 1,
+                           np.arange(8) * 2 ** 29 + 1, [0, 1, 2 ** 32 - 1]]).astype(np.uint64)
+    u = bits.astype(np.float64) * 2.0 ** -32
     got = _run(2, u, mult=2).reshape(-1, 2)
     # reference in extended precision: angle = 2 pi u exactly via long double
     ang = (np.longdouble(6.283185307179586476925286766559) * u.astype(np.longdouble))
