@@ -4,10 +4,15 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -21,6 +26,8 @@
 namespace {
 
 thread_local std::string g_err;
+thread_local double g_is_timing[2] = {0.0, 0.0};  // last IS post-correction on this thread: host set-up ms, device phase ms
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -43,18 +50,80 @@ int no_device() {
               "no HIP device available: bssm_amd has no CPU fallback (the particle filters run only on the GPU)");
 }
 
+// Device memory arena: freed buffers are kept and handed out again.  A filter call needs GBs of scratch (particle
+// history, ancestor table, workspace); hipMalloc / hipFree of that size cost milliseconds to seconds and hipFree
+// synchronises the device, which dominated repeated calls (pseudo-marginal MCMC, post-correction batches).  Blocks are
+// keyed by (device, size rounded up to 2 MiB above 1 MiB, 4 KiB below); a request takes the smallest cached block that
+// is at most 25 % larger.  Everything in this library runs on the caller's stream or the null stream and every entry
+// point drains its work before its buffers go out of scope, so a cached block is idle when it is reused.
+struct DeviceArena {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void*> free_blocks;
+  size_t cached = 0;
+  size_t cap;
+  DeviceArena() {
+    const char* env = std::getenv("BSSM_AMD_CACHE_GB");
+    cap = (size_t)(env ? std::atof(env) : 96.0) << 30;
+  }
+  static size_t round_up(size_t b) {
+    const size_t g = b >= ((size_t)1 << 20) ? ((size_t)2 << 20) : 4096;
+    return (b + g - 1) / g * g;
+  }
+  hipError_t get(size_t bytes, void** out, size_t* got) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t want = round_up(bytes);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_blocks.lower_bound({dev, want});
+      if (it != free_blocks.end() && it->first.first == dev && it->first.second <= want + want / 4) {
+        *out = it->second; *got = it->first.second;
+        cached -= *got;
+        free_blocks.erase(it);
+        return hipSuccess;
+      }
+    }
+    hipError_t e = hipMalloc(out, want);
+    if (e != hipSuccess) {  // out of memory: give the cache back and retry once
+      (void)hipGetLastError();
+      trim();
+      e = hipMalloc(out, want);
+    }
+    *got = want;
+    return e;
+  }
+  void put(void* p, size_t size) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (cached + size <= cap) { free_blocks.insert({{dev, size}, p}); cached += size; return; }
+    }
+    (void)hipFree(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& kv : free_blocks) (void)hipFree(kv.second);
+    free_blocks.clear();
+    cached = 0;
+  }
+};
+DeviceArena& arena() { static DeviceArena* a = new DeviceArena; return *a; }  // leaked on purpose: no hipFree at exit
+
 struct DevBuf {
   void* p = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0;     // requested size
+  size_t capacity = 0;  // size of the arena block behind it
   DevBuf() {}
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { release(); }
+  void release() { if (p) { arena().put(p, capacity); p = nullptr; } }
   hipError_t alloc(size_t b) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    release();
     bytes = b;
     if (b == 0) return hipSuccess;
-    return hipMalloc(&p, b);
+    return arena().get(b, &p, &capacity);
   }
   template <class T> T* as() const { return (T*)p; }
 };
@@ -296,6 +365,8 @@ int bssm_amd_device_count(void) {
 }
 const char* bssm_amd_last_error(void) { return g_err.c_str(); }
 const char* bssm_amd_version(void) { return "bssm_amd 0.1 (gfx950)"; }
+void bssm_amd_trim_cache(void) { arena().trim(); }
+void bssm_amd_last_is_timing(double out[2]) { out[0] = g_is_timing[0]; out[1] = g_is_timing[1]; }
 
 void bssm_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   const bssm::u32x4 r = bssm::philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
@@ -625,6 +696,68 @@ int bssm_update_model_builtin(int model_type, const int32_t* flags, const double
   return BSSM_OK;
 }
 
+// ------------------------------------------------------------------ exported helpers
+int bssm_stratified_sample(double* p, const double* r, uint32_t n_elem, uint32_t N, uint32_t* out) {
+  if (!p || !r || !out || n_elem < 1 || N < 1) return fail(BSSM_ERR_INVALID, "NULL argument or empty input");
+  for (uint32_t j = 0; j < N; j++)
+    if (!(r[j] >= 0.0 && r[j] < 1.0)) return fail(BSSM_ERR_INVALID, "r must hold U(0,1) draws (src/stratified_sample.cpp:6)");
+  if (!have_device()) return no_device();
+  DevBuf dp, dr, dout;
+  HIP_TRY(dp.alloc(n_elem * sizeof(double)));
+  HIP_TRY(dr.alloc(N * sizeof(double)));
+  HIP_TRY(dout.alloc(N * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(dp.p, p, dp.bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dr.p, r, dr.bytes, hipMemcpyHostToDevice));
+  HIP_TRY(bssm::launch_stratified_sample(dp.as<double>(), dr.as<double>(), dout.as<uint32_t>(), (int)n_elem, (int)N, nullptr));
+  HIP_TRY(hipMemcpy(out, dout.p, dout.bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(p, dp.p, dp.bytes, hipMemcpyDeviceToHost));  // the reference takes p by reference and leaves the cumsum in it (:9,:12-13)
+  return BSSM_OK;
+}
+
+namespace {
+// arma::stddev (N - 1 normalisation), src/R_postcorrection.cpp:35
+double sample_sd(const std::vector<double>& x) {
+  const size_t n = x.size();
+  if (n < 2) return 0.0;
+  double mean = 0.0;
+  for (double v : x) mean += v;
+  mean /= (double)n;
+  double ss = 0.0;
+  for (double v : x) ss += (v - mean) * (v - mean);
+  return std::sqrt(ss / (double)(n - 1));
+}
+int suggest_n_core(const uint32_t* candidates, int32_t n_candidates, uint32_t replications, double* sds,
+                   const std::function<int(uint32_t, uint32_t, double*)>& batch) {
+  if (!candidates || !sds || n_candidates < 1 || replications < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  bool deg = false;
+  std::vector<double> ll(replications);
+  for (int i = 0; i < n_candidates; i++) {
+    if (candidates[i] < 1) return fail(BSSM_ERR_INVALID, "candidates must be positive");
+    // the `replications` runs of one candidate are ONE device batch; streams i * replications + j keep candidates independent
+    const int rc = batch(candidates[i], (uint32_t)i * replications, ll.data());
+    if (rc < 0) return rc;
+    deg = deg || rc == BSSM_WARN_DEGENERATE;
+    sds[i] = sample_sd(ll);
+  }
+  return deg ? BSSM_WARN_DEGENERATE : BSSM_OK;
+}
+}  // namespace
+
+int bssm_suggest_n_nongaussian(const bssm_ung_model* model, const uint32_t* candidates, int32_t n_candidates,
+                               uint32_t replications, uint32_t seed, int model_type, double* sds) {
+  if (!is_gaussian_type_ok(0, model_type)) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
+  return suggest_n_core(candidates, n_candidates, replications, sds, [&](uint32_t nsim, uint32_t stream0, double* ll) {
+    return bssm_nongaussian_loglik_batch(model, nsim, BSSM_PSI, seed, stream0, replications, ll);
+  });
+}
+
+int bssm_suggest_n_nonlinear(const bssm_fn_model* model, const uint32_t* candidates, int32_t n_candidates,
+                             uint32_t replications, uint32_t seed, double* sds) {
+  return suggest_n_core(candidates, n_candidates, replications, sds, [&](uint32_t nsim, uint32_t stream0, double* ll) {
+    return bssm_fn_loglik_batch(model, nsim, BSSM_PSI, seed, stream0, replications, ll);
+  });
+}
+
 // ------------------------------------------------------------------ IS post-correction
 namespace {
 // Shared core of the IS post-correction drivers: filter `cnt` prepared draws (tables already built), then
@@ -663,16 +796,35 @@ int run_is_core(IsCore& J, double* weights, double* loglik, double* alpha, doubl
     const int N = nsim_of(order[pos]);
     size_t end = pos;
     while (end < order.size() && nsim_of(order[end]) == N) end++;
-    // cap the batch so the kept history fits comfortably in HBM (<= 64 GiB per batch)
-    const size_t per_filter = need_hist ? (size_t)(n + 1) * N * (m * 8 * 2 + 8 + 4) : 0;
-    size_t maxF = per_filter ? std::max<size_t>(1, ((size_t)64 << 30) / per_filter) : (size_t)1 << 20;
+    // Batches of draws: the kept history (particle system + ancestor table) lives in pools allocated ONCE per particle
+    // count and reused by every batch.  A batch is a multiple of 256 filters (one workgroup per CU per round) within
+    // ~24 GiB.  Nothing is back-traced into a second copy: output 1 traces the one trajectory it keeps, output 2 fuses
+    // back-trace and summary (m <= 8; larger states fall back to backtrace + summary through a smoothed copy).
+    const size_t hist_elems_f = (size_t)(n + 1) * m * N, idx_elems_f = (size_t)n * N;
+    const bool fused = m <= 8;
+    const size_t per_filter = need_hist ? hist_elems_f * (fused ? 8 : 16) + idx_elems_f * 4 + (size_t)N * 4 : 0;
+    size_t maxF = (size_t)1 << 20;
+    if (per_filter) {
+      maxF = std::max<size_t>(1, ((size_t)24 << 30) / per_filter);
+      if (maxF >= 256) maxF = maxF / 256 * 256;
+    }
+    DevBuf hist_pool, idx_pool, smooth_pool, bcur_pool;
+    if (need_hist) {
+      const size_t Fp = std::min(maxF, end - pos);
+      HIP_TRY(hist_pool.alloc(Fp * hist_elems_f * sizeof(double)));
+      HIP_TRY(idx_pool.alloc(Fp * idx_elems_f * sizeof(uint32_t)));
+      if (!fused && job->output_type == 2) HIP_TRY(smooth_pool.alloc(Fp * hist_elems_f * sizeof(double)));
+      if (fused && job->output_type == 2) HIP_TRY(bcur_pool.alloc(Fp * (size_t)N * sizeof(uint32_t)));
+    }
     while (pos < end) {
+      const double tb0 = now_ms();
       const size_t F = std::min(maxF, end - pos);
       std::vector<bssm::FilterTables> bt(F);
       for (size_t f = 0; f < F; f++) bt[f] = tabs[order[pos + f]];
       DeviceBatch db;
-      int rc = db.upload(bt, n, m, k, pp, N, psi, need_hist, 0, false);
+      int rc = db.upload(bt, n, m, k, pp, N, psi, false, 0, false);
       if (rc) return rc;
+      if (need_hist) { db.fb.alpha_hist = hist_pool.as<double>(); db.fb.indices = idx_pool.as<uint32_t>(); db.fb.weights = nullptr; }
       DevBuf fparb, amatb;  // per-draw functor parameters / approximating (T_t, C_t), in batch order
       if (!J.fpar.empty()) {
         std::vector<double> hb(F * bssm::FP_SIZE);
@@ -689,9 +841,9 @@ int run_is_core(IsCore& J, double* weights, double* loglik, double* alpha, doubl
         HIP_TRY(hipMemcpy(amatb.p, hb.data(), amatb.bytes, hipMemcpyHostToDevice));
         db.fb.amats = amatb.as<double>(); db.fb.amats_fstride = as;
       }
-      // Philox stream = global draw index: filters of this batch are not contiguous in draw order, so
-      // launch per contiguous run when needed.  Simplest exact approach: a per-filter stream table is
-      // emulated by running contiguous runs separately.
+      const double tb1 = now_ms();
+      // Philox stream = global draw index: the draws of a batch are sorted by particle count, so they are launched
+      // per run of consecutive draw indices (a single run unless is1 mixes particle counts).
       size_t f0 = 0;
       std::vector<double> ll(F);
       while (f0 < F) {
@@ -723,21 +875,38 @@ int run_is_core(IsCore& J, double* weights, double* loglik, double* alpha, doubl
         f0 = f1;
       }
       HIP_TRY(hipMemcpy(ll.data(), db.loglik.p, F * sizeof(double), hipMemcpyDeviceToHost));
+      const double tb2 = now_ms();
       // smoothing outputs
-      DevBuf smooth, d_mean, d_cov;
+      DevBuf d_mean, d_cov, d_picks, d_traj;
       std::vector<double> hmean, hcov, htraj;
-      if (need_hist) {
-        HIP_TRY(smooth.alloc((size_t)F * (n + 1) * m * N * sizeof(double)));
-        HIP_TRY(bssm::launch_backtrace(db.hist.as<double>(), db.indices.as<uint32_t>(), smooth.as<double>(), (int)F, n, m, N, nullptr));
-        if (job->output_type == 2) {
-          HIP_TRY(d_mean.alloc((size_t)F * (n + 1) * m * sizeof(double)));
-          HIP_TRY(d_cov.alloc((size_t)F * (n + 1) * m * m * sizeof(double)));
-          HIP_TRY(bssm::launch_summary(smooth.as<double>(), d_mean.as<double>(), d_cov.as<double>(), (int)F, n + 1, m, N, nullptr));
-          hmean.resize((size_t)F * (n + 1) * m);
-          hcov.resize((size_t)F * (n + 1) * m * m);
-          HIP_TRY(hipMemcpy(hmean.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost));
-          HIP_TRY(hipMemcpy(hcov.data(), d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost));
+      if (job->output_type == 2) {
+        HIP_TRY(d_mean.alloc((size_t)F * (n + 1) * m * sizeof(double)));
+        HIP_TRY(d_cov.alloc((size_t)F * (n + 1) * m * m * sizeof(double)));
+        if (fused) {
+          HIP_TRY(bssm::launch_smooth_summary(db.fb.alpha_hist, db.fb.indices, bcur_pool.as<uint32_t>(), d_mean.as<double>(),
+                                              d_cov.as<double>(), (int)F, n, m, N, nullptr));
+        } else {
+          HIP_TRY(bssm::launch_backtrace(db.fb.alpha_hist, db.fb.indices, smooth_pool.as<double>(), (int)F, n, m, N, nullptr));
+          HIP_TRY(bssm::launch_summary(smooth_pool.as<double>(), d_mean.as<double>(), d_cov.as<double>(), (int)F, n + 1, m, N, nullptr));
         }
+        hmean.resize((size_t)F * (n + 1) * m);
+        hcov.resize((size_t)F * (n + 1) * m * m);
+        HIP_TRY(hipMemcpy(hmean.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hcov.data(), d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost));
+      } else if (job->output_type == 1) {  // one uniformly chosen back-traced trajectory per draw (:391-392)
+        std::vector<uint32_t> picks(F);
+        for (size_t f = 0; f < F; f++) {
+          const bssm::u32x4 w = bssm::philox4x32_10(0, 0, 0, bssm::RNG_PICK, job->seed, (uint32_t)(job->first + order[pos + f]));
+          const double u = (double)bssm::bits53(w.x, w.y) * 0x1.0p-53;
+          int pick = (int)(u * N);
+          picks[f] = (uint32_t)(pick >= N ? N - 1 : pick);
+        }
+        HIP_TRY(d_picks.alloc(F * sizeof(uint32_t)));
+        HIP_TRY(d_traj.alloc((size_t)F * (n + 1) * m * sizeof(double)));
+        HIP_TRY(hipMemcpy(d_picks.p, picks.data(), d_picks.bytes, hipMemcpyHostToDevice));
+        HIP_TRY(bssm::launch_pick_trajectory(db.fb.alpha_hist, db.fb.indices, d_picks.as<uint32_t>(), d_traj.as<double>(), (int)F, n, m, N, nullptr));
+        htraj.resize((size_t)F * (n + 1) * m);
+        HIP_TRY(hipMemcpy(htraj.data(), d_traj.p, d_traj.bytes, hipMemcpyDeviceToHost));
       }
       for (size_t f = 0; f < F; f++) {
         const int i = order[pos + f];
@@ -746,22 +915,18 @@ int run_is_core(IsCore& J, double* weights, double* loglik, double* alpha, doubl
         const double full = l + J.const_add[i];
         weights[i] = std::exp(full - J.sub[i]);  // src/approx_mcmc.cpp:385 (psi: approx_loglik = 0), :479 (bsf)
         if (loglik) loglik[i] = full;
-        if (job->output_type == 1) {  // one uniformly chosen back-traced trajectory, stored (n+1) x m (:391-392)
-          const bssm::u32x4 w = bssm::philox4x32_10(0, 0, 0, bssm::RNG_PICK, job->seed, (uint32_t)(job->first + i));
-          const double u = (double)bssm::bits53(w.x, w.y) * 0x1.0p-53;
-          int pick = (int)(u * N);
-          if (pick >= N) pick = N - 1;
-          htraj.resize((size_t)(n + 1) * m);
-          // strided gather of one particle: [t][c][pick]
-          HIP_TRY(hipMemcpy2D(htraj.data(), sizeof(double), smooth.as<double>() + (size_t)f * (n + 1) * m * N + pick,
-                              (size_t)N * sizeof(double), sizeof(double), (size_t)(n + 1) * m, hipMemcpyDeviceToHost));
+        if (job->output_type == 1) {  // stored (n+1) x m
+          const double* tr = htraj.data() + f * (size_t)(n + 1) * m;
           for (int t = 0; t <= n; t++) for (int c = 0; c < m; c++)
-            alpha[t + (size_t)(n + 1) * (c + (size_t)m * i)] = htraj[(size_t)t * m + c];
+            alpha[t + (size_t)(n + 1) * (c + (size_t)m * i)] = tr[(size_t)t * m + c];
         } else if (job->output_type == 2) {
           std::memcpy(alphahat_i + (size_t)i * (n + 1) * m, hmean.data() + f * (size_t)(n + 1) * m, (size_t)(n + 1) * m * sizeof(double));
           std::memcpy(Vt_i + (size_t)i * (n + 1) * m * m, hcov.data() + f * (size_t)(n + 1) * m * m, (size_t)(n + 1) * m * m * sizeof(double));
         }
       }
+      if (std::getenv("BSSM_AMD_TRACE"))
+        std::fprintf(stderr, "[bssm_amd] is batch F=%zu N=%d: upload %.2f ms, filter %.2f ms, outputs %.2f ms\n", F, N, tb1 - tb0,
+                     tb2 - tb1, now_ms() - tb2);
       pos += F;
     }
   }
@@ -785,6 +950,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   if (!job->counts) return fail(BSSM_ERR_INVALID, "counts NULL");
 
   // per-draw host set-up (the reference does this inside its OpenMP region, src/approx_mcmc.cpp:372-373)
+  const double t_begin = now_ms();
   std::vector<bssm::HostModel> hms(cnt);
   std::vector<bssm::FilterTables> tabs(cnt);
   std::vector<std::string> errs(cnt);
@@ -824,7 +990,10 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   J.bad = bad;
   J.const_add.assign(cnt, 0.0); J.sub.assign(cnt, 0.0);
   for (int i = 0; i < cnt; i++) if (!psi) { J.const_add[i] = bssm::const_term(hms[i]); J.sub[i] = job->approx_loglik[i]; }
-  return run_is_core(J, weights, loglik, alpha, alphahat_i, Vt_i);
+  const double t_mid = now_ms();
+  const int rc = run_is_core(J, weights, loglik, alpha, alphahat_i, Vt_i);
+  g_is_timing[0] = t_mid - t_begin; g_is_timing[1] = now_ms() - t_mid;
+  return rc;
 }
 
 // postcorrection_nonlinear (src/R_postcorrection.cpp:252-317) / is_correction_psi<ssm_nlg>, is_correction_bsf<ssm_nlg>
@@ -852,6 +1021,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   if (psi) J.amats.assign((size_t)count * n * (m * m + m), 0.0);
   std::vector<int> rcs(count, 0);
   std::vector<std::string> errs(count);
+  const double t_begin = now_ms();
   parallel_for(count, n_threads, [&](int i) {
     if (models[i].n != n || models[i].model_id != id) { rcs[i] = BSSM_ERR_INVALID; errs[i] = "all draws must share n and model id"; return; }
     std::vector<double> fp, am;
@@ -877,7 +1047,10 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   });
   for (int i = 0; i < count; i++) if (rcs[i]) return fail(rcs[i], "draw " + std::to_string(i) + ": " + errs[i]);
   if (!have_device()) return no_device();
-  return run_is_core(J, weights, loglik, alpha, alphahat_i, Vt_i);
+  const double t_mid = now_ms();
+  const int rc = run_is_core(J, weights, loglik, alpha, alphahat_i, Vt_i);
+  g_is_timing[0] = t_mid - t_begin; g_is_timing[1] = now_ms() - t_mid;
+  return rc;
 }
 
 int bssm_is_merge(int32_t n, int32_t m, int32_t n_stored, const double* weights, const uint32_t* counts,
@@ -950,7 +1123,11 @@ bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int3
   return p.release();
 }
 
-void bssm_plan_destroy(bssm_plan* plan) { delete plan; }
+void bssm_plan_destroy(bssm_plan* plan) {
+  if (!plan) return;
+  (void)hipDeviceSynchronize();  // the plan's buffers return to the arena: nothing may still be running on them
+  delete plan;
+}
 
 int bssm_plan_run(bssm_plan* plan, uint32_t seed, uint32_t stream0, void* hip_stream) {
   if (!plan) return fail(BSSM_ERR_INVALID, "plan NULL");

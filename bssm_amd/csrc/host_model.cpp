@@ -19,14 +19,21 @@ constexpr double kEps = std::numeric_limits<double>::epsilon();
 constexpr double kPi = 3.14159265358979323846;
 
 // ------------------------------------------------------------------ tiny dense matrix
+// Inline storage (no heap): the psi set-up builds thousands of these per draw, and with a std::vector behind each
+// one the allocator was most of the set-up time.  16 x 16 covers the largest padded dimension the kernels support;
+// copies move only the r * c entries in use.
 struct Mat {
+  static constexpr int kMaxElems = 256;
   int r = 0, c = 0;
-  std::vector<double> a;
+  double a[kMaxElems];
   Mat() {}
-  Mat(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
-  Mat(int r_, int c_, const double* src) : r(r_), c(c_), a(src, src + (size_t)r_ * c_) {}
-  double& operator()(int i, int j) { return a[i + (size_t)r * j]; }
-  double operator()(int i, int j) const { return a[i + (size_t)r * j]; }
+  Mat(int r_, int c_) : r(r_), c(c_) { for (int i = 0; i < r * c; i++) a[i] = 0.0; }
+  Mat(int r_, int c_, const double* src) : r(r_), c(c_) { std::memcpy(a, src, sizeof(double) * (size_t)(r * c)); }
+  Mat(const Mat& o) : r(o.r), c(o.c) { std::memcpy(a, o.a, sizeof(double) * (size_t)(r * c)); }
+  Mat& operator=(const Mat& o) { r = o.r; c = o.c; std::memcpy(a, o.a, sizeof(double) * (size_t)(r * c)); return *this; }
+  int size() const { return r * c; }
+  double& operator()(int i, int j) { return a[i + r * j]; }
+  double operator()(int i, int j) const { return a[i + r * j]; }
   static Mat eye(int m) { Mat I(m, m); for (int i = 0; i < m; i++) I(i, i) = 1.0; return I; }
 };
 Mat operator*(const Mat& A, const Mat& B) {
@@ -38,9 +45,9 @@ Mat operator*(const Mat& A, const Mat& B) {
     }
   return C;
 }
-Mat operator+(const Mat& A, const Mat& B) { Mat C = A; for (size_t i = 0; i < C.a.size(); i++) C.a[i] += B.a[i]; return C; }
-Mat operator-(const Mat& A, const Mat& B) { Mat C = A; for (size_t i = 0; i < C.a.size(); i++) C.a[i] -= B.a[i]; return C; }
-Mat operator*(const Mat& A, double s) { Mat C = A; for (auto& v : C.a) v *= s; return C; }
+Mat operator+(const Mat& A, const Mat& B) { Mat C = A; for (int i = 0; i < C.size(); i++) C.a[i] += B.a[i]; return C; }
+Mat operator-(const Mat& A, const Mat& B) { Mat C = A; for (int i = 0; i < C.size(); i++) C.a[i] -= B.a[i]; return C; }
+Mat operator*(const Mat& A, double s) { Mat C = A; for (int i = 0; i < C.size(); i++) C.a[i] *= s; return C; }
 Mat tr(const Mat& A) { Mat B(A.c, A.r); for (int j = 0; j < A.c; j++) for (int i = 0; i < A.r; i++) B(j, i) = A(i, j); return B; }
 void symmatu(Mat& A) { for (int j = 0; j < A.c; j++) for (int i = j + 1; i < A.r; i++) A(i, j) = A(j, i); }
 
@@ -163,7 +170,7 @@ KfStep kf_predict(const Sys& S, const Approx& ap, int t, const Mat& at, const Ma
     st.logdetF = std::log(Fs);
     st.quad = st.v(0, 0) * st.v(0, 0) / Fs;
   } else {
-    for (double f : F.a) if (!std::isfinite(f)) { st.ok = false; return st; }
+    for (int q = 0; q < F.size(); q++) if (!std::isfinite(F.a[q])) { st.ok = false; return st; }
     for (int j = 0; j < p; j++) if (!(F(j, j) > 0)) { st.ok = false; return st; }
     std::vector<int> all(p);
     for (int j = 0; j < p; j++) all[j] = j;

@@ -71,6 +71,12 @@ hipError_t launch_backtrace(const double* hist, const uint32_t* indices, double*
 // summary() (src/summary.cpp:4-17): mean [f][n+1][m] and cov [f][n+1][m][m] over particles
 hipError_t launch_summary(const double* hist, double* mean, double* cov, int F, int n1, int m, int N,
                           hipStream_t stream);
+// one back-traced trajectory per filter (particle picks[f]): out [f][n+1][m]
+hipError_t launch_pick_trajectory(const double* hist, const uint32_t* indices, const uint32_t* picks, double* out, int F,
+                                  int n, int m, int N, hipStream_t stream);
+// filter_smoother + summary fused (m <= 8): mean [f][n+1][m], cov [f][n+1][m][m]; bcur [F][N] scratch
+hipError_t launch_smooth_summary(const double* hist, const uint32_t* indices, uint32_t* bcur, double* mean, double* cov, int F,
+                                 int n, int m, int N, hipStream_t stream);
 // filter_summary() (src/summary.cpp:42-79): at [f][n+1][m], att [f][n][m], Pt [f][n+1][m*m], Ptt [f][n][m*m]
 hipError_t launch_filter_summary(const double* hist, const double* weights, double* at, double* att, double* Pt,
                                  double* Ptt, int F, int n, int m, int N, hipStream_t stream);
@@ -84,6 +90,8 @@ hipError_t launch_zero_dead_tail(const FilterBatch& b, bool weights_too, hipStre
 // exact simulation smoother of a linear-Gaussian model; mats [n][2 m m + m] unpadded, init [m + m m], hist [n+1][m][N]
 hipError_t launch_sim_smoother(const double* mats, const double* init, double* hist, int n, int m, int N, uint32_t seed,
                                hipStream_t stream);
+// stratified_sample (src/stratified_sample.cpp:9-28): p [len] is overwritten by its cumulative sum, out [N]
+hipError_t launch_stratified_sample(double* p, const double* r, uint32_t* out, int len, int N, hipStream_t stream);
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream);
 
 }  // namespace bssm

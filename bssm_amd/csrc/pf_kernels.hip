@@ -156,6 +156,35 @@ hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipSt
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- stratified_sample on its own
+// src/stratified_sample.cpp:9-28 as the exported helper `_bssm_stratified_sample`: p <- cumsum(p), p[last] = 1,
+// sample j -> first k with (r_j + j) / N <= p_k.  The cumulative sum is a SEQUENTIAL fp64 recurrence in the
+// reference (arma::cumsum); one lane reproduces it term by term so the returned indices are bit-for-bit the
+// reference's (a tree scan rounds differently and can move a boundary).  The N searches then run in parallel.
+__global__ void cumsum_sequential_kernel(double* __restrict__ p, int len) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double s = 0.0;
+  for (int k = 0; k < len; k++) { s += p[k]; p[k] = s; }
+  p[len - 1] = 1.0;
+}
+__global__ void __launch_bounds__(256) stratified_search_kernel(const double* __restrict__ cdf, const double* __restrict__ r,
+                                                                uint32_t* __restrict__ out, int len, int N) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const double v = (r[j] + (double)j) * (1.0 / (double)N);  // (r(j) + j) * alpha, alpha = 1.0 / N (:17,:19)
+  int lo = 0, hi = len - 1;  // first k with v <= cdf[k]; none (v > 1) -> len - 1 (:24-27)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (v <= cdf[mid]) hi = mid; else lo = mid + 1;
+  }
+  out[j] = (uint32_t)lo;
+}
+hipError_t launch_stratified_sample(double* p, const double* r, uint32_t* out, int len, int N, hipStream_t stream) {
+  hipLaunchKernelGGL(cumsum_sequential_kernel, dim3(1), dim3(64), 0, stream, p, len);
+  hipLaunchKernelGGL(stratified_search_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, p, r, out, len, N);
+  return hipGetLastError();
+}
+
 hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream) {
   switch (b.MP) {
     case 1: return launch_wg_mp<1>(b, stream);
@@ -243,6 +272,115 @@ hipError_t launch_summary(const double* hist, double* mean, double* cov, int F, 
                           hipStream_t stream) {
   if (m > 16) return hipErrorInvalidValue;
   hipLaunchKernelGGL(summary_kernel, dim3(n1, F), dim3(256), 0, stream, hist, mean, cov, n1, m, N);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- IS post-correction outputs without a smoothed copy
+// output_type 1 (src/approx_mcmc.cpp:389-393): ONE back-traced trajectory per draw is kept, so only that one is
+// traced (filter_smoother.cpp:7-16 restricted to particle `pick`): out [f][t][c], t in [0, n], slot n left as is.
+__global__ void pick_trajectory_kernel(const double* __restrict__ hist, const uint32_t* __restrict__ indices,
+                                       const uint32_t* __restrict__ picks, double* __restrict__ out, int F, int n, int m,
+                                       int N) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const double* __restrict__ h = hist + (size_t)f * (n + 1) * m * N;
+  const uint32_t* __restrict__ idx = indices + (size_t)f * n * N;
+  double* __restrict__ o = out + (size_t)f * (n + 1) * m;
+  uint32_t b = picks[f];
+  for (int c = 0; c < m; c++) o[(size_t)n * m + c] = h[((size_t)n * m + c) * N + b];
+  for (int t = n - 1; t >= 0; t--) {
+    b = idx[(size_t)t * N + b];
+    for (int c = 0; c < m; c++) o[(size_t)t * m + c] = h[((size_t)t * m + c) * N + b];
+  }
+}
+hipError_t launch_pick_trajectory(const double* hist, const uint32_t* indices, const uint32_t* picks, double* out, int F,
+                                  int n, int m, int N, hipStream_t stream) {
+  hipLaunchKernelGGL(pick_trajectory_kernel, dim3((F + 63) / 64), dim3(64), 0, stream, hist, indices, picks, out, F, n, m, N);
+  return hipGetLastError();
+}
+
+// output_type 2 (src/approx_mcmc.cpp:394-400): filter_smoother + summary fused.  One workgroup per draw walks the
+// ancestor table backwards with all N trajectories in step (b_i <- idx(b_i, t), filter_smoother.cpp:11-15) and
+// reduces mean / population covariance of the gathered states at every time point (summary.cpp:4-17), so the
+// back-traced particle system is never written: traffic per particle-step is one index gather + the state gathers
+// instead of a full smoothed copy (write 8m) and its re-reads.  bcur [F][N] holds the current ancestors.
+constexpr int SS_NT = 1024;
+template <int M>
+__global__ void __launch_bounds__(SS_NT) smooth_summary_kernel(const double* __restrict__ hist,
+                                                               const uint32_t* __restrict__ indices,
+                                                               uint32_t* __restrict__ bcur_all, double* __restrict__ mean,
+                                                               double* __restrict__ cov, int n, int m, int N) {
+  constexpr int NC = M * (M + 1) / 2, NW = SS_NT / 64;
+  __shared__ double s_part[NW][NC > M ? NC : M];
+  __shared__ double s_mean[M];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n1 = n + 1;
+  const double* __restrict__ h = hist + (size_t)f * n1 * m * N;
+  const uint32_t* __restrict__ idx = indices + (size_t)f * n * N;
+  uint32_t* __restrict__ bcur = bcur_all + (size_t)f * N;
+  const double dN = (double)N;
+  for (int t = n; t >= 0; t--) {
+    const double* __restrict__ ht = h + (size_t)t * m * N;
+    // ---- advance the ancestors and accumulate the sums
+    double acc[M];
+#pragma unroll
+    for (int c = 0; c < M; c++) acc[c] = 0.0;
+    for (int i = tid; i < N; i += SS_NT) {
+      const uint32_t b = (t == n) ? (uint32_t)i : idx[(size_t)t * N + bcur[i]];
+      bcur[i] = b;
+#pragma unroll
+      for (int c = 0; c < M; c++) if (c < m) acc[c] += ht[(size_t)c * N + b];
+    }
+#pragma unroll
+    for (int c = 0; c < M; c++) { const double v = wave_sum(acc[c]); if (lane == 0) s_part[wave][c] = v; }
+    __syncthreads();
+    if (tid < m) {
+      double tot = 0.0;
+      for (int w = 0; w < NW; w++) tot += s_part[w][tid];
+      s_mean[tid] = tot / dN;
+      mean[((size_t)f * n1 + t) * m + tid] = tot / dN;
+    }
+    __syncthreads();
+    // ---- second pass: centred cross products (lower triangle)
+    double mu[M], cc[NC];
+#pragma unroll
+    for (int c = 0; c < M; c++) mu[c] = c < m ? s_mean[c] : 0.0;
+#pragma unroll
+    for (int q = 0; q < NC; q++) cc[q] = 0.0;
+    for (int i = tid; i < N; i += SS_NT) {
+      const uint32_t b = bcur[i];
+      double d[M];
+#pragma unroll
+      for (int c = 0; c < M; c++) d[c] = c < m ? ht[(size_t)c * N + b] - mu[c] : 0.0;
+      int q = 0;
+#pragma unroll
+      for (int c = 0; c < M; c++)
+#pragma unroll
+        for (int j = 0; j <= c; j++) cc[q++] += d[c] * d[j];
+    }
+#pragma unroll
+    for (int q = 0; q < NC; q++) { const double v = wave_sum(cc[q]); if (lane == 0) s_part[wave][q] = v; }
+    __syncthreads();
+    if (tid < NC) {
+      int c = 0;
+      while ((c + 1) * (c + 2) / 2 <= tid) c++;
+      const int j = tid - c * (c + 1) / 2;
+      if (c < m) {
+        double tot = 0.0;
+        for (int w = 0; w < NW; w++) tot += s_part[w][tid];
+        cov[(((size_t)f * n1 + t) * m + c) * m + j] = tot / dN;
+        cov[(((size_t)f * n1 + t) * m + j) * m + c] = tot / dN;
+      }
+    }
+    __syncthreads();
+  }
+}
+hipError_t launch_smooth_summary(const double* hist, const uint32_t* indices, uint32_t* bcur, double* mean, double* cov, int F,
+                                 int n, int m, int N, hipStream_t stream) {
+  if (m <= 1) hipLaunchKernelGGL(smooth_summary_kernel<1>, dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
+  else if (m <= 2) hipLaunchKernelGGL(smooth_summary_kernel<2>, dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
+  else if (m <= 4) hipLaunchKernelGGL(smooth_summary_kernel<4>, dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
+  else if (m <= 8) hipLaunchKernelGGL(smooth_summary_kernel<8>, dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

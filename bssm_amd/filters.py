@@ -247,3 +247,17 @@ def psi_setup(model: BssmModel, is_mode=None):
         for k in ("approx_y", "approx_H", "mode"):
             res[k] = res[k].reshape((p, n), order="F")
     return res
+
+
+def stratified_sample(p, r, N=None):
+    """R/RcppExports.R:228-230 `stratified_sample(p, r, N)` -> bssm_stratified_sample (src/stratified_sample.cpp:9-28).
+    Returns (zero-based indices [N], the cumulative sum the reference leaves in p)."""
+    p = np.array(p, dtype=np.float64).reshape(-1)
+    r = np.ascontiguousarray(r, dtype=np.float64).reshape(-1)
+    N = r.size if N is None else int(N)
+    if N > r.size:
+        raise ValueError("'r' must hold at least N uniforms")
+    out = np.zeros(N, dtype=np.uint32)
+    _lib.check(_lib.lib().bssm_stratified_sample(_lib.dptr(p), _lib.dptr(r), C.c_uint32(p.size), C.c_uint32(N),
+                                                  out.ctypes.data_as(_lib.c_u32_p)))
+    return out, p

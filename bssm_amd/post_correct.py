@@ -97,6 +97,12 @@ def shard_bounds(work: np.ndarray, world: int):
     return np.asarray(bounds, dtype=np.int64)
 
 
+def _last_timing():
+    t = (C.c_double * 2)()
+    _lib.lib().bssm_amd_last_is_timing(t)
+    return dict(host_setup=t[0], device=t[1])
+
+
 def _run_local_block(arrs, modes, counts, first, n_stored, nsim, seed, is_type, output_type, n_threads,
                      method=1, approx_loglik=None):
     """Filter draws [first, first+len(arrs)) on this process's GPU through the C ABI."""
@@ -125,7 +131,7 @@ def _run_local_block(arrs, modes, counts, first, n_stored, nsim, seed, is_type, 
     vt = np.zeros((m, m, n + 1, cnt), order="F") if output_type == 2 else None
     rc = _lib.check(_lib.lib().bssm_is_correction(C.byref(job), _lib.dptr(weights), _lib.dptr(loglik), _lib.dptr(alpha),
                                                   _lib.dptr(ah), _lib.dptr(vt)))
-    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1)
+    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1, timing_ms=_last_timing())
 
 
 def is_correction(model: BssmModel, theta, counts, particles: int, method: str = "psi", modes=None, approx_loglik=None,
@@ -164,7 +170,7 @@ def _run_local_block_nlg(model, theta, modes, counts, first, n_stored, nsim, see
         models, C.c_int32(first), C.c_int32(cnt), _lib.dptr(modes_c), _lib.dptr(al_c), counts_c.ctypes.data_as(_lib.c_u32_p),
         C.c_int32(method), C.c_int32(is_type), C.c_int32(output_type), C.c_uint32(nsim), C.c_uint32(seed), C.c_int32(n_threads),
         _lib.dptr(weights), _lib.dptr(loglik), _lib.dptr(alpha), _lib.dptr(ah), _lib.dptr(vt)))
-    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1)
+    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1, timing_ms=_last_timing())
 
 
 def _all_gather_blocks(local: np.ndarray, bounds, rank, world, group, device):
@@ -254,7 +260,8 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
                                threads)
     else:
         loc = dict(weights=np.zeros(0), loglik=np.zeros(0), alpha=np.zeros((n + 1, m, 0)),
-                   alphahat_i=np.zeros((m, n + 1, 0)), Vt_i=np.zeros((m, m, n + 1, 0)), degenerate=False)
+                   alphahat_i=np.zeros((m, n + 1, 0)), Vt_i=np.zeros((m, m, n + 1, 0)), degenerate=False,
+                   timing_ms=dict(host_setup=0.0, device=0.0))
 
     # ---- ONE collective phase: all-gather the per-draw results
     if world > 1:
@@ -300,6 +307,7 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     out["seed"] = list(np.atleast_1d(mcmc_output.get("seed", []))) + [seed]
     out["time_postcorrection"] = time.perf_counter() - t0
     out["shards"] = bounds
+    out["timing_ms"] = loc.get("timing_ms")  # this rank's split: per-draw host set-up vs device phase
     return out
 
 
@@ -308,7 +316,7 @@ def suggest_N(model: BssmModel, theta, candidates=range(10, 101, 10), replicatio
     of the psi-APF log-likelihood at ``theta`` over ``replications`` runs for each candidate N; N = first
     candidate with sd < 1 (None if there is none, R's NA).  The replications of one candidate run as ONE device
     batch (bssm_nongaussian_loglik_batch) instead of the reference's sequential loop."""
-    from .filters import logLik_batch
+    from .filters import _prep
     replications = check_intmax(replications, "replications", max=1000)
     seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
     candidates = [int(c) for c in candidates]
@@ -319,13 +327,21 @@ def suggest_N(model: BssmModel, theta, candidates=range(10, 101, 10), replicatio
     theta = np.asarray(theta, dtype=np.float64).reshape(-1)
     if theta.size != np.asarray(model["theta"]).size:
         raise ValueError("Length of 'theta' does not match length of 'model$theta'.")
+    cand = np.asarray(candidates, dtype=np.uint32)
+    sds = np.zeros(cand.size)
+    if model.inherits("ssm_nlg"):  # suggest_n_nonlinear, src/R_postcorrection.cpp:107-148
+        smod, keep = _lib.pack_fn_model({**model, "theta": theta})
+        _lib.check(_lib.lib().bssm_suggest_n_nonlinear(C.byref(smod), cand.ctypes.data_as(_lib.c_u32_p), C.c_int32(cand.size),
+                                                        C.c_uint32(replications), C.c_uint32(seed), _lib.dptr(sds)))
+        ok = np.nonzero(sds < 1.0)[0]
+        return dict(N=candidates[int(ok[0])] if ok.size else None, results=dict(N=np.asarray(candidates), sd=sds))
     arr = expand_models(model, theta[None, :])[0]
     fields = {**model, **{k: arr[k] for k in ("Z", "T", "R", "P1", "a1", "C", "D", "beta")}, "phi": arr["phi"]}
     mdl = BssmModel(model.classes, **fields)
-    sds = []
-    for i, N in enumerate(candidates):
-        ll = logLik_batch(mdl, N, replications, method="psi", seed=seed, stream0=i * replications)
-        sds.append(float(np.std(ll, ddof=1)))  # arma::stddev: N - 1 normalisation
-    sds = np.asarray(sds)
+    # one C-ABI call: bssm_suggest_n_nongaussian runs the replications of each candidate as a device batch
+    arrs, smod, keep = _prep(mdl, True)
+    _lib.check(_lib.lib().bssm_suggest_n_nongaussian(C.byref(smod), cand.ctypes.data_as(_lib.c_u32_p), C.c_int32(cand.size),
+                                                           C.c_uint32(replications), C.c_uint32(seed), C.c_int32(model_type(mdl)),
+                                                           _lib.dptr(sds)))
     ok = np.nonzero(sds < 1.0)[0]
     return dict(N=candidates[int(ok[0])] if ok.size else None, results=dict(N=np.asarray(candidates), sd=sds))

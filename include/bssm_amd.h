@@ -107,6 +107,12 @@ typedef struct bssm_filter_out {
 int bssm_amd_device_count(void);
 const char* bssm_amd_last_error(void);
 const char* bssm_amd_version(void);
+/* The library keeps freed device buffers in an arena (default cap 96 GiB, env BSSM_AMD_CACHE_GB) because
+ * hipMalloc/hipFree of multi-GB scratch dominate repeated calls; this returns all cached blocks to the driver. */
+void bssm_amd_trim_cache(void);
+/* wall-clock split of the last bssm_is_correction / bssm_is_correction_nlg call on this thread:
+ * out[0] = per-draw host set-up (ms), out[1] = device phase incl. copies (ms) */
+void bssm_amd_last_is_timing(double out[2]);
 
 /* ---- drop-in entry points (host buffers in, host buffers out) ---- */
 
@@ -144,7 +150,7 @@ int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, ui
  * The reference takes user C++ compiled at run time behind function pointers (src/model_ssm_nlg.h:10-21,
  * src/model_ssm_sde.h:8-11); device code cannot call those, so the examples shipped in
  * R/cpp_example_models.R are built in and selected by id (theta / known_params keep the snippets' meaning).
- * Only the bootstrap filter is provided for them in this version (psi-APF / EKPF of ssm_nlg: DESIGN.md section 7). */
+ * Bootstrap filter for all six; psi-APF for the four ssm_nlg models (the reference has no psi-APF for ssm_sde). */
 enum { BSSM_FN_NLG_GROWTH = 1, BSSM_FN_NLG_AR_EXP = 2, BSSM_FN_NLG_SIN_EXP = 3, BSSM_FN_NLG_LINEAR_GAUSSIAN = 4,
        BSSM_FN_SDE_GBM = 5, BSSM_FN_SDE_POISSON_OU = 6 };
 typedef struct bssm_fn_model {
@@ -185,6 +191,23 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
                            const double* approx_loglik, const uint32_t* counts, int32_t sampling_method, int32_t is_type,
                            int32_t output_type, uint32_t nsim, uint32_t seed, int32_t n_threads, double* weights,
                            double* loglik, double* alpha, double* alphahat_i, double* Vt_i);
+
+/* replaces _bssm_stratified_sample: `arma::uvec stratified_sample(arma::vec& p, const arma::vec& r, const unsigned int N)`
+ * src/stratified_sample.cpp:9-28 (registered src/RcppExports.cpp:1275,1344).  p [n_elem] normalised weights, OVERWRITTEN
+ * with their cumulative sum (last entry forced to 1) exactly as the reference does through its reference argument;
+ * r [N] U[0,1) draws; out [N] zero-based ancestor indices.  The cumulative sum is evaluated in the reference's
+ * sequential order, so the indices are bit-for-bit the reference's. */
+int bssm_stratified_sample(double* p, const double* r, uint32_t n_elem, uint32_t N, uint32_t* out);
+
+/* replaces _bssm_suggest_n_nongaussian (6 args, src/R_postcorrection.cpp:13-140) and _bssm_suggest_n_nonlinear
+ * (20 args, src/R_postcorrection.cpp:107-148): standard deviation (N-1 normalisation) of the psi-APF
+ * log-likelihood over `replications` runs for every candidate particle count.  `model` carries the theta-updated
+ * components (what model.update_model(theta) leaves, :23,:41).  The replications of one candidate run as one device
+ * batch on Philox streams i * replications + j.  sds [n_candidates]. */
+int bssm_suggest_n_nongaussian(const bssm_ung_model* model, const uint32_t* candidates, int32_t n_candidates,
+                               uint32_t replications, uint32_t seed, int model_type, double* sds);
+int bssm_suggest_n_nonlinear(const bssm_fn_model* model, const uint32_t* candidates, int32_t n_candidates,
+                             uint32_t replications, uint32_t seed, double* sds);
 
 /* ---- IS post-correction ----
  * replaces _bssm_postcorrection_nongaussian: `postcorrection_nongaussian(model_, model_type, output_type,

@@ -209,15 +209,19 @@ static inline double ung_log_weight(const orc_ung_model *mod, const orc_psi_setu
 /* ------------------------------------------------------------------ */
 /* stratified resampling: stratified_sample.cpp:9-28                   */
 /* ------------------------------------------------------------------ */
-void orc_stratified_sample(double *p, const double *r, unsigned N, unsigned *out) {
-  for (unsigned k = 1; k < N; k++) p[k] += p[k - 1]; /* arma::cumsum */
-  p[N - 1] = 1;
+/* general form: p has n_elem entries, N samples are drawn (the filters always call it with n_elem == N) */
+void orc_stratified_sample_n(double *p, unsigned n_elem, const double *r, unsigned N, unsigned *out) {
+  for (unsigned k = 1; k < n_elem; k++) p[k] += p[k - 1]; /* arma::cumsum, :12 */
+  p[n_elem - 1] = 1;                                      /* :13 */
   unsigned j = 0;
-  double alpha = 1.0 / N;
-  for (unsigned k = 0; k < N && j < N; k++) {
+  double alpha = 1.0 / N;                                 /* :17 */
+  for (unsigned k = 0; k < n_elem && j < N; k++) {        /* :18-23 */
     while (j < N && (r[j] + j) * alpha <= p[k]) { out[j] = k; j++; }
   }
-  while (j < N) { out[j] = N - 1; j++; }
+  while (j < N) { out[j] = n_elem - 1; j++; }             /* :24-27 */
+}
+void orc_stratified_sample(double *p, const double *r, unsigned N, unsigned *out) {
+  orc_stratified_sample_n(p, N, r, N, out);
 }
 
 /* shared tail of every filter step: model_ssm_ung.cpp:634-647 / 672-687.

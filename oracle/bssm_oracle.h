@@ -82,6 +82,7 @@ void orc_rng_normal_pair(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_
 /* ---- helpers ---- */
 /* src/stratified_sample.cpp:9-28. p is overwritten by its cumsum. */
 void orc_stratified_sample(double *p, const double *r, unsigned N, unsigned *out);
+void orc_stratified_sample_n(double *p, unsigned n_elem, const double *r, unsigned N, unsigned *out);
 /* src/filter_smoother.cpp:5-18 */
 void orc_filter_smoother(double *alpha, const unsigned *indices, int m, int n, unsigned N);
 /* src/summary.cpp:4-17 */

@@ -196,12 +196,14 @@ def filter_summary(alpha, weights):
     return at, att, Pt, Ptt
 
 
-def stratified_sample(p, r):
+def stratified_sample(p, r, N=None):
+    """src/stratified_sample.cpp:9-28: (zero-based indices [N], cumulative sum left in p)"""
     L = lib()
     p = np.array(p, dtype=np.float64)
     r = np.ascontiguousarray(r, dtype=np.float64)
-    out = np.zeros(p.size, dtype=np.uint32)
-    L.orc_stratified_sample(_p(p), _p(r), C.c_uint(p.size), out.ctypes.data_as(c_uint_p))
+    N = r.size if N is None else int(N)
+    out = np.zeros(N, dtype=np.uint32)
+    L.orc_stratified_sample_n(_p(p), C.c_uint(p.size), _p(r), C.c_uint(N), out.ctypes.data_as(c_uint_p))
     return out, p
 
 
