@@ -57,6 +57,7 @@ int no_device() {
 // is at most 25 % larger.  Everything in this library runs on the caller's stream or the null stream and every entry
 // point drains its work before its buffers go out of scope, so a cached block is idle when it is reused.
 struct DeviceArena {
+  bool pinned_host = false;  // true: hipHostMalloc'd staging blocks instead of device memory
   std::mutex mu;
   std::multimap<std::pair<int, size_t>, void*> free_blocks;
   size_t cached = 0;
@@ -83,15 +84,17 @@ struct DeviceArena {
         return hipSuccess;
       }
     }
-    hipError_t e = hipMalloc(out, want);
+    hipError_t e = raw_alloc(out, want);
     if (e != hipSuccess) {  // out of memory: give the cache back and retry once
       (void)hipGetLastError();
       trim();
-      e = hipMalloc(out, want);
+      e = raw_alloc(out, want);
     }
     *got = want;
     return e;
   }
+  hipError_t raw_alloc(void** out, size_t b) { return pinned_host ? hipHostMalloc(out, b, hipHostMallocDefault) : hipMalloc(out, b); }
+  void raw_free(void* p) { if (pinned_host) (void)hipHostFree(p); else (void)hipFree(p); }
   void put(void* p, size_t size) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -99,16 +102,30 @@ struct DeviceArena {
       std::lock_guard<std::mutex> lk(mu);
       if (cached + size <= cap) { free_blocks.insert({{dev, size}, p}); cached += size; return; }
     }
-    (void)hipFree(p);
+    raw_free(p);
   }
   void trim() {
     std::lock_guard<std::mutex> lk(mu);
-    for (auto& kv : free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : free_blocks) raw_free(kv.second);
     free_blocks.clear();
     cached = 0;
   }
 };
 DeviceArena& arena() { static DeviceArena* a = new DeviceArena; return *a; }  // leaked on purpose: no hipFree at exit
+// pinned staging for host -> device table uploads (pageable copies run at a few GB/s and block the launch thread)
+DeviceArena& stage_arena() {
+  static DeviceArena* a = [] { DeviceArena* x = new DeviceArena; x->pinned_host = true; x->cap = (size_t)4 << 30; return x; }();
+  return *a;
+}
+struct StageBuf {
+  void* p = nullptr;
+  size_t capacity = 0;
+  StageBuf() {}
+  StageBuf(const StageBuf&) = delete;
+  StageBuf& operator=(const StageBuf&) = delete;
+  ~StageBuf() { if (p) stage_arena().put(p, capacity); }
+  hipError_t alloc(size_t b) { return stage_arena().get(b, &p, &capacity); }
+};
 
 struct DevBuf {
   void* p = nullptr;
@@ -150,24 +167,36 @@ struct DeviceBatch {
   // tables: one per filter (all with the same MP/KP/mats_tstride)
   int upload(const std::vector<bssm::FilterTables>& tabs, int n, int m, int k, int p, int N, int psi, bool keep_hist,
              unsigned path_flags, bool keep_weights = true) {
+    std::vector<const bssm::FilterTables*> ptrs(tabs.size());
+    for (size_t f = 0; f < tabs.size(); f++) ptrs[f] = &tabs[f];
+    return upload(ptrs, n, m, k, p, N, psi, keep_hist, path_flags, keep_weights);
+  }
+  int upload(const std::vector<const bssm::FilterTables*>& tabs, int n, int m, int k, int p, int N, int psi, bool keep_hist,
+             unsigned path_flags, bool keep_weights = true, int copy_threads = 1) {
     const int F = (int)tabs.size();
-    const int MP = tabs[0].MP, KP = tabs[0].KP;
+    const int MP = tabs[0]->MP, KP = tabs[0]->KP;
     fb.n = n; fb.m = m; fb.k = k; fb.p = p; fb.MP = MP; fb.KP = KP; fb.N = N; fb.F = F; fb.psi = psi;
-    const size_t ms = tabs[0].mats.size(), os = tabs[0].obs.size(), is = tabs[0].init.size();
-    std::vector<double> hm(ms * F), ho(os * F), hi(is * F);
-    for (int f = 0; f < F; f++) {
-      if (tabs[f].mats.size() != ms || tabs[f].MP != MP || tabs[f].KP != KP) return fail(BSSM_ERR_INVALID, "filters of a batch must share padding and time-variation");
-      std::memcpy(hm.data() + ms * f, tabs[f].mats.data(), ms * sizeof(double));
-      std::memcpy(ho.data() + os * f, tabs[f].obs.data(), os * sizeof(double));
-      std::memcpy(hi.data() + is * f, tabs[f].init.data(), is * sizeof(double));
-    }
-    HIP_TRY(mats.alloc(hm.size() * sizeof(double)));
-    HIP_TRY(obs.alloc(ho.size() * sizeof(double)));
-    HIP_TRY(init.alloc(hi.size() * sizeof(double)));
-    HIP_TRY(hipMemcpy(mats.p, hm.data(), mats.bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(obs.p, ho.data(), obs.bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(init.p, hi.data(), init.bytes, hipMemcpyHostToDevice));
-    fb.mats = mats.as<double>(); fb.mats_fstride = ms; fb.mats_tstride = tabs[0].mats_tstride;
+    const size_t ms = tabs[0]->mats.size(), os = tabs[0]->obs.size(), is = tabs[0]->init.size();
+    for (int f = 0; f < F; f++)
+      if (tabs[f]->mats.size() != ms || tabs[f]->obs.size() != os || tabs[f]->init.size() != is || tabs[f]->MP != MP || tabs[f]->KP != KP)
+        return fail(BSSM_ERR_INVALID, "filters of a batch must share padding and time-variation");
+    // one pinned staging block [mats | obs | init], filled by a few threads, one asynchronous copy each
+    StageBuf stage;
+    HIP_TRY(stage.alloc((ms + os + is) * F * sizeof(double)));
+    double* hm = (double*)stage.p; double* ho = hm + ms * F; double* hi = ho + os * F;
+    parallel_for(F, copy_threads, [&](int f) {
+      std::memcpy(hm + ms * f, tabs[f]->mats.data(), ms * sizeof(double));
+      std::memcpy(ho + os * f, tabs[f]->obs.data(), os * sizeof(double));
+      std::memcpy(hi + is * f, tabs[f]->init.data(), is * sizeof(double));
+    });
+    HIP_TRY(mats.alloc(ms * F * sizeof(double)));
+    HIP_TRY(obs.alloc(os * F * sizeof(double)));
+    HIP_TRY(init.alloc(is * F * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(mats.p, hm, ms * F * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(obs.p, ho, os * F * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(init.p, hi, is * F * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));  // the staging block returns to its arena when this function ends
+    fb.mats = mats.as<double>(); fb.mats_fstride = ms; fb.mats_tstride = tabs[0]->mats_tstride;
     fb.obs = obs.as<double>(); fb.obs_fstride = os;
     fb.init = init.as<double>(); fb.init_fstride = is;
     HIP_TRY(loglik.alloc(F * sizeof(double)));
@@ -365,7 +394,7 @@ int bssm_amd_device_count(void) {
 }
 const char* bssm_amd_last_error(void) { return g_err.c_str(); }
 const char* bssm_amd_version(void) { return "bssm_amd 0.1 (gfx950)"; }
-void bssm_amd_trim_cache(void) { arena().trim(); }
+void bssm_amd_trim_cache(void) { arena().trim(); stage_arena().trim(); }
 void bssm_amd_last_is_timing(double out[2]) { out[0] = g_is_timing[0]; out[1] = g_is_timing[1]; }
 
 void bssm_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
@@ -776,8 +805,9 @@ struct IsCore {
   std::vector<char> bad;
 };
 
-int run_is_core(IsCore& J, double* weights, double* loglik, double* alpha, double* alphahat_i, double* Vt_i) {
-  const int cnt = (int)J.tabs.size(), n = J.n, m = J.m, k = J.k, pp = J.pp;
+// draws [lo, hi) of the prepared job
+int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, double* alpha, double* alphahat_i, double* Vt_i) {
+  const int cnt = hi - lo, n = J.n, m = J.m, k = J.k, pp = J.pp;
   const bool psi = J.psi;
   std::vector<bssm::FilterTables>& tabs = J.tabs;
   const std::vector<char>& bad = J.bad;
@@ -787,7 +817,7 @@ int run_is_core(IsCore& J, double* weights, double* loglik, double* alpha, doubl
 
   // group draws by particle count (is1 multiplies nsim by count_i, src/approx_mcmc.cpp:376-378)
   std::vector<int> order(cnt);
-  for (int i = 0; i < cnt; i++) order[i] = i;
+  for (int i = 0; i < cnt; i++) order[i] = lo + i;
   auto nsim_of = [&](int i) { return (int)(job->is_type == 1 ? job->nsim * job->counts[i] : job->nsim); };
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nsim_of(a) < nsim_of(b); });
   bool any_degenerate = false;
@@ -819,26 +849,29 @@ int run_is_core(IsCore& J, double* weights, double* loglik, double* alpha, doubl
     while (pos < end) {
       const double tb0 = now_ms();
       const size_t F = std::min(maxF, end - pos);
-      std::vector<bssm::FilterTables> bt(F);
-      for (size_t f = 0; f < F; f++) bt[f] = tabs[order[pos + f]];
+      std::vector<const bssm::FilterTables*> bt(F);
+      for (size_t f = 0; f < F; f++) bt[f] = &tabs[order[pos + f]];
       DeviceBatch db;
-      int rc = db.upload(bt, n, m, k, pp, N, psi, false, 0, false);
+      int rc = db.upload(bt, n, m, k, pp, N, psi, false, 0, false, 4);
       if (rc) return rc;
       if (need_hist) { db.fb.alpha_hist = hist_pool.as<double>(); db.fb.indices = idx_pool.as<uint32_t>(); db.fb.weights = nullptr; }
       DevBuf fparb, amatb;  // per-draw functor parameters / approximating (T_t, C_t), in batch order
+      StageBuf st_fpar, st_amat;
       if (!J.fpar.empty()) {
-        std::vector<double> hb(F * bssm::FP_SIZE);
-        for (size_t f = 0; f < F; f++) std::memcpy(hb.data() + f * bssm::FP_SIZE, J.fpar.data() + (size_t)order[pos + f] * bssm::FP_SIZE, bssm::FP_SIZE * sizeof(double));
-        HIP_TRY(fparb.alloc(hb.size() * sizeof(double)));
-        HIP_TRY(hipMemcpy(fparb.p, hb.data(), fparb.bytes, hipMemcpyHostToDevice));
+        HIP_TRY(st_fpar.alloc(F * bssm::FP_SIZE * sizeof(double)));
+        double* hb = (double*)st_fpar.p;
+        for (size_t f = 0; f < F; f++) std::memcpy(hb + f * bssm::FP_SIZE, J.fpar.data() + (size_t)order[pos + f] * bssm::FP_SIZE, bssm::FP_SIZE * sizeof(double));
+        HIP_TRY(fparb.alloc(F * bssm::FP_SIZE * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(fparb.p, hb, fparb.bytes, hipMemcpyHostToDevice, nullptr));
         db.fb.fpar = fparb.as<double>(); db.fb.fpar_fstride = bssm::FP_SIZE;
       }
       if (!J.amats.empty()) {
         const size_t as = (size_t)n * (m * m + m);
-        std::vector<double> hb(F * as);
-        for (size_t f = 0; f < F; f++) std::memcpy(hb.data() + f * as, J.amats.data() + (size_t)order[pos + f] * as, as * sizeof(double));
-        HIP_TRY(amatb.alloc(hb.size() * sizeof(double)));
-        HIP_TRY(hipMemcpy(amatb.p, hb.data(), amatb.bytes, hipMemcpyHostToDevice));
+        HIP_TRY(st_amat.alloc(F * as * sizeof(double)));
+        double* hb = (double*)st_amat.p;
+        for (size_t f = 0; f < F; f++) std::memcpy(hb + f * as, J.amats.data() + (size_t)order[pos + f] * as, as * sizeof(double));
+        HIP_TRY(amatb.alloc(F * as * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(amatb.p, hb, amatb.bytes, hipMemcpyHostToDevice, nullptr));
         db.fb.amats = amatb.as<double>(); db.fb.amats_fstride = as;
       }
       const double tb1 = now_ms();
@@ -932,6 +965,49 @@ int run_is_core(IsCore& J, double* weights, double* loglik, double* alpha, doubl
   }
   return any_degenerate ? BSSM_WARN_DEGENERATE : BSSM_OK;
 }
+
+// Host set-up and device work of the post-correction overlap: the draws are cut into chunks, and while the device
+// filters chunk c (on its own host thread, which only waits on HIP) the caller's thread pool prepares chunk c + 1.
+// prepare(i) fills draw i's slots of J and returns "" or an error; results do not depend on the chunking because every
+// draw has its own Philox stream.
+int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::string(int)>& prepare,
+                    const std::function<void(int, int)>& finish_chunk, double* weights, double* loglik, double* alpha,
+                    double* alphahat_i, double* Vt_i) {
+  if (!have_device()) return no_device();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int chunk = 512;  // two rounds of one workgroup per CU
+  std::vector<std::string> errs(cnt);
+  std::thread worker;
+  int dev_rc = BSSM_OK, worst = BSSM_OK;
+  std::string dev_err;
+  double t_host = 0, t_dev = 0;
+  auto join = [&]() {
+    if (worker.joinable()) worker.join();
+    if (dev_rc < 0) return false;
+    if (dev_rc == BSSM_WARN_DEGENERATE) worst = BSSM_WARN_DEGENERATE;
+    return true;
+  };
+  for (int lo = 0; lo < cnt; lo += chunk) {
+    const int hi = std::min(cnt, lo + chunk);
+    const double t0 = now_ms();
+    parallel_for(hi - lo, n_threads, [&](int q) { errs[lo + q] = prepare(lo + q); });
+    for (int i = lo; i < hi; i++) if (!errs[i].empty()) { join(); return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]); }
+    if (finish_chunk) finish_chunk(lo, hi);
+    t_host += now_ms() - t0;
+    if (!join()) return fail(dev_rc, dev_err);
+    worker = std::thread([&, lo, hi]() {
+      (void)hipSetDevice(dev);  // the current device is per host thread
+      const double t1 = now_ms();
+      dev_rc = run_is_core(J, lo, hi, weights, loglik, alpha, alphahat_i, Vt_i);
+      if (dev_rc < 0) dev_err = g_err;
+      t_dev += now_ms() - t1;
+    });
+  }
+  if (!join()) return fail(dev_rc, dev_err);
+  g_is_timing[0] = t_host; g_is_timing[1] = t_dev;
+  return worst;
+}
 }  // namespace
 
 int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, double* alpha, double* alphahat_i,
@@ -949,51 +1025,49 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   if (!psi && !job->approx_loglik) return fail(BSSM_ERR_INVALID, "approx_loglik required for bsf");
   if (!job->counts) return fail(BSSM_ERR_INVALID, "counts NULL");
 
-  // per-draw host set-up (the reference does this inside its OpenMP region, src/approx_mcmc.cpp:372-373)
-  const double t_begin = now_ms();
+  // per-draw host set-up (the reference does this inside its OpenMP region, src/approx_mcmc.cpp:372-373), overlapped
+  // with the device work of the previous chunk of draws
   std::vector<bssm::HostModel> hms(cnt);
-  std::vector<bssm::FilterTables> tabs(cnt);
-  std::vector<std::string> errs(cnt);
-  std::vector<char> bad(cnt, 0);
-  const int n = job->models[0].n, m = job->models[0].m, k = job->models[0].k;
+  const int n = job->models[0].n, m = job->models[0].m, k = job->models[0].k, p0 = job->models[0].p > 1 ? job->models[0].p : 1;
   const int MP = bssm::pad_dim(m), KP = psi ? MP : bssm::pad_dim(k);
-  // a batch shares one table layout: force time-varying rows when any draw needs them
-  parallel_for(cnt, job->n_threads, [&](int i) {
-    errs[i] = bssm::ingest_model(&job->models[i], false, &hms[i]);
-    if (!errs[i].empty()) return;
-    if (hms[i].n != n || hms[i].m != m || hms[i].k != k || hms[i].p != (job->models[0].p > 1 ? job->models[0].p : 1)) { errs[i] = "all draws must share n, m, k, p"; return; }
+  IsCore J;
+  J.n = n; J.m = m; J.k = k; J.pp = p0; J.psi = psi;
+  J.first = job->first; J.is_type = job->is_type; J.output_type = job->output_type; J.nsim = job->nsim; J.seed = job->seed;
+  J.counts = job->counts;
+  J.tabs.resize(cnt);
+  J.bad.assign(cnt, 0);
+  J.const_add.assign(cnt, 0.0); J.sub.assign(cnt, 0.0);
+  auto prepare = [&](int i) -> std::string {
+    std::string err = bssm::ingest_model(&job->models[i], false, &hms[i]);
+    if (!err.empty()) return err;
+    if (hms[i].n != n || hms[i].m != m || hms[i].k != k || hms[i].p != p0) return "all draws must share n, m, k, p";
     if (psi) {
       bssm::PsiSetup su;
-      if (!bssm::psi_setup(hms[i], job->modes + (size_t)n * hms[i].p * i, &su)) bad[i] = 1;
-      bssm::build_psi_tables(hms[i], su, MP, &tabs[i]);
+      if (!bssm::psi_setup(hms[i], job->modes + (size_t)n * hms[i].p * i, &su)) J.bad[i] = 1;
+      bssm::build_psi_tables(hms[i], su, MP, &J.tabs[i]);
     } else {
-      bssm::build_bsf_tables(hms[i], MP, KP, &tabs[i]);
+      bssm::build_bsf_tables(hms[i], MP, KP, &J.tabs[i]);
+      J.const_add[i] = bssm::const_term(hms[i]);
+      J.sub[i] = job->approx_loglik[i];
     }
-  });
-  for (int i = 0; i < cnt; i++) if (!errs[i].empty()) return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]);
-  if (!have_device()) return no_device();
-  if (!psi) {  // equalise mats rows (time-invariant draws replicate to n rows if any draw is time-varying)
+    hms[i] = bssm::HostModel();  // the tables carry everything the device needs
+    return "";
+  };
+  auto finish_chunk = [&](int lo, int hi) {
+    if (psi) return;
+    // a device batch shares one table layout: time-invariant draws replicate to n rows if any draw of the chunk is time-varying
     int ts = 0;
-    for (auto& t : tabs) ts = std::max(ts, t.mats_tstride);
-    for (auto& t : tabs) if (t.mats_tstride != ts) {
+    for (int i = lo; i < hi; i++) ts = std::max(ts, J.tabs[i].mats_tstride);
+    for (int i = lo; i < hi; i++) {
+      bssm::FilterTables& t = J.tabs[i];
+      if (t.mats_tstride == ts) continue;
       std::vector<double> rep((size_t)n * ts);
       for (int tt = 0; tt < n; tt++) std::memcpy(rep.data() + (size_t)tt * ts, t.mats.data(), ts * sizeof(double));
       t.mats.swap(rep);
       t.mats_tstride = ts;
     }
-  }
-  IsCore J;
-  J.n = n; J.m = m; J.k = k; J.pp = hms[0].p; J.psi = psi;
-  J.first = job->first; J.is_type = job->is_type; J.output_type = job->output_type; J.nsim = job->nsim; J.seed = job->seed;
-  J.counts = job->counts;
-  J.tabs.swap(tabs);
-  J.bad = bad;
-  J.const_add.assign(cnt, 0.0); J.sub.assign(cnt, 0.0);
-  for (int i = 0; i < cnt; i++) if (!psi) { J.const_add[i] = bssm::const_term(hms[i]); J.sub[i] = job->approx_loglik[i]; }
-  const double t_mid = now_ms();
-  const int rc = run_is_core(J, weights, loglik, alpha, alphahat_i, Vt_i);
-  g_is_timing[0] = t_mid - t_begin; g_is_timing[1] = now_ms() - t_mid;
-  return rc;
+  };
+  return run_is_pipeline(J, cnt, job->n_threads, prepare, finish_chunk, weights, loglik, alpha, alphahat_i, Vt_i);
 }
 
 // postcorrection_nonlinear (src/R_postcorrection.cpp:252-317) / is_correction_psi<ssm_nlg>, is_correction_bsf<ssm_nlg>
@@ -1019,38 +1093,29 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   J.const_add.assign(count, 0.0); J.sub.assign(count, 0.0);
   J.fpar.assign((size_t)count * bssm::FP_SIZE, 0.0);
   if (psi) J.amats.assign((size_t)count * n * (m * m + m), 0.0);
-  std::vector<int> rcs(count, 0);
-  std::vector<std::string> errs(count);
-  const double t_begin = now_ms();
-  parallel_for(count, n_threads, [&](int i) {
-    if (models[i].n != n || models[i].model_id != id) { rcs[i] = BSSM_ERR_INVALID; errs[i] = "all draws must share n and model id"; return; }
+  auto prepare = [&](int i) -> std::string {
+    if (models[i].n != n || models[i].model_id != id) return "all draws must share n and model id";
     std::vector<double> fp, am;
     int mm_ = 1, kk_ = 1;
     if (psi) {
       double al = 0; bool ok = true;
       // approximate_for_is(mode_i): scales 0, approx_loglik 0 (src/approx_mcmc.cpp:372-373)
-      rcs[i] = functor_psi_tables(&models[i], modes + (size_t)m * n * i, 0, 1e-8, &J.tabs[i], &fp, &am, &al, &ok, &mm_);
-      if (rcs[i]) { errs[i] = g_err; return; }
+      if (functor_psi_tables(&models[i], modes + (size_t)m * n * i, 0, 1e-8, &J.tabs[i], &fp, &am, &al, &ok, &mm_)) return g_err;
       if (!ok) {  // non-finite Vt/Ct: the filter returns -Inf (:988-990); run a harmless bootstrap table in its place
         J.bad[i] = 1;
-        rcs[i] = functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_);
+        if (functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_)) return g_err;
         J.tabs[i].mats.assign((size_t)n * (m * m * 2 + m), 0.0); J.tabs[i].mats_tstride = m * m * 2 + m;
         am.assign((size_t)n * (m * m + m), 0.0);
       }
       std::memcpy(J.amats.data() + (size_t)i * am.size(), am.data(), am.size() * sizeof(double));
     } else {
-      rcs[i] = functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_);
-      if (rcs[i]) { errs[i] = g_err; return; }
+      if (functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_)) return g_err;
       J.sub[i] = approx_loglik[i];
     }
     std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
-  });
-  for (int i = 0; i < count; i++) if (rcs[i]) return fail(rcs[i], "draw " + std::to_string(i) + ": " + errs[i]);
-  if (!have_device()) return no_device();
-  const double t_mid = now_ms();
-  const int rc = run_is_core(J, weights, loglik, alpha, alphahat_i, Vt_i);
-  g_is_timing[0] = t_mid - t_begin; g_is_timing[1] = now_ms() - t_mid;
-  return rc;
+    return "";
+  };
+  return run_is_pipeline(J, count, n_threads, prepare, nullptr, weights, loglik, alpha, alphahat_i, Vt_i);
 }
 
 int bssm_is_merge(int32_t n, int32_t m, int32_t n_stored, const double* weights, const uint32_t* counts,
