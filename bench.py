@@ -34,13 +34,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def pmc_traffic(R, N):
+def pmc_traffic(R, N, ppt):
     """HBM bytes per pf_grid_step launch from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
     --pmc FETCH_SIZE / WRITE_SIZE runs of this script, corrected as MI355X_MICROARCH.md prescribes and calibrated on
     weights_finalize_kernel's known byte count); None when the profile does not match this workload."""
     try:
         p = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if p["replicas"] == R and p["particles"] == N:
+        if p["replicas"] == R and p["particles"] == N and p["particles_per_thread"] == ppt:
             return p["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--particles", type=int, default=65536)
-    ap.add_argument("--replicas", type=int, default=12,
+    ap.add_argument("--replicas", type=int, default=24,
                     help="independent filters (different Philox streams) in flight per step; 1 = latency regime")
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,10 +127,11 @@ def main():
         # ---- roofline of the dominant kernel: HIP events around sampled pf_grid_step launches
         k_ms, k_n = plan.time_kernel(77, sample_every=16, hip_stream=stream)
         bytes_per_launch = float(R) * N * info["bytes_per_particle_step"]
+        ppt = max(1, -(-N // (info["blocks"] // info["n_filters"] * info["threads"])))  # particles per thread of the step kernel
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R, N),
-                           "kernel": "pf_grid_step<4,4,1>", "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R, N, ppt),
+                           "kernel": "pf_grid_step<4,4,%d>" % ppt, "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
                            "wall_per_launch_us": ms_per_step * 1e3 / (T + 1),
                            "algorithmic_bytes_per_launch": bytes_per_launch,
                            "frac_of_measured_copy_6290GBs": achieved / 6290.0}
@@ -188,6 +189,13 @@ def main():
         out["cpu_baseline"] = {"value": float(N) * Ts / ec, "unit": "particle-steps/s", "cores": 1, "kind": "port",
                                "sample": "one full filter call of the benchmark model: N=%d, T=%d, 1 thread (the reference has no "
                                          "intra-filter parallelism), gcc -O2, %.1f s" % (N, Ts, ec)}
+
+    if rank == 0 and os.environ.get("BSSM_BENCH_CALIB"):
+        # profiling runs only (scripts/profile_round.sh): one kernel of known traffic (2 GiB read + 2 GiB written) so that
+        # the PMC FETCH_SIZE / WRITE_SIZE factors can be calibrated inside the same process
+        import ctypes
+        from bssm_amd import _lib
+        _lib.check(_lib.lib().bssm_debug_stream_copy(ctypes.c_uint64(1 << 28)))
 
     if rank == 0:
         print(json.dumps(out))

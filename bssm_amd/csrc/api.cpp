@@ -270,7 +270,7 @@ struct DeviceBatch {
     }
     // the reference zero-fills its outputs (src/R_bootstrap_filter.cpp:136-138): only a degenerate filter leaves
     // slots unwritten, so zero just those instead of memset-ing tens of GB per run
-    HIP_TRY(bssm::launch_zero_dead_tail(fb, !use_grid, st));
+    HIP_TRY(bssm::launch_zero_dead_tail(fb, true, st));
     return BSSM_OK;
   }
 
@@ -904,7 +904,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         } else {
           HIP_TRY(bssm::launch_wg_filter(sub, nullptr));
         }
-        HIP_TRY(bssm::launch_zero_dead_tail(sub, !db.use_grid, nullptr));
+        HIP_TRY(bssm::launch_zero_dead_tail(sub, true, nullptr));
         f0 = f1;
       }
       HIP_TRY(hipMemcpy(ll.data(), db.loglik.p, F * sizeof(double), hipMemcpyDeviceToHost));
@@ -1252,6 +1252,17 @@ int bssm_plan_time(bssm_plan* plan, uint32_t seed, int32_t reps, void* hip_strea
 }
 
 // test hook: the device elementary functions (0 exp, 1 log, 2 sincos(2 pi x) -> 2n outputs, 3 Box-Muller pairs)
+int bssm_debug_stream_copy(uint64_t n_doubles) {
+  if (!have_device()) return no_device();
+  DevBuf a, b;
+  HIP_TRY(a.alloc(n_doubles * sizeof(double)));
+  HIP_TRY(b.alloc(n_doubles * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(a.p, 0, a.bytes, nullptr));
+  HIP_TRY(bssm::launch_calib_copy(a.as<double>(), b.as<double>(), (size_t)n_doubles, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  return BSSM_OK;
+}
+
 int bssm_debug_math(int fn, const double* in, double* out, int32_t n) {
   if (!have_device()) return no_device();
   if (!in || !out || n < 1) return fail(BSSM_ERR_INVALID, "bad arguments");

@@ -87,7 +87,7 @@ __device__ __forceinline__ double sqrt_small(double x) {
 // Box-Muller pair from one Philox block
 __device__ __forceinline__ void box_muller(const u32x4& w, double& z0, double& z1) {
   const double u1 = (u53_to_double(w.x >> 5, w.y >> 6) + 1.0) * 0x1.0p-53;  // (0,1]
-  const double rad = sqrt_small(-2.0 * fast_log(u1));
+  const double rad = sqrt_small(-2.0 * fast_log<false>(u1));
   double sn, cs;
   fast_sincos_2pi(w.z, sn, cs);  // angle 2*pi*w2*2^-32
   z0 = rad * cs;

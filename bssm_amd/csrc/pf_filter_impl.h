@@ -22,8 +22,6 @@
 
 namespace bssm {
 
-__global__ void weights_finalize_kernel(double* __restrict__ weights, const double* __restrict__ maxhist,
-                                        const int* __restrict__ dead_at, int n1, int N);
 __global__ void loglik_finalize_kernel(double* __restrict__ loglik, const double* __restrict__ llinc,
                                        const int* __restrict__ dead_at, int n, int F);
 
@@ -425,6 +423,7 @@ template <int MP, int KP, int PPT, bool DBG = false, bool FN = false>
 __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   __shared__ double s_Q[GRID_NT];      // inclusive prefix of scaled block sums
   __shared__ double s_iscale[GRID_NT];  // 1 / exp(max_b - M)
+  __shared__ double s_myscale;          // exp(max_pb - M) of this block (weights finalisation)
   __shared__ double s_red[8];
   __shared__ double s_tot[PPT * 4];
   constexpr bool kMfma = MP == 8 && PPT == 1 && !FN;  // fp64 MFMA transition (ssm_mng m = 8)
@@ -470,6 +469,16 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
     const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
     const double pmax = (tid < B) ? part[2 * tid] : -INFINITY;
     const double psum = (tid < B) ? part[2 * tid + 1] : 0.0;
+    // this block's stored weights of time t are exp(w - max_pb): they are rescaled to exp(w - M) below, once the
+    // global maximum is known (one read-modify-write here replaces a separate finalisation pass over the array)
+    double wt_old[PPT];
+    if (b.weights) {
+#pragma unroll
+      for (int r = 0; r < PPT; r++) {
+        const int li = r * GRID_NT + tid;
+        wt_old[r] = (li < len) ? b.weights[((size_t)f * (n + 1) + t) * N + base + li] : 0.0;
+      }
+    }
     // ... and draw this step's random numbers while they are in flight (PPT <= 2 keeps them in registers)
     constexpr bool kEarlyRng = PPT <= 2 && !FN;
     double u_pre[kEarlyRng ? PPT : 1], z_pre[kEarlyRng ? PPT : 1][KP];
@@ -484,22 +493,40 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
     }
     BSSM_STAMP(1)
     // ---- combine the partials of the time-t weights (every block redundantly, same order)
-    double mx = wave_max(pmax);
+    // waves whose 64 slots lie beyond the B partials only publish identities (wave-uniform branch): with more than one
+    // particle per thread (B < 256) the combine is then paid by B / 64 waves instead of all four
+    const bool wave_has_partials = wave * 64 < B;
+    double mx = -INFINITY;
+    if (wave_has_partials) mx = wave_max(pmax);
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
     const double M = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-    const double scale = (tid < B) ? fast_exp(pmax - M) : 0.0;
-    const double ss = psum * scale;
-    double qi = wave_scan_incl(ss);
-    if (lane == 63) s_red[4 + wave] = qi;
-    __syncthreads();
-    double off = 0.0;
-    for (int q = 0; q < wave; q++) off += s_red[4 + q];
-    qi += off;
-    s_Q[tid] = qi;
-    s_iscale[tid] = 1.0 / scale;
+    if (wave_has_partials) {
+      const double scale = (tid < B) ? fast_exp(pmax - M) : 0.0;
+      const double ss = psum * scale;
+      double qi = wave_scan_incl(ss);
+      if (lane == 63) s_red[4 + wave] = qi;
+      __syncthreads();
+      double off = 0.0;
+      for (int q = 0; q < wave; q++) off += s_red[4 + q];
+      qi += off;
+      s_Q[tid] = qi;
+      s_iscale[tid] = 1.0 / scale;
+      if (tid == pb) s_myscale = scale;
+    } else {
+      if (lane == 63) s_red[4 + wave] = 0.0;
+      __syncthreads();
+    }
     const double S = ((s_red[4] + s_red[5]) + s_red[6]) + s_red[7];
     __syncthreads();
+    if (b.weights) {  // also on the degenerate step: the reference stores exp(w - max) before it tests the sum (:676-682)
+      const double myscale = s_myscale;
+#pragma unroll
+      for (int r = 0; r < PPT; r++) {
+        const int li = r * GRID_NT + tid;
+        if (li < len) b.weights[((size_t)f * (n + 1) + t) * N + base + li] = wt_old[r] * myscale;
+      }
+    }
     if (!(S > 0.0)) {
       // Degenerate weights (src/model_ssm_ung.cpp:678-682): stop here and poison this block's slot of the
       // next parity so that every later launch sees a non-finite S as well and returns too (no flag load
@@ -508,13 +535,12 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
         double* __restrict__ pn = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
         pn[2 * pb] = __builtin_nan("");
         pn[2 * pb + 1] = __builtin_nan("");
-        if (pb == 0) { atomicCAS(&b.dead_at[f], 0, t + 1); ws.maxhist[(size_t)f * (n + 1) + t] = M; }
+        if (pb == 0) atomicCAS(&b.dead_at[f], 0, t + 1);
       }
       return;
     }
     if (pb == B - 1 && tid == GRID_NT - 1) {  // single writer, store-only: summed in time order afterwards
       ws.llinc[(size_t)f * (n + 1) + t] = M + fast_log(S / (double)N);  // src/model_ssm_ung.cpp:683
-      ws.maxhist[(size_t)f * (n + 1) + t] = M;
     }
     BSSM_STAMP(2)
     // ---- resample + gather + propagate
@@ -618,7 +644,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
     e[r] = (li < len) ? fast_exp(w[r] - Mb) : 0.0;
-    if (b.weights && li < len) b.weights[((size_t)f * (n + 1) + tn) * N + base + li] = w[r];  // raw; finalised later
+    if (b.weights && li < len) b.weights[((size_t)f * (n + 1) + tn) * N + base + li] = e[r];  // block-scaled; rescaled by launch tn
   }
   BSSM_STAMP(9)
   const double tot = block_scan_strided<PPT>(e, sc, s_tot);
@@ -666,7 +692,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   }
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(ws.maxhist, 0, sizeof(double) * 2 * b.F * (b.n + 1), stream)) != hipSuccess) return e;  // maxhist + llinc
+  if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
   const dim3 grid(ws.B, b.F), block(GRID_NT);
   if (!timing || timing->every <= 0) {
     for (int t = -1; t < b.n; t++) hipLaunchKernelGGL(kern, grid, block, 0, stream, b, ws, t);
@@ -704,11 +730,6 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
   hipLaunchKernelGGL(loglik_finalize_kernel, dim3((b.F + 63) / 64), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);
-  if (b.weights) {
-    const int gx = (b.N + 255) / 256 < 64 ? (b.N + 255) / 256 : 64;
-    hipLaunchKernelGGL(weights_finalize_kernel, dim3(gx, b.n + 1, b.F), dim3(256), 0, stream, b.weights, ws.maxhist,
-                       b.dead_at, b.n + 1, b.N);
-  }
   return hipGetLastError();
 }
 

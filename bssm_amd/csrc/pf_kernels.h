@@ -50,7 +50,7 @@ struct GridWorkspace {
   double* coarse;      // [2][F][B][chunk/16] last entry of every row of 16 of lcdf
   double* partials;    // [2][F][B][2]  (max_b, sum_b)
   double* logw;        // [F][N] raw log-weights when weights output is wanted
-  double* maxhist;     // [F][n+1] global max per time point (weights finalisation)
+  double* maxhist;     // [F][n+1] spare (was: global max per time point for a separate weights finalisation pass)
   double* llinc;       // [F][n+1] log-likelihood increment per time point (summed in time order at the end)
   long long* dbg;      // optional [n][16] cycle stamps of block 0 / thread 0 (debug builds of the step kernel)
   int B;               // particle blocks per filter
@@ -92,6 +92,7 @@ hipError_t launch_sim_smoother(const double* mats, const double* init, double* h
                                hipStream_t stream);
 // stratified_sample (src/stratified_sample.cpp:9-28): p [len] is overwritten by its cumulative sum, out [N]
 hipError_t launch_stratified_sample(double* p, const double* r, uint32_t* out, int len, int N, hipStream_t stream);
+hipError_t launch_calib_copy(const double* in, double* out, size_t n, hipStream_t stream);
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream);
 
 }  // namespace bssm

@@ -1,6 +1,9 @@
 // pf_kernels.hip -- launch dispatch plus the smoothing / summary / layout kernels.
 // The filter kernels themselves are templates in pf_filter_impl.h, instantiated per padded
 // state dimension in pf_inst_mp*.hip.
+#include <algorithm>
+#include <cstdlib>
+
 #include "pf_filter_impl.h"
 
 namespace bssm {
@@ -12,19 +15,6 @@ int wg_filter_capacity(int MP) {
   const size_t cap = avail / ((size_t)(MP + 1) * sizeof(double));
   for (int c = (MP <= 2 ? 8192 : 4096); c >= 512; c >>= 1) if ((size_t)c <= cap) return c;
   return (int)(cap / 64 * 64);
-}
-
-// weights[f][tt][i] <- exp(w - M_tt); zero after a degenerate step (reference leaves zeros)
-__global__ void weights_finalize_kernel(double* __restrict__ weights, const double* __restrict__ maxhist,
-                                        const int* __restrict__ dead_at, int n1, int N) {
-  const int tt = blockIdx.y, f = blockIdx.z;
-  const double M = maxhist[(size_t)f * n1 + tt];
-  double* __restrict__ col = weights + ((size_t)f * n1 + tt) * N;
-  const int da = dead_at[f];  // 0 = alive, else (time of degeneracy) + 1
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    if (da && tt > da - 1) col[i] = 0.0;
-    else col[i] = fast_exp(col[i] - M);
-  }
 }
 
 // loglik[f] = sum_t llinc[f][t] in time order (the reference's accumulation order), -inf after a degenerate step
@@ -39,7 +29,13 @@ __global__ void loglik_finalize_kernel(double* __restrict__ loglik, const double
 
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   // one particle per thread until the chip is full, then more particles per thread
-  int ppt = 1;
+  // One particle per thread keeps a single filter's dependent chain shortest.  When the batch already oversubscribes
+  // the chip several times (>= 2048 workgroups of 256), two particles per thread halve the per-particle cost of the
+  // partial combine (measured +2-3 % particle-steps/s at 12-24 filters of 65 536 particles).
+  // (only for states of at most 4 doubles without functor parameters: larger live state costs occupancy, and the
+  // fp64-MFMA transition of the 8-dimensional state needs one particle per lane)
+  int ppt = ((size_t)b.F * ((b.N + GRID_NT - 1) / GRID_NT) >= 2048 && b.N >= 2 * GRID_NT && b.MP <= 4 && !b.fpar) ? 2 : 1;
+  if (const char* env = std::getenv("BSSM_AMD_GRID_PPT")) ppt = std::max(1, std::min(8, std::atoi(env)));  // tuning hook
   while ((b.N + GRID_NT * ppt - 1) / (GRID_NT * ppt) > GRID_NT && ppt < 8) ppt *= 2;
   const int chunk = GRID_NT * ppt;
   const int B = (b.N + chunk - 1) / chunk;
@@ -153,6 +149,16 @@ __global__ void debug_math_kernel(int fn, const double* __restrict__ in, double*
 }
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream) {
   hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, in, out, n);
+  return hipGetLastError();
+}
+
+// known-traffic kernel for calibrating the rocprofv3 FETCH_SIZE / WRITE_SIZE counters on this library's own access
+// pattern (8 bytes per lane, coalesced): reads n doubles and writes n doubles, nothing else
+__global__ void __launch_bounds__(256) calib_copy_kernel(const double* __restrict__ in, double* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i] + 1.0;
+}
+hipError_t launch_calib_copy(const double* in, double* out, size_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(calib_copy_kernel, dim3(8192), dim3(256), 0, stream, in, out, n);
   return hipGetLastError();
 }
 

@@ -25,17 +25,32 @@ __device__ __forceinline__ double u53_to_double(uint32_t hi27, uint32_t lo26) {
   return __builtin_fma((double)hi27, 67108864.0, (double)lo26);
 }
 
-// natural log for finite x > 0 (subnormals included via the slow path)
+// f / d for d in [1.5, 2.5] and |f| < 1: v_rcp_f64 seed, two Newton steps on the reciprocal and one residual
+// correction of the quotient (<= 1 ulp; the IEEE division sequence with its scaling and fix-up steps is not needed
+// on this range and costs twice as many instructions)
+__device__ __forceinline__ double div_near2(double f, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  const double q = f * r;
+  return __builtin_fma(__builtin_fma(-d, q, f), r, q);
+}
+
+// natural log; CHECKED = false skips the range test for arguments known to be normal positive numbers
+// (the Box-Muller radius argument lies in [2^-53, 1])
+template <bool CHECKED = true>
 __device__ __forceinline__ double fast_log(double x) {
 #if BSSM_FAST_MATH
-  if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0)) return log(x);
+  if constexpr (CHECKED) {
+    if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0)) return log(x);
+  }
   double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
   int k = __builtin_amdgcn_frexp_exp(x);
   const bool lowhalf = m < 0.70710678118654752440;
   m = lowhalf ? m + m : m;  // [sqrt(1/2), sqrt(2))
   k = lowhalf ? k - 1 : k;
   const double f = m - 1.0;
-  const double s = f / (2.0 + f);
+  const double s = div_near2(f, 2.0 + f);
   const double dk = (double)k;
   const double z = s * s, w = z * z;
   const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),

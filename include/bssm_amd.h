@@ -295,6 +295,9 @@ int bssm_plan_time_kernel(bssm_plan* plan, uint32_t seed, int32_t sample_every, 
  * 3 Box-Muller pairs of the stream (seed 1, stream 0, purpose 2, t 0, particle i) -> 2n outputs) and the
  * cycle-stamp timeline of the grid step kernel (12 averaged phase durations). */
 int bssm_debug_math(int fn, const double* in, double* out, int32_t n);
+/* runs one kernel that reads n_doubles and writes n_doubles (8 B per lane, coalesced): a known byte count for
+ * calibrating the profiler's FETCH_SIZE / WRITE_SIZE counters on this library's access pattern */
+int bssm_debug_stream_copy(uint64_t n_doubles);
 int bssm_plan_debug_timeline(bssm_plan* plan, uint32_t seed, double* avg_delta_cycles);
 
 /* exposed for tests: the exact Philox block and uniform / normal pair the kernels use */
