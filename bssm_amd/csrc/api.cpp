@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -789,6 +790,81 @@ int bssm_suggest_n_nonlinear(const bssm_fn_model* model, const uint32_t* candida
 
 // ------------------------------------------------------------------ IS post-correction
 namespace {
+// psi set-up smoothers of several draws as ONE device batch (lg_setup_kernel, one lane per draw) on a stream of its
+// own, so that it overlaps the filter kernels of the previous chunk running on the null stream.  outs[q] = {alphahat,
+// Vt, Ct} of draw q; ok[q] = 0 where the result is not finite.  Returns 1 when the draws do not share one layout
+// (the caller then runs them on the host), 0 on success, negative on a HIP error.
+int device_lg_batch(const std::vector<const bssm::LgPacked*>& lgs, const std::vector<std::array<double*, 3>>& outs,
+                    std::vector<char>* ok) {
+  const int F = (int)lgs.size();
+  if (F == 0) return 0;
+  const bssm::LgPacked& L0 = *lgs[0];
+  for (int q = 1; q < F; q++) if (!L0.same_layout(*lgs[q])) return 1;
+  static thread_local hipStream_t st = nullptr;
+  if (!st) {  // highest priority: the lanes of this small kernel compete with filter workgroups that fill every CU
+    int lo_p = 0, hi_p = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+    HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi_p));
+  }
+  const size_t n = L0.n, m = L0.m, mm = m * m, n1 = n + 1, ins = L0.buf.size();
+  const size_t o_at = 0, o_pt = o_at + n1 * m, o_cc = o_pt + n1 * mm, outs_per = o_cc + n1 * mm;
+  StageBuf sin, sout;
+  HIP_TRY(sin.alloc(ins * F * sizeof(double)));
+  HIP_TRY(sout.alloc((outs_per * sizeof(double) + sizeof(int)) * F));
+  for (int q = 0; q < F; q++) std::memcpy((double*)sin.p + ins * q, lgs[q]->buf.data(), ins * sizeof(double));
+  DevBuf din, din_t, dat, dpt, dcc, dat_t, dpt_t, dcc_t, dK, dv, dF, dok;
+  HIP_TRY(din.alloc(ins * F * sizeof(double)));
+  HIP_TRY(din_t.alloc(ins * F * sizeof(double)));
+  HIP_TRY(dat.alloc(n1 * m * F * sizeof(double)));
+  HIP_TRY(dpt.alloc(n1 * mm * F * sizeof(double)));
+  HIP_TRY(dcc.alloc(n1 * mm * F * sizeof(double)));
+  HIP_TRY(dat_t.alloc(n1 * m * F * sizeof(double)));
+  HIP_TRY(dpt_t.alloc(n1 * mm * F * sizeof(double)));
+  HIP_TRY(dcc_t.alloc(n1 * mm * F * sizeof(double)));
+  HIP_TRY(dK.alloc(n * m * F * sizeof(double)));
+  HIP_TRY(dv.alloc(n * F * sizeof(double)));
+  HIP_TRY(dF.alloc(n * F * sizeof(double)));
+  HIP_TRY(dok.alloc(F * sizeof(int)));
+  const double t_in = now_ms();
+  HIP_TRY(hipMemcpyAsync(din.p, sin.p, ins * F * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(bssm::launch_transpose(din.as<double>(), din_t.as<double>(), F, (int)ins, st));  // [F][E] -> [E][F]
+  bssm::LgBatchDev b{};
+  b.F = F; b.n = (int)n; b.m = (int)m;
+  b.Zs = L0.Zs; b.Ts = L0.Ts; b.Rs = L0.Rs; b.Ds = L0.Ds; b.Cs = L0.Cs; b.Hs = L0.Hs;
+  b.oZ = L0.oZ; b.oT = L0.oT; b.oR = L0.oR; b.oD = L0.oD; b.oC = L0.oC; b.oy = L0.oy; b.oH = L0.oH; b.oa = L0.oa; b.oP = L0.oP;
+  b.in_stride = ins;
+  b.in = din_t.as<double>(); b.at = dat_t.as<double>(); b.Pt = dpt_t.as<double>(); b.cc = dcc_t.as<double>();
+  b.K = dK.as<double>(); b.v = dv.as<double>(); b.Fs = dF.as<double>(); b.ok = dok.as<int>();
+  HIP_TRY(bssm::launch_lg_setup(b, st));
+  HIP_TRY(bssm::launch_transpose(dat_t.as<double>(), dat.as<double>(), (int)(n1 * m), F, st));   // [E][F] -> [F][E]
+  HIP_TRY(bssm::launch_transpose(dpt_t.as<double>(), dpt.as<double>(), (int)(n1 * mm), F, st));
+  HIP_TRY(bssm::launch_transpose(dcc_t.as<double>(), dcc.as<double>(), (int)(n1 * mm), F, st));
+  double* ho = (double*)sout.p;
+  int* hok = (int*)(ho + outs_per * F);
+  HIP_TRY(hipMemcpyAsync(ho + o_at * F, dat.p, n1 * m * F * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ho + o_pt * F, dpt.p, n1 * mm * F * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ho + o_cc * F, dcc.p, n1 * mm * F * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hok, dok.p, F * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (std::getenv("BSSM_AMD_TRACE"))
+    std::fprintf(stderr, "[bssm_amd] psi set-up smoother on device: F=%d n=%zu m=%zu: %.2f ms (copies + kernel)\n", F, n, m, now_ms() - t_in);
+  ok->assign(F, 1);
+  for (int q = 0; q < F; q++) {
+    std::memcpy(outs[q][0], ho + o_at * F + n1 * m * q, n1 * m * sizeof(double));
+    std::memcpy(outs[q][1], ho + o_pt * F + n1 * mm * q, n1 * mm * sizeof(double));
+    std::memcpy(outs[q][2], ho + o_cc * F + n1 * mm * q, n1 * mm * sizeof(double));
+    (*ok)[q] = hok[q] ? 1 : 0;
+  }
+  return 0;
+}
+// The device smoother shares the GPU with the filter kernels of the previous chunk (measured 4 ms alone, 10-20 ms
+// under contention per 512 draws of n = 300, m = 2); the host smoother costs 0.19 ms per draw and thread.  With fewer
+// than 8 host threads the device batch wins (C5 at threads = 1: 0.60 s -> 0.22 s), with more the host pool does.
+bool device_setup_enabled(int n_threads) {
+  if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) return env[0] != '0';
+  return n_threads < 8;
+}
+
 // Shared core of the IS post-correction drivers: filter `cnt` prepared draws (tables already built), then
 // back-trace / summarise as output_type asks.  const_add[i] is added to the device log-likelihood
 // (bootstrap: state-independent constants); weight_i = exp(loglik_i - sub[i]) (src/approx_mcmc.cpp:385, 479).
@@ -970,9 +1046,12 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
 // filters chunk c (on its own host thread, which only waits on HIP) the caller's thread pool prepares chunk c + 1.
 // prepare(i) fills draw i's slots of J and returns "" or an error; results do not depend on the chunking because every
 // draw has its own Philox stream.
+// Optional middle phase: device_chunk(lo, hi) runs once per chunk on the caller's thread between prepare and post
+// (the batched psi set-up smoother), post(i) then finishes draw i (table building) on the thread pool.
 int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::string(int)>& prepare,
                     const std::function<void(int, int)>& finish_chunk, double* weights, double* loglik, double* alpha,
-                    double* alphahat_i, double* Vt_i) {
+                    double* alphahat_i, double* Vt_i, const std::function<int(int, int)>& device_chunk = nullptr,
+                    const std::function<std::string(int)>& post = nullptr) {
   if (!have_device()) return no_device();
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -993,6 +1072,14 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
     const double t0 = now_ms();
     parallel_for(hi - lo, n_threads, [&](int q) { errs[lo + q] = prepare(lo + q); });
     for (int i = lo; i < hi; i++) if (!errs[i].empty()) { join(); return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]); }
+    if (device_chunk) {
+      const int rc = device_chunk(lo, hi);
+      if (rc < 0) { join(); return rc; }
+    }
+    if (post) {
+      parallel_for(hi - lo, n_threads, [&](int q) { errs[lo + q] = post(lo + q); });
+      for (int i = lo; i < hi; i++) if (!errs[i].empty()) { join(); return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]); }
+    }
     if (finish_chunk) finish_chunk(lo, hi);
     t_host += now_ms() - t0;
     if (!join()) return fail(dev_rc, dev_err);
@@ -1037,13 +1124,19 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   J.tabs.resize(cnt);
   J.bad.assign(cnt, 0);
   J.const_add.assign(cnt, 0.0); J.sub.assign(cnt, 0.0);
+  const bool dev_setup = psi && device_setup_enabled(job->n_threads) && have_device();
+  std::vector<bssm::PsiSetup> sus(dev_setup ? cnt : 0);
+  std::vector<bssm::LgPacked> lgs(dev_setup ? cnt : 0);
+  std::vector<char> pending(cnt, 0);
   auto prepare = [&](int i) -> std::string {
     std::string err = bssm::ingest_model(&job->models[i], false, &hms[i]);
     if (!err.empty()) return err;
     if (hms[i].n != n || hms[i].m != m || hms[i].k != k || hms[i].p != p0) return "all draws must share n, m, k, p";
     if (psi) {
+      const double* mode_i = job->modes + (size_t)n * hms[i].p * i;
+      if (dev_setup && bssm::psi_setup_begin(hms[i], mode_i, &sus[i], &lgs[i])) { pending[i] = 1; return ""; }
       bssm::PsiSetup su;
-      if (!bssm::psi_setup(hms[i], job->modes + (size_t)n * hms[i].p * i, &su)) J.bad[i] = 1;
+      if (!bssm::psi_setup(hms[i], mode_i, &su)) J.bad[i] = 1;
       bssm::build_psi_tables(hms[i], su, MP, &J.tabs[i]);
     } else {
       bssm::build_bsf_tables(hms[i], MP, KP, &J.tabs[i]);
@@ -1051,6 +1144,35 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       J.sub[i] = job->approx_loglik[i];
     }
     hms[i] = bssm::HostModel();  // the tables carry everything the device needs
+    return "";
+  };
+  // the O(n m^3) smoothers of the chunk as one device batch, then the tables on the thread pool
+  auto device_chunk = [&](int lo, int hi) -> int {
+    std::vector<const bssm::LgPacked*> lp;
+    std::vector<std::array<double*, 3>> outs;
+    std::vector<int> who;
+    for (int i = lo; i < hi; i++) if (pending[i]) {
+      lp.push_back(&lgs[i]); who.push_back(i);
+      outs.push_back({sus[i].alphahat.data(), sus[i].Vt.data(), sus[i].Ct.data()});
+    }
+    std::vector<char> okv;
+    const int rc = device_lg_batch(lp, outs, &okv);
+    if (rc < 0) return rc;
+    if (rc == 1) {  // mixed layouts: the same smoother on the host
+      parallel_for((int)who.size(), job->n_threads, [&](int q) {
+        const int i = who[q];
+        if (!bssm::lg_packed_run(lgs[i], sus[i].alphahat.data(), sus[i].Vt.data(), sus[i].Ct.data())) J.bad[i] = 1;
+      });
+    } else {
+      for (size_t q = 0; q < who.size(); q++) if (!okv[q]) J.bad[who[q]] = 1;
+    }
+    return 0;
+  };
+  auto post = [&](int i) -> std::string {
+    if (!pending[i]) return "";
+    bssm::build_psi_tables(hms[i], sus[i], MP, &J.tabs[i]);
+    hms[i] = bssm::HostModel(); sus[i] = bssm::PsiSetup(); lgs[i] = bssm::LgPacked();
+    pending[i] = 0;
     return "";
   };
   auto finish_chunk = [&](int lo, int hi) {
@@ -1067,6 +1189,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       t.mats_tstride = ts;
     }
   };
+  if (dev_setup) return run_is_pipeline(J, cnt, job->n_threads, prepare, finish_chunk, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk, post);
   return run_is_pipeline(J, cnt, job->n_threads, prepare, finish_chunk, weights, loglik, alpha, alphahat_i, Vt_i);
 }
 
@@ -1093,20 +1216,36 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   J.const_add.assign(count, 0.0); J.sub.assign(count, 0.0);
   J.fpar.assign((size_t)count * bssm::FP_SIZE, 0.0);
   if (psi) J.amats.assign((size_t)count * n * (m * m + m), 0.0);
+  const bool dev_setup = psi && device_setup_enabled(n_threads) && have_device();
+  std::vector<bssm::FnModel> fms(dev_setup ? count : 0);
+  std::vector<bssm::FnSetup> fsus(dev_setup ? count : 0);
+  std::vector<bssm::LgPacked> lgs(dev_setup ? count : 0);
+  std::vector<char> pending(count, 0);
+  // non-finite Vt/Ct: the filter returns -Inf (src/model_ssm_nlg.cpp:988-990); run a harmless bootstrap table in its place
+  auto bad_draw = [&](int i, std::vector<double>* fp, std::vector<double>* am) -> bool {
+    int mm_ = 1, kk_ = 1;
+    J.bad[i] = 1;
+    if (functor_tables(&models[i], &J.tabs[i], fp, &mm_, &kk_)) return false;
+    J.tabs[i].mats.assign((size_t)n * (m * m * 2 + m), 0.0); J.tabs[i].mats_tstride = m * m * 2 + m;
+    am->assign((size_t)n * (m * m + m), 0.0);
+    return true;
+  };
   auto prepare = [&](int i) -> std::string {
     if (models[i].n != n || models[i].model_id != id) return "all draws must share n and model id";
     std::vector<double> fp, am;
     int mm_ = 1, kk_ = 1;
     if (psi) {
-      double al = 0; bool ok = true;
       // approximate_for_is(mode_i): scales 0, approx_loglik 0 (src/approx_mcmc.cpp:372-373)
-      if (functor_psi_tables(&models[i], modes + (size_t)m * n * i, 0, 1e-8, &J.tabs[i], &fp, &am, &al, &ok, &mm_)) return g_err;
-      if (!ok) {  // non-finite Vt/Ct: the filter returns -Inf (:988-990); run a harmless bootstrap table in its place
-        J.bad[i] = 1;
-        if (functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_)) return g_err;
-        J.tabs[i].mats.assign((size_t)n * (m * m * 2 + m), 0.0); J.tabs[i].mats_tstride = m * m * 2 + m;
-        am.assign((size_t)n * (m * m + m), 0.0);
+      if (dev_setup) {
+        bssm::FilterTables dummy;
+        if (to_fn_model(&models[i], &fms[i])) return g_err;
+        if (functor_tables(&models[i], &dummy, &fp, &mm_, &kk_)) return g_err;
+        std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
+        if (bssm::fn_psi_setup_begin(fms[i], modes + (size_t)m * n * i, &fsus[i], &lgs[i])) { pending[i] = 1; return ""; }
       }
+      double al = 0; bool ok = true;
+      if (functor_psi_tables(&models[i], modes + (size_t)m * n * i, 0, 1e-8, &J.tabs[i], &fp, &am, &al, &ok, &mm_)) return g_err;
+      if (!ok && !bad_draw(i, &fp, &am)) return g_err;
       std::memcpy(J.amats.data() + (size_t)i * am.size(), am.data(), am.size() * sizeof(double));
     } else {
       if (functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_)) return g_err;
@@ -1115,6 +1254,42 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
     std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
     return "";
   };
+  auto device_chunk = [&](int lo, int hi) -> int {
+    std::vector<const bssm::LgPacked*> lp;
+    std::vector<std::array<double*, 3>> outs;
+    std::vector<int> who;
+    for (int i = lo; i < hi; i++) if (pending[i]) {
+      lp.push_back(&lgs[i]); who.push_back(i);
+      outs.push_back({fsus[i].alphahat.data(), fsus[i].Vt.data(), fsus[i].Ct.data()});
+    }
+    std::vector<char> okv;
+    const int rc = device_lg_batch(lp, outs, &okv);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      parallel_for((int)who.size(), n_threads, [&](int q) {
+        const int i = who[q];
+        fsus[i].ok = bssm::lg_packed_run(lgs[i], fsus[i].alphahat.data(), fsus[i].Vt.data(), fsus[i].Ct.data());
+      });
+    } else {
+      for (size_t q = 0; q < who.size(); q++) fsus[who[q]].ok = okv[q] != 0;
+    }
+    return 0;
+  };
+  auto post = [&](int i) -> std::string {
+    if (!pending[i]) return "";
+    std::vector<double> fp, am;
+    if (fsus[i].ok) {
+      bssm::build_fn_psi_tables(fms[i], fsus[i], &J.tabs[i], &am);
+    } else {
+      if (!bad_draw(i, &fp, &am)) return g_err;
+      std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
+    }
+    std::memcpy(J.amats.data() + (size_t)i * am.size(), am.data(), am.size() * sizeof(double));
+    fms[i] = bssm::FnModel(); fsus[i] = bssm::FnSetup(); lgs[i] = bssm::LgPacked();
+    pending[i] = 0;
+    return "";
+  };
+  if (dev_setup) return run_is_pipeline(J, count, n_threads, prepare, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk, post);
   return run_is_pipeline(J, count, n_threads, prepare, nullptr, weights, loglik, alpha, alphahat_i, Vt_i);
 }
 

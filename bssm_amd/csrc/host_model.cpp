@@ -5,9 +5,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
+#include "lg_smoother.h"
 #include "pf_device.h"
 
 namespace bssm {
@@ -227,9 +229,12 @@ double gaussian_loglik(const Sys& S, const Approx& ap) {
 }
 
 // src/model_ssm_ulg.cpp:252-305, src/model_ssm_mlg.cpp fast_smoother -> smoothed state means, m x (n+1)
+bool lg_fast_mean(const HostModel& h, const Approx& ap, std::vector<Mat>* atp);
+
 bool fast_smoother(const Sys& S, const Approx& ap, std::vector<Mat>* atp) {
   const HostModel& h = S.h;
   const int n = h.n, m = h.m;
+  if (lg_fast_mean(h, ap, atp)) return true;
   std::vector<Mat>& at = *atp;
   at.assign(n + 1, Mat(m, 1));
   std::vector<KfStep> st(n);
@@ -325,6 +330,62 @@ void conditional_cov(std::vector<Mat>* Vt, std::vector<Mat>* Ct) {
   }
   sym_singular((*Vt)[0], &U, &s);
   for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) (*Vt)[0](i, c) = U(i, c) * std::sqrt(s[c]);
+}
+
+// Fixed-size fast paths of smoother_ccov + conditional_cov and of fast_smoother for univariate observations and
+// m <= 8 (lg_smoother.h: the same operation order as the generic routines above, so the numbers are the same).
+struct LgHostModel {
+  LgModel g;
+  std::vector<double> RR, yx;
+  static bool applies(const HostModel& h) {
+    if (std::getenv("BSSM_AMD_GENERIC_SETUP")) return false;  // test hook: force the generic Mat routines
+    return h.p == 1 && h.m >= 1 && h.m <= 8;
+  }
+  LgHostModel(const HostModel& h, const Approx& ap) {
+    const int n = h.n, m = h.m, k = h.k, nR = h.Rtv ? n : 1;
+    RR.resize((size_t)nR * m * m); yx.resize(n);
+    for (int t = 0; t < nR; t++) {
+      const double* R = h.R.data() + (size_t)m * k * t;
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) {
+        double sacc = 0.0;
+        for (int q = 0; q < k; q++) sacc += R[i + m * q] * R[j + m * q];
+        RR[i + m * j + (size_t)m * m * t] = sacc;
+      }
+    }
+    for (int t = 0; t < n; t++) yx[t] = ap.y[t] - h.xbeta[t];
+    g.n = n;
+    g.Z = h.Z.data(); g.Zs = h.Ztv ? m : 0;
+    g.T = h.T.data(); g.Ts = h.Ttv ? m * m : 0;
+    g.RR = RR.data(); g.Rs = h.Rtv ? m * m : 0;
+    g.D = h.D.data(); g.Ds = h.Dtv ? 1 : 0;
+    g.C = h.C.data(); g.Cs = h.Ctv ? m : 0;
+    g.y = yx.data();
+    g.H = ap.H.data(); g.Hs = 1;
+    g.a1 = h.a1.data(); g.P1 = h.P1.data();
+  }
+};
+bool lg_fast_mean(const HostModel& h, const Approx& ap, std::vector<Mat>* atp) {
+  if (!LgHostModel::applies(h)) return false;
+  const int n = h.n, m = h.m;
+  LgHostModel lm(h, ap);
+  std::vector<double> at((size_t)m * (n + 1)), rts((size_t)n * m), K((size_t)n * m), v(n), Fs(n);
+  lg_smoother_mean(m, lm.g, at.data(), rts.data(), K.data(), v.data(), Fs.data());
+  atp->assign(n + 1, Mat(m, 1));
+  for (int t = 0; t <= n; t++) for (int i = 0; i < m; i++) (*atp)[t](i, 0) = at[i + (size_t)m * t];
+  return true;
+}
+// Returns false when it does not apply; *ok then is untouched.
+bool lg_fast_path(const HostModel& h, const Approx& ap, std::vector<double>* alphahat, std::vector<double>* Vt,
+                  std::vector<double>* Ct, bool* ok) {
+  if (!LgHostModel::applies(h)) return false;
+  const int n = h.n, m = h.m;
+  LgHostModel lm(h, ap);
+  std::vector<double> K((size_t)n * m), v(n), Fs(n);
+  alphahat->assign((size_t)m * (n + 1), 0.0);
+  Vt->assign((size_t)m * m * (n + 1), 0.0);
+  Ct->assign((size_t)m * m * (n + 1), 0.0);
+  *ok = lg_smoother_run(m, lm.g, alphahat->data(), Vt->data(), Ct->data(), K.data(), v.data(), Fs.data());
+  return true;
 }
 
 // src/model_ssm_ung.cpp:302-342, src/model_ssm_mng.cpp:269-315
@@ -535,6 +596,10 @@ bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out) {
   }
   out->approx_y = ap.y;
   out->approx_H = ap.H;
+  {
+    bool fok = true;
+    if (ok && lg_fast_path(h, ap, &out->alphahat, &out->Vt, &out->Ct, &fok)) return fok;
+  }
   std::vector<Mat> at, Vt, Ct;
   ok = ok && smoother_ccov(S, ap, &at, &Vt, &Ct);  // :533
   out->alphahat.assign((size_t)m * (n + 1), 0.0);
@@ -553,6 +618,62 @@ bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out) {
   return ok;
 }
 
+namespace {
+void lg_pack(const HostModel& h, const Approx& ap, LgPacked* lg) {
+  const LgHostModel lm(h, ap);
+  const int n = h.n, m = h.m;
+  lg->n = n; lg->m = m;
+  lg->Zs = lm.g.Zs; lg->Ts = lm.g.Ts; lg->Rs = lm.g.Rs; lg->Ds = lm.g.Ds; lg->Cs = lm.g.Cs; lg->Hs = 1;
+  const size_t nZ = (size_t)(lg->Zs ? n : 1) * m, nT = (size_t)(lg->Ts ? n : 1) * m * m, nR = (size_t)(lg->Rs ? n : 1) * m * m;
+  const size_t nD = lg->Ds ? n : 1, nC = (size_t)(lg->Cs ? n : 1) * m;
+  size_t o = 0;
+  lg->oZ = o; o += nZ; lg->oT = o; o += nT; lg->oR = o; o += nR; lg->oD = o; o += nD; lg->oC = o; o += nC;
+  lg->oy = o; o += n; lg->oH = o; o += n; lg->oa = o; o += m; lg->oP = o; o += (size_t)m * m;
+  lg->buf.resize(o);
+  double* b = lg->buf.data();
+  std::memcpy(b + lg->oZ, lm.g.Z, nZ * sizeof(double));
+  std::memcpy(b + lg->oT, lm.g.T, nT * sizeof(double));
+  std::memcpy(b + lg->oR, lm.g.RR, nR * sizeof(double));
+  std::memcpy(b + lg->oD, lm.g.D, nD * sizeof(double));
+  std::memcpy(b + lg->oC, lm.g.C, nC * sizeof(double));
+  std::memcpy(b + lg->oy, lm.g.y, (size_t)n * sizeof(double));
+  std::memcpy(b + lg->oH, lm.g.H, (size_t)n * sizeof(double));
+  std::memcpy(b + lg->oa, lm.g.a1, (size_t)m * sizeof(double));
+  std::memcpy(b + lg->oP, lm.g.P1, (size_t)m * m * sizeof(double));
+}
+}  // namespace
+
+bool psi_setup_begin(const HostModel& h, const double* is_mode, PsiSetup* out, LgPacked* lg) {
+  if (!is_mode || !LgHostModel::applies(h)) return false;
+  const int n = h.n, m = h.m, p = h.p;
+  Approx ap;
+  ap.y.assign((size_t)p * n, 0.0);
+  ap.H.assign((size_t)p * n, 0.0);
+  out->mode.assign(is_mode, is_mode + (size_t)p * n);  // approximate_for_is: src/model_ssm_ung.cpp:143-161
+  laplace_iter(h, out->mode, &ap);
+  update_scales(h, ap, out->mode, &out->scales);
+  out->approx_loglik = 0.0;
+  out->iterations = 0;
+  out->approx_y = ap.y;
+  out->approx_H = ap.H;
+  out->alphahat.assign((size_t)m * (n + 1), 0.0);
+  out->Vt.assign((size_t)m * m * (n + 1), 0.0);
+  out->Ct.assign((size_t)m * m * (n + 1), 0.0);
+  lg_pack(h, ap, lg);
+  return true;
+}
+
+bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct) {
+  const double* b = lg.buf.data();
+  LgModel g;
+  g.n = lg.n;
+  g.Z = b + lg.oZ; g.Zs = lg.Zs; g.T = b + lg.oT; g.Ts = lg.Ts; g.RR = b + lg.oR; g.Rs = lg.Rs;
+  g.D = b + lg.oD; g.Ds = lg.Ds; g.C = b + lg.oC; g.Cs = lg.Cs; g.y = b + lg.oy; g.H = b + lg.oH; g.Hs = lg.Hs;
+  g.a1 = b + lg.oa; g.P1 = b + lg.oP;
+  std::vector<double> K((size_t)lg.n * lg.m), v(lg.n), Fs(lg.n);
+  return lg_smoother_run(lg.m, g, alphahat, Vt, Ct, K.data(), v.data(), Fs.data());
+}
+
 bool gaussian_smoothing_setup(const HostModel& h, PsiSetup* out) {
   if (!h.gaussian()) return false;
   const int n = h.n, m = h.m;
@@ -561,11 +682,15 @@ bool gaussian_smoothing_setup(const HostModel& h, PsiSetup* out) {
   ap.y = h.y;
   ap.H.resize(n);
   for (int t = 0; t < n; t++) ap.H[t] = h.H[t * h.Htv];
+  out->scales.assign(n, 0.0);
+  out->approx_y = ap.y; out->approx_H = ap.H; out->mode.assign(n, 0.0);
+  {
+    bool fok = true;
+    if (lg_fast_path(h, ap, &out->alphahat, &out->Vt, &out->Ct, &fok)) return fok;
+  }
   std::vector<Mat> at, Vt, Ct;
   if (!smoother_ccov(S, ap, &at, &Vt, &Ct)) return false;
   conditional_cov(&Vt, &Ct);
-  out->scales.assign(n, 0.0);
-  out->approx_y = ap.y; out->approx_H = ap.H; out->mode.assign(n, 0.0);
   out->alphahat.assign((size_t)m * (n + 1), 0.0);
   out->Vt.assign((size_t)m * m * (n + 1), 0.0);
   out->Ct.assign((size_t)m * m * (n + 1), 0.0);
@@ -908,6 +1033,10 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
   }
   fn_gaussian_model(f, *su, &g);
   ap.H.assign(n, su->H);
+  {
+    bool fok = true;
+    if (lg_fast_path(g, ap, &su->alphahat, &su->Vt, &su->Ct, &fok)) { su->ok = fok; return fok; }
+  }
   const Sys S(g);
   std::vector<Mat> at, Vt, Ct;
   if (!smoother_ccov(S, ap, &at, &Vt, &Ct)) { su->ok = false; return false; }
@@ -917,6 +1046,23 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
     for (int i = 0; i < m; i++) su->alphahat[i + (size_t)m * t] = at[t](i, 0);
     for (int q = 0; q < mm; q++) { su->Vt[q + (size_t)mm * t] = Vt[t].a[q]; su->Ct[q + (size_t)mm * t] = Ct[t].a[q]; }
   }
+  return true;
+}
+
+bool fn_psi_setup_begin(const FnModel& f, const double* is_mode, FnSetup* su, LgPacked* lg) {
+  if (!is_mode || std::getenv("BSSM_AMD_GENERIC_SETUP")) return false;
+  const int n = f.n, m = f.m, mm = m * m;
+  su->Z.assign((size_t)m * n, 0.0); su->T.assign((size_t)mm * n, 0.0); su->D.assign(n, 0.0); su->C.assign((size_t)m * n, 0.0);
+  su->mode.assign(is_mode, is_mode + (size_t)m * n); su->scales.assign(n, 0.0);
+  su->alphahat.assign((size_t)m * (n + 1), 0.0); su->Vt.assign((size_t)mm * (n + 1), 0.0); su->Ct.assign((size_t)mm * (n + 1), 0.0);
+  su->approx_loglik = 0; su->iters = 0; su->ok = true;
+  fn_linearise(f, su->mode.data(), su->mode.data(), su);  // approximate_for_is (:146-176): scales stay 0
+  HostModel g;
+  fn_gaussian_model(f, *su, &g);
+  Approx ap;
+  ap.y = f.y;
+  ap.H.assign(n, su->H);
+  lg_pack(g, ap, lg);
   return true;
 }
 

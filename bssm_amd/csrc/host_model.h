@@ -45,6 +45,24 @@ bool psi_setup(const HostModel& hm, const double* is_mode, PsiSetup* out);
 // exact smoothing factors of a linear-Gaussian (ssm_ulg family) model for gaussian_psi_smoother:
 // smoother_ccov + conditional_cov on the model itself (src/model_ssm_ulg.cpp:646-652)
 bool gaussian_smoothing_setup(const HostModel& hm, PsiSetup* out);
+// ---- two-phase psi set-up, so that the O(n m^3) smoother of MANY draws can run as one device batch
+// (lg_smoother.h; one GPU lane per draw).  *_begin does everything up to the smoother (approximation at the stored
+// mode, scales) and packs the approximating linear-Gaussian model; the caller runs the smoother (device batch or
+// lg_packed_run on the host) into su->alphahat / Vt / Ct; build_*_tables then proceeds as after psi_setup().
+// They return false when the fixed-size smoother does not apply (multivariate observations, m > 8): use psi_setup().
+struct LgPacked {
+  int n = 0, m = 0;
+  int Zs = 0, Ts = 0, Rs = 0, Ds = 0, Cs = 0, Hs = 0;            // strides in doubles, 0 = time-invariant
+  size_t oZ = 0, oT = 0, oR = 0, oD = 0, oC = 0, oy = 0, oH = 0, oa = 0, oP = 0;  // offsets into buf
+  std::vector<double> buf;                                        // [Z | T | R R' | D | C | y - x'beta | H | a1 | P1]
+  bool same_layout(const LgPacked& o) const {
+    return n == o.n && m == o.m && Zs == o.Zs && Ts == o.Ts && Rs == o.Rs && Ds == o.Ds && Cs == o.Cs && Hs == o.Hs && buf.size() == o.buf.size();
+  }
+};
+bool psi_setup_begin(const HostModel& hm, const double* is_mode, PsiSetup* out, LgPacked* lg);
+// host execution of the packed smoother (what the device kernel does per lane); false = non-finite result
+bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct);
+
 // log-likelihood of the Gaussian approximation only (nsim = 0 path, src/model_ssm_ung.cpp:214-234)
 double approx_loglik_only(const HostModel& hm);
 
@@ -82,6 +100,8 @@ struct FnSetup {
   bool ok = false;
 };
 bool fn_psi_setup(const FnModel& mod, const double* is_mode, int max_iter, double conv_tol, FnSetup* out);
+// two-phase variant for approximate_for_is (is_mode must be given): see psi_setup_begin
+bool fn_psi_setup_begin(const FnModel& mod, const double* is_mode, FnSetup* out, LgPacked* lg);
 // psi proposal operands (as build_psi_tables), observation rows carrying the approximating D_t / Z_t / 1/H / scales,
 // and the approximating (T_t, C_t) rows used by the transition-density ratio
 void build_fn_psi_tables(const FnModel& mod, const FnSetup& su, FilterTables* ft, std::vector<double>* amats);

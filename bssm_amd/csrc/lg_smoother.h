@@ -1,0 +1,374 @@
+// lg_smoother.h -- Kalman filter + covariance smoother + conditional factors of a univariate-observation
+// linear-Gaussian model with an M-dimensional state, written once for host and device.
+//
+// This is the O(n M^3) core of the psi-APF set-up:
+//   forward   ssm_ulg::smoother_ccov's Kalman pass        src/model_ssm_ulg.cpp:419-447 (update :122-136 in Joseph form)
+//   backward  r_t / N_t recursions, smoothed mean, variance and lag-one cross-covariance   :448-473
+//   factors   conditional_cov (use_svd = true)             src/conditional_dist.cpp:4-31
+// The operation order follows the generic host routines in host_model.cpp (kf_predict / smoother_ccov /
+// conditional_cov / sym_singular) term by term, so both give the same numbers; here everything lives in fixed-size
+// arrays, which is what makes it (a) several times faster on the host and (b) runnable as one GPU lane per theta-draw.
+#pragma once
+#include <float.h>
+#include <math.h>
+
+#ifndef __HIPCC__
+#define LG_HD
+#else
+#include <hip/hip_runtime.h>
+#define LG_HD __host__ __device__
+#endif
+
+namespace bssm {
+
+// One draw's model, as plain pointers.  "(1|n)": stride 0 = time-invariant.
+struct LgModel {
+  int n;
+  const double* Z;  int Zs;   // [(1|n)][M]      observation row
+  const double* T;  int Ts;   // [(1|n)][M*M]    column-major
+  const double* RR; int Rs;   // [(1|n)][M*M]    R R'
+  const double* D;  int Ds;   // [(1|n)]
+  const double* C;  int Cs;   // [(1|n)][M]
+  const double* y;            // [n]  observations minus x'beta, NaN = missing
+  const double* H;  int Hs;   // [(1|n)] observation sd
+  const double* a1;           // [M]
+  const double* P1;           // [M*M]
+};
+
+LG_HD inline bool lg_finite(double x) { return x == x && fabs(x) <= DBL_MAX; }
+
+template <int M>
+struct LgSmoother {
+  static constexpr int MM = M * M;
+  static constexpr double kZeroTol = 1e-12;  // src/model_ssm_ulg.h:19
+  static constexpr double kEps = DBL_EPSILON;
+
+  // C = A * B (all M x M, column-major), accumulation over the inner index in ascending order from 0
+  LG_HD static void mul(const double* A, const double* B, double* C) {
+    for (int j = 0; j < M; j++)
+      for (int i = 0; i < M; i++) {
+        double s = 0.0;
+        for (int q = 0; q < M; q++) s += A[i + M * q] * B[q + M * j];
+        C[i + M * j] = s;
+      }
+  }
+  LG_HD static void mul_bt(const double* A, const double* B, double* C) {  // A * B'
+    for (int j = 0; j < M; j++)
+      for (int i = 0; i < M; i++) {
+        double s = 0.0;
+        for (int q = 0; q < M; q++) s += A[i + M * q] * B[j + M * q];
+        C[i + M * j] = s;
+      }
+  }
+  LG_HD static void mul_at(const double* A, const double* B, double* C) {  // A' * B
+    for (int j = 0; j < M; j++)
+      for (int i = 0; i < M; i++) {
+        double s = 0.0;
+        for (int q = 0; q < M; q++) s += A[q + M * i] * B[q + M * j];
+        C[i + M * j] = s;
+      }
+  }
+  LG_HD static void symmatu(double* A) { for (int j = 0; j < M; j++) for (int i = j + 1; i < M; i++) A[i + M * j] = A[j + M * i]; }
+
+  // |eigenvalues| (descending) and vectors of a symmetric matrix by cyclic Jacobi, sign convention: the largest
+  // component of every vector is positive -- what arma::svd_econ(..., "left") yields for a PSD input up to sign
+  LG_HD static void sym_singular(const double* Ain, double* U, double* s) {
+    double A[MM], W[MM];
+    for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) A[i + M * j] = 0.5 * (Ain[i + M * j] + Ain[j + M * i]);
+    for (int q = 0; q < MM; q++) W[q] = 0.0;
+    for (int i = 0; i < M; i++) W[i + M * i] = 1.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+      double off = 0.0;
+      for (int j = 0; j < M; j++) for (int i = 0; i < j; i++) off += A[i + M * j] * A[i + M * j];
+      if (off < 1e-300) break;
+      for (int p = 0; p < M - 1; p++)
+        for (int q = p + 1; q < M; q++) {
+          const double apq = A[p + M * q];
+          if (apq == 0.0) continue;
+          const double tau = (A[q + M * q] - A[p + M * p]) / (2.0 * apq);
+          const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+          for (int r = 0; r < M; r++) { const double x = A[r + M * p], y = A[r + M * q]; A[r + M * p] = cs * x - sn * y; A[r + M * q] = sn * x + cs * y; }
+          for (int r = 0; r < M; r++) { const double x = A[p + M * r], y = A[q + M * r]; A[p + M * r] = cs * x - sn * y; A[q + M * r] = sn * x + cs * y; }
+          for (int r = 0; r < M; r++) { const double x = W[r + M * p], y = W[r + M * q]; W[r + M * p] = cs * x - sn * y; W[r + M * q] = sn * x + cs * y; }
+        }
+    }
+    double sv[M];
+    int ord[M];
+    for (int j = 0; j < M; j++) { sv[j] = fabs(A[j + M * j]); ord[j] = j; }
+    for (int a = 1; a < M; a++) {  // stable insertion sort, descending
+      const int o = ord[a];
+      int b = a - 1;
+      while (b >= 0 && sv[ord[b]] < sv[o]) { ord[b + 1] = ord[b]; b--; }
+      ord[b + 1] = o;
+    }
+    for (int j = 0; j < M; j++) {
+      s[j] = sv[ord[j]];
+      int big = 0;
+      for (int r = 1; r < M; r++) if (fabs(W[r + M * ord[j]]) > fabs(W[big + M * ord[j]])) big = r;
+      const double sg = W[big + M * ord[j]] < 0 ? -1.0 : 1.0;
+      for (int r = 0; r < M; r++) U[r + M * j] = sg * W[r + M * ord[j]];
+    }
+  }
+
+  // Outputs (and working storage): alphahat [(n+1)][M], Vt [(n+1)][M*M], Ct [(n+1)][M*M].
+  // Scratch: K [n][M], v [n], Fs [n] (0 where the update was skipped).
+  // Every array element k of the model, the outputs and the scratch lives at ptr[k * es]: es = 1 on the host; the
+  // device batch interleaves the draws (es = number of draws, lane d starts at ptr + d), so that the 64 lanes of a
+  // wave touch consecutive doubles -- per-draw contiguous arrays cost 64 cache lines per wave instruction and were
+  // 3x slower end to end.  Each step loads its operands into locals, computes as the generic host routines do, and
+  // stores the results back.
+  // Returns false when a Kalman step or a result is not finite (the filter then returns -Inf, :988-990 analogue).
+  LG_HD static void ldv(const double* p, size_t es, int cnt, double* out) { for (int q = 0; q < cnt; q++) out[q] = p[(size_t)q * es]; }
+  LG_HD static void stv(double* p, size_t es, int cnt, const double* in) { for (int q = 0; q < cnt; q++) p[(size_t)q * es] = in[q]; }
+
+  LG_HD static bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es = 1) {
+    const int n = g.n;
+    double a[M], P[MM], a1n[M], P1n[MM], Z[M], T[MM], RR[MM], Cv[M];
+    double tmp[MM], tmp2[MM], inner[MM], IKZ[MM];
+    ldv(g.a1, es, M, a); ldv(g.P1, es, MM, P);
+    stv(at, es, M, a); stv(Pt, es, MM, P);
+    // ---- forward pass (kf_predict, univariate branch, Joseph form)
+    for (int t = 0; t < n; t++) {
+      ldv(g.Z + (size_t)t * g.Zs * es, es, M, Z);
+      ldv(g.T + (size_t)t * g.Ts * es, es, MM, T);
+      ldv(g.RR + (size_t)t * g.Rs * es, es, MM, RR);
+      ldv(g.C + (size_t)t * g.Cs * es, es, M, Cv);
+      const double yt = g.y[(size_t)t * es];
+      const bool na = !lg_finite(yt);
+      const double sd = g.H[(size_t)t * g.Hs * es];
+      const double HH = na ? 1.0 : sd * sd;
+      double F = 0.0;
+      if (!na) {
+        double zp[M];
+        for (int j = 0; j < M; j++) { double s = 0.0; for (int q = 0; q < M; q++) s += Z[q] * P[q + M * j]; zp[j] = s; }
+        for (int q = 0; q < M; q++) F += zp[q] * Z[q];
+      }
+      F += HH;
+      const bool upd = !na && F > kZeroTol;
+      Fs[(size_t)t * es] = upd ? F : 0.0;
+      double Kt[M];
+      if (!upd) {
+        v[(size_t)t * es] = 0.0;
+        for (int i = 0; i < M; i++) Kt[i] = 0.0;
+        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += T[i + M * q] * a[q]; a1n[i] = Cv[i] + s; }
+        mul(T, P, tmp); mul_bt(tmp, T, P1n);
+        for (int q = 0; q < MM; q++) P1n[q] = P1n[q] + RR[q];
+        symmatu(P1n);
+      } else {
+        double za = 0.0;
+        for (int c = 0; c < M; c++) za += Z[c] * a[c];
+        const double vt = yt - g.D[(size_t)t * g.Ds * es] - za;
+        v[(size_t)t * es] = vt;
+        double au[M];
+        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += P[i + M * q] * Z[q]; Kt[i] = s / F; }
+        for (int i = 0; i < M; i++) au[i] = a[i] + Kt[i] * vt;
+        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += T[i + M * q] * au[q]; a1n[i] = Cv[i] + s; }
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) IKZ[i + M * j] = (i == j ? 1.0 : 0.0) - Kt[i] * Z[j];
+        mul(IKZ, P, tmp); mul_bt(tmp, IKZ, inner);
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) inner[i + M * j] = inner[i + M * j] + Kt[i] * HH * Kt[j];
+        mul(T, inner, tmp); mul_bt(tmp, T, P1n);
+        for (int q = 0; q < MM; q++) P1n[q] = P1n[q] + RR[q];
+        symmatu(P1n);
+      }
+      stv(K + (size_t)t * M * es, es, M, Kt);
+      for (int i = 0; i < M; i++) if (!lg_finite(a1n[i])) return false;
+      for (int q = 0; q < MM; q++) if (!lg_finite(P1n[q])) return false;
+      stv(at + (size_t)(t + 1) * M * es, es, M, a1n);
+      stv(Pt + (size_t)(t + 1) * MM * es, es, MM, P1n);
+      stv(cc + (size_t)t * MM * es, es, MM, P1n);
+      for (int i = 0; i < M; i++) a[i] = a1n[i];
+      for (int q = 0; q < MM; q++) P[q] = P1n[q];
+    }
+    // ---- backward pass (smoother_ccov)
+    double rt[M], Nt[MM], L[MM], N2[MM], ct[MM], Kt[M];
+    for (int i = 0; i < M; i++) rt[i] = 0.0;
+    for (int q = 0; q < MM; q++) Nt[q] = 0.0;
+    for (int t = n - 1; t >= 0; t--) {
+      ldv(g.Z + (size_t)t * g.Zs * es, es, M, Z);
+      ldv(g.T + (size_t)t * g.Ts * es, es, MM, T);
+      ldv(at + (size_t)t * M * es, es, M, a);
+      ldv(Pt + (size_t)t * MM * es, es, MM, P);
+      ldv(cc + (size_t)t * MM * es, es, MM, ct);
+      const double F = Fs[(size_t)t * es];
+      const double* Lm = T;
+      if (F > 0.0) {
+        ldv(K + (size_t)t * M * es, es, M, Kt);
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) IKZ[i + M * j] = (i == j ? 1.0 : 0.0) - Kt[i] * Z[j];
+        mul(T, IKZ, L);
+        Lm = L;
+      }
+      // cc[t] = Pt[t] L' (I - Nt cc[t])
+      mul(Nt, ct, tmp);
+      for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) tmp[i + M * j] = (i == j ? 1.0 : 0.0) - tmp[i + M * j];
+      mul_bt(P, Lm, tmp2);
+      mul(tmp2, tmp, ct);
+      double rn[M];
+      for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += Lm[q + M * i] * rt[q]; rn[i] = s; }
+      mul_at(Lm, Nt, tmp); mul(tmp, Lm, N2);
+      if (F > 0.0) {
+        const double vt = v[(size_t)t * es];
+        for (int i = 0; i < M; i++) rn[i] = Z[i] / F * vt + rn[i];
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) N2[i + M * j] = Z[i] * Z[j] / F + N2[i + M * j];
+      }
+      for (int i = 0; i < M; i++) rt[i] = rn[i];
+      for (int q = 0; q < MM; q++) Nt[q] = N2[q];
+      symmatu(Nt);
+      for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += P[i + M * q] * rt[q]; a[i] = a[i] + s; }
+      mul(P, Nt, tmp); mul(tmp, P, tmp2);
+      symmatu(tmp2);
+      for (int q = 0; q < MM; q++) P[q] = P[q] - tmp2[q];
+      for (int q = 0; q < MM; q++) if (!lg_finite(P[q]) || !lg_finite(ct[q])) return false;
+      stv(cc + (size_t)t * MM * es, es, MM, ct);
+      stv(at + (size_t)t * M * es, es, M, a);
+      stv(Pt + (size_t)t * MM * es, es, MM, P);
+    }
+    for (int q = 0; q < MM; q++) cc[((size_t)n * MM + q) * es] = 0.0;
+    // ---- conditional_cov: Vt <- U sqrt(s) of Var(alpha_t | alpha_{t-1}, y), Ct <- Cov' pinv(V_{t-1})
+    double U[MM], s[M], W[MM], Vp[MM], Vc[MM], Cp[MM];
+    for (int t = n; t > 0; t--) {
+      ldv(Pt + (size_t)(t - 1) * MM * es, es, MM, Vp);
+      ldv(Pt + (size_t)t * MM * es, es, MM, Vc);
+      ldv(cc + (size_t)(t - 1) * MM * es, es, MM, Cp);
+      sym_singular(Vp, U, s);
+      for (int q = 0; q < MM; q++) W[q] = 0.0;
+      for (int c = 0; c < M; c++) {
+        if (!(s[c] > kEps * M * s[0])) continue;
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) W[i + M * j] += U[i + M * c] * U[j + M * c] / s[c];
+      }
+      mul_at(Cp, W, tmp);       // tr(Ct[t-1]) * W
+      mul(tmp, Cp, tmp2);
+      for (int q = 0; q < MM; q++) Vc[q] = Vc[q] - tmp2[q];
+      stv(cc + (size_t)t * MM * es, es, MM, tmp);
+      sym_singular(Vc, U, s);
+      for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vc[i + M * c] = U[i + M * c] * sqrt(s[c]);
+      stv(Pt + (size_t)t * MM * es, es, MM, Vc);
+    }
+    ldv(Pt, es, MM, Vp);
+    sym_singular(Vp, U, s);
+    for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vp[i + M * c] = U[i + M * c] * sqrt(s[c]);
+    stv(Pt, es, MM, Vp);
+    bool ok = true;
+    for (int t = 0; t <= n; t++) {
+      for (int i = 0; i < M; i++) ok = ok && lg_finite(at[((size_t)t * M + i) * es]);
+      for (int q = 0; q < MM; q++) ok = ok && lg_finite(Pt[((size_t)t * MM + q) * es]) && lg_finite(cc[((size_t)t * MM + q) * es]);
+    }
+    return ok;
+  }
+
+  // Smoothed state means only (ssm_ulg::fast_smoother, src/model_ssm_ulg.cpp:252-305): the inner step of the mode
+  // search.  at [(n+1)][M] out; scratch rts [n][M], K [n][M], v [n], Fs [n].
+  LG_HD static bool run_mean(const LgModel& g, double* at, double* rts, double* K, double* v, double* Fs) {
+    const int n = g.n;
+    double P[MM], Pn[MM], tmp[MM], inner[MM], IKZ[MM], L[MM];
+    for (int i = 0; i < M; i++) at[i] = g.a1[i];
+    for (int q = 0; q < MM; q++) P[q] = g.P1[q];
+    for (int t = 0; t < n; t++) {
+      const double* Z = g.Z + (size_t)t * g.Zs;
+      const double* T = g.T + (size_t)t * g.Ts;
+      const double* RR = g.RR + (size_t)t * g.Rs;
+      const double* Cv = g.C + (size_t)t * g.Cs;
+      const double* a = at + (size_t)t * M;
+      double* a1n = at + (size_t)(t + 1) * M;
+      const double yt = g.y[t];
+      const bool na = !lg_finite(yt);
+      const double sd = g.H[(size_t)t * g.Hs];
+      const double HH = na ? 1.0 : sd * sd;
+      double F = 0.0;
+      if (!na) {
+        double zp[M];
+        for (int j = 0; j < M; j++) { double s = 0.0; for (int q = 0; q < M; q++) s += Z[q] * P[q + M * j]; zp[j] = s; }
+        for (int q = 0; q < M; q++) F += zp[q] * Z[q];
+      }
+      F += HH;
+      const bool upd = !na && F > kZeroTol;
+      Fs[t] = upd ? F : 0.0;
+      if (!upd) {
+        v[t] = 0.0;
+        for (int i = 0; i < M; i++) K[(size_t)t * M + i] = 0.0;
+        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += T[i + M * q] * a[q]; a1n[i] = Cv[i] + s; }
+        mul(T, P, tmp); mul_bt(tmp, T, Pn);
+      } else {
+        double za = 0.0;
+        for (int c = 0; c < M; c++) za += Z[c] * a[c];
+        const double vt = yt - g.D[(size_t)t * g.Ds] - za;
+        v[t] = vt;
+        double Kt[M], au[M];
+        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += P[i + M * q] * Z[q]; Kt[i] = s / F; K[(size_t)t * M + i] = Kt[i]; }
+        for (int i = 0; i < M; i++) au[i] = a[i] + Kt[i] * vt;
+        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += T[i + M * q] * au[q]; a1n[i] = Cv[i] + s; }
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) IKZ[i + M * j] = (i == j ? 1.0 : 0.0) - Kt[i] * Z[j];
+        mul(IKZ, P, tmp); mul_bt(tmp, IKZ, inner);
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) inner[i + M * j] = inner[i + M * j] + Kt[i] * HH * Kt[j];
+        mul(T, inner, tmp); mul_bt(tmp, T, Pn);
+      }
+      for (int q = 0; q < MM; q++) P[q] = Pn[q] + RR[q];
+      symmatu(P);
+    }
+    double rprev[M];
+    for (int i = 0; i < M; i++) { rprev[i] = 0.0; if (n > 0) rts[(size_t)(n - 1) * M + i] = 0.0; }
+    for (int t = n - 1; t >= 0; t--) {
+      const double* Z = g.Z + (size_t)t * g.Zs;
+      const double* T = g.T + (size_t)t * g.Ts;
+      const double* rt = rts + (size_t)t * M;
+      const double F = Fs[t];
+      const double* Lm = T;
+      if (F > 0.0) {
+        const double* Kt = K + (size_t)t * M;
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) IKZ[i + M * j] = (i == j ? 1.0 : 0.0) - Kt[i] * Z[j];
+        mul(T, IKZ, L);
+        Lm = L;
+      }
+      double r0[M];
+      for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += Lm[q + M * i] * rt[q]; r0[i] = s; }
+      if (F > 0.0) for (int i = 0; i < M; i++) r0[i] = Z[i] / F * v[t] + r0[i];
+      for (int i = 0; i < M; i++) { if (t > 0) rts[(size_t)(t - 1) * M + i] = r0[i]; else rprev[i] = r0[i]; }
+    }
+    for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += g.P1[i + M * q] * rprev[q]; at[i] = g.a1[i] + s; }
+    for (int t = 0; t < n - 1; t++) {
+      const double* T = g.T + (size_t)t * g.Ts;
+      const double* RR = g.RR + (size_t)t * g.Rs;
+      const double* Cv = g.C + (size_t)t * g.Cs;
+      const double* a = at + (size_t)t * M;
+      const double* rt = rts + (size_t)t * M;
+      double* an = at + (size_t)(t + 1) * M;
+      for (int i = 0; i < M; i++) {
+        double s = 0.0, q2 = 0.0;
+        for (int q = 0; q < M; q++) s += T[i + M * q] * a[q];
+        for (int q = 0; q < M; q++) q2 += RR[i + M * q] * rt[q];
+        an[i] = Cv[i] + s + q2;
+      }
+    }
+    return true;
+  }
+};
+
+// run-time dispatch over the state dimension (1..8)
+LG_HD inline bool lg_smoother_run(int m, const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs) {
+  switch (m) {
+    case 1: return LgSmoother<1>::run(g, at, Pt, cc, K, v, Fs);
+    case 2: return LgSmoother<2>::run(g, at, Pt, cc, K, v, Fs);
+    case 3: return LgSmoother<3>::run(g, at, Pt, cc, K, v, Fs);
+    case 4: return LgSmoother<4>::run(g, at, Pt, cc, K, v, Fs);
+    case 5: return LgSmoother<5>::run(g, at, Pt, cc, K, v, Fs);
+    case 6: return LgSmoother<6>::run(g, at, Pt, cc, K, v, Fs);
+    case 7: return LgSmoother<7>::run(g, at, Pt, cc, K, v, Fs);
+    case 8: return LgSmoother<8>::run(g, at, Pt, cc, K, v, Fs);
+  }
+  return false;
+}
+LG_HD inline bool lg_smoother_mean(int m, const LgModel& g, double* at, double* rts, double* K, double* v, double* Fs) {
+  switch (m) {
+    case 1: return LgSmoother<1>::run_mean(g, at, rts, K, v, Fs);
+    case 2: return LgSmoother<2>::run_mean(g, at, rts, K, v, Fs);
+    case 3: return LgSmoother<3>::run_mean(g, at, rts, K, v, Fs);
+    case 4: return LgSmoother<4>::run_mean(g, at, rts, K, v, Fs);
+    case 5: return LgSmoother<5>::run_mean(g, at, rts, K, v, Fs);
+    case 6: return LgSmoother<6>::run_mean(g, at, rts, K, v, Fs);
+    case 7: return LgSmoother<7>::run_mean(g, at, rts, K, v, Fs);
+    case 8: return LgSmoother<8>::run_mean(g, at, rts, K, v, Fs);
+  }
+  return false;
+}
+
+}  // namespace bssm

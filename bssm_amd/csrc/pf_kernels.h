@@ -92,6 +92,21 @@ hipError_t launch_sim_smoother(const double* mats, const double* init, double* h
                                hipStream_t stream);
 // stratified_sample (src/stratified_sample.cpp:9-28): p [len] is overwritten by its cumulative sum, out [N]
 hipError_t launch_stratified_sample(double* p, const double* r, uint32_t* out, int len, int N, hipStream_t stream);
+// psi-APF set-up smoother of F draws as one batch, one lane per draw (lg_smoother.h).  Every array is
+// DRAW-INTERLEAVED: element k of draw d at base[k * F + d] (a wave's 64 lanes then touch consecutive doubles).
+// `in` holds the F packed models (LgPacked element order, in_stride elements per draw); outputs alphahat [(n+1) m][F],
+// Vt / Ct [(n+1) m m][F]; scratch K [n m][F], v / Fs [n][F]; ok [F] = 1 when every result is finite.
+// launch_transpose converts between per-draw contiguous [rows][cols] and interleaved [cols][rows].
+struct LgBatchDev {
+  int F, n, m;
+  int Zs, Ts, Rs, Ds, Cs, Hs;
+  size_t oZ, oT, oR, oD, oC, oy, oH, oa, oP, in_stride;
+  const double* in;
+  double *at, *Pt, *cc, *K, *v, *Fs;
+  int* ok;
+};
+hipError_t launch_lg_setup(const LgBatchDev& b, hipStream_t stream);
+hipError_t launch_transpose(const double* in, double* out, int rows, int cols, hipStream_t stream);
 hipError_t launch_calib_copy(const double* in, double* out, size_t n, hipStream_t stream);
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream);
 

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "lg_smoother.h"
 #include "pf_filter_impl.h"
 
 namespace bssm {
@@ -149,6 +150,60 @@ __global__ void debug_math_kernel(int fn, const double* __restrict__ in, double*
 }
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream) {
   hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, in, out, n);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- psi set-up smoother, batched over theta-draws
+// One lane per draw runs the whole Kalman filter / covariance smoother / conditional-factor recursion of its draw
+// (sequential in time, O(n m^3)); draws are independent, so a post-correction chunk is one launch.  The same
+// template runs on the host (host_model.cpp), which is what the device result is tested against.
+template <int M>
+__global__ void __launch_bounds__(64) lg_setup_kernel(const LgBatchDev b) {
+  const int d = blockIdx.x * 64 + threadIdx.x;
+  if (d >= b.F) return;
+  // draw-interleaved arrays: element k of draw d lives at base[k * F + d]
+  const size_t F = (size_t)b.F;
+  const double* in = b.in + d;
+  LgModel g;
+  g.n = b.n;
+  g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
+  g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = in + b.oy * F; g.H = in + b.oH * F; g.Hs = b.Hs;
+  g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
+  const bool ok = LgSmoother<M>::run(g, b.at + d, b.Pt + d, b.cc + d, b.K + d, b.v + d, b.Fs + d, F);
+  b.ok[d] = ok ? 1 : 0;
+}
+hipError_t launch_lg_setup(const LgBatchDev& b, hipStream_t stream) {
+  const dim3 grid((b.F + 63) / 64), block(64);
+  switch (b.m) {  // one instantiation per state dimension keeps the small cases in registers
+    case 1: hipLaunchKernelGGL(lg_setup_kernel<1>, grid, block, 0, stream, b); break;
+    case 2: hipLaunchKernelGGL(lg_setup_kernel<2>, grid, block, 0, stream, b); break;
+    case 3: hipLaunchKernelGGL(lg_setup_kernel<3>, grid, block, 0, stream, b); break;
+    case 4: hipLaunchKernelGGL(lg_setup_kernel<4>, grid, block, 0, stream, b); break;
+    case 5: hipLaunchKernelGGL(lg_setup_kernel<5>, grid, block, 0, stream, b); break;
+    case 6: hipLaunchKernelGGL(lg_setup_kernel<6>, grid, block, 0, stream, b); break;
+    case 7: hipLaunchKernelGGL(lg_setup_kernel<7>, grid, block, 0, stream, b); break;
+    case 8: hipLaunchKernelGGL(lg_setup_kernel<8>, grid, block, 0, stream, b); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+// out[c * rows + r] = in[r * cols + c], 32 x 32 tiles through LDS (both sides coalesced): per-draw contiguous <->
+// draw-interleaved layouts of the smoother batch
+__global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ in, double* __restrict__ out, int rows, int cols) {
+  __shared__ double tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    if (r < rows && c < cols) tile[k][tx] = in[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][k];
+  }
+}
+hipError_t launch_transpose(const double* in, double* out, int rows, int cols, hipStream_t stream) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, stream, in, out, rows, cols);
   return hipGetLastError();
 }
 

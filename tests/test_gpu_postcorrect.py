@@ -72,3 +72,40 @@ def test_suggest_N(oracle):
     mdl = M.BssmModel(model.classes, **{**model, **{k: arr[k] for k in ("T", "R", "P1", "a1", "C")}})
     got = logLik_batch(mdl, 5, 40, method="psi", seed=1, stream0=0)
     assert abs(got[3] - ll) <= 1e-9 * model.n
+
+
+@pytest.mark.parametrize("kind", ["bsm_ng", "nlg_growth"])
+def test_device_psi_setup_equals_host_setup(monkeypatch, kind):
+    """The batched device smoother of the psi set-up (lg_setup_kernel, one lane per draw) and the
+    host smoother are the same template (lg_smoother.h): identical ancestors, log-likelihoods to 1e-9 n."""
+    if kind == "bsm_ng":
+        from oracle import oracle as O
+        model, theta, counts = _job(ns=40, n=60)
+        arrs = PC.expand_models(model, theta)
+        modes = np.stack([O.psi_setup(a)["mode"] for a in arrs], axis=1)
+        n = model.n
+    else:
+        from bssm_amd import filters as F
+        rng = np.random.default_rng(12)
+        n, K, dT = 80, 500.0, 0.1
+        r = np.zeros(n); p = np.zeros(n); p[0] = 50.0
+        for t in range(1, n):
+            r[t] = r[t - 1] + rng.normal(0, 0.05)
+            rr = np.exp(r[t - 1]) / (1 + np.exp(r[t - 1]))
+            p[t] = K * p[t - 1] * np.exp(rr * dT) / (K + p[t - 1] * (np.exp(rr * dT) - 1)) + rng.normal(0, 1)
+        y = p + rng.normal(0, 1, n); y[[7, 8]] = np.nan
+        th0 = np.array([0.0, np.log(0.05), 0.0])
+        model = M.ssm_nlg(y, "nlg_growth", theta=th0, known_params=[dT, K, 0.0, 50.0, 1.0, 100.0])
+        theta = th0 + rng.normal(0, 0.05, (40, 3))
+        counts = rng.integers(1, 4, 40).astype(np.uint32)
+        mode = F.psi_setup(model)["mode"]
+        modes = np.repeat(mode.reshape(-1, 1, order="F"), 40, axis=1).reshape(2, n, 40, order="F")
+    res = {}
+    for dev in ("1", "0"):
+        monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+        mo = dict(theta=theta, counts=counts, modes=modes, output_type=2)
+        res[dev] = PC.post_correct(model, mo, 64, threads=3, is_type="is2", seed=4)
+    assert np.all(np.isfinite(res["1"]["loglik"]))
+    assert np.allclose(res["1"]["loglik"], res["0"]["loglik"], rtol=0, atol=1e-9 * n)
+    assert np.allclose(res["1"]["alphahat"], res["0"]["alphahat"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(res["1"]["Vt"], res["0"]["Vt"], rtol=1e-7, atol=1e-10)
