@@ -317,7 +317,7 @@ int run_single_filter(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
     bssm::build_psi_tables(hm, su, MP, &tabs[0]);
     base_ll = su.approx_loglik;  // src/model_ssm_ung.cpp:561
   } else {
-    bssm::build_bsf_tables(hm, MP, bssm::pad_dim(hm.k), &tabs[0]);
+    bssm::build_bsf_tables(hm, MP, bssm::pad_noise_dim(MP, hm.k), &tabs[0]);
     base_ll = bssm::const_term(hm);  // src/model_ssm_ung.cpp:690-710
   }
   return run_tables(tabs, nullptr, n, m, hm.k, hm.p, N, psi, smoother, seed, base_ll, out);
@@ -677,7 +677,7 @@ int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, ui
     bssm::build_psi_tables(hm, su, MP, &tabs[0]);
     base = su.approx_loglik;
   } else {
-    bssm::build_bsf_tables(hm, MP, bssm::pad_dim(hm.k), &tabs[0]);
+    bssm::build_bsf_tables(hm, MP, bssm::pad_noise_dim(MP, hm.k), &tabs[0]);
     base = bssm::const_term(hm);
   }
   // replicas share one table: stride 0 between filters
@@ -1116,7 +1116,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   // with the device work of the previous chunk of draws
   std::vector<bssm::HostModel> hms(cnt);
   const int n = job->models[0].n, m = job->models[0].m, k = job->models[0].k, p0 = job->models[0].p > 1 ? job->models[0].p : 1;
-  const int MP = bssm::pad_dim(m), KP = psi ? MP : bssm::pad_dim(k);
+  const int MP = bssm::pad_dim(m), KP = psi ? MP : bssm::pad_noise_dim(MP, k);
   IsCore J;
   J.n = n; J.m = m; J.k = k; J.pp = p0; J.psi = psi;
   J.first = job->first; J.is_type = job->is_type; J.output_type = job->output_type; J.nsim = job->nsim; J.seed = job->seed;
@@ -1348,7 +1348,7 @@ bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int3
       bssm::build_psi_tables(hm, su, MP, &ft);
       base = su.approx_loglik;
     } else {
-      bssm::build_bsf_tables(hm, MP, bssm::pad_dim(k), &ft);
+      bssm::build_bsf_tables(hm, MP, bssm::pad_noise_dim(MP, k), &ft);
       base = bssm::const_term(hm);
     }
     for (int r = 0; r < n_rep; r++) { tabs.push_back(ft); consts.push_back(base); }

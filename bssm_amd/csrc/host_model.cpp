@@ -486,6 +486,14 @@ double approx_const_term(const HostModel& h, const Approx& ap) {  // src/model_s
 
 // ------------------------------------------------------------------ public pieces
 int pad_dim(int d) { int p = 1; while (p < d) p <<= 1; return p; }
+// padded noise dimension the kernels are instantiated for (pf_inst_mp*.hip): every power of two up to MP for MP <= 4,
+// {2, 4, 8} for MP = 8 and {4, 16} for MP = 16 -- the smallest of those that holds k
+int pad_noise_dim(int MP, int k) {
+  int kp = pad_dim(k);
+  if (MP == 8 && kp < 2) kp = 2;
+  if (MP == 16) kp = kp <= 4 ? 4 : 16;
+  return kp > MP ? MP : kp;
+}
 
 std::string ingest_model(const bssm_ung_model* s, bool need_mode, HostModel* o) {
   if (!s) return "model is NULL";

@@ -67,6 +67,7 @@ bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct)
 double approx_loglik_only(const HostModel& hm);
 
 int pad_dim(int d);  // 1,2,4,8,16
+int pad_noise_dim(int MP, int k);  // padded noise dimension with a kernel instantiation for this MP
 
 // Padded tables for ONE filter, laid out as pf_kernels.h describes.
 struct FilterTables {

@@ -1,0 +1,17 @@
+"""Latency of ONE log-likelihood call at the sizes of the reference's pseudo-marginal MCMC benchmark
+(benchmarks/replications.Rmd:27-62: bsm_ng Poisson, m=2, T=100; bsf N=200, psi N=10): this is the inner call of
+run_mcmc(mcmc_type="pm"), 6.5 ms per iteration in the reference's published run (replications.html:388)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from bssm_amd import filters as F, models as M
+y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "poisson_series.txt"))[:100]
+model = M.bsm_ng(y, sd_level=M.halfnormal(0.1, 1), sd_slope=M.halfnormal(0.01, 0.1), distribution="poisson", P1=np.diag([10.0, 0.1]))
+for method, N in (("bsf", 200), ("psi", 10), ("psi", 100), ("bsf", 1000)):
+    F.logLik(model, N, method=method, seed=1)
+    t0 = time.perf_counter()
+    for s in range(200):
+        ll = F.logLik(model, N, method=method, seed=s)
+    e = (time.perf_counter() - t0) / 200
+    print(f"logLik {method} N={N} T=100 m=2: {e*1e3:.3f} ms per call ({ll:.3f})", flush=True)

@@ -1,0 +1,78 @@
+"""Edge cases of the filter entry points against the oracle: smallest and largest sizes the reference accepts
+(R/check_arguments.R:407-418: particles <= 1e5), one time point, one particle, a 16-dimensional state, a series
+with no observation at all."""
+import numpy as np
+import pytest
+
+from bssm_amd import filters as F
+from bssm_amd import models as M
+from models_zoo import negbin_ar1
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / (1e-300 + np.maximum(1.0, np.abs(b))))
+
+
+@pytest.mark.parametrize("n,N", [(1, 1), (1, 7), (2, 1), (3, 64), (5, 65)])
+def test_tiny_sizes(oracle, n, N):
+    rng = np.random.default_rng(n * 100 + N)
+    y = rng.poisson(3.0, n).astype(float)
+    model = M.bsm_ng(y, sd_level=0.3, sd_slope=0.05, distribution="poisson", P1=np.diag([1.0, 0.1]), a1=[1.0, 0.0])
+    arr = M.model_arrays(model)
+    out = F.bootstrap_filter(model, N, seed=3, return_indices=True)
+    ref = oracle.bsf_filter(arr, N, seed=3)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    sm = F.particle_smoother(model, N, method="psi", seed=3)
+    rs = oracle.psi_filter(arr, N, seed=3)
+    assert abs(sm["logLik"] - rs["logLik"]) <= 1e-9 * max(n, 1) * 10
+
+
+def test_maximum_particles_ragged(oracle):
+    """particles = 1e5 is the reference's upper limit; not a multiple of the 256-thread block nor of the wave"""
+    model = negbin_ar1(12, seed=31)
+    N = 100000
+    out = F.bootstrap_filter(model, N, seed=5, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), N, seed=5)
+    frac = np.mean(out["indices"] != ref["indices"])
+    assert frac < 1e-6, frac
+    assert abs(out["logLik"] - ref["logLik"]) <= (1e-9 if frac == 0 else 1e-4) * 12
+    assert _rel(out["weights"], ref["weights"]) <= (1e-9 if frac == 0 else 1e-3)
+    with pytest.raises(ValueError):
+        F.bootstrap_filter(model, 100001, seed=5)
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+def test_state_dimension_16(oracle, monkeypatch, path):
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    rng = np.random.default_rng(16)
+    m, k, n = 16, 5, 9
+    T = 0.8 * np.linalg.qr(rng.normal(size=(m, m)))[0]
+    R = 0.2 * rng.normal(size=(m, k))
+    Z = rng.normal(0, 0.3, m)
+    model = M.ssm_ung(rng.poisson(3, n).astype(float), Z=Z, T=T, R=R, a1=np.zeros(m), P1=0.1 * np.eye(m), distribution="poisson")
+    out = F.bootstrap_filter(model, 300, seed=2, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), 300, seed=2)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["Pt"], ref_summary(oracle, ref)[2]) <= 1e-8
+
+
+def ref_summary(oracle, ref):
+    return oracle.filter_summary(ref["alpha"], ref["weights"])
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+def test_no_observation_at_all(oracle, monkeypatch, path):
+    """every y missing: all weight columns are ones, resampling uses uniform weights, logLik = 0 (model_ssm_ung.cpp:644-647)"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    model = M.bsm_ng(np.full(6, np.nan), sd_level=0.3, distribution="poisson", P1=np.array([[1.0]]))
+    out = F.bootstrap_filter(model, 500, seed=8, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), 500, seed=8)
+    assert np.all(out["weights"] == 1.0)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert out["logLik"] == ref["logLik"] == 0.0
