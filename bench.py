@@ -47,6 +47,76 @@ def pmc_traffic(R, N, ppt):
     return None
 
 
+def post_correct_phase(rank, world, dist, cdev="cuda", reps=3):
+    """SURVEY.md 8d config C5 (north_star: IS post-correction sharded over the GPUs of a node): 2 340 retained draws of
+    the ssm_nlg growth model, psi-APF N = 4096, T = 300, split into contiguous blocks over the ranks (strong scaling of
+    one job), log-weights all-gathered over RCCL.  Every rank takes part in every collective whatever happens locally
+    (a local failure is flagged through an all-reduce first), so this phase cannot dead-lock the benchmark."""
+    import numpy as np
+    import torch
+    from bssm_amd import filters as F, models as M, post_correct as PC
+    rng = np.random.default_rng(105)
+    n, K, dT, ns, nsim = 300, 500.0, 0.1, 2340, 4096
+    r = np.zeros(n); pp = np.zeros(n); pp[0] = 50.0
+    for t in range(1, n):
+        r[t] = r[t - 1] + rng.normal(0, 0.05)
+        rr = np.exp(r[t - 1]) / (1 + np.exp(r[t - 1]))
+        pp[t] = K * pp[t - 1] * np.exp(rr * dT) / (K + pp[t - 1] * (np.exp(rr * dT) - 1)) + rng.normal(0, 1)
+    y = pp + rng.normal(0, 1, n)
+    th0 = np.array([0.0, np.log(0.05), 0.0])
+    model = M.ssm_nlg(y, "nlg_growth", theta=th0, known_params=[dT, K, 0.0, 50.0, 1.0, 100.0])
+    theta = th0 + rng.normal(0, 0.05, (ns, 3))
+    counts = rng.geometric(0.234, ns).astype(np.uint32)
+    bounds = PC.shard_bounds(np.ones(ns), world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    threads = max(1, min(8, (os.cpu_count() or 8) // max(1, world)))
+    times, weights, err = [], None, ""
+    for it in range(reps + 1):  # first pass warms the arena and the module
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loc_w = np.zeros(hi - lo)
+        ok = 1.0
+        try:
+            if it == 0:  # the stored modes: here the mode at theta-hat for every draw (approximate_for_is re-linearises there)
+                mode = F.psi_setup(model)["mode"].reshape(-1, order="F")
+                modes = np.repeat(mode[:, None], hi - lo, axis=1)
+            if hi > lo:
+                loc = PC._run_local_block_nlg(model, theta[lo:hi], modes, counts[lo:hi], lo, ns, nsim, 1, 2, 3, threads)
+                loc_w = np.log(loc["weights"])
+        except Exception as e:  # noqa: BLE001 -- reported, never raised past the collectives
+            ok, err = 0.0, repr(e)[:200]
+        if dist is not None:
+            flag = torch.tensor([ok], device=cdev, dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = float(flag.item())
+            mx = int(np.diff(bounds).max())
+            pad = torch.zeros(mx, device=cdev, dtype=torch.float64)
+            pad[:hi - lo] = torch.from_numpy(loc_w).to(cdev)
+            outs = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(outs, pad)
+            weights = np.concatenate([outs[q].cpu().numpy()[:int(bounds[q + 1] - bounds[q])] for q in range(world)])
+        else:
+            weights = loc_w
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=cdev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        if ok < 1.0:
+            return {"error": err or "a rank failed"}
+        if it > 0:
+            times.append(el)
+    best = min(times)
+    return {"workload": "C5: ssm_nlg growth, T=300, m=2, %d retained draws, psi-APF N=%d, IS2 weights (output theta), draws split in "
+                        "contiguous blocks over the ranks, log-weights all-gathered (RCCL)" % (ns, nsim),
+            "scaling": "strong", "n_gpus": world, "seconds": best, "draws_per_s": ns / best,
+            "value": ns * float(nsim) * n / best, "unit": "particle-steps/s", "host_threads_per_rank": threads,
+            "finite_weights": bool(np.all(np.isfinite(weights))), "checksum_logw": float(np.sum(weights))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +129,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-regime-b", action="store_true")
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--no-post-correct", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,12 +140,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the particle filters have no CPU path)")
-    torch.cuda.set_device(local_rank)
+    # BSSM_BENCH_BACKEND=gloo is a test hook: several ranks sharing one GPU (collectives on CPU tensors) to exercise the
+    # multi-rank control flow on a single-GPU box; the driver's runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("BSSM_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"  # where the tensors of a collective live
 
     from bssm_amd.plan import FilterPlan
     from models_zoo import negbin_m4
@@ -101,7 +180,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ll = plan.loglik(stream)
@@ -189,6 +268,15 @@ def main():
         out["cpu_baseline"] = {"value": float(N) * Ts / ec, "unit": "particle-steps/s", "cores": 1, "kind": "port",
                                "sample": "one full filter call of the benchmark model: N=%d, T=%d, 1 thread (the reference has no "
                                          "intra-filter parallelism), gcc -O2, %.1f s" % (N, Ts, ec)}
+
+    if not args.no_post_correct:
+        # ---- the sharded half of the path (all ranks): IS post-correction, SURVEY.md 8e
+        try:
+            pc = post_correct_phase(rank, world, dist, cdev)
+        except Exception as e:  # noqa: BLE001
+            pc = {"error": repr(e)[:200]}
+        if rank == 0:
+            out["post_correct"] = pc
 
     if rank == 0 and os.environ.get("BSSM_BENCH_CALIB"):
         # profiling runs only (scripts/profile_round.sh): one kernel of known traffic (2 GiB read + 2 GiB written) so that

@@ -16,6 +16,8 @@
 // fixed-shape reductions/scans only (no floating-point atomics): results are bit-reproducible
 // run to run and independent of the number of GPUs a batch is sharded over.
 #pragma once
+#include <cstdlib>
+
 #include "pf_device.h"
 #include "pf_functors.h"
 #include "pf_kernels.h"
@@ -146,8 +148,8 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
 constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the fp64 transcendental code
 // Particle i = r * NT + tid (r < PPT): consecutive lanes own consecutive particles, so LDS
 // accesses to the own slot are conflict-free and history stores are coalesced.
-template <int MP, int KP, int PPT, bool FN = false>
-__global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
+template <int MP, int KP, int PPT, bool FN = false, int NTB = WG_NT_MAX>
+__global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = NT >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,12 +301,32 @@ __global__ void __launch_bounds__(WG_NT_MAX) pf_wg_kernel(const FilterBatch b) {
 template <int MP, int KP>
 hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   const int N = b.N;
+  // 1024-thread workgroups (16 waves, 128 VGPRs per lane) for small states and large N: four waves per SIMD instead
+  // of two hide the barrier and LDS latency of the one workgroup a CU can hold at these sizes
+  bool wide = false;
+  if constexpr (MP <= 2) {
+    wide = N >= 2048;
+    if (const char* env = std::getenv("BSSM_AMD_WG_WIDE")) wide = env[0] != '0' && N > 1024;
+  }
+  const int ntmax = wide ? 1024 : WG_NT_MAX;
   int ppt = 1;
-  while (ppt < 16 && N > WG_NT_MAX * ppt) ppt *= 2;
-  const int nt = ppt == 1 ? (N + 63) / 64 * 64 : WG_NT_MAX;
+  while (ppt < 16 && N > ntmax * ppt) ppt *= 2;
+  const int nt = ppt == 1 ? (N + 63) / 64 * 64 : ntmax;
   const size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16 + (MP * MP + MP * KP + MP)) * sizeof(double);
   if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch) = nullptr;
+  if (wide) {
+    if constexpr (MP <= 2) {
+      const bool fn = b.fpar != nullptr;
+      if (fn && MP != KP) return hipErrorInvalidValue;
+      switch (ppt) {
+        case 2: kern = fn ? (MP == KP ? pf_wg_kernel<MP, MP, 2, true, 1024> : nullptr) : pf_wg_kernel<MP, KP, 2, false, 1024>; break;
+        case 4: kern = fn ? (MP == KP ? pf_wg_kernel<MP, MP, 4, true, 1024> : nullptr) : pf_wg_kernel<MP, KP, 4, false, 1024>; break;
+        default: kern = fn ? (MP == KP ? pf_wg_kernel<MP, MP, 8, true, 1024> : nullptr) : pf_wg_kernel<MP, KP, 8, false, 1024>; break;
+      }
+      if (ppt > 8 || !kern) return hipErrorInvalidValue;
+    }
+  } else {
   switch (ppt) {
     case 1: kern = pf_wg_kernel<MP, KP, 1>; break;
     case 2: kern = pf_wg_kernel<MP, KP, 2>; break;
@@ -325,6 +347,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
     } else {
       return hipErrorInvalidValue;
     }
+  }
   }
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -109,3 +109,24 @@ def test_device_psi_setup_equals_host_setup(monkeypatch, kind):
     assert np.allclose(res["1"]["loglik"], res["0"]["loglik"], rtol=0, atol=1e-9 * n)
     assert np.allclose(res["1"]["alphahat"], res["0"]["alphahat"], rtol=1e-8, atol=1e-10)
     assert np.allclose(res["1"]["Vt"], res["0"]["Vt"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("output_type", [1, 2])
+def test_post_correct_is1_large_particle_counts(oracle, output_type):
+    """is1 multiplies the particle count by the jump-chain count (src/approx_mcmc.cpp:376-378): mixed particle counts in
+    one job, some beyond the workgroup-resident capacity, so both kernel shapes serve one call"""
+    model, theta, counts = _job(ns=6, n=25, seed=14)
+    counts = np.array([1, 4, 2, 1, 4, 3], dtype=np.uint32)
+    arrs = PC.expand_models(model, theta)
+    modes = np.stack([oracle.psi_setup(a)["mode"] for a in arrs], axis=1)
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(6), output_type=output_type)
+    nsim = 3000  # x4 = 12000 particles > 8192 (capacity of the LDS-resident shape for m <= 2)
+    out = PC.post_correct(model, mo, nsim, threads=2, is_type="is1", seed=21)
+    ref = oracle.is_correction(arrs, nsim, 21, method=1, counts=counts, modes=modes, is_type=1, output_type=output_type, n_threads=2)
+    assert np.allclose(out["loglik"], ref["loglik"], rtol=0, atol=1e-8 * model.n)
+    assert np.allclose(out["weights"], ref["weights"], rtol=1e-7)
+    if output_type == 1:
+        assert np.allclose(out["alpha"], ref["alpha"], rtol=1e-7, atol=1e-9)
+    else:
+        assert np.allclose(out["alphahat"], ref["alphahat"].T, rtol=1e-7, atol=1e-9)
+        assert np.allclose(out["Vt"], ref["Vt"], rtol=1e-6, atol=1e-9)
