@@ -1,7 +1,8 @@
 /*
  * bssm_oracle.c -- CPU restatement of the helske/bssm particle-filter hot path.
- * TEST INFRASTRUCTURE ONLY; see bssm_oracle.h for the parity status ("parity
- * unpinned" at bit level; pinned by analytic / closed-form checks).
+ * TEST INFRASTRUCTURE ONLY; see bssm_oracle.h for the parity status (deterministic
+ * half pinned by the reference tests' stated values; particle systems "parity
+ * unpinned" at bit level, pinned statistically and analytically).
  *
  * Citations are file:line under the reference tree (src/ unless stated).
  */
@@ -1500,6 +1501,7 @@ static double dmvnorm_cov(const double *x, const double *mean, const double *S, 
   }
   return out;
 }
+double orc_dmvnorm_cov(const double *x, const double *mean, const double *S, int d) { return dmvnorm_cov(x, mean, S, d); }
 static double dnorm_sd(double y, double mean, double sd) { /* dmvnorm(..., lwr = true) with one element, dmvnorm.cpp:10-11 */
   return -0.5 * (log(2.0 * ORC_PI) + 2.0 * log(sd) + pow((y - mean) / sd, 2));
 }
@@ -1520,7 +1522,8 @@ void orc_fn_setup_free(orc_fn_setup *s) {
 }
 
 /* extended Kalman filter with iekf_iter = 0: src/model_ssm_nlg.cpp:284-381 (p = 1) */
-static int fn_ekf(const orc_fn_model *mod, double *at, double *att, double *Pt, double *Ptt) {
+static int fn_ekf_ll(const orc_fn_model *mod, double *at, double *att, double *Pt, double *Ptt, double *loglik) {
+  double ll = 0.0;
   const int n = mod->n, m = mod->id == 1 ? 2 : 1, mm = m * m;
   double a1[2], P1[4], H = fn_H(mod), rd[2];
   fn_a1P1(mod, a1, P1); fn_Rdiag(mod, rd);
@@ -1537,6 +1540,7 @@ static int fn_ekf(const orc_fn_model *mod, double *at, double *att, double *Pt, 
       for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
       if (!isfinite(F) || !(F > 0)) return 0;
       double cF = sqrt(F), v = mod->y[t] - fn_Z(mod, a);
+      ll -= 0.5 * (log(2.0 * ORC_PI) + 2.0 * log(cF) + (v / cF) * (v / cF)); /* :363-365 */
       for (int i = 0; i < m; i++) K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF);
       for (int i = 0; i < m; i++) af[i] = a[i] + K[i] * v;
       double IKZ[4], tmp[4], tmp2[4];
@@ -1550,7 +1554,19 @@ static int fn_ekf(const orc_fn_model *mod, double *at, double *att, double *Pt, 
     mat_mul(Tg, Pf, m, m, m, tmp); mat_mul_bt(tmp, Tg, m, m, m, tmp2);
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = tmp2[i + m * j] + (i == j ? rd[i] * rd[i] : 0.0);
   }
+  if (loglik) *loglik = ll;
   return 1;
+}
+static int fn_ekf(const orc_fn_model *mod, double *at, double *att, double *Pt, double *Ptt) { return fn_ekf_ll(mod, at, att, Pt, Ptt, NULL); }
+/* ekf(model)$logLik with iekf_iter = 0 (src/model_ssm_nlg.cpp:284-381); pinned by tests/testthat/test_ekpf.R:64 */
+double orc_fn_ekf_loglik(const orc_fn_model *mod) {
+  const int n = mod->n, m = mod->id == 1 ? 2 : 1;
+  double *at = (double *)calloc((size_t)m * (n + 1), sizeof(double)), *att = (double *)calloc((size_t)m * n, sizeof(double));
+  double *Pt = (double *)calloc((size_t)m * m * (n + 1), sizeof(double)), *Ptt = (double *)calloc((size_t)m * m * n, sizeof(double));
+  double ll = 0.0;
+  if (!fn_ekf_ll(mod, at, att, Pt, Ptt, &ll)) ll = -INFINITY;
+  free(at); free(att); free(Pt); free(Ptt);
+  return ll;
 }
 
 static void fn_linearise(const orc_fn_model *mod, const double *zpts /* m x n: where Z is linearised */,

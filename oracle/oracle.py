@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg
 of bench.py.  Nothing in bssm_amd/ imports this module.  Parity status: see bssm_oracle.h
-("parity unpinned" at the bit level; pinned by analytic and closed-form checks).
+(deterministic half pinned by the values the reference's own tests state; particle systems "parity unpinned" at the
+bit level, pinned statistically and analytically).
 """
 from __future__ import annotations
 
@@ -196,6 +197,15 @@ def filter_summary(alpha, weights):
     return at, att, Pt, Ptt
 
 
+def dmvnorm_cov(x, mean, S):
+    """src/dmvnorm.cpp:4-58 with lwr = FALSE, logd = TRUE"""
+    L = lib()
+    L.orc_dmvnorm_cov.restype = C.c_double
+    x = np.ascontiguousarray(x, dtype=np.float64); mean = np.ascontiguousarray(mean, dtype=np.float64)
+    S = np.asfortranarray(S, dtype=np.float64)
+    return float(L.orc_dmvnorm_cov(_p(x), _p(mean), _p(S), C.c_int(x.size)))
+
+
 def stratified_sample(p, r, N=None):
     """src/stratified_sample.cpp:9-28: (zero-based indices [N], cumulative sum left in p)"""
     L = lib()
@@ -362,6 +372,18 @@ def mng_psi_filter(arr: dict, nsim: int, seed=1, stream=0, is_mode=None, setup=N
 class OrcFn(C.Structure):
     _fields_ = [("id", C.c_int), ("n", C.c_int), ("y", c_double_p), ("theta", C.c_double * 8), ("known", C.c_double * 8),
                 ("x0", C.c_double), ("positive", C.c_int), ("L", C.c_int)]
+
+
+def fn_ekf_loglik(model: dict) -> float:
+    """ekf(model)$logLik, iekf_iter = 0 (src/model_ssm_nlg.cpp:284-381)"""
+    L = lib()
+    L.orc_fn_ekf_loglik.restype = C.c_double
+    s = OrcFn()
+    y = np.ascontiguousarray(model["y"], dtype=np.float64)
+    s.id, s.n, s.y = int(model["model_id"]), y.size, _p(y)
+    for i, v in enumerate(np.asarray(model["theta"], dtype=float)): s.theta[i] = v
+    for i, v in enumerate(np.asarray(model.get("known_params", []), dtype=float)): s.known[i] = v
+    return float(L.orc_fn_ekf_loglik(C.byref(s)))
 
 
 def fn_bsf_filter(model: dict, nsim: int, seed=1, stream=0):
