@@ -1522,7 +1522,7 @@ void orc_fn_setup_free(orc_fn_setup *s) {
 }
 
 /* extended Kalman filter with iekf_iter = 0: src/model_ssm_nlg.cpp:284-381 (p = 1) */
-static int fn_ekf_ll(const orc_fn_model *mod, double *at, double *att, double *Pt, double *Ptt, double *loglik) {
+static int fn_ekf_ll(const orc_fn_model *mod, double *at, double *att, double *Pt, double *Ptt, double *loglik, int iekf_iter) {
   double ll = 0.0;
   const int n = mod->n, m = mod->id == 1 ? 2 : 1, mm = m * m;
   double a1[2], P1[4], H = fn_H(mod), rd[2];
@@ -1540,9 +1540,30 @@ static int fn_ekf_ll(const orc_fn_model *mod, double *at, double *att, double *P
       for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
       if (!isfinite(F) || !(F > 0)) return 0;
       double cF = sqrt(F), v = mod->y[t] - fn_Z(mod, a);
-      ll -= 0.5 * (log(2.0 * ORC_PI) + 2.0 * log(cF) + (v / cF) * (v / cF)); /* :363-365 */
       for (int i = 0; i < m; i++) K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF);
       for (int i = 0; i < m; i++) af[i] = a[i] + K[i] * v;
+      { /* iterated EKF (:326-355): re-linearise the observation equation at the filtered estimate */
+        double diff = 1.0;
+        int it = 0;
+        while (diff > 1e-4 && it < iekf_iter) {
+          it++;
+          fn_Zg(mod, af, Zg);
+          for (int i = 0; i < m; i++) { PZ[i] = 0; for (int j = 0; j < m; j++) PZ[i] += P[i + m * j] * Zg[j]; }
+          F = H * H;
+          for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
+          if (!isfinite(F) || !(F > 0)) return 0;
+          cF = sqrt(F);
+          double zd = 0;
+          for (int j = 0; j < m; j++) zd += Zg[j] * (a[j] - af[j]);
+          v = mod->y[t] - fn_Z(mod, af) - zd;
+          double an[2];
+          diff = 0;
+          for (int i = 0; i < m; i++) { K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF); an[i] = a[i] + K[i] * v; diff += (af[i] - an[i]) * (af[i] - an[i]); }
+          diff /= m;
+          for (int i = 0; i < m; i++) af[i] = an[i];
+        }
+      }
+      ll -= 0.5 * (log(2.0 * ORC_PI) + 2.0 * log(cF) + (v / cF) * (v / cF)); /* :363-365 */
       double IKZ[4], tmp[4], tmp2[4];
       for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
       mat_mul(IKZ, P, m, m, m, tmp); mat_mul_bt(tmp, IKZ, m, m, m, tmp2);
@@ -1557,14 +1578,14 @@ static int fn_ekf_ll(const orc_fn_model *mod, double *at, double *att, double *P
   if (loglik) *loglik = ll;
   return 1;
 }
-static int fn_ekf(const orc_fn_model *mod, double *at, double *att, double *Pt, double *Ptt) { return fn_ekf_ll(mod, at, att, Pt, Ptt, NULL); }
-/* ekf(model)$logLik with iekf_iter = 0 (src/model_ssm_nlg.cpp:284-381); pinned by tests/testthat/test_ekpf.R:64 */
-double orc_fn_ekf_loglik(const orc_fn_model *mod) {
+static int fn_ekf(const orc_fn_model *mod, double *at, double *att, double *Pt, double *Ptt) { return fn_ekf_ll(mod, at, att, Pt, Ptt, NULL, 0); }
+/* ekf(model, iekf_iter)$logLik (src/model_ssm_nlg.cpp:284-381); pinned by tests/testthat/test_ekpf.R:64,67 */
+double orc_fn_ekf_loglik(const orc_fn_model *mod, int iekf_iter) {
   const int n = mod->n, m = mod->id == 1 ? 2 : 1;
   double *at = (double *)calloc((size_t)m * (n + 1), sizeof(double)), *att = (double *)calloc((size_t)m * n, sizeof(double));
   double *Pt = (double *)calloc((size_t)m * m * (n + 1), sizeof(double)), *Ptt = (double *)calloc((size_t)m * m * n, sizeof(double));
   double ll = 0.0;
-  if (!fn_ekf_ll(mod, at, att, Pt, Ptt, &ll)) ll = -INFINITY;
+  if (!fn_ekf_ll(mod, at, att, Pt, Ptt, &ll, iekf_iter)) ll = -INFINITY;
   free(at); free(att); free(Pt); free(Ptt);
   return ll;
 }

@@ -374,8 +374,8 @@ class OrcFn(C.Structure):
                 ("x0", C.c_double), ("positive", C.c_int), ("L", C.c_int)]
 
 
-def fn_ekf_loglik(model: dict) -> float:
-    """ekf(model)$logLik, iekf_iter = 0 (src/model_ssm_nlg.cpp:284-381)"""
+def fn_ekf_loglik(model: dict, iekf_iter: int = 0) -> float:
+    """ekf(model, iekf_iter)$logLik (src/model_ssm_nlg.cpp:284-381)"""
     L = lib()
     L.orc_fn_ekf_loglik.restype = C.c_double
     s = OrcFn()
@@ -383,7 +383,7 @@ def fn_ekf_loglik(model: dict) -> float:
     s.id, s.n, s.y = int(model["model_id"]), y.size, _p(y)
     for i, v in enumerate(np.asarray(model["theta"], dtype=float)): s.theta[i] = v
     for i, v in enumerate(np.asarray(model.get("known_params", []), dtype=float)): s.known[i] = v
-    return float(L.orc_fn_ekf_loglik(C.byref(s)))
+    return float(L.orc_fn_ekf_loglik(C.byref(s), C.c_int(iekf_iter)))
 
 
 def fn_bsf_filter(model: dict, nsim: int, seed=1, stream=0):

@@ -57,6 +57,9 @@ def test_ekf_loglik_equals_reference_test_value(oracle):
     y = np.array(g["y"]); y[1:3] = np.nan
     model = M.ssm_nlg(y, "nlg_sin_exp", theta=g["theta"])
     assert abs(oracle.fn_ekf_loglik(model) - g["expected_ekf_loglik_with_y2_y3_missing"]) <= 1.5e-8 * 2.65
+    # iterated EKF, test_ekpf.R:67-69
+    assert abs(oracle.fn_ekf_loglik(model, 1) - g["expected_iekf1_loglik_with_y2_y3_missing"]) <= 1.5e-8 * 2.62
+    assert oracle.fn_ekf_loglik(model, 1) == oracle.fn_ekf_loglik(model, 2)
 
 
 @pytest.mark.gpu
@@ -71,3 +74,53 @@ def test_particle_smoother_means_equal_reference_test_values(method, N):
     target = np.array(g["expected_smoothed_alphahat_9_10"])
     got = out["alphahat"][8:10, 0]
     assert np.mean(np.abs(got - target)) / np.mean(np.abs(target)) < g["tolerance"], (got, target)
+
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's published Monte-Carlo study of its own particle filters (vignettes/psi_pf.Rmd, results shipped as
+# vignettes/psi_pf_experiments/*.rds): mean and SD of the log-likelihood estimate over 10 000 runs per method and
+# particle count, on data drawn with set.seed(1) -- regenerated here bit for bit by tests/golden/r_rng.py.  The device
+# filters use a different random stream, so the comparison is distributional: over R = 1024 device runs the mean must
+# lie within 4 standard errors of the reference's mean and the SD within 15 % of the reference's SD.
+def _vignette_model(key):
+    g = V[key]
+    if key == "vignette_growth_model":
+        return g, M.ssm_nlg(np.array(g["y"]), "nlg_growth", theta=g["theta"], known_params=g["known_params"])
+    return g, M.ssm_nlg(np.array(g["y"]), "nlg_ar_exp", theta=g["theta"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["vignette_growth_model", "vignette_ar_exp_model"])
+def test_loglik_estimator_distribution_equals_the_references_published_study(key):
+    g, model = _vignette_model(key)
+    R = 1024
+    for method, rows in g["loglik_mean_sd"].items():
+        for N, (mu, sd) in rows.items():
+            ll = F.logLik_batch(model, int(N), R, method=method, seed=20 + int(N))
+            assert np.all(np.isfinite(ll))
+            z = (ll.mean() - mu) / (sd / np.sqrt(R))
+            ratio = ll.std(ddof=1) / sd
+            assert abs(z) < 4.0, (key, method, N, ll.mean(), mu, z)
+            assert 0.85 < ratio < 1.18, (key, method, N, ll.std(ddof=1), sd)
+
+
+@pytest.mark.gpu
+def test_bootstrap_smoother_equals_the_references_truth_runs():
+    """gm_truth.rds / ar_truth.rds: one bootstrap particle_smoother run with 1e5 (1e6) particles in the reference; the
+    device run with 1e5 particles agrees within the Monte-Carlo error of two such runs"""
+    g, model = _vignette_model("vignette_growth_model")
+    t = g["truth_bsf_1e5"]
+    out = F.particle_smoother(model, 100000, method="bsf", seed=1)
+    n = model.n
+    assert abs(out["logLik"] - t["logLik"]) < 0.5          # SD of one run ~ 0.09 (0.92 at N = 1000)
+    assert abs(out["alphahat"][0, 0] - t["alpha_11"]) < 0.1 and abs(out["alphahat"][0, 1] - t["alpha_21"]) < 0.5
+    assert abs(out["alphahat"][n - 1, 0] - t["alpha_1n"]) < 0.15 and abs(out["alphahat"][n - 1, 1] - t["alpha_2n"]) < 0.5
+    assert abs(out["Vt"][1, 1, 0] - t["V_21"]) < 0.2 and abs(out["Vt"][1, 1, n - 1] - t["V_2n"]) < 0.1
+    g, model = _vignette_model("vignette_ar_exp_model")
+    t = g["truth_bsf_1e6"]
+    out = F.particle_smoother(model, 100000, method="bsf", seed=1)
+    n = model.n
+    assert abs(out["logLik"] - t["logLik"]) < 0.1           # SD of one run ~ 0.011 (0.109 at N = 1000)
+    assert abs(out["alphahat"][0, 0] - t["alpha_1"]) < 0.01 and abs(out["Vt"][0, 0, 0] - t["V_1"]) < 0.005
+    assert abs(out["alphahat"][n - 1, 0] - t["alpha_n"]) < 0.01 and abs(out["Vt"][0, 0, n - 1] - t["V_n"]) < 0.005
