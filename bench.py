@@ -216,7 +216,7 @@ def main():
                            "frac_of_measured_copy_6290GBs": achieved / 6290.0}
     plan.close()
 
-    if rank == 0 and R != 1 and not args.no_single:
+    if rank == 0 and world == 1 and R != 1 and not args.no_single:
         # ---- regime A: ONE filter, latency-bound (1000 dependent launches, one wave per SIMD)
         p1 = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=1)
         p1.run(3, hip_stream=stream); torch.cuda.synchronize()
@@ -232,7 +232,7 @@ def main():
                                 "algorithmic_GBs": N * info["bytes_per_particle_step"] / (k1_ms * 1e-3) / 1e9}
         p1.close()
 
-    if rank == 0 and not args.no_regime_b:
+    if rank == 0 and world == 1 and not args.no_regime_b:
         # ---- regime B: many independent filters, one workgroup each (post-correction shape)
         nb, fb = 2048, 512
         pb = FilterPlan(model, nb, method="bsf", n_rep=fb, keep_history=False, force="wg")
@@ -254,7 +254,7 @@ def main():
                            "note": "state never leaves LDS: HBM traffic ~0, bound by fp64 VALU/transcendentals"}
         pb.close()
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only: the other ranks would idle behind it
         # ---- CPU baseline: the oracle (reference loop structure, one thread per filter) on a bounded sample
         from bssm_amd import models as M
         from oracle import oracle as O
