@@ -77,6 +77,19 @@ def ar_exp_series():
     return np.exp(x[nstart:]) + np.array([nr() for _ in range(n)])
 
 
+def study_table(prefix, cols):
+    """mean / SD over the 10 000 runs per (method, N) of every reported quantity, from the shipped result files
+    vignettes/psi_pf_experiments/{gm,ar}_result_{10,100,1000}.rds (needs /root/reference; run in the build container)"""
+    from rds_reader import data_frame, load_rds
+    out = {}
+    for N in (10, 100, 1000):
+        df = data_frame(load_rds("/root/reference/vignettes/psi_pf_experiments/%s_result_%d.rds" % (prefix, N)))
+        for meth, key in (("BSF", "bsf"), ("PSI", "psi")):
+            sel = df["method"] == meth
+            out.setdefault(key, {})[str(N)] = {c: [float(np.mean(df[c][sel])), float(np.std(df[c][sel], ddof=1))] for c in cols}
+    return out
+
+
 out = {
     # The reference's published Monte-Carlo study of its own filters (10 000 replications each): mean and standard
     # deviation of the log-likelihood estimate per method and particle count, decoded from
@@ -87,6 +100,7 @@ out = {
         "known_params": [0.1, 500.0, -1.5, 50.0, 1.0, 100.0],
         "loglik_mean_sd": {"psi": {"10": [-606.2218, 0.1201], "100": [-606.2149, 0.0425], "1000": [-606.2138, 0.0157]},
                            "bsf": {"100": [-611.0850, 3.7534], "1000": [-606.6395, 0.9176]}},
+        "smoother_mean_sd": study_table("gm", ["logLik", "alpha_11", "alpha_21", "V_11", "V_21", "alpha_1n", "alpha_2n", "V_1n", "V_2n"]),
         "truth_bsf_1e5": {"logLik": -606.162991, "alpha_11": -1.2331292, "alpha_21": 50.2930218, "V_11": 0.0509254108,
                           "V_21": 0.695909774, "alpha_1n": -1.11484755, "alpha_2n": 497.234985, "V_1n": 0.252791374, "V_2n": 0.619154356},
     },
@@ -95,6 +109,7 @@ out = {
         "y": list(ar_exp_series()), "theta": [0.0, 0.95, float(np.log(0.1)), 0.0],  # built-in nlg_ar_exp: (mu, rho, log sigma, log H)
         "loglik_mean_sd": {"psi": {"10": [-143.6263, 0.2560], "100": [-143.6000, 0.0932], "1000": [-143.5959, 0.0320]},
                            "bsf": {"10": [-144.2271, 1.2130], "100": [-143.6519, 0.3493], "1000": [-143.6016, 0.1091]}},
+        "smoother_mean_sd": study_table("ar", ["logLik", "alpha_1", "V_1", "alpha_n", "V_n"]),
         "truth_bsf_1e6": {"logLik": -143.594352, "alpha_1": -0.137113564, "V_1": 0.0677577735, "alpha_n": 0.206234604, "V_n": 0.0518723271},
     },
     "svm_gaussian_approx": {

@@ -124,3 +124,36 @@ def test_bootstrap_smoother_equals_the_references_truth_runs():
     assert abs(out["logLik"] - t["logLik"]) < 0.1           # SD of one run ~ 0.011 (0.109 at N = 1000)
     assert abs(out["alphahat"][0, 0] - t["alpha_1"]) < 0.01 and abs(out["Vt"][0, 0, 0] - t["V_1"]) < 0.005
     assert abs(out["alphahat"][n - 1, 0] - t["alpha_n"]) < 0.01 and abs(out["Vt"][0, 0, n - 1] - t["V_n"]) < 0.005
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["vignette_growth_model", "vignette_ar_exp_model"])
+def test_particle_smoother_distribution_equals_the_references_published_study(key):
+    """vignettes/psi_pf_experiments/{gm,ar}_result_*.rds: the smoothed state means and variances at the first and last time
+    point (filter-smoother back-trace + summary) and the log-likelihood of every one of the reference's 10 000 runs per
+    (method, N).  400 device particle_smoother calls per cell: mean within 4.5 standard errors of the reference's mean, SD
+    within 25 % (the variance estimates at N = 10 are heavy-tailed)."""
+    g, model = _vignette_model(key)
+    n, R = model.n, 400
+    growth = key == "vignette_growth_model"
+    cells = [("psi", 10), ("psi", 100), ("psi", 1000), ("bsf", 100), ("bsf", 1000)] + ([] if growth else [("bsf", 10)])
+    for method, N in cells:
+        ref = g["smoother_mean_sd"][method][str(N)]
+        rows = []
+        for rep in range(R):
+            o = F.particle_smoother(model, N, method=method, seed=1000 * N + rep)
+            ah, vt = o["alphahat"], o["Vt"]
+            if growth:
+                rows.append([o["logLik"], ah[0, 0], ah[0, 1], vt[0, 0, 0], vt[1, 1, 0], ah[n - 1, 0], ah[n - 1, 1], vt[0, 0, n - 1], vt[1, 1, n - 1]])
+            else:
+                rows.append([o["logLik"], ah[0, 0], vt[0, 0, 0], ah[n - 1, 0], vt[0, 0, n - 1]])
+        got = np.array(rows)
+        names = ["logLik", "alpha_11", "alpha_21", "V_11", "V_21", "alpha_1n", "alpha_2n", "V_1n", "V_2n"] if growth else ["logLik", "alpha_1", "V_1", "alpha_n", "V_n"]
+        for j, nm in enumerate(names):
+            mu, sd = ref[nm]
+            if not sd > 0 or (nm.startswith("V_") and sd > 2.0 * abs(mu)):
+                continue  # trajectories fully coalesced at that time point in (almost) every reference run: rare-event SD
+            z = (got[:, j].mean() - mu) / (sd / np.sqrt(R))
+            ratio = got[:, j].std(ddof=1) / sd
+            assert abs(z) < 4.5, (key, method, N, nm, got[:, j].mean(), mu, z)
+            assert 0.75 < ratio < 1.33, (key, method, N, nm, got[:, j].std(ddof=1), sd)
