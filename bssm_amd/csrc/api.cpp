@@ -293,7 +293,7 @@ void transpose_to(const std::vector<double>& src, int rows, int cols, double* ds
 }
 
 int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<double>* fpar, int n, int m, int k, int p, int N,
-               bool psi, bool smoother, uint32_t seed, double base_ll, bssm_filter_out* out);
+               int psi /* 0 bootstrap, 1 psi-APF, 2 EKF proposal */, bool smoother, uint32_t seed, double base_ll, bssm_filter_out* out);
 
 // one filter, full outputs: shared by bsf / bsf_smoother / psi_smoother
 int run_single_filter(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, bool psi, bool smoother,
@@ -320,14 +320,14 @@ int run_single_filter(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
     bssm::build_bsf_tables(hm, MP, bssm::pad_noise_dim(MP, hm.k), &tabs[0]);
     base_ll = bssm::const_term(hm);  // src/model_ssm_ung.cpp:690-710
   }
-  return run_tables(tabs, nullptr, n, m, hm.k, hm.p, N, psi, smoother, seed, base_ll, out);
+  return run_tables(tabs, nullptr, n, m, hm.k, hm.p, N, psi ? 1 : 0, smoother, seed, base_ll, out);
 }
 
 // one filter from prepared tables, full outputs (+ optional built-in functor parameters)
 int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<double>* fpar, int n, int m, int k, int p, int N,
-               bool psi, bool smoother, uint32_t seed, double base_ll, bssm_filter_out* out) {
+               int psi, bool smoother, uint32_t seed, double base_ll, bssm_filter_out* out) {
   DeviceBatch db;
-  int rc = db.upload(tabs, n, m, k, p, N, psi ? 1 : 0, true, 0);
+  int rc = db.upload(tabs, n, m, k, p, N, psi, true, 0);
   if (rc) return rc;
   if (fpar) {  // functor parameters, optionally followed by the approximating (T_t, C_t) rows of the psi-APF
     std::vector<double> fp(fpar->begin(), fpar->begin() + bssm::FP_SIZE), am(fpar->begin() + bssm::FP_SIZE, fpar->end());
@@ -526,9 +526,48 @@ int run_functor(const bssm_fn_model* mod, uint32_t nsim, uint32_t seed, bool smo
   const int rc = functor_tables(mod, &tabs[0], &fpar, &m, &k);
   if (rc) return rc;
   if (!have_device()) return no_device();
-  return run_tables(tabs, &fpar, mod->n, m, k, 1, (int)nsim, false, smoother, seed, 0.0, out);
+  return run_tables(tabs, &fpar, mod->n, m, k, 1, (int)nsim, 0, smoother, seed, 0.0, out);
 }
 }  // namespace
+
+namespace {
+// EKF-proposal particle filter of a built-in ssm_nlg model: bootstrap-style tables, the initial proposal (att1, L1) as
+// the initial table, and [a1 | P1 | att1 | L1] behind the functor parameters for the time-0 weights
+int functor_ekpf_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector<double>* fpar, int* m_out) {
+  bssm::FnModel f;
+  int rc = to_fn_model(mod, &f);
+  if (rc) return rc;
+  int m = 1, k = 1;
+  if ((rc = functor_tables(mod, ft, fpar, &m, &k))) return rc;
+  double a1[2], P1[4], att1[2], L1[4];
+  bssm::fn_ekpf_init(f, a1, P1, att1, L1);
+  for (int j = 0; j < m; j++) ft->init[j] = att1[j];
+  for (int q = 0; q < m * m; q++) ft->init[m + q] = L1[q];
+  fpar->insert(fpar->end(), a1, a1 + m);
+  fpar->insert(fpar->end(), P1, P1 + m * m);
+  fpar->insert(fpar->end(), att1, att1 + m);
+  fpar->insert(fpar->end(), L1, L1 + m * m);
+  *m_out = m;
+  return BSSM_OK;
+}
+int run_ekpf(const bssm_fn_model* mod, uint32_t nsim, uint32_t seed, bool smoother, bssm_filter_out* out) {
+  if (!out || nsim < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  std::vector<bssm::FilterTables> tabs(1);
+  std::vector<double> fpar;
+  int m = 1;
+  const int rc = functor_ekpf_tables(mod, &tabs[0], &fpar, &m);
+  if (rc) return rc;
+  if (!have_device()) return no_device();
+  return run_tables(tabs, &fpar, mod->n, m, m, 1, (int)nsim, 2, smoother, seed, 0.0, out);
+}
+}  // namespace
+
+int bssm_ekpf_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
+  return run_ekpf(model, nsim, seed, false, out);
+}
+int bssm_ekpf_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
+  return run_ekpf(model, nsim, seed, true, out);
+}
 
 int bssm_bsf_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
   if (model && model->model_id >= bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_nlg model id");
@@ -557,7 +596,7 @@ int bssm_psi_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t se
   if (!ok) { out->logLik = -INFINITY; return BSSM_WARN_DEGENERATE; }  // src/model_ssm_nlg.cpp:988-990
   if (!have_device()) return no_device();
   fpar.insert(fpar.end(), amats.begin(), amats.end());  // run_tables splits them again
-  return run_tables(tabs, &fpar, model->n, m, m, 1, (int)nsim, true, true, seed, al, out);
+  return run_tables(tabs, &fpar, model->n, m, m, 1, (int)nsim, 1, true, seed, al, out);
 }
 
 int bssm_fn_psi_setup(const bssm_fn_model* model, const double* is_mode, int32_t max_iter, double conv_tol, double* mode,
@@ -578,26 +617,32 @@ int bssm_fn_psi_setup(const bssm_fn_model* model, const double* is_mode, int32_t
 int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed, uint32_t stream0,
                          uint32_t n_rep, double* loglik) {
   if (!loglik || n_rep < 1 || nsim < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
-  if (sampling_method != BSSM_PSI && sampling_method != BSSM_BSF) return fail(BSSM_ERR_UNSUPPORTED, "sampling_method must be psi or bsf");
+  if (sampling_method != BSSM_PSI && sampling_method != BSSM_BSF && sampling_method != BSSM_EKPF)
+    return fail(BSSM_ERR_UNSUPPORTED, "sampling_method must be 1 (psi), 2 (bsf) or 4 (ekf particle filter)");
   std::vector<bssm::FilterTables> tabs(1);
   std::vector<double> fpar, amats;
   int m = 1, k = 1, rc;
   double base = 0.0;
-  const bool psi = sampling_method == BSSM_PSI;
+  const bool psi = sampling_method == BSSM_PSI, ekpf = sampling_method == BSSM_EKPF;
   if (psi) {
     bool ok = true;
     if ((rc = functor_psi_tables(model, nullptr, 100, 1e-8, &tabs[0], &fpar, &amats, &base, &ok, &m))) return rc;
     k = m;
     if (!ok) { for (uint32_t r = 0; r < n_rep; r++) loglik[r] = -INFINITY; return BSSM_WARN_DEGENERATE; }
+  } else if (ekpf) {
+    if ((rc = functor_ekpf_tables(model, &tabs[0], &fpar, &m))) return rc;
+    k = m;
+    amats.assign(fpar.begin() + bssm::FP_SIZE, fpar.end());
+    fpar.resize(bssm::FP_SIZE);
   } else {
     if ((rc = functor_tables(model, &tabs[0], &fpar, &m, &k))) return rc;
   }
   if (!have_device()) return no_device();
   std::vector<bssm::FilterTables> all(n_rep, tabs[0]);
   DeviceBatch db;
-  if ((rc = db.upload(all, model->n, m, k, 1, (int)nsim, psi ? 1 : 0, false, 0))) return rc;
+  if ((rc = db.upload(all, model->n, m, k, 1, (int)nsim, psi ? 1 : (ekpf ? 2 : 0), false, 0))) return rc;
   if ((rc = db.set_fpar(fpar))) return rc;
-  if (psi && (rc = db.set_amats(amats))) return rc;
+  if ((psi || ekpf) && (rc = db.set_amats(amats))) return rc;
   db.const_terms.assign(n_rep, base);
   if ((rc = db.run(seed, stream0, nullptr))) return rc;
   if ((rc = db.fetch_loglik(nullptr, loglik))) return rc;

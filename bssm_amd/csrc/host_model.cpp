@@ -969,6 +969,44 @@ void fn_a1P1(const FnModel& f, double* a1, double* P1) {
   }
 }
 
+// initial proposal of the EKF particle filter (src/model_ssm_nlg.cpp:1154-1161): EKF update of (a1, P1) with y_0, then
+// psd_chol of the updated covariance.  Everything m x m column-major, m <= 2.
+void fn_ekpf_init(const FnModel& f, double* a1, double* P1, double* att1, double* L1) {
+  const int m = f.m;
+  fn_a1P1(f, a1, P1);
+  double Ptt[4] = {0, 0, 0, 0};
+  const double y = f.y[0];
+  if (std::isfinite(y)) {  // ekf_update_step (:1264-1293)
+    double Zg[2] = {0, 0}, PZ[2] = {0, 0}, K[2];
+    fnZg(f, a1, Zg);
+    const double H = fnH(f);
+    double F = H * H;
+    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += P1[i + m * j] * Zg[j];
+    for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
+    const double cF = std::sqrt(F), v = y - fnZ(f, a1);
+    for (int i = 0; i < m; i++) { K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF); att1[i] = a1[i] + K[i] * v; }
+    double IKZ[4], tmp[4];
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double acc = 0; for (int q = 0; q < m; q++) acc += IKZ[i + m * q] * P1[q + m * j]; tmp[i + m * j] = acc; }
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double acc = 0; for (int q = 0; q < m; q++) acc += tmp[i + m * q] * IKZ[j + m * q]; Ptt[i + m * j] = acc + K[i] * H * H * K[j]; }
+  } else {
+    for (int i = 0; i < m; i++) att1[i] = a1[i];
+    for (int q = 0; q < m * m; q++) Ptt[q] = P1[q];
+  }
+  // psd_chol (src/psd_chol.cpp:5-18)
+  for (int q = 0; q < m * m; q++) L1[q] = 0.0;
+  double dmax = Ptt[0];
+  for (int j = 1; j < m; j++) dmax = std::max(dmax, Ptt[j + m * j]);
+  const double thr = std::max(kEps, kEps * m * dmax);
+  std::vector<int> idx;
+  for (int j = 0; j < m; j++) if (Ptt[j + m * j] > thr) idx.push_back(j);
+  if (!idx.empty()) {
+    Mat Lm;
+    chol_lower_on(Mat(m, m, Ptt), idx, &Lm);
+    for (int q = 0; q < m * m; q++) L1[q] = Lm.a[q];
+  }
+}
+
 bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double conv_tol, FnSetup* su) {
   const int n = f.n, m = f.m, mm = m * m;
   su->Z.assign((size_t)m * n, 0.0); su->T.assign((size_t)mm * n, 0.0); su->D.assign(n, 0.0); su->C.assign((size_t)m * n, 0.0);

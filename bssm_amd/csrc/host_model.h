@@ -107,6 +107,8 @@ bool fn_psi_setup_begin(const FnModel& mod, const double* is_mode, FnSetup* out,
 // and the approximating (T_t, C_t) rows used by the transition-density ratio
 void build_fn_psi_tables(const FnModel& mod, const FnSetup& su, FilterTables* ft, std::vector<double>* amats);
 void fn_a1P1(const FnModel& mod, double* a1, double* P1 /* m x m */);
+// EKF particle filter: prior (a1, P1) and the initial proposal (att1, lower factor L1), src/model_ssm_nlg.cpp:1154-1161
+void fn_ekpf_init(const FnModel& mod, double* a1, double* P1, double* att1, double* L1);
 
 // built-in update_model maps (see bssm_update_model_builtin in bssm_amd.h)
 std::string update_model_builtin(int model_type, const int32_t* flags, const double* theta, int n_par,

@@ -139,6 +139,7 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
                                                   const double* __restrict__ row, const double* __restrict__ amat, int t,
                                                   const double (&x)[MP], const double (&aprev)[MP]) {
   if constexpr (FN) {
+    if (b.psi == 2) return functor_ekpf_weight<MP>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
     return b.psi ? functor_psi_weight<MP>(fpar, row, amat, t, x, aprev) : functor_log_weight<MP>(fpar, row, x);
   } else {
     return log_weight_of<MP>(b, row, x);
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
     // stage this step's transition operands in LDS (every wave is past the previous transition here;
     // they become visible at barrier (2)/(3), before the transition after barrier (4))
-    if ((!FN || b.psi) && t < n && (t == 0 || b.mats_tstride != 0)) {
+    if ((!FN || b.psi == 1) && t < n && (t == 0 || b.mats_tstride != 0)) {
       const double* __restrict__ src = mats + (size_t)t * b.mats_tstride;
       for (int q = tid; q < MS; q += NT) s_mats[q] = src[q];
     }
@@ -279,6 +280,8 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       double x[MP];
       if (FN && !b.psi) {
         if constexpr (FN) functor_propagate<MP, KP>(fpar, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
+      } else if (FN && b.psi == 2) {
+        if constexpr (FN) functor_ekpf_propagate<MP>(fpar, ob, t + 1 >= n, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
       } else {
         double z[KP];
         rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
@@ -291,7 +294,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
           if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1) + (t + 1)) * m + c) * N + i] = x[c];
         }
       }
-      w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN>(b, fpar, ob, amats + (size_t)t * (MP * MP + MP), t + 1, x, a[r]) : 0.0) : -INFINITY;
+      w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN>(b, fpar, ob, (FN && b.psi == 2) ? amats : amats + (size_t)t * (MP * MP + MP), t + 1, x, a[r]) : 0.0) : -INFINITY;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -619,7 +622,9 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
         for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
         BSSM_STAMP(6)
         if constexpr (FN) {
-          if (b.psi) {
+          if (b.psi == 2) {
+            functor_ekpf_propagate<MP>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
+          } else if (b.psi) {
             double z[KP];
             rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
             propagate<MP, KP>(mt, a, z, x[r]);
@@ -654,7 +659,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
-    w[r] = (li < len) ? (have_obs ? weight_dispatch<MP, FN>(b, fpar, ob, amats + (size_t)(t < 0 ? 0 : t) * (MP * MP + MP), tn, x[r], aprev[FN ? r : 0]) : 0.0) : -INFINITY;
+    w[r] = (li < len) ? (have_obs ? weight_dispatch<MP, FN>(b, fpar, ob, (FN && b.psi == 2) ? amats : amats + (size_t)(t < 0 ? 0 : t) * (MP * MP + MP), tn, x[r], aprev[FN ? r : 0]) : 0.0) : -INFINITY;
     mx = fmax(mx, w[r]);
   }
   BSSM_STAMP(8)

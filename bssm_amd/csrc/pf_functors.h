@@ -164,4 +164,190 @@ __device__ __forceinline__ double functor_psi_weight(const double* __restrict__ 
   return w - row[RH_SCALE];
 }
 
+// ---- EKF-proposal particle filter of ssm_nlg (van der Merwe et al.; src/model_ssm_nlg.cpp:1148-1293).
+// Every particle runs one EKF update from its ancestor: a_t = T(anc), P_t = R R' (diagonal in the shipped models),
+// then att / Ptt from y_{t+1} (:1264-1293), proposal alpha' = att + psd_chol(Ptt) u, weight = g(y | alpha') N(alpha';
+// T(anc), R R') / N(alpha'; att, Ptt).  The proposal is recomputed from the ancestor when the weight is evaluated
+// (a few dozen flops) instead of being carried between the two places.
+template <int MP>
+__device__ __forceinline__ void nlg_Z_gn(int id, const double (&x)[MP], double (&Zg)[MP]) {
+#pragma unroll
+  for (int c = 0; c < MP; c++) Zg[c] = 0.0;
+  switch (id) {
+    case FN_NLG_GROWTH: if constexpr (MP > 1) Zg[1] = 1.0; break;
+    case FN_NLG_AR_EXP:
+    case FN_NLG_SIN_EXP: Zg[0] = fast_exp(x[0]); break;
+    default: Zg[0] = 1.0; break;
+  }
+}
+// lower Cholesky factor of a PSD MP x MP matrix with psd_chol's zero-diagonal rule (src/psd_chol.cpp:5-18), MP <= 2
+template <int MP>
+__device__ __forceinline__ void psd_chol_small(const double (&P)[MP * MP], double (&L)[MP * MP]) {
+  const double eps = 2.220446049250313e-16;
+#pragma unroll
+  for (int q = 0; q < MP * MP; q++) L[q] = 0.0;
+  if constexpr (MP == 1) {
+    if (P[0] > fmax(eps, eps * P[0])) L[0] = sqrt(P[0]);
+  } else {
+    const double thr = fmax(eps, eps * 2.0 * fmax(P[0], P[3]));
+    const bool n0 = P[0] > thr, n1 = P[3] > thr;
+    if (n0 && n1) {
+      L[0] = sqrt(P[0]);
+      L[1] = P[1] / L[0];
+      L[3] = sqrt(P[3] - L[1] * L[1]);
+    } else if (n0) {
+      L[0] = sqrt(P[0]);
+    } else if (n1) {
+      L[3] = sqrt(P[3]);
+    }
+  }
+}
+// dmvnorm(x, mean, S, lwr = false, logd = true) for a covariance S (src/dmvnorm.cpp:4-37), MP <= 2
+template <int MP>
+__device__ __forceinline__ double dmvnorm_cov_small(const double (&x)[MP], const double (&mean)[MP], const double (&S)[MP * MP]) {
+  const double l2pi = 1.8378770664093453;  // log(2 pi)
+  if constexpr (MP == 1) {
+    const double d = x[0] - mean[0];
+    return -0.5 * (l2pi + fast_log(S[0]) + d * d / S[0]);
+  } else {
+    const double eps = 2.220446049250313e-16;
+    const bool n0 = S[0] > eps, n1 = S[3] > eps;
+    const double z0 = x[0] - mean[0], z1 = x[1] - mean[1];
+    if (n0 && n1) {
+      const double l00 = sqrt(S[0]), l10 = S[1] / l00, l11 = sqrt(S[3] - l10 * l10);
+      const double w0 = z0 / l00, w1 = (z1 - l10 * w0) / l11;
+      return -fast_log(l00) - fast_log(l11) - l2pi - 0.5 * (w0 * w0 + w1 * w1);
+    } else if (n0 || n1) {
+      const double v = n0 ? S[0] : S[3], z = n0 ? z0 : z1, l = sqrt(v), w = z / l;
+      return -fast_log(l) - 0.5 * l2pi - 0.5 * w * w;
+    }
+    return 0.0;
+  }
+}
+// dmvnorm(x, mean, L, lwr = true, logd = true): L is a factor (src/dmvnorm.cpp:9-11, 23-25)
+template <int MP>
+__device__ __forceinline__ double dmvnorm_lwr_small(const double (&x)[MP], const double (&mean)[MP], const double (&L)[MP * MP]) {
+  if constexpr (MP == 1) {
+    const double q = (x[0] - mean[0]) / L[0];
+    return -0.5 * (1.8378770664093453 + 2.0 * fast_log(L[0]) + q * q);
+  } else {
+    double S[MP * MP];
+#pragma unroll
+    for (int j = 0; j < MP; j++)
+#pragma unroll
+      for (int i = 0; i < MP; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < MP; q++) acc += L[i + MP * q] * L[j + MP * q];
+        S[i + MP * j] = acc;
+      }
+    return dmvnorm_cov_small<MP>(x, mean, S);
+  }
+}
+// the EKF proposal of one particle: at = T(anc); (att, Lf) = proposal mean and factor for the step to time tn
+template <int MP>
+__device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, const double* __restrict__ row, bool last,
+                                              const double (&anc)[MP], double (&at)[MP], double (&att)[MP], double (&Lf)[MP * MP]) {
+  const int id = (int)fp[FP_ID];
+  nlg_T_fn<MP>(id, fp, anc, at);
+  double Pt[MP * MP];
+#pragma unroll
+  for (int q = 0; q < MP * MP; q++) Pt[q] = 0.0;
+#pragma unroll
+  for (int j = 0; j < MP; j++) Pt[j + MP * j] = fp[FP_R + j] * fp[FP_R + j];
+  if (last) {  // the final, never-weighted slot: the reference uses P_t itself as the factor (:1223-1226)
+#pragma unroll
+    for (int j = 0; j < MP; j++) att[j] = at[j];
+#pragma unroll
+    for (int q = 0; q < MP * MP; q++) Lf[q] = Pt[q];
+    return;
+  }
+  double Ptt[MP * MP];
+  if (row[RH_FLAG] != 0.0) {  // ekf_update_step (:1264-1293)
+    const double y = row[ROW_HDR + OB_Y], H = fp[FP_H];
+    double Zg[MP], PZ[MP], K[MP];
+    nlg_Z_gn<MP>(id, at, Zg);
+    double F = H * H;
+#pragma unroll
+    for (int i = 0; i < MP; i++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < MP; j++) acc += Pt[i + MP * j] * Zg[j];
+      PZ[i] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < MP; j++) F += Zg[j] * PZ[j];
+    const double icf = 1.0 / sqrt(F), v = y - nlg_Z_fn<MP>(id, at);
+#pragma unroll
+    for (int i = 0; i < MP; i++) { K[i] = PZ[i] * icf * icf; att[i] = at[i] + K[i] * v; }
+    double IKZ[MP * MP], tmp[MP * MP];
+#pragma unroll
+    for (int j = 0; j < MP; j++)
+#pragma unroll
+      for (int i = 0; i < MP; i++) IKZ[i + MP * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
+#pragma unroll
+    for (int j = 0; j < MP; j++)
+#pragma unroll
+      for (int i = 0; i < MP; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < MP; q++) acc += IKZ[i + MP * q] * Pt[q + MP * j];
+        tmp[i + MP * j] = acc;
+      }
+#pragma unroll
+    for (int j = 0; j < MP; j++)
+#pragma unroll
+      for (int i = 0; i < MP; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < MP; q++) acc += tmp[i + MP * q] * IKZ[j + MP * q];
+        Ptt[i + MP * j] = acc + K[i] * H * H * K[j];
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < MP; j++) att[j] = at[j];
+#pragma unroll
+    for (int q = 0; q < MP * MP; q++) Ptt[q] = Pt[q];
+  }
+  psd_chol_small<MP>(Ptt, Lf);
+}
+template <int MP>
+__device__ __forceinline__ void functor_ekpf_propagate(const double* __restrict__ fp, const double* __restrict__ row_next, bool last,
+                                                       RngKey key, const u32x4& blk0, uint32_t t, uint32_t i,
+                                                       const double (&anc)[MP], double (&x)[MP]) {
+  double at[MP], att[MP], Lf[MP * MP], z[MP];
+  ekpf_proposal<MP>(fp, row_next, last, anc, at, att, Lf);
+  rng_normals_blk<MP>(blk0, key, RNG_TRANSITION, t, i, z);
+#pragma unroll
+  for (int j = 0; j < MP; j++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < MP; c++) acc += Lf[j + MP * c] * z[c];
+    x[j] = att[j] + acc;
+  }
+}
+// EKPF weight at time t (:1178-1182 for t = 0, :1236-1244 after): `init` = [a1 | P1 | att1 | L1] of the filter
+template <int MP>
+__device__ __forceinline__ double functor_ekpf_weight(const double* __restrict__ fp, const double* __restrict__ row,
+                                                      const double* __restrict__ init, int t, const double (&x)[MP],
+                                                      const double (&anc)[MP]) {
+  if (row[RH_FLAG] == 0.0) return 0.0;
+  double w = functor_log_weight<MP>(fp, row, x);
+  if (t == 0) {
+    double a1[MP], P1[MP * MP], att1[MP], L1[MP * MP];
+#pragma unroll
+    for (int j = 0; j < MP; j++) { a1[j] = init[j]; att1[j] = init[MP + MP * MP + j]; }
+#pragma unroll
+    for (int q = 0; q < MP * MP; q++) { P1[q] = init[MP + q]; L1[q] = init[2 * MP + MP * MP + q]; }
+    return w + dmvnorm_cov_small<MP>(x, a1, P1) - dmvnorm_lwr_small<MP>(x, att1, L1);
+  }
+  double at[MP], att[MP], Lf[MP * MP], RR[MP * MP];
+  ekpf_proposal<MP>(fp, row, false, anc, at, att, Lf);
+#pragma unroll
+  for (int q = 0; q < MP * MP; q++) RR[q] = 0.0;
+#pragma unroll
+  for (int j = 0; j < MP; j++) RR[j + MP * j] = fp[FP_R + j] * fp[FP_R + j];
+  return w + dmvnorm_cov_small<MP>(x, at, RR) - dmvnorm_lwr_small<MP>(x, att, Lf);
+}
+
 }  // namespace bssm

@@ -51,7 +51,8 @@ def _warn_if_degenerate(rc):
         warnings.warn("Particle filtering stopped prematurely due to nonfinite log-likelihood.")
 
 
-def _functor_filter(model: BssmModel, particles: int, seed: int, smoother: bool, L, return_indices: bool, psi: bool = False):
+def _functor_filter(model: BssmModel, particles: int, seed: int, smoother: bool, L, return_indices: bool, psi: bool = False,
+                    ekpf: bool = False):
     """ssm_nlg / ssm_sde bootstrap filter (R/bootstrap_filter.R:126-202) and bsf smoother (R/particle_smoother.R:193-291)."""
     sde = model.inherits("ssm_sde")
     if sde:
@@ -74,7 +75,10 @@ def _functor_filter(model: BssmModel, particles: int, seed: int, smoother: bool,
     if indices is not None:
         out.indices = indices.ctypes.data_as(_lib.c_u32_p)
     L_ = _lib.lib()
-    if psi:
+    if ekpf:
+        fn = L_.bssm_ekpf_smoother_nlg if smoother else L_.bssm_ekpf_nlg
+        rc = fn(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed), C.byref(out))
+    elif psi:
         rc = L_.bssm_psi_smoother_nlg(C.byref(smod), C.c_uint32(particles), C.c_uint32(seed),
                                       C.c_int32(int(model.get("max_iter", 100))), C.c_double(float(model.get("conv_tol", 1e-8))),
                                       C.byref(out))
@@ -138,8 +142,10 @@ def particle_smoother(model: BssmModel, particles: int, method: str = "psi", see
     if method not in ("psi", "bsf", "ekf"):
         raise ValueError("'arg' should be one of 'psi', 'bsf', 'ekf'")
     if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
-        if method == "ekf":
-            raise NotImplementedError("the EKF particle filter of ssm_nlg is not built (SURVEY.md 2a N22)")
+        if method == "ekf":  # R/particle_smoother.R:222-238 -> ekpf_smoother (src/R_ekpf.cpp:56-100)
+            if not model.inherits("ssm_nlg"):
+                raise ValueError("Method 'ekf' is only applicable to ssm_nlg models.")
+            return _functor_filter(model, particles, seed, True, L, return_indices, ekpf=True)
         psi = method == "psi" and model.inherits("ssm_nlg")
         return _functor_filter(model, particles, seed, True, L, return_indices, psi=psi)
     if method == "ekf":
@@ -181,8 +187,10 @@ def logLik(model: BssmModel, particles: int, method: str = "psi", seed: int | No
     Gaussian-approximation log-likelihood."""
     particles = check_intmax(particles, "particles", positive=False)
     seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
-    if method not in ("psi", "bsf", "spdk"):
-        raise ValueError("'arg' should be one of 'psi', 'bsf', 'spdk'")
+    if method not in ("psi", "bsf", "spdk", "ekf"):
+        raise ValueError("'arg' should be one of 'psi', 'bsf', 'spdk', 'ekf'")
+    if method == "ekf" and not model.inherits("ssm_nlg"):
+        raise ValueError("Method 'ekf' is only applicable to ssm_nlg models.")
     if method == "spdk":
         raise NotImplementedError("SPDK importance sampling is not a particle-filter path (SURVEY.md 2a N23).")
     if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
@@ -203,7 +211,7 @@ def logLik_batch(model: BssmModel, particles: int, n_rep: int, method: str = "bs
     if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
         smod, keep = _lib.pack_fn_model(model, L)
         out = np.zeros(n_rep)
-        meth = 1 if (method == "psi" and model.inherits("ssm_nlg")) else 2
+        meth = 1 if (method == "psi" and model.inherits("ssm_nlg")) else (4 if (method == "ekf" and model.inherits("ssm_nlg")) else 2)
         rc = _lib.check(_lib.lib().bssm_fn_loglik_batch(C.byref(smod), C.c_uint32(particles), C.c_uint32(meth), C.c_uint32(seed),
                                                         C.c_uint32(stream0), C.c_uint32(n_rep), _lib.dptr(out)))
         _warn_if_degenerate(rc)
@@ -261,3 +269,13 @@ def stratified_sample(p, r, N=None):
     _lib.check(_lib.lib().bssm_stratified_sample(_lib.dptr(p), _lib.dptr(r), C.c_uint32(p.size), C.c_uint32(N),
                                                   out.ctypes.data_as(_lib.c_u32_p)))
     return out, p
+
+
+def ekpf_filter(model: BssmModel, particles: int, seed: int | None = None, return_indices: bool = False):
+    """R/ekpf_filter.R -> ekpf (src/R_ekpf.cpp:11-54): the EKF-proposal particle filter of an ssm_nlg model; outputs as
+    bootstrap_filter."""
+    particles = check_intmax(particles, "particles")
+    seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
+    if not model.inherits("ssm_nlg"):
+        raise TypeError("ekpf_filter is for ssm_nlg models")
+    return _functor_filter(model, particles, seed, False, None, return_indices, ekpf=True)

@@ -46,7 +46,7 @@ enum { BSSM_SVM = 0, BSSM_POISSON = 1, BSSM_BINOMIAL = 2, BSSM_NEGBIN = 3, BSSM_
 /* model_type(): R/model_type.R:1-16 (non-gaussian branch; gaussian branch uses 1..3 too) */
 enum { BSSM_SSM_MNG = 0, BSSM_SSM_UNG = 1, BSSM_BSM_NG = 2, BSSM_SVM_MODEL = 3, BSSM_AR1_NG = 4 };
 /* sampling_method: src/model_ssm_ung.cpp:163 */
-enum { BSSM_PSI = 1, BSSM_BSF = 2 };
+enum { BSSM_PSI = 1, BSSM_BSF = 2, BSSM_EKPF = 4 };  /* 4: EKF-proposal particle filter, ssm_nlg only (src/model_ssm_nlg.cpp:237-238) */
 
 /* Fields read by ssm_ung::ssm_ung (src/model_ssm_ung.cpp:9-32) and, for gaussian = TRUE,
  * ssm_ulg::ssm_ulg (src/model_ssm_ulg.cpp:8-38).  "(1|n)": 1 when time-invariant, n
@@ -178,6 +178,11 @@ int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t sam
  * ssm_nlg model.  max_iter / conv_tol are the mode-search controls of ssm_nlg (src/model_ssm_nlg.cpp:19-20). */
 int bssm_psi_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, int32_t max_iter, double conv_tol,
                           bssm_filter_out* out);
+/* replaces _bssm_ekpf / _bssm_ekpf_smoother (18 args each, src/R_ekpf.cpp:11-100): the EKF-proposal particle filter
+ * ssm_nlg::ekf_filter (src/model_ssm_nlg.cpp:1148-1293) of a built-in model; outputs as bssm_bsf / bssm_bsf_smoother.
+ * Its log-likelihood alone: bssm_fn_loglik_batch with sampling_method = BSSM_EKPF. */
+int bssm_ekpf_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);
+int bssm_ekpf_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);
 /* host-side psi set-up of ssm_nlg on its own (EKF, mode search, linearised model, conditional factors); is_mode m x n
  * selects approximate_for_is.  Outputs (any may be NULL): mode m x n, scales n, approx_loglik, alphahat m x (n+1),
  * Vt / Ct m x m x (n+1), linearised Z_t m x n, T_t m x m x n, D_t n, C_t m x n. */

@@ -1521,6 +1521,94 @@ void orc_fn_setup_free(orc_fn_setup *s) {
   free(s->Z); free(s->T); free(s->D); free(s->C); free(s->mode); free(s->scales); free(s->alphahat); free(s->Vt); free(s->Ct); free(s);
 }
 
+/* ================================================================== */
+/* ssm_nlg EKF-based particle filter (van der Merwe et al.):           */
+/* src/model_ssm_nlg.cpp:1148-1262 (ekf_filter), :1264-1293 (ekf_update_step) */
+/* ================================================================== */
+static void fn_ekf_update_step(const orc_fn_model *mod, double y, const double *at, const double *Pt, int m, double *att, double *Ptt) {
+  if (isfinite(y)) {
+    double Zg[2], PZ[2] = {0, 0}, K[2], H = fn_H(mod), F = H * H;
+    fn_Zg(mod, at, Zg);
+    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += Pt[i + m * j] * Zg[j];
+    for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
+    double cF = sqrt(F), v = y - fn_Z(mod, at);
+    for (int i = 0; i < m; i++) K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF);
+    for (int i = 0; i < m; i++) att[i] = at[i] + K[i] * v;
+    double IKZ[4], tmp[4], tmp2[4];
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
+    mat_mul(IKZ, Pt, m, m, m, tmp); mat_mul_bt(tmp, IKZ, m, m, m, tmp2);
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Ptt[i + m * j] = tmp2[i + m * j] + K[i] * H * H * K[j];
+  } else {
+    memcpy(att, at, sizeof(double) * m); memcpy(Ptt, Pt, sizeof(double) * m * m);
+  }
+}
+/* dmvnorm(x, mean, sigma, lwr = true, logd = true): sigma is a factor (src/dmvnorm.cpp:9-11, 23-25) */
+static double dmvnorm_lwr(const double *x, const double *mean, const double *L, int d) {
+  if (d == 1) return -0.5 * (log(2.0 * ORC_PI) + 2.0 * log(L[0]) + pow((x[0] - mean[0]) / L[0], 2));
+  double S[ORC_MAXM * ORC_MAXM];
+  mat_mul_bt(L, L, d, d, d, S);
+  return dmvnorm_cov(x, mean, S, d);
+}
+
+double orc_fn_ekpf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rng, double *alpha, double *weights, unsigned *indices) {
+  const int n = mod->n, m = mod->id == 1 ? 2 : 1, mm = m * m;
+  if (mod->id > 4) return NAN; /* ssm_nlg only */
+  double a1[2], P1d[4], P1[4] = {0, 0, 0, 0}, rd[2], RR[4] = {0, 0, 0, 0}, um[2];
+  fn_a1P1(mod, a1, P1d); fn_Rdiag(mod, rd);
+  if (m == 1) { P1[0] = P1d[0]; RR[0] = rd[0] * rd[0]; } else { P1[0] = P1d[0]; P1[3] = P1d[3]; RR[0] = rd[0] * rd[0]; RR[3] = rd[1] * rd[1]; }
+  double *nw = (double *)malloc(sizeof(double) * N), *lw = (double *)malloc(sizeof(double) * N), *r = (double *)malloc(sizeof(double) * N);
+  double *atmp = (double *)malloc(sizeof(double) * N * m), *att = (double *)malloc(sizeof(double) * N * m);
+  double *Lp = (double *)malloc(sizeof(double) * N * mm);
+  double att1[2], Ptt1[4], L[4];
+  fn_ekf_update_step(mod, mod->y[0], a1, P1, m, att1, Ptt1); /* :1157-1158 */
+  orc_psd_chol(Ptt1, m, L);                                   /* :1161 */
+  for (unsigned i = 0; i < N; i++) {                          /* :1163-1172 */
+    rng_normals(rng, 0, 0, i, m, um);
+    for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += L[j + m * c] * um[c]; A_(j, 0, i) = att1[j] + s; }
+  }
+  double loglik = 0.0, inc;
+  if (isfinite(mod->y[0])) {                                  /* :1178-1196 */
+    for (unsigned i = 0; i < N; i++)
+      lw[i] = fn_log_obs(mod, 0, &A_(0, 0, i)) + dmvnorm_cov(&A_(0, 0, i), a1, P1, m) - dmvnorm_lwr(&A_(0, 0, i), att1, L, m);
+    if (!normalise_step(lw, N, weights, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+    loglik = inc;
+  } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
+  for (int t = 0; t < n; t++) {
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    for (unsigned i = 0; i < N; i++) {                        /* :1212-1227 */
+      double at[2], Ptt[4];
+      for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
+      fn_T(mod, atmp + (size_t)m * i, at);
+      if (t < n - 1) {
+        fn_ekf_update_step(mod, mod->y[t + 1], at, RR, m, att + (size_t)m * i, Ptt);
+        orc_psd_chol(Ptt, m, Lp + (size_t)mm * i);
+      } else { /* the last, never-weighted slot uses Pt itself as the factor (:1223-1226) */
+        memcpy(att + (size_t)m * i, at, sizeof(double) * m); memcpy(Lp + (size_t)mm * i, RR, sizeof(double) * mm);
+      }
+    }
+    for (unsigned i = 0; i < N; i++) {                        /* :1229-1235 */
+      rng_normals(rng, 2, t, i, m, um);
+      const double *Li = Lp + (size_t)mm * i;
+      for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += Li[j + m * c] * um[c]; A_(j, t + 1, i) = att[j + (size_t)m * i] + s; }
+    }
+    double *wcol = weights + (size_t)N * (t + 1);
+    if ((t < n - 1) && isfinite(mod->y[t + 1])) {             /* :1236-1256 */
+      for (unsigned i = 0; i < N; i++) {
+        double mean[2];
+        fn_T(mod, atmp + (size_t)m * i, mean);
+        lw[i] = fn_log_obs(mod, t + 1, &A_(0, t + 1, i)) + dmvnorm_cov(&A_(0, t + 1, i), mean, RR, m) -
+                dmvnorm_lwr(&A_(0, t + 1, i), att + (size_t)m * i, Lp + (size_t)mm * i, m);
+      }
+      if (!normalise_step(lw, N, wcol, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+      loglik += inc;
+    } else for (unsigned i = 0; i < N; i++) { wcol[i] = 1.0; nw[i] = 1.0 / N; }
+  }
+done:
+  free(nw); free(lw); free(r); free(atmp); free(att); free(Lp);
+  return loglik;
+}
+
 /* extended Kalman filter with iekf_iter = 0: src/model_ssm_nlg.cpp:284-381 (p = 1) */
 static int fn_ekf_ll(const orc_fn_model *mod, double *at, double *att, double *Pt, double *Ptt, double *loglik, int iekf_iter) {
   double ll = 0.0;

@@ -421,6 +421,23 @@ def _pack_fn(model):
     return s, [y]
 
 
+def fn_ekpf_filter(model: dict, nsim: int, seed=1, stream=0):
+    """ssm_nlg::ekf_filter (src/model_ssm_nlg.cpp:1148-1293)"""
+    L = lib()
+    L.orc_fn_ekpf_filter.restype = C.c_double
+    s = OrcFn()
+    y = np.ascontiguousarray(model["y"], dtype=np.float64)
+    s.id, s.n, s.y = int(model["model_id"]), y.size, _p(y)
+    for i, v in enumerate(np.asarray(model["theta"], dtype=float)): s.theta[i] = v
+    for i, v in enumerate(np.asarray(model.get("known_params", []), dtype=float)): s.known[i] = v
+    rng, _ = make_rng(seed, stream)
+    n, m = y.size, 2 if s.id == 1 else 1
+    alpha = np.zeros((m, n + 1, nsim), order="F"); weights = np.zeros((nsim, n + 1), order="F")
+    indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+    ll = L.orc_fn_ekpf_filter(C.byref(s), C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights), indices.ctypes.data_as(c_uint_p))
+    return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices)
+
+
 def fn_psi_setup(model: dict, is_mode=None, max_iter=100, conv_tol=1e-8):
     """is_mode: m x n state mode (mode_storage of the approximate chain) or None"""
     L = lib()

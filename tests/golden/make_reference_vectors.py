@@ -99,7 +99,8 @@ out = {
         "y": list(growth_series()), "theta": [0.0, float(np.log(0.05)), 0.0],   # vignette theta (H, R1, R2) = (1, 0.05, 1), unlogged there
         "known_params": [0.1, 500.0, -1.5, 50.0, 1.0, 100.0],
         "loglik_mean_sd": {"psi": {"10": [-606.2218, 0.1201], "100": [-606.2149, 0.0425], "1000": [-606.2138, 0.0157]},
-                           "bsf": {"100": [-611.0850, 3.7534], "1000": [-606.6395, 0.9176]}},
+                           "bsf": {"100": [-611.0850, 3.7534], "1000": [-606.6395, 0.9176]},
+                           "ekf": {"100": [-607.7500, 1.8476], "1000": [-606.3727, 0.5524]}},   # EKPF N = 10: -629.56 (29.4), heavy-tailed
         "smoother_mean_sd": study_table("gm", ["logLik", "alpha_11", "alpha_21", "V_11", "V_21", "alpha_1n", "alpha_2n", "V_1n", "V_2n"]),
         "truth_bsf_1e5": {"logLik": -606.162991, "alpha_11": -1.2331292, "alpha_21": 50.2930218, "V_11": 0.0509254108,
                           "V_21": 0.695909774, "alpha_1n": -1.11484755, "alpha_2n": 497.234985, "V_1n": 0.252791374, "V_2n": 0.619154356},
@@ -108,7 +109,8 @@ out = {
         "source": "vignettes/psi_pf.Rmd:316-404, vignettes/psi_pf_experiments/{table3,ar_truth}.rds",
         "y": list(ar_exp_series()), "theta": [0.0, 0.95, float(np.log(0.1)), 0.0],  # built-in nlg_ar_exp: (mu, rho, log sigma, log H)
         "loglik_mean_sd": {"psi": {"10": [-143.6263, 0.2560], "100": [-143.6000, 0.0932], "1000": [-143.5959, 0.0320]},
-                           "bsf": {"10": [-144.2271, 1.2130], "100": [-143.6519, 0.3493], "1000": [-143.6016, 0.1091]}},
+                           "bsf": {"10": [-144.2271, 1.2130], "100": [-143.6519, 0.3493], "1000": [-143.6016, 0.1091]},
+                           "ekf": {"10": [-144.1348, 1.1224], "100": [-143.6475, 0.3316], "1000": [-143.6014, 0.1045]}},
         "smoother_mean_sd": study_table("ar", ["logLik", "alpha_1", "V_1", "alpha_n", "V_n"]),
         "truth_bsf_1e6": {"logLik": -143.594352, "alpha_1": -0.137113564, "V_1": 0.0677577735, "alpha_n": 0.206234604, "V_n": 0.0518723271},
     },

@@ -133,3 +133,22 @@ def test_nlg_post_correct(oracle):
     assert np.allclose(out["weights"], w, rtol=1e-8)
     wc = w * counts
     assert np.allclose(out["alphahat"], (np.tensordot(ah, wc, axes=([2], [0])) / wc.sum()).T, rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+@pytest.mark.parametrize("name", ["nlg_growth", "nlg_ar_exp", "nlg_sin_exp", "nlg_linear_gaussian"])
+@pytest.mark.parametrize("N", [20, 700])
+def test_ekpf_filter_matches_oracle(oracle, monkeypatch, name, N, path):
+    """EKF-proposal particle filter (src/model_ssm_nlg.cpp:1148-1293) against its oracle restatement, same stream"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    model, _ = MODELS[name]
+    out = F.ekpf_filter(model, N, seed=6, return_indices=True)
+    ref = oracle.fn_ekpf_filter(model, N, seed=6)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    sm = F.particle_smoother(model, N, method="ekf", seed=6)
+    assert abs(sm["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+    ll = F.logLik(model, N, method="ekf", seed=6)
+    assert abs(ll - ref["logLik"]) <= 1e-9 * model.n
