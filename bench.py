@@ -47,7 +47,7 @@ def pmc_traffic(R, N, ppt):
     return None
 
 
-def post_correct_phase(rank, world, dist, cdev="cuda", reps=3):
+def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=False):
     """SURVEY.md 8d config C5 (north_star: IS post-correction sharded over the GPUs of a node): 2 340 retained draws of
     the ssm_nlg growth model, psi-APF N = 4096, T = 300, split into contiguous blocks over the ranks (strong scaling of
     one job), log-weights all-gathered over RCCL.  Every rank takes part in every collective whatever happens locally
@@ -110,7 +110,21 @@ def post_correct_phase(rank, world, dist, cdev="cuda", reps=3):
         if it > 0:
             times.append(el)
     best = min(times)
-    return {"workload": "C5: ssm_nlg growth, T=300, m=2, %d retained draws, psi-APF N=%d, IS2 weights (output theta), draws split in "
+    extra = {}
+    if cpu_baseline and world == 1:
+        # the reference-equivalent CPU path of THIS phase: one psi-APF per draw, OpenMP static schedule over the draws on
+        # all host cores (src/approx_mcmc.cpp:364-369), on a bounded sample of the same draws; also the parity check
+        from oracle import oracle as O
+        cores = os.cpu_count() or 1
+        sample = min(ns, max(64, 2 * cores))
+        t0 = time.perf_counter()
+        ref = O.fn_is_logweights(model, theta[:sample], modes[:, :sample], nsim, seed=1, first_stream=0, n_threads=cores)
+        ec = time.perf_counter() - t0
+        extra["cpu_baseline"] = {"value": sample * float(nsim) * n / ec, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+                                 "sample": "%d of the %d draws, OpenMP schedule(static) over draws with %d threads, gcc -O2, %.1f s"
+                                           % (sample, ns, cores, ec)}
+        extra["parity_max_abs_dlogw_vs_oracle"] = float(np.max(np.abs(weights[:sample] - ref)))
+    return {**extra, "workload": "C5: ssm_nlg growth, T=300, m=2, %d retained draws, psi-APF N=%d, IS2 weights (output theta), draws split in "
                         "contiguous blocks over the ranks, log-weights all-gathered (RCCL)" % (ns, nsim),
             "scaling": "strong", "n_gpus": world, "seconds": best, "draws_per_s": ns / best,
             "value": ns * float(nsim) * n / best, "unit": "particle-steps/s", "host_threads_per_rank": threads,
@@ -272,7 +286,7 @@ def main():
     if not args.no_post_correct:
         # ---- the sharded half of the path (all ranks): IS post-correction, SURVEY.md 8e
         try:
-            pc = post_correct_phase(rank, world, dist, cdev)
+            pc = post_correct_phase(rank, world, dist, cdev, cpu_baseline=not args.no_cpu_baseline)
         except Exception as e:  # noqa: BLE001
             pc = {"error": repr(e)[:200]}
         if rank == 0:

@@ -1521,6 +1521,30 @@ void orc_fn_setup_free(orc_fn_setup *s) {
   free(s->Z); free(s->T); free(s->D); free(s->C); free(s->mode); free(s->scales); free(s->alphahat); free(s->Vt); free(s->Ct); free(s);
 }
 
+/* approx_mcmc::is_correction_psi<ssm_nlg> reduced to its log-weights (src/approx_mcmc.cpp:353-427, output_type 3): one
+ * psi-APF per retained draw, OpenMP parallel for schedule(static) over the draws with n_threads threads exactly as the
+ * reference (:364-369).  Used as the multi-core CPU baseline of the post-correction phase in bench.py. */
+int orc_fn_is_logweights(const orc_fn_model *mods, int count, const double *modes, unsigned nsim, uint32_t seed,
+                         uint32_t first_stream, int n_threads, double *loglik) {
+  int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1) reduction(+ : bad)
+  for (int i = 0; i < count; i++) {
+    const int n = mods[i].n, m = mods[i].id == 1 ? 2 : 1;
+    orc_fn_setup *su = orc_fn_setup_alloc(n, m);
+    double *alpha = (double *)malloc(sizeof(double) * (size_t)m * (n + 1) * nsim);
+    double *weights = (double *)malloc(sizeof(double) * (size_t)nsim * (n + 1));
+    unsigned *indices = (unsigned *)malloc(sizeof(unsigned) * (size_t)nsim * n);
+    orc_rng rng;
+    memset(&rng, 0, sizeof(rng));
+    rng.seed = seed; rng.stream = first_stream + (uint32_t)i;
+    if (orc_fn_psi_setup(&mods[i], modes + (size_t)m * n * i, 0, 1e-8, su) != 0) { loglik[i] = -INFINITY; bad++; }
+    else loglik[i] = orc_fn_psi_filter(&mods[i], su, nsim, &rng, alpha, weights, indices);
+    free(alpha); free(weights); free(indices);
+    orc_fn_setup_free(su);
+  }
+  return bad;
+}
+
 /* ================================================================== */
 /* ssm_nlg EKF-based particle filter (van der Merwe et al.):           */
 /* src/model_ssm_nlg.cpp:1148-1262 (ekf_filter), :1264-1293 (ekf_update_step) */

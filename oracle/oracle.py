@@ -421,6 +421,26 @@ def _pack_fn(model):
     return s, [y]
 
 
+def fn_is_logweights(model: dict, theta, modes, nsim: int, seed=1, first_stream=0, n_threads=1):
+    """log-weights of the psi-APF IS correction of an ssm_nlg model, one draw per row of theta, OpenMP over the draws with
+    n_threads threads as approx_mcmc::is_correction_psi does (src/approx_mcmc.cpp:364-369)"""
+    L = lib()
+    theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+    cnt = theta.shape[0]
+    y = np.ascontiguousarray(model["y"], dtype=np.float64)
+    mods = (OrcFn * cnt)()
+    for i in range(cnt):
+        s = mods[i]
+        s.id, s.n, s.y = int(model["model_id"]), y.size, _p(y)
+        for q, v in enumerate(theta[i]): s.theta[q] = v
+        for q, v in enumerate(np.asarray(model.get("known_params", []), dtype=float)): s.known[q] = v
+    modes = np.asfortranarray(modes, dtype=np.float64)
+    out = np.zeros(cnt)
+    L.orc_fn_is_logweights(mods, C.c_int(cnt), _p(modes), C.c_uint(nsim), C.c_uint32(seed), C.c_uint32(first_stream),
+                           C.c_int(n_threads), _p(out))
+    return out
+
+
 def fn_ekpf_filter(model: dict, nsim: int, seed=1, stream=0):
     """ssm_nlg::ekf_filter (src/model_ssm_nlg.cpp:1148-1293)"""
     L = lib()
