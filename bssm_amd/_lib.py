@@ -29,7 +29,8 @@ class UngModel(C.Structure):
 class FnModel(C.Structure):
     _fields_ = [("model_id", C.c_int32), ("n", C.c_int32), ("y", c_double_p), ("theta", c_double_p), ("n_theta", C.c_int32),
                 ("known_params", c_double_p), ("n_known", C.c_int32), ("x0", C.c_double), ("positive", C.c_int32),
-                ("L", C.c_int32)]
+                ("L", C.c_int32), ("user_slot", C.c_int32), ("n_states", C.c_int32), ("H", C.c_double),
+                ("R_diag", C.c_double * 2), ("a1", C.c_double * 2), ("P1", C.c_double * 4)]
 
 
 def pack_fn_model(model, L=None):
@@ -41,7 +42,33 @@ def pack_fn_model(model, L=None):
     s.known_params, s.n_known = (dptr(kp) if kp.size else None), kp.size
     s.x0, s.positive = float(model.get("x0", 0.0)), int(bool(model.get("positive", False)))
     s.L = int(model.get("L", 0) if L is None else L)
+    if s.model_id >= 7:  # user-defined: compiled at run time, numbers for the state-independent parts
+        s.user_slot = user_model_slot(model["user_source"], int(model.get("n_states", 1)))
+        s.n_states = int(model.get("n_states", 1))
+        if s.model_id == 7:
+            m = s.n_states
+            s.H = float(model["H"])
+            for j, v in enumerate(np.asarray(model["R_diag"], dtype=float).reshape(-1)[:m]): s.R_diag[j] = v
+            for j, v in enumerate(np.asarray(model["a1"], dtype=float).reshape(-1)[:m]): s.a1[j] = v
+            for j, v in enumerate(np.asfortranarray(np.asarray(model["P1"], dtype=float).reshape(m, m)).reshape(-1, order="F")): s.P1[j] = v
     return s, [y, th, kp]
+
+
+_user_slots = {}
+
+
+def user_model_slot(source: str, n_states: int) -> int:
+    """Compile (cached by content hash) and load a user-defined model's device functions; returns the registry slot."""
+    key = (source, n_states)
+    if key not in _user_slots:
+        L = lib()
+        buf = C.create_string_buffer(4096)
+        check(L.bssm_user_model_build(source.encode(), C.c_int32(n_states), buf, C.c_int32(4096)))
+        slot = L.bssm_user_model_load(buf.value)
+        if slot < 1:
+            raise BssmAmdError(f"bssm_amd error {slot}: {L.bssm_amd_last_error().decode()}")
+        _user_slots[key] = slot
+    return _user_slots[key]
 
 
 class FilterOut(C.Structure):

@@ -1,6 +1,7 @@
 // api.cpp -- the C ABI (include/bssm_amd.h): host orchestration around the HIP kernels.
 // There is no CPU compute path in this library: every filter runs on the HIP device or fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <array>
@@ -237,6 +238,7 @@ struct DeviceBatch {
     HIP_TRY(hipMemcpy(fparbuf.p, fp.data(), fparbuf.bytes, hipMemcpyHostToDevice));
     fb.fpar = fparbuf.as<double>();
     fb.fpar_fstride = fp.size() > (size_t)bssm::FP_SIZE ? bssm::FP_SIZE : 0;
+    fb.user_slot = (int)fp[bssm::FP_SLOT];  // run-time compiled user model: its library holds the kernels
     return BSSM_OK;
   }
 
@@ -433,13 +435,16 @@ namespace {
 int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector<double>* fpar, int* m_out, int* k_out) {
   if (!mod || !mod->y || !mod->theta) return fail(BSSM_ERR_INVALID, "model, y, theta must be non-NULL");
   const int id = mod->model_id, n = mod->n;
-  if (id < bssm::FN_NLG_GROWTH || id > bssm::FN_SDE_POISSON_OU)
-    return fail(BSSM_ERR_UNSUPPORTED, "unknown built-in model id: arbitrary user snippets need a device JIT (SURVEY.md 8f rank 4)");
+  if (id < bssm::FN_NLG_GROWTH || id > bssm::FN_USER_SDE) return fail(BSSM_ERR_UNSUPPORTED, "unknown model id");
+  const bool user = id >= bssm::FN_USER_NLG;
   if (n < 1) return fail(BSSM_ERR_INVALID, "n must be positive");
-  const int need_theta[] = {0, 3, 4, 2, 1, 3, 3}, need_known[] = {0, 6, 0, 0, 0, 0, 0};
+  const int need_theta[] = {0, 3, 4, 2, 1, 3, 3, 0, 0}, need_known[] = {0, 6, 0, 0, 0, 0, 0, 0, 0};
   if (mod->n_theta < need_theta[id] || mod->n_known < need_known[id]) return fail(BSSM_ERR_INVALID, "theta / known_params too short for this model");
   if (mod->n_theta > 8 || mod->n_known > 8) return fail(BSSM_ERR_INVALID, "at most 8 theta / known_params");
-  const int m = id == bssm::FN_NLG_GROWTH ? 2 : 1, MP = m;
+  if (user && mod->user_slot < 1) return fail(BSSM_ERR_INVALID, "user-defined model without a loaded library (bssm_user_model_load)");
+  if (id == bssm::FN_USER_NLG && (mod->n_states < 1 || mod->n_states > 2)) return fail(BSSM_ERR_UNSUPPORTED, "user-defined ssm_nlg models: n_states must be 1 or 2");
+  if (id == bssm::FN_USER_NLG && !(mod->H > 0)) return fail(BSSM_ERR_INVALID, "user-defined ssm_nlg model: H must be positive");
+  const int m = id == bssm::FN_NLG_GROWTH ? 2 : (id == bssm::FN_USER_NLG ? mod->n_states : 1), MP = m;
   *m_out = m; *k_out = m;
   const double* th = mod->theta;
   const double* kp = mod->known_params;
@@ -458,7 +463,14 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
     case bssm::FN_NLG_LINEAR_GAUSSIAN: a1[0] = 0; P1[0] = 1; H = std::exp(th[0]); fp[bssm::FP_R] = 1.0; break;
     case bssm::FN_SDE_GBM: H = th[2]; if (mod->L < 0 || mod->L > 20) return fail(BSSM_ERR_INVALID, "L must be in 0..20"); break;
     case bssm::FN_SDE_POISSON_OU: fp[bssm::FP_R] = std::exp(th[2]); if (mod->L < 0 || mod->L > 20) return fail(BSSM_ERR_INVALID, "L must be in 0..20"); break;
+    case bssm::FN_USER_NLG:
+      for (int j = 0; j < m; j++) { a1[j] = mod->a1[j]; fp[bssm::FP_R + j] = mod->R_diag[j]; }
+      for (int q = 0; q < m * m; q++) P1[q] = mod->P1[q];
+      H = mod->H;
+      break;
+    case bssm::FN_USER_SDE: if (mod->L < 0 || mod->L > 20) return fail(BSSM_ERR_INVALID, "L must be in 0..20"); break;
   }
+  fp[bssm::FP_SLOT] = user ? mod->user_slot : 0;
   fp[bssm::FP_H] = H;
   fp[bssm::FP_LOGC] = -0.5 * (std::log(2.0 * 3.14159265358979323846) + 2.0 * std::log(H));
   // tables: no linear transition operands; one observation series carrying y (and lgamma(y + 1) for the Poisson model)
@@ -477,6 +489,19 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   }
   // initial factor: psd_chol(P1) (src/model_ssm_nlg.cpp:1072); the shipped P1 are diagonal
   ft->init.assign((size_t)MP + (size_t)MP * MP, 0.0);
+  if (id == bssm::FN_USER_NLG && m == 2 && (P1[1] != 0.0 || P1[2] != 0.0)) {  // a full 2 x 2 prior covariance
+    const double thr = std::max(2.220446049250313e-16, 2.220446049250313e-16 * 2 * std::max(P1[0], P1[3]));
+    ft->init[0] = a1[0]; ft->init[1] = a1[1];
+    if (P1[0] > thr && P1[3] > thr) {
+      const double l00 = std::sqrt(P1[0]), l10 = P1[1] / l00, d = P1[3] - l10 * l10;
+      if (!(d > 0)) return fail(BSSM_ERR_INVALID, "P1 is not positive semi-definite");
+      ft->init[MP + 0] = l00; ft->init[MP + 1] = l10; ft->init[MP + 3] = std::sqrt(d);
+    } else {
+      if (P1[0] > thr) ft->init[MP + 0] = std::sqrt(P1[0]);
+      if (P1[3] > thr) ft->init[MP + 3] = std::sqrt(P1[3]);
+    }
+    return BSSM_OK;
+  }
   for (int j = 0; j < m; j++) {
     ft->init[j] = a1[j];
     const double d = P1[j + m * j];
@@ -570,19 +595,19 @@ int bssm_ekpf_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t s
 }
 
 int bssm_bsf_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
-  if (model && model->model_id >= bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_nlg model id");
+  if (model && bssm::fn_is_sde(model->model_id)) return fail(BSSM_ERR_INVALID, "not an ssm_nlg model id");
   return run_functor(model, nsim, seed, false, out);
 }
 int bssm_bsf_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
-  if (model && model->model_id >= bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_nlg model id");
+  if (model && bssm::fn_is_sde(model->model_id)) return fail(BSSM_ERR_INVALID, "not an ssm_nlg model id");
   return run_functor(model, nsim, seed, true, out);
 }
 int bssm_bsf_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
-  if (model && model->model_id < bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");
+  if (model && !bssm::fn_is_sde(model->model_id)) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");
   return run_functor(model, nsim, seed, false, out);
 }
 int bssm_bsf_smoother_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
-  if (model && model->model_id < bssm::FN_SDE_GBM) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");
+  if (model && !bssm::fn_is_sde(model->model_id)) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");
   return run_functor(model, nsim, seed, true, out);
 }
 int bssm_psi_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, int32_t max_iter, double conv_tol,
@@ -769,6 +794,82 @@ int bssm_update_model_builtin(int model_type, const int32_t* flags, const double
   const std::string err = bssm::update_model_builtin(model_type, flags, theta, n_par, model, T, R, P1, a1, C, beta);
   if (!err.empty()) return fail(BSSM_ERR_UNSUPPORTED, err);
   return BSSM_OK;
+}
+
+// ------------------------------------------------------------------ user-defined models (run-time compiled)
+namespace {
+std::string library_dir() {
+  Dl_info info;
+  if (dladdr((const void*)&bssm_amd_version, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    const size_t k = p.rfind('/');
+    return k == std::string::npos ? std::string(".") : p.substr(0, k);
+  }
+  return ".";
+}
+uint64_t fnv1a(const std::string& s) {
+  uint64_t h = 1469598103934665603ull;
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+std::mutex g_user_mu;
+std::map<std::string, int> g_user_loaded;  // library path -> registry slot
+}  // namespace
+
+int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity) {
+  if (!source || !lib_path || lib_path_capacity < 16) return fail(BSSM_ERR_INVALID, "NULL argument");
+  if (n_states < 1 || n_states > 2) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 or 2");
+  const std::string dir = library_dir();
+  const char* env = std::getenv("BSSM_AMD_USER_CACHE");
+  const std::string cache = env ? std::string(env) : dir + "/user_models";
+  char hbuf[32];
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(std::string(bssm_amd_version()) + "|" + std::to_string(n_states) + "|" + source));
+  const std::string stem = cache + "/um_" + hbuf, snippet = stem + ".h", so = cache + "/libbssm_user_" + hbuf + ".so", log = stem + ".log";
+  if ((int)so.size() + 1 > lib_path_capacity) return fail(BSSM_ERR_INVALID, "lib_path buffer too small");
+  std::lock_guard<std::mutex> lk(g_user_mu);
+  if (FILE* f = std::fopen(so.c_str(), "rb")) {  // already built: the hash covers the source, n_states and the version
+    std::fclose(f);
+    std::strcpy(lib_path, so.c_str());
+    return BSSM_OK;
+  }
+  if (std::system(("mkdir -p '" + cache + "'").c_str()) != 0) return fail(BSSM_ERR_INVALID, "cannot create " + cache);
+  FILE* f = std::fopen(snippet.c_str(), "w");
+  if (!f) return fail(BSSM_ERR_INVALID, "cannot write " + snippet);
+  std::fputs(source, f);
+  std::fclose(f);
+  const char* hipcc = std::getenv("HIPCC");
+  const std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I'" + dir +
+                          "/csrc' -DBSSM_USER_M=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet + "\"' '" + dir +
+                          "/csrc/user_model_tu.hip' -o '" + so + ".tmp' > '" + log + "' 2>&1 && mv '" + so + ".tmp' '" + so + "'";
+  if (std::system(cmd.c_str()) != 0) {
+    std::string tail;
+    if (FILE* lf = std::fopen(log.c_str(), "r")) {
+      char buf[4096];
+      const size_t got = std::fread(buf, 1, sizeof buf - 1, lf);
+      buf[got] = 0;
+      tail = buf;
+      std::fclose(lf);
+    }
+    return fail(BSSM_ERR_INVALID, "compiling the user model failed (" + log + "):\n" + tail);
+  }
+  std::strcpy(lib_path, so.c_str());
+  return BSSM_OK;
+}
+
+int bssm_user_model_load(const char* lib_path) {
+  if (!lib_path) return fail(BSSM_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> lk(g_user_mu);
+  auto it = g_user_loaded.find(lib_path);
+  if (it != g_user_loaded.end()) return it->second;
+  void* h = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return fail(BSSM_ERR_INVALID, std::string("dlopen failed: ") + dlerror());
+  auto wg = (bssm::user_wg_launcher_t)dlsym(h, "bssm_user_launch_wg");
+  auto grid = (bssm::user_grid_launcher_t)dlsym(h, "bssm_user_launch_grid");
+  if (!wg || !grid) return fail(BSSM_ERR_INVALID, "the library does not export the user-model launchers");
+  const int slot = bssm::register_user_launchers(wg, grid);
+  if (slot < 1) return fail(BSSM_ERR_UNSUPPORTED, "too many user models loaded");
+  g_user_loaded[lib_path] = slot;
+  return slot;
 }
 
 // ------------------------------------------------------------------ exported helpers
@@ -985,6 +1086,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         HIP_TRY(fparb.alloc(F * bssm::FP_SIZE * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(fparb.p, hb, fparb.bytes, hipMemcpyHostToDevice, nullptr));
         db.fb.fpar = fparb.as<double>(); db.fb.fpar_fstride = bssm::FP_SIZE;
+        db.fb.user_slot = (int)J.fpar[bssm::FP_SLOT];
       }
       if (!J.amats.empty()) {
         const size_t as = (size_t)n * (m * m + m);

@@ -24,8 +24,17 @@
 
 namespace bssm {
 
-__global__ void loglik_finalize_kernel(double* __restrict__ loglik, const double* __restrict__ llinc,
-                                       const int* __restrict__ dead_at, int n, int F);
+// loglik[f] = sum_t llinc[f][t] in time order (the reference's accumulation order), -inf after a degenerate step.
+// (static: every translation unit that instantiates the step kernels carries its own copy, incl. run-time compiled
+// user models)
+static __global__ void loglik_finalize_kernel(double* __restrict__ loglik, const double* __restrict__ llinc,
+                                              const int* __restrict__ dead_at, int n, int F) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double acc = 0.0;
+  for (int t = 0; t < n; t++) acc += llinc[(size_t)f * (n + 1) + t];
+  loglik[f] = dead_at[f] ? -INFINITY : acc;
+}
 
 
 // ------------------------------------------------------------------------------------------
@@ -323,13 +332,20 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
       const bool fn = b.fpar != nullptr;
       if (fn && MP != KP) return hipErrorInvalidValue;
       switch (ppt) {
+#ifndef BSSM_USER_MODEL
         case 2: kern = fn ? (MP == KP ? pf_wg_kernel<MP, MP, 2, true, 1024> : nullptr) : pf_wg_kernel<MP, KP, 2, false, 1024>; break;
         case 4: kern = fn ? (MP == KP ? pf_wg_kernel<MP, MP, 4, true, 1024> : nullptr) : pf_wg_kernel<MP, KP, 4, false, 1024>; break;
         default: kern = fn ? (MP == KP ? pf_wg_kernel<MP, MP, 8, true, 1024> : nullptr) : pf_wg_kernel<MP, KP, 8, false, 1024>; break;
+#else
+        case 2: kern = fn ? pf_wg_kernel<MP, MP, 2, true, 1024> : nullptr; break;
+        case 4: kern = fn ? pf_wg_kernel<MP, MP, 4, true, 1024> : nullptr; break;
+        default: kern = fn ? pf_wg_kernel<MP, MP, 8, true, 1024> : nullptr; break;
+#endif
       }
       if (ppt > 8 || !kern) return hipErrorInvalidValue;
     }
   } else {
+#ifndef BSSM_USER_MODEL  // a user-model library only needs the functor (FN) variants: halves its compile time
   switch (ppt) {
     case 1: kern = pf_wg_kernel<MP, KP, 1>; break;
     case 2: kern = pf_wg_kernel<MP, KP, 2>; break;
@@ -338,6 +354,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
     default:
       if constexpr (MP <= 2) kern = pf_wg_kernel<MP, KP, 16>; else return hipErrorInvalidValue;
   }
+#endif
   if (b.fpar) {  // built-in non-linear / SDE functors: instantiated for the shapes the shipped models have
     if constexpr (MP == KP && MP <= 2) {
       switch (ppt) {
@@ -352,6 +369,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
     }
   }
   }
+  if (!kern) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
@@ -699,6 +717,7 @@ template <int MP, int KP>
 hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   const int ppt = ws.chunk / GRID_NT;
   void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
+#ifndef BSSM_USER_MODEL
   switch (ppt) {
     case 1: kern = pf_grid_step<MP, KP, 1>; break;
     case 2: kern = pf_grid_step<MP, KP, 2>; break;
@@ -706,6 +725,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     default: kern = pf_grid_step<MP, KP, 8>; break;
   }
   if constexpr (MP == 4 && KP == 4) { if (ws.dbg && ppt == 1) kern = pf_grid_step<MP, KP, 1, true>; }
+#endif
   if (b.fpar) {
     if constexpr (MP == KP && MP <= 2) {
       switch (ppt) {
@@ -718,6 +738,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
       return hipErrorInvalidValue;
     }
   }
+  if (!kern) return hipErrorInvalidValue;
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;

@@ -9,9 +9,23 @@
 
 namespace bssm {
 
-enum { FN_NLG_GROWTH = 1, FN_NLG_AR_EXP = 2, FN_NLG_SIN_EXP = 3, FN_NLG_LINEAR_GAUSSIAN = 4, FN_SDE_GBM = 5, FN_SDE_POISSON_OU = 6 };
-// per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser
-enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, FP_H = 20, FP_R = 21, FP_LOGC = 23, FP_SIZE = 24 };
+enum { FN_NLG_GROWTH = 1, FN_NLG_AR_EXP = 2, FN_NLG_SIN_EXP = 3, FN_NLG_LINEAR_GAUSSIAN = 4, FN_SDE_GBM = 5, FN_SDE_POISSON_OU = 6,
+       FN_USER_NLG = 7, FN_USER_SDE = 8 };  // 7 / 8: functions supplied by the user and compiled at run time (user_model_tu.hip)
+__host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || id == FN_SDE_POISSON_OU || id == FN_USER_SDE; }
+
+// ---- user-defined models (the reference's ssm_nlg / ssm_sde take arbitrary user C++ compiled at run time by
+// Rcpp::sourceCpp behind function pointers, src/model_ssm_nlg.h:10-21, src/model_ssm_sde.h:8-11).  The analogue here:
+// the user's snippet of __device__ functions is compiled by hipcc at run time INTO the filter kernels (one small
+// shared library per snippet, user_model_tu.hip), selected by FN_USER_NLG / FN_USER_SDE.  theta and known_params arrive
+// as in bssm_fn_model (up to 8 doubles each).  A snippet defines BSSM_USER_NLG and/or BSSM_USER_SDE and the functions:
+//   BSSM_USER_NLG: void bssm_user_T(const double* alpha, const double* theta, const double* known, double* out);   T_fn
+//                  double bssm_user_Z(const double* alpha, const double* theta, const double* known);              Z_fn
+//   BSSM_USER_SDE: double bssm_user_drift(double x, const double* theta);  bssm_user_diffusion;  bssm_user_ddiffusion;
+//                  double bssm_user_log_obs(double y, double x, const double* theta);   normalised log-density of y | x
+// H (observation sd), the diagonal of R, a1 and P1 are state-independent numbers the caller passes with the model.
+// per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser, user slot
+enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, FP_H = 20, FP_R = 21, FP_LOGC = 23, FP_SLOT = 24 /* user-model registry slot (host only) */,
+       FP_SIZE = 26 };
 
 // ---- ssm_nlg: alpha_{t+1} = T(alpha_t) + R eta,  y_t ~ N(Z(alpha_t), H^2)   (src/model_ssm_nlg.cpp:1118-1126, 943-956)
 template <int MP>
@@ -27,12 +41,18 @@ __device__ __forceinline__ void nlg_T_fn(int id, const double* __restrict__ fp, 
     } break;
     case FN_NLG_AR_EXP: x[0] = fp[FP_THETA + 0] * (1.0 - fp[FP_THETA + 1]) + fp[FP_THETA + 1] * a[0]; break;  // :296-300
     case FN_NLG_SIN_EXP: x[0] = sin(a[0]); break;                                                            // :726-730
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
+    case FN_USER_NLG: bssm_user_T(&a[0], fp + FP_THETA, fp + FP_KNOWN, &x[0]); break;
+#endif
     default: x[0] = a[0]; break;                                                                             // linear_gaussian
   }
 }
 template <int MP>
-__device__ __forceinline__ double nlg_Z_fn(int id, const double (&x)[MP]) {
+__device__ __forceinline__ double nlg_Z_fn(int id, const double* __restrict__ fp, const double (&x)[MP]) {
   switch (id) {
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
+    case FN_USER_NLG: return bssm_user_Z(&x[0], fp + FP_THETA, fp + FP_KNOWN);
+#endif
     case FN_NLG_GROWTH: return MP > 1 ? x[MP > 1 ? 1 : 0] : x[0];  // second state (:393-400)
     case FN_NLG_AR_EXP:
     case FN_NLG_SIN_EXP: return fast_exp(x[0]);
@@ -42,12 +62,21 @@ __device__ __forceinline__ double nlg_Z_fn(int id, const double (&x)[MP]) {
 
 // ---- ssm_sde: Milstein scheme with 2^L sub-steps per unit time (src/milstein.cpp:18-48)
 __device__ __forceinline__ double sde_drift(int id, const double* __restrict__ fp, double x) {
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
+  if (id == FN_USER_SDE) return bssm_user_drift(x, fp + FP_THETA);
+#endif
   return id == FN_SDE_GBM ? fp[FP_THETA + 0] * x : fast_exp(fp[FP_THETA + 0]) * (fp[FP_THETA + 1] - x);
 }
 __device__ __forceinline__ double sde_diffusion(int id, const double* __restrict__ fp, double x) {
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
+  if (id == FN_USER_SDE) return bssm_user_diffusion(x, fp + FP_THETA);
+#endif
   return id == FN_SDE_GBM ? fmax(0.0, fp[FP_THETA + 1] * x) : fp[FP_R];  // poisson_ou: exp(theta2), precomputed
 }
 __device__ __forceinline__ double sde_ddiffusion(int id, const double* __restrict__ fp, double x) {
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
+  if (id == FN_USER_SDE) return bssm_user_ddiffusion(x, fp + FP_THETA);
+#endif
   return id == FN_SDE_GBM ? (x > 0.0 ? fp[FP_THETA + 1] : 0.0) : 0.0;
 }
 __device__ __forceinline__ double milstein(int id, const double* __restrict__ fp, RngKey key, uint32_t purpose, uint32_t t,
@@ -76,7 +105,7 @@ template <int MP>
 __device__ __forceinline__ void functor_initial(const double* __restrict__ fp, const double* __restrict__ ini, RngKey key,
                                                 uint32_t i, double (&x)[MP]) {
   const int id = (int)fp[FP_ID];
-  if (id >= FN_SDE_GBM) {  // alpha_0 = milstein(x0) (src/model_ssm_sde.cpp:25-28)
+  if (fn_is_sde(id)) {  // alpha_0 = milstein(x0) (src/model_ssm_sde.cpp:25-28)
     x[0] = milstein(id, fp, key, RNG_INIT, 0u, i, fp[FP_X0]);
 #pragma unroll
     for (int c = 1; c < MP; c++) x[c] = 0.0;
@@ -97,7 +126,7 @@ template <int MP, int KP>
 __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp, RngKey key, const u32x4& blk0, uint32_t t,
                                                   uint32_t i, const double (&a)[MP], double (&x)[MP]) {
   const int id = (int)fp[FP_ID];
-  if (id >= FN_SDE_GBM) {
+  if (fn_is_sde(id)) {
     x[0] = milstein(id, fp, key, RNG_SDE, t, i, a[0]);
 #pragma unroll
     for (int c = 1; c < MP; c++) x[c] = 0.0;
@@ -117,11 +146,14 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
   const double* __restrict__ ob = row + ROW_HDR;
   const int id = (int)fp[FP_ID];
   const double y = ob[OB_Y];
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
+  if (id == FN_USER_SDE) return bssm_user_log_obs(y, x[0], fp + FP_THETA);
+#endif
   if (id == FN_SDE_POISSON_OU) {  // R::dpois(y, exp(x), log): y x - e^x - lgamma(y + 1) (host puts lgamma in OB_AUX)
     return y * x[0] - fast_exp(x[0]) - ob[OB_AUX];
   }
   // normalised Gaussian log-density (dmvnorm(..., lwr = true, logd = true), src/dmvnorm.cpp:10-13)
-  const double mu = id == FN_SDE_GBM ? fast_log(x[0]) : nlg_Z_fn<MP>(id, x);
+  const double mu = id == FN_SDE_GBM ? fast_log(x[0]) : nlg_Z_fn<MP>(id, fp, x);
   const double q = (y - mu) / fp[FP_H];
   return fp[FP_LOGC] - 0.5 * q * q;
 }
@@ -141,7 +173,7 @@ __device__ __forceinline__ double functor_psi_weight(const double* __restrict__ 
   {
     const double* __restrict__ ob = row + ROW_HDR;
     const double y = ob[OB_Y], ih = ob[OB_PSIIH];
-    const double q1 = (y - nlg_Z_fn<MP>(id, x)) * ih;
+    const double q1 = (y - nlg_Z_fn<MP>(id, fp, x)) * ih;
     double lin = ob[OB_D];
 #pragma unroll
     for (int c = 0; c < MP; c++) lin += ob[SER_HDR + c] * x[c];
@@ -277,7 +309,7 @@ __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, con
     }
 #pragma unroll
     for (int j = 0; j < MP; j++) F += Zg[j] * PZ[j];
-    const double icf = 1.0 / sqrt(F), v = y - nlg_Z_fn<MP>(id, at);
+    const double icf = 1.0 / sqrt(F), v = y - nlg_Z_fn<MP>(id, fp, at);
 #pragma unroll
     for (int i = 0; i < MP; i++) { K[i] = PZ[i] * icf * icf; att[i] = at[i] + K[i] * v; }
     double IKZ[MP * MP], tmp[MP * MP];

@@ -36,6 +36,7 @@ struct FilterBatch {
   double* weights;      // [f][n+1][N]      exp(w - max_t), ones where unobserved
   double* loglik;       // [f]              sum_t (max_t + log mean exp), no constants
   int* dead_at;         // [f] 0 = alive, else (time whose weights were degenerate) + 1; zeroed by the launcher
+  int user_slot;        // 0, or the registry slot of a run-time compiled user model whose library holds the kernels
 };
 
 // Largest N the workgroup-resident kernel can hold for a given padded state size
@@ -63,6 +64,10 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
 struct StepTiming { int every = 0; int count = 0; double total_ms = 0.0; };
 hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream,
                               StepTiming* timing = nullptr);
+// launchers a run-time compiled user-model library exports (user_model_tu.hip); register returns the slot (>= 1)
+typedef hipError_t (*user_wg_launcher_t)(const FilterBatch*, hipStream_t);
+typedef hipError_t (*user_grid_launcher_t)(const FilterBatch*, const GridWorkspace*, hipStream_t, StepTiming*);
+int register_user_launchers(user_wg_launcher_t wg, user_grid_launcher_t grid);
 
 // Ancestor back-trace (src/filter_smoother.cpp:5-18) on the particle-minor history, in place is not
 // possible in parallel, so it writes `out` [f][n+1][m][N].

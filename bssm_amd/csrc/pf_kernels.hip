@@ -18,16 +18,6 @@ int wg_filter_capacity(int MP) {
   return (int)(cap / 64 * 64);
 }
 
-// loglik[f] = sum_t llinc[f][t] in time order (the reference's accumulation order), -inf after a degenerate step
-__global__ void loglik_finalize_kernel(double* __restrict__ loglik, const double* __restrict__ llinc,
-                                       const int* __restrict__ dead_at, int n, int F) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
-  double acc = 0.0;
-  for (int t = 0; t < n; t++) acc += llinc[(size_t)f * (n + 1) + t];
-  loglik[f] = dead_at[f] ? -INFINITY : acc;
-}
-
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   // one particle per thread until the chip is full, then more particles per thread
   // One particle per thread keeps a single filter's dependent chain shortest.  When the batch already oversubscribes
@@ -246,7 +236,20 @@ hipError_t launch_stratified_sample(double* p, const double* r, uint32_t* out, i
   return hipGetLastError();
 }
 
+// run-time compiled user models: launchers exported by the user's library (user_model_tu.hip), by slot (1-based)
+namespace {
+struct UserLaunchers { user_wg_launcher_t wg; user_grid_launcher_t grid; };
+UserLaunchers g_user[64];
+int g_user_count = 0;
+}  // namespace
+int register_user_launchers(user_wg_launcher_t wg, user_grid_launcher_t grid) {
+  if (g_user_count >= 63) return -1;
+  g_user[++g_user_count] = UserLaunchers{wg, grid};
+  return g_user_count;
+}
+
 hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream) {
+  if (b.user_slot > 0) return b.user_slot <= g_user_count ? g_user[b.user_slot].wg(&b, stream) : hipErrorInvalidValue;
   switch (b.MP) {
     case 1: return launch_wg_mp<1>(b, stream);
     case 2: return launch_wg_mp<2>(b, stream);
@@ -257,6 +260,7 @@ hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream) {
   }
 }
 hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
+  if (b.user_slot > 0) return b.user_slot <= g_user_count ? g_user[b.user_slot].grid(&b, &ws, stream, timing) : hipErrorInvalidValue;
   switch (b.MP) {
     case 1: return launch_grid_mp<1>(b, ws, stream, timing);
     case 2: return launch_grid_mp<2>(b, ws, stream, timing);

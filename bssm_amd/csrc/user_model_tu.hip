@@ -1,0 +1,32 @@
+// user_model_tu.hip -- translation unit of a run-time compiled user model.
+//
+// bssm's ssm_nlg / ssm_sde models are user C++ compiled at run time (Rcpp::sourceCpp) and called through function
+// pointers (src/model_ssm_nlg.h:10-21, src/model_ssm_sde.h:8-11).  Device code cannot call host pointers, so here the
+// user's snippet of __device__ functions is compiled INTO the filter kernels: bssm_user_model_build() (api.cpp) runs
+//   hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I<csrc> -DBSSM_USER_M=<m> -DBSSM_USER_SNIPPET='"<file>"'
+//         user_model_tu.hip -o libbssm_user_<hash>.so
+// and registers the two launchers below.  The snippet's contract is documented in pf_functors.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define BSSM_USER_MODEL 1
+#include BSSM_USER_SNIPPET
+
+#include "pf_filter_impl.h"
+
+#ifndef BSSM_USER_M
+#error "BSSM_USER_M (state dimension: 1 or 2) must be defined"
+#endif
+
+extern "C" hipError_t bssm_user_launch_wg(const bssm::FilterBatch* b, hipStream_t stream) {
+  bssm::FilterBatch local = *b;
+  local.user_slot = 0;
+  return bssm::launch_wg_mk<BSSM_USER_M, BSSM_USER_M>(local, stream);
+}
+extern "C" hipError_t bssm_user_launch_grid(const bssm::FilterBatch* b, const bssm::GridWorkspace* ws, hipStream_t stream,
+                                            bssm::StepTiming* timing) {
+  bssm::FilterBatch local = *b;
+  local.user_slot = 0;
+  return bssm::launch_grid_mk<BSSM_USER_M, BSSM_USER_M>(local, *ws, stream, timing);
+}

@@ -61,7 +61,7 @@ def _functor_filter(model: BssmModel, particles: int, seed: int, smoother: bool,
         L = check_intmax(L, "L", max=20)
     smod, keep = _lib.pack_fn_model(model, L)
     n = model.n
-    m = 2 if int(model["model_id"]) == 1 else 1
+    m = int(model.get("n_states", 1))
     out = _lib.FilterOut()
     at, att = _alloc((n + 1, m)), _alloc((n, m))
     Pt, Ptt = _alloc((m, m, n + 1)), _alloc((m, m, n))
@@ -229,7 +229,7 @@ def psi_setup(model: BssmModel, is_mode=None):
     """Gaussian approximation + conditional factors used by the psi-APF (host side of the library)."""
     if model.inherits("ssm_nlg"):
         smod, keep = _lib.pack_fn_model(model)
-        n, m = model.n, 2 if int(model["model_id"]) == 1 else 1
+        n, m = model.n, int(model.get("n_states", 1))
         res = dict(mode=_alloc((m, n)), scales=np.zeros(n), alphahat=_alloc((m, n + 1)), Vt=_alloc((m, m, n + 1)),
                    Ct=_alloc((m, m, n + 1)), Z=_alloc((m, n)), T=_alloc((m, m, n)), D=np.zeros(n), C=_alloc((m, n)))
         al = C.c_double(0.0)

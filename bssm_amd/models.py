@@ -470,6 +470,33 @@ def ssm_sde(y, example: str, theta, x0, positive: bool):
                      positive=bool(positive), a1=np.zeros(1), L=0)
 
 
+def ssm_nlg_user(y, device_code: str, theta, a1, P1, H, R_diag, known_params=(), n_states=None):
+    """ssm_nlg (R/models.R:1472-1570) with USER functions.  The reference takes pointers to user C++ compiled at run time
+    (Z, H, T, R, Z_gn, T_gn, a1, P1); here ``device_code`` is a snippet of ``__device__`` functions compiled by hipcc into
+    the filter kernels (contract: bssm_amd/csrc/pf_functors.h -- ``#define BSSM_USER_NLG 1``, ``bssm_user_T``,
+    ``bssm_user_Z``), and the state-independent pieces are numbers: H (observation sd), the diagonal of R, a1, P1.
+    Bootstrap filter / smoother / log-likelihood are available for user models."""
+    y = _f(np.asarray(y, dtype=float).reshape(-1))
+    a1 = np.asarray(a1, dtype=float).reshape(-1)
+    m = int(n_states or a1.size)
+    if m not in (1, 2):
+        raise ValueError("user-defined ssm_nlg models: n_states must be 1 or 2")
+    return BssmModel(("ssm_nlg", "bssm_model"), y=y, model_id=7, example="user", user_source=str(device_code),
+                     theta=np.asarray(theta, dtype=float), known_params=np.asarray(known_params, dtype=float),
+                     n_states=m, n_etas=m, a1=a1, P1=np.asarray(P1, dtype=float).reshape(m, m), H=float(H),
+                     R_diag=np.asarray(R_diag, dtype=float).reshape(-1), x0=0.0, positive=False, L=0)
+
+
+def ssm_sde_user(y, device_code: str, theta, x0, positive: bool):
+    """ssm_sde (R/models.R:1600-1647) with USER drift / diffusion / ddiffusion / observation log-density
+    (``#define BSSM_USER_SDE 1``, ``bssm_user_drift``, ``bssm_user_diffusion``, ``bssm_user_ddiffusion``,
+    ``bssm_user_log_obs``), compiled at run time."""
+    y = _f(np.asarray(y, dtype=float).reshape(-1))
+    return BssmModel(("ssm_sde", "bssm_model"), y=y, model_id=8, example="user", user_source=str(device_code),
+                     theta=np.asarray(theta, dtype=float), known_params=np.zeros(0), x0=float(x0), positive=bool(positive),
+                     n_states=1, a1=np.zeros(1), L=0)
+
+
 def model_arrays(model: BssmModel) -> dict:
     """Flatten a model into the plain column-major arrays + flags the C ABI struct carries
     (the field list of src/model_ssm_ung.cpp:9-32)."""

@@ -153,7 +153,7 @@ def _run_local_block_nlg(model, theta, modes, counts, first, n_stored, nsim, see
     """ssm_nlg draws [first, first + len(theta)) through bssm_is_correction_nlg (only theta differs between draws)."""
     cnt = theta.shape[0]
     n = model.n
-    m = 2 if int(model["model_id"]) == 1 else 1
+    m = int(model.get("n_states", 1))
     packed, keep = [], []
     for i in range(cnt):
         s, k = _lib.pack_fn_model({**model, "theta": theta[i]})
@@ -228,7 +228,7 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     counts = np.asarray(mcmc_output["counts"], dtype=np.uint32).reshape(-1)
     modes = np.asarray(mcmc_output["modes"], dtype=np.float64)
     n = model.n
-    p_dim = (2 if int(model["model_id"]) == 1 else 1) if nlg else model.p   # rows of one draw's mode: states (nlg) / series
+    p_dim = (int(model.get("n_states", 1))) if nlg else model.p   # rows of one draw's mode: states (nlg) / series
     modes = modes.reshape(p_dim * n, -1, order="F")
     if theta.shape[0] != counts.size or modes.shape != (p_dim * n, counts.size):
         raise ValueError("theta, counts and modes of 'mcmc_output' do not agree")
@@ -250,7 +250,7 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     bounds = shard_bounds(work, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
 
-    m = (2 if int(model["model_id"]) == 1 else 1) if nlg else model.m
+    m = (int(model.get("n_states", 1))) if nlg else model.m
     if hi > lo and nlg:
         loc = _run_local_block_nlg(model, theta[lo:hi], modes[:, lo:hi], counts[lo:hi], lo, n_stored, particles, seed, is_t,
                                    output_type, threads)

@@ -152,7 +152,8 @@ int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, ui
  * R/cpp_example_models.R are built in and selected by id (theta / known_params keep the snippets' meaning).
  * Bootstrap filter for all six; psi-APF for the four ssm_nlg models (the reference has no psi-APF for ssm_sde). */
 enum { BSSM_FN_NLG_GROWTH = 1, BSSM_FN_NLG_AR_EXP = 2, BSSM_FN_NLG_SIN_EXP = 3, BSSM_FN_NLG_LINEAR_GAUSSIAN = 4,
-       BSSM_FN_SDE_GBM = 5, BSSM_FN_SDE_POISSON_OU = 6 };
+       BSSM_FN_SDE_GBM = 5, BSSM_FN_SDE_POISSON_OU = 6,
+       BSSM_FN_USER_NLG = 7, BSSM_FN_USER_SDE = 8 /* user-defined, compiled at run time: bssm_user_model_build / _load */ };
 typedef struct bssm_fn_model {
   int32_t model_id;
   int32_t n;                  /* time points */
@@ -162,7 +163,24 @@ typedef struct bssm_fn_model {
   double x0;                  /* ssm_sde: initial value */
   int32_t positive;           /* ssm_sde: reflect to stay positive (milstein.cpp:44) */
   int32_t L;                  /* ssm_sde: 2^L Milstein sub-steps per unit time */
+  /* ---- user-defined models only (model_id BSSM_FN_USER_NLG / BSSM_FN_USER_SDE); ignored for the built-in ids */
+  int32_t user_slot;          /* from bssm_user_model_load */
+  int32_t n_states;           /* ssm_nlg: 1 or 2 (= n_etas; R is diagonal) */
+  double H;                   /* ssm_nlg: observation sd (the value H_fn returns) */
+  double R_diag[2];           /* ssm_nlg: diagonal of R_fn's value */
+  double a1[2], P1[4];        /* ssm_nlg: a1_fn, P1_fn values (P1 column-major, n_states x n_states) */
 } bssm_fn_model;
+
+/* User-defined ssm_nlg / ssm_sde models.  The reference compiles the user's C++ at run time (Rcpp::sourceCpp) and
+ * calls it through function pointers (src/model_ssm_nlg.h:10-21, src/model_ssm_sde.h:8-11); device code cannot call host
+ * pointers, so the user's __device__ functions (contract: bssm_amd/csrc/pf_functors.h) are compiled by hipcc INTO the
+ * filter kernels, one shared library per snippet, cached by content hash next to libbssm_amd.so (or in
+ * $BSSM_AMD_USER_CACHE).  bssm_user_model_build compiles `source` for `n_states` (1 or 2) and writes the library path;
+ * bssm_user_model_load maps it and returns a slot >= 1 for bssm_fn_model.user_slot (negative = error).
+ * Built for user models in this version: bootstrap filter / smoother / log-likelihood (bssm_bsf_nlg, bssm_bsf_smoother_nlg,
+ * bssm_bsf_sde, bssm_bsf_smoother_sde, bssm_fn_loglik_batch with BSSM_BSF). */
+int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity);
+int bssm_user_model_load(const char* lib_path);
 /* replaces _bssm_bsf_nlg (18 args, src/R_bootstrap_filter.cpp:461-504) / _bssm_bsf_smoother_nlg (:508-551):
  * outputs as bssm_bsf / bssm_bsf_smoother */
 int bssm_bsf_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);

@@ -152,3 +152,76 @@ def test_ekpf_filter_matches_oracle(oracle, monkeypatch, name, N, path):
     assert abs(sm["logLik"] - ref["logLik"]) <= 1e-9 * model.n
     ll = F.logLik(model, N, method="ekf", seed=6)
     assert abs(ll - ref["logLik"]) <= 1e-9 * model.n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# User-defined models: the reference compiles the user's C++ at run time and calls it through function pointers; here
+# the user's __device__ functions are compiled by hipcc into the filter kernels (bssm_user_model_build).  Writing the
+# shipped example models as USER snippets must reproduce the built-in versions exactly.
+USER_SIN_EXP = r"""
+#define BSSM_USER_NLG 1
+__device__ inline void bssm_user_T(const double* alpha, const double* theta, const double* known, double* out) { out[0] = sin(alpha[0]); }
+__device__ inline double bssm_user_Z(const double* alpha, const double* theta, const double* known) { return exp(alpha[0]); }
+"""
+USER_GROWTH = r"""
+#define BSSM_USER_NLG 1
+// logistic growth: R/cpp_example_models.R:393-428 (known = dT, K, ...)
+__device__ inline void bssm_user_T(const double* a, const double* theta, const double* known, double* out) {
+  const double dT = known[0], K = known[1];
+  const double r = exp(a[0]) / (1.0 + exp(a[0]));
+  const double e = exp(r * dT);
+  out[0] = a[0];
+  out[1] = K * a[1] * e / (K + a[1] * (e - 1.0));
+}
+__device__ inline double bssm_user_Z(const double* a, const double* theta, const double* known) { return a[1]; }
+"""
+USER_GBM = r"""
+#define BSSM_USER_SDE 1
+// geometric Brownian motion with Gaussian observations of log(x): R/cpp_example_models.R:109-193
+__device__ inline double bssm_user_drift(double x, const double* theta) { return theta[0] * x; }
+__device__ inline double bssm_user_diffusion(double x, const double* theta) { return fmax(0.0, theta[1] * x); }
+__device__ inline double bssm_user_ddiffusion(double x, const double* theta) { return x > 0.0 ? theta[1] : 0.0; }
+__device__ inline double bssm_user_log_obs(double y, double x, const double* theta) {
+  const double q = (y - log(x)) / theta[2];
+  return -0.5 * (1.8378770664093453 + 2.0 * log(theta[2])) - 0.5 * q * q;
+}
+"""
+
+
+@pytest.mark.parametrize("path", ["wg", "grid"])
+def test_user_defined_nlg_models_equal_builtin(oracle, monkeypatch, path):
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    # one state
+    b, _ = MODELS["nlg_sin_exp"]
+    th = np.asarray(b["theta"])
+    u = M.ssm_nlg_user(b["y"], USER_SIN_EXP, theta=th, a1=[0.0], P1=[[1.0]], H=np.exp(th[0]), R_diag=[np.exp(th[1])])
+    for N in (50, 900):
+        ob, ou = F.bootstrap_filter(b, N, seed=4, return_indices=True), F.bootstrap_filter(u, N, seed=4, return_indices=True)
+        ref = oracle.fn_bsf_filter({**b, "L": 0}, N, seed=4)
+        assert np.array_equal(ou["indices"], ref["indices"]) and np.array_equal(ou["indices"], ob["indices"])
+        assert abs(ou["logLik"] - ref["logLik"]) <= 1e-9 * b.n
+        assert _rel(ou["alpha"], ob["alpha"]) <= 1e-9
+    # two states
+    b, _ = MODELS["nlg_growth"]
+    th, kp = np.asarray(b["theta"]), np.asarray(b["known_params"])
+    u = M.ssm_nlg_user(b["y"], USER_GROWTH, theta=th, known_params=kp, a1=kp[2:4], P1=np.diag(kp[4:6]), H=np.exp(th[0]),
+                       R_diag=np.exp(th[1:3]))
+    ob, ou = F.particle_smoother(b, 600, method="bsf", seed=9), F.particle_smoother(u, 600, method="bsf", seed=9)
+    assert abs(ou["logLik"] - ob["logLik"]) <= 1e-9 * b.n
+    assert _rel(ou["alphahat"], ob["alphahat"]) <= 1e-9 and _rel(ou["Vt"], ob["Vt"]) <= 1e-8
+    assert abs(F.logLik(u, 600, method="bsf", seed=9) - ob["logLik"]) <= 1e-9 * b.n
+
+
+def test_user_defined_sde_model_equals_builtin(oracle):
+    b, L = MODELS["sde_gbm"]
+    u = M.ssm_sde_user(b["y"], USER_GBM, theta=b["theta"], x0=b["x0"], positive=True)
+    ob, ou = F.bootstrap_filter(b, 400, seed=3, return_indices=True, L=L), F.bootstrap_filter(u, 400, seed=3, return_indices=True, L=L)
+    ref = oracle.fn_bsf_filter({**b, "L": L}, 400, seed=3)
+    assert np.array_equal(ou["indices"], ref["indices"])
+    assert abs(ou["logLik"] - ref["logLik"]) <= 1e-9 * b.n and abs(ou["logLik"] - ob["logLik"]) <= 1e-9 * b.n
+
+
+def test_user_model_compile_error_is_reported():
+    with pytest.raises(Exception, match="compiling the user model failed"):
+        M_bad = M.ssm_nlg_user(np.zeros(5), "#define BSSM_USER_NLG 1\nthis is not C++", theta=[0.0], a1=[0.0], P1=[[1.0]], H=1.0, R_diag=[1.0])
+        F.bootstrap_filter(M_bad, 10, seed=1)
