@@ -822,8 +822,18 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   const std::string dir = library_dir();
   const char* env = std::getenv("BSSM_AMD_USER_CACHE");
   const std::string cache = env ? std::string(env) : dir + "/user_models";
+  // the cache key covers everything that is compiled into the library: the kernel headers, the state dimension, the snippet
+  std::string key = std::string(bssm_amd_version()) + "|" + std::to_string(n_states) + "|" + source;
+  for (const char* hdr : {"pf_filter_impl.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "user_model_tu.hip"}) {
+    FILE* hf = std::fopen((dir + "/csrc/" + hdr).c_str(), "rb");
+    if (!hf) return fail(BSSM_ERR_INVALID, "kernel sources not found next to the library: " + dir + "/csrc/" + hdr);
+    char buf[1 << 16];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof buf, hf)) > 0) key.append(buf, got);
+    std::fclose(hf);
+  }
   char hbuf[32];
-  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(std::string(bssm_amd_version()) + "|" + std::to_string(n_states) + "|" + source));
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(key));
   const std::string stem = cache + "/um_" + hbuf, snippet = stem + ".h", so = cache + "/libbssm_user_" + hbuf + ".so", log = stem + ".log";
   if ((int)so.size() + 1 > lib_path_capacity) return fail(BSSM_ERR_INVALID, "lib_path buffer too small");
   std::lock_guard<std::mutex> lk(g_user_mu);
