@@ -28,6 +28,7 @@
 namespace {
 
 thread_local std::string g_err;
+bssm::UserHostFns g_user_host[64];  // host entry points of the loaded user-model libraries, by registry slot
 thread_local double g_is_timing[2] = {0.0, 0.0};  // last IS post-correction on this thread: host set-up ms, device phase ms
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -515,10 +516,24 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
 
 int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f) {
   if (!mod || !mod->y || !mod->theta) return fail(BSSM_ERR_INVALID, "model, y, theta must be non-NULL");
-  if (mod->model_id < bssm::FN_NLG_GROWTH || mod->model_id > bssm::FN_NLG_LINEAR_GAUSSIAN)
-    return fail(BSSM_ERR_UNSUPPORTED, "the psi-APF is available for the built-in ssm_nlg models only");
+  const bool user = mod->model_id == bssm::FN_USER_NLG;
+  if (!user && (mod->model_id < bssm::FN_NLG_GROWTH || mod->model_id > bssm::FN_NLG_LINEAR_GAUSSIAN))
+    return fail(BSSM_ERR_UNSUPPORTED, "the psi-APF and the EKF particle filter are for ssm_nlg models");
   if (mod->n_theta > 8 || mod->n_known > 8) return fail(BSSM_ERR_INVALID, "at most 8 theta / known_params");
-  f->id = mod->model_id; f->n = mod->n; f->m = mod->model_id == bssm::FN_NLG_GROWTH ? 2 : 1;
+  f->id = mod->model_id; f->n = mod->n; f->m = mod->model_id == bssm::FN_NLG_GROWTH ? 2 : (user ? mod->n_states : 1);
+  if (user) {
+    if (mod->user_slot < 1 || mod->user_slot > 63) return fail(BSSM_ERR_INVALID, "user-defined model without a loaded library");
+    const bssm::UserHostFns& h = g_user_host[mod->user_slot];
+    if (!h.T || !h.Z || !h.Tg || !h.Zg)
+      return fail(BSSM_ERR_UNSUPPORTED, "this user model was compiled without BSSM_USER_JACOBIANS (bssm_user_Tg, bssm_user_Zg): the psi-APF and the EKF particle filter need them");
+    if (mod->n_states < 1 || mod->n_states > 2) return fail(BSSM_ERR_UNSUPPORTED, "user-defined ssm_nlg models: n_states must be 1 or 2");
+    if (mod->n_states == 2 && (mod->P1[1] != 0.0 || mod->P1[2] != 0.0))
+      return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: P1 must be diagonal");
+    f->user = &h;
+    f->uH = mod->H;
+    for (int j = 0; j < mod->n_states; j++) { f->uR[j] = mod->R_diag[j]; f->ua1[j] = mod->a1[j]; }
+    for (int q = 0; q < mod->n_states * mod->n_states; q++) f->uP1[q] = mod->P1[q];
+  }
   f->y.assign(mod->y, mod->y + mod->n);
   for (int q = 0; q < mod->n_theta; q++) f->theta[q] = mod->theta[q];
   for (int q = 0; q < mod->n_known; q++) f->known[q] = mod->known_params[q];
@@ -878,6 +893,10 @@ int bssm_user_model_load(const char* lib_path) {
   if (!wg || !grid) return fail(BSSM_ERR_INVALID, "the library does not export the user-model launchers");
   const int slot = bssm::register_user_launchers(wg, grid);
   if (slot < 1) return fail(BSSM_ERR_UNSUPPORTED, "too many user models loaded");
+  g_user_host[slot].T = (decltype(bssm::UserHostFns::T))dlsym(h, "bssm_user_host_T");
+  g_user_host[slot].Z = (decltype(bssm::UserHostFns::Z))dlsym(h, "bssm_user_host_Z");
+  g_user_host[slot].Tg = (decltype(bssm::UserHostFns::Tg))dlsym(h, "bssm_user_host_Tg");
+  g_user_host[slot].Zg = (decltype(bssm::UserHostFns::Zg))dlsym(h, "bssm_user_host_Zg");
   g_user_loaded[lib_path] = slot;
   return slot;
 }
@@ -1364,7 +1383,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   const bool psi = sampling_method == BSSM_PSI;
   if (psi && !modes) return fail(BSSM_ERR_INVALID, "modes required for psi");
   if (!psi && !approx_loglik) return fail(BSSM_ERR_INVALID, "approx_loglik required for bsf");
-  const int n = models[0].n, id = models[0].model_id, m = id == bssm::FN_NLG_GROWTH ? 2 : 1;
+  const int n = models[0].n, id = models[0].model_id, m = id == bssm::FN_NLG_GROWTH ? 2 : (id == bssm::FN_USER_NLG ? models[0].n_states : 1);
   IsCore J;
   J.n = n; J.m = m; J.k = m; J.pp = 1; J.psi = psi;
   J.first = first; J.is_type = is_type; J.output_type = output_type; J.nsim = nsim; J.seed = seed; J.counts = counts;

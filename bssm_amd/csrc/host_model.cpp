@@ -838,13 +838,15 @@ void build_psi_tables(const HostModel& h, const PsiSetup& su, int MP, FilterTabl
 
 // ------------------------------------------------------------------ built-in ssm_nlg functors (host side)
 namespace {
-double fnH(const FnModel& f) { return f.id == 1 ? std::exp(f.theta[0]) : (f.id == 2 ? std::exp(f.theta[3]) : std::exp(f.theta[0])); }
+double fnH(const FnModel& f) { if (f.id == 7) return f.uH; return f.id == 1 ? std::exp(f.theta[0]) : (f.id == 2 ? std::exp(f.theta[3]) : std::exp(f.theta[0])); }
 void fnRdiag(const FnModel& f, double* r) {
   r[0] = r[1] = 0;
+  if (f.id == 7) { r[0] = f.uR[0]; r[1] = f.uR[1]; return; }
   switch (f.id) { case 1: r[0] = std::exp(f.theta[1]); r[1] = std::exp(f.theta[2]); break; case 2: r[0] = std::exp(f.theta[2]); break;
                   case 3: r[0] = std::exp(f.theta[1]); break; default: r[0] = 1.0; }
 }
 void fnT(const FnModel& f, const double* a, double* x) {  // T_fn, R/cpp_example_models.R:415-428 etc.
+  if (f.id == 7) { f.user->T(a, f.theta, f.known, x); return; }
   switch (f.id) {
     case 1: { const double dT = f.known[0], K = f.known[1]; x[0] = a[0]; const double r = std::exp(a[0]) / (1.0 + std::exp(a[0]));
               x[1] = K * a[1] * std::exp(r * dT) / (K + a[1] * (std::exp(r * dT) - 1)); } break;
@@ -854,6 +856,7 @@ void fnT(const FnModel& f, const double* a, double* x) {  // T_fn, R/cpp_example
   }
 }
 void fnTg(const FnModel& f, const double* a, double* Tg) {  // T_gn, :432-450
+  if (f.id == 7) { f.user->Tg(a, f.theta, f.known, Tg); return; }
   switch (f.id) {
     case 1: { const double dT = f.known[0], K = f.known[1]; const double r = std::exp(a[0]) / (1 + std::exp(a[0]));
               const double tmp = std::exp(r * dT) / std::pow(K + a[1] * (std::exp(r * dT) - 1), 2);
@@ -863,8 +866,9 @@ void fnTg(const FnModel& f, const double* a, double* Tg) {  // T_gn, :432-450
     default: Tg[0] = 1.0;
   }
 }
-double fnZ(const FnModel& f, const double* x) { return f.id == 1 ? x[1] : ((f.id == 2 || f.id == 3) ? std::exp(x[0]) : x[0]); }
+double fnZ(const FnModel& f, const double* x) { if (f.id == 7) return f.user->Z(x, f.theta, f.known); return f.id == 1 ? x[1] : ((f.id == 2 || f.id == 3) ? std::exp(x[0]) : x[0]); }
 void fnZg(const FnModel& f, const double* a, double* Zg) {
+  if (f.id == 7) { f.user->Zg(a, f.theta, f.known, Zg); return; }
   switch (f.id) { case 1: Zg[0] = 0.0; Zg[1] = 1.0; break; case 2: case 3: Zg[0] = std::exp(a[0]); break; default: Zg[0] = 1.0; }
 }
 // dmvnorm(x, mean, cov, lwr = false, logd = true) for a DIAGONAL covariance (all shipped P1 / RR are diagonal)
@@ -962,6 +966,7 @@ void fn_a1P1(const FnModel& f, double* a1, double* P1) {
   const int m = f.m;
   for (int j = 0; j < m; j++) a1[j] = 0;
   for (int q = 0; q < m * m; q++) P1[q] = 0;
+  if (f.id == 7) { for (int j = 0; j < m; j++) a1[j] = f.ua1[j]; for (int q = 0; q < m * m; q++) P1[q] = f.uP1[q]; return; }
   switch (f.id) {
     case 1: a1[0] = f.known[2]; a1[1] = f.known[3]; P1[0] = f.known[4]; P1[3] = f.known[5]; break;
     case 2: a1[0] = f.theta[0]; P1[0] = std::pow(std::exp(f.theta[2]), 2) / (1 - std::pow(f.theta[1], 2)); break;

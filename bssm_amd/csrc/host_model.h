@@ -84,12 +84,23 @@ void build_psi_tables(const HostModel& hm, const PsiSetup& su, int MP, FilterTab
 
 // ---- built-in ssm_nlg model functors on the host: psi-APF set-up (EKF, mode search, linearised model,
 // smoother_ccov + conditional_cov), src/model_ssm_nlg.cpp:62-222, 284-381, 854-879, 974-991, 1295-1319
+// host entry points of a run-time compiled user model (exported by its library, user_model_tu.hip): the psi-APF / EKF
+// set-up evaluates T, Z and their Jacobians on the host
+struct UserHostFns {
+  void (*T)(const double* alpha, const double* theta, const double* known, double* out) = nullptr;
+  double (*Z)(const double* alpha, const double* theta, const double* known) = nullptr;
+  void (*Tg)(const double* alpha, const double* theta, const double* known, double* out) = nullptr;  // m x m column-major
+  void (*Zg)(const double* alpha, const double* theta, const double* known, double* out) = nullptr;  // m
+};
 struct FnModel {
   int id = 0, n = 0, m = 1;
   std::vector<double> y;
   double theta[8] = {0}, known[8] = {0};
   double x0 = 0;
   int positive = 0, L = 0;
+  // user-defined ssm_nlg (id 7): host functions and the state-independent numbers the caller supplied
+  const UserHostFns* user = nullptr;
+  double uH = 1, uR[2] = {0, 0}, ua1[2] = {0, 0}, uP1[4] = {0, 0, 0, 0};
 };
 struct FnSetup {
   std::vector<double> Z, T, D, C;   // m x n, m x m x n, n, m x n : the mode-linearised model

@@ -18,8 +18,12 @@ __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || i
 // the user's snippet of __device__ functions is compiled by hipcc at run time INTO the filter kernels (one small
 // shared library per snippet, user_model_tu.hip), selected by FN_USER_NLG / FN_USER_SDE.  theta and known_params arrive
 // as in bssm_fn_model (up to 8 doubles each).  A snippet defines BSSM_USER_NLG and/or BSSM_USER_SDE and the functions:
+// Every function is declared with BSSM_FN (= __host__ __device__ inline; the psi / EKF set-up runs them on the host).
 //   BSSM_USER_NLG: void bssm_user_T(const double* alpha, const double* theta, const double* known, double* out);   T_fn
 //                  double bssm_user_Z(const double* alpha, const double* theta, const double* known);              Z_fn
+//   + BSSM_USER_JACOBIANS (needed by the psi-APF and the EKF particle filter, as in the reference):
+//                  void bssm_user_Tg(alpha, theta, known, double* out /* m x m, column-major */);                  T_gn
+//                  void bssm_user_Zg(alpha, theta, known, double* out /* m */);                                    Z_gn
 //   BSSM_USER_SDE: double bssm_user_drift(double x, const double* theta);  bssm_user_diffusion;  bssm_user_ddiffusion;
 //                  double bssm_user_log_obs(double y, double x, const double* theta);   normalised log-density of y | x
 // H (observation sd), the diagonal of R, a1 and P1 are state-independent numbers the caller passes with the model.
@@ -202,10 +206,13 @@ __device__ __forceinline__ double functor_psi_weight(const double* __restrict__ 
 // T(anc), R R') / N(alpha'; att, Ptt).  The proposal is recomputed from the ancestor when the weight is evaluated
 // (a few dozen flops) instead of being carried between the two places.
 template <int MP>
-__device__ __forceinline__ void nlg_Z_gn(int id, const double (&x)[MP], double (&Zg)[MP]) {
+__device__ __forceinline__ void nlg_Z_gn(int id, const double* __restrict__ fp, const double (&x)[MP], double (&Zg)[MP]) {
 #pragma unroll
   for (int c = 0; c < MP; c++) Zg[c] = 0.0;
   switch (id) {
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_JACOBIANS)
+    case FN_USER_NLG: bssm_user_Zg(&x[0], fp + FP_THETA, fp + FP_KNOWN, &Zg[0]); break;
+#endif
     case FN_NLG_GROWTH: if constexpr (MP > 1) Zg[1] = 1.0; break;
     case FN_NLG_AR_EXP:
     case FN_NLG_SIN_EXP: Zg[0] = fast_exp(x[0]); break;
@@ -298,7 +305,7 @@ __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, con
   if (row[RH_FLAG] != 0.0) {  // ekf_update_step (:1264-1293)
     const double y = row[ROW_HDR + OB_Y], H = fp[FP_H];
     double Zg[MP], PZ[MP], K[MP];
-    nlg_Z_gn<MP>(id, at, Zg);
+    nlg_Z_gn<MP>(id, fp, at, Zg);
     double F = H * H;
 #pragma unroll
     for (int i = 0; i < MP; i++) {

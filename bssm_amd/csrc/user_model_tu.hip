@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #define BSSM_USER_MODEL 1
+#define BSSM_FN __host__ __device__ inline   // every user function is needed on the device (kernels) and on the host (psi / EKF set-up)
 #include BSSM_USER_SNIPPET
 
 #include "pf_filter_impl.h"
@@ -30,3 +31,13 @@ extern "C" hipError_t bssm_user_launch_grid(const bssm::FilterBatch* b, const bs
   local.user_slot = 0;
   return bssm::launch_grid_mk<BSSM_USER_M, BSSM_USER_M>(local, *ws, stream, timing);
 }
+
+// host entry points for the psi-APF / EKF set-up (mode search, linearisation) of a user-defined ssm_nlg model
+#ifdef BSSM_USER_NLG
+extern "C" void bssm_user_host_T(const double* a, const double* th, const double* kn, double* out) { bssm_user_T(a, th, kn, out); }
+extern "C" double bssm_user_host_Z(const double* a, const double* th, const double* kn) { return bssm_user_Z(a, th, kn); }
+#ifdef BSSM_USER_JACOBIANS
+extern "C" void bssm_user_host_Tg(const double* a, const double* th, const double* kn, double* out) { bssm_user_Tg(a, th, kn, out); }
+extern "C" void bssm_user_host_Zg(const double* a, const double* th, const double* kn, double* out) { bssm_user_Zg(a, th, kn, out); }
+#endif
+#endif

@@ -475,7 +475,8 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H, R_diag, known_params=(),
     (Z, H, T, R, Z_gn, T_gn, a1, P1); here ``device_code`` is a snippet of ``__device__`` functions compiled by hipcc into
     the filter kernels (contract: bssm_amd/csrc/pf_functors.h -- ``#define BSSM_USER_NLG 1``, ``bssm_user_T``,
     ``bssm_user_Z``), and the state-independent pieces are numbers: H (observation sd), the diagonal of R, a1, P1.
-    Bootstrap filter / smoother / log-likelihood are available for user models."""
+    With the Jacobians in the snippet (``BSSM_USER_JACOBIANS``, ``bssm_user_Tg``, ``bssm_user_Zg``) the psi-APF and the
+    EKF particle filter work as for the built-in models."""
     y = _f(np.asarray(y, dtype=float).reshape(-1))
     a1 = np.asarray(a1, dtype=float).reshape(-1)
     m = int(n_states or a1.size)

@@ -177,8 +177,9 @@ typedef struct bssm_fn_model {
  * filter kernels, one shared library per snippet, cached by content hash next to libbssm_amd.so (or in
  * $BSSM_AMD_USER_CACHE).  bssm_user_model_build compiles `source` for `n_states` (1 or 2) and writes the library path;
  * bssm_user_model_load maps it and returns a slot >= 1 for bssm_fn_model.user_slot (negative = error).
- * Built for user models in this version: bootstrap filter / smoother / log-likelihood (bssm_bsf_nlg, bssm_bsf_smoother_nlg,
- * bssm_bsf_sde, bssm_bsf_smoother_sde, bssm_fn_loglik_batch with BSSM_BSF). */
+ * Built for user models: every single-model entry point of the built-in models -- bootstrap, psi-APF (bssm_psi_smoother_nlg,
+ * bssm_fn_psi_setup) and EKF particle filter (bssm_ekpf_*) with their smoothers and bssm_fn_loglik_batch; the psi-APF and
+ * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS) and a diagonal P1.  Not built: IS post-correction. */
 int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity);
 int bssm_user_model_load(const char* lib_path);
 /* replaces _bssm_bsf_nlg (18 args, src/R_bootstrap_filter.cpp:461-504) / _bssm_bsf_smoother_nlg (:508-551):

@@ -160,28 +160,42 @@ def test_ekpf_filter_matches_oracle(oracle, monkeypatch, name, N, path):
 # shipped example models as USER snippets must reproduce the built-in versions exactly.
 USER_SIN_EXP = r"""
 #define BSSM_USER_NLG 1
-__device__ inline void bssm_user_T(const double* alpha, const double* theta, const double* known, double* out) { out[0] = sin(alpha[0]); }
-__device__ inline double bssm_user_Z(const double* alpha, const double* theta, const double* known) { return exp(alpha[0]); }
+#define BSSM_USER_JACOBIANS 1
+// nlg_sin_exp of R/cpp_example_models.R:635-760 written as a user model: T(a) = sin(a), Z(a) = exp(a)
+BSSM_FN void bssm_user_T(const double* alpha, const double* theta, const double* known, double* out) { out[0] = sin(alpha[0]); }
+BSSM_FN double bssm_user_Z(const double* alpha, const double* theta, const double* known) { return exp(alpha[0]); }
+BSSM_FN void bssm_user_Tg(const double* alpha, const double* theta, const double* known, double* out) { out[0] = cos(alpha[0]); }
+BSSM_FN void bssm_user_Zg(const double* alpha, const double* theta, const double* known, double* out) { out[0] = exp(alpha[0]); }
 """
 USER_GROWTH = r"""
 #define BSSM_USER_NLG 1
-// logistic growth: R/cpp_example_models.R:393-428 (known = dT, K, ...)
-__device__ inline void bssm_user_T(const double* a, const double* theta, const double* known, double* out) {
+#define BSSM_USER_JACOBIANS 1
+// logistic growth: R/cpp_example_models.R:393-450 (known = dT, K, ...)
+BSSM_FN void bssm_user_T(const double* a, const double* theta, const double* known, double* out) {
   const double dT = known[0], K = known[1];
   const double r = exp(a[0]) / (1.0 + exp(a[0]));
   const double e = exp(r * dT);
   out[0] = a[0];
   out[1] = K * a[1] * e / (K + a[1] * (e - 1.0));
 }
-__device__ inline double bssm_user_Z(const double* a, const double* theta, const double* known) { return a[1]; }
+BSSM_FN double bssm_user_Z(const double* a, const double* theta, const double* known) { return a[1]; }
+BSSM_FN void bssm_user_Tg(const double* a, const double* theta, const double* known, double* Tg) {
+  const double dT = known[0], K = known[1];
+  const double r = exp(a[0]) / (1.0 + exp(a[0]));
+  const double tmp = exp(r * dT) / pow(K + a[1] * (exp(r * dT) - 1.0), 2);
+  Tg[0] = 1.0; Tg[2] = 0.0;
+  Tg[1] = dT * K * a[1] * (K - a[1]) * tmp * r / (1.0 + exp(a[0]));
+  Tg[3] = K * K * tmp;
+}
+BSSM_FN void bssm_user_Zg(const double* a, const double* theta, const double* known, double* Zg) { Zg[0] = 0.0; Zg[1] = 1.0; }
 """
 USER_GBM = r"""
 #define BSSM_USER_SDE 1
 // geometric Brownian motion with Gaussian observations of log(x): R/cpp_example_models.R:109-193
-__device__ inline double bssm_user_drift(double x, const double* theta) { return theta[0] * x; }
-__device__ inline double bssm_user_diffusion(double x, const double* theta) { return fmax(0.0, theta[1] * x); }
-__device__ inline double bssm_user_ddiffusion(double x, const double* theta) { return x > 0.0 ? theta[1] : 0.0; }
-__device__ inline double bssm_user_log_obs(double y, double x, const double* theta) {
+BSSM_FN double bssm_user_drift(double x, const double* theta) { return theta[0] * x; }
+BSSM_FN double bssm_user_diffusion(double x, const double* theta) { return fmax(0.0, theta[1] * x); }
+BSSM_FN double bssm_user_ddiffusion(double x, const double* theta) { return x > 0.0 ? theta[1] : 0.0; }
+BSSM_FN double bssm_user_log_obs(double y, double x, const double* theta) {
   const double q = (y - log(x)) / theta[2];
   return -0.5 * (1.8378770664093453 + 2.0 * log(theta[2])) - 0.5 * q * q;
 }
@@ -210,6 +224,25 @@ def test_user_defined_nlg_models_equal_builtin(oracle, monkeypatch, path):
     assert abs(ou["logLik"] - ob["logLik"]) <= 1e-9 * b.n
     assert _rel(ou["alphahat"], ob["alphahat"]) <= 1e-9 and _rel(ou["Vt"], ob["Vt"]) <= 1e-8
     assert abs(F.logLik(u, 600, method="bsf", seed=9) - ob["logLik"]) <= 1e-9 * b.n
+
+
+@pytest.mark.parametrize("name,snippet", [("nlg_sin_exp", "sin"), ("nlg_growth", "growth")])
+def test_user_defined_nlg_psi_and_ekf_equal_builtin(name, snippet):
+    """psi-APF (host mode search through the user's host entry points + device weights) and the EKF particle filter"""
+    b, _ = MODELS[name]
+    th = np.asarray(b["theta"])
+    if snippet == "sin":
+        u = M.ssm_nlg_user(b["y"], USER_SIN_EXP, theta=th, a1=[0.0], P1=[[1.0]], H=np.exp(th[0]), R_diag=[np.exp(th[1])])
+    else:
+        kp = np.asarray(b["known_params"])
+        u = M.ssm_nlg_user(b["y"], USER_GROWTH, theta=th, known_params=kp, a1=kp[2:4], P1=np.diag(kp[4:6]), H=np.exp(th[0]),
+                           R_diag=np.exp(th[1:3]))
+    for method in ("psi", "ekf"):
+        ob, ou = F.particle_smoother(b, 300, method=method, seed=5), F.particle_smoother(u, 300, method=method, seed=5)
+        assert abs(ou["logLik"] - ob["logLik"]) <= 1e-8 * b.n, method
+        assert _rel(ou["alphahat"], ob["alphahat"]) <= 1e-8 and _rel(ou["Vt"], ob["Vt"]) <= 1e-7
+    sb, su = F.psi_setup(b), F.psi_setup(u)
+    assert _rel(su["mode"], sb["mode"]) <= 1e-9 and abs(su["approx_loglik"] - sb["approx_loglik"]) <= 1e-8 * b.n
 
 
 def test_user_defined_sde_model_equals_builtin(oracle):
