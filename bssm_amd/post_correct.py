@@ -138,8 +138,18 @@ def is_correction(model: BssmModel, theta, counts, particles: int, method: str =
                   is_type: int = 2, output_type: int = 3, seed: int = 1, threads: int = 1):
     """Single-process IS correction with either sampler (approx_mcmc::is_correction_psi / _bsf,
     src/approx_mcmc.cpp:353-427, 447-518) -- the step run_mcmc's `is` types run after the approximate chain."""
-    arrs = expand_models(model, theta)
     counts = np.asarray(counts, dtype=np.uint32)
+    if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
+        # is_correction_psi / _bsf<ssm_nlg> (src/approx_mcmc.cpp:685-921) and, with the bootstrap sampler, the ssm_sde
+        # correction of sde_is_mcmc / sde_state_sampler_bsf_is2 (src/approx_mcmc.cpp:1038-1273, src/R_sde_state_sampler.cpp:10-50)
+        theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+        res = _run_local_block_nlg(model, theta, modes, counts, 0, theta.shape[0], particles, seed, is_type, output_type, threads,
+                                   method=1 if method == "psi" else 2, approx_loglik=approx_loglik)
+        if output_type == 2:
+            m = int(model.get("n_states", 1))
+            res["alphahat"], res["Vt"] = is_merge(model.n, m, res["weights"], counts, res["alphahat_i"], res["Vt_i"])
+        return res
+    arrs = expand_models(model, theta)
     res = _run_local_block(arrs, modes, counts, 0, len(arrs), particles, seed, is_type, output_type, threads,
                            method=1 if method == "psi" else 2, approx_loglik=approx_loglik)
     if output_type == 2:

@@ -130,3 +130,28 @@ def test_post_correct_is1_large_particle_counts(oracle, output_type):
     else:
         assert np.allclose(out["alphahat"], ref["alphahat"].T, rtol=1e-7, atol=1e-9)
         assert np.allclose(out["Vt"], ref["Vt"], rtol=1e-6, atol=1e-9)
+
+
+def test_sde_bootstrap_is_correction_matches_oracle(oracle):
+    """The ssm_sde state sampler / IS correction (src/R_sde_state_sampler.cpp:10-50, approx_mcmc::is_correction_bsf for
+    ssm_sde): one bootstrap filter with 2^L Milstein sub-steps per stored theta, weight exp(loglik - approx_loglik_i), one
+    back-traced trajectory picked uniformly per draw"""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    x = np.exp(np.cumsum(rng.normal(0.01, 0.1, 20)))
+    y = np.log(x) + rng.normal(0, 0.5, 20)
+    model = M.ssm_sde(y, "sde_gbm", theta=[0.05, 0.3, 1.0], x0=1.0, positive=True)
+    model = M.BssmModel(model.classes, **{**model, "L": 3})
+    ns, N, seed = 7, 200, 11
+    theta = np.column_stack([rng.uniform(0.02, 0.08, ns), rng.uniform(0.2, 0.4, ns), rng.uniform(0.8, 1.2, ns)])
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    al = rng.normal(-25, 0.3, ns)
+    res = PC.is_correction(model, theta, counts, N, method="bsf", approx_loglik=al, output_type=1, seed=seed)
+    for i in range(ns):
+        ref = oracle.fn_bsf_filter({**model, "theta": theta[i], "L": 3}, N, seed=seed, stream=i)
+        assert abs(res["loglik"][i] - ref["logLik"]) <= 1e-9 * model.n
+        assert abs(res["weights"][i] - np.exp(ref["logLik"] - al[i])) <= 1e-8 * res["weights"][i]
+        sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
+        r, _ = oracle.make_rng(seed=seed, stream=i)
+        pick = min(int(oracle.lib().orc_rng_uniform(C.byref(r), 3, 0, 0, 0) * N), N - 1)
+        assert np.allclose(res["alpha"][:, 0, i], sm[0, :, pick], rtol=1e-9, atol=1e-12)
