@@ -55,3 +55,30 @@ def test_mng_loglik_and_setup(oracle):
     assert np.isclose(so["approx_loglik"], sp["approx_loglik"], rtol=1e-12)
     assert abs(F.logLik(model, 50, method="bsf", seed=4) - oracle.mng_bsf_filter(arr, 50, seed=4)["logLik"]) <= 1e-9 * model.n
     assert abs(F.logLik(model, 50, method="psi", seed=4) - oracle.mng_psi_filter(arr, 50, seed=4)["logLik"]) <= 1e-9 * model.n
+
+
+def test_mng_post_correct_with_update_fn(oracle):
+    """post_correct of an ssm_mng model whose theta enters through an update_fn closure (parset_mng,
+    src/parset_ng.cpp:74-111): one psi-APF per retained draw against the oracle's per-draw filters"""
+    from bssm_amd import post_correct as PC
+    base = ZOO["tv_binom_gamma"]
+    T0 = np.array(base["T"], dtype=float).reshape(2, 2)
+
+    def update_fn(theta):  # theta = (log sd of the two disturbances): R = diag(exp(theta)), phi of the gamma series
+        return dict(R=np.diag(np.exp(theta[:2])))
+
+    model = M.BssmModel(base.classes, **{**base, "update_fn": update_fn, "theta": np.log([0.3, 0.2])})
+    rng = np.random.default_rng(5)
+    ns = 6
+    theta = np.log([0.3, 0.2]) + rng.normal(0, 0.1, (ns, 2))
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    arrs = PC.expand_models(model, theta)
+    modes = np.stack([oracle.mng_psi_setup(a)["mode"].reshape(-1, order="F") for a in arrs], axis=1)
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type=2)
+    out = PC.post_correct(model, mo, 48, threads=2, is_type="is2", seed=13)
+    n, p = model.n, model.p
+    for i in range(ns):
+        ref = oracle.mng_psi_filter(arrs[i], 48, seed=13, stream=i, is_mode=modes[:, i].reshape(p, n, order="F"))
+        assert abs(out["loglik"][i] - ref["logLik"]) <= 1e-8 * n
+    assert np.all(np.isfinite(out["alphahat"])) and np.all(np.isfinite(out["Vt"]))
+    assert T0.shape == (2, 2)
