@@ -84,7 +84,7 @@ def study_table(prefix, cols):
     out = {}
     for N in (10, 100, 1000):
         df = data_frame(load_rds("/root/reference/vignettes/psi_pf_experiments/%s_result_%d.rds" % (prefix, N)))
-        for meth, key in (("BSF", "bsf"), ("PSI", "psi")):
+        for meth, key in (("BSF", "bsf"), ("PSI", "psi"), ("EKPF", "ekf")):
             sel = df["method"] == meth
             out.setdefault(key, {})[str(N)] = {c: [float(np.mean(df[c][sel])), float(np.std(df[c][sel], ddof=1))] for c in cols}
     return out

@@ -136,7 +136,8 @@ def test_particle_smoother_distribution_equals_the_references_published_study(ke
     g, model = _vignette_model(key)
     n, R = model.n, 400
     growth = key == "vignette_growth_model"
-    cells = [("psi", 10), ("psi", 100), ("psi", 1000), ("bsf", 100), ("bsf", 1000)] + ([] if growth else [("bsf", 10)])
+    cells = [("psi", 10), ("psi", 100), ("psi", 1000), ("bsf", 100), ("bsf", 1000), ("ekf", 100), ("ekf", 1000)] + \
+            ([] if growth else [("bsf", 10), ("ekf", 10)])
     for method, N in cells:
         ref = g["smoother_mean_sd"][method][str(N)]
         rows = []
