@@ -283,6 +283,24 @@ def main():
                                "sample": "one full filter call of the benchmark model: N=%d, T=%d, 1 thread (the reference has no "
                                          "intra-filter parallelism), gcc -O2, %.1f s" % (N, Ts, ec)}
 
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- the metric's second half: log-likelihood RMSE against the reference-equivalent CPU path on identical seeds
+        # (same model, T = 1000, m = 4; N = 4096 so that 16 oracle runs stay within ~10 s of one core)
+        from bssm_amd import filters as Fm, models as M
+        from oracle import oracle as O
+        arr = M.model_arrays(model)
+        seeds = list(range(1, 17))
+        gpu = Fm.logLik_batch(model, 4096, 1, method="bsf", seed=seeds[0])  # warm
+        d = []
+        for sd in seeds:
+            g = float(Fm.logLik_batch(model, 4096, 1, method="bsf", seed=sd)[0])
+            c = float(O.bsf_filter(arr, 4096, seed=sd)["logLik"])
+            d.append(g - c)
+        d = np.asarray(d)
+        out["accuracy"] = {"loglik_rmse_vs_cpu_same_seeds": float(np.sqrt(np.mean(d * d))), "max_abs_diff": float(np.max(np.abs(d))),
+                           "seeds": len(seeds), "N": 4096, "T": T, "m": m,
+                           "note": "identical Philox streams on both sides; differences come from libm vs device elementary functions and reduction shape"}
+
     if not args.no_post_correct:
         # ---- the sharded half of the path (all ranks): IS post-correction, SURVEY.md 8e
         try:
