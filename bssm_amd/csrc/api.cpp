@@ -2,6 +2,7 @@
 // There is no CPU compute path in this library: every filter runs on the HIP device or fails.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <array>
@@ -851,6 +852,10 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(key));
   const std::string stem = cache + "/um_" + hbuf, snippet = stem + ".h", so = cache + "/libbssm_user_" + hbuf + ".so", log = stem + ".log";
   if ((int)so.size() + 1 > lib_path_capacity) return fail(BSSM_ERR_INVALID, "lib_path buffer too small");
+  // the paths go through a shell command line inside single quotes: refuse anything that could end the quoting
+  for (const std::string* pth : {&dir, &cache})
+    if (pth->find('\'') != std::string::npos || pth->find('\n') != std::string::npos)
+      return fail(BSSM_ERR_INVALID, "unsupported character in the library / cache path: " + *pth);
   std::lock_guard<std::mutex> lk(g_user_mu);
   if (FILE* f = std::fopen(so.c_str(), "rb")) {  // already built: the hash covers the source, n_states and the version
     std::fclose(f);
@@ -862,10 +867,11 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   if (!f) return fail(BSSM_ERR_INVALID, "cannot write " + snippet);
   std::fputs(source, f);
   std::fclose(f);
+  const std::string tmp = so + ".tmp." + std::to_string((long)getpid());  // several ranks may build the same model at once
   const char* hipcc = std::getenv("HIPCC");
   const std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I'" + dir +
                           "/csrc' -DBSSM_USER_M=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet + "\"' '" + dir +
-                          "/csrc/user_model_tu.hip' -o '" + so + ".tmp' > '" + log + "' 2>&1 && mv '" + so + ".tmp' '" + so + "'";
+                          "/csrc/user_model_tu.hip' -o '" + tmp + "' > '" + log + "' 2>&1 && mv '" + tmp + "' '" + so + "'";
   if (std::system(cmd.c_str()) != 0) {
     std::string tail;
     if (FILE* lf = std::fopen(log.c_str(), "r")) {
