@@ -1506,6 +1506,35 @@ struct bssm_plan {
   double bytes_per_pstep = 0;
 };
 
+namespace {
+// tables (one per model x replica) and additive log-likelihood terms of a plan's models
+int plan_tables(const bssm_ung_model* models, int n_models, int n_rep, bool psi, std::vector<bssm::FilterTables>* tabs,
+                std::vector<double>* consts, int* n, int* m, int* k, int* pp) {
+  tabs->clear(); consts->clear();
+  for (int i = 0; i < n_models; i++) {
+    bssm::HostModel hm;
+    const std::string err = bssm::ingest_model(&models[i], psi, &hm);
+    if (!err.empty()) return fail(BSSM_ERR_INVALID, err);
+    if (i == 0) { *n = hm.n; *m = hm.m; *k = hm.k; *pp = hm.p; }
+    else if (hm.n != *n || hm.m != *m || hm.k != *k || hm.p != *pp) return fail(BSSM_ERR_INVALID, "models of a plan must share n, m, k, p");
+    bssm::FilterTables ft;
+    double base;
+    const int MP = bssm::pad_dim(*m);
+    if (psi) {
+      bssm::PsiSetup su;
+      if (!bssm::psi_setup(hm, nullptr, &su)) return fail(BSSM_ERR_NUMERIC, "psi set-up produced non-finite values");
+      bssm::build_psi_tables(hm, su, MP, &ft);
+      base = su.approx_loglik;
+    } else {
+      bssm::build_bsf_tables(hm, MP, bssm::pad_noise_dim(MP, *k), &ft);
+      base = bssm::const_term(hm);
+    }
+    for (int r = 0; r < n_rep; r++) { tabs->push_back(ft); consts->push_back(base); }
+  }
+  return BSSM_OK;
+}
+}  // namespace
+
 bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int32_t n_rep, uint32_t nsim,
                             uint32_t sampling_method, uint32_t flags) {
   if (!models || n_models < 1 || n_rep < 1 || nsim < 1) { fail(BSSM_ERR_INVALID, "bad plan arguments"); return nullptr; }
@@ -1515,26 +1544,7 @@ bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int3
   std::vector<bssm::FilterTables> tabs;
   std::vector<double> consts;
   int n = 0, m = 0, k = 0, pp = 1;
-  for (int i = 0; i < n_models; i++) {
-    bssm::HostModel hm;
-    const std::string err = bssm::ingest_model(&models[i], psi, &hm);
-    if (!err.empty()) { fail(BSSM_ERR_INVALID, err); return nullptr; }
-    if (i == 0) { n = hm.n; m = hm.m; k = hm.k; pp = hm.p; }
-    else if (hm.n != n || hm.m != m || hm.k != k || hm.p != pp) { fail(BSSM_ERR_INVALID, "models of a plan must share n, m, k, p"); return nullptr; }
-    bssm::FilterTables ft;
-    double base;
-    const int MP = bssm::pad_dim(m);
-    if (psi) {
-      bssm::PsiSetup su;
-      if (!bssm::psi_setup(hm, nullptr, &su)) { fail(BSSM_ERR_NUMERIC, "psi set-up produced non-finite values"); return nullptr; }
-      bssm::build_psi_tables(hm, su, MP, &ft);
-      base = su.approx_loglik;
-    } else {
-      bssm::build_bsf_tables(hm, MP, bssm::pad_noise_dim(MP, k), &ft);
-      base = bssm::const_term(hm);
-    }
-    for (int r = 0; r < n_rep; r++) { tabs.push_back(ft); consts.push_back(base); }
-  }
+  if (plan_tables(models, n_models, n_rep, psi, &tabs, &consts, &n, &m, &k, &pp) != BSSM_OK) return nullptr;
   std::unique_ptr<bssm_plan> p(new bssm_plan);
   p->n_models = n_models; p->n_rep = n_rep; p->psi = psi;
   const bool keep = flags & BSSM_PLAN_KEEP_HISTORY;
@@ -1543,6 +1553,80 @@ bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int3
   // full-output filter 16m + 24 bytes per particle-step; log-likelihood only 16m + 16
   p->bytes_per_pstep = keep ? 16.0 * m + 24.0 : 16.0 * m + 16.0;
   return p.release();
+}
+
+// New parameter values for the same model structure (pseudo-marginal / delayed-acceptance MCMC proposes a theta per
+// iteration, src/mcmc.cpp:337-491): the tables are rebuilt on the host and copied into the plan's EXISTING device buffers
+// -- no allocation, no change of kernel shape.
+int bssm_plan_update(bssm_plan* plan, const bssm_ung_model* models, void* hip_stream) {
+  if (!plan || !models) return fail(BSSM_ERR_INVALID, "NULL argument");
+  std::vector<bssm::FilterTables> tabs;
+  std::vector<double> consts;
+  int n = 0, m = 0, k = 0, pp = 1;
+  const int rc = plan_tables(models, plan->n_models, plan->n_rep, plan->psi, &tabs, &consts, &n, &m, &k, &pp);
+  if (rc) return rc;
+  const bssm::FilterBatch& fb = plan->db.fb;
+  if (n != fb.n || m != fb.m || k != fb.k || pp != fb.p || tabs[0].MP != fb.MP || tabs[0].KP != fb.KP ||
+      tabs[0].mats.size() != fb.mats_fstride || tabs[0].obs.size() != fb.obs_fstride || tabs[0].mats_tstride != fb.mats_tstride)
+    return fail(BSSM_ERR_INVALID, "bssm_plan_update: the models must keep the structure the plan was created with");
+  const size_t ms = fb.mats_fstride, os = fb.obs_fstride, is = fb.init_fstride, F = tabs.size();
+  StageBuf stage;
+  HIP_TRY(stage.alloc((ms + os + is) * F * sizeof(double)));
+  double* hm = (double*)stage.p; double* ho = hm + ms * F; double* hi = ho + os * F;
+  for (size_t f = 0; f < F; f++) {
+    std::memcpy(hm + ms * f, tabs[f].mats.data(), ms * sizeof(double));
+    std::memcpy(ho + os * f, tabs[f].obs.data(), os * sizeof(double));
+    std::memcpy(hi + is * f, tabs[f].init.data(), is * sizeof(double));
+  }
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipMemcpyAsync(plan->db.mats.p, hm, ms * F * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(plan->db.obs.p, ho, os * F * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(plan->db.init.p, hi, is * F * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  plan->db.const_terms = consts;
+  return BSSM_OK;
+}
+
+// sample_or_summarise (src/summary.cpp:82-103) on the plan's kept particle system of filter `filter`:
+//   alpha    != NULL: one back-traced trajectory, (n+1) x m, drawn uniformly (the weights of the extra time point are
+//                     ones) from the stream (seed, purpose 3) of that filter
+//   alphahat != NULL: smoothed means m x (n+1) and covariances Vt m x m x (n+1) of the back-traced system (weights uniform)
+int bssm_plan_sample_or_summarise(bssm_plan* plan, int32_t filter, uint32_t seed, void* hip_stream, double* alpha,
+                                  double* alphahat, double* Vt) {
+  if (!plan) return fail(BSSM_ERR_INVALID, "plan NULL");
+  const bssm::FilterBatch& fb = plan->db.fb;
+  if (!fb.alpha_hist || !fb.indices) return fail(BSSM_ERR_INVALID, "the plan was created without BSSM_PLAN_KEEP_HISTORY");
+  if (filter < 0 || filter >= fb.F) return fail(BSSM_ERR_INVALID, "filter index out of range");
+  const int n = fb.n, m = fb.m, N = fb.N;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const double* hist = fb.alpha_hist + (size_t)filter * (n + 1) * m * N;
+  const uint32_t* idx = fb.indices + (size_t)filter * n * N;
+  if (alpha) {
+    const bssm::u32x4 w = bssm::philox4x32_10(0, 0, 0, bssm::RNG_PICK, seed, fb.stream0 + (uint32_t)filter);
+    int pick = (int)((double)bssm::bits53(w.x, w.y) * 0x1.0p-53 * N);
+    const uint32_t pk = (uint32_t)(pick >= N ? N - 1 : pick);
+    DevBuf d_pick, d_traj;
+    HIP_TRY(d_pick.alloc(sizeof(uint32_t)));
+    HIP_TRY(d_traj.alloc((size_t)(n + 1) * m * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(d_pick.p, &pk, sizeof pk, hipMemcpyHostToDevice, st));
+    HIP_TRY(bssm::launch_pick_trajectory(hist, idx, d_pick.as<uint32_t>(), d_traj.as<double>(), 1, n, m, N, st));
+    std::vector<double> tr((size_t)(n + 1) * m);
+    HIP_TRY(hipMemcpyAsync(tr.data(), d_traj.p, d_traj.bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int t = 0; t <= n; t++) for (int c = 0; c < m; c++) alpha[t + (size_t)(n + 1) * c] = tr[(size_t)t * m + c];
+  }
+  if (alphahat || Vt) {
+    if (m > 8) return fail(BSSM_ERR_UNSUPPORTED, "summaries of the plan's particle system: m <= 8");
+    DevBuf d_b, d_mean, d_cov;
+    HIP_TRY(d_b.alloc((size_t)N * sizeof(uint32_t)));
+    HIP_TRY(d_mean.alloc((size_t)(n + 1) * m * sizeof(double)));
+    HIP_TRY(d_cov.alloc((size_t)(n + 1) * m * m * sizeof(double)));
+    HIP_TRY(bssm::launch_smooth_summary(hist, idx, d_b.as<uint32_t>(), d_mean.as<double>(), d_cov.as<double>(), 1, n, m, N, st));
+    if (alphahat) HIP_TRY(hipMemcpyAsync(alphahat, d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost, st));
+    if (Vt) HIP_TRY(hipMemcpyAsync(Vt, d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return BSSM_OK;
 }
 
 void bssm_plan_destroy(bssm_plan* plan) {

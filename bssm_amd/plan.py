@@ -34,6 +34,35 @@ class FilterPlan:
         self.n = models[0].n
         self.m = models[0].m
 
+    def update(self, models, hip_stream: int = 0):
+        """New parameter values for the same model structure (the theta proposal of a PM / DA MCMC iteration): the
+        tables are rebuilt and copied into the plan's existing device buffers (bssm_plan_update)."""
+        if not isinstance(models, (list, tuple)):
+            models = [models]
+        keep, packed = [], []
+        for mdl in models:
+            s, k = _lib.pack_model(model_arrays(mdl))
+            packed.append(s); keep.append(k)
+        arr = (_lib.UngModel * len(packed))(*packed)
+        L = _lib.lib()
+        L.bssm_plan_update.argtypes = [C.c_void_p, C.POINTER(_lib.UngModel), C.c_void_p]
+        _lib.check(L.bssm_plan_update(self._h, arr, C.c_void_p(hip_stream)))
+
+    def sample_or_summarise(self, filter_index: int = 0, seed: int = 1, sample: bool = True, hip_stream: int = 0):
+        """src/summary.cpp:82-103 on the kept particle system (needs keep_history): a uniformly drawn back-traced
+        trajectory (n+1) x m, or (alphahat m x (n+1), Vt m x m x (n+1))."""
+        L = _lib.lib()
+        L.bssm_plan_sample_or_summarise.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, _lib.c_double_p,
+                                                    _lib.c_double_p, _lib.c_double_p]
+        n, m = self.n, self.m
+        if sample:
+            alpha = np.zeros((n + 1, m), order="F")
+            _lib.check(L.bssm_plan_sample_or_summarise(self._h, filter_index, seed, C.c_void_p(hip_stream), _lib.dptr(alpha), None, None))
+            return alpha
+        ah, vt = np.zeros((m, n + 1), order="F"), np.zeros((m, m, n + 1), order="F")
+        _lib.check(L.bssm_plan_sample_or_summarise(self._h, filter_index, seed, C.c_void_p(hip_stream), None, _lib.dptr(ah), _lib.dptr(vt)))
+        return ah, vt
+
     def info(self):
         path, nf, blocks, threads = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         bps = C.c_double()

@@ -296,6 +296,14 @@ typedef struct bssm_plan bssm_plan;
 bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int32_t n_rep, uint32_t nsim,
                             uint32_t sampling_method, uint32_t flags);
 void bssm_plan_destroy(bssm_plan* plan);
+/* new parameter values for the same model structure, copied into the plan's existing device tables (no allocation):
+ * the per-iteration step of pseudo-marginal / delayed-acceptance MCMC (src/mcmc.cpp:337-491, 530-685) */
+int bssm_plan_update(bssm_plan* plan, const bssm_ung_model* models, void* hip_stream);
+/* sample_or_summarise (src/summary.cpp:82-103) on the kept particle system of filter `filter` after bssm_plan_run:
+ * alpha (n+1) x m = one uniformly drawn back-traced trajectory; alphahat m x (n+1), Vt m x m x (n+1) = smoothed summary.
+ * Needs BSSM_PLAN_KEEP_HISTORY; any output may be NULL. */
+int bssm_plan_sample_or_summarise(bssm_plan* plan, int32_t filter, uint32_t seed, void* hip_stream, double* alpha,
+                                  double* alphahat, double* Vt);
 /* enqueue one pass on `hip_stream` (a hipStream_t, may be NULL for the default stream); async */
 int bssm_plan_run(bssm_plan* plan, uint32_t seed, uint32_t stream0, void* hip_stream);
 /* wait for the stream and copy the n_models*n_rep log-likelihoods (constants included) */

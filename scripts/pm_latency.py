@@ -15,3 +15,18 @@ for method, N in (("bsf", 200), ("psi", 10), ("psi", 100), ("bsf", 1000)):
         ll = F.logLik(model, N, method=method, seed=s)
     e = (time.perf_counter() - t0) / 200
     print(f"logLik {method} N={N} T=100 m=2: {e*1e3:.3f} ms per call ({ll:.3f})", flush=True)
+
+# the same inner step on a device-resident plan: theta update in place + filter + log-likelihood + one sampled trajectory
+from bssm_amd.plan import FilterPlan
+for method, N in (("bsf", 200), ("psi", 10)):
+    plan = FilterPlan(model, N, method=method, keep_history=True)
+    plan.update(model); plan.run(1); plan.loglik()
+    t0 = time.perf_counter()
+    for s in range(200):
+        plan.update(model)
+        plan.run(s)
+        ll = plan.loglik()[0]
+        tr = plan.sample_or_summarise(0, s, sample=True)
+    e = (time.perf_counter() - t0) / 200
+    print(f"plan: update + run + loglik + sampled trajectory, {method} N={N}: {e*1e3:.3f} ms per iteration ({ll:.3f})", flush=True)
+    plan.close()

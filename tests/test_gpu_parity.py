@@ -159,3 +159,35 @@ def test_gaussian_psi_smoother(oracle):
     assert np.allclose(out["alphahat"], at.T[:5], atol=1e-2) and np.allclose(out["Vt"], Pt[:, :, :5], atol=1e-2)
     bsf = F.particle_smoother(model, 10000, method="bsf", seed=1)
     assert np.allclose(out["alphahat"], bsf["alphahat"], atol=1e-2) and np.allclose(out["Vt"], bsf["Vt"], atol=1e-2)
+
+
+def test_plan_update_and_sample_or_summarise(oracle):
+    """The inner step of pseudo-marginal MCMC on a device-resident plan: new theta -> tables updated
+    in place -> filter -> log-likelihood and one sampled back-traced trajectory / smoothed summary (src/summary.cpp:82-103)"""
+    import ctypes as C
+    from bssm_amd.plan import FilterPlan
+    rng = np.random.default_rng(8)
+    y = rng.poisson(4.0, 40).astype(float); y[6] = np.nan
+    def mk(sd_level, sd_slope):
+        return M.bsm_ng(y, sd_level=sd_level, sd_slope=sd_slope, distribution="poisson", P1=np.diag([1.0, 0.1]), a1=[1.0, 0.0])
+    N, seed = 300, 17
+    m0, m1 = mk(0.3, 0.05), mk(0.2, 0.08)
+    plan = FilterPlan(m0, N, method="bsf", keep_history=True)
+    for mdl in (m0, m1, m0):
+        plan.update(mdl)
+        plan.run(seed)
+        ll = plan.loglik()[0]
+        ref = oracle.bsf_filter(M.model_arrays(mdl), N, seed=seed)
+        assert abs(ll - ref["logLik"]) <= 1e-9 * 40
+        sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
+        r, _ = oracle.make_rng(seed=seed, stream=0)
+        pick = min(int(oracle.lib().orc_rng_uniform(C.byref(r), 3, 0, 0, 0) * N), N - 1)
+        traj = plan.sample_or_summarise(0, seed, sample=True)
+        assert np.allclose(traj, sm[:, :, pick].T, rtol=1e-9, atol=1e-12)
+        ah, vt = plan.sample_or_summarise(0, seed, sample=False)
+        mean, cov = oracle.summary(sm)
+        assert np.allclose(ah, mean, rtol=1e-9, atol=1e-12) and np.allclose(vt, cov, rtol=1e-8, atol=1e-12)
+    # a model of a different structure is refused
+    with pytest.raises(Exception):
+        plan.update(M.bsm_ng(y, sd_level=0.3, distribution="poisson", P1=np.array([[1.0]])))
+    plan.close()
