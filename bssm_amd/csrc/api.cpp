@@ -34,6 +34,9 @@ thread_local double g_is_timing[2] = {0.0, 0.0};  // last IS post-correction on 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
+}  // namespace
+namespace bssm { int set_error(int code, const std::string& msg) { return fail(code, msg); } }
+namespace {
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
@@ -813,6 +816,7 @@ int bssm_update_model_builtin(int model_type, const int32_t* flags, const double
 }
 
 // ------------------------------------------------------------------ user-defined models (run-time compiled)
+}  // extern "C"
 namespace {
 std::string library_dir() {
   Dl_info info;
@@ -831,6 +835,7 @@ uint64_t fnv1a(const std::string& s) {
 std::mutex g_user_mu;
 std::map<std::string, int> g_user_loaded;  // library path -> registry slot
 }  // namespace
+extern "C" {
 
 int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity) {
   if (!source || !lib_path || lib_path_capacity < 16) return fail(BSSM_ERR_INVALID, "NULL argument");
@@ -1584,6 +1589,13 @@ int bssm_plan_update(bssm_plan* plan, const bssm_ung_model* models, void* hip_st
   HIP_TRY(hipMemcpyAsync(plan->db.init.p, hi, is * F * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));
   plan->db.const_terms = consts;
+  return BSSM_OK;
+}
+
+int bssm_plan_approx_loglik(const bssm_plan* plan, double* approx_loglik) {
+  if (!plan || !approx_loglik) return fail(BSSM_ERR_INVALID, "NULL argument");
+  if (!plan->psi) return fail(BSSM_ERR_INVALID, "a bootstrap plan has no approximate log-likelihood");
+  for (size_t f = 0; f < plan->db.const_terms.size(); f++) approx_loglik[f] = plan->db.const_terms[f];
   return BSSM_OK;
 }
 

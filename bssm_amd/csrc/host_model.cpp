@@ -710,7 +710,9 @@ bool gaussian_smoothing_setup(const HostModel& h, PsiSetup* out) {
   return ok;
 }
 
-double approx_loglik_only(const HostModel& h) {
+double approx_loglik_only(const HostModel& h) { return approx_loglik_mode(h, nullptr); }
+
+double approx_loglik_mode(const HostModel& h, std::vector<double>* mode_out) {
   const Sys S(h);
   Approx ap;
   ap.y.assign((size_t)h.p * h.n, 0.0);
@@ -719,6 +721,7 @@ double approx_loglik_only(const HostModel& h) {
   bool ok = true;
   run_laplace(h, S, &ap, &mode, &ok);
   if (!ok) return -INFINITY;
+  if (mode_out) *mode_out = mode;
   const double gll = gaussian_loglik(S, ap);
   update_scales(h, ap, mode, &scales);
   double ssc = 0;

@@ -65,6 +65,10 @@ bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct)
 
 // log-likelihood of the Gaussian approximation only (nsim = 0 path, src/model_ssm_ung.cpp:214-234)
 double approx_loglik_only(const HostModel& hm);
+// same, also returning the converged mode (p x n) -- what approx_mcmc::amcmc stores per accepted value
+double approx_loglik_mode(const HostModel& hm, std::vector<double>* mode);
+// records the message bssm_amd_last_error() returns on this thread; returns `code`
+int set_error(int code, const std::string& msg);
 
 int pad_dim(int d);  // 1,2,4,8,16
 int pad_noise_dim(int MP, int k);  // padded noise dimension with a kernel instantiation for this MP

@@ -27,13 +27,36 @@ namespace bssm {
 // loglik[f] = sum_t llinc[f][t] in time order (the reference's accumulation order), -inf after a degenerate step.
 // (static: every translation unit that instantiates the step kernels carries its own copy, incl. run-time compiled
 // user models)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)) before it arrives; the filter kernels exchange data between lanes through
+// LDS alone (history / state stores are never read back inside a launch), so their barriers need not wait for the
+// HBM round trip of stores that are still in flight.
+__device__ __forceinline__ void lds_barrier() {
+  __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 static __global__ void loglik_finalize_kernel(double* __restrict__ loglik, const double* __restrict__ llinc,
                                               const int* __restrict__ dead_at, int n, int F) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per filter: coalesced loads of 64 increments, then the increments are added in time order by reading the
+  // lanes one after the other (the same summation order as a sequential loop, without its serialised load latency)
+  const int f = blockIdx.x, lane = threadIdx.x;
   if (f >= F) return;
+  const double* src = llinc + (size_t)f * (n + 1);
   double acc = 0.0;
-  for (int t = 0; t < n; t++) acc += llinc[(size_t)f * (n + 1) + t];
-  loglik[f] = dead_at[f] ? -INFINITY : acc;
+  for (int t0 = 0; t0 < n; t0 += 64) {
+    const double v = (t0 + lane < n) ? src[t0 + lane] : 0.0;
+    const int cnt = min(64, n - t0);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    if (cnt == 64) {
+#pragma unroll
+      for (int j = 0; j < 64; j++)
+        acc += __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+    } else {
+      for (int j = 0; j < cnt; j++)
+        acc += __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+    }
+  }
+  if (lane == 0) loglik[f] = dead_at[f] ? -INFINITY : acc;
 }
 
 
@@ -213,7 +236,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     for (int r = 1; r < PPT; r++) mx = fmax(mx, w[r]);
     mx = wave_max(mx);
     if (lane == 0) s_max[wave] = mx;
-    __syncthreads();  // (1)
+    lds_barrier();  // (1)
     double M = s_max[0];
     for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
     // stage this step's transition operands in LDS (every wave is past the previous transition here;
@@ -232,7 +255,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       if (lane == 63) s_tot[r * nw + wave] = sc[r];
       if (b.weights && i < N) b.weights[((size_t)f * (n + 1) + t) * N + i] = e;
     }
-    __syncthreads();  // (2)
+    lds_barrier();  // (2)
     // every wave scans the <= 128 chunk totals redundantly (saves a barrier)
     const int Q = PPT * nw;
     const double t0 = (lane < Q) ? s_tot[lane] : 0.0;
@@ -256,7 +279,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     }
     loglik += M + fast_log(S / dN);                       // :683
     if (t == n) break;
-    __syncthreads();  // (3) cdf visible
+    lds_barrier();  // (3) cdf visible
 
     // ---- stratified resampling (stratified_sample.cpp:15-26) + ancestor gather (:657-661)
     const double c_scale = S / dN;
@@ -278,7 +301,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       if (b.indices && i < N) b.indices[((size_t)f * n + t) * N + i] = (uint32_t)lo;
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();  // (4) all ancestors read before the slots are overwritten
+    lds_barrier();  // (4) all ancestors read before the slots are overwritten
 
     // ---- transition to t+1 and the weights there
     const double* mt = s_mats;
@@ -402,7 +425,7 @@ __device__ __forceinline__ double block_scan_strided(const double (&e)[PPT], dou
     sc[r] = wave_scan_incl(e[r]);
     if (lane == 63) s_tot[r * NW + wave] = sc[r];
   }
-  __syncthreads();
+  lds_barrier();
   constexpr int Q = PPT * NW;  // <= 32
   const double tq = (lane < Q) ? s_tot[lane] : 0.0;
   const double incl = wave_scan_incl(tq);
@@ -543,14 +566,14 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
     double mx = -INFINITY;
     if (wave_has_partials) mx = wave_max(pmax);
     if (lane == 0) s_red[wave] = mx;
-    __syncthreads();
+    lds_barrier();
     const double M = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
     if (wave_has_partials) {
       const double scale = (tid < B) ? fast_exp(pmax - M) : 0.0;
       const double ss = psum * scale;
       double qi = wave_scan_incl(ss);
       if (lane == 63) s_red[4 + wave] = qi;
-      __syncthreads();
+      lds_barrier();
       double off = 0.0;
       for (int q = 0; q < wave; q++) off += s_red[4 + q];
       qi += off;
@@ -559,10 +582,10 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
       if (tid == pb) s_myscale = scale;
     } else {
       if (lane == 63) s_red[4 + wave] = 0.0;
-      __syncthreads();
+      lds_barrier();
     }
     const double S = ((s_red[4] + s_red[5]) + s_red[6]) + s_red[7];
-    __syncthreads();
+    lds_barrier();
     if (b.weights) {  // also on the degenerate step: the reference stores exp(w - max) before it tests the sum (:676-682)
       const double myscale = s_myscale;
 #pragma unroll
@@ -681,10 +704,10 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
     mx = fmax(mx, w[r]);
   }
   BSSM_STAMP(8)
-  __syncthreads();  // s_red reuse
+  lds_barrier();  // s_red reuse
   mx = wave_max(mx);
   if (lane == 0) s_red[wave] = mx;
-  __syncthreads();
+  lds_barrier();
   const double Mb = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
@@ -778,7 +801,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     }
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  hipLaunchKernelGGL(loglik_finalize_kernel, dim3((b.F + 63) / 64), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);
+  hipLaunchKernelGGL(loglik_finalize_kernel, dim3(b.F), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);
   return hipGetLastError();
 }
 

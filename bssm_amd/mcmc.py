@@ -1,0 +1,266 @@
+"""``run_mcmc`` for non-Gaussian models: Python mirror of R/run_mcmc.R:392-559 over the C ABI.
+
+The chains themselves run in the library (bssm_run_mcmc, csrc/mcmc.cpp): pseudo-marginal (``pm``) and delayed
+acceptance (``da``) filter on the GPU once per iteration through a device-resident plan; the approximate chain
+(``approx``, and the first stage of ``is1``/``is2``/``is3``) is host arithmetic, and the IS types finish with
+``post_correct``'s device pass over the stored values (src/R_mcmc.cpp:331-470).
+
+As in the reference the standard deviations and dispersion parameters of ``bsm_ng`` / ``ar1_ng`` are sampled on the
+log scale (R/run_mcmc.R:471-489) and returned on the natural scale (:537-543).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+from .filters import check_intmax, _default_seed, _INT_MAX
+from .models import BssmModel, model_arrays, model_type, prior_tables
+from . import post_correct as PC
+
+_PRIOR_FN = C.CFUNCTYPE(C.c_double, _lib.c_double_p, C.c_int32, C.c_void_p)
+_UPDATE_FN = C.CFUNCTYPE(C.c_int, _lib.c_double_p, C.c_int32, C.POINTER(_lib.UngModel), C.c_void_p)
+
+
+class McmcJob(C.Structure):
+    _fields_ = [("model_type", C.c_int32), ("flags", C.POINTER(C.c_int32)), ("n_par", C.c_int32),
+                ("prior_distributions", C.POINTER(C.c_int32)), ("prior_parameters", _lib.c_double_p),
+                ("update_fn", _UPDATE_FN), ("prior_fn", _PRIOR_FN), ("user", C.c_void_p),
+                ("mcmc_type", C.c_int32), ("sampling_method", C.c_uint32), ("nsim", C.c_uint32),
+                ("iter", C.c_uint64), ("burnin", C.c_uint64), ("thin", C.c_uint32),
+                ("gamma", C.c_double), ("target_acceptance", C.c_double), ("end_ram", C.c_int32), ("seed", C.c_uint32),
+                ("output_type", C.c_int32)]
+
+
+class McmcOut(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("n_stored", C.c_int32), ("acceptance_rate", C.c_double),
+                ("S", _lib.c_double_p), ("theta", _lib.c_double_p), ("counts", _lib.c_u32_p),
+                ("posterior", _lib.c_double_p), ("approx_loglik", _lib.c_double_p), ("prior", _lib.c_double_p),
+                ("modes", _lib.c_double_p), ("alpha", _lib.c_double_p), ("alphahat", _lib.c_double_p),
+                ("Vt", _lib.c_double_p)]
+
+
+_MCMC_TYPES = {"approx": 0, "pm": 1, "da": 2}
+_UPDATABLE = ("Z", "T", "R", "a1", "P1", "D", "C", "beta")
+
+
+def _transformed(model: BssmModel):
+    """names sampled on the log scale, R/run_mcmc.R:471-489"""
+    names = list(model.get("theta_names", []))
+    dispersion = model["distribution"] in ("negative binomial", "gamma")
+    if model.inherits("bsm_ng"):
+        return [i for i, nm in enumerate(names) if nm.startswith("sd_") or (nm == "phi" and dispersion)]
+    if model.inherits("ar1_ng"):
+        return [i for i, nm in enumerate(names) if nm == "sigma" or (nm == "phi" and dispersion)]
+    return []
+
+
+def run_mcmc(model: BssmModel, iter: int, particles: int | None = None, output_type: str = "full", mcmc_type: str = "is2",
+             sampling_method: str = "psi", burnin: int | None = None, thin: int = 1, gamma: float = 2 / 3,
+             target_acceptance: float = 0.234, S=None, end_adaptive_phase: bool = False, local_approx: bool = True,
+             threads: int = 1, seed: int | None = None, max_iter: int = 100, conv_tol: float = 1e-8):
+    """R/run_mcmc.R:392-559 (run_mcmc.nongaussian).  Returns the ``mcmc_output`` dictionary: theta (n_stored x n_par,
+    natural scale), counts, posterior, S, acceptance_rate, and by type weights / modes (approx, is*), alpha
+    ((n+1) x m x n_stored, output 'full'), alphahat ((n+1) x m) and Vt (output 'summary')."""
+    if not model.inherits("nongaussian"):
+        raise TypeError("run_mcmc here covers models of class 'nongaussian'")
+    if not isinstance(end_adaptive_phase, (bool, np.bool_)):
+        raise ValueError("Argument 'end_adaptive_phase' should be TRUE or FALSE. ")
+    if not isinstance(local_approx, (bool, np.bool_)):
+        raise ValueError("Argument 'local_approx' should be TRUE or FALSE. ")
+    seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
+    threads = check_intmax(threads, "threads")
+    thin = check_intmax(thin, "thin", max=100)
+    iter = check_intmax(iter, "iter", max=int(1e12))
+    burnin = check_intmax(iter // 2 if burnin is None else burnin, "burnin", False, max=int(1e12))
+    if burnin > iter:
+        raise ValueError("Argument 'burnin' should be smaller than 'iter'.")
+    for nm, v in (("target_acceptance", target_acceptance), ("gamma", gamma)):
+        if not (0 < v < 1):
+            raise ValueError(f"Argument '{nm}' must be on interval (0, 1).")
+    if np.asarray(model["theta"]).size == 0:
+        raise ValueError("No unknown parameters ('model$theta' has length of zero).")
+    if np.any(np.isnan(np.asarray(model["u"], dtype=float))):
+        raise ValueError("Missing values not allowed in 'u'.")
+    otype = PC._OUTPUT_TYPES[output_type.lower() if isinstance(output_type, str) else output_type]
+    mcmc_type = mcmc_type.lower()
+    if mcmc_type not in ("pm", "da", "is1", "is2", "is3", "approx"):
+        raise ValueError("'arg' should be one of 'pm', 'da', 'is1', 'is2', 'is3', 'approx'")
+    if mcmc_type == "approx":
+        particles = 0
+    elif particles is None or particles < 2:
+        raise ValueError("Number of state samples less than 2, use 'mcmc_type' 'approx' instead.")
+    else:
+        particles = check_intmax(particles, "particles")
+    sampling_method = sampling_method.lower()
+    if sampling_method not in ("psi", "bsf"):
+        raise ValueError("sampling_method must be 'psi' or 'bsf' (SPDK is not a particle filter path)")
+    t0 = time.perf_counter()
+
+    model = BssmModel(model.classes, **{**model, "max_iter": check_intmax(max_iter, "max_iter", False),
+                                        "conv_tol": float(conv_tol), "local_approx": bool(local_approx)})
+    theta0 = np.array(model["theta"], dtype=np.float64).reshape(-1)
+    d = theta0.size
+    tr = _transformed(model)
+    theta0[tr] = np.log(np.maximum(0.001, theta0[tr]))
+    S_in = np.diag(0.1 * np.maximum(0.1, np.abs(theta0))) if S is None else np.array(S, dtype=np.float64).reshape(d, d)
+    S_buf = np.asfortranarray(np.tril(S_in))
+
+    # ---- the model struct over writable buffers
+    arr = model_arrays(model)
+    for k in _UPDATABLE + ("initial_mode",):
+        if arr.get(k) is not None:
+            arr[k] = np.array(arr[k], dtype=np.float64, order="F", copy=True)
+    smod, keep = _lib.pack_model(arr)
+    mt = model_type(model)
+    flags = PC._builtin_flags(model)
+
+    job = McmcJob()
+    job.model_type, job.n_par = mt, d
+    cb_keep = []
+    if flags is not None:
+        fl = (C.c_int32 * len(flags))(*flags)
+        pd, pp = prior_tables(model["priors"])
+        if pd.size != d:
+            raise ValueError("the model's priors do not match its theta")
+        job.flags = fl
+        job.prior_distributions = pd.ctypes.data_as(C.POINTER(C.c_int32))
+        job.prior_parameters = _lib.dptr(pp)
+        cb_keep += [fl, pd, pp]
+    else:
+        update, prior = model.get("update_fn"), model.get("prior_fn")
+        if update is None or prior is None:
+            raise ValueError("ssm_ung / ssm_mng models need 'update_fn' and 'prior_fn' for run_mcmc")
+        failure = []
+
+        def _update(th_p, n_par, mod_p, _user):
+            try:
+                th = np.ctypeslib.as_array(th_p, shape=(n_par,)).copy()
+                for k, v in (update(th) or {}).items():
+                    if k == "phi":
+                        if arr.get("p", 1) > 1:
+                            arr["phi_p"][...] = np.asarray(v, dtype=np.float64).reshape(-1)
+                        else:
+                            mod_p.contents.phi = float(v)
+                    elif k in _UPDATABLE:
+                        arr[k][...] = np.asarray(v, dtype=np.float64).reshape(arr[k].shape, order="F")
+                    else:
+                        raise ValueError(f"update_fn returned unknown component '{k}'")
+                return 0
+            except Exception as e:  # reported through the return code: exceptions cannot cross the C frames
+                failure.append(e)
+                return 1
+
+        def _prior(th_p, n_par, _user):
+            try:
+                return float(prior(np.ctypeslib.as_array(th_p, shape=(n_par,)).copy()))
+            except Exception as e:
+                failure.append(e)
+                return float("nan")
+
+        job.update_fn, job.prior_fn = _UPDATE_FN(_update), _PRIOR_FN(_prior)
+        cb_keep += [job.update_fn, job.prior_fn]
+    chain = _MCMC_TYPES.get(mcmc_type, 0)
+    job.mcmc_type = chain
+    job.sampling_method = 1 if sampling_method == "psi" else 2
+    job.nsim = particles
+    job.iter, job.burnin, job.thin = iter, burnin, thin
+    job.gamma, job.target_acceptance, job.end_ram, job.seed = gamma, target_acceptance, int(end_adaptive_phase), seed
+    job.output_type = otype
+
+    n, m, p = model.n, model.m, model.p
+    cap = max(1, (iter - burnin) // thin + 1)
+    out = McmcOut()
+    out.capacity = cap
+    theta_s = np.zeros((d, cap), order="F")
+    counts = np.zeros(cap, dtype=np.uint32)
+    posterior = np.zeros(cap)
+    out.S, out.theta, out.counts, out.posterior = _lib.dptr(S_buf), _lib.dptr(theta_s), counts.ctypes.data_as(_lib.c_u32_p), _lib.dptr(posterior)
+    al = prior_s = modes = alpha = ah = vt = None
+    if chain == 0:
+        al, prior_s, modes = np.zeros(cap), np.zeros(cap), np.zeros((p * n, cap), order="F")
+        out.approx_loglik, out.prior, out.modes = _lib.dptr(al), _lib.dptr(prior_s), _lib.dptr(modes)
+    elif otype == 1:
+        alpha = np.zeros((n + 1, m, cap), order="F")
+        out.alpha = _lib.dptr(alpha)
+    elif otype == 2:
+        ah, vt = np.zeros((m, n + 1), order="F"), np.zeros((m, m, n + 1), order="F")
+        out.alphahat, out.Vt = _lib.dptr(ah), _lib.dptr(vt)
+    L = _lib.lib()
+    L.bssm_run_mcmc.argtypes = [C.POINTER(_lib.UngModel), _lib.c_double_p, C.POINTER(McmcJob), C.POINTER(McmcOut)]
+    rc = L.bssm_run_mcmc(C.byref(smod), _lib.dptr(theta0), C.byref(job), C.byref(out))
+    if flags is None and failure:
+        raise failure[0]
+    _lib.check(rc)
+    ns = out.n_stored
+    res = dict(theta=np.ascontiguousarray(theta_s[:, :ns].T), counts=counts[:ns].copy(), posterior=posterior[:ns].copy(),
+               S=np.array(S_buf), acceptance_rate=out.acceptance_rate, iter=iter, burnin=burnin, thin=thin,
+               mcmc_type=mcmc_type, output_type=otype, seed=seed, theta_names=list(model.get("theta_names", [])),
+               model_type=model.classes[0], time_chain=time.perf_counter() - t0)
+    if chain == 0:
+        res["modes"] = modes[:, :ns].reshape(p, n, ns, order="F") if p > 1 else modes[:, :ns].reshape(n, 1, ns, order="F")
+        res["approx_loglik"], res["prior"] = al[:ns].copy(), prior_s[:ns].copy()
+        res["weights"] = np.ones(ns)
+        if mcmc_type != "approx":
+            # IS correction of the stored values on the sampling scale, as nongaussian_is_mcmc does before run_mcmc.R
+            # maps theta back (src/R_mcmc.cpp:376-392)
+            tc = time.perf_counter()
+            if sampling_method == "psi":
+                corrected = PC.post_correct(model, res, particles, threads=threads, is_type=mcmc_type, seed=seed)
+            else:  # approx_mcmc::is_correction_bsf (src/approx_mcmc.cpp:447-518): weight = exp(loglik - approx_loglik)
+                it = int(mcmc_type[-1])
+                th_c, cn_c, al_c, post_c = res["theta"], res["counts"], res["approx_loglik"], res["posterior"]
+                if it == 3:  # expand(), src/approx_mcmc.cpp:49-88
+                    rep = cn_c.astype(np.int64)
+                    th_c, al_c, post_c = np.repeat(th_c, rep, axis=0), np.repeat(al_c, rep), np.repeat(post_c, rep)
+                    cn_c = np.ones(int(rep.sum()), dtype=np.uint32)
+                r = PC.is_correction(model, th_c, cn_c, particles, method="bsf", approx_loglik=al_c, is_type=it,
+                                     output_type=otype, seed=seed, threads=threads)
+                with np.errstate(divide="ignore"):
+                    corrected = dict(weights=r["weights"], loglik=r["loglik"], theta=th_c, counts=cn_c,
+                                     posterior=post_c + np.log(r["weights"]), timing_ms=r.get("timing_ms"))
+                if otype == 1:
+                    corrected["alpha"] = r["alpha"]
+                elif otype == 2:
+                    corrected["alphahat"], corrected["Vt"] = np.ascontiguousarray(r["alphahat"].T), r["Vt"]
+            for k in ("weights", "posterior", "theta", "counts", "modes", "alpha", "alphahat", "Vt", "loglik", "timing_ms"):
+                if k in corrected:
+                    res[k] = corrected[k]
+            res["time_postcorrection"] = time.perf_counter() - tc
+    elif otype == 1:
+        res["alpha"] = alpha[:, :, :ns].copy()
+    elif otype == 2:
+        res["alphahat"], res["Vt"] = np.ascontiguousarray(ah.T), vt
+    res["theta"] = np.array(res["theta"])
+    res["theta"][:, tr] = np.exp(res["theta"][:, tr])
+    res["time"] = time.perf_counter() - t0
+    return res
+
+
+def summary(out: dict, variable: str = "theta", times=None):
+    """Weighted posterior means and standard deviations (R/summary.R: weights = counts x IS weights): for
+    ``variable='theta'`` per parameter, for ``'states'`` per state at the (1-based) ``times`` from the stored
+    trajectories (output 'full') or the running summary (output 'summary')."""
+    w = np.asarray(out["counts"], dtype=np.float64) * np.asarray(out.get("weights", np.ones(len(out["counts"]))), dtype=np.float64)
+    w = w / w.sum()
+    if variable == "theta":
+        mean = w @ out["theta"]
+        sd = np.sqrt(np.maximum(0.0, w @ (out["theta"] - mean) ** 2))
+        return dict(Mean=mean, SD=sd, names=out.get("theta_names"))
+    if variable != "states":
+        raise ValueError("variable must be 'theta' or 'states'")
+    if "alpha" in out:
+        a = out["alpha"]  # (n+1) x m x n_stored
+        mean = a @ w
+        sd = np.sqrt(np.maximum(0.0, (a - mean[:, :, None]) ** 2 @ w))
+    elif "alphahat" in out:
+        mean = np.asarray(out["alphahat"])
+        sd = np.sqrt(np.stack([np.diag(out["Vt"][:, :, t]) for t in range(mean.shape[0])]))
+    else:
+        raise ValueError("the run kept no state output (output_type 'theta')")
+    if times is not None:
+        idx = np.atleast_1d(np.asarray(times, dtype=int)) - 1
+        mean, sd = mean[idx], sd[idx]
+    return dict(Mean=mean, SD=sd)

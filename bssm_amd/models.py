@@ -23,7 +23,8 @@ DISTRIBUTIONS = ("svm", "poisson", "binomial", "negative binomial", "gamma", "ga
 
 @dataclass
 class Prior:
-    """Stand-in for bssm's prior objects (R/priors.R): only ``init`` matters on this path."""
+    """bssm's prior objects (R/priors.R): ``init`` is the parameter value the filters use; ``kind`` / ``params`` feed the
+    chains of mcmc.run_mcmc (prior tables as R/priors.R:246-261 builds them)."""
     init: float
     kind: str = "fixed"
     params: tuple = ()
@@ -34,6 +35,30 @@ def halfnormal(init, sd=1.0): return Prior(float(init), "halfnormal", (sd,))
 def uniform(init, min=0.0, max=1.0): return Prior(float(init), "uniform", (min, max))
 def tnormal(init, mean=0.0, sd=1.0, min=-np.inf, max=np.inf): return Prior(float(init), "tnormal", (mean, sd, min, max))
 def gamma(init, shape=1.0, rate=1.0): return Prior(float(init), "gamma", (shape, rate))
+
+
+_PRIOR_CODES = {"uniform": 0, "halfnormal": 1, "normal": 2, "tnormal": 3, "gamma": 4}
+
+
+def prior_tables(priors):
+    """(prior_distributions int32[n_par], prior_parameters 4 x n_par column-major) -- combine_priors, R/priors.R:246-261"""
+    pd = np.zeros(len(priors), dtype=np.int32)
+    pp = np.full((4, len(priors)), np.nan, order="F")
+    for i, pr in enumerate(priors):
+        if not isinstance(pr, Prior) or pr.kind not in _PRIOR_CODES:
+            raise ValueError("every estimated parameter needs a prior (uniform, halfnormal, normal, tnormal or gamma)")
+        pd[i] = _PRIOR_CODES[pr.kind]
+        pp[:len(pr.params), i] = pr.params
+    return pd, pp
+
+
+def _beta_priors(beta):
+    if beta is None:
+        return [], []
+    bl = list(beta) if isinstance(beta, (list, tuple)) else [beta]
+    if all(_is_prior(b) for b in bl):
+        return bl, ["coef_%d" % (i + 1) for i in range(len(bl))]
+    return [], []
 
 
 def _val(x):
@@ -295,15 +320,20 @@ def bsm_ng(y, sd_level=None, sd_slope=None, sd_seasonal=None, sd_noise=None, dis
             raise ValueError("Parameter 'phi' must be positive.")
     else:
         phi_v = 1.0
-    theta = [p.init for p in (sd_level, sd_slope, sd_seasonal, sd_noise) if _is_prior(p)]
+    named = [(nm, p) for nm, p in (("sd_level", sd_level), ("sd_slope", sd_slope), ("sd_seasonal", sd_seasonal),
+                                   ("sd_noise", sd_noise)) if _is_prior(p)]
+    theta = [p.init for _, p in named]
+    priors, names = [p for _, p in named], [nm for nm, _ in named]
     if phi_est:
-        theta.append(phi_v)
-    theta += list(bt) if xr.shape[1] and _is_prior(beta if not isinstance(beta, (list, tuple)) else beta[0]) else []
+        theta.append(phi_v); priors.append(phi); names.append("phi")
+    bpri, bnames = _beta_priors(beta) if xr.shape[1] else ([], [])
+    theta += list(bt) if bpri else []
+    priors += bpri; names += bnames
     return BssmModel(("bsm_ng", "ssm_ung", "nongaussian", "bssm_model"), **_common_tail(dict(
         y=y, Z=Z, T=T, R=R, a1=a1v, P1=P1m, phi=phi_v, u=u, xreg=xr, beta=bt, D=_f(np.zeros(1)),
         C=_check_C(C, m, n), slope=slope, seasonal=seasonal, noise=noise, period=period, fixed=fixed,
         distribution=distribution, initial_mode=_f(init_mode(y, u, distribution)).reshape(-1, 1),
-        theta=np.asarray(theta, dtype=float), phi_est=phi_est)))
+        theta=np.asarray(theta, dtype=float), phi_est=phi_est, priors=priors, theta_names=names)))
 
 
 def svm(y, mu=None, rho=None, sd_ar=None, sigma=None):
@@ -333,7 +363,8 @@ def svm(y, mu=None, rho=None, sd_ar=None, sigma=None):
         a1=_f(a1), P1=_f(np.array([[sd_v ** 2 / (1 - rho_v ** 2)]])), phi=phi, xreg=_f(np.zeros((y.shape[0], 0))),
         beta=_f(np.zeros(0)), D=_f(np.zeros(1)), C=_f(C), initial_mode=_f(initial_mode).reshape(-1, 1),
         svm_type=svm_type, distribution="svm", u=_f(np.ones(y.shape[0])), phi_est=not svm_type,
-        theta=np.array([rho_v, sd_v, third]))))
+        theta=np.array([rho_v, sd_v, third]), priors=[rho, sd_ar, mu if mu is not None else sigma],
+        theta_names=["rho", "sd_ar", "mu" if mu is not None else "sigma"])))
 
 
 def ar1_ng(y, rho, sigma, mu, distribution, phi=None, u=None, beta=None, xreg=None):
@@ -351,13 +382,16 @@ def ar1_ng(y, rho, sigma, mu, distribution, phi=None, u=None, beta=None, xreg=No
     use_phi = distribution in ("negative binomial", "gamma")
     phi_est = use_phi and _is_prior(phi)
     phi_v = _val(phi) if use_phi else 1.0
+    bpri, bnames = _beta_priors(beta) if xr.shape[1] else ([], [])
     theta = [rho_v, sig_v] + ([mu_v] if _is_prior(mu) else []) + ([phi_v] if phi_est else []) + list(bt)
+    priors = [rho, sigma] + ([mu] if _is_prior(mu) else []) + ([phi] if phi_est else []) + bpri
+    names = ["rho", "sigma"] + (["mu"] if _is_prior(mu) else []) + (["phi"] if phi_est else []) + bnames
     return BssmModel(("ar1_ng", "ssm_ung", "nongaussian", "bssm_model"), **_common_tail(dict(
         y=y, Z=_f(np.ones((1, 1))), T=_f(np.full((1, 1, 1), rho_v)), R=_f(np.full((1, 1, 1), sig_v)),
         a1=_f(np.array([mu_v])), P1=_f(np.array([[sig_v ** 2 / (1 - rho_v ** 2)]])), phi=phi_v, u=u, xreg=xr, beta=bt,
         D=_f(np.zeros(1)), C=_f(np.array([[mu_v * (1 - rho_v)]])),
         initial_mode=_f(init_mode(y, u, distribution)).reshape(-1, 1), distribution=distribution,
-        mu_est=_is_prior(mu), phi_est=phi_est, theta=np.asarray(theta, dtype=float))))
+        mu_est=_is_prior(mu), phi_est=phi_est, theta=np.asarray(theta, dtype=float), priors=priors, theta_names=names)))
 
 
 def ssm_mng(y, Z, T, R, a1=None, P1=None, distribution="poisson", phi=1.0, u=None, init_theta=(), D=None, C=None,

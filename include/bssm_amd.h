@@ -332,6 +332,73 @@ int bssm_debug_math(int fn, const double* in, double* out, int32_t n);
 int bssm_debug_stream_copy(uint64_t n_doubles);
 int bssm_plan_debug_timeline(bssm_plan* plan, uint32_t seed, double* avg_delta_cycles);
 
+/* approximate log-likelihood of each of the plan's filters (psi plans: the Gaussian-approximation term ll(1) of
+ * log_likelihood(), src/model_ssm_ung.cpp:196-208; bsf plans have none and the call fails) */
+int bssm_plan_approx_loglik(const bssm_plan* plan, double* approx_loglik);
+
+/* ---- Markov chain Monte Carlo drivers: the callers of the path ----
+ * replaces _bssm_nongaussian_pm_mcmc / _bssm_nongaussian_da_mcmc / _bssm_nongaussian_is_mcmc's chain stage:
+ *   mcmc::pm_mcmc (src/mcmc.cpp:337-491), mcmc::da_mcmc (src/mcmc.cpp:530-685), approx_mcmc::amcmc
+ *   (src/approx_mcmc.cpp:110-232), with ramcmc::adapt_S (CRAN ramcmc, Vihola 2012: S S' <- S (I + eta (a - a*) u u' / |u|^2) S',
+ *   eta = min(1, d i^-gamma)) as the proposal adaptation.
+ * The per-iteration likelihood of pm / da is one pass of a device-resident plan (bssm_plan_update + bssm_plan_run);
+ * the approximate chain (mcmc_type 0) is host-only and is followed by bssm_is_correction() for the `is` types
+ * (src/R_mcmc.cpp:331-470).
+ *
+ * Built-in models (bsm_ng / svm / ar1_ng) use the library's update_model maps and the reference's prior tables:
+ * prior_distributions[n_par] (0 uniform, 1 half-normal, 2 normal, 3 truncated normal, 4 gamma) and prior_parameters
+ * 4 x n_par column-major, as R/priors.R:246-261 builds them; log_prior_pdf follows src/model_bsm_ng.cpp:90-136,
+ * src/model_svm.cpp:50-88, src/model_ar1_ng.cpp:63-118.  General ssm_ung / ssm_mng models supply the two callbacks the
+ * reference takes as R closures (src/model_ssm_ung.cpp:41-82): update_fn rewrites the arrays the model points at (and
+ * model->phi), prior_fn returns log p(theta). */
+typedef double (*bssm_prior_fn)(const double* theta, int32_t n_par, void* user);
+typedef int (*bssm_update_fn)(const double* theta, int32_t n_par, bssm_ung_model* model, void* user);
+enum { BSSM_MCMC_APPROX = 0, BSSM_MCMC_PM = 1, BSSM_MCMC_DA = 2 };
+typedef struct bssm_mcmc_job {
+  int32_t model_type;                 /* BSSM_SSM_MNG .. BSSM_AR1_NG */
+  const int32_t* flags;               /* built-in models: as bssm_update_model_builtin */
+  int32_t n_par;
+  const int32_t* prior_distributions; /* built-in models */
+  const double* prior_parameters;
+  bssm_update_fn update_fn;           /* general models (NULL for built-ins) */
+  bssm_prior_fn prior_fn;
+  void* user;
+  int32_t mcmc_type;                  /* BSSM_MCMC_* */
+  uint32_t sampling_method;           /* BSSM_PSI / BSSM_BSF (pm, da) */
+  uint32_t nsim;
+  uint64_t iter, burnin;
+  uint32_t thin;
+  double gamma, target_acceptance;
+  int32_t end_ram;                    /* stop adapting after the burn-in */
+  uint32_t seed;
+  int32_t output_type;                /* pm / da: 1 one trajectory per stored value, 2 running summary, 3 theta only */
+} bssm_mcmc_job;
+typedef struct bssm_mcmc_out {
+  int32_t capacity;        /* in: room for this many stored values (floor((iter - burnin) / thin) always suffices) */
+  int32_t n_stored;        /* out */
+  double acceptance_rate;  /* out */
+  double* S;               /* n_par x n_par lower triangular, in: initial proposal factor, out: adapted */
+  double* theta;           /* n_par x capacity */
+  uint32_t* counts;        /* capacity */
+  double* posterior;       /* capacity: log prior + log-likelihood (approximate chain: + approximate log-likelihood) */
+  double* approx_loglik;   /* capacity, approximate chain only (may be NULL) */
+  double* prior;           /* capacity, approximate chain only (may be NULL) */
+  double* modes;           /* (p n) x capacity, approximate chain only (may be NULL) */
+  double* alpha;           /* (n+1) x m x capacity, pm / da with output_type 1 */
+  double* alphahat;        /* m x (n+1), pm / da with output_type 2 */
+  double* Vt;              /* m x m x (n+1), pm / da with output_type 2 */
+} bssm_mcmc_out;
+/* `model` carries the structure and the initial values; the chain works on its own copies of the theta-dependent
+ * arrays (T, R, P1, a1, C, beta) for built-in models.  With callbacks the arrays `model` points at are the caller's and
+ * update_fn rewrites them in place.  Errors: BSSM_ERR_INVALID for a non-finite initial prior / log-likelihood or when no
+ * proposal was accepted (the reference stops with the same conditions, src/mcmc.cpp:352,363,485). */
+int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_job* job, bssm_mcmc_out* out);
+/* the chain's own random numbers (tests): standard normals of iteration `iter` and its acceptance uniforms */
+void bssm_mcmc_draws(uint32_t seed, uint64_t iter, int32_t n_par, double* normals, double* uniforms2);
+/* log_prior_pdf of a built-in model (tests, host-only) */
+double bssm_log_prior_builtin(int model_type, const int32_t* flags, int32_t n_xreg, const double* theta, int32_t n_par,
+                              const int32_t* prior_distributions, const double* prior_parameters);
+
 /* exposed for tests: the exact Philox block and uniform / normal pair the kernels use */
 void bssm_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -496,3 +496,235 @@ def ulg_psi_filter(arr: dict, nsim: int, seed=1):
     alpha = np.zeros((m, n + 1, nsim), order="F")
     lib().orc_ulg_psi_filter(C.byref(g), C.c_uint(nsim), C.byref(rng), _p(alpha))
     return alpha
+
+
+# ------------------------------------------------------------------ chains (callers of the filters)
+# Restatement of approx_mcmc::amcmc (src/approx_mcmc.cpp:110-232), mcmc::pm_mcmc (src/mcmc.cpp:337-491) and
+# mcmc::da_mcmc (src/mcmc.cpp:530-685) in plain numpy over the oracle's filters.  ramcmc::adapt_S (CRAN ramcmc,
+# Vihola 2012) is stated through its definition S S' <- S (I + eta (a - a*) u u' / |u|^2) S' with a fresh Cholesky
+# factorisation, not through the rank-one update the library uses.
+def builtin_update(arr: dict, kind: str, flags, theta):
+    """bsm_ng / svm / ar1_ng ::update_model (src/model_bsm_ng.cpp:17-51, src/model_svm.cpp:12-29,
+    src/model_ar1_ng.cpp:12-36) on a copy of the flattened model"""
+    a = dict(arr)
+    for k in ("T", "R", "P1", "a1", "C", "beta"):
+        a[k] = np.array(arr[k], dtype=np.float64, order="F", copy=True)
+    th = np.asarray(theta, dtype=np.float64)
+    nx = a["xreg"].shape[1]
+    if kind == "bsm_ng":
+        slope, seasonal, noise, f0, f1, f2, phi_est = flags
+        est = [f0 == 0, bool(slope) and f1 == 0, bool(seasonal) and f2 == 0]
+        j = 0
+        if f0 + f1 + f2 < 3 or noise:
+            if est[0]:
+                a["R"][0, 0, 0] = np.exp(th[j]); j += 1
+            if est[1]:
+                a["R"][1, 1, 0] = np.exp(th[j]); j += 1
+            if est[2]:
+                a["R"][1 + slope, 1 + slope, 0] = np.exp(th[j]); j += 1
+            if noise:
+                m = a["R"].shape[0]
+                a["R"][m - 1, 1 + slope + seasonal, 0] = np.exp(th[j])
+                a["P1"][m - 1, m - 1] = np.exp(th[j]) ** 2
+                j += 1
+        if phi_est:
+            a["phi"] = float(np.exp(th[j]))
+        if nx:
+            a["beta"] = th[th.size - nx:].copy()
+    elif kind == "svm":
+        if flags[0] == 0:
+            a["phi"] = float(th[2])
+        else:
+            a["a1"][0] = th[2]
+            a["C"][...] = th[2] * (1 - th[0])
+        a["T"][...] = th[0]
+        a["R"][...] = th[1]
+        a["P1"][...] = th[1] ** 2 / (1 - th[0] ** 2)
+    elif kind == "ar1_ng":
+        mu_est, phi_est = flags
+        rho, sigma = th[0], np.exp(th[1])
+        a["T"][...] = rho
+        a["R"][...] = sigma
+        if mu_est:
+            a["a1"][0] = th[2]
+            a["C"][...] = th[2] * (1 - rho)
+        a["P1"][...] = sigma ** 2 / (1 - rho ** 2)
+        if phi_est:
+            a["phi"] = float(np.exp(th[2 + mu_est]))
+        if nx:
+            a["beta"] = th[th.size - nx:].copy()
+    else:
+        raise ValueError(kind)
+    if nx:
+        a["xbeta"] = a["xreg"] @ a["beta"]
+    return a
+
+
+def builtin_log_prior(kind: str, flags, n_xreg, theta, pd, pp):
+    """log_prior_pdf: src/model_bsm_ng.cpp:90-136, src/model_svm.cpp:50-88, src/model_ar1_ng.cpp:63-118"""
+    x = np.asarray(theta, dtype=np.float64)
+    pars = x.copy()
+    lp = 0.0
+    if kind == "bsm_ng":
+        if flags[3] + flags[4] + flags[5] < 3 or flags[2] or flags[6]:
+            k = x.size - n_xreg
+            pars[:k] = np.exp(x[:k])
+            lp += x[:k].sum()
+    elif kind == "ar1_ng":
+        pars[1] = np.exp(x[1]); lp += x[1]
+        if flags[1]:
+            pars[2 + flags[0]] = np.exp(x[2 + flags[0]]); lp += x[2 + flags[0]]
+    for i, v in enumerate(pars):
+        q = pp[:, i]
+        c = pd[i]
+        if c == 0:
+            if v < q[0] or v > q[1]:
+                return -np.inf
+        elif c == 1:
+            if v < 0:
+                return -np.inf
+            lp -= 0.5 * (v / q[0]) ** 2
+        elif c == 2:
+            lp -= 0.5 * ((v - q[0]) / q[1]) ** 2
+        elif c == 3:
+            if v < q[2] or v > q[3]:
+                return -np.inf
+            lp -= 0.5 * ((v - q[0]) / q[1]) ** 2
+        elif c == 4:
+            if v < 0:
+                return -np.inf
+            lp += (q[0] - 1) * np.log(v) - q[1] * v
+    return float(lp)
+
+
+def chain_draws(seed, it, d):
+    """the chain's counter-based draws: normals from blocks (iter_lo, iter_hi, j/2, purpose 5), uniforms from blocks
+    (iter_lo, iter_hi, 2^31 + which, purpose 5) of the key (seed, 0)"""
+    L = lib()
+    r, _ = make_rng(seed=seed, stream=0)
+    lo, hi = it & 0xFFFFFFFF, it >> 32
+    u = np.zeros(d + 1)
+    z0, z1 = C.c_double(), C.c_double()
+    for j in range(0, d, 2):
+        L.orc_rng_normal_pair(C.byref(r), 5, hi, lo, j // 2, C.byref(z0), C.byref(z1))
+        u[j], u[j + 1] = z0.value, z1.value
+    un = [L.orc_rng_uniform(C.byref(r), 5, hi, lo, 0x80000000 + w) for w in (0, 1)]
+    return u[:d], un
+
+
+def adapt_S(S, u, acc, target, i, gamma):
+    d = u.size
+    eta = min(1.0, d * i ** (-gamma))
+    M = np.eye(d) + eta * (acc - target) * np.outer(u, u) / (u @ u)
+    return np.linalg.cholesky(S @ M @ S.T)
+
+
+def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target, seed, end_ram=False, kind="approx",
+              nsim=0, method="psi", output_type=3):
+    """One chain.  ``update(theta) -> arr`` gives the flattened model, ``log_prior(theta) -> float``.
+    kind: 'approx' | 'pm' | 'da'.  Returns theta (n_stored x d), counts, posterior, S, acceptance_rate and by kind
+    approx_loglik / prior / modes, alpha (n+1) x m x n_stored, alphahat / Vt."""
+    theta = np.asarray(theta0, dtype=np.float64).copy()
+    d = theta.size
+    S = np.tril(np.asarray(S0, dtype=np.float64)).copy()
+    filtered = kind != "approx"
+    L = lib()
+
+    def approx(arr):
+        su = psi_setup(arr)
+        return su["approx_loglik"], su["mode"], su
+
+    def filt(arr, it):
+        """(ll0, ll1, particle system) with the filter's stream = iteration"""
+        sd, st = seed + (it >> 32), it & 0xFFFFFFFF
+        if method == "psi":
+            r = psi_filter(arr, nsim, seed=sd, stream=st)
+            return r["logLik"], r["setup"]["approx_loglik"], r
+        r = bsf_filter(arr, nsim, seed=sd, stream=st)
+        return r["logLik"], r["logLik"], r
+
+    def sample_or_summarise(res, it):
+        sm = filter_smoother(res["alpha"], res["indices"])  # m x (n+1) x N
+        if output_type == 1:
+            r, _ = make_rng(seed=seed + (it >> 32), stream=it & 0xFFFFFFFF)
+            pick = min(int(L.orc_rng_uniform(C.byref(r), 3, 0, 0, 0) * nsim), nsim - 1)
+            return sm[:, :, pick].T.copy(), None, None
+        if output_type == 2:
+            mean, cov = summary(sm)
+            return None, mean, cov
+        return None, None, None
+
+    arr = update(theta)
+    logprior = log_prior(theta)
+    assert np.isfinite(logprior)
+    mode = None
+    if filtered:
+        ll0, ll1, res = filt(arr, 0)
+        sampled, ah_i, vt_i = sample_or_summarise(res, 0)
+    else:
+        ll0, mode, _ = approx(arr)
+        ll1 = ll0
+    n, m = arr["n"], arr["m"]
+    alphahat = np.zeros((m, n + 1)); Vt = np.zeros((m, m, n + 1)); valpha = np.zeros((m, m, n + 1))
+    st_theta, st_counts, st_post, st_al, st_prior, st_modes, st_alpha = [], [], [], [], [], [], []
+    new_value, n_values, accepted = True, 0, 0
+    for i in range(1, iters + 1):
+        u, (un0, un1) = chain_draws(seed, i, d)
+        prop = theta + S @ u
+        lp_prop = log_prior(prop)
+        acc_prob = 0.0
+        if lp_prop > -np.inf and not np.isnan(lp_prop):
+            arr_p = update(prop)
+            accept = False
+            if kind == "approx":
+                llp0, mode_p, _ = approx(arr_p)
+                llp1 = llp0
+                acc_prob = min(1.0, np.exp(llp0 - ll0 + lp_prop - logprior))
+                accept = un0 < acc_prob
+            elif kind == "pm":
+                llp0, llp1, res_p = filt(arr_p, i)
+                acc_prob = min(1.0, np.exp(llp1 - ll1 + lp_prop - logprior))
+                accept = np.log(un0) < llp0 - ll0 + lp_prop - logprior
+            else:
+                llp1 = approx(arr_p)[0]
+                acc_prob = min(1.0, np.exp(llp1 - ll1 + lp_prop - logprior))
+                if un0 < acc_prob:
+                    llp0, llp1, res_p = filt(arr_p, i)
+                    accept = np.log(un1) < llp0 + ll1 - ll0 - llp1
+            if accept:
+                if i > burnin:
+                    accepted += 1; n_values += 1
+                if filtered:
+                    sampled, ah_i, vt_i = sample_or_summarise(res_p, i)
+                else:
+                    mode = mode_p
+                ll0, ll1, logprior, theta = llp0, llp1, lp_prop, prop
+                new_value = True
+        if i > burnin and filtered and output_type == 2:
+            cnt = i - burnin
+            diff = ah_i - alphahat
+            alphahat = (alphahat * (cnt - 1) + ah_i) / cnt
+            Vt = (Vt * (cnt - 1) + vt_i) / cnt
+            for t in range(n + 1):
+                valpha[:, :, t] += np.outer(diff[:, t], ah_i[:, t] - alphahat[:, t])
+        if i > burnin and n_values % thin == 0:
+            if new_value:
+                st_theta.append(theta.copy()); st_counts.append(1); st_post.append(logprior + ll0)
+                if not filtered:
+                    st_al.append(ll0); st_prior.append(logprior); st_modes.append(np.array(mode).copy())
+                elif output_type == 1:
+                    st_alpha.append(sampled)
+                new_value = False
+            else:
+                st_counts[-1] += 1
+        if not end_ram or i <= burnin:
+            S = adapt_S(S, u, acc_prob, target, i, gamma)
+    out = dict(theta=np.array(st_theta), counts=np.array(st_counts, dtype=np.uint32), posterior=np.array(st_post), S=S,
+               acceptance_rate=accepted / (iters - burnin))
+    if not filtered:
+        out.update(approx_loglik=np.array(st_al), prior=np.array(st_prior), modes=np.array(st_modes).T)
+    elif output_type == 1:
+        out["alpha"] = np.stack(st_alpha, axis=2)
+    elif output_type == 2:
+        out["alphahat"], out["Vt"] = alphahat, Vt + valpha / (iters - burnin)
+    return out

@@ -30,3 +30,24 @@ for method, N in (("bsf", 200), ("psi", 10)):
     e = (time.perf_counter() - t0) / 200
     print(f"plan: update + run + loglik + sampled trajectory, {method} N={N}: {e*1e3:.3f} ms per iteration ({ll:.3f})", flush=True)
     plan.close()
+
+# component split of the plan iteration
+for method, N in (("bsf", 200), ("psi", 10)):
+    plan = FilterPlan(model, N, method=method, keep_history=True)
+    plan.update(model); plan.run(1); plan.loglik()
+    R = 300
+    t0 = time.perf_counter()
+    for s in range(R):
+        plan.update(model)
+    t_up = (time.perf_counter() - t0) / R
+    t0 = time.perf_counter()
+    for s in range(R):
+        plan.run(s); plan.loglik()
+    t_run = (time.perf_counter() - t0) / R
+    t0 = time.perf_counter()
+    for s in range(R):
+        plan.sample_or_summarise(0, s, sample=True)
+    t_s = (time.perf_counter() - t0) / R
+    dev = plan.time(1, 50)
+    print(f"split {method} N={N}: update {t_up*1e3:.3f} ms, run + loglik {t_run*1e3:.3f} ms (device {dev:.3f} ms), sample {t_s*1e3:.3f} ms", flush=True)
+    plan.close()

@@ -6,6 +6,8 @@ to the EXPECTED VALUES those tests state.  The expected numbers are data quoted 
   tests/testthat/test_ekpf.R:7-40,43-69 (nlg_sin_exp data; ekf / iekf logLik; smoothed means of the particle smoothers)
   vignettes/psi_pf_experiments/*.rds   (the published Monte-Carlo study of the bootstrap filter and the psi-APF on the
                                         growth and AR-exp models: means / SDs over 10 000 runs, single-run truths)
+  tests/testthat/test_mcmc.R:39-65     (posterior means of the bssm paper's negative binomial example, IS2-MCMC)
+  benchmarks/replications.html         (posterior means, standard errors and run times of every MCMC type on poisson_series)
 (tests/testthat/test_sde.R:57-60 states logLik = -17 "within tolerance 1" for a 50-point series whose log-likelihood is
 about -83 -- all.equal scales by the actual value, so that test passes for any value below -8.5; it pins nothing and is
 not used.)
@@ -136,6 +138,51 @@ out = {
         "expected_iekf1_loglik_with_y2_y3_missing": 2.61650080342709,   # test_ekpf.R:67; :68-69: iekf_iter 1 == iekf_iter 2
         "expected_smoothed_alphahat_9_10": [0.0263875638744833, 0.0734903567971838], "tolerance": 0.1,
     },
+}
+
+
+def replication_table():
+    """benchmarks/replications.html (knitted from benchmarks/replications.Rmd:27-100): one run_mcmc of 1e4 iterations per
+    (mcmc_type, sampling_method, local_approx) on bsm_ng(poisson_series): weighted posterior means, their asymptotic
+    standard errors, elapsed seconds and acceptance rates as printed in the document."""
+    import html
+    import re
+    txt = html.unescape(re.sub(r"<[^>]+>", "", open("/root/reference/benchmarks/replications.html").read()))
+    head = txt.index("arrange(local_approx, variable, mcmc_type, sampling_method)")
+    rows, times = {}, {}
+    for ln in txt[head:].splitlines():
+        mm = re.match(r"## (\d+)\s+(-?[\d.]+)\s+([\d.]+)\s+(\w+)\s+(\w+)\s+(\w+)\s+(TRUE|FALSE)\s*$", ln)
+        if mm:
+            rows[int(mm.group(1))] = (float(mm.group(2)), float(mm.group(3)), mm.group(4), mm.group(5), mm.group(6), mm.group(7) == "TRUE")
+            continue
+        mm = re.match(r"## (\d+)\s+([\d.]+)\s+(0\.\d+)\s*$", ln)
+        if mm and int(mm.group(1)) not in times:
+            times[int(mm.group(1))] = (float(mm.group(2)), float(mm.group(3)))
+    table = []
+    for i in sorted(rows):
+        mean, se, var, typ, meth, local = rows[i]
+        table.append(dict(variable=var, mcmc_type=typ, sampling_method=meth, local_approx=local, mean=mean, se=se,
+                          seconds=times[i][0], acceptance_rate=times[i][1]))
+    assert len(table) == 104, len(table)
+    return table
+
+
+out["mcmc_paper_negbin"] = {
+    "source": "tests/testthat/test_mcmc.R:39-65 (\"MCMC results from bssm paper are still correct\")",
+    "model": "bsm_ng(negbin_series[,1], xreg = negbin_series[,2], beta = normal(0,0,10), phi = halfnormal(1,10), "
+             "sd_level = halfnormal(0.1,1), sd_slope = halfnormal(0.01,0.1), a1 = c(0,0), P1 = diag(c(10,0.1)^2), "
+             "distribution = 'negative binomial'); run_mcmc(iter = 6e4, burnin = 1e4, particles = 10, seed = 1)",
+    "theta_order": ["coef_1", "phi", "sd_level", "sd_slope"],
+    "paper_theta": [-0.912, 5.392, 0.092, 0.003],
+    "paper_alpha_time_200": [6.962, 0.006],
+    "tolerance_all_equal": 0.01,
+}
+out["mcmc_replications_poisson"] = {
+    "source": "benchmarks/replications.html / benchmarks/replications.Rmd:27-100",
+    "model": "s <- sd(log(pmax(0.1, poisson_series))); bsm_ng(poisson_series, sd_level = uniform(0.115, 0, 2*s), "
+             "sd_slope = uniform(0.004, 0, 2*s), P1 = diag(0.1, 2), distribution = 'poisson'); iter = 1e4, "
+             "end_adaptive_phase = TRUE, particles: bsf 200, psi 10, spdk 10",
+    "table": replication_table(),
 }
 json.dump(out, open(os.path.join(HERE, "reference_test_vectors.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

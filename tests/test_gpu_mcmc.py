@@ -1,0 +1,209 @@
+"""The chains that call the particle-filter path (SURVEY.md 8f rank 2 and the run_mcmc callers of 8b): the library's
+bssm_run_mcmc (csrc/mcmc.cpp) against the oracle's numpy restatement of approx_mcmc::amcmc / mcmc::pm_mcmc /
+mcmc::da_mcmc with identical counter-based draws, and against the posterior means the reference's own test pins
+(tests/testthat/test_mcmc.R:39-65, "MCMC results from bssm paper are still correct")."""
+import os
+
+import numpy as np
+import pytest
+
+from bssm_amd import mcmc, models as M
+from bssm_amd import post_correct as PC
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _small(kind="bsm_ng", n=40, seed=5):
+    rng = np.random.default_rng(seed)
+    if kind == "bsm_ng":
+        y = rng.poisson(4.0, n).astype(float); y[7] = np.nan
+        return M.bsm_ng(y, sd_level=M.halfnormal(0.2, 1), sd_slope=M.halfnormal(0.02, 0.1), distribution="poisson",
+                        P1=np.diag([1.0, 0.1]), a1=[1.3, 0.0])
+    if kind == "negbin":
+        x = rng.normal(0, 1, n)
+        y = rng.negative_binomial(5, 0.4, n).astype(float)
+        return M.bsm_ng(y, sd_level=M.halfnormal(0.2, 1), phi=M.gamma(4.0, 2, 0.5), xreg=x, beta=M.normal(0.1, 0, 2),
+                        distribution="negative binomial", P1=np.array([[1.0]]), a1=[1.5])
+    if kind == "svm":
+        y = rng.normal(0, 0.7, n)
+        return M.svm(y, rho=M.uniform(0.9, -0.999, 0.999), sd_ar=M.halfnormal(0.3, 5), sigma=M.halfnormal(0.8, 2))
+    if kind == "ar1_ng":
+        y = rng.poisson(3.0, n).astype(float)
+        return M.ar1_ng(y, rho=M.uniform(0.7, -0.99, 0.99), sigma=M.halfnormal(0.3, 2), mu=M.normal(1.0, 0, 5),
+                        distribution="poisson")
+    raise ValueError(kind)
+
+
+def _oracle_fns(oracle, model):
+    kind = model.classes[0]
+    flags = PC._builtin_flags(model)
+    base = M.model_arrays(model)
+    pd, pp = M.prior_tables(model["priors"])
+    nx = base["xreg"].shape[1]
+    return (lambda th: oracle.builtin_update(base, kind, flags, th)), \
+        (lambda th: oracle.builtin_log_prior(kind, flags, nx, th, pd, pp))
+
+
+def _sampling_scale(model, theta):
+    th = np.array(theta, dtype=float)
+    tr = mcmc._transformed(model)
+    th[..., tr] = np.log(th[..., tr])
+    return th
+
+
+@pytest.mark.parametrize("kind", ["bsm_ng", "negbin", "svm", "ar1_ng"])
+def test_approx_chain_matches_oracle(oracle, kind):
+    model = _small(kind)
+    iters, burnin, seed = 300, 100, 11
+    out = mcmc.run_mcmc(model, iters, burnin=burnin, mcmc_type="approx", seed=seed)
+    upd, prior = _oracle_fns(oracle, model)
+    th0 = np.array(model["theta"], dtype=float)
+    tr = mcmc._transformed(model)
+    th0[tr] = np.log(np.maximum(0.001, th0[tr]))
+    S0 = np.diag(0.1 * np.maximum(0.1, np.abs(th0)))
+    ref = oracle.run_chain(upd, prior, th0, S0, iters, burnin, 1, 2 / 3, 0.234, seed)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(_sampling_scale(model, out["theta"]), ref["theta"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["approx_loglik"], ref["approx_loglik"], rtol=0, atol=1e-8 * model.n)
+    assert np.allclose(out["prior"], ref["prior"], rtol=1e-9, atol=1e-10)
+    assert np.allclose(out["posterior"], ref["posterior"], rtol=0, atol=1e-8 * model.n)
+    assert np.allclose(out["modes"][:, 0, :], ref["modes"], rtol=1e-6, atol=1e-8)
+    assert np.allclose(out["S"], ref["S"], rtol=1e-7, atol=1e-10)
+    assert abs(out["acceptance_rate"] - ref["acceptance_rate"]) < 1e-12
+
+
+@pytest.mark.parametrize("kind,method,otype", [("pm", "psi", 1), ("pm", "bsf", 2), ("da", "psi", 2), ("da", "psi", 1),
+                                               ("pm", "psi", 3), ("da", "bsf", 3)])
+def test_pm_da_chain_matches_oracle(oracle, kind, method, otype):
+    """One device filter pass per iteration (plan update -> run -> log-likelihood -> sample_or_summarise) inside the
+    library's chain equals the oracle's chain over the oracle's filters, draw for draw."""
+    model = _small("bsm_ng", n=30, seed=9)
+    iters, burnin, seed, N = 60, 20, 23, 24
+    out = mcmc.run_mcmc(model, iters, particles=N, burnin=burnin, mcmc_type=kind, sampling_method=method,
+                        output_type={1: "full", 2: "summary", 3: "theta"}[otype], seed=seed)
+    upd, prior = _oracle_fns(oracle, model)
+    th0 = np.log(np.maximum(0.001, np.array(model["theta"], dtype=float)))
+    S0 = np.diag(0.1 * np.maximum(0.1, np.abs(th0)))
+    ref = oracle.run_chain(upd, prior, th0, S0, iters, burnin, 1, 2 / 3, 0.234, seed, kind=kind, nsim=N, method=method,
+                           output_type=otype)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(np.log(out["theta"]), ref["theta"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["posterior"], ref["posterior"], rtol=0, atol=1e-8 * model.n)
+    assert np.allclose(out["S"], ref["S"], rtol=1e-7, atol=1e-10)
+    if otype == 1:
+        assert np.allclose(out["alpha"], ref["alpha"], rtol=1e-8, atol=1e-10)
+    if otype == 2:
+        assert np.allclose(out["alphahat"], ref["alphahat"].T, rtol=1e-8, atol=1e-10)
+        assert np.allclose(out["Vt"], ref["Vt"], rtol=1e-7, atol=1e-10)
+
+
+def test_thinning_and_end_of_adaptation(oracle):
+    model = _small("bsm_ng")
+    out = mcmc.run_mcmc(model, 240, burnin=60, thin=3, mcmc_type="approx", seed=4, end_adaptive_phase=True)
+    upd, prior = _oracle_fns(oracle, model)
+    th0 = np.log(np.maximum(0.001, np.array(model["theta"], dtype=float)))
+    ref = oracle.run_chain(upd, prior, th0, np.diag(0.1 * np.maximum(0.1, np.abs(th0))), 240, 60, 3, 2 / 3, 0.234, 4,
+                           end_ram=True)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(np.log(out["theta"]), ref["theta"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["S"], ref["S"], rtol=1e-7, atol=1e-10)
+
+
+def test_general_ssm_ung_with_callbacks(oracle):
+    """ssm_ung takes the two closures the reference takes (update_fn, prior_fn; src/model_ssm_ung.cpp:41-82)"""
+    rng = np.random.default_rng(2)
+    n = 30
+    y = rng.poisson(3.0, n).astype(float)
+
+    def update_fn(theta):
+        return dict(R=np.array([[[np.exp(theta[0])]]]), P1=np.array([[np.exp(2 * theta[1])]]))
+
+    def prior_fn(theta):
+        return float(-0.5 * np.exp(theta[0]) ** 2 + theta[0] - 0.5 * (theta[1] / 2.0) ** 2)
+
+    model = M.ssm_ung(y, Z=1.0, T=1.0, R=0.2, a1=1.0, P1=1.0, distribution="poisson", init_theta=[np.log(0.2), 0.0],
+                      update_fn=update_fn, prior_fn=prior_fn)
+    out = mcmc.run_mcmc(model, 200, burnin=50, mcmc_type="approx", seed=6)
+    base = M.model_arrays(model)
+
+    def upd(th):
+        a = dict(base)
+        a["R"] = np.asfortranarray(np.full((1, 1, 1), np.exp(th[0])))
+        a["P1"] = np.asfortranarray(np.full((1, 1), np.exp(2 * th[1])))
+        return a
+    th0 = np.array([np.log(0.2), 0.0])
+    ref = oracle.run_chain(upd, prior_fn, th0, np.diag(0.1 * np.maximum(0.1, np.abs(th0))), 200, 50, 1, 2 / 3, 0.234, 6)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(out["theta"], ref["theta"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["approx_loglik"], ref["approx_loglik"], rtol=0, atol=1e-8 * n)
+    # pseudo-marginal chain through the same callbacks
+    pm = mcmc.run_mcmc(model, 40, particles=16, burnin=10, mcmc_type="pm", output_type="theta", seed=6)
+    refpm = oracle.run_chain(upd, prior_fn, th0, np.diag(0.1 * np.maximum(0.1, np.abs(th0))), 40, 10, 1, 2 / 3, 0.234, 6,
+                             kind="pm", nsim=16)
+    assert np.array_equal(pm["counts"], refpm["counts"])
+    assert np.allclose(pm["theta"], refpm["theta"], rtol=1e-8, atol=1e-10)
+
+
+def test_is_types_reweight_the_approximate_chain(oracle):
+    """is1 / is2 / is3 = approximate chain + IS correction of its stored values on the sampling scale
+    (src/R_mcmc.cpp:331-470): the weights equal a separate post-correction of the approx output"""
+    model = _small("bsm_ng")
+    base = mcmc.run_mcmc(model, 200, burnin=50, mcmc_type="approx", seed=8)
+    for is_type in ("is1", "is2", "is3"):
+        out = mcmc.run_mcmc(model, 200, particles=12, burnin=50, mcmc_type=is_type, output_type="summary", seed=8, threads=2)
+        stored = dict(base, theta=_sampling_scale(model, base["theta"]), output_type=2)
+        ref = PC.post_correct(model, stored, 12, threads=2, is_type=is_type, seed=8)
+        assert np.allclose(out["weights"], ref["weights"], rtol=1e-12)
+        assert np.allclose(out["alphahat"], ref["alphahat"], rtol=1e-12)
+        assert np.allclose(out["posterior"], ref["posterior"], rtol=1e-12)
+        assert out["theta"].shape[0] == (base["counts"].sum() if is_type == "is3" else base["counts"].size)
+    bsf = mcmc.run_mcmc(model, 200, particles=12, burnin=50, mcmc_type="is2", sampling_method="bsf", output_type="theta", seed=8)
+    arrs = PC.expand_models(model, _sampling_scale(model, base["theta"]))
+    for i in (0, len(arrs) - 1):
+        ll = oracle.bsf_filter(arrs[i], 12, seed=8, stream=i)["logLik"]
+        assert abs(bsf["weights"][i] - np.exp(ll - base["approx_loglik"][i])) <= 1e-8 * bsf["weights"][i]
+
+
+def test_errors():
+    model = _small("bsm_ng")
+    with pytest.raises(ValueError, match="less than 2"):
+        mcmc.run_mcmc(model, 100, particles=1, mcmc_type="pm")
+    with pytest.raises(ValueError, match="burnin"):
+        mcmc.run_mcmc(model, 100, burnin=200, mcmc_type="approx")
+    bad = M.bsm_ng(np.asarray(model["y"]), sd_level=M.uniform(0.2, 0.5, 1.0), distribution="poisson")  # init outside the support
+    with pytest.raises(Exception, match="Initial prior probability is not finite"):
+        mcmc.run_mcmc(bad, 100, mcmc_type="approx", seed=1)
+    fixed = M.bsm_ng(np.asarray(model["y"]), sd_level=0.2, distribution="poisson")
+    with pytest.raises(ValueError, match="No unknown parameters"):
+        mcmc.run_mcmc(fixed, 100, mcmc_type="approx")
+
+
+def test_pm_and_is2_agree_statistically():
+    """Both chains target the same posterior: posterior means of theta agree within Monte-Carlo error"""
+    model = _small("bsm_ng", n=60, seed=3)
+    a = mcmc.run_mcmc(model, 6000, particles=16, burnin=1000, mcmc_type="is2", output_type="theta", seed=1)
+    b = mcmc.run_mcmc(model, 6000, particles=64, burnin=1000, mcmc_type="pm", output_type="theta", seed=2)
+    ma, mb = mcmc.summary(a), mcmc.summary(b)
+    # a handful of MC standard errors (effective sample sizes of a few hundred per chain)
+    assert np.all(np.abs(ma["Mean"] - mb["Mean"]) < 0.35 * np.maximum(ma["SD"], mb["SD"]))
+    assert 0.1 < b["acceptance_rate"] < 0.5
+
+
+def test_paper_negbin_posterior_means():
+    """tests/testthat/test_mcmc.R:39-65: bsm_ng on negbin_series, IS2-MCMC, 6e4 iterations, 10 particles.  The reference
+    pins the posterior means of (beta, phi, sd_level, sd_slope) and of the states at time 200 to the bssm paper's values
+    with all.equal tolerance 0.01 (mean relative difference); the same run here must meet the same tolerance."""
+    d = np.loadtxt(os.path.join(GOLD, "negbin_series.txt"))
+    model = M.bsm_ng(d[:, 0], xreg=d[:, 1], beta=M.normal(0, 0, 10), phi=M.halfnormal(1, 10),
+                     sd_level=M.halfnormal(0.1, 1), sd_slope=M.halfnormal(0.01, 0.1), a1=[0, 0],
+                     P1=np.diag([10.0, 0.1]) ** 2, distribution="negative binomial")
+    fit = mcmc.run_mcmc(model, iter=60000, burnin=10000, particles=10, seed=1, threads=8)
+    s = mcmc.summary(fit)
+    got = dict(zip(s["names"], s["Mean"]))
+    mine = np.array([got["coef_1"], got["phi"], got["sd_level"], got["sd_slope"]])
+    paper_theta = np.array([-0.912, 5.392, 0.092, 0.003])
+    assert np.mean(np.abs(mine - paper_theta)) / np.mean(np.abs(paper_theta)) < 0.01
+    st = mcmc.summary(fit, variable="states", times=200)["Mean"].reshape(-1)
+    paper_alpha = np.array([6.962, 0.006])
+    assert np.mean(np.abs(st - paper_alpha)) / np.mean(np.abs(paper_alpha)) < 0.01
