@@ -144,71 +144,30 @@ struct PlanGuard {
   ~PlanGuard() { if (p) bssm_plan_destroy(p); }
 };
 
-}  // namespace
-
-extern "C" {
-
-void bssm_mcmc_draws(uint32_t seed, uint64_t iter, int32_t n_par, double* normals, double* uniforms2) {
-  const ChainRng rng{seed};
-  if (normals) rng.normals(iter, n_par, normals);
-  if (uniforms2) { uniforms2[0] = rng.uniform(iter, 0); uniforms2[1] = rng.uniform(iter, 1); }
-}
-
-double bssm_log_prior_builtin(int model_type, const int32_t* flags, int32_t n_xreg, const double* theta, int32_t n_par,
-                              const int32_t* prior_distributions, const double* prior_parameters) {
-  return log_prior_builtin(model_type, flags, n_xreg, theta, n_par, prior_distributions, prior_parameters);
-}
-
-int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_job* job, bssm_mcmc_out* out) {
-  using bssm::set_error;
-  if (!model || !theta0 || !job || !out) return set_error(BSSM_ERR_INVALID, "NULL argument");
-  const int d = job->n_par;
-  if (d < 1) return set_error(BSSM_ERR_INVALID, "No unknown parameters ('model$theta' has length of zero).");
-  if (job->burnin > job->iter) return set_error(BSSM_ERR_INVALID, "Argument 'burnin' should be smaller than 'iter'.");
-  if (job->thin < 1) return set_error(BSSM_ERR_INVALID, "thin must be positive");
-  if (!out->S || !out->theta || !out->counts || !out->posterior || out->capacity < 1)
-    return set_error(BSSM_ERR_INVALID, "output storage missing");
-  const bool builtin = job->model_type == BSSM_BSM_NG || job->model_type == BSSM_SVM_MODEL || job->model_type == BSSM_AR1_NG;
-  if (builtin && !job->update_fn && (!job->flags || !job->prior_distributions || !job->prior_parameters))
-    return set_error(BSSM_ERR_INVALID, "built-in models need flags and the prior tables");
-  if (!builtin && (!job->update_fn || !job->prior_fn))
-    return set_error(BSSM_ERR_INVALID, "ssm_ung / ssm_mng chains need update_fn and prior_fn");
-  const int type = job->mcmc_type;
-  if (type != BSSM_MCMC_APPROX && type != BSSM_MCMC_PM && type != BSSM_MCMC_DA) return set_error(BSSM_ERR_INVALID, "unknown mcmc_type");
-  const bool filtered = type != BSSM_MCMC_APPROX;
-  const bool psi = job->sampling_method == BSSM_PSI;
-  if (filtered && job->sampling_method != BSSM_PSI && job->sampling_method != BSSM_BSF)
-    return set_error(BSSM_ERR_UNSUPPORTED, "sampling_method must be 1 (psi) or 2 (bsf); SPDK is not a particle filter path");
-  if (filtered && job->nsim < 2)
-    return set_error(BSSM_ERR_INVALID, "Number of state samples less than 2, use 'mcmc_type' 'approx' instead.");
-  const int otype = filtered ? job->output_type : 3;
-  if (otype == 1 && !out->alpha) return set_error(BSSM_ERR_INVALID, "output_type 1 needs alpha storage");
-  if (otype == 2 && (!out->alphahat || !out->Vt)) return set_error(BSSM_ERR_INVALID, "output_type 2 needs alphahat and Vt");
-
+// ---- what a chain needs from a model family
+// ssm_ung / ssm_mng family: host Gaussian approximation, device filter on a resident plan
+struct UngTarget {
   WorkModel wm;
-  wm.init(model, job);
-  std::vector<double> theta(theta0, theta0 + d), theta_prop(d), u(d);
-  std::string err = wm.update(theta.data());  // "just in case", src/mcmc.cpp:348
-  if (!err.empty()) return set_error(BSSM_ERR_INVALID, err);
-  double logprior = wm.log_prior(theta.data());
-  if (!std::isfinite(logprior)) return set_error(BSSM_ERR_INVALID, "Initial prior probability is not finite.");
-
-  const int n = wm.mod.n, m = wm.mod.m, p = wm.mod.p > 1 ? wm.mod.p : 1;
-  const ChainRng rng{job->seed};
-
-  // approximate log-likelihood (and mode) of the working model
-  auto approx_ll = [&](std::vector<double>* mode, double* val) -> int {
+  const bssm_mcmc_job* job;
+  PlanGuard plan;
+  int otype = 3;
+  int n() const { return wm.mod.n; }
+  int m() const { return wm.mod.m; }
+  int mode_rows() const { return wm.mod.p > 1 ? wm.mod.p : 1; }
+  std::string update(const double* theta) { return wm.update(theta); }
+  double log_prior(const double* theta) const { return wm.log_prior(theta); }
+  int approx_ll(std::vector<double>* mode, double* val) {
     bssm::HostModel hm;
     const std::string e = bssm::ingest_model(&wm.mod, true, &hm);
-    if (!e.empty()) return set_error(BSSM_ERR_INVALID, e);
+    if (!e.empty()) return bssm::set_error(BSSM_ERR_INVALID, e);
     *val = bssm::approx_loglik_mode(hm, mode);
     return BSSM_OK;
-  };
+  }
   // one device filter pass of the working model; ll[0] unbiased estimate, ll[1] approximate (psi) or the same (bsf),
   // src/model_ssm_ung.cpp:176-213
-  PlanGuard plan;
-  auto filter_ll = [&](uint64_t it, double* ll) -> int {
+  int filter_ll(uint64_t it, double* ll) {
     int rc;
+    const bool psi = job->sampling_method == BSSM_PSI;
     if (!plan.p) {
       plan.p = bssm_plan_create(&wm.mod, 1, 1, job->nsim, job->sampling_method, otype != 3 ? BSSM_PLAN_KEEP_HISTORY : 0u);
       if (!plan.p) return BSSM_ERR_INVALID;  // message already recorded
@@ -222,29 +181,112 @@ int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_j
     if (psi && (rc = bssm_plan_approx_loglik(plan.p, &ll[1])) != BSSM_OK) return rc;
     if (!std::isfinite(ll[0])) ll[0] = -INFINITY;
     return BSSM_OK;
-  };
+  }
+  // src/summary.cpp:82-103 on the particle system just filtered
+  int sample_or_summarise(uint64_t it, double* sampled, double* ah, double* vt) {
+    const uint32_t sd = job->seed + (uint32_t)(it >> 32);
+    if (otype == 1) return bssm_plan_sample_or_summarise(plan.p, 0, sd, nullptr, sampled, nullptr, nullptr);
+    if (otype == 2) return bssm_plan_sample_or_summarise(plan.p, 0, sd, nullptr, nullptr, ah, vt);
+    return BSSM_OK;
+  }
+};
 
+// ssm_nlg / ssm_sde (model functors): theta is the model's parameter vector itself; approximate log-likelihood from the
+// mode search (ssm_nlg::log_likelihood with nsim = 0, src/model_ssm_nlg.cpp:258-277); filters through the functor
+// entry points, the random stream of iteration i being the seed  seed + i.
+struct FnTarget {
+  bssm_fn_model mod;
+  std::vector<double> theta;
+  const bssm_mcmc_job* job;
+  int otype = 3;
+  std::vector<double> alpha_all, w_dummy;  // smoother outputs of the accepted proposal
+  int n() const { return mod.n; }
+  int m() const { return mod.model_id == BSSM_FN_NLG_GROWTH ? 2 : (mod.model_id == BSSM_FN_USER_NLG ? mod.n_states : 1); }
+  int mode_rows() const { return m(); }
+  bool is_sde() const { return mod.model_id == BSSM_FN_SDE_GBM || mod.model_id == BSSM_FN_SDE_POISSON_OU || mod.model_id == BSSM_FN_USER_SDE; }
+  std::string update(const double* th) { std::memcpy(theta.data(), th, theta.size() * sizeof(double)); return ""; }
+  double log_prior(const double* th) const { return job->prior_fn(th, job->n_par, job->user); }
+  int approx_ll(std::vector<double>* mode, double* val) {
+    std::vector<double> md((size_t)m() * n());
+    const int rc = bssm_fn_psi_setup(&mod, nullptr, job->max_iter, job->conv_tol, md.data(), nullptr, val, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc == BSSM_ERR_NUMERIC || rc == BSSM_WARN_DEGENERATE) { *val = -INFINITY; return BSSM_OK; }
+    if (rc != BSSM_OK) return rc;
+    if (mode) *mode = md;
+    return BSSM_OK;
+  }
+  int filter_ll(uint64_t it, double* ll) {
+    int rc = bssm_fn_loglik_batch(&mod, job->nsim, job->sampling_method, job->seed + (uint32_t)it, 0u, 1u, &ll[0]);
+    if (rc < 0) return rc;
+    if (!std::isfinite(ll[0])) ll[0] = -INFINITY;
+    ll[1] = ll[0];
+    if (job->sampling_method == BSSM_PSI && std::isfinite(ll[0])) {  // ll(1) = approx_loglik, src/model_ssm_nlg.cpp:253-254
+      if ((rc = approx_ll(nullptr, &ll[1])) != BSSM_OK) return rc;
+    }
+    return BSSM_OK;
+  }
+  int sample_or_summarise(uint64_t it, double* sampled, double* ah, double* vt) {
+    if (otype == 3) return BSSM_OK;
+    const int nn = n(), mm = m();
+    const uint32_t N = job->nsim, sd = job->seed + (uint32_t)it;
+    alpha_all.resize((size_t)mm * (nn + 1) * N);
+    w_dummy.resize((size_t)N * (nn + 1));
+    std::vector<double> ahat((size_t)(nn + 1) * mm), v((size_t)mm * mm * (nn + 1));
+    bssm_filter_out o;
+    std::memset(&o, 0, sizeof o);
+    o.alphahat = ahat.data(); o.Vt = v.data(); o.weights = w_dummy.data(); o.alpha = alpha_all.data();
+    int rc;
+    if (job->sampling_method == BSSM_PSI) rc = bssm_psi_smoother_nlg(&mod, N, sd, job->max_iter, job->conv_tol, &o);
+    else if (job->sampling_method == BSSM_EKPF) rc = bssm_ekpf_smoother_nlg(&mod, N, sd, &o);
+    else if (is_sde()) rc = bssm_bsf_smoother_sde(&mod, N, sd, &o);
+    else rc = bssm_bsf_smoother_nlg(&mod, N, sd, &o);
+    if (rc < 0) return rc;
+    if (otype == 1) {  // one of the back-traced trajectories, uniformly (the weights of the extra time point are ones)
+      const bssm::u32x4 w = bssm::philox4x32_10(0, 0, 0, bssm::RNG_PICK, sd, 0u);
+      uint32_t pick = (uint32_t)((double)bssm::bits53(w.x, w.y) * 0x1.0p-53 * N);
+      if (pick >= N) pick = N - 1;
+      for (int t = 0; t <= nn; t++)
+        for (int c = 0; c < mm; c++) sampled[t + (size_t)(nn + 1) * c] = alpha_all[c + (size_t)mm * t + (size_t)mm * (nn + 1) * pick];
+    } else {
+      for (int t = 0; t <= nn; t++)
+        for (int c = 0; c < mm; c++) ah[c + (size_t)mm * t] = ahat[t + (size_t)(nn + 1) * c];
+      std::memcpy(vt, v.data(), v.size() * sizeof(double));
+    }
+    return BSSM_OK;
+  }
+};
+
+// ---- the chain: approx_mcmc::amcmc / mcmc::pm_mcmc / mcmc::da_mcmc over a target
+template <class Target>
+int run_chain(Target& tg, const double* theta0, const bssm_mcmc_job* job, bssm_mcmc_out* out) {
+  using bssm::set_error;
+  const int d = job->n_par, type = job->mcmc_type;
+  const bool filtered = type != BSSM_MCMC_APPROX;
+  const int otype = tg.otype;
+  std::vector<double> theta(theta0, theta0 + d), theta_prop(d), u(d);
+  std::string err = tg.update(theta.data());  // "just in case", src/mcmc.cpp:348
+  if (!err.empty()) return set_error(BSSM_ERR_INVALID, err);
+  double logprior = tg.log_prior(theta.data());
+  if (!std::isfinite(logprior)) return set_error(BSSM_ERR_INVALID, "Initial prior probability is not finite.");
+
+  const int n = tg.n(), m = tg.m(), prow = tg.mode_rows();
+  const ChainRng rng{job->seed};
   const size_t sz_a = (size_t)(n + 1) * m, sz_v = (size_t)m * m * (n + 1);
   std::vector<double> sampled(otype == 1 ? sz_a : 0), ah_i(otype == 2 ? sz_a : 0), vt_i(otype == 2 ? sz_v : 0),
       valpha(otype == 2 ? sz_v : 0, 0.0), mode, mode_prop;
-  auto sample_or_summarise = [&](uint64_t it) -> int {  // src/summary.cpp:82-103 on the particle system just filtered
-    if (otype == 1) return bssm_plan_sample_or_summarise(plan.p, 0, job->seed + (uint32_t)(it >> 32), nullptr, sampled.data(), nullptr, nullptr);
-    if (otype == 2) return bssm_plan_sample_or_summarise(plan.p, 0, job->seed + (uint32_t)(it >> 32), nullptr, nullptr, ah_i.data(), vt_i.data());
-    return BSSM_OK;
-  };
 
   double ll[2] = {0, 0}, ll_prop[2] = {0, 0};
   int rc;
   if (filtered) {
-    if ((rc = filter_ll(0, ll)) != BSSM_OK) return rc;
+    if ((rc = tg.filter_ll(0, ll)) != BSSM_OK) return rc;
     if (!std::isfinite(ll[0])) return set_error(BSSM_ERR_INVALID, "Initial log-likelihood is not finite.");
-    if ((rc = sample_or_summarise(0)) != BSSM_OK) return rc;
+    if ((rc = tg.sample_or_summarise(0, sampled.data(), ah_i.data(), vt_i.data())) != BSSM_OK) return rc;
     if (otype == 2) {
       std::fill(out->alphahat, out->alphahat + sz_a, 0.0);
       std::fill(out->Vt, out->Vt + sz_v, 0.0);
     }
   } else {
-    if ((rc = approx_ll(&mode, &ll[0])) != BSSM_OK) return rc;
+    if ((rc = tg.approx_ll(&mode, &ll[0])) != BSSM_OK) return rc;
     ll[1] = ll[0];
     if (!std::isfinite(ll[0])) return set_error(BSSM_ERR_INVALID, "Initial log-likelihood is not finite.");
   }
@@ -261,27 +303,27 @@ int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_j
       theta_prop[r] = acc;
     }
     double acceptance_prob = 0.0;
-    const double logprior_prop = wm.log_prior(theta_prop.data());
+    const double logprior_prop = tg.log_prior(theta_prop.data());
     if (logprior_prop > -INFINITY && !std::isnan(logprior_prop)) {
-      err = wm.update(theta_prop.data());
+      err = tg.update(theta_prop.data());
       if (!err.empty()) return set_error(BSSM_ERR_INVALID, err);
       bool accept = false;
       if (type == BSSM_MCMC_APPROX) {
-        if ((rc = approx_ll(&mode_prop, &ll_prop[0])) != BSSM_OK) return rc;
+        if ((rc = tg.approx_ll(&mode_prop, &ll_prop[0])) != BSSM_OK) return rc;
         ll_prop[1] = ll_prop[0];
         acceptance_prob = std::fmin(1.0, std::exp(ll_prop[0] - ll[0] + logprior_prop - logprior));
         accept = rng.uniform(i, 0) < acceptance_prob;
       } else if (type == BSSM_MCMC_PM) {
-        if ((rc = filter_ll(i, ll_prop)) != BSSM_OK) return rc;
+        if ((rc = tg.filter_ll(i, ll_prop)) != BSSM_OK) return rc;
         // the adaptation sees the approximate likelihoods, the chain the unbiased ones (src/mcmc.cpp:414-424)
         acceptance_prob = std::fmin(1.0, std::exp(ll_prop[1] - ll[1] + logprior_prop - logprior));
         const double log_alpha = ll_prop[0] - ll[0] + logprior_prop - logprior;
         accept = std::log(rng.uniform(i, 0)) < log_alpha;
       } else {  // delayed acceptance: the filter runs only for proposals that pass the approximate stage
-        if ((rc = approx_ll(nullptr, &ll_prop[1])) != BSSM_OK) return rc;
+        if ((rc = tg.approx_ll(nullptr, &ll_prop[1])) != BSSM_OK) return rc;
         acceptance_prob = std::fmin(1.0, std::exp(ll_prop[1] - ll[1] + logprior_prop - logprior));
         if (rng.uniform(i, 0) < acceptance_prob) {
-          if ((rc = filter_ll(i, ll_prop)) != BSSM_OK) return rc;
+          if ((rc = tg.filter_ll(i, ll_prop)) != BSSM_OK) return rc;
           const double log_alpha = ll_prop[0] + ll[1] - ll[0] - ll_prop[1];
           accept = std::log(rng.uniform(i, 1)) < log_alpha;
         }
@@ -289,7 +331,7 @@ int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_j
       if (std::isnan(acceptance_prob)) acceptance_prob = 0.0;
       if (accept) {
         if (i > job->burnin) { accepted++; n_values++; }
-        if (filtered && (rc = sample_or_summarise(i)) != BSSM_OK) return rc;
+        if (filtered && (rc = tg.sample_or_summarise(i, sampled.data(), ah_i.data(), vt_i.data())) != BSSM_OK) return rc;
         ll[0] = ll_prop[0]; ll[1] = ll_prop[1];
         logprior = logprior_prop;
         theta = theta_prop;
@@ -326,7 +368,7 @@ int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_j
         if (!filtered) {
           if (out->approx_loglik) out->approx_loglik[n_stored] = ll[0];
           if (out->prior) out->prior[n_stored] = logprior;
-          if (out->modes) std::memcpy(out->modes + (size_t)p * n * n_stored, mode.data(), (size_t)p * n * sizeof(double));
+          if (out->modes) std::memcpy(out->modes + (size_t)prow * n * n_stored, mode.data(), (size_t)prow * n * sizeof(double));
         }
         if (otype == 1) std::memcpy(out->alpha + sz_a * n_stored, sampled.data(), sz_a * sizeof(double));
         n_stored++;
@@ -345,6 +387,78 @@ int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_j
   out->n_stored = n_stored;
   out->acceptance_rate = (double)accepted / (double)(job->iter - job->burnin);
   return BSSM_OK;
+}
+
+// argument checks shared by the two entry points; returns the effective output type through *otype
+int check_job(const bssm_mcmc_job* job, const bssm_mcmc_out* out, bool fn, int* otype) {
+  using bssm::set_error;
+  if (job->n_par < 1) return set_error(BSSM_ERR_INVALID, "No unknown parameters ('model$theta' has length of zero).");
+  if (job->burnin > job->iter) return set_error(BSSM_ERR_INVALID, "Argument 'burnin' should be smaller than 'iter'.");
+  if (job->thin < 1) return set_error(BSSM_ERR_INVALID, "thin must be positive");
+  if (!out->S || !out->theta || !out->counts || !out->posterior || out->capacity < 1)
+    return set_error(BSSM_ERR_INVALID, "output storage missing");
+  const int type = job->mcmc_type;
+  if (type != BSSM_MCMC_APPROX && type != BSSM_MCMC_PM && type != BSSM_MCMC_DA) return set_error(BSSM_ERR_INVALID, "unknown mcmc_type");
+  const bool filtered = type != BSSM_MCMC_APPROX;
+  const bool method_ok = job->sampling_method == BSSM_PSI || job->sampling_method == BSSM_BSF || (fn && job->sampling_method == BSSM_EKPF);
+  if (filtered && !method_ok)
+    return set_error(BSSM_ERR_UNSUPPORTED, "sampling_method must be 1 (psi) or 2 (bsf) (4, ekf, for ssm_nlg); SPDK is not a particle filter path");
+  if (filtered && job->nsim < 2)
+    return set_error(BSSM_ERR_INVALID, "Number of state samples less than 2, use 'mcmc_type' 'approx' instead.");
+  *otype = filtered ? job->output_type : 3;
+  if (*otype == 1 && !out->alpha) return set_error(BSSM_ERR_INVALID, "output_type 1 needs alpha storage");
+  if (*otype == 2 && (!out->alphahat || !out->Vt)) return set_error(BSSM_ERR_INVALID, "output_type 2 needs alphahat and Vt");
+  return BSSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void bssm_mcmc_draws(uint32_t seed, uint64_t iter, int32_t n_par, double* normals, double* uniforms2) {
+  const ChainRng rng{seed};
+  if (normals) rng.normals(iter, n_par, normals);
+  if (uniforms2) { uniforms2[0] = rng.uniform(iter, 0); uniforms2[1] = rng.uniform(iter, 1); }
+}
+
+double bssm_log_prior_builtin(int model_type, const int32_t* flags, int32_t n_xreg, const double* theta, int32_t n_par,
+                              const int32_t* prior_distributions, const double* prior_parameters) {
+  return log_prior_builtin(model_type, flags, n_xreg, theta, n_par, prior_distributions, prior_parameters);
+}
+
+int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_job* job, bssm_mcmc_out* out) {
+  using bssm::set_error;
+  if (!model || !theta0 || !job || !out) return set_error(BSSM_ERR_INVALID, "NULL argument");
+  const bool builtin = job->model_type == BSSM_BSM_NG || job->model_type == BSSM_SVM_MODEL || job->model_type == BSSM_AR1_NG;
+  if (builtin && !job->update_fn && (!job->flags || !job->prior_distributions || !job->prior_parameters))
+    return set_error(BSSM_ERR_INVALID, "built-in models need flags and the prior tables");
+  if (!builtin && (!job->update_fn || !job->prior_fn))
+    return set_error(BSSM_ERR_INVALID, "ssm_ung / ssm_mng chains need update_fn and prior_fn");
+  UngTarget tg;
+  int rc = check_job(job, out, false, &tg.otype);
+  if (rc != BSSM_OK) return rc;
+  tg.job = job;
+  tg.wm.init(model, job);
+  return run_chain(tg, theta0, job, out);
+}
+
+int bssm_run_mcmc_fn(const bssm_fn_model* model, const double* theta0, const bssm_mcmc_job* job, bssm_mcmc_out* out) {
+  using bssm::set_error;
+  if (!model || !theta0 || !job || !out) return set_error(BSSM_ERR_INVALID, "NULL argument");
+  if (!job->prior_fn) return set_error(BSSM_ERR_INVALID, "ssm_nlg / ssm_sde chains need prior_fn (the model's log_prior_pdf)");
+  if (job->n_par != model->n_theta) return set_error(BSSM_ERR_INVALID, "n_par must equal the model's n_theta");
+  FnTarget tg;
+  int rc = check_job(job, out, true, &tg.otype);
+  if (rc != BSSM_OK) return rc;
+  const bool sde = model->model_id == BSSM_FN_SDE_GBM || model->model_id == BSSM_FN_SDE_POISSON_OU || model->model_id == BSSM_FN_USER_SDE;
+  if (sde && (job->mcmc_type != BSSM_MCMC_PM || job->sampling_method != BSSM_BSF))
+    return set_error(BSSM_ERR_UNSUPPORTED, "ssm_sde: pseudo-marginal chain with the bootstrap filter only (the coarse-level chains "
+                                           "of run_mcmc.ssm_sde are the same chain run with a smaller L)");
+  tg.job = job;
+  tg.mod = *model;
+  tg.theta.assign(theta0, theta0 + job->n_par);
+  tg.mod.theta = tg.theta.data();
+  return run_chain(tg, theta0, job, out);
 }
 
 }  // extern "C"

@@ -31,7 +31,7 @@ class McmcJob(C.Structure):
                 ("mcmc_type", C.c_int32), ("sampling_method", C.c_uint32), ("nsim", C.c_uint32),
                 ("iter", C.c_uint64), ("burnin", C.c_uint64), ("thin", C.c_uint32),
                 ("gamma", C.c_double), ("target_acceptance", C.c_double), ("end_ram", C.c_int32), ("seed", C.c_uint32),
-                ("output_type", C.c_int32)]
+                ("output_type", C.c_int32), ("max_iter", C.c_int32), ("conv_tol", C.c_double)]
 
 
 class McmcOut(C.Structure):
@@ -64,8 +64,11 @@ def run_mcmc(model: BssmModel, iter: int, particles: int | None = None, output_t
     """R/run_mcmc.R:392-559 (run_mcmc.nongaussian).  Returns the ``mcmc_output`` dictionary: theta (n_stored x n_par,
     natural scale), counts, posterior, S, acceptance_rate, and by type weights / modes (approx, is*), alpha
     ((n+1) x m x n_stored, output 'full'), alphahat ((n+1) x m) and Vt (output 'summary')."""
+    if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
+        return _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method, burnin, thin, gamma,
+                            target_acceptance, S, end_adaptive_phase, threads, seed, max_iter, conv_tol)
     if not model.inherits("nongaussian"):
-        raise TypeError("run_mcmc here covers models of class 'nongaussian'")
+        raise TypeError("run_mcmc covers models of class 'nongaussian', 'ssm_nlg' and 'ssm_sde'")
     if not isinstance(end_adaptive_phase, (bool, np.bool_)):
         raise ValueError("Argument 'end_adaptive_phase' should be TRUE or FALSE. ")
     if not isinstance(local_approx, (bool, np.bool_)):
@@ -239,6 +242,132 @@ def run_mcmc(model: BssmModel, iter: int, particles: int | None = None, output_t
     return res
 
 
+def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method, burnin, thin, gamma, target_acceptance, S,
+                 end_adaptive_phase, threads, seed, max_iter, conv_tol):
+    """run_mcmc.ssm_nlg / run_mcmc.ssm_sde (R/run_mcmc.R:561-900) for the model functors: the chain runs in the library
+    (bssm_run_mcmc_fn), the prior is ``model['prior_fn']`` or the shipped example's log_prior_pdf."""
+    from .models import example_log_prior
+    sde = model.inherits("ssm_sde")
+    seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
+    threads = check_intmax(threads, "threads")
+    thin = check_intmax(thin, "thin", max=100)
+    iter = check_intmax(iter, "iter", max=int(1e12))
+    burnin = check_intmax(iter // 2 if burnin is None else burnin, "burnin", False, max=int(1e12))
+    if burnin > iter:
+        raise ValueError("Argument 'burnin' should be smaller than 'iter'.")
+    otype = PC._OUTPUT_TYPES[output_type.lower() if isinstance(output_type, str) else output_type]
+    mcmc_type = mcmc_type.lower()
+    if sde:
+        mcmc_type, sampling_method = ("pm" if mcmc_type == "is2" else mcmc_type), "bsf"
+        if mcmc_type != "pm":
+            raise ValueError("ssm_sde: mcmc_type 'pm' (the two-level chains re-run it at a coarser discretisation)")
+    elif mcmc_type not in ("pm", "da", "is1", "is2", "is3", "approx"):
+        raise ValueError("'arg' should be one of 'pm', 'da', 'is1', 'is2', 'is3', 'approx'")
+    sampling_method = sampling_method.lower()
+    if sampling_method not in ("psi", "bsf", "ekf"):
+        raise ValueError("'arg' should be one of 'psi', 'bsf', 'ekf'")
+    if mcmc_type == "approx":
+        particles = 0
+    elif particles is None or particles < 2:
+        raise ValueError("Number of state samples less than 2, use 'mcmc_type' 'approx' instead.")
+    else:
+        particles = check_intmax(particles, "particles")
+    t0 = time.perf_counter()
+    theta0 = np.array(model["theta"], dtype=np.float64).reshape(-1)
+    d = theta0.size
+    if d == 0:
+        raise ValueError("No unknown parameters ('model$theta' has length of zero).")
+    prior = model.get("prior_fn") or (example_log_prior(model["example"]) if model.get("example") not in (None, "user") else None)
+    if prior is None:
+        raise ValueError("user-defined models need 'prior_fn' (the model's log_prior_pdf) for run_mcmc")
+    S_in = np.diag(0.1 * np.maximum(0.1, np.abs(theta0))) if S is None else np.array(S, dtype=np.float64).reshape(d, d)
+    S_buf = np.asfortranarray(np.tril(S_in))
+    failure = []
+
+    def _prior(th_p, n_par, _user):
+        try:
+            return float(prior(np.ctypeslib.as_array(th_p, shape=(n_par,)).copy()))
+        except Exception as e:  # exceptions cannot cross the C frames
+            failure.append(e)
+            return float("nan")
+
+    smod, keep = _lib.pack_fn_model(model)
+    job = McmcJob()
+    job.n_par = d
+    job.prior_fn = _PRIOR_FN(_prior)
+    chain = _MCMC_TYPES.get(mcmc_type, 0)
+    job.mcmc_type = chain
+    job.sampling_method = {"psi": 1, "bsf": 2, "ekf": 4}[sampling_method]
+    job.nsim = particles
+    job.iter, job.burnin, job.thin = iter, burnin, thin
+    job.gamma, job.target_acceptance, job.end_ram, job.seed = gamma, target_acceptance, int(bool(end_adaptive_phase)), seed
+    job.output_type = otype
+    job.max_iter, job.conv_tol = int(max_iter), float(conv_tol)
+    n, m = model.n, int(model.get("n_states", 1))
+    cap = max(1, (iter - burnin) // thin + 1)
+    out = McmcOut()
+    out.capacity = cap
+    theta_s = np.zeros((d, cap), order="F")
+    counts = np.zeros(cap, dtype=np.uint32)
+    posterior = np.zeros(cap)
+    out.S, out.theta, out.counts, out.posterior = _lib.dptr(S_buf), _lib.dptr(theta_s), counts.ctypes.data_as(_lib.c_u32_p), _lib.dptr(posterior)
+    al = prior_s = modes = alpha = ah = vt = None
+    if chain == 0:
+        al, prior_s, modes = np.zeros(cap), np.zeros(cap), np.zeros((m * n, cap), order="F")
+        out.approx_loglik, out.prior, out.modes = _lib.dptr(al), _lib.dptr(prior_s), _lib.dptr(modes)
+    elif otype == 1:
+        alpha = np.zeros((n + 1, m, cap), order="F")
+        out.alpha = _lib.dptr(alpha)
+    elif otype == 2:
+        ah, vt = np.zeros((m, n + 1), order="F"), np.zeros((m, m, n + 1), order="F")
+        out.alphahat, out.Vt = _lib.dptr(ah), _lib.dptr(vt)
+    L = _lib.lib()
+    L.bssm_run_mcmc_fn.argtypes = [C.POINTER(_lib.FnModel), _lib.c_double_p, C.POINTER(McmcJob), C.POINTER(McmcOut)]
+    rc = L.bssm_run_mcmc_fn(C.byref(smod), _lib.dptr(theta0), C.byref(job), C.byref(out))
+    if failure:
+        raise failure[0]
+    _lib.check(rc)
+    ns = out.n_stored
+    res = dict(theta=np.ascontiguousarray(theta_s[:, :ns].T), counts=counts[:ns].copy(), posterior=posterior[:ns].copy(),
+               S=np.array(S_buf), acceptance_rate=out.acceptance_rate, iter=iter, burnin=burnin, thin=thin,
+               mcmc_type=mcmc_type, output_type=otype, seed=seed, theta_names=list(model.get("theta_names", [])),
+               model_type=model.classes[0], time_chain=time.perf_counter() - t0)
+    if chain == 0:
+        res["modes"] = modes[:, :ns].reshape(m, n, ns, order="F")
+        res["approx_loglik"], res["prior"] = al[:ns].copy(), prior_s[:ns].copy()
+        res["weights"] = np.ones(ns)
+        if mcmc_type != "approx":
+            tc = time.perf_counter()
+            if sampling_method == "psi":
+                corrected = PC.post_correct(model, res, particles, threads=threads, is_type=mcmc_type, seed=seed)
+            else:  # is_correction_bsf<ssm_nlg> (src/approx_mcmc.cpp:807-921)
+                it = int(mcmc_type[-1])
+                th_c, cn_c, al_c, post_c = res["theta"], res["counts"], res["approx_loglik"], res["posterior"]
+                if it == 3:
+                    rep = cn_c.astype(np.int64)
+                    th_c, al_c, post_c = np.repeat(th_c, rep, axis=0), np.repeat(al_c, rep), np.repeat(post_c, rep)
+                    cn_c = np.ones(int(rep.sum()), dtype=np.uint32)
+                r = PC.is_correction(model, th_c, cn_c, particles, method="bsf", approx_loglik=al_c, is_type=it,
+                                     output_type=otype, seed=seed, threads=threads)
+                with np.errstate(divide="ignore"):
+                    corrected = dict(weights=r["weights"], loglik=r["loglik"], theta=th_c, counts=cn_c,
+                                     posterior=post_c + np.log(r["weights"]), timing_ms=r.get("timing_ms"))
+                if otype == 1:
+                    corrected["alpha"] = r["alpha"]
+                elif otype == 2:
+                    corrected["alphahat"], corrected["Vt"] = np.ascontiguousarray(r["alphahat"].T), r["Vt"]
+            for k in ("weights", "posterior", "theta", "counts", "modes", "alpha", "alphahat", "Vt", "loglik", "timing_ms"):
+                if k in corrected:
+                    res[k] = corrected[k]
+            res["time_postcorrection"] = time.perf_counter() - tc
+    elif otype == 1:
+        res["alpha"] = alpha[:, :, :ns].copy()
+    elif otype == 2:
+        res["alphahat"], res["Vt"] = np.ascontiguousarray(ah.T), vt
+    res["time"] = time.perf_counter() - t0
+    return res
+
+
 def summary(out: dict, variable: str = "theta", times=None):
     """Weighted posterior means and standard deviations (R/summary.R: weights = counts x IS weights): for
     ``variable='theta'`` per parameter, for ``'states'`` per state at the (1-based) ``times`` from the stored
@@ -264,3 +393,28 @@ def summary(out: dict, variable: str = "theta", times=None):
         idx = np.atleast_1d(np.asarray(times, dtype=int)) - 1
         mean, sd = mean[idx], sd[idx]
     return dict(Mean=mean, SD=sd)
+
+
+def asymptotic_var(x, w=None):
+    """Asymptotic variance of the IS-weighted chain mean (R/asymptotic_var.R:9-33): with z = w (x - weighted mean), the
+    long-run variance of z over n and mean(w)^2.  The long-run variance uses the initial-positive-sequence estimator of the
+    autocovariances (the reference's 'geyer' flavour)."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.ones_like(x) if w is None else np.asarray(w, dtype=np.float64)
+    if np.any(w < 0) or not np.all(np.isfinite(w)):
+        raise ValueError("Nonfinite or negative weights in 'w'.")
+    if not np.any(w > 0):
+        raise ValueError("No positive weights in 'w'.")
+    mu = np.sum(w * x) / np.sum(w)
+    z = w * (x - mu)
+    n = z.size
+    zc = z - z.mean()
+    f = np.fft.rfft(zc, 2 * n)
+    acov = np.fft.irfft(f * np.conj(f))[:n] / n
+    lrv = -acov[0]
+    for k in range(0, n - 1, 2):
+        g = acov[k] + acov[k + 1]
+        if g <= 0:
+            break
+        lrv += 2 * g
+    return float(max(lrv, 0.0) / n / np.mean(w) ** 2)

@@ -480,6 +480,41 @@ def ar1_lg(y, rho, sigma, mu, sd_y):
 FN_IDS = {"nlg_growth": 1, "nlg_ar_exp": 2, "nlg_sin_exp": 3, "nlg_linear_gaussian": 4, "sde_gbm": 5, "sde_poisson_ou": 6}
 
 
+def _dnorm(x, mu, sd):
+    return -0.9189385332046727 - np.log(sd) - 0.5 * ((x - mu) / sd) ** 2
+
+
+def example_log_prior(example: str):
+    """log_prior_pdf of the shipped example models (R/cpp_example_models.R:59-70, 145-158, 290-299, 454-473, 595-597,
+    718-721), the default ``prior_fn`` of ssm_nlg / ssm_sde models built from them."""
+    def growth(th):
+        return float(np.sum(_dnorm(np.exp(th[:3]), 0.0, 2.0)) + np.sum(th))
+
+    def ar_exp(th):
+        if not 0.0 < th[1] < 1.0:
+            return -np.inf
+        return float(_dnorm(th[0], 0, 10) + np.log(6.0) + np.log(th[1]) + np.log1p(-th[1]) +
+                     _dnorm(np.exp(th[2]), 0, 1) + th[2] + _dnorm(np.exp(th[3]), 0, 1) + th[3])
+
+    def sin_exp(th):
+        return float(_dnorm(np.exp(th[0]), 0, 1) + th[0] + _dnorm(np.exp(th[1]), 0, 1) + th[1])
+
+    def linear_gaussian(th):
+        return float(_dnorm(np.exp(th[0]), 0, 1) + th[0])
+
+    def gbm(th):
+        if th[0] < 0 or th[1] < 0 or th[2] < 0.5:
+            return -np.inf
+        return float(_dnorm(th[0], 0, 0.1) + _dnorm(th[1], 0, 0.5) + _dnorm(th[2], 1.5, 0.5))
+
+    def poisson_ou(th):
+        x = np.exp(th[0])
+        return float(np.log(x) - 2.0 * x + 2.0 * np.log(2.0) + _dnorm(th[1], 0, 4) + _dnorm(np.exp(th[2]), 0, 1) + th[0] + th[2])
+
+    return {"nlg_growth": growth, "nlg_ar_exp": ar_exp, "nlg_sin_exp": sin_exp, "nlg_linear_gaussian": linear_gaussian,
+            "sde_gbm": gbm, "sde_poisson_ou": poisson_ou}[example]
+
+
 def ssm_nlg(y, example: str, theta, known_params=(), n_states=None, n_etas=None):
     """R/models.R:1472-1570 with the function pointers of `cpp_example_model(example)` (R/cpp_example_models.R):
     only the shipped example models are available on the device (nlg_growth, nlg_ar_exp, nlg_sin_exp,

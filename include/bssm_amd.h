@@ -372,6 +372,8 @@ typedef struct bssm_mcmc_job {
   int32_t end_ram;                    /* stop adapting after the burn-in */
   uint32_t seed;
   int32_t output_type;                /* pm / da: 1 one trajectory per stored value, 2 running summary, 3 theta only */
+  int32_t max_iter;                   /* ssm_nlg mode search (src/model_ssm_nlg.cpp:19-20); ssm_ung models carry their own */
+  double conv_tol;
 } bssm_mcmc_job;
 typedef struct bssm_mcmc_out {
   int32_t capacity;        /* in: room for this many stored values (floor((iter - burnin) / thin) always suffices) */
@@ -393,6 +395,13 @@ typedef struct bssm_mcmc_out {
  * update_fn rewrites them in place.  Errors: BSSM_ERR_INVALID for a non-finite initial prior / log-likelihood or when no
  * proposal was accepted (the reference stops with the same conditions, src/mcmc.cpp:352,363,485). */
 int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_job* job, bssm_mcmc_out* out);
+/* The same chains for ssm_nlg / ssm_sde models (run_mcmc.ssm_nlg, R/run_mcmc.R:561-700 -> nonlinear_pm_mcmc / _da_mcmc /
+ * _is_mcmc, src/R_mcmc.cpp:534-830; run_mcmc.ssm_sde -> sde_pm_mcmc, src/R_sde.cpp:134-170): theta IS the model's
+ * parameter vector, prior_fn its log_prior_pdf; sampling_method BSSM_PSI / BSSM_BSF / BSSM_EKPF.  The approximate
+ * log-likelihood is the mode-based one (ssm_nlg::log_likelihood with nsim = 0, src/model_ssm_nlg.cpp:258-277).
+ * ssm_sde: pseudo-marginal chain with the bootstrap filter (the reference's only exact sde chain besides the two-level
+ * variants, which re-run this chain at a coarser L). */
+int bssm_run_mcmc_fn(const bssm_fn_model* model, const double* theta0, const bssm_mcmc_job* job, bssm_mcmc_out* out);
 /* the chain's own random numbers (tests): standard normals of iteration `iter` and its acceptance uniforms */
 void bssm_mcmc_draws(uint32_t seed, uint64_t iter, int32_t n_par, double* normals, double* uniforms2);
 /* log_prior_pdf of a built-in model (tests, host-only) */

@@ -620,7 +620,7 @@ def adapt_S(S, u, acc, target, i, gamma):
 
 
 def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target, seed, end_ram=False, kind="approx",
-              nsim=0, method="psi", output_type=3):
+              nsim=0, method="psi", output_type=3, fn_model=False):
     """One chain.  ``update(theta) -> arr`` gives the flattened model, ``log_prior(theta) -> float``.
     kind: 'approx' | 'pm' | 'da'.  Returns theta (n_stored x d), counts, posterior, S, acceptance_rate and by kind
     approx_loglik / prior / modes, alpha (n+1) x m x n_stored, alphahat / Vt."""
@@ -631,11 +631,21 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
     L = lib()
 
     def approx(arr):
+        if fn_model:  # ssm_nlg: mode-based approximation (src/model_ssm_nlg.cpp:258-277)
+            su = fn_psi_setup(arr)
+            return (su["approx_loglik"] if su["rc"] == 0 and su["ok"] else -np.inf), su["mode"].reshape(-1, order="F"), su
         su = psi_setup(arr)
         return su["approx_loglik"], su["mode"], su
 
     def filt(arr, it):
-        """(ll0, ll1, particle system) with the filter's stream = iteration"""
+        """(ll0, ll1, particle system) with the filter's stream = iteration (functor models: seed + iteration)"""
+        if fn_model:
+            sd = (seed + it) & 0xFFFFFFFF
+            if method == "psi":
+                r = fn_psi_filter(arr, nsim, seed=sd, stream=0)
+                return r["logLik"], r["setup"]["approx_loglik"], r
+            r = fn_ekpf_filter(arr, nsim, seed=sd, stream=0) if method == "ekf" else fn_bsf_filter(arr, nsim, seed=sd, stream=0)
+            return r["logLik"], r["logLik"], r
         sd, st = seed + (it >> 32), it & 0xFFFFFFFF
         if method == "psi":
             r = psi_filter(arr, nsim, seed=sd, stream=st)
@@ -646,7 +656,7 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
     def sample_or_summarise(res, it):
         sm = filter_smoother(res["alpha"], res["indices"])  # m x (n+1) x N
         if output_type == 1:
-            r, _ = make_rng(seed=seed + (it >> 32), stream=it & 0xFFFFFFFF)
+            r, _ = make_rng(seed=(seed + it) & 0xFFFFFFFF, stream=0) if fn_model else make_rng(seed=seed + (it >> 32), stream=it & 0xFFFFFFFF)
             pick = min(int(L.orc_rng_uniform(C.byref(r), 3, 0, 0, 0) * nsim), nsim - 1)
             return sm[:, :, pick].T.copy(), None, None
         if output_type == 2:

@@ -15,22 +15,7 @@ from bssm_amd import mcmc, models as M
 
 
 def asymptotic_se(x, w):
-    """sqrt(asymptotic_var) of the IS-weighted chain mean (R/asymptotic_var.R: weighted mean of a jump chain; initial
-    positive sequence estimator on z = w (x - mean))"""
-    w = np.asarray(w, dtype=float); x = np.asarray(x, dtype=float)
-    mu = np.sum(w * x) / np.sum(w)
-    z = w * (x - mu)
-    n = z.size
-    zc = z - z.mean()
-    f = np.fft.rfft(zc, 2 * n)
-    acov = np.fft.irfft(f * np.conj(f))[:n] / n
-    s = -acov[0]
-    for k in range(0, n - 1, 2):
-        g = acov[k] + acov[k + 1]
-        if g <= 0:
-            break
-        s += 2 * g
-    return float(np.sqrt(max(s, 0.0) / n) / np.mean(w))
+    return float(np.sqrt(mcmc.asymptotic_var(x, w)))
 
 
 def main():

@@ -207,3 +207,119 @@ def test_paper_negbin_posterior_means():
     st = mcmc.summary(fit, variable="states", times=200)["Mean"].reshape(-1)
     paper_alpha = np.array([6.962, 0.006])
     assert np.mean(np.abs(st - paper_alpha)) / np.mean(np.abs(paper_alpha)) < 0.01
+
+
+def test_replication_table_poisson():
+    """benchmarks/replications.html: every MCMC type of the reference on bsm_ng(poisson_series), 1e4 iterations each.  The
+    document prints the weighted posterior means with their asymptotic standard errors; the same runs here must agree
+    with those means within the combined Monte-Carlo error (34 comparisons, |z| < 4)."""
+    import json
+    ref = json.load(open(os.path.join(GOLD, "reference_test_vectors.json")))["mcmc_replications_poisson"]["table"]
+    y = np.loadtxt(os.path.join(GOLD, "poisson_series.txt"))
+    s = np.std(np.log(np.maximum(0.1, y)), ddof=1)
+    model = M.bsm_ng(y, sd_level=M.uniform(0.115, 0, 2 * s), sd_slope=M.uniform(0.004, 0, 2 * s), P1=np.diag([0.1, 0.1]),
+                     distribution="poisson")
+    worst = 0.0
+    for typ, meth in (("approx", "psi"), ("da", "bsf"), ("da", "psi"), ("is1", "bsf"), ("is1", "psi"), ("is2", "bsf"),
+                      ("is2", "psi"), ("pm", "bsf"), ("pm", "psi")):
+        res = mcmc.run_mcmc(model, 10000, particles={"bsf": 200, "psi": 10}[meth], mcmc_type=typ, sampling_method=meth,
+                            end_adaptive_phase=True, seed=77, threads=8)
+        assert 0.15 < res["acceptance_rate"] < 0.35
+        w = res["counts"] * (res["weights"] if typ in ("is1", "is2") else 1.0)
+        series = dict(sd_level=res["theta"][:, 0], sd_slope=res["theta"][:, 1])
+        if "alpha" in res:
+            series.update(u_1=res["alpha"][0, 0, :], u_100=res["alpha"][99, 0, :])
+        for var, x in series.items():
+            r = [q for q in ref if q["variable"] == var and q["mcmc_type"] == typ and q["sampling_method"] == meth and q["local_approx"]][0]
+            mean = np.sum(w * x) / np.sum(w)
+            z = (mean - r["mean"]) / np.hypot(r["se"], np.sqrt(mcmc.asymptotic_var(x, w)))
+            worst = max(worst, abs(z))
+            assert abs(z) < 4.0, (typ, meth, var, mean, r["mean"], z)
+
+
+# ------------------------------------------------------------------ ssm_nlg / ssm_sde (model functors)
+def _nlg(kind="sin_exp", n=25, seed=4):
+    rng = np.random.default_rng(seed)
+    if kind == "sin_exp":
+        x = np.zeros(n); y = np.zeros(n)
+        for t in range(n):
+            if t:
+                x[t] = np.sin(x[t - 1]) + rng.normal(0, 0.3)
+            y[t] = np.exp(x[t]) + rng.normal(0, 0.3)
+        y[3] = np.nan
+        return M.ssm_nlg(y, "nlg_sin_exp", theta=[np.log(0.3), np.log(0.3)])
+    if kind == "growth":
+        K, dT = 500.0, 0.1
+        r = np.zeros(n); p = np.zeros(n); p[0] = 50.0
+        for t in range(1, n):
+            r[t] = r[t - 1] + rng.normal(0, 0.05)
+            rr = np.exp(r[t - 1]) / (1 + np.exp(r[t - 1]))
+            p[t] = K * p[t - 1] * np.exp(rr * dT) / (K + p[t - 1] * (np.exp(rr * dT) - 1)) + rng.normal(0, 1)
+        y = p + rng.normal(0, 1, n)
+        return M.ssm_nlg(y, "nlg_growth", theta=[0.0, np.log(0.05), 0.0], known_params=[dT, K, 0.0, 50.0, 1.0, 100.0])
+    if kind == "gbm":
+        x = np.exp(np.cumsum(rng.normal(0.01, 0.1, n)))
+        y = np.log(x) + rng.normal(0, 0.5, n)
+        mdl = M.ssm_sde(y, "sde_gbm", theta=[0.05, 0.3, 1.0], x0=1.0, positive=True)
+        return M.BssmModel(mdl.classes, **{**mdl, "L": 2})
+    raise ValueError(kind)
+
+
+def _fn_oracle_fns(model):
+    prior = M.example_log_prior(model["example"])
+    m = int(model.get("n_states", 1))
+    return (lambda th: {**model, "theta": np.asarray(th, dtype=float), "n": model.n, "m": m}), prior
+
+
+@pytest.mark.parametrize("kind", ["sin_exp", "growth"])
+def test_nlg_approx_chain_matches_oracle(oracle, kind):
+    model = _nlg(kind)
+    iters, burnin, seed = 150, 50, 5
+    out = mcmc.run_mcmc(model, iters, burnin=burnin, mcmc_type="approx", seed=seed)
+    upd, prior = _fn_oracle_fns(model)
+    th0 = np.array(model["theta"], dtype=float)
+    ref = oracle.run_chain(upd, prior, th0, np.diag(0.1 * np.maximum(0.1, np.abs(th0))), iters, burnin, 1, 2 / 3, 0.234, seed,
+                           fn_model=True)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(out["theta"], ref["theta"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["approx_loglik"], ref["approx_loglik"], rtol=0, atol=1e-7 * model.n)
+    m = int(model["n_states"])
+    assert np.allclose(out["modes"].reshape(m * model.n, -1, order="F"), ref["modes"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(out["S"], ref["S"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("mdl,kind,method,otype", [("sin_exp", "pm", "psi", 1), ("sin_exp", "pm", "bsf", 2), ("sin_exp", "da", "psi", 2),
+                                                   ("sin_exp", "pm", "ekf", 3), ("growth", "pm", "psi", 1), ("growth", "da", "bsf", 3),
+                                                   ("gbm", "pm", "bsf", 1), ("gbm", "pm", "bsf", 2)])
+def test_nlg_sde_pm_da_chain_matches_oracle(oracle, mdl, kind, method, otype):
+    model = _nlg(mdl, n=20)
+    iters, burnin, seed, N = 40, 10, 31, 32
+    out = mcmc.run_mcmc(model, iters, particles=N, burnin=burnin, mcmc_type=kind, sampling_method=method,
+                        output_type={1: "full", 2: "summary", 3: "theta"}[otype], seed=seed)
+    upd, prior = _fn_oracle_fns(model)
+    th0 = np.array(model["theta"], dtype=float)
+    ref = oracle.run_chain(upd, prior, th0, np.diag(0.1 * np.maximum(0.1, np.abs(th0))), iters, burnin, 1, 2 / 3, 0.234, seed,
+                           kind=kind, nsim=N, method=method, output_type=otype, fn_model=True)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(out["theta"], ref["theta"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["posterior"], ref["posterior"], rtol=0, atol=1e-7 * model.n)
+    if otype == 1:
+        assert np.allclose(out["alpha"], ref["alpha"], rtol=1e-7, atol=1e-9)
+    if otype == 2:
+        assert np.allclose(out["alphahat"], ref["alphahat"].T, rtol=1e-7, atol=1e-9)
+        assert np.allclose(out["Vt"], ref["Vt"], rtol=1e-6, atol=1e-9)
+
+
+def test_nlg_is2_reweights_the_approximate_chain():
+    """run_mcmc.ssm_nlg with an `is` type (R/run_mcmc.R:561-700 -> nonlinear_is_mcmc, src/R_mcmc.cpp:736-830): the chain that
+    produces the draws of BASELINE config C5, followed by their post-correction"""
+    model = _nlg("growth", n=40)
+    base = mcmc.run_mcmc(model, 300, burnin=100, mcmc_type="approx", seed=3)
+    out = mcmc.run_mcmc(model, 300, particles=64, burnin=100, mcmc_type="is2", sampling_method="psi", output_type="summary",
+                        seed=3, threads=2)
+    ref = PC.post_correct(model, dict(base, output_type=2), 64, threads=2, is_type="is2", seed=3)
+    assert np.allclose(out["weights"], ref["weights"], rtol=1e-12)
+    assert np.allclose(out["alphahat"], ref["alphahat"], rtol=1e-12)
+    assert np.all(np.isfinite(out["weights"])) and out["alphahat"].shape == (41, 2)
+    bsf = mcmc.run_mcmc(model, 300, particles=64, burnin=100, mcmc_type="is2", sampling_method="bsf", output_type="theta", seed=3)
+    assert np.all(np.isfinite(bsf["weights"])) and bsf["weights"].size == base["counts"].size
