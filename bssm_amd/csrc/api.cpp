@@ -1509,12 +1509,15 @@ struct bssm_plan {
   int n_models = 0, n_rep = 0;
   bool psi = false;
   double bytes_per_pstep = 0;
+  // local_approx = FALSE: pseudo-observations of each model's first approximation, reused by bssm_plan_update
+  std::vector<bssm::GlobalApprox> global;
 };
 
 namespace {
 // tables (one per model x replica) and additive log-likelihood terms of a plan's models
 int plan_tables(const bssm_ung_model* models, int n_models, int n_rep, bool psi, std::vector<bssm::FilterTables>* tabs,
-                std::vector<double>* consts, int* n, int* m, int* k, int* pp) {
+                std::vector<double>* consts, int* n, int* m, int* k, int* pp, std::vector<bssm::GlobalApprox>* global) {
+  if (global) global->resize(n_models);
   tabs->clear(); consts->clear();
   for (int i = 0; i < n_models; i++) {
     bssm::HostModel hm;
@@ -1527,7 +1530,9 @@ int plan_tables(const bssm_ung_model* models, int n_models, int n_rep, bool psi,
     const int MP = bssm::pad_dim(*m);
     if (psi) {
       bssm::PsiSetup su;
-      if (!bssm::psi_setup(hm, nullptr, &su)) return fail(BSSM_ERR_NUMERIC, "psi set-up produced non-finite values");
+      bssm::GlobalApprox* g = (global && !hm.local_approx) ? &(*global)[i] : nullptr;
+      if (!bssm::psi_setup(hm, nullptr, &su, g)) return fail(BSSM_ERR_NUMERIC, "psi set-up produced non-finite values");
+      if (g && !g->set) { g->y = su.approx_y; g->H = su.approx_H; g->set = true; }
       bssm::build_psi_tables(hm, su, MP, &ft);
       base = su.approx_loglik;
     } else {
@@ -1549,8 +1554,8 @@ bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int3
   std::vector<bssm::FilterTables> tabs;
   std::vector<double> consts;
   int n = 0, m = 0, k = 0, pp = 1;
-  if (plan_tables(models, n_models, n_rep, psi, &tabs, &consts, &n, &m, &k, &pp) != BSSM_OK) return nullptr;
   std::unique_ptr<bssm_plan> p(new bssm_plan);
+  if (plan_tables(models, n_models, n_rep, psi, &tabs, &consts, &n, &m, &k, &pp, &p->global) != BSSM_OK) return nullptr;
   p->n_models = n_models; p->n_rep = n_rep; p->psi = psi;
   const bool keep = flags & BSSM_PLAN_KEEP_HISTORY;
   if (p->db.upload(tabs, n, m, k, pp, (int)nsim, psi, keep, flags) != BSSM_OK) return nullptr;
@@ -1568,7 +1573,7 @@ int bssm_plan_update(bssm_plan* plan, const bssm_ung_model* models, void* hip_st
   std::vector<bssm::FilterTables> tabs;
   std::vector<double> consts;
   int n = 0, m = 0, k = 0, pp = 1;
-  const int rc = plan_tables(models, plan->n_models, plan->n_rep, plan->psi, &tabs, &consts, &n, &m, &k, &pp);
+  const int rc = plan_tables(models, plan->n_models, plan->n_rep, plan->psi, &tabs, &consts, &n, &m, &k, &pp, &plan->global);
   if (rc) return rc;
   const bssm::FilterBatch& fb = plan->db.fb;
   if (n != fb.n || m != fb.m || k != fb.k || pp != fb.p || tabs[0].MP != fb.MP || tabs[0].KP != fb.KP ||

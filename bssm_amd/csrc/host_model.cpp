@@ -581,7 +581,7 @@ double const_term(const HostModel& h) {
   return res;
 }
 
-bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out) {
+bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out, const GlobalApprox* global) {
   const int n = h.n, m = h.m, p = h.p;
   const Sys S(h);
   Approx ap;
@@ -595,7 +595,15 @@ bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out) {
     out->approx_loglik = 0.0;
     out->iterations = 0;
   } else {  // psi_filter set-up: src/model_ssm_ung.cpp:514-528
-    out->iterations = run_laplace(h, S, &ap, &out->mode, &ok);
+    if (global && global->set) {  // local_approx = FALSE after the first approximation: src/model_ssm_ung.cpp:104-116
+      ap.y = global->y; ap.H = global->H;
+      std::vector<Mat> sm;
+      ok = fast_smoother(S, ap, &sm);
+      if (ok) signal_from_states(h, S, sm, &out->mode); else out->mode = h.initial_mode;
+      out->iterations = 0;
+    } else {
+      out->iterations = run_laplace(h, S, &ap, &out->mode, &ok);
+    }
     const double gll = gaussian_loglik(S, ap);
     update_scales(h, ap, out->mode, &out->scales);
     double ssc = 0;
@@ -710,16 +718,24 @@ bool gaussian_smoothing_setup(const HostModel& h, PsiSetup* out) {
   return ok;
 }
 
-double approx_loglik_only(const HostModel& h) { return approx_loglik_mode(h, nullptr); }
+double approx_loglik_only(const HostModel& h) { return approx_loglik_mode(h, nullptr, nullptr); }
 
-double approx_loglik_mode(const HostModel& h, std::vector<double>* mode_out) {
+double approx_loglik_mode(const HostModel& h, std::vector<double>* mode_out, GlobalApprox* global) {
   const Sys S(h);
   Approx ap;
   ap.y.assign((size_t)h.p * h.n, 0.0);
   ap.H.assign((size_t)h.p * h.n, 0.0);
   std::vector<double> mode, scales;
   bool ok = true;
-  run_laplace(h, S, &ap, &mode, &ok);
+  if (global && global->set) {  // the pseudo-observations of the first approximation are kept (src/model_ssm_ung.cpp:104-116)
+    ap.y = global->y; ap.H = global->H;
+    std::vector<Mat> sm;
+    ok = fast_smoother(S, ap, &sm);
+    if (ok) signal_from_states(h, S, sm, &mode);
+  } else {
+    run_laplace(h, S, &ap, &mode, &ok);
+    if (global && ok) { global->y = ap.y; global->H = ap.H; global->set = true; }
+  }
   if (!ok) return -INFINITY;
   if (mode_out) *mode_out = mode;
   const double gll = gaussian_loglik(S, ap);

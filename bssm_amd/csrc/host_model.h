@@ -41,7 +41,13 @@ struct PsiSetup {
   int iterations = 0;
 };
 // is_mode == nullptr: iterate from hm.initial_mode.  Returns false on a numerical failure.
-bool psi_setup(const HostModel& hm, const double* is_mode, PsiSetup* out);
+// local_approx = FALSE (src/model_ssm_ung.cpp:104-116): the pseudo-observations (approx y, H) of the FIRST approximation
+// of a chain are kept; later parameter values only re-run the smoother against them.  `set` is false until then.
+struct GlobalApprox {
+  std::vector<double> y, H;
+  bool set = false;
+};
+bool psi_setup(const HostModel& hm, const double* is_mode, PsiSetup* out, const GlobalApprox* global = nullptr);
 // exact smoothing factors of a linear-Gaussian (ssm_ulg family) model for gaussian_psi_smoother:
 // smoother_ccov + conditional_cov on the model itself (src/model_ssm_ulg.cpp:646-652)
 bool gaussian_smoothing_setup(const HostModel& hm, PsiSetup* out);
@@ -66,7 +72,8 @@ bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct)
 // log-likelihood of the Gaussian approximation only (nsim = 0 path, src/model_ssm_ung.cpp:214-234)
 double approx_loglik_only(const HostModel& hm);
 // same, also returning the converged mode (p x n) -- what approx_mcmc::amcmc stores per accepted value
-double approx_loglik_mode(const HostModel& hm, std::vector<double>* mode);
+// `global` (may be NULL): filled by the first call, used by the later ones -- the chain's state for local_approx = FALSE
+double approx_loglik_mode(const HostModel& hm, std::vector<double>* mode, GlobalApprox* global = nullptr);
 // records the message bssm_amd_last_error() returns on this thread; returns `code`
 int set_error(int code, const std::string& msg);
 

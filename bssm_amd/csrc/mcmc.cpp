@@ -151,6 +151,7 @@ struct UngTarget {
   const bssm_mcmc_job* job;
   PlanGuard plan;
   int otype = 3;
+  bssm::GlobalApprox global;  // local_approx = FALSE: the pseudo-observations of the chain's first approximation
   int n() const { return wm.mod.n; }
   int m() const { return wm.mod.m; }
   int mode_rows() const { return wm.mod.p > 1 ? wm.mod.p : 1; }
@@ -160,7 +161,7 @@ struct UngTarget {
     bssm::HostModel hm;
     const std::string e = bssm::ingest_model(&wm.mod, true, &hm);
     if (!e.empty()) return bssm::set_error(BSSM_ERR_INVALID, e);
-    *val = bssm::approx_loglik_mode(hm, mode);
+    *val = bssm::approx_loglik_mode(hm, mode, wm.mod.local_approx ? nullptr : &global);
     return BSSM_OK;
   }
   // one device filter pass of the working model; ll[0] unbiased estimate, ll[1] approximate (psi) or the same (bsf),
@@ -171,6 +172,9 @@ struct UngTarget {
     if (!plan.p) {
       plan.p = bssm_plan_create(&wm.mod, 1, 1, job->nsim, job->sampling_method, otype != 3 ? BSSM_PLAN_KEEP_HISTORY : 0u);
       if (!plan.p) return BSSM_ERR_INVALID;  // message already recorded
+      // local_approx = FALSE: the psi filter of the initial value made the chain's first approximation
+      // (src/model_ssm_ung.cpp:514-518); the approximate stage of delayed acceptance reuses its pseudo-observations
+      if (psi && !wm.mod.local_approx && !global.set) { double tmp; if ((rc = approx_ll(nullptr, &tmp)) != BSSM_OK) return rc; }
     } else if ((rc = bssm_plan_update(plan.p, &wm.mod, nullptr)) != BSSM_OK) {
       if (rc == BSSM_ERR_NUMERIC) { ll[0] = ll[1] = -INFINITY; return BSSM_OK; }  // a failed approximation rejects the proposal
       return rc;

@@ -597,6 +597,40 @@ def builtin_log_prior(kind: str, flags, n_xreg, theta, pd, pp):
     return float(lp)
 
 
+def global_approx_loglik(arr: dict, approx_y, approx_H):
+    """approximate() + log_likelihood(nsim = 0) with local_approx = FALSE once an approximation exists
+    (src/model_ssm_ung.cpp:104-116, 216-232): the pseudo-observations stay, one smoother pass against the new parameters
+    gives the mode; log-likelihood = Gaussian part + constants + the mode-based scales (:241-290, 347-370).
+    Univariate, Poisson / binomial / negative binomial / gamma."""
+    ga = {**arr, "y": np.asarray(approx_y, dtype=np.float64), "H": np.asarray(approx_H, dtype=np.float64)}
+    at, _, _ = ulg_smoother(ga)
+    n = arr["n"]
+    Z = np.asarray(arr["Z"], dtype=np.float64).reshape(arr["m"], -1, order="F")
+    D = np.asarray(arr["D"], dtype=np.float64).reshape(-1)
+    mode = np.array([arr["xbeta"][t] + D[t * arr["Dtv"]] + Z[:, t * arr["Ztv"]] @ at[:, t] for t in range(n)])
+    gll = ulg_loglik(ga)
+    y, u, phi, dist = np.asarray(arr["y"], dtype=float), np.asarray(arr["u"], dtype=float).reshape(-1), arr["phi"], arr["distribution"]
+    sc = 0.0
+    cterm = const_term(arr)
+    for t in range(n):
+        if not np.isfinite(y[t]):
+            continue
+        md = mode[t]
+        if dist == 1:
+            v = y[t] * md - u[t] * np.exp(md)
+        elif dist == 2:
+            v = y[t] * md - u[t] * np.log1p(np.exp(md))
+        elif dist == 3:
+            v = y[t] * md - (y[t] + phi) * np.log(phi + u[t] * np.exp(md))
+        elif dist == 4:
+            v = -phi * (md + y[t] * np.exp(-md) / u[t])
+        else:
+            raise ValueError("distribution")
+        sc += v + 0.5 * ((ga["y"][t] - md) / ga["H"][t]) ** 2
+        cterm -= -0.9189385332046727 - np.log(ga["H"][t])
+    return gll + cterm + sc, mode
+
+
 def chain_draws(seed, it, d):
     """the chain's counter-based draws: normals from blocks (iter_lo, iter_hi, j/2, purpose 5), uniforms from blocks
     (iter_lo, iter_hi, 2^31 + which, purpose 5) of the key (seed, 0)"""
@@ -620,7 +654,7 @@ def adapt_S(S, u, acc, target, i, gamma):
 
 
 def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target, seed, end_ram=False, kind="approx",
-              nsim=0, method="psi", output_type=3, fn_model=False):
+              nsim=0, method="psi", output_type=3, fn_model=False, local_approx=True):
     """One chain.  ``update(theta) -> arr`` gives the flattened model, ``log_prior(theta) -> float``.
     kind: 'approx' | 'pm' | 'da'.  Returns theta (n_stored x d), counts, posterior, S, acceptance_rate and by kind
     approx_loglik / prior / modes, alpha (n+1) x m x n_stored, alphahat / Vt."""
@@ -634,8 +668,15 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
         if fn_model:  # ssm_nlg: mode-based approximation (src/model_ssm_nlg.cpp:258-277)
             su = fn_psi_setup(arr)
             return (su["approx_loglik"] if su["rc"] == 0 and su["ok"] else -np.inf), su["mode"].reshape(-1, order="F"), su
+        if not local_approx and kept:  # the first approximation's pseudo-observations are kept
+            ll, md = global_approx_loglik(arr, kept["y"], kept["H"])
+            return ll, md, None
         su = psi_setup(arr)
+        if not local_approx:
+            kept.update(y=su["approx_y"], H=su["approx_H"])
         return su["approx_loglik"], su["mode"], su
+
+    kept = {}
 
     def filt(arr, it):
         """(ll0, ll1, particle system) with the filter's stream = iteration (functor models: seed + iteration)"""

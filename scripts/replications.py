@@ -27,27 +27,28 @@ def main():
     rows = []
     threads = int(os.environ.get("BSSM_THREADS", "8"))
     mcmc.run_mcmc(model, 200, particles=10, mcmc_type="pm", seed=1)  # library / device warm-up
-    for typ, meth in (("approx", "psi"), ("da", "bsf"), ("da", "psi"), ("is1", "bsf"), ("is1", "psi"), ("is2", "bsf"),
-                      ("is2", "psi"), ("pm", "bsf"), ("pm", "psi")):
+    grid = (("approx", "psi"), ("da", "bsf"), ("da", "psi"), ("is1", "bsf"), ("is1", "psi"), ("is2", "bsf"), ("is2", "psi"),
+            ("pm", "bsf"), ("pm", "psi"))
+    for local, typ, meth in [(lo, t, m) for lo in (True, False) for t, m in grid]:
         t0 = time.perf_counter()
         res = mcmc.run_mcmc(model, 10000, particles={"bsf": 200, "psi": 10}[meth], mcmc_type=typ, sampling_method=meth,
-                            end_adaptive_phase=True, seed=2021, threads=threads)
+                            end_adaptive_phase=True, seed=2021, threads=threads, local_approx=local)
         el = time.perf_counter() - t0
         w = res["counts"] * (res["weights"] if typ in ("is1", "is2") else 1.0)
         series = dict(sd_level=res["theta"][:, 0], sd_slope=res["theta"][:, 1])
         if "alpha" in res:  # the approximate chain keeps no state draws here (approx_state_posterior is not a particle path)
             series.update(u_1=res["alpha"][0, 0, :], u_100=res["alpha"][99, 0, :])
         for var, x in series.items():
-            r = [q for q in ref if q["variable"] == var and q["mcmc_type"] == typ and q["sampling_method"] == meth and q["local_approx"]][0]
+            r = [q for q in ref if q["variable"] == var and q["mcmc_type"] == typ and q["sampling_method"] == meth and q["local_approx"] == local][0]
             mean = float(np.sum(w * x) / np.sum(w))
-            rows.append(dict(variable=var, mcmc_type=typ, sampling_method=meth, mean=mean, se=asymptotic_se(x, w), seconds=el,
+            rows.append(dict(variable=var, mcmc_type=typ, sampling_method=meth, local_approx=local, mean=mean, se=asymptotic_se(x, w), seconds=el,
                              acceptance_rate=res["acceptance_rate"], reference_mean=r["mean"], reference_se=r["se"],
                              reference_seconds=r["seconds"], reference_acceptance_rate=r["acceptance_rate"],
                              z=(mean - r["mean"]) / np.hypot(r["se"], asymptotic_se(x, w))))
-    print("%-9s %-7s %-4s %10s %9s %10s %9s %6s %8s %8s" % ("variable", "type", "pf", "mean", "se", "ref mean", "ref se", "z", "sec", "ref sec"))
+    print("%-9s %-7s %-4s %-6s %10s %9s %10s %9s %6s %8s %8s" % ("variable", "type", "pf", "local", "mean", "se", "ref mean", "ref se", "z", "sec", "ref sec"))
     for r in rows:
-        print("%-9s %-7s %-4s %10.5f %9.5f %10.5f %9.5f %6.2f %8.2f %8.2f" % (
-            r["variable"], r["mcmc_type"], r["sampling_method"], r["mean"], r["se"], r["reference_mean"], r["reference_se"], r["z"],
+        print("%-9s %-7s %-4s %-6s %10.5f %9.5f %10.5f %9.5f %6.2f %8.2f %8.2f" % (
+            r["variable"], r["mcmc_type"], r["sampling_method"], r["local_approx"], r["mean"], r["se"], r["reference_mean"], r["reference_se"], r["z"],
             r["seconds"], r["reference_seconds"]))
     if len(sys.argv) > 1:
         json.dump(rows, open(sys.argv[1], "w"), indent=1)

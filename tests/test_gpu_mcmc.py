@@ -212,7 +212,7 @@ def test_paper_negbin_posterior_means():
 def test_replication_table_poisson():
     """benchmarks/replications.html: every MCMC type of the reference on bsm_ng(poisson_series), 1e4 iterations each.  The
     document prints the weighted posterior means with their asymptotic standard errors; the same runs here must agree
-    with those means within the combined Monte-Carlo error (34 comparisons, |z| < 4)."""
+    with those means within the combined Monte-Carlo error (68 comparisons over local_approx TRUE / FALSE, |z| < 4)."""
     import json
     ref = json.load(open(os.path.join(GOLD, "reference_test_vectors.json")))["mcmc_replications_poisson"]["table"]
     y = np.loadtxt(os.path.join(GOLD, "poisson_series.txt"))
@@ -220,21 +220,22 @@ def test_replication_table_poisson():
     model = M.bsm_ng(y, sd_level=M.uniform(0.115, 0, 2 * s), sd_slope=M.uniform(0.004, 0, 2 * s), P1=np.diag([0.1, 0.1]),
                      distribution="poisson")
     worst = 0.0
-    for typ, meth in (("approx", "psi"), ("da", "bsf"), ("da", "psi"), ("is1", "bsf"), ("is1", "psi"), ("is2", "bsf"),
-                      ("is2", "psi"), ("pm", "bsf"), ("pm", "psi")):
+    grid = (("approx", "psi"), ("da", "bsf"), ("da", "psi"), ("is1", "bsf"), ("is1", "psi"), ("is2", "bsf"), ("is2", "psi"),
+            ("pm", "bsf"), ("pm", "psi"))
+    for local, typ, meth in [(lo, t, m) for lo in (True, False) for t, m in grid]:
         res = mcmc.run_mcmc(model, 10000, particles={"bsf": 200, "psi": 10}[meth], mcmc_type=typ, sampling_method=meth,
-                            end_adaptive_phase=True, seed=77, threads=8)
+                            end_adaptive_phase=True, seed=77, threads=8, local_approx=local)
         assert 0.15 < res["acceptance_rate"] < 0.35
         w = res["counts"] * (res["weights"] if typ in ("is1", "is2") else 1.0)
         series = dict(sd_level=res["theta"][:, 0], sd_slope=res["theta"][:, 1])
         if "alpha" in res:
             series.update(u_1=res["alpha"][0, 0, :], u_100=res["alpha"][99, 0, :])
         for var, x in series.items():
-            r = [q for q in ref if q["variable"] == var and q["mcmc_type"] == typ and q["sampling_method"] == meth and q["local_approx"]][0]
+            r = [q for q in ref if q["variable"] == var and q["mcmc_type"] == typ and q["sampling_method"] == meth and q["local_approx"] == local][0]
             mean = np.sum(w * x) / np.sum(w)
             z = (mean - r["mean"]) / np.hypot(r["se"], np.sqrt(mcmc.asymptotic_var(x, w)))
             worst = max(worst, abs(z))
-            assert abs(z) < 4.0, (typ, meth, var, mean, r["mean"], z)
+            assert abs(z) < 4.0, (local, typ, meth, var, mean, r["mean"], z)
 
 
 # ------------------------------------------------------------------ ssm_nlg / ssm_sde (model functors)
@@ -323,3 +324,57 @@ def test_nlg_is2_reweights_the_approximate_chain():
     assert np.all(np.isfinite(out["weights"])) and out["alphahat"].shape == (41, 2)
     bsf = mcmc.run_mcmc(model, 300, particles=64, burnin=100, mcmc_type="is2", sampling_method="bsf", output_type="theta", seed=3)
     assert np.all(np.isfinite(bsf["weights"])) and bsf["weights"].size == base["counts"].size
+
+
+def test_ssm_mng_with_callbacks(oracle):
+    """The bivariate Poisson example of run_mcmc's documentation (R/run_mcmc.R:354-377): ssm_mng with update_fn / prior_fn
+    closures; approximate chain and a pseudo-marginal chain through the multivariate filter."""
+    rng = np.random.default_rng(1)
+    x = np.cumsum(np.concatenate([[3.0], rng.normal(0, 0.5, 19)]))
+    y = np.column_stack([rng.poisson(np.exp(x)), rng.poisson(np.exp(x))]).astype(float)
+
+    def prior_fn(theta):  # half-normal on exp(theta) plus the Jacobian
+        return float(-0.5 * np.exp(theta[0]) ** 2 + theta[0])
+
+    def update_fn(theta):
+        return dict(R=np.full((1, 1, 1), np.exp(theta[0])))
+
+    model = M.ssm_mng(y, Z=np.ones((2, 1)), T=1.0, R=0.1, P1=1.0, distribution="poisson", init_theta=[np.log(0.1)],
+                      prior_fn=prior_fn, update_fn=update_fn)
+    out = mcmc.run_mcmc(model, 400, burnin=100, mcmc_type="approx", seed=5)
+    assert out["modes"].shape[:2] == (2, 20) and np.all(np.isfinite(out["approx_loglik"]))
+    assert 0.05 < out["acceptance_rate"] < 0.8
+    # every stored value: approximate log-likelihood = the oracle's multivariate psi set-up at that theta
+    base = M.model_arrays(model)
+    for i in (0, len(out["counts"]) - 1):
+        arr = dict(base); arr["R"] = np.asfortranarray(np.full((1, 1, 1), np.exp(out["theta"][i, 0])))
+        su = oracle.mng_psi_setup(arr)
+        assert abs(su["approx_loglik"] - out["approx_loglik"][i]) <= 1e-8 * 20
+    pm = mcmc.run_mcmc(model, 300, particles=32, burnin=100, mcmc_type="pm", output_type="summary", seed=5)
+    is2 = mcmc.run_mcmc(model, 400, particles=32, burnin=100, mcmc_type="is2", output_type="summary", seed=5)
+    assert pm["alphahat"].shape == (21, 1) and is2["alphahat"].shape == (21, 1)
+    assert np.all(np.isfinite(pm["alphahat"])) and np.all(np.isfinite(is2["weights"]))
+    # both smoothed levels track log of the observed mean count
+    target = np.log(np.maximum(0.5, y.mean(axis=1)))
+    assert np.mean(np.abs(pm["alphahat"][:20, 0] - target)) < 0.5 and np.mean(np.abs(is2["alphahat"][:20, 0] - target)) < 0.5
+
+
+@pytest.mark.parametrize("kind", ["bsm_ng", "negbin"])
+def test_global_approximation_chain_matches_oracle(oracle, kind):
+    """local_approx = FALSE (src/model_ssm_ung.cpp:104-116): the pseudo-observations of the chain's first approximation are
+    kept and every later theta only re-runs the smoother against them."""
+    model = _small(kind)
+    iters, burnin, seed = 200, 50, 13
+    out = mcmc.run_mcmc(model, iters, burnin=burnin, mcmc_type="approx", seed=seed, local_approx=False)
+    loc = mcmc.run_mcmc(model, iters, burnin=burnin, mcmc_type="approx", seed=seed, local_approx=True)
+    assert not np.allclose(out["approx_loglik"][:5], loc["approx_loglik"][:5], rtol=0, atol=1e-9)  # a different target
+    upd, prior = _oracle_fns(oracle, model)
+    th0 = np.array(model["theta"], dtype=float)
+    tr = mcmc._transformed(model)
+    th0[tr] = np.log(np.maximum(0.001, th0[tr]))
+    ref = oracle.run_chain(upd, prior, th0, np.diag(0.1 * np.maximum(0.1, np.abs(th0))), iters, burnin, 1, 2 / 3, 0.234, seed,
+                           local_approx=False)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(_sampling_scale(model, out["theta"]), ref["theta"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["approx_loglik"], ref["approx_loglik"], rtol=0, atol=1e-8 * model.n)
+    assert np.allclose(out["modes"][:, 0, :], ref["modes"], rtol=1e-6, atol=1e-8)
