@@ -124,6 +124,19 @@ if want("C5"):
                                                         finite=bool(np.all(np.isfinite(out["loglik"]))))
     row["host_cpus"] = os.cpu_count()
     res["C5"] = row
+    # the whole workflow that produces and corrects those draws: run_mcmc(mcmc_type = "is2") = approximate chain on the
+    # host (one mode search per iteration) + the post-correction above on its own stored values and modes
+    from bssm_amd import mcmc
+    t0 = time.perf_counter()
+    fit = mcmc.run_mcmc(growth, 10000, particles=4096, burnin=0, mcmc_type="is2", sampling_method="psi", output_type="theta",
+                        seed=1, threads=8)
+    e = time.perf_counter() - t0
+    res["C5-chain"] = dict(workload="run_mcmc(ssm_nlg growth T=300, iter=1e4, is2, psi-APF N=4096): approximate chain + IS correction",
+                           s=e, chain_s=fit["time_chain"], postcorrection_s=fit["time_postcorrection"],
+                           n_stored=int(fit["counts"].size), acceptance_rate=fit["acceptance_rate"],
+                           psteps_s=fit["counts"].size * 4096.0 * n / fit["time_postcorrection"],
+                           theta_mean=[float(v) for v in mcmc.summary(fit)["Mean"]],
+                           finite=bool(np.all(np.isfinite(fit["weights"]))))
 
 print(json.dumps(res, indent=1))
 if len(sys.argv) > 1:
