@@ -321,7 +321,29 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     return out
 
 
-def suggest_N(model: BssmModel, theta, candidates=range(10, 101, 10), replications: int = 100, seed: int | None = None):
+def _loglik_replications(mdl: BssmModel, particles: int, n_rep: int, seed: int, stream0: int):
+    """psi-APF log-likelihoods of streams stream0 .. stream0 + n_rep - 1 as one device batch (the unit suggest_N shards)"""
+    from .filters import logLik_batch
+    return logLik_batch(mdl, particles, n_rep, method="psi", seed=seed, stream0=stream0)
+
+
+def _suggest_N_sharded(mdl, candidates, replications, seed, dist, rank, world, group):
+    """Replications of every candidate split in contiguous blocks over the ranks (independent replications
+    x candidates, gather scalars): streams are those of the single-process call, so the sds agree to rounding."""
+    import torch
+    bounds = shard_bounds(np.ones(replications), world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    local = np.zeros((len(candidates), hi - lo))
+    for i, c in enumerate(candidates):
+        if hi > lo:
+            local[i] = _loglik_replications(mdl, c, hi - lo, seed, i * replications + lo)
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    full = _all_gather_blocks(local, bounds, rank, world, group, device)
+    return full.std(axis=1, ddof=1), full
+
+
+def suggest_N(model: BssmModel, theta, candidates=range(10, 101, 10), replications: int = 100, seed: int | None = None,
+              group=None):
     """R/post_correction.R:84-130 -> suggest_n_nongaussian (src/R_postcorrection.cpp:13-140): standard deviation
     of the psi-APF log-likelihood at ``theta`` over ``replications`` runs for each candidate N; N = first
     candidate with sd < 1 (None if there is none, R's NA).  The replications of one candidate run as ONE device
@@ -339,6 +361,23 @@ def suggest_N(model: BssmModel, theta, candidates=range(10, 101, 10), replicatio
         raise ValueError("Length of 'theta' does not match length of 'model$theta'.")
     cand = np.asarray(candidates, dtype=np.uint32)
     sds = np.zeros(cand.size)
+    rank, world, dist = 0, 1, None
+    try:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            dist, rank, world = _dist, _dist.get_rank(group), _dist.get_world_size(group)
+    except ImportError:
+        pass
+    if world > 1:  # one process per GPU: the replications shard, one all-gather of the log-likelihoods
+        if model.inherits("ssm_nlg"):
+            mdl = BssmModel(model.classes, **{**model, "theta": theta})
+        else:
+            arr = expand_models(model, theta[None, :])[0]
+            mdl = BssmModel(model.classes, **{**model, **{k: arr[k] for k in ("Z", "T", "R", "P1", "a1", "C", "D", "beta")},
+                                              "phi": arr["phi"]})
+        sds, _ = _suggest_N_sharded(mdl, candidates, replications, seed, dist, rank, world, group)
+        ok = np.nonzero(sds < 1.0)[0]
+        return dict(N=candidates[int(ok[0])] if ok.size else None, results=dict(N=np.asarray(candidates), sd=sds))
     if model.inherits("ssm_nlg"):  # suggest_n_nonlinear, src/R_postcorrection.cpp:107-148
         smod, keep = _lib.pack_fn_model({**model, "theta": theta})
         _lib.check(_lib.lib().bssm_suggest_n_nonlinear(C.byref(smod), cand.ctypes.data_as(_lib.c_u32_p), C.c_int32(cand.size),

@@ -109,3 +109,45 @@ def test_shard_bounds_balance_by_work():
     assert list(shard_bounds(np.ones(2), 4)) == [0, 1, 1, 2, 2] or shard_bounds(np.ones(2), 4)[-1] == 2
     b = shard_bounds(np.ones(5), 1)
     assert list(b) == [0, 5]
+
+
+def _oracle_replications(mdl, particles, n_rep, seed, stream0):
+    """Stand-in for bssm_amd.post_correct._loglik_replications built on the oracle"""
+    from bssm_amd import models as M
+    from oracle import oracle as O
+    arr = M.model_arrays(mdl)
+    su = O.psi_setup(arr)
+    return np.array([O.psi_filter(arr, particles, seed=seed, stream=stream0 + j, setup=su)["logLik"] for j in range(n_rep)])
+
+
+def _suggest_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bssm_amd.post_correct as PC
+    PC._loglik_replications = _oracle_replications
+    model, mo = _make_job()
+    res = PC.suggest_N(model, mo["theta"][0], candidates=[4, 8, 16], replications=9, seed=3)
+    np.savez(os.path.join(outdir, f"s{rank}.npz"), sd=res["results"]["sd"], N=np.array([-1 if res["N"] is None else res["N"]]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_suggest_N_equals_single_process(tmp_path):
+    """suggest_N (R/post_correction.R:84-130) shards its independent replications over the ranks: streams are
+    keyed by (candidate, replication), so two ranks reproduce the single-process standard deviations"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_suggest_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "s0.npz"), np.load(tmp_path / "s1.npz")
+    assert np.array_equal(r0["sd"], r1["sd"]) and r0["N"][0] == r1["N"][0]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from bssm_amd.post_correct import expand_models
+    from bssm_amd import models as M
+    model, mo = _make_job()
+    arr = expand_models(model, mo["theta"][:1])[0]
+    mdl = M.BssmModel(model.classes, **{**model, **{k: arr[k] for k in ("Z", "T", "R", "P1", "a1", "C", "D", "beta")}, "phi": arr["phi"]})
+    for i, c in enumerate([4, 8, 16]):
+        ll = _oracle_replications(mdl, c, 9, 3, i * 9)
+        assert abs(r0["sd"][i] - ll.std(ddof=1)) <= 1e-12

@@ -155,3 +155,16 @@ def test_sde_bootstrap_is_correction_matches_oracle(oracle):
         r, _ = oracle.make_rng(seed=seed, stream=i)
         pick = min(int(oracle.lib().orc_rng_uniform(C.byref(r), 3, 0, 0, 0) * N), N - 1)
         assert np.allclose(res["alpha"][:, 0, i], sm[0, :, pick], rtol=1e-9, atol=1e-12)
+
+
+def test_suggest_N_shard_unit_matches_single_call():
+    """The unit the multi-GPU suggest_N shards (`_loglik_replications`: streams candidate * replications + j) reproduces the
+    one-call standard deviations of bssm_suggest_n_nongaussian, in any split of the replications"""
+    model, theta, counts = _job()
+    cands, R, seed = [5, 10, 20], 24, 6
+    res = PC.suggest_N(model, theta[0], candidates=cands, replications=R, seed=seed)
+    arr = PC.expand_models(model, theta[:1])[0]
+    mdl = M.BssmModel(model.classes, **{**model, **{k: arr[k] for k in ("Z", "T", "R", "P1", "a1", "C", "D", "beta")}, "phi": arr["phi"]})
+    for i, c in enumerate(cands):
+        parts = [PC._loglik_replications(mdl, c, hi - lo, seed, i * R + lo) for lo, hi in ((0, 7), (7, 16), (16, 24))]
+        assert abs(np.concatenate(parts).std(ddof=1) - res["results"]["sd"][i]) <= 1e-12
