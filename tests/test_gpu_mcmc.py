@@ -378,3 +378,21 @@ def test_global_approximation_chain_matches_oracle(oracle, kind):
     assert np.allclose(_sampling_scale(model, out["theta"]), ref["theta"], rtol=1e-8, atol=1e-10)
     assert np.allclose(out["approx_loglik"], ref["approx_loglik"], rtol=0, atol=1e-8 * model.n)
     assert np.allclose(out["modes"][:, 0, :], ref["modes"], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("N", [3000, 20000])
+def test_pm_chain_with_large_particle_counts(oracle, N):
+    """The chain's plan picks the kernel shape by particle count: workgroup-resident (3000) and one-launch-per-step (20000);
+    ancestors may differ in a rare last-ulp CDF tie at these sizes, so the accepted values are compared, not every draw"""
+    model = _small("bsm_ng", n=25, seed=12)
+    iters, burnin, seed = 8, 2, 41
+    out = mcmc.run_mcmc(model, iters, particles=N, burnin=burnin, mcmc_type="pm", sampling_method="bsf", output_type="summary",
+                        seed=seed)
+    upd, prior = _oracle_fns(oracle, model)
+    th0 = np.log(np.maximum(0.001, np.array(model["theta"], dtype=float)))
+    ref = oracle.run_chain(upd, prior, th0, np.diag(0.1 * np.maximum(0.1, np.abs(th0))), iters, burnin, 1, 2 / 3, 0.234, seed,
+                           kind="pm", nsim=N, method="bsf", output_type=2)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(np.log(out["theta"]), ref["theta"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["posterior"], ref["posterior"], rtol=0, atol=1e-6 * model.n)
+    assert np.allclose(out["alphahat"], ref["alphahat"].T, rtol=1e-5, atol=1e-7)
