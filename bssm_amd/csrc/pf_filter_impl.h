@@ -627,19 +627,37 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
         if constexpr (kEarlyRng) u = u_pre[r];
         else { blk = rng_step_block(key, (uint32_t)t, (uint32_t)j); u = block_uniform(blk); }
         const double v = (u + (double)j) * c_scale;
-        // level 1: source block, two 16-ary rounds over the block prefixes in LDS
-        const int nrow = (B + 15) >> 4;
-        int row = 0;
-        if (nrow > 1) {  // pivots = last entry of each row of 16 (the final row may be short)
-          int cnt = 0;
-  #pragma unroll
-          for (int q = 0; q < 16; q++) {
-            const int e = min(16 * q + 15, B - 1);
-            cnt += (q < nrow && s_Q[e] < v) ? 1 : 0;
+        // level 1: source block = number of block prefixes below v.  The 64 slots of a wave are consecutive, so v
+        // increases along the lanes and covers 64 / N of the total mass: at most B of a filter's N / 64 wave-ranges
+        // contain a block boundary.  The wave first counts cooperatively (one prefix per lane, ballots) for its first
+        // and last lane; when the two agree every lane has that source block ...
+        int sb = -1;
+        if (r * GRID_NT + (wave + 1) * 64 <= len) {  // whole wave active (wave-uniform)
+          const double v_lo = lane_broadcast(v, 0), v_hi = lane_broadcast(v, 63);
+          int c_lo = 0, c_hi = 0;
+          for (int e0 = 0; e0 < B; e0 += 64) {
+            const int e = e0 + lane;
+            const double qv = s_Q[e < B ? e : B - 1];
+            c_lo += __builtin_popcountll(__builtin_amdgcn_ballot_w64(e < B && qv < v_lo));
+            c_hi += __builtin_popcountll(__builtin_amdgcn_ballot_w64(e < B && qv < v_hi));
           }
-          row = cnt < nrow ? cnt : nrow - 1;
+          if (c_lo == c_hi) sb = c_lo < B ? c_lo : B - 1;
         }
-        const int sb = 16 * row + search16_lds(s_Q + 16 * row, 1, min(16, B - 16 * row), v);
+        const bool sb_uniform = sb >= 0;
+        if (sb < 0) {  // ... otherwise (a boundary inside the wave, or a ragged last wave) two 16-ary rounds per lane
+          const int nrow = (B + 15) >> 4;
+          int row = 0;
+          if (nrow > 1) {  // pivots = last entry of each row of 16 (the final row may be short)
+            int cnt = 0;
+  #pragma unroll
+            for (int q = 0; q < 16; q++) {
+              const int e = min(16 * q + 15, B - 1);
+              cnt += (q < nrow && s_Q[e] < v) ? 1 : 0;
+            }
+            row = cnt < nrow ? cnt : nrow - 1;
+          }
+          sb = 16 * row + search16_lds(s_Q + 16 * row, 1, min(16, B - 16 * row), v);
+        }
         // target inside the source block's own (unscaled) local scan: (v - P_b) / exp(max_b - M)
         const double vp = (v - (sb > 0 ? s_Q[sb - 1] : 0.0)) * s_iscale[sb];
         BSSM_STAMP(3)
@@ -647,12 +665,29 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
         const int slen = min(chunk, N - sb * chunk);
         const int ncr = (slen + 15) >> 4;
         const double* __restrict__ cr = coarse + (size_t)sb * crow;
-        int lo = 0, hi = ncr - 1;
-        while (hi - lo >= 16) {  // only for chunk > 256 (N > 65 536)
-          const int mid = (lo + hi) >> 1;
-          if (vp <= cr[mid]) hi = mid; else lo = mid + 1;
+        int crw = -1;
+        if (sb_uniform && ncr <= 64) {
+          // one source block for the whole wave: its coarse entries are loaded once per wave (one per lane) and counted
+          // for the first and the last lane by ballot; the lanes in between differ only in the few entries between the
+          // two counts, which are broadcast from the lanes that hold them
+          const double cv = cr[lane < ncr ? lane : ncr - 1];
+          const double vp_lo = lane_broadcast(vp, 0), vp_hi = lane_broadcast(vp, 63);
+          const int k_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv < vp_lo));
+          const int k_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv < vp_hi));
+          if (k_hi - k_lo <= 6) {
+            int cnt = k_lo;
+            for (int e = k_lo; e < k_hi; e++) cnt += (lane_broadcast(cv, e) < vp) ? 1 : 0;
+            crw = cnt < ncr ? cnt : ncr - 1;
+          }
         }
-        const int crw = lo + search16_global(cr + lo, hi - lo + 1, vp);
+        if (crw < 0) {
+          int lo = 0, hi = ncr - 1;
+          while (hi - lo >= 16) {  // chunk > 256
+            const int mid = (lo + hi) >> 1;
+            if (vp <= cr[mid]) hi = mid; else lo = mid + 1;
+          }
+          crw = lo + search16_global(cr + lo, hi - lo + 1, vp);
+        }
         BSSM_STAMP(4)
         const int fine = search16_global(lcdf + (size_t)sb * chunk + 16 * crw, min(16, slen - 16 * crw), vp);
         const int anc = sb * chunk + 16 * crw + fine;
