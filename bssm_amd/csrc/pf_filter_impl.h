@@ -292,6 +292,20 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       const double u = block_uniform(blk[r]);
       const double v = (u + (double)i) * c_scale;
       int lo = 0, hi = N - 1;
+      if (N >= 256 && r * NT + (wave + 1) * 64 <= N) {
+        // the 64 slots of a wave are consecutive, so v increases along the lanes and their ancestors lie between those
+        // of the first and the last lane: one cooperative 64-ary round (a pivot per lane, ballot counts) bounds both,
+        // and the per-lane bisection then runs over that short range instead of [0, N)
+        const int W = (N + 63) >> 6;
+        const int pe = min((lane + 1) * W, N) - 1;
+        const double pv = s_cdf[pe];
+        const bool valid = lane * W < N;
+        const double v_lo = lane_broadcast(v, 0), v_hi = lane_broadcast(v, 63);
+        const int c_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && pv < v_lo));
+        const int c_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && pv < v_hi));
+        lo = min(c_lo * W, N - 1);
+        hi = min((c_hi + 1) * W, N) - 1;
+      }
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (v <= s_cdf[mid]) hi = mid; else lo = mid + 1;
@@ -495,6 +509,9 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
   __shared__ double s_tot[PPT * 4];
   constexpr bool kMfma = MP == 8 && PPT == 1 && !FN;  // fp64 MFMA transition (ssm_mng m = 8)
   __shared__ double s_tile[kMfma ? 4 * 16 * 64 : 1];
+  // per wave: the window of the source block's local scan its 64 slots fall into (the MFMA variant stages it in its
+  // operand tile, which is idle during the search)
+  __shared__ double s_win[kMfma ? 1 : 4 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pb = blockIdx.x, f = blockIdx.y, B = ws.B, chunk = ws.chunk, crow = chunk >> 4;
   const int N = b.N, n = b.n, m = b.m;
@@ -665,7 +682,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
         const int slen = min(chunk, N - sb * chunk);
         const int ncr = (slen + 15) >> 4;
         const double* __restrict__ cr = coarse + (size_t)sb * crow;
-        int crw = -1;
+        int crw = -1, win_row0 = -1;
         if (sb_uniform && ncr <= 64) {
           // one source block for the whole wave: its coarse entries are loaded once per wave (one per lane) and counted
           // for the first and the last lane by ballot; the lanes in between differ only in the few entries between the
@@ -678,6 +695,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
             int cnt = k_lo;
             for (int e = k_lo; e < k_hi; e++) cnt += (lane_broadcast(cv, e) < vp) ? 1 : 0;
             crw = cnt < ncr ? cnt : ncr - 1;
+            win_row0 = k_lo < ncr ? k_lo : ncr - 1;  // rows win_row0 .. win_row0 + 6 hold every lane's row: <= 112 entries
           }
         }
         if (crw < 0) {
@@ -689,7 +707,31 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
           crw = lo + search16_global(cr + lo, hi - lo + 1, vp);
         }
         BSSM_STAMP(4)
-        const int fine = search16_global(lcdf + (size_t)sb * chunk + 16 * crw, min(16, slen - 16 * crw), vp);
+        int fine;
+        if (win_row0 >= 0) {
+          // the <= 7 rows the wave's slots fall into are staged once per wave (two coalesced loads per lane, wave-private
+          // LDS) and each lane runs a 4-step binary search in its own row there, instead of 16 loads per lane
+          double* sw = kMfma ? s_tile + wave * (16 * 64) : s_win + wave * 128;
+          const int wlen = min(128, slen - 16 * win_row0);
+          const double* __restrict__ src = lcdf + (size_t)sb * chunk + 16 * win_row0;
+          __builtin_amdgcn_wave_barrier();  // the previous particle's reads of the window are done (same wave, in order)
+          sw[lane] = src[lane < wlen ? lane : wlen - 1];
+          sw[lane + 64] = src[lane + 64 < wlen ? lane + 64 : wlen - 1];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const double* row = sw + 16 * (crw - win_row0);
+          const int len16 = min(16, slen - 16 * crw);
+          int lo = 0;
+#pragma unroll
+          for (int step = 8; step >= 1; step >>= 1) {
+            const int idx = lo + step - 1;
+            if (idx < len16 && row[idx] < vp) lo += step;
+          }
+          fine = lo < len16 ? lo : len16 - 1;
+        } else {
+          fine = search16_global(lcdf + (size_t)sb * chunk + 16 * crw, min(16, slen - 16 * crw), vp);
+        }
         const int anc = sb * chunk + 16 * crw + fine;
         BSSM_STAMP(5)
         if (b.indices && li < len) b.indices[((size_t)f * n + t) * N + j] = (uint32_t)anc;
