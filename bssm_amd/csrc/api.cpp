@@ -1511,6 +1511,7 @@ struct bssm_plan {
   double bytes_per_pstep = 0;
   // local_approx = FALSE: pseudo-observations of each model's first approximation, reused by bssm_plan_update
   std::vector<bssm::GlobalApprox> global;
+  int launch_sequences = 1;  // concurrent step-launch sequences of the last bssm_plan_time_kernel run
 };
 
 namespace {
@@ -1770,7 +1771,10 @@ int bssm_plan_time_kernel(bssm_plan* plan, uint32_t seed, int32_t sample_every, 
   HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
   *avg_kernel_ms = tm.count ? tm.total_ms / tm.count : 0.0;
   if (n_samples) *n_samples = tm.count;
+  plan->launch_sequences = tm.concurrent;
   return BSSM_OK;
 }
+
+int bssm_plan_launch_sequences(const bssm_plan* plan) { return plan ? plan->launch_sequences : 0; }
 
 }  // extern "C"

@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
   // operand tile, which is idle during the search)
   __shared__ double s_win[kMfma ? 1 : 4 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pb = blockIdx.x, f = blockIdx.y, B = ws.B, chunk = ws.chunk, crow = chunk >> 4;
+  const int pb = blockIdx.x, f = ws.f0 + blockIdx.y, B = ws.B, chunk = ws.chunk, crow = chunk >> 4;
   const int N = b.N, n = b.n, m = b.m;
   BSSM_STAMP(0)
 
@@ -842,12 +842,34 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
-  const dim3 grid(ws.B, b.F), block(GRID_NT);
+  // A launch cannot start before every workgroup of the previous step has finished, so each step ends with SIMDs idling
+  // behind the slowest waves.  A batch of at least 512 workgroups per step is therefore stepped as TWO interleaved launch
+  // sequences (the two halves of its filters, independent of each other) on two streams: the tail of one half's step
+  // runs under the body of the other's (measured +13 % particle-steps/s at 24 filters of 65 536 particles, m = 4; +19 % at
+  // m = 1; +25 % at 12 filters; below ~400 workgroups the second sequence costs more than it hides).
+  int parts = ((long long)b.F * ws.B >= 512 && b.F >= 2) ? 2 : 1;
+  if (const char* env = std::getenv("BSSM_AMD_GRID_STREAMS")) parts = (std::atoi(env) >= 2 && b.F >= 2) ? 2 : 1;
+  const dim3 block(GRID_NT);
+  if (!ws.side) parts = 1;
+  hipStream_t lanes[2] = {stream, stream};
+  hipEvent_t fork = nullptr, join = nullptr;
+  GridWorkspace wsp[2] = {ws, ws};
+  int fcount[2] = {b.F, 0};
+  if (parts == 2) {  // first half on the caller's stream, second half on the library's side stream (ws.side)
+    lanes[1] = ws.side;
+    fcount[0] = b.F / 2; fcount[1] = b.F - fcount[0];
+    wsp[1].f0 = fcount[0];
+    if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return e;
+    (void)hipEventRecord(fork, stream);
+    (void)hipStreamWaitEvent(lanes[1], fork, 0);
+  }
+  if (timing) timing->concurrent = parts;
   if (!timing || timing->every <= 0) {
-    for (int t = -1; t < b.n; t++) hipLaunchKernelGGL(kern, grid, block, 0, stream, b, ws, t);
+    for (int t = -1; t < b.n; t++)
+      for (int q = 0; q < parts; q++) hipLaunchKernelGGL(kern, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q], t);
   } else {
-    // windows of kWin consecutive step launches bracketed by one event pair each: the event overhead
-    // (a few us) is amortised over the window, so total/count is the per-launch kernel cadence
+    // windows of kWin consecutive step launches (of the first sequence) bracketed by one event pair each: the event
+    // overhead (a few us) is amortised over the window, so total/count is the per-launch kernel cadence
     constexpr int kMaxSamples = 64, kWin = 8;
     hipEvent_t ev[2 * kMaxSamples];
     int ns = 0;
@@ -857,17 +879,18 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
       if (open_t < 0 && t >= 0 && t % period == 0 && t + kWin <= b.n && ns < kMaxSamples) {
         (void)hipEventCreate(&ev[2 * ns]);
         (void)hipEventCreate(&ev[2 * ns + 1]);
-        (void)hipEventRecord(ev[2 * ns], stream);
+        (void)hipEventRecord(ev[2 * ns], lanes[0]);
         open_t = t;
       }
-      hipLaunchKernelGGL(kern, grid, block, 0, stream, b, ws, t);
+      for (int q = 0; q < parts; q++) hipLaunchKernelGGL(kern, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q], t);
       if (open_t >= 0 && t == open_t + kWin - 1) {
-        (void)hipEventRecord(ev[2 * ns + 1], stream);
+        (void)hipEventRecord(ev[2 * ns + 1], lanes[0]);
         ns++;
         open_t = -1;
       }
     }
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    for (int q = 0; q < parts; q++)
+      if ((e = hipStreamSynchronize(lanes[q])) != hipSuccess) return e;
     for (int i = 0; i < ns; i++) {
       float ms = 0;
       (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
@@ -876,6 +899,13 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
       (void)hipEventDestroy(ev[2 * i]);
       (void)hipEventDestroy(ev[2 * i + 1]);
     }
+  }
+  if (parts == 2) {  // join: the caller's stream continues after the side sequence too
+    if ((e = hipEventCreateWithFlags(&join, hipEventDisableTiming)) != hipSuccess) return e;
+    (void)hipEventRecord(join, lanes[1]);
+    (void)hipStreamWaitEvent(stream, join, 0);
+    (void)hipEventDestroy(join);
+    (void)hipEventDestroy(fork);
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
   hipLaunchKernelGGL(loglik_finalize_kernel, dim3(b.F), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);

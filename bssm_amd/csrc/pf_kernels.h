@@ -56,12 +56,14 @@ struct GridWorkspace {
   long long* dbg;      // optional [n][16] cycle stamps of block 0 / thread 0 (debug builds of the step kernel)
   int B;               // particle blocks per filter
   int chunk;           // particles per block
+  int f0;              // first filter of this launch (a batch may be stepped as two interleaved launch sequences)
+  hipStream_t side;    // the library's side stream for the second launch sequence (one per host thread); null = none
 };
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out);
 void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
 // Optional per-launch timing of the step kernel: every `every`-th step launch is bracketed by HIP
 // events on `stream`; the caller reads total_ms / count after the stream has drained.
-struct StepTiming { int every = 0; int count = 0; double total_ms = 0.0; };
+struct StepTiming { int every = 0; int count = 0; double total_ms = 0.0; int concurrent = 1; };  // concurrent: launch sequences in flight
 hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream,
                               StepTiming* timing = nullptr);
 // launchers a run-time compiled user-model library exports (user_model_tu.hip); register returns the slot (>= 1)

@@ -58,6 +58,12 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   ws->dbg = nullptr;
   ws->B = B;
   ws->chunk = chunk;
+  ws->f0 = 0;
+  // ONE side stream per host thread for the whole library (streams share a small number of hardware queues: a pair per
+  // kernel variant ended up serialised against each other)
+  static thread_local hipStream_t side = nullptr;
+  if (!side && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
+  ws->side = side;
 }
 
 

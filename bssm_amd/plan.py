@@ -91,6 +91,12 @@ class FilterPlan:
                                                      C.byref(cnt)))
         return ms.value, cnt.value
 
+    def launch_sequences(self) -> int:
+        """concurrent step-launch sequences of the last time_kernel run (each timed launch covers n_filters / this)"""
+        L = _lib.lib()
+        L.bssm_plan_launch_sequences.argtypes = [C.c_void_p]
+        return int(L.bssm_plan_launch_sequences(self._h))
+
     def close(self):
         if self._h:
             _lib.lib().bssm_plan_destroy(self._h)

@@ -327,6 +327,9 @@ int bssm_plan_time_kernel(bssm_plan* plan, uint32_t seed, int32_t sample_every, 
  * 3 Box-Muller pairs of the stream (seed 1, stream 0, purpose 2, t 0, particle i) -> 2n outputs) and the
  * cycle-stamp timeline of the grid step kernel (12 averaged phase durations). */
 int bssm_debug_math(int fn, const double* in, double* out, int32_t n);
+/* how many step-launch sequences the last bssm_plan_time_kernel run kept in flight (a batch that fills the chip more than
+ * once is stepped as two interleaved sequences over the halves of its filters; each timed launch then covers half of them) */
+int bssm_plan_launch_sequences(const bssm_plan* plan);
 /* runs one kernel that reads n_doubles and writes n_doubles (8 B per lane, coalesced): a known byte count for
  * calibrating the profiler's FETCH_SIZE / WRITE_SIZE counters on this library's access pattern */
 int bssm_debug_stream_copy(uint64_t n_doubles);
