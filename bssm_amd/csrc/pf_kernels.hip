@@ -19,13 +19,20 @@ int wg_filter_capacity(int MP) {
 }
 
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
-  // one particle per thread until the chip is full, then more particles per thread
-  // One particle per thread keeps a single filter's dependent chain shortest.  When the batch already oversubscribes
-  // the chip several times (>= 2048 workgroups of 256), two particles per thread halve the per-particle cost of the
-  // partial combine (measured +2-3 % particle-steps/s at 12-24 filters of 65 536 particles).
+  // One particle per thread keeps a single filter's dependent chain shortest and is best until the batch oversubscribes
+  // the chip about three times (workgroups of 256 at one particle per thread: w1 = F * ceil(N / 256); the chip holds 1024).
+  // Beyond that more particles per thread amortise the per-wave work of a step -- the partial combine and the
+  // wave-cooperative ancestor search -- over more particles: two from w1 >= 3072, four from w1 >= 6144 (measured on the
+  // metric model and on m = 1, full output and log-likelihood only: scripts/ppt_probe.py; 24 filters of 65 536 particles:
+  // 2.79e10 / 2.96e10 / 3.15e10 particle-steps/s at 1 / 2 / 4).
   // (only for states of at most 4 doubles without functor parameters: larger live state costs occupancy, and the
   // fp64-MFMA transition of the 8-dimensional state needs one particle per lane)
-  int ppt = ((size_t)b.F * ((b.N + GRID_NT - 1) / GRID_NT) >= 2048 && b.N >= 2 * GRID_NT && b.MP <= 4 && !b.fpar) ? 2 : 1;
+  const size_t w1 = (size_t)b.F * ((b.N + GRID_NT - 1) / GRID_NT);
+  int ppt = 1;
+  if (b.MP <= 4 && !b.fpar) {
+    if (w1 >= 6144 && b.N >= 4 * GRID_NT) ppt = 4;
+    else if (w1 >= 3072 && b.N >= 2 * GRID_NT) ppt = 2;
+  }
   if (const char* env = std::getenv("BSSM_AMD_GRID_PPT")) ppt = std::max(1, std::min(8, std::atoi(env)));  // tuning hook
   while ((b.N + GRID_NT * ppt - 1) / (GRID_NT * ppt) > GRID_NT && ppt < 8) ppt *= 2;
   const int chunk = GRID_NT * ppt;
