@@ -128,10 +128,10 @@ if want("C5"):
     # host (one mode search per iteration) + the post-correction above on its own stored values and modes
     from bssm_amd import mcmc
     t0 = time.perf_counter()
-    fit = mcmc.run_mcmc(growth, 10000, particles=4096, burnin=0, mcmc_type="is2", sampling_method="psi", output_type="theta",
-                        seed=1, threads=8)
+    fit = mcmc.run_mcmc(growth, 20000, particles=4096, mcmc_type="is2", sampling_method="psi", output_type="theta",
+                        seed=1, threads=8)  # BASELINE config 5: 20 000 iterations, half of them burn-in
     e = time.perf_counter() - t0
-    res["C5-chain"] = dict(workload="run_mcmc(ssm_nlg growth T=300, iter=1e4, is2, psi-APF N=4096): approximate chain + IS correction",
+    res["C5-chain"] = dict(workload="run_mcmc(ssm_nlg growth T=300, iter=20000, is2, psi-APF N=4096): approximate chain + IS correction",
                            s=e, chain_s=fit["time_chain"], postcorrection_s=fit["time_postcorrection"],
                            n_stored=int(fit["counts"].size), acceptance_rate=fit["acceptance_rate"],
                            psteps_s=fit["counts"].size * 4096.0 * n / fit["time_postcorrection"],

@@ -151,3 +151,42 @@ def test_two_rank_suggest_N_equals_single_process(tmp_path):
     for i, c in enumerate([4, 8, 16]):
         ll = _oracle_replications(mdl, c, 9, 3, i * 9)
         assert abs(r0["sd"][i] - ll.std(ddof=1)) <= 1e-12
+
+
+def _mcmc_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bssm_amd.post_correct as PC
+    from bssm_amd import mcmc
+    PC._run_local_block = _oracle_block
+    model, _ = _make_job()
+    out = mcmc.run_mcmc(model, 120, particles=8, burnin=40, mcmc_type="is2", output_type="theta", seed=8)
+    np.savez(os.path.join(outdir, f"m{rank}.npz"), theta=out["theta"], counts=out["counts"], weights=out["weights"],
+             posterior=out["posterior"])
+    dist.destroy_process_group()
+
+
+def test_two_rank_run_mcmc_is2_equals_single_process(tmp_path):
+    """BASELINE config C5's shape: run_mcmc(mcmc_type = "is2") under torch.distributed -- every rank runs the (deterministic,
+    host-side) approximate chain, the post-correction of its stored values shards over the ranks; the result is the same on
+    every rank and equal to the single-process run.  The per-block filters are injected from the oracle here."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_mcmc_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "m0.npz"), np.load(tmp_path / "m1.npz")
+    import bssm_amd.post_correct as PC
+    from bssm_amd import mcmc
+    old = PC._run_local_block
+    PC._run_local_block = _oracle_block
+    try:
+        model, _ = _make_job()
+        single = mcmc.run_mcmc(model, 120, particles=8, burnin=40, mcmc_type="is2", output_type="theta", seed=8)
+    finally:
+        PC._run_local_block = old
+    for k in ("theta", "counts", "weights", "posterior"):
+        assert np.array_equal(r0[k], r1[k]), k
+        assert np.array_equal(r0[k], single[k]), k
+    assert np.all(np.isfinite(r0["weights"])) and r0["weights"].size == r0["counts"].size > 5
