@@ -650,7 +650,8 @@ int bssm_fn_psi_setup(const bssm_fn_model* model, const double* is_mode, int32_t
   const int rc = to_fn_model(model, &f);
   if (rc) return rc;
   bssm::FnSetup su;
-  const bool ok = bssm::fn_psi_setup(f, is_mode, max_iter, conv_tol > 0 ? conv_tol : 1e-8, &su);
+  const bool loglik_only = !alphahat && !Vt && !Ct;  // (what the approximate MCMC chain asks for every iteration)
+  const bool ok = bssm::fn_psi_setup(f, is_mode, max_iter, conv_tol > 0 ? conv_tol : 1e-8, &su, loglik_only);
   auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
   cp(mode, su.mode); cp(scales, su.scales); cp(alphahat, su.alphahat); cp(Vt, su.Vt); cp(Ct, su.Ct);
   cp(Zt, su.Z); cp(Tt, su.T); cp(Dt, su.D); cp(Cc, su.C);

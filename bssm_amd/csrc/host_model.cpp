@@ -1031,7 +1031,7 @@ void fn_ekpf_init(const FnModel& f, double* a1, double* P1, double* att1, double
   }
 }
 
-bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double conv_tol, FnSetup* su) {
+bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double conv_tol, FnSetup* su, bool loglik_only) {
   const int n = f.n, m = f.m, mm = m * m;
   su->Z.assign((size_t)m * n, 0.0); su->T.assign((size_t)mm * n, 0.0); su->D.assign(n, 0.0); su->C.assign((size_t)m * n, 0.0);
   su->mode.assign((size_t)m * n, 0.0); su->scales.assign(n, 0.0);
@@ -1101,6 +1101,7 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
     double ssc = 0; for (double v : su->scales) ssc += v;
     su->approx_loglik = gll + ssc;
   }
+  if (loglik_only) return true;  // the approximate chain needs the mode and the log-likelihood only
   fn_gaussian_model(f, *su, &g);
   ap.H.assign(n, su->H);
   {

@@ -122,7 +122,8 @@ struct FnSetup {
   int iters = 0;
   bool ok = false;
 };
-bool fn_psi_setup(const FnModel& mod, const double* is_mode, int max_iter, double conv_tol, FnSetup* out);
+// loglik_only: stop after the mode search and the approximate log-likelihood (no smoothing covariances / conditional factors)
+bool fn_psi_setup(const FnModel& mod, const double* is_mode, int max_iter, double conv_tol, FnSetup* out, bool loglik_only = false);
 // two-phase variant for approximate_for_is (is_mode must be given): see psi_setup_begin
 bool fn_psi_setup_begin(const FnModel& mod, const double* is_mode, FnSetup* out, LgPacked* lg);
 // psi proposal operands (as build_psi_tables), observation rows carrying the approximating D_t / Z_t / 1/H / scales,
