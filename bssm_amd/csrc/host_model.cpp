@@ -867,8 +867,9 @@ void fnRdiag(const FnModel& f, double* r) {
 void fnT(const FnModel& f, const double* a, double* x) {  // T_fn, R/cpp_example_models.R:415-428 etc.
   if (f.id == 7) { f.user->T(a, f.theta, f.known, x); return; }
   switch (f.id) {
-    case 1: { const double dT = f.known[0], K = f.known[1]; x[0] = a[0]; const double r = std::exp(a[0]) / (1.0 + std::exp(a[0]));
-              x[1] = K * a[1] * std::exp(r * dT) / (K + a[1] * (std::exp(r * dT) - 1)); } break;
+    case 1: { const double dT = f.known[0], K = f.known[1]; x[0] = a[0]; const double e0 = std::exp(a[0]), r = e0 / (1.0 + e0);
+              const double er = std::exp(r * dT);  // (each exponential evaluated once; same values as the snippet's repeated calls)
+              x[1] = K * a[1] * er / (K + a[1] * (er - 1)); } break;
     case 2: x[0] = f.theta[0] * (1 - f.theta[1]) + f.theta[1] * a[0]; break;
     case 3: x[0] = std::sin(a[0]); break;
     default: x[0] = a[0];
@@ -877,9 +878,10 @@ void fnT(const FnModel& f, const double* a, double* x) {  // T_fn, R/cpp_example
 void fnTg(const FnModel& f, const double* a, double* Tg) {  // T_gn, :432-450
   if (f.id == 7) { f.user->Tg(a, f.theta, f.known, Tg); return; }
   switch (f.id) {
-    case 1: { const double dT = f.known[0], K = f.known[1]; const double r = std::exp(a[0]) / (1 + std::exp(a[0]));
-              const double tmp = std::exp(r * dT) / std::pow(K + a[1] * (std::exp(r * dT) - 1), 2);
-              Tg[0] = 1.0; Tg[2] = 0; Tg[1] = dT * K * a[1] * (K - a[1]) * tmp * r / (1 + std::exp(a[0])); Tg[3] = K * K * tmp; } break;
+    case 1: { const double dT = f.known[0], K = f.known[1]; const double e0 = std::exp(a[0]), r = e0 / (1 + e0);
+              const double er = std::exp(r * dT);
+              const double tmp = er / std::pow(K + a[1] * (er - 1), 2);
+              Tg[0] = 1.0; Tg[2] = 0; Tg[1] = dT * K * a[1] * (K - a[1]) * tmp * r / (1 + e0); Tg[3] = K * K * tmp; } break;
     case 2: Tg[0] = f.theta[1]; break;
     case 3: Tg[0] = std::cos(a[0]); break;
     default: Tg[0] = 1.0;
