@@ -149,3 +149,40 @@ def test_is_merge_matches_oracle_merge(oracle):
         for t in range(n + 1):
             ve[:, :, t] += wc[i] * np.outer(d[:, t], d[:, t])
     assert np.allclose(Vt, ev + ve / wc.sum(), rtol=1e-10, atol=1e-12)
+
+
+def test_chain_draws_and_builtin_priors_match_oracle(oracle):
+    """Host pieces of the run_mcmc chains (csrc/mcmc.cpp): the chain's counter-based draws and log_prior_pdf of the built-in
+    models (src/model_bsm_ng.cpp:90-136, src/model_svm.cpp:50-88, src/model_ar1_ng.cpp:63-118) against the oracle's
+    restatement.  (The chains themselves are compared in tests/test_gpu_mcmc.py.)"""
+    L = _lib.lib()
+    L.bssm_mcmc_draws.argtypes = [C.c_uint32, C.c_uint64, C.c_int32, _lib.c_double_p, _lib.c_double_p]
+    for seed, it, d in ((1, 1, 1), (7, 12345, 4), (3, (1 << 33) + 5, 5)):
+        z, u = np.zeros(d), np.zeros(2)
+        L.bssm_mcmc_draws(seed, it, d, _lib.dptr(z), _lib.dptr(u))
+        zr, ur = oracle.chain_draws(seed, it, d)
+        assert np.allclose(z, zr, rtol=1e-14, atol=1e-15) and np.allclose(u, ur, rtol=0, atol=0)
+    L.bssm_log_prior_builtin.restype = C.c_double
+    L.bssm_log_prior_builtin.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_int32, _lib.c_double_p, C.c_int32,
+                                         C.POINTER(C.c_int32), _lib.c_double_p]
+    from bssm_amd.post_correct import _builtin_flags
+    from bssm_amd.models import model_type, prior_tables
+    rng = np.random.default_rng(0)
+    y = rng.poisson(3.0, 12).astype(float)
+    cases = [
+        M.bsm_ng(y, sd_level=M.halfnormal(0.2, 1), sd_slope=M.gamma(0.02, 2, 10), phi=M.tnormal(2.0, 1, 3, 0.1, 9), xreg=rng.normal(size=12),
+                 beta=M.normal(0.1, 0, 2), distribution="negative binomial"),
+        M.svm(rng.normal(0, 1, 12), rho=M.uniform(0.9, -0.99, 0.99), sd_ar=M.halfnormal(0.3, 5), sigma=M.halfnormal(0.8, 2)),
+        M.ar1_ng(y, rho=M.uniform(0.7, -0.99, 0.99), sigma=M.halfnormal(0.3, 2), mu=M.normal(1.0, 0, 5), distribution="poisson"),
+    ]
+    for mdl in cases:
+        fl = _builtin_flags(mdl)
+        flags = (C.c_int32 * len(fl))(*fl)
+        pd, pp = prior_tables(mdl["priors"])
+        nx = int(np.asarray(mdl["xreg"]).shape[1])
+        d = pd.size
+        for trial in range(6):
+            th = np.ascontiguousarray(rng.normal(0, 1.2, d))
+            got = L.bssm_log_prior_builtin(model_type(mdl), flags, nx, _lib.dptr(th), d, pd.ctypes.data_as(C.POINTER(C.c_int32)), _lib.dptr(pp))
+            ref = oracle.builtin_log_prior(mdl.classes[0], fl, nx, th, pd, pp)
+            assert (np.isinf(got) and np.isinf(ref) and got < 0 and ref < 0) or abs(got - ref) <= 1e-12 * max(1.0, abs(ref)), (mdl.classes[0], th)
