@@ -17,7 +17,7 @@ def rate(mdl, N, T, R, keep, reps=4):
     return R * N * T / e, R * N * T / (ms * 1e-3)
 for name, mk, N, T in (("m1", negbin_ar1, 65536, 1000), ("m4", negbin_m4, 65536, 1000), ("c4", mng_c4, 16384, 2000)):
     mdl = mk(T)
-    for R, keep in ((2, True), (4, True), (6, True), (8, True)):
+    for R, keep in ((2, True), (4, True), (8, True), (12, True), (24, True), (32, False)):
         for order in (("1", "2"),):
             row = {}
             for s in order:
