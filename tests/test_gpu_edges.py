@@ -76,3 +76,26 @@ def test_no_observation_at_all(oracle, monkeypatch, path):
     assert np.all(out["weights"] == 1.0)
     assert np.array_equal(out["indices"], ref["indices"])
     assert out["logLik"] == ref["logLik"] == 0.0
+
+
+@pytest.mark.parametrize("N,R,ppt", [(20000, 8, None), (65536, 12, None), (65536, 6, "4"), (16384, 8, "2")])
+def test_skewed_weights_batches_match_oracle(oracle, monkeypatch, N, R, ppt):
+    """Nearly degenerate weights (a few particles carry the mass at every step) through every shape of the step kernel:
+    the wave-cooperative ancestor search takes its fall-backs (many block boundaries per wave-range, wide coarse spans),
+    the batch is stepped as two launch sequences, and 1 / 2 / 4 particles per lane are used.  A wrong ancestor anywhere
+    moves the log-likelihood by far more than the bound."""
+    from bssm_amd.filters import logLik_batch
+    rng = np.random.default_rng(31)
+    n = 14
+    y = np.where(np.arange(n) % 3 == 0, 60.0, 1.0) + rng.poisson(1.0, n)
+    model = M.bsm_ng(y, sd_level=0.9, sd_slope=0.2, distribution="poisson", P1=np.diag([4.0, 0.5]), a1=[1.0, 0.0])
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "grid")
+    if ppt:
+        monkeypatch.setenv("BSSM_AMD_GRID_PPT", ppt)
+    got = logLik_batch(model, N, R, method="bsf", seed=5, stream0=3)
+    arr = M.model_arrays(model)
+    for r in (0, R // 2, R - 1):  # first filter of each launch sequence and the last one
+        ref = oracle.bsf_filter(arr, N, seed=5, stream=3 + r)
+        ess = 1.0 / np.sum((ref["weights"][:, 6] / ref["weights"][:, 6].sum()) ** 2)
+        assert ess < 0.05 * N  # the case is as skewed as intended
+        assert abs(got[r] - ref["logLik"]) <= 1e-9 * n, (r, got[r], ref["logLik"])
