@@ -229,12 +229,14 @@ double gaussian_loglik(const Sys& S, const Approx& ap) {
 }
 
 // src/model_ssm_ulg.cpp:252-305, src/model_ssm_mlg.cpp fast_smoother -> smoothed state means, m x (n+1)
-bool lg_fast_mean(const HostModel& h, const Approx& ap, std::vector<Mat>* atp);
+bool lg_fast_mean(const HostModel& h, const Approx& ap, std::vector<Mat>* atp, double* gll = nullptr);
 
-bool fast_smoother(const Sys& S, const Approx& ap, std::vector<Mat>* atp) {
+// gll (optional): set to the Gaussian log-likelihood of the same model when the fixed-size path ran (its forward pass has
+// the innovations and their variances), left untouched otherwise
+bool fast_smoother(const Sys& S, const Approx& ap, std::vector<Mat>* atp, double* gll = nullptr) {
   const HostModel& h = S.h;
   const int n = h.n, m = h.m;
-  if (lg_fast_mean(h, ap, atp)) return true;
+  if (lg_fast_mean(h, ap, atp, gll)) return true;
   std::vector<Mat>& at = *atp;
   at.assign(n + 1, Mat(m, 1));
   std::vector<KfStep> st(n);
@@ -364,12 +366,25 @@ struct LgHostModel {
     g.a1 = h.a1.data(); g.P1 = h.P1.data();
   }
 };
-bool lg_fast_mean(const HostModel& h, const Approx& ap, std::vector<Mat>* atp) {
+bool lg_fast_mean(const HostModel& h, const Approx& ap, std::vector<Mat>* atp, double* gll) {
   if (!LgHostModel::applies(h)) return false;
   const int n = h.n, m = h.m;
   LgHostModel lm(h, ap);
   std::vector<double> at((size_t)m * (n + 1)), rts((size_t)n * m), K((size_t)n * m), v(n), Fs(n);
   lg_smoother_mean(m, lm.g, at.data(), rts.data(), K.data(), v.data(), Fs.data());
+  if (gll) {  // gaussian_loglik() of the same model from this forward pass: the same v_t, F_t and the same guards
+    double accH = 0, accR = 0;
+    for (double q : ap.H) accH += q;
+    for (double q : h.R) accR += q;
+    if (accH + accR < kZeroTol) {
+      *gll = -INFINITY;
+    } else {
+      const double LOG2PI = std::log(2.0 * kPi);
+      double ll = 0.0;
+      for (int t = 0; t < n; t++) if (Fs[t] > 0.0) ll -= 0.5 * (LOG2PI + std::log(Fs[t]) + v[t] * v[t] / Fs[t]);
+      *gll = ll;
+    }
+  }
   atp->assign(n + 1, Mat(m, 1));
   for (int t = 0; t <= n; t++) for (int i = 0; i < m; i++) (*atp)[t](i, 0) = at[i + (size_t)m * t];
   return true;
@@ -455,7 +470,10 @@ void signal_from_states(const HostModel& h, const Sys& S, const std::vector<Mat>
 }
 
 // approximate(): src/model_ssm_ung.cpp:87-140, src/model_ssm_mng.cpp:73-114 (first call, approx_state == -1)
-int run_laplace(const HostModel& h, const Sys& S, Approx* ap, std::vector<double>* mode, bool* ok) {
+// gll (optional): Gaussian log-likelihood of the final approximating model when the last smoother pass could supply it
+// (NaN otherwise): that pass ran on exactly the (approx y, H) the loop ends with
+int run_laplace(const HostModel& h, const Sys& S, Approx* ap, std::vector<double>* mode, bool* ok, double* gll = nullptr) {
+  if (gll) *gll = std::nan("");
   *mode = h.initial_mode;
   int it = 0;
   double diff = h.conv_tol + 1;
@@ -465,7 +483,8 @@ int run_laplace(const HostModel& h, const Sys& S, Approx* ap, std::vector<double
   while (it < h.max_iter && diff > h.conv_tol) {
     it++;
     laplace_iter(h, *mode, ap);
-    if (!fast_smoother(S, *ap, &sm)) { *ok = false; break; }
+    if (gll) *gll = std::nan("");
+    if (!fast_smoother(S, *ap, &sm, gll)) { *ok = false; break; }
     signal_from_states(h, S, sm, &nm);
     diff = 0.0;
     for (size_t q = 0; q < nm.size(); q++) diff += (nm[q] - (*mode)[q]) * (nm[q] - (*mode)[q]);
@@ -727,18 +746,19 @@ double approx_loglik_mode(const HostModel& h, std::vector<double>* mode_out, Glo
   ap.H.assign((size_t)h.p * h.n, 0.0);
   std::vector<double> mode, scales;
   bool ok = true;
+  double gll_pass = std::nan("");
   if (global && global->set) {  // the pseudo-observations of the first approximation are kept (src/model_ssm_ung.cpp:104-116)
     ap.y = global->y; ap.H = global->H;
     std::vector<Mat> sm;
     ok = fast_smoother(S, ap, &sm);
     if (ok) signal_from_states(h, S, sm, &mode);
   } else {
-    run_laplace(h, S, &ap, &mode, &ok);
+    run_laplace(h, S, &ap, &mode, &ok, &gll_pass);
     if (global && ok) { global->y = ap.y; global->H = ap.H; global->set = true; }
   }
   if (!ok) return -INFINITY;
   if (mode_out) *mode_out = mode;
-  const double gll = gaussian_loglik(S, ap);
+  const double gll = std::isnan(gll_pass) ? gaussian_loglik(S, ap) : gll_pass;
   update_scales(h, ap, mode, &scales);
   double ssc = 0;
   for (double v : scales) ssc += v;
@@ -948,6 +968,15 @@ double fn_log_signal_pdf(const FnModel& f, const double* al) {  // src/model_ssm
   }
   return ll;
 }
+// out = A B A' for m x m column-major operands, m <= 2: the products are formed in the order the generic Mat operators
+// use ((A B) first, every entry summed over the inner index from zero), without their temporaries
+static inline void small_abat(int m, const double* A, const double* B, double* out) {
+  double X[4];
+  for (int j = 0; j < m; j++)
+    for (int i = 0; i < m; i++) { double c = 0.0; for (int q = 0; q < m; q++) c += A[i + m * q] * B[q + m * j]; X[i + m * j] = c; }
+  for (int j = 0; j < m; j++)
+    for (int i = 0; i < m; i++) { double c = 0.0; for (int q = 0; q < m; q++) c += X[i + m * q] * A[j + m * q]; out[i + m * j] = c; }
+}
 bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att) {  // :284-381 with iekf_iter = 0
   const int n = f.n, m = f.m, mm = m * m;
   std::vector<double> Pt((size_t)mm * (n + 1), 0.0), Ptt((size_t)mm * n, 0.0);
@@ -967,17 +996,17 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
       const double cF = std::sqrt(F), v = f.y[t] - fnZ(f, a);
       for (int i = 0; i < m; i++) K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF);
       for (int i = 0; i < m; i++) af[i] = a[i] + K[i] * v;
-      Mat IKZ(m, m), Pm(m, m, P);
-      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ(i, j) = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
-      const Mat J = IKZ * Pm * tr(IKZ);
-      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pf[i + m * j] = J(i, j) + K[i] * H * H * K[j];
+      double IKZ[4], J[4];
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
+      small_abat(m, IKZ, P, J);
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pf[i + m * j] = J[i + m * j] + K[i] * H * H * K[j];
     } else { std::memcpy(af, a, sizeof(double) * m); std::memcpy(Pf, P, sizeof(double) * mm); }
     double Tg[4];
     fnT(f, af, at->data() + (size_t)m * (t + 1));
     fnTg(f, af, Tg);
-    const Mat TgM(m, m, Tg), PfM(m, m, Pf);
-    const Mat Pn = TgM * PfM * tr(TgM);
-    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = Pn(i, j) + (i == j ? rd[i] * rd[i] : 0.0);
+    double Pn[4];
+    small_abat(m, Tg, Pf, Pn);
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = Pn[i + m * j] + (i == j ? rd[i] * rd[i] : 0.0);
   }
   return true;
 }
@@ -1043,11 +1072,14 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
   Approx ap;
   ap.y = f.y;
   std::vector<Mat> sm;
+  double gll_last = 0.0; bool have_gll = false;  // Gaussian log-likelihood of the model the LAST smoother pass ran on
   auto smooth_mode = [&](std::vector<double>* out) {
     fn_gaussian_model(f, *su, &g);
     ap.H.assign(n, su->H);
     const Sys S(g);
-    if (!fast_smoother(S, ap, &sm)) return false;
+    double gl = std::nan("");
+    if (!fast_smoother(S, ap, &sm, &gl)) return false;
+    have_gll = !std::isnan(gl); gll_last = gl;
     out->resize((size_t)m * n);
     for (int t = 0; t < n; t++) for (int j = 0; j < m; j++) (*out)[j + (size_t)m * t] = sm[t](j, 0);
     for (double v : *out) if (!std::isfinite(v)) return false;
@@ -1076,10 +1108,16 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
       }
       su->iters = i;
     }
-    fn_gaussian_model(f, *su, &g);
-    ap.H.assign(n, su->H);
-    const Sys S(g);
-    const double gll = gaussian_loglik(S, ap);
+    // the approximating model is the one the last smoother pass was run on: its forward pass already gave the likelihood
+    double gll;
+    if (have_gll) {
+      gll = gll_last;
+    } else {
+      fn_gaussian_model(f, *su, &g);
+      ap.H.assign(n, su->H);
+      const Sys S(g);
+      gll = gaussian_loglik(S, ap);
+    }
     // update_scales (:854-879)
     double rd[2], rv[2];
     fnRdiag(f, rd);
