@@ -186,3 +186,32 @@ def test_chain_draws_and_builtin_priors_match_oracle(oracle):
             got = L.bssm_log_prior_builtin(model_type(mdl), flags, nx, _lib.dptr(th), d, pd.ctypes.data_as(C.POINTER(C.c_int32)), _lib.dptr(pp))
             ref = oracle.builtin_log_prior(mdl.classes[0], fl, nx, th, pd, pp)
             assert (np.isinf(got) and np.isinf(ref) and got < 0 and ref < 0) or abs(got - ref) <= 1e-12 * max(1.0, abs(ref)), (mdl.classes[0], th)
+
+
+def test_mcmc_output_summaries():
+    """summary() / asymptotic_var() of bssm_amd.mcmc on hand-made chain output (R/summary.R weights = counts x IS weights;
+    R/asymptotic_var.R:9-33)"""
+    from bssm_amd import mcmc
+    rng = np.random.default_rng(4)
+    theta = rng.normal(size=(50, 2))
+    counts = rng.integers(1, 5, 50).astype(np.uint32)
+    weights = rng.uniform(0.5, 1.5, 50)
+    alpha = rng.normal(size=(6, 2, 50))
+    out = dict(theta=theta, counts=counts, weights=weights, alpha=alpha, theta_names=["a", "b"])
+    w = counts * weights / np.sum(counts * weights)
+    s = mcmc.summary(out)
+    assert np.allclose(s["Mean"], w @ theta) and np.allclose(s["SD"], np.sqrt(w @ (theta - w @ theta) ** 2))
+    st = mcmc.summary(out, variable="states", times=[1, 6])
+    assert np.allclose(st["Mean"], (alpha @ w)[[0, 5]])
+    # iid draws with unit weights: asymptotic variance of the mean ~ var / n
+    x = rng.normal(0, 2.0, 20000)
+    av = mcmc.asymptotic_var(x)
+    assert 0.8 * 4.0 / x.size < av < 1.25 * 4.0 / x.size
+    # an AR(1) chain with rho = 0.9 has integrated autocorrelation time (1 + rho) / (1 - rho) = 19
+    e = rng.normal(size=40000); y = np.zeros_like(e)
+    for t in range(1, e.size):
+        y[t] = 0.9 * y[t - 1] + e[t]
+    ratio = mcmc.asymptotic_var(y) / (y.var() / y.size)
+    assert 13 < ratio < 26
+    with pytest.raises(ValueError):
+        mcmc.asymptotic_var(x, -np.ones_like(x))
