@@ -369,11 +369,11 @@ int run_chain(Target& tg, const double* theta0, const bssm_mcmc_job* job, bssm_m
         std::memcpy(out->theta + (size_t)d * n_stored, theta.data(), d * sizeof(double));
         out->counts[n_stored] = 1;
         out->posterior[n_stored] = logprior + ll[0];
-        if (!filtered) {
-          if (out->approx_loglik) out->approx_loglik[n_stored] = ll[0];
-          if (out->prior) out->prior[n_stored] = logprior;
-          if (out->modes) std::memcpy(out->modes + (size_t)prow * n * n_stored, mode.data(), (size_t)prow * n * sizeof(double));
-        }
+        // (filtered chains store them too: the coarse-level ssm_sde chain is the "approximate" chain of its IS types,
+        // src/approx_mcmc.cpp:236-330, and its log-likelihood estimates are what the correction divides by)
+        if (out->approx_loglik) out->approx_loglik[n_stored] = ll[0];
+        if (out->prior) out->prior[n_stored] = logprior;
+        if (!filtered && out->modes) std::memcpy(out->modes + (size_t)prow * n * n_stored, mode.data(), (size_t)prow * n * sizeof(double));
         if (otype == 1) std::memcpy(out->alpha + sz_a * n_stored, sampled.data(), sz_a * sizeof(double));
         n_stored++;
         new_value = false;

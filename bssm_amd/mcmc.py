@@ -60,13 +60,14 @@ def _transformed(model: BssmModel):
 def run_mcmc(model: BssmModel, iter: int, particles: int | None = None, output_type: str = "full", mcmc_type: str = "is2",
              sampling_method: str = "psi", burnin: int | None = None, thin: int = 1, gamma: float = 2 / 3,
              target_acceptance: float = 0.234, S=None, end_adaptive_phase: bool = False, local_approx: bool = True,
-             threads: int = 1, seed: int | None = None, max_iter: int = 100, conv_tol: float = 1e-8):
+             threads: int = 1, seed: int | None = None, max_iter: int = 100, conv_tol: float = 1e-8,
+             L_c: int | None = None, L_f: int | None = None):
     """R/run_mcmc.R:392-559 (run_mcmc.nongaussian).  Returns the ``mcmc_output`` dictionary: theta (n_stored x n_par,
     natural scale), counts, posterior, S, acceptance_rate, and by type weights / modes (approx, is*), alpha
     ((n+1) x m x n_stored, output 'full'), alphahat ((n+1) x m) and Vt (output 'summary')."""
     if model.inherits("ssm_nlg") or model.inherits("ssm_sde"):
         return _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method, burnin, thin, gamma,
-                            target_acceptance, S, end_adaptive_phase, threads, seed, max_iter, conv_tol)
+                            target_acceptance, S, end_adaptive_phase, threads, seed, max_iter, conv_tol, L_c, L_f)
     if not model.inherits("nongaussian"):
         raise TypeError("run_mcmc covers models of class 'nongaussian', 'ssm_nlg' and 'ssm_sde'")
     if not isinstance(end_adaptive_phase, (bool, np.bool_)):
@@ -243,7 +244,7 @@ def run_mcmc(model: BssmModel, iter: int, particles: int | None = None, output_t
 
 
 def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method, burnin, thin, gamma, target_acceptance, S,
-                 end_adaptive_phase, threads, seed, max_iter, conv_tol):
+                 end_adaptive_phase, threads, seed, max_iter, conv_tol, L_c=None, L_f=None):
     """run_mcmc.ssm_nlg / run_mcmc.ssm_sde (R/run_mcmc.R:561-900) for the model functors: the chain runs in the library
     (bssm_run_mcmc_fn), the prior is ``model['prior_fn']`` or the shipped example's log_prior_pdf."""
     from .models import example_log_prior
@@ -257,10 +258,27 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
         raise ValueError("Argument 'burnin' should be smaller than 'iter'.")
     otype = PC._OUTPUT_TYPES[output_type.lower() if isinstance(output_type, str) else output_type]
     mcmc_type = mcmc_type.lower()
-    if sde:
-        mcmc_type, sampling_method = ("pm" if mcmc_type == "is2" else mcmc_type), "bsf"
-        if mcmc_type != "pm":
-            raise ValueError("ssm_sde: mcmc_type 'pm' (the two-level chains re-run it at a coarser discretisation)")
+    sde_is = None
+    if sde:  # run_mcmc.ssm_sde, R/run_mcmc.R:733-860: discretisation levels 2^L_c (chain) / 2^L_f (correction, pm)
+        sampling_method = "bsf"
+        if mcmc_type not in ("pm", "is1", "is2", "is3"):
+            raise ValueError("ssm_sde: mcmc_type 'pm', 'is1', 'is2' or 'is3' (the two-level delayed acceptance chain is not built)")
+        if mcmc_type == "pm":
+            L = max(int(L_c or 0), int(L_f or 0), 0) or int(model.get("L", 0))
+            if L <= 0:
+                raise ValueError("L should be positive.")
+            model = BssmModel(model.classes, **{**model, "L": L})
+        else:
+            if L_c is None or L_f is None:
+                raise ValueError("ssm_sde IS types need L_c and L_f")
+            if L_f <= L_c:
+                raise ValueError("L_f should be larger than L_c.")
+            if L_c < 1:
+                raise ValueError("L_c should be at least 1")
+            # the chain is the pseudo-marginal chain at the coarse level (approx_mcmc::amcmc(ssm_sde), src/approx_mcmc.cpp:236-330)
+            sde_is, mcmc_type = mcmc_type, "pm"
+            model_fine = BssmModel(model.classes, **{**model, "L": int(L_f)})
+            model = BssmModel(model.classes, **{**model, "L": int(L_c)})
     elif mcmc_type not in ("pm", "da", "is1", "is2", "is3", "approx"):
         raise ValueError("'arg' should be one of 'pm', 'da', 'is1', 'is2', 'is3', 'approx'")
     sampling_method = sampling_method.lower()
@@ -301,7 +319,7 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
     job.nsim = particles
     job.iter, job.burnin, job.thin = iter, burnin, thin
     job.gamma, job.target_acceptance, job.end_ram, job.seed = gamma, target_acceptance, int(bool(end_adaptive_phase)), seed
-    job.output_type = otype
+    job.output_type = 3 if sde_is else otype
     job.max_iter, job.conv_tol = int(max_iter), float(conv_tol)
     n, m = model.n, int(model.get("n_states", 1))
     cap = max(1, (iter - burnin) // thin + 1)
@@ -315,6 +333,9 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
     if chain == 0:
         al, prior_s, modes = np.zeros(cap), np.zeros(cap), np.zeros((m * n, cap), order="F")
         out.approx_loglik, out.prior, out.modes = _lib.dptr(al), _lib.dptr(prior_s), _lib.dptr(modes)
+    elif sde_is:
+        al, prior_s = np.zeros(cap), np.zeros(cap)
+        out.approx_loglik, out.prior = _lib.dptr(al), _lib.dptr(prior_s)
     elif otype == 1:
         alpha = np.zeros((n + 1, m, cap), order="F")
         out.alpha = _lib.dptr(alpha)
@@ -360,6 +381,25 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
                 if k in corrected:
                     res[k] = corrected[k]
             res["time_postcorrection"] = time.perf_counter() - tc
+    elif sde_is:  # correction at the fine level: weight = exp(loglik_fine - loglik_coarse), src/approx_mcmc.cpp:523-600
+        tc = time.perf_counter()
+        it = int(sde_is[-1])
+        res["approx_loglik"], res["prior"] = al[:ns].copy(), prior_s[:ns].copy()
+        th_c, cn_c, al_c, post_c = res["theta"], res["counts"], res["approx_loglik"], res["posterior"]
+        if it == 3:
+            rep = cn_c.astype(np.int64)
+            th_c, al_c, post_c = np.repeat(th_c, rep, axis=0), np.repeat(al_c, rep), np.repeat(post_c, rep)
+            cn_c = np.ones(int(rep.sum()), dtype=np.uint32)
+        r = PC.is_correction(model_fine, th_c, cn_c, particles, method="bsf", approx_loglik=al_c, is_type=it, output_type=otype,
+                             seed=seed, threads=threads)
+        with np.errstate(divide="ignore"):
+            res.update(weights=r["weights"], loglik=r["loglik"], theta=th_c, counts=cn_c, posterior=post_c + np.log(r["weights"]))
+        if otype == 1:
+            res["alpha"] = r["alpha"]
+        elif otype == 2:
+            res["alphahat"], res["Vt"] = np.ascontiguousarray(r["alphahat"].T), r["Vt"]
+        res["mcmc_type"] = sde_is
+        res["time_postcorrection"] = time.perf_counter() - tc
     elif otype == 1:
         res["alpha"] = alpha[:, :, :ns].copy()
     elif otype == 2:

@@ -402,8 +402,9 @@ int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_j
  * _is_mcmc, src/R_mcmc.cpp:534-830; run_mcmc.ssm_sde -> sde_pm_mcmc, src/R_sde.cpp:134-170): theta IS the model's
  * parameter vector, prior_fn its log_prior_pdf; sampling_method BSSM_PSI / BSSM_BSF / BSSM_EKPF.  The approximate
  * log-likelihood is the mode-based one (ssm_nlg::log_likelihood with nsim = 0, src/model_ssm_nlg.cpp:258-277).
- * ssm_sde: pseudo-marginal chain with the bootstrap filter (the reference's only exact sde chain besides the two-level
- * variants, which re-run this chain at a coarser L). */
+ * ssm_sde: pseudo-marginal chain with the bootstrap filter at the model's L.  The IS types of run_mcmc.ssm_sde are this
+ * chain at the coarse level L_c (approx_mcmc::amcmc(ssm_sde), src/approx_mcmc.cpp:236-330; out->approx_loglik / prior are
+ * filled for filtered chains too) followed by bssm_is_correction_nlg at the fine level L_f (src/approx_mcmc.cpp:523-600). */
 int bssm_run_mcmc_fn(const bssm_fn_model* model, const double* theta0, const bssm_mcmc_job* job, bssm_mcmc_out* out);
 /* the chain's own random numbers (tests): standard normals of iteration `iter` and its acceptance uniforms */
 void bssm_mcmc_draws(uint32_t seed, uint64_t iter, int32_t n_par, double* normals, double* uniforms2);

@@ -396,3 +396,27 @@ def test_pm_chain_with_large_particle_counts(oracle, N):
     assert np.allclose(np.log(out["theta"]), ref["theta"], rtol=1e-8, atol=1e-10)
     assert np.allclose(out["posterior"], ref["posterior"], rtol=0, atol=1e-6 * model.n)
     assert np.allclose(out["alphahat"], ref["alphahat"].T, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("is_type", ["is2", "is1"])
+def test_sde_is_types(oracle, is_type):
+    """run_mcmc.ssm_sde with an IS type (R/run_mcmc.R:733-860 -> sde_is_mcmc): pseudo-marginal chain at the coarse
+    discretisation 2^L_c, then one bootstrap filter per stored value at the fine level 2^L_f with weight
+    exp(loglik_fine - loglik_coarse) (src/approx_mcmc.cpp:236-330, 523-600)"""
+    model = _nlg("gbm", n=15)
+    iters, burnin, seed, N, L_c, L_f = 40, 10, 19, 48, 1, 3
+    out = mcmc.run_mcmc(model, iters, particles=N, burnin=burnin, mcmc_type=is_type, output_type="theta", seed=seed, L_c=L_c, L_f=L_f)
+    coarse = M.BssmModel(model.classes, **{**model, "L": L_c})
+    upd, prior = _fn_oracle_fns(coarse)
+    th0 = np.array(model["theta"], dtype=float)
+    ref = oracle.run_chain(upd, prior, th0, np.diag(0.1 * np.maximum(0.1, np.abs(th0))), iters, burnin, 1, 2 / 3, 0.234, seed,
+                           kind="pm", nsim=N, method="bsf", output_type=3, fn_model=True)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(out["theta"], ref["theta"], rtol=1e-8, atol=1e-10)
+    ll_c = ref["posterior"] - np.array([prior(th) for th in ref["theta"]])
+    assert np.allclose(out["approx_loglik"], ll_c, rtol=0, atol=1e-8 * model.n)
+    for i in (0, len(ll_c) - 1):
+        Ni = N * int(ref["counts"][i]) if is_type == "is1" else N
+        fine = oracle.fn_bsf_filter({**model, "theta": ref["theta"][i], "L": L_f}, Ni, seed=seed, stream=i)
+        assert abs(out["weights"][i] - np.exp(fine["logLik"] - ll_c[i])) <= 1e-7 * out["weights"][i]
+    assert out["mcmc_type"] == is_type and np.all(np.isfinite(out["weights"]))
