@@ -157,7 +157,7 @@ struct UngTarget {
   int mode_rows() const { return wm.mod.p > 1 ? wm.mod.p : 1; }
   std::string update(const double* theta) { return wm.update(theta); }
   double log_prior(const double* theta) const { return wm.log_prior(theta); }
-  int approx_ll(std::vector<double>* mode, double* val) {
+  int approx_ll(uint64_t /*it*/, std::vector<double>* mode, double* val) {
     bssm::HostModel hm;
     const std::string e = bssm::ingest_model(&wm.mod, true, &hm);
     if (!e.empty()) return bssm::set_error(BSSM_ERR_INVALID, e);
@@ -174,7 +174,7 @@ struct UngTarget {
       if (!plan.p) return BSSM_ERR_INVALID;  // message already recorded
       // local_approx = FALSE: the psi filter of the initial value made the chain's first approximation
       // (src/model_ssm_ung.cpp:514-518); the approximate stage of delayed acceptance reuses its pseudo-observations
-      if (psi && !wm.mod.local_approx && !global.set) { double tmp; if ((rc = approx_ll(nullptr, &tmp)) != BSSM_OK) return rc; }
+      if (psi && !wm.mod.local_approx && !global.set) { double tmp; if ((rc = approx_ll(it, nullptr, &tmp)) != BSSM_OK) return rc; }
     } else if ((rc = bssm_plan_update(plan.p, &wm.mod, nullptr)) != BSSM_OK) {
       if (rc == BSSM_ERR_NUMERIC) { ll[0] = ll[1] = -INFINITY; return BSSM_OK; }  // a failed approximation rejects the proposal
       return rc;
@@ -210,7 +210,17 @@ struct FnTarget {
   bool is_sde() const { return mod.model_id == BSSM_FN_SDE_GBM || mod.model_id == BSSM_FN_SDE_POISSON_OU || mod.model_id == BSSM_FN_USER_SDE; }
   std::string update(const double* th) { std::memcpy(theta.data(), th, theta.size() * sizeof(double)); return ""; }
   double log_prior(const double* th) const { return job->prior_fn(th, job->n_par, job->user); }
-  int approx_ll(std::vector<double>* mode, double* val) {
+  int L_c = 0, L_f = 0;  // ssm_sde delayed acceptance: coarse / fine discretisation levels (0 = single level, mod.L)
+  bool two_level() const { return L_c > 0 && L_f > L_c; }
+  int approx_ll(uint64_t it, std::vector<double>* mode, double* val) {
+    if (two_level()) {  // first stage of sde_da_mcmc: a bootstrap filter at the coarse level (src/mcmc.cpp:859,908), stream 1
+      mod.L = L_c;
+      const int rc = bssm_fn_loglik_batch(&mod, job->nsim, BSSM_BSF, job->seed + (uint32_t)it, 1u, 1u, val);
+      mod.L = L_f;
+      if (rc < 0) return rc;
+      if (!std::isfinite(*val)) *val = -INFINITY;
+      return BSSM_OK;
+    }
     std::vector<double> md((size_t)m() * n());
     const int rc = bssm_fn_psi_setup(&mod, nullptr, job->max_iter, job->conv_tol, md.data(), nullptr, val, nullptr, nullptr,
                                      nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -223,9 +233,13 @@ struct FnTarget {
     int rc = bssm_fn_loglik_batch(&mod, job->nsim, job->sampling_method, job->seed + (uint32_t)it, 0u, 1u, &ll[0]);
     if (rc < 0) return rc;
     if (!std::isfinite(ll[0])) ll[0] = -INFINITY;
+    if (two_level()) {  // ll[1] is the coarse-level estimate: the caller's first stage made it, except for the initial value
+      if (it == 0 && (rc = approx_ll(0, nullptr, &ll[1])) != BSSM_OK) return rc;
+      return BSSM_OK;
+    }
     ll[1] = ll[0];
     if (job->sampling_method == BSSM_PSI && std::isfinite(ll[0])) {  // ll(1) = approx_loglik, src/model_ssm_nlg.cpp:253-254
-      if ((rc = approx_ll(nullptr, &ll[1])) != BSSM_OK) return rc;
+      if ((rc = approx_ll(it, nullptr, &ll[1])) != BSSM_OK) return rc;
     }
     return BSSM_OK;
   }
@@ -290,7 +304,7 @@ int run_chain(Target& tg, const double* theta0, const bssm_mcmc_job* job, bssm_m
       std::fill(out->Vt, out->Vt + sz_v, 0.0);
     }
   } else {
-    if ((rc = tg.approx_ll(&mode, &ll[0])) != BSSM_OK) return rc;
+    if ((rc = tg.approx_ll(0, &mode, &ll[0])) != BSSM_OK) return rc;
     ll[1] = ll[0];
     if (!std::isfinite(ll[0])) return set_error(BSSM_ERR_INVALID, "Initial log-likelihood is not finite.");
   }
@@ -313,7 +327,7 @@ int run_chain(Target& tg, const double* theta0, const bssm_mcmc_job* job, bssm_m
       if (!err.empty()) return set_error(BSSM_ERR_INVALID, err);
       bool accept = false;
       if (type == BSSM_MCMC_APPROX) {
-        if ((rc = tg.approx_ll(&mode_prop, &ll_prop[0])) != BSSM_OK) return rc;
+        if ((rc = tg.approx_ll(i, &mode_prop, &ll_prop[0])) != BSSM_OK) return rc;
         ll_prop[1] = ll_prop[0];
         acceptance_prob = std::fmin(1.0, std::exp(ll_prop[0] - ll[0] + logprior_prop - logprior));
         accept = rng.uniform(i, 0) < acceptance_prob;
@@ -324,7 +338,7 @@ int run_chain(Target& tg, const double* theta0, const bssm_mcmc_job* job, bssm_m
         const double log_alpha = ll_prop[0] - ll[0] + logprior_prop - logprior;
         accept = std::log(rng.uniform(i, 0)) < log_alpha;
       } else {  // delayed acceptance: the filter runs only for proposals that pass the approximate stage
-        if ((rc = tg.approx_ll(nullptr, &ll_prop[1])) != BSSM_OK) return rc;
+        if ((rc = tg.approx_ll(i, nullptr, &ll_prop[1])) != BSSM_OK) return rc;
         acceptance_prob = std::fmin(1.0, std::exp(ll_prop[1] - ll[1] + logprior_prop - logprior));
         if (rng.uniform(i, 0) < acceptance_prob) {
           if ((rc = tg.filter_ll(i, ll_prop)) != BSSM_OK) return rc;
@@ -455,13 +469,14 @@ int bssm_run_mcmc_fn(const bssm_fn_model* model, const double* theta0, const bss
   int rc = check_job(job, out, true, &tg.otype);
   if (rc != BSSM_OK) return rc;
   const bool sde = model->model_id == BSSM_FN_SDE_GBM || model->model_id == BSSM_FN_SDE_POISSON_OU || model->model_id == BSSM_FN_USER_SDE;
-  if (sde && (job->mcmc_type != BSSM_MCMC_PM || job->sampling_method != BSSM_BSF))
-    return set_error(BSSM_ERR_UNSUPPORTED, "ssm_sde: pseudo-marginal chain with the bootstrap filter only (the coarse-level chains "
-                                           "of run_mcmc.ssm_sde are the same chain run with a smaller L)");
+  const bool two_level = job->L_c > 0 && job->L_f > job->L_c;
+  if (sde && (job->sampling_method != BSSM_BSF || !(job->mcmc_type == BSSM_MCMC_PM || (job->mcmc_type == BSSM_MCMC_DA && two_level))))
+    return set_error(BSSM_ERR_UNSUPPORTED, "ssm_sde: bootstrap filter with mcmc_type pm, or da with discretisation levels 1 <= L_c < L_f");
   tg.job = job;
   tg.mod = *model;
   tg.theta.assign(theta0, theta0 + job->n_par);
   tg.mod.theta = tg.theta.data();
+  if (sde && job->mcmc_type == BSSM_MCMC_DA) { tg.L_c = job->L_c; tg.L_f = job->L_f; tg.mod.L = job->L_f; }
   return run_chain(tg, theta0, job, out);
 }
 

@@ -31,7 +31,7 @@ class McmcJob(C.Structure):
                 ("mcmc_type", C.c_int32), ("sampling_method", C.c_uint32), ("nsim", C.c_uint32),
                 ("iter", C.c_uint64), ("burnin", C.c_uint64), ("thin", C.c_uint32),
                 ("gamma", C.c_double), ("target_acceptance", C.c_double), ("end_ram", C.c_int32), ("seed", C.c_uint32),
-                ("output_type", C.c_int32), ("max_iter", C.c_int32), ("conv_tol", C.c_double)]
+                ("output_type", C.c_int32), ("max_iter", C.c_int32), ("conv_tol", C.c_double), ("L_c", C.c_int32), ("L_f", C.c_int32)]
 
 
 class McmcOut(C.Structure):
@@ -261,8 +261,9 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
     sde_is = None
     if sde:  # run_mcmc.ssm_sde, R/run_mcmc.R:733-860: discretisation levels 2^L_c (chain) / 2^L_f (correction, pm)
         sampling_method = "bsf"
-        if mcmc_type not in ("pm", "is1", "is2", "is3"):
-            raise ValueError("ssm_sde: mcmc_type 'pm', 'is1', 'is2' or 'is3' (the two-level delayed acceptance chain is not built)")
+        if mcmc_type not in ("pm", "da", "is1", "is2", "is3"):
+            raise ValueError("'arg' should be one of 'pm', 'da', 'is1', 'is2', 'is3'")
+        sde_levels = (0, 0)
         if mcmc_type == "pm":
             L = max(int(L_c or 0), int(L_f or 0), 0) or int(model.get("L", 0))
             if L <= 0:
@@ -275,6 +276,10 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
                 raise ValueError("L_f should be larger than L_c.")
             if L_c < 1:
                 raise ValueError("L_c should be at least 1")
+        if mcmc_type == "da":  # sde_da_mcmc: coarse filter first, fine filter for the proposals that pass
+            sde_levels = (int(L_c), int(L_f))
+            model = BssmModel(model.classes, **{**model, "L": int(L_f)})
+        elif mcmc_type != "pm":
             # the chain is the pseudo-marginal chain at the coarse level (approx_mcmc::amcmc(ssm_sde), src/approx_mcmc.cpp:236-330)
             sde_is, mcmc_type = mcmc_type, "pm"
             model_fine = BssmModel(model.classes, **{**model, "L": int(L_f)})
@@ -321,6 +326,8 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
     job.gamma, job.target_acceptance, job.end_ram, job.seed = gamma, target_acceptance, int(bool(end_adaptive_phase)), seed
     job.output_type = 3 if sde_is else otype
     job.max_iter, job.conv_tol = int(max_iter), float(conv_tol)
+    if sde:
+        job.L_c, job.L_f = sde_levels
     n, m = model.n, int(model.get("n_states", 1))
     cap = max(1, (iter - burnin) // thin + 1)
     out = McmcOut()

@@ -377,6 +377,7 @@ typedef struct bssm_mcmc_job {
   int32_t output_type;                /* pm / da: 1 one trajectory per stored value, 2 running summary, 3 theta only */
   int32_t max_iter;                   /* ssm_nlg mode search (src/model_ssm_nlg.cpp:19-20); ssm_ung models carry their own */
   double conv_tol;
+  int32_t L_c, L_f;                   /* ssm_sde delayed acceptance (sde_da_mcmc, src/mcmc.cpp:840-960): coarse / fine levels; 0 otherwise */
 } bssm_mcmc_job;
 typedef struct bssm_mcmc_out {
   int32_t capacity;        /* in: room for this many stored values (floor((iter - burnin) / thin) always suffices) */
@@ -402,7 +403,8 @@ int bssm_run_mcmc(bssm_ung_model* model, const double* theta0, const bssm_mcmc_j
  * _is_mcmc, src/R_mcmc.cpp:534-830; run_mcmc.ssm_sde -> sde_pm_mcmc, src/R_sde.cpp:134-170): theta IS the model's
  * parameter vector, prior_fn its log_prior_pdf; sampling_method BSSM_PSI / BSSM_BSF / BSSM_EKPF.  The approximate
  * log-likelihood is the mode-based one (ssm_nlg::log_likelihood with nsim = 0, src/model_ssm_nlg.cpp:258-277).
- * ssm_sde: pseudo-marginal chain with the bootstrap filter at the model's L.  The IS types of run_mcmc.ssm_sde are this
+ * ssm_sde: pseudo-marginal chain with the bootstrap filter at the model's L, or the two-level delayed-acceptance chain
+ * (first stage a bootstrap filter at 2^L_c sub-steps, second stage at 2^L_f; job->L_c, job->L_f).  The IS types of run_mcmc.ssm_sde are this
  * chain at the coarse level L_c (approx_mcmc::amcmc(ssm_sde), src/approx_mcmc.cpp:236-330; out->approx_loglik / prior are
  * filled for filtered chains too) followed by bssm_is_correction_nlg at the fine level L_f (src/approx_mcmc.cpp:523-600). */
 int bssm_run_mcmc_fn(const bssm_fn_model* model, const double* theta0, const bssm_mcmc_job* job, bssm_mcmc_out* out);

@@ -654,7 +654,7 @@ def adapt_S(S, u, acc, target, i, gamma):
 
 
 def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target, seed, end_ram=False, kind="approx",
-              nsim=0, method="psi", output_type=3, fn_model=False, local_approx=True):
+              nsim=0, method="psi", output_type=3, fn_model=False, local_approx=True, sde_levels=None):
     """One chain.  ``update(theta) -> arr`` gives the flattened model, ``log_prior(theta) -> float``.
     kind: 'approx' | 'pm' | 'da'.  Returns theta (n_stored x d), counts, posterior, S, acceptance_rate and by kind
     approx_loglik / prior / modes, alpha (n+1) x m x n_stored, alphahat / Vt."""
@@ -664,7 +664,10 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
     filtered = kind != "approx"
     L = lib()
 
-    def approx(arr):
+    def approx(arr, it=0):
+        if sde_levels:  # first stage of sde_da_mcmc (src/mcmc.cpp:859,908): bootstrap filter at the coarse level, stream 1
+            r = fn_bsf_filter({**arr, "L": sde_levels[0]}, nsim, seed=(seed + it) & 0xFFFFFFFF, stream=1)
+            return (r["logLik"] if np.isfinite(r["logLik"]) else -np.inf), None, None
         if fn_model:  # ssm_nlg: mode-based approximation (src/model_ssm_nlg.cpp:258-277)
             su = fn_psi_setup(arr)
             return (su["approx_loglik"] if su["rc"] == 0 and su["ok"] else -np.inf), su["mode"].reshape(-1, order="F"), su
@@ -685,6 +688,8 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
             if method == "psi":
                 r = fn_psi_filter(arr, nsim, seed=sd, stream=0)
                 return r["logLik"], r["setup"]["approx_loglik"], r
+            if sde_levels:
+                arr = {**arr, "L": sde_levels[1]}
             r = fn_ekpf_filter(arr, nsim, seed=sd, stream=0) if method == "ekf" else fn_bsf_filter(arr, nsim, seed=sd, stream=0)
             return r["logLik"], r["logLik"], r
         sd, st = seed + (it >> 32), it & 0xFFFFFFFF
@@ -711,6 +716,8 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
     mode = None
     if filtered:
         ll0, ll1, res = filt(arr, 0)
+        if sde_levels:
+            ll1 = approx(arr, 0)[0]
         sampled, ah_i, vt_i = sample_or_summarise(res, 0)
     else:
         ll0, mode, _ = approx(arr)
@@ -737,10 +744,12 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
                 acc_prob = min(1.0, np.exp(llp1 - ll1 + lp_prop - logprior))
                 accept = np.log(un0) < llp0 - ll0 + lp_prop - logprior
             else:
-                llp1 = approx(arr_p)[0]
+                llp1 = approx(arr_p, i)[0]
                 acc_prob = min(1.0, np.exp(llp1 - ll1 + lp_prop - logprior))
                 if un0 < acc_prob:
-                    llp0, llp1, res_p = filt(arr_p, i)
+                    llp0, llp1_f, res_p = filt(arr_p, i)
+                    if not sde_levels:
+                        llp1 = llp1_f
                     accept = np.log(un1) < llp0 + ll1 - ll0 - llp1
             if accept:
                 if i > burnin:

@@ -420,3 +420,25 @@ def test_sde_is_types(oracle, is_type):
         fine = oracle.fn_bsf_filter({**model, "theta": ref["theta"][i], "L": L_f}, Ni, seed=seed, stream=i)
         assert abs(out["weights"][i] - np.exp(fine["logLik"] - ll_c[i])) <= 1e-7 * out["weights"][i]
     assert out["mcmc_type"] == is_type and np.all(np.isfinite(out["weights"]))
+
+
+@pytest.mark.parametrize("otype", [1, 3])
+def test_sde_two_level_delayed_acceptance(oracle, otype):
+    """sde_da_mcmc (src/mcmc.cpp:840-960): first stage a bootstrap filter at the coarse level 2^L_c, second stage at the fine
+    level 2^L_f with log alpha = ll_f' + ll_c - ll_f - ll_c'; states from the fine filter"""
+    model = _nlg("gbm", n=15)
+    iters, burnin, seed, N, L_c, L_f = 50, 10, 29, 40, 1, 3
+    out = mcmc.run_mcmc(model, iters, particles=N, burnin=burnin, mcmc_type="da", output_type={1: "full", 3: "theta"}[otype],
+                        seed=seed, L_c=L_c, L_f=L_f)
+    upd, prior = _fn_oracle_fns(model)
+    th0 = np.array(model["theta"], dtype=float)
+    ref = oracle.run_chain(upd, prior, th0, np.diag(0.1 * np.maximum(0.1, np.abs(th0))), iters, burnin, 1, 2 / 3, 0.234, seed,
+                           kind="da", nsim=N, method="bsf", output_type=otype, fn_model=True, sde_levels=(L_c, L_f))
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert np.allclose(out["theta"], ref["theta"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["posterior"], ref["posterior"], rtol=0, atol=1e-7 * model.n)
+    assert np.allclose(out["S"], ref["S"], rtol=1e-7, atol=1e-10)
+    if otype == 1:
+        assert np.allclose(out["alpha"], ref["alpha"], rtol=1e-7, atol=1e-9)
+    with pytest.raises(ValueError, match="L_f should be larger"):
+        mcmc.run_mcmc(model, 20, particles=N, mcmc_type="da", L_c=3, L_f=2)
