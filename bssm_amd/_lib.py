@@ -46,12 +46,19 @@ def pack_fn_model(model, L=None):
         s.user_slot = user_model_slot(model["user_source"], int(model.get("n_states", 1)))
         s.n_states = int(model.get("n_states", 1))
         if s.model_id == 7:
-            m = s.n_states
-            s.H = float(model["H"])
-            for j, v in enumerate(np.asarray(model["R_diag"], dtype=float).reshape(-1)[:m]): s.R_diag[j] = v
-            for j, v in enumerate(np.asarray(model["a1"], dtype=float).reshape(-1)[:m]): s.a1[j] = v
-            for j, v in enumerate(np.asfortranarray(np.asarray(model["P1"], dtype=float).reshape(m, m)).reshape(-1, order="F")): s.P1[j] = v
+            fill_user_numbers(s, model, th)
     return s, [y, th, kp]
+
+
+def fill_user_numbers(s, model, theta):
+    """H, diag(R), a1, P1 of a user-defined ssm_nlg model: numbers, or functions of theta (the reference's H_fn / R_fn /
+    a1_fn / P1_fn take theta too, src/model_ssm_nlg.h:10-21) evaluated at ``theta``"""
+    m = int(s.n_states)
+    val = lambda k: model[k](np.array(theta, dtype=float)) if callable(model[k]) else model[k]
+    s.H = float(val("H"))
+    for j, v in enumerate(np.asarray(val("R_diag"), dtype=float).reshape(-1)[:m]): s.R_diag[j] = v
+    for j, v in enumerate(np.asarray(val("a1"), dtype=float).reshape(-1)[:m]): s.a1[j] = v
+    for j, v in enumerate(np.asfortranarray(np.asarray(val("P1"), dtype=float).reshape(m, m)).reshape(-1, order="F")): s.P1[j] = v
 
 
 _user_slots = {}

@@ -208,7 +208,12 @@ struct FnTarget {
   int m() const { return mod.model_id == BSSM_FN_NLG_GROWTH ? 2 : (mod.model_id == BSSM_FN_USER_NLG ? mod.n_states : 1); }
   int mode_rows() const { return m(); }
   bool is_sde() const { return mod.model_id == BSSM_FN_SDE_GBM || mod.model_id == BSSM_FN_SDE_POISSON_OU || mod.model_id == BSSM_FN_USER_SDE; }
-  std::string update(const double* th) { std::memcpy(theta.data(), th, theta.size() * sizeof(double)); return ""; }
+  std::string update(const double* th) {
+    std::memcpy(theta.data(), th, theta.size() * sizeof(double));
+    if (job->fn_update_fn && job->fn_update_fn(th, job->n_par, &mod, job->user) != 0) return "fn_update_fn failed";
+    mod.theta = theta.data();
+    return "";
+  }
   double log_prior(const double* th) const { return job->prior_fn(th, job->n_par, job->user); }
   int L_c = 0, L_f = 0;  // ssm_sde delayed acceptance: coarse / fine discretisation levels (0 = single level, mod.L)
   bool two_level() const { return L_c > 0 && L_f > L_c; }

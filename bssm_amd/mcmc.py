@@ -31,7 +31,7 @@ class McmcJob(C.Structure):
                 ("mcmc_type", C.c_int32), ("sampling_method", C.c_uint32), ("nsim", C.c_uint32),
                 ("iter", C.c_uint64), ("burnin", C.c_uint64), ("thin", C.c_uint32),
                 ("gamma", C.c_double), ("target_acceptance", C.c_double), ("end_ram", C.c_int32), ("seed", C.c_uint32),
-                ("output_type", C.c_int32), ("max_iter", C.c_int32), ("conv_tol", C.c_double), ("L_c", C.c_int32), ("L_f", C.c_int32)]
+                ("output_type", C.c_int32), ("max_iter", C.c_int32), ("conv_tol", C.c_double), ("L_c", C.c_int32), ("L_f", C.c_int32), ("fn_update_fn", C.c_void_p)]
 
 
 class McmcOut(C.Structure):
@@ -318,6 +318,18 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
     job = McmcJob()
     job.n_par = d
     job.prior_fn = _PRIOR_FN(_prior)
+    if int(model.get("model_id", 0)) == 7 and any(callable(model.get(k)) for k in ("H", "R_diag", "a1", "P1")):
+        FN_UPDATE = C.CFUNCTYPE(C.c_int, _lib.c_double_p, C.c_int32, C.POINTER(_lib.FnModel), C.c_void_p)
+
+        def _fn_update(th_p, n_par, mod_p, _user):
+            try:
+                _lib.fill_user_numbers(mod_p.contents, model, np.ctypeslib.as_array(th_p, shape=(n_par,)).copy())
+                return 0
+            except Exception as e:
+                failure.append(e)
+                return 1
+        fn_update_cb = FN_UPDATE(_fn_update)
+        job.fn_update_fn = C.cast(fn_update_cb, C.c_void_p)
     chain = _MCMC_TYPES.get(mcmc_type, 0)
     job.mcmc_type = chain
     job.sampling_method = {"psi": 1, "bsf": 2, "ekf": 4}[sampling_method]

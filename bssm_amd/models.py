@@ -547,14 +547,17 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H, R_diag, known_params=(),
     With the Jacobians in the snippet (``BSSM_USER_JACOBIANS``, ``bssm_user_Tg``, ``bssm_user_Zg``) the psi-APF and the
     EKF particle filter work as for the built-in models."""
     y = _f(np.asarray(y, dtype=float).reshape(-1))
-    a1 = np.asarray(a1, dtype=float).reshape(-1)
-    m = int(n_states or a1.size)
+    theta = np.asarray(theta, dtype=float)
+    m = int(n_states or np.asarray(a1(theta) if callable(a1) else a1, dtype=float).size)
     if m not in (1, 2):
         raise ValueError("user-defined ssm_nlg models: n_states must be 1 or 2")
+    # H, R_diag, a1, P1 may be functions of theta (as the reference's H_fn / R_fn / a1_fn / P1_fn are): post_correct and
+    # run_mcmc then evaluate them for every theta
+    num = lambda v, shape: v if callable(v) else np.asarray(v, dtype=float).reshape(shape)
     return BssmModel(("ssm_nlg", "bssm_model"), y=y, model_id=7, example="user", user_source=str(device_code),
-                     theta=np.asarray(theta, dtype=float), known_params=np.asarray(known_params, dtype=float),
-                     n_states=m, n_etas=m, a1=a1, P1=np.asarray(P1, dtype=float).reshape(m, m), H=float(H),
-                     R_diag=np.asarray(R_diag, dtype=float).reshape(-1), x0=0.0, positive=False, L=0)
+                     theta=theta, known_params=np.asarray(known_params, dtype=float),
+                     n_states=m, n_etas=m, a1=num(a1, -1), P1=num(P1, (m, m)), H=H if callable(H) else float(H),
+                     R_diag=num(R_diag, -1), x0=0.0, positive=False, L=0)
 
 
 def ssm_sde_user(y, device_code: str, theta, x0, positive: bool):

@@ -378,6 +378,9 @@ typedef struct bssm_mcmc_job {
   int32_t max_iter;                   /* ssm_nlg mode search (src/model_ssm_nlg.cpp:19-20); ssm_ung models carry their own */
   double conv_tol;
   int32_t L_c, L_f;                   /* ssm_sde delayed acceptance (sde_da_mcmc, src/mcmc.cpp:840-960): coarse / fine levels; 0 otherwise */
+  /* user-defined ssm_nlg models whose H, diag(R), a1, P1 depend on theta (the reference's H_fn / R_fn / a1_fn / P1_fn take
+   * theta): called after every theta change to rewrite those fields of the chain's model copy; NULL = they are constants */
+  int (*fn_update_fn)(const double* theta, int32_t n_par, bssm_fn_model* model, void* user);
 } bssm_mcmc_job;
 typedef struct bssm_mcmc_out {
   int32_t capacity;        /* in: room for this many stored values (floor((iter - burnin) / thin) always suffices) */

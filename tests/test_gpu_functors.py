@@ -258,3 +258,28 @@ def test_user_model_compile_error_is_reported():
     with pytest.raises(Exception, match="compiling the user model failed"):
         M_bad = M.ssm_nlg_user(np.zeros(5), "#define BSSM_USER_NLG 1\nthis is not C++", theta=[0.0], a1=[0.0], P1=[[1.0]], H=1.0, R_diag=[1.0])
         F.bootstrap_filter(M_bad, 10, seed=1)
+
+
+def test_user_model_with_theta_dependent_numbers_in_post_correct_and_run_mcmc(oracle):
+    """User-defined ssm_nlg whose H, diag(R) are functions of theta (as the reference's H_fn / R_fn are): the IS
+    post-correction and run_mcmc evaluate them for every theta and agree with the built-in model of the same equations."""
+    from bssm_amd import mcmc, post_correct as PC
+    b, _ = MODELS["nlg_growth"]
+    th, kp = np.asarray(b["theta"], dtype=float), np.asarray(b["known_params"])
+    u = M.ssm_nlg_user(b["y"], USER_GROWTH, theta=th, known_params=kp, a1=kp[2:4], P1=np.diag(kp[4:6]),
+                       H=lambda t: np.exp(t[0]), R_diag=lambda t: np.exp(t[1:3]))
+    u = M.BssmModel(u.classes, **{**u, "prior_fn": M.example_log_prior("nlg_growth")})
+    # the approximate chain (host) of the two models is the same chain
+    cb = mcmc.run_mcmc(b, 120, burnin=40, mcmc_type="approx", seed=2)
+    cu = mcmc.run_mcmc(u, 120, burnin=40, mcmc_type="approx", seed=2)
+    assert np.array_equal(cb["counts"], cu["counts"]) and np.allclose(cb["theta"], cu["theta"], rtol=1e-10, atol=1e-12)
+    assert np.allclose(cb["approx_loglik"], cu["approx_loglik"], rtol=0, atol=1e-8 * b.n)
+    assert len(np.unique(cb["theta"][:, 0])) > 3  # H really varies along the chain
+    # post-correction of the stored values
+    pb = PC.post_correct(b, dict(cb, output_type=3), 64, threads=2, is_type="is2", seed=5)
+    pu = PC.post_correct(u, dict(cu, output_type=3), 64, threads=2, is_type="is2", seed=5)
+    assert np.allclose(pb["weights"], pu["weights"], rtol=1e-7)
+    # and a pseudo-marginal chain through the device filter
+    mb = mcmc.run_mcmc(b, 40, particles=32, burnin=10, mcmc_type="pm", sampling_method="bsf", output_type="theta", seed=3)
+    mu = mcmc.run_mcmc(u, 40, particles=32, burnin=10, mcmc_type="pm", sampling_method="bsf", output_type="theta", seed=3)
+    assert np.array_equal(mb["counts"], mu["counts"]) and np.allclose(mb["theta"], mu["theta"], rtol=1e-9, atol=1e-11)
