@@ -46,6 +46,41 @@ _MCMC_TYPES = {"approx": 0, "pm": 1, "da": 2}
 _UPDATABLE = ("Z", "T", "R", "a1", "P1", "D", "C", "beta")
 
 
+def approximating_gaussian_model(model: BssmModel, theta_row, mode_i):
+    """The Gaussian model approximate_for_is() builds at a stored mode (src/model_ssm_ung.cpp:143-161): the model at
+    ``theta_row`` (sampling scale) with the pseudo-observations / standard deviations of the Laplace step.  ssm_ulg has no
+    regression term, so x'beta joins D."""
+    from .filters import psi_setup
+    from .models import ssm_ulg
+    arr = PC.expand_models(model, np.asarray(theta_row, dtype=np.float64)[None, :])[0]
+    mdl = BssmModel(model.classes, **{**model, **{k: arr[k] for k in ("Z", "T", "R", "P1", "a1", "C", "D", "beta")}, "phi": arr["phi"]})
+    su = psi_setup(mdl, is_mode=np.asarray(mode_i, dtype=np.float64).reshape(-1))
+    n = model.n
+    D = np.broadcast_to(np.asarray(arr["D"], dtype=np.float64).reshape(-1), (n,)) if np.asarray(arr["D"]).size in (1, n) else arr["D"]
+    D = np.array(D, dtype=np.float64) + (arr["xreg"] @ arr["beta"] if arr["xreg"].shape[1] else 0.0)
+    Z = np.asarray(arr["Z"]) if model["distribution"] != "svm" else np.eye(model.m)[:, :1]
+    return ssm_ulg(su["approx_y"], Z, su["approx_H"], arr["T"], arr["R"], a1=arr["a1"], P1=arr["P1"], D=D, C=arr["C"])
+
+
+def approx_state_posterior(model: BssmModel, theta, modes, seed: int):
+    """approx_mcmc::approx_state_posterior (src/approx_mcmc.cpp:1399-1448): one exact draw of the states from the Gaussian
+    approximation at every stored (theta, mode) -- ssm_ulg::psi_filter with one draw (the device simulation smoother,
+    bssm_gaussian_psi_smoother), stream seed + 1 + i for stored value i.  Returns (n+1) x m x n_stored."""
+    from .filters import _prep, _alloc
+    from .models import model_type as _mt
+    theta = np.atleast_2d(theta)
+    n, m, ns = model.n, model.m, theta.shape[0]
+    alpha = np.zeros((n + 1, m, ns), order="F")
+    L = _lib.lib()
+    for i in range(ns):
+        g = approximating_gaussian_model(model, theta[i], modes[..., i])
+        arr, smod, keep = _prep(g, False)
+        a = _alloc((m, n + 1, 1))
+        _lib.check(L.bssm_gaussian_psi_smoother(C.byref(smod), C.c_uint32(1), C.c_uint32((seed + 1 + i) % 2147483647), _mt(g), _lib.dptr(a)))
+        alpha[:, :, i] = a[:, :, 0].T
+    return alpha
+
+
 def _transformed(model: BssmModel):
     """names sampled on the log scale, R/run_mcmc.R:471-489"""
     names = list(model.get("theta_names", []))
@@ -207,6 +242,9 @@ def run_mcmc(model: BssmModel, iter: int, particles: int | None = None, output_t
         res["modes"] = modes[:, :ns].reshape(p, n, ns, order="F") if p > 1 else modes[:, :ns].reshape(n, 1, ns, order="F")
         res["approx_loglik"], res["prior"] = al[:ns].copy(), prior_s[:ns].copy()
         res["weights"] = np.ones(ns)
+        if mcmc_type == "approx" and otype == 1 and p == 1:
+            # state draws of the purely approximate chain (nongaussian_is_mcmc with approx = TRUE, src/R_mcmc.cpp:397-404)
+            res["alpha"] = approx_state_posterior(model, res["theta"], res["modes"], seed)
         if mcmc_type != "approx":
             # IS correction of the stored values on the sampling scale, as nongaussian_is_mcmc does before run_mcmc.R
             # maps theta back (src/R_mcmc.cpp:376-392)

@@ -212,7 +212,7 @@ def test_paper_negbin_posterior_means():
 def test_replication_table_poisson():
     """benchmarks/replications.html: every MCMC type of the reference on bsm_ng(poisson_series), 1e4 iterations each.  The
     document prints the weighted posterior means with their asymptotic standard errors; the same runs here must agree
-    with those means within the combined Monte-Carlo error (68 comparisons over local_approx TRUE / FALSE, |z| < 4)."""
+    with those means within the combined Monte-Carlo error (72 comparisons over local_approx TRUE / FALSE, |z| < 4)."""
     import json
     ref = json.load(open(os.path.join(GOLD, "reference_test_vectors.json")))["mcmc_replications_poisson"]["table"]
     y = np.loadtxt(os.path.join(GOLD, "poisson_series.txt"))
@@ -442,3 +442,20 @@ def test_sde_two_level_delayed_acceptance(oracle, otype):
         assert np.allclose(out["alpha"], ref["alpha"], rtol=1e-7, atol=1e-9)
     with pytest.raises(ValueError, match="L_f should be larger"):
         mcmc.run_mcmc(model, 20, particles=N, mcmc_type="da", L_c=3, L_f=2)
+
+
+def test_approx_chain_state_draws(oracle):
+    """output 'full' of the purely approximate chain: one exact draw from the Gaussian approximation at every stored
+    (theta, mode) (approx_mcmc::approx_state_posterior, src/approx_mcmc.cpp:1399-1448) = ssm_ulg::psi_filter with one draw"""
+    model = _small("negbin")
+    out = mcmc.run_mcmc(model, 150, burnin=50, mcmc_type="approx", output_type="full", seed=21)
+    ns = out["counts"].size
+    assert out["alpha"].shape == (model.n + 1, model.m, ns) and np.all(np.isfinite(out["alpha"]))
+    th = _sampling_scale(model, out["theta"])
+    for i in (0, ns // 2, ns - 1):
+        g = mcmc.approximating_gaussian_model(model, th[i], out["modes"][..., i])
+        ref = oracle.ulg_psi_filter(M.model_arrays(g), 1, seed=21 + 1 + i)
+        assert np.allclose(out["alpha"][:, :, i], ref[:, :, 0].T, rtol=1e-8, atol=1e-10)
+    # the draws scatter around the mode-implied signal: level + x'beta close to the stored mode on average
+    lvl = out["alpha"][:-1, 0, :] + (np.asarray(model["xreg"]) @ out["theta"][:, -1:].T)
+    assert np.mean(np.abs(lvl.mean(axis=1) - out["modes"][:, 0, :].mean(axis=1))) < 0.3
