@@ -743,6 +743,19 @@ int bssm_psi_setup(const bssm_ung_model* model, const double* is_mode, double* a
   return ok ? BSSM_OK : BSSM_ERR_NUMERIC;
 }
 
+int bssm_gaussian_smoother(const bssm_ung_model* model, double* alphahat, double* Vt) {
+  if (!model || !alphahat || !Vt) return fail(BSSM_ERR_INVALID, "NULL argument");
+  bssm::HostModel hm;
+  const std::string err = bssm::ingest_model(model, false, &hm);
+  if (!err.empty()) return fail(BSSM_ERR_INVALID, err);
+  if (!hm.gaussian()) return fail(BSSM_ERR_UNSUPPORTED, "bssm_gaussian_smoother: linear-Gaussian (ssm_ulg family) models only");
+  std::vector<double> a, v;
+  if (!bssm::gaussian_smoother(hm, &a, &v)) return fail(BSSM_ERR_NUMERIC, "the Kalman smoother produced non-finite values");
+  std::memcpy(alphahat, a.data(), a.size() * sizeof(double));
+  std::memcpy(Vt, v.data(), v.size() * sizeof(double));
+  return BSSM_OK;
+}
+
 int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed,
                                   uint32_t stream0, uint32_t n_rep, double* loglik) {
   if (!loglik || n_rep < 1) return fail(BSSM_ERR_INVALID, "loglik NULL or n_rep < 1");

@@ -709,6 +709,27 @@ bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct)
   return lg_smoother_run(lg.m, g, alphahat, Vt, Ct, K.data(), v.data(), Fs.data());
 }
 
+// smoothed means and covariances of a linear-Gaussian model (ssm_ulg::smoother, src/model_ssm_ulg.cpp:307-417)
+bool gaussian_smoother(const HostModel& h, std::vector<double>* alphahat, std::vector<double>* Vt_out) {
+  if (!h.gaussian()) return false;
+  const int n = h.n, m = h.m;
+  const Sys S(h);
+  Approx ap;
+  ap.y = h.y;
+  ap.H.resize(n);
+  for (int t = 0; t < n; t++) ap.H[t] = h.H[t * h.Htv];
+  std::vector<Mat> at, Vt, Ct;
+  if (!smoother_ccov(S, ap, &at, &Vt, &Ct)) return false;
+  alphahat->assign((size_t)m * (n + 1), 0.0);
+  Vt_out->assign((size_t)m * m * (n + 1), 0.0);
+  bool ok = true;
+  for (int t = 0; t <= n; t++) {
+    for (int i = 0; i < m; i++) { (*alphahat)[i + (size_t)m * t] = at[t](i, 0); ok &= std::isfinite(at[t](i, 0)); }
+    for (int q = 0; q < m * m; q++) { (*Vt_out)[q + (size_t)m * m * t] = Vt[t].a[q]; ok &= std::isfinite(Vt[t].a[q]); }
+  }
+  return ok;
+}
+
 bool gaussian_smoothing_setup(const HostModel& h, PsiSetup* out) {
   if (!h.gaussian()) return false;
   const int n = h.n, m = h.m;

@@ -51,6 +51,8 @@ bool psi_setup(const HostModel& hm, const double* is_mode, PsiSetup* out, const 
 // exact smoothing factors of a linear-Gaussian (ssm_ulg family) model for gaussian_psi_smoother:
 // smoother_ccov + conditional_cov on the model itself (src/model_ssm_ulg.cpp:646-652)
 bool gaussian_smoothing_setup(const HostModel& hm, PsiSetup* out);
+// smoothed means m x (n+1) and covariances m x m x (n+1) of a linear-Gaussian model (host Kalman smoother)
+bool gaussian_smoother(const HostModel& hm, std::vector<double>* alphahat, std::vector<double>* Vt);
 // ---- two-phase psi set-up, so that the O(n m^3) smoother of MANY draws can run as one device batch
 // (lg_smoother.h; one GPU lane per draw).  *_begin does everything up to the smoother (approximation at the stored
 // mode, scales) and packs the approximating linear-Gaussian model; the caller runs the smoother (device batch or

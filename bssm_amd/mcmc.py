@@ -81,6 +81,25 @@ def approx_state_posterior(model: BssmModel, theta, modes, seed: int):
     return alpha
 
 
+def approx_state_summary(model: BssmModel, theta, modes, counts):
+    """approx_mcmc::approx_state_summary (src/approx_mcmc.cpp:1494-1520): Kalman smoother of the Gaussian approximation at
+    every stored (theta, mode), merged over the stored values with their counts.  Returns alphahat (n+1) x m, Vt."""
+    from .filters import _prep, _alloc
+    theta = np.atleast_2d(theta)
+    n, m, ns = model.n, model.m, theta.shape[0]
+    ah_i, vt_i = np.zeros((m, n + 1, ns), order="F"), np.zeros((m, m, n + 1, ns), order="F")
+    L = _lib.lib()
+    L.bssm_gaussian_smoother.argtypes = [C.POINTER(_lib.UngModel), _lib.c_double_p, _lib.c_double_p]
+    for i in range(ns):
+        g = approximating_gaussian_model(model, theta[i], modes[..., i])
+        arr, smod, keep = _prep(g, False)
+        a, v = _alloc((m, n + 1)), _alloc((m, m, n + 1))
+        _lib.check(L.bssm_gaussian_smoother(C.byref(smod), _lib.dptr(a), _lib.dptr(v)))
+        ah_i[:, :, i], vt_i[:, :, :, i] = a, v
+    alphahat, Vt = PC.is_merge(n, m, np.ones(ns), np.asarray(counts, dtype=np.uint32), ah_i, vt_i)
+    return np.ascontiguousarray(alphahat.T), Vt
+
+
 def _transformed(model: BssmModel):
     """names sampled on the log scale, R/run_mcmc.R:471-489"""
     names = list(model.get("theta_names", []))
@@ -245,6 +264,8 @@ def run_mcmc(model: BssmModel, iter: int, particles: int | None = None, output_t
         if mcmc_type == "approx" and otype == 1 and p == 1:
             # state draws of the purely approximate chain (nongaussian_is_mcmc with approx = TRUE, src/R_mcmc.cpp:397-404)
             res["alpha"] = approx_state_posterior(model, res["theta"], res["modes"], seed)
+        if mcmc_type == "approx" and otype == 2 and p == 1:
+            res["alphahat"], res["Vt"] = approx_state_summary(model, res["theta"], res["modes"], res["counts"])
         if mcmc_type != "approx":
             # IS correction of the stored values on the sampling scale, as nongaussian_is_mcmc does before run_mcmc.R
             # maps theta back (src/R_mcmc.cpp:376-392)

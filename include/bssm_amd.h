@@ -134,6 +134,11 @@ int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
  * distribution; model_type 1..3).  alpha: m x (n+1) x N. */
 int bssm_gaussian_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int model_type, double* alpha);
 
+/* host Kalman smoother of a linear-Gaussian model (ssm_ulg::smoother, src/model_ssm_ulg.cpp:307-417): alphahat m x (n+1),
+ * Vt m x m x (n+1).  Used by the state summary of the purely approximate chain (approx_mcmc::approx_state_summary,
+ * src/approx_mcmc.cpp:1494-1520), which smooths the Gaussian approximation at every stored value. */
+int bssm_gaussian_smoother(const bssm_ung_model* model, double* alphahat, double* Vt);
+
 /* replaces _bssm_nongaussian_loglik: `double nongaussian_loglik(model_, nsim, sampling_method, seed,
  * model_type)` src/R_loglik.cpp:41-87.  nsim = 0 returns the Gaussian-approximation log-likelihood
  * (src/model_ssm_ung.cpp:214-234). */

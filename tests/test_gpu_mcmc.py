@@ -459,3 +459,24 @@ def test_approx_chain_state_draws(oracle):
     # the draws scatter around the mode-implied signal: level + x'beta close to the stored mode on average
     lvl = out["alpha"][:-1, 0, :] + (np.asarray(model["xreg"]) @ out["theta"][:, -1:].T)
     assert np.mean(np.abs(lvl.mean(axis=1) - out["modes"][:, 0, :].mean(axis=1))) < 0.3
+
+
+def test_approx_chain_state_summary(oracle):
+    """output 'summary' of the purely approximate chain (approx_mcmc::approx_state_summary, src/approx_mcmc.cpp:1494-1520):
+    Kalman smoother of the Gaussian approximation at every stored value, merged with the counts as weights"""
+    model = _small("negbin")
+    out = mcmc.run_mcmc(model, 150, burnin=50, mcmc_type="approx", output_type="summary", seed=21)
+    n, m, ns = model.n, model.m, out["counts"].size
+    th = _sampling_scale(model, out["theta"])
+    w = out["counts"].astype(float)
+    ah, vt = np.zeros((m, n + 1, ns)), np.zeros((m, m, n + 1, ns))
+    for i in range(ns):
+        g = mcmc.approximating_gaussian_model(model, th[i], out["modes"][..., i])
+        ah[:, :, i], vt[:, :, :, i], _ = oracle.ulg_smoother(M.model_arrays(g))
+    mean = (ah * w).sum(axis=2) / w.sum()
+    V = (vt * w).sum(axis=3) / w.sum()
+    for t in range(n + 1):
+        d = ah[:, t, :] - mean[:, [t]]
+        V[:, :, t] += (d * w) @ d.T / w.sum()
+    assert np.allclose(out["alphahat"], mean.T, rtol=1e-8, atol=1e-10)
+    assert np.allclose(out["Vt"], V, rtol=1e-7, atol=1e-10)
