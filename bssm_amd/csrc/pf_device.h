@@ -87,9 +87,9 @@ __device__ __forceinline__ double sqrt_small(double x) {
 // Box-Muller pair from one Philox block
 __device__ __forceinline__ void box_muller(const u32x4& w, double& z0, double& z1) {
   const double u1 = (u53_to_double(w.x >> 5, w.y >> 6) + 1.0) * 0x1.0p-53;  // (0,1]
-  const double rad = sqrt_small(-2.0 * fast_log<false>(u1));
+  const double rad = sqrt_small(-2.0 * tl_log<false>(u1));
   double sn, cs;
-  fast_sincos_2pi(w.z, sn, cs);  // angle 2*pi*w2*2^-32
+  tl_sincos_2pi(w.z, sn, cs);  // angle 2*pi*w2*2^-32
   z0 = rad * cs;
   z1 = rad * sn;
 }
@@ -170,11 +170,11 @@ __device__ __forceinline__ double wave_sum(double v) { return lane_broadcast(wav
 __device__ __forceinline__ double log_obs_density(int dist, const double* __restrict__ ob, double phi, double s) {
   const double y = ob[OB_Y];
   switch (dist) {
-    case DIST_SVM: return -0.5 * (s + ob[OB_AUX] * fast_exp(-s));
-    case DIST_POISSON: return y * s - ob[OB_U] * fast_exp(s);
-    case DIST_BINOMIAL: return y * s - ob[OB_U] * log1p(fast_exp(s));
-    case DIST_NEGBIN: return y * s - ob[OB_AUX] * fast_log(phi + ob[OB_U] * fast_exp(s));
-    case DIST_GAMMA: return -phi * (s + ob[OB_AUX] * fast_exp(-s));
+    case DIST_SVM: return -0.5 * (s + ob[OB_AUX] * tl_exp(-s));
+    case DIST_POISSON: return y * s - ob[OB_U] * tl_exp(s);
+    case DIST_BINOMIAL: return y * s - ob[OB_U] * log1p(tl_exp(s));
+    case DIST_NEGBIN: return y * s - ob[OB_AUX] * tl_log(phi + ob[OB_U] * tl_exp(s));
+    case DIST_GAMMA: return -phi * (s + ob[OB_AUX] * tl_exp(-s));
     case DIST_GAUSSIAN: { const double r = y - s; return -0.5 * r * r * ob[OB_AUX]; }
   }
   return 0.0;

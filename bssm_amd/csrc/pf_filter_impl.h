@@ -184,6 +184,7 @@ constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the
 template <int MP, int KP, int PPT, bool FN = false, int NTB = WG_NT_MAX>
 __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  math_tab_init();
   const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = NT >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Ncap = NT * PPT, N = b.N, n = b.n, f = blockIdx.x;
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
-      const double e = (i < N) ? fast_exp(w[r] - M) : 0.0;
+      const double e = (i < N) ? tl_exp(w[r] - M) : 0.0;
       sc[r] = wave_scan_incl(e);
       if (lane == 63) s_tot[r * nw + wave] = sc[r];
       if (b.weights && i < N) b.weights[((size_t)f * (n + 1) + t) * N + i] = e;
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       if (tid == 0) b.dead_at[f] = t + 1;
       break;
     }
-    loglik += M + fast_log(S / dN);                       // :683
+    loglik += M + tl_log(S / dN);                       // :683
     if (t == n) break;
     lds_barrier();  // (3) cdf visible
 
@@ -525,6 +526,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
   }
   const int pb = lin % B, f = ws.f0 + lin / B;
   const int N = b.N, n = b.n, m = b.m;
+  const MathTabRegs mtab = math_tab_load_begin256();  // lands in LDS before the first barrier below
   BSSM_STAMP(0)
 
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
@@ -542,6 +544,8 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
   double aprev[FN ? PPT : 1][MP];  // ancestors, needed by the ssm_nlg psi weights
 
   if (t < 0) {
+    math_tab_load_end256(mtab);
+    lds_barrier();
     const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
@@ -573,8 +577,9 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
         wt_old[r] = (li < len) ? b.weights[((size_t)f * (n + 1) + t) * N + base + li] : 0.0;
       }
     }
+    math_tab_load_end256(mtab);
     // ... and draw this step's random numbers while they are in flight (PPT <= 2 keeps them in registers)
-    constexpr bool kEarlyRng = PPT <= 2 && !FN;
+    constexpr bool kEarlyRng = false;  // (was PPT <= 2 && !FN: the normals now need the LDS tables, published by the barrier below)
     double u_pre[kEarlyRng ? PPT : 1], z_pre[kEarlyRng ? PPT : 1][KP];
     if constexpr (kEarlyRng) {
 #pragma unroll
@@ -596,7 +601,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
     lds_barrier();
     const double M = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
     if (wave_has_partials) {
-      const double scale = (tid < B) ? fast_exp(pmax - M) : 0.0;
+      const double scale = (tid < B) ? tl_exp(pmax - M) : 0.0;
       const double ss = psum * scale;
       double qi = wave_scan_incl(ss);
       if (lane == 63) s_red[4 + wave] = qi;
@@ -634,7 +639,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
       return;
     }
     if (pb == B - 1 && tid == GRID_NT - 1) {  // single writer, store-only: summed in time order afterwards
-      ws.llinc[(size_t)f * (n + 1) + t] = M + fast_log(S / (double)N);  // src/model_ssm_ung.cpp:683
+      ws.llinc[(size_t)f * (n + 1) + t] = M + tl_log(S / (double)N);  // src/model_ssm_ung.cpp:683
     }
     BSSM_STAMP(2)
     // ---- resample + gather + propagate
@@ -762,7 +767,11 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
 #pragma unroll
           for (int c = 0; c < MP; c++) aprev[r][c] = a[c];
         } else if constexpr (kMfma) {
-          if constexpr (MP == 8) propagate_mfma8<KP>(mt, a, z_pre[r], x[r], s_tile + wave * (16 * 64), lane);
+          if constexpr (MP == 8) {
+            double z[KP];
+            rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+            propagate_mfma8<KP>(mt, a, z, x[r], s_tile + wave * (16 * 64), lane);
+          }
         } else if constexpr (kEarlyRng) {
           propagate<MP, KP>(mt, a, z_pre[r], x[r]);
         } else {
@@ -799,7 +808,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
-    e[r] = (li < len) ? fast_exp(w[r] - Mb) : 0.0;
+    e[r] = (li < len) ? tl_exp(w[r] - Mb) : 0.0;
     if (b.weights && li < len) b.weights[((size_t)f * (n + 1) + tn) * N + base + li] = e[r];  // block-scaled; rescaled by launch tn
   }
   BSSM_STAMP(9)

@@ -37,9 +37,9 @@ __device__ __forceinline__ void nlg_T_fn(int id, const double* __restrict__ fp, 
   switch (id) {
     case FN_NLG_GROWTH: {  // R/cpp_example_models.R:415-428
       const double dT = fp[FP_KNOWN + 0], K = fp[FP_KNOWN + 1];
-      const double ea = fast_exp(a[0]);
+      const double ea = tl_exp(a[0]);
       const double r = ea / (1.0 + ea);
-      const double e = fast_exp(r * dT);
+      const double e = tl_exp(r * dT);
       x[0] = a[0];
       if constexpr (MP > 1) x[1] = K * a[1] * e / (K + a[1] * (e - 1.0));
     } break;
@@ -59,7 +59,7 @@ __device__ __forceinline__ double nlg_Z_fn(int id, const double* __restrict__ fp
 #endif
     case FN_NLG_GROWTH: return MP > 1 ? x[MP > 1 ? 1 : 0] : x[0];  // second state (:393-400)
     case FN_NLG_AR_EXP:
-    case FN_NLG_SIN_EXP: return fast_exp(x[0]);
+    case FN_NLG_SIN_EXP: return tl_exp(x[0]);
     default: return x[0];
   }
 }
@@ -69,7 +69,7 @@ __device__ __forceinline__ double sde_drift(int id, const double* __restrict__ f
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
   if (id == FN_USER_SDE) return bssm_user_drift(x, fp + FP_THETA);
 #endif
-  return id == FN_SDE_GBM ? fp[FP_THETA + 0] * x : fast_exp(fp[FP_THETA + 0]) * (fp[FP_THETA + 1] - x);
+  return id == FN_SDE_GBM ? fp[FP_THETA + 0] * x : tl_exp(fp[FP_THETA + 0]) * (fp[FP_THETA + 1] - x);
 }
 __device__ __forceinline__ double sde_diffusion(int id, const double* __restrict__ fp, double x) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
@@ -154,10 +154,10 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
   if (id == FN_USER_SDE) return bssm_user_log_obs(y, x[0], fp + FP_THETA);
 #endif
   if (id == FN_SDE_POISSON_OU) {  // R::dpois(y, exp(x), log): y x - e^x - lgamma(y + 1) (host puts lgamma in OB_AUX)
-    return y * x[0] - fast_exp(x[0]) - ob[OB_AUX];
+    return y * x[0] - tl_exp(x[0]) - ob[OB_AUX];
   }
   // normalised Gaussian log-density (dmvnorm(..., lwr = true, logd = true), src/dmvnorm.cpp:10-13)
-  const double mu = id == FN_SDE_GBM ? fast_log(x[0]) : nlg_Z_fn<MP>(id, fp, x);
+  const double mu = id == FN_SDE_GBM ? tl_log(x[0]) : nlg_Z_fn<MP>(id, fp, x);
   const double q = (y - mu) / fp[FP_H];
   return fp[FP_LOGC] - 0.5 * q * q;
 }
@@ -215,7 +215,7 @@ __device__ __forceinline__ void nlg_Z_gn(int id, const double* __restrict__ fp, 
 #endif
     case FN_NLG_GROWTH: if constexpr (MP > 1) Zg[1] = 1.0; break;
     case FN_NLG_AR_EXP:
-    case FN_NLG_SIN_EXP: Zg[0] = fast_exp(x[0]); break;
+    case FN_NLG_SIN_EXP: Zg[0] = tl_exp(x[0]); break;
     default: Zg[0] = 1.0; break;
   }
 }
@@ -247,7 +247,7 @@ __device__ __forceinline__ double dmvnorm_cov_small(const double (&x)[MP], const
   const double l2pi = 1.8378770664093453;  // log(2 pi)
   if constexpr (MP == 1) {
     const double d = x[0] - mean[0];
-    return -0.5 * (l2pi + fast_log(S[0]) + d * d / S[0]);
+    return -0.5 * (l2pi + tl_log(S[0]) + d * d / S[0]);
   } else {
     const double eps = 2.220446049250313e-16;
     const bool n0 = S[0] > eps, n1 = S[3] > eps;
@@ -255,10 +255,10 @@ __device__ __forceinline__ double dmvnorm_cov_small(const double (&x)[MP], const
     if (n0 && n1) {
       const double l00 = sqrt(S[0]), l10 = S[1] / l00, l11 = sqrt(S[3] - l10 * l10);
       const double w0 = z0 / l00, w1 = (z1 - l10 * w0) / l11;
-      return -fast_log(l00) - fast_log(l11) - l2pi - 0.5 * (w0 * w0 + w1 * w1);
+      return -tl_log(l00) - tl_log(l11) - l2pi - 0.5 * (w0 * w0 + w1 * w1);
     } else if (n0 || n1) {
       const double v = n0 ? S[0] : S[3], z = n0 ? z0 : z1, l = sqrt(v), w = z / l;
-      return -fast_log(l) - 0.5 * l2pi - 0.5 * w * w;
+      return -tl_log(l) - 0.5 * l2pi - 0.5 * w * w;
     }
     return 0.0;
   }
@@ -268,7 +268,7 @@ template <int MP>
 __device__ __forceinline__ double dmvnorm_lwr_small(const double (&x)[MP], const double (&mean)[MP], const double (&L)[MP * MP]) {
   if constexpr (MP == 1) {
     const double q = (x[0] - mean[0]) / L[0];
-    return -0.5 * (1.8378770664093453 + 2.0 * fast_log(L[0]) + q * q);
+    return -0.5 * (1.8378770664093453 + 2.0 * tl_log(L[0]) + q * q);
   } else {
     double S[MP * MP];
 #pragma unroll

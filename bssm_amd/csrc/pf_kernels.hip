@@ -105,6 +105,7 @@ hipError_t launch_zero_dead_tail(const FilterBatch& b, bool weights_too, hipStre
 // resampling, so one lane walks one trajectory.  `mats` rows hold (C_{t+1}, V_{t+1}, alphahat_{t+1} - C_{t+1} alphahat_t).
 __global__ void __launch_bounds__(256) sim_smoother_kernel(const double* __restrict__ mats, const double* __restrict__ init,
                                                            double* __restrict__ hist, int n, int m, int N, uint32_t seed) {
+  math_tab_init();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const RngKey key{seed, 0u};
@@ -137,14 +138,21 @@ hipError_t launch_sim_smoother(const double* mats, const double* init, double* h
 
 // test hook: evaluate the kernels' elementary functions on an array (see tests/test_gpu_math.py)
 __global__ void debug_math_kernel(int fn, const double* __restrict__ in, double* __restrict__ out, int n) {
+  math_tab_init();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double x = in[i];
-  if (fn == 0) out[i] = fast_exp(x);
-  else if (fn == 1) out[i] = fast_log(x);
+  if (fn == 0) out[i] = tl_exp(x);
+  else if (fn == 1) out[i] = tl_log(x);
   else if (fn == 2) {
     double sn, cs;
-    fast_sincos_2pi((uint32_t)(x * 0x1.0p32), sn, cs);  // x in [0,1), a multiple of 2^-32
+    tl_sincos_2pi((uint32_t)(x * 0x1.0p32), sn, cs);  // x in [0,1), a multiple of 2^-32
+    out[2 * i] = sn; out[2 * i + 1] = cs;
+  } else if (fn == 10) out[i] = fast_exp(x);  // the polynomial forms of round 1, kept for comparison
+  else if (fn == 11) out[i] = fast_log(x);
+  else if (fn == 12) {
+    double sn, cs;
+    fast_sincos_2pi((uint32_t)(x * 0x1.0p32), sn, cs);
     out[2 * i] = sn; out[2 * i + 1] = cs;
   } else if (fn == 3) {  // Box-Muller pair for Philox key (seed = 1, stream = 0), counter (i, 0, 0, purpose 2)
     double z0, z1;

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pf_math_tables.h"
+
 namespace bssm {
 
 #ifndef BSSM_FAST_MATH
@@ -122,6 +124,113 @@ __device__ __forceinline__ void fast_sincos_2pi(uint32_t a, double& sn, double& 
 #else
   sincos(2.0 * 3.14159265358979323846 * ((double)a * 0x1.0p-32), &sn, &cs);
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Table-driven versions (round 2).  The polynomial forms above spend 25-45 fp64 instructions per call and a quarter-rate
+// v_rcp_f64; measured issue costs on gfx950 (scripts/ubench/valu_rates.hip): every fp64 / VOP3 instruction 4.4-4.7
+// cycles per wave, plain 32-bit VOP2 2.6, v_rcp/v_rsq/v_sqrt_f64 16.4.  With a 6.5 KB table set in LDS (one
+// ds_read_b128 / b64 per call, on the LDS pipe, not the VALU) the reduced argument is small enough for a degree 4-7
+// polynomial: log 19, exp 20, sincos 21 instructions, no reciprocal.  <= 1.5 ulp (tests/test_gpu_math.py).
+//
+// The tables live in LDS: a kernel calls math_tab_init() once (all threads, before the first use; it ends with a
+// workgroup barrier); device code then reaches them through math_tab().
+static __device__ const double g_math_tab[kMathTabDoubles] __attribute__((aligned(16))) = {BSSM_MATH_TABLE_VALUES};
+
+__device__ __forceinline__ double* math_tab() {
+  __shared__ __attribute__((aligned(16))) double s_math_tab[kMathTabDoubles];
+  return s_math_tab;
+}
+__device__ __forceinline__ void math_tab_init() {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2* dst = (d2*)math_tab();
+  const d2* src = (const d2*)g_math_tab;
+  for (int q = threadIdx.x; q < kMathTabDoubles / 2; q += blockDim.x) dst[q] = src[q];
+  __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// split form for 256-thread kernels: issue the global loads first (begin), store them to LDS later (end), so that the
+// round trip overlaps whatever the kernel loads next; the caller's next workgroup barrier publishes the table
+struct MathTabRegs { double v[4]; };
+__device__ __forceinline__ MathTabRegs math_tab_load_begin256() {
+  static_assert(kMathTabDoubles <= 4 * 256, "table does not fit two 16-byte loads per thread");
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2* src = (const d2*)g_math_tab;
+  const int q0 = threadIdx.x, q1 = threadIdx.x + 256;
+  const d2 a = src[q0];
+  const d2 b = src[q1 < kMathTabDoubles / 2 ? q1 : q0];
+  return MathTabRegs{{a.x, a.y, b.x, b.y}};
+}
+__device__ __forceinline__ void math_tab_load_end256(const MathTabRegs& r) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2* dst = (d2*)math_tab();
+  dst[threadIdx.x] = d2{r.v[0], r.v[1]};
+  if (threadIdx.x + 256 < kMathTabDoubles / 2) dst[threadIdx.x + 256] = d2{r.v[2], r.v[3]};
+}
+
+__device__ __forceinline__ uint32_t dbl_hi(double x) { return (uint32_t)__double2hiint(x); }
+__device__ __forceinline__ uint32_t dbl_lo(double x) { return (uint32_t)__double2loint(x); }
+
+// natural log.  x = 2^k z with z in [0.6865, 1.373); interval i of the table (uniform in the bits of z, 7 index bits)
+// has centre c_i, invc ~ 1/c_i, logc = -log(invc); r = z invc - 1 (one fma), |r| < 2^-7.9;
+// log x = k ln2 + logc + log1p(r), log1p by its Taylor polynomial to degree 7 (Estrin).  z = 1 is the centre of its
+// interval with invc = 1, logc = 0 exactly, so results near 0 keep full relative accuracy.
+template <bool CHECKED = true>
+__device__ __forceinline__ double tl_log(double x) {
+  const uint32_t hx = dbl_hi(x);
+  if constexpr (CHECKED) {  // zero, negative, subnormal, inf, nan: the library routine
+    if (__builtin_expect(hx - 0x00100000u >= 0x7FE00000u, 0)) return log(x);
+  }
+  const uint32_t tmp = hx - 0x3FE5F000u;
+  const int k = (int)tmp >> 20;
+  const uint32_t i2 = (tmp >> 9) & 0x7F0u;  // byte offset of entry i = (tmp >> 13) & 127 (16 bytes each)
+  const double z = __hiloint2double((int)(hx - (tmp & 0xFFF00000u)), (int)dbl_lo(x));
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2 e = *(const d2*)((const char*)(math_tab() + kMathTabLog) + i2);
+  const double r = __builtin_fma(z, e.x, -1.0);
+  const double kd = (double)k;
+  const double w = __builtin_fma(kd, 6.93147180369123816490e-01, e.y);
+  const double r2 = r * r;
+  const double a = __builtin_fma(r, 3.33333333333333333e-01, -0.5);
+  const double b = __builtin_fma(r, 0.2, -0.25);
+  const double c = __builtin_fma(r, 1.42857142857142857e-01, -1.66666666666666667e-01);
+  const double q = __builtin_fma(r2, __builtin_fma(r2, c, b), a);
+  double t = __builtin_fma(kd, 1.90821492927058770002e-10, r);
+  t = __builtin_fma(r2, q, t);
+  return w + t;
+}
+
+// e^x for any double (overflow -> inf, underflow -> 0, NaN -> NaN): x = (64 e + j) ln2/64 + r, |r| <= ln2/128,
+// e^x = 2^e * T[j] * (1 + expm1(r)), expm1 by its Taylor polynomial to degree 5
+__device__ __forceinline__ double tl_exp(double x) {
+  const double xc = fmin(fmax(x, -800.0), 800.0);
+  const double kd = __builtin_rint(xc * 9.23324826168936567e+01);                // 64 / ln2
+  double r = __builtin_fma(-kd, 1.08304246932675596327e-02, xc);                 // ln2_hi / 64: 32 significant bits, exact product
+  r = __builtin_fma(-kd, 2.98158582698529328128e-12, r);                         // ln2_lo / 64
+  const int ki = (int)kd;
+  const double T = math_tab()[kMathTabExp + (ki & 63)];
+  const double r2 = r * r;
+  double q = __builtin_fma(r, 8.33333333333333333e-03, 4.16666666666666667e-02);
+  q = __builtin_fma(r, q, 1.66666666666666667e-01);
+  q = __builtin_fma(r, q, 0.5);
+  const double p = __builtin_fma(r2, q, r);
+  const double res = __builtin_amdgcn_ldexp(__builtin_fma(T, p, T), ki >> 6);
+  return x != x ? x : res;
+}
+
+// sin and cos of 2*pi*a*2^-32: the top 8 bits select one of 256 tabulated angles (interval centres), the low 24 bits
+// are the signed offset d from it, |d| <= 2*pi/512; sin/cos(centre + d) by the addition formulas with short Taylor
+// polynomials for sin d and cos d - 1
+__device__ __forceinline__ void tl_sincos_2pi(uint32_t a, double& sn, double& cs) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2 e = *(const d2*)((const char*)(math_tab() + kMathTabSin) + ((a >> 20) & 0xFF0u));
+  const int d256 = (int)((a << 8) ^ 0x80000000u);                                // 256 * (low 24 bits - 2^23), exact
+  const double d = (double)d256 * (6.283185307179586476925 * 0x1.0p-40);
+  const double z = d * d;
+  const double sd = __builtin_fma(d * z, __builtin_fma(z, __builtin_fma(z, -1.98412698412698413e-04, 8.33333333333333333e-03),
+                                                       -1.66666666666666667e-01), d);
+  const double cm = z * __builtin_fma(z, __builtin_fma(z, -1.38888888888888889e-03, 4.16666666666666667e-02), -0.5);
+  sn = e.x + __builtin_fma(e.y, sd, e.x * cm);
+  cs = e.y + __builtin_fma(-e.x, sd, e.y * cm);
 }
 
 }  // namespace bssm

@@ -41,7 +41,9 @@ def test_fast_log():
     with np.errstate(divide="ignore"):
         ref = np.log(x)
     fin = np.isfinite(ref) & (ref != 0)
-    assert _ulps(got[fin], ref[fin]).max() <= 2.0
+    # table-driven log: <= 1 ulp except next to the interval around 1 (x just below 1 - 2^-9), where log c and r cancel
+    # to half their size: 2.1 ulp worst case (scripts/ubench/math_check.cpp)
+    assert _ulps(got[fin], ref[fin]).max() <= 2.5
     assert got[x == 1.0][0] == 0.0 and got[-2] == np.inf and got[-1] == -np.inf
     assert np.isnan(_run(1, np.array([-1.0]))[0])
 
