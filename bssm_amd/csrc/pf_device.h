@@ -25,6 +25,20 @@ enum { DIST_SVM = 0, DIST_POISSON = 1, DIST_BINOMIAL = 2, DIST_NEGBIN = 3, DIST_
 // RNG purposes (1 is retired: the resampling uniform rides in the step block, see rng_step_block)
 enum { RNG_INIT = 0, RNG_RESAMPLE = 1, RNG_TRANSITION = 2, RNG_PICK = 3, RNG_SDE = 4 };
 
+// Read-only model tables (T_t, R_t, C_t, observation rows, initial moments) are wave-uniform: loaded with s_load they cost
+// no vector-memory instruction and no VGPR.  The compiler only scalarises a load it can prove unclobbered, and every
+// load after the kernel's first global store fails that test, so such pointers are re-typed to the constant address
+// space (same addresses; tells the compiler the memory is not written while the kernel runs -- true for these tables).
+// Second obstacle: gfx950 has no scalar 64-bit multiply, so `base + (size_t)f * stride` of wave-uniform operands is
+// evaluated on the VALU and the (uniform) address stays in VGPRs -- again vector loads.  v_readfirstlane on the two
+// halves of the pointer moves it to SGPRs.
+typedef __attribute__((address_space(4))) const double cdbl;
+__device__ __forceinline__ const cdbl* as_uniform_table(const double* p) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (const cdbl*)(((uint64_t)hi << 32) | lo);
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 struct u32x4 { uint32_t x, y, z, w; };
 

@@ -90,12 +90,12 @@ __device__ __forceinline__ double log_weight_of(const FilterBatch& b, const doub
 
 // alpha_{t+1} = C_t + T_t a + R_t eta   (src/model_ssm_ung.cpp:663-670); for the psi-APF the host
 // folds alphahat/Ct/Vt into the same three operands (src/model_ssm_ung.cpp:585-586).
-template <int MP, int KP>
-__device__ __forceinline__ void propagate(const double* mt, const double (&a)[MP], const double (&z)[KP],
+template <int MP, int KP, class PT>
+__device__ __forceinline__ void propagate(PT mt, const double (&a)[MP], const double (&z)[KP],
                                           double (&x)[MP]) {
-  const double* Tm = mt;
-  const double* Rm = mt + MP * MP;
-  const double* Cv = mt + MP * MP + MP * KP;
+  const PT Tm = mt;
+  const PT Rm = mt + MP * MP;
+  const PT Cv = mt + MP * MP + MP * KP;
 #pragma unroll
   for (int j = 0; j < MP; j++) {
     double s = 0.0, q = 0.0;
@@ -107,8 +107,8 @@ __device__ __forceinline__ void propagate(const double* mt, const double (&a)[MP
   }
 }
 
-template <int MP>
-__device__ __forceinline__ void initial_state(const double* __restrict__ ini, const double (&z)[MP], double (&x)[MP]) {
+template <int MP, class PT>
+__device__ __forceinline__ void initial_state(PT ini, const double (&z)[MP], double (&x)[MP]) {
   // a1 + L u   (src/model_ssm_ung.cpp:626; psi: alphahat_0 + V_0 u, :543)
 #pragma unroll
   for (int j = 0; j < MP; j++) {
@@ -832,10 +832,15 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
   BSSM_STAMP(11)
 }
 
+}  // namespace bssm
+#include "pf_grid_v2.h"
+namespace bssm {
+
 template <int MP, int KP>
 hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   const int ppt = ws.chunk / GRID_NT;
   void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
+  void (*kern_init)(const FilterBatch, const GridWorkspace) = nullptr;  // round-2 kernels: the step t = -1 has its own
 #ifndef BSSM_USER_MODEL
   switch (ppt) {
     case 1: kern = pf_grid_step<MP, KP, 1>; break;
@@ -857,6 +862,20 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
       return hipErrorInvalidValue;
     }
   }
+#ifndef BSSM_USER_MODEL
+  // round-2 step kernel (pf_grid_v2.h): linear-state models with one observation series, at most 64 particle blocks
+  if constexpr (MP <= 4) {
+    bool v2 = !b.fpar && b.p == 1 && ws.B <= 64 && ppt <= 4 && !ws.dbg;
+    if (const char* env = std::getenv("BSSM_AMD_GRID_V2")) v2 = v2 && env[0] != '0';
+    if (v2) {
+      switch (ppt) {
+        case 1: kern = pf_grid_step_v2<MP, KP, 1>; kern_init = pf_grid_init_v2<MP, 1>; break;
+        case 2: kern = pf_grid_step_v2<MP, KP, 2>; kern_init = pf_grid_init_v2<MP, 2>; break;
+        default: kern = pf_grid_step_v2<MP, KP, 4>; kern_init = pf_grid_init_v2<MP, 4>; break;
+      }
+    }
+  }
+#endif
   if (!kern) return hipErrorInvalidValue;
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
@@ -884,9 +903,13 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   }
   if (const char* env = std::getenv("BSSM_AMD_XCD_REMAP")) { wsp[0].xcd_remap = wsp[1].xcd_remap = std::atoi(env); }
   if (timing) timing->concurrent = parts;
+  auto step = [&](int q, int t) {
+    if (t < 0 && kern_init) hipLaunchKernelGGL(kern_init, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q]);
+    else hipLaunchKernelGGL(kern, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q], t);
+  };
   if (!timing || timing->every <= 0) {
     for (int t = -1; t < b.n; t++)
-      for (int q = 0; q < parts; q++) hipLaunchKernelGGL(kern, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q], t);
+      for (int q = 0; q < parts; q++) step(q, t);
   } else {
     // windows of kWin consecutive step launches (of the first sequence) bracketed by one event pair each: the event
     // overhead (a few us) is amortised over the window, so total/count is the per-launch kernel cadence
@@ -902,7 +925,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
         (void)hipEventRecord(ev[2 * ns], lanes[0]);
         open_t = t;
       }
-      for (int q = 0; q < parts; q++) hipLaunchKernelGGL(kern, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q], t);
+      for (int q = 0; q < parts; q++) step(q, t);
       if (open_t >= 0 && t == open_t + kWin - 1) {
         (void)hipEventRecord(ev[2 * ns + 1], lanes[0]);
         ns++;

@@ -1,0 +1,418 @@
+// pf_grid_v2.h -- round-2 step kernel of the multi-workgroup filter (univariate-observation, linear-state models:
+// ssm_ung / bsm_ng / svm / ar1_ng / ssm_ulg, bootstrap and psi-APF; src/model_ssm_ung.cpp:511-712).
+//
+// Same exchange between launches as pf_grid_step (block-local scans `lcdf`, row ends `coarse`, (max, sum) partials; the
+// kernel boundary is the grid-wide synchronisation) and the same random stream, so results are interchangeable.
+// What changed, and why (PMC of round 1: a wave executes VALU during only ~21 % of its lifetime, the launch pair is
+// VALU-busy 66 %: the step is bound by its dependent chain -- 7 workgroup barriers and, per particle of a lane, three
+// dependent global round trips -- as much as by instruction count):
+//   * the partial combine is WAVE-LOCAL: a filter has at most 64 particle blocks here, so every wave keeps one block
+//     prefix per lane in registers (max via DPP, one exp, one DPP scan) -- no LDS exchange, no barrier; the source block of
+//     a wave's slots comes from two ballots, its prefix and scale from v_readlane;
+//   * block statistics use the WAVE maximum for the exponentials and rescale by exp(max_wave - max_block) after a single
+//     exchange: one barrier for max + scan instead of three;  => 2 barriers per launch (+ the table publish) instead of 7;
+//   * the particles of a lane go through the search PHASE BY PHASE (all coarse-row loads, then all window loads, then all
+//     ancestor gathers), each phase's loads in flight together: 3 dependent global rounds per wave-step instead of 3 per
+//     particle;  every particle row has its own LDS window, so no wave-level fences serialise them;
+//   * one generic search (`v2_search_generic`, a loop over the source blocks a wave's slots touch and over 128-entry
+//     windows of their local scans) replaces the unrolled 16-ary per-lane fallbacks: a wave that straddles a block
+//     boundary, a ragged wave or a wide window costs a second trip through the same cooperative code;
+//   * the observation density is selected by a wave-uniform switch OUTSIDE the particle loop (one density body runs);
+//   * table-driven log / exp / sincos (pf_math.h).
+#pragma once
+
+namespace bssm {
+
+constexpr int V2_WIN = 128;  // entries of a source block's local scan staged per (wave, particle row)
+
+// number of entries of sw[0, wlen) below vp (entries non-decreasing), wlen <= 128; exact when STEPS = 8, min(count, 127)
+// when STEPS = 7
+template <int STEPS>
+__device__ __forceinline__ int v2_count_below(const double* sw, int wlen, double vp) {
+  int lo = 0;
+#pragma unroll
+  for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
+    const int idx = lo + step - 1;
+    if (idx < wlen && sw[idx] < vp) lo += step;
+  }
+  return lo;
+}
+
+// Ancestor of the wave's active slots (a prefix of its lanes), any shape: loops over the source blocks the slots fall
+// into and over 128-entry windows of each block's local scan.  Every loop bound is wave-uniform.
+//   Q / iscale: this lane's block prefix (inclusive, scaled) and 1 / scale of block `lane`
+template <int PPT>
+__device__ __forceinline__ int v2_search_generic(const double v, const bool act, const double Q, const double iscale, const int B,
+                                                 const int N, const double* __restrict__ coarse, const double* __restrict__ lcdf,
+                                                 double* sw, const int lane) {
+  constexpr int chunk = GRID_NT * PPT, crow = chunk / 16;
+  const unsigned long long amask = __builtin_amdgcn_ballot_w64(act);
+  if (amask == 0ull) return 0;
+  const int l_last = 63 - __builtin_clzll(amask);
+  const double v_lo = lane_broadcast(v, 0), v_hi = lane_broadcast(v, l_last);
+  int c_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_lo));
+  int c_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_hi));
+  c_lo = min(c_lo, B - 1); c_hi = min(c_hi, B - 1);
+  int sb = c_lo;
+  for (int e = c_lo; e < c_hi; e++) sb += (lane_broadcast(Q, e) < v) ? 1 : 0;
+  int anc = 0;
+  for (int e = c_lo; e <= c_hi; e++) {
+    const bool mine = act && sb == e;
+    const unsigned long long mm = __builtin_amdgcn_ballot_w64(mine);
+    if (mm == 0ull) continue;
+    const int f0 = __builtin_ctzll(mm), f1 = 63 - __builtin_clzll(mm);
+    const double Pm1 = e > 0 ? lane_broadcast(Q, e - 1) : 0.0;
+    const double vp = (v - Pm1) * lane_broadcast(iscale, e);
+    const double vp_lo = lane_broadcast(vp, f0), vp_hi = lane_broadcast(vp, f1);
+    const int slen = min(chunk, N - e * chunk), ncr = (slen + 15) >> 4;
+    const double cv = coarse[(size_t)e * crow + (lane < ncr ? lane : ncr - 1)];
+    const int k_lo = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv < vp_lo)), ncr - 1);
+    const int k_hi = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv < vp_hi)), ncr - 1);
+    const int wend = min(16 * (k_hi + 1), slen);
+    const double* __restrict__ src = lcdf + (size_t)e * chunk;
+    int pos = 16 * k_lo;
+    for (int w0 = 16 * k_lo; w0 < wend; w0 += V2_WIN) {
+      const int wlen = min(V2_WIN, wend - w0);
+      __builtin_amdgcn_wave_barrier();  // the previous window's reads are done (same wave, LDS is in order)
+      sw[lane] = src[w0 + (lane < wlen ? lane : wlen - 1)];
+      sw[lane + 64] = src[w0 + (lane + 64 < wlen ? lane + 64 : wlen - 1)];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      pos += v2_count_below<8>(sw, wlen, vp);
+    }
+    if (mine) anc = e * chunk + min(pos, slen - 1);
+  }
+  return anc;
+}
+
+// unnormalised log-density of the observation given the signals of a lane's PPT particles; the distribution is
+// wave-uniform, so ONE body runs (src/model_ssm_ung.cpp:447-493; gaussian: src/model_ssm_ulg.cpp:582-586)
+template <int PPT>
+__device__ __forceinline__ void v2_log_weights(const cdbl* row, const bool psi, const double (&s)[PPT], double (&w)[PPT]) {
+  const cdbl* ob = row + ROW_HDR;
+  const int dist = (int)ob[OB_DIST];
+  const double y = ob[OB_Y], u = ob[OB_U], aux = ob[OB_AUX], phi = ob[OB_PHI];
+  switch (dist) {
+    case DIST_SVM:
+#pragma unroll
+      for (int r = 0; r < PPT; r++) { w[r] = -0.5 * (s[r] + aux * tl_exp(-s[r])); __builtin_amdgcn_sched_barrier(0); }
+      break;
+    case DIST_POISSON:
+#pragma unroll
+      for (int r = 0; r < PPT; r++) { w[r] = y * s[r] - u * tl_exp(s[r]); __builtin_amdgcn_sched_barrier(0); }
+      break;
+    case DIST_BINOMIAL:
+#pragma unroll
+      for (int r = 0; r < PPT; r++) { w[r] = y * s[r] - u * log1p(tl_exp(s[r])); __builtin_amdgcn_sched_barrier(0); }
+      break;
+    case DIST_NEGBIN:
+#pragma unroll
+      for (int r = 0; r < PPT; r++) { w[r] = y * s[r] - aux * tl_log(phi + u * tl_exp(s[r])); __builtin_amdgcn_sched_barrier(0); }
+      break;
+    case DIST_GAMMA:
+#pragma unroll
+      for (int r = 0; r < PPT; r++) { w[r] = -phi * (s[r] + aux * tl_exp(-s[r])); __builtin_amdgcn_sched_barrier(0); }
+      break;
+    default:  // DIST_GAUSSIAN
+#pragma unroll
+      for (int r = 0; r < PPT; r++) { const double d = y - s[r]; w[r] = -0.5 * d * d * aux; }
+      break;
+  }
+  if (psi) {  // psi-APF weight: minus the approximating Gaussian density and scales_t (src/model_ssm_ung.cpp:385-439, :550, :590)
+    const double py = ob[OB_PSIY], pih = ob[OB_PSIIH], rs = row[RH_SCALE];
+#pragma unroll
+    for (int r = 0; r < PPT; r++) { const double q = (py - s[r]) * pih; w[r] = __builtin_fma(0.5 * q, q, w[r]) - rs; }
+  }
+}
+
+// Block statistics of the new weights and their hand-over to the next launch: block-local inclusive scan of
+// exp(w - max_b) (`lcdf`), row ends (`coarse`), (max_b, sum_b) (`partials`); optional block-scaled weights output.
+// One workgroup barrier.  s_x: 4 + 4 * PPT doubles of LDS.
+template <int PPT>
+__device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridWorkspace& ws, const int f, const int pb, const int base,
+                                               const int len, const int tn, const double (&w)[PPT], double* s_x) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = b.N, n = b.n, B = ws.B;
+  constexpr int crow = GRID_NT * PPT / 16;
+  double mx = w[0];
+#pragma unroll
+  for (int r = 1; r < PPT; r++) mx = fmax(mx, w[r]);
+  const double Mw = wave_max(mx);
+  const double Mws = Mw == -INFINITY ? 0.0 : Mw;  // a wave without mass: exp(-inf - 0) = 0 instead of exp(nan)
+  double e[PPT], sc[PPT];
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    e[r] = tl_exp(w[r] - Mws);  // inactive slots carry w = -inf: 0
+    sc[r] = wave_scan_incl(e[r]);
+    if (lane == 63) s_x[4 + r * 4 + wave] = sc[r];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (lane == 0) s_x[wave] = Mw;
+  lds_barrier();
+  // every wave combines the 4 wave maxima and the 4 * PPT chunk totals (chunks in particle order: q = 4 r + wave)
+  const double m0 = s_x[0], m1 = s_x[1], m2 = s_x[2], m3 = s_x[3];
+  const double Mb = fmax(fmax(m0, m1), fmax(m2, m3));
+  const double Mbs = Mb == -INFINITY ? 0.0 : Mb;
+  const int qw = lane & 3;
+  const double Mq = qw == 0 ? m0 : (qw == 1 ? m1 : (qw == 2 ? m2 : m3));
+  const double scq = tl_exp(Mq - Mbs);                       // lanes 0..3 (and their repeats): exp(max_wave - max_block)
+  const double tq = lane < 4 * PPT ? s_x[4 + lane] : 0.0;
+  const double incl = wave_scan_incl(tq * scq);              // lanes >= 4 PPT add zeros
+  const double total = lane_broadcast(incl, 4 * PPT - 1);
+  const double swv = lane_broadcast(scq, wave);
+  double* __restrict__ lcdf_new = ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N + base;
+  double* __restrict__ coarse_new = ws.coarse + (((size_t)(tn & 1) * b.F + f) * B + pb) * crow;
+  double* __restrict__ wout = b.weights ? b.weights + ((size_t)f * (n + 1) + tn) * N + base : nullptr;
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int q = r * 4 + wave, li = r * GRID_NT + tid;
+    const double off = q == 0 ? 0.0 : lane_broadcast(incl, (q - 1) & 63);
+    const double lc = __builtin_fma(sc[r], swv, off);
+    if (li < len) {
+      lcdf_new[li] = lc;
+      if ((li & 15) == 15 || li == len - 1) coarse_new[li >> 4] = lc;  // last entry of each row of 16
+      if (wout) wout[li] = e[r] * swv;  // block-scaled; rescaled to the global maximum by launch tn
+    }
+  }
+  if (tid == 0) {
+    double* __restrict__ part = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
+    part[2 * pb] = Mb;
+    part[2 * pb + 1] = total;
+  }
+}
+
+#ifndef BSSM_V2_OCC16
+#define BSSM_V2_OCC16 4
+#endif
+constexpr int v2_occupancy(int mp, int ppt) {
+  const int live = mp * ppt;
+  return live <= 4 ? 5 : (live <= 8 ? 4 : (live <= 16 ? BSSM_V2_OCC16 : (live <= 32 ? 3 : 2)));
+}
+
+template <int MP>
+__device__ __forceinline__ double v2_signal(const cdbl* ob, const double (&x)[MP]) {
+  double za = ob[OB_D];
+#pragma unroll
+  for (int c = 0; c < MP; c++) za = __builtin_fma(ob[SER_HDR + c], x[c], za);
+  return za;
+}
+
+__device__ __forceinline__ void v2_block_of(const GridWorkspace& ws, int& pb, int& f) {
+  int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int total = gridDim.x * gridDim.y;
+  if ((total & 7) == 0 && ws.xcd_remap) lin = (lin & 7) * (total >> 3) + (lin >> 3);  // XCD-contiguous (filter, block) ranges
+  // the quotient is computed on the VALU (float reciprocal); without the readfirstlane the compiler keeps it in a VGPR and
+  // every "uniform" table address derived from it becomes a per-lane address: vector loads instead of s_load
+  pb = __builtin_amdgcn_readfirstlane(lin % ws.B);
+  f = __builtin_amdgcn_readfirstlane(ws.f0 + lin / ws.B);
+}
+
+// t = -1: initial particles a1 + L u (src/model_ssm_ung.cpp:626; psi: alphahat_0 + V_0 u, :543) and their weights
+template <int MP, int PPT>
+__global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, const GridWorkspace ws) {
+  __shared__ double s_x[4 + 4 * PPT];
+  int pb, f;
+  v2_block_of(ws, pb, f);
+  math_tab_init();
+  const int tid = threadIdx.x, N = b.N, n = b.n, m = b.m;
+  constexpr int chunk = GRID_NT * PPT;
+  const int base = pb * chunk, len = min(chunk, N - base);
+  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
+  const cdbl* ini = as_uniform_table(b.init + (size_t)f * b.init_fstride);
+  const cdbl* row = as_uniform_table(b.obs + (size_t)f * b.obs_fstride);
+  double* __restrict__ st_new = (b.alpha_hist ? b.alpha_hist + (size_t)f * (n + 1) * m * N : ws.state[0] + (size_t)f * m * N) + base;
+  const bool observed = n > 0 && row[RH_FLAG] != 0.0;
+  double s[PPT], w[PPT];
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int li = r * GRID_NT + tid;
+    double z[MP], x[MP];
+    rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)(base + li), z);
+    initial_state<MP>(ini, z, x);
+    if (li < len) {
+#pragma unroll
+      for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + li] = x[c];
+    }
+    s[r] = v2_signal<MP>(row + ROW_HDR, x);
+  }
+  if (observed) {
+    v2_log_weights<PPT>(row, b.psi != 0, s, w);
+  } else {
+#pragma unroll
+    for (int r = 0; r < PPT; r++) w[r] = 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < PPT; r++) if (r * GRID_NT + tid >= len) w[r] = -INFINITY;
+  v2_block_stats<PPT>(b, ws, f, pb, base, len, 0, w, s_x);
+}
+
+// t in [0, n): resample on the time-t weights, propagate to t+1, weigh at t+1 (ones when t+1 == n or y_{t+1} is missing)
+template <int MP, int KP, int PPT>
+__global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v2(const FilterBatch b, const GridWorkspace ws, const int t) {
+  __shared__ double s_win[4 * PPT * V2_WIN];
+  __shared__ double s_x[4 + 4 * PPT];
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int pb, f;
+  v2_block_of(ws, pb, f);
+  const MathTabRegs mtab = math_tab_load_begin256();
+  const int B = ws.B, N = b.N, n = b.n, m = b.m, tn = t + 1;
+  constexpr int chunk = GRID_NT * PPT, crow = chunk / 16;
+  const int base = pb * chunk, len = min(chunk, N - base);
+  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
+
+  // ---- exchange loads: the (max, sum) partials of the time-t weights, one block per lane, in every wave
+  const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
+  double pmax = -INFINITY, psum = 0.0;
+  if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
+  double* __restrict__ wt = b.weights ? b.weights + ((size_t)f * (n + 1) + t) * N + base : nullptr;
+  double wt_old[PPT];
+  if (wt) {
+#pragma unroll
+    for (int r = 0; r < PPT; r++) { const int li = r * GRID_NT + tid; wt_old[r] = li < len ? wt[li] : 0.0; }
+  }
+  math_tab_load_end256(mtab);
+  lds_barrier();  // (1) tables published
+  // ---- wave-local combine: global maximum, scaled block sums, their inclusive prefix (lane = block), total
+  const double M = wave_max(pmax);
+  const double scale = tl_exp(pmax - M);  // lanes >= B: 0; a poisoned (NaN) partial makes S NaN below
+  const double Q = wave_scan_incl(psum * scale);
+  const double S = lane_broadcast(Q, 63);
+  const double iscale = 1.0 / scale;
+  if (wt) {  // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
+    const double myscale = lane_broadcast(scale, pb);
+#pragma unroll
+    for (int r = 0; r < PPT; r++) { const int li = r * GRID_NT + tid; if (li < len) wt[li] = wt_old[r] * myscale; }
+  }
+  if (!(S > 0.0)) {
+    // degenerate weights (src/model_ssm_ung.cpp:678-682): stop and poison this block's slot of the next parity, so every
+    // later launch sees a non-finite S too (no flag load on healthy steps); later output slots stay zero like the reference's
+    if (tid == 0) {
+      double* __restrict__ pn = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
+      pn[2 * pb] = __builtin_nan("");
+      pn[2 * pb + 1] = __builtin_nan("");
+      if (pb == 0) atomicCAS(&b.dead_at[f], 0, t + 1);
+    }
+    return;
+  }
+  if (pb == B - 1 && tid == GRID_NT - 1) ws.llinc[(size_t)f * (n + 1) + t] = M + tl_log(S / (double)N);  // :683
+  const double c_scale = S / (double)N;
+
+  const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
+  const double* __restrict__ coarse = ws.coarse + ((size_t)(t & 1) * b.F + f) * B * crow;
+  const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N;
+  double* __restrict__ st_new = (b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N) + base;
+  const cdbl* mt = as_uniform_table(b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride);
+  double* sw_base = s_win + wave * (PPT * V2_WIN);
+
+  // ---- phase A: step blocks, targets, source block (two ballots), coarse row of the source block in flight
+  u32x4 blk[PPT];
+  double vp[PPT], cv[PPT];
+  int sbk[PPT];
+  unsigned slow = 0;  // bit r: particle row r goes through the generic search
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int li = r * GRID_NT + tid, j = base + li;
+    blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)j);
+    const double v = (block_uniform(blk[r]) + (double)j) * c_scale;
+    const bool full = r * GRID_NT + (wave + 1) * 64 <= len;  // wave-uniform
+    const double v_lo = lane_broadcast(v, 0), v_hi = lane_broadcast(v, 63);
+    const int c_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_lo));
+    const int c_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_hi));
+    const int sb = min(c_lo, B - 1);
+    sbk[r] = sb;
+    if (!full || c_lo != c_hi) slow |= 1u << r;
+    const double Pm1 = sb > 0 ? lane_broadcast(Q, (sb - 1) & 63) : 0.0;
+    vp[r] = (v - Pm1) * lane_broadcast(iscale, sb);
+    const int ncr = (min(chunk, N - sb * chunk) + 15) >> 4;
+    cv[r] = coarse[(size_t)sb * crow + (lane < ncr ? lane : ncr - 1)];
+  }
+  // ---- phase B: rows of the source block the wave's slots fall into; their entries (<= 128) in flight
+  double wr0[PPT], wr1[PPT];
+  int w0k[PPT], wlenk[PPT];
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int sb = sbk[r];
+    const int slen = min(chunk, N - sb * chunk), ncr = (slen + 15) >> 4;
+    const double vp_lo = lane_broadcast(vp[r], 0), vp_hi = lane_broadcast(vp[r], 63);
+    const int k_lo = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv[r] < vp_lo)), ncr - 1);
+    const int k_hi = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv[r] < vp_hi)), ncr - 1);
+    const int w0 = 16 * k_lo, wend = min(16 * (k_hi + 1), slen);
+    if (wend - w0 > V2_WIN) slow |= 1u << r;
+    const int wlen = max(1, min(V2_WIN, wend - w0));  // (rows headed for the generic search may carry an empty range)
+    w0k[r] = w0; wlenk[r] = wlen;
+    const double* __restrict__ src = lcdf + (size_t)sb * chunk + w0;
+    wr0[r] = src[lane < wlen ? lane : wlen - 1];
+    wr1[r] = src[lane + 64 < wlen ? lane + 64 : wlen - 1];
+  }
+  // ---- phase C: windows to LDS (one per particle row: no reuse, no fences between rows), bisection, ancestors
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    double* sw = sw_base + r * V2_WIN;
+    sw[lane] = wr0[r];
+    sw[lane + 64] = wr1[r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int anc[PPT];
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int sb = sbk[r];
+    const int slen = min(chunk, N - sb * chunk);
+    const int cnt = v2_count_below<7>(sw_base + r * V2_WIN, wlenk[r], vp[r]);
+    anc[r] = sb * chunk + min(w0k[r] + cnt, slen - 1);
+  }
+  if (slow) {  // wave-uniform, rare: a block boundary inside the wave's slots, a ragged wave, or a window beyond 128 entries
+#pragma unroll 1
+    for (int r = 0; r < PPT; r++) {
+      if (!((slow >> r) & 1u)) continue;
+      uint32_t ur = blk[0].w;
+#pragma unroll
+      for (int q = 1; q < PPT; q++) ur = (r == q) ? blk[q].w : ur;  // r is wave-uniform: scalar compare + select
+      const double vr = ((double)ur * 0x1.0p-32 + (double)(base + r * GRID_NT + tid)) * c_scale;  // the target, as in phase A
+      const int ar = v2_search_generic<PPT>(vr, r * GRID_NT + tid < len, Q, iscale, B, N, coarse, lcdf, sw_base, lane);
+#pragma unroll
+      for (int q = 0; q < PPT; q++) anc[q] = (r == q) ? ar : anc[q];
+    }
+  }
+  // ---- phase D: ancestor indices out, ancestor states in flight
+  double a[PPT][MP];
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int li = r * GRID_NT + tid;
+    if (li >= len) anc[r] = 0;
+    if (b.indices && li < len) b.indices[((size_t)f * n + t) * N + base + li] = (uint32_t)anc[r];
+#pragma unroll
+    for (int c = 0; c < MP; c++) a[r][c] = (c < m) ? st_old[(size_t)c * N + anc[r]] : 0.0;
+  }
+  // ---- phase E: transition normals, alpha_{t+1} = C_t + T_t a + R_t eta (:663-670), signal at t+1
+  const bool have_obs = tn < n;
+  const cdbl* row = as_uniform_table(b.obs + (size_t)f * b.obs_fstride + (size_t)(have_obs ? tn : 0) * (ROW_HDR + SER_HDR + MP));
+  double s[PPT], w[PPT];
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    const int li = r * GRID_NT + tid, j = base + li;
+    double z[KP], x[MP];
+    rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+    propagate<MP, KP>(mt, a[r], z, x);
+    if (li < len) {
+#pragma unroll
+      for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + li] = x[c];
+    }
+    s[r] = v2_signal<MP>(row + ROW_HDR, x);
+    __builtin_amdgcn_sched_barrier(0);  // particles one after the other: bounds the live registers of the transcendental code
+  }
+  if (have_obs && row[RH_FLAG] != 0.0) {
+    v2_log_weights<PPT>(row, b.psi != 0, s, w);
+  } else {  // nothing observed at t+1: weights are ones (src/model_ssm_ung.cpp:644-647)
+#pragma unroll
+    for (int r = 0; r < PPT; r++) w[r] = 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < PPT; r++) if (r * GRID_NT + tid >= len) w[r] = -INFINITY;
+  v2_block_stats<PPT>(b, ws, f, pb, base, len, tn, w, s_x);
+}
+
+}  // namespace bssm
