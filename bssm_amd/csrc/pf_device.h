@@ -181,7 +181,8 @@ __device__ __forceinline__ double wave_sum(double v) { return lane_broadcast(wav
 // src/model_ssm_ulg.cpp:582-586.  `ob` points at the obs-row header; state-
 // independent quotients are precomputed on the host into OB_AUX:
 //   svm (y/phi)^2, negbin y+phi, gamma y/u, gaussian 1/H^2.
-__device__ __forceinline__ double log_obs_density(int dist, const double* __restrict__ ob, double phi, double s) {
+template <class PT>
+__device__ __forceinline__ double log_obs_density(int dist, PT ob, double phi, double s) {
   const double y = ob[OB_Y];
   switch (dist) {
     case DIST_SVM: return -0.5 * (s + ob[OB_AUX] * tl_exp(-s));
@@ -195,7 +196,8 @@ __device__ __forceinline__ double log_obs_density(int dist, const double* __rest
 }
 
 // psi-APF weight, src/model_ssm_ung.cpp:385-439 and the `- scales(t)` of :550,590
-__device__ __forceinline__ double log_psi_weight(int dist, const double* __restrict__ ob, double phi, double s) {
+template <class PT>
+__device__ __forceinline__ double log_psi_weight(int dist, PT ob, double phi, double s) {
   const double q = (ob[OB_PSIY] - s) * ob[OB_PSIIH];
   return log_obs_density(dist, ob, phi, s) + 0.5 * q * q;   // the caller subtracts scales_t once per row
 }

@@ -63,8 +63,8 @@ static __global__ void loglik_finalize_kernel(double* __restrict__ loglik, const
 // ------------------------------------------------------------------------------------------
 // shared per-particle pieces
 // ------------------------------------------------------------------------------------------
-template <int MP>
-__device__ __forceinline__ double signal_of(const double* __restrict__ ob, const double (&x)[MP]) {
+template <int MP, class PT>
+__device__ __forceinline__ double signal_of(PT ob, const double (&x)[MP]) {
   // D(t) + Z_t' alpha + xbeta(t)   (src/model_ssm_ung.cpp:462-463); D + xbeta pre-added on the host
   double za = 0.0;
 #pragma unroll
@@ -74,14 +74,14 @@ __device__ __forceinline__ double signal_of(const double* __restrict__ ob, const
 
 // log-weight of one particle at one time point: sum over the observed series of the row
 // (univariate: src/model_ssm_ung.cpp:447-493 / :385-439; multivariate: src/model_ssm_mng.cpp:407-442 / :357-393)
-template <int MP>
-__device__ __forceinline__ double log_weight_of(const FilterBatch& b, const double* __restrict__ row, const double (&x)[MP]) {
+template <int MP, class PT>
+__device__ __forceinline__ double log_weight_of(const FilterBatch& b, PT row, const double (&x)[MP]) {
   if (row[RH_FLAG] == 0.0) return 0.0;  // nothing observed at t: weights are ones (src/model_ssm_ung.cpp:644-647)
   double w = 0.0;
   for (int j = 0; j < b.p; j++) {
-    const double* __restrict__ ob = row + ROW_HDR + j * (SER_HDR + MP);
+    const PT ob = row + ROW_HDR + j * (SER_HDR + MP);
     if (ob[OB_FLAG] == 0.0) continue;
-    const double s = signal_of<MP>(ob, x);
+    const double s = signal_of<MP, PT>(ob, x);
     const int dist = (int)ob[OB_DIST];
     w += b.psi ? log_psi_weight(dist, ob, ob[OB_PHI], s) : log_obs_density(dist, ob, ob[OB_PHI], s);
   }
@@ -128,8 +128,8 @@ __device__ __forceinline__ void initial_state(PT ini, const double (&z)[MP], dou
 // src/model_ssm_mng.cpp:611-618).  Operand staging goes through a per-wave LDS tile: lanes hold "my particle, all
 // components", the MFMA wants B[k = lane>>4 (+4kk)][j = lane&15] and returns D[row = (lane>>4) + 4 reg][col = lane&15]
 // (f64 fragment layout, cdna_hip_programming.md section 3).  Rows 8..15 of [T R] are zero padding.
-template <int KP>
-__device__ __forceinline__ void propagate_mfma8(const double* __restrict__ mt, const double (&a)[8], const double (&z)[KP],
+template <int KP, class PT>
+__device__ __forceinline__ void propagate_mfma8(PT mt, const double (&a)[8], const double (&z)[KP],
                                                 double (&x)[8], double* tile /* 16 x 64 doubles, this wave's */, int lane) {
   typedef double d4 __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -143,7 +143,7 @@ __device__ __forceinline__ void propagate_mfma8(const double* __restrict__ mt, c
     const int k = 4 * kk + kq;  // column of [T R]
     afr[kk] = (i < 8) ? (k < 8 ? mt[i + 8 * k] : ((k - 8) < KP ? mt[64 + i + 8 * (k - 8)] : 0.0)) : 0.0;
   }
-  const double* __restrict__ Cv = mt + 64 + 8 * KP;
+  const PT Cv = mt + 64 + 8 * KP;
   const double c0 = Cv[kq], c1 = Cv[kq + 4];
   __builtin_amdgcn_wave_barrier();
   d4 acc[4];
@@ -174,7 +174,7 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
     if (b.psi == 2) return functor_ekpf_weight<MP>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
     return b.psi ? functor_psi_weight<MP>(fpar, row, amat, t, x, aprev) : functor_log_weight<MP>(fpar, row, x);
   } else {
-    return log_weight_of<MP>(b, row, x);
+    return log_weight_of<MP>(b, as_uniform_table(row), x);  // wave-uniform row: scalar loads (pf_device.h)
   }
 }
 
@@ -192,8 +192,6 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   double* __restrict__ s_cdf = smem + MP * Ncap;  // [Ncap]
   double* __restrict__ s_max = s_cdf + Ncap;      // [16]
   double* __restrict__ s_tot = s_max + 16;        // [PPT*16] wave totals in particle order
-  double* __restrict__ s_mats = s_tot + PPT * 16; // [MP*MP + MP*KP + MP] T_t, R_t, C_t of the current step
-  constexpr int MS = MP * MP + MP * KP + MP;
 
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
   const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
@@ -242,10 +240,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
     // stage this step's transition operands in LDS (every wave is past the previous transition here;
     // they become visible at barrier (2)/(3), before the transition after barrier (4))
-    if ((!FN || b.psi == 1) && t < n && (t == 0 || b.mats_tstride != 0)) {
-      const double* __restrict__ src = mats + (size_t)t * b.mats_tstride;
-      for (int q = tid; q < MS; q += NT) s_mats[q] = src[q];
-    }
+    // (the transition operands T_t, R_t, C_t are wave-uniform: read by scalar loads below, no LDS staging)
     // ... exp(w - max) and its inclusive scan in particle order (:676-679, stratified_sample.cpp:12)
     double sc[PPT];
 #pragma unroll
@@ -319,7 +314,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     lds_barrier();  // (4) all ancestors read before the slots are overwritten
 
     // ---- transition to t+1 and the weights there
-    const double* mt = s_mats;
+    const cdbl* mt = as_uniform_table(mats + (size_t)t * b.mats_tstride);
     const double* __restrict__ ob = obs + (size_t)(t + 1 < n ? t + 1 : 0) * obs_stride;
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
@@ -648,7 +643,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
     const double* __restrict__ coarse = ws.coarse + ((size_t)(t & 1) * b.F + f) * B * crow;
     const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N
                                                      : ws.state[t & 1] + (size_t)f * m * N;
-    const double* __restrict__ mt = b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride;
+    const cdbl* mt = as_uniform_table(b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride);
     {
     #pragma unroll
       for (int r = 0; r < PPT; r++) {
