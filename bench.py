@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--particles", type=int, default=65536)
-    ap.add_argument("--replicas", type=int, default=24,
+    ap.add_argument("--replicas", type=int, default=32,
                     help="independent filters (different Philox streams) in flight per step; 1 = latency regime")
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -228,7 +228,7 @@ def main():
         achieved = seqs * bytes_per_launch / (k_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R // seqs, N, ppt),
-                           "kernel": "pf_grid_step<4,4,%d>" % ppt, "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
+                           "kernel": plan.last_kernel(), "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
                            "concurrent_launches": seqs, "filters_per_launch": R // seqs,
                            "wall_per_launch_us": ms_per_step * 1e3 / (T + 1) / seqs,
                            "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -270,7 +270,7 @@ def main():
         out["regime_b"] = {"workload": "%d independent bootstrap filters, N=%d, T=%d, m=4, log-likelihood only "
                                        "(one workgroup per filter, state in LDS)" % (fb, nb, T),
                            "value": ps / eb, "unit": "particle-steps/s", "ms_per_pass": eb * 1e3,
-                           "kernel": "pf_wg_kernel<4,4,2>", "kernel_ms": kb_ms,
+                           "kernel": pb.last_kernel(), "kernel_ms": kb_ms,
                            "algorithmic_GBs": ps * ib["bytes_per_particle_step"] / (kb_ms * 1e-3) / 1e9,
                            "note": "state never leaves LDS: HBM traffic ~0, bound by fp64 VALU/transcendentals"}
         pb.close()

@@ -210,6 +210,7 @@ struct DeviceBatch {
     fb.loglik = loglik.as<double>();
     HIP_TRY(dead.alloc(F * sizeof(int)));
     fb.dead_at = dead.as<int>();
+    if (std::getenv("BSSM_AMD_PROBE_NO_WEIGHTS")) keep_weights = false;  // measurement probe (scripts/traffic_probe.sh): what the weights output costs
     if (keep_hist) {
       HIP_TRY(hist.alloc((size_t)F * (n + 1) * m * N * sizeof(double)));
       HIP_TRY(indices.alloc((size_t)F * n * N * sizeof(uint32_t)));
@@ -1692,6 +1693,12 @@ int bssm_plan_info(const bssm_plan* plan, int32_t* path, int32_t* n_filters, int
     if (threads) *threads = N <= 512 ? (N + 63) / 64 * 64 : 512;
   }
   if (bytes_per_particle_step) *bytes_per_particle_step = plan->bytes_per_pstep;
+  return BSSM_OK;
+}
+
+int bssm_amd_last_kernel(char* buf, int32_t len) {
+  if (!buf || len < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  std::snprintf(buf, (size_t)len, "%s", bssm::last_filter_kernel());
   return BSSM_OK;
 }
 

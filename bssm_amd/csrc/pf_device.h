@@ -39,6 +39,38 @@ __device__ __forceinline__ const cdbl* as_uniform_table(const double* p) {
   return (const cdbl*)(((uint64_t)hi << 32) | lo);
 }
 
+// Per-lane element of an array whose base is wave-uniform, with a 32-bit byte offset: selects the
+// `global_load/store v, v_offset, s[base:base+1]` addressing form (no 64-bit address arithmetic on the VALU).
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (T*)(((uint64_t)hi << 32) | lo);
+}
+// (the pointer is re-typed to the global address space: after the integer round trip of uniform_ptr the compiler would
+// otherwise fall back to flat_load / flat_store)
+template <class T>
+__device__ __forceinline__ T ld32(const T* uniform_base, uint32_t index) {
+  typedef __attribute__((address_space(1))) const T gT;
+  typedef __attribute__((address_space(1))) const char gC;
+  return *(gT*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * (uint32_t)sizeof(T)));
+}
+template <class T>
+__device__ __forceinline__ void st32(T* uniform_base, uint32_t index, T value) {
+  typedef __attribute__((address_space(1))) T gT;
+  typedef __attribute__((address_space(1))) char gC;
+  *(gT*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * (uint32_t)sizeof(T))) = value;
+}
+
+// Hides a uniform table pointer from common-subexpression elimination: loads through the result are re-issued (cheap
+// s_loads from the scalar cache) instead of being kept live in dozens of SGPRs across the code in between -- the
+// m = k = 4 transition needs 72 SGPRs for T, R, C, and holding them across the four particles of a lane spilt 55 SGPRs
+// to VGPR lanes (a v_readlane per use).
+__device__ __forceinline__ const cdbl* reload_table(const cdbl* p) {
+  __asm__ volatile("" : "+s"(p));
+  return p;
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 struct u32x4 { uint32_t x, y, z, w; };
 
@@ -151,6 +183,14 @@ __device__ __forceinline__ double lane_broadcast(double v, int src_lane) {  // s
   return __hiloint2double(hi, lo);
 }
 
+// row shift with zero fill (bound_ctrl:1): lanes whose source lies outside the row read 0, so -- unlike dpp_move -- no
+// identity has to be moved into the destination first (2 instructions per double instead of 4)
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr_zero(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 // inclusive prefix sum over the 64 lanes, fixed shape: 4 steps inside each row of 16, then row 0->1 and
 // 2->3 (bcast15), then rows 0-1 -> 2-3 (bcast31).  Same association on every call => reproducible bits.
 __device__ __forceinline__ double wave_scan_incl(double v) {

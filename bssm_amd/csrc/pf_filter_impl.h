@@ -16,6 +16,7 @@
 // fixed-shape reductions/scans only (no floating-point atomics): results are bit-reproducible
 // run to run and independent of the number of GPUs a batch is sharded over.
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 
 #include "pf_device.h"
@@ -403,6 +404,9 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   }
   }
   if (!kern) return hipErrorInvalidValue;
+#ifndef BSSM_USER_MODEL
+  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_wg_kernel<%d,%d,%d,%s,%d>", MP, KP, ppt, b.fpar ? "true" : "false", wide ? 1024 : WG_NT_MAX); note_filter_kernel(nm); }
+#endif
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
@@ -872,6 +876,14 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   }
 #endif
   if (!kern) return hipErrorInvalidValue;
+#ifndef BSSM_USER_MODEL
+  {
+    char nm[96];
+    if (kern_init) std::snprintf(nm, sizeof nm, "pf_grid_step_v2<%d,%d,%d>", MP, KP, ppt);
+    else std::snprintf(nm, sizeof nm, "pf_grid_step<%d,%d,%d,%s,%s>", MP, KP, ppt, "false", b.fpar ? "true" : "false");
+    note_filter_kernel(nm);
+  }
+#endif
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;

@@ -21,6 +21,13 @@
 //   * table-driven log / exp / sincos (pf_math.h).
 #pragma once
 
+// analysis builds (-DBSSM_V2_MARKS): comment markers in the ISA listing at the phase boundaries (scripts/isa_phases.py)
+#ifdef BSSM_V2_MARKS
+#define V2_MARK(name) __asm__ volatile("; V2MARK " name ::: "memory")
+#else
+#define V2_MARK(name)
+#endif
+
 namespace bssm {
 
 constexpr int V2_WIN = 128;  // entries of a source block's local scan staged per (wave, particle row)
@@ -161,18 +168,18 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
   const double incl = wave_scan_incl(tq * scq);              // lanes >= 4 PPT add zeros
   const double total = lane_broadcast(incl, 4 * PPT - 1);
   const double swv = lane_broadcast(scq, wave);
-  double* __restrict__ lcdf_new = ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N + base;
-  double* __restrict__ coarse_new = ws.coarse + (((size_t)(tn & 1) * b.F + f) * B + pb) * crow;
-  double* __restrict__ wout = b.weights ? b.weights + ((size_t)f * (n + 1) + tn) * N + base : nullptr;
+  double* __restrict__ lcdf_new = uniform_ptr(ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N + base);
+  double* __restrict__ coarse_new = uniform_ptr(ws.coarse + (((size_t)(tn & 1) * b.F + f) * B + pb) * crow);
+  double* __restrict__ wout = b.weights ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + tn) * N + base) : nullptr;
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int q = r * 4 + wave, li = r * GRID_NT + tid;
     const double off = q == 0 ? 0.0 : lane_broadcast(incl, (q - 1) & 63);
     const double lc = __builtin_fma(sc[r], swv, off);
     if (li < len) {
-      lcdf_new[li] = lc;
-      if ((li & 15) == 15 || li == len - 1) coarse_new[li >> 4] = lc;  // last entry of each row of 16
-      if (wout) wout[li] = e[r] * swv;  // block-scaled; rescaled to the global maximum by launch tn
+      st32(lcdf_new, li, lc);
+      if ((li & 15) == 15 || li == len - 1) st32(coarse_new, li >> 4, lc);  // last entry of each row of 16
+      if (wout) st32(wout, li, e[r] * swv);  // block-scaled; rescaled to the global maximum by launch tn
     }
   }
   if (tid == 0) {
@@ -252,6 +259,7 @@ template <int MP, int KP, int PPT>
 __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v2(const FilterBatch b, const GridWorkspace ws, const int t) {
   __shared__ double s_win[4 * PPT * V2_WIN];
   __shared__ double s_x[4 + 4 * PPT];
+  __shared__ double s_comb[3 * 64 + 1];  // combine of wave 0: block prefixes, 1 / scale, scale, global maximum
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int pb, f;
@@ -262,28 +270,41 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
   const int base = pb * chunk, len = min(chunk, N - base);
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
 
-  // ---- exchange loads: the (max, sum) partials of the time-t weights, one block per lane, in every wave
-  const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
-  double pmax = -INFINITY, psum = 0.0;
-  if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
-  double* __restrict__ wt = b.weights ? b.weights + ((size_t)f * (n + 1) + t) * N + base : nullptr;
+  V2_MARK("loads");
+  // ---- exchange loads: the (max, sum) partials of the time-t weights, one block per lane -- combined by wave 0 only
+  // (global maximum, scaled block sums, their inclusive prefix, total; the polynomial exp needs no table) while every
+  // wave draws the step blocks of its particles (integer work, independent of the exchange); barrier (1) then
+  // publishes both the math tables and the combine
+  double* __restrict__ wt = b.weights ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + t) * N + base) : nullptr;
   double wt_old[PPT];
   if (wt) {
 #pragma unroll
-    for (int r = 0; r < PPT; r++) { const int li = r * GRID_NT + tid; wt_old[r] = li < len ? wt[li] : 0.0; }
+    for (int r = 0; r < PPT; r++) { const int li = r * GRID_NT + tid; wt_old[r] = li < len ? ld32(wt, li) : 0.0; }
   }
-  math_tab_load_end256(mtab);
-  lds_barrier();  // (1) tables published
-  // ---- wave-local combine: global maximum, scaled block sums, their inclusive prefix (lane = block), total
-  const double M = wave_max(pmax);
-  const double scale = tl_exp(pmax - M);  // lanes >= B: 0; a poisoned (NaN) partial makes S NaN below
-  const double Q = wave_scan_incl(psum * scale);
-  const double S = lane_broadcast(Q, 63);
-  const double iscale = 1.0 / scale;
-  if (wt) {  // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
-    const double myscale = lane_broadcast(scale, pb);
+  V2_MARK("combine");
+  if (wave == 0) {
+    const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
+    double pmax = -INFINITY, psum = 0.0;
+    if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
+    const double M0 = wave_max(pmax);
+    const double scale0 = fast_exp(pmax - M0);  // lanes >= B: 0; a poisoned (NaN) partial makes S NaN below
+    const double Q0 = wave_scan_incl(psum * scale0);
+    s_comb[lane] = Q0;
+    s_comb[64 + lane] = 1.0 / scale0;
+    s_comb[128 + lane] = scale0;
+    if (lane == 0) s_comb[192] = M0;
+  }
+  u32x4 blk[PPT];
 #pragma unroll
-    for (int r = 0; r < PPT; r++) { const int li = r * GRID_NT + tid; if (li < len) wt[li] = wt_old[r] * myscale; }
+  for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + r * GRID_NT + tid));
+  math_tab_load_end256(mtab);
+  lds_barrier();  // (1)
+  const double Q = s_comb[lane], iscale = s_comb[64 + lane], S = s_comb[63], M = s_comb[192];
+  V2_MARK("rmw");
+  if (wt) {  // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
+    const double myscale = s_comb[128 + pb];
+#pragma unroll
+    for (int r = 0; r < PPT; r++) { const int li = r * GRID_NT + tid; if (li < len) st32(wt, li, wt_old[r] * myscale); }
   }
   if (!(S > 0.0)) {
     // degenerate weights (src/model_ssm_ung.cpp:678-682): stop and poison this block's slot of the next parity, so every
@@ -299,22 +320,22 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
   if (pb == B - 1 && tid == GRID_NT - 1) ws.llinc[(size_t)f * (n + 1) + t] = M + tl_log(S / (double)N);  // :683
   const double c_scale = S / (double)N;
 
-  const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
-  const double* __restrict__ coarse = ws.coarse + ((size_t)(t & 1) * b.F + f) * B * crow;
-  const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N;
-  double* __restrict__ st_new = (b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N) + base;
+  const double* __restrict__ lcdf = uniform_ptr(ws.lcdf + ((size_t)(t & 1) * b.F + f) * N);
+  const double* __restrict__ coarse = uniform_ptr(ws.coarse + ((size_t)(t & 1) * b.F + f) * B * crow);
+  const double* __restrict__ st_old = uniform_ptr(b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N);
+  double* __restrict__ st_new = uniform_ptr((b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N) + base);
+  uint32_t* __restrict__ idx_out = b.indices ? uniform_ptr(b.indices + ((size_t)f * n + t) * N + base) : nullptr;
   const cdbl* mt = as_uniform_table(b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride);
   double* sw_base = s_win + wave * (PPT * V2_WIN);
 
+  V2_MARK("phaseA");
   // ---- phase A: step blocks, targets, source block (two ballots), coarse row of the source block in flight
-  u32x4 blk[PPT];
   double vp[PPT], cv[PPT];
   int sbk[PPT];
   unsigned slow = 0;  // bit r: particle row r goes through the generic search
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid, j = base + li;
-    blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)j);
     const double v = (block_uniform(blk[r]) + (double)j) * c_scale;
     const bool full = r * GRID_NT + (wave + 1) * 64 <= len;  // wave-uniform
     const double v_lo = lane_broadcast(v, 0), v_hi = lane_broadcast(v, 63);
@@ -326,8 +347,9 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
     const double Pm1 = sb > 0 ? lane_broadcast(Q, (sb - 1) & 63) : 0.0;
     vp[r] = (v - Pm1) * lane_broadcast(iscale, sb);
     const int ncr = (min(chunk, N - sb * chunk) + 15) >> 4;
-    cv[r] = coarse[(size_t)sb * crow + (lane < ncr ? lane : ncr - 1)];
+    cv[r] = ld32(coarse + (size_t)sb * crow, lane < ncr ? lane : ncr - 1);
   }
+  V2_MARK("phaseB");
   // ---- phase B: rows of the source block the wave's slots fall into; their entries (<= 128) in flight
   double wr0[PPT], wr1[PPT];
   int w0k[PPT], wlenk[PPT];
@@ -342,10 +364,11 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
     if (wend - w0 > V2_WIN) slow |= 1u << r;
     const int wlen = max(1, min(V2_WIN, wend - w0));  // (rows headed for the generic search may carry an empty range)
     w0k[r] = w0; wlenk[r] = wlen;
-    const double* __restrict__ src = lcdf + (size_t)sb * chunk + w0;
-    wr0[r] = src[lane < wlen ? lane : wlen - 1];
-    wr1[r] = src[lane + 64 < wlen ? lane + 64 : wlen - 1];
+    const double* __restrict__ src = lcdf + (size_t)sb * chunk + w0;  // uniform
+    wr0[r] = ld32(src, lane < wlen ? lane : wlen - 1);
+    wr1[r] = ld32(src, lane + 64 < wlen ? lane + 64 : wlen - 1);
   }
+  V2_MARK("phaseC");
   // ---- phase C: windows to LDS (one per particle row: no reuse, no fences between rows), bisection, ancestors
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
@@ -364,6 +387,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
     const int cnt = v2_count_below<7>(sw_base + r * V2_WIN, wlenk[r], vp[r]);
     anc[r] = sb * chunk + min(w0k[r] + cnt, slen - 1);
   }
+  V2_MARK("slow");
   if (slow) {  // wave-uniform, rare: a block boundary inside the wave's slots, a ragged wave, or a window beyond 128 entries
 #pragma unroll 1
     for (int r = 0; r < PPT; r++) {
@@ -377,16 +401,18 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
       for (int q = 0; q < PPT; q++) anc[q] = (r == q) ? ar : anc[q];
     }
   }
+  V2_MARK("phaseD");
   // ---- phase D: ancestor indices out, ancestor states in flight
   double a[PPT][MP];
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
     if (li >= len) anc[r] = 0;
-    if (b.indices && li < len) b.indices[((size_t)f * n + t) * N + base + li] = (uint32_t)anc[r];
+    if (idx_out && li < len) st32(idx_out, li, (uint32_t)anc[r]);
 #pragma unroll
-    for (int c = 0; c < MP; c++) a[r][c] = (c < m) ? st_old[(size_t)c * N + anc[r]] : 0.0;
+    for (int c = 0; c < MP; c++) a[r][c] = (c < m) ? ld32(st_old + (size_t)c * N, anc[r]) : 0.0;
   }
+  V2_MARK("phaseE");
   // ---- phase E: transition normals, alpha_{t+1} = C_t + T_t a + R_t eta (:663-670), signal at t+1
   const bool have_obs = tn < n;
   const cdbl* row = as_uniform_table(b.obs + (size_t)f * b.obs_fstride + (size_t)(have_obs ? tn : 0) * (ROW_HDR + SER_HDR + MP));
@@ -399,17 +425,19 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
     propagate<MP, KP>(mt, a[r], z, x);
     if (li < len) {
 #pragma unroll
-      for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + li] = x[c];
+      for (int c = 0; c < MP; c++) if (c < m) st32(st_new + (size_t)c * N, li, x[c]);
     }
     s[r] = v2_signal<MP>(row + ROW_HDR, x);
     __builtin_amdgcn_sched_barrier(0);  // particles one after the other: bounds the live registers of the transcendental code
   }
+  V2_MARK("density");
   if (have_obs && row[RH_FLAG] != 0.0) {
     v2_log_weights<PPT>(row, b.psi != 0, s, w);
   } else {  // nothing observed at t+1: weights are ones (src/model_ssm_ung.cpp:644-647)
 #pragma unroll
     for (int r = 0; r < PPT; r++) w[r] = 0.0;
   }
+  V2_MARK("stats");
 #pragma unroll
   for (int r = 0; r < PPT; r++) if (r * GRID_NT + tid >= len) w[r] = -INFINITY;
   v2_block_stats<PPT>(b, ws, f, pb, base, len, tn, w, s_x);

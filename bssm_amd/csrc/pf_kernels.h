@@ -67,6 +67,10 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
 struct StepTiming { int every = 0; int count = 0; double total_ms = 0.0; int concurrent = 1; };  // concurrent: launch sequences in flight
 hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream,
                               StepTiming* timing = nullptr);
+// Name (with template arguments) of the filter kernel variant the calling thread launched last, as the launcher picked
+// it -- benchmarks report this instead of a format string of their own.
+void note_filter_kernel(const char* name);
+const char* last_filter_kernel();
 // launchers a run-time compiled user-model library exports (user_model_tu.hip); register returns the slot (>= 1)
 typedef hipError_t (*user_wg_launcher_t)(const FilterBatch*, hipStream_t);
 typedef hipError_t (*user_grid_launcher_t)(const FilterBatch*, const GridWorkspace*, hipStream_t, StepTiming*);

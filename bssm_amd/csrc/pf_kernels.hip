@@ -2,12 +2,17 @@
 // The filter kernels themselves are templates in pf_filter_impl.h, instantiated per padded
 // state dimension in pf_inst_mp*.hip.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "lg_smoother.h"
 #include "pf_filter_impl.h"
 
 namespace bssm {
+
+static thread_local char g_last_kernel[96] = "";
+void note_filter_kernel(const char* name) { std::snprintf(g_last_kernel, sizeof g_last_kernel, "%s", name); }
+const char* last_filter_kernel() { return g_last_kernel; }
 
 int wg_filter_capacity(int MP) {
   // 160 KiB LDS per CU: (MP + 1) doubles per particle + reduction slots; 512 threads x up to 16 particles

@@ -97,6 +97,13 @@ class FilterPlan:
         L.bssm_plan_launch_sequences.argtypes = [C.c_void_p]
         return int(L.bssm_plan_launch_sequences(self._h))
 
+    @staticmethod
+    def last_kernel() -> str:
+        """the filter kernel variant this thread launched last, as named by the launcher"""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.lib().bssm_amd_last_kernel(buf, C.c_int32(128)))
+        return buf.value.decode()
+
     def close(self):
         if self._h:
             _lib.lib().bssm_plan_destroy(self._h)

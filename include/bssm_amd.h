@@ -335,6 +335,8 @@ int bssm_debug_math(int fn, const double* in, double* out, int32_t n);
 /* how many step-launch sequences the last bssm_plan_time_kernel run kept in flight (a batch that fills the chip more than
  * once is stepped as two interleaved sequences over the halves of its filters; each timed launch then covers half of them) */
 int bssm_plan_launch_sequences(const bssm_plan* plan);
+/* name, with template arguments, of the filter kernel variant the calling thread launched last (as the launcher chose it) */
+int bssm_amd_last_kernel(char* buf, int32_t len);
 /* runs one kernel that reads n_doubles and writes n_doubles (8 B per lane, coalesced): a known byte count for
  * calibrating the profiler's FETCH_SIZE / WRITE_SIZE counters on this library's access pattern */
 int bssm_debug_stream_copy(uint64_t n_doubles);

@@ -147,6 +147,108 @@ def test_full_size_c2_m4_against_oracle(oracle):
     assert abs(out["logLik"] - ref["logLik"]) <= (1e-9 if same else 1e-4) * 60
 
 
+def _first_divergence(a, b):
+    """first time column at which two ancestor tables differ (n when they never do)"""
+    bad = np.flatnonzero((a != b).any(axis=0))
+    return int(bad[0]) if bad.size else a.shape[1]
+
+
+def _compare_full_size(out, ref, n, alpha_t_major):
+    """Device vs oracle at a BASELINE configuration's full size.  On identical ancestor tables everything is compared at
+    the fp64 parity bar.  A last-ulp difference in one CDF entry can flip one ancestor (about 1e-11 per particle-step,
+    DESIGN.md section 2); from that step on the two particle systems are different (equally valid) systems, so after a
+    flip the strict comparison covers the steps before it and the log-likelihoods must agree within Monte-Carlo error."""
+    t_div = _first_divergence(out["indices"], ref["indices"])
+    assert t_div >= min(n, 50), f"ancestors diverge at step {t_div}"
+    ga = out["alpha"] if alpha_t_major else np.transpose(out["alpha"], (1, 0, 2))   # -> (t, m, N)
+    ra = np.transpose(ref["alpha"], (1, 0, 2))                                      # oracle: m x (n+1) x N
+    T1 = t_div + 1
+    scale = max(1.0, float(np.abs(ra[:T1]).max()))
+    assert np.max(np.abs(ga[:T1] - ra[:T1])) <= 1e-9 * scale
+    assert np.allclose(out["weights"][:, :T1], ref["weights"][:, :T1], rtol=1e-8, atol=1e-13)
+    if t_div == n:
+        assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    else:
+        assert abs(out["logLik"] - ref["logLik"]) <= 0.5
+    return t_div
+
+
+def test_metric_config_full_size_against_oracle(oracle):
+    """BASELINE metric config at its full size: ssm_ung negbin m = 4, N = 65 536, T = 1000 (8 s of oracle): ancestor table,
+    particle history, weights and log-likelihood of the device bootstrap filter against the CPU oracle on the same seed"""
+    n = 1000
+    model = negbin_m4(n, seed=103)
+    out = F.bootstrap_filter(model, 65536, seed=1, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), 65536, seed=1)
+    t_div = _compare_full_size(out, ref, n, alpha_t_major=True)
+    # weighted filtered means (north_star: "log-likelihood and weighted state means") up to the divergence point
+    T1 = min(t_div + 1, n)
+    w = ref["weights"][:, :T1]
+    att_ref = np.einsum("mtn,nt->tm", ref["alpha"][:, :T1, :], w / w.sum(axis=0))
+    assert np.allclose(out["att"][:T1], att_ref, rtol=1e-8, atol=1e-10)
+
+
+def test_c3_full_size_against_oracle(oracle):
+    """configs[2] at full size: svm on the exchange data (T = 945), psi-APF N = 32 768 + filter-smoother back-trace"""
+    y = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "exchange.txt"))
+    model = M.svm(y, rho=M.uniform(0.98, -0.999, 0.999), sd_ar=M.halfnormal(0.2, 5), sigma=M.halfnormal(1.0, 2))
+    n, N = y.size, 32768
+    out = F.particle_smoother(model, N, method="psi", seed=11, return_indices=True)
+    ref = oracle.psi_filter(M.model_arrays(model), N, seed=11)
+    t_div = _first_divergence(out["indices"], ref["indices"])
+    assert t_div >= 50, f"ancestors diverge at step {t_div}"
+    assert np.allclose(out["weights"][:, :t_div + 1], ref["weights"][:, :t_div + 1], rtol=1e-8, atol=1e-13)
+    if t_div == n:
+        assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+        sm = oracle.filter_smoother(ref["alpha"], ref["indices"])      # m x (n+1) x N back-traced
+        mean, cov = oracle.summary(sm)
+        assert _rel(np.transpose(out["alpha"], (1, 0, 2)), sm[:, :n, :]) <= 1e-8
+        assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8
+        assert _rel(out["Vt"], cov[:, :, :n]) <= 1e-7
+    else:
+        assert abs(out["logLik"] - ref["logLik"]) <= 0.5
+
+
+def test_c4_full_size_against_oracle(oracle):
+    """configs[3] at full size: ssm_mng m = 8, p = 4, T = 2000, N = 16 384 -- the fp64-MFMA transition against the oracle's
+    plain loops (about 30 s of oracle)"""
+    from models_zoo import mng_c4
+    n, N = 2000, 16384
+    model = mng_c4(n)
+    os.environ["BSSM_AMD_FORCE_PATH"] = "grid"
+    try:
+        out = F.bootstrap_filter(model, N, seed=4, return_indices=True)
+    finally:
+        del os.environ["BSSM_AMD_FORCE_PATH"]
+    ref = oracle.mng_bsf_filter(M.model_arrays(model), N, seed=4)
+    _compare_full_size(out, ref, n, alpha_t_major=True)
+
+
+def test_device_matches_committed_golden_vectors():
+    """tests/golden/golden_filters.npz (made by tests/golden/make_golden.py from the oracle): the device filters against
+    the committed fixtures, no oracle involved at run time"""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_filters.npz"))
+    from models_zoo import mng_zoo
+    zoo = small_zoo()
+    for name in sorted(zoo):
+        for tag, method in (("bsf", "bsf"), ("psi", "psi")):
+            if f"{name}/{tag}/indices" not in gold or (tag == "psi" and name.startswith("gaussian")):
+                continue
+            out = F.bootstrap_filter(zoo[name], 24, seed=17, return_indices=True) if tag == "bsf" else \
+                F.particle_smoother(zoo[name], 24, method="psi", seed=17, return_indices=True)
+            assert np.array_equal(out["indices"], gold[f"{name}/{tag}/indices"]), (name, tag)
+            assert abs(out["logLik"] - float(gold[f"{name}/{tag}/logLik"])) <= 1e-9 * max(1, zoo[name].n), (name, tag)
+            if tag == "bsf":
+                ga = np.transpose(out["alpha"], (1, 0, 2))
+                ra = gold[f"{name}/bsf/alpha"]
+                assert np.max(np.abs(ga - ra)) <= 1e-9 * max(1.0, np.abs(ra).max()), name
+                assert np.allclose(out["weights"], gold[f"{name}/bsf/weights"], rtol=1e-8, atol=1e-13), name
+    for name, mdl in sorted(mng_zoo().items()):
+        out = F.bootstrap_filter(mdl, 24, seed=17, return_indices=True)
+        assert np.array_equal(out["indices"], gold[f"mng/{name}/bsf/indices"]), name
+        assert abs(out["logLik"] - float(gold[f"mng/{name}/bsf/logLik"])) <= 1e-9 * mdl.n, name
+
+
 def test_gaussian_psi_smoother(oracle):
     """gaussian_psi_smoother (src/R_psi.cpp:14-50): exact draws from the joint smoothing distribution; parity with
     the oracle on the same stream and agreement with the exact Kalman smoother (tests/testthat/test_particle_smoother.R:33-45)."""
