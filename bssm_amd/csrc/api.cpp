@@ -8,6 +8,7 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -150,6 +151,131 @@ struct DevBuf {
     return arena().get(b, &p, &capacity);
   }
   template <class T> T* as() const { return (T*)p; }
+};
+
+
+// ------------------------------------------------------------------ device -> pageable host output pipe
+// The drop-in entry points hand back host buffers the CALLER allocated (R vectors, numpy arrays): pageable, and usually
+// never touched, so a plain hipMemcpy into them runs at the page-fault rate (measured 10 GB/s, scripts/pcie_probe.py)
+// and only starts when everything before it has finished.  OutPipe streams instead: chunks go device -> pinned ring
+// buffer by DMA on a copy stream (57 GB/s, each chunk gated by the event that says its device data is final), and a few
+// host threads move every landed chunk pinned -> caller memory in parallel slices (first-touch included: 68 GB/s with 8
+// threads, 88 with 16), while the next chunk is in flight and -- for finished time slabs -- the filter is still stepping.
+// Reference contract: src/R_bootstrap_filter.cpp:136-155 (outputs are ordinary R arrays).
+class OutPipe {
+ public:
+  explicit OutPipe(size_t total_bytes) {
+    int hw = (int)std::thread::hardware_concurrency();
+    threads_ = std::max(1, std::min(16, hw / 2));
+    if (const char* env = std::getenv("BSSM_AMD_COPY_THREADS")) threads_ = std::max(1, std::min(64, std::atoi(env)));
+    chunk_ = (size_t)32 << 20;
+    if (total_bytes < chunk_ * 2) threads_ = std::min(threads_, 4);
+    (void)hipGetDevice(&dev_);
+  }
+  ~OutPipe() { (void)finish(); }
+  OutPipe(const OutPipe&) = delete;
+  OutPipe& operator=(const OutPipe&) = delete;
+
+  // copy `bytes` from device `src` to host `dst` once `ready` has fired (nullptr: once everything enqueued on `after` so
+  // far has finished)
+  int push(const void* src, void* dst, size_t bytes, hipEvent_t ready, hipStream_t after = nullptr) {
+    if (bytes == 0) return BSSM_OK;
+    if (int rc = start()) return rc;
+    if (ready) {
+      HIP_TRY(hipStreamWaitEvent(cs_, ready, 0));
+    } else {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(ev, after));
+      HIP_TRY(hipStreamWaitEvent(cs_, ev, 0));
+      (void)hipEventDestroy(ev);
+    }
+    for (size_t off = 0; off < bytes; off += chunk_) {
+      const size_t len = std::min(chunk_, bytes - off);
+      const long k = posted_;
+      const int slot = (int)(k % kSlots);
+      if (k >= kSlots) {  // the slot's previous chunk must have left the ring
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return finished_[(size_t)(k - kSlots)] == threads_; });
+      }
+      HIP_TRY(hipMemcpyAsync(ring_[slot].p, (const char*)src + off, len, hipMemcpyDeviceToHost, cs_));
+      HIP_TRY(hipEventRecord(done_[slot], cs_));
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        chunks_.push_back(Chunk{(char*)dst + off, len, slot});
+        finished_.push_back(0);
+        posted_++;
+      }
+      cv_post_.notify_all();
+    }
+    return BSSM_OK;
+  }
+
+  int finish() {
+    if (!started_ || joined_) return BSSM_OK;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      closing_ = true;
+    }
+    cv_post_.notify_all();
+    for (auto& t : pool_) t.join();
+    joined_ = true;
+    for (int s = 0; s < kSlots; s++) if (done_[s]) (void)hipEventDestroy(done_[s]);
+    return failed_ ? fail(BSSM_ERR_HIP, "output pipe: event wait failed") : BSSM_OK;
+  }
+
+ private:
+  static constexpr int kSlots = 4;
+  struct Chunk { char* dst; size_t len; int slot; };
+
+  int start() {
+    if (started_) return BSSM_OK;
+    static thread_local hipStream_t cs = nullptr;
+    if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    cs_ = cs;
+    for (int s = 0; s < kSlots; s++) {
+      HIP_TRY(ring_[s].alloc(chunk_));
+      HIP_TRY(hipEventCreateWithFlags(&done_[s], hipEventDisableTiming));
+    }
+    started_ = true;
+    for (int q = 0; q < threads_; q++) pool_.emplace_back([this, q] { worker(q); });
+    return BSSM_OK;
+  }
+
+  void worker(int q) {
+    (void)hipSetDevice(dev_);
+    for (long k = 0;; k++) {
+      Chunk c;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_post_.wait(lk, [&] { return posted_ > k || closing_; });
+        if (posted_ <= k) return;
+        c = chunks_[(size_t)k];
+      }
+      if (hipEventSynchronize(done_[c.slot]) != hipSuccess) failed_ = true;
+      const size_t lo = c.len * (size_t)q / (size_t)threads_ / 64 * 64, hi = q + 1 == threads_ ? c.len : c.len * (size_t)(q + 1) / (size_t)threads_ / 64 * 64;
+      if (hi > lo) std::memcpy(c.dst + lo, (const char*)ring_[c.slot].p + lo, hi - lo);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        finished_[(size_t)k]++;
+      }
+      cv_done_.notify_all();
+    }
+  }
+
+  int threads_ = 1, dev_ = 0;
+  size_t chunk_ = 0;
+  hipStream_t cs_ = nullptr;
+  StageBuf ring_[kSlots];
+  hipEvent_t done_[kSlots] = {};
+  std::vector<std::thread> pool_;
+  std::mutex mu_;
+  std::condition_variable cv_post_, cv_done_;
+  std::vector<Chunk> chunks_;
+  std::vector<int> finished_;
+  long posted_ = 0;
+  bool started_ = false, joined_ = false, closing_ = false;
+  std::atomic<bool> failed_{false};
 };
 
 template <class F>
@@ -342,28 +468,75 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
     if ((rc = db.set_fpar(fp))) return rc;
     if (!am.empty() && (rc = db.set_amats(am))) return rc;
   }
-  hipStream_t st = nullptr;
-  if ((rc = db.run(seed, 0, st))) return rc;
+  // Everything runs on one non-blocking stream of this host thread; finished time slabs of weights / ancestors leave
+  // through the output pipe while the filter is still stepping, the particle cube follows block by block after it.
+  static thread_local hipStream_t st_own = nullptr;
+  if (!st_own) HIP_TRY(hipStreamCreateWithFlags(&st_own, hipStreamNonBlocking));
+  hipStream_t st = st_own;
+  const size_t hist_elems = (size_t)(n + 1) * m * N;
+  const size_t out_bytes = (out->alpha ? hist_elems * sizeof(double) : 0) + (out->weights ? db.weights.bytes : 0) +
+                           (out->indices ? db.indices.bytes : 0);
+  const bool piped = out_bytes >= ((size_t)8 << 20) && !std::getenv("BSSM_AMD_NO_OUTPIPE");
+  bssm::StepTiming hooks;
+  if (piped && db.use_grid && (out->weights || out->indices) && n >= 64) hooks.progress_every = std::max(16, n / 24);
+  if ((rc = db.run(seed, 0, st, &hooks))) return rc;
+  std::unique_ptr<OutPipe> pipe(piped ? new OutPipe(out_bytes) : nullptr);
+  int slab_done = 0;  // weights / ancestor columns [0, slab_done) are on their way
+  for (int k = 0; k < hooks.progress_count; k++) {
+    const int t1 = hooks.progress_steps[k];
+    if (out->weights && (rc = pipe->push(db.weights.as<double>() + (size_t)slab_done * N, out->weights + (size_t)slab_done * N,
+                                         (size_t)(t1 - slab_done) * N * sizeof(double), hooks.progress_events[k]))) return rc;
+    if (out->indices && (rc = pipe->push(db.indices.as<uint32_t>() + (size_t)slab_done * N, out->indices + (size_t)slab_done * N,
+                                         (size_t)(t1 - slab_done) * N * sizeof(uint32_t), hooks.progress_events[k]))) return rc;
+    slab_done = t1;
+  }
+  for (int k = 0; k < hooks.progress_count; k++) (void)hipEventDestroy(hooks.progress_events[k]);
+  if (pipe) {  // the rest (the launcher's stream order covers it)
+    if (out->weights && (rc = pipe->push(db.weights.as<double>() + (size_t)slab_done * N, out->weights + (size_t)slab_done * N,
+                                         (size_t)(n + 1 - slab_done) * N * sizeof(double), nullptr, st))) return rc;
+    if (out->indices && (rc = pipe->push(db.indices.as<uint32_t>() + (size_t)slab_done * N, out->indices + (size_t)slab_done * N,
+                                         (size_t)(n - slab_done) * N * sizeof(uint32_t), nullptr, st))) return rc;
+  }
   double ll = 0;
-  HIP_TRY(hipMemcpy(&ll, db.loglik.p, sizeof(double), hipMemcpyDeviceToHost));
+  int dead = 0;
+  HIP_TRY(hipMemcpyAsync(&ll, db.loglik.p, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&dead, db.dead.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   const bool degenerate = !std::isfinite(ll);
   out->logLik = degenerate ? -INFINITY : ll + base_ll;
+  if (pipe && dead != 0 && slab_done > 0) {
+    // a degenerate filter: the slots after the dead step are zero-filled at the END of the run (launch_zero_dead_tail),
+    // so slabs that left earlier may hold stale values there -- send those columns again
+    if (out->weights && (rc = pipe->push(db.weights.p, out->weights, (size_t)slab_done * N * sizeof(double), nullptr, st))) return rc;
+    if (out->indices && (rc = pipe->push(db.indices.p, out->indices, (size_t)slab_done * N * sizeof(uint32_t), nullptr, st))) return rc;
+  }
 
-  const size_t hist_elems = (size_t)(n + 1) * m * N;
   DevBuf cube, smooth, d_mean, d_cov, d_att, d_Ptt;
   const double* final_hist = db.hist.as<double>();
   if (smoother) {  // filter_smoother + summary (src/R_bootstrap_filter.cpp:368-369, src/R_psi.cpp:94-95)
     HIP_TRY(smooth.alloc(hist_elems * sizeof(double)));
     HIP_TRY(bssm::launch_backtrace(db.hist.as<double>(), db.indices.as<uint32_t>(), smooth.as<double>(), 1, n, m, N, st));
     final_hist = smooth.as<double>();
+  }
+  if (out->alpha) {  // the cube first: its transfer is the long pole, the summaries below run under it
+    HIP_TRY(cube.alloc(hist_elems * sizeof(double)));
+    HIP_TRY(bssm::launch_to_cube(final_hist, cube.as<double>(), 1, n + 1, m, N, st));
+    if (pipe) {
+      if ((rc = pipe->push(cube.p, out->alpha, cube.bytes, nullptr, st))) return rc;
+    } else {
+      HIP_TRY(hipMemcpyAsync(out->alpha, cube.p, cube.bytes, hipMemcpyDeviceToHost, st));
+    }
+  }
+  if (smoother) {
     if (out->alphahat || out->Vt) {
       HIP_TRY(d_mean.alloc((size_t)(n + 1) * m * sizeof(double)));
       HIP_TRY(d_cov.alloc((size_t)(n + 1) * m * m * sizeof(double)));
       HIP_TRY(bssm::launch_summary(final_hist, d_mean.as<double>(), d_cov.as<double>(), 1, n + 1, m, N, st));
       std::vector<double> hmean((size_t)(n + 1) * m);
-      HIP_TRY(hipMemcpy(hmean.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpyAsync(hmean.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost, st));
+      if (out->Vt) HIP_TRY(hipMemcpyAsync(out->Vt, d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
       if (out->alphahat) transpose_to(hmean, m, n + 1, out->alphahat);  // arma::inplace_trans(alphahat)
-      if (out->Vt) HIP_TRY(hipMemcpy(out->Vt, d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost));
     }
   } else if (out->at || out->att || out->Pt || out->Ptt) {  // filter_summary (src/R_bootstrap_filter.cpp:143-147)
     HIP_TRY(d_mean.alloc((size_t)(n + 1) * m * sizeof(double)));
@@ -373,20 +546,20 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
     HIP_TRY(bssm::launch_filter_summary(final_hist, db.weights.as<double>(), d_mean.as<double>(), d_att.as<double>(),
                                         d_cov.as<double>(), d_Ptt.as<double>(), 1, n, m, N, st));
     std::vector<double> h1((size_t)(n + 1) * m), h2((size_t)n * m);
-    HIP_TRY(hipMemcpy(h1.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h2.data(), d_att.p, d_att.bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(h1.data(), d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h2.data(), d_att.p, d_att.bytes, hipMemcpyDeviceToHost, st));
+    if (out->Pt) HIP_TRY(hipMemcpyAsync(out->Pt, d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost, st));
+    if (out->Ptt) HIP_TRY(hipMemcpyAsync(out->Ptt, d_Ptt.p, d_Ptt.bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (out->at) transpose_to(h1, m, n + 1, out->at);
     if (out->att) transpose_to(h2, m, n, out->att);
-    if (out->Pt) HIP_TRY(hipMemcpy(out->Pt, d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost));
-    if (out->Ptt) HIP_TRY(hipMemcpy(out->Ptt, d_Ptt.p, d_Ptt.bytes, hipMemcpyDeviceToHost));
   }
-  if (out->alpha) {
-    HIP_TRY(cube.alloc(hist_elems * sizeof(double)));
-    HIP_TRY(bssm::launch_to_cube(final_hist, cube.as<double>(), 1, n + 1, m, N, st));
-    HIP_TRY(hipMemcpy(out->alpha, cube.p, cube.bytes, hipMemcpyDeviceToHost));
+  if (!pipe) {
+    if (out->weights) HIP_TRY(hipMemcpyAsync(out->weights, db.weights.p, db.weights.bytes, hipMemcpyDeviceToHost, st));
+    if (out->indices) HIP_TRY(hipMemcpyAsync(out->indices, db.indices.p, db.indices.bytes, hipMemcpyDeviceToHost, st));
   }
-  if (out->weights) HIP_TRY(hipMemcpy(out->weights, db.weights.p, db.weights.bytes, hipMemcpyDeviceToHost));
-  if (out->indices) HIP_TRY(hipMemcpy(out->indices, db.indices.p, db.indices.bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (pipe && (rc = pipe->finish())) return rc;
   HIP_TRY(hipDeviceSynchronize());
   return degenerate ? BSSM_WARN_DEGENERATE : BSSM_OK;
 }

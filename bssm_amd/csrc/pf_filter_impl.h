@@ -915,8 +915,19 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     else hipLaunchKernelGGL(kern, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q], t);
   };
   if (!timing || timing->every <= 0) {
-    for (int t = -1; t < b.n; t++)
+    const int pe = (timing && parts == 1) ? timing->progress_every : 0;
+    for (int t = -1; t < b.n; t++) {
       for (int q = 0; q < parts; q++) step(q, t);
+      // launch t completes time point t + 1 of the history and time point t of weights / ancestors
+      if (pe > 0 && t >= 0 && (t + 1) % pe == 0 && t + 1 < b.n && timing->progress_count < StepTiming::kMaxProgress) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+          (void)hipEventRecord(ev, stream);
+          timing->progress_events[timing->progress_count] = ev;
+          timing->progress_steps[timing->progress_count++] = t + 1;
+        }
+      }
+    }
   } else {
     // windows of kWin consecutive step launches (of the first sequence) bracketed by one event pair each: the event
     // overhead (a few us) is amortised over the window, so total/count is the per-launch kernel cadence

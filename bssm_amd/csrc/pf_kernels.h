@@ -64,7 +64,16 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out);
 void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
 // Optional per-launch timing of the step kernel: every `every`-th step launch is bracketed by HIP
 // events on `stream`; the caller reads total_ms / count after the stream has drained.
-struct StepTiming { int every = 0; int count = 0; double total_ms = 0.0; int concurrent = 1; };  // concurrent: launch sequences in flight
+// `progress_every` > 0 (single-sequence launches only): an event is recorded on the launch stream after every that many
+// time steps (progress_steps[k] = time points complete when progress_events[k] fires), so that the caller can stream
+// finished time slabs of the outputs to the host while the filter is still stepping.
+struct StepTiming {
+  int every = 0; int count = 0; double total_ms = 0.0; int concurrent = 1;  // concurrent: launch sequences in flight
+  int progress_every = 0, progress_count = 0;
+  static constexpr int kMaxProgress = 64;
+  hipEvent_t progress_events[kMaxProgress] = {};
+  int progress_steps[kMaxProgress] = {};
+};
 hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream,
                               StepTiming* timing = nullptr);
 // Name (with template arguments) of the filter kernel variant the calling thread launched last, as the launcher picked
