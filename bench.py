@@ -47,16 +47,12 @@ def pmc_traffic(R, N, ppt):
     return None
 
 
-def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=False):
-    """SURVEY.md 8d config C5 (north_star: IS post-correction sharded over the GPUs of a node): 2 340 retained draws of
-    the ssm_nlg growth model, psi-APF N = 4096, T = 300, split into contiguous blocks over the ranks (strong scaling of
-    one job), log-weights all-gathered over RCCL.  Every rank takes part in every collective whatever happens locally
-    (a local failure is flagged through an all-reduce first), so this phase cannot dead-lock the benchmark."""
+def _c5_job(ns):
+    """ssm_nlg growth model, T = 300, m = 2; `ns` retained draws around theta-hat"""
     import numpy as np
-    import torch
-    from bssm_amd import filters as F, models as M, post_correct as PC
+    from bssm_amd import models as M
     rng = np.random.default_rng(105)
-    n, K, dT, ns, nsim = 300, 500.0, 0.1, 2340, 4096
+    n, K, dT = 300, 500.0, 0.1
     r = np.zeros(n); pp = np.zeros(n); pp[0] = 50.0
     for t in range(1, n):
         r[t] = r[t - 1] + rng.normal(0, 0.05)
@@ -67,10 +63,23 @@ def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=Fals
     model = M.ssm_nlg(y, "nlg_growth", theta=th0, known_params=[dT, K, 0.0, 50.0, 1.0, 100.0])
     theta = th0 + rng.normal(0, 0.05, (ns, 3))
     counts = rng.geometric(0.234, ns).astype(np.uint32)
+    return model, theta, counts, n
+
+
+def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=False, ns=2340, label="C5"):
+    """SURVEY.md 8d config C5 (north_star: IS post-correction sharded over the GPUs of a node): `ns` retained draws of
+    the ssm_nlg growth model, psi-APF N = 4096, T = 300, split into contiguous blocks over the ranks (strong scaling of
+    one job), log-weights all-gathered over RCCL.  Every rank takes part in every collective whatever happens locally
+    (a local failure is flagged through an all-reduce first), so this phase cannot dead-lock the benchmark."""
+    import numpy as np
+    import torch
+    from bssm_amd import filters as F, post_correct as PC
+    nsim = 4096
+    model, theta, counts, n = _c5_job(ns)
     bounds = PC.shard_bounds(np.ones(ns), world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    threads = max(1, min(8, (os.cpu_count() or 8) // max(1, world)))
-    times, weights, err = [], None, ""
+    threads = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))  # the host cores are shared by the ranks of the node
+    times, splits, weights, err = [], [], None, ""
     for it in range(reps + 1):  # first pass warms the arena and the module
         if dist is not None:
             dist.barrier()
@@ -78,6 +87,7 @@ def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=Fals
         t0 = time.perf_counter()
         loc_w = np.zeros(hi - lo)
         ok = 1.0
+        split = [0.0, 0.0, 0.0]  # this rank: per-draw host set-up ms, device phase ms (they overlap), collective ms
         try:
             if it == 0:  # the stored modes: here the mode at theta-hat for every draw (approximate_for_is re-linearises there)
                 mode = F.psi_setup(model)["mode"].reshape(-1, order="F")
@@ -85,9 +95,11 @@ def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=Fals
             if hi > lo:
                 loc = PC._run_local_block_nlg(model, theta[lo:hi], modes, counts[lo:hi], lo, ns, nsim, 1, 2, 3, threads)
                 loc_w = np.log(loc["weights"])
+                split[0], split[1] = loc["timing_ms"]["host_setup"], loc["timing_ms"]["device"]
         except Exception as e:  # noqa: BLE001 -- reported, never raised past the collectives
             ok, err = 0.0, repr(e)[:200]
         if dist is not None:
+            tc = time.perf_counter()
             flag = torch.tensor([ok], device=cdev, dtype=torch.float64)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = float(flag.item())
@@ -97,19 +109,25 @@ def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=Fals
             outs = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(outs, pad)
             weights = np.concatenate([outs[q].cpu().numpy()[:int(bounds[q + 1] - bounds[q])] for q in range(world)])
+            split[2] = (time.perf_counter() - tc) * 1e3  # includes waiting for the slowest rank
         else:
             weights = loc_w
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([el], device=cdev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
+            tt = torch.tensor([el] + split, device=cdev, dtype=torch.float64)
+            allt = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            el = max(float(x[0]) for x in allt)
+            split_all = [[float(v) for v in x[1:]] for x in allt]
+        else:
+            split_all = [split]
         if ok < 1.0:
             return {"error": err or "a rank failed"}
         if it > 0:
             times.append(el)
-    best = min(times)
+            splits.append(split_all)
+    best = int(np.argmin(times))
     extra = {}
     if cpu_baseline and world == 1:
         # the reference-equivalent CPU path of THIS phase: one psi-APF per draw, OpenMP static schedule over the draws on
@@ -124,11 +142,66 @@ def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=Fals
                                  "sample": "%d of the %d draws, OpenMP schedule(static) over draws with %d threads, gcc -O2, %.1f s"
                                            % (sample, ns, cores, ec)}
         extra["parity_max_abs_dlogw_vs_oracle"] = float(np.max(np.abs(weights[:sample] - ref)))
-    return {**extra, "workload": "C5: ssm_nlg growth, T=300, m=2, %d retained draws, psi-APF N=%d, IS2 weights (output theta), draws split in "
-                        "contiguous blocks over the ranks, log-weights all-gathered (RCCL)" % (ns, nsim),
-            "scaling": "strong", "n_gpus": world, "seconds": best, "draws_per_s": ns / best,
-            "value": ns * float(nsim) * n / best, "unit": "particle-steps/s", "host_threads_per_rank": threads,
+    return {**extra, "workload": "%s: ssm_nlg growth, T=300, m=2, %d retained draws, psi-APF N=%d, IS2 weights (output theta), draws split in "
+                        "contiguous blocks over the ranks, log-weights all-gathered (RCCL)" % (label, ns, nsim),
+            "scaling": "strong", "n_gpus": world, "seconds": times[best], "draws_per_s": ns / times[best],
+            "value": ns * float(nsim) * n / times[best], "unit": "particle-steps/s", "host_threads_per_rank": threads,
+            "per_rank_ms": [{"rank": q, "setup_ms": round(v[0], 2), "device_ms": round(v[1], 2), "collective_ms": round(v[2], 2)}
+                            for q, v in enumerate(splits[best])],
+            "per_rank_note": "set-up (host threads) and device phase overlap inside a rank; collective_ms includes waiting for the slowest rank",
             "finite_weights": bool(np.all(np.isfinite(weights))), "checksum_logw": float(np.sum(weights))}
+
+
+_SINGLE_PROCESS_SNIPPET = r"""
+import json, os, sys, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+import bench
+from bssm_amd import filters as F, post_correct as PC
+ns, nsim = int(sys.argv[1]), 4096
+model, theta, counts, n = bench._c5_job(ns)
+mode = F.psi_setup(model)["mode"].reshape(-1, order="F")
+modes = np.repeat(mode[:, None], ns, axis=1)
+threads = max(1, min(64, (os.cpu_count() or 8)))
+res = {}
+for devices in (None, "all"):
+    best, tm = 1e9, None
+    for it in range(3):
+        t0 = time.perf_counter()
+        loc = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, nsim, 1, 2, 3, threads, devices=devices)
+        el = time.perf_counter() - t0
+        if it and el < best:
+            best, tm = el, loc["timing_ms"]
+    res["one_device" if devices is None else "all_devices"] = {"seconds": best, "timing": tm, "checksum_logw": float(np.sum(np.log(loc["weights"])))}
+print("RESULT " + json.dumps(res))
+"""
+
+
+def single_process_multi_device(ns):
+    """The in-library sharding (bssm_is_correction_nlg_multi: one host thread + hipSetDevice per GPU, one RCCL all-gather
+    from ncclCommInitAll) on every GPU this process can see, in a child process with a time limit so that a collective
+    that cannot start never blocks the benchmark.  Only when more than one GPU is visible."""
+    import subprocess
+    import sys
+    import torch
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        return {"skipped": "one visible GPU", "visible_gpus": nd}
+    try:
+        cp = subprocess.run([sys.executable, "-c", _SINGLE_PROCESS_SNIPPET, str(ns)], capture_output=True, text=True, timeout=300,
+                            cwd=os.path.dirname(os.path.abspath(__file__)))
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout (300 s)", "visible_gpus": nd}
+    for line in cp.stdout.splitlines():
+        if line.startswith("RESULT "):
+            r = json.loads(line[7:])
+            r["visible_gpus"] = nd
+            r["draws"] = ns
+            a, b = r["one_device"], r["all_devices"]
+            r["speedup"] = a["seconds"] / b["seconds"]
+            r["identical_weights"] = a["checksum_logw"] == b["checksum_logw"]
+            return r
+    return {"error": (cp.stderr or cp.stdout)[-300:], "visible_gpus": nd}
 
 
 def main():
@@ -316,6 +389,18 @@ def main():
             pc = {"error": repr(e)[:200]}
         if rank == 0:
             out["post_correct"] = pc
+        # the same job eight times larger (what a 160 000-iteration chain retains): long enough for a scaling curve
+        try:
+            pc8 = post_correct_phase(rank, world, dist, cdev, reps=2, ns=8 * 2340, label="C5 x8 draws")
+        except Exception as e:  # noqa: BLE001
+            pc8 = {"error": repr(e)[:200]}
+        if rank == 0:
+            out["post_correct_large"] = pc8
+        if rank == 0 and world == 1:
+            try:
+                out["post_correct_single_process"] = single_process_multi_device(8 * 2340)
+            except Exception as e:  # noqa: BLE001
+                out["post_correct_single_process"] = {"error": repr(e)[:200]}
 
     if rank == 0 and os.environ.get("BSSM_BENCH_CALIB"):
         # profiling runs only (scripts/profile_round.sh): one kernel of known traffic (2 GiB read + 2 GiB written) so that

@@ -26,6 +26,8 @@
 #include "pf_device.h"
 #include "pf_functors.h"
 #include "pf_kernels.h"
+#include "rccl_gather.h"
+#include "tls_stream.h"
 
 namespace {
 
@@ -230,9 +232,9 @@ class OutPipe {
 
   int start() {
     if (started_) return BSSM_OK;
-    static thread_local hipStream_t cs = nullptr;
-    if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    cs_ = cs;
+    static thread_local bssm::TlsStream cs;
+    cs_ = cs.get();
+    if (!cs_) return fail(BSSM_ERR_HIP, "output pipe: no copy stream");
     for (int s = 0; s < kSlots; s++) {
       HIP_TRY(ring_[s].alloc(chunk_));
       HIP_TRY(hipEventCreateWithFlags(&done_[s], hipEventDisableTiming));
@@ -470,9 +472,9 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
   }
   // Everything runs on one non-blocking stream of this host thread; finished time slabs of weights / ancestors leave
   // through the output pipe while the filter is still stepping, the particle cube follows block by block after it.
-  static thread_local hipStream_t st_own = nullptr;
-  if (!st_own) HIP_TRY(hipStreamCreateWithFlags(&st_own, hipStreamNonBlocking));
-  hipStream_t st = st_own;
+  static thread_local bssm::TlsStream st_own;
+  hipStream_t st = st_own.get();
+  if (!st) return fail(BSSM_ERR_HIP, "no stream for the filter call");
   const size_t hist_elems = (size_t)(n + 1) * m * N;
   const size_t out_bytes = (out->alpha ? hist_elems * sizeof(double) : 0) + (out->weights ? db.weights.bytes : 0) +
                            (out->indices ? db.indices.bytes : 0);
@@ -1174,12 +1176,10 @@ int device_lg_batch(const std::vector<const bssm::LgPacked*>& lgs, const std::ve
   if (F == 0) return 0;
   const bssm::LgPacked& L0 = *lgs[0];
   for (int q = 1; q < F; q++) if (!L0.same_layout(*lgs[q])) return 1;
-  static thread_local hipStream_t st = nullptr;
-  if (!st) {  // highest priority: the lanes of this small kernel compete with filter workgroups that fill every CU
-    int lo_p = 0, hi_p = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-    HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi_p));
-  }
+  // highest priority: the lanes of this small kernel compete with filter workgroups that fill every CU
+  static thread_local bssm::TlsStream st_tls;
+  hipStream_t st = st_tls.get(true);
+  if (!st) return fail(BSSM_ERR_HIP, "no stream for the set-up smoother");
   const size_t n = L0.n, m = L0.m, mm = m * m, n1 = n + 1, ins = L0.buf.size();
   const size_t o_at = 0, o_pt = o_at + n1 * m, o_cc = o_pt + n1 * mm, outs_per = o_cc + n1 * mm;
   StageBuf sin, sout;
@@ -1430,43 +1430,65 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
   if (!have_device()) return no_device();
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const int chunk = 512;  // two rounds of one workgroup per CU
+  // Chunk = two rounds of one workgroup per CU, but never fewer than four chunks per call: a shard of a few hundred
+  // draws (eight ranks on a 2 340-draw job) would otherwise be ONE chunk and lose the set-up / filter overlap.
+  int chunk = 512;
+  if (const char* env = std::getenv("BSSM_AMD_IS_CHUNK")) chunk = std::max(1, std::atoi(env));
+  else if (cnt < 4 * chunk) chunk = std::max(64, ((cnt + 3) / 4 + 63) / 64 * 64);
   std::vector<std::string> errs(cnt);
-  std::thread worker;
+  // ONE device thread for the whole call (it only waits on HIP): chunks are handed over through a queue, so its
+  // thread-local streams are made once, and chunk c + 1 is prepared while chunk c filters.
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::pair<int, int>> queue;
+  size_t taken = 0;
+  bool closing = false;
   int dev_rc = BSSM_OK, worst = BSSM_OK;
   std::string dev_err;
   double t_host = 0, t_dev = 0;
-  auto join = [&]() {
-    if (worker.joinable()) worker.join();
-    if (dev_rc < 0) return false;
-    if (dev_rc == BSSM_WARN_DEGENERATE) worst = BSSM_WARN_DEGENERATE;
-    return true;
+  std::thread worker([&]() {
+    (void)hipSetDevice(dev);  // the current device is per host thread
+    for (;;) {
+      std::pair<int, int> job;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return taken < queue.size() || closing; });
+        if (taken >= queue.size()) return;
+        job = queue[taken++];
+      }
+      if (dev_rc < 0) continue;  // drain
+      const double t1 = now_ms();
+      const int rc = run_is_core(J, job.first, job.second, weights, loglik, alpha, alphahat_i, Vt_i);
+      if (rc < 0) { dev_err = g_err; dev_rc = rc; }
+      else if (rc == BSSM_WARN_DEGENERATE) worst = BSSM_WARN_DEGENERATE;
+      t_dev += now_ms() - t1;
+    }
+  });
+  auto close = [&]() {
+    { std::lock_guard<std::mutex> lk(mu); closing = true; }
+    cv.notify_all();
+    worker.join();
   };
   for (int lo = 0; lo < cnt; lo += chunk) {
     const int hi = std::min(cnt, lo + chunk);
     const double t0 = now_ms();
     parallel_for(hi - lo, n_threads, [&](int q) { errs[lo + q] = prepare(lo + q); });
-    for (int i = lo; i < hi; i++) if (!errs[i].empty()) { join(); return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]); }
+    for (int i = lo; i < hi; i++) if (!errs[i].empty()) { close(); return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]); }
     if (device_chunk) {
       const int rc = device_chunk(lo, hi);
-      if (rc < 0) { join(); return rc; }
+      if (rc < 0) { close(); return rc; }
     }
     if (post) {
       parallel_for(hi - lo, n_threads, [&](int q) { errs[lo + q] = post(lo + q); });
-      for (int i = lo; i < hi; i++) if (!errs[i].empty()) { join(); return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]); }
+      for (int i = lo; i < hi; i++) if (!errs[i].empty()) { close(); return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]); }
     }
     if (finish_chunk) finish_chunk(lo, hi);
     t_host += now_ms() - t0;
-    if (!join()) return fail(dev_rc, dev_err);
-    worker = std::thread([&, lo, hi]() {
-      (void)hipSetDevice(dev);  // the current device is per host thread
-      const double t1 = now_ms();
-      dev_rc = run_is_core(J, lo, hi, weights, loglik, alpha, alphahat_i, Vt_i);
-      if (dev_rc < 0) dev_err = g_err;
-      t_dev += now_ms() - t1;
-    });
+    { std::lock_guard<std::mutex> lk(mu); queue.emplace_back(lo, hi); }
+    cv.notify_all();
   }
-  if (!join()) return fail(dev_rc, dev_err);
+  close();
+  if (dev_rc < 0) return fail(dev_rc, dev_err);
   g_is_timing[0] = t_host; g_is_timing[1] = t_dev;
   return worst;
 }
@@ -1689,6 +1711,216 @@ int bssm_is_merge(int32_t n, int32_t m, int32_t n_stored, const double* weights,
   }
   for (size_t q = 0; q < mmt; q++) Vt[q] += Valpha[q] / sum_w;  // :422-424
   return BSSM_OK;
+}
+
+// ------------------------------------------------------------------ one call, several GPUs
+}  // extern "C"
+namespace {
+// Shard record of the last multi-device post-correction on this thread (bssm_amd_last_is_shards)
+struct ShardInfo { int device, first, count; double setup_ms, device_ms, total_ms; };
+thread_local std::vector<ShardInfo> g_shards;
+thread_local double g_collective_ms = 0.0;
+thread_local int g_gather_kind = 0;  // 0 none, 1 RCCL all-gather, 2 device copies (shards sharing a device)
+
+// contiguous blocks with (nearly) equal total work: bssm_amd/post_correct.py shard_bounds, so that the single-process
+// and the one-process-per-GPU drivers cut the draws at the same places
+std::vector<int> shard_bounds(const uint32_t* counts, int cnt, int is_type, int world) {
+  std::vector<double> cum(cnt + 1, 0.0);
+  for (int i = 0; i < cnt; i++) cum[i + 1] = cum[i] + (is_type == 1 ? (double)counts[i] : 1.0);
+  std::vector<int> b(world + 1, 0);
+  for (int r = 1; r < world; r++) {
+    const double target = cum[cnt] * r / world;
+    const int k = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+    b[r] = std::min(std::max(k, b[r - 1]), cnt);
+  }
+  b[world] = cnt;
+  return b;
+}
+
+// The draws of one post-correction call spread over `devices` (HIP ordinals; the same ordinal may appear more than
+// once = logical shards on one GPU): one host thread per shard sets its device and runs the single-device driver on
+// its block (run_shard(lo, hi, threads)), which fills the caller's per-draw alpha / summary blocks directly (every
+// draw has a slot of its own) and hands weights / log-likelihoods to `w_loc`, `ll_loc`.  Those two vectors are what
+// the shards exchange: each puts its padded block in device memory, ONE ncclAllGather (RCCL over xGMI; comms from
+// ncclCommInitAll, cached) gives every device the whole vector, and the caller's arrays are filled from the first
+// device's copy.  Mirrors approx_mcmc::is_correction_* spreading the draws over OpenMP threads inside one call
+// (src/approx_mcmc.cpp:364-369, schedule(static)).
+int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t* devices_in, int n_devices_in, int n_threads,
+                     const std::function<int(int, int, int, double*, double*)>& run_shard, double* weights, double* loglik) {
+  if (!have_device()) return no_device();
+  int visible = 0;
+  HIP_TRY(hipGetDeviceCount(&visible));
+  std::vector<int> devices;
+  if (devices_in && n_devices_in > 0) devices.assign(devices_in, devices_in + n_devices_in);
+  else for (int d = 0; d < visible; d++) devices.push_back(d);
+  for (int d : devices) if (d < 0 || d >= visible) return fail(BSSM_ERR_INVALID, "device ordinal " + std::to_string(d) + " is not visible");
+  const int world = (int)devices.size();
+  const std::vector<int> bounds = shard_bounds(counts, cnt, is_type, world);
+  int block = 0;
+  for (int r = 0; r < world; r++) block = std::max(block, bounds[r + 1] - bounds[r]);
+  bool distinct = true;
+  for (int a = 0; a < world; a++) for (int b = a + 1; b < world; b++) if (devices[a] == devices[b]) distinct = false;
+  int dev0 = 0;
+  (void)hipGetDevice(&dev0);
+  const int threads_each = std::max(1, n_threads / world);  // the host cores are shared by the shards
+
+  std::vector<ShardInfo> info(world);
+  std::vector<int> rcs(world, BSSM_OK);
+  std::vector<std::string> errs(world);
+  std::vector<double*> d_send(world, nullptr), d_recv(world, nullptr);
+  std::vector<size_t> cap_send(world, 0), cap_recv(world, 0);
+  std::vector<hipStream_t> streams(world, nullptr);
+  std::vector<std::thread> pool;
+  const double t_all = now_ms();
+  for (int r = 0; r < world; r++) {
+    pool.emplace_back([&, r]() {
+      const int lo = bounds[r], hi = bounds[r + 1];
+      info[r] = ShardInfo{devices[r], lo, hi - lo, 0.0, 0.0, 0.0};
+      auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        errs[r] = std::string(what) + ": " + hipGetErrorString(e); rcs[r] = BSSM_ERR_HIP; return false;
+      };
+      if (!hip_ok(hipSetDevice(devices[r]), "hipSetDevice")) return;
+      const double t0 = now_ms();
+      std::vector<double> buf((size_t)2 * block, 0.0);  // [weights | log-likelihoods], padded to the largest block
+      if (hi > lo) {
+        const int rc = run_shard(lo, hi, threads_each, buf.data(), buf.data() + block);
+        rcs[r] = rc;
+        if (rc < 0) { errs[r] = g_err; return; }
+        info[r].setup_ms = g_is_timing[0]; info[r].device_ms = g_is_timing[1];
+      }
+      // the shard's block into device memory for the exchange (these two buffers outlive the thread: raw arena blocks)
+      void *ps = nullptr, *pr = nullptr;
+      if (!hip_ok(arena().get((size_t)2 * block * sizeof(double), &ps, &cap_send[r]), "exchange buffer")) return;
+      d_send[r] = (double*)ps;
+      if (!hip_ok(arena().get((size_t)2 * block * world * sizeof(double), &pr, &cap_recv[r]), "exchange buffer")) return;
+      d_recv[r] = (double*)pr;
+      if (!hip_ok(hipStreamCreateWithFlags(&streams[r], hipStreamNonBlocking), "hipStreamCreate")) return;
+      if (!hip_ok(hipMemcpyAsync(d_send[r], buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice, streams[r]), "upload of the shard's weights")) return;
+      if (!hip_ok(hipStreamSynchronize(streams[r]), "hipStreamSynchronize")) return;
+      info[r].total_ms = now_ms() - t0;
+    });
+  }
+  for (auto& th : pool) th.join();
+  int worst = BSSM_OK;
+  std::string err;
+  for (int r = 0; r < world && worst >= 0; r++) {
+    if (rcs[r] < 0) { worst = rcs[r]; err = "shard " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + errs[r]; }
+    else if (rcs[r] == BSSM_WARN_DEGENERATE) worst = BSSM_WARN_DEGENERATE;
+  }
+  // ---- the collective
+  const double t_c = now_ms();
+  const size_t blk = (size_t)2 * block;
+  std::vector<double> gathered(blk * world, 0.0);
+  int kind = 0;
+  if (worst >= 0 && blk > 0) {
+    std::string why;
+    const char* env = std::getenv("BSSM_AMD_GATHER");  // "copy" forces the device-copy exchange
+    const bool want_rccl = distinct && !(env && std::string(env) == "copy");
+    if (want_rccl) {
+      std::vector<const double*> snd(d_send.begin(), d_send.end());
+      if (bssm::rccl_all_gather(devices, snd, d_recv, blk, streams, &why) != 0) { worst = BSSM_ERR_HIP; err = why; }
+      else {
+        kind = 1;
+        for (int r = 0; r < world && worst >= 0; r++) {
+          (void)hipSetDevice(devices[r]);
+          if (hipStreamSynchronize(streams[r]) != hipSuccess) { worst = BSSM_ERR_HIP; err = "all-gather: stream synchronise failed"; }
+        }
+      }
+    } else {  // shards sharing a GPU cannot be ranks of one communicator: same exchange as plain device copies
+      kind = 2;
+      (void)hipSetDevice(devices[0]);
+      for (int r = 0; r < world && worst >= 0; r++)
+        if (hipMemcpyAsync(d_recv[0] + blk * r, d_send[r], blk * sizeof(double), hipMemcpyDefault, streams[0]) != hipSuccess) { worst = BSSM_ERR_HIP; err = "exchange copy failed"; }
+      if (worst >= 0 && hipStreamSynchronize(streams[0]) != hipSuccess) { worst = BSSM_ERR_HIP; err = "exchange copy failed"; }
+    }
+    if (worst >= 0) {
+      (void)hipSetDevice(devices[0]);
+      if (hipMemcpy(gathered.data(), d_recv[0], gathered.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { worst = BSSM_ERR_HIP; err = "download of the gathered weights failed"; }
+    }
+  }
+  for (int r = 0; r < world; r++) {
+    (void)hipSetDevice(devices[r]);
+    if (streams[r]) (void)hipStreamDestroy(streams[r]);
+    if (d_send[r]) arena().put(d_send[r], cap_send[r]);
+    if (d_recv[r]) arena().put(d_recv[r], cap_recv[r]);
+  }
+  (void)hipSetDevice(dev0);
+  if (worst < 0) return fail(worst, err);
+  for (int r = 0; r < world; r++) {
+    const int lo = bounds[r], c = bounds[r + 1] - lo;
+    std::memcpy(weights + lo, gathered.data() + blk * r, (size_t)c * sizeof(double));
+    if (loglik) std::memcpy(loglik + lo, gathered.data() + blk * r + block, (size_t)c * sizeof(double));
+  }
+  g_collective_ms = now_ms() - t_c;
+  g_gather_kind = kind;
+  g_shards = info;
+  double th = 0, td = 0;
+  for (const ShardInfo& si : info) { th = std::max(th, si.setup_ms); td = std::max(td, si.device_ms); }
+  g_is_timing[0] = th; g_is_timing[1] = td;
+  if (std::getenv("BSSM_AMD_TRACE"))
+    std::fprintf(stderr, "[bssm_amd] post-correction over %d shard(s): %.1f ms, of which the exchange (%s) %.2f ms\n", world,
+                 now_ms() - t_all, kind == 1 ? "RCCL all-gather" : "device copies", g_collective_ms);
+  return worst;
+}
+}  // namespace
+extern "C" {
+
+int bssm_is_correction_multi(const bssm_is_job* job, const int32_t* devices, int32_t n_devices, double* weights,
+                             double* loglik, double* alpha, double* alphahat_i, double* Vt_i) {
+  if (!job || !weights) return fail(BSSM_ERR_INVALID, "job/weights NULL");
+  if (job->count <= 0) return BSSM_OK;
+  if (!job->counts || !job->models) return fail(BSSM_ERR_INVALID, "counts/models NULL");
+  const size_t n = job->models[0].n, m = job->models[0].m, p = job->models[0].p > 1 ? job->models[0].p : 1;
+  auto run_shard = [&](int lo, int hi, int threads, double* w_loc, double* ll_loc) -> int {
+    bssm_is_job sub = *job;
+    sub.first = job->first + lo; sub.count = hi - lo;
+    sub.models = job->models + lo;
+    sub.modes = job->modes ? job->modes + n * p * lo : nullptr;
+    sub.approx_loglik = job->approx_loglik ? job->approx_loglik + lo : nullptr;
+    sub.counts = job->counts + lo;
+    sub.n_threads = threads;
+    return bssm_is_correction(&sub, w_loc, ll_loc, alpha ? alpha + (n + 1) * m * lo : nullptr,
+                              alphahat_i ? alphahat_i + (n + 1) * m * lo : nullptr, Vt_i ? Vt_i + (n + 1) * m * m * lo : nullptr);
+  };
+  return run_multi_device(job->count, job->counts, job->is_type, devices, n_devices, job->n_threads, run_shard, weights, loglik);
+}
+
+int bssm_is_correction_nlg_multi(const bssm_fn_model* models, int32_t first, int32_t count, const double* modes,
+                                 const double* approx_loglik, const uint32_t* counts, int32_t sampling_method,
+                                 int32_t is_type, int32_t output_type, uint32_t nsim, uint32_t seed, int32_t n_threads,
+                                 const int32_t* devices, int32_t n_devices, double* weights, double* loglik, double* alpha,
+                                 double* alphahat_i, double* Vt_i) {
+  if (!models || !weights || !counts) return fail(BSSM_ERR_INVALID, "models/weights/counts NULL");
+  if (count <= 0) return BSSM_OK;
+  const int id = models[0].model_id;
+  const size_t n = models[0].n, m = id == bssm::FN_NLG_GROWTH ? 2 : (id == bssm::FN_USER_NLG ? models[0].n_states : 1);
+  auto run_shard = [&](int lo, int hi, int threads, double* w_loc, double* ll_loc) -> int {
+    return bssm_is_correction_nlg(models + lo, first + lo, hi - lo, modes ? modes + m * n * lo : nullptr,
+                                  approx_loglik ? approx_loglik + lo : nullptr, counts + lo, sampling_method, is_type,
+                                  output_type, nsim, seed, threads, w_loc, ll_loc, alpha ? alpha + (n + 1) * m * lo : nullptr,
+                                  alphahat_i ? alphahat_i + (n + 1) * m * lo : nullptr, Vt_i ? Vt_i + (n + 1) * m * m * lo : nullptr);
+  };
+  return run_multi_device(count, counts, is_type, devices, n_devices, n_threads, run_shard, weights, loglik);
+}
+
+int bssm_amd_last_is_shards(double* out, int32_t capacity, double* collective_ms, int32_t* gather_kind) {
+  const int ns = (int)g_shards.size();
+  for (int r = 0; r < ns && r < capacity; r++) {
+    const ShardInfo& s = g_shards[r];
+    double* o = out + (size_t)6 * r;
+    o[0] = s.device; o[1] = s.first; o[2] = s.count; o[3] = s.setup_ms; o[4] = s.device_ms; o[5] = s.total_ms;
+  }
+  if (collective_ms) *collective_ms = g_collective_ms;
+  if (gather_kind) *gather_kind = g_gather_kind;
+  return ns;
+}
+
+int bssm_amd_rccl_available(void) {
+  std::string why;
+  if (bssm::rccl_available(&why)) return 1;
+  g_err = why;
+  return 0;
 }
 
 // ------------------------------------------------------------------ device-resident plan

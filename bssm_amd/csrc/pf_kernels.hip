@@ -7,6 +7,7 @@
 
 #include "lg_smoother.h"
 #include "pf_filter_impl.h"
+#include "tls_stream.h"
 
 namespace bssm {
 
@@ -74,9 +75,8 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   ws->xcd_remap = 1;
   // ONE side stream per host thread for the whole library (streams share a small number of hardware queues: a pair per
   // kernel variant ended up serialised against each other)
-  static thread_local hipStream_t side = nullptr;
-  if (!side && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
-  ws->side = side;
+  static thread_local TlsStream side;
+  ws->side = side.get();
 }
 
 

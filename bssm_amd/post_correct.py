@@ -97,14 +97,48 @@ def shard_bounds(work: np.ndarray, world: int):
     return np.asarray(bounds, dtype=np.int64)
 
 
-def _last_timing():
+def _process_group(group):
+    """(rank, world, torch.distributed or None).  A process that never imported torch.distributed cannot have a process
+    group, and importing torch here would pull a second ROCm stack into callers that only use this library."""
+    import sys
+    _dist = sys.modules.get("torch.distributed")
+    if _dist is not None and _dist.is_available() and _dist.is_initialized():
+        return _dist.get_rank(group), _dist.get_world_size(group), _dist
+    return 0, 1, None
+
+
+def _last_timing(devices=None):
     t = (C.c_double * 2)()
     _lib.lib().bssm_amd_last_is_timing(t)
-    return dict(host_setup=t[0], device=t[1])
+    out = dict(host_setup=t[0], device=t[1])
+    if devices is not None:  # per-shard split of the in-library multi-device call
+        cap = 64
+        buf = (C.c_double * (6 * cap))()
+        coll, kind = C.c_double(0.0), C.c_int32(0)
+        ns = _lib.lib().bssm_amd_last_is_shards(buf, C.c_int32(cap), C.byref(coll), C.byref(kind))
+        out["shards"] = [dict(device=int(buf[6 * r]), first=int(buf[6 * r + 1]), count=int(buf[6 * r + 2]), setup_ms=buf[6 * r + 3],
+                              device_ms=buf[6 * r + 4], total_ms=buf[6 * r + 5]) for r in range(min(ns, cap))]
+        out["collective_ms"] = coll.value
+        out["gather"] = {0: "none", 1: "rccl_all_gather", 2: "device_copies"}[int(kind.value)]
+    return out
+
+
+def _devices_arg(devices):
+    """devices: None = the single-device entry point; "all" = every visible GPU; a list of HIP ordinals otherwise"""
+    if devices is None:
+        return None, 0
+    if isinstance(devices, str):
+        if devices != "all":
+            raise ValueError("devices must be None, 'all' or a list of HIP ordinals")
+        return None, 0
+    d = np.ascontiguousarray(list(devices), dtype=np.int32)
+    if d.size == 0:
+        raise ValueError("devices must not be empty")
+    return d, int(d.size)
 
 
 def _run_local_block(arrs, modes, counts, first, n_stored, nsim, seed, is_type, output_type, n_threads,
-                     method=1, approx_loglik=None):
+                     method=1, approx_loglik=None, devices=None):
     """Filter draws [first, first+len(arrs)) on this process's GPU through the C ABI."""
     cnt = len(arrs)
     n, m = arrs[0]["n"], arrs[0]["m"]
@@ -129,13 +163,20 @@ def _run_local_block(arrs, modes, counts, first, n_stored, nsim, seed, is_type, 
     alpha = np.zeros((n + 1, m, cnt), order="F") if output_type == 1 else None
     ah = np.zeros((m, n + 1, cnt), order="F") if output_type == 2 else None
     vt = np.zeros((m, m, n + 1, cnt), order="F") if output_type == 2 else None
-    rc = _lib.check(_lib.lib().bssm_is_correction(C.byref(job), _lib.dptr(weights), _lib.dptr(loglik), _lib.dptr(alpha),
-                                                  _lib.dptr(ah), _lib.dptr(vt)))
-    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1, timing_ms=_last_timing())
+    if devices is None:
+        rc = _lib.check(_lib.lib().bssm_is_correction(C.byref(job), _lib.dptr(weights), _lib.dptr(loglik), _lib.dptr(alpha),
+                                                      _lib.dptr(ah), _lib.dptr(vt)))
+    else:  # one call, several GPUs: host threads + hipSetDevice + RCCL all-gather inside the library
+        dv, nd = _devices_arg(devices)
+        rc = _lib.check(_lib.lib().bssm_is_correction_multi(
+            C.byref(job), None if dv is None else dv.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(nd), _lib.dptr(weights),
+            _lib.dptr(loglik), _lib.dptr(alpha), _lib.dptr(ah), _lib.dptr(vt)))
+    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1,
+                timing_ms=_last_timing(devices))
 
 
 def is_correction(model: BssmModel, theta, counts, particles: int, method: str = "psi", modes=None, approx_loglik=None,
-                  is_type: int = 2, output_type: int = 3, seed: int = 1, threads: int = 1):
+                  is_type: int = 2, output_type: int = 3, seed: int = 1, threads: int = 1, devices=None):
     """Single-process IS correction with either sampler (approx_mcmc::is_correction_psi / _bsf,
     src/approx_mcmc.cpp:353-427, 447-518) -- the step run_mcmc's `is` types run after the approximate chain."""
     counts = np.asarray(counts, dtype=np.uint32)
@@ -144,14 +185,14 @@ def is_correction(model: BssmModel, theta, counts, particles: int, method: str =
         # correction of sde_is_mcmc / sde_state_sampler_bsf_is2 (src/approx_mcmc.cpp:1038-1273, src/R_sde_state_sampler.cpp:10-50)
         theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
         res = _run_local_block_nlg(model, theta, modes, counts, 0, theta.shape[0], particles, seed, is_type, output_type, threads,
-                                   method=1 if method == "psi" else 2, approx_loglik=approx_loglik)
+                                   method=1 if method == "psi" else 2, approx_loglik=approx_loglik, devices=devices)
         if output_type == 2:
             m = int(model.get("n_states", 1))
             res["alphahat"], res["Vt"] = is_merge(model.n, m, res["weights"], counts, res["alphahat_i"], res["Vt_i"])
         return res
     arrs = expand_models(model, theta)
     res = _run_local_block(arrs, modes, counts, 0, len(arrs), particles, seed, is_type, output_type, threads,
-                           method=1 if method == "psi" else 2, approx_loglik=approx_loglik)
+                           method=1 if method == "psi" else 2, approx_loglik=approx_loglik, devices=devices)
     if output_type == 2:
         ah, vt = is_merge(model.n, model.m, res["weights"], counts, res["alphahat_i"], res["Vt_i"])
         res["alphahat"], res["Vt"] = ah, vt
@@ -159,16 +200,24 @@ def is_correction(model: BssmModel, theta, counts, particles: int, method: str =
 
 
 def _run_local_block_nlg(model, theta, modes, counts, first, n_stored, nsim, seed, is_type, output_type, n_threads,
-                         method=1, approx_loglik=None):
+                         method=1, approx_loglik=None, devices=None):
     """ssm_nlg draws [first, first + len(theta)) through bssm_is_correction_nlg (only theta differs between draws)."""
     cnt = theta.shape[0]
     n = model.n
     m = int(model.get("n_states", 1))
-    packed, keep = [], []
-    for i in range(cnt):
-        s, k = _lib.pack_fn_model({**model, "theta": theta[i]})
-        packed.append(s); keep.append(k)
-    models = (_lib.FnModel * cnt)(*packed)
+    # one struct per draw, only the theta pointer differs: replicate the packed template bytes and patch the pointer
+    # field (a Python loop over 18 720 draws cost more than the device phase)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    s0, keep = _lib.pack_fn_model({**model, "theta": theta[0]})
+    models = (_lib.FnModel * cnt)()
+    sz = C.sizeof(_lib.FnModel)
+    raw = np.frombuffer(models, dtype=np.uint8).reshape(cnt, sz)
+    raw[:] = np.frombuffer(bytes(s0), dtype=np.uint8)
+    off = _lib.FnModel.theta.offset
+    raw[:, off:off + 8].view(np.uint64)[:, 0] = theta.ctypes.data + np.arange(cnt, dtype=np.uint64) * np.uint64(theta.strides[0])
+    if int(s0.model_id) == 7 and any(callable(model.get(k)) for k in ("H", "R_diag", "a1", "P1")):
+        for i in range(cnt):  # user-defined model with theta-dependent H / R / a1 / P1 (src/model_ssm_nlg.h:10-21)
+            _lib.fill_user_numbers(models[i], model, theta[i])
     modes_c = None if modes is None else np.asfortranarray(modes, dtype=np.float64)
     al_c = None if approx_loglik is None else np.ascontiguousarray(approx_loglik, dtype=np.float64)
     counts_c = np.ascontiguousarray(counts, dtype=np.uint32)
@@ -176,11 +225,17 @@ def _run_local_block_nlg(model, theta, modes, counts, first, n_stored, nsim, see
     alpha = np.zeros((n + 1, m, cnt), order="F") if output_type == 1 else None
     ah = np.zeros((m, n + 1, cnt), order="F") if output_type == 2 else None
     vt = np.zeros((m, m, n + 1, cnt), order="F") if output_type == 2 else None
-    rc = _lib.check(_lib.lib().bssm_is_correction_nlg(
-        models, C.c_int32(first), C.c_int32(cnt), _lib.dptr(modes_c), _lib.dptr(al_c), counts_c.ctypes.data_as(_lib.c_u32_p),
-        C.c_int32(method), C.c_int32(is_type), C.c_int32(output_type), C.c_uint32(nsim), C.c_uint32(seed), C.c_int32(n_threads),
-        _lib.dptr(weights), _lib.dptr(loglik), _lib.dptr(alpha), _lib.dptr(ah), _lib.dptr(vt)))
-    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1, timing_ms=_last_timing())
+    head = (models, C.c_int32(first), C.c_int32(cnt), _lib.dptr(modes_c), _lib.dptr(al_c), counts_c.ctypes.data_as(_lib.c_u32_p),
+            C.c_int32(method), C.c_int32(is_type), C.c_int32(output_type), C.c_uint32(nsim), C.c_uint32(seed), C.c_int32(n_threads))
+    tail = (_lib.dptr(weights), _lib.dptr(loglik), _lib.dptr(alpha), _lib.dptr(ah), _lib.dptr(vt))
+    if devices is None:
+        rc = _lib.check(_lib.lib().bssm_is_correction_nlg(*head, *tail))
+    else:
+        dv, nd = _devices_arg(devices)
+        rc = _lib.check(_lib.lib().bssm_is_correction_nlg_multi(
+            *head, None if dv is None else dv.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(nd), *tail))
+    return dict(weights=weights, loglik=loglik, alpha=alpha, alphahat_i=ah, Vt_i=vt, degenerate=rc == 1,
+                timing_ms=_last_timing(devices))
 
 
 def _all_gather_blocks(local: np.ndarray, bounds, rank, world, group, device):
@@ -214,10 +269,15 @@ def is_merge(n, m, weights, counts, alphahat_i, Vt_i):
 
 
 def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: int = 1, is_type: str = "is2",
-                 seed: int | None = None, group=None):
+                 seed: int | None = None, group=None, devices=None):
     """R/post_correction.R:245-308.  ``mcmc_output`` needs: theta (n_stored x n_par), counts, modes
     (n x n_stored, or 1 x n x n_stored as R stores it), posterior, output_type ('full'|'summary'|'theta' or 1..3).
-    Returns a copy with weights / posterior (and alpha or alphahat, Vt) updated."""
+    Returns a copy with weights / posterior (and alpha or alphahat, Vt) updated.
+
+    Two ways onto several GPUs, both cutting the draws at the same places with the same streams (identical output):
+    ``devices="all"`` or a list of HIP ordinals -- ONE process, the library shards the call itself (host threads +
+    hipSetDevice + one RCCL all-gather; what an R caller gets); or ``torch.distributed`` initialised with one process
+    per GPU -- every rank filters its block and the results are all-gathered here."""
     particles = check_intmax(particles, "particles")
     threads = check_intmax(threads, "threads")
     seed = check_intmax(_default_seed() if seed is None else seed, "seed", False, max=_INT_MAX)
@@ -249,13 +309,7 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     n_stored = counts.size
 
     # ---- shard the draws over the process group
-    rank, world, dist = 0, 1, None
-    try:
-        import torch.distributed as _dist
-        if _dist.is_available() and _dist.is_initialized():
-            dist, rank, world = _dist, _dist.get_rank(group), _dist.get_world_size(group)
-    except ImportError:
-        pass
+    rank, world, dist = _process_group(group)
     work = counts.astype(np.float64) if is_t == 1 else np.ones(n_stored)
     bounds = shard_bounds(work, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
@@ -263,11 +317,11 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     m = (int(model.get("n_states", 1))) if nlg else model.m
     if hi > lo and nlg:
         loc = _run_local_block_nlg(model, theta[lo:hi], modes[:, lo:hi], counts[lo:hi], lo, n_stored, particles, seed, is_t,
-                                   output_type, threads)
+                                   output_type, threads, devices=devices)
     elif hi > lo:
         arrs = expand_models(model, theta[lo:hi])
         loc = _run_local_block(arrs, modes[:, lo:hi], counts[lo:hi], lo, n_stored, particles, seed, is_t, output_type,
-                               threads)
+                               threads, devices=devices)
     else:
         loc = dict(weights=np.zeros(0), loglik=np.zeros(0), alpha=np.zeros((n + 1, m, 0)),
                    alphahat_i=np.zeros((m, n + 1, 0)), Vt_i=np.zeros((m, m, n + 1, 0)), degenerate=False,
@@ -361,13 +415,7 @@ def suggest_N(model: BssmModel, theta, candidates=range(10, 101, 10), replicatio
         raise ValueError("Length of 'theta' does not match length of 'model$theta'.")
     cand = np.asarray(candidates, dtype=np.uint32)
     sds = np.zeros(cand.size)
-    rank, world, dist = 0, 1, None
-    try:
-        import torch.distributed as _dist
-        if _dist.is_available() and _dist.is_initialized():
-            dist, rank, world = _dist, _dist.get_rank(group), _dist.get_world_size(group)
-    except ImportError:
-        pass
+    rank, world, dist = _process_group(group)
     if world > 1:  # one process per GPU: the replications shard, one all-gather of the log-likelihoods
         if model.inherits("ssm_nlg"):
             mdl = BssmModel(model.classes, **{**model, "theta": theta})

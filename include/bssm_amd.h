@@ -270,6 +270,31 @@ typedef struct bssm_is_job {
 int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, double* alpha,
                        double* alphahat_i, double* Vt_i);
 
+/* ---- one post-correction call over several GPUs of the node (single process) ----
+ * The reference's postcorrection_nongaussian / postcorrection_nonlinear are ONE call whose `n_threads` argument spreads
+ * the retained draws over OpenMP threads (src/approx_mcmc.cpp:364-369, `omp parallel for schedule(static)`;
+ * src/R_postcorrection.cpp:150-158, 252-262).  The _multi entry points are that call for a node of GPUs: the draws are
+ * cut into contiguous static blocks (balanced by sum(count_i) for is1), one host thread per block sets its device
+ * (`devices[r]`, HIP ordinals; NULL / 0 = every visible device) and runs the single-device driver, and the per-draw
+ * weights / log-likelihoods are exchanged by ONE ncclAllGather (RCCL over xGMI, communicators from ncclCommInitAll,
+ * librccl opened lazily with dlopen).  The same ordinal may be listed more than once (logical shards on one GPU; the
+ * exchange is then plain device copies).  Streams are keyed by the global draw index, so the outputs are bit-identical
+ * to the single-device call for any device list.  `job->n_threads` host threads are divided between the shards.
+ * Arguments and outputs otherwise as bssm_is_correction / bssm_is_correction_nlg. */
+int bssm_is_correction_multi(const bssm_is_job* job, const int32_t* devices, int32_t n_devices, double* weights,
+                             double* loglik, double* alpha, double* alphahat_i, double* Vt_i);
+int bssm_is_correction_nlg_multi(const bssm_fn_model* models, int32_t first, int32_t count, const double* modes,
+                                 const double* approx_loglik, const uint32_t* counts, int32_t sampling_method,
+                                 int32_t is_type, int32_t output_type, uint32_t nsim, uint32_t seed, int32_t n_threads,
+                                 const int32_t* devices, int32_t n_devices, double* weights, double* loglik, double* alpha,
+                                 double* alphahat_i, double* Vt_i);
+/* shards of the last _multi call on this thread: out[6 * r + ...] = device, first draw, draws, host set-up ms, device
+ * phase ms, total ms of shard r (at most `capacity` shards written); *collective_ms = the exchange;
+ * *gather_kind = 1 RCCL all-gather, 2 device copies, 0 nothing exchanged.  Returns the number of shards. */
+int bssm_amd_last_is_shards(double* out, int32_t capacity, double* collective_ms, int32_t* gather_kind);
+/* 1 when librccl could be opened and resolved (bssm_amd_last_error() says why not otherwise) */
+int bssm_amd_rccl_available(void);
+
 /* West/Chan merge of per-draw summaries in draw order (src/approx_mcmc.cpp:397-414, 422-424):
  * alphahat m x (n+1), Vt m x m x (n+1). Host-side, O(n_stored * n * m^2). */
 int bssm_is_merge(int32_t n, int32_t m, int32_t n_stored, const double* weights, const uint32_t* counts,

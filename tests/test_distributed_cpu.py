@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _oracle_block(arrs, modes, counts, first, n_stored, nsim, seed, is_type, output_type, n_threads):
+def _oracle_block(arrs, modes, counts, first, n_stored, nsim, seed, is_type, output_type, n_threads, devices=None):
     """Stand-in for bssm_amd.post_correct._run_local_block built on the oracle (streams keyed by global index)."""
     from oracle import oracle as O
     cnt = len(arrs)
