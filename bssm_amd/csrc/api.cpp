@@ -33,6 +33,7 @@ namespace {
 
 thread_local std::string g_err;
 bssm::UserHostFns g_user_host[64];  // host entry points of the loaded user-model libraries, by registry slot
+thread_local uint32_t g_call_stream0 = 0;  // Philox stream of the next single-filter call on this thread (bssm_fn_smoother_stream)
 thread_local double g_is_timing[2] = {0.0, 0.0};  // last IS post-correction on this thread: host set-up ms, device phase ms
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -481,7 +482,7 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
   const bool piped = out_bytes >= ((size_t)8 << 20) && !std::getenv("BSSM_AMD_NO_OUTPIPE");
   bssm::StepTiming hooks;
   if (piped && db.use_grid && (out->weights || out->indices) && n >= 64) hooks.progress_every = std::max(16, n / 24);
-  if ((rc = db.run(seed, 0, st, &hooks))) return rc;
+  if ((rc = db.run(seed, g_call_stream0, st, &hooks))) return rc;
   std::unique_ptr<OutPipe> pipe(piped ? new OutPipe(out_bytes) : nullptr);
   int slab_done = 0;  // weights / ancestor columns [0, slab_done) are on their way
   for (int k = 0; k < hooks.progress_count; k++) {
@@ -837,7 +838,29 @@ int bssm_fn_psi_setup(const bssm_fn_model* model, const double* is_mode, int32_t
 
 int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed, uint32_t stream0,
                          uint32_t n_rep, double* loglik) {
+  return bssm_fn_loglik_batch_ex(model, nsim, sampling_method, seed, stream0, n_rep, 100, 1e-8, loglik, nullptr);
+}
+
+// One single-filter smoother call of a functor model on Philox stream `stream0` (the chains key their filters by
+// (seed, 2 * iteration [+ 1]) and must be able to re-create the accepted particle system)
+int bssm_fn_smoother_stream(const bssm_fn_model* model, uint32_t sampling_method, uint32_t nsim, uint32_t seed,
+                            uint32_t stream0, int32_t max_iter, double conv_tol, bssm_filter_out* out) {
+  if (!model) return fail(BSSM_ERR_INVALID, "model is NULL");
+  g_call_stream0 = stream0;
+  int rc;
+  if (sampling_method == BSSM_PSI) rc = bssm_psi_smoother_nlg(model, nsim, seed, max_iter, conv_tol, out);
+  else if (sampling_method == BSSM_EKPF) rc = bssm_ekpf_smoother_nlg(model, nsim, seed, out);
+  else if (sampling_method != BSSM_BSF) rc = fail(BSSM_ERR_UNSUPPORTED, "sampling_method must be 1 (psi), 2 (bsf) or 4 (ekf particle filter)");
+  else if (bssm::fn_is_sde(model->model_id)) rc = bssm_bsf_smoother_sde(model, nsim, seed, out);
+  else rc = bssm_bsf_smoother_nlg(model, nsim, seed, out);
+  g_call_stream0 = 0;
+  return rc;
+}
+
+int bssm_fn_loglik_batch_ex(const bssm_fn_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed, uint32_t stream0,
+                            uint32_t n_rep, int32_t max_iter, double conv_tol, double* loglik, double* approx_loglik) {
   if (!loglik || n_rep < 1 || nsim < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  if (approx_loglik) *approx_loglik = 0.0;
   if (sampling_method != BSSM_PSI && sampling_method != BSSM_BSF && sampling_method != BSSM_EKPF)
     return fail(BSSM_ERR_UNSUPPORTED, "sampling_method must be 1 (psi), 2 (bsf) or 4 (ekf particle filter)");
   std::vector<bssm::FilterTables> tabs(1);
@@ -847,8 +870,9 @@ int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t sam
   const bool psi = sampling_method == BSSM_PSI, ekpf = sampling_method == BSSM_EKPF;
   if (psi) {
     bool ok = true;
-    if ((rc = functor_psi_tables(model, nullptr, 100, 1e-8, &tabs[0], &fpar, &amats, &base, &ok, &m))) return rc;
+    if ((rc = functor_psi_tables(model, nullptr, max_iter, conv_tol > 0 ? conv_tol : 1e-8, &tabs[0], &fpar, &amats, &base, &ok, &m))) return rc;
     k = m;
+    if (approx_loglik) *approx_loglik = ok ? base : -INFINITY;  // of the very set-up the particles are drawn from
     if (!ok) { for (uint32_t r = 0; r < n_rep; r++) loglik[r] = -INFINITY; return BSSM_WARN_DEGENERATE; }
   } else if (ekpf) {
     if ((rc = functor_ekpf_tables(model, &tabs[0], &fpar, &m))) return rc;

@@ -197,7 +197,10 @@ struct UngTarget {
 
 // ssm_nlg / ssm_sde (model functors): theta is the model's parameter vector itself; approximate log-likelihood from the
 // mode search (ssm_nlg::log_likelihood with nsim = 0, src/model_ssm_nlg.cpp:258-277); filters through the functor
-// entry points, the random stream of iteration i being the seed  seed + i.
+// entry points.  Random streams: Philox key (chain_seed(), 2 * iteration) for the fine / only filter of an iteration and
+// (chain_seed(), 2 * iteration + 1) for the coarse first stage of the two-level ssm_sde chain; chain_seed() is the job's
+// seed in a domain of its own, so chains started with consecutive seeds share nothing and the IS correction that
+// follows (key (seed, draw index)) never re-uses a chain stream.
 struct FnTarget {
   bssm_fn_model mod;
   std::vector<double> theta;
@@ -217,10 +220,12 @@ struct FnTarget {
   double log_prior(const double* th) const { return job->prior_fn(th, job->n_par, job->user); }
   int L_c = 0, L_f = 0;  // ssm_sde delayed acceptance: coarse / fine discretisation levels (0 = single level, mod.L)
   bool two_level() const { return L_c > 0 && L_f > L_c; }
+  uint32_t chain_seed() const { return job->seed ^ 0x5bd1e995u; }
+  double psi_approx_ll = 0.0;  // approximate log-likelihood of the set-up the last psi filter drew from
   int approx_ll(uint64_t it, std::vector<double>* mode, double* val) {
-    if (two_level()) {  // first stage of sde_da_mcmc: a bootstrap filter at the coarse level (src/mcmc.cpp:859,908), stream 1
+    if (two_level()) {  // first stage of sde_da_mcmc: a bootstrap filter at the coarse level (src/mcmc.cpp:859,908)
       mod.L = L_c;
-      const int rc = bssm_fn_loglik_batch(&mod, job->nsim, BSSM_BSF, job->seed + (uint32_t)it, 1u, 1u, val);
+      const int rc = bssm_fn_loglik_batch(&mod, job->nsim, BSSM_BSF, chain_seed(), 2u * (uint32_t)it + 1u, 1u, val);
       mod.L = L_f;
       if (rc < 0) return rc;
       if (!std::isfinite(*val)) *val = -INFINITY;
@@ -235,7 +240,8 @@ struct FnTarget {
     return BSSM_OK;
   }
   int filter_ll(uint64_t it, double* ll) {
-    int rc = bssm_fn_loglik_batch(&mod, job->nsim, job->sampling_method, job->seed + (uint32_t)it, 0u, 1u, &ll[0]);
+    int rc = bssm_fn_loglik_batch_ex(&mod, job->nsim, job->sampling_method, chain_seed(), 2u * (uint32_t)it, 1u, job->max_iter,
+                                     job->conv_tol, &ll[0], &psi_approx_ll);
     if (rc < 0) return rc;
     if (!std::isfinite(ll[0])) ll[0] = -INFINITY;
     if (two_level()) {  // ll[1] is the coarse-level estimate: the caller's first stage made it, except for the initial value
@@ -243,29 +249,25 @@ struct FnTarget {
       return BSSM_OK;
     }
     ll[1] = ll[0];
-    if (job->sampling_method == BSSM_PSI && std::isfinite(ll[0])) {  // ll(1) = approx_loglik, src/model_ssm_nlg.cpp:253-254
-      if ((rc = approx_ll(it, nullptr, &ll[1])) != BSSM_OK) return rc;
-    }
+    // ll(1) = approx_loglik of the same Gaussian approximation (one mode search serves both), src/model_ssm_nlg.cpp:253-254
+    if (job->sampling_method == BSSM_PSI && std::isfinite(ll[0])) ll[1] = psi_approx_ll;
     return BSSM_OK;
   }
   int sample_or_summarise(uint64_t it, double* sampled, double* ah, double* vt) {
     if (otype == 3) return BSSM_OK;
     const int nn = n(), mm = m();
-    const uint32_t N = job->nsim, sd = job->seed + (uint32_t)it;
+    const uint32_t N = job->nsim, sd = chain_seed(), st = 2u * (uint32_t)it;
     alpha_all.resize((size_t)mm * (nn + 1) * N);
     w_dummy.resize((size_t)N * (nn + 1));
     std::vector<double> ahat((size_t)(nn + 1) * mm), v((size_t)mm * mm * (nn + 1));
     bssm_filter_out o;
     std::memset(&o, 0, sizeof o);
     o.alphahat = ahat.data(); o.Vt = v.data(); o.weights = w_dummy.data(); o.alpha = alpha_all.data();
-    int rc;
-    if (job->sampling_method == BSSM_PSI) rc = bssm_psi_smoother_nlg(&mod, N, sd, job->max_iter, job->conv_tol, &o);
-    else if (job->sampling_method == BSSM_EKPF) rc = bssm_ekpf_smoother_nlg(&mod, N, sd, &o);
-    else if (is_sde()) rc = bssm_bsf_smoother_sde(&mod, N, sd, &o);
-    else rc = bssm_bsf_smoother_nlg(&mod, N, sd, &o);
+    // the accepted particle system again: same set-up (max_iter, conv_tol), same (seed, stream)
+    const int rc = bssm_fn_smoother_stream(&mod, job->sampling_method, N, sd, st, job->max_iter, job->conv_tol, &o);
     if (rc < 0) return rc;
     if (otype == 1) {  // one of the back-traced trajectories, uniformly (the weights of the extra time point are ones)
-      const bssm::u32x4 w = bssm::philox4x32_10(0, 0, 0, bssm::RNG_PICK, sd, 0u);
+      const bssm::u32x4 w = bssm::philox4x32_10(0, 0, 0, bssm::RNG_PICK, sd, st);
       uint32_t pick = (uint32_t)((double)bssm::bits53(w.x, w.y) * 0x1.0p-53 * N);
       if (pick >= N) pick = N - 1;
       for (int t = 0; t <= nn; t++)

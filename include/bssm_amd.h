@@ -198,6 +198,15 @@ int bssm_bsf_smoother_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t se
  * batched over n_rep Philox streams */
 int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed, uint32_t stream0,
                          uint32_t n_rep, double* loglik);
+/* the same with the mode search's max_iter / conv_tol (R: the model's `max_iter`, `conv_tol`) and, for the psi-APF, the
+ * approximate log-likelihood of the very Gaussian approximation the particles were drawn from (*approx_loglik, may be
+ * NULL): ll(1) of ssm_nlg::log_likelihood, src/model_ssm_nlg.cpp:253-254 */
+int bssm_fn_loglik_batch_ex(const bssm_fn_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed,
+                            uint32_t stream0, uint32_t n_rep, int32_t max_iter, double conv_tol, double* loglik,
+                            double* approx_loglik);
+/* one smoother call (psi / bsf / ekf particle filter, ssm_nlg or ssm_sde) on Philox stream `stream0` instead of 0 */
+int bssm_fn_smoother_stream(const bssm_fn_model* model, uint32_t sampling_method, uint32_t nsim, uint32_t seed,
+                            uint32_t stream0, int32_t max_iter, double conv_tol, bssm_filter_out* out);
 /* replaces _bssm_psi_smoother_nlg (21 args, src/R_psi.cpp:175-222): psi-APF + back-trace + summary of a built-in
  * ssm_nlg model.  max_iter / conv_tol are the mode-search controls of ssm_nlg (src/model_ssm_nlg.cpp:19-20). */
 int bssm_psi_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, int32_t max_iter, double conv_tol,

@@ -663,10 +663,11 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
     S = np.tril(np.asarray(S0, dtype=np.float64)).copy()
     filtered = kind != "approx"
     L = lib()
+    fn_chain_seed = (seed ^ 0x5bd1e995) & 0xFFFFFFFF  # functor-model chains filter in a seed domain of their own
 
     def approx(arr, it=0):
-        if sde_levels:  # first stage of sde_da_mcmc (src/mcmc.cpp:859,908): bootstrap filter at the coarse level, stream 1
-            r = fn_bsf_filter({**arr, "L": sde_levels[0]}, nsim, seed=(seed + it) & 0xFFFFFFFF, stream=1)
+        if sde_levels:  # first stage of sde_da_mcmc (src/mcmc.cpp:859,908): bootstrap filter at the coarse level, odd stream
+            r = fn_bsf_filter({**arr, "L": sde_levels[0]}, nsim, seed=fn_chain_seed, stream=(2 * it + 1) & 0xFFFFFFFF)
             return (r["logLik"] if np.isfinite(r["logLik"]) else -np.inf), None, None
         if fn_model:  # ssm_nlg: mode-based approximation (src/model_ssm_nlg.cpp:258-277)
             su = fn_psi_setup(arr)
@@ -682,15 +683,16 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
     kept = {}
 
     def filt(arr, it):
-        """(ll0, ll1, particle system) with the filter's stream = iteration (functor models: seed + iteration)"""
+        """(ll0, ll1, particle system) with the filter's stream = iteration (functor models: the chain's own seed domain,
+        stream 2 * iteration; 2 * iteration + 1 is the coarse first stage of the two-level ssm_sde chain)"""
         if fn_model:
-            sd = (seed + it) & 0xFFFFFFFF
+            sd, st = fn_chain_seed, (2 * it) & 0xFFFFFFFF
             if method == "psi":
-                r = fn_psi_filter(arr, nsim, seed=sd, stream=0)
+                r = fn_psi_filter(arr, nsim, seed=sd, stream=st)
                 return r["logLik"], r["setup"]["approx_loglik"], r
             if sde_levels:
                 arr = {**arr, "L": sde_levels[1]}
-            r = fn_ekpf_filter(arr, nsim, seed=sd, stream=0) if method == "ekf" else fn_bsf_filter(arr, nsim, seed=sd, stream=0)
+            r = fn_ekpf_filter(arr, nsim, seed=sd, stream=st) if method == "ekf" else fn_bsf_filter(arr, nsim, seed=sd, stream=st)
             return r["logLik"], r["logLik"], r
         sd, st = seed + (it >> 32), it & 0xFFFFFFFF
         if method == "psi":
@@ -702,7 +704,7 @@ def run_chain(update, log_prior, theta0, S0, iters, burnin, thin, gamma, target,
     def sample_or_summarise(res, it):
         sm = filter_smoother(res["alpha"], res["indices"])  # m x (n+1) x N
         if output_type == 1:
-            r, _ = make_rng(seed=(seed + it) & 0xFFFFFFFF, stream=0) if fn_model else make_rng(seed=seed + (it >> 32), stream=it & 0xFFFFFFFF)
+            r, _ = make_rng(seed=fn_chain_seed, stream=(2 * it) & 0xFFFFFFFF) if fn_model else make_rng(seed=seed + (it >> 32), stream=it & 0xFFFFFFFF)
             pick = min(int(L.orc_rng_uniform(C.byref(r), 3, 0, 0, 0) * nsim), nsim - 1)
             return sm[:, :, pick].T.copy(), None, None
         if output_type == 2:
