@@ -194,10 +194,11 @@ __device__ __forceinline__ double dpp_shr_zero(double v) {
 // inclusive prefix sum over the 64 lanes, fixed shape: 4 steps inside each row of 16, then row 0->1 and
 // 2->3 (bcast15), then rows 0-1 -> 2-3 (bcast31).  Same association on every call => reproducible bits.
 __device__ __forceinline__ double wave_scan_incl(double v) {
-  v += dpp_move<DPP_ROW_SHR1, 0xf>(0.0, v);
-  v += dpp_move<DPP_ROW_SHR2, 0xf>(0.0, v);
-  v += dpp_move<DPP_ROW_SHR4, 0xf>(0.0, v);
-  v += dpp_move<DPP_ROW_SHR8, 0xf>(0.0, v);
+  // (the in-row shifts read 0 outside the row through bound_ctrl: no identity moved into the destination first)
+  v += dpp_shr_zero<DPP_ROW_SHR1>(v);
+  v += dpp_shr_zero<DPP_ROW_SHR2>(v);
+  v += dpp_shr_zero<DPP_ROW_SHR4>(v);
+  v += dpp_shr_zero<DPP_ROW_SHR8>(v);
   v += dpp_move<DPP_ROW_BCAST15, 0xa>(0.0, v);
   v += dpp_move<DPP_ROW_BCAST31, 0xc>(0.0, v);
   return v;

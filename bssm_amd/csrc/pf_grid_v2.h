@@ -260,6 +260,11 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
   __shared__ double s_win[4 * PPT * V2_WIN];
   __shared__ double s_x[4 + 4 * PPT];
   __shared__ double s_comb[3 * 64 + 1];  // combine of wave 0: block prefixes, 1 / scale, scale, global maximum
+  // T_t, R_t, C_t of this step.  Read from LDS (broadcast ds_read, same address in every lane) and not through scalar
+  // loads: 36 doubles are 72 SGPRs, which with the kernel arguments and the observation row overflowed the scalar file --
+  // 58 SGPRs spilled to VGPR lanes and came back through ~250 v_readlane / v_writelane per wave-step (10 % of the VALU work)
+  constexpr int NMAT = MP * MP + MP * KP + MP;
+  __shared__ double s_mat[NMAT];
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int pb, f;
@@ -275,7 +280,11 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
   // (global maximum, scaled block sums, their inclusive prefix, total; the polynomial exp needs no table) while every
   // wave draws the step blocks of its particles (integer work, independent of the exchange); barrier (1) then
   // publishes both the math tables and the combine
+#ifdef BSSM_V2_NO_RMW
+  double* __restrict__ wt = nullptr;
+#else
   double* __restrict__ wt = b.weights ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + t) * N + base) : nullptr;
+#endif
   double wt_old[PPT];
   if (wt) {
 #pragma unroll
@@ -294,6 +303,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
     s_comb[128 + lane] = scale0;
     if (lane == 0) s_comb[192] = M0;
   }
+  if (tid < NMAT) s_mat[tid] = (b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride)[tid];
   u32x4 blk[PPT];
 #pragma unroll
   for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + r * GRID_NT + tid));
@@ -325,7 +335,6 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
   const double* __restrict__ st_old = uniform_ptr(b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N);
   double* __restrict__ st_new = uniform_ptr((b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N) + base);
   uint32_t* __restrict__ idx_out = b.indices ? uniform_ptr(b.indices + ((size_t)f * n + t) * N + base) : nullptr;
-  const cdbl* mt = as_uniform_table(b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride);
   double* sw_base = s_win + wave * (PPT * V2_WIN);
 
   V2_MARK("phaseA");
@@ -422,7 +431,11 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
     const int li = r * GRID_NT + tid, j = base + li;
     double z[KP], x[MP];
     rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
-    propagate<MP, KP>(mt, a[r], z, x);
+    {
+      int zero = 0;  // opaque: the matrix is re-read per particle instead of being kept live in 72 VGPRs
+      __asm__ volatile("" : "+v"(zero));
+      propagate<MP, KP>((const double*)(s_mat + zero), a[r], z, x);
+    }
     if (li < len) {
 #pragma unroll
       for (int c = 0; c < MP; c++) if (c < m) st32(st_new + (size_t)c * N, li, x[c]);
