@@ -31,6 +31,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# fp64 VALU issue roof: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles (16 lanes per clock) at 2.4 GHz
+VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
+# wave-level VALU instructions per particle-step of the workgroup-resident kernels, from the PMC passes committed under
+# profiles/r02_pmc_other_kernels.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_others.sh)
+REGB_VALU_PER_PSTEP = 10628740724.8 / (512 * 2048 * 1000.0)   # pf_wg_kernel<4,4,4,false,512>
+C5_VALU_PER_PSTEP = 4393378021.9 / (468.0 * 4096 * 300.0)     # pf_wg_kernel<2,2,4,true,1024>, 50 dispatches of 2340 draws per 5
+
+
+def valu_roofline(valu_per_pstep, psteps_per_s, kernel):
+    a = valu_per_pstep * psteps_per_s
+    return {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
+            "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
+            "lane_instr_per_particle_step": valu_per_pstep * 64,
+            "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r02_pmc_other_kernels.txt); rate: measured live"}
+
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -146,6 +162,8 @@ def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=Fals
                         "contiguous blocks over the ranks, log-weights all-gathered (RCCL)" % (label, ns, nsim),
             "scaling": "strong", "n_gpus": world, "seconds": times[best], "draws_per_s": ns / times[best],
             "value": ns * float(nsim) * n / times[best], "unit": "particle-steps/s", "host_threads_per_rank": threads,
+            "roofline_valu": valu_roofline(C5_VALU_PER_PSTEP, ns * float(nsim) * n / (max(v[1] for v in splits[best]) * 1e-3),
+                                           "pf_wg_kernel<2,2,4,true,1024>") if max(v[1] for v in splits[best]) > 0 else None,
             "per_rank_ms": [{"rank": q, "setup_ms": round(v[0], 2), "device_ms": round(v[1], 2), "collective_ms": round(v[2], 2)}
                             for q, v in enumerate(splits[best])],
             "per_rank_note": "set-up (host threads) and device phase overlap inside a rank; collective_ms includes waiting for the slowest rank",
@@ -217,6 +235,7 @@ def main():
     ap.add_argument("--no-regime-b", action="store_true")
     ap.add_argument("--no-single", action="store_true")
     ap.add_argument("--no-post-correct", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -345,7 +364,8 @@ def main():
                            "value": ps / eb, "unit": "particle-steps/s", "ms_per_pass": eb * 1e3,
                            "kernel": pb.last_kernel(), "kernel_ms": kb_ms,
                            "algorithmic_GBs": ps * ib["bytes_per_particle_step"] / (kb_ms * 1e-3) / 1e9,
-                           "note": "state never leaves LDS: HBM traffic ~0, bound by fp64 VALU/transcendentals"}
+                           "note": "state never leaves LDS: HBM traffic ~0, bound by fp64 VALU/transcendentals",
+                           "roofline_valu": valu_roofline(REGB_VALU_PER_PSTEP, ps / (kb_ms * 1e-3), "pf_wg_kernel<4,4,4,false,512>")}
         pb.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only: the other ranks would idle behind it
@@ -380,6 +400,33 @@ def main():
         out["accuracy"] = {"loglik_rmse_vs_cpu_same_seeds": float(np.sqrt(np.mean(d * d))), "max_abs_diff": float(np.max(np.abs(d))),
                            "seeds": len(seeds), "N": 4096, "T": T, "m": m,
                            "note": "identical Philox streams on both sides; differences come from libm vs device elementary functions and reduction shape"}
+
+    if rank == 0 and not args.no_dropin:
+        # ---- the drop-in boundary as R sees it: host buffers in, host buffers out (PCIe-inclusive; never `value`).
+        # Reference contract: src/R_bootstrap_filter.cpp:136-155 (outputs are ordinary R arrays).
+        try:
+            from bssm_amd import filters as Fd, models as Md
+
+            def best_of(fn, reps=3):
+                fn()
+                bt = 1e9
+                for _ in range(reps):
+                    t1 = time.perf_counter(); fn(); bt = min(bt, time.perf_counter() - t1)
+                return bt
+
+            e1 = best_of(lambda: Fd.bootstrap_filter(model, N, seed=1))
+            yx = np.loadtxt(os.path.join(ROOT, "tests", "golden", "exchange.txt"))
+            svm = Md.svm(yx, rho=Md.uniform(0.98, -0.999, 0.999), sd_ar=Md.halfnormal(0.2, 5), sigma=Md.halfnormal(1.0, 2))
+            e3 = best_of(lambda: Fd.particle_smoother(svm, 32768, method="psi", seed=1))
+            out["dropin"] = {
+                "note": "one call through the C ABI with host (pageable numpy) buffers: model upload, filter, and every output "
+                        "(particle cube m x (n+1) x N, weights, summaries) copied back; output slabs stream out while the filter steps",
+                "C2-m4_bootstrap_filter": {"ms_per_call": e1 * 1e3, "value": N * float(T) / e1, "unit": "particle-steps/s",
+                                           "output_GB": (m * (T + 1) * N + (T + 1) * N) * 8 / 1e9},
+                "C3_psi_particle_smoother": {"ms_per_call": e3 * 1e3, "value": 32768 * float(len(yx)) / e3, "unit": "particle-steps/s",
+                                             "workload": "svm on the exchange series (n = 945), psi-APF N = 32768, back-trace + summary"}}
+        except Exception as e:  # noqa: BLE001
+            out["dropin"] = {"error": repr(e)[:200]}
 
     if not args.no_post_correct:
         # ---- the sharded half of the path (all ranks): IS post-correction, SURVEY.md 8e

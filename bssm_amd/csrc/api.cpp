@@ -896,19 +896,26 @@ int bssm_fn_loglik_batch_ex(const bssm_fn_model* model, uint32_t nsim, uint32_t 
   return deg ? BSSM_WARN_DEGENERATE : BSSM_OK;
 }
 
-// replaces _bssm_gaussian_psi_smoother (src/R_psi.cpp:14-50) for the ssm_ulg family (model_type 1..3)
+// replaces _bssm_gaussian_psi_smoother (src/R_psi.cpp:14-50): ssm_mlg (model_type 0) and the ssm_ulg family (1..3)
 int bssm_gaussian_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int model_type, double* alpha) {
   if (!alpha || nsim < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
-  if (model_type == 0) return fail(BSSM_ERR_UNSUPPORTED, "ssm_mlg (multivariate gaussian) is outside the particle-filter scope of this build");
-  if (model_type < 1 || model_type > 3) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
-  bssm::HostModel hm;
-  const std::string err = bssm::ingest_model(model, false, &hm);
-  if (!err.empty()) return fail(BSSM_ERR_INVALID, err);
-  if (!hm.gaussian()) return fail(BSSM_ERR_INVALID, "gaussian_psi_smoother needs a linear-Gaussian model");
+  if (model_type < 0 || model_type > 3) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
   bssm::PsiSetup su;
-  if (!bssm::gaussian_smoothing_setup(hm, &su)) return fail(BSSM_ERR_NUMERIC, "smoother produced non-finite values");
+  int n = 0, m = 0;
+  if (model_type == 0) {  // ssm_mlg (src/R_psi.cpp:20-25): the multivariate smoother on the host, the draws on the device as below
+    const std::string err = bssm::mlg_smoothing_setup(model, &su);
+    if (!err.empty()) return fail(err.find("non-finite") != std::string::npos ? BSSM_ERR_NUMERIC : BSSM_ERR_INVALID, err);
+    n = model->n; m = model->m;
+  } else {
+    bssm::HostModel hm;
+    const std::string err = bssm::ingest_model(model, false, &hm);
+    if (!err.empty()) return fail(BSSM_ERR_INVALID, err);
+    if (!hm.gaussian()) return fail(BSSM_ERR_INVALID, "gaussian_psi_smoother needs a linear-Gaussian model");
+    if (!bssm::gaussian_smoothing_setup(hm, &su)) return fail(BSSM_ERR_NUMERIC, "smoother produced non-finite values");
+    n = hm.n; m = hm.m;
+  }
   if (!have_device()) return no_device();
-  const int n = hm.n, m = hm.m, N = (int)nsim, MS = 2 * m * m + m;
+  const int N = (int)nsim, MS = 2 * m * m + m;
   std::vector<double> mats((size_t)n * MS), init((size_t)m + m * m);
   for (int t = 0; t < n; t++) {
     double* mt = mats.data() + (size_t)t * MS;

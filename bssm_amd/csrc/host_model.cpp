@@ -126,6 +126,9 @@ struct Sys {
 // ------------------------------------------------------------------ Kalman machinery of the approximating model
 struct Approx {  // pseudo-observations of the Gaussian approximation, p x n (H = diagonal sd)
   std::vector<double> y, H;
+  // a genuine ssm_mlg model instead: full observation-noise covariance HH = H H', p x p x (1|n) (src/model_ssm_mlg.cpp compute_HH)
+  std::vector<double> HHfull;
+  int HHtv = 0;
 };
 
 // one prediction step.  Univariate: src/model_ssm_ulg.cpp:122-136 / :268-283; multivariate with missing
@@ -151,7 +154,11 @@ KfStep kf_predict(const Sys& S, const Approx& ap, int t, const Mat& at, const Ma
     const double yt = ap.y[j + (size_t)p * t] - (p == 1 ? h.xbeta[t] : 0.0);
     na[j] = !std::isfinite(yt);
     if (na[j]) { for (int c = 0; c < m; c++) st.Zz(j, c) = 0.0; HH(j, j) = 1.0; }
-    else { HH(j, j) = ap.H[j + (size_t)p * t] * ap.H[j + (size_t)p * t]; st.nobs++; }
+    else { if (ap.HHfull.empty()) HH(j, j) = ap.H[j + (size_t)p * t] * ap.H[j + (size_t)p * t]; st.nobs++; }
+  }
+  if (!ap.HHfull.empty()) {  // rows / columns of missing series zeroed, unit diagonal there (src/model_ssm_mlg.cpp:324-328)
+    const double* Hs = ap.HHfull.data() + (size_t)p * p * (t * ap.HHtv);
+    for (int j = 0; j < p; j++) for (int i = 0; i < p; i++) HH(i, j) = (na[i] || na[j]) ? (i == j ? 1.0 : 0.0) : Hs[i + (size_t)p * j];
   }
   Mat F = st.Zz * Pt * tr(st.Zz) + HH;
   if (p == 1 && st.nobs == 1 && !(F(0, 0) > kZeroTol)) st.nobs = 0;  // univariate guard F > zero_tol (:123)
@@ -756,6 +763,53 @@ bool gaussian_smoothing_setup(const HostModel& h, PsiSetup* out) {
     for (int q = 0; q < m * m; q++) { out->Vt[q + (size_t)m * m * t] = Vt[t].a[q]; out->Ct[q + (size_t)m * m * t] = Ct[t].a[q]; ok &= std::isfinite(Vt[t].a[q]) && std::isfinite(Ct[t].a[q]); }
   }
   return ok;
+}
+
+// ssm_mlg (gaussian_psi_smoother case 0, src/R_psi.cpp:20-25): smoother_ccov (src/model_ssm_mlg.cpp:310-396) +
+// conditional_cov on the model itself.  `s` carries y n x p, Z p x m x (1|n), D p x (1|n), H p x p x (1|n) lower factor.
+std::string mlg_smoothing_setup(const bssm_ung_model* s, PsiSetup* out) {
+  if (!s) return "model is NULL";
+  if (s->n < 1 || s->m < 1 || s->k < 1 || s->p < 1) return "n, m, k, p must be positive";
+  if (s->m > 16 || s->p > 8) return "ssm_mlg: m <= 16 and p <= 8 are supported";
+  if (!s->y || !s->Z || !s->T || !s->R || !s->a1 || !s->P1 || !s->H) return "y, Z, H, T, R, a1, P1 must be non-NULL";
+  HostModel h;
+  const int n = s->n, m = s->m, k = s->k, p = s->p;
+  h.n = n; h.m = m; h.k = k; h.p = p;
+  h.Ztv = s->Ztv != 0; h.Ttv = s->Ttv != 0; h.Rtv = s->Rtv != 0; h.Dtv = s->Dtv != 0; h.Ctv = s->Ctv != 0; h.Htv = s->Htv != 0;
+  h.dist.assign(p, BSSM_GAUSSIAN); h.phis.assign(p, 1.0);
+  h.y.resize((size_t)p * n);
+  for (int t = 0; t < n; t++) for (int j = 0; j < p; j++) h.y[j + (size_t)p * t] = s->y[t + (size_t)n * j];  // y.t(), :15
+  h.Z.assign(s->Z, s->Z + (size_t)p * m * (h.Ztv ? n : 1));
+  h.T.assign(s->T, s->T + (size_t)m * m * (h.Ttv ? n : 1));
+  h.R.assign(s->R, s->R + (size_t)m * k * (h.Rtv ? n : 1));
+  h.a1.assign(s->a1, s->a1 + m);
+  h.P1.assign(s->P1, s->P1 + (size_t)m * m);
+  if (s->D) h.D.assign(s->D, s->D + (size_t)p * (h.Dtv ? n : 1)); else { h.D.assign(p, 0.0); h.Dtv = 0; }
+  if (s->C) h.C.assign(s->C, s->C + (size_t)m * (h.Ctv ? n : 1)); else { h.C.assign(m, 0.0); h.Ctv = 0; }
+  h.xbeta.assign(n, 0.0);
+  Approx ap;
+  ap.y = h.y;
+  ap.HHtv = h.Htv;
+  const int ns = h.Htv ? n : 1;
+  ap.HHfull.assign((size_t)p * p * ns, 0.0);
+  for (int q = 0; q < ns; q++) {
+    const Mat Hm(p, p, s->H + (size_t)p * p * q);
+    const Mat HHm = Hm * tr(Hm);
+    std::copy(HHm.a, HHm.a + p * p, ap.HHfull.begin() + (size_t)p * p * q);
+  }
+  const Sys S(h);
+  std::vector<Mat> at, Vt, Ct;
+  if (!smoother_ccov(S, ap, &at, &Vt, &Ct)) return "smoother produced non-finite values";
+  conditional_cov(&Vt, &Ct);
+  out->alphahat.assign((size_t)m * (n + 1), 0.0);
+  out->Vt.assign((size_t)m * m * (n + 1), 0.0);
+  out->Ct.assign((size_t)m * m * (n + 1), 0.0);
+  bool ok = true;
+  for (int t = 0; t <= n; t++) {
+    for (int i = 0; i < m; i++) { out->alphahat[i + (size_t)m * t] = at[t](i, 0); ok &= std::isfinite(at[t](i, 0)); }
+    for (int q = 0; q < m * m; q++) { out->Vt[q + (size_t)m * m * t] = Vt[t].a[q]; out->Ct[q + (size_t)m * m * t] = Ct[t].a[q]; ok &= std::isfinite(Vt[t].a[q]) && std::isfinite(Ct[t].a[q]); }
+  }
+  return ok ? "" : "smoother produced non-finite values";
 }
 
 double approx_loglik_only(const HostModel& h) { return approx_loglik_mode(h, nullptr, nullptr); }

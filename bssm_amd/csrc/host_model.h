@@ -51,6 +51,9 @@ bool psi_setup(const HostModel& hm, const double* is_mode, PsiSetup* out, const 
 // exact smoothing factors of a linear-Gaussian (ssm_ulg family) model for gaussian_psi_smoother:
 // smoother_ccov + conditional_cov on the model itself (src/model_ssm_ulg.cpp:646-652)
 bool gaussian_smoothing_setup(const HostModel& hm, PsiSetup* out);
+// the same for a multivariate Gaussian model (ssm_mlg: `src` carries y n x p, Z p x m x (1|n), D p x (1|n) and H p x p x
+// (1|n), the lower factor of the observation noise; src/model_ssm_mlg.cpp:310-396, 473-480).  Returns "" or the error.
+std::string mlg_smoothing_setup(const bssm_ung_model* src, PsiSetup* out);
 // smoothed means m x (n+1) and covariances m x m x (n+1) of a linear-Gaussian model (host Kalman smoother)
 bool gaussian_smoother(const HostModel& hm, std::vector<double>* alphahat, std::vector<double>* Vt);
 // ---- two-phase psi set-up, so that the O(n m^3) smoother of MANY draws can run as one device batch

@@ -452,6 +452,35 @@ def ssm_ulg(y, Z, H, T, R, a1=None, P1=None, D=None, C=None):
                      xreg=_f(np.zeros((n, 0))), beta=_f(np.zeros(0)), theta=np.zeros(0))
 
 
+def ssm_mlg(y, Z, H, T, R, a1=None, P1=None, D=None, C=None):
+    """R/models.R ssm_mlg: y_t = D_t + Z_t alpha_t + H_t eps_t with y n x p, Z p x m x (1|n), H p x p x (1|n) (lower factor of
+    the observation noise), D p x (1|n).  On the path only through the gaussian psi smoother (src/R_psi.cpp:20-25)."""
+    y = np.asarray(y, dtype=float)
+    if y.ndim != 2:
+        raise ValueError("Argument 'y' must be a matrix or multivariate ts object for a multivariate model")
+    n, p = y.shape
+    Z = np.asarray(Z, dtype=float)
+    if Z.ndim == 2:
+        Z = Z.reshape(Z.shape[0], Z.shape[1], 1)
+    if Z.shape[0] != p or Z.shape[2] not in (1, n):
+        raise ValueError("'Z' must be p x m or p x m x n")
+    m = Z.shape[1]
+    H = np.asarray(H, dtype=float)
+    if H.ndim == 2:
+        H = H.reshape(p, p, 1)
+    if H.shape[:2] != (p, p) or H.shape[2] not in (1, n):
+        raise ValueError("'H' must be p x p or p x p x n")
+    T = _check_cube(T, m, m, n, "T")
+    R = _check_cube(R, m, np.asarray(R).shape[1] if np.asarray(R).ndim >= 2 else 1, n, "R")
+    a1, P1 = _check_a1P1(a1, P1, m)
+    D = np.zeros((p, 1)) if D is None else np.asarray(D, dtype=float)
+    D = D.reshape(p, -1) if D.ndim <= 1 else D
+    if D.shape[0] != p or D.shape[1] not in (1, n):
+        raise ValueError("'D' must be p x 1 or p x n")
+    return BssmModel(("ssm_mlg", "lineargaussian", "bssm_model"), y=_f(y), Z=_f(Z), H=_f(H), T=T, R=R, a1=a1, P1=P1,
+                     D=_f(D), C=_check_C(C, m, n), distribution="gaussian", theta=np.zeros(0))
+
+
 def bsm_lg(y, sd_y, sd_level=None, sd_slope=None, sd_seasonal=None, period=None, a1=None, P1=None, D=None, C=None):
     """R/models.R bsm_lg (structure shared with bsm_ng), gaussian observation sd_y"""
     y = _f(np.asarray(y, dtype=float).reshape(-1))
@@ -575,6 +604,8 @@ def model_arrays(model: BssmModel) -> dict:
     (the field list of src/model_ssm_ung.cpp:9-32)."""
     if model.inherits("ssm_mng"):
         return _mng_arrays(model)
+    if model.inherits("ssm_mlg"):
+        return _mlg_arrays(model)
     y = np.ascontiguousarray(np.asarray(model["y"], dtype=np.float64).reshape(-1))
     n = y.shape[0]
     Z = np.asfortranarray(model["Z"], dtype=np.float64)
@@ -605,6 +636,20 @@ def model_arrays(model: BssmModel) -> dict:
         out["initial_mode"] = np.ascontiguousarray(np.asarray(model["initial_mode"], dtype=np.float64).reshape(-1))
     out["xbeta"] = (xreg @ beta) if xreg.shape[1] else np.zeros(n)
     return out
+
+
+def _mlg_arrays(model: BssmModel) -> dict:
+    """ssm_mlg fields (src/model_ssm_mlg.cpp:7-31): y n x p as R holds it, H p x p x (1|n)"""
+    y = np.asfortranarray(model["y"], dtype=np.float64)
+    n, p = y.shape
+    Z, H = np.asfortranarray(model["Z"], dtype=np.float64), np.asfortranarray(model["H"], dtype=np.float64)
+    T, R = np.asfortranarray(model["T"], dtype=np.float64), np.asfortranarray(model["R"], dtype=np.float64)
+    D, C = np.asfortranarray(model["D"], dtype=np.float64), np.asfortranarray(model["C"], dtype=np.float64)
+    return dict(n=n, m=Z.shape[1], k=R.shape[1], p=p, Ztv=int(Z.shape[2] > 1), Ttv=int(T.shape[2] > 1), Rtv=int(R.shape[2] > 1),
+                Dtv=int(D.shape[1] > 1), Ctv=int(C.shape[1] > 1), Htv=int(H.shape[2] > 1), distribution=5, n_xreg=0, max_iter=100,
+                local_approx=1, conv_tol=1e-8, phi=1.0, y=y, Z=Z, T=T, R=R, a1=np.ascontiguousarray(model["a1"], dtype=np.float64),
+                P1=np.asfortranarray(model["P1"], dtype=np.float64), D=D, C=C, xreg=np.zeros((n, 0)), beta=np.zeros(0), u=None, H=H,
+                initial_mode=None, xbeta=np.zeros(n), distribution_p=np.full(p, 5, dtype=np.int32), phi_p=np.ones(p))
 
 
 def _mng_arrays(model: BssmModel) -> dict:

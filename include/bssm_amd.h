@@ -130,8 +130,10 @@ int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
                       bssm_filter_out* out);
 
 /* replaces _bssm_gaussian_psi_smoother: `arma::cube gaussian_psi_smoother(model_, nsim, seed, model_type)`
- * src/R_psi.cpp:14-50 -> ssm_ulg::psi_filter src/model_ssm_ulg.cpp:644-672 (exact draws from the joint smoothing
- * distribution; model_type 1..3).  alpha: m x (n+1) x N. */
+ * src/R_psi.cpp:14-50 -> ssm_ulg::psi_filter src/model_ssm_ulg.cpp:644-672 (model_type 1..3) or ssm_mlg::psi_filter
+ * src/model_ssm_mlg.cpp:473-501 (model_type 0): exact draws from the joint smoothing distribution.  alpha: m x (n+1) x N.
+ * ssm_mlg: p > 1, y n x p, Z p x m x (1|n), D p x (1|n), H p x p x (1|n) = lower factor of the observation noise
+ * (Htv says whether it varies); distribution_p / phi_p / u are not read. */
 int bssm_gaussian_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int model_type, double* alpha);
 
 /* host Kalman smoother of a linear-Gaussian model (ssm_ulg::smoother, src/model_ssm_ulg.cpp:307-417): alphahat m x (n+1),

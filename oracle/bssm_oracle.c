@@ -1083,6 +1083,10 @@ void orc_mng_setup_free(orc_mng_setup *s) {
 /* one multivariate Kalman prediction step, the "zeroed rows" form of src/model_ssm_mlg.cpp:259-291,318-356
  * (numerically the same update as the observed-rows form of :103-128: missing rows decouple exactly).
  * gy, gH: p x n pseudo-observations and their sd.  ZFinv (m x p) = Z' F^-1, K = P ZFinv. */
+/* observation-noise covariance of a genuine ssm_mlg model (p x p x (1|n), HH = H H'): set by orc_mlg_psi_filter around
+ * its smoother call; NULL = the diagonal pseudo-observation noise gH of the Gaussian approximations */
+static const double *g_mlg_HH = NULL;
+static int g_mlg_HHtv = 0;
 static int mlg_step(const orc_mng_model *mod, const double *gy, const double *gH, int t, const double *at, const double *Pt,
                     double *at1, double *Pt1, double *v, double *ZFinv, double *K, double *Zz, int *nobs, double *logdetF) {
   const int m = mod->m, p = mod->p;
@@ -1103,7 +1107,12 @@ static int mlg_step(const orc_mng_model *mod, const double *gy, const double *gH
   }
   double HH[ORC_MAXP * ORC_MAXP] = {0}, F[ORC_MAXP * ORC_MAXP], Lf[ORC_MAXP * ORC_MAXP] = {0}, Fi[ORC_MAXP * ORC_MAXP];
   for (int c = 0; c < m; c++) for (int i = 0; i < p; i++) Zz[i + p * c] = na[i] ? 0.0 : Zt[i + p * c];
-  for (int i = 0; i < p; i++) HH[i + p * i] = na[i] ? 1.0 : gH[i + (size_t)p * t] * gH[i + (size_t)p * t];
+  if (g_mlg_HH) { /* HHt.rows(na).zeros(); HHt.cols(na).zeros(); HHt(na, na) = I: src/model_ssm_mlg.cpp:324-328 */
+    const double *Hs = g_mlg_HH + (size_t)p * p * (t * g_mlg_HHtv);
+    for (int j = 0; j < p; j++) for (int i = 0; i < p; i++) HH[i + p * j] = (na[i] || na[j]) ? (i == j ? 1.0 : 0.0) : Hs[i + p * j];
+  } else {
+    for (int i = 0; i < p; i++) HH[i + p * i] = na[i] ? 1.0 : gH[i + (size_t)p * t] * gH[i + (size_t)p * t];
+  }
   double ZP[ORC_MAXP * ORC_MAXM];
   mat_mul(Zz, Pt, p, m, m, ZP);
   mat_mul_bt(ZP, Zz, p, m, p, F);
@@ -1910,4 +1919,38 @@ void orc_ulg_psi_filter(const orc_ulg_model *g, unsigned N, const orc_rng *rng, 
       }
     }
   free(ah); free(Vt); free(Ct);
+}
+
+/* ssm_mlg::psi_filter, src/model_ssm_mlg.cpp:473-501 (gaussian_psi_smoother case 0, src/R_psi.cpp:20-25): smoother_ccov
+ * (:310-396) + conditional_cov, then exact draws from the joint smoothing distribution.  `mod` carries y (p x n), Z, T, R,
+ * a1, P1, D, C; H is the p x p x (1|n) lower factor of the observation noise (HH = H H', compute_HH). */
+int orc_mlg_psi_filter(const orc_mng_model *mod, const double *H, int Htv, unsigned N, const orc_rng *rng, double *alpha) {
+  const int n = mod->n, m = mod->m, p = mod->p, mm = m * m, ns = Htv ? n : 1;
+  double *HH = (double *)calloc((size_t)p * p * ns, sizeof(double));
+  for (int s = 0; s < ns; s++) mat_mul_bt(H + (size_t)p * p * s, H + (size_t)p * p * s, p, p, p, HH + (size_t)p * p * s);
+  double *ah = (double *)calloc((size_t)m * (n + 1), sizeof(double));
+  double *Vt = (double *)calloc((size_t)mm * (n + 1), sizeof(double)), *Ct = (double *)calloc((size_t)mm * (n + 1), sizeof(double));
+  double um[ORC_MAXM];
+  g_mlg_HH = HH; g_mlg_HHtv = Htv;
+  const int ok = mlg_smoother_ccov(mod, mod->y, NULL, ah, Vt, Ct);
+  g_mlg_HH = NULL;
+  if (ok) {
+    orc_conditional_cov(Vt, Ct, m, n + 1);
+    for (unsigned i = 0; i < N; i++) {
+      rng_normals(rng, 0, 0, i, m, um);
+      for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += Vt[j + m * c] * um[c]; A_(j, 0, i) = ah[j] + s; }
+    }
+    for (int t = 0; t < n; t++)
+      for (unsigned i = 0; i < N; i++) {
+        rng_normals(rng, 2, t, i, m, um);
+        for (int j = 0; j < m; j++) {
+          double s = 0, q = 0;
+          for (int c = 0; c < m; c++) s += Ct[j + m * c + (size_t)mm * (t + 1)] * (A_(c, t, i) - ah[c + (size_t)m * t]);
+          for (int c = 0; c < m; c++) q += Vt[j + m * c + (size_t)mm * (t + 1)] * um[c];
+          A_(j, t + 1, i) = ah[j + (size_t)m * (t + 1)] + s + q;
+        }
+      }
+  }
+  free(HH); free(ah); free(Vt); free(Ct);
+  return ok;
 }

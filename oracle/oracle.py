@@ -488,6 +488,28 @@ def fn_psi_filter(model: dict, nsim: int, seed=1, stream=0, is_mode=None, setup=
     return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices, setup=su)
 
 
+def mlg_psi_filter(arr: dict, nsim: int, seed=1):
+    """ssm_mlg::psi_filter (gaussian_psi_smoother case 0, src/R_psi.cpp:20-25): alpha m x (n+1) x N.  ``arr`` from
+    bssm_amd.models.model_arrays of an ssm_mlg model (y n x p as R holds it; the reference transposes on entry)."""
+    L = lib()
+    n, m, p = arr["n"], arr["m"], arr["p"]
+    mod = OrcMng()
+    yt = np.asfortranarray(np.asarray(arr["y"], dtype=np.float64).T)  # p x n
+    keep = [yt] + [np.asfortranarray(arr[k], dtype=np.float64) for k in ("Z", "T", "R", "a1", "P1", "D", "C", "H")]
+    mod.n, mod.m, mod.k, mod.p = n, m, arr["k"], p
+    mod.Ztv, mod.Ttv, mod.Rtv, mod.Dtv, mod.Ctv = arr["Ztv"], arr["Ttv"], arr["Rtv"], arr["Dtv"], arr["Ctv"]
+    mod.y = _p(yt)
+    for name, a in zip(("Z", "T", "R", "a1", "P1", "D", "C"), keep[1:8]):
+        setattr(mod, name, _p(a))
+    rng, _ = make_rng(seed, 0)
+    alpha = np.zeros((m, n + 1, nsim), order="F")
+    L.orc_mlg_psi_filter.restype = C.c_int
+    ok = L.orc_mlg_psi_filter(C.byref(mod), _p(keep[8]), C.c_int(arr["Htv"]), C.c_uint(nsim), C.byref(rng), _p(alpha))
+    if not ok:
+        raise FloatingPointError("mlg smoother failed")
+    return alpha
+
+
 def ulg_psi_filter(arr: dict, nsim: int, seed=1):
     """ssm_ulg::psi_filter (gaussian_psi_smoother): alpha m x (n+1) x N"""
     g, keep = _pack_ulg(arr)

@@ -65,3 +65,41 @@ def test_suggest_N_nonlinear(oracle):
     ll = F.logLik_batch(model, 32, 10, method="psi", seed=2, stream0=10)
     assert abs(res["results"]["sd"][1] - np.std(ll, ddof=1)) <= 1e-12
     assert np.all(np.isfinite(res["results"]["sd"]))
+
+
+def _mlg_model(n=40, p=3, m=2, tv=False, seed=5):
+    """a small ssm_mlg model with a full (non-diagonal) observation-noise factor and missing values"""
+    rng = np.random.default_rng(seed)
+    T = np.array([[0.9, 0.1], [0.0, 0.7]])
+    R = np.diag([0.3, 0.2])
+    Z = rng.normal(0, 1, (p, m, n if tv else 1))
+    H = np.tril(rng.normal(0, 0.3, (p, p))) + np.diag(np.full(p, 0.5))
+    Hc = np.repeat(H[:, :, None], n, axis=2) * (1 + 0.1 * np.sin(np.arange(n)))[None, None, :] if tv else H
+    x = np.zeros((n, m)); y = np.zeros((n, p))
+    a = rng.normal(0, 1, m)
+    for t in range(n):
+        y[t] = 0.2 + Z[:, :, t if tv else 0] @ a + (Hc[:, :, t] if tv else H) @ rng.normal(0, 1, p)
+        x[t] = a
+        a = T @ a + R @ rng.normal(0, 1, m)
+    y[3, 1] = np.nan; y[7, :] = np.nan; y[12, [0, 2]] = np.nan
+    return M.ssm_mlg(y, Z, Hc, T, R, a1=np.zeros(m), P1=np.eye(m), D=np.full((p, 1), 0.2))
+
+
+@pytest.mark.parametrize("tv", [False, True])
+def test_gaussian_psi_smoother_mlg_matches_oracle(oracle, tv):
+    """gaussian_psi_smoother for ssm_mlg (src/R_psi.cpp:20-25 -> ssm_mlg::psi_filter, src/model_ssm_mlg.cpp:473-501): the
+    multivariate smoother_ccov with a full H H' and partially / fully missing observation vectors, then exact draws"""
+    import ctypes as C
+    from bssm_amd import _lib
+    model = _mlg_model(tv=tv)
+    arr = M.model_arrays(model)
+    smod, keep = _lib.pack_model(arr)
+    N = 300
+    alpha = np.zeros((arr["m"], arr["n"] + 1, N), order="F")
+    _lib.check(_lib.lib().bssm_gaussian_psi_smoother(C.byref(smod), C.c_uint32(N), C.c_uint32(7), C.c_int(0), _lib.dptr(alpha)))
+    ref = oracle.mlg_psi_filter(arr, N, seed=7)
+    assert np.all(np.isfinite(alpha))
+    assert np.allclose(alpha, ref, rtol=1e-9, atol=1e-10)
+    # and through the front-end: smoothed moments over the draws
+    out = F.particle_smoother(model, 20000, method="psi", seed=3)
+    assert out["alphahat"].shape == (arr["n"], arr["m"]) and np.all(np.isfinite(out["Vt"]))

@@ -215,3 +215,29 @@ def test_mcmc_output_summaries():
     assert 13 < ratio < 26
     with pytest.raises(ValueError):
         mcmc.asymptotic_var(x, -np.ones_like(x))
+
+
+def test_shim_source_is_well_formed():
+    """shim/bssm_amd_shim.c (the R-side binding; no R in this image, so it is never built) at least parses and type-checks
+    against the C ABI header, with declaration-only stand-ins for the R API, and registers every path entry point of
+    src/RcppExports.cpp:1288-1344 that SURVEY.md 8b lists"""
+    import subprocess
+    shim = os.path.join(ROOT, "shim", "bssm_amd_shim.c")
+    cp = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-cast-function-type",
+                         "-Werror", "-I" + os.path.join(ROOT, "shim", "check"), "-I" + os.path.join(ROOT, "include"), shim],
+                        capture_output=True, text=True)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    src = open(shim).read()
+    expected = {"_bssm_bsf": 5, "_bssm_bsf_smoother": 5, "_bssm_bsf_nlg": 18, "_bssm_bsf_smoother_nlg": 18, "_bssm_psi_smoother": 4,
+                "_bssm_gaussian_psi_smoother": 4, "_bssm_psi_smoother_nlg": 21, "_bssm_bsf_sde": 12, "_bssm_bsf_smoother_sde": 12,
+                "_bssm_loglik_sde": 12, "_bssm_nongaussian_loglik": 5, "_bssm_nonlinear_loglik": 22, "_bssm_suggest_n_nongaussian": 6,
+                "_bssm_suggest_n_nonlinear": 20, "_bssm_postcorrection_nongaussian": 10, "_bssm_postcorrection_nonlinear": 24,
+                "_bssm_stratified_sample": 3, "_bssm_nongaussian_is_mcmc": 17, "_bssm_nonlinear_is_mcmc": 34, "_bssm_sde_is_mcmc": 24,
+                "_bssm_sde_state_sampler_bsf_is2": 13}
+    for name, nargs in expected.items():
+        assert re.search(r"ENTRY\(%s, %d\)" % (name, nargs), src), (name, nargs)
+        # the definition takes exactly that many SEXP arguments
+        mdef = re.search(r"^SEXP %s\((.*?)\) \{" % name, src, re.S | re.M)
+        assert mdef, name
+        args = mdef.group(1).replace("NLG_ARGS", ",".join(["SEXP a"] * 16)).replace("SDE_ARGS", ",".join(["SEXP a"] * 8))
+        assert args.count("SEXP") == nargs, (name, args.count("SEXP"), nargs)
