@@ -335,6 +335,19 @@ struct DeviceBatch {
     fb.mats = mats.as<double>(); fb.mats_fstride = ms; fb.mats_tstride = tabs[0]->mats_tstride;
     fb.obs = obs.as<double>(); fb.obs_fstride = os;
     fb.init = init.as<double>(); fb.init_fstride = is;
+    return configure(keep_hist, path_flags, keep_weights);
+  }
+  // tables that are already in device memory (built there by fn_setup_kernel): F filters starting at the given pointers
+  int attach(const double* d_mats, size_t ms, int tstride, const double* d_obs, size_t os, const double* d_init, size_t is,
+             int F, int n, int m, int k, int p, int N, int psi, int MP, int KP) {
+    fb.n = n; fb.m = m; fb.k = k; fb.p = p; fb.MP = MP; fb.KP = KP; fb.N = N; fb.F = F; fb.psi = psi;
+    fb.mats = d_mats; fb.mats_fstride = ms; fb.mats_tstride = tstride;
+    fb.obs = d_obs; fb.obs_fstride = os;
+    fb.init = d_init; fb.init_fstride = is;
+    return configure(false, 0, false);
+  }
+  int configure(bool keep_hist, unsigned path_flags, bool keep_weights) {
+    const int F = fb.F, n = fb.n, m = fb.m, N = fb.N, MP = fb.MP;
     HIP_TRY(loglik.alloc(F * sizeof(double)));
     fb.loglik = loglik.as<double>();
     HIP_TRY(dead.alloc(F * sizeof(int)));
@@ -614,7 +627,9 @@ int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
 
 // ---------------------------------------------------------------- built-in non-linear / SDE models
 namespace {
-int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector<double>* fpar, int* m_out, int* k_out) {
+// params_only (may be NULL): stop after the parameter block and hand back a1 (2) and P1 (4) -- what the device set-up needs
+int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector<double>* fpar, int* m_out, int* k_out,
+                   double* params_only = nullptr) {
   if (!mod || !mod->y || !mod->theta) return fail(BSSM_ERR_INVALID, "model, y, theta must be non-NULL");
   const int id = mod->model_id, n = mod->n;
   if (id < bssm::FN_NLG_GROWTH || id > bssm::FN_USER_SDE) return fail(BSSM_ERR_UNSUPPORTED, "unknown model id");
@@ -655,6 +670,11 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   fp[bssm::FP_SLOT] = user ? mod->user_slot : 0;
   fp[bssm::FP_H] = H;
   fp[bssm::FP_LOGC] = -0.5 * (std::log(2.0 * 3.14159265358979323846) + 2.0 * std::log(H));
+  if (params_only) {
+    for (int j = 0; j < 2; j++) params_only[j] = a1[j];
+    for (int q = 0; q < 4; q++) params_only[2 + q] = P1[q];
+    return BSSM_OK;
+  }
   // tables: no linear transition operands; one observation series carrying y (and lgamma(y + 1) for the Poisson model)
   ft->MP = MP; ft->KP = MP; ft->mats_tstride = 0;
   ft->mats.assign((size_t)MP * MP * 2 + MP, 0.0);
@@ -1273,7 +1293,23 @@ bool device_setup_enabled(int n_threads) {
 // Shared core of the IS post-correction drivers: filter `cnt` prepared draws (tables already built), then
 // back-trace / summarise as output_type asks.  const_add[i] is added to the device log-likelihood
 // (bootstrap: state-independent constants); weight_i = exp(loglik_i - sub[i]) (src/approx_mcmc.cpp:385, 479).
+// tables of one pipeline chunk built on the device (fn_setup_kernel): draws [lo, lo + F) in draw order
+struct ChunkTables {
+  int lo = 0, F = 0;
+  size_t ms = 0, os = 0, is = 0, as = 0;
+  DevBuf fpar, ext, modes, y, scratch, mats, obs, init, amats, ok;
+};
 struct IsCore {
+  std::mutex chunk_mu;
+  std::map<int, std::shared_ptr<ChunkTables>> chunk_tabs;  // by first draw of the chunk; taken by the device thread
+  std::shared_ptr<ChunkTables> take_chunk(int lo) {
+    std::lock_guard<std::mutex> lk(chunk_mu);
+    auto it = chunk_tabs.find(lo);
+    if (it == chunk_tabs.end()) return nullptr;
+    auto p = it->second;
+    chunk_tabs.erase(it);
+    return p;
+  }
   int n = 0, m = 0, k = 0, pp = 1;
   bool psi = false;
   int first = 0, is_type = 2, output_type = 3;
@@ -1303,6 +1339,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nsim_of(a) < nsim_of(b); });
   bool any_degenerate = false;
   size_t pos = 0;
+  const std::shared_ptr<ChunkTables> ctabs = J.take_chunk(lo);  // non-null: the tables of [lo, hi) are already in HBM, in draw order
   while (pos < order.size()) {
     const int N = nsim_of(order[pos]);
     size_t end = pos;
@@ -1333,12 +1370,23 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
       std::vector<const bssm::FilterTables*> bt(F);
       for (size_t f = 0; f < F; f++) bt[f] = &tabs[order[pos + f]];
       DeviceBatch db;
-      int rc = db.upload(bt, n, m, k, pp, N, psi, false, 0, false, 4);
+      int rc;
+      if (ctabs) {
+        const size_t off = pos;  // (uniform particle count: `order` is the identity on this chunk)
+        rc = db.attach(ctabs->mats.as<double>() + off * ctabs->ms, ctabs->ms, (int)(ctabs->ms / (size_t)n), ctabs->obs.as<double>() + off * ctabs->os,
+                       ctabs->os, ctabs->init.as<double>() + off * ctabs->is, ctabs->is, (int)F, n, m, k, pp, N, psi, m, m);
+      } else {
+        rc = db.upload(bt, n, m, k, pp, N, psi, false, 0, false, 4);
+      }
       if (rc) return rc;
       if (need_hist) { db.fb.alpha_hist = hist_pool.as<double>(); db.fb.indices = idx_pool.as<uint32_t>(); db.fb.weights = nullptr; }
       DevBuf fparb, amatb;  // per-draw functor parameters / approximating (T_t, C_t), in batch order
       StageBuf st_fpar, st_amat;
-      if (!J.fpar.empty()) {
+      if (ctabs) {
+        db.fb.fpar = ctabs->fpar.as<double>() + pos * bssm::FP_SIZE; db.fb.fpar_fstride = bssm::FP_SIZE;
+        db.fb.user_slot = 0;
+        db.fb.amats = ctabs->amats.as<double>() + pos * ctabs->as; db.fb.amats_fstride = ctabs->as;
+      } else if (!J.fpar.empty()) {
         HIP_TRY(st_fpar.alloc(F * bssm::FP_SIZE * sizeof(double)));
         double* hb = (double*)st_fpar.p;
         for (size_t f = 0; f < F; f++) std::memcpy(hb + f * bssm::FP_SIZE, J.fpar.data() + (size_t)order[pos + f] * bssm::FP_SIZE, bssm::FP_SIZE * sizeof(double));
@@ -1347,7 +1395,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         db.fb.fpar = fparb.as<double>(); db.fb.fpar_fstride = bssm::FP_SIZE;
         db.fb.user_slot = (int)J.fpar[bssm::FP_SLOT];
       }
-      if (!J.amats.empty()) {
+      if (!ctabs && !J.amats.empty()) {
         const size_t as = (size_t)n * (m * m + m);
         HIP_TRY(st_amat.alloc(F * as * sizeof(double)));
         double* hb = (double*)st_amat.p;
@@ -1643,6 +1691,75 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   J.bad.assign(count, 0);
   J.const_add.assign(count, 0.0); J.sub.assign(count, 0.0);
   J.fpar.assign((size_t)count * bssm::FP_SIZE, 0.0);
+  // ---- SURVEY.md 8f rank 1, all of it on the device (built-in models, uniform particle count): per draw the host packs
+  // theta and (a1, P1); linearisation at the stored mode, smoother, conditional factors and the filter's tables are ONE
+  // kernel per pipeline chunk (fn_setup_kernel), whose outputs the filter reads in place.  BSSM_AMD_DEVICE_SETUP = 0 / 1
+  // select the host set-up / the device smoother alone instead (they are tested against each other and the oracle).
+  bool dev_full = psi && have_device() && id >= bssm::FN_NLG_GROWTH && id <= bssm::FN_NLG_LINEAR_GAUSSIAN && is_type != 1;
+  if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) dev_full = dev_full && env[0] == '2';
+  for (int i = 1; i < count && dev_full; i++) if (models[i].y != models[0].y || models[i].n != n || models[i].model_id != id) dev_full = false;
+  if (dev_full) {
+    const int mm = m * m, EXT = m + mm;
+    std::vector<double> ext((size_t)count * EXT);
+    auto prepare = [&](int i) -> std::string {
+      std::vector<double> fp;
+      bssm::FilterTables none;
+      double ap[6];
+      int mm_ = 1, kk_ = 1;
+      if (functor_tables(&models[i], &none, &fp, &mm_, &kk_, ap)) return g_err;
+      std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
+      double* e = ext.data() + (size_t)i * EXT;
+      for (int j = 0; j < m; j++) e[j] = ap[j];
+      if (m == 1) e[1] = ap[2]; else for (int q = 0; q < 4; q++) e[2 + q] = ap[2 + q];
+      return "";
+    };
+    auto device_chunk = [&](int lo, int hi) -> int {
+      static thread_local bssm::TlsStream st_tls;
+      hipStream_t st = st_tls.get(true);
+      if (!st) return fail(BSSM_ERR_HIP, "no stream for the set-up kernel");
+      const int F = hi - lo;
+      auto ct = std::make_shared<ChunkTables>();
+      ct->lo = lo; ct->F = F;
+      ct->ms = (size_t)n * (2 * mm + m); ct->os = (size_t)n * (bssm::ROW_HDR + bssm::SER_HDR + m); ct->is = (size_t)m + mm; ct->as = (size_t)n * (mm + m);
+      StageBuf stage;
+      const size_t nf = (size_t)F * bssm::FP_SIZE, ne = (size_t)F * EXT, nm = (size_t)F * m * n;
+      HIP_TRY(stage.alloc((nf + ne + nm + n) * sizeof(double)));
+      double* h = (double*)stage.p;
+      std::memcpy(h, J.fpar.data() + (size_t)lo * bssm::FP_SIZE, nf * sizeof(double));
+      std::memcpy(h + nf, ext.data() + (size_t)lo * EXT, ne * sizeof(double));
+      std::memcpy(h + nf + ne, modes + (size_t)m * n * lo, nm * sizeof(double));
+      std::memcpy(h + nf + ne + nm, models[0].y, (size_t)n * sizeof(double));
+      HIP_TRY(ct->fpar.alloc(nf * sizeof(double))); HIP_TRY(ct->ext.alloc(ne * sizeof(double)));
+      HIP_TRY(ct->modes.alloc(nm * sizeof(double))); HIP_TRY(ct->y.alloc((size_t)n * sizeof(double)));
+      HIP_TRY(ct->scratch.alloc(bssm::fn_setup_scratch_doubles(n, m) * F * sizeof(double)));
+      HIP_TRY(ct->mats.alloc(ct->ms * F * sizeof(double))); HIP_TRY(ct->obs.alloc(ct->os * F * sizeof(double)));
+      HIP_TRY(ct->init.alloc(ct->is * F * sizeof(double))); HIP_TRY(ct->amats.alloc(ct->as * F * sizeof(double)));
+      HIP_TRY(ct->ok.alloc((size_t)F * sizeof(int)));
+      HIP_TRY(hipMemcpyAsync(ct->fpar.p, h, nf * sizeof(double), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ct->ext.p, h + nf, ne * sizeof(double), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ct->modes.p, h + nf + ne, nm * sizeof(double), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ct->y.p, h + nf + ne + nm, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+      bssm::FnSetupDev b{};
+      b.F = F; b.n = n; b.m = m;
+      b.fpar = ct->fpar.as<double>(); b.ext = ct->ext.as<double>(); b.modes = ct->modes.as<double>(); b.y = ct->y.as<double>();
+      b.scratch = ct->scratch.as<double>();
+      b.mats = ct->mats.as<double>(); b.obs = ct->obs.as<double>(); b.init = ct->init.as<double>(); b.amats = ct->amats.as<double>();
+      b.ok = ct->ok.as<int>();
+      const double t0 = now_ms();
+      HIP_TRY(bssm::launch_fn_setup(b, st));
+      std::vector<int> okv(F);
+      HIP_TRY(hipMemcpyAsync(okv.data(), ct->ok.p, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (std::getenv("BSSM_AMD_TRACE"))
+        std::fprintf(stderr, "[bssm_amd] psi set-up on device (linearisation + smoother + tables): F=%d n=%d m=%d: %.2f ms\n", F, n, m, now_ms() - t0);
+      for (int q = 0; q < F; q++) if (!okv[q]) J.bad[lo + q] = 1;  // non-finite Vt / Ct: the filter returns -Inf (src/model_ssm_nlg.cpp:988-990)
+      ct->scratch.release(); ct->modes.release(); ct->ext.release(); ct->ok.release();
+      std::lock_guard<std::mutex> lk(J.chunk_mu);
+      J.chunk_tabs[lo] = ct;
+      return 0;
+    };
+    return run_is_pipeline(J, count, n_threads, prepare, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk, nullptr);
+  }
   if (psi) J.amats.assign((size_t)count * n * (m * m + m), 0.0);
   const bool dev_setup = psi && device_setup_enabled(n_threads) && have_device();
   std::vector<bssm::FnModel> fms(dev_setup ? count : 0);

@@ -64,6 +64,30 @@ __device__ __forceinline__ double nlg_Z_fn(int id, const double* __restrict__ fp
   }
 }
 
+// Jacobian of T_fn (T_gn, R/cpp_example_models.R:432-450 etc.), MP x MP column-major: the mode-linearised model of the
+// psi-APF set-up when it runs on the device (fn_setup_kernel); built-in models only (a user model's Jacobians are host
+// entry points of its library)
+template <int MP>
+__device__ __forceinline__ void nlg_T_gn(int id, const double* __restrict__ fp, const double (&a)[MP], double (&Tg)[MP * MP]) {
+#pragma unroll
+  for (int q = 0; q < MP * MP; q++) Tg[q] = 0.0;
+  switch (id) {
+    case FN_NLG_GROWTH:
+      if constexpr (MP > 1) {
+        const double dT = fp[FP_KNOWN + 0], K = fp[FP_KNOWN + 1];
+        const double e0 = exp(a[0]), r = e0 / (1.0 + e0), er = exp(r * dT);
+        const double den = K + a[1] * (er - 1.0), tmp = er / (den * den);
+        Tg[0] = 1.0;
+        Tg[1] = dT * K * a[1] * (K - a[1]) * tmp * r / (1.0 + e0);
+        Tg[3] = K * K * tmp;
+      }
+      break;
+    case FN_NLG_AR_EXP: Tg[0] = fp[FP_THETA + 1]; break;
+    case FN_NLG_SIN_EXP: Tg[0] = cos(a[0]); break;
+    default: Tg[0] = 1.0; break;
+  }
+}
+
 // ---- ssm_sde: Milstein scheme with 2^L sub-steps per unit time (src/milstein.cpp:18-48)
 __device__ __forceinline__ double sde_drift(int id, const double* __restrict__ fp, double x) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)

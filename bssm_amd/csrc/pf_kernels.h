@@ -127,6 +127,21 @@ struct LgBatchDev {
   int* ok;
 };
 hipError_t launch_lg_setup(const LgBatchDev& b, hipStream_t stream);
+// psi-APF set-up of ssm_nlg draws entirely on the device: linearisation at the stored mode
+// (approximate_for_is, src/model_ssm_nlg.cpp:146-176), Kalman / covariance smoother + conditional factors
+// (lg_smoother.h), and the filter's tables written straight into the batch layout -- one lane per draw.
+struct FnSetupDev {
+  int F, n, m;
+  const double* fpar;   // [F][FP_SIZE]
+  const double* ext;    // [F][m + m*m]: a1, P1 of the draw
+  const double* modes;  // [F][m*n], m x n column-major per draw
+  const double* y;      // [n], shared by the draws
+  double* scratch;      // draw-interleaved work arrays, fn_setup_scratch_doubles(n, m) * F doubles
+  double *mats, *obs, *init, *amats;  // per-draw contiguous outputs: [F][n][2 m^2 + m], [F][n][ROW_HDR + SER_HDR + m], [F][m + m^2], [F][n][m^2 + m]
+  int* ok;              // [F]: 0 = the smoother failed (tables are then neutral and the caller reports -Inf)
+};
+size_t fn_setup_scratch_doubles(int n, int m);
+hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream);
 hipError_t launch_transpose(const double* in, double* out, int rows, int cols, hipStream_t stream);
 hipError_t launch_calib_copy(const double* in, double* out, size_t n, hipStream_t stream);
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream);

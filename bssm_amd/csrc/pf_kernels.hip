@@ -204,6 +204,137 @@ hipError_t launch_lg_setup(const LgBatchDev& b, hipStream_t stream) {
   }
   return hipGetLastError();
 }
+// ---------------------------------------------------------------- psi set-up of ssm_nlg draws, all of it on the device
+// What psi_setup / fn_psi_setup_begin + build_fn_psi_tables do per draw on the host (host_model.cpp), as one lane per
+// draw: the host then only packs theta (FP_SIZE doubles) and a1 / P1 per draw.  Work arrays are draw-interleaved
+// (element k of draw d at base[k * F + d]) like lg_setup_kernel's; the tables go out per draw, contiguous, in the
+// layout DeviceBatch hands to the filter kernels.
+size_t fn_setup_scratch_doubles(int n, int m) {
+  const size_t mm = (size_t)m * m, n1 = (size_t)n + 1;
+  //      Z            T        RR   D   C            y   H   a1  P1   at       Pt        cc        K            v   Fs
+  return (size_t)n * m + n * mm + mm + n + (size_t)n * m + n + 1 + m + mm + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n;
+}
+template <int M>
+__global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
+  math_tab_init();
+  const int d = blockIdx.x * 64 + threadIdx.x;
+  if (d >= b.F) return;
+  constexpr int MM = M * M;
+  const size_t F = (size_t)b.F;
+  const int n = b.n;
+  const double* __restrict__ fp = b.fpar + (size_t)d * FP_SIZE;
+  const int id = (int)fp[FP_ID];
+  double* w = b.scratch + d;
+  double* sZ = w;                 w += (size_t)n * M * F;
+  double* sT = w;                 w += (size_t)n * MM * F;
+  double* sRR = w;                w += (size_t)MM * F;
+  double* sD = w;                 w += (size_t)n * F;
+  double* sC = w;                 w += (size_t)n * M * F;
+  double* sy = w;                 w += (size_t)n * F;
+  double* sH = w;                 w += F;
+  double* sa1 = w;                w += (size_t)M * F;
+  double* sP1 = w;                w += (size_t)MM * F;
+  double* at = w;                 w += (size_t)(n + 1) * M * F;
+  double* Pt = w;                 w += (size_t)(n + 1) * MM * F;
+  double* cc = w;                 w += (size_t)(n + 1) * MM * F;
+  double* K = w;                  w += (size_t)n * M * F;
+  double* v = w;                  w += (size_t)n * F;
+  double* Fs = w;
+  // ---- linearisation at the stored mode: Z_t = Z'(mode_t), D_t = Z(mode_t) - Z_t mode_t, T_t = T'(mode_t),
+  // C_t = T(mode_t) - T_t mode_t  (approximate_for_is, src/model_ssm_nlg.cpp:146-176; scales and approx_loglik stay 0)
+  const double* __restrict__ mode = b.modes + (size_t)d * M * n;
+  for (int t = 0; t < n; t++) {
+    double a[M], Zg[M], Tg[MM], Tf[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) a[j] = mode[(size_t)M * t + j];
+    nlg_Z_gn<M>(id, fp, a, Zg);
+    nlg_T_gn<M>(id, fp, a, Tg);
+    double za = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; j++) za += Zg[j] * a[j];
+    sD[(size_t)t * F] = nlg_Z_fn<M>(id, fp, a) - za;
+    nlg_T_fn<M>(id, fp, a, Tf);
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < M; j++) s += Tg[i + M * j] * a[j];
+      sC[((size_t)t * M + i) * F] = Tf[i] - s;
+      sZ[((size_t)t * M + i) * F] = Zg[i];
+    }
+#pragma unroll
+    for (int q = 0; q < MM; q++) sT[((size_t)t * MM + q) * F] = Tg[q];
+    sy[(size_t)t * F] = b.y[t];
+  }
+#pragma unroll
+  for (int q = 0; q < MM; q++) sRR[(size_t)q * F] = 0.0;
+#pragma unroll
+  for (int j = 0; j < M; j++) sRR[(size_t)(j + M * j) * F] = fp[FP_R + j] * fp[FP_R + j];  // R is diagonal in every shipped model
+  sH[0] = fp[FP_H];
+  const double* __restrict__ ex = b.ext + (size_t)d * (M + MM);
+#pragma unroll
+  for (int j = 0; j < M; j++) sa1[(size_t)j * F] = ex[j];
+#pragma unroll
+  for (int q = 0; q < MM; q++) sP1[(size_t)q * F] = ex[M + q];
+  LgModel g;
+  g.n = n;
+  g.Z = sZ; g.Zs = M; g.T = sT; g.Ts = MM; g.RR = sRR; g.Rs = 0; g.D = sD; g.Ds = 1; g.C = sC; g.Cs = M;
+  g.y = sy; g.H = sH; g.Hs = 0; g.a1 = sa1; g.P1 = sP1;
+  const bool ok = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F);  // at = alphahat, Pt = V_t^(1/2), cc = C_t after conditional_cov
+  b.ok[d] = ok ? 1 : 0;
+  // ---- tables (build_fn_psi_tables): proposal operands, observation rows, initial state, approximating (T_t, C_t)
+  constexpr int MS = 2 * MM + M, OS = ROW_HDR + SER_HDR + M, AS = MM + M;
+  double* __restrict__ mats = b.mats + (size_t)d * n * MS;
+  double* __restrict__ obs = b.obs + (size_t)d * n * OS;
+  double* __restrict__ ini = b.init + (size_t)d * (M + MM);
+  double* __restrict__ am = b.amats + (size_t)d * n * AS;
+  const double ih = 1.0 / fp[FP_H];
+  for (int t = 0; t < n; t++) {
+    double* mt = mats + (size_t)t * MS;
+    double ah0[M], ah1[M], Ct1[MM];
+#pragma unroll
+    for (int j = 0; j < M; j++) { ah0[j] = at[((size_t)t * M + j) * F]; ah1[j] = at[((size_t)(t + 1) * M + j) * F]; }
+#pragma unroll
+    for (int q = 0; q < MM; q++) { Ct1[q] = cc[((size_t)(t + 1) * MM + q) * F]; mt[q] = ok ? Ct1[q] : 0.0; mt[MM + q] = ok ? Pt[((size_t)(t + 1) * MM + q) * F] : 0.0; }
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < M; c++) s += Ct1[j + M * c] * ah0[c];
+      mt[2 * MM + j] = ok ? ah1[j] - s : 0.0;
+    }
+    double* row = obs + (size_t)t * OS;
+    const double yt = b.y[t];
+    const bool seen = ok && yt == yt && fabs(yt) <= 1.7976931348623157e308;
+#pragma unroll
+    for (int q = 0; q < OS; q++) row[q] = 0.0;
+    if (seen) {
+      row[RH_FLAG] = 1.0;  // (RH_SCALE: the scales of approximate_for_is are zero)
+      double* ob = row + ROW_HDR;
+      ob[OB_FLAG] = 1.0; ob[OB_Y] = yt; ob[OB_D] = sD[(size_t)t * F]; ob[OB_PSIIH] = ih;
+#pragma unroll
+      for (int c = 0; c < M; c++) ob[SER_HDR + c] = sZ[((size_t)t * M + c) * F];
+    }
+    double* a2 = am + (size_t)t * AS;
+#pragma unroll
+    for (int q = 0; q < MM; q++) a2[q] = ok ? sT[((size_t)t * MM + q) * F] : 0.0;
+#pragma unroll
+    for (int j = 0; j < M; j++) a2[MM + j] = ok ? sC[((size_t)t * M + j) * F] : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < M; j++) ini[j] = ok ? at[(size_t)j * F] : 0.0;
+#pragma unroll
+  for (int q = 0; q < MM; q++) ini[M + q] = ok ? Pt[(size_t)q * F] : 0.0;
+}
+hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream) {
+  const dim3 grid((b.F + 63) / 64), block(64);
+  switch (b.m) {
+    case 1: hipLaunchKernelGGL(fn_setup_kernel<1>, grid, block, 0, stream, b); break;
+    case 2: hipLaunchKernelGGL(fn_setup_kernel<2>, grid, block, 0, stream, b); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 // out[c * rows + r] = in[r * cols + c], 32 x 32 tiles through LDS (both sides coalesced): per-draw contiguous <->
 // draw-interleaved layouts of the smoother batch
 __global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ in, double* __restrict__ out, int rows, int cols) {

@@ -186,7 +186,9 @@ typedef struct bssm_fn_model {
  * bssm_user_model_load maps it and returns a slot >= 1 for bssm_fn_model.user_slot (negative = error).
  * Built for user models: every single-model entry point of the built-in models -- bootstrap, psi-APF (bssm_psi_smoother_nlg,
  * bssm_fn_psi_setup) and EKF particle filter (bssm_ekpf_*) with their smoothers and bssm_fn_loglik_batch; the psi-APF and
- * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS) and a diagonal P1.  Not built: IS post-correction. */
+ * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS) and a diagonal P1.  IS post-correction
+ * (bssm_is_correction_nlg / _multi) and the chains (bssm_run_mcmc_fn; theta-dependent H / R / a1 / P1 through
+ * bssm_mcmc_job.fn_update_fn) work for user models too. */
 int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity);
 int bssm_user_model_load(const char* lib_path);
 /* replaces _bssm_bsf_nlg (18 args, src/R_bootstrap_filter.cpp:461-504) / _bssm_bsf_smoother_nlg (:508-551):
@@ -426,7 +428,7 @@ typedef struct bssm_mcmc_job {
   int (*fn_update_fn)(const double* theta, int32_t n_par, bssm_fn_model* model, void* user);
 } bssm_mcmc_job;
 typedef struct bssm_mcmc_out {
-  int32_t capacity;        /* in: room for this many stored values (floor((iter - burnin) / thin) always suffices) */
+  int32_t capacity;        /* in: room for this many stored values (floor((iter - burnin) / thin) + 1 always suffices) */
   int32_t n_stored;        /* out */
   double acceptance_rate;  /* out */
   double* S;               /* n_par x n_par lower triangular, in: initial proposal factor, out: adapted */

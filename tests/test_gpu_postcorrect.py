@@ -101,14 +101,51 @@ def test_device_psi_setup_equals_host_setup(monkeypatch, kind):
         mode = F.psi_setup(model)["mode"]
         modes = np.repeat(mode.reshape(-1, 1, order="F"), 40, axis=1).reshape(2, n, 40, order="F")
     res = {}
-    for dev in ("1", "0"):
+    # "0": everything on the host; "1": the smoother as a device batch; "2": linearisation + smoother + tables on the
+    # device (ssm_nlg built-ins; the default there) -- for bsm_ng "2" is the same as unset
+    for dev in ("2", "1", "0"):
         monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
         mo = dict(theta=theta, counts=counts, modes=modes, output_type=2)
         res[dev] = PC.post_correct(model, mo, 64, threads=3, is_type="is2", seed=4)
-    assert np.all(np.isfinite(res["1"]["loglik"]))
-    assert np.allclose(res["1"]["loglik"], res["0"]["loglik"], rtol=0, atol=1e-9 * n)
-    assert np.allclose(res["1"]["alphahat"], res["0"]["alphahat"], rtol=1e-8, atol=1e-10)
-    assert np.allclose(res["1"]["Vt"], res["0"]["Vt"], rtol=1e-7, atol=1e-10)
+    for dev in ("2", "1"):
+        assert np.all(np.isfinite(res[dev]["loglik"]))
+        assert np.allclose(res[dev]["loglik"], res["0"]["loglik"], rtol=0, atol=1e-9 * n)
+        assert np.allclose(res[dev]["alphahat"], res["0"]["alphahat"], rtol=1e-8, atol=1e-10)
+        assert np.allclose(res[dev]["Vt"], res["0"]["Vt"], rtol=1e-7, atol=1e-10)
+    # ... and against the ORACLE's restatement of the same set-up + filter (not only against the product's host path)
+    from oracle import oracle as O
+    if kind == "bsm_ng":
+        ref = O.is_correction(arrs, 64, 4, method=1, counts=counts, modes=modes, is_type=2, output_type=2, n_threads=2)
+        for dev in ("2", "1", "0"):
+            assert np.allclose(res[dev]["loglik"], ref["loglik"], rtol=0, atol=1e-9 * n)
+            assert np.allclose(res[dev]["alphahat"], ref["alphahat"].T, rtol=1e-8, atol=1e-10)
+    else:
+        lw = O.fn_is_logweights(model, theta, modes.reshape(2 * n, 40, order="F"), 64, seed=4, first_stream=0, n_threads=2)
+        for dev in ("2", "1", "0"):
+            assert np.allclose(np.log(res[dev]["weights"]), lw, rtol=0, atol=1e-9 * n)
+
+
+def test_device_set_up_marks_failed_draws(monkeypatch):
+    """a draw whose smoother fails (non-finite factors) gets weight 0 / logLik -Inf on every set-up path, the others are
+    unaffected (src/model_ssm_nlg.cpp:988-990)"""
+    from bssm_amd import filters as F
+    rng = np.random.default_rng(3)
+    n = 40
+    y = 50 + np.cumsum(rng.normal(0.5, 1, n))
+    th0 = np.array([0.0, np.log(0.05), 0.0])
+    model = M.ssm_nlg(y, "nlg_growth", theta=th0, known_params=[0.1, 500.0, 0.0, 50.0, 1.0, 100.0])
+    theta = th0 + rng.normal(0, 0.05, (6, 3))
+    theta[2, 0] = 800.0  # exp(800) overflows: H = Inf
+    counts = np.ones(6, dtype=np.uint32)
+    mode = F.psi_setup(model)["mode"]
+    modes = np.repeat(mode.reshape(-1, 1, order="F"), 6, axis=1).reshape(2, n, 6, order="F")
+    out = {}
+    for dev in ("2", "0"):
+        monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+        out[dev] = PC.post_correct(model, dict(theta=theta, counts=counts, modes=modes, output_type=3), 32, is_type="is2", seed=2)
+        assert out[dev]["weights"][2] == 0.0 and np.isneginf(out[dev]["loglik"][2])
+        assert np.all(np.isfinite(np.delete(out[dev]["loglik"], 2)))
+    assert np.allclose(np.delete(out["2"]["loglik"], 2), np.delete(out["0"]["loglik"], 2), rtol=0, atol=1e-9 * n)
 
 
 @pytest.mark.parametrize("output_type", [1, 2])
