@@ -1374,7 +1374,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
       if (ctabs) {
         const size_t off = pos;  // (uniform particle count: `order` is the identity on this chunk)
         rc = db.attach(ctabs->mats.as<double>() + off * ctabs->ms, ctabs->ms, (int)(ctabs->ms / (size_t)n), ctabs->obs.as<double>() + off * ctabs->os,
-                       ctabs->os, ctabs->init.as<double>() + off * ctabs->is, ctabs->is, (int)F, n, m, k, pp, N, psi, m, m);
+                       ctabs->os, ctabs->init.as<double>() + off * ctabs->is, ctabs->is, (int)F, n, m, k, pp, N, psi, bssm::pad_dim(m), bssm::pad_dim(m));
       } else {
         rc = db.upload(bt, n, m, k, pp, N, psi, false, 0, false, 4);
       }
@@ -1382,7 +1382,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
       if (need_hist) { db.fb.alpha_hist = hist_pool.as<double>(); db.fb.indices = idx_pool.as<uint32_t>(); db.fb.weights = nullptr; }
       DevBuf fparb, amatb;  // per-draw functor parameters / approximating (T_t, C_t), in batch order
       StageBuf st_fpar, st_amat;
-      if (ctabs) {
+      if (ctabs && ctabs->fpar.p) {
         db.fb.fpar = ctabs->fpar.as<double>() + pos * bssm::FP_SIZE; db.fb.fpar_fstride = bssm::FP_SIZE;
         db.fb.user_slot = 0;
         db.fb.amats = ctabs->amats.as<double>() + pos * ctabs->as; db.fb.amats_fstride = ctabs->as;
@@ -1600,6 +1600,82 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   J.tabs.resize(cnt);
   J.bad.assign(cnt, 0);
   J.const_add.assign(cnt, 0.0); J.sub.assign(cnt, 0.0);
+  // ---- SURVEY.md 8f rank 1, all of it on the device (univariate observations, m <= 8, uniform particle count): the host
+  // ingests and packs the draw; Laplace step at the stored mode, scales, smoother, conditional factors and the filter's
+  // tables are ONE kernel per pipeline chunk (ung_setup_kernel), whose outputs the filter reads in place.
+  // BSSM_AMD_DEVICE_SETUP = 0 / 1 select the host set-up / the device smoother alone (tested against each other and the oracle).
+  bool dev_full = psi && have_device() && p0 == 1 && m <= 8 && job->is_type != 1 && job->models[0].distribution != BSSM_GAUSSIAN;
+  if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) dev_full = dev_full && env[0] == '2';
+  if (std::getenv("BSSM_AMD_GENERIC_SETUP")) dev_full = false;
+  if (dev_full) {
+    std::vector<bssm::LgPacked> packs(cnt);
+    auto prepare_full = [&](int i) -> std::string {
+      std::string err = bssm::ingest_model(&job->models[i], false, &hms[i]);
+      if (!err.empty()) return err;
+      if (hms[i].n != n || hms[i].m != m || hms[i].k != k || hms[i].p != p0) return "all draws must share n, m, k, p";
+      if (!bssm::ung_pack(hms[i], job->modes + (size_t)n * i, &packs[i])) return "draw cannot be packed for the device set-up";
+      return "";
+    };
+    auto device_chunk_full = [&](int lo, int hi) -> int {
+      const int F = hi - lo;
+      const bssm::LgPacked& L0 = packs[lo];
+      bool same = true;
+      for (int i = lo + 1; i < hi; i++) same = same && L0.same_layout(packs[i]);
+      if (!same) {  // draws that differ in what varies with time: the host set-up for this chunk (tables uploaded by the filter stage)
+        parallel_for(F, job->n_threads, [&](int q) {
+          const int i = lo + q;
+          bssm::PsiSetup su;
+          if (!bssm::psi_setup(hms[i], job->modes + (size_t)n * i, &su)) J.bad[i] = 1;
+          bssm::build_psi_tables(hms[i], su, MP, &J.tabs[i]);
+          hms[i] = bssm::HostModel(); packs[i] = bssm::LgPacked();
+        });
+        return 0;
+      }
+      static thread_local bssm::TlsStream st_tls;
+      hipStream_t st = st_tls.get(true);
+      if (!st) return fail(BSSM_ERR_HIP, "no stream for the set-up kernel");
+      const size_t E = L0.buf.size();
+      auto ct = std::make_shared<ChunkTables>();
+      ct->lo = lo; ct->F = F;
+      ct->ms = (size_t)n * (2 * MP * MP + MP); ct->os = (size_t)n * (bssm::ROW_HDR + bssm::SER_HDR + MP); ct->is = (size_t)MP + (size_t)MP * MP; ct->as = 0;
+      StageBuf stage;
+      HIP_TRY(stage.alloc(E * F * sizeof(double)));
+      double* h = (double*)stage.p;
+      parallel_for(F, std::min(job->n_threads, 8), [&](int q) {
+        std::memcpy(h + E * q, packs[lo + q].buf.data(), E * sizeof(double));
+        hms[lo + q] = bssm::HostModel(); packs[lo + q].buf = std::vector<double>();
+      });
+      DevBuf din, din_t;
+      HIP_TRY(din.alloc(E * F * sizeof(double)));
+      HIP_TRY(din_t.alloc(E * F * sizeof(double)));
+      HIP_TRY(ct->scratch.alloc(bssm::ung_setup_scratch_doubles(n, m) * F * sizeof(double)));
+      HIP_TRY(ct->mats.alloc(ct->ms * F * sizeof(double))); HIP_TRY(ct->obs.alloc(ct->os * F * sizeof(double)));
+      HIP_TRY(ct->init.alloc(ct->is * F * sizeof(double)));
+      HIP_TRY(ct->ok.alloc((size_t)F * sizeof(int)));
+      const double t0 = now_ms();
+      HIP_TRY(hipMemcpyAsync(din.p, h, E * F * sizeof(double), hipMemcpyHostToDevice, st));
+      HIP_TRY(bssm::launch_transpose(din.as<double>(), din_t.as<double>(), F, (int)E, st));  // [F][E] -> [E][F]
+      bssm::UngSetupDev b{};
+      b.F = F; b.n = n; b.m = m;
+      b.Zs = L0.Zs; b.Ts = L0.Ts; b.Rs = L0.Rs; b.Ds = L0.Ds; b.Cs = L0.Cs;
+      b.oZ = L0.oZ; b.oT = L0.oT; b.oR = L0.oR; b.oD = L0.oD; b.oC = L0.oC; b.oy = L0.oy; b.oa = L0.oa; b.oP = L0.oP;
+      b.ou = L0.ou; b.ox = L0.ox; b.om = L0.om; b.oh = L0.oh;
+      b.in = din_t.as<double>(); b.scratch = ct->scratch.as<double>();
+      b.mats = ct->mats.as<double>(); b.obs = ct->obs.as<double>(); b.init = ct->init.as<double>(); b.ok = ct->ok.as<int>();
+      HIP_TRY(bssm::launch_ung_setup(b, st));
+      std::vector<int> okv(F);
+      HIP_TRY(hipMemcpyAsync(okv.data(), ct->ok.p, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (std::getenv("BSSM_AMD_TRACE"))
+        std::fprintf(stderr, "[bssm_amd] psi set-up on device (Laplace step + smoother + tables): F=%d n=%d m=%d: %.2f ms\n", F, n, m, now_ms() - t0);
+      for (int q = 0; q < F; q++) if (!okv[q]) J.bad[lo + q] = 1;
+      ct->scratch.release(); ct->ok.release();
+      std::lock_guard<std::mutex> lk(J.chunk_mu);
+      J.chunk_tabs[lo] = ct;
+      return 0;
+    };
+    return run_is_pipeline(J, cnt, job->n_threads, prepare_full, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk_full, nullptr);
+  }
   const bool dev_setup = psi && device_setup_enabled(job->n_threads) && have_device();
   std::vector<bssm::PsiSetup> sus(dev_setup ? cnt : 0);
   std::vector<bssm::LgPacked> lgs(dev_setup ? cnt : 0);

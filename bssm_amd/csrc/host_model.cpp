@@ -705,6 +705,44 @@ bool psi_setup_begin(const HostModel& h, const double* is_mode, PsiSetup* out, L
   return true;
 }
 
+bool ung_pack(const HostModel& h, const double* is_mode, LgPacked* lg) {
+  if (!is_mode || !LgHostModel::applies(h) || h.gaussian()) return false;
+  const int n = h.n, m = h.m, k = h.k;
+  lg->n = n; lg->m = m;
+  lg->Zs = h.Ztv ? m : 0; lg->Ts = h.Ttv ? m * m : 0; lg->Rs = h.Rtv ? m * m : 0; lg->Ds = h.Dtv ? 1 : 0; lg->Cs = h.Ctv ? m : 0; lg->Hs = 1;
+  const int nR = h.Rtv ? n : 1;
+  const size_t nZ = (size_t)(h.Ztv ? n : 1) * m, nT = (size_t)(h.Ttv ? n : 1) * m * m, nRR = (size_t)nR * m * m;
+  const size_t nD = h.Dtv ? n : 1, nC = (size_t)(h.Ctv ? n : 1) * m;
+  size_t o = 0;
+  lg->oZ = o; o += nZ; lg->oT = o; o += nT; lg->oR = o; o += nRR; lg->oD = o; o += nD; lg->oC = o; o += nC;
+  lg->oy = o; o += n; lg->oH = lg->oy; lg->oa = o; o += m; lg->oP = o; o += (size_t)m * m;
+  lg->ou = o; o += n; lg->ox = o; o += n; lg->om = o; o += n; lg->oh = o; o += 2;
+  lg->buf.resize(o);
+  double* b = lg->buf.data();
+  std::memcpy(b + lg->oZ, h.Z.data(), nZ * sizeof(double));
+  std::memcpy(b + lg->oT, h.T.data(), nT * sizeof(double));
+  for (int t = 0; t < nR; t++) {  // R R' in LgHostModel's operation order
+    const double* R = h.R.data() + (size_t)m * k * t;
+    double* RR = b + lg->oR + (size_t)m * m * t;
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) {
+      double sacc = 0.0;
+      for (int q = 0; q < k; q++) sacc += R[i + m * q] * R[j + m * q];
+      RR[i + m * j] = sacc;
+    }
+  }
+  std::memcpy(b + lg->oD, h.D.data(), nD * sizeof(double));
+  std::memcpy(b + lg->oC, h.C.data(), nC * sizeof(double));
+  std::memcpy(b + lg->oy, h.y.data(), (size_t)n * sizeof(double));
+  std::memcpy(b + lg->oa, h.a1.data(), (size_t)m * sizeof(double));
+  std::memcpy(b + lg->oP, h.P1.data(), (size_t)m * m * sizeof(double));
+  std::memcpy(b + lg->ou, h.u.data(), (size_t)n * sizeof(double));
+  std::memcpy(b + lg->ox, h.xbeta.data(), (size_t)n * sizeof(double));
+  std::memcpy(b + lg->om, is_mode, (size_t)n * sizeof(double));
+  b[lg->oh] = (double)h.dist[0];
+  b[lg->oh + 1] = h.phis[0];
+  return true;
+}
+
 bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct) {
   const double* b = lg.buf.data();
   LgModel g;

@@ -65,12 +65,17 @@ struct LgPacked {
   int n = 0, m = 0;
   int Zs = 0, Ts = 0, Rs = 0, Ds = 0, Cs = 0, Hs = 0;            // strides in doubles, 0 = time-invariant
   size_t oZ = 0, oT = 0, oR = 0, oD = 0, oC = 0, oy = 0, oH = 0, oa = 0, oP = 0;  // offsets into buf
+  size_t ou = 0, ox = 0, om = 0, oh = 0;                          // ung_pack only: u, x'beta, stored mode, (distribution, phi)
   std::vector<double> buf;                                        // [Z | T | R R' | D | C | y - x'beta | H | a1 | P1]
   bool same_layout(const LgPacked& o) const {
     return n == o.n && m == o.m && Zs == o.Zs && Ts == o.Ts && Rs == o.Rs && Ds == o.Ds && Cs == o.Cs && Hs == o.Hs && buf.size() == o.buf.size();
   }
 };
 bool psi_setup_begin(const HostModel& hm, const double* is_mode, PsiSetup* out, LgPacked* lg);
+// The WHOLE psi set-up of an ssm_ung draw on the device (ung_setup_kernel: Laplace step at the stored mode, scales,
+// smoother, conditional factors, the filter's tables): the host only packs the draw -- [Z | T | R R' | D | C | y (raw) |
+// a1 | P1 | u | x'beta | mode | distribution, phi].  False when the fixed-size smoother does not apply.
+bool ung_pack(const HostModel& hm, const double* is_mode, LgPacked* lg);
 // host execution of the packed smoother (what the device kernel does per lane); false = non-finite result
 bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct);
 

@@ -142,6 +142,21 @@ struct FnSetupDev {
 };
 size_t fn_setup_scratch_doubles(int n, int m);
 hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream);
+// psi-APF set-up of ssm_ung draws (univariate observations) entirely on the device: Laplace step at the stored mode and
+// scales (approximate_for_is, src/model_ssm_ung.cpp:143-161, 241-292, 302-342), smoother + conditional factors, and the
+// filter's tables (what build_psi_tables / fill_obs_rows write on the host) -- one lane per draw.  `in` holds the packed
+// draws (ung_pack element order) DRAW-INTERLEAVED: element k of draw d at in[k * F + d].
+struct UngSetupDev {
+  int F, n, m;
+  int Zs, Ts, Rs, Ds, Cs;
+  size_t oZ, oT, oR, oD, oC, oy, oa, oP, ou, ox, om, oh;
+  const double* in;
+  double* scratch;           // draw-interleaved work arrays, ung_setup_scratch_doubles(n, m) * F doubles
+  double *mats, *obs, *init; // per-draw contiguous outputs, padded to MP = pad(m): [F][n][2 MP^2 + MP], [F][n][ROW_HDR + SER_HDR + MP], [F][MP + MP^2]
+  int* ok;
+};
+size_t ung_setup_scratch_doubles(int n, int m);
+hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream);
 hipError_t launch_transpose(const double* in, double* out, int rows, int cols, hipStream_t stream);
 hipError_t launch_calib_copy(const double* in, double* out, size_t n, hipStream_t stream);
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream);

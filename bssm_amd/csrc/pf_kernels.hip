@@ -335,6 +335,148 @@ hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream) {
   }
   return hipGetLastError();
 }
+// ---------------------------------------------------------------- psi set-up of ssm_ung draws, all of it on the device
+// What psi_setup_begin (laplace_iter + update_scales) + the smoother + build_psi_tables / fill_obs_rows do per draw on
+// the host (host_model.cpp), as one lane per draw.  Elementary functions are the device library's (not the filter
+// kernels' table-driven forms): the result is compared with the host set-up at 1e-12.
+size_t ung_setup_scratch_doubles(int n, int m) {
+  const size_t mm = (size_t)m * m, n1 = (size_t)n + 1;
+  //      ay  aH  ayraw scales  at       Pt        cc        K              v   Fs
+  return (size_t)4 * n + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n;
+}
+template <int M>
+__global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
+  const int d = blockIdx.x * 64 + threadIdx.x;
+  if (d >= b.F) return;
+  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+  const size_t F = (size_t)b.F;
+  const int n = b.n;
+  const double* in = b.in + d;
+  double* w = b.scratch + d;
+  double* ay = w;     w += (size_t)n * F;   // approximating y minus x'beta: what the smoother sees
+  double* aH = w;     w += (size_t)n * F;
+  double* ayr = w;    w += (size_t)n * F;   // approximating y
+  double* scl = w;    w += (size_t)n * F;
+  double* at = w;     w += (size_t)(n + 1) * M * F;
+  double* Pt = w;     w += (size_t)(n + 1) * MM * F;
+  double* cc = w;     w += (size_t)(n + 1) * MM * F;
+  double* K = w;      w += (size_t)n * M * F;
+  double* v = w;      w += (size_t)n * F;
+  double* Fs = w;
+  const int dist = (int)in[b.oh * F];
+  const double phi = in[(b.oh + 1) * F];
+  // ---- approximate_for_is: one Laplace step at the stored mode (src/model_ssm_ung.cpp:302-342) and the scales (:241-292)
+  for (int t = 0; t < n; t++) {
+    const double y = in[(b.oy + t) * F], sg = in[(b.om + t) * F], u = in[(b.ou + t) * F];
+    double HH = 0.0, yy = 0.0, sv = 0.0;
+    switch (dist) {
+      case DIST_SVM: {
+        double tmp = y;
+        if (fabs(tmp) < 1e-4) tmp = 1e-4;
+        HH = 2.0 * exp(sg) / ((tmp / phi) * (tmp / phi));
+        yy = sg + 1.0 - 0.5 * HH;
+        sv = -0.5 * (sg + (y / phi) * (y / phi) * exp(-sg));
+      } break;
+      case DIST_POISSON: HH = 1.0 / (exp(sg) * u); yy = y * HH + sg - 1.0; sv = y * sg - u * exp(sg); break;
+      case DIST_BINOMIAL: { const double e = exp(sg); HH = (1.0 + e) * (1.0 + e) / (u * e); yy = y * HH + sg - 1.0 - e; sv = y * sg - u * log1p(e); } break;
+      case DIST_NEGBIN: { const double e = exp(sg) * u; HH = (phi + e) * (phi + e) / (phi * e * (y + phi)); yy = sg + (phi + e) * (y - e) / ((y + phi) * e);
+                          sv = y * sg - (y + phi) * log(phi + u * exp(sg)); } break;
+      case DIST_GAMMA: { const double e = exp(sg) * u; HH = e / (y * phi); yy = sg - e / y + 1.0; sv = -phi * (sg + (y * exp(-sg) / u)); } break;
+      default: break;
+    }
+    const double sd = sqrt(HH);
+    const bool seen = y == y && fabs(y) <= 1.7976931348623157e308;
+    const double q = (yy - sg) / sd;
+    ay[(size_t)t * F] = yy - in[(b.ox + t) * F];
+    ayr[(size_t)t * F] = yy;
+    aH[(size_t)t * F] = sd;
+    scl[(size_t)t * F] = seen ? sv + 0.5 * q * q : 0.0;
+  }
+  LgModel g;
+  g.n = n;
+  g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
+  g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = ay; g.H = aH; g.Hs = 1;
+  g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
+  const bool ok = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F);  // at = alphahat, Pt = V_t^(1/2), cc = C_t after conditional_cov
+  b.ok[d] = ok ? 1 : 0;
+  // ---- tables: psi proposal operands (src/model_ssm_ung.cpp:585-586), observation rows, initial state (:543)
+  constexpr int MS = 2 * MP * MP + MP, OS = ROW_HDR + SER_HDR + MP;
+  double* __restrict__ mats = b.mats + (size_t)d * n * MS;
+  double* __restrict__ obs = b.obs + (size_t)d * n * OS;
+  double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
+  for (int t = 0; t < n; t++) {
+    double* mt = mats + (size_t)t * MS;
+    for (int q = 0; q < MS; q++) mt[q] = 0.0;
+    double ah0[M], ah1[M], Ct1[MM];
+#pragma unroll
+    for (int j = 0; j < M; j++) { ah0[j] = at[((size_t)t * M + j) * F]; ah1[j] = at[((size_t)(t + 1) * M + j) * F]; }
+#pragma unroll
+    for (int q = 0; q < MM; q++) Ct1[q] = cc[((size_t)(t + 1) * MM + q) * F];
+    if (ok) {
+#pragma unroll
+      for (int c = 0; c < M; c++)
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+          mt[j + MP * c] = Ct1[j + M * c];
+          mt[MP * MP + j + MP * c] = Pt[((size_t)(t + 1) * MM + j + M * c) * F];
+        }
+#pragma unroll
+      for (int j = 0; j < M; j++) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < M; c++) s += Ct1[j + M * c] * ah0[c];
+        mt[2 * MP * MP + j] = ah1[j] - s;
+      }
+    }
+    double* row = obs + (size_t)t * OS;
+    for (int q = 0; q < OS; q++) row[q] = 0.0;
+    double* ob = row + ROW_HDR;
+    const double y = in[(b.oy + t) * F], u = in[(b.ou + t) * F];
+    ob[OB_DIST] = (double)dist;
+    ob[OB_PHI] = phi;
+    const bool seen = y == y && fabs(y) <= 1.7976931348623157e308;
+    if (seen) {
+      ob[OB_FLAG] = 1.0; ob[OB_Y] = y; ob[OB_U] = u;
+      if (dist == DIST_SVM) {  // signal = first state; Z, D, x'beta are ignored (src/model_ssm_ung.cpp:456)
+        ob[SER_HDR] = 1.0;
+        ob[OB_AUX] = (y / phi) * (y / phi);
+      } else {
+        ob[OB_D] = in[(b.oD + (size_t)t * b.Ds) * F] + in[(b.ox + t) * F];
+#pragma unroll
+        for (int c = 0; c < M; c++) ob[SER_HDR + c] = in[(b.oZ + (size_t)t * b.Zs + c) * F];
+        ob[OB_AUX] = dist == DIST_NEGBIN ? y + phi : (dist == DIST_GAMMA ? y / u : 0.0);
+      }
+      ob[OB_PSIY] = ayr[(size_t)t * F];
+      ob[OB_PSIIH] = 1.0 / aH[(size_t)t * F];
+      row[RH_FLAG] = 1.0;
+      row[RH_SCALE] = scl[(size_t)t * F];
+    }
+  }
+  for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
+  if (ok) {
+#pragma unroll
+    for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
+#pragma unroll
+    for (int c = 0; c < M; c++)
+#pragma unroll
+      for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
+  }
+}
+hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream) {
+  const dim3 grid((b.F + 63) / 64), block(64);
+  switch (b.m) {
+    case 1: hipLaunchKernelGGL(ung_setup_kernel<1>, grid, block, 0, stream, b); break;
+    case 2: hipLaunchKernelGGL(ung_setup_kernel<2>, grid, block, 0, stream, b); break;
+    case 3: hipLaunchKernelGGL(ung_setup_kernel<3>, grid, block, 0, stream, b); break;
+    case 4: hipLaunchKernelGGL(ung_setup_kernel<4>, grid, block, 0, stream, b); break;
+    case 5: hipLaunchKernelGGL(ung_setup_kernel<5>, grid, block, 0, stream, b); break;
+    case 6: hipLaunchKernelGGL(ung_setup_kernel<6>, grid, block, 0, stream, b); break;
+    case 7: hipLaunchKernelGGL(ung_setup_kernel<7>, grid, block, 0, stream, b); break;
+    case 8: hipLaunchKernelGGL(ung_setup_kernel<8>, grid, block, 0, stream, b); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 // out[c * rows + r] = in[r * cols + c], 32 x 32 tiles through LDS (both sides coalesced): per-draw contiguous <->
 // draw-interleaved layouts of the smoother batch
 __global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ in, double* __restrict__ out, int rows, int cols) {

@@ -256,3 +256,71 @@ def test_multi_device_nlg_and_rccl_all_gather():
     assert rc["timing_ms"]["gather"] == "rccl_all_gather"
     assert np.array_equal(one["weights"], rc["weights"]) and np.array_equal(one["loglik"], rc["loglik"])
     assert np.array_equal(one["Vt"], rc["Vt"])
+
+
+def _ung_zoo(kind, rng, n=50):
+    """(model, theta draws) per model family / distribution for the full-device psi set-up (ung_setup_kernel)"""
+    ns = 70  # more than one wave of draws
+    if kind == "svm":
+        y = rng.normal(0, 1, n) * np.exp(0.5 * np.cumsum(rng.normal(0, 0.2, n))); y[3] = np.nan; y[10] = 0.0
+        model = M.svm(y, rho=M.uniform(0.9, -0.99, 0.99), sd_ar=M.halfnormal(0.2, 5), sigma=M.halfnormal(1.0, 2))
+        theta = np.column_stack([rng.uniform(0.8, 0.97, ns), rng.uniform(0.1, 0.4, ns), rng.uniform(0.7, 1.3, ns)])
+    elif kind == "ar1_negbin_xreg":
+        x = rng.normal(0, 1, (n, 2))
+        y = rng.negative_binomial(5, 0.5, n).astype(float); y[[0, 17]] = np.nan
+        model = M.ar1_ng(y, rho=M.uniform(0.7, -0.99, 0.99), sigma=M.halfnormal(0.3, 2), mu=M.normal(1.0, 0, 5),
+                         distribution="negative binomial", phi=M.gamma(4.0, 2, 0.5), u=rng.uniform(0.5, 2.0, n),
+                         beta=[M.normal(0.1, 0, 1), M.normal(-0.2, 0, 1)], xreg=x)
+        theta = np.column_stack([rng.uniform(0.5, 0.9, ns), rng.uniform(0.2, 0.5, ns), rng.normal(1.0, 0.1, ns),
+                                 rng.uniform(3, 6, ns), rng.normal(0.1, 0.05, ns), rng.normal(-0.2, 0.05, ns)])
+    elif kind == "bsm_gamma_seasonal":  # m = 2 + 3 = 5 states: padded to 8
+        y = rng.gamma(3.0, 2.0, n); y[5] = np.nan
+        model = M.bsm_ng(y, sd_level=M.halfnormal(0.1, 1), sd_slope=M.halfnormal(0.02, 1), sd_seasonal=M.halfnormal(0.05, 1),
+                         period=4, distribution="gamma", phi=M.gamma(3.0, 2, 0.5), u=rng.uniform(0.8, 1.2, n),
+                         P1=np.diag([1.0, 0.1, 0.5, 0.5, 0.5]), a1=np.array([1.5, 0, 0, 0, 0]))
+        theta = np.column_stack([rng.uniform(0.05, 0.2, ns), rng.uniform(0.01, 0.03, ns), rng.uniform(0.02, 0.08, ns), rng.uniform(2, 4, ns)])
+    else:  # bsm_binomial, local level + noise: m = 2... with sd_noise the state is (level, noise)
+        u = rng.integers(5, 20, n).astype(float)
+        y = rng.binomial(u.astype(int), 0.4).astype(float); y[8] = np.nan
+        model = M.bsm_ng(y, sd_level=M.halfnormal(0.2, 1), sd_noise=M.halfnormal(0.1, 1), distribution="binomial", u=u)
+        theta = np.column_stack([rng.uniform(0.1, 0.3, ns), rng.uniform(0.05, 0.2, ns)])
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    return model, theta, counts
+
+
+@pytest.mark.parametrize("kind", ["svm", "ar1_negbin_xreg", "bsm_gamma_seasonal", "bsm_binomial"])
+@pytest.mark.parametrize("output_type", [2, 3])
+def test_full_device_ung_setup_against_oracle(oracle, monkeypatch, kind, output_type):
+    """SURVEY.md 8f rank 1 for ssm_ung draws: the Laplace step at the stored mode, the scales, the smoother and the
+    filter's tables are built by ung_setup_kernel (the default); compared with the ORACLE's restatement
+    (src/model_ssm_ung.cpp:143-161, 241-342, 511-609) and with the product's host set-up."""
+    rng = np.random.default_rng(31)
+    model, theta, counts = _ung_zoo(kind, rng)
+    n = model.n
+    arrs = PC.expand_models(model, theta)
+    modes = np.stack([oracle.psi_setup(a)["mode"] for a in arrs], axis=1)
+    # perturb the stored modes: approximate_for_is takes whatever the chain stored, not the converged mode of this theta
+    modes = modes + rng.normal(0, 0.05, modes.shape)
+    mo = dict(theta=theta, counts=counts, modes=modes, output_type=output_type)
+    res = {}
+    for dev in ("2", "0"):
+        monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+        res[dev] = PC.post_correct(model, mo, 32, threads=2, is_type="is2", seed=6)
+    monkeypatch.delenv("BSSM_AMD_DEVICE_SETUP")
+    res["default"] = PC.post_correct(model, mo, 32, threads=2, is_type="is2", seed=6)
+    assert np.array_equal(res["default"]["loglik"], res["2"]["loglik"])  # the full-device set-up is the default
+    ref = oracle.is_correction(arrs, 32, 6, method=1, counts=counts, modes=modes, is_type=2, output_type=output_type, n_threads=2)
+    for dev in ("2", "0"):
+        assert np.all(np.isfinite(res[dev]["loglik"]))
+        assert np.allclose(res[dev]["loglik"], ref["loglik"], rtol=0, atol=1e-9 * n)
+        assert np.allclose(res[dev]["weights"], ref["weights"], rtol=1e-8)
+        if output_type == 2:
+            # (the seasonal model's smoothing covariances are singular: the factors amplify last-ulp differences between the
+            # oracle's generic matrix code and the fixed-size template to ~1e-8 of the state scale)
+            assert np.allclose(res[dev]["alphahat"], ref["alphahat"].T, rtol=1e-6, atol=1e-8)
+            assert np.allclose(res[dev]["Vt"], ref["Vt"], rtol=1e-6, atol=1e-8)
+    # device set-up vs host set-up: the same template and operation order (the device contracts to FMA, its exp / log differ
+    # from libm's in the last place, and near-singular factors amplify that: 1e-8 of the state scale at most)
+    assert np.allclose(res["2"]["loglik"], res["0"]["loglik"], rtol=0, atol=1e-10 * n)
+    if output_type == 2:
+        assert np.allclose(res["2"]["alphahat"], res["0"]["alphahat"], rtol=1e-7, atol=1e-9)
