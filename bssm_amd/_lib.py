@@ -30,7 +30,9 @@ class FnModel(C.Structure):
     _fields_ = [("model_id", C.c_int32), ("n", C.c_int32), ("y", c_double_p), ("theta", c_double_p), ("n_theta", C.c_int32),
                 ("known_params", c_double_p), ("n_known", C.c_int32), ("x0", C.c_double), ("positive", C.c_int32),
                 ("L", C.c_int32), ("user_slot", C.c_int32), ("n_states", C.c_int32), ("H", C.c_double),
-                ("R_diag", C.c_double * 2), ("a1", C.c_double * 2), ("P1", C.c_double * 4)]
+                ("R_diag", C.c_double * 2), ("a1", C.c_double * 2), ("P1", C.c_double * 4),
+                ("use_ext", C.c_int32), ("n_etas", C.c_int32), ("R_ext", C.c_double * 16), ("a1_ext", C.c_double * 4),
+                ("P1_ext", C.c_double * 16)]
 
 
 def pack_fn_model(model, L=None):
@@ -56,9 +58,19 @@ def fill_user_numbers(s, model, theta):
     m = int(s.n_states)
     val = lambda k: model[k](np.array(theta, dtype=float)) if callable(model[k]) else model[k]
     s.H = float(val("H"))
+    a1 = np.asarray(val("a1"), dtype=float).reshape(-1)[:m]
+    P1 = np.asarray(val("P1"), dtype=float).reshape(m, m)
+    if model.get("R") is not None or m > 2:  # any m x k matrix R, up to 4 states (bootstrap paths)
+        k = int(model.get("n_etas", m))
+        R = np.asarray(val("R"), dtype=float).reshape(m, k) if model.get("R") is not None else np.diag(np.asarray(val("R_diag"), dtype=float).reshape(-1)[:m])
+        s.use_ext, s.n_etas = 1, R.shape[1]
+        for j, v in enumerate(R.reshape(-1, order="F")): s.R_ext[j] = v
+        for j, v in enumerate(a1): s.a1_ext[j] = v
+        for j, v in enumerate(P1.reshape(-1, order="F")): s.P1_ext[j] = v
+        return
     for j, v in enumerate(np.asarray(val("R_diag"), dtype=float).reshape(-1)[:m]): s.R_diag[j] = v
-    for j, v in enumerate(np.asarray(val("a1"), dtype=float).reshape(-1)[:m]): s.a1[j] = v
-    for j, v in enumerate(np.asfortranarray(np.asarray(val("P1"), dtype=float).reshape(m, m)).reshape(-1, order="F")): s.P1[j] = v
+    for j, v in enumerate(a1): s.a1[j] = v
+    for j, v in enumerate(P1.reshape(-1, order="F")): s.P1[j] = v
 
 
 _user_slots = {}

@@ -639,9 +639,12 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   if (mod->n_theta < need_theta[id] || mod->n_known < need_known[id]) return fail(BSSM_ERR_INVALID, "theta / known_params too short for this model");
   if (mod->n_theta > 8 || mod->n_known > 8) return fail(BSSM_ERR_INVALID, "at most 8 theta / known_params");
   if (user && mod->user_slot < 1) return fail(BSSM_ERR_INVALID, "user-defined model without a loaded library (bssm_user_model_load)");
-  if (id == bssm::FN_USER_NLG && (mod->n_states < 1 || mod->n_states > 2)) return fail(BSSM_ERR_UNSUPPORTED, "user-defined ssm_nlg models: n_states must be 1 or 2");
+  if (id == bssm::FN_USER_NLG && (mod->n_states < 1 || mod->n_states > 4)) return fail(BSSM_ERR_UNSUPPORTED, "user-defined ssm_nlg models: n_states must be 1 ... 4");
+  if (id == bssm::FN_USER_NLG && mod->n_states > 2 && !mod->use_ext) return fail(BSSM_ERR_INVALID, "user-defined ssm_nlg model with more than 2 states: fill R_ext / a1_ext / P1_ext and set use_ext");
   if (id == bssm::FN_USER_NLG && !(mod->H > 0)) return fail(BSSM_ERR_INVALID, "user-defined ssm_nlg model: H must be positive");
-  const int m = id == bssm::FN_NLG_GROWTH ? 2 : (id == bssm::FN_USER_NLG ? mod->n_states : 1), MP = m;
+  const bool ext = id == bssm::FN_USER_NLG && mod->use_ext;
+  if (ext && (mod->n_etas < 1 || mod->n_etas > mod->n_states)) return fail(BSSM_ERR_INVALID, "user-defined ssm_nlg model: n_etas must be in 1 ... n_states");
+  const int m = id == bssm::FN_NLG_GROWTH ? 2 : (id == bssm::FN_USER_NLG ? mod->n_states : 1), MP = bssm::pad_dim(m);
   *m_out = m; *k_out = m;
   const double* th = mod->theta;
   const double* kp = mod->known_params;
@@ -661,16 +664,24 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
     case bssm::FN_SDE_GBM: H = th[2]; if (mod->L < 0 || mod->L > 20) return fail(BSSM_ERR_INVALID, "L must be in 0..20"); break;
     case bssm::FN_SDE_POISSON_OU: fp[bssm::FP_R] = std::exp(th[2]); if (mod->L < 0 || mod->L > 20) return fail(BSSM_ERR_INVALID, "L must be in 0..20"); break;
     case bssm::FN_USER_NLG:
-      for (int j = 0; j < m; j++) { a1[j] = mod->a1[j]; fp[bssm::FP_R + j] = mod->R_diag[j]; }
-      for (int q = 0; q < m * m; q++) P1[q] = mod->P1[q];
+      if (!ext) {
+        for (int j = 0; j < m; j++) { a1[j] = mod->a1[j]; fp[bssm::FP_R + j] = mod->R_diag[j]; }
+        for (int q = 0; q < m * m; q++) P1[q] = mod->P1[q];
+      }
       H = mod->H;
       break;
     case bssm::FN_USER_SDE: if (mod->L < 0 || mod->L > 20) return fail(BSSM_ERR_INVALID, "L must be in 0..20"); break;
   }
   fp[bssm::FP_SLOT] = user ? mod->user_slot : 0;
+  fp[bssm::FP_M] = m;
+  if (id == bssm::FN_USER_NLG) {  // full R, MP x MP column-major, zero-padded (the user-model kernels read this block)
+    if (ext) { for (int c = 0; c < mod->n_etas; c++) for (int j = 0; j < m; j++) fp[bssm::FP_RMAT + j + MP * c] = mod->R_ext[j + m * c]; }
+    else for (int j = 0; j < m; j++) fp[bssm::FP_RMAT + j + MP * j] = mod->R_diag[j];
+  }
   fp[bssm::FP_H] = H;
   fp[bssm::FP_LOGC] = -0.5 * (std::log(2.0 * 3.14159265358979323846) + 2.0 * std::log(H));
   if (params_only) {
+    if (ext) return fail(BSSM_ERR_UNSUPPORTED, "the psi-APF / EKF particle filter of a user model take R_diag / a1 / P1 (at most 2 states, constant diagonal R)");
     for (int j = 0; j < 2; j++) params_only[j] = a1[j];
     for (int q = 0; q < 4; q++) params_only[2 + q] = P1[q];
     return BSSM_OK;
@@ -691,6 +702,31 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   }
   // initial factor: psd_chol(P1) (src/model_ssm_nlg.cpp:1072); the shipped P1 are diagonal
   ft->init.assign((size_t)MP + (size_t)MP * MP, 0.0);
+  if (ext) {  // psd_chol of any P1 (src/psd_chol.cpp:5-18): Cholesky factor of the rows / columns with a non-zero diagonal
+    const double eps = 2.220446049250313e-16;
+    double dmax = mod->P1_ext[0];
+    for (int q = 1; q < m; q++) dmax = std::max(dmax, mod->P1_ext[q + m * q]);
+    const double thr = std::max(eps, eps * m * dmax);
+    bool nz[4];
+    double Lf[16] = {0};
+    for (int j = 0; j < m; j++) nz[j] = mod->P1_ext[j + m * j] > thr;
+    for (int j = 0; j < m; j++) {
+      ft->init[j] = mod->a1_ext[j];
+      if (!nz[j]) continue;
+      double d = mod->P1_ext[j + m * j];
+      for (int q = 0; q < j; q++) d -= Lf[j + 4 * q] * Lf[j + 4 * q];
+      if (!(d > 0)) return fail(BSSM_ERR_INVALID, "P1 is not positive semi-definite");
+      Lf[j + 4 * j] = std::sqrt(d);
+      for (int i = j + 1; i < m; i++) {
+        if (!nz[i]) continue;
+        double v = mod->P1_ext[i + m * j];
+        for (int q = 0; q < j; q++) v -= Lf[i + 4 * q] * Lf[j + 4 * q];
+        Lf[i + 4 * j] = v / Lf[j + 4 * j];
+      }
+    }
+    for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) ft->init[MP + j + MP * c] = Lf[j + 4 * c];
+    return BSSM_OK;
+  }
   if (id == bssm::FN_USER_NLG && m == 2 && (P1[1] != 0.0 || P1[2] != 0.0)) {  // a full 2 x 2 prior covariance
     const double thr = std::max(2.220446049250313e-16, 2.220446049250313e-16 * 2 * std::max(P1[0], P1[3]));
     ft->init[0] = a1[0]; ft->init[1] = a1[1];
@@ -725,9 +761,10 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f) {
   if (user) {
     if (mod->user_slot < 1 || mod->user_slot > 63) return fail(BSSM_ERR_INVALID, "user-defined model without a loaded library");
     const bssm::UserHostFns& h = g_user_host[mod->user_slot];
+    if (mod->n_states < 1 || mod->n_states > 2 || mod->use_ext)
+      return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: at most 2 states, constant diagonal R (R_diag, a1, P1 fields)");
     if (!h.T || !h.Z || !h.Tg || !h.Zg)
       return fail(BSSM_ERR_UNSUPPORTED, "this user model was compiled without BSSM_USER_JACOBIANS (bssm_user_Tg, bssm_user_Zg): the psi-APF and the EKF particle filter need them");
-    if (mod->n_states < 1 || mod->n_states > 2) return fail(BSSM_ERR_UNSUPPORTED, "user-defined ssm_nlg models: n_states must be 1 or 2");
     if (mod->n_states == 2 && (mod->P1[1] != 0.0 || mod->P1[2] != 0.0))
       return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: P1 must be diagonal");
     f->user = &h;
@@ -1080,7 +1117,7 @@ extern "C" {
 
 int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity) {
   if (!source || !lib_path || lib_path_capacity < 16) return fail(BSSM_ERR_INVALID, "NULL argument");
-  if (n_states < 1 || n_states > 2) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 or 2");
+  if (n_states < 1 || n_states > 4) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 ... 4");
   const std::string dir = library_dir();
   const char* env = std::getenv("BSSM_AMD_USER_CACHE");
   const std::string cache = env ? std::string(env) : dir + "/user_models";
@@ -1116,7 +1153,7 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   const std::string tmp = so + ".tmp." + std::to_string((long)getpid());  // several ranks may build the same model at once
   const char* hipcc = std::getenv("HIPCC");
   const std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I'" + dir +
-                          "/csrc' -DBSSM_USER_M=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet + "\"' '" + dir +
+                          "/csrc' -DBSSM_USER_M=" + std::to_string(bssm::pad_dim(n_states)) + " -DBSSM_USER_NSTATES=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet + "\"' '" + dir +
                           "/csrc/user_model_tu.hip' -o '" + tmp + "' > '" + log + "' 2>&1 && mv '" + tmp + "' '" + so + "'";
   if (std::system(cmd.c_str()) != 0) {
     std::string tail;

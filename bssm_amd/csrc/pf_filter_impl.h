@@ -172,13 +172,22 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
                                                   const double* __restrict__ row, const double* __restrict__ amat, int t,
                                                   const double (&x)[MP], const double (&aprev)[MP]) {
   if constexpr (FN) {
-    if (b.psi == 2) return functor_ekpf_weight<MP>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
-    return b.psi ? functor_psi_weight<MP>(fpar, row, amat, t, x, aprev) : functor_log_weight<MP>(fpar, row, x);
+    if constexpr (MP <= 2) {  // psi-APF / EKF particle filter: the shapes of the shipped models (the host refuses the others)
+      if (b.psi == 2) return functor_ekpf_weight<MP>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
+      if (b.psi) return functor_psi_weight<MP>(fpar, row, amat, t, x, aprev);
+    }
+    return functor_log_weight<MP>(fpar, row, x);
   } else {
     return log_weight_of<MP>(b, as_uniform_table(row), x);  // wave-uniform row: scalar loads (pf_device.h)
   }
 }
 
+// functor-model (FN) kernel shapes: the shipped models have 1 or 2 states; a run-time compiled user model may have up to 4
+#ifdef BSSM_USER_MODEL
+constexpr int FN_MP_MAX = 4;
+#else
+constexpr int FN_MP_MAX = 2;
+#endif
 constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the fp64 transcendental code
 // Particle i = r * NT + tid (r < PPT): consecutive lanes own consecutive particles, so LDS
 // accesses to the own slot are conflict-free and history stores are coalesced.
@@ -323,8 +332,8 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       double x[MP];
       if (FN && !b.psi) {
         if constexpr (FN) functor_propagate<MP, KP>(fpar, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
-      } else if (FN && b.psi == 2) {
-        if constexpr (FN) functor_ekpf_propagate<MP>(fpar, ob, t + 1 >= n, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
+      } else if (FN && MP <= 2 && b.psi == 2) {
+        if constexpr (FN && MP <= 2) functor_ekpf_propagate<MP>(fpar, ob, t + 1 >= n, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
       } else {
         double z[KP];
         rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
@@ -390,13 +399,14 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   }
 #endif
   if (b.fpar) {  // built-in non-linear / SDE functors: instantiated for the shapes the shipped models have
-    if constexpr (MP == KP && MP <= 2) {
+    if constexpr (MP == KP && MP <= FN_MP_MAX) {
       switch (ppt) {
         case 1: kern = pf_wg_kernel<MP, KP, 1, true>; break;
         case 2: kern = pf_wg_kernel<MP, KP, 2, true>; break;
         case 4: kern = pf_wg_kernel<MP, KP, 4, true>; break;
         case 8: kern = pf_wg_kernel<MP, KP, 8, true>; break;
-        default: kern = pf_wg_kernel<MP, KP, 16, true>; break;
+        default:
+          if constexpr (MP <= 2) kern = pf_wg_kernel<MP, KP, 16, true>; else return hipErrorInvalidValue;
       }
     } else {
       return hipErrorInvalidValue;
@@ -754,8 +764,8 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
         for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
         BSSM_STAMP(6)
         if constexpr (FN) {
-          if (b.psi == 2) {
-            functor_ekpf_propagate<MP>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
+          if (MP <= 2 && b.psi == 2) {
+            if constexpr (MP <= 2) functor_ekpf_propagate<MP>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
           } else if (b.psi) {
             double z[KP];
             rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
@@ -850,7 +860,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   if constexpr (MP == 4 && KP == 4) { if (ws.dbg && ppt == 1) kern = pf_grid_step<MP, KP, 1, true>; }
 #endif
   if (b.fpar) {
-    if constexpr (MP == KP && MP <= 2) {
+    if constexpr (MP == KP && MP <= FN_MP_MAX) {
       switch (ppt) {
         case 1: kern = pf_grid_step<MP, KP, 1, false, true>; break;
         case 2: kern = pf_grid_step<MP, KP, 2, false, true>; break;

@@ -26,10 +26,18 @@ __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || i
 //                  void bssm_user_Zg(alpha, theta, known, double* out /* m */);                                    Z_gn
 //   BSSM_USER_SDE: double bssm_user_drift(double x, const double* theta);  bssm_user_diffusion;  bssm_user_ddiffusion;
 //                  double bssm_user_log_obs(double y, double x, const double* theta);   normalised log-density of y | x
-// H (observation sd), the diagonal of R, a1 and P1 are state-independent numbers the caller passes with the model.
-// per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser, user slot
+// H (observation sd), R, a1 and P1 are state-independent numbers the caller passes with the model -- unless the snippet
+// supplies the reference's state-dependent H_fn / R_fn (src/model_ssm_nlg.h:12-13; evaluated at the particle for the
+// observation density and at the ANCESTOR for the transition, src/model_ssm_nlg.cpp:952, 1125):
+//   BSSM_USER_HFN: double bssm_user_H(const double* alpha, const double* theta, const double* known);   observation sd
+//   BSSM_USER_RFN: void bssm_user_R(alpha, theta, known, double* out /* m x k, column-major */);         R_fn
+// The state may have up to 4 components (BSSM_USER_M = 1, 2 or 4 is the padded dimension the kernels are instantiated
+// for; a 3-state model leaves the fourth component alone) and R any m x k matrix, k <= m (bootstrap filter / smoother /
+// bootstrap IS correction; the psi-APF and the EKF particle filter stay limited to 2 states and constant diagonal R).
+// per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser,
+// user slot, number of states, full R (MP x MP, column-major, zero-padded; user models)
 enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, FP_H = 20, FP_R = 21, FP_LOGC = 23, FP_SLOT = 24 /* user-model registry slot (host only) */,
-       FP_SIZE = 26 };
+       FP_M = 25, FP_RMAT = 26, FP_SIZE = 42 };
 
 // ---- ssm_nlg: alpha_{t+1} = T(alpha_t) + R eta,  y_t ~ N(Z(alpha_t), H^2)   (src/model_ssm_nlg.cpp:1118-1126, 943-956)
 template <int MP>
@@ -161,6 +169,37 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
   } else {
     double z[KP];
     rng_normals_blk<KP>(blk0, key, RNG_TRANSITION, t, i, z);  // blk0 = the step block
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
+    if (id == FN_USER_NLG) {  // alpha' = T(a) + R(a) eta with any m x k matrix R (src/model_ssm_nlg.cpp:1118-1126)
+#pragma unroll
+      for (int j = 0; j < MP; j++) x[j] = 0.0;
+      bssm_user_T(&a[0], fp + FP_THETA, fp + FP_KNOWN, &x[0]);
+      double Rm[MP * MP];
+#pragma unroll
+      for (int q = 0; q < MP * MP; q++) Rm[q] = fp[FP_RMAT + q];
+#ifdef BSSM_USER_RFN
+      {
+        constexpr int mu = BSSM_USER_NSTATES <= MP ? BSSM_USER_NSTATES : MP;  // states of the user's model (3 pads to MP = 4)
+        double Ru[MP * MP];
+#pragma unroll
+        for (int q = 0; q < MP * MP; q++) Ru[q] = 0.0;
+        bssm_user_R(&a[0], fp + FP_THETA, fp + FP_KNOWN, &Ru[0]);  // m x k, column-major with leading dimension m
+#pragma unroll
+        for (int c = 0; c < MP; c++)
+#pragma unroll
+          for (int j = 0; j < MP; j++) Rm[j + MP * c] = j < mu ? Ru[j + mu * c] : 0.0;  // columns >= k were left zero
+      }
+#endif
+#pragma unroll
+      for (int j = 0; j < MP; j++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < KP; c++) acc += Rm[j + MP * c] * z[c];
+        x[j] += acc;
+      }
+      return;
+    }
+#endif
     nlg_T_fn<MP>(id, fp, a, x);
 #pragma unroll
     for (int j = 0; j < MP; j++) if (j < KP) x[j] += fp[FP_R + j] * z[j];  // R is diagonal in every shipped model
@@ -181,6 +220,13 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
     return y * x[0] - tl_exp(x[0]) - ob[OB_AUX];
   }
   // normalised Gaussian log-density (dmvnorm(..., lwr = true, logd = true), src/dmvnorm.cpp:10-13)
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_HFN)
+  if (id == FN_USER_NLG) {  // H_fn at the particle (src/model_ssm_nlg.cpp:950-953)
+    const double h = bssm_user_H(&x[0], fp + FP_THETA, fp + FP_KNOWN);
+    const double q = (y - bssm_user_Z(&x[0], fp + FP_THETA, fp + FP_KNOWN)) / h;
+    return -0.9189385332046727 - tl_log(h) - 0.5 * q * q;  // -0.5 log(2 pi) - log h - q^2 / 2
+  }
+#endif
   const double mu = id == FN_SDE_GBM ? tl_log(x[0]) : nlg_Z_fn<MP>(id, fp, x);
   const double q = (y - mu) / fp[FP_H];
   return fp[FP_LOGC] - 0.5 * q * q;

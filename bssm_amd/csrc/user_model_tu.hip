@@ -3,7 +3,7 @@
 // bssm's ssm_nlg / ssm_sde models are user C++ compiled at run time (Rcpp::sourceCpp) and called through function
 // pointers (src/model_ssm_nlg.h:10-21, src/model_ssm_sde.h:8-11).  Device code cannot call host pointers, so here the
 // user's snippet of __device__ functions is compiled INTO the filter kernels: bssm_user_model_build() (api.cpp) runs
-//   hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I<csrc> -DBSSM_USER_M=<m> -DBSSM_USER_SNIPPET='"<file>"'
+//   hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I<csrc> -DBSSM_USER_M=<pad(m)> -DBSSM_USER_NSTATES=<m> -DBSSM_USER_SNIPPET='"<file>"'
 //         user_model_tu.hip -o libbssm_user_<hash>.so
 // and registers the two launchers below.  The snippet's contract is documented in pf_functors.h.
 #include <hip/hip_runtime.h>
@@ -14,11 +14,14 @@
 #define BSSM_FN __host__ __device__ inline   // every user function is needed on the device (kernels) and on the host (psi / EKF set-up)
 #include BSSM_USER_SNIPPET
 
-#include "pf_filter_impl.h"
-
 #ifndef BSSM_USER_M
-#error "BSSM_USER_M (state dimension: 1 or 2) must be defined"
+#error "BSSM_USER_M (padded state dimension: 1, 2 or 4) must be defined"
 #endif
+#ifndef BSSM_USER_NSTATES
+#define BSSM_USER_NSTATES BSSM_USER_M   // states of the model (3 runs in the kernels padded to 4)
+#endif
+
+#include "pf_filter_impl.h"
 
 extern "C" hipError_t bssm_user_launch_wg(const bssm::FilterBatch* b, hipStream_t stream) {
   bssm::FilterBatch local = *b;
@@ -36,6 +39,12 @@ extern "C" hipError_t bssm_user_launch_grid(const bssm::FilterBatch* b, const bs
 #ifdef BSSM_USER_NLG
 extern "C" void bssm_user_host_T(const double* a, const double* th, const double* kn, double* out) { bssm_user_T(a, th, kn, out); }
 extern "C" double bssm_user_host_Z(const double* a, const double* th, const double* kn) { return bssm_user_Z(a, th, kn); }
+#ifdef BSSM_USER_HFN
+extern "C" double bssm_user_host_H(const double* a, const double* th, const double* kn) { return bssm_user_H(a, th, kn); }
+#endif
+#ifdef BSSM_USER_RFN
+extern "C" void bssm_user_host_R(const double* a, const double* th, const double* kn, double* out) { bssm_user_R(a, th, kn, out); }
+#endif
 #ifdef BSSM_USER_JACOBIANS
 extern "C" void bssm_user_host_Tg(const double* a, const double* th, const double* kn, double* out) { bssm_user_Tg(a, th, kn, out); }
 extern "C" void bssm_user_host_Zg(const double* a, const double* th, const double* kn, double* out) { bssm_user_Zg(a, th, kn, out); }

@@ -377,7 +377,7 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
     job = McmcJob()
     job.n_par = d
     job.prior_fn = _PRIOR_FN(_prior)
-    if int(model.get("model_id", 0)) == 7 and any(callable(model.get(k)) for k in ("H", "R_diag", "a1", "P1")):
+    if int(model.get("model_id", 0)) == 7 and any(callable(model.get(k)) for k in ("H", "R_diag", "R", "a1", "P1")):
         FN_UPDATE = C.CFUNCTYPE(C.c_int, _lib.c_double_p, C.c_int32, C.POINTER(_lib.FnModel), C.c_void_p)
 
         def _fn_update(th_p, n_par, mod_p, _user):

@@ -568,25 +568,34 @@ def ssm_sde(y, example: str, theta, x0, positive: bool):
                      positive=bool(positive), a1=np.zeros(1), L=0)
 
 
-def ssm_nlg_user(y, device_code: str, theta, a1, P1, H, R_diag, known_params=(), n_states=None):
+def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_params=(), n_states=None, R=None):
     """ssm_nlg (R/models.R:1472-1570) with USER functions.  The reference takes pointers to user C++ compiled at run time
     (Z, H, T, R, Z_gn, T_gn, a1, P1); here ``device_code`` is a snippet of ``__device__`` functions compiled by hipcc into
     the filter kernels (contract: bssm_amd/csrc/pf_functors.h -- ``#define BSSM_USER_NLG 1``, ``bssm_user_T``,
     ``bssm_user_Z``), and the state-independent pieces are numbers: H (observation sd), the diagonal of R, a1, P1.
     With the Jacobians in the snippet (``BSSM_USER_JACOBIANS``, ``bssm_user_Tg``, ``bssm_user_Zg``) the psi-APF and the
-    EKF particle filter work as for the built-in models."""
+    EKF particle filter work as for the built-in models (1 or 2 states, diagonal R).
+    The bootstrap filter / smoother also take up to 4 states, any ``R`` (n_states x n_etas matrix, or a function of theta)
+    and the reference's state-dependent ``H_fn`` / ``R_fn`` as snippet functions (``BSSM_USER_HFN`` + ``bssm_user_H``,
+    ``BSSM_USER_RFN`` + ``bssm_user_R``; src/model_ssm_nlg.h:12-13), which then replace ``H`` / ``R``."""
     y = _f(np.asarray(y, dtype=float).reshape(-1))
     theta = np.asarray(theta, dtype=float)
     m = int(n_states or np.asarray(a1(theta) if callable(a1) else a1, dtype=float).size)
-    if m not in (1, 2):
-        raise ValueError("user-defined ssm_nlg models: n_states must be 1 or 2")
+    if m not in (1, 2, 3, 4):
+        raise ValueError("user-defined ssm_nlg models: n_states must be 1 ... 4")
+    if R is None and R_diag is None:
+        if "BSSM_USER_RFN" not in device_code:
+            raise ValueError("give R_diag, R, or a snippet with BSSM_USER_RFN / bssm_user_R")
+        R_diag = np.zeros(m)
+    k = m if R is None else int(np.asarray(R(theta) if callable(R) else R, dtype=float).reshape(m, -1).shape[1])
     # H, R_diag, a1, P1 may be functions of theta (as the reference's H_fn / R_fn / a1_fn / P1_fn are): post_correct and
     # run_mcmc then evaluate them for every theta
     num = lambda v, shape: v if callable(v) else np.asarray(v, dtype=float).reshape(shape)
     return BssmModel(("ssm_nlg", "bssm_model"), y=y, model_id=7, example="user", user_source=str(device_code),
                      theta=theta, known_params=np.asarray(known_params, dtype=float),
-                     n_states=m, n_etas=m, a1=num(a1, -1), P1=num(P1, (m, m)), H=H if callable(H) else float(H),
-                     R_diag=num(R_diag, -1), x0=0.0, positive=False, L=0)
+                     n_states=m, n_etas=k, a1=num(a1, -1), P1=num(P1, (m, m)), H=H if callable(H) else float(H),
+                     R_diag=None if R_diag is None else num(R_diag, -1), R=None if R is None else num(R, (m, k)),
+                     x0=0.0, positive=False, L=0)
 
 
 def ssm_sde_user(y, device_code: str, theta, x0, positive: bool):

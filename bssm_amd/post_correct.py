@@ -215,7 +215,7 @@ def _run_local_block_nlg(model, theta, modes, counts, first, n_stored, nsim, see
     raw[:] = np.frombuffer(bytes(s0), dtype=np.uint8)
     off = _lib.FnModel.theta.offset
     raw[:, off:off + 8].view(np.uint64)[:, 0] = theta.ctypes.data + np.arange(cnt, dtype=np.uint64) * np.uint64(theta.strides[0])
-    if int(s0.model_id) == 7 and any(callable(model.get(k)) for k in ("H", "R_diag", "a1", "P1")):
+    if int(s0.model_id) == 7 and any(callable(model.get(k)) for k in ("H", "R_diag", "R", "a1", "P1")):
         for i in range(cnt):  # user-defined model with theta-dependent H / R / a1 / P1 (src/model_ssm_nlg.h:10-21)
             _lib.fill_user_numbers(models[i], model, theta[i])
     modes_c = None if modes is None else np.asfortranarray(modes, dtype=np.float64)

@@ -172,21 +172,30 @@ typedef struct bssm_fn_model {
   int32_t L;                  /* ssm_sde: 2^L Milstein sub-steps per unit time */
   /* ---- user-defined models only (model_id BSSM_FN_USER_NLG / BSSM_FN_USER_SDE); ignored for the built-in ids */
   int32_t user_slot;          /* from bssm_user_model_load */
-  int32_t n_states;           /* ssm_nlg: 1 or 2 (= n_etas; R is diagonal) */
-  double H;                   /* ssm_nlg: observation sd (the value H_fn returns) */
-  double R_diag[2];           /* ssm_nlg: diagonal of R_fn's value */
-  double a1[2], P1[4];        /* ssm_nlg: a1_fn, P1_fn values (P1 column-major, n_states x n_states) */
+  int32_t n_states;           /* ssm_nlg: 1 ... 4 (psi-APF / EKF particle filter: 1 or 2) */
+  double H;                   /* ssm_nlg: observation sd (the value H_fn returns; unused when the snippet defines BSSM_USER_HFN) */
+  double R_diag[2];           /* ssm_nlg: diagonal of R_fn's value (n_states <= 2, diagonal R) */
+  double a1[2], P1[4];        /* ssm_nlg: a1_fn, P1_fn values (P1 column-major, n_states x n_states), n_states <= 2 */
+  /* ---- wider user-defined ssm_nlg models (src/model_ssm_nlg.h:10-21 allows any m, k and matrix R): read instead of
+   * R_diag / a1 / P1 when use_ext != 0; required for n_states > 2 */
+  int32_t use_ext;
+  int32_t n_etas;             /* columns of R, 1 ... n_states */
+  double R_ext[16];           /* R_fn's value, n_states x n_etas column-major (the bootstrap kernels call the snippet's
+                                 bssm_user_R instead when it defines BSSM_USER_RFN) */
+  double a1_ext[4], P1_ext[16]; /* a1_fn, P1_fn values; P1 any positive semi-definite n_states x n_states matrix */
 } bssm_fn_model;
 
 /* User-defined ssm_nlg / ssm_sde models.  The reference compiles the user's C++ at run time (Rcpp::sourceCpp) and
  * calls it through function pointers (src/model_ssm_nlg.h:10-21, src/model_ssm_sde.h:8-11); device code cannot call host
  * pointers, so the user's __device__ functions (contract: bssm_amd/csrc/pf_functors.h) are compiled by hipcc INTO the
  * filter kernels, one shared library per snippet, cached by content hash next to libbssm_amd.so (or in
- * $BSSM_AMD_USER_CACHE).  bssm_user_model_build compiles `source` for `n_states` (1 or 2) and writes the library path;
+ * $BSSM_AMD_USER_CACHE).  bssm_user_model_build compiles `source` for `n_states` (1 ... 4) and writes the library path;
  * bssm_user_model_load maps it and returns a slot >= 1 for bssm_fn_model.user_slot (negative = error).
  * Built for user models: every single-model entry point of the built-in models -- bootstrap, psi-APF (bssm_psi_smoother_nlg,
  * bssm_fn_psi_setup) and EKF particle filter (bssm_ekpf_*) with their smoothers and bssm_fn_loglik_batch; the psi-APF and
- * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS) and a diagonal P1.  IS post-correction
+ * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS), a diagonal P1, at most 2 states and a constant
+ * diagonal R.  The bootstrap filter / smoother / bootstrap IS correction take up to 4 states, any n_states x n_etas matrix
+ * R and the reference's state-dependent H_fn / R_fn (snippet functions bssm_user_H / bssm_user_R).  IS post-correction
  * (bssm_is_correction_nlg / _multi) and the chains (bssm_run_mcmc_fn; theta-dependent H / R / a1 / P1 through
  * bssm_mcmc_job.fn_update_fn) work for user models too. */
 int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity);

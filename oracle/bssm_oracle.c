@@ -1471,6 +1471,54 @@ done:
 }
 
 
+/* ------------------------------------------------------------------ */
+/* ssm_nlg::bsf_filter for ANY model behind function pointers -- the reference's own interface (src/model_ssm_nlg.h:10-21:
+ * Z_fn, H_fn, T_fn, R_fn take (t, alpha, theta, known_params); H and R may depend on the state) -- restating
+ * src/model_ssm_nlg.cpp:1066-1146 with log_obs_density (:943-956) for one observation series.  m <= ORC_MAXM, k <= m. */
+double orc_nlg_general_bsf_filter(const orc_nlg_general *mod, unsigned N, const orc_rng *rng, double *alpha, double *weights,
+                                  unsigned *indices) {
+  const int n = mod->n, m = mod->m, k = mod->k;
+  double L[ORC_MAXM * ORC_MAXM], um[ORC_MAXM], x[ORC_MAXM], Rm[ORC_MAXM * ORC_MAXM];
+  double *nw = (double *)malloc(sizeof(double) * N), *lw = (double *)malloc(sizeof(double) * N);
+  double *r = (double *)malloc(sizeof(double) * N), *atmp = (double *)malloc(sizeof(double) * N * m);
+  orc_psd_chol(mod->P1, m, L); /* :1071 */
+  for (unsigned i = 0; i < N; i++) {
+    rng_normals(rng, 0, 0, i, m, um);
+    for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += L[j + m * c] * um[c]; A_(j, 0, i) = mod->a1[j] + s; }
+  }
+  double loglik = 0.0, inc;
+#define NLG_LOG_OBS(t_, xp_, out_) do { double z_, h_; mod->Z_fn((t_), (xp_), mod->theta, mod->known, &z_); \
+    mod->H_fn((t_), (xp_), mod->theta, mod->known, &h_); \
+    (out_) = -0.5 * (log(2.0 * ORC_PI) + 2.0 * log(h_) + pow((mod->y[t_] - z_) / h_, 2)); } while (0) /* dmvnorm.cpp:10-13 (lwr) */
+  if (isfinite(mod->y[0])) {
+    for (unsigned i = 0; i < N; i++) NLG_LOG_OBS(0, &A_(0, 0, i), lw[i]);
+    if (!normalise_step(lw, N, weights, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+    loglik = inc;
+  } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
+  for (int t = 0; t < n; t++) {
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
+    for (unsigned i = 0; i < N; i++) { /* :1118-1126: T_fn and R_fn at the ancestor */
+      rng_normals(rng, 2, t, i, k, um);
+      mod->T_fn(t, atmp + (size_t)m * i, mod->theta, mod->known, x);
+      mod->R_fn(t, atmp + (size_t)m * i, mod->theta, mod->known, Rm);
+      for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < k; c++) s += Rm[j + m * c] * um[c]; A_(j, t + 1, i) = x[j] + s; }
+    }
+    double *wcol = weights + (size_t)N * (t + 1);
+    if ((t < n - 1) && isfinite(mod->y[t + 1])) {
+      for (unsigned i = 0; i < N; i++) NLG_LOG_OBS(t + 1, &A_(0, t + 1, i), lw[i]);
+      if (!normalise_step(lw, N, wcol, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+      loglik += inc;
+    } else for (unsigned i = 0; i < N; i++) { wcol[i] = 1.0; nw[i] = 1.0 / N; }
+  }
+#undef NLG_LOG_OBS
+done:
+  free(nw); free(lw); free(r); free(atmp);
+  return loglik;
+}
+
+
 /* ================================================================== */
 /* ssm_nlg psi-APF                                                     */
 /* ================================================================== */

@@ -404,6 +404,42 @@ def fn_bsf_filter(model: dict, nsim: int, seed=1, stream=0):
     return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices)
 
 
+_NLG_FN = C.CFUNCTYPE(None, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p)
+
+
+class OrcNlgGeneral(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("k", C.c_int), ("y", c_double_p), ("theta", c_double_p), ("known", c_double_p),
+                ("a1", c_double_p), ("P1", c_double_p), ("Z_fn", _NLG_FN), ("H_fn", _NLG_FN), ("T_fn", _NLG_FN), ("R_fn", _NLG_FN)]
+
+
+def nlg_general_bsf_filter(y, m, k, theta, known, a1, P1, Z_fn, H_fn, T_fn, R_fn, nsim: int, seed=1, stream=0):
+    """ssm_nlg::bsf_filter (src/model_ssm_nlg.cpp:1066-1146) for a model given as Python functions of
+    (t, alpha, theta, known) -- the reference's function-pointer interface (src/model_ssm_nlg.h:10-21): Z_fn and H_fn
+    (observation sd) return scalars, T_fn an m-vector, R_fn an m x k matrix; H and R may depend on the state."""
+    L = lib()
+    L.orc_nlg_general_bsf_filter.restype = C.c_double
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    th = np.ascontiguousarray(theta, dtype=np.float64); kn = np.ascontiguousarray(known if len(known) else [0.0], dtype=np.float64)
+    a1 = np.ascontiguousarray(a1, dtype=np.float64); P1 = np.asfortranarray(np.asarray(P1, dtype=np.float64).reshape(m, m))
+    nth, nkn = th.size, kn.size
+
+    def wrap(fn, cnt, mat=False):
+        def cb(t, al, thp, knp, out):
+            v = fn(t, np.ctypeslib.as_array(al, (m,)).copy(), np.ctypeslib.as_array(thp, (nth,)), np.ctypeslib.as_array(knp, (nkn,)))
+            v = np.asarray(v, dtype=float)
+            v = v.reshape(m, k).reshape(-1, order="F") if mat else v.reshape(-1)
+            for q in range(cnt): out[q] = v[q]
+        return _NLG_FN(cb)
+    cbs = [wrap(Z_fn, 1), wrap(H_fn, 1), wrap(T_fn, m), wrap(R_fn, m * k, True)]
+    s = OrcNlgGeneral(y.size, m, k, _p(y), _p(th), _p(kn), _p(a1), _p(P1), *cbs)
+    rng, _ = make_rng(seed, stream)
+    n = y.size
+    alpha = np.zeros((m, n + 1, nsim), order="F"); weights = np.zeros((nsim, n + 1), order="F")
+    indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+    ll = L.orc_nlg_general_bsf_filter(C.byref(s), C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights), indices.ctypes.data_as(c_uint_p))
+    return dict(logLik=float(ll), alpha=alpha, weights=weights, indices=indices)
+
+
 class OrcFnSetup(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("Z", c_double_p), ("T", c_double_p), ("D", c_double_p), ("C", c_double_p),
                 ("H", C.c_double), ("R", C.c_double * 4), ("mode", c_double_p), ("scales", c_double_p),

@@ -16,7 +16,7 @@
  * identity from attributes of the first pointer argument, which the R constructor attaches:
  *   attr(Z, "bssm_amd_model_id")     integer, BSSM_FN_* (the shipped example models are built in), or
  *   attr(Z, "bssm_amd_device_code")  character, the user's __device__ functions (contract: bssm_amd/csrc/pf_functors.h),
- *                                    with numeric attributes "bssm_amd_H", "bssm_amd_R_diag", "bssm_amd_a1", "bssm_amd_P1".
+ *                                    with numeric attributes "bssm_amd_H", "bssm_amd_R_diag" (or the matrix "bssm_amd_R"), "bssm_amd_a1", "bssm_amd_P1".
  * Link: PKG_LIBS = -L$(BSSM_AMD) -lbssm_amd -Wl,-rpath,$(BSSM_AMD)
  */
 #include <R.h>
@@ -583,6 +583,15 @@ static void fn_identity(SEXP first_ptr, int n_states, int sde, bssm_fn_model* f)
     read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_R_diag")), f->R_diag, 2);
     read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_a1")), f->a1, 2);
     read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_P1")), f->P1, 4);
+    /* wider models (up to 4 states, any n_states x n_etas matrix R; bootstrap paths): attr "bssm_amd_R" = R_fn's value */
+    SEXP Rm = Rf_getAttrib(first_ptr, Rf_install("bssm_amd_R"));
+    if (Rm != R_NilValue || n_states > 2) {
+      f->use_ext = 1;
+      f->n_etas = Rm != R_NilValue ? Rf_length(Rm) / n_states : n_states;
+      read_numbers(Rm, f->R_ext, 16);
+      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_a1")), f->a1_ext, 4);
+      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_P1")), f->P1_ext, 16);
+    }
   }
 }
 /* the 16 leading arguments every ssm_nlg stub shares (src/R_bootstrap_filter.cpp:461-466) */

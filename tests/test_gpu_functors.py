@@ -283,3 +283,91 @@ def test_user_model_with_theta_dependent_numbers_in_post_correct_and_run_mcmc(or
     mb = mcmc.run_mcmc(b, 40, particles=32, burnin=10, mcmc_type="pm", sampling_method="bsf", output_type="theta", seed=3)
     mu = mcmc.run_mcmc(u, 40, particles=32, burnin=10, mcmc_type="pm", sampling_method="bsf", output_type="theta", seed=3)
     assert np.array_equal(mb["counts"], mu["counts"]) and np.allclose(mb["theta"], mu["theta"], rtol=1e-9, atol=1e-11)
+
+
+# A three-state, two-noise model with state-dependent H_fn and R_fn (src/model_ssm_nlg.h:10-21 allows any m, k and
+# state-dependent H / R): stochastic-volatility-like level + log-scale + damped slope
+#   T(a) = (a0 + a2, th0 + th1 (a1 - th0), th2 a2),   R(a) = [[exp(a1 / 2) th3, 0], [0, th4], [0.3 exp(a1 / 2) th3, th5]],
+#   Z(a) = a0 + 0.1 a0^2 / (1 + a0^2),   H(a) = kn0 (1 + 0.5 / (1 + a0^2))
+USER_WIDE3 = r"""
+#define BSSM_USER_NLG 1
+#define BSSM_USER_HFN 1
+#define BSSM_USER_RFN 1
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  out[0] = a[0] + a[2]; out[1] = th[0] + th[1] * (a[1] - th[0]); out[2] = th[2] * a[2];
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + 0.1 * a[0] * a[0] / (1.0 + a[0] * a[0]); }
+BSSM_FN double bssm_user_H(const double* a, const double* th, const double* kn) { return kn[0] * (1.0 + 0.5 / (1.0 + a[0] * a[0])); }
+BSSM_FN void bssm_user_R(const double* a, const double* th, const double* kn, double* out) {
+  const double s = exp(0.5 * a[1]) * th[3];
+  out[0] = s; out[1] = 0.0; out[2] = 0.3 * s;        /* first column */
+  out[3] = 0.0; out[4] = th[4]; out[5] = th[5];      /* second column */
+}
+"""
+
+
+def _wide3_python():
+    Z = lambda t, a, th, kn: a[0] + 0.1 * a[0] ** 2 / (1.0 + a[0] ** 2)
+    H = lambda t, a, th, kn: kn[0] * (1.0 + 0.5 / (1.0 + a[0] ** 2))
+    T = lambda t, a, th, kn: np.array([a[0] + a[2], th[0] + th[1] * (a[1] - th[0]), th[2] * a[2]])
+    def R(t, a, th, kn):
+        s = np.exp(0.5 * a[1]) * th[3]
+        return np.array([[s, 0.0], [0.0, th[4]], [0.3 * s, th[5]]])
+    return Z, H, T, R
+
+
+@pytest.mark.parametrize("path,N", [("wg", 300), ("wg", 1500), ("grid", 5000)])
+def test_user_model_three_states_state_dependent_H_and_R(oracle, monkeypatch, path, N):
+    """bootstrap filter of a user model with 3 states, a 3 x 2 matrix R_fn and state-dependent H_fn / R_fn against the
+    oracle's restatement of ssm_nlg::bsf_filter for function-pointer models (src/model_ssm_nlg.cpp:1066-1146)"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    rng = np.random.default_rng(8)
+    n = 25
+    th = np.array([-1.0, 0.9, 0.8, 0.5, 0.2, 0.05]); kn = np.array([0.7])
+    Z, H, T, R = _wide3_python()
+    a = np.array([0.5, -1.0, 0.1]); y = np.zeros(n)
+    for t in range(n):
+        y[t] = Z(t, a, th, kn) + H(t, a, th, kn) * rng.normal()
+        a = T(t, a, th, kn) + R(t, a, th, kn) @ rng.normal(size=2)
+    y[6] = np.nan
+    a1 = np.array([0.5, -1.0, 0.0]); P1 = np.array([[1.0, 0.2, 0.0], [0.2, 0.5, 0.0], [0.0, 0.0, 0.0]])  # singular: psd_chol drops the third state
+    u = M.ssm_nlg_user(y, USER_WIDE3, theta=th, known_params=kn, a1=a1, P1=P1, n_states=3,
+                       R=np.zeros((3, 2)))  # (R only sets n_etas here: the kernels call bssm_user_R)
+    out = F.bootstrap_filter(u, N, seed=5, return_indices=True)
+    ref = oracle.nlg_general_bsf_filter(y, 3, 2, th, kn, a1, P1, Z, H, T, R, N, seed=5)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    sm = F.particle_smoother(u, N, method="bsf", seed=5)
+    assert abs(sm["logLik"] - ref["logLik"]) <= 1e-9 * n
+    ah, Vt = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert _rel(sm["alphahat"], ah.T[:n]) <= 1e-8 and _rel(sm["Vt"], Vt[:, :, :n]) <= 1e-7
+    # the psi-APF / EKF particle filter refuse what they are not built for (more than 2 states, matrix R)
+    with pytest.raises(Exception, match="at most 2 states"):
+        F.particle_smoother(u, 50, method="psi", seed=1)
+
+
+def test_user_model_constant_matrix_R_four_states(oracle):
+    """4 states, constant 4 x 3 matrix R and constant H passed as numbers (no snippet R / H functions)"""
+    code = r"""
+#define BSSM_USER_NLG 1
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  out[0] = a[0] + a[1]; out[1] = th[0] * a[1] + sin(a[2]); out[2] = 0.9 * a[2] + a[3]; out[3] = 0.5 * a[3];
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + a[2]; }
+"""
+    rng = np.random.default_rng(2)
+    n, N = 20, 700
+    th = np.array([0.7])
+    Rm = np.array([[0.3, 0.0, 0.0], [0.1, 0.2, 0.0], [0.0, 0.0, 0.4], [0.0, 0.1, 0.1]])
+    y = np.cumsum(rng.normal(0, 0.5, n))
+    a1 = np.array([0.0, 0.1, 0.0, 0.0]); P1 = np.diag([1.0, 0.5, 0.3, 0.2]); P1[0, 1] = P1[1, 0] = 0.3
+    u = M.ssm_nlg_user(y, code, theta=th, a1=a1, P1=P1, H=0.6, R=Rm, n_states=4)
+    out = F.bootstrap_filter(u, N, seed=3, return_indices=True)
+    Z = lambda t, a, th, kn: a[0] + a[2]
+    T = lambda t, a, th, kn: np.array([a[0] + a[1], th[0] * a[1] + np.sin(a[2]), 0.9 * a[2] + a[3], 0.5 * a[3]])
+    ref = oracle.nlg_general_bsf_filter(y, 4, 3, th, [], a1, P1, Z, lambda *q: 0.6, T, lambda *q: Rm, N, seed=3)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9

@@ -347,3 +347,34 @@ def test_functor_models_analytic_pins(oracle):
     # GBM with positive = True stays positive
     g = M.ssm_sde(rng.normal(0, 1, 10), "sde_gbm", theta=[0.05, 0.3, 1.0], x0=1.0, positive=True)
     assert np.all(oracle.fn_bsf_filter({**g, "L": 3}, 50, seed=2)["alpha"] > 0)
+
+
+def test_general_nlg_bootstrap_equals_builtin_functor_path(oracle):
+    """orc_nlg_general_bsf_filter (function-pointer models, state-dependent H / R allowed) given the shipped growth
+    model's functions reproduces the built-in-functor restatement (same ancestors, values to the last places); on a linear-Gaussian model written as
+    functions it agrees with the exact Kalman log-likelihood within Monte-Carlo error."""
+    rng = np.random.default_rng(3)
+    n, K, dT = 30, 500.0, 0.1
+    y = 50 + np.cumsum(rng.normal(0.5, 1, n)); y[4] = np.nan
+    th = np.array([0.0, np.log(0.05), 0.0]); kp = np.array([dT, K, 0.0, 50.0, 1.0, 100.0])
+    model = M.ssm_nlg(y, "nlg_growth", theta=th, known_params=kp)
+    ref = oracle.fn_bsf_filter({**model, "L": 0}, 200, seed=7)
+
+    def T(t, a, th_, kn):
+        r = np.exp(a[0]) / (1.0 + np.exp(a[0]))
+        return np.array([a[0], kn[1] * a[1] * np.exp(r * kn[0]) / (kn[1] + a[1] * (np.exp(r * kn[0]) - 1))])
+    got = oracle.nlg_general_bsf_filter(y, 2, 2, th, kp, kp[2:4], np.diag(kp[4:6]), lambda t, a, th_, kn: a[1],
+                                        lambda t, a, th_, kn: np.exp(th_[0]), T,
+                                        lambda t, a, th_, kn: np.diag([np.exp(th_[1]), np.exp(th_[2])]), 200, seed=7)
+    assert np.array_equal(got["indices"], ref["indices"])
+    # (numpy's exp and libm's differ in the last place inside T_fn)
+    assert abs(got["logLik"] - ref["logLik"]) <= 1e-12 * n and np.allclose(got["alpha"], ref["alpha"], rtol=1e-12, atol=1e-12)
+    # linear-Gaussian: local level + slope with a full 2 x 1 matrix R (one noise term drives both states)
+    n = 40
+    yl = np.cumsum(rng.normal(0.1, 0.3, n)) + rng.normal(0, 0.5, n)
+    Tm = np.array([[1.0, 1.0], [0.0, 1.0]]); Rm = np.array([[0.3], [0.05]])
+    lls = [oracle.nlg_general_bsf_filter(yl, 2, 1, [0.0], [], [0.0, 0.1], np.diag([1.0, 0.01]), lambda t, a, *_: a[0],
+                                         lambda *_: 0.5, lambda t, a, *_: Tm @ a, lambda *_: Rm, 400, seed=s)["logLik"] for s in range(1, 9)]
+    arr = M.model_arrays(M.ssm_ulg(yl, Z=np.array([1.0, 0.0]), H=0.5, T=Tm, R=Rm, a1=np.array([0.0, 0.1]), P1=np.diag([1.0, 0.01])))
+    exact = oracle.ulg_loglik(arr)
+    assert abs(np.mean(lls) - exact) < 4 * np.std(lls) / np.sqrt(len(lls)) + 0.05
