@@ -166,6 +166,59 @@ __device__ __forceinline__ void propagate_mfma8(PT mt, const double (&a)[8], con
   for (int c = 0; c < 8; c++) x[c] = tile[c * 64 + lane];
 }
 
+// The same contraction through an 8 x 64 tile (4 KB per wave instead of 8): the ancestors' half of [A ; Z] first, then
+// the noise half into the same rows -- the round-2 step kernel keeps four workgroups per CU with it.
+__device__ __forceinline__ void lds_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int KP, class PT>
+__device__ __forceinline__ void propagate_mfma8_h(PT mt, const double (&a)[8], const double (&z)[KP],
+                                                  double (&x)[8], double* tile /* 8 x 64 doubles, this wave's */, int lane) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int i = lane & 15, kq = lane >> 4;
+  double afr[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    const int k = 4 * kk + kq;  // column of [T R]
+    afr[kk] = (i < 8) ? (k < 8 ? mt[i + 8 * k] : ((k - 8) < KP ? mt[64 + i + 8 * (k - 8)] : 0.0)) : 0.0;
+  }
+  const PT Cv = mt + 64 + 8 * KP;
+  const double c0 = Cv[kq], c1 = Cv[kq + 4];
+  lds_wave_sync();  // earlier readers of the tile (the search window) are done
+#pragma unroll
+  for (int c = 0; c < 8; c++) tile[c * 64 + lane] = a[c];
+  lds_wave_sync();
+  d4 acc[4];
+#pragma unroll
+  for (int blk = 0; blk < 4; blk++) {
+    acc[blk] = d4{c0, c1, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+      acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], tile[(4 * kk + kq) * 64 + 16 * blk + i], acc[blk], 0, 0, 0);
+  }
+  lds_wave_sync();
+#pragma unroll
+  for (int c = 0; c < 8; c++) tile[c * 64 + lane] = c < KP ? z[c < KP ? c : 0] : 0.0;
+  lds_wave_sync();
+#pragma unroll
+  for (int blk = 0; blk < 4; blk++) {
+#pragma unroll
+    for (int kk = 0; kk < (KP > 4 ? 2 : 1); kk++)
+      acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[2 + kk], tile[(4 * kk + kq) * 64 + 16 * blk + i], acc[blk], 0, 0, 0);
+  }
+  lds_wave_sync();
+#pragma unroll
+  for (int blk = 0; blk < 4; blk++) {  // rows kq and kq + 4 of the result are state components
+    tile[kq * 64 + 16 * blk + i] = acc[blk][0];
+    tile[(kq + 4) * 64 + 16 * blk + i] = acc[blk][1];
+  }
+  lds_wave_sync();
+#pragma unroll
+  for (int c = 0; c < 8; c++) x[c] = tile[c * 64 + lane];
+}
+
 // one particle's log-weight for whichever model family the kernel was instantiated for
 template <int MP, bool FN>
 __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const double* __restrict__ fpar,
@@ -873,15 +926,25 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   }
 #ifndef BSSM_USER_MODEL
   // round-2 step kernel (pf_grid_v2.h): linear-state models with one observation series, at most 64 particle blocks
-  if constexpr (MP <= 4) {
-    bool v2 = !b.fpar && b.p == 1 && ws.B <= 64 && ppt <= 4 && !ws.dbg;
+  bool v2ms = false;
+  if constexpr (MP <= 8) {
+    bool v2 = !b.fpar && ws.B <= 64 && ppt <= 4 && !ws.dbg;
     if (const char* env = std::getenv("BSSM_AMD_GRID_V2")) v2 = v2 && env[0] != '0';
-    if (v2) {
-      switch (ppt) {
-        case 1: kern = pf_grid_step_v2<MP, KP, 1>; kern_init = pf_grid_init_v2<MP, 1>; break;
-        case 2: kern = pf_grid_step_v2<MP, KP, 2>; kern_init = pf_grid_init_v2<MP, 2>; break;
-        default: kern = pf_grid_step_v2<MP, KP, 4>; kern_init = pf_grid_init_v2<MP, 4>; break;
+    if constexpr (MP <= 4) {
+      if (v2 && b.p == 1) {
+        switch (ppt) {
+          case 1: kern = pf_grid_step_v2<MP, KP, 1>; kern_init = pf_grid_init_v2<MP, 1>; break;
+          case 2: kern = pf_grid_step_v2<MP, KP, 2>; kern_init = pf_grid_init_v2<MP, 2>; break;
+          default: kern = pf_grid_step_v2<MP, KP, 4>; kern_init = pf_grid_init_v2<MP, 4>; break;
+        }
       }
+    }
+    // rows of several observation series (ssm_mng) and every 8-dimensional state: the multi-series variants, one or two
+    // particles per lane (MP = 8, one particle per lane: fp64 MFMA transition)
+    if (v2 && !kern_init && ppt <= 2 && (MP == 8 || b.p > 1)) {
+      v2ms = true;
+      if (ppt == 1) { kern = pf_grid_step_v2<MP, KP, 1, true>; kern_init = pf_grid_init_v2<MP, 1, true>; }
+      else { kern = pf_grid_step_v2<MP, KP, 2, true>; kern_init = pf_grid_init_v2<MP, 2, true>; }
     }
   }
 #endif
@@ -889,7 +952,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
 #ifndef BSSM_USER_MODEL
   {
     char nm[96];
-    if (kern_init) std::snprintf(nm, sizeof nm, "pf_grid_step_v2<%d,%d,%d>", MP, KP, ppt);
+    if (kern_init) std::snprintf(nm, sizeof nm, v2ms ? "pf_grid_step_v2<%d,%d,%d,true>" : "pf_grid_step_v2<%d,%d,%d>", MP, KP, ppt);
     else std::snprintf(nm, sizeof nm, "pf_grid_step<%d,%d,%d,%s,%s>", MP, KP, ppt, "false", b.fpar ? "true" : "false");
     note_filter_kernel(nm);
   }

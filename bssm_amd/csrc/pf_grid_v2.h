@@ -133,6 +133,69 @@ __device__ __forceinline__ void v2_log_weights(const cdbl* row, const bool psi, 
   }
 }
 
+template <int MP>
+__device__ __forceinline__ double v2_signal(const cdbl* ob, const double (&x)[MP]) {
+  double za = ob[OB_D];
+#pragma unroll
+  for (int c = 0; c < MP; c++) za = __builtin_fma(ob[SER_HDR + c], x[c], za);
+  return za;
+}
+
+// the same for a row of p observation series (ssm_mng: src/model_ssm_mng.cpp:357-442): the log-weight is the sum over the
+// observed series, each with its own distribution -- a wave-uniform loop, one density body per series
+template <int MP, int PPT>
+__device__ __forceinline__ void v2_log_weights_multi(const int p, const cdbl* row, const bool psi, const double (&x)[PPT][MP], double (&w)[PPT]) {
+#pragma unroll
+  for (int r = 0; r < PPT; r++) w[r] = 0.0;
+  for (int j = 0; j < p; j++) {
+    const cdbl* ob = row + ROW_HDR + j * (SER_HDR + MP);
+    if (ob[OB_FLAG] == 0.0) continue;  // this series is missing at t (src/model_ssm_mng.cpp:414)
+    double sj[PPT], dj[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; r++) sj[r] = v2_signal<MP>(ob, x[r]);
+    const int dist = (int)ob[OB_DIST];
+    const double y = ob[OB_Y], u = ob[OB_U], aux = ob[OB_AUX], phi = ob[OB_PHI];
+    switch (dist) {
+      case DIST_SVM:
+#pragma unroll
+        for (int r = 0; r < PPT; r++) { dj[r] = -0.5 * (sj[r] + aux * tl_exp(-sj[r])); __builtin_amdgcn_sched_barrier(0); }
+        break;
+      case DIST_POISSON:
+#pragma unroll
+        for (int r = 0; r < PPT; r++) { dj[r] = y * sj[r] - u * tl_exp(sj[r]); __builtin_amdgcn_sched_barrier(0); }
+        break;
+      case DIST_BINOMIAL:
+#pragma unroll
+        for (int r = 0; r < PPT; r++) { dj[r] = y * sj[r] - u * log1p(tl_exp(sj[r])); __builtin_amdgcn_sched_barrier(0); }
+        break;
+      case DIST_NEGBIN:
+#pragma unroll
+        for (int r = 0; r < PPT; r++) { dj[r] = y * sj[r] - aux * tl_log(phi + u * tl_exp(sj[r])); __builtin_amdgcn_sched_barrier(0); }
+        break;
+      case DIST_GAMMA:
+#pragma unroll
+        for (int r = 0; r < PPT; r++) { dj[r] = -phi * (sj[r] + aux * tl_exp(-sj[r])); __builtin_amdgcn_sched_barrier(0); }
+        break;
+      default:  // DIST_GAUSSIAN
+#pragma unroll
+        for (int r = 0; r < PPT; r++) { const double d = y - sj[r]; dj[r] = -0.5 * d * d * aux; }
+        break;
+    }
+    if (psi) {
+      const double py = ob[OB_PSIY], pih = ob[OB_PSIIH];
+#pragma unroll
+      for (int r = 0; r < PPT; r++) { const double q = (py - sj[r]) * pih; dj[r] = __builtin_fma(0.5 * q, q, dj[r]); }
+    }
+#pragma unroll
+    for (int r = 0; r < PPT; r++) w[r] += dj[r];
+  }
+  if (psi) {
+    const double rs = row[RH_SCALE];
+#pragma unroll
+    for (int r = 0; r < PPT; r++) w[r] -= rs;
+  }
+}
+
 // Block statistics of the new weights and their hand-over to the next launch: block-local inclusive scan of
 // exp(w - max_b) (`lcdf`), row ends (`coarse`), (max_b, sum_b) (`partials`); optional block-scaled weights output.
 // One workgroup barrier.  s_x: 4 + 4 * PPT doubles of LDS.
@@ -192,17 +255,13 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
 #ifndef BSSM_V2_OCC16
 #define BSSM_V2_OCC16 4
 #endif
-constexpr int v2_occupancy(int mp, int ppt) {
-  const int live = mp * ppt;
+#ifndef BSSM_V2_OCC_MS16
+#define BSSM_V2_OCC_MS16 4   // MP = 8, two particles per lane: 128 VGPRs with 5 spilled beat 132 at three waves (C4, 64 filters: +4 ... +7 %)
+#endif
+constexpr int v2_occupancy(int mp, int ppt, bool ms = false) {
+  if (ms && mp * ppt == 16) return BSSM_V2_OCC_MS16;
+  const int live = mp * ppt * (ms && mp * ppt > 8 ? 2 : 1);  // the multi-series variants keep the new states until the density
   return live <= 4 ? 5 : (live <= 8 ? 4 : (live <= 16 ? BSSM_V2_OCC16 : (live <= 32 ? 3 : 2)));
-}
-
-template <int MP>
-__device__ __forceinline__ double v2_signal(const cdbl* ob, const double (&x)[MP]) {
-  double za = ob[OB_D];
-#pragma unroll
-  for (int c = 0; c < MP; c++) za = __builtin_fma(ob[SER_HDR + c], x[c], za);
-  return za;
 }
 
 __device__ __forceinline__ void v2_block_of(const GridWorkspace& ws, int& pb, int& f) {
@@ -216,7 +275,7 @@ __device__ __forceinline__ void v2_block_of(const GridWorkspace& ws, int& pb, in
 }
 
 // t = -1: initial particles a1 + L u (src/model_ssm_ung.cpp:626; psi: alphahat_0 + V_0 u, :543) and their weights
-template <int MP, int PPT>
+template <int MP, int PPT, bool MS = false>
 __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, const GridWorkspace ws) {
   __shared__ double s_x[4 + 4 * PPT];
   int pb, f;
@@ -230,7 +289,7 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, 
   const cdbl* row = as_uniform_table(b.obs + (size_t)f * b.obs_fstride);
   double* __restrict__ st_new = (b.alpha_hist ? b.alpha_hist + (size_t)f * (n + 1) * m * N : ws.state[0] + (size_t)f * m * N) + base;
   const bool observed = n > 0 && row[RH_FLAG] != 0.0;
-  double s[PPT], w[PPT];
+  double s[PPT], w[PPT], xs[MS ? PPT : 1][MP];
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
@@ -241,10 +300,16 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, 
 #pragma unroll
       for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + li] = x[c];
     }
-    s[r] = v2_signal<MP>(row + ROW_HDR, x);
+    if constexpr (MS) {
+#pragma unroll
+      for (int c = 0; c < MP; c++) xs[r][c] = x[c];
+    } else {
+      s[r] = v2_signal<MP>(row + ROW_HDR, x);
+    }
   }
   if (observed) {
-    v2_log_weights<PPT>(row, b.psi != 0, s, w);
+    if constexpr (MS) v2_log_weights_multi<MP, PPT>(b.p, row, b.psi != 0, xs, w);
+    else v2_log_weights<PPT>(row, b.psi != 0, s, w);
   } else {
 #pragma unroll
     for (int r = 0; r < PPT; r++) w[r] = 0.0;
@@ -255,9 +320,16 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, 
 }
 
 // t in [0, n): resample on the time-t weights, propagate to t+1, weigh at t+1 (ones when t+1 == n or y_{t+1} is missing)
-template <int MP, int KP, int PPT>
-__global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v2(const FilterBatch b, const GridWorkspace ws, const int t) {
-  __shared__ double s_win[4 * PPT * V2_WIN];
+// MS: a row of p >= 1 observation series (ssm_mng, and every model with an 8-dimensional state); with MP = 8 and one
+// particle per lane the transition runs on the matrix cores (propagate_mfma8), whose per-wave operand tile doubles as the
+// wave's search window
+template <int MP, int KP, int PPT, bool MS = false>
+__global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_step_v2(const FilterBatch b, const GridWorkspace ws, const int t) {
+  #ifndef BSSM_V2_MFMA_PPT
+#define BSSM_V2_MFMA_PPT 2
+#endif
+  constexpr bool kMfma = MS && MP == 8 && PPT <= BSSM_V2_MFMA_PPT;
+  __shared__ double s_win[kMfma ? 4 * 8 * 64 : 4 * PPT * V2_WIN];
   __shared__ double s_x[4 + 4 * PPT];
   __shared__ double s_comb[3 * 64 + 1];  // combine of wave 0: block prefixes, 1 / scale, scale, global maximum
   // T_t, R_t, C_t of this step.  Read from LDS (broadcast ds_read, same address in every lane) and not through scalar
@@ -335,7 +407,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
   const double* __restrict__ st_old = uniform_ptr(b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N);
   double* __restrict__ st_new = uniform_ptr((b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N) + base);
   uint32_t* __restrict__ idx_out = b.indices ? uniform_ptr(b.indices + ((size_t)f * n + t) * N + base) : nullptr;
-  double* sw_base = s_win + wave * (PPT * V2_WIN);
+  double* sw_base = s_win + wave * (kMfma ? 8 * 64 : PPT * V2_WIN);
 
   V2_MARK("phaseA");
   // ---- phase A: step blocks, targets, source block (two ballots), coarse row of the source block in flight
@@ -424,14 +496,16 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
   V2_MARK("phaseE");
   // ---- phase E: transition normals, alpha_{t+1} = C_t + T_t a + R_t eta (:663-670), signal at t+1
   const bool have_obs = tn < n;
-  const cdbl* row = as_uniform_table(b.obs + (size_t)f * b.obs_fstride + (size_t)(have_obs ? tn : 0) * (ROW_HDR + SER_HDR + MP));
-  double s[PPT], w[PPT];
+  const cdbl* row = as_uniform_table(b.obs + (size_t)f * b.obs_fstride + (size_t)(have_obs ? tn : 0) * (ROW_HDR + (MS ? b.p : 1) * (SER_HDR + MP)));
+  double s[PPT], w[PPT], xs[MS ? PPT : 1][MP];
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid, j = base + li;
     double z[KP], x[MP];
     rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
-    {
+    if constexpr (kMfma) {
+      propagate_mfma8_h<KP>((const double*)s_mat, a[r], z, x, sw_base, lane);
+    } else {
       int zero = 0;  // opaque: the matrix is re-read per particle instead of being kept live in 72 VGPRs
       __asm__ volatile("" : "+v"(zero));
       propagate<MP, KP>((const double*)(s_mat + zero), a[r], z, x);
@@ -440,12 +514,18 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT)) pf_grid_step_v
 #pragma unroll
       for (int c = 0; c < MP; c++) if (c < m) st32(st_new + (size_t)c * N, li, x[c]);
     }
-    s[r] = v2_signal<MP>(row + ROW_HDR, x);
+    if constexpr (MS) {
+#pragma unroll
+      for (int c = 0; c < MP; c++) xs[r][c] = x[c];
+    } else {
+      s[r] = v2_signal<MP>(row + ROW_HDR, x);
+    }
     __builtin_amdgcn_sched_barrier(0);  // particles one after the other: bounds the live registers of the transcendental code
   }
   V2_MARK("density");
   if (have_obs && row[RH_FLAG] != 0.0) {
-    v2_log_weights<PPT>(row, b.psi != 0, s, w);
+    if constexpr (MS) v2_log_weights_multi<MP, PPT>(b.p, row, b.psi != 0, xs, w);
+    else v2_log_weights<PPT>(row, b.psi != 0, s, w);
   } else {  // nothing observed at t+1: weights are ones (src/model_ssm_ung.cpp:644-647)
 #pragma unroll
     for (int r = 0; r < PPT; r++) w[r] = 0.0;

@@ -39,6 +39,9 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
     if (w1 >= 6144 && b.N >= 4 * GRID_NT) ppt = 4;
     else if (w1 >= 3072 && b.N >= 2 * GRID_NT) ppt = 2;
   }
+  // 8-dimensional states (round-2 multi-series kernel): two particles per lane once the batch fills the chip twice
+  // (C4, 16 384 particles: 32 filters 1.92e10 -> 1.99e10, 64 filters 1.90e10 -> 2.19e10 particle-steps/s; 16 filters 1.58e10 -> 1.37e10)
+  if (b.MP == 8 && !b.fpar && w1 >= 2048 && b.N >= 2 * GRID_NT) ppt = 2;
   if (const char* env = std::getenv("BSSM_AMD_GRID_PPT")) ppt = std::max(1, std::min(8, std::atoi(env)));  // tuning hook
   while ((b.N + GRID_NT * ppt - 1) / (GRID_NT * ppt) > GRID_NT && ppt < 8) ppt *= 2;
   const int chunk = GRID_NT * ppt;

@@ -80,13 +80,14 @@ if want("C3"):
 if want("C4"):
     mdl = mng_c4(2000)
     row = dict(workload="ssm_mng m=8 k=8 p=4 T=2000 N=16384 bootstrap filter")
-    for R, keep in ((1, True), (16, True), (64, False)):
+    for R, keep in ((1, True), (16, True), (64, True), (64, False)):
         p = FilterPlan(mdl, 16384, method="bsf", force="grid", keep_history=keep, n_rep=R)
         p.run(1); p.loglik()
         ms = p.time(2, 3)
         bps = 16 * 8 + (24 if keep else 16)
         row["R%d_%s" % (R, "full" if keep else "loglik")] = dict(ms=ms, psteps_s=R * 16384 * 2000 / ms * 1e3,
-                                                                alg_GBs=R * 16384 * 2000 / ms * 1e3 * bps / 1e9)
+                                                                alg_GBs=R * 16384 * 2000 / ms * 1e3 * bps / 1e9,
+                                                                kernel=FilterPlan.last_kernel())
         p.close()
     res["C4"] = row
 

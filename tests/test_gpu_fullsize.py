@@ -82,14 +82,21 @@ def test_c3_svm_exchange_psi_smoother_full_size():
 
 
 def test_c4_mng_mfma_transition_equals_valu_transition(monkeypatch):
-    """configs[3]: ssm_mng m=8 p=4 T=2000 N=16384: the fp64-MFMA state transition and the plain FMA transition
-    (selected by two particles per thread) are independent implementations of alpha' = C + T a + R eta"""
+    """configs[3]: ssm_mng m=8 p=4 T=2000 N=16384: the fp64-MFMA state transition (round-2 multi-series step kernel,
+    one and two particles per lane) and the plain FMA transition (round-1 step kernel at two particles per lane) are
+    independent implementations of alpha' = C + T a + R eta"""
     model = mng_c4(2000)
     N = 16384
     monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "grid")
     mfma = F.bootstrap_filter(model, N, seed=4, return_indices=True)
+    from bssm_amd.plan import FilterPlan
+    assert "pf_grid_step_v2<8," in FilterPlan.last_kernel() and "true" in FilterPlan.last_kernel()
     monkeypatch.setenv("BSSM_AMD_GRID_PPT", "2")
+    mfma2 = F.bootstrap_filter(model, N, seed=4, return_indices=True)
+    assert np.mean(mfma["indices"] != mfma2["indices"]) < 1e-6
+    monkeypatch.setenv("BSSM_AMD_GRID_V2", "0")
     valu = F.bootstrap_filter(model, N, seed=4, return_indices=True)
+    assert "pf_grid_step<8," in FilterPlan.last_kernel()
     _check_particle_system(mfma, 2000, N, model["y"])
     frac = np.mean(mfma["indices"] != valu["indices"])
     assert frac < 1e-6, f"ancestor mismatch fraction {frac}"
