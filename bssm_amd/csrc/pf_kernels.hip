@@ -36,7 +36,9 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   const size_t w1 = (size_t)b.F * ((b.N + GRID_NT - 1) / GRID_NT);
   int ppt = 1;
   if (b.MP <= 4 && !b.fpar) {
-    if (w1 >= 6144 && b.N >= 4 * GRID_NT) ppt = 4;
+    // (states of one or two doubles: the round-2 kernel at four particles per lane wins from 4096 workgroups -- m = 1,
+    // 16 / 20 filters of 65 536 particles: 4.95e10 -> 5.31e10, 5.49e10 -> 6.17e10; scripts/mid_batch_probe.py)
+    if (w1 >= (size_t)(b.MP <= 2 ? 4096 : 6144) && b.N >= 4 * GRID_NT) ppt = 4;
     else if (w1 >= 3072 && b.N >= 2 * GRID_NT) ppt = 2;
   }
   // 8-dimensional states (round-2 multi-series kernel): two particles per lane once the batch fills the chip twice
