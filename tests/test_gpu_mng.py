@@ -30,6 +30,24 @@ def test_mng_bootstrap_filter(oracle, monkeypatch, name, N, path):
     assert _rel(out["att"], att.T) <= 1e-9 and _rel(out["Ptt"], Ptt) <= 1e-8
 
 
+@pytest.mark.parametrize("name", sorted(ZOO))
+@pytest.mark.parametrize("N", [700, 1100])
+def test_mng_step_kernel_two_particles_per_lane(oracle, monkeypatch, name, N):
+    """the multi-series step kernel at two particles per lane (what large batches use; fp64-MFMA transition twice per
+    lane for m = 8), ragged last block, against the oracle"""
+    from bssm_amd.plan import FilterPlan
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "grid")
+    monkeypatch.setenv("BSSM_AMD_GRID_PPT", "2")
+    model = ZOO[name]
+    out = F.bootstrap_filter(model, N, seed=3, return_indices=True)
+    assert "pf_grid_step_v2" in FilterPlan.last_kernel() and ",2,true>" in FilterPlan.last_kernel()
+    ref = oracle.mng_bsf_filter(M.model_arrays(model), N, seed=3)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-9
+
+
 @pytest.mark.parametrize("path", ["wg", "grid"])
 @pytest.mark.parametrize("name", sorted(ZOO))
 def test_mng_psi_smoother(oracle, monkeypatch, name, path):
