@@ -368,6 +368,25 @@ def main():
                            "roofline_valu": valu_roofline(REGB_VALU_PER_PSTEP, ps / (kb_ms * 1e-3), "pf_wg_kernel<4,4,4,false,512>")}
         pb.close()
 
+    if rank == 0 and world == 1 and not args.no_regime_b:
+        # ---- BASELINE configs[3]: ssm_mng m = 8, p = 4, T = 2000, N = 16384 -- the fp64-MFMA transition path
+        # (pf_grid_step_v2<8,8,.,true>), 32 filters in flight, full output; 16 m + 24 = 152 algorithmic bytes per particle-step
+        from models_zoo import mng_c4
+        nm, fm, Tm = 16384, 32, 2000  # (32 filters: 80 GB of outputs, within the arena the headline batch leaves behind)
+        pm = FilterPlan(mng_c4(Tm), nm, method="bsf", keep_history=True, force="grid", n_rep=fm)
+        pm.run(5, hip_stream=stream); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(2):
+            pm.run(6 + s, hip_stream=stream)
+        torch.cuda.synchronize()
+        em = (time.perf_counter() - t0) / 2
+        psm = float(nm) * fm * Tm
+        out["mng_c4"] = {"workload": "ssm_mng m=8 k=8 p=4 (poisson, poisson, negbin, gaussian), T=%d, N=%d, bootstrap filter, full output, "
+                                     "%d filters in flight" % (Tm, nm, fm),
+                         "value": psm / em, "unit": "particle-steps/s", "ms_per_pass": em * 1e3, "kernel": pm.last_kernel(),
+                         "algorithmic_GBs": psm * 152 / em / 1e9, "frac_of_8TBs": psm * 152 / em / 8e12}
+        pm.close()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only: the other ranks would idle behind it
         # ---- CPU baseline: the oracle (reference loop structure, one thread per filter) on a bounded sample
         from bssm_amd import models as M
