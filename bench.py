@@ -36,7 +36,7 @@ VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 # wave-level VALU instructions per particle-step of the workgroup-resident kernels, from the PMC passes committed under
 # profiles/r02_pmc_other_kernels.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_others.sh)
 REGB_VALU_PER_PSTEP = 10628740724.8 / (512 * 2048 * 1000.0)   # pf_wg_kernel<4,4,4,false,512>
-C5_VALU_PER_PSTEP = 4393378021.9 / (468.0 * 4096 * 300.0)     # pf_wg_kernel<2,2,4,true,1024>, 50 dispatches of 2340 draws per 5
+C5_VALU_PER_PSTEP = 4216487378.5 / (468.0 * 4096 * 300.0)     # pf_wg_kernel<2,2,4,1,1024,1> (nlg_growth, psi-APF), 50 dispatches of 2340 draws per 5 (profiles/r02_pmc_C5_v2.txt)
 
 
 def valu_roofline(valu_per_pstep, psteps_per_s, kernel):
@@ -44,7 +44,7 @@ def valu_roofline(valu_per_pstep, psteps_per_s, kernel):
     return {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
             "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
             "lane_instr_per_particle_step": valu_per_pstep * 64,
-            "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r02_pmc_other_kernels.txt); rate: measured live"}
+            "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r02_pmc_other_kernels.txt, r02_pmc_C5_v2.txt); rate: measured live"}
 
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -163,7 +163,7 @@ def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=Fals
             "scaling": "strong", "n_gpus": world, "seconds": times[best], "draws_per_s": ns / times[best],
             "value": ns * float(nsim) * n / times[best], "unit": "particle-steps/s", "host_threads_per_rank": threads,
             "roofline_valu": valu_roofline(C5_VALU_PER_PSTEP, ns * float(nsim) * n / (max(v[1] for v in splits[best]) * 1e-3),
-                                           "pf_wg_kernel<2,2,4,true,1024>") if max(v[1] for v in splits[best]) > 0 else None,
+                                           "pf_wg_kernel<2,2,4,1,1024,1>") if max(v[1] for v in splits[best]) > 0 else None,
             "per_rank_ms": [{"rank": q, "setup_ms": round(v[0], 2), "device_ms": round(v[1], 2), "collective_ms": round(v[2], 2)}
                             for q, v in enumerate(splits[best])],
             "per_rank_note": "set-up (host threads) and device phase overlap inside a rank; collective_ms includes waiting for the slowest rank",

@@ -387,6 +387,7 @@ struct DeviceBatch {
     fb.fpar = fparbuf.as<double>();
     fb.fpar_fstride = fp.size() > (size_t)bssm::FP_SIZE ? bssm::FP_SIZE : 0;
     fb.user_slot = (int)fp[bssm::FP_SLOT];  // run-time compiled user model: its library holds the kernels
+    fb.fn_id = (int)fp[bssm::FP_ID];
     return BSSM_OK;
   }
 
@@ -1422,6 +1423,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
       if (ctabs && ctabs->fpar.p) {
         db.fb.fpar = ctabs->fpar.as<double>() + pos * bssm::FP_SIZE; db.fb.fpar_fstride = bssm::FP_SIZE;
         db.fb.user_slot = 0;
+        db.fb.fn_id = (int)J.fpar[bssm::FP_ID];
         db.fb.amats = ctabs->amats.as<double>() + pos * ctabs->as; db.fb.amats_fstride = ctabs->as;
       } else if (!J.fpar.empty()) {
         HIP_TRY(st_fpar.alloc(F * bssm::FP_SIZE * sizeof(double)));
@@ -1431,6 +1433,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         HIP_TRY(hipMemcpyAsync(fparb.p, hb, fparb.bytes, hipMemcpyHostToDevice, nullptr));
         db.fb.fpar = fparb.as<double>(); db.fb.fpar_fstride = bssm::FP_SIZE;
         db.fb.user_slot = (int)J.fpar[bssm::FP_SLOT];
+        db.fb.fn_id = (int)J.fpar[bssm::FP_ID];
       }
       if (!ctabs && !J.amats.empty()) {
         const size_t as = (size_t)n * (m * m + m);

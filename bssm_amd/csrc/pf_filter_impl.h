@@ -220,32 +220,56 @@ __device__ __forceinline__ void propagate_mfma8_h(PT mt, const double (&a)[8], c
 }
 
 // one particle's log-weight for whichever model family the kernel was instantiated for
-template <int MP, bool FN>
+// PM: the sampler of a functor kernel fixed at compile time (0 bootstrap, 1 psi-APF, 2 EKF particle filter; -1 = read
+// b.psi): a kernel that carries all three keeps the union of their registers live (the nlg_growth psi-APF kernel at 1024
+// threads spilt 52 VGPRs and 161 SGPRs that way)
+template <int MP, int FN, int PM = -1>
 __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const double* __restrict__ fpar,
                                                   const double* __restrict__ row, const double* __restrict__ amat, int t,
                                                   const double (&x)[MP], const double (&aprev)[MP]) {
-  if constexpr (FN) {
+  if constexpr (FN != FN_NONE) {
+    constexpr int FID = FN > 0 ? FN : 0;
+    const int psi = PM >= 0 ? PM : b.psi;
     if constexpr (MP <= 2) {  // psi-APF / EKF particle filter: the shapes of the shipped models (the host refuses the others)
-      if (b.psi == 2) return functor_ekpf_weight<MP>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
-      if (b.psi) return functor_psi_weight<MP>(fpar, row, amat, t, x, aprev);
+      if (psi == 2) return functor_ekpf_weight<MP, FID>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
+      if (psi) return functor_psi_weight<MP, FID>(fpar, row, amat, t, x, aprev);
     }
-    return functor_log_weight<MP>(fpar, row, x);
+    return functor_log_weight<MP, FID>(fpar, row, x);
   } else {
     return log_weight_of<MP>(b, as_uniform_table(row), x);  // wave-uniform row: scalar loads (pf_device.h)
   }
 }
 
-// functor-model (FN) kernel shapes: the shipped models have 1 or 2 states; a run-time compiled user model may have up to 4
+// functor-model (FN) kernel shapes: the shipped models have 1 or 2 states; a run-time compiled user model may have up to 4.
+// fn_kernel_id<MP>(): the model id the functor kernels of this translation unit are compiled for (FN_ANY: dispatch per
+// call) -- a user-model library holds ONE model, and the only shipped two-state model is nlg_growth.
 #ifdef BSSM_USER_MODEL
 constexpr int FN_MP_MAX = 4;
+#if defined(BSSM_USER_NLG) && !defined(BSSM_USER_SDE)
+template <int MP> constexpr int fn_kernel_id() { return FN_USER_NLG; }
+#elif defined(BSSM_USER_SDE) && !defined(BSSM_USER_NLG)
+template <int MP> constexpr int fn_kernel_id() { return FN_USER_SDE; }
+#else
+template <int MP> constexpr int fn_kernel_id() { return FN_ANY; }
+#endif
 #else
 constexpr int FN_MP_MAX = 2;
+template <int MP> constexpr int fn_kernel_id() { return MP == 2 ? FN_NLG_GROWTH : FN_ANY; }
+#endif
+// analysis builds (-DBSSM_WG_STAMPS): shader-clock deltas per phase of the time loop, accumulated by the first lane of
+// the first and the last wave of workgroup 0 and printed at the end (scripts/wg_phase_probe.py)
+#ifdef BSSM_WG_STAMPS
+#define WG_STAMP(k) do { if (stamp_on) { const long long now_ = (long long)__builtin_readcyclecounter(); st_acc[k] += now_ - st_last; st_last = now_; } } while (0)
+#else
+#define WG_STAMP(k)
 #endif
 constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the fp64 transcendental code
 // Particle i = r * NT + tid (r < PPT): consecutive lanes own consecutive particles, so LDS
 // accesses to the own slot are conflict-free and history stores are coalesced.
-template <int MP, int KP, int PPT, bool FN = false, int NTB = WG_NT_MAX>
+template <int MP, int KP, int PPT, int FN = FN_NONE, int NTB = WG_NT_MAX, int PM = -1>
 __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
+  constexpr int FID = FN > 0 ? FN : 0;
+  const int psi_mode = PM >= 0 ? PM : b.psi;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   math_tab_init();
   const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = NT >> 6;
@@ -267,14 +291,18 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
 
   double w[PPT];  // log-weights of my particles at the current time
   double loglik = 0.0;
+#ifdef BSSM_WG_STAMPS
+  const bool stamp_on = blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == nw - 1);
+  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = (long long)__builtin_readcyclecounter();
+#endif
 
   // ---- initial particles and their weights
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int i = r * NT + tid;
     double x[MP];
-    if (FN && !b.psi) {
-      if constexpr (FN) functor_initial<MP>(fpar, ini, key, (uint32_t)i, x);
+    if (FN && !psi_mode) {
+      if constexpr (FN != FN_NONE) functor_initial<MP, FID>(fpar, ini, key, (uint32_t)i, x);
     } else {
       double z[MP];
       rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)i, z);
@@ -287,49 +315,54 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
         if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1)) * m + c) * N + i] = x[c];
       }
     }
-    w[r] = (i < N) ? weight_dispatch<MP, FN>(b, fpar, obs, amats, 0, x, x) : -INFINITY;
+    w[r] = (i < N) ? weight_dispatch<MP, FN, PM>(b, fpar, obs, amats, 0, x, x) : -INFINITY;
     __builtin_amdgcn_sched_barrier(0);  // keep the unrolled particles sequential: bounds live registers
   }
 
   for (int t = 0; t <= n; t++) {
-    // ---- normalise the time-t weights: block max (src/model_ssm_ung.cpp:675) ...
+    WG_STAMP(7);
+    // ---- normalise the time-t weights (src/model_ssm_ung.cpp:675-679): exponentials against the WAVE maximum and their
+    // inclusive scan in particle order first, the block maximum and the rescale exp(max_wave - max_block) after ONE exchange
+    // (the same trick as the round-2 step kernel: one barrier for maximum + scan instead of two)
     double mx = w[0];
 #pragma unroll
     for (int r = 1; r < PPT; r++) mx = fmax(mx, w[r]);
-    mx = wave_max(mx);
-    if (lane == 0) s_max[wave] = mx;
-    lds_barrier();  // (1)
-    double M = s_max[0];
-    for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
-    // stage this step's transition operands in LDS (every wave is past the previous transition here;
-    // they become visible at barrier (2)/(3), before the transition after barrier (4))
-    // (the transition operands T_t, R_t, C_t are wave-uniform: read by scalar loads below, no LDS staging)
-    // ... exp(w - max) and its inclusive scan in particle order (:676-679, stratified_sample.cpp:12)
-    double sc[PPT];
+    const double Mw = wave_max(mx);
+    const double Mws = Mw == -INFINITY ? 0.0 : Mw;  // a wave without mass: exp(-inf - 0) = 0 instead of exp(nan)
+    double e[PPT], sc[PPT];
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
-      const double e = (i < N) ? tl_exp(w[r] - M) : 0.0;
-      sc[r] = wave_scan_incl(e);
+      e[r] = (i < N) ? tl_exp(w[r] - Mws) : 0.0;
+      sc[r] = wave_scan_incl(e[r]);
       if (lane == 63) s_tot[r * nw + wave] = sc[r];
-      if (b.weights && i < N) b.weights[((size_t)f * (n + 1) + t) * N + i] = e;
     }
-    lds_barrier();  // (2)
-    // every wave scans the <= 128 chunk totals redundantly (saves a barrier)
+    if (lane == 0) s_max[wave] = Mw;
+    WG_STAMP(2);
+    lds_barrier();  // (1)
+    WG_STAMP(1);
+    double M = s_max[0];
+    for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
+    const double Ms = M == -INFINITY ? 0.0 : M;
+    // every wave scans the <= 128 scaled chunk totals redundantly (saves a barrier); chunk q belongs to wave q % nw
     const int Q = PPT * nw;
-    const double t0 = (lane < Q) ? s_tot[lane] : 0.0;
-    const double t1 = (lane + 64 < Q) ? s_tot[lane + 64] : 0.0;
+    const double t0 = (lane < Q) ? s_tot[lane] * tl_exp(s_max[lane % nw] - Ms) : 0.0;
+    const double t1 = (lane + 64 < Q) ? s_tot[lane + 64] * tl_exp(s_max[(lane + 64) % nw] - Ms) : 0.0;
     const double i0 = wave_scan_incl(t0);
     const double half = lane_broadcast(i0, 63);
     const double i1 = wave_scan_incl(t1) + half;
     const double S = lane_broadcast(i1, 63);
+    const double swv = tl_exp(Mw - Ms);  // this wave's rescale
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int q = r * nw + wave;  // my chunk; exclusive offset = inclusive prefix of chunk q-1
       const double p0 = lane_broadcast(i0, (q - 1) & 63), p1 = lane_broadcast(i1, (q - 65) & 63);
       const double off = (q == 0) ? 0.0 : (q <= 64 ? p0 : p1);
       const int i = r * NT + tid;
-      if (i < N) s_cdf[i] = off + sc[r];
+      if (i < N) {
+        s_cdf[i] = __builtin_fma(sc[r], swv, off);
+        if (b.weights) b.weights[((size_t)f * (n + 1) + t) * N + i] = e[r] * swv;
+      }
     }
     if (!(S > 0.0)) {  // :678-682 (uniform across the block)
       loglik = -INFINITY;
@@ -338,19 +371,22 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     }
     loglik += M + tl_log(S / dN);                       // :683
     if (t == n) break;
+    WG_STAMP(3);
     lds_barrier();  // (3) cdf visible
+    WG_STAMP(1);
 
     // ---- stratified resampling (stratified_sample.cpp:15-26) + ancestor gather (:657-661)
     const double c_scale = S / dN;
     double a[PPT][MP];
     u32x4 blk[PPT];  // step blocks: spare word -> resampling uniform now, words 0-2 -> transition normals below
+    double v[PPT];
+    int lo[PPT], hi[PPT], width = 0;
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
       blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)i);
-      const double u = block_uniform(blk[r]);
-      const double v = (u + (double)i) * c_scale;
-      int lo = 0, hi = N - 1;
+      v[r] = (block_uniform(blk[r]) + (double)i) * c_scale;
+      lo[r] = 0; hi[r] = N - 1;
       if (N >= 256 && r * NT + (wave + 1) * 64 <= N) {
         // the 64 slots of a wave are consecutive, so v increases along the lanes and their ancestors lie between those
         // of the first and the last lane: one cooperative 64-ary round (a pivot per lane, ballot counts) bounds both,
@@ -359,22 +395,37 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
         const int pe = min((lane + 1) * W, N) - 1;
         const double pv = s_cdf[pe];
         const bool valid = lane * W < N;
-        const double v_lo = lane_broadcast(v, 0), v_hi = lane_broadcast(v, 63);
+        const double v_lo = lane_broadcast(v[r], 0), v_hi = lane_broadcast(v[r], 63);
         const int c_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && pv < v_lo));
         const int c_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && pv < v_hi));
-        lo = min(c_lo * W, N - 1);
-        hi = min((c_hi + 1) * W, N) - 1;
+        lo[r] = min(c_lo * W, N - 1);
+        hi[r] = min((c_hi + 1) * W, N) - 1;
       }
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (v <= s_cdf[mid]) hi = mid; else lo = mid + 1;
-      }
-#pragma unroll
-      for (int c = 0; c < MP; c++) a[r][c] = s_alpha[c * Ncap + lo];
-      if (b.indices && i < N) b.indices[((size_t)f * n + t) * N + i] = (uint32_t)lo;
-      __builtin_amdgcn_sched_barrier(0);
+      width = max(width, hi[r] - lo[r]);  // wave-uniform: the bounds come from ballots
     }
+    // the bisections of a lane's particles advance together: their LDS reads are independent, so PPT of them are in flight
+    // per step instead of one (the search is bound by LDS latency and bank conflicts, not by instructions)
+    const int steps = __builtin_amdgcn_readfirstlane(width > 0 ? 32 - __builtin_clz((unsigned)width) : 0);
+    for (int sidx = 0; sidx < steps; sidx++) {
+#pragma unroll
+      for (int r = 0; r < PPT; r++) {
+        const int mid = (lo[r] + hi[r]) >> 1;
+        const double cm = s_cdf[mid];
+        const bool open = lo[r] < hi[r];
+        if (open && v[r] <= cm) hi[r] = mid;
+        else if (open) lo[r] = mid + 1;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      const int i = r * NT + tid;
+#pragma unroll
+      for (int c = 0; c < MP; c++) a[r][c] = s_alpha[c * Ncap + lo[r]];
+      if (b.indices && i < N) b.indices[((size_t)f * n + t) * N + i] = (uint32_t)lo[r];
+    }
+    WG_STAMP(4);
     lds_barrier();  // (4) all ancestors read before the slots are overwritten
+    WG_STAMP(1);
 
     // ---- transition to t+1 and the weights there
     const cdbl* mt = as_uniform_table(mats + (size_t)t * b.mats_tstride);
@@ -383,10 +434,10 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
       double x[MP];
-      if (FN && !b.psi) {
-        if constexpr (FN) functor_propagate<MP, KP>(fpar, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
-      } else if (FN && MP <= 2 && b.psi == 2) {
-        if constexpr (FN && MP <= 2) functor_ekpf_propagate<MP>(fpar, ob, t + 1 >= n, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
+      if (FN && !psi_mode) {
+        if constexpr (FN != FN_NONE) functor_propagate<MP, KP, FID>(fpar, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
+      } else if (FN && MP <= 2 && psi_mode == 2) {
+        if constexpr (FN != FN_NONE && MP <= 2) functor_ekpf_propagate<MP, FID>(fpar, ob, t + 1 >= n, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
       } else {
         double z[KP];
         rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
@@ -399,16 +450,31 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
           if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1) + (t + 1)) * m + c) * N + i] = x[c];
         }
       }
-      w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN>(b, fpar, ob, (FN && b.psi == 2) ? amats : amats + (size_t)t * (MP * MP + MP), t + 1, x, a[r]) : 0.0) : -INFINITY;
+      w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)t * (MP * MP + MP), t + 1, x, a[r]) : 0.0) : -INFINITY;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+#ifdef BSSM_WG_STAMPS
+  if (stamp_on)
+    printf("wg stamps wave %d: max %lld | barrier waits %lld | exp+scan %lld | totals+cdf %lld | search+gather %lld | propagate+weigh %lld cycles (n = %d)\n",
+           wave, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[7], n);
+#endif
   if (tid == 0 && b.loglik) b.loglik[f] = loglik;
 }
 
+// the functor kernel of one shape for the batch's sampler (0 bootstrap, 1 psi-APF, 2 EKF particle filter; MP <= 2 only)
+template <int MP, int PPT, int FNV, int NTB>
+auto wg_fn_kernel(int psi) -> void (*)(const FilterBatch) {
+  if constexpr (MP > 2) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0>;  // (the host refuses psi / EKF filters beyond two states)
+  else return psi == 0 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0> : (psi == 1 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 2>);
+}
+#define WG_FN_KERNEL(PPT_, NTB_) wg_fn_kernel<MP, PPT_, kFn, NTB_>(b.psi)
+#define GRID_FN_KERNEL(PPT_) grid_fn_kernel<MP, KP, PPT_, kFn>(b.psi)
 template <int MP, int KP>
 hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   const int N = b.N;
+  constexpr int kFn = fn_kernel_id<MP>();
+  if (b.fpar && kFn > 0 && b.fn_id != kFn) return hipErrorInvalidValue;  // not the model these kernels were compiled for
   // 1024-thread workgroups (16 waves, 128 VGPRs per lane) for small states and large N: four waves per SIMD instead
   // of two hide the barrier and LDS latency of the one workgroup a CU can hold at these sizes
   bool wide = false;
@@ -429,13 +495,13 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
       if (fn && MP != KP) return hipErrorInvalidValue;
       switch (ppt) {
 #ifndef BSSM_USER_MODEL
-        case 2: kern = fn ? (MP == KP ? pf_wg_kernel<MP, MP, 2, true, 1024> : nullptr) : pf_wg_kernel<MP, KP, 2, false, 1024>; break;
-        case 4: kern = fn ? (MP == KP ? pf_wg_kernel<MP, MP, 4, true, 1024> : nullptr) : pf_wg_kernel<MP, KP, 4, false, 1024>; break;
-        default: kern = fn ? (MP == KP ? pf_wg_kernel<MP, MP, 8, true, 1024> : nullptr) : pf_wg_kernel<MP, KP, 8, false, 1024>; break;
+        case 2: kern = fn ? (MP == KP ? WG_FN_KERNEL(2, 1024) : nullptr) : pf_wg_kernel<MP, KP, 2, FN_NONE, 1024>; break;
+        case 4: kern = fn ? (MP == KP ? WG_FN_KERNEL(4, 1024) : nullptr) : pf_wg_kernel<MP, KP, 4, FN_NONE, 1024>; break;
+        default: kern = fn ? (MP == KP ? WG_FN_KERNEL(8, 1024) : nullptr) : pf_wg_kernel<MP, KP, 8, FN_NONE, 1024>; break;
 #else
-        case 2: kern = fn ? pf_wg_kernel<MP, MP, 2, true, 1024> : nullptr; break;
-        case 4: kern = fn ? pf_wg_kernel<MP, MP, 4, true, 1024> : nullptr; break;
-        default: kern = fn ? pf_wg_kernel<MP, MP, 8, true, 1024> : nullptr; break;
+        case 2: kern = fn ? WG_FN_KERNEL(2, 1024) : nullptr; break;
+        case 4: kern = fn ? WG_FN_KERNEL(4, 1024) : nullptr; break;
+        default: kern = fn ? WG_FN_KERNEL(8, 1024) : nullptr; break;
 #endif
       }
       if (ppt > 8 || !kern) return hipErrorInvalidValue;
@@ -454,12 +520,12 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   if (b.fpar) {  // built-in non-linear / SDE functors: instantiated for the shapes the shipped models have
     if constexpr (MP == KP && MP <= FN_MP_MAX) {
       switch (ppt) {
-        case 1: kern = pf_wg_kernel<MP, KP, 1, true>; break;
-        case 2: kern = pf_wg_kernel<MP, KP, 2, true>; break;
-        case 4: kern = pf_wg_kernel<MP, KP, 4, true>; break;
-        case 8: kern = pf_wg_kernel<MP, KP, 8, true>; break;
+        case 1: kern = WG_FN_KERNEL(1, WG_NT_MAX); break;
+        case 2: kern = WG_FN_KERNEL(2, WG_NT_MAX); break;
+        case 4: kern = WG_FN_KERNEL(4, WG_NT_MAX); break;
+        case 8: kern = WG_FN_KERNEL(8, WG_NT_MAX); break;
         default:
-          if constexpr (MP <= 2) kern = pf_wg_kernel<MP, KP, 16, true>; else return hipErrorInvalidValue;
+          if constexpr (MP <= 2) kern = WG_FN_KERNEL(16, WG_NT_MAX); else return hipErrorInvalidValue;
       }
     } else {
       return hipErrorInvalidValue;
@@ -468,7 +534,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   }
   if (!kern) return hipErrorInvalidValue;
 #ifndef BSSM_USER_MODEL
-  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_wg_kernel<%d,%d,%d,%s,%d>", MP, KP, ppt, b.fpar ? "true" : "false", wide ? 1024 : WG_NT_MAX); note_filter_kernel(nm); }
+  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_wg_kernel<%d,%d,%d,%s,%d>", MP, KP, ppt, b.fpar ? (kFn > 0 ? "model" : "any") : "false", wide ? 1024 : WG_NT_MAX); note_filter_kernel(nm); }
 #endif
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -563,14 +629,16 @@ __device__ __forceinline__ int search16_lds(const double* a, int stride, int len
       ws.dbg[(size_t)t * 16 + (k)] = (long long)__builtin_readcyclecounter();                 \
   }
 
-template <int MP, int KP, int PPT, bool DBG = false, bool FN = false>
-__global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
+template <int MP, int KP, int PPT, bool DBG = false, int FN = FN_NONE, int PM = -1>
+__global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE)) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
+  constexpr int FID = FN > 0 ? FN : 0;
+  const int psi_mode = PM >= 0 ? PM : b.psi;
   __shared__ double s_Q[GRID_NT];      // inclusive prefix of scaled block sums
   __shared__ double s_iscale[GRID_NT];  // 1 / exp(max_b - M)
   __shared__ double s_myscale;          // exp(max_pb - M) of this block (weights finalisation)
   __shared__ double s_red[8];
   __shared__ double s_tot[PPT * 4];
-  constexpr bool kMfma = MP == 8 && PPT == 1 && !FN;  // fp64 MFMA transition (ssm_mng m = 8)
+  constexpr bool kMfma = MP == 8 && PPT == 1 && FN == FN_NONE;  // fp64 MFMA transition (ssm_mng m = 8)
   __shared__ double s_tile[kMfma ? 4 * 16 * 64 : 1];
   // per wave: the window of the source block's local scan its 64 slots fall into (the MFMA variant stages it in its
   // operand tile, which is idle during the search)
@@ -612,8 +680,8 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int li = r * GRID_NT + tid, j = base + li;
-      if (FN && !b.psi) {
-        if constexpr (FN) functor_initial<MP>(fpar, ini, key, (uint32_t)j, x[r]);
+      if (FN && !psi_mode) {
+        if constexpr (FN != FN_NONE) functor_initial<MP, FID>(fpar, ini, key, (uint32_t)j, x[r]);
       } else {
         double z[MP];
         rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)j, z);
@@ -816,15 +884,15 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
   #pragma unroll
         for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
         BSSM_STAMP(6)
-        if constexpr (FN) {
-          if (MP <= 2 && b.psi == 2) {
-            if constexpr (MP <= 2) functor_ekpf_propagate<MP>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
-          } else if (b.psi) {
+        if constexpr (FN != FN_NONE) {
+          if (MP <= 2 && psi_mode == 2) {
+            if constexpr (MP <= 2) functor_ekpf_propagate<MP, FID>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
+          } else if (psi_mode) {
             double z[KP];
             rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
             propagate<MP, KP>(mt, a, z, x[r]);
           } else {
-            functor_propagate<MP, KP>(fpar, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
+            functor_propagate<MP, KP, FID>(fpar, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
           }
 #pragma unroll
           for (int c = 0; c < MP; c++) aprev[r][c] = a[c];
@@ -858,7 +926,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
-    w[r] = (li < len) ? (have_obs ? weight_dispatch<MP, FN>(b, fpar, ob, (FN && b.psi == 2) ? amats : amats + (size_t)(t < 0 ? 0 : t) * (MP * MP + MP), tn, x[r], aprev[FN ? r : 0]) : 0.0) : -INFINITY;
+    w[r] = (li < len) ? (have_obs ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)(t < 0 ? 0 : t) * (MP * MP + MP), tn, x[r], aprev[FN ? r : 0]) : 0.0) : -INFINITY;
     mx = fmax(mx, w[r]);
   }
   BSSM_STAMP(8)
@@ -898,9 +966,16 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN)) pf_grid_
 #include "pf_grid_v2.h"
 namespace bssm {
 
+template <int MP, int KP, int PPT, int FNV>
+auto grid_fn_kernel(int psi) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
+  if constexpr (MP > 2) return pf_grid_step<MP, KP, PPT, false, FNV, 0>;
+  else return psi == 0 ? pf_grid_step<MP, KP, PPT, false, FNV, 0> : (psi == 1 ? pf_grid_step<MP, KP, PPT, false, FNV, 1> : pf_grid_step<MP, KP, PPT, false, FNV, 2>);
+}
 template <int MP, int KP>
 hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   const int ppt = ws.chunk / GRID_NT;
+  constexpr int kFn = fn_kernel_id<MP>();
+  if (b.fpar && kFn > 0 && b.fn_id != kFn) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
   void (*kern_init)(const FilterBatch, const GridWorkspace) = nullptr;  // round-2 kernels: the step t = -1 has its own
 #ifndef BSSM_USER_MODEL
@@ -915,10 +990,10 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   if (b.fpar) {
     if constexpr (MP == KP && MP <= FN_MP_MAX) {
       switch (ppt) {
-        case 1: kern = pf_grid_step<MP, KP, 1, false, true>; break;
-        case 2: kern = pf_grid_step<MP, KP, 2, false, true>; break;
-        case 4: kern = pf_grid_step<MP, KP, 4, false, true>; break;
-        default: kern = pf_grid_step<MP, KP, 8, false, true>; break;
+        case 1: kern = GRID_FN_KERNEL(1); break;
+        case 2: kern = GRID_FN_KERNEL(2); break;
+        case 4: kern = GRID_FN_KERNEL(4); break;
+        default: kern = GRID_FN_KERNEL(8); break;
       }
     } else {
       return hipErrorInvalidValue;

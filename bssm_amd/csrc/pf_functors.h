@@ -11,6 +11,10 @@ namespace bssm {
 
 enum { FN_NLG_GROWTH = 1, FN_NLG_AR_EXP = 2, FN_NLG_SIN_EXP = 3, FN_NLG_LINEAR_GAUSSIAN = 4, FN_SDE_GBM = 5, FN_SDE_POISSON_OU = 6,
        FN_USER_NLG = 7, FN_USER_SDE = 8 };  // 7 / 8: functions supplied by the user and compiled at run time (user_model_tu.hip)
+// The filter kernels carry the model family as a template value: FN_NONE (linear-state models), FN_ANY (functor model,
+// id read from the parameter block and dispatched per call) or a model id > 0 fixed at compile time -- the per-particle
+// code then contains one model's functions only (C5 device phase: 72 -> 62 ms with the growth model fixed)
+constexpr int FN_NONE = 0, FN_ANY = -1;
 __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || id == FN_SDE_POISSON_OU || id == FN_USER_SDE; }
 
 // ---- user-defined models (the reference's ssm_nlg / ssm_sde take arbitrary user C++ compiled at run time by
@@ -46,10 +50,10 @@ __device__ __forceinline__ void nlg_T_fn(int id, const double* __restrict__ fp, 
     case FN_NLG_GROWTH: {  // R/cpp_example_models.R:415-428
       const double dT = fp[FP_KNOWN + 0], K = fp[FP_KNOWN + 1];
       const double ea = tl_exp(a[0]);
-      const double r = ea / (1.0 + ea);
+      const double r = fdiv(ea, 1.0 + ea);
       const double e = tl_exp(r * dT);
       x[0] = a[0];
-      if constexpr (MP > 1) x[1] = K * a[1] * e / (K + a[1] * (e - 1.0));
+      if constexpr (MP > 1) x[1] = fdiv(K * a[1] * e, K + a[1] * (e - 1.0));
     } break;
     case FN_NLG_AR_EXP: x[0] = fp[FP_THETA + 0] * (1.0 - fp[FP_THETA + 1]) + fp[FP_THETA + 1] * a[0]; break;  // :296-300
     case FN_NLG_SIN_EXP: x[0] = sin(a[0]); break;                                                            // :726-730
@@ -137,10 +141,10 @@ __device__ __forceinline__ double milstein(int id, const double* __restrict__ fp
 }
 
 // ---- unified entry points used by the filter kernels when the FN template flag is set
-template <int MP>
+template <int MP, int FID = 0>
 __device__ __forceinline__ void functor_initial(const double* __restrict__ fp, const double* __restrict__ ini, RngKey key,
                                                 uint32_t i, double (&x)[MP]) {
-  const int id = (int)fp[FP_ID];
+  const int id = FID > 0 ? FID : (int)fp[FP_ID];
   if (fn_is_sde(id)) {  // alpha_0 = milstein(x0) (src/model_ssm_sde.cpp:25-28)
     x[0] = milstein(id, fp, key, RNG_INIT, 0u, i, fp[FP_X0]);
 #pragma unroll
@@ -158,10 +162,10 @@ __device__ __forceinline__ void functor_initial(const double* __restrict__ fp, c
   }
 }
 
-template <int MP, int KP>
+template <int MP, int KP, int FID = 0>
 __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp, RngKey key, const u32x4& blk0, uint32_t t,
                                                   uint32_t i, const double (&a)[MP], double (&x)[MP]) {
-  const int id = (int)fp[FP_ID];
+  const int id = FID > 0 ? FID : (int)fp[FP_ID];
   if (fn_is_sde(id)) {
     x[0] = milstein(id, fp, key, RNG_SDE, t, i, a[0]);
 #pragma unroll
@@ -206,12 +210,12 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
   }
 }
 
-template <int MP>
+template <int MP, int FID = 0>
 __device__ __forceinline__ double functor_log_weight(const double* __restrict__ fp, const double* __restrict__ row,
                                                      const double (&x)[MP]) {
   if (row[RH_FLAG] == 0.0) return 0.0;
   const double* __restrict__ ob = row + ROW_HDR;
-  const int id = (int)fp[FP_ID];
+  const int id = FID > 0 ? FID : (int)fp[FP_ID];
   const double y = ob[OB_Y];
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
   if (id == FN_USER_SDE) return bssm_user_log_obs(y, x[0], fp + FP_THETA);
@@ -237,12 +241,12 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
 // at the ANCESTOR.  H and R are constant in every shipped model, so the Gaussian normalisers cancel exactly.
 //   row  : observation row of time t (y, approximating D_t in OB_D, approximating Z_t after the header, 1/H in OB_PSIIH)
 //   amat : approximating T_{t-1} (MP x MP) and C_{t-1} (MP) -- only read when t > 0
-template <int MP>
+template <int MP, int FID = 0>
 __device__ __forceinline__ double functor_psi_weight(const double* __restrict__ fp, const double* __restrict__ row,
                                                      const double* __restrict__ amat, int t, const double (&x)[MP],
                                                      const double (&aprev)[MP]) {
   if (row[RH_FLAG] == 0.0) return 0.0;  // y_t missing: weights are ones, transition ratio included (:1040-1056)
-  const int id = (int)fp[FP_ID];
+  const int id = FID > 0 ? FID : (int)fp[FP_ID];
   double w = 0.0;
   {
     const double* __restrict__ ob = row + ROW_HDR;
@@ -262,7 +266,7 @@ __device__ __forceinline__ double functor_psi_weight(const double* __restrict__ 
       double am = amat[MP * MP + j];
 #pragma unroll
       for (int c = 0; c < MP; c++) am += amat[j + MP * c] * aprev[c];
-      const double ir = 1.0 / fp[FP_R + j];
+      const double ir = fdiv(1.0, fp[FP_R + j]);
       const double da = (x[j] - am) * ir, dm = (x[j] - mean[j]) * ir;
       w += 0.5 * (da * da - dm * dm);
     }
@@ -354,10 +358,10 @@ __device__ __forceinline__ double dmvnorm_lwr_small(const double (&x)[MP], const
   }
 }
 // the EKF proposal of one particle: at = T(anc); (att, Lf) = proposal mean and factor for the step to time tn
-template <int MP>
+template <int MP, int FID = 0>
 __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, const double* __restrict__ row, bool last,
                                               const double (&anc)[MP], double (&at)[MP], double (&att)[MP], double (&Lf)[MP * MP]) {
-  const int id = (int)fp[FP_ID];
+  const int id = FID > 0 ? FID : (int)fp[FP_ID];
   nlg_T_fn<MP>(id, fp, anc, at);
   double Pt[MP * MP];
 #pragma unroll
@@ -420,12 +424,12 @@ __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, con
   }
   psd_chol_small<MP>(Ptt, Lf);
 }
-template <int MP>
+template <int MP, int FID = 0>
 __device__ __forceinline__ void functor_ekpf_propagate(const double* __restrict__ fp, const double* __restrict__ row_next, bool last,
                                                        RngKey key, const u32x4& blk0, uint32_t t, uint32_t i,
                                                        const double (&anc)[MP], double (&x)[MP]) {
   double at[MP], att[MP], Lf[MP * MP], z[MP];
-  ekpf_proposal<MP>(fp, row_next, last, anc, at, att, Lf);
+  ekpf_proposal<MP, FID>(fp, row_next, last, anc, at, att, Lf);
   rng_normals_blk<MP>(blk0, key, RNG_TRANSITION, t, i, z);
 #pragma unroll
   for (int j = 0; j < MP; j++) {
@@ -436,12 +440,12 @@ __device__ __forceinline__ void functor_ekpf_propagate(const double* __restrict_
   }
 }
 // EKPF weight at time t (:1178-1182 for t = 0, :1236-1244 after): `init` = [a1 | P1 | att1 | L1] of the filter
-template <int MP>
+template <int MP, int FID = 0>
 __device__ __forceinline__ double functor_ekpf_weight(const double* __restrict__ fp, const double* __restrict__ row,
                                                       const double* __restrict__ init, int t, const double (&x)[MP],
                                                       const double (&anc)[MP]) {
   if (row[RH_FLAG] == 0.0) return 0.0;
-  double w = functor_log_weight<MP>(fp, row, x);
+  double w = functor_log_weight<MP, FID>(fp, row, x);
   if (t == 0) {
     double a1[MP], P1[MP * MP], att1[MP], L1[MP * MP];
 #pragma unroll
@@ -451,7 +455,7 @@ __device__ __forceinline__ double functor_ekpf_weight(const double* __restrict__
     return w + dmvnorm_cov_small<MP>(x, a1, P1) - dmvnorm_lwr_small<MP>(x, att1, L1);
   }
   double at[MP], att[MP], Lf[MP * MP], RR[MP * MP];
-  ekpf_proposal<MP>(fp, row, false, anc, at, att, Lf);
+  ekpf_proposal<MP, FID>(fp, row, false, anc, at, att, Lf);
 #pragma unroll
   for (int q = 0; q < MP * MP; q++) RR[q] = 0.0;
 #pragma unroll

@@ -37,6 +37,7 @@ struct FilterBatch {
   double* loglik;       // [f]              sum_t (max_t + log mean exp), no constants
   int* dead_at;         // [f] 0 = alive, else (time whose weights were degenerate) + 1; zeroed by the launcher
   int user_slot;        // 0, or the registry slot of a run-time compiled user model whose library holds the kernels
+  int fn_id;            // functor models: the model id of the parameter blocks (all filters of a batch share it)
 };
 
 // Largest N the workgroup-resident kernel can hold for a given padded state size
