@@ -1121,7 +1121,11 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   if (n_states < 1 || n_states > 4) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 ... 4");
   const std::string dir = library_dir();
   const char* env = std::getenv("BSSM_AMD_USER_CACHE");
-  const std::string cache = env ? std::string(env) : dir + "/user_models";
+  std::string cache = env ? std::string(env) : dir + "/user_models";
+  if (!env && access(dir.c_str(), W_OK) != 0) {  // the package directory is read-only (a system-wide install): a per-user cache
+    const char* home = std::getenv("HOME");
+    cache = std::string(home ? home : "/tmp") + "/.cache/bssm_amd/user_models";
+  }
   // the cache key covers everything that is compiled into the library: the kernel headers, the state dimension, the snippet
   std::string key = std::string(bssm_amd_version()) + "|" + std::to_string(n_states) + "|" + source;
   for (const char* hdr : {"pf_filter_impl.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "user_model_tu.hip"}) {
@@ -1137,8 +1141,9 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   const std::string stem = cache + "/um_" + hbuf, snippet = stem + ".h", so = cache + "/libbssm_user_" + hbuf + ".so", log = stem + ".log";
   if ((int)so.size() + 1 > lib_path_capacity) return fail(BSSM_ERR_INVALID, "lib_path buffer too small");
   // the paths go through a shell command line inside single quotes: refuse anything that could end the quoting
-  for (const std::string* pth : {&dir, &cache})
-    if (pth->find('\'') != std::string::npos || pth->find('\n') != std::string::npos)
+  // (and the snippet path sits inside a double-quoted -D value: no double quote or backslash either)
+  for (const std::string* pth : {&dir, (const std::string*)&cache})
+    if (pth->find_first_of("'\"\\\n") != std::string::npos)
       return fail(BSSM_ERR_INVALID, "unsupported character in the library / cache path: " + *pth);
   std::lock_guard<std::mutex> lk(g_user_mu);
   if (FILE* f = std::fopen(so.c_str(), "rb")) {  // already built: the hash covers the source, n_states and the version
@@ -1147,16 +1152,24 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
     return BSSM_OK;
   }
   if (std::system(("mkdir -p '" + cache + "'").c_str()) != 0) return fail(BSSM_ERR_INVALID, "cannot create " + cache);
-  FILE* f = std::fopen(snippet.c_str(), "w");
-  if (!f) return fail(BSSM_ERR_INVALID, "cannot write " + snippet);
+  // several processes (ranks) may build the same model at once: every file of a build carries the pid until it is complete,
+  // so no process ever reads a file another one is writing; the finished library appears by one rename
+  const std::string pid = std::to_string((long)getpid());
+  const std::string snippet_final = snippet, log_final = log;
+  const std::string snippet_tmp = stem + "." + pid + ".h", log_tmp = stem + "." + pid + ".log";
+  FILE* f = std::fopen(snippet_tmp.c_str(), "w");
+  if (!f) return fail(BSSM_ERR_INVALID, "cannot write " + snippet_tmp);
   std::fputs(source, f);
   std::fclose(f);
-  const std::string tmp = so + ".tmp." + std::to_string((long)getpid());  // several ranks may build the same model at once
+  const std::string tmp = so + ".tmp." + pid;
   const char* hipcc = std::getenv("HIPCC");
   const std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I'" + dir +
-                          "/csrc' -DBSSM_USER_M=" + std::to_string(bssm::pad_dim(n_states)) + " -DBSSM_USER_NSTATES=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet + "\"' '" + dir +
-                          "/csrc/user_model_tu.hip' -o '" + tmp + "' > '" + log + "' 2>&1 && mv '" + tmp + "' '" + so + "'";
-  if (std::system(cmd.c_str()) != 0) {
+                          "/csrc' -DBSSM_USER_M=" + std::to_string(bssm::pad_dim(n_states)) + " -DBSSM_USER_NSTATES=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet_tmp + "\"' '" + dir +
+                          "/csrc/user_model_tu.hip' -o '" + tmp + "' > '" + log_tmp + "' 2>&1 && mv '" + tmp + "' '" + so + "'";
+  const int build_rc = std::system(cmd.c_str());
+  (void)std::rename(snippet_tmp.c_str(), snippet_final.c_str());  // kept next to the library for reference
+  (void)std::rename(log_tmp.c_str(), log_final.c_str());
+  if (build_rc != 0) {
     std::string tail;
     if (FILE* lf = std::fopen(log.c_str(), "r")) {
       char buf[4096];
