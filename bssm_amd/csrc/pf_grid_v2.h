@@ -18,7 +18,16 @@
 //     windows of their local scans) replaces the unrolled 16-ary per-lane fallbacks: a wave that straddles a block
 //     boundary, a ragged wave or a wide window costs a second trip through the same cooperative code;
 //   * the observation density is selected by a wave-uniform switch OUTSIDE the particle loop (one density body runs);
-//   * table-driven log / exp / sincos (pf_math.h).
+//   * table-driven log / exp / sincos (pf_math.h);
+//   * ONE SEARCH PER WAVE.  A wave owns 64 * PPT CONSECUTIVE output slots (row r of a lane is slot wave * 64 PPT + 64 r +
+//     lane, so every load / store instruction still covers 64 consecutive slots).  For the search the resampling
+//     uniforms are transposed through the wave's LDS window so that a lane holds PPT consecutive slots: the wave's
+//     targets are then one contiguous stratum range, and source block (two ballots), coarse row and window are found
+//     ONCE per wave instead of once per particle row (an experiment build that merely reused row 0's search for the
+//     other rows ran +16 %); the PPT bisections of a lane advance together, branch-free, over a window padded with
+//     +inf; the ancestors go back through LDS to the row layout.  A wave whose range crosses ONE block boundary (63 of a
+//     65 536-particle filter's 256 waves at four particles per lane) stays on the fast path: its window is the tail of
+//     one block's local scan followed by the head of the next one's, and each particle bisects its own segment.
 #pragma once
 
 // analysis builds (-DBSSM_V2_MARKS): comment markers in the ISA listing at the phase boundaries (scripts/isa_phases.py)
@@ -30,7 +39,11 @@
 
 namespace bssm {
 
-constexpr int V2_WIN = 128;  // entries of a source block's local scan staged per (wave, particle row)
+constexpr int V2_WIN = 128;  // entries of a source block's local scan staged per wave and particle of a lane
+
+constexpr int v2_log2(int x) { return x <= 1 ? 0 : 1 + v2_log2(x >> 1); }
+// slot (inside its block) of row r of thread tid: a wave owns 64 * PPT consecutive slots, a row 64 consecutive ones
+template <int PPT> __device__ __forceinline__ int v2_li(int r, int tid) { return (tid >> 6) * (64 * PPT) + r * 64 + (tid & 63); }
 
 // number of entries of sw[0, wlen) below vp (entries non-decreasing), wlen <= 128; exact when STEPS = 8, min(count, 127)
 // when STEPS = 7
@@ -215,28 +228,28 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
   for (int r = 0; r < PPT; r++) {
     e[r] = tl_exp(w[r] - Mws);  // inactive slots carry w = -inf: 0
     sc[r] = wave_scan_incl(e[r]);
-    if (lane == 63) s_x[4 + r * 4 + wave] = sc[r];
+    if (lane == 63) s_x[4 + wave * PPT + r] = sc[r];
     __builtin_amdgcn_sched_barrier(0);
   }
   if (lane == 0) s_x[wave] = Mw;
   lds_barrier();
-  // every wave combines the 4 wave maxima and the 4 * PPT chunk totals (chunks in particle order: q = 4 r + wave)
+  // every wave combines the 4 wave maxima and the 4 * PPT chunk totals (chunks in particle order: q = PPT wave + r)
   const double m0 = s_x[0], m1 = s_x[1], m2 = s_x[2], m3 = s_x[3];
   const double Mb = fmax(fmax(m0, m1), fmax(m2, m3));
   const double Mbs = Mb == -INFINITY ? 0.0 : Mb;
-  const int qw = lane & 3;
+  const int qw = (lane / PPT) & 3;  // chunk `lane` belongs to wave lane / PPT
   const double Mq = qw == 0 ? m0 : (qw == 1 ? m1 : (qw == 2 ? m2 : m3));
-  const double scq = tl_exp(Mq - Mbs);                       // lanes 0..3 (and their repeats): exp(max_wave - max_block)
+  const double scq = tl_exp(Mq - Mbs);                       // lane q: exp(max of chunk q's wave - max_block)
   const double tq = lane < 4 * PPT ? s_x[4 + lane] : 0.0;
   const double incl = wave_scan_incl(tq * scq);              // lanes >= 4 PPT add zeros
   const double total = lane_broadcast(incl, 4 * PPT - 1);
-  const double swv = lane_broadcast(scq, wave);
+  const double swv = lane_broadcast(scq, wave * PPT);
   double* __restrict__ lcdf_new = uniform_ptr(ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N + base);
   double* __restrict__ coarse_new = uniform_ptr(ws.coarse + (((size_t)(tn & 1) * b.F + f) * B + pb) * crow);
   double* __restrict__ wout = b.weights ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + tn) * N + base) : nullptr;
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
-    const int q = r * 4 + wave, li = r * GRID_NT + tid;
+    const int q = wave * PPT + r, li = v2_li<PPT>(r, tid);
     const double off = q == 0 ? 0.0 : lane_broadcast(incl, (q - 1) & 63);
     const double lc = __builtin_fma(sc[r], swv, off);
     if (li < len) {
@@ -292,7 +305,7 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, 
   double s[PPT], w[PPT], xs[MS ? PPT : 1][MP];
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
-    const int li = r * GRID_NT + tid;
+    const int li = v2_li<PPT>(r, tid);
     double z[MP], x[MP];
     rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)(base + li), z);
     initial_state<MP>(ini, z, x);
@@ -315,8 +328,53 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, 
     for (int r = 0; r < PPT; r++) w[r] = 0.0;
   }
 #pragma unroll
-  for (int r = 0; r < PPT; r++) if (r * GRID_NT + tid >= len) w[r] = -INFINITY;
+  for (int r = 0; r < PPT; r++) if (v2_li<PPT>(r, tid) >= len) w[r] = -INFINITY;
   v2_block_stats<PPT>(b, ws, f, pb, base, len, 0, w, s_x);
+}
+
+// Ancestors of a wave's 64 * PPT consecutive slots whose targets fall into one source block (TWO = false) or into two
+// neighbouring ones (TWO = true): the window staged in `sw` holds rows [k_lo, ...) of block e1's local scan and, with
+// TWO, the first rows of block e2's behind them, then +inf up to 128 * PPT entries; every particle bisects its own block's
+// segment.  The bisections of a lane's particles advance together (PPT independent LDS reads in flight per step) and
+// are branch-free (the loads are pinned: the compiler otherwise turns the length test into a branch around each read).
+//   vp[r]: the target in its source block's local scale;  in2 bit r: particle r's source block is e2
+template <int PPT, bool TWO>
+__device__ __forceinline__ void v2_window_ancestors(const double* sw, const double (&vp)[PPT], const unsigned in2, const int e1, const int e2,
+                                                    const int w0, const int len1, const int len2, const int slen1, const int slen2,
+                                                    int (&anc)[PPT]) {
+  constexpr int chunk = GRID_NT * PPT, STEPS = 7 + v2_log2(PPT);
+  int lo[PPT], off[PPT], seg[PPT];
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    lo[r] = 0;
+    if constexpr (TWO) { const bool second = (in2 >> r) & 1u; off[r] = second ? len1 : 0; seg[r] = second ? max(len2, 1) : len1; }
+  }
+#pragma unroll
+  for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
+    double x[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      if constexpr (TWO) x[r] = sw[off[r] + min(lo[r] + step - 1, seg[r] - 1)];
+      else x[r] = sw[lo[r] + step - 1];  // (entries beyond the window are +inf)
+    }
+#pragma unroll
+    for (int r = 0; r < PPT; r++) __asm__ volatile("" : "+v"(x[r]));
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      bool below = x[r] < vp[r];
+      if constexpr (TWO) below = below && lo[r] + step - 1 < seg[r];
+      lo[r] += below ? step : 0;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < PPT; r++) {
+    if constexpr (TWO) {
+      const bool second = (in2 >> r) & 1u;
+      anc[r] = second ? e2 * chunk + min(lo[r], slen2 - 1) : e1 * chunk + min(w0 + lo[r], slen1 - 1);
+    } else {
+      anc[r] = e1 * chunk + min(w0 + lo[r], slen1 - 1);
+    }
+  }
 }
 
 // t in [0, n): resample on the time-t weights, propagate to t+1, weigh at t+1 (ones when t+1 == n or y_{t+1} is missing)
@@ -330,6 +388,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #endif
   constexpr bool kMfma = MS && MP == 8 && PPT <= BSSM_V2_MFMA_PPT;
   __shared__ double s_win[kMfma ? 4 * 8 * 64 : 4 * PPT * V2_WIN];
+  static_assert(!kMfma || PPT * V2_WIN <= 8 * 64, "the MFMA operand tile doubles as the search window");
   __shared__ double s_x[4 + 4 * PPT];
   __shared__ double s_comb[3 * 64 + 1];  // combine of wave 0: block prefixes, 1 / scale, scale, global maximum
   // T_t, R_t, C_t of this step.  Read from LDS (broadcast ds_read, same address in every lane) and not through scalar
@@ -360,7 +419,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   double wt_old[PPT];
   if (wt) {
 #pragma unroll
-    for (int r = 0; r < PPT; r++) { const int li = r * GRID_NT + tid; wt_old[r] = li < len ? ld32(wt, li) : 0.0; }
+    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wt_old[r] = li < len ? ld32(wt, li) : 0.0; }
   }
   V2_MARK("combine");
   if (wave == 0) {
@@ -378,7 +437,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   if (tid < NMAT) s_mat[tid] = (b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride)[tid];
   u32x4 blk[PPT];
 #pragma unroll
-  for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + r * GRID_NT + tid));
+  for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + v2_li<PPT>(r, tid)));
   math_tab_load_end256(mtab);
   lds_barrier();  // (1)
   const double Q = s_comb[lane], iscale = s_comb[64 + lane], S = s_comb[63], M = s_comb[192];
@@ -386,7 +445,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   if (wt) {  // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
     const double myscale = s_comb[128 + pb];
 #pragma unroll
-    for (int r = 0; r < PPT; r++) { const int li = r * GRID_NT + tid; if (li < len) st32(wt, li, wt_old[r] * myscale); }
+    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); if (li < len) st32(wt, li, wt_old[r] * myscale); }
   }
   if (!(S > 0.0)) {
     // degenerate weights (src/model_ssm_ung.cpp:678-682): stop and poison this block's slot of the next parity, so every
@@ -410,74 +469,106 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   double* sw_base = s_win + wave * (kMfma ? 8 * 64 : PPT * V2_WIN);
 
   V2_MARK("phaseA");
-  // ---- phase A: step blocks, targets, source block (two ballots), coarse row of the source block in flight
-  double vp[PPT], cv[PPT];
-  int sbk[PPT];
-  unsigned slow = 0;  // bit r: particle row r goes through the generic search
+  // ---- phase A (once per wave): the resampling uniforms go through the wave's LDS window so that a lane holds PPT
+  // CONSECUTIVE slots (wave * 64 PPT + PPT lane + q); targets; the source blocks of the wave's first and last target (two
+  // ballots over the block prefixes); coarse rows of those blocks in flight
+  constexpr int WIN = PPT * V2_WIN;  // window entries per wave
+  uint32_t* sw_u32 = (uint32_t*)sw_base;
+  if constexpr (PPT > 1) {
 #pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    const int li = r * GRID_NT + tid, j = base + li;
-    const double v = (block_uniform(blk[r]) + (double)j) * c_scale;
-    const bool full = r * GRID_NT + (wave + 1) * 64 <= len;  // wave-uniform
-    const double v_lo = lane_broadcast(v, 0), v_hi = lane_broadcast(v, 63);
+    for (int r = 0; r < PPT; r++) sw_u32[r * 64 + lane] = blk[r].w;
+    lds_wave_sync();
+  }
+  double vp[PPT];
+  unsigned in2 = 0;  // bit q: particle q draws from the second of the wave's two source blocks
+  bool slow = (wave + 1) * 64 * PPT > len;  // wave-uniform: a ragged wave goes through the generic search
+  int e1, e2, slen1, slen2, ncr1, ncr2;
+  double cv1, cv2;
+  {
+    double v[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; q++) {
+      const uint32_t u = PPT > 1 ? sw_u32[PPT * lane + q] : blk[0].w;
+      v[q] = ((double)u * 0x1.0p-32 + (double)(base + wave * (64 * PPT) + PPT * lane + q)) * c_scale;
+    }
+    const double v_lo = lane_broadcast(v[0], 0), v_hi = lane_broadcast(v[PPT - 1], 63);
     const int c_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_lo));
     const int c_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_hi));
-    const int sb = min(c_lo, B - 1);
-    sbk[r] = sb;
-    if (!full || c_lo != c_hi) slow |= 1u << r;
-    const double Pm1 = sb > 0 ? lane_broadcast(Q, (sb - 1) & 63) : 0.0;
-    vp[r] = (v - Pm1) * lane_broadcast(iscale, sb);
-    const int ncr = (min(chunk, N - sb * chunk) + 15) >> 4;
-    cv[r] = ld32(coarse + (size_t)sb * crow, lane < ncr ? lane : ncr - 1);
+    e1 = min(c_lo, B - 1); e2 = min(c_hi, B - 1);
+    if (e2 > e1 + 1) { slow = true; e2 = e1; }
+    const double Pm1 = e1 > 0 ? lane_broadcast(Q, (e1 - 1) & 63) : 0.0;
+    const double is1 = lane_broadcast(iscale, e1);
+    slen1 = min(chunk, N - e1 * chunk); ncr1 = (slen1 + 15) >> 4;
+    slen2 = min(chunk, N - e2 * chunk); ncr2 = (slen2 + 15) >> 4;
+    cv1 = ld32(coarse + (size_t)e1 * crow, lane < ncr1 ? lane : ncr1 - 1);
+    if (e2 != e1) {
+      const double P1 = lane_broadcast(Q, e1), is2 = lane_broadcast(iscale, e2);
+      cv2 = ld32(coarse + (size_t)e2 * crow, lane < ncr2 ? lane : ncr2 - 1);
+#pragma unroll
+      for (int q = 0; q < PPT; q++) {
+        const bool second = P1 < v[q];  // the rule of the generic search: the source block is the number of prefixes below v
+        in2 |= second ? 1u << q : 0u;
+        vp[q] = second ? (v[q] - P1) * is2 : (v[q] - Pm1) * is1;
+      }
+    } else {
+      cv2 = cv1;
+#pragma unroll
+      for (int q = 0; q < PPT; q++) vp[q] = (v[q] - Pm1) * is1;
+    }
   }
   V2_MARK("phaseB");
-  // ---- phase B: rows of the source block the wave's slots fall into; their entries (<= 128) in flight
-  double wr0[PPT], wr1[PPT];
-  int w0k[PPT], wlenk[PPT];
+  // ---- phase B: the rows of the source blocks the wave's targets fall into; their entries (<= 128 per particle of a lane)
+  // in flight -- only as many loads as the window has entries
+  int w0, len1, len2;
+  {
+    double wr[2 * PPT];
+    const double vp_lo = lane_broadcast(vp[0], 0), vp_hi = lane_broadcast(vp[PPT - 1], 63);
+    const int k_lo = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr1 && cv1 < vp_lo)), ncr1 - 1);
+    const int k_hi = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr2 && cv2 < vp_hi)), ncr2 - 1);
+    w0 = 16 * k_lo;
+    if (e2 != e1) { len1 = slen1 - w0; len2 = min(16 * (k_hi + 1), slen2); }
+    else { len1 = max(1, min(16 * (k_hi + 1), slen1) - w0); len2 = 0; }
+    int total = len1 + len2;
+    if (total > WIN) { slow = true; total = 1; len1 = 1; len2 = 0; }
+    const uint32_t off1 = (uint32_t)(e1 * chunk + w0), off2 = (uint32_t)(e2 * chunk - len1);
 #pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    const int sb = sbk[r];
-    const int slen = min(chunk, N - sb * chunk), ncr = (slen + 15) >> 4;
-    const double vp_lo = lane_broadcast(vp[r], 0), vp_hi = lane_broadcast(vp[r], 63);
-    const int k_lo = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv[r] < vp_lo)), ncr - 1);
-    const int k_hi = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv[r] < vp_hi)), ncr - 1);
-    const int w0 = 16 * k_lo, wend = min(16 * (k_hi + 1), slen);
-    if (wend - w0 > V2_WIN) slow |= 1u << r;
-    const int wlen = max(1, min(V2_WIN, wend - w0));  // (rows headed for the generic search may carry an empty range)
-    w0k[r] = w0; wlenk[r] = wlen;
-    const double* __restrict__ src = lcdf + (size_t)sb * chunk + w0;  // uniform
-    wr0[r] = ld32(src, lane < wlen ? lane : wlen - 1);
-    wr1[r] = ld32(src, lane + 64 < wlen ? lane + 64 : wlen - 1);
-  }
-  V2_MARK("phaseC");
-  // ---- phase C: windows to LDS (one per particle row: no reuse, no fences between rows), bisection, ancestors
+    for (int q = 0; q < 2 * PPT; q++) {
+      wr[q] = __builtin_huge_val();
+      if (q * 64 < total) {  // wave-uniform
+        const int i = min(q * 64 + lane, total - 1);
+        wr[q] = ld32(lcdf, (i < len1 ? off1 : off2) + (uint32_t)i);
+      }
+    }
+    V2_MARK("phaseC");
+    // ---- phase C: window to LDS (+inf behind its entries), bisection, ancestors back to the row layout
+    if constexpr (PPT > 1) lds_wave_sync();  // the transposed uniforms have been read
 #pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    double* sw = sw_base + r * V2_WIN;
-    sw[lane] = wr0[r];
-    sw[lane + 64] = wr1[r];
+    for (int q = 0; q < 2 * PPT; q++) sw_base[q * 64 + lane] = wr[q];
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  lds_wave_sync();
   int anc[PPT];
+  if (e2 != e1) v2_window_ancestors<PPT, true>(sw_base, vp, in2, e1, e2, w0, len1, len2, slen1, slen2, anc);
+  else v2_window_ancestors<PPT, false>(sw_base, vp, in2, e1, e2, w0, len1, len2, slen1, slen2, anc);
+  if constexpr (PPT > 1) {  // anc[q] is the ancestor of slot PPT lane + q: back through LDS to rows of 64 consecutive slots
+    lds_wave_sync();
 #pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    const int sb = sbk[r];
-    const int slen = min(chunk, N - sb * chunk);
-    const int cnt = v2_count_below<7>(sw_base + r * V2_WIN, wlenk[r], vp[r]);
-    anc[r] = sb * chunk + min(w0k[r] + cnt, slen - 1);
+    for (int q = 0; q < PPT; q++) sw_u32[PPT * lane + q] = (uint32_t)anc[q];
+    lds_wave_sync();
+#pragma unroll
+    for (int r = 0; r < PPT; r++) anc[r] = (int)sw_u32[r * 64 + lane];
   }
   V2_MARK("slow");
-  if (slow) {  // wave-uniform, rare: a block boundary inside the wave's slots, a ragged wave, or a window beyond 128 entries
+  if (slow) {  // wave-uniform, rare: more than one block boundary inside the wave's slots, a ragged wave, or a window beyond WIN
+               // entries: the cooperative search row by row (64 consecutive slots each)
+    lds_wave_sync();
 #pragma unroll 1
     for (int r = 0; r < PPT; r++) {
-      if (!((slow >> r) & 1u)) continue;
       uint32_t ur = blk[0].w;
 #pragma unroll
       for (int q = 1; q < PPT; q++) ur = (r == q) ? blk[q].w : ur;  // r is wave-uniform: scalar compare + select
-      const double vr = ((double)ur * 0x1.0p-32 + (double)(base + r * GRID_NT + tid)) * c_scale;  // the target, as in phase A
-      const int ar = v2_search_generic<PPT>(vr, r * GRID_NT + tid < len, Q, iscale, B, N, coarse, lcdf, sw_base, lane);
+      const int li = v2_li<PPT>(r, tid);
+      const double vr = ((double)ur * 0x1.0p-32 + (double)(base + li)) * c_scale;  // the target, as in phase A
+      const int ar = v2_search_generic<PPT>(vr, li < len, Q, iscale, B, N, coarse, lcdf, sw_base, lane);
 #pragma unroll
       for (int q = 0; q < PPT; q++) anc[q] = (r == q) ? ar : anc[q];
     }
@@ -487,7 +578,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   double a[PPT][MP];
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
-    const int li = r * GRID_NT + tid;
+    const int li = v2_li<PPT>(r, tid);
     if (li >= len) anc[r] = 0;
     if (idx_out && li < len) st32(idx_out, li, (uint32_t)anc[r]);
 #pragma unroll
@@ -500,7 +591,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   double s[PPT], w[PPT], xs[MS ? PPT : 1][MP];
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
-    const int li = r * GRID_NT + tid, j = base + li;
+    const int li = v2_li<PPT>(r, tid), j = base + li;
     double z[KP], x[MP];
     rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
     if constexpr (kMfma) {
@@ -532,7 +623,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   }
   V2_MARK("stats");
 #pragma unroll
-  for (int r = 0; r < PPT; r++) if (r * GRID_NT + tid >= len) w[r] = -INFINITY;
+  for (int r = 0; r < PPT; r++) if (v2_li<PPT>(r, tid) >= len) w[r] = -INFINITY;
   v2_block_stats<PPT>(b, ws, f, pb, base, len, tn, w, s_x);
 }
 
