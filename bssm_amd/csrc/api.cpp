@@ -96,9 +96,20 @@ struct DeviceArena {
       }
     }
     hipError_t e = raw_alloc(out, want);
-    if (e != hipSuccess) {  // out of memory: give the cache back and retry once
-      (void)hipGetLastError();
-      trim();
+    while (e != hipSuccess) {  // out of memory: give cached blocks back, largest first, until the request fits (freeing
+      (void)hipGetLastError();  // the whole cache -- tens of GB after a large job -- stalls the caller for seconds)
+      void* victim = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        auto best = free_blocks.end();
+        for (auto it = free_blocks.begin(); it != free_blocks.end(); ++it)
+          if (it->first.first == dev && (best == free_blocks.end() || it->first.second > best->first.second)) best = it;
+        if (best == free_blocks.end()) break;
+        victim = best->second;
+        cached -= best->first.second;
+        free_blocks.erase(best);
+      }
+      raw_free(victim);
       e = raw_alloc(out, want);
     }
     *got = want;

@@ -1003,7 +1003,11 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   // round-2 step kernel (pf_grid_v2.h): linear-state models with one observation series, at most 64 particle blocks
   bool v2ms = false;
   if constexpr (MP <= 8) {
+#ifdef BSSM_V2_STAMPS
+    bool v2 = !b.fpar && ws.B <= 64 && ppt <= 4;
+#else
     bool v2 = !b.fpar && ws.B <= 64 && ppt <= 4 && !ws.dbg;
+#endif
     if (const char* env = std::getenv("BSSM_AMD_GRID_V2")) v2 = v2 && env[0] != '0';
     if constexpr (MP <= 4) {
       if (v2 && b.p == 1) {

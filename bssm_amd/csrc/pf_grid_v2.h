@@ -36,6 +36,19 @@
 #else
 #define V2_MARK(name)
 #endif
+// analysis builds (-DBSSM_V2_STAMPS): shader-clock stamps of one wave at the phase boundaries (scripts/v2_phase_probe.py
+// through bssm_plan_debug_timeline)
+#ifdef BSSM_V2_STAMPS
+#define V2_STAMP(k)                                                                                  \
+  do {                                                                                               \
+    __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+    if (ws.dbg && blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 64 && t >= 1)                   \
+      ws.dbg[(size_t)t * 16 + (k)] = (long long)__builtin_readcyclecounter();                        \
+    __asm__ volatile("" ::: "memory");                                                               \
+  } while (0)
+#else
+#define V2_STAMP(k)
+#endif
 
 namespace bssm {
 
@@ -406,7 +419,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   const int base = pb * chunk, len = min(chunk, N - base);
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
 
-  V2_MARK("loads");
+  V2_MARK("loads"); V2_STAMP(0);
   // ---- exchange loads: the (max, sum) partials of the time-t weights, one block per lane -- combined by wave 0 only
   // (global maximum, scaled block sums, their inclusive prefix, total; the polynomial exp needs no table) while every
   // wave draws the step blocks of its particles (integer work, independent of the exchange); barrier (1) then
@@ -421,7 +434,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #pragma unroll
     for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wt_old[r] = li < len ? ld32(wt, li) : 0.0; }
   }
-  V2_MARK("combine");
+  V2_MARK("combine"); V2_STAMP(1);
   if (wave == 0) {
     const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
     double pmax = -INFINITY, psum = 0.0;
@@ -441,7 +454,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   math_tab_load_end256(mtab);
   lds_barrier();  // (1)
   const double Q = s_comb[lane], iscale = s_comb[64 + lane], S = s_comb[63], M = s_comb[192];
-  V2_MARK("rmw");
+  V2_MARK("rmw"); V2_STAMP(2);
   if (wt) {  // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
     const double myscale = s_comb[128 + pb];
 #pragma unroll
@@ -468,7 +481,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   uint32_t* __restrict__ idx_out = b.indices ? uniform_ptr(b.indices + ((size_t)f * n + t) * N + base) : nullptr;
   double* sw_base = s_win + wave * (kMfma ? 8 * 64 : PPT * V2_WIN);
 
-  V2_MARK("phaseA");
+  V2_MARK("phaseA"); V2_STAMP(3);
   // ---- phase A (once per wave): the resampling uniforms go through the wave's LDS window so that a lane holds PPT
   // CONSECUTIVE slots (wave * 64 PPT + PPT lane + q); targets; the source blocks of the wave's first and last target (two
   // ballots over the block prefixes); coarse rows of those blocks in flight
@@ -500,10 +513,11 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     const double is1 = lane_broadcast(iscale, e1);
     slen1 = min(chunk, N - e1 * chunk); ncr1 = (slen1 + 15) >> 4;
     slen2 = min(chunk, N - e2 * chunk); ncr2 = (slen2 + 15) >> 4;
-    cv1 = ld32(coarse + (size_t)e1 * crow, lane < ncr1 ? lane : ncr1 - 1);
+    auto coarse_row = [&](int e, int ncr) -> double { return ld32(coarse + (size_t)e * crow, lane < ncr ? lane : ncr - 1); };
+    cv1 = coarse_row(e1, ncr1);
     if (e2 != e1) {
       const double P1 = lane_broadcast(Q, e1), is2 = lane_broadcast(iscale, e2);
-      cv2 = ld32(coarse + (size_t)e2 * crow, lane < ncr2 ? lane : ncr2 - 1);
+      cv2 = coarse_row(e2, ncr2);
 #pragma unroll
       for (int q = 0; q < PPT; q++) {
         const bool second = P1 < v[q];  // the rule of the generic search: the source block is the number of prefixes below v
@@ -516,7 +530,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       for (int q = 0; q < PPT; q++) vp[q] = (v[q] - Pm1) * is1;
     }
   }
-  V2_MARK("phaseB");
+  V2_MARK("phaseB"); V2_STAMP(4);
   // ---- phase B: the rows of the source blocks the wave's targets fall into; their entries (<= 128 per particle of a lane)
   // in flight -- only as many loads as the window has entries
   int w0, len1, len2;
@@ -539,7 +553,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
         wr[q] = ld32(lcdf, (i < len1 ? off1 : off2) + (uint32_t)i);
       }
     }
-    V2_MARK("phaseC");
+    V2_MARK("phaseC"); V2_STAMP(5);
     // ---- phase C: window to LDS (+inf behind its entries), bisection, ancestors back to the row layout
     if constexpr (PPT > 1) lds_wave_sync();  // the transposed uniforms have been read
 #pragma unroll
@@ -557,7 +571,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #pragma unroll
     for (int r = 0; r < PPT; r++) anc[r] = (int)sw_u32[r * 64 + lane];
   }
-  V2_MARK("slow");
+  V2_MARK("slow"); V2_STAMP(6);
   if (slow) {  // wave-uniform, rare: more than one block boundary inside the wave's slots, a ragged wave, or a window beyond WIN
                // entries: the cooperative search row by row (64 consecutive slots each)
     lds_wave_sync();
@@ -573,7 +587,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       for (int q = 0; q < PPT; q++) anc[q] = (r == q) ? ar : anc[q];
     }
   }
-  V2_MARK("phaseD");
+  V2_MARK("phaseD"); V2_STAMP(7);
   // ---- phase D: ancestor indices out, ancestor states in flight
   double a[PPT][MP];
 #pragma unroll
@@ -584,7 +598,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #pragma unroll
     for (int c = 0; c < MP; c++) a[r][c] = (c < m) ? ld32(st_old + (size_t)c * N, anc[r]) : 0.0;
   }
-  V2_MARK("phaseE");
+  V2_MARK("phaseE"); V2_STAMP(8);
   // ---- phase E: transition normals, alpha_{t+1} = C_t + T_t a + R_t eta (:663-670), signal at t+1
   const bool have_obs = tn < n;
   const cdbl* row = as_uniform_table(b.obs + (size_t)f * b.obs_fstride + (size_t)(have_obs ? tn : 0) * (ROW_HDR + (MS ? b.p : 1) * (SER_HDR + MP)));
@@ -613,7 +627,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     }
     __builtin_amdgcn_sched_barrier(0);  // particles one after the other: bounds the live registers of the transcendental code
   }
-  V2_MARK("density");
+  V2_MARK("density"); V2_STAMP(9);
   if (have_obs && row[RH_FLAG] != 0.0) {
     if constexpr (MS) v2_log_weights_multi<MP, PPT>(b.p, row, b.psi != 0, xs, w);
     else v2_log_weights<PPT>(row, b.psi != 0, s, w);
@@ -621,10 +635,11 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #pragma unroll
     for (int r = 0; r < PPT; r++) w[r] = 0.0;
   }
-  V2_MARK("stats");
+  V2_MARK("stats"); V2_STAMP(10);
 #pragma unroll
   for (int r = 0; r < PPT; r++) if (v2_li<PPT>(r, tid) >= len) w[r] = -INFINITY;
   v2_block_stats<PPT>(b, ws, f, pb, base, len, tn, w, s_x);
+  V2_STAMP(11);
 }
 
 }  // namespace bssm
