@@ -298,6 +298,10 @@ def run_mcmc(model: BssmModel, iter: int, particles: int | None = None, output_t
         res["alphahat"], res["Vt"] = np.ascontiguousarray(ah.T), vt
     res["theta"] = np.array(res["theta"])
     res["theta"][:, tr] = np.exp(res["theta"][:, tr])
+    # theta is now on the natural scale (run_mcmc.R maps the log-sd / log-phi columns back); post_correct() needs the
+    # sampling scale again and reads which columns to log from here (the reference passes the stored theta unchanged,
+    # R/post_correction.R:266, and so filters at exp(sd))
+    res["theta_scale"], res["transformed"] = "natural", [int(i) for i in np.atleast_1d(tr)]
     res["time"] = time.perf_counter() - t0
     return res
 
@@ -346,6 +350,10 @@ def _run_mcmc_fn(model, iter, particles, output_type, mcmc_type, sampling_method
     elif mcmc_type not in ("pm", "da", "is1", "is2", "is3", "approx"):
         raise ValueError("'arg' should be one of 'pm', 'da', 'is1', 'is2', 'is3', 'approx'")
     sampling_method = sampling_method.lower()
+    if sampling_method == "ekf" and mcmc_type.lower() != "pm":
+        # the reference's approximate chain / DA first stage / IS correction of method "ekf" use ekf_loglik() and an
+        # EKPF correction (src/model_ssm_nlg.cpp:259-261); only the pseudo-marginal chain is built for it here
+        raise ValueError("sampling_method 'ekf' is available with mcmc_type 'pm' only (use 'psi' or 'bsf' for approx / da / is*)")
     if sampling_method not in ("psi", "bsf", "ekf"):
         raise ValueError("'arg' should be one of 'psi', 'bsf', 'ekf'")
     if mcmc_type == "approx":

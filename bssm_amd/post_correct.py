@@ -294,7 +294,12 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
     output_type = _OUTPUT_TYPES[mcmc_output.get("output_type", 3)]
     t0 = time.perf_counter()
 
-    theta = np.atleast_2d(np.asarray(mcmc_output["theta"], dtype=np.float64))
+    theta = np.atleast_2d(np.array(mcmc_output["theta"], dtype=np.float64))
+    # run_mcmc() returns theta on the natural scale and says which columns it exponentiated: back to the sampling scale
+    # the model update expects (inside run_mcmc the stored values arrive untransformed, without the marker)
+    back = [int(i) for i in mcmc_output.get("transformed", [])] if mcmc_output.get("theta_scale") == "natural" else []
+    if back:
+        theta[:, back] = np.log(theta[:, back])
     counts = np.asarray(mcmc_output["counts"], dtype=np.uint32).reshape(-1)
     modes = np.asarray(mcmc_output["modes"], dtype=np.float64)
     n = model.n
@@ -356,6 +361,8 @@ def post_correct(model: BssmModel, mcmc_output: dict, particles: int, threads: i
         # posterior = prior (0) + approx_loglik (0) + log(weight): src/approx_mcmc.cpp:425-426, R_postcorrection.cpp:178-179
         inc = np.log(weights)
     if is_t == 3:
+        if back:
+            theta[:, back] = np.exp(theta[:, back])
         out["theta"], out["counts"], out["modes"] = theta, counts, modes
         out["posterior"] = np.repeat(np.asarray(mcmc_output.get("posterior", np.zeros(rep.size)), dtype=float), rep) + inc
     else:

@@ -152,12 +152,17 @@ def test_is_types_reweight_the_approximate_chain(oracle):
     base = mcmc.run_mcmc(model, 200, burnin=50, mcmc_type="approx", seed=8)
     for is_type in ("is1", "is2", "is3"):
         out = mcmc.run_mcmc(model, 200, particles=12, burnin=50, mcmc_type=is_type, output_type="summary", seed=8, threads=2)
-        stored = dict(base, theta=_sampling_scale(model, base["theta"]), output_type=2)
+        stored = dict(base, output_type=2)  # natural-scale theta + the 'transformed' marker: post_correct maps it back
         ref = PC.post_correct(model, stored, 12, threads=2, is_type=is_type, seed=8)
         assert np.allclose(out["weights"], ref["weights"], rtol=1e-12)
         assert np.allclose(out["alphahat"], ref["alphahat"], rtol=1e-12)
         assert np.allclose(out["posterior"], ref["posterior"], rtol=1e-12)
         assert out["theta"].shape[0] == (base["counts"].sum() if is_type == "is3" else base["counts"].size)
+    # the documented two-step workflow: the approx output goes to post_correct as returned (natural-scale theta)
+    two = PC.post_correct(model, dict(base, output_type=2), 12, threads=2, is_type="is2", seed=8)
+    one = mcmc.run_mcmc(model, 200, particles=12, burnin=50, mcmc_type="is2", output_type="summary", seed=8, threads=2)
+    assert np.allclose(two["weights"], one["weights"], rtol=1e-12) and np.allclose(two["alphahat"], one["alphahat"], rtol=1e-12)
+    assert np.allclose(two["theta"], one["theta"], rtol=1e-14)
     bsf = mcmc.run_mcmc(model, 200, particles=12, burnin=50, mcmc_type="is2", sampling_method="bsf", output_type="theta", seed=8)
     arrs = PC.expand_models(model, _sampling_scale(model, base["theta"]))
     for i in (0, len(arrs) - 1):

@@ -241,3 +241,21 @@ def test_shim_source_is_well_formed():
         assert mdef, name
         args = mdef.group(1).replace("NLG_ARGS", ",".join(["SEXP a"] * 16)).replace("SDE_ARGS", ",".join(["SEXP a"] * 8))
         assert args.count("SEXP") == nargs, (name, args.count("SEXP"), nargs)
+
+
+def test_run_mcmc_scale_marker_and_ekf_guard():
+    """run_mcmc output says which theta columns were mapped back to the natural scale (post_correct undoes it), and
+    sampling_method 'ekf' outside the pseudo-marginal chain is an error instead of a silent bootstrap / mode-based run"""
+    from bssm_amd import mcmc, post_correct as PC
+    y = np.arange(20.0)
+    growth = M.ssm_nlg(y, "nlg_growth", theta=np.array([0.0, np.log(0.05), 0.0]), known_params=[0.1, 500.0, 0.0, 50.0, 1.0, 100.0])
+    for typ in ("approx", "is2", "da"):
+        with pytest.raises(ValueError, match="ekf"):
+            mcmc.run_mcmc(growth, 10, particles=8, mcmc_type=typ, sampling_method="ekf", seed=1)
+    # post_correct maps a natural-scale theta back before anything touches the device: shape errors come after the mapping
+    model = small_zoo()["bsm_ng"] if "bsm_ng" in small_zoo() else None
+    if model is not None:
+        bad = dict(theta=np.exp(np.zeros((3, 2))), counts=np.ones(3, dtype=np.uint32), modes=np.zeros((model.n, 2)),
+                   theta_scale="natural", transformed=[0, 1])
+        with pytest.raises(ValueError, match="do not agree"):
+            PC.post_correct(model, bad, 8, seed=1)
