@@ -429,11 +429,23 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #else
   double* __restrict__ wt = b.weights ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + t) * N + base) : nullptr;
 #endif
-  double wt_old[PPT];
-  if (wt) {
+  // the read-modify-write that rescales the stored time-t weights from the block maximum to the global one; LATE: behind
+  // the transition, where few registers are live (BSSM_V2_RMW_LATE, the five-waves-per-SIMD builds), otherwise loaded
+  // here and stored right behind the barrier
+#ifndef BSSM_V2_RMW_LATE
+#define BSSM_V2_RMW_LATE 0
+#endif
+  auto rmw_load = [&](double (&wo)[PPT]) {
 #pragma unroll
-    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wt_old[r] = li < len ? ld32(wt, li) : 0.0; }
-  }
+    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wo[r] = li < len ? ld32(wt, li) : 0.0; }
+  };
+  auto rmw_store = [&](const double (&wo)[PPT]) {
+    const double myscale = s_comb[128 + pb];
+#pragma unroll
+    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); if (li < len) st32(wt, li, wo[r] * myscale); }
+  };
+  double wt_old[PPT];
+  if (!BSSM_V2_RMW_LATE && wt) rmw_load(wt_old);
   V2_MARK("combine"); V2_STAMP(1);
   if (wave == 0) {
     const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
@@ -455,12 +467,10 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   lds_barrier();  // (1)
   const double Q = s_comb[lane], iscale = s_comb[64 + lane], S = s_comb[63], M = s_comb[192];
   V2_MARK("rmw"); V2_STAMP(2);
-  if (wt) {  // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
-    const double myscale = s_comb[128 + pb];
-#pragma unroll
-    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); if (li < len) st32(wt, li, wt_old[r] * myscale); }
-  }
+  // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
+  if (!BSSM_V2_RMW_LATE && wt) rmw_store(wt_old);
   if (!(S > 0.0)) {
+    if (BSSM_V2_RMW_LATE && wt) { rmw_load(wt_old); rmw_store(wt_old); }
     // degenerate weights (src/model_ssm_ung.cpp:678-682): stop and poison this block's slot of the next parity, so every
     // later launch sees a non-finite S too (no flag load on healthy steps); later output slots stay zero like the reference's
     if (tid == 0) {
@@ -588,16 +598,37 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     }
   }
   V2_MARK("phaseD"); V2_STAMP(7);
-  // ---- phase D: ancestor indices out, ancestor states in flight
-  double a[PPT][MP];
+  // ---- phase D: ancestor indices out, ancestor states in flight -- at most ROLL rows of them at a time: row r + ROLL is
+  // requested as soon as row r has been propagated (BSSM_V2_ROLL = PPT: all rows at once, as before)
+#ifndef BSSM_V2_ROLL
+#define BSSM_V2_ROLL PPT
+#endif
+#ifndef BSSM_V2_PIN_BLK
+#define BSSM_V2_PIN_BLK 0
+#endif
+  constexpr int ROLL = (BSSM_V2_ROLL) < PPT ? (BSSM_V2_ROLL) : PPT;
+  double a[ROLL][MP];
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = v2_li<PPT>(r, tid);
     if (li >= len) anc[r] = 0;
     if (idx_out && li < len) st32(idx_out, li, (uint32_t)anc[r]);
-#pragma unroll
-    for (int c = 0; c < MP; c++) a[r][c] = (c < m) ? ld32(st_old + (size_t)c * N, anc[r]) : 0.0;
   }
+  auto gather = [&](int r) {
+#pragma unroll
+    for (int c = 0; c < MP; c++) {  // (padding components re-read the last real one: no branch per load)
+      const double av = ld32(st_old + (size_t)min(c, m - 1) * N, anc[r]);
+      a[r % ROLL][c] = (c < m) ? av : 0.0;
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < ROLL; r++) gather(r);
+#if BSSM_V2_PIN_BLK
+  // the Philox words of the transition normals stay raw integers until here: the compiler otherwise starts the
+  // Box-Muller arithmetic before the search and carries (spills) its double intermediates across it
+#pragma unroll
+  for (int r = 0; r < PPT; r++) __asm__ volatile("" : "+v"(blk[r].x), "+v"(blk[r].y), "+v"(blk[r].z));
+#endif
   V2_MARK("phaseE"); V2_STAMP(8);
   // ---- phase E: transition normals, alpha_{t+1} = C_t + T_t a + R_t eta (:663-670), signal at t+1
   const bool have_obs = tn < n;
@@ -609,11 +640,15 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     double z[KP], x[MP];
     rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
     if constexpr (kMfma) {
-      propagate_mfma8_h<KP>((const double*)s_mat, a[r], z, x, sw_base, lane);
+      propagate_mfma8_h<KP>((const double*)s_mat, a[r % ROLL], z, x, sw_base, lane);
     } else {
       int zero = 0;  // opaque: the matrix is re-read per particle instead of being kept live in 72 VGPRs
       __asm__ volatile("" : "+v"(zero));
-      propagate<MP, KP>((const double*)(s_mat + zero), a[r], z, x);
+      propagate<MP, KP>((const double*)(s_mat + zero), a[r % ROLL], z, x);
+    }
+    if (r + ROLL < PPT) {
+      __builtin_amdgcn_sched_barrier(0);
+      gather(r + ROLL);
     }
     if (li < len) {
 #pragma unroll
@@ -624,10 +659,12 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       for (int c = 0; c < MP; c++) xs[r][c] = x[c];
     } else {
       s[r] = v2_signal<MP>(row + ROW_HDR, x);
+      __asm__ volatile("" : "+v"(s[r]));  // now, not in the density phase: the compiler otherwise keeps (spills) x until then
     }
     __builtin_amdgcn_sched_barrier(0);  // particles one after the other: bounds the live registers of the transcendental code
   }
   V2_MARK("density"); V2_STAMP(9);
+  if (BSSM_V2_RMW_LATE && wt) rmw_load(wt_old);
   if (have_obs && row[RH_FLAG] != 0.0) {
     if constexpr (MS) v2_log_weights_multi<MP, PPT>(b.p, row, b.psi != 0, xs, w);
     else v2_log_weights<PPT>(row, b.psi != 0, s, w);
@@ -635,6 +672,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #pragma unroll
     for (int r = 0; r < PPT; r++) w[r] = 0.0;
   }
+  if (BSSM_V2_RMW_LATE && wt) rmw_store(wt_old);
   V2_MARK("stats"); V2_STAMP(10);
 #pragma unroll
   for (int r = 0; r < PPT; r++) if (v2_li<PPT>(r, tid) >= len) w[r] = -INFINITY;
