@@ -38,7 +38,13 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   if (b.MP <= 4 && !b.fpar) {
     // (states of one or two doubles: the round-2 kernel at four particles per lane wins from 4096 workgroups -- m = 1,
     // 16 / 20 filters of 65 536 particles: 4.95e10 -> 5.31e10, 5.49e10 -> 6.17e10; scripts/mid_batch_probe.py)
-    if (w1 >= (size_t)(b.MP <= 2 ? 4096 : 6144) && b.N >= 4 * GRID_NT) ppt = 4;
+    // (with one ancestor search per wave the round-2 kernel wins earlier wherever four particles per lane are what brings a
+    // filter down to its limit of 64 blocks -- 65 536 particles: m = 4, 16 / 20 filters 4.06e10 -> 4.33e10, 4.31e10 ->
+    // 4.53e10; m = 1, 8 / 12 filters 3.59e10 -> 4.08e10, 4.39e10 -> 4.91e10)
+    const size_t b1 = (size_t)(b.N + GRID_NT - 1) / GRID_NT, b4 = (size_t)(b.N + 4 * GRID_NT - 1) / (4 * GRID_NT);
+    const bool v2_needs4 = b1 > 64 && b4 <= 64;
+    const size_t thr4 = b.MP <= 2 ? (v2_needs4 ? 2048 : 4096) : (v2_needs4 ? 4096 : 6144);
+    if (w1 >= thr4 && b.N >= 4 * GRID_NT) ppt = 4;
     else if (w1 >= 3072 && b.N >= 2 * GRID_NT) ppt = 2;
   }
   // 8-dimensional states (round-2 multi-series kernel): two particles per lane once the batch fills the chip twice
