@@ -1001,7 +1001,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   }
 #ifndef BSSM_USER_MODEL
   // round-2 step kernel (pf_grid_v2.h): linear-state models with one observation series, at most 64 particle blocks
-  bool v2ms = false;
+  bool v2ms = false, v2wx = false;
   if constexpr (MP <= 8) {
 #ifdef BSSM_V2_STAMPS
     bool v2 = !b.fpar && ws.B <= 64 && ppt <= 4;
@@ -1009,12 +1009,16 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     bool v2 = !b.fpar && ws.B <= 64 && ppt <= 4 && !ws.dbg;
 #endif
     if (const char* env = std::getenv("BSSM_AMD_GRID_V2")) v2 = v2 && env[0] != '0';
+    // weights exchange (pf_grid_v2.h): with the weights output on, blocks hand over their block-scaled weights instead of
+    // the scan of them -- one array less written per particle-step
+    v2wx = b.weights != nullptr;
+    if (const char* env = std::getenv("BSSM_AMD_GRID_V2_WX")) v2wx = v2wx && env[0] != '0';
     if constexpr (MP <= 4) {
       if (v2 && b.p == 1) {
         switch (ppt) {
-          case 1: kern = pf_grid_step_v2<MP, KP, 1>; kern_init = pf_grid_init_v2<MP, 1>; break;
-          case 2: kern = pf_grid_step_v2<MP, KP, 2>; kern_init = pf_grid_init_v2<MP, 2>; break;
-          default: kern = pf_grid_step_v2<MP, KP, 4>; kern_init = pf_grid_init_v2<MP, 4>; break;
+          case 1: kern = v2wx ? pf_grid_step_v2<MP, KP, 1, false, true> : pf_grid_step_v2<MP, KP, 1>; kern_init = pf_grid_init_v2<MP, 1>; break;
+          case 2: kern = v2wx ? pf_grid_step_v2<MP, KP, 2, false, true> : pf_grid_step_v2<MP, KP, 2>; kern_init = pf_grid_init_v2<MP, 2>; break;
+          default: kern = v2wx ? pf_grid_step_v2<MP, KP, 4, false, true> : pf_grid_step_v2<MP, KP, 4>; kern_init = pf_grid_init_v2<MP, 4>; break;
         }
       }
     }
@@ -1022,16 +1026,17 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     // particles per lane (MP = 8, one particle per lane: fp64 MFMA transition)
     if (v2 && !kern_init && ppt <= 2 && (MP == 8 || b.p > 1)) {
       v2ms = true;
-      if (ppt == 1) { kern = pf_grid_step_v2<MP, KP, 1, true>; kern_init = pf_grid_init_v2<MP, 1, true>; }
-      else { kern = pf_grid_step_v2<MP, KP, 2, true>; kern_init = pf_grid_init_v2<MP, 2, true>; }
+      if (ppt == 1) { kern = v2wx ? pf_grid_step_v2<MP, KP, 1, true, true> : pf_grid_step_v2<MP, KP, 1, true>; kern_init = pf_grid_init_v2<MP, 1, true>; }
+      else { kern = v2wx ? pf_grid_step_v2<MP, KP, 2, true, true> : pf_grid_step_v2<MP, KP, 2, true>; kern_init = pf_grid_init_v2<MP, 2, true>; }
     }
+    if (!kern_init) v2wx = false;
   }
 #endif
   if (!kern) return hipErrorInvalidValue;
 #ifndef BSSM_USER_MODEL
   {
     char nm[96];
-    if (kern_init) std::snprintf(nm, sizeof nm, v2ms ? "pf_grid_step_v2<%d,%d,%d,true>" : "pf_grid_step_v2<%d,%d,%d>", MP, KP, ppt);
+    if (kern_init) std::snprintf(nm, sizeof nm, v2ms ? "pf_grid_step_v2<%d,%d,%d,true%s>" : "pf_grid_step_v2<%d,%d,%d%s>", MP, KP, ppt, v2wx ? (v2ms ? ",true" : ",false,true") : "");
     else std::snprintf(nm, sizeof nm, "pf_grid_step<%d,%d,%d,%s,%s>", MP, KP, ppt, "false", b.fpar ? "true" : "false");
     note_filter_kernel(nm);
   }
@@ -1051,6 +1056,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   hipStream_t lanes[2] = {stream, stream};
   hipEvent_t fork = nullptr, join = nullptr;
   GridWorkspace wsp[2] = {ws, ws};
+  wsp[0].wx = wsp[1].wx = v2wx ? 1 : 0;
   int fcount[2] = {b.F, 0};
   if (parts == 2) {  // first half on the caller's stream, second half on the library's side stream (ws.side)
     lanes[1] = ws.side;

@@ -58,6 +58,26 @@ constexpr int v2_log2(int x) { return x <= 1 ? 0 : 1 + v2_log2(x >> 1); }
 // slot (inside its block) of row r of thread tid: a wave owns 64 * PPT consecutive slots, a row 64 consecutive ones
 template <int PPT> __device__ __forceinline__ int v2_li(int r, int tid) { return (tid >> 6) * (64 * PPT) + r * 64 + (tid & 63); }
 
+// value of lane `src` (any lane, per-lane choice): ds_bpermute on the two halves (LDS crossbar, no LDS memory)
+__device__ __forceinline__ double v2_lane_gather(double v, int src) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// Weights exchange (WX): blocks hand over their block-scaled WEIGHTS instead of the scan of them (the `lcdf` array then
+// holds exp(w - max_b)), and a consumer rebuilds the scan values of the entries it stages: rows of 16 entries sit in
+// rows of 16 lanes, so the prefix inside the row is four DPP row shifts, and the base of the row is the block's coarse
+// entry of the row before (held by lane `row - 1` of `cv`).  One array is written per particle-step instead of two.
+//   x: block-scaled weight of this lane's entry;  row: the entry's row inside its block;  cv: coarse row of that block
+__device__ __forceinline__ double v2_entry_scan(double x, const double cv, const int row) {
+  x += dpp_shr_zero<DPP_ROW_SHR1>(x);
+  x += dpp_shr_zero<DPP_ROW_SHR2>(x);
+  x += dpp_shr_zero<DPP_ROW_SHR4>(x);
+  x += dpp_shr_zero<DPP_ROW_SHR8>(x);
+  const double base = v2_lane_gather(cv, max(row - 1, 0));
+  return row > 0 ? base + x : x;
+}
+
 // number of entries of sw[0, wlen) below vp (entries non-decreasing), wlen <= 128; exact when STEPS = 8, min(count, 127)
 // when STEPS = 7
 template <int STEPS>
@@ -74,7 +94,7 @@ __device__ __forceinline__ int v2_count_below(const double* sw, int wlen, double
 // Ancestor of the wave's active slots (a prefix of its lanes), any shape: loops over the source blocks the slots fall
 // into and over 128-entry windows of each block's local scan.  Every loop bound is wave-uniform.
 //   Q / iscale: this lane's block prefix (inclusive, scaled) and 1 / scale of block `lane`
-template <int PPT>
+template <int PPT, bool WX = false>
 __device__ __forceinline__ int v2_search_generic(const double v, const bool act, const double Q, const double iscale, const int B,
                                                  const int N, const double* __restrict__ coarse, const double* __restrict__ lcdf,
                                                  double* sw, const int lane) {
@@ -107,8 +127,13 @@ __device__ __forceinline__ int v2_search_generic(const double v, const bool act,
     for (int w0 = 16 * k_lo; w0 < wend; w0 += V2_WIN) {
       const int wlen = min(V2_WIN, wend - w0);
       __builtin_amdgcn_wave_barrier();  // the previous window's reads are done (same wave, LDS is in order)
-      sw[lane] = src[w0 + (lane < wlen ? lane : wlen - 1)];
-      sw[lane + 64] = src[w0 + (lane + 64 < wlen ? lane + 64 : wlen - 1)];
+      double x0 = src[w0 + (lane < wlen ? lane : wlen - 1)], x1 = src[w0 + (lane + 64 < wlen ? lane + 64 : wlen - 1)];
+      if constexpr (WX) {  // (w0 is a multiple of 16: rows of entries sit in rows of lanes)
+        x0 = v2_entry_scan(x0, cv, (w0 + lane) >> 4);
+        x1 = v2_entry_scan(x1, cv, (w0 + 64 + lane) >> 4);
+      }
+      sw[lane] = x0;
+      sw[lane + 64] = x1;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -259,14 +284,18 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
   const double swv = lane_broadcast(scq, wave * PPT);
   double* __restrict__ lcdf_new = uniform_ptr(ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N + base);
   double* __restrict__ coarse_new = uniform_ptr(ws.coarse + (((size_t)(tn & 1) * b.F + f) * B + pb) * crow);
-  double* __restrict__ wout = b.weights ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + tn) * N + base) : nullptr;
+  // weights exchange (ws.wx): the exchange array carries the block-scaled weights themselves and the owner writes the
+  // output weights of time tn in launch tn, once, in the global scale; the last time point has no launch of its own and
+  // its weights (ones: nothing is observed behind the series) leave here
+  const bool wx = ws.wx != 0;
+  double* __restrict__ wout = (b.weights && (!wx || tn == n)) ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + tn) * N + base) : nullptr;
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int q = wave * PPT + r, li = v2_li<PPT>(r, tid);
     const double off = q == 0 ? 0.0 : lane_broadcast(incl, (q - 1) & 63);
     const double lc = __builtin_fma(sc[r], swv, off);
     if (li < len) {
-      st32(lcdf_new, li, lc);
+      st32(lcdf_new, li, wx ? e[r] * swv : lc);
       if ((li & 15) == 15 || li == len - 1) st32(coarse_new, li >> 4, lc);  // last entry of each row of 16
       if (wout) st32(wout, li, e[r] * swv);  // block-scaled; rescaled to the global maximum by launch tn
     }
@@ -394,7 +423,9 @@ __device__ __forceinline__ void v2_window_ancestors(const double* sw, const doub
 // MS: a row of p >= 1 observation series (ssm_mng, and every model with an 8-dimensional state); with MP = 8 and one
 // particle per lane the transition runs on the matrix cores (propagate_mfma8), whose per-wave operand tile doubles as the
 // wave's search window
-template <int MP, int KP, int PPT, bool MS = false>
+// WX: weights exchange (see v2_entry_scan): with the weights output on, the owner's read-modify-write becomes "read my
+// exchanged weights, write the output once", and the `lcdf` write (8 of the 109 bytes a particle-step moved) disappears
+template <int MP, int KP, int PPT, bool MS = false, bool WX = false>
 __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_step_v2(const FilterBatch b, const GridWorkspace ws, const int t) {
   #ifndef BSSM_V2_MFMA_PPT
 #define BSSM_V2_MFMA_PPT 2
@@ -435,9 +466,10 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #ifndef BSSM_V2_RMW_LATE
 #define BSSM_V2_RMW_LATE 0
 #endif
+  const double* __restrict__ wsrc = WX ? uniform_ptr(ws.lcdf + ((size_t)(t & 1) * b.F + f) * N + base) : wt;
   auto rmw_load = [&](double (&wo)[PPT]) {
 #pragma unroll
-    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wo[r] = li < len ? ld32(wt, li) : 0.0; }
+    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wo[r] = li < len ? ld32(wsrc, li) : 0.0; }
   };
   auto rmw_store = [&](const double (&wo)[PPT]) {
     const double myscale = s_comb[128 + pb];
@@ -561,6 +593,25 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       if (q * 64 < total) {  // wave-uniform
         const int i = min(q * 64 + lane, total - 1);
         wr[q] = ld32(lcdf, (i < len1 ? off1 : off2) + (uint32_t)i);
+        if constexpr (WX) {  // the exchanged values are weights: their scan inside the row + the coarse entry of the row before
+          // (w0 and len1 are multiples of 16 wherever a second segment exists: rows of entries sit in rows of lanes)
+          const int i0 = q * 64 + lane;
+          double c;
+          if (e2 != e1) {
+            const bool second = i0 >= len1;
+            const int row = second ? (i0 - len1) >> 4 : (w0 + i0) >> 4;
+            double x = wr[q];
+            x += dpp_shr_zero<DPP_ROW_SHR1>(x);
+            x += dpp_shr_zero<DPP_ROW_SHR2>(x);
+            x += dpp_shr_zero<DPP_ROW_SHR4>(x);
+            x += dpp_shr_zero<DPP_ROW_SHR8>(x);
+            const double b1 = v2_lane_gather(cv1, max(row - 1, 0)), b2 = v2_lane_gather(cv2, max(row - 1, 0));
+            c = row > 0 ? (second ? b2 : b1) + x : x;
+          } else {
+            c = v2_entry_scan(wr[q], cv1, (w0 + i0) >> 4);
+          }
+          wr[q] = i0 < total ? c : __builtin_huge_val();
+        }
       }
     }
     V2_MARK("phaseC"); V2_STAMP(5);
@@ -592,7 +643,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       for (int q = 1; q < PPT; q++) ur = (r == q) ? blk[q].w : ur;  // r is wave-uniform: scalar compare + select
       const int li = v2_li<PPT>(r, tid);
       const double vr = ((double)ur * 0x1.0p-32 + (double)(base + li)) * c_scale;  // the target, as in phase A
-      const int ar = v2_search_generic<PPT>(vr, li < len, Q, iscale, B, N, coarse, lcdf, sw_base, lane);
+      const int ar = v2_search_generic<PPT, WX>(vr, li < len, Q, iscale, B, N, coarse, lcdf, sw_base, lane);
 #pragma unroll
       for (int q = 0; q < PPT; q++) anc[q] = (r == q) ? ar : anc[q];
     }

@@ -59,6 +59,7 @@ struct GridWorkspace {
   int chunk;           // particles per block
   int f0;              // first filter of this launch (a batch may be stepped as two interleaved launch sequences)
   int xcd_remap;       // 1: workgroup ids are remapped so that every XCD owns a contiguous range of (filter, block) pairs
+  int wx;              // 1: the exchange array `lcdf` carries block-scaled weights, not their scan (round-2 step kernel, full output)
   hipStream_t side;    // the library's side stream for the second launch sequence (one per host thread); null = none
 };
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out);

@@ -84,6 +84,7 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   ws->chunk = chunk;
   ws->f0 = 0;
   ws->xcd_remap = 1;
+  ws->wx = 0;
   // ONE side stream per host thread for the whole library (streams share a small number of hardware queues: a pair per
   // kernel variant ended up serialised against each other)
   static thread_local TlsStream side;
