@@ -999,9 +999,10 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
       return hipErrorInvalidValue;
     }
   }
+  bool v2ms = false, v2wx = false, v2exact = false;
+  (void)v2ms; (void)v2exact;
 #ifndef BSSM_USER_MODEL
   // round-2 step kernel (pf_grid_v2.h): linear-state models with one observation series, at most 64 particle blocks
-  bool v2ms = false, v2wx = false;
   if constexpr (MP <= 8) {
 #ifdef BSSM_V2_STAMPS
     bool v2 = !b.fpar && ws.B <= 64 && ppt <= 4;
@@ -1013,12 +1014,14 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     // the scan of them -- one array less written per particle-step
     v2wx = b.weights != nullptr;
     if (const char* env = std::getenv("BSSM_AMD_GRID_V2_WX")) v2wx = v2wx && env[0] != '0';
+    v2exact = b.N % ws.chunk == 0 && b.m == MP;  // complete blocks, no padding components: the variants without tail guards
+    if (const char* env = std::getenv("BSSM_AMD_GRID_V2_EXACT")) v2exact = v2exact && env[0] != '0';
     if constexpr (MP <= 4) {
       if (v2 && b.p == 1) {
         switch (ppt) {
-          case 1: kern = v2wx ? pf_grid_step_v2<MP, KP, 1, false, true> : pf_grid_step_v2<MP, KP, 1>; kern_init = pf_grid_init_v2<MP, 1>; break;
-          case 2: kern = v2wx ? pf_grid_step_v2<MP, KP, 2, false, true> : pf_grid_step_v2<MP, KP, 2>; kern_init = pf_grid_init_v2<MP, 2>; break;
-          default: kern = v2wx ? pf_grid_step_v2<MP, KP, 4, false, true> : pf_grid_step_v2<MP, KP, 4>; kern_init = pf_grid_init_v2<MP, 4>; break;
+          case 1: kern = v2_step_kernel<MP, KP, 1, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1>; break;
+          case 2: kern = v2_step_kernel<MP, KP, 2, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2>; break;
+          default: kern = v2_step_kernel<MP, KP, 4, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 4>; break;
         }
       }
     }
@@ -1026,17 +1029,17 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     // particles per lane (MP = 8, one particle per lane: fp64 MFMA transition)
     if (v2 && !kern_init && ppt <= 2 && (MP == 8 || b.p > 1)) {
       v2ms = true;
-      if (ppt == 1) { kern = v2wx ? pf_grid_step_v2<MP, KP, 1, true, true> : pf_grid_step_v2<MP, KP, 1, true>; kern_init = pf_grid_init_v2<MP, 1, true>; }
-      else { kern = v2wx ? pf_grid_step_v2<MP, KP, 2, true, true> : pf_grid_step_v2<MP, KP, 2, true>; kern_init = pf_grid_init_v2<MP, 2, true>; }
+      if (ppt == 1) { kern = v2_step_kernel<MP, KP, 1, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1, true>; }
+      else { kern = v2_step_kernel<MP, KP, 2, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2, true>; }
     }
-    if (!kern_init) v2wx = false;
+    if (!kern_init) v2wx = v2exact = false;
   }
 #endif
   if (!kern) return hipErrorInvalidValue;
 #ifndef BSSM_USER_MODEL
   {
     char nm[96];
-    if (kern_init) std::snprintf(nm, sizeof nm, v2ms ? "pf_grid_step_v2<%d,%d,%d,true%s>" : "pf_grid_step_v2<%d,%d,%d%s>", MP, KP, ppt, v2wx ? (v2ms ? ",true" : ",false,true") : "");
+    if (kern_init) std::snprintf(nm, sizeof nm, "pf_grid_step_v2<%d,%d,%d,%s,%s,%s>", MP, KP, ppt, v2ms ? "true" : "false", v2wx ? "true" : "false", v2exact ? "true" : "false");
     else std::snprintf(nm, sizeof nm, "pf_grid_step<%d,%d,%d,%s,%s>", MP, KP, ppt, "false", b.fpar ? "true" : "false");
     note_filter_kernel(nm);
   }
