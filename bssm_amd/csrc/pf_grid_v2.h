@@ -58,6 +58,13 @@ constexpr int v2_log2(int x) { return x <= 1 ? 0 : 1 + v2_log2(x >> 1); }
 // slot (inside its block) of row r of thread tid: a wave owns 64 * PPT consecutive slots, a row 64 consecutive ones
 template <int PPT> __device__ __forceinline__ int v2_li(int r, int tid) { return (tid >> 6) * (64 * PPT) + r * 64 + (tid & 63); }
 
+// two consecutive doubles (16-byte aligned) of an array whose base is wave-uniform
+typedef double v2_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2_d2 v2_ld32_d2(const double* uniform_base, uint32_t index) {
+  typedef __attribute__((address_space(1))) const v2_d2 gD2;
+  typedef __attribute__((address_space(1))) const char gC;
+  return *(gD2*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * 8u));
+}
 // value of lane `src` (any lane, per-lane choice): ds_bpermute on the two halves (LDS crossbar, no LDS memory)
 __device__ __forceinline__ double v2_lane_gather(double v, int src) {
   const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
@@ -589,6 +596,40 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     int total = len1 + len2;
     if (total > WIN) { slow = true; total = 1; len1 = 1; len2 = 0; }
     const uint32_t off1 = (uint32_t)(e1 * chunk + w0), off2 = (uint32_t)(e2 * chunk - len1);
+    if constexpr (WX && EXACT && PPT >= 2) {
+      // Weights exchange with complete blocks: the lane stages E = 2 PPT CONSECUTIVE entries (16-byte loads; the window and
+      // both of its segments are whole rows of 16 entries, so a lane's run is all inside one segment and all valid or all
+      // beyond the window).  Their scan is serial inside the lane, a short DPP scan over the 16 / E lanes of a row, plus the
+      // coarse entry of the row before: ~30 VALU instructions per wave-step instead of ~100 for the row-per-16-lanes form.
+      constexpr int E = 2 * PPT, G = 16 / E;
+      const int i0 = E * lane, g = lane & (G - 1);
+      const bool valid = i0 < total;
+      const bool second = e2 != e1 && i0 >= len1;
+      double x[E];
+#pragma unroll
+      for (int j = 0; j < E; j++) x[j] = 0.0;
+      if (valid) {
+        const uint32_t src0 = (second ? off2 : off1) + (uint32_t)i0;
+#pragma unroll
+        for (int k = 0; k < E; k += 2) { const v2_d2 d = v2_ld32_d2(lcdf, src0 + k); x[k] = d.x; x[k + 1] = d.y; }
+      }
+#pragma unroll
+      for (int j = 1; j < E; j++) x[j] += x[j - 1];
+      double T = x[E - 1];
+      if constexpr (G >= 2) { const double u = dpp_shr_zero<DPP_ROW_SHR1>(T); T += g >= 1 ? u : 0.0; }
+      if constexpr (G >= 4) { const double u = dpp_shr_zero<DPP_ROW_SHR2>(T); T += g >= 2 ? u : 0.0; }
+      if constexpr (G >= 8) { const double u = dpp_shr_zero<DPP_ROW_SHR4>(T); T += g >= 4 ? u : 0.0; }
+      const double before = dpp_shr_zero<DPP_ROW_SHR1>(T);  // the lanes of my row in front of me
+      const int row = second ? (i0 - len1) >> 4 : (w0 + i0) >> 4;
+      double rbase = v2_lane_gather(cv1, max(row - 1, 0));
+      if (e2 != e1) { const double b2 = v2_lane_gather(cv2, max(row - 1, 0)); rbase = second ? b2 : rbase; }
+      double offs = (row > 0 ? rbase : 0.0) + (g >= 1 ? before : 0.0);
+      offs = valid ? offs : __builtin_huge_val();
+      V2_MARK("phaseC"); V2_STAMP(5);
+      if constexpr (PPT > 1) lds_wave_sync();  // the transposed uniforms have been read
+#pragma unroll
+      for (int k = 0; k < E; k += 2) *(v2_d2*)(sw_base + i0 + k) = v2_d2{x[k] + offs, x[k + 1] + offs};
+    } else {
 #pragma unroll
     for (int q = 0; q < 2 * PPT; q++) {
       wr[q] = __builtin_huge_val();
@@ -621,6 +662,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     if constexpr (PPT > 1) lds_wave_sync();  // the transposed uniforms have been read
 #pragma unroll
     for (int q = 0; q < 2 * PPT; q++) sw_base[q * 64 + lane] = wr[q];
+    }
   }
   lds_wave_sync();
   int anc[PPT];
