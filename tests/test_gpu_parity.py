@@ -293,3 +293,34 @@ def test_plan_update_and_sample_or_summarise(oracle):
     with pytest.raises(Exception):
         plan.update(M.bsm_ng(y, sd_level=0.3, distribution="poisson", P1=np.array([[1.0]])))
     plan.close()
+
+
+@pytest.mark.parametrize("psi", [False, True])
+@pytest.mark.parametrize("name", sorted(ZOO))
+@pytest.mark.parametrize("N,ppt", [(4096, "4"), (3072, "4"), (2048, "2"), (1500, "2")])
+def test_step_kernel_variants_match_oracle(oracle, monkeypatch, name, N, ppt, psi):
+    """Full output of the round-2 step kernel at two and four particles per lane: one ancestor search per wave, weights
+    exchange (the blocks hand over block-scaled weights, consumers rebuild their scan), the variants without tail guards
+    (N a multiple of the block size and no padding components) and with them (ragged N, m = 3), windows crossing a block
+    boundary (every N here has several blocks) -- bootstrap and psi-APF, against the oracle"""
+    from bssm_amd.plan import FilterPlan
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "grid")
+    monkeypatch.setenv("BSSM_AMD_GRID_PPT", ppt)
+    model = ZOO[name]
+    if psi and name.startswith("gaussian"):
+        pytest.skip("psi-APF of a Gaussian model is exact")
+    arr = M.model_arrays(model)
+    if psi:
+        out = F.particle_smoother(model, N, method="psi", seed=13, return_indices=True)
+        ref = oracle.psi_filter(arr, N, seed=13)
+        assert np.array_equal(out["indices"], ref["indices"])
+        assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+        assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    else:
+        out = F.bootstrap_filter(model, N, seed=13, return_indices=True)
+        ref = oracle.bsf_filter(arr, N, seed=13)
+        _check_filter(out, ref, model.n)
+    k = FilterPlan.last_kernel()
+    assert k.startswith("pf_grid_step_v2<") and ",%s," % ppt in k and ",true," in k, k  # (weights exchange on: full output)
+    exact = N % (256 * int(ppt)) == 0 and model.m in (1, 2, 4, 8)
+    assert k.endswith(",true>") == exact, (k, model.m)
