@@ -90,6 +90,10 @@ if want("C4"):
                                                                 kernel=FilterPlan.last_kernel())
         p.close()
     res["C4"] = row
+    # the 64-filter plan held 160 GB of device memory: hand the cached blocks back now (hipFree of that much takes
+    # seconds and would otherwise be charged to the first call of the next configuration)
+    from bssm_amd import _lib as _L
+    _L.lib().bssm_amd_trim_cache()
 
 
 # ---- C5: ssm_nlg growth, T=300, 2340 retained draws, psi N=4096, one GPU's view (all draws on this GPU)
@@ -114,6 +118,11 @@ if want("C5"):
     modes = np.tile(modes, (1, (ns + 63) // 64))[:, :ns]  # modes of nearby draws: approximate_for_is re-linearises at them
     row = dict(workload="ssm_nlg growth T=300 m=2, %d retained draws, psi-APF N=4096, IS2 post-correction on ONE GPU" % ns,
                host_mode_search_ms_per_draw=e_mode * 1e3)
+    # one untimed call per output type first: the previous configuration released > 100 GB of device memory, which the
+    # driver reclaims lazily -- the first large allocation afterwards waits seconds for it (not a property of this job)
+    for ot in (3, 2, 1):
+        PC.post_correct(growth, dict(theta=theta, counts=counts, modes=modes.reshape(2, n, ns, order="F"), output_type=ot),
+                        4096, threads=8, is_type="is2", seed=1)
     for ot in (3, 2, 1):
         for thr in (1, 8, 32):
             mo = dict(theta=theta, counts=counts, modes=modes.reshape(2, n, ns, order="F"), output_type=ot)
