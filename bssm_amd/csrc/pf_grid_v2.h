@@ -257,7 +257,7 @@ __device__ __forceinline__ void v2_log_weights_multi(const int p, const cdbl* ro
 // Block statistics of the new weights and their hand-over to the next launch: block-local inclusive scan of
 // exp(w - max_b) (`lcdf`), row ends (`coarse`), (max_b, sum_b) (`partials`); optional block-scaled weights output.
 // One workgroup barrier.  s_x: 4 + 4 * PPT doubles of LDS.
-template <int PPT>
+template <int PPT, bool WX>
 __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridWorkspace& ws, const int f, const int pb, const int base,
                                                const int len, const int tn, const double (&w)[PPT], double* s_x) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -268,49 +268,95 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
   for (int r = 1; r < PPT; r++) mx = fmax(mx, w[r]);
   const double Mw = wave_max(mx);
   const double Mws = Mw == -INFINITY ? 0.0 : Mw;  // a wave without mass: exp(-inf - 0) = 0 instead of exp(nan)
-  double e[PPT], sc[PPT];
-#pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    e[r] = tl_exp(w[r] - Mws);  // inactive slots carry w = -inf: 0
-    sc[r] = wave_scan_incl(e[r]);
-    if (lane == 63) s_x[4 + wave * PPT + r] = sc[r];
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (lane == 0) s_x[wave] = Mw;
-  lds_barrier();
-  // every wave combines the 4 wave maxima and the 4 * PPT chunk totals (chunks in particle order: q = PPT wave + r)
-  const double m0 = s_x[0], m1 = s_x[1], m2 = s_x[2], m3 = s_x[3];
-  const double Mb = fmax(fmax(m0, m1), fmax(m2, m3));
-  const double Mbs = Mb == -INFINITY ? 0.0 : Mb;
-  const int qw = (lane / PPT) & 3;  // chunk `lane` belongs to wave lane / PPT
-  const double Mq = qw == 0 ? m0 : (qw == 1 ? m1 : (qw == 2 ? m2 : m3));
-  const double scq = tl_exp(Mq - Mbs);                       // lane q: exp(max of chunk q's wave - max_block)
-  const double tq = lane < 4 * PPT ? s_x[4 + lane] : 0.0;
-  const double incl = wave_scan_incl(tq * scq);              // lanes >= 4 PPT add zeros
-  const double total = lane_broadcast(incl, 4 * PPT - 1);
-  const double swv = lane_broadcast(scq, wave * PPT);
   double* __restrict__ lcdf_new = uniform_ptr(ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N + base);
   double* __restrict__ coarse_new = uniform_ptr(ws.coarse + (((size_t)(tn & 1) * b.F + f) * B + pb) * crow);
-  // weights exchange (ws.wx): the exchange array carries the block-scaled weights themselves and the owner writes the
-  // output weights of time tn in launch tn, once, in the global scale; the last time point has no launch of its own and
-  // its weights (ones: nothing is observed behind the series) leave here
-  const bool wx = ws.wx != 0;
-  double* __restrict__ wout = (b.weights && (!wx || tn == n)) ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + tn) * N + base) : nullptr;
+  if constexpr (WX) {
+    // Weights exchange: the next launch needs the block-scaled weights, the scan value at the end of every row of 16
+    // entries (`coarse`) and the block's (max, sum) -- not the scan of every entry.  So: the sum of every row of 16 lanes
+    // (four DPP steps), the 16 PPT row sums of the block through LDS, and ONE wave scans them (a single coalesced store
+    // of the coarse row) while the others only scale and store their weights.  The output weights of time tn are written
+    // by launch tn, once, in the global scale; the last time point has no launch of its own and its weights (ones:
+    // nothing is observed behind the series) leave here.
+    double e[PPT];
 #pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    const int q = wave * PPT + r, li = v2_li<PPT>(r, tid);
-    const double off = q == 0 ? 0.0 : lane_broadcast(incl, (q - 1) & 63);
-    const double lc = __builtin_fma(sc[r], swv, off);
-    if (li < len) {
-      st32(lcdf_new, li, wx ? e[r] * swv : lc);
-      if ((li & 15) == 15 || li == len - 1) st32(coarse_new, li >> 4, lc);  // last entry of each row of 16
-      if (wout) st32(wout, li, e[r] * swv);  // block-scaled; rescaled to the global maximum by launch tn
+    for (int r = 0; r < PPT; r++) {
+      e[r] = tl_exp(w[r] - Mws);  // inactive slots carry w = -inf: 0
+      double rs = e[r];
+      rs += dpp_shr_zero<DPP_ROW_SHR1>(rs);
+      rs += dpp_shr_zero<DPP_ROW_SHR2>(rs);
+      rs += dpp_shr_zero<DPP_ROW_SHR4>(rs);
+      rs += dpp_shr_zero<DPP_ROW_SHR8>(rs);
+      if ((lane & 15) == 15) s_x[4 + (wave * PPT + r) * 4 + (lane >> 4)] = rs;  // row (li >> 4) of the block
+      __builtin_amdgcn_sched_barrier(0);
     }
-  }
-  if (tid == 0) {
-    double* __restrict__ part = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
-    part[2 * pb] = Mb;
-    part[2 * pb + 1] = total;
+    if (lane == 0) s_x[wave] = Mw;
+    lds_barrier();
+    const double m0 = s_x[0], m1 = s_x[1], m2 = s_x[2], m3 = s_x[3];
+    const double Mb = fmax(fmax(m0, m1), fmax(m2, m3));
+    const double Mbs = Mb == -INFINITY ? 0.0 : Mb;
+    const double swv = tl_exp(Mws - Mbs) * (Mw == -INFINITY ? 0.0 : 1.0);  // exp(max_wave - max_block)
+    double* __restrict__ wout = (b.weights && tn == n) ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + tn) * N + base) : nullptr;
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      const int li = v2_li<PPT>(r, tid);
+      if (li < len) {
+        st32(lcdf_new, li, e[r] * swv);
+        if (wout) st32(wout, li, e[r] * swv);
+      }
+    }
+    if (wave == 0) {  // rows of the block in lanes: row i belongs to wave i / (4 PPT)
+      const int wq = lane / (4 * PPT);
+      const double Mq = wq == 0 ? m0 : (wq == 1 ? m1 : (wq == 2 ? m2 : m3));
+      const double scq = Mq == -INFINITY ? 0.0 : tl_exp(Mq - Mbs);
+      const double rt = lane < crow ? s_x[4 + lane] : 0.0;
+      const double c = wave_scan_incl(rt * scq);
+      const int nrow = (len + 15) >> 4;
+      if (lane < nrow) st32(coarse_new, lane, c);
+      if (lane == 63) {
+        double* __restrict__ part = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
+        part[2 * pb] = Mb;
+        part[2 * pb + 1] = c;
+      }
+    }
+  } else {
+    double e[PPT], sc[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      e[r] = tl_exp(w[r] - Mws);  // inactive slots carry w = -inf: 0
+      sc[r] = wave_scan_incl(e[r]);
+      if (lane == 63) s_x[4 + wave * PPT + r] = sc[r];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane == 0) s_x[wave] = Mw;
+    lds_barrier();
+    // every wave combines the 4 wave maxima and the 4 * PPT chunk totals (chunks in particle order: q = PPT wave + r)
+    const double m0 = s_x[0], m1 = s_x[1], m2 = s_x[2], m3 = s_x[3];
+    const double Mb = fmax(fmax(m0, m1), fmax(m2, m3));
+    const double Mbs = Mb == -INFINITY ? 0.0 : Mb;
+    const int qw = (lane / PPT) & 3;  // chunk `lane` belongs to wave lane / PPT
+    const double Mq = qw == 0 ? m0 : (qw == 1 ? m1 : (qw == 2 ? m2 : m3));
+    const double scq = tl_exp(Mq - Mbs);                       // lane q: exp(max of chunk q's wave - max_block)
+    const double tq = lane < 4 * PPT ? s_x[4 + lane] : 0.0;
+    const double incl = wave_scan_incl(tq * scq);              // lanes >= 4 PPT add zeros
+    const double total = lane_broadcast(incl, 4 * PPT - 1);
+    const double swv = lane_broadcast(scq, wave * PPT);
+    double* __restrict__ wout = b.weights ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + tn) * N + base) : nullptr;
+#pragma unroll
+    for (int r = 0; r < PPT; r++) {
+      const int q = wave * PPT + r, li = v2_li<PPT>(r, tid);
+      const double off = q == 0 ? 0.0 : lane_broadcast(incl, (q - 1) & 63);
+      const double lc = __builtin_fma(sc[r], swv, off);
+      if (li < len) {
+        st32(lcdf_new, li, lc);
+        if ((li & 15) == 15 || li == len - 1) st32(coarse_new, li >> 4, lc);  // last entry of each row of 16
+        if (wout) st32(wout, li, e[r] * swv);  // block-scaled; rescaled to the global maximum by launch tn
+      }
+    }
+    if (tid == 0) {
+      double* __restrict__ part = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
+      part[2 * pb] = Mb;
+      part[2 * pb + 1] = total;
+    }
   }
 }
 
@@ -339,7 +385,7 @@ __device__ __forceinline__ void v2_block_of(const GridWorkspace& ws, int& pb, in
 // t = -1: initial particles a1 + L u (src/model_ssm_ung.cpp:626; psi: alphahat_0 + V_0 u, :543) and their weights
 template <int MP, int PPT, bool MS = false>
 __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, const GridWorkspace ws) {
-  __shared__ double s_x[4 + 4 * PPT];
+  __shared__ double s_x[4 + 16 * PPT];
   int pb, f;
   v2_block_of(ws, pb, f);
   math_tab_init();
@@ -378,7 +424,8 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, 
   }
 #pragma unroll
   for (int r = 0; r < PPT; r++) if (v2_li<PPT>(r, tid) >= len) w[r] = -INFINITY;
-  v2_block_stats<PPT>(b, ws, f, pb, base, len, 0, w, s_x);
+  if (ws.wx) v2_block_stats<PPT, true>(b, ws, f, pb, base, len, 0, w, s_x);
+  else v2_block_stats<PPT, false>(b, ws, f, pb, base, len, 0, w, s_x);
 }
 
 // Ancestors of a wave's 64 * PPT consecutive slots whose targets fall into one source block (TWO = false) or into two
@@ -442,7 +489,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   constexpr bool kMfma = MS && MP == 8 && PPT <= BSSM_V2_MFMA_PPT;
   __shared__ double s_win[kMfma ? 4 * 8 * 64 : 4 * PPT * V2_WIN];
   static_assert(!kMfma || PPT * V2_WIN <= 8 * 64, "the MFMA operand tile doubles as the search window");
-  __shared__ double s_x[4 + 4 * PPT];
+  __shared__ double s_x[4 + 16 * PPT];
   __shared__ double s_comb[3 * 64 + 1];  // combine of wave 0: block prefixes, 1 / scale, scale, global maximum
   // T_t, R_t, C_t of this step.  Read from LDS (broadcast ds_read, same address in every lane) and not through scalar
   // loads: 36 doubles are 72 SGPRs, which with the kernel arguments and the observation row overflowed the scalar file --
@@ -771,7 +818,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   V2_MARK("stats"); V2_STAMP(10);
 #pragma unroll
   for (int r = 0; r < PPT; r++) if (v2_li<PPT>(r, tid) >= len) w[r] = -INFINITY;
-  v2_block_stats<PPT>(b, ws, f, pb, base, len, tn, w, s_x);
+  v2_block_stats<PPT, WX>(b, ws, f, pb, base, len, tn, w, s_x);
   V2_STAMP(11);
 }
 
