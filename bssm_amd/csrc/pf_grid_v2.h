@@ -551,6 +551,17 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   u32x4 blk[PPT];
 #pragma unroll
   for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + v2_li<PPT>(r, tid)));
+  // (BSSM_V2_EARLY_B: the second Philox block of a particle with 3 or 4 noise terms is drawn here too, in the shadow of the
+  // exchange loads and the first barrier, instead of on the critical path behind the ancestor gathers)
+#ifndef BSSM_V2_EARLY_B
+#define BSSM_V2_EARLY_B 0
+#endif
+  constexpr bool kEarlyB = BSSM_V2_EARLY_B && !MS && (KP == 3 || KP == 4);
+  u32x4 blkB[kEarlyB ? PPT : 1];
+  if constexpr (kEarlyB) {
+#pragma unroll
+    for (int r = 0; r < PPT; r++) blkB[r] = philox4x32_10((uint32_t)(base + v2_li<PPT>(r, tid)), (uint32_t)t, 1u, RNG_TRANSITION, key.seed, key.stream);
+  }
   math_tab_load_end256(mtab);
   lds_barrier();  // (1)
   const double Q = s_comb[lane], iscale = s_comb[64 + lane], S = s_comb[63], M = s_comb[192];
@@ -780,7 +791,16 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   for (int r = 0; r < PPT; r++) {
     const int li = v2_li<PPT>(r, tid), j = base + li;
     double z[KP], x[MP];
-    rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+    if constexpr (kEarlyB) {
+      __asm__ volatile("" : "+v"(blkB[r].x), "+v"(blkB[r].y), "+v"(blkB[r].z));
+      double z0, z1, z2, z3;
+      box_muller(blk[r], z0, z1);
+      box_muller(blkB[r], z2, z3);
+      z[0] = z0; z[1] = z1; z[2] = z2;
+      if constexpr (KP == 4) z[3] = z3;
+    } else {
+      rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+    }
     if constexpr (kMfma) {
       propagate_mfma8_h<KP>((const double*)s_mat, a[r % ROLL], z, x, sw_base, lane);
     } else {
