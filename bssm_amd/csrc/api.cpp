@@ -1139,7 +1139,7 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   }
   // the cache key covers everything that is compiled into the library: the kernel headers, the state dimension, the snippet
   std::string key = std::string(bssm_amd_version()) + "|" + std::to_string(n_states) + "|" + source;
-  for (const char* hdr : {"pf_filter_impl.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "user_model_tu.hip"}) {
+  for (const char* hdr : {"pf_filter_impl.h", "pf_grid_v2.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "pf_math_tables.h", "user_model_tu.hip"}) {
     FILE* hf = std::fopen((dir + "/csrc/" + hdr).c_str(), "rb");
     if (!hf) return fail(BSSM_ERR_INVALID, "kernel sources not found next to the library: " + dir + "/csrc/" + hdr);
     char buf[1 << 16];
