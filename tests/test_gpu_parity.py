@@ -324,3 +324,24 @@ def test_step_kernel_variants_match_oracle(oracle, monkeypatch, name, N, ppt, ps
     assert k.startswith("pf_grid_step_v2<") and ",%s," % ppt in k and ",true," in k, k  # (weights exchange on: full output)
     exact = N % (256 * int(ppt)) == 0 and model.m in (1, 2, 4, 8)
     assert k.endswith(",true>") == exact, (k, model.m)
+
+
+@pytest.mark.parametrize("N,ppt", [(2048, "2"), (4096, "4"), (1500, "2")])
+def test_degenerate_filter_outputs_match_oracle(oracle, monkeypatch, N, ppt):
+    """The degenerate stop (src/model_ssm_ung.cpp:678-682) in the round-2 step kernel with the weights exchange on: the
+    weights of the last healthy time point still leave in the global scale, every later slot of weights / particles /
+    ancestors is zero like the reference's, the log-likelihood is -Inf"""
+    y = np.array([1.0, 2.0, 3.0, 2.0, 3.0, 1.0, 2.0])
+    D = np.array([0.0, 0.0, 0.0, 800.0, 0.0, 0.0, 0.0])  # exp(signal) overflows at t = 3: every log-weight is -Inf there
+    model = M.ssm_ung(y, Z=1.0, T=1.0, R=0.3, a1=0.0, P1=1.0, distribution="poisson", D=D)
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "grid")
+    monkeypatch.setenv("BSSM_AMD_GRID_PPT", ppt)
+    with pytest.warns(UserWarning, match="stopped prematurely"):
+        out = F.bootstrap_filter(model, N, seed=3, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), N, seed=3)
+    assert out["logLik"] == -np.inf and ref["logLik"] == -np.inf
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert np.all(np.isfinite(ref["weights"][:, :3])) and ref["weights"][:, :3].max() == 1.0  # healthy up to t = 2
+    np.testing.assert_allclose(out["weights"], ref["weights"], rtol=1e-9, atol=0, equal_nan=True)
+    np.testing.assert_allclose(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"], rtol=1e-9, atol=1e-12, equal_nan=True)
+    assert np.all(out["weights"][:, 4:] == 0.0) and np.all(out["indices"][:, 3:] == 0)
