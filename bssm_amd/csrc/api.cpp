@@ -1316,7 +1316,7 @@ int device_lg_batch(const std::vector<const bssm::LgPacked*>& lgs, const std::ve
   HIP_TRY(hipMemcpyAsync(din.p, sin.p, ins * F * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(bssm::launch_transpose(din.as<double>(), din_t.as<double>(), F, (int)ins, st));  // [F][E] -> [E][F]
   bssm::LgBatchDev b{};
-  b.F = F; b.n = (int)n; b.m = (int)m;
+  b.F = F; b.n = (int)n; b.m = (int)m; b.sub = L0.sub;
   b.Zs = L0.Zs; b.Ts = L0.Ts; b.Rs = L0.Rs; b.Ds = L0.Ds; b.Cs = L0.Cs; b.Hs = L0.Hs;
   b.oZ = L0.oZ; b.oT = L0.oT; b.oR = L0.oR; b.oD = L0.oD; b.oC = L0.oC; b.oy = L0.oy; b.oH = L0.oH; b.oa = L0.oa; b.oP = L0.oP;
   b.in_stride = ins;
@@ -1786,6 +1786,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   };
   auto post = [&](int i) -> std::string {
     if (!pending[i]) return "";
+    bssm::psi_setup_compact(lgs[i], &sus[i]);  // multivariate observations: the smoother ran one series at a time
     bssm::build_psi_tables(hms[i], sus[i], MP, &J.tabs[i]);
     hms[i] = bssm::HostModel(); sus[i] = bssm::PsiSetup(); lgs[i] = bssm::LgPacked();
     pending[i] = 0;

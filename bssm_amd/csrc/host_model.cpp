@@ -608,6 +608,15 @@ double const_term(const HostModel& h) {
 }
 
 bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out, const GlobalApprox* global) {
+  if (is_mode && h.p > 1 && std::getenv("BSSM_AMD_MV_SEQUENTIAL")) {
+    // test hook: the series-at-a-time smoother the device batch runs for multivariate observations, on the host
+    LgPacked lg;
+    if (psi_setup_begin(h, is_mode, out, &lg)) {
+      const bool ok = lg_packed_run(lg, out->alphahat.data(), out->Vt.data(), out->Ct.data());
+      psi_setup_compact(lg, out);
+      return ok;
+    }
+  }
   const int n = h.n, m = h.m, p = h.p;
   const Sys S(h);
   Approx ap;
@@ -685,9 +694,79 @@ void lg_pack(const HostModel& h, const Approx& ap, LgPacked* lg) {
 }
 }  // namespace
 
+namespace {
+// ssm_mng's approximating model (independent series) packed for the series-at-a-time smoother: Z rows per (time point,
+// series), D / y / H per (time point, series), T / R R' / C per time point
+bool lg_pack_mv(const HostModel& h, const Approx& ap, LgPacked* lg) {
+  const int n = h.n, m = h.m, k = h.k, p = h.p;
+  lg->n = n * p; lg->m = m; lg->sub = p;
+  lg->Zs = h.Ztv ? p * m : 0; lg->Ts = h.Ttv ? m * m : 0; lg->Rs = h.Rtv ? m * m : 0; lg->Ds = h.Dtv ? p : 0; lg->Cs = h.Ctv ? m : 0; lg->Hs = 1;
+  const int nZt = h.Ztv ? n : 1, nR = h.Rtv ? n : 1;
+  const size_t nZ = (size_t)nZt * p * m, nT = (size_t)(h.Ttv ? n : 1) * m * m, nRR = (size_t)nR * m * m;
+  const size_t nD = (size_t)(h.Dtv ? n : 1) * p, nC = (size_t)(h.Ctv ? n : 1) * m, nv = (size_t)n * p;
+  size_t o = 0;
+  lg->oZ = o; o += nZ; lg->oT = o; o += nT; lg->oR = o; o += nRR; lg->oD = o; o += nD; lg->oC = o; o += nC;
+  lg->oy = o; o += nv; lg->oH = o; o += nv; lg->oa = o; o += m; lg->oP = o; o += (size_t)m * m;
+  lg->buf.resize(o);
+  double* b = lg->buf.data();
+  for (int t = 0; t < nZt; t++)  // h.Z is p x m column-major per time point: one contiguous row per series here
+    for (int j = 0; j < p; j++) for (int c = 0; c < m; c++) b[lg->oZ + ((size_t)t * p + j) * m + c] = h.Z[j + (size_t)p * c + (size_t)p * m * t];
+  std::memcpy(b + lg->oT, h.T.data(), nT * sizeof(double));
+  for (int t = 0; t < nR; t++) {
+    const double* R = h.R.data() + (size_t)m * k * t;
+    double* RR = b + lg->oR + (size_t)m * m * t;
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) {
+      double sacc = 0.0;
+      for (int q = 0; q < k; q++) sacc += R[i + m * q] * R[j + m * q];
+      RR[i + m * j] = sacc;
+    }
+  }
+  std::memcpy(b + lg->oD, h.D.data(), nD * sizeof(double));
+  std::memcpy(b + lg->oC, h.C.data(), nC * sizeof(double));
+  std::memcpy(b + lg->oy, ap.y.data(), nv * sizeof(double));
+  std::memcpy(b + lg->oH, ap.H.data(), nv * sizeof(double));
+  std::memcpy(b + lg->oa, h.a1.data(), (size_t)m * sizeof(double));
+  std::memcpy(b + lg->oP, h.P1.data(), (size_t)m * m * sizeof(double));
+  return true;
+}
+}  // namespace
+
+// the smoother ran over n * sub virtual steps: keep the entries of the time points (index s * sub)
+void psi_setup_compact(const LgPacked& lg, PsiSetup* su) {
+  if (lg.sub <= 1) return;
+  const int m = lg.m, sub = lg.sub, n = lg.n / sub;
+  const size_t mm = (size_t)m * m;
+  for (int s = 1; s <= n; s++) {
+    std::memmove(su->alphahat.data() + (size_t)m * s, su->alphahat.data() + (size_t)m * s * sub, (size_t)m * sizeof(double));
+    std::memmove(su->Vt.data() + mm * s, su->Vt.data() + mm * s * sub, mm * sizeof(double));
+    std::memmove(su->Ct.data() + mm * s, su->Ct.data() + mm * s * sub, mm * sizeof(double));
+  }
+  su->alphahat.resize((size_t)m * (n + 1));
+  su->Vt.resize(mm * (n + 1));
+  su->Ct.resize(mm * (n + 1));
+}
+
 bool psi_setup_begin(const HostModel& h, const double* is_mode, PsiSetup* out, LgPacked* lg) {
-  if (!is_mode || !LgHostModel::applies(h)) return false;
+  const bool mv = h.p > 1 && h.m >= 1 && h.m <= 8 && !std::getenv("BSSM_AMD_GENERIC_SETUP");
+  if (!is_mode || !(mv || LgHostModel::applies(h))) return false;
   const int n = h.n, m = h.m, p = h.p;
+  if (mv) {
+    Approx ap;
+    ap.y.assign((size_t)p * n, 0.0);
+    ap.H.assign((size_t)p * n, 0.0);
+    out->mode.assign(is_mode, is_mode + (size_t)p * n);  // approximate_for_is: src/model_ssm_mng.cpp:117-133
+    laplace_iter(h, out->mode, &ap);
+    update_scales(h, ap, out->mode, &out->scales);
+    out->approx_loglik = 0.0;
+    out->iterations = 0;
+    out->approx_y = ap.y;
+    out->approx_H = ap.H;
+    const size_t nv1 = (size_t)n * p + 1;  // virtual steps + 1 until psi_setup_compact
+    out->alphahat.assign((size_t)m * nv1, 0.0);
+    out->Vt.assign((size_t)m * m * nv1, 0.0);
+    out->Ct.assign((size_t)m * m * nv1, 0.0);
+    return lg_pack_mv(h, ap, lg);
+  }
   Approx ap;
   ap.y.assign((size_t)p * n, 0.0);
   ap.H.assign((size_t)p * n, 0.0);
@@ -746,7 +825,7 @@ bool ung_pack(const HostModel& h, const double* is_mode, LgPacked* lg) {
 bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct) {
   const double* b = lg.buf.data();
   LgModel g;
-  g.n = lg.n;
+  g.n = lg.n; g.sub = lg.sub;
   g.Z = b + lg.oZ; g.Zs = lg.Zs; g.T = b + lg.oT; g.Ts = lg.Ts; g.RR = b + lg.oR; g.Rs = lg.Rs;
   g.D = b + lg.oD; g.Ds = lg.Ds; g.C = b + lg.oC; g.Cs = lg.Cs; g.y = b + lg.oy; g.H = b + lg.oH; g.Hs = lg.Hs;
   g.a1 = b + lg.oa; g.P1 = b + lg.oP;

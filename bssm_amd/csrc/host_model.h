@@ -60,18 +60,22 @@ bool gaussian_smoother(const HostModel& hm, std::vector<double>* alphahat, std::
 // (lg_smoother.h; one GPU lane per draw).  *_begin does everything up to the smoother (approximation at the stored
 // mode, scales) and packs the approximating linear-Gaussian model; the caller runs the smoother (device batch or
 // lg_packed_run on the host) into su->alphahat / Vt / Ct; build_*_tables then proceeds as after psi_setup().
-// They return false when the fixed-size smoother does not apply (multivariate observations, m > 8): use psi_setup().
+// They return false when the fixed-size smoother does not apply (m > 8): use psi_setup().  Multivariate observations
+// (ssm_mng: independent series) go through the same smoother one series at a time (LgModel::sub); psi_setup_compact then
+// keeps the entries of the time points.
 struct LgPacked {
-  int n = 0, m = 0;
+  int n = 0, m = 0;   // n: (virtual) steps of the smoother = time points x sub
+  int sub = 1;        // series per time point treated one at a time (LgModel::sub); > 1: ssm_mng's approximating model
   int Zs = 0, Ts = 0, Rs = 0, Ds = 0, Cs = 0, Hs = 0;            // strides in doubles, 0 = time-invariant
   size_t oZ = 0, oT = 0, oR = 0, oD = 0, oC = 0, oy = 0, oH = 0, oa = 0, oP = 0;  // offsets into buf
   size_t ou = 0, ox = 0, om = 0, oh = 0;                          // ung_pack only: u, x'beta, stored mode, (distribution, phi)
   std::vector<double> buf;                                        // [Z | T | R R' | D | C | y - x'beta | H | a1 | P1]
   bool same_layout(const LgPacked& o) const {
-    return n == o.n && m == o.m && Zs == o.Zs && Ts == o.Ts && Rs == o.Rs && Ds == o.Ds && Cs == o.Cs && Hs == o.Hs && buf.size() == o.buf.size();
+    return n == o.n && m == o.m && sub == o.sub && Zs == o.Zs && Ts == o.Ts && Rs == o.Rs && Ds == o.Ds && Cs == o.Cs && Hs == o.Hs && buf.size() == o.buf.size();
   }
 };
 bool psi_setup_begin(const HostModel& hm, const double* is_mode, PsiSetup* out, LgPacked* lg);
+void psi_setup_compact(const LgPacked& lg, PsiSetup* su);
 // The WHOLE psi set-up of an ssm_ung draw on the device (ung_setup_kernel: Laplace step at the stored mode, scales,
 // smoother, conditional factors, the filter's tables): the host only packs the draw -- [Z | T | R R' | D | C | y (raw) |
 // a1 | P1 | u | x'beta | mode | distribution, phi].  False when the fixed-size smoother does not apply.

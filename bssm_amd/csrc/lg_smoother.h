@@ -33,6 +33,13 @@ struct LgModel {
   const double* H;  int Hs;   // [(1|n)] observation sd
   const double* a1;           // [M]
   const double* P1;           // [M*M]
+  // Multivariate observations with independent series (ssm_mng's approximating model: H diagonal), treated one series
+  // at a time: `sub` = p virtual steps per time point, n = p * (time points).  Virtual step t observes series t % sub of
+  // time point t / sub (Z row at Z + (t / sub) * Zs + (t % sub) * M, D at D + (t / sub) * Ds + t % sub, y and H at [t]);
+  // the state moves (T, RR, C of time point t / sub) only behind the last series of a time point, in between the
+  // transition is the identity without noise.  Smoothed moments of time point s sit at index s * sub; the conditional
+  // factors are computed at those indices only.  sub = 1: the plain univariate model.
+  int sub = 1;
 };
 
 LG_HD inline bool lg_finite(double x) { return x == x && fabs(x) <= DBL_MAX; }
@@ -129,11 +136,19 @@ struct LgSmoother {
     ldv(g.a1, es, M, a); ldv(g.P1, es, MM, P);
     stv(at, es, M, a); stv(Pt, es, MM, P);
     // ---- forward pass (kf_predict, univariate branch, Joseph form)
+    const int sub = g.sub;
     for (int t = 0; t < n; t++) {
-      ldv(g.Z + (size_t)t * g.Zs * es, es, M, Z);
-      ldv(g.T + (size_t)t * g.Ts * es, es, MM, T);
-      ldv(g.RR + (size_t)t * g.Rs * es, es, MM, RR);
-      ldv(g.C + (size_t)t * g.Cs * es, es, M, Cv);
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      const bool moves = sub == 1 || js == sub - 1;  // the state moves behind this (virtual) step
+      ldv(g.Z + ((size_t)tr * g.Zs + (size_t)js * M) * es, es, M, Z);
+      if (moves) {
+        ldv(g.T + (size_t)tr * g.Ts * es, es, MM, T);
+        ldv(g.RR + (size_t)tr * g.Rs * es, es, MM, RR);
+        ldv(g.C + (size_t)tr * g.Cs * es, es, M, Cv);
+      } else {
+        for (int q = 0; q < MM; q++) { T[q] = 0.0; RR[q] = 0.0; }
+        for (int i = 0; i < M; i++) { T[i + M * i] = 1.0; Cv[i] = 0.0; }
+      }
       const double yt = g.y[(size_t)t * es];
       const bool na = !lg_finite(yt);
       const double sd = g.H[(size_t)t * g.Hs * es];
@@ -158,7 +173,7 @@ struct LgSmoother {
       } else {
         double za = 0.0;
         for (int c = 0; c < M; c++) za += Z[c] * a[c];
-        const double vt = yt - g.D[(size_t)t * g.Ds * es] - za;
+        const double vt = yt - g.D[((size_t)tr * g.Ds + js) * es] - za;
         v[(size_t)t * es] = vt;
         double au[M];
         for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += P[i + M * q] * Z[q]; Kt[i] = s / F; }
@@ -185,8 +200,14 @@ struct LgSmoother {
     for (int i = 0; i < M; i++) rt[i] = 0.0;
     for (int q = 0; q < MM; q++) Nt[q] = 0.0;
     for (int t = n - 1; t >= 0; t--) {
-      ldv(g.Z + (size_t)t * g.Zs * es, es, M, Z);
-      ldv(g.T + (size_t)t * g.Ts * es, es, MM, T);
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      ldv(g.Z + ((size_t)tr * g.Zs + (size_t)js * M) * es, es, M, Z);
+      if (sub == 1 || js == sub - 1) {
+        ldv(g.T + (size_t)tr * g.Ts * es, es, MM, T);
+      } else {
+        for (int q = 0; q < MM; q++) T[q] = 0.0;
+        for (int i = 0; i < M; i++) T[i + M * i] = 1.0;
+      }
       ldv(at + (size_t)t * M * es, es, M, a);
       ldv(Pt + (size_t)t * MM * es, es, MM, P);
       ldv(cc + (size_t)t * MM * es, es, MM, ct);
@@ -227,6 +248,7 @@ struct LgSmoother {
     // ---- conditional_cov: Vt <- U sqrt(s) of Var(alpha_t | alpha_{t-1}, y), Ct <- Cov' pinv(V_{t-1})
     double U[MM], s[M], W[MM], Vp[MM], Vc[MM], Cp[MM];
     for (int t = n; t > 0; t--) {
+      if (sub > 1 && t % sub != 0) continue;  // a virtual step inside a time point: no factor of its own
       ldv(Pt + (size_t)(t - 1) * MM * es, es, MM, Vp);
       ldv(Pt + (size_t)t * MM * es, es, MM, Vc);
       ldv(cc + (size_t)(t - 1) * MM * es, es, MM, Cp);

@@ -121,7 +121,7 @@ hipError_t launch_stratified_sample(double* p, const double* r, uint32_t* out, i
 // Vt / Ct [(n+1) m m][F]; scratch K [n m][F], v / Fs [n][F]; ok [F] = 1 when every result is finite.
 // launch_transpose converts between per-draw contiguous [rows][cols] and interleaved [cols][rows].
 struct LgBatchDev {
-  int F, n, m;
+  int F, n, m, sub;   // sub: series per time point treated one at a time (LgModel::sub), 1 = univariate observations
   int Zs, Ts, Rs, Ds, Cs, Hs;
   size_t oZ, oT, oR, oD, oC, oy, oH, oa, oP, in_stride;
   const double* in;

@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64) lg_setup_kernel(const LgBatchDev b) {
   const size_t F = (size_t)b.F;
   const double* in = b.in + d;
   LgModel g;
-  g.n = b.n;
+  g.n = b.n; g.sub = b.sub > 1 ? b.sub : 1;
   g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
   g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = in + b.oy * F; g.H = in + b.oH * F; g.Hs = b.Hs;
   g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;

@@ -100,3 +100,30 @@ def test_mng_post_correct_with_update_fn(oracle):
         assert abs(out["loglik"][i] - ref["logLik"]) <= 1e-8 * n
     assert np.all(np.isfinite(out["alphahat"])) and np.all(np.isfinite(out["Vt"]))
     assert T0.shape == (2, 2)
+
+
+def test_mng_post_correct_device_smoother_equals_host(oracle, monkeypatch):
+    """SURVEY 8f rank 1 for multivariate observations: the covariance smoother of every retained draw runs on the device
+    (one lane per draw, the series of a time point one at a time) -- same weights, log-likelihoods and summaries as the
+    matrix-form host set-up"""
+    from bssm_amd import post_correct as PC
+    base = ZOO["tv_binom_gamma"]
+
+    def update_fn(theta):
+        return dict(R=np.diag(np.exp(theta[:2])))
+
+    model = M.BssmModel(base.classes, **{**base, "update_fn": update_fn, "theta": np.log([0.3, 0.2])})
+    rng = np.random.default_rng(6)
+    ns = 40
+    theta = np.log([0.3, 0.2]) + rng.normal(0, 0.1, (ns, 2))
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    arrs = PC.expand_models(model, theta)
+    modes = np.stack([oracle.mng_psi_setup(a)["mode"].reshape(-1, order="F") for a in arrs], axis=1)
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type=2)
+    res = {}
+    for dev in ("0", "1"):
+        monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+        res[dev] = PC.post_correct(model, mo, 64, threads=2, is_type="is2", seed=3)
+    for k in ("weights", "loglik", "alphahat", "Vt"):
+        assert np.allclose(res["0"][k], res["1"][k], rtol=1e-9, atol=1e-12), k
+    assert np.all(np.isfinite(res["1"]["loglik"]))

@@ -259,3 +259,27 @@ def test_run_mcmc_scale_marker_and_ekf_guard():
                    theta_scale="natural", transformed=[0, 1])
         with pytest.raises(ValueError, match="do not agree"):
             PC.post_correct(model, bad, 8, seed=1)
+
+
+def test_series_at_a_time_smoother_equals_matrix_form(monkeypatch):
+    """ssm_mng's approximating model has independent series, so the covariance smoother may treat them one at a time
+    (LgModel::sub: what the device batch runs for multivariate observations) -- against the matrix-form host routines:
+    smoothed means, conditional regression matrices and covariances agree to rounding; the factor of a covariance with
+    repeated eigenvalues is a convention inside the eigenspace, so factors are compared through V V'"""
+    from models_zoo import mng_zoo
+    for name, model in sorted(mng_zoo().items()):
+        mode = F.psi_setup(model)["mode"]
+        monkeypatch.delenv("BSSM_AMD_MV_SEQUENTIAL", raising=False)
+        a = F.psi_setup(model, is_mode=mode)
+        monkeypatch.setenv("BSSM_AMD_MV_SEQUENTIAL", "1")
+        b = F.psi_setup(model, is_mode=mode)
+        monkeypatch.delenv("BSSM_AMD_MV_SEQUENTIAL")
+        n = model.n
+        assert np.allclose(a["alphahat"], b["alphahat"], rtol=1e-11, atol=1e-13), name
+        assert np.allclose(a["Ct"][:, :, 1:], b["Ct"][:, :, 1:], rtol=1e-9, atol=1e-12), name
+        for t in range(n + 1):
+            va, vb = a["Vt"][:, :, t], b["Vt"][:, :, t]
+            assert np.allclose(va @ va.T, vb @ vb.T, rtol=1e-9, atol=1e-13), (name, t)
+        for k in ("scales", "approx_y", "approx_H"):
+            ok = np.isfinite(a[k])
+            assert np.array_equal(a[k][ok], b[k][ok]), (name, k)
