@@ -99,3 +99,34 @@ def test_skewed_weights_batches_match_oracle(oracle, monkeypatch, N, R, ppt):
         ess = 1.0 / np.sum((ref["weights"][:, 6] / ref["weights"][:, 6].sum()) ** 2)
         assert ess < 0.05 * N  # the case is as skewed as intended
         assert abs(got[r] - ref["logLik"]) <= 1e-9 * n, (r, got[r], ref["logLik"])
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_step_kernel_random_shapes_match_oracle(oracle, monkeypatch, case):
+    """Random (particle count, particles per lane, weight skew, state dimension) through the round-2 step kernel's search:
+    windows of one and two source blocks, windows that overflow (the generic search), ragged and complete last blocks --
+    ancestors, weights and log-likelihood against the oracle"""
+    rng = np.random.default_rng(1000 + case)
+    ppt = int(rng.choice([2, 4]))
+    chunk = 256 * ppt
+    nblocks = int(rng.integers(2, 17))
+    N = nblocks * chunk if rng.random() < 0.6 else nblocks * chunk - int(rng.integers(1, chunk))
+    n = 12
+    skew = float(rng.choice([0.05, 0.3, 1.0, 3.0]))          # observation scale: small = nearly degenerate weights
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        y = rng.poisson(np.exp(rng.normal(1.0, 0.5, n))).astype(float)
+        model = M.bsm_ng(y, sd_level=0.4 / skew, sd_slope=0.1, distribution="poisson", P1=np.diag([2.0 / skew, 0.3]), a1=[1.0, 0.0])
+    elif kind == 1:
+        y = rng.normal(0, 1, n)
+        model = M.ssm_ung(rng.poisson(3.0, n).astype(float), Z=1.0, T=0.9, R=0.5 / skew, a1=1.0, P1=1.0 / skew, distribution="poisson")
+    else:
+        from models_zoo import negbin_m4
+        model = negbin_m4(n, seed=2000 + case)
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "grid")
+    monkeypatch.setenv("BSSM_AMD_GRID_PPT", str(ppt))
+    out = F.bootstrap_filter(model, N, seed=7 + case, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), N, seed=7 + case)
+    assert np.array_equal(out["indices"], ref["indices"]), (N, ppt, kind, skew)
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert np.max(np.abs(out["weights"] - ref["weights"])) <= 1e-9
