@@ -124,7 +124,7 @@ __device__ __forceinline__ double sqrt_small(double x) {
   h = __builtin_fma(h, r, h);
   g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
   g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
-  return x > 0.0 ? g : 0.0;
+  return fmax(g, 0.0);  // x = 0 (u = 1): rsq gives inf, g is NaN, and v_max_f64 returns the other operand: 0
 #else
   return sqrt(x);
 #endif
@@ -132,7 +132,8 @@ __device__ __forceinline__ double sqrt_small(double x) {
 
 // Box-Muller pair from one Philox block
 __device__ __forceinline__ void box_muller(const u32x4& w, double& z0, double& z1) {
-  const double u1 = (u53_to_double(w.x >> 5, w.y >> 6) + 1.0) * 0x1.0p-53;  // (0,1]
+  // (0,1]: (hi27 * 2^26 + lo26 + 1) * 2^-53, every step exact (two conversions and two fused multiply-adds)
+  const double u1 = __builtin_fma((double)(w.x >> 5), 0x1.0p-27, __builtin_fma((double)(w.y >> 6), 0x1.0p-53, 0x1.0p-53));
   const double rad = sqrt_small(-2.0 * tl_log<false>(u1));
   double sn, cs;
   tl_sincos_2pi(w.z, sn, cs);  // angle 2*pi*w2*2^-32
