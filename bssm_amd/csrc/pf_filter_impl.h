@@ -1002,12 +1002,12 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   bool v2ms = false, v2wx = false, v2exact = false;
   (void)v2ms; (void)v2exact;
 #ifndef BSSM_USER_MODEL
-  // round-2 step kernel (pf_grid_v2.h): linear-state models with one observation series, at most 64 particle blocks
+  // round-2 step kernel (pf_grid_v2.h): linear-state models, at most 128 particle blocks per filter
   if constexpr (MP <= 8) {
 #ifdef BSSM_V2_STAMPS
-    bool v2 = !b.fpar && ws.B <= 64 && ppt <= 4;
+    bool v2 = !b.fpar && ws.B <= 128 && ppt <= 4;
 #else
-    bool v2 = !b.fpar && ws.B <= 64 && ppt <= 4 && !ws.dbg;
+    bool v2 = !b.fpar && ws.B <= 128 && ppt <= 4 && !ws.dbg;
 #endif
     if (const char* env = std::getenv("BSSM_AMD_GRID_V2")) v2 = v2 && env[0] != '0';
     // weights exchange (pf_grid_v2.h): with the weights output on, blocks hand over their block-scaled weights instead of

@@ -98,11 +98,25 @@ __device__ __forceinline__ int v2_count_below(const double* sw, int wlen, double
   return lo;
 }
 
+// Block prefixes of a filter as the lanes of a wave hold them: lane l has the inclusive, scaled prefix (and 1 / scale) of
+// block l and of block 64 + l -- up to 128 particle blocks per filter (131 072 particles at four per lane)
+struct V2Prefix {
+  double Qa, Qb, ia, ib;
+  int B;
+  __device__ __forceinline__ int count_below(const double v, const int lane) const {  // number of block prefixes below v
+    int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Qa < v));
+    if (B > 64) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane + 64 < B && Qb < v));  // wave-uniform
+    return c;
+  }
+  __device__ __forceinline__ double q(const int e) const { return e < 64 ? lane_broadcast(Qa, e) : lane_broadcast(Qb, e - 64); }   // e wave-uniform
+  __device__ __forceinline__ double is(const int e) const { return e < 64 ? lane_broadcast(ia, e) : lane_broadcast(ib, e - 64); }
+};
+
 // Ancestor of the wave's active slots (a prefix of its lanes), any shape: loops over the source blocks the slots fall
 // into and over 128-entry windows of each block's local scan.  Every loop bound is wave-uniform.
 //   Q / iscale: this lane's block prefix (inclusive, scaled) and 1 / scale of block `lane`
 template <int PPT, bool WX = false>
-__device__ __forceinline__ int v2_search_generic(const double v, const bool act, const double Q, const double iscale, const int B,
+__device__ __forceinline__ int v2_search_generic(const double v, const bool act, const V2Prefix& px, const int B,
                                                  const int N, const double* __restrict__ coarse, const double* __restrict__ lcdf,
                                                  double* sw, const int lane) {
   constexpr int chunk = GRID_NT * PPT, crow = chunk / 16;
@@ -110,19 +124,19 @@ __device__ __forceinline__ int v2_search_generic(const double v, const bool act,
   if (amask == 0ull) return 0;
   const int l_last = 63 - __builtin_clzll(amask);
   const double v_lo = lane_broadcast(v, 0), v_hi = lane_broadcast(v, l_last);
-  int c_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_lo));
-  int c_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_hi));
+  int c_lo = px.count_below(v_lo, lane);
+  int c_hi = px.count_below(v_hi, lane);
   c_lo = min(c_lo, B - 1); c_hi = min(c_hi, B - 1);
   int sb = c_lo;
-  for (int e = c_lo; e < c_hi; e++) sb += (lane_broadcast(Q, e) < v) ? 1 : 0;
+  for (int e = c_lo; e < c_hi; e++) sb += (px.q(e) < v) ? 1 : 0;
   int anc = 0;
   for (int e = c_lo; e <= c_hi; e++) {
     const bool mine = act && sb == e;
     const unsigned long long mm = __builtin_amdgcn_ballot_w64(mine);
     if (mm == 0ull) continue;
     const int f0 = __builtin_ctzll(mm), f1 = 63 - __builtin_clzll(mm);
-    const double Pm1 = e > 0 ? lane_broadcast(Q, e - 1) : 0.0;
-    const double vp = (v - Pm1) * lane_broadcast(iscale, e);
+    const double Pm1 = e > 0 ? px.q(e - 1) : 0.0;
+    const double vp = (v - Pm1) * px.is(e);
     const double vp_lo = lane_broadcast(vp, f0), vp_hi = lane_broadcast(vp, f1);
     const int slen = min(chunk, N - e * chunk), ncr = (slen + 15) >> 4;
     const double cv = coarse[(size_t)e * crow + (lane < ncr ? lane : ncr - 1)];
@@ -490,7 +504,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   __shared__ double s_win[kMfma ? 4 * 8 * 64 : 4 * PPT * V2_WIN];
   static_assert(!kMfma || PPT * V2_WIN <= 8 * 64, "the MFMA operand tile doubles as the search window");
   __shared__ double s_x[4 + 16 * PPT];
-  __shared__ double s_comb[3 * 64 + 1];  // combine of wave 0: block prefixes, 1 / scale, scale, global maximum
+  __shared__ double s_comb[3 * 128 + 1];  // combine of wave 0: block prefixes, 1 / scale, scale (128 blocks each), global maximum
   // T_t, R_t, C_t of this step.  Read from LDS (broadcast ds_read, same address in every lane) and not through scalar
   // loads: 36 doubles are 72 SGPRs, which with the kernel arguments and the observation row overflowed the scalar file --
   // 58 SGPRs spilled to VGPR lanes and came back through ~250 v_readlane / v_writelane per wave-step (10 % of the VALU work)
@@ -528,7 +542,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wo[r] = li < len ? ld32(wsrc, li) : 0.0; }
   };
   auto rmw_store = [&](const double (&wo)[PPT]) {
-    const double myscale = s_comb[128 + pb];
+    const double myscale = s_comb[256 + pb];
 #pragma unroll
     for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); if (li < len) st32(wt, li, wo[r] * myscale); }
   };
@@ -537,15 +551,24 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   V2_MARK("combine"); V2_STAMP(1);
   if (wave == 0) {
     const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
-    double pmax = -INFINITY, psum = 0.0;
+    double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
     if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
-    const double M0 = wave_max(pmax);
+    if (lane + 64 < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64)); pmaxb = pp.x; psumb = pp.y; }
+    const double M0 = wave_max(fmax(pmax, pmaxb));
     const double scale0 = fast_exp(pmax - M0);  // lanes >= B: 0; a poisoned (NaN) partial makes S NaN below
     const double Q0 = wave_scan_incl(psum * scale0);
     s_comb[lane] = Q0;
-    s_comb[64 + lane] = 1.0 / scale0;
-    s_comb[128 + lane] = scale0;
-    if (lane == 0) s_comb[192] = M0;
+    s_comb[128 + lane] = 1.0 / scale0;
+    s_comb[256 + lane] = scale0;
+    double Q1 = lane_broadcast(Q0, 63);
+    if (B > 64) {  // wave-uniform: blocks 64 ... 127
+      const double scale1 = fast_exp(pmaxb - M0);
+      Q1 += wave_scan_incl(psumb * scale1);
+      s_comb[128 + 64 + lane] = 1.0 / scale1;
+      s_comb[256 + 64 + lane] = scale1;
+    }
+    s_comb[64 + lane] = Q1;  // (B <= 64: the total in every lane)
+    if (lane == 0) s_comb[384] = M0;
   }
   if (tid < NMAT) s_mat[tid] = (b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride)[tid];
   u32x4 blk[PPT];
@@ -564,7 +587,8 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   }
   math_tab_load_end256(mtab);
   lds_barrier();  // (1)
-  const double Q = s_comb[lane], iscale = s_comb[64 + lane], S = s_comb[63], M = s_comb[192];
+  const V2Prefix px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[128 + 64 + lane], B};
+  const double S = s_comb[127], M = s_comb[384];
   V2_MARK("rmw"); V2_STAMP(2);
   // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
   if (!BSSM_V2_RMW_LATE && wt) rmw_store(wt_old);
@@ -614,18 +638,18 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       v[q] = ((double)u * 0x1.0p-32 + (double)(base + wave * (64 * PPT) + PPT * lane + q)) * c_scale;
     }
     const double v_lo = lane_broadcast(v[0], 0), v_hi = lane_broadcast(v[PPT - 1], 63);
-    const int c_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_lo));
-    const int c_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q < v_hi));
+    const int c_lo = px.count_below(v_lo, lane);
+    const int c_hi = px.count_below(v_hi, lane);
     e1 = min(c_lo, B - 1); e2 = min(c_hi, B - 1);
     if (e2 > e1 + 1) { slow = true; e2 = e1; }
-    const double Pm1 = e1 > 0 ? lane_broadcast(Q, (e1 - 1) & 63) : 0.0;
-    const double is1 = lane_broadcast(iscale, e1);
+    const double Pm1 = e1 > 0 ? px.q(e1 - 1) : 0.0;
+    const double is1 = px.is(e1);
     slen1 = min(chunk, N - e1 * chunk); ncr1 = (slen1 + 15) >> 4;
     slen2 = min(chunk, N - e2 * chunk); ncr2 = (slen2 + 15) >> 4;
     auto coarse_row = [&](int e, int ncr) -> double { return ld32(coarse + (size_t)e * crow, lane < ncr ? lane : ncr - 1); };
     cv1 = coarse_row(e1, ncr1);
     if (e2 != e1) {
-      const double P1 = lane_broadcast(Q, e1), is2 = lane_broadcast(iscale, e2);
+      const double P1 = px.q(e1), is2 = px.is(e2);
       cv2 = coarse_row(e2, ncr2);
 #pragma unroll
       for (int q = 0; q < PPT; q++) {
@@ -745,7 +769,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       for (int q = 1; q < PPT; q++) ur = (r == q) ? blk[q].w : ur;  // r is wave-uniform: scalar compare + select
       const int li = v2_li<PPT>(r, tid);
       const double vr = ((double)ur * 0x1.0p-32 + (double)(base + li)) * c_scale;  // the target, as in phase A
-      const int ar = v2_search_generic<PPT, WX>(vr, li < len, Q, iscale, B, N, coarse, lcdf, sw_base, lane);
+      const int ar = v2_search_generic<PPT, WX>(vr, li < len, px, B, N, coarse, lcdf, sw_base, lane);
 #pragma unroll
       for (int q = 0; q < PPT; q++) anc[q] = (r == q) ? ar : anc[q];
     }

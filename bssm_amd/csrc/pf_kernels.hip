@@ -36,16 +36,23 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   const size_t w1 = (size_t)b.F * ((b.N + GRID_NT - 1) / GRID_NT);
   int ppt = 1;
   if (b.MP <= 4 && !b.fpar) {
-    // (states of one or two doubles: the round-2 kernel at four particles per lane wins from 4096 workgroups -- m = 1,
-    // 16 / 20 filters of 65 536 particles: 4.95e10 -> 5.31e10, 5.49e10 -> 6.17e10; scripts/mid_batch_probe.py)
-    // (with one ancestor search per wave the round-2 kernel wins earlier wherever four particles per lane are what brings a
-    // filter down to its limit of 64 blocks -- 65 536 particles: m = 4, 16 / 20 filters 4.06e10 -> 4.33e10, 4.31e10 ->
-    // 4.53e10; m = 1, 8 / 12 filters 3.59e10 -> 4.08e10, 4.39e10 -> 4.91e10)
-    const size_t b1 = (size_t)(b.N + GRID_NT - 1) / GRID_NT, b4 = (size_t)(b.N + 4 * GRID_NT - 1) / (4 * GRID_NT);
-    const bool v2_needs4 = b1 > 64 && b4 <= 64;
-    const size_t thr4 = b.MP <= 2 ? (v2_needs4 ? 2048 : 4096) : (v2_needs4 ? 4096 : 6144);
-    if (w1 >= thr4 && b.N >= 4 * GRID_NT) ppt = 4;
-    else if (w1 >= 3072 && b.N >= 2 * GRID_NT) ppt = 2;
+    // The round-2 kernel (one ancestor search per wave; at most 128 particle blocks per filter) wins wherever more particles per
+    // lane are what make a filter eligible for it.  65 536 particles (256 blocks at one particle per lane, 128 at two), full
+    // output, particle-steps/s at 1 / 2 / 4 particles per lane (scripts/ppt_sweep.py): m = 4 -- 4 filters 2.28 / 2.42 / 1.99e10,
+    // 8: 3.09 / 3.60 / 3.26e10, 16: 3.66 / 4.93 / 4.75e10, 24: 3.60 / 5.15 / 5.36e10; m = 1 -- 3 filters 1.96 / 2.09 / 1.91e10,
+    // 8: 3.56 / 4.89 / 4.51e10, 16: 4.41 / 6.89 / 6.89e10, 20: 4.49 / 7.51 / 7.76e10.
+    const size_t b1 = (size_t)(b.N + GRID_NT - 1) / GRID_NT, b2 = (b1 + 1) / 2, b4 = (b1 + 3) / 4;
+    const bool small = b.MP <= 2;
+    if (b1 > 128 && b2 <= 128) {           // two particles per lane bring the filter into the round-2 kernel
+      if (w1 >= (size_t)(small ? 5120 : 6144) && b.N >= 4 * GRID_NT) ppt = 4;
+      else if (w1 >= (size_t)(small ? 768 : 1024)) ppt = 2;
+    } else if (b2 > 128 && b4 <= 128) {    // only four do
+      if (w1 >= (size_t)(small ? 2048 : 4096)) ppt = 4;
+      else if (w1 >= 3072) ppt = 2;
+    } else {
+      if (w1 >= (size_t)(small ? 4096 : 6144) && b.N >= 4 * GRID_NT) ppt = 4;
+      else if (w1 >= 3072 && b.N >= 2 * GRID_NT) ppt = 2;
+    }
   }
   // 8-dimensional states (round-2 multi-series kernel): two particles per lane once the batch fills the chip twice
   // (C4, 16 384 particles: 32 filters 1.92e10 -> 1.99e10, 64 filters 1.90e10 -> 2.19e10 particle-steps/s; 16 filters 1.58e10 -> 1.37e10)

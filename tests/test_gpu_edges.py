@@ -130,3 +130,23 @@ def test_step_kernel_random_shapes_match_oracle(oracle, monkeypatch, case):
     assert np.array_equal(out["indices"], ref["indices"]), (N, ppt, kind, skew)
     assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
     assert np.max(np.abs(out["weights"] - ref["weights"])) <= 1e-9
+
+
+@pytest.mark.parametrize("N,ppt", [(20000, "1"), (40000, "2"), (100000, "4"), (98304, "4"), (65536, "2")])
+def test_step_kernel_more_than_64_blocks_matches_oracle(oracle, monkeypatch, N, ppt):
+    """Filters of 65 ... 128 particle blocks in the round-2 step kernel (two block prefixes per lane in the wave-local
+    combine, ballots over both halves): ancestors, weights and log-likelihood against the oracle"""
+    from bssm_amd.plan import FilterPlan
+    rng = np.random.default_rng(77)
+    n = 8
+    y = rng.poisson(np.exp(rng.normal(1.0, 0.5, n))).astype(float)
+    model = M.bsm_ng(y, sd_level=0.4, sd_slope=0.1, distribution="poisson", P1=np.diag([2.0, 0.3]), a1=[1.0, 0.0])
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "grid")
+    monkeypatch.setenv("BSSM_AMD_GRID_PPT", ppt)
+    out = F.bootstrap_filter(model, N, seed=21, return_indices=True)
+    k = FilterPlan.last_kernel()
+    assert k.startswith("pf_grid_step_v2<"), k
+    ref = oracle.bsf_filter(M.model_arrays(model), N, seed=21)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert np.max(np.abs(out["weights"] - ref["weights"])) <= 1e-9
