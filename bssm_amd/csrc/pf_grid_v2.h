@@ -6,7 +6,7 @@
 // What changed, and why (PMC of round 1: a wave executes VALU during only ~21 % of its lifetime, the launch pair is
 // VALU-busy 66 %: the step is bound by its dependent chain -- 7 workgroup barriers and, per particle of a lane, three
 // dependent global round trips -- as much as by instruction count):
-//   * the partial combine is WAVE-LOCAL: a filter has at most 64 particle blocks here, so every wave keeps one block
+//   * the partial combine is WAVE-LOCAL: a filter has at most 128 particle blocks here, so every wave keeps one or two block
 //     prefix per lane in registers (max via DPP, one exp, one DPP scan) -- no LDS exchange, no barrier; the source block of
 //     a wave's slots comes from two ballots, its prefix and scale from v_readlane;
 //   * block statistics use the WAVE maximum for the exponentials and rescale by exp(max_wave - max_block) after a single
