@@ -1569,7 +1569,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
 int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::string(int)>& prepare,
                     const std::function<void(int, int)>& finish_chunk, double* weights, double* loglik, double* alpha,
                     double* alphahat_i, double* Vt_i, const std::function<int(int, int)>& device_chunk = nullptr,
-                    const std::function<std::string(int)>& post = nullptr) {
+                    const std::function<std::string(int)>& post = nullptr, int chunk_hint = 0) {
   if (!have_device()) return no_device();
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1577,6 +1577,7 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
   // draws (eight ranks on a 2 340-draw job) would otherwise be ONE chunk and lose the set-up / filter overlap.
   int chunk = 512;
   if (const char* env = std::getenv("BSSM_AMD_IS_CHUNK")) chunk = std::max(1, std::atoi(env));
+  else if (chunk_hint > 0) chunk = chunk_hint;
   else if (cnt < 4 * chunk) chunk = std::max(64, ((cnt + 3) / 4 + 63) / 64 * 64);
   std::vector<std::string> errs(cnt);
   // ONE device thread for the whole call (it only waits on HIP): chunks are handed over through a queue, so its
@@ -1668,7 +1669,10 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   // ingests and packs the draw; Laplace step at the stored mode, scales, smoother, conditional factors and the filter's
   // tables are ONE kernel per pipeline chunk (ung_setup_kernel), whose outputs the filter reads in place.
   // BSSM_AMD_DEVICE_SETUP = 0 / 1 select the host set-up / the device smoother alone (tested against each other and the oracle).
-  bool dev_full = psi && have_device() && p0 == 1 && m <= 8 && job->is_type != 1 && job->models[0].distribution != BSSM_GAUSSIAN;
+  // ssm_mng draws (p0 > 1 independent series per time point): the same through mng_setup_kernel, by default where the
+  // device smoother is the default (few host threads: device_setup_enabled).
+  bool dev_full = psi && have_device() && m <= 8 && job->is_type != 1 &&
+                  (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : device_setup_enabled(job->n_threads));
   if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) dev_full = dev_full && env[0] == '2';
   if (std::getenv("BSSM_AMD_GENERIC_SETUP")) dev_full = false;
   if (dev_full) {
@@ -1677,7 +1681,9 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       std::string err = bssm::ingest_model(&job->models[i], false, &hms[i]);
       if (!err.empty()) return err;
       if (hms[i].n != n || hms[i].m != m || hms[i].k != k || hms[i].p != p0) return "all draws must share n, m, k, p";
-      if (!bssm::ung_pack(hms[i], job->modes + (size_t)n * i, &packs[i])) return "draw cannot be packed for the device set-up";
+      const double* mode_i = job->modes + (size_t)n * p0 * i;
+      if (!(p0 > 1 ? bssm::mng_pack(hms[i], mode_i, &packs[i]) : bssm::ung_pack(hms[i], mode_i, &packs[i])))
+        return "draw cannot be packed for the device set-up";
       return "";
     };
     auto device_chunk_full = [&](int lo, int hi) -> int {
@@ -1689,7 +1695,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
         parallel_for(F, job->n_threads, [&](int q) {
           const int i = lo + q;
           bssm::PsiSetup su;
-          if (!bssm::psi_setup(hms[i], job->modes + (size_t)n * i, &su)) J.bad[i] = 1;
+          if (!bssm::psi_setup(hms[i], job->modes + (size_t)n * p0 * i, &su)) J.bad[i] = 1;
           bssm::build_psi_tables(hms[i], su, MP, &J.tabs[i]);
           hms[i] = bssm::HostModel(); packs[i] = bssm::LgPacked();
         });
@@ -1701,7 +1707,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       const size_t E = L0.buf.size();
       auto ct = std::make_shared<ChunkTables>();
       ct->lo = lo; ct->F = F;
-      ct->ms = (size_t)n * (2 * MP * MP + MP); ct->os = (size_t)n * (bssm::ROW_HDR + bssm::SER_HDR + MP); ct->is = (size_t)MP + (size_t)MP * MP; ct->as = 0;
+      ct->ms = (size_t)n * (2 * MP * MP + MP); ct->os = (size_t)n * (bssm::ROW_HDR + (size_t)p0 * (bssm::SER_HDR + MP)); ct->is = (size_t)MP + (size_t)MP * MP; ct->as = 0;
       StageBuf stage;
       HIP_TRY(stage.alloc(E * F * sizeof(double)));
       double* h = (double*)stage.p;
@@ -1712,7 +1718,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       DevBuf din, din_t;
       HIP_TRY(din.alloc(E * F * sizeof(double)));
       HIP_TRY(din_t.alloc(E * F * sizeof(double)));
-      HIP_TRY(ct->scratch.alloc(bssm::ung_setup_scratch_doubles(n, m) * F * sizeof(double)));
+      HIP_TRY(ct->scratch.alloc((p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m, p0) : bssm::ung_setup_scratch_doubles(n, m)) * F * sizeof(double)));
       HIP_TRY(ct->mats.alloc(ct->ms * F * sizeof(double))); HIP_TRY(ct->obs.alloc(ct->os * F * sizeof(double)));
       HIP_TRY(ct->init.alloc(ct->is * F * sizeof(double)));
       HIP_TRY(ct->ok.alloc((size_t)F * sizeof(int)));
@@ -1720,13 +1726,13 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       HIP_TRY(hipMemcpyAsync(din.p, h, E * F * sizeof(double), hipMemcpyHostToDevice, st));
       HIP_TRY(bssm::launch_transpose(din.as<double>(), din_t.as<double>(), F, (int)E, st));  // [F][E] -> [E][F]
       bssm::UngSetupDev b{};
-      b.F = F; b.n = n; b.m = m;
+      b.F = F; b.n = n; b.m = m; b.p = p0;
       b.Zs = L0.Zs; b.Ts = L0.Ts; b.Rs = L0.Rs; b.Ds = L0.Ds; b.Cs = L0.Cs;
       b.oZ = L0.oZ; b.oT = L0.oT; b.oR = L0.oR; b.oD = L0.oD; b.oC = L0.oC; b.oy = L0.oy; b.oa = L0.oa; b.oP = L0.oP;
       b.ou = L0.ou; b.ox = L0.ox; b.om = L0.om; b.oh = L0.oh;
       b.in = din_t.as<double>(); b.scratch = ct->scratch.as<double>();
       b.mats = ct->mats.as<double>(); b.obs = ct->obs.as<double>(); b.init = ct->init.as<double>(); b.ok = ct->ok.as<int>();
-      HIP_TRY(bssm::launch_ung_setup(b, st));
+      HIP_TRY(p0 > 1 ? bssm::launch_mng_setup(b, st) : bssm::launch_ung_setup(b, st));
       std::vector<int> okv(F);
       HIP_TRY(hipMemcpyAsync(okv.data(), ct->ok.p, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
@@ -1738,7 +1744,10 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       J.chunk_tabs[lo] = ct;
       return 0;
     };
-    return run_is_pipeline(J, cnt, job->n_threads, prepare_full, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk_full, nullptr);
+    // one lane per draw: the set-up kernel of m > 4 states with several series takes as long for 64 draws as for 2 048
+    // (tens of ms per 100 time points), so such jobs go in chunks of up to 2 048 draws instead of >= 4 short ones
+    const int hint = p0 > 1 && m > 4 ? std::min(cnt, 2048) : 0;
+    return run_is_pipeline(J, cnt, job->n_threads, prepare_full, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk_full, nullptr, hint);
   }
   const bool dev_setup = psi && device_setup_enabled(job->n_threads) && have_device();
   std::vector<bssm::PsiSetup> sus(dev_setup ? cnt : 0);

@@ -80,6 +80,8 @@ void psi_setup_compact(const LgPacked& lg, PsiSetup* su);
 // smoother, conditional factors, the filter's tables): the host only packs the draw -- [Z | T | R R' | D | C | y (raw) |
 // a1 | P1 | u | x'beta | mode | distribution, phi].  False when the fixed-size smoother does not apply.
 bool ung_pack(const HostModel& hm, const double* is_mode, LgPacked* lg);
+// the same for an ssm_mng draw (p > 1 independent series per time point, m <= 8): mng_setup_kernel
+bool mng_pack(const HostModel& hm, const double* is_mode, LgPacked* lg);
 // host execution of the packed smoother (what the device kernel does per lane); false = non-finite result
 bool lg_packed_run(const LgPacked& lg, double* alphahat, double* Vt, double* Ct);
 

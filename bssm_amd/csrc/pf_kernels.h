@@ -150,6 +150,7 @@ hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream);
 // draws (ung_pack element order) DRAW-INTERLEAVED: element k of draw d at in[k * F + d].
 struct UngSetupDev {
   int F, n, m;
+  int p = 1;                 // series per time point (ssm_mng: mng_setup_kernel, mng_pack element order; obs rows ROW_HDR + p (SER_HDR + MP))
   int Zs, Ts, Rs, Ds, Cs;
   size_t oZ, oT, oR, oD, oC, oy, oa, oP, ou, ox, om, oh;
   const double* in;
@@ -159,6 +160,8 @@ struct UngSetupDev {
 };
 size_t ung_setup_scratch_doubles(int n, int m);
 hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream);
+size_t mng_setup_scratch_doubles(int n, int m, int p);
+hipError_t launch_mng_setup(const UngSetupDev& b, hipStream_t stream);
 hipError_t launch_transpose(const double* in, double* out, int rows, int cols, hipStream_t stream);
 hipError_t launch_calib_copy(const double* in, double* out, size_t n, hipStream_t stream);
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream);

@@ -496,6 +496,149 @@ hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream) {
   }
   return hipGetLastError();
 }
+// ---------------------------------------------------------------- psi set-up of ssm_mng draws, all of it on the device
+// The same for p > 1 independent observation series per time point (src/model_ssm_mng.cpp:117-133 approximate_for_is,
+// :269-315 Laplace step, :218-255 scales): pseudo-observations per (time point, series), one scale per time point, the
+// smoother over n p virtual steps (LgModel::sub: one series at a time, moments of time point s at index s p), tables
+// with rows of p series.  What psi_setup_begin + lg_setup_kernel + psi_setup_compact + build_psi_tables do between host
+// and device otherwise.
+size_t mng_setup_scratch_doubles(int n, int m, int p) {
+  const size_t mm = (size_t)m * m, nv = (size_t)n * p, n1 = nv + 1;
+  //      ay  aH    scales  at       Pt        cc        K        v    Fs
+  return 2 * nv + n + n1 * m + n1 * mm + n1 * mm + nv * m + nv + nv;
+}
+template <int M>
+__global__ void __launch_bounds__(64) mng_setup_kernel(const UngSetupDev b) {
+  const int d = blockIdx.x * 64 + threadIdx.x;
+  if (d >= b.F) return;
+  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+  const size_t F = (size_t)b.F;
+  const int n = b.n, p = b.p, nv = n * p;
+  const double* in = b.in + d;
+  double* w = b.scratch + d;
+  double* ay = w;     w += (size_t)nv * F;   // approximating y
+  double* aH = w;     w += (size_t)nv * F;
+  double* scl = w;    w += (size_t)n * F;
+  double* at = w;     w += (size_t)(nv + 1) * M * F;
+  double* Pt = w;     w += (size_t)(nv + 1) * MM * F;
+  double* cc = w;     w += (size_t)(nv + 1) * MM * F;
+  double* K = w;      w += (size_t)nv * M * F;
+  double* v = w;      w += (size_t)nv * F;
+  double* Fs = w;
+  for (int t = 0; t < n; t++) {
+    double sc = 0.0;
+    for (int j = 0; j < p; j++) {
+      const size_t q = (size_t)t * p + j;
+      const int dist = (int)in[(b.oh + j) * F];
+      const double phi = in[(b.oh + p + j) * F];
+      const double y = in[(b.oy + q) * F], sg = in[(b.om + q) * F], u = in[(b.ou + q) * F];
+      double HH = 0.0, yy = 0.0, sv = 0.0;
+      switch (dist) {
+        case DIST_POISSON: HH = 1.0 / (exp(sg) * u); yy = y * HH + sg - 1.0; sv = y * sg - u * exp(sg); break;
+        case DIST_BINOMIAL: { const double e = exp(sg); HH = (1.0 + e) * (1.0 + e) / (u * e); yy = y * HH + sg - 1.0 - e; sv = y * sg - u * log1p(e); } break;
+        case DIST_NEGBIN: { const double e = exp(sg) * u; HH = (phi + e) * (phi + e) / (phi * e * (y + phi)); yy = sg + (phi + e) * (y - e) / ((y + phi) * e);
+                            sv = y * sg - (y + phi) * log(phi + u * exp(sg)); } break;
+        case DIST_GAMMA: { const double e = exp(sg) * u; HH = e / (y * phi); yy = sg - e / y + 1.0; sv = -phi * sg - (y * phi * exp(-sg) / u); } break;
+        case DIST_GAUSSIAN: { HH = phi * phi; yy = y; const double r = (y - sg) / phi; sv = -0.5 * r * r; } break;
+        default: break;
+      }
+      const double sd = sqrt(HH);
+      const bool seen = y == y && fabs(y) <= 1.7976931348623157e308;
+      const double r = (yy - sg) / sd;
+      ay[q * F] = yy;
+      aH[q * F] = sd;
+      if (seen) sc += sv + 0.5 * r * r;
+    }
+    scl[(size_t)t * F] = sc;
+  }
+  LgModel g;
+  g.n = nv; g.sub = p;
+  g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
+  g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = ay; g.H = aH; g.Hs = 1;
+  g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
+  const bool ok = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F);
+  b.ok[d] = ok ? 1 : 0;
+  // ---- tables (build_psi_tables, fill_obs_rows): the moments of time point s sit at virtual step s p
+  const int sstride = SER_HDR + MP, OS = ROW_HDR + p * sstride;
+  constexpr int MS = 2 * MP * MP + MP;
+  double* __restrict__ mats = b.mats + (size_t)d * n * MS;
+  double* __restrict__ obs = b.obs + (size_t)d * n * OS;
+  double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
+  for (int t = 0; t < n; t++) {
+    double* mt = mats + (size_t)t * MS;
+    for (int q = 0; q < MS; q++) mt[q] = 0.0;
+    const size_t i0 = (size_t)t * p, i1 = (size_t)(t + 1) * p;
+    double ah0[M], ah1[M], Ct1[MM];
+#pragma unroll
+    for (int j = 0; j < M; j++) { ah0[j] = at[(i0 * M + j) * F]; ah1[j] = at[(i1 * M + j) * F]; }
+#pragma unroll
+    for (int q = 0; q < MM; q++) Ct1[q] = cc[(i1 * MM + q) * F];
+    if (ok) {
+#pragma unroll
+      for (int c = 0; c < M; c++)
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+          mt[j + MP * c] = Ct1[j + M * c];
+          mt[MP * MP + j + MP * c] = Pt[(i1 * MM + j + M * c) * F];
+        }
+#pragma unroll
+      for (int j = 0; j < M; j++) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < M; c++) s += Ct1[j + M * c] * ah0[c];
+        mt[2 * MP * MP + j] = ah1[j] - s;
+      }
+    }
+    double* row = obs + (size_t)t * OS;
+    for (int q = 0; q < OS; q++) row[q] = 0.0;
+    bool any = false;
+    for (int j = 0; j < p; j++) {
+      double* ob = row + ROW_HDR + j * sstride;
+      const size_t q = (size_t)t * p + j;
+      const int dist = (int)in[(b.oh + j) * F];
+      const double phi = in[(b.oh + p + j) * F];
+      const double y = in[(b.oy + q) * F], u = in[(b.ou + q) * F];
+      ob[OB_DIST] = (double)dist;
+      ob[OB_PHI] = phi;
+      const bool seen = y == y && fabs(y) <= 1.7976931348623157e308;
+      if (!seen) continue;
+      any = true;
+      ob[OB_FLAG] = 1.0; ob[OB_Y] = y; ob[OB_U] = u;
+      ob[OB_D] = in[(b.oD + (size_t)t * b.Ds + j) * F];
+#pragma unroll
+      for (int c = 0; c < M; c++) ob[SER_HDR + c] = in[(b.oZ + (size_t)t * b.Zs + (size_t)j * M + c) * F];
+      ob[OB_AUX] = dist == DIST_NEGBIN ? y + phi : (dist == DIST_GAMMA ? y / u : (dist == DIST_GAUSSIAN ? 1.0 / (phi * phi) : 0.0));
+      ob[OB_PSIY] = ay[q * F];
+      ob[OB_PSIIH] = 1.0 / aH[q * F];
+    }
+    row[RH_FLAG] = any ? 1.0 : 0.0;
+    row[RH_SCALE] = any ? scl[(size_t)t * F] : 0.0;
+  }
+  for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
+  if (ok) {
+#pragma unroll
+    for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
+#pragma unroll
+    for (int c = 0; c < M; c++)
+#pragma unroll
+      for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
+  }
+}
+hipError_t launch_mng_setup(const UngSetupDev& b, hipStream_t stream) {
+  const dim3 grid((b.F + 63) / 64), block(64);
+  switch (b.m) {
+    case 1: hipLaunchKernelGGL(mng_setup_kernel<1>, grid, block, 0, stream, b); break;
+    case 2: hipLaunchKernelGGL(mng_setup_kernel<2>, grid, block, 0, stream, b); break;
+    case 3: hipLaunchKernelGGL(mng_setup_kernel<3>, grid, block, 0, stream, b); break;
+    case 4: hipLaunchKernelGGL(mng_setup_kernel<4>, grid, block, 0, stream, b); break;
+    case 5: hipLaunchKernelGGL(mng_setup_kernel<5>, grid, block, 0, stream, b); break;
+    case 6: hipLaunchKernelGGL(mng_setup_kernel<6>, grid, block, 0, stream, b); break;
+    case 7: hipLaunchKernelGGL(mng_setup_kernel<7>, grid, block, 0, stream, b); break;
+    case 8: hipLaunchKernelGGL(mng_setup_kernel<8>, grid, block, 0, stream, b); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 // out[c * rows + r] = in[r * cols + c], 32 x 32 tiles through LDS (both sides coalesced): per-draw contiguous <->
 // draw-interleaved layouts of the smoother batch
 __global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ in, double* __restrict__ out, int rows, int cols) {

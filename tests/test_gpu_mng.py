@@ -127,3 +127,48 @@ def test_mng_post_correct_device_smoother_equals_host(oracle, monkeypatch):
     for k in ("weights", "loglik", "alphahat", "Vt"):
         assert np.allclose(res["0"][k], res["1"][k], rtol=1e-9, atol=1e-12), k
     assert np.all(np.isfinite(res["1"]["loglik"]))
+
+
+@pytest.mark.parametrize("name", sorted(ZOO))
+@pytest.mark.parametrize("output_type", [2, 3])
+def test_mng_full_device_setup_against_oracle(oracle, monkeypatch, name, output_type):
+    """SURVEY 8f rank 1 for ssm_mng draws, all of it on the device (mng_setup_kernel: Laplace step at the stored mode
+    src/model_ssm_mng.cpp:117-133, 269-315, scales :218-255, series-at-a-time smoother, conditional factors, the
+    filter's tables with rows of p series): against the ORACLE's per-draw psi filters at perturbed stored modes and
+    against the product's host set-up"""
+    from bssm_amd import post_correct as PC
+    base = ZOO[name]
+    m = int(base.m)
+    k = np.shape(base["R"])[1]
+
+    def update_fn(theta):
+        R = np.zeros((m, k))
+        R[0, 0], R[min(1, m - 1), min(1, k - 1)] = np.exp(theta[0]), np.exp(theta[1])
+        return dict(R=R)
+
+    th0 = np.log([0.3, 0.2])
+    model = M.BssmModel(base.classes, **{**base, "update_fn": update_fn, "theta": th0})
+    rng = np.random.default_rng(17)
+    ns = 70  # more than one wave of draws
+    theta = th0 + rng.normal(0, 0.1, (ns, 2))
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    arrs = PC.expand_models(model, theta)
+    n, p = model.n, model.p
+    modes = np.stack([oracle.mng_psi_setup(a)["mode"].reshape(-1, order="F") for a in arrs], axis=1)
+    modes = modes + rng.normal(0, 0.05, modes.shape)  # approximate_for_is takes whatever the chain stored
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type=output_type)
+    res = {}
+    for dev in ("2", "1", "0"):
+        monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+        monkeypatch.setenv("BSSM_AMD_TRACE", "1")
+        res[dev] = PC.post_correct(model, mo, 48, threads=2, is_type="is2", seed=13)
+    for i in range(0, ns, 7):
+        ref = oracle.mng_psi_filter(arrs[i], 48, seed=13, stream=i, is_mode=modes[:, i].reshape(p, n, order="F"))
+        assert abs(res["2"]["loglik"][i] - ref["logLik"]) <= 1e-8 * n
+    for dev in ("1", "0"):
+        assert np.allclose(res["2"]["loglik"], res[dev]["loglik"], rtol=0, atol=1e-9 * n)
+        assert np.allclose(res["2"]["weights"], res[dev]["weights"], rtol=1e-8)
+        if output_type == 2:
+            assert np.allclose(res["2"]["alphahat"], res[dev]["alphahat"], rtol=1e-7, atol=1e-9)
+            assert np.allclose(res["2"]["Vt"], res[dev]["Vt"], rtol=1e-6, atol=1e-9)
+    assert np.all(np.isfinite(res["2"]["loglik"]))
