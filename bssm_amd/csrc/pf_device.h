@@ -62,6 +62,20 @@ __device__ __forceinline__ void st32(T* uniform_base, uint32_t index, T value) {
   *(gT*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * (uint32_t)sizeof(T))) = value;
 }
 
+template <class T>
+__device__ __forceinline__ T ld32_nt(const T* uniform_base, uint32_t index) {
+  typedef __attribute__((address_space(1))) const T gT;
+  typedef __attribute__((address_space(1))) const char gC;
+  return __builtin_nontemporal_load((gT*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * (uint32_t)sizeof(T))));
+}
+// the same as a non-temporal store (`nt`: streamed, not kept in the caches): outputs nobody on the device reads again
+template <class T>
+__device__ __forceinline__ void st32_nt(T* uniform_base, uint32_t index, T value) {
+  typedef __attribute__((address_space(1))) T gT;
+  typedef __attribute__((address_space(1))) char gC;
+  __builtin_nontemporal_store(value, (gT*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * (uint32_t)sizeof(T))));
+}
+
 // Hides a uniform table pointer from common-subexpression elimination: loads through the result are re-issued (cheap
 // s_loads from the scalar cache) instead of being kept live in dozens of SGPRs across the code in between -- the
 // m = k = 4 transition needs 72 SGPRs for T, R, C, and holding them across the four particles of a lane spilt 55 SGPRs

@@ -629,6 +629,11 @@ __device__ __forceinline__ int search16_lds(const double* a, int stride, int len
       ws.dbg[(size_t)t * 16 + (k)] = (long long)__builtin_readcyclecounter();                 \
   }
 
+// BSSM_R1_NT: non-temporal cache policy in pf_grid_step, as BSSM_V2_NT in pf_grid_v2.h -- bit 0 ancestor-index stores, bit 1
+// the second (final) store of the output weights, bit 3 the ancestor gathers
+#ifndef BSSM_R1_NT
+#define BSSM_R1_NT 0
+#endif
 template <int MP, int KP, int PPT, bool DBG = false, int FN = FN_NONE, int PM = -1>
 __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE)) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   constexpr int FID = FN > 0 ? FN : 0;
@@ -753,7 +758,10 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
 #pragma unroll
       for (int r = 0; r < PPT; r++) {
         const int li = r * GRID_NT + tid;
-        if (li < len) b.weights[((size_t)f * (n + 1) + t) * N + base + li] = wt_old[r] * myscale;
+        if (li < len) {
+          if constexpr ((BSSM_R1_NT) & 2) __builtin_nontemporal_store(wt_old[r] * myscale, &b.weights[((size_t)f * (n + 1) + t) * N + base + li]);
+          else b.weights[((size_t)f * (n + 1) + t) * N + base + li] = wt_old[r] * myscale;
+        }
       }
     }
     if (!(S > 0.0)) {
@@ -879,10 +887,16 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
         }
         const int anc = sb * chunk + 16 * crw + fine;
         BSSM_STAMP(5)
-        if (b.indices && li < len) b.indices[((size_t)f * n + t) * N + j] = (uint32_t)anc;
+        if (b.indices && li < len) {
+          if constexpr ((BSSM_R1_NT) & 1) __builtin_nontemporal_store((uint32_t)anc, &b.indices[((size_t)f * n + t) * N + j]);
+          else b.indices[((size_t)f * n + t) * N + j] = (uint32_t)anc;
+        }
         double a[MP];
   #pragma unroll
-        for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
+        for (int c = 0; c < MP; c++) {
+          if constexpr ((BSSM_R1_NT) & 8) a[c] = (c < m) ? __builtin_nontemporal_load(&st_old[(size_t)c * N + anc]) : 0.0;
+          else a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
+        }
         BSSM_STAMP(6)
         if constexpr (FN != FN_NONE) {
           if (MP <= 2 && psi_mode == 2) {

@@ -65,6 +65,11 @@ __device__ __forceinline__ v2_d2 v2_ld32_d2(const double* uniform_base, uint32_t
   typedef __attribute__((address_space(1))) const char gC;
   return *(gD2*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * 8u));
 }
+__device__ __forceinline__ v2_d2 v2_ld32_d2_nt(const double* uniform_base, uint32_t index) {
+  typedef __attribute__((address_space(1))) const v2_d2 gD2;
+  typedef __attribute__((address_space(1))) const char gC;
+  return __builtin_nontemporal_load((gD2*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * 8u)));
+}
 // value of lane `src` (any lane, per-lane choice): ds_bpermute on the two halves (LDS crossbar, no LDS memory)
 __device__ __forceinline__ double v2_lane_gather(double v, int src) {
   const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
@@ -536,15 +541,27 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #ifndef BSSM_V2_RMW_LATE
 #define BSSM_V2_RMW_LATE 0
 #endif
+  // BSSM_V2_NT: non-temporal (`nt`, streaming) cache policy -- stores of the outputs the device never reads again: bit 0
+  // ancestor indices, bit 1 output weights; bit 3: the ancestor gathers as non-temporal loads (each line is wanted by
+  // one or two neighbouring waves, then never again; only where kNtGather below says).  Default 11: C2-m4 +2.9 %
+  // (profiles/r02c_ab_nontemporal.txt).
+  // Measured and not kept: bit 2 the new states (read again by the next launch's gathers: -1.3 %), bit 4 the owner's read of
+  // its exchanged weights (-7 %: the consumers' windows want those lines), bit 5 the window loads (-1.3 %)
+#ifndef BSSM_V2_NT
+#define BSSM_V2_NT 11
+#endif
   const double* __restrict__ wsrc = WX ? uniform_ptr(ws.lcdf + ((size_t)(t & 1) * b.F + f) * N + base) : wt;
   auto rmw_load = [&](double (&wo)[PPT]) {
 #pragma unroll
-    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wo[r] = li < len ? ld32(wsrc, li) : 0.0; }
+    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wo[r] = li < len ? (((BSSM_V2_NT) & 16) ? ld32_nt(wsrc, li) : ld32(wsrc, li)) : 0.0; }
   };
   auto rmw_store = [&](const double (&wo)[PPT]) {
     const double myscale = s_comb[256 + pb];
 #pragma unroll
-    for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); if (li < len) st32(wt, li, wo[r] * myscale); }
+    for (int r = 0; r < PPT; r++) {
+      const int li = v2_li<PPT>(r, tid);
+      if (li < len) { if constexpr ((BSSM_V2_NT) & 2) st32_nt(wt, li, wo[r] * myscale); else st32(wt, li, wo[r] * myscale); }
+    }
   };
   double wt_old[PPT];
   if (!BSSM_V2_RMW_LATE && wt) rmw_load(wt_old);
@@ -693,7 +710,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       if (valid) {
         const uint32_t src0 = (second ? off2 : off1) + (uint32_t)i0;
 #pragma unroll
-        for (int k = 0; k < E; k += 2) { const v2_d2 d = v2_ld32_d2(lcdf, src0 + k); x[k] = d.x; x[k + 1] = d.y; }
+        for (int k = 0; k < E; k += 2) { const v2_d2 d = ((BSSM_V2_NT) & 32) ? v2_ld32_d2_nt(lcdf, src0 + k) : v2_ld32_d2(lcdf, src0 + k); x[k] = d.x; x[k + 1] = d.y; }
       }
 #pragma unroll
       for (int j = 1; j < E; j++) x[j] += x[j - 1];
@@ -789,12 +806,16 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   for (int r = 0; r < PPT; r++) {
     const int li = v2_li<PPT>(r, tid);
     if (li >= len) anc[r] = 0;
-    if (idx_out && li < len) st32(idx_out, li, (uint32_t)anc[r]);
+    if (idx_out && li < len) { if constexpr ((BSSM_V2_NT) & 1) st32_nt(idx_out, li, (uint32_t)anc[r]); else st32(idx_out, li, (uint32_t)anc[r]); }
   }
+  // (measured per shape, profiles/r02c_ab_nontemporal.txt: +2.3 % for the full-output m = 4 batch whose two launches'
+  // state slabs, 67 MB, exceed the L2s; -1 ... -3 % for log-likelihood-only runs (the state ping-pong stays cached), for
+  // m = 1 and for the rows of several series -- bit 6 forces it on everywhere)
+  constexpr bool kNtGather = ((BSSM_V2_NT) & 8) && ((WX && !MS && MP == 4) || ((BSSM_V2_NT) & 64));
   auto gather = [&](int r) {
 #pragma unroll
     for (int c = 0; c < MP; c++) {  // (padding components re-read the last real one: no branch per load)
-      const double av = ld32(st_old + (size_t)min(c, m - 1) * N, anc[r]);
+      const double av = kNtGather ? ld32_nt(st_old + (size_t)min(c, m - 1) * N, anc[r]) : ld32(st_old + (size_t)min(c, m - 1) * N, anc[r]);
       a[r % ROLL][c] = (c < m) ? av : 0.0;
     }
   };
@@ -838,7 +859,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     }
     if (li < len) {
 #pragma unroll
-      for (int c = 0; c < MP; c++) if (c < m) st32(st_new + (size_t)c * N, li, x[c]);
+      for (int c = 0; c < MP; c++) if (c < m) { if constexpr ((BSSM_V2_NT) & 4) st32_nt(st_new + (size_t)c * N, li, x[c]); else st32(st_new + (size_t)c * N, li, x[c]); }
     }
     if constexpr (MS) {
 #pragma unroll
