@@ -631,6 +631,12 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   uint32_t* __restrict__ idx_out = b.indices ? uniform_ptr(b.indices + ((size_t)f * n + t) * N + base) : nullptr;
   double* sw_base = s_win + wave * (kMfma ? 8 * 64 : PPT * V2_WIN);
 
+#ifndef BSSM_V2_PRIO
+#define BSSM_V2_PRIO 0
+#endif
+  // BSSM_V2_PRIO: wave priority (s_setprio) raised from here until the ancestor gathers have been requested (1), or only
+  // around the search's global rounds and the gathers (2): measurement option, profiles/r02d_ab_setprio.txt
+  if constexpr ((BSSM_V2_PRIO) == 1 || (BSSM_V2_PRIO) == 3) __builtin_amdgcn_s_setprio(2);
   V2_MARK("phaseA"); V2_STAMP(3);
   // ---- phase A (once per wave): the resampling uniforms go through the wave's LDS window so that a lane holds PPT
   // CONSECUTIVE slots (wave * 64 PPT + PPT lane + q); targets; the source blocks of the wave's first and last target (two
@@ -791,6 +797,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       for (int q = 0; q < PPT; q++) anc[q] = (r == q) ? ar : anc[q];
     }
   }
+  if constexpr ((BSSM_V2_PRIO) == 2) __builtin_amdgcn_s_setprio(2);
   V2_MARK("phaseD"); V2_STAMP(7);
   // ---- phase D: ancestor indices out, ancestor states in flight -- at most ROLL rows of them at a time: row r + ROLL is
   // requested as soon as row r has been propagated (BSSM_V2_ROLL = PPT: all rows at once, as before)
@@ -827,6 +834,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #pragma unroll
   for (int r = 0; r < PPT; r++) __asm__ volatile("" : "+v"(blk[r].x), "+v"(blk[r].y), "+v"(blk[r].z));
 #endif
+  if constexpr ((BSSM_V2_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
   V2_MARK("phaseE"); V2_STAMP(8);
   // ---- phase E: transition normals, alpha_{t+1} = C_t + T_t a + R_t eta (:663-670), signal at t+1
   const bool have_obs = tn < n;
@@ -880,6 +888,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     for (int r = 0; r < PPT; r++) w[r] = 0.0;
   }
   if (BSSM_V2_RMW_LATE && wt) rmw_store(wt_old);
+  if constexpr ((BSSM_V2_PRIO) == 3 || (BSSM_V2_PRIO) == 4) __builtin_amdgcn_s_setprio(3);  // the block statistics: waves about to finish first
   V2_MARK("stats"); V2_STAMP(10);
 #pragma unroll
   for (int r = 0; r < PPT; r++) if (v2_li<PPT>(r, tid) >= len) w[r] = -INFINITY;
