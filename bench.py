@@ -51,11 +51,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def pmc_traffic(R, N, ppt):
-    """HBM bytes per pf_grid_step launch from the committed PMC passes (profiles/r02b_pmc_traffic.json: separate
+    """HBM bytes per pf_grid_step launch from the committed PMC passes (profiles/r02d_pmc_traffic.json: separate
     --pmc FETCH_SIZE / WRITE_SIZE runs of this script, corrected as MI355X_MICROARCH.md prescribes and calibrated on
-    weights_finalize_kernel's known byte count); None when the profile does not match this workload."""
+    calib_copy_kernel's known byte count); None when the profile does not match this workload."""
     try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "r02b_pmc_traffic.json")))
+        p = json.load(open(os.path.join(ROOT, "profiles", "r02d_pmc_traffic.json")))
         if p["replicas"] == R and p["particles"] == N and p["particles_per_thread"] == ppt:
             return p["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
