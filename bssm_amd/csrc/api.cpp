@@ -763,7 +763,9 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   return BSSM_OK;
 }
 
-int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f) {
+// max_states: 4 for the psi-APF (constant diagonal R, diagonal P1), 2 for the EKF particle filter (its device code
+// factors full 2 x 2 covariances per particle)
+int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states = 4) {
   if (!mod || !mod->y || !mod->theta) return fail(BSSM_ERR_INVALID, "model, y, theta must be non-NULL");
   const bool user = mod->model_id == bssm::FN_USER_NLG;
   if (!user && (mod->model_id < bssm::FN_NLG_GROWTH || mod->model_id > bssm::FN_NLG_LINEAR_GAUSSIAN))
@@ -773,16 +775,26 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f) {
   if (user) {
     if (mod->user_slot < 1 || mod->user_slot > 63) return fail(BSSM_ERR_INVALID, "user-defined model without a loaded library");
     const bssm::UserHostFns& h = g_user_host[mod->user_slot];
-    if (mod->n_states < 1 || mod->n_states > 2 || mod->use_ext)
-      return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: at most 2 states, constant diagonal R (R_diag, a1, P1 fields)");
+    const int ms = mod->n_states;
+    if (ms < 1 || ms > max_states)
+      return fail(BSSM_ERR_UNSUPPORTED, max_states == 2 ? "EKF particle filter of a user model: at most 2 states" : "psi-APF of a user model: at most 4 states");
     if (!h.T || !h.Z || !h.Tg || !h.Zg)
       return fail(BSSM_ERR_UNSUPPORTED, "this user model was compiled without BSSM_USER_JACOBIANS (bssm_user_Tg, bssm_user_Zg): the psi-APF and the EKF particle filter need them");
-    if (mod->n_states == 2 && (mod->P1[1] != 0.0 || mod->P1[2] != 0.0))
-      return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: P1 must be diagonal");
+    // the state-independent numbers: R_diag / a1 / P1 (up to 2 states) or the R_ext / a1_ext / P1_ext blocks
+    const double* Rsrc = mod->use_ext ? mod->R_ext : nullptr;
+    const double* asrc = mod->use_ext ? mod->a1_ext : mod->a1;
+    const double* Psrc = mod->use_ext ? mod->P1_ext : mod->P1;
+    if (mod->use_ext && mod->n_etas != ms)
+      return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: constant diagonal R (n_etas = n_states)");
+    for (int c = 0; c < ms; c++) for (int j = 0; j < ms; j++) {
+      if (j == c) continue;
+      if (Rsrc && Rsrc[j + ms * c] != 0.0) return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: constant diagonal R");
+      if (Psrc[j + ms * c] != 0.0) return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: P1 must be diagonal");
+    }
     f->user = &h;
     f->uH = mod->H;
-    for (int j = 0; j < mod->n_states; j++) { f->uR[j] = mod->R_diag[j]; f->ua1[j] = mod->a1[j]; }
-    for (int q = 0; q < mod->n_states * mod->n_states; q++) f->uP1[q] = mod->P1[q];
+    for (int j = 0; j < ms; j++) { f->uR[j] = Rsrc ? Rsrc[j + ms * j] : mod->R_diag[j]; f->ua1[j] = asrc[j]; }
+    for (int q = 0; q < ms * ms; q++) f->uP1[q] = Psrc[q];
   }
   f->y.assign(mod->y, mod->y + mod->n);
   for (int q = 0; q < mod->n_theta; q++) f->theta[q] = mod->theta[q];
@@ -825,7 +837,7 @@ namespace {
 // the initial table, and [a1 | P1 | att1 | L1] behind the functor parameters for the time-0 weights
 int functor_ekpf_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector<double>* fpar, int* m_out) {
   bssm::FnModel f;
-  int rc = to_fn_model(mod, &f);
+  int rc = to_fn_model(mod, &f, 2);
   if (rc) return rc;
   int m = 1, k = 1;
   if ((rc = functor_tables(mod, ft, fpar, &m, &k))) return rc;
@@ -1460,7 +1472,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         db.fb.fn_id = (int)J.fpar[bssm::FP_ID];
       }
       if (!ctabs && !J.amats.empty()) {
-        const size_t as = (size_t)n * (m * m + m);
+        const size_t mp = (size_t)bssm::pad_dim(m), as = (size_t)n * (mp * mp + mp);
         HIP_TRY(st_amat.alloc(F * as * sizeof(double)));
         double* hb = (double*)st_amat.p;
         for (size_t f = 0; f < F; f++) std::memcpy(hb + f * as, J.amats.data() + (size_t)order[pos + f] * as, as * sizeof(double));
@@ -1910,7 +1922,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
     };
     return run_is_pipeline(J, count, n_threads, prepare, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk, nullptr);
   }
-  if (psi) J.amats.assign((size_t)count * n * (m * m + m), 0.0);
+  if (psi) { const size_t mp = (size_t)bssm::pad_dim(m); J.amats.assign((size_t)count * n * (mp * mp + mp), 0.0); }
   const bool dev_setup = psi && device_setup_enabled(n_threads) && have_device();
   std::vector<bssm::FnModel> fms(dev_setup ? count : 0);
   std::vector<bssm::FnSetup> fsus(dev_setup ? count : 0);

@@ -1110,8 +1110,8 @@ void build_psi_tables(const HostModel& h, const PsiSetup& su, int MP, FilterTabl
 namespace {
 double fnH(const FnModel& f) { if (f.id == 7) return f.uH; return f.id == 1 ? std::exp(f.theta[0]) : (f.id == 2 ? std::exp(f.theta[3]) : std::exp(f.theta[0])); }
 void fnRdiag(const FnModel& f, double* r) {
-  r[0] = r[1] = 0;
-  if (f.id == 7) { r[0] = f.uR[0]; r[1] = f.uR[1]; return; }
+  r[0] = r[1] = r[2] = r[3] = 0;  // (callers hold 4 entries: a user model may have up to 4 states)
+  if (f.id == 7) { for (int j = 0; j < f.m; j++) r[j] = f.uR[j]; return; }
   switch (f.id) { case 1: r[0] = std::exp(f.theta[1]); r[1] = std::exp(f.theta[2]); break; case 2: r[0] = std::exp(f.theta[2]); break;
                   case 3: r[0] = std::exp(f.theta[1]); break; default: r[0] = 1.0; }
 }
@@ -1161,7 +1161,7 @@ void fn_linearise(const FnModel& f, const double* zpts, const double* tpts, FnSe
   const int n = f.n, m = f.m;
   for (int t = 0; t < n; t++) {
     const double* zp = zpts + (size_t)m * t; const double* tp = tpts + (size_t)m * t;
-    double* Zt = su->Z.data() + (size_t)m * t; double* Tt = su->T.data() + (size_t)m * m * t; double Tf[2];
+    double* Zt = su->Z.data() + (size_t)m * t; double* Tt = su->T.data() + (size_t)m * m * t; double Tf[4];
     fnZg(f, zp, Zt); fnTg(f, tp, Tt);
     double za = 0; for (int j = 0; j < m; j++) za += Zt[j] * zp[j];
     su->D[t] = fnZ(f, zp) - za;
@@ -1169,7 +1169,7 @@ void fn_linearise(const FnModel& f, const double* zpts, const double* tpts, FnSe
     for (int i = 0; i < m; i++) { double sacc = 0; for (int j = 0; j < m; j++) sacc += Tt[i + m * j] * tp[j]; su->C[i + (size_t)m * t] = Tf[i] - sacc; }
   }
   su->H = fnH(f);
-  double rd[2]; fnRdiag(f, rd);
+  double rd[4]; fnRdiag(f, rd);
   std::memset(su->R, 0, sizeof(su->R));
   for (int i = 0; i < m; i++) su->R[i + m * i] = rd[i];
 }
@@ -1186,23 +1186,23 @@ void fn_gaussian_model(const FnModel& f, const FnSetup& su, HostModel* g) {
 }
 double fn_log_signal_pdf(const FnModel& f, const double* al) {  // src/model_ssm_nlg.cpp:1295-1319
   const int n = f.n, m = f.m;
-  double a1[2], P1[4], rd[2], pv[2], rv[2];
+  double a1[4], P1[16], rd[4], pv[4], rv[4];
   fn_a1P1(f, a1, P1); fnRdiag(f, rd);
   for (int j = 0; j < m; j++) { pv[j] = P1[j + m * j]; rv[j] = rd[j] * rd[j]; }
   double ll = dmvnorm_diag(al, a1, pv, m);
   if (std::isfinite(f.y[0])) ll += dnorm_sd(f.y[0], fnZ(f, al), fnH(f));
   for (int t = 0; t < n - 1; t++) {
-    double mean[2];
+    double mean[4];
     fnT(f, al + (size_t)m * t, mean);
     ll += dmvnorm_diag(al + (size_t)m * (t + 1), mean, rv, m);
     if (std::isfinite(f.y[t + 1])) ll += dnorm_sd(f.y[t + 1], fnZ(f, al + (size_t)m * (t + 1)), fnH(f));
   }
   return ll;
 }
-// out = A B A' for m x m column-major operands, m <= 2: the products are formed in the order the generic Mat operators
+// out = A B A' for m x m column-major operands, m <= 4: the products are formed in the order the generic Mat operators
 // use ((A B) first, every entry summed over the inner index from zero), without their temporaries
 static inline void small_abat(int m, const double* A, const double* B, double* out) {
-  double X[4];
+  double X[16];
   for (int j = 0; j < m; j++)
     for (int i = 0; i < m; i++) { double c = 0.0; for (int q = 0; q < m; q++) c += A[i + m * q] * B[q + m * j]; X[i + m * j] = c; }
   for (int j = 0; j < m; j++)
@@ -1212,14 +1212,14 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
   const int n = f.n, m = f.m, mm = m * m;
   std::vector<double> Pt((size_t)mm * (n + 1), 0.0), Ptt((size_t)mm * n, 0.0);
   at->assign((size_t)m * (n + 1), 0.0); att->assign((size_t)m * n, 0.0);
-  double rd[2]; const double H = fnH(f);
+  double rd[4]; const double H = fnH(f);
   fnRdiag(f, rd);
   fn_a1P1(f, at->data(), Pt.data());
   for (int t = 0; t < n; t++) {
     const double* a = at->data() + (size_t)m * t; const double* P = Pt.data() + (size_t)mm * t;
     double* af = att->data() + (size_t)m * t; double* Pf = Ptt.data() + (size_t)mm * t;
     if (std::isfinite(f.y[t])) {
-      double Zg[2], PZ[2] = {0, 0}, K[2], F = H * H;
+      double Zg[4], PZ[4] = {0, 0, 0, 0}, K[4], F = H * H;
       fnZg(f, a, Zg);
       for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += P[i + m * j] * Zg[j];
       for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
@@ -1227,15 +1227,15 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
       const double cF = std::sqrt(F), v = f.y[t] - fnZ(f, a);
       for (int i = 0; i < m; i++) K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF);
       for (int i = 0; i < m; i++) af[i] = a[i] + K[i] * v;
-      double IKZ[4], J[4];
+      double IKZ[16], J[16];
       for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
       small_abat(m, IKZ, P, J);
       for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pf[i + m * j] = J[i + m * j] + K[i] * H * H * K[j];
     } else { std::memcpy(af, a, sizeof(double) * m); std::memcpy(Pf, P, sizeof(double) * mm); }
-    double Tg[4];
+    double Tg[16];
     fnT(f, af, at->data() + (size_t)m * (t + 1));
     fnTg(f, af, Tg);
-    double Pn[4];
+    double Pn[16];
     small_abat(m, Tg, Pf, Pn);
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = Pn[i + m * j] + (i == j ? rd[i] * rd[i] : 0.0);
   }
@@ -1256,14 +1256,14 @@ void fn_a1P1(const FnModel& f, double* a1, double* P1) {
 }
 
 // initial proposal of the EKF particle filter (src/model_ssm_nlg.cpp:1154-1161): EKF update of (a1, P1) with y_0, then
-// psd_chol of the updated covariance.  Everything m x m column-major, m <= 2.
+// psd_chol of the updated covariance.  Everything m x m column-major, m <= 4.
 void fn_ekpf_init(const FnModel& f, double* a1, double* P1, double* att1, double* L1) {
   const int m = f.m;
   fn_a1P1(f, a1, P1);
-  double Ptt[4] = {0, 0, 0, 0};
+  double Ptt[16] = {0};
   const double y = f.y[0];
   if (std::isfinite(y)) {  // ekf_update_step (:1264-1293)
-    double Zg[2] = {0, 0}, PZ[2] = {0, 0}, K[2];
+    double Zg[4] = {0, 0, 0, 0}, PZ[4] = {0, 0, 0, 0}, K[4];
     fnZg(f, a1, Zg);
     const double H = fnH(f);
     double F = H * H;
@@ -1271,7 +1271,7 @@ void fn_ekpf_init(const FnModel& f, double* a1, double* P1, double* att1, double
     for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
     const double cF = std::sqrt(F), v = y - fnZ(f, a1);
     for (int i = 0; i < m; i++) { K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF); att1[i] = a1[i] + K[i] * v; }
-    double IKZ[4], tmp[4];
+    double IKZ[16], tmp[16];
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double acc = 0; for (int q = 0; q < m; q++) acc += IKZ[i + m * q] * P1[q + m * j]; tmp[i + m * j] = acc; }
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double acc = 0; for (int q = 0; q < m; q++) acc += tmp[i + m * q] * IKZ[j + m * q]; Ptt[i + m * j] = acc + K[i] * H * H * K[j]; }
@@ -1350,7 +1350,7 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
       gll = gaussian_loglik(S, ap);
     }
     // update_scales (:854-879)
-    double rd[2], rv[2];
+    double rd[4], rv[4];
     fnRdiag(f, rd);
     for (int j = 0; j < m; j++) rv[j] = rd[j] * rd[j];
     const double HH = su->H * su->H;
@@ -1364,7 +1364,7 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
     }
     for (int t = 1; t < n; t++) {
       const double* mp = su->mode.data() + (size_t)m * (t - 1); const double* md = su->mode.data() + (size_t)m * t;
-      double mean[2], amean[2];
+      double mean[4], amean[4];
       fnT(f, mp, mean);
       for (int i = 0; i < m; i++) { double sacc = 0; for (int j = 0; j < m; j++) sacc += su->T[i + m * j + (size_t)mm * (t - 1)] * mp[j]; amean[i] = su->C[i + (size_t)m * (t - 1)] + sacc; }
       su->scales[t] += dmvnorm_diag(md, mean, rv, m) - dmvnorm_diag(md, amean, rv, m);
@@ -1409,7 +1409,7 @@ bool fn_psi_setup_begin(const FnModel& f, const double* is_mode, FnSetup* su, Lg
 }
 
 void build_fn_psi_tables(const FnModel& f, const FnSetup& su, FilterTables* ft, std::vector<double>* amats) {
-  const int n = f.n, m = f.m, MP = m, KP = m, mm = m * m;
+  const int n = f.n, m = f.m, MP = pad_dim(m), KP = MP, mm = m * m;  // (a 3-state user model runs in the 4-state kernels)
   const int MS = MP * MP + MP * KP + MP;
   ft->MP = MP; ft->KP = KP; ft->mats_tstride = MS;
   ft->mats.assign((size_t)n * MS, 0.0);
@@ -1436,7 +1436,7 @@ void build_fn_psi_tables(const FnModel& f, const FnSetup& su, FilterTables* ft, 
   amats->assign((size_t)n * (MP * MP + MP), 0.0);
   for (int t = 0; t < n; t++) {
     double* am = amats->data() + (size_t)t * (MP * MP + MP);
-    for (int q = 0; q < mm; q++) am[q] = su.T[q + (size_t)mm * t];
+    for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) am[j + MP * c] = su.T[j + m * c + (size_t)mm * t];
     for (int j = 0; j < m; j++) am[MP * MP + j] = su.C[j + (size_t)m * t];
   }
 }

@@ -127,11 +127,11 @@ struct FnModel {
   int positive = 0, L = 0;
   // user-defined ssm_nlg (id 7): host functions and the state-independent numbers the caller supplied
   const UserHostFns* user = nullptr;
-  double uH = 1, uR[2] = {0, 0}, ua1[2] = {0, 0}, uP1[4] = {0, 0, 0, 0};
+  double uH = 1, uR[4] = {0, 0, 0, 0}, ua1[4] = {0, 0, 0, 0}, uP1[16] = {0};
 };
 struct FnSetup {
   std::vector<double> Z, T, D, C;   // m x n, m x m x n, n, m x n : the mode-linearised model
-  double H = 1, R[4] = {0, 0, 0, 0};
+  double H = 1, R[16] = {0};
   std::vector<double> mode, scales;
   double approx_loglik = 0;
   std::vector<double> alphahat, Vt, Ct;

@@ -230,9 +230,11 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
   if constexpr (FN != FN_NONE) {
     constexpr int FID = FN > 0 ? FN : 0;
     const int psi = PM >= 0 ? PM : b.psi;
-    if constexpr (MP <= 2) {  // psi-APF / EKF particle filter: the shapes of the shipped models (the host refuses the others)
+    if constexpr (MP <= 2) {  // EKF particle filter: the shapes of the shipped models (the host refuses the others)
       if (psi == 2) return functor_ekpf_weight<MP, FID>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
-      if (psi) return functor_psi_weight<MP, FID>(fpar, row, amat, t, x, aprev);
+    }
+    if constexpr (MP <= 4) {  // psi-APF: up to 4 states (user-defined models; constant diagonal R)
+      if (psi == 1) return functor_psi_weight<MP, FID>(fpar, row, amat, t, x, aprev);
     }
     return functor_log_weight<MP, FID>(fpar, row, x);
   } else {
@@ -462,10 +464,10 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   if (tid == 0 && b.loglik) b.loglik[f] = loglik;
 }
 
-// the functor kernel of one shape for the batch's sampler (0 bootstrap, 1 psi-APF, 2 EKF particle filter; MP <= 2 only)
+// the functor kernel of one shape for the batch's sampler (0 bootstrap, 1 psi-APF, 2 EKF particle filter: MP <= 2 only)
 template <int MP, int PPT, int FNV, int NTB>
 auto wg_fn_kernel(int psi) -> void (*)(const FilterBatch) {
-  if constexpr (MP > 2) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0>;  // (the host refuses psi / EKF filters beyond two states)
+  if constexpr (MP > 2) return psi == 1 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0>;  // (the host refuses EKF filters beyond two states)
   else return psi == 0 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0> : (psi == 1 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 2>);
 }
 #define WG_FN_KERNEL(PPT_, NTB_) wg_fn_kernel<MP, PPT_, kFn, NTB_>(b.psi)
@@ -982,7 +984,7 @@ namespace bssm {
 
 template <int MP, int KP, int PPT, int FNV>
 auto grid_fn_kernel(int psi) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
-  if constexpr (MP > 2) return pf_grid_step<MP, KP, PPT, false, FNV, 0>;
+  if constexpr (MP > 2) return psi == 1 ? pf_grid_step<MP, KP, PPT, false, FNV, 1> : pf_grid_step<MP, KP, PPT, false, FNV, 0>;
   else return psi == 0 ? pf_grid_step<MP, KP, PPT, false, FNV, 0> : (psi == 1 ? pf_grid_step<MP, KP, PPT, false, FNV, 1> : pf_grid_step<MP, KP, PPT, false, FNV, 2>);
 }
 template <int MP, int KP>

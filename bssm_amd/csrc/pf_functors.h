@@ -261,6 +261,22 @@ __device__ __forceinline__ double functor_psi_weight(const double* __restrict__ 
   if (t > 0) {
     double mean[MP];
     nlg_T_fn<MP>(id, fp, aprev, mean);
+    if constexpr (MP > 2) {
+      // user-defined models with 3 or 4 states (constant diagonal R in the FP_RMAT block; a 3-state model has one padding
+      // component, which carries no noise and no density term)
+      const int m = (int)fp[FP_M];
+#pragma unroll
+      for (int j = 0; j < MP; j++) {
+        if (j < m) {
+          double am = amat[MP * MP + j];
+#pragma unroll
+          for (int c = 0; c < MP; c++) am += (c < m) ? amat[j + MP * c] * aprev[c] : 0.0;
+          const double ir = fdiv(1.0, fp[FP_RMAT + j + MP * j]);
+          const double da = (x[j] - am) * ir, dm = (x[j] - mean[j]) * ir;
+          w += 0.5 * (da * da - dm * dm);
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < MP; j++) {
       double am = amat[MP * MP + j];
@@ -269,6 +285,7 @@ __device__ __forceinline__ double functor_psi_weight(const double* __restrict__ 
       const double ir = fdiv(1.0, fp[FP_R + j]);
       const double da = (x[j] - am) * ir, dm = (x[j] - mean[j]) * ir;
       w += 0.5 * (da * da - dm * dm);
+    }
     }
   }
   return w - row[RH_SCALE];

@@ -574,7 +574,8 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
     the filter kernels (contract: bssm_amd/csrc/pf_functors.h -- ``#define BSSM_USER_NLG 1``, ``bssm_user_T``,
     ``bssm_user_Z``), and the state-independent pieces are numbers: H (observation sd), the diagonal of R, a1, P1.
     With the Jacobians in the snippet (``BSSM_USER_JACOBIANS``, ``bssm_user_Tg``, ``bssm_user_Zg``) the psi-APF and the
-    EKF particle filter work as for the built-in models (1 or 2 states, diagonal R).
+    EKF particle filter work as for the built-in models (constant diagonal R, diagonal P1; psi-APF up to 4 states, EKF
+    particle filter 1 or 2).
     The bootstrap filter / smoother also take up to 4 states, any ``R`` (n_states x n_etas matrix, or a function of theta)
     and the reference's state-dependent ``H_fn`` / ``R_fn`` as snippet functions (``BSSM_USER_HFN`` + ``bssm_user_H``,
     ``BSSM_USER_RFN`` + ``bssm_user_R``; src/model_ssm_nlg.h:12-13), which then replace ``H`` / ``R``."""

@@ -193,8 +193,8 @@ typedef struct bssm_fn_model {
  * bssm_user_model_load maps it and returns a slot >= 1 for bssm_fn_model.user_slot (negative = error).
  * Built for user models: every single-model entry point of the built-in models -- bootstrap, psi-APF (bssm_psi_smoother_nlg,
  * bssm_fn_psi_setup) and EKF particle filter (bssm_ekpf_*) with their smoothers and bssm_fn_loglik_batch; the psi-APF and
- * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS), a diagonal P1, at most 2 states and a constant
- * diagonal R.  The bootstrap filter / smoother / bootstrap IS correction take up to 4 states, any n_states x n_etas matrix
+ * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS), a diagonal P1 and a constant diagonal R (R_diag, or
+ * a diagonal R_ext with n_etas = n_states); the psi-APF takes up to 4 states, the EKF particle filter at most 2.  The bootstrap filter / smoother / bootstrap IS correction take up to 4 states, any n_states x n_etas matrix
  * R and the reference's state-dependent H_fn / R_fn (snippet functions bssm_user_H / bssm_user_R).  IS post-correction
  * (bssm_is_correction_nlg / _multi) and the chains (bssm_run_mcmc_fn; theta-dependent H / R / a1 / P1 through
  * bssm_mcmc_job.fn_update_fn) work for user models too. */

@@ -343,8 +343,8 @@ def test_user_model_three_states_state_dependent_H_and_R(oracle, monkeypatch, pa
     assert abs(sm["logLik"] - ref["logLik"]) <= 1e-9 * n
     ah, Vt = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
     assert _rel(sm["alphahat"], ah.T[:n]) <= 1e-8 and _rel(sm["Vt"], Vt[:, :, :n]) <= 1e-7
-    # the psi-APF / EKF particle filter refuse what they are not built for (more than 2 states, matrix R)
-    with pytest.raises(Exception, match="at most 2 states"):
+    # the psi-APF / EKF particle filter refuse what they are not built for (this snippet has no Jacobians; R is a matrix)
+    with pytest.raises(Exception, match="JACOBIANS|diagonal R"):
         F.particle_smoother(u, 50, method="psi", seed=1)
 
 
@@ -371,3 +371,121 @@ BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) 
     assert np.array_equal(out["indices"], ref["indices"])
     assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
     assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+
+
+USER_LINEAR3 = r"""
+#define BSSM_USER_NLG 1
+#define BSSM_USER_JACOBIANS 1
+// linear-Gaussian model with 3 states written as a user model: T(a) = A a with A column-major in theta[0..7], known[3]
+// (at most 8 theta); Z(a) = z'a with z = known[0..2]
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  out[0] = th[0] * a[0] + th[3] * a[1] + th[6] * a[2];
+  out[1] = th[1] * a[0] + th[4] * a[1] + th[7] * a[2];
+  out[2] = th[2] * a[0] + th[5] * a[1] + kn[3] * a[2];
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return kn[0] * a[0] + kn[1] * a[1] + kn[2] * a[2]; }
+BSSM_FN void bssm_user_Tg(const double* a, const double* th, const double* kn, double* Tg) { for (int q = 0; q < 8; q++) Tg[q] = th[q]; Tg[8] = kn[3]; }
+BSSM_FN void bssm_user_Zg(const double* a, const double* th, const double* kn, double* Zg) { for (int c = 0; c < 3; c++) Zg[c] = kn[c]; }
+"""
+USER_NONLIN4 = r"""
+#define BSSM_USER_NLG 1
+#define BSSM_USER_JACOBIANS 1
+// 4 states, mildly non-linear transition and observation
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  out[0] = a[0] + a[1]; out[1] = th[0] * a[1] + 0.3 * sin(a[2]); out[2] = 0.9 * a[2] + 0.2 * a[3]; out[3] = 0.5 * a[3];
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + 0.5 * a[2] + 0.1 * a[0] * a[0] / (1.0 + a[0] * a[0]); }
+BSSM_FN void bssm_user_Tg(const double* a, const double* th, const double* kn, double* Tg) {
+  for (int q = 0; q < 16; q++) Tg[q] = 0.0;
+  Tg[0 + 4 * 0] = 1.0; Tg[0 + 4 * 1] = 1.0; Tg[1 + 4 * 1] = th[0]; Tg[1 + 4 * 2] = 0.3 * cos(a[2]);
+  Tg[2 + 4 * 2] = 0.9; Tg[2 + 4 * 3] = 0.2; Tg[3 + 4 * 3] = 0.5;
+}
+BSSM_FN void bssm_user_Zg(const double* a, const double* th, const double* kn, double* Zg) {
+  const double q = 1.0 + a[0] * a[0];
+  Zg[0] = 1.0 + 0.2 * a[0] / (q * q); Zg[1] = 0.0; Zg[2] = 0.5; Zg[3] = 0.0;
+}
+"""
+
+
+@pytest.mark.parametrize("path,N", [("wg", 64), ("wg", 1500), ("grid", 5000)])
+def test_user_model_three_states_psi_apf_is_exact_for_a_linear_gaussian_model(oracle, monkeypatch, path, N):
+    """psi-APF of a user model with 3 states (constant diagonal R, diagonal P1; runs in the 4-state kernels with one padding
+    component): for a linear-Gaussian model the approximating model IS the model, every psi weight is one and the
+    estimate equals the Kalman-filter log-likelihood for any N (src/model_ssm_nlg.cpp:993-1064; the oracle's ulg_loglik)"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    rng = np.random.default_rng(21)
+    n = 30
+    A = np.array([[0.8, 0.1, 0.0], [-0.2, 0.7, 0.1], [0.05, 0.0, 0.9]])
+    z = np.array([1.0, 0.5, -0.3]); rd = np.array([0.3, 0.2, 0.1]); Hs = 0.6
+    a1 = np.array([0.2, -0.1, 0.0]); P1 = np.diag([0.5, 0.3, 0.2])
+    a = a1 + rng.normal(size=3) * np.sqrt(np.diag(P1)); y = np.zeros(n)
+    for t in range(n):
+        y[t] = z @ a + Hs * rng.normal(); a = A @ a + rd * rng.normal(size=3)
+    y[7] = np.nan
+    u = M.ssm_nlg_user(y, USER_LINEAR3, theta=A.reshape(-1, order="F")[:8], known_params=np.append(z, A[2, 2]), a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=3)
+    lg = M.ssm_ulg(y, Z=z, H=Hs, T=A, R=np.diag(rd), a1=a1, P1=P1)
+    kal = oracle.ulg_loglik(M.model_arrays(lg))
+    out = F.particle_smoother(u, N, method="psi", seed=3)
+    assert abs(out["logLik"] - kal) <= 1e-8 * n
+    ah = oracle.ulg_smoother(M.model_arrays(lg))[0]  # m x (n + 1)
+    assert abs(F.logLik(u, N, method="psi", seed=11) - kal) <= 1e-8 * n
+    su = F.psi_setup(u)
+    assert abs(su["approx_loglik"] - kal) <= 1e-8 * n
+    # the smoothed means of the particle system scatter around the Kalman smoother's (exact draws, equal weights)
+    if N >= 1500:
+        sm = np.asarray(out["alphahat"])  # (n + 1) x m, or n x m
+        assert np.max(np.abs(sm - ah.T[:sm.shape[0]])) < 6.0 * np.sqrt(np.max(P1) / N) + 0.02
+
+
+def test_user_model_four_states_psi_apf_agrees_with_the_bootstrap_filter(monkeypatch):
+    """non-linear user model with 4 states: the psi-APF and the bootstrap filter estimate the same likelihood (both
+    unbiased; log-mean-exp over seeds), the psi-APF with the smaller spread; IS post-correction through the psi-APF
+    reproduces the single calls"""
+    from bssm_amd import post_correct as PC
+    rng = np.random.default_rng(4)
+    n = 40
+    th = np.array([0.7]); rd = np.array([0.2, 0.15, 0.3, 0.1]); Hs = 0.5
+    a1 = np.zeros(4); P1 = np.diag([0.5, 0.2, 0.3, 0.1])
+    a = rng.normal(size=4) * np.sqrt(np.diag(P1)); y = np.zeros(n)
+    for t in range(n):
+        y[t] = a[0] + 0.5 * a[2] + 0.1 * a[0] ** 2 / (1 + a[0] ** 2) + Hs * rng.normal()
+        a = np.array([a[0] + a[1], th[0] * a[1] + 0.3 * np.sin(a[2]), 0.9 * a[2] + 0.2 * a[3], 0.5 * a[3]]) + rd * rng.normal(size=4)
+    u = M.ssm_nlg_user(y, USER_NONLIN4, theta=th, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=4)
+    lme = lambda v: np.max(v) + np.log(np.mean(np.exp(v - np.max(v))))
+    psi = np.array([F.logLik(u, 2000, method="psi", seed=s) for s in range(24)])
+    bsf = np.array([F.logLik(u, 2000, method="bsf", seed=s) for s in range(24)])
+    assert np.all(np.isfinite(psi)) and np.all(np.isfinite(bsf))
+    assert abs(lme(psi) - lme(bsf)) < 4.0 * (np.std(psi) + np.std(bsf)) / np.sqrt(24) + 0.05
+    assert np.std(psi) < np.std(bsf)
+    for path in ("wg", "grid"):  # both kernel shapes give the same particle system
+        monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+        o = F.particle_smoother(u, 700, method="psi", seed=2)
+        if path == "wg": ref = o
+    assert abs(o["logLik"] - ref["logLik"]) <= 1e-9 * n and _rel(o["alphahat"], ref["alphahat"]) <= 1e-8
+
+
+@pytest.mark.parametrize("dev", ["0", "1"])
+def test_user_model_three_states_post_correct_psi(monkeypatch, dev):
+    """IS post-correction (is2, approximate_for_is at stored modes, src/model_ssm_nlg.cpp:146-176) of the 3-state
+    linear-Gaussian user model: the linearisation of a linear model is the model whatever the stored mode, so every
+    psi weight and every IS weight is exactly one -- through the host set-up (0) and the device smoother (1), with the
+    approximating (T_t, C_t) rows padded to the 4-state kernels"""
+    from bssm_amd import post_correct as PC
+    monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+    rng = np.random.default_rng(23)
+    n, ns = 25, 9
+    A = np.array([[0.8, 0.1, 0.0], [-0.2, 0.7, 0.1], [0.05, 0.0, 0.9]])
+    z = np.array([1.0, 0.5, -0.3]); rd = np.array([0.3, 0.2, 0.1])
+    y = np.cumsum(rng.normal(0, 0.4, n)); y[3] = np.nan
+    u = M.ssm_nlg_user(y, USER_LINEAR3, theta=A.reshape(-1, order="F")[:8], known_params=np.append(z, A[2, 2]), a1=np.zeros(3),
+                       P1=np.diag([0.5, 0.3, 0.2]), H=0.6, R=np.diag(rd), n_states=3)
+    theta = A.reshape(-1, order="F")[:8] + 0.03 * rng.normal(size=(ns, 8))
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    modes = rng.normal(0, 0.5, (3 * n, ns))  # any stored mode
+    for output_type in (2, 3):
+        mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type=output_type)
+        out = PC.post_correct(u, mo, 200, threads=2, is_type="is2", seed=7)
+        assert np.max(np.abs(out["loglik"])) <= 1e-9 * n
+        assert np.allclose(out["weights"], 1.0, rtol=1e-8)
+        if output_type == 2:
+            assert np.all(np.isfinite(out["alphahat"])) and np.all(np.isfinite(out["Vt"]))
