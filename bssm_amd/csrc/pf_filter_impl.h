@@ -268,6 +268,11 @@ template <int MP> constexpr int fn_kernel_id() { return MP == 2 ? FN_NLG_GROWTH 
 constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the fp64 transcendental code
 // Particle i = r * NT + tid (r < PPT): consecutive lanes own consecutive particles, so LDS
 // accesses to the own slot are conflict-free and history stores are coalesced.
+// BSSM_WG_NT: the kept history of the workgroup-resident filters (particle system and ancestor table, written once per step,
+// read once by the back-trace / summary kernels after the filter) goes out with non-temporal stores
+#ifndef BSSM_WG_NT
+#define BSSM_WG_NT 1
+#endif
 template <int MP, int KP, int PPT, int FN = FN_NONE, int NTB = WG_NT_MAX, int PM = -1>
 __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   constexpr int FID = FN > 0 ? FN : 0;
@@ -423,7 +428,10 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       const int i = r * NT + tid;
 #pragma unroll
       for (int c = 0; c < MP; c++) a[r][c] = s_alpha[c * Ncap + lo[r]];
-      if (b.indices && i < N) b.indices[((size_t)f * n + t) * N + i] = (uint32_t)lo[r];
+      if (b.indices && i < N) {
+        if constexpr (BSSM_WG_NT) __builtin_nontemporal_store((uint32_t)lo[r], &b.indices[((size_t)f * n + t) * N + i]);
+        else b.indices[((size_t)f * n + t) * N + i] = (uint32_t)lo[r];
+      }
     }
     WG_STAMP(4);
     lds_barrier();  // (4) all ancestors read before the slots are overwritten
@@ -449,7 +457,10 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
 #pragma unroll
         for (int c = 0; c < MP; c++) {
           s_alpha[c * Ncap + i] = x[c];
-          if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1) + (t + 1)) * m + c) * N + i] = x[c];
+          if (b.alpha_hist && c < m) {
+            if constexpr (BSSM_WG_NT) __builtin_nontemporal_store(x[c], &b.alpha_hist[(((size_t)f * (n + 1) + (t + 1)) * m + c) * N + i]);
+            else b.alpha_hist[(((size_t)f * (n + 1) + (t + 1)) * m + c) * N + i] = x[c];
+          }
         }
       }
       w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)t * (MP * MP + MP), t + 1, x, a[r]) : 0.0) : -INFINITY;

@@ -832,7 +832,11 @@ hipError_t launch_pick_trajectory(const double* hist, const uint32_t* indices, c
 // back-traced particle system is never written: traffic per particle-step is one index gather + the state gathers
 // instead of a full smoothed copy (write 8m) and its re-reads.  bcur [F][N] holds the current ancestors.
 constexpr int SS_NT = 1024;
-template <int M>
+#ifndef BSSM_SS_NT
+#define BSSM_SS_NT 1   // history and ancestor table read with non-temporal loads (each entry is read once)
+#endif
+constexpr int SS_RPT = 4;  // trajectories per thread of the register-resident variant (N <= 4096 at 1024 threads)
+template <int M, bool REG = false>
 __global__ void __launch_bounds__(SS_NT) smooth_summary_kernel(const double* __restrict__ hist,
                                                                const uint32_t* __restrict__ indices,
                                                                uint32_t* __restrict__ bcur_all, double* __restrict__ mean,
@@ -845,17 +849,34 @@ __global__ void __launch_bounds__(SS_NT) smooth_summary_kernel(const double* __r
   const uint32_t* __restrict__ idx = indices + (size_t)f * n * N;
   uint32_t* __restrict__ bcur = bcur_all + (size_t)f * N;
   const double dN = (double)N;
+  uint32_t rb[REG ? SS_RPT : 1];
+  double rv[REG ? SS_RPT : 1][M];
   for (int t = n; t >= 0; t--) {
     const double* __restrict__ ht = h + (size_t)t * m * N;
     // ---- advance the ancestors and accumulate the sums
     double acc[M];
 #pragma unroll
     for (int c = 0; c < M; c++) acc[c] = 0.0;
+    if constexpr (REG) {
+      // N <= SS_RPT * SS_NT: a thread keeps the current ancestors of its trajectories and the values it gathered in
+      // registers -- no ancestor array in global memory, one gather per trajectory and time point (same summation order)
+#pragma unroll
+      for (int r = 0; r < SS_RPT; r++) {
+        const int i = tid + r * SS_NT;
+        if (i < N) {
+          const uint32_t b = (t == n) ? (uint32_t)i : (BSSM_SS_NT ? __builtin_nontemporal_load(&idx[(size_t)t * N + rb[r]]) : idx[(size_t)t * N + rb[r]]);
+          rb[r] = b;
+#pragma unroll
+          for (int c = 0; c < M; c++) { rv[r][c] = c < m ? (BSSM_SS_NT ? __builtin_nontemporal_load(&ht[(size_t)c * N + b]) : ht[(size_t)c * N + b]) : 0.0; acc[c] += rv[r][c]; }
+        }
+      }
+    } else {
     for (int i = tid; i < N; i += SS_NT) {
       const uint32_t b = (t == n) ? (uint32_t)i : idx[(size_t)t * N + bcur[i]];
       bcur[i] = b;
 #pragma unroll
       for (int c = 0; c < M; c++) if (c < m) acc[c] += ht[(size_t)c * N + b];
+    }
     }
 #pragma unroll
     for (int c = 0; c < M; c++) { const double v = wave_sum(acc[c]); if (lane == 0) s_part[wave][c] = v; }
@@ -873,6 +894,21 @@ __global__ void __launch_bounds__(SS_NT) smooth_summary_kernel(const double* __r
     for (int c = 0; c < M; c++) mu[c] = c < m ? s_mean[c] : 0.0;
 #pragma unroll
     for (int q = 0; q < NC; q++) cc[q] = 0.0;
+    if constexpr (REG) {
+#pragma unroll
+      for (int r = 0; r < SS_RPT; r++) {
+        if (tid + r * SS_NT < N) {
+          double d[M];
+#pragma unroll
+          for (int c = 0; c < M; c++) d[c] = c < m ? rv[r][c] - mu[c] : 0.0;
+          int q = 0;
+#pragma unroll
+          for (int c = 0; c < M; c++)
+#pragma unroll
+            for (int j = 0; j <= c; j++) cc[q++] += d[c] * d[j];
+        }
+      }
+    } else {
     for (int i = tid; i < N; i += SS_NT) {
       const uint32_t b = bcur[i];
       double d[M];
@@ -883,6 +919,7 @@ __global__ void __launch_bounds__(SS_NT) smooth_summary_kernel(const double* __r
       for (int c = 0; c < M; c++)
 #pragma unroll
         for (int j = 0; j <= c; j++) cc[q++] += d[c] * d[j];
+    }
     }
 #pragma unroll
     for (int q = 0; q < NC; q++) { const double v = wave_sum(cc[q]); if (lane == 0) s_part[wave][q] = v; }
@@ -903,7 +940,12 @@ __global__ void __launch_bounds__(SS_NT) smooth_summary_kernel(const double* __r
 }
 hipError_t launch_smooth_summary(const double* hist, const uint32_t* indices, uint32_t* bcur, double* mean, double* cov, int F,
                                  int n, int m, int N, hipStream_t stream) {
-  if (m <= 1) hipLaunchKernelGGL(smooth_summary_kernel<1>, dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
+  // register-resident variant (no ancestor array in memory, one gather per trajectory and time point): C5 output 2
+  const bool reg = N <= SS_RPT * SS_NT && m <= 4 && !std::getenv("BSSM_AMD_SS_GLOBAL");
+  if (reg && m <= 1) hipLaunchKernelGGL((smooth_summary_kernel<1, true>), dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
+  else if (reg && m <= 2) hipLaunchKernelGGL((smooth_summary_kernel<2, true>), dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
+  else if (reg) hipLaunchKernelGGL((smooth_summary_kernel<4, true>), dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
+  else if (m <= 1) hipLaunchKernelGGL(smooth_summary_kernel<1>, dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
   else if (m <= 2) hipLaunchKernelGGL(smooth_summary_kernel<2>, dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
   else if (m <= 4) hipLaunchKernelGGL(smooth_summary_kernel<4>, dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
   else if (m <= 8) hipLaunchKernelGGL(smooth_summary_kernel<8>, dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
