@@ -95,7 +95,8 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   // ONE side stream per host thread for the whole library (streams share a small number of hardware queues: a pair per
   // kernel variant ended up serialised against each other)
   static thread_local TlsStream side;
-  ws->side = side.get();
+  static const bool side_hi = std::getenv("BSSM_AMD_SIDE_PRIO") != nullptr;  // measurement: the side sequence at the highest stream priority
+  ws->side = side.get(side_hi);
 }
 
 
