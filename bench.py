@@ -206,10 +206,10 @@ def single_process_multi_device(ns):
     if nd < 2:
         return {"skipped": "one visible GPU", "visible_gpus": nd}
     try:
-        cp = subprocess.run([sys.executable, "-c", _SINGLE_PROCESS_SNIPPET, str(ns)], capture_output=True, text=True, timeout=300,
+        cp = subprocess.run([sys.executable, "-c", _SINGLE_PROCESS_SNIPPET, str(ns)], capture_output=True, text=True, timeout=150,
                             cwd=os.path.dirname(os.path.abspath(__file__)))
     except subprocess.TimeoutExpired:
-        return {"error": "timeout (300 s)", "visible_gpus": nd}
+        return {"error": "timeout (150 s)", "visible_gpus": nd}
     for line in cp.stdout.splitlines():
         if line.startswith("RESULT "):
             r = json.loads(line[7:])
