@@ -234,11 +234,17 @@ size_t fn_setup_scratch_doubles(int n, int m) {
   //      Z            T        RR   D   C            y   H   a1  P1   at       Pt        cc        K            v   Fs
   return (size_t)n * m + n * mm + mm + n + (size_t)n * m + n + 1 + m + mm + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n;
 }
+#ifndef BSSM_FN_SETUP_NT
+#define BSSM_FN_SETUP_NT 512
+#endif
+constexpr int FN_SETUP_NT = BSSM_FN_SETUP_NT;  // threads per workgroup of fn_setup_kernel: 64 draws x FN_SETUP_NT / 64 waves
 template <int M>
-__global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
+__global__ void __launch_bounds__(FN_SETUP_NT) fn_setup_kernel(const FnSetupDev b) {
   math_tab_init();
-  const int d = blockIdx.x * 64 + threadIdx.x;
-  if (d >= b.F) return;
+  // lane = draw; the FN_SETUP_NT / 64 waves of a workgroup share its 64 draws: the loops whose time points are independent
+  // (linearisation, tables) are split over the waves, the Kalman / smoother recursion runs on wave 0
+  const int wv = threadIdx.x >> 6, nwv = FN_SETUP_NT / 64;
+  const int d = min(blockIdx.x * 64 + (int)(threadIdx.x & 63), b.F - 1);  // (surplus lanes redo the last draw: same values, no branch around the barriers)
   constexpr int MM = M * M;
   const size_t F = (size_t)b.F;
   const int n = b.n;
@@ -263,7 +269,7 @@ __global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
   // ---- linearisation at the stored mode: Z_t = Z'(mode_t), D_t = Z(mode_t) - Z_t mode_t, T_t = T'(mode_t),
   // C_t = T(mode_t) - T_t mode_t  (approximate_for_is, src/model_ssm_nlg.cpp:146-176; scales and approx_loglik stay 0)
   const double* __restrict__ mode = b.modes + (size_t)d * M * n;
-  for (int t = 0; t < n; t++) {
+  for (int t = wv; t < n; t += nwv) {
     double a[M], Zg[M], Tg[MM], Tf[M];
 #pragma unroll
     for (int j = 0; j < M; j++) a[j] = mode[(size_t)M * t + j];
@@ -286,6 +292,7 @@ __global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
     for (int q = 0; q < MM; q++) sT[((size_t)t * MM + q) * F] = Tg[q];
     sy[(size_t)t * F] = b.y[t];
   }
+  if (wv == 0) {
 #pragma unroll
   for (int q = 0; q < MM; q++) sRR[(size_t)q * F] = 0.0;
 #pragma unroll
@@ -296,12 +303,15 @@ __global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
   for (int j = 0; j < M; j++) sa1[(size_t)j * F] = ex[j];
 #pragma unroll
   for (int q = 0; q < MM; q++) sP1[(size_t)q * F] = ex[M + q];
+  }
+  __syncthreads();  // the linearised model of every time point is in memory
   LgModel g;
   g.n = n;
   g.Z = sZ; g.Zs = M; g.T = sT; g.Ts = MM; g.RR = sRR; g.Rs = 0; g.D = sD; g.Ds = 1; g.C = sC; g.Cs = M;
   g.y = sy; g.H = sH; g.Hs = 0; g.a1 = sa1; g.P1 = sP1;
-  const bool ok = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F);  // at = alphahat, Pt = V_t^(1/2), cc = C_t after conditional_cov
-  b.ok[d] = ok ? 1 : 0;
+  if (wv == 0) b.ok[d] = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F) ? 1 : 0;  // at = alphahat, Pt = V_t^(1/2), cc = C_t after conditional_cov
+  __syncthreads();
+  const bool ok = b.ok[d] != 0;
   // ---- tables (build_fn_psi_tables): proposal operands, observation rows, initial state, approximating (T_t, C_t)
   constexpr int MS = 2 * MM + M, OS = ROW_HDR + SER_HDR + M, AS = MM + M;
   double* __restrict__ mats = b.mats + (size_t)d * n * MS;
@@ -309,7 +319,7 @@ __global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
   double* __restrict__ ini = b.init + (size_t)d * (M + MM);
   double* __restrict__ am = b.amats + (size_t)d * n * AS;
   const double ih = 1.0 / fp[FP_H];
-  for (int t = 0; t < n; t++) {
+  for (int t = wv; t < n; t += nwv) {
     double* mt = mats + (size_t)t * MS;
     double ah0[M], ah1[M], Ct1[MM];
 #pragma unroll
@@ -341,13 +351,15 @@ __global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
 #pragma unroll
     for (int j = 0; j < M; j++) a2[MM + j] = ok ? sC[((size_t)t * M + j) * F] : 0.0;
   }
+  if (wv == 0) {
 #pragma unroll
   for (int j = 0; j < M; j++) ini[j] = ok ? at[(size_t)j * F] : 0.0;
 #pragma unroll
   for (int q = 0; q < MM; q++) ini[M + q] = ok ? Pt[(size_t)q * F] : 0.0;
+  }
 }
 hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream) {
-  const dim3 grid((b.F + 63) / 64), block(64);
+  const dim3 grid((b.F + 63) / 64), block(FN_SETUP_NT);
   switch (b.m) {
     case 1: hipLaunchKernelGGL(fn_setup_kernel<1>, grid, block, 0, stream, b); break;
     case 2: hipLaunchKernelGGL(fn_setup_kernel<2>, grid, block, 0, stream, b); break;
@@ -365,9 +377,11 @@ size_t ung_setup_scratch_doubles(int n, int m) {
   return (size_t)4 * n + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n;
 }
 template <int M>
-__global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
-  const int d = blockIdx.x * 64 + threadIdx.x;
-  if (d >= b.F) return;
+__global__ void __launch_bounds__(FN_SETUP_NT) ung_setup_kernel(const UngSetupDev b) {
+  // lane = draw, the waves of a workgroup share its 64 draws (as fn_setup_kernel): Laplace step and tables split over the
+  // waves by time point, the recursion on wave 0
+  const int wv = threadIdx.x >> 6, nwv = FN_SETUP_NT / 64;
+  const int d = min(blockIdx.x * 64 + (int)(threadIdx.x & 63), b.F - 1);
   constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
   const size_t F = (size_t)b.F;
   const int n = b.n;
@@ -386,7 +400,7 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
   const int dist = (int)in[b.oh * F];
   const double phi = in[(b.oh + 1) * F];
   // ---- approximate_for_is: one Laplace step at the stored mode (src/model_ssm_ung.cpp:302-342) and the scales (:241-292)
-  for (int t = 0; t < n; t++) {
+  for (int t = wv; t < n; t += nwv) {
     const double y = in[(b.oy + t) * F], sg = in[(b.om + t) * F], u = in[(b.ou + t) * F];
     double HH = 0.0, yy = 0.0, sv = 0.0;
     switch (dist) {
@@ -417,14 +431,16 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
   g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
   g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = ay; g.H = aH; g.Hs = 1;
   g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
-  const bool ok = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F);  // at = alphahat, Pt = V_t^(1/2), cc = C_t after conditional_cov
-  b.ok[d] = ok ? 1 : 0;
+  __syncthreads();  // pseudo-observations of every time point are in memory
+  if (wv == 0) b.ok[d] = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F) ? 1 : 0;  // at = alphahat, Pt = V_t^(1/2), cc = C_t after conditional_cov
+  __syncthreads();
+  const bool ok = b.ok[d] != 0;
   // ---- tables: psi proposal operands (src/model_ssm_ung.cpp:585-586), observation rows, initial state (:543)
   constexpr int MS = 2 * MP * MP + MP, OS = ROW_HDR + SER_HDR + MP;
   double* __restrict__ mats = b.mats + (size_t)d * n * MS;
   double* __restrict__ obs = b.obs + (size_t)d * n * OS;
   double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
-  for (int t = 0; t < n; t++) {
+  for (int t = wv; t < n; t += nwv) {
     double* mt = mats + (size_t)t * MS;
     for (int q = 0; q < MS; q++) mt[q] = 0.0;
     double ah0[M], ah1[M], Ct1[MM];
@@ -472,6 +488,7 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
       row[RH_SCALE] = scl[(size_t)t * F];
     }
   }
+  if (wv != 0) return;
   for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
   if (ok) {
 #pragma unroll
@@ -483,7 +500,7 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
   }
 }
 hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream) {
-  const dim3 grid((b.F + 63) / 64), block(64);
+  const dim3 grid((b.F + 63) / 64), block(FN_SETUP_NT);
   switch (b.m) {
     case 1: hipLaunchKernelGGL(ung_setup_kernel<1>, grid, block, 0, stream, b); break;
     case 2: hipLaunchKernelGGL(ung_setup_kernel<2>, grid, block, 0, stream, b); break;
