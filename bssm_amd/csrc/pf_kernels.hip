@@ -45,7 +45,10 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
     const bool small = b.MP <= 2;
     if (b1 > 128 && b2 <= 128) {           // two particles per lane bring the filter into the round-2 kernel
       if (w1 >= (size_t)(small ? 5120 : 6144) && b.N >= 4 * GRID_NT) ppt = 4;
-      else if (w1 >= (size_t)(small ? 768 : 1024)) ppt = 2;
+      // (below that only with complete blocks -- the variant without tail guards: a single 65 536-particle call 9.30 -> 8.96 us per
+      // step, m = 1 8.73 -> 8.21, two in flight 9.83 -> 9.33 / 9.09 -> 8.40; 40 000 particles, ragged: 9.0 -> 10.1, stays at one;
+      // scripts/ppt_single.py, profiles/r02d_ppt_single.txt)
+      else if (w1 >= (size_t)(small ? 768 : 1024) || b.N % (2 * GRID_NT) == 0) ppt = 2;
     } else if (b2 > 128 && b4 <= 128) {    // only four do
       if (w1 >= (size_t)(small ? 2048 : 4096)) ppt = 4;
       else if (w1 >= 3072) ppt = 2;
