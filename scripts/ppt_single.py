@@ -6,11 +6,11 @@ from bssm_amd.plan import FilterPlan
 from models_zoo import negbin_m4, negbin_ar1
 for name, mk in (("m4", negbin_m4), ("m1", negbin_ar1)):
     mdl = mk(1000)
-    for N in (40000, 65536):
+    for N in ([int(a) for a in sys.argv[1:]] or (40000, 65536)):
         for keep in (True, False):
             for R in (1, 2):
                 row = []
-                for ppt in ("1", "2"):
+                for ppt in os.environ.get("PPTS", "1,2").split(","):
                     os.environ["BSSM_AMD_GRID_PPT"] = ppt
                     p = FilterPlan(mdl, N, method="bsf", force="grid", keep_history=keep, n_rep=R)
                     p.run(1); p.loglik()
