@@ -1079,7 +1079,9 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   // sequences (the two halves of its filters, independent of each other) on two streams: the tail of one half's step
   // runs under the body of the other's (measured +13 % particle-steps/s at 24 filters of 65 536 particles, m = 4; +19 % at
   // m = 1; +25 % at 12 filters; below ~400 workgroups the second sequence costs more than it hides).
-  int parts = ((long long)b.F * ws.B >= 512 && b.F >= 2) ? 2 : 1;
+  // (with two or more particles per lane a workgroup carries twice the work: from 384 workgroups -- three 65 536-particle
+  // filters at two per lane 1.80e10 -> 1.92e10, m = 1 2.12e10 -> 2.21e10; two filters, 256 workgroups: 1.41e10 -> 1.33e10, stays one)
+  int parts = ((long long)b.F * ws.B >= (ws.chunk >= 2 * GRID_NT ? 384 : 512) && b.F >= 2) ? 2 : 1;
   if (const char* env = std::getenv("BSSM_AMD_GRID_STREAMS")) parts = (std::atoi(env) >= 2 && b.F >= 2) ? 2 : 1;
   const dim3 block(GRID_NT);
   if (!ws.side) parts = 1;
