@@ -54,8 +54,11 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
       if (w1 >= (size_t)(small ? 2048 : 4096) || b.N % (4 * GRID_NT) == 0) ppt = 4;
       else if (w1 >= 3072) ppt = 2;
     } else {
-      if (w1 >= (size_t)(small ? 4096 : 6144) && b.N >= 4 * GRID_NT) ppt = 4;
-      else if (w1 >= 3072 && b.N >= 2 * GRID_NT) ppt = 2;
+      // (32 768 particles, full output, 1 / 2 / 4 per lane: m = 4 -- 8 filters 2.63 / 2.54 / 2.06e10, 16: 3.70 / 3.81 / 3.41e10,
+      // 24: 4.15 / 4.61 / 3.98e10, 48: 4.38 / 5.30 / 5.41e10; m = 1 -- 16: 4.70 / 5.08 / 4.69e10, 32: 5.87 / 7.40 / 7.24e10,
+      // 48: 5.99 / 8.23 / 8.44e10; profiles/r02d_ppt_single.txt)
+      if (w1 >= 6144 && b.N >= 4 * GRID_NT) ppt = 4;
+      else if (w1 >= 2048 && b.N >= 2 * GRID_NT) ppt = 2;
     }
   }
   // 8-dimensional states (round-2 multi-series kernel): two particles per lane once the batch fills the chip twice

@@ -5,15 +5,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from bssm_amd.plan import FilterPlan
 from models_zoo import negbin_m4, negbin_ar1
+NP = int(os.environ.get("NP", "65536"))  # particles per filter
 for name, mk in (("m4", negbin_m4), ("m1", negbin_ar1)):
     mdl = mk(1000)
     for R in ([int(a) for a in sys.argv[1:]] or (3, 4, 6, 8, 12, 16, 20, 24, 32)):
         row = []
         for ppt in ("1", "2", "4"):
             os.environ["BSSM_AMD_GRID_PPT"] = ppt
-            p = FilterPlan(mdl, 65536, method="bsf", force="grid", keep_history=True, n_rep=R)
+            p = FilterPlan(mdl, NP, method="bsf", force="grid", keep_history=True, n_rep=R)
             p.run(1); p.loglik()
             ms = min(p.time(9, 3) for _ in range(2))
-            row.append("ppt %s %.3e" % (ppt, R * 65536 * 1000 / (ms * 1e-3)))
+            row.append("ppt %s %.3e" % (ppt, R * NP * 1000 / (ms * 1e-3)))
             p.close()
         print("%s R=%d: " % (name, R) + " | ".join(row), flush=True)
