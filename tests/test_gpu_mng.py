@@ -162,6 +162,9 @@ def test_mng_full_device_setup_against_oracle(oracle, monkeypatch, name, output_
         monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
         monkeypatch.setenv("BSSM_AMD_TRACE", "1")
         res[dev] = PC.post_correct(model, mo, 48, threads=2, is_type="is2", seed=13)
+    monkeypatch.delenv("BSSM_AMD_DEVICE_SETUP")
+    dflt = PC.post_correct(model, mo, 48, threads=2, is_type="is2", seed=13)
+    assert np.array_equal(dflt["loglik"], res["2"]["loglik"])  # few host threads: the full-device set-up is the default
     for i in range(0, ns, 7):
         ref = oracle.mng_psi_filter(arrs[i], 48, seed=13, stream=i, is_mode=modes[:, i].reshape(p, n, order="F"))
         assert abs(res["2"]["loglik"][i] - ref["logLik"]) <= 1e-8 * n
