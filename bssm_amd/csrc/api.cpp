@@ -2,6 +2,7 @@
 // There is no CPU compute path in this library: every filter runs on the HIP device or fails.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -35,6 +36,9 @@ thread_local std::string g_err;
 bssm::UserHostFns g_user_host[64];  // host entry points of the loaded user-model libraries, by registry slot
 thread_local uint32_t g_call_stream0 = 0;  // Philox stream of the next single-filter call on this thread (bssm_fn_smoother_stream)
 thread_local double g_is_timing[2] = {0.0, 0.0};  // last IS post-correction on this thread: host set-up ms, device phase ms
+// the same call split further: per-draw host packing (prepare / post / finish), the per-chunk device set-up call (uploads,
+// set-up kernel launch and, where the pipeline waits for it, the wait), the filter thread's busy time, wall time of the call
+thread_local double g_is_timing4[4] = {0.0, 0.0, 0.0, 0.0};
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -248,8 +252,10 @@ class OutPipe {
     cs_ = cs.get();
     if (!cs_) return fail(BSSM_ERR_HIP, "output pipe: no copy stream");
     for (int s = 0; s < kSlots; s++) {
-      HIP_TRY(ring_[s].alloc(chunk_));
-      HIP_TRY(hipEventCreateWithFlags(&done_[s], hipEventDisableTiming));
+      if (ring_[s].alloc(chunk_) != hipSuccess || hipEventCreateWithFlags(&done_[s], hipEventDisableTiming) != hipSuccess) {
+        for (int q = 0; q <= s; q++) if (done_[q]) { (void)hipEventDestroy(done_[q]); done_[q] = nullptr; }  // (the ring blocks return with the object)
+        return fail(BSSM_ERR_HIP, "output pipe: no pinned ring / events");
+      }
     }
     started_ = true;
     for (int q = 0; q < threads_; q++) pool_.emplace_back([this, q] { worker(q); });
@@ -508,11 +514,15 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
   bssm::StepTiming hooks;
   if (piped && db.use_grid && (out->weights || out->indices) && n >= 64) hooks.progress_every = std::max(16, n / 24);
   if ((rc = db.run(seed, g_call_stream0, st, &hooks))) return rc;
+  // declared before the pipe: on an early return the pipe drains (its destructor) before these go back to the arena
+  DevBuf cube, smooth, d_mean, d_cov, d_att, d_Ptt;
+  // (BSSM_AMD_PROBE_NO_WEIGHTS drops the device weights: nothing to copy then)
+  double* const out_weights = db.weights.p ? out->weights : nullptr;
   std::unique_ptr<OutPipe> pipe(piped ? new OutPipe(out_bytes) : nullptr);
   int slab_done = 0;  // weights / ancestor columns [0, slab_done) are on their way
   for (int k = 0; k < hooks.progress_count; k++) {
     const int t1 = hooks.progress_steps[k];
-    if (out->weights && (rc = pipe->push(db.weights.as<double>() + (size_t)slab_done * N, out->weights + (size_t)slab_done * N,
+    if (out_weights && (rc = pipe->push(db.weights.as<double>() + (size_t)slab_done * N, out_weights + (size_t)slab_done * N,
                                          (size_t)(t1 - slab_done) * N * sizeof(double), hooks.progress_events[k]))) return rc;
     if (out->indices && (rc = pipe->push(db.indices.as<uint32_t>() + (size_t)slab_done * N, out->indices + (size_t)slab_done * N,
                                          (size_t)(t1 - slab_done) * N * sizeof(uint32_t), hooks.progress_events[k]))) return rc;
@@ -520,7 +530,7 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
   }
   for (int k = 0; k < hooks.progress_count; k++) (void)hipEventDestroy(hooks.progress_events[k]);
   if (pipe) {  // the rest (the launcher's stream order covers it)
-    if (out->weights && (rc = pipe->push(db.weights.as<double>() + (size_t)slab_done * N, out->weights + (size_t)slab_done * N,
+    if (out_weights && (rc = pipe->push(db.weights.as<double>() + (size_t)slab_done * N, out_weights + (size_t)slab_done * N,
                                          (size_t)(n + 1 - slab_done) * N * sizeof(double), nullptr, st))) return rc;
     if (out->indices && (rc = pipe->push(db.indices.as<uint32_t>() + (size_t)slab_done * N, out->indices + (size_t)slab_done * N,
                                          (size_t)(n - slab_done) * N * sizeof(uint32_t), nullptr, st))) return rc;
@@ -535,11 +545,10 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
   if (pipe && dead != 0 && slab_done > 0) {
     // a degenerate filter: the slots after the dead step are zero-filled at the END of the run (launch_zero_dead_tail),
     // so slabs that left earlier may hold stale values there -- send those columns again
-    if (out->weights && (rc = pipe->push(db.weights.p, out->weights, (size_t)slab_done * N * sizeof(double), nullptr, st))) return rc;
+    if (out_weights && (rc = pipe->push(db.weights.p, out_weights, (size_t)slab_done * N * sizeof(double), nullptr, st))) return rc;
     if (out->indices && (rc = pipe->push(db.indices.p, out->indices, (size_t)slab_done * N * sizeof(uint32_t), nullptr, st))) return rc;
   }
 
-  DevBuf cube, smooth, d_mean, d_cov, d_att, d_Ptt;
   const double* final_hist = db.hist.as<double>();
   if (smoother) {  // filter_smoother + summary (src/R_bootstrap_filter.cpp:368-369, src/R_psi.cpp:94-95)
     HIP_TRY(smooth.alloc(hist_elems * sizeof(double)));
@@ -583,7 +592,7 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
     if (out->att) transpose_to(h2, m, n, out->att);
   }
   if (!pipe) {
-    if (out->weights) HIP_TRY(hipMemcpyAsync(out->weights, db.weights.p, db.weights.bytes, hipMemcpyDeviceToHost, st));
+    if (out_weights) HIP_TRY(hipMemcpyAsync(out_weights, db.weights.p, db.weights.bytes, hipMemcpyDeviceToHost, st));
     if (out->indices) HIP_TRY(hipMemcpyAsync(out->indices, db.indices.p, db.indices.bytes, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
@@ -606,6 +615,7 @@ const char* bssm_amd_last_error(void) { return g_err.c_str(); }
 const char* bssm_amd_version(void) { return "bssm_amd 0.1 (gfx950)"; }
 void bssm_amd_trim_cache(void) { arena().trim(); stage_arena().trim(); }
 void bssm_amd_last_is_timing(double out[2]) { out[0] = g_is_timing[0]; out[1] = g_is_timing[1]; }
+void bssm_amd_last_is_timing4(double out[4]) { for (int q = 0; q < 4; q++) out[q] = g_is_timing4[q]; }
 
 void bssm_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   const bssm::u32x4 r = bssm::philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
@@ -1146,8 +1156,10 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   const char* env = std::getenv("BSSM_AMD_USER_CACHE");
   std::string cache = env ? std::string(env) : dir + "/user_models";
   if (!env && access(dir.c_str(), W_OK) != 0) {  // the package directory is read-only (a system-wide install): a per-user cache
+    // never a shared directory such as /tmp: the library name is predictable and a cached library is dlopen'ed
     const char* home = std::getenv("HOME");
-    cache = std::string(home ? home : "/tmp") + "/.cache/bssm_amd/user_models";
+    if (!home || !*home) return fail(BSSM_ERR_INVALID, "user-defined models: the package directory is read-only and HOME is unset; set BSSM_AMD_USER_CACHE to a private directory");
+    cache = std::string(home) + "/.cache/bssm_amd/user_models";
   }
   // the cache key covers everything that is compiled into the library: the kernel headers, the state dimension, the snippet
   std::string key = std::string(bssm_amd_version()) + "|" + std::to_string(n_states) + "|" + source;
@@ -1169,12 +1181,30 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
     if (pth->find_first_of("'\"\\\n") != std::string::npos)
       return fail(BSSM_ERR_INVALID, "unsupported character in the library / cache path: " + *pth);
   std::lock_guard<std::mutex> lk(g_user_mu);
-  if (FILE* f = std::fopen(so.c_str(), "rb")) {  // already built: the hash covers the source, n_states and the version
-    std::fclose(f);
+  // a cached library is loaded into the caller's process: trust it only when the cache directory and the file belong to
+  // this user (or root) and nobody else can write to them
+  auto private_to_us = [](const std::string& path, bool is_dir) -> bool {
+    struct stat sb;
+    if (stat(path.c_str(), &sb) != 0) return false;
+    if (is_dir ? !S_ISDIR(sb.st_mode) : !S_ISREG(sb.st_mode)) return false;
+    if (sb.st_uid != geteuid() && sb.st_uid != 0) return false;
+    return (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+  };
+  auto make_private_dir = [&](const std::string& path) -> bool {  // our own directory with loose permissions: tighten it
+    struct stat sb;
+    if (stat(path.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != geteuid()) return false;
+    return chmod(path.c_str(), sb.st_mode & 07777 & ~(S_IWGRP | S_IWOTH)) == 0;
+  };
+  struct stat sb_so;
+  if (stat(so.c_str(), &sb_so) == 0 && (private_to_us(cache, true) || make_private_dir(cache)) && private_to_us(so, false)) {
+    // already built: the hash covers the source, n_states and the version.  (A cached library that fails the ownership /
+    // permission test is not loaded: it is rebuilt below and replaced by rename.)
     std::strcpy(lib_path, so.c_str());
     return BSSM_OK;
   }
-  if (std::system(("mkdir -p '" + cache + "'").c_str()) != 0) return fail(BSSM_ERR_INVALID, "cannot create " + cache);
+  if (std::system(("mkdir -p -m 0700 '" + cache + "'").c_str()) != 0) return fail(BSSM_ERR_INVALID, "cannot create " + cache);
+  if (!private_to_us(cache, true) && !make_private_dir(cache))
+    return fail(BSSM_ERR_INVALID, "the user-model cache " + cache + " belongs to another user or is writable by others (set BSSM_AMD_USER_CACHE to a private directory)");
   // several processes (ranks) may build the same model at once: every file of a build carries the pid until it is complete,
   // so no process ever reads a file another one is writing; the finished library appears by one rename
   const std::string pid = std::to_string((long)getpid());
@@ -1618,7 +1648,8 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
   bool closing = false;
   int dev_rc = BSSM_OK, worst = BSSM_OK;
   std::string dev_err;
-  double t_host = 0, t_dev = 0;
+  double t_host = 0, t_dev = 0, t_pack = 0, t_chunk = 0;
+  const double t_call0 = now_ms();
   std::thread worker([&]() {
     (void)hipSetDevice(dev);  // the current device is per host thread
     for (;;) {
@@ -1648,10 +1679,12 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
     const double t0 = now_ms();
     parallel_for(hi - lo, n_threads, [&](int q) { errs[lo + q] = prepare(lo + q); });
     for (int i = lo; i < hi; i++) if (!errs[i].empty()) { close(); return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]); }
+    const double tc0 = now_ms();
     if (device_chunk) {
       const int rc = device_chunk(lo, hi);
       if (rc < 0) { close(); return rc; }
     }
+    t_chunk += now_ms() - tc0;
     if (post) {
       parallel_for(hi - lo, n_threads, [&](int q) { errs[lo + q] = post(lo + q); });
       for (int i = lo; i < hi; i++) if (!errs[i].empty()) { close(); return fail(BSSM_ERR_INVALID, "draw " + std::to_string(i) + ": " + errs[i]); }
@@ -1667,6 +1700,8 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
   close();
   if (dev_rc < 0) return fail(dev_rc, dev_err);
   g_is_timing[0] = t_host; g_is_timing[1] = t_dev;
+  t_pack = t_host - t_chunk;
+  g_is_timing4[0] = t_pack; g_is_timing4[1] = t_chunk; g_is_timing4[2] = t_dev; g_is_timing4[3] = now_ms() - t_call0;
   return worst;
 }
 }  // namespace
@@ -1956,9 +1991,18 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
     int mm_ = 1, kk_ = 1;
     J.bad[i] = 1;
     if (functor_tables(&models[i], &J.tabs[i], fp, &mm_, &kk_)) return false;
-    J.tabs[i].mats.assign((size_t)n * (m * m * 2 + m), 0.0); J.tabs[i].mats_tstride = m * m * 2 + m;
-    am->assign((size_t)n * (m * m + m), 0.0);
+    // same padding and time-variation as the good draws' tables (build_fn_psi_tables): a batch shares both
+    const size_t mp = (size_t)bssm::pad_dim(m);
+    J.tabs[i].MP = (int)mp; J.tabs[i].KP = (int)mp;
+    J.tabs[i].mats.assign((size_t)n * (mp * mp * 2 + mp), 0.0); J.tabs[i].mats_tstride = (int)(mp * mp * 2 + mp);
+    am->assign((size_t)n * (mp * mp + mp), 0.0);
     return true;
+  };
+  const size_t am_stride = (size_t)n * ((size_t)bssm::pad_dim(m) * bssm::pad_dim(m) + bssm::pad_dim(m));  // per-draw slot of J.amats
+  auto store_amats = [&](int i, const std::vector<double>& am) -> std::string {
+    if (am.size() != am_stride) return "internal: approximating rows of unexpected size";
+    std::memcpy(J.amats.data() + (size_t)i * am_stride, am.data(), am_stride * sizeof(double));
+    return "";
   };
   auto prepare = [&](int i) -> std::string {
     if (models[i].n != n || models[i].model_id != id) return "all draws must share n and model id";
@@ -1976,7 +2020,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       double al = 0; bool ok = true;
       if (functor_psi_tables(&models[i], modes + (size_t)m * n * i, 0, 1e-8, &J.tabs[i], &fp, &am, &al, &ok, &mm_)) return g_err;
       if (!ok && !bad_draw(i, &fp, &am)) return g_err;
-      std::memcpy(J.amats.data() + (size_t)i * am.size(), am.data(), am.size() * sizeof(double));
+      { const std::string e = store_amats(i, am); if (!e.empty()) return e; }
     } else {
       if (functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_)) return g_err;
       J.sub[i] = approx_loglik[i];
@@ -2014,7 +2058,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       if (!bad_draw(i, &fp, &am)) return g_err;
       std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
     }
-    std::memcpy(J.amats.data() + (size_t)i * am.size(), am.data(), am.size() * sizeof(double));
+    { const std::string e = store_amats(i, am); if (!e.empty()) return e; }
     fms[i] = bssm::FnModel(); fsus[i] = bssm::FnSetup(); lgs[i] = bssm::LgPacked();
     pending[i] = 0;
     return "";
@@ -2053,7 +2097,7 @@ namespace {
 struct ShardInfo { int device, first, count; double setup_ms, device_ms, total_ms; };
 thread_local std::vector<ShardInfo> g_shards;
 thread_local double g_collective_ms = 0.0;
-thread_local int g_gather_kind = 0;  // 0 none, 1 RCCL all-gather, 2 device copies (shards sharing a device)
+thread_local int g_gather_kind = 0;  // 0 none, 1 RCCL all-gather, 2 device copies (shards sharing a device), 3 host blocks (no device exchange possible)
 
 // contiguous blocks with (nearly) equal total work: bssm_amd/post_correct.py shard_bounds, so that the single-process
 // and the one-process-per-GPU drivers cut the draws at the same places
@@ -2104,6 +2148,9 @@ int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t
   std::vector<size_t> cap_send(world, 0), cap_recv(world, 0);
   std::vector<hipStream_t> streams(world, nullptr);
   std::vector<std::thread> pool;
+  // every shard's [weights | log-likelihoods] block, padded to the largest block: what the exchange moves, and what the
+  // caller's arrays are filled from should no device exchange be possible
+  std::vector<std::vector<double>> host_blocks(world, std::vector<double>((size_t)2 * block, 0.0));
   const double t_all = now_ms();
   for (int r = 0; r < world; r++) {
     pool.emplace_back([&, r]() {
@@ -2115,7 +2162,7 @@ int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t
       };
       if (!hip_ok(hipSetDevice(devices[r]), "hipSetDevice")) return;
       const double t0 = now_ms();
-      std::vector<double> buf((size_t)2 * block, 0.0);  // [weights | log-likelihoods], padded to the largest block
+      std::vector<double>& buf = host_blocks[r];
       if (hi > lo) {
         const int rc = run_shard(lo, hi, threads_each, buf.data(), buf.data() + block);
         rcs[r] = rc;
@@ -2146,31 +2193,45 @@ int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t
   const size_t blk = (size_t)2 * block;
   std::vector<double> gathered(blk * world, 0.0);
   int kind = 0;
+  std::string gather_note;
   if (worst >= 0 && blk > 0) {
-    std::string why;
-    const char* env = std::getenv("BSSM_AMD_GATHER");  // "copy" forces the device-copy exchange
-    const bool want_rccl = distinct && !(env && std::string(env) == "copy");
-    if (want_rccl) {
+    // RCCL is the fast path, not a requirement: every filter has finished by now and the blocks also sit in host memory, so
+    // a collective that cannot start (librccl of another ROCm stack, ncclCommInitAll failing) degrades to device copies and,
+    // failing those, to the host blocks -- the call never fails after the work is done
+    const char* env = std::getenv("BSSM_AMD_GATHER");  // "copy" forces the device-copy exchange, "host" the host blocks
+    const std::string mode = env ? env : "";
+    bool done = false;
+    if (distinct && mode != "copy" && mode != "host") {
+      std::string why;
       std::vector<const double*> snd(d_send.begin(), d_send.end());
-      if (bssm::rccl_all_gather(devices, snd, d_recv, blk, streams, &why) != 0) { worst = BSSM_ERR_HIP; err = why; }
-      else {
-        kind = 1;
-        for (int r = 0; r < world && worst >= 0; r++) {
-          (void)hipSetDevice(devices[r]);
-          if (hipStreamSynchronize(streams[r]) != hipSuccess) { worst = BSSM_ERR_HIP; err = "all-gather: stream synchronise failed"; }
-        }
+      bool ok = bssm::rccl_all_gather(devices, snd, d_recv, blk, streams, &why) == 0;
+      for (int r = 0; r < world && ok; r++) {
+        (void)hipSetDevice(devices[r]);
+        if (hipStreamSynchronize(streams[r]) != hipSuccess) { ok = false; why = "all-gather: stream synchronise failed"; }
       }
-    } else {  // shards sharing a GPU cannot be ranks of one communicator: same exchange as plain device copies
-      kind = 2;
-      (void)hipSetDevice(devices[0]);
-      for (int r = 0; r < world && worst >= 0; r++)
-        if (hipMemcpyAsync(d_recv[0] + blk * r, d_send[r], blk * sizeof(double), hipMemcpyDefault, streams[0]) != hipSuccess) { worst = BSSM_ERR_HIP; err = "exchange copy failed"; }
-      if (worst >= 0 && hipStreamSynchronize(streams[0]) != hipSuccess) { worst = BSSM_ERR_HIP; err = "exchange copy failed"; }
+      if (ok) { kind = 1; done = true; }
+      else { gather_note = "RCCL all-gather unavailable (" + why + "); "; (void)hipGetLastError(); }
     }
-    if (worst >= 0) {
+    if (!done && mode != "host") {  // shards sharing a GPU cannot be ranks of one communicator: the same exchange as device copies
       (void)hipSetDevice(devices[0]);
-      if (hipMemcpy(gathered.data(), d_recv[0], gathered.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { worst = BSSM_ERR_HIP; err = "download of the gathered weights failed"; }
+      bool ok = true;
+      for (int r = 0; r < world && ok; r++)
+        ok = hipMemcpyAsync(d_recv[0] + blk * r, d_send[r], blk * sizeof(double), hipMemcpyDefault, streams[0]) == hipSuccess;
+      ok = ok && hipStreamSynchronize(streams[0]) == hipSuccess;
+      if (ok) { kind = 2; done = true; }
+      else { gather_note += "device-copy exchange failed; "; (void)hipGetLastError(); }
     }
+    if (done) {
+      (void)hipSetDevice(devices[0]);
+      if (hipMemcpy(gathered.data(), d_recv[0], gathered.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+        done = false; gather_note += "download of the gathered weights failed; "; (void)hipGetLastError();
+      }
+    }
+    if (!done) {
+      kind = 3;
+      for (int r = 0; r < world; r++) std::memcpy(gathered.data() + blk * r, host_blocks[r].data(), blk * sizeof(double));
+    }
+    if (!gather_note.empty() && std::getenv("BSSM_AMD_TRACE")) std::fprintf(stderr, "[bssm_amd] %sfell back\n", gather_note.c_str());
   }
   for (int r = 0; r < world; r++) {
     (void)hipSetDevice(devices[r]);
@@ -2193,7 +2254,7 @@ int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t
   g_is_timing[0] = th; g_is_timing[1] = td;
   if (std::getenv("BSSM_AMD_TRACE"))
     std::fprintf(stderr, "[bssm_amd] post-correction over %d shard(s): %.1f ms, of which the exchange (%s) %.2f ms\n", world,
-                 now_ms() - t_all, kind == 1 ? "RCCL all-gather" : "device copies", g_collective_ms);
+                 now_ms() - t_all, kind == 1 ? "RCCL all-gather" : kind == 2 ? "device copies" : "host blocks", g_collective_ms);
   return worst;
 }
 }  // namespace
@@ -2264,7 +2325,7 @@ struct bssm_plan {
   double bytes_per_pstep = 0;
   // local_approx = FALSE: pseudo-observations of each model's first approximation, reused by bssm_plan_update
   std::vector<bssm::GlobalApprox> global;
-  int launch_sequences = 1;  // concurrent step-launch sequences of the last bssm_plan_time_kernel run
+  int launch_sequences = 1;  // concurrent step-launch sequences of the last bssm_plan_run / bssm_plan_time_kernel
 };
 
 namespace {
@@ -2408,7 +2469,10 @@ void bssm_plan_destroy(bssm_plan* plan) {
 
 int bssm_plan_run(bssm_plan* plan, uint32_t seed, uint32_t stream0, void* hip_stream) {
   if (!plan) return fail(BSSM_ERR_INVALID, "plan NULL");
-  return plan->db.run(seed, stream0, (hipStream_t)hip_stream);
+  bssm::StepTiming tm;  // no timing requested: only records how many launch sequences the step kernels were issued as
+  const int rc = plan->db.run(seed, stream0, (hipStream_t)hip_stream, &tm);
+  plan->launch_sequences = tm.concurrent;
+  return rc;
 }
 
 int bssm_plan_loglik(bssm_plan* plan, void* hip_stream, double* loglik) {
@@ -2445,6 +2509,23 @@ int bssm_plan_device_outputs(const bssm_plan* plan, void** alpha_hist, void** in
   if (alpha_hist) *alpha_hist = plan->db.hist.p;
   if (indices) *indices = plan->db.indices.p;
   if (weights) *weights = plan->db.weights.p;
+  return BSSM_OK;
+}
+
+int bssm_plan_fetch(const bssm_plan* plan, int32_t filter, void* hip_stream, double* alpha_hist, uint32_t* indices, double* weights) {
+  if (!plan) return fail(BSSM_ERR_INVALID, "plan NULL");
+  const bssm::FilterBatch& fb = plan->db.fb;
+  if (filter < 0 || filter >= fb.F) return fail(BSSM_ERR_INVALID, "filter index outside the plan");
+  if (!plan->db.hist.p) return fail(BSSM_ERR_INVALID, "the plan was created without BSSM_PLAN_KEEP_HISTORY");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const size_t n = fb.n, m = fb.m, N = fb.N, f = (size_t)filter;
+  if (alpha_hist) HIP_TRY(hipMemcpyAsync(alpha_hist, plan->db.hist.as<double>() + f * (n + 1) * m * N, (n + 1) * m * N * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (indices) HIP_TRY(hipMemcpyAsync(indices, plan->db.indices.as<uint32_t>() + f * n * N, n * N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  if (weights) {
+    if (!plan->db.weights.p) return fail(BSSM_ERR_INVALID, "the plan keeps no weights");
+    HIP_TRY(hipMemcpyAsync(weights, plan->db.weights.as<double>() + f * (n + 1) * N, (n + 1) * N * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
   return BSSM_OK;
 }
 

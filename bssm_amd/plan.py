@@ -79,6 +79,19 @@ class FilterPlan:
         _lib.check(_lib.lib().bssm_plan_loglik(self._h, C.c_void_p(hip_stream), _lib.dptr(out)))
         return out
 
+    def fetch(self, filter_index: int, hip_stream: int = 0, alpha: bool = True, indices: bool = True, weights: bool = True):
+        """Kept outputs of one filter of the plan after run() (needs keep_history): alpha (n+1, m, N), indices (n, N) --
+        row t = ancestors of the particles of slot t+1 --, weights (n+1, N), as numpy arrays (bssm_plan_fetch)."""
+        L = _lib.lib()
+        L.bssm_plan_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, _lib.c_double_p, _lib.c_u32_p, _lib.c_double_p]
+        n, m, N = self.n, self.m, self.particles
+        a = np.empty((n + 1, m, N)) if alpha else None
+        ix = np.empty((n, N), dtype=np.uint32) if indices else None
+        w = np.empty((n + 1, N)) if weights else None
+        _lib.check(L.bssm_plan_fetch(self._h, filter_index, C.c_void_p(hip_stream), _lib.dptr(a),
+                                     None if ix is None else ix.ctypes.data_as(_lib.c_u32_p), _lib.dptr(w)))
+        return dict(alpha=a, indices=ix, weights=w)
+
     def time(self, seed: int, reps: int, hip_stream: int = 0) -> float:
         ms = C.c_double()
         _lib.check(_lib.lib().bssm_plan_time(self._h, seed, reps, C.c_void_p(hip_stream), C.byref(ms)))

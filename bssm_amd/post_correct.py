@@ -111,6 +111,9 @@ def _last_timing(devices=None):
     t = (C.c_double * 2)()
     _lib.lib().bssm_amd_last_is_timing(t)
     out = dict(host_setup=t[0], device=t[1])
+    t4 = (C.c_double * 4)()
+    _lib.lib().bssm_amd_last_is_timing4(t4)
+    out.update(host_pack=t4[0], setup_call=t4[1], filter=t4[2], wall=t4[3])
     if devices is not None:  # per-shard split of the in-library multi-device call
         cap = 64
         buf = (C.c_double * (6 * cap))()
@@ -119,7 +122,7 @@ def _last_timing(devices=None):
         out["shards"] = [dict(device=int(buf[6 * r]), first=int(buf[6 * r + 1]), count=int(buf[6 * r + 2]), setup_ms=buf[6 * r + 3],
                               device_ms=buf[6 * r + 4], total_ms=buf[6 * r + 5]) for r in range(min(ns, cap))]
         out["collective_ms"] = coll.value
-        out["gather"] = {0: "none", 1: "rccl_all_gather", 2: "device_copies"}[int(kind.value)]
+        out["gather"] = {0: "none", 1: "rccl_all_gather", 2: "device_copies", 3: "host_blocks"}[int(kind.value)]
     return out
 
 

@@ -113,6 +113,11 @@ void bssm_amd_trim_cache(void);
 /* wall-clock split of the last bssm_is_correction / bssm_is_correction_nlg call on this thread:
  * out[0] = per-draw host set-up (ms), out[1] = device phase incl. copies (ms) */
 void bssm_amd_last_is_timing(double out[2]);
+/* the same call split four ways (ms): out[0] = per-draw host packing (prepare / table building on the caller's threads),
+ * out[1] = the per-chunk device set-up call (uploads, set-up kernel launch and -- on calls of more than 4 096 draws --
+ * the wait for that kernel), out[2] = busy time of the thread that runs the filters (overlaps out[0] and out[1]),
+ * out[3] = wall time of the pipeline */
+void bssm_amd_last_is_timing4(double out[4]);
 
 /* ---- drop-in entry points (host buffers in, host buffers out) ---- */
 
@@ -312,7 +317,8 @@ int bssm_is_correction_nlg_multi(const bssm_fn_model* models, int32_t first, int
                                  double* alphahat_i, double* Vt_i);
 /* shards of the last _multi call on this thread: out[6 * r + ...] = device, first draw, draws, host set-up ms, device
  * phase ms, total ms of shard r (at most `capacity` shards written); *collective_ms = the exchange;
- * *gather_kind = 1 RCCL all-gather, 2 device copies, 0 nothing exchanged.  Returns the number of shards. */
+ * *gather_kind = 1 RCCL all-gather, 2 device copies, 3 host blocks (no device exchange
+ * was possible: RCCL is an optimisation, the call does not fail after the filters have run), 0 nothing exchanged.  Returns the number of shards. */
 int bssm_amd_last_is_shards(double* out, int32_t capacity, double* collective_ms, int32_t* gather_kind);
 /* 1 when librccl could be opened and resolved (bssm_amd_last_error() says why not otherwise) */
 int bssm_amd_rccl_available(void);
@@ -366,6 +372,11 @@ int bssm_plan_info(const bssm_plan* plan, int32_t* path /*0 wg, 1 grid*/, int32_
 /* device pointers of the kept outputs (NULL when not kept): alpha_hist [f][n+1][m][N],
  * indices [f][n][N], weights [f][n+1][N] */
 int bssm_plan_device_outputs(const bssm_plan* plan, void** alpha_hist, void** indices, void** weights);
+/* waits for `hip_stream` and copies the kept outputs of ONE filter of the plan to host memory, in the device layout:
+ * alpha_hist (n+1) x m x N with the particle index fastest, indices n x N, weights (n+1) x N; any may be NULL
+ * (parity tests and bench.py's accuracy leg read the very batch that was timed) */
+int bssm_plan_fetch(const bssm_plan* plan, int32_t filter, void* hip_stream, double* alpha_hist, uint32_t* indices,
+                    double* weights);
 /* average device time per bssm_plan_run over `reps` runs, measured with HIP events on `hip_stream` */
 int bssm_plan_time(bssm_plan* plan, uint32_t seed, int32_t reps, void* hip_stream, double* ms_per_run);
 
@@ -379,7 +390,7 @@ int bssm_plan_time_kernel(bssm_plan* plan, uint32_t seed, int32_t sample_every, 
  * 3 Box-Muller pairs of the stream (seed 1, stream 0, purpose 2, t 0, particle i) -> 2n outputs) and the
  * cycle-stamp timeline of the grid step kernel (12 averaged phase durations). */
 int bssm_debug_math(int fn, const double* in, double* out, int32_t n);
-/* how many step-launch sequences the last bssm_plan_time_kernel run kept in flight (a batch that fills the chip more than
+/* how many step-launch sequences the last bssm_plan_run / bssm_plan_time_kernel kept in flight (a batch that fills the chip more than
  * once is stepped as two interleaved sequences over the halves of its filters; each timed launch then covers half of them) */
 int bssm_plan_launch_sequences(const bssm_plan* plan);
 /* name, with template arguments, of the filter kernel variant the calling thread launched last (as the launcher chose it) */

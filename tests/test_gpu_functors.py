@@ -348,15 +348,18 @@ def test_user_model_three_states_state_dependent_H_and_R(oracle, monkeypatch, pa
         F.particle_smoother(u, 50, method="psi", seed=1)
 
 
-def test_user_model_constant_matrix_R_four_states(oracle):
-    """4 states, constant 4 x 3 matrix R and constant H passed as numbers (no snippet R / H functions)"""
-    code = r"""
+USER_CONST_R4 = r"""
 #define BSSM_USER_NLG 1
 BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
   out[0] = a[0] + a[1]; out[1] = th[0] * a[1] + sin(a[2]); out[2] = 0.9 * a[2] + a[3]; out[3] = 0.5 * a[3];
 }
 BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + a[2]; }
 """
+
+
+def test_user_model_constant_matrix_R_four_states(oracle):
+    """4 states, constant 4 x 3 matrix R and constant H passed as numbers (no snippet R / H functions)"""
+    code = USER_CONST_R4
     rng = np.random.default_rng(2)
     n, N = 20, 700
     th = np.array([0.7])
@@ -489,3 +492,30 @@ def test_user_model_three_states_post_correct_psi(monkeypatch, dev):
         assert np.allclose(out["weights"], 1.0, rtol=1e-8)
         if output_type == 2:
             assert np.all(np.isfinite(out["alphahat"])) and np.all(np.isfinite(out["Vt"]))
+
+
+@pytest.mark.parametrize("dev", ["0", "1"])
+def test_user_model_three_states_post_correct_with_a_failed_draw(monkeypatch, dev):
+    """one draw of the 3-state user model whose approximation is non-finite (transition coefficient overflows): that draw
+    gets weight 0 / logLik -Inf as in the reference (src/model_ssm_nlg.cpp:988-990), the other draws are untouched -- its
+    stand-in tables carry the 4-state padding of the good draws' tables (a batch shares padding and time-variation)"""
+    from bssm_amd import post_correct as PC
+    monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+    rng = np.random.default_rng(29)
+    n, ns = 25, 7
+    A = np.array([[0.8, 0.1, 0.0], [-0.2, 0.7, 0.1], [0.05, 0.0, 0.9]])
+    z = np.array([1.0, 0.5, -0.3]); rd = np.array([0.3, 0.2, 0.1])
+    y = np.cumsum(rng.normal(0, 0.4, n)); y[3] = np.nan
+    u = M.ssm_nlg_user(y, USER_LINEAR3, theta=A.reshape(-1, order="F")[:8], known_params=np.append(z, A[2, 2]), a1=np.zeros(3),
+                       P1=np.diag([0.5, 0.3, 0.2]), H=0.6, R=np.diag(rd), n_states=3)
+    theta = A.reshape(-1, order="F")[:8] + 0.03 * rng.normal(size=(ns, 8))
+    theta[4, 0] = 1e200
+    counts = np.ones(ns, dtype=np.uint32)
+    modes = rng.normal(0, 0.5, (3 * n, ns))
+    for output_type in (2, 3):
+        mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type=output_type)
+        out = PC.post_correct(u, mo, 200, threads=3, is_type="is2", seed=7)
+        assert out["weights"][4] == 0.0 and np.isneginf(out["loglik"][4])
+        good = np.delete(np.arange(ns), 4)
+        assert np.max(np.abs(out["loglik"][good])) <= 1e-9 * n
+        assert np.allclose(out["weights"][good], 1.0, rtol=1e-8)

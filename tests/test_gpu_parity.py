@@ -188,6 +188,29 @@ def test_metric_config_full_size_against_oracle(oracle):
     assert np.allclose(out["att"][:T1], att_ref, rtol=1e-8, atol=1e-10)
 
 
+def test_bench_plan_variant_against_oracle(oracle):
+    """The exact thing bench.py times, compared with the oracle as such: FilterPlan(negbin_m4, N = 65 536, full output,
+    grid shape, 32 filters in flight) -> pf_grid_step_v2<4,4,4,false,true,true> (four particles per lane, weights exchange,
+    no tail guards), stepped as TWO interleaved launch sequences of 16 filters.  Filters 0 / 15 (first and last of the
+    sequence on the caller's stream) and 16 / 31 (first and last of the side-stream sequence): ancestors, particle history,
+    weights and log-likelihood against orc_ung_bsf_filter on the same (seed, stream)."""
+    from bssm_amd.plan import FilterPlan
+    n, N, R, seed, s0 = 120, 65536, 32, 9, 64
+    model = negbin_m4(n, seed=103)
+    plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R)
+    plan.run(seed, stream0=s0)
+    ll = plan.loglik()
+    assert FilterPlan.last_kernel() == "pf_grid_step_v2<4,4,4,false,true,true>"
+    assert plan.launch_sequences() == 2
+    arr = M.model_arrays(model)
+    for f in (0, 15, 16, 31):
+        got = plan.fetch(f)
+        ref = oracle.bsf_filter(arr, N, seed=seed, stream=s0 + f)
+        out = dict(indices=got["indices"].T, alpha=got["alpha"], weights=got["weights"].T, logLik=ll[f])
+        _compare_full_size(out, ref, n, alpha_t_major=True)  # (tolerates a last-ulp ancestor flip after step 50, probability ~1e-4)
+    plan.close()
+
+
 def test_c3_full_size_against_oracle(oracle):
     """configs[2] at full size: svm on the exchange data (T = 945), psi-APF N = 32 768 + filter-smoother back-trace"""
     y = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "exchange.txt"))
