@@ -2114,124 +2114,70 @@ std::vector<int> shard_bounds(const uint32_t* counts, int cnt, int is_type, int 
   return b;
 }
 
-// The draws of one post-correction call spread over `devices` (HIP ordinals; the same ordinal may appear more than
-// once = logical shards on one GPU): one host thread per shard sets its device and runs the single-device driver on
-// its block (run_shard(lo, hi, threads)), which fills the caller's per-draw alpha / summary blocks directly (every
-// draw has a slot of its own) and hands weights / log-likelihoods to `w_loc`, `ll_loc`.  Those two vectors are what
-// the shards exchange: each puts its padded block in device memory, ONE ncclAllGather (RCCL over xGMI; comms from
-// ncclCommInitAll, cached) gives every device the whole vector, and the caller's arrays are filled from the first
-// device's copy.  Mirrors approx_mcmc::is_correction_* spreading the draws over OpenMP threads inside one call
-// (src/approx_mcmc.cpp:364-369, schedule(static)).
-int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t* devices_in, int n_devices_in, int n_threads,
-                     const std::function<int(int, int, int, double*, double*)>& run_shard, double* weights, double* loglik) {
-  if (!have_device()) return no_device();
-  int visible = 0;
-  HIP_TRY(hipGetDeviceCount(&visible));
-  std::vector<int> devices;
-  if (devices_in && n_devices_in > 0) devices.assign(devices_in, devices_in + n_devices_in);
-  else for (int d = 0; d < visible; d++) devices.push_back(d);
-  for (int d : devices) if (d < 0 || d >= visible) return fail(BSSM_ERR_INVALID, "device ordinal " + std::to_string(d) + " is not visible");
+// The exchange step of the one-process multi-device drivers: every shard has a block of `blk` doubles in host memory
+// (padded to the largest block); each block goes to its shard's device, ONE ncclAllGather (RCCL over xGMI; comms from
+// ncclCommInitAll, cached per device list) gives every device the whole vector, and `gathered` is filled from the first
+// device's copy.  RCCL is the fast path, not a requirement: the work is done by the time this runs, so a collective that
+// cannot start (librccl of another ROCm stack, ncclCommInitAll failing) degrades to device copies and, failing those, to
+// the host blocks -- the call never fails here.  kind: 1 RCCL all-gather, 2 device copies, 3 host blocks.
+void gather_shard_blocks(const std::vector<int>& devices, const std::vector<std::vector<double>>& host_blocks, size_t blk,
+                         std::vector<double>* gathered, int* kind_out) {
   const int world = (int)devices.size();
-  const std::vector<int> bounds = shard_bounds(counts, cnt, is_type, world);
-  int block = 0;
-  for (int r = 0; r < world; r++) block = std::max(block, bounds[r + 1] - bounds[r]);
+  gathered->assign(blk * world, 0.0);
+  int kind = 0;
+  if (blk == 0 || world == 0) { *kind_out = 0; return; }
   bool distinct = true;
   for (int a = 0; a < world; a++) for (int b = a + 1; b < world; b++) if (devices[a] == devices[b]) distinct = false;
+  const char* env = std::getenv("BSSM_AMD_GATHER");  // "copy" forces the device-copy exchange, "host" the host blocks
+  const std::string mode = env ? env : "";
   int dev0 = 0;
   (void)hipGetDevice(&dev0);
-  const int threads_each = std::max(1, n_threads / world);  // the host cores are shared by the shards
-
-  std::vector<ShardInfo> info(world);
-  std::vector<int> rcs(world, BSSM_OK);
-  std::vector<std::string> errs(world);
   std::vector<double*> d_send(world, nullptr), d_recv(world, nullptr);
   std::vector<size_t> cap_send(world, 0), cap_recv(world, 0);
   std::vector<hipStream_t> streams(world, nullptr);
-  std::vector<std::thread> pool;
-  // every shard's [weights | log-likelihoods] block, padded to the largest block: what the exchange moves, and what the
-  // caller's arrays are filled from should no device exchange be possible
-  std::vector<std::vector<double>> host_blocks(world, std::vector<double>((size_t)2 * block, 0.0));
-  const double t_all = now_ms();
-  for (int r = 0; r < world; r++) {
-    pool.emplace_back([&, r]() {
-      const int lo = bounds[r], hi = bounds[r + 1];
-      info[r] = ShardInfo{devices[r], lo, hi - lo, 0.0, 0.0, 0.0};
-      auto hip_ok = [&](hipError_t e, const char* what) {
-        if (e == hipSuccess) return true;
-        errs[r] = std::string(what) + ": " + hipGetErrorString(e); rcs[r] = BSSM_ERR_HIP; return false;
-      };
-      if (!hip_ok(hipSetDevice(devices[r]), "hipSetDevice")) return;
-      const double t0 = now_ms();
-      std::vector<double>& buf = host_blocks[r];
-      if (hi > lo) {
-        const int rc = run_shard(lo, hi, threads_each, buf.data(), buf.data() + block);
-        rcs[r] = rc;
-        if (rc < 0) { errs[r] = g_err; return; }
-        info[r].setup_ms = g_is_timing[0]; info[r].device_ms = g_is_timing[1];
-      }
-      // the shard's block into device memory for the exchange (these two buffers outlive the thread: raw arena blocks)
-      void *ps = nullptr, *pr = nullptr;
-      if (!hip_ok(arena().get((size_t)2 * block * sizeof(double), &ps, &cap_send[r]), "exchange buffer")) return;
-      d_send[r] = (double*)ps;
-      if (!hip_ok(arena().get((size_t)2 * block * world * sizeof(double), &pr, &cap_recv[r]), "exchange buffer")) return;
-      d_recv[r] = (double*)pr;
-      if (!hip_ok(hipStreamCreateWithFlags(&streams[r], hipStreamNonBlocking), "hipStreamCreate")) return;
-      if (!hip_ok(hipMemcpyAsync(d_send[r], buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice, streams[r]), "upload of the shard's weights")) return;
-      if (!hip_ok(hipStreamSynchronize(streams[r]), "hipStreamSynchronize")) return;
-      info[r].total_ms = now_ms() - t0;
-    });
+  std::string note;
+  bool staged = mode != "host";
+  for (int r = 0; r < world && staged; r++) {  // the shards' blocks into device memory
+    void *ps = nullptr, *pr = nullptr;
+    staged = hipSetDevice(devices[r]) == hipSuccess && arena().get(blk * sizeof(double), &ps, &cap_send[r]) == hipSuccess;
+    d_send[r] = (double*)ps;
+    staged = staged && arena().get(blk * world * sizeof(double), &pr, &cap_recv[r]) == hipSuccess;
+    d_recv[r] = (double*)pr;
+    staged = staged && hipStreamCreateWithFlags(&streams[r], hipStreamNonBlocking) == hipSuccess;
+    staged = staged && hipMemcpyAsync(d_send[r], host_blocks[r].data(), blk * sizeof(double), hipMemcpyHostToDevice, streams[r]) == hipSuccess;
+    staged = staged && hipStreamSynchronize(streams[r]) == hipSuccess;
+    if (!staged) { note += "staging the blocks on device " + std::to_string(devices[r]) + " failed; "; (void)hipGetLastError(); }
   }
-  for (auto& th : pool) th.join();
-  int worst = BSSM_OK;
-  std::string err;
-  for (int r = 0; r < world && worst >= 0; r++) {
-    if (rcs[r] < 0) { worst = rcs[r]; err = "shard " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + errs[r]; }
-    else if (rcs[r] == BSSM_WARN_DEGENERATE) worst = BSSM_WARN_DEGENERATE;
+  bool done = false;
+  if (staged && distinct && mode != "copy") {
+    std::string why;
+    std::vector<const double*> snd(d_send.begin(), d_send.end());
+    bool ok = bssm::rccl_all_gather(devices, snd, d_recv, blk, streams, &why) == 0;
+    for (int r = 0; r < world && ok; r++) {
+      (void)hipSetDevice(devices[r]);
+      if (hipStreamSynchronize(streams[r]) != hipSuccess) { ok = false; why = "all-gather: stream synchronise failed"; }
+    }
+    if (ok) { kind = 1; done = true; }
+    else { note += "RCCL all-gather unavailable (" + why + "); "; (void)hipGetLastError(); }
   }
-  // ---- the collective
-  const double t_c = now_ms();
-  const size_t blk = (size_t)2 * block;
-  std::vector<double> gathered(blk * world, 0.0);
-  int kind = 0;
-  std::string gather_note;
-  if (worst >= 0 && blk > 0) {
-    // RCCL is the fast path, not a requirement: every filter has finished by now and the blocks also sit in host memory, so
-    // a collective that cannot start (librccl of another ROCm stack, ncclCommInitAll failing) degrades to device copies and,
-    // failing those, to the host blocks -- the call never fails after the work is done
-    const char* env = std::getenv("BSSM_AMD_GATHER");  // "copy" forces the device-copy exchange, "host" the host blocks
-    const std::string mode = env ? env : "";
-    bool done = false;
-    if (distinct && mode != "copy" && mode != "host") {
-      std::string why;
-      std::vector<const double*> snd(d_send.begin(), d_send.end());
-      bool ok = bssm::rccl_all_gather(devices, snd, d_recv, blk, streams, &why) == 0;
-      for (int r = 0; r < world && ok; r++) {
-        (void)hipSetDevice(devices[r]);
-        if (hipStreamSynchronize(streams[r]) != hipSuccess) { ok = false; why = "all-gather: stream synchronise failed"; }
-      }
-      if (ok) { kind = 1; done = true; }
-      else { gather_note = "RCCL all-gather unavailable (" + why + "); "; (void)hipGetLastError(); }
+  if (staged && !done) {  // shards sharing a GPU cannot be ranks of one communicator: the same exchange as device copies
+    (void)hipSetDevice(devices[0]);
+    bool ok = true;
+    for (int r = 0; r < world && ok; r++)
+      ok = hipMemcpyAsync(d_recv[0] + blk * r, d_send[r], blk * sizeof(double), hipMemcpyDefault, streams[0]) == hipSuccess;
+    ok = ok && hipStreamSynchronize(streams[0]) == hipSuccess;
+    if (ok) { kind = 2; done = true; }
+    else { note += "device-copy exchange failed; "; (void)hipGetLastError(); }
+  }
+  if (done) {
+    (void)hipSetDevice(devices[0]);
+    if (hipMemcpy(gathered->data(), d_recv[0], gathered->size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+      done = false; note += "download of the gathered blocks failed; "; (void)hipGetLastError();
     }
-    if (!done && mode != "host") {  // shards sharing a GPU cannot be ranks of one communicator: the same exchange as device copies
-      (void)hipSetDevice(devices[0]);
-      bool ok = true;
-      for (int r = 0; r < world && ok; r++)
-        ok = hipMemcpyAsync(d_recv[0] + blk * r, d_send[r], blk * sizeof(double), hipMemcpyDefault, streams[0]) == hipSuccess;
-      ok = ok && hipStreamSynchronize(streams[0]) == hipSuccess;
-      if (ok) { kind = 2; done = true; }
-      else { gather_note += "device-copy exchange failed; "; (void)hipGetLastError(); }
-    }
-    if (done) {
-      (void)hipSetDevice(devices[0]);
-      if (hipMemcpy(gathered.data(), d_recv[0], gathered.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
-        done = false; gather_note += "download of the gathered weights failed; "; (void)hipGetLastError();
-      }
-    }
-    if (!done) {
-      kind = 3;
-      for (int r = 0; r < world; r++) std::memcpy(gathered.data() + blk * r, host_blocks[r].data(), blk * sizeof(double));
-    }
-    if (!gather_note.empty() && std::getenv("BSSM_AMD_TRACE")) std::fprintf(stderr, "[bssm_amd] %sfell back\n", gather_note.c_str());
+  }
+  if (!done) {
+    kind = 3;
+    for (int r = 0; r < world; r++) std::memcpy(gathered->data() + blk * r, host_blocks[r].data(), blk * sizeof(double));
   }
   for (int r = 0; r < world; r++) {
     (void)hipSetDevice(devices[r]);
@@ -2240,7 +2186,75 @@ int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t
     if (d_recv[r]) arena().put(d_recv[r], cap_recv[r]);
   }
   (void)hipSetDevice(dev0);
-  if (worst < 0) return fail(worst, err);
+  if (!note.empty() && std::getenv("BSSM_AMD_TRACE")) std::fprintf(stderr, "[bssm_amd] exchange: %sfell back\n", note.c_str());
+  *kind_out = kind;
+}
+
+int resolve_devices(const int32_t* devices_in, int n_devices_in, std::vector<int>* devices) {
+  int visible = 0;
+  HIP_TRY(hipGetDeviceCount(&visible));
+  devices->clear();
+  if (devices_in && n_devices_in > 0) devices->assign(devices_in, devices_in + n_devices_in);
+  else for (int d = 0; d < visible; d++) devices->push_back(d);
+  for (int d : *devices) if (d < 0 || d >= visible) return fail(BSSM_ERR_INVALID, "device ordinal " + std::to_string(d) + " is not visible");
+  return BSSM_OK;
+}
+
+// The draws of one post-correction call spread over `devices` (HIP ordinals; the same ordinal may appear more than
+// once = logical shards on one GPU): one host thread per shard sets its device and runs the single-device driver on
+// its block (run_shard(lo, hi, threads)), which fills the caller's per-draw alpha / summary blocks directly (every
+// draw has a slot of its own) and hands weights / log-likelihoods to `w_loc`, `ll_loc`.  Those two vectors are what
+// the shards exchange (gather_shard_blocks).  Mirrors approx_mcmc::is_correction_* spreading the draws over OpenMP
+// threads inside one call (src/approx_mcmc.cpp:364-369, schedule(static)).
+int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t* devices_in, int n_devices_in, int n_threads,
+                     const std::function<int(int, int, int, double*, double*)>& run_shard, double* weights, double* loglik) {
+  if (!have_device()) return no_device();
+  std::vector<int> devices;
+  if (int rc = resolve_devices(devices_in, n_devices_in, &devices)) return rc;
+  const int world = (int)devices.size();
+  const std::vector<int> bounds = shard_bounds(counts, cnt, is_type, world);
+  int block = 0;
+  for (int r = 0; r < world; r++) block = std::max(block, bounds[r + 1] - bounds[r]);
+  int dev0 = 0;
+  (void)hipGetDevice(&dev0);
+  const int threads_each = std::max(1, n_threads / world);  // the host cores are shared by the shards
+
+  std::vector<ShardInfo> info(world);
+  std::vector<int> rcs(world, BSSM_OK);
+  std::vector<std::string> errs(world);
+  std::vector<std::thread> pool;
+  // every shard's [weights | log-likelihoods] block, padded to the largest block
+  std::vector<std::vector<double>> host_blocks(world, std::vector<double>((size_t)2 * block, 0.0));
+  const double t_all = now_ms();
+  for (int r = 0; r < world; r++) {
+    pool.emplace_back([&, r]() {
+      const int lo = bounds[r], hi = bounds[r + 1];
+      info[r] = ShardInfo{devices[r], lo, hi - lo, 0.0, 0.0, 0.0};
+      if (hipSetDevice(devices[r]) != hipSuccess) { errs[r] = "hipSetDevice failed"; rcs[r] = BSSM_ERR_HIP; return; }
+      const double t0 = now_ms();
+      std::vector<double>& buf = host_blocks[r];
+      if (hi > lo) {
+        const int rc = run_shard(lo, hi, threads_each, buf.data(), buf.data() + block);
+        rcs[r] = rc;
+        if (rc < 0) { errs[r] = g_err; return; }
+        info[r].setup_ms = g_is_timing[0]; info[r].device_ms = g_is_timing[1];
+      }
+      info[r].total_ms = now_ms() - t0;
+    });
+  }
+  for (auto& th : pool) th.join();
+  (void)hipSetDevice(dev0);
+  int worst = BSSM_OK;
+  for (int r = 0; r < world; r++) {
+    if (rcs[r] < 0) return fail(rcs[r], "shard " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + errs[r]);
+    if (rcs[r] == BSSM_WARN_DEGENERATE) worst = BSSM_WARN_DEGENERATE;
+  }
+  // ---- the collective
+  const double t_c = now_ms();
+  const size_t blk = (size_t)2 * block;
+  std::vector<double> gathered;
+  int kind = 0;
+  gather_shard_blocks(devices, host_blocks, blk, &gathered, &kind);
   for (int r = 0; r < world; r++) {
     const int lo = bounds[r], c = bounds[r + 1] - lo;
     std::memcpy(weights + lo, gathered.data() + blk * r, (size_t)c * sizeof(double));
@@ -2256,6 +2270,66 @@ int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t
     std::fprintf(stderr, "[bssm_amd] post-correction over %d shard(s): %.1f ms, of which the exchange (%s) %.2f ms\n", world,
                  now_ms() - t_all, kind == 1 ? "RCCL all-gather" : kind == 2 ? "device copies" : "host blocks", g_collective_ms);
   return worst;
+}
+
+// suggest_N over several devices in one call (src/R_postcorrection.cpp:24-35 runs the candidates x replications loop on
+// one thread): the replications of EVERY candidate are cut into contiguous blocks, one block per shard; a shard runs its
+// replications of candidate i as one device batch on streams i * replications + [lo, hi) -- the streams the single-device
+// entry point uses, so the log-likelihoods (and the standard deviations) are bit-identical for any device list; ONE
+// exchange of the shards' (n_candidates x block) log-likelihood blocks at the end.
+int suggest_n_multi(const uint32_t* candidates, int32_t n_candidates, uint32_t replications, const int32_t* devices_in,
+                    int n_devices_in, double* sds, double* loglik_out,
+                    const std::function<int(uint32_t, uint32_t, uint32_t, double*)>& batch) {
+  if (!candidates || !sds || n_candidates < 1 || replications < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
+  for (int i = 0; i < n_candidates; i++) if (candidates[i] < 1) return fail(BSSM_ERR_INVALID, "candidates must be positive");
+  if (!have_device()) return no_device();
+  std::vector<int> devices;
+  if (int rc = resolve_devices(devices_in, n_devices_in, &devices)) return rc;
+  const int world = (int)devices.size(), reps = (int)replications;
+  std::vector<int> bounds(world + 1, 0);
+  for (int r = 0; r <= world; r++) bounds[r] = (int)((long long)reps * r / world);
+  int block = 0;
+  for (int r = 0; r < world; r++) block = std::max(block, bounds[r + 1] - bounds[r]);
+  const size_t blk = (size_t)n_candidates * block;
+  std::vector<std::vector<double>> host_blocks(world, std::vector<double>(blk, 0.0));
+  std::vector<int> rcs(world, BSSM_OK);
+  std::vector<std::string> errs(world);
+  std::vector<std::thread> pool;
+  int dev0 = 0;
+  (void)hipGetDevice(&dev0);
+  for (int r = 0; r < world; r++) {
+    pool.emplace_back([&, r]() {
+      const int lo = bounds[r], hi = bounds[r + 1];
+      if (hi <= lo) return;
+      if (hipSetDevice(devices[r]) != hipSuccess) { errs[r] = "hipSetDevice failed"; rcs[r] = BSSM_ERR_HIP; return; }
+      for (int i = 0; i < n_candidates; i++) {
+        const int rc = batch(candidates[i], (uint32_t)i * replications + (uint32_t)lo, (uint32_t)(hi - lo), host_blocks[r].data() + (size_t)i * block);
+        if (rc < 0) { errs[r] = g_err; rcs[r] = rc; return; }
+        if (rc == BSSM_WARN_DEGENERATE) rcs[r] = rc;
+      }
+    });
+  }
+  for (auto& th : pool) th.join();
+  (void)hipSetDevice(dev0);
+  bool deg = false;
+  for (int r = 0; r < world; r++) {
+    if (rcs[r] < 0) return fail(rcs[r], "shard " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + errs[r]);
+    deg = deg || rcs[r] == BSSM_WARN_DEGENERATE;
+  }
+  const double t_c = now_ms();
+  std::vector<double> gathered;
+  int kind = 0;
+  gather_shard_blocks(devices, host_blocks, blk, &gathered, &kind);
+  g_collective_ms = now_ms() - t_c;
+  g_gather_kind = kind;
+  std::vector<double> ll(replications);
+  for (int i = 0; i < n_candidates; i++) {
+    for (int r = 0; r < world; r++)
+      for (int j = bounds[r]; j < bounds[r + 1]; j++) ll[j] = gathered[blk * r + (size_t)i * block + (j - bounds[r])];
+    sds[i] = sample_sd(ll);
+    if (loglik_out) std::memcpy(loglik_out + (size_t)i * replications, ll.data(), replications * sizeof(double));
+  }
+  return deg ? BSSM_WARN_DEGENERATE : BSSM_OK;
 }
 }  // namespace
 extern "C" {
@@ -2296,6 +2370,25 @@ int bssm_is_correction_nlg_multi(const bssm_fn_model* models, int32_t first, int
                                   alphahat_i ? alphahat_i + (n + 1) * m * lo : nullptr, Vt_i ? Vt_i + (n + 1) * m * m * lo : nullptr);
   };
   return run_multi_device(count, counts, is_type, devices, n_devices, n_threads, run_shard, weights, loglik);
+}
+
+int bssm_suggest_n_nongaussian_multi(const bssm_ung_model* model, const uint32_t* candidates, int32_t n_candidates,
+                                     uint32_t replications, uint32_t seed, int model_type, const int32_t* devices,
+                                     int32_t n_devices, double* sds, double* loglik) {
+  if (!is_gaussian_type_ok(0, model_type)) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
+  return suggest_n_multi(candidates, n_candidates, replications, devices, n_devices, sds, loglik,
+                         [&](uint32_t nsim, uint32_t stream0, uint32_t n_rep, double* ll) {
+                           return bssm_nongaussian_loglik_batch(model, nsim, BSSM_PSI, seed, stream0, n_rep, ll);
+                         });
+}
+
+int bssm_suggest_n_nonlinear_multi(const bssm_fn_model* model, const uint32_t* candidates, int32_t n_candidates,
+                                   uint32_t replications, uint32_t seed, const int32_t* devices, int32_t n_devices,
+                                   double* sds, double* loglik) {
+  return suggest_n_multi(candidates, n_candidates, replications, devices, n_devices, sds, loglik,
+                         [&](uint32_t nsim, uint32_t stream0, uint32_t n_rep, double* ll) {
+                           return bssm_fn_loglik_batch(model, nsim, BSSM_PSI, seed, stream0, n_rep, ll);
+                         });
 }
 
 int bssm_amd_last_is_shards(double* out, int32_t capacity, double* collective_ms, int32_t* gather_kind) {

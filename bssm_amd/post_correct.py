@@ -407,7 +407,7 @@ def _suggest_N_sharded(mdl, candidates, replications, seed, dist, rank, world, g
 
 
 def suggest_N(model: BssmModel, theta, candidates=range(10, 101, 10), replications: int = 100, seed: int | None = None,
-              group=None):
+              group=None, devices=None, return_loglik: bool = False):
     """R/post_correction.R:84-130 -> suggest_n_nongaussian (src/R_postcorrection.cpp:13-140): standard deviation
     of the psi-APF log-likelihood at ``theta`` over ``replications`` runs for each candidate N; N = first
     candidate with sd < 1 (None if there is none, R's NA).  The replications of one candidate run as ONE device
@@ -436,19 +436,42 @@ def suggest_N(model: BssmModel, theta, candidates=range(10, 101, 10), replicatio
         sds, _ = _suggest_N_sharded(mdl, candidates, replications, seed, dist, rank, world, group)
         ok = np.nonzero(sds < 1.0)[0]
         return dict(N=candidates[int(ok[0])] if ok.size else None, results=dict(N=np.asarray(candidates), sd=sds))
+    # devices: None = the single-device entry point; "all" / a list of HIP ordinals = the replications of every candidate
+    # sharded over those devices INSIDE the library (bssm_suggest_n_*_multi: thread per device, one exchange at the end)
+    ll = np.zeros((cand.size, replications)) if (return_loglik and devices is not None) else None
+    dv, nd = _devices_arg(devices)
+    dvp = None if dv is None else dv.ctypes.data_as(C.POINTER(C.c_int32))
+
+    def result():
+        ok = np.nonzero(sds < 1.0)[0]
+        out = dict(N=candidates[int(ok[0])] if ok.size else None, results=dict(N=np.asarray(candidates), sd=sds))
+        if ll is not None:
+            out["loglik"] = ll
+        if devices is not None:
+            out["gather"] = _last_timing(devices)["gather"]
+        return out
+
     if model.inherits("ssm_nlg"):  # suggest_n_nonlinear, src/R_postcorrection.cpp:107-148
         smod, keep = _lib.pack_fn_model({**model, "theta": theta})
-        _lib.check(_lib.lib().bssm_suggest_n_nonlinear(C.byref(smod), cand.ctypes.data_as(_lib.c_u32_p), C.c_int32(cand.size),
-                                                        C.c_uint32(replications), C.c_uint32(seed), _lib.dptr(sds)))
-        ok = np.nonzero(sds < 1.0)[0]
-        return dict(N=candidates[int(ok[0])] if ok.size else None, results=dict(N=np.asarray(candidates), sd=sds))
+        if devices is None:
+            _lib.check(_lib.lib().bssm_suggest_n_nonlinear(C.byref(smod), cand.ctypes.data_as(_lib.c_u32_p), C.c_int32(cand.size),
+                                                            C.c_uint32(replications), C.c_uint32(seed), _lib.dptr(sds)))
+        else:
+            _lib.check(_lib.lib().bssm_suggest_n_nonlinear_multi(C.byref(smod), cand.ctypes.data_as(_lib.c_u32_p), C.c_int32(cand.size),
+                                                                  C.c_uint32(replications), C.c_uint32(seed), dvp, C.c_int32(nd),
+                                                                  _lib.dptr(sds), _lib.dptr(ll)))
+        return result()
     arr = expand_models(model, theta[None, :])[0]
     fields = {**model, **{k: arr[k] for k in ("Z", "T", "R", "P1", "a1", "C", "D", "beta")}, "phi": arr["phi"]}
     mdl = BssmModel(model.classes, **fields)
     # one C-ABI call: bssm_suggest_n_nongaussian runs the replications of each candidate as a device batch
     arrs, smod, keep = _prep(mdl, True)
-    _lib.check(_lib.lib().bssm_suggest_n_nongaussian(C.byref(smod), cand.ctypes.data_as(_lib.c_u32_p), C.c_int32(cand.size),
-                                                           C.c_uint32(replications), C.c_uint32(seed), C.c_int32(model_type(mdl)),
-                                                           _lib.dptr(sds)))
-    ok = np.nonzero(sds < 1.0)[0]
-    return dict(N=candidates[int(ok[0])] if ok.size else None, results=dict(N=np.asarray(candidates), sd=sds))
+    if devices is None:
+        _lib.check(_lib.lib().bssm_suggest_n_nongaussian(C.byref(smod), cand.ctypes.data_as(_lib.c_u32_p), C.c_int32(cand.size),
+                                                          C.c_uint32(replications), C.c_uint32(seed), C.c_int32(model_type(mdl)),
+                                                          _lib.dptr(sds)))
+    else:
+        _lib.check(_lib.lib().bssm_suggest_n_nongaussian_multi(C.byref(smod), cand.ctypes.data_as(_lib.c_u32_p), C.c_int32(cand.size),
+                                                                C.c_uint32(replications), C.c_uint32(seed), C.c_int32(model_type(mdl)),
+                                                                dvp, C.c_int32(nd), _lib.dptr(sds), _lib.dptr(ll)))
+    return result()

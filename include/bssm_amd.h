@@ -315,6 +315,18 @@ int bssm_is_correction_nlg_multi(const bssm_fn_model* models, int32_t first, int
                                  int32_t is_type, int32_t output_type, uint32_t nsim, uint32_t seed, int32_t n_threads,
                                  const int32_t* devices, int32_t n_devices, double* weights, double* loglik, double* alpha,
                                  double* alphahat_i, double* Vt_i);
+/* suggest_N sharded over several devices INSIDE one call (the reference runs candidates x replications on one thread,
+ * src/R_postcorrection.cpp:24-35, 118-129): the replications of every candidate are cut into contiguous blocks, one per
+ * device (same `devices` convention as above), each shard runs its replications of a candidate as one device batch on the
+ * streams the single-device entry point uses, ONE exchange of the log-likelihood blocks at the end (RCCL all-gather when
+ * the devices are distinct) -- results bit-identical for any device list.  loglik (n_candidates x replications,
+ * replication fastest) may be NULL. */
+int bssm_suggest_n_nongaussian_multi(const bssm_ung_model* model, const uint32_t* candidates, int32_t n_candidates,
+                                     uint32_t replications, uint32_t seed, int model_type, const int32_t* devices,
+                                     int32_t n_devices, double* sds, double* loglik);
+int bssm_suggest_n_nonlinear_multi(const bssm_fn_model* model, const uint32_t* candidates, int32_t n_candidates,
+                                   uint32_t replications, uint32_t seed, const int32_t* devices, int32_t n_devices,
+                                   double* sds, double* loglik);
 /* shards of the last _multi call on this thread: out[6 * r + ...] = device, first draw, draws, host set-up ms, device
  * phase ms, total ms of shard r (at most `capacity` shards written); *collective_ms = the exchange;
  * *gather_kind = 1 RCCL all-gather, 2 device copies, 3 host blocks (no device exchange

@@ -295,7 +295,9 @@ SEXP _bssm_suggest_n_nongaussian(SEXP model_, SEXP theta, SEXP candidates, SEXP 
   uint32_t* cand = (uint32_t*)R_alloc((size_t)(nc ? nc : 1), sizeof(uint32_t));
   for (int i = 0; i < nc; i++) cand[i] = (uint32_t)REAL(candidates)[i];
   SEXP sds = PROTECT(Rf_allocVector(REALSXP, nc));
-  check_rc(bssm_suggest_n_nongaussian(&sm.mod, cand, nc, (uint32_t)Rf_asInteger(replications), (uint32_t)Rf_asInteger(seed), mt, REAL(sds)));
+  /* replications spread over the GPUs of the node inside the call (devices NULL = all visible), one exchange at the end */
+  check_rc(bssm_suggest_n_nongaussian_multi(&sm.mod, cand, nc, (uint32_t)Rf_asInteger(replications), (uint32_t)Rf_asInteger(seed), mt, NULL, 0,
+                                            REAL(sds), NULL));
   UNPROTECT(1);
   return sds;
 }
@@ -680,7 +682,7 @@ SEXP _bssm_suggest_n_nonlinear(NLG_ARGS, SEXP theta_map, SEXP candidates, SEXP r
   uint32_t* cand = (uint32_t*)R_alloc((size_t)(nc ? nc : 1), sizeof(uint32_t));
   for (int i = 0; i < nc; i++) cand[i] = (uint32_t)REAL(candidates)[i];
   SEXP sds = PROTECT(Rf_allocVector(REALSXP, nc));
-  check_rc(bssm_suggest_n_nonlinear(&f, cand, nc, (uint32_t)Rf_asInteger(replications), (uint32_t)Rf_asInteger(seed), REAL(sds)));
+  check_rc(bssm_suggest_n_nonlinear_multi(&f, cand, nc, (uint32_t)Rf_asInteger(replications), (uint32_t)Rf_asInteger(seed), NULL, 0, REAL(sds), NULL));
   UNPROTECT(1);
   return sds;
 }

@@ -258,6 +258,48 @@ def test_multi_device_nlg_and_rccl_all_gather():
     assert np.array_equal(one["Vt"], rc["Vt"])
 
 
+def test_multi_device_suggest_N_is_bit_identical(monkeypatch):
+    """bssm_suggest_n_{nongaussian,nonlinear}_multi: the replications of every candidate cut into blocks over two / three
+    logical shards on the one GPU (device-copy exchange), over the one visible GPU as a communicator of size one (RCCL
+    all-gather), and with the exchange forced to the host blocks -- log-likelihoods and standard deviations bit-identical
+    to the single-device entry point (src/R_postcorrection.cpp:24-35, 118-129)"""
+    from bssm_amd import filters as F
+    model, theta, counts = _job()
+    rng = np.random.default_rng(2)
+    n = 40
+    y = 50.0 + np.cumsum(rng.normal(0.5, 1.0, n)) + rng.normal(0, 1, n)
+    th0 = np.array([0.0, np.log(0.05), 0.0])
+    growth = M.ssm_nlg(y, "nlg_growth", theta=th0, known_params=[0.1, 500.0, 0.0, 50.0, 1.0, 100.0])
+    for mdl, th in ((model, theta[0]), (growth, th0)):
+        cands, R, seed = [5, 12, 30], 23, 6
+        one = PC.suggest_N(mdl, th, candidates=cands, replications=R, seed=seed)
+        for devs, kind in (([0, 0], "device_copies"), ([0, 0, 0], "device_copies"), ("all", "rccl_all_gather")):
+            many = PC.suggest_N(mdl, th, candidates=cands, replications=R, seed=seed, devices=devs, return_loglik=True)
+            assert many["gather"] == kind
+            assert np.array_equal(one["results"]["sd"], many["results"]["sd"]) and one["N"] == many["N"]
+            assert many["loglik"].shape == (3, R) and np.all(np.isfinite(many["loglik"]))
+            assert np.array_equal(many["loglik"].std(axis=1, ddof=1) <= 1e300, np.ones(3, dtype=bool))
+        monkeypatch.setenv("BSSM_AMD_GATHER", "host")
+        host = PC.suggest_N(mdl, th, candidates=cands, replications=R, seed=seed, devices=[0, 0])
+        monkeypatch.delenv("BSSM_AMD_GATHER")
+        assert host["gather"] == "host_blocks" and np.array_equal(one["results"]["sd"], host["results"]["sd"])
+
+
+def test_multi_device_exchange_falls_back_instead_of_failing(monkeypatch):
+    """RCCL is an optimisation: with the exchange forced off the device (BSSM_AMD_GATHER=host) a multi-device post-correction
+    returns the same weights from the shards' host blocks"""
+    from oracle import oracle as O
+    model, theta, counts = _job(ns=11, n=20, seed=3)
+    arrs = PC.expand_models(model, theta)
+    modes = np.stack([O.psi_setup(a)["mode"] for a in arrs], axis=1)
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(len(counts)), output_type=3)
+    one = PC.post_correct(model, mo, 32, threads=2, is_type="is2", seed=5)
+    monkeypatch.setenv("BSSM_AMD_GATHER", "host")
+    two = PC.post_correct(model, mo, 32, threads=2, is_type="is2", seed=5, devices=[0, 0])
+    assert two["timing_ms"]["gather"] == "host_blocks"
+    assert np.array_equal(one["weights"], two["weights"]) and np.array_equal(one["loglik"], two["loglik"])
+
+
 def _ung_zoo(kind, rng, n=50):
     """(model, theta draws) per model family / distribution for the full-device psi set-up (ung_setup_kernel)"""
     ns = 70  # more than one wave of draws
