@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbssm_amd.so")
 
 BSSM_OK, BSSM_WARN_DEGENERATE = 0, 1
-PLAN_KEEP_HISTORY, PLAN_FORCE_GRID, PLAN_FORCE_WG = 1, 2, 4
+PLAN_KEEP_HISTORY, PLAN_FORCE_GRID, PLAN_FORCE_WG, PLAN_FACTORED_WEIGHTS = 1, 2, 4, 8
 
 c_double_p = C.POINTER(C.c_double)
 c_u32_p = C.POINTER(C.c_uint32)

@@ -315,6 +315,8 @@ struct DeviceBatch {
   DevBuf mats, obs, init, hist, indices, weights, loglik, dead, ws, fparbuf, amatbuf;
   bssm::GridWorkspace gws{};
   bool use_grid = false;
+  bool want_factored = false;     // BSSM_PLAN_FACTORED_WEIGHTS: ask the step kernels for the factored weights output
+  bool weights_factored = false;  // the last run left `weights` in factored form (GridWorkspace::fw was granted)
   std::vector<double> const_terms;  // per filter, added to the device log-likelihood on the host
 
   // tables: one per filter (all with the same MP/KP/mats_tstride)
@@ -418,8 +420,13 @@ struct DeviceBatch {
 
   int run(uint32_t seed, uint32_t stream0, hipStream_t st, bssm::StepTiming* timing = nullptr) {
     fb.seed = seed; fb.stream0 = stream0;
+    weights_factored = false;
     if (use_grid) {
+      bssm::StepTiming local;
+      if (!timing) timing = &local;
+      gws.fw = want_factored ? 1 : 0;
       HIP_TRY(bssm::launch_grid_filter(fb, gws, st, timing));
+      weights_factored = timing->factored != 0;
     } else if (timing && timing->every > 0) {  // one launch holds the whole filter: time that launch
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0));
@@ -2466,6 +2473,7 @@ bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int3
   if (plan_tables(models, n_models, n_rep, psi, &tabs, &consts, &n, &m, &k, &pp, &p->global) != BSSM_OK) return nullptr;
   p->n_models = n_models; p->n_rep = n_rep; p->psi = psi;
   const bool keep = flags & BSSM_PLAN_KEEP_HISTORY;
+  p->db.want_factored = keep && (flags & BSSM_PLAN_FACTORED_WEIGHTS);
   if (p->db.upload(tabs, n, m, k, pp, (int)nsim, psi, keep, flags) != BSSM_OK) return nullptr;
   p->db.const_terms = consts;
   // full-output filter 16m + 24 bytes per particle-step; log-likelihood only 16m + 16
@@ -2614,11 +2622,38 @@ int bssm_plan_fetch(const bssm_plan* plan, int32_t filter, void* hip_stream, dou
   const size_t n = fb.n, m = fb.m, N = fb.N, f = (size_t)filter;
   if (alpha_hist) HIP_TRY(hipMemcpyAsync(alpha_hist, plan->db.hist.as<double>() + f * (n + 1) * m * N, (n + 1) * m * N * sizeof(double), hipMemcpyDeviceToHost, st));
   if (indices) HIP_TRY(hipMemcpyAsync(indices, plan->db.indices.as<uint32_t>() + f * n * N, n * N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  std::vector<double> scales;
+  const size_t B = plan->db.gws.B, chunk = plan->db.gws.chunk;
   if (weights) {
     if (!plan->db.weights.p) return fail(BSSM_ERR_INVALID, "the plan keeps no weights");
     HIP_TRY(hipMemcpyAsync(weights, plan->db.weights.as<double>() + f * (n + 1) * N, (n + 1) * N * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (plan->db.weights_factored) {
+      scales.resize((n + 1) * B);
+      HIP_TRY(hipMemcpyAsync(scales.data(), plan->db.gws.wscale + f * (n + 1) * B, scales.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
   }
   HIP_TRY(hipStreamSynchronize(st));
+  if (weights && plan->db.weights_factored) {
+    // factored form -> the reference's exp(w - max_t): one factor per (time point, particle block); the last column (ones,
+    // or zeros behind a degenerate step) is final as stored
+    for (size_t t = 0; t < n; t++)
+      for (size_t blk = 0; blk < B; blk++) {
+        const double sc = scales[t * B + blk];
+        double* w = weights + t * N + blk * chunk;
+        const size_t len = std::min(chunk, N - blk * chunk);
+        for (size_t i = 0; i < len; i++) w[i] *= sc;
+      }
+  }
+  return BSSM_OK;
+}
+
+int bssm_plan_weights_layout(const bssm_plan* plan, int32_t* factored, int32_t* block_particles, int32_t* n_blocks, void** scales) {
+  if (!plan) return fail(BSSM_ERR_INVALID, "plan NULL");
+  const bool fw = plan->db.weights_factored;
+  if (factored) *factored = fw ? 1 : 0;
+  if (block_particles) *block_particles = fw ? plan->db.gws.chunk : 0;
+  if (n_blocks) *n_blocks = fw ? plan->db.gws.B : 0;
+  if (scales) *scales = fw ? (void*)plan->db.gws.wscale : nullptr;
   return BSSM_OK;
 }
 

@@ -279,13 +279,24 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   const int psi_mode = PM >= 0 ? PM : b.psi;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   math_tab_init();
-  const int NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = NT >> 6;
+  // more than one particle per lane: the workgroup has exactly NTB threads (launch_wg_mk), so the thread count, the wave
+  // count and every index derived from them are compile-time constants
+  constexpr bool kFixedNT = PPT > 1;
+  const int NT = kFixedNT ? NTB : (int)blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = NT >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // psi-APF of a functor model: parameter block, observation row and approximating rows are wave-uniform -- scalar loads
+  constexpr bool kPsiFn = FN != FN_NONE && PM == 1 && MP <= 4;
   const int Ncap = NT * PPT, N = b.N, n = b.n, f = blockIdx.x;
   double* __restrict__ s_alpha = smem;            // [MP][Ncap]
   double* __restrict__ s_cdf = smem + MP * Ncap;  // [Ncap]
   double* __restrict__ s_max = s_cdf + Ncap;      // [16]
   double* __restrict__ s_tot = s_max + 16;        // [PPT*16] wave totals in particle order
+  // [64] pivots of the cooperative search round: entry (l + 1) W - 1 of the CDF for lane l (W = N / 64).  Read straight
+  // from s_cdf the 64 lanes' addresses are W doubles apart -- one bank for W = 64: a 64-way conflict per particle row.
+  // Used when N is a power of two (W a power of two: the owner of a pivot entry is found with a mask).
+  double* __restrict__ s_piv = s_tot + PPT * 16;
+  const bool piv_tab = N >= 256 && (N & (N - 1)) == 0;
+  const int piv_mask = (N >> 6) - 1, piv_shift = 31 - __builtin_clz((unsigned)((N >> 6) > 0 ? (N >> 6) : 1));
 
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
   const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
@@ -322,7 +333,8 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
         if (b.alpha_hist && c < m) b.alpha_hist[(((size_t)f * (n + 1)) * m + c) * N + i] = x[c];
       }
     }
-    w[r] = (i < N) ? weight_dispatch<MP, FN, PM>(b, fpar, obs, amats, 0, x, x) : -INFINITY;
+    if constexpr (kPsiFn) w[r] = (i < N) ? functor_psi_weight<MP, FID>(as_uniform_table(fpar), as_uniform_table(obs), as_uniform_table(amats), 0, x, x) : -INFINITY;
+    else w[r] = (i < N) ? weight_dispatch<MP, FN, PM>(b, fpar, obs, amats, 0, x, x) : -INFINITY;
     __builtin_amdgcn_sched_barrier(0);  // keep the unrolled particles sequential: bounds live registers
   }
 
@@ -353,21 +365,33 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     const double Ms = M == -INFINITY ? 0.0 : M;
     // every wave scans the <= 128 scaled chunk totals redundantly (saves a barrier); chunk q belongs to wave q % nw
     const int Q = PPT * nw;
+    constexpr bool kOneScan = kFixedNT && PPT * (NTB / 64) <= 64;  // at most 64 chunk totals: one wave scan covers them
     const double t0 = (lane < Q) ? s_tot[lane] * tl_exp(s_max[lane % nw] - Ms) : 0.0;
-    const double t1 = (lane + 64 < Q) ? s_tot[lane + 64] * tl_exp(s_max[(lane + 64) % nw] - Ms) : 0.0;
     const double i0 = wave_scan_incl(t0);
-    const double half = lane_broadcast(i0, 63);
-    const double i1 = wave_scan_incl(t1) + half;
+    double i1 = i0;
+    if constexpr (!kOneScan) {
+      const double t1 = (lane + 64 < Q) ? s_tot[lane + 64] * tl_exp(s_max[(lane + 64) % nw] - Ms) : 0.0;
+      const double half = lane_broadcast(i0, 63);
+      i1 = wave_scan_incl(t1) + half;
+    }
     const double S = lane_broadcast(i1, 63);
     const double swv = tl_exp(Mw - Ms);  // this wave's rescale
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int q = r * nw + wave;  // my chunk; exclusive offset = inclusive prefix of chunk q-1
-      const double p0 = lane_broadcast(i0, (q - 1) & 63), p1 = lane_broadcast(i1, (q - 65) & 63);
-      const double off = (q == 0) ? 0.0 : (q <= 64 ? p0 : p1);
+      double off;
+      if constexpr (kOneScan) {
+        const double p0 = lane_broadcast(i0, (q - 1) & 63);
+        off = (q == 0) ? 0.0 : p0;
+      } else {
+        const double p0 = lane_broadcast(i0, (q - 1) & 63), p1 = lane_broadcast(i1, (q - 65) & 63);
+        off = (q == 0) ? 0.0 : (q <= 64 ? p0 : p1);
+      }
       const int i = r * NT + tid;
       if (i < N) {
-        s_cdf[i] = __builtin_fma(sc[r], swv, off);
+        const double cd = __builtin_fma(sc[r], swv, off);
+        s_cdf[i] = cd;
+        if (piv_tab && ((i + 1) & piv_mask) == 0) s_piv[i >> piv_shift] = cd;
         if (b.weights) b.weights[((size_t)f * (n + 1) + t) * N + i] = e[r] * swv;
       }
     }
@@ -388,10 +412,15 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     u32x4 blk[PPT];  // step blocks: spare word -> resampling uniform now, words 0-2 -> transition normals below
     double v[PPT];
     int lo[PPT], hi[PPT], width = 0;
+    // The 20 Philox round keys (seed + r * const, stream + r * const) are loop-invariant: hoisted out of the time loop they
+    // sat in SGPRs for its whole body, were spilt to VGPR lanes and came back through 80 v_readlane per wave-step.  Opaque
+    // copies of the key make them step-local: 20 scalar adds per step, live only while the step blocks are drawn.
+    RngKey key_t = key;
+    __asm__ volatile("" : "+s"(key_t.seed), "+s"(key_t.stream));
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
-      blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)i);
+      blk[r] = rng_step_block(key_t, (uint32_t)t, (uint32_t)i);
       v[r] = (block_uniform(blk[r]) + (double)i) * c_scale;
       lo[r] = 0; hi[r] = N - 1;
       if (N >= 256 && r * NT + (wave + 1) * 64 <= N) {
@@ -400,7 +429,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
         // and the per-lane bisection then runs over that short range instead of [0, N)
         const int W = (N + 63) >> 6;
         const int pe = min((lane + 1) * W, N) - 1;
-        const double pv = s_cdf[pe];
+        const double pv = piv_tab ? s_piv[lane] : s_cdf[pe];
         const bool valid = lane * W < N;
         const double v_lo = lane_broadcast(v[r], 0), v_hi = lane_broadcast(v[r], 63);
         const int c_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && pv < v_lo));
@@ -440,17 +469,19 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     // ---- transition to t+1 and the weights there
     const cdbl* mt = as_uniform_table(mats + (size_t)t * b.mats_tstride);
     const double* __restrict__ ob = obs + (size_t)(t + 1 < n ? t + 1 : 0) * obs_stride;
+    RngKey key_p = key;  // (as key_t above: the round keys of the further transition blocks stay local to this section)
+    __asm__ volatile("" : "+s"(key_p.seed), "+s"(key_p.stream));
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
       double x[MP];
       if (FN && !psi_mode) {
-        if constexpr (FN != FN_NONE) functor_propagate<MP, KP, FID>(fpar, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
+        if constexpr (FN != FN_NONE) functor_propagate<MP, KP, FID>(fpar, key_p, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
       } else if (FN && MP <= 2 && psi_mode == 2) {
-        if constexpr (FN != FN_NONE && MP <= 2) functor_ekpf_propagate<MP, FID>(fpar, ob, t + 1 >= n, key, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
+        if constexpr (FN != FN_NONE && MP <= 2) functor_ekpf_propagate<MP, FID>(fpar, ob, t + 1 >= n, key_p, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
       } else {
         double z[KP];
-        rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
+        rng_normals_blk<KP>(blk[r], key_p, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
         propagate<MP, KP>(mt, a[r], z, x);
       }
       if (i < N) {
@@ -463,7 +494,8 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
           }
         }
       }
-      w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)t * (MP * MP + MP), t + 1, x, a[r]) : 0.0) : -INFINITY;
+      if constexpr (kPsiFn) w[r] = (i < N) ? (t + 1 < n ? functor_psi_weight<MP, FID>(as_uniform_table(fpar), as_uniform_table(ob), as_uniform_table(amats + (size_t)t * (MP * MP + MP)), t + 1, x, a[r]) : 0.0) : -INFINITY;
+      else w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)t * (MP * MP + MP), t + 1, x, a[r]) : 0.0) : -INFINITY;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -499,7 +531,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   int ppt = 1;
   while (ppt < 16 && N > ntmax * ppt) ppt *= 2;
   const int nt = ppt == 1 ? (N + 63) / 64 * 64 : ntmax;
-  const size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16 + (MP * MP + MP * KP + MP)) * sizeof(double);
+  const size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16 + 64 + (MP * MP + MP * KP + MP)) * sizeof(double);
   if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch) = nullptr;
   if (wide) {
@@ -1054,10 +1086,11 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     }
     // rows of several observation series (ssm_mng) and every 8-dimensional state: the multi-series variants, one or two
     // particles per lane (MP = 8, one particle per lane: fp64 MFMA transition)
-    if (v2 && !kern_init && ppt <= 2 && (MP == 8 || b.p > 1)) {
+    if (v2 && !kern_init && ppt <= 4 && (MP == 8 || b.p > 1)) {
       v2ms = true;
       if (ppt == 1) { kern = v2_step_kernel<MP, KP, 1, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1, true>; }
-      else { kern = v2_step_kernel<MP, KP, 2, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2, true>; }
+      else if (ppt == 2) { kern = v2_step_kernel<MP, KP, 2, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2, true>; }
+      else { kern = v2_step_kernel<MP, KP, 4, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 4, true>; }
     }
     if (!kern_init) v2wx = v2exact = false;
   }
@@ -1089,6 +1122,10 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   hipEvent_t fork = nullptr, join = nullptr;
   GridWorkspace wsp[2] = {ws, ws};
   wsp[0].wx = wsp[1].wx = v2wx ? 1 : 0;
+  const int fw = (v2wx && kern_init && ws.fw && b.weights) ? 1 : 0;  // factored weights output: only with the weights-exchange kernels
+  wsp[0].fw = wsp[1].fw = fw;
+  if (timing) timing->factored = fw;
+  if (fw && (e = hipMemsetAsync(ws.wscale, 0, sizeof(double) * b.F * (b.n + 1) * ws.B, stream)) != hipSuccess) return e;  // (columns behind a degenerate step stay zero)
   int fcount[2] = {b.F, 0};
   if (parts == 2) {  // first half on the caller's stream, second half on the library's side stream (ws.side)
     lanes[1] = ws.side;

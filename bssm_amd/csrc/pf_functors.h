@@ -44,8 +44,10 @@ enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, 
        FP_M = 25, FP_RMAT = 26, FP_SIZE = 42 };
 
 // ---- ssm_nlg: alpha_{t+1} = T(alpha_t) + R eta,  y_t ~ N(Z(alpha_t), H^2)   (src/model_ssm_nlg.cpp:1118-1126, 943-956)
-template <int MP>
-__device__ __forceinline__ void nlg_T_fn(int id, const double* __restrict__ fp, const double (&a)[MP], double (&x)[MP]) {
+// (PF / PR / PA: pointer types of the parameter block, the observation row and the approximating rows -- plain pointers, or
+// constant-address-space pointers from as_uniform_table, which turn the loads of these wave-uniform values into s_load)
+template <int MP, class PF>
+__device__ __forceinline__ void nlg_T_fn(int id, PF fp, const double (&a)[MP], double (&x)[MP]) {
   switch (id) {
     case FN_NLG_GROWTH: {  // R/cpp_example_models.R:415-428
       const double dT = fp[FP_KNOWN + 0], K = fp[FP_KNOWN + 1];
@@ -58,16 +60,16 @@ __device__ __forceinline__ void nlg_T_fn(int id, const double* __restrict__ fp, 
     case FN_NLG_AR_EXP: x[0] = fp[FP_THETA + 0] * (1.0 - fp[FP_THETA + 1]) + fp[FP_THETA + 1] * a[0]; break;  // :296-300
     case FN_NLG_SIN_EXP: x[0] = sin(a[0]); break;                                                            // :726-730
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
-    case FN_USER_NLG: bssm_user_T(&a[0], fp + FP_THETA, fp + FP_KNOWN, &x[0]); break;
+    case FN_USER_NLG: bssm_user_T(&a[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN), &x[0]); break;
 #endif
     default: x[0] = a[0]; break;                                                                             // linear_gaussian
   }
 }
-template <int MP>
-__device__ __forceinline__ double nlg_Z_fn(int id, const double* __restrict__ fp, const double (&x)[MP]) {
+template <int MP, class PF>
+__device__ __forceinline__ double nlg_Z_fn(int id, PF fp, const double (&x)[MP]) {
   switch (id) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
-    case FN_USER_NLG: return bssm_user_Z(&x[0], fp + FP_THETA, fp + FP_KNOWN);
+    case FN_USER_NLG: return bssm_user_Z(&x[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN));
 #endif
     case FN_NLG_GROWTH: return MP > 1 ? x[MP > 1 ? 1 : 0] : x[0];  // second state (:393-400)
     case FN_NLG_AR_EXP:
@@ -241,15 +243,14 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
 // at the ANCESTOR.  H and R are constant in every shipped model, so the Gaussian normalisers cancel exactly.
 //   row  : observation row of time t (y, approximating D_t in OB_D, approximating Z_t after the header, 1/H in OB_PSIIH)
 //   amat : approximating T_{t-1} (MP x MP) and C_{t-1} (MP) -- only read when t > 0
-template <int MP, int FID = 0>
-__device__ __forceinline__ double functor_psi_weight(const double* __restrict__ fp, const double* __restrict__ row,
-                                                     const double* __restrict__ amat, int t, const double (&x)[MP],
+template <int MP, int FID = 0, class PF, class PR, class PA>
+__device__ __forceinline__ double functor_psi_weight(PF fp, PR row, PA amat, int t, const double (&x)[MP],
                                                      const double (&aprev)[MP]) {
   if (row[RH_FLAG] == 0.0) return 0.0;  // y_t missing: weights are ones, transition ratio included (:1040-1056)
   const int id = FID > 0 ? FID : (int)fp[FP_ID];
   double w = 0.0;
   {
-    const double* __restrict__ ob = row + ROW_HDR;
+    const PR ob = row + ROW_HDR;
     const double y = ob[OB_Y], ih = ob[OB_PSIIH];
     const double q1 = (y - nlg_Z_fn<MP>(id, fp, x)) * ih;
     double lin = ob[OB_D];

@@ -273,6 +273,34 @@ __device__ __forceinline__ void v2_log_weights_multi(const int p, const cdbl* ro
   }
 }
 
+// One particle's log-weight over a row of p series, evaluated right behind its transition while its state is still in
+// registers (the four-particles-per-lane multi-series variant: nothing of the state is kept for a density phase).  Same
+// operations in the same order as v2_log_weights_multi, so the two give identical bits.
+template <int MP>
+__device__ __forceinline__ double v2_log_weight_multi_one(const int p, const cdbl* row, const bool psi, const double (&x)[MP]) {
+  double w = 0.0;
+  for (int j = 0; j < p; j++) {
+    const cdbl* ob = row + ROW_HDR + j * (SER_HDR + MP);
+    if (ob[OB_FLAG] == 0.0) continue;
+    const double sj = v2_signal<MP>(ob, x);
+    const int dist = (int)ob[OB_DIST];
+    const double y = ob[OB_Y], u = ob[OB_U], aux = ob[OB_AUX], phi = ob[OB_PHI];
+    double dj;
+    switch (dist) {
+      case DIST_SVM: dj = -0.5 * (sj + aux * tl_exp(-sj)); break;
+      case DIST_POISSON: dj = y * sj - u * tl_exp(sj); break;
+      case DIST_BINOMIAL: dj = y * sj - u * log1p(tl_exp(sj)); break;
+      case DIST_NEGBIN: dj = y * sj - aux * tl_log(phi + u * tl_exp(sj)); break;
+      case DIST_GAMMA: dj = -phi * (sj + aux * tl_exp(-sj)); break;
+      default: { const double d = y - sj; dj = -0.5 * d * d * aux; } break;
+    }
+    if (psi) { const double q = (ob[OB_PSIY] - sj) * ob[OB_PSIIH]; dj = __builtin_fma(0.5 * q, q, dj); }
+    w += dj;
+  }
+  if (psi) w -= row[RH_SCALE];
+  return w;
+}
+
 // Block statistics of the new weights and their hand-over to the next launch: block-local inclusive scan of
 // exp(w - max_b) (`lcdf`), row ends (`coarse`), (max_b, sum_b) (`partials`); optional block-scaled weights output.
 // One workgroup barrier.  s_x: 4 + 4 * PPT doubles of LDS.
@@ -287,7 +315,8 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
   for (int r = 1; r < PPT; r++) mx = fmax(mx, w[r]);
   const double Mw = wave_max(mx);
   const double Mws = Mw == -INFINITY ? 0.0 : Mw;  // a wave without mass: exp(-inf - 0) = 0 instead of exp(nan)
-  double* __restrict__ lcdf_new = uniform_ptr(ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N + base);
+  const bool fw = WX && ws.fw != 0;  // factored weights output: the weights column of time tn is the exchange array
+  double* __restrict__ lcdf_new = uniform_ptr(fw ? b.weights + ((size_t)f * (n + 1) + tn) * N + base : ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N + base);
   double* __restrict__ coarse_new = uniform_ptr(ws.coarse + (((size_t)(tn & 1) * b.F + f) * B + pb) * crow);
   if constexpr (WX) {
     // Weights exchange: the next launch needs the block-scaled weights, the scan value at the end of every row of 16
@@ -314,7 +343,7 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
     const double Mb = fmax(fmax(m0, m1), fmax(m2, m3));
     const double Mbs = Mb == -INFINITY ? 0.0 : Mb;
     const double swv = tl_exp(Mws - Mbs) * (Mw == -INFINITY ? 0.0 : 1.0);  // exp(max_wave - max_block)
-    double* __restrict__ wout = (b.weights && tn == n) ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + tn) * N + base) : nullptr;
+    double* __restrict__ wout = (b.weights && tn == n && !fw) ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + tn) * N + base) : nullptr;
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int li = v2_li<PPT>(r, tid);
@@ -385,8 +414,12 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
 #ifndef BSSM_V2_OCC_MS16
 #define BSSM_V2_OCC_MS16 4   // MP = 8, two particles per lane: 128 VGPRs with 5 spilled beat 132 at three waves (C4, 64 filters: +4 ... +7 %)
 #endif
+#ifndef BSSM_V2_OCC_MS32
+#define BSSM_V2_OCC_MS32 3   // MP = 8, four particles per lane (weights fused into the particle loop)
+#endif
 constexpr int v2_occupancy(int mp, int ppt, bool ms = false) {
   if (ms && mp * ppt == 16) return BSSM_V2_OCC_MS16;
+  if (ms && ppt >= 4) return mp * ppt >= 32 ? BSSM_V2_OCC_MS32 : 4;
   const int live = mp * ppt * (ms && mp * ppt > 8 ? 2 : 1);  // the multi-series variants keep the new states until the density
   return live <= 4 ? 5 : (live <= 8 ? 4 : (live <= 16 ? BSSM_V2_OCC16 : (live <= 32 ? 3 : 2)));
 }
@@ -503,7 +536,7 @@ __device__ __forceinline__ void v2_window_ancestors(const double* sw, const doub
 template <int MP, int KP, int PPT, bool MS = false, bool WX = false, bool EXACT = false>
 __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_step_v2(const FilterBatch b, const GridWorkspace ws, const int t) {
   #ifndef BSSM_V2_MFMA_PPT
-#define BSSM_V2_MFMA_PPT 2
+#define BSSM_V2_MFMA_PPT 4
 #endif
   constexpr bool kMfma = MS && MP == 8 && PPT <= BSSM_V2_MFMA_PPT;
   __shared__ double s_win[kMfma ? 4 * 8 * 64 : 4 * PPT * V2_WIN];
@@ -533,7 +566,8 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #ifdef BSSM_V2_NO_RMW
   double* __restrict__ wt = nullptr;
 #else
-  double* __restrict__ wt = b.weights ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + t) * N + base) : nullptr;
+  const bool fw = WX && ws.fw != 0;  // factored weights output (GridWorkspace::fw): no rescaling pass over the time-t weights
+  double* __restrict__ wt = (b.weights && !fw) ? uniform_ptr(b.weights + ((size_t)f * (n + 1) + t) * N + base) : nullptr;
 #endif
   // the read-modify-write that rescales the stored time-t weights from the block maximum to the global one; LATE: behind
   // the transition, where few registers are live (BSSM_V2_RMW_LATE, the five-waves-per-SIMD builds), otherwise loaded
@@ -606,6 +640,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   lds_barrier();  // (1)
   const V2Prefix px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[128 + 64 + lane], B};
   const double S = s_comb[127], M = s_comb[384];
+  if (fw && pb == 0 && tid < B) ws.wscale[((size_t)f * (n + 1) + t) * B + tid] = s_comb[256 + tid];  // exp(max_block - max_t)
   V2_MARK("rmw"); V2_STAMP(2);
   // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
   if (!BSSM_V2_RMW_LATE && wt) rmw_store(wt_old);
@@ -624,7 +659,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   if (pb == B - 1 && tid == GRID_NT - 1) ws.llinc[(size_t)f * (n + 1) + t] = M + tl_log(S / (double)N);  // :683
   const double c_scale = S / (double)N;
 
-  const double* __restrict__ lcdf = uniform_ptr(ws.lcdf + ((size_t)(t & 1) * b.F + f) * N);
+  const double* __restrict__ lcdf = uniform_ptr(fw ? b.weights + ((size_t)f * (n + 1) + t) * N : ws.lcdf + ((size_t)(t & 1) * b.F + f) * N);
   const double* __restrict__ coarse = uniform_ptr(ws.coarse + ((size_t)(t & 1) * b.F + f) * B * crow);
   const double* __restrict__ st_old = uniform_ptr(b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N);
   double* __restrict__ st_new = uniform_ptr((b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N) + base);
@@ -807,7 +842,10 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #ifndef BSSM_V2_PIN_BLK
 #define BSSM_V2_PIN_BLK 0
 #endif
-  constexpr int ROLL = (BSSM_V2_ROLL) < PPT ? (BSSM_V2_ROLL) : PPT;
+  // kFuse (rows of several series at four particles per lane): a particle's log-weight is evaluated right behind its
+  // transition, its state never outlives the iteration, and the ancestor rows are requested two at a time
+  constexpr bool kFuse = MS && PPT >= 4;
+  constexpr int ROLL = kFuse ? 2 : ((BSSM_V2_ROLL) < PPT ? (BSSM_V2_ROLL) : PPT);
   double a[ROLL][MP];
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
@@ -839,7 +877,8 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   // ---- phase E: transition normals, alpha_{t+1} = C_t + T_t a + R_t eta (:663-670), signal at t+1
   const bool have_obs = tn < n;
   const cdbl* row = as_uniform_table(b.obs + (size_t)f * b.obs_fstride + (size_t)(have_obs ? tn : 0) * (ROW_HDR + (MS ? b.p : 1) * (SER_HDR + MP)));
-  double s[PPT], w[PPT], xs[MS ? PPT : 1][MP];
+  double s[PPT], w[PPT], xs[(MS && !kFuse) ? PPT : 1][MP];
+  const bool weigh = have_obs && row[RH_FLAG] != 0.0;  // otherwise nothing is observed at t+1: the weights are ones
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = v2_li<PPT>(r, tid), j = base + li;
@@ -869,7 +908,10 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #pragma unroll
       for (int c = 0; c < MP; c++) if (c < m) { if constexpr ((BSSM_V2_NT) & 4) st32_nt(st_new + (size_t)c * N, li, x[c]); else st32(st_new + (size_t)c * N, li, x[c]); }
     }
-    if constexpr (MS) {
+    if constexpr (kFuse) {
+      w[r] = weigh ? v2_log_weight_multi_one<MP>(b.p, row, b.psi != 0, x) : 0.0;
+      __asm__ volatile("" : "+v"(w[r]));
+    } else if constexpr (MS) {
 #pragma unroll
       for (int c = 0; c < MP; c++) xs[r][c] = x[c];
     } else {
@@ -880,12 +922,14 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   }
   V2_MARK("density"); V2_STAMP(9);
   if (BSSM_V2_RMW_LATE && wt) rmw_load(wt_old);
-  if (have_obs && row[RH_FLAG] != 0.0) {
-    if constexpr (MS) v2_log_weights_multi<MP, PPT>(b.p, row, b.psi != 0, xs, w);
-    else v2_log_weights<PPT>(row, b.psi != 0, s, w);
-  } else {  // nothing observed at t+1: weights are ones (src/model_ssm_ung.cpp:644-647)
+  if constexpr (!kFuse) {
+    if (weigh) {
+      if constexpr (MS) v2_log_weights_multi<MP, PPT>(b.p, row, b.psi != 0, xs, w);
+      else v2_log_weights<PPT>(row, b.psi != 0, s, w);
+    } else {  // nothing observed at t+1: weights are ones (src/model_ssm_ung.cpp:644-647)
 #pragma unroll
-    for (int r = 0; r < PPT; r++) w[r] = 0.0;
+      for (int r = 0; r < PPT; r++) w[r] = 0.0;
+    }
   }
   if (BSSM_V2_RMW_LATE && wt) rmw_store(wt_old);
   if constexpr ((BSSM_V2_PRIO) == 3 || (BSSM_V2_PRIO) == 4) __builtin_amdgcn_s_setprio(3);  // the block statistics: waves about to finish first

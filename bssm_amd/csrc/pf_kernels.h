@@ -60,6 +60,15 @@ struct GridWorkspace {
   int f0;              // first filter of this launch (a batch may be stepped as two interleaved launch sequences)
   int xcd_remap;       // 1: workgroup ids are remapped so that every XCD owns a contiguous range of (filter, block) pairs
   int wx;              // 1: the exchange array `lcdf` carries block-scaled weights, not their scan (round-2 step kernel, full output)
+  // Factored weights output (round 3, opt-in: BSSM_PLAN_FACTORED_WEIGHTS).  fw = 1 on entry asks for it; the launcher
+  // grants it where the weights-exchange step kernel runs (and reports it in StepTiming::factored).  The weights output
+  // then IS the exchange array: column t of `weights` holds exp(w_i - max of i's particle block), written once by the launch
+  // that computes the weights, read by the next launch's search windows, never rewritten; the factor that takes a block to
+  // the reference's scale, exp(max_block - max_t), is stored per (filter, time point, block) in `wscale`
+  //   reference weight (t, i) = weights[f][t][i] * wscale[f][t][i / chunk]        (t < n; column n is final as stored)
+  // -- 16 of the 104 bytes a particle-step moved disappear (the owner's read of its exchanged weights and the second write).
+  int fw;
+  double* wscale;      // [F][n+1][B]
   hipStream_t side;    // the library's side stream for the second launch sequence (one per host thread); null = none
 };
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out);
@@ -71,6 +80,7 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
 // finished time slabs of the outputs to the host while the filter is still stepping.
 struct StepTiming {
   int every = 0; int count = 0; double total_ms = 0.0; int concurrent = 1;  // concurrent: launch sequences in flight
+  int factored = 0;  // 1: the weights output of this run is in factored form (GridWorkspace::fw was granted)
   int progress_every = 0, progress_count = 0;
   static constexpr int kMaxProgress = 64;
   hipEvent_t progress_events[kMaxProgress] = {};

@@ -18,7 +18,7 @@ const char* last_filter_kernel() { return g_last_kernel; }
 int wg_filter_capacity(int MP) {
   // 160 KiB LDS per CU: (MP + 1) doubles per particle + reduction slots; 512 threads x up to 16 particles
   // (8 for padded state dimensions above 2)
-  const size_t avail = 160 * 1024 - (16 + 16 * 16 + MP * MP * 2 + MP) * sizeof(double);
+  const size_t avail = 160 * 1024 - (16 + 16 * 16 + 64 + MP * MP * 2 + MP) * sizeof(double);
   const size_t cap = avail / ((size_t)(MP + 1) * sizeof(double));
   for (int c = (MP <= 2 ? 8192 : 4096); c >= 512; c >>= 1) if ((size_t)c <= cap) return c;
   return (int)(cap / 64 * 64);
@@ -77,6 +77,7 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   bytes += al((size_t)2 * b.F * B * (chunk / 16) * sizeof(double));  // coarse
   bytes += al((size_t)2 * b.F * B * 2 * sizeof(double));      // partials
   bytes += al((size_t)2 * b.F * (b.n + 1) * sizeof(double));  // maxhist + llinc (contiguous)
+  bytes += al((size_t)b.F * (b.n + 1) * B * sizeof(double));  // wscale (factored weights output)
   return bytes;
 }
 
@@ -92,6 +93,8 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   ws->partials = (double*)p; p += al((size_t)2 * b.F * B * 2 * sizeof(double));
   ws->maxhist = (double*)p; ws->llinc = ws->maxhist + (size_t)b.F * (b.n + 1);
   p += al((size_t)2 * b.F * (b.n + 1) * sizeof(double));
+  ws->wscale = (double*)p; p += al((size_t)b.F * (b.n + 1) * B * sizeof(double));
+  ws->fw = 0;
   ws->logw = nullptr;
   ws->dbg = nullptr;
   ws->B = B;

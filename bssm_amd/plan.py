@@ -12,7 +12,7 @@ from .models import model_arrays
 
 class FilterPlan:
     def __init__(self, models, particles: int, method: str = "bsf", n_rep: int = 1, keep_history: bool = False,
-                 force: str | None = None):
+                 force: str | None = None, factored_weights: bool = False):
         if not isinstance(models, (list, tuple)):
             models = [models]
         self._keep = []
@@ -25,6 +25,9 @@ class FilterPlan:
         self._models = arr_t(*packed)
         flags = (_lib.PLAN_KEEP_HISTORY if keep_history else 0)
         flags |= {"grid": _lib.PLAN_FORCE_GRID, "wg": _lib.PLAN_FORCE_WG, None: 0}[force]
+        # opt-in: weights kept as block-scaled value x per-(time point, block) factor (BSSM_PLAN_FACTORED_WEIGHTS); fetch()
+        # multiplies them out, weights_layout() says whether the last run produced that form
+        flags |= _lib.PLAN_FACTORED_WEIGHTS if factored_weights else 0
         L = _lib.lib()
         self._h = L.bssm_plan_create(self._models, len(packed), n_rep, particles, 1 if method == "psi" else 2, flags)
         if not self._h:
@@ -91,6 +94,15 @@ class FilterPlan:
         _lib.check(L.bssm_plan_fetch(self._h, filter_index, C.c_void_p(hip_stream), _lib.dptr(a),
                                      None if ix is None else ix.ctypes.data_as(_lib.c_u32_p), _lib.dptr(w)))
         return dict(alpha=a, indices=ix, weights=w)
+
+    def weights_layout(self):
+        """dict(factored, block_particles, n_blocks) of the weights the last run() left on the device"""
+        L = _lib.lib()
+        L.bssm_plan_weights_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_void_p)]
+        fa, bp, nb, sc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_void_p()
+        _lib.check(L.bssm_plan_weights_layout(self._h, C.byref(fa), C.byref(bp), C.byref(nb), C.byref(sc)))
+        return dict(factored=bool(fa.value), block_particles=bp.value, n_blocks=nb.value)
 
     def time(self, seed: int, reps: int, hip_stream: int = 0) -> float:
         ms = C.c_double()

@@ -362,6 +362,15 @@ typedef struct bssm_plan bssm_plan;
 #define BSSM_PLAN_KEEP_HISTORY 1u  /* alpha, indices, weights kept (full-output filter) */
 #define BSSM_PLAN_FORCE_GRID 2u
 #define BSSM_PLAN_FORCE_WG 4u
+/* Opt-in (device-resident callers): keep the weights output in FACTORED form where the step kernel supports it --
+ * column t of `weights` holds exp(w_i - max over i's particle block), written once, and one factor per (filter, time point,
+ * particle block) takes it to the reference's exp(w_i - max_t) (src/model_ssm_ung.cpp:675-677):
+ *   reference weight (t, i) = weights[f][t][i] * scales[f][t][i / block_particles]     for t < n; column n is final.
+ * The launch that computes the weights then writes them once and nothing reads them back to rescale them: 16 of the 104
+ * bytes a particle-step moves disappear.  bssm_plan_weights_layout() says whether the last run used it (the layout is
+ * granted per run: only the weights-exchange step kernels produce it); bssm_plan_fetch() always returns the reference's
+ * form.  The drop-in entry points (bssm_bsf, ...) never use it. */
+#define BSSM_PLAN_FACTORED_WEIGHTS 8u
 /* n_models filters x n_rep replicas each; model i, replica r uses stream stream0 + i*n_rep + r */
 bssm_plan* bssm_plan_create(const bssm_ung_model* models, int32_t n_models, int32_t n_rep, uint32_t nsim,
                             uint32_t sampling_method, uint32_t flags);
@@ -384,6 +393,10 @@ int bssm_plan_info(const bssm_plan* plan, int32_t* path /*0 wg, 1 grid*/, int32_
 /* device pointers of the kept outputs (NULL when not kept): alpha_hist [f][n+1][m][N],
  * indices [f][n][N], weights [f][n+1][N] */
 int bssm_plan_device_outputs(const bssm_plan* plan, void** alpha_hist, void** indices, void** weights);
+/* layout of the weights the last bssm_plan_run left in device memory: *factored = 1 when they are in the factored form of
+ * BSSM_PLAN_FACTORED_WEIGHTS, then *block_particles / *n_blocks give the particle blocks and *scales the device pointer of
+ * the factors [f][n+1][n_blocks] (column n unused); otherwise 0 / 0 / 0 / NULL and `weights` holds the reference's form */
+int bssm_plan_weights_layout(const bssm_plan* plan, int32_t* factored, int32_t* block_particles, int32_t* n_blocks, void** scales);
 /* waits for `hip_stream` and copies the kept outputs of ONE filter of the plan to host memory, in the device layout:
  * alpha_hist (n+1) x m x N with the particle index fastest, indices n x N, weights (n+1) x N; any may be NULL
  * (parity tests and bench.py's accuracy leg read the very batch that was timed) */

@@ -150,3 +150,53 @@ def test_step_kernel_more_than_64_blocks_matches_oracle(oracle, monkeypatch, N, 
     assert np.array_equal(out["indices"], ref["indices"])
     assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
     assert np.max(np.abs(out["weights"] - ref["weights"])) <= 1e-9
+
+
+@pytest.mark.parametrize("case", ["ragged_ppt2", "psi_ppt4", "mng_ppt2", "degenerate", "wg_shape"])
+def test_factored_weights_layout_multiplies_out_to_the_reference_form(oracle, monkeypatch, case):
+    """BSSM_PLAN_FACTORED_WEIGHTS (opt-in layout of device-resident plans: block-scaled weights written once + one factor per
+    (time point, particle block)): fetch() multiplies the factors out, and weights / ancestors / log-likelihood then meet the
+    oracle exactly as the standard layout does -- ragged last block, psi-APF, rows of several series, a filter that
+    degenerates half way (later columns zero), and a kernel shape that cannot produce the layout (the flag is then not
+    granted and the weights are in the reference's form already)"""
+    from bssm_amd.plan import FilterPlan
+    from models_zoo import mng_zoo, negbin_m4
+    rng = np.random.default_rng(5)
+    n, method, force, ppt, N = 10, "bsf", "grid", "2", 3000
+    if case == "ragged_ppt2":
+        model = negbin_m4(n, seed=7)
+    elif case == "psi_ppt4":
+        y = rng.poisson(np.exp(rng.normal(1.0, 0.5, n))).astype(float)
+        model, method, ppt, N = M.bsm_ng(y, sd_level=0.4, sd_slope=0.1, distribution="poisson", P1=np.diag([2.0, 0.3]), a1=[1.0, 0.0]), "psi", "4", 4096
+    elif case == "mng_ppt2":
+        model = mng_zoo()["mixed_m4_p3"]; n = model.n
+    elif case == "degenerate":
+        y = rng.poisson(3.0, n).astype(float); y[5] = 1e300  # Poisson log-density -> -inf for every particle at t = 5
+        model = M.ssm_ung(y, Z=1.0, T=0.9, R=0.3, a1=1.0, P1=1.0, distribution="poisson")
+    else:
+        model, force, N = negbin_m4(n, seed=7), "wg", 512
+    monkeypatch.setenv("BSSM_AMD_GRID_PPT", ppt)
+    outs = {}
+    for fw in (False, True):
+        plan = FilterPlan(model, N, method=method, keep_history=True, force=force, n_rep=2, factored_weights=fw)
+        plan.run(11, stream0=4)
+        lay = plan.weights_layout()
+        assert lay["factored"] == (fw and case != "wg_shape"), (case, lay, FilterPlan.last_kernel())
+        outs[fw] = (plan.fetch(1), plan.loglik()[1])
+        plan.close()
+    (a, lla), (b, llb) = outs[False], outs[True]
+    assert np.array_equal(a["indices"], b["indices"]) and np.array_equal(a["alpha"], b["alpha"])
+    assert (lla == llb) or (np.isneginf(lla) and np.isneginf(llb))
+    # same numbers up to the order of two exact-to-1-ulp multiplications (exp(w - max_block) * exp(max_block - max_t))
+    assert np.allclose(a["weights"], b["weights"], rtol=4e-16, atol=0.0)
+    arr = M.model_arrays(model)
+    if case == "mng_ppt2":
+        ref = oracle.mng_bsf_filter(arr, N, seed=11, stream=5)
+    elif method == "psi":
+        ref = oracle.psi_filter(arr, N, seed=11, stream=5)
+    else:
+        ref = oracle.bsf_filter(arr, N, seed=11, stream=5)
+    assert np.array_equal(b["indices"].T, ref["indices"])
+    assert np.max(np.abs(b["weights"].T - ref["weights"])) <= 1e-9
+    if case == "degenerate":
+        assert np.isneginf(llb) and np.all(b["weights"][6:] == 0.0)

@@ -48,6 +48,33 @@ def test_mng_step_kernel_two_particles_per_lane(oracle, monkeypatch, name, N):
     assert _rel(out["weights"], ref["weights"]) <= 1e-9
 
 
+@pytest.mark.parametrize("psi", [False, True])
+@pytest.mark.parametrize("name", sorted(ZOO))
+@pytest.mark.parametrize("N", [4096, 3000])
+def test_mng_step_kernel_four_particles_per_lane(oracle, monkeypatch, name, N, psi):
+    """the multi-series step kernel at four particles per lane (round 3: the log-weight of a particle is evaluated right
+    behind its transition, ancestor rows requested two at a time; fp64-MFMA transition four times per lane for m = 8):
+    complete blocks (4096 = 4 blocks of 1024, windows crossing block boundaries) and a ragged last block, bootstrap and
+    psi-APF, against the oracle"""
+    from bssm_amd.plan import FilterPlan
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "grid")
+    monkeypatch.setenv("BSSM_AMD_GRID_PPT", "4")
+    model = ZOO[name]
+    arr = M.model_arrays(model)
+    if psi:
+        out = F.particle_smoother(model, N, method="psi", seed=5, return_indices=True)
+        ref = oracle.mng_psi_filter(arr, N, seed=5)
+    else:
+        out = F.bootstrap_filter(model, N, seed=5, return_indices=True)
+        ref = oracle.mng_bsf_filter(arr, N, seed=5)
+    assert "pf_grid_step_v2" in FilterPlan.last_kernel() and ",4,true" in FilterPlan.last_kernel()
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    if not psi:
+        assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+
+
 @pytest.mark.parametrize("path", ["wg", "grid"])
 @pytest.mark.parametrize("name", sorted(ZOO))
 def test_mng_psi_smoother(oracle, monkeypatch, name, path):

@@ -188,20 +188,27 @@ def test_metric_config_full_size_against_oracle(oracle):
     assert np.allclose(out["att"][:T1], att_ref, rtol=1e-8, atol=1e-10)
 
 
-def test_bench_plan_variant_against_oracle(oracle):
+@pytest.mark.parametrize("factored", [False, True])
+def test_bench_plan_variant_against_oracle(oracle, factored):
     """The exact thing bench.py times, compared with the oracle as such: FilterPlan(negbin_m4, N = 65 536, full output,
     grid shape, 32 filters in flight) -> pf_grid_step_v2<4,4,4,false,true,true> (four particles per lane, weights exchange,
     no tail guards), stepped as TWO interleaved launch sequences of 16 filters.  Filters 0 / 15 (first and last of the
     sequence on the caller's stream) and 16 / 31 (first and last of the side-stream sequence): ancestors, particle history,
-    weights and log-likelihood against orc_ung_bsf_filter on the same (seed, stream)."""
+    weights and log-likelihood against orc_ung_bsf_filter on the same (seed, stream).
+    factored: the opt-in weights layout bench.py runs with (BSSM_PLAN_FACTORED_WEIGHTS: block-scaled weights written once +
+    one factor per (time point, particle block)); fetch() multiplies it out, and the result must meet the same bar."""
     from bssm_amd.plan import FilterPlan
     n, N, R, seed, s0 = 120, 65536, 32, 9, 64
     model = negbin_m4(n, seed=103)
-    plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R)
+    plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R, factored_weights=factored)
     plan.run(seed, stream0=s0)
     ll = plan.loglik()
     assert FilterPlan.last_kernel() == "pf_grid_step_v2<4,4,4,false,true,true>"
     assert plan.launch_sequences() == 2
+    lay = plan.weights_layout()
+    assert lay["factored"] == factored
+    if factored:
+        assert lay["block_particles"] == 1024 and lay["n_blocks"] == 64
     arr = M.model_arrays(model)
     for f in (0, 15, 16, 31):
         got = plan.fetch(f)
