@@ -38,6 +38,7 @@ VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 REGB_VALU_PER_PSTEP = 10628740724.8 / (512 * 2048 * 1000.0)   # pf_wg_kernel<4,4,4,false,512>
 C5_VALU_PER_PSTEP = 4216487378.5 / (468.0 * 4096 * 300.0)     # pf_wg_kernel<2,2,4,1,1024,1> (nlg_growth, psi-APF), 50 dispatches of 2340 draws per 5 (profiles/r02_pmc_C5_v2.txt)
 C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1>"
+C4_VALU_PER_PSTEP = 8066112.5 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r02_pmc_C4_v2.txt)
 
 
 def valu_roofline(valu_per_pstep, psteps_per_s, kernel):
@@ -291,6 +292,8 @@ def main():
     ap.add_argument("--no-post-correct", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--reference-weights-layout", action="store_true",
+                    help="keep the weights output as exp(w - max_t) (what the drop-in entry points return) instead of the factored layout")
     ap.add_argument("--no-mng", action="store_true")
     ap.add_argument("--pc-draws", type=int, default=2340, help="retained draws of the post_correct job (C5: 2340)")
     args = ap.parse_args()
@@ -344,7 +347,11 @@ def main():
     N, T, m = args.particles, args.T, 4
     model = negbin_m4(T, seed=103)
     R = args.replicas
-    plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R)
+    # weights kept in the library's factored layout (opt-in for device-resident callers, include/bssm_amd.h
+    # BSSM_PLAN_FACTORED_WEIGHTS: block-scaled weight x one factor per (time point, particle block); bssm_plan_fetch multiplies
+    # it out); --reference-weights-layout times the reference's exp(w - max_t) layout instead
+    fw = not args.reference_weights_layout
+    plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R, factored_weights=fw)
     info = plan.info()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -368,6 +375,7 @@ def main():
         elapsed = float(tt.item())
     ll = plan.loglik(stream)
     assert np.all(np.isfinite(ll)), ll
+    layout = plan.weights_layout()
 
     psteps_per_pass = float(N) * T * R
     value = world * psteps_per_pass * args.steps / elapsed
@@ -381,7 +389,9 @@ def main():
         "config": {"workload": "C2-m4: ssm_ung negative binomial, m=k=4, T=%d, N=%d, full-output bootstrap filter "
                                "(alpha, indices, weights kept in HBM); one step = %d independent filter calls "
                                "(different Philox streams) advanced together; --gpus N = the same batch on each GPU" % (T, N, R),
-                   "filters_in_flight": R, "kernel_shape": info["path"], "blocks_per_launch": info["blocks"],
+                   "filters_in_flight": R, "weights_layout": ("factored: exp(w - max_block) written once + exp(max_block - max_t) per (t, block of %d)"
+                                                               % layout["block_particles"]) if layout["factored"] else "reference: exp(w - max_t)",
+                   "kernel_shape": info["path"], "blocks_per_launch": info["blocks"],
                    "threads": info["threads"], "launches_per_step": T + 3, "parallelism": "replicas only x%d" % world},
     }
 
@@ -447,10 +457,15 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_regime_b and not args.no_mng:
         # ---- BASELINE configs[3]: ssm_mng m = 8, p = 4, T = 2000, N = 16384 -- the fp64-MFMA transition path
-        # (pf_grid_step_v2<8,8,.,true>), 32 filters in flight, full output; 16 m + 24 = 152 algorithmic bytes per particle-step
+        # (pf_grid_step_v2<8,8,2,true,...>), full output; 16 m + 24 = 152 algorithmic bytes per particle-step.  64 filters in
+        # flight: a 16 384-particle filter is 32 workgroups at two particles per lane, and the step kernels of this shape reach
+        # their steady rate from ~48 filters on (profiles/r03_c4_fill.txt: 32 -> 0.42, 48 -> 0.51, 64 -> 0.52, 80 -> 0.52 of
+        # 8 TB/s); 160 GB of outputs stay resident, so the cached blocks of the earlier legs go back to the driver first
+        from bssm_amd import _lib as _L
         from models_zoo import mng_c4
-        nm, fm, Tm = 16384, 32, 2000  # (32 filters: 80 GB of outputs, within the arena the headline batch leaves behind)
-        pm = FilterPlan(mng_c4(Tm), nm, method="bsf", keep_history=True, force="grid", n_rep=fm)
+        _L.lib().bssm_amd_trim_cache()
+        nm, fm, Tm = 16384, 64, 2000
+        pm = FilterPlan(mng_c4(Tm), nm, method="bsf", keep_history=True, force="grid", n_rep=fm, factored_weights=fw)
         pm.run(5, hip_stream=stream); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for s in range(2):
@@ -461,8 +476,11 @@ def main():
         out["mng_c4"] = {"workload": "ssm_mng m=8 k=8 p=4 (poisson, poisson, negbin, gaussian), T=%d, N=%d, bootstrap filter, full output, "
                                      "%d filters in flight" % (Tm, nm, fm),
                          "value": psm / em, "unit": "particle-steps/s", "ms_per_pass": em * 1e3, "kernel": pm.last_kernel(),
-                         "algorithmic_GBs": psm * 152 / em / 1e9, "frac_of_8TBs": psm * 152 / em / 8e12}
+                         "weights_layout_factored": pm.weights_layout()["factored"], "launch_sequences": pm.launch_sequences(),
+                         "algorithmic_GBs": psm * 152 / em / 1e9, "frac_of_8TBs": psm * 152 / em / 8e12,
+                         "roofline_valu": valu_roofline(C4_VALU_PER_PSTEP, psm / em, "pf_grid_step_v2<8,8,2,true,true,true>")}
         pm.close()
+        _L.lib().bssm_amd_trim_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only: the other ranks would idle behind it
         # ---- CPU baseline: the oracle (reference loop structure, one thread per filter) on a bounded sample
@@ -488,7 +506,7 @@ def main():
         from bssm_amd import models as M
         from oracle import oracle as O
         arr = M.model_arrays(model)
-        pa = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R)
+        pa = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R, factored_weights=fw)
         acc_seeds = (20011, 20012)
         slots = sorted(set([0, max(0, R // 2 - 1), R // 2, R - 1]))
         gpu_ll, gpu_w, gpu_ix = {}, {}, {}
@@ -502,7 +520,7 @@ def main():
                 w = got["weights"][:T]
                 wn = w / w.sum(axis=1, keepdims=True)
                 gpu_w[(sd, f)] = np.einsum("tmn,tn->tm", got["alpha"][:T], wn)  # weighted filtered state means, T x m
-        acc_kernel, acc_seqs = FilterPlan.last_kernel(), pa.launch_sequences()
+        acc_kernel, acc_seqs, acc_layout = FilterPlan.last_kernel(), pa.launch_sequences(), pa.weights_layout()
         pa.close()
 
         def one(key):
@@ -515,19 +533,26 @@ def main():
         keys = sorted(gpu_ll)
         with ThreadPoolExecutor(max_workers=min(len(keys), max(1, (os.cpu_count() or 1) // 2))) as ex:
             refs = list(ex.map(one, keys))
+        # A last-ulp difference in one CDF entry moves one ancestor (about 1e-8 per particle-step at N = 65 536: the CDF of
+        # 65 536 terms carries ~1e-13 of rounding, the strata are 1.5e-5 wide), after which the two sides are different, equally
+        # valid particle systems whose log-likelihoods differ by Monte-Carlo noise of one particle (~1e-6 relative).  Both are
+        # reported: every checked pair, and the pairs whose ancestor tables are identical over all T steps.
         flipped = [list(k) for k, _, _, same in refs if not same]
-        kept = [r for r in refs if r[3]] or refs
-        d = np.asarray([gpu_ll[k] - c for k, c, _, _ in kept])
-        dm = max(float(np.max(np.abs(gpu_w[k] - att) / (1.0 + np.abs(att)))) for k, _, att, _ in kept)
-        out["accuracy"] = {"loglik_rmse_vs_cpu_same_seeds": float(np.sqrt(np.mean(d * d))), "max_abs_diff": float(np.max(np.abs(d))),
-                           "weighted_state_means_max_rel_diff": dm,
-                           "ancestor_tables_identical": len(refs) - len(flipped), "pairs_with_an_ancestor_flip_excluded": flipped,
+        d_all = np.asarray([gpu_ll[k] - c for k, c, _, _ in refs])
+        kept = [r for r in refs if r[3]]
+        d = np.asarray([gpu_ll[k] - c for k, c, _, _ in kept]) if kept else d_all
+        dm = max(float(np.max(np.abs(gpu_w[k] - att) / (1.0 + np.abs(att)))) for k, _, att, _ in (kept or refs))
+        out["accuracy"] = {"loglik_rmse_vs_cpu_same_seeds": float(np.sqrt(np.mean(d_all * d_all))), "max_abs_diff": float(np.max(np.abs(d_all))),
+                           "loglik_rmse_pairs_with_identical_ancestor_tables": float(np.sqrt(np.mean(d * d))) if kept else None,
+                           "weighted_state_means_max_rel_diff_identical_tables": dm,
+                           "ancestor_tables_identical": len(refs) - len(flipped), "pairs_with_an_ancestor_flip": flipped,
                            "device_pairs": len(acc_seeds) * R, "oracle_checked_pairs": len(keys), "checked_slots": slots, "seeds": list(acc_seeds),
-                           "N": N, "T": T, "m": m, "filters_in_flight": R, "kernel": acc_kernel, "launch_sequences": acc_seqs,
+                           "N": N, "T": T, "m": m, "filters_in_flight": R, "kernel": acc_kernel, "launch_sequences": acc_seqs, "weights_layout_factored": acc_layout["factored"],
                            "note": "the timed variant itself: same plan shape, (seed, batch slot) pairs; the oracle re-runs the first and last "
                                    "filter of each launch sequence of both passes (one N x T filter each).  Identical Philox streams on both "
                                    "sides; differences come from libm vs device elementary functions and reduction shape; a last-ulp "
-                                   "ancestor flip (probability ~2e-3 per filter at this size) would show as a difference of Monte-Carlo size"}
+                                   "difference in a CDF entry can move one ancestor (about one per filter at this size), after which the "
+                                   "log-likelihoods differ by one particle's Monte-Carlo noise: both RMSEs are given"}
 
     if rank == 0 and not args.no_dropin:
         # ---- the drop-in boundary as R sees it: host buffers in, host buffers out (PCIe-inclusive; never `value`).

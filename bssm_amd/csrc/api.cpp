@@ -446,7 +446,7 @@ struct DeviceBatch {
     }
     // the reference zero-fills its outputs (src/R_bootstrap_filter.cpp:136-138): only a degenerate filter leaves
     // slots unwritten, so zero just those instead of memset-ing tens of GB per run
-    HIP_TRY(bssm::launch_zero_dead_tail(fb, true, st));
+    HIP_TRY(bssm::launch_zero_dead_tail(fb, true, st, weights_factored ? gws.wscale : nullptr, gws.B));
     return BSSM_OK;
   }
 

@@ -119,7 +119,7 @@ hipError_t launch_to_cube(const double* hist, double* cube, int F, int n1, int m
 
 // zero the output slots a degenerate filter never wrote (the reference hands back zero-filled buffers,
 // src/R_bootstrap_filter.cpp:136-138); a no-op for healthy filters, so outputs need no memset per run
-hipError_t launch_zero_dead_tail(const FilterBatch& b, bool weights_too, hipStream_t stream);
+hipError_t launch_zero_dead_tail(const FilterBatch& b, bool weights_too, hipStream_t stream, double* wscale = nullptr, int B = 0);  // wscale: the factors of a factored weights output [F][n+1][B]
 // exact simulation smoother of a linear-Gaussian model; mats [n][2 m m + m] unpadded, init [m + m m], hist [n+1][m][N]
 hipError_t launch_sim_smoother(const double* mats, const double* init, double* hist, int n, int m, int N, uint32_t seed,
                                hipStream_t stream);

@@ -110,7 +110,7 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
 }
 
 
-__global__ void zero_dead_tail_kernel(const FilterBatch b, const bool weights_too) {
+__global__ void zero_dead_tail_kernel(const FilterBatch b, const bool weights_too, double* __restrict__ wscale, const int B) {
   const int f = blockIdx.y;
   const int da = b.dead_at[f];
   if (da == 0) return;
@@ -127,11 +127,15 @@ __global__ void zero_dead_tail_kernel(const FilterBatch b, const bool weights_to
   if (weights_too && b.weights) {  // columns td+1 .. n
     double* __restrict__ w = b.weights + ((size_t)f * (n + 1) + (td + 1)) * N;
     for (size_t i = i0; i < (size_t)(n - td) * N; i += stride) w[i] = 0.0;
+    if (wscale) {  // factored weights output: the launches behind the dead step wrote factors from poisoned partials
+      double* __restrict__ sc = wscale + ((size_t)f * (n + 1) + (td + 1)) * B;
+      for (size_t i = i0; i < (size_t)(n - td) * B; i += stride) sc[i] = 0.0;
+    }
   }
 }
-hipError_t launch_zero_dead_tail(const FilterBatch& b, bool weights_too, hipStream_t stream) {
+hipError_t launch_zero_dead_tail(const FilterBatch& b, bool weights_too, hipStream_t stream, double* wscale, int B) {
   if (!b.alpha_hist && !b.indices && !b.weights) return hipSuccess;
-  hipLaunchKernelGGL(zero_dead_tail_kernel, dim3(256, b.F), dim3(256), 0, stream, b, weights_too);
+  hipLaunchKernelGGL(zero_dead_tail_kernel, dim3(256, b.F), dim3(256), 0, stream, b, weights_too, wscale, B);
   return hipGetLastError();
 }
 

@@ -1944,6 +1944,278 @@ done:
 }
 
 
+/* ================================================================== */
+/* ssm_nlg psi-APF behind function pointers (general m, k; p = 1)      */
+/* ================================================================== */
+orc_nlg_setup *orc_nlg_setup_alloc(int n, int m, int k) {
+  orc_nlg_setup *s = (orc_nlg_setup *)calloc(1, sizeof(orc_nlg_setup));
+  s->n = n; s->m = m; s->k = k;
+  s->Z = (double *)calloc((size_t)m * n, sizeof(double)); s->T = (double *)calloc((size_t)m * m * n, sizeof(double));
+  s->D = (double *)calloc(n, sizeof(double)); s->C = (double *)calloc((size_t)m * n, sizeof(double));
+  s->H = (double *)calloc(n, sizeof(double)); s->R = (double *)calloc((size_t)m * k * n, sizeof(double));
+  s->mode = (double *)calloc((size_t)m * n, sizeof(double)); s->scales = (double *)calloc(n, sizeof(double));
+  s->alphahat = (double *)calloc((size_t)m * (n + 1), sizeof(double));
+  s->Vt = (double *)calloc((size_t)m * m * (n + 1), sizeof(double)); s->Ct = (double *)calloc((size_t)m * m * (n + 1), sizeof(double));
+  return s;
+}
+void orc_nlg_setup_free(orc_nlg_setup *s) {
+  if (!s) return;
+  free(s->Z); free(s->T); free(s->D); free(s->C); free(s->H); free(s->R); free(s->mode); free(s->scales);
+  free(s->alphahat); free(s->Vt); free(s->Ct); free(s);
+}
+#define GEN_CALL(fn_, t_, a_, out_) mod->fn_((t_), (a_), mod->base.theta, mod->base.known, (out_))
+
+/* ekf with iekf_iter = 0 (:284-381), one observation series; returns 0 when the innovation variance fails the checks */
+static int gen_ekf(const orc_nlg_general_psi *mod, double *at, double *att, double *Pt, double *Ptt, double *loglik) {
+  const orc_nlg_general *b = &mod->base;
+  const int n = b->n, m = b->m, k = b->k, mm = m * m;
+  double ll = 0.0;
+  memcpy(at, b->a1, sizeof(double) * m);
+  memcpy(Pt, b->P1, sizeof(double) * mm);
+  for (int t = 0; t < n; t++) {
+    const double *a = at + (size_t)m * t, *P = Pt + (size_t)mm * t;
+    double *af = att + (size_t)m * t, *Pf = Ptt + (size_t)mm * t;
+    if (isfinite(b->y[t])) {
+      double Zg[ORC_MAXM], PZ[ORC_MAXM], K[ORC_MAXM], h, z;
+      GEN_CALL(Z_gn, t, a, Zg); b->H_fn(t, a, b->theta, b->known, &h);
+      double F = h * h;
+      for (int i = 0; i < m; i++) { PZ[i] = 0; for (int j = 0; j < m; j++) PZ[i] += P[i + m * j] * Zg[j]; }
+      for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
+      if (!isfinite(F) || !(F > 0)) return 0;
+      const double cF = sqrt(F);
+      b->Z_fn(t, a, b->theta, b->known, &z);
+      const double v = b->y[t] - z;
+      for (int i = 0; i < m; i++) { K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF); af[i] = a[i] + K[i] * v; }
+      double IKZ[ORC_MAXM * ORC_MAXM], tmp[ORC_MAXM * ORC_MAXM], tmp2[ORC_MAXM * ORC_MAXM];
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
+      mat_mul(IKZ, P, m, m, m, tmp); mat_mul_bt(tmp, IKZ, m, m, m, tmp2);
+      for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pf[i + m * j] = tmp2[i + m * j] + K[i] * h * h * K[j];
+      ll -= 0.5 * (log(2.0 * ORC_PI) + 2.0 * log(cF) + (v / cF) * (v / cF));
+    } else { memcpy(af, a, sizeof(double) * m); memcpy(Pf, P, sizeof(double) * mm); }
+    double Tg[ORC_MAXM * ORC_MAXM], Rt[ORC_MAXM * ORC_MAXM], RR[ORC_MAXM * ORC_MAXM], tmp[ORC_MAXM * ORC_MAXM], tmp2[ORC_MAXM * ORC_MAXM];
+    b->T_fn(t, af, b->theta, b->known, at + (size_t)m * (t + 1));
+    GEN_CALL(T_gn, t, af, Tg); b->R_fn(t, af, b->theta, b->known, Rt);
+    compute_RR(Rt, m, k, RR);
+    mat_mul(Tg, Pf, m, m, m, tmp); mat_mul_bt(tmp, Tg, m, m, m, tmp2);
+    for (int q = 0; q < mm; q++) Pt[q + (size_t)mm * (t + 1)] = tmp2[q] + RR[q];
+  }
+  if (loglik) *loglik = ll;
+  return 1;
+}
+double orc_nlg_general_ekf_loglik(const orc_nlg_general_psi *mod) {
+  const int n = mod->base.n, m = mod->base.m;
+  double *at = (double *)calloc((size_t)m * (n + 1), sizeof(double)), *att = (double *)calloc((size_t)m * n, sizeof(double));
+  double *Pt = (double *)calloc((size_t)m * m * (n + 1), sizeof(double)), *Ptt = (double *)calloc((size_t)m * m * n, sizeof(double));
+  double ll = 0.0;
+  if (!gen_ekf(mod, at, att, Pt, Ptt, &ll)) ll = -INFINITY;
+  free(at); free(att); free(Pt); free(Ptt);
+  return ll;
+}
+/* the approximating model's operands from the points where the reference linearises: Z, H at zpts, T, R at tpts */
+static void gen_linearise(const orc_nlg_general_psi *mod, const double *zpts, const double *tpts, orc_nlg_setup *su) {
+  const orc_nlg_general *b = &mod->base;
+  const int n = b->n, m = b->m, k = b->k;
+  for (int t = 0; t < n; t++) {
+    const double *zp = zpts + (size_t)m * t, *tp = tpts + (size_t)m * t;
+    double *Zt = su->Z + (size_t)m * t, *Tt = su->T + (size_t)m * m * t, Tf[ORC_MAXM], z;
+    GEN_CALL(Z_gn, t, zp, Zt); GEN_CALL(T_gn, t, tp, Tt);
+    b->Z_fn(t, zp, b->theta, b->known, &z);
+    su->D[t] = z - dotv(Zt, zp, m);
+    b->T_fn(t, tp, b->theta, b->known, Tf);
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += Tt[i + m * j] * tp[j]; su->C[i + (size_t)m * t] = Tf[i] - s; }
+    b->H_fn(t, zp, b->theta, b->known, &su->H[t]);
+    b->R_fn(t, tp, b->theta, b->known, su->R + (size_t)m * k * t);
+  }
+}
+static void gen_approx_ulg(const orc_nlg_general_psi *mod, const orc_nlg_setup *su, double *xb, orc_ulg_model *g) {
+  const orc_nlg_general *b = &mod->base;
+  memset(xb, 0, sizeof(double) * b->n);
+  g->n = b->n; g->m = b->m; g->k = b->k;
+  g->Ztv = 1; g->Ttv = 1; g->Rtv = 1; g->Dtv = 1; g->Ctv = 1; g->Htv = 1;
+  g->y = b->y; g->Z = su->Z; g->T = su->T; g->R = su->R; g->a1 = b->a1; g->P1 = b->P1; g->D = su->D; g->C = su->C; g->xbeta = xb; g->H = su->H;
+}
+/* :1295-1319 */
+static double gen_log_signal_pdf(const orc_nlg_general_psi *mod, const double *al) {
+  const orc_nlg_general *b = &mod->base;
+  const int n = b->n, m = b->m, k = b->k;
+  double z, h, mean[ORC_MAXM], Rt[ORC_MAXM * ORC_MAXM], RR[ORC_MAXM * ORC_MAXM];
+  double ll = dmvnorm_cov(al, b->a1, b->P1, m);
+  if (isfinite(b->y[0])) { b->Z_fn(0, al, b->theta, b->known, &z); b->H_fn(0, al, b->theta, b->known, &h); ll += dnorm_sd(b->y[0], z, h); }
+  for (int t = 0; t < n - 1; t++) {
+    const double *a0 = al + (size_t)m * t, *a1 = al + (size_t)m * (t + 1);
+    b->T_fn(t, a0, b->theta, b->known, mean); b->R_fn(t, a0, b->theta, b->known, Rt);
+    compute_RR(Rt, m, k, RR);
+    ll += dmvnorm_cov(a1, mean, RR, m);
+    if (isfinite(b->y[t + 1])) { b->Z_fn(t + 1, a1, b->theta, b->known, &z); b->H_fn(t + 1, a1, b->theta, b->known, &h); ll += dnorm_sd(b->y[t + 1], z, h); }
+  }
+  return ll;
+}
+/* update_scales :854-879 */
+static void gen_update_scales(const orc_nlg_general_psi *mod, orc_nlg_setup *su) {
+  const orc_nlg_general *b = &mod->base;
+  const int n = b->n, m = b->m, k = b->k, mm = m * m;
+  for (int t = 0; t < n; t++) {
+    su->scales[t] = 0.0;
+    const double *md = su->mode + (size_t)m * t;
+    if (isfinite(b->y[t])) {
+      double z, h, am = su->D[t] + dotv(su->Z + (size_t)m * t, md, m), HH = su->H[t] * su->H[t];
+      b->Z_fn(t, md, b->theta, b->known, &z); b->H_fn(t, md, b->theta, b->known, &h);
+      su->scales[t] = dnorm_sd(b->y[t], z, h) - dmvnorm_cov(&b->y[t], &am, &HH, 1);
+    }
+  }
+  for (int t = 1; t < n; t++) {
+    const double *mp = su->mode + (size_t)m * (t - 1), *md = su->mode + (size_t)m * t;
+    double mean[ORC_MAXM], amean[ORC_MAXM], Rt[ORC_MAXM * ORC_MAXM], RR[ORC_MAXM * ORC_MAXM], RRa[ORC_MAXM * ORC_MAXM];
+    b->T_fn(t - 1, mp, b->theta, b->known, mean); b->R_fn(t - 1, mp, b->theta, b->known, Rt);
+    compute_RR(Rt, m, k, RR);
+    compute_RR(su->R + (size_t)m * k * (t - 1), m, k, RRa);
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += su->T[i + m * j + (size_t)mm * (t - 1)] * mp[j]; amean[i] = su->C[i + (size_t)m * (t - 1)] + s; }
+    su->scales[t] += dmvnorm_cov(md, mean, RR, m) - dmvnorm_cov(md, amean, RRa, m);
+  }
+}
+int orc_nlg_general_psi_setup(const orc_nlg_general_psi *mod, const double *is_mode, int max_iter, double conv_tol, orc_nlg_setup *su) {
+  const orc_nlg_general *b = &mod->base;
+  const int n = b->n, m = b->m, mm = m * m;
+  double *xb = (double *)calloc(n, sizeof(double));
+  orc_ulg_model g;
+  su->ok = 1; su->iters = 0;
+  if (is_mode) { /* approximate_for_is :146-176 */
+    memcpy(su->mode, is_mode, sizeof(double) * m * n);
+    gen_linearise(mod, su->mode, su->mode, su);
+    gen_approx_ulg(mod, su, xb, &g);
+  } else {
+    double *at = (double *)calloc((size_t)m * (n + 1), sizeof(double)), *att = (double *)calloc((size_t)m * n, sizeof(double));
+    double *Pt = (double *)calloc((size_t)mm * (n + 1), sizeof(double)), *Ptt = (double *)calloc((size_t)mm * n, sizeof(double));
+    double *sm = (double *)calloc((size_t)m * (n + 1), sizeof(double)), *newmode = (double *)calloc((size_t)m * n, sizeof(double));
+    double *oldmode = (double *)calloc((size_t)m * n, sizeof(double));
+    su->ok = gen_ekf(mod, at, att, Pt, Ptt, NULL);
+    if (su->ok) {
+      gen_linearise(mod, at, att, su); /* approximate_by_ekf :179-222: Z, H at a_t; T, R at a_t|t */
+      gen_approx_ulg(mod, su, xb, &g);
+      orc_ulg_fast_smoother(&g, sm);
+      memcpy(su->mode, sm, sizeof(double) * m * n);
+      for (size_t q = 0; q < (size_t)m * n; q++) if (!isfinite(su->mode[q])) su->ok = 0;
+    }
+    if (su->ok && max_iter > 0) {
+      double ll = gen_log_signal_pdf(mod, su->mode), rel = 1.0e300, ad = 1;
+      int i = 0;
+      while (i < max_iter && rel > conv_tol && ad > 1e-4) {
+        i++;
+        gen_linearise(mod, su->mode, su->mode, su);
+        orc_ulg_fast_smoother(&g, sm);
+        memcpy(newmode, sm, sizeof(double) * m * n);
+        double lln = gen_log_signal_pdf(mod, newmode);
+        ad = lln - ll; rel = ad / fabs(ll);
+        int fin = isfinite(lln);
+        for (size_t q = 0; q < (size_t)m * n && fin; q++) if (!isfinite(newmode[q])) fin = 0;
+        if (!fin) { su->ok = 0; break; }
+        if (rel < -conv_tol && i > 1 && ad > 1e-4) { /* :118-138 (unreachable: ad > 1e-4 makes rel positive; kept as written) */
+          int ii = 0; double step = 1.0;
+          memcpy(oldmode, su->mode, sizeof(double) * m * n);
+          while (rel < -conv_tol && ii < 15 && ad > 1e-4) {
+            step /= 2.0;
+            for (size_t q = 0; q < (size_t)m * n; q++) su->mode[q] = (1.0 - step) * oldmode[q] + step * newmode[q];
+            lln = gen_log_signal_pdf(mod, su->mode);
+            ad = lln - ll; rel = ad / fabs(ll); ii++;
+            if (!isfinite(lln)) { su->ok = 0; break; }
+          }
+          if (ii == 15) su->ok = 0;
+          if (!su->ok) break;
+          memcpy(newmode, su->mode, sizeof(double) * m * n);
+        }
+        memcpy(su->mode, newmode, sizeof(double) * m * n);
+        ll = lln;
+      }
+      su->iters = i;
+    }
+    free(at); free(att); free(Pt); free(Ptt); free(sm); free(newmode); free(oldmode);
+  }
+  if (su->ok) {
+    if (is_mode) { /* approximate_for_is leaves approx_state = 2: psi_filter skips its own scales / approx_loglik branch, and the
+                      IS driver has set approx_loglik = 0 (src/approx_mcmc.cpp:372-373); at the linearisation point both density
+                      ratios are exactly one, so the scales are zero */
+      memset(su->scales, 0, sizeof(double) * n);
+      su->approx_loglik = 0.0;
+    } else { /* :974-982 */
+      const double gll = orc_ulg_loglik(&g);
+      gen_update_scales(mod, su);
+      double ssc = 0; for (int t = 0; t < n; t++) ssc += su->scales[t];
+      su->approx_loglik = gll + ssc;
+    }
+    orc_ulg_smoother_ccov(&g, su->alphahat, su->Vt, su->Ct); /* :984-991 */
+    for (size_t q = 0; q < (size_t)mm * (n + 1); q++) if (!isfinite(su->Vt[q]) || !isfinite(su->Ct[q])) su->ok = 0;
+    if (su->ok) orc_conditional_cov(su->Vt, su->Ct, m, n + 1);
+  }
+  free(xb);
+  return su->ok ? 0 : -1;
+}
+/* log_weights :880-935 for one particle (x at time t, aprev its ancestor, used for t > 0) */
+static double gen_psi_log_weight(const orc_nlg_general_psi *mod, const orc_nlg_setup *su, int t, const double *x, const double *aprev) {
+  const orc_nlg_general *b = &mod->base;
+  const int m = b->m, k = b->k, mm = m * m;
+  double w = 0.0;
+  if (isfinite(b->y[t])) {
+    double z, h, am = su->D[t] + dotv(su->Z + (size_t)m * t, x, m), HH = su->H[t] * su->H[t];
+    b->Z_fn(t, x, b->theta, b->known, &z); b->H_fn(t, x, b->theta, b->known, &h);
+    w = dnorm_sd(b->y[t], z, h) - dmvnorm_cov(&b->y[t], &am, &HH, 1);
+  }
+  if (t > 0) {
+    double mean[ORC_MAXM], amean[ORC_MAXM], Rt[ORC_MAXM * ORC_MAXM], RR[ORC_MAXM * ORC_MAXM], RRa[ORC_MAXM * ORC_MAXM];
+    b->T_fn(t - 1, aprev, b->theta, b->known, mean); b->R_fn(t - 1, aprev, b->theta, b->known, Rt);
+    compute_RR(Rt, m, k, RR);
+    compute_RR(su->R + (size_t)m * k * (t - 1), m, k, RRa);
+    for (int i = 0; i < m; i++) { double s = 0; for (int j = 0; j < m; j++) s += su->T[i + m * j + (size_t)mm * (t - 1)] * aprev[j]; amean[i] = su->C[i + (size_t)m * (t - 1)] + s; }
+    w -= dmvnorm_cov(x, amean, RRa, m) - dmvnorm_cov(x, mean, RR, m);
+  }
+  return w;
+}
+double orc_nlg_general_psi_filter(const orc_nlg_general_psi *mod, const orc_nlg_setup *su, unsigned N, const orc_rng *rng,
+                                  double *alpha, double *weights, unsigned *indices) {
+  const orc_nlg_general *b = &mod->base;
+  const int n = b->n, m = b->m, mm = m * m;
+  if (!su->ok) return -INFINITY;
+  double *nw = (double *)malloc(sizeof(double) * N), *lw = (double *)malloc(sizeof(double) * N);
+  double *r = (double *)malloc(sizeof(double) * N), *atmp = (double *)calloc((size_t)N * m, sizeof(double));
+  double um[ORC_MAXM];
+  for (unsigned i = 0; i < N; i++) {
+    rng_normals(rng, 0, 0, i, m, um);
+    for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += su->Vt[j + m * c] * um[c]; A_(j, 0, i) = su->alphahat[j] + s; }
+  }
+  double loglik = su->approx_loglik, inc;
+  if (isfinite(b->y[0])) {
+    for (unsigned i = 0; i < N; i++) lw[i] = gen_psi_log_weight(mod, su, 0, &A_(0, 0, i), atmp) - su->scales[0];
+    if (!normalise_step(lw, N, weights, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+    loglik += inc;
+  } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
+  for (int t = 0; t < n; t++) {
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
+    const double *ah0 = su->alphahat + (size_t)m * t, *ah1 = su->alphahat + (size_t)m * (t + 1);
+    const double *Ct1 = su->Ct + (size_t)mm * (t + 1), *Vt1 = su->Vt + (size_t)mm * (t + 1);
+    for (unsigned i = 0; i < N; i++) {
+      rng_normals(rng, 2, t, i, m, um);
+      for (int j = 0; j < m; j++) {
+        double s = 0, q = 0;
+        for (int c = 0; c < m; c++) s += Ct1[j + m * c] * (atmp[c + (size_t)m * i] - ah0[c]);
+        for (int c = 0; c < m; c++) q += Vt1[j + m * c] * um[c];
+        A_(j, t + 1, i) = ah1[j] + s + q;
+      }
+    }
+    double *wcol = weights + (size_t)N * (t + 1);
+    if ((t < n - 1) && isfinite(b->y[t + 1])) {
+      for (unsigned i = 0; i < N; i++) lw[i] = gen_psi_log_weight(mod, su, t + 1, &A_(0, t + 1, i), atmp + (size_t)m * i) - su->scales[t + 1];
+      if (!normalise_step(lw, N, wcol, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+      loglik += inc;
+    } else for (unsigned i = 0; i < N; i++) { wcol[i] = 1.0; nw[i] = 1.0 / N; }
+  }
+done:
+  free(nw); free(lw); free(r); free(atmp);
+  return loglik;
+}
+#undef GEN_CALL
+
+
 /* ssm_ulg::psi_filter, src/model_ssm_ulg.cpp:644-672: exact draws from the joint smoothing distribution */
 void orc_ulg_psi_filter(const orc_ulg_model *g, unsigned N, const orc_rng *rng, double *alpha) {
   const int n = g->n, m = g->m, mm = m * m;

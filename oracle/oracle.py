@@ -440,6 +440,64 @@ def nlg_general_bsf_filter(y, m, k, theta, known, a1, P1, Z_fn, H_fn, T_fn, R_fn
     return dict(logLik=float(ll), alpha=alpha, weights=weights, indices=indices)
 
 
+class OrcNlgGeneralPsi(C.Structure):
+    _fields_ = [("base", OrcNlgGeneral), ("Z_gn", _NLG_FN), ("T_gn", _NLG_FN)]
+
+
+class OrcNlgSetup(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("k", C.c_int), ("Z", c_double_p), ("T", c_double_p), ("D", c_double_p),
+                ("C", c_double_p), ("H", c_double_p), ("R", c_double_p), ("mode", c_double_p), ("scales", c_double_p),
+                ("approx_loglik", C.c_double), ("alphahat", c_double_p), ("Vt", c_double_p), ("Ct", c_double_p),
+                ("iters", C.c_int), ("ok", C.c_int)]
+
+
+def nlg_general_psi(y, m, k, theta, known, a1, P1, Z_fn, H_fn, T_fn, R_fn, Z_gn, T_gn, nsim: int, seed=1, stream=0, is_mode=None,
+                    max_iter=100, conv_tol=1e-8, filter=True):
+    """ssm_nlg psi-APF (src/model_ssm_nlg.cpp:62-222 set-up, 854-935 scales / weights, 971-1063 filter) for a model given as
+    Python functions of (t, alpha, theta, known) -- the reference's function-pointer interface incl. the Jacobians
+    (src/model_ssm_nlg.h:10-21): Z_fn, H_fn scalars, T_fn m-vector, R_fn m x k, Z_gn m-vector (1 x m), T_gn m x m; H and R
+    may depend on time and state.  Returns the set-up (mode, scales, approx_loglik, alphahat, Vt, Ct, D, Z, T, C) and,
+    with filter=True, logLik / alpha / weights / indices; ekf_loglik is ekf(model)$logLik."""
+    L = lib()
+    L.orc_nlg_general_psi_filter.restype = C.c_double
+    L.orc_nlg_general_ekf_loglik.restype = C.c_double
+    L.orc_nlg_setup_alloc.restype = C.POINTER(OrcNlgSetup)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    n = y.size
+    th = np.ascontiguousarray(theta, dtype=np.float64); kn = np.ascontiguousarray(known if len(known) else [0.0], dtype=np.float64)
+    a1 = np.ascontiguousarray(a1, dtype=np.float64); P1 = np.asfortranarray(np.asarray(P1, dtype=np.float64).reshape(m, m))
+    nth, nkn = th.size, kn.size
+
+    def wrap(fn, shape):
+        cnt = int(np.prod(shape))
+        def cb(t, al, thp, knp, out):
+            v = fn(t, np.ctypeslib.as_array(al, (m,)).copy(), np.ctypeslib.as_array(thp, (nth,)), np.ctypeslib.as_array(knp, (nkn,)))
+            v = np.asarray(v, dtype=float).reshape(shape).reshape(-1, order="F")
+            for q in range(cnt): out[q] = v[q]
+        return _NLG_FN(cb)
+    cbs = [wrap(Z_fn, (1,)), wrap(H_fn, (1,)), wrap(T_fn, (m,)), wrap(R_fn, (m, k))]
+    base = OrcNlgGeneral(n, m, k, _p(y), _p(th), _p(kn), _p(a1), _p(P1), *cbs)
+    g1, g2 = wrap(Z_gn, (m,)), wrap(T_gn, (m, m))
+    s = OrcNlgGeneralPsi(base, g1, g2)
+    su = L.orc_nlg_setup_alloc(n, m, k)
+    mode = None if is_mode is None else np.ascontiguousarray(np.asarray(is_mode, dtype=np.float64).reshape(m, n, order="F").reshape(-1, order="F"))
+    rc = L.orc_nlg_general_psi_setup(C.byref(s), _p(mode), C.c_int(max_iter), C.c_double(conv_tol), su)
+    c = su.contents
+    get = lambda ptr, shape: np.ctypeslib.as_array(ptr, (int(np.prod(shape)),)).copy().reshape(shape, order="F")
+    out = dict(ok=rc == 0, iterations=c.iters, approx_loglik=c.approx_loglik, mode=get(c.mode, (m, n)), scales=get(c.scales, (n,)),
+               alphahat=get(c.alphahat, (m, n + 1)), Vt=get(c.Vt, (m, m, n + 1)), Ct=get(c.Ct, (m, m, n + 1)),
+               D=get(c.D, (n,)), Z=get(c.Z, (m, n)), T=get(c.T, (m, m, n)), C=get(c.C, (m, n)), H=get(c.H, (n,)),
+               ekf_loglik=float(L.orc_nlg_general_ekf_loglik(C.byref(s))))
+    if filter:
+        rng, _ = make_rng(seed, stream)
+        alpha = np.zeros((m, n + 1, nsim), order="F"); weights = np.zeros((nsim, n + 1), order="F")
+        indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+        ll = L.orc_nlg_general_psi_filter(C.byref(s), su, C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights), indices.ctypes.data_as(c_uint_p))
+        out.update(logLik=float(ll), alpha=alpha, weights=weights, indices=indices)
+    L.orc_nlg_setup_free(su)
+    return out
+
+
 class OrcFnSetup(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("Z", c_double_p), ("T", c_double_p), ("D", c_double_p), ("C", c_double_p),
                 ("H", C.c_double), ("R", C.c_double * 4), ("mode", c_double_p), ("scales", c_double_p),

@@ -519,3 +519,54 @@ def test_user_model_three_states_post_correct_with_a_failed_draw(monkeypatch, de
         good = np.delete(np.arange(ns), 4)
         assert np.max(np.abs(out["loglik"][good])) <= 1e-9 * n
         assert np.allclose(out["weights"][good], 1.0, rtol=1e-8)
+
+
+@pytest.mark.parametrize("path,N", [("wg", 700), ("grid", 3000)])
+@pytest.mark.parametrize("which", ["linear3", "nonlin4"])
+def test_user_model_psi_apf_against_the_general_oracle(oracle, monkeypatch, which, path, N):
+    """psi-APF of user-defined models with 3 and 4 states against orc_nlg_general_psi_* -- the restatement of
+    ssm_nlg::psi_filter / log_weights / approximate over function pointers (src/model_ssm_nlg.cpp:62-143, 854-935, 971-1063),
+    itself pinned in tests/test_reference_goldens.py: mode, approximate log-likelihood, ancestors, weights, log-likelihood"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    rng = np.random.default_rng(41)
+    n = 30
+    if which == "linear3":
+        A = np.array([[0.8, 0.1, 0.0], [-0.2, 0.7, 0.1], [0.05, 0.0, 0.9]])
+        z = np.array([1.0, 0.5, -0.3]); rd = np.array([0.3, 0.2, 0.1]); Hs = 0.6; m = 3
+        a1 = np.array([0.2, -0.1, 0.0]); P1 = np.diag([0.5, 0.3, 0.2])
+        y = np.cumsum(rng.normal(0, 0.4, n)); y[7] = np.nan
+        th, kn = A.reshape(-1, order="F")[:8], np.append(z, A[2, 2])
+        u = M.ssm_nlg_user(y, USER_LINEAR3, theta=th, known_params=kn, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=3)
+        Af = lambda th, kn: np.append(th, kn[3]).reshape(3, 3, order="F")
+        fns = dict(Z_fn=lambda t, a, th, kn: kn[:3] @ a, T_fn=lambda t, a, th, kn: Af(th, kn) @ a,
+                   Z_gn=lambda t, a, th, kn: kn[:3], T_gn=lambda t, a, th, kn: Af(th, kn))
+    else:
+        th, kn = np.array([0.7]), []
+        rd = np.array([0.2, 0.15, 0.3, 0.1]); Hs = 0.5; m = 4
+        a1 = np.zeros(4); P1 = np.diag([0.5, 0.2, 0.3, 0.1])
+        a = rng.normal(size=4) * np.sqrt(np.diag(P1)); y = np.zeros(n)
+        for t in range(n):
+            y[t] = a[0] + 0.5 * a[2] + 0.1 * a[0] ** 2 / (1 + a[0] ** 2) + Hs * rng.normal()
+            a = np.array([a[0] + a[1], th[0] * a[1] + 0.3 * np.sin(a[2]), 0.9 * a[2] + 0.2 * a[3], 0.5 * a[3]]) + rd * rng.normal(size=4)
+        y[11] = np.nan
+        u = M.ssm_nlg_user(y, USER_NONLIN4, theta=th, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=4)
+
+        def Tg(t, a, th, kn):
+            J = np.zeros((4, 4))
+            J[0, 0] = 1.0; J[0, 1] = 1.0; J[1, 1] = th[0]; J[1, 2] = 0.3 * np.cos(a[2]); J[2, 2] = 0.9; J[2, 3] = 0.2; J[3, 3] = 0.5
+            return J
+        fns = dict(Z_fn=lambda t, a, th, kn: a[0] + 0.5 * a[2] + 0.1 * a[0] * a[0] / (1.0 + a[0] * a[0]),
+                   T_fn=lambda t, a, th, kn: np.array([a[0] + a[1], th[0] * a[1] + 0.3 * np.sin(a[2]), 0.9 * a[2] + 0.2 * a[3], 0.5 * a[3]]),
+                   Z_gn=lambda t, a, th, kn: np.array([1.0 + 0.2 * a[0] / (1.0 + a[0] * a[0]) ** 2, 0.0, 0.5, 0.0]), T_gn=Tg)
+    ref = oracle.nlg_general_psi(y, m, m, th, kn, a1, P1, H_fn=lambda t, a, th, kn: Hs, R_fn=lambda t, a, th, kn: np.diag(rd), nsim=N, seed=3, **fns)
+    assert ref["ok"]
+    su = F.psi_setup(u)
+    assert np.allclose(np.asarray(su["mode"]).reshape(m, n, order="F"), ref["mode"], rtol=0, atol=1e-9)
+    assert abs(su["approx_loglik"] - ref["approx_loglik"]) <= 1e-9 * n
+    out = F.particle_smoother(u, N, method="psi", seed=3, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
+    mean, cov = oracle.summary(sm)
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8

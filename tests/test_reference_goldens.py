@@ -62,6 +62,57 @@ def test_ekf_loglik_equals_reference_test_value(oracle):
     assert oracle.fn_ekf_loglik(model, 1) == oracle.fn_ekf_loglik(model, 2)
 
 
+def _growth_callbacks():
+    """the growth model of R/cpp_example_models.R:336-511 as plain functions of (t, alpha, theta, known_params)"""
+    def T(t, a, th, kn):
+        dT, K = kn[0], kn[1]
+        r = np.exp(a[0]) / (1 + np.exp(a[0]))
+        return np.array([a[0], K * a[1] * np.exp(r * dT) / (K + a[1] * (np.exp(r * dT) - 1))])
+
+    def Tg(t, a, th, kn):
+        dT, K = kn[0], kn[1]
+        r = np.exp(a[0]) / (1 + np.exp(a[0]))
+        tmp = np.exp(r * dT) / (K + a[1] * (np.exp(r * dT) - 1)) ** 2
+        return np.array([[1.0, 0.0], [dT * K * a[1] * (K - a[1]) * tmp * r / (1 + np.exp(a[0])), K * K * tmp]])
+    return dict(Z_fn=lambda t, a, th, kn: a[1], H_fn=lambda t, a, th, kn: np.exp(th[0]), T_fn=T,
+                R_fn=lambda t, a, th, kn: np.diag([np.exp(th[1]), np.exp(th[2])]), Z_gn=lambda t, a, th, kn: np.array([0.0, 1.0]), T_gn=Tg)
+
+
+def test_general_callback_psi_oracle_is_pinned(oracle):
+    """orc_nlg_general_psi_* (the psi-APF of ssm_nlg over function pointers, what the 3- / 4-state user-model tests are
+    checked against) is pinned twice: (1) its EKF reproduces the log-likelihood the reference's own test states for
+    nlg_sin_exp (test_ekpf.R:43-64); (2) on the shipped growth model -- mode search from the EKF start, scales, approximate
+    log-likelihood, smoother, conditional factors, weights with the transition-density ratio at the ancestor -- it agrees
+    with the functor restatement orc_fn_psi_*, which the same reference values and the published study pin."""
+    g = V["nlg_sin_exp"]
+    y = np.array(g["y"]); y[1:3] = np.nan
+    th = np.asarray(g["theta"], dtype=float)
+    r = oracle.nlg_general_psi(y, 1, 1, th, [], [0.0], [[1.0]], lambda t, a, th, kn: np.exp(a[0]), lambda t, a, th, kn: np.exp(th[0]),
+                               lambda t, a, th, kn: np.sin(a), lambda t, a, th, kn: np.array([[np.exp(th[1])]]),
+                               lambda t, a, th, kn: np.exp(a), lambda t, a, th, kn: np.array([[np.cos(a[0])]]), 16, filter=False)
+    assert abs(r["ekf_loglik"] - g["expected_ekf_loglik_with_y2_y3_missing"]) <= 1.5e-8 * 2.65
+    rng = np.random.default_rng(3)
+    n = 40
+    y = 50 + np.cumsum(rng.normal(0.5, 1, n)); y[7] = np.nan
+    th = np.array([0.0, np.log(0.05), 0.0]); kn = np.array([0.1, 500.0, 0.0, 50.0, 1.0, 100.0])
+    model = M.ssm_nlg(y, "nlg_growth", theta=th, known_params=kn)
+    su = oracle.fn_psi_setup(model)
+    ref = oracle.fn_psi_filter(model, 300, seed=2, setup=su)
+    gen = oracle.nlg_general_psi(y, 2, 2, th, kn, [kn[2], kn[3]], np.diag([kn[4], kn[5]]), nsim=300, seed=2, **_growth_callbacks())
+    assert gen["ok"] and abs(gen["approx_loglik"] - su["approx_loglik"]) <= 1e-12 * abs(su["approx_loglik"])
+    assert np.allclose(gen["mode"], np.asarray(su["mode"]).reshape(2, n, order="F"), rtol=0, atol=1e-12)
+    assert np.array_equal(gen["indices"], ref["indices"]) and abs(gen["logLik"] - ref["logLik"]) <= 1e-11 * n
+    assert np.allclose(gen["weights"], ref["weights"], rtol=1e-10, atol=1e-14)
+    # approximate_for_is at a stored mode (IS post-correction): same agreement
+    mode = np.asarray(su["mode"]).reshape(-1, order="F") + 0.01
+    su2 = oracle.fn_psi_setup(model, is_mode=mode)
+    ref2 = oracle.fn_psi_filter(model, 200, seed=5, setup=su2)
+    gen2 = oracle.nlg_general_psi(y, 2, 2, th, kn, [kn[2], kn[3]], np.diag([kn[4], kn[5]]), nsim=200, seed=5, is_mode=mode, **_growth_callbacks())
+    assert np.array_equal(gen2["indices"], ref2["indices"]) and abs(gen2["logLik"] - ref2["logLik"]) <= 1e-11 * n
+    assert gen2["approx_loglik"] == 0.0 and np.all(gen2["scales"] == 0.0)  # the IS driver's state (src/approx_mcmc.cpp:372-373)
+    assert np.allclose(gen2["weights"], ref2["weights"], rtol=1e-10, atol=1e-14)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["psi", "bsf"])
 @pytest.mark.parametrize("N", [1000, 50000])
