@@ -845,7 +845,10 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   // kFuse (rows of several series at four particles per lane): a particle's log-weight is evaluated right behind its
   // transition, its state never outlives the iteration, and the ancestor rows are requested two at a time
   constexpr bool kFuse = MS && PPT >= 4;
-  constexpr int ROLL = kFuse ? 2 : ((BSSM_V2_ROLL) < PPT ? (BSSM_V2_ROLL) : PPT);
+#ifndef BSSM_V2_FUSE_ROLL
+#define BSSM_V2_FUSE_ROLL 2
+#endif
+  constexpr int ROLL = kFuse ? (BSSM_V2_FUSE_ROLL) : ((BSSM_V2_ROLL) < PPT ? (BSSM_V2_ROLL) : PPT);
   double a[ROLL][MP];
 #pragma unroll
   for (int r = 0; r < PPT; r++) {

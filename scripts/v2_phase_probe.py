@@ -14,10 +14,16 @@ from bssm_amd import _lib
 from bssm_amd.plan import FilterPlan
 from models_zoo import negbin_m4
 
-R = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
-T = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
-plan = FilterPlan(negbin_m4(T, seed=103), N, method="bsf", keep_history=True, force="grid", n_rep=R)
+c4 = "--c4" in sys.argv  # configuration C4 instead: ssm_mng m = 8, p = 4, N = 16 384, T = 2000, 64 filters in flight
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+R = int(args[0]) if len(args) > 0 else (64 if c4 else 32)
+N = int(args[1]) if len(args) > 1 else (16384 if c4 else 65536)
+T = int(args[2]) if len(args) > 2 else (2000 if c4 else 1000)
+if c4:
+    from models_zoo import mng_c4
+    plan = FilterPlan(mng_c4(T), N, method="bsf", keep_history=True, force="grid", n_rep=R)
+else:
+    plan = FilterPlan(negbin_m4(T, seed=103), N, method="bsf", keep_history=True, force="grid", n_rep=R)
 plan.run(1)
 L = _lib.lib()
 L.bssm_plan_debug_timeline.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
