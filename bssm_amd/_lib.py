@@ -32,7 +32,7 @@ class FnModel(C.Structure):
                 ("L", C.c_int32), ("user_slot", C.c_int32), ("n_states", C.c_int32), ("H", C.c_double),
                 ("R_diag", C.c_double * 2), ("a1", C.c_double * 2), ("P1", C.c_double * 4),
                 ("use_ext", C.c_int32), ("n_etas", C.c_int32), ("R_ext", C.c_double * 16), ("a1_ext", C.c_double * 4),
-                ("P1_ext", C.c_double * 16)]
+                ("P1_ext", C.c_double * 16), ("known_tv_params", c_double_p), ("tv_rows", C.c_int32), ("tv_cols", C.c_int32)]
 
 
 def pack_fn_model(model, L=None):
@@ -49,7 +49,13 @@ def pack_fn_model(model, L=None):
         s.n_states = int(model.get("n_states", 1))
         if s.model_id == 7:
             fill_user_numbers(s, model, th)
-    return s, [y, th, kp]
+    keep = [y, th, kp]
+    tv = model.get("known_tv_params")
+    if tv is not None and np.size(tv):  # the reference's known_tv_params matrix (snippets with BSSM_USER_TV read it)
+        tv = np.asfortranarray(np.atleast_2d(np.asarray(tv, dtype=np.float64)))
+        s.known_tv_params, s.tv_rows, s.tv_cols = dptr(tv), tv.shape[0], tv.shape[1]
+        keep.append(tv)
+    return s, keep
 
 
 def fill_user_numbers(s, model, theta):

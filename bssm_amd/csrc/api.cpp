@@ -656,6 +656,27 @@ int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
 
 // ---------------------------------------------------------------- built-in non-linear / SDE models
 namespace {
+// known_tv_params of user models (BSSM_USER_TV) in device memory: uploaded once per (device, content) and kept -- the
+// parameter blocks of every filter carry the device address, and a matrix is a few KB
+int device_known_tv(const double* host, int rows, int cols, double** dev) {
+  static std::mutex mu;
+  static std::map<std::pair<int, uint64_t>, double*> cache;
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const size_t cnt = (size_t)rows * cols;
+  uint64_t h = 1469598103934665603ull ^ ((uint64_t)rows << 32 | (uint32_t)cols);
+  for (size_t q = 0; q < cnt; q++) { uint64_t b; std::memcpy(&b, &host[q], 8); h = (h ^ b) * 1099511628211ull; }
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({d, h});
+  if (it == cache.end()) {
+    double* p = nullptr;
+    HIP_TRY(hipMalloc((void**)&p, cnt * sizeof(double)));
+    HIP_TRY(hipMemcpy(p, host, cnt * sizeof(double), hipMemcpyHostToDevice));
+    it = cache.emplace(std::make_pair(d, h), p).first;
+  }
+  *dev = it->second;
+  return BSSM_OK;
+}
 // params_only (may be NULL): stop after the parameter block and hand back a1 (2) and P1 (4) -- what the device set-up needs
 int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector<double>* fpar, int* m_out, int* k_out,
                    double* params_only = nullptr) {
@@ -706,6 +727,43 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   if (id == bssm::FN_USER_NLG) {  // full R, MP x MP column-major, zero-padded (the user-model kernels read this block)
     if (ext) { for (int c = 0; c < mod->n_etas; c++) for (int j = 0; j < m; j++) fp[bssm::FP_RMAT + j + MP * c] = mod->R_ext[j + m * c]; }
     else for (int j = 0; j < m; j++) fp[bssm::FP_RMAT + j + MP * j] = mod->R_diag[j];
+  }
+  if (id == bssm::FN_USER_NLG) {
+    // inverse lower Cholesky factor of R R' on its non-zero diagonal (the psi-APF's transition-density ratio, pf_functors.h);
+    // NaN when R R' is not positive definite there -- only the psi-APF reads it, and its host set-up then fails loudly
+    double RR[16] = {0}, Lc[16] = {0}, Li[16] = {0};
+    const int kk = ext ? mod->n_etas : m;
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) {
+      double acc = 0;
+      for (int q = 0; q < kk; q++) acc += fp[bssm::FP_RMAT + i + MP * q] * fp[bssm::FP_RMAT + j + MP * q];
+      RR[i + 4 * j] = acc;
+    }
+    int nz[4], cnt = 0;
+    for (int j = 0; j < m; j++) if (RR[j + 4 * j] > 2.220446049250313e-16) nz[cnt++] = j;
+    bool pd = true;
+    for (int a = 0; a < cnt && pd; a++)
+      for (int b2 = 0; b2 <= a; b2++) {
+        double v = RR[nz[a] + 4 * nz[b2]];
+        for (int q = 0; q < b2; q++) v -= Lc[a + 4 * q] * Lc[b2 + 4 * q];
+        if (a == b2) { if (!(v > 0)) { pd = false; break; } Lc[a + 4 * a] = std::sqrt(v); }
+        else Lc[a + 4 * b2] = v / Lc[b2 + 4 * b2];
+      }
+    for (int c = 0; c < cnt && pd; c++) {  // forward substitution column by column: Lc Li = I
+      for (int a = c; a < cnt; a++) {
+        double v = a == c ? 1.0 : 0.0;
+        for (int q = c; q < a; q++) v -= Lc[a + 4 * q] * Li[q + 4 * c];
+        Li[a + 4 * c] = v / Lc[a + 4 * a];
+      }
+    }
+    for (int a = 0; a < cnt; a++) for (int c = 0; c <= a; c++)
+      fp[bssm::FP_RLINV + nz[a] + MP * nz[c]] = pd ? Li[a + 4 * c] : std::nan("");
+    if (mod->known_tv_params && mod->tv_rows > 0 && mod->tv_cols > 0 && have_device()) {  // BSSM_USER_TV snippets: matrix on the device
+      double* dtv = nullptr;
+      if (int rc = device_known_tv(mod->known_tv_params, mod->tv_rows, mod->tv_cols, &dtv)) return rc;
+      uint64_t bits = (uint64_t)(uintptr_t)dtv;
+      std::memcpy(&fp[bssm::FP_TVPTR], &bits, sizeof bits);
+      fp[bssm::FP_TVROWS] = mod->tv_rows; fp[bssm::FP_TVCOLS] = mod->tv_cols;
+    }
   }
   fp[bssm::FP_H] = H;
   fp[bssm::FP_LOGC] = -0.5 * (std::log(2.0 * 3.14159265358979323846) + 2.0 * std::log(H));
@@ -780,7 +838,7 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   return BSSM_OK;
 }
 
-// max_states: 4 for the psi-APF (constant diagonal R, diagonal P1), 2 for the EKF particle filter (its device code
+// max_states: 4 for the psi-APF (any constant R with R R' positive definite on its non-zero diagonal, any P1), 2 for the EKF particle filter (its device code
 // factors full 2 x 2 covariances per particle)
 int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states = 4) {
   if (!mod || !mod->y || !mod->theta) return fail(BSSM_ERR_INVALID, "model, y, theta must be non-NULL");
@@ -801,17 +859,25 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states = 4) 
     const double* Rsrc = mod->use_ext ? mod->R_ext : nullptr;
     const double* asrc = mod->use_ext ? mod->a1_ext : mod->a1;
     const double* Psrc = mod->use_ext ? mod->P1_ext : mod->P1;
-    if (mod->use_ext && mod->n_etas != ms)
-      return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: constant diagonal R (n_etas = n_states)");
-    for (int c = 0; c < ms; c++) for (int j = 0; j < ms; j++) {
-      if (j == c) continue;
-      if (Rsrc && Rsrc[j + ms * c] != 0.0) return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: constant diagonal R");
-      if (Psrc[j + ms * c] != 0.0) return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: P1 must be diagonal");
+    const int ks = mod->use_ext ? mod->n_etas : ms;
+    if (max_states == 2) {  // EKF particle filter: its device code factors 2 x 2 covariances built from a diagonal R
+      if (ks != ms) return fail(BSSM_ERR_UNSUPPORTED, "EKF particle filter of a user model: constant diagonal R (n_etas = n_states)");
+      for (int c = 0; c < ms; c++) for (int j = 0; j < ms; j++) {
+        if (j == c) continue;
+        if (Rsrc && Rsrc[j + ms * c] != 0.0) return fail(BSSM_ERR_UNSUPPORTED, "EKF particle filter of a user model: constant diagonal R");
+        if (Psrc[j + ms * c] != 0.0) return fail(BSSM_ERR_UNSUPPORTED, "EKF particle filter of a user model: P1 must be diagonal");
+      }
     }
     f->user = &h;
     f->uH = mod->H;
-    for (int j = 0; j < ms; j++) { f->uR[j] = Rsrc ? Rsrc[j + ms * j] : mod->R_diag[j]; f->ua1[j] = asrc[j]; }
+    for (int q = 0; q < 16; q++) f->uRm[q] = 0.0;
+    if (Rsrc) { for (int c = 0; c < ks; c++) for (int j = 0; j < ms; j++) f->uRm[j + ms * c] = Rsrc[j + ms * c]; }  // m x k, zero columns behind
+    else for (int j = 0; j < ms; j++) f->uRm[j + ms * j] = mod->R_diag[j];
+    for (int j = 0; j < ms; j++) { f->uR[j] = f->uRm[j + ms * j]; f->ua1[j] = asrc[j]; }
     for (int q = 0; q < ms * ms; q++) f->uP1[q] = Psrc[q];
+    f->known_tv = mod->known_tv_params; f->tv_rows = mod->tv_rows; f->tv_cols = mod->tv_cols;
+    if (h.has_tv && (!mod->known_tv_params || mod->tv_rows < 1 || mod->tv_cols < 1))
+      return fail(BSSM_ERR_INVALID, "this user model was compiled with BSSM_USER_TV: known_tv_params (tv_rows x tv_cols) must be given");
   }
   f->y.assign(mod->y, mod->y + mod->n);
   for (int q = 0; q < mod->n_theta; q++) f->theta[q] = mod->theta[q];
@@ -828,6 +894,8 @@ int functor_psi_tables(const bssm_fn_model* mod, const double* is_mode, int max_
   bssm::FilterTables dummy;
   int m = 1, k = 1;
   if ((rc = functor_tables(mod, &dummy, fpar, &m, &k))) return rc;  // fpar block (id, theta, H, R ...)
+  for (int q = 0; q < 16; q++)
+    if (std::isnan((*fpar)[bssm::FP_RLINV + q])) return fail(BSSM_ERR_INVALID, "psi-APF of a user model: R R' must be positive definite on its non-zero diagonal");
   bssm::FnSetup su;
   *ok = bssm::fn_psi_setup(f, is_mode, max_iter, conv_tol, &su);
   *approx_loglik = su.approx_loglik;
@@ -1260,6 +1328,7 @@ int bssm_user_model_load(const char* lib_path) {
   g_user_host[slot].Z = (decltype(bssm::UserHostFns::Z))dlsym(h, "bssm_user_host_Z");
   g_user_host[slot].Tg = (decltype(bssm::UserHostFns::Tg))dlsym(h, "bssm_user_host_Tg");
   g_user_host[slot].Zg = (decltype(bssm::UserHostFns::Zg))dlsym(h, "bssm_user_host_Zg");
+  if (auto has_tv = (int (*)())dlsym(h, "bssm_user_host_has_tv")) g_user_host[slot].has_tv = has_tv();
   g_user_loaded[lib_path] = slot;
   return slot;
 }

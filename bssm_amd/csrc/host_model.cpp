@@ -1115,8 +1115,9 @@ void fnRdiag(const FnModel& f, double* r) {
   switch (f.id) { case 1: r[0] = std::exp(f.theta[1]); r[1] = std::exp(f.theta[2]); break; case 2: r[0] = std::exp(f.theta[2]); break;
                   case 3: r[0] = std::exp(f.theta[1]); break; default: r[0] = 1.0; }
 }
-void fnT(const FnModel& f, const double* a, double* x) {  // T_fn, R/cpp_example_models.R:415-428 etc.
-  if (f.id == 7) { f.user->T(a, f.theta, f.known, x); return; }
+// (t: the time index the reference passes; only user models compiled with BSSM_USER_TV read it, with known_tv_params)
+void fnT(const FnModel& f, const double* a, double* x, int t) {  // T_fn, R/cpp_example_models.R:415-428 etc.
+  if (f.id == 7) { f.user->T(t, f.known_tv, f.tv_rows, f.tv_cols, a, f.theta, f.known, x); return; }
   switch (f.id) {
     case 1: { const double dT = f.known[0], K = f.known[1]; x[0] = a[0]; const double e0 = std::exp(a[0]), r = e0 / (1.0 + e0);
               const double er = std::exp(r * dT);  // (each exponential evaluated once; same values as the snippet's repeated calls)
@@ -1126,8 +1127,8 @@ void fnT(const FnModel& f, const double* a, double* x) {  // T_fn, R/cpp_example
     default: x[0] = a[0];
   }
 }
-void fnTg(const FnModel& f, const double* a, double* Tg) {  // T_gn, :432-450
-  if (f.id == 7) { f.user->Tg(a, f.theta, f.known, Tg); return; }
+void fnTg(const FnModel& f, const double* a, double* Tg, int t) {  // T_gn, :432-450
+  if (f.id == 7) { f.user->Tg(t, f.known_tv, f.tv_rows, f.tv_cols, a, f.theta, f.known, Tg); return; }
   switch (f.id) {
     case 1: { const double dT = f.known[0], K = f.known[1]; const double e0 = std::exp(a[0]), r = e0 / (1 + e0);
               const double er = std::exp(r * dT);
@@ -1138,9 +1139,9 @@ void fnTg(const FnModel& f, const double* a, double* Tg) {  // T_gn, :432-450
     default: Tg[0] = 1.0;
   }
 }
-double fnZ(const FnModel& f, const double* x) { if (f.id == 7) return f.user->Z(x, f.theta, f.known); return f.id == 1 ? x[1] : ((f.id == 2 || f.id == 3) ? std::exp(x[0]) : x[0]); }
-void fnZg(const FnModel& f, const double* a, double* Zg) {
-  if (f.id == 7) { f.user->Zg(a, f.theta, f.known, Zg); return; }
+double fnZ(const FnModel& f, const double* x, int t) { if (f.id == 7) return f.user->Z(t, f.known_tv, f.tv_rows, f.tv_cols, x, f.theta, f.known); return f.id == 1 ? x[1] : ((f.id == 2 || f.id == 3) ? std::exp(x[0]) : x[0]); }
+void fnZg(const FnModel& f, const double* a, double* Zg, int t) {
+  if (f.id == 7) { f.user->Zg(t, f.known_tv, f.tv_rows, f.tv_cols, a, f.theta, f.known, Zg); return; }
   switch (f.id) { case 1: Zg[0] = 0.0; Zg[1] = 1.0; break; case 2: case 3: Zg[0] = std::exp(a[0]); break; default: Zg[0] = 1.0; }
 }
 // dmvnorm(x, mean, cov, lwr = false, logd = true) for a DIAGONAL covariance (all shipped P1 / RR are diagonal)
@@ -1156,22 +1157,61 @@ double dmvnorm_diag(const double* x, const double* mean, const double* var, int 
   return out - 0.5 * cnt * std::log(2.0 * kPi);
 }
 double dnorm_sd(double y, double mean, double sd) { return -0.5 * (std::log(2.0 * kPi) + 2.0 * std::log(sd) + std::pow((y - mean) / sd, 2)); }
+// dmvnorm(x, mean, S, lwr = false, logd = true) for any covariance, d <= 4 (src/dmvnorm.cpp:4-58): the components with a
+// zero diagonal are dropped, the rest goes through the Cholesky factor
+double dmvnorm_cov4(const double* x, const double* mean, const double* S, int d) {
+  int idx[4], cnt = 0;
+  for (int j = 0; j < d; j++) if (S[j + d * j] > kEps) idx[cnt++] = j;
+  double L[16] = {0}, z2[4], out = -0.5 * cnt * std::log(2.0 * kPi);
+  for (int a = 0; a < cnt; a++) {
+    for (int b = 0; b <= a; b++) {
+      double v = S[idx[a] + d * idx[b]];
+      for (int q = 0; q < b; q++) v -= L[a + 4 * q] * L[b + 4 * q];
+      L[a + 4 * b] = a == b ? std::sqrt(v) : v / L[b + 4 * b];
+    }
+    double sacc = x[idx[a]] - mean[idx[a]];
+    for (int b = 0; b < a; b++) sacc -= L[a + 4 * b] * z2[b];
+    z2[a] = sacc / L[a + 4 * a];
+    out += -std::log(L[a + 4 * a]) - 0.5 * z2[a] * z2[a];
+  }
+  return out;
+}
+// the model's constant R as an m x m matrix (shipped models: diagonal) and R R'
+void fnRmat(const FnModel& f, double* Rm) {
+  const int m = f.m;
+  for (int q = 0; q < m * m; q++) Rm[q] = 0.0;
+  if (f.id == 7) { for (int q = 0; q < m * m; q++) Rm[q] = f.uRm[q]; return; }
+  double rd[4]; fnRdiag(f, rd);
+  for (int j = 0; j < m; j++) Rm[j + m * j] = rd[j];
+}
+void fnRR(const FnModel& f, double* RR) {
+  const int m = f.m;
+  double Rm[16]; fnRmat(f, Rm);
+  for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double sacc = 0; for (int q = 0; q < m; q++) sacc += Rm[i + m * q] * Rm[j + m * q]; RR[i + m * j] = sacc; }
+}
+// a user model whose R or P1 has off-diagonal entries: the densities below go through the general routine (the shipped
+// models and diagonal user models keep the diagonal forms they have always used)
+bool fn_full_cov(const FnModel& f) {
+  if (f.id != 7) return false;
+  const int m = f.m;
+  for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) if (j != c && (f.uRm[j + m * c] != 0.0 || f.uP1[j + m * c] != 0.0)) return true;
+  return false;
+}
 
 void fn_linearise(const FnModel& f, const double* zpts, const double* tpts, FnSetup* su) {
   const int n = f.n, m = f.m;
   for (int t = 0; t < n; t++) {
     const double* zp = zpts + (size_t)m * t; const double* tp = tpts + (size_t)m * t;
     double* Zt = su->Z.data() + (size_t)m * t; double* Tt = su->T.data() + (size_t)m * m * t; double Tf[4];
-    fnZg(f, zp, Zt); fnTg(f, tp, Tt);
+    fnZg(f, zp, Zt, t); fnTg(f, tp, Tt, t);
     double za = 0; for (int j = 0; j < m; j++) za += Zt[j] * zp[j];
-    su->D[t] = fnZ(f, zp) - za;
-    fnT(f, tp, Tf);
+    su->D[t] = fnZ(f, zp, t) - za;
+    fnT(f, tp, Tf, t);
     for (int i = 0; i < m; i++) { double sacc = 0; for (int j = 0; j < m; j++) sacc += Tt[i + m * j] * tp[j]; su->C[i + (size_t)m * t] = Tf[i] - sacc; }
   }
   su->H = fnH(f);
-  double rd[4]; fnRdiag(f, rd);
   std::memset(su->R, 0, sizeof(su->R));
-  for (int i = 0; i < m; i++) su->R[i + m * i] = rd[i];
+  fnRmat(f, su->R);
 }
 // the approximating Gaussian model as a HostModel the Kalman routines understand
 void fn_gaussian_model(const FnModel& f, const FnSetup& su, HostModel* g) {
@@ -1186,16 +1226,18 @@ void fn_gaussian_model(const FnModel& f, const FnSetup& su, HostModel* g) {
 }
 double fn_log_signal_pdf(const FnModel& f, const double* al) {  // src/model_ssm_nlg.cpp:1295-1319
   const int n = f.n, m = f.m;
-  double a1[4], P1[16], rd[4], pv[4], rv[4];
+  double a1[4], P1[16], rd[4], pv[4], rv[4], RR[16];
   fn_a1P1(f, a1, P1); fnRdiag(f, rd);
+  const bool full = fn_full_cov(f);
+  if (full) fnRR(f, RR);
   for (int j = 0; j < m; j++) { pv[j] = P1[j + m * j]; rv[j] = rd[j] * rd[j]; }
-  double ll = dmvnorm_diag(al, a1, pv, m);
-  if (std::isfinite(f.y[0])) ll += dnorm_sd(f.y[0], fnZ(f, al), fnH(f));
+  double ll = full ? dmvnorm_cov4(al, a1, P1, m) : dmvnorm_diag(al, a1, pv, m);
+  if (std::isfinite(f.y[0])) ll += dnorm_sd(f.y[0], fnZ(f, al, 0), fnH(f));
   for (int t = 0; t < n - 1; t++) {
     double mean[4];
-    fnT(f, al + (size_t)m * t, mean);
-    ll += dmvnorm_diag(al + (size_t)m * (t + 1), mean, rv, m);
-    if (std::isfinite(f.y[t + 1])) ll += dnorm_sd(f.y[t + 1], fnZ(f, al + (size_t)m * (t + 1)), fnH(f));
+    fnT(f, al + (size_t)m * t, mean, t);
+    ll += full ? dmvnorm_cov4(al + (size_t)m * (t + 1), mean, RR, m) : dmvnorm_diag(al + (size_t)m * (t + 1), mean, rv, m);
+    if (std::isfinite(f.y[t + 1])) ll += dnorm_sd(f.y[t + 1], fnZ(f, al + (size_t)m * (t + 1), t + 1), fnH(f));
   }
   return ll;
 }
@@ -1212,19 +1254,19 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
   const int n = f.n, m = f.m, mm = m * m;
   std::vector<double> Pt((size_t)mm * (n + 1), 0.0), Ptt((size_t)mm * n, 0.0);
   at->assign((size_t)m * (n + 1), 0.0); att->assign((size_t)m * n, 0.0);
-  double rd[4]; const double H = fnH(f);
-  fnRdiag(f, rd);
+  double RRf[16]; const double H = fnH(f);
+  fnRR(f, RRf);  // (diagonal R: exactly diag(r_i * r_i))
   fn_a1P1(f, at->data(), Pt.data());
   for (int t = 0; t < n; t++) {
     const double* a = at->data() + (size_t)m * t; const double* P = Pt.data() + (size_t)mm * t;
     double* af = att->data() + (size_t)m * t; double* Pf = Ptt.data() + (size_t)mm * t;
     if (std::isfinite(f.y[t])) {
       double Zg[4], PZ[4] = {0, 0, 0, 0}, K[4], F = H * H;
-      fnZg(f, a, Zg);
+      fnZg(f, a, Zg, t);
       for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += P[i + m * j] * Zg[j];
       for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
       if (!std::isfinite(F) || !(F > 0)) return false;
-      const double cF = std::sqrt(F), v = f.y[t] - fnZ(f, a);
+      const double cF = std::sqrt(F), v = f.y[t] - fnZ(f, a, t);
       for (int i = 0; i < m; i++) K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF);
       for (int i = 0; i < m; i++) af[i] = a[i] + K[i] * v;
       double IKZ[16], J[16];
@@ -1233,11 +1275,11 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
       for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pf[i + m * j] = J[i + m * j] + K[i] * H * H * K[j];
     } else { std::memcpy(af, a, sizeof(double) * m); std::memcpy(Pf, P, sizeof(double) * mm); }
     double Tg[16];
-    fnT(f, af, at->data() + (size_t)m * (t + 1));
-    fnTg(f, af, Tg);
+    fnT(f, af, at->data() + (size_t)m * (t + 1), t);
+    fnTg(f, af, Tg, t);
     double Pn[16];
     small_abat(m, Tg, Pf, Pn);
-    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = Pn[i + m * j] + (i == j ? rd[i] * rd[i] : 0.0);
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = Pn[i + m * j] + RRf[i + m * j];
   }
   return true;
 }
@@ -1264,12 +1306,12 @@ void fn_ekpf_init(const FnModel& f, double* a1, double* P1, double* att1, double
   const double y = f.y[0];
   if (std::isfinite(y)) {  // ekf_update_step (:1264-1293)
     double Zg[4] = {0, 0, 0, 0}, PZ[4] = {0, 0, 0, 0}, K[4];
-    fnZg(f, a1, Zg);
+    fnZg(f, a1, Zg, 0);
     const double H = fnH(f);
     double F = H * H;
     for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += P1[i + m * j] * Zg[j];
     for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
-    const double cF = std::sqrt(F), v = y - fnZ(f, a1);
+    const double cF = std::sqrt(F), v = y - fnZ(f, a1, 0);
     for (int i = 0; i < m; i++) { K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF); att1[i] = a1[i] + K[i] * v; }
     double IKZ[16], tmp[16];
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
@@ -1350,8 +1392,10 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
       gll = gaussian_loglik(S, ap);
     }
     // update_scales (:854-879)
-    double rd[4], rv[4];
+    double rd[4], rv[4], RRs[16];
     fnRdiag(f, rd);
+    const bool full = fn_full_cov(f);
+    if (full) fnRR(f, RRs);
     for (int j = 0; j < m; j++) rv[j] = rd[j] * rd[j];
     const double HH = su->H * su->H;
     for (int t = 0; t < n; t++) {
@@ -1359,15 +1403,15 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
       if (std::isfinite(f.y[t])) {
         double am = su->D[t];
         for (int j = 0; j < m; j++) am += su->Z[j + (size_t)m * t] * md[j];
-        su->scales[t] = dnorm_sd(f.y[t], fnZ(f, md), fnH(f)) - dmvnorm_diag(&f.y[t], &am, &HH, 1);
+        su->scales[t] = dnorm_sd(f.y[t], fnZ(f, md, t), fnH(f)) - dmvnorm_diag(&f.y[t], &am, &HH, 1);
       }
     }
     for (int t = 1; t < n; t++) {
       const double* mp = su->mode.data() + (size_t)m * (t - 1); const double* md = su->mode.data() + (size_t)m * t;
       double mean[4], amean[4];
-      fnT(f, mp, mean);
+      fnT(f, mp, mean, t - 1);
       for (int i = 0; i < m; i++) { double sacc = 0; for (int j = 0; j < m; j++) sacc += su->T[i + m * j + (size_t)mm * (t - 1)] * mp[j]; amean[i] = su->C[i + (size_t)m * (t - 1)] + sacc; }
-      su->scales[t] += dmvnorm_diag(md, mean, rv, m) - dmvnorm_diag(md, amean, rv, m);
+      su->scales[t] += full ? dmvnorm_cov4(md, mean, RRs, m) - dmvnorm_cov4(md, amean, RRs, m) : dmvnorm_diag(md, mean, rv, m) - dmvnorm_diag(md, amean, rv, m);
     }
     double ssc = 0; for (double v : su->scales) ssc += v;
     su->approx_loglik = gll + ssc;

@@ -113,11 +113,13 @@ void build_psi_tables(const HostModel& hm, const PsiSetup& su, int MP, FilterTab
 // smoother_ccov + conditional_cov), src/model_ssm_nlg.cpp:62-222, 284-381, 854-879, 974-991, 1295-1319
 // host entry points of a run-time compiled user model (exported by its library, user_model_tu.hip): the psi-APF / EKF
 // set-up evaluates T, Z and their Jacobians on the host
+// (t, known_tv_params as a host pointer, its rows and columns) come first: src/model_ssm_nlg.h:10-21
 struct UserHostFns {
-  void (*T)(const double* alpha, const double* theta, const double* known, double* out) = nullptr;
-  double (*Z)(const double* alpha, const double* theta, const double* known) = nullptr;
-  void (*Tg)(const double* alpha, const double* theta, const double* known, double* out) = nullptr;  // m x m column-major
-  void (*Zg)(const double* alpha, const double* theta, const double* known, double* out) = nullptr;  // m
+  void (*T)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known, double* out) = nullptr;
+  double (*Z)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known) = nullptr;
+  void (*Tg)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known, double* out) = nullptr;  // m x m column-major
+  void (*Zg)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known, double* out) = nullptr;  // m
+  int has_tv = 0;  // the snippet was compiled with BSSM_USER_TV
 };
 struct FnModel {
   int id = 0, n = 0, m = 1;
@@ -128,6 +130,9 @@ struct FnModel {
   // user-defined ssm_nlg (id 7): host functions and the state-independent numbers the caller supplied
   const UserHostFns* user = nullptr;
   double uH = 1, uR[4] = {0, 0, 0, 0}, ua1[4] = {0, 0, 0, 0}, uP1[16] = {0};
+  double uRm[16] = {0};  // the full constant R (m x m, column-major, unpadded) of a user model; uR is its diagonal
+  const double* known_tv = nullptr;  // known_tv_params (host), tv_rows x tv_cols column-major: passed to BSSM_USER_TV snippets with t
+  int tv_rows = 0, tv_cols = 0;
 };
 struct FnSetup {
   std::vector<double> Z, T, D, C;   // m x n, m x m x n, n, m x n : the mode-linearised model

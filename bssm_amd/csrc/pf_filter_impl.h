@@ -236,7 +236,7 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
     if constexpr (MP <= 4) {  // psi-APF: up to 4 states (user-defined models; constant diagonal R)
       if (psi == 1) return functor_psi_weight<MP, FID>(fpar, row, amat, t, x, aprev);
     }
-    return functor_log_weight<MP, FID>(fpar, row, x);
+    return functor_log_weight<MP, FID>(fpar, row, x, t);
   } else {
     return log_weight_of<MP>(b, as_uniform_table(row), x);  // wave-uniform row: scalar loads (pf_device.h)
   }

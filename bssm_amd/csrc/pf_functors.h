@@ -35,19 +35,38 @@ __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || i
 // observation density and at the ANCESTOR for the transition, src/model_ssm_nlg.cpp:952, 1125):
 //   BSSM_USER_HFN: double bssm_user_H(const double* alpha, const double* theta, const double* known);   observation sd
 //   BSSM_USER_RFN: void bssm_user_R(alpha, theta, known, double* out /* m x k, column-major */);         R_fn
+//   BSSM_USER_TV:  the reference's time argument and `known_tv_params` matrix (src/model_ssm_nlg.h:10-21: every function is
+//                  called as f(t, alpha, theta, known_params, known_tv_params)).  With this macro defined EVERY bssm_user_*
+//                  function of the snippet takes a leading `const bssm_user_tv& tv` argument: tv.t is the time index the
+//                  reference passes (Z, H at the time of the observation; T, R at the time of the ancestor), tv.known_tv the
+//                  matrix, column-major, tv.rows x tv.cols, exactly as the caller handed it over.
 // The state may have up to 4 components (BSSM_USER_M = 1, 2 or 4 is the padded dimension the kernels are instantiated
 // for; a 3-state model leaves the fourth component alone) and R any m x k matrix, k <= m (bootstrap filter / smoother /
 // bootstrap IS correction; the psi-APF and the EKF particle filter stay limited to 2 states and constant diagonal R).
 // per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser,
 // user slot, number of states, full R (MP x MP, column-major, zero-padded; user models)
 enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, FP_H = 20, FP_R = 21, FP_LOGC = 23, FP_SLOT = 24 /* user-model registry slot (host only) */,
-       FP_M = 25, FP_RMAT = 26, FP_SIZE = 42 };
+       FP_M = 25, FP_RMAT = 26,
+       // user models with BSSM_USER_TV: the known_tv_params matrix (device pointer as a bit pattern; rows, columns), and the
+       // inverse lower factor of R R' for the psi-APF's transition-density ratio with any constant R (MP x MP, column-major)
+       FP_TVPTR = 42, FP_TVROWS = 43, FP_TVCOLS = 44, FP_RLINV = 46, FP_SIZE = 62 };
+
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_TV)
+template <class PF>
+__device__ __forceinline__ bssm_user_tv fn_user_tv(PF fp, int t) {
+  return bssm_user_tv{t, (const double*)(uintptr_t)__double_as_longlong(fp[FP_TVPTR]), (int)fp[FP_TVROWS], (int)fp[FP_TVCOLS]};
+}
+#define BSSM_UTV(fp_, t_) fn_user_tv((fp_), (t_)),
+#else
+#define BSSM_UTV(fp_, t_)
+#endif
 
 // ---- ssm_nlg: alpha_{t+1} = T(alpha_t) + R eta,  y_t ~ N(Z(alpha_t), H^2)   (src/model_ssm_nlg.cpp:1118-1126, 943-956)
+// (t: the time index the reference passes to the model functions; only user models with BSSM_USER_TV read it)
 // (PF / PR / PA: pointer types of the parameter block, the observation row and the approximating rows -- plain pointers, or
 // constant-address-space pointers from as_uniform_table, which turn the loads of these wave-uniform values into s_load)
 template <int MP, class PF>
-__device__ __forceinline__ void nlg_T_fn(int id, PF fp, const double (&a)[MP], double (&x)[MP]) {
+__device__ __forceinline__ void nlg_T_fn(int id, PF fp, const double (&a)[MP], double (&x)[MP], int t = 0) {
   switch (id) {
     case FN_NLG_GROWTH: {  // R/cpp_example_models.R:415-428
       const double dT = fp[FP_KNOWN + 0], K = fp[FP_KNOWN + 1];
@@ -60,16 +79,16 @@ __device__ __forceinline__ void nlg_T_fn(int id, PF fp, const double (&a)[MP], d
     case FN_NLG_AR_EXP: x[0] = fp[FP_THETA + 0] * (1.0 - fp[FP_THETA + 1]) + fp[FP_THETA + 1] * a[0]; break;  // :296-300
     case FN_NLG_SIN_EXP: x[0] = sin(a[0]); break;                                                            // :726-730
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
-    case FN_USER_NLG: bssm_user_T(&a[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN), &x[0]); break;
+    case FN_USER_NLG: bssm_user_T(BSSM_UTV(fp, t) &a[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN), &x[0]); break;
 #endif
     default: x[0] = a[0]; break;                                                                             // linear_gaussian
   }
 }
 template <int MP, class PF>
-__device__ __forceinline__ double nlg_Z_fn(int id, PF fp, const double (&x)[MP]) {
+__device__ __forceinline__ double nlg_Z_fn(int id, PF fp, const double (&x)[MP], int t = 0) {
   switch (id) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
-    case FN_USER_NLG: return bssm_user_Z(&x[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN));
+    case FN_USER_NLG: return bssm_user_Z(BSSM_UTV(fp, t) &x[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN));
 #endif
     case FN_NLG_GROWTH: return MP > 1 ? x[MP > 1 ? 1 : 0] : x[0];  // second state (:393-400)
     case FN_NLG_AR_EXP:
@@ -179,7 +198,7 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
     if (id == FN_USER_NLG) {  // alpha' = T(a) + R(a) eta with any m x k matrix R (src/model_ssm_nlg.cpp:1118-1126)
 #pragma unroll
       for (int j = 0; j < MP; j++) x[j] = 0.0;
-      bssm_user_T(&a[0], fp + FP_THETA, fp + FP_KNOWN, &x[0]);
+      bssm_user_T(BSSM_UTV(fp, (int)t) &a[0], fp + FP_THETA, fp + FP_KNOWN, &x[0]);
       double Rm[MP * MP];
 #pragma unroll
       for (int q = 0; q < MP * MP; q++) Rm[q] = fp[FP_RMAT + q];
@@ -189,7 +208,7 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
         double Ru[MP * MP];
 #pragma unroll
         for (int q = 0; q < MP * MP; q++) Ru[q] = 0.0;
-        bssm_user_R(&a[0], fp + FP_THETA, fp + FP_KNOWN, &Ru[0]);  // m x k, column-major with leading dimension m
+        bssm_user_R(BSSM_UTV(fp, (int)t) &a[0], fp + FP_THETA, fp + FP_KNOWN, &Ru[0]);  // m x k, column-major with leading dimension m
 #pragma unroll
         for (int c = 0; c < MP; c++)
 #pragma unroll
@@ -206,7 +225,7 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
       return;
     }
 #endif
-    nlg_T_fn<MP>(id, fp, a, x);
+    nlg_T_fn<MP>(id, fp, a, x, (int)t);
 #pragma unroll
     for (int j = 0; j < MP; j++) if (j < KP) x[j] += fp[FP_R + j] * z[j];  // R is diagonal in every shipped model
   }
@@ -214,7 +233,7 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
 
 template <int MP, int FID = 0>
 __device__ __forceinline__ double functor_log_weight(const double* __restrict__ fp, const double* __restrict__ row,
-                                                     const double (&x)[MP]) {
+                                                     const double (&x)[MP], int t = 0) {
   if (row[RH_FLAG] == 0.0) return 0.0;
   const double* __restrict__ ob = row + ROW_HDR;
   const int id = FID > 0 ? FID : (int)fp[FP_ID];
@@ -228,12 +247,12 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
   // normalised Gaussian log-density (dmvnorm(..., lwr = true, logd = true), src/dmvnorm.cpp:10-13)
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_HFN)
   if (id == FN_USER_NLG) {  // H_fn at the particle (src/model_ssm_nlg.cpp:950-953)
-    const double h = bssm_user_H(&x[0], fp + FP_THETA, fp + FP_KNOWN);
-    const double q = (y - bssm_user_Z(&x[0], fp + FP_THETA, fp + FP_KNOWN)) / h;
+    const double h = bssm_user_H(BSSM_UTV(fp, t) &x[0], fp + FP_THETA, fp + FP_KNOWN);
+    const double q = (y - bssm_user_Z(BSSM_UTV(fp, t) &x[0], fp + FP_THETA, fp + FP_KNOWN)) / h;
     return -0.9189385332046727 - tl_log(h) - 0.5 * q * q;  // -0.5 log(2 pi) - log h - q^2 / 2
   }
 #endif
-  const double mu = id == FN_SDE_GBM ? tl_log(x[0]) : nlg_Z_fn<MP>(id, fp, x);
+  const double mu = id == FN_SDE_GBM ? tl_log(x[0]) : nlg_Z_fn<MP>(id, fp, x, t);
   const double q = (y - mu) / fp[FP_H];
   return fp[FP_LOGC] - 0.5 * q * q;
 }
@@ -252,7 +271,7 @@ __device__ __forceinline__ double functor_psi_weight(PF fp, PR row, PA amat, int
   {
     const PR ob = row + ROW_HDR;
     const double y = ob[OB_Y], ih = ob[OB_PSIIH];
-    const double q1 = (y - nlg_Z_fn<MP>(id, fp, x)) * ih;
+    const double q1 = (y - nlg_Z_fn<MP>(id, fp, x, t)) * ih;
     double lin = ob[OB_D];
 #pragma unroll
     for (int c = 0; c < MP; c++) lin += ob[SER_HDR + c] * x[c];
@@ -261,23 +280,31 @@ __device__ __forceinline__ double functor_psi_weight(PF fp, PR row, PA amat, int
   }
   if (t > 0) {
     double mean[MP];
-    nlg_T_fn<MP>(id, fp, aprev, mean);
-    if constexpr (MP > 2) {
-      // user-defined models with 3 or 4 states (constant diagonal R in the FP_RMAT block; a 3-state model has one padding
-      // component, which carries no noise and no density term)
-      const int m = (int)fp[FP_M];
+    nlg_T_fn<MP>(id, fp, aprev, mean, t - 1);
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
+    if (id == FN_USER_NLG) {
+      // user-defined models, any constant m x k matrix R: both densities share the covariance R R', so the normalisers cancel
+      // and the ratio is a difference of two quadratic forms in (R R')^-1 = Linv' Linv.  Linv (FP_RLINV, from the host) is
+      // the inverse lower Cholesky factor of R R' on the components with a non-zero diagonal, zero elsewhere: components
+      // without noise carry no density term, as in dmvnorm (src/dmvnorm.cpp:17-21, 40-45)
+      double da[MP], dm[MP];
 #pragma unroll
       for (int j = 0; j < MP; j++) {
-        if (j < m) {
-          double am = amat[MP * MP + j];
+        double am = amat[MP * MP + j];
 #pragma unroll
-          for (int c = 0; c < MP; c++) am += (c < m) ? amat[j + MP * c] * aprev[c] : 0.0;
-          const double ir = fdiv(1.0, fp[FP_RMAT + j + MP * j]);
-          const double da = (x[j] - am) * ir, dm = (x[j] - mean[j]) * ir;
-          w += 0.5 * (da * da - dm * dm);
-        }
+        for (int c = 0; c < MP; c++) am += amat[j + MP * c] * aprev[c];
+        da[j] = x[j] - am; dm[j] = x[j] - mean[j];
       }
-    } else {
+#pragma unroll
+      for (int i = 0; i < MP; i++) {
+        double qa = 0.0, qm = 0.0;
+#pragma unroll
+        for (int j = 0; j <= i; j++) { const double l = fp[FP_RLINV + i + MP * j]; qa += l * da[j]; qm += l * dm[j]; }
+        w += 0.5 * (qa * qa - qm * qm);
+      }
+    } else
+#endif
+    {
 #pragma unroll
     for (int j = 0; j < MP; j++) {
       double am = amat[MP * MP + j];
@@ -298,12 +325,12 @@ __device__ __forceinline__ double functor_psi_weight(PF fp, PR row, PA amat, int
 // T(anc), R R') / N(alpha'; att, Ptt).  The proposal is recomputed from the ancestor when the weight is evaluated
 // (a few dozen flops) instead of being carried between the two places.
 template <int MP>
-__device__ __forceinline__ void nlg_Z_gn(int id, const double* __restrict__ fp, const double (&x)[MP], double (&Zg)[MP]) {
+__device__ __forceinline__ void nlg_Z_gn(int id, const double* __restrict__ fp, const double (&x)[MP], double (&Zg)[MP], int t = 0) {
 #pragma unroll
   for (int c = 0; c < MP; c++) Zg[c] = 0.0;
   switch (id) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_JACOBIANS)
-    case FN_USER_NLG: bssm_user_Zg(&x[0], fp + FP_THETA, fp + FP_KNOWN, &Zg[0]); break;
+    case FN_USER_NLG: bssm_user_Zg(BSSM_UTV(fp, t) &x[0], fp + FP_THETA, fp + FP_KNOWN, &Zg[0]); break;
 #endif
     case FN_NLG_GROWTH: if constexpr (MP > 1) Zg[1] = 1.0; break;
     case FN_NLG_AR_EXP:
@@ -378,9 +405,10 @@ __device__ __forceinline__ double dmvnorm_lwr_small(const double (&x)[MP], const
 // the EKF proposal of one particle: at = T(anc); (att, Lf) = proposal mean and factor for the step to time tn
 template <int MP, int FID = 0>
 __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, const double* __restrict__ row, bool last,
-                                              const double (&anc)[MP], double (&at)[MP], double (&att)[MP], double (&Lf)[MP * MP]) {
+                                              const double (&anc)[MP], double (&at)[MP], double (&att)[MP], double (&Lf)[MP * MP],
+                                              int t = 0 /* time of the ancestor: T at t, Z and its Jacobian at t + 1 */) {
   const int id = FID > 0 ? FID : (int)fp[FP_ID];
-  nlg_T_fn<MP>(id, fp, anc, at);
+  nlg_T_fn<MP>(id, fp, anc, at, t);
   double Pt[MP * MP];
 #pragma unroll
   for (int q = 0; q < MP * MP; q++) Pt[q] = 0.0;
@@ -397,7 +425,7 @@ __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, con
   if (row[RH_FLAG] != 0.0) {  // ekf_update_step (:1264-1293)
     const double y = row[ROW_HDR + OB_Y], H = fp[FP_H];
     double Zg[MP], PZ[MP], K[MP];
-    nlg_Z_gn<MP>(id, fp, at, Zg);
+    nlg_Z_gn<MP>(id, fp, at, Zg, t + 1);
     double F = H * H;
 #pragma unroll
     for (int i = 0; i < MP; i++) {
@@ -408,7 +436,7 @@ __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, con
     }
 #pragma unroll
     for (int j = 0; j < MP; j++) F += Zg[j] * PZ[j];
-    const double icf = 1.0 / sqrt(F), v = y - nlg_Z_fn<MP>(id, fp, at);
+    const double icf = 1.0 / sqrt(F), v = y - nlg_Z_fn<MP>(id, fp, at, t + 1);
 #pragma unroll
     for (int i = 0; i < MP; i++) { K[i] = PZ[i] * icf * icf; att[i] = at[i] + K[i] * v; }
     double IKZ[MP * MP], tmp[MP * MP];
@@ -447,7 +475,7 @@ __device__ __forceinline__ void functor_ekpf_propagate(const double* __restrict_
                                                        RngKey key, const u32x4& blk0, uint32_t t, uint32_t i,
                                                        const double (&anc)[MP], double (&x)[MP]) {
   double at[MP], att[MP], Lf[MP * MP], z[MP];
-  ekpf_proposal<MP, FID>(fp, row_next, last, anc, at, att, Lf);
+  ekpf_proposal<MP, FID>(fp, row_next, last, anc, at, att, Lf, (int)t);
   rng_normals_blk<MP>(blk0, key, RNG_TRANSITION, t, i, z);
 #pragma unroll
   for (int j = 0; j < MP; j++) {
@@ -463,7 +491,7 @@ __device__ __forceinline__ double functor_ekpf_weight(const double* __restrict__
                                                       const double* __restrict__ init, int t, const double (&x)[MP],
                                                       const double (&anc)[MP]) {
   if (row[RH_FLAG] == 0.0) return 0.0;
-  double w = functor_log_weight<MP, FID>(fp, row, x);
+  double w = functor_log_weight<MP, FID>(fp, row, x, t);
   if (t == 0) {
     double a1[MP], P1[MP * MP], att1[MP], L1[MP * MP];
 #pragma unroll
@@ -473,7 +501,7 @@ __device__ __forceinline__ double functor_ekpf_weight(const double* __restrict__
     return w + dmvnorm_cov_small<MP>(x, a1, P1) - dmvnorm_lwr_small<MP>(x, att1, L1);
   }
   double at[MP], att[MP], Lf[MP * MP], RR[MP * MP];
-  ekpf_proposal<MP, FID>(fp, row, false, anc, at, att, Lf);
+  ekpf_proposal<MP, FID>(fp, row, false, anc, at, att, Lf, t - 1);
 #pragma unroll
   for (int q = 0; q < MP * MP; q++) RR[q] = 0.0;
 #pragma unroll

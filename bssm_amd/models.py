@@ -568,14 +568,19 @@ def ssm_sde(y, example: str, theta, x0, positive: bool):
                      positive=bool(positive), a1=np.zeros(1), L=0)
 
 
-def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_params=(), n_states=None, R=None):
+def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_params=(), n_states=None, R=None,
+                 known_tv_params=None):
     """ssm_nlg (R/models.R:1472-1570) with USER functions.  The reference takes pointers to user C++ compiled at run time
     (Z, H, T, R, Z_gn, T_gn, a1, P1); here ``device_code`` is a snippet of ``__device__`` functions compiled by hipcc into
     the filter kernels (contract: bssm_amd/csrc/pf_functors.h -- ``#define BSSM_USER_NLG 1``, ``bssm_user_T``,
     ``bssm_user_Z``), and the state-independent pieces are numbers: H (observation sd), the diagonal of R, a1, P1.
     With the Jacobians in the snippet (``BSSM_USER_JACOBIANS``, ``bssm_user_Tg``, ``bssm_user_Zg``) the psi-APF and the
-    EKF particle filter work as for the built-in models (constant diagonal R, diagonal P1; psi-APF up to 4 states, EKF
-    particle filter 1 or 2).
+    EKF particle filter work as for the built-in models (psi-APF: up to 4 states, any constant matrix ``R`` with R R'
+    positive definite on its non-zero diagonal, any positive semi-definite P1; EKF particle filter: 1 or 2 states,
+    constant diagonal R, diagonal P1).
+    ``known_tv_params``: the reference's matrix of known time-varying values (R/models.R:1507); a snippet that defines
+    ``BSSM_USER_TV`` receives it, with the time index, as the leading ``const bssm_user_tv& tv`` argument of every function
+    (``tv.t``, ``tv.known_tv`` column-major ``tv.rows x tv.cols``).
     The bootstrap filter / smoother also take up to 4 states, any ``R`` (n_states x n_etas matrix, or a function of theta)
     and the reference's state-dependent ``H_fn`` / ``R_fn`` as snippet functions (``BSSM_USER_HFN`` + ``bssm_user_H``,
     ``BSSM_USER_RFN`` + ``bssm_user_R``; src/model_ssm_nlg.h:12-13), which then replace ``H`` / ``R``."""
@@ -596,6 +601,7 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
                      theta=theta, known_params=np.asarray(known_params, dtype=float),
                      n_states=m, n_etas=k, a1=num(a1, -1), P1=num(P1, (m, m)), H=H if callable(H) else float(H),
                      R_diag=None if R_diag is None else num(R_diag, -1), R=None if R is None else num(R, (m, k)),
+                     known_tv_params=None if known_tv_params is None else np.asfortranarray(np.atleast_2d(np.asarray(known_tv_params, dtype=float))),
                      x0=0.0, positive=False, L=0)
 
 

@@ -188,6 +188,11 @@ typedef struct bssm_fn_model {
   double R_ext[16];           /* R_fn's value, n_states x n_etas column-major (the bootstrap kernels call the snippet's
                                  bssm_user_R instead when it defines BSSM_USER_RFN) */
   double a1_ext[4], P1_ext[16]; /* a1_fn, P1_fn values; P1 any positive semi-definite n_states x n_states matrix */
+  /* ---- the reference's `known_tv_params` (R/models.R:1507, 1546; every model function receives it together with the
+   * time index, src/model_ssm_nlg.h:10-21): any matrix, column-major, tv_rows x tv_cols.  Read by user models whose
+   * snippet defines BSSM_USER_TV (its functions then take a leading `const bssm_user_tv&`); NULL / 0 / 0 otherwise */
+  const double* known_tv_params;
+  int32_t tv_rows, tv_cols;
 } bssm_fn_model;
 
 /* User-defined ssm_nlg / ssm_sde models.  The reference compiles the user's C++ at run time (Rcpp::sourceCpp) and
@@ -198,8 +203,10 @@ typedef struct bssm_fn_model {
  * bssm_user_model_load maps it and returns a slot >= 1 for bssm_fn_model.user_slot (negative = error).
  * Built for user models: every single-model entry point of the built-in models -- bootstrap, psi-APF (bssm_psi_smoother_nlg,
  * bssm_fn_psi_setup) and EKF particle filter (bssm_ekpf_*) with their smoothers and bssm_fn_loglik_batch; the psi-APF and
- * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS), a diagonal P1 and a constant diagonal R (R_diag, or
- * a diagonal R_ext with n_etas = n_states); the psi-APF takes up to 4 states, the EKF particle filter at most 2.  The bootstrap filter / smoother / bootstrap IS correction take up to 4 states, any n_states x n_etas matrix
+ * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS).  The psi-APF takes up to 4 states, any constant
+ * n_states x n_etas matrix R whose R R' is positive definite on its non-zero diagonal, and any positive semi-definite P1
+ * (round 3); the EKF particle filter at most 2 states with a diagonal P1 and a constant diagonal R.  Snippets that define
+ * BSSM_USER_TV receive the time index and known_tv_params in every function.  The bootstrap filter / smoother / bootstrap IS correction take up to 4 states, any n_states x n_etas matrix
  * R and the reference's state-dependent H_fn / R_fn (snippet functions bssm_user_H / bssm_user_R).  IS post-correction
  * (bssm_is_correction_nlg / _multi) and the chains (bssm_run_mcmc_fn; theta-dependent H / R / a1 / P1 through
  * bssm_mcmc_job.fn_update_fn) work for user models too. */

@@ -570,3 +570,84 @@ def test_user_model_psi_apf_against_the_general_oracle(oracle, monkeypatch, whic
     sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
     mean, cov = oracle.summary(sm)
     assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8
+
+
+USER_TV3 = r"""
+#define BSSM_USER_NLG 1
+#define BSSM_USER_JACOBIANS 1
+#define BSSM_USER_TV 1
+// 3 states with the reference's time argument and known_tv_params (src/model_ssm_nlg.h:10-21): a forcing term and a
+// time-varying loading read from the matrix (2 x n: row 0 forcing, row 1 loading), and an explicit dependence on t
+BSSM_FN void bssm_user_T(const bssm_user_tv& tv, const double* a, const double* th, const double* kn, double* out) {
+  const double f = tv.known_tv[0 + tv.rows * tv.t];
+  out[0] = th[0] * a[0] + 0.2 * sin(a[1]) + f;
+  out[1] = 0.8 * a[1] + 0.1 * a[2] + 0.01 * tv.t;
+  out[2] = 0.5 * a[2] + 0.1 * a[0];
+}
+BSSM_FN double bssm_user_Z(const bssm_user_tv& tv, const double* a, const double* th, const double* kn) {
+  return tv.known_tv[1 + tv.rows * tv.t] * a[0] + a[2];
+}
+BSSM_FN void bssm_user_Tg(const bssm_user_tv& tv, const double* a, const double* th, const double* kn, double* Tg) {
+  for (int q = 0; q < 9; q++) Tg[q] = 0.0;
+  Tg[0 + 3 * 0] = th[0]; Tg[0 + 3 * 1] = 0.2 * cos(a[1]);
+  Tg[1 + 3 * 1] = 0.8;   Tg[1 + 3 * 2] = 0.1;
+  Tg[2 + 3 * 0] = 0.1;   Tg[2 + 3 * 2] = 0.5;
+}
+BSSM_FN void bssm_user_Zg(const bssm_user_tv& tv, const double* a, const double* th, const double* kn, double* Zg) {
+  Zg[0] = tv.known_tv[1 + tv.rows * tv.t]; Zg[1] = 0.0; Zg[2] = 1.0;
+}
+"""
+
+
+def _tv3_case(seed=51, n=28):
+    rng = np.random.default_rng(seed)
+    tvm = np.vstack([0.3 * np.sin(np.arange(n) / 3.0), 1.0 + 0.5 * np.cos(np.arange(n) / 5.0)])  # 2 x n
+    th = np.array([0.7])
+    Rm = np.array([[0.3, 0.0, 0.0], [0.1, 0.25, 0.0], [0.05, -0.1, 0.2]])  # full lower-triangular R: R R' is not diagonal
+    a1 = np.array([0.1, 0.0, -0.1]); P1 = np.array([[0.5, 0.1, 0.0], [0.1, 0.3, 0.05], [0.0, 0.05, 0.2]])
+    Hs = 0.4
+    y = np.cumsum(rng.normal(0, 0.3, n)); y[9] = np.nan
+    fns = dict(Z_fn=lambda t, a, th, kn: tvm[1, t] * a[0] + a[2],
+               T_fn=lambda t, a, th, kn: np.array([th[0] * a[0] + 0.2 * np.sin(a[1]) + tvm[0, t], 0.8 * a[1] + 0.1 * a[2] + 0.01 * t, 0.5 * a[2] + 0.1 * a[0]]),
+               H_fn=lambda t, a, th, kn: Hs, R_fn=lambda t, a, th, kn: Rm)
+    jac = dict(Z_gn=lambda t, a, th, kn: np.array([tvm[1, t], 0.0, 1.0]),
+               T_gn=lambda t, a, th, kn: np.array([[th[0], 0.2 * np.cos(a[1]), 0.0], [0.0, 0.8, 0.1], [0.1, 0.0, 0.5]]))
+    u = M.ssm_nlg_user(y, USER_TV3, theta=th, a1=a1, P1=P1, H=Hs, R=Rm, n_states=3, known_tv_params=tvm)
+    return u, y, th, a1, P1, fns, jac
+
+
+@pytest.mark.parametrize("path,N", [("wg", 600), ("grid", 3000)])
+def test_user_model_time_argument_and_known_tv_params_bootstrap(oracle, monkeypatch, path, N):
+    """a user model that reads the reference's time index and known_tv_params in T and Z (BSSM_USER_TV), with a full
+    matrix R and a full P1: bootstrap filter against orc_nlg_general_bsf_filter (callbacks take t as in the reference)"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    u, y, th, a1, P1, fns, _ = _tv3_case()
+    out = F.bootstrap_filter(u, N, seed=6, return_indices=True)
+    ref = oracle.nlg_general_bsf_filter(y, 3, 3, th, [], a1, P1, fns["Z_fn"], fns["H_fn"], fns["T_fn"], fns["R_fn"], N, seed=6)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * y.size
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+
+
+@pytest.mark.parametrize("path,N", [("wg", 600), ("grid", 3000)])
+def test_user_model_time_argument_full_R_psi_apf(oracle, monkeypatch, path, N):
+    """the same model through the psi-APF: host mode search with t and known_tv_params, full constant R in the
+    transition-density ratio (inverse Cholesky factor of R R'), full P1 -- against orc_nlg_general_psi_*"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    u, y, th, a1, P1, fns, jac = _tv3_case()
+    ref = oracle.nlg_general_psi(y, 3, 3, th, [], a1, P1, nsim=N, seed=8, **fns, **jac)
+    assert ref["ok"]
+    su = F.psi_setup(u)
+    assert np.allclose(np.asarray(su["mode"]).reshape(3, y.size, order="F"), ref["mode"], rtol=0, atol=1e-9)
+    assert abs(su["approx_loglik"] - ref["approx_loglik"]) <= 1e-9 * y.size
+    out = F.particle_smoother(u, N, method="psi", seed=8, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * y.size
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+
+
+def test_user_model_tv_snippet_without_matrix_is_refused():
+    u, y, th, a1, P1, fns, jac = _tv3_case()
+    bad = M.BssmModel(u.classes, **{**u, "known_tv_params": None})
+    with pytest.raises(Exception, match="known_tv_params"):
+        F.particle_smoother(bad, 64, method="psi", seed=1)
