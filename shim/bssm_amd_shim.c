@@ -599,10 +599,16 @@ static void fn_identity(SEXP first_ptr, int n_states, int sde, bssm_fn_model* f)
 /* the 16 leading arguments every ssm_nlg stub shares (src/R_bootstrap_filter.cpp:461-466) */
 #define NLG_ARGS SEXP y, SEXP Z, SEXP H, SEXP T, SEXP R, SEXP Zg, SEXP Tg, SEXP a1, SEXP P1, SEXP theta, SEXP log_prior_pdf, \
                  SEXP known_params, SEXP known_tv_params, SEXP n_states, SEXP n_etas, SEXP time_varying
-#define NLG_UNUSED (void)H; (void)T; (void)R; (void)Zg; (void)Tg; (void)a1; (void)P1; (void)log_prior_pdf; (void)known_tv_params; (void)n_etas; (void)time_varying
-static bssm_fn_model nlg_model(SEXP y, SEXP Z, SEXP theta, SEXP known_params, SEXP n_states) {
+#define NLG_UNUSED (void)H; (void)T; (void)R; (void)Zg; (void)Tg; (void)a1; (void)P1; (void)log_prior_pdf; (void)n_etas; (void)time_varying
+static bssm_fn_model nlg_model_tv(SEXP y, SEXP Z, SEXP theta, SEXP known_params, SEXP known_tv_params, SEXP n_states) {
   bssm_fn_model f;
   memset(&f, 0, sizeof(f));
+  /* known_tv_params (R/models.R:1507; default matrix(NA)): handed to BSSM_USER_TV snippets with the time index */
+  if (TYPEOF(known_tv_params) == REALSXP && Rf_length(known_tv_params) > 0 && !isnan(REAL(known_tv_params)[0])) {
+    f.known_tv_params = REAL(known_tv_params);
+    f.tv_rows = dim_at(known_tv_params, 0) > 1 || dim_at(known_tv_params, 1) > 1 ? dim_at(known_tv_params, 0) : Rf_length(known_tv_params);
+    f.tv_cols = Rf_length(known_tv_params) / (f.tv_rows > 0 ? f.tv_rows : 1);
+  }
   f.n = Rf_length(y);                /* every built-in ssm_nlg model is univariate: y is 1 x n after t(y) on the R side */
   f.y = REAL(y);
   f.theta = REAL(theta); f.n_theta = Rf_length(theta);
@@ -631,39 +637,39 @@ static int call_ekpf(const void* mod, uint32_t N, uint32_t seed, bssm_filter_out
 /* .Call('_bssm_bsf_nlg', <16 model args>, nsim, seed): src/R_bootstrap_filter.cpp:461-504 */
 SEXP _bssm_bsf_nlg(NLG_ARGS, SEXP nsim, SEXP seed) {
   NLG_UNUSED;
-  bssm_fn_model f = nlg_model(y, Z, theta, known_params, n_states);
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
   return run_filter_like(f.n, fn_states(&f), (uint32_t)Rf_asInteger(nsim), (uint32_t)Rf_asInteger(seed), 0, call_fn_filter, &f, NULL);
 }
 /* .Call('_bssm_bsf_smoother_nlg', ...): src/R_bootstrap_filter.cpp:508-551 */
 SEXP _bssm_bsf_smoother_nlg(NLG_ARGS, SEXP nsim, SEXP seed) {
   NLG_UNUSED;
-  bssm_fn_model f = nlg_model(y, Z, theta, known_params, n_states);
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
   fn_extra ex = {BSSM_BSF, 0, 0.0};
   return run_filter_like(f.n, fn_states(&f), (uint32_t)Rf_asInteger(nsim), (uint32_t)Rf_asInteger(seed), 1, call_fn_smoother, &f, &ex);
 }
 /* .Call('_bssm_psi_smoother_nlg', <16>, nsim, seed, max_iter, conv_tol, iekf_iter): src/R_psi.cpp:173-222 */
 SEXP _bssm_psi_smoother_nlg(NLG_ARGS, SEXP nsim, SEXP seed, SEXP max_iter, SEXP conv_tol, SEXP iekf_iter) {
   NLG_UNUSED; (void)iekf_iter;
-  bssm_fn_model f = nlg_model(y, Z, theta, known_params, n_states);
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
   fn_extra ex = {BSSM_PSI, Rf_asInteger(max_iter), Rf_asReal(conv_tol)};
   return run_filter_like(f.n, fn_states(&f), (uint32_t)Rf_asInteger(nsim), (uint32_t)Rf_asInteger(seed), 1, call_fn_smoother, &f, &ex);
 }
 /* .Call('_bssm_ekpf', <16>, nsim, seed) / '_bssm_ekpf_smoother': src/R_ekpf.cpp:11-100 */
 SEXP _bssm_ekpf(NLG_ARGS, SEXP nsim, SEXP seed) {
   NLG_UNUSED;
-  bssm_fn_model f = nlg_model(y, Z, theta, known_params, n_states);
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
   return run_filter_like(f.n, fn_states(&f), (uint32_t)Rf_asInteger(nsim), (uint32_t)Rf_asInteger(seed), 0, call_ekpf, &f, NULL);
 }
 SEXP _bssm_ekpf_smoother(NLG_ARGS, SEXP nsim, SEXP seed) {
   NLG_UNUSED;
-  bssm_fn_model f = nlg_model(y, Z, theta, known_params, n_states);
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
   fn_extra ex = {BSSM_EKPF, 0, 0.0};
   return run_filter_like(f.n, fn_states(&f), (uint32_t)Rf_asInteger(nsim), (uint32_t)Rf_asInteger(seed), 1, call_fn_smoother, &f, &ex);
 }
 /* .Call('_bssm_nonlinear_loglik', <16>, nsim, seed, max_iter, conv_tol, iekf_iter, method): src/R_loglik.cpp:91-124 */
 SEXP _bssm_nonlinear_loglik(NLG_ARGS, SEXP nsim, SEXP seed, SEXP max_iter, SEXP conv_tol, SEXP iekf_iter, SEXP method) {
   NLG_UNUSED; (void)iekf_iter;
-  bssm_fn_model f = nlg_model(y, Z, theta, known_params, n_states);
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
   double ll = R_NegInf;
   const uint32_t N = (uint32_t)Rf_asInteger(nsim);
   if (N == 0) { /* the mode-based approximate log-likelihood, src/model_ssm_nlg.cpp:258-277 */
@@ -677,7 +683,7 @@ SEXP _bssm_nonlinear_loglik(NLG_ARGS, SEXP nsim, SEXP seed, SEXP max_iter, SEXP 
 /* .Call('_bssm_suggest_n_nonlinear', <16>, theta_map, candidates, replications, seed): src/R_postcorrection.cpp:107-148 */
 SEXP _bssm_suggest_n_nonlinear(NLG_ARGS, SEXP theta_map, SEXP candidates, SEXP replications, SEXP seed) {
   NLG_UNUSED; (void)theta;
-  bssm_fn_model f = nlg_model(y, Z, theta_map, known_params, n_states);  /* model.update_model(theta_map), :137 */
+  bssm_fn_model f = nlg_model_tv(y, Z, theta_map, known_params, known_tv_params, n_states);  /* model.update_model(theta_map), :137 */
   const int nc = Rf_length(candidates);
   uint32_t* cand = (uint32_t*)R_alloc((size_t)(nc ? nc : 1), sizeof(uint32_t));
   for (int i = 0; i < nc; i++) cand[i] = (uint32_t)REAL(candidates)[i];
@@ -720,7 +726,7 @@ static is_out run_is_fn(const bssm_fn_model* tmpl, const double* theta, int n_pa
 SEXP _bssm_postcorrection_nonlinear(NLG_ARGS, SEXP output_type, SEXP nsim, SEXP seed, SEXP n_threads, SEXP is_type, SEXP counts,
                                     SEXP theta_mat, SEXP modes) {
   NLG_UNUSED;
-  bssm_fn_model f = nlg_model(y, Z, theta, known_params, n_states);
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
   const int ot = Rf_asInteger(output_type), it = Rf_asInteger(is_type), n_par = dim_at(theta_mat, 0);
   int ns = dim_at(theta_mat, 1), np = 0;
   const double *th = REAL(theta_mat), *md = REAL(modes);
@@ -776,7 +782,7 @@ SEXP _bssm_nonlinear_is_mcmc(SEXP y, SEXP Z, SEXP H, SEXP T, SEXP R, SEXP Zg, SE
                              SEXP output_type, SEXP approx, SEXP verbose) {
   (void)H; (void)T; (void)R; (void)Zg; (void)Tg; (void)a1; (void)P1; (void)known_tv_params; (void)time_varying; (void)n_etas;
   (void)iekf_iter; (void)verbose;
-  bssm_fn_model f = nlg_model(y, Z, theta, known_params, n_states);
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
   const int ot = Rf_asInteger(output_type), it = Rf_asInteger(is_type), sm_ = Rf_asInteger(sampling_method), n_par = Rf_length(theta);
   const int n = f.n, m = fn_states(&f);
   int np = 0;
