@@ -36,9 +36,9 @@ VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 # wave-level VALU instructions per particle-step of the workgroup-resident kernels, from the PMC passes committed under
 # profiles/r02_pmc_other_kernels.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_others.sh)
 REGB_VALU_PER_PSTEP = 10628740724.8 / (512 * 2048 * 1000.0)   # pf_wg_kernel<4,4,4,false,512>
-C5_VALU_PER_PSTEP = 4216487378.5 / (468.0 * 4096 * 300.0)     # pf_wg_kernel<2,2,4,1,1024,1> (nlg_growth, psi-APF), 50 dispatches of 2340 draws per 5 (profiles/r02_pmc_C5_v2.txt)
+C5_VALU_PER_PSTEP = 3939823392.2 / (468.0 * 4096 * 300.0)     # pf_wg_kernel<2,2,4,1,1024,1> (nlg_growth, psi-APF), dispatches of 468 draws (profiles/r03_pmc_C5.txt)
 C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1>"
-C4_VALU_PER_PSTEP = 8066112.5 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r02_pmc_C4_v2.txt)
+C4_VALU_PER_PSTEP = 7137180.9 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r03_pmc_C4.txt)
 
 
 def valu_roofline(valu_per_pstep, psteps_per_s, kernel):
@@ -46,19 +46,22 @@ def valu_roofline(valu_per_pstep, psteps_per_s, kernel):
     return {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
             "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
             "lane_instr_per_particle_step": valu_per_pstep * 64,
-            "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r02_pmc_other_kernels.txt, r02_pmc_C5_v2.txt); rate: measured live"}
+            "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r03_pmc_C4.txt, r03_pmc_C5.txt; regime B: r02_pmc_other_kernels.txt); rate: measured live"}
 
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def pmc_traffic(R, N, ppt):
-    """HBM bytes per pf_grid_step launch from the committed PMC passes (profiles/r02d_pmc_traffic.json: separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this script, corrected as MI355X_MICROARCH.md prescribes and calibrated on
-    calib_copy_kernel's known byte count); None when the profile does not match this workload."""
+def pmc_traffic(R, N, ppt, kernel, factored):
+    """HBM bytes per pf_grid_step launch from the PMC passes committed for THIS round's kernel (profiles/r03_pmc_traffic*.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this script by scripts/profile_r03.sh, corrected as MI355X_MICROARCH.md
+    prescribes and calibrated on calib_copy_kernel's known byte count in the same process); None unless the profile was
+    taken on exactly this workload, kernel variant and weights layout (a counter pass cannot run inside a timed run)."""
+    name = "r03_pmc_traffic.json" if factored else "r03_pmc_traffic_reference_layout.json"
     try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "r02d_pmc_traffic.json")))
-        if p["replicas"] == R and p["particles"] == N and p["particles_per_thread"] == ppt:
+        p = json.load(open(os.path.join(ROOT, "profiles", name)))
+        same_kernel = p["kernel"].replace(" ", "").endswith(kernel.replace(" ", ""))
+        if p["replicas"] == R and p["particles"] == N and p["particles_per_thread"] == ppt and same_kernel:
             return p["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -406,7 +409,8 @@ def main():
         ppt = max(1, -(-N // (info["blocks"] // info["n_filters"] * info["threads"])))  # particles per thread of the step kernel
         achieved = seqs * bytes_per_launch / (k_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R // seqs, N, ppt),
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R // seqs, N, ppt, plan.last_kernel(), layout["factored"]),
+                           "traffic_source": "profiles/r03_pmc_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script at this kernel)" % ("" if layout["factored"] else "_reference_layout"),
                            "kernel": plan.last_kernel(), "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
                            "concurrent_launches": seqs, "filters_per_launch": R // seqs,
                            "wall_per_launch_us": ms_per_step * 1e3 / (T + 1) / seqs,

@@ -1495,7 +1495,35 @@ struct ChunkTables {
     return 0;
   }
 };
+// Output 2 of a post-correction chunk, finished behind the NEXT chunk's filters: the fused back-trace + summary kernel
+// (one workgroup per draw, latency-bound gathers: 12 ms of a 90 ms C5 job) runs on a stream of its own while the filter
+// kernels of the following chunk occupy the null stream.  The object owns what that kernel reads and writes -- the chunk's
+// history / ancestor pools, the per-draw means and covariances, their pinned host copies -- until drain() has copied the
+// results into the caller's arrays; the next chunk therefore filters into fresh pools (the arena hands out cached blocks).
+struct PendingSummary {
+  DevBuf hist_pool, idx_pool, bcur_pool, d_mean, d_cov;
+  StageBuf h_mean, h_cov;
+  hipEvent_t done = nullptr;
+  std::vector<int> draws;  // draw index of every filter of the batch
+  size_t n1m = 0, n1mm = 0;
+  ~PendingSummary() {
+    if (done) { (void)hipEventSynchronize(done); (void)hipEventDestroy(done); }  // nothing is released under a running kernel
+  }
+  int drain(double* alphahat_i, double* Vt_i) {
+    if (!done) return BSSM_OK;
+    HIP_TRY(hipEventSynchronize(done));
+    (void)hipEventDestroy(done); done = nullptr;
+    const double* hm = (const double*)h_mean.p; const double* hc = (const double*)h_cov.p;
+    for (size_t f = 0; f < draws.size(); f++) {
+      std::memcpy(alphahat_i + (size_t)draws[f] * n1m, hm + f * n1m, n1m * sizeof(double));
+      std::memcpy(Vt_i + (size_t)draws[f] * n1mm, hc + f * n1mm, n1mm * sizeof(double));
+    }
+    return BSSM_OK;
+  }
+};
+
 struct IsCore {
+  std::shared_ptr<PendingSummary> pending;  // the previous chunk's summary, still running (device thread only)
   std::mutex chunk_mu;
   std::map<int, std::shared_ptr<ChunkTables>> chunk_tabs;  // by first draw of the chunk; taken by the device thread
   std::shared_ptr<ChunkTables> take_chunk(int lo) {
@@ -1553,7 +1581,14 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
       maxF = std::max<size_t>(1, ((size_t)24 << 30) / per_filter);
       if (maxF >= 256) maxF = maxF / 256 * 256;
     }
-    DevBuf hist_pool, idx_pool, smooth_pool, bcur_pool;
+    // deferred summary (PendingSummary): the whole chunk is ONE batch of one particle count with the fused kernel
+    const bool defer_off = std::getenv("BSSM_AMD_SYNC_SUMMARY") != nullptr;  // (test switch: the synchronous path)
+    const bool defer = job->output_type == 2 && fused && !defer_off && pos == 0 && end == order.size() && (end - pos) <= maxF;
+    std::shared_ptr<PendingSummary> pend = defer ? std::make_shared<PendingSummary>() : nullptr;
+    DevBuf hist_local, idx_local, smooth_pool, bcur_local;
+    DevBuf& hist_pool = pend ? pend->hist_pool : hist_local;
+    DevBuf& idx_pool = pend ? pend->idx_pool : idx_local;
+    DevBuf& bcur_pool = pend ? pend->bcur_pool : bcur_local;
     if (need_hist) {
       const size_t Fp = std::min(maxF, end - pos);
       HIP_TRY(hist_pool.alloc(Fp * hist_elems_f * sizeof(double)));
@@ -1636,12 +1671,32 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         HIP_TRY(bssm::launch_zero_dead_tail(sub, true, nullptr));
         f0 = f1;
       }
+      // the previous chunk's summary has been running beside these filters: collect it while they finish
+      if (J.pending) { const int prc = J.pending->drain(alphahat_i, Vt_i); J.pending.reset(); if (prc) return prc; }
       HIP_TRY(hipMemcpy(ll.data(), db.loglik.p, F * sizeof(double), hipMemcpyDeviceToHost));
       const double tb2 = now_ms();
       // smoothing outputs
       DevBuf d_mean, d_cov, d_picks, d_traj;
       std::vector<double> hmean, hcov, htraj;
-      if (job->output_type == 2) {
+      if (pend) {  // (the filters are complete: the copy above waited for the null stream)
+        static thread_local bssm::TlsStream st_sum_tls;
+        hipStream_t ss = st_sum_tls.get();
+        if (!ss) return fail(BSSM_ERR_HIP, "no stream for the summary kernel");
+        pend->n1m = (size_t)(n + 1) * m; pend->n1mm = pend->n1m * m;
+        HIP_TRY(pend->d_mean.alloc(F * pend->n1m * sizeof(double)));
+        HIP_TRY(pend->d_cov.alloc(F * pend->n1mm * sizeof(double)));
+        HIP_TRY(pend->h_mean.alloc(F * pend->n1m * sizeof(double)));
+        HIP_TRY(pend->h_cov.alloc(F * pend->n1mm * sizeof(double)));
+        HIP_TRY(bssm::launch_smooth_summary(db.fb.alpha_hist, db.fb.indices, bcur_pool.as<uint32_t>(), pend->d_mean.as<double>(),
+                                            pend->d_cov.as<double>(), (int)F, n, m, N, ss));
+        HIP_TRY(hipMemcpyAsync(pend->h_mean.p, pend->d_mean.p, F * pend->n1m * sizeof(double), hipMemcpyDeviceToHost, ss));
+        HIP_TRY(hipMemcpyAsync(pend->h_cov.p, pend->d_cov.p, F * pend->n1mm * sizeof(double), hipMemcpyDeviceToHost, ss));
+        HIP_TRY(hipEventCreateWithFlags(&pend->done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(pend->done, ss));
+        pend->draws.resize(F);
+        for (size_t f = 0; f < F; f++) pend->draws[f] = order[pos + f];
+        J.pending = pend;
+      } else if (job->output_type == 2) {
         HIP_TRY(d_mean.alloc((size_t)F * (n + 1) * m * sizeof(double)));
         HIP_TRY(d_cov.alloc((size_t)F * (n + 1) * m * m * sizeof(double)));
         if (fused) {
@@ -1681,7 +1736,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           const double* tr = htraj.data() + f * (size_t)(n + 1) * m;
           for (int t = 0; t <= n; t++) for (int c = 0; c < m; c++)
             alpha[t + (size_t)(n + 1) * (c + (size_t)m * i)] = tr[(size_t)t * m + c];
-        } else if (job->output_type == 2) {
+        } else if (job->output_type == 2 && !pend) {
           std::memcpy(alphahat_i + (size_t)i * (n + 1) * m, hmean.data() + f * (size_t)(n + 1) * m, (size_t)(n + 1) * m * sizeof(double));
           std::memcpy(Vt_i + (size_t)i * (n + 1) * m * m, hcov.data() + f * (size_t)(n + 1) * m * m, (size_t)(n + 1) * m * m * sizeof(double));
         }
@@ -1745,6 +1800,12 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
       t_dev += now_ms() - t1;
     }
   });
+  auto drain_pending = [&]() -> int {  // the last chunk's summary (after the device thread has gone)
+    if (!J.pending) return BSSM_OK;
+    const int rc = J.pending->drain(alphahat_i, Vt_i);
+    J.pending.reset();
+    return rc;
+  };
   auto close = [&]() {
     { std::lock_guard<std::mutex> lk(mu); closing = true; }
     cv.notify_all();
@@ -1774,7 +1835,8 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
     { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return queue.size() - taken <= 2; }); }
   }
   close();
-  if (dev_rc < 0) return fail(dev_rc, dev_err);
+  if (dev_rc < 0) { J.pending.reset(); return fail(dev_rc, dev_err); }
+  { const double td0 = now_ms(); const int rc = drain_pending(); if (rc) return rc; t_dev += now_ms() - td0; }
   g_is_timing[0] = t_host; g_is_timing[1] = t_dev;
   t_pack = t_host - t_chunk;
   g_is_timing4[0] = t_pack; g_is_timing4[1] = t_chunk; g_is_timing4[2] = t_dev; g_is_timing4[3] = now_ms() - t_call0;

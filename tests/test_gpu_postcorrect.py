@@ -366,3 +366,38 @@ def test_full_device_ung_setup_against_oracle(oracle, monkeypatch, kind, output_
     assert np.allclose(res["2"]["loglik"], res["0"]["loglik"], rtol=0, atol=1e-10 * n)
     if output_type == 2:
         assert np.allclose(res["2"]["alphahat"], res["0"]["alphahat"], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["bsm_ng", "nlg_growth"])
+def test_summary_behind_the_next_chunk_equals_the_synchronous_path(monkeypatch, kind):
+    """output 2 (smoothed summaries): the fused back-trace + summary kernel of chunk c runs on its own stream beside the
+    filters of chunk c + 1 (PendingSummary) -- several chunks per call here -- and must give exactly what the synchronous
+    path gives (BSSM_AMD_SYNC_SUMMARY), chunk boundaries notwithstanding"""
+    from bssm_amd import filters as F
+    if kind == "bsm_ng":
+        from oracle import oracle as O
+        model, theta, counts = _job(ns=37, n=30, seed=4)
+        arrs = PC.expand_models(model, theta)
+        modes = np.stack([O.psi_setup(a)["mode"] for a in arrs], axis=1)
+    else:
+        rng = np.random.default_rng(12)
+        n = 40
+        y = 50.0 + np.cumsum(rng.normal(0.5, 1.0, n)) + rng.normal(0, 1, n)
+        th0 = np.array([0.0, np.log(0.05), 0.0])
+        model = M.ssm_nlg(y, "nlg_growth", theta=th0, known_params=[0.1, 500.0, 0.0, 50.0, 1.0, 100.0])
+        theta = th0 + rng.normal(0, 0.05, (37, 3))
+        counts = rng.integers(1, 4, 37).astype(np.uint32)
+        mode = F.psi_setup(model)["mode"]
+        modes = np.repeat(mode.reshape(-1, 1, order="F"), 37, axis=1).reshape(2, n, 37, order="F")
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(len(counts)), output_type=2)
+    monkeypatch.setenv("BSSM_AMD_IS_CHUNK", "8")  # 5 chunks
+    a = PC.post_correct(model, mo, 64, threads=2, is_type="is2", seed=9)
+    monkeypatch.setenv("BSSM_AMD_SYNC_SUMMARY", "1")
+    b = PC.post_correct(model, mo, 64, threads=2, is_type="is2", seed=9)
+    monkeypatch.delenv("BSSM_AMD_SYNC_SUMMARY")
+    monkeypatch.delenv("BSSM_AMD_IS_CHUNK")
+    c = PC.post_correct(model, mo, 64, threads=2, is_type="is2", seed=9)  # one chunk
+    for key in ("weights", "loglik", "alphahat", "Vt"):
+        assert np.array_equal(a[key], b[key]), key
+        assert np.array_equal(a[key], c[key]), key
+    assert np.all(np.isfinite(a["alphahat"])) and np.all(np.isfinite(a["Vt"]))
