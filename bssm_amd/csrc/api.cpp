@@ -1582,8 +1582,12 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
       if (maxF >= 256) maxF = maxF / 256 * 256;
     }
     // deferred summary (PendingSummary): the whole chunk is ONE batch of one particle count with the fused kernel
-    const bool defer_off = std::getenv("BSSM_AMD_SYNC_SUMMARY") != nullptr;  // (test switch: the synchronous path)
-    const bool defer = job->output_type == 2 && fused && !defer_off && pos == 0 && end == order.size() && (end - pos) <= maxF;
+    // Off unless BSSM_AMD_DEFER_SUMMARY is set: measured on C5 with summaries (2 340 draws) the call takes 81.2 ms either way
+    // (filter thread 75.5 vs 78.2 ms) -- a filter workgroup of 1024 threads at 128 VGPRs owns the whole register file of its
+    // CU, so the summary's workgroups only find room in the tail of a filter launch (profiles/r03_c5_output2_ab.txt) -- and
+    // the deferral holds a second set of history pools.
+    const bool defer_on = std::getenv("BSSM_AMD_DEFER_SUMMARY") != nullptr;
+    const bool defer = job->output_type == 2 && fused && defer_on && pos == 0 && end == order.size() && (end - pos) <= maxF;
     std::shared_ptr<PendingSummary> pend = defer ? std::make_shared<PendingSummary>() : nullptr;
     DevBuf hist_local, idx_local, smooth_pool, bcur_local;
     DevBuf& hist_pool = pend ? pend->hist_pool : hist_local;

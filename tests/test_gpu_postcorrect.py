@@ -371,8 +371,9 @@ def test_full_device_ung_setup_against_oracle(oracle, monkeypatch, kind, output_
 @pytest.mark.parametrize("kind", ["bsm_ng", "nlg_growth"])
 def test_summary_behind_the_next_chunk_equals_the_synchronous_path(monkeypatch, kind):
     """output 2 (smoothed summaries): the fused back-trace + summary kernel of chunk c runs on its own stream beside the
-    filters of chunk c + 1 (PendingSummary) -- several chunks per call here -- and must give exactly what the synchronous
-    path gives (BSSM_AMD_SYNC_SUMMARY), chunk boundaries notwithstanding"""
+    filters of chunk c + 1 (PendingSummary, opt-in: BSSM_AMD_DEFER_SUMMARY; measured neutral on C5, so not the default)
+    -- several chunks per call here -- and must give exactly what the synchronous path gives, chunk boundaries
+    notwithstanding"""
     from bssm_amd import filters as F
     if kind == "bsm_ng":
         from oracle import oracle as O
@@ -391,10 +392,10 @@ def test_summary_behind_the_next_chunk_equals_the_synchronous_path(monkeypatch, 
         modes = np.repeat(mode.reshape(-1, 1, order="F"), 37, axis=1).reshape(2, n, 37, order="F")
     mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(len(counts)), output_type=2)
     monkeypatch.setenv("BSSM_AMD_IS_CHUNK", "8")  # 5 chunks
+    monkeypatch.setenv("BSSM_AMD_DEFER_SUMMARY", "1")
     a = PC.post_correct(model, mo, 64, threads=2, is_type="is2", seed=9)
-    monkeypatch.setenv("BSSM_AMD_SYNC_SUMMARY", "1")
+    monkeypatch.delenv("BSSM_AMD_DEFER_SUMMARY")
     b = PC.post_correct(model, mo, 64, threads=2, is_type="is2", seed=9)
-    monkeypatch.delenv("BSSM_AMD_SYNC_SUMMARY")
     monkeypatch.delenv("BSSM_AMD_IS_CHUNK")
     c = PC.post_correct(model, mo, 64, threads=2, is_type="is2", seed=9)  # one chunk
     for key in ("weights", "loglik", "alphahat", "Vt"):
