@@ -273,7 +273,9 @@ constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the
 #ifndef BSSM_WG_NT
 #define BSSM_WG_NT 1
 #endif
-template <int MP, int KP, int PPT, int FN = FN_NONE, int NTB = WG_NT_MAX, int PM = -1>
+// EX: the particle count is exactly NTB * PPT (4096 = 1024 x 4, the shape IS post-correction of config C5 runs): N is a
+// compile-time constant, every `i < N` guard and the pivot / window arithmetic derived from N fold away
+template <int MP, int KP, int PPT, int FN = FN_NONE, int NTB = WG_NT_MAX, int PM = -1, bool EX = false>
 __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   constexpr int FID = FN > 0 ? FN : 0;
   const int psi_mode = PM >= 0 ? PM : b.psi;
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // psi-APF of a functor model: parameter block, observation row and approximating rows are wave-uniform -- scalar loads
   constexpr bool kPsiFn = FN != FN_NONE && PM == 1 && MP <= 4;
-  const int Ncap = NT * PPT, N = b.N, n = b.n, f = blockIdx.x;
+  const int Ncap = NT * PPT, N = EX ? NTB * PPT : b.N, n = b.n, f = blockIdx.x;
   double* __restrict__ s_alpha = smem;            // [MP][Ncap]
   double* __restrict__ s_cdf = smem + MP * Ncap;  // [Ncap]
   double* __restrict__ s_max = s_cdf + Ncap;      // [16]
@@ -508,6 +510,12 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
 }
 
 // the functor kernel of one shape for the batch's sampler (0 bootstrap, 1 psi-APF, 2 EKF particle filter: MP <= 2 only)
+// the exact-size psi-APF variant: instantiated for the 1024-thread kernels at four particles per lane only
+template <int MP, int PPT, int FNV, int NTB>
+auto wg_fn_kernel_exact(int psi) -> void (*)(const FilterBatch) {
+  if constexpr (NTB == 1024 && PPT == 4 && MP <= 2) { if (psi == 1) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1, true>; }
+  return nullptr;
+}
 template <int MP, int PPT, int FNV, int NTB>
 auto wg_fn_kernel(int psi) -> void (*)(const FilterBatch) {
   if constexpr (MP > 2) return psi == 1 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0>;  // (the host refuses EKF filters beyond two states)
@@ -541,7 +549,9 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
       switch (ppt) {
 #ifndef BSSM_USER_MODEL
         case 2: kern = fn ? (MP == KP ? WG_FN_KERNEL(2, 1024) : nullptr) : pf_wg_kernel<MP, KP, 2, FN_NONE, 1024>; break;
-        case 4: kern = fn ? (MP == KP ? WG_FN_KERNEL(4, 1024) : nullptr) : pf_wg_kernel<MP, KP, 4, FN_NONE, 1024>; break;
+        case 4: kern = fn ? (MP == KP ? WG_FN_KERNEL(4, 1024) : nullptr) : pf_wg_kernel<MP, KP, 4, FN_NONE, 1024>;
+          if (fn && MP == KP && N == 4096 && !std::getenv("BSSM_AMD_WG_NO_EXACT")) { if (auto kx = wg_fn_kernel_exact<MP, 4, kFn, 1024>(b.psi)) kern = kx; }
+          break;
         default: kern = fn ? (MP == KP ? WG_FN_KERNEL(8, 1024) : nullptr) : pf_wg_kernel<MP, KP, 8, FN_NONE, 1024>; break;
 #else
         case 2: kern = fn ? WG_FN_KERNEL(2, 1024) : nullptr; break;
