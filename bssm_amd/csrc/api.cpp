@@ -765,6 +765,8 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
       fp[bssm::FP_TVROWS] = mod->tv_rows; fp[bssm::FP_TVCOLS] = mod->tv_cols;
     }
   }
+  if (id >= bssm::FN_NLG_GROWTH && id <= bssm::FN_NLG_LINEAR_GAUSSIAN)  // shipped models: diagonal R, the psi weight reads 1 / R_j
+    for (int j = 0; j < m; j++) fp[bssm::FP_RLINV + j + MP * j] = 1.0 / fp[bssm::FP_R + j];
   fp[bssm::FP_H] = H;
   fp[bssm::FP_LOGC] = -0.5 * (std::log(2.0 * 3.14159265358979323846) + 2.0 * std::log(H));
   if (params_only) {

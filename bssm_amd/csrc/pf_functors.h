@@ -310,7 +310,7 @@ __device__ __forceinline__ double functor_psi_weight(PF fp, PR row, PA amat, int
       double am = amat[MP * MP + j];
 #pragma unroll
       for (int c = 0; c < MP; c++) am += amat[j + MP * c] * aprev[c];
-      const double ir = fdiv(1.0, fp[FP_R + j]);
+      const double ir = fp[FP_RLINV + j + MP * j];  // 1 / R_j, from the host (it was a per-particle division of two constants)
       const double da = (x[j] - am) * ir, dm = (x[j] - mean[j]) * ir;
       w += 0.5 * (da * da - dm * dm);
     }
