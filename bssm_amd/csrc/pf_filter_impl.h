@@ -417,8 +417,11 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     // The 20 Philox round keys (seed + r * const, stream + r * const) are loop-invariant: hoisted out of the time loop they
     // sat in SGPRs for its whole body, were spilt to VGPR lanes and came back through 80 v_readlane per wave-step.  Opaque
     // copies of the key make them step-local: 20 scalar adds per step, live only while the step blocks are drawn.
+    // (functor kernels only: in the linear-state kernels the same trick costs more scalar registers than it frees -- regime B of
+    // bench.py, 512 filters of 2048 particles with four noise terms: 25.8 ms without it, 26.1 with it, and 30.6 with a second
+    // opaque key in front of the further transition blocks: profiles/r03_regb_ab.txt)
     RngKey key_t = key;
-    __asm__ volatile("" : "+s"(key_t.seed), "+s"(key_t.stream));
+    if constexpr (FN != FN_NONE) __asm__ volatile("" : "+s"(key_t.seed), "+s"(key_t.stream));
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
@@ -471,8 +474,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     // ---- transition to t+1 and the weights there
     const cdbl* mt = as_uniform_table(mats + (size_t)t * b.mats_tstride);
     const double* __restrict__ ob = obs + (size_t)(t + 1 < n ? t + 1 : 0) * obs_stride;
-    RngKey key_p = key;  // (as key_t above: the round keys of the further transition blocks stay local to this section)
-    __asm__ volatile("" : "+s"(key_p.seed), "+s"(key_p.stream));
+    const RngKey key_p = key;
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
