@@ -22,6 +22,7 @@
 #include "pf_device.h"
 #include "pf_functors.h"
 #include "pf_kernels.h"
+#include "tls_stream.h"
 
 namespace bssm {
 
@@ -1127,27 +1128,29 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   // (with two or more particles per lane a workgroup carries twice the work: from 384 workgroups -- three 65 536-particle
   // filters at two per lane 1.80e10 -> 1.92e10, m = 1 2.12e10 -> 2.21e10; two filters, 256 workgroups: 1.41e10 -> 1.33e10, stays one)
   int parts = ((long long)b.F * ws.B >= (ws.chunk >= 2 * GRID_NT ? 384 : 512) && b.F >= 2) ? 2 : 1;
-  if (const char* env = std::getenv("BSSM_AMD_GRID_STREAMS")) parts = (std::atoi(env) >= 2 && b.F >= 2) ? 2 : 1;
+  constexpr int kMaxParts = 4;  // (more than two sequences: measurement option, BSSM_AMD_GRID_STREAMS=3|4 -- extra side streams per host thread)
+  if (const char* env = std::getenv("BSSM_AMD_GRID_STREAMS")) parts = std::max(1, std::min({std::atoi(env), kMaxParts, b.F}));
   const dim3 block(GRID_NT);
   if (!ws.side) parts = 1;
-  hipStream_t lanes[2] = {stream, stream};
+  hipStream_t lanes[kMaxParts] = {stream, stream, stream, stream};
   hipEvent_t fork = nullptr, join = nullptr;
-  GridWorkspace wsp[2] = {ws, ws};
-  wsp[0].wx = wsp[1].wx = v2wx ? 1 : 0;
+  GridWorkspace wsp[kMaxParts] = {ws, ws, ws, ws};
   const int fw = (v2wx && kern_init && ws.fw && b.weights) ? 1 : 0;  // factored weights output: only with the weights-exchange kernels
-  wsp[0].fw = wsp[1].fw = fw;
+  for (int q = 0; q < kMaxParts; q++) { wsp[q].wx = v2wx ? 1 : 0; wsp[q].fw = fw; }
   if (timing) timing->factored = fw;
   if (fw && (e = hipMemsetAsync(ws.wscale, 0, sizeof(double) * b.F * (b.n + 1) * ws.B, stream)) != hipSuccess) return e;  // (columns behind a degenerate step stay zero)
-  int fcount[2] = {b.F, 0};
-  if (parts == 2) {  // first half on the caller's stream, second half on the library's side stream (ws.side)
+  int fcount[kMaxParts] = {b.F, 0, 0, 0};
+  if (parts >= 2) {  // first part on the caller's stream, the others on the library's side streams
+    static thread_local TlsStream extra_side[kMaxParts - 2];
     lanes[1] = ws.side;
-    fcount[0] = b.F / 2; fcount[1] = b.F - fcount[0];
-    wsp[1].f0 = fcount[0];
+    for (int q = 2; q < parts; q++) { lanes[q] = extra_side[q - 2].get(); if (!lanes[q]) { parts = q; break; } }
+    int f_at = 0;
+    for (int q = 0; q < parts; q++) { fcount[q] = (b.F * (q + 1)) / parts - (b.F * q) / parts; wsp[q].f0 = f_at; f_at += fcount[q]; }
     if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return e;
     (void)hipEventRecord(fork, stream);
-    (void)hipStreamWaitEvent(lanes[1], fork, 0);
+    for (int q = 1; q < parts; q++) (void)hipStreamWaitEvent(lanes[q], fork, 0);
   }
-  if (const char* env = std::getenv("BSSM_AMD_XCD_REMAP")) { wsp[0].xcd_remap = wsp[1].xcd_remap = std::atoi(env); }
+  if (const char* env = std::getenv("BSSM_AMD_XCD_REMAP")) { for (int q = 0; q < kMaxParts; q++) wsp[q].xcd_remap = std::atoi(env); }
   if (timing) timing->concurrent = parts;
   auto step = [&](int q, int t) {
     if (t < 0 && kern_init) hipLaunchKernelGGL(kern_init, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q]);
@@ -1200,11 +1203,13 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
       (void)hipEventDestroy(ev[2 * i + 1]);
     }
   }
-  if (parts == 2) {  // join: the caller's stream continues after the side sequence too
-    if ((e = hipEventCreateWithFlags(&join, hipEventDisableTiming)) != hipSuccess) return e;
-    (void)hipEventRecord(join, lanes[1]);
-    (void)hipStreamWaitEvent(stream, join, 0);
-    (void)hipEventDestroy(join);
+  if (parts >= 2) {  // join: the caller's stream continues after the side sequences too
+    for (int q = 1; q < parts; q++) {
+      if ((e = hipEventCreateWithFlags(&join, hipEventDisableTiming)) != hipSuccess) return e;
+      (void)hipEventRecord(join, lanes[q]);
+      (void)hipStreamWaitEvent(stream, join, 0);
+      (void)hipEventDestroy(join);
+    }
     (void)hipEventDestroy(fork);
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;
