@@ -924,18 +924,27 @@ namespace {
 // the initial table, and [a1 | P1 | att1 | L1] behind the functor parameters for the time-0 weights
 int functor_ekpf_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector<double>* fpar, int* m_out) {
   bssm::FnModel f;
-  int rc = to_fn_model(mod, &f, 2);
+  int rc = to_fn_model(mod, &f, 4);  // (round 3: up to 4 states, any constant R, any P1 -- as the psi-APF)
   if (rc) return rc;
   int m = 1, k = 1;
   if ((rc = functor_tables(mod, ft, fpar, &m, &k))) return rc;
-  double a1[2], P1[4], att1[2], L1[4];
+  const int MP = bssm::pad_dim(m);
+  if (mod->model_id == bssm::FN_USER_NLG && m <= 2) {  // the 1- / 2-state device code builds R R' from the diagonal of R
+    for (int c = 0; c < m; c++) for (int j = 0; j < m; j++)
+      if (j != c && f.uRm[j + m * c] != 0.0) return fail(BSSM_ERR_UNSUPPORTED, "EKF particle filter of a user model with 1 or 2 states: constant diagonal R");
+  }
+  double a1[4], P1[16], att1[4], L1[16];
   bssm::fn_ekpf_init(f, a1, P1, att1, L1);
-  for (int j = 0; j < m; j++) ft->init[j] = att1[j];
-  for (int q = 0; q < m * m; q++) ft->init[m + q] = L1[q];
-  fpar->insert(fpar->end(), a1, a1 + m);
-  fpar->insert(fpar->end(), P1, P1 + m * m);
-  fpar->insert(fpar->end(), att1, att1 + m);
-  fpar->insert(fpar->end(), L1, L1 + m * m);
+  // the initial table and the [a1 | P1 | att1 | L1] block in the kernels' padded layout (MP, MP x MP column-major)
+  std::fill(ft->init.begin(), ft->init.end(), 0.0);
+  std::vector<double> blk((size_t)2 * MP + 2 * MP * MP, 0.0);
+  for (int j = 0; j < m; j++) { ft->init[j] = att1[j]; blk[j] = a1[j]; blk[MP + MP * MP + j] = att1[j]; }
+  for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) {
+    ft->init[MP + j + MP * c] = L1[j + m * c];
+    blk[MP + j + MP * c] = P1[j + m * c];
+    blk[2 * MP + MP * MP + j + MP * c] = L1[j + m * c];
+  }
+  fpar->insert(fpar->end(), blk.begin(), blk.end());
   *m_out = m;
   return BSSM_OK;
 }

@@ -231,7 +231,7 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
   if constexpr (FN != FN_NONE) {
     constexpr int FID = FN > 0 ? FN : 0;
     const int psi = PM >= 0 ? PM : b.psi;
-    if constexpr (MP <= 2) {  // EKF particle filter: the shapes of the shipped models (the host refuses the others)
+    if constexpr (MP <= 4) {  // EKF particle filter: up to 4 states (3 / 4: user models, general small factorisations)
       if (psi == 2) return functor_ekpf_weight<MP, FID>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
     }
     if constexpr (MP <= 4) {  // psi-APF: up to 4 states (user-defined models; constant diagonal R)
@@ -482,8 +482,8 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       double x[MP];
       if (FN && !psi_mode) {
         if constexpr (FN != FN_NONE) functor_propagate<MP, KP, FID>(fpar, key_p, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
-      } else if (FN && MP <= 2 && psi_mode == 2) {
-        if constexpr (FN != FN_NONE && MP <= 2) functor_ekpf_propagate<MP, FID>(fpar, ob, t + 1 >= n, key_p, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
+      } else if (FN && MP <= 4 && psi_mode == 2) {
+        if constexpr (FN != FN_NONE && MP <= 4) functor_ekpf_propagate<MP, FID>(fpar, ob, t + 1 >= n, key_p, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
       } else {
         double z[KP];
         rng_normals_blk<KP>(blk[r], key_p, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
@@ -521,7 +521,7 @@ auto wg_fn_kernel_exact(int psi) -> void (*)(const FilterBatch) {
 }
 template <int MP, int PPT, int FNV, int NTB>
 auto wg_fn_kernel(int psi) -> void (*)(const FilterBatch) {
-  if constexpr (MP > 2) return psi == 1 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0>;  // (the host refuses EKF filters beyond two states)
+  if constexpr (MP > 4) return psi == 1 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0>;  // (no EKF filter beyond four states)
   else return psi == 0 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0> : (psi == 1 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 2>);
 }
 #define WG_FN_KERNEL(PPT_, NTB_) wg_fn_kernel<MP, PPT_, kFn, NTB_>(b.psi)
@@ -957,8 +957,8 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
         }
         BSSM_STAMP(6)
         if constexpr (FN != FN_NONE) {
-          if (MP <= 2 && psi_mode == 2) {
-            if constexpr (MP <= 2) functor_ekpf_propagate<MP, FID>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
+          if (MP <= 4 && psi_mode == 2) {
+            if constexpr (MP <= 4) functor_ekpf_propagate<MP, FID>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
           } else if (psi_mode) {
             double z[KP];
             rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
@@ -1040,7 +1040,7 @@ namespace bssm {
 
 template <int MP, int KP, int PPT, int FNV>
 auto grid_fn_kernel(int psi) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
-  if constexpr (MP > 2) return psi == 1 ? pf_grid_step<MP, KP, PPT, false, FNV, 1> : pf_grid_step<MP, KP, PPT, false, FNV, 0>;
+  if constexpr (MP > 4) return psi == 1 ? pf_grid_step<MP, KP, PPT, false, FNV, 1> : pf_grid_step<MP, KP, PPT, false, FNV, 0>;
   else return psi == 0 ? pf_grid_step<MP, KP, PPT, false, FNV, 0> : (psi == 1 ? pf_grid_step<MP, KP, PPT, false, FNV, 1> : pf_grid_step<MP, KP, PPT, false, FNV, 2>);
 }
 template <int MP, int KP>

@@ -42,7 +42,7 @@ __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || i
 //                  matrix, column-major, tv.rows x tv.cols, exactly as the caller handed it over.
 // The state may have up to 4 components (BSSM_USER_M = 1, 2 or 4 is the padded dimension the kernels are instantiated
 // for; a 3-state model leaves the fourth component alone) and R any m x k matrix, k <= m (bootstrap filter / smoother /
-// bootstrap IS correction; the psi-APF and the EKF particle filter stay limited to 2 states and constant diagonal R).
+// bootstrap IS correction; psi-APF and EKF particle filter: up to 4 states and any constant R since round 3).
 // per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser,
 // user slot, number of states, full R (MP x MP, column-major, zero-padded; user models)
 enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, FP_H = 20, FP_R = 21, FP_LOGC = 23, FP_SLOT = 24 /* user-model registry slot (host only) */,
@@ -339,12 +339,36 @@ __device__ __forceinline__ void nlg_Z_gn(int id, const double* __restrict__ fp, 
   }
 }
 // lower Cholesky factor of a PSD MP x MP matrix with psd_chol's zero-diagonal rule (src/psd_chol.cpp:5-18), MP <= 2
+// (MP > 2, user models with 3 or 4 states: general loops; `m` = the model's states, the threshold counts its columns; a
+// padding component has a zero diagonal and drops out like any component without variance)
 template <int MP>
-__device__ __forceinline__ void psd_chol_small(const double (&P)[MP * MP], double (&L)[MP * MP]) {
+__device__ __forceinline__ void psd_chol_small(const double (&P)[MP * MP], double (&L)[MP * MP], int m = MP) {
   const double eps = 2.220446049250313e-16;
 #pragma unroll
   for (int q = 0; q < MP * MP; q++) L[q] = 0.0;
-  if constexpr (MP == 1) {
+  if constexpr (MP > 2) {
+    double dmax = P[0];
+#pragma unroll
+    for (int j = 1; j < MP; j++) dmax = fmax(dmax, P[j + MP * j]);
+    const double thr = fmax(eps, eps * (double)m * dmax);
+#pragma unroll
+    for (int j = 0; j < MP; j++) {  // column j of the factor on the components above the threshold (left-looking)
+      const bool nzj = P[j + MP * j] > thr;
+      double d = P[j + MP * j];
+#pragma unroll
+      for (int q = 0; q < j; q++) d -= L[j + MP * q] * L[j + MP * q];
+      const double ljj = nzj ? sqrt(d) : 0.0;
+      L[j + MP * j] = ljj;
+      const double inv = nzj ? 1.0 / ljj : 0.0;
+#pragma unroll
+      for (int i = j + 1; i < MP; i++) {
+        double v = P[i + MP * j];
+#pragma unroll
+        for (int q = 0; q < j; q++) v -= L[i + MP * q] * L[j + MP * q];
+        L[i + MP * j] = (nzj && P[i + MP * i] > thr) ? v * inv : 0.0;
+      }
+    }
+  } else if constexpr (MP == 1) {
     if (P[0] > fmax(eps, eps * P[0])) L[0] = sqrt(P[0]);
   } else {
     const double thr = fmax(eps, eps * 2.0 * fmax(P[0], P[3]));
@@ -364,7 +388,34 @@ __device__ __forceinline__ void psd_chol_small(const double (&P)[MP * MP], doubl
 template <int MP>
 __device__ __forceinline__ double dmvnorm_cov_small(const double (&x)[MP], const double (&mean)[MP], const double (&S)[MP * MP]) {
   const double l2pi = 1.8378770664093453;  // log(2 pi)
-  if constexpr (MP == 1) {
+  if constexpr (MP > 2) {  // components with S_jj <= eps dropped, Cholesky of the rest, forward substitution (src/dmvnorm.cpp:14-37)
+    const double eps = 2.220446049250313e-16;
+    double L[MP * MP], z[MP], out = 0.0;
+#pragma unroll
+    for (int q = 0; q < MP * MP; q++) L[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < MP; j++) {
+      const bool nzj = S[j + MP * j] > eps;
+      double d = S[j + MP * j];
+#pragma unroll
+      for (int q = 0; q < j; q++) d -= L[j + MP * q] * L[j + MP * q];
+      const double ljj = nzj ? sqrt(d) : 1.0;
+      L[j + MP * j] = nzj ? ljj : 0.0;
+      double sacc = x[j] - mean[j];
+#pragma unroll
+      for (int q = 0; q < j; q++) sacc -= L[j + MP * q] * z[q];
+      z[j] = nzj ? sacc / ljj : 0.0;
+      out += nzj ? (-0.5 * l2pi - tl_log(ljj) - 0.5 * z[j] * z[j]) : 0.0;
+#pragma unroll
+      for (int i = j + 1; i < MP; i++) {
+        double v = S[i + MP * j];
+#pragma unroll
+        for (int q = 0; q < j; q++) v -= L[i + MP * q] * L[j + MP * q];
+        L[i + MP * j] = (nzj && S[i + MP * i] > eps) ? v / ljj : 0.0;
+      }
+    }
+    return out;
+  } else if constexpr (MP == 1) {
     const double d = x[0] - mean[0];
     return -0.5 * (l2pi + tl_log(S[0]) + d * d / S[0]);
   } else {
@@ -410,10 +461,22 @@ __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, con
   const int id = FID > 0 ? FID : (int)fp[FP_ID];
   nlg_T_fn<MP>(id, fp, anc, at, t);
   double Pt[MP * MP];
+  if constexpr (MP > 2) {  // user models: R R' of the constant matrix R (FP_RMAT, MP x MP with zero padding)
 #pragma unroll
-  for (int q = 0; q < MP * MP; q++) Pt[q] = 0.0;
+    for (int j = 0; j < MP; j++)
 #pragma unroll
-  for (int j = 0; j < MP; j++) Pt[j + MP * j] = fp[FP_R + j] * fp[FP_R + j];
+      for (int i = 0; i < MP; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < MP; q++) acc += fp[FP_RMAT + i + MP * q] * fp[FP_RMAT + j + MP * q];
+        Pt[i + MP * j] = acc;
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < MP * MP; q++) Pt[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < MP; j++) Pt[j + MP * j] = fp[FP_R + j] * fp[FP_R + j];
+  }
   if (last) {  // the final, never-weighted slot: the reference uses P_t itself as the factor (:1223-1226)
 #pragma unroll
     for (int j = 0; j < MP; j++) att[j] = at[j];
@@ -468,7 +531,7 @@ __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, con
 #pragma unroll
     for (int q = 0; q < MP * MP; q++) Ptt[q] = Pt[q];
   }
-  psd_chol_small<MP>(Ptt, Lf);
+  psd_chol_small<MP>(Ptt, Lf, MP > 2 ? (int)fp[FP_M] : MP);
 }
 template <int MP, int FID = 0>
 __device__ __forceinline__ void functor_ekpf_propagate(const double* __restrict__ fp, const double* __restrict__ row_next, bool last,
@@ -502,10 +565,22 @@ __device__ __forceinline__ double functor_ekpf_weight(const double* __restrict__
   }
   double at[MP], att[MP], Lf[MP * MP], RR[MP * MP];
   ekpf_proposal<MP, FID>(fp, row, false, anc, at, att, Lf, t - 1);
+  if constexpr (MP > 2) {
 #pragma unroll
-  for (int q = 0; q < MP * MP; q++) RR[q] = 0.0;
+    for (int j = 0; j < MP; j++)
 #pragma unroll
-  for (int j = 0; j < MP; j++) RR[j + MP * j] = fp[FP_R + j] * fp[FP_R + j];
+      for (int i = 0; i < MP; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < MP; q++) acc += fp[FP_RMAT + i + MP * q] * fp[FP_RMAT + j + MP * q];
+        RR[i + MP * j] = acc;
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < MP * MP; q++) RR[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < MP; j++) RR[j + MP * j] = fp[FP_R + j] * fp[FP_R + j];
+  }
   return w + dmvnorm_cov_small<MP>(x, at, RR) - dmvnorm_lwr_small<MP>(x, att, Lf);
 }
 

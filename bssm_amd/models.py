@@ -576,8 +576,8 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
     ``bssm_user_Z``), and the state-independent pieces are numbers: H (observation sd), the diagonal of R, a1, P1.
     With the Jacobians in the snippet (``BSSM_USER_JACOBIANS``, ``bssm_user_Tg``, ``bssm_user_Zg``) the psi-APF and the
     EKF particle filter work as for the built-in models (psi-APF: up to 4 states, any constant matrix ``R`` with R R'
-    positive definite on its non-zero diagonal, any positive semi-definite P1; EKF particle filter: 1 or 2 states,
-    constant diagonal R, diagonal P1).
+    positive definite on its non-zero diagonal, any positive semi-definite P1; the EKF particle filter likewise, with a constant diagonal R
+    for 1- and 2-state models).
     ``known_tv_params``: the reference's matrix of known time-varying values (R/models.R:1507); a snippet that defines
     ``BSSM_USER_TV`` receives it, with the time index, as the leading ``const bssm_user_tv& tv`` argument of every function
     (``tv.t``, ``tv.known_tv`` column-major ``tv.rows x tv.cols``).

@@ -177,7 +177,7 @@ typedef struct bssm_fn_model {
   int32_t L;                  /* ssm_sde: 2^L Milstein sub-steps per unit time */
   /* ---- user-defined models only (model_id BSSM_FN_USER_NLG / BSSM_FN_USER_SDE); ignored for the built-in ids */
   int32_t user_slot;          /* from bssm_user_model_load */
-  int32_t n_states;           /* ssm_nlg: 1 ... 4 (psi-APF / EKF particle filter: 1 or 2) */
+  int32_t n_states;           /* ssm_nlg: 1 ... 4 */
   double H;                   /* ssm_nlg: observation sd (the value H_fn returns; unused when the snippet defines BSSM_USER_HFN) */
   double R_diag[2];           /* ssm_nlg: diagonal of R_fn's value (n_states <= 2, diagonal R) */
   double a1[2], P1[4];        /* ssm_nlg: a1_fn, P1_fn values (P1 column-major, n_states x n_states), n_states <= 2 */
@@ -205,7 +205,7 @@ typedef struct bssm_fn_model {
  * bssm_fn_psi_setup) and EKF particle filter (bssm_ekpf_*) with their smoothers and bssm_fn_loglik_batch; the psi-APF and
  * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS).  The psi-APF takes up to 4 states, any constant
  * n_states x n_etas matrix R whose R R' is positive definite on its non-zero diagonal, and any positive semi-definite P1
- * (round 3); the EKF particle filter at most 2 states with a diagonal P1 and a constant diagonal R.  Snippets that define
+ * (round 3); so does the EKF particle filter (1- and 2-state models: constant diagonal R).  Snippets that define
  * BSSM_USER_TV receive the time index and known_tv_params in every function.  The bootstrap filter / smoother / bootstrap IS correction take up to 4 states, any n_states x n_etas matrix
  * R and the reference's state-dependent H_fn / R_fn (snippet functions bssm_user_H / bssm_user_R).  IS post-correction
  * (bssm_is_correction_nlg / _multi) and the chains (bssm_run_mcmc_fn; theta-dependent H / R / a1 / P1 through

@@ -2213,6 +2213,94 @@ done:
   free(nw); free(lw); free(r); free(atmp);
   return loglik;
 }
+/* ekf_update_step :1264-1293, one observation series; t = the time of the observation */
+static void gen_ekf_update_step(const orc_nlg_general_psi *mod, int t, const double *at, const double *Pt, double *att, double *Ptt) {
+  const orc_nlg_general *b = &mod->base;
+  const int m = b->m;
+  if (isfinite(b->y[t])) {
+    double Zg[ORC_MAXM], PZ[ORC_MAXM], K[ORC_MAXM], h, z;
+    GEN_CALL(Z_gn, t, at, Zg); b->H_fn(t, at, b->theta, b->known, &h);
+    double F = h * h;
+    for (int i = 0; i < m; i++) { PZ[i] = 0; for (int j = 0; j < m; j++) PZ[i] += Pt[i + m * j] * Zg[j]; }
+    for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
+    const double cF = sqrt(F);
+    b->Z_fn(t, at, b->theta, b->known, &z);
+    const double v = b->y[t] - z;
+    for (int i = 0; i < m; i++) { K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF); att[i] = at[i] + K[i] * v; }
+    double IKZ[ORC_MAXM * ORC_MAXM], tmp[ORC_MAXM * ORC_MAXM], tmp2[ORC_MAXM * ORC_MAXM];
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
+    mat_mul(IKZ, Pt, m, m, m, tmp); mat_mul_bt(tmp, IKZ, m, m, m, tmp2);
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Ptt[i + m * j] = tmp2[i + m * j] + K[i] * h * h * K[j];
+  } else {
+    memcpy(att, at, sizeof(double) * m); memcpy(Ptt, Pt, sizeof(double) * m * m);
+  }
+}
+/* ssm_nlg::ekf_filter (EKF-proposal particle filter) :1148-1262 over function pointers; R_fn and T_fn at the ancestor */
+double orc_nlg_general_ekpf_filter(const orc_nlg_general_psi *mod, unsigned N, const orc_rng *rng, double *alpha, double *weights,
+                                   unsigned *indices) {
+  const orc_nlg_general *b = &mod->base;
+  const int n = b->n, m = b->m, k = b->k, mm = m * m;
+  double um[ORC_MAXM], att1[ORC_MAXM], Ptt1[ORC_MAXM * ORC_MAXM], L[ORC_MAXM * ORC_MAXM];
+  double *nw = (double *)malloc(sizeof(double) * N), *lw = (double *)malloc(sizeof(double) * N), *r = (double *)malloc(sizeof(double) * N);
+  double *atmp = (double *)malloc(sizeof(double) * N * m), *att = (double *)malloc(sizeof(double) * N * m);
+  double *Lp = (double *)malloc(sizeof(double) * N * mm);
+#define GEN_LOG_OBS(t_, xp_, out_) do { double z_, h_; b->Z_fn((t_), (xp_), b->theta, b->known, &z_); \
+    b->H_fn((t_), (xp_), b->theta, b->known, &h_); (out_) = dnorm_sd(b->y[t_], z_, h_); } while (0)
+  gen_ekf_update_step(mod, 0, b->a1, b->P1, att1, Ptt1); /* :1157-1158 */
+  orc_psd_chol(Ptt1, m, L);                                /* :1161 */
+  for (unsigned i = 0; i < N; i++) {
+    rng_normals(rng, 0, 0, i, m, um);
+    for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += L[j + m * c] * um[c]; A_(j, 0, i) = att1[j] + s; }
+  }
+  double loglik = 0.0, inc;
+  if (isfinite(b->y[0])) {
+    for (unsigned i = 0; i < N; i++) {
+      double lo; GEN_LOG_OBS(0, &A_(0, 0, i), lo);
+      lw[i] = lo + dmvnorm_cov(&A_(0, 0, i), b->a1, b->P1, m) - dmvnorm_lwr(&A_(0, 0, i), att1, L, m);
+    }
+    if (!normalise_step(lw, N, weights, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+    loglik = inc;
+  } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
+  for (int t = 0; t < n; t++) {
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    for (unsigned i = 0; i < N; i++) { /* :1212-1227 */
+      double at[ORC_MAXM], Rt[ORC_MAXM * ORC_MAXM], Pt[ORC_MAXM * ORC_MAXM], Ptt[ORC_MAXM * ORC_MAXM];
+      for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
+      b->R_fn(t, atmp + (size_t)m * i, b->theta, b->known, Rt);
+      compute_RR(Rt, m, k, Pt);
+      b->T_fn(t, atmp + (size_t)m * i, b->theta, b->known, at);
+      if (t < n - 1) {
+        gen_ekf_update_step(mod, t + 1, at, Pt, att + (size_t)m * i, Ptt);
+        orc_psd_chol(Ptt, m, Lp + (size_t)mm * i);
+      } else { /* the last, never-weighted slot uses Pt itself as the factor (:1223-1226) */
+        memcpy(att + (size_t)m * i, at, sizeof(double) * m); memcpy(Lp + (size_t)mm * i, Pt, sizeof(double) * mm);
+      }
+    }
+    for (unsigned i = 0; i < N; i++) {
+      rng_normals(rng, 2, t, i, m, um);
+      const double *Li = Lp + (size_t)mm * i;
+      for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += Li[j + m * c] * um[c]; A_(j, t + 1, i) = att[j + (size_t)m * i] + s; }
+    }
+    double *wcol = weights + (size_t)N * (t + 1);
+    if ((t < n - 1) && isfinite(b->y[t + 1])) { /* :1236-1256 */
+      for (unsigned i = 0; i < N; i++) {
+        double mean[ORC_MAXM], Rt[ORC_MAXM * ORC_MAXM], RR[ORC_MAXM * ORC_MAXM], lo;
+        b->R_fn(t, atmp + (size_t)m * i, b->theta, b->known, Rt);
+        compute_RR(Rt, m, k, RR);
+        b->T_fn(t, atmp + (size_t)m * i, b->theta, b->known, mean);
+        GEN_LOG_OBS(t + 1, &A_(0, t + 1, i), lo);
+        lw[i] = lo + dmvnorm_cov(&A_(0, t + 1, i), mean, RR, m) - dmvnorm_lwr(&A_(0, t + 1, i), att + (size_t)m * i, Lp + (size_t)mm * i, m);
+      }
+      if (!normalise_step(lw, N, wcol, 1, nw, &inc)) { loglik = -INFINITY; goto done; }
+      loglik += inc;
+    } else for (unsigned i = 0; i < N; i++) { wcol[i] = 1.0; nw[i] = 1.0 / N; }
+  }
+#undef GEN_LOG_OBS
+done:
+  free(nw); free(lw); free(r); free(atmp); free(att); free(Lp);
+  return loglik;
+}
 #undef GEN_CALL
 
 

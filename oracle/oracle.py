@@ -451,6 +451,39 @@ class OrcNlgSetup(C.Structure):
                 ("iters", C.c_int), ("ok", C.c_int)]
 
 
+def _nlg_general_struct(y, m, k, theta, known, a1, P1, Z_fn, H_fn, T_fn, R_fn, Z_gn, T_gn):
+    """OrcNlgGeneralPsi for Python callbacks + the objects that must stay alive while it is used"""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    th = np.ascontiguousarray(theta, dtype=np.float64); kn = np.ascontiguousarray(known if len(known) else [0.0], dtype=np.float64)
+    a1 = np.ascontiguousarray(a1, dtype=np.float64); P1 = np.asfortranarray(np.asarray(P1, dtype=np.float64).reshape(m, m))
+    nth, nkn = th.size, kn.size
+
+    def wrap(fn, shape):
+        cnt = int(np.prod(shape))
+        def cb(t, al, thp, knp, out):
+            v = fn(t, np.ctypeslib.as_array(al, (m,)).copy(), np.ctypeslib.as_array(thp, (nth,)), np.ctypeslib.as_array(knp, (nkn,)))
+            v = np.asarray(v, dtype=float).reshape(shape).reshape(-1, order="F")
+            for q in range(cnt): out[q] = v[q]
+        return _NLG_FN(cb)
+    cbs = [wrap(Z_fn, (1,)), wrap(H_fn, (1,)), wrap(T_fn, (m,)), wrap(R_fn, (m, k)), wrap(Z_gn, (m,)), wrap(T_gn, (m, m))]
+    base = OrcNlgGeneral(y.size, m, k, _p(y), _p(th), _p(kn), _p(a1), _p(P1), *cbs[:4])
+    return OrcNlgGeneralPsi(base, cbs[4], cbs[5]), [y, th, kn, a1, P1, cbs]
+
+
+def nlg_general_ekpf_filter(y, m, k, theta, known, a1, P1, Z_fn, H_fn, T_fn, R_fn, Z_gn, T_gn, nsim: int, seed=1, stream=0):
+    """ssm_nlg::ekf_filter (EKF-proposal particle filter, src/model_ssm_nlg.cpp:1148-1293) for a model given as Python
+    functions of (t, alpha, theta, known) incl. the observation Jacobian -- same interface as nlg_general_psi"""
+    L = lib()
+    L.orc_nlg_general_ekpf_filter.restype = C.c_double
+    s, keep = _nlg_general_struct(y, m, k, theta, known, a1, P1, Z_fn, H_fn, T_fn, R_fn, Z_gn, T_gn)
+    n = keep[0].size
+    rng, _ = make_rng(seed, stream)
+    alpha = np.zeros((m, n + 1, nsim), order="F"); weights = np.zeros((nsim, n + 1), order="F")
+    indices = np.zeros((nsim, n), dtype=np.uint32, order="F")
+    ll = L.orc_nlg_general_ekpf_filter(C.byref(s), C.c_uint(nsim), C.byref(rng), _p(alpha), _p(weights), indices.ctypes.data_as(c_uint_p))
+    return dict(logLik=float(ll), alpha=alpha, weights=weights, indices=indices)
+
+
 def nlg_general_psi(y, m, k, theta, known, a1, P1, Z_fn, H_fn, T_fn, R_fn, Z_gn, T_gn, nsim: int, seed=1, stream=0, is_mode=None,
                     max_iter=100, conv_tol=1e-8, filter=True):
     """ssm_nlg psi-APF (src/model_ssm_nlg.cpp:62-222 set-up, 854-935 scales / weights, 971-1063 filter) for a model given as

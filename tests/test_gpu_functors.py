@@ -651,3 +651,40 @@ def test_user_model_tv_snippet_without_matrix_is_refused():
     bad = M.BssmModel(u.classes, **{**u, "known_tv_params": None})
     with pytest.raises(Exception, match="known_tv_params"):
         F.particle_smoother(bad, 64, method="psi", seed=1)
+
+
+@pytest.mark.parametrize("path,N", [("wg", 500), ("grid", 3000)])
+@pytest.mark.parametrize("which", ["tv3_full_R", "nonlin4"])
+def test_user_model_ekf_particle_filter_three_and_four_states(oracle, monkeypatch, which, path, N):
+    """EKF-proposal particle filter (src/model_ssm_nlg.cpp:1148-1293) of user models with 3 states (time argument,
+    known_tv_params, full matrix R, full P1) and 4 states: one EKF update per particle from its ancestor with general small
+    factorisations on the device (psd_chol, dmvnorm on covariance / factor) -- against orc_nlg_general_ekpf_filter"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    if which == "tv3_full_R":
+        u, y, th, a1, P1, fns, jac = _tv3_case(seed=61, n=22)
+        m, kn = 3, []
+    else:
+        rng = np.random.default_rng(63)
+        n = 22
+        th, kn = np.array([0.7]), []
+        rd = np.array([0.2, 0.15, 0.3, 0.1]); Hs = 0.5; m = 4
+        a1 = np.zeros(4); P1 = np.diag([0.5, 0.2, 0.3, 0.1])
+        y = np.cumsum(rng.normal(0, 0.3, n)); y[6] = np.nan
+        u = M.ssm_nlg_user(y, USER_NONLIN4, theta=th, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=4)
+
+        def Tg(t, a, th, kn):
+            J = np.zeros((4, 4))
+            J[0, 0] = 1.0; J[0, 1] = 1.0; J[1, 1] = th[0]; J[1, 2] = 0.3 * np.cos(a[2]); J[2, 2] = 0.9; J[2, 3] = 0.2; J[3, 3] = 0.5
+            return J
+        fns = dict(Z_fn=lambda t, a, th, kn: a[0] + 0.5 * a[2] + 0.1 * a[0] * a[0] / (1.0 + a[0] * a[0]),
+                   T_fn=lambda t, a, th, kn: np.array([a[0] + a[1], th[0] * a[1] + 0.3 * np.sin(a[2]), 0.9 * a[2] + 0.2 * a[3], 0.5 * a[3]]),
+                   H_fn=lambda t, a, th, kn: Hs, R_fn=lambda t, a, th, kn: np.diag(rd))
+        jac = dict(Z_gn=lambda t, a, th, kn: np.array([1.0 + 0.2 * a[0] / (1.0 + a[0] * a[0]) ** 2, 0.0, 0.5, 0.0]), T_gn=Tg)
+    ref = oracle.nlg_general_ekpf_filter(y, m, m, th, kn, a1, P1, nsim=N, seed=4, **fns, **jac)
+    out = F.particle_smoother(u, N, method="ekf", seed=4, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * y.size
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
+    mean, cov = oracle.summary(sm)
+    assert _rel(out["alphahat"], mean.T[:y.size]) <= 1e-8

@@ -111,6 +111,12 @@ def test_general_callback_psi_oracle_is_pinned(oracle):
     assert np.array_equal(gen2["indices"], ref2["indices"]) and abs(gen2["logLik"] - ref2["logLik"]) <= 1e-11 * n
     assert gen2["approx_loglik"] == 0.0 and np.all(gen2["scales"] == 0.0)  # the IS driver's state (src/approx_mcmc.cpp:372-373)
     assert np.allclose(gen2["weights"], ref2["weights"], rtol=1e-10, atol=1e-14)
+    # the EKF-proposal particle filter over the same callbacks (orc_nlg_general_ekpf_filter) against the functor restatement
+    # (pinned by the EKPF rows of the reference's published study)
+    ek = oracle.fn_ekpf_filter(model, 250, seed=7)
+    gek = oracle.nlg_general_ekpf_filter(y, 2, 2, th, kn, [kn[2], kn[3]], np.diag([kn[4], kn[5]]), nsim=250, seed=7, **_growth_callbacks())
+    assert np.array_equal(gek["indices"], ek["indices"]) and abs(gek["logLik"] - ek["logLik"]) <= 1e-11 * n
+    assert np.allclose(gek["weights"], ek["weights"], rtol=1e-10, atol=1e-14)
 
 
 @pytest.mark.gpu
