@@ -34,10 +34,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # fp64 VALU issue roof: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles (16 lanes per clock) at 2.4 GHz
 VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 # wave-level VALU instructions per particle-step of the workgroup-resident kernels, from the PMC passes committed under
-# profiles/r02_pmc_other_kernels.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_others.sh)
-REGB_VALU_PER_PSTEP = 10628740724.8 / (512 * 2048 * 1000.0)   # pf_wg_kernel<4,4,4,false,512>
-C5_VALU_PER_PSTEP = 3939823392.2 / (468.0 * 4096 * 300.0)     # pf_wg_kernel<2,2,4,1,1024,1> (nlg_growth, psi-APF), dispatches of 468 draws (profiles/r03_pmc_C5.txt)
-C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1>"
+# profiles/r03_pmc_*.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_r03.sh, profile_r03_wg.sh)
+REGB_VALU_PER_PSTEP = 9940959411.4 / (512 * 2048 * 1000.0)    # pf_wg_kernel<4,4,4,false,512> (profiles/r03_pmc_regb.txt)
+C5_VALU_PER_PSTEP = 3625005408.2 / (468.0 * 4096 * 300.0)     # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), dispatches of 468 draws (profiles/r03_pmc_C5.txt)
+C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1,exact>"
 C4_VALU_PER_PSTEP = 7137180.9 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r03_pmc_C4.txt)
 
 
@@ -46,7 +46,7 @@ def valu_roofline(valu_per_pstep, psteps_per_s, kernel):
     return {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
             "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
             "lane_instr_per_particle_step": valu_per_pstep * 64,
-            "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r03_pmc_C4.txt, r03_pmc_C5.txt; regime B: r02_pmc_other_kernels.txt); rate: measured live"}
+            "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r03_pmc_C4.txt, r03_pmc_C5.txt, r03_pmc_regb.txt); rate: measured live"}
 
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
