@@ -283,3 +283,17 @@ def test_series_at_a_time_smoother_equals_matrix_form(monkeypatch):
         for k in ("scales", "approx_y", "approx_H"):
             ok = np.isfinite(a[k])
             assert np.array_equal(a[k][ok], b[k][ok]), (name, k)
+
+
+def test_bench_gpus_flag_is_not_silently_ignored_without_gpus():
+    """bench.py --gpus N outside a launcher starts N ranks itself (one per GPU); on a box without that many GPUs it must stop
+    with a clear message instead of printing a one-GPU line labelled n_gpus: 1 (the round-2 behaviour)"""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BSSM_BENCH_BACKEND")}
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                        env=env, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert cp.returncode != 0
+        assert "one rank per GPU" in (cp.stderr + cp.stdout)
+        assert not any(ln.startswith("{") for ln in cp.stdout.splitlines())
