@@ -1780,9 +1780,25 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
   (void)hipGetDevice(&dev);
   // Chunk = two rounds of one workgroup per CU, but never fewer than four chunks per call: a shard of a few hundred
   // draws (eight ranks on a 2 340-draw job) would otherwise be ONE chunk and lose the set-up / filter overlap.
+  // With the set-up of a chunk as ONE device kernel and next to no per-draw host work (chunk_hint = -1) that rule is
+  // wrong: the kernel's latency does not depend on the chunk size (one lane per draw, ~4.6 ms on the C5 shape) and nothing on
+  // the host needs hiding, so every chunk boundary only costs: a filter launch cannot start before the previous one has
+  // drained, and a launch of fewer workgroups than CUs leaves the rest of the chip idle.  Calls of up to 4 096 draws
+  // therefore go as ONE chunk (the dispatcher keeps every CU busy until the last workgroup), longer calls in chunks of 4 096
+  // (bounded tables in memory, the next chunk's set-up kernel under this chunk's filters).  Measured: C5 (2 340 draws) 57.1 ->
+  // 49.3 ms against chunks of 512; the 8 x job (18 720 draws) 434-470 ms at 512, 395 at 1 024, 359 at 2 048, 340 at 4 096, 338 at
+  // 9 360 (profiles/r03_c5_large_chunks.txt).
+  // Shards of the C5 job as N ranks would see them (scripts/c5_shard_probe.py, profiles/r03_c5_shard_probe.txt).
   int chunk = 512;
   if (const char* env = std::getenv("BSSM_AMD_IS_CHUNK")) chunk = std::max(1, std::atoi(env));
   else if (chunk_hint > 0) chunk = chunk_hint;
+  else if (chunk_hint == -1) {  // (the ssm_nlg path: packing a draw on the host is a memcpy of theta)
+    hipDeviceProp_t prop;
+    const int cus = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    (void)cus;
+    chunk = std::min(cnt, 4096);
+    if (const char* env = std::getenv("BSSM_AMD_IS_BIG_CHUNK")) { if (cnt > 4096) chunk = std::max(64, std::atoi(env)); }  // measurement option
+  }
   else if (cnt < 4 * chunk) chunk = std::max(64, ((cnt + 3) / 4 + 63) / 64 * 64);
   std::vector<std::string> errs(cnt);
   // ONE device thread for the whole call (it only waits on HIP): chunks are handed over through a queue, so its
@@ -2131,7 +2147,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       J.chunk_tabs[lo] = ct;
       return 0;
     };
-    return run_is_pipeline(J, count, n_threads, prepare, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk, nullptr);
+    return run_is_pipeline(J, count, n_threads, prepare, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk, nullptr, -1);
   }
   if (psi) { const size_t mp = (size_t)bssm::pad_dim(m); J.amats.assign((size_t)count * n * (mp * mp + mp), 0.0); }
   const bool dev_setup = psi && device_setup_enabled(n_threads) && have_device();
