@@ -36,7 +36,7 @@ VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 # wave-level VALU instructions per particle-step of the workgroup-resident kernels, from the PMC passes committed under
 # profiles/r03_pmc_*.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_r03.sh, profile_r03_wg.sh)
 REGB_VALU_PER_PSTEP = 9940959411.4 / (512 * 2048 * 1000.0)    # pf_wg_kernel<4,4,4,false,512> (profiles/r03_pmc_regb.txt)
-C5_VALU_PER_PSTEP = 3625005408.2 / (468.0 * 4096 * 300.0)     # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), dispatches of 468 draws (profiles/r03_pmc_C5.txt)
+C5_VALU_PER_PSTEP = 18125027041.0 / (2340.0 * 4096 * 300.0)   # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), one dispatch of 2 340 draws (profiles/r03_pmc_C5.txt)
 C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1,exact>"
 C4_VALU_PER_PSTEP = 7137180.9 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r03_pmc_C4.txt)
 
