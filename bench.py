@@ -24,6 +24,7 @@ Extra objects in the JSON line:
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -38,15 +39,63 @@ VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 REGB_VALU_PER_PSTEP = 9940959411.4 / (512 * 2048 * 1000.0)    # pf_wg_kernel<4,4,4,false,512> (profiles/r03_pmc_regb.txt)
 C5_VALU_PER_PSTEP = 18125027041.0 / (2340.0 * 4096 * 300.0)   # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), one dispatch of 2 340 draws (profiles/r03_pmc_C5.txt)
 C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1,exact>"
+HEAD_VALU_PER_PSTEP = 8360000.0 / (16 * 65536.0)                # pf_grid_step_v2<4,4,4,false,true,true>: 8.36 M per launch of 16 filters x 65 536 particles (profiles/r03_pmc_sq1_summary.txt)
 C4_VALU_PER_PSTEP = 7137180.9 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r03_pmc_C4.txt)
 
 
-def valu_roofline(valu_per_pstep, psteps_per_s, kernel):
+def valu_roofline(valu_per_pstep, psteps_per_s, kernel, clock=None):
     a = valu_per_pstep * psteps_per_s
-    return {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
-            "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
-            "lane_instr_per_particle_step": valu_per_pstep * 64,
-            "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r03_pmc_C4.txt, r03_pmc_C5.txt, r03_pmc_regb.txt); rate: measured live"}
+    out = {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
+           "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
+           "lane_instr_per_particle_step": valu_per_pstep * 64,
+           "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r03_pmc_sq1_summary.txt, r03_pmc_C4.txt, r03_pmc_C5.txt, r03_pmc_regb.txt); rate: measured live"}
+    if clock and clock.get("sclk_mhz"):
+        # the issue roof at the engine clock the kernel actually ran at (the socket power limit holds it under 2.4 GHz)
+        out["frac_at_sampled_clock"] = a / (256 * 4 * clock["sclk_mhz"] * 1e6 / 4)
+    return out
+
+
+def clock_power_while(run_once, samples=3):
+    """Engine clock (MHz) and socket power (W) read through rocm-smi while `run_once` repeats on another thread: the median of
+    `samples` readings, the first one after a second of load.  Outside every timed region; None where rocm-smi is missing."""
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    stop = threading.Event()
+
+    def load():
+        k = 0
+        while not stop.is_set():
+            run_once(k)
+            k += 1
+
+    th = threading.Thread(target=load, daemon=True)
+    th.start()
+    got = []
+    try:
+        time.sleep(1.0)
+        for _ in range(samples):
+            try:
+                txt = subprocess.run([exe, "-d", os.environ.get("LOCAL_RANK", "0"), "--showclocks", "--showpower"],
+                                     capture_output=True, text=True, timeout=20).stdout
+            except Exception:  # noqa: BLE001
+                continue
+            ck = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", txt)
+            pw = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+            if ck:
+                got.append((float(ck.group(1)), float(pw.group(1)) if pw else float("nan")))
+    finally:
+        stop.set()
+        th.join()
+    if not got:
+        return None
+    got.sort()
+    mid = got[len(got) // 2]
+    return {"sclk_mhz": mid[0], "socket_power_w": mid[1], "samples": [list(g) for g in got],
+            "source": "rocm-smi --showclocks --showpower, sampled while the same plan repeats on another thread (outside the timed region)"}
 
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -298,6 +347,7 @@ def main():
     ap.add_argument("--reference-weights-layout", action="store_true",
                     help="keep the weights output as exp(w - max_t) (what the drop-in entry points return) instead of the factored layout")
     ap.add_argument("--no-mng", action="store_true")
+    ap.add_argument("--no-clock", action="store_true", help="skip the rocm-smi clock / power samples under load")
     ap.add_argument("--pc-draws", type=int, default=2340, help="retained draws of the post_correct job (C5: 2340)")
     args = ap.parse_args()
 
@@ -418,6 +468,12 @@ def main():
                            "achieved_note": "concurrent_launches x algorithmic_bytes_per_launch / avg_launch_us: the launches "
                                             "of the two sequences overlap in time, each lasting avg_launch_us",
                            "frac_of_measured_copy_6290GBs": achieved / 6290.0}
+        if world == 1 and not args.no_clock:
+            ck = clock_power_while(lambda k: (plan.run(5000 + k, stream0=0, hip_stream=stream), torch.cuda.synchronize()))
+            torch.cuda.synchronize()
+            out["roofline"]["clock_power_under_load"] = ck
+            out["roofline"]["valu"] = valu_roofline(HEAD_VALU_PER_PSTEP, seqs * (R // seqs) * float(N) / (k_ms * 1e-3),
+                                                    "pf_grid_step_v2<4,4,4,false,true,true>", ck) if ppt == 4 and m == 4 and layout["factored"] else None
     plan.close()
 
     if rank == 0 and world == 1 and R != 1 and not args.no_single:
@@ -483,6 +539,11 @@ def main():
                          "weights_layout_factored": pm.weights_layout()["factored"], "launch_sequences": pm.launch_sequences(),
                          "algorithmic_GBs": psm * 152 / em / 1e9, "frac_of_8TBs": psm * 152 / em / 8e12,
                          "roofline_valu": valu_roofline(C4_VALU_PER_PSTEP, psm / em, "pf_grid_step_v2<8,8,2,true,true,true>")}
+        if not args.no_clock:
+            ckm = clock_power_while(lambda k: (pm.run(5000 + k, hip_stream=stream), torch.cuda.synchronize()), samples=2)
+            torch.cuda.synchronize()
+            out["mng_c4"]["clock_power_under_load"] = ckm
+            out["mng_c4"]["roofline_valu"] = valu_roofline(C4_VALU_PER_PSTEP, psm / em, "pf_grid_step_v2<8,8,2,true,true,true>", ckm)
         pm.close()
         _L.lib().bssm_amd_trim_cache()
 
