@@ -871,6 +871,7 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states = 4) 
       }
     }
     f->user = &h;
+    f->k = ks;
     f->uH = mod->H;
     for (int q = 0; q < 16; q++) f->uRm[q] = 0.0;
     if (Rsrc) { for (int c = 0; c < ks; c++) for (int j = 0; j < ms; j++) f->uRm[j + ms * c] = Rsrc[j + ms * c]; }  // m x k, zero columns behind
@@ -1340,6 +1341,8 @@ int bssm_user_model_load(const char* lib_path) {
   g_user_host[slot].Tg = (decltype(bssm::UserHostFns::Tg))dlsym(h, "bssm_user_host_Tg");
   g_user_host[slot].Zg = (decltype(bssm::UserHostFns::Zg))dlsym(h, "bssm_user_host_Zg");
   if (auto has_tv = (int (*)())dlsym(h, "bssm_user_host_has_tv")) g_user_host[slot].has_tv = has_tv();
+  g_user_host[slot].H = (decltype(bssm::UserHostFns::H))dlsym(h, "bssm_user_host_H");
+  g_user_host[slot].R = (decltype(bssm::UserHostFns::R))dlsym(h, "bssm_user_host_R");
   g_user_loaded[lib_path] = slot;
   return slot;
 }
@@ -1552,7 +1555,8 @@ struct IsCore {
   const uint32_t* counts = nullptr;
   std::vector<bssm::FilterTables> tabs;
   std::vector<double> fpar;    // FP_SIZE per draw, or empty
-  std::vector<double> amats;   // per draw n * (m*m + m), or empty
+  std::vector<double> amats;   // per draw n approximating rows (fn_amats_row doubles each), or empty
+  int count_draws = 1;         // draws the amats slots were laid out for
   std::vector<double> const_add, sub;
   std::vector<char> bad;
 };
@@ -1645,7 +1649,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         db.fb.fn_id = (int)J.fpar[bssm::FP_ID];
       }
       if (!ctabs && !J.amats.empty()) {
-        const size_t mp = (size_t)bssm::pad_dim(m), as = (size_t)n * (mp * mp + mp);
+        const size_t as = J.amats.size() / (size_t)J.count_draws;  // per-draw slot: n approximating rows (host_model.h: fn_amats_row)
         HIP_TRY(st_amat.alloc(F * as * sizeof(double)));
         double* hb = (double*)st_amat.p;
         for (size_t f = 0; f < F; f++) std::memcpy(hb + f * as, J.amats.data() + (size_t)order[pos + f] * as, as * sizeof(double));
@@ -2149,7 +2153,10 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
     };
     return run_is_pipeline(J, count, n_threads, prepare, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk, nullptr, -1);
   }
-  if (psi) { const size_t mp = (size_t)bssm::pad_dim(m); J.amats.assign((size_t)count * n * (mp * mp + mp), 0.0); }
+  // (a user snippet with a state-dependent R_fn carries R_t R_t' in its approximating rows: fn_amats_row)
+  const bool user_rfn = models[0].model_id == bssm::FN_USER_NLG && models[0].user_slot >= 1 && models[0].user_slot <= 63 && g_user_host[models[0].user_slot].R;
+  const size_t am_stride = (size_t)n * (size_t)bssm::fn_amats_row(bssm::pad_dim(m), user_rfn);  // per-draw slot of J.amats
+  if (psi) { J.amats.assign((size_t)count * am_stride, 0.0); J.count_draws = count; }
   const bool dev_setup = psi && device_setup_enabled(n_threads) && have_device();
   std::vector<bssm::FnModel> fms(dev_setup ? count : 0);
   std::vector<bssm::FnSetup> fsus(dev_setup ? count : 0);
@@ -2164,10 +2171,9 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
     const size_t mp = (size_t)bssm::pad_dim(m);
     J.tabs[i].MP = (int)mp; J.tabs[i].KP = (int)mp;
     J.tabs[i].mats.assign((size_t)n * (mp * mp * 2 + mp), 0.0); J.tabs[i].mats_tstride = (int)(mp * mp * 2 + mp);
-    am->assign((size_t)n * (mp * mp + mp), 0.0);
+    am->assign(am_stride, 0.0);
     return true;
   };
-  const size_t am_stride = (size_t)n * ((size_t)bssm::pad_dim(m) * bssm::pad_dim(m) + bssm::pad_dim(m));  // per-draw slot of J.amats
   auto store_amats = [&](int i, const std::vector<double>& am) -> std::string {
     if (am.size() != am_stride) return "internal: approximating rows of unexpected size";
     std::memcpy(J.amats.data() + (size_t)i * am_stride, am.data(), am_stride * sizeof(double));

@@ -1198,6 +1198,31 @@ bool fn_full_cov(const FnModel& f) {
   return false;
 }
 
+// H_fn / R_fn at a state (src/model_ssm_nlg.h:12-13): the snippet's functions where it defines them, the model's numbers otherwise
+double fnH_at(const FnModel& f, const double* x, int t) {
+  if (f.id == 7 && f.user && f.user->H) return f.user->H(t, f.known_tv, f.tv_rows, f.tv_cols, x, f.theta, f.known);
+  return fnH(f);
+}
+void fnRmat_at(const FnModel& f, const double* x, int t, double* Rm) {  // m x m, zero columns behind k
+  if (f.id == 7 && f.user && f.user->R) {
+    const int m = f.m;
+    double Ru[16] = {0};
+    f.user->R(t, f.known_tv, f.tv_rows, f.tv_cols, x, f.theta, f.known, Ru);  // m x k, leading dimension m
+    for (int q = 0; q < m * m; q++) Rm[q] = 0.0;
+    for (int c = 0; c < f.k && c < m; c++) for (int j = 0; j < m; j++) Rm[j + m * c] = Ru[j + m * c];
+    return;
+  }
+  fnRmat(f, Rm);
+}
+void small_rrt(int m, const double* Rm, double* RR) {
+  for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double sacc = 0; for (int q = 0; q < m; q++) sacc += Rm[i + m * q] * Rm[j + m * q]; RR[i + m * j] = sacc; }
+}
+void fnRR_at(const FnModel& f, const double* x, int t, double* RR) { double Rm[16]; fnRmat_at(f, x, t, Rm); small_rrt(f.m, Rm, RR); }
+// the approximating model's observation sd per time point
+void fn_approx_H(const FnModel& f, const FnSetup& su, std::vector<double>* H) {
+  if (f.state_noise()) *H = su.Ht; else H->assign(f.n, su.H);
+}
+
 void fn_linearise(const FnModel& f, const double* zpts, const double* tpts, FnSetup* su) {
   const int n = f.n, m = f.m;
   for (int t = 0; t < n; t++) {
@@ -1212,6 +1237,13 @@ void fn_linearise(const FnModel& f, const double* zpts, const double* tpts, FnSe
   su->H = fnH(f);
   std::memset(su->R, 0, sizeof(su->R));
   fnRmat(f, su->R);
+  if (f.state_noise()) {  // H at the points Z is linearised at, R at the points T is (src/model_ssm_nlg.cpp:100-107, 162-169, 194-203)
+    su->Ht.assign(n, 0.0); su->Rt.assign((size_t)m * m * n, 0.0);
+    for (int t = 0; t < n; t++) {
+      su->Ht[t] = fnH_at(f, zpts + (size_t)m * t, t);
+      fnRmat_at(f, tpts + (size_t)m * t, t, su->Rt.data() + (size_t)m * m * t);
+    }
+  }
 }
 // the approximating Gaussian model as a HostModel the Kalman routines understand
 void fn_gaussian_model(const FnModel& f, const FnSetup& su, HostModel* g) {
@@ -1223,6 +1255,7 @@ void fn_gaussian_model(const FnModel& f, const FnSetup& su, HostModel* g) {
   g->a1.assign(m, 0.0); g->P1.assign((size_t)m * m, 0.0);
   fn_a1P1(f, g->a1.data(), g->P1.data());
   g->xbeta.assign(n, 0.0); g->u.assign(n, 1.0); g->H.assign(1, su.H);
+  if (f.state_noise()) { g->Rtv = 1; g->R = su.Rt; }  // (the observation sd per time point travels in Approx::H: fn_approx_H)
 }
 double fn_log_signal_pdf(const FnModel& f, const double* al) {  // src/model_ssm_nlg.cpp:1295-1319
   const int n = f.n, m = f.m;
@@ -1231,13 +1264,15 @@ double fn_log_signal_pdf(const FnModel& f, const double* al) {  // src/model_ssm
   const bool full = fn_full_cov(f);
   if (full) fnRR(f, RR);
   for (int j = 0; j < m; j++) { pv[j] = P1[j + m * j]; rv[j] = rd[j] * rd[j]; }
-  double ll = full ? dmvnorm_cov4(al, a1, P1, m) : dmvnorm_diag(al, a1, pv, m);
-  if (std::isfinite(f.y[0])) ll += dnorm_sd(f.y[0], fnZ(f, al, 0), fnH(f));
+  const bool sn = f.state_noise();
+  double ll = (full || sn) ? dmvnorm_cov4(al, a1, P1, m) : dmvnorm_diag(al, a1, pv, m);
+  if (std::isfinite(f.y[0])) ll += dnorm_sd(f.y[0], fnZ(f, al, 0), fnH_at(f, al, 0));
   for (int t = 0; t < n - 1; t++) {
     double mean[4];
     fnT(f, al + (size_t)m * t, mean, t);
-    ll += full ? dmvnorm_cov4(al + (size_t)m * (t + 1), mean, RR, m) : dmvnorm_diag(al + (size_t)m * (t + 1), mean, rv, m);
-    if (std::isfinite(f.y[t + 1])) ll += dnorm_sd(f.y[t + 1], fnZ(f, al + (size_t)m * (t + 1), t + 1), fnH(f));
+    if (sn) { fnRR_at(f, al + (size_t)m * t, t, RR); ll += dmvnorm_cov4(al + (size_t)m * (t + 1), mean, RR, m); }
+    else ll += full ? dmvnorm_cov4(al + (size_t)m * (t + 1), mean, RR, m) : dmvnorm_diag(al + (size_t)m * (t + 1), mean, rv, m);
+    if (std::isfinite(f.y[t + 1])) ll += dnorm_sd(f.y[t + 1], fnZ(f, al + (size_t)m * (t + 1), t + 1), fnH_at(f, al + (size_t)m * (t + 1), t + 1));
   }
   return ll;
 }
@@ -1254,13 +1289,15 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
   const int n = f.n, m = f.m, mm = m * m;
   std::vector<double> Pt((size_t)mm * (n + 1), 0.0), Ptt((size_t)mm * n, 0.0);
   at->assign((size_t)m * (n + 1), 0.0); att->assign((size_t)m * n, 0.0);
-  double RRf[16]; const double H = fnH(f);
+  double RRf[16]; double H = fnH(f);
+  const bool sn = f.state_noise();
   fnRR(f, RRf);  // (diagonal R: exactly diag(r_i * r_i))
   fn_a1P1(f, at->data(), Pt.data());
   for (int t = 0; t < n; t++) {
     const double* a = at->data() + (size_t)m * t; const double* P = Pt.data() + (size_t)mm * t;
     double* af = att->data() + (size_t)m * t; double* Pf = Ptt.data() + (size_t)mm * t;
     if (std::isfinite(f.y[t])) {
+      if (sn) H = fnH_at(f, a, t);  // H_fn at the predicted state (:311)
       double Zg[4], PZ[4] = {0, 0, 0, 0}, K[4], F = H * H;
       fnZg(f, a, Zg, t);
       for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += P[i + m * j] * Zg[j];
@@ -1278,6 +1315,7 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
     fnT(f, af, at->data() + (size_t)m * (t + 1), t);
     fnTg(f, af, Tg, t);
     double Pn[16];
+    if (sn) fnRR_at(f, af, t, RRf);  // R_fn at the filtered state (:366-370)
     small_abat(m, Tg, Pf, Pn);
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = Pn[i + m * j] + RRf[i + m * j];
   }
@@ -1307,7 +1345,7 @@ void fn_ekpf_init(const FnModel& f, double* a1, double* P1, double* att1, double
   if (std::isfinite(y)) {  // ekf_update_step (:1264-1293)
     double Zg[4] = {0, 0, 0, 0}, PZ[4] = {0, 0, 0, 0}, K[4];
     fnZg(f, a1, Zg, 0);
-    const double H = fnH(f);
+    const double H = fnH_at(f, a1, 0);
     double F = H * H;
     for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += P1[i + m * j] * Zg[j];
     for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
@@ -1348,7 +1386,7 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
   double gll_last = 0.0; bool have_gll = false;  // Gaussian log-likelihood of the model the LAST smoother pass ran on
   auto smooth_mode = [&](std::vector<double>* out) {
     fn_gaussian_model(f, *su, &g);
-    ap.H.assign(n, su->H);
+    fn_approx_H(f, *su, &ap.H);
     const Sys S(g);
     double gl = std::nan("");
     if (!fast_smoother(S, ap, &sm, &gl)) return false;
@@ -1387,7 +1425,7 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
       gll = gll_last;
     } else {
       fn_gaussian_model(f, *su, &g);
-      ap.H.assign(n, su->H);
+      fn_approx_H(f, *su, &ap.H);
       const Sys S(g);
       gll = gaussian_loglik(S, ap);
     }
@@ -1397,13 +1435,14 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
     const bool full = fn_full_cov(f);
     if (full) fnRR(f, RRs);
     for (int j = 0; j < m; j++) rv[j] = rd[j] * rd[j];
-    const double HH = su->H * su->H;
+    const bool sn = f.state_noise();
     for (int t = 0; t < n; t++) {
       const double* md = su->mode.data() + (size_t)m * t;
       if (std::isfinite(f.y[t])) {
         double am = su->D[t];
         for (int j = 0; j < m; j++) am += su->Z[j + (size_t)m * t] * md[j];
-        su->scales[t] = dnorm_sd(f.y[t], fnZ(f, md, t), fnH(f)) - dmvnorm_diag(&f.y[t], &am, &HH, 1);
+        const double Ha = sn ? su->Ht[t] : su->H, HH = Ha * Ha;
+        su->scales[t] = dnorm_sd(f.y[t], fnZ(f, md, t), fnH_at(f, md, t)) - dmvnorm_diag(&f.y[t], &am, &HH, 1);
       }
     }
     for (int t = 1; t < n; t++) {
@@ -1411,6 +1450,12 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
       double mean[4], amean[4];
       fnT(f, mp, mean, t - 1);
       for (int i = 0; i < m; i++) { double sacc = 0; for (int j = 0; j < m; j++) sacc += su->T[i + m * j + (size_t)mm * (t - 1)] * mp[j]; amean[i] = su->C[i + (size_t)m * (t - 1)] + sacc; }
+      if (sn) {  // the model's R at the previous mode point against the approximating R_{t-1} (:869-876)
+        double RRm[16], RRa[16];
+        fnRR_at(f, mp, t - 1, RRm);
+        small_rrt(m, su->Rt.data() + (size_t)mm * (t - 1), RRa);
+        su->scales[t] += dmvnorm_cov4(md, mean, RRm, m) - dmvnorm_cov4(md, amean, RRa, m);
+      } else
       su->scales[t] += full ? dmvnorm_cov4(md, mean, RRs, m) - dmvnorm_cov4(md, amean, RRs, m) : dmvnorm_diag(md, mean, rv, m) - dmvnorm_diag(md, amean, rv, m);
     }
     double ssc = 0; for (double v : su->scales) ssc += v;
@@ -1418,7 +1463,7 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
   }
   if (loglik_only) return true;  // the approximate chain needs the mode and the log-likelihood only
   fn_gaussian_model(f, *su, &g);
-  ap.H.assign(n, su->H);
+  fn_approx_H(f, *su, &ap.H);
   {
     bool fok = true;
     if (lg_fast_path(g, ap, &su->alphahat, &su->Vt, &su->Ct, &fok)) { su->ok = fok; return fok; }
@@ -1447,7 +1492,7 @@ bool fn_psi_setup_begin(const FnModel& f, const double* is_mode, FnSetup* su, Lg
   fn_gaussian_model(f, *su, &g);
   Approx ap;
   ap.y = f.y;
-  ap.H.assign(n, su->H);
+  fn_approx_H(f, *su, &ap.H);
   lg_pack(g, ap, lg);
   return true;
 }
@@ -1471,17 +1516,26 @@ void build_fn_psi_tables(const FnModel& f, const FnSetup& su, FilterTables* ft, 
     if (!std::isfinite(f.y[t])) continue;
     row[RH_FLAG] = 1.0; row[RH_SCALE] = su.scales[t];
     double* ob = row + ROW_HDR;
-    ob[OB_FLAG] = 1.0; ob[OB_Y] = f.y[t]; ob[OB_D] = su.D[t]; ob[OB_PSIIH] = 1.0 / su.H;
+    ob[OB_FLAG] = 1.0; ob[OB_Y] = f.y[t]; ob[OB_D] = su.D[t]; ob[OB_PSIIH] = 1.0 / (f.state_noise() ? su.Ht[t] : su.H);
     for (int c = 0; c < m; c++) ob[SER_HDR + c] = su.Z[c + (size_t)m * t];
   }
   ft->init.assign((size_t)MP + (size_t)MP * MP, 0.0);
   for (int j = 0; j < m; j++) ft->init[j] = su.alphahat[j];
   for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) ft->init[MP + j + MP * c] = su.Vt[j + m * c];
-  amats->assign((size_t)n * (MP * MP + MP), 0.0);
+  // a snippet with an R_fn carries the approximating R_t R_t' behind (T_t, C_t): the row the kernels of ITS library step by
+  // (pf_functors.h: fn_amat_row)
+  const bool rfn = f.id == 7 && f.user && f.user->R;
+  const int AR = fn_amats_row(MP, rfn);
+  amats->assign((size_t)n * AR, 0.0);
   for (int t = 0; t < n; t++) {
-    double* am = amats->data() + (size_t)t * (MP * MP + MP);
+    double* am = amats->data() + (size_t)t * AR;
     for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) am[j + MP * c] = su.T[j + m * c + (size_t)mm * t];
     for (int j = 0; j < m; j++) am[MP * MP + j] = su.C[j + (size_t)m * t];
+    if (rfn) {
+      double RRa[16];
+      small_rrt(m, su.Rt.data() + (size_t)mm * t, RRa);
+      for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) am[MP * MP + MP + j + MP * c] = RRa[j + m * c];
+    }
   }
 }
 

@@ -119,10 +119,15 @@ struct UserHostFns {
   double (*Z)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known) = nullptr;
   void (*Tg)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known, double* out) = nullptr;  // m x m column-major
   void (*Zg)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known, double* out) = nullptr;  // m
+  // the reference's state-dependent H_fn / R_fn (src/model_ssm_nlg.h:12-13), exported by snippets with BSSM_USER_HFN / BSSM_USER_RFN:
+  // the observation sd at a state, and the m x k matrix R at a state (column-major, leading dimension m)
+  double (*H)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known) = nullptr;
+  void (*R)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known, double* out) = nullptr;
   int has_tv = 0;  // the snippet was compiled with BSSM_USER_TV
 };
 struct FnModel {
   int id = 0, n = 0, m = 1;
+  int k = 1;  // noise terms (columns of R); read for user models with an R_fn only
   std::vector<double> y;
   double theta[8] = {0}, known[8] = {0};
   double x0 = 0;
@@ -133,10 +138,13 @@ struct FnModel {
   double uRm[16] = {0};  // the full constant R (m x m, column-major, unpadded) of a user model; uR is its diagonal
   const double* known_tv = nullptr;  // known_tv_params (host), tv_rows x tv_cols column-major: passed to BSSM_USER_TV snippets with t
   int tv_rows = 0, tv_cols = 0;
+  // H or R depends on the state: the approximating model then has H_t = H_fn(mode_t), R_t = R_fn(mode_t) per time point
+  bool state_noise() const { return id == 7 && user && (user->H || user->R); }
 };
 struct FnSetup {
   std::vector<double> Z, T, D, C;   // m x n, m x m x n, n, m x n : the mode-linearised model
   double H = 1, R[16] = {0};
+  std::vector<double> Ht, Rt;       // models with state-dependent noise: H_t (n) and R_t (m x m x n, zero columns behind k); else empty
   std::vector<double> mode, scales;
   double approx_loglik = 0;
   std::vector<double> alphahat, Vt, Ct;
@@ -150,6 +158,9 @@ bool fn_psi_setup_begin(const FnModel& mod, const double* is_mode, FnSetup* out,
 // psi proposal operands (as build_psi_tables), observation rows carrying the approximating D_t / Z_t / 1/H / scales,
 // and the approximating (T_t, C_t) rows used by the transition-density ratio
 void build_fn_psi_tables(const FnModel& mod, const FnSetup& su, FilterTables* ft, std::vector<double>* amats);
+// doubles per time point of the approximating rows: T_t (MP x MP), C_t (MP), and for a user snippet with a state-dependent R_fn
+// the approximating R_t R_t' (MP x MP) -- must match fn_amat_row<MP>() of the kernels compiled with that snippet
+inline int fn_amats_row(int MP, bool user_rfn) { return MP * MP + MP + (user_rfn ? MP * MP : 0); }
 void fn_a1P1(const FnModel& mod, double* a1, double* P1 /* m x m */);
 // EKF particle filter: prior (a1, P1) and the initial proposal (att1, lower factor L1), src/model_ssm_nlg.cpp:1154-1161
 void fn_ekpf_init(const FnModel& mod, double* a1, double* P1, double* att1, double* L1);

@@ -499,8 +499,8 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
           }
         }
       }
-      if constexpr (kPsiFn) w[r] = (i < N) ? (t + 1 < n ? functor_psi_weight<MP, FID>(as_uniform_table(fpar), as_uniform_table(ob), as_uniform_table(amats + (size_t)t * (MP * MP + MP)), t + 1, x, a[r]) : 0.0) : -INFINITY;
-      else w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)t * (MP * MP + MP), t + 1, x, a[r]) : 0.0) : -INFINITY;
+      if constexpr (kPsiFn) w[r] = (i < N) ? (t + 1 < n ? functor_psi_weight<MP, FID>(as_uniform_table(fpar), as_uniform_table(ob), as_uniform_table(amats + (size_t)t * fn_amat_row<MP>()), t + 1, x, a[r]) : 0.0) : -INFINITY;
+      else w[r] = (i < N) ? (t + 1 < n ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)t * fn_amat_row<MP>(), t + 1, x, a[r]) : 0.0) : -INFINITY;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -998,7 +998,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = r * GRID_NT + tid;
-    w[r] = (li < len) ? (have_obs ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)(t < 0 ? 0 : t) * (MP * MP + MP), tn, x[r], aprev[FN ? r : 0]) : 0.0) : -INFINITY;
+    w[r] = (li < len) ? (have_obs ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)(t < 0 ? 0 : t) * fn_amat_row<MP>(), tn, x[r], aprev[FN ? r : 0]) : 0.0) : -INFINITY;
     mx = fmax(mx, w[r]);
   }
   BSSM_STAMP(8)

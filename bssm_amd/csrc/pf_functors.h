@@ -32,7 +32,8 @@ __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || i
 //                  double bssm_user_log_obs(double y, double x, const double* theta);   normalised log-density of y | x
 // H (observation sd), R, a1 and P1 are state-independent numbers the caller passes with the model -- unless the snippet
 // supplies the reference's state-dependent H_fn / R_fn (src/model_ssm_nlg.h:12-13; evaluated at the particle for the
-// observation density and at the ANCESTOR for the transition, src/model_ssm_nlg.cpp:952, 1125):
+// observation density and at the ANCESTOR for the transition, src/model_ssm_nlg.cpp:952, 1125; in the psi-APF weight and the
+// EKF proposal too, :892-932, 1212-1256):
 //   BSSM_USER_HFN: double bssm_user_H(const double* alpha, const double* theta, const double* known);   observation sd
 //   BSSM_USER_RFN: void bssm_user_R(alpha, theta, known, double* out /* m x k, column-major */);         R_fn
 //   BSSM_USER_TV:  the reference's time argument and `known_tv_params` matrix (src/model_ssm_nlg.h:10-21: every function is
@@ -42,7 +43,7 @@ __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || i
 //                  matrix, column-major, tv.rows x tv.cols, exactly as the caller handed it over.
 // The state may have up to 4 components (BSSM_USER_M = 1, 2 or 4 is the padded dimension the kernels are instantiated
 // for; a 3-state model leaves the fourth component alone) and R any m x k matrix, k <= m (bootstrap filter / smoother /
-// bootstrap IS correction; psi-APF and EKF particle filter: up to 4 states and any constant R since round 3).
+// bootstrap IS correction; psi-APF and EKF particle filter: up to 4 states, any constant R, or a state-dependent R_fn / H_fn).
 // per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser,
 // user slot, number of states, full R (MP x MP, column-major, zero-padded; user models)
 enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, FP_H = 20, FP_R = 21, FP_LOGC = 23, FP_SLOT = 24 /* user-model registry slot (host only) */,
@@ -60,6 +61,18 @@ __device__ __forceinline__ bssm_user_tv fn_user_tv(PF fp, int t) {
 #else
 #define BSSM_UTV(fp_, t_)
 #endif
+
+// doubles per time point of the psi-APF's approximating rows (`amats`): T~_t (MP x MP), C~_t (MP); a user model with a
+// state-dependent R_fn (BSSM_USER_RFN) carries the approximating R~_t R~_t' = R_fn(mode_t) R_fn(mode_t)' behind them, because the
+// two covariances of the transition-density ratio then differ (src/model_ssm_nlg.cpp:919-932)
+template <int MP>
+__host__ __device__ constexpr int fn_amat_row() {
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_RFN)
+  return MP * MP + MP + MP * MP;
+#else
+  return MP * MP + MP;
+#endif
+}
 
 // ---- ssm_nlg: alpha_{t+1} = T(alpha_t) + R eta,  y_t ~ N(Z(alpha_t), H^2)   (src/model_ssm_nlg.cpp:1118-1126, 943-956)
 // (t: the time index the reference passes to the model functions; only user models with BSSM_USER_TV read it)
@@ -257,6 +270,63 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
   return fp[FP_LOGC] - 0.5 * q * q;
 }
 
+// observation standard deviation at a state (H_fn, src/model_ssm_nlg.h:12): a number for every model except user snippets
+// with BSSM_USER_HFN
+template <int MP, class PF>
+__device__ __forceinline__ double nlg_H_at(int id, PF fp, const double (&x)[MP], int t) {
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_HFN)
+  if (id == FN_USER_NLG) return bssm_user_H(BSSM_UTV(fp, t) &x[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN));
+#endif
+  return fp[FP_H];
+}
+template <int MP>
+__device__ __forceinline__ double dmvnorm_cov_small(const double (&x)[MP], const double (&mean)[MP], const double (&S)[MP * MP]);
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_RFN)
+// R(a) R(a)' of a user snippet with BSSM_USER_RFN (R_fn at the ancestor, src/model_ssm_nlg.cpp:924-925), MP x MP zero-padded
+template <int MP, class PF>
+__device__ __forceinline__ void user_RR_at(PF fp, const double (&a)[MP], int t, double (&RR)[MP * MP]) {
+  constexpr int mu = BSSM_USER_NSTATES <= MP ? BSSM_USER_NSTATES : MP;
+  double Ru[MP * MP];
+#pragma unroll
+  for (int q = 0; q < MP * MP; q++) Ru[q] = 0.0;
+  bssm_user_R(BSSM_UTV(fp, t) &a[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN), &Ru[0]);  // m x k, leading dimension m; columns >= k stay zero
+#pragma unroll
+  for (int j = 0; j < MP; j++)
+#pragma unroll
+    for (int i = 0; i < MP; i++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < MP; q++) acc += ((i < mu) ? Ru[i + mu * q] : 0.0) * ((j < mu) ? Ru[j + mu * q] : 0.0);
+      RR[i + MP * j] = acc;
+    }
+}
+#endif
+
+// R R' at the ancestor as the EKF particle filter needs it (src/model_ssm_nlg.cpp:1214-1216, 1240-1242): R_fn of a snippet with
+// BSSM_USER_RFN, else the constant matrix R of a user model with 3 / 4 states (FP_RMAT, zero-padded), else diag(R_j^2)
+template <int MP, class PF>
+__device__ __forceinline__ void nlg_RR_at(int id, PF fp, const double (&a)[MP], int t, double (&RR)[MP * MP]) {
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_RFN)
+  if (id == FN_USER_NLG) { user_RR_at<MP>(fp, a, t, RR); return; }
+#endif
+  if constexpr (MP > 2) {
+#pragma unroll
+    for (int j = 0; j < MP; j++)
+#pragma unroll
+      for (int i = 0; i < MP; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < MP; q++) acc += fp[FP_RMAT + i + MP * q] * fp[FP_RMAT + j + MP * q];
+        RR[i + MP * j] = acc;
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < MP * MP; q++) RR[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < MP; j++) RR[j + MP * j] = fp[FP_R + j] * fp[FP_R + j];
+  }
+}
+
 // psi-APF weight of ssm_nlg (src/model_ssm_nlg.cpp:880-935 minus scales_t): observation-density ratio between
 // the model and its mode-linearised Gaussian approximation, and for t > 0 the transition-density ratio evaluated
 // at the ANCESTOR.  H and R are constant in every shipped model, so the Gaussian normalisers cancel exactly.
@@ -271,17 +341,46 @@ __device__ __forceinline__ double functor_psi_weight(PF fp, PR row, PA amat, int
   {
     const PR ob = row + ROW_HDR;
     const double y = ob[OB_Y], ih = ob[OB_PSIIH];
-    const double q1 = (y - nlg_Z_fn<MP>(id, fp, x, t)) * ih;
     double lin = ob[OB_D];
 #pragma unroll
     for (int c = 0; c < MP; c++) lin += ob[SER_HDR + c] * x[c];
     const double q2 = (y - lin) * ih;
-    w = 0.5 * (q2 * q2 - q1 * q1);
+#if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_HFN)
+    if (id == FN_USER_NLG) {
+      // state-dependent H_fn: the model's sd at the particle against the approximating sd H_fn(mode_t) = 1 / ih of the row; the
+      // normalisers no longer cancel (src/model_ssm_nlg.cpp:892-900)
+      const double h = nlg_H_at<MP>(id, fp, x, t);
+      const double q1 = (y - nlg_Z_fn<MP>(id, fp, x, t)) / h;
+      w = (-tl_log(h) - 0.5 * q1 * q1) - (tl_log(ih) - 0.5 * q2 * q2);
+    } else
+#endif
+    {
+      const double q1 = (y - nlg_Z_fn<MP>(id, fp, x, t)) * ih;
+      w = 0.5 * (q2 * q2 - q1 * q1);
+    }
   }
   if (t > 0) {
     double mean[MP];
     nlg_T_fn<MP>(id, fp, aprev, mean, t - 1);
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
+#if defined(BSSM_USER_RFN)
+    if (id == FN_USER_NLG) {
+      // state-dependent R_fn: N(x; T(a), R(a) R(a)') against N(x; T~ a + C~, R~ R~') with R~ = R_fn(mode_{t-1}) from the host
+      // (behind T~, C~ in the approximating row): two general densities (src/model_ssm_nlg.cpp:919-932, src/dmvnorm.cpp:4-37)
+      double am[MP], RR[MP * MP], RRa[MP * MP];
+#pragma unroll
+      for (int j = 0; j < MP; j++) {
+        double v = amat[MP * MP + j];
+#pragma unroll
+        for (int c = 0; c < MP; c++) v += amat[j + MP * c] * aprev[c];
+        am[j] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < MP * MP; q++) RRa[q] = amat[MP * MP + MP + q];
+      user_RR_at<MP>(fp, aprev, t - 1, RR);
+      w -= dmvnorm_cov_small<MP>(x, am, RRa) - dmvnorm_cov_small<MP>(x, mean, RR);
+    } else
+#else
     if (id == FN_USER_NLG) {
       // user-defined models, any constant m x k matrix R: both densities share the covariance R R', so the normalisers cancel
       // and the ratio is a difference of two quadratic forms in (R R')^-1 = Linv' Linv.  Linv (FP_RLINV, from the host) is
@@ -303,6 +402,7 @@ __device__ __forceinline__ double functor_psi_weight(PF fp, PR row, PA amat, int
         w += 0.5 * (qa * qa - qm * qm);
       }
     } else
+#endif
 #endif
     {
 #pragma unroll
@@ -461,22 +561,7 @@ __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, con
   const int id = FID > 0 ? FID : (int)fp[FP_ID];
   nlg_T_fn<MP>(id, fp, anc, at, t);
   double Pt[MP * MP];
-  if constexpr (MP > 2) {  // user models: R R' of the constant matrix R (FP_RMAT, MP x MP with zero padding)
-#pragma unroll
-    for (int j = 0; j < MP; j++)
-#pragma unroll
-      for (int i = 0; i < MP; i++) {
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < MP; q++) acc += fp[FP_RMAT + i + MP * q] * fp[FP_RMAT + j + MP * q];
-        Pt[i + MP * j] = acc;
-      }
-  } else {
-#pragma unroll
-    for (int q = 0; q < MP * MP; q++) Pt[q] = 0.0;
-#pragma unroll
-    for (int j = 0; j < MP; j++) Pt[j + MP * j] = fp[FP_R + j] * fp[FP_R + j];
-  }
+  nlg_RR_at<MP>(id, fp, anc, t, Pt);
   if (last) {  // the final, never-weighted slot: the reference uses P_t itself as the factor (:1223-1226)
 #pragma unroll
     for (int j = 0; j < MP; j++) att[j] = at[j];
@@ -486,7 +571,7 @@ __device__ __forceinline__ void ekpf_proposal(const double* __restrict__ fp, con
   }
   double Ptt[MP * MP];
   if (row[RH_FLAG] != 0.0) {  // ekf_update_step (:1264-1293)
-    const double y = row[ROW_HDR + OB_Y], H = fp[FP_H];
+    const double y = row[ROW_HDR + OB_Y], H = nlg_H_at<MP>(id, fp, at, t + 1);  // H_fn at the predicted state (:1272)
     double Zg[MP], PZ[MP], K[MP];
     nlg_Z_gn<MP>(id, fp, at, Zg, t + 1);
     double F = H * H;
@@ -565,22 +650,7 @@ __device__ __forceinline__ double functor_ekpf_weight(const double* __restrict__
   }
   double at[MP], att[MP], Lf[MP * MP], RR[MP * MP];
   ekpf_proposal<MP, FID>(fp, row, false, anc, at, att, Lf, t - 1);
-  if constexpr (MP > 2) {
-#pragma unroll
-    for (int j = 0; j < MP; j++)
-#pragma unroll
-      for (int i = 0; i < MP; i++) {
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < MP; q++) acc += fp[FP_RMAT + i + MP * q] * fp[FP_RMAT + j + MP * q];
-        RR[i + MP * j] = acc;
-      }
-  } else {
-#pragma unroll
-    for (int q = 0; q < MP * MP; q++) RR[q] = 0.0;
-#pragma unroll
-    for (int j = 0; j < MP; j++) RR[j + MP * j] = fp[FP_R + j] * fp[FP_R + j];
-  }
+  nlg_RR_at<MP>((int)(FID > 0 ? FID : (int)fp[FP_ID]), fp, anc, t - 1, RR);
   return w + dmvnorm_cov_small<MP>(x, at, RR) - dmvnorm_lwr_small<MP>(x, att, Lf);
 }
 

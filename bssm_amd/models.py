@@ -581,9 +581,10 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
     ``known_tv_params``: the reference's matrix of known time-varying values (R/models.R:1507); a snippet that defines
     ``BSSM_USER_TV`` receives it, with the time index, as the leading ``const bssm_user_tv& tv`` argument of every function
     (``tv.t``, ``tv.known_tv`` column-major ``tv.rows x tv.cols``).
-    The bootstrap filter / smoother also take up to 4 states, any ``R`` (n_states x n_etas matrix, or a function of theta)
-    and the reference's state-dependent ``H_fn`` / ``R_fn`` as snippet functions (``BSSM_USER_HFN`` + ``bssm_user_H``,
-    ``BSSM_USER_RFN`` + ``bssm_user_R``; src/model_ssm_nlg.h:12-13), which then replace ``H`` / ``R``."""
+    Every sampler also takes up to 4 states, any ``R`` (n_states x n_etas matrix, or a function of theta) and the
+    reference's state-dependent ``H_fn`` / ``R_fn`` as snippet functions (``BSSM_USER_HFN`` + ``bssm_user_H``,
+    ``BSSM_USER_RFN`` + ``bssm_user_R``; src/model_ssm_nlg.h:12-13), which then replace ``H`` / ``R`` (``R`` still fixes
+    n_etas; for the psi-APF R(a) R(a)' must be positive definite on its non-zero diagonal)."""
     y = _f(np.asarray(y, dtype=float).reshape(-1))
     theta = np.asarray(theta, dtype=float)
     m = int(n_states or np.asarray(a1(theta) if callable(a1) else a1, dtype=float).size)

@@ -207,7 +207,9 @@ typedef struct bssm_fn_model {
  * n_states x n_etas matrix R whose R R' is positive definite on its non-zero diagonal, and any positive semi-definite P1
  * (round 3); so does the EKF particle filter (1- and 2-state models: constant diagonal R).  Snippets that define
  * BSSM_USER_TV receive the time index and known_tv_params in every function.  The bootstrap filter / smoother / bootstrap IS correction take up to 4 states, any n_states x n_etas matrix
- * R and the reference's state-dependent H_fn / R_fn (snippet functions bssm_user_H / bssm_user_R).  IS post-correction
+ * R and the reference's state-dependent H_fn / R_fn (snippet functions bssm_user_H / bssm_user_R); so do the psi-APF and the
+ * EKF particle filter (the approximating model then has H_t = H_fn(mode_t), R_t = R_fn(mode_t), src/model_ssm_nlg.cpp:100-107;
+ * R(a) R(a)' must be positive definite on its non-zero diagonal, since the psi weight contains the transition density).  IS post-correction
  * (bssm_is_correction_nlg / _multi) and the chains (bssm_run_mcmc_fn; theta-dependent H / R / a1 / P1 through
  * bssm_mcmc_job.fn_update_fn) work for user models too. */
 int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity);

@@ -688,3 +688,147 @@ def test_user_model_ekf_particle_filter_three_and_four_states(oracle, monkeypatc
     sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
     mean, cov = oracle.summary(sm)
     assert _rel(out["alphahat"], mean.T[:y.size]) <= 1e-8
+
+
+# Two user models whose observation sd AND noise matrix depend on the state (the reference's H_fn / R_fn take alpha,
+# src/model_ssm_nlg.h:12-13), with Jacobians, so that the psi-APF and the EKF particle filter apply:
+#   2 states: T(a) = (th0 a0 + 0.3 sin(a1), 0.85 a1),  R(a) = [[th1 (1 + 0.5 tanh(a1)), 0], [0.1, th2 exp(0.2 a0)]],
+#             Z(a) = a0 + 0.2 a1^2,  H(a) = kn0 (1 + 0.3 / (1 + a0^2))
+#   3 states: T(a) = (a0 + a2, th0 a1 + 0.2 sin(a0), 0.8 a2),
+#             R(a) = [[th1 exp(0.3 a1), 0, 0], [0, th2, 0], [0.2 th1 exp(0.3 a1), th3, 0.15]]  (R R' must be positive definite for
+#             the psi-APF: its weights contain the transition density, src/model_ssm_nlg.cpp:919-932),
+#             Z(a) = a0 + 0.5 a1,  H(a) = kn0 sqrt(1 + 0.5 a1^2)
+USER_SNOISE2 = r"""
+#define BSSM_USER_NLG 1
+#define BSSM_USER_JACOBIANS 1
+#define BSSM_USER_HFN 1
+#define BSSM_USER_RFN 1
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) { out[0] = th[0] * a[0] + 0.3 * sin(a[1]); out[1] = 0.85 * a[1]; }
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + 0.2 * a[1] * a[1]; }
+BSSM_FN double bssm_user_H(const double* a, const double* th, const double* kn) { return kn[0] * (1.0 + 0.3 / (1.0 + a[0] * a[0])); }
+BSSM_FN void bssm_user_R(const double* a, const double* th, const double* kn, double* out) {
+  out[0] = th[1] * (1.0 + 0.5 * tanh(a[1])); out[1] = 0.1; out[2] = 0.0; out[3] = th[2] * exp(0.2 * a[0]);
+}
+BSSM_FN void bssm_user_Tg(const double* a, const double* th, const double* kn, double* Tg) { Tg[0] = th[0]; Tg[1] = 0.0; Tg[2] = 0.3 * cos(a[1]); Tg[3] = 0.85; }
+BSSM_FN void bssm_user_Zg(const double* a, const double* th, const double* kn, double* Zg) { Zg[0] = 1.0; Zg[1] = 0.4 * a[1]; }
+"""
+USER_SNOISE3 = r"""
+#define BSSM_USER_NLG 1
+#define BSSM_USER_JACOBIANS 1
+#define BSSM_USER_HFN 1
+#define BSSM_USER_RFN 1
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) { out[0] = a[0] + a[2]; out[1] = th[0] * a[1] + 0.2 * sin(a[0]); out[2] = 0.8 * a[2]; }
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + 0.5 * a[1]; }
+BSSM_FN double bssm_user_H(const double* a, const double* th, const double* kn) { return kn[0] * sqrt(1.0 + 0.5 * a[1] * a[1]); }
+BSSM_FN void bssm_user_R(const double* a, const double* th, const double* kn, double* out) {
+  const double s = th[1] * exp(0.3 * a[1]);
+  out[0] = s; out[1] = 0.0; out[2] = 0.2 * s;       /* first column */
+  out[3] = 0.0; out[4] = th[2]; out[5] = th[3];     /* second column */
+  out[6] = 0.0; out[7] = 0.0; out[8] = 0.15;        /* third column */
+}
+BSSM_FN void bssm_user_Tg(const double* a, const double* th, const double* kn, double* Tg) {
+  Tg[0] = 1.0; Tg[1] = 0.2 * cos(a[0]); Tg[2] = 0.0;  Tg[3] = 0.0; Tg[4] = th[0]; Tg[5] = 0.0;  Tg[6] = 1.0; Tg[7] = 0.0; Tg[8] = 0.8;
+}
+BSSM_FN void bssm_user_Zg(const double* a, const double* th, const double* kn, double* Zg) { Zg[0] = 1.0; Zg[1] = 0.5; Zg[2] = 0.0; }
+"""
+
+
+def _snoise_case(which, seed, n):
+    rng = np.random.default_rng(seed)
+    if which == "snoise2":
+        m, k = 2, 2
+        th, kn = np.array([0.9, 0.25, 0.15]), np.array([0.5])
+        fns = dict(Z_fn=lambda t, a, th, kn: a[0] + 0.2 * a[1] ** 2,
+                   H_fn=lambda t, a, th, kn: kn[0] * (1.0 + 0.3 / (1.0 + a[0] ** 2)),
+                   T_fn=lambda t, a, th, kn: np.array([th[0] * a[0] + 0.3 * np.sin(a[1]), 0.85 * a[1]]),
+                   R_fn=lambda t, a, th, kn: np.array([[th[1] * (1.0 + 0.5 * np.tanh(a[1])), 0.0], [0.1, th[2] * np.exp(0.2 * a[0])]]))
+        jac = dict(Z_gn=lambda t, a, th, kn: np.array([1.0, 0.4 * a[1]]),
+                   T_gn=lambda t, a, th, kn: np.array([[th[0], 0.3 * np.cos(a[1])], [0.0, 0.85]]))
+        a1 = np.array([0.3, -0.2]); P1 = np.array([[0.4, 0.1], [0.1, 0.3]])
+        code = USER_SNOISE2
+    else:
+        m, k = 3, 3
+        th, kn = np.array([0.8, 0.3, 0.2, 0.1]), np.array([0.6])
+
+        def R(t, a, th, kn):
+            s = th[1] * np.exp(0.3 * a[1])
+            return np.array([[s, 0.0, 0.0], [0.0, th[2], 0.0], [0.2 * s, th[3], 0.15]])
+        fns = dict(Z_fn=lambda t, a, th, kn: a[0] + 0.5 * a[1],
+                   H_fn=lambda t, a, th, kn: kn[0] * np.sqrt(1.0 + 0.5 * a[1] ** 2),
+                   T_fn=lambda t, a, th, kn: np.array([a[0] + a[2], th[0] * a[1] + 0.2 * np.sin(a[0]), 0.8 * a[2]]), R_fn=R)
+        jac = dict(Z_gn=lambda t, a, th, kn: np.array([1.0, 0.5, 0.0]),
+                   T_gn=lambda t, a, th, kn: np.array([[1.0, 0.0, 1.0], [0.2 * np.cos(a[0]), th[0], 0.0], [0.0, 0.0, 0.8]]))
+        a1 = np.array([0.2, 0.0, 0.1]); P1 = np.diag([0.5, 0.3, 0.2]); P1[0, 1] = P1[1, 0] = 0.1
+        code = USER_SNOISE3
+    a = a1.copy(); y = np.zeros(n)
+    for t in range(n):
+        y[t] = fns["Z_fn"](t, a, th, kn) + fns["H_fn"](t, a, th, kn) * rng.normal()
+        a = fns["T_fn"](t, a, th, kn) + fns["R_fn"](t, a, th, kn) @ rng.normal(size=k)
+    y[5] = np.nan
+    u = M.ssm_nlg_user(y, code, theta=th, known_params=kn, a1=a1, P1=P1, n_states=m, H=1.0,
+                       R=np.zeros((m, k)))  # (H and R only fix the shapes here: the snippet's H_fn / R_fn are what is evaluated)
+    return u, y, m, k, th, kn, a1, P1, fns, jac
+
+
+@pytest.mark.parametrize("path,N", [("wg", 600), ("grid", 3000)])
+@pytest.mark.parametrize("which", ["snoise2", "snoise3"])
+def test_user_model_psi_apf_with_state_dependent_H_and_R(oracle, monkeypatch, which, path, N):
+    """psi-APF of user models whose H_fn and R_fn depend on the state: the approximating model takes H_t = H_fn(mode_t) and
+    R_t = R_fn(mode_t) per time point (src/model_ssm_nlg.cpp:62-143), and neither density ratio of the weight has equal
+    covariances any more (:880-935) -- mode, approximate log-likelihood, ancestors, weights and log-likelihood against
+    orc_nlg_general_psi_*, the restatement over function pointers"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    u, y, m, k, th, kn, a1, P1, fns, jac = _snoise_case(which, seed=71, n=26)
+    n = y.size
+    ref = oracle.nlg_general_psi(y, m, k, th, kn, a1, P1, nsim=N, seed=6, **fns, **jac)
+    assert ref["ok"]
+    su = F.psi_setup(u)
+    assert np.allclose(np.asarray(su["mode"]).reshape(m, n, order="F"), ref["mode"], rtol=0, atol=1e-9)
+    assert abs(su["approx_loglik"] - ref["approx_loglik"]) <= 1e-9 * n
+    out = F.particle_smoother(u, N, method="psi", seed=6, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    mean, cov = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8
+    # the state dependence matters in this case: with H and R frozen at their values in a1 the log-likelihood moves
+    frozen = oracle.nlg_general_psi(y, m, k, th, kn, a1, P1, nsim=N, seed=6, **{**fns, "H_fn": lambda t, a, th_, kn_: fns["H_fn"](t, a1, th_, kn_),
+                                                                         "R_fn": lambda t, a, th_, kn_: fns["R_fn"](t, a1, th_, kn_)}, **jac)
+    assert abs(frozen["logLik"] - ref["logLik"]) > 1e-3
+
+
+@pytest.mark.parametrize("path,N", [("wg", 600), ("grid", 3000)])
+@pytest.mark.parametrize("which", ["snoise2", "snoise3"])
+def test_user_model_ekf_particle_filter_with_state_dependent_H_and_R(oracle, monkeypatch, which, path, N):
+    """EKF-proposal particle filter of the same models: R_fn at the ancestor, H_fn at the predicted state inside the EKF
+    update and at the particle in the weight (src/model_ssm_nlg.cpp:1148-1293) -- against orc_nlg_general_ekpf_filter"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    u, y, m, k, th, kn, a1, P1, fns, jac = _snoise_case(which, seed=73, n=22)
+    ref = oracle.nlg_general_ekpf_filter(y, m, k, th, kn, a1, P1, nsim=N, seed=8, **fns, **jac)
+    out = F.particle_smoother(u, N, method="ekf", seed=8, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * y.size
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    mean, cov = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert _rel(out["alphahat"], mean.T[:y.size]) <= 1e-8
+
+
+@pytest.mark.parametrize("dev", ["0", "1"])
+def test_user_model_state_dependent_noise_post_correct_at_the_mode(oracle, monkeypatch, dev):
+    """IS post-correction (psi) of draws of the 3-state model with state-dependent H / R against the general oracle run per
+    draw at the stored mode (approximate_for_is, src/model_ssm_nlg.cpp:146-176): log-weights per draw, host set-up and the
+    device smoother behind the host linearisation"""
+    from bssm_amd import post_correct as PC
+    monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+    u, y, m, k, th, kn, a1, P1, fns, jac = _snoise_case("snoise3", seed=75, n=18)
+    n, ns, N = y.size, 5, 150
+    rng = np.random.default_rng(5)
+    theta = th + 0.02 * rng.normal(size=(ns, th.size))
+    counts = np.ones(ns, dtype=np.uint32)
+    modes = np.stack([oracle.nlg_general_psi(y, m, k, theta[i], kn, a1, P1, nsim=8, seed=1, filter=False, **fns, **jac)["mode"].reshape(-1, order="F")
+                      for i in range(ns)], axis=1)
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type=3)
+    out = PC.post_correct(u, mo, N, threads=2, is_type="is2", seed=9)
+    for i in range(ns):
+        ref = oracle.nlg_general_psi(y, m, k, theta[i], kn, a1, P1, nsim=N, seed=9, stream=i, is_mode=modes[:, i], **fns, **jac)
+        assert abs(out["loglik"][i] - ref["logLik"]) <= 1e-9 * n, (i, out["loglik"][i], ref["logLik"])
