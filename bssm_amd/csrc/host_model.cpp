@@ -75,9 +75,10 @@ void sym_singular(const Mat& Ain, Mat* U, std::vector<double>* s) {
   for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) A(i, j) = 0.5 * (Ain(i, j) + Ain(j, i));
   *U = Mat::eye(m);
   for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0.0;
+    double off = 0.0, dg = 0.0;
     for (int j = 0; j < m; j++) for (int i = 0; i < j; i++) off += A(i, j) * A(i, j);
-    if (off < 1e-300) break;
+    for (int j = 0; j < m; j++) dg += A(j, j) * A(j, j);
+    if (off < 1e-300 || off < 1e-60 * dg) break;  // (the same stopping rule as LgSmoother::sym_singular, lg_smoother.h)
     for (int p = 0; p < m - 1; p++)
       for (int q = p + 1; q < m; q++) {
         const double apq = A(p, q);

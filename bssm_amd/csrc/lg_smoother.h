@@ -19,6 +19,11 @@
 #define LG_HD __host__ __device__
 #endif
 
+// analysis builds: the includer may define LG_STAMP(i) to record a clock at the phase boundaries of LgSmoother::run
+#ifndef LG_STAMP
+#define LG_STAMP(i)
+#endif
+
 namespace bssm {
 
 // One draw's model, as plain pointers.  "(1|n)": stride 0 = time-invariant.
@@ -85,9 +90,13 @@ struct LgSmoother {
     for (int q = 0; q < MM; q++) W[q] = 0.0;
     for (int i = 0; i < M; i++) W[i + M * i] = 1.0;
     for (int sweep = 0; sweep < 60; sweep++) {
-      double off = 0.0;
+      double off = 0.0, dg = 0.0;
       for (int j = 0; j < M; j++) for (int i = 0; i < j; i++) off += A[i + M * j] * A[i + M * j];
-      if (off < 1e-300) break;
+      for (int j = 0; j < M; j++) dg += A[j + M * j] * A[j + M * j];
+      // converged: the off-diagonal mass is below 1e-30 of the diagonal's, so every further rotation has |sin| < 1e-30 and
+      // leaves the eigenvalues and vectors unchanged in double precision (the sweeps go 1e-17, 1e-33, 1e-49, ... relative;
+      // running them down to the absolute 1e-300 cost 6-9 sweeps per call where 2 do the work)
+      if (off < 1e-300 || off < 1e-60 * dg) break;
       for (int p = 0; p < M - 1; p++)
         for (int q = p + 1; q < M; q++) {
           const double apq = A[p + M * q];
@@ -129,7 +138,41 @@ struct LgSmoother {
   LG_HD static void ldv(const double* p, size_t es, int cnt, double* out) { for (int q = 0; q < cnt; q++) out[q] = p[(size_t)q * es]; }
   LG_HD static void stv(double* p, size_t es, int cnt, const double* in) { for (int q = 0; q < cnt; q++) p[(size_t)q * es] = in[q]; }
 
-  LG_HD static bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es = 1) {
+  // with_factors = false stops behind the backward pass: at / Pt / cc then hold the smoothed means, covariances and lag-one
+  // cross-covariances, and the caller turns them into factors itself, one call of cond_step per time point in any order
+  // (the set-up kernels split the time points over their waves)
+  // conditional_cov (src/conditional_dist.cpp:4-31) at one time point t: from the smoothed covariances Pt[t - 1], Pt[t] and the
+  // cross-covariance cc[t - 1] to Vout[t] = U sqrt(s) of Var(alpha_t | alpha_{t-1}, y) and Cout[t] = Cov' pinv(V_{t-1}); t = 0 has
+  // the factor of Pt[0] only.  Vout / Cout may be Pt / cc themselves when the caller goes from the last time point down.
+  LG_HD static void cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es) {
+    double U[MM], s[M], W[MM], Vp[MM], Vc[MM], Cp[MM], tmp[MM], tmp2[MM];
+    if (t == 0) {
+      ldv(Pt, es, MM, Vp);
+      sym_singular(Vp, U, s);
+      for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vp[i + M * c] = U[i + M * c] * sqrt(s[c]);
+      stv(Vout, es, MM, Vp);
+      return;
+    }
+    ldv(Pt + (size_t)(t - 1) * MM * es, es, MM, Vp);
+    ldv(Pt + (size_t)t * MM * es, es, MM, Vc);
+    ldv(cc + (size_t)(t - 1) * MM * es, es, MM, Cp);
+    sym_singular(Vp, U, s);
+    for (int q = 0; q < MM; q++) W[q] = 0.0;
+    for (int c = 0; c < M; c++) {
+      if (!(s[c] > kEps * M * s[0])) continue;
+      for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) W[i + M * j] += U[i + M * c] * U[j + M * c] / s[c];
+    }
+    mul_at(Cp, W, tmp);       // tr(Ct[t-1]) * W
+    mul(tmp, Cp, tmp2);
+    for (int q = 0; q < MM; q++) Vc[q] = Vc[q] - tmp2[q];
+    stv(Cout + (size_t)t * MM * es, es, MM, tmp);
+    sym_singular(Vc, U, s);
+    for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vc[i + M * c] = U[i + M * c] * sqrt(s[c]);
+    stv(Vout + (size_t)t * MM * es, es, MM, Vc);
+  }
+
+  LG_HD static bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es = 1,
+                        bool with_factors = true) {
     const int n = g.n;
     double a[M], P[MM], a1n[M], P1n[MM], Z[M], T[MM], RR[MM], Cv[M];
     double tmp[MM], tmp2[MM], inner[MM], IKZ[MM];
@@ -195,6 +238,7 @@ struct LgSmoother {
       for (int i = 0; i < M; i++) a[i] = a1n[i];
       for (int q = 0; q < MM; q++) P[q] = P1n[q];
     }
+    LG_STAMP(2);
     // ---- backward pass (smoother_ccov)
     double rt[M], Nt[MM], L[MM], N2[MM], ct[MM], Kt[M];
     for (int i = 0; i < M; i++) rt[i] = 0.0;
@@ -245,37 +289,22 @@ struct LgSmoother {
       stv(Pt + (size_t)t * MM * es, es, MM, P);
     }
     for (int q = 0; q < MM; q++) cc[((size_t)n * MM + q) * es] = 0.0;
-    // ---- conditional_cov: Vt <- U sqrt(s) of Var(alpha_t | alpha_{t-1}, y), Ct <- Cov' pinv(V_{t-1})
-    double U[MM], s[M], W[MM], Vp[MM], Vc[MM], Cp[MM];
-    for (int t = n; t > 0; t--) {
+    LG_STAMP(3);
+    if (!with_factors) return true;
+    // ---- conditional_cov: Vt <- U sqrt(s) of Var(alpha_t | alpha_{t-1}, y), Ct <- Cov' pinv(V_{t-1}); in place, so from the
+    // last time point down (step t reads the covariances of t - 1 and t and the cross-covariance of t - 1)
+    for (int t = n; t >= 0; t--) {
       if (sub > 1 && t % sub != 0) continue;  // a virtual step inside a time point: no factor of its own
-      ldv(Pt + (size_t)(t - 1) * MM * es, es, MM, Vp);
-      ldv(Pt + (size_t)t * MM * es, es, MM, Vc);
-      ldv(cc + (size_t)(t - 1) * MM * es, es, MM, Cp);
-      sym_singular(Vp, U, s);
-      for (int q = 0; q < MM; q++) W[q] = 0.0;
-      for (int c = 0; c < M; c++) {
-        if (!(s[c] > kEps * M * s[0])) continue;
-        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) W[i + M * j] += U[i + M * c] * U[j + M * c] / s[c];
-      }
-      mul_at(Cp, W, tmp);       // tr(Ct[t-1]) * W
-      mul(tmp, Cp, tmp2);
-      for (int q = 0; q < MM; q++) Vc[q] = Vc[q] - tmp2[q];
-      stv(cc + (size_t)t * MM * es, es, MM, tmp);
-      sym_singular(Vc, U, s);
-      for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vc[i + M * c] = U[i + M * c] * sqrt(s[c]);
-      stv(Pt + (size_t)t * MM * es, es, MM, Vc);
+      cond_step(t, Pt, cc, Pt, cc, es);
     }
-    ldv(Pt, es, MM, Vp);
-    sym_singular(Vp, U, s);
-    for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vp[i + M * c] = U[i + M * c] * sqrt(s[c]);
-    stv(Pt, es, MM, Vp);
-    bool ok = true;
+    LG_STAMP(4);
+    // (no short-circuit: the loads of this sweep are independent of each other and of `bad`, so they overlap)
+    int bad = 0;
     for (int t = 0; t <= n; t++) {
-      for (int i = 0; i < M; i++) ok = ok && lg_finite(at[((size_t)t * M + i) * es]);
-      for (int q = 0; q < MM; q++) ok = ok && lg_finite(Pt[((size_t)t * MM + q) * es]) && lg_finite(cc[((size_t)t * MM + q) * es]);
+      for (int i = 0; i < M; i++) bad |= !lg_finite(at[((size_t)t * M + i) * es]);
+      for (int q = 0; q < MM; q++) bad |= (!lg_finite(Pt[((size_t)t * MM + q) * es])) | (!lg_finite(cc[((size_t)t * MM + q) * es]));
     }
-    return ok;
+    return bad == 0;
   }
 
   // Smoothed state means only (ssm_ulg::fast_smoother, src/model_ssm_ulg.cpp:252-305): the inner step of the mode

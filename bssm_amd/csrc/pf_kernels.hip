@@ -5,6 +5,13 @@
 #include <cstdio>
 #include <cstdlib>
 
+// analysis builds (-DBSSM_SETUP_STAMPS): wall-clock stamps (100 MHz) of workgroup 0, lane 0 at the phase boundaries of the set-up
+// kernels, printed by the kernel itself (scripts/setup_phase_probe.sh)
+#ifdef BSSM_SETUP_STAMPS
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_setup_stamps[8];
+#define LG_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_setup_stamps[i] = wall_clock64(); } while (0)
+#endif
 #include "lg_smoother.h"
 #include "pf_filter_impl.h"
 #include "tls_stream.h"
@@ -243,21 +250,50 @@ hipError_t launch_lg_setup(const LgBatchDev& b, hipStream_t stream) {
 // draw: the host then only packs theta (FP_SIZE doubles) and a1 / P1 per draw.  Work arrays are draw-interleaved
 // (element k of draw d at base[k * F + d]) like lg_setup_kernel's; the tables go out per draw, contiguous, in the
 // layout DeviceBatch hands to the filter kernels.
+// Conditional factors of a set-up kernel whose waves share 64 draws (lane = draw): the Kalman filter / covariance smoother has run
+// on wave 0 (s_ok[lane] = its verdict); the factors of the time points are independent of each other given its output, so the
+// waves take them round-robin, into Vf / Cf (the smoother's arrays are still being read by the other waves).  Ends with a barrier;
+// returns the draw's verdict incl. the finiteness of every smoothed mean and factor (as LgSmoother::run's last loop).
+template <int M>
+__device__ __forceinline__ bool setup_factors_by_wave(int n, int wv, int nwv, int* s_ok, const double* at, const double* Pt, const double* cc,
+                                                      double* Vf, double* Cf, size_t F) {
+  constexpr int MM = M * M;
+  const int lane = threadIdx.x & 63;
+  __syncthreads();
+  if (s_ok[lane]) {
+    int bad = 0;
+    for (int t = n - wv; t >= 0; t -= nwv) {
+      LgSmoother<M>::cond_step(t, Pt, cc, Vf, Cf, F);
+#pragma unroll
+      for (int i = 0; i < M; i++) bad |= !lg_finite(at[((size_t)t * M + i) * F]);
+#pragma unroll
+      for (int q = 0; q < MM; q++) bad |= (!lg_finite(Vf[((size_t)t * MM + q) * F])) | (t > 0 && !lg_finite(Cf[((size_t)t * MM + q) * F]));
+    }
+    if (bad) s_ok[lane] = 0;  // (every writer stores the same value)
+  }
+  __syncthreads();
+  return s_ok[lane] != 0;
+}
 size_t fn_setup_scratch_doubles(int n, int m) {
   const size_t mm = (size_t)m * m, n1 = (size_t)n + 1;
-  //      Z            T        RR   D   C            y   H   a1  P1   at       Pt        cc        K            v   Fs
-  return (size_t)n * m + n * mm + mm + n + (size_t)n * m + n + 1 + m + mm + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n;
+  //      Z            T        RR   D   C            y   H   a1  P1   at       Pt        cc        K            v   Fs   Vf        Cf
+  return (size_t)n * m + n * mm + mm + n + (size_t)n * m + n + 1 + m + mm + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n + n1 * mm + n1 * mm;
 }
 #ifndef BSSM_FN_SETUP_NT
 #define BSSM_FN_SETUP_NT 512
 #endif
-constexpr int FN_SETUP_NT = BSSM_FN_SETUP_NT;  // threads per workgroup of fn_setup_kernel: 64 draws x FN_SETUP_NT / 64 waves
+constexpr int FN_SETUP_NT = BSSM_FN_SETUP_NT;  // threads per workgroup of ung_setup_kernel: 64 draws x FN_SETUP_NT / 64 waves
+#ifndef BSSM_NLG_SETUP_NT
+#define BSSM_NLG_SETUP_NT 1024
+#endif
+constexpr int NLG_SETUP_NT = BSSM_NLG_SETUP_NT;  // fn_setup_kernel (1 or 2 states: 128 VGPRs are plenty): 16 waves share the 64 draws
 template <int M>
-__global__ void __launch_bounds__(FN_SETUP_NT) fn_setup_kernel(const FnSetupDev b) {
+__global__ void __launch_bounds__(NLG_SETUP_NT) fn_setup_kernel(const FnSetupDev b) {
+  LG_STAMP(0);
   math_tab_init();
-  // lane = draw; the FN_SETUP_NT / 64 waves of a workgroup share its 64 draws: the loops whose time points are independent
-  // (linearisation, tables) are split over the waves, the Kalman / smoother recursion runs on wave 0
-  const int wv = threadIdx.x >> 6, nwv = FN_SETUP_NT / 64;
+  // lane = draw; the NLG_SETUP_NT / 64 waves of a workgroup share its 64 draws: the loops whose time points are independent
+  // (linearisation, conditional factors, tables) are split over the waves, the Kalman / smoother recursion runs on wave 0
+  const int wv = threadIdx.x >> 6, nwv = NLG_SETUP_NT / 64;
   const int d = min(blockIdx.x * 64 + (int)(threadIdx.x & 63), b.F - 1);  // (surplus lanes redo the last draw: same values, no branch around the barriers)
   constexpr int MM = M * M;
   const size_t F = (size_t)b.F;
@@ -279,7 +315,9 @@ __global__ void __launch_bounds__(FN_SETUP_NT) fn_setup_kernel(const FnSetupDev 
   double* cc = w;                 w += (size_t)(n + 1) * MM * F;
   double* K = w;                  w += (size_t)n * M * F;
   double* v = w;                  w += (size_t)n * F;
-  double* Fs = w;
+  double* Fs = w;                 w += (size_t)n * F;
+  double* Vf = w;                 w += (size_t)(n + 1) * MM * F;  // V_t^(1/2) and C_t: written by whichever wave has time point t
+  double* Cf = w;
   // ---- linearisation at the stored mode: Z_t = Z'(mode_t), D_t = Z(mode_t) - Z_t mode_t, T_t = T'(mode_t),
   // C_t = T(mode_t) - T_t mode_t  (approximate_for_is, src/model_ssm_nlg.cpp:146-176; scales and approx_loglik stay 0)
   const double* __restrict__ mode = b.modes + (size_t)d * M * n;
@@ -319,13 +357,21 @@ __global__ void __launch_bounds__(FN_SETUP_NT) fn_setup_kernel(const FnSetupDev 
   for (int q = 0; q < MM; q++) sP1[(size_t)q * F] = ex[M + q];
   }
   __syncthreads();  // the linearised model of every time point is in memory
+  LG_STAMP(1);
   LgModel g;
   g.n = n;
   g.Z = sZ; g.Zs = M; g.T = sT; g.Ts = MM; g.RR = sRR; g.Rs = 0; g.D = sD; g.Ds = 1; g.C = sC; g.Cs = M;
   g.y = sy; g.H = sH; g.Hs = 0; g.a1 = sa1; g.P1 = sP1;
-  if (wv == 0) b.ok[d] = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F) ? 1 : 0;  // at = alphahat, Pt = V_t^(1/2), cc = C_t after conditional_cov
-  __syncthreads();
-  const bool ok = b.ok[d] != 0;
+  // Kalman filter and covariance smoother on wave 0 (sequential in time); the conditional factors of the time points are
+  // independent of each other given the smoother's output, so the waves share them (2.2 of this kernel's 4.1 ms were that loop on
+  // one wave; profiles/r03_setup_phases.txt)
+  __shared__ int s_ok[64];
+  if (wv == 0) s_ok[threadIdx.x & 63] = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F, false) ? 1 : 0;  // at = alphahat, Pt = Var, cc = lag-one Cov
+  LG_STAMP(4);
+  const bool ok = setup_factors_by_wave<M>(n, wv, nwv, s_ok, at, Pt, cc, Vf, Cf, F);
+  LG_STAMP(5);
+  if (wv == 0) b.ok[d] = ok ? 1 : 0;
+  Pt = Vf; cc = Cf;  // what the tables read: V_t^(1/2) and C_t
   // ---- tables (build_fn_psi_tables): proposal operands, observation rows, initial state, approximating (T_t, C_t)
   constexpr int MS = 2 * MM + M, OS = ROW_HDR + SER_HDR + M, AS = MM + M;
   double* __restrict__ mats = b.mats + (size_t)d * n * MS;
@@ -371,9 +417,17 @@ __global__ void __launch_bounds__(FN_SETUP_NT) fn_setup_kernel(const FnSetupDev 
 #pragma unroll
   for (int q = 0; q < MM; q++) ini[M + q] = ok ? Pt[(size_t)q * F] : 0.0;
   }
+#ifdef BSSM_SETUP_STAMPS
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned long long e = wall_clock64(), *q = g_setup_stamps;
+    printf("fn_setup_kernel F=%d n=%d us: linearise %.1f forward %.1f backward %.1f conditional %.1f check %.1f tables %.1f total %.1f\n", b.F, n,
+           (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (e - q[5]) * 0.01, (e - q[0]) * 0.01);
+  }
+#endif
 }
 hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream) {
-  const dim3 grid((b.F + 63) / 64), block(FN_SETUP_NT);
+  const dim3 grid((b.F + 63) / 64), block(NLG_SETUP_NT);
   switch (b.m) {
     case 1: hipLaunchKernelGGL(fn_setup_kernel<1>, grid, block, 0, stream, b); break;
     case 2: hipLaunchKernelGGL(fn_setup_kernel<2>, grid, block, 0, stream, b); break;
@@ -387,8 +441,8 @@ hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream) {
 // kernels' table-driven forms): the result is compared with the host set-up at 1e-12.
 size_t ung_setup_scratch_doubles(int n, int m) {
   const size_t mm = (size_t)m * m, n1 = (size_t)n + 1;
-  //      ay  aH  ayraw scales  at       Pt        cc        K              v   Fs
-  return (size_t)4 * n + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n;
+  //      ay  aH  ayraw scales  at       Pt        cc        K              v   Fs   Vf        Cf
+  return (size_t)4 * n + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n + n1 * mm + n1 * mm;
 }
 template <int M>
 __global__ void __launch_bounds__(FN_SETUP_NT) ung_setup_kernel(const UngSetupDev b) {
@@ -410,7 +464,9 @@ __global__ void __launch_bounds__(FN_SETUP_NT) ung_setup_kernel(const UngSetupDe
   double* cc = w;     w += (size_t)(n + 1) * MM * F;
   double* K = w;      w += (size_t)n * M * F;
   double* v = w;      w += (size_t)n * F;
-  double* Fs = w;
+  double* Fs = w;     w += (size_t)n * F;
+  double* Vf = w;     w += (size_t)(n + 1) * MM * F;
+  double* Cf = w;
   const int dist = (int)in[b.oh * F];
   const double phi = in[(b.oh + 1) * F];
   // ---- approximate_for_is: one Laplace step at the stored mode (src/model_ssm_ung.cpp:302-342) and the scales (:241-292)
@@ -446,9 +502,11 @@ __global__ void __launch_bounds__(FN_SETUP_NT) ung_setup_kernel(const UngSetupDe
   g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = ay; g.H = aH; g.Hs = 1;
   g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
   __syncthreads();  // pseudo-observations of every time point are in memory
-  if (wv == 0) b.ok[d] = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F) ? 1 : 0;  // at = alphahat, Pt = V_t^(1/2), cc = C_t after conditional_cov
-  __syncthreads();
-  const bool ok = b.ok[d] != 0;
+  __shared__ int s_ok[64];
+  if (wv == 0) s_ok[threadIdx.x & 63] = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F, false) ? 1 : 0;  // at = alphahat, Pt = Var, cc = lag-one Cov
+  const bool ok = setup_factors_by_wave<M>(n, wv, nwv, s_ok, at, Pt, cc, Vf, Cf, F);  // the waves share the conditional factors
+  if (wv == 0) b.ok[d] = ok ? 1 : 0;
+  Pt = Vf; cc = Cf;  // what the tables read: V_t^(1/2) and C_t
   // ---- tables: psi proposal operands (src/model_ssm_ung.cpp:585-586), observation rows, initial state (:543)
   constexpr int MS = 2 * MP * MP + MP, OS = ROW_HDR + SER_HDR + MP;
   double* __restrict__ mats = b.mats + (size_t)d * n * MS;
