@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -1662,6 +1663,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
       // per run of consecutive draw indices (a single run unless is1 mixes particle counts).
       size_t f0 = 0;
       std::vector<double> ll(F);
+      std::deque<DevBuf> tail_ws;  // step-kernel workspaces of the tail filters: alive until the read-back below has waited for them
       while (f0 < F) {
         size_t f1 = f0 + 1;
         while (f1 < F && order[pos + f1] == order[pos + f1 - 1] + 1) f1++;
@@ -1684,10 +1686,45 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           bssm::grid_workspace_carve(sub, wsb.p, &gw);
           HIP_TRY(bssm::launch_grid_filter(sub, gw, nullptr));
           HIP_TRY(hipDeviceSynchronize());
+          HIP_TRY(bssm::launch_zero_dead_tail(sub, true, nullptr));
         } else {
-          HIP_TRY(bssm::launch_wg_filter(sub, nullptr));
+          // A particle system that takes more than half a CU's LDS runs one workgroup per CU, so the filters go through the chip in
+          // rounds of `cus` workgroups that all take the same time; a sparsely filled LAST round (C5: 2 340 = 9 x 256 + 36; one rank's
+          // shard of it at 8 ranks: 292 = 256 + 36) costs a full round.  Those filters go through the step kernels instead (several
+          // workgroups per filter, one launch per time step), behind the full rounds on the same stream: 36 filters of the C5 shape
+          // 3.7 -> 2.5 ms alone, about 1 ms behind other work (profiles/r03_c5_tail_round.txt).  Not when a path is forced.
+          int tail = 0;
+          if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && !std::getenv("BSSM_AMD_FORCE_PATH") && !std::getenv("BSSM_AMD_NO_TAIL_SPLIT")) {
+            int dev = 0; hipDeviceProp_t prop;
+            const int cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            const int r = sub.F % cus;
+            if (r > 0 && r <= cus * 3 / 8) tail = r;
+          }
+          bssm::FilterBatch head = sub;
+          head.F = sub.F - tail;
+          if (head.F > 0) {
+            HIP_TRY(bssm::launch_wg_filter(head, nullptr));
+            HIP_TRY(bssm::launch_zero_dead_tail(head, true, nullptr));
+          }
+          if (tail > 0) {
+            const size_t h0 = (size_t)head.F;
+            bssm::FilterBatch tl = sub;
+            tl.F = tail;
+            tl.mats += db.fb.mats_fstride * h0; tl.obs += db.fb.obs_fstride * h0; tl.init += db.fb.init_fstride * h0;
+            tl.loglik += h0; tl.dead_at += h0;
+            if (tl.fpar) tl.fpar += tl.fpar_fstride * h0;
+            if (tl.amats) tl.amats += tl.amats_fstride * h0;
+            if (need_hist) { tl.alpha_hist += h0 * (size_t)(n + 1) * m * N; tl.indices += h0 * (size_t)n * N; }
+            tl.stream0 = sub.stream0 + (uint32_t)h0;
+            tail_ws.emplace_back();
+            int B, chunk;
+            HIP_TRY(tail_ws.back().alloc(bssm::grid_workspace_bytes(tl, &B, &chunk)));
+            bssm::GridWorkspace gw;
+            bssm::grid_workspace_carve(tl, tail_ws.back().p, &gw);
+            HIP_TRY(bssm::launch_grid_filter(tl, gw, nullptr));
+            HIP_TRY(bssm::launch_zero_dead_tail(tl, true, nullptr));
+          }
         }
-        HIP_TRY(bssm::launch_zero_dead_tail(sub, true, nullptr));
         f0 = f1;
       }
       // the previous chunk's summary has been running beside these filters: collect it while they finish

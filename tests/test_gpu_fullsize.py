@@ -135,3 +135,37 @@ def test_c5_post_correct_block_invariance():
     # the IS weights are likelihood ratios to the Gaussian approximation at the stored mode: spread stays moderate
     lw = full["loglik"]
     assert lw.std() < 5.0
+
+
+def test_c5_post_correct_tail_round_through_the_step_kernels(monkeypatch):
+    """configs[4] shape, 300 draws: one workgroup-resident filter per CU, so 256 draws fill a round and the 44 left over go
+    through the step kernels behind it (api.cpp run_is_core; profiles/r03_c5_tail_round.txt).  Same Philox streams either way:
+    against the all-workgroup run (BSSM_AMD_NO_TAIL_SPLIT) and against two blocks of 150 (what two GPUs would filter, no
+    tail there) the log-weights agree to reduction-order rounding, and the draws that kept their kernel family bit for bit"""
+    rng = np.random.default_rng(106)
+    n, K, dT = 300, 500.0, 0.1
+    r = np.zeros(n); pp = np.zeros(n); pp[0] = 50.0
+    for t in range(1, n):
+        r[t] = r[t - 1] + rng.normal(0, 0.05)
+        rr = np.exp(r[t - 1]) / (1 + np.exp(r[t - 1]))
+        pp[t] = K * pp[t - 1] * np.exp(rr * dT) / (K + pp[t - 1] * (np.exp(rr * dT) - 1)) + rng.normal(0, 1)
+    y = pp + rng.normal(0, 1, n)
+    th0 = np.array([0.0, np.log(0.05), 0.0])
+    model = M.ssm_nlg(y, "nlg_growth", theta=th0, known_params=[dT, K, 0.0, 50.0, 1.0, 100.0])
+    ns = 300
+    theta = th0 + rng.normal(0, 0.05, (ns, 3))
+    counts = np.ones(ns, dtype=np.uint32)
+    mode = F.psi_setup(model)["mode"].reshape(-1, order="F")
+    modes = np.tile(mode[:, None], (1, ns))
+    split = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4)
+    monkeypatch.setenv("BSSM_AMD_NO_TAIL_SPLIT", "1")
+    whole = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4)
+    monkeypatch.delenv("BSSM_AMD_NO_TAIL_SPLIT")
+    lo = PC._run_local_block_nlg(model, theta[:150], modes[:, :150], counts[:150], 0, ns, 4096, 9, 2, 3, 2)
+    hi = PC._run_local_block_nlg(model, theta[150:], modes[:, 150:], counts[150:], 150, ns, 4096, 9, 2, 3, 2)
+    two = np.concatenate([lo["loglik"], hi["loglik"]])
+    assert np.all(np.isfinite(split["loglik"]))
+    assert np.array_equal(split["loglik"][:256], whole["loglik"][:256])      # the full round: same kernels, same bits
+    assert np.array_equal(whole["loglik"], two)                               # workgroup-resident everywhere
+    assert not np.array_equal(split["loglik"][256:], whole["loglik"][256:])   # the tail really took the other kernels
+    assert np.max(np.abs(split["loglik"] - whole["loglik"])) <= 1e-10 * n
