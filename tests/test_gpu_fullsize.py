@@ -169,3 +169,11 @@ def test_c5_post_correct_tail_round_through_the_step_kernels(monkeypatch):
     assert np.array_equal(whole["loglik"], two)                               # workgroup-resident everywhere
     assert not np.array_equal(split["loglik"][256:], whole["loglik"][256:])   # the tail really took the other kernels
     assert np.max(np.abs(split["loglik"] - whole["loglik"])) <= 1e-10 * n
+    # with the smoothing summaries (history pools shared by the two kernel families of the chunk)
+    s2 = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 2, 4)
+    monkeypatch.setenv("BSSM_AMD_NO_TAIL_SPLIT", "1")
+    w2 = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 2, 4)
+    assert np.array_equal(s2["loglik"], split["loglik"]) and np.array_equal(w2["loglik"], whole["loglik"])
+    for k in ("alphahat_i", "Vt_i"):
+        assert np.array_equal(s2[k][..., :256], w2[k][..., :256]), k
+        assert np.allclose(s2[k], w2[k], rtol=1e-6, atol=1e-9), k  # (a last-ulp weight can move an ancestor: loose on purpose)
