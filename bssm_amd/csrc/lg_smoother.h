@@ -209,9 +209,14 @@ struct LgSmoother {
       if (!upd) {
         v[(size_t)t * es] = 0.0;
         for (int i = 0; i < M; i++) Kt[i] = 0.0;
-        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += T[i + M * q] * a[q]; a1n[i] = Cv[i] + s; }
-        mul(T, P, tmp); mul_bt(tmp, T, P1n);
-        for (int q = 0; q < MM; q++) P1n[q] = P1n[q] + RR[q];
+        if (moves) {
+          for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += T[i + M * q] * a[q]; a1n[i] = Cv[i] + s; }
+          mul(T, P, tmp); mul_bt(tmp, T, P1n);
+          for (int q = 0; q < MM; q++) P1n[q] = P1n[q] + RR[q];
+        } else {  // identity transition without noise: the products with I and the sums with 0 are exact, so they are skipped
+          for (int i = 0; i < M; i++) a1n[i] = a[i];
+          for (int q = 0; q < MM; q++) P1n[q] = P[q];
+        }
         symmatu(P1n);
       } else {
         double za = 0.0;
@@ -221,12 +226,17 @@ struct LgSmoother {
         double au[M];
         for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += P[i + M * q] * Z[q]; Kt[i] = s / F; }
         for (int i = 0; i < M; i++) au[i] = a[i] + Kt[i] * vt;
-        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += T[i + M * q] * au[q]; a1n[i] = Cv[i] + s; }
+        if (moves) { for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += T[i + M * q] * au[q]; a1n[i] = Cv[i] + s; } }
+        else for (int i = 0; i < M; i++) a1n[i] = au[i];
         for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) IKZ[i + M * j] = (i == j ? 1.0 : 0.0) - Kt[i] * Z[j];
         mul(IKZ, P, tmp); mul_bt(tmp, IKZ, inner);
         for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) inner[i + M * j] = inner[i + M * j] + Kt[i] * HH * Kt[j];
-        mul(T, inner, tmp); mul_bt(tmp, T, P1n);
-        for (int q = 0; q < MM; q++) P1n[q] = P1n[q] + RR[q];
+        if (moves) {
+          mul(T, inner, tmp); mul_bt(tmp, T, P1n);
+          for (int q = 0; q < MM; q++) P1n[q] = P1n[q] + RR[q];
+        } else {
+          for (int q = 0; q < MM; q++) P1n[q] = inner[q];
+        }
         symmatu(P1n);
       }
       stv(K + (size_t)t * M * es, es, M, Kt);
@@ -246,7 +256,8 @@ struct LgSmoother {
     for (int t = n - 1; t >= 0; t--) {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
       ldv(g.Z + ((size_t)tr * g.Zs + (size_t)js * M) * es, es, M, Z);
-      if (sub == 1 || js == sub - 1) {
+      const bool movesb = sub == 1 || js == sub - 1;
+      if (movesb) {
         ldv(g.T + (size_t)tr * g.Ts * es, es, MM, T);
       } else {
         for (int q = 0; q < MM; q++) T[q] = 0.0;
@@ -260,8 +271,8 @@ struct LgSmoother {
       if (F > 0.0) {
         ldv(K + (size_t)t * M * es, es, M, Kt);
         for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) IKZ[i + M * j] = (i == j ? 1.0 : 0.0) - Kt[i] * Z[j];
-        mul(T, IKZ, L);
-        Lm = L;
+        if (movesb) { mul(T, IKZ, L); Lm = L; }
+        else Lm = IKZ;  // (I times IKZ, exactly)
       }
       // cc[t] = Pt[t] L' (I - Nt cc[t])
       mul(Nt, ct, tmp);
