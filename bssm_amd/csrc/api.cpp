@@ -1950,10 +1950,10 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   // ingests and packs the draw; Laplace step at the stored mode, scales, smoother, conditional factors and the filter's
   // tables are ONE kernel per pipeline chunk (ung_setup_kernel), whose outputs the filter reads in place.
   // BSSM_AMD_DEVICE_SETUP = 0 / 1 select the host set-up / the device smoother alone (tested against each other and the oracle).
-  // ssm_mng draws (p0 > 1 independent series per time point): the same through mng_setup_kernel, by default where the
-  // device smoother is the default (few host threads: device_setup_enabled).
-  bool dev_full = psi && have_device() && m <= 8 && job->is_type != 1 &&
-                  (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : device_setup_enabled(job->n_threads));
+  // ssm_mng draws (p0 > 1 independent series per time point): the same through mng_setup_kernel + mng_factors_kernel +
+  // mng_tables_kernel; the default for any number of host threads since late round 3 (512 draws of the C4 shape: 0.069 s against
+  // 0.109 s with 32 host threads; until the factors left the sequential kernel it was 0.26 s and only the default below 8 threads).
+  bool dev_full = psi && have_device() && m <= 8 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
   if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) dev_full = dev_full && env[0] == '2';
   if (std::getenv("BSSM_AMD_GENERIC_SETUP")) dev_full = false;
   if (dev_full) {

@@ -19,6 +19,15 @@
 #define LG_HD __host__ __device__
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LG_UNROLL _Pragma("unroll")
+// the big routines are inlined into the set-up kernels: as separate device functions they get the default register budget of a
+// callee (256 VGPRs) instead of the 512 a one-wave-per-SIMD kernel owns, and keep their 8 x 8 work arrays in scratch memory
+#define LG_INL __attribute__((always_inline))
+#else
+#define LG_UNROLL
+#define LG_INL
+#endif
 // analysis builds: the includer may define LG_STAMP(i) to record a clock at the phase boundaries of LgSmoother::run
 #ifndef LG_STAMP
 #define LG_STAMP(i)
@@ -56,35 +65,50 @@ struct LgSmoother {
   static constexpr double kEps = DBL_EPSILON;
 
   // C = A * B (all M x M, column-major), accumulation over the inner index in ascending order from 0
+  // (LG_UNROLL: on the device the three loops are unrolled completely, so that the operands of a product are read in one batch
+  // and the M^3 multiply-adds run on registers; left as loops, the arrays are indexed dynamically and every element access of an
+  // 8 x 8 product is a dependent round trip to scratch memory)
   LG_HD static void mul(const double* A, const double* B, double* C) {
-    for (int j = 0; j < M; j++)
+    LG_UNROLL
+    for (int j = 0; j < M; j++) {
+      LG_UNROLL
       for (int i = 0; i < M; i++) {
         double s = 0.0;
+        LG_UNROLL
         for (int q = 0; q < M; q++) s += A[i + M * q] * B[q + M * j];
         C[i + M * j] = s;
       }
+    }
   }
   LG_HD static void mul_bt(const double* A, const double* B, double* C) {  // A * B'
-    for (int j = 0; j < M; j++)
+    LG_UNROLL
+    for (int j = 0; j < M; j++) {
+      LG_UNROLL
       for (int i = 0; i < M; i++) {
         double s = 0.0;
+        LG_UNROLL
         for (int q = 0; q < M; q++) s += A[i + M * q] * B[j + M * q];
         C[i + M * j] = s;
       }
+    }
   }
   LG_HD static void mul_at(const double* A, const double* B, double* C) {  // A' * B
-    for (int j = 0; j < M; j++)
+    LG_UNROLL
+    for (int j = 0; j < M; j++) {
+      LG_UNROLL
       for (int i = 0; i < M; i++) {
         double s = 0.0;
+        LG_UNROLL
         for (int q = 0; q < M; q++) s += A[q + M * i] * B[q + M * j];
         C[i + M * j] = s;
       }
+    }
   }
   LG_HD static void symmatu(double* A) { for (int j = 0; j < M; j++) for (int i = j + 1; i < M; i++) A[i + M * j] = A[j + M * i]; }
 
   // |eigenvalues| (descending) and vectors of a symmetric matrix by cyclic Jacobi, sign convention: the largest
   // component of every vector is positive -- what arma::svd_econ(..., "left") yields for a PSD input up to sign
-  LG_HD static void sym_singular(const double* Ain, double* U, double* s) {
+  LG_HD LG_INL static void sym_singular(const double* Ain, double* U, double* s) {
     double A[MM], W[MM];
     for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) A[i + M * j] = 0.5 * (Ain[i + M * j] + Ain[j + M * i]);
     for (int q = 0; q < MM; q++) W[q] = 0.0;
@@ -144,14 +168,17 @@ struct LgSmoother {
   // conditional_cov (src/conditional_dist.cpp:4-31) at one time point t: from the smoothed covariances Pt[t - 1], Pt[t] and the
   // cross-covariance cc[t - 1] to Vout[t] = U sqrt(s) of Var(alpha_t | alpha_{t-1}, y) and Cout[t] = Cov' pinv(V_{t-1}); t = 0 has
   // the factor of Pt[0] only.  Vout / Cout may be Pt / cc themselves when the caller goes from the last time point down.
-  LG_HD static void cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es) {
+  // Returns whether everything it wrote is finite.
+  LG_HD LG_INL static bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es) {
     double U[MM], s[M], W[MM], Vp[MM], Vc[MM], Cp[MM], tmp[MM], tmp2[MM];
+    int bad = 0;
     if (t == 0) {
       ldv(Pt, es, MM, Vp);
       sym_singular(Vp, U, s);
       for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vp[i + M * c] = U[i + M * c] * sqrt(s[c]);
       stv(Vout, es, MM, Vp);
-      return;
+      for (int q = 0; q < MM; q++) bad |= !lg_finite(Vp[q]);
+      return bad == 0;
     }
     ldv(Pt + (size_t)(t - 1) * MM * es, es, MM, Vp);
     ldv(Pt + (size_t)t * MM * es, es, MM, Vc);
@@ -166,12 +193,15 @@ struct LgSmoother {
     mul(tmp, Cp, tmp2);
     for (int q = 0; q < MM; q++) Vc[q] = Vc[q] - tmp2[q];
     stv(Cout + (size_t)t * MM * es, es, MM, tmp);
+    for (int q = 0; q < MM; q++) bad |= !lg_finite(tmp[q]);
     sym_singular(Vc, U, s);
     for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vc[i + M * c] = U[i + M * c] * sqrt(s[c]);
     stv(Vout + (size_t)t * MM * es, es, MM, Vc);
+    for (int q = 0; q < MM; q++) bad |= !lg_finite(Vc[q]);
+    return bad == 0;
   }
 
-  LG_HD static bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es = 1,
+  LG_HD LG_INL static bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es = 1,
                         bool with_factors = true) {
     const int n = g.n;
     double a[M], P[MM], a1n[M], P1n[MM], Z[M], T[MM], RR[MM], Cv[M];
@@ -263,25 +293,45 @@ struct LgSmoother {
         for (int q = 0; q < MM; q++) T[q] = 0.0;
         for (int i = 0; i < M; i++) T[i + M * i] = 1.0;
       }
+      // Series at a time (sub > 1): the conditional factors are taken at the time points only (virtual steps s * sub), from the
+      // covariances of the steps s * sub - 1 and s * sub and the cross-covariance of step s * sub - 1 -- the other virtual steps only
+      // carry r_t / N_t through, so their smoothed covariance and cross-covariance (five of a step's seven matrix products) are
+      // not formed; what is needed comes out bit for bit as before
+      const bool need_P = sub == 1 || js == 0 || js == sub - 1, need_cc = sub == 1 || js == sub - 1;
       ldv(at + (size_t)t * M * es, es, M, a);
       ldv(Pt + (size_t)t * MM * es, es, MM, P);
-      ldv(cc + (size_t)t * MM * es, es, MM, ct);
+      if (need_cc) ldv(cc + (size_t)t * MM * es, es, MM, ct);
       const double F = Fs[(size_t)t * es];
       const double* Lm = T;
-      if (F > 0.0) {
-        ldv(K + (size_t)t * M * es, es, M, Kt);
+      if (F > 0.0) ldv(K + (size_t)t * M * es, es, M, Kt);
+      if (F > 0.0 && movesb) {
         for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) IKZ[i + M * j] = (i == j ? 1.0 : 0.0) - Kt[i] * Z[j];
-        if (movesb) { mul(T, IKZ, L); Lm = L; }
-        else Lm = IKZ;  // (I times IKZ, exactly)
+        mul(T, IKZ, L); Lm = L;
       }
       // cc[t] = Pt[t] L' (I - Nt cc[t])
-      mul(Nt, ct, tmp);
-      for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) tmp[i + M * j] = (i == j ? 1.0 : 0.0) - tmp[i + M * j];
-      mul_bt(P, Lm, tmp2);
-      mul(tmp2, tmp, ct);
+      if (need_cc) {
+        mul(Nt, ct, tmp);
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) tmp[i + M * j] = (i == j ? 1.0 : 0.0) - tmp[i + M * j];
+        mul_bt(P, Lm, tmp2);
+        mul(tmp2, tmp, ct);
+      }
       double rn[M];
-      for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += Lm[q + M * i] * rt[q]; rn[i] = s; }
-      mul_at(Lm, Nt, tmp); mul(tmp, Lm, N2);
+      if (movesb) {
+        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += Lm[q + M * i] * rt[q]; rn[i] = s; }
+        mul_at(Lm, Nt, tmp); mul(tmp, Lm, N2);
+      } else if (F > 0.0) {
+        // a virtual step inside a time point: L = I - K Z' is a rank-one change of the identity, so L' r and L' N L are formed in
+        // O(M^2) instead of two M^3 products: with w = N K (N symmetric) and kappa = K' w,
+        //   L' r = r - Z (K' r),   L' N L = N - Z w' - w Z' + kappa Z Z'
+        double w[M], kr = 0.0, kappa = 0.0;
+        for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += Nt[i + M * q] * Kt[q]; w[i] = s; }
+        for (int q = 0; q < M; q++) { kr += Kt[q] * rt[q]; kappa += Kt[q] * w[q]; }
+        for (int i = 0; i < M; i++) rn[i] = rt[i] - Z[i] * kr;
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) N2[i + M * j] = Nt[i + M * j] - Z[i] * w[j] - w[i] * Z[j] + kappa * Z[i] * Z[j];
+      } else {  // no update at this virtual step: L = I
+        for (int i = 0; i < M; i++) rn[i] = rt[i];
+        for (int q = 0; q < MM; q++) N2[q] = Nt[q];
+      }
       if (F > 0.0) {
         const double vt = v[(size_t)t * es];
         for (int i = 0; i < M; i++) rn[i] = Z[i] / F * vt + rn[i];
@@ -291,31 +341,35 @@ struct LgSmoother {
       for (int q = 0; q < MM; q++) Nt[q] = N2[q];
       symmatu(Nt);
       for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += P[i + M * q] * rt[q]; a[i] = a[i] + s; }
-      mul(P, Nt, tmp); mul(tmp, P, tmp2);
-      symmatu(tmp2);
-      for (int q = 0; q < MM; q++) P[q] = P[q] - tmp2[q];
-      for (int q = 0; q < MM; q++) if (!lg_finite(P[q]) || !lg_finite(ct[q])) return false;
-      stv(cc + (size_t)t * MM * es, es, MM, ct);
+      for (int i = 0; i < M; i++) if (!lg_finite(a[i])) return false;
       stv(at + (size_t)t * M * es, es, M, a);
-      stv(Pt + (size_t)t * MM * es, es, MM, P);
+      if (need_cc) {
+        for (int q = 0; q < MM; q++) if (!lg_finite(ct[q])) return false;
+        stv(cc + (size_t)t * MM * es, es, MM, ct);
+      }
+      if (need_P) {
+        mul(P, Nt, tmp); mul(tmp, P, tmp2);
+        symmatu(tmp2);
+        for (int q = 0; q < MM; q++) P[q] = P[q] - tmp2[q];
+        for (int q = 0; q < MM; q++) if (!lg_finite(P[q])) return false;
+        stv(Pt + (size_t)t * MM * es, es, MM, P);
+      }
     }
     for (int q = 0; q < MM; q++) cc[((size_t)n * MM + q) * es] = 0.0;
     LG_STAMP(3);
     if (!with_factors) return true;
     // ---- conditional_cov: Vt <- U sqrt(s) of Var(alpha_t | alpha_{t-1}, y), Ct <- Cov' pinv(V_{t-1}); in place, so from the
     // last time point down (step t reads the covariances of t - 1 and t and the cross-covariance of t - 1)
+    bool ok = true;
     for (int t = n; t >= 0; t--) {
       if (sub > 1 && t % sub != 0) continue;  // a virtual step inside a time point: no factor of its own
-      cond_step(t, Pt, cc, Pt, cc, es);
+      const bool okt = cond_step(t, Pt, cc, Pt, cc, es);
+      ok = ok && okt;
     }
     LG_STAMP(4);
-    // (no short-circuit: the loads of this sweep are independent of each other and of `bad`, so they overlap)
-    int bad = 0;
-    for (int t = 0; t <= n; t++) {
-      for (int i = 0; i < M; i++) bad |= !lg_finite(at[((size_t)t * M + i) * es]);
-      for (int q = 0; q < MM; q++) bad |= (!lg_finite(Pt[((size_t)t * MM + q) * es])) | (!lg_finite(cc[((size_t)t * MM + q) * es]));
-    }
-    return bad == 0;
+    // (every smoothed mean, covariance and cross-covariance was tested where the backward pass produced it, every factor in
+    // cond_step; the predicted mean of slot n in the forward pass: a last sweep over the arrays has nothing left to find)
+    return ok;
   }
 
   // Smoothed state means only (ssm_ulg::fast_smoother, src/model_ssm_ulg.cpp:252-305): the inner step of the mode

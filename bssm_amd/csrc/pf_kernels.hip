@@ -257,17 +257,12 @@ hipError_t launch_lg_setup(const LgBatchDev& b, hipStream_t stream) {
 template <int M>
 __device__ __forceinline__ bool setup_factors_by_wave(int n, int wv, int nwv, int* s_ok, const double* at, const double* Pt, const double* cc,
                                                       double* Vf, double* Cf, size_t F) {
-  constexpr int MM = M * M;
   const int lane = threadIdx.x & 63;
   __syncthreads();
   if (s_ok[lane]) {
     int bad = 0;
     for (int t = n - wv; t >= 0; t -= nwv) {
-      LgSmoother<M>::cond_step(t, Pt, cc, Vf, Cf, F);
-#pragma unroll
-      for (int i = 0; i < M; i++) bad |= !lg_finite(at[((size_t)t * M + i) * F]);
-#pragma unroll
-      for (int q = 0; q < MM; q++) bad |= (!lg_finite(Vf[((size_t)t * MM + q) * F])) | (t > 0 && !lg_finite(Cf[((size_t)t * MM + q) * F]));
+      bad |= !LgSmoother<M>::cond_step(t, Pt, cc, Vf, Cf, F);  // (the smoothed means were tested where the backward pass produced them)
     }
     if (bad) s_ok[lane] = 0;  // (every writer stores the same value)
   }
@@ -594,27 +589,45 @@ hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream) {
 // and device otherwise.
 size_t mng_setup_scratch_doubles(int n, int m, int p) {
   const size_t mm = (size_t)m * m, nv = (size_t)n * p, n1 = nv + 1;
-  //      ay  aH    scales  at       Pt        cc        K        v    Fs
-  return 2 * nv + n + n1 * m + n1 * mm + n1 * mm + nv * m + nv + nv;
+  //      ay  aH    scales  at       Pt        cc        K        v    Fs   Vf        Cf
+  return 2 * nv + n + n1 * m + n1 * mm + n1 * mm + nv * m + nv + nv + n1 * mm + n1 * mm;
 }
+// Three kernels per chunk: (A) Laplace step + Kalman filter + covariance smoother, one lane per draw, sequential in time -- the only
+// sequential part; (B) the conditional factors, independent across time points given the smoother's output: one wave per (64 draws,
+// time point); (C) the tables, likewise.  As ONE kernel the factors (two 8 x 8 Jacobi eigen-decompositions per time point) and the last
+// sweep were 60 % of 229 ms on the C4 shape (512 draws, m = 8, p = 4, T = 200: profiles/r03_setup_phases.txt).
+template <int M>
+struct MngWork {
+  const double* in;
+  double *ay, *aH, *scl, *at, *Pt, *cc, *K, *v, *Fs, *Vf, *Cf;
+  __device__ MngWork(const UngSetupDev& b, int d) {
+    constexpr int MM = M * M;
+    const size_t F = (size_t)b.F;
+    const int n = b.n, nv = n * b.p;
+    in = b.in + d;
+    double* w = b.scratch + d;
+    ay = w;     w += (size_t)nv * F;   // approximating y
+    aH = w;     w += (size_t)nv * F;
+    scl = w;    w += (size_t)n * F;
+    at = w;     w += (size_t)(nv + 1) * M * F;
+    Pt = w;     w += (size_t)(nv + 1) * MM * F;
+    cc = w;     w += (size_t)(nv + 1) * MM * F;
+    K = w;      w += (size_t)nv * M * F;
+    v = w;      w += (size_t)nv * F;
+    Fs = w;     w += (size_t)nv * F;
+    Vf = w;     w += (size_t)(nv + 1) * MM * F;  // V_t^(1/2) and C_t at the time points (virtual steps s p)
+    Cf = w;
+  }
+};
 template <int M>
 __global__ void __launch_bounds__(64) mng_setup_kernel(const UngSetupDev b) {
   const int d = blockIdx.x * 64 + threadIdx.x;
   if (d >= b.F) return;
-  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
   const size_t F = (size_t)b.F;
   const int n = b.n, p = b.p, nv = n * p;
-  const double* in = b.in + d;
-  double* w = b.scratch + d;
-  double* ay = w;     w += (size_t)nv * F;   // approximating y
-  double* aH = w;     w += (size_t)nv * F;
-  double* scl = w;    w += (size_t)n * F;
-  double* at = w;     w += (size_t)(nv + 1) * M * F;
-  double* Pt = w;     w += (size_t)(nv + 1) * MM * F;
-  double* cc = w;     w += (size_t)(nv + 1) * MM * F;
-  double* K = w;      w += (size_t)nv * M * F;
-  double* v = w;      w += (size_t)nv * F;
-  double* Fs = w;
+  const MngWork<M> W(b, d);
+  const double* in = W.in;
+  double *ay = W.ay, *aH = W.aH, *scl = W.scl;
   for (int t = 0; t < n; t++) {
     double sc = 0.0;
     for (int j = 0; j < p; j++) {
@@ -646,15 +659,43 @@ __global__ void __launch_bounds__(64) mng_setup_kernel(const UngSetupDev b) {
   g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
   g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = ay; g.H = aH; g.Hs = 1;
   g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
-  const bool ok = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F);
+  LG_STAMP(1);
+  const bool ok = LgSmoother<M>::run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F, false);  // at = alphahat, Pt = Var, cc = lag-one Cov
+  LG_STAMP(5);
   b.ok[d] = ok ? 1 : 0;
-  // ---- tables (build_psi_tables, fill_obs_rows): the moments of time point s sit at virtual step s p
+#ifdef BSSM_SETUP_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned long long* q = g_setup_stamps;
+    printf("mng_setup_kernel<%d> F=%d n=%d p=%d us: forward %.1f backward %.1f\n", M, b.F, n, p, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01);
+  }
+#endif
+}
+// (B) conditional factors of time point blockIdx.y (virtual step blockIdx.y * p) for the 64 draws of blockIdx.x
+template <int M>
+__global__ void __launch_bounds__(64) mng_factors_kernel(const UngSetupDev b) {
+  const int d = blockIdx.x * 64 + threadIdx.x;
+  if (d >= b.F || !b.ok[d]) return;
+  const MngWork<M> W(b, d);
+  if (!LgSmoother<M>::cond_step((int)blockIdx.y * b.p, W.Pt, W.cc, W.Vf, W.Cf, (size_t)b.F)) b.ok[d] = 0;  // (every writer stores 0)
+}
+// (C) tables of time point blockIdx.y (build_psi_tables, fill_obs_rows): the moments of time point s sit at virtual step s p
+template <int M>
+__global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
+  const int d = blockIdx.x * 64 + threadIdx.x;
+  if (d >= b.F) return;
+  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+  const size_t F = (size_t)b.F;
+  const int n = b.n, p = b.p, t = blockIdx.y;
+  const MngWork<M> W(b, d);
+  const double* in = W.in;
+  const double *at = W.at, *Pt = W.Vf, *cc = W.Cf, *ay = W.ay, *aH = W.aH, *scl = W.scl;
+  const bool ok = b.ok[d] != 0;
   const int sstride = SER_HDR + MP, OS = ROW_HDR + p * sstride;
   constexpr int MS = 2 * MP * MP + MP;
   double* __restrict__ mats = b.mats + (size_t)d * n * MS;
   double* __restrict__ obs = b.obs + (size_t)d * n * OS;
   double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
-  for (int t = 0; t < n; t++) {
+  {
     double* mt = mats + (size_t)t * MS;
     for (int q = 0; q < MS; q++) mt[q] = 0.0;
     const size_t i0 = (size_t)t * p, i1 = (size_t)(t + 1) * p;
@@ -662,7 +703,7 @@ __global__ void __launch_bounds__(64) mng_setup_kernel(const UngSetupDev b) {
 #pragma unroll
     for (int j = 0; j < M; j++) { ah0[j] = at[(i0 * M + j) * F]; ah1[j] = at[(i1 * M + j) * F]; }
 #pragma unroll
-    for (int q = 0; q < MM; q++) Ct1[q] = cc[(i1 * MM + q) * F];
+    for (int q = 0; q < MM; q++) Ct1[q] = ok ? cc[(i1 * MM + q) * F] : 0.0;
     if (ok) {
 #pragma unroll
       for (int c = 0; c < M; c++)
@@ -704,30 +745,39 @@ __global__ void __launch_bounds__(64) mng_setup_kernel(const UngSetupDev b) {
     row[RH_FLAG] = any ? 1.0 : 0.0;
     row[RH_SCALE] = any ? scl[(size_t)t * F] : 0.0;
   }
-  for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
-  if (ok) {
+  if (t == 0) {
+    for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
+    if (ok) {
 #pragma unroll
-    for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
+      for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
 #pragma unroll
-    for (int c = 0; c < M; c++)
+      for (int c = 0; c < M; c++)
 #pragma unroll
-      for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
+        for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
+    }
   }
 }
+template <int M>
+static hipError_t launch_mng_setup_m(const UngSetupDev& b, hipStream_t stream) {
+  const unsigned gx = (unsigned)((b.F + 63) / 64);
+  hipLaunchKernelGGL(mng_setup_kernel<M>, dim3(gx), dim3(64), 0, stream, b);
+  hipLaunchKernelGGL(mng_factors_kernel<M>, dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
+  hipLaunchKernelGGL(mng_tables_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  return hipGetLastError();
+}
 hipError_t launch_mng_setup(const UngSetupDev& b, hipStream_t stream) {
-  const dim3 grid((b.F + 63) / 64), block(64);
+  if (b.n < 1 || b.n >= 65535) return hipErrorInvalidValue;  // (time points ride in gridDim.y)
   switch (b.m) {
-    case 1: hipLaunchKernelGGL(mng_setup_kernel<1>, grid, block, 0, stream, b); break;
-    case 2: hipLaunchKernelGGL(mng_setup_kernel<2>, grid, block, 0, stream, b); break;
-    case 3: hipLaunchKernelGGL(mng_setup_kernel<3>, grid, block, 0, stream, b); break;
-    case 4: hipLaunchKernelGGL(mng_setup_kernel<4>, grid, block, 0, stream, b); break;
-    case 5: hipLaunchKernelGGL(mng_setup_kernel<5>, grid, block, 0, stream, b); break;
-    case 6: hipLaunchKernelGGL(mng_setup_kernel<6>, grid, block, 0, stream, b); break;
-    case 7: hipLaunchKernelGGL(mng_setup_kernel<7>, grid, block, 0, stream, b); break;
-    case 8: hipLaunchKernelGGL(mng_setup_kernel<8>, grid, block, 0, stream, b); break;
+    case 1: return launch_mng_setup_m<1>(b, stream);
+    case 2: return launch_mng_setup_m<2>(b, stream);
+    case 3: return launch_mng_setup_m<3>(b, stream);
+    case 4: return launch_mng_setup_m<4>(b, stream);
+    case 5: return launch_mng_setup_m<5>(b, stream);
+    case 6: return launch_mng_setup_m<6>(b, stream);
+    case 7: return launch_mng_setup_m<7>(b, stream);
+    case 8: return launch_mng_setup_m<8>(b, stream);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 // out[c * rows + r] = in[r * cols + c], 32 x 32 tiles through LDS (both sides coalesced): per-draw contiguous <->
 // draw-interleaved layouts of the smoother batch

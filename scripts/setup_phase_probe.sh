@@ -6,4 +6,5 @@ set -e
 cp bssm_amd/libbssm_amd.so /tmp/lib_keep.so
 cp bssm_amd/ab_stamps.so bssm_amd/libbssm_amd.so
 for ns in 2340 292; do echo "== $ns draws"; python scripts/c5_quick.py $ns 2 2>&1 | grep -E "fn_setup_kernel|seconds" | tail -4; done
+echo "== ssm_mng C4 shape, 512 draws"; python scripts/mng_one_call.py 2>&1 | grep -E "mng_setup_kernel|call" | tail -4
 cp /tmp/lib_keep.so bssm_amd/libbssm_amd.so
