@@ -278,45 +278,55 @@ size_t fn_setup_scratch_doubles(int n, int m) {
 #define BSSM_FN_SETUP_NT 512
 #endif
 constexpr int FN_SETUP_NT = BSSM_FN_SETUP_NT;  // threads per workgroup of ung_setup_kernel: 64 draws x FN_SETUP_NT / 64 waves
-#ifndef BSSM_NLG_SETUP_NT
-#define BSSM_NLG_SETUP_NT 1024
-#endif
-constexpr int NLG_SETUP_NT = BSSM_NLG_SETUP_NT;  // fn_setup_kernel (1 or 2 states: 128 VGPRs are plenty): 16 waves share the 64 draws
+// Four kernels per chunk, every one with lane = draw and 64 draws per single-wave workgroup:
+//   0  linearisation of time point blockIdx.y (and the prior / noise blocks by blockIdx.y == 0)     grid (F / 64, n)
+//   1  Kalman filter + covariance smoother, sequential in time -- the only sequential part           grid (F / 64)
+//   2  conditional factors of time point blockIdx.y (independent given the smoother's output)        grid (F / 64, n + 1)
+//   3  tables of time point blockIdx.y (and the initial state by blockIdx.y == 0)                    grid (F / 64, n)
+// As one kernel whose waves shared the draws, a chunk took 1.5 ms on the C5 shape with five busy CUs (292 draws): the tables alone
+// 0.5 ms, because each of their store instructions touches 64 cache lines (per-draw contiguous output) and only those CUs issued
+// them; spread over the chip by time point the three parallel phases cost a few launches (profiles/r03_setup_phases.txt).
 template <int M>
-__global__ void __launch_bounds__(NLG_SETUP_NT) fn_setup_kernel(const FnSetupDev b) {
-  LG_STAMP(0);
-  math_tab_init();
-  // lane = draw; the NLG_SETUP_NT / 64 waves of a workgroup share its 64 draws: the loops whose time points are independent
-  // (linearisation, conditional factors, tables) are split over the waves, the Kalman / smoother recursion runs on wave 0
-  const int wv = threadIdx.x >> 6, nwv = NLG_SETUP_NT / 64;
-  const int d = min(blockIdx.x * 64 + (int)(threadIdx.x & 63), b.F - 1);  // (surplus lanes redo the last draw: same values, no branch around the barriers)
+struct FnWork {
+  double *sZ, *sT, *sRR, *sD, *sC, *sy, *sH, *sa1, *sP1, *at, *Pt, *cc, *K, *v, *Fs, *Vf, *Cf;
+  __device__ FnWork(const FnSetupDev& b, int d) {
+    constexpr int MM = M * M;
+    const size_t F = (size_t)b.F;
+    const int n = b.n;
+    double* w = b.scratch + d;
+    sZ = w;                 w += (size_t)n * M * F;
+    sT = w;                 w += (size_t)n * MM * F;
+    sRR = w;                w += (size_t)MM * F;
+    sD = w;                 w += (size_t)n * F;
+    sC = w;                 w += (size_t)n * M * F;
+    sy = w;                 w += (size_t)n * F;
+    sH = w;                 w += F;
+    sa1 = w;                w += (size_t)M * F;
+    sP1 = w;                w += (size_t)MM * F;
+    at = w;                 w += (size_t)(n + 1) * M * F;
+    Pt = w;                 w += (size_t)(n + 1) * MM * F;
+    cc = w;                 w += (size_t)(n + 1) * MM * F;
+    K = w;                  w += (size_t)n * M * F;
+    v = w;                  w += (size_t)n * F;
+    Fs = w;                 w += (size_t)n * F;
+    Vf = w;                 w += (size_t)(n + 1) * MM * F;  // V_t^(1/2) and C_t
+    Cf = w;
+  }
+};
+template <int M, int PHASE>
+__global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
   constexpr int MM = M * M;
   const size_t F = (size_t)b.F;
   const int n = b.n;
-  const double* __restrict__ fp = b.fpar + (size_t)d * FP_SIZE;
-  const int id = (int)fp[FP_ID];
-  double* w = b.scratch + d;
-  double* sZ = w;                 w += (size_t)n * M * F;
-  double* sT = w;                 w += (size_t)n * MM * F;
-  double* sRR = w;                w += (size_t)MM * F;
-  double* sD = w;                 w += (size_t)n * F;
-  double* sC = w;                 w += (size_t)n * M * F;
-  double* sy = w;                 w += (size_t)n * F;
-  double* sH = w;                 w += F;
-  double* sa1 = w;                w += (size_t)M * F;
-  double* sP1 = w;                w += (size_t)MM * F;
-  double* at = w;                 w += (size_t)(n + 1) * M * F;
-  double* Pt = w;                 w += (size_t)(n + 1) * MM * F;
-  double* cc = w;                 w += (size_t)(n + 1) * MM * F;
-  double* K = w;                  w += (size_t)n * M * F;
-  double* v = w;                  w += (size_t)n * F;
-  double* Fs = w;                 w += (size_t)n * F;
-  double* Vf = w;                 w += (size_t)(n + 1) * MM * F;  // V_t^(1/2) and C_t: written by whichever wave has time point t
-  double* Cf = w;
-  // ---- linearisation at the stored mode: Z_t = Z'(mode_t), D_t = Z(mode_t) - Z_t mode_t, T_t = T'(mode_t),
-  // C_t = T(mode_t) - T_t mode_t  (approximate_for_is, src/model_ssm_nlg.cpp:146-176; scales and approx_loglik stay 0)
-  const double* __restrict__ mode = b.modes + (size_t)d * M * n;
-  for (int t = wv; t < n; t += nwv) {
+  if constexpr (PHASE == 0) {
+    // ---- linearisation at the stored mode: Z_t = Z'(mode_t), D_t = Z(mode_t) - Z_t mode_t, T_t = T'(mode_t),
+    // C_t = T(mode_t) - T_t mode_t  (approximate_for_is, src/model_ssm_nlg.cpp:146-176; scales and approx_loglik stay 0)
+    math_tab_init();  // (a workgroup barrier inside: surplus lanes redo the last draw instead of leaving)
+    const int d = min((int)(blockIdx.x * 64 + threadIdx.x), b.F - 1), t = blockIdx.y;
+    const FnWork<M> W(b, d);
+    const double* __restrict__ fp = b.fpar + (size_t)d * FP_SIZE;
+    const int id = (int)fp[FP_ID];
+    const double* __restrict__ mode = b.modes + (size_t)d * M * n;
     double a[M], Zg[M], Tg[MM], Tf[M];
 #pragma unroll
     for (int j = 0; j < M; j++) a[j] = mode[(size_t)M * t + j];
@@ -325,110 +335,118 @@ __global__ void __launch_bounds__(NLG_SETUP_NT) fn_setup_kernel(const FnSetupDev
     double za = 0.0;
 #pragma unroll
     for (int j = 0; j < M; j++) za += Zg[j] * a[j];
-    sD[(size_t)t * F] = nlg_Z_fn<M>(id, fp, a) - za;
+    W.sD[(size_t)t * F] = nlg_Z_fn<M>(id, fp, a) - za;
     nlg_T_fn<M>(id, fp, a, Tf);
 #pragma unroll
     for (int i = 0; i < M; i++) {
       double s = 0.0;
 #pragma unroll
       for (int j = 0; j < M; j++) s += Tg[i + M * j] * a[j];
-      sC[((size_t)t * M + i) * F] = Tf[i] - s;
-      sZ[((size_t)t * M + i) * F] = Zg[i];
+      W.sC[((size_t)t * M + i) * F] = Tf[i] - s;
+      W.sZ[((size_t)t * M + i) * F] = Zg[i];
     }
 #pragma unroll
-    for (int q = 0; q < MM; q++) sT[((size_t)t * MM + q) * F] = Tg[q];
-    sy[(size_t)t * F] = b.y[t];
-  }
-  if (wv == 0) {
+    for (int q = 0; q < MM; q++) W.sT[((size_t)t * MM + q) * F] = Tg[q];
+    W.sy[(size_t)t * F] = b.y[t];
+    if (t == 0) {
 #pragma unroll
-  for (int q = 0; q < MM; q++) sRR[(size_t)q * F] = 0.0;
+      for (int q = 0; q < MM; q++) W.sRR[(size_t)q * F] = 0.0;
 #pragma unroll
-  for (int j = 0; j < M; j++) sRR[(size_t)(j + M * j) * F] = fp[FP_R + j] * fp[FP_R + j];  // R is diagonal in every shipped model
-  sH[0] = fp[FP_H];
-  const double* __restrict__ ex = b.ext + (size_t)d * (M + MM);
+      for (int j = 0; j < M; j++) W.sRR[(size_t)(j + M * j) * F] = fp[FP_R + j] * fp[FP_R + j];  // R is diagonal in every shipped model
+      W.sH[0] = fp[FP_H];
+      const double* __restrict__ ex = b.ext + (size_t)d * (M + MM);
 #pragma unroll
-  for (int j = 0; j < M; j++) sa1[(size_t)j * F] = ex[j];
+      for (int j = 0; j < M; j++) W.sa1[(size_t)j * F] = ex[j];
 #pragma unroll
-  for (int q = 0; q < MM; q++) sP1[(size_t)q * F] = ex[M + q];
-  }
-  __syncthreads();  // the linearised model of every time point is in memory
-  LG_STAMP(1);
-  LgModel g;
-  g.n = n;
-  g.Z = sZ; g.Zs = M; g.T = sT; g.Ts = MM; g.RR = sRR; g.Rs = 0; g.D = sD; g.Ds = 1; g.C = sC; g.Cs = M;
-  g.y = sy; g.H = sH; g.Hs = 0; g.a1 = sa1; g.P1 = sP1;
-  // Kalman filter and covariance smoother on wave 0 (sequential in time); the conditional factors of the time points are
-  // independent of each other given the smoother's output, so the waves share them (2.2 of this kernel's 4.1 ms were that loop on
-  // one wave; profiles/r03_setup_phases.txt)
-  __shared__ int s_ok[64];
-  if (wv == 0) s_ok[threadIdx.x & 63] = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F, false) ? 1 : 0;  // at = alphahat, Pt = Var, cc = lag-one Cov
-  LG_STAMP(4);
-  const bool ok = setup_factors_by_wave<M>(n, wv, nwv, s_ok, at, Pt, cc, Vf, Cf, F);
-  LG_STAMP(5);
-  if (wv == 0) b.ok[d] = ok ? 1 : 0;
-  Pt = Vf; cc = Cf;  // what the tables read: V_t^(1/2) and C_t
-  // ---- tables (build_fn_psi_tables): proposal operands, observation rows, initial state, approximating (T_t, C_t)
-  constexpr int MS = 2 * MM + M, OS = ROW_HDR + SER_HDR + M, AS = MM + M;
-  double* __restrict__ mats = b.mats + (size_t)d * n * MS;
-  double* __restrict__ obs = b.obs + (size_t)d * n * OS;
-  double* __restrict__ ini = b.init + (size_t)d * (M + MM);
-  double* __restrict__ am = b.amats + (size_t)d * n * AS;
-  const double ih = 1.0 / fp[FP_H];
-  for (int t = wv; t < n; t += nwv) {
-    double* mt = mats + (size_t)t * MS;
-    double ah0[M], ah1[M], Ct1[MM];
-#pragma unroll
-    for (int j = 0; j < M; j++) { ah0[j] = at[((size_t)t * M + j) * F]; ah1[j] = at[((size_t)(t + 1) * M + j) * F]; }
-#pragma unroll
-    for (int q = 0; q < MM; q++) { Ct1[q] = cc[((size_t)(t + 1) * MM + q) * F]; mt[q] = ok ? Ct1[q] : 0.0; mt[MM + q] = ok ? Pt[((size_t)(t + 1) * MM + q) * F] : 0.0; }
-#pragma unroll
-    for (int j = 0; j < M; j++) {
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < M; c++) s += Ct1[j + M * c] * ah0[c];
-      mt[2 * MM + j] = ok ? ah1[j] - s : 0.0;
+      for (int q = 0; q < MM; q++) W.sP1[(size_t)q * F] = ex[M + q];
     }
-    double* row = obs + (size_t)t * OS;
-    const double yt = b.y[t];
-    const bool seen = ok && yt == yt && fabs(yt) <= 1.7976931348623157e308;
-#pragma unroll
-    for (int q = 0; q < OS; q++) row[q] = 0.0;
-    if (seen) {
-      row[RH_FLAG] = 1.0;  // (RH_SCALE: the scales of approximate_for_is are zero)
-      double* ob = row + ROW_HDR;
-      ob[OB_FLAG] = 1.0; ob[OB_Y] = yt; ob[OB_D] = sD[(size_t)t * F]; ob[OB_PSIIH] = ih;
-#pragma unroll
-      for (int c = 0; c < M; c++) ob[SER_HDR + c] = sZ[((size_t)t * M + c) * F];
-    }
-    double* a2 = am + (size_t)t * AS;
-#pragma unroll
-    for (int q = 0; q < MM; q++) a2[q] = ok ? sT[((size_t)t * MM + q) * F] : 0.0;
-#pragma unroll
-    for (int j = 0; j < M; j++) a2[MM + j] = ok ? sC[((size_t)t * M + j) * F] : 0.0;
-  }
-  if (wv == 0) {
-#pragma unroll
-  for (int j = 0; j < M; j++) ini[j] = ok ? at[(size_t)j * F] : 0.0;
-#pragma unroll
-  for (int q = 0; q < MM; q++) ini[M + q] = ok ? Pt[(size_t)q * F] : 0.0;
-  }
+  } else {
+    const int d = blockIdx.x * 64 + threadIdx.x;
+    if (d >= b.F) return;
+    const FnWork<M> W(b, d);
+    if constexpr (PHASE == 1) {
+      LG_STAMP(1);
+      LgModel g;
+      g.n = n;
+      g.Z = W.sZ; g.Zs = M; g.T = W.sT; g.Ts = MM; g.RR = W.sRR; g.Rs = 0; g.D = W.sD; g.Ds = 1; g.C = W.sC; g.Cs = M;
+      g.y = W.sy; g.H = W.sH; g.Hs = 0; g.a1 = W.sa1; g.P1 = W.sP1;
+      b.ok[d] = LgSmoother<M>::run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F, false) ? 1 : 0;  // at = alphahat, Pt = Var, cc = lag-one Cov
 #ifdef BSSM_SETUP_STAMPS
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const unsigned long long e = wall_clock64(), *q = g_setup_stamps;
-    printf("fn_setup_kernel F=%d n=%d us: linearise %.1f forward %.1f backward %.1f conditional %.1f check %.1f tables %.1f total %.1f\n", b.F, n,
-           (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (e - q[5]) * 0.01, (e - q[0]) * 0.01);
-  }
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long* q = g_setup_stamps;
+        printf("fn_setup_kernel<%d, 1> F=%d n=%d us: forward %.1f backward %.1f\n", M, b.F, n, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01);
+      }
 #endif
+    } else if constexpr (PHASE == 2) {
+      if (!b.ok[d]) return;
+      if (!LgSmoother<M>::cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, F)) b.ok[d] = 0;  // (every writer stores 0)
+    } else {
+      // ---- tables (build_fn_psi_tables): proposal operands, observation rows, initial state, approximating (T_t, C_t)
+      const int t = blockIdx.y;
+      const double *at = W.at, *Pt = W.Vf, *cc = W.Cf;
+      const double* __restrict__ fp = b.fpar + (size_t)d * FP_SIZE;
+      const bool ok = b.ok[d] != 0;
+      constexpr int MS = 2 * MM + M, OS = ROW_HDR + SER_HDR + M, AS = MM + M;
+      double* __restrict__ mats = b.mats + (size_t)d * n * MS;
+      double* __restrict__ obs = b.obs + (size_t)d * n * OS;
+      double* __restrict__ ini = b.init + (size_t)d * (M + MM);
+      double* __restrict__ am = b.amats + (size_t)d * n * AS;
+      const double ih = 1.0 / fp[FP_H];
+      double* mt = mats + (size_t)t * MS;
+      double ah0[M], ah1[M], Ct1[MM];
+#pragma unroll
+      for (int j = 0; j < M; j++) { ah0[j] = at[((size_t)t * M + j) * F]; ah1[j] = at[((size_t)(t + 1) * M + j) * F]; }
+#pragma unroll
+      for (int q = 0; q < MM; q++) { Ct1[q] = ok ? cc[((size_t)(t + 1) * MM + q) * F] : 0.0; mt[q] = Ct1[q]; mt[MM + q] = ok ? Pt[((size_t)(t + 1) * MM + q) * F] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < M; j++) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < M; c++) s += Ct1[j + M * c] * ah0[c];
+        mt[2 * MM + j] = ok ? ah1[j] - s : 0.0;
+      }
+      double* row = obs + (size_t)t * OS;
+      const double yt = b.y[t];
+      const bool seen = ok && yt == yt && fabs(yt) <= 1.7976931348623157e308;
+#pragma unroll
+      for (int q = 0; q < OS; q++) row[q] = 0.0;
+      if (seen) {
+        row[RH_FLAG] = 1.0;  // (RH_SCALE: the scales of approximate_for_is are zero)
+        double* ob = row + ROW_HDR;
+        ob[OB_FLAG] = 1.0; ob[OB_Y] = yt; ob[OB_D] = W.sD[(size_t)t * F]; ob[OB_PSIIH] = ih;
+#pragma unroll
+        for (int c = 0; c < M; c++) ob[SER_HDR + c] = W.sZ[((size_t)t * M + c) * F];
+      }
+      double* a2 = am + (size_t)t * AS;
+#pragma unroll
+      for (int q = 0; q < MM; q++) a2[q] = ok ? W.sT[((size_t)t * MM + q) * F] : 0.0;
+#pragma unroll
+      for (int j = 0; j < M; j++) a2[MM + j] = ok ? W.sC[((size_t)t * M + j) * F] : 0.0;
+      if (t == 0) {
+#pragma unroll
+        for (int j = 0; j < M; j++) ini[j] = ok ? at[(size_t)j * F] : 0.0;
+#pragma unroll
+        for (int q = 0; q < MM; q++) ini[M + q] = ok ? Pt[(size_t)q * F] : 0.0;
+      }
+    }
+  }
+}
+template <int M>
+static hipError_t launch_fn_setup_m(const FnSetupDev& b, hipStream_t stream) {
+  const unsigned gx = (unsigned)((b.F + 63) / 64);
+  hipLaunchKernelGGL((fn_setup_kernel<M, 0>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  hipLaunchKernelGGL((fn_setup_kernel<M, 1>), dim3(gx), dim3(64), 0, stream, b);
+  hipLaunchKernelGGL((fn_setup_kernel<M, 2>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
+  hipLaunchKernelGGL((fn_setup_kernel<M, 3>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  return hipGetLastError();
 }
 hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream) {
-  const dim3 grid((b.F + 63) / 64), block(NLG_SETUP_NT);
+  if (b.n < 1 || b.n >= 65535) return hipErrorInvalidValue;  // (time points ride in gridDim.y)
   switch (b.m) {
-    case 1: hipLaunchKernelGGL(fn_setup_kernel<1>, grid, block, 0, stream, b); break;
-    case 2: hipLaunchKernelGGL(fn_setup_kernel<2>, grid, block, 0, stream, b); break;
+    case 1: return launch_fn_setup_m<1>(b, stream);
+    case 2: return launch_fn_setup_m<2>(b, stream);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 // ---------------------------------------------------------------- psi set-up of ssm_ung draws, all of it on the device
 // What psi_setup_begin (laplace_iter + update_scales) + the smoother + build_psi_tables / fill_obs_rows do per draw on
