@@ -13,6 +13,7 @@ __device__ unsigned long long g_setup_stamps[8];
 #define LG_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_setup_stamps[i] = wall_clock64(); } while (0)
 #endif
 #include "lg_smoother.h"
+#include "lg_smoother_rows.h"
 #include "pf_filter_impl.h"
 #include "tls_stream.h"
 
@@ -637,56 +638,74 @@ struct MngWork {
     Cf = w;
   }
 };
+// (L) Laplace step at the stored mode for time point blockIdx.y: approximating y / H of its p series and the scale (src/model_ssm_mng.cpp:117-133, 218-255, 269-315)
 template <int M>
-__global__ void __launch_bounds__(64) mng_setup_kernel(const UngSetupDev b) {
+__global__ void __launch_bounds__(64) mng_laplace_kernel(const UngSetupDev b) {
   const int d = blockIdx.x * 64 + threadIdx.x;
   if (d >= b.F) return;
+  const size_t F = (size_t)b.F;
+  const int p = b.p, t = blockIdx.y;
+  const MngWork<M> W(b, d);
+  const double* in = W.in;
+  double sc = 0.0;
+  for (int j = 0; j < p; j++) {
+    const size_t q = (size_t)t * p + j;
+    const int dist = (int)in[(b.oh + j) * F];
+    const double phi = in[(b.oh + p + j) * F];
+    const double y = in[(b.oy + q) * F], sg = in[(b.om + q) * F], u = in[(b.ou + q) * F];
+    double HH = 0.0, yy = 0.0, sv = 0.0;
+    switch (dist) {
+      case DIST_POISSON: HH = 1.0 / (exp(sg) * u); yy = y * HH + sg - 1.0; sv = y * sg - u * exp(sg); break;
+      case DIST_BINOMIAL: { const double e = exp(sg); HH = (1.0 + e) * (1.0 + e) / (u * e); yy = y * HH + sg - 1.0 - e; sv = y * sg - u * log1p(e); } break;
+      case DIST_NEGBIN: { const double e = exp(sg) * u; HH = (phi + e) * (phi + e) / (phi * e * (y + phi)); yy = sg + (phi + e) * (y - e) / ((y + phi) * e);
+                          sv = y * sg - (y + phi) * log(phi + u * exp(sg)); } break;
+      case DIST_GAMMA: { const double e = exp(sg) * u; HH = e / (y * phi); yy = sg - e / y + 1.0; sv = -phi * sg - (y * phi * exp(-sg) / u); } break;
+      case DIST_GAUSSIAN: { HH = phi * phi; yy = y; const double r = (y - sg) / phi; sv = -0.5 * r * r; } break;
+      default: break;
+    }
+    const double sd = sqrt(HH);
+    const bool seen = y == y && fabs(y) <= 1.7976931348623157e308;
+    const double r = (yy - sg) / sd;
+    W.ay[q * F] = yy;
+    W.aH[q * F] = sd;
+    if (seen) sc += sv + 0.5 * r * r;
+  }
+  W.scl[(size_t)t * F] = sc;
+}
+// (A) Kalman filter + covariance smoother over the n p virtual steps, sequential in time.  ROWS = false: one lane per draw
+// (LgSmoother<M>::run); ROWS = true: M lanes per draw, one matrix row each (lg_smoother_rows.h) -- 64 / M draws per single-wave workgroup
+template <int M, bool ROWS>
+__global__ void __launch_bounds__(64) mng_setup_kernel(const UngSetupDev b) {
+  constexpr int DPW = ROWS ? 64 / M : 64;  // draws per workgroup
+  const int lane = threadIdx.x;
+  const int d0 = blockIdx.x * DPW + (ROWS ? lane / M : lane);
+  if (!ROWS && d0 >= b.F) return;
+  const int d = min(d0, b.F - 1);  // (rows: the surplus groups of the last workgroup redo the last draw -- every lane takes part in the LDS exchanges)
   const size_t F = (size_t)b.F;
   const int n = b.n, p = b.p, nv = n * p;
   const MngWork<M> W(b, d);
   const double* in = W.in;
-  double *ay = W.ay, *aH = W.aH, *scl = W.scl;
-  for (int t = 0; t < n; t++) {
-    double sc = 0.0;
-    for (int j = 0; j < p; j++) {
-      const size_t q = (size_t)t * p + j;
-      const int dist = (int)in[(b.oh + j) * F];
-      const double phi = in[(b.oh + p + j) * F];
-      const double y = in[(b.oy + q) * F], sg = in[(b.om + q) * F], u = in[(b.ou + q) * F];
-      double HH = 0.0, yy = 0.0, sv = 0.0;
-      switch (dist) {
-        case DIST_POISSON: HH = 1.0 / (exp(sg) * u); yy = y * HH + sg - 1.0; sv = y * sg - u * exp(sg); break;
-        case DIST_BINOMIAL: { const double e = exp(sg); HH = (1.0 + e) * (1.0 + e) / (u * e); yy = y * HH + sg - 1.0 - e; sv = y * sg - u * log1p(e); } break;
-        case DIST_NEGBIN: { const double e = exp(sg) * u; HH = (phi + e) * (phi + e) / (phi * e * (y + phi)); yy = sg + (phi + e) * (y - e) / ((y + phi) * e);
-                            sv = y * sg - (y + phi) * log(phi + u * exp(sg)); } break;
-        case DIST_GAMMA: { const double e = exp(sg) * u; HH = e / (y * phi); yy = sg - e / y + 1.0; sv = -phi * sg - (y * phi * exp(-sg) / u); } break;
-        case DIST_GAUSSIAN: { HH = phi * phi; yy = y; const double r = (y - sg) / phi; sv = -0.5 * r * r; } break;
-        default: break;
-      }
-      const double sd = sqrt(HH);
-      const bool seen = y == y && fabs(y) <= 1.7976931348623157e308;
-      const double r = (yy - sg) / sd;
-      ay[q * F] = yy;
-      aH[q * F] = sd;
-      if (seen) sc += sv + 0.5 * r * r;
-    }
-    scl[(size_t)t * F] = sc;
-  }
   LgModel g;
   g.n = nv; g.sub = p;
   g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
-  g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = ay; g.H = aH; g.Hs = 1;
+  g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
   g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
-  LG_STAMP(1);
-  const bool ok = LgSmoother<M>::run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F, false);  // at = alphahat, Pt = Var, cc = lag-one Cov
-  LG_STAMP(5);
-  b.ok[d] = ok ? 1 : 0;
+  bool ok;
+  if constexpr (ROWS) {
+    __shared__ double lds[LgRows<M>::kLdsDoubles];
+    LgRows<M> rows(lds);
+    ok = rows.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F);
+  } else {
+    LG_STAMP(1);
+    ok = LgSmoother<M>::run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F, false);  // at = alphahat, Pt = Var, cc = lag-one Cov
 #ifdef BSSM_SETUP_STAMPS
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const unsigned long long* q = g_setup_stamps;
-    printf("mng_setup_kernel<%d> F=%d n=%d p=%d us: forward %.1f backward %.1f\n", M, b.F, n, p, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01);
-  }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const unsigned long long* q = g_setup_stamps;
+      printf("mng_setup_kernel<%d> F=%d n=%d p=%d us: forward %.1f backward %.1f\n", M, b.F, n, p, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01);
+    }
 #endif
+  }
+  b.ok[d] = ok ? 1 : 0;
 }
 // (B) conditional factors of time point blockIdx.y (virtual step blockIdx.y * p) for the 64 draws of blockIdx.x
 template <int M>
@@ -778,7 +797,11 @@ __global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
 template <int M>
 static hipError_t launch_mng_setup_m(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64);
-  hipLaunchKernelGGL(mng_setup_kernel<M>, dim3(gx), dim3(64), 0, stream, b);
+  hipLaunchKernelGGL(mng_laplace_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  // 8-dimensional states: a lane cannot hold the recursion's matrices (BSSM_AMD_MNG_LANE_PER_DRAW=1 keeps the one-lane form for comparison)
+  const bool lane_form = std::getenv("BSSM_AMD_MNG_LANE_PER_DRAW") != nullptr;
+  if (M == 8 && !lane_form) hipLaunchKernelGGL((mng_setup_kernel<M == 8 ? 8 : 1, true>), dim3((unsigned)((b.F + 7) / 8)), dim3(64), 0, stream, b);
+  else hipLaunchKernelGGL((mng_setup_kernel<M, false>), dim3(gx), dim3(64), 0, stream, b);
   hipLaunchKernelGGL(mng_factors_kernel<M>, dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   hipLaunchKernelGGL(mng_tables_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   return hipGetLastError();

@@ -202,3 +202,45 @@ def test_mng_full_device_setup_against_oracle(oracle, monkeypatch, name, output_
             assert np.allclose(res["2"]["alphahat"], res[dev]["alphahat"], rtol=1e-7, atol=1e-9)
             assert np.allclose(res["2"]["Vt"], res[dev]["Vt"], rtol=1e-6, atol=1e-9)
     assert np.all(np.isfinite(res["2"]["loglik"]))
+
+
+def test_mng_eight_states_rows_smoother_with_missing_observations(oracle, monkeypatch):
+    """m = 8 draws go through the row-distributed smoother (lg_smoother_rows.h: eight lanes per draw, one matrix row each; a
+    step without an update runs the update formulas with K = 0).  C4-shaped model with single series and whole time points
+    missing, 70 draws (a ragged last workgroup of 8-draw groups): against the one-lane-per-draw kernel, the host set-up and the
+    oracle's per-draw psi filters"""
+    from bssm_amd import post_correct as PC
+    rng = np.random.default_rng(23)
+    n, p, m = 26, 4, 8
+    Q = np.linalg.qr(rng.normal(size=(m, m)))[0]
+    Z = rng.normal(0, 0.5, (p, m))
+    y = np.column_stack([rng.poisson(2, n), rng.poisson(4, n), rng.negative_binomial(5, 0.6, n), rng.normal(0, 0.8, n)]).astype(float)
+    y[3, 1] = np.nan; y[9, :] = np.nan; y[10, :] = np.nan; y[17, [0, 3]] = np.nan; y[n - 1, 2] = np.nan
+    base = M.ssm_mng(y, Z, 0.95 * Q, 0.1 * np.eye(m), a1=np.zeros(m), P1=0.05 * np.eye(m),
+                     distribution=["poisson", "poisson", "negative binomial", "gaussian"], phi=[1, 1, 5, 0.5])
+    R0 = 0.1 * np.eye(m)
+    model = M.BssmModel(base.classes, **{**base, "update_fn": (lambda th: dict(R=R0 * np.exp(th[0]))), "theta": np.zeros(1)})
+    ns = 70
+    theta = rng.normal(0, 0.15, (ns, 1))
+    counts = np.ones(ns, dtype=np.uint32)
+    arrs = PC.expand_models(model, theta)
+    modes = np.stack([oracle.mng_psi_setup(a)["mode"].reshape(-1, order="F") for a in arrs], axis=1)
+    modes = modes + rng.normal(0, 0.05, modes.shape)
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type=2)
+    rows = PC.post_correct(model, mo, 48, threads=2, is_type="is2", seed=21)
+    monkeypatch.setenv("BSSM_AMD_MNG_LANE_PER_DRAW", "1")
+    lane = PC.post_correct(model, mo, 48, threads=2, is_type="is2", seed=21)
+    monkeypatch.delenv("BSSM_AMD_MNG_LANE_PER_DRAW")
+    monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", "0")
+    host = PC.post_correct(model, mo, 48, threads=2, is_type="is2", seed=21)
+    assert np.all(np.isfinite(rows["loglik"]))
+    # the two device kernels do the same arithmetic in the same order: the same bits, summaries included
+    assert np.array_equal(rows["loglik"], lane["loglik"]) and np.array_equal(rows["alphahat"], lane["alphahat"]) and np.array_equal(rows["Vt"], lane["Vt"])
+    # against the matrix-form host set-up: log-likelihoods to rounding; the smoothed means up to the last two slots, where the
+    # conditional covariance has a repeated eigenvalue (no future observations: R R' is isotropic on the null space of Z) and the
+    # basis of its factor inside that eigenspace is a convention -- the particles differ there inside null(Z), the weights do not
+    assert np.allclose(rows["loglik"], host["loglik"], rtol=0, atol=1e-9 * n)
+    assert np.allclose(rows["alphahat"][:n - 1], host["alphahat"][:n - 1], rtol=1e-6, atol=1e-8)
+    for i in range(0, ns, 9):
+        ref = oracle.mng_psi_filter(arrs[i], 48, seed=21, stream=i, is_mode=modes[:, i].reshape(p, n, order="F"))
+        assert abs(rows["loglik"][i] - ref["logLik"]) <= 1e-8 * n
