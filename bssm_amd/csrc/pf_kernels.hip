@@ -251,34 +251,11 @@ hipError_t launch_lg_setup(const LgBatchDev& b, hipStream_t stream) {
 // draw: the host then only packs theta (FP_SIZE doubles) and a1 / P1 per draw.  Work arrays are draw-interleaved
 // (element k of draw d at base[k * F + d]) like lg_setup_kernel's; the tables go out per draw, contiguous, in the
 // layout DeviceBatch hands to the filter kernels.
-// Conditional factors of a set-up kernel whose waves share 64 draws (lane = draw): the Kalman filter / covariance smoother has run
-// on wave 0 (s_ok[lane] = its verdict); the factors of the time points are independent of each other given its output, so the
-// waves take them round-robin, into Vf / Cf (the smoother's arrays are still being read by the other waves).  Ends with a barrier;
-// returns the draw's verdict incl. the finiteness of every smoothed mean and factor (as LgSmoother::run's last loop).
-template <int M>
-__device__ __forceinline__ bool setup_factors_by_wave(int n, int wv, int nwv, int* s_ok, const double* at, const double* Pt, const double* cc,
-                                                      double* Vf, double* Cf, size_t F) {
-  const int lane = threadIdx.x & 63;
-  __syncthreads();
-  if (s_ok[lane]) {
-    int bad = 0;
-    for (int t = n - wv; t >= 0; t -= nwv) {
-      bad |= !LgSmoother<M>::cond_step(t, Pt, cc, Vf, Cf, F);  // (the smoothed means were tested where the backward pass produced them)
-    }
-    if (bad) s_ok[lane] = 0;  // (every writer stores the same value)
-  }
-  __syncthreads();
-  return s_ok[lane] != 0;
-}
 size_t fn_setup_scratch_doubles(int n, int m) {
   const size_t mm = (size_t)m * m, n1 = (size_t)n + 1;
   //      Z            T        RR   D   C            y   H   a1  P1   at       Pt        cc        K            v   Fs   Vf        Cf
   return (size_t)n * m + n * mm + mm + n + (size_t)n * m + n + 1 + m + mm + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n + n1 * mm + n1 * mm;
 }
-#ifndef BSSM_FN_SETUP_NT
-#define BSSM_FN_SETUP_NT 512
-#endif
-constexpr int FN_SETUP_NT = BSSM_FN_SETUP_NT;  // threads per workgroup of ung_setup_kernel: 64 draws x FN_SETUP_NT / 64 waves
 // Four kernels per chunk, every one with lane = draw and 64 draws per single-wave workgroup:
 //   0  linearisation of time point blockIdx.y (and the prior / noise blocks by blockIdx.y == 0)     grid (F / 64, n)
 //   1  Kalman filter + covariance smoother, sequential in time -- the only sequential part           grid (F / 64)
@@ -458,33 +435,49 @@ size_t ung_setup_scratch_doubles(int n, int m) {
   //      ay  aH  ayraw scales  at       Pt        cc        K              v   Fs   Vf        Cf
   return (size_t)4 * n + n1 * m + n1 * mm + n1 * mm + (size_t)n * m + n + n + n1 * mm + n1 * mm;
 }
+// Four kernels per chunk, as for ssm_nlg draws (fn_setup_kernel): PHASE 0 the Laplace step of time point blockIdx.y, 1 the Kalman filter +
+// covariance smoother (sequential in time; ROWS: eight lanes per draw for 8-dimensional states, lg_smoother_rows.h), 2 the conditional
+// factors of time point blockIdx.y, 3 its tables.
 template <int M>
-__global__ void __launch_bounds__(FN_SETUP_NT) ung_setup_kernel(const UngSetupDev b) {
-  // lane = draw, the waves of a workgroup share its 64 draws (as fn_setup_kernel): Laplace step and tables split over the
-  // waves by time point, the recursion on wave 0
-  const int wv = threadIdx.x >> 6, nwv = FN_SETUP_NT / 64;
-  const int d = min(blockIdx.x * 64 + (int)(threadIdx.x & 63), b.F - 1);
+struct UngWork {
+  const double* in;
+  double *ay, *aH, *ayr, *scl, *at, *Pt, *cc, *K, *v, *Fs, *Vf, *Cf;
+  __device__ UngWork(const UngSetupDev& b, int d) {
+    constexpr int MM = M * M;
+    const size_t F = (size_t)b.F;
+    const int n = b.n;
+    in = b.in + d;
+    double* w = b.scratch + d;
+    ay = w;     w += (size_t)n * F;   // approximating y minus x'beta: what the smoother sees
+    aH = w;     w += (size_t)n * F;
+    ayr = w;    w += (size_t)n * F;   // approximating y
+    scl = w;    w += (size_t)n * F;
+    at = w;     w += (size_t)(n + 1) * M * F;
+    Pt = w;     w += (size_t)(n + 1) * MM * F;
+    cc = w;     w += (size_t)(n + 1) * MM * F;
+    K = w;      w += (size_t)n * M * F;
+    v = w;      w += (size_t)n * F;
+    Fs = w;     w += (size_t)n * F;
+    Vf = w;     w += (size_t)(n + 1) * MM * F;
+    Cf = w;
+  }
+};
+template <int M, int PHASE, bool ROWS>
+__global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
   constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+  constexpr int DPW = (PHASE == 1 && ROWS) ? 64 / M : 64;  // draws per workgroup
+  const int d0 = blockIdx.x * DPW + ((PHASE == 1 && ROWS) ? (int)threadIdx.x / M : (int)threadIdx.x);
+  if (!(PHASE == 1 && ROWS) && d0 >= b.F) return;
+  const int d = min(d0, b.F - 1);  // (rows: surplus groups redo the last draw -- every lane takes part in the LDS exchanges)
   const size_t F = (size_t)b.F;
   const int n = b.n;
-  const double* in = b.in + d;
-  double* w = b.scratch + d;
-  double* ay = w;     w += (size_t)n * F;   // approximating y minus x'beta: what the smoother sees
-  double* aH = w;     w += (size_t)n * F;
-  double* ayr = w;    w += (size_t)n * F;   // approximating y
-  double* scl = w;    w += (size_t)n * F;
-  double* at = w;     w += (size_t)(n + 1) * M * F;
-  double* Pt = w;     w += (size_t)(n + 1) * MM * F;
-  double* cc = w;     w += (size_t)(n + 1) * MM * F;
-  double* K = w;      w += (size_t)n * M * F;
-  double* v = w;      w += (size_t)n * F;
-  double* Fs = w;     w += (size_t)n * F;
-  double* Vf = w;     w += (size_t)(n + 1) * MM * F;
-  double* Cf = w;
+  const UngWork<M> W(b, d);
+  const double* in = W.in;
   const int dist = (int)in[b.oh * F];
   const double phi = in[(b.oh + 1) * F];
-  // ---- approximate_for_is: one Laplace step at the stored mode (src/model_ssm_ung.cpp:302-342) and the scales (:241-292)
-  for (int t = wv; t < n; t += nwv) {
+  if constexpr (PHASE == 0) {
+    // ---- approximate_for_is: one Laplace step at the stored mode (src/model_ssm_ung.cpp:302-342) and the scales (:241-292)
+    const int t = blockIdx.y;
     const double y = in[(b.oy + t) * F], sg = in[(b.om + t) * F], u = in[(b.ou + t) * F];
     double HH = 0.0, yy = 0.0, sv = 0.0;
     switch (dist) {
@@ -505,36 +498,45 @@ __global__ void __launch_bounds__(FN_SETUP_NT) ung_setup_kernel(const UngSetupDe
     const double sd = sqrt(HH);
     const bool seen = y == y && fabs(y) <= 1.7976931348623157e308;
     const double q = (yy - sg) / sd;
-    ay[(size_t)t * F] = yy - in[(b.ox + t) * F];
-    ayr[(size_t)t * F] = yy;
-    aH[(size_t)t * F] = sd;
-    scl[(size_t)t * F] = seen ? sv + 0.5 * q * q : 0.0;
-  }
-  LgModel g;
-  g.n = n;
-  g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
-  g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = ay; g.H = aH; g.Hs = 1;
-  g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
-  __syncthreads();  // pseudo-observations of every time point are in memory
-  __shared__ int s_ok[64];
-  if (wv == 0) s_ok[threadIdx.x & 63] = LgSmoother<M>::run(g, at, Pt, cc, K, v, Fs, F, false) ? 1 : 0;  // at = alphahat, Pt = Var, cc = lag-one Cov
-  const bool ok = setup_factors_by_wave<M>(n, wv, nwv, s_ok, at, Pt, cc, Vf, Cf, F);  // the waves share the conditional factors
-  if (wv == 0) b.ok[d] = ok ? 1 : 0;
-  Pt = Vf; cc = Cf;  // what the tables read: V_t^(1/2) and C_t
-  // ---- tables: psi proposal operands (src/model_ssm_ung.cpp:585-586), observation rows, initial state (:543)
-  constexpr int MS = 2 * MP * MP + MP, OS = ROW_HDR + SER_HDR + MP;
-  double* __restrict__ mats = b.mats + (size_t)d * n * MS;
-  double* __restrict__ obs = b.obs + (size_t)d * n * OS;
-  double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
-  for (int t = wv; t < n; t += nwv) {
+    W.ay[(size_t)t * F] = yy - in[(b.ox + t) * F];
+    W.ayr[(size_t)t * F] = yy;
+    W.aH[(size_t)t * F] = sd;
+    W.scl[(size_t)t * F] = seen ? sv + 0.5 * q * q : 0.0;
+  } else if constexpr (PHASE == 1) {
+    LgModel g;
+    g.n = n;
+    g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
+    g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
+    g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
+    bool ok;
+    if constexpr (ROWS) {
+      __shared__ double lds[LgRows<M>::kLdsDoubles];
+      LgRows<M> rows(lds);
+      ok = rows.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F);
+    } else {
+      ok = LgSmoother<M>::run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F, false);  // at = alphahat, Pt = Var, cc = lag-one Cov
+    }
+    b.ok[d] = ok ? 1 : 0;
+  } else if constexpr (PHASE == 2) {
+    if (!b.ok[d]) return;
+    if (!LgSmoother<M>::cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, F)) b.ok[d] = 0;  // (every writer stores 0)
+  } else {
+    // ---- tables: psi proposal operands (src/model_ssm_ung.cpp:585-586), observation rows, initial state (:543)
+    const int t = blockIdx.y;
+    const double *at = W.at, *Pt = W.Vf, *cc = W.Cf;
+    const bool ok = b.ok[d] != 0;
+    constexpr int MS = 2 * MP * MP + MP, OS = ROW_HDR + SER_HDR + MP;
+    double* __restrict__ mats = b.mats + (size_t)d * n * MS;
+    double* __restrict__ obs = b.obs + (size_t)d * n * OS;
+    double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
     double* mt = mats + (size_t)t * MS;
     for (int q = 0; q < MS; q++) mt[q] = 0.0;
-    double ah0[M], ah1[M], Ct1[MM];
-#pragma unroll
-    for (int j = 0; j < M; j++) { ah0[j] = at[((size_t)t * M + j) * F]; ah1[j] = at[((size_t)(t + 1) * M + j) * F]; }
-#pragma unroll
-    for (int q = 0; q < MM; q++) Ct1[q] = cc[((size_t)(t + 1) * MM + q) * F];
     if (ok) {
+      double ah0[M], ah1[M], Ct1[MM];
+#pragma unroll
+      for (int j = 0; j < M; j++) { ah0[j] = at[((size_t)t * M + j) * F]; ah1[j] = at[((size_t)(t + 1) * M + j) * F]; }
+#pragma unroll
+      for (int q = 0; q < MM; q++) Ct1[q] = cc[((size_t)(t + 1) * MM + q) * F];
 #pragma unroll
       for (int c = 0; c < M; c++)
 #pragma unroll
@@ -568,37 +570,48 @@ __global__ void __launch_bounds__(FN_SETUP_NT) ung_setup_kernel(const UngSetupDe
         for (int c = 0; c < M; c++) ob[SER_HDR + c] = in[(b.oZ + (size_t)t * b.Zs + c) * F];
         ob[OB_AUX] = dist == DIST_NEGBIN ? y + phi : (dist == DIST_GAMMA ? y / u : 0.0);
       }
-      ob[OB_PSIY] = ayr[(size_t)t * F];
-      ob[OB_PSIIH] = 1.0 / aH[(size_t)t * F];
+      ob[OB_PSIY] = W.ayr[(size_t)t * F];
+      ob[OB_PSIIH] = 1.0 / W.aH[(size_t)t * F];
       row[RH_FLAG] = 1.0;
-      row[RH_SCALE] = scl[(size_t)t * F];
+      row[RH_SCALE] = W.scl[(size_t)t * F];
+    }
+    if (t == 0) {
+      for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
+#pragma unroll
+        for (int c = 0; c < M; c++)
+#pragma unroll
+          for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
+      }
     }
   }
-  if (wv != 0) return;
-  for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
-  if (ok) {
-#pragma unroll
-    for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
-#pragma unroll
-    for (int c = 0; c < M; c++)
-#pragma unroll
-      for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
-  }
+}
+template <int M>
+static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
+  const unsigned gx = (unsigned)((b.F + 63) / 64);
+  hipLaunchKernelGGL((ung_setup_kernel<M, 0, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  const bool lane_form = std::getenv("BSSM_AMD_MNG_LANE_PER_DRAW") != nullptr;  // (comparison switch, shared with the ssm_mng set-up)
+  if (M == 8 && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<M == 8 ? 8 : 1, 1, true>), dim3((unsigned)((b.F + 7) / 8)), dim3(64), 0, stream, b);
+  else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
+  hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
+  hipLaunchKernelGGL((ung_setup_kernel<M, 3, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  return hipGetLastError();
 }
 hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream) {
-  const dim3 grid((b.F + 63) / 64), block(FN_SETUP_NT);
+  if (b.n < 1 || b.n >= 65535) return hipErrorInvalidValue;  // (time points ride in gridDim.y)
   switch (b.m) {
-    case 1: hipLaunchKernelGGL(ung_setup_kernel<1>, grid, block, 0, stream, b); break;
-    case 2: hipLaunchKernelGGL(ung_setup_kernel<2>, grid, block, 0, stream, b); break;
-    case 3: hipLaunchKernelGGL(ung_setup_kernel<3>, grid, block, 0, stream, b); break;
-    case 4: hipLaunchKernelGGL(ung_setup_kernel<4>, grid, block, 0, stream, b); break;
-    case 5: hipLaunchKernelGGL(ung_setup_kernel<5>, grid, block, 0, stream, b); break;
-    case 6: hipLaunchKernelGGL(ung_setup_kernel<6>, grid, block, 0, stream, b); break;
-    case 7: hipLaunchKernelGGL(ung_setup_kernel<7>, grid, block, 0, stream, b); break;
-    case 8: hipLaunchKernelGGL(ung_setup_kernel<8>, grid, block, 0, stream, b); break;
+    case 1: return launch_ung_setup_m<1>(b, stream);
+    case 2: return launch_ung_setup_m<2>(b, stream);
+    case 3: return launch_ung_setup_m<3>(b, stream);
+    case 4: return launch_ung_setup_m<4>(b, stream);
+    case 5: return launch_ung_setup_m<5>(b, stream);
+    case 6: return launch_ung_setup_m<6>(b, stream);
+    case 7: return launch_ung_setup_m<7>(b, stream);
+    case 8: return launch_ung_setup_m<8>(b, stream);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 // ---------------------------------------------------------------- psi set-up of ssm_mng draws, all of it on the device
 // The same for p > 1 independent observation series per time point (src/model_ssm_mng.cpp:117-133 approximate_for_is,

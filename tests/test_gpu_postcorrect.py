@@ -321,6 +321,12 @@ def _ung_zoo(kind, rng, n=50):
                          period=4, distribution="gamma", phi=M.gamma(3.0, 2, 0.5), u=rng.uniform(0.8, 1.2, n),
                          P1=np.diag([1.0, 0.1, 0.5, 0.5, 0.5]), a1=np.array([1.5, 0, 0, 0, 0]))
         theta = np.column_stack([rng.uniform(0.05, 0.2, ns), rng.uniform(0.01, 0.03, ns), rng.uniform(0.02, 0.08, ns), rng.uniform(2, 4, ns)])
+    elif kind == "bsm_poisson_weekly":  # level + slope + six seasonal states: m = 8 -> the row-distributed smoother (lg_smoother_rows.h)
+        y = rng.poisson(6.0, n).astype(float); y[[4, 21]] = np.nan
+        model = M.bsm_ng(y, sd_level=M.halfnormal(0.1, 1), sd_slope=M.halfnormal(0.02, 1), sd_seasonal=M.halfnormal(0.05, 1),
+                         period=7, distribution="poisson", u=rng.uniform(0.8, 1.2, n),
+                         P1=np.diag([1.0, 0.1] + [0.5] * 6), a1=np.array([1.7] + [0.0] * 7))
+        theta = np.column_stack([rng.uniform(0.05, 0.2, ns), rng.uniform(0.01, 0.03, ns), rng.uniform(0.02, 0.08, ns)])
     else:  # bsm_binomial, local level + noise: m = 2... with sd_noise the state is (level, noise)
         u = rng.integers(5, 20, n).astype(float)
         y = rng.binomial(u.astype(int), 0.4).astype(float); y[8] = np.nan
@@ -330,7 +336,7 @@ def _ung_zoo(kind, rng, n=50):
     return model, theta, counts
 
 
-@pytest.mark.parametrize("kind", ["svm", "ar1_negbin_xreg", "bsm_gamma_seasonal", "bsm_binomial"])
+@pytest.mark.parametrize("kind", ["svm", "ar1_negbin_xreg", "bsm_gamma_seasonal", "bsm_poisson_weekly", "bsm_binomial"])
 @pytest.mark.parametrize("output_type", [2, 3])
 def test_full_device_ung_setup_against_oracle(oracle, monkeypatch, kind, output_type):
     """SURVEY.md 8f rank 1 for ssm_ung draws: the Laplace step at the stored mode, the scales, the smoother and the
@@ -355,7 +361,8 @@ def test_full_device_ung_setup_against_oracle(oracle, monkeypatch, kind, output_
     for dev in ("2", "0"):
         assert np.all(np.isfinite(res[dev]["loglik"]))
         assert np.allclose(res[dev]["loglik"], ref["loglik"], rtol=0, atol=1e-9 * n)
-        assert np.allclose(res[dev]["weights"], ref["weights"], rtol=1e-8)
+        # (eight states with singular smoothing covariances: the same last-ulp amplification as below reaches 1e-8 of the log-weights)
+        assert np.allclose(res[dev]["weights"], ref["weights"], rtol=1e-7 if kind == "bsm_poisson_weekly" else 1e-8)
         if output_type == 2:
             # (the seasonal model's smoothing covariances are singular: the factors amplify last-ulp differences between the
             # oracle's generic matrix code and the fixed-size template to ~1e-8 of the state scale)
@@ -363,9 +370,12 @@ def test_full_device_ung_setup_against_oracle(oracle, monkeypatch, kind, output_
             assert np.allclose(res[dev]["Vt"], ref["Vt"], rtol=1e-6, atol=1e-8)
     # device set-up vs host set-up: the same template and operation order (the device contracts to FMA, its exp / log differ
     # from libm's in the last place, and near-singular factors amplify that: 1e-8 of the state scale at most)
-    assert np.allclose(res["2"]["loglik"], res["0"]["loglik"], rtol=0, atol=1e-10 * n)
+    # (the weekly-seasonal model: eight states, singular smoothing covariances -- the amplification reaches 2e-8 of the
+    # log-likelihood; the one-lane and the row-distributed device kernels agree bit for bit there, the host agrees with the oracle)
+    assert np.allclose(res["2"]["loglik"], res["0"]["loglik"], rtol=0, atol=(2e-9 if kind == "bsm_poisson_weekly" else 1e-10) * n)
     if output_type == 2:
-        assert np.allclose(res["2"]["alphahat"], res["0"]["alphahat"], rtol=1e-7, atol=1e-9)
+        loose = kind == "bsm_poisson_weekly"
+        assert np.allclose(res["2"]["alphahat"], res["0"]["alphahat"], rtol=1e-6 if loose else 1e-7, atol=1e-7 if loose else 1e-9)
 
 
 @pytest.mark.parametrize("kind", ["bsm_ng", "nlg_growth"])
