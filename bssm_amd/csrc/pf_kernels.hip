@@ -593,7 +593,8 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64);
   hipLaunchKernelGGL((ung_setup_kernel<M, 0, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   const bool lane_form = std::getenv("BSSM_AMD_MNG_LANE_PER_DRAW") != nullptr;  // (comparison switch, shared with the ssm_mng set-up)
-  if (M == 8 && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<M == 8 ? 8 : 1, 1, true>), dim3((unsigned)((b.F + 7) / 8)), dim3(64), 0, stream, b);
+  constexpr int MR = (M == 8 || M == 4) ? M : 1;  // (as the ssm_mng set-up: rows for 8 and 4 states)
+  if ((M == 8 || M == 4) && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<MR, 1, true>), dim3((unsigned)((b.F + 64 / MR - 1) / (64 / MR))), dim3(64), 0, stream, b);
   else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
   hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   hipLaunchKernelGGL((ung_setup_kernel<M, 3, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
@@ -811,9 +812,12 @@ template <int M>
 static hipError_t launch_mng_setup_m(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64);
   hipLaunchKernelGGL(mng_laplace_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
-  // 8-dimensional states: a lane cannot hold the recursion's matrices (BSSM_AMD_MNG_LANE_PER_DRAW=1 keeps the one-lane form for comparison)
+  // (BSSM_AMD_MNG_LANE_PER_DRAW=1 keeps the one-lane form for comparison)
   const bool lane_form = std::getenv("BSSM_AMD_MNG_LANE_PER_DRAW") != nullptr;
-  if (M == 8 && !lane_form) hipLaunchKernelGGL((mng_setup_kernel<M == 8 ? 8 : 1, true>), dim3((unsigned)((b.F + 7) / 8)), dim3(64), 0, stream, b);
+  // row-distributed for 8 and 4 states (M lanes per draw must tile the wave): m = 8 cannot be held by one lane (49 -> 5.2 ms on the C4
+  // shape); m = 4 fits one lane but gains from four times as many waves (1 024 draws, p = 3, T = 300: the call 0.0485 -> 0.0436 s)
+  constexpr int MR = (M == 8 || M == 4) ? M : 1;
+  if ((M == 8 || M == 4) && !lane_form) hipLaunchKernelGGL((mng_setup_kernel<MR, true>), dim3((unsigned)((b.F + 64 / MR - 1) / (64 / MR))), dim3(64), 0, stream, b);
   else hipLaunchKernelGGL((mng_setup_kernel<M, false>), dim3(gx), dim3(64), 0, stream, b);
   hipLaunchKernelGGL(mng_factors_kernel<M>, dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   hipLaunchKernelGGL(mng_tables_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
