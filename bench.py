@@ -302,6 +302,35 @@ def single_process_multi_device(ns, devices=None):
     return {"error": (cp.stderr or cp.stdout)[-300:], "visible_gpus": nd}
 
 
+def mng_post_correct_leg(ns=512, n=200, nsim=256, threads=8):
+    """One psi post-correction call over `ns` theta-draws of the C4-shaped ssm_mng model (T = n), device set-up (the default)."""
+    import numpy as np
+    from bssm_amd import filters as F, models as M, post_correct as PC
+    from models_zoo import mng_c4
+    base = mng_c4(n)
+    m, k = int(base.m), np.shape(base["R"])[1]
+    R0 = np.array(base["R"], dtype=float).reshape(m, k)
+    model = M.BssmModel(base.classes, **{**base, "update_fn": (lambda theta: dict(R=R0 * np.exp(theta[0]))), "theta": np.zeros(1)})
+    rng = np.random.default_rng(5)
+    theta = rng.normal(0, 0.1, (ns, 1))
+    counts = np.ones(ns, dtype=np.uint32)
+    mode = F.psi_setup(model)["mode"].reshape(-1, order="F")
+    modes = np.repeat(mode[:, None], ns, axis=1)
+    arrs = PC.expand_models(model, theta)
+    best, r = 1e9, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = PC._run_local_block(arrs, modes, counts, 0, ns, nsim, 1, 2, 3, threads)
+        best = min(best, time.perf_counter() - t0)
+    assert np.all(np.isfinite(r["loglik"]))
+    return {"workload": "ssm_mng C4 shape (m=8, k=8, p=4), T=%d, %d theta-draws, psi-APF N=%d, is2, output theta; one bssm_is_correction call, "
+                        "%d host threads for ingesting / packing the draws" % (n, ns, nsim, threads),
+            "seconds": best, "draws_per_s": ns / best,
+            "setup": "device: mng_laplace_kernel, mng_setup_kernel<8, rows> (eight lanes per draw), mng_factors_kernel, mng_tables_kernel",
+            "checksum_loglik": float(np.sum(r["loglik"])),
+            "round_history_s": {"round 2 (one kernel, one lane per draw)": 0.26, "host set-up, 32 threads": 0.107}}
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -669,6 +698,15 @@ def main():
                 out["post_correct_single_process"] = single_process_multi_device(8 * args.pc_draws)
             except Exception as e:  # noqa: BLE001
                 out["post_correct_single_process"] = {"error": repr(e)[:200]}
+
+    if rank == 0 and world == 1 and not args.no_post_correct and not args.no_mng:
+        # ---- IS post-correction of ssm_mng draws of the C4 shape (m = 8, p = 4): the psi set-up (Laplace step, Kalman filter +
+        # covariance smoother over n p virtual steps, conditional factors, tables) runs on the device for every draw -- the
+        # smoother row-distributed over eight lanes per draw -- in front of small filters; SURVEY.md 8f rank 1
+        try:
+            out["post_correct_mng"] = mng_post_correct_leg()
+        except Exception as e:  # noqa: BLE001
+            out["post_correct_mng"] = {"error": repr(e)[:200]}
 
     if rank == 0 and os.environ.get("BSSM_BENCH_CALIB"):
         # profiling runs only (scripts/profile_round.sh): one kernel of known traffic (2 GiB read + 2 GiB written) so that
