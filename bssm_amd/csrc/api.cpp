@@ -2026,7 +2026,13 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
     };
     // one lane per draw: the set-up kernel of m > 4 states with several series takes as long for 64 draws as for 2 048
     // (tens of ms per 100 time points), so such jobs go in chunks of up to 2 048 draws instead of >= 4 short ones
-    const int hint = p0 > 1 && m > 4 ? std::min(cnt, 2048) : 0;
+    // (and bounded by the work arrays: 16 GB per chunk -- up to three chunks are alive at once; the C4 shape at T = 2000 takes 17.6 MB per draw)
+    int hint = 0;
+    if (p0 > 1 && m > 4) {
+      const double per_draw = (double)bssm::mng_setup_scratch_doubles(n, m, p0) * sizeof(double);
+      const int by_mem = (int)std::max(64.0, std::floor(16e9 / per_draw / 64.0) * 64.0);
+      hint = std::min(cnt, std::min(2048, by_mem));
+    }
     return run_is_pipeline(J, cnt, job->n_threads, prepare_full, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk_full, nullptr, hint);
   }
   const bool dev_setup = psi && device_setup_enabled(job->n_threads) && have_device();
