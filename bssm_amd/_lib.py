@@ -150,6 +150,50 @@ def dptr(a):
     return None if a is None else a.ctypes.data_as(c_double_p)
 
 
+_PTR_FIELDS = ("y", "Z", "T", "R", "a1", "P1", "D", "C", "xreg", "beta", "u", "H", "initial_mode")
+
+
+def pack_models(arrs):
+    """One UngModel per dict of ``arrs`` (models.model_arrays / post_correct.expand_models) as a ctypes array: the first draw is
+    packed field by field, the others are byte copies of it whose pointer fields are patched only where the draw holds a DIFFERENT
+    array object (expand_models shares what update_fn did not replace) -- packing 2 048 draws one by one cost 50 ms of Python
+    around a 10 ms library call.  Returns (array, keepalive)."""
+    cnt = len(arrs)
+    s0, keep0 = pack_model(arrs[0])
+    models = (UngModel * cnt)()
+    sz = C.sizeof(UngModel)
+    raw = np.frombuffer(models, dtype=np.uint8).reshape(cnt, sz)
+    raw[:] = np.frombuffer(bytes(s0), dtype=np.uint8)
+    keep = [keep0]
+    base = arrs[0]
+    ints = ("n", "m", "k", "Ztv", "Ttv", "Rtv", "Dtv", "Ctv", "Htv", "distribution", "n_xreg", "max_iter", "local_approx")
+    scal = ints + ("conv_tol", "p")
+    base_scal = tuple(map(base.get, scal))
+    base_ptrs = tuple(map(base.get, _PTR_FIELDS))
+    for i in range(1, cnt):
+        a = arrs[i]
+        if tuple(map(a.get, scal)) != base_scal or a.get("distribution_p") is not base.get("distribution_p") or a.get("phi_p") is not base.get("phi_p"):
+            si, ki = pack_model(a)  # (a draw that differs in more than its arrays: the slow way)
+            raw[i] = np.frombuffer(bytes(si), dtype=np.uint8)
+            keep.append(ki)
+            continue
+        for f, v, b0 in zip(_PTR_FIELDS, map(a.get, _PTR_FIELDS), base_ptrs):
+            if v is b0:
+                continue
+            if v is not None and v.size == 0:
+                v = None
+            addr = 0
+            if v is not None:
+                v = np.asfortranarray(v, dtype=np.float64)
+                keep.append(v)
+                addr = v.ctypes.data
+            off = getattr(UngModel, f).offset
+            raw[i, off:off + 8].view(np.uint64)[0] = addr
+    off = UngModel.phi.offset
+    raw[:, off:off + 8].view(np.float64)[:, 0] = np.asarray([float(a["phi"]) for a in arrs])
+    return models, keep
+
+
 def pack_model(arr: dict):
     """dict from models.model_arrays -> (UngModel, keepalive list)"""
     s = UngModel()

@@ -145,12 +145,7 @@ def _run_local_block(arrs, modes, counts, first, n_stored, nsim, seed, is_type, 
     """Filter draws [first, first+len(arrs)) on this process's GPU through the C ABI."""
     cnt = len(arrs)
     n, m = arrs[0]["n"], arrs[0]["m"]
-    packed, keep = [], []
-    for a in arrs:
-        s, k = _lib.pack_model(a)
-        packed.append(s)
-        keep.append(k)
-    models = (_lib.UngModel * cnt)(*packed)
+    models, keep = _lib.pack_models(arrs)
     job = _lib.IsJob()
     job.n_stored, job.first, job.count = n_stored, first, cnt
     job.models = models
