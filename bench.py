@@ -328,7 +328,7 @@ def mng_post_correct_leg(ns=512, n=200, nsim=256, threads=8):
             "seconds": best, "draws_per_s": ns / best,
             "setup": "device: mng_laplace_kernel, mng_setup_kernel<8, rows> (eight lanes per draw), mng_factors_kernel, mng_tables_kernel",
             "checksum_loglik": float(np.sum(r["loglik"])),
-            "round_history_s": {"round 2 (one kernel, one lane per draw)": 0.26, "host set-up, 32 threads": 0.107}}
+            "round_history_s": {"round 2 (one kernel, one lane per draw)": 0.26, "host set-up, 32 threads": 0.10}}
 
 
 def _free_port():
