@@ -1953,7 +1953,8 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   // ssm_mng draws (p0 > 1 independent series per time point): the same through mng_setup_kernel + mng_factors_kernel +
   // mng_tables_kernel; the default for any number of host threads since late round 3 (512 draws of the C4 shape: 0.069 s against
   // 0.109 s with 32 host threads; until the factors left the sequential kernel it was 0.26 s and only the default below 8 threads).
-  bool dev_full = psi && have_device() && m <= 8 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
+  // (n < 65535: the set-up's parallel kernels carry the time point in gridDim.y; longer series take the host set-up)
+  bool dev_full = psi && have_device() && m <= 8 && n < 65535 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
   if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) dev_full = dev_full && env[0] == '2';
   if (std::getenv("BSSM_AMD_GENERIC_SETUP")) dev_full = false;
   if (dev_full) {
@@ -2131,7 +2132,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   // theta and (a1, P1); linearisation at the stored mode, smoother, conditional factors and the filter's tables are ONE
   // kernel per pipeline chunk (fn_setup_kernel), whose outputs the filter reads in place.  BSSM_AMD_DEVICE_SETUP = 0 / 1
   // select the host set-up / the device smoother alone instead (they are tested against each other and the oracle).
-  bool dev_full = psi && have_device() && id >= bssm::FN_NLG_GROWTH && id <= bssm::FN_NLG_LINEAR_GAUSSIAN && is_type != 1;
+  bool dev_full = psi && have_device() && id >= bssm::FN_NLG_GROWTH && id <= bssm::FN_NLG_LINEAR_GAUSSIAN && is_type != 1 && n < 65535;  // (time points ride in gridDim.y)
   if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) dev_full = dev_full && env[0] == '2';
   for (int i = 1; i < count && dev_full; i++) if (models[i].y != models[0].y || models[i].n != n || models[i].model_id != id) dev_full = false;
   if (dev_full) {
