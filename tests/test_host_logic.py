@@ -297,3 +297,42 @@ def test_bench_gpus_flag_is_not_silently_ignored_without_gpus():
         assert cp.returncode != 0
         assert "one rank per GPU" in (cp.stderr + cp.stdout)
         assert not any(ln.startswith("{") for ln in cp.stdout.splitlines())
+
+
+def test_batched_model_packing_equals_packing_every_draw():
+    """_lib.pack_models (first draw packed field by field, the others byte copies with only the differing array pointers and phi
+    patched) must hand the library what packing every draw on its own hands it: same scalars, and pointers to arrays with the
+    same contents -- built-in update map (bsm_ng: R and phi change per draw), update_fn closure (ssm_mng) and a draw whose
+    scalars differ (the slow path)"""
+    from bssm_amd import post_correct as PC
+    from models_zoo import mng_zoo
+    rng = np.random.default_rng(4)
+    y = rng.negative_binomial(5, 0.5, 40).astype(float)
+    bsm = M.bsm_ng(y, sd_level=M.halfnormal(0.1, 1), sd_slope=M.halfnormal(0.02, 1), distribution="negative binomial", phi=M.gamma(4.0, 2, 0.5))
+    theta = np.column_stack([rng.uniform(0.05, 0.2, 9), rng.uniform(0.01, 0.03, 9), rng.uniform(3, 6, 9)])
+    base = mng_zoo()["mixed_m4_p3"]
+    R0 = np.array(base["R"], dtype=float)
+    mng = M.BssmModel(base.classes, **{**base, "update_fn": (lambda th: dict(R=R0 * np.exp(th[0]))), "theta": np.zeros(1)})
+    cases = [PC.expand_models(bsm, theta), PC.expand_models(mng, rng.normal(0, 0.1, (7, 1)))]
+    odd = PC.expand_models(bsm, theta)
+    odd[3] = dict(odd[3]); odd[3]["max_iter"] = int(odd[3]["max_iter"]) + 1  # scalars differ: that draw is packed on its own
+    cases.append(odd)
+    ptr_fields = [k for k, t in _lib.UngModel._fields_ if t is _lib.c_double_p]
+    for arrs in cases:
+        models, keep = _lib.pack_models(arrs)
+        for i, a in enumerate(arrs):
+            one, keep1 = _lib.pack_model(a)
+            got = models[i]
+            for k, t in _lib.UngModel._fields_:
+                if t is C.c_int32 or t is C.c_double:
+                    assert getattr(got, k) == getattr(one, k), (i, k)
+            for k in ptr_fields:
+                src = a.get("phi_p") if k == "phi_p" else a.get(k)
+                cnt = 0 if src is None else int(np.asarray(src).size)
+                pg, po = getattr(got, k), getattr(one, k)
+                assert bool(pg) == bool(po), (i, k)
+                if cnt and pg:
+                    assert np.array_equal(np.ctypeslib.as_array(pg, (cnt,)), np.ctypeslib.as_array(po, (cnt,)), equal_nan=True), (i, k)
+            if int(a.get("p", 1)) > 1:
+                p = int(a["p"])
+                assert np.array_equal(np.ctypeslib.as_array(got.distribution_p, (p,)), np.ctypeslib.as_array(one.distribution_p, (p,)))
