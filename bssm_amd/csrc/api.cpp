@@ -1215,6 +1215,29 @@ int bssm_update_model_builtin(int model_type, const int32_t* flags, const double
   return BSSM_OK;
 }
 
+int bssm_update_model_builtin_batch(int model_type, const int32_t* flags, const double* theta, int32_t n_par, int32_t count,
+                                    const bssm_ung_model* model, double* T, double* R, double* P1, double* a1, double* C,
+                                    double* beta, double* phi) {
+  if (!flags || !theta || !model || !T || !R || !P1 || !a1 || !C || !phi || count < 0 || n_par < 1) return fail(BSSM_ERR_INVALID, "NULL argument");
+  if (!model->T || !model->R || !model->P1 || !model->a1 || !model->C) return fail(BSSM_ERR_INVALID, "the model's T, R, P1, a1, C must be set");
+  const size_t n = model->n, m = model->m, k = model->k;
+  const size_t sT = m * m * (model->Ttv ? n : 1), sR = m * k * (model->Rtv ? n : 1), sP = m * m, sa = m, sC = m * (model->Ctv ? n : 1),
+               sb = model->n_xreg > 0 ? (size_t)model->n_xreg : 0;
+  if (sb && (!beta || !model->beta)) return fail(BSSM_ERR_INVALID, "beta required with regressors");
+  for (int32_t i = 0; i < count; i++) {
+    double *Ti = T + sT * i, *Ri = R + sR * i, *Pi = P1 + sP * i, *ai = a1 + sa * i, *Ci = C + sC * i, *bi = sb ? beta + sb * i : nullptr;
+    std::memcpy(Ti, model->T, sT * sizeof(double)); std::memcpy(Ri, model->R, sR * sizeof(double));
+    std::memcpy(Pi, model->P1, sP * sizeof(double)); std::memcpy(ai, model->a1, sa * sizeof(double));
+    std::memcpy(Ci, model->C, sC * sizeof(double));
+    if (sb) std::memcpy(bi, model->beta, sb * sizeof(double));
+    bssm_ung_model mi = *model;
+    const std::string err = bssm::update_model_builtin(model_type, flags, theta + (size_t)n_par * i, n_par, &mi, Ti, Ri, Pi, ai, Ci, bi);
+    if (!err.empty()) return fail(BSSM_ERR_UNSUPPORTED, "draw " + std::to_string(i) + ": " + err);
+    phi[i] = mi.phi;
+  }
+  return BSSM_OK;
+}
+
 // ------------------------------------------------------------------ user-defined models (run-time compiled)
 }  // extern "C"
 namespace {

@@ -52,6 +52,30 @@ def expand_models(model: BssmModel, theta: np.ndarray):
     flags = _builtin_flags(model)
     out = []
     L = _lib.lib()
+    if flags is not None and theta.shape[0] > 1:
+        # built-in maps, every draw in ONE library call (the reference's parset_ung, src/parset_ng.cpp:5-72); the per-draw dicts
+        # then hold views into the batch arrays
+        cnt = theta.shape[0]
+        keys = ("T", "R", "P1", "a1", "C", "beta")
+        bf = {k: np.asfortranarray(base[k], dtype=np.float64) for k in keys}
+        big = {k: np.empty((cnt, bf[k].size)) for k in keys}
+        phi = np.empty(cnt)
+        s0, keep0 = _lib.pack_model({**base, **bf})
+        fl = (C.c_int32 * len(flags))(*flags)
+        thc = np.ascontiguousarray(theta, dtype=np.float64)  # row i = draw i = column i of the n_par x count matrix
+        _lib.check(L.bssm_update_model_builtin_batch(C.c_int(mt), fl, _lib.dptr(thc), C.c_int32(thc.shape[1]), C.c_int32(cnt), C.byref(s0),
+                                                     _lib.dptr(big["T"]), _lib.dptr(big["R"]), _lib.dptr(big["P1"]), _lib.dptr(big["a1"]),
+                                                     _lib.dptr(big["C"]), _lib.dptr(big["beta"]) if bf["beta"].size else None, _lib.dptr(phi)))
+        has_x = bool(base["xreg"].shape[1])
+        for i in range(cnt):
+            arr = dict(base)
+            for k in keys:
+                arr[k] = big[k][i].reshape(bf[k].shape, order="F")
+            arr["phi"] = float(phi[i])
+            if has_x:
+                arr["xbeta"] = arr["xreg"] @ arr["beta"]
+            out.append(arr)
+        return out
     for i in range(theta.shape[0]):
         arr = dict(base)
         th = np.ascontiguousarray(theta[i])

@@ -357,6 +357,14 @@ int bssm_is_merge(int32_t n, int32_t m, int32_t n_stored, const double* weights,
 int bssm_update_model_builtin(int model_type, const int32_t* flags, const double* theta, int32_t n_par,
                               bssm_ung_model* model, double* T, double* R, double* P1, double* a1, double* C,
                               double* beta);
+/* The same for every stored draw at once -- what parset_ung does with update_fn before the parallel region of the
+ * post-correction (src/parset_ng.cpp:5-72).  theta: n_par x count, one draw per column.  T, R, P1, a1, C, beta: room for
+ * `count` consecutive copies of the model's arrays (their sizes follow from n, m, k, n_xreg and the time-variation flags
+ * of `model`); each slot is filled with the model's array and then rewritten by the map of its draw; beta may be NULL when
+ * n_xreg = 0.  phi[count] receives the dispersion of every draw.  `model` itself is not modified. */
+int bssm_update_model_builtin_batch(int model_type, const int32_t* flags, const double* theta, int32_t n_par, int32_t count,
+                                    const bssm_ung_model* model, double* T, double* R, double* P1, double* a1, double* C,
+                                    double* beta, double* phi);
 
 /* ---- psi-APF set-up on its own (host): approximate() + smoother_ccov + conditional_cov,
  * src/model_ssm_ung.cpp:87-161, 514-534.  is_mode (p x n) NULL = iterate from initial_mode.

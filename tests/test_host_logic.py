@@ -336,3 +336,32 @@ def test_batched_model_packing_equals_packing_every_draw():
             if int(a.get("p", 1)) > 1:
                 p = int(a["p"])
                 assert np.array_equal(np.ctypeslib.as_array(got.distribution_p, (p,)), np.ctypeslib.as_array(one.distribution_p, (p,)))
+
+
+def test_builtin_update_maps_for_all_draws_at_once_equal_the_per_draw_maps():
+    """bssm_update_model_builtin_batch (the reference's parset_ung for the built-in maps, src/parset_ng.cpp:5-72) against one
+    bssm_update_model_builtin call per draw: ar1_ng with regressors, svm, bsm_ng with a seasonal component"""
+    from bssm_amd import post_correct as PC
+    rng = np.random.default_rng(12)
+    n = 30
+    x = rng.normal(0, 1, (n, 2))
+    ar1 = M.ar1_ng(rng.negative_binomial(5, 0.5, n).astype(float), rho=M.uniform(0.7, -0.99, 0.99), sigma=M.halfnormal(0.3, 2), mu=M.normal(1.0, 0, 5),
+                   distribution="negative binomial", phi=M.gamma(4.0, 2, 0.5), beta=[M.normal(0.1, 0, 1), M.normal(-0.2, 0, 1)], xreg=x)
+    th_ar1 = np.column_stack([rng.uniform(0.5, 0.9, 6), rng.uniform(0.2, 0.5, 6), rng.normal(1.0, 0.1, 6), rng.uniform(3, 6, 6),
+                              rng.normal(0.1, 0.05, 6), rng.normal(-0.2, 0.05, 6)])
+    sv = M.svm(rng.normal(0, 1, n), rho=M.uniform(0.9, -0.99, 0.99), sd_ar=M.halfnormal(0.2, 5), sigma=M.halfnormal(1.0, 2))
+    th_sv = np.column_stack([rng.uniform(0.8, 0.97, 5), rng.uniform(0.1, 0.4, 5), rng.uniform(0.7, 1.3, 5)])
+    bsm = M.bsm_ng(rng.gamma(3.0, 2.0, n), sd_level=M.halfnormal(0.1, 1), sd_slope=M.halfnormal(0.02, 1), sd_seasonal=M.halfnormal(0.05, 1),
+                   period=4, distribution="gamma", phi=M.gamma(3.0, 2, 0.5))
+    th_bsm = np.column_stack([rng.uniform(0.05, 0.2, 7), rng.uniform(0.01, 0.03, 7), rng.uniform(0.02, 0.08, 7), rng.uniform(2, 4, 7)])
+    for model, theta in ((ar1, th_ar1), (sv, th_sv), (bsm, th_bsm)):
+        batch = PC.expand_models(model, theta)
+        assert len(batch) == theta.shape[0]
+        for i in range(theta.shape[0]):
+            one = PC.expand_models(model, theta[i:i + 1])[0]  # a single row takes the per-draw call
+            assert set(one) == set(batch[i])
+            for k, v in one.items():
+                if isinstance(v, np.ndarray):
+                    assert batch[i][k].shape == v.shape and np.array_equal(batch[i][k], v, equal_nan=True), (i, k)
+                else:
+                    assert batch[i][k] == v, (i, k)
