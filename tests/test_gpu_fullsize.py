@@ -169,6 +169,10 @@ def test_c5_post_correct_tail_round_through_the_step_kernels(monkeypatch):
     assert np.array_equal(whole["loglik"], two)                               # workgroup-resident everywhere
     assert not np.array_equal(split["loglik"][256:], whole["loglik"][256:])   # the tail really took the other kernels
     assert np.max(np.abs(split["loglik"] - whole["loglik"])) <= 1e-10 * n
+    # the same job cut over two logical devices inside the library (bssm_is_correction_nlg_multi; both shards on this GPU): shards
+    # of 150 have no tail round, so every draw is workgroup-resident there
+    shard = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4, devices=[0, 0])
+    assert np.array_equal(shard["loglik"], whole["loglik"])
     # with the smoothing summaries (history pools shared by the two kernel families of the chunk)
     s2 = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 2, 4)
     monkeypatch.setenv("BSSM_AMD_NO_TAIL_SPLIT", "1")
