@@ -63,6 +63,11 @@ struct LgSmoother {
   static constexpr int MM = M * M;
   static constexpr double kZeroTol = 1e-12;  // src/model_ssm_ulg.h:19
   static constexpr double kEps = DBL_EPSILON;
+#if defined(__HIP_DEVICE_COMPILE__)
+  static constexpr bool kAhead = M <= 2;  // operands of the next step requested while this one computes (device, small states: registers to spare)
+#else
+  static constexpr bool kAhead = false;
+#endif
 
   // C = A * B (all M x M, column-major), accumulation over the inner index in ascending order from 0
   // (LG_UNROLL: on the device the three loops are unrolled completely, so that the operands of a product are read in one batch
@@ -204,27 +209,43 @@ struct LgSmoother {
   LG_HD LG_INL static bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es = 1,
                         bool with_factors = true) {
     const int n = g.n;
-    double a[M], P[MM], a1n[M], P1n[MM], Z[M], T[MM], RR[MM], Cv[M];
+    double a[M], P[MM], a1n[M], P1n[MM];
     double tmp[MM], tmp2[MM], inner[MM], IKZ[MM];
     ldv(g.a1, es, M, a); ldv(g.P1, es, MM, P);
     stv(at, es, M, a); stv(Pt, es, MM, P);
     // ---- forward pass (kf_predict, univariate branch, Joseph form)
     const int sub = g.sub;
+    // the operands of a step that do not depend on the recursion (model matrices, observation): on the device and for small states
+    // they are requested ONE STEP AHEAD, so that their round trip runs under the previous step's arithmetic -- with one lane per
+    // draw a step is otherwise a load round trip followed by a dependent chain, nothing else to switch to
+    struct FwdIn { double Z[M], T[MM], RR[MM], Cv[M], yt, sd, Dv; };
+    auto load_fwd = [&](int t, FwdIn& I) {
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      ldv(g.Z + ((size_t)tr * g.Zs + (size_t)js * M) * es, es, M, I.Z);
+      if (sub == 1 || js == sub - 1) {
+        ldv(g.T + (size_t)tr * g.Ts * es, es, MM, I.T);
+        ldv(g.RR + (size_t)tr * g.Rs * es, es, MM, I.RR);
+        ldv(g.C + (size_t)tr * g.Cs * es, es, M, I.Cv);
+      } else {
+        for (int q = 0; q < MM; q++) { I.T[q] = 0.0; I.RR[q] = 0.0; }
+        for (int i = 0; i < M; i++) { I.T[i + M * i] = 1.0; I.Cv[i] = 0.0; }
+      }
+      I.yt = g.y[(size_t)t * es];
+      I.sd = g.H[(size_t)t * g.Hs * es];
+      I.Dv = g.D[((size_t)tr * g.Ds + js) * es];
+    };
+    FwdIn fin, fnx;
+    if (kAhead && n > 0) load_fwd(0, fin);
     for (int t = 0; t < n; t++) {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
       const bool moves = sub == 1 || js == sub - 1;  // the state moves behind this (virtual) step
-      ldv(g.Z + ((size_t)tr * g.Zs + (size_t)js * M) * es, es, M, Z);
-      if (moves) {
-        ldv(g.T + (size_t)tr * g.Ts * es, es, MM, T);
-        ldv(g.RR + (size_t)tr * g.Rs * es, es, MM, RR);
-        ldv(g.C + (size_t)tr * g.Cs * es, es, M, Cv);
-      } else {
-        for (int q = 0; q < MM; q++) { T[q] = 0.0; RR[q] = 0.0; }
-        for (int i = 0; i < M; i++) { T[i + M * i] = 1.0; Cv[i] = 0.0; }
-      }
-      const double yt = g.y[(size_t)t * es];
+      (void)tr;
+      if (kAhead) { if (t + 1 < n) load_fwd(t + 1, fnx); } else load_fwd(t, fin);
+      double (&Z)[M] = fin.Z; double (&T)[MM] = fin.T; double (&RR)[MM] = fin.RR; double (&Cv)[M] = fin.Cv;
+      const double yt = fin.yt;
       const bool na = !lg_finite(yt);
-      const double sd = g.H[(size_t)t * g.Hs * es];
+      const double sd = fin.sd;
+      const double Dt = fin.Dv;
       const double HH = na ? 1.0 : sd * sd;
       double F = 0.0;
       if (!na) {
@@ -251,7 +272,7 @@ struct LgSmoother {
       } else {
         double za = 0.0;
         for (int c = 0; c < M; c++) za += Z[c] * a[c];
-        const double vt = yt - g.D[((size_t)tr * g.Ds + js) * es] - za;
+        const double vt = yt - Dt - za;
         v[(size_t)t * es] = vt;
         double au[M];
         for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += P[i + M * q] * Z[q]; Kt[i] = s / F; }
@@ -277,33 +298,47 @@ struct LgSmoother {
       stv(cc + (size_t)t * MM * es, es, MM, P1n);
       for (int i = 0; i < M; i++) a[i] = a1n[i];
       for (int q = 0; q < MM; q++) P[q] = P1n[q];
+      if (kAhead) fin = fnx;
     }
     LG_STAMP(2);
     // ---- backward pass (smoother_ccov)
-    double rt[M], Nt[MM], L[MM], N2[MM], ct[MM], Kt[M];
+    double rt[M], Nt[MM], L[MM], N2[MM];
     for (int i = 0; i < M; i++) rt[i] = 0.0;
     for (int q = 0; q < MM; q++) Nt[q] = 0.0;
+    // (the same one step ahead: what step t reads was written by the forward pass, and step t + 1 only rewrites its own slots)
+    struct BwdIn { double Z[M], T[MM], a[M], P[MM], ct[MM], Kt[M], F, vt; };
+    auto load_bwd = [&](int t, BwdIn& I) {
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      ldv(g.Z + ((size_t)tr * g.Zs + (size_t)js * M) * es, es, M, I.Z);
+      if (sub == 1 || js == sub - 1) {
+        ldv(g.T + (size_t)tr * g.Ts * es, es, MM, I.T);
+      } else {
+        for (int q = 0; q < MM; q++) I.T[q] = 0.0;
+        for (int i = 0; i < M; i++) I.T[i + M * i] = 1.0;
+      }
+      ldv(at + (size_t)t * M * es, es, M, I.a);
+      ldv(Pt + (size_t)t * MM * es, es, MM, I.P);
+      if (sub == 1 || js == sub - 1) ldv(cc + (size_t)t * MM * es, es, MM, I.ct);
+      I.F = Fs[(size_t)t * es];
+      ldv(K + (size_t)t * M * es, es, M, I.Kt);  // (zeros where the step had no update)
+      I.vt = v[(size_t)t * es];
+    };
+    BwdIn bin, bnx;
+    if (kAhead && n > 0) load_bwd(n - 1, bin);
     for (int t = n - 1; t >= 0; t--) {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
-      ldv(g.Z + ((size_t)tr * g.Zs + (size_t)js * M) * es, es, M, Z);
+      (void)tr;
       const bool movesb = sub == 1 || js == sub - 1;
-      if (movesb) {
-        ldv(g.T + (size_t)tr * g.Ts * es, es, MM, T);
-      } else {
-        for (int q = 0; q < MM; q++) T[q] = 0.0;
-        for (int i = 0; i < M; i++) T[i + M * i] = 1.0;
-      }
       // Series at a time (sub > 1): the conditional factors are taken at the time points only (virtual steps s * sub), from the
       // covariances of the steps s * sub - 1 and s * sub and the cross-covariance of step s * sub - 1 -- the other virtual steps only
       // carry r_t / N_t through, so their smoothed covariance and cross-covariance (five of a step's seven matrix products) are
       // not formed; what is needed comes out bit for bit as before
       const bool need_P = sub == 1 || js == 0 || js == sub - 1, need_cc = sub == 1 || js == sub - 1;
-      ldv(at + (size_t)t * M * es, es, M, a);
-      ldv(Pt + (size_t)t * MM * es, es, MM, P);
-      if (need_cc) ldv(cc + (size_t)t * MM * es, es, MM, ct);
-      const double F = Fs[(size_t)t * es];
+      if (kAhead) { if (t > 0) load_bwd(t - 1, bnx); } else load_bwd(t, bin);
+      double (&Z)[M] = bin.Z; double (&T)[MM] = bin.T; double (&a)[M] = bin.a; double (&P)[MM] = bin.P; double (&ct)[MM] = bin.ct;
+      double (&Kt)[M] = bin.Kt;
+      const double F = bin.F, vt_b = bin.vt;
       const double* Lm = T;
-      if (F > 0.0) ldv(K + (size_t)t * M * es, es, M, Kt);
       if (F > 0.0 && movesb) {
         for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) IKZ[i + M * j] = (i == j ? 1.0 : 0.0) - Kt[i] * Z[j];
         mul(T, IKZ, L); Lm = L;
@@ -333,7 +368,7 @@ struct LgSmoother {
         for (int q = 0; q < MM; q++) N2[q] = Nt[q];
       }
       if (F > 0.0) {
-        const double vt = v[(size_t)t * es];
+        const double vt = vt_b;
         for (int i = 0; i < M; i++) rn[i] = Z[i] / F * vt + rn[i];
         for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) N2[i + M * j] = Z[i] * Z[j] / F + N2[i + M * j];
       }
@@ -354,6 +389,7 @@ struct LgSmoother {
         for (int q = 0; q < MM; q++) if (!lg_finite(P[q])) return false;
         stv(Pt + (size_t)t * MM * es, es, MM, P);
       }
+      if (kAhead) bin = bnx;
     }
     for (int q = 0; q < MM; q++) cc[((size_t)n * MM + q) * es] = 0.0;
     LG_STAMP(3);
