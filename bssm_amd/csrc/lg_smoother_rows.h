@@ -68,20 +68,37 @@ struct LgRows {
 #pragma unroll
     for (int j = 0; j < M; j++) Pt[(size_t)(r + M * j) * es] = P[j];
     // ---- forward pass (kf_predict, univariate branch, Joseph form)
+    // the operands of a step that do not depend on the recursion are requested one step ahead (their round trip runs under the
+    // previous step's LDS exchanges and arithmetic)
+    struct FwdIn { double Z[M], T[M], RR[M], Cv[M], yt, sd, Dv; };
+    auto load_fwd = [&](int t, FwdIn& I) {
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+#pragma unroll
+      for (int q = 0; q < M; q++) I.Z[q] = g.Z[((size_t)tr * g.Zs + (size_t)js * M + q) * es];
+      if (sub == 1 || js == sub - 1) {
+#pragma unroll
+        for (int j = 0; j < M; j++) { I.T[j] = g.T[((size_t)tr * g.Ts + r + M * j) * es]; I.RR[j] = g.RR[((size_t)tr * g.Rs + r + M * j) * es]; }
+#pragma unroll
+        for (int q = 0; q < M; q++) I.Cv[q] = g.C[((size_t)tr * g.Cs + q) * es];
+      }
+      I.yt = g.y[(size_t)t * es];
+      I.sd = g.H[(size_t)t * g.Hs * es];
+      I.Dv = g.D[((size_t)tr * g.Ds + js) * es];
+    };
+    FwdIn fin, fnx;
+    if (n > 0) load_fwd(0, fin);
     for (int t = 0; t < n; t++) {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
       const bool moves = sub == 1 || js == sub - 1;
+      (void)tr;
+      if (t + 1 < n) load_fwd(t + 1, fnx);
 #pragma unroll
-      for (int q = 0; q < M; q++) Z[q] = g.Z[((size_t)tr * g.Zs + (size_t)js * M + q) * es];
-      if (moves) {
-#pragma unroll
-        for (int j = 0; j < M; j++) { T[j] = g.T[((size_t)tr * g.Ts + r + M * j) * es]; RR[j] = g.RR[((size_t)tr * g.Rs + r + M * j) * es]; }
-#pragma unroll
-        for (int q = 0; q < M; q++) Cv[q] = g.C[((size_t)tr * g.Cs + q) * es];
-      }
-      const double yt = g.y[(size_t)t * es];
+      for (int q = 0; q < M; q++) { Z[q] = fin.Z[q]; T[q] = fin.T[q]; RR[q] = fin.RR[q]; Cv[q] = fin.Cv[q]; }
+      const double yt = fin.yt;
       const bool na = !lg_finite(yt);
-      const double sd = g.H[(size_t)t * g.Hs * es];
+      const double sd = fin.sd;
+      const double Dt = fin.Dv;
+      fin = fnx;
       const double HH = na ? 1.0 : sd * sd;
       // zp = Z' P = P Z (P is symmetric to the last bit: symmatu below): row r times Z
       double pz = 0.0, zp[M];
@@ -98,7 +115,7 @@ struct LgRows {
       double za = 0.0;
 #pragma unroll
       for (int c = 0; c < M; c++) za += Z[c] * a[c];
-      const double vt = upd ? yt - g.D[((size_t)tr * g.Ds + js) * es] - za : 0.0;
+      const double vt = upd ? yt - Dt - za : 0.0;
       if (r == 0) { Fs[(size_t)t * es] = upd ? F : 0.0; v[(size_t)t * es] = vt; }
       // K = P Z / F (zero without an update): lane r has (P Z)_r = pz
       gather(upd ? pz / F : 0.0, Kt);
@@ -172,27 +189,42 @@ struct LgRows {
     double rt[M], N[M], L[M], ct[M];
 #pragma unroll
     for (int q = 0; q < M; q++) { rt[q] = 0.0; N[q] = 0.0; ct[q] = 0.0; }
+    // (one step ahead here too: what step t reads was written by the forward pass, and step t + 1 only rewrites its own slots)
+    struct BwdIn { double Z[M], T[M], P[M], ct[M], Kt[M], ar, F, vt; };
+    auto load_bwd = [&](int t, BwdIn& I) {
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+#pragma unroll
+      for (int q = 0; q < M; q++) I.Z[q] = g.Z[((size_t)tr * g.Zs + (size_t)js * M + q) * es];
+      if (sub == 1 || js == sub - 1) {
+#pragma unroll
+        for (int j = 0; j < M; j++) { I.T[j] = g.T[((size_t)tr * g.Ts + r + M * j) * es]; I.ct[j] = cc[((size_t)t * MM + r + M * j) * es]; }
+      }
+      I.ar = at[((size_t)t * M + r) * es];
+#pragma unroll
+      for (int j = 0; j < M; j++) I.P[j] = Pt[((size_t)t * MM + r + M * j) * es];
+      I.F = Fs[(size_t)t * es];
+#pragma unroll
+      for (int q = 0; q < M; q++) I.Kt[q] = K[((size_t)t * M + q) * es];  // (zeros where the step had no update)
+      I.vt = v[(size_t)t * es];
+    };
+    BwdIn bin, bnx;
+    if (n > 0) load_bwd(n - 1, bin);
     for (int t = n - 1; t >= 0; t--) {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      (void)tr;
       const bool movesb = sub == 1 || js == sub - 1;
       const bool need_P = sub == 1 || js == 0 || js == sub - 1, need_cc = sub == 1 || js == sub - 1;
+      if (t > 0) load_bwd(t - 1, bnx);
+      const double F = bin.F, vt_b = bin.vt;
+      const bool upd = F > 0.0;
+      const double ar = bin.ar;
 #pragma unroll
-      for (int q = 0; q < M; q++) Z[q] = g.Z[((size_t)tr * g.Zs + (size_t)js * M + q) * es];
-      if (movesb) {
-#pragma unroll
-        for (int j = 0; j < M; j++) T[j] = g.T[((size_t)tr * g.Ts + r + M * j) * es];
-      }
-      const double ar = at[((size_t)t * M + r) * es];
-#pragma unroll
-      for (int j = 0; j < M; j++) P[j] = Pt[((size_t)t * MM + r + M * j) * es];
+      for (int q = 0; q < M; q++) { Z[q] = bin.Z[q]; T[q] = bin.T[q]; P[q] = bin.P[q]; Kt[q] = upd ? bin.Kt[q] : 0.0; }
       if (need_cc) {
 #pragma unroll
-        for (int j = 0; j < M; j++) ct[j] = cc[((size_t)t * MM + r + M * j) * es];
+        for (int j = 0; j < M; j++) ct[j] = bin.ct[j];
       }
-      const double F = Fs[(size_t)t * es];
-      const bool upd = F > 0.0;
-#pragma unroll
-      for (int q = 0; q < M; q++) Kt[q] = upd ? K[((size_t)t * M + q) * es] : 0.0;
+      bin = bnx;
       double rn[M], N2[M], tmp[M], tmp2[M];
       if (movesb) {
         // L = T (I - K Z'), row r
@@ -264,7 +296,7 @@ struct LgRows {
         for (int j = 0; j < M; j++) N2[j] = upd ? N[j] - Z[r] * w[j] - w[r] * Z[j] + kappa * Z[r] * Z[j] : N[j];
       }
       if (upd) {
-        const double vt = v[(size_t)t * es];
+        const double vt = vt_b;
 #pragma unroll
         for (int i = 0; i < M; i++) rn[i] = Z[i] / F * vt + rn[i];
 #pragma unroll
