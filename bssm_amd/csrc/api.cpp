@@ -2048,12 +2048,13 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       J.chunk_tabs[lo] = ct;
       return 0;
     };
-    // one lane per draw: the set-up kernel of m > 4 states with several series takes as long for 64 draws as for 2 048
-    // (tens of ms per 100 time points), so such jobs go in chunks of up to 2 048 draws instead of >= 4 short ones
     // (and bounded by the work arrays: 16 GB per chunk -- up to three chunks are alive at once; the C4 shape at T = 2000 takes 17.6 MB per draw)
+    // Since the set-up became four kernels whose only sequential one takes the same time for 64 draws as for 2 048, and the host's share
+    // is ingesting and packing a draw, EVERY job of this path goes in chunks of up to 2 048 draws (512 weekly-seasonal bsm_ng draws:
+    // 21.4 ms in four chunks, 12.5 ms in one; 2 048 draws 46.9 -> 38.3 ms; two-state draws unchanged)
     int hint = 0;
-    if (p0 > 1 && m > 4) {
-      const double per_draw = (double)bssm::mng_setup_scratch_doubles(n, m, p0) * sizeof(double);
+    {
+      const double per_draw = (double)(p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m, p0) : bssm::ung_setup_scratch_doubles(n, m)) * sizeof(double);
       const int by_mem = (int)std::max(64.0, std::floor(16e9 / per_draw / 64.0) * 64.0);
       hint = std::min(cnt, std::min(2048, by_mem));
     }
