@@ -331,6 +331,105 @@ def mng_post_correct_leg(ns=512, n=200, nsim=256, threads=8):
             "round_history_s": {"round 2 (one kernel, one lane per draw)": 0.26, "host set-up, 32 threads": 0.10}}
 
 
+def accuracy_leg(model, N, T, R, m, fw, stream, max_pairs=64):
+    """The metric's second half: log-likelihood RMSE (and weighted state means, states, weights, ancestors) against the
+    reference-equivalent CPU path on identical seeds, on the very variant that was timed: the same plan shape (N, T, R
+    filters in flight, two launch sequences), two passes with fresh seeds = 2 R (seed, batch slot) pairs, EVERY one of
+    them re-run by the oracle (one N x T filter, ~8 s of one core, per host thread).
+
+    The oracle runs in tie-following mode (oracle/bssm_oracle.c): it resamples exactly as the reference does and compares
+    its ancestors with the device's; where they differ it adopts the device's choice only if that is the adjacent particle
+    and the slot's target lies within tie_tolerance(N) strata of the cumulative weight between the two (either answer is a
+    correctly rounded evaluation of the same comparison) -- anything else is counted as unexplained and breaks the
+    comparison.  The oracle is then the reference recursion along the device's own path and everything is compared at the
+    fp64 bar on every pair.  For the pairs that had a tie, a free-running oracle is run as well: what its log-likelihood
+    differs by is Monte-Carlo noise of two equally valid particle systems, reported separately."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from bssm_amd import models as M
+    from bssm_amd.plan import FilterPlan
+    from oracle import oracle as O
+    arr = M.model_arrays(model)
+    acc_seeds = (20011, 20012)
+    keys = [(sd, f) for sd in acc_seeds for f in range(R)][:max_pairs] if max_pairs >= 2 * R else \
+        [(sd, f) for sd in acc_seeds for f in sorted(set([0, max(0, R // 2 - 1), R // 2, R - 1]))][:max(1, max_pairs)]
+    try:
+        avail_gb = int(re.search(r"MemAvailable:\s+(\d+)", open("/proc/meminfo").read()).group(1)) / 1e6
+    except Exception:  # noqa: BLE001
+        avail_gb = 64.0
+    per_pair_gb = 2.6 * (8.0 * ((m + 1) * (T + 1) + T / 2.0) * N) / 1e9   # device copy + oracle outputs + temporaries
+    workers = int(max(1, min(len(keys), (os.cpu_count() or 1) // 2, (0.6 * avail_gb) // per_pair_gb)))
+    pa = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R, factored_weights=fw)
+
+    def one(job):
+        sd, f, got, gll = job
+        with O.following(got["indices"], N) as fo:
+            ref = O.bsf_filter(arr, N, seed=sd, stream=f)
+        rec = {"seed": sd, "slot": f, "dloglik": gll - float(ref["logLik"]), "ties": fo.ties, "unexplained": fo.unexplained,
+               "tables_identical_after_following": bool(np.array_equal(got["indices"], ref["indices"].T))}
+        w = got["weights"][:T]
+        att_gpu = np.einsum("tmn,tn->tm", got["alpha"][:T], w / w.sum(axis=1, keepdims=True))   # weighted filtered means, T x m
+        rw = ref["weights"][:, :T]
+        att_ref = np.einsum("mtn,nt->tm", ref["alpha"][:, :T, :], rw / rw.sum(axis=0))
+        rec["att_max_rel_diff"] = float(np.max(np.abs(att_gpu - att_ref) / (1.0 + np.abs(att_ref))))
+        ra = np.transpose(ref["alpha"], (1, 0, 2))
+        rec["alpha_max_abs_diff_over_scale"] = float(np.max(np.abs(got["alpha"] - ra)) / max(1.0, float(np.abs(ra).max())))
+        rec["weights_max_rel_diff"] = float(np.max(np.abs(got["weights"] - ref["weights"].T) / (1e-300 + np.abs(ref["weights"].T))))
+        if fo.ties:
+            t0, j0 = fo.first_tie
+            rec.update(first_tie_t=t0, first_tie_slot=j0, max_margin_strata=fo.max_margin)
+            del ref
+            free = O.bsf_filter(arr, N, seed=sd, stream=f)     # the oracle left alone: diverges at the first tie
+            neq = (got["indices"] != free["indices"].T).sum(axis=1)
+            rec["free_running_dloglik"] = gll - float(free["logLik"])
+            rec["free_running_differing_ancestors_by_step_from_first_tie"] = [int(v) for v in neq[t0:t0 + 5]]
+            rec["free_running_differing_entries"] = int(neq.sum())
+        return rec
+
+    recs, dev_ll = [], {}
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        for sd in acc_seeds:
+            mine = [k for k in keys if k[0] == sd]
+            if not mine:
+                continue
+            pa.run(sd, stream0=0, hip_stream=stream)
+            llv = pa.loglik(stream)
+            dev_ll[sd] = [float(v) for v in llv]
+            for g in range(0, len(mine), workers):
+                jobs = [(sd, f, pa.fetch(f, hip_stream=stream), float(llv[f])) for _, f in mine[g:g + workers]]
+                recs += list(ex.map(one, jobs))
+                del jobs
+    acc_kernel, acc_seqs, acc_layout = FilterPlan.last_kernel(), pa.launch_sequences(), pa.weights_layout()
+    pa.close()
+    d = np.asarray([r["dloglik"] for r in recs])
+    tied = [r for r in recs if r["ties"]]
+    free = np.asarray([r.get("free_running_dloglik", r["dloglik"]) for r in recs])
+    sd_est = float(np.mean([np.std(v, ddof=1) for v in dev_ll.values() if len(v) > 1])) if dev_ll else None
+    return {"loglik_rmse_vs_cpu_same_seeds": float(np.sqrt(np.mean(d * d))), "max_abs_diff": float(np.max(np.abs(d))),
+            "oracle_mode": "tie-following (adopts the device's ancestor only at explained last-ulp ties)",
+            "device_pairs": len(acc_seeds) * R, "oracle_checked_pairs": len(recs), "oracle_threads": workers,
+            "pairs_without_a_tie": len(recs) - len(tied), "pairs_with_ties": len(tied), "ties_total": int(sum(r["ties"] for r in recs)),
+            "unexplained_ancestor_differences": int(sum(r["unexplained"] for r in recs)),
+            "ancestor_tables_identical_after_following": int(sum(r["tables_identical_after_following"] for r in recs)),
+            "tie_tolerance_strata": O.tie_tolerance(N), "max_tie_margin_strata": max([r["max_margin_strata"] for r in tied], default=0.0),
+            "weighted_state_means_max_rel_diff": max(r["att_max_rel_diff"] for r in recs),
+            "states_max_abs_diff_over_scale": max(r["alpha_max_abs_diff_over_scale"] for r in recs),
+            "weights_max_rel_diff": max(r["weights_max_rel_diff"] for r in recs),
+            "loglik_rmse_free_running_oracle": float(np.sqrt(np.mean(free * free))),
+            "loglik_sd_of_the_estimator_across_streams": sd_est,
+            "tied_pairs": [{k: r[k] for k in ("seed", "slot", "ties", "first_tie_t", "first_tie_slot", "max_margin_strata", "dloglik",
+                                               "free_running_dloglik", "free_running_differing_ancestors_by_step_from_first_tie")} for r in tied],
+            "seeds": list(acc_seeds), "N": N, "T": T, "m": m, "filters_in_flight": R, "kernel": acc_kernel, "launch_sequences": acc_seqs,
+            "weights_layout_factored": acc_layout["factored"],
+            "note": "identical Philox streams on both sides; they differ in libm vs device elementary functions (<= 2 ulp) and in "
+                    "reduction shape.  A slot's stratified target lands within rounding distance of a cumulative weight about once per "
+                    "1e9 particle-steps; two free-running systems then differ from that step on by Monte-Carlo noise of the estimator "
+                    "(loglik_sd_of_the_estimator_across_streams; free_running_* fields) -- or not at all on a series whose weights "
+                    "are all 1 - O(1e-9).  loglik_rmse_vs_cpu_same_seeds is against the oracle that follows the device through "
+                    "those ties and is held to the fp64 bar on every pair; loglik_rmse_free_running_oracle leaves the oracle alone"}
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -373,9 +472,14 @@ def main():
     ap.add_argument("--no-post-correct", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--accuracy-pairs", type=int, default=64, help="(seed, slot) pairs of the timed plan the oracle re-runs (64 = all of two passes)")
+    ap.add_argument("--series", choices=["informative", "model"], default="informative",
+                    help="the observed series of the metric model: counts that stay informative (default), or simulated from the "
+                         "model itself (rounds 1-3: its integrated-random-walk level drifts off, 98 %% zeros, weights ~ 1)")
     ap.add_argument("--reference-weights-layout", action="store_true",
                     help="keep the weights output as exp(w - max_t) (what the drop-in entry points return) instead of the factored layout")
     ap.add_argument("--no-mng", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the reference-layout / other-series runs of the same batch")
     ap.add_argument("--no-clock", action="store_true", help="skip the rocm-smi clock / power samples under load")
     ap.add_argument("--pc-draws", type=int, default=2340, help="retained draws of the post_correct job (C5: 2340)")
     args = ap.parse_args()
@@ -424,10 +528,15 @@ def main():
                 "world_size": dist.get_world_size(), "distinct_gpus": len(set(ids))}
 
     from bssm_amd.plan import FilterPlan
-    from models_zoo import negbin_m4
+    from models_zoo import negbin_m4, negbin_m4_informative
 
     N, T, m = args.particles, args.T, 4
-    model = negbin_m4(T, seed=103)
+    # The metric model on counts that stay informative (default since round 4), or on a series simulated
+    # from the model itself -- rounds 1-3: the model's level is an integrated random walk, on seed 103 the signal sits at
+    # -15 ... -38 after ~100 steps, 98 % of the counts are 0, every weight is 1 - O(1e-9) and resampling is the identity map.
+    # Same matrices, same kernel, same bytes; what differs is what the ancestor search and the gathers see.
+    make_model = negbin_m4_informative if args.series == "informative" else negbin_m4
+    model = make_model(T, seed=103)
     R = args.replicas
     # weights kept in the library's factored layout (opt-in for device-resident callers, include/bssm_amd.h
     # BSSM_PLAN_FACTORED_WEIGHTS: block-scaled weight x one factor per (time point, particle block); bssm_plan_fetch multiplies
@@ -470,8 +579,13 @@ def main():
         "dtype": "f64", "data": "synthetic", "rccl_ranks": comm["ranks"] if comm["backend"] == "rccl" else 0, "communicator": comm,
         "config": {"workload": "C2-m4: ssm_ung negative binomial, m=k=4, T=%d, N=%d, full-output bootstrap filter "
                                "(alpha, indices, weights kept in HBM); one step = %d independent filter calls "
-                               "(different Philox streams) advanced together; --gpus N = the same batch on each GPU" % (T, N, R),
-                   "filters_in_flight": R, "weights_layout": ("factored: exp(w - max_block) written once + exp(max_block - max_t) per (t, block of %d)"
+                               "(different Philox streams) advanced together; --gpus N = the same batch on each GPU; "
+                               "observed series: %s; weights layout of `value`: %s" % (T, N, R,
+                               "informative counts (ESS ~0.76 N, every step resamples for real)" if args.series == "informative"
+                               else "simulated from the model (98 % zeros, weights ~ 1, resampling ~ identity)",
+                               "factored (library layout, opt-in for device-resident plans); the reference's exp(w - max_t) layout "
+                               "is timed beside it as roofline_reference_layout" if fw else "reference: exp(w - max_t)"),
+                   "series": args.series, "filters_in_flight": R, "weights_layout": ("factored: exp(w - max_block) written once + exp(max_block - max_t) per (t, block of %d)"
                                                                % layout["block_particles"]) if layout["factored"] else "reference: exp(w - max_t)",
                    "kernel_shape": info["path"], "blocks_per_launch": info["blocks"],
                    "threads": info["threads"], "launches_per_step": T + 3, "parallelism": "replicas only x%d" % world},
@@ -504,6 +618,32 @@ def main():
             out["roofline"]["valu"] = valu_roofline(HEAD_VALU_PER_PSTEP, seqs * (R // seqs) * float(N) / (k_ms * 1e-3),
                                                     "pf_grid_step_v2<4,4,4,false,true,true>", ck) if ppt == 4 and m == 4 and layout["factored"] else None
     plan.close()
+
+    def side_run(mdl, factored):
+        """the same batch on another (series, weights layout): a short timed run + the kernel's launch duration"""
+        pl = FilterPlan(mdl, N, method="bsf", keep_history=True, force="grid", n_rep=R, factored_weights=factored)
+        pl.run(999, stream0=0, hip_stream=stream); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for q in range(5):
+            pl.run(50 + q, stream0=0, hip_stream=stream)
+        torch.cuda.synchronize()
+        e = (time.perf_counter() - t1) / 5
+        kms, _ = pl.time_kernel(77, sample_every=16, hip_stream=stream)
+        sq = max(1, pl.launch_sequences())
+        ach = sq * (float(R) / sq * N * pl.info()["bytes_per_particle_step"]) / (kms * 1e-3) / 1e9
+        res = {"value": float(N) * T * R / e, "unit": "particle-steps/s", "ms_per_step": e * 1e3, "steps": 5, "kernel": FilterPlan.last_kernel(),
+               "avg_launch_us": kms * 1e3, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "frac_by_wall_clock": float(N) * T * R / e * 88.0 / 8e12,
+               "weights_layout_factored": pl.weights_layout()["factored"]}
+        pl.close()
+        return res
+
+    if rank == 0 and world == 1 and not args.no_side_runs:
+        if fw:   # the layout the drop-in entry points return, next to the factored one `value` is quoted on
+            out["roofline_reference_layout"] = side_run(model, False)
+        other = negbin_m4 if args.series == "informative" else negbin_m4_informative
+        out["other_series"] = {"series": "model" if args.series == "informative" else "informative", **side_run(other(T, seed=103), fw),
+                               "note": "the same model matrices and plan on the other observed series (see config.workload); rounds 1-3 "
+                                       "quoted `value` on the model-simulated series"}
 
     if rank == 0 and world == 1 and R != 1 and not args.no_single:
         # ---- regime A (SURVEY.md 8d): ONE filter, latency-bound (1000 dependent launches, one wave per SIMD)
@@ -581,7 +721,7 @@ def main():
         from bssm_amd import models as M
         from oracle import oracle as O
         Ts = T  # the whole single-filter workload: ~10 s of one core
-        sample = negbin_m4(Ts, seed=103)
+        sample = make_model(Ts, seed=103)
         arr = M.model_arrays(sample)
         O.bsf_filter(arr, 1024, seed=1)  # warm
         t0 = time.perf_counter()
@@ -592,61 +732,7 @@ def main():
                                          "intra-filter parallelism), gcc -O2, %.1f s" % (N, Ts, ec)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_accuracy:
-        # ---- the metric's second half: log-likelihood RMSE against the reference-equivalent CPU path on identical seeds,
-        # on the very variant that was timed: the same plan shape (N, T, R filters in flight, two launch sequences), two more
-        # passes with fresh seeds = 2 R (seed, batch slot) pairs on the device; the oracle re-runs a SAMPLE of them -- the first
-        # and last filter of each launch sequence, both passes -- one full filter (N x T, ~8 s of one core) per host thread
-        from concurrent.futures import ThreadPoolExecutor
-        from bssm_amd import models as M
-        from oracle import oracle as O
-        arr = M.model_arrays(model)
-        pa = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R, factored_weights=fw)
-        acc_seeds = (20011, 20012)
-        slots = sorted(set([0, max(0, R // 2 - 1), R // 2, R - 1]))
-        gpu_ll, gpu_w, gpu_ix = {}, {}, {}
-        for sd in acc_seeds:
-            pa.run(sd, stream0=0, hip_stream=stream)
-            llv = pa.loglik(stream)
-            for f in slots:
-                gpu_ll[(sd, f)] = float(llv[f])
-                got = pa.fetch(f, hip_stream=stream, alpha=True, indices=True, weights=True)
-                gpu_ix[(sd, f)] = got["indices"]
-                w = got["weights"][:T]
-                wn = w / w.sum(axis=1, keepdims=True)
-                gpu_w[(sd, f)] = np.einsum("tmn,tn->tm", got["alpha"][:T], wn)  # weighted filtered state means, T x m
-        acc_kernel, acc_seqs, acc_layout = FilterPlan.last_kernel(), pa.launch_sequences(), pa.weights_layout()
-        pa.close()
-
-        def one(key):
-            sd, f = key
-            ref = O.bsf_filter(arr, N, seed=sd, stream=f)
-            w = ref["weights"][:, :T]
-            att = np.einsum("mtn,nt->tm", ref["alpha"][:, :T, :], w / w.sum(axis=0))
-            return key, float(ref["logLik"]), att, bool(np.array_equal(gpu_ix[key].T, ref["indices"]))
-
-        keys = sorted(gpu_ll)
-        with ThreadPoolExecutor(max_workers=min(len(keys), max(1, (os.cpu_count() or 1) // 2))) as ex:
-            refs = list(ex.map(one, keys))
-        # A last-ulp difference in one CDF entry moves one ancestor (about 1e-8 per particle-step at N = 65 536: the CDF of
-        # 65 536 terms carries ~1e-13 of rounding, the strata are 1.5e-5 wide), after which the two sides are different, equally
-        # valid particle systems whose log-likelihoods differ by Monte-Carlo noise of one particle (~1e-6 relative).  Both are
-        # reported: every checked pair, and the pairs whose ancestor tables are identical over all T steps.
-        flipped = [list(k) for k, _, _, same in refs if not same]
-        d_all = np.asarray([gpu_ll[k] - c for k, c, _, _ in refs])
-        kept = [r for r in refs if r[3]]
-        d = np.asarray([gpu_ll[k] - c for k, c, _, _ in kept]) if kept else d_all
-        dm = max(float(np.max(np.abs(gpu_w[k] - att) / (1.0 + np.abs(att)))) for k, _, att, _ in (kept or refs))
-        out["accuracy"] = {"loglik_rmse_vs_cpu_same_seeds": float(np.sqrt(np.mean(d_all * d_all))), "max_abs_diff": float(np.max(np.abs(d_all))),
-                           "loglik_rmse_pairs_with_identical_ancestor_tables": float(np.sqrt(np.mean(d * d))) if kept else None,
-                           "weighted_state_means_max_rel_diff_identical_tables": dm,
-                           "ancestor_tables_identical": len(refs) - len(flipped), "pairs_with_an_ancestor_flip": flipped,
-                           "device_pairs": len(acc_seeds) * R, "oracle_checked_pairs": len(keys), "checked_slots": slots, "seeds": list(acc_seeds),
-                           "N": N, "T": T, "m": m, "filters_in_flight": R, "kernel": acc_kernel, "launch_sequences": acc_seqs, "weights_layout_factored": acc_layout["factored"],
-                           "note": "the timed variant itself: same plan shape, (seed, batch slot) pairs; the oracle re-runs the first and last "
-                                   "filter of each launch sequence of both passes (one N x T filter each).  Identical Philox streams on both "
-                                   "sides; differences come from libm vs device elementary functions and reduction shape; a last-ulp "
-                                   "difference in a CDF entry can move one ancestor (about one per filter at this size), after which the "
-                                   "log-likelihoods differ by one particle's Monte-Carlo noise: both RMSEs are given"}
+        out["accuracy"] = accuracy_leg(model, N, T, R, m, fw, stream, args.accuracy_pairs)
 
     if rank == 0 and not args.no_dropin:
         # ---- the drop-in boundary as R sees it: host buffers in, host buffers out (PCIe-inclusive; never `value`).
@@ -693,6 +779,21 @@ def main():
             pc8 = {"error": repr(e)[:200]}
         if rank == 0:
             out["post_correct_large"] = pc8
+            # the strong-scaling evidence of the path that shards (north_star: "near-linear post_correct scaling to 8 GPUs"),
+            # at the top level: the whole job's wall time at this N against the one-GPU time of the SAME job (measured in this
+            # run when N = 1; otherwise the figure stored by the round's one-GPU run, profiles/r04_post_correct_n1.json)
+            try:
+                n1 = json.load(open(os.path.join(ROOT, "profiles", "r04_post_correct_n1.json")))
+            except (OSError, ValueError):
+                n1 = {}
+            sc = {"scaling": "strong", "n_gpus": world, "rccl_ranks": comm["ranks"] if comm["backend"] == "rccl" else 0,
+                  "distinct_gpus": comm["distinct_gpus"], "n1_source": "this run" if world == 1 else "profiles/r04_post_correct_n1.json (one MI355X, same job)"}
+            for key, obj, name in (("C5", pc, "post_correct"), ("C5_x8_draws", pc8, "post_correct_large")):
+                if isinstance(obj, dict) and "seconds" in obj:
+                    base = obj["seconds"] if world == 1 else n1.get(name, {}).get("seconds")
+                    sc[key] = {"seconds": obj["seconds"], "seconds_n1": base, "speedup_vs_n1": (base / obj["seconds"]) if base else None,
+                               "particle_steps_per_s": obj["value"]}
+            out["post_correct_scaling"] = sc
         if rank == 0 and world == 1:
             try:
                 out["post_correct_single_process"] = single_process_multi_device(8 * args.pc_draws)

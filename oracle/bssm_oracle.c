@@ -225,6 +225,41 @@ void orc_stratified_sample(double *p, const double *r, unsigned N, unsigned *out
   orc_stratified_sample_n(p, N, r, N, out);
 }
 
+/* ---- tie-following (test instrument for full-size parity; NOT part of the reference's algorithm) ----
+ * At N = 65 536 a slot's target (r_j + j) / N lands within rounding distance of a cumulative-sum entry about once per
+ * 10^9 particle-steps; the other implementation under test (different summation order, different last bits in exp / log)
+ * may then pick the neighbouring ancestor, after which two free-running systems are different, equally valid particle
+ * systems.  With a follow table installed, every filter of this file still resamples exactly as the reference does
+ * (stratified_sample.cpp:9-28) and compares its ancestors with the table's: an entry that differs is ADOPTED iff it is the
+ * adjacent particle AND the slot's target lies within `tol` strata of the cumulative-sum entry that separates the two
+ * (an "explained tie": either answer is a correctly rounded evaluation of the same comparison); anything else is counted
+ * as unexplained and NOT adopted, so the run diverges and the caller's comparison fails.  The caller then holds the
+ * reference recursion along the very path the device took and can compare everything strictly. */
+static _Thread_local orc_follow *g_follow = 0;
+void orc_follow_begin(orc_follow *f) { f->ties = 0; f->unexplained = 0; f->max_margin = 0.0; f->first_tie_t = -1; f->first_tie_slot = -1; g_follow = f; }
+void orc_follow_end(void) { g_follow = 0; }
+
+static void filter_resample(double *nw, const double *r, unsigned N, unsigned *out, int t) {
+  orc_stratified_sample(nw, r, N, out); /* nw now holds its cumulative sum */
+  orc_follow *f = g_follow;
+  if (!f) return;
+  const unsigned *want = f->table + (size_t)N * t;
+  for (unsigned j = 0; j < N; j++) {
+    if (out[j] == want[j]) continue;
+    unsigned a = out[j], b = want[j];
+    unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+    double margin = fabs((r[j] + j) / N - nw[lo]) * N; /* in strata (1 / N) */
+    if (hi - lo == 1 && margin <= f->tol) {
+      if (f->ties == 0) { f->first_tie_t = t; f->first_tie_slot = (int)j; }
+      f->ties++;
+      if (margin > f->max_margin) f->max_margin = margin;
+      out[j] = b;
+    } else {
+      f->unexplained++;
+    }
+  }
+}
+
 /* shared tail of every filter step: model_ssm_ung.cpp:634-647 / 672-687.
  * logw holds N log-weights; on return wcol = exp(logw - max), nw = normalised.
  * returns 0 on degeneracy. */
@@ -276,7 +311,7 @@ double orc_ung_bsf_filter(const orc_ung_model *mod, unsigned N, const orc_rng *r
   }
   for (int t = 0; t < n; t++) {
     for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0); /* :650-653 */
-    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);                 /* :655 */
+    filter_resample(nw, r, N, indices + (size_t)N * t, t);                 /* :655 */
     for (unsigned i = 0; i < N; i++)                                          /* :659-661 */
       for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     const double *Tt = mod->T + (size_t)m * m * (t * mod->Ttv);
@@ -744,7 +779,7 @@ double orc_ung_psi_filter(const orc_ung_model *mod, const orc_psi_setup *su, uns
   }
   for (int t = 0; t < n; t++) {
     for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
-    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++)
       for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     const double *ah0 = su->alphahat + (size_t)m * t, *ah1 = su->alphahat + (size_t)m * (t + 1);
@@ -1019,7 +1054,7 @@ static double mng_filter_core(const orc_mng_model *mod, const orc_mng_setup *su,
   }
   for (int t = 0; t < n; t++) {
     for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
-    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++)
       for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     const double *Tt = mod->T + (size_t)mm * (t * mod->Ttv), *Rt = mod->R + (size_t)m * mod->k * (t * mod->Rtv);
@@ -1447,7 +1482,7 @@ double orc_fn_bsf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rng
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
     for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
-    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     for (unsigned i = 0; i < N; i++) {
       if (sde) A_(0, t + 1, i) = fn_milstein(mod, rng, 4, t, i, atmp[i]); /* :59-62 */
@@ -1497,7 +1532,7 @@ double orc_nlg_general_bsf_filter(const orc_nlg_general *mod, unsigned N, const 
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
     for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
-    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     for (unsigned i = 0; i < N; i++) { /* :1118-1126: T_fn and R_fn at the ancestor */
       rng_normals(rng, 2, t, i, k, um);
@@ -1656,7 +1691,7 @@ double orc_fn_ekpf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rn
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
     for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
-    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) {                        /* :1212-1227 */
       double at[2], Ptt[4];
       for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
@@ -1918,7 +1953,7 @@ double orc_fn_psi_filter(const orc_fn_model *mod, const orc_fn_setup *su, unsign
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
     for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
-    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     const double *ah0 = su->alphahat + (size_t)m * t, *ah1 = su->alphahat + (size_t)m * (t + 1);
     const double *Ct1 = su->Ct + (size_t)mm * (t + 1), *Vt1 = su->Vt + (size_t)mm * (t + 1);
@@ -2189,7 +2224,7 @@ double orc_nlg_general_psi_filter(const orc_nlg_general_psi *mod, const orc_nlg_
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
     for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
-    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     const double *ah0 = su->alphahat + (size_t)m * t, *ah1 = su->alphahat + (size_t)m * (t + 1);
     const double *Ct1 = su->Ct + (size_t)mm * (t + 1), *Vt1 = su->Vt + (size_t)mm * (t + 1);
@@ -2263,7 +2298,7 @@ double orc_nlg_general_ekpf_filter(const orc_nlg_general_psi *mod, unsigned N, c
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
     for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
-    orc_stratified_sample(nw, r, N, indices + (size_t)N * t);
+    filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) { /* :1212-1227 */
       double at[ORC_MAXM], Rt[ORC_MAXM * ORC_MAXM], Pt[ORC_MAXM * ORC_MAXM], Ptt[ORC_MAXM * ORC_MAXM];
       for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);

@@ -49,6 +49,50 @@ class OrcIsJob(C.Structure):
                 ("output_type", C.c_int), ("nsim", C.c_uint), ("seed", C.c_uint32), ("n_threads", C.c_int)]
 
 
+class OrcFollow(C.Structure):
+    _fields_ = [("table", c_uint_p), ("tol", C.c_double), ("ties", C.c_uint), ("unexplained", C.c_uint),
+                ("max_margin", C.c_double), ("first_tie_t", C.c_int), ("first_tie_slot", C.c_int)]
+
+
+def tie_tolerance(N: int) -> float:
+    """In strata (1 / N): twice the worst-case rounding error of a sequential sum of N terms in (0, 1], (N - 1) 2^-53,
+    seen from the top stratum (x N) -- what two correctly rounded evaluations of the reference's cumulative sum may differ
+    by.  N = 65 536: 9.5e-7 of a stratum; measured margins at that size: 3e-10 ... 2.3e-8 (profiles/r04_flip_probe.json)."""
+    return max(2.0 * N * N * 2.0 ** -53, 1e-10)
+
+
+class following:
+    """with following(table, N) as f: ...  -- the filters called inside (on this thread) adopt `table`'s ancestor at
+    explained ties (bssm_oracle.c, "tie-following"); afterwards f.ties, f.unexplained, f.max_margin, f.first_tie.
+    table: (n, N) C-contiguous uint32 (the device's layout) or (N, n) Fortran-ordered (the oracle's) -- the same bytes."""
+
+    def __init__(self, table, N, tol=None):
+        t = np.asarray(table, dtype=np.uint32)
+        assert t.ndim == 2 and N in t.shape, t.shape
+        if t.shape[0] == N and t.shape[1] != N:      # the oracle's N x n: wanted column-major
+            t = np.asfortranarray(t)
+        else:                                         # the device's n x N: wanted row-major (the same bytes)
+            t = np.ascontiguousarray(t)
+        self._table = t
+        self._f = OrcFollow()
+        self._f.table = self._table.ctypes.data_as(c_uint_p)
+        self._f.tol = tie_tolerance(N) if tol is None else tol
+
+    def __enter__(self):
+        lib().orc_follow_begin(C.byref(self._f))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_follow_end()
+        return False
+
+    ties = property(lambda self: int(self._f.ties))
+    unexplained = property(lambda self: int(self._f.unexplained))
+    max_margin = property(lambda self: float(self._f.max_margin))
+    first_tie = property(lambda self: (int(self._f.first_tie_t), int(self._f.first_tie_slot)))
+    tol = property(lambda self: float(self._f.tol))
+
+
 _lib = None
 
 

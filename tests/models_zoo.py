@@ -42,6 +42,28 @@ def negbin_m4(n=1000, seed=103, phi=5.0):
     return M.ssm_ung(y, Z=Z, T=T, R=R, a1=a1, P1=P1, distribution="negative binomial", phi=phi)
 
 
+def negbin_m4_informative(n=1000, seed=103, phi=5.0):
+    """The metric model (same T, R, Z, a1, P1, phi as negbin_m4) on a series whose counts stay informative.
+
+    negbin_m4 simulates y from the model itself, and the model's level is an integrated random walk: on seed 103 the signal
+    leaves the range of counts after ~100 steps (-15 ... -38, clipped at -20), 98 % of the y are 0, every weight is
+    1 - O(1e-9) and stratified resampling is the identity map.  Here y follows a bounded signal the same model can track
+    (a slow cycle between log-means 0.5 and 2.5 plus the model's two AR components), so the weights spread over orders of
+    magnitude and every step resamples for real (ancestors with 0, 1, 2, ... children)."""
+    rng = np.random.default_rng(seed)
+    base = negbin_m4(8, seed=seed, phi=phi)     # the model matrices
+    a3, a4 = 0.0, 0.0
+    y = np.zeros(n)
+    for t in range(n):
+        s = 1.5 + np.sin(2 * np.pi * t / 250.0) + a3 + a4
+        y[t] = rng.negative_binomial(phi, phi / (phi + np.exp(s)))
+        a3 = 0.9 * a3 + 0.2 * rng.normal()
+        a4 = 0.5 * a4 + 0.3 * rng.normal()
+    arr = M.model_arrays(base)
+    return M.ssm_ung(y, Z=np.array([1.0, 0, 1, 1]), T=np.asarray(arr["T"]).reshape(4, 4, order="F"), R=np.asarray(arr["R"]).reshape(4, 4, order="F"),
+                     a1=np.array([1.0, 0, 0, 0]), P1=np.diag([1, 0.01, 0.21, 0.12]), distribution="negative binomial", phi=phi)
+
+
 def small_zoo():
     """Small models covering every distribution, missing values, time-varying matrices, xreg."""
     rng = np.random.default_rng(7)

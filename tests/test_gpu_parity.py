@@ -11,7 +11,7 @@ import pytest
 
 from bssm_amd import filters as F
 from bssm_amd import models as M
-from models_zoo import negbin_ar1, negbin_m4, small_zoo
+from models_zoo import negbin_ar1, negbin_m4, negbin_m4_informative, small_zoo
 
 pytestmark = pytest.mark.gpu
 
@@ -136,70 +136,78 @@ def test_large_filter_grid_vs_wg_agree():
     assert abs(outs["wg"]["logLik"] - outs["grid"]["logLik"]) <= 1e-9 * 120
 
 
+def _follow(oracle, table, N, run):
+    """the oracle filter `run` with the device's ancestor table installed (oracle.following: explained last-ulp ties are
+    adopted, anything else is counted and left alone) -> (reference outputs, tie statistics)"""
+    with oracle.following(table, N) as f:
+        ref = run()
+    return ref, f
+
+
+def _compare_full_size(out, ref, f, n, alpha_t_major=True, max_ties=8):
+    """Device vs oracle at a BASELINE configuration's full size, STRICT everywhere.
+
+    At N = 65 536 a slot's stratified target lands within rounding distance of a cumulative-weight entry about once per
+    1e9 particle-steps, and the two implementations (different summation order, <= 2 ulp apart in exp / log) may then pick
+    adjacent ancestors.  Two free-running systems differ from there on -- by Monte-Carlo noise where the observations are
+    informative (round 4 measured 1 -> 2526 -> 56 114 -> 64 493 differing ancestors over the next three steps and
+    |dlogLik| = 0.196), not at all where every weight is 1 (profiles/r04_flip_probe.json).  So the oracle FOLLOWS the
+    device through such ties (bssm_oracle.c "tie-following"): a differing entry is adopted only when it is the adjacent
+    particle and the target lies within oracle.tie_tolerance(N) strata (N = 65 536: 9.5e-7 of a stratum) of the entry
+    between the two.  After that the oracle is the reference recursion along the device's own path, and EVERYTHING must
+    agree at the fp64 bar: ancestors identical, |dlogLik| <= 1e-9 n, states 1e-9, weights 1e-8 -- whether or not a tie
+    occurred."""
+    assert f.unexplained == 0, f"{f.unexplained} ancestor differences that are not last-ulp ties (first tie {f.first_tie})"
+    assert f.ties <= max_ties, f"{f.ties} ties (max margin {f.max_margin:.3g} strata)"
+    assert np.array_equal(out["indices"], ref["indices"])
+    ga = out["alpha"] if alpha_t_major else np.transpose(out["alpha"], (1, 0, 2))   # -> (t, m, N)
+    ra = np.transpose(ref["alpha"], (1, 0, 2))                                      # oracle: m x (n+1) x N
+    T1 = min(ga.shape[0], ra.shape[0])
+    scale = max(1.0, float(np.abs(ra).max()))
+    assert np.max(np.abs(ga[:T1] - ra[:T1])) <= 1e-9 * scale
+    assert np.allclose(out["weights"], ref["weights"], rtol=1e-8, atol=1e-13)
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    return f.ties
+
+
 def test_full_size_c2_m4_against_oracle(oracle):
     """BASELINE metric config at reduced T: ssm_ung negbin m=4, N=65536 (grid kernel), T=60."""
     model = negbin_m4(60, seed=103)
     out = F.bootstrap_filter(model, 65536, seed=1, return_indices=True)
-    ref = oracle.bsf_filter(M.model_arrays(model), 65536, seed=1)
-    same = np.array_equal(out["indices"], ref["indices"])
-    frac = np.mean(out["indices"] != ref["indices"])
-    assert same or frac < 1e-6, f"ancestor mismatch fraction {frac}"
-    assert abs(out["logLik"] - ref["logLik"]) <= (1e-9 if same else 1e-4) * 60
+    ref, f = _follow(oracle, out["indices"], 65536, lambda: oracle.bsf_filter(M.model_arrays(model), 65536, seed=1))
+    _compare_full_size(out, ref, f, 60, max_ties=1)
 
 
-def _first_divergence(a, b):
-    """first time column at which two ancestor tables differ (n when they never do)"""
-    bad = np.flatnonzero((a != b).any(axis=0))
-    return int(bad[0]) if bad.size else a.shape[1]
-
-
-def _compare_full_size(out, ref, n, alpha_t_major):
-    """Device vs oracle at a BASELINE configuration's full size.  On identical ancestor tables everything is compared at
-    the fp64 parity bar.  A last-ulp difference in one CDF entry can flip one ancestor (about 1e-11 per particle-step,
-    DESIGN.md section 2); from that step on the two particle systems are different (equally valid) systems, so after a
-    flip the strict comparison covers the steps before it and the log-likelihoods must agree within Monte-Carlo error."""
-    t_div = _first_divergence(out["indices"], ref["indices"])
-    assert t_div >= min(n, 50), f"ancestors diverge at step {t_div}"
-    ga = out["alpha"] if alpha_t_major else np.transpose(out["alpha"], (1, 0, 2))   # -> (t, m, N)
-    ra = np.transpose(ref["alpha"], (1, 0, 2))                                      # oracle: m x (n+1) x N
-    T1 = t_div + 1
-    scale = max(1.0, float(np.abs(ra[:T1]).max()))
-    assert np.max(np.abs(ga[:T1] - ra[:T1])) <= 1e-9 * scale
-    assert np.allclose(out["weights"][:, :T1], ref["weights"][:, :T1], rtol=1e-8, atol=1e-13)
-    if t_div == n:
-        assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
-    else:
-        assert abs(out["logLik"] - ref["logLik"]) <= 0.5
-    return t_div
-
-
-def test_metric_config_full_size_against_oracle(oracle):
+@pytest.mark.parametrize("series", ["model", "informative"])
+def test_metric_config_full_size_against_oracle(oracle, series):
     """BASELINE metric config at its full size: ssm_ung negbin m = 4, N = 65 536, T = 1000 (8 s of oracle): ancestor table,
-    particle history, weights and log-likelihood of the device bootstrap filter against the CPU oracle on the same seed"""
+    particle history, weights, log-likelihood and weighted filtered means of the device bootstrap filter against the CPU
+    oracle on the same seed.  `model`: y simulated from the model itself (its integrated-random-walk level leaves the range
+    of counts: 98 % zeros, weights 1 - O(1e-9)); `informative`: the same model on counts that stay informative (bench.py's
+    headline series since round 4)."""
     n = 1000
-    model = negbin_m4(n, seed=103)
+    model = (negbin_m4 if series == "model" else negbin_m4_informative)(n, seed=103)
     out = F.bootstrap_filter(model, 65536, seed=1, return_indices=True)
-    ref = oracle.bsf_filter(M.model_arrays(model), 65536, seed=1)
-    t_div = _compare_full_size(out, ref, n, alpha_t_major=True)
-    # weighted filtered means (north_star: "log-likelihood and weighted state means") up to the divergence point
-    T1 = min(t_div + 1, n)
-    w = ref["weights"][:, :T1]
-    att_ref = np.einsum("mtn,nt->tm", ref["alpha"][:, :T1, :], w / w.sum(axis=0))
-    assert np.allclose(out["att"][:T1], att_ref, rtol=1e-8, atol=1e-10)
+    ref, f = _follow(oracle, out["indices"], 65536, lambda: oracle.bsf_filter(M.model_arrays(model), 65536, seed=1))
+    _compare_full_size(out, ref, f, n)
+    # weighted filtered means (north_star: "log-likelihood and weighted state means"), every time point
+    w = ref["weights"][:, :n]
+    att_ref = np.einsum("mtn,nt->tm", ref["alpha"][:, :n, :], w / w.sum(axis=0))
+    assert np.allclose(out["att"][:n], att_ref, rtol=1e-8, atol=1e-10)
 
 
 @pytest.mark.parametrize("factored", [False, True])
 def test_bench_plan_variant_against_oracle(oracle, factored):
-    """The exact thing bench.py times, compared with the oracle as such: FilterPlan(negbin_m4, N = 65 536, full output,
-    grid shape, 32 filters in flight) -> pf_grid_step_v2<4,4,4,false,true,true> (four particles per lane, weights exchange,
-    no tail guards), stepped as TWO interleaved launch sequences of 16 filters.  Filters 0 / 15 (first and last of the
-    sequence on the caller's stream) and 16 / 31 (first and last of the side-stream sequence): ancestors, particle history,
-    weights and log-likelihood against orc_ung_bsf_filter on the same (seed, stream).
-    factored: the opt-in weights layout bench.py runs with (BSSM_PLAN_FACTORED_WEIGHTS: block-scaled weights written once +
-    one factor per (time point, particle block)); fetch() multiplies it out, and the result must meet the same bar."""
+    """The exact thing bench.py times, compared with the oracle as such: FilterPlan(metric model on the informative
+    series, N = 65 536, full output, grid shape, 32 filters in flight) -> pf_grid_step_v2<4,4,4,false,true,true> (four
+    particles per lane, weights exchange, no tail guards), stepped as TWO interleaved launch sequences of 16 filters.
+    Filters 0 / 15 (first and last of the sequence on the caller's stream) and 16 / 31 (first and last of the side-stream
+    sequence): ancestors, particle history, weights and log-likelihood against orc_ung_bsf_filter on the same (seed, stream).
+    factored: the opt-in weights layout (BSSM_PLAN_FACTORED_WEIGHTS: block-scaled weights written once + one factor per
+    (time point, particle block)); fetch() multiplies it out, and the result must meet the same bar."""
     from bssm_amd.plan import FilterPlan
     n, N, R, seed, s0 = 120, 65536, 32, 9, 64
-    model = negbin_m4(n, seed=103)
+    model = negbin_m4_informative(n, seed=103)
     plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R, factored_weights=factored)
     plan.run(seed, stream0=s0)
     ll = plan.loglik()
@@ -212,9 +220,9 @@ def test_bench_plan_variant_against_oracle(oracle, factored):
     arr = M.model_arrays(model)
     for f in (0, 15, 16, 31):
         got = plan.fetch(f)
-        ref = oracle.bsf_filter(arr, N, seed=seed, stream=s0 + f)
+        ref, fl = _follow(oracle, got["indices"], N, lambda: oracle.bsf_filter(arr, N, seed=seed, stream=s0 + f))
         out = dict(indices=got["indices"].T, alpha=got["alpha"], weights=got["weights"].T, logLik=ll[f])
-        _compare_full_size(out, ref, n, alpha_t_major=True)  # (tolerates a last-ulp ancestor flip after step 50, probability ~1e-4)
+        _compare_full_size(out, ref, fl, n, max_ties=2)
     plan.close()
 
 
@@ -224,19 +232,16 @@ def test_c3_full_size_against_oracle(oracle):
     model = M.svm(y, rho=M.uniform(0.98, -0.999, 0.999), sd_ar=M.halfnormal(0.2, 5), sigma=M.halfnormal(1.0, 2))
     n, N = y.size, 32768
     out = F.particle_smoother(model, N, method="psi", seed=11, return_indices=True)
-    ref = oracle.psi_filter(M.model_arrays(model), N, seed=11)
-    t_div = _first_divergence(out["indices"], ref["indices"])
-    assert t_div >= 50, f"ancestors diverge at step {t_div}"
-    assert np.allclose(out["weights"][:, :t_div + 1], ref["weights"][:, :t_div + 1], rtol=1e-8, atol=1e-13)
-    if t_div == n:
-        assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
-        sm = oracle.filter_smoother(ref["alpha"], ref["indices"])      # m x (n+1) x N back-traced
-        mean, cov = oracle.summary(sm)
-        assert _rel(np.transpose(out["alpha"], (1, 0, 2)), sm[:, :n, :]) <= 1e-8
-        assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8
-        assert _rel(out["Vt"], cov[:, :, :n]) <= 1e-7
-    else:
-        assert abs(out["logLik"] - ref["logLik"]) <= 0.5
+    ref, f = _follow(oracle, out["indices"], N, lambda: oracle.psi_filter(M.model_arrays(model), N, seed=11))
+    assert f.unexplained == 0 and f.ties <= 4, (f.ties, f.unexplained, f.max_margin)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert np.allclose(out["weights"], ref["weights"], rtol=1e-8, atol=1e-13)
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    sm = oracle.filter_smoother(ref["alpha"], ref["indices"])      # m x (n+1) x N back-traced
+    mean, cov = oracle.summary(sm)
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), sm[:, :n, :]) <= 1e-8
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8
+    assert _rel(out["Vt"], cov[:, :, :n]) <= 1e-7
 
 
 def test_c4_full_size_against_oracle(oracle):
@@ -250,8 +255,8 @@ def test_c4_full_size_against_oracle(oracle):
         out = F.bootstrap_filter(model, N, seed=4, return_indices=True)
     finally:
         del os.environ["BSSM_AMD_FORCE_PATH"]
-    ref = oracle.mng_bsf_filter(M.model_arrays(model), N, seed=4)
-    _compare_full_size(out, ref, n, alpha_t_major=True)
+    ref, f = _follow(oracle, out["indices"], N, lambda: oracle.mng_bsf_filter(M.model_arrays(model), N, seed=4))
+    _compare_full_size(out, ref, f, n, max_ties=4)
 
 
 def test_device_matches_committed_golden_vectors():

@@ -378,3 +378,31 @@ def test_general_nlg_bootstrap_equals_builtin_functor_path(oracle):
     arr = M.model_arrays(M.ssm_ulg(yl, Z=np.array([1.0, 0.0]), H=0.5, T=Tm, R=Rm, a1=np.array([0.0, 0.1]), P1=np.diag([1.0, 0.01])))
     exact = oracle.ulg_loglik(arr)
     assert abs(np.mean(lls) - exact) < 4 * np.std(lls) / np.sqrt(len(lls)) + 0.05
+
+
+def test_tie_following_adopts_only_explained_ties(oracle):
+    """oracle.following (the instrument behind the full-size GPU parity tests): following its own table changes nothing;
+    a table entry moved to the adjacent particle far from a tie is NOT adopted (counted as unexplained); with a tolerance
+    wide enough to call it a tie it is adopted and the run continues along that path (layouts N x n and n x N alike)."""
+    from bssm_amd import models as M
+    from models_zoo import negbin_m4_informative
+    arr = M.model_arrays(negbin_m4_informative(40))
+    N = 1024
+    base = oracle.bsf_filter(arr, N, seed=3)
+    with oracle.following(base["indices"], N) as f:
+        again = oracle.bsf_filter(arr, N, seed=3)
+    assert (f.ties, f.unexplained) == (0, 0) and again["logLik"] == base["logLik"]
+    assert np.array_equal(again["alpha"], base["alpha"])
+    moved = base["indices"].copy(order="F")
+    moved[100, 20] += 1
+    with oracle.following(moved, N) as f:
+        kept = oracle.bsf_filter(arr, N, seed=3)
+    assert (f.ties, f.unexplained) == (0, 1)
+    assert np.array_equal(kept["indices"], base["indices"]) and kept["logLik"] == base["logLik"]
+    assert f.tol == oracle.tie_tolerance(N) and 0 < f.tol < 1e-9
+    with oracle.following(np.ascontiguousarray(moved.T), N, tol=2.0) as f:     # the device's (n, N) layout
+        taken = oracle.bsf_filter(arr, N, seed=3)
+    assert f.ties >= 1 and f.first_tie == (20, 100) and taken["indices"][100, 20] == moved[100, 20]
+    assert taken["logLik"] != base["logLik"]
+    # outside the with-block nothing is followed
+    assert oracle.bsf_filter(arr, N, seed=3)["logLik"] == base["logLik"]
