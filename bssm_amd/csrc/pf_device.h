@@ -114,17 +114,40 @@ __device__ __forceinline__ double rng_uniform(RngKey k, uint32_t purpose, uint32
   return u53_to_double(w.x >> 5, w.y >> 6) * 0x1.0p-53;
 }
 
-// One Philox block serves a Box-Muller pair and leaves one word over:
-//   words 0,1 -> 53-bit radius uniform in (0,1];  word 2 -> 32-bit angle;  word 3 -> spare 32-bit uniform.
-// The block (particle i, step t, draw 0, RNG_TRANSITION) is the "step block": its spare word is the stratified
-// resampling uniform of output slot i at step t, its pair the first two transition normals of the same slot, so
-// a particle-step of a model with <= 2 noise terms costs a single Philox call.
+// Two block formats, chosen by the number of normals a draw needs (the oracle's rng_normals / orc_rng_uniform follow
+// the same rule, oracle/bssm_oracle.c):
+//   WIDE (a draw of <= 2 normals, and every pair drawn on its own -- the Milstein sub-steps): one block per pair,
+//     words 0,1 -> 53-bit radius uniform in (0,1];  word 2 -> 32-bit angle;  word 3 -> spare 32-bit uniform.
+//     The block (particle i, step t, draw 0, RNG_TRANSITION) is the "step block": its spare word is the stratified
+//     resampling uniform of output slot i at step t, its pair the transition normals of the same slot, so a particle-step
+//     of a model with <= 2 noise terms costs a single Philox call.
+//   PACKED (a draw of > 2 normals by a linear-state filter -- ssm_ung / ssm_mng / ssm_ulg families: bootstrap, psi-APF,
+//     simulation smoother; the functor-model filters keep WIDE blocks whatever the count; round 4): two pairs per block -- pair p comes from block (i, t, p >> 1, purpose), words
+//     (0,1) for even p and (2,3) for odd p: 40-bit radius uniform in (0,1] (first word, then the top 8 bits of the second;
+//     |z| <= 7.45) and 24-bit angle (the low 24 bits of the second word).  No word is left over, so the resampling uniforms
+//     of such a filter come from blocks of their own, shared by FOUR consecutive slots: slot i at step t takes word i & 3
+//     of block (i >> 2, t, 0, RNG_RESAMPLE).  A particle-step with four noise terms costs 1.25 Philox calls instead of 2,
+//     one with eight 2.25 instead of 4 (a lane that holds four consecutive slots for the search draws their uniforms at once).
 __device__ __forceinline__ u32x4 rng_step_block(RngKey k, uint32_t t, uint32_t i) {
   return philox4x32_10(i, t, 0u, RNG_TRANSITION, k.seed, k.stream);
 }
 __device__ __forceinline__ double block_uniform(const u32x4& w) { return (double)w.w * 0x1.0p-32; }  // [0,1)
-__device__ __forceinline__ double rng_resample_uniform(RngKey k, uint32_t t, uint32_t i) {
-  return block_uniform(rng_step_block(k, t, i));
+// the four resampling uniforms of slots 4 g ... 4 g + 3 at step t (filters whose step draw is PACKED)
+__device__ __forceinline__ u32x4 rng_resample_block(RngKey k, uint32_t t, uint32_t g) {
+  return philox4x32_10(g, t, 0u, RNG_RESAMPLE, k.seed, k.stream);
+}
+__device__ __forceinline__ uint32_t u32x4_word(const u32x4& w, uint32_t j) {
+  const uint32_t lo = (j & 1u) ? w.y : w.x, hi = (j & 1u) ? w.w : w.z;
+  return (j & 2u) ? hi : lo;
+}
+// resampling uniform word of slot i at step t for a filter whose step draw has CNT normals; blk0 = the slot's step block
+template <int CNT>
+__device__ __forceinline__ uint32_t rng_resample_word(RngKey k, uint32_t t, uint32_t i, const u32x4& blk0) {
+  if constexpr (CNT <= 2) return blk0.w;
+  else return u32x4_word(rng_resample_block(k, t, i >> 2), i & 3u);
+}
+__device__ __forceinline__ uint32_t rng_resample_word_rt(int cnt, RngKey k, uint32_t t, uint32_t i, const u32x4& blk0) {
+  return cnt <= 2 ? blk0.w : u32x4_word(rng_resample_block(k, t, i >> 2), i & 3u);
 }
 
 // sqrt for the Box-Muller radius argument x = -2 log(u) in [0, 74]: v_rsq_f64 seed, one coupled
@@ -144,7 +167,7 @@ __device__ __forceinline__ double sqrt_small(double x) {
 #endif
 }
 
-// Box-Muller pair from one Philox block
+// Box-Muller pair from one WIDE block
 __device__ __forceinline__ void box_muller(const u32x4& w, double& z0, double& z1) {
   // (0,1]: (hi27 * 2^26 + lo26 + 1) * 2^-53, every step exact (two conversions and two fused multiply-adds)
   const double u1 = __builtin_fma((double)(w.x >> 5), 0x1.0p-27, __builtin_fma((double)(w.y >> 6), 0x1.0p-53, 0x1.0p-53));
@@ -154,27 +177,64 @@ __device__ __forceinline__ void box_muller(const u32x4& w, double& z0, double& z
   z0 = rad * cs;
   z1 = rad * sn;
 }
+// Box-Muller pair from one half (two words) of a PACKED block
+__device__ __forceinline__ void box_muller_packed(const uint32_t a, const uint32_t b, double& z0, double& z1) {
+  // (0,1]: ((a << 8 | b >> 24) + 1) * 2^-40, exact
+  const double u1 = __builtin_fma((double)a, 0x1.0p-32, __builtin_fma((double)(b >> 24), 0x1.0p-40, 0x1.0p-40));
+  const double rad = sqrt_small(-2.0 * tl_log<false>(u1));
+  double sn, cs;
+  tl_sincos_2pi(b << 8, sn, cs);  // angle 2*pi*(b & 0xffffff)*2^-24
+  z0 = rad * cs;
+  z1 = rad * sn;
+}
 __device__ __forceinline__ void rng_normal_pair(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d,
                                                 double& z0, double& z1) {
   box_muller(philox4x32_10(i, t, d, purpose, k.seed, k.stream), z0, z1);
 }
 
-// CNT normals for (purpose, t, i): pair d comes from block (i, t, d, purpose); blk0 is block d = 0, already drawn
-template <int CNT>
+// CNT normals for (purpose, t, i); blk0 is block (i, t, 0, purpose), already drawn.  CNT <= 2: the WIDE pair of blk0;
+// CNT > 2: PACKED, pair p from half p & 1 of block p >> 1
+// PACK = false: one WIDE block per pair whatever the count (the functor-model filters: ssm_nlg, ssm_sde, EKF particle filter)
+template <int CNT, bool PACK = true>
 __device__ __forceinline__ void rng_normals_blk(const u32x4& blk0, RngKey k, uint32_t purpose, uint32_t t, uint32_t i,
                                                 double (&out)[CNT]) {
+  if constexpr (CNT <= 2 || !PACK) {
 #pragma unroll
-  for (int j = 0; j < CNT; j += 2) {
-    double z0, z1;
-    if (j == 0) box_muller(blk0, z0, z1);
-    else rng_normal_pair(k, purpose, t, i, (uint32_t)(j / 2), z0, z1);
-    out[j] = z0;
-    if (j + 1 < CNT) out[j + 1] = z1;
+    for (int j = 0; j < CNT; j += 2) {
+      double z0, z1;
+      if (j == 0) box_muller(blk0, z0, z1);
+      else rng_normal_pair(k, purpose, t, i, (uint32_t)(j / 2), z0, z1);
+      out[j] = z0;
+      if (j + 1 < CNT) out[j + 1] = z1;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < CNT; j += 4) {
+      const u32x4 w = j == 0 ? blk0 : philox4x32_10(i, t, (uint32_t)(j / 4), purpose, k.seed, k.stream);
+      double z0, z1;
+      box_muller_packed(w.x, w.y, z0, z1);
+      out[j] = z0;
+      if (j + 1 < CNT) out[j + 1] = z1;
+      if (j + 2 < CNT) {
+        box_muller_packed(w.z, w.w, z0, z1);
+        out[j + 2] = z0;
+        if (j + 3 < CNT) out[j + 3] = z1;
+      }
+    }
   }
 }
-template <int CNT>
+template <int CNT, bool PACK = true>
 __device__ __forceinline__ void rng_normals(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, double (&out)[CNT]) {
-  rng_normals_blk<CNT>(philox4x32_10(i, t, 0u, purpose, k.seed, k.stream), k, purpose, t, i, out);
+  rng_normals_blk<CNT, PACK>(philox4x32_10(i, t, 0u, purpose, k.seed, k.stream), k, purpose, t, i, out);
+}
+// the same rule for a count known only at run time (out has room for cnt rounded up to even)
+__device__ __forceinline__ void rng_normals_rt(RngKey k, uint32_t purpose, uint32_t t, uint32_t i, int cnt, double* out) {
+  if (cnt <= 2) { rng_normal_pair(k, purpose, t, i, 0u, out[0], out[1]); return; }
+  for (int j = 0; j < cnt; j += 4) {
+    const u32x4 w = philox4x32_10(i, t, (uint32_t)(j / 4), purpose, k.seed, k.stream);
+    box_muller_packed(w.x, w.y, out[j], out[j + 1]);
+    if (j + 2 < cnt) box_muller_packed(w.z, w.w, out[j + 2], out[j + 3]);
+  }
 }
 
 // ---------------------------------------------------------------- wavefront primitives (64 lanes)
@@ -231,6 +291,24 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 // sum over the wave in every lane (the last lane of the scan holds the total)
 __device__ __forceinline__ double wave_sum(double v) { return lane_broadcast(wave_scan_incl(v), 63); }
+
+// Resampling uniforms of a lane's FOUR rows (slots r * NT + tid, r = 0 ... 3; NT a multiple of 4) in a filter whose step
+// draw is PACKED: the four lanes of a quad hold four consecutive slots in every row, i.e. they need the same four
+// RNG_RESAMPLE blocks (one per row).  Lane q of the quad draws row q's block, and a 4 x 4 transpose inside the quad (DPP
+// quad_perm broadcasts + selects: 28 instructions instead of three more Philox blocks) hands every lane word (lane & 3) of
+// each row's block.  All four lanes of every quad must be active.
+template <int R>
+__device__ __forceinline__ uint32_t quad_bcast_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, R * 0x55, 0xf, 0xf, true);
+}
+__device__ __forceinline__ void rng_resample_words_quad4(RngKey k, uint32_t t, uint32_t NT, uint32_t tid, uint32_t (&uw)[4]) {
+  const uint32_t q = tid & 3u;
+  const u32x4 b = rng_resample_block(k, t, (q * NT + (tid & ~3u)) >> 2);
+  uw[0] = u32x4_word(u32x4{quad_bcast_u32<0>(b.x), quad_bcast_u32<0>(b.y), quad_bcast_u32<0>(b.z), quad_bcast_u32<0>(b.w)}, q);
+  uw[1] = u32x4_word(u32x4{quad_bcast_u32<1>(b.x), quad_bcast_u32<1>(b.y), quad_bcast_u32<1>(b.z), quad_bcast_u32<1>(b.w)}, q);
+  uw[2] = u32x4_word(u32x4{quad_bcast_u32<2>(b.x), quad_bcast_u32<2>(b.y), quad_bcast_u32<2>(b.z), quad_bcast_u32<2>(b.w)}, q);
+  uw[3] = u32x4_word(u32x4{quad_bcast_u32<3>(b.x), quad_bcast_u32<3>(b.y), quad_bcast_u32<3>(b.z), quad_bcast_u32<3>(b.w)}, q);
+}
 
 // ---------------------------------------------------------------- observation log-densities
 // Unnormalised log g(y_t | signal s), src/model_ssm_ung.cpp:447-493; gaussian:

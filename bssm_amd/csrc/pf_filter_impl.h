@@ -267,6 +267,12 @@ template <int MP> constexpr int fn_kernel_id() { return MP == 2 ? FN_NLG_GROWTH 
 #define WG_STAMP(k)
 #endif
 constexpr int WG_NT_MAX = 512;  // 8 waves: 256 VGPRs per lane, no spills in the fp64 transcendental code
+// Number of normals of the step draw of a filter variant as far as the stream format goes (pf_device.h): the linear-state
+// kernels draw KP normals -- PACKED above two, their resampling uniforms then come from shared RNG_RESAMPLE blocks; the functor
+// kernels (ssm_nlg, ssm_sde, EKF particle filter) keep WIDE blocks and the step block's spare word whatever their count.
+template <int KP, int FN>
+__device__ __forceinline__ constexpr int step_draw_count() { return FN == FN_NONE ? KP : 0; }
+
 // Particle i = r * NT + tid (r < PPT): consecutive lanes own consecutive particles, so LDS
 // accesses to the own slot are conflict-free and history stores are coalesced.
 // BSSM_WG_NT: the kept history of the workgroup-resident filters (particle system and ancestor table, written once per step,
@@ -306,6 +312,8 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
   const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
   const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
+  constexpr int ucnt = step_draw_count<KP, FN>();
+  constexpr bool kPack = FN == FN_NONE;
   const double* __restrict__ amats = (FN && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
   const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP), m = b.m;
   const double dN = (double)N;
@@ -326,7 +334,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       if constexpr (FN != FN_NONE) functor_initial<MP, FID>(fpar, ini, key, (uint32_t)i, x);
     } else {
       double z[MP];
-      rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)i, z);
+      rng_normals<MP, kPack>(key, RNG_INIT, 0, (uint32_t)i, z);
       initial_state<MP>(ini, z, x);
     }
     if (i < N) {
@@ -423,11 +431,16 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
     // opaque key in front of the further transition blocks: profiles/r03_regb_ab.txt)
     RngKey key_t = key;
     if constexpr (FN != FN_NONE) __asm__ volatile("" : "+s"(key_t.seed), "+s"(key_t.stream));
+    // (a PACKED step draw at four particles per lane: the four lanes of a quad share their rows' RNG_RESAMPLE blocks)
+    constexpr bool kQuadU = ucnt > 2 && PPT == 4;
+    uint32_t uq[4] = {0u, 0u, 0u, 0u};
+    if constexpr (kQuadU) rng_resample_words_quad4(key_t, (uint32_t)t, (uint32_t)NT, (uint32_t)tid, uq);
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
       blk[r] = rng_step_block(key_t, (uint32_t)t, (uint32_t)i);
-      v[r] = (block_uniform(blk[r]) + (double)i) * c_scale;
+      const uint32_t uword = kQuadU ? uq[r & 3] : rng_resample_word<ucnt>(key_t, (uint32_t)t, (uint32_t)i, blk[r]);
+      v[r] = ((double)uword * 0x1.0p-32 + (double)i) * c_scale;
       lo[r] = 0; hi[r] = N - 1;
       if (N >= 256 && r * NT + (wave + 1) * 64 <= N) {
         // the 64 slots of a wave are consecutive, so v increases along the lanes and their ancestors lie between those
@@ -486,7 +499,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
         if constexpr (FN != FN_NONE && MP <= 4) functor_ekpf_propagate<MP, FID>(fpar, ob, t + 1 >= n, key_p, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
       } else {
         double z[KP];
-        rng_normals_blk<KP>(blk[r], key_p, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
+        rng_normals_blk<KP, kPack>(blk[r], key_p, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
         propagate<MP, KP>(mt, a[r], z, x);
       }
       if (i < N) {
@@ -726,6 +739,8 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
   const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
   const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
+  constexpr int ucnt = step_draw_count<KP, FN>();
+  constexpr bool kPack = FN == FN_NONE;
   const double* __restrict__ amats = (FN && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
   const int base = pb * chunk;
   const int len = min(chunk, N - base);
@@ -747,7 +762,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
         if constexpr (FN != FN_NONE) functor_initial<MP, FID>(fpar, ini, key, (uint32_t)j, x[r]);
       } else {
         double z[MP];
-        rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)j, z);
+        rng_normals<MP, kPack>(key, RNG_INIT, 0, (uint32_t)j, z);
         initial_state<MP>(ini, z, x[r]);
       }
       if (li < len) {
@@ -779,8 +794,8 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
       for (int r = 0; r < PPT; r++) {
         const uint32_t j = (uint32_t)(base + r * GRID_NT + tid);
         const u32x4 blk = rng_step_block(key, (uint32_t)t, j);
-        u_pre[r] = block_uniform(blk);
-        rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, j, z_pre[r]);
+        u_pre[r] = (double)rng_resample_word<ucnt>(key, (uint32_t)t, j, blk) * 0x1.0p-32;
+        rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, j, z_pre[r]);
       }
     }
     BSSM_STAMP(1)
@@ -853,7 +868,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
         double u;
         u32x4 blk{0u, 0u, 0u, 0u};
         if constexpr (kEarlyRng) u = u_pre[r];
-        else { blk = rng_step_block(key, (uint32_t)t, (uint32_t)j); u = block_uniform(blk); }
+        else { blk = rng_step_block(key, (uint32_t)t, (uint32_t)j); u = (double)rng_resample_word<ucnt>(key, (uint32_t)t, (uint32_t)j, blk) * 0x1.0p-32; }
         const double v = (u + (double)j) * c_scale;
         // level 1: source block = number of block prefixes below v.  The 64 slots of a wave are consecutive, so v
         // increases along the lanes and covers 64 / N of the total mass: at most B of a filter's N / 64 wave-ranges
@@ -961,7 +976,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
             if constexpr (MP <= 4) functor_ekpf_propagate<MP, FID>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
           } else if (psi_mode) {
             double z[KP];
-            rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+            rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
             propagate<MP, KP>(mt, a, z, x[r]);
           } else {
             functor_propagate<MP, KP, FID>(fpar, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
@@ -971,14 +986,14 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
         } else if constexpr (kMfma) {
           if constexpr (MP == 8) {
             double z[KP];
-            rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+            rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
             propagate_mfma8<KP>(mt, a, z, x[r], s_tile + wave * (16 * 64), lane);
           }
         } else if constexpr (kEarlyRng) {
           propagate<MP, KP>(mt, a, z_pre[r], x[r]);
         } else {
           double z[KP];
-          rng_normals_blk<KP>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+          rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
           propagate<MP, KP>(mt, a, z, x[r]);
         }
         if (li < len) {

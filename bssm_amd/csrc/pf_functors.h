@@ -185,7 +185,7 @@ __device__ __forceinline__ void functor_initial(const double* __restrict__ fp, c
     for (int c = 1; c < MP; c++) x[c] = 0.0;
   } else {  // a1 + psd_chol(P1) u (src/model_ssm_nlg.cpp:1069-1081)
     double z[MP];
-    rng_normals<MP>(key, RNG_INIT, 0u, i, z);
+    rng_normals<MP, false>(key, RNG_INIT, 0u, i, z);
 #pragma unroll
     for (int j = 0; j < MP; j++) {
       double s = 0.0;
@@ -206,7 +206,7 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
     for (int c = 1; c < MP; c++) x[c] = 0.0;
   } else {
     double z[KP];
-    rng_normals_blk<KP>(blk0, key, RNG_TRANSITION, t, i, z);  // blk0 = the step block
+    rng_normals_blk<KP, false>(blk0, key, RNG_TRANSITION, t, i, z);  // blk0 = the step block (functor models: WIDE blocks)
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
     if (id == FN_USER_NLG) {  // alpha' = T(a) + R(a) eta with any m x k matrix R (src/model_ssm_nlg.cpp:1118-1126)
 #pragma unroll
@@ -624,7 +624,7 @@ __device__ __forceinline__ void functor_ekpf_propagate(const double* __restrict_
                                                        const double (&anc)[MP], double (&x)[MP]) {
   double at[MP], att[MP], Lf[MP * MP], z[MP];
   ekpf_proposal<MP, FID>(fp, row_next, last, anc, at, att, Lf, (int)t);
-  rng_normals_blk<MP>(blk0, key, RNG_TRANSITION, t, i, z);
+  rng_normals_blk<MP, false>(blk0, key, RNG_TRANSITION, t, i, z);
 #pragma unroll
   for (int j = 0; j < MP; j++) {
     double acc = 0.0;

@@ -625,17 +625,6 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   u32x4 blk[PPT];
 #pragma unroll
   for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + v2_li<PPT>(r, tid)));
-  // (BSSM_V2_EARLY_B: the second Philox block of a particle with 3 or 4 noise terms is drawn here too, in the shadow of the
-  // exchange loads and the first barrier, instead of on the critical path behind the ancestor gathers)
-#ifndef BSSM_V2_EARLY_B
-#define BSSM_V2_EARLY_B 0
-#endif
-  constexpr bool kEarlyB = BSSM_V2_EARLY_B && !MS && (KP == 3 || KP == 4);
-  u32x4 blkB[kEarlyB ? PPT : 1];
-  if constexpr (kEarlyB) {
-#pragma unroll
-    for (int r = 0; r < PPT; r++) blkB[r] = philox4x32_10((uint32_t)(base + v2_li<PPT>(r, tid)), (uint32_t)t, 1u, RNG_TRANSITION, key.seed, key.stream);
-  }
   math_tab_load_end256(mtab);
   lds_barrier();  // (1)
   const V2Prefix px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[128 + 64 + lane], B};
@@ -678,7 +667,11 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   // ballots over the block prefixes); coarse rows of those blocks in flight
   constexpr int WIN = PPT * V2_WIN;  // window entries per wave
   uint32_t* sw_u32 = (uint32_t*)sw_base;
-  if constexpr (PPT > 1) {
+  // a PACKED step draw (more than two noise terms, pf_device.h) leaves no spare word in the step blocks: the uniforms of four
+  // consecutive slots share one RNG_RESAMPLE block, which the lane that holds those slots for the search draws directly --
+  // no transposition through LDS
+  constexpr bool kSharedU = KP > 2;
+  if constexpr (PPT > 1 && !kSharedU) {
 #pragma unroll
     for (int r = 0; r < PPT; r++) sw_u32[r * 64 + lane] = blk[r].w;
     lds_wave_sync();
@@ -690,11 +683,26 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   double cv1, cv2;
   {
     double v[PPT];
+    uint32_t uw[PPT];
+    if constexpr (kSharedU) {
+      const uint32_t s0 = (uint32_t)(base + wave * (64 * PPT) + PPT * lane);  // first of this lane's PPT consecutive slots
+      if constexpr (PPT >= 4) {
 #pragma unroll
-    for (int q = 0; q < PPT; q++) {
-      const uint32_t u = PPT > 1 ? sw_u32[PPT * lane + q] : blk[0].w;
-      v[q] = ((double)u * 0x1.0p-32 + (double)(base + wave * (64 * PPT) + PPT * lane + q)) * c_scale;
+        for (int q = 0; q < PPT; q += 4) {
+          const u32x4 ub = rng_resample_block(key, (uint32_t)t, (s0 + q) >> 2);
+          uw[q] = ub.x; uw[q + 1] = ub.y; uw[q + 2] = ub.z; uw[q + 3] = ub.w;
+        }
+      } else {
+        const u32x4 ub = rng_resample_block(key, (uint32_t)t, s0 >> 2);
+#pragma unroll
+        for (int q = 0; q < PPT; q++) uw[q] = u32x4_word(ub, (s0 + q) & 3u);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < PPT; q++) uw[q] = PPT > 1 ? sw_u32[PPT * lane + q] : blk[0].w;
     }
+#pragma unroll
+    for (int q = 0; q < PPT; q++) v[q] = ((double)uw[q] * 0x1.0p-32 + (double)(base + wave * (64 * PPT) + PPT * lane + q)) * c_scale;
     const double v_lo = lane_broadcast(v[0], 0), v_hi = lane_broadcast(v[PPT - 1], 63);
     const int c_lo = px.count_below(v_lo, lane);
     const int c_hi = px.count_below(v_hi, lane);
@@ -826,6 +834,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
 #pragma unroll
       for (int q = 1; q < PPT; q++) ur = (r == q) ? blk[q].w : ur;  // r is wave-uniform: scalar compare + select
       const int li = v2_li<PPT>(r, tid);
+      if constexpr (kSharedU) ur = rng_resample_word<KP>(key, (uint32_t)t, (uint32_t)(base + li), blk[0]);
       const double vr = ((double)ur * 0x1.0p-32 + (double)(base + li)) * c_scale;  // the target, as in phase A
       const int ar = v2_search_generic<PPT, WX>(vr, li < len, px, B, N, coarse, lcdf, sw_base, lane);
 #pragma unroll
@@ -886,16 +895,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   for (int r = 0; r < PPT; r++) {
     const int li = v2_li<PPT>(r, tid), j = base + li;
     double z[KP], x[MP];
-    if constexpr (kEarlyB) {
-      __asm__ volatile("" : "+v"(blkB[r].x), "+v"(blkB[r].y), "+v"(blkB[r].z));
-      double z0, z1, z2, z3;
-      box_muller(blk[r], z0, z1);
-      box_muller(blkB[r], z2, z3);
-      z[0] = z0; z[1] = z1; z[2] = z2;
-      if constexpr (KP == 4) z[3] = z3;
-    } else {
-      rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
-    }
+    rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
     if constexpr (kMfma) {
       propagate_mfma8_h<KP>((const double*)s_mat, a[r % ROLL], z, x, sw_base, lane);
     } else {

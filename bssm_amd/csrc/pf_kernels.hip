@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) sim_smoother_kernel(const double* __restr
   const RngKey key{seed, 0u};
   const int MS = 2 * m * m + m;
   double x[16], z[16], xn[16];
-  for (int d = 0; d < m; d += 2) rng_normal_pair(key, RNG_INIT, 0u, (uint32_t)i, (uint32_t)(d >> 1), z[d], z[d + 1]);
+  rng_normals_rt(key, RNG_INIT, 0u, (uint32_t)i, m, z);
   for (int j = 0; j < m; j++) {
     double s = init[j];
     for (int c = 0; c < m; c++) s += init[m + j + m * c] * z[c];
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) sim_smoother_kernel(const double* __restr
   }
   for (int t = 0; t < n; t++) {
     const double* __restrict__ mt = mats + (size_t)t * MS;
-    for (int d = 0; d < m; d += 2) rng_normal_pair(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, (uint32_t)(d >> 1), z[d], z[d + 1]);
+    rng_normals_rt(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, m, z);
     for (int j = 0; j < m; j++) {
       double s = 0.0, q = 0.0;
       for (int c = 0; c < m; c++) { s += mt[j + m * c] * x[c]; q += mt[m * m + j + m * c] * z[c]; }
@@ -201,6 +201,12 @@ __global__ void debug_math_kernel(int fn, const double* __restrict__ in, double*
     double sn, cs;
     fast_sincos_2pi((uint32_t)(x * 0x1.0p32), sn, cs);
     out[2 * i] = sn; out[2 * i + 1] = cs;
+  } else if (fn == 4) {  // four PACKED normals of (seed = 1, stream = 0), counter (i, 0, 0, purpose 2)
+    double z[4];
+    rng_normals<4>(RngKey{1u, 0u}, RNG_TRANSITION, 0u, (uint32_t)i, z);
+    for (int q = 0; q < 4; q++) out[4 * i + q] = z[q];
+  } else if (fn == 5) {  // resampling uniform of slot i at step 3 of a filter with a PACKED step draw
+    out[i] = (double)rng_resample_word<4>(RngKey{1u, 0u}, 3u, (uint32_t)i, u32x4{0u, 0u, 0u, 0u}) * 0x1.0p-32;
   } else if (fn == 3) {  // Box-Muller pair for Philox key (seed = 1, stream = 0), counter (i, 0, 0, purpose 2)
     double z0, z1;
     rng_normal_pair(RngKey{1u, 0u}, RNG_TRANSITION, 0u, (uint32_t)i, 0u, z0, z1);

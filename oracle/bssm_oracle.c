@@ -52,15 +52,27 @@ static void draw(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uin
 
 /* purpose: 0 initial-state normals, 1 resampling uniform, 2 transition normals,
  * 3 trajectory pick, 4 SDE increments.
- * A block feeds one Box-Muller pair from words 0-2 (53-bit radius uniform, 32-bit angle) and leaves word 3
- * over.  The resampling uniform of slot i at step t is that spare word of the "step block"
- * (i, t, draw 0, purpose 2), i.e. of the block that also carries the slot's first two transition normals. */
+ * Two block formats, chosen by the number of normals a draw needs (the kernels' pf_device.h states the same rule):
+ *   WIDE (a draw of <= 2 normals; every Milstein sub-step pair): one block per pair -- words 0-1 a 53-bit radius uniform,
+ *     word 2 a 32-bit angle, word 3 left over.  The resampling uniform of slot i at step t of a filter whose step draw is
+ *     WIDE is that spare word of the "step block" (i, t, draw 0, purpose 2), the block that also carries the slot's
+ *     transition normals.
+ *   PACKED (a draw of > 2 normals): pair p comes from block (i, t, p / 2, purpose), words (0,1) for even p and (2,3) for
+ *     odd p: 40-bit radius uniform (first word, then the top 8 bits of the second) and 24-bit angle (the low 24 bits of the
+ *     second).  Nothing is left over, so the resampling uniform of slot i at step t of such a filter is word i % 4 of block
+ *     (i / 4, t, 0, purpose 1), shared by four consecutive slots.
+ * PACKED applies to the linear-state filters (ssm_ung / ssm_mng / ssm_ulg / ssm_mlg: bootstrap, psi-APF, simulation smoother);
+ * the functor-model filters (ssm_nlg, ssm_sde, EKF particle filter) draw WIDE blocks whatever the count. */
 double orc_rng_uniform(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uint32_t d) {
   if (r->mode == 1 && purpose == 1) return r->unif[(size_t)t * r->N + i];
   uint32_t w[4];
-  if (purpose == 1) {
-    draw(r, 2, t, i, 0, w);
-    return (double)w[3] * 0x1.0p-32;
+  if (purpose == 1) { /* d = number of normals of the filter's step draw */
+    if (d <= 2) {
+      draw(r, 2, t, i, 0, w);
+      return (double)w[3] * 0x1.0p-32;
+    }
+    draw(r, 1, t, i >> 2, 0, w);
+    return (double)w[i & 3u] * 0x1.0p-32;
   }
   draw(r, purpose, t, i, d, w);
   return (double)bits53(w[0], w[1]) * 0x1.0p-53;
@@ -78,8 +90,36 @@ void orc_rng_normal_pair(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_
   *z1 = rad * sin(ang);
 }
 
+/* pair p of a PACKED draw */
+void orc_rng_normal_pair_packed(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, uint32_t p,
+                                double *z0, double *z1) {
+  uint32_t w[4];
+  draw(r, purpose, t, i, p >> 1, w);
+  const uint32_t a = w[2 * (p & 1u)], b = w[2 * (p & 1u) + 1];
+  double u1 = (double)((((uint64_t)a << 8) | (uint64_t)(b >> 24)) + 1) * 0x1.0p-40; /* (0,1] */
+  double u2 = (double)(b & 0xFFFFFFu) * 0x1.0p-24;                                  /* [0,1) */
+  double rad = sqrt(-2.0 * log(u1));
+  double ang = 2.0 * ORC_PI * u2;
+  *z0 = rad * cos(ang);
+  *z1 = rad * sin(ang);
+}
+
 /* cnt standard normals for particle i at step t */
-static void rng_normals(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, int cnt, double *out) {
+void orc_rng_normals(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, int cnt, double *out) {
+  for (int j = 0; j < cnt; j += 2) {
+    double z0, z1;
+    if (cnt <= 2) orc_rng_normal_pair(r, purpose, t, i, 0, &z0, &z1);
+    else orc_rng_normal_pair_packed(r, purpose, t, i, (uint32_t)(j / 2), &z0, &z1);
+    out[j] = z0;
+    if (j + 1 < cnt) out[j + 1] = z1;
+  }
+}
+/* test helper: the draws of particles i0 ... i0 + count - 1 at step t, cnt normals each (out: count x cnt, row-major) */
+void orc_rng_normals_bulk(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i0, uint32_t count, int cnt, double *out) {
+#pragma omp parallel for schedule(static)
+  for (uint32_t q = 0; q < count; q++) orc_rng_normals(r, purpose, t, i0 + q, cnt, out + (size_t)q * cnt);
+}
+static void rng_normals_fmt(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, int cnt, double *out, int wide_only) {
   if (r->mode == 1) {
     if (purpose == 0) {
       for (int j = 0; j < cnt; j++) out[j] = r->init_normals[(size_t)i * cnt + j];
@@ -88,12 +128,21 @@ static void rng_normals(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t
     }
     return;
   }
+  if (!wide_only) { orc_rng_normals(r, purpose, t, i, cnt, out); return; }
   for (int j = 0; j < cnt; j += 2) {
     double z0, z1;
     orc_rng_normal_pair(r, purpose, t, i, (uint32_t)(j / 2), &z0, &z1);
     out[j] = z0;
     if (j + 1 < cnt) out[j + 1] = z1;
   }
+}
+static void rng_normals(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, int cnt, double *out) {
+  rng_normals_fmt(r, purpose, t, i, cnt, out, 0);
+}
+/* the functor-model filters (ssm_nlg, ssm_sde, EKF particle filter) keep WIDE blocks whatever the count: one block per pair,
+ * the resampling uniform in the spare word of the step block (their kernels are instantiated for the padded dimensions) */
+static void rng_normals_wide(const orc_rng *r, uint32_t purpose, uint32_t t, uint32_t i, int cnt, double *out) {
+  rng_normals_fmt(r, purpose, t, i, cnt, out, 1);
 }
 
 /* ------------------------------------------------------------------ */
@@ -310,7 +359,7 @@ double orc_ung_bsf_filter(const orc_ung_model *mod, unsigned N, const orc_rng *r
     for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   }
   for (int t = 0; t < n; t++) {
-    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0); /* :650-653 */
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, (uint32_t)k); /* :650-653 */
     filter_resample(nw, r, N, indices + (size_t)N * t, t);                 /* :655 */
     for (unsigned i = 0; i < N; i++)                                          /* :659-661 */
       for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
@@ -778,7 +827,7 @@ double orc_ung_psi_filter(const orc_ung_model *mod, const orc_psi_setup *su, uns
     loglik = su->approx_loglik;
   }
   for (int t = 0; t < n; t++) {
-    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, (uint32_t)m);
     filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++)
       for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
@@ -1053,7 +1102,7 @@ static double mng_filter_core(const orc_mng_model *mod, const orc_mng_setup *su,
     for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   }
   for (int t = 0; t < n; t++) {
-    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, (uint32_t)k);
     filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++)
       for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
@@ -1470,7 +1519,7 @@ double orc_fn_bsf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rng
   for (unsigned i = 0; i < N; i++) {
     if (sde) A_(0, 0, i) = fn_milstein(mod, rng, 0, 0, i, mod->x0); /* model_ssm_sde.cpp:25-28 */
     else {
-      rng_normals(rng, 0, 0, i, m, um);
+      rng_normals_wide(rng, 0, 0, i, m, um);
       for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += L[j + m * c] * um[c]; A_(j, 0, i) = a1[j] + s; }
     }
   }
@@ -1481,14 +1530,14 @@ double orc_fn_bsf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rng
     loglik = inc;
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
-    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0); /* functor-model filters draw WIDE blocks */
     filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     for (unsigned i = 0; i < N; i++) {
       if (sde) A_(0, t + 1, i) = fn_milstein(mod, rng, 4, t, i, atmp[i]); /* :59-62 */
       else {
         double x[2];
-        rng_normals(rng, 2, t, i, m, um);
+        rng_normals_wide(rng, 2, t, i, m, um);
         fn_T(mod, atmp + (size_t)m * i, x);
         for (int j = 0; j < m; j++) A_(j, t + 1, i) = x[j] + rdiag[j] * um[j]; /* model_ssm_nlg.cpp:1118-1126 */
       }
@@ -1518,7 +1567,7 @@ double orc_nlg_general_bsf_filter(const orc_nlg_general *mod, unsigned N, const 
   double *r = (double *)malloc(sizeof(double) * N), *atmp = (double *)malloc(sizeof(double) * N * m);
   orc_psd_chol(mod->P1, m, L); /* :1071 */
   for (unsigned i = 0; i < N; i++) {
-    rng_normals(rng, 0, 0, i, m, um);
+    rng_normals_wide(rng, 0, 0, i, m, um);
     for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += L[j + m * c] * um[c]; A_(j, 0, i) = mod->a1[j] + s; }
   }
   double loglik = 0.0, inc;
@@ -1531,11 +1580,11 @@ double orc_nlg_general_bsf_filter(const orc_nlg_general *mod, unsigned N, const 
     loglik = inc;
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
-    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0); /* functor-model filters draw WIDE blocks */
     filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     for (unsigned i = 0; i < N; i++) { /* :1118-1126: T_fn and R_fn at the ancestor */
-      rng_normals(rng, 2, t, i, k, um);
+      rng_normals_wide(rng, 2, t, i, k, um);
       mod->T_fn(t, atmp + (size_t)m * i, mod->theta, mod->known, x);
       mod->R_fn(t, atmp + (size_t)m * i, mod->theta, mod->known, Rm);
       for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < k; c++) s += Rm[j + m * c] * um[c]; A_(j, t + 1, i) = x[j] + s; }
@@ -1679,7 +1728,7 @@ double orc_fn_ekpf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rn
   fn_ekf_update_step(mod, mod->y[0], a1, P1, m, att1, Ptt1); /* :1157-1158 */
   orc_psd_chol(Ptt1, m, L);                                   /* :1161 */
   for (unsigned i = 0; i < N; i++) {                          /* :1163-1172 */
-    rng_normals(rng, 0, 0, i, m, um);
+    rng_normals_wide(rng, 0, 0, i, m, um);
     for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += L[j + m * c] * um[c]; A_(j, 0, i) = att1[j] + s; }
   }
   double loglik = 0.0, inc;
@@ -1690,7 +1739,7 @@ double orc_fn_ekpf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rn
     loglik = inc;
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
-    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0); /* functor-model filters draw WIDE blocks */
     filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) {                        /* :1212-1227 */
       double at[2], Ptt[4];
@@ -1704,7 +1753,7 @@ double orc_fn_ekpf_filter(const orc_fn_model *mod, unsigned N, const orc_rng *rn
       }
     }
     for (unsigned i = 0; i < N; i++) {                        /* :1229-1235 */
-      rng_normals(rng, 2, t, i, m, um);
+      rng_normals_wide(rng, 2, t, i, m, um);
       const double *Li = Lp + (size_t)mm * i;
       for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += Li[j + m * c] * um[c]; A_(j, t + 1, i) = att[j + (size_t)m * i] + s; }
     }
@@ -1942,7 +1991,7 @@ double orc_fn_psi_filter(const orc_fn_model *mod, const orc_fn_setup *su, unsign
   double *r = (double *)malloc(sizeof(double) * N), *atmp = (double *)calloc((size_t)N * m, sizeof(double));
   double um[2];
   for (unsigned i = 0; i < N; i++) {
-    rng_normals(rng, 0, 0, i, m, um);
+    rng_normals_wide(rng, 0, 0, i, m, um);
     for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += su->Vt[j + m * c] * um[c]; A_(j, 0, i) = su->alphahat[j] + s; }
   }
   double loglik = su->approx_loglik, inc;
@@ -1952,13 +2001,13 @@ double orc_fn_psi_filter(const orc_fn_model *mod, const orc_fn_setup *su, unsign
     loglik += inc;
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
-    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0); /* functor-model filters draw WIDE blocks */
     filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     const double *ah0 = su->alphahat + (size_t)m * t, *ah1 = su->alphahat + (size_t)m * (t + 1);
     const double *Ct1 = su->Ct + (size_t)mm * (t + 1), *Vt1 = su->Vt + (size_t)mm * (t + 1);
     for (unsigned i = 0; i < N; i++) {
-      rng_normals(rng, 2, t, i, m, um);
+      rng_normals_wide(rng, 2, t, i, m, um);
       for (int j = 0; j < m; j++) {
         double s = 0, q = 0;
         for (int c = 0; c < m; c++) s += Ct1[j + m * c] * (atmp[c + (size_t)m * i] - ah0[c]);
@@ -2213,7 +2262,7 @@ double orc_nlg_general_psi_filter(const orc_nlg_general_psi *mod, const orc_nlg_
   double *r = (double *)malloc(sizeof(double) * N), *atmp = (double *)calloc((size_t)N * m, sizeof(double));
   double um[ORC_MAXM];
   for (unsigned i = 0; i < N; i++) {
-    rng_normals(rng, 0, 0, i, m, um);
+    rng_normals_wide(rng, 0, 0, i, m, um);
     for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += su->Vt[j + m * c] * um[c]; A_(j, 0, i) = su->alphahat[j] + s; }
   }
   double loglik = su->approx_loglik, inc;
@@ -2223,13 +2272,13 @@ double orc_nlg_general_psi_filter(const orc_nlg_general_psi *mod, const orc_nlg_
     loglik += inc;
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
-    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0); /* functor-model filters draw WIDE blocks */
     filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) for (int j = 0; j < m; j++) atmp[j + (size_t)m * i] = A_(j, t, indices[i + (size_t)N * t]);
     const double *ah0 = su->alphahat + (size_t)m * t, *ah1 = su->alphahat + (size_t)m * (t + 1);
     const double *Ct1 = su->Ct + (size_t)mm * (t + 1), *Vt1 = su->Vt + (size_t)mm * (t + 1);
     for (unsigned i = 0; i < N; i++) {
-      rng_normals(rng, 2, t, i, m, um);
+      rng_normals_wide(rng, 2, t, i, m, um);
       for (int j = 0; j < m; j++) {
         double s = 0, q = 0;
         for (int c = 0; c < m; c++) s += Ct1[j + m * c] * (atmp[c + (size_t)m * i] - ah0[c]);
@@ -2284,7 +2333,7 @@ double orc_nlg_general_ekpf_filter(const orc_nlg_general_psi *mod, unsigned N, c
   gen_ekf_update_step(mod, 0, b->a1, b->P1, att1, Ptt1); /* :1157-1158 */
   orc_psd_chol(Ptt1, m, L);                                /* :1161 */
   for (unsigned i = 0; i < N; i++) {
-    rng_normals(rng, 0, 0, i, m, um);
+    rng_normals_wide(rng, 0, 0, i, m, um);
     for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += L[j + m * c] * um[c]; A_(j, 0, i) = att1[j] + s; }
   }
   double loglik = 0.0, inc;
@@ -2297,7 +2346,7 @@ double orc_nlg_general_ekpf_filter(const orc_nlg_general_psi *mod, unsigned N, c
     loglik = inc;
   } else for (unsigned i = 0; i < N; i++) { weights[i] = 1.0; nw[i] = 1.0 / N; }
   for (int t = 0; t < n; t++) {
-    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0);
+    for (unsigned i = 0; i < N; i++) r[i] = orc_rng_uniform(rng, 1, t, i, 0); /* functor-model filters draw WIDE blocks */
     filter_resample(nw, r, N, indices + (size_t)N * t, t);
     for (unsigned i = 0; i < N; i++) { /* :1212-1227 */
       double at[ORC_MAXM], Rt[ORC_MAXM * ORC_MAXM], Pt[ORC_MAXM * ORC_MAXM], Ptt[ORC_MAXM * ORC_MAXM];
@@ -2313,7 +2362,7 @@ double orc_nlg_general_ekpf_filter(const orc_nlg_general_psi *mod, unsigned N, c
       }
     }
     for (unsigned i = 0; i < N; i++) {
-      rng_normals(rng, 2, t, i, m, um);
+      rng_normals_wide(rng, 2, t, i, m, um);
       const double *Li = Lp + (size_t)mm * i;
       for (int j = 0; j < m; j++) { double s = 0; for (int c = 0; c < m; c++) s += Li[j + m * c] * um[c]; A_(j, t + 1, i) = att[j + (size_t)m * i] + s; }
     }

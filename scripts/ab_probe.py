@@ -1,0 +1,39 @@
+"""One line of throughputs for an A/B of library builds on one box (scripts/ab2.sh): the headline batch (C2-m4, informative
+series, 32 in flight, factored weights), C4 at 64 and 32 filters in flight, regime B (512 LDS-resident filters, m = k = 4)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from bssm_amd import _lib  # noqa: E402
+from bssm_amd.plan import FilterPlan  # noqa: E402
+from models_zoo import mng_c4, negbin_m4_informative  # noqa: E402
+
+st = torch.cuda.current_stream().cuda_stream
+what = sys.argv[1].split(",") if len(sys.argv) > 1 else ["head", "c4_64", "c4_32", "regb"]
+out = []
+
+
+def run(model, N, R, T, reps, **kw):
+    p = FilterPlan(model, N, method="bsf", n_rep=R, **kw)
+    p.run(3, hip_stream=st); torch.cuda.synchronize()
+    ms = p.time(5, reps, hip_stream=st)
+    k = FilterPlan.last_kernel()
+    p.close()
+    _lib.lib().bssm_amd_trim_cache()
+    return float(N) * T * R / (ms * 1e-3), k
+
+
+if "head" in what:
+    v, k = run(negbin_m4_informative(1000), 65536, 32, 1000, 10, keep_history=True, force="grid", factored_weights=True)
+    out.append("head %.4g" % v)
+for tag, R in (("c4_64", 64), ("c4_32", 32)):
+    if tag in what:
+        v, k = run(mng_c4(2000), 16384, R, 2000, 3, keep_history=True, force="grid", factored_weights=True)
+        out.append("%s %.4g" % (tag, v))
+if "regb" in what:
+    v, k = run(negbin_m4_informative(1000), 2048, 512, 1000, 5, keep_history=False, force="wg")
+    out.append("regb %.4g" % v)
+print("  ".join(out))

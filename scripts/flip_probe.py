@@ -83,7 +83,7 @@ def main():
             # of one stratum (1 / N): the reference's arithmetic (normalise, sequential cumsum, (j + u) / N)
             wcol = ref["weights"][:, t0]
             cdf = np.cumsum(wcol / wcol.sum())
-            u = O.lib().orc_rng_uniform(C.byref(O.make_rng(sd, f)[0]), 1, t0, j0, 0)
+            u = O.lib().orc_rng_uniform(C.byref(O.make_rng(sd, f)[0]), 1, t0, j0, 4)
             kk = min(int(gix[t0, j0]), int(rix[t0, j0]))
             rec["resampling_uniform"] = float(u)
             rec["margin_in_strata"] = float(((j0 + u) / N - cdf[kk]) * N)

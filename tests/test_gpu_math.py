@@ -76,3 +76,20 @@ def test_box_muller_stream_matches_oracle(oracle):
         ref[i] = (z0.value, z1.value)
     assert np.abs(got - ref).max() <= 4e-15      # |z| <= 8.6; a few ulp of the radius
     assert np.abs(got - ref).mean() <= 3e-16
+
+
+def test_packed_normals_and_shared_uniforms_match_oracle(oracle):
+    """round 4: draws of more than two normals pack two Box-Muller pairs into a Philox block (40-bit radius, 24-bit angle),
+    and the resampling uniforms of such a filter come from blocks shared by four consecutive slots (pf_device.h)"""
+    n = 50000
+    got = _run(4, np.zeros(n), mult=4).reshape(-1, 4)
+    L = oracle.lib()
+    rng, _ = oracle.make_rng(seed=1, stream=0)
+    ref = np.zeros((n, 4))
+    L.orc_rng_normals_bulk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+    L.orc_rng_normals_bulk(C.byref(rng), 2, 0, 0, n, 4, ref.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.abs(got - ref).max() <= 4e-15      # |z| <= 7.45; a few ulp of the radius
+    assert np.abs(got - ref).mean() <= 3e-16
+    gu = _run(5, np.zeros(n), mult=2)[:n]
+    ru = np.array([L.orc_rng_uniform(C.byref(rng), 1, 3, i, 4) for i in range(n)])
+    assert np.array_equal(gu, ru)

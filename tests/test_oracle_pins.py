@@ -43,6 +43,82 @@ def test_stream_moments(oracle):
     assert stats.kstest(zs, "norm").pvalue > 1e-3
 
 
+def test_packed_block_format_is_what_the_header_says(oracle):
+    """PACKED draws (more than two normals): pair p = half p % 2 of block (i, t, p / 2, purpose), 40-bit radius + 24-bit
+    angle; the resampling uniform of a filter with such a step draw = word i % 4 of block (i / 4, t, 0, purpose 1).
+    Re-derived here from the raw Philox words."""
+    import ctypes as C
+    L = oracle.lib()
+    seed, stream, t = 77, 3, 12
+    rng, _ = oracle.make_rng(seed=seed, stream=stream)
+    for i in (0, 5, 1023, 65535):
+        out = (C.c_double * 7)()
+        L.orc_rng_normals(C.byref(rng), 2, t, i, 7, out)
+        want = []
+        for p in range(4):
+            w = oracle.philox([i, t, p // 2, 2], [seed, stream])
+            a, b = w[2 * (p % 2)], w[2 * (p % 2) + 1]
+            u1 = (((a << 8) | (b >> 24)) + 1) * 2.0 ** -40
+            ang = 2 * np.pi * (b & 0xFFFFFF) * 2.0 ** -24
+            rad = np.sqrt(-2 * np.log(u1))
+            want += [rad * np.cos(ang), rad * np.sin(ang)]
+        assert np.allclose(list(out), want[:7], rtol=0, atol=1e-15)
+        for cnt in (3, 4, 8):
+            assert L.orc_rng_uniform(C.byref(rng), 1, t, i, cnt) == oracle.philox([i >> 2, t, 0, 1], [seed, stream])[i & 3] * 2.0 ** -32
+        for cnt in (0, 1, 2):   # WIDE step draw: the spare word of the step block
+            assert L.orc_rng_uniform(C.byref(rng), 1, t, i, cnt) == oracle.philox([i, t, 0, 2], [seed, stream])[3] * 2.0 ** -32
+        two = (C.c_double * 2)()
+        L.orc_rng_normals(C.byref(rng), 2, t, i, 2, two)
+        z0, z1 = C.c_double(), C.c_double()
+        L.orc_rng_normal_pair(C.byref(rng), 2, t, i, 0, C.byref(z0), C.byref(z1))
+        assert list(two) == [z0.value, z1.value]
+
+
+def test_packed_normals_distribution_1e8(oracle):
+    """Quality gate of the PACKED format (round 4: two Box-Muller pairs per Philox block, 40-bit radius, 24-bit angle):
+    1e8 normals drawn as the filters draw them (8 per particle-step), against N(0, 1) -- moments, a 4000-cell chi-square
+    on equiprobable cells, tail counts out to 6 sigma, and the correlations a packing mistake would show (between the two
+    normals of a pair, between the pairs of a block, between blocks, between neighbouring particles)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.orc_rng_normals_bulk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+    rng, _ = oracle.make_rng(seed=2024, stream=7)
+    cnt, steps, parts = 8, 50, 250000
+    z = np.empty((steps, parts, cnt))
+    for t in range(steps):
+        L.orc_rng_normals_bulk(C.byref(rng), 2, t, 0, parts, cnt, z[t].ctypes.data_as(C.POINTER(C.c_double)))
+    flat = z.reshape(-1)
+    n = flat.size
+    assert n == 100_000_000
+    se = 1 / np.sqrt(n)
+    assert abs(flat.mean()) < 5 * se
+    assert abs(flat.var() - 1) < 5 * np.sqrt(2) * se
+    assert abs(np.mean(flat ** 3)) < 5 * np.sqrt(15) * se
+    assert abs(np.mean(flat ** 4) - 3) < 5 * np.sqrt(96) * se
+    cells = 4000
+    edges = stats.norm.ppf(np.arange(1, cells) / cells)
+    counts = np.bincount(np.searchsorted(edges, flat), minlength=cells)
+    chi2 = float(np.sum((counts - n / cells) ** 2 / (n / cells)))
+    assert stats.chi2.sf(chi2, cells - 1) > 1e-4, chi2
+    for k in (4.0, 5.0, 6.0):      # two-sided tail counts are Poisson around n * 2 * sf(k)
+        exp = n * 2 * stats.norm.sf(k)
+        got = int(np.sum(np.abs(flat) > k))
+        assert abs(got - exp) <= 5 * np.sqrt(exp) + 3, (k, got, exp)
+    assert np.abs(flat).max() < 7.46   # sqrt(2 * 40 * log 2)
+    c = lambda a, b: float(np.mean(a * b))
+    lim = 5 / np.sqrt(steps * parts)
+    assert abs(c(z[..., 0], z[..., 1])) < lim and abs(c(z[..., 2], z[..., 3])) < lim          # inside a pair
+    assert abs(c(z[..., 0], z[..., 2])) < lim and abs(c(z[..., 1], z[..., 3])) < lim          # the two pairs of a block
+    assert abs(c(z[..., 0], z[..., 4])) < lim and abs(c(z[..., 3], z[..., 7])) < lim          # consecutive blocks
+    assert abs(c(z[:, :-1, 0], z[:, 1:, 0])) < lim and abs(c(z[:-1, :, 5], z[1:, :, 5])) < lim  # neighbouring particles / steps
+    assert abs(c(z[..., 0] ** 2, z[..., 1] ** 2) - 1) < 5 * 2 / np.sqrt(steps * parts)        # radius shared, angle independent
+    # the shared resampling uniforms of the same stream: 24 M words, uniform and uncorrelated with the slot index
+    u = np.array([L.orc_rng_uniform(C.byref(rng), 1, 3, i, cnt) for i in range(200000)])
+    assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 5 / np.sqrt(12 * u.size)
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 5 / np.sqrt(u.size)
+    assert stats.kstest(u, "uniform").pvalue > 1e-4
+
+
 def test_stratified_sample_hand_case(oracle):
     # src/stratified_sample.cpp:9-28 on a case checkable by hand
     p = np.array([0.1, 0.2, 0.3, 0.4]); r = np.array([0.5, 0.5, 0.5, 0.5])
@@ -204,16 +280,13 @@ def test_injected_randoms_reproduce_philox_mode(oracle):
     N, n, m, k = 12, arr["n"], arr["m"], arr["k"]
     L = oracle.lib()
     rng, _ = oracle.make_rng(seed=9, stream=1)
-    z0, z1 = C.c_double(), C.c_double()
 
-    def normals(purpose, t, i, cnt):
-        out = []
-        for d in range((cnt + 1) // 2):
-            L.orc_rng_normal_pair(C.byref(rng), purpose, t, i, d, C.byref(z0), C.byref(z1))
-            out += [z0.value, z1.value]
-        return out[:cnt]
+    def normals(purpose, t, i, cnt):   # the stream's rule: a draw of <= 2 normals is WIDE, of more PACKED (bssm_oracle.c)
+        out = (C.c_double * cnt)()
+        L.orc_rng_normals(C.byref(rng), purpose, t, i, cnt, out)
+        return list(out)
     init = np.array([normals(0, 0, i, m) for i in range(N)])
-    unif = np.array([[L.orc_rng_uniform(C.byref(rng), 1, t, i, 0) for i in range(N)] for t in range(n)])
+    unif = np.array([[L.orc_rng_uniform(C.byref(rng), 1, t, i, k) for i in range(N)] for t in range(n)])  # k = normals of the step draw
     nor = np.array([[normals(2, t, i, k) for i in range(N)] for t in range(n)])
     a = oracle.bsf_filter(arr, N, seed=9, stream=1)
     b = oracle.bsf_filter(arr, N, injected=(init, unif, nor))
