@@ -137,7 +137,18 @@ def lib():
         L.bssm_plan_time.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, c_double_p]
         L.bssm_plan_time_kernel.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, c_double_p, C.POINTER(C.c_int32)]
         _lib = L
+    # the library reads its BSSM_AMD_* switches once, at load (csrc/options.h); a process that changes one afterwards (the
+    # parity tests and tuning scripts do, between calls) has it re-read them
+    global _env_seen
+    env = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("BSSM_AMD_")))
+    if env != _env_seen:
+        if _env_seen is not None or env:
+            _lib.bssm_amd_reload_env()
+        _env_seen = env
     return _lib
+
+
+_env_seen = None
 
 
 def check(rc: int) -> int:

@@ -25,6 +25,7 @@
 
 #include "../../include/bssm_amd.h"
 #include "host_model.h"
+#include "options.h"
 #include "pf_device.h"
 #include "pf_functors.h"
 #include "pf_kernels.h"
@@ -79,8 +80,8 @@ struct DeviceArena {
   size_t cached = 0;
   size_t cap;
   DeviceArena() {
-    const char* env = std::getenv("BSSM_AMD_CACHE_GB");
-    cap = (size_t)(env ? std::atof(env) : 96.0) << 30;
+    const double gb = bssm::opt().cache_gb;
+    cap = (size_t)(gb >= 0.0 ? gb : 96.0) << 30;
   }
   static size_t round_up(size_t b) {
     const size_t g = b >= ((size_t)1 << 20) ? ((size_t)2 << 20) : 4096;
@@ -186,7 +187,7 @@ class OutPipe {
   explicit OutPipe(size_t total_bytes) {
     int hw = (int)std::thread::hardware_concurrency();
     threads_ = std::max(1, std::min(16, hw / 2));
-    if (const char* env = std::getenv("BSSM_AMD_COPY_THREADS")) threads_ = std::max(1, std::min(64, std::atoi(env)));
+    if (bssm::opt().copy_threads > 0) threads_ = std::max(1, std::min(64, bssm::opt().copy_threads));
     chunk_ = (size_t)32 << 20;
     if (total_bytes < chunk_ * 2) threads_ = std::min(threads_, 4);
     (void)hipGetDevice(&dev_);
@@ -372,7 +373,7 @@ struct DeviceBatch {
     fb.loglik = loglik.as<double>();
     HIP_TRY(dead.alloc(F * sizeof(int)));
     fb.dead_at = dead.as<int>();
-    if (std::getenv("BSSM_AMD_PROBE_NO_WEIGHTS")) keep_weights = false;  // measurement probe (scripts/traffic_probe.sh): what the weights output costs
+    if (bssm::opt().probe_no_weights) keep_weights = false;  // measurement probe, -DBSSM_PROBES builds only (scripts/traffic_probe.sh): what the weights output costs
     if (keep_hist) {
       HIP_TRY(hist.alloc((size_t)F * (n + 1) * m * N * sizeof(double)));
       HIP_TRY(indices.alloc((size_t)F * n * N * sizeof(uint32_t)));
@@ -383,10 +384,8 @@ struct DeviceBatch {
     // enough filters to fill the chip (or the filter is small); otherwise one launch per time step.
     const int cap = bssm::wg_filter_capacity(MP);
     use_grid = !(N <= cap && (F >= 32 || N <= 2048));
-    if (const char* env = std::getenv("BSSM_AMD_FORCE_PATH")) {
-      if (!std::strcmp(env, "grid")) use_grid = true;
-      if (!std::strcmp(env, "wg")) use_grid = false;
-    }
+    if (bssm::opt().force_path == 2) use_grid = true;
+    if (bssm::opt().force_path == 1) use_grid = false;
     if (path_flags & BSSM_PLAN_FORCE_GRID) use_grid = true;
     if (path_flags & BSSM_PLAN_FORCE_WG) use_grid = false;
     if (!use_grid && N > cap) return fail(BSSM_ERR_INVALID, "nsim exceeds the workgroup-resident capacity");
@@ -518,7 +517,7 @@ int run_tables(const std::vector<bssm::FilterTables>& tabs, const std::vector<do
   const size_t hist_elems = (size_t)(n + 1) * m * N;
   const size_t out_bytes = (out->alpha ? hist_elems * sizeof(double) : 0) + (out->weights ? db.weights.bytes : 0) +
                            (out->indices ? db.indices.bytes : 0);
-  const bool piped = out_bytes >= ((size_t)8 << 20) && !std::getenv("BSSM_AMD_NO_OUTPIPE");
+  const bool piped = out_bytes >= ((size_t)8 << 20) && !bssm::opt().no_outpipe;
   bssm::StepTiming hooks;
   if (piped && db.use_grid && (out->weights || out->indices) && n >= 64) hooks.progress_every = std::max(16, n / 24);
   if ((rc = db.run(seed, g_call_stream0, st, &hooks))) return rc;
@@ -658,24 +657,34 @@ int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
 // ---------------------------------------------------------------- built-in non-linear / SDE models
 namespace {
 // known_tv_params of user models (BSSM_USER_TV) in device memory: uploaded once per (device, content) and kept -- the
-// parameter blocks of every filter carry the device address, and a matrix is a few KB
+// parameter blocks of every filter (and of device-resident plans) carry the device address, and a matrix is a few KB.  Entries
+// are found by a hash and CONFIRMED by comparing dimensions and content; the cache is bounded (256 MiB per process), beyond
+// which the call fails instead of growing without limit.
 int device_known_tv(const double* host, int rows, int cols, double** dev) {
+  struct Entry { int rows, cols; std::vector<double> copy; double* p; };
   static std::mutex mu;
-  static std::map<std::pair<int, uint64_t>, double*> cache;
+  static std::multimap<std::pair<int, uint64_t>, Entry> cache;
+  static size_t kept_bytes = 0;
   int d = 0;
   (void)hipGetDevice(&d);
   const size_t cnt = (size_t)rows * cols;
   uint64_t h = 1469598103934665603ull ^ ((uint64_t)rows << 32 | (uint32_t)cols);
   for (size_t q = 0; q < cnt; q++) { uint64_t b; std::memcpy(&b, &host[q], 8); h = (h ^ b) * 1099511628211ull; }
   std::lock_guard<std::mutex> lk(mu);
-  auto it = cache.find({d, h});
-  if (it == cache.end()) {
-    double* p = nullptr;
-    HIP_TRY(hipMalloc((void**)&p, cnt * sizeof(double)));
-    HIP_TRY(hipMemcpy(p, host, cnt * sizeof(double), hipMemcpyHostToDevice));
-    it = cache.emplace(std::make_pair(d, h), p).first;
+  auto range = cache.equal_range({d, h});
+  for (auto it = range.first; it != range.second; ++it) {
+    const Entry& e = it->second;
+    if (e.rows == rows && e.cols == cols && std::memcmp(e.copy.data(), host, cnt * sizeof(double)) == 0) { *dev = e.p; return BSSM_OK; }
   }
-  *dev = it->second;
+  if (kept_bytes + cnt * sizeof(double) > ((size_t)256 << 20))
+    return fail(BSSM_ERR_UNSUPPORTED, "more than 256 MiB of distinct known_tv_params matrices kept on the device by this process");
+  double* p = nullptr;
+  HIP_TRY(hipMalloc((void**)&p, cnt * sizeof(double)));
+  const hipError_t ce = hipMemcpy(p, host, cnt * sizeof(double), hipMemcpyHostToDevice);
+  if (ce != hipSuccess) { (void)hipFree(p); return fail(BSSM_ERR_HIP, std::string("known_tv_params upload: ") + hipGetErrorString(ce)); }
+  cache.emplace(std::make_pair(d, h), Entry{rows, cols, std::vector<double>(host, host + cnt), p});
+  kept_bytes += cnt * sizeof(double);
+  *dev = p;
   return BSSM_OK;
 }
 // params_only (may be NULL): stop after the parameter block and hand back a1 (2) and P1 (4) -- what the device set-up needs
@@ -1181,10 +1190,8 @@ int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, ui
   db.fb.dead_at = db.dead.as<int>();
   const int cap = bssm::wg_filter_capacity(MP);
   db.use_grid = !((int)nsim <= cap && (n_rep >= 32 || nsim <= 2048));
-  if (const char* env = std::getenv("BSSM_AMD_FORCE_PATH")) {
-    if (!std::strcmp(env, "grid")) db.use_grid = true;
-    if (!std::strcmp(env, "wg") && (int)nsim <= cap) db.use_grid = false;
-  }
+  if (bssm::opt().force_path == 2) db.use_grid = true;
+  if (bssm::opt().force_path == 1 && (int)nsim <= cap) db.use_grid = false;
   if (db.use_grid) {
     int B, chunk;
     const size_t bytes = bssm::grid_workspace_bytes(db.fb, &B, &chunk);
@@ -1264,8 +1271,9 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   if (!source || !lib_path || lib_path_capacity < 16) return fail(BSSM_ERR_INVALID, "NULL argument");
   if (n_states < 1 || n_states > 4) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 ... 4");
   const std::string dir = library_dir();
-  const char* env = std::getenv("BSSM_AMD_USER_CACHE");
-  std::string cache = env ? std::string(env) : dir + "/user_models";
+  const std::string& env_cache = bssm::opt().user_cache;
+  const bool env = !env_cache.empty();
+  std::string cache = env ? env_cache : dir + "/user_models";
   if (!env && access(dir.c_str(), W_OK) != 0) {  // the package directory is read-only (a system-wide install): a per-user cache
     // never a shared directory such as /tmp: the library name is predictable and a cached library is dlopen'ed
     const char* home = std::getenv("HOME");
@@ -1274,7 +1282,7 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   }
   // the cache key covers everything that is compiled into the library: the kernel headers, the state dimension, the snippet
   std::string key = std::string(bssm_amd_version()) + "|" + std::to_string(n_states) + "|" + source;
-  for (const char* hdr : {"pf_filter_impl.h", "pf_grid_v2.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "pf_math_tables.h", "user_model_tu.hip"}) {
+  for (const char* hdr : {"pf_filter_impl.h", "pf_grid_v2.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "pf_math_tables.h", "options.h", "tls_stream.h", "user_model_tu.hip"}) {
     FILE* hf = std::fopen((dir + "/csrc/" + hdr).c_str(), "rb");
     if (!hf) return fail(BSSM_ERR_INVALID, "kernel sources not found next to the library: " + dir + "/csrc/" + hdr);
     char buf[1 << 16];
@@ -1301,7 +1309,11 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
     if (sb.st_uid != geteuid() && sb.st_uid != 0) return false;
     return (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
   };
-  auto make_private_dir = [&](const std::string& path) -> bool {  // our own directory with loose permissions: tighten it
+  // a directory of OURS with loose permissions is tightened -- only the library's own default cache (created by the library, or
+  // left behind by an older version of it): a caller-supplied BSSM_AMD_USER_CACHE that others can write to is refused, never
+  // chmod-ed (it may be a shared directory such as /tmp or /scratch, and this process may be root)
+  auto make_private_dir = [&](const std::string& path) -> bool {
+    if (env) return false;
     struct stat sb;
     if (stat(path.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != geteuid()) return false;
     return chmod(path.c_str(), sb.st_mode & 07777 & ~(S_IWGRP | S_IWOTH)) == 0;
@@ -1326,10 +1338,21 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   std::fputs(source, f);
   std::fclose(f);
   const std::string tmp = so + ".tmp." + pid;
-  const char* hipcc = std::getenv("HIPCC");
-  const std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I'" + dir +
-                          "/csrc' -DBSSM_USER_M=" + std::to_string(bssm::pad_dim(n_states)) + " -DBSSM_USER_NSTATES=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet_tmp + "\"' '" + dir +
-                          "/csrc/user_model_tu.hip' -o '" + tmp + "' > '" + log_tmp + "' 2>&1 && mv '" + tmp + "' '" + so + "'";
+  const char* hipcc_env = std::getenv("HIPCC");
+  const std::string hipcc = hipcc_env ? hipcc_env : "/opt/rocm/bin/hipcc";
+  // six parts side by side (sampler x kernel family -- user_model_tu.hip), then one link: ~8 s of wall clock on six cores
+  // instead of ~27 s for the single unit
+  const std::string common = hipcc + " -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I'" + dir + "/csrc' -DBSSM_USER_M=" + std::to_string(bssm::pad_dim(n_states)) +
+                             " -DBSSM_USER_NSTATES=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet_tmp + "\"' ";
+  std::string cmd = "( ", objs, logs;
+  for (int part = 0; part < 6; part++) {
+    const std::string obj = tmp + ".p" + std::to_string(part) + ".o", plog = log_tmp + ".p" + std::to_string(part);
+    cmd += common + "-DBSSM_USER_PART=" + std::to_string(part) + " -c '" + dir + "/csrc/user_model_tu.hip' -o '" + obj + "' > '" + plog + "' 2>&1 & ";
+    objs += " '" + obj + "'";
+    logs += " '" + plog + "'";
+  }
+  cmd += "wait ) ; cat" + logs + " > '" + log_tmp + "' 2>/dev/null ; rm -f" + logs + " ; ( for o in" + objs + " ; do test -s \"$o\" || exit 1 ; done ) && " + hipcc +
+         " --offload-arch=gfx950 -shared -fPIC" + objs + " -o '" + tmp + "' >> '" + log_tmp + "' 2>&1 && mv '" + tmp + "' '" + so + "' ; rc=$? ; rm -f" + objs + " ; exit $rc";
   const int build_rc = std::system(cmd.c_str());
   (void)std::rename(snippet_tmp.c_str(), snippet_final.c_str());  // kept next to the library for reference
   (void)std::rename(log_tmp.c_str(), log_final.c_str());
@@ -1358,6 +1381,7 @@ int bssm_user_model_load(const char* lib_path) {
   auto wg = (bssm::user_wg_launcher_t)dlsym(h, "bssm_user_launch_wg");
   auto grid = (bssm::user_grid_launcher_t)dlsym(h, "bssm_user_launch_grid");
   if (!wg || !grid) return fail(BSSM_ERR_INVALID, "the library does not export the user-model launchers");
+  if (auto set_opt = (void (*)(const bssm::Options& (*)()))dlsym(h, "bssm_user_set_options")) set_opt(&bssm::opt);  // the library reads this library's switches
   const int slot = bssm::register_user_launchers(wg, grid);
   if (slot < 1) return fail(BSSM_ERR_UNSUPPORTED, "too many user models loaded");
   g_user_host[slot].T = (decltype(bssm::UserHostFns::T))dlsym(h, "bssm_user_host_T");
@@ -1372,6 +1396,11 @@ int bssm_user_model_load(const char* lib_path) {
 }
 
 // ------------------------------------------------------------------ exported helpers
+int bssm_amd_reload_env(void) {
+  bssm::reload_options();
+  return BSSM_OK;
+}
+
 int bssm_stratified_sample(double* p, const double* r, uint32_t n_elem, uint32_t N, uint32_t* out) {
   if (!p || !r || !out || n_elem < 1 || N < 1) return fail(BSSM_ERR_INVALID, "NULL argument or empty input");
   for (uint32_t j = 0; j < N; j++)
@@ -1489,7 +1518,7 @@ int device_lg_batch(const std::vector<const bssm::LgPacked*>& lgs, const std::ve
   HIP_TRY(hipMemcpyAsync(ho + o_cc * F, dcc.p, n1 * mm * F * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(hok, dok.p, F * sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  if (std::getenv("BSSM_AMD_TRACE"))
+  if (bssm::opt().trace)
     std::fprintf(stderr, "[bssm_amd] psi set-up smoother on device: F=%d n=%zu m=%zu: %.2f ms (copies + kernel)\n", F, n, m, now_ms() - t_in);
   ok->assign(F, 1);
   for (int q = 0; q < F; q++) {
@@ -1504,7 +1533,7 @@ int device_lg_batch(const std::vector<const bssm::LgPacked*>& lgs, const std::ve
 // under contention per 512 draws of n = 300, m = 2); the host smoother costs 0.19 ms per draw and thread.  With fewer
 // than 8 host threads the device batch wins (C5 at threads = 1: 0.60 s -> 0.22 s), with more the host pool does.
 bool device_setup_enabled(int n_threads) {
-  if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) return env[0] != '0';
+  if (bssm::opt().device_setup >= 0) return bssm::opt().device_setup != 0;
   return n_threads < 8;
 }
 
@@ -1625,7 +1654,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
     // (filter thread 75.5 vs 78.2 ms) -- a filter workgroup of 1024 threads at 128 VGPRs owns the whole register file of its
     // CU, so the summary's workgroups only find room in the tail of a filter launch (profiles/r03_c5_output2_ab.txt) -- and
     // the deferral holds a second set of history pools.
-    const bool defer_on = std::getenv("BSSM_AMD_DEFER_SUMMARY") != nullptr;
+    const bool defer_on = bssm::opt().defer_summary;
     const bool defer = job->output_type == 2 && fused && defer_on && pos == 0 && end == order.size() && (end - pos) <= maxF;
     std::shared_ptr<PendingSummary> pend = defer ? std::make_shared<PendingSummary>() : nullptr;
     DevBuf hist_local, idx_local, smooth_pool, bcur_local;
@@ -1716,8 +1745,13 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           // shard of it at 8 ranks: 292 = 256 + 36) costs a full round.  Those filters go through the step kernels instead (several
           // workgroups per filter, one launch per time step), behind the full rounds on the same stream: 36 filters of the C5 shape
           // 3.7 -> 2.5 ms alone, about 1 ms behind other work (profiles/r03_c5_tail_round.txt).  Not when a path is forced.
+          // OPT-IN since round 4 (BSSM_AMD_TAIL_SPLIT=1): the two kernel families agree to reduction-order rounding only (a log-weight
+          // to ~1e-15 relative, and through a moved ancestor a summary to 1e-6), and which draws land in the tail depends on the
+          // draws per chunk, the shard layout and the CU count -- with the split on, a draw's result would depend on how many GPUs
+          // the job ran on.  The default keeps every draw workgroup-resident: outputs bit-identical for any device list
+          // (include/bssm_amd.h), at the price of a sparsely filled last round (one rank's 292-draw shard of C5: 8.2 -> 9.8 ms).
           int tail = 0;
-          if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && !std::getenv("BSSM_AMD_FORCE_PATH") && !std::getenv("BSSM_AMD_NO_TAIL_SPLIT")) {
+          if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && bssm::opt().force_path == 0 && bssm::opt().tail_split) {
             int dev = 0; hipDeviceProp_t prop;
             const int cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
             const int r = sub.F % cus;
@@ -1820,7 +1854,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           std::memcpy(Vt_i + (size_t)i * (n + 1) * m * m, hcov.data() + f * (size_t)(n + 1) * m * m, (size_t)(n + 1) * m * m * sizeof(double));
         }
       }
-      if (std::getenv("BSSM_AMD_TRACE"))
+      if (bssm::opt().trace)
         std::fprintf(stderr, "[bssm_amd] is batch F=%zu N=%d: upload %.2f ms, filter %.2f ms, outputs %.2f ms\n", F, N, tb1 - tb0,
                      tb2 - tb1, now_ms() - tb2);
       pos += F;
@@ -1854,14 +1888,14 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
   // 9 360 (profiles/r03_c5_large_chunks.txt).
   // Shards of the C5 job as N ranks would see them (scripts/c5_shard_probe.py, profiles/r03_c5_shard_probe.txt).
   int chunk = 512;
-  if (const char* env = std::getenv("BSSM_AMD_IS_CHUNK")) chunk = std::max(1, std::atoi(env));
+  if (bssm::opt().is_chunk > 0) chunk = bssm::opt().is_chunk;
   else if (chunk_hint > 0) chunk = chunk_hint;
   else if (chunk_hint == -1) {  // (the ssm_nlg path: packing a draw on the host is a memcpy of theta)
     hipDeviceProp_t prop;
     const int cus = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     (void)cus;
     chunk = std::min(cnt, 4096);
-    if (const char* env = std::getenv("BSSM_AMD_IS_BIG_CHUNK")) { if (cnt > 4096) chunk = std::max(64, std::atoi(env)); }  // measurement option
+    if (bssm::opt().is_big_chunk > 0 && cnt > 4096) chunk = std::max(64, bssm::opt().is_big_chunk);  // measurement option (-DBSSM_PROBES builds)
   }
   else if (cnt < 4 * chunk) chunk = std::max(64, ((cnt + 3) / 4 + 63) / 64 * 64);
   std::vector<std::string> errs(cnt);
@@ -1978,8 +2012,8 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   // 0.109 s with 32 host threads; until the factors left the sequential kernel it was 0.26 s and only the default below 8 threads).
   // (n < 65535: the set-up's parallel kernels carry the time point in gridDim.y; longer series take the host set-up)
   bool dev_full = psi && have_device() && m <= 8 && n < 65535 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
-  if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) dev_full = dev_full && env[0] == '2';
-  if (std::getenv("BSSM_AMD_GENERIC_SETUP")) dev_full = false;
+  if (bssm::opt().device_setup >= 0) dev_full = dev_full && bssm::opt().device_setup == 2;
+  if (bssm::opt().generic_setup) dev_full = false;
   if (dev_full) {
     std::vector<bssm::LgPacked> packs(cnt);
     auto prepare_full = [&](int i) -> std::string {
@@ -2041,8 +2075,8 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       HIP_TRY(hipMemcpyAsync(ct->okst.p, ct->ok.p, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventCreateWithFlags(&ct->ready, hipEventDisableTiming));
       HIP_TRY(hipEventRecord(ct->ready, st));
-      if (cnt > 4096 || std::getenv("BSSM_AMD_TRACE")) HIP_TRY(hipStreamSynchronize(st));  // (see bssm_is_correction_nlg)
-      if (std::getenv("BSSM_AMD_TRACE"))
+      if (cnt > 4096 || bssm::opt().trace) HIP_TRY(hipStreamSynchronize(st));  // (see bssm_is_correction_nlg)
+      if (bssm::opt().trace)
         std::fprintf(stderr, "[bssm_amd] psi set-up on device (Laplace step + smoother + tables): F=%d n=%d m=%d: %.2f ms\n", F, n, m, now_ms() - t0);
       std::lock_guard<std::mutex> lk(J.chunk_mu);
       J.chunk_tabs[lo] = ct;
@@ -2055,7 +2089,13 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
     int hint = 0;
     {
       const double per_draw = (double)(p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m, p0) : bssm::ung_setup_scratch_doubles(n, m)) * sizeof(double);
-      const int by_mem = (int)std::max(64.0, std::floor(16e9 / per_draw / 64.0) * 64.0);
+      // the budget of a chunk's work arrays: 16 GB, and never more than a twelfth of what the device has free right now plus
+      // what this library's arena could hand back (up to three chunks alive at once, beside their staging blocks, tables and
+      // the filters' history pools of up to 24 GiB) -- a smaller or shared GPU gets smaller chunks instead of hipErrorOutOfMemory
+      size_t free_b = 0, total_b = 0;
+      double budget = 16e9;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, ((double)free_b + (double)arena().cached) / 12.0);
+      const int by_mem = (int)std::max(64.0, std::floor(budget / per_draw / 64.0) * 64.0);
       hint = std::min(cnt, std::min(2048, by_mem));
     }
     return run_is_pipeline(J, cnt, job->n_threads, prepare_full, nullptr, weights, loglik, alpha, alphahat_i, Vt_i, device_chunk_full, nullptr, hint);
@@ -2157,7 +2197,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   // kernel per pipeline chunk (fn_setup_kernel), whose outputs the filter reads in place.  BSSM_AMD_DEVICE_SETUP = 0 / 1
   // select the host set-up / the device smoother alone instead (they are tested against each other and the oracle).
   bool dev_full = psi && have_device() && id >= bssm::FN_NLG_GROWTH && id <= bssm::FN_NLG_LINEAR_GAUSSIAN && is_type != 1 && n < 65535;  // (time points ride in gridDim.y)
-  if (const char* env = std::getenv("BSSM_AMD_DEVICE_SETUP")) dev_full = dev_full && env[0] == '2';
+  if (bssm::opt().device_setup >= 0) dev_full = dev_full && bssm::opt().device_setup == 2;
   for (int i = 1; i < count && dev_full; i++) if (models[i].y != models[0].y || models[i].n != n || models[i].model_id != id) dev_full = false;
   if (dev_full) {
     const int mm = m * m, EXT = m + mm;
@@ -2215,8 +2255,8 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       // filters is a visible share of the call (C5, 2 340 draws: 0.071 -> 0.068 s, one host thread 0.100 -> 0.086 s); on
       // long jobs the preparing thread waiting here paces the set-up kernels into the gaps between filter rounds, which
       // measured 12 % faster than letting them run ahead (18 720 draws: 0.49 s against 0.55 s).
-      if (count > 4096 || std::getenv("BSSM_AMD_TRACE")) HIP_TRY(hipStreamSynchronize(st));
-      if (std::getenv("BSSM_AMD_TRACE"))
+      if (count > 4096 || bssm::opt().trace) HIP_TRY(hipStreamSynchronize(st));
+      if (bssm::opt().trace)
         std::fprintf(stderr, "[bssm_amd] psi set-up on device (linearisation + smoother + tables): F=%d n=%d m=%d: %.2f ms\n", F, n, m, now_ms() - t0);
       std::lock_guard<std::mutex> lk(J.chunk_mu);
       J.chunk_tabs[lo] = ct;
@@ -2374,8 +2414,8 @@ void gather_shard_blocks(const std::vector<int>& devices, const std::vector<std:
   if (blk == 0 || world == 0) { *kind_out = 0; return; }
   bool distinct = true;
   for (int a = 0; a < world; a++) for (int b = a + 1; b < world; b++) if (devices[a] == devices[b]) distinct = false;
-  const char* env = std::getenv("BSSM_AMD_GATHER");  // "copy" forces the device-copy exchange, "host" the host blocks
-  const std::string mode = env ? env : "";
+  // BSSM_AMD_GATHER: "copy" forces the device-copy exchange, "host" the host blocks
+  const std::string mode = bssm::opt().gather == 1 ? "copy" : (bssm::opt().gather == 2 ? "host" : "");
   int dev0 = 0;
   (void)hipGetDevice(&dev0);
   std::vector<double*> d_send(world, nullptr), d_recv(world, nullptr);
@@ -2432,7 +2472,7 @@ void gather_shard_blocks(const std::vector<int>& devices, const std::vector<std:
     if (d_recv[r]) arena().put(d_recv[r], cap_recv[r]);
   }
   (void)hipSetDevice(dev0);
-  if (!note.empty() && std::getenv("BSSM_AMD_TRACE")) std::fprintf(stderr, "[bssm_amd] exchange: %sfell back\n", note.c_str());
+  if (!note.empty() && bssm::opt().trace) std::fprintf(stderr, "[bssm_amd] exchange: %sfell back\n", note.c_str());
   *kind_out = kind;
 }
 
@@ -2512,7 +2552,7 @@ int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t
   double th = 0, td = 0;
   for (const ShardInfo& si : info) { th = std::max(th, si.setup_ms); td = std::max(td, si.device_ms); }
   g_is_timing[0] = th; g_is_timing[1] = td;
-  if (std::getenv("BSSM_AMD_TRACE"))
+  if (bssm::opt().trace)
     std::fprintf(stderr, "[bssm_amd] post-correction over %d shard(s): %.1f ms, of which the exchange (%s) %.2f ms\n", world,
                  now_ms() - t_all, kind == 1 ? "RCCL all-gather" : kind == 2 ? "device copies" : "host blocks", g_collective_ms);
   return worst;

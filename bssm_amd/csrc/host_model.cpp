@@ -2,6 +2,7 @@
 // The O(n m^3) Gaussian-approximation set-up of the psi-APF stays on the host (SURVEY.md
 // section 8a row a12: serial per theta, small); it is threaded over theta-draws by the caller.
 #include "host_model.h"
+#include "options.h"
 
 #include <algorithm>
 #include <cmath>
@@ -348,7 +349,7 @@ struct LgHostModel {
   LgModel g;
   std::vector<double> RR, yx;
   static bool applies(const HostModel& h) {
-    if (std::getenv("BSSM_AMD_GENERIC_SETUP")) return false;  // test hook: force the generic Mat routines
+    if (bssm::opt().generic_setup) return false;  // test hook: force the generic Mat routines
     return h.p == 1 && h.m >= 1 && h.m <= 8;
   }
   LgHostModel(const HostModel& h, const Approx& ap) {
@@ -609,7 +610,7 @@ double const_term(const HostModel& h) {
 }
 
 bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out, const GlobalApprox* global) {
-  if (is_mode && h.p > 1 && std::getenv("BSSM_AMD_MV_SEQUENTIAL")) {
+  if (is_mode && h.p > 1 && bssm::opt().mv_sequential) {
     // test hook: the series-at-a-time smoother the device batch runs for multivariate observations, on the host
     LgPacked lg;
     if (psi_setup_begin(h, is_mode, out, &lg)) {
@@ -748,7 +749,7 @@ void psi_setup_compact(const LgPacked& lg, PsiSetup* su) {
 }
 
 bool psi_setup_begin(const HostModel& h, const double* is_mode, PsiSetup* out, LgPacked* lg) {
-  const bool mv = h.p > 1 && h.m >= 1 && h.m <= 8 && !std::getenv("BSSM_AMD_GENERIC_SETUP");
+  const bool mv = h.p > 1 && h.m >= 1 && h.m <= 8 && !bssm::opt().generic_setup;
   if (!is_mode || !(mv || LgHostModel::applies(h))) return false;
   const int n = h.n, m = h.m, p = h.p;
   if (mv) {
@@ -1482,7 +1483,7 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
 }
 
 bool fn_psi_setup_begin(const FnModel& f, const double* is_mode, FnSetup* su, LgPacked* lg) {
-  if (!is_mode || std::getenv("BSSM_AMD_GENERIC_SETUP")) return false;
+  if (!is_mode || bssm::opt().generic_setup) return false;
   const int n = f.n, m = f.m, mm = m * m;
   su->Z.assign((size_t)m * n, 0.0); su->T.assign((size_t)mm * n, 0.0); su->D.assign(n, 0.0); su->C.assign((size_t)m * n, 0.0);
   su->mode.assign(is_mode, is_mode + (size_t)m * n); su->scales.assign(n, 0.0);

@@ -208,6 +208,9 @@ struct LgRows {
       I.vt = v[(size_t)t * es];
     };
     BwdIn bin, bnx;
+    // the first backward load reads what OTHER lanes of this draw stored in the last forward iteration (K, Fs, v): make those
+    // stores visible first (the M lanes of a draw share a wave, one wave per workgroup here, so the barrier is cheap)
+    __syncthreads();
     if (n > 0) load_bwd(n - 1, bin);
     for (int t = n - 1; t >= 0; t--) {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;

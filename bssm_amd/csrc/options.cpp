@@ -1,0 +1,78 @@
+// options.cpp -- see options.h
+#include "options.h"
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace bssm {
+namespace {
+
+int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return (e && *e) ? std::atoi(e) : dflt;
+}
+bool env_set(const char* name) { return std::getenv(name) != nullptr; }
+int env_tri(const char* name) {  // -1 unset, 0 when the value starts with '0', else 1
+  const char* e = std::getenv(name);
+  return !e ? -1 : (e[0] != '0' ? 1 : 0);
+}
+
+Options read_env() {
+  Options o;
+  if (const char* e = std::getenv("BSSM_AMD_CACHE_GB")) o.cache_gb = std::atof(e);
+  o.copy_threads = env_int("BSSM_AMD_COPY_THREADS", 0);
+  if (const char* e = std::getenv("BSSM_AMD_USER_CACHE")) o.user_cache = e;
+  o.is_chunk = env_int("BSSM_AMD_IS_CHUNK", 0);
+  if (const char* e = std::getenv("BSSM_AMD_GATHER")) o.gather = !std::strcmp(e, "copy") ? 1 : (!std::strcmp(e, "host") ? 2 : 0);
+  o.trace = env_set("BSSM_AMD_TRACE");
+  { const char* e = std::getenv("BSSM_AMD_TAIL_SPLIT"); o.tail_split = e && e[0] != '0' && e[0] != 0; }
+  if (const char* e = std::getenv("BSSM_AMD_FORCE_PATH")) o.force_path = !std::strcmp(e, "wg") ? 1 : (!std::strcmp(e, "grid") ? 2 : 0);
+  o.grid_ppt = env_int("BSSM_AMD_GRID_PPT", 0);
+  o.grid_v2 = env_tri("BSSM_AMD_GRID_V2");
+  o.grid_v2_wx = env_tri("BSSM_AMD_GRID_V2_WX");
+  o.grid_v2_exact = env_tri("BSSM_AMD_GRID_V2_EXACT");
+  o.grid_streams = env_int("BSSM_AMD_GRID_STREAMS", 0);
+  o.xcd_remap = env_int("BSSM_AMD_XCD_REMAP", -1);
+  o.wg_wide = env_tri("BSSM_AMD_WG_WIDE");
+  if (const char* e = std::getenv("BSSM_AMD_DEVICE_SETUP")) o.device_setup = e[0] == '2' ? 2 : (e[0] != '0' ? 1 : 0);
+  o.generic_setup = env_set("BSSM_AMD_GENERIC_SETUP");
+  o.mv_sequential = env_set("BSSM_AMD_MV_SEQUENTIAL");
+  o.mng_lane_per_draw = env_set("BSSM_AMD_MNG_LANE_PER_DRAW");
+  o.defer_summary = env_set("BSSM_AMD_DEFER_SUMMARY");
+  o.xcd_persist = env_tri("BSSM_AMD_XCD_PERSIST");
+#ifdef BSSM_PROBES
+  o.probe_no_weights = env_set("BSSM_AMD_PROBE_NO_WEIGHTS");
+  o.no_outpipe = env_set("BSSM_AMD_NO_OUTPIPE");
+  o.side_prio = env_set("BSSM_AMD_SIDE_PRIO");
+  o.ss_global = env_set("BSSM_AMD_SS_GLOBAL");
+  o.wg_no_exact = env_set("BSSM_AMD_WG_NO_EXACT");
+  o.is_big_chunk = env_int("BSSM_AMD_IS_BIG_CHUNK", 0);
+#endif
+  return o;
+}
+
+std::mutex g_mu;
+std::atomic<const Options*> g_cur{nullptr};
+
+}  // namespace
+
+const Options& opt() {
+  const Options* p = g_cur.load(std::memory_order_acquire);
+  if (p) return *p;
+  std::lock_guard<std::mutex> lk(g_mu);
+  p = g_cur.load(std::memory_order_acquire);
+  if (!p) { p = new Options(read_env()); g_cur.store(p, std::memory_order_release); }
+  return *p;
+}
+
+void reload_options() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  // snapshots are never freed: a call in flight on another thread may still hold a reference (a few hundred bytes per reload)
+  g_cur.store(new Options(read_env()), std::memory_order_release);
+}
+
+namespace { struct AtLoad { AtLoad() { (void)opt(); } } g_at_load; }
+
+}  // namespace bssm

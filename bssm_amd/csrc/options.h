@@ -1,0 +1,61 @@
+// options.h -- the library's environment switches, read ONCE (at load, and again only on bssm_amd_reload_env()).
+//
+// Three kinds:
+//   configuration   BSSM_AMD_CACHE_GB, BSSM_AMD_COPY_THREADS, BSSM_AMD_USER_CACHE, BSSM_AMD_IS_CHUNK, BSSM_AMD_GATHER,
+//                   BSSM_AMD_TRACE, BSSM_AMD_TAIL_SPLIT (opt-in: a sparsely filled last round of a post-correction chunk through
+//                   the step kernels -- faster, but a draw's result then depends on the shard layout; default off)
+//   test / tuning   kernel-shape and set-up choices the parity tests and the tuning scripts flip between calls:
+//                   BSSM_AMD_FORCE_PATH, BSSM_AMD_GRID_PPT, BSSM_AMD_GRID_V2, BSSM_AMD_GRID_V2_WX, BSSM_AMD_GRID_V2_EXACT,
+//                   BSSM_AMD_GRID_STREAMS, BSSM_AMD_XCD_REMAP, BSSM_AMD_WG_WIDE, BSSM_AMD_DEVICE_SETUP, BSSM_AMD_GENERIC_SETUP,
+//                   BSSM_AMD_MV_SEQUENTIAL, BSSM_AMD_MNG_LANE_PER_DRAW, BSSM_AMD_DEFER_SUMMARY
+//   probes          measurement-only switches that change what a production entry point does (skip an output, bypass the output
+//                   pipe, ...): compiled in only with -DBSSM_PROBES (`make probes` -> ../ab_probes.so):
+//                   BSSM_AMD_PROBE_NO_WEIGHTS, BSSM_AMD_NO_OUTPIPE, BSSM_AMD_IS_BIG_CHUNK, BSSM_AMD_SIDE_PRIO, BSSM_AMD_SS_GLOBAL,
+//                   BSSM_AMD_WG_NO_EXACT
+// A process that changes one of them after the library was loaded calls bssm_amd_reload_env() (the Python mirror does so by
+// itself when it sees a changed BSSM_AMD_* variable: bssm_amd/_lib.py).
+#pragma once
+#include <string>
+
+namespace bssm {
+
+struct Options {
+  // configuration
+  double cache_gb = -1.0;       // < 0: default
+  int copy_threads = 0;         // 0: default
+  std::string user_cache;       // empty: default
+  int is_chunk = 0;             // 0: default
+  int gather = 0;               // 0 auto (RCCL -> device copies -> host), 1 "copy", 2 "host"
+  bool trace = false;
+  bool tail_split = false;
+  // test / tuning
+  int force_path = 0;           // 0 none, 1 "wg", 2 "grid"
+  int grid_ppt = 0;             // 0: automatic
+  int grid_v2 = -1, grid_v2_wx = -1, grid_v2_exact = -1;   // -1: automatic; 0 / 1
+  int grid_streams = 0;         // 0: automatic
+  int xcd_remap = -1;           // -1: default
+  int wg_wide = -1;             // -1: automatic
+  int device_setup = -1;        // -1: default; 0 host, 1 smoother on the device, 2 everything on the device
+  bool generic_setup = false, mv_sequential = false, mng_lane_per_draw = false, defer_summary = false;
+  int xcd_persist = -1;         // -1: automatic; 0 never, 1 whenever eligible (the XCD-resident persistent step kernel)
+  // probes (constant defaults unless built with -DBSSM_PROBES)
+  bool probe_no_weights = false, no_outpipe = false, side_prio = false, ss_global = false, wg_no_exact = false;
+  int is_big_chunk = 0;
+};
+
+#ifdef BSSM_USER_MODEL
+// a run-time compiled user-model library (user_model_tu.hip) is self-contained: it reads the main library's snapshot through a
+// getter the main library hands over when it loads the library (bssm_user_set_options); defaults until then
+typedef const Options& (*options_getter_t)();
+inline options_getter_t& user_options_getter() { static options_getter_t g = nullptr; return g; }
+inline const Options& opt() {
+  static const Options dflt;
+  const options_getter_t g = user_options_getter();
+  return g ? g() : dflt;
+}
+#else
+const Options& opt();     // the current snapshot (lock-free read)
+void reload_options();    // re-read the environment
+#endif
+
+}  // namespace bssm

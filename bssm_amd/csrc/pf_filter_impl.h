@@ -22,6 +22,7 @@
 #include "pf_device.h"
 #include "pf_functors.h"
 #include "pf_kernels.h"
+#include "options.h"
 #include "tls_stream.h"
 
 namespace bssm {
@@ -532,10 +533,17 @@ auto wg_fn_kernel_exact(int psi) -> void (*)(const FilterBatch) {
   if constexpr (NTB == 1024 && PPT == 4 && MP <= 2) { if (psi == 1) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1, true>; }
   return nullptr;
 }
+// BSSM_FN_PSI_MASK: the samplers (bit 0 bootstrap, bit 1 psi-APF, bit 2 EKF particle filter) a translation unit instantiates
+// functor kernels for -- a run-time compiled user model is built as three such parts side by side (user_model_tu.hip)
+#ifndef BSSM_FN_PSI_MASK
+#define BSSM_FN_PSI_MASK 7
+#endif
 template <int MP, int PPT, int FNV, int NTB>
 auto wg_fn_kernel(int psi) -> void (*)(const FilterBatch) {
-  if constexpr (MP > 4) return psi == 1 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0>;  // (no EKF filter beyond four states)
-  else return psi == 0 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0> : (psi == 1 ? pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 2>);
+  if constexpr (((BSSM_FN_PSI_MASK) & 1) != 0) { if (psi == 0) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0>; }
+  if constexpr (((BSSM_FN_PSI_MASK) & 2) != 0) { if (psi == 1) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1>; }
+  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0 && MP <= 4) { if (psi == 2) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 2>; }  // (no EKF filter beyond four states)
+  return nullptr;
 }
 #define WG_FN_KERNEL(PPT_, NTB_) wg_fn_kernel<MP, PPT_, kFn, NTB_>(b.psi)
 #define GRID_FN_KERNEL(PPT_) grid_fn_kernel<MP, KP, PPT_, kFn>(b.psi)
@@ -549,7 +557,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   bool wide = false;
   if constexpr (MP <= 2) {
     wide = N >= 2048;
-    if (const char* env = std::getenv("BSSM_AMD_WG_WIDE")) wide = env[0] != '0' && N > 1024;
+    if (opt().wg_wide >= 0) wide = opt().wg_wide != 0 && N > 1024;
   }
   const int ntmax = wide ? 1024 : WG_NT_MAX;
   int ppt = 1;
@@ -566,7 +574,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
 #ifndef BSSM_USER_MODEL
         case 2: kern = fn ? (MP == KP ? WG_FN_KERNEL(2, 1024) : nullptr) : pf_wg_kernel<MP, KP, 2, FN_NONE, 1024>; break;
         case 4: kern = fn ? (MP == KP ? WG_FN_KERNEL(4, 1024) : nullptr) : pf_wg_kernel<MP, KP, 4, FN_NONE, 1024>;
-          if (fn && MP == KP && N == 4096 && !std::getenv("BSSM_AMD_WG_NO_EXACT")) { if (auto kx = wg_fn_kernel_exact<MP, 4, kFn, 1024>(b.psi)) kern = kx; }
+          if (fn && MP == KP && N == 4096 && !opt().wg_no_exact) { if (auto kx = wg_fn_kernel_exact<MP, 4, kFn, 1024>(b.psi)) kern = kx; }
           break;
         default: kern = fn ? (MP == KP ? WG_FN_KERNEL(8, 1024) : nullptr) : pf_wg_kernel<MP, KP, 8, FN_NONE, 1024>; break;
 #else
@@ -1055,8 +1063,10 @@ namespace bssm {
 
 template <int MP, int KP, int PPT, int FNV>
 auto grid_fn_kernel(int psi) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
-  if constexpr (MP > 4) return psi == 1 ? pf_grid_step<MP, KP, PPT, false, FNV, 1> : pf_grid_step<MP, KP, PPT, false, FNV, 0>;
-  else return psi == 0 ? pf_grid_step<MP, KP, PPT, false, FNV, 0> : (psi == 1 ? pf_grid_step<MP, KP, PPT, false, FNV, 1> : pf_grid_step<MP, KP, PPT, false, FNV, 2>);
+  if constexpr (((BSSM_FN_PSI_MASK) & 1) != 0) { if (psi == 0) return pf_grid_step<MP, KP, PPT, false, FNV, 0>; }
+  if constexpr (((BSSM_FN_PSI_MASK) & 2) != 0) { if (psi == 1) return pf_grid_step<MP, KP, PPT, false, FNV, 1>; }
+  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0 && MP <= 4) { if (psi == 2) return pf_grid_step<MP, KP, PPT, false, FNV, 2>; }
+  return nullptr;
 }
 template <int MP, int KP>
 hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
@@ -1096,13 +1106,13 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
 #else
     bool v2 = !b.fpar && ws.B <= 128 && ppt <= 4 && !ws.dbg;
 #endif
-    if (const char* env = std::getenv("BSSM_AMD_GRID_V2")) v2 = v2 && env[0] != '0';
+    if (opt().grid_v2 >= 0) v2 = v2 && opt().grid_v2 != 0;
     // weights exchange (pf_grid_v2.h): with the weights output on, blocks hand over their block-scaled weights instead of
     // the scan of them -- one array less written per particle-step
     v2wx = b.weights != nullptr;
-    if (const char* env = std::getenv("BSSM_AMD_GRID_V2_WX")) v2wx = v2wx && env[0] != '0';
+    if (opt().grid_v2_wx >= 0) v2wx = v2wx && opt().grid_v2_wx != 0;
     v2exact = b.N % ws.chunk == 0 && b.m == MP;  // complete blocks, no padding components: the variants without tail guards
-    if (const char* env = std::getenv("BSSM_AMD_GRID_V2_EXACT")) v2exact = v2exact && env[0] != '0';
+    if (opt().grid_v2_exact >= 0) v2exact = v2exact && opt().grid_v2_exact != 0;
     if constexpr (MP <= 4) {
       if (v2 && b.p == 1) {
         switch (ppt) {
@@ -1144,7 +1154,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   // filters at two per lane 1.80e10 -> 1.92e10, m = 1 2.12e10 -> 2.21e10; two filters, 256 workgroups: 1.41e10 -> 1.33e10, stays one)
   int parts = ((long long)b.F * ws.B >= (ws.chunk >= 2 * GRID_NT ? 384 : 512) && b.F >= 2) ? 2 : 1;
   constexpr int kMaxParts = 4;  // (more than two sequences: measurement option, BSSM_AMD_GRID_STREAMS=3|4 -- extra side streams per host thread)
-  if (const char* env = std::getenv("BSSM_AMD_GRID_STREAMS")) parts = std::max(1, std::min({std::atoi(env), kMaxParts, b.F}));
+  if (opt().grid_streams > 0) parts = std::max(1, std::min({opt().grid_streams, kMaxParts, b.F}));
   const dim3 block(GRID_NT);
   if (!ws.side) parts = 1;
   hipStream_t lanes[kMaxParts] = {stream, stream, stream, stream};
@@ -1165,7 +1175,7 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     (void)hipEventRecord(fork, stream);
     for (int q = 1; q < parts; q++) (void)hipStreamWaitEvent(lanes[q], fork, 0);
   }
-  if (const char* env = std::getenv("BSSM_AMD_XCD_REMAP")) { for (int q = 0; q < kMaxParts; q++) wsp[q].xcd_remap = std::atoi(env); }
+  if (opt().xcd_remap >= 0) { for (int q = 0; q < kMaxParts; q++) wsp[q].xcd_remap = opt().xcd_remap; }
   if (timing) timing->concurrent = parts;
   auto step = [&](int q, int t) {
     if (t < 0 && kern_init) hipLaunchKernelGGL(kern_init, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q]);

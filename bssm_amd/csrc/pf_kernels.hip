@@ -72,7 +72,7 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   // 8-dimensional states (round-2 multi-series kernel): two particles per lane once the batch fills the chip twice
   // (C4, 16 384 particles: 32 filters 1.92e10 -> 1.99e10, 64 filters 1.90e10 -> 2.19e10 particle-steps/s; 16 filters 1.58e10 -> 1.37e10)
   if (b.MP == 8 && !b.fpar && w1 >= 2048 && b.N >= 2 * GRID_NT) ppt = 2;
-  if (const char* env = std::getenv("BSSM_AMD_GRID_PPT")) ppt = std::max(1, std::min(8, std::atoi(env)));  // tuning hook
+  if (opt().grid_ppt > 0) ppt = std::max(1, std::min(8, opt().grid_ppt));  // tuning hook (BSSM_AMD_GRID_PPT)
   while ((b.N + GRID_NT * ppt - 1) / (GRID_NT * ppt) > GRID_NT && ppt < 8) ppt *= 2;
   const int chunk = GRID_NT * ppt;
   const int B = (b.N + chunk - 1) / chunk;
@@ -113,7 +113,7 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   // ONE side stream per host thread for the whole library (streams share a small number of hardware queues: a pair per
   // kernel variant ended up serialised against each other)
   static thread_local TlsStream side;
-  static const bool side_hi = std::getenv("BSSM_AMD_SIDE_PRIO") != nullptr;  // measurement: the side sequence at the highest stream priority
+  static const bool side_hi = opt().side_prio;  // measurement: the side sequence at the highest stream priority
   ws->side = side.get(side_hi);
 }
 
@@ -599,7 +599,7 @@ template <int M>
 static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64);
   hipLaunchKernelGGL((ung_setup_kernel<M, 0, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
-  const bool lane_form = std::getenv("BSSM_AMD_MNG_LANE_PER_DRAW") != nullptr;  // (comparison switch, shared with the ssm_mng set-up)
+  const bool lane_form = opt().mng_lane_per_draw;  // (comparison switch, shared with the ssm_mng set-up)
   constexpr int MR = (M == 8 || M == 4) ? M : 1;  // (as the ssm_mng set-up: rows for 8 and 4 states)
   if ((M == 8 || M == 4) && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<MR, 1, true>), dim3((unsigned)((b.F + 64 / MR - 1) / (64 / MR))), dim3(64), 0, stream, b);
   else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
@@ -820,7 +820,7 @@ static hipError_t launch_mng_setup_m(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64);
   hipLaunchKernelGGL(mng_laplace_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   // (BSSM_AMD_MNG_LANE_PER_DRAW=1 keeps the one-lane form for comparison)
-  const bool lane_form = std::getenv("BSSM_AMD_MNG_LANE_PER_DRAW") != nullptr;
+  const bool lane_form = opt().mng_lane_per_draw;
   // row-distributed for 8 and 4 states (M lanes per draw must tile the wave): m = 8 cannot be held by one lane (49 -> 5.2 ms on the C4
   // shape); m = 4 fits one lane but gains from four times as many waves (1 024 draws, p = 3, T = 300: the call 0.0485 -> 0.0436 s)
   constexpr int MR = (M == 8 || M == 4) ? M : 1;
@@ -1146,7 +1146,7 @@ __global__ void __launch_bounds__(SS_NT) smooth_summary_kernel(const double* __r
 hipError_t launch_smooth_summary(const double* hist, const uint32_t* indices, uint32_t* bcur, double* mean, double* cov, int F,
                                  int n, int m, int N, hipStream_t stream) {
   // register-resident variant (no ancestor array in memory, one gather per trajectory and time point): C5 output 2
-  const bool reg = N <= SS_RPT * SS_NT && m <= 4 && !std::getenv("BSSM_AMD_SS_GLOBAL");
+  const bool reg = N <= SS_RPT * SS_NT && m <= 4 && !opt().ss_global;
   if (reg && m <= 1) hipLaunchKernelGGL((smooth_summary_kernel<1, true>), dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
   else if (reg && m <= 2) hipLaunchKernelGGL((smooth_summary_kernel<2, true>), dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);
   else if (reg) hipLaunchKernelGGL((smooth_summary_kernel<4, true>), dim3(F), dim3(SS_NT), 0, stream, hist, indices, bcur, mean, cov, n, m, N);

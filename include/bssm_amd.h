@@ -110,6 +110,9 @@ const char* bssm_amd_version(void);
 /* The library keeps freed device buffers in an arena (default cap 96 GiB, env BSSM_AMD_CACHE_GB) because
  * hipMalloc/hipFree of multi-GB scratch dominate repeated calls; this returns all cached blocks to the driver. */
 void bssm_amd_trim_cache(void);
+/* The library reads its BSSM_AMD_* environment switches once, when it is loaded (bssm_amd/csrc/options.h lists them); a process
+ * that changes one afterwards calls this to have them read again.  Calls already in flight keep the snapshot they started with. */
+int bssm_amd_reload_env(void);
 /* wall-clock split of the last bssm_is_correction / bssm_is_correction_nlg call on this thread:
  * out[0] = per-draw host set-up (ms), out[1] = device phase incl. copies (ms) */
 void bssm_amd_last_is_timing(double out[2]);

@@ -1,10 +1,13 @@
 /* bssm_amd_shim.c -- the R-side binding: bssm's `.Call` entry points of the particle-filter / IS-MCMC path, re-pointed
  * at libbssm_amd.so (include/bssm_amd.h).
  *
- * STATUS: NOT COMPILED AGAINST R AND NEVER RUN.  Neither this image nor the GPU box has R; the file is syntax-checked
- * against declaration-only stand-ins of the R API (shim/check/, tests/test_host_logic.py) and that is all.  It is the
- * complete source a maintainer drops into bssm's src/ in place of the Rcpp stubs it names; R code does not change
- * (R/RcppExports.R keeps calling `.Call('_bssm_bsf', PACKAGE = 'bssm', ...)`).
+ * STATUS: never met real R (neither this image nor the GPU box has R), but EXECUTED since round 4 against a mock of the R C
+ * API (shim/mockr/: SEXP vectors / lists / attributes, closures, a PROTECT stack checked gctorture-style, Rf_error as a
+ * non-local exit): tests/test_gpu_shim.py runs the registered entry points with model lists built field for field as the
+ * reference's R constructors build them and requires the outputs of the ctypes path bit for bit, the protect stack back at
+ * zero, R errors for hand-edited lists (tests/test_host_logic.py: registry and argument counts against the reference's
+ * CallEntries, error paths without a GPU).  It is the complete source a maintainer drops into bssm's src/ in place of the Rcpp
+ * stubs it names; R code does not change (R/RcppExports.R keeps calling `.Call('_bssm_bsf', PACKAGE = 'bssm', ...)`).
  *
  * What it replaces: the rows of `CallEntries` in /root/reference/src/RcppExports.cpp:1287-1351 that belong to the
  * path, each stub citing the wrapper whose argument order and return list it reproduces.  Everything is
@@ -58,6 +61,7 @@ typedef struct {
   int32_t* dist_p; /* ssm_mng: per-series distribution codes as int32 */
 } shim_model;
 
+static void check_model_extents(SEXP m, const shim_model* o, int gaussian);
 static void unpack_model(SEXP m, int model_type, int gaussian, shim_model* o) {
   SEXP Z = elt(m, "Z"), T = elt(m, "T"), R = elt(m, "R"), D = elt(m, "D"), C = elt(m, "C"), xreg = elt(m, "xreg");
   bssm_ung_model* q = &o->mod;
@@ -95,6 +99,7 @@ static void unpack_model(SEXP m, int model_type, int gaussian, shim_model* o) {
       q->u = REAL(elt(m, "u"));
       q->phi = Rf_asReal(elt(m, "phi"));
       q->distribution = Rf_asInteger(elt(m, "distribution")); /* already pmatch(...) - 1 on the R side */
+      if (q->distribution == BSSM_SVM) q->u = NULL; /* svm() stores u = 1 (R/models.R:1231), the density never reads it: the library then takes ones */
     }
   }
   if (!gaussian) {
@@ -103,6 +108,34 @@ static void unpack_model(SEXP m, int model_type, int gaussian, shim_model* o) {
     q->local_approx = Rf_asLogical(elt(m, "local_approx"));
     q->initial_mode = REAL(elt(m, "initial_mode"));
   }
+  check_model_extents(m, o, gaussian);
+}
+
+/* The C ABI takes bare pointers, so the extents the library will read are checked HERE against the lengths R holds (the Rcpp
+ * constructors get them from the arma objects; a list edited by hand must fail with an R error, not read out of bounds) */
+static void need_len(SEXP m, const char* name, R_xlen_t a, R_xlen_t b) {
+  const R_xlen_t got = Rf_xlength(elt(m, name));
+  if (got != a && got != b) {
+    if (a == b) Rf_error("model$%s has length %ld, expected %ld", name, (long)got, (long)a);
+    Rf_error("model$%s has length %ld, expected %ld or %ld", name, (long)got, (long)a, (long)b);
+  }
+}
+static void check_model_extents(SEXP m, const shim_model* o, int gaussian) {
+  const bssm_ung_model* q = &o->mod;
+  const R_xlen_t n = q->n, ms = q->m, k = q->k, p = q->p;
+  if (n < 1 || ms < 1 || k < 1) Rf_error("model with an empty series, state or noise dimension (n = %ld, m = %ld, k = %ld)", (long)n, (long)ms, (long)k);
+  need_len(m, "T", ms * ms, ms * ms * n);
+  need_len(m, "R", ms * k, ms * k * n);
+  need_len(m, "P1", ms * ms, ms * ms);
+  need_len(m, "C", ms, ms * n);
+  need_len(m, "y", n * p, n * p);
+  need_len(m, "Z", p * ms, p * ms * n);
+  need_len(m, "D", p, p * n);
+  if (gaussian) { need_len(m, "H", 1, n); return; }
+  if (q->u) need_len(m, "u", n * p, n * p);   /* (svm carries u = 1, R/models.R:1231: not handed over) */
+  need_len(m, "initial_mode", n * p, n * p);
+  if (p > 1) { need_len(m, "phi", p, p); need_len(m, "distribution", p, p); }
+  if (q->n_xreg) { need_len(m, "xreg", n * q->n_xreg, n * q->n_xreg); need_len(m, "beta", q->n_xreg, q->n_xreg); }
 }
 
 /* theta-dependent components get private copies so that update_model can rewrite them */
@@ -448,6 +481,7 @@ static SEXP counts_sexp(const uint32_t* c, int ns) {
   UNPROTECT(1);
   return v;
 }
+static SEXP real_vec(const double* x, int ns) __attribute__((unused));
 static SEXP real_vec(const double* x, int ns) {
   SEXP v = PROTECT(Rf_allocVector(REALSXP, ns));
   if (ns) memcpy(REAL(v), x, (size_t)ns * sizeof(double));

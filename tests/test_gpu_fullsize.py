@@ -138,10 +138,12 @@ def test_c5_post_correct_block_invariance():
 
 
 def test_c5_post_correct_tail_round_through_the_step_kernels(monkeypatch):
-    """configs[4] shape, 300 draws: one workgroup-resident filter per CU, so 256 draws fill a round and the 44 left over go
-    through the step kernels behind it (api.cpp run_is_core; profiles/r03_c5_tail_round.txt).  Same Philox streams either way:
-    against the all-workgroup run (BSSM_AMD_NO_TAIL_SPLIT) and against two blocks of 150 (what two GPUs would filter, no
-    tail there) the log-weights agree to reduction-order rounding, and the draws that kept their kernel family bit for bit"""
+    """configs[4] shape, 300 draws: one workgroup-resident filter per CU, so 256 draws fill a round and 44 are left over.
+    DEFAULT (round 4): every draw stays workgroup-resident, so a draw's result does not depend on how the job is cut -- the whole
+    job, two blocks of 150 (what two GPUs would filter) and the in-library two-shard call agree BIT FOR BIT although only the
+    first has a sparsely filled last round.  OPT-IN (BSSM_AMD_TAIL_SPLIT=1): the 44 go through the step kernels behind the full
+    round (api.cpp run_is_core; profiles/r03_c5_tail_round.txt) -- same Philox streams, log-weights equal to reduction-order
+    rounding, the draws that kept their kernel family bit for bit."""
     rng = np.random.default_rng(106)
     n, K, dT = 300, 500.0, 0.1
     r = np.zeros(n); pp = np.zeros(n); pp[0] = 50.0
@@ -157,10 +159,10 @@ def test_c5_post_correct_tail_round_through_the_step_kernels(monkeypatch):
     counts = np.ones(ns, dtype=np.uint32)
     mode = F.psi_setup(model)["mode"].reshape(-1, order="F")
     modes = np.tile(mode[:, None], (1, ns))
+    monkeypatch.setenv("BSSM_AMD_TAIL_SPLIT", "1")
     split = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4)
-    monkeypatch.setenv("BSSM_AMD_NO_TAIL_SPLIT", "1")
+    monkeypatch.delenv("BSSM_AMD_TAIL_SPLIT")
     whole = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4)
-    monkeypatch.delenv("BSSM_AMD_NO_TAIL_SPLIT")
     lo = PC._run_local_block_nlg(model, theta[:150], modes[:, :150], counts[:150], 0, ns, 4096, 9, 2, 3, 2)
     hi = PC._run_local_block_nlg(model, theta[150:], modes[:, 150:], counts[150:], 150, ns, 4096, 9, 2, 3, 2)
     two = np.concatenate([lo["loglik"], hi["loglik"]])
@@ -174,9 +176,13 @@ def test_c5_post_correct_tail_round_through_the_step_kernels(monkeypatch):
     shard = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4, devices=[0, 0])
     assert np.array_equal(shard["loglik"], whole["loglik"])
     # with the smoothing summaries (history pools shared by the two kernel families of the chunk)
+    monkeypatch.setenv("BSSM_AMD_TAIL_SPLIT", "1")
     s2 = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 2, 4)
-    monkeypatch.setenv("BSSM_AMD_NO_TAIL_SPLIT", "1")
+    monkeypatch.delenv("BSSM_AMD_TAIL_SPLIT")
     w2 = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 2, 4)
+    sh2 = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 2, 4, devices=[0, 0])
+    for k in ("alphahat_i", "Vt_i"):     # default: summaries too are independent of the shard layout
+        assert np.array_equal(sh2[k], w2[k]), k
     assert np.array_equal(s2["loglik"], split["loglik"]) and np.array_equal(w2["loglik"], whole["loglik"])
     for k in ("alphahat_i", "Vt_i"):
         assert np.array_equal(s2[k][..., :256], w2[k][..., :256]), k

@@ -365,3 +365,111 @@ def test_builtin_update_maps_for_all_draws_at_once_equal_the_per_draw_maps():
                     assert batch[i][k].shape == v.shape and np.array_equal(batch[i][k], v, equal_nan=True), (i, k)
                 else:
                     assert batch[i][k] == v, (i, k)
+
+
+# ---------------------------------------------------------------- the R-side binding, executed against a mock of R's C API
+def _mockr():
+    from mockr import MockR
+    return MockR()
+
+
+def test_mock_r_runtime_catches_protect_bugs():
+    """shim/mockr/ is only worth something if it catches what R's garbage collector would: an object used after an
+    allocation it was not protected across, a returned value in that state, a protect-stack imbalance; and a correct routine
+    must pass, attributes and all"""
+    import ctypes as C
+    from mockr import RError
+    R = _mockr()
+    L = R.L
+
+    def run(name, x):
+        fn = C.cast(getattr(L, name), C.c_void_p).value
+        args = (C.c_void_p * 1)(R.value(x))
+        L.mockr_building(0)
+        try:
+            res = L.mockr_call(fn, 1, args)
+        finally:
+            L.mockr_building(1)
+        if not res:
+            raise RError(L.mockr_last_error().decode())
+        return R.to_py(res)
+
+    assert np.array_equal(run("mockr_selftest_ok", np.array([1.0, 2.5])), [2.0, 5.0])
+    with pytest.raises(RError, match="garbage collection would have freed"):
+        run("mockr_selftest_unprotected", np.array([1.0]))
+    with pytest.raises(RError, match="stack imbalance"):
+        run("mockr_selftest_imbalance", np.array([1.0]))
+    with pytest.raises(RError, match="not protected"):
+        run("mockr_selftest_returns_collected", np.array([1.0]))
+    with pytest.raises(RError, match="deliberate failure 7"):
+        run("mockr_selftest_error", 7)
+    assert L.mockr_protect_depth() == 0
+    # with the torture off the unprotected use goes through (as it mostly does under R: the bug class the mock exists for)
+    L.mockr_gctorture(0)
+    assert run("mockr_selftest_unprotected", np.array([1.0])).shape == (3,)
+    L.mockr_gctorture(1)
+    R.reset()
+
+
+def test_shim_registry_matches_the_reference_call_table():
+    """The routines bssm_amd_register() hands to R_registerRoutines: names and argument counts of the reference's own
+    CallEntries rows for this path (/root/reference/src/RcppExports.cpp:1288-1344), dynamic lookup disabled
+    as the reference does (:1350)"""
+    R = _mockr()
+    want = {"_bssm_bsf": 5, "_bssm_bsf_smoother": 5, "_bssm_bsf_nlg": 18, "_bssm_bsf_smoother_nlg": 18, "_bssm_ekpf": 18,
+            "_bssm_ekpf_smoother": 18, "_bssm_psi_smoother": 4, "_bssm_gaussian_psi_smoother": 4, "_bssm_psi_smoother_nlg": 21,
+            "_bssm_bsf_sde": 12, "_bssm_bsf_smoother_sde": 12, "_bssm_loglik_sde": 12, "_bssm_nongaussian_loglik": 5,
+            "_bssm_nonlinear_loglik": 22, "_bssm_suggest_n_nongaussian": 6, "_bssm_suggest_n_nonlinear": 20,
+            "_bssm_postcorrection_nongaussian": 10, "_bssm_postcorrection_nonlinear": 24, "_bssm_stratified_sample": 3,
+            "_bssm_nongaussian_is_mcmc": 17, "_bssm_nonlinear_is_mcmc": 34, "_bssm_sde_is_mcmc": 24,
+            "_bssm_sde_state_sampler_bsf_is2": 13}
+    assert R.L.mockr_registered_count() == len(want)
+    for name, nargs in want.items():
+        fn, got = R.registered(name)
+        assert fn and got == nargs, (name, got)
+    assert R.L.mockr_dynamic_symbols() == 0
+    ref = os.path.join("/root/reference", "src", "RcppExports.cpp")
+    if os.path.exists(ref):   # in the build container: the counts above against the reference's own table
+        import re
+        table = dict((m.group(1), int(m.group(2))) for m in re.finditer(r'\{"(_bssm_\w+)", \(DL_FUNC\) &\w+, (\d+)\}', open(ref).read()))
+        for name, nargs in want.items():
+            assert table[name] == nargs, (name, table[name])
+    R.reset()
+
+
+def test_shim_runs_up_to_the_device_and_reports_r_errors():
+    """Without a GPU every compute entry point of the library says so; through the shim that must arrive as an R error, after
+    the model list was unpacked and the outputs allocated, with the protect stack unwound.  Hand-edited lists fail as R errors
+    too: a missing field, a field of the wrong length, the wrong number of arguments."""
+    from mockr import RError, r_model_list
+    from bssm_amd import models as M
+    from bssm_amd import _lib
+    from models_zoo import mng_zoo, small_zoo
+    R = _mockr()
+    zoo = small_zoo()
+    for name in ("poisson_ll", "svm", "negbin_m4", "binomial_ar1_xreg"):
+        mdl = zoo[name]
+        lst = r_model_list(mdl)
+        if name == "svm":
+            lst["u"] = 1.0          # what R's svm() stores (R/models.R:1231); the shim must not hand it over as a series
+        if _lib.lib().bssm_amd_device_count() == 0:
+            with pytest.raises(RError, match="no HIP device"):
+                R.call("_bssm_bsf", lst, 10, 1, False, M.model_type(mdl))
+            with pytest.raises(RError, match="no HIP device"):
+                R.call("_bssm_psi_smoother", lst, 10, 1, M.model_type(mdl))
+        assert R.L.mockr_protect_depth() == 0
+    mdl = zoo["poisson_ll"]
+    lst = r_model_list(mdl)
+    with pytest.raises(RError, match="Incorrect number of arguments"):
+        R.call("_bssm_bsf", lst, 10, 1, False)
+    for field, bad, msg in (("T", np.zeros(3), r"model\$T has length 3, expected 1 or 40"), ("u", np.ones(7), r"model\$u has length 7"),
+                            ("initial_mode", np.zeros(39), r"model\$initial_mode has length 39"), ("P1", np.zeros((2, 2)), r"model\$P1 has length 4")):
+        with pytest.raises(RError, match=msg):
+            R.call("_bssm_bsf", {**lst, field: bad}, 10, 1, False, M.model_type(mdl))
+    with pytest.raises(RError, match="REAL\\(\\) can only be applied"):
+        R.call("_bssm_bsf", {k: v for k, v in lst.items() if k != "a1"}, 10, 1, False, M.model_type(mdl))
+    mng = mng_zoo()["mixed_m4_p3"]
+    with pytest.raises(RError, match=r"model\$phi has length 2, expected 3"):
+        R.call("_bssm_bsf", {**r_model_list(mng), "phi": np.ones(2)}, 10, 1, False, M.model_type(mng))
+    assert R.L.mockr_poisoned_touches() == 0 and R.L.mockr_protect_depth() == 0
+    R.reset()
