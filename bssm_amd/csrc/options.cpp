@@ -41,7 +41,7 @@ Options read_env() {
   o.mv_sequential = env_set("BSSM_AMD_MV_SEQUENTIAL");
   o.mng_lane_per_draw = env_set("BSSM_AMD_MNG_LANE_PER_DRAW");
   o.defer_summary = env_set("BSSM_AMD_DEFER_SUMMARY");
-  o.xcd_persist = env_tri("BSSM_AMD_XCD_PERSIST");
+  o.xcd_persist = env_tri("BSSM_AMD_XCD_PERSIST");   // (acts in -DBSSM_XCD_PERSIST builds only)
 #ifdef BSSM_PROBES
   o.probe_no_weights = env_set("BSSM_AMD_PROBE_NO_WEIGHTS");
   o.no_outpipe = env_set("BSSM_AMD_NO_OUTPIPE");
@@ -49,6 +49,7 @@ Options read_env() {
   o.ss_global = env_set("BSSM_AMD_SS_GLOBAL");
   o.wg_no_exact = env_set("BSSM_AMD_WG_NO_EXACT");
   o.is_big_chunk = env_int("BSSM_AMD_IS_BIG_CHUNK", 0);
+  o.xcd_persist_dbg = env_int("BSSM_AMD_XCD_PERSIST_DBG", 0);
 #endif
   return o;
 }

@@ -38,6 +38,7 @@ struct Options {
   int device_setup = -1;        // -1: default; 0 host, 1 smoother on the device, 2 everything on the device
   bool generic_setup = false, mv_sequential = false, mng_lane_per_draw = false, defer_summary = false;
   int xcd_persist = -1;         // -1: automatic; 0 never, 1 whenever eligible (the XCD-resident persistent step kernel)
+  int xcd_persist_dbg = 0;      // measurement bits of the persistent kernel (BSSM_AMD_XCD_PERSIST_DBG; -DBSSM_PROBES builds)
   // probes (constant defaults unless built with -DBSSM_PROBES)
   bool probe_no_weights = false, no_outpipe = false, side_prio = false, ss_global = false, wg_no_exact = false;
   int is_big_chunk = 0;

@@ -1075,6 +1075,12 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   if (b.fpar && kFn > 0 && b.fn_id != kFn) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
   void (*kern_init)(const FilterBatch, const GridWorkspace) = nullptr;  // round-2 kernels: the step t = -1 has its own
+#ifdef BSSM_XCD_PERSIST
+  void (*kern_persist)(const FilterBatch*, const GridWorkspace*, const PersistCtl, const int, const int) = nullptr;  // XCD-resident time loop (pf_grid_v2.h; experiment builds)
+#define BSSM_PERSIST_PICK(...) kern_persist = __VA_ARGS__
+#else
+#define BSSM_PERSIST_PICK(...) ((void)0)
+#endif
 #ifndef BSSM_USER_MODEL
   switch (ppt) {
     case 1: kern = pf_grid_step<MP, KP, 1>; break;
@@ -1116,9 +1122,9 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     if constexpr (MP <= 4) {
       if (v2 && b.p == 1) {
         switch (ppt) {
-          case 1: kern = v2_step_kernel<MP, KP, 1, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1>; break;
-          case 2: kern = v2_step_kernel<MP, KP, 2, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2>; break;
-          default: kern = v2_step_kernel<MP, KP, 4, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 4>; break;
+          case 1: kern = v2_step_kernel<MP, KP, 1, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 1, false>(v2wx, v2exact)); break;
+          case 2: kern = v2_step_kernel<MP, KP, 2, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 2, false>(v2wx, v2exact)); break;
+          default: kern = v2_step_kernel<MP, KP, 4, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 4>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 4, false>(v2wx, v2exact)); break;
         }
       }
     }
@@ -1126,11 +1132,11 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     // particles per lane (MP = 8, one particle per lane: fp64 MFMA transition)
     if (v2 && !kern_init && ppt <= 4 && (MP == 8 || b.p > 1)) {
       v2ms = true;
-      if (ppt == 1) { kern = v2_step_kernel<MP, KP, 1, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1, true>; }
-      else if (ppt == 2) { kern = v2_step_kernel<MP, KP, 2, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2, true>; }
+      if (ppt == 1) { kern = v2_step_kernel<MP, KP, 1, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1, true>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 1, true>(v2wx, v2exact)); }
+      else if (ppt == 2) { kern = v2_step_kernel<MP, KP, 2, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2, true>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 2, true>(v2wx, v2exact)); }
       else { kern = v2_step_kernel<MP, KP, 4, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 4, true>; }
     }
-    if (!kern_init) v2wx = v2exact = false;
+    if (!kern_init) { v2wx = v2exact = false; BSSM_PERSIST_PICK(nullptr); }
   }
 #endif
   if (!kern) return hipErrorInvalidValue;
@@ -1176,6 +1182,49 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     for (int q = 1; q < parts; q++) (void)hipStreamWaitEvent(lanes[q], fork, 0);
   }
   if (opt().xcd_remap >= 0) { for (int q = 0; q < kMaxParts; q++) wsp[q].xcd_remap = opt().xcd_remap; }
+#if !defined(BSSM_USER_MODEL) && defined(BSSM_XCD_PERSIST)
+  // ---- the XCD-resident persistent form (pf_grid_v2.h; experiment builds): ONE launch for the whole time loop of every filter of the batch.
+  // BSSM_AMD_XCD_PERSIST=1 asks for it wherever a kernel exists; it is left through the ordinary path below when the device did
+  // not complete every filter (an uneven dispatch left no complete team, or a wait timed out).
+  if (kern_persist && kern_init && opt().xcd_persist >= 1 && (!timing || timing->every <= 0) && ws.persist) {
+    int occ = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern_persist, GRID_NT, 0) == hipSuccess && occ > 0 &&
+        hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) {
+      const int per_xcd = prop.multiProcessorCount / 8 * occ;
+      const int teams_xcd_max = std::min(per_xcd / ws.B, kPersistMaxTeams);
+      if (teams_xcd_max >= 1) {
+        const int teams_xcd = std::min(teams_xcd_max, (b.F + 7) / 8);
+        const int total = 8 * teams_xcd * ws.B;
+        GridWorkspace w0 = wsp[0];
+        w0.f0 = 0;
+        const PersistCtl ctl{ws.persist, total, b.F, 0, 20000000ull /* 0.2 s of the 100 MHz wall clock per wait */, opt().xcd_persist_dbg};
+        if ((e = hipMemsetAsync(ws.persist, 0, sizeof(unsigned) * kPersistWords, stream)) != hipSuccess) return e;
+        // the descriptors the persistent kernel re-reads every step: device memory behind the control words
+        static_assert(sizeof(FilterBatch) % 8 == 0 && sizeof(GridWorkspace) % 8 == 0, "descriptors are copied and read as 64-bit words");
+        char* dparams = (char*)(ws.persist + kPersistWords);
+        if ((e = hipMemcpyAsync(dparams, &b, sizeof(FilterBatch), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(dparams + sizeof(FilterBatch), &w0, sizeof(GridWorkspace), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(kern_init, dim3(ws.B, b.F), block, 0, stream, b, w0);
+        hipLaunchKernelGGL(kern_persist, dim3(total), block, 0, stream, (const FilterBatch*)dparams, (const GridWorkspace*)(dparams + sizeof(FilterBatch)), ctl, ws.B, b.n);
+        unsigned tail[4] = {0, 0, 0, 0};
+        if ((e = hipMemcpyAsync(tail, ws.persist + PC_REGISTERED, sizeof tail, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        const bool complete = tail[PC_ERROR - PC_REGISTERED] == 0u && tail[PC_DONE - PC_REGISTERED] == (unsigned)b.F;
+        if (timing) { timing->concurrent = 1; timing->persistent = complete ? teams_xcd * 8 : -1; }
+        if (complete) {
+          { char nm[112]; std::snprintf(nm, sizeof nm, "pf_xcd_persist_v2<%d,%d,%d,%s,%s,%s>", MP, KP, ppt, v2ms ? "true" : "false", v2wx ? "true" : "false", v2exact ? "true" : "false"); note_filter_kernel(nm); }
+          hipLaunchKernelGGL(loglik_finalize_kernel, dim3(b.F), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);
+          return hipGetLastError();
+        }
+        // not every filter was completed: start over, one launch per step (the outputs are rewritten from t = -1)
+        if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
+        if (fw && (e = hipMemsetAsync(ws.wscale, 0, sizeof(double) * b.F * (b.n + 1) * ws.B, stream)) != hipSuccess) return e;
+      }
+    }
+  }
+#endif
   if (timing) timing->concurrent = parts;
   auto step = [&](int q, int t) {
     if (t < 0 && kern_init) hipLaunchKernelGGL(kern_init, dim3(ws.B, fcount[q]), block, 0, lanes[q], b, wsp[q]);

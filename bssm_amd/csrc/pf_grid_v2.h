@@ -70,6 +70,21 @@ __device__ __forceinline__ v2_d2 v2_ld32_d2_nt(const double* uniform_base, uint3
   typedef __attribute__((address_space(1))) const char gC;
   return __builtin_nontemporal_load((gD2*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * 8u)));
 }
+// Loads of data that ANOTHER workgroup of the same launch has written (the XCD-resident persistent kernel below): `sc1` loads
+// -- relaxed agent-scope atomic loads -- are served by the L2 of this XCD and never by the CU's vector L1, which another CU's
+// stores do not refresh (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility").  COH = false:
+// the plain load of the launch-per-step kernels, where the kernel boundary is the synchronisation.
+template <class T>
+__device__ __forceinline__ T ld32_sc1(const T* uniform_base, uint32_t index) {
+  typedef __attribute__((address_space(1))) T gT;
+  typedef __attribute__((address_space(1))) char gC;
+  return __hip_atomic_load((gT*)((gC*)(uint64_t)uniform_base + (uint32_t)(index * (uint32_t)sizeof(T))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH, class T>
+__device__ __forceinline__ T v2_ldx(const T* uniform_base, uint32_t index) {
+  if constexpr (COH) return ld32_sc1(uniform_base, index);
+  else return ld32(uniform_base, index);
+}
 // value of lane `src` (any lane, per-lane choice): ds_bpermute on the two halves (LDS crossbar, no LDS memory)
 __device__ __forceinline__ double v2_lane_gather(double v, int src) {
   const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
@@ -120,7 +135,7 @@ struct V2Prefix {
 // Ancestor of the wave's active slots (a prefix of its lanes), any shape: loops over the source blocks the slots fall
 // into and over 128-entry windows of each block's local scan.  Every loop bound is wave-uniform.
 //   Q / iscale: this lane's block prefix (inclusive, scaled) and 1 / scale of block `lane`
-template <int PPT, bool WX = false>
+template <int PPT, bool WX = false, bool COH = false>
 __device__ __forceinline__ int v2_search_generic(const double v, const bool act, const V2Prefix& px, const int B,
                                                  const int N, const double* __restrict__ coarse, const double* __restrict__ lcdf,
                                                  double* sw, const int lane) {
@@ -144,7 +159,7 @@ __device__ __forceinline__ int v2_search_generic(const double v, const bool act,
     const double vp = (v - Pm1) * px.is(e);
     const double vp_lo = lane_broadcast(vp, f0), vp_hi = lane_broadcast(vp, f1);
     const int slen = min(chunk, N - e * chunk), ncr = (slen + 15) >> 4;
-    const double cv = coarse[(size_t)e * crow + (lane < ncr ? lane : ncr - 1)];
+    const double cv = v2_ldx<COH>(coarse, (uint32_t)(e * crow + (lane < ncr ? lane : ncr - 1)));
     const int k_lo = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv < vp_lo)), ncr - 1);
     const int k_hi = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv < vp_hi)), ncr - 1);
     const int wend = min(16 * (k_hi + 1), slen);
@@ -153,7 +168,7 @@ __device__ __forceinline__ int v2_search_generic(const double v, const bool act,
     for (int w0 = 16 * k_lo; w0 < wend; w0 += V2_WIN) {
       const int wlen = min(V2_WIN, wend - w0);
       __builtin_amdgcn_wave_barrier();  // the previous window's reads are done (same wave, LDS is in order)
-      double x0 = src[w0 + (lane < wlen ? lane : wlen - 1)], x1 = src[w0 + (lane + 64 < wlen ? lane + 64 : wlen - 1)];
+      double x0 = v2_ldx<COH>(src, (uint32_t)(w0 + (lane < wlen ? lane : wlen - 1))), x1 = v2_ldx<COH>(src, (uint32_t)(w0 + (lane + 64 < wlen ? lane + 64 : wlen - 1)));
       if constexpr (WX) {  // (w0 is a multiple of 16: rows of entries sit in rows of lanes)
         x0 = v2_entry_scan(x0, cv, (w0 + lane) >> 4);
         x1 = v2_entry_scan(x1, cv, (w0 + 64 + lane) >> 4);
@@ -533,8 +548,12 @@ __device__ __forceinline__ void v2_window_ancestors(const double* sw, const doub
 // exchanged weights, write the output once", and the `lcdf` write (8 of the 109 bytes a particle-step moved) disappears
 // EXACT: every block is complete (N a multiple of 256 * PPT) and the state has no padding components (m == MP): the tail
 // guards of every load and store fold away (-18 % SALU instructions; C2-m4 +4.4 %)
-template <int MP, int KP, int PPT, bool MS = false, bool WX = false, bool EXACT = false>
-__global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_step_v2(const FilterBatch b, const GridWorkspace ws, const int t) {
+// The body of one step for workgroup (filter f, particle block pb).  COH: the data other workgroups wrote (partials, coarse
+// rows, windows, ancestor states) is read with sc1 loads -- the persistent kernel, where they were written in the SAME launch.
+// load_tables: the first step of a launch publishes the math tables through barrier (1).  Returns false when the filter has
+// degenerated at this step (every workgroup of the filter sees the same S and returns the same).
+template <int MP, int KP, int PPT, bool MS, bool WX, bool EXACT, bool COH>
+__device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWorkspace& ws, const int t, const int pb, const int f, const bool load_tables) {
   #ifndef BSSM_V2_MFMA_PPT
 #define BSSM_V2_MFMA_PPT 4
 #endif
@@ -550,9 +569,8 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   __shared__ double s_mat[NMAT];
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int pb, f;
-  v2_block_of(ws, pb, f);
-  const MathTabRegs mtab = math_tab_load_begin256();
+  MathTabRegs mtab{};
+  if (load_tables) mtab = math_tab_load_begin256();
   const int B = ws.B, N = b.N, n = b.n, m = EXACT ? MP : b.m, tn = t + 1;
   constexpr int chunk = GRID_NT * PPT, crow = chunk / 16;
   const int base = pb * chunk, len = EXACT ? chunk : min(chunk, N - base);
@@ -603,8 +621,13 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   if (wave == 0) {
     const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
     double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
-    if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
-    if (lane + 64 < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64)); pmaxb = pp.x; psumb = pp.y; }
+    if constexpr (COH) {
+      if (lane < B) { pmax = ld32_sc1(part, (uint32_t)(2 * lane)); psum = ld32_sc1(part, (uint32_t)(2 * lane + 1)); }
+      if (lane + 64 < B) { pmaxb = ld32_sc1(part, (uint32_t)(2 * (lane + 64))); psumb = ld32_sc1(part, (uint32_t)(2 * (lane + 64) + 1)); }
+    } else {
+      if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
+      if (lane + 64 < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64)); pmaxb = pp.x; psumb = pp.y; }
+    }
     const double M0 = wave_max(fmax(pmax, pmaxb));
     const double scale0 = fast_exp(pmax - M0);  // lanes >= B: 0; a poisoned (NaN) partial makes S NaN below
     const double Q0 = wave_scan_incl(psum * scale0);
@@ -625,7 +648,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   u32x4 blk[PPT];
 #pragma unroll
   for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + v2_li<PPT>(r, tid)));
-  math_tab_load_end256(mtab);
+  if (load_tables) math_tab_load_end256(mtab);
   lds_barrier();  // (1)
   const V2Prefix px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[128 + 64 + lane], B};
   const double S = s_comb[127], M = s_comb[384];
@@ -643,7 +666,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       pn[2 * pb + 1] = __builtin_nan("");
       if (pb == 0) atomicCAS(&b.dead_at[f], 0, t + 1);
     }
-    return;
+    return false;
   }
   if (pb == B - 1 && tid == GRID_NT - 1) ws.llinc[(size_t)f * (n + 1) + t] = M + tl_log(S / (double)N);  // :683
   const double c_scale = S / (double)N;
@@ -712,7 +735,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
     const double is1 = px.is(e1);
     slen1 = min(chunk, N - e1 * chunk); ncr1 = (slen1 + 15) >> 4;
     slen2 = min(chunk, N - e2 * chunk); ncr2 = (slen2 + 15) >> 4;
-    auto coarse_row = [&](int e, int ncr) -> double { return ld32(coarse + (size_t)e * crow, lane < ncr ? lane : ncr - 1); };
+    auto coarse_row = [&](int e, int ncr) -> double { return v2_ldx<COH>(coarse + (size_t)e * crow, (uint32_t)(lane < ncr ? lane : ncr - 1)); };
     cv1 = coarse_row(e1, ncr1);
     if (e2 != e1) {
       const double P1 = px.q(e1), is2 = px.is(e2);
@@ -759,7 +782,10 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       if (valid) {
         const uint32_t src0 = (second ? off2 : off1) + (uint32_t)i0;
 #pragma unroll
-        for (int k = 0; k < E; k += 2) { const v2_d2 d = ((BSSM_V2_NT) & 32) ? v2_ld32_d2_nt(lcdf, src0 + k) : v2_ld32_d2(lcdf, src0 + k); x[k] = d.x; x[k + 1] = d.y; }
+        for (int k = 0; k < E; k += 2) {
+          if constexpr (COH) { x[k] = ld32_sc1(lcdf, src0 + k); x[k + 1] = ld32_sc1(lcdf, src0 + k + 1); }
+          else { const v2_d2 d = ((BSSM_V2_NT) & 32) ? v2_ld32_d2_nt(lcdf, src0 + k) : v2_ld32_d2(lcdf, src0 + k); x[k] = d.x; x[k + 1] = d.y; }
+        }
       }
 #pragma unroll
       for (int j = 1; j < E; j++) x[j] += x[j - 1];
@@ -783,7 +809,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       wr[q] = __builtin_huge_val();
       if (q * 64 < total) {  // wave-uniform
         const int i = min(q * 64 + lane, total - 1);
-        wr[q] = ld32(lcdf, (i < len1 ? off1 : off2) + (uint32_t)i);
+        wr[q] = v2_ldx<COH>(lcdf, (i < len1 ? off1 : off2) + (uint32_t)i);
         if constexpr (WX) {  // the exchanged values are weights: their scan inside the row + the coarse entry of the row before
           // (w0 and len1 are multiples of 16 wherever a second segment exists: rows of entries sit in rows of lanes)
           const int i0 = q * 64 + lane;
@@ -836,7 +862,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
       const int li = v2_li<PPT>(r, tid);
       if constexpr (kSharedU) ur = rng_resample_word<KP>(key, (uint32_t)t, (uint32_t)(base + li), blk[0]);
       const double vr = ((double)ur * 0x1.0p-32 + (double)(base + li)) * c_scale;  // the target, as in phase A
-      const int ar = v2_search_generic<PPT, WX>(vr, li < len, px, B, N, coarse, lcdf, sw_base, lane);
+      const int ar = v2_search_generic<PPT, WX, COH>(vr, li < len, px, B, N, coarse, lcdf, sw_base, lane);
 #pragma unroll
       for (int q = 0; q < PPT; q++) anc[q] = (r == q) ? ar : anc[q];
     }
@@ -872,7 +898,8 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   auto gather = [&](int r) {
 #pragma unroll
     for (int c = 0; c < MP; c++) {  // (padding components re-read the last real one: no branch per load)
-      const double av = kNtGather ? ld32_nt(st_old + (size_t)min(c, m - 1) * N, anc[r]) : ld32(st_old + (size_t)min(c, m - 1) * N, anc[r]);
+      const double av = COH ? ld32_sc1(st_old + (size_t)min(c, m - 1) * N, (uint32_t)anc[r])
+                            : (kNtGather ? ld32_nt(st_old + (size_t)min(c, m - 1) * N, anc[r]) : ld32(st_old + (size_t)min(c, m - 1) * N, anc[r]));
       a[r % ROLL][c] = (c < m) ? av : 0.0;
     }
   };
@@ -941,8 +968,149 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   for (int r = 0; r < PPT; r++) if (v2_li<PPT>(r, tid) >= len) w[r] = -INFINITY;
   v2_block_stats<PPT, WX>(b, ws, f, pb, base, len, tn, w, s_x);
   V2_STAMP(11);
+  return true;
 }
 
+// one launch per time step: the kernel boundary is the grid-wide synchronisation
+template <int MP, int KP, int PPT, bool MS = false, bool WX = false, bool EXACT = false>
+__global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_step_v2(const FilterBatch b, const GridWorkspace ws, const int t) {
+  int pb, f;
+  v2_block_of(ws, pb, f);
+  (void)v2_step_body<MP, KP, PPT, MS, WX, EXACT, false>(b, ws, t, pb, f, true);
+}
+
+
+#ifdef BSSM_XCD_PERSIST
+// ------------------------------------------------------------------------------------------------------------------
+// XCD-RESIDENT PERSISTENT FILTER (round 4; an EXPERIMENT that was measured and NOT kept -- profiles/r04_xcd_persistent.txt:
+// correct and bit-identical to the step kernels, but 0.57x for a single C4 filter and 0.35x at 64 filters in flight; compiled
+// only with -DBSSM_XCD_PERSIST, `make persist` -> ab_persist.so, scripts/xcd_persist_probe.py): the whole time loop of a
+// filter in ONE launch, its B workgroups confined to
+// one XCD and synchronised by a counter in that XCD's L2 instead of by kernel boundaries.
+//
+// Why an XCD: the per-XCD L2s are not coherent with each other, so a grid-wide barrier needs an agent-scope release +
+// acquire per step (4-7 us, MI355X_MICROARCH.md price list) -- more than the 1.5-1.9 us kernel boundary it would replace.
+// Inside one XCD the L2 IS the point of coherence: a producer's plain stores are in it once acknowledged (s_waitcnt
+// vmcnt(0)), and a consumer on another CU of the same XCD sees them through sc1 loads, which bypass only the CU's own vector
+// L1 (v2_step_body<..., COH = true>).  No fences, no L2 write-back, no L1 invalidation per step.
+//
+// Placement is MEASURED, not assumed: every workgroup reads the id of the XCD it actually runs on (HW_REG_XCC_ID) and takes a
+// slot on THAT XCD; B consecutive slots form a team, a team is one filter's B particle blocks.  Teams pull filters from a
+// queue until it is empty.  A team whose slots are not all taken once every workgroup of the grid has registered (an uneven
+// dispatch) simply leaves; its share of the filters is done by the others.  The host sizes the grid to the occupancy of the
+// kernel, so every workgroup is resident from the start; every wait is bounded by a wall-clock timeout that raises the error
+// word instead of hanging the device (the host then falls back to one launch per step).
+struct PersistCtl { unsigned* w; int total, F, f_base; unsigned long long timeout_ticks; int dbg; /* measurement: bit 1 no step body, bit 2 no waiting at the barrier */ };
+
+__device__ __forceinline__ unsigned pc_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned pc_add(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pc_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// all B workgroups of a team: everything each of them stored before is visible to the sc1 loads the others issue after
+__device__ __forceinline__ bool v2_team_barrier(const PersistCtl& ctl, unsigned* bar, const unsigned target, unsigned* s_flag) {
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores have been acknowledged by the L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    pc_add(bar, 1u);
+    unsigned ok = 1u;
+    const unsigned long long t0 = wall_clock64();
+    while (!(ctl.dbg & 4) && (int)(pc_load(bar) - target) < 0) {
+      __builtin_amdgcn_s_sleep(6);
+      if (wall_clock64() - t0 > ctl.timeout_ticks) { pc_store(ctl.w + PC_ERROR, 1u); ok = 0u; break; }
+    }
+    if (pc_load(ctl.w + PC_ERROR) != 0u) ok = 0u;   // another team gave up: leave too
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0u;
+}
+
+// a parameter struct read from device memory through scalar loads (the pointer is wave-uniform; the words land in SGPRs)
+template <class T>
+__device__ __forceinline__ T v2_load_params(const T* p) {
+  typedef __attribute__((address_space(4))) const char cc;
+  T out;
+  __builtin_memcpy(&out, (cc*)(uint64_t)p, sizeof(T));
+  return out;
+}
+
+// One step as a REAL function call (noinline): inlined into the time loop the body's loop invariants -- base addresses, Philox
+// keys, ~90 scalar words of descriptors -- are hoisted in front of the loop and overflow the register files (145 spilt SGPRs,
+// 60 spilt VGPRs however the inputs are disguised); as a function the step has the register allocation of the launch-per-step
+// kernel (2 + 2 spills), and the call costs a few hundred cycles per 10-20 us step.  The descriptors come from device memory
+// through scalar loads, the way a kernel reads its arguments.
+template <int MP, int KP, int PPT, bool MS, bool WX, bool EXACT>
+__device__ __attribute__((noinline)) bool v2_step_call(const FilterBatch* bp, const GridWorkspace* wp, int t, int pb, int f) {
+  bp = uniform_ptr(bp);
+  wp = uniform_ptr(wp);
+  t = __builtin_amdgcn_readfirstlane(t); pb = __builtin_amdgcn_readfirstlane(pb); f = __builtin_amdgcn_readfirstlane(f);
+  const FilterBatch b = v2_load_params(bp);
+  const GridWorkspace ws = v2_load_params(wp);
+  return v2_step_body<MP, KP, PPT, MS, WX, EXACT, true>(b, ws, t, pb, f, false);
+}
+
+// bp / wp: the batch and workspace descriptors in DEVICE memory (behind the control block).  As by-value kernel arguments the
+// compiler loads all of their ~90 scalar words in front of the time loop and keeps them there (they are loop invariants):
+// 145 spilt SGPRs.  Read afresh at the top of every step through a pointer the compiler cannot see through, they live exactly
+// as long as in the launch-per-step kernel.
+template <int MP, int KP, int PPT, bool MS, bool WX, bool EXACT>
+__global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_xcd_persist_v2(const FilterBatch* bp, const GridWorkspace* wp, const PersistCtl ctl, const int B, const int n_steps) {
+  __shared__ unsigned s_ctl[8];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    unsigned xcc;
+    __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const unsigned slot = pc_add(ctl.w + PC_REG + xcc, 1u);
+    pc_add(ctl.w + PC_REGISTERED, 1u);
+    const unsigned team = slot / (unsigned)B, member = slot % (unsigned)B;
+    unsigned ok = 0u;
+    if (team < (unsigned)kPersistMaxTeams) {
+      const unsigned long long t0 = wall_clock64();
+      for (;;) {  // is my team complete?
+        if (pc_load(ctl.w + PC_REG + xcc) >= (team + 1u) * (unsigned)B) { ok = 1u; break; }
+        if (pc_load(ctl.w + PC_REGISTERED) >= (unsigned)ctl.total) { ok = pc_load(ctl.w + PC_REG + xcc) >= (team + 1u) * (unsigned)B ? 1u : 0u; break; }
+        if (wall_clock64() - t0 > ctl.timeout_ticks) break;   // (part of the grid never became resident)
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    s_ctl[0] = xcc; s_ctl[1] = team; s_ctl[2] = member; s_ctl[3] = ok;
+  }
+  __syncthreads();
+  if (s_ctl[3] == 0u) return;
+  math_tab_init();   // once per launch (the step kernels publish the tables through their first barrier, every launch)
+  const unsigned xcc = __builtin_amdgcn_readfirstlane(s_ctl[0]), team = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+  const int pb = __builtin_amdgcn_readfirstlane((int)s_ctl[2]);
+  unsigned* bar = ctl.w + PC_TEAM + (xcc * kPersistMaxTeams + team) * kPersistLine;
+  unsigned* team_f = bar + 16;
+  unsigned gen = 0u;
+  for (;;) {
+    if (pb == 0 && tid == 0) pc_store(team_f, pc_add(ctl.w + PC_HEAD, 1u));   // the team's leader takes the next filter
+    if (!v2_team_barrier(ctl, bar, ++gen * (unsigned)B, &s_ctl[4])) return;
+    if (tid == 0) s_ctl[5] = pc_load(team_f);
+    __syncthreads();
+    const unsigned fq = __builtin_amdgcn_readfirstlane(s_ctl[5]);
+    if (fq >= (unsigned)ctl.F) return;
+    const int f = ctl.f_base + (int)fq;
+    for (int t = 0; t < n_steps; t++) {
+      const bool alive = (ctl.dbg & 2) ? true : v2_step_call<MP, KP, PPT, MS, WX, EXACT>(bp, wp, t, pb, f);
+      if (!v2_team_barrier(ctl, bar, ++gen * (unsigned)B, &s_ctl[4])) return;
+      if (!alive) break;   // degenerate weights: every workgroup of the filter takes this exit at the same step
+    }
+    if (pb == 0 && tid == 0) pc_add(ctl.w + PC_DONE, 1u);
+  }
+}
+
+template <int MP, int KP, int PPT, bool MS>
+inline auto v2_persist_kernel(bool wx, bool exact) -> void (*)(const FilterBatch*, const GridWorkspace*, const PersistCtl, const int, const int) {
+  // instantiated where it can pay: complete blocks (EXACT), the 4- and 8-dimensional shapes of the BASELINE configurations
+  if constexpr ((MP == 8 && KP == 8 && MS && PPT <= 2) || (MP == 4 && KP == 4 && !MS)) {
+    if (exact) return wx ? pf_xcd_persist_v2<MP, KP, PPT, MS, true, true> : pf_xcd_persist_v2<MP, KP, PPT, MS, false, true>;
+  }
+  return nullptr;
+}
+
+#endif  // BSSM_XCD_PERSIST
 
 template <int MP, int KP, int PPT, bool MS>
 inline auto v2_step_kernel(bool wx, bool exact) -> void (*)(const FilterBatch, const GridWorkspace, const int) {

@@ -46,6 +46,12 @@ int wg_filter_capacity(int MP);
 hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream);
 
 // Multi-workgroup filter for large N: workspace + per-time-step launches.
+// control block of the XCD-resident persistent step kernel (pf_grid_v2.h): word offsets
+constexpr int kPersistMaxTeams = 64;   // teams per XCD
+constexpr int kPersistLine = 32;       // words per 128-byte line: every team's barrier counter and mailbox sit in a line of their own
+enum { PC_REG = 0 /* [8] workgroups registered per XCD */, PC_REGISTERED = 8, PC_HEAD = 9 /* next filter */, PC_ERROR = 10,
+       PC_DONE = 11 /* filters completed */, PC_TEAM = 32 /* [8][kPersistMaxTeams] lines: word 0 barrier counter, word 16 the team's filter */,
+       kPersistWords = 32 + 8 * kPersistMaxTeams * kPersistLine };
 struct GridWorkspace {
   double* state[2];    // [F][m][N] ping-pong when no history is kept
   double* lcdf;        // [2][F][N] block-local inclusive scans of exp(w - max_b)
@@ -69,6 +75,7 @@ struct GridWorkspace {
   // -- 16 of the 104 bytes a particle-step moved disappear (the owner's read of its exchanged weights and the second write).
   int fw;
   double* wscale;      // [F][n+1][B]
+  unsigned* persist;   // [kPersistWords] control block of the XCD-resident persistent kernel (zeroed before every launch)
   hipStream_t side;    // the library's side stream for the second launch sequence (one per host thread); null = none
 };
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out);
@@ -81,6 +88,7 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
 struct StepTiming {
   int every = 0; int count = 0; double total_ms = 0.0; int concurrent = 1;  // concurrent: launch sequences in flight
   int factored = 0;  // 1: the weights output of this run is in factored form (GridWorkspace::fw was granted)
+  int persistent = 0;  // > 0: teams of the XCD-resident persistent kernel that ran the batch; -1: it was tried and left for the step kernels
   int progress_every = 0, progress_count = 0;
   static constexpr int kMaxProgress = 64;
   hipEvent_t progress_events[kMaxProgress] = {};
