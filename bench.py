@@ -35,12 +35,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # fp64 VALU issue roof: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles (16 lanes per clock) at 2.4 GHz
 VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 # wave-level VALU instructions per particle-step of the workgroup-resident kernels, from the PMC passes committed under
-# profiles/r03_pmc_*.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_r03.sh, profile_r03_wg.sh)
-REGB_VALU_PER_PSTEP = 9940959411.4 / (512 * 2048 * 1000.0)    # pf_wg_kernel<4,4,4,false,512> (profiles/r03_pmc_regb.txt)
-C5_VALU_PER_PSTEP = 18125027041.0 / (2340.0 * 4096 * 300.0)   # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), one dispatch of 2 340 draws (profiles/r03_pmc_C5.txt)
+# profiles/r04_pmc_*.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_r04.sh; regime B: profiles/r04_pmc_regb.txt)
+REGB_VALU_PER_PSTEP = 9588020533.1 / (512 * 2048 * 1000.0)    # pf_wg_kernel<4,4,4,false,512> (profiles/r04_pmc_regb.txt; round 3: 9.94e9)
+C5_VALU_PER_PSTEP = 18125027041.0 / (2340.0 * 4096 * 300.0)   # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), one dispatch of 2 340 draws (profiles/r04_pmc_C5.txt)
 C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1,exact>"
-HEAD_VALU_PER_PSTEP = 8360000.0 / (16 * 65536.0)                # pf_grid_step_v2<4,4,4,false,true,true>: 8.36 M per launch of 16 filters x 65 536 particles (profiles/r03_pmc_sq1_summary.txt)
-C4_VALU_PER_PSTEP = 7137180.9 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r03_pmc_C4.txt)
+HEAD_VALU_PER_PSTEP = 7798567.3 / (16 * 65536.0)                # pf_grid_step_v2<4,4,4,false,true,true>: 7.80 M per launch of 16 filters x 65 536 particles (profiles/r04_pmc_sq1_summary.txt; round 3: 8.36 M)
+C4_VALU_PER_PSTEP = 6540006.7 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r04_pmc_C4.txt; round 3: 7.14 M)
 
 
 def valu_roofline(valu_per_pstep, psteps_per_s, kernel, clock=None):
@@ -48,7 +48,7 @@ def valu_roofline(valu_per_pstep, psteps_per_s, kernel, clock=None):
     out = {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
            "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
            "lane_instr_per_particle_step": valu_per_pstep * 64,
-           "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r03_pmc_sq1_summary.txt, r03_pmc_C4.txt, r03_pmc_C5.txt, r03_pmc_regb.txt); rate: measured live"}
+           "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r04_pmc_sq1_summary.txt, r04_pmc_C4.txt, r04_pmc_C5.txt, r04_pmc_regb.txt); rate: measured live"}
     if clock and clock.get("sclk_mhz"):
         # the issue roof at the engine clock the kernel actually ran at (the socket power limit holds it under 2.4 GHz)
         out["frac_at_sampled_clock"] = a / (256 * 4 * clock["sclk_mhz"] * 1e6 / 4)
@@ -102,11 +102,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def pmc_traffic(R, N, ppt, kernel, factored):
-    """HBM bytes per pf_grid_step launch from the PMC passes committed for THIS round's kernel (profiles/r03_pmc_traffic*.json:
+    """HBM bytes per pf_grid_step launch from the PMC passes committed for THIS round's kernel (profiles/r04_pmc_traffic*.json:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this script by scripts/profile_r03.sh, corrected as MI355X_MICROARCH.md
     prescribes and calibrated on calib_copy_kernel's known byte count in the same process); None unless the profile was
     taken on exactly this workload, kernel variant and weights layout (a counter pass cannot run inside a timed run)."""
-    name = "r03_pmc_traffic.json" if factored else "r03_pmc_traffic_reference_layout.json"
+    name = "r04_pmc_traffic.json" if factored else "r04_pmc_traffic_reference_layout.json"
     try:
         p = json.load(open(os.path.join(ROOT, "profiles", name)))
         same_kernel = p["kernel"].replace(" ", "").endswith(kernel.replace(" ", ""))
@@ -603,7 +603,7 @@ def main():
         achieved = seqs * bytes_per_launch / (k_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R // seqs, N, ppt, plan.last_kernel(), layout["factored"]),
-                           "traffic_source": "profiles/r03_pmc_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script at this kernel)" % ("" if layout["factored"] else "_reference_layout"),
+                           "traffic_source": "profiles/r04_pmc_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script at this kernel)" % ("" if layout["factored"] else "_reference_layout"),
                            "kernel": plan.last_kernel(), "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
                            "concurrent_launches": seqs, "filters_per_launch": R // seqs,
                            "wall_per_launch_us": ms_per_step * 1e3 / (T + 1) / seqs,

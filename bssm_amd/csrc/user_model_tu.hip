@@ -2,7 +2,7 @@
 //
 // bssm's ssm_nlg / ssm_sde models are user C++ compiled at run time (Rcpp::sourceCpp) and called through function
 // pointers (src/model_ssm_nlg.h:10-21, src/model_ssm_sde.h:8-11).  Device code cannot call host pointers, so here the
-// user's snippet of __device__ functions is compiled INTO the filter kernels: bssm_user_model_build() (api.cpp) compiles this
+// user's snippet of __device__ functions is compiled INTO the filter kernels: bssm_user_model_build() (api_filters.cpp) compiles this
 // file SIX times side by side, one part per (sampler, kernel family) (-DBSSM_USER_PART=0...5: sampler = part % 3 -- bootstrap,
 // psi-APF, EKF particle filter --, family = part / 3 -- workgroup-resident, step kernels; 4-8 s each instead of ~27 s in a row),
 //   hipcc -O3 -std=c++17 -fPIC -c --offload-arch=gfx950 -I<csrc> -DBSSM_USER_M=<pad(m)> -DBSSM_USER_NSTATES=<m>

@@ -142,7 +142,7 @@ def test_c5_post_correct_tail_round_through_the_step_kernels(monkeypatch):
     DEFAULT (round 4): every draw stays workgroup-resident, so a draw's result does not depend on how the job is cut -- the whole
     job, two blocks of 150 (what two GPUs would filter) and the in-library two-shard call agree BIT FOR BIT although only the
     first has a sparsely filled last round.  OPT-IN (BSSM_AMD_TAIL_SPLIT=1): the 44 go through the step kernels behind the full
-    round (api.cpp run_is_core; profiles/r03_c5_tail_round.txt) -- same Philox streams, log-weights equal to reduction-order
+    round (api_postcorrect.cpp run_is_core; profiles/r03_c5_tail_round.txt) -- same Philox streams, log-weights equal to reduction-order
     rounding, the draws that kept their kernel family bit for bit."""
     rng = np.random.default_rng(106)
     n, K, dT = 300, 500.0, 0.1
