@@ -423,8 +423,11 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
   }
 }
 
+// 16 live state doubles per lane (m = 4 at four particles per lane: the headline shape).  Five waves per SIMD since round 4: with
+// the PACKED random stream the kernel fits 96 VGPRs without a spill (round 2 needed three tricks to get there and gained 0.6 %);
+// same-box A/B 5.58 -> 5.74e10 particle-steps/s, +3.0 % (profiles/r04_ab_occ5.txt).  LDS: 5 x 27 KB per CU.
 #ifndef BSSM_V2_OCC16
-#define BSSM_V2_OCC16 4
+#define BSSM_V2_OCC16 5
 #endif
 #ifndef BSSM_V2_OCC_MS16
 #define BSSM_V2_OCC_MS16 4   // MP = 8, two particles per lane: 128 VGPRs with 5 spilled beat 132 at three waves (C4, 64 filters: +4 ... +7 %)
@@ -432,8 +435,12 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
 #ifndef BSSM_V2_OCC_MS32
 #define BSSM_V2_OCC_MS32 3   // MP = 8, four particles per lane (weights fused into the particle loop)
 #endif
+#ifndef BSSM_V2_OCC_MS8
+#define BSSM_V2_OCC_MS8 4    // MP = 8, one particle per lane
+#endif
 constexpr int v2_occupancy(int mp, int ppt, bool ms = false) {
   if (ms && mp * ppt == 16) return BSSM_V2_OCC_MS16;
+  if (ms && mp * ppt == 8) return BSSM_V2_OCC_MS8;
   if (ms && ppt >= 4) return mp * ppt >= 32 ? BSSM_V2_OCC_MS32 : 4;
   const int live = mp * ppt * (ms && mp * ppt > 8 ? 2 : 1);  // the multi-series variants keep the new states until the density
   return live <= 4 ? 5 : (live <= 8 ? 4 : (live <= 16 ? BSSM_V2_OCC16 : (live <= 32 ? 3 : 2)));
