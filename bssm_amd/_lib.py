@@ -31,8 +31,8 @@ class FnModel(C.Structure):
                 ("known_params", c_double_p), ("n_known", C.c_int32), ("x0", C.c_double), ("positive", C.c_int32),
                 ("L", C.c_int32), ("user_slot", C.c_int32), ("n_states", C.c_int32), ("H", C.c_double),
                 ("R_diag", C.c_double * 2), ("a1", C.c_double * 2), ("P1", C.c_double * 4),
-                ("use_ext", C.c_int32), ("n_etas", C.c_int32), ("R_ext", C.c_double * 16), ("a1_ext", C.c_double * 4),
-                ("P1_ext", C.c_double * 16), ("known_tv_params", c_double_p), ("tv_rows", C.c_int32), ("tv_cols", C.c_int32)]
+                ("use_ext", C.c_int32), ("n_etas", C.c_int32), ("R_ext", C.c_double * 64), ("a1_ext", C.c_double * 8),
+                ("P1_ext", C.c_double * 64), ("known_tv_params", c_double_p), ("tv_rows", C.c_int32), ("tv_cols", C.c_int32)]
 
 
 def pack_fn_model(model, L=None):
@@ -66,7 +66,7 @@ def fill_user_numbers(s, model, theta):
     s.H = float(val("H"))
     a1 = np.asarray(val("a1"), dtype=float).reshape(-1)[:m]
     P1 = np.asarray(val("P1"), dtype=float).reshape(m, m)
-    if model.get("R") is not None or m > 2:  # any m x k matrix R, up to 4 states (bootstrap paths)
+    if model.get("R") is not None or m > 2:  # any m x k matrix R, up to 8 states (bootstrap paths; psi-APF / EKPF up to 4)
         k = int(model.get("n_etas", m))
         R = np.asarray(val("R"), dtype=float).reshape(m, k) if model.get("R") is not None else np.diag(np.asarray(val("R_diag"), dtype=float).reshape(-1)[:m])
         s.use_ext, s.n_etas = 1, R.shape[1]

@@ -244,11 +244,11 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
   }
 }
 
-// functor-model (FN) kernel shapes: the shipped models have 1 or 2 states; a run-time compiled user model may have up to 4.
+// functor-model (FN) kernel shapes: the shipped models have 1 or 2 states; a run-time compiled user model may have up to 8.
 // fn_kernel_id<MP>(): the model id the functor kernels of this translation unit are compiled for (FN_ANY: dispatch per
 // call) -- a user-model library holds ONE model, and the only shipped two-state model is nlg_growth.
 #ifdef BSSM_USER_MODEL
-constexpr int FN_MP_MAX = 4;
+constexpr int FN_MP_MAX = 8;   // (bootstrap paths up to 8 states since round 4; the psi-APF and the EKF particle filter up to 4)
 #if defined(BSSM_USER_NLG) && !defined(BSSM_USER_SDE)
 template <int MP> constexpr int fn_kernel_id() { return FN_USER_NLG; }
 #elif defined(BSSM_USER_SDE) && !defined(BSSM_USER_NLG)

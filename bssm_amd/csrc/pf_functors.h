@@ -45,12 +45,14 @@ __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || i
 // for; a 3-state model leaves the fourth component alone) and R any m x k matrix, k <= m (bootstrap filter / smoother /
 // bootstrap IS correction; psi-APF and EKF particle filter: up to 4 states, any constant R, or a state-dependent R_fn / H_fn).
 // per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser,
-// user slot, number of states, full R (MP x MP, column-major, zero-padded; user models)
+// user slot, number of states, known_tv_params, full R (MP x MP, column-major, zero-padded; user models), inverse factor of R R'
 enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, FP_H = 20, FP_R = 21, FP_LOGC = 23, FP_SLOT = 24 /* user-model registry slot (host only) */,
-       FP_M = 25, FP_RMAT = 26,
-       // user models with BSSM_USER_TV: the known_tv_params matrix (device pointer as a bit pattern; rows, columns), and the
-       // inverse lower factor of R R' for the psi-APF's transition-density ratio with any constant R (MP x MP, column-major)
-       FP_TVPTR = 42, FP_TVROWS = 43, FP_TVCOLS = 44, FP_RLINV = 46, FP_SIZE = 62 };
+       FP_M = 25,
+       // user models with BSSM_USER_TV: the known_tv_params matrix (device pointer as a bit pattern; rows, columns)
+       FP_TVPTR = 26, FP_TVROWS = 27, FP_TVCOLS = 28,
+       // full R (MP x MP, column-major, zero-padded; user models: up to 8 x 8 since round 4) and the inverse lower factor of
+       // R R' for the psi-APF's transition-density ratio with any constant R (MP x MP, column-major; psi-APF: MP <= 4)
+       FP_RMAT = 30, FP_RLINV = 94, FP_SIZE = 158 };
 
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_TV)
 template <class PF>

@@ -180,7 +180,7 @@ typedef struct bssm_fn_model {
   int32_t L;                  /* ssm_sde: 2^L Milstein sub-steps per unit time */
   /* ---- user-defined models only (model_id BSSM_FN_USER_NLG / BSSM_FN_USER_SDE); ignored for the built-in ids */
   int32_t user_slot;          /* from bssm_user_model_load */
-  int32_t n_states;           /* ssm_nlg: 1 ... 4 */
+  int32_t n_states;           /* ssm_nlg: 1 ... 8 (bootstrap filter / smoother / bootstrap IS correction; psi-APF and EKF particle filter: 1 ... 4) */
   double H;                   /* ssm_nlg: observation sd (the value H_fn returns; unused when the snippet defines BSSM_USER_HFN) */
   double R_diag[2];           /* ssm_nlg: diagonal of R_fn's value (n_states <= 2, diagonal R) */
   double a1[2], P1[4];        /* ssm_nlg: a1_fn, P1_fn values (P1 column-major, n_states x n_states), n_states <= 2 */
@@ -188,9 +188,9 @@ typedef struct bssm_fn_model {
    * R_diag / a1 / P1 when use_ext != 0; required for n_states > 2 */
   int32_t use_ext;
   int32_t n_etas;             /* columns of R, 1 ... n_states */
-  double R_ext[16];           /* R_fn's value, n_states x n_etas column-major (the bootstrap kernels call the snippet's
+  double R_ext[64];           /* R_fn's value, n_states x n_etas column-major (the bootstrap kernels call the snippet's
                                  bssm_user_R instead when it defines BSSM_USER_RFN) */
-  double a1_ext[4], P1_ext[16]; /* a1_fn, P1_fn values; P1 any positive semi-definite n_states x n_states matrix */
+  double a1_ext[8], P1_ext[64]; /* a1_fn, P1_fn values; P1 any positive semi-definite n_states x n_states matrix */
   /* ---- the reference's `known_tv_params` (R/models.R:1507, 1546; every model function receives it together with the
    * time index, src/model_ssm_nlg.h:10-21): any matrix, column-major, tv_rows x tv_cols.  Read by user models whose
    * snippet defines BSSM_USER_TV (its functions then take a leading `const bssm_user_tv&`); NULL / 0 / 0 otherwise */

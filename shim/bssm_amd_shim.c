@@ -619,14 +619,14 @@ static void fn_identity(SEXP first_ptr, int n_states, int sde, bssm_fn_model* f)
     read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_R_diag")), f->R_diag, 2);
     read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_a1")), f->a1, 2);
     read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_P1")), f->P1, 4);
-    /* wider models (up to 4 states, any n_states x n_etas matrix R; bootstrap paths): attr "bssm_amd_R" = R_fn's value */
+    /* wider models (up to 8 states, any n_states x n_etas matrix R; bootstrap paths): attr "bssm_amd_R" = R_fn's value */
     SEXP Rm = Rf_getAttrib(first_ptr, Rf_install("bssm_amd_R"));
     if (Rm != R_NilValue || n_states > 2) {
       f->use_ext = 1;
       f->n_etas = Rm != R_NilValue ? Rf_length(Rm) / n_states : n_states;
-      read_numbers(Rm, f->R_ext, 16);
-      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_a1")), f->a1_ext, 4);
-      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_P1")), f->P1_ext, 16);
+      read_numbers(Rm, f->R_ext, 64);
+      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_a1")), f->a1_ext, 8);
+      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_P1")), f->P1_ext, 64);
     }
   }
 }

@@ -832,3 +832,53 @@ def test_user_model_state_dependent_noise_post_correct_at_the_mode(oracle, monke
     for i in range(ns):
         ref = oracle.nlg_general_psi(y, m, k, theta[i], kn, a1, P1, nsim=N, seed=9, stream=i, is_mode=modes[:, i], **fns, **jac)
         assert abs(out["loglik"][i] - ref["logLik"]) <= 1e-9 * n, (i, out["loglik"][i], ref["logLik"])
+
+
+# ---------------------------------------------------------------- round 4: user models with more than four states (bootstrap paths)
+USER_SIX = r"""
+#define BSSM_USER_NLG 1
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  out[0] = a[0] + a[1]; out[1] = 0.9 * a[1] + 0.1 * sin(a[2]); out[2] = th[0] * a[2] + 0.05 * a[3];
+  out[3] = 0.8 * a[3] - 0.1 * a[4]; out[4] = 0.7 * a[4] + 0.2 * tanh(a[5]); out[5] = 0.5 * a[5];
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + 0.5 * a[2] + 0.1 * a[5] * a[5]; }
+"""
+
+
+@pytest.mark.parametrize("path,N", [("wg", 200), ("wg", 1200), ("grid", 4000)])
+def test_user_model_six_states_bootstrap_against_the_general_oracle(oracle, monkeypatch, path, N):
+    """A user model with SIX states and a constant 6 x 4 matrix R (the MP = 8 functor kernels; the reference's function-pointer
+    interface has no state limit, src/model_ssm_nlg.h:10-21): bootstrap filter and smoother against orc_nlg_general_bsf_filter --
+    ancestors identical, log-likelihood to 1e-9 n, states and weights to 1e-9 / 1e-8; the psi-APF and the EKF particle filter stay
+    at four states and say so."""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    rng = np.random.default_rng(12)
+    n, m, k = 30, 6, 4
+    th = np.array([0.85]); kn = np.zeros(0)
+    Rm = np.zeros((m, k)); Rm[0, 0] = 0.05; Rm[1, 0] = 0.02; Rm[2, 1] = 0.3; Rm[3, 1] = -0.1; Rm[3, 2] = 0.2; Rm[4, 2] = 0.1; Rm[5, 3] = 0.4
+    Z = lambda t, a, th_, kn_: a[0] + 0.5 * a[2] + 0.1 * a[5] ** 2
+    H = lambda t, a, th_, kn_: 0.6
+    T = lambda t, a, th_, kn_: np.array([a[0] + a[1], 0.9 * a[1] + 0.1 * np.sin(a[2]), th_[0] * a[2] + 0.05 * a[3], 0.8 * a[3] - 0.1 * a[4],
+                                         0.7 * a[4] + 0.2 * np.tanh(a[5]), 0.5 * a[5]])
+    R = lambda t, a, th_, kn_: Rm
+    a = np.array([1.0, 0.05, 0.3, -0.2, 0.1, 0.4]); y = np.zeros(n)
+    for t in range(n):
+        y[t] = Z(t, a, th, kn) + 0.6 * rng.normal()
+        a = T(t, a, th, kn) + Rm @ rng.normal(size=k)
+    y[9] = np.nan
+    a1 = np.array([1.0, 0.0, 0.3, 0.0, 0.0, 0.4])
+    P1 = np.diag([0.5, 0.01, 0.2, 0.1, 0.0, 0.3]); P1[0, 2] = P1[2, 0] = 0.1
+    u = M.ssm_nlg_user(y, USER_SIX, theta=th, known_params=kn, a1=a1, P1=P1, H=0.6, n_states=m, R=Rm)
+    out = F.bootstrap_filter(u, N, seed=7, return_indices=True)
+    ref = oracle.nlg_general_bsf_filter(y, m, k, th, kn, a1, P1, Z, H, T, R, N, seed=7)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    sm = F.particle_smoother(u, N, method="bsf", seed=7)
+    assert abs(sm["logLik"] - ref["logLik"]) <= 1e-9 * n
+    ah, Vt = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert _rel(sm["alphahat"], ah.T[:n]) <= 1e-8 and _rel(sm["Vt"], Vt[:, :, :n]) <= 1e-7
+    if path == "wg" and N == 200:
+        with pytest.raises(Exception, match="at most 4 states|Jacobians|BSSM_USER_JACOBIANS"):
+            F.particle_smoother(u, N, method="psi", seed=7)
