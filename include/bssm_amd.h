@@ -317,8 +317,10 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
  * (`devices[r]`, HIP ordinals; NULL / 0 = every visible device) and runs the single-device driver, and the per-draw
  * weights / log-likelihoods are exchanged by ONE ncclAllGather (RCCL over xGMI, communicators from ncclCommInitAll,
  * librccl opened lazily with dlopen).  The same ordinal may be listed more than once (logical shards on one GPU; the
- * exchange is then plain device copies).  Streams are keyed by the global draw index, so the outputs are bit-identical
- * to the single-device call for any device list.  `job->n_threads` host threads are divided between the shards.
+ * exchange is then plain device copies).  Streams are keyed by the global draw index and every draw runs in the same kernel
+ * family however the job is cut, so the outputs are bit-identical to the single-device call for any device list (unless the
+ * process opted into BSSM_AMD_TAIL_SPLIT=1, which sends a sparsely filled last round of a shard through the step kernels:
+ * faster, equal to reduction-order rounding only).  `job->n_threads` host threads are divided between the shards.
  * Arguments and outputs otherwise as bssm_is_correction / bssm_is_correction_nlg. */
 int bssm_is_correction_multi(const bssm_is_job* job, const int32_t* devices, int32_t n_devices, double* weights,
                              double* loglik, double* alpha, double* alphahat_i, double* Vt_i);

@@ -42,6 +42,12 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     sp = out["post_correct_single_process"]
     assert "error" not in sp, sp
     assert sp["devices"] == [0, 0] and sp["identical_weights"] and sp["gather"] == "device_copies"
+    # the strong-scaling evidence at the top level (round 4): both jobs, the communicator's facts, the one-GPU reference
+    sc = out["post_correct_scaling"]
+    assert sc["scaling"] == "strong" and sc["n_gpus"] == 2 and sc["distinct_gpus"] == 1 and "r04_post_correct_n1.json" in sc["n1_source"]
+    for job in ("C5", "C5_x8_draws"):
+        assert sc[job]["seconds"] > 0 and sc[job]["particle_steps_per_s"] > 0 and sc[job]["seconds_n1"] > 0
+        assert abs(sc[job]["speedup_vs_n1"] - sc[job]["seconds_n1"] / sc[job]["seconds"]) < 1e-12
 
 
 def test_bench_single_rank_line_has_the_contract_fields():
@@ -52,3 +58,21 @@ def test_bench_single_rank_line_has_the_contract_fields():
         assert k in out
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert out["post_correct"]["per_rank_ms"][0]["draws"] == 96
+    # what `value` was quoted on, and the same batch in the reference's weights layout / on the other observed series
+    assert out["config"]["series"] == "informative" and "weights layout of `value`" in out["config"]["workload"]
+    for key in ("roofline_reference_layout", "other_series"):
+        assert out[key]["value"] > 0 and 0 < out[key]["frac"] < 1
+    assert out["roofline_reference_layout"]["weights_layout_factored"] is False and out["other_series"]["series"] == "model"
+    assert out["post_correct_scaling"]["n1_source"] == "this run" and out["post_correct_scaling"]["C5"]["speedup_vs_n1"] == 1.0
+
+
+def test_bench_accuracy_object_checks_every_pair_with_the_following_oracle():
+    """the metric's second half on a small instance of the timed plan: every (seed, slot) pair re-run by the tie-following oracle"""
+    out = _run_bench(["--steps", "1", "--warmup", "1", "--replicas", "4", "--T", "40", "--particles", "8192", "--no-dropin", "--no-mng",
+                      "--no-regime-b", "--no-single", "--no-post-correct", "--no-side-runs", "--no-clock"])
+    acc = out["accuracy"]
+    assert acc["device_pairs"] == 8 and acc["oracle_checked_pairs"] == 8
+    assert acc["unexplained_ancestor_differences"] == 0 and acc["ancestor_tables_identical_after_following"] == 8
+    assert acc["loglik_rmse_vs_cpu_same_seeds"] <= 1e-9 * 40 and acc["weighted_state_means_max_rel_diff"] <= 1e-9
+    assert acc["pairs_without_a_tie"] + acc["pairs_with_ties"] == 8 and acc["loglik_sd_of_the_estimator_across_streams"] > 0
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] == 1
