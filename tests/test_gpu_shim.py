@@ -318,3 +318,60 @@ def test_nongaussian_is_mcmc_through_the_shim(R):
     assert np.array_equal(out["weights"], ref["weights"]) and np.array_equal(out["posterior"], ref["posterior"])
     assert out["acceptance_rate"][0] == ref["acceptance_rate"] and np.array_equal(np.tril(out["S"]), np.tril(ref["S"]))
     assert out["modes"].shape == (1, mdl.n, out["counts"].size)
+
+
+def test_nonlinear_and_sde_is_mcmc_and_the_sde_state_sampler_through_the_shim(R):
+    """The last three registered stubs.  .Call('_bssm_nonlinear_is_mcmc', <34>) (src/R_mcmc.cpp:736-832),
+    .Call('_bssm_sde_is_mcmc', <24>) (src/R_sde.cpp:221-290) and .Call('_bssm_sde_state_sampler_bsf_is2', <13>)
+    (src/R_sde_state_sampler.cpp:10-50) against run_mcmc / is_correction of the Python mirror: the same library calls with the
+    same seeds, so theta, counts, weights, posterior, S and the acceptance rate must be equal bit for bit.  The log prior is
+    an R function here (attr(log_prior_pdf, 'bssm_amd_prior_fn'): INTEGRATION.md) -- a Python callable behind the mock."""
+    from bssm_amd import mcmc
+    g = _growth(n=40)
+    prior = M.example_log_prior("nlg_growth")
+    it, burn, nsim, seed = 300, 150, 16, 31
+    ref = mcmc.run_mcmc(g, iter=it, particles=nsim, output_type="theta", mcmc_type="is2", sampling_method="psi", burnin=burn, seed=seed)
+    th0 = np.asarray(g["theta"], dtype=float)
+    S0 = np.diag(0.1 * np.maximum(0.1, np.abs(th0)))
+    a = _nlg_args(R, g, prior=lambda th: float(prior(th)))
+    # (y, Z, H, T, R, Zg, Tg, a1, P1, theta, log_prior_pdf, known_params, known_tv_params, time_varying, n_states, n_etas, seed, nsim, iter,
+    #  burnin, thin, gamma, target_acceptance, S, end_ram, n_threads, is_type, sampling_method, max_iter, conv_tol, iekf_iter, output_type,
+    #  approx, verbose)
+    out = R.call("_bssm_nonlinear_is_mcmc", *a[:13], a[15], a[13], a[14], seed, nsim, it, burn, 1, 2 / 3, 0.234, S0, False, 1, 2, 1, 100,
+                 1e-8, 0, 3, False, False)
+    _after(R)
+    assert list(out) == ["theta", "weights", "counts", "acceptance_rate", "S", "posterior", "modes"]
+    assert np.array_equal(out["theta"], ref["theta"]) and np.array_equal(out["counts"], ref["counts"].astype(float))
+    assert np.array_equal(out["weights"], ref["weights"]) and np.array_equal(out["posterior"], ref["posterior"])
+    assert out["acceptance_rate"][0] == ref["acceptance_rate"] and np.array_equal(np.tril(out["S"]), np.tril(ref["S"]))
+    assert out["modes"].shape == (2, g.n, out["counts"].size)
+
+    rng = np.random.default_rng(8)
+    n = 24
+    y = np.exp(np.cumsum(rng.normal(0.01, 0.05, n)))
+    sde = M.ssm_sde(y, "sde_gbm", theta=np.array([0.02, 0.2, 0.6]), x0=1.0, positive=True)
+    sprior = M.example_log_prior("sde_gbm")
+    drift = R.extptr(bssm_amd_model_id=np.asarray([sde["model_id"]], dtype=np.int32))
+    lp = R.extptr(bssm_amd_prior_fn=lambda th: float(sprior(th)))
+    sargs = [y, 1.0, True, drift, R.extptr(), R.extptr(), lp, R.extptr()]
+    th0 = np.asarray(sde["theta"], dtype=float)
+    S0 = np.diag(0.1 * np.maximum(0.1, np.abs(th0)))
+    it, burn, nsim, seed = 200, 100, 32, 5
+    ref = mcmc.run_mcmc(sde, iter=it, particles=nsim, output_type="theta", mcmc_type="is2", burnin=burn, seed=seed, L_c=2, L_f=4)
+    # (<8>, theta, nsim, L_c, L_f, seed, iter, burnin, thin, gamma, target_acceptance, S, end_ram, is_type, n_threads, type, verbose)
+    out = R.call("_bssm_sde_is_mcmc", *sargs, th0, nsim, 2, 4, seed, it, burn, 1, 2 / 3, 0.234, S0, False, 2, 1, 3, False)
+    _after(R)
+    assert list(out) == ["theta", "weights", "counts", "acceptance_rate", "S", "posterior"]          # no `modes` (src/R_sde.cpp:262-285)
+    assert np.array_equal(out["theta"], ref["theta"]) and np.array_equal(out["counts"], ref["counts"].astype(float))
+    assert np.array_equal(out["weights"], ref["weights"]) and np.array_equal(out["posterior"], ref["posterior"])
+    assert out["acceptance_rate"][0] == ref["acceptance_rate"]
+    # the state sampler: bootstrap IS2 correction with one trajectory per stored theta
+    ns = ref["theta"].shape[0]
+    fine = M.BssmModel(sde.classes, **{**sde, "L": 4})
+    r = PC.is_correction(fine, ref["theta"], np.ones(ns, dtype=np.uint32), nsim, method="bsf", approx_loglik=ref["approx_loglik"], is_type=2,
+                         output_type=1, seed=seed, threads=1)
+    # (<8>, nsim, L_f, seed, approx_loglik_storage, theta n_par x n_stored)
+    st = R.call("_bssm_sde_state_sampler_bsf_is2", *sargs, nsim, 4, seed, ref["approx_loglik"], ref["theta"].T)
+    _after(R)
+    assert list(st) == ["alpha", "weights"]
+    assert np.array_equal(st["weights"], r["weights"]) and np.array_equal(st["alpha"], r["alpha"])
