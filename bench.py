@@ -117,6 +117,61 @@ def pmc_traffic(R, N, ppt, kernel, factored):
     return None
 
 
+def live_pmc_traffic(args, kernel, layout_factored, timeout=150):
+    """HBM bytes per launch of the dominant kernel, MEASURED during this run: two short `rocprofv3 --pmc` passes of this very
+    script (FETCH_SIZE, then WRITE_SIZE -- separate passes, as MI355X_MICROARCH.md prescribes; one timed step of the same batch, nothing
+    else), the gfx950 FETCH_SIZE factor calibrated in the same process on calib_copy_kernel (2 GiB read + 2 GiB written).  Outside
+    every timed region.  None when rocprofv3 is missing, a pass fails or takes too long (the committed profile value is used then)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--replicas", str(args.replicas), "--particles",
+            str(args.particles), "--T", str(args.T), "--series", args.series, "--no-cpu-baseline", "--no-single", "--no-regime-b",
+            "--no-post-correct", "--no-dropin", "--no-accuracy", "--no-side-runs", "--no-clock", "--no-mng", "--no-live-pmc"]
+    if not layout_factored:
+        base.append("--reference-weights-layout")
+    env = dict(os.environ, BSSM_BENCH_CALIB="1", TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="bssm_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, ctr)
+            cp = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", out_dir, "--"] + base, cwd="/tmp", env=env,
+                                capture_output=True, text=True, timeout=timeout)
+            if cp.returncode != 0:
+                return None
+            acc = {}
+            for path in glob.glob(out_dir + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    a = acc.setdefault(row["Kernel_Name"].split("(")[0], [0.0, 0])
+                    a[0] += float(row["Counter_Value"]); a[1] += 1
+            step = [k for k in acc if kernel.replace(" ", "") in k.replace(" ", "")]
+            cal = [k for k in acc if "calib_copy" in k]
+            if not step or not cal:
+                return None
+            got[ctr] = (acc[step[0]][0] / acc[step[0]][1], acc[cal[0]][0] / acc[cal[0]][1], acc[step[0]][1])
+    except Exception:  # noqa: BLE001 -- a measurement aid: never fails the benchmark
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    known = float((1 << 28) * 8)
+    rf = known / (got["FETCH_SIZE"][1] * 1024.0)
+    wf = known / (got["WRITE_SIZE"][1] * 1024.0)
+    wf_used = 1.0 if abs(wf - 1.0) < 0.05 else wf
+    rd, wr = got["FETCH_SIZE"][0] * 1024.0 * rf, got["WRITE_SIZE"][0] * 1024.0 * wf_used
+    return {"hbm_bytes_per_launch": rd + wr, "read": rd, "written": wr, "read_factor_calibrated": rf, "write_factor_measured": wf,
+            "launches_sampled": int(min(got["FETCH_SIZE"][2], got["WRITE_SIZE"][2]))}
+
+
 def _c5_job(ns):
     """ssm_nlg growth model, T = 300, m = 2; `ns` retained draws around theta-hat"""
     import numpy as np
@@ -479,6 +534,7 @@ def main():
     ap.add_argument("--reference-weights-layout", action="store_true",
                     help="keep the weights output as exp(w - max_t) (what the drop-in entry points return) instead of the factored layout")
     ap.add_argument("--no-mng", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed profile instead of two rocprofv3 --pmc passes of this run")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the reference-layout / other-series runs of the same batch")
     ap.add_argument("--no-clock", action="store_true", help="skip the rocm-smi clock / power samples under load")
     ap.add_argument("--pc-draws", type=int, default=2340, help="retained draws of the post_correct job (C5: 2340)")
@@ -601,9 +657,11 @@ def main():
         bytes_per_launch = float(R) / seqs * N * info["bytes_per_particle_step"]
         ppt = max(1, -(-N // (info["blocks"] // info["n_filters"] * info["threads"])))  # particles per thread of the step kernel
         achieved = seqs * bytes_per_launch / (k_ms * 1e-3) / 1e9
+        committed = pmc_traffic(R // seqs, N, ppt, plan.last_kernel(), layout["factored"])
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(R // seqs, N, ppt, plan.last_kernel(), layout["factored"]),
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": committed,
                            "traffic_source": "profiles/r04_pmc_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script at this kernel)" % ("" if layout["factored"] else "_reference_layout"),
+                           "traffic_committed_profile": committed,
                            "kernel": plan.last_kernel(), "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
                            "concurrent_launches": seqs, "filters_per_launch": R // seqs,
                            "wall_per_launch_us": ms_per_step * 1e3 / (T + 1) / seqs,
@@ -617,7 +675,18 @@ def main():
             out["roofline"]["clock_power_under_load"] = ck
             out["roofline"]["valu"] = valu_roofline(HEAD_VALU_PER_PSTEP, seqs * (R // seqs) * float(N) / (k_ms * 1e-3),
                                                     "pf_grid_step_v2<4,4,4,false,true,true>", ck) if ppt == 4 and m == 4 and layout["factored"] else None
+    head_kernel, head_factored = (FilterPlan.last_kernel(), layout["factored"]) if rank == 0 else ("", True)
     plan.close()
+    if rank == 0 and world == 1 and not args.no_live_pmc and "roofline" in out:
+        from bssm_amd import _lib as _Lp
+        _Lp.lib().bssm_amd_trim_cache()   # the child processes need the memory this process has cached
+        live = live_pmc_traffic(args, head_kernel, head_factored)
+        if live:
+            out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one timed step of the "
+                                                 "same batch, FETCH factor calibrated in-process on calib_copy_kernel")
+            out["roofline"]["traffic_live"] = live
+            out["roofline"]["traffic_over_algorithmic"] = live["hbm_bytes_per_launch"] / out["roofline"]["algorithmic_bytes_per_launch"]
 
     def side_run(mdl, factored):
         """the same batch on another (series, weights layout): a short timed run + the kernel's launch duration"""

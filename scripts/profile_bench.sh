@@ -5,9 +5,9 @@ set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-single --no-regime-b --no-post-correct"
+B="python bench.py --no-live-pmc --steps 5 --warmup 1 --no-cpu-baseline --no-single --no-regime-b --no-post-correct"
 export BSSM_BENCH_CALIB=1
-B1="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-single --no-regime-b --no-post-correct"
+B1="python bench.py --no-live-pmc --steps 1 --warmup 0 --no-cpu-baseline --no-single --no-regime-b --no-post-correct"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- $B > $OUT/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B1 > $OUT/pmc_write.log 2>&1

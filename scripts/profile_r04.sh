@@ -6,9 +6,9 @@ set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof4
 rm -rf $OUT; mkdir -p $OUT
-B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-single --no-regime-b --no-post-correct --no-dropin"
+B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-single --no-regime-b --no-post-correct --no-dropin --no-live-pmc --no-side-runs --no-accuracy"
 export BSSM_BENCH_CALIB=1
-B1="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-single --no-regime-b --no-post-correct --no-dropin"
+B1="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-single --no-regime-b --no-post-correct --no-dropin --no-live-pmc --no-side-runs --no-accuracy"
 run_pmc() {
   local name=$1; shift
   local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift

@@ -1,7 +1,7 @@
 #!/bin/bash
 # What bounds the step kernel: the same batch with and without the weights output (24 of its 111 HBM bytes per
 # particle-step), at several batch sizes.  Through gpurun from the repo root.
-B="python bench.py --no-cpu-baseline --no-post-correct --no-regime-b --no-single"
+B="python bench.py --no-live-pmc --no-cpu-baseline --no-post-correct --no-regime-b --no-single"
 show() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.4g p-steps/s  %.2f ms' % (d['value'], d['ms_per_step']))"; }
 for R in 16 24 32 48; do echo -n "replicas $R            "; $B --replicas $R 2>/dev/null | show; done
 for R in 24 32; do echo -n "replicas $R no weights "; BSSM_AMD_PROBE_NO_WEIGHTS=1 $B --replicas $R 2>/dev/null | show; done

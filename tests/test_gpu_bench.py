@@ -24,7 +24,7 @@ def _run_bench(extra, timeout=900):
 
 def test_bench_gpus_flag_starts_the_ranks_itself():
     out = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--replicas", "4", "--T", "64", "--pc-draws", "96",
-                      "--no-cpu-baseline", "--no-dropin"])
+                      "--no-cpu-baseline", "--no-dropin", "--no-live-pmc"])
     assert out["n_gpus"] == 2 and out["steps"] == 1
     assert out["communicator"]["ranks"] == 2 and out["communicator"]["world_size"] == 2
     assert out["communicator"]["backend"] == "gloo" and out["rccl_ranks"] == 0  # (RCCL only when the backend is nccl)
@@ -57,6 +57,13 @@ def test_bench_single_rank_line_has_the_contract_fields():
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    # traffic measured in the run (two rocprofv3 --pmc passes of one step of the same batch) wherever rocprofv3 exists
+    import shutil
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+        live = out["roofline"]["traffic_live"]
+        assert out["roofline"]["traffic_source"].startswith("measured in this run") and out["roofline"]["traffic"] == live["hbm_bytes_per_launch"]
+        assert 1.9 < live["read_factor_calibrated"] < 2.1 and live["read"] > 0 and live["written"] > 0
+        assert 0.5 < out["roofline"]["traffic_over_algorithmic"] < 2.0
     assert out["post_correct"]["per_rank_ms"][0]["draws"] == 96
     # what `value` was quoted on, and the same batch in the reference's weights layout / on the other observed series
     assert out["config"]["series"] == "informative" and "weights layout of `value`" in out["config"]["workload"]
@@ -69,7 +76,7 @@ def test_bench_single_rank_line_has_the_contract_fields():
 def test_bench_accuracy_object_checks_every_pair_with_the_following_oracle():
     """the metric's second half on a small instance of the timed plan: every (seed, slot) pair re-run by the tie-following oracle"""
     out = _run_bench(["--steps", "1", "--warmup", "1", "--replicas", "4", "--T", "40", "--particles", "8192", "--no-dropin", "--no-mng",
-                      "--no-regime-b", "--no-single", "--no-post-correct", "--no-side-runs", "--no-clock"])
+                      "--no-regime-b", "--no-single", "--no-post-correct", "--no-side-runs", "--no-clock", "--no-live-pmc"])
     acc = out["accuracy"]
     assert acc["device_pairs"] == 8 and acc["oracle_checked_pairs"] == 8
     assert acc["unexplained_ancestor_differences"] == 0 and acc["ancestor_tables_identical_after_following"] == 8
