@@ -292,7 +292,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           // to ~1e-15 relative, and through a moved ancestor a summary to 1e-6), and which draws land in the tail depends on the
           // draws per chunk, the shard layout and the CU count -- with the split on, a draw's result would depend on how many GPUs
           // the job ran on.  The default keeps every draw workgroup-resident: outputs bit-identical for any device list
-          // (include/bssm_amd.h), at the price of a sparsely filled last round (one rank's 292-draw shard of C5: 8.2 -> 9.8 ms).
+          // (include/bssm_amd.h), at the price of a sparsely filled last round (one rank's 293-draw shard of C5: 8.5 -> 9.6 ms, profiles/r04_c5_shard_probe.txt).
           int tail = 0;
           if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && bssm::opt().force_path == 0 && bssm::opt().tail_split) {
             int dev = 0; hipDeviceProp_t prop;
