@@ -624,10 +624,42 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
   };
   double wt_old[PPT];
   if (!BSSM_V2_RMW_LATE && wt) rmw_load(wt_old);
+  // BSSM_V2_EARLY_Z (rows of several series, PACKED step draw; round 4): the transition normals are drawn UNDER the round trips
+  // of the exchange and the search instead of behind the gathers -- they depend on nothing but (seed, t, slot), and the
+  // Box-Muller code no longer overlaps the live ranges of the gathered states (C4, two particles per lane: 127 VGPRs with two
+  // spilt -> 121 with none).  1: the pairs of the step block while the coarse rows travel; 2: the second block there too;
+  // 3 (default): the math tables are published by a barrier of their own, so that waves 1-3 draw the first block while
+  // wave 0 combines the partials; wave 0's first block and every wave's second block while the coarse rows travel.
+  // Same-box A/B (profiles/r04_c4_earlyz_ab.txt): C4 at 64 / 32 filters in flight +3.0 % / +6.5 %
+#ifndef BSSM_V2_EARLY_Z
+#define BSSM_V2_EARLY_Z 3
+#endif
+  constexpr int kEarlyZ = (MS && KP > 2 && KP <= 8 && PPT <= 2) ? (BSSM_V2_EARLY_Z) : 0;
+  double zq[kEarlyZ ? PPT : 1][kEarlyZ ? KP : 1];
+  auto early_block = [&](const int r, const int j0, const u32x4 w) {
+    double z0, z1;
+    box_muller_packed(w.x, w.y, z0, z1);
+    zq[r][j0] = z0;
+    if (j0 + 1 < KP) zq[r][j0 + 1] = z1;
+    if (j0 + 2 < KP) {
+      box_muller_packed(w.z, w.w, z0, z1);
+      zq[r][j0 + 2] = z0;
+      if (j0 + 3 < KP) zq[r][j0 + 3] = z1;
+    }
+#pragma unroll
+    for (int j = j0; j < j0 + 4 && j < KP; j++) __asm__ volatile("" : "+v"(zq[r][j]));
+  };
+  auto early_second = [&]() {
+    if constexpr (KP > 4) {
+#pragma unroll
+      for (int r = 0; r < PPT; r++)
+        early_block(r, 4, philox4x32_10((uint32_t)(base + v2_li<PPT>(r, tid)), (uint32_t)t, 1u, RNG_TRANSITION, key.seed, key.stream));
+    }
+  };
   V2_MARK("combine"); V2_STAMP(1);
+  double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
   if (wave == 0) {
     const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
-    double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
     if constexpr (COH) {
       if (lane < B) { pmax = ld32_sc1(part, (uint32_t)(2 * lane)); psum = ld32_sc1(part, (uint32_t)(2 * lane + 1)); }
       if (lane + 64 < B) { pmaxb = ld32_sc1(part, (uint32_t)(2 * (lane + 64))); psumb = ld32_sc1(part, (uint32_t)(2 * (lane + 64) + 1)); }
@@ -635,6 +667,11 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
       if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
       if (lane + 64 < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64)); pmaxb = pp.x; psumb = pp.y; }
     }
+  }
+  if constexpr (kEarlyZ == 3) {
+    if (load_tables) { math_tab_load_end256(mtab); lds_barrier(); }
+  }
+  if (wave == 0) {
     const double M0 = wave_max(fmax(pmax, pmaxb));
     const double scale0 = fast_exp(pmax - M0);  // lanes >= B: 0; a poisoned (NaN) partial makes S NaN below
     const double Q0 = wave_scan_incl(psum * scale0);
@@ -655,7 +692,13 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
   u32x4 blk[PPT];
 #pragma unroll
   for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + v2_li<PPT>(r, tid)));
-  if (load_tables) math_tab_load_end256(mtab);
+  if constexpr (kEarlyZ == 3) {
+    if (wave != 0) {
+#pragma unroll
+      for (int r = 0; r < PPT; r++) early_block(r, 0, blk[r]);
+    }
+  }
+  if (load_tables && kEarlyZ != 3) math_tab_load_end256(mtab);
   lds_barrier();  // (1)
   const V2Prefix px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[128 + 64 + lane], B};
   const double S = s_comb[127], M = s_comb[384];
@@ -758,6 +801,15 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
 #pragma unroll
       for (int q = 0; q < PPT; q++) vp[q] = (v[q] - Pm1) * is1;
     }
+  }
+  if constexpr (kEarlyZ >= 1) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (kEarlyZ != 3 || wave == 0) {
+#pragma unroll
+      for (int r = 0; r < PPT; r++) early_block(r, 0, blk[r]);
+    }
+    if constexpr (kEarlyZ >= 2) early_second();
+    __builtin_amdgcn_sched_barrier(0);
   }
   V2_MARK("phaseB"); V2_STAMP(4);
   // ---- phase B: the rows of the source blocks the wave's targets fall into; their entries (<= 128 per particle of a lane)
@@ -929,7 +981,22 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
   for (int r = 0; r < PPT; r++) {
     const int li = v2_li<PPT>(r, tid), j = base + li;
     double z[KP], x[MP];
-    rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+    if constexpr (kEarlyZ >= 1) {
+#pragma unroll
+      for (int c = 0; c < 4 && c < KP; c++) z[c] = zq[r][c];
+      if constexpr (KP > 4) {
+        if constexpr (kEarlyZ >= 2) {
+#pragma unroll
+          for (int c = 4; c < KP; c++) z[c] = zq[r][c];
+        } else {
+          const u32x4 w2 = philox4x32_10((uint32_t)j, (uint32_t)t, 1u, RNG_TRANSITION, key.seed, key.stream);
+          box_muller_packed(w2.x, w2.y, z[4], z[5 < KP ? 5 : 4]);
+          if constexpr (KP > 6) box_muller_packed(w2.z, w2.w, z[6], z[7 < KP ? 7 : 6]);
+        }
+      }
+    } else {
+      rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+    }
     if constexpr (kMfma) {
       propagate_mfma8_h<KP>((const double*)s_mat, a[r % ROLL], z, x, sw_base, lane);
     } else {

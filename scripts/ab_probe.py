@@ -29,7 +29,7 @@ def run(model, N, R, T, reps, **kw):
 if "head" in what:
     v, k = run(negbin_m4_informative(1000), 65536, 32, 1000, 10, keep_history=True, force="grid", factored_weights=True)
     out.append("head %.4g" % v)
-for tag, R in (("c4_64", 64), ("c4_32", 32)):
+for tag, R in (("c4_64", 64), ("c4_32", 32), ("c4_8", 8), ("c4_1", 1)):
     if tag in what:
         v, k = run(mng_c4(2000), 16384, R, 2000, 3, keep_history=True, force="grid", factored_weights=True)
         out.append("%s %.4g" % (tag, v))
