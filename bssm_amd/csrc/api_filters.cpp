@@ -396,8 +396,8 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   return BSSM_OK;
 }
 
-// max_states: 4 for the psi-APF (any constant R with R R' positive definite on its non-zero diagonal, any P1), 2 for the EKF particle filter (its device code
-// factors full 2 x 2 covariances per particle)
+// max_states: 8 for the psi-APF (any constant R with R R' positive definite on its non-zero diagonal, any P1; more than four states
+// since late round 4), 4 for the EKF particle filter (its device code carries one m x m covariance update per particle)
 int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
   if (!mod || !mod->y || !mod->theta) return fail(BSSM_ERR_INVALID, "model, y, theta must be non-NULL");
   const bool user = mod->model_id == bssm::FN_USER_NLG;
@@ -410,7 +410,7 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
     const bssm::UserHostFns& h = g_user_host[mod->user_slot];
     const int ms = mod->n_states;
     if (ms < 1 || ms > max_states)
-      return fail(BSSM_ERR_UNSUPPORTED, max_states == 2 ? "EKF particle filter of a user model: at most 2 states" : "psi-APF of a user model: at most 4 states");
+      return fail(BSSM_ERR_UNSUPPORTED, max_states <= 4 ? "EKF particle filter of a user model: at most 4 states" : "psi-APF of a user model: at most 8 states");
     if (!h.T || !h.Z || !h.Tg || !h.Zg)
       return fail(BSSM_ERR_UNSUPPORTED, "this user model was compiled without BSSM_USER_JACOBIANS (bssm_user_Tg, bssm_user_Zg): the psi-APF and the EKF particle filter need them");
     // the state-independent numbers: R_diag / a1 / P1 (up to 2 states) or the R_ext / a1_ext / P1_ext blocks
@@ -429,7 +429,7 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
     f->user = &h;
     f->k = ks;
     f->uH = mod->H;
-    for (int q = 0; q < 16; q++) f->uRm[q] = 0.0;
+    for (int q = 0; q < 64; q++) f->uRm[q] = 0.0;
     if (Rsrc) { for (int c = 0; c < ks; c++) for (int j = 0; j < ms; j++) f->uRm[j + ms * c] = Rsrc[j + ms * c]; }  // m x k, zero columns behind
     else for (int j = 0; j < ms; j++) f->uRm[j + ms * j] = mod->R_diag[j];
     for (int j = 0; j < ms; j++) { f->uR[j] = f->uRm[j + ms * j]; f->ua1[j] = asrc[j]; }
@@ -453,7 +453,7 @@ int functor_psi_tables(const bssm_fn_model* mod, const double* is_mode, int max_
   bssm::FilterTables dummy;
   int m = 1, k = 1;
   if ((rc = functor_tables(mod, &dummy, fpar, &m, &k))) return rc;  // fpar block (id, theta, H, R ...)
-  for (int q = 0; q < 16; q++)
+  for (int q = 0; q < 64; q++)
     if (std::isnan((*fpar)[bssm::FP_RLINV + q])) return fail(BSSM_ERR_INVALID, "psi-APF of a user model: R R' must be positive definite on its non-zero diagonal");
   bssm::FnSetup su;
   *ok = bssm::fn_psi_setup(f, is_mode, max_iter, conv_tol, &su);
@@ -892,9 +892,9 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   const std::string common = hipcc + " -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I'" + dir + "/csrc' -DBSSM_USER_M=" + std::to_string(bssm::pad_dim(n_states)) +
                              " -DBSSM_USER_NSTATES=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet_tmp + "\"' ";
   std::string cmd = "( ", objs, logs;
-  const bool wide_state = bssm::pad_dim(n_states) > 4;   // more than four states: bootstrap parts only (0: workgroup-resident, 3: step kernels)
+  const bool wide_state = bssm::pad_dim(n_states) > 4;   // more than four states: no EKF particle filter (parts 2 and 5)
   for (int part = 0; part < 6; part++) {
-    if (wide_state && part % 3 != 0) continue;
+    if (wide_state && part % 3 == 2) continue;
     const std::string obj = tmp + ".p" + std::to_string(part) + ".o", plog = log_tmp + ".p" + std::to_string(part);
     cmd += common + "-DBSSM_USER_PART=" + std::to_string(part) + " -c '" + dir + "/csrc/user_model_tu.hip' -o '" + obj + "' > '" + plog + "' 2>&1 & ";
     objs += " '" + obj + "'";

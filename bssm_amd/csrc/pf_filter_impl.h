@@ -235,7 +235,7 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
     if constexpr (MP <= 4) {  // EKF particle filter: up to 4 states (3 / 4: user models, general small factorisations)
       if (psi == 2) return functor_ekpf_weight<MP, FID>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
     }
-    if constexpr (MP <= 4) {  // psi-APF: up to 4 states (user-defined models; constant diagonal R)
+    {  // psi-APF: user-defined models with up to 8 states
       if (psi == 1) return functor_psi_weight<MP, FID>(fpar, row, amat, t, x, aprev);
     }
     return functor_log_weight<MP, FID>(fpar, row, x, t);
@@ -248,7 +248,7 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
 // fn_kernel_id<MP>(): the model id the functor kernels of this translation unit are compiled for (FN_ANY: dispatch per
 // call) -- a user-model library holds ONE model, and the only shipped two-state model is nlg_growth.
 #ifdef BSSM_USER_MODEL
-constexpr int FN_MP_MAX = 8;   // (bootstrap paths up to 8 states since round 4; the psi-APF and the EKF particle filter up to 4)
+constexpr int FN_MP_MAX = 8;   // (bootstrap filter and psi-APF up to 8 states since round 4; the EKF particle filter up to 4)
 #if defined(BSSM_USER_NLG) && !defined(BSSM_USER_SDE)
 template <int MP> constexpr int fn_kernel_id() { return FN_USER_NLG; }
 #elif defined(BSSM_USER_SDE) && !defined(BSSM_USER_NLG)
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   const int NT = kFixedNT ? NTB : (int)blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = NT >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // psi-APF of a functor model: parameter block, observation row and approximating rows are wave-uniform -- scalar loads
-  constexpr bool kPsiFn = FN != FN_NONE && PM == 1 && MP <= 4;
+  constexpr bool kPsiFn = FN != FN_NONE && PM == 1;
   const int Ncap = NT * PPT, N = EX ? NTB * PPT : b.N, n = b.n, f = blockIdx.x;
   double* __restrict__ s_alpha = smem;            // [MP][Ncap]
   double* __restrict__ s_cdf = smem + MP * Ncap;  // [Ncap]

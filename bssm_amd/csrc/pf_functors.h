@@ -43,7 +43,7 @@ __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || i
 //                  matrix, column-major, tv.rows x tv.cols, exactly as the caller handed it over.
 // The state may have up to 4 components (BSSM_USER_M = 1, 2 or 4 is the padded dimension the kernels are instantiated
 // for; a 3-state model leaves the fourth component alone) and R any m x k matrix, k <= m (bootstrap filter / smoother /
-// bootstrap IS correction; psi-APF and EKF particle filter: up to 4 states, any constant R, or a state-dependent R_fn / H_fn).
+// bootstrap IS correction; psi-APF: up to 8 states since late round 4, EKF particle filter up to 4; any constant R, or a state-dependent R_fn / H_fn).
 // per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser,
 // user slot, number of states, known_tv_params, full R (MP x MP, column-major, zero-padded; user models), inverse factor of R R'
 enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, FP_H = 20, FP_R = 21, FP_LOGC = 23, FP_SLOT = 24 /* user-model registry slot (host only) */,
@@ -51,7 +51,7 @@ enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, 
        // user models with BSSM_USER_TV: the known_tv_params matrix (device pointer as a bit pattern; rows, columns)
        FP_TVPTR = 26, FP_TVROWS = 27, FP_TVCOLS = 28,
        // full R (MP x MP, column-major, zero-padded; user models: up to 8 x 8 since round 4) and the inverse lower factor of
-       // R R' for the psi-APF's transition-density ratio with any constant R (MP x MP, column-major; psi-APF: MP <= 4)
+       // R R' for the psi-APF's transition-density ratio with any constant R (MP x MP, column-major)
        FP_RMAT = 30, FP_RLINV = 94, FP_SIZE = 158 };
 
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_TV)
@@ -94,7 +94,11 @@ __device__ __forceinline__ void nlg_T_fn(int id, PF fp, const double (&a)[MP], d
     case FN_NLG_AR_EXP: x[0] = fp[FP_THETA + 0] * (1.0 - fp[FP_THETA + 1]) + fp[FP_THETA + 1] * a[0]; break;  // :296-300
     case FN_NLG_SIN_EXP: x[0] = sin(a[0]); break;                                                            // :726-730
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
-    case FN_USER_NLG: bssm_user_T(BSSM_UTV(fp, t) &a[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN), &x[0]); break;
+    case FN_USER_NLG:
+#pragma unroll
+      for (int j = 0; j < MP; j++) x[j] = 0.0;  // (the snippet writes its own states: the padding components must not stay undefined)
+      bssm_user_T(BSSM_UTV(fp, t) &a[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN), &x[0]);
+      break;
 #endif
     default: x[0] = a[0]; break;                                                                             // linear_gaussian
   }

@@ -880,5 +880,110 @@ def test_user_model_six_states_bootstrap_against_the_general_oracle(oracle, monk
     ah, Vt = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
     assert _rel(sm["alphahat"], ah.T[:n]) <= 1e-8 and _rel(sm["Vt"], Vt[:, :, :n]) <= 1e-7
     if path == "wg" and N == 200:
-        with pytest.raises(Exception, match="at most 4 states|Jacobians|BSSM_USER_JACOBIANS"):
+        with pytest.raises(Exception, match="Jacobians|BSSM_USER_JACOBIANS"):
             F.particle_smoother(u, N, method="psi", seed=7)
+
+
+USER_SIX_J = r"""
+#define BSSM_USER_NLG 1
+#define BSSM_USER_JACOBIANS 1
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  out[0] = a[0] + a[1]; out[1] = 0.9 * a[1] + 0.1 * sin(a[2]); out[2] = th[0] * a[2] + 0.05 * a[3];
+  out[3] = 0.8 * a[3] - 0.1 * a[4]; out[4] = 0.7 * a[4] + 0.2 * tanh(a[5]); out[5] = 0.5 * a[5];
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + 0.5 * a[2] + 0.1 * a[5] * a[5]; }
+BSSM_FN void bssm_user_Tg(const double* a, const double* th, const double* kn, double* Tg) {
+  for (int q = 0; q < 36; q++) Tg[q] = 0.0;
+  Tg[0 + 6 * 0] = 1.0; Tg[0 + 6 * 1] = 1.0;
+  Tg[1 + 6 * 1] = 0.9; Tg[1 + 6 * 2] = 0.1 * cos(a[2]);
+  Tg[2 + 6 * 2] = th[0]; Tg[2 + 6 * 3] = 0.05;
+  Tg[3 + 6 * 3] = 0.8; Tg[3 + 6 * 4] = -0.1;
+  Tg[4 + 6 * 4] = 0.7; const double th5 = tanh(a[5]); Tg[4 + 6 * 5] = 0.2 * (1.0 - th5 * th5);
+  Tg[5 + 6 * 5] = 0.5;
+}
+BSSM_FN void bssm_user_Zg(const double* a, const double* th, const double* kn, double* Zg) {
+  Zg[0] = 1.0; Zg[1] = 0.0; Zg[2] = 0.5; Zg[3] = 0.0; Zg[4] = 0.0; Zg[5] = 0.2 * a[5];
+}
+"""
+
+
+def _six_case(seed=12, n=30):
+    rng = np.random.default_rng(seed)
+    m = 6
+    th = np.array([0.85]); kn = np.zeros(0)
+    # a full-rank 6 x 6 lower-triangular R: R R' is positive definite and not diagonal
+    Rm = np.diag([0.05, 0.1, 0.3, 0.2, 0.15, 0.4]); Rm[1, 0] = 0.02; Rm[3, 2] = -0.1; Rm[4, 3] = 0.1; Rm[5, 1] = 0.05
+    Z = lambda t, a, th_, kn_: a[0] + 0.5 * a[2] + 0.1 * a[5] ** 2
+    H = lambda t, a, th_, kn_: 0.6
+    T = lambda t, a, th_, kn_: np.array([a[0] + a[1], 0.9 * a[1] + 0.1 * np.sin(a[2]), th_[0] * a[2] + 0.05 * a[3], 0.8 * a[3] - 0.1 * a[4],
+                                         0.7 * a[4] + 0.2 * np.tanh(a[5]), 0.5 * a[5]])
+    R = lambda t, a, th_, kn_: Rm
+
+    def Tg(t, a, th_, kn_):
+        J = np.zeros((6, 6))
+        J[0, 0] = 1.0; J[0, 1] = 1.0; J[1, 1] = 0.9; J[1, 2] = 0.1 * np.cos(a[2]); J[2, 2] = th_[0]; J[2, 3] = 0.05
+        J[3, 3] = 0.8; J[3, 4] = -0.1; J[4, 4] = 0.7; J[4, 5] = 0.2 * (1.0 - np.tanh(a[5]) ** 2); J[5, 5] = 0.5
+        return J
+    Zg = lambda t, a, th_, kn_: np.array([1.0, 0.0, 0.5, 0.0, 0.0, 0.2 * a[5]])
+    a = np.array([1.0, 0.05, 0.3, -0.2, 0.1, 0.4]); y = np.zeros(n)
+    for t in range(n):
+        y[t] = Z(t, a, th, kn) + 0.6 * rng.normal()
+        a = T(t, a, th, kn) + Rm @ rng.normal(size=m)
+    y[9] = np.nan
+    a1 = np.array([1.0, 0.0, 0.3, 0.0, 0.0, 0.4])
+    P1 = np.diag([0.5, 0.01, 0.2, 0.1, 0.05, 0.3]); P1[0, 2] = P1[2, 0] = 0.1
+    u = M.ssm_nlg_user(y, USER_SIX_J, theta=th, known_params=kn, a1=a1, P1=P1, H=0.6, n_states=m, R=Rm)
+    return u, y, m, th, kn, a1, P1, dict(Z_fn=Z, H_fn=H, T_fn=T, R_fn=R, Z_gn=Zg, T_gn=Tg)
+
+
+@pytest.mark.parametrize("path,N", [("wg", 300), ("wg", 1200), ("grid", 4000)])
+def test_user_model_six_states_psi_apf_against_the_general_oracle(oracle, monkeypatch, path, N):
+    """psi-APF of a user model with SIX states and a full lower-triangular R (late round 4: the MP = 8 functor kernels carry the
+    psi-APF too; src/model_ssm_nlg.cpp:62-143, 854-935, 971-1063 over function pointers): mode, approximate log-likelihood,
+    ancestors, weights, log-likelihood and smoothed means against orc_nlg_general_psi_*; the EKF particle filter stays at four
+    states and says so."""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    u, y, m, th, kn, a1, P1, fns = _six_case()
+    n = y.size
+    ref = oracle.nlg_general_psi(y, m, m, th, kn, a1, P1, nsim=N, seed=3, **fns)
+    assert ref["ok"]
+    su = F.psi_setup(u)
+    assert np.allclose(np.asarray(su["mode"]).reshape(m, n, order="F"), ref["mode"], rtol=0, atol=1e-9)
+    assert abs(su["approx_loglik"] - ref["approx_loglik"]) <= 1e-9 * n
+    out = F.particle_smoother(u, N, method="psi", seed=3, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    mean, cov = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8
+    if path == "wg" and N == 300:
+        with pytest.raises(Exception, match="at most 4 states"):
+            F.particle_smoother(u, N, method="ekf", seed=3)
+
+
+@pytest.mark.parametrize("dev", ["0", "1"])
+def test_user_model_six_states_post_correct_psi_against_the_general_oracle(oracle, monkeypatch, dev):
+    """IS post-correction (is2) of the six-state user model over theta-draws with their stored modes (approximate_for_is,
+    src/model_ssm_nlg.cpp:146-176; src/approx_mcmc.cpp:364-417): every draw's psi-APF log-likelihood against
+    orc_nlg_general_psi_filter on stream = draw index, weights = exp(logLik), through the host set-up and the device smoother"""
+    from bssm_amd import post_correct as PC
+    monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+    u, y, m, th0, kn, a1, P1, fns = _six_case()
+    n, ns, N = y.size, 5, 300
+    rng = np.random.default_rng(5)
+    theta = th0 + 0.03 * rng.normal(size=(ns, 1))
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    sus = [oracle.nlg_general_psi(y, m, m, th, kn, a1, P1, nsim=N, seed=9, filter=False, **fns) for th in theta]
+    modes = np.stack([s["mode"].reshape(-1, order="F") for s in sus], axis=1)
+    mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.zeros(ns), output_type=2)
+    out = PC.post_correct(u, mo, N, threads=2, is_type="is2", seed=9)
+    w = np.zeros(ns); ah = np.zeros((m, n + 1, ns))
+    for i, th in enumerate(theta):
+        ref = oracle.nlg_general_psi(y, m, m, th, kn, a1, P1, nsim=N, seed=9, stream=i, is_mode=modes[:, i].reshape((m, n), order="F"), **fns)
+        assert ref["ok"]
+        assert abs(out["loglik"][i] - ref["logLik"]) <= 1e-9 * n
+        w[i] = np.exp(ref["logLik"])
+        ah[:, :, i], _ = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert np.allclose(out["weights"], w, rtol=1e-8)
+    wc = w * counts
+    assert np.allclose(out["alphahat"], (np.tensordot(ah, wc, axes=([2], [0])) / wc.sum()).T[:out["alphahat"].shape[0]], rtol=1e-7, atol=1e-9)
