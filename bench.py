@@ -39,8 +39,8 @@ VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 REGB_VALU_PER_PSTEP = 9588020533.1 / (512 * 2048 * 1000.0)    # pf_wg_kernel<4,4,4,false,512> (profiles/r04_pmc_regb.txt; round 3: 9.94e9)
 C5_VALU_PER_PSTEP = 18125027041.0 / (2340.0 * 4096 * 300.0)   # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), one dispatch of 2 340 draws (profiles/r04_pmc_C5.txt)
 C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1,exact>"
-HEAD_VALU_PER_PSTEP = 7798567.3 / (16 * 65536.0)                # pf_grid_step_v2<4,4,4,false,true,true>: 7.80 M per launch of 16 filters x 65 536 particles (profiles/r04_pmc_sq1_summary.txt; round 3: 8.36 M)
-C4_VALU_PER_PSTEP = 6540006.7 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r04_pmc_C4.txt; round 3: 7.14 M)
+HEAD_VALU_PER_PSTEP = 7813185.0 / (16 * 65536.0)                # pf_grid_step_v2<4,4,4,false,true,true>: 7.81 M per launch of 16 filters x 65 536 particles (profiles/r04_pmc_sq1_summary.txt; round 3: 8.36 M)
+C4_VALU_PER_PSTEP = 6583014.7 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r04_pmc_C4.txt; round 3: 7.14 M)
 
 
 def valu_roofline(valu_per_pstep, psteps_per_s, kernel, clock=None):
