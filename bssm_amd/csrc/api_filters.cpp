@@ -396,8 +396,8 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   return BSSM_OK;
 }
 
-// max_states: 8 for the psi-APF (any constant R with R R' positive definite on its non-zero diagonal, any P1; more than four states
-// since late round 4), 4 for the EKF particle filter (its device code carries one m x m covariance update per particle)
+// max_states: 8 for the psi-APF and the EKF particle filter of user models (any constant R with R R' positive definite on its non-zero
+// diagonal, any P1; more than four states since late round 4)
 int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
   if (!mod || !mod->y || !mod->theta) return fail(BSSM_ERR_INVALID, "model, y, theta must be non-NULL");
   const bool user = mod->model_id == bssm::FN_USER_NLG;
@@ -410,7 +410,7 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
     const bssm::UserHostFns& h = g_user_host[mod->user_slot];
     const int ms = mod->n_states;
     if (ms < 1 || ms > max_states)
-      return fail(BSSM_ERR_UNSUPPORTED, max_states <= 4 ? "EKF particle filter of a user model: at most 4 states" : "psi-APF of a user model: at most 8 states");
+      return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: at most 8 states");
     if (!h.T || !h.Z || !h.Tg || !h.Zg)
       return fail(BSSM_ERR_UNSUPPORTED, "this user model was compiled without BSSM_USER_JACOBIANS (bssm_user_Tg, bssm_user_Zg): the psi-APF and the EKF particle filter need them");
     // the state-independent numbers: R_diag / a1 / P1 (up to 2 states) or the R_ext / a1_ext / P1_ext blocks
@@ -482,7 +482,7 @@ namespace {
 // the initial table, and [a1 | P1 | att1 | L1] behind the functor parameters for the time-0 weights
 int functor_ekpf_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector<double>* fpar, int* m_out) {
   bssm::FnModel f;
-  int rc = to_fn_model(mod, &f, 4);  // (round 3: up to 4 states, any constant R, any P1 -- as the psi-APF)
+  int rc = to_fn_model(mod, &f);  // (up to 8 states since late round 4, any constant R, any P1 -- as the psi-APF)
   if (rc) return rc;
   int m = 1, k = 1;
   if ((rc = functor_tables(mod, ft, fpar, &m, &k))) return rc;
@@ -491,7 +491,7 @@ int functor_ekpf_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::v
     for (int c = 0; c < m; c++) for (int j = 0; j < m; j++)
       if (j != c && f.uRm[j + m * c] != 0.0) return fail(BSSM_ERR_UNSUPPORTED, "EKF particle filter of a user model with 1 or 2 states: constant diagonal R");
   }
-  double a1[4], P1[16], att1[4], L1[16];
+  double a1[8], P1[64], att1[8], L1[64];
   bssm::fn_ekpf_init(f, a1, P1, att1, L1);
   // the initial table and the [a1 | P1 | att1 | L1] block in the kernels' padded layout (MP, MP x MP column-major)
   std::fill(ft->init.begin(), ft->init.end(), 0.0);
@@ -892,9 +892,7 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   const std::string common = hipcc + " -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I'" + dir + "/csrc' -DBSSM_USER_M=" + std::to_string(bssm::pad_dim(n_states)) +
                              " -DBSSM_USER_NSTATES=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet_tmp + "\"' ";
   std::string cmd = "( ", objs, logs;
-  const bool wide_state = bssm::pad_dim(n_states) > 4;   // more than four states: no EKF particle filter (parts 2 and 5)
   for (int part = 0; part < 6; part++) {
-    if (wide_state && part % 3 == 2) continue;
     const std::string obj = tmp + ".p" + std::to_string(part) + ".o", plog = log_tmp + ".p" + std::to_string(part);
     cmd += common + "-DBSSM_USER_PART=" + std::to_string(part) + " -c '" + dir + "/csrc/user_model_tu.hip' -o '" + obj + "' > '" + plog + "' 2>&1 & ";
     objs += " '" + obj + "'";

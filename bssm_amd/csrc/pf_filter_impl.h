@@ -232,7 +232,7 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
   if constexpr (FN != FN_NONE) {
     constexpr int FID = FN > 0 ? FN : 0;
     const int psi = PM >= 0 ? PM : b.psi;
-    if constexpr (MP <= 4) {  // EKF particle filter: up to 4 states (3 / 4: user models, general small factorisations)
+    {  // EKF particle filter (3 ... 8 states: user models, general small factorisations)
       if (psi == 2) return functor_ekpf_weight<MP, FID>(fpar, row, amat, t, x, aprev);  // amat = the filter's [a1 | P1 | att1 | L1]
     }
     {  // psi-APF: user-defined models with up to 8 states
@@ -248,7 +248,7 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
 // fn_kernel_id<MP>(): the model id the functor kernels of this translation unit are compiled for (FN_ANY: dispatch per
 // call) -- a user-model library holds ONE model, and the only shipped two-state model is nlg_growth.
 #ifdef BSSM_USER_MODEL
-constexpr int FN_MP_MAX = 8;   // (bootstrap filter and psi-APF up to 8 states since round 4; the EKF particle filter up to 4)
+constexpr int FN_MP_MAX = 8;   // (every sampler up to 8 states since round 4)
 #if defined(BSSM_USER_NLG) && !defined(BSSM_USER_SDE)
 template <int MP> constexpr int fn_kernel_id() { return FN_USER_NLG; }
 #elif defined(BSSM_USER_SDE) && !defined(BSSM_USER_NLG)
@@ -496,8 +496,8 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       double x[MP];
       if (FN && !psi_mode) {
         if constexpr (FN != FN_NONE) functor_propagate<MP, KP, FID>(fpar, key_p, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
-      } else if (FN && MP <= 4 && psi_mode == 2) {
-        if constexpr (FN != FN_NONE && MP <= 4) functor_ekpf_propagate<MP, FID>(fpar, ob, t + 1 >= n, key_p, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
+      } else if (FN && psi_mode == 2) {
+        if constexpr (FN != FN_NONE) functor_ekpf_propagate<MP, FID>(fpar, ob, t + 1 >= n, key_p, blk[r], (uint32_t)t, (uint32_t)i, a[r], x);
       } else {
         double z[KP];
         rng_normals_blk<KP, kPack>(blk[r], key_p, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
@@ -542,7 +542,7 @@ template <int MP, int PPT, int FNV, int NTB>
 auto wg_fn_kernel(int psi) -> void (*)(const FilterBatch) {
   if constexpr (((BSSM_FN_PSI_MASK) & 1) != 0) { if (psi == 0) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 0>; }
   if constexpr (((BSSM_FN_PSI_MASK) & 2) != 0) { if (psi == 1) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1>; }
-  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0 && MP <= 4) { if (psi == 2) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 2>; }  // (no EKF filter beyond four states)
+  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0) { if (psi == 2) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 2>; }
   return nullptr;
 }
 #define WG_FN_KERNEL(PPT_, NTB_) wg_fn_kernel<MP, PPT_, kFn, NTB_>(b.psi)
@@ -980,8 +980,8 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
         }
         BSSM_STAMP(6)
         if constexpr (FN != FN_NONE) {
-          if (MP <= 4 && psi_mode == 2) {
-            if constexpr (MP <= 4) functor_ekpf_propagate<MP, FID>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
+          if (psi_mode == 2) {
+            functor_ekpf_propagate<MP, FID>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
           } else if (psi_mode) {
             double z[KP];
             rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
@@ -1065,7 +1065,7 @@ template <int MP, int KP, int PPT, int FNV>
 auto grid_fn_kernel(int psi) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
   if constexpr (((BSSM_FN_PSI_MASK) & 1) != 0) { if (psi == 0) return pf_grid_step<MP, KP, PPT, false, FNV, 0>; }
   if constexpr (((BSSM_FN_PSI_MASK) & 2) != 0) { if (psi == 1) return pf_grid_step<MP, KP, PPT, false, FNV, 1>; }
-  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0 && MP <= 4) { if (psi == 2) return pf_grid_step<MP, KP, PPT, false, FNV, 2>; }
+  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0) { if (psi == 2) return pf_grid_step<MP, KP, PPT, false, FNV, 2>; }
   return nullptr;
 }
 template <int MP, int KP>

@@ -43,7 +43,7 @@ __host__ __device__ inline bool fn_is_sde(int id) { return id == FN_SDE_GBM || i
 //                  matrix, column-major, tv.rows x tv.cols, exactly as the caller handed it over.
 // The state may have up to 4 components (BSSM_USER_M = 1, 2 or 4 is the padded dimension the kernels are instantiated
 // for; a 3-state model leaves the fourth component alone) and R any m x k matrix, k <= m (bootstrap filter / smoother /
-// bootstrap IS correction; psi-APF: up to 8 states since late round 4, EKF particle filter up to 4; any constant R, or a state-dependent R_fn / H_fn).
+// bootstrap IS correction; psi-APF and EKF particle filter: up to 8 states since late round 4; any constant R, or a state-dependent R_fn / H_fn).
 // per-filter parameter block (doubles): id, L, positive, x0, theta[8], known[8], H (sd), R diagonal[2], log-normaliser,
 // user slot, number of states, known_tv_params, full R (MP x MP, column-major, zero-padded; user models), inverse factor of R R'
 enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, FP_H = 20, FP_R = 21, FP_LOGC = 23, FP_SLOT = 24 /* user-model registry slot (host only) */,

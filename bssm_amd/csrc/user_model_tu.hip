@@ -90,15 +90,6 @@ extern "C" hipError_t bssm_user_launch_grid_p0(const bssm::FilterBatch*, const b
 extern "C" hipError_t bssm_user_launch_wg_p2(const bssm::FilterBatch*, hipStream_t);
 extern "C" hipError_t bssm_user_launch_grid_p1(const bssm::FilterBatch*, const bssm::GridWorkspace*, hipStream_t, bssm::StepTiming*);
 extern "C" hipError_t bssm_user_launch_grid_p2(const bssm::FilterBatch*, const bssm::GridWorkspace*, hipStream_t, bssm::StepTiming*);
-#if BSSM_USER_M > 4   // more than four states: bootstrap and psi-APF parts (0, 1, 3, 4); the EKF particle filter is refused on the host
-extern "C" hipError_t bssm_user_launch_wg(const bssm::FilterBatch* b, hipStream_t stream) {
-  return b->psi == 0 ? bssm_user_launch_wg_p0(b, stream) : (b->psi == 1 ? bssm_user_launch_wg_p1(b, stream) : hipErrorInvalidValue);
-}
-extern "C" hipError_t bssm_user_launch_grid(const bssm::FilterBatch* b, const bssm::GridWorkspace* ws, hipStream_t stream,
-                                            bssm::StepTiming* timing) {
-  return b->psi == 0 ? bssm_user_launch_grid_p0(b, ws, stream, timing) : (b->psi == 1 ? bssm_user_launch_grid_p1(b, ws, stream, timing) : hipErrorInvalidValue);
-}
-#else
 extern "C" hipError_t bssm_user_launch_wg(const bssm::FilterBatch* b, hipStream_t stream) {
   return b->psi == 0 ? bssm_user_launch_wg_p0(b, stream) : (b->psi == 1 ? bssm_user_launch_wg_p1(b, stream) : bssm_user_launch_wg_p2(b, stream));
 }
@@ -107,7 +98,6 @@ extern "C" hipError_t bssm_user_launch_grid(const bssm::FilterBatch* b, const bs
   return b->psi == 0 ? bssm_user_launch_grid_p0(b, ws, stream, timing)
                      : (b->psi == 1 ? bssm_user_launch_grid_p1(b, ws, stream, timing) : bssm_user_launch_grid_p2(b, ws, stream, timing));
 }
-#endif
 #endif
 
 #if !defined(BSSM_USER_PART) || BSSM_USER_PART == 0

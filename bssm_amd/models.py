@@ -575,13 +575,13 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
     the filter kernels (contract: bssm_amd/csrc/pf_functors.h -- ``#define BSSM_USER_NLG 1``, ``bssm_user_T``,
     ``bssm_user_Z``), and the state-independent pieces are numbers: H (observation sd), the diagonal of R, a1, P1.
     With the Jacobians in the snippet (``BSSM_USER_JACOBIANS``, ``bssm_user_Tg``, ``bssm_user_Zg``) the psi-APF and the
-    EKF particle filter work as for the built-in models (psi-APF: up to 8 states, EKF particle filter up to 4; any constant matrix ``R`` with R R'
+    EKF particle filter work as for the built-in models (up to 8 states; any constant matrix ``R`` with R R'
     positive definite on its non-zero diagonal, any positive semi-definite P1; the EKF particle filter likewise, with a constant diagonal R
     for 1- and 2-state models).
     ``known_tv_params``: the reference's matrix of known time-varying values (R/models.R:1507); a snippet that defines
     ``BSSM_USER_TV`` receives it, with the time index, as the leading ``const bssm_user_tv& tv`` argument of every function
     (``tv.t``, ``tv.known_tv`` column-major ``tv.rows x tv.cols``).
-    The bootstrap filter / smoother / bootstrap IS correction take up to 8 states (round 4), the psi-APF too, the EKF particle filter up to 4, with any ``R`` (n_states x n_etas matrix, or a function of theta) and the
+    The bootstrap filter / smoother / bootstrap IS correction take up to 8 states (round 4), like the psi-APF and the EKF particle filter, with any ``R`` (n_states x n_etas matrix, or a function of theta) and the
     reference's state-dependent ``H_fn`` / ``R_fn`` as snippet functions (``BSSM_USER_HFN`` + ``bssm_user_H``,
     ``BSSM_USER_RFN`` + ``bssm_user_R``; src/model_ssm_nlg.h:12-13), which then replace ``H`` / ``R`` (``R`` still fixes
     n_etas; for the psi-APF R(a) R(a)' must be positive definite on its non-zero diagonal)."""
@@ -589,7 +589,7 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
     theta = np.asarray(theta, dtype=float)
     m = int(n_states or np.asarray(a1(theta) if callable(a1) else a1, dtype=float).size)
     if not 1 <= m <= 8:
-        raise ValueError("user-defined ssm_nlg models: n_states must be 1 ... 8 (EKF particle filter: 1 ... 4)")
+        raise ValueError("user-defined ssm_nlg models: n_states must be 1 ... 8")
     if R is None and R_diag is None:
         if "BSSM_USER_RFN" not in device_code:
             raise ValueError("give R_diag, R, or a snippet with BSSM_USER_RFN / bssm_user_R")

@@ -180,7 +180,7 @@ typedef struct bssm_fn_model {
   int32_t L;                  /* ssm_sde: 2^L Milstein sub-steps per unit time */
   /* ---- user-defined models only (model_id BSSM_FN_USER_NLG / BSSM_FN_USER_SDE); ignored for the built-in ids */
   int32_t user_slot;          /* from bssm_user_model_load */
-  int32_t n_states;           /* ssm_nlg: 1 ... 8 (bootstrap filter / smoother, psi-APF, IS corrections; EKF particle filter: 1 ... 4) */
+  int32_t n_states;           /* ssm_nlg: 1 ... 8 (every sampler) */
   double H;                   /* ssm_nlg: observation sd (the value H_fn returns; unused when the snippet defines BSSM_USER_HFN) */
   double R_diag[2];           /* ssm_nlg: diagonal of R_fn's value (n_states <= 2, diagonal R) */
   double a1[2], P1[4];        /* ssm_nlg: a1_fn, P1_fn values (P1 column-major, n_states x n_states), n_states <= 2 */
@@ -206,7 +206,7 @@ typedef struct bssm_fn_model {
  * bssm_user_model_load maps it and returns a slot >= 1 for bssm_fn_model.user_slot (negative = error).
  * Built for user models: every single-model entry point of the built-in models -- bootstrap, psi-APF (bssm_psi_smoother_nlg,
  * bssm_fn_psi_setup) and EKF particle filter (bssm_ekpf_*) with their smoothers and bssm_fn_loglik_batch; the psi-APF and
- * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS).  The psi-APF takes up to 8 states (late round 4; the EKF particle filter up to 4), any constant
+ * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS).  The psi-APF and the EKF particle filter take up to 8 states (late round 4), any constant
  * n_states x n_etas matrix R whose R R' is positive definite on its non-zero diagonal, and any positive semi-definite P1
  * (round 3); so does the EKF particle filter (1- and 2-state models: constant diagonal R).  Snippets that define
  * BSSM_USER_TV receive the time index and known_tv_params in every function.  The bootstrap filter / smoother / bootstrap IS correction take up to 8 states, any n_states x n_etas matrix

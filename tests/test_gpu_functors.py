@@ -940,8 +940,7 @@ def _six_case(seed=12, n=30):
 def test_user_model_six_states_psi_apf_against_the_general_oracle(oracle, monkeypatch, path, N):
     """psi-APF of a user model with SIX states and a full lower-triangular R (late round 4: the MP = 8 functor kernels carry the
     psi-APF too; src/model_ssm_nlg.cpp:62-143, 854-935, 971-1063 over function pointers): mode, approximate log-likelihood,
-    ancestors, weights, log-likelihood and smoothed means against orc_nlg_general_psi_*; the EKF particle filter stays at four
-    states and says so."""
+    ancestors, weights, log-likelihood and smoothed means against orc_nlg_general_psi_*."""
     monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
     u, y, m, th, kn, a1, P1, fns = _six_case()
     n = y.size
@@ -956,9 +955,25 @@ def test_user_model_six_states_psi_apf_against_the_general_oracle(oracle, monkey
     assert _rel(out["weights"], ref["weights"]) <= 1e-8
     mean, cov = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
     assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8
-    if path == "wg" and N == 300:
-        with pytest.raises(Exception, match="at most 4 states"):
-            F.particle_smoother(u, N, method="ekf", seed=3)
+
+
+@pytest.mark.parametrize("path,N", [("wg", 300), ("grid", 3000)])
+def test_user_model_six_states_ekf_particle_filter_against_the_general_oracle(oracle, monkeypatch, path, N):
+    """EKF-proposal particle filter (src/model_ssm_nlg.cpp:1148-1293) of the six-state user model: one 6 x 6 EKF update per particle
+    with the general small factorisations of the MP = 8 functor kernels -- against orc_nlg_general_ekpf_filter: ancestors, weights,
+    log-likelihood, smoothed means; nine states are refused with a clear message"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    u, y, m, th, kn, a1, P1, fns = _six_case()
+    ref = oracle.nlg_general_ekpf_filter(y, m, m, th, kn, a1, P1, nsim=N, seed=4, **fns)
+    out = F.particle_smoother(u, N, method="ekf", seed=4, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * y.size
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    mean, cov = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert _rel(out["alphahat"], mean.T[:y.size]) <= 1e-8
+    if path == "wg":
+        with pytest.raises(ValueError, match="1 ... 8"):
+            M.ssm_nlg_user(np.zeros(5), USER_SIX_J, theta=th, a1=np.zeros(9), P1=np.eye(9), H=0.6, n_states=9, R=np.eye(9))
 
 
 @pytest.mark.parametrize("dev", ["0", "1"])
