@@ -3,7 +3,9 @@ missing or no HIP device is usable the compute entry points fail loudly -- there
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -115,12 +117,37 @@ class BssmAmdError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (torch/lib), and libbssm_amd.so
+    names the runtime by its SONAME only: loaded after `import torch` it binds to torch's copy -- one runtime, torch streams are
+    valid handles for the `hip_stream` arguments, RCCL comes from the same stack.  Loaded BEFORE torch it binds to the system
+    ROCm's runtime, and a later `import torch` brings a second HSA runtime into the process that finds no device
+    ("No HIP GPUs are available"; scripts/runtime_order_probe.py shows both orders on the GPU box).  So where torch is
+    installed but not imported yet, its runtime is loaded here first (a dlopen of one file -- torch itself is not imported) and
+    the order stops mattering.  BSSM_AMD_SYSTEM_HIP=1 keeps the system runtime (a process that will never import torch)."""
+    if os.environ.get("BSSM_AMD_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # (a CPU-only torch build, a broken install: the system runtime is used as before)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise BssmAmdError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(bssm_amd has no CPU fallback)")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.bssm_amd_last_error.restype = C.c_char_p
         L.bssm_amd_version.restype = C.c_char_p

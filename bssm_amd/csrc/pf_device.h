@@ -88,10 +88,13 @@ __device__ __forceinline__ const cdbl* reload_table(const cdbl* p) {
 // ---------------------------------------------------------------- Philox4x32-10
 struct u32x4 { uint32_t x, y, z, w; };
 
+#ifndef BSSM_PHILOX_ROUNDS
+#define BSSM_PHILOX_ROUNDS 10
+#endif
 __host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                          uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
+  for (int r = 0; r < BSSM_PHILOX_ROUNDS; r++) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

@@ -262,7 +262,9 @@ template <int MP> constexpr int fn_kernel_id() { return MP == 2 ? FN_NLG_GROWTH 
 #endif
 // analysis builds (-DBSSM_WG_STAMPS): shader-clock deltas per phase of the time loop, accumulated by the first lane of
 // the first and the last wave of workgroup 0 and printed at the end (scripts/wg_phase_probe.py)
-#ifdef BSSM_WG_STAMPS
+#ifdef BSSM_WG_MARKS
+#define WG_STAMP(k) __asm__ volatile("; WGMARK " #k ::: "memory")
+#elif defined(BSSM_WG_STAMPS)
 #define WG_STAMP(k) do { if (stamp_on) { const long long now_ = (long long)__builtin_readcyclecounter(); st_acc[k] += now_ - st_last; st_last = now_; } } while (0)
 #else
 #define WG_STAMP(k)
