@@ -533,6 +533,10 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   if (psi && !job->modes) return fail(BSSM_ERR_INVALID, "modes required for psi");
   if (!psi && !job->approx_loglik) return fail(BSSM_ERR_INVALID, "approx_loglik required for bsf");
   if (!job->counts) return fail(BSSM_ERR_INVALID, "counts NULL");
+  if (!job->models) return fail(BSSM_ERR_INVALID, "models NULL");
+  if (job->nsim < 1) return fail(BSSM_ERR_INVALID, "nsim must be positive");
+  if (job->is_type < 1 || job->is_type > 3) return fail(BSSM_ERR_INVALID, "is_type must be 1..3");
+  if (job->first < 0) return fail(BSSM_ERR_INVALID, "first must not be negative");
 
   // per-draw host set-up (the reference does this inside its OpenMP region, src/approx_mcmc.cpp:372-373), overlapped
   // with the device work of the previous chunk of draws
@@ -727,6 +731,9 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   const bool psi = sampling_method == BSSM_PSI;
   if (psi && !modes) return fail(BSSM_ERR_INVALID, "modes required for psi");
   if (!psi && !approx_loglik) return fail(BSSM_ERR_INVALID, "approx_loglik required for bsf");
+  if (nsim < 1) return fail(BSSM_ERR_INVALID, "nsim must be positive");
+  if (is_type < 1 || is_type > 3) return fail(BSSM_ERR_INVALID, "is_type must be 1..3");
+  if (first < 0) return fail(BSSM_ERR_INVALID, "first must not be negative");
   const int n = models[0].n, id = models[0].model_id, m = id == bssm::FN_NLG_GROWTH ? 2 : (id == bssm::FN_USER_NLG ? models[0].n_states : 1);
   IsCore J;
   J.n = n; J.m = m; J.k = m; J.pp = 1; J.psi = psi;
