@@ -202,3 +202,34 @@ def test_factored_weights_layout_multiplies_out_to_the_reference_form(oracle, mo
     np.testing.assert_allclose(b["weights"].T, ref["weights"], rtol=1e-9, atol=1e-13, equal_nan=True)
     if case == "degenerate":
         assert np.isneginf(llb) and np.all(b["weights"][6:] == 0.0) and np.all(b["indices"][5:] == 0)
+
+
+def test_series_longer_than_65535_time_points(oracle):
+    """n = 70 000: beyond what a grid's y dimension carries (the set-up kernels of the psi paths index time points with it
+    and hand such series to the host set-up), beyond 2^16 launches of the step kernels; bootstrap filter, psi-APF smoother
+    and the IS post-correction of three draws against the oracle"""
+    from bssm_amd import post_correct as PC
+    n = 70000
+    rng = np.random.default_rng(70)
+    level = 1.0 + np.cumsum(rng.normal(0, 0.02, n))
+    level -= np.linspace(0, level[-1] - 1.0, n)           # stays near 1: informative counts all along
+    y = rng.poisson(np.exp(level)).astype(float)
+    y[[17, 40000, 69999]] = np.nan
+    model = M.bsm_ng(y, sd_level=M.halfnormal(0.05, 1), distribution="poisson", P1=np.array([[0.5]]), a1=[1.0])
+    arr = M.model_arrays(model)
+    for N in (64, 1500):   # workgroup-resident and step kernels
+        out = F.bootstrap_filter(model, N, seed=8, return_indices=True)
+        ref = oracle.bsf_filter(arr, N, seed=8)
+        assert np.array_equal(out["indices"], ref["indices"])
+        assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    sm = F.particle_smoother(model, 64, method="psi", seed=9)
+    rs = oracle.psi_filter(arr, 64, seed=9)
+    assert abs(sm["logLik"] - rs["logLik"]) <= 1e-9 * n
+    theta = np.log(np.array([[0.04], [0.05], [0.07]]))
+    counts = np.array([2, 1, 3], dtype=np.uint32)
+    arrs = PC.expand_models(model, theta)
+    modes = np.stack([oracle.psi_setup(a)["mode"] for a in arrs], axis=1)
+    res = PC.is_correction(model, theta, counts, 32, method="psi", modes=modes, seed=4, threads=2, output_type=3)
+    ref = oracle.is_correction(arrs, 32, 4, method=1, counts=counts, modes=modes, is_type=2, output_type=3, n_threads=2)
+    assert np.allclose(res["loglik"], ref["loglik"], rtol=0, atol=1e-9 * n)
+    assert np.allclose(res["weights"], ref["weights"], rtol=1e-7)
