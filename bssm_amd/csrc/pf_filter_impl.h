@@ -285,8 +285,12 @@ __device__ __forceinline__ constexpr int step_draw_count() { return FN == FN_NON
 #endif
 // EX: the particle count is exactly NTB * PPT (4096 = 1024 x 4, the shape IS post-correction of config C5 runs): N is a
 // compile-time constant, every `i < N` guard and the pivot / window arithmetic derived from N fold away
+// waves per SIMD the 512-thread kernels are budgeted for: two particles per lane of a linear-state filter with at most four
+// states came out at 132 VGPRs -- four over the 128 that let TWO workgroups share a CU (N <= 1024 needs 40 KB of LDS each)
+template <int MP, int PPT, int FN, int NTB>
+constexpr int wg_waves_per_simd() { return (FN == FN_NONE && MP <= 4 && NTB == WG_NT_MAX && PPT == 2) ? 4 : (NTB + 255) / 256; }
 template <int MP, int KP, int PPT, int FN = FN_NONE, int NTB = WG_NT_MAX, int PM = -1, bool EX = false>
-__global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
+__global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) pf_wg_kernel(const FilterBatch b) {
   constexpr int FID = FN > 0 ? FN : 0;
   const int psi_mode = PM >= 0 ? PM : b.psi;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -307,6 +311,19 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
   // from s_cdf the 64 lanes' addresses are W doubles apart -- one bank for W = 64: a 64-way conflict per particle row.
   // Used when N is a power of two (W a power of two: the owner of a pivot entry is found with a mask).
   double* __restrict__ s_piv = s_tot + PPT * 16;
+  // T_t, R_t, C_t of the step for the linear-state transition, staged by the first threads under the search and published by
+  // barrier (4); read back as broadcast ds_reads.  Through scalar loads the 36 doubles of a four-dimensional state are 72 SGPRs
+  // on top of the loop invariants of the time loop: 130-150 SGPRs lived in VGPR lanes and came back through v_readlane (the
+  // round-2 finding of the step kernels, pf_grid_v2.h `s_mat`, here too).  BSSM_WG_LDS_MAT=0: the scalar-load form.
+#ifndef BSSM_WG_LDS_MAT
+#define BSSM_WG_LDS_MAT 0
+#endif
+#ifndef BSSM_WG_RELOAD_MAT
+#define BSSM_WG_RELOAD_MAT 1
+#endif
+  constexpr int NMAT = MP * MP + MP * KP + MP;
+  constexpr bool kLdsMat = FN == FN_NONE && (BSSM_WG_LDS_MAT) != 0;
+  double* __restrict__ s_mat = s_piv + 64;  // [NMAT]
   const bool piv_tab = N >= 256 && (N & (N - 1)) == 0;
   const int piv_mask = (N >> 6) - 1, piv_shift = 31 - __builtin_clz((unsigned)((N >> 6) > 0 ? (N >> 6) : 1));
 
@@ -422,6 +439,10 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
 
     // ---- stratified resampling (stratified_sample.cpp:15-26) + ancestor gather (:657-661)
     const double c_scale = S / dN;
+    if constexpr (kLdsMat) {  // (the previous step's transition has been read: every wave has passed barriers (1) and (3) since)
+      const double* __restrict__ msrc = mats + (size_t)t * b.mats_tstride;
+      for (int q = tid; q < NMAT; q += NT) s_mat[q] = msrc[q];
+    }
     double a[PPT][MP];
     u32x4 blk[PPT];  // step blocks: spare word -> resampling uniform now, words 0-2 -> transition normals below
     double v[PPT];
@@ -503,7 +524,15 @@ __global__ void __launch_bounds__(NTB) pf_wg_kernel(const FilterBatch b) {
       } else {
         double z[KP];
         rng_normals_blk<KP, kPack>(blk[r], key_p, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
-        propagate<MP, KP>(mt, a[r], z, x);
+        if constexpr (kLdsMat) {
+          int zero = 0;  // opaque: the matrix is re-read per particle instead of being kept live in 2 NMAT VGPRs
+          __asm__ volatile("" : "+v"(zero));
+          propagate<MP, KP>((const double*)(s_mat + zero), a[r], z, x);
+        } else if constexpr ((BSSM_WG_RELOAD_MAT) != 0) {
+          propagate<MP, KP>(reload_table(mt), a[r], z, x);  // scalar loads re-issued per particle: the matrix lives in SGPRs only here
+        } else {
+          propagate<MP, KP>(mt, a[r], z, x);
+        }
       }
       if (i < N) {
 #pragma unroll
@@ -561,6 +590,14 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
     wide = N >= 2048;
     if (opt().wg_wide >= 0) wide = opt().wg_wide != 0 && N > 1024;
   }
+  // four-dimensional states of the linear-state models (late round 4): above 1024 particles a filter is given 2048 slots, more than
+  // half of a CU's LDS (5 x 2048 doubles + tables > 80 KB), so a CU holds ONE 512-thread workgroup = two waves per SIMD, and the barriers of a
+  // step leave the VALU idle (regime B of bench.py: 0.60 of the issue roof).  The table-driven math of rounds 2-3 fits the
+  // 128-register budget of a 1024-thread workgroup at two / four particles per lane without a spill
+  if constexpr (MP == 4) {
+    wide = N > 1024 && !b.fpar;
+    if (opt().wg_wide >= 0) wide = opt().wg_wide != 0 && N > 1024 && !b.fpar;
+  }
   const int ntmax = wide ? 1024 : WG_NT_MAX;
   int ppt = 1;
   while (ppt < 16 && N > ntmax * ppt) ppt *= 2;
@@ -569,6 +606,15 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch) = nullptr;
   if (wide) {
+#ifndef BSSM_USER_MODEL
+    if constexpr (MP == 4) {
+      switch (ppt) {
+        case 2: kern = pf_wg_kernel<MP, KP, 2, FN_NONE, 1024>; break;
+        case 4: kern = pf_wg_kernel<MP, KP, 4, FN_NONE, 1024>; break;
+        default: return hipErrorInvalidValue;
+      }
+    }
+#endif
     if constexpr (MP <= 2) {
       const bool fn = b.fpar != nullptr;
       if (fn && MP != KP) return hipErrorInvalidValue;

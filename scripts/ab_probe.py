@@ -36,4 +36,8 @@ for tag, R in (("c4_64", 64), ("c4_32", 32), ("c4_8", 8), ("c4_1", 1)):
 if "regb" in what:
     v, k = run(negbin_m4_informative(1000), 2048, 512, 1000, 5, keep_history=False, force="wg")
     out.append("regb %.4g" % v)
+for tag, (Nb, Rb) in (("regb1k", (1024, 1024)), ("regb512", (512, 2048)), ("regb1536", (1536, 512))):
+    if tag in what:
+        v, k = run(negbin_m4_informative(1000), Nb, Rb, 1000, 5, keep_history=False, force="wg")
+        out.append("%s %.4g" % (tag, v))
 print("  ".join(out))
