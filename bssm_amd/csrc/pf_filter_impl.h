@@ -311,18 +311,26 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
   // from s_cdf the 64 lanes' addresses are W doubles apart -- one bank for W = 64: a 64-way conflict per particle row.
   // Used when N is a power of two (W a power of two: the owner of a pivot entry is found with a mask).
   double* __restrict__ s_piv = s_tot + PPT * 16;
-  // T_t, R_t, C_t of the step for the linear-state transition, staged by the first threads under the search and published by
-  // barrier (4); read back as broadcast ds_reads.  Through scalar loads the 36 doubles of a four-dimensional state are 72 SGPRs
-  // on top of the loop invariants of the time loop: 130-150 SGPRs lived in VGPR lanes and came back through v_readlane (the
-  // round-2 finding of the step kernels, pf_grid_v2.h `s_mat`, here too).  BSSM_WG_LDS_MAT=0: the scalar-load form.
+  // T_t, R_t, C_t of the step for the linear-state transition.  Through scalar loads the 36 doubles of a four-dimensional state are
+  // 72 SGPRs on top of the loop invariants of the time loop (130-150 SGPRs lived in VGPR lanes and came back through v_readlane).
+  // Two remedies measured late in round 4 (same-box A/B, 512 ... 2048 particles, profiles/r04_wg_occupancy_ab.txt):
+  //   BSSM_WG_RELOAD_MAT (default): the scalar loads are re-issued per particle (reload_table), so the matrix occupies the scalar
+  //     file only inside one transition: +1.5 ... +4 %;
+  //   BSSM_WG_LDS_MAT: staged in LDS by the first threads under the search, published by barrier (4), read back as broadcast
+  //     ds_reads (what the step kernels do, pf_grid_v2.h `s_mat`): +5 ... +7 % at two / four particles per lane of a 512-thread
+  //     workgroup, -18 % in the 1024-thread form, -35 % at one particle per lane, -20 % for eight-dimensional states (136 reads
+  //     per particle through the one LDS pipe of the CU) -- not used.
 #ifndef BSSM_WG_LDS_MAT
 #define BSSM_WG_LDS_MAT 0
+#endif
+#ifndef BSSM_WG_LDS_MAT_FROM
+#define BSSM_WG_LDS_MAT_FROM 99  // padded state dimension from which the LDS form is used: never -- measured slower overall (above)
 #endif
 #ifndef BSSM_WG_RELOAD_MAT
 #define BSSM_WG_RELOAD_MAT 1
 #endif
   constexpr int NMAT = MP * MP + MP * KP + MP;
-  constexpr bool kLdsMat = FN == FN_NONE && (BSSM_WG_LDS_MAT) != 0;
+  constexpr bool kLdsMat = FN == FN_NONE && ((BSSM_WG_LDS_MAT) != 0 || MP >= (BSSM_WG_LDS_MAT_FROM));
   double* __restrict__ s_mat = s_piv + 64;  // [NMAT]
   const bool piv_tab = N >= 256 && (N & (N - 1)) == 0;
   const int piv_mask = (N >> 6) - 1, piv_shift = 31 - __builtin_clz((unsigned)((N >> 6) > 0 ? (N >> 6) : 1));
@@ -578,6 +586,9 @@ auto wg_fn_kernel(int psi) -> void (*)(const FilterBatch) {
 }
 #define WG_FN_KERNEL(PPT_, NTB_) wg_fn_kernel<MP, PPT_, kFn, NTB_>(b.psi)
 #define GRID_FN_KERNEL(PPT_) grid_fn_kernel<MP, KP, PPT_, kFn>(b.psi)
+#ifndef BSSM_WG_WIDE_FROM
+#define BSSM_WG_WIDE_FROM 1025   // (2048 until late round 4: N = 1536, m = 1 ran 512 x 4 at 144 VGPRs, one workgroup of two waves per SIMD per CU: +30 % as 1024 x 2)
+#endif
 template <int MP, int KP>
 hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   const int N = b.N;
@@ -587,7 +598,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   // of two hide the barrier and LDS latency of the one workgroup a CU can hold at these sizes
   bool wide = false;
   if constexpr (MP <= 2) {
-    wide = N >= 2048;
+    wide = N >= (BSSM_WG_WIDE_FROM);
     if (opt().wg_wide >= 0) wide = opt().wg_wide != 0 && N > 1024;
   }
   // four-dimensional states of the linear-state models (late round 4): above 1024 particles a filter is given 2048 slots, more than

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 from bssm_amd import _lib  # noqa: E402
 from bssm_amd.plan import FilterPlan  # noqa: E402
-from models_zoo import mng_c4, negbin_m4_informative  # noqa: E402
+from models_zoo import mng_c4, negbin_ar1, negbin_m4_informative  # noqa: E402
 
 st = torch.cuda.current_stream().cuda_stream
 what = sys.argv[1].split(",") if len(sys.argv) > 1 else ["head", "c4_64", "c4_32", "regb"]
@@ -39,5 +39,13 @@ if "regb" in what:
 for tag, (Nb, Rb) in (("regb1k", (1024, 1024)), ("regb512", (512, 2048)), ("regb1536", (1536, 512))):
     if tag in what:
         v, k = run(negbin_m4_informative(1000), Nb, Rb, 1000, 5, keep_history=False, force="wg")
+        out.append("%s %.4g" % (tag, v))
+for tag, (Nb, Rb) in (("wg8_1k", (1024, 512)), ("wg8_256", (256, 2048)), ("wg8_2k", (2048, 256))):
+    if tag in what:
+        v, k = run(mng_c4(500), Nb, Rb, 500, 5, keep_history=False, force="wg")
+        out.append("%s %.4g" % (tag, v))
+for tag, (Nb, Rb) in (("m1_1k", (1024, 1024)), ("m1_1536", (1536, 512)), ("m1_2k", (2048, 512))):
+    if tag in what:
+        v, k = run(negbin_ar1(1000), Nb, Rb, 1000, 5, keep_history=False, force="wg")
         out.append("%s %.4g" % (tag, v))
 print("  ".join(out))
