@@ -16,6 +16,7 @@
 // fixed-shape reductions/scans only (no floating-point atomics): results are bit-reproducible
 // run to run and independent of the number of GPUs a batch is sharded over.
 #pragma once
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -93,12 +94,43 @@ __device__ __forceinline__ double log_weight_of(const FilterBatch& b, PT row, co
 
 // alpha_{t+1} = C_t + T_t a + R_t eta   (src/model_ssm_ung.cpp:663-670); for the psi-APF the host
 // folds alphahat/Ct/Vt into the same three operands (src/model_ssm_ung.cpp:585-586).
+// BSSM_PROPAGATE_COLS: for eight- and sixteen-dimensional states read through scalar loads the matrices go through the scalar
+// file ONE COLUMN AT A TIME (16 / 32 SGPRs), each column's loads re-issued behind an opaque pointer and pinned in place.  In the
+// row-by-row form the compiler requests all 136 / 528 doubles up front -- 272+ SGPRs against a file of 106: the rest lived in VGPR
+// lanes (600-2000 spill slots in the m = 8 workgroup kernels) and every use came back through v_readlane.  Every x_j is still
+// accumulated over the columns in the same order with the same fused multiply-adds: same bits.
+#ifndef BSSM_PROPAGATE_COLS
+#define BSSM_PROPAGATE_COLS 1
+#endif
 template <int MP, int KP, class PT>
 __device__ __forceinline__ void propagate(PT mt, const double (&a)[MP], const double (&z)[KP],
                                           double (&x)[MP]) {
   const PT Tm = mt;
   const PT Rm = mt + MP * MP;
   const PT Cv = mt + MP * MP + MP * KP;
+  if constexpr ((BSSM_PROPAGATE_COLS) != 0 && MP >= 8 && std::is_same<PT, const cdbl*>::value) {
+    double s[MP], q[MP];
+#pragma unroll
+    for (int j = 0; j < MP; j++) { s[j] = 0.0; q[j] = 0.0; }
+#pragma unroll
+    for (int c = 0; c < MP; c++) {
+      const cdbl* col = reload_table(Tm + MP * c);
+#pragma unroll
+      for (int j = 0; j < MP; j++) s[j] += col[j] * a[c];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < KP; c++) {
+      const cdbl* col = reload_table(Rm + MP * c);
+#pragma unroll
+      for (int j = 0; j < MP; j++) q[j] += col[j] * z[c];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const cdbl* cv = reload_table(Cv);
+#pragma unroll
+    for (int j = 0; j < MP; j++) x[j] = cv[j] + s[j] + q[j];
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MP; j++) {
     double s = 0.0, q = 0.0;
@@ -283,12 +315,21 @@ __device__ __forceinline__ constexpr int step_draw_count() { return FN == FN_NON
 #ifndef BSSM_WG_NT
 #define BSSM_WG_NT 1
 #endif
+// Waves per SIMD the 512-thread kernels are budgeted for.  Two particles per lane of a linear-state filter with at most four
+// states came out at 132 VGPRs -- four over the 128 that let TWO workgroups share a CU (N <= 1024 needs 40 KB of LDS each).
+// Eight-dimensional states, one particle per lane (N <= 512, 36 KB of LDS): 170 -> 128 VGPRs, four workgroups of 256 threads per
+// CU instead of two: +28 % at N = 256; at two particles per lane the same budget spills and loses 7 % (BSSM_WG_OCC8 = 1).
+// profiles/r04_wg_occupancy_ab.txt
+#ifndef BSSM_WG_OCC8
+#define BSSM_WG_OCC8 1
+#endif
+template <int MP, int PPT, int FN, int NTB>
+constexpr int wg_waves_per_simd() {
+  if (FN == FN_NONE && MP == 8 && NTB == WG_NT_MAX && PPT <= (BSSM_WG_OCC8)) return 4;
+  return (FN == FN_NONE && MP <= 4 && NTB == WG_NT_MAX && PPT == 2) ? 4 : (NTB + 255) / 256;
+}
 // EX: the particle count is exactly NTB * PPT (4096 = 1024 x 4, the shape IS post-correction of config C5 runs): N is a
 // compile-time constant, every `i < N` guard and the pivot / window arithmetic derived from N fold away
-// waves per SIMD the 512-thread kernels are budgeted for: two particles per lane of a linear-state filter with at most four
-// states came out at 132 VGPRs -- four over the 128 that let TWO workgroups share a CU (N <= 1024 needs 40 KB of LDS each)
-template <int MP, int PPT, int FN, int NTB>
-constexpr int wg_waves_per_simd() { return (FN == FN_NONE && MP <= 4 && NTB == WG_NT_MAX && PPT == 2) ? 4 : (NTB + 255) / 256; }
 template <int MP, int KP, int PPT, int FN = FN_NONE, int NTB = WG_NT_MAX, int PM = -1, bool EX = false>
 __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) pf_wg_kernel(const FilterBatch b) {
   constexpr int FID = FN > 0 ? FN : 0;
