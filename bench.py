@@ -36,8 +36,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 # wave-level VALU instructions per particle-step of the workgroup-resident kernels, from the PMC passes committed under
 # profiles/r04_pmc_*.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_r04.sh; regime B: profiles/r04_pmc_regb.txt)
-REGB_VALU_PER_PSTEP = 9588020533.1 / (512 * 2048 * 1000.0)    # pf_wg_kernel<4,4,4,false,512> (profiles/r04_pmc_regb.txt; round 3: 9.94e9)
-C5_VALU_PER_PSTEP = 18125027041.0 / (2340.0 * 4096 * 300.0)   # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), one dispatch of 2 340 draws (profiles/r04_pmc_C5.txt)
+REGB_VALU_PER_PSTEP = 10595336946.0 / (512 * 2048 * 1000.0)   # pf_wg_kernel<4,4,2,false,1024> (profiles/r04_pmc_regb_v2.txt; the 512-thread kernel of rounds 3-4: 9.59e9, r04_pmc_regb.txt)
+C5_VALU_PER_PSTEP = 17732461621.0 / (2340.0 * 4096 * 300.0)   # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), one dispatch of 2 340 draws (profiles/r04_pmc_C5.txt, late-round-4 entry; 18.13e9 before the logarithm of the log-likelihood moved to one wave)
 C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1,exact>"
 HEAD_VALU_PER_PSTEP = 7813185.0 / (16 * 65536.0)                # pf_grid_step_v2<4,4,4,false,true,true>: 7.81 M per launch of 16 filters x 65 536 particles (profiles/r04_pmc_sq1_summary.txt; round 3: 8.36 M)
 C4_VALU_PER_PSTEP = 6583014.7 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r04_pmc_C4.txt; round 3: 7.14 M)
@@ -48,7 +48,7 @@ def valu_roofline(valu_per_pstep, psteps_per_s, kernel, clock=None):
     out = {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
            "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
            "lane_instr_per_particle_step": valu_per_pstep * 64,
-           "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r04_pmc_sq1_summary.txt, r04_pmc_C4.txt, r04_pmc_C5.txt, r04_pmc_regb.txt); rate: measured live"}
+           "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r04_pmc_sq1_summary.txt, r04_pmc_C4.txt, r04_pmc_C5.txt, r04_pmc_regb_v2.txt); rate: measured live"}
     if clock and clock.get("sclk_mhz"):
         # the issue roof at the engine clock the kernel actually ran at (the socket power limit holds it under 2.4 GHz)
         out["frac_at_sampled_clock"] = a / (256 * 4 * clock["sclk_mhz"] * 1e6 / 4)
@@ -750,7 +750,7 @@ def main():
                            "kernel": pb.last_kernel(), "kernel_ms": kb_ms,
                            "algorithmic_GBs": ps * ib["bytes_per_particle_step"] / (kb_ms * 1e-3) / 1e9,
                            "note": "state never leaves LDS: HBM traffic ~0, bound by fp64 VALU/transcendentals",
-                           "roofline_valu": valu_roofline(REGB_VALU_PER_PSTEP, ps / (kb_ms * 1e-3), "pf_wg_kernel<4,4,4,false,512>")}
+                           "roofline_valu": valu_roofline(REGB_VALU_PER_PSTEP, ps / (kb_ms * 1e-3), pb.last_kernel())}
         pb.close()
 
     if rank == 0 and world == 1 and not args.no_regime_b and not args.no_mng:

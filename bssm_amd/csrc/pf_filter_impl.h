@@ -385,7 +385,8 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
   constexpr bool kPack = FN == FN_NONE;
   const double* __restrict__ amats = (FN && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
   const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP), m = b.m;
-  const double dN = (double)N;
+  const double dN = (double)N, inv_dN = 1.0 / dN;
+  const bool n_pow2 = (N & (N - 1)) == 0;
 
   double w[PPT];  // log-weights of my particles at the current time
   double loglik = 0.0;
@@ -480,14 +481,17 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
       if (tid == 0) b.dead_at[f] = t + 1;
       break;
     }
-    loglik += M + tl_log(S / dN);                       // :683
+    // S / N: a multiplication where N is a power of two (exact, the same bits as the division: the 25 instructions of an fp64
+    // division once per wave-step were 2 % of the two-particles-per-lane kernels); the logarithm only where the sum is read
+    // (thread 0 writes the log-likelihood)
+    const double c_scale = n_pow2 ? S * inv_dN : S / dN;
+    if (wave == 0) loglik += M + tl_log(c_scale);       // :683
     if (t == n) break;
     WG_STAMP(3);
     lds_barrier();  // (3) cdf visible
     WG_STAMP(1);
 
     // ---- stratified resampling (stratified_sample.cpp:15-26) + ancestor gather (:657-661)
-    const double c_scale = S / dN;
     if constexpr (kLdsMat) {  // (the previous step's transition has been read: every wave has passed barriers (1) and (3) since)
       const double* __restrict__ msrc = mats + (size_t)t * b.mats_tstride;
       for (int q = tid; q < NMAT; q += NT) s_mat[q] = msrc[q];
