@@ -373,6 +373,15 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
   constexpr int NMAT = MP * MP + MP * KP + MP;
   constexpr bool kLdsMat = FN == FN_NONE && ((BSSM_WG_LDS_MAT) != 0 || MP >= (BSSM_WG_LDS_MAT_FROM));
   double* __restrict__ s_mat = s_piv + 64;  // [NMAT]
+  // Eight-dimensional states, linear transition, one or two particles per lane: the transition on the matrix cores through a
+  // 4 KB operand tile per wave (propagate_mfma8_h, the step kernels' routine) -- the scalar-load form spent 41 % of its VALU
+  // instructions on v_readlane of spilt dwordx16 tuples (profiles/r04_wg_occupancy_ab.txt).  The tile sits behind s_mat
+  // (launch_wg_mk sizes the dynamic LDS for it); above 1024 slots a filter's LDS has no room for it.
+#ifndef BSSM_WG_MFMA8
+#define BSSM_WG_MFMA8 1
+#endif
+  constexpr bool kWgMfma = FN == FN_NONE && MP == 8 && PPT <= 2 && NTB == WG_NT_MAX && (BSSM_WG_MFMA8) != 0;
+  double* __restrict__ s_tile = s_mat + ((NMAT + 1) & ~1) + (kWgMfma ? wave * 512 : 0);
   const bool piv_tab = N >= 256 && (N & (N - 1)) == 0;
   const int piv_mask = (N >> 6) - 1, piv_shift = 31 - __builtin_clz((unsigned)((N >> 6) > 0 ? (N >> 6) : 1));
 
@@ -577,7 +586,9 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
       } else {
         double z[KP];
         rng_normals_blk<KP, kPack>(blk[r], key_p, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
-        if constexpr (kLdsMat) {
+        if constexpr (kWgMfma) {
+          propagate_mfma8_h<KP>((const double*)(mats + (size_t)t * b.mats_tstride), a[r], z, x, s_tile, lane);
+        } else if constexpr (kLdsMat) {
           int zero = 0;  // opaque: the matrix is re-read per particle instead of being kept live in 2 NMAT VGPRs
           __asm__ volatile("" : "+v"(zero));
           propagate<MP, KP>((const double*)(s_mat + zero), a[r], z, x);
@@ -658,7 +669,8 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   int ppt = 1;
   while (ppt < 16 && N > ntmax * ppt) ppt *= 2;
   const int nt = ppt == 1 ? (N + 63) / 64 * 64 : ntmax;
-  const size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16 + 64 + (MP * MP + MP * KP + MP)) * sizeof(double);
+  size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16 + 64 + (MP * MP + MP * KP + MP)) * sizeof(double);
+  if (MP == 8 && !b.fpar && !wide && ppt <= 2) lds += (1 + (size_t)(nt / 64) * 512) * sizeof(double);  // per-wave MFMA operand tiles (pf_wg_kernel, kWgMfma)
   if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch) = nullptr;
   if (wide) {
