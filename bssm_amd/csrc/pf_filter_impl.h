@@ -253,6 +253,51 @@ __device__ __forceinline__ void propagate_mfma8_h(PT mt, const double (&a)[8], c
   for (int c = 0; c < 8; c++) x[c] = tile[c * 64 + lane];
 }
 
+// The same contraction through a 4 x 64 tile (2 KB per wave): one K = 4 chunk of [A ; Z] at a time, the result in two halves.
+// Same multiply-accumulate order as propagate_mfma8_h (same bits).  For the workgroup-resident filter at four particles per lane,
+// whose only free LDS during the transition is its own CDF array (dead between barrier (4) and the next step's barrier (1)).
+template <int KP, class PT>
+__device__ __forceinline__ void propagate_mfma8_q(PT mt, const double (&a)[8], const double (&z)[KP],
+                                                  double (&x)[8], double* tile /* 4 x 64 doubles, this wave's */, int lane) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int i = lane & 15, kq = lane >> 4;
+  double afr[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    const int k = 4 * kk + kq;  // column of [T R]
+    afr[kk] = (i < 8) ? (k < 8 ? mt[i + 8 * k] : ((k - 8) < KP ? mt[64 + i + 8 * (k - 8)] : 0.0)) : 0.0;
+  }
+  const PT Cv = mt + 64 + 8 * KP;
+  const double c0 = Cv[kq], c1 = Cv[kq + 4];
+  d4 acc[4];
+#pragma unroll
+  for (int blk = 0; blk < 4; blk++) acc[blk] = d4{c0, c1, 0.0, 0.0};
+#pragma unroll
+  for (int st = 0; st < (KP > 4 ? 4 : 3); st++) {
+    lds_wave_sync();  // earlier readers of the tile are done
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      double v;
+      if (st < 2) v = a[4 * st + c];
+      else { const int zc = 4 * (st - 2) + c; v = zc < KP ? z[zc < KP ? zc : 0] : 0.0; }
+      tile[c * 64 + lane] = v;
+    }
+    lds_wave_sync();
+#pragma unroll
+    for (int blk = 0; blk < 4; blk++)
+      acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[st], tile[kq * 64 + 16 * blk + i], acc[blk], 0, 0, 0);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++) {  // rows kq (h = 0) and kq + 4 (h = 1) of the result are state components
+    lds_wave_sync();
+#pragma unroll
+    for (int blk = 0; blk < 4; blk++) tile[kq * 64 + 16 * blk + i] = acc[blk][h];
+    lds_wave_sync();
+#pragma unroll
+    for (int c = 0; c < 4; c++) x[4 * h + c] = tile[c * 64 + lane];
+  }
+}
+
 // one particle's log-weight for whichever model family the kernel was instantiated for
 // PM: the sampler of a functor kernel fixed at compile time (0 bootstrap, 1 psi-APF, 2 EKF particle filter; -1 = read
 // b.psi): a kernel that carries all three keeps the union of their registers live (the nlg_growth psi-APF kernel at 1024
@@ -382,6 +427,9 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
 #endif
   constexpr bool kWgMfma = FN == FN_NONE && MP == 8 && PPT <= 2 && NTB == WG_NT_MAX && (BSSM_WG_MFMA8) != 0;
   double* __restrict__ s_tile = s_mat + ((NMAT + 1) & ~1) + (kWgMfma ? wave * 512 : 0);
+  // four particles per lane (1025 ... 2048 slots, 147 KB of state): 2 KB tiles inside the filter's CDF array, which nobody reads
+  // between barrier (4) and the next step's barrier (1) (eight waves x 256 doubles = the array's 2048 entries)
+  constexpr bool kWgMfmaQ = FN == FN_NONE && MP == 8 && PPT == 4 && NTB == WG_NT_MAX && (BSSM_WG_MFMA8) != 0;
   const bool piv_tab = N >= 256 && (N & (N - 1)) == 0;
   const int piv_mask = (N >> 6) - 1, piv_shift = 31 - __builtin_clz((unsigned)((N >> 6) > 0 ? (N >> 6) : 1));
 
@@ -588,6 +636,8 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
         rng_normals_blk<KP, kPack>(blk[r], key_p, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
         if constexpr (kWgMfma) {
           propagate_mfma8_h<KP>((const double*)(mats + (size_t)t * b.mats_tstride), a[r], z, x, s_tile, lane);
+        } else if constexpr (kWgMfmaQ) {
+          propagate_mfma8_q<KP>((const double*)(mats + (size_t)t * b.mats_tstride), a[r], z, x, s_cdf + wave * 256, lane);
         } else if constexpr (kLdsMat) {
           int zero = 0;  // opaque: the matrix is re-read per particle instead of being kept live in 2 NMAT VGPRs
           __asm__ volatile("" : "+v"(zero));

@@ -244,3 +244,24 @@ def test_mng_eight_states_rows_smoother_with_missing_observations(oracle, monkey
     for i in range(0, ns, 9):
         ref = oracle.mng_psi_filter(arrs[i], 48, seed=21, stream=i, is_mode=modes[:, i].reshape(p, n, order="F"))
         assert abs(rows["loglik"][i] - ref["logLik"]) <= 1e-8 * n
+
+
+@pytest.mark.parametrize("N", [300, 1000, 1500, 2048])
+def test_mng_eight_states_workgroup_resident_transition_on_the_matrix_cores(oracle, monkeypatch, N):
+    """m = 8 workgroup-resident filters run their transition through v_mfma_f64_16x16x4 (late round 4): one / two particles per
+    lane with a 4 KB operand tile per wave (N = 300, 1000), four per lane with 2 KB tiles inside the filter's CDF array
+    (N = 1500 ragged, 2048 full); bootstrap filter and psi-APF smoother against the oracle"""
+    from bssm_amd.plan import FilterPlan
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "wg")
+    model = ZOO["c4_m8_p4"]
+    arr = M.model_arrays(model)
+    out = F.bootstrap_filter(model, N, seed=11, return_indices=True)
+    assert "pf_wg_kernel<8" in FilterPlan.last_kernel()
+    ref = oracle.mng_bsf_filter(arr, N, seed=11)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-9
+    sm = F.particle_smoother(model, N, method="psi", seed=12)
+    rs = oracle.mng_psi_filter(arr, N, seed=12)
+    assert abs(sm["logLik"] - rs["logLik"]) <= 1e-9 * model.n
