@@ -298,6 +298,69 @@ __device__ __forceinline__ void propagate_mfma8_q(PT mt, const double (&a)[8], c
   }
 }
 
+// Sixteen-dimensional states (m = 9 ... 16: seasonal components): X' (16 x 64) = C + [T R] (16 x (16 + KP)) . [A ; Z], every row of
+// the 16 x 16 result tile a state component.  One K = 4 chunk of [A ; Z] at a time through a 4 x 64 tile (2 KB per wave), the result
+// in four quarters.  The scalar-load form needs 336 ... 528 doubles in a scalar file of 106 registers: 4 300 VALU instructions per
+// particle-step, most of them v_readlane (profiles/r04_wg_occupancy_ab.txt).
+// W = 64: the tile holds a chunk of all 64 particles of the wave; W = 32: of one half-wave at a time (1 KB per wave -- what the CDF
+// array of a two-particles-per-lane filter leaves per wave); same multiply-accumulate order per particle either way.
+template <int KP, int W, class PT>
+__device__ __forceinline__ void propagate_mfma16_q(PT mt, const double (&a)[16], const double (&z)[KP],
+                                                   double (&x)[16], double* tile /* 4 x W doubles, this wave's */, int lane) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int KZ = (KP + 3) / 4, NK = 4 + KZ;  // K chunks: four of the state, KZ of the noise
+  constexpr int NH = 64 / W, BPH = W / 16;        // passes per chunk, 16-particle blocks per pass
+  const int i = lane & 15, kq = lane >> 4, lw = lane & (W - 1);
+  const bool mine[2] = {NH == 1 || lane < 32, NH == 2 && lane >= 32};
+  double afr[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; kk++) {
+    const int k = 4 * kk + kq;  // column of [T R]
+    afr[kk] = k < 16 ? mt[i + 16 * k] : ((k - 16) < KP ? mt[256 + i + 16 * (k - 16)] : 0.0);
+  }
+  const PT Cv = mt + 256 + 16 * KP;
+  d4 acc[4];
+  {
+    const double c0 = Cv[kq], c1 = Cv[kq + 4], c2 = Cv[kq + 8], c3 = Cv[kq + 12];
+#pragma unroll
+    for (int blk = 0; blk < 4; blk++) acc[blk] = d4{c0, c1, c2, c3};
+  }
+#pragma unroll
+  for (int st = 0; st < NK; st++) {
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      lds_wave_sync();  // earlier readers of the tile are done
+      if (mine[h]) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          double v;
+          if (st < 4) v = a[4 * st + c];
+          else { const int zc = 4 * (st - 4) + c; v = zc < KP ? z[zc < KP ? zc : 0] : 0.0; }
+          tile[c * W + lw] = v;
+        }
+      }
+      lds_wave_sync();
+#pragma unroll
+      for (int bb = 0; bb < BPH; bb++)
+        acc[BPH * h + bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[st], tile[kq * W + 16 * bb + i], acc[BPH * h + bb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {  // rows kq + 4 q of the result
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      lds_wave_sync();
+#pragma unroll
+      for (int bb = 0; bb < BPH; bb++) tile[kq * W + 16 * bb + i] = acc[BPH * h + bb][q];
+      lds_wave_sync();
+      if (mine[h]) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) x[4 * q + c] = tile[c * W + lw];
+      }
+    }
+  }
+}
+
 // one particle's log-weight for whichever model family the kernel was instantiated for
 // PM: the sampler of a functor kernel fixed at compile time (0 bootstrap, 1 psi-APF, 2 EKF particle filter; -1 = read
 // b.psi): a kernel that carries all three keeps the union of their registers live (the nlg_growth psi-APF kernel at 1024
@@ -430,6 +493,11 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
   // four particles per lane (1025 ... 2048 slots, 147 KB of state): 2 KB tiles inside the filter's CDF array, which nobody reads
   // between barrier (4) and the next step's barrier (1) (eight waves x 256 doubles = the array's 2048 entries)
   constexpr bool kWgMfmaQ = FN == FN_NONE && MP == 8 && PPT == 4 && NTB == WG_NT_MAX && (BSSM_WG_MFMA8) != 0;
+  // sixteen-dimensional states, one particle per lane (N <= 512): 2 KB tiles behind s_mat (launch_wg_mk adds them)
+  constexpr bool kWgMfma16 = FN == FN_NONE && MP == 16 && PPT == 1 && NTB == WG_NT_MAX && (BSSM_WG_MFMA8) != 0;
+  double* __restrict__ s_tile16 = s_mat + ((NMAT + 1) & ~1) + (kWgMfma16 ? wave * 256 : 0);
+  // two particles per lane (513 ... 1024 slots, 139 KB of state): half-wave tiles of 1 KB inside the CDF array (8 waves x 128 doubles)
+  constexpr bool kWgMfma16H = FN == FN_NONE && MP == 16 && PPT == 2 && NTB == WG_NT_MAX && (BSSM_WG_MFMA8) != 0;
   const bool piv_tab = N >= 256 && (N & (N - 1)) == 0;
   const int piv_mask = (N >> 6) - 1, piv_shift = 31 - __builtin_clz((unsigned)((N >> 6) > 0 ? (N >> 6) : 1));
 
@@ -636,6 +704,10 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
         rng_normals_blk<KP, kPack>(blk[r], key_p, RNG_TRANSITION, (uint32_t)t, (uint32_t)i, z);
         if constexpr (kWgMfma) {
           propagate_mfma8_h<KP>((const double*)(mats + (size_t)t * b.mats_tstride), a[r], z, x, s_tile, lane);
+        } else if constexpr (kWgMfma16) {
+          propagate_mfma16_q<KP, 64>((const double*)(mats + (size_t)t * b.mats_tstride), a[r], z, x, s_tile16, lane);
+        } else if constexpr (kWgMfma16H) {
+          propagate_mfma16_q<KP, 32>((const double*)(mats + (size_t)t * b.mats_tstride), a[r], z, x, s_cdf + wave * 128, lane);
         } else if constexpr (kWgMfmaQ) {
           propagate_mfma8_q<KP>((const double*)(mats + (size_t)t * b.mats_tstride), a[r], z, x, s_cdf + wave * 256, lane);
         } else if constexpr (kLdsMat) {
@@ -721,6 +793,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   const int nt = ppt == 1 ? (N + 63) / 64 * 64 : ntmax;
   size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16 + 64 + (MP * MP + MP * KP + MP)) * sizeof(double);
   if (MP == 8 && !b.fpar && !wide && ppt <= 2) lds += (1 + (size_t)(nt / 64) * 512) * sizeof(double);  // per-wave MFMA operand tiles (pf_wg_kernel, kWgMfma)
+  if (MP == 16 && !b.fpar && !wide && ppt == 1) lds += (1 + (size_t)(nt / 64) * 256) * sizeof(double);  // (kWgMfma16)
   if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch) = nullptr;
   if (wide) {

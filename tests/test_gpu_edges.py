@@ -46,6 +46,33 @@ def test_maximum_particles_ragged(oracle):
         F.bootstrap_filter(model, 100001, seed=5)
 
 
+@pytest.mark.parametrize("N", [300, 800])
+def test_seasonal_model_thirteen_states_workgroup_resident(oracle, monkeypatch, N):
+    """bsm_ng with a monthly seasonal (m = 13, padded to 16): the workgroup-resident filter runs its transition on the matrix
+    cores (late round 4; one particle per lane with 2 KB tiles per wave, two per lane with half-wave tiles inside the CDF
+    array); bootstrap filter and psi-APF smoother against the oracle"""
+    from bssm_amd.plan import FilterPlan
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "wg")
+    rng = np.random.default_rng(13)
+    tt = np.arange(40)
+    y = rng.poisson(np.exp(1.5 + 0.5 * np.sin(2 * np.pi * tt / 12.0))).astype(float)
+    y[7] = np.nan
+    a1 = np.zeros(13); a1[0] = 1.5
+    model = M.bsm_ng(y, sd_level=0.05, sd_slope=0.005, sd_seasonal=0.02, distribution="poisson", period=12, a1=a1, P1=0.05 * np.eye(13))
+    arr = M.model_arrays(model)
+    assert arr["m"] == 13
+    out = F.bootstrap_filter(model, N, seed=4, return_indices=True)
+    assert "pf_wg_kernel<16" in FilterPlan.last_kernel()
+    ref = oracle.bsf_filter(arr, N, seed=4)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-9
+    sm = F.particle_smoother(model, N, method="psi", seed=5)
+    rs = oracle.psi_filter(arr, N, seed=5)
+    assert abs(sm["logLik"] - rs["logLik"]) <= 1e-9 * model.n
+
+
 @pytest.mark.parametrize("path", ["wg", "grid"])
 def test_state_dimension_16(oracle, monkeypatch, path):
     monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
