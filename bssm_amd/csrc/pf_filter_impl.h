@@ -952,6 +952,9 @@ __device__ __forceinline__ int search16_lds(const double* a, int stride, int len
 #ifndef BSSM_R1_NT
 #define BSSM_R1_NT 0
 #endif
+#ifndef BSSM_GRID_MFMA16
+#define BSSM_GRID_MFMA16 1
+#endif
 template <int MP, int KP, int PPT, bool DBG = false, int FN = FN_NONE, int PM = -1>
 __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE)) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   constexpr int FID = FN > 0 ? FN : 0;
@@ -963,6 +966,10 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
   __shared__ double s_tot[PPT * 4];
   constexpr bool kMfma = MP == 8 && PPT == 1 && FN == FN_NONE;  // fp64 MFMA transition (ssm_mng m = 8)
   __shared__ double s_tile[kMfma ? 4 * 16 * 64 : 1];
+  // sixteen-dimensional states (seasonal models beyond the workgroup-resident capacity): the transition on the matrix cores through
+  // 2 KB tiles per wave (propagate_mfma16_q); the scalar-load form kept 336 ... 528 doubles of T, R, C in a scalar file of 106 registers
+  constexpr bool kMfma16 = MP == 16 && FN == FN_NONE && (BSSM_GRID_MFMA16) != 0;
+  __shared__ double s_tile16[kMfma16 ? 4 * 256 : 1];
   // per wave: the window of the source block's local scan its 64 slots fall into (the MFMA variant stages it in its
   // operand tile, which is idle during the search)
   __shared__ double s_win[kMfma ? 1 : 4 * 128];
@@ -1111,7 +1118,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
     #pragma unroll
       for (int r = 0; r < PPT; r++) {
         const int li = r * GRID_NT + tid, j = base + li;
-        if (!kMfma && li >= len) { for (int c = 0; c < MP; c++) x[r][c] = 0.0; continue; }  // (MFMA needs the whole wave)
+        if (!kMfma && !kMfma16 && li >= len) { for (int c = 0; c < MP; c++) x[r][c] = 0.0; continue; }  // (MFMA needs the whole wave)
         double u;
         u32x4 blk{0u, 0u, 0u, 0u};
         if constexpr (kEarlyRng) u = u_pre[r];
@@ -1238,6 +1245,12 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
           }
         } else if constexpr (kEarlyRng) {
           propagate<MP, KP>(mt, a, z_pre[r], x[r]);
+        } else if constexpr (kMfma16) {
+          if constexpr (MP == 16) {
+            double z[KP];
+            rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+            propagate_mfma16_q<KP, 64>((const double*)(b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride), a, z, x[r], s_tile16 + wave * 256, lane);
+          }
         } else {
           double z[KP];
           rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);

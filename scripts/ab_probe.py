@@ -48,13 +48,17 @@ for tag, (Nb, Rb) in (("m1_1k", (1024, 1024)), ("m1_1536", (1536, 512)), ("m1_2k
     if tag in what:
         v, k = run(negbin_ar1(1000), Nb, Rb, 1000, 5, keep_history=False, force="wg")
         out.append("%s %.4g" % (tag, v))
-if any(t.startswith("wg16") for t in what):
+if any(t.startswith(("wg16", "g16")) for t in what):
     import numpy as np
     from bssm_amd import models as M
     rng = np.random.default_rng(5)
     tt = np.arange(300)
     ys = rng.poisson(np.exp(1.5 + 0.5 * np.sin(2 * np.pi * tt / 12.0))).astype(float)
     seas = M.bsm_ng(ys, sd_level=0.05, sd_slope=0.005, sd_seasonal=0.02, distribution="poisson", period=12)   # m = 13
+    for tag, (Nb, Rb) in (("g16_16k", (16384, 16)), ("g16_4k", (4096, 64))):
+        if tag in what:
+            v, k = run(seas, Nb, Rb, 300, 3, keep_history=True, force="grid")
+            out.append("%s %.4g (%s)" % (tag, v, k))
     for tag, (Nb, Rb) in (("wg16_256", (256, 2048)), ("wg16_512", (512, 1024)), ("wg16_1k", (1024, 512))):
         if tag in what:
             v, k = run(seas, Nb, Rb, 300, 5, keep_history=False, force="wg")

@@ -46,13 +46,13 @@ def test_maximum_particles_ragged(oracle):
         F.bootstrap_filter(model, 100001, seed=5)
 
 
-@pytest.mark.parametrize("N", [300, 800])
-def test_seasonal_model_thirteen_states_workgroup_resident(oracle, monkeypatch, N):
+@pytest.mark.parametrize("N,path", [(300, "wg"), (800, "wg"), (300, "grid"), (1500, "grid")])
+def test_seasonal_model_thirteen_states_workgroup_resident(oracle, monkeypatch, N, path):
     """bsm_ng with a monthly seasonal (m = 13, padded to 16): the workgroup-resident filter runs its transition on the matrix
     cores (late round 4; one particle per lane with 2 KB tiles per wave, two per lane with half-wave tiles inside the CDF
-    array); bootstrap filter and psi-APF smoother against the oracle"""
+    array), and so does the step kernel of sixteen-dimensional states (path = grid); bootstrap filter and psi-APF smoother against the oracle"""
     from bssm_amd.plan import FilterPlan
-    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "wg")
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
     rng = np.random.default_rng(13)
     tt = np.arange(40)
     y = rng.poisson(np.exp(1.5 + 0.5 * np.sin(2 * np.pi * tt / 12.0))).astype(float)
@@ -62,7 +62,7 @@ def test_seasonal_model_thirteen_states_workgroup_resident(oracle, monkeypatch, 
     arr = M.model_arrays(model)
     assert arr["m"] == 13
     out = F.bootstrap_filter(model, N, seed=4, return_indices=True)
-    assert "pf_wg_kernel<16" in FilterPlan.last_kernel()
+    assert ("pf_wg_kernel<16" if path == "wg" else "pf_grid_step<16") in FilterPlan.last_kernel()
     ref = oracle.bsf_filter(arr, N, seed=4)
     assert np.array_equal(out["indices"], ref["indices"])
     assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
