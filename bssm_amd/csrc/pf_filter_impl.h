@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
 #ifndef BSSM_WG_MFMA8
 #define BSSM_WG_MFMA8 1
 #endif
-  constexpr bool kWgMfma = FN == FN_NONE && MP == 8 && PPT <= 2 && NTB == WG_NT_MAX && (BSSM_WG_MFMA8) != 0;
+  constexpr bool kWgMfma = FN == FN_NONE && MP == 8 && PPT <= 2 && NTB <= WG_NT_MAX && (BSSM_WG_MFMA8) != 0;
   double* __restrict__ s_tile = s_mat + ((NMAT + 1) & ~1) + (kWgMfma ? wave * 512 : 0);
   // four particles per lane (1025 ... 2048 slots, 147 KB of state): 2 KB tiles inside the filter's CDF array, which nobody reads
   // between barrier (4) and the next step's barrier (1) (eight waves x 256 doubles = the array's 2048 entries)
@@ -827,7 +827,12 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   } else {
 #ifndef BSSM_USER_MODEL  // a user-model library only needs the functor (FN) variants: halves its compile time
   switch (ppt) {
-    case 1: kern = pf_wg_kernel<MP, KP, 1>; break;
+    case 1:
+      kern = pf_wg_kernel<MP, KP, 1>;
+      // eight-dimensional states, up to 256 particles: the variant without the 128-register budget (the budget buys a second /
+      // fourth workgroup per CU for 512-thread workgroups; small workgroups have the occupancy anyway and lose 5 ... 30 % to its spills)
+      if constexpr (MP == 8) { if (nt <= 256) kern = pf_wg_kernel<MP, KP, 1, FN_NONE, 256>; }
+      break;
     case 2: kern = pf_wg_kernel<MP, KP, 2>; break;
     case 4: kern = pf_wg_kernel<MP, KP, 4>; break;
     case 8: kern = pf_wg_kernel<MP, KP, 8>; break;

@@ -40,7 +40,7 @@ for tag, (Nb, Rb) in (("regb1k", (1024, 1024)), ("regb512", (512, 2048)), ("regb
     if tag in what:
         v, k = run(negbin_m4_informative(1000), Nb, Rb, 1000, 5, keep_history=False, force="wg")
         out.append("%s %.4g" % (tag, v))
-for tag, (Nb, Rb) in (("wg8_1k", (1024, 512)), ("wg8_256", (256, 2048)), ("wg8_2k", (2048, 256))):
+for tag, (Nb, Rb) in (("wg8_1k", (1024, 512)), ("wg8_256", (256, 2048)), ("wg8_2k", (2048, 256)), ("wg8_64", (64, 8192)), ("wg8_512", (512, 1024))):
     if tag in what:
         v, k = run(mng_c4(500), Nb, Rb, 500, 5, keep_history=False, force="wg")
         out.append("%s %.4g" % (tag, v))
