@@ -515,11 +515,13 @@ double approx_const_term(const HostModel& h, const Approx& ap) {  // src/model_s
 // ------------------------------------------------------------------ public pieces
 int pad_dim(int d) { int p = 1; while (p < d) p <<= 1; return p; }
 // padded noise dimension the kernels are instantiated for (pf_inst_mp*.hip): every power of two up to MP for MP <= 4,
-// {2, 4, 8} for MP = 8 and {4, 16} for MP = 16 -- the smallest of those that holds k
+// {2, 4, 8} for MP = 8 and {2, 4, 16} for MP = 16 -- the smallest of those that holds k.  The random-stream format of a step
+// draw (pf_device.h: WIDE up to two normals, PACKED above) is a function of the REAL k; the kernels choose it from the padded
+// KP, so KP > 2 must imply k > 2: every MP has an instantiation with KP = 2.
 int pad_noise_dim(int MP, int k) {
   int kp = pad_dim(k);
-  if (MP == 8 && kp < 2) kp = 2;
-  if (MP == 16) kp = kp <= 4 ? 4 : 16;
+  if (MP >= 8 && kp < 2) kp = 2;
+  if (MP == 16) kp = kp <= 2 ? 2 : (kp <= 4 ? 4 : 16);
   return kp > MP ? MP : kp;
 }
 

@@ -90,6 +90,27 @@ def test_state_dimension_16(oracle, monkeypatch, path):
     assert _rel(out["Pt"], ref_summary(oracle, ref)[2]) <= 1e-8
 
 
+@pytest.mark.parametrize("path", ["wg", "grid"])
+@pytest.mark.parametrize("m,k", [(12, 2), (16, 1), (9, 1), (6, 2), (16, 3)])
+def test_stream_format_follows_the_real_noise_dimension(oracle, monkeypatch, path, m, k):
+    """The random-stream format of a step draw (WIDE up to two normals, PACKED above; pf_device.h) is a function of the REAL
+    number of noise terms k, not of the padded dimension the kernel is instantiated for: a 12-state seasonal model with two
+    noise terms, or 16 states with one, must draw exactly as the oracle does (round-4 advisor finding: pad_noise_dim forced
+    KP = 4 for MP = 16)."""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    rng = np.random.default_rng(100 * m + k)
+    n = 8
+    T = 0.8 * np.linalg.qr(rng.normal(size=(m, m)))[0]
+    R = 0.2 * rng.normal(size=(m, k))
+    Z = rng.normal(0, 0.3, m)
+    model = M.ssm_ung(rng.poisson(3, n).astype(float), Z=Z, T=T, R=R, a1=np.zeros(m), P1=0.1 * np.eye(m), distribution="poisson")
+    out = F.bootstrap_filter(model, 300, seed=5, return_indices=True)
+    ref = oracle.bsf_filter(M.model_arrays(model), 300, seed=5)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+
+
 def ref_summary(oracle, ref):
     return oracle.filter_summary(ref["alpha"], ref["weights"])
 

@@ -178,6 +178,21 @@ def test_full_size_c2_m4_against_oracle(oracle):
     _compare_full_size(out, ref, f, 60, max_ties=1)
 
 
+def test_c2_full_size_against_oracle(oracle):
+    """configs[1] as worded, at its full size and STRICT: ssm_ung negbin AR(1), m = k = 1, T = 1000, N = 65 536, full-output
+    bootstrap filter -- the <1,1,...> instantiation of the step kernel (WIDE stream: the resampling uniform rides in the step
+    block) against the oracle on the same seed (round-4 review: this shape met the oracle only on series of 8-14 time points)."""
+    from models_zoo import negbin_ar1
+    n, N = 1000, 65536
+    model = negbin_ar1(n, seed=102)
+    out = F.bootstrap_filter(model, N, seed=7, return_indices=True)
+    ref, f = _follow(oracle, out["indices"], N, lambda: oracle.bsf_filter(M.model_arrays(model), N, seed=7))
+    _compare_full_size(out, ref, f, n, max_ties=2)
+    w = ref["weights"][:, :n]
+    att_ref = np.einsum("mtn,nt->tm", ref["alpha"][:, :n, :], w / w.sum(axis=0))
+    assert np.allclose(out["att"][:n], att_ref, rtol=1e-8, atol=1e-10)
+
+
 @pytest.mark.parametrize("series", ["model", "informative"])
 def test_metric_config_full_size_against_oracle(oracle, series):
     """BASELINE metric config at its full size: ssm_ung negbin m = 4, N = 65 536, T = 1000 (8 s of oracle): ancestor table,
