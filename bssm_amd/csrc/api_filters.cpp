@@ -739,13 +739,8 @@ int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, ui
   db.use_grid = !((int)nsim <= cap && (n_rep >= 32 || nsim <= 2048));
   if (bssm::opt().force_path == 2) db.use_grid = true;
   if (bssm::opt().force_path == 1 && (int)nsim <= cap) db.use_grid = false;
-  if (db.use_grid) {
-    int B, chunk;
-    const size_t bytes = bssm::grid_workspace_bytes(db.fb, &B, &chunk);
-    if (B > 256) return fail(BSSM_ERR_UNSUPPORTED, "nsim too large for the grid filter");
-    HIP_TRY(db.ws.alloc(bytes));
-    bssm::grid_workspace_carve(db.fb, db.ws.p, &db.gws);
-  }
+  if (bssm::opt().force_path == 3 && bssm::row_filter_supported(db.fb)) db.use_grid = true;
+  if (db.use_grid && (rc = db.alloc_step_workspace())) return rc;
   db.const_terms.assign(n_rep, base);
   if ((rc = db.run(seed, stream0, nullptr))) return rc;
   if ((rc = db.fetch_loglik(nullptr, loglik))) return rc;

@@ -390,13 +390,23 @@ struct DeviceBatch {
     if (path_flags & BSSM_PLAN_FORCE_GRID) use_grid = true;
     if (path_flags & BSSM_PLAN_FORCE_WG) use_grid = false;
     if (!use_grid && N > cap) return fail(BSSM_ERR_INVALID, "nsim exceeds the workgroup-resident capacity");
-    if (use_grid) {
-      int B, chunk;
-      const size_t bytes = bssm::grid_workspace_bytes(fb, &B, &chunk);
-      if (B > 256) return fail(BSSM_ERR_UNSUPPORTED, "nsim too large for the grid filter (max 524288)");
-      HIP_TRY(ws.alloc(bytes));
-      bssm::grid_workspace_carve(fb, ws.p, &gws);
+    if (bssm::opt().force_path == 3 && bssm::row_filter_supported(fb)) use_grid = true;  // test hook: the row family (pf_row_step.h)
+    if (use_grid) return alloc_step_workspace();
+    return BSSM_OK;
+  }
+  // workspace of the one-launch-per-step families: the row family when BSSM_AMD_FORCE_PATH=row asks for it and the batch has such
+  // kernels (pf_row_step.h; otherwise it is reached through the tail split of a post-correction chunk only), else the step kernels
+  int alloc_step_workspace() {
+    if (bssm::opt().force_path == 3 && bssm::row_filter_supported(fb)) {
+      HIP_TRY(ws.alloc(bssm::row_workspace_bytes(fb)));
+      bssm::row_workspace_carve(fb, ws.p, &gws);
+      return BSSM_OK;
     }
+    int B, chunk;
+    const size_t bytes = bssm::grid_workspace_bytes(fb, &B, &chunk);
+    if (B > 256) return fail(BSSM_ERR_UNSUPPORTED, "nsim too large for the grid filter (max 524288)");
+    HIP_TRY(ws.alloc(bytes));
+    bssm::grid_workspace_carve(fb, ws.p, &gws);
     return BSSM_OK;
   }
 

@@ -193,6 +193,15 @@ int bssm_amd_last_kernel(char* buf, int32_t len) {
   return BSSM_OK;
 }
 
+int bssm_amd_family_launches(uint64_t* wg, uint64_t* step, uint64_t* row) {
+  unsigned long long c[3];
+  bssm::family_launches(c);
+  if (wg) *wg = c[0];
+  if (step) *step = c[1];
+  if (row) *row = c[2];
+  return BSSM_OK;
+}
+
 int bssm_plan_device_outputs(const bssm_plan* plan, void** alpha_hist, void** indices, void** weights) {
   if (!plan) return fail(BSSM_ERR_INVALID, "plan NULL");
   if (alpha_hist) *alpha_hist = plan->db.hist.p;

@@ -285,20 +285,20 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         } else {
           // A particle system that takes more than half a CU's LDS runs one workgroup per CU, so the filters go through the chip in
           // rounds of `cus` workgroups that all take the same time; a sparsely filled LAST round (C5: 2 340 = 9 x 256 + 36; one rank's
-          // shard of it at 8 ranks: 292 = 256 + 36) costs a full round.  Those filters go through the step kernels instead (several
-          // workgroups per filter, one launch per time step), behind the full rounds on the same stream: 36 filters of the C5 shape
-          // 3.7 -> 2.5 ms alone, about 1 ms behind other work (profiles/r03_c5_tail_round.txt).  Not when a path is forced.
-          // OPT-IN since round 4 (BSSM_AMD_TAIL_SPLIT=1): the two kernel families agree to reduction-order rounding only (a log-weight
-          // to ~1e-15 relative, and through a moved ancestor a summary to 1e-6), and which draws land in the tail depends on the
-          // draws per chunk, the shard layout and the CU count -- with the split on, a draw's result would depend on how many GPUs
-          // the job ran on.  The default keeps every draw workgroup-resident: outputs bit-identical for any device list
-          // (include/bssm_amd.h), at the price of a sparsely filled last round (one rank's 293-draw shard of C5: 8.5 -> 9.6 ms, profiles/r04_c5_shard_probe.txt).
+          // shard of it at 8 ranks: 293 = 256 + 37) costs a full round.  Those filters go through the ROW family instead (pf_row_step.h:
+          // one wave per row of 64 particles, one launch per time step, the whole chip), behind the full rounds.
+          // ON by default since round 5: both families evaluate pf_canon.h, so a draw's result is the same bits whichever ran it
+          // (tests/test_gpu_postcorrect.py, tests/test_gpu_fullsize.py assert split == whole bit for bit) -- which draws land in the
+          // tail depends on the draws per chunk, the shard layout and the CU count, and the output does not.  (Rounds 3-4 sent the
+          // tail through the step kernels, whose reduction shape differs: opt-in, results depended on the device list.)
+          // Not when a path is forced, and only for the shapes the row family carries (row_filter_supported).  BSSM_AMD_TAIL_SPLIT=0 turns it off.
           int tail = 0;
-          if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && bssm::opt().force_path == 0 && bssm::opt().tail_split) {
+          if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && bssm::opt().force_path == 0 && bssm::opt().tail_split &&
+              bssm::row_filter_supported(sub)) {
             int dev = 0; hipDeviceProp_t prop;
             const int cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
             const int r = sub.F % cus;
-            if (r > 0 && r <= cus * 3 / 8) tail = r;
+            if (r > 0 && r <= cus * bssm::opt().tail_max_eighths / 8) tail = r;
           }
           bssm::FilterBatch head = sub;
           head.F = sub.F - tail;
@@ -317,10 +317,9 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
             if (need_hist) { tl.alpha_hist += h0 * (size_t)(n + 1) * m * N; tl.indices += h0 * (size_t)n * N; }
             tl.stream0 = sub.stream0 + (uint32_t)h0;
             tail_ws.emplace_back();
-            int B, chunk;
-            HIP_TRY(tail_ws.back().alloc(bssm::grid_workspace_bytes(tl, &B, &chunk)));
+            HIP_TRY(tail_ws.back().alloc(bssm::row_workspace_bytes(tl)));
             bssm::GridWorkspace gw;
-            bssm::grid_workspace_carve(tl, tail_ws.back().p, &gw);
+            bssm::row_workspace_carve(tl, tail_ws.back().p, &gw);
             HIP_TRY(bssm::launch_grid_filter(tl, gw, nullptr));
             HIP_TRY(bssm::launch_zero_dead_tail(tl, true, nullptr));
           }

@@ -1,6 +1,7 @@
 // options.cpp -- see options.h
 #include "options.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -27,8 +28,9 @@ Options read_env() {
   o.is_chunk = env_int("BSSM_AMD_IS_CHUNK", 0);
   if (const char* e = std::getenv("BSSM_AMD_GATHER")) o.gather = !std::strcmp(e, "copy") ? 1 : (!std::strcmp(e, "host") ? 2 : 0);
   o.trace = env_set("BSSM_AMD_TRACE");
-  { const char* e = std::getenv("BSSM_AMD_TAIL_SPLIT"); o.tail_split = e && e[0] != '0' && e[0] != 0; }
-  if (const char* e = std::getenv("BSSM_AMD_FORCE_PATH")) o.force_path = !std::strcmp(e, "wg") ? 1 : (!std::strcmp(e, "grid") ? 2 : 0);
+  { const char* e = std::getenv("BSSM_AMD_TAIL_SPLIT"); o.tail_split = !(e && e[0] == '0'); }  // on unless BSSM_AMD_TAIL_SPLIT=0
+  if (const char* e = std::getenv("BSSM_AMD_TAIL_MAX_EIGHTHS")) o.tail_max_eighths = std::max(0, std::min(8, std::atoi(e)));
+  if (const char* e = std::getenv("BSSM_AMD_FORCE_PATH")) o.force_path = !std::strcmp(e, "wg") ? 1 : (!std::strcmp(e, "grid") ? 2 : (!std::strcmp(e, "row") ? 3 : 0));
   o.grid_ppt = env_int("BSSM_AMD_GRID_PPT", 0);
   o.grid_v2 = env_tri("BSSM_AMD_GRID_V2");
   o.grid_v2_wx = env_tri("BSSM_AMD_GRID_V2_WX");

@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "pf_device.h"
+#include "pf_canon.h"
 #include "pf_functors.h"
 #include "pf_kernels.h"
 #include "options.h"
@@ -454,12 +455,8 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
   const int Ncap = NT * PPT, N = EX ? NTB * PPT : b.N, n = b.n, f = blockIdx.x;
   double* __restrict__ s_alpha = smem;            // [MP][Ncap]
   double* __restrict__ s_cdf = smem + MP * Ncap;  // [Ncap]
-  double* __restrict__ s_max = s_cdf + Ncap;      // [16]
-  double* __restrict__ s_tot = s_max + 16;        // [PPT*16] wave totals in particle order
-  // [64] pivots of the cooperative search round: entry (l + 1) W - 1 of the CDF for lane l (W = N / 64).  Read straight
-  // from s_cdf the 64 lanes' addresses are W doubles apart -- one bank for W = 64: a 64-way conflict per particle row.
-  // Used when N is a power of two (W a power of two: the owner of a pivot entry is found with a mask).
-  double* __restrict__ s_piv = s_tot + PPT * 16;
+  double* __restrict__ s_max = s_cdf + Ncap;      // [128] row maxima (row g = particles 64 g ... 64 g + 63, pf_canon.h)
+  double* __restrict__ s_tot = s_max + CANON_MAX_ROWS;  // [128] row totals
   // T_t, R_t, C_t of the step for the linear-state transition.  Through scalar loads the 36 doubles of a four-dimensional state are
   // 72 SGPRs on top of the loop invariants of the time loop (130-150 SGPRs lived in VGPR lanes and came back through v_readlane).
   // Two remedies measured late in round 4 (same-box A/B, 512 ... 2048 particles, profiles/r04_wg_occupancy_ab.txt):
@@ -480,7 +477,7 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
 #endif
   constexpr int NMAT = MP * MP + MP * KP + MP;
   constexpr bool kLdsMat = FN == FN_NONE && ((BSSM_WG_LDS_MAT) != 0 || MP >= (BSSM_WG_LDS_MAT_FROM));
-  double* __restrict__ s_mat = s_piv + 64;  // [NMAT]
+  double* __restrict__ s_mat = s_tot + CANON_MAX_ROWS;  // [NMAT]
   // Eight-dimensional states, linear transition, one or two particles per lane: the transition on the matrix cores through a
   // 4 KB operand tile per wave (propagate_mfma8_h, the step kernels' routine) -- the scalar-load form spent 41 % of its VALU
   // instructions on v_readlane of spilt dwordx16 tuples (profiles/r04_wg_occupancy_ab.txt).  The tile sits behind s_mat
@@ -498,8 +495,8 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
   double* __restrict__ s_tile16 = s_mat + ((NMAT + 1) & ~1) + (kWgMfma16 ? wave * 256 : 0);
   // two particles per lane (513 ... 1024 slots, 139 KB of state): half-wave tiles of 1 KB inside the CDF array (8 waves x 128 doubles)
   constexpr bool kWgMfma16H = FN == FN_NONE && MP == 16 && PPT == 2 && NTB == WG_NT_MAX && (BSSM_WG_MFMA8) != 0;
-  const bool piv_tab = N >= 256 && (N & (N - 1)) == 0;
-  const int piv_mask = (N >> 6) - 1, piv_shift = 31 - __builtin_clz((unsigned)((N >> 6) > 0 ? (N >> 6) : 1));
+  // (these two stage their MFMA operands in the CDF array, which the row statistics of the next time point overwrite: barrier (0))
+  constexpr bool kTileInCdf = kWgMfmaQ || kWgMfma16H;
 
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
   const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
@@ -510,8 +507,6 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
   constexpr bool kPack = FN == FN_NONE;
   const double* __restrict__ amats = (FN && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
   const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP), m = b.m;
-  const double dN = (double)N, inv_dN = 1.0 / dN;
-  const bool n_pow2 = (N & (N - 1)) == 0;
 
   double w[PPT];  // log-weights of my particles at the current time
   double loglik = 0.0;
@@ -546,59 +541,37 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
 
   for (int t = 0; t <= n; t++) {
     WG_STAMP(7);
-    // ---- normalise the time-t weights (src/model_ssm_ung.cpp:675-679): exponentials against the WAVE maximum and their
-    // inclusive scan in particle order first, the block maximum and the rescale exp(max_wave - max_block) after ONE exchange
-    // (the same trick as the round-2 step kernel: one barrier for maximum + scan instead of two)
-    double mx = w[0];
-#pragma unroll
-    for (int r = 1; r < PPT; r++) mx = fmax(mx, w[r]);
-    const double Mw = wave_max(mx);
-    const double Mws = Mw == -INFINITY ? 0.0 : Mw;  // a wave without mass: exp(-inf - 0) = 0 instead of exp(nan)
-    double e[PPT], sc[PPT];
+    // ---- normalise the time-t weights (src/model_ssm_ung.cpp:675-679) in the canonical row form (pf_canon.h): every row of 64
+    // consecutive particles -- chunk q = r * nw + wave of this wave -- is scaled by ITS OWN maximum and scanned; the row-local
+    // scans are what the search reads, so they are final here and ONE barrier publishes maxima, totals and scans (the rescaled
+    // global CDF of rounds 1-4 needed a second pass and a second barrier)
+    double e[PPT];
+    if constexpr (kTileInCdf) lds_barrier();  // (0) the CDF array doubled as the waves' MFMA operand tiles during the transition
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
-      e[r] = (i < N) ? tl_exp(w[r] - Mws) : 0.0;
-      sc[r] = wave_scan_incl(e[r]);
-      if (lane == 63) s_tot[r * nw + wave] = sc[r];
+      const CanonRow rs = canon_row_stats(w[r]);  // (slots beyond N carry w = -inf)
+      e[r] = rs.e;
+      if (i < N) s_cdf[i] = rs.sc;
+      if (lane == 63) s_tot[r * nw + wave] = rs.sc;
+      if (lane == 0) s_max[r * nw + wave] = rs.M;
     }
-    if (lane == 0) s_max[wave] = Mw;
     WG_STAMP(2);
     lds_barrier();  // (1)
     WG_STAMP(1);
-    double M = s_max[0];
-    for (int q = 1; q < nw; q++) M = fmax(M, s_max[q]);
-    const double Ms = M == -INFINITY ? 0.0 : M;
-    // every wave scans the <= 128 scaled chunk totals redundantly (saves a barrier); chunk q belongs to wave q % nw
-    const int Q = PPT * nw;
-    constexpr bool kOneScan = kFixedNT && PPT * (NTB / 64) <= 64;  // at most 64 chunk totals: one wave scan covers them
-    const double t0 = (lane < Q) ? s_tot[lane] * tl_exp(s_max[lane % nw] - Ms) : 0.0;
-    const double i0 = wave_scan_incl(t0);
-    double i1 = i0;
-    if constexpr (!kOneScan) {
-      const double t1 = (lane + 64 < Q) ? s_tot[lane + 64] * tl_exp(s_max[(lane + 64) % nw] - Ms) : 0.0;
-      const double half = lane_broadcast(i0, 63);
-      i1 = wave_scan_incl(t1) + half;
-    }
-    const double S = lane_broadcast(i1, 63);
-    const double swv = tl_exp(Mw - Ms);  // this wave's rescale
+    // every wave combines the <= 128 row partials redundantly (two per lane, in registers: saves a barrier)
+    // (B = rows that hold particles: a function of N alone, whatever the thread geometry)
+    const int B = EX ? (NTB * PPT) / CANON_ROW : (N + CANON_ROW - 1) / CANON_ROW;
+    constexpr bool kTwo = PPT * NTB > 64 * CANON_ROW;  // the kernel's capacity exceeds 64 rows: a lane holds two row prefixes
+    const CanonComb<kTwo> cc = canon_combine<kTwo>(lane < B ? s_max[lane] : -INFINITY, lane < B ? s_tot[lane] : 0.0,
+                                                   kTwo && lane + 64 < B ? s_max[lane + 64] : -INFINITY, kTwo && lane + 64 < B ? s_tot[lane + 64] : 0.0, B);
+    const double S = cc.S, M = cc.M;
+    if (b.weights) {
 #pragma unroll
-    for (int r = 0; r < PPT; r++) {
-      const int q = r * nw + wave;  // my chunk; exclusive offset = inclusive prefix of chunk q-1
-      double off;
-      if constexpr (kOneScan) {
-        const double p0 = lane_broadcast(i0, (q - 1) & 63);
-        off = (q == 0) ? 0.0 : p0;
-      } else {
-        const double p0 = lane_broadcast(i0, (q - 1) & 63), p1 = lane_broadcast(i1, (q - 65) & 63);
-        off = (q == 0) ? 0.0 : (q <= 64 ? p0 : p1);
-      }
-      const int i = r * NT + tid;
-      if (i < N) {
-        const double cd = __builtin_fma(sc[r], swv, off);
-        s_cdf[i] = cd;
-        if (piv_tab && ((i + 1) & piv_mask) == 0) s_piv[i >> piv_shift] = cd;
-        if (b.weights) b.weights[((size_t)f * (n + 1) + t) * N + i] = e[r] * swv;
+      for (int r = 0; r < PPT; r++) {
+        const int i = r * NT + tid;
+        const double sq = canon_row_scale(cc, r * nw + wave);
+        if (i < N) b.weights[((size_t)f * (n + 1) + t) * N + i] = e[r] * sq;
       }
     }
     if (!(S > 0.0)) {  // :678-682 (uniform across the block)
@@ -606,25 +579,18 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
       if (tid == 0) b.dead_at[f] = t + 1;
       break;
     }
-    // S / N: a multiplication where N is a power of two (exact, the same bits as the division: the 25 instructions of an fp64
-    // division once per wave-step were 2 % of the two-particles-per-lane kernels); the logarithm only where the sum is read
-    // (thread 0 writes the log-likelihood)
-    const double c_scale = n_pow2 ? S * inv_dN : S / dN;
-    if (wave == 0) loglik += M + tl_log(c_scale);       // :683
+    const double c_scale = canon_stratum(S, N);
+    if (wave == 0) loglik += canon_llinc(M, c_scale);       // :683 (thread 0 writes the log-likelihood)
     if (t == n) break;
     WG_STAMP(3);
-    lds_barrier();  // (3) cdf visible
-    WG_STAMP(1);
 
     // ---- stratified resampling (stratified_sample.cpp:15-26) + ancestor gather (:657-661)
-    if constexpr (kLdsMat) {  // (the previous step's transition has been read: every wave has passed barriers (1) and (3) since)
+    if constexpr (kLdsMat) {  // (the previous step's transition has been read: every wave has passed barrier (1) since)
       const double* __restrict__ msrc = mats + (size_t)t * b.mats_tstride;
       for (int q = tid; q < NMAT; q += NT) s_mat[q] = msrc[q];
     }
     double a[PPT][MP];
     u32x4 blk[PPT];  // step blocks: spare word -> resampling uniform now, words 0-2 -> transition normals below
-    double v[PPT];
-    int lo[PPT], hi[PPT], width = 0;
     // The 20 Philox round keys (seed + r * const, stream + r * const) are loop-invariant: hoisted out of the time loop they
     // sat in SGPRs for its whole body, were spilt to VGPR lanes and came back through 80 v_readlane per wave-step.  Opaque
     // copies of the key make them step-local: 20 scalar adds per step, live only while the step blocks are drawn.
@@ -637,45 +603,35 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
     constexpr bool kQuadU = ucnt > 2 && PPT == 4;
     uint32_t uq[4] = {0u, 0u, 0u, 0u};
     if constexpr (kQuadU) rng_resample_words_quad4(key_t, (uint32_t)t, (uint32_t)NT, (uint32_t)tid, uq);
+    // source row and target in the row's scale for every particle of the lane (pf_canon.h: the 64 slots of a wave-row are
+    // consecutive, two ballots bound the source rows), then the bisections inside the rows: those of a lane's particles advance
+    // together -- their LDS reads are independent, so PPT of them are in flight per step instead of one
+    int lo[PPT], srow[PPT], slen[PPT];
+    double vp[PPT];
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
       blk[r] = rng_step_block(key_t, (uint32_t)t, (uint32_t)i);
       const uint32_t uword = kQuadU ? uq[r & 3] : rng_resample_word<ucnt>(key_t, (uint32_t)t, (uint32_t)i, blk[r]);
-      v[r] = ((double)uword * 0x1.0p-32 + (double)i) * c_scale;
-      lo[r] = 0; hi[r] = N - 1;
-      if (N >= 256 && r * NT + (wave + 1) * 64 <= N) {
-        // the 64 slots of a wave are consecutive, so v increases along the lanes and their ancestors lie between those
-        // of the first and the last lane: one cooperative 64-ary round (a pivot per lane, ballot counts) bounds both,
-        // and the per-lane bisection then runs over that short range instead of [0, N)
-        const int W = (N + 63) >> 6;
-        const int pe = min((lane + 1) * W, N) - 1;
-        const double pv = piv_tab ? s_piv[lane] : s_cdf[pe];
-        const bool valid = lane * W < N;
-        const double v_lo = lane_broadcast(v[r], 0), v_hi = lane_broadcast(v[r], 63);
-        const int c_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && pv < v_lo));
-        const int c_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && pv < v_hi));
-        lo[r] = min(c_lo * W, N - 1);
-        hi[r] = min((c_hi + 1) * W, N) - 1;
-      }
-      width = max(width, hi[r] - lo[r]);  // wave-uniform: the bounds come from ballots
+      const CanonSource src = canon_source_row(canon_target(uword, i, c_scale), i < N, cc.px, lane);
+      srow[r] = src.e * CANON_ROW;
+      slen[r] = EX ? CANON_ROW : min(CANON_ROW, N - srow[r]);
+      vp[r] = src.vp;
+      lo[r] = 0;
     }
-    // the bisections of a lane's particles advance together: their LDS reads are independent, so PPT of them are in flight
-    // per step instead of one (the search is bound by LDS latency and bank conflicts, not by instructions)
-    const int steps = __builtin_amdgcn_readfirstlane(width > 0 ? 32 - __builtin_clz((unsigned)width) : 0);
-    for (int sidx = 0; sidx < steps; sidx++) {
 #pragma unroll
-      for (int r = 0; r < PPT; r++) {
-        const int mid = (lo[r] + hi[r]) >> 1;
-        const double cm = s_cdf[mid];
-        const bool open = lo[r] < hi[r];
-        if (open && v[r] <= cm) hi[r] = mid;
-        else if (open) lo[r] = mid + 1;
-      }
+    for (int step = 32; step >= 1; step >>= 1) {
+      double xm[PPT];
+#pragma unroll
+      for (int r = 0; r < PPT; r++) xm[r] = s_cdf[srow[r] + min(lo[r] + step - 1, slen[r] - 1)];
+#pragma unroll
+      for (int r = 0; r < PPT; r++) lo[r] += (lo[r] + step - 1 < slen[r] && xm[r] < vp[r]) ? step : 0;
     }
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int i = r * NT + tid;
+      lo[r] = srow[r] + min(lo[r], slen[r] - 1);
+      if (i >= N) lo[r] = 0;
 #pragma unroll
       for (int c = 0; c < MP; c++) a[r][c] = s_alpha[c * Ncap + lo[r]];
       if (b.indices && i < N) {
@@ -791,7 +747,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   int ppt = 1;
   while (ppt < 16 && N > ntmax * ppt) ppt *= 2;
   const int nt = ppt == 1 ? (N + 63) / 64 * 64 : ntmax;
-  size_t lds = ((size_t)(MP + 1) * nt * ppt + 16 + (size_t)ppt * 16 + 64 + (MP * MP + MP * KP + MP)) * sizeof(double);
+  size_t lds = ((size_t)(MP + 1) * nt * ppt + 2 * CANON_MAX_ROWS + (MP * MP + MP * KP + MP)) * sizeof(double);
   if (MP == 8 && !b.fpar && !wide && ppt <= 2) lds += (1 + (size_t)(nt / 64) * 512) * sizeof(double);  // per-wave MFMA operand tiles (pf_wg_kernel, kWgMfma)
   if (MP == 16 && !b.fpar && !wide && ppt == 1) lds += (1 + (size_t)(nt / 64) * 256) * sizeof(double);  // (kWgMfma16)
   if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
@@ -1316,6 +1272,7 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
 
 }  // namespace bssm
 #include "pf_grid_v2.h"
+#include "pf_row_step.h"
 namespace bssm {
 
 template <int MP, int KP, int PPT, int FNV>
@@ -1327,6 +1284,7 @@ auto grid_fn_kernel(int psi) -> void (*)(const FilterBatch, const GridWorkspace,
 }
 template <int MP, int KP>
 hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
+  if (ws.chunk == CANON_ROW) return launch_row_mk<MP, KP>(b, ws, stream, timing);  // the row family (pf_row_step.h): a workspace carved by row_workspace_carve
   const int ppt = ws.chunk / GRID_NT;
   constexpr int kFn = fn_kernel_id<MP>();
   if (b.fpar && kFn > 0 && b.fn_id != kFn) return hipErrorInvalidValue;

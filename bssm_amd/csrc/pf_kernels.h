@@ -80,6 +80,13 @@ struct GridWorkspace {
 };
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out);
 void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
+// The ROW family (pf_row_step.h): a filter of at most 8192 particles spread over its rows of 64, one launch per time step,
+// bit-identical to the workgroup-resident kernel (pf_canon.h).  row_filter_supported: the batch's shape has such kernels (no
+// weights output; functor models, and linear-state models of at most four states).  The workspace is a GridWorkspace with
+// chunk = 64; launch_grid_filter runs it.
+bool row_filter_supported(const FilterBatch& b);
+size_t row_workspace_bytes(const FilterBatch& b);
+void row_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
 // Optional per-launch timing of the step kernel: every `every`-th step launch is bracketed by HIP
 // events on `stream`; the caller reads total_ms / count after the stream has drained.
 // `progress_every` > 0 (single-sequence launches only): an event is recorded on the launch stream after every that many
@@ -98,6 +105,7 @@ hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hip
                               StepTiming* timing = nullptr);
 // Name (with template arguments) of the filter kernel variant the calling thread launched last, as the launcher picked
 // it -- benchmarks report this instead of a format string of their own.
+void family_launches(unsigned long long (&out)[3]);  // filter batches launched so far by family: workgroup-resident, step kernels, row family (process-wide)
 void note_filter_kernel(const char* name);
 const char* last_filter_kernel();
 // launchers a run-time compiled user-model library exports (user_model_tu.hip); register returns the slot (>= 1)

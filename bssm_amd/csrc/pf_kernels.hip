@@ -2,6 +2,7 @@
 // The filter kernels themselves are templates in pf_filter_impl.h, instantiated per padded
 // state dimension in pf_inst_mp*.hip.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -26,10 +27,18 @@ const char* last_filter_kernel() { return g_last_kernel; }
 int wg_filter_capacity(int MP) {
   // 160 KiB LDS per CU: (MP + 1) doubles per particle + reduction slots; 512 threads x up to 16 particles
   // (8 for padded state dimensions above 2)
-  const size_t avail = 160 * 1024 - (16 + 16 * 16 + 64 + MP * MP * 2 + MP) * sizeof(double);
+  const size_t avail = 160 * 1024 - (2 * CANON_MAX_ROWS + MP * MP * 2 + MP) * sizeof(double);
   const size_t cap = avail / ((size_t)(MP + 1) * sizeof(double));
   for (int c = (MP <= 2 ? 8192 : 4096); c >= 512; c >>= 1) if ((size_t)c <= cap) return c;
   return (int)(cap / 64 * 64);
+}
+
+// ONE side stream per host thread for the whole library (streams share a small number of hardware queues: a pair per
+// kernel variant ended up serialised against each other)
+static hipStream_t library_side_stream() {
+  static thread_local TlsStream side;
+  static const bool side_hi = opt().side_prio;  // measurement: the side sequence at the highest stream priority
+  return side.get(side_hi);
 }
 
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
@@ -112,13 +121,28 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   ws->f0 = 0;
   ws->xcd_remap = 1;
   ws->wx = 0;
-  // ONE side stream per host thread for the whole library (streams share a small number of hardware queues: a pair per
-  // kernel variant ended up serialised against each other)
-  static thread_local TlsStream side;
-  static const bool side_hi = opt().side_prio;  // measurement: the side sequence at the highest stream priority
-  ws->side = side.get(side_hi);
+  ws->side = library_side_stream();
 }
 
+bool row_filter_supported(const FilterBatch& b) {
+  if (b.weights || b.N > CANON_ROW * CANON_MAX_ROWS || b.N < 1) return false;
+  if (b.fpar) return b.MP == b.KP && (b.user_slot > 0 ? b.MP <= 8 : b.MP <= 2);
+  return b.MP <= 4;
+}
+size_t row_workspace_bytes(const FilterBatch& b) { return row_workspace_bytes_impl(b); }
+void row_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const int B = (b.N + CANON_ROW - 1) / CANON_ROW;
+  char* p = (char*)base;
+  ws->state[0] = (double*)p; p += al((size_t)b.F * b.m * b.N * sizeof(double));
+  ws->state[1] = (double*)p; p += al((size_t)b.F * b.m * b.N * sizeof(double));
+  ws->lcdf = (double*)p; p += al((size_t)2 * b.F * b.N * sizeof(double));
+  ws->partials = (double*)p; p += al((size_t)2 * b.F * B * 2 * sizeof(double));
+  ws->maxhist = (double*)p; ws->llinc = ws->maxhist + (size_t)b.F * (b.n + 1);
+  ws->coarse = nullptr; ws->wscale = nullptr; ws->persist = nullptr; ws->logw = nullptr; ws->dbg = nullptr;
+  ws->fw = 0; ws->wx = 0; ws->B = B; ws->chunk = CANON_ROW; ws->f0 = 0; ws->xcd_remap = 0;
+  ws->side = library_side_stream();
+}
 
 __global__ void zero_dead_tail_kernel(const FilterBatch b, const bool weights_too, double* __restrict__ wscale, const int B) {
   const int f = blockIdx.y;
@@ -917,7 +941,12 @@ int register_user_launchers(user_wg_launcher_t wg, user_grid_launcher_t grid) {
   return g_user_count;
 }
 
+// process-wide counts of filter batches launched per kernel family (any host thread; post-correction filters on a worker thread)
+static std::atomic<unsigned long long> g_family_launches[3];
+void family_launches(unsigned long long (&out)[3]) { for (int i = 0; i < 3; i++) out[i] = g_family_launches[i].load(); }
+
 hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream) {
+  g_family_launches[0]++;
   if (b.user_slot > 0) return b.user_slot <= g_user_count ? g_user[b.user_slot].wg(&b, stream) : hipErrorInvalidValue;
   switch (b.MP) {
     case 1: return launch_wg_mp<1>(b, stream);
@@ -929,6 +958,7 @@ hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream) {
   }
 }
 hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
+  g_family_launches[ws.chunk == CANON_ROW ? 2 : 1]++;
   if (b.user_slot > 0) return b.user_slot <= g_user_count ? g_user[b.user_slot].grid(&b, &ws, stream, timing) : hipErrorInvalidValue;
   switch (b.MP) {
     case 1: return launch_grid_mp<1>(b, ws, stream, timing);

@@ -1,0 +1,254 @@
+// pf_row_step.h -- a filter of at most 8192 particles spread over its ROWS: one wave per row of 64 particles, one launch
+// per time step, results BIT-IDENTICAL to pf_wg_kernel's (both evaluate pf_canon.h).
+//
+// Why it exists (round-4 review, item 1; src/approx_mcmc.cpp:364-417): a particle system that takes more than half a CU's LDS
+// runs one workgroup-resident filter per CU, so a post-correction shard goes through the chip in rounds of 256 filters that all
+// take the same time, and a sparsely filled LAST round (one rank's 293-draw share of config C5 at eight ranks = 256 + 37) costs a
+// full round on 14 % of the CUs.  Those tail draws go through this kernel instead: 37 filters x 64 rows = 2 368 waves per
+// step over the whole chip.  Because a draw's bits do not depend on which family ran it, the split is invisible in the output
+// -- the result of a post-correction call is the same for every device list.
+//
+// Exchange between launches (GridWorkspace with chunk = 64, B = rows): `lcdf[2][F][N]` the row-local inclusive scans of
+// exp(w - M_row), `partials[2][F][B]` = (M_row, S_row); the kernel boundary is the grid-wide synchronisation.  A step has two
+// dependent global round trips behind the partials (the rows a wave draws from -- contiguous in `lcdf`, <= 4 per round -- and the
+// ancestor states), one workgroup barrier (math tables + the combine of wave 0), no coarse table, no weights output.
+#pragma once
+
+namespace bssm {
+
+constexpr int ROW_NT = 256;    // four rows per workgroup
+constexpr int ROW_WIN = 256;   // entries of the exchange array a wave stages per search round (four source rows)
+
+// the filter variants this family carries: functor models of every sampler and the linear-state models without a matrix-core
+// transition (pf_wg_kernel runs eight- and sixteen-dimensional states on the MFMA units, whose summation order differs)
+template <int MP, int FN> constexpr bool row_step_shape() { return FN != FN_NONE || MP <= 4; }
+constexpr int row_occupancy(int mp, bool fn) { return fn ? (mp <= 2 ? 4 : 2) : (mp <= 2 ? 5 : 4); }
+
+// row statistics of the new weights and their hand-over to the next launch
+__device__ __forceinline__ void row_publish(const FilterBatch& b, const GridWorkspace& ws, const int f, const int g, const int j,
+                                            const bool act, const int tn, const double w, const int lane) {
+  const CanonRow rs = canon_row_stats(act ? w : -INFINITY);
+  double* __restrict__ lcdf_new = ws.lcdf + ((size_t)(tn & 1) * b.F + f) * b.N;
+  if (act) lcdf_new[j] = rs.sc;
+  double* __restrict__ part = ws.partials + (((size_t)(tn & 1) * b.F + f) * ws.B + g) * 2;
+  if (lane == 0) part[0] = rs.M;
+  if (lane == 63) part[1] = rs.sc;
+}
+
+// t = -1: initial particles and their weights (src/model_ssm_ung.cpp:626, :543; functor models: pf_functors.h)
+template <int MP, int KP, int FN = FN_NONE, int PM = -1>
+__global__ void __launch_bounds__(ROW_NT) pf_row_init(const FilterBatch b, const GridWorkspace ws) {
+  constexpr int FID = FN > 0 ? FN : 0;
+  constexpr bool kPsiFn = FN != FN_NONE && PM == 1, kPack = FN == FN_NONE;
+  const int psi_mode = PM >= 0 ? PM : b.psi;
+  math_tab_init();
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int f = ws.f0 + blockIdx.y, g = blockIdx.x * 4 + wave, N = b.N, n = b.n, m = b.m;
+  if (g >= ws.B) return;
+  const int j = g * CANON_ROW + lane;
+  const bool act = j < N;
+  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
+  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
+  const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
+  const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
+  const double* __restrict__ amats = (FN && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
+  double x[MP];
+  if (FN && !psi_mode) {
+    if constexpr (FN != FN_NONE) functor_initial<MP, FID>(fpar, ini, key, (uint32_t)j, x);
+  } else {
+    double z[MP];
+    rng_normals<MP, kPack>(key, RNG_INIT, 0, (uint32_t)j, z);
+    initial_state<MP>(ini, z, x);
+  }
+  double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + (size_t)f * (n + 1) * m * N : ws.state[0] + (size_t)f * m * N;
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[c];
+  }
+  double w;
+  if constexpr (kPsiFn) w = functor_psi_weight<MP, FID>(as_uniform_table(fpar), as_uniform_table(obs), as_uniform_table(amats), 0, x, x);
+  else w = weight_dispatch<MP, FN, PM>(b, fpar, obs, amats, 0, x, x);
+  row_publish(b, ws, f, g, j, act, 0, w, lane);
+}
+
+// t in [0, n): resample on the time-t weights, propagate to t + 1, weigh there (ones when t + 1 == n or nothing is observed)
+template <int MP, int KP, int FN = FN_NONE, int PM = -1>
+__global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_row_step(const FilterBatch b, const GridWorkspace ws, const int t) {
+  constexpr int FID = FN > 0 ? FN : 0;
+  constexpr bool kPsiFn = FN != FN_NONE && PM == 1, kPack = FN == FN_NONE;
+  constexpr int ucnt = step_draw_count<KP, FN>();
+  const int psi_mode = PM >= 0 ? PM : b.psi;
+  __shared__ double s_win[4 * ROW_WIN];
+  __shared__ double s_comb[4 * 64 + 2];  // row prefixes (128), 1 / scale (128), M, S
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int f = ws.f0 + blockIdx.y, g = blockIdx.x * 4 + wave, B = ws.B, N = b.N, n = b.n, m = b.m, tn = t + 1;
+  const MathTabRegs mtab = math_tab_load_begin256();
+  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
+  const int j = g * CANON_ROW + lane;
+  const bool has_row = g < B, act = has_row && j < N;
+
+  // ---- the (M_row, S_row) partials of the time-t weights: combined by wave 0 while the others draw their step blocks
+  if (wave == 0) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
+    double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
+    if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
+    if (lane + 64 < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64)); pmaxb = pp.x; psumb = pp.y; }
+    const CanonComb<true> cc = canon_combine<true>(pmax, psum, pmaxb, psumb, B);
+    s_comb[lane] = cc.px.Qa;
+    s_comb[64 + lane] = cc.px.Qb;
+    s_comb[128 + lane] = cc.px.ia;
+    s_comb[192 + lane] = cc.px.ib;
+    if (lane == 0) { s_comb[256] = cc.M; s_comb[257] = cc.S; }
+  }
+  const u32x4 blk = rng_step_block(key, (uint32_t)t, (uint32_t)j);
+  const uint32_t uword = rng_resample_word<ucnt>(key, (uint32_t)t, (uint32_t)j, blk);
+  math_tab_load_end256(mtab);
+  lds_barrier();  // (1) the only workgroup barrier of the step
+  const CanonPrefix<true> px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[192 + lane], B};
+  const double M = s_comb[256], S = s_comb[257];
+  if (!(S > 0.0)) {
+    // degenerate weights (src/model_ssm_ung.cpp:678-682): stop and poison this row's slot of the next parity, so every later
+    // launch sees a non-finite S too (no flag load on healthy steps); later output slots stay zero like the reference's
+    if (has_row && lane == 0) {
+      double* __restrict__ pn = ws.partials + (((size_t)(tn & 1) * b.F + f) * B + g) * 2;
+      pn[0] = __builtin_nan("");
+      pn[1] = __builtin_nan("");
+      if (g == 0) atomicCAS(&b.dead_at[f], 0, t + 1);
+    }
+    return;
+  }
+  if (!has_row) return;  // (a workgroup's spare waves: nothing below synchronises across waves)
+  const double c_scale = canon_stratum(S, N);
+  if (g == B - 1 && lane == 63) ws.llinc[(size_t)f * (n + 1) + t] = canon_llinc(M, c_scale);  // :683, single writer
+
+  // ---- stratified resampling (pf_canon.h): source row per slot, then the bisection inside it.  The rows [c_lo, c_hi] a wave draws
+  // from are contiguous in the exchange array: staged four at a time in the wave's window
+  const CanonSource src = canon_source_row<true>(canon_target(uword, j, c_scale), act, px, lane);
+  const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
+  double* sw = s_win + wave * ROW_WIN;
+  int anc = 0;
+  for (int r0 = src.c_lo; r0 <= src.c_hi; r0 += 4) {  // wave-uniform bounds
+    const int nr = min(4, src.c_hi - r0 + 1);
+    double xr[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = (r0 + q) * CANON_ROW + lane;
+      xr[q] = (q < nr && k < N) ? lcdf[k] : 0.0;
+    }
+    if (r0 != src.c_lo) lds_wave_sync();  // the previous round's reads are done
+#pragma unroll
+    for (int q = 0; q < 4; q++) sw[q * CANON_ROW + lane] = xr[q];
+    lds_wave_sync();
+    if (act && src.e >= r0 && src.e < r0 + 4) {
+      const int slen = min(CANON_ROW, N - src.e * CANON_ROW);
+      anc = src.e * CANON_ROW + min(canon_count_below(sw + (src.e - r0) * CANON_ROW, slen, src.vp), slen - 1);
+    }
+  }
+  if (b.indices && act) __builtin_nontemporal_store((uint32_t)anc, &b.indices[((size_t)f * n + t) * N + j]);
+
+  // ---- ancestor state, transition to t + 1 (src/model_ssm_ung.cpp:657-670; functor models: pf_functors.h), weight there
+  const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N;
+  double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N;
+  double a[MP], x[MP];
+#pragma unroll
+  for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
+  const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
+  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
+  const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
+  const double* __restrict__ amats = (FN && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
+  const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
+  const double* __restrict__ ob = obs + (size_t)(tn < n ? tn : 0) * obs_stride;
+  if (FN && !psi_mode) {
+    if constexpr (FN != FN_NONE) functor_propagate<MP, KP, FID>(fpar, key, blk, (uint32_t)t, (uint32_t)j, a, x);
+  } else if (FN && psi_mode == 2) {
+    if constexpr (FN != FN_NONE) functor_ekpf_propagate<MP, FID>(fpar, ob, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x);
+  } else {
+    double z[KP];
+    rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+    propagate<MP, KP>(as_uniform_table(mats + (size_t)t * b.mats_tstride), a, z, x);
+  }
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[c];
+  }
+  double w;
+  if constexpr (kPsiFn) w = tn < n ? functor_psi_weight<MP, FID>(as_uniform_table(fpar), as_uniform_table(ob), as_uniform_table(amats + (size_t)t * fn_amat_row<MP>()), tn, x, a) : 0.0;
+  else w = tn < n ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)t * fn_amat_row<MP>(), tn, x, a) : 0.0;
+  row_publish(b, ws, f, g, j, act, tn, w, lane);
+}
+
+// workspace of the row family: GridWorkspace with chunk = 64 (no coarse table, no weights scale factors, no control block)
+inline size_t row_workspace_bytes_impl(const FilterBatch& b) {
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t B = (size_t)(b.N + CANON_ROW - 1) / CANON_ROW;
+  return 2 * al((size_t)b.F * b.m * b.N * sizeof(double)) + al((size_t)2 * b.F * b.N * sizeof(double)) + al((size_t)2 * b.F * B * 2 * sizeof(double)) +
+         al((size_t)2 * b.F * (b.n + 1) * sizeof(double));
+}
+
+template <int MP, int KP, int FNV>
+auto row_fn_kernels(int psi, void (**init)(const FilterBatch, const GridWorkspace)) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
+  if constexpr (((BSSM_FN_PSI_MASK) & 1) != 0) { if (psi == 0) { *init = pf_row_init<MP, KP, FNV, 0>; return pf_row_step<MP, KP, FNV, 0>; } }
+  if constexpr (((BSSM_FN_PSI_MASK) & 2) != 0) { if (psi == 1) { *init = pf_row_init<MP, KP, FNV, 1>; return pf_row_step<MP, KP, FNV, 1>; } }
+  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0) { if (psi == 2) { *init = pf_row_init<MP, KP, FNV, 2>; return pf_row_step<MP, KP, FNV, 2>; } }
+  return nullptr;
+}
+
+// the time loop: one launch per step; batches of at least 512 workgroups per step as TWO interleaved launch sequences over
+// the halves of their filters (the tail of one half's step runs under the body of the other's, as in launch_grid_mk)
+template <int MP, int KP>
+hipError_t launch_row_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
+  constexpr int kFn = fn_kernel_id<MP>();
+  if (b.fpar && kFn > 0 && b.fn_id != kFn) return hipErrorInvalidValue;
+  if (b.weights || b.N > CANON_ROW * CANON_MAX_ROWS || ws.chunk != CANON_ROW || ws.B != (b.N + CANON_ROW - 1) / CANON_ROW) return hipErrorInvalidValue;
+  void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
+  void (*kern_init)(const FilterBatch, const GridWorkspace) = nullptr;
+  if (b.fpar) {
+    if constexpr (MP == KP && MP <= FN_MP_MAX) kern = row_fn_kernels<MP, KP, kFn>(b.psi, &kern_init);
+  } else {
+#ifndef BSSM_USER_MODEL
+    if constexpr (row_step_shape<MP, FN_NONE>()) { kern = pf_row_step<MP, KP>; kern_init = pf_row_init<MP, KP>; }
+#endif
+  }
+  if (!kern || !kern_init) return hipErrorInvalidValue;
+#ifndef BSSM_USER_MODEL
+  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_row_step<%d,%d,%s>", MP, KP, b.fpar ? (kFn > 0 ? "model" : "any") : "false"); note_filter_kernel(nm); }
+#endif
+  hipError_t e;
+  if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
+  const int wgs = (ws.B + 3) / 4;
+  int parts = ((long long)b.F * wgs >= 512 && b.F >= 2 && ws.side) ? 2 : 1;
+  if (opt().grid_streams > 0) parts = std::max(1, std::min({opt().grid_streams, 2, b.F}));
+  if (!ws.side) parts = 1;
+  hipStream_t lanes[2] = {stream, parts == 2 ? ws.side : stream};
+  GridWorkspace wsp[2] = {ws, ws};
+  int fcount[2] = {b.F, 0};
+  hipEvent_t fork = nullptr, join = nullptr;
+  if (parts == 2) {
+    fcount[0] = b.F / 2; fcount[1] = b.F - fcount[0];
+    wsp[1].f0 = ws.f0 + fcount[0];
+    if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return e;
+    (void)hipEventRecord(fork, stream);
+    (void)hipStreamWaitEvent(lanes[1], fork, 0);
+  }
+  if (timing) timing->concurrent = parts;
+  for (int t = -1; t < b.n; t++) {
+    for (int q = 0; q < parts; q++) {
+      if (t < 0) hipLaunchKernelGGL(kern_init, dim3(wgs, fcount[q]), dim3(ROW_NT), 0, lanes[q], b, wsp[q]);
+      else hipLaunchKernelGGL(kern, dim3(wgs, fcount[q]), dim3(ROW_NT), 0, lanes[q], b, wsp[q], t);
+    }
+  }
+  if (parts == 2) {
+    if ((e = hipEventCreateWithFlags(&join, hipEventDisableTiming)) != hipSuccess) return e;
+    (void)hipEventRecord(join, lanes[1]);
+    (void)hipStreamWaitEvent(stream, join, 0);
+    (void)hipEventDestroy(join);
+    (void)hipEventDestroy(fork);
+  }
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(loglik_finalize_kernel, dim3(b.F), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);
+  return hipGetLastError();
+}
+
+}  // namespace bssm

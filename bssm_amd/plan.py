@@ -129,6 +129,13 @@ class FilterPlan:
         _lib.check(_lib.lib().bssm_amd_last_kernel(buf, C.c_int32(128)))
         return buf.value.decode()
 
+    @staticmethod
+    def family_launches() -> dict:
+        """filter batches launched so far by kernel family, process-wide (post-correction filters on a worker thread)"""
+        c = [C.c_uint64(0) for _ in range(3)]
+        _lib.check(_lib.lib().bssm_amd_family_launches(*[C.byref(x) for x in c]))
+        return dict(wg=c[0].value, step=c[1].value, row=c[2].value)
+
     def close(self):
         if self._h:
             _lib.lib().bssm_plan_destroy(self._h)

@@ -442,6 +442,9 @@ int bssm_debug_math(int fn, const double* in, double* out, int32_t n);
 int bssm_plan_launch_sequences(const bssm_plan* plan);
 /* name, with template arguments, of the filter kernel variant the calling thread launched last (as the launcher chose it) */
 int bssm_amd_last_kernel(char* buf, int32_t len);
+/* filter batches launched so far, process-wide (any host thread), by kernel family: workgroup-resident, step kernels, row family
+ * (pf_row_step.h: the tail round of a post-correction chunk) -- tests use it to see which family a call really took */
+int bssm_amd_family_launches(uint64_t* wg, uint64_t* step, uint64_t* row);
 /* runs one kernel that reads n_doubles and writes n_doubles (8 B per lane, coalesced): a known byte count for
  * calibrating the profiler's FETCH_SIZE / WRITE_SIZE counters on this library's access pattern */
 int bssm_debug_stream_copy(uint64_t n_doubles);

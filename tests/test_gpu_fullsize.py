@@ -137,13 +137,14 @@ def test_c5_post_correct_block_invariance():
     assert lw.std() < 5.0
 
 
-def test_c5_post_correct_tail_round_through_the_step_kernels(monkeypatch):
-    """configs[4] shape, 300 draws: one workgroup-resident filter per CU, so 256 draws fill a round and 44 are left over.
-    DEFAULT (round 4): every draw stays workgroup-resident, so a draw's result does not depend on how the job is cut -- the whole
-    job, two blocks of 150 (what two GPUs would filter) and the in-library two-shard call agree BIT FOR BIT although only the
-    first has a sparsely filled last round.  OPT-IN (BSSM_AMD_TAIL_SPLIT=1): the 44 go through the step kernels behind the full
-    round (api_postcorrect.cpp run_is_core; profiles/r03_c5_tail_round.txt) -- same Philox streams, log-weights equal to reduction-order
-    rounding, the draws that kept their kernel family bit for bit."""
+def test_c5_post_correct_tail_round_is_invisible_in_the_output(monkeypatch):
+    """configs[4] shape, 300 draws: one workgroup-resident filter per CU, so 256 draws fill a round and 44 are left over.  By
+    DEFAULT (round 5) the 44 go through the row family behind the full round (pf_row_step.h: one wave per row of 64 particles, one
+    launch per time step).  Both families evaluate pf_canon.h, so a draw's result is the SAME BITS whichever ran it: the job with the
+    split, the job without it (BSSM_AMD_TAIL_SPLIT=0: every draw workgroup-resident), two blocks of 150 (what two GPUs would filter:
+    no tail round there) and the in-library two-shard call agree bit for bit -- log-weights, the smoothing summaries (output 2) and
+    the sampled trajectories (output 1).  (Rounds 3-4: the tail took the step kernels, opt-in, equal to reduction-order rounding.)"""
+    from bssm_amd.plan import FilterPlan
     rng = np.random.default_rng(106)
     n, K, dT = 300, 500.0, 0.1
     r = np.zeros(n); pp = np.zeros(n); pp[0] = 50.0
@@ -159,31 +160,25 @@ def test_c5_post_correct_tail_round_through_the_step_kernels(monkeypatch):
     counts = np.ones(ns, dtype=np.uint32)
     mode = F.psi_setup(model)["mode"].reshape(-1, order="F")
     modes = np.tile(mode[:, None], (1, ns))
-    monkeypatch.setenv("BSSM_AMD_TAIL_SPLIT", "1")
-    split = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4)
-    monkeypatch.delenv("BSSM_AMD_TAIL_SPLIT")
-    whole = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4)
-    lo = PC._run_local_block_nlg(model, theta[:150], modes[:, :150], counts[:150], 0, ns, 4096, 9, 2, 3, 2)
-    hi = PC._run_local_block_nlg(model, theta[150:], modes[:, 150:], counts[150:], 150, ns, 4096, 9, 2, 3, 2)
-    two = np.concatenate([lo["loglik"], hi["loglik"]])
-    assert np.all(np.isfinite(split["loglik"]))
-    assert np.array_equal(split["loglik"][:256], whole["loglik"][:256])      # the full round: same kernels, same bits
-    assert np.array_equal(whole["loglik"], two)                               # workgroup-resident everywhere
-    assert not np.array_equal(split["loglik"][256:], whole["loglik"][256:])   # the tail really took the other kernels
-    assert np.max(np.abs(split["loglik"] - whole["loglik"])) <= 1e-10 * n
-    # the same job cut over two logical devices inside the library (bssm_is_correction_nlg_multi; both shards on this GPU): shards
-    # of 150 have no tail round, so every draw is workgroup-resident there
-    shard = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4, devices=[0, 0])
-    assert np.array_equal(shard["loglik"], whole["loglik"])
-    # with the smoothing summaries (history pools shared by the two kernel families of the chunk)
-    monkeypatch.setenv("BSSM_AMD_TAIL_SPLIT", "1")
-    s2 = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 2, 4)
-    monkeypatch.delenv("BSSM_AMD_TAIL_SPLIT")
-    w2 = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 2, 4)
-    sh2 = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 2, 4, devices=[0, 0])
-    for k in ("alphahat_i", "Vt_i"):     # default: summaries too are independent of the shard layout
-        assert np.array_equal(sh2[k], w2[k]), k
-    assert np.array_equal(s2["loglik"], split["loglik"]) and np.array_equal(w2["loglik"], whole["loglik"])
-    for k in ("alphahat_i", "Vt_i"):
-        assert np.array_equal(s2[k][..., :256], w2[k][..., :256]), k
-        assert np.allclose(s2[k], w2[k], rtol=1e-6, atol=1e-9), k  # (a last-ulp weight can move an ancestor: loose on purpose)
+    for output_type, keys in ((3, ("loglik", "weights")), (2, ("loglik", "weights", "alphahat_i", "Vt_i")), (1, ("loglik", "weights", "alpha"))):
+        c0 = FilterPlan.family_launches()
+        split = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, output_type, 4)
+        c1 = FilterPlan.family_launches()
+        assert c1["row"] == c0["row"] + 1 and c1["wg"] == c0["wg"] + 1, (c0, c1)   # the tail really took the row family
+        monkeypatch.setenv("BSSM_AMD_TAIL_SPLIT", "0")
+        whole = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, output_type, 4)
+        c2 = FilterPlan.family_launches()
+        assert c2["row"] == c1["row"] and c2["wg"] == c1["wg"] + 1, (c1, c2)
+        monkeypatch.delenv("BSSM_AMD_TAIL_SPLIT")
+        assert np.all(np.isfinite(split["loglik"]))
+        for k in keys:
+            assert np.array_equal(split[k], whole[k]), (output_type, k)
+        lo = PC._run_local_block_nlg(model, theta[:150], modes[:, :150], counts[:150], 0, ns, 4096, 9, 2, output_type, 2)
+        hi = PC._run_local_block_nlg(model, theta[150:], modes[:, 150:], counts[150:], 150, ns, 4096, 9, 2, output_type, 2)
+        for k in keys:
+            ax = 0 if split[k].ndim == 1 else -1
+            assert np.array_equal(split[k], np.concatenate([lo[k], hi[k]], axis=ax)), (output_type, k)
+        # the same job cut over two logical devices inside the library (bssm_is_correction_nlg_multi; both shards on this GPU)
+        shard = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, output_type, 4, devices=[0, 0])
+        for k in keys:
+            assert np.array_equal(shard[k], split[k]), (output_type, k)
