@@ -290,7 +290,7 @@ int bssm_debug_stream_copy(uint64_t n_doubles) {
 int bssm_debug_math(int fn, const double* in, double* out, int32_t n) {
   if (!have_device()) return no_device();
   if (!in || !out || n < 1) return fail(BSSM_ERR_INVALID, "bad arguments");
-  const int mult = fn == 4 ? 4 : (fn >= 2 ? 2 : 1);
+  const int mult = fn == 4 ? 4 : ((fn == 2 || fn == 3 || fn == 12) ? 2 : 1);  // doubles written per input (debug_math_kernel)
   DevBuf di, dout;
   HIP_TRY(di.alloc((size_t)n * sizeof(double)));
   HIP_TRY(dout.alloc((size_t)n * mult * sizeof(double)));

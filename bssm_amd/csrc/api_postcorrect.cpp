@@ -95,6 +95,13 @@ struct ChunkTables {
   DevBuf in_a, in_b;      // ung / mng: packed draws and their transpose
   ~ChunkTables() { if (ready) (void)hipEventDestroy(ready); }
   // device thread: wait for the set-up kernel, mark failed draws, give the work arrays back
+  // device thread, in front of the chunk's filters: the filter stream waits for the set-up kernel ON THE DEVICE -- the host goes
+  // on to enqueue the filter launches under it (round 5: a host-side wait here cost the 293-draw shard ~0.1 ms of idle device
+  // between the two, and the 600 launches of its tail round were enqueued 0.75 ms later than they could be)
+  int wait_on(hipStream_t filters) {
+    if (!ready) return 0;
+    return hipStreamWaitEvent(filters, ready, 0) == hipSuccess ? 0 : -1;
+  }
   int finish(std::vector<char>* bad) {
     if (!ready) return 0;
     if (hipEventSynchronize(ready) != hipSuccess) return -1;
@@ -174,8 +181,10 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nsim_of(a) < nsim_of(b); });
   bool any_degenerate = false;
   size_t pos = 0;
+  const double tcore0 = now_ms();
   const std::shared_ptr<ChunkTables> ctabs = J.take_chunk(lo);  // non-null: the tables of [lo, hi) are already in HBM, in draw order
-  if (ctabs && ctabs->finish(&J.bad)) return fail(BSSM_ERR_HIP, "psi set-up kernel failed");
+  if (ctabs && ctabs->wait_on(nullptr)) return fail(BSSM_ERR_HIP, "psi set-up kernel failed");
+  (void)tcore0;
   while (pos < order.size()) {
     const int N = nsim_of(order[pos]);
     size_t end = pos;
@@ -273,7 +282,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         }
         sub.seed = job->seed;
         sub.stream0 = (uint32_t)(job->first + order[pos + f0]);
-        if (db.use_grid) {
+        if (db.use_grid && !(bssm::opt().force_path == 3 && bssm::row_filter_supported(sub))) {
           DevBuf wsb;  // workspace sized for the sub-batch
           int B, chunk;
           HIP_TRY(wsb.alloc(bssm::grid_workspace_bytes(sub, &B, &chunk)));
@@ -293,7 +302,8 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           // tail through the step kernels, whose reduction shape differs: opt-in, results depended on the device list.)
           // Not when a path is forced, and only for the shapes the row family carries (row_filter_supported).  BSSM_AMD_TAIL_SPLIT=0 turns it off.
           int tail = 0;
-          if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && bssm::opt().force_path == 0 && bssm::opt().tail_split &&
+          if (bssm::opt().force_path == 3 && bssm::row_filter_supported(sub)) tail = sub.F;  // (test / measurement hook: every draw through the row family)
+          else if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && bssm::opt().force_path == 0 && bssm::opt().tail_split &&
               bssm::row_filter_supported(sub)) {
             int dev = 0; hipDeviceProp_t prop;
             const int cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -328,7 +338,10 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
       }
       // the previous chunk's summary has been running beside these filters: collect it while they finish
       if (J.pending) { const int prc = J.pending->drain(alphahat_i, Vt_i); J.pending.reset(); if (prc) return prc; }
+      const double tq = now_ms();
       HIP_TRY(hipMemcpy(ll.data(), db.loglik.p, F * sizeof(double), hipMemcpyDeviceToHost));
+      if (ctabs && ctabs->finish(&J.bad)) return fail(BSSM_ERR_HIP, "psi set-up kernel failed");  // (complete: the copy waited for the filters behind it) failed draws, work arrays back
+      if (bssm::opt().trace) std::fprintf(stderr, "[bssm_amd] core: launches enqueued after %.3f ms, device done after %.3f ms\n", tq - tb1, now_ms() - tb1);
       const double tb2 = now_ms();
       // smoothing outputs
       DevBuf d_mean, d_cov, d_picks, d_traj;
@@ -466,6 +479,7 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
       if (dev_rc < 0) continue;  // drain
       const double t1 = now_ms();
       const int rc = run_is_core(J, job.first, job.second, weights, loglik, alpha, alphahat_i, Vt_i);
+      if (bssm::opt().trace) std::fprintf(stderr, "[bssm_amd] device thread: chunk [%d, %d) taken at %.3f ms, returned at %.3f ms of the call\n", job.first, job.second, t1 - t_call0, now_ms() - t_call0);
       if (rc < 0) { dev_err = g_err; dev_rc = rc; }
       else if (rc == BSSM_WARN_DEGENERATE) worst = BSSM_WARN_DEGENERATE;
       t_dev += now_ms() - t1;
@@ -508,7 +522,9 @@ int run_is_pipeline(IsCore& J, int cnt, int n_threads, const std::function<std::
     // work arrays are only given back by the device thread
     { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return queue.size() - taken <= 2; }); }
   }
+  const double tclose0 = now_ms();
   close();
+  if (bssm::opt().trace) std::fprintf(stderr, "[bssm_amd] pipeline: chunks handed over after %.3f ms, device thread joined after %.3f ms\n", tclose0 - t_call0, now_ms() - t_call0);
   if (dev_rc < 0) { J.pending.reset(); return fail(dev_rc, dev_err); }
   { const double td0 = now_ms(); const int rc = drain_pending(); if (rc) return rc; t_dev += now_ms() - td0; }
   g_is_timing[0] = t_host; g_is_timing[1] = t_dev;
@@ -804,8 +820,8 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       // filters is a visible share of the call (C5, 2 340 draws: 0.071 -> 0.068 s, one host thread 0.100 -> 0.086 s); on
       // long jobs the preparing thread waiting here paces the set-up kernels into the gaps between filter rounds, which
       // measured 12 % faster than letting them run ahead (18 720 draws: 0.49 s against 0.55 s).
-      if (count > 4096 || bssm::opt().trace) HIP_TRY(hipStreamSynchronize(st));
-      if (bssm::opt().trace)
+      if (count > 4096 || bssm::opt().trace >= 2) HIP_TRY(hipStreamSynchronize(st));
+      if (bssm::opt().trace >= 2)
         std::fprintf(stderr, "[bssm_amd] psi set-up on device (linearisation + smoother + tables): F=%d n=%d m=%d: %.2f ms\n", F, n, m, now_ms() - t0);
       std::lock_guard<std::mutex> lk(J.chunk_mu);
       J.chunk_tabs[lo] = ct;

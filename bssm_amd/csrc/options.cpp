@@ -7,7 +7,34 @@
 #include <cstring>
 #include <mutex>
 
+#include <hip/hip_runtime.h>
+#include <map>
+#include <vector>
+
+#include "tls_stream.h"
+
 namespace bssm {
+// process-wide pool of idle HIP streams (tls_stream.h): a stream a thread no longer needs waits here for the next thread
+namespace {
+std::mutex g_stream_pool_mu;
+std::map<std::pair<int, bool>, std::vector<hipStream_t>>& stream_pool() {
+  static auto* pool = new std::map<std::pair<int, bool>, std::vector<hipStream_t>>();  // (never destroyed: threads may exit after main)
+  return *pool;
+}
+}  // namespace
+hipStream_t stream_pool_take(int dev, bool highest_priority) {
+  std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+  auto& v = stream_pool()[{dev, highest_priority}];
+  if (v.empty()) return nullptr;
+  hipStream_t s = v.back();
+  v.pop_back();
+  return s;
+}
+void stream_pool_give(int dev, bool highest_priority, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+  stream_pool()[{dev, highest_priority}].push_back(s);
+}
+
 namespace {
 
 int env_int(const char* name, int dflt) {
@@ -27,7 +54,7 @@ Options read_env() {
   if (const char* e = std::getenv("BSSM_AMD_USER_CACHE")) o.user_cache = e;
   o.is_chunk = env_int("BSSM_AMD_IS_CHUNK", 0);
   if (const char* e = std::getenv("BSSM_AMD_GATHER")) o.gather = !std::strcmp(e, "copy") ? 1 : (!std::strcmp(e, "host") ? 2 : 0);
-  o.trace = env_set("BSSM_AMD_TRACE");
+  o.trace = env_set("BSSM_AMD_TRACE") ? std::max(1, env_int("BSSM_AMD_TRACE", 1)) : 0;
   { const char* e = std::getenv("BSSM_AMD_TAIL_SPLIT"); o.tail_split = !(e && e[0] == '0'); }  // on unless BSSM_AMD_TAIL_SPLIT=0
   if (const char* e = std::getenv("BSSM_AMD_TAIL_MAX_EIGHTHS")) o.tail_max_eighths = std::max(0, std::min(8, std::atoi(e)));
   if (const char* e = std::getenv("BSSM_AMD_FORCE_PATH")) o.force_path = !std::strcmp(e, "wg") ? 1 : (!std::strcmp(e, "grid") ? 2 : (!std::strcmp(e, "row") ? 3 : 0));

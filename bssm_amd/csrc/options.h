@@ -26,10 +26,10 @@ struct Options {
   std::string user_cache;       // empty: default
   int is_chunk = 0;             // 0: default
   int gather = 0;               // 0 auto (RCCL -> device copies -> host), 1 "copy", 2 "host"
-  bool trace = false;
+  int trace = 0;                // BSSM_AMD_TRACE: 1 = timing lines on stderr, 2 = also synchronise after each set-up kernel to time it alone
   bool tail_split = true;       // a sparsely filled last round of a post-correction chunk through the row family (bit-identical: pf_canon.h)
   // test / tuning
-  int tail_max_eighths = 3;     // the last round goes through the row family when it fills at most this many eighths of the CUs (BSSM_AMD_TAIL_MAX_EIGHTHS)
+  int tail_max_eighths = 4;     // the last round goes through the row family when it fills at most this many eighths of the CUs (BSSM_AMD_TAIL_MAX_EIGHTHS)
   int force_path = 0;           // 0 none, 1 "wg", 2 "grid", 3 "row" (the row family where the batch has such kernels; test hook)
   int grid_ppt = 0;             // 0: automatic
   int grid_v2 = -1, grid_v2_wx = -1, grid_v2_exact = -1;   // -1: automatic; 0 / 1

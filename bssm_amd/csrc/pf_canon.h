@@ -59,7 +59,7 @@ __device__ __forceinline__ double canon_opaque(double x) {
 // statistics of the row this wave's lanes hold (w = -inf in lanes without a particle)
 struct CanonRow { double e, sc, M; };
 __device__ __forceinline__ CanonRow canon_row_stats(const double w) {
-  const double M = wave_max(w);
+  const double M = wave_max_key(w);
   const double Ms = M == -INFINITY ? 0.0 : M;  // a row without mass: exp(-inf - 0) = 0 instead of exp(nan)
   const double e = tl_exp(w - Ms);
   const double sc = wave_scan_incl(e);
@@ -77,7 +77,7 @@ struct CanonComb {
 template <bool TWO>
 __device__ __forceinline__ CanonComb<TWO> canon_combine(const double pmax, const double psum, const double pmaxb, const double psumb, const int B) {
   CanonComb<TWO> c;
-  c.M = TWO ? wave_max(fmax(pmax, pmaxb)) : wave_max(pmax);
+  c.M = TWO ? wave_max_key(fmax(pmax, pmaxb)) : wave_max_key(pmax);
   c.sa = fast_exp(pmax - c.M);  // rows beyond B: 0; a poisoned (NaN) partial makes S NaN
   const double Q0 = wave_scan_incl(canon_opaque(psum * c.sa));
   double Q1 = lane_broadcast(Q0, 63);

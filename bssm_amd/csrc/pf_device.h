@@ -292,6 +292,35 @@ __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_move<DPP_ROW_BCAST31, 0xc>(ninf, v));
   return lane_broadcast(v, 63);
 }
+// The same maximum through an order-preserving map to unsigned integers: the 32-bit maximum folds its DPP move into the
+// instruction (v_max_u32_dpp: one instruction per step against five for a double -- two v_mov_dpp with an identity each, one
+// v_max_f64), so two reductions -- the high words, then the low words of the lanes that hold the largest high word -- cost 18
+// instructions where wave_max costs 32, and the result lands in scalar registers.  Exact (the value of one of the lanes); a NaN
+// with a clear sign bit orders above +inf, so a NaN weight gives a NaN maximum (the filters then stop as degenerate, which is
+// what a NaN weight did before through the sum).  Used by the row statistics of pf_canon.h: one maximum per row of 64 particles.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umax_step(uint32_t v) {
+  const uint32_t s = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+  return v > s ? v : s;
+}
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+  v = dpp_umax_step<DPP_ROW_SHR1, 0xf>(v);
+  v = dpp_umax_step<DPP_ROW_SHR2, 0xf>(v);
+  v = dpp_umax_step<DPP_ROW_SHR4, 0xf>(v);
+  v = dpp_umax_step<DPP_ROW_SHR8, 0xf>(v);
+  v = dpp_umax_step<DPP_ROW_BCAST15, 0xa>(v);
+  v = dpp_umax_step<DPP_ROW_BCAST31, 0xc>(v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ double wave_max_key(double x) {
+  const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
+  const uint32_t sg = (uint32_t)((int)hi >> 31);              // all ones for negative numbers
+  const uint32_t kh = hi ^ (sg | 0x80000000u), kl = lo ^ sg;  // unsigned order of (kh, kl) = order of the doubles
+  const uint32_t mh = wave_umax(kh);
+  const uint32_t ml = wave_umax(kh == mh ? kl : 0u);
+  const uint32_t rs = (mh & 0x80000000u) ? 0u : 0xFFFFFFFFu;  // undo the map (wave-uniform: scalar)
+  return __hiloint2double((int)(mh ^ (rs | 0x80000000u)), (int)(ml ^ rs));
+}
 // sum over the wave in every lane (the last lane of the scan holds the total)
 __device__ __forceinline__ double wave_sum(double v) { return lane_broadcast(wave_scan_incl(v), 63); }
 

@@ -233,6 +233,8 @@ __global__ void debug_math_kernel(int fn, const double* __restrict__ in, double*
     for (int q = 0; q < 4; q++) out[4 * i + q] = z[q];
   } else if (fn == 5) {  // resampling uniform of slot i at step 3 of a filter with a PACKED step draw
     out[i] = (double)rng_resample_word<4>(RngKey{1u, 0u}, 3u, (uint32_t)i, u32x4{0u, 0u, 0u, 0u}) * 0x1.0p-32;
+  } else if (fn == 6) {  // maximum of the wave's 64 values through the integer-key reduction (pf_device.h: wave_max_key)
+    out[i] = wave_max_key(x);
   } else if (fn == 3) {  // Box-Muller pair for Philox key (seed = 1, stream = 0), counter (i, 0, 0, purpose 2)
     double z0, z1;
     rng_normal_pair(RngKey{1u, 0u}, RNG_TRANSITION, 0u, (uint32_t)i, 0u, z0, z1);

@@ -14,9 +14,27 @@
 // ancestor states), one workgroup barrier (math tables + the combine of wave 0), no coarse table, no weights output.
 #pragma once
 
+// analysis builds (-DBSSM_ROW_STAMPS, `make rowstamps`): shader-clock stamps of one wave (workgroup 3 of filter 0, wave 1) at the
+// phase boundaries, each behind a wait for the wave's outstanding memory operations so that latency is charged to the phase
+// that issued the loads (scripts/row_phase_probe.py through bssm_plan_debug_timeline)
+#ifdef BSSM_ROW_STAMPS
+#define ROW_STAMP(k)                                                                                 \
+  do {                                                                                               \
+    __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+    if (ws.dbg && blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 64 && t >= 1)                   \
+      ws.dbg[(size_t)t * 16 + (k)] = (long long)__builtin_readcyclecounter();                        \
+    __asm__ volatile("" ::: "memory");                                                               \
+  } while (0)
+#else
+#define ROW_STAMP(k)
+#endif
+
 namespace bssm {
 
 constexpr int ROW_NT = 256;    // four rows per workgroup
+#ifndef ROW_PARTS
+#define ROW_PARTS 2     // launch sequences of a batch of 24 filters or more (profiles/r05_row_family_probe.txt)
+#endif
 constexpr int ROW_WIN = 256;   // entries of the exchange array a wave stages per search round (four source rows)
 
 // the filter variants this family carries: functor models of every sampler and the linear-state models without a matrix-core
@@ -82,16 +100,18 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   __shared__ double s_comb[4 * 64 + 2];  // row prefixes (128), 1 / scale (128), M, S
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int f = ws.f0 + blockIdx.y, g = blockIdx.x * 4 + wave, B = ws.B, N = b.N, n = b.n, m = b.m, tn = t + 1;
+  ROW_STAMP(0);
   const MathTabRegs mtab = math_tab_load_begin256();
   const RngKey key{b.seed, b.stream0 + (uint32_t)f};
   const int j = g * CANON_ROW + lane;
   const bool has_row = g < B, act = has_row && j < N;
-
-  // ---- the (M_row, S_row) partials of the time-t weights: combined by wave 0 while the others draw their step blocks
+  const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
+  const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N;
+  // ---- the (M_row, S_row) partials of the time-t weights: requested first, combined by wave 0 while the others draw their step blocks
+  double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
   if (wave == 0) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
-    double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
     if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
     if (lane + 64 < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64)); pmaxb = pp.x; psumb = pp.y; }
     const CanonComb<true> cc = canon_combine<true>(pmax, psum, pmaxb, psumb, B);
@@ -103,8 +123,10 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   }
   const u32x4 blk = rng_step_block(key, (uint32_t)t, (uint32_t)j);
   const uint32_t uword = rng_resample_word<ucnt>(key, (uint32_t)t, (uint32_t)j, blk);
+  ROW_STAMP(1);  // tables + partials (wave 0: + combine) + step block
   math_tab_load_end256(mtab);
   lds_barrier();  // (1) the only workgroup barrier of the step
+  ROW_STAMP(2);  // barrier wait
   const CanonPrefix<true> px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[192 + lane], B};
   const double M = s_comb[256], S = s_comb[257];
   if (!(S > 0.0)) {
@@ -125,9 +147,11 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   // ---- stratified resampling (pf_canon.h): source row per slot, then the bisection inside it.  The rows [c_lo, c_hi] a wave draws
   // from are contiguous in the exchange array: staged four at a time in the wave's window
   const CanonSource src = canon_source_row<true>(canon_target(uword, j, c_scale), act, px, lane);
-  const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
+  ROW_STAMP(3);  // source rows
   double* sw = s_win + wave * ROW_WIN;
   int anc = 0;
+  constexpr bool kLinearStep = FN == FN_NONE || PM == 1;  // the transition is C_t + T_t a + R_t eta (linear-state models, psi-APF proposal)
+  double z[KP];
   for (int r0 = src.c_lo; r0 <= src.c_hi; r0 += 4) {  // wave-uniform bounds
     const int nr = min(4, src.c_hi - r0 + 1);
     double xr[4];
@@ -136,7 +160,15 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
       const int k = (r0 + q) * CANON_ROW + lane;
       xr[q] = (q < nr && k < N) ? lcdf[k] : 0.0;
     }
-    if (r0 != src.c_lo) lds_wave_sync();  // the previous round's reads are done
+    if constexpr (kLinearStep) {  // the transition normals depend on nothing but (seed, t, slot): drawn under the round trip of the rows
+      if (r0 == src.c_lo) {
+        rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+#pragma unroll
+        for (int c = 0; c < KP; c++) __asm__ volatile("" : "+v"(z[c]));
+      }
+    }
+    if (r0 == src.c_lo) ROW_STAMP(4);  // rows loaded, transition normals drawn under them
+    lds_wave_sync();  // the previous round's reads are done
 #pragma unroll
     for (int q = 0; q < 4; q++) sw[q * CANON_ROW + lane] = xr[q];
     lds_wave_sync();
@@ -145,14 +177,15 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
       anc = src.e * CANON_ROW + min(canon_count_below(sw + (src.e - r0) * CANON_ROW, slen, src.vp), slen - 1);
     }
   }
+  ROW_STAMP(5);  // staged, bisected
   if (b.indices && act) __builtin_nontemporal_store((uint32_t)anc, &b.indices[((size_t)f * n + t) * N + j]);
 
   // ---- ancestor state, transition to t + 1 (src/model_ssm_ung.cpp:657-670; functor models: pf_functors.h), weight there
-  const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N;
   double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N;
   double a[MP], x[MP];
 #pragma unroll
   for (int c = 0; c < MP; c++) a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
+  ROW_STAMP(6);  // ancestor gather
   const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
   const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
@@ -164,10 +197,10 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   } else if (FN && psi_mode == 2) {
     if constexpr (FN != FN_NONE) functor_ekpf_propagate<MP, FID>(fpar, ob, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x);
   } else {
-    double z[KP];
-    rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+    if constexpr (!kLinearStep) rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);  // (PM = -1: the sampler is a run-time value)
     propagate<MP, KP>(as_uniform_table(mats + (size_t)t * b.mats_tstride), a, z, x);
   }
+  ROW_STAMP(7);  // transition
   if (act) {
 #pragma unroll
     for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[c];
@@ -175,7 +208,10 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   double w;
   if constexpr (kPsiFn) w = tn < n ? functor_psi_weight<MP, FID>(as_uniform_table(fpar), as_uniform_table(ob), as_uniform_table(amats + (size_t)t * fn_amat_row<MP>()), tn, x, a) : 0.0;
   else w = tn < n ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)t * fn_amat_row<MP>(), tn, x, a) : 0.0;
+  ROW_STAMP(8);  // state store + weight
   row_publish(b, ws, f, g, j, act, tn, w, lane);
+  ROW_STAMP(9);  // row statistics + hand-over
+  ROW_STAMP(10); ROW_STAMP(11);
 }
 
 // workspace of the row family: GridWorkspace with chunk = 64 (no coarse table, no weights scale factors, no control block)
@@ -218,19 +254,27 @@ hipError_t launch_row_mk(const FilterBatch& b, const GridWorkspace& ws, hipStrea
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
   const int wgs = (ws.B + 3) / 4;
-  int parts = ((long long)b.F * wgs >= 512 && b.F >= 2 && ws.side) ? 2 : 1;
-  if (opt().grid_streams > 0) parts = std::max(1, std::min({opt().grid_streams, 2, b.F}));
+  // A step is a chain of dependent latencies, not work (a 19-filter launch: 6.7 us, of which the chip is busy a fraction), so a
+  // batch is stepped as several interleaved launch sequences over disjoint groups of its filters -- the library's side stream plus
+  // up to two more per host thread: the chains overlap
+  constexpr int kMaxParts = 4;
+  int parts = b.F >= 8 ? (b.F >= 24 ? ROW_PARTS : 2) : 1;
+  if (opt().grid_streams > 0) parts = opt().grid_streams;
+  parts = std::max(1, std::min({parts, kMaxParts, b.F}));
   if (!ws.side) parts = 1;
-  hipStream_t lanes[2] = {stream, parts == 2 ? ws.side : stream};
-  GridWorkspace wsp[2] = {ws, ws};
-  int fcount[2] = {b.F, 0};
+  hipStream_t lanes[kMaxParts] = {stream, stream, stream, stream};
+  GridWorkspace wsp[kMaxParts] = {ws, ws, ws, ws};
+  int fcount[kMaxParts] = {b.F, 0, 0, 0};
   hipEvent_t fork = nullptr, join = nullptr;
-  if (parts == 2) {
-    fcount[0] = b.F / 2; fcount[1] = b.F - fcount[0];
-    wsp[1].f0 = ws.f0 + fcount[0];
+  if (parts >= 2) {
+    static thread_local TlsStream extra_side[kMaxParts - 2];
+    lanes[1] = ws.side;
+    for (int q = 2; q < parts; q++) { lanes[q] = extra_side[q - 2].get(); if (!lanes[q]) { parts = q; break; } }
+    int f_at = 0;
+    for (int q = 0; q < parts; q++) { fcount[q] = (b.F * (q + 1)) / parts - (b.F * q) / parts; wsp[q].f0 = ws.f0 + f_at; f_at += fcount[q]; }
     if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return e;
     (void)hipEventRecord(fork, stream);
-    (void)hipStreamWaitEvent(lanes[1], fork, 0);
+    for (int q = 1; q < parts; q++) (void)hipStreamWaitEvent(lanes[q], fork, 0);
   }
   if (timing) timing->concurrent = parts;
   for (int t = -1; t < b.n; t++) {
@@ -239,11 +283,13 @@ hipError_t launch_row_mk(const FilterBatch& b, const GridWorkspace& ws, hipStrea
       else hipLaunchKernelGGL(kern, dim3(wgs, fcount[q]), dim3(ROW_NT), 0, lanes[q], b, wsp[q], t);
     }
   }
-  if (parts == 2) {
-    if ((e = hipEventCreateWithFlags(&join, hipEventDisableTiming)) != hipSuccess) return e;
-    (void)hipEventRecord(join, lanes[1]);
-    (void)hipStreamWaitEvent(stream, join, 0);
-    (void)hipEventDestroy(join);
+  if (parts >= 2) {
+    for (int q = 1; q < parts; q++) {
+      if ((e = hipEventCreateWithFlags(&join, hipEventDisableTiming)) != hipSuccess) return e;
+      (void)hipEventRecord(join, lanes[q]);
+      (void)hipStreamWaitEvent(stream, join, 0);
+      (void)hipEventDestroy(join);
+    }
     (void)hipEventDestroy(fork);
   }
   if ((e = hipGetLastError()) != hipSuccess) return e;

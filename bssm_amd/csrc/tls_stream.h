@@ -1,7 +1,10 @@
 // tls_stream.h -- one cached HIP stream per (host thread, purpose), re-made when the thread's current device changes
-// and destroyed when the thread exits.  The library keeps a few long-lived streams per host thread (side launch
+// and handed back when the thread exits.  The library keeps a few long-lived streams per host thread (side launch
 // sequence, output-copy stream, set-up smoother); a plain `static thread_local hipStream_t` leaked one stream per
 // short-lived worker thread and handed a stream of the wrong device to a thread that had switched devices.
+// Round 5: a post-correction call runs its filters on a worker thread of its own, and creating / destroying that thread's
+// streams cost 0.4 ms of a 7.6 ms call (hipStreamDestroy at thread exit) -- streams now return to a process-wide pool
+// (options.cpp) keyed by (device, priority) and are taken from there first; nothing is destroyed before the process ends.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <sys/syscall.h>
@@ -9,15 +12,25 @@
 
 namespace bssm {
 
+#ifndef BSSM_USER_MODEL
+hipStream_t stream_pool_take(int dev, bool highest_priority);  // nullptr when the pool has none
+void stream_pool_give(int dev, bool highest_priority, hipStream_t s);
+#endif
+
 struct TlsStream {
   hipStream_t s = nullptr;
   int dev = -1;
+  bool hi = false;
   // highest_priority: for small latency-critical kernels that compete with grids filling every CU
   hipStream_t get(bool highest_priority = false) {
     int cur = 0;
     if (hipGetDevice(&cur) != hipSuccess) return nullptr;
     if (s && cur == dev) return s;
     drop();
+    hi = highest_priority;
+#ifndef BSSM_USER_MODEL
+    if ((s = stream_pool_take(cur, hi)) != nullptr) { dev = cur; return s; }
+#endif
     hipError_t e;
     if (highest_priority) {
       int lo_p = 0, hi_p = 0;
@@ -32,6 +45,11 @@ struct TlsStream {
   }
   void drop() {
     if (!s) return;
+#ifndef BSSM_USER_MODEL
+    stream_pool_give(dev, hi, s);
+    s = nullptr;
+    return;
+#endif
     int cur = 0;
     (void)hipGetDevice(&cur);
     if (cur != dev) (void)hipSetDevice(dev);

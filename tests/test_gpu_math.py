@@ -93,3 +93,18 @@ def test_packed_normals_and_shared_uniforms_match_oracle(oracle):
     gu = _run(5, np.zeros(n), mult=2)[:n]
     ru = np.array([L.orc_rng_uniform(C.byref(rng), 1, 3, i, 4) for i in range(n)])
     assert np.array_equal(gu, ru)
+
+
+def test_wave_max_key_is_the_exact_maximum():
+    """wave_max_key (pf_device.h): the maximum of a wave's 64 doubles through two 32-bit DPP reductions on an order-preserving
+    integer key -- exact for every sign / magnitude mix, -inf rows, signed zeros, denormals and equal high words"""
+    rng = np.random.default_rng(5)
+    blocks = [rng.normal(0, 1e3, 64), -np.abs(rng.normal(0, 1e-3, 64)), np.full(64, -np.inf), rng.normal(0, 1, 64) * 1e-310,
+              -1.0 - rng.integers(0, 2 ** 30, 64) * 2.0 ** -52, 1.0 + rng.integers(0, 2 ** 30, 64) * 2.0 ** -52,
+              np.where(rng.random(64) < 0.5, -np.inf, rng.normal(-700, 30, 64)), np.r_[np.full(63, -5.0), 1e308], np.r_[0.0, np.full(63, -0.0)]]
+    for _ in range(23):
+        blocks.append(rng.normal(0, 1, 64) * 10.0 ** rng.integers(-300, 300))
+    x = np.concatenate(blocks)
+    got = _run(6, x)
+    want = np.repeat(x.reshape(-1, 64).max(axis=1), 64)
+    assert np.array_equal(got, want)
