@@ -43,11 +43,14 @@ HEAD_VALU_PER_PSTEP = 7813185.0 / (16 * 65536.0)                # pf_grid_step_v
 C4_VALU_PER_PSTEP = 6583014.7 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r04_pmc_C4.txt; round 3: 7.14 M)
 
 
-def valu_roofline(valu_per_pstep, psteps_per_s, kernel, clock=None):
+def valu_roofline(valu_per_pstep, psteps_per_s, kernel, clock=None, key=None):
+    valu_source = "committed"
+    if key is not None:
+        valu_per_pstep, valu_source = valu_count(key, valu_per_pstep)
     a = valu_per_pstep * psteps_per_s
     out = {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
            "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
-           "lane_instr_per_particle_step": valu_per_pstep * 64,
+           "lane_instr_per_particle_step": valu_per_pstep * 64, "valu_source": valu_source,
            "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r04_pmc_sq1_summary.txt, r04_pmc_C4.txt, r04_pmc_C5.txt, r04_pmc_regb_v2.txt); rate: measured live"}
     if clock and clock.get("sclk_mhz"):
         # the issue roof at the engine clock the kernel actually ran at (the socket power limit holds it under 2.4 GHz)
@@ -172,6 +175,64 @@ def live_pmc_traffic(args, kernel, layout_factored, timeout=150):
             "launches_sampled": int(min(got["FETCH_SIZE"][2], got["WRITE_SIZE"][2]))}
 
 
+def live_valu_counts(args, timeout=240):
+    """Wave-level VALU instructions per particle-step of the kernels the VALU rooflines of this line are quoted on, MEASURED
+    during this run: ONE `rocprofv3 --pmc SQ_INSTS_VALU` pass of this very script (one step of the metric batch, regime B, C4, the
+    C5 post-correction; nothing else), the count of a dispatch divided by the particle-steps it advanced (Grid_Size of the
+    dispatch x particles per thread x time points per launch).  Outside every timed region.  None when rocprofv3 is missing or
+    the pass fails: the constants committed with the round's profiles (above) are used then, and `valu_source` says which."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--replicas", str(args.replicas), "--particles",
+            str(args.particles), "--T", str(args.T), "--series", args.series, "--no-cpu-baseline", "--no-single", "--no-dropin",
+            "--no-accuracy", "--no-side-runs", "--no-clock", "--no-live-pmc", "--no-live-valu", "--pc-c5-only"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tmp = tempfile.mkdtemp(prefix="bssm_valu_", dir="/tmp")
+    acc = {}
+    try:
+        cp = subprocess.run([exe, "--pmc", "SQ_INSTS_VALU", "--output-format", "csv", "-d", tmp, "--"] + base, cwd="/tmp", env=env,
+                            capture_output=True, text=True, timeout=timeout)
+        if cp.returncode != 0:
+            return None
+        for path in glob.glob(tmp + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(path)):
+                if row["Counter_Name"] != "SQ_INSTS_VALU":
+                    continue
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("bssm::", "").replace(" ", "")
+                a = acc.setdefault(name, [0.0, 0.0, 0])   # instructions, work-items, dispatches
+                a[0] += float(row["Counter_Value"]); a[1] += float(row["Grid_Size"]); a[2] += 1
+    except Exception:  # noqa: BLE001 -- a measurement aid: never fails the benchmark
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def per_pstep(kernel, particles_per_thread, steps_per_launch):
+        a = acc.get(kernel)
+        return a[0] / (a[1] * particles_per_thread * steps_per_launch) if a and a[1] > 0 else None
+    got = {"head": per_pstep("pf_grid_step_v2<4,4,4,false,true,true>", 4, 1), "c4": per_pstep("pf_grid_step_v2<8,8,2,true,true,true>", 2, 1),
+           "regb": per_pstep("pf_wg_kernel<4,4,2,0,1024,-1,false>", 2, args.T), "c5": per_pstep("pf_wg_kernel<2,2,4,1,1024,1,true>", 4, 300),
+           "c5_row": per_pstep("pf_row_step<2,2,1,1>", 1, 1)}
+    got["dispatches"] = {k: v[2] for k, v in acc.items() if k.startswith("pf_")}
+    return got
+
+
+LIVE_VALU = None   # filled once per run by live_valu_counts (rank 0, one GPU)
+
+
+def valu_count(key, committed):
+    """(instructions per particle-step, where the number comes from)"""
+    v = (LIVE_VALU or {}).get(key)
+    return (v, "live: rocprofv3 --pmc SQ_INSTS_VALU pass of this run") if v else (committed, "committed: profiles/r04_pmc_* (the live pass did not run)")
+
+
 def _c5_job(ns):
     """ssm_nlg growth model, T = 300, m = 2; `ns` retained draws around theta-hat"""
     import numpy as np
@@ -288,7 +349,7 @@ def post_correct_phase(rank, world, dist, cdev="cuda", reps=3, cpu_baseline=Fals
             "scaling": "strong", "n_gpus": world, "seconds": times[best], "draws_per_s": ns / times[best],
             "value": ns * float(nsim) * n / times[best], "unit": "particle-steps/s", "host_threads_per_rank": threads,
             "roofline_valu": valu_roofline(C5_VALU_PER_PSTEP, (float(np.diff(bounds).max()) * world) * float(nsim) * n / (filt * 1e-3),
-                                           C5_KERNEL) if filt > 0 else None,
+                                           C5_KERNEL, key="c5") if filt > 0 else None,
             "per_rank_ms": [{"rank": q, "draws": int(bounds[q + 1] - bounds[q]), "host_pack_ms": round(v[0], 2),
                              "setup_call_ms": round(v[1], 2), "filter_ms": round(v[2], 2), "local_ms": round(v[3], 2),
                              "wait_ms": round(v[4], 2), "collective_ms": round(v[5], 2)}
@@ -538,6 +599,9 @@ def main():
     ap.add_argument("--no-side-runs", action="store_true", help="skip the reference-layout / other-series runs of the same batch")
     ap.add_argument("--no-clock", action="store_true", help="skip the rocm-smi clock / power samples under load")
     ap.add_argument("--pc-draws", type=int, default=2340, help="retained draws of the post_correct job (C5: 2340)")
+    ap.add_argument("--no-live-valu", action="store_true", help="take the VALU instruction counts of the roofline_valu objects from the committed profiles instead of one rocprofv3 --pmc SQ_INSTS_VALU pass of this run")
+    ap.add_argument("--pc-c5-only", action="store_true", help="post_correct leg: the C5 job alone (the counter pass of live_valu_counts)")
+    ap.add_argument("--no-projection", action="store_true", help="skip post_correct_scaling.projected (one rank's share of the job at 1 / 2 / 4 / 8 ranks, measured on this GPU)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -585,6 +649,11 @@ def main():
 
     from bssm_amd.plan import FilterPlan
     from models_zoo import negbin_m4, negbin_m4_informative
+
+    global LIVE_VALU
+    if rank == 0 and world == 1 and not args.no_live_valu and not args.no_live_pmc:
+        # (before this process holds device memory: the counter pass is a child process running the same legs once)
+        LIVE_VALU = live_valu_counts(args)
 
     N, T, m = args.particles, args.T, 4
     # The metric model on counts that stay informative (default since round 4), or on a series simulated
@@ -674,7 +743,7 @@ def main():
             torch.cuda.synchronize()
             out["roofline"]["clock_power_under_load"] = ck
             out["roofline"]["valu"] = valu_roofline(HEAD_VALU_PER_PSTEP, seqs * (R // seqs) * float(N) / (k_ms * 1e-3),
-                                                    "pf_grid_step_v2<4,4,4,false,true,true>", ck) if ppt == 4 and m == 4 and layout["factored"] else None
+                                                    "pf_grid_step_v2<4,4,4,false,true,true>", ck, key="head") if ppt == 4 and m == 4 and layout["factored"] else None
     head_kernel, head_factored = (FilterPlan.last_kernel(), layout["factored"]) if rank == 0 else ("", True)
     plan.close()
     if rank == 0 and world == 1 and not args.no_live_pmc and "roofline" in out:
@@ -713,6 +782,13 @@ def main():
         out["other_series"] = {"series": "model" if args.series == "informative" else "informative", **side_run(other(T, seed=103), fw),
                                "note": "the same model matrices and plan on the other observed series (see config.workload); rounds 1-3 "
                                        "quoted `value` on the model-simulated series"}
+        # the same batch under the CONTRACT's choices, in `config` so that the record is self-contained (round-4 review 6a): the
+        # reference's weights layout (what the drop-in entry points return) and the SURVEY 8d series simulated from the model
+        if "roofline_reference_layout" in out:
+            out["config"]["reference_layout_frac"] = out["roofline_reference_layout"]["frac"]
+        out["config"]["contract_series_frac" if args.series == "informative" else "informative_series_frac"] = out["other_series"]["frac"]
+        out["config"]["fracs_note"] = ("roofline.frac of the same 32-filter batch: reference_layout_frac = weights as exp(w - max_t) (reference layout), "
+                                       "contract_series_frac = y simulated from the model (SURVEY.md 8d seed 103: 98 % zeros); HIP-event launch durations, 88 B per particle-step")
 
     if rank == 0 and world == 1 and R != 1 and not args.no_single:
         # ---- regime A: ONE filter, latency-bound (1000 dependent launches, one wave per SIMD)
@@ -750,7 +826,7 @@ def main():
                            "kernel": pb.last_kernel(), "kernel_ms": kb_ms,
                            "algorithmic_GBs": ps * ib["bytes_per_particle_step"] / (kb_ms * 1e-3) / 1e9,
                            "note": "state never leaves LDS: HBM traffic ~0, bound by fp64 VALU/transcendentals",
-                           "roofline_valu": valu_roofline(REGB_VALU_PER_PSTEP, ps / (kb_ms * 1e-3), pb.last_kernel())}
+                           "roofline_valu": valu_roofline(REGB_VALU_PER_PSTEP, ps / (kb_ms * 1e-3), pb.last_kernel(), key="regb")}
         pb.close()
 
     if rank == 0 and world == 1 and not args.no_regime_b and not args.no_mng:
@@ -776,12 +852,12 @@ def main():
                          "value": psm / em, "unit": "particle-steps/s", "ms_per_pass": em * 1e3, "kernel": pm.last_kernel(),
                          "weights_layout_factored": pm.weights_layout()["factored"], "launch_sequences": pm.launch_sequences(),
                          "algorithmic_GBs": psm * 152 / em / 1e9, "frac_of_8TBs": psm * 152 / em / 8e12,
-                         "roofline_valu": valu_roofline(C4_VALU_PER_PSTEP, psm / em, "pf_grid_step_v2<8,8,2,true,true,true>")}
+                         "roofline_valu": valu_roofline(C4_VALU_PER_PSTEP, psm / em, "pf_grid_step_v2<8,8,2,true,true,true>", key="c4")}
         if not args.no_clock:
             ckm = clock_power_while(lambda k: (pm.run(5000 + k, hip_stream=stream), torch.cuda.synchronize()), samples=2)
             torch.cuda.synchronize()
             out["mng_c4"]["clock_power_under_load"] = ckm
-            out["mng_c4"]["roofline_valu"] = valu_roofline(C4_VALU_PER_PSTEP, psm / em, "pf_grid_step_v2<8,8,2,true,true,true>", ckm)
+            out["mng_c4"]["roofline_valu"] = valu_roofline(C4_VALU_PER_PSTEP, psm / em, "pf_grid_step_v2<8,8,2,true,true,true>", ckm, key="c4")
         pm.close()
         _L.lib().bssm_amd_trim_cache()
 
@@ -809,25 +885,45 @@ def main():
         try:
             from bssm_amd import filters as Fd, models as Md
 
-            def best_of(fn, reps=3):
+            first = {}
+
+            def best_of(fn, reps=3, tag=None):
                 # the call alone: releasing the previous result (2.6 GB of pageable host memory, ~90 ms of munmap) is the
                 # caller's garbage collection, not the entry point, and stays outside the timed region
-                res = fn()
+                t1 = time.perf_counter(); res = fn(); first[tag] = time.perf_counter() - t1
                 bt = 1e9
                 for _ in range(reps):
                     del res
                     t1 = time.perf_counter(); res = fn(); bt = min(bt, time.perf_counter() - t1)
                 return bt
 
-            e1 = best_of(lambda: Fd.bootstrap_filter(model, N, seed=1))
+            # the floor of such a call: its outputs over PCIe at the rate THIS box copies device memory into pinned host memory
+            gib = 1 << 30
+            dsrc = torch.empty(gib, dtype=torch.uint8, device=cdev)
+            hdst = torch.empty(gib, dtype=torch.uint8, pin_memory=True)
+            hdst.copy_(dsrc, non_blocking=True); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                hdst.copy_(dsrc, non_blocking=True)
+            torch.cuda.synchronize()
+            d2h_gbs = 3 * gib / (time.perf_counter() - t1) / 1e9
+            del dsrc, hdst
+            e1 = best_of(lambda: Fd.bootstrap_filter(model, N, seed=1), tag="c2m4")
             yx = np.loadtxt(os.path.join(ROOT, "tests", "golden", "exchange.txt"))
             svm = Md.svm(yx, rho=Md.uniform(0.98, -0.999, 0.999), sd_ar=Md.halfnormal(0.2, 5), sigma=Md.halfnormal(1.0, 2))
             e3 = best_of(lambda: Fd.particle_smoother(svm, 32768, method="psi", seed=1))
             out["dropin"] = {
                 "note": "one call through the C ABI with host (pageable numpy) buffers: model upload, filter, and every output "
                         "(particle cube m x (n+1) x N, weights, summaries) copied back; output slabs stream out while the filter steps",
+                "pinned_d2h_GBs": d2h_gbs,
                 "C2-m4_bootstrap_filter": {"ms_per_call": e1 * 1e3, "value": N * float(T) / e1, "unit": "particle-steps/s",
-                                           "output_GB": (m * (T + 1) * N + (T + 1) * N) * 8 / 1e9},
+                                           "output_GB": (m * (T + 1) * N + (T + 1) * N) * 8 / 1e9,
+                                           "pcie_floor_ms": (m * (T + 1) * N + (T + 1) * N) * 8 / 1e9 / d2h_gbs * 1e3,
+                                           "first_call_ms": first["c2m4"] * 1e3,
+                                           "floor_note": "pcie_floor_ms = output bytes / the pinned device-to-host rate measured in this run (1 GiB copies); "
+                                                         "the entry point writes into the caller's PAGEABLE arrays, as R's are.  first_call_ms = the first call of "
+                                                         "this entry point in this process (device arena already warm from the legs above; pinned staging and the "
+                                                         "2.6 GB of fresh pageable output pages are not)"},
                 "C3_psi_particle_smoother": {"ms_per_call": e3 * 1e3, "value": 32768 * float(len(yx)) / e3, "unit": "particle-steps/s",
                                              "workload": "svm on the exchange series (n = 945), psi-APF N = 32768, back-trace + summary"}}
         except Exception as e:  # noqa: BLE001
@@ -843,25 +939,40 @@ def main():
             out["post_correct"] = pc
         # the same job eight times larger (what a 160 000-iteration chain retains): long enough for a scaling curve
         try:
-            pc8 = post_correct_phase(rank, world, dist, cdev, reps=2, ns=8 * args.pc_draws, label="C5 x8 draws")
+            pc8 = {"skipped": "--pc-c5-only"} if args.pc_c5_only else post_correct_phase(rank, world, dist, cdev, reps=2, ns=8 * args.pc_draws, label="C5 x8 draws")
         except Exception as e:  # noqa: BLE001
             pc8 = {"error": repr(e)[:200]}
         if rank == 0:
             out["post_correct_large"] = pc8
             # the strong-scaling evidence of the path that shards (north_star: "near-linear post_correct scaling to 8 GPUs"),
             # at the top level: the whole job's wall time at this N against the one-GPU time of the SAME job (measured in this
-            # run when N = 1; otherwise the figure stored by the round's one-GPU run, profiles/r04_post_correct_n1.json)
+            # run when N = 1; otherwise the figure stored by the round's one-GPU run, profiles/r05_post_correct_n1.json)
             try:
                 n1 = json.load(open(os.path.join(ROOT, "profiles", "r04_post_correct_n1.json")))
             except (OSError, ValueError):
                 n1 = {}
             sc = {"scaling": "strong", "n_gpus": world, "rccl_ranks": comm["ranks"] if comm["backend"] == "rccl" else 0,
-                  "distinct_gpus": comm["distinct_gpus"], "n1_source": "this run" if world == 1 else "profiles/r04_post_correct_n1.json (one MI355X, same job)"}
+                  "distinct_gpus": comm["distinct_gpus"], "n1_source": "this run" if world == 1 else "profiles/r05_post_correct_n1.json (one MI355X, same job)"}
             for key, obj, name in (("C5", pc, "post_correct"), ("C5_x8_draws", pc8, "post_correct_large")):
                 if isinstance(obj, dict) and "seconds" in obj:
                     base = obj["seconds"] if world == 1 else n1.get(name, {}).get("seconds")
                     sc[key] = {"seconds": obj["seconds"], "seconds_n1": base, "speedup_vs_n1": (base / obj["seconds"]) if base else None,
                                "particle_steps_per_s": obj["value"]}
+            if world == 1 and not args.no_projection and not args.pc_c5_only:
+                # PROJECTED strong scaling, measured on this one GPU (no multi-GPU node is available to the builder; the driver's
+                # SCALE run is the real curve): what ONE rank of an N-rank job does -- ceil(draws / N) draws, streams keyed by the
+                # global draw index -- timed as a whole call of the library, BEFORE the collective (one all-gather of <= 150 KB).
+                # A rank's share of a job this size is 1-10 rounds of 256 workgroup-resident filters; a sparsely filled last
+                # round goes through the row family (pf_row_step.h), bit-identical, which is what keeps the 8-rank share near 1 / 8.
+                proj = {"what": "projected, one rank's share of the job on one MI355X, before the collective", "ranks": [1, 2, 4, 8]}
+                for key, total in (("C5", args.pc_draws), ("C5_x8_draws", 8 * args.pc_draws)):
+                    ms = []
+                    for wr in proj["ranks"]:
+                        r = post_correct_phase(0, 1, None, cdev, reps=2 if total > 5000 else 3, ns=-(-total // wr), label="%s / %d ranks" % (key, wr))
+                        ms.append(r["seconds"] * 1e3)
+                    proj[key] = {"draws_per_rank": [-(-total // wr) for wr in proj["ranks"]], "shard_ms": [round(v, 3) for v in ms],
+                                 "speedup": [round(ms[0] / v, 3) for v in ms]}
+                sc["projected"] = proj
             out["post_correct_scaling"] = sc
         if rank == 0 and world == 1:
             try:
