@@ -397,7 +397,9 @@ struct DeviceBatch {
   // workspace of the one-launch-per-step families: the row family when BSSM_AMD_FORCE_PATH=row asks for it and the batch has such
   // kernels (pf_row_step.h; otherwise it is reached through the tail split of a post-correction chunk only), else the step kernels
   int alloc_step_workspace() {
-    if (bssm::opt().force_path == 3 && bssm::row_filter_supported(fb)) {
+    // (states of more than 16 dimensions -- pf_big.h -- have no other step shape than the row family: up to 8192 particles)
+    if (fb.MP >= 32 && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "nsim above 8192 is not supported for states of more than 16 dimensions");
+    if ((bssm::opt().force_path == 3 || fb.MP >= 32) && bssm::row_filter_supported(fb)) {
       HIP_TRY(ws.alloc(bssm::row_workspace_bytes(fb)));
       bssm::row_workspace_carve(fb, ws.p, &gws);
       return BSSM_OK;

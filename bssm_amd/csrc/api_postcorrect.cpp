@@ -282,7 +282,10 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
         }
         sub.seed = job->seed;
         sub.stream0 = (uint32_t)(job->first + order[pos + f0]);
-        if (db.use_grid && !(bssm::opt().force_path == 3 && bssm::row_filter_supported(sub))) {
+        // every draw through the row family: states of more than 16 dimensions beyond the workgroup-resident capacity (their only step
+        // shape), or BSSM_AMD_FORCE_PATH=row (test / measurement hook)
+        const bool all_rows = bssm::row_filter_supported(sub) && (bssm::opt().force_path == 3 || (db.use_grid && sub.MP >= 32));
+        if (db.use_grid && !all_rows) {
           DevBuf wsb;  // workspace sized for the sub-batch
           int B, chunk;
           HIP_TRY(wsb.alloc(bssm::grid_workspace_bytes(sub, &B, &chunk)));
@@ -302,7 +305,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           // tail through the step kernels, whose reduction shape differs: opt-in, results depended on the device list.)
           // Not when a path is forced, and only for the shapes the row family carries (row_filter_supported).  BSSM_AMD_TAIL_SPLIT=0 turns it off.
           int tail = 0;
-          if (bssm::opt().force_path == 3 && bssm::row_filter_supported(sub)) tail = sub.F;  // (test / measurement hook: every draw through the row family)
+          if (all_rows) tail = sub.F;
           else if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && bssm::opt().force_path == 0 && bssm::opt().tail_split &&
               bssm::row_filter_supported(sub)) {
             int dev = 0; hipDeviceProp_t prop;

@@ -23,10 +23,10 @@ constexpr double kPi = 3.14159265358979323846;
 
 // ------------------------------------------------------------------ tiny dense matrix
 // Inline storage (no heap): the psi set-up builds thousands of these per draw, and with a std::vector behind each
-// one the allocator was most of the set-up time.  16 x 16 covers the largest padded dimension the kernels support;
+// one the allocator was most of the set-up time.  64 x 64 covers the largest state dimension the kernels support;
 // copies move only the r * c entries in use.
 struct Mat {
-  static constexpr int kMaxElems = 256;
+  static constexpr int kMaxElems = 64 * 64;  // (round 5: states of up to 64 dimensions -- seasonal components of period 24 / 52, R/models.R:995-997; nothing beyond r * c is initialised or copied)
   int r = 0, c = 0;
   double a[kMaxElems];
   Mat() {}
@@ -519,6 +519,10 @@ int pad_dim(int d) { int p = 1; while (p < d) p <<= 1; return p; }
 // draw (pf_device.h: WIDE up to two normals, PACKED above) is a function of the REAL k; the kernels choose it from the padded
 // KP, so KP > 2 must imply k > 2: every MP has an instantiation with KP = 2.
 int pad_noise_dim(int MP, int k) {
+  if (MP >= 32) {  // the matrix-core filters of 17 ... 64 states (pf_big.h) take the noise in chunks of four columns; the stream format follows the real k
+    const int kp = (std::max(k, 1) + 3) / 4 * 4;
+    return kp > MP ? MP : kp;
+  }
   int kp = pad_dim(k);
   if (MP >= 8 && kp < 2) kp = 2;
   if (MP == 16) kp = kp <= 2 ? 2 : (kp <= 4 ? 4 : 16);
@@ -528,11 +532,11 @@ int pad_noise_dim(int MP, int k) {
 std::string ingest_model(const bssm_ung_model* s, bool need_mode, HostModel* o) {
   if (!s) return "model is NULL";
   if (s->n < 1 || s->m < 1 || s->k < 1) return "n, m, k must be positive";
-  if (s->m > 16) return "state dimension m > 16 is not supported by the kernels";
+  if (s->m > 64) return "state dimension m > 64 is not supported by the kernels";
   if (s->k > s->m) return "k (columns of R) must not exceed m";
   if (!s->y || !s->Z || !s->T || !s->R || !s->a1 || !s->P1) return "y, Z, T, R, a1, P1 must be non-NULL";
   const int n = s->n, m = s->m, k = s->k, p = s->p > 1 ? s->p : 1;
-  if (p > 8) return "more than 8 observation series is not supported";
+  if (p > 16) return "more than 16 observation series is not supported";
   o->n = n; o->m = m; o->k = k; o->p = p;
   o->Ztv = s->Ztv != 0; o->Ttv = s->Ttv != 0; o->Rtv = s->Rtv != 0; o->Dtv = s->Dtv != 0; o->Ctv = s->Ctv != 0; o->Htv = s->Htv != 0;
   o->max_iter = s->max_iter > 0 ? s->max_iter : 100;

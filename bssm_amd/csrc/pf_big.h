@@ -1,0 +1,394 @@
+// pf_big.h -- particle filters of the linear-state models with 17 ... 64 state dimensions (bootstrap and psi-APF;
+// src/model_ssm_ung.cpp:511-712, src/model_ssm_mng.cpp:461-668).
+//
+// The reference has no limit on the state dimension (src/model_ssm_ung.cpp:9-32 reads any m); bsm_ng / bsm_lg with a seasonal
+// component of period 24 or 52 have m = 1 + slope + (period - 1) + noise = 25 ... 54 states (R/models.R:995-997).  The kernels of
+// pf_filter_impl.h keep "my particle, all components" in the registers of a lane, which ends at 16 components.  Here the
+// transition
+//     X' (MP x 64) = C + [T R] (MP x (m + k)) . [A ; Z] ((m + k) x 64)          alpha_{t+1} = C_t + T_t alpha_t + R_t eta_t (:663-670)
+// of the 64 particles of a wave is a real dense contraction and runs on the matrix cores in their NATIVE fragment layout
+// (v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D[row = (lane >> 4) + 4 q][col = lane & 15]):
+//   * the particle system is COMPONENT-MAJOR ([component][particle], in LDS or in HBM), so a B fragment is "component 4 kk + kq of
+//     the ancestor of particle 16 pb + i" -- one gather per lane, no transposition; the ancestors of a wave's 64 slots come from a
+//     64-entry table in LDS;
+//   * A fragments ([T R], column-major, zero-padded to MP = 32 / 64 rows) are read straight from the filter's table (L1 / L2);
+//   * the noise goes through a 2 KB tile per wave four rows at a time: four normals are exactly one PACKED Philox block
+//     (pf_device.h), drawn by the lane that owns the particle;
+//   * k-chunks of four are skipped beyond the real m and k, so padding costs rows, not columns;
+//   * the D fragments ARE the new component-major state: stored as they are (128-byte segments per component and 16 particles);
+//     the signals Z_j x' are partial sums over a lane's 4 MB components and two cross-lane adds.
+// Everything that involves more than one particle is pf_canon.h, so the two shapes below give the same bits for a filter:
+//   pf_big_wg        one workgroup per filter, particle system in LDS, one wave per row of 64 particles (N <= 512 at MP = 32,
+//                    <= 256 at MP = 64), the whole time loop in one launch, 3 workgroup barriers per step;
+//   pf_big_row_step  one wave per row, particle system in HBM, one launch per time step (N <= 8192), the exchange of pf_row_step.h.
+// fp64 MFMA and fp64 VALU have the same peak on MI355X (78.6 TFLOP/s): the matrix cores buy the operand delivery (no m^2 scalar
+// operands per particle) and the registers (64 accumulators per lane at MP = 64 instead of three arrays of 64), not flops.
+#pragma once
+
+namespace bssm {
+
+typedef double big_d4 __attribute__((ext_vector_type(4)));
+constexpr int BIG_NT_MAX = 512;
+
+// new states of the wave's 64 particles in D-fragment layout: v[rb][pb][q] = x'[16 rb + kq + 4 q][particle 16 pb + i]
+template <int MB> struct BigAcc { big_d4 v[MB][4]; };
+
+__device__ __forceinline__ double big_xor_add(double x) {  // sum over the four lanes that share i = lane & 15 (fixed order)
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+// acc += A[:, 4 kk ... 4 kk + 3] . B chunk, every row block; Acol = first of the four columns (column-major, leading dimension MP)
+template <int MB>
+__device__ __forceinline__ void big_chunk(BigAcc<MB>& acc, const double* __restrict__ Acol, const double (&bf)[4], const int lane) {
+  constexpr int MP = 16 * MB;
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int rb = 0; rb < MB; rb++) {
+    const double afr = Acol[16 * rb + i + MP * kq];
+#pragma unroll
+    for (int pb = 0; pb < 4; pb++) acc.v[rb][pb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr, bf[pb], acc.v[rb][pb], 0, 0, 0);
+  }
+}
+
+// X' = c0 + A1 . S(ancestors) + A2 . noise for the 64 particles of this wave:
+//   c0  [MP]                     the constant (C_t; a1 at t = 0)
+//   A1  [MP x MP] column-major   T_t, applied to components [0, ms) of the ancestors' states (ms = 0: no state term)
+//   A2  [MP x KP] column-major   R_t (L at t = 0), applied to `ncnt` normals per particle
+//   state_at(c, pb)              component c of the ancestor of particle 16 pb + (lane & 15); rows >= ms are never asked for
+//   noise4(kk, z)                normals 4 kk ... 4 kk + 3 of THIS lane's particle (lane = particle inside the wave's row)
+//   tile                         4 x 64 doubles of LDS, this wave's
+template <int MB, class StateAt, class Noise4>
+__device__ __forceinline__ void big_affine(BigAcc<MB>& acc, const double* __restrict__ c0, const double* __restrict__ A1, const int ms,
+                                           const double* __restrict__ A2, const int ncnt, StateAt&& state_at, Noise4&& noise4,
+                                           double* tile, const int lane) {
+  constexpr int MP = 16 * MB;
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int rb = 0; rb < MB; rb++) {
+    const big_d4 cv{c0[16 * rb + kq], c0[16 * rb + kq + 4], c0[16 * rb + kq + 8], c0[16 * rb + kq + 12]};
+#pragma unroll
+    for (int pb = 0; pb < 4; pb++) acc.v[rb][pb] = cv;
+  }
+  for (int kk = 0; 4 * kk < ms; kk++) {
+    const int c = 4 * kk + kq;
+    double bf[4];
+#pragma unroll
+    for (int pb = 0; pb < 4; pb++) bf[pb] = c < ms ? state_at(c, pb) : 0.0;
+    big_chunk<MB>(acc, A1 + (size_t)MP * 4 * kk, bf, lane);
+  }
+  for (int kk = 0; 4 * kk < ncnt; kk++) {
+    double z[4];
+    noise4(kk, z);
+    lds_wave_sync();  // the previous chunk's reads of the tile are done
+#pragma unroll
+    for (int c = 0; c < 4; c++) tile[c * 64 + lane] = 4 * kk + c < ncnt ? z[c] : 0.0;
+    lds_wave_sync();
+    double bf[4];
+#pragma unroll
+    for (int pb = 0; pb < 4; pb++) bf[pb] = tile[kq * 64 + 16 * pb + i];
+    big_chunk<MB>(acc, A2 + (size_t)MP * 4 * kk, bf, lane);
+  }
+}
+
+// normals 4 kk ... 4 kk + 3 of draw (purpose, t, particle): the stream format follows the number of normals of the whole draw
+// (pf_device.h: WIDE up to two, PACKED above -- four normals are one block)
+__device__ __forceinline__ void big_normals4(const RngKey key, const uint32_t purpose, const uint32_t t, const uint32_t particle, const int cnt,
+                                             const int kk, const u32x4& blk0, double (&z)[4]) {
+  z[0] = z[1] = z[2] = z[3] = 0.0;
+  if (cnt <= 2) { box_muller(blk0, z[0], z[1]); return; }
+  const u32x4 w = kk == 0 ? blk0 : philox4x32_10(particle, t, (uint32_t)kk, purpose, key.seed, key.stream);
+  box_muller_packed(w.x, w.y, z[0], z[1]);
+  box_muller_packed(w.z, w.w, z[2], z[3]);
+}
+
+// log-weight of this lane's particle (lane = particle inside the row) from the D fragments: the signals D_j + Z_j x' of the row's
+// p series (src/model_ssm_ung.cpp:447-493, :385-439; src/model_ssm_mng.cpp:357-442), then the densities as log_weight_of
+template <int MB>
+__device__ __forceinline__ double big_log_weight(const FilterBatch& b, const double* __restrict__ row, const BigAcc<MB>& acc, const int lane) {
+  constexpr int MP = 16 * MB;
+  if (row[RH_FLAG] == 0.0) return 0.0;  // nothing observed at t: weights are ones (src/model_ssm_ung.cpp:644-647)
+  const int kq = lane >> 4;
+  double w = 0.0;
+  for (int j = 0; j < b.p; j++) {
+    const double* __restrict__ ob = row + ROW_HDR + j * (SER_HDR + MP);
+    if (ob[OB_FLAG] == 0.0) continue;
+    double own = 0.0;
+#pragma unroll
+    for (int pb = 0; pb < 4; pb++) {
+      double part = 0.0;
+#pragma unroll
+      for (int rb = 0; rb < MB; rb++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) part = __builtin_fma(ob[SER_HDR + 16 * rb + kq + 4 * q], acc.v[rb][pb][q], part);
+      const double s = big_xor_add(part);
+      own = kq == pb ? s : own;  // this lane's particle is 16 kq + i
+    }
+    const double s = ob[OB_D] + own;
+    const int dist = (int)ob[OB_DIST];
+    w += b.psi ? log_psi_weight(dist, ob, ob[OB_PHI], s) : log_obs_density(dist, ob, ob[OB_PHI], s);
+  }
+  return b.psi ? w - row[RH_SCALE] : w;
+}
+
+// the D fragments as the new component-major particle system: dst[c * stride + particle]
+template <int MB, bool NT>
+__device__ __forceinline__ void big_store(const BigAcc<MB>& acc, double* __restrict__ dst, const size_t stride, const int rows, const int first,
+                                          const int count, const int lane) {
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int rb = 0; rb < MB; rb++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = 16 * rb + kq + 4 * q;
+      if (c >= rows) continue;
+#pragma unroll
+      for (int pb = 0; pb < 4; pb++) {
+        const int prt = 16 * pb + i;
+        if (prt < count) {
+          if constexpr (NT) __builtin_nontemporal_store(acc.v[rb][pb][q], &dst[(size_t)c * stride + first + prt]);
+          else dst[(size_t)c * stride + first + prt] = acc.v[rb][pb][q];
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// one workgroup per filter, one wave per row of 64 particles, particle system in LDS
+// ------------------------------------------------------------------------------------------------------------------
+template <int MB>
+__global__ void __launch_bounds__(BIG_NT_MAX, 1) pf_big_wg(const FilterBatch b) {
+  constexpr int MP = 16 * MB;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  math_tab_init();
+  const int NT = (int)blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = NT >> 6, i16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Ncap = NT, N = b.N, n = b.n, m = b.m, KP = b.KP, f = blockIdx.x;
+  double* __restrict__ s_state = smem;                          // [MP][Ncap]
+  double* __restrict__ s_cdf = smem + (size_t)MP * Ncap;        // [Ncap] row-local scans (pf_canon.h)
+  double* __restrict__ s_max = s_cdf + Ncap;                    // [8]
+  double* __restrict__ s_tot = s_max + 8;                       // [8]
+  double* __restrict__ s_tile = s_tot + 8 + wave * 256;         // [nw][4 x 64]
+  int* __restrict__ s_anc = (int*)(s_tot + 8 + nw * 256);       // [Ncap]
+  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
+  const double* __restrict__ mats = b.mats + (size_t)f * b.mats_fstride;
+  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
+  const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
+  const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
+  const int j = tid;                 // this lane's particle
+  const int row0 = wave * CANON_ROW;  // first particle of this wave's row
+  const int cnt_row = min(CANON_ROW, N - row0);  // (<= 0: a wave without particles cannot occur: NT = 64 ceil(N / 64))
+  const int ncnt_step = b.psi ? m : b.k;  // normals of a step draw (psi-APF: the m-dimensional proposal noise, src/model_ssm_ung.cpp:585-586)
+  const int B = (N + CANON_ROW - 1) / CANON_ROW;
+  double loglik = 0.0, w;
+  BigAcc<MB> acc;
+
+  // ---- initial particles a1 + L u (src/model_ssm_ung.cpp:626; psi: alphahat_0 + V_0 u, :543) and their weights
+  {
+    const u32x4 blk0 = philox4x32_10((uint32_t)j, 0u, 0u, RNG_INIT, key.seed, key.stream);
+    big_affine<MB>(acc, ini, ini, 0, ini + MP, m, [](int, int) { return 0.0; },
+                   [&](int kk, double (&z)[4]) { big_normals4(key, RNG_INIT, 0u, (uint32_t)j, m, kk, blk0, z); }, s_tile, lane);
+    big_store<MB, false>(acc, s_state, (size_t)Ncap, MP, row0, CANON_ROW, lane);
+    if (b.alpha_hist) big_store<MB, true>(acc, b.alpha_hist + (size_t)f * (n + 1) * m * N, (size_t)N, m, row0, cnt_row, lane);
+    w = n > 0 ? big_log_weight<MB>(b, obs, acc, lane) : 0.0;
+    if (j >= N) w = -INFINITY;
+  }
+
+  for (int t = 0; t <= n; t++) {
+    // ---- normalise the time-t weights, canonical row form (pf_canon.h; src/model_ssm_ung.cpp:675-679)
+    const CanonRow rs = canon_row_stats(w);
+    if (j < N) s_cdf[j] = rs.sc;
+    if (lane == 63) s_tot[wave] = rs.sc;
+    if (lane == 0) s_max[wave] = rs.M;
+    lds_barrier();  // (1)
+    const CanonComb<false> cc = canon_combine<false>(lane < B ? s_max[lane] : -INFINITY, lane < B ? s_tot[lane] : 0.0, -INFINITY, 0.0, B);
+    if (b.weights && j < N) b.weights[((size_t)f * (n + 1) + t) * N + j] = rs.e * canon_row_scale(cc, wave);
+    if (!(cc.S > 0.0)) {  // :678-682 (uniform across the block)
+      loglik = -INFINITY;
+      if (tid == 0) b.dead_at[f] = t + 1;
+      break;
+    }
+    const double c_scale = canon_stratum(cc.S, N);
+    if (wave == 0) loglik += canon_llinc(cc.M, c_scale);  // :683
+    if (t == n) break;
+
+    // ---- stratified resampling (stratified_sample.cpp:15-26): source row, bisection inside it
+    const u32x4 blk = rng_step_block(key, (uint32_t)t, (uint32_t)j);
+    const uint32_t uword = rng_resample_word_rt(ncnt_step, key, (uint32_t)t, (uint32_t)j, blk);
+    const CanonSource src = canon_source_row(canon_target(uword, j, c_scale), j < N, cc.px, lane);
+    int anc = 0;
+    if (j < N) {
+      const int slen = min(CANON_ROW, N - src.e * CANON_ROW);
+      anc = src.e * CANON_ROW + min(canon_count_below(s_cdf + src.e * CANON_ROW, slen, src.vp), slen - 1);
+      if (b.indices) __builtin_nontemporal_store((uint32_t)anc, &b.indices[((size_t)f * n + t) * N + j]);
+    }
+    s_anc[j] = anc;
+    lds_barrier();  // (2) every search has read the scans; the ancestor table is visible
+
+    // ---- transition on the matrix cores: B fragments gathered from the component-major particle system
+    const double* __restrict__ mt = mats + (size_t)t * b.mats_tstride;
+    int ancs[4];
+#pragma unroll
+    for (int pb = 0; pb < 4; pb++) ancs[pb] = s_anc[row0 + 16 * pb + i16];
+    big_affine<MB>(acc, mt + MP * MP + MP * KP, mt, m, mt + MP * MP, ncnt_step,
+                   [&](int c, int pb) { return s_state[c * Ncap + ancs[pb]]; },
+                   [&](int kk, double (&z)[4]) { big_normals4(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, ncnt_step, kk, blk, z); }, s_tile, lane);
+    lds_barrier();  // (3) every gather has read the old particle system
+    big_store<MB, false>(acc, s_state, (size_t)Ncap, MP, row0, CANON_ROW, lane);
+    if (b.alpha_hist) big_store<MB, true>(acc, b.alpha_hist + ((size_t)f * (n + 1) + (t + 1)) * m * N, (size_t)N, m, row0, cnt_row, lane);
+    w = t + 1 < n ? big_log_weight<MB>(b, obs + (size_t)(t + 1) * obs_stride, acc, lane) : 0.0;
+    if (j >= N) w = -INFINITY;
+  }
+  if (tid == 0 && b.loglik) b.loglik[f] = loglik;
+}
+
+// largest N of the workgroup-resident shape: one wave per row, at most BIG_NT_MAX threads, the particle system in 160 KB of LDS
+inline int big_wg_capacity(int MP) {
+  for (int N = BIG_NT_MAX; N >= 64; N -= 64) {
+    const size_t lds = ((size_t)(MP + 1) * N + 16 + (size_t)(N / 64) * 256) * sizeof(double) + (size_t)N * sizeof(int);
+    if (lds <= 160 * 1024) return N;
+  }
+  return 0;
+}
+
+template <int MB>
+hipError_t launch_big_wg(const FilterBatch& b, hipStream_t stream) {
+  constexpr int MP = 16 * MB;
+  if (b.MP != MP || b.fpar || b.KP % 4 != 0 || b.KP < 4 || b.KP > MP || b.N > big_wg_capacity(MP)) return hipErrorInvalidValue;
+  const int nt = (b.N + 63) / 64 * 64;
+  const size_t lds = ((size_t)(MP + 1) * nt + 16 + (size_t)(nt / 64) * 256) * sizeof(double) + (size_t)nt * sizeof(int);
+  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_big_wg<%d>", MB); note_filter_kernel(nm); }
+  hipError_t e = hipFuncSetAttribute((const void*)pf_big_wg<MB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(pf_big_wg<MB>, dim3(b.F), dim3(nt), lds, stream, b);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// one wave per row, particle system in HBM, one launch per time step (the exchange of pf_row_step.h)
+// ------------------------------------------------------------------------------------------------------------------
+template <int MB>
+__global__ void __launch_bounds__(ROW_NT) pf_big_row_init(const FilterBatch b, const GridWorkspace ws) {
+  constexpr int MP = 16 * MB;
+  __shared__ double s_tiles[4 * 256];
+  math_tab_init();
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int f = ws.f0 + blockIdx.y, g = blockIdx.x * 4 + wave, N = b.N, n = b.n, m = b.m;
+  if (g >= ws.B) return;
+  const int j = g * CANON_ROW + lane, cnt_row = min(CANON_ROW, N - g * CANON_ROW);
+  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
+  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
+  const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
+  BigAcc<MB> acc;
+  const u32x4 blk0 = philox4x32_10((uint32_t)j, 0u, 0u, RNG_INIT, key.seed, key.stream);
+  big_affine<MB>(acc, ini, ini, 0, ini + MP, m, [](int, int) { return 0.0; },
+                 [&](int kk, double (&z)[4]) { big_normals4(key, RNG_INIT, 0u, (uint32_t)j, m, kk, blk0, z); }, s_tiles + wave * 256, lane);
+  double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + (size_t)f * (n + 1) * m * N : ws.state[0] + (size_t)f * m * N;
+  big_store<MB, false>(acc, st_new, (size_t)N, m, g * CANON_ROW, cnt_row, lane);
+  const double w = n > 0 ? big_log_weight<MB>(b, obs, acc, lane) : 0.0;
+  row_publish(b, ws, f, g, j, j < N, 0, w, lane);
+}
+
+template <int MB>
+__global__ void __launch_bounds__(ROW_NT) pf_big_row_step(const FilterBatch b, const GridWorkspace ws, const int t) {
+  constexpr int MP = 16 * MB;
+  __shared__ double s_win[4 * ROW_WIN];
+  __shared__ double s_comb[4 * 64 + 2 + 128];  // row prefixes (128), 1 / scale (128), M, S, scales (128)
+  __shared__ double s_tiles[4 * 256];
+  __shared__ int s_ancs[4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i16 = lane & 15;
+  const int f = ws.f0 + blockIdx.y, g = blockIdx.x * 4 + wave, B = ws.B, N = b.N, n = b.n, m = b.m, KP = b.KP, tn = t + 1;
+  const MathTabRegs mtab = math_tab_load_begin256();
+  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
+  const int j = g * CANON_ROW + lane;
+  const bool has_row = g < B, act = has_row && j < N;
+  const int ncnt_step = b.psi ? m : b.k;
+  const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
+  if (wave == 0) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
+    double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
+    if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
+    if (lane + 64 < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64)); pmaxb = pp.x; psumb = pp.y; }
+    const CanonComb<true> cc = canon_combine<true>(pmax, psum, pmaxb, psumb, B);
+    s_comb[lane] = cc.px.Qa; s_comb[64 + lane] = cc.px.Qb; s_comb[128 + lane] = cc.px.ia; s_comb[192 + lane] = cc.px.ib;
+    s_comb[258 + lane] = cc.sa; s_comb[258 + 64 + lane] = cc.sb;
+    if (lane == 0) { s_comb[256] = cc.M; s_comb[257] = cc.S; }
+  }
+  const u32x4 blk = rng_step_block(key, (uint32_t)t, (uint32_t)j);
+  const uint32_t uword = rng_resample_word_rt(ncnt_step, key, (uint32_t)t, (uint32_t)j, blk);
+  math_tab_load_end256(mtab);
+  lds_barrier();  // (1) the only workgroup barrier of the step
+  const CanonPrefix<true> px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[192 + lane], B};
+  const double M = s_comb[256], S = s_comb[257];
+  if (b.weights && act) {  // the stored weights of time t are exp(w - M_row): to the scale of the whole time point (also on a degenerate step, :676-682)
+    double* __restrict__ wt = b.weights + ((size_t)f * (n + 1) + t) * N;
+    wt[j] = wt[j] * s_comb[258 + g];
+  }
+  if (!(S > 0.0)) {
+    if (has_row && lane == 0) {
+      double* __restrict__ pn = ws.partials + (((size_t)(tn & 1) * b.F + f) * B + g) * 2;
+      pn[0] = __builtin_nan("");
+      pn[1] = __builtin_nan("");
+      if (g == 0) atomicCAS(&b.dead_at[f], 0, t + 1);
+    }
+    return;
+  }
+  if (!has_row) return;
+  const double c_scale = canon_stratum(S, N);
+  if (g == B - 1 && lane == 63) ws.llinc[(size_t)f * (n + 1) + t] = canon_llinc(M, c_scale);
+
+  const CanonSource src = canon_source_row<true>(canon_target(uword, j, c_scale), act, px, lane);
+  double* sw = s_win + wave * ROW_WIN;
+  int anc = 0;
+  for (int r0 = src.c_lo; r0 <= src.c_hi; r0 += 4) {  // wave-uniform bounds
+    const int nr = min(4, src.c_hi - r0 + 1);
+    double xr[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = (r0 + q) * CANON_ROW + lane;
+      xr[q] = (q < nr && k < N) ? lcdf[k] : 0.0;
+    }
+    lds_wave_sync();
+#pragma unroll
+    for (int q = 0; q < 4; q++) sw[q * CANON_ROW + lane] = xr[q];
+    lds_wave_sync();
+    if (act && src.e >= r0 && src.e < r0 + 4) {
+      const int slen = min(CANON_ROW, N - src.e * CANON_ROW);
+      anc = src.e * CANON_ROW + min(canon_count_below(sw + (src.e - r0) * CANON_ROW, slen, src.vp), slen - 1);
+    }
+  }
+  if (b.indices && act) __builtin_nontemporal_store((uint32_t)anc, &b.indices[((size_t)f * n + t) * N + j]);
+  int* sa = s_ancs + wave * 64;
+  sa[lane] = anc;
+  lds_wave_sync();
+  int ancs[4];
+#pragma unroll
+  for (int pb = 0; pb < 4; pb++) ancs[pb] = sa[16 * pb + i16];
+
+  const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N;
+  double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N;
+  const double* __restrict__ mt = b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride;
+  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
+  const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
+  BigAcc<MB> acc;
+  big_affine<MB>(acc, mt + MP * MP + MP * KP, mt, m, mt + MP * MP, ncnt_step,
+                 [&](int c, int pb) { return st_old[(size_t)c * N + ancs[pb]]; },
+                 [&](int kk, double (&z)[4]) { big_normals4(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, ncnt_step, kk, blk, z); },
+                 s_tiles + wave * 256, lane);
+  big_store<MB, false>(acc, st_new, (size_t)N, m, g * CANON_ROW, min(CANON_ROW, N - g * CANON_ROW), lane);
+  const double w = tn < n ? big_log_weight<MB>(b, obs + (size_t)tn * obs_stride, acc, lane) : 0.0;
+  row_publish(b, ws, f, g, j, act, tn, w, lane);
+}
+
+template <int MB>
+hipError_t launch_big_row(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
+  constexpr int MP = 16 * MB;
+  if (b.MP != MP || b.fpar || b.KP % 4 != 0 || b.KP < 4 || b.KP > MP) return hipErrorInvalidValue;
+  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_big_row_step<%d>", MB); note_filter_kernel(nm); }
+  return launch_row_loop(b, ws, stream, timing, pf_big_row_step<MB>, pf_big_row_init<MB>);
+}
+
+}  // namespace bssm

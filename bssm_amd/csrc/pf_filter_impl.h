@@ -1273,6 +1273,9 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
 }  // namespace bssm
 #include "pf_grid_v2.h"
 #include "pf_row_step.h"
+#ifndef BSSM_USER_MODEL
+#include "pf_big.h"
+#endif
 namespace bssm {
 
 template <int MP, int KP, int PPT, int FNV>

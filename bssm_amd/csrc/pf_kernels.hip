@@ -25,6 +25,7 @@ void note_filter_kernel(const char* name) { std::snprintf(g_last_kernel, sizeof 
 const char* last_filter_kernel() { return g_last_kernel; }
 
 int wg_filter_capacity(int MP) {
+  if (MP >= 32) return big_wg_capacity(MP);  // pf_big.h: one wave per row of 64 particles, at most 512 threads
   // 160 KiB LDS per CU: (MP + 1) doubles per particle + reduction slots; 512 threads x up to 16 particles
   // (8 for padded state dimensions above 2)
   const size_t avail = 160 * 1024 - (2 * CANON_MAX_ROWS + MP * MP * 2 + MP) * sizeof(double);
@@ -125,9 +126,9 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
 }
 
 bool row_filter_supported(const FilterBatch& b) {
-  if (b.weights || b.N > CANON_ROW * CANON_MAX_ROWS || b.N < 1) return false;
+  if (b.N > CANON_ROW * CANON_MAX_ROWS || b.N < 1) return false;
   if (b.fpar) return b.MP == b.KP && (b.user_slot > 0 ? b.MP <= 8 : b.MP <= 2);
-  return b.MP <= 4;
+  return b.MP <= 4 || b.MP >= 32;  // (eight- and sixteen-dimensional states: pf_wg_kernel's matrix-core transitions sum in another order)
 }
 size_t row_workspace_bytes(const FilterBatch& b) { return row_workspace_bytes_impl(b); }
 void row_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
@@ -956,6 +957,8 @@ hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream) {
     case 4: return launch_wg_mp<4>(b, stream);
     case 8: return launch_wg_mp<8>(b, stream);
     case 16: return launch_wg_mp<16>(b, stream);
+    case 32: return launch_wg_mp<32>(b, stream);
+    case 64: return launch_wg_mp<64>(b, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -968,6 +971,8 @@ hipError_t launch_grid_filter(const FilterBatch& b, const GridWorkspace& ws, hip
     case 4: return launch_grid_mp<4>(b, ws, stream, timing);
     case 8: return launch_grid_mp<8>(b, ws, stream, timing);
     case 16: return launch_grid_mp<16>(b, ws, stream, timing);
+    case 32: return launch_grid_mp<32>(b, ws, stream, timing);
+    case 64: return launch_grid_mp<64>(b, ws, stream, timing);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1014,7 +1019,7 @@ __device__ __forceinline__ double block_sum_256(double v, double* s_red) {
 __global__ void __launch_bounds__(256) summary_kernel(const double* __restrict__ hist, double* __restrict__ mean,
                                                       double* __restrict__ cov, int n1, int m, int N) {
   __shared__ double s_red[4];
-  __shared__ double s_mean[16];
+  __shared__ double s_mean[64];
   const int t = blockIdx.x, f = blockIdx.y;
   const double* __restrict__ h = hist + ((size_t)f * n1 + t) * m * N;
   for (int j = 0; j < m; j++) {
@@ -1036,7 +1041,7 @@ __global__ void __launch_bounds__(256) summary_kernel(const double* __restrict__
 
 hipError_t launch_summary(const double* hist, double* mean, double* cov, int F, int n1, int m, int N,
                           hipStream_t stream) {
-  if (m > 16) return hipErrorInvalidValue;
+  if (m > 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(summary_kernel, dim3(n1, F), dim3(256), 0, stream, hist, mean, cov, n1, m, N);
   return hipGetLastError();
 }
@@ -1199,7 +1204,7 @@ __global__ void __launch_bounds__(256) filter_summary_kernel(const double* __res
                                                              double* __restrict__ Pt, double* __restrict__ Ptt, int n,
                                                              int m, int N) {
   __shared__ double s_red[4];
-  __shared__ double s_at[16], s_att[16];
+  __shared__ double s_at[64], s_att[64];
   const int t = blockIdx.x, f = blockIdx.y, n1 = n + 1;
   const double* __restrict__ h = hist + ((size_t)f * n1 + t) * m * N;
   const double* __restrict__ w = weights + ((size_t)f * n1 + t) * N;
@@ -1245,7 +1250,7 @@ __global__ void __launch_bounds__(256) filter_summary_kernel(const double* __res
 
 hipError_t launch_filter_summary(const double* hist, const double* weights, double* at, double* att, double* Pt,
                                  double* Ptt, int F, int n, int m, int N, hipStream_t stream) {
-  if (m > 16) return hipErrorInvalidValue;
+  if (m > 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(filter_summary_kernel, dim3(n + 1, F), dim3(256), 0, stream, hist, weights, at, att, Pt, Ptt, n, m,
                      N);
   return hipGetLastError();

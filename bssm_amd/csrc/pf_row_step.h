@@ -11,7 +11,8 @@
 // Exchange between launches (GridWorkspace with chunk = 64, B = rows): `lcdf[2][F][N]` the row-local inclusive scans of
 // exp(w - M_row), `partials[2][F][B]` = (M_row, S_row); the kernel boundary is the grid-wide synchronisation.  A step has two
 // dependent global round trips behind the partials (the rows a wave draws from -- contiguous in `lcdf`, <= 4 per round -- and the
-// ancestor states), one workgroup barrier (math tables + the combine of wave 0), no coarse table, no weights output.
+// ancestor states), one workgroup barrier (math tables + the combine of wave 0), no coarse table; the weights output of time t is
+// written row-scaled by the launch that computes it and rescaled by the next one.
 #pragma once
 
 // analysis builds (-DBSSM_ROW_STAMPS, `make rowstamps`): shader-clock stamps of one wave (workgroup 3 of filter 0, wave 1) at the
@@ -32,9 +33,6 @@
 namespace bssm {
 
 constexpr int ROW_NT = 256;    // four rows per workgroup
-#ifndef ROW_PARTS
-#define ROW_PARTS 2     // launch sequences of a batch of 24 filters or more (profiles/r05_row_family_probe.txt)
-#endif
 constexpr int ROW_WIN = 256;   // entries of the exchange array a wave stages per search round (four source rows)
 
 // the filter variants this family carries: functor models of every sampler and the linear-state models without a matrix-core
@@ -48,6 +46,9 @@ __device__ __forceinline__ void row_publish(const FilterBatch& b, const GridWork
   const CanonRow rs = canon_row_stats(act ? w : -INFINITY);
   double* __restrict__ lcdf_new = ws.lcdf + ((size_t)(tn & 1) * b.F + f) * b.N;
   if (act) lcdf_new[j] = rs.sc;
+  // weights output: exp(w - M_row) now; launch tn multiplies by exp(M_row - M) once the maximum of the time point is known (the
+  // last time point has no launch of its own: its weights are ones and leave here as they are)
+  if (b.weights && act) b.weights[((size_t)f * (b.n + 1) + tn) * b.N + j] = rs.e;
   double* __restrict__ part = ws.partials + (((size_t)(tn & 1) * b.F + f) * ws.B + g) * 2;
   if (lane == 0) part[0] = rs.M;
   if (lane == 63) part[1] = rs.sc;
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   constexpr int ucnt = step_draw_count<KP, FN>();
   const int psi_mode = PM >= 0 ? PM : b.psi;
   __shared__ double s_win[4 * ROW_WIN];
-  __shared__ double s_comb[4 * 64 + 2];  // row prefixes (128), 1 / scale (128), M, S
+  __shared__ double s_comb[4 * 64 + 2 + 128];  // row prefixes (128), 1 / scale (128), M, S, scales (128)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int f = ws.f0 + blockIdx.y, g = blockIdx.x * 4 + wave, B = ws.B, N = b.N, n = b.n, m = b.m, tn = t + 1;
   ROW_STAMP(0);
@@ -119,6 +120,8 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
     s_comb[64 + lane] = cc.px.Qb;
     s_comb[128 + lane] = cc.px.ia;
     s_comb[192 + lane] = cc.px.ib;
+    s_comb[258 + lane] = cc.sa;
+    s_comb[258 + 64 + lane] = cc.sb;
     if (lane == 0) { s_comb[256] = cc.M; s_comb[257] = cc.S; }
   }
   const u32x4 blk = rng_step_block(key, (uint32_t)t, (uint32_t)j);
@@ -129,6 +132,10 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   ROW_STAMP(2);  // barrier wait
   const CanonPrefix<true> px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[192 + lane], B};
   const double M = s_comb[256], S = s_comb[257];
+  if (b.weights && act) {  // the stored weights of time t are exp(w - M_row): to the scale of the whole time point (also on a degenerate step, :676-682)
+    double* __restrict__ wt = b.weights + ((size_t)f * (n + 1) + t) * N;
+    wt[j] = wt[j] * s_comb[258 + g];
+  }
   if (!(S > 0.0)) {
     // degenerate weights (src/model_ssm_ung.cpp:678-682): stop and poison this row's slot of the next parity, so every later
     // launch sees a non-finite S too (no flag load on healthy steps); later output slots stay zero like the reference's
@@ -230,35 +237,19 @@ auto row_fn_kernels(int psi, void (**init)(const FilterBatch, const GridWorkspac
   return nullptr;
 }
 
-// the time loop: one launch per step; batches of at least 512 workgroups per step as TWO interleaved launch sequences over
-// the halves of their filters (the tail of one half's step runs under the body of the other's, as in launch_grid_mk)
-template <int MP, int KP>
-hipError_t launch_row_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
-  constexpr int kFn = fn_kernel_id<MP>();
-  if (b.fpar && kFn > 0 && b.fn_id != kFn) return hipErrorInvalidValue;
-  if (b.weights || b.N > CANON_ROW * CANON_MAX_ROWS || ws.chunk != CANON_ROW || ws.B != (b.N + CANON_ROW - 1) / CANON_ROW) return hipErrorInvalidValue;
-  void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
-  void (*kern_init)(const FilterBatch, const GridWorkspace) = nullptr;
-  if (b.fpar) {
-    if constexpr (MP == KP && MP <= FN_MP_MAX) kern = row_fn_kernels<MP, KP, kFn>(b.psi, &kern_init);
-  } else {
-#ifndef BSSM_USER_MODEL
-    if constexpr (row_step_shape<MP, FN_NONE>()) { kern = pf_row_step<MP, KP>; kern_init = pf_row_init<MP, KP>; }
-#endif
-  }
-  if (!kern || !kern_init) return hipErrorInvalidValue;
-#ifndef BSSM_USER_MODEL
-  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_row_step<%d,%d,%s>", MP, KP, b.fpar ? (kFn > 0 ? "model" : "any") : "false"); note_filter_kernel(nm); }
-#endif
+// the time loop of the row family: one launch per step
+inline hipError_t launch_row_loop(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing,
+                                  void (*kern)(const FilterBatch, const GridWorkspace, const int), void (*kern_init)(const FilterBatch, const GridWorkspace)) {
+  if (b.N > CANON_ROW * CANON_MAX_ROWS || ws.chunk != CANON_ROW || ws.B != (b.N + CANON_ROW - 1) / CANON_ROW) return hipErrorInvalidValue;
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
   const int wgs = (ws.B + 3) / 4;
-  // A step is a chain of dependent latencies, not work (a 19-filter launch: 6.7 us, of which the chip is busy a fraction), so a
-  // batch is stepped as several interleaved launch sequences over disjoint groups of its filters -- the library's side stream plus
-  // up to two more per host thread: the chains overlap
+  // A step is a chain of dependent latencies, not work (a 19-filter launch of the C5 shape: 6.7 us, during which the chip is busy a
+  // fraction of the time), so a batch is stepped as interleaved launch sequences over disjoint groups of its filters; more than
+  // two sequences measured no better (profiles/r05_row_family_probe.txt), BSSM_AMD_GRID_STREAMS = 1 ... 4 overrides
   constexpr int kMaxParts = 4;
-  int parts = b.F >= 8 ? (b.F >= 24 ? ROW_PARTS : 2) : 1;
+  int parts = b.F >= 8 ? 2 : 1;
   if (opt().grid_streams > 0) parts = opt().grid_streams;
   parts = std::max(1, std::min({parts, kMaxParts, b.F}));
   if (!ws.side) parts = 1;
@@ -295,6 +286,26 @@ hipError_t launch_row_mk(const FilterBatch& b, const GridWorkspace& ws, hipStrea
   if ((e = hipGetLastError()) != hipSuccess) return e;
   hipLaunchKernelGGL(loglik_finalize_kernel, dim3(b.F), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);
   return hipGetLastError();
+}
+
+template <int MP, int KP>
+hipError_t launch_row_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
+  constexpr int kFn = fn_kernel_id<MP>();
+  if (b.fpar && kFn > 0 && b.fn_id != kFn) return hipErrorInvalidValue;
+  void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
+  void (*kern_init)(const FilterBatch, const GridWorkspace) = nullptr;
+  if (b.fpar) {
+    if constexpr (MP == KP && MP <= FN_MP_MAX) kern = row_fn_kernels<MP, KP, kFn>(b.psi, &kern_init);
+  } else {
+#ifndef BSSM_USER_MODEL
+    if constexpr (row_step_shape<MP, FN_NONE>()) { kern = pf_row_step<MP, KP>; kern_init = pf_row_init<MP, KP>; }
+#endif
+  }
+  if (!kern || !kern_init) return hipErrorInvalidValue;
+#ifndef BSSM_USER_MODEL
+  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_row_step<%d,%d,%s>", MP, KP, b.fpar ? (kFn > 0 ? "model" : "any") : "false"); note_filter_kernel(nm); }
+#endif
+  return launch_row_loop(b, ws, stream, timing, kern, kern_init);
 }
 
 }  // namespace bssm

@@ -148,7 +148,7 @@ static void rng_normals_wide(const orc_rng *r, uint32_t purpose, uint32_t t, uin
 /* ------------------------------------------------------------------ */
 /* Small dense helpers (m <= ORC_MAXM)                                 */
 /* ------------------------------------------------------------------ */
-#define ORC_MAXM 16
+#define ORC_MAXM 64
 
 /* lower Cholesky of the sub-matrix selected by idx (count entries); arma::chol(.,"lower") */
 static int chol_lower_sub(const double *P, int m, const int *idx, int cnt, double *L /* m x m, zeroed */) {
@@ -1027,7 +1027,7 @@ int orc_is_correction(const orc_is_job *job, double *weights, double *loglik_out
 /* ================================================================== */
 /* ssm_mng: multivariate observations                                  */
 /* ================================================================== */
-#define ORC_MAXP 8
+#define ORC_MAXP 16
 #define MZ(t) (mod->Z + (size_t)mod->p * mod->m * ((t) * mod->Ztv))
 #define MD(t) (mod->D + (size_t)mod->p * ((t) * mod->Dtv))
 

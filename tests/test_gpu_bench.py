@@ -44,7 +44,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert sp["devices"] == [0, 0] and sp["identical_weights"] and sp["gather"] == "device_copies"
     # the strong-scaling evidence at the top level (round 4): both jobs, the communicator's facts, the one-GPU reference
     sc = out["post_correct_scaling"]
-    assert sc["scaling"] == "strong" and sc["n_gpus"] == 2 and sc["distinct_gpus"] == 1 and "r04_post_correct_n1.json" in sc["n1_source"]
+    assert sc["scaling"] == "strong" and sc["n_gpus"] == 2 and sc["distinct_gpus"] == 1 and "r05_post_correct_n1.json" in sc["n1_source"]
     for job in ("C5", "C5_x8_draws"):
         assert sc[job]["seconds"] > 0 and sc[job]["particle_steps_per_s"] > 0 and sc[job]["seconds_n1"] > 0
         assert abs(sc[job]["speedup_vs_n1"] - sc[job]["seconds_n1"] / sc[job]["seconds"]) < 1e-12
@@ -52,7 +52,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
 
 def test_bench_single_rank_line_has_the_contract_fields():
     out = _run_bench(["--steps", "1", "--warmup", "1", "--replicas", "4", "--T", "64", "--pc-draws", "96", "--no-cpu-baseline",
-                      "--no-dropin", "--no-mng", "--no-regime-b", "--no-single"])
+                      "--no-dropin", "--no-mng", "--no-regime-b", "--no-single", "--no-live-valu"])
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 0 and out["communicator"]["ranks"] == 1
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out
@@ -71,6 +71,14 @@ def test_bench_single_rank_line_has_the_contract_fields():
         assert out[key]["value"] > 0 and 0 < out[key]["frac"] < 1
     assert out["roofline_reference_layout"]["weights_layout_factored"] is False and out["other_series"]["series"] == "model"
     assert out["post_correct_scaling"]["n1_source"] == "this run" and out["post_correct_scaling"]["C5"]["speedup_vs_n1"] == 1.0
+    # the same batch under the contract's choices, inside `config` (round-4 review 6a)
+    assert 0 < out["config"]["reference_layout_frac"] < 1 and 0 < out["config"]["contract_series_frac"] < 1
+    # projected strong scaling: one rank's share of the job at 1 / 2 / 4 / 8 ranks, measured on this GPU (round-4 review 1c)
+    pj = out["post_correct_scaling"]["projected"]
+    assert pj["ranks"] == [1, 2, 4, 8] and "before the collective" in pj["what"]
+    for job, total in (("C5", 96), ("C5_x8_draws", 768)):
+        assert pj[job]["draws_per_rank"] == [-(-total // r) for r in pj["ranks"]]
+        assert len(pj[job]["shard_ms"]) == 4 and all(v > 0 for v in pj[job]["shard_ms"]) and pj[job]["speedup"][0] == 1.0
 
 
 def test_bench_accuracy_object_checks_every_pair_with_the_following_oracle():

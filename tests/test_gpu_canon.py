@@ -70,3 +70,17 @@ def test_degenerate_filter_stops_at_the_same_step_in_both_families(monkeypatch):
         warnings.simplefilter("ignore")
         wg, row = _both(monkeypatch, lambda: F.logLik_batch(model, 2048, 2, method="bsf", seed=1))
     assert np.all(wg == -np.inf) and np.all(row == -np.inf)
+
+
+@pytest.mark.parametrize("name,N", [("negbin_ar1", 4096), ("negbin_m4", 2000), ("poisson_slope_missing", 777), ("svm", 1500)])
+def test_full_outputs_same_bits_in_both_families(monkeypatch, name, N):
+    """bootstrap_filter / particle_smoother with every output: particle history, ancestor table, WEIGHTS (the row family writes them
+    row-scaled and rescales them one launch later) and summaries equal bit for bit"""
+    model = dict(small_zoo(), negbin_ar1=negbin_ar1(30, seed=3), negbin_m4=negbin_m4(30, seed=4))[name]
+    wg, row = _both(monkeypatch, lambda: F.bootstrap_filter(model, N, seed=13, return_indices=True))
+    for k in ("indices", "weights", "alpha", "at", "att", "Pt", "Ptt"):
+        assert np.array_equal(wg[k], row[k]), (name, k)
+    assert wg["logLik"] == row["logLik"]
+    wg, row = _both(monkeypatch, lambda: F.particle_smoother(model, N, method="psi", seed=14))
+    for k in ("alphahat", "Vt", "alpha"):
+        assert np.array_equal(wg[k], row[k]), (name, k)

@@ -28,7 +28,7 @@ def outputs(n, m, N):
 
 def call(arr, nsim=N, model_type=None, psi=False):
     s, keep = _lib.pack_model(arr)
-    n, m = max(int(arr["n"]), 1), max(min(int(arr["m"]), 16), 1)
+    n, m = max(int(arr["n"]), 1), max(min(int(arr["m"]), 64), 1)
     o, k2 = outputs(n, m, max(nsim, 1) if nsim < 100000 else 1)
     mt = model_type if model_type is not None else (0 if int(arr.get("p", 1)) != 1 else 1)
     if psi:
@@ -52,7 +52,7 @@ negP = np.array(base["P1"], dtype=float, copy=True); negP.flat[0] = -1.0
 nany = np.full_like(np.asarray(base["y"], dtype=float), np.nan)
 cases = {
     "n = 0": (mutated(base, n=0), {}), "n < 0": (mutated(base, n=-5), {}),
-    "m = 0": (mutated(base, m=0), {}), "m = 17": (mutated(base, m=17), {}), "m < 0": (mutated(base, m=-1), {}),
+    "m = 0": (mutated(base, m=0), {}), "m = 65": (mutated(base, m=65), {}), "m < 0": (mutated(base, m=-1), {}),
     "k = 0": (mutated(base, k=0), {}), "k > m": (mutated(base, k=9), {}),
     "distribution 99": (mutated(base, distribution=99), {}), "distribution -1": (mutated(base, distribution=-1), {}),
     "y NULL": (mutated(base, y=None), {}), "Z NULL": (mutated(base, Z=None), {}), "T NULL": (mutated(base, T=None), {}),
