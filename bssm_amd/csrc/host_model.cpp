@@ -934,7 +934,7 @@ bool gaussian_smoothing_setup(const HostModel& h, PsiSetup* out) {
 std::string mlg_smoothing_setup(const bssm_ung_model* s, PsiSetup* out) {
   if (!s) return "model is NULL";
   if (s->n < 1 || s->m < 1 || s->k < 1 || s->p < 1) return "n, m, k, p must be positive";
-  if (s->m > 16 || s->p > 8) return "ssm_mlg: m <= 16 and p <= 8 are supported";
+  if (s->m > 64 || s->p > 16) return "ssm_mlg: m <= 64 and p <= 16 are supported";
   if (!s->y || !s->Z || !s->T || !s->R || !s->a1 || !s->P1 || !s->H) return "y, Z, H, T, R, a1, P1 must be non-NULL";
   HostModel h;
   const int n = s->n, m = s->m, k = s->k, p = s->p;

@@ -145,3 +145,28 @@ def test_post_correction_of_a_seasonal_model(oracle):
     two = PC.post_correct(model, mo, 64, threads=4, is_type="is2", seed=5, devices=[0, 0])
     for key in ("weights", "alphahat", "Vt"):
         assert np.array_equal(one[key], two[key]), key
+
+
+@pytest.mark.parametrize("m,p,path,N", [(20, 12, "wg", 256), (20, 12, "row", 600), (4, 12, "wg", 512), (4, 12, "grid", 4096), (33, 16, "wg", 200)])
+def test_many_observation_series(oracle, monkeypatch, m, p, path, N):
+    """ssm_mng with 12 / 16 observation series of mixed distributions (the round-4 cap was p <= 8), on a 20- / 33-dimensional state
+    (pf_big.h: one signal per series from the D fragments) and on a four-dimensional one (the kernels of pf_filter_impl.h)"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    rng = np.random.default_rng(100 * m + p)
+    n = 10
+    T = 0.9 * np.linalg.qr(rng.normal(size=(m, m)))[0]
+    R = 0.2 * rng.normal(size=(m, 3))
+    Z = rng.normal(0, 0.3, (p, m))
+    dists = (["poisson", "negative binomial", "gaussian", "binomial", "gamma", "poisson"] * 3)[:p]
+    y = np.abs(rng.poisson(2, (n, p)).astype(float))
+    y[:, [i for i, d in enumerate(dists) if d == "gamma"]] += 0.5
+    bi = [i for i, d in enumerate(dists) if d == "binomial"]
+    y[:, bi] = np.minimum(y[:, bi], 3.0)
+    y[2, 1] = np.nan; y[5, :] = np.nan
+    model = M.ssm_mng(y, Z=Z, T=T, R=R, a1=np.zeros(m), P1=0.1 * np.eye(m), distribution=dists, phi=np.full(p, 2.0), u=np.full((n, p), 3.0))
+    out = F.bootstrap_filter(model, N, seed=4, return_indices=True)
+    ref = oracle.mng_bsf_filter(M.model_arrays(model), N, seed=4)
+    assert np.isfinite(ref["logLik"])
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert np.allclose(out["weights"], ref["weights"], rtol=1e-8, atol=1e-13)
