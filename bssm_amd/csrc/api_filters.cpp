@@ -164,7 +164,9 @@ int bssm_amd_device_count(void) {
   return cnt;
 }
 const char* bssm_amd_last_error(void) { return g_err.c_str(); }
-const char* bssm_amd_version(void) { return "bssm_amd 0.1 (gfx950)"; }
+// (stream format 2 = PACKED normals for draws of more than two, round 4; normalisation 2 = pf_canon.h rows for N <= 8192, round 5:
+// results for a given seed are not bit-reproducible across these numbers -- the parity bar against the reference is unaffected)
+const char* bssm_amd_version(void) { return "bssm_amd 0.5 (gfx950; random-stream format 2, normalisation 2)"; }
 void bssm_amd_trim_cache(void) { arena().trim(); stage_arena().trim(); }
 void bssm_amd_last_is_timing(double out[2]) { out[0] = g_is_timing[0]; out[1] = g_is_timing[1]; }
 void bssm_amd_last_is_timing4(double out[4]) { for (int q = 0; q < 4; q++) out[q] = g_is_timing4[q]; }
@@ -824,7 +826,7 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   }
   // the cache key covers everything that is compiled into the library: the kernel headers, the state dimension, the snippet
   std::string key = std::string(bssm_amd_version()) + "|" + std::to_string(n_states) + "|" + source;
-  for (const char* hdr : {"pf_filter_impl.h", "pf_grid_v2.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "pf_math_tables.h", "options.h", "tls_stream.h", "user_model_tu.hip"}) {
+  for (const char* hdr : {"pf_filter_impl.h", "pf_grid_v2.h", "pf_row_step.h", "pf_canon.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "pf_math_tables.h", "options.h", "tls_stream.h", "user_model_tu.hip"}) {
     FILE* hf = std::fopen((dir + "/csrc/" + hdr).c_str(), "rb");
     if (!hf) return fail(BSSM_ERR_INVALID, "kernel sources not found next to the library: " + dir + "/csrc/" + hdr);
     char buf[1 << 16];
@@ -886,10 +888,21 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
   // instead of ~27 s for the single unit
   const std::string common = hipcc + " -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I'" + dir + "/csrc' -DBSSM_USER_M=" + std::to_string(bssm::pad_dim(n_states)) +
                              " -DBSSM_USER_NSTATES=" + std::to_string(n_states) + " -DBSSM_USER_SNIPPET='\"" + snippet_tmp + "\"' ";
+  // (at most `jobs` compilers at a time: the host's hardware threads divided by the ranks of the node -- LOCAL_WORLD_SIZE of the
+  // launcher -- so that eight ranks building a model at once do not start 48 compilers; BSSM_AMD_USER_BUILD_JOBS overrides)
+  int jobs = 6;
+  {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const char* lws = std::getenv("LOCAL_WORLD_SIZE");
+    const int ranks = lws && std::atoi(lws) > 0 ? std::atoi(lws) : 1;
+    if (hw > 0) jobs = std::max(1, std::min(6, (int)hw / ranks));
+    if (const char* ej = std::getenv("BSSM_AMD_USER_BUILD_JOBS")) jobs = std::max(1, std::min(6, std::atoi(ej)));
+  }
   std::string cmd = "( ", objs, logs;
   for (int part = 0; part < 6; part++) {
     const std::string obj = tmp + ".p" + std::to_string(part) + ".o", plog = log_tmp + ".p" + std::to_string(part);
     cmd += common + "-DBSSM_USER_PART=" + std::to_string(part) + " -c '" + dir + "/csrc/user_model_tu.hip' -o '" + obj + "' > '" + plog + "' 2>&1 & ";
+    if ((part + 1) % jobs == 0 && part + 1 < 6) cmd += "wait ; ";
     objs += " '" + obj + "'";
     logs += " '" + plog + "'";
   }

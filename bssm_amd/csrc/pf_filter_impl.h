@@ -1401,46 +1401,11 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   }
   if (opt().xcd_remap >= 0) { for (int q = 0; q < kMaxParts; q++) wsp[q].xcd_remap = opt().xcd_remap; }
 #if !defined(BSSM_USER_MODEL) && defined(BSSM_XCD_PERSIST)
-  // ---- the XCD-resident persistent form (pf_grid_v2.h; experiment builds): ONE launch for the whole time loop of every filter of the batch.
-  // BSSM_AMD_XCD_PERSIST=1 asks for it wherever a kernel exists; it is left through the ordinary path below when the device did
-  // not complete every filter (an uneven dispatch left no complete team, or a wait timed out).
-  if (kern_persist && kern_init && opt().xcd_persist >= 1 && (!timing || timing->every <= 0) && ws.persist) {
-    int occ = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern_persist, GRID_NT, 0) == hipSuccess && occ > 0 &&
-        hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) {
-      const int per_xcd = prop.multiProcessorCount / 8 * occ;
-      const int teams_xcd_max = std::min(per_xcd / ws.B, kPersistMaxTeams);
-      if (teams_xcd_max >= 1) {
-        const int teams_xcd = std::min(teams_xcd_max, (b.F + 7) / 8);
-        const int total = 8 * teams_xcd * ws.B;
-        GridWorkspace w0 = wsp[0];
-        w0.f0 = 0;
-        const PersistCtl ctl{ws.persist, total, b.F, 0, 20000000ull /* 0.2 s of the 100 MHz wall clock per wait */, opt().xcd_persist_dbg};
-        if ((e = hipMemsetAsync(ws.persist, 0, sizeof(unsigned) * kPersistWords, stream)) != hipSuccess) return e;
-        // the descriptors the persistent kernel re-reads every step: device memory behind the control words
-        static_assert(sizeof(FilterBatch) % 8 == 0 && sizeof(GridWorkspace) % 8 == 0, "descriptors are copied and read as 64-bit words");
-        char* dparams = (char*)(ws.persist + kPersistWords);
-        if ((e = hipMemcpyAsync(dparams, &b, sizeof(FilterBatch), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(dparams + sizeof(FilterBatch), &w0, sizeof(GridWorkspace), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern_init, dim3(ws.B, b.F), block, 0, stream, b, w0);
-        hipLaunchKernelGGL(kern_persist, dim3(total), block, 0, stream, (const FilterBatch*)dparams, (const GridWorkspace*)(dparams + sizeof(FilterBatch)), ctl, ws.B, b.n);
-        unsigned tail[4] = {0, 0, 0, 0};
-        if ((e = hipMemcpyAsync(tail, ws.persist + PC_REGISTERED, sizeof tail, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        const bool complete = tail[PC_ERROR - PC_REGISTERED] == 0u && tail[PC_DONE - PC_REGISTERED] == (unsigned)b.F;
-        if (timing) { timing->concurrent = 1; timing->persistent = complete ? teams_xcd * 8 : -1; }
-        if (complete) {
-          { char nm[112]; std::snprintf(nm, sizeof nm, "pf_xcd_persist_v2<%d,%d,%d,%s,%s,%s>", MP, KP, ppt, v2ms ? "true" : "false", v2wx ? "true" : "false", v2exact ? "true" : "false"); note_filter_kernel(nm); }
-          hipLaunchKernelGGL(loglik_finalize_kernel, dim3(b.F), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);
-          return hipGetLastError();
-        }
-        // not every filter was completed: start over, one launch per step (the outputs are rewritten from t = -1)
-        if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
-        if (fw && (e = hipMemsetAsync(ws.wscale, 0, sizeof(double) * b.F * (b.n + 1) * ws.B, stream)) != hipSuccess) return e;
-      }
-    }
+  {  // experiment builds only (experiments/xcd_persist.h): ONE launch for the whole time loop of every filter of the batch
+    char pname[112];
+    std::snprintf(pname, sizeof pname, "pf_xcd_persist_v2<%d,%d,%d,%s,%s,%s>", MP, KP, ppt, v2ms ? "true" : "false", v2wx ? "true" : "false", v2exact ? "true" : "false");
+    hipError_t pe = hipSuccess;
+    if (xcd_persist_try(b, ws, wsp[0], stream, timing, kern_persist, kern_init, fw, pname, &pe)) return pe;
   }
 #endif
   if (timing) timing->concurrent = parts;

@@ -96,7 +96,9 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   bytes += al((size_t)2 * b.F * B * 2 * sizeof(double));      // partials
   bytes += al((size_t)2 * b.F * (b.n + 1) * sizeof(double));  // maxhist + llinc (contiguous)
   bytes += al((size_t)b.F * (b.n + 1) * B * sizeof(double));  // wscale (factored weights output)
+#ifdef BSSM_XCD_PERSIST
   bytes += al((size_t)kPersistWords * sizeof(unsigned) + sizeof(FilterBatch) + sizeof(GridWorkspace));  // control block + descriptors of the persistent kernel
+#endif
   return bytes;
 }
 
@@ -113,7 +115,11 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   ws->maxhist = (double*)p; ws->llinc = ws->maxhist + (size_t)b.F * (b.n + 1);
   p += al((size_t)2 * b.F * (b.n + 1) * sizeof(double));
   ws->wscale = (double*)p; p += al((size_t)b.F * (b.n + 1) * B * sizeof(double));
+#ifdef BSSM_XCD_PERSIST
   ws->persist = (unsigned*)p; p += al((size_t)kPersistWords * sizeof(unsigned) + sizeof(FilterBatch) + sizeof(GridWorkspace));
+#else
+  ws->persist = nullptr;  // (the control block of the round-4 persistent-kernel experiment: experiments/xcd_persist.h, `make persist` builds only)
+#endif
   ws->fw = 0;
   ws->logw = nullptr;
   ws->dbg = nullptr;
