@@ -420,6 +420,9 @@ struct DeviceBatch {
     fb.fpar_fstride = fp.size() > (size_t)bssm::FP_SIZE ? bssm::FP_SIZE : 0;
     fb.user_slot = (int)fp[bssm::FP_SLOT];  // run-time compiled user model: its library holds the kernels
     fb.fn_id = (int)fp[bssm::FP_ID];
+    // the step-kernel workspace was carved before the batch was known to be a functor model: its particles per lane follow the
+    // kernel family (pf_kernels.hip: grid_workspace_bytes brings a functor filter under the round-2 kernel's 128 particle blocks)
+    if (use_grid) return alloc_step_workspace();
     return BSSM_OK;
   }
 

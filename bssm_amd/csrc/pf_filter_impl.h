@@ -1356,12 +1356,30 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
     }
     if (!kern_init) { v2wx = v2exact = false; BSSM_PERSIST_PICK(nullptr); }
   }
+  // functor models (the shipped ssm_nlg / ssm_sde models: one or two states) on the round-2 step kernel (round 5)
+  bool v2fn = false;
+  if constexpr (MP == KP && MP <= 2) {
+    if (b.fpar && ws.B <= 128 && ppt <= 4 && !ws.dbg && opt().grid_v2 != 0) {
+      v2wx = b.weights != nullptr;
+      if (opt().grid_v2_wx >= 0) v2wx = v2wx && opt().grid_v2_wx != 0;
+      void (*ki)(const FilterBatch, const GridWorkspace) = nullptr;
+      void (*ks)(const FilterBatch, const GridWorkspace, const int) = nullptr;
+      switch (ppt) {
+        case 1: ks = v2_fn_kernels<MP, 1, kFn>(b.psi, v2wx, &ki); break;
+        case 2: ks = v2_fn_kernels<MP, 2, kFn>(b.psi, v2wx, &ki); break;
+        default: ks = v2_fn_kernels<MP, 4, kFn>(b.psi, v2wx, &ki); break;
+      }
+      if (ks && ki) { kern = ks; kern_init = ki; v2fn = true; v2exact = false; }
+      else v2wx = false;
+    }
+  }
 #endif
   if (!kern) return hipErrorInvalidValue;
 #ifndef BSSM_USER_MODEL
   {
     char nm[96];
-    if (kern_init) std::snprintf(nm, sizeof nm, "pf_grid_step_v2<%d,%d,%d,%s,%s,%s>", MP, KP, ppt, v2ms ? "true" : "false", v2wx ? "true" : "false", v2exact ? "true" : "false");
+    if (v2fn) std::snprintf(nm, sizeof nm, "pf_grid_step_v2_fn<%d,%d,%s,%s,%d>", MP, ppt, v2wx ? "true" : "false", kFn > 0 ? "model" : "any", b.psi);
+    else if (kern_init) std::snprintf(nm, sizeof nm, "pf_grid_step_v2<%d,%d,%d,%s,%s,%s>", MP, KP, ppt, v2ms ? "true" : "false", v2wx ? "true" : "false", v2exact ? "true" : "false");
     else std::snprintf(nm, sizeof nm, "pf_grid_step<%d,%d,%d,%s,%s>", MP, KP, ppt, "false", b.fpar ? "true" : "false");
     note_filter_kernel(nm);
   }

@@ -457,8 +457,10 @@ __device__ __forceinline__ void v2_block_of(const GridWorkspace& ws, int& pb, in
 }
 
 // t = -1: initial particles a1 + L u (src/model_ssm_ung.cpp:626; psi: alphahat_0 + V_0 u, :543) and their weights
-template <int MP, int PPT, bool MS = false>
+template <int MP, int PPT, bool MS = false, int FN = FN_NONE, int PM = -1>
 __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, const GridWorkspace ws) {
+  constexpr int FID = FN > 0 ? FN : 0;
+  const int psi_mode = PM >= 0 ? PM : b.psi;
   __shared__ double s_x[4 + 16 * PPT];
   int pb, f;
   v2_block_of(ws, pb, f);
@@ -476,25 +478,36 @@ __global__ void __launch_bounds__(GRID_NT) pf_grid_init_v2(const FilterBatch b, 
   for (int r = 0; r < PPT; r++) {
     const int li = v2_li<PPT>(r, tid);
     double z[MP], x[MP];
-    rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)(base + li), z);
-    initial_state<MP>(ini, z, x);
+    if constexpr (FN != FN_NONE) {  // functor models (ssm_nlg / ssm_sde): pf_functors.h
+      const double* __restrict__ fpar = b.fpar + (size_t)f * b.fpar_fstride;
+      if (!psi_mode) functor_initial<MP, FID>(fpar, b.init + (size_t)f * b.init_fstride, key, (uint32_t)(base + li), x);
+      else { rng_normals<MP, false>(key, RNG_INIT, 0, (uint32_t)(base + li), z); initial_state<MP>(ini, z, x); }
+      const double* __restrict__ amats = b.amats ? b.amats + (size_t)f * b.amats_fstride : nullptr;
+      w[r] = n > 0 ? weight_dispatch<MP, FN, PM>(b, fpar, b.obs + (size_t)f * b.obs_fstride, amats, 0, x, x) : 0.0;
+    } else {
+      rng_normals<MP>(key, RNG_INIT, 0, (uint32_t)(base + li), z);
+      initial_state<MP>(ini, z, x);
+    }
     if (li < len) {
 #pragma unroll
       for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + li] = x[c];
     }
-    if constexpr (MS) {
+    if constexpr (FN != FN_NONE) {
+    } else if constexpr (MS) {
 #pragma unroll
       for (int c = 0; c < MP; c++) xs[r][c] = x[c];
     } else {
       s[r] = v2_signal<MP>(row + ROW_HDR, x);
     }
   }
+  if constexpr (FN == FN_NONE) {
   if (observed) {
     if constexpr (MS) v2_log_weights_multi<MP, PPT>(b.p, row, b.psi != 0, xs, w);
     else v2_log_weights<PPT>(row, b.psi != 0, s, w);
   } else {
 #pragma unroll
     for (int r = 0; r < PPT; r++) w[r] = 0.0;
+  }
   }
 #pragma unroll
   for (int r = 0; r < PPT; r++) if (v2_li<PPT>(r, tid) >= len) w[r] = -INFINITY;
@@ -559,8 +572,13 @@ __device__ __forceinline__ void v2_window_ancestors(const double* sw, const doub
 // rows, windows, ancestor states) is read with sc1 loads -- the persistent kernel, where they were written in the SAME launch.
 // load_tables: the first step of a launch publishes the math tables through barrier (1).  Returns false when the filter has
 // degenerated at this step (every workgroup of the filter sees the same S and returns the same).
-template <int MP, int KP, int PPT, bool MS, bool WX, bool EXACT, bool COH>
+// FN / PM: a functor model (ssm_nlg / ssm_sde, pf_functors.h) and its sampler (0 bootstrap, 1 psi-APF, 2 EKF particle filter) -- round 5:
+// filters of more than 8192 particles (the row family's limit) no longer fall back to the round-1 step kernel
+template <int MP, int KP, int PPT, bool MS, bool WX, bool EXACT, bool COH, int FN = FN_NONE, int PM = -1>
 __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWorkspace& ws, const int t, const int pb, const int f, const bool load_tables) {
+  constexpr int FID = FN > 0 ? FN : 0;
+  constexpr bool kFn = FN != FN_NONE;
+  const int psi_mode = PM >= 0 ? PM : b.psi;
   #ifndef BSSM_V2_MFMA_PPT
 #define BSSM_V2_MFMA_PPT 4
 #endif
@@ -688,7 +706,7 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
     s_comb[64 + lane] = Q1;  // (B <= 64: the total in every lane)
     if (lane == 0) s_comb[384] = M0;
   }
-  if (tid < NMAT) s_mat[tid] = (b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride)[tid];
+  if (!kFn || psi_mode == 1) { if (tid < NMAT) s_mat[tid] = (b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride)[tid]; }  // (functor models: only the psi-APF proposal is linear)
   u32x4 blk[PPT];
 #pragma unroll
   for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + v2_li<PPT>(r, tid)));
@@ -743,7 +761,7 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
   // a PACKED step draw (more than two noise terms, pf_device.h) leaves no spare word in the step blocks: the uniforms of four
   // consecutive slots share one RNG_RESAMPLE block, which the lane that holds those slots for the search draws directly --
   // no transposition through LDS
-  constexpr bool kSharedU = KP > 2;
+  constexpr bool kSharedU = !kFn && KP > 2;  // (the functor filters keep WIDE blocks whatever their count: pf_device.h)
   if constexpr (PPT > 1 && !kSharedU) {
 #pragma unroll
     for (int r = 0; r < PPT; r++) sw_u32[r * 64 + lane] = blk[r].w;
@@ -938,7 +956,7 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
 #endif
   // kFuse (rows of several series at four particles per lane): a particle's log-weight is evaluated right behind its
   // transition, its state never outlives the iteration, and the ancestor rows are requested two at a time
-  constexpr bool kFuse = MS && PPT >= 4;
+  constexpr bool kFuse = (MS && PPT >= 4) || kFn;  // (functor weights need the ancestor next to the new state: pf_functors.h)
 #ifndef BSSM_V2_FUSE_ROLL
 #define BSSM_V2_FUSE_ROLL 2
 #endif
@@ -977,6 +995,9 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
   const cdbl* row = as_uniform_table(b.obs + (size_t)f * b.obs_fstride + (size_t)(have_obs ? tn : 0) * (ROW_HDR + (MS ? b.p : 1) * (SER_HDR + MP)));
   double s[PPT], w[PPT], xs[(MS && !kFuse) ? PPT : 1][MP];
   const bool weigh = have_obs && row[RH_FLAG] != 0.0;  // otherwise nothing is observed at t+1: the weights are ones
+  const double* __restrict__ fpar = kFn ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
+  const double* __restrict__ fn_ob = kFn ? b.obs + (size_t)f * b.obs_fstride + (size_t)(have_obs ? tn : 0) * (ROW_HDR + SER_HDR + MP) : nullptr;
+  const double* __restrict__ fn_amats = (kFn && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
 #pragma unroll
   for (int r = 0; r < PPT; r++) {
     const int li = v2_li<PPT>(r, tid), j = base + li;
@@ -994,15 +1015,28 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
           if constexpr (KP > 6) box_muller_packed(w2.z, w2.w, z[6], z[7 < KP ? 7 : 6]);
         }
       }
-    } else {
+    } else if constexpr (!kFn) {
       rng_normals_blk<KP>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
     }
-    if constexpr (kMfma) {
+    if constexpr (kFn) {
+      if (!psi_mode) functor_propagate<MP, KP, FID>(fpar, key, blk[r], (uint32_t)t, (uint32_t)j, a[r % ROLL], x);
+      else if (psi_mode == 2) functor_ekpf_propagate<MP, FID>(fpar, fn_ob, tn >= n, key, blk[r], (uint32_t)t, (uint32_t)j, a[r % ROLL], x);
+      else {
+        rng_normals_blk<KP, false>(blk[r], key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
+        int zero = 0;
+        __asm__ volatile("" : "+v"(zero));
+        propagate<MP, KP>((const double*)(s_mat + zero), a[r % ROLL], z, x);
+      }
+    } else if constexpr (kMfma) {
       propagate_mfma8_h<KP>((const double*)s_mat, a[r % ROLL], z, x, sw_base, lane);
     } else {
       int zero = 0;  // opaque: the matrix is re-read per particle instead of being kept live in 72 VGPRs
       __asm__ volatile("" : "+v"(zero));
       propagate<MP, KP>((const double*)(s_mat + zero), a[r % ROLL], z, x);
+    }
+    if constexpr (kFn) {  // (before the next row's gather overwrites the ancestor)
+      w[r] = have_obs ? weight_dispatch<MP, FN, PM>(b, fpar, fn_ob, psi_mode == 2 ? fn_amats : fn_amats + (size_t)t * fn_amat_row<MP>(), tn, x, a[r % ROLL]) : 0.0;
+      __asm__ volatile("" : "+v"(w[r]));
     }
     if (r + ROLL < PPT) {
       __builtin_amdgcn_sched_barrier(0);
@@ -1012,7 +1046,8 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
 #pragma unroll
       for (int c = 0; c < MP; c++) if (c < m) { if constexpr ((BSSM_V2_NT) & 4) st32_nt(st_new + (size_t)c * N, li, x[c]); else st32(st_new + (size_t)c * N, li, x[c]); }
     }
-    if constexpr (kFuse) {
+    if constexpr (kFn) {
+    } else if constexpr (kFuse) {
       w[r] = weigh ? v2_log_weight_multi_one<MP>(b.p, row, b.psi != 0, x) : 0.0;
       __asm__ volatile("" : "+v"(w[r]));
     } else if constexpr (MS) {
@@ -1051,6 +1086,21 @@ __global__ void __launch_bounds__(GRID_NT, v2_occupancy(MP, PPT, MS)) pf_grid_st
   int pb, f;
   v2_block_of(ws, pb, f);
   (void)v2_step_body<MP, KP, PPT, MS, WX, EXACT, false>(b, ws, t, pb, f, true);
+}
+// the same step for a functor model (ssm_nlg / ssm_sde; FN = its id or FN_ANY, PM = the sampler); tail guards always on
+constexpr int v2_fn_occupancy(int mp, int ppt) { return mp * ppt <= 2 ? 4 : (mp * ppt <= 4 ? 3 : 2); }
+template <int MP, int PPT, bool WX, int FN, int PM>
+__global__ void __launch_bounds__(GRID_NT, v2_fn_occupancy(MP, PPT)) pf_grid_step_v2_fn(const FilterBatch b, const GridWorkspace ws, const int t) {
+  int pb, f;
+  v2_block_of(ws, pb, f);
+  (void)v2_step_body<MP, MP, PPT, false, WX, false, false, FN, PM>(b, ws, t, pb, f, true);
+}
+template <int MP, int PPT, int FNV>
+auto v2_fn_kernels(int psi, bool wx, void (**init)(const FilterBatch, const GridWorkspace)) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
+  if (psi == 0) { *init = pf_grid_init_v2<MP, PPT, false, FNV, 0>; return wx ? pf_grid_step_v2_fn<MP, PPT, true, FNV, 0> : pf_grid_step_v2_fn<MP, PPT, false, FNV, 0>; }
+  if (psi == 1) { *init = pf_grid_init_v2<MP, PPT, false, FNV, 1>; return wx ? pf_grid_step_v2_fn<MP, PPT, true, FNV, 1> : pf_grid_step_v2_fn<MP, PPT, false, FNV, 1>; }
+  if (psi == 2) { *init = pf_grid_init_v2<MP, PPT, false, FNV, 2>; return wx ? pf_grid_step_v2_fn<MP, PPT, true, FNV, 2> : pf_grid_step_v2_fn<MP, PPT, false, FNV, 2>; }
+  return nullptr;
 }
 
 

@@ -79,6 +79,12 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
       else if (w1 >= 2048 && b.N >= 2 * GRID_NT) ppt = 2;
     }
   }
+  // functor models (the shipped ssm_nlg / ssm_sde models) on the round-2 step kernel: as many particles per lane as bring the filter
+  // under its 128 particle blocks (32 768 particles at one per lane, 131 072 at four)
+  if (b.fpar && b.MP <= 2 && b.user_slot == 0) {
+    const size_t b1 = (size_t)(b.N + GRID_NT - 1) / GRID_NT;
+    if (b1 > 128) ppt = (b1 + 1) / 2 <= 128 ? 2 : 4;
+  }
   // 8-dimensional states (round-2 multi-series kernel): two particles per lane once the batch fills the chip twice
   // (C4, 16 384 particles: 32 filters 1.92e10 -> 1.99e10, 64 filters 1.90e10 -> 2.19e10 particle-steps/s; 16 filters 1.58e10 -> 1.37e10)
   if (b.MP == 8 && !b.fpar && w1 >= 2048 && b.N >= 2 * GRID_NT) ppt = 2;

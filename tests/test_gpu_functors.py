@@ -1002,3 +1002,29 @@ def test_user_model_six_states_post_correct_psi_against_the_general_oracle(oracl
     assert np.allclose(out["weights"], w, rtol=1e-8)
     wc = w * counts
     assert np.allclose(out["alphahat"], (np.tensordot(ah, wc, axes=([2], [0])) / wc.sum()).T[:out["alphahat"].shape[0]], rtol=1e-7, atol=1e-9)
+
+
+# ---------------------------------------------------------------- functor models beyond the row family's 8192 particles: round-2 step kernel
+@pytest.mark.parametrize("name,N,method", [("nlg_growth", 20000, "bsf"), ("nlg_growth", 50000, "psi"), ("nlg_growth", 100000, "bsf"),
+                                           ("sde_poisson_ou", 40000, "bsf"), ("nlg_sin_exp", 100000, "psi"), ("nlg_growth", 30000, "ekf")])
+def test_functor_models_on_the_round2_step_kernel(oracle, name, N, method):
+    """ssm_nlg / ssm_sde filters larger than one workgroup ran the round-1 step kernel through round 4 (seven barriers, a search per
+    particle); since round 5 they take pf_grid_step_v2_fn (one search per wave, wave-local combine, weights exchange) at one, two
+    or four particles per lane: the reference's own study runs the growth model at N = 1e5 (vignettes/psi_pf_experiments/gm_truth.rds)"""
+    from bssm_amd.plan import FilterPlan
+    model, L = MODELS[name]
+    n = model.n
+    if method == "bsf":
+        out = F.bootstrap_filter(model, N, seed=12, return_indices=True, L=L)
+        ref = oracle.fn_bsf_filter({**model, "L": L or 0}, N, seed=12)
+    elif method == "psi":
+        out = F.particle_smoother(model, N, method="psi", seed=12, return_indices=True)
+        ref = oracle.fn_psi_filter(model, N, seed=12)
+    else:
+        out = F.ekpf_filter(model, N, seed=12, return_indices=True)
+        ref = oracle.fn_ekpf_filter(model, N, seed=12)
+    assert FilterPlan.last_kernel().startswith("pf_grid_step_v2_fn<"), FilterPlan.last_kernel()
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    if "weights" in out and method != "psi":
+        assert _rel(out["weights"], ref["weights"]) <= 1e-8
