@@ -22,6 +22,11 @@
  *  - Random numbers: counter-based Philox4x32-10 keyed by (seed, filter index); see
  *    DESIGN.md.  Same (model, nsim, seed) => bit-identical output on every call,
  *    for any number of GPUs (reference property: tests/testthat/test_bootstrap_filter.R:5-17).
+ *    ("Any number of GPUs" is verified on logical shards of ONE physical GPU and with two gloo ranks: no multi-GPU
+ *    node has been available to this build.)  Results for a given seed are not reproducible ACROSS library versions
+ *    whose bssm_amd_version() names another random-stream format or normalisation.
+ *  - Limits: state dimension m <= 64, observation series p <= 16, user-defined models <= 8 states; particles up to
+ *    524 288 for m <= 16 and up to 8192 for 17 <= m <= 64.  Beyond them the entry points refuse with a message.
  */
 #ifndef BSSM_AMD_H
 #define BSSM_AMD_H
@@ -317,10 +322,11 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
  * (`devices[r]`, HIP ordinals; NULL / 0 = every visible device) and runs the single-device driver, and the per-draw
  * weights / log-likelihoods are exchanged by ONE ncclAllGather (RCCL over xGMI, communicators from ncclCommInitAll,
  * librccl opened lazily with dlopen).  The same ordinal may be listed more than once (logical shards on one GPU; the
- * exchange is then plain device copies).  Streams are keyed by the global draw index and every draw runs in the same kernel
- * family however the job is cut, so the outputs are bit-identical to the single-device call for any device list (unless the
- * process opted into BSSM_AMD_TAIL_SPLIT=1, which sends a sparsely filled last round of a shard through the step kernels:
- * faster, equal to reduction-order rounding only).  `job->n_threads` host threads are divided between the shards.
+ * exchange is then plain device copies).  Streams are keyed by the global draw index and every kernel family that can run a
+ * draw evaluates the same arithmetic (csrc/pf_canon.h), so the outputs are bit-identical to the single-device call for any
+ * device list -- also when a sparsely filled last round of a shard goes through the row family (csrc/pf_row_step.h; default
+ * since round 5, BSSM_AMD_TAIL_SPLIT=0 keeps every draw workgroup-resident).  Verified on logical shards of one physical GPU
+ * (tests/test_gpu_postcorrect.py, tests/test_gpu_fullsize.py).  `job->n_threads` host threads are divided between the shards.
  * Arguments and outputs otherwise as bssm_is_correction / bssm_is_correction_nlg. */
 int bssm_is_correction_multi(const bssm_is_job* job, const int32_t* devices, int32_t n_devices, double* weights,
                              double* loglik, double* alpha, double* alphahat_i, double* Vt_i);
