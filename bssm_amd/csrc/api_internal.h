@@ -398,7 +398,7 @@ struct DeviceBatch {
   // kernels (pf_row_step.h; otherwise it is reached through the tail split of a post-correction chunk only), else the step kernels
   int alloc_step_workspace() {
     // (states of more than 16 dimensions -- pf_big.h -- have no other step shape than the row family: up to 8192 particles)
-    if (fb.MP >= 32 && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "nsim above 8192 is not supported for states of more than 16 dimensions");
+    if (fb.MP >= 32 && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "nsim above 16384 is not supported for states of more than 16 dimensions");
     if ((bssm::opt().force_path == 3 || fb.MP >= 32) && bssm::row_filter_supported(fb)) {
       HIP_TRY(ws.alloc(bssm::row_workspace_bytes(fb)));
       bssm::row_workspace_carve(fb, ws.p, &gws);

@@ -20,7 +20,7 @@
 // Everything that involves more than one particle is pf_canon.h, so the two shapes below give the same bits for a filter:
 //   pf_big_wg        one workgroup per filter, particle system in LDS, one wave per row of 64 particles (N <= 512 at MP = 32,
 //                    <= 256 at MP = 64), the whole time loop in one launch, 3 workgroup barriers per step;
-//   pf_big_row_step  one wave per row, particle system in HBM, one launch per time step (N <= 8192), the exchange of pf_row_step.h.
+//   pf_big_row_step  one wave per row, particle system in HBM, one launch per time step (N <= 16 384), the exchange of pf_row_step.h.
 // fp64 MFMA and fp64 VALU have the same peak on MI355X (78.6 TFLOP/s): the matrix cores buy the operand delivery (no m^2 scalar
 // operands per particle) and the registers (64 accumulators per lane at MP = 64 instead of three arrays of 64), not flops.
 #pragma once
@@ -40,13 +40,14 @@ __device__ __forceinline__ double big_xor_add(double x) {  // sum over the four 
 }
 
 // acc += A[:, 4 kk ... 4 kk + 3] . B chunk, every row block; Acol = first of the four columns (column-major, leading dimension MP)
-template <int MB>
+// (LD: leading dimension of the tables = the padded state dimension of the batch; LD < 16 MB -- an eight-dimensional state in one
+// 16-row block, the C4 experiment -- leaves the rows beyond LD zero)
+template <int MB, int LD>
 __device__ __forceinline__ void big_chunk(BigAcc<MB>& acc, const double* __restrict__ Acol, const double (&bf)[4], const int lane) {
-  constexpr int MP = 16 * MB;
   const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int rb = 0; rb < MB; rb++) {
-    const double afr = Acol[16 * rb + i + MP * kq];
+    const double afr = (LD == 16 * MB || 16 * rb + i < LD) ? Acol[(LD == 16 * MB ? 16 * rb + i : min(16 * rb + i, LD - 1)) + LD * kq] : 0.0;
 #pragma unroll
     for (int pb = 0; pb < 4; pb++) acc.v[rb][pb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr, bf[pb], acc.v[rb][pb], 0, 0, 0);
   }
@@ -59,15 +60,16 @@ __device__ __forceinline__ void big_chunk(BigAcc<MB>& acc, const double* __restr
 //   state_at(c, pb)              component c of the ancestor of particle 16 pb + (lane & 15); rows >= ms are never asked for
 //   noise4(kk, z)                normals 4 kk ... 4 kk + 3 of THIS lane's particle (lane = particle inside the wave's row)
 //   tile                         4 x 64 doubles of LDS, this wave's
-template <int MB, class StateAt, class Noise4>
+template <int MB, int LD, class StateAt, class Noise4>
 __device__ __forceinline__ void big_affine(BigAcc<MB>& acc, const double* __restrict__ c0, const double* __restrict__ A1, const int ms,
                                            const double* __restrict__ A2, const int ncnt, StateAt&& state_at, Noise4&& noise4,
                                            double* tile, const int lane) {
-  constexpr int MP = 16 * MB;
+  constexpr int MP = LD;
   const int i = lane & 15, kq = lane >> 4;
+  auto c_at = [&](int r) { return (LD == 16 * MB || r < LD) ? c0[LD == 16 * MB ? r : min(r, LD - 1)] : 0.0; };
 #pragma unroll
   for (int rb = 0; rb < MB; rb++) {
-    const big_d4 cv{c0[16 * rb + kq], c0[16 * rb + kq + 4], c0[16 * rb + kq + 8], c0[16 * rb + kq + 12]};
+    const big_d4 cv{c_at(16 * rb + kq), c_at(16 * rb + kq + 4), c_at(16 * rb + kq + 8), c_at(16 * rb + kq + 12)};
 #pragma unroll
     for (int pb = 0; pb < 4; pb++) acc.v[rb][pb] = cv;
   }
@@ -76,7 +78,7 @@ __device__ __forceinline__ void big_affine(BigAcc<MB>& acc, const double* __rest
     double bf[4];
 #pragma unroll
     for (int pb = 0; pb < 4; pb++) bf[pb] = c < ms ? state_at(c, pb) : 0.0;
-    big_chunk<MB>(acc, A1 + (size_t)MP * 4 * kk, bf, lane);
+    big_chunk<MB, LD>(acc, A1 + (size_t)MP * 4 * kk, bf, lane);
   }
   for (int kk = 0; 4 * kk < ncnt; kk++) {
     double z[4];
@@ -88,7 +90,7 @@ __device__ __forceinline__ void big_affine(BigAcc<MB>& acc, const double* __rest
     double bf[4];
 #pragma unroll
     for (int pb = 0; pb < 4; pb++) bf[pb] = tile[kq * 64 + 16 * pb + i];
-    big_chunk<MB>(acc, A2 + (size_t)MP * 4 * kk, bf, lane);
+    big_chunk<MB, LD>(acc, A2 + (size_t)MP * 4 * kk, bf, lane);
   }
 }
 
@@ -105,9 +107,9 @@ __device__ __forceinline__ void big_normals4(const RngKey key, const uint32_t pu
 
 // log-weight of this lane's particle (lane = particle inside the row) from the D fragments: the signals D_j + Z_j x' of the row's
 // p series (src/model_ssm_ung.cpp:447-493, :385-439; src/model_ssm_mng.cpp:357-442), then the densities as log_weight_of
-template <int MB>
+template <int MB, int LD>
 __device__ __forceinline__ double big_log_weight(const FilterBatch& b, const double* __restrict__ row, const BigAcc<MB>& acc, const int lane) {
-  constexpr int MP = 16 * MB;
+  constexpr int MP = LD;
   if (row[RH_FLAG] == 0.0) return 0.0;  // nothing observed at t: weights are ones (src/model_ssm_ung.cpp:644-647)
   const int kq = lane >> 4;
   double w = 0.0;
@@ -121,7 +123,7 @@ __device__ __forceinline__ double big_log_weight(const FilterBatch& b, const dou
 #pragma unroll
       for (int rb = 0; rb < MB; rb++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) part = __builtin_fma(ob[SER_HDR + 16 * rb + kq + 4 * q], acc.v[rb][pb][q], part);
+        for (int q = 0; q < 4; q++) { if (LD == 16 * MB || 16 * rb + kq + 4 * q < LD) part = __builtin_fma(ob[SER_HDR + (LD == 16 * MB ? 16 * rb + kq + 4 * q : min(16 * rb + kq + 4 * q, LD - 1))], acc.v[rb][pb][q], part); }
       const double s = big_xor_add(part);
       own = kq == pb ? s : own;  // this lane's particle is 16 kq + i
     }
@@ -187,11 +189,11 @@ __global__ void __launch_bounds__(BIG_NT_MAX, 1) pf_big_wg(const FilterBatch b) 
   // ---- initial particles a1 + L u (src/model_ssm_ung.cpp:626; psi: alphahat_0 + V_0 u, :543) and their weights
   {
     const u32x4 blk0 = philox4x32_10((uint32_t)j, 0u, 0u, RNG_INIT, key.seed, key.stream);
-    big_affine<MB>(acc, ini, ini, 0, ini + MP, m, [](int, int) { return 0.0; },
+    big_affine<MB, MP>(acc, ini, ini, 0, ini + MP, m, [](int, int) { return 0.0; },
                    [&](int kk, double (&z)[4]) { big_normals4(key, RNG_INIT, 0u, (uint32_t)j, m, kk, blk0, z); }, s_tile, lane);
     big_store<MB, false>(acc, s_state, (size_t)Ncap, MP, row0, CANON_ROW, lane);
     if (b.alpha_hist) big_store<MB, true>(acc, b.alpha_hist + (size_t)f * (n + 1) * m * N, (size_t)N, m, row0, cnt_row, lane);
-    w = n > 0 ? big_log_weight<MB>(b, obs, acc, lane) : 0.0;
+    w = n > 0 ? big_log_weight<MB, MP>(b, obs, acc, lane) : 0.0;
     if (j >= N) w = -INFINITY;
   }
 
@@ -202,7 +204,8 @@ __global__ void __launch_bounds__(BIG_NT_MAX, 1) pf_big_wg(const FilterBatch b) 
     if (lane == 63) s_tot[wave] = rs.sc;
     if (lane == 0) s_max[wave] = rs.M;
     lds_barrier();  // (1)
-    const CanonComb<false> cc = canon_combine<false>(lane < B ? s_max[lane] : -INFINITY, lane < B ? s_tot[lane] : 0.0, -INFINITY, 0.0, B);
+    const double pmx[1] = {lane < B ? s_max[lane] : -INFINITY}, psm[1] = {lane < B ? s_tot[lane] : 0.0};
+    const CanonComb<1> cc = canon_combine<1>(pmx, psm, B);
     if (b.weights && j < N) b.weights[((size_t)f * (n + 1) + t) * N + j] = rs.e * canon_row_scale(cc, wave);
     if (!(cc.S > 0.0)) {  // :678-682 (uniform across the block)
       loglik = -INFINITY;
@@ -231,13 +234,13 @@ __global__ void __launch_bounds__(BIG_NT_MAX, 1) pf_big_wg(const FilterBatch b) 
     int ancs[4];
 #pragma unroll
     for (int pb = 0; pb < 4; pb++) ancs[pb] = s_anc[row0 + 16 * pb + i16];
-    big_affine<MB>(acc, mt + MP * MP + MP * KP, mt, m, mt + MP * MP, ncnt_step,
+    big_affine<MB, MP>(acc, mt + MP * MP + MP * KP, mt, m, mt + MP * MP, ncnt_step,
                    [&](int c, int pb) { return s_state[c * Ncap + ancs[pb]]; },
                    [&](int kk, double (&z)[4]) { big_normals4(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, ncnt_step, kk, blk, z); }, s_tile, lane);
     lds_barrier();  // (3) every gather has read the old particle system
     big_store<MB, false>(acc, s_state, (size_t)Ncap, MP, row0, CANON_ROW, lane);
     if (b.alpha_hist) big_store<MB, true>(acc, b.alpha_hist + ((size_t)f * (n + 1) + (t + 1)) * m * N, (size_t)N, m, row0, cnt_row, lane);
-    w = t + 1 < n ? big_log_weight<MB>(b, obs + (size_t)(t + 1) * obs_stride, acc, lane) : 0.0;
+    w = t + 1 < n ? big_log_weight<MB, MP>(b, obs + (size_t)(t + 1) * obs_stride, acc, lane) : 0.0;
     if (j >= N) w = -INFINITY;
   }
   if (tid == 0 && b.loglik) b.loglik[f] = loglik;
@@ -269,9 +272,9 @@ hipError_t launch_big_wg(const FilterBatch& b, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------------------------
 // one wave per row, particle system in HBM, one launch per time step (the exchange of pf_row_step.h)
 // ------------------------------------------------------------------------------------------------------------------
-template <int MB>
+template <int MB, int LD = 16 * MB>
 __global__ void __launch_bounds__(ROW_NT) pf_big_row_init(const FilterBatch b, const GridWorkspace ws) {
-  constexpr int MP = 16 * MB;
+  constexpr int MP = LD;
   __shared__ double s_tiles[4 * 256];
   math_tab_init();
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,19 +286,19 @@ __global__ void __launch_bounds__(ROW_NT) pf_big_row_init(const FilterBatch b, c
   const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
   BigAcc<MB> acc;
   const u32x4 blk0 = philox4x32_10((uint32_t)j, 0u, 0u, RNG_INIT, key.seed, key.stream);
-  big_affine<MB>(acc, ini, ini, 0, ini + MP, m, [](int, int) { return 0.0; },
+  big_affine<MB, LD>(acc, ini, ini, 0, ini + MP, m, [](int, int) { return 0.0; },
                  [&](int kk, double (&z)[4]) { big_normals4(key, RNG_INIT, 0u, (uint32_t)j, m, kk, blk0, z); }, s_tiles + wave * 256, lane);
   double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + (size_t)f * (n + 1) * m * N : ws.state[0] + (size_t)f * m * N;
   big_store<MB, false>(acc, st_new, (size_t)N, m, g * CANON_ROW, cnt_row, lane);
-  const double w = n > 0 ? big_log_weight<MB>(b, obs, acc, lane) : 0.0;
+  const double w = n > 0 ? big_log_weight<MB, LD>(b, obs, acc, lane) : 0.0;
   row_publish(b, ws, f, g, j, j < N, 0, w, lane);
 }
 
-template <int MB>
+template <int MB, int LD = 16 * MB>
 __global__ void __launch_bounds__(ROW_NT) pf_big_row_step(const FilterBatch b, const GridWorkspace ws, const int t) {
-  constexpr int MP = 16 * MB;
+  constexpr int MP = LD;
   __shared__ double s_win[4 * ROW_WIN];
-  __shared__ double s_comb[4 * 64 + 2 + 128];  // row prefixes (128), 1 / scale (128), M, S, scales (128)
+  __shared__ double s_comb[3 * ROW_NP * 64 + 2];  // the combine of wave 0 (pf_canon.h: canon_publish)
   __shared__ double s_tiles[4 * 256];
   __shared__ int s_ancs[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i16 = lane & 15;
@@ -306,26 +309,16 @@ __global__ void __launch_bounds__(ROW_NT) pf_big_row_step(const FilterBatch b, c
   const bool has_row = g < B, act = has_row && j < N;
   const int ncnt_step = b.psi ? m : b.k;
   const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
-  if (wave == 0) {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
-    double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
-    if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
-    if (lane + 64 < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64)); pmaxb = pp.x; psumb = pp.y; }
-    const CanonComb<true> cc = canon_combine<true>(pmax, psum, pmaxb, psumb, B);
-    s_comb[lane] = cc.px.Qa; s_comb[64 + lane] = cc.px.Qb; s_comb[128 + lane] = cc.px.ia; s_comb[192 + lane] = cc.px.ib;
-    s_comb[258 + lane] = cc.sa; s_comb[258 + 64 + lane] = cc.sb;
-    if (lane == 0) { s_comb[256] = cc.M; s_comb[257] = cc.S; }
-  }
+  if (wave == 0) row_combine_publish(ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2, B, s_comb, lane);
   const u32x4 blk = rng_step_block(key, (uint32_t)t, (uint32_t)j);
   const uint32_t uword = rng_resample_word_rt(ncnt_step, key, (uint32_t)t, (uint32_t)j, blk);
   math_tab_load_end256(mtab);
   lds_barrier();  // (1) the only workgroup barrier of the step
-  const CanonPrefix<true> px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[192 + lane], B};
-  const double M = s_comb[256], S = s_comb[257];
+  const CanonPrefix<ROW_NP> px = canon_prefix_load<ROW_NP>(s_comb, lane, B);
+  const double M = canon_published_M<ROW_NP>(s_comb), S = canon_published_S<ROW_NP>(s_comb);
   if (b.weights && act) {  // the stored weights of time t are exp(w - M_row): to the scale of the whole time point (also on a degenerate step, :676-682)
     double* __restrict__ wt = b.weights + ((size_t)f * (n + 1) + t) * N;
-    wt[j] = wt[j] * s_comb[258 + g];
+    wt[j] = wt[j] * canon_published_scale<ROW_NP>(s_comb, g);
   }
   if (!(S > 0.0)) {
     if (has_row && lane == 0) {
@@ -340,7 +333,7 @@ __global__ void __launch_bounds__(ROW_NT) pf_big_row_step(const FilterBatch b, c
   const double c_scale = canon_stratum(S, N);
   if (g == B - 1 && lane == 63) ws.llinc[(size_t)f * (n + 1) + t] = canon_llinc(M, c_scale);
 
-  const CanonSource src = canon_source_row<true>(canon_target(uword, j, c_scale), act, px, lane);
+  const CanonSource src = canon_source_row(canon_target(uword, j, c_scale), act, px, lane);
   double* sw = s_win + wave * ROW_WIN;
   int anc = 0;
   for (int r0 = src.c_lo; r0 <= src.c_hi; r0 += 4) {  // wave-uniform bounds
@@ -374,21 +367,21 @@ __global__ void __launch_bounds__(ROW_NT) pf_big_row_step(const FilterBatch b, c
   const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
   const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
   BigAcc<MB> acc;
-  big_affine<MB>(acc, mt + MP * MP + MP * KP, mt, m, mt + MP * MP, ncnt_step,
+  big_affine<MB, LD>(acc, mt + MP * MP + MP * KP, mt, m, mt + MP * MP, ncnt_step,
                  [&](int c, int pb) { return st_old[(size_t)c * N + ancs[pb]]; },
                  [&](int kk, double (&z)[4]) { big_normals4(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, ncnt_step, kk, blk, z); },
                  s_tiles + wave * 256, lane);
   big_store<MB, false>(acc, st_new, (size_t)N, m, g * CANON_ROW, min(CANON_ROW, N - g * CANON_ROW), lane);
-  const double w = tn < n ? big_log_weight<MB>(b, obs + (size_t)tn * obs_stride, acc, lane) : 0.0;
+  const double w = tn < n ? big_log_weight<MB, LD>(b, obs + (size_t)tn * obs_stride, acc, lane) : 0.0;
   row_publish(b, ws, f, g, j, act, tn, w, lane);
 }
 
-template <int MB>
+template <int MB, int LD = 16 * MB>
 hipError_t launch_big_row(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
-  constexpr int MP = 16 * MB;
+  constexpr int MP = LD;
   if (b.MP != MP || b.fpar || b.KP % 4 != 0 || b.KP < 4 || b.KP > MP) return hipErrorInvalidValue;
-  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_big_row_step<%d>", MB); note_filter_kernel(nm); }
-  return launch_row_loop(b, ws, stream, timing, pf_big_row_step<MB>, pf_big_row_init<MB>);
+  { char nm[96]; if (LD == 16 * MB) std::snprintf(nm, sizeof nm, "pf_big_row_step<%d>", MB); else std::snprintf(nm, sizeof nm, "pf_big_row_step<%d,%d>", MB, LD); note_filter_kernel(nm); }
+  return launch_row_loop(b, ws, stream, timing, pf_big_row_step<MB, LD>, pf_big_row_init<MB, LD>);
 }
 
 }  // namespace bssm

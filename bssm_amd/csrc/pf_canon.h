@@ -10,7 +10,7 @@
 //     M_g  = max_i w_i                                 (exact: the largest weight of a time point is exp(0) = 1)
 //     e_i  = tl_exp(w_i - M_g)                         (a row without mass: M_g = -inf, e = 0)
 //     sc_i = inclusive scan of e over the row, fixed DPP shape (wave_scan_incl);  S_g = sc_63
-//   filter (at most 128 rows, lane l of a wave holds rows l and 64 + l):
+//   filter (lane l of a wave holds rows l, 64 + l, ...: up to 128 rows in the workgroup kernels, 256 in the row family):
 //     M    = max_g M_g;  scale_g = fast_exp(M_g - M);  Q_g = inclusive scan of S_g scale_g (fixed shape: two wave scans)
 //     S    = Q_last;  log-likelihood increment M + tl_log(S / N)           (src/model_ssm_ung.cpp:675-683)
 //     weights_i = e_i scale_g                                               (exp(w_i - M), :676)
@@ -27,27 +27,35 @@
 namespace bssm {
 
 constexpr int CANON_ROW = 64;        // particles per row block
-constexpr int CANON_MAX_ROWS = 128;  // rows per filter: two per lane of a wave
+constexpr int CANON_MAX_ROWS = 128;  // rows of a workgroup-resident filter (8192 particles): two prefix slots per lane
+constexpr int ROW_NP = 4;            // prefix slots per lane of the row family: filters of up to 256 rows (16 384 particles)
+constexpr int ROW_MAX_ROWS = 64 * ROW_NP;
 
-// Row prefixes of a filter as the lanes of a wave hold them: lane l has the inclusive, scaled prefix (and 1 / scale) of row l
-// and, for filters of more than 64 rows (TWO), of row 64 + l.  TWO is a property of the KERNEL (its capacity); the values of
-// the rows a filter has are the same either way.
-template <bool TWO>
+// Row prefixes of a filter as the lanes of a wave hold them: lane l has the inclusive, scaled prefix (and 1 / scale) of rows
+// l, 64 + l, ... 64 (NP - 1) + l.  NP (1, 2 or 4 slots per lane: filters of up to 64, 128, 256 rows) is a property of the KERNEL,
+// its capacity; the values of the rows a filter has are the same for every NP that holds them.
+template <int NP>
 struct CanonPrefix {
-  double Qa, Qb, ia, ib;  // (Qb, ib unused without TWO)
+  double Q[NP], I[NP];
   int B;
   __device__ __forceinline__ int count_below(const double v, const int lane) const {  // number of row prefixes below v
-    int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Qa < v));
-    if constexpr (TWO) { if (B > 64) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane + 64 < B && Qb < v)); }  // wave-uniform
+    int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Q[0] < v));
+#pragma unroll
+    for (int k = 1; k < NP; k++)
+      if (B > 64 * k) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane + 64 * k < B && Q[k] < v));  // wave-uniform
     return c;
   }
   __device__ __forceinline__ double q(const int e) const {  // e wave-uniform
-    if constexpr (TWO) return e < 64 ? lane_broadcast(Qa, e) : lane_broadcast(Qb, e - 64);
-    else return lane_broadcast(Qa, e);
+    double r = lane_broadcast(Q[0], e & 63);
+#pragma unroll
+    for (int k = 1; k < NP; k++) { const double rk = lane_broadcast(Q[k], e & 63); r = (e >> 6) == k ? rk : r; }
+    return r;
   }
   __device__ __forceinline__ double is(const int e) const {
-    if constexpr (TWO) return e < 64 ? lane_broadcast(ia, e) : lane_broadcast(ib, e - 64);
-    else return lane_broadcast(ia, e);
+    double r = lane_broadcast(I[0], e & 63);
+#pragma unroll
+    for (int k = 1; k < NP; k++) { const double rk = lane_broadcast(I[k], e & 63); r = (e >> 6) == k ? rk : r; }
+    return r;
   }
 };
 
@@ -66,37 +74,69 @@ __device__ __forceinline__ CanonRow canon_row_stats(const double w) {
   return CanonRow{e, sc, M};
 }
 
-// combine of the (M_g, S_g) partials; lane l passes rows l (pmax, psum) and 64 + l (pmaxb, psumb), identities (-inf, 0)
-// beyond the filter's B rows.  Every lane returns the same M and S.
-template <bool TWO>
+// combine of the (M_g, S_g) partials; lane l passes rows l, 64 + l, ... in pmax[k], psum[k], identities (-inf, 0) beyond the
+// filter's B rows.  Every lane returns the same M and S.
+template <int NP>
 struct CanonComb {
-  CanonPrefix<TWO> px;
-  double sa, sb;  // scale of rows l and 64 + l
+  CanonPrefix<NP> px;
+  double sc[NP];  // scale exp(M_g - M) of rows 64 k + l
   double M, S;
 };
-template <bool TWO>
-__device__ __forceinline__ CanonComb<TWO> canon_combine(const double pmax, const double psum, const double pmaxb, const double psumb, const int B) {
-  CanonComb<TWO> c;
-  c.M = TWO ? wave_max_key(fmax(pmax, pmaxb)) : wave_max_key(pmax);
-  c.sa = fast_exp(pmax - c.M);  // rows beyond B: 0; a poisoned (NaN) partial makes S NaN
-  const double Q0 = wave_scan_incl(canon_opaque(psum * c.sa));
-  double Q1 = lane_broadcast(Q0, 63);
-  c.sb = 0.0;
-  if constexpr (TWO) {
-    if (B > 64) {  // wave-uniform
-      c.sb = fast_exp(pmaxb - c.M);
-      Q1 = Q1 + wave_scan_incl(canon_opaque(psumb * c.sb));
+template <int NP>
+__device__ __forceinline__ CanonComb<NP> canon_combine(const double (&pmax)[NP], const double (&psum)[NP], const int B) {
+  CanonComb<NP> c;
+  double mx = pmax[0];
+#pragma unroll
+  for (int k = 1; k < NP; k++) mx = fmax(mx, pmax[k]);
+  c.M = wave_max_key(mx);
+  c.px.B = B;
+  double run = 0.0;  // total of the slots in front (every lane)
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    if (k == 0 || B > 64 * k) {  // wave-uniform
+      c.sc[k] = fast_exp(pmax[k] - c.M);  // rows beyond B: 0; a poisoned (NaN) partial makes S NaN
+      const double Qk = wave_scan_incl(canon_opaque(psum[k] * c.sc[k]));
+      c.px.Q[k] = k == 0 ? Qk : run + Qk;
+      c.px.I[k] = 1.0 / c.sc[k];
+    } else {
+      c.sc[k] = 0.0;
+      c.px.Q[k] = run;
+      c.px.I[k] = 0.0;
     }
+    run = lane_broadcast(c.px.Q[k], 63);
   }
-  c.S = lane_broadcast(Q1, 63);
-  c.px = CanonPrefix<TWO>{Q0, Q1, 1.0 / c.sa, TWO ? 1.0 / c.sb : 0.0, B};
+  c.S = run;
   return c;
 }
-template <bool TWO>
-__device__ __forceinline__ double canon_row_scale(const CanonComb<TWO>& c, const int g) {  // g wave-uniform
-  if constexpr (TWO) return g < 64 ? lane_broadcast(c.sa, g) : lane_broadcast(c.sb, g - 64);
-  else return lane_broadcast(c.sa, g);
+template <int NP>
+__device__ __forceinline__ double canon_row_scale(const CanonComb<NP>& c, const int g) {  // g wave-uniform
+  double r = lane_broadcast(c.sc[0], g & 63);
+#pragma unroll
+  for (int k = 1; k < NP; k++) { const double rk = lane_broadcast(c.sc[k], g & 63); r = (g >> 6) == k ? rk : r; }
+  return r;
 }
+// the combine of one wave handed to the other waves of a workgroup through LDS: [3 NP x 64 + 2] doubles
+template <int NP>
+__device__ __forceinline__ void canon_publish(const CanonComb<NP>& c, double* s_comb, const int lane) {
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    s_comb[(3 * k) * 64 + lane] = c.px.Q[k];
+    s_comb[(3 * k + 1) * 64 + lane] = c.px.I[k];
+    s_comb[(3 * k + 2) * 64 + lane] = c.sc[k];
+  }
+  if (lane == 0) { s_comb[3 * NP * 64] = c.M; s_comb[3 * NP * 64 + 1] = c.S; }
+}
+template <int NP>
+__device__ __forceinline__ CanonPrefix<NP> canon_prefix_load(const double* s_comb, const int lane, const int B) {
+  CanonPrefix<NP> px;
+#pragma unroll
+  for (int k = 0; k < NP; k++) { px.Q[k] = s_comb[(3 * k) * 64 + lane]; px.I[k] = s_comb[(3 * k + 1) * 64 + lane]; }
+  px.B = B;
+  return px;
+}
+template <int NP> __device__ __forceinline__ double canon_published_scale(const double* s_comb, const int g) { return s_comb[(3 * (g >> 6) + 2) * 64 + (g & 63)]; }
+template <int NP> __device__ __forceinline__ double canon_published_M(const double* s_comb) { return s_comb[3 * NP * 64]; }
+template <int NP> __device__ __forceinline__ double canon_published_S(const double* s_comb) { return s_comb[3 * NP * 64 + 1]; }
 // log-likelihood increment of a time point (src/model_ssm_ung.cpp:683) and the stratum width S / N
 __device__ __forceinline__ double canon_stratum(const double S, const int N) { return S / (double)N; }
 __device__ __forceinline__ double canon_llinc(const double M, const double c_scale) { return M + canon_opaque(tl_log(c_scale)); }
@@ -110,8 +150,8 @@ __device__ __forceinline__ double canon_target(const uint32_t uword, const int j
 // so their targets increase along the lanes: two ballots bound the rows [c_lo, c_hi] the wave draws from (wave-uniform), and a
 // lane walks the few prefixes in between.
 struct CanonSource { int e; double vp; int c_lo, c_hi; };
-template <bool TWO>
-__device__ __forceinline__ CanonSource canon_source_row(const double v, const bool act, const CanonPrefix<TWO>& px, const int lane) {
+template <int NP>
+__device__ __forceinline__ CanonSource canon_source_row(const double v, const bool act, const CanonPrefix<NP>& px, const int lane) {
   const unsigned long long amask = __builtin_amdgcn_ballot_w64(act);
   CanonSource s{0, 0.0, 0, -1};
   if (amask == 0ull) return s;

@@ -562,9 +562,11 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
     // every wave combines the <= 128 row partials redundantly (two per lane, in registers: saves a barrier)
     // (B = rows that hold particles: a function of N alone, whatever the thread geometry)
     const int B = EX ? (NTB * PPT) / CANON_ROW : (N + CANON_ROW - 1) / CANON_ROW;
-    constexpr bool kTwo = PPT * NTB > 64 * CANON_ROW;  // the kernel's capacity exceeds 64 rows: a lane holds two row prefixes
-    const CanonComb<kTwo> cc = canon_combine<kTwo>(lane < B ? s_max[lane] : -INFINITY, lane < B ? s_tot[lane] : 0.0,
-                                                   kTwo && lane + 64 < B ? s_max[lane + 64] : -INFINITY, kTwo && lane + 64 < B ? s_tot[lane + 64] : 0.0, B);
+    constexpr int kNP = PPT * NTB > 64 * CANON_ROW ? 2 : 1;  // the kernel's capacity exceeds 64 rows: a lane holds two row prefixes
+    double pmx[kNP], psm[kNP];
+#pragma unroll
+    for (int k = 0; k < kNP; k++) { pmx[k] = lane + 64 * k < B ? s_max[lane + 64 * k] : -INFINITY; psm[k] = lane + 64 * k < B ? s_tot[lane + 64 * k] : 0.0; }
+    const CanonComb<kNP> cc = canon_combine<kNP>(pmx, psm, B);
     const double S = cc.S, M = cc.M;
     if (b.weights) {
 #pragma unroll
@@ -1287,7 +1289,14 @@ auto grid_fn_kernel(int psi) -> void (*)(const FilterBatch, const GridWorkspace,
 }
 template <int MP, int KP>
 hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
-  if (ws.chunk == CANON_ROW) return launch_row_mk<MP, KP>(b, ws, stream, timing);  // the row family (pf_row_step.h): a workspace carved by row_workspace_carve
+  if (ws.chunk == CANON_ROW) {  // the row family (pf_row_step.h): a workspace carved by row_workspace_carve
+#ifndef BSSM_USER_MODEL
+    // EXPERIMENT (round 5, BSSM_AMD_FORCE_PATH=row): an eight-dimensional linear state through the fragment-native matrix-core
+    // transition of pf_big.h -- one 16-row block, half of it padding -- instead of the step kernel's LDS transposes
+    if constexpr (MP == 8 && KP % 4 == 0) { if (!b.fpar) return launch_big_row<1, 8>(b, ws, stream, timing); }
+#endif
+    return launch_row_mk<MP, KP>(b, ws, stream, timing);
+  }
   const int ppt = ws.chunk / GRID_NT;
   constexpr int kFn = fn_kernel_id<MP>();
   if (b.fpar && kFn > 0 && b.fn_id != kFn) return hipErrorInvalidValue;

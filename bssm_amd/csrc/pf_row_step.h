@@ -1,4 +1,4 @@
-// pf_row_step.h -- a filter of at most 8192 particles spread over its ROWS: one wave per row of 64 particles, one launch
+// pf_row_step.h -- a filter of at most 16 384 particles spread over its ROWS: one wave per row of 64 particles, one launch
 // per time step, results BIT-IDENTICAL to pf_wg_kernel's (both evaluate pf_canon.h).
 //
 // Why it exists (round-4 review, item 1; src/approx_mcmc.cpp:364-417): a particle system that takes more than half a CU's LDS
@@ -54,6 +54,18 @@ __device__ __forceinline__ void row_publish(const FilterBatch& b, const GridWork
   if (lane == 63) part[1] = rs.sc;
 }
 
+// wave 0 of a workgroup: the (M_row, S_row) partials of the time-t weights of one filter, combined and handed to the other waves
+__device__ __forceinline__ void row_combine_publish(const double* __restrict__ part, const int B, double* s_comb, const int lane) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  double pmx[ROW_NP], psm[ROW_NP];
+#pragma unroll
+  for (int k = 0; k < ROW_NP; k++) {
+    pmx[k] = -INFINITY; psm[k] = 0.0;
+    if (lane + 64 * k < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64 * k)); pmx[k] = pp.x; psm[k] = pp.y; }
+  }
+  canon_publish(canon_combine<ROW_NP>(pmx, psm, B), s_comb, lane);
+}
+
 // t = -1: initial particles and their weights (src/model_ssm_ung.cpp:626, :543; functor models: pf_functors.h)
 template <int MP, int KP, int FN = FN_NONE, int PM = -1>
 __global__ void __launch_bounds__(ROW_NT) pf_row_init(const FilterBatch b, const GridWorkspace ws) {
@@ -98,7 +110,7 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   constexpr int ucnt = step_draw_count<KP, FN>();
   const int psi_mode = PM >= 0 ? PM : b.psi;
   __shared__ double s_win[4 * ROW_WIN];
-  __shared__ double s_comb[4 * 64 + 2 + 128];  // row prefixes (128), 1 / scale (128), M, S, scales (128)
+  __shared__ double s_comb[3 * ROW_NP * 64 + 2];  // the combine of wave 0 (pf_canon.h: canon_publish)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int f = ws.f0 + blockIdx.y, g = blockIdx.x * 4 + wave, B = ws.B, N = b.N, n = b.n, m = b.m, tn = t + 1;
   ROW_STAMP(0);
@@ -108,33 +120,19 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   const bool has_row = g < B, act = has_row && j < N;
   const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
   const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N;
-  // ---- the (M_row, S_row) partials of the time-t weights: requested first, combined by wave 0 while the others draw their step blocks
-  double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
-  if (wave == 0) {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
-    if (lane < B) { const d2 pp = *(const d2*)(part + 2 * lane); pmax = pp.x; psum = pp.y; }
-    if (lane + 64 < B) { const d2 pp = *(const d2*)(part + 2 * (lane + 64)); pmaxb = pp.x; psumb = pp.y; }
-    const CanonComb<true> cc = canon_combine<true>(pmax, psum, pmaxb, psumb, B);
-    s_comb[lane] = cc.px.Qa;
-    s_comb[64 + lane] = cc.px.Qb;
-    s_comb[128 + lane] = cc.px.ia;
-    s_comb[192 + lane] = cc.px.ib;
-    s_comb[258 + lane] = cc.sa;
-    s_comb[258 + 64 + lane] = cc.sb;
-    if (lane == 0) { s_comb[256] = cc.M; s_comb[257] = cc.S; }
-  }
+  // ---- the (M_row, S_row) partials of the time-t weights: combined by wave 0 while the others draw their step blocks
+  if (wave == 0) row_combine_publish(ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2, B, s_comb, lane);
   const u32x4 blk = rng_step_block(key, (uint32_t)t, (uint32_t)j);
   const uint32_t uword = rng_resample_word<ucnt>(key, (uint32_t)t, (uint32_t)j, blk);
   ROW_STAMP(1);  // tables + partials (wave 0: + combine) + step block
   math_tab_load_end256(mtab);
   lds_barrier();  // (1) the only workgroup barrier of the step
   ROW_STAMP(2);  // barrier wait
-  const CanonPrefix<true> px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[192 + lane], B};
-  const double M = s_comb[256], S = s_comb[257];
+  const CanonPrefix<ROW_NP> px = canon_prefix_load<ROW_NP>(s_comb, lane, B);
+  const double M = canon_published_M<ROW_NP>(s_comb), S = canon_published_S<ROW_NP>(s_comb);
   if (b.weights && act) {  // the stored weights of time t are exp(w - M_row): to the scale of the whole time point (also on a degenerate step, :676-682)
     double* __restrict__ wt = b.weights + ((size_t)f * (n + 1) + t) * N;
-    wt[j] = wt[j] * s_comb[258 + g];
+    wt[j] = wt[j] * canon_published_scale<ROW_NP>(s_comb, g);
   }
   if (!(S > 0.0)) {
     // degenerate weights (src/model_ssm_ung.cpp:678-682): stop and poison this row's slot of the next parity, so every later
@@ -153,7 +151,7 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
 
   // ---- stratified resampling (pf_canon.h): source row per slot, then the bisection inside it.  The rows [c_lo, c_hi] a wave draws
   // from are contiguous in the exchange array: staged four at a time in the wave's window
-  const CanonSource src = canon_source_row<true>(canon_target(uword, j, c_scale), act, px, lane);
+  const CanonSource src = canon_source_row(canon_target(uword, j, c_scale), act, px, lane);
   ROW_STAMP(3);  // source rows
   double* sw = s_win + wave * ROW_WIN;
   int anc = 0;
@@ -240,7 +238,7 @@ auto row_fn_kernels(int psi, void (**init)(const FilterBatch, const GridWorkspac
 // the time loop of the row family: one launch per step
 inline hipError_t launch_row_loop(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing,
                                   void (*kern)(const FilterBatch, const GridWorkspace, const int), void (*kern_init)(const FilterBatch, const GridWorkspace)) {
-  if (b.N > CANON_ROW * CANON_MAX_ROWS || ws.chunk != CANON_ROW || ws.B != (b.N + CANON_ROW - 1) / CANON_ROW) return hipErrorInvalidValue;
+  if (b.N > CANON_ROW * ROW_MAX_ROWS || ws.chunk != CANON_ROW || ws.B != (b.N + CANON_ROW - 1) / CANON_ROW) return hipErrorInvalidValue;
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
