@@ -170,3 +170,22 @@ def test_many_observation_series(oracle, monkeypatch, m, p, path, N):
     assert np.array_equal(out["indices"], ref["indices"])
     assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
     assert np.allclose(out["weights"], ref["weights"], rtol=1e-8, atol=1e-13)
+
+
+def test_degenerate_and_unobserved_series_on_a_big_state(oracle, monkeypatch):
+    """25 states: (a) every observation missing -- weights are ones, logLik 0, resampling on uniform weights; (b) exp(signal)
+    overflows at the first time point -- -Inf with a warning from both shapes (src/model_ssm_ung.cpp:644-647, :678-682)"""
+    import warnings
+    model = seasonal(24, n=8)
+    arr = dict(M.model_arrays(model))
+    none = M.ssm_ung(np.full(8, np.nan), Z=arr["Z"], T=arr["T"], R=arr["R"], a1=arr["a1"], P1=arr["P1"], distribution="poisson")
+    for path, N in (("wg", 200), ("row", 700)):
+        monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+        out = F.bootstrap_filter(none, N, seed=8, return_indices=True)
+        ref = oracle.bsf_filter(M.model_arrays(none), N, seed=8)
+        assert np.all(out["weights"] == 1.0) and out["logLik"] == ref["logLik"] == 0.0
+        assert np.array_equal(out["indices"], ref["indices"])
+        bad = M.ssm_ung(np.array([1.0, 2.0, 3.0]), Z=arr["Z"], T=arr["T"], R=arr["R"], a1=arr["a1"], P1=arr["P1"], distribution="poisson", D=800.0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert F.bootstrap_filter(bad, N, seed=1)["logLik"] == -np.inf

@@ -84,3 +84,18 @@ def test_full_outputs_same_bits_in_both_families(monkeypatch, name, N):
     wg, row = _both(monkeypatch, lambda: F.particle_smoother(model, N, method="psi", seed=14))
     for k in ("alphahat", "Vt", "alpha"):
         assert np.array_equal(wg[k], row[k]), (name, k)
+
+
+@pytest.mark.parametrize("name,N", [("negbin_ar1", 12000), ("poisson_slope_missing", 16384), ("negbin_m4", 9000)])
+def test_row_family_beyond_the_workgroup_capacity_against_the_oracle(oracle, monkeypatch, name, N):
+    """the row family takes filters of up to 16 384 particles (four row-prefix slots per lane): 129 ... 256 rows, against the oracle"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "row")
+    model = dict(small_zoo(), negbin_ar1=negbin_ar1(25, seed=3), negbin_m4=negbin_m4(25, seed=4))[name]
+    c0 = FilterPlan.family_launches()
+    out = F.bootstrap_filter(model, N, seed=21, return_indices=True)
+    assert FilterPlan.family_launches()["row"] == c0["row"] + 1
+    arr = M.model_arrays(model)
+    ref = oracle.bsf_filter(arr, N, seed=21)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * model.n
+    assert np.allclose(out["weights"], ref["weights"], rtol=1e-8, atol=1e-13)
