@@ -739,6 +739,7 @@ int bssm_nongaussian_loglik_batch(const bssm_ung_model* model, uint32_t nsim, ui
   db.fb.dead_at = db.dead.as<int>();
   const int cap = bssm::wg_filter_capacity(MP);
   db.use_grid = !((int)nsim <= cap && (n_rep >= 32 || nsim <= 2048));
+  db.use_grid = bssm::prefer_step_shape(db.fb, db.use_grid);
   if (bssm::opt().force_path == 2) db.use_grid = true;
   if (bssm::opt().force_path == 1 && (int)nsim <= cap) db.use_grid = false;
   if (bssm::opt().force_path == 3 && bssm::row_filter_supported(db.fb)) db.use_grid = true;

@@ -385,6 +385,7 @@ struct DeviceBatch {
     // enough filters to fill the chip (or the filter is small); otherwise one launch per time step.
     const int cap = bssm::wg_filter_capacity(MP);
     use_grid = !(N <= cap && (F >= 32 || N <= 2048));
+    use_grid = bssm::prefer_step_shape(fb, use_grid);
     if (bssm::opt().force_path == 2) use_grid = true;
     if (bssm::opt().force_path == 1) use_grid = false;
     if (path_flags & BSSM_PLAN_FORCE_GRID) use_grid = true;

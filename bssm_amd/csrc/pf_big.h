@@ -43,14 +43,19 @@ __device__ __forceinline__ double big_xor_add(double x) {  // sum over the four 
 // (LD: leading dimension of the tables = the padded state dimension of the batch; LD < 16 MB -- an eight-dimensional state in one
 // 16-row block, the C4 experiment -- leaves the rows beyond LD zero)
 template <int MB, int LD>
-__device__ __forceinline__ void big_chunk(BigAcc<MB>& acc, const double* __restrict__ Acol, const double (&bf)[4], const int lane) {
+__device__ __forceinline__ void big_afrag(const double* __restrict__ Acol, double (&afr)[MB], const int lane) {
   const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
-  for (int rb = 0; rb < MB; rb++) {
-    const double afr = (LD == 16 * MB || 16 * rb + i < LD) ? Acol[(LD == 16 * MB ? 16 * rb + i : min(16 * rb + i, LD - 1)) + LD * kq] : 0.0;
+  for (int rb = 0; rb < MB; rb++)
+    afr[rb] = (LD == 16 * MB || 16 * rb + i < LD) ? Acol[(LD == 16 * MB ? 16 * rb + i : min(16 * rb + i, LD - 1)) + LD * kq] : 0.0;
+}
+// acc += A[:, 4 kk ... 4 kk + 3] . B chunk, every row block
+template <int MB>
+__device__ __forceinline__ void big_chunk(BigAcc<MB>& acc, const double (&afr)[MB], const double (&bf)[4]) {
 #pragma unroll
-    for (int pb = 0; pb < 4; pb++) acc.v[rb][pb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr, bf[pb], acc.v[rb][pb], 0, 0, 0);
-  }
+  for (int rb = 0; rb < MB; rb++)
+#pragma unroll
+    for (int pb = 0; pb < 4; pb++) acc.v[rb][pb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[rb], bf[pb], acc.v[rb][pb], 0, 0, 0);
 }
 
 // X' = c0 + A1 . S(ancestors) + A2 . noise for the 64 particles of this wave:
@@ -60,6 +65,10 @@ __device__ __forceinline__ void big_chunk(BigAcc<MB>& acc, const double* __restr
 //   state_at(c, pb)              component c of the ancestor of particle 16 pb + (lane & 15); rows >= ms are never asked for
 //   noise4(kk, z)                normals 4 kk ... 4 kk + 3 of THIS lane's particle (lane = particle inside the wave's row)
 //   tile                         4 x 64 doubles of LDS, this wave's
+// The operands of k-chunk kk + 1 (A fragments from the table, B fragments from the particle system) are requested BEFORE the
+// matrix instructions of chunk kk are issued: the loops have run-time bounds (real m, real k), so nothing else would overlap a
+// chunk's load round trip with the previous chunk's 8 ... 16 MFMAs (round 5, workgroup shape: psi-APF m = 53 54 -> 28 ms per 1024 filters,
+// m = 25 15.6 -> 11.0 ms; bootstrap m = 53 15.1 -> 12.8 ms; profiles/r05_big_states.txt).
 template <int MB, int LD, class StateAt, class Noise4>
 __device__ __forceinline__ void big_affine(BigAcc<MB>& acc, const double* __restrict__ c0, const double* __restrict__ A1, const int ms,
                                            const double* __restrict__ A2, const int ncnt, StateAt&& state_at, Noise4&& noise4,
@@ -73,24 +82,38 @@ __device__ __forceinline__ void big_affine(BigAcc<MB>& acc, const double* __rest
 #pragma unroll
     for (int pb = 0; pb < 4; pb++) acc.v[rb][pb] = cv;
   }
-  for (int kk = 0; 4 * kk < ms; kk++) {
+  const int nks = (ms + 3) >> 2, nkn = (ncnt + 3) >> 2;
+  double afr[MB], bf[4], afn[MB], bfn[4];
+  auto fetch_state = [&](int kk, double (&a)[MB], double (&bq)[4]) {
+    big_afrag<MB, LD>(A1 + (size_t)MP * 4 * kk, a, lane);
     const int c = 4 * kk + kq;
-    double bf[4];
 #pragma unroll
-    for (int pb = 0; pb < 4; pb++) bf[pb] = c < ms ? state_at(c, pb) : 0.0;
-    big_chunk<MB, LD>(acc, A1 + (size_t)MP * 4 * kk, bf, lane);
+    for (int pb = 0; pb < 4; pb++) bq[pb] = c < ms ? state_at(c, pb) : 0.0;
+  };
+  if (nks > 0) fetch_state(0, afr, bf);
+  for (int kk = 0; kk < nks; kk++) {
+    if (kk + 1 < nks) fetch_state(kk + 1, afn, bfn);
+    else if (nkn > 0) big_afrag<MB, LD>(A2, afn, lane);  // (the first noise chunk's A fragments under the last state chunk)
+    big_chunk<MB>(acc, afr, bf);
+#pragma unroll
+    for (int rb = 0; rb < MB; rb++) afr[rb] = afn[rb];
+#pragma unroll
+    for (int pb = 0; pb < 4; pb++) bf[pb] = bfn[pb];
   }
-  for (int kk = 0; 4 * kk < ncnt; kk++) {
+  if (nks == 0 && nkn > 0) big_afrag<MB, LD>(A2, afr, lane);
+  for (int kk = 0; kk < nkn; kk++) {
     double z[4];
     noise4(kk, z);
+    if (kk + 1 < nkn) big_afrag<MB, LD>(A2 + (size_t)MP * 4 * (kk + 1), afn, lane);
     lds_wave_sync();  // the previous chunk's reads of the tile are done
 #pragma unroll
     for (int c = 0; c < 4; c++) tile[c * 64 + lane] = 4 * kk + c < ncnt ? z[c] : 0.0;
     lds_wave_sync();
-    double bf[4];
 #pragma unroll
     for (int pb = 0; pb < 4; pb++) bf[pb] = tile[kq * 64 + 16 * pb + i];
-    big_chunk<MB, LD>(acc, A2 + (size_t)MP * 4 * kk, bf, lane);
+    big_chunk<MB>(acc, afr, bf);
+#pragma unroll
+    for (int rb = 0; rb < MB; rb++) afr[rb] = afn[rb];
   }
 }
 
@@ -159,6 +182,8 @@ __device__ __forceinline__ void big_store(const BigAcc<MB>& acc, double* __restr
 // ------------------------------------------------------------------------------------------------------------------
 // one workgroup per filter, one wave per row of 64 particles, particle system in LDS
 // ------------------------------------------------------------------------------------------------------------------
+// (MB = 4 runs 256 threads = one wave per SIMD; budgeted for 512 anyway: with the 470 registers a 256-thread bound allows it measured
+// 16.8 ms against 12.8 ms per 1024 bootstrap filters of 256 particles at 256 registers and 67 spilt, profiles/r05_big_states.txt)
 template <int MB>
 __global__ void __launch_bounds__(BIG_NT_MAX, 1) pf_big_wg(const FilterBatch b) {
   constexpr int MP = 16 * MB;
@@ -272,6 +297,9 @@ hipError_t launch_big_wg(const FilterBatch& b, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------------------------
 // one wave per row, particle system in HBM, one launch per time step (the exchange of pf_row_step.h)
 // ------------------------------------------------------------------------------------------------------------------
+// waves per SIMD the row shape is budgeted for: a step is a chain of dependent round trips (partials, source rows, one gather per
+// k-chunk), hidden by other waves, not by a deeper pipeline inside one (MB = 2: 196 VGPRs unconstrained, 128 with two spilt)
+constexpr int big_row_occupancy(int mb) { return mb <= 2 ? 4 : 2; }
 template <int MB, int LD = 16 * MB>
 __global__ void __launch_bounds__(ROW_NT) pf_big_row_init(const FilterBatch b, const GridWorkspace ws) {
   constexpr int MP = LD;
@@ -295,7 +323,7 @@ __global__ void __launch_bounds__(ROW_NT) pf_big_row_init(const FilterBatch b, c
 }
 
 template <int MB, int LD = 16 * MB>
-__global__ void __launch_bounds__(ROW_NT) pf_big_row_step(const FilterBatch b, const GridWorkspace ws, const int t) {
+__global__ void __launch_bounds__(ROW_NT, big_row_occupancy(MB)) pf_big_row_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   constexpr int MP = LD;
   __shared__ double s_win[4 * ROW_WIN];
   __shared__ double s_comb[3 * ROW_NP * 64 + 2];  // the combine of wave 0 (pf_canon.h: canon_publish)

@@ -143,6 +143,14 @@ bool row_filter_supported(const FilterBatch& b) {
   if (opt().force_path == 3 && b.MP == 8 && b.KP % 4 == 0) return true;  // EXPERIMENT hook only (pf_filter_impl.h launch_grid_mk): not bit-identical to pf_wg_kernel
   return b.MP <= 4 || b.MP >= 32;  // (eight- and sixteen-dimensional states: pf_wg_kernel's matrix-core transitions sum in another order)
 }
+bool prefer_step_shape(const FilterBatch& b, bool use_grid) {
+  if (use_grid || b.MP < 32 || b.fpar) return use_grid;
+  const long long rows = (long long)b.F * ((b.N + CANON_ROW - 1) / CANON_ROW);
+  // (profiles/r05_big_states.txt: m = 53, 1024 x 256 particles 12.8 ms workgroup-resident, 10.6 ms as rows; m = 25: 256 particles per filter 5.9 ms
+  // against 5.3 ms, but 512 particles per filter 2.15 ms against 2.6 ms)
+  if (b.MP >= 64) return rows >= 1024;
+  return b.N <= 256 && rows >= 2048;
+}
 size_t row_workspace_bytes(const FilterBatch& b) { return row_workspace_bytes_impl(b); }
 void row_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };

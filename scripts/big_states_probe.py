@@ -20,8 +20,9 @@ for period in (24, 52):
     for method, ncnt in (("bsf", 3), ("psi", m)):
         m4, k4 = (m + 3) // 4 * 4, (ncnt + 3) // 4 * 4
         flops = 2.0 * MP * (m4 + k4)
-        for force, N, R in (("wg", 256, 1024), ("wg", 256 if MP == 64 else 512, 256), ("row", 1024, 256), ("row", 4096, 64)):
-            os.environ["BSSM_AMD_FORCE_PATH"] = force
+        for force, N, R in (("wg", 256, 1024), ("wg", 256 if MP == 64 else 512, 256), ("row", 256, 1024), ("auto", 256, 1024), ("auto", 64, 2048), ("row", 1024, 256), ("row", 4096, 64)):
+            if force == "auto": os.environ.pop("BSSM_AMD_FORCE_PATH", None)
+            else: os.environ["BSSM_AMD_FORCE_PATH"] = force
             plan = FilterPlan(model, N, method=method, keep_history=False, n_rep=R)
             plan.run(1)
             ll = plan.loglik()
