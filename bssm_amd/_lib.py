@@ -47,7 +47,7 @@ def pack_fn_model(model, L=None):
     s.x0, s.positive = float(model.get("x0", 0.0)), int(bool(model.get("positive", False)))
     s.L = int(model.get("L", 0) if L is None else L)
     if s.model_id >= 7:  # user-defined: compiled at run time, numbers for the state-independent parts
-        s.user_slot = user_model_slot(model["user_source"], int(model.get("n_states", 1)))
+        s.user_slot = user_model_slot(model["user_source"], int(model.get("n_states", 1)), jit=bool(model.get("user_jit", False)))
         s.n_states = int(model.get("n_states", 1))
         if s.model_id == 7:
             fill_user_numbers(s, model, th)
@@ -84,11 +84,18 @@ def fill_user_numbers(s, model, theta):
 _user_slots = {}
 
 
-def user_model_slot(source: str, n_states: int) -> int:
-    """Compile (cached by content hash) and load a user-defined model's device functions; returns the registry slot."""
-    key = (source, n_states)
+def user_model_slot(source: str, n_states: int, jit: bool = False) -> int:
+    """Compile (cached by content hash) and load a user-defined model's device functions; returns the registry slot.
+    jit: in process through hiprtc (bssm_user_model_jit: bootstrap filter only) instead of a hipcc-built shared library."""
+    key = (source, n_states, bool(jit))
     if key not in _user_slots:
         L = lib()
+        if jit:
+            slot = L.bssm_user_model_jit(source.encode(), C.c_int32(n_states))
+            if slot < 1:
+                raise BssmAmdError(f"bssm_amd error {slot}: {L.bssm_amd_last_error().decode()}")
+            _user_slots[key] = slot
+            return slot
         buf = C.create_string_buffer(4096)
         check(L.bssm_user_model_build(source.encode(), C.c_int32(n_states), buf, C.c_int32(4096)))
         slot = L.bssm_user_model_load(buf.value)

@@ -413,6 +413,7 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
     const int ms = mod->n_states;
     if (ms < 1 || ms > max_states)
       return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: at most 8 states");
+    if (h.jit) return fail(BSSM_ERR_UNSUPPORTED, "this user model was compiled in process (bssm_user_model_jit): bootstrap filter only -- the psi-APF and the EKF particle filter run the snippet on the host, build it with bssm_user_model_build");
     if (!h.T || !h.Z || !h.Tg || !h.Zg)
       return fail(BSSM_ERR_UNSUPPORTED, "this user model was compiled without BSSM_USER_JACOBIANS (bssm_user_Tg, bssm_user_Zg): the psi-APF and the EKF particle filter need them");
     // the state-independent numbers: R_diag / a1 / P1 (up to 2 states) or the R_ext / a1_ext / P1_ext blocks
@@ -948,6 +949,255 @@ int bssm_user_model_load(const char* lib_path) {
   g_user_host[slot].H = (decltype(bssm::UserHostFns::H))dlsym(h, "bssm_user_host_H");
   g_user_host[slot].R = (decltype(bssm::UserHostFns::R))dlsym(h, "bssm_user_host_R");
   g_user_loaded[lib_path] = slot;
+  return slot;
+}
+
+// ------------------------------------------------------------------ user-defined models compiled IN PROCESS (hiprtc)
+// The reference compiles a user's model inside the R session (Rcpp::sourceCpp, R/cpp_example_models.R:762) and calls it through
+// pointers (src/model_ssm_nlg.h:10-21).  bssm_user_model_build above needs the ROCm compiler driver on the machine and builds every
+// kernel variant of every sampler (10-18 s).  A model that is only ever run through the BOOTSTRAP filter needs neither: its device
+// functions are compiled by hiprtc (libhiprtc: the compiler as a library, no host compiler, no process) into exactly the kernel
+// variant a call asks for, the first time it asks -- ~1-2 s per variant, code objects cached on disk by content hash next to the
+// hipcc-built libraries.  What such a model cannot do: the psi-APF and the EKF particle filter, whose set-up runs the snippet's functions
+// ON THE HOST (mode search, linearisation) -- those entry points refuse a JIT slot with a message that names bssm_user_model_build.
+// Kernel shapes: workgroup-resident (512-thread form) and the row family (up to 16 384 particles); both evaluate pf_canon.h, so a model
+// gives the same bits whether it was built by hipcc or compiled here.
+}  // extern "C"
+#include <hip/hiprtc.h>
+#include "pf_canon.h"
+namespace {
+constexpr int kJitWgThreads = 512;  // = WG_NT_MAX of pf_filter_impl.h: the 512-thread form of the workgroup-resident kernel
+struct JitModel {
+  std::string source;
+  int n_states = 0, MP = 0, fn_id = 0;
+  std::mutex mu;
+  std::map<std::string, hipFunction_t> kernels;  // "<device>|<name expression>" -> loaded function
+};
+JitModel* g_jit[64] = {};
+
+std::string jit_cache_dir() {
+  const std::string& env_cache = bssm::opt().user_cache;
+  if (!env_cache.empty()) return env_cache;
+  const std::string dir = library_dir();
+  if (access(dir.c_str(), W_OK) == 0) return dir + "/user_models";
+  const char* home = std::getenv("HOME");
+  return (home && *home) ? std::string(home) + "/.cache/bssm_amd/user_models" : std::string();
+}
+bool jit_private_file(const std::string& path) {  // ours (or root's), not writable by anybody else: only such a code object is loaded
+  struct stat sb;
+  if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
+  if (sb.st_uid != geteuid() && sb.st_uid != 0) return false;
+  return (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+bool jit_private_dir(const std::string& path) {
+  struct stat sb;
+  if (stat(path.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) return false;
+  if (sb.st_uid != geteuid() && sb.st_uid != 0) return false;
+  return (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+
+// the translation unit hiprtc sees: the snippet, then the kernel templates (device view of the headers: __HIPCC_RTC__)
+std::string jit_translation_unit(const JitModel& jm) {
+  return "#define BSSM_USER_MODEL 1\n#define BSSM_FN __device__ inline\n"
+         "struct bssm_user_tv { int t; const double* known_tv; int rows, cols; };\n" + jm.source +
+         "\n#define BSSM_USER_M " + std::to_string(jm.MP) + "\n#define BSSM_USER_NSTATES " + std::to_string(jm.n_states) +
+         "\n#define BSSM_FN_PSI_MASK 1\n#include \"pf_filter_impl.h\"\n";
+}
+
+// compile (or load from the disk cache) ONE kernel variant for the current device; nullptr + *err on failure
+hipFunction_t jit_kernel(JitModel& jm, const std::string& name, std::string* err) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const std::string key = std::to_string(dev) + "|" + name;
+  std::lock_guard<std::mutex> lk(jm.mu);
+  auto it = jm.kernels.find(key);
+  if (it != jm.kernels.end()) return it->second;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { *err = "no device properties"; return nullptr; }
+  std::string arch = prop.gcnArchName;
+  if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
+  const std::string dir = library_dir(), tu = jit_translation_unit(jm);
+  // cache key: everything that is compiled into the code object
+  std::string hk = std::string(bssm_amd_version()) + "|" + arch + "|" + name + "|" + tu;
+  for (const char* hdr : {"pf_filter_impl.h", "pf_row_step.h", "pf_canon.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "pf_math_tables.h"}) {
+    FILE* hf = std::fopen((dir + "/csrc/" + hdr).c_str(), "rb");
+    if (!hf) { *err = "kernel sources not found next to the library: " + dir + "/csrc/" + hdr; return nullptr; }
+    char buf[1 << 16];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof buf, hf)) > 0) hk.append(buf, got);
+    std::fclose(hf);
+  }
+  char hbuf[32];
+  std::snprintf(hbuf, sizeof hbuf, "%016llx", (unsigned long long)fnv1a(hk));
+  const std::string cache = jit_cache_dir();
+  const std::string co_path = cache.empty() ? std::string() : cache + "/jit_" + hbuf + ".hsaco", ln_path = co_path + ".name";
+  std::vector<char> code;
+  std::string lowered;
+  if (!co_path.empty() && jit_private_dir(cache) && jit_private_file(co_path) && jit_private_file(ln_path)) {
+    if (FILE* cf = std::fopen(co_path.c_str(), "rb")) {
+      std::fseek(cf, 0, SEEK_END); const long sz = std::ftell(cf); std::fseek(cf, 0, SEEK_SET);
+      code.resize(sz > 0 ? (size_t)sz : 0);
+      if (sz <= 0 || std::fread(code.data(), 1, (size_t)sz, cf) != (size_t)sz) code.clear();
+      std::fclose(cf);
+    }
+    if (FILE* nf = std::fopen(ln_path.c_str(), "r")) { char nb[512] = {0}; if (std::fgets(nb, sizeof nb, nf)) lowered = nb; std::fclose(nf); }
+    while (!lowered.empty() && (lowered.back() == '\n' || lowered.back() == ' ')) lowered.pop_back();
+    if (lowered.empty()) code.clear();
+  }
+  if (code.empty()) {
+    const double t0 = now_ms();
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, tu.c_str(), "bssm_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *err = "hiprtcCreateProgram failed"; return nullptr; }
+    (void)hiprtcAddNameExpression(prog, name.c_str());
+    const std::string o_arch = "--offload-arch=" + arch, o_inc = "-I" + dir + "/csrc";
+    const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", o_inc.c_str()};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+    if (rc != HIPRTC_SUCCESS) {
+      size_t ls = 0;
+      (void)hiprtcGetProgramLogSize(prog, &ls);
+      std::string log(ls, 0);
+      if (ls) (void)hiprtcGetProgramLog(prog, &log[0]);
+      (void)hiprtcDestroyProgram(&prog);
+      *err = "compiling the user model in process failed (" + std::string(hiprtcGetErrorString(rc)) + "):\n" + log.substr(0, 4000);
+      return nullptr;
+    }
+    size_t cs = 0;
+    (void)hiprtcGetCodeSize(prog, &cs);
+    code.resize(cs);
+    (void)hiprtcGetCode(prog, code.data());
+    const char* ln = nullptr;
+    if (hiprtcGetLoweredName(prog, name.c_str(), &ln) != HIPRTC_SUCCESS || !ln) { (void)hiprtcDestroyProgram(&prog); *err = "no lowered name for " + name; return nullptr; }
+    lowered = ln;
+    (void)hiprtcDestroyProgram(&prog);
+    if (bssm::opt().trace) std::fprintf(stderr, "[bssm_amd] hiprtc: %s in %.0f ms (%zu bytes)\n", name.c_str(), now_ms() - t0, cs);
+    if (!co_path.empty()) {  // best effort: a cache that cannot be written only costs the next process a recompile
+      (void)std::system(("mkdir -p -m 0700 '" + cache + "' 2>/dev/null").c_str());
+      if (jit_private_dir(cache) && cache.find_first_of("'\"\\\n") == std::string::npos) {
+        const std::string tmp = co_path + ".tmp." + std::to_string((long)getpid());
+        if (FILE* cf = std::fopen(tmp.c_str(), "wb")) {
+          const bool okw = std::fwrite(code.data(), 1, code.size(), cf) == code.size();
+          std::fclose(cf);
+          (void)chmod(tmp.c_str(), 0600);
+          if (FILE* nf = std::fopen((ln_path + ".tmp").c_str(), "w")) { std::fputs(lowered.c_str(), nf); std::fclose(nf); (void)chmod((ln_path + ".tmp").c_str(), 0600); (void)std::rename((ln_path + ".tmp").c_str(), ln_path.c_str()); }
+          if (okw) (void)std::rename(tmp.c_str(), co_path.c_str()); else (void)std::remove(tmp.c_str());
+        }
+      }
+    }
+  }
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, lowered.c_str()) != hipSuccess) {
+    (void)hipGetLastError();
+    *err = "loading the compiled user-model kernel failed: " + name;
+    return nullptr;
+  }
+  jm.kernels[key] = fn;
+  return fn;
+}
+
+JitModel* jit_of(int slot) { return slot >= 1 && slot <= 63 ? g_jit[slot] : nullptr; }
+
+// workgroup-resident shape: the 512-thread form of launch_wg_mk (pf_filter_impl.h), bootstrap sampler
+hipError_t jit_launch_wg(const bssm::FilterBatch* bp, hipStream_t stream) {
+  JitModel* jm = jit_of(bp->user_slot);
+  if (!jm || bp->psi != 0 || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process runs the bootstrap filter only (psi-APF / EKF particle filter: bssm_user_model_build)"); return hipErrorInvalidValue; }
+  bssm::FilterBatch b = *bp;
+  b.user_slot = 0;
+  const int MP = jm->MP, N = b.N;
+  int ppt = 1;
+  while (ppt < 16 && N > kJitWgThreads * ppt) ppt *= 2;
+  if (ppt == 16 && MP > 2) return hipErrorInvalidValue;
+  const int nt = ppt == 1 ? (N + 63) / 64 * 64 : kJitWgThreads;
+  const size_t lds = ((size_t)(MP + 1) * nt * ppt + 2 * bssm::CANON_MAX_ROWS + (size_t)(2 * MP * MP + MP)) * sizeof(double);
+  if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
+  char name[160];
+  std::snprintf(name, sizeof name, "bssm::pf_wg_kernel<%d,%d,%d,%d,%d,0,false>", MP, MP, ppt, jm->fn_id, kJitWgThreads);
+  std::string err;
+  hipFunction_t fn = jit_kernel(*jm, name, &err);
+  if (!fn) { fail(BSSM_ERR_INVALID, err); return hipErrorInvalidValue; }
+  bssm::note_filter_kernel((std::string(name) + " [hiprtc]").c_str());
+  hipError_t e;
+  if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
+  void* args[] = {&b};
+  return hipModuleLaunchKernel(fn, (unsigned)b.F, 1, 1, (unsigned)nt, 1, 1, (unsigned)lds, stream, args, nullptr);
+}
+
+// row family (pf_row_step.h): the time loop of launch_row_loop with module launches
+hipError_t jit_launch_grid(const bssm::FilterBatch* bp, const bssm::GridWorkspace* wsp_in, hipStream_t stream, bssm::StepTiming* timing) {
+  JitModel* jm = jit_of(bp->user_slot);
+  if (!jm || bp->psi != 0 || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process runs the bootstrap filter only (psi-APF / EKF particle filter: bssm_user_model_build)"); return hipErrorInvalidValue; }
+  const bssm::GridWorkspace& ws = *wsp_in;
+  if (ws.chunk != bssm::CANON_ROW || bp->N > bssm::CANON_ROW * bssm::ROW_MAX_ROWS) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process takes up to 16384 particles (more: bssm_user_model_build)"); return hipErrorInvalidValue; }
+  bssm::FilterBatch b = *bp;
+  b.user_slot = 0;
+  const int MP = jm->MP;
+  char n_step[160], n_init[160];
+  std::snprintf(n_step, sizeof n_step, "bssm::pf_row_step<%d,%d,%d,0>", MP, MP, jm->fn_id);
+  std::snprintf(n_init, sizeof n_init, "bssm::pf_row_init<%d,%d,%d,0>", MP, MP, jm->fn_id);
+  std::string err;
+  hipFunction_t f_step = jit_kernel(*jm, n_step, &err), f_init = f_step ? jit_kernel(*jm, n_init, &err) : nullptr;
+  if (!f_step || !f_init) { fail(BSSM_ERR_INVALID, err); return hipErrorInvalidValue; }
+  bssm::note_filter_kernel((std::string(n_step) + " [hiprtc]").c_str());
+  hipError_t e;
+  if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
+  const int wgs = (ws.B + 3) / 4;
+  int parts = (b.F >= 8 && ws.side) ? 2 : 1;
+  hipStream_t lanes[2] = {stream, parts == 2 ? ws.side : stream};
+  bssm::GridWorkspace w2[2] = {ws, ws};
+  int fcount[2] = {b.F, 0};
+  hipEvent_t fork = nullptr, join = nullptr;
+  if (parts == 2) {
+    fcount[0] = b.F / 2; fcount[1] = b.F - fcount[0];
+    w2[1].f0 = ws.f0 + fcount[0];
+    if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return e;
+    (void)hipEventRecord(fork, stream);
+    (void)hipStreamWaitEvent(lanes[1], fork, 0);
+  }
+  if (timing) timing->concurrent = parts;
+  for (int t = -1; t < b.n; t++)
+    for (int q = 0; q < parts; q++) {
+      int tt = t;
+      void* a_init[] = {&b, &w2[q]};
+      void* a_step[] = {&b, &w2[q], &tt};
+      e = hipModuleLaunchKernel(t < 0 ? f_init : f_step, (unsigned)wgs, (unsigned)fcount[q], 1, 256, 1, 1, 0, lanes[q], t < 0 ? a_init : a_step, nullptr);
+      if (e != hipSuccess) return e;
+    }
+  if (parts == 2) {
+    if ((e = hipEventCreateWithFlags(&join, hipEventDisableTiming)) != hipSuccess) return e;
+    (void)hipEventRecord(join, lanes[1]);
+    (void)hipStreamWaitEvent(stream, join, 0);
+    (void)hipEventDestroy(join);
+    (void)hipEventDestroy(fork);
+  }
+  return bssm::launch_loglik_finalize(b, ws, stream);
+}
+}  // namespace
+extern "C" {
+
+int bssm_user_model_jit(const char* source, int32_t n_states) {
+  if (!source) return fail(BSSM_ERR_INVALID, "NULL argument");
+  if (n_states < 1 || n_states > 8) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 ... 8");
+  if (!have_device()) return no_device();
+  const std::string src(source);
+  const bool sde = src.find("BSSM_USER_SDE") != std::string::npos, nlg = src.find("BSSM_USER_NLG") != std::string::npos;
+  if (sde == nlg) return fail(BSSM_ERR_INVALID, "the snippet must define exactly one of BSSM_USER_NLG and BSSM_USER_SDE");
+  auto* jm = new JitModel();
+  jm->source = src; jm->n_states = n_states; jm->MP = bssm::pad_dim(n_states); jm->fn_id = sde ? bssm::FN_USER_SDE : bssm::FN_USER_NLG;
+  // the smallest workgroup-resident variant now: a snippet that does not compile fails HERE, with the compiler's log, and a first
+  // filter call of up to 512 particles finds its kernel ready
+  char name[160];
+  std::snprintf(name, sizeof name, "bssm::pf_wg_kernel<%d,%d,1,%d,%d,0,false>", jm->MP, jm->MP, jm->fn_id, kJitWgThreads);
+  std::string err;
+  if (!jit_kernel(*jm, name, &err)) { delete jm; return fail(BSSM_ERR_INVALID, err); }
+  std::lock_guard<std::mutex> lk(g_user_mu);
+  const int slot = bssm::register_user_launchers(jit_launch_wg, jit_launch_grid);
+  if (slot < 1) { delete jm; return fail(BSSM_ERR_UNSUPPORTED, "too many user models loaded"); }
+  g_jit[slot] = jm;
+  g_user_host[slot] = bssm::UserHostFns();
+  g_user_host[slot].has_tv = src.find("BSSM_USER_TV") != std::string::npos ? 1 : 0;
+  g_user_host[slot].jit = 1;
+  bssm::mark_user_slot_rows_only(slot);
   return slot;
 }
 

@@ -400,7 +400,8 @@ struct DeviceBatch {
   int alloc_step_workspace() {
     // (states of more than 16 dimensions -- pf_big.h -- have no other step shape than the row family: up to 8192 particles)
     if (fb.MP >= 32 && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "nsim above 16384 is not supported for states of more than 16 dimensions");
-    if ((bssm::opt().force_path == 3 || fb.MP >= 32) && bssm::row_filter_supported(fb)) {
+    if (bssm::user_slot_rows_only(fb.user_slot) && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process takes up to 16384 particles (more: bssm_user_model_build)");
+    if ((bssm::opt().force_path == 3 || fb.MP >= 32 || bssm::user_slot_rows_only(fb.user_slot)) && bssm::row_filter_supported(fb)) {
       HIP_TRY(ws.alloc(bssm::row_workspace_bytes(fb)));
       bssm::row_workspace_carve(fb, ws.p, &gws);
       return BSSM_OK;

@@ -124,6 +124,7 @@ struct UserHostFns {
   double (*H)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known) = nullptr;
   void (*R)(int t, const double* ktv, int rows, int cols, const double* alpha, const double* theta, const double* known, double* out) = nullptr;
   int has_tv = 0;  // the snippet was compiled with BSSM_USER_TV
+  int jit = 0;     // compiled in process (bssm_user_model_jit): device code only, no host entry points
 };
 struct FnModel {
   int id = 0, n = 0, m = 1;

@@ -6,8 +6,12 @@
 // sequential stream cannot be consumed by 65 536 lanes, so every draw here is
 // a pure function of (seed, filter stream, purpose, time, particle, draw#).
 #pragma once
+// (__HIPCC_RTC__: the in-process compile of a user model, api_filters.cpp bssm_user_model_jit -- hiprtc supplies the HIP runtime
+// declarations and the fixed-width integer types itself and has no host headers)
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "pf_math.h"
 

@@ -16,18 +16,25 @@
 // fixed-shape reductions/scans only (no floating-point atomics): results are bit-reproducible
 // run to run and independent of the number of GPUs a batch is sharded over.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <type_traits>
 #include <cstdio>
 #include <cstdlib>
+#endif
 
 #include "pf_device.h"
 #include "pf_canon.h"
 #include "pf_functors.h"
 #include "pf_kernels.h"
+#ifndef __HIPCC_RTC__
 #include "options.h"
 #include "tls_stream.h"
+#endif
 
 namespace bssm {
+
+template <class A, class B> struct bssm_same_type { static constexpr bool value = false; };
+template <class A> struct bssm_same_type<A, A> { static constexpr bool value = true; };
 
 // loglik[f] = sum_t llinc[f][t] in time order (the reference's accumulation order), -inf after a degenerate step.
 // (static: every translation unit that instantiates the step kernels carries its own copy, incl. run-time compiled
@@ -109,7 +116,7 @@ __device__ __forceinline__ void propagate(PT mt, const double (&a)[MP], const do
   const PT Tm = mt;
   const PT Rm = mt + MP * MP;
   const PT Cv = mt + MP * MP + MP * KP;
-  if constexpr ((BSSM_PROPAGATE_COLS) != 0 && MP >= 8 && std::is_same<PT, const cdbl*>::value) {
+  if constexpr ((BSSM_PROPAGATE_COLS) != 0 && MP >= 8 && bssm_same_type<PT, const cdbl*>::value) {
     double s[MP], q[MP];
 #pragma unroll
     for (int j = 0; j < MP; j++) { s[j] = 0.0; q[j] = 0.0; }
@@ -701,6 +708,7 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
   if (tid == 0 && b.loglik) b.loglik[f] = loglik;
 }
 
+#ifndef __HIPCC_RTC__   // host side: kernel selection and launch (the in-process compile of a user model takes the kernels only)
 // the functor kernel of one shape for the batch's sampler (0 bootstrap, 1 psi-APF, 2 EKF particle filter: MP <= 2 only)
 // the exact-size psi-APF variant: instantiated for the 1024-thread kernels at four particles per lane only
 template <int MP, int PPT, int FNV, int NTB>
@@ -823,6 +831,8 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(b.F), dim3(nt), lds, stream, b);
   return hipGetLastError();
 }
+
+#endif  // !__HIPCC_RTC__
 
 // ------------------------------------------------------------------------------------------
 // Multi-workgroup filter: one launch per time step
@@ -1273,8 +1283,11 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
 }
 
 }  // namespace bssm
+#ifndef __HIPCC_RTC__
 #include "pf_grid_v2.h"
+#endif
 #include "pf_row_step.h"
+#ifndef __HIPCC_RTC__
 #ifndef BSSM_USER_MODEL
 #include "pf_big.h"
 #endif
@@ -1507,3 +1520,4 @@ template <int MP> hipError_t launch_wg_mp(const FilterBatch& b, hipStream_t stre
 template <int MP> hipError_t launch_grid_mp(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing);
 
 }  // namespace bssm
+#endif  // !__HIPCC_RTC__

@@ -1,8 +1,10 @@
 // pf_kernels.h -- launch interface between the host library and the HIP kernels.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#endif
 
 namespace bssm {
 
@@ -41,10 +43,12 @@ struct FilterBatch {
 };
 
 // Largest N the workgroup-resident kernel can hold for a given padded state size
+#ifndef __HIPCC_RTC__
 int wg_filter_capacity(int MP);
 // One workgroup per filter, whole time loop inside the kernel.
 hipError_t launch_wg_filter(const FilterBatch& b, hipStream_t stream);
 
+#endif
 // Multi-workgroup filter for large N: workspace + per-time-step launches.
 // control block of the XCD-resident persistent step kernel (pf_grid_v2.h): word offsets
 constexpr int kPersistMaxTeams = 64;   // teams per XCD
@@ -76,8 +80,13 @@ struct GridWorkspace {
   int fw;
   double* wscale;      // [F][n+1][B]
   unsigned* persist;   // [kPersistWords] control block of the XCD-resident persistent kernel (zeroed before every launch)
+#ifdef __HIPCC_RTC__
+  void* side;          // (device view of the struct: same size and alignment)
+#else
   hipStream_t side;    // the library's side stream for the second launch sequence (one per host thread); null = none
+#endif
 };
+#ifndef __HIPCC_RTC__   // everything below is the host's launch interface
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out);
 void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
 // The ROW family (pf_row_step.h): a filter of at most 8192 particles spread over its rows of 64, one launch per time step,
@@ -115,6 +124,11 @@ const char* last_filter_kernel();
 typedef hipError_t (*user_wg_launcher_t)(const FilterBatch*, hipStream_t);
 typedef hipError_t (*user_grid_launcher_t)(const FilterBatch*, const GridWorkspace*, hipStream_t, StepTiming*);
 int register_user_launchers(user_wg_launcher_t wg, user_grid_launcher_t grid);
+// a slot whose only step shape is the row family (models compiled in process: api_filters.cpp bssm_user_model_jit)
+void mark_user_slot_rows_only(int slot);
+bool user_slot_rows_only(int slot);
+// log-likelihoods of a row-family run from its per-step increments (for launch loops outside pf_row_step.h)
+hipError_t launch_loglik_finalize(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream);
 
 // Ancestor back-trace (src/filter_smoother.cpp:5-18) on the particle-minor history, in place is not
 // possible in parallel, so it writes `out` [f][n+1][m][N].
@@ -194,5 +208,7 @@ hipError_t launch_mng_setup(const UngSetupDev& b, hipStream_t stream);
 hipError_t launch_transpose(const double* in, double* out, int rows, int cols, hipStream_t stream);
 hipError_t launch_calib_copy(const double* in, double* out, size_t n, hipStream_t stream);
 hipError_t launch_debug_math(int fn, const double* in, double* out, int n, hipStream_t stream);
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace bssm

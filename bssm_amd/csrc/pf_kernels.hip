@@ -959,6 +959,13 @@ struct UserLaunchers { user_wg_launcher_t wg; user_grid_launcher_t grid; };
 UserLaunchers g_user[64];
 int g_user_count = 0;
 }  // namespace
+static bool g_user_rows_only[64];
+void mark_user_slot_rows_only(int slot) { if (slot >= 1 && slot <= 63) g_user_rows_only[slot] = true; }
+bool user_slot_rows_only(int slot) { return slot >= 1 && slot <= 63 && g_user_rows_only[slot]; }
+hipError_t launch_loglik_finalize(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream) {
+  hipLaunchKernelGGL(loglik_finalize_kernel, dim3(b.F), dim3(64), 0, stream, b.loglik, ws.llinc, b.dead_at, b.n, b.F);
+  return hipGetLastError();
+}
 int register_user_launchers(user_wg_launcher_t wg, user_grid_launcher_t grid) {
   if (g_user_count >= 63) return -1;
   g_user[++g_user_count] = UserLaunchers{wg, grid};

@@ -11,8 +11,18 @@
 //   * exp uses a two-constant ln2 reduction and a degree-13 polynomial + v_ldexp_f64.
 // Coefficients: fdlibm (e_log.c, k_sin.c, k_cos.c), Sun Microsystems, freely redistributable.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+#ifndef INFINITY
+#define INFINITY (__builtin_huge_val())
+#endif
+#endif
 
 #include "pf_math_tables.h"
 

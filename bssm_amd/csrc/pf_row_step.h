@@ -219,6 +219,7 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   ROW_STAMP(10); ROW_STAMP(11);
 }
 
+#ifndef __HIPCC_RTC__   // host side
 // workspace of the row family: GridWorkspace with chunk = 64 (no coarse table, no weights scale factors, no control block)
 inline size_t row_workspace_bytes_impl(const FilterBatch& b) {
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -305,5 +306,7 @@ hipError_t launch_row_mk(const FilterBatch& b, const GridWorkspace& ws, hipStrea
 #endif
   return launch_row_loop(b, ws, stream, timing, kern, kern_init);
 }
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace bssm

@@ -569,7 +569,7 @@ def ssm_sde(y, example: str, theta, x0, positive: bool):
 
 
 def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_params=(), n_states=None, R=None,
-                 known_tv_params=None):
+                 known_tv_params=None, jit=False):
     """ssm_nlg (R/models.R:1472-1570) with USER functions.  The reference takes pointers to user C++ compiled at run time
     (Z, H, T, R, Z_gn, T_gn, a1, P1); here ``device_code`` is a snippet of ``__device__`` functions compiled by hipcc into
     the filter kernels (contract: bssm_amd/csrc/pf_functors.h -- ``#define BSSM_USER_NLG 1``, ``bssm_user_T``,
@@ -584,7 +584,9 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
     The bootstrap filter / smoother / bootstrap IS correction take up to 8 states (round 4), like the psi-APF and the EKF particle filter, with any ``R`` (n_states x n_etas matrix, or a function of theta) and the
     reference's state-dependent ``H_fn`` / ``R_fn`` as snippet functions (``BSSM_USER_HFN`` + ``bssm_user_H``,
     ``BSSM_USER_RFN`` + ``bssm_user_R``; src/model_ssm_nlg.h:12-13), which then replace ``H`` / ``R`` (``R`` still fixes
-    n_etas; for the psi-APF R(a) R(a)' must be positive definite on its non-zero diagonal)."""
+    n_etas; for the psi-APF R(a) R(a)' must be positive definite on its non-zero diagonal).
+    ``jit=True``: the snippet is compiled IN PROCESS by hiprtc (no hipcc, ~1-2 s per kernel variant on first use) instead of being
+    built into a shared library by hipcc (10-18 s); such a model runs the bootstrap filter / smoother / bootstrap IS correction only."""
     y = _f(np.asarray(y, dtype=float).reshape(-1))
     theta = np.asarray(theta, dtype=float)
     m = int(n_states or np.asarray(a1(theta) if callable(a1) else a1, dtype=float).size)
@@ -603,17 +605,17 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
                      n_states=m, n_etas=k, a1=num(a1, -1), P1=num(P1, (m, m)), H=H if callable(H) else float(H),
                      R_diag=None if R_diag is None else num(R_diag, -1), R=None if R is None else num(R, (m, k)),
                      known_tv_params=None if known_tv_params is None else np.asfortranarray(np.atleast_2d(np.asarray(known_tv_params, dtype=float))),
-                     x0=0.0, positive=False, L=0)
+                     x0=0.0, positive=False, L=0, user_jit=bool(jit))
 
 
-def ssm_sde_user(y, device_code: str, theta, x0, positive: bool):
+def ssm_sde_user(y, device_code: str, theta, x0, positive: bool, jit=False):
     """ssm_sde (R/models.R:1600-1647) with USER drift / diffusion / ddiffusion / observation log-density
     (``#define BSSM_USER_SDE 1``, ``bssm_user_drift``, ``bssm_user_diffusion``, ``bssm_user_ddiffusion``,
     ``bssm_user_log_obs``), compiled at run time."""
     y = _f(np.asarray(y, dtype=float).reshape(-1))
     return BssmModel(("ssm_sde", "bssm_model"), y=y, model_id=8, example="user", user_source=str(device_code),
                      theta=np.asarray(theta, dtype=float), known_params=np.zeros(0), x0=float(x0), positive=bool(positive),
-                     n_states=1, a1=np.zeros(1), L=0)
+                     n_states=1, a1=np.zeros(1), L=0, user_jit=bool(jit))
 
 
 def model_arrays(model: BssmModel) -> dict:

@@ -221,6 +221,14 @@ typedef struct bssm_fn_model {
  * (bssm_is_correction_nlg / _multi) and the chains (bssm_run_mcmc_fn; theta-dependent H / R / a1 / P1 through
  * bssm_mcmc_job.fn_update_fn) work for user models too. */
 int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity);
+/* The same snippet compiled IN PROCESS by hiprtc (the compiler as a library: no hipcc on the machine, no process, no shared library) --
+ * what Rcpp::sourceCpp is to the reference's session (R/cpp_example_models.R:762).  Returns the registry slot (>= 1) directly.  Only the
+ * kernel variant a call needs is compiled, the first time it is needed (1-2 s; the smallest workgroup-resident variant at once, so a
+ * snippet with an error fails here with the compiler's log); code objects are cached on disk by content hash.  Such a slot runs the
+ * BOOTSTRAP filter / smoother / bootstrap IS correction (up to 16384 particles); the psi-APF and the EKF particle filter evaluate the
+ * snippet on the host during their set-up and refuse a JIT slot with a message -- use bssm_user_model_build + _load for those.  Results
+ * are bit-identical to the hipcc-built library of the same snippet (same kernel templates, same arithmetic). */
+int bssm_user_model_jit(const char* source, int32_t n_states);
 int bssm_user_model_load(const char* lib_path);
 /* replaces _bssm_bsf_nlg (18 args, src/R_bootstrap_filter.cpp:461-504) / _bssm_bsf_smoother_nlg (:508-551):
  * outputs as bssm_bsf / bssm_bsf_smoother */

@@ -607,9 +607,17 @@ static void fn_identity(SEXP first_ptr, int n_states, int sde, bssm_fn_model* f)
   if (code == R_NilValue)
     Rf_error("this build of bssm runs ssm_nlg / ssm_sde models on the GPU: the model needs attr(., 'bssm_amd_model_id') or "
              "attr(., 'bssm_amd_device_code') on its first function pointer (see INTEGRATION.md)");
-  char path[4096];
-  check_rc(bssm_user_model_build(CHAR(STRING_ELT(code, 0)), n_states, path, (int32_t)sizeof(path)));  /* hipcc once, cached by content */
-  const int slot = bssm_user_model_load(path);
+  /* attr(., "bssm_amd_jit") = TRUE: compile the snippet in process (hiprtc; no hipcc, 0.2-0.3 s per kernel variant) -- for models that
+   * are only run through the bootstrap filter; the psi-APF / EKF particle filter need the hipcc-built library (host-side set-up) */
+  SEXP jit = Rf_getAttrib(first_ptr, Rf_install("bssm_amd_jit"));
+  int slot;
+  if (jit != R_NilValue && Rf_asLogical(jit) == 1) {
+    slot = bssm_user_model_jit(CHAR(STRING_ELT(code, 0)), n_states);
+  } else {
+    char path[4096];
+    check_rc(bssm_user_model_build(CHAR(STRING_ELT(code, 0)), n_states, path, (int32_t)sizeof(path)));  /* hipcc once, cached by content */
+    slot = bssm_user_model_load(path);
+  }
   if (slot < 1) Rf_error("%s", bssm_amd_last_error());
   f->model_id = sde ? BSSM_FN_USER_SDE : BSSM_FN_USER_NLG;
   f->user_slot = slot; f->n_states = n_states;

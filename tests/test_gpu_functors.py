@@ -1028,3 +1028,67 @@ def test_functor_models_on_the_round2_step_kernel(oracle, name, N, method):
     assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
     if "weights" in out and method != "psi":
         assert _rel(out["weights"], ref["weights"]) <= 1e-8
+
+
+# ---------------------------------------------------------------- user models compiled IN PROCESS (hiprtc): bssm_user_model_jit
+def test_user_model_compiled_in_process_equals_the_hipcc_built_library(oracle, tmp_path, monkeypatch):
+    """The reference compiles a user's model inside the session (Rcpp::sourceCpp, R/cpp_example_models.R:762).  jit=True compiles
+    the snippet's device functions with hiprtc -- no hipcc, no process, no shared library -- into exactly the kernel variant a call
+    needs: bootstrap filter / smoother / log-likelihood batches of the two-state growth model, the six-state model and the SDE model
+    give the SAME BITS as the hipcc-built library (same kernel templates), on the workgroup-resident shape and on the row family;
+    the psi-APF and the EKF particle filter, whose set-up runs the snippet on the host, refuse such a model with a message."""
+    import os
+    import time
+    from bssm_amd import _lib
+    from bssm_amd.plan import FilterPlan
+    monkeypatch.setenv("BSSM_AMD_USER_CACHE", str(tmp_path))   # an empty code-object cache: the compile is really cold
+    os.chmod(tmp_path, 0o700)
+    b, _ = MODELS["nlg_growth"]
+    th, kp = np.asarray(b["theta"]), np.asarray(b["known_params"])
+    mk = lambda jit: M.ssm_nlg_user(b["y"], USER_GROWTH, theta=th, known_params=kp, a1=kp[2:4], P1=np.diag(kp[4:6]), H=np.exp(th[0]),
+                                     R_diag=np.exp(th[1:3]), jit=jit)
+    t0 = time.perf_counter()
+    uj = mk(True)
+    first = F.bootstrap_filter(uj, 300, seed=4, return_indices=True)
+    cold = time.perf_counter() - t0
+    assert "[hiprtc]" in FilterPlan.last_kernel(), FilterPlan.last_kernel()
+    assert cold < 6.0, f"cold in-process build + first filter call took {cold:.1f} s"
+    print(f"in-process build of a two-state model + first filter call: {cold:.2f} s")
+    monkeypatch.delenv("BSSM_AMD_USER_CACHE")
+    uh = mk(False)
+    ref = oracle.fn_bsf_filter({**b, "L": 0}, 300, seed=4)
+    assert np.array_equal(first["indices"], ref["indices"]) and abs(first["logLik"] - ref["logLik"]) <= 1e-9 * b.n
+    for N, path in ((300, None), (1500, None), (5000, None), (3000, "row"), (12000, None)):
+        if path: monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+        oj = F.bootstrap_filter(uj, N, seed=6, return_indices=True)
+        kern = FilterPlan.last_kernel()
+        if path: monkeypatch.delenv("BSSM_AMD_FORCE_PATH")
+        assert "[hiprtc]" in kern, kern
+        if N <= 8192:   # (the hipcc-built library takes the round-1 step kernel beyond the row family's reach by default)
+            monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "row" if ("pf_row_step" in kern) else "wg")
+            oh = F.bootstrap_filter(uh, N, seed=6, return_indices=True)
+            monkeypatch.delenv("BSSM_AMD_FORCE_PATH")
+            for k in ("indices", "weights", "alpha"):
+                assert np.array_equal(oj[k], oh[k]), (N, k)
+            assert oj["logLik"] == oh["logLik"]
+        else:
+            r2 = oracle.fn_bsf_filter({**b, "L": 0}, N, seed=6)
+            assert np.array_equal(oj["indices"], r2["indices"]) and abs(oj["logLik"] - r2["logLik"]) <= 1e-9 * b.n
+    sj, sh = F.particle_smoother(uj, 700, method="bsf", seed=2), F.particle_smoother(uh, 700, method="bsf", seed=2)
+    assert np.array_equal(sj["alphahat"], sh["alphahat"]) and np.array_equal(sj["Vt"], sh["Vt"])
+    assert np.array_equal(F.logLik_batch(uj, 200, 40, method="bsf", seed=3), F.logLik_batch(uh, 200, 40, method="bsf", seed=3))
+    for method in ("psi", "ekf"):
+        with pytest.raises(_lib.BssmAmdError, match="compiled in process"):
+            F.particle_smoother(uj, 100, method=method, seed=1)
+    # an SDE model (Milstein sub-steps)
+    g, L = MODELS["sde_gbm"]
+    gj = M.ssm_sde_user(g["y"], USER_GBM, theta=g["theta"], x0=g["x0"], positive=True, jit=True)
+    gh = M.ssm_sde_user(g["y"], USER_GBM, theta=g["theta"], x0=g["x0"], positive=True)
+    a, c = F.bootstrap_filter(gj, 400, seed=3, return_indices=True, L=L), F.bootstrap_filter(gh, 400, seed=3, return_indices=True, L=L)
+    assert np.array_equal(a["indices"], c["indices"]) and a["logLik"] == c["logLik"]
+
+
+def test_user_model_in_process_compile_error_is_reported():
+    with pytest.raises(Exception, match="compiling the user model in process failed"):
+        bad = M.ssm_nlg_user(np.zeros(5), "#define BSSM_USER_NLG 1\nthis is not C++", theta=[0.0], a1=[0.0], P1=[[1.0]], H=1.0, R_diag=[1.0], jit=True)
+        F.bootstrap_filter(bad, 10, seed=1)
