@@ -861,6 +861,40 @@ def main():
         pm.close()
         _L.lib().bssm_amd_trim_cache()
 
+    if rank == 0 and world == 1 and not args.no_regime_b and not args.no_mng:
+        # ---- round 5: linear-state models of 17 ... 64 state dimensions (bsm_ng with a seasonal component of period 24 / 52:
+        # 25 / 53 states, R/models.R:995-997) on the fp64 matrix cores in fragment-native layout (bssm_amd/csrc/pf_big.h);
+        # roofline = the matrix peak by the flops the v_mfma_f64_16x16x4_f64 sequence executes on the padded tiles
+        try:
+            from bssm_amd import models as Mb
+            big = {}
+            for period in (24, 52):
+                Tb, mb = 200, 2 + period - 1
+                rngb = np.random.default_rng(1)
+                yb = rngb.poisson(np.exp(1.5 + 0.4 * np.sin(2 * np.pi * np.arange(Tb) / period))).astype(float)
+                mdl = Mb.bsm_ng(yb, sd_level=0.1, sd_slope=0.01, sd_seasonal=0.05, period=period, distribution="poisson",
+                                a1=np.r_[1.5, 0.0, np.zeros(period - 1)], P1=np.diag(np.r_[1.0, 0.01, np.full(period - 1, 0.05)]))
+                MPb = 32 if mb <= 32 else 64
+                Nb, Fb = 1024, 256
+                pbg = FilterPlan(mdl, Nb, method="bsf", n_rep=Fb, keep_history=False)
+                pbg.run(5, hip_stream=stream); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for s in range(3):
+                    pbg.run(6 + s, hip_stream=stream)
+                torch.cuda.synchronize()
+                eb = (time.perf_counter() - t0) / 3
+                flops = 2.0 * MPb * ((mb + 3) // 4 * 4 + 4)   # [T R] tile: MP rows x (m, k = 3 rounded up to fours) columns
+                psb = float(Nb) * Fb * Tb / eb
+                big["period_%d" % period] = {"workload": "bsm_ng(period = %d): m = %d states, k = 3, T = %d, bootstrap filter, N = %d x %d filters, log-likelihood only"
+                                                         % (period, mb, Tb, Nb, Fb),
+                                             "value": psb, "unit": "particle-steps/s", "ms_per_pass": eb * 1e3, "kernel": pbg.last_kernel(),
+                                             "roofline": {"bound": "mfma", "achieved": psb * flops / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                                          "frac": psb * flops / 78.6e12, "flops_per_particle_step_on_the_tiles": flops}}
+                pbg.close()
+            out["big_states"] = big
+        except Exception as e:  # noqa: BLE001
+            out["big_states"] = {"error": repr(e)[:200]}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only: the other ranks would idle behind it
         # ---- CPU baseline: the oracle (reference loop structure, one thread per filter) on a bounded sample
         from bssm_amd import models as M

@@ -48,13 +48,13 @@ struct CanonPrefix {
   __device__ __forceinline__ double q(const int e) const {  // e wave-uniform
     double r = lane_broadcast(Q[0], e & 63);
 #pragma unroll
-    for (int k = 1; k < NP; k++) { const double rk = lane_broadcast(Q[k], e & 63); r = (e >> 6) == k ? rk : r; }
+    for (int k = 1; k < NP; k++) { if (B > 64 * k) { const double rk = lane_broadcast(Q[k], e & 63); r = (e >> 6) == k ? rk : r; } }  // (wave-uniform: slots a filter does not have cost a scalar branch)
     return r;
   }
   __device__ __forceinline__ double is(const int e) const {
     double r = lane_broadcast(I[0], e & 63);
 #pragma unroll
-    for (int k = 1; k < NP; k++) { const double rk = lane_broadcast(I[k], e & 63); r = (e >> 6) == k ? rk : r; }
+    for (int k = 1; k < NP; k++) { if (B > 64 * k) { const double rk = lane_broadcast(I[k], e & 63); r = (e >> 6) == k ? rk : r; } }
     return r;
   }
 };
