@@ -33,8 +33,8 @@ class FnModel(C.Structure):
                 ("known_params", c_double_p), ("n_known", C.c_int32), ("x0", C.c_double), ("positive", C.c_int32),
                 ("L", C.c_int32), ("user_slot", C.c_int32), ("n_states", C.c_int32), ("H", C.c_double),
                 ("R_diag", C.c_double * 2), ("a1", C.c_double * 2), ("P1", C.c_double * 4),
-                ("use_ext", C.c_int32), ("n_etas", C.c_int32), ("R_ext", C.c_double * 64), ("a1_ext", C.c_double * 8),
-                ("P1_ext", C.c_double * 64), ("known_tv_params", c_double_p), ("tv_rows", C.c_int32), ("tv_cols", C.c_int32)]
+                ("use_ext", C.c_int32), ("n_etas", C.c_int32), ("R_ext", C.c_double * 256), ("a1_ext", C.c_double * 16),
+                ("P1_ext", C.c_double * 256), ("known_tv_params", c_double_p), ("tv_rows", C.c_int32), ("tv_cols", C.c_int32)]
 
 
 def pack_fn_model(model, L=None):

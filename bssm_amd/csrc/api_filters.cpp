@@ -247,7 +247,7 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   if (mod->n_theta < need_theta[id] || mod->n_known < need_known[id]) return fail(BSSM_ERR_INVALID, "theta / known_params too short for this model");
   if (mod->n_theta > 8 || mod->n_known > 8) return fail(BSSM_ERR_INVALID, "at most 8 theta / known_params");
   if (user && mod->user_slot < 1) return fail(BSSM_ERR_INVALID, "user-defined model without a loaded library (bssm_user_model_load)");
-  if (id == bssm::FN_USER_NLG && (mod->n_states < 1 || mod->n_states > 8)) return fail(BSSM_ERR_UNSUPPORTED, "user-defined ssm_nlg models: n_states must be 1 ... 8");
+  if (id == bssm::FN_USER_NLG && (mod->n_states < 1 || mod->n_states > 16)) return fail(BSSM_ERR_UNSUPPORTED, "user-defined ssm_nlg models: n_states must be 1 ... 16");
   if (id == bssm::FN_USER_NLG && mod->n_states > 2 && !mod->use_ext) return fail(BSSM_ERR_INVALID, "user-defined ssm_nlg model with more than 2 states: fill R_ext / a1_ext / P1_ext and set use_ext");
   if (id == bssm::FN_USER_NLG && !(mod->H > 0)) return fail(BSSM_ERR_INVALID, "user-defined ssm_nlg model: H must be positive");
   const bool ext = id == bssm::FN_USER_NLG && mod->use_ext;
@@ -289,32 +289,33 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   if (id == bssm::FN_USER_NLG) {
     // inverse lower Cholesky factor of R R' on its non-zero diagonal (the psi-APF's transition-density ratio, pf_functors.h);
     // NaN when R R' is not positive definite there -- only the psi-APF reads it, and its host set-up then fails loudly
-    double RR[64] = {0}, Lc[64] = {0}, Li[64] = {0};
+    constexpr int S = 16;  // stride of the work arrays: the largest state dimension of a user model
+    double RR[S * S] = {0}, Lc[S * S] = {0}, Li[S * S] = {0};
     const int kk = ext ? mod->n_etas : m;
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) {
       double acc = 0;
       for (int q = 0; q < kk; q++) acc += fp[bssm::FP_RMAT + i + MP * q] * fp[bssm::FP_RMAT + j + MP * q];
-      RR[i + 8 * j] = acc;
+      RR[i + S * j] = acc;
     }
-    int nz[8], cnt = 0;
-    for (int j = 0; j < m; j++) if (RR[j + 8 * j] > 2.220446049250313e-16) nz[cnt++] = j;
+    int nz[S], cnt = 0;
+    for (int j = 0; j < m; j++) if (RR[j + S * j] > 2.220446049250313e-16) nz[cnt++] = j;
     bool pd = true;
     for (int a = 0; a < cnt && pd; a++)
       for (int b2 = 0; b2 <= a; b2++) {
-        double v = RR[nz[a] + 8 * nz[b2]];
-        for (int q = 0; q < b2; q++) v -= Lc[a + 8 * q] * Lc[b2 + 8 * q];
-        if (a == b2) { if (!(v > 0)) { pd = false; break; } Lc[a + 8 * a] = std::sqrt(v); }
-        else Lc[a + 8 * b2] = v / Lc[b2 + 8 * b2];
+        double v = RR[nz[a] + S * nz[b2]];
+        for (int q = 0; q < b2; q++) v -= Lc[a + S * q] * Lc[b2 + S * q];
+        if (a == b2) { if (!(v > 0)) { pd = false; break; } Lc[a + S * a] = std::sqrt(v); }
+        else Lc[a + S * b2] = v / Lc[b2 + S * b2];
       }
     for (int c = 0; c < cnt && pd; c++) {  // forward substitution column by column: Lc Li = I
       for (int a = c; a < cnt; a++) {
         double v = a == c ? 1.0 : 0.0;
-        for (int q = c; q < a; q++) v -= Lc[a + 8 * q] * Li[q + 8 * c];
-        Li[a + 8 * c] = v / Lc[a + 8 * a];
+        for (int q = c; q < a; q++) v -= Lc[a + S * q] * Li[q + S * c];
+        Li[a + S * c] = v / Lc[a + S * a];
       }
     }
     for (int a = 0; a < cnt; a++) for (int c = 0; c <= a; c++)
-      fp[bssm::FP_RLINV + nz[a] + MP * nz[c]] = pd ? Li[a + 8 * c] : std::nan("");
+      fp[bssm::FP_RLINV + nz[a] + MP * nz[c]] = pd ? Li[a + S * c] : std::nan("");
     if (mod->known_tv_params && mod->tv_rows > 0 && mod->tv_cols > 0 && have_device()) {  // BSSM_USER_TV snippets: matrix on the device
       double* dtv = nullptr;
       if (int rc = device_known_tv(mod->known_tv_params, mod->tv_rows, mod->tv_cols, &dtv)) return rc;
@@ -354,24 +355,25 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
     double dmax = mod->P1_ext[0];
     for (int q = 1; q < m; q++) dmax = std::max(dmax, mod->P1_ext[q + m * q]);
     const double thr = std::max(eps, eps * m * dmax);
-    bool nz[8];
-    double Lf[64] = {0};
+    constexpr int S = 16;
+    bool nz[S];
+    double Lf[S * S] = {0};
     for (int j = 0; j < m; j++) nz[j] = mod->P1_ext[j + m * j] > thr;
     for (int j = 0; j < m; j++) {
       ft->init[j] = mod->a1_ext[j];
       if (!nz[j]) continue;
       double d = mod->P1_ext[j + m * j];
-      for (int q = 0; q < j; q++) d -= Lf[j + 8 * q] * Lf[j + 8 * q];
+      for (int q = 0; q < j; q++) d -= Lf[j + S * q] * Lf[j + S * q];
       if (!(d > 0)) return fail(BSSM_ERR_INVALID, "P1 is not positive semi-definite");
-      Lf[j + 8 * j] = std::sqrt(d);
+      Lf[j + S * j] = std::sqrt(d);
       for (int i = j + 1; i < m; i++) {
         if (!nz[i]) continue;
         double v = mod->P1_ext[i + m * j];
-        for (int q = 0; q < j; q++) v -= Lf[i + 8 * q] * Lf[j + 8 * q];
-        Lf[i + 8 * j] = v / Lf[j + 8 * j];
+        for (int q = 0; q < j; q++) v -= Lf[i + S * q] * Lf[j + S * q];
+        Lf[i + S * j] = v / Lf[j + S * j];
       }
     }
-    for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) ft->init[MP + j + MP * c] = Lf[j + 8 * c];
+    for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) ft->init[MP + j + MP * c] = Lf[j + S * c];
     return BSSM_OK;
   }
   if (id == bssm::FN_USER_NLG && m == 2 && (P1[1] != 0.0 || P1[2] != 0.0)) {  // a full 2 x 2 prior covariance
@@ -815,7 +817,7 @@ extern "C" {
 
 int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, int32_t lib_path_capacity) {
   if (!source || !lib_path || lib_path_capacity < 16) return fail(BSSM_ERR_INVALID, "NULL argument");
-  if (n_states < 1 || n_states > 8) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 ... 8");
+  if (n_states < 1 || n_states > 16) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 ... 16");
   const std::string dir = library_dir();
   const std::string& env_cache = bssm::opt().user_cache;
   const bool env = !env_cache.empty();
@@ -900,10 +902,13 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
     if (hw > 0) jobs = std::max(1, std::min(6, (int)hw / ranks));
     if (const char* ej = std::getenv("BSSM_AMD_USER_BUILD_JOBS")) jobs = std::max(1, std::min(6, std::atoi(ej)));
   }
+  // (more than 8 states: the bootstrap sampler only -- parts 0 and 3; the psi-APF / EKF particle filter of a user model end at 8 states)
+  const bool bsf_only = n_states > 8;
   std::string cmd = "( ", objs, logs;
   for (int part = 0; part < 6; part++) {
+    if (bsf_only && part % 3 != 0) continue;
     const std::string obj = tmp + ".p" + std::to_string(part) + ".o", plog = log_tmp + ".p" + std::to_string(part);
-    cmd += common + "-DBSSM_USER_PART=" + std::to_string(part) + " -c '" + dir + "/csrc/user_model_tu.hip' -o '" + obj + "' > '" + plog + "' 2>&1 & ";
+    cmd += common + (bsf_only ? "-DBSSM_USER_BSF_ONLY=1 " : "") + "-DBSSM_USER_PART=" + std::to_string(part) + " -c '" + dir + "/csrc/user_model_tu.hip' -o '" + obj + "' > '" + plog + "' 2>&1 & ";
     if ((part + 1) % jobs == 0 && part + 1 < 6) cmd += "wait ; ";
     objs += " '" + obj + "'";
     logs += " '" + plog + "'";
@@ -1177,7 +1182,7 @@ extern "C" {
 
 int bssm_user_model_jit(const char* source, int32_t n_states) {
   if (!source) return fail(BSSM_ERR_INVALID, "NULL argument");
-  if (n_states < 1 || n_states > 8) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 ... 8");
+  if (n_states < 1 || n_states > 16) return fail(BSSM_ERR_UNSUPPORTED, "user-defined models: n_states must be 1 ... 16");
   if (!have_device()) return no_device();
   const std::string src(source);
   const bool sde = src.find("BSSM_USER_SDE") != std::string::npos, nlg = src.find("BSSM_USER_NLG") != std::string::npos;

@@ -396,7 +396,7 @@ __device__ __forceinline__ double weight_dispatch(const FilterBatch& b, const do
 // fn_kernel_id<MP>(): the model id the functor kernels of this translation unit are compiled for (FN_ANY: dispatch per
 // call) -- a user-model library holds ONE model, and the only shipped two-state model is nlg_growth.
 #ifdef BSSM_USER_MODEL
-constexpr int FN_MP_MAX = 8;   // (every sampler up to 8 states since round 4)
+constexpr int FN_MP_MAX = BSSM_USER_M > 8 ? 16 : 8;   // (every sampler up to 8 states since round 4; the bootstrap filter up to 16 since round 5)
 #if defined(BSSM_USER_NLG) && !defined(BSSM_USER_SDE)
 template <int MP> constexpr int fn_kernel_id() { return FN_USER_NLG; }
 #elif defined(BSSM_USER_SDE) && !defined(BSSM_USER_NLG)

@@ -50,9 +50,9 @@ enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, 
        FP_M = 25,
        // user models with BSSM_USER_TV: the known_tv_params matrix (device pointer as a bit pattern; rows, columns)
        FP_TVPTR = 26, FP_TVROWS = 27, FP_TVCOLS = 28,
-       // full R (MP x MP, column-major, zero-padded; user models: up to 8 x 8 since round 4) and the inverse lower factor of
+       // full R (MP x MP, column-major, zero-padded; user models: up to 16 x 16 since round 5) and the inverse lower factor of
        // R R' for the psi-APF's transition-density ratio with any constant R (MP x MP, column-major)
-       FP_RMAT = 30, FP_RLINV = 94, FP_SIZE = 158 };
+       FP_RMAT = 30, FP_RLINV = 30 + 256, FP_SIZE = 30 + 512 };  // (16 x 16 blocks since round 5: user models of up to 16 states for the bootstrap filter)
 
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_TV)
 template <class PF>
@@ -218,10 +218,8 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
 #pragma unroll
       for (int j = 0; j < MP; j++) x[j] = 0.0;
       bssm_user_T(BSSM_UTV(fp, (int)t) &a[0], fp + FP_THETA, fp + FP_KNOWN, &x[0]);
-      double Rm[MP * MP];
-#pragma unroll
-      for (int q = 0; q < MP * MP; q++) Rm[q] = fp[FP_RMAT + q];
 #ifdef BSSM_USER_RFN
+      double Rm[MP * MP];
       {
         constexpr int mu = BSSM_USER_NSTATES <= MP ? BSSM_USER_NSTATES : MP;  // states of the user's model (3 pads to MP = 4)
         double Ru[MP * MP];
@@ -233,6 +231,8 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
 #pragma unroll
           for (int j = 0; j < MP; j++) Rm[j + MP * c] = j < mu ? Ru[j + mu * c] : 0.0;  // columns >= k were left zero
       }
+#else
+      const double* __restrict__ Rm = fp + FP_RMAT;  // (constant R: read from the parameter block where it is used -- wave-uniform loads)
 #endif
 #pragma unroll
       for (int j = 0; j < MP; j++) {

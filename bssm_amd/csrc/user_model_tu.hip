@@ -21,7 +21,7 @@ struct bssm_user_tv { int t; const double* known_tv; int rows, cols; };
 #include BSSM_USER_SNIPPET
 
 #ifndef BSSM_USER_M
-#error "BSSM_USER_M (padded state dimension: 1, 2, 4 or 8) must be defined"
+#error "BSSM_USER_M (padded state dimension: 1, 2, 4, 8 or 16) must be defined"
 #endif
 #ifndef BSSM_USER_NSTATES
 #define BSSM_USER_NSTATES BSSM_USER_M   // states of the model (3 runs in the kernels padded to 4)
@@ -92,6 +92,15 @@ extern "C" hipError_t bssm_user_launch_grid_p0(const bssm::FilterBatch*, const b
 extern "C" hipError_t bssm_user_launch_wg_p2(const bssm::FilterBatch*, hipStream_t);
 extern "C" hipError_t bssm_user_launch_grid_p1(const bssm::FilterBatch*, const bssm::GridWorkspace*, hipStream_t, bssm::StepTiming*);
 extern "C" hipError_t bssm_user_launch_grid_p2(const bssm::FilterBatch*, const bssm::GridWorkspace*, hipStream_t, bssm::StepTiming*);
+#ifdef BSSM_USER_BSF_ONLY   // more than 8 states: only the bootstrap sampler's parts (0 and 3) are built
+extern "C" hipError_t bssm_user_launch_wg(const bssm::FilterBatch* b, hipStream_t stream) {
+  return b->psi == 0 ? bssm_user_launch_wg_p0(b, stream) : hipErrorInvalidValue;
+}
+extern "C" hipError_t bssm_user_launch_grid(const bssm::FilterBatch* b, const bssm::GridWorkspace* ws, hipStream_t stream,
+                                            bssm::StepTiming* timing) {
+  return b->psi == 0 ? bssm_user_launch_grid_p0(b, ws, stream, timing) : hipErrorInvalidValue;
+}
+#else
 extern "C" hipError_t bssm_user_launch_wg(const bssm::FilterBatch* b, hipStream_t stream) {
   return b->psi == 0 ? bssm_user_launch_wg_p0(b, stream) : (b->psi == 1 ? bssm_user_launch_wg_p1(b, stream) : bssm_user_launch_wg_p2(b, stream));
 }
@@ -100,6 +109,7 @@ extern "C" hipError_t bssm_user_launch_grid(const bssm::FilterBatch* b, const bs
   return b->psi == 0 ? bssm_user_launch_grid_p0(b, ws, stream, timing)
                      : (b->psi == 1 ? bssm_user_launch_grid_p1(b, ws, stream, timing) : bssm_user_launch_grid_p2(b, ws, stream, timing));
 }
+#endif
 #endif
 
 #if !defined(BSSM_USER_PART) || BSSM_USER_PART == 0

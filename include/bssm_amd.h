@@ -25,7 +25,7 @@
  *    ("Any number of GPUs" is verified on logical shards of ONE physical GPU and with two gloo ranks: no multi-GPU
  *    node has been available to this build.)  Results for a given seed are not reproducible ACROSS library versions
  *    whose bssm_amd_version() names another random-stream format or normalisation.
- *  - Limits: state dimension m <= 64, observation series p <= 16, user-defined models <= 8 states; particles up to
+ *  - Limits: state dimension m <= 64, observation series p <= 16, user-defined models <= 16 states (psi-APF / EKF: 8); particles up to
  *    524 288 for m <= 16 and up to 8192 for 17 <= m <= 64.  Beyond them the entry points refuse with a message.
  */
 #ifndef BSSM_AMD_H
@@ -185,7 +185,7 @@ typedef struct bssm_fn_model {
   int32_t L;                  /* ssm_sde: 2^L Milstein sub-steps per unit time */
   /* ---- user-defined models only (model_id BSSM_FN_USER_NLG / BSSM_FN_USER_SDE); ignored for the built-in ids */
   int32_t user_slot;          /* from bssm_user_model_load */
-  int32_t n_states;           /* ssm_nlg: 1 ... 8 (every sampler) */
+  int32_t n_states;           /* ssm_nlg: 1 ... 16 for the bootstrap filter / smoother / bootstrap IS correction (round 5), 1 ... 8 for the psi-APF and the EKF particle filter */
   double H;                   /* ssm_nlg: observation sd (the value H_fn returns; unused when the snippet defines BSSM_USER_HFN) */
   double R_diag[2];           /* ssm_nlg: diagonal of R_fn's value (n_states <= 2, diagonal R) */
   double a1[2], P1[4];        /* ssm_nlg: a1_fn, P1_fn values (P1 column-major, n_states x n_states), n_states <= 2 */
@@ -193,9 +193,9 @@ typedef struct bssm_fn_model {
    * R_diag / a1 / P1 when use_ext != 0; required for n_states > 2 */
   int32_t use_ext;
   int32_t n_etas;             /* columns of R, 1 ... n_states */
-  double R_ext[64];           /* R_fn's value, n_states x n_etas column-major (the bootstrap kernels call the snippet's
+  double R_ext[256];          /* R_fn's value, n_states x n_etas column-major (the bootstrap kernels call the snippet's
                                  bssm_user_R instead when it defines BSSM_USER_RFN) */
-  double a1_ext[8], P1_ext[64]; /* a1_fn, P1_fn values; P1 any positive semi-definite n_states x n_states matrix */
+  double a1_ext[16], P1_ext[256]; /* a1_fn, P1_fn values; P1 any positive semi-definite n_states x n_states matrix */
   /* ---- the reference's `known_tv_params` (R/models.R:1507, 1546; every model function receives it together with the
    * time index, src/model_ssm_nlg.h:10-21): any matrix, column-major, tv_rows x tv_cols.  Read by user models whose
    * snippet defines BSSM_USER_TV (its functions then take a leading `const bssm_user_tv&`); NULL / 0 / 0 otherwise */
@@ -214,7 +214,7 @@ typedef struct bssm_fn_model {
  * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS).  The psi-APF and the EKF particle filter take up to 8 states (late round 4), any constant
  * n_states x n_etas matrix R whose R R' is positive definite on its non-zero diagonal, and any positive semi-definite P1
  * (round 3); so does the EKF particle filter (1- and 2-state models: constant diagonal R).  Snippets that define
- * BSSM_USER_TV receive the time index and known_tv_params in every function.  The bootstrap filter / smoother / bootstrap IS correction take up to 8 states, any n_states x n_etas matrix
+ * BSSM_USER_TV receive the time index and known_tv_params in every function.  The bootstrap filter / smoother / bootstrap IS correction take up to 16 states (round 5), any n_states x n_etas matrix
  * R and the reference's state-dependent H_fn / R_fn (snippet functions bssm_user_H / bssm_user_R); so do the psi-APF and the
  * EKF particle filter (the approximating model then has H_t = H_fn(mode_t), R_t = R_fn(mode_t), src/model_ssm_nlg.cpp:100-107;
  * R(a) R(a)' must be positive definite on its non-zero diagonal, since the psi weight contains the transition density).  IS post-correction

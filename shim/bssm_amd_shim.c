@@ -632,9 +632,9 @@ static void fn_identity(SEXP first_ptr, int n_states, int sde, bssm_fn_model* f)
     if (Rm != R_NilValue || n_states > 2) {
       f->use_ext = 1;
       f->n_etas = Rm != R_NilValue ? Rf_length(Rm) / n_states : n_states;
-      read_numbers(Rm, f->R_ext, 64);
-      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_a1")), f->a1_ext, 8);
-      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_P1")), f->P1_ext, 64);
+      read_numbers(Rm, f->R_ext, 256);
+      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_a1")), f->a1_ext, 16);
+      read_numbers(Rf_getAttrib(first_ptr, Rf_install("bssm_amd_P1")), f->P1_ext, 256);
     }
   }
 }

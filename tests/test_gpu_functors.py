@@ -972,8 +972,8 @@ def test_user_model_six_states_ekf_particle_filter_against_the_general_oracle(or
     mean, cov = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
     assert _rel(out["alphahat"], mean.T[:y.size]) <= 1e-8
     if path == "wg":
-        with pytest.raises(ValueError, match="1 ... 8"):
-            M.ssm_nlg_user(np.zeros(5), USER_SIX_J, theta=th, a1=np.zeros(9), P1=np.eye(9), H=0.6, n_states=9, R=np.eye(9))
+        with pytest.raises(ValueError, match="1 ... 16"):
+            M.ssm_nlg_user(np.zeros(5), USER_SIX_J, theta=th, a1=np.zeros(17), P1=np.eye(17), H=0.6, n_states=17, R=np.eye(17))
 
 
 @pytest.mark.parametrize("dev", ["0", "1"])
@@ -1092,3 +1092,73 @@ def test_user_model_in_process_compile_error_is_reported():
     with pytest.raises(Exception, match="compiling the user model in process failed"):
         bad = M.ssm_nlg_user(np.zeros(5), "#define BSSM_USER_NLG 1\nthis is not C++", theta=[0.0], a1=[0.0], P1=[[1.0]], H=1.0, R_diag=[1.0], jit=True)
         F.bootstrap_filter(bad, 10, seed=1)
+
+
+# ---------------------------------------------------------------- user models of 9 ... 16 states (round 5): bootstrap paths
+USER_TWELVE = r"""
+#define BSSM_USER_NLG 1
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  for (int j = 0; j < 11; j++) out[j] = (0.5 + 0.03 * j) * a[j] + 0.1 * sin(a[j + 1]);
+  out[11] = th[0] * a[11] + 0.05 * tanh(a[0]);
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) {
+  double z = 0.0;
+  for (int j = 0; j < 12; j += 3) z += a[j];
+  return z + 0.1 * a[7] * a[7];
+}
+"""
+
+
+def _twelve_case(seed=21, n=24):
+    rng = np.random.default_rng(seed)
+    m, k = 12, 5
+    th = np.array([0.8]); kn = np.zeros(0)
+    Rm = np.zeros((m, k))
+    for j in range(m): Rm[j, j % k] = 0.1 + 0.02 * j
+    Rm[3, 1] = -0.05; Rm[10, 4] = 0.07
+    Z = lambda t, a, th_, kn_: a[0] + a[3] + a[6] + a[9] + 0.1 * a[7] ** 2
+    H = lambda t, a, th_, kn_: 0.5
+    T = lambda t, a, th_, kn_: np.array([(0.5 + 0.03 * j) * a[j] + 0.1 * np.sin(a[j + 1]) for j in range(11)] + [th_[0] * a[11] + 0.05 * np.tanh(a[0])])
+    R = lambda t, a, th_, kn_: Rm
+    a = 0.3 * rng.normal(size=m); y = np.zeros(n)
+    for t in range(n):
+        y[t] = Z(t, a, th, kn) + 0.5 * rng.normal()
+        a = T(t, a, th, kn) + Rm @ rng.normal(size=k)
+    y[5] = np.nan
+    a1 = 0.1 * np.arange(m) - 0.5
+    P1 = np.diag(0.05 + 0.02 * np.arange(m)); P1[11, 11] = 0.0; P1[0, 4] = P1[4, 0] = 0.03
+    return dict(y=y, m=m, k=k, th=th, kn=kn, Rm=Rm, Z=Z, H=H, T=T, R=R, a1=a1, P1=P1, n=n)
+
+
+@pytest.mark.parametrize("path,N", [("wg", 300), ("row", 2000), ("grid", 20000)])
+def test_user_model_twelve_states_bootstrap_against_the_general_oracle(oracle, monkeypatch, path, N):
+    """A user model with TWELVE states and a constant 12 x 5 matrix R (round 5: the MP = 16 functor kernels; the reference's
+    function-pointer interface has no state limit, src/model_ssm_nlg.h:10-21): bootstrap filter and smoother against
+    orc_nlg_general_bsf_filter on the workgroup-resident shape, the row family and the round-1 step kernel (above 16 384 particles)
+    -- ancestors identical, log-likelihood to 1e-9 n; the hiprtc-compiled model gives the bits of the hipcc-built one; the psi-APF
+    and the EKF particle filter of user models end at eight states and say so."""
+    c = _twelve_case()
+    mk = lambda jit: M.ssm_nlg_user(c["y"], USER_TWELVE, theta=c["th"], known_params=c["kn"], a1=c["a1"], P1=c["P1"], H=0.5,
+                                     n_states=c["m"], R=c["Rm"], jit=jit)
+    u = mk(False)
+    if path != "grid": monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    out = F.bootstrap_filter(u, N, seed=7, return_indices=True)
+    ref = oracle.nlg_general_bsf_filter(c["y"], c["m"], c["k"], c["th"], c["kn"], c["a1"], c["P1"], c["Z"], c["H"], c["T"], c["R"], N, seed=7)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * c["n"]
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    if path == "grid": return
+    sm = F.particle_smoother(u, N, method="bsf", seed=7)
+    ah, Vt = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert _rel(sm["alphahat"], ah.T[:c["n"]]) <= 1e-8 and _rel(sm["Vt"], Vt[:, :, :c["n"]]) <= 1e-7
+    oj = F.bootstrap_filter(mk(True), N, seed=7, return_indices=True)
+    for key in ("indices", "weights", "alpha"):
+        assert np.array_equal(oj[key], out[key]), key
+    assert oj["logLik"] == out["logLik"]
+    if path == "wg":
+        for method in ("psi", "ekf"):
+            with pytest.raises(Exception, match="at most 8 states"):
+                F.particle_smoother(u, 100, method=method, seed=7)
+        with pytest.raises(Exception, match="16"):
+            M.ssm_nlg_user(np.zeros(4), USER_TWELVE, theta=c["th"], a1=np.zeros(17), P1=np.eye(17), H=0.5, n_states=17, R=np.eye(17))
