@@ -398,7 +398,7 @@ struct DeviceBatch {
   // workspace of the one-launch-per-step families: the row family when BSSM_AMD_FORCE_PATH=row asks for it and the batch has such
   // kernels (pf_row_step.h; otherwise it is reached through the tail split of a post-correction chunk only), else the step kernels
   int alloc_step_workspace() {
-    // (states of more than 16 dimensions -- pf_big.h -- have no other step shape than the row family: up to 8192 particles)
+    // (states of more than 16 dimensions -- pf_big.h -- have no other step shape than the row family: up to 16 384 particles)
     if (fb.MP >= 32 && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "nsim above 16384 is not supported for states of more than 16 dimensions");
     if (bssm::user_slot_rows_only(fb.user_slot) && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process takes up to 16384 particles (more: bssm_user_model_build)");
     if ((bssm::opt().force_path == 3 || fb.MP >= 32 || bssm::user_slot_rows_only(fb.user_slot)) && bssm::row_filter_supported(fb)) {
@@ -408,7 +408,7 @@ struct DeviceBatch {
     }
     int B, chunk;
     const size_t bytes = bssm::grid_workspace_bytes(fb, &B, &chunk);
-    if (B > 256) return fail(BSSM_ERR_UNSUPPORTED, "nsim too large for the grid filter (max 524288)");
+    if (B > 256) return fail(BSSM_ERR_UNSUPPORTED, "nsim too large for the step kernels (max 262144; the reference's front-end stops at 1e5)");
     HIP_TRY(ws.alloc(bytes));
     bssm::grid_workspace_carve(fb, ws.p, &gws);
     return BSSM_OK;

@@ -59,7 +59,6 @@ Options read_env() {
   if (const char* e = std::getenv("BSSM_AMD_TAIL_MAX_EIGHTHS")) o.tail_max_eighths = std::max(0, std::min(8, std::atoi(e)));
   if (const char* e = std::getenv("BSSM_AMD_FORCE_PATH")) o.force_path = !std::strcmp(e, "wg") ? 1 : (!std::strcmp(e, "grid") ? 2 : (!std::strcmp(e, "row") ? 3 : 0));
   o.grid_ppt = env_int("BSSM_AMD_GRID_PPT", 0);
-  o.grid_v2 = env_tri("BSSM_AMD_GRID_V2");
   o.grid_v2_wx = env_tri("BSSM_AMD_GRID_V2_WX");
   o.grid_v2_exact = env_tri("BSSM_AMD_GRID_V2_EXACT");
   o.grid_streams = env_int("BSSM_AMD_GRID_STREAMS", 0);

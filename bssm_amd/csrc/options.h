@@ -5,7 +5,7 @@
 //                   BSSM_AMD_TRACE, BSSM_AMD_TAIL_SPLIT (opt-in: a sparsely filled last round of a post-correction chunk through
 //                   the step kernels -- faster, but a draw's result then depends on the shard layout; default off)
 //   test / tuning   kernel-shape and set-up choices the parity tests and the tuning scripts flip between calls:
-//                   BSSM_AMD_FORCE_PATH, BSSM_AMD_GRID_PPT, BSSM_AMD_GRID_V2, BSSM_AMD_GRID_V2_WX, BSSM_AMD_GRID_V2_EXACT,
+//                   BSSM_AMD_FORCE_PATH, BSSM_AMD_GRID_PPT, BSSM_AMD_GRID_V2_WX, BSSM_AMD_GRID_V2_EXACT,
 //                   BSSM_AMD_GRID_STREAMS, BSSM_AMD_XCD_REMAP, BSSM_AMD_WG_WIDE, BSSM_AMD_DEVICE_SETUP, BSSM_AMD_GENERIC_SETUP,
 //                   BSSM_AMD_MV_SEQUENTIAL, BSSM_AMD_MNG_LANE_PER_DRAW, BSSM_AMD_DEFER_SUMMARY
 //   probes          measurement-only switches that change what a production entry point does (skip an output, bypass the output
@@ -32,7 +32,7 @@ struct Options {
   int tail_max_eighths = 4;     // the last round goes through the row family when it fills at most this many eighths of the CUs (BSSM_AMD_TAIL_MAX_EIGHTHS)
   int force_path = 0;           // 0 none, 1 "wg", 2 "grid", 3 "row" (the row family where the batch has such kernels; test hook)
   int grid_ppt = 0;             // 0: automatic
-  int grid_v2 = -1, grid_v2_wx = -1, grid_v2_exact = -1;   // -1: automatic; 0 / 1
+  int grid_v2_wx = -1, grid_v2_exact = -1;   // -1: automatic; 0 / 1
   int grid_streams = 0;         // 0: automatic
   int xcd_remap = -1;           // -1: default
   int wg_wide = -1;             // -1: automatic

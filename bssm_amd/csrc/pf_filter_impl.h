@@ -1,16 +1,19 @@
-// pf_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the bssm particle-filter hot path.
+// pf_filter_impl.h -- hand-written CDNA4 (gfx950) kernels for the bssm particle-filter hot path.
 //
-// Two execution shapes for the same recursion (src/model_ssm_ung.cpp:611-712 bootstrap,
+// Execution shapes for the same recursion (src/model_ssm_ung.cpp:611-712 bootstrap,
 // :536-609 psi-APF, src/model_ssm_ulg.cpp:557-643 gaussian):
 //
-//  * pf_wg_kernel    one WORKGROUP per filter, particle system resident in LDS, the whole
-//                    time loop inside one launch (4 workgroup barriers per time step, no
-//                    grid-wide synchronisation).  This is the shape of IS post-correction:
-//                    thousands of independent filters (src/approx_mcmc.cpp:370-417).
-//  * pf_grid_step    one filter spread over many workgroups (N up to 1e5), one launch per
-//                    time step; the kernel boundary is the only grid-wide synchronisation.
-//                    Blocks exchange (max, sum) partials and block-local inclusive scans so
-//                    that the global CDF never has to be materialised.
+//  * pf_wg_kernel      one WORKGROUP per filter, particle system resident in LDS, the whole
+//                      time loop inside one launch (2 workgroup barriers per time step, no
+//                      grid-wide synchronisation).  This is the shape of IS post-correction:
+//                      thousands of independent filters (src/approx_mcmc.cpp:370-417).
+//  * pf_grid_step_v2   (pf_grid_v2.h) one filter spread over many workgroups (N up to 131 072), one
+//                      launch per time step; the kernel boundary is the only grid-wide synchronisation.
+//                      Blocks exchange (max, sum) partials and block-local weights / scans so
+//                      that the global CDF never has to be materialised.
+//  * pf_row_step       (pf_row_step.h) one wave per row of 64 particles, one launch per step, the
+//                      arithmetic of the workgroup kernel (pf_canon.h): N <= 16 384.
+//  * pf_big_*          (pf_big.h) states of 17 ... 64 dimensions on the matrix cores.
 //
 // Both draw every random number from the counter-based stream in pf_device.h and use
 // fixed-shape reductions/scans only (no floating-point atomics): results are bit-reproducible
@@ -729,7 +732,6 @@ auto wg_fn_kernel(int psi) -> void (*)(const FilterBatch) {
   return nullptr;
 }
 #define WG_FN_KERNEL(PPT_, NTB_) wg_fn_kernel<MP, PPT_, kFn, NTB_>(b.psi)
-#define GRID_FN_KERNEL(PPT_) grid_fn_kernel<MP, KP, PPT_, kFn>(b.psi)
 #ifndef BSSM_WG_WIDE_FROM
 #define BSSM_WG_WIDE_FROM 1025   // (2048 until late round 4: N = 1536, m = 1 ran 512 x 4 at 144 VGPRs, one workgroup of two waves per SIMD per CU: +30 % as 1024 x 2)
 #endif
@@ -838,449 +840,8 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
 // Multi-workgroup filter: one launch per time step
 // ------------------------------------------------------------------------------------------
 constexpr int GRID_NT = 256;
-// Waves per SIMD the register budget of a step-kernel variant is sized for.  The kernel is bound by a mix of
-// fp64 VALU issue and dependent latency, so occupancy matters, but scratch reloads on the dependent chain cost
-// more: 6 waves (80 VGPRs) spilt 22 registers and ran 14% slower than 5 waves (96 VGPRs, 2 spilt) on C2-m4.
-constexpr int grid_occupancy(int mp, int ppt, bool fn) {
-  const int live = mp * ppt * (fn ? 2 : 1);  // state doubles held per lane (functor psi weights keep the ancestors too)
-  const int occ = live <= 4 ? 5 : (live <= 8 ? 4 : (live < 16 ? 3 : (live <= 32 ? 2 : 1)));
-  return fn && occ > 4 ? 4 : occ;
-}
-
-// block-wide inclusive scan of PPT strided values per thread; returns the block total.
-// s_tot must hold PPT * 4 doubles.  One barrier.
-template <int PPT>
-__device__ __forceinline__ double block_scan_strided(const double (&e)[PPT], double (&out)[PPT], double* s_tot) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int NW = GRID_NT / 64;
-  double sc[PPT];
-#pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    sc[r] = wave_scan_incl(e[r]);
-    if (lane == 63) s_tot[r * NW + wave] = sc[r];
-  }
-  lds_barrier();
-  constexpr int Q = PPT * NW;  // <= 32
-  const double tq = (lane < Q) ? s_tot[lane] : 0.0;
-  const double incl = wave_scan_incl(tq);
-  const double total = lane_broadcast(incl, 63);
-#pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    const int q = r * NW + wave;
-    const double prev = lane_broadcast(incl, (q - 1) & 63);
-    out[r] = (q == 0 ? 0.0 : prev) + sc[r];
-  }
-  return total;
-}
-
-// First index i in [0, len) with v <= a[i] for a non-decreasing array of at most 16 entries,
-// loaded in ONE round of independent loads (a 16-ary search step instead of 4 dependent binary steps);
-// len - 1 when no entry qualifies (the reference forces the last CDF entry to 1, stratified_sample.cpp:13).
-__device__ __forceinline__ int search16_global(const double* __restrict__ a, int len, double v) {
-  double c[16];
-#pragma unroll
-  for (int q = 0; q < 16; q++) c[q] = a[q < len ? q : len - 1];
-  int cnt = 0;
-#pragma unroll
-  for (int q = 0; q < 16; q++) cnt += (q < len && c[q] < v) ? 1 : 0;
-  return cnt < len ? cnt : len - 1;
-}
-__device__ __forceinline__ void load16_global(const double* __restrict__ a, int len, double (&c)[16]) {
-#pragma unroll
-  for (int q = 0; q < 16; q++) c[q] = a[q < len ? q : len - 1];
-}
-__device__ __forceinline__ int count16(const double (&c)[16], int len, double v) {
-  int cnt = 0;
-#pragma unroll
-  for (int q = 0; q < 16; q++) cnt += (q < len && c[q] < v) ? 1 : 0;
-  return cnt < len ? cnt : len - 1;
-}
-__device__ __forceinline__ int search16_lds(const double* a, int stride, int len, double v) {
-  double c[16];
-#pragma unroll
-  for (int q = 0; q < 16; q++) c[q] = a[(q < len ? q : len - 1) * stride];
-  int cnt = 0;
-#pragma unroll
-  for (int q = 0; q < 16; q++) cnt += (q < len && c[q] < v) ? 1 : 0;
-  return cnt < len ? cnt : len - 1;
-}
-
-// t = -1: initial particles + weights at time 0.  t in [0, n): resample on the time-t
-// weights, propagate to t+1, weigh at t+1 (ones when t+1 == n or y_{t+1} is missing).
-//
-// Dependent-latency budget of one launch (one wave per SIMD at N = 65 536, so nothing hides latency):
-//   partials load  ||  Philox + Box-Muller for this step (independent of the exchange)
-//   -> block combine (2 barriers) -> 16-ary search over block prefixes in LDS (2 rounds)
-//   -> coarse row of the source block (1 global round) -> 16 fine entries (1 global round)
-//   -> ancestor state gather (1 global round) -> transition, density, block max/scan, stores.
-#define BSSM_STAMP(k)                                                                         \
-  if constexpr (DBG) {                                                                        \
-    asm volatile("" ::: "memory");                                                            \
-    if (ws.dbg && blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 64 && t >= 1)          \
-      ws.dbg[(size_t)t * 16 + (k)] = (long long)__builtin_readcyclecounter();                 \
-  }
-
-// BSSM_R1_NT: non-temporal cache policy in pf_grid_step, as BSSM_V2_NT in pf_grid_v2.h -- bit 0 ancestor-index stores, bit 1
-// the second (final) store of the output weights, bit 3 the ancestor gathers
-#ifndef BSSM_R1_NT
-#define BSSM_R1_NT 0
-#endif
-#ifndef BSSM_GRID_MFMA16
-#define BSSM_GRID_MFMA16 1
-#endif
-template <int MP, int KP, int PPT, bool DBG = false, int FN = FN_NONE, int PM = -1>
-__global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE)) pf_grid_step(const FilterBatch b, const GridWorkspace ws, const int t) {
-  constexpr int FID = FN > 0 ? FN : 0;
-  const int psi_mode = PM >= 0 ? PM : b.psi;
-  __shared__ double s_Q[GRID_NT];      // inclusive prefix of scaled block sums
-  __shared__ double s_iscale[GRID_NT];  // 1 / exp(max_b - M)
-  __shared__ double s_myscale;          // exp(max_pb - M) of this block (weights finalisation)
-  __shared__ double s_red[8];
-  __shared__ double s_tot[PPT * 4];
-  constexpr bool kMfma = MP == 8 && PPT == 1 && FN == FN_NONE;  // fp64 MFMA transition (ssm_mng m = 8)
-  __shared__ double s_tile[kMfma ? 4 * 16 * 64 : 1];
-  // sixteen-dimensional states (seasonal models beyond the workgroup-resident capacity): the transition on the matrix cores through
-  // 2 KB tiles per wave (propagate_mfma16_q); the scalar-load form kept 336 ... 528 doubles of T, R, C in a scalar file of 106 registers
-  constexpr bool kMfma16 = MP == 16 && FN == FN_NONE && (BSSM_GRID_MFMA16) != 0;
-  __shared__ double s_tile16[kMfma16 ? 4 * 256 : 1];
-  // per wave: the window of the source block's local scan its 64 slots fall into (the MFMA variant stages it in its
-  // operand tile, which is idle during the search)
-  __shared__ double s_win[kMfma ? 1 : 4 * 128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int B = ws.B, chunk = ws.chunk, crow = chunk >> 4;
-  // XCD-aware mapping: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  Give every XCD a
-  // contiguous range of (filter, block) pairs, so that the blocks which gather from a filter's previous state slice and
-  // search its local scans are the ones whose L2 saw them written one step earlier (single filter of 65 536 particles:
-  // +3 % particle-steps/s; batches that stream through the Infinity Cache anyway: no change).  BSSM_AMD_XCD_REMAP=0 turns it off.
-  int lin = blockIdx.y * gridDim.x + blockIdx.x;
-  {
-    const int total = gridDim.x * gridDim.y;
-    if ((total & 7) == 0 && ws.xcd_remap) lin = (lin & 7) * (total >> 3) + (lin >> 3);
-  }
-  const int pb = lin % B, f = ws.f0 + lin / B;
-  const int N = b.N, n = b.n, m = b.m;
-  const MathTabRegs mtab = math_tab_load_begin256();  // lands in LDS before the first barrier below
-  BSSM_STAMP(0)
-
-  const RngKey key{b.seed, b.stream0 + (uint32_t)f};
-  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
-  const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
-  const double* __restrict__ fpar = FN ? b.fpar + (size_t)f * b.fpar_fstride : nullptr;
-  constexpr int ucnt = step_draw_count<KP, FN>();
-  constexpr bool kPack = FN == FN_NONE;
-  const double* __restrict__ amats = (FN && b.amats) ? b.amats + (size_t)f * b.amats_fstride : nullptr;
-  const int base = pb * chunk;
-  const int len = min(chunk, N - base);
-  const int tn = t + 1;  // time index of the particles produced by this launch
-
-  double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N
-                                             : ws.state[tn & 1] + (size_t)f * m * N;
-  double x[PPT][MP];
-  double aprev[FN ? PPT : 1][MP];  // ancestors, needed by the ssm_nlg psi weights
-
-  if (t < 0) {
-    math_tab_load_end256(mtab);
-    lds_barrier();
-    const double* __restrict__ ini = b.init + (size_t)f * b.init_fstride;
-#pragma unroll
-    for (int r = 0; r < PPT; r++) {
-      const int li = r * GRID_NT + tid, j = base + li;
-      if (FN && !psi_mode) {
-        if constexpr (FN != FN_NONE) functor_initial<MP, FID>(fpar, ini, key, (uint32_t)j, x[r]);
-      } else {
-        double z[MP];
-        rng_normals<MP, kPack>(key, RNG_INIT, 0, (uint32_t)j, z);
-        initial_state<MP>(ini, z, x[r]);
-      }
-      if (li < len) {
-#pragma unroll
-        for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[r][c];
-      }
-    }
-  } else {
-    // ---- issue the exchange loads first ...
-    const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
-    const double pmax = (tid < B) ? part[2 * tid] : -INFINITY;
-    const double psum = (tid < B) ? part[2 * tid + 1] : 0.0;
-    // this block's stored weights of time t are exp(w - max_pb): they are rescaled to exp(w - M) below, once the
-    // global maximum is known (one read-modify-write here replaces a separate finalisation pass over the array)
-    double wt_old[PPT];
-    if (b.weights) {
-#pragma unroll
-      for (int r = 0; r < PPT; r++) {
-        const int li = r * GRID_NT + tid;
-        wt_old[r] = (li < len) ? b.weights[((size_t)f * (n + 1) + t) * N + base + li] : 0.0;
-      }
-    }
-    math_tab_load_end256(mtab);
-    // ... and draw this step's random numbers while they are in flight (PPT <= 2 keeps them in registers)
-    constexpr bool kEarlyRng = false;  // (was PPT <= 2 && !FN: the normals now need the LDS tables, published by the barrier below)
-    double u_pre[kEarlyRng ? PPT : 1], z_pre[kEarlyRng ? PPT : 1][KP];
-    if constexpr (kEarlyRng) {
-#pragma unroll
-      for (int r = 0; r < PPT; r++) {
-        const uint32_t j = (uint32_t)(base + r * GRID_NT + tid);
-        const u32x4 blk = rng_step_block(key, (uint32_t)t, j);
-        u_pre[r] = (double)rng_resample_word<ucnt>(key, (uint32_t)t, j, blk) * 0x1.0p-32;
-        rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, j, z_pre[r]);
-      }
-    }
-    BSSM_STAMP(1)
-    // ---- combine the partials of the time-t weights (every block redundantly, same order)
-    // waves whose 64 slots lie beyond the B partials only publish identities (wave-uniform branch): with more than one
-    // particle per thread (B < 256) the combine is then paid by B / 64 waves instead of all four
-    const bool wave_has_partials = wave * 64 < B;
-    double mx = -INFINITY;
-    if (wave_has_partials) mx = wave_max(pmax);
-    if (lane == 0) s_red[wave] = mx;
-    lds_barrier();
-    const double M = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-    if (wave_has_partials) {
-      const double scale = (tid < B) ? tl_exp(pmax - M) : 0.0;
-      const double ss = psum * scale;
-      double qi = wave_scan_incl(ss);
-      if (lane == 63) s_red[4 + wave] = qi;
-      lds_barrier();
-      double off = 0.0;
-      for (int q = 0; q < wave; q++) off += s_red[4 + q];
-      qi += off;
-      s_Q[tid] = qi;
-      s_iscale[tid] = 1.0 / scale;
-      if (tid == pb) s_myscale = scale;
-    } else {
-      if (lane == 63) s_red[4 + wave] = 0.0;
-      lds_barrier();
-    }
-    const double S = ((s_red[4] + s_red[5]) + s_red[6]) + s_red[7];
-    lds_barrier();
-    if (b.weights) {  // also on the degenerate step: the reference stores exp(w - max) before it tests the sum (:676-682)
-      const double myscale = s_myscale;
-#pragma unroll
-      for (int r = 0; r < PPT; r++) {
-        const int li = r * GRID_NT + tid;
-        if (li < len) {
-          if constexpr ((BSSM_R1_NT) & 2) __builtin_nontemporal_store(wt_old[r] * myscale, &b.weights[((size_t)f * (n + 1) + t) * N + base + li]);
-          else b.weights[((size_t)f * (n + 1) + t) * N + base + li] = wt_old[r] * myscale;
-        }
-      }
-    }
-    if (!(S > 0.0)) {
-      // Degenerate weights (src/model_ssm_ung.cpp:678-682): stop here and poison this block's slot of the
-      // next parity so that every later launch sees a non-finite S as well and returns too (no flag load
-      // on the critical path of healthy steps); later output slots stay zero like the reference's.
-      if (tid == 0) {
-        double* __restrict__ pn = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
-        pn[2 * pb] = __builtin_nan("");
-        pn[2 * pb + 1] = __builtin_nan("");
-        if (pb == 0) atomicCAS(&b.dead_at[f], 0, t + 1);
-      }
-      return;
-    }
-    if (pb == B - 1 && tid == GRID_NT - 1) {  // single writer, store-only: summed in time order afterwards
-      ws.llinc[(size_t)f * (n + 1) + t] = M + tl_log(S / (double)N);  // src/model_ssm_ung.cpp:683
-    }
-    BSSM_STAMP(2)
-    // ---- resample + gather + propagate
-    const double c_scale = S / (double)N;
-    const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
-    const double* __restrict__ coarse = ws.coarse + ((size_t)(t & 1) * b.F + f) * B * crow;
-    const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N
-                                                     : ws.state[t & 1] + (size_t)f * m * N;
-    const cdbl* mt = as_uniform_table(b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride);
-    {
-    #pragma unroll
-      for (int r = 0; r < PPT; r++) {
-        const int li = r * GRID_NT + tid, j = base + li;
-        if (!kMfma && !kMfma16 && li >= len) { for (int c = 0; c < MP; c++) x[r][c] = 0.0; continue; }  // (MFMA needs the whole wave)
-        double u;
-        u32x4 blk{0u, 0u, 0u, 0u};
-        if constexpr (kEarlyRng) u = u_pre[r];
-        else { blk = rng_step_block(key, (uint32_t)t, (uint32_t)j); u = (double)rng_resample_word<ucnt>(key, (uint32_t)t, (uint32_t)j, blk) * 0x1.0p-32; }
-        const double v = (u + (double)j) * c_scale;
-        // level 1: source block = number of block prefixes below v.  The 64 slots of a wave are consecutive, so v
-        // increases along the lanes and covers 64 / N of the total mass: at most B of a filter's N / 64 wave-ranges
-        // contain a block boundary.  The wave first counts cooperatively (one prefix per lane, ballots) for its first
-        // and last lane; when the two agree every lane has that source block ...
-        int sb = -1;
-        if (r * GRID_NT + (wave + 1) * 64 <= len) {  // whole wave active (wave-uniform)
-          const double v_lo = lane_broadcast(v, 0), v_hi = lane_broadcast(v, 63);
-          int c_lo = 0, c_hi = 0;
-          for (int e0 = 0; e0 < B; e0 += 64) {
-            const int e = e0 + lane;
-            const double qv = s_Q[e < B ? e : B - 1];
-            c_lo += __builtin_popcountll(__builtin_amdgcn_ballot_w64(e < B && qv < v_lo));
-            c_hi += __builtin_popcountll(__builtin_amdgcn_ballot_w64(e < B && qv < v_hi));
-          }
-          if (c_lo == c_hi) sb = c_lo < B ? c_lo : B - 1;
-        }
-        const bool sb_uniform = sb >= 0;
-        if (sb < 0) {  // ... otherwise (a boundary inside the wave, or a ragged last wave) two 16-ary rounds per lane
-          const int nrow = (B + 15) >> 4;
-          int row = 0;
-          if (nrow > 1) {  // pivots = last entry of each row of 16 (the final row may be short)
-            int cnt = 0;
-  #pragma unroll
-            for (int q = 0; q < 16; q++) {
-              const int e = min(16 * q + 15, B - 1);
-              cnt += (q < nrow && s_Q[e] < v) ? 1 : 0;
-            }
-            row = cnt < nrow ? cnt : nrow - 1;
-          }
-          sb = 16 * row + search16_lds(s_Q + 16 * row, 1, min(16, B - 16 * row), v);
-        }
-        // target inside the source block's own (unscaled) local scan: (v - P_b) / exp(max_b - M)
-        const double vp = (v - (sb > 0 ? s_Q[sb - 1] : 0.0)) * s_iscale[sb];
-        BSSM_STAMP(3)
-        // level 2: inside the source block: coarse entries (every 16th of its local scan), then 16 fine ones
-        const int slen = min(chunk, N - sb * chunk);
-        const int ncr = (slen + 15) >> 4;
-        const double* __restrict__ cr = coarse + (size_t)sb * crow;
-        int crw = -1, win_row0 = -1;
-        if (sb_uniform && ncr <= 64) {
-          // one source block for the whole wave: its coarse entries are loaded once per wave (one per lane) and counted
-          // for the first and the last lane by ballot; the lanes in between differ only in the few entries between the
-          // two counts, which are broadcast from the lanes that hold them
-          const double cv = cr[lane < ncr ? lane : ncr - 1];
-          const double vp_lo = lane_broadcast(vp, 0), vp_hi = lane_broadcast(vp, 63);
-          const int k_lo = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv < vp_lo));
-          const int k_hi = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < ncr && cv < vp_hi));
-          if (k_hi - k_lo <= 6) {
-            int cnt = k_lo;
-            for (int e = k_lo; e < k_hi; e++) cnt += (lane_broadcast(cv, e) < vp) ? 1 : 0;
-            crw = cnt < ncr ? cnt : ncr - 1;
-            win_row0 = k_lo < ncr ? k_lo : ncr - 1;  // rows win_row0 .. win_row0 + 6 hold every lane's row: <= 112 entries
-          }
-        }
-        if (crw < 0) {
-          int lo = 0, hi = ncr - 1;
-          while (hi - lo >= 16) {  // chunk > 256
-            const int mid = (lo + hi) >> 1;
-            if (vp <= cr[mid]) hi = mid; else lo = mid + 1;
-          }
-          crw = lo + search16_global(cr + lo, hi - lo + 1, vp);
-        }
-        BSSM_STAMP(4)
-        int fine;
-        if (win_row0 >= 0) {
-          // the <= 7 rows the wave's slots fall into are staged once per wave (two coalesced loads per lane, wave-private
-          // LDS) and each lane runs a 4-step binary search in its own row there, instead of 16 loads per lane
-          double* sw = kMfma ? s_tile + wave * (16 * 64) : s_win + wave * 128;
-          const int wlen = min(128, slen - 16 * win_row0);
-          const double* __restrict__ src = lcdf + (size_t)sb * chunk + 16 * win_row0;
-          __builtin_amdgcn_wave_barrier();  // the previous particle's reads of the window are done (same wave, in order)
-          sw[lane] = src[lane < wlen ? lane : wlen - 1];
-          sw[lane + 64] = src[lane + 64 < wlen ? lane + 64 : wlen - 1];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          const double* row = sw + 16 * (crw - win_row0);
-          const int len16 = min(16, slen - 16 * crw);
-          int lo = 0;
-#pragma unroll
-          for (int step = 8; step >= 1; step >>= 1) {
-            const int idx = lo + step - 1;
-            if (idx < len16 && row[idx] < vp) lo += step;
-          }
-          fine = lo < len16 ? lo : len16 - 1;
-        } else {
-          fine = search16_global(lcdf + (size_t)sb * chunk + 16 * crw, min(16, slen - 16 * crw), vp);
-        }
-        const int anc = sb * chunk + 16 * crw + fine;
-        BSSM_STAMP(5)
-        if (b.indices && li < len) {
-          if constexpr ((BSSM_R1_NT) & 1) __builtin_nontemporal_store((uint32_t)anc, &b.indices[((size_t)f * n + t) * N + j]);
-          else b.indices[((size_t)f * n + t) * N + j] = (uint32_t)anc;
-        }
-        double a[MP];
-  #pragma unroll
-        for (int c = 0; c < MP; c++) {
-          if constexpr ((BSSM_R1_NT) & 8) a[c] = (c < m) ? __builtin_nontemporal_load(&st_old[(size_t)c * N + anc]) : 0.0;
-          else a[c] = (c < m) ? st_old[(size_t)c * N + anc] : 0.0;
-        }
-        BSSM_STAMP(6)
-        if constexpr (FN != FN_NONE) {
-          if (psi_mode == 2) {
-            functor_ekpf_propagate<MP, FID>(fpar, obs + (size_t)(tn < n ? tn : 0) * obs_stride, tn >= n, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
-          } else if (psi_mode) {
-            double z[KP];
-            rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
-            propagate<MP, KP>(mt, a, z, x[r]);
-          } else {
-            functor_propagate<MP, KP, FID>(fpar, key, blk, (uint32_t)t, (uint32_t)j, a, x[r]);
-          }
-#pragma unroll
-          for (int c = 0; c < MP; c++) aprev[r][c] = a[c];
-        } else if constexpr (kMfma) {
-          if constexpr (MP == 8) {
-            double z[KP];
-            rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
-            propagate_mfma8<KP>(mt, a, z, x[r], s_tile + wave * (16 * 64), lane);
-          }
-        } else if constexpr (kEarlyRng) {
-          propagate<MP, KP>(mt, a, z_pre[r], x[r]);
-        } else if constexpr (kMfma16) {
-          if constexpr (MP == 16) {
-            double z[KP];
-            rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
-            propagate_mfma16_q<KP, 64>((const double*)(b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride), a, z, x[r], s_tile16 + wave * 256, lane);
-          }
-        } else {
-          double z[KP];
-          rng_normals_blk<KP, kPack>(blk, key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, z);
-          propagate<MP, KP>(mt, a, z, x[r]);
-        }
-        if (li < len) {
-  #pragma unroll
-          for (int c = 0; c < MP; c++) if (c < m) st_new[(size_t)c * N + j] = x[r][c];
-        }
-      }
-    }
-  }
-
-  BSSM_STAMP(7)
-  // ---- weights at time tn, block-local max / scan, partials
-  double w[PPT], e[PPT], sc[PPT];
-  const bool have_obs = tn < n;
-  const double* __restrict__ ob = obs + (size_t)(have_obs ? tn : 0) * obs_stride;
-  double mx = -INFINITY;
-#pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    const int li = r * GRID_NT + tid;
-    w[r] = (li < len) ? (have_obs ? weight_dispatch<MP, FN, PM>(b, fpar, ob, (FN && psi_mode == 2) ? amats : amats + (size_t)(t < 0 ? 0 : t) * fn_amat_row<MP>(), tn, x[r], aprev[FN ? r : 0]) : 0.0) : -INFINITY;
-    mx = fmax(mx, w[r]);
-  }
-  BSSM_STAMP(8)
-  lds_barrier();  // s_red reuse
-  mx = wave_max(mx);
-  if (lane == 0) s_red[wave] = mx;
-  lds_barrier();
-  const double Mb = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-#pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    const int li = r * GRID_NT + tid;
-    e[r] = (li < len) ? tl_exp(w[r] - Mb) : 0.0;
-    if (b.weights && li < len) b.weights[((size_t)f * (n + 1) + tn) * N + base + li] = e[r];  // block-scaled; rescaled by launch tn
-  }
-  BSSM_STAMP(9)
-  const double tot = block_scan_strided<PPT>(e, sc, s_tot);
-  BSSM_STAMP(10)
-  double* __restrict__ lcdf_new = ws.lcdf + ((size_t)(tn & 1) * b.F + f) * N;
-  double* __restrict__ coarse_new = ws.coarse + (((size_t)(tn & 1) * b.F + f) * B + pb) * crow;
-#pragma unroll
-  for (int r = 0; r < PPT; r++) {
-    const int li = r * GRID_NT + tid;
-    if (li < len) {
-      lcdf_new[base + li] = sc[r];
-      if ((li & 15) == 15 || li == len - 1) coarse_new[li >> 4] = sc[r];  // last entry of each row of 16
-    }
-  }
-  if (tid == 0) {
-    double* __restrict__ part = ws.partials + ((size_t)(tn & 1) * b.F + f) * B * 2;
-    part[2 * pb] = Mb;
-    part[2 * pb + 1] = tot;
-  }
-  BSSM_STAMP(11)
-}
+// (the step kernel itself: pf_grid_v2.h; the round-1 kernel that lived here until round 5 -- seven workgroup barriers, one ancestor search
+// per particle -- is gone: every model class steps through pf_grid_step_v2 / pf_grid_step_v2_fn or the row family, pf_row_step.h)
 
 }  // namespace bssm
 #ifndef __HIPCC_RTC__
@@ -1293,13 +854,6 @@ __global__ void __launch_bounds__(GRID_NT, grid_occupancy(MP, PPT, FN != FN_NONE
 #endif
 namespace bssm {
 
-template <int MP, int KP, int PPT, int FNV>
-auto grid_fn_kernel(int psi) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
-  if constexpr (((BSSM_FN_PSI_MASK) & 1) != 0) { if (psi == 0) return pf_grid_step<MP, KP, PPT, false, FNV, 0>; }
-  if constexpr (((BSSM_FN_PSI_MASK) & 2) != 0) { if (psi == 1) return pf_grid_step<MP, KP, PPT, false, FNV, 1>; }
-  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0) { if (psi == 2) return pf_grid_step<MP, KP, PPT, false, FNV, 2>; }
-  return nullptr;
-}
 template <int MP, int KP>
 hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   if (ws.chunk == CANON_ROW) {  // the row family (pf_row_step.h): a workspace carved by row_workspace_carve
@@ -1313,96 +867,69 @@ hipError_t launch_grid_mk(const FilterBatch& b, const GridWorkspace& ws, hipStre
   const int ppt = ws.chunk / GRID_NT;
   constexpr int kFn = fn_kernel_id<MP>();
   if (b.fpar && kFn > 0 && b.fn_id != kFn) return hipErrorInvalidValue;
+  // ONE step-kernel generation since round 5 (pf_grid_v2.h: one ancestor search per wave, weights exchange, wave-local combine) for
+  // every model class: at most 256 particle blocks of 256 * {1, 2, 4} particles per filter = 262 144 particles (the reference's
+  // front-end stops at 1e5).  The round-1 kernel (seven workgroup barriers, per-particle search) is gone.
+  if (ws.B > V2_MAX_BLOCKS || (ppt != 1 && ppt != 2 && ppt != 4)) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch, const GridWorkspace, const int) = nullptr;
-  void (*kern_init)(const FilterBatch, const GridWorkspace) = nullptr;  // round-2 kernels: the step t = -1 has its own
+  void (*kern_init)(const FilterBatch, const GridWorkspace) = nullptr;  // the step t = -1 has its own kernel
 #ifdef BSSM_XCD_PERSIST
-  void (*kern_persist)(const FilterBatch*, const GridWorkspace*, const PersistCtl, const int, const int) = nullptr;  // XCD-resident time loop (pf_grid_v2.h; experiment builds)
+  void (*kern_persist)(const FilterBatch*, const GridWorkspace*, const PersistCtl, const int, const int) = nullptr;  // XCD-resident time loop (experiment builds)
 #define BSSM_PERSIST_PICK(...) kern_persist = __VA_ARGS__
 #else
 #define BSSM_PERSIST_PICK(...) ((void)0)
 #endif
-#ifndef BSSM_USER_MODEL
-  switch (ppt) {
-    case 1: kern = pf_grid_step<MP, KP, 1>; break;
-    case 2: kern = pf_grid_step<MP, KP, 2>; break;
-    case 4: kern = pf_grid_step<MP, KP, 4>; break;
-    default: kern = pf_grid_step<MP, KP, 8>; break;
-  }
-  if constexpr (MP == 4 && KP == 4) { if (ws.dbg && ppt == 1) kern = pf_grid_step<MP, KP, 1, true>; }
-#endif
+  // weights exchange (pf_grid_v2.h): with the weights output on, blocks hand over their block-scaled weights instead of
+  // the scan of them -- one array less written per particle-step
+  bool v2ms = false, v2exact = false, v2fn = false;
+  (void)v2fn; (void)v2exact;
+  bool v2wx = b.weights != nullptr;
+  if (opt().grid_v2_wx >= 0) v2wx = v2wx && opt().grid_v2_wx != 0;
+  (void)v2ms;
   if (b.fpar) {
+    // functor models (ssm_nlg / ssm_sde: the shipped ones have one or two states, a run-time compiled user model up to 16)
     if constexpr (MP == KP && MP <= FN_MP_MAX) {
       switch (ppt) {
-        case 1: kern = GRID_FN_KERNEL(1); break;
-        case 2: kern = GRID_FN_KERNEL(2); break;
-        case 4: kern = GRID_FN_KERNEL(4); break;
-        default: kern = GRID_FN_KERNEL(8); break;
+        case 1: kern = v2_fn_kernels<MP, 1, kFn>(b.psi, v2wx, &kern_init); break;
+        case 2: kern = v2_fn_kernels<MP, 2, kFn>(b.psi, v2wx, &kern_init); break;
+        default: kern = v2_fn_kernels<MP, 4, kFn>(b.psi, v2wx, &kern_init); break;
       }
+      v2fn = true;
     } else {
       return hipErrorInvalidValue;
     }
   }
-  bool v2ms = false, v2wx = false, v2exact = false;
-  (void)v2ms; (void)v2exact;
 #ifndef BSSM_USER_MODEL
-  // round-2 step kernel (pf_grid_v2.h): linear-state models, at most 128 particle blocks per filter
-  if constexpr (MP <= 8) {
-#ifdef BSSM_V2_STAMPS
-    bool v2 = !b.fpar && ws.B <= 128 && ppt <= 4;
-#else
-    bool v2 = !b.fpar && ws.B <= 128 && ppt <= 4 && !ws.dbg;
-#endif
-    if (opt().grid_v2 >= 0) v2 = v2 && opt().grid_v2 != 0;
-    // weights exchange (pf_grid_v2.h): with the weights output on, blocks hand over their block-scaled weights instead of
-    // the scan of them -- one array less written per particle-step
-    v2wx = b.weights != nullptr;
-    if (opt().grid_v2_wx >= 0) v2wx = v2wx && opt().grid_v2_wx != 0;
-    v2exact = b.N % ws.chunk == 0 && b.m == MP;  // complete blocks, no padding components: the variants without tail guards
-    if (opt().grid_v2_exact >= 0) v2exact = v2exact && opt().grid_v2_exact != 0;
-    if constexpr (MP <= 4) {
-      if (v2 && b.p == 1) {
-        switch (ppt) {
-          case 1: kern = v2_step_kernel<MP, KP, 1, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 1, false>(v2wx, v2exact)); break;
-          case 2: kern = v2_step_kernel<MP, KP, 2, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 2, false>(v2wx, v2exact)); break;
-          default: kern = v2_step_kernel<MP, KP, 4, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 4>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 4, false>(v2wx, v2exact)); break;
+  else {
+    if constexpr (MP <= 16) {
+      v2exact = b.N % ws.chunk == 0 && b.m == MP;  // complete blocks, no padding components: the variants without tail guards
+      if (opt().grid_v2_exact >= 0) v2exact = v2exact && opt().grid_v2_exact != 0;
+      if constexpr (MP <= 4) {
+        if (b.p == 1) {
+          switch (ppt) {
+            case 1: kern = v2_step_kernel<MP, KP, 1, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 1, false>(v2wx, v2exact)); break;
+            case 2: kern = v2_step_kernel<MP, KP, 2, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 2, false>(v2wx, v2exact)); break;
+            default: kern = v2_step_kernel<MP, KP, 4, false>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 4>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 4, false>(v2wx, v2exact)); break;
+          }
         }
       }
-    }
-    // rows of several observation series (ssm_mng) and every 8-dimensional state: the multi-series variants, one or two
-    // particles per lane (MP = 8, one particle per lane: fp64 MFMA transition)
-    if (v2 && !kern_init && ppt <= 4 && (MP == 8 || b.p > 1)) {
-      v2ms = true;
-      if (ppt == 1) { kern = v2_step_kernel<MP, KP, 1, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1, true>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 1, true>(v2wx, v2exact)); }
-      else if (ppt == 2) { kern = v2_step_kernel<MP, KP, 2, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2, true>; BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 2, true>(v2wx, v2exact)); }
-      else { kern = v2_step_kernel<MP, KP, 4, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 4, true>; }
-    }
-    if (!kern_init) { v2wx = v2exact = false; BSSM_PERSIST_PICK(nullptr); }
-  }
-  // functor models (the shipped ssm_nlg / ssm_sde models: one or two states) on the round-2 step kernel (round 5)
-  bool v2fn = false;
-  if constexpr (MP == KP && MP <= 2) {
-    if (b.fpar && ws.B <= 128 && ppt <= 4 && !ws.dbg && opt().grid_v2 != 0) {
-      v2wx = b.weights != nullptr;
-      if (opt().grid_v2_wx >= 0) v2wx = v2wx && opt().grid_v2_wx != 0;
-      void (*ki)(const FilterBatch, const GridWorkspace) = nullptr;
-      void (*ks)(const FilterBatch, const GridWorkspace, const int) = nullptr;
-      switch (ppt) {
-        case 1: ks = v2_fn_kernels<MP, 1, kFn>(b.psi, v2wx, &ki); break;
-        case 2: ks = v2_fn_kernels<MP, 2, kFn>(b.psi, v2wx, &ki); break;
-        default: ks = v2_fn_kernels<MP, 4, kFn>(b.psi, v2wx, &ki); break;
+      // rows of several observation series (ssm_mng) and every state of 8 or 16 dimensions: the multi-series variants (one or two
+      // particles per lane of an 8-dimensional state and every 16-dimensional one: fp64 MFMA transition)
+      if (!kern_init) {
+        v2ms = true;
+        if (ppt == 1) { kern = v2_step_kernel<MP, KP, 1, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 1, true>; if constexpr (MP <= 8) BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 1, true>(v2wx, v2exact)); }
+        else if (ppt == 2) { kern = v2_step_kernel<MP, KP, 2, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 2, true>; if constexpr (MP <= 8) BSSM_PERSIST_PICK(v2_persist_kernel<MP, KP, 2, true>(v2wx, v2exact)); }
+        else { kern = v2_step_kernel<MP, KP, 4, true>(v2wx, v2exact); kern_init = pf_grid_init_v2<MP, 4, true>; }
       }
-      if (ks && ki) { kern = ks; kern_init = ki; v2fn = true; v2exact = false; }
-      else v2wx = false;
     }
   }
 #endif
-  if (!kern) return hipErrorInvalidValue;
+  if (!kern || !kern_init) return hipErrorInvalidValue;
 #ifndef BSSM_USER_MODEL
   {
     char nm[96];
     if (v2fn) std::snprintf(nm, sizeof nm, "pf_grid_step_v2_fn<%d,%d,%s,%s,%d>", MP, ppt, v2wx ? "true" : "false", kFn > 0 ? "model" : "any", b.psi);
-    else if (kern_init) std::snprintf(nm, sizeof nm, "pf_grid_step_v2<%d,%d,%d,%s,%s,%s>", MP, KP, ppt, v2ms ? "true" : "false", v2wx ? "true" : "false", v2exact ? "true" : "false");
-    else std::snprintf(nm, sizeof nm, "pf_grid_step<%d,%d,%d,%s,%s>", MP, KP, ppt, "false", b.fpar ? "true" : "false");
+    else std::snprintf(nm, sizeof nm, "pf_grid_step_v2<%d,%d,%d,%s,%s,%s>", MP, KP, ppt, v2ms ? "true" : "false", v2wx ? "true" : "false", v2exact ? "true" : "false");
     note_filter_kernel(nm);
   }
 #endif

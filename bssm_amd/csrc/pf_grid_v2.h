@@ -119,17 +119,25 @@ __device__ __forceinline__ int v2_count_below(const double* sw, int wlen, double
 }
 
 // Block prefixes of a filter as the lanes of a wave hold them: lane l has the inclusive, scaled prefix (and 1 / scale) of
-// block l and of block 64 + l -- up to 128 particle blocks per filter (131 072 particles at four per lane)
+// block l and of block 64 + l.  Blocks 128 ... 255 of a filter of more than 128 blocks (round 5: 256 blocks = 65 536 particles at
+// one per lane, 262 144 at four) stay in LDS (`up`: prefixes [0, 128), 1 / scale [128, 256) of the combine's upper half) and are
+// read where a wave's targets reach them -- no register of the kernels that never see such a filter
+constexpr int V2_MAX_BLOCKS = 256;
 struct V2Prefix {
   double Qa, Qb, ia, ib;
   int B;
+  const double* up;
   __device__ __forceinline__ int count_below(const double v, const int lane) const {  // number of block prefixes below v
     int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < B && Qa < v));
     if (B > 64) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane + 64 < B && Qb < v));  // wave-uniform
+    if (B > 128) {
+      c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane + 128 < B && up[lane] < v));
+      if (B > 192) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane + 192 < B && up[64 + lane] < v));
+    }
     return c;
   }
-  __device__ __forceinline__ double q(const int e) const { return e < 64 ? lane_broadcast(Qa, e) : lane_broadcast(Qb, e - 64); }   // e wave-uniform
-  __device__ __forceinline__ double is(const int e) const { return e < 64 ? lane_broadcast(ia, e) : lane_broadcast(ib, e - 64); }
+  __device__ __forceinline__ double q(const int e) const { return e < 64 ? lane_broadcast(Qa, e) : (e < 128 ? lane_broadcast(Qb, e - 64) : up[e - 128]); }   // e wave-uniform
+  __device__ __forceinline__ double is(const int e) const { return e < 64 ? lane_broadcast(ia, e) : (e < 128 ? lane_broadcast(ib, e - 64) : up[e]); }
 };
 
 // Ancestor of the wave's active slots (a prefix of its lanes), any shape: loops over the source blocks the slots fall
@@ -439,6 +447,7 @@ __device__ __forceinline__ void v2_block_stats(const FilterBatch& b, const GridW
 #define BSSM_V2_OCC_MS8 4    // MP = 8, one particle per lane
 #endif
 constexpr int v2_occupancy(int mp, int ppt, bool ms = false) {
+  if (mp >= 16) return ppt == 1 ? 3 : 2;  // sixteen-dimensional states: ancestor, new state, normals and the MFMA fragments of one particle: 90 ... 138 VGPRs at one per lane
   if (ms && mp * ppt == 16) return BSSM_V2_OCC_MS16;
   if (ms && mp * ppt == 8) return BSSM_V2_OCC_MS8;
   if (ms && ppt >= 4) return mp * ppt >= 32 ? BSSM_V2_OCC_MS32 : 4;
@@ -583,10 +592,15 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
 #define BSSM_V2_MFMA_PPT 4
 #endif
   constexpr bool kMfma = MS && MP == 8 && PPT <= BSSM_V2_MFMA_PPT;
-  __shared__ double s_win[kMfma ? 4 * 8 * 64 : 4 * PPT * V2_WIN];
+  // sixteen-dimensional states (m = 9 ... 16, round 5): the transition on the matrix cores through a 4 x 64 tile per wave
+  // (propagate_mfma16_q, pf_filter_impl.h) that doubles as the search window
+  constexpr bool kMfma16 = MS && MP == 16 && FN == FN_NONE;
+  constexpr int kWinWave = kMfma ? 8 * 64 : ((kMfma16 && PPT * V2_WIN < 256) ? 256 : PPT * V2_WIN);  // doubles of LDS per wave
+  __shared__ double s_win[4 * kWinWave];
   static_assert(!kMfma || PPT * V2_WIN <= 8 * 64, "the MFMA operand tile doubles as the search window");
   __shared__ double s_x[4 + 16 * PPT];
   __shared__ double s_comb[3 * 128 + 1];  // combine of wave 0: block prefixes, 1 / scale, scale (128 blocks each), global maximum
+  __shared__ double s_comb_up[3 * 128];   // the same three arrays for blocks 128 ... 255 (filters of more than 128 blocks)
   // T_t, R_t, C_t of this step.  Read from LDS (broadcast ds_read, same address in every lane) and not through scalar
   // loads: 36 doubles are 72 SGPRs, which with the kernel arguments and the observation row overflowed the scalar file --
   // 58 SGPRs spilled to VGPR lanes and came back through ~250 v_readlane / v_writelane per wave-step (10 % of the VALU work)
@@ -633,7 +647,7 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
     for (int r = 0; r < PPT; r++) { const int li = v2_li<PPT>(r, tid); wo[r] = li < len ? (((BSSM_V2_NT) & 16) ? ld32_nt(wsrc, li) : ld32(wsrc, li)) : 0.0; }
   };
   auto rmw_store = [&](const double (&wo)[PPT]) {
-    const double myscale = s_comb[256 + pb];
+    const double myscale = pb < 128 ? s_comb[256 + pb] : s_comb_up[128 + pb];
 #pragma unroll
     for (int r = 0; r < PPT; r++) {
       const int li = v2_li<PPT>(r, tid);
@@ -675,9 +689,13 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
     }
   };
   V2_MARK("combine"); V2_STAMP(1);
-  double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0;
+  double pmax = -INFINITY, psum = 0.0, pmaxb = -INFINITY, psumb = 0.0, pmaxc = -INFINITY, psumc = 0.0, pmaxd = -INFINITY, psumd = 0.0;
   if (wave == 0) {
     const double* __restrict__ part = ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2;
+    if (B > 128) {  // wave-uniform
+      if (lane + 128 < B) { pmaxc = v2_ldx<COH>(part, (uint32_t)(2 * (lane + 128))); psumc = v2_ldx<COH>(part, (uint32_t)(2 * (lane + 128) + 1)); }
+      if (lane + 192 < B) { pmaxd = v2_ldx<COH>(part, (uint32_t)(2 * (lane + 192))); psumd = v2_ldx<COH>(part, (uint32_t)(2 * (lane + 192) + 1)); }
+    }
     if constexpr (COH) {
       if (lane < B) { pmax = ld32_sc1(part, (uint32_t)(2 * lane)); psum = ld32_sc1(part, (uint32_t)(2 * lane + 1)); }
       if (lane + 64 < B) { pmaxb = ld32_sc1(part, (uint32_t)(2 * (lane + 64))); psumb = ld32_sc1(part, (uint32_t)(2 * (lane + 64) + 1)); }
@@ -690,7 +708,7 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
     if (load_tables) { math_tab_load_end256(mtab); lds_barrier(); }
   }
   if (wave == 0) {
-    const double M0 = wave_max(fmax(pmax, pmaxb));
+    const double M0 = wave_max(B > 128 ? fmax(fmax(pmax, pmaxb), fmax(pmaxc, pmaxd)) : fmax(pmax, pmaxb));
     const double scale0 = fast_exp(pmax - M0);  // lanes >= B: 0; a poisoned (NaN) partial makes S NaN below
     const double Q0 = wave_scan_incl(psum * scale0);
     s_comb[lane] = Q0;
@@ -704,9 +722,27 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
       s_comb[256 + 64 + lane] = scale1;
     }
     s_comb[64 + lane] = Q1;  // (B <= 64: the total in every lane)
+    if (B > 128) {  // blocks 128 ... 255
+      const double scale2 = fast_exp(pmaxc - M0);
+      const double Q2 = lane_broadcast(Q1, 63) + wave_scan_incl(psumc * scale2);
+      s_comb_up[lane] = Q2;
+      s_comb_up[128 + lane] = 1.0 / scale2;
+      s_comb_up[256 + lane] = scale2;
+      double Q3 = lane_broadcast(Q2, 63);
+      if (B > 192) {
+        const double scale3 = fast_exp(pmaxd - M0);
+        Q3 += wave_scan_incl(psumd * scale3);
+        s_comb_up[128 + 64 + lane] = 1.0 / scale3;
+        s_comb_up[256 + 64 + lane] = scale3;
+      }
+      s_comb_up[64 + lane] = Q3;
+    }
     if (lane == 0) s_comb[384] = M0;
   }
-  if (!kFn || psi_mode == 1) { if (tid < NMAT) s_mat[tid] = (b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride)[tid]; }  // (functor models: only the psi-APF proposal is linear)
+  if (!kFn || psi_mode == 1) {  // (functor models: only the psi-APF proposal is linear)
+#pragma unroll
+    for (int i = tid; i < NMAT; i += GRID_NT) s_mat[i] = (b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride)[i];
+  }
   u32x4 blk[PPT];
 #pragma unroll
   for (int r = 0; r < PPT; r++) blk[r] = rng_step_block(key, (uint32_t)t, (uint32_t)(base + v2_li<PPT>(r, tid)));
@@ -718,9 +754,9 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
   }
   if (load_tables && kEarlyZ != 3) math_tab_load_end256(mtab);
   lds_barrier();  // (1)
-  const V2Prefix px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[128 + 64 + lane], B};
-  const double S = s_comb[127], M = s_comb[384];
-  if (fw && pb == 0 && tid < B) ws.wscale[((size_t)f * (n + 1) + t) * B + tid] = s_comb[256 + tid];  // exp(max_block - max_t)
+  const V2Prefix px{s_comb[lane], s_comb[64 + lane], s_comb[128 + lane], s_comb[128 + 64 + lane], B, s_comb_up};
+  const double S = B > 128 ? s_comb_up[127] : s_comb[127], M = s_comb[384];
+  if (fw && pb == 0 && tid < B) ws.wscale[((size_t)f * (n + 1) + t) * B + tid] = tid < 128 ? s_comb[256 + tid] : s_comb_up[128 + tid];  // exp(max_block - max_t)
   V2_MARK("rmw"); V2_STAMP(2);
   // stored weights of time t are exp(w - max_block): rescale to exp(w - M) (also on the degenerate step, :676-682)
   if (!BSSM_V2_RMW_LATE && wt) rmw_store(wt_old);
@@ -744,7 +780,7 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
   const double* __restrict__ st_old = uniform_ptr(b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N);
   double* __restrict__ st_new = uniform_ptr((b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N) + base);
   uint32_t* __restrict__ idx_out = b.indices ? uniform_ptr(b.indices + ((size_t)f * n + t) * N + base) : nullptr;
-  double* sw_base = s_win + wave * (kMfma ? 8 * 64 : PPT * V2_WIN);
+  double* sw_base = s_win + wave * kWinWave;
 
 #ifndef BSSM_V2_PRIO
 #define BSSM_V2_PRIO 0
@@ -1029,6 +1065,8 @@ __device__ __forceinline__ bool v2_step_body(const FilterBatch& b, const GridWor
       }
     } else if constexpr (kMfma) {
       propagate_mfma8_h<KP>((const double*)s_mat, a[r % ROLL], z, x, sw_base, lane);
+    } else if constexpr (kMfma16) {
+      propagate_mfma16_q<KP, 64>((const double*)s_mat, a[r % ROLL], z, x, sw_base, lane);
     } else {
       int zero = 0;  // opaque: the matrix is re-read per particle instead of being kept live in 72 VGPRs
       __asm__ volatile("" : "+v"(zero));
@@ -1097,9 +1135,10 @@ __global__ void __launch_bounds__(GRID_NT, v2_fn_occupancy(MP, PPT)) pf_grid_ste
 }
 template <int MP, int PPT, int FNV>
 auto v2_fn_kernels(int psi, bool wx, void (**init)(const FilterBatch, const GridWorkspace)) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
-  if (psi == 0) { *init = pf_grid_init_v2<MP, PPT, false, FNV, 0>; return wx ? pf_grid_step_v2_fn<MP, PPT, true, FNV, 0> : pf_grid_step_v2_fn<MP, PPT, false, FNV, 0>; }
-  if (psi == 1) { *init = pf_grid_init_v2<MP, PPT, false, FNV, 1>; return wx ? pf_grid_step_v2_fn<MP, PPT, true, FNV, 1> : pf_grid_step_v2_fn<MP, PPT, false, FNV, 1>; }
-  if (psi == 2) { *init = pf_grid_init_v2<MP, PPT, false, FNV, 2>; return wx ? pf_grid_step_v2_fn<MP, PPT, true, FNV, 2> : pf_grid_step_v2_fn<MP, PPT, false, FNV, 2>; }
+  // (BSSM_FN_PSI_MASK, pf_filter_impl.h: the samplers this translation unit instantiates -- a user model's library builds them in separate units)
+  if constexpr (((BSSM_FN_PSI_MASK) & 1) != 0) { if (psi == 0) { *init = pf_grid_init_v2<MP, PPT, false, FNV, 0>; return wx ? pf_grid_step_v2_fn<MP, PPT, true, FNV, 0> : pf_grid_step_v2_fn<MP, PPT, false, FNV, 0>; } }
+  if constexpr (((BSSM_FN_PSI_MASK) & 2) != 0) { if (psi == 1) { *init = pf_grid_init_v2<MP, PPT, false, FNV, 1>; return wx ? pf_grid_step_v2_fn<MP, PPT, true, FNV, 1> : pf_grid_step_v2_fn<MP, PPT, false, FNV, 1>; } }
+  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0) { if (psi == 2) { *init = pf_grid_init_v2<MP, PPT, false, FNV, 2>; return wx ? pf_grid_step_v2_fn<MP, PPT, true, FNV, 2> : pf_grid_step_v2_fn<MP, PPT, false, FNV, 2>; } }
   return nullptr;
 }
 

@@ -66,7 +66,9 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
       // (below that only with complete blocks -- the variant without tail guards: a single 65 536-particle call 9.30 -> 8.96 us per
       // step, m = 1 8.73 -> 8.21, two in flight 9.83 -> 9.33 / 9.09 -> 8.40; 40 000 particles, ragged: 9.0 -> 10.1, stays at one;
       // scripts/ppt_single.py, profiles/r02d_ppt_single.txt)
-      else if (w1 >= (size_t)(small ? 768 : 1024) || b.N % (2 * GRID_NT) == 0) ppt = 2;
+      // (round 5, the step kernel carries 256 blocks: a single m = 4 call of 65 536 particles 9.16 -> 8.57 us per step at ONE per lane, two in
+      // flight 9.52 -> 9.17; m = 1 even / 8.54 vs 8.85: stays -- profiles/r05_step_kernel_unified.txt)
+      else if (w1 >= (size_t)(small ? 768 : 1024) || (small && b.N % (2 * GRID_NT) == 0)) ppt = 2;
     } else if (b2 > 128 && b4 <= 128) {    // only four do
       // (with complete blocks from one filter on: 131 072 particles, single call 12.8 -> 12.1 us per step, m = 1 11.4 -> 10.2)
       if (w1 >= (size_t)(small ? 2048 : 4096) || b.N % (4 * GRID_NT) == 0) ppt = 4;
@@ -79,17 +81,14 @@ size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
       else if (w1 >= 2048 && b.N >= 2 * GRID_NT) ppt = 2;
     }
   }
-  // functor models (the shipped ssm_nlg / ssm_sde models) on the round-2 step kernel: as many particles per lane as bring the filter
-  // under its 128 particle blocks (32 768 particles at one per lane, 131 072 at four)
-  if (b.fpar && b.MP <= 2 && b.user_slot == 0) {
-    const size_t b1 = (size_t)(b.N + GRID_NT - 1) / GRID_NT;
-    if (b1 > 128) ppt = (b1 + 1) / 2 <= 128 ? 2 : 4;
-  }
+  // (every other class -- functor models, run-time compiled user models, sixteen-dimensional states: one particle per lane up to the
+  // step kernel's 256 blocks = 65 536 particles, two up to 131 072: a single filter of 1e5 particles as 196 workgroups of two per lane,
+  // not 98 of four -- scripts/step_kernel_unified_probe.py)
   // 8-dimensional states (round-2 multi-series kernel): two particles per lane once the batch fills the chip twice
   // (C4, 16 384 particles: 32 filters 1.92e10 -> 1.99e10, 64 filters 1.90e10 -> 2.19e10 particle-steps/s; 16 filters 1.58e10 -> 1.37e10)
   if (b.MP == 8 && !b.fpar && w1 >= 2048 && b.N >= 2 * GRID_NT) ppt = 2;
-  if (opt().grid_ppt > 0) ppt = std::max(1, std::min(8, opt().grid_ppt));  // tuning hook (BSSM_AMD_GRID_PPT)
-  while ((b.N + GRID_NT * ppt - 1) / (GRID_NT * ppt) > GRID_NT && ppt < 8) ppt *= 2;
+  if (opt().grid_ppt > 0) ppt = opt().grid_ppt >= 4 ? 4 : (opt().grid_ppt >= 2 ? 2 : 1);  // tuning hook (BSSM_AMD_GRID_PPT)
+  while ((b.N + GRID_NT * ppt - 1) / (GRID_NT * ppt) > 256 && ppt < 4) ppt *= 2;  // (at most 256 blocks per filter: pf_grid_v2.h; callers refuse N > 262 144)
   const int chunk = GRID_NT * ppt;
   const int B = (b.N + chunk - 1) / chunk;
   if (B_out) *B_out = B;

@@ -26,7 +26,7 @@
  *    node has been available to this build.)  Results for a given seed are not reproducible ACROSS library versions
  *    whose bssm_amd_version() names another random-stream format or normalisation.
  *  - Limits: state dimension m <= 64, observation series p <= 16, user-defined models <= 16 states (psi-APF / EKF: 8); particles up to
- *    524 288 for m <= 16 and up to 8192 for 17 <= m <= 64.  Beyond them the entry points refuse with a message.
+ *    262 144 for m <= 16 and up to 16 384 for 17 <= m <= 64.  Beyond them the entry points refuse with a message.
  */
 #ifndef BSSM_AMD_H
 #define BSSM_AMD_H

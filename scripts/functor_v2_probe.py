@@ -1,5 +1,5 @@
-"""Functor models larger than one workgroup: the round-1 step kernel (BSSM_AMD_GRID_V2=0: seven workgroup barriers and one ancestor search
-per particle) against pf_grid_step_v2_fn (round 5).  The growth model of the reference's psi-APF study (T = 300, m = 2; the study's
+"""Functor models larger than one workgroup on pf_grid_step_v2_fn (round 5; the round-1 step kernel it was compared with in
+profiles/r05_functor_v2.txt -- BSSM_AMD_GRID_V2=0 -- is gone since): particles per lane (BSSM_AMD_GRID_PPT) default / 1 / 2 / 4.  The growth model of the reference's psi-APF study (T = 300, m = 2; the study's
 "truth" run uses N = 1e5 bootstrap particles, vignettes/psi_pf_experiments/gm_truth.rds): bootstrap particle_smoother and psi-APF
 log-likelihood, single calls and batches -> profiles/r05_functor_v2.txt"""
 import os, sys, time
@@ -15,15 +15,16 @@ def timed(fn, reps=3):
     for _ in range(reps):
         t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)
     return best
-for N in (20000, 100000):
+for N in (20000, 50000, 100000):
     for label, fn in (("particle_smoother(bsf)", lambda: F.particle_smoother(model, N, method="bsf", seed=3)),
                       ("logLik(bsf)", lambda: F.logLik(model, N, method="bsf", seed=3)),
                       ("logLik(psi)", lambda: F.logLik(model, N, method="psi", seed=3)),
                       ("logLik_batch(bsf) x 16", lambda: F.logLik_batch(model, N, 16, method="bsf", seed=3))):
         row = []
-        for v in ("0", "1"):
-            os.environ["BSSM_AMD_GRID_V2"] = v
+        for v in ("0", "1", "2", "4"):
+            if v == "1" and N > 65536: continue
+            os.environ["BSSM_AMD_GRID_PPT"] = v
             e = timed(fn)
-            row.append("%s %.2f ms [%s]" % ("round-1 kernel" if v == "0" else "round-2 kernel", e * 1e3, FilterPlan.last_kernel()))
-        os.environ.pop("BSSM_AMD_GRID_V2")
+            row.append("%s %.2f ms [%s]" % ("default" if v == "0" else v + " per lane", e * 1e3, FilterPlan.last_kernel()))
+        os.environ.pop("BSSM_AMD_GRID_PPT")
         print("N = %6d %-24s | " % (N, label) + " | ".join(row), flush=True)

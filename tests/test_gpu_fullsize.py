@@ -81,10 +81,11 @@ def test_c3_svm_exchange_psi_smoother_full_size():
     assert np.max(np.abs(out["alphahat"] - bsf["alphahat"])) < 0.25  # smoothed log-volatility, sd ~ 0.5
 
 
-def test_c4_mng_mfma_transition_equals_valu_transition(monkeypatch):
-    """configs[3]: ssm_mng m=8 p=4 T=2000 N=16384: the fp64-MFMA state transition (round-2 multi-series step kernel,
-    one and two particles per lane) and the plain FMA transition (round-1 step kernel at two particles per lane) are
-    independent implementations of alpha' = C + T a + R eta"""
+def test_c4_mng_two_matrix_core_transitions_agree(monkeypatch):
+    """configs[3]: ssm_mng m=8 p=4 T=2000 N=16384: the step kernel's fp64-MFMA state transition through LDS tiles (one and two
+    particles per lane) and the row family's fragment-native transition (pf_big.h, one 16-row block) are independent
+    implementations of alpha' = C + T a + R eta (the round-1 step kernel with the plain FMA transition, the third one until
+    round 5, is gone; the oracle comparison at full size is tests/test_gpu_parity.py)"""
     model = mng_c4(2000)
     N = 16384
     monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "grid")
@@ -94,9 +95,10 @@ def test_c4_mng_mfma_transition_equals_valu_transition(monkeypatch):
     monkeypatch.setenv("BSSM_AMD_GRID_PPT", "2")
     mfma2 = F.bootstrap_filter(model, N, seed=4, return_indices=True)
     assert np.mean(mfma["indices"] != mfma2["indices"]) < 1e-6
-    monkeypatch.setenv("BSSM_AMD_GRID_V2", "0")
+    monkeypatch.delenv("BSSM_AMD_GRID_PPT")
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "row")
     valu = F.bootstrap_filter(model, N, seed=4, return_indices=True)
-    assert "pf_grid_step<8," in FilterPlan.last_kernel()
+    assert "pf_big_row_step<1,8>" in FilterPlan.last_kernel(), FilterPlan.last_kernel()
     _check_particle_system(mfma, 2000, N, model["y"])
     frac = np.mean(mfma["indices"] != valu["indices"])
     assert frac < 1e-6, f"ancestor mismatch fraction {frac}"
