@@ -315,7 +315,7 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
       }
     }
     for (int a = 0; a < cnt; a++) for (int c = 0; c <= a; c++)
-      fp[bssm::FP_RLINV + nz[a] + MP * nz[c]] = pd ? Li[a + S * c] : std::nan("");
+      fp[bssm::fp_rlinv(MP) + nz[a] + MP * nz[c]] = pd ? Li[a + S * c] : std::nan("");
     if (mod->known_tv_params && mod->tv_rows > 0 && mod->tv_cols > 0 && have_device()) {  // BSSM_USER_TV snippets: matrix on the device
       double* dtv = nullptr;
       if (int rc = device_known_tv(mod->known_tv_params, mod->tv_rows, mod->tv_cols, &dtv)) return rc;
@@ -325,7 +325,7 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
     }
   }
   if (id >= bssm::FN_NLG_GROWTH && id <= bssm::FN_NLG_LINEAR_GAUSSIAN)  // shipped models: diagonal R, the psi weight reads 1 / R_j
-    for (int j = 0; j < m; j++) fp[bssm::FP_RLINV + j + MP * j] = 1.0 / fp[bssm::FP_R + j];
+    for (int j = 0; j < m; j++) fp[bssm::fp_rlinv(MP) + j + MP * j] = 1.0 / fp[bssm::FP_R + j];
   fp[bssm::FP_H] = H;
   fp[bssm::FP_LOGC] = -0.5 * (std::log(2.0 * 3.14159265358979323846) + 2.0 * std::log(H));
   if (params_only) {
@@ -458,8 +458,8 @@ int functor_psi_tables(const bssm_fn_model* mod, const double* is_mode, int max_
   bssm::FilterTables dummy;
   int m = 1, k = 1;
   if ((rc = functor_tables(mod, &dummy, fpar, &m, &k))) return rc;  // fpar block (id, theta, H, R ...)
-  for (int q = 0; q < 64; q++)
-    if (std::isnan((*fpar)[bssm::FP_RLINV + q])) return fail(BSSM_ERR_INVALID, "psi-APF of a user model: R R' must be positive definite on its non-zero diagonal");
+  for (int q = 0, MPq = bssm::pad_dim(m); q < MPq * MPq; q++)
+    if (std::isnan((*fpar)[bssm::fp_rlinv(MPq) + q])) return fail(BSSM_ERR_INVALID, "psi-APF of a user model: R R' must be positive definite on its non-zero diagonal");
   bssm::FnSetup su;
   *ok = bssm::fn_psi_setup(f, is_mode, max_iter, conv_tol, &su);
   *approx_loglik = su.approx_loglik;

@@ -157,7 +157,8 @@ struct IsCore {
   uint32_t nsim = 0, seed = 0;
   const uint32_t* counts = nullptr;
   std::vector<bssm::FilterTables> tabs;
-  std::vector<double> fpar;    // FP_SIZE per draw, or empty
+  std::vector<double> fpar;    // fps per draw, or empty
+  size_t fps = bssm::FP_SIZE;  // doubles per draw of fpar: fp_size(padded state dimension), pf_functors.h
   std::vector<double> amats;   // per draw n approximating rows (fn_amats_row doubles each), or empty
   int count_draws = 1;         // draws the amats slots were laid out for
   std::vector<double> const_add, sub;
@@ -239,17 +240,17 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
       DevBuf fparb, amatb;  // per-draw functor parameters / approximating (T_t, C_t), in batch order
       StageBuf st_fpar, st_amat;
       if (ctabs && ctabs->fpar.p) {
-        db.fb.fpar = ctabs->fpar.as<double>() + pos * bssm::FP_SIZE; db.fb.fpar_fstride = bssm::FP_SIZE;
+        db.fb.fpar = ctabs->fpar.as<double>() + pos * J.fps; db.fb.fpar_fstride = J.fps;
         db.fb.user_slot = 0;
         db.fb.fn_id = (int)J.fpar[bssm::FP_ID];
         db.fb.amats = ctabs->amats.as<double>() + pos * ctabs->as; db.fb.amats_fstride = ctabs->as;
       } else if (!J.fpar.empty()) {
-        HIP_TRY(st_fpar.alloc(F * bssm::FP_SIZE * sizeof(double)));
+        HIP_TRY(st_fpar.alloc(F * J.fps * sizeof(double)));
         double* hb = (double*)st_fpar.p;
-        for (size_t f = 0; f < F; f++) std::memcpy(hb + f * bssm::FP_SIZE, J.fpar.data() + (size_t)order[pos + f] * bssm::FP_SIZE, bssm::FP_SIZE * sizeof(double));
-        HIP_TRY(fparb.alloc(F * bssm::FP_SIZE * sizeof(double)));
+        for (size_t f = 0; f < F; f++) std::memcpy(hb + f * J.fps, J.fpar.data() + (size_t)order[pos + f] * J.fps, J.fps * sizeof(double));
+        HIP_TRY(fparb.alloc(F * J.fps * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(fparb.p, hb, fparb.bytes, hipMemcpyHostToDevice, nullptr));
-        db.fb.fpar = fparb.as<double>(); db.fb.fpar_fstride = bssm::FP_SIZE;
+        db.fb.fpar = fparb.as<double>(); db.fb.fpar_fstride = J.fps;
         db.fb.user_slot = (int)J.fpar[bssm::FP_SLOT];
         db.fb.fn_id = (int)J.fpar[bssm::FP_ID];
       }
@@ -759,7 +760,8 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   J.tabs.resize(count);
   J.bad.assign(count, 0);
   J.const_add.assign(count, 0.0); J.sub.assign(count, 0.0);
-  J.fpar.assign((size_t)count * bssm::FP_SIZE, 0.0);
+  J.fps = (size_t)bssm::fp_size(bssm::pad_dim(m));
+  J.fpar.assign((size_t)count * J.fps, 0.0);
   // ---- SURVEY.md 8f rank 1, all of it on the device (built-in models, uniform particle count): per draw the host packs
   // theta and (a1, P1); linearisation at the stored mode, smoother, conditional factors and the filter's tables are ONE
   // kernel per pipeline chunk (fn_setup_kernel), whose outputs the filter reads in place.  BSSM_AMD_DEVICE_SETUP = 0 / 1
@@ -776,7 +778,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       double ap[6];
       int mm_ = 1, kk_ = 1;
       if (functor_tables(&models[i], &none, &fp, &mm_, &kk_, ap)) return g_err;
-      std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
+      std::memcpy(J.fpar.data() + (size_t)i * J.fps, fp.data(), J.fps * sizeof(double));
       double* e = ext.data() + (size_t)i * EXT;
       for (int j = 0; j < m; j++) e[j] = ap[j];
       if (m == 1) e[1] = ap[2]; else for (int q = 0; q < 4; q++) e[2 + q] = ap[2 + q];
@@ -790,11 +792,11 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       auto ct = std::make_shared<ChunkTables>();
       ct->lo = lo; ct->F = F;
       ct->ms = (size_t)n * (2 * mm + m); ct->os = (size_t)n * (bssm::ROW_HDR + bssm::SER_HDR + m); ct->is = (size_t)m + mm; ct->as = (size_t)n * (mm + m);
-      const size_t nf = (size_t)F * bssm::FP_SIZE, ne = (size_t)F * EXT, nm = (size_t)F * m * n;
+      const size_t nf = (size_t)F * J.fps, ne = (size_t)F * EXT, nm = (size_t)F * m * n;
       HIP_TRY(ct->stage.alloc((nf + ne + nm + n) * sizeof(double)));
       HIP_TRY(ct->okst.alloc((size_t)F * sizeof(int)));
       double* h = (double*)ct->stage.p;
-      std::memcpy(h, J.fpar.data() + (size_t)lo * bssm::FP_SIZE, nf * sizeof(double));
+      std::memcpy(h, J.fpar.data() + (size_t)lo * J.fps, nf * sizeof(double));
       std::memcpy(h + nf, ext.data() + (size_t)lo * EXT, ne * sizeof(double));
       std::memcpy(h + nf + ne, modes + (size_t)m * n * lo, nm * sizeof(double));
       std::memcpy(h + nf + ne + nm, models[0].y, (size_t)n * sizeof(double));
@@ -868,7 +870,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
         bssm::FilterTables dummy;
         if (to_fn_model(&models[i], &fms[i])) return g_err;
         if (functor_tables(&models[i], &dummy, &fp, &mm_, &kk_)) return g_err;
-        std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
+        std::memcpy(J.fpar.data() + (size_t)i * J.fps, fp.data(), J.fps * sizeof(double));
         if (bssm::fn_psi_setup_begin(fms[i], modes + (size_t)m * n * i, &fsus[i], &lgs[i])) { pending[i] = 1; return ""; }
       }
       double al = 0; bool ok = true;
@@ -879,7 +881,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       if (functor_tables(&models[i], &J.tabs[i], &fp, &mm_, &kk_)) return g_err;
       J.sub[i] = approx_loglik[i];
     }
-    std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
+    std::memcpy(J.fpar.data() + (size_t)i * J.fps, fp.data(), J.fps * sizeof(double));
     return "";
   };
   auto device_chunk = [&](int lo, int hi) -> int {
@@ -910,7 +912,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       bssm::build_fn_psi_tables(fms[i], fsus[i], &J.tabs[i], &am);
     } else {
       if (!bad_draw(i, &fp, &am)) return g_err;
-      std::memcpy(J.fpar.data() + (size_t)i * bssm::FP_SIZE, fp.data(), bssm::FP_SIZE * sizeof(double));
+      std::memcpy(J.fpar.data() + (size_t)i * J.fps, fp.data(), J.fps * sizeof(double));
     }
     { const std::string e = store_amats(i, am); if (!e.empty()) return e; }
     fms[i] = bssm::FnModel(); fsus[i] = bssm::FnSetup(); lgs[i] = bssm::LgPacked();

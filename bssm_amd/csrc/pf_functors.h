@@ -52,7 +52,19 @@ enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, 
        FP_TVPTR = 26, FP_TVROWS = 27, FP_TVCOLS = 28,
        // full R (MP x MP, column-major, zero-padded; user models: up to 16 x 16 since round 5) and the inverse lower factor of
        // R R' for the psi-APF's transition-density ratio with any constant R (MP x MP, column-major)
-       FP_RMAT = 30, FP_RLINV = 30 + 256, FP_SIZE = 30 + 512 };  // (16 x 16 blocks since round 5: user models of up to 16 states for the bootstrap filter)
+       FP_RMAT = 30, FP_SIZE = 30 + 512 };  // (FP_SIZE: the largest block -- 16 x 16, user models of up to 16 states for the bootstrap filter)
+// The two matrices sit back to back in the padded dimension of the model, so that a block is as short as its model needs: the growth
+// model's (MP = 2) is 38 doubles, and a post-correction job packs, uploads and reads fp_size(MP) per draw -- with fixed 16 x 16 slots a
+// 2 340-draw job moved 10 MB of zeros and its call went from 40 to 47 ms.
+#if defined(__HIPCC_RTC__)
+#define BSSM_FP_HD __device__
+#elif defined(__HIPCC__)
+#define BSSM_FP_HD __host__ __device__
+#else
+#define BSSM_FP_HD
+#endif
+BSSM_FP_HD constexpr int fp_rlinv(int mp) { return FP_RMAT + mp * mp; }   // offset of the inverse lower factor of R R'
+BSSM_FP_HD constexpr int fp_size(int mp) { return FP_RMAT + 2 * mp * mp; }  // doubles of one block
 
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_TV)
 template <class PF>
@@ -404,7 +416,7 @@ __device__ __forceinline__ double functor_psi_weight(PF fp, PR row, PA amat, int
       for (int i = 0; i < MP; i++) {
         double qa = 0.0, qm = 0.0;
 #pragma unroll
-        for (int j = 0; j <= i; j++) { const double l = fp[FP_RLINV + i + MP * j]; qa += l * da[j]; qm += l * dm[j]; }
+        for (int j = 0; j <= i; j++) { const double l = fp[fp_rlinv(MP) + i + MP * j]; qa += l * da[j]; qm += l * dm[j]; }
         w += 0.5 * (qa * qa - qm * qm);
       }
     } else
@@ -416,7 +428,7 @@ __device__ __forceinline__ double functor_psi_weight(PF fp, PR row, PA amat, int
       double am = amat[MP * MP + j];
 #pragma unroll
       for (int c = 0; c < MP; c++) am += amat[j + MP * c] * aprev[c];
-      const double ir = fp[FP_RLINV + j + MP * j];  // 1 / R_j, from the host (it was a per-particle division of two constants)
+      const double ir = fp[fp_rlinv(MP) + j + MP * j];  // 1 / R_j, from the host (it was a per-particle division of two constants)
       const double da = (x[j] - am) * ir, dm = (x[j] - mean[j]) * ir;
       w += 0.5 * (da * da - dm * dm);
     }

@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
     math_tab_init();  // (a workgroup barrier inside: surplus lanes redo the last draw instead of leaving)
     const int d = min((int)(blockIdx.x * 64 + threadIdx.x), b.F - 1), t = blockIdx.y;
     const FnWork<M> W(b, d);
-    const double* __restrict__ fp = b.fpar + (size_t)d * FP_SIZE;
+    const double* __restrict__ fp = b.fpar + (size_t)d * fp_size(M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8)));
     const int id = (int)fp[FP_ID];
     const double* __restrict__ mode = b.modes + (size_t)d * M * n;
     double a[M], Zg[M], Tg[MM], Tf[M];
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
       // ---- tables (build_fn_psi_tables): proposal operands, observation rows, initial state, approximating (T_t, C_t)
       const int t = blockIdx.y;
       const double *at = W.at, *Pt = W.Vf, *cc = W.Cf;
-      const double* __restrict__ fp = b.fpar + (size_t)d * FP_SIZE;
+      const double* __restrict__ fp = b.fpar + (size_t)d * fp_size(M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8)));
       const bool ok = b.ok[d] != 0;
       constexpr int MS = 2 * MM + M, OS = ROW_HDR + SER_HDR + M, AS = MM + M;
       double* __restrict__ mats = b.mats + (size_t)d * n * MS;
