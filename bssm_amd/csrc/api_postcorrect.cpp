@@ -577,7 +577,9 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   // mng_tables_kernel; the default for any number of host threads since late round 3 (512 draws of the C4 shape: 0.069 s against
   // 0.109 s with 32 host threads; until the factors left the sequential kernel it was 0.26 s and only the default below 8 threads).
   // (n < 65535: the set-up's parallel kernels carry the time point in gridDim.y; longer series take the host set-up)
-  bool dev_full = psi && have_device() && m <= 8 && n < 65535 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
+  // (univariate observations: 9 ... 16 states go padded to 16 -- ung_pack, round 5)
+  const int m_dev = (p0 == 1 && m > 8) ? 16 : m;   // the state dimension the set-up kernels are instantiated for
+  bool dev_full = psi && have_device() && (p0 == 1 ? m <= 16 : m <= 8) && n < 65535 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
   if (bssm::opt().device_setup >= 0) dev_full = dev_full && bssm::opt().device_setup == 2;
   if (bssm::opt().generic_setup) dev_full = false;
   if (dev_full) {
@@ -623,7 +625,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       DevBuf& din = ct->in_a; DevBuf& din_t = ct->in_b;
       HIP_TRY(din.alloc(E * F * sizeof(double)));
       HIP_TRY(din_t.alloc(E * F * sizeof(double)));
-      HIP_TRY(ct->scratch.alloc((p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m, p0) : bssm::ung_setup_scratch_doubles(n, m)) * F * sizeof(double)));
+      HIP_TRY(ct->scratch.alloc((p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m, p0) : bssm::ung_setup_scratch_doubles(n, m_dev)) * F * sizeof(double)));
       HIP_TRY(ct->mats.alloc(ct->ms * F * sizeof(double))); HIP_TRY(ct->obs.alloc(ct->os * F * sizeof(double)));
       HIP_TRY(ct->init.alloc(ct->is * F * sizeof(double)));
       HIP_TRY(ct->ok.alloc((size_t)F * sizeof(int)));
@@ -631,7 +633,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       HIP_TRY(hipMemcpyAsync(din.p, h, E * F * sizeof(double), hipMemcpyHostToDevice, st));
       HIP_TRY(bssm::launch_transpose(din.as<double>(), din_t.as<double>(), F, (int)E, st));  // [F][E] -> [E][F]
       bssm::UngSetupDev b{};
-      b.F = F; b.n = n; b.m = m; b.p = p0;
+      b.F = F; b.n = n; b.m = m_dev; b.p = p0;
       b.Zs = L0.Zs; b.Ts = L0.Ts; b.Rs = L0.Rs; b.Ds = L0.Ds; b.Cs = L0.Cs;
       b.oZ = L0.oZ; b.oT = L0.oT; b.oR = L0.oR; b.oD = L0.oD; b.oC = L0.oC; b.oy = L0.oy; b.oa = L0.oa; b.oP = L0.oP;
       b.ou = L0.ou; b.ox = L0.ox; b.om = L0.om; b.oh = L0.oh;
@@ -654,7 +656,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
     // 21.4 ms in four chunks, 12.5 ms in one; 2 048 draws 46.9 -> 38.3 ms; two-state draws unchanged)
     int hint = 0;
     {
-      const double per_draw = (double)(p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m, p0) : bssm::ung_setup_scratch_doubles(n, m)) * sizeof(double);
+      const double per_draw = (double)(p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m, p0) : bssm::ung_setup_scratch_doubles(n, m_dev)) * sizeof(double);
       // the budget of a chunk's work arrays: 16 GB, and never more than a twelfth of what the device has free right now plus
       // what this library's arena could hand back (up to three chunks alive at once, beside their staging blocks, tables and
       // the filters' history pools of up to 24 GiB) -- a smaller or shared GPU gets smaller chunks instead of hipErrorOutOfMemory

@@ -793,35 +793,38 @@ bool psi_setup_begin(const HostModel& h, const double* is_mode, PsiSetup* out, L
 }
 
 bool ung_pack(const HostModel& h, const double* is_mode, LgPacked* lg) {
-  if (!is_mode || !LgHostModel::applies(h) || h.gaussian()) return false;
-  const int n = h.n, m = h.m, k = h.k;
+  // states of 9 ... 16 dimensions (a monthly seasonal: m = 13) are packed PADDED to 16 (round 5): zero rows / columns of Z, T, R R', C, a1,
+  // P1 -- the padded components stay exactly zero through the filter and the smoother, the products only gain exact zero terms, and the
+  // Jacobi rotations of the factors skip zero off-diagonals -- so that ONE device instantiation (ung_setup_kernel<16>) carries them
+  if (!is_mode || h.gaussian() || h.p != 1 || h.m < 1 || h.m > 16 || bssm::opt().generic_setup) return false;
+  const int n = h.n, mr = h.m, m = mr <= 8 ? mr : 16, k = h.k;
   lg->n = n; lg->m = m;
   lg->Zs = h.Ztv ? m : 0; lg->Ts = h.Ttv ? m * m : 0; lg->Rs = h.Rtv ? m * m : 0; lg->Ds = h.Dtv ? 1 : 0; lg->Cs = h.Ctv ? m : 0; lg->Hs = 1;
-  const int nR = h.Rtv ? n : 1;
-  const size_t nZ = (size_t)(h.Ztv ? n : 1) * m, nT = (size_t)(h.Ttv ? n : 1) * m * m, nRR = (size_t)nR * m * m;
-  const size_t nD = h.Dtv ? n : 1, nC = (size_t)(h.Ctv ? n : 1) * m;
+  const int nR = h.Rtv ? n : 1, nZt = h.Ztv ? n : 1, nTt = h.Ttv ? n : 1, nCt = h.Ctv ? n : 1;
+  const size_t nZ = (size_t)nZt * m, nT = (size_t)nTt * m * m, nRR = (size_t)nR * m * m;
+  const size_t nD = h.Dtv ? n : 1, nC = (size_t)nCt * m;
   size_t o = 0;
   lg->oZ = o; o += nZ; lg->oT = o; o += nT; lg->oR = o; o += nRR; lg->oD = o; o += nD; lg->oC = o; o += nC;
   lg->oy = o; o += n; lg->oH = lg->oy; lg->oa = o; o += m; lg->oP = o; o += (size_t)m * m;
   lg->ou = o; o += n; lg->ox = o; o += n; lg->om = o; o += n; lg->oh = o; o += 2;
-  lg->buf.resize(o);
+  lg->buf.assign(o, 0.0);
   double* b = lg->buf.data();
-  std::memcpy(b + lg->oZ, h.Z.data(), nZ * sizeof(double));
-  std::memcpy(b + lg->oT, h.T.data(), nT * sizeof(double));
+  for (int t = 0; t < nZt; t++) for (int c = 0; c < mr; c++) b[lg->oZ + (size_t)t * m + c] = h.Z[(size_t)t * mr + c];
+  for (int t = 0; t < nTt; t++) for (int j = 0; j < mr; j++) for (int i = 0; i < mr; i++) b[lg->oT + (size_t)t * m * m + i + m * j] = h.T[(size_t)t * mr * mr + i + mr * j];
   for (int t = 0; t < nR; t++) {  // R R' in LgHostModel's operation order
-    const double* R = h.R.data() + (size_t)m * k * t;
+    const double* R = h.R.data() + (size_t)mr * k * t;
     double* RR = b + lg->oR + (size_t)m * m * t;
-    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) {
+    for (int j = 0; j < mr; j++) for (int i = 0; i < mr; i++) {
       double sacc = 0.0;
-      for (int q = 0; q < k; q++) sacc += R[i + m * q] * R[j + m * q];
+      for (int q = 0; q < k; q++) sacc += R[i + mr * q] * R[j + mr * q];
       RR[i + m * j] = sacc;
     }
   }
   std::memcpy(b + lg->oD, h.D.data(), nD * sizeof(double));
-  std::memcpy(b + lg->oC, h.C.data(), nC * sizeof(double));
+  for (int t = 0; t < nCt; t++) for (int c = 0; c < mr; c++) b[lg->oC + (size_t)t * m + c] = h.C[(size_t)t * mr + c];
   std::memcpy(b + lg->oy, h.y.data(), (size_t)n * sizeof(double));
-  std::memcpy(b + lg->oa, h.a1.data(), (size_t)m * sizeof(double));
-  std::memcpy(b + lg->oP, h.P1.data(), (size_t)m * m * sizeof(double));
+  for (int c = 0; c < mr; c++) b[lg->oa + c] = h.a1[c];
+  for (int j = 0; j < mr; j++) for (int i = 0; i < mr; i++) b[lg->oP + i + m * j] = h.P1[i + mr * j];
   std::memcpy(b + lg->ou, h.u.data(), (size_t)n * sizeof(double));
   std::memcpy(b + lg->ox, h.xbeta.data(), (size_t)n * sizeof(double));
   std::memcpy(b + lg->om, is_mode, (size_t)n * sizeof(double));

@@ -20,7 +20,8 @@
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define LG_UNROLL _Pragma("unroll")
+// (complete unrolling up to 8 x 8; a 16 x 16 product -- states padded from 9 ... 16, round 5 -- stays a loop nest over scratch memory)
+#define LG_UNROLL _Pragma("unroll kUnroll")
 // the big routines are inlined into the set-up kernels: as separate device functions they get the default register budget of a
 // callee (256 VGPRs) instead of the 512 a one-wave-per-SIMD kernel owns, and keep their 8 x 8 work arrays in scratch memory
 #define LG_INL __attribute__((always_inline))
@@ -61,6 +62,7 @@ LG_HD inline bool lg_finite(double x) { return x == x && fabs(x) <= DBL_MAX; }
 template <int M>
 struct LgSmoother {
   static constexpr int MM = M * M;
+  static constexpr int kUnroll = M <= 8 ? M : 1;  // (LG_UNROLL)
   static constexpr double kZeroTol = 1e-12;  // src/model_ssm_ulg.h:19
   static constexpr double kEps = DBL_EPSILON;
 #if defined(__HIP_DEVICE_COMPILE__)

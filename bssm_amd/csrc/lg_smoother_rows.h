@@ -16,6 +16,10 @@
 
 namespace bssm {
 
+// (M = 16: the products stay completely unrolled -- static register indices -- but a scheduling fence ends every output element, so that
+// the compiler does not hoist the 256 LDS reads of a product in front of its multiply-adds: 920 spilt registers otherwise)
+#define LGR_FENCE do { if constexpr (M > 8) __builtin_amdgcn_sched_barrier(0); } while (0)
+
 template <int M>
 struct LgRows {
   static_assert(64 % M == 0, "M lanes per draw must tile the wave");
@@ -85,20 +89,22 @@ struct LgRows {
       I.sd = g.H[(size_t)t * g.Hs * es];
       I.Dv = g.D[((size_t)tr * g.Ds + js) * es];
     };
+    // (M = 16: the operands are loaded where they are used -- two sets of 67 doubles on top of the seven row arrays overflow the 512 registers)
+    constexpr bool kAhead = M <= 8;
     FwdIn fin, fnx;
-    if (n > 0) load_fwd(0, fin);
+    if (kAhead && n > 0) load_fwd(0, fin);
     for (int t = 0; t < n; t++) {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
       const bool moves = sub == 1 || js == sub - 1;
       (void)tr;
-      if (t + 1 < n) load_fwd(t + 1, fnx);
+      if constexpr (kAhead) { if (t + 1 < n) load_fwd(t + 1, fnx); } else load_fwd(t, fin);
 #pragma unroll
       for (int q = 0; q < M; q++) { Z[q] = fin.Z[q]; T[q] = fin.T[q]; RR[q] = fin.RR[q]; Cv[q] = fin.Cv[q]; }
       const double yt = fin.yt;
       const bool na = !lg_finite(yt);
       const double sd = fin.sd;
       const double Dt = fin.Dv;
-      fin = fnx;
+      if constexpr (kAhead) fin = fnx;
       const double HH = na ? 1.0 : sd * sd;
       // zp = Z' P = P Z (P is symmetric to the last bit: symmatu below): row r times Z
       double pz = 0.0, zp[M];
@@ -140,6 +146,7 @@ struct LgRows {
 #pragma unroll
         for (int q = 0; q < M; q++) s += ((r == q ? 1.0 : 0.0) - Kt[r] * Z[q]) * get(0, q, j);
         tmp[j] = s;
+        LGR_FENCE;
       }
 #pragma unroll
       for (int j = 0; j < M; j++) {
@@ -156,6 +163,7 @@ struct LgRows {
 #pragma unroll
           for (int q = 0; q < M; q++) s += T[q] * get(0, q, j);
           tmp[j] = s;
+          LGR_FENCE;
         }
         put(1, T);
 #pragma unroll
@@ -164,6 +172,7 @@ struct LgRows {
 #pragma unroll
           for (int q = 0; q < M; q++) s += tmp[q] * get(1, j, q);
           P1n[j] = s + RR[j];
+          LGR_FENCE;
         }
       } else {
 #pragma unroll
@@ -211,13 +220,13 @@ struct LgRows {
     // the first backward load reads what OTHER lanes of this draw stored in the last forward iteration (K, Fs, v): make those
     // stores visible first (the M lanes of a draw share a wave, one wave per workgroup here, so the barrier is cheap)
     __syncthreads();
-    if (n > 0) load_bwd(n - 1, bin);
+    if (kAhead && n > 0) load_bwd(n - 1, bin);
     for (int t = n - 1; t >= 0; t--) {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
       (void)tr;
       const bool movesb = sub == 1 || js == sub - 1;
       const bool need_P = sub == 1 || js == 0 || js == sub - 1, need_cc = sub == 1 || js == sub - 1;
-      if (t > 0) load_bwd(t - 1, bnx);
+      if constexpr (kAhead) { if (t > 0) load_bwd(t - 1, bnx); } else load_bwd(t, bin);
       const double F = bin.F, vt_b = bin.vt;
       const bool upd = F > 0.0;
       const double ar = bin.ar;
@@ -227,7 +236,7 @@ struct LgRows {
 #pragma unroll
         for (int j = 0; j < M; j++) ct[j] = bin.ct[j];
       }
-      bin = bnx;
+      if constexpr (kAhead) bin = bnx;
       double rn[M], N2[M], tmp[M], tmp2[M];
       if (movesb) {
         // L = T (I - K Z'), row r
@@ -247,6 +256,7 @@ struct LgRows {
 #pragma unroll
             for (int q = 0; q < M; q++) s += N[q] * get(0, q, j);
             tmp[j] = (r == j ? 1.0 : 0.0) - s;
+            LGR_FENCE;
           }
 #pragma unroll
           for (int j = 0; j < M; j++) {
@@ -254,6 +264,7 @@ struct LgRows {
 #pragma unroll
             for (int q = 0; q < M; q++) s += P[q] * get(1, j, q);
             tmp2[j] = s;
+            LGR_FENCE;
           }
           put(0, tmp);
 #pragma unroll
@@ -262,6 +273,7 @@ struct LgRows {
 #pragma unroll
             for (int q = 0; q < M; q++) s += tmp2[q] * get(0, q, j);
             ct[j] = s;
+            LGR_FENCE;
           }
         }
         // r_{t-1} = L' r_t ; N_{t-1} = L' N L  (column r of L from buffer 1)
@@ -276,6 +288,7 @@ struct LgRows {
 #pragma unroll
           for (int q = 0; q < M; q++) s += get(1, q, r) * get(0, q, j);
           tmp[j] = s;
+          LGR_FENCE;
         }
 #pragma unroll
         for (int j = 0; j < M; j++) {
@@ -283,6 +296,7 @@ struct LgRows {
 #pragma unroll
           for (int q = 0; q < M; q++) s += tmp[q] * get(1, q, j);
           N2[j] = s;
+          LGR_FENCE;
         }
       } else {
         // a virtual step inside a time point: L = I - K Z' (the identity without an update); with w = N K, kappa = K' w:
@@ -326,6 +340,7 @@ struct LgRows {
 #pragma unroll
           for (int q = 0; q < M; q++) s += P[q] * get(0, q, j);
           tmp[j] = s;
+          LGR_FENCE;
         }
         put(1, P);
 #pragma unroll
@@ -334,6 +349,7 @@ struct LgRows {
 #pragma unroll
           for (int q = 0; q < M; q++) s += tmp[q] * get(1, q, j);
           tmp2[j] = s;
+          LGR_FENCE;
         }
         symmatu(tmp2);
 #pragma unroll

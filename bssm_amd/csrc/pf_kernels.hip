@@ -520,7 +520,7 @@ struct UngWork {
 };
 template <int M, int PHASE, bool ROWS>
 __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
-  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16)));
   constexpr int DPW = (PHASE == 1 && ROWS) ? 64 / M : 64;  // draws per workgroup
   const int d0 = blockIdx.x * DPW + ((PHASE == 1 && ROWS) ? (int)threadIdx.x / M : (int)threadIdx.x);
   if (!(PHASE == 1 && ROWS) && d0 >= b.F) return;
@@ -649,9 +649,13 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64);
   hipLaunchKernelGGL((ung_setup_kernel<M, 0, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   const bool lane_form = opt().mng_lane_per_draw;  // (comparison switch, shared with the ssm_mng set-up)
-  constexpr int MR = (M == 8 || M == 4) ? M : 1;  // (as the ssm_mng set-up: rows for 8 and 4 states)
-  if ((M == 8 || M == 4) && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<MR, 1, true>), dim3((unsigned)((b.F + 64 / MR - 1) / (64 / MR))), dim3(64), 0, stream, b);
-  else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
+  constexpr int MR = (M == 16 || M == 8 || M == 4) ? M : 1;  // (as the ssm_mng set-up: rows for 16, 8 and 4 states)
+  if constexpr (M == 16) {  // (no one-lane-per-draw form: five 16 x 16 matrices do not fit a lane)
+    hipLaunchKernelGGL((ung_setup_kernel<16, 1, true>), dim3((unsigned)((b.F + 3) / 4)), dim3(64), 0, stream, b);
+  } else {
+    if ((M == 8 || M == 4) && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<MR, 1, true>), dim3((unsigned)((b.F + 64 / MR - 1) / (64 / MR))), dim3(64), 0, stream, b);
+    else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
+  }
   hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   hipLaunchKernelGGL((ung_setup_kernel<M, 3, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   return hipGetLastError();
@@ -667,6 +671,7 @@ hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream) {
     case 6: return launch_ung_setup_m<6>(b, stream);
     case 7: return launch_ung_setup_m<7>(b, stream);
     case 8: return launch_ung_setup_m<8>(b, stream);
+    case 16: return launch_ung_setup_m<16>(b, stream);  // (9 ... 16 states arrive padded to 16: ung_pack)
     default: return hipErrorInvalidValue;
   }
 }
