@@ -30,4 +30,4 @@ for period, n, ns in ((12, 200, 2048), (12, 200, 256), (7, 200, 2048)):
         ll[dev] = r["loglik"]
         row.append("%s %8.1f ms" % ("device set-up" if dev == "2" else "host set-up, %d thread(s)" % threads, best * 1e3))
     print("bsm_ng period %2d (m = %2d), T = %d, %4d draws x psi-APF N = 64 | " % (period, m, n, ns) + " | ".join(row)
-          + " | max |dloglik| device vs host %.1e" % np.abs(ll["2"] - ll["0"]).max(), flush=True)
+          + " | |dloglik| device vs host: max %.1e, median %.1e, draws above 1e-6: %d" % (np.abs(ll["2"] - ll["0"]).max(), np.median(np.abs(ll["2"] - ll["0"])), int((np.abs(ll["2"] - ll["0"]) > 1e-6).sum())), flush=True)

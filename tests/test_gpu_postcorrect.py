@@ -375,15 +375,18 @@ def test_full_device_ung_setup_against_oracle(oracle, monkeypatch, kind, output_
         if output_type == 2:
             # (the seasonal model's smoothing covariances are singular: the factors amplify last-ulp differences between the
             # oracle's generic matrix code and the fixed-size template to ~1e-8 of the state scale)
-            assert np.allclose(res[dev]["alphahat"], ref["alphahat"].T, rtol=1e-6, atol=1e-8)
-            assert np.allclose(res[dev]["Vt"], ref["Vt"], rtol=1e-6, atol=1e-8)
+            # (thirteen states: 1e-7 of the state scale -- the device-vs-host differences of the log-likelihoods are of the same size at m = 8
+            # and m = 13, median 2e-8 / 3e-8, profiles/r05_seasonal_setup.txt)
+            at = 2e-7 if kind == "bsm_poisson_monthly" else 1e-8
+            assert np.allclose(res[dev]["alphahat"], ref["alphahat"].T, rtol=1e-6, atol=at)
+            assert np.allclose(res[dev]["Vt"], ref["Vt"], rtol=1e-6, atol=at)
     # device set-up vs host set-up: the same template and operation order (the device contracts to FMA, its exp / log differ
     # from libm's in the last place, and near-singular factors amplify that: 1e-8 of the state scale at most)
     # (the weekly-seasonal model: eight states, singular smoothing covariances -- the amplification reaches 2e-8 of the
     # log-likelihood; the one-lane and the row-distributed device kernels agree bit for bit there, the host agrees with the oracle)
     assert np.allclose(res["2"]["loglik"], res["0"]["loglik"], rtol=0, atol=(2e-9 if kind in ("bsm_poisson_weekly", "bsm_poisson_monthly") else 1e-10) * n)
     if output_type == 2:
-        loose = kind == "bsm_poisson_weekly"
+        loose = kind in ("bsm_poisson_weekly", "bsm_poisson_monthly")
         assert np.allclose(res["2"]["alphahat"], res["0"]["alphahat"], rtol=1e-6 if loose else 1e-7, atol=1e-7 if loose else 1e-9)
 
 
