@@ -890,6 +890,12 @@ def main():
                                              "value": psb, "unit": "particle-steps/s", "ms_per_pass": eb * 1e3, "kernel": pbg.last_kernel(),
                                              "roofline": {"bound": "mfma", "achieved": psb * flops / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                                           "frac": psb * flops / 78.6e12, "flops_per_particle_step_on_the_tiles": flops}}
+                if "row" in big["period_%d" % period]["kernel"]:
+                    # the row shape keeps the particle system in HBM: SURVEY 8(d)'s log-likelihood-only figure, 16 m + 16 bytes per particle-step
+                    # (ancestor gather + new state, weights exchange) -- at these dimensions that roof is the nearer one
+                    hb = psb * (16.0 * mb + 16.0)
+                    big["period_%d" % period]["roofline_hbm"] = {"bound": "hbm", "achieved": hb / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hb / 8e12,
+                                                                 "bytes_per_particle_step": 16.0 * mb + 16.0}
                 pbg.close()
             out["big_states"] = big
         except Exception as e:  # noqa: BLE001
