@@ -1024,7 +1024,7 @@ hipFunction_t jit_kernel(JitModel& jm, const std::string& name, std::string* err
   const std::string dir = library_dir(), tu = jit_translation_unit(jm);
   // cache key: everything that is compiled into the code object
   std::string hk = std::string(bssm_amd_version()) + "|" + arch + "|" + name + "|" + tu;
-  for (const char* hdr : {"pf_filter_impl.h", "pf_row_step.h", "pf_canon.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "pf_math_tables.h"}) {
+  for (const char* hdr : {"pf_filter_impl.h", "pf_grid_v2.h", "pf_row_step.h", "pf_canon.h", "pf_functors.h", "pf_device.h", "pf_kernels.h", "pf_math.h", "pf_math_tables.h"}) {
     FILE* hf = std::fopen((dir + "/csrc/" + hdr).c_str(), "rb");
     if (!hf) { *err = "kernel sources not found next to the library: " + dir + "/csrc/" + hdr; return nullptr; }
     char buf[1 << 16];
@@ -1127,18 +1127,29 @@ hipError_t jit_launch_wg(const bssm::FilterBatch* bp, hipStream_t stream) {
   return hipModuleLaunchKernel(fn, (unsigned)b.F, 1, 1, (unsigned)nt, 1, 1, (unsigned)lds, stream, args, nullptr);
 }
 
-// row family (pf_row_step.h): the time loop of launch_row_loop with module launches
+// one launch per time step: the row family (pf_row_step.h, the time loop of launch_row_loop) up to 16 384 particles, the step kernel
+// (pf_grid_v2.h, the time loop of launch_grid_mk) beyond -- with module launches
 hipError_t jit_launch_grid(const bssm::FilterBatch* bp, const bssm::GridWorkspace* wsp_in, hipStream_t stream, bssm::StepTiming* timing) {
   JitModel* jm = jit_of(bp->user_slot);
   if (!jm || bp->psi != 0 || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process runs the bootstrap filter only (psi-APF / EKF particle filter: bssm_user_model_build)"); return hipErrorInvalidValue; }
   const bssm::GridWorkspace& ws = *wsp_in;
-  if (ws.chunk != bssm::CANON_ROW || bp->N > bssm::CANON_ROW * bssm::ROW_MAX_ROWS) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process takes up to 16384 particles (more: bssm_user_model_build)"); return hipErrorInvalidValue; }
+  constexpr int kGridNT = 256, kMaxBlocks = 256;  // GRID_NT (pf_filter_impl.h), V2_MAX_BLOCKS (pf_grid_v2.h)
+  const bool rows = ws.chunk == bssm::CANON_ROW;
+  if (rows && bp->N > bssm::CANON_ROW * bssm::ROW_MAX_ROWS) return hipErrorInvalidValue;
+  const int ppt = rows ? 0 : ws.chunk / kGridNT;
+  if (!rows && (ws.B > kMaxBlocks || (ppt != 1 && ppt != 2 && ppt != 4))) return hipErrorInvalidValue;
   bssm::FilterBatch b = *bp;
   b.user_slot = 0;
   const int MP = jm->MP;
+  const bool wx = !rows && b.weights != nullptr && bssm::opt().grid_v2_wx != 0;  // weights exchange, as launch_grid_mk
   char n_step[160], n_init[160];
-  std::snprintf(n_step, sizeof n_step, "bssm::pf_row_step<%d,%d,%d,0>", MP, MP, jm->fn_id);
-  std::snprintf(n_init, sizeof n_init, "bssm::pf_row_init<%d,%d,%d,0>", MP, MP, jm->fn_id);
+  if (rows) {
+    std::snprintf(n_step, sizeof n_step, "bssm::pf_row_step<%d,%d,%d,0>", MP, MP, jm->fn_id);
+    std::snprintf(n_init, sizeof n_init, "bssm::pf_row_init<%d,%d,%d,0>", MP, MP, jm->fn_id);
+  } else {
+    std::snprintf(n_step, sizeof n_step, "bssm::pf_grid_step_v2_fn<%d,%d,%s,%d,0>", MP, ppt, wx ? "true" : "false", jm->fn_id);
+    std::snprintf(n_init, sizeof n_init, "bssm::pf_grid_init_v2<%d,%d,false,%d,0>", MP, ppt, jm->fn_id);
+  }
   std::string err;
   hipFunction_t f_step = jit_kernel(*jm, n_step, &err), f_init = f_step ? jit_kernel(*jm, n_init, &err) : nullptr;
   if (!f_step || !f_init) { fail(BSSM_ERR_INVALID, err); return hipErrorInvalidValue; }
@@ -1146,10 +1157,11 @@ hipError_t jit_launch_grid(const bssm::FilterBatch* bp, const bssm::GridWorkspac
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;
-  const int wgs = (ws.B + 3) / 4;
-  int parts = (b.F >= 8 && ws.side) ? 2 : 1;
+  const int wgs = rows ? (ws.B + 3) / 4 : ws.B;
+  int parts = ((rows ? b.F >= 8 : ((long long)b.F * ws.B >= (ws.chunk >= 2 * kGridNT ? 384 : 512) && b.F >= 2)) && ws.side) ? 2 : 1;
   hipStream_t lanes[2] = {stream, parts == 2 ? ws.side : stream};
   bssm::GridWorkspace w2[2] = {ws, ws};
+  for (int q = 0; q < 2; q++) { w2[q].wx = wx ? 1 : 0; w2[q].fw = 0; }
   int fcount[2] = {b.F, 0};
   hipEvent_t fork = nullptr, join = nullptr;
   if (parts == 2) {

@@ -400,7 +400,7 @@ struct DeviceBatch {
   int alloc_step_workspace() {
     // (states of more than 16 dimensions -- pf_big.h -- have no other step shape than the row family: up to 16 384 particles)
     if (fb.MP >= 32 && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "nsim above 16384 is not supported for states of more than 16 dimensions");
-    if (bssm::user_slot_rows_only(fb.user_slot) && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process takes up to 16384 particles (more: bssm_user_model_build)");
+    // (a user model compiled in process takes the row family wherever it reaches -- one kernel variant to compile instead of one per particles-per-lane)
     if ((bssm::opt().force_path == 3 || fb.MP >= 32 || bssm::user_slot_rows_only(fb.user_slot)) && bssm::row_filter_supported(fb)) {
       HIP_TRY(ws.alloc(bssm::row_workspace_bytes(fb)));
       bssm::row_workspace_carve(fb, ws.p, &gws);

@@ -844,9 +844,7 @@ constexpr int GRID_NT = 256;
 // per particle -- is gone: every model class steps through pf_grid_step_v2 / pf_grid_step_v2_fn or the row family, pf_row_step.h)
 
 }  // namespace bssm
-#ifndef __HIPCC_RTC__
 #include "pf_grid_v2.h"
-#endif
 #include "pf_row_step.h"
 #ifndef __HIPCC_RTC__
 #ifndef BSSM_USER_MODEL

@@ -1133,6 +1133,7 @@ __global__ void __launch_bounds__(GRID_NT, v2_fn_occupancy(MP, PPT)) pf_grid_ste
   v2_block_of(ws, pb, f);
   (void)v2_step_body<MP, MP, PPT, false, WX, false, false, FN, PM>(b, ws, t, pb, f, true);
 }
+#ifndef __HIPCC_RTC__   // (host-side kernel selection: not part of the device-only view hiprtc compiles)
 template <int MP, int PPT, int FNV>
 auto v2_fn_kernels(int psi, bool wx, void (**init)(const FilterBatch, const GridWorkspace)) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
   // (BSSM_FN_PSI_MASK, pf_filter_impl.h: the samplers this translation unit instantiates -- a user model's library builds them in separate units)
@@ -1143,16 +1144,21 @@ auto v2_fn_kernels(int psi, bool wx, void (**init)(const FilterBatch, const Grid
 }
 
 
+#endif
+
 #ifdef BSSM_XCD_PERSIST
 }  // namespace bssm
 #include "experiments/xcd_persist.h"   // measured and NOT kept (profiles/r04_xcd_persistent.txt): only `make persist` builds see it
 namespace bssm {
 #endif
 
+#ifndef __HIPCC_RTC__
 template <int MP, int KP, int PPT, bool MS>
 inline auto v2_step_kernel(bool wx, bool exact) -> void (*)(const FilterBatch, const GridWorkspace, const int) {
   if (wx) return exact ? pf_grid_step_v2<MP, KP, PPT, MS, true, true> : pf_grid_step_v2<MP, KP, PPT, MS, true, false>;
   return exact ? pf_grid_step_v2<MP, KP, PPT, MS, false, true> : pf_grid_step_v2<MP, KP, PPT, MS, false, false>;
 }
+
+#endif
 
 }  // namespace bssm

@@ -225,7 +225,7 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
  * what Rcpp::sourceCpp is to the reference's session (R/cpp_example_models.R:762).  Returns the registry slot (>= 1) directly.  Only the
  * kernel variant a call needs is compiled, the first time it is needed (1-2 s; the smallest workgroup-resident variant at once, so a
  * snippet with an error fails here with the compiler's log); code objects are cached on disk by content hash.  Such a slot runs the
- * BOOTSTRAP filter / smoother / bootstrap IS correction (up to 16384 particles); the psi-APF and the EKF particle filter evaluate the
+ * BOOTSTRAP filter / smoother / bootstrap IS correction (any particle count the hipcc-built library takes); the psi-APF and the EKF particle filter evaluate the
  * snippet on the host during their set-up and refuse a JIT slot with a message -- use bssm_user_model_build + _load for those.  Results
  * are bit-identical to the hipcc-built library of the same snippet (same kernel templates, same arithmetic). */
 int bssm_user_model_jit(const char* source, int32_t n_states);

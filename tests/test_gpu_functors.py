@@ -1058,19 +1058,27 @@ def test_user_model_compiled_in_process_equals_the_hipcc_built_library(oracle, t
     uh = mk(False)
     ref = oracle.fn_bsf_filter({**b, "L": 0}, 300, seed=4)
     assert np.array_equal(first["indices"], ref["indices"]) and abs(first["logLik"] - ref["logLik"]) <= 1e-9 * b.n
-    for N, path in ((300, None), (1500, None), (5000, None), (3000, "row"), (12000, None)):
+    for N, path in ((300, None), (1500, None), (5000, None), (3000, "row"), (12000, None), (40000, None)):
         if path: monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
         oj = F.bootstrap_filter(uj, N, seed=6, return_indices=True)
         kern = FilterPlan.last_kernel()
         if path: monkeypatch.delenv("BSSM_AMD_FORCE_PATH")
         assert "[hiprtc]" in kern, kern
-        if N <= 8192:   # (the hipcc-built library takes the round-1 step kernel beyond the row family's reach by default)
+        if N <= 8192:   # (the hipcc-built library takes the step kernel above the workgroup-resident sizes by default, the in-process one the row family)
             monkeypatch.setenv("BSSM_AMD_FORCE_PATH", "row" if ("pf_row_step" in kern) else "wg")
             oh = F.bootstrap_filter(uh, N, seed=6, return_indices=True)
             monkeypatch.delenv("BSSM_AMD_FORCE_PATH")
             for k in ("indices", "weights", "alpha"):
                 assert np.array_equal(oj[k], oh[k]), (N, k)
             assert oj["logLik"] == oh["logLik"]
+        elif N > 16384:   # beyond the row family: the step kernel (pf_grid_step_v2_fn) on both routes since round 5 -- same template, same bits
+            assert "pf_grid_step_v2_fn" in kern, kern
+            oh = F.bootstrap_filter(uh, N, seed=6, return_indices=True)
+            for k in ("indices", "weights", "alpha"):
+                assert np.array_equal(oj[k], oh[k]), (N, k)
+            assert oj["logLik"] == oh["logLik"]
+            r2 = oracle.fn_bsf_filter({**b, "L": 0}, N, seed=6)
+            assert np.array_equal(oj["indices"], r2["indices"]) and abs(oj["logLik"] - r2["logLik"]) <= 1e-9 * b.n
         else:
             r2 = oracle.fn_bsf_filter({**b, "L": 0}, N, seed=6)
             assert np.array_equal(oj["indices"], r2["indices"]) and abs(oj["logLik"] - r2["logLik"]) <= 1e-9 * b.n
