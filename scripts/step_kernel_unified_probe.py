@@ -8,6 +8,7 @@ import time
 
 import numpy as np
 
+if not os.environ.get("PYTHONPATH"): sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # (a PYTHONPATH selects the build under test)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from bssm_amd import filters as F, models as M   # noqa: E402
 from bssm_amd.plan import FilterPlan             # noqa: E402
