@@ -35,12 +35,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # fp64 VALU issue roof: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles (16 lanes per clock) at 2.4 GHz
 VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 4
 # wave-level VALU instructions per particle-step of the workgroup-resident kernels, from the PMC passes committed under
-# profiles/r04_pmc_*.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_r04.sh; regime B: profiles/r04_pmc_regb.txt)
+# profiles/r05_pmc_*.txt (SQ_INSTS_VALU per dispatch / particle-steps per dispatch; scripts/profile_r05.sh; regime B: profiles/r04_pmc_regb_v2.txt);
+# fallbacks only: the run measures them live (live_valu_counts)
 REGB_VALU_PER_PSTEP = 10595336946.0 / (512 * 2048 * 1000.0)   # pf_wg_kernel<4,4,2,false,1024> (profiles/r04_pmc_regb_v2.txt; the 512-thread kernel of rounds 3-4: 9.59e9, r04_pmc_regb.txt)
-C5_VALU_PER_PSTEP = 17732461621.0 / (2340.0 * 4096 * 300.0)   # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), one dispatch of 2 340 draws (profiles/r04_pmc_C5.txt, late-round-4 entry; 18.13e9 before the logarithm of the log-likelihood moved to one wave)
+C5_VALU_PER_PSTEP = 16856741689.0 / (2304.0 * 4096 * 300.0)   # pf_wg_kernel<2,2,4,1,1024,1,exact> (nlg_growth, psi-APF), one dispatch of 2 304 of the 2 340 draws -- the other 36 take the row family (profiles/r05_pmc_C5.txt; round 4: 17.73e9 for 2 340)
 C5_KERNEL = "pf_wg_kernel<2,2,4,1,1024,1,exact>"
-HEAD_VALU_PER_PSTEP = 7813185.0 / (16 * 65536.0)                # pf_grid_step_v2<4,4,4,false,true,true>: 7.81 M per launch of 16 filters x 65 536 particles (profiles/r04_pmc_sq1_summary.txt; round 3: 8.36 M)
-C4_VALU_PER_PSTEP = 6583014.7 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r04_pmc_C4.txt; round 3: 7.14 M)
+HEAD_VALU_PER_PSTEP = 7874668.9 / (16 * 65536.0)                # pf_grid_step_v2<4,4,4,false,true,true>: 7.87 M per launch of 16 filters x 65 536 particles (profiles/r05_pmc_sq1_summary.txt; round 4: 7.81 M, round 3: 8.36 M)
+C4_VALU_PER_PSTEP = 6658864.9 / (32 * 16384.0)                 # pf_grid_step_v2<8,8,2,true,...>: SQ_INSTS_VALU per launch of 32 filters x 16 384 particles (profiles/r05_pmc_C4.txt; round 4: 6.58 M, round 3: 7.14 M)
 
 
 def valu_roofline(valu_per_pstep, psteps_per_s, kernel, clock=None, key=None):
@@ -51,7 +52,7 @@ def valu_roofline(valu_per_pstep, psteps_per_s, kernel, clock=None, key=None):
     out = {"bound": "valu_fp64_issue", "kernel": kernel, "achieved": a / 1e9, "peak": VALU_PEAK_WAVE_INSTR_S / 1e9,
            "unit": "G wave-instr/s", "frac": a / VALU_PEAK_WAVE_INSTR_S, "valu_wave_instr_per_particle_step": valu_per_pstep,
            "lane_instr_per_particle_step": valu_per_pstep * 64, "valu_source": valu_source,
-           "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r04_pmc_sq1_summary.txt, r04_pmc_C4.txt, r04_pmc_C5.txt, r04_pmc_regb_v2.txt); rate: measured live"}
+           "source": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU (profiles/r05_pmc_sq1_summary.txt, r05_pmc_C4.txt, r05_pmc_C5.txt, r04_pmc_regb_v2.txt); rate: measured live"}
     if clock and clock.get("sclk_mhz"):
         # the issue roof at the engine clock the kernel actually ran at (the socket power limit holds it under 2.4 GHz)
         out["frac_at_sampled_clock"] = a / (256 * 4 * clock["sclk_mhz"] * 1e6 / 4)
@@ -105,11 +106,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def pmc_traffic(R, N, ppt, kernel, factored):
-    """HBM bytes per pf_grid_step launch from the PMC passes committed for THIS round's kernel (profiles/r04_pmc_traffic*.json:
+    """HBM bytes per pf_grid_step launch from the PMC passes committed for THIS round's kernel (profiles/r05_pmc_traffic*.json:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this script by scripts/profile_r03.sh, corrected as MI355X_MICROARCH.md
     prescribes and calibrated on calib_copy_kernel's known byte count in the same process); None unless the profile was
     taken on exactly this workload, kernel variant and weights layout (a counter pass cannot run inside a timed run)."""
-    name = "r04_pmc_traffic.json" if factored else "r04_pmc_traffic_reference_layout.json"
+    name = "r05_pmc_traffic.json" if factored else "r05_pmc_traffic_reference_layout.json"
     try:
         p = json.load(open(os.path.join(ROOT, "profiles", name)))
         same_kernel = p["kernel"].replace(" ", "").endswith(kernel.replace(" ", ""))
@@ -729,7 +730,7 @@ def main():
         committed = pmc_traffic(R // seqs, N, ppt, plan.last_kernel(), layout["factored"])
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": committed,
-                           "traffic_source": "profiles/r04_pmc_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script at this kernel)" % ("" if layout["factored"] else "_reference_layout"),
+                           "traffic_source": "profiles/r05_pmc_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script at this kernel)" % ("" if layout["factored"] else "_reference_layout"),
                            "traffic_committed_profile": committed,
                            "kernel": plan.last_kernel(), "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
                            "concurrent_launches": seqs, "filters_per_launch": R // seqs,
