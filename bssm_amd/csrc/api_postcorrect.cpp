@@ -305,37 +305,80 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           // tail depends on the draws per chunk, the shard layout and the CU count, and the output does not.  (Rounds 3-4 sent the
           // tail through the step kernels, whose reduction shape differs: opt-in, results depended on the device list.)
           // Not when a path is forced, and only for the shapes the row family carries (row_filter_supported).  BSSM_AMD_TAIL_SPLIT=0 turns it off.
-          int tail = 0;
+          int tail = 0, cus_round = 0;
           if (all_rows) tail = sub.F;
           else if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && bssm::opt().force_path == 0 && bssm::opt().tail_split &&
               bssm::row_filter_supported(sub)) {
             int dev = 0; hipDeviceProp_t prop;
             const int cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
             const int r = sub.F % cus;
-            if (r > 0 && r <= cus * bssm::opt().tail_max_eighths / 8) tail = r;
+            if (r > 0 && r <= cus * bssm::opt().tail_max_eighths / 8) { tail = r; cus_round = cus; }
           }
           bssm::FilterBatch head = sub;
           head.F = sub.F - tail;
-          if (head.F > 0) {
-            HIP_TRY(bssm::launch_wg_filter(head, nullptr));
-            HIP_TRY(bssm::launch_zero_dead_tail(head, true, nullptr));
+          // Round 5, late: with BOTH a full round and a tail, the tail steps BESIDE the last full round instead of behind it -- that round runs
+          // the 96-register form of the workgroup kernel where one exists (pf_wg_kernel_lean: same bits), which leaves register file and LDS
+          // for the tail's row-family workgroups on every CU.  The tail's launch sequence goes on a stream of its own, forked from and joined
+          // to the chunk's stream.  BSSM_AMD_TAIL_CONCURRENT=0: the tail behind the round, as before.
+          hipStream_t tstream = nullptr;
+          hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+          bool conc = bssm::opt().tail_concurrent && head.F > 0 && tail > 0;
+          if (conc) {
+            static thread_local bssm::TlsStream tail_stream;   // (at the highest stream priority: measured, no difference)
+            tstream = tail_stream.get();
+            conc = tstream != nullptr && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess;
           }
-          if (tail > 0) {
-            const size_t h0 = (size_t)head.F;
-            bssm::FilterBatch tl = sub;
-            tl.F = tail;
-            tl.mats += db.fb.mats_fstride * h0; tl.obs += db.fb.obs_fstride * h0; tl.init += db.fb.init_fstride * h0;
-            tl.loglik += h0; tl.dead_at += h0;
-            if (tl.fpar) tl.fpar += tl.fpar_fstride * h0;
-            if (tl.amats) tl.amats += tl.amats_fstride * h0;
-            if (need_hist) { tl.alpha_hist += h0 * (size_t)(n + 1) * m * N; tl.indices += h0 * (size_t)n * N; }
-            tl.stream0 = sub.stream0 + (uint32_t)h0;
+          // filters [f_begin, f_begin + count) of the sub-batch
+          auto slice = [&](int f_begin, int count) {
+            const size_t h0 = (size_t)f_begin;
+            bssm::FilterBatch q = sub;
+            q.F = count;
+            q.mats += db.fb.mats_fstride * h0; q.obs += db.fb.obs_fstride * h0; q.init += db.fb.init_fstride * h0;
+            q.loglik += h0; q.dead_at += h0;
+            if (q.fpar) q.fpar += q.fpar_fstride * h0;
+            if (q.amats) q.amats += q.amats_fstride * h0;
+            if (need_hist) { q.alpha_hist += h0 * (size_t)(n + 1) * m * N; q.indices += h0 * (size_t)n * N; }
+            q.stream0 = sub.stream0 + (uint32_t)h0;
+            return q;
+          };
+          auto launch_wg_part = [&](int f_begin, int count, bool lean) -> int {
+            if (count <= 0) return 0;
+            bssm::FilterBatch q = slice(f_begin, count);
+            q.lean = lean ? 1 : 0;
+            HIP_TRY(bssm::launch_wg_filter(q, nullptr));
+            HIP_TRY(bssm::launch_zero_dead_tail(q, true, nullptr));
+            return 0;
+          };
+          auto launch_tail = [&](hipStream_t st) -> int {
+            if (tail <= 0) return 0;
+            bssm::FilterBatch tl = slice(head.F, tail);
             tail_ws.emplace_back();
             HIP_TRY(tail_ws.back().alloc(bssm::row_workspace_bytes(tl)));
             bssm::GridWorkspace gw;
             bssm::row_workspace_carve(tl, tail_ws.back().p, &gw);
-            HIP_TRY(bssm::launch_grid_filter(tl, gw, nullptr));
-            HIP_TRY(bssm::launch_zero_dead_tail(tl, true, nullptr));
+            HIP_TRY(bssm::launch_grid_filter(tl, gw, st));
+            HIP_TRY(bssm::launch_zero_dead_tail(tl, true, st));
+            return 0;
+          };
+          if (conc) {
+            // the full rounds before the last one keep the 128-register kernel (the 96-register form spills more: 2 340 draws as ONE lean
+            // launch took 41.8 ms against 40.7); the tail is released when they are done and runs beside the last round
+            const int last = cus_round > 0 && head.F > cus_round ? cus_round : head.F;
+            if (int rc2 = launch_wg_part(0, head.F - last, false)) return rc2;
+            HIP_TRY(hipEventRecord(ev_fork, nullptr));
+            HIP_TRY(hipStreamWaitEvent(tstream, ev_fork, 0));
+            // (the round first: enqueueing the tail's ~600 launches takes the host ~0.6 ms, which the round must not wait for)
+            if (int rc2 = launch_wg_part(head.F - last, last, true)) return rc2;
+            if (int rc2 = launch_tail(tstream)) return rc2;
+            HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ev_join, tstream));
+            HIP_TRY(hipStreamWaitEvent(nullptr, ev_join, 0));
+            (void)hipEventDestroy(ev_join);
+            (void)hipEventDestroy(ev_fork);
+          } else {
+            if (ev_fork) (void)hipEventDestroy(ev_fork);
+            if (int rc2 = launch_wg_part(0, head.F, false)) return rc2;
+            if (int rc2 = launch_tail(nullptr)) return rc2;
           }
         }
         f0 = f1;

@@ -57,6 +57,7 @@ Options read_env() {
   o.trace = env_set("BSSM_AMD_TRACE") ? std::max(1, env_int("BSSM_AMD_TRACE", 1)) : 0;
   { const char* e = std::getenv("BSSM_AMD_TAIL_SPLIT"); o.tail_split = !(e && e[0] == '0'); }  // on unless BSSM_AMD_TAIL_SPLIT=0
   if (const char* e = std::getenv("BSSM_AMD_TAIL_MAX_EIGHTHS")) o.tail_max_eighths = std::max(0, std::min(8, std::atoi(e)));
+  if (const char* e = std::getenv("BSSM_AMD_TAIL_CONCURRENT")) o.tail_concurrent = std::atoi(e) != 0;
   if (const char* e = std::getenv("BSSM_AMD_FORCE_PATH")) o.force_path = !std::strcmp(e, "wg") ? 1 : (!std::strcmp(e, "grid") ? 2 : (!std::strcmp(e, "row") ? 3 : 0));
   o.grid_ppt = env_int("BSSM_AMD_GRID_PPT", 0);
   o.grid_v2_wx = env_tri("BSSM_AMD_GRID_V2_WX");

@@ -23,6 +23,7 @@
 #include <type_traits>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #endif
 
 #include "pf_device.h"
@@ -450,7 +451,7 @@ constexpr int wg_waves_per_simd() {
 // EX: the particle count is exactly NTB * PPT (4096 = 1024 x 4, the shape IS post-correction of config C5 runs): N is a
 // compile-time constant, every `i < N` guard and the pivot / window arithmetic derived from N fold away
 template <int MP, int KP, int PPT, int FN = FN_NONE, int NTB = WG_NT_MAX, int PM = -1, bool EX = false>
-__global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) pf_wg_kernel(const FilterBatch b) {
+__device__ __forceinline__ void pf_wg_body(const FilterBatch& b) {
   constexpr int FID = FN > 0 ? FN : 0;
   const int psi_mode = PM >= 0 ? PM : b.psi;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -710,13 +711,25 @@ __global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) 
 #endif
   if (tid == 0 && b.loglik) b.loglik[f] = loglik;
 }
+template <int MP, int KP, int PPT, int FN = FN_NONE, int NTB = WG_NT_MAX, int PM = -1, bool EX = false>
+__global__ void __launch_bounds__(NTB, (wg_waves_per_simd<MP, PPT, FN, NTB>())) pf_wg_kernel(const FilterBatch b) {
+  pf_wg_body<MP, KP, PPT, FN, NTB, PM, EX>(b);
+}
+// LEAN: the same filter in 96 registers (five waves per SIMD budgeted, four used by the workgroup) -- the LAST round of a post-correction
+// chunk runs it when the chunk has a tail: the register file then has room for the tail's row-family workgroups (64 registers per lane),
+// and the tail steps BESIDE that round instead of behind it (api_postcorrect.cpp).  Same arithmetic, same bits; more spills, so the
+// full rounds keep the 128-register kernel.
+template <int MP, int KP, int PPT, int FN = FN_NONE, int NTB = WG_NT_MAX, int PM = -1, bool EX = false>
+__global__ void __launch_bounds__(NTB, NTB / 256 + 1) pf_wg_kernel_lean(const FilterBatch b) {
+  pf_wg_body<MP, KP, PPT, FN, NTB, PM, EX>(b);
+}
 
 #ifndef __HIPCC_RTC__   // host side: kernel selection and launch (the in-process compile of a user model takes the kernels only)
 // the functor kernel of one shape for the batch's sampler (0 bootstrap, 1 psi-APF, 2 EKF particle filter: MP <= 2 only)
 // the exact-size psi-APF variant: instantiated for the 1024-thread kernels at four particles per lane only
 template <int MP, int PPT, int FNV, int NTB>
-auto wg_fn_kernel_exact(int psi) -> void (*)(const FilterBatch) {
-  if constexpr (NTB == 1024 && PPT == 4 && MP <= 2) { if (psi == 1) return pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1, true>; }
+auto wg_fn_kernel_exact(int psi, bool lean = false) -> void (*)(const FilterBatch) {
+  if constexpr (NTB == 1024 && PPT == 4 && MP <= 2) { if (psi == 1) return lean ? pf_wg_kernel_lean<MP, MP, PPT, FNV, NTB, 1, true> : pf_wg_kernel<MP, MP, PPT, FNV, NTB, 1, true>; }
   return nullptr;
 }
 // BSSM_FN_PSI_MASK: the samplers (bit 0 bootstrap, bit 1 psi-APF, bit 2 EKF particle filter) a translation unit instantiates
@@ -732,6 +745,15 @@ auto wg_fn_kernel(int psi) -> void (*)(const FilterBatch) {
   return nullptr;
 }
 #define WG_FN_KERNEL(PPT_, NTB_) wg_fn_kernel<MP, PPT_, kFn, NTB_>(b.psi)
+// the 96-register forms (pf_wg_kernel_lean): four particles per lane of the 1024-thread kernels -- the shapes a post-correction chunk with a
+// tail runs as its last full round (api_postcorrect.cpp); at eight per lane the 128-register kernel already spills 116 ... 167 registers
+template <int MP, int FNV>
+auto wg_fn_kernel_lean4(int psi) -> void (*)(const FilterBatch) {
+  if constexpr (((BSSM_FN_PSI_MASK) & 1) != 0) { if (psi == 0) return pf_wg_kernel_lean<MP, MP, 4, FNV, 1024, 0>; }
+  if constexpr (((BSSM_FN_PSI_MASK) & 2) != 0) { if (psi == 1) return pf_wg_kernel_lean<MP, MP, 4, FNV, 1024, 1>; }
+  if constexpr (((BSSM_FN_PSI_MASK) & 4) != 0) { if (psi == 2) return pf_wg_kernel_lean<MP, MP, 4, FNV, 1024, 2>; }
+  return nullptr;
+}
 #ifndef BSSM_WG_WIDE_FROM
 #define BSSM_WG_WIDE_FROM 1025   // (2048 until late round 4: N = 1536, m = 1 ran 512 x 4 at 144 VGPRs, one workgroup of two waves per SIMD per CU: +30 % as 1024 x 2)
 #endif
@@ -764,12 +786,14 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   if (MP == 16 && !b.fpar && !wide && ppt == 1) lds += (1 + (size_t)(nt / 64) * 256) * sizeof(double);  // (kWgMfma16)
   if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
   void (*kern)(const FilterBatch) = nullptr;
+  bool lean_used = false;
+  (void)lean_used;
   if (wide) {
 #ifndef BSSM_USER_MODEL
     if constexpr (MP == 4) {
       switch (ppt) {
         case 2: kern = pf_wg_kernel<MP, KP, 2, FN_NONE, 1024>; break;
-        case 4: kern = pf_wg_kernel<MP, KP, 4, FN_NONE, 1024>; break;
+        case 4: kern = pf_wg_kernel<MP, KP, 4, FN_NONE, 1024>; break;   // (no 96-register form: measured, four-dimensional states lose more to its spills than the tail gains -- profiles/r05_tail_concurrent.txt)
         default: return hipErrorInvalidValue;
       }
     }
@@ -781,12 +805,18 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
 #ifndef BSSM_USER_MODEL
         case 2: kern = fn ? (MP == KP ? WG_FN_KERNEL(2, 1024) : nullptr) : pf_wg_kernel<MP, KP, 2, FN_NONE, 1024>; break;
         case 4: kern = fn ? (MP == KP ? WG_FN_KERNEL(4, 1024) : nullptr) : pf_wg_kernel<MP, KP, 4, FN_NONE, 1024>;
-          if (fn && MP == KP && N == 4096 && !opt().wg_no_exact) { if (auto kx = wg_fn_kernel_exact<MP, 4, kFn, 1024>(b.psi)) kern = kx; }
+          if (b.lean) {
+            if (!fn) { kern = pf_wg_kernel_lean<MP, KP, 4, FN_NONE, 1024>; lean_used = true; }
+            else if constexpr (MP == KP) { if (auto kl = wg_fn_kernel_lean4<MP, kFn>(b.psi)) { kern = kl; lean_used = true; } }
+          }
+          if (fn && MP == KP && N == 4096 && !opt().wg_no_exact) { if (auto kx = wg_fn_kernel_exact<MP, 4, kFn, 1024>(b.psi, b.lean != 0)) { kern = kx; lean_used = b.lean != 0; } }
           break;
         default: kern = fn ? (MP == KP ? WG_FN_KERNEL(8, 1024) : nullptr) : pf_wg_kernel<MP, KP, 8, FN_NONE, 1024>; break;
 #else
         case 2: kern = fn ? WG_FN_KERNEL(2, 1024) : nullptr; break;
-        case 4: kern = fn ? WG_FN_KERNEL(4, 1024) : nullptr; break;
+        case 4: kern = fn ? WG_FN_KERNEL(4, 1024) : nullptr;
+          if (fn && b.lean) { if (auto kl = wg_fn_kernel_lean4<MP, kFn>(b.psi)) { kern = kl; lean_used = true; } }
+          break;
         default: kern = fn ? WG_FN_KERNEL(8, 1024) : nullptr; break;
 #endif
       }
@@ -825,7 +855,7 @@ hipError_t launch_wg_mk(const FilterBatch& b, hipStream_t stream) {
   }
   if (!kern) return hipErrorInvalidValue;
 #ifndef BSSM_USER_MODEL
-  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_wg_kernel<%d,%d,%d,%s,%d>", MP, KP, ppt, b.fpar ? (kFn > 0 ? "model" : "any") : "false", wide ? 1024 : WG_NT_MAX); note_filter_kernel(nm); }
+  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_wg_kernel<%d,%d,%d,%s,%d>", MP, KP, ppt, b.fpar ? (kFn > 0 ? "model" : "any") : "false", wide ? 1024 : WG_NT_MAX); if (lean_used) std::strncat(nm, " lean", sizeof nm - std::strlen(nm) - 1); note_filter_kernel(nm); }
 #endif
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

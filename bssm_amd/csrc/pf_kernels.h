@@ -40,6 +40,7 @@ struct FilterBatch {
   int* dead_at;         // [f] 0 = alive, else (time whose weights were degenerate) + 1; zeroed by the launcher
   int user_slot;        // 0, or the registry slot of a run-time compiled user model whose library holds the kernels
   int fn_id;            // functor models: the model id of the parameter blocks (all filters of a batch share it)
+  int lean;             // host only: the workgroup-resident kernel in its 96-register form where one exists (a last round with a tail beside it)
 };
 
 // Largest N the workgroup-resident kernel can hold for a given padded state size

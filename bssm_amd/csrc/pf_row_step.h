@@ -109,6 +109,10 @@ __global__ void __launch_bounds__(ROW_NT, row_occupancy(MP, FN != FN_NONE)) pf_r
   constexpr bool kPsiFn = FN != FN_NONE && PM == 1, kPack = FN == FN_NONE;
   constexpr int ucnt = step_draw_count<KP, FN>();
   const int psi_mode = PM >= 0 ? PM : b.psi;
+  // wave priority: a step of the row family is a short chain of dependent latencies; when it runs BESIDE a full round of the workgroup
+  // kernel (the tail of a post-correction chunk, api_postcorrect.cpp) its waves share SIMDs with waves that are bound by VALU issue, and
+  // at equal priority a step took ~25 us instead of ~7 -- the tail then outlasted the round it was meant to hide under
+  __builtin_amdgcn_s_setprio(3);
   __shared__ double s_win[4 * ROW_WIN];
   __shared__ double s_comb[3 * ROW_NP * 64 + 2];  // the combine of wave 0 (pf_canon.h: canon_publish)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -58,6 +58,7 @@ struct bssm_user_tv { int t; const double* known_tv; int rows, cols; };
 #define launch_grid_mk BSSM_UM_CAT(launch_grid_mk_part, BSSM_USER_PART)
 #define wg_fn_kernel BSSM_UM_CAT(wg_fn_kernel_part, BSSM_USER_PART)
 #define wg_fn_kernel_exact BSSM_UM_CAT(wg_fn_kernel_exact_part, BSSM_USER_PART)
+#define wg_fn_kernel_lean4 BSSM_UM_CAT(wg_fn_kernel_lean4_part, BSSM_USER_PART)
 #define v2_fn_kernels BSSM_UM_CAT(v2_fn_kernels_part, BSSM_USER_PART)
 #define launch_row_mk BSSM_UM_CAT(launch_row_mk_part, BSSM_USER_PART)
 #define row_fn_kernels BSSM_UM_CAT(row_fn_kernels_part, BSSM_USER_PART)

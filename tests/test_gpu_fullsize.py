@@ -141,8 +141,8 @@ def test_c5_post_correct_block_invariance():
 
 def test_c5_post_correct_tail_round_is_invisible_in_the_output(monkeypatch):
     """configs[4] shape, 300 draws: one workgroup-resident filter per CU, so 256 draws fill a round and 44 are left over.  By
-    DEFAULT (round 5) the 44 go through the row family behind the full round (pf_row_step.h: one wave per row of 64 particles, one
-    launch per time step).  Both families evaluate pf_canon.h, so a draw's result is the SAME BITS whichever ran it: the job with the
+    DEFAULT (round 5) the 44 go through the row family beside the full round (pf_row_step.h: one wave per row of 64 particles, one
+    launch per time step; the round in the 96-register form of its kernel).  Both families evaluate pf_canon.h, so a draw's result is the SAME BITS whichever ran it: the job with the
     split, the job without it (BSSM_AMD_TAIL_SPLIT=0: every draw workgroup-resident), two blocks of 150 (what two GPUs would filter:
     no tail round there) and the in-library two-shard call agree bit for bit -- log-weights, the smoothing summaries (output 2) and
     the sampled trajectories (output 1).  (Rounds 3-4: the tail took the step kernels, opt-in, equal to reduction-order rounding.)"""
@@ -175,6 +175,13 @@ def test_c5_post_correct_tail_round_is_invisible_in_the_output(monkeypatch):
         assert np.all(np.isfinite(split["loglik"]))
         for k in keys:
             assert np.array_equal(split[k], whole[k]), (output_type, k)
+        # (late round 5) by default the tail steps BESIDE the full round, which then runs the 96-register form of the workgroup kernel
+        # (pf_wg_kernel_lean); BSSM_AMD_TAIL_CONCURRENT=0 puts it behind the round and the round back on the 128-register kernel: same bits
+        monkeypatch.setenv("BSSM_AMD_TAIL_CONCURRENT", "0")
+        behind = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, output_type, 4)
+        monkeypatch.delenv("BSSM_AMD_TAIL_CONCURRENT")
+        for k in keys:
+            assert np.array_equal(split[k], behind[k]), (output_type, k)
         lo = PC._run_local_block_nlg(model, theta[:150], modes[:, :150], counts[:150], 0, ns, 4096, 9, 2, output_type, 2)
         hi = PC._run_local_block_nlg(model, theta[150:], modes[:, 150:], counts[150:], 150, ns, 4096, 9, 2, output_type, 2)
         for k in keys:
