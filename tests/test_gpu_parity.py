@@ -241,6 +241,34 @@ def test_bench_plan_variant_against_oracle(oracle, factored):
     plan.close()
 
 
+def test_factored_weights_with_more_than_128_blocks(oracle, monkeypatch):
+    """The factored weights layout and the weights exchange where a filter has 256 particle blocks (65 536 particles at ONE per lane, round
+    5: blocks 128 ... 255 of the combine stay in LDS -- V2Prefix::up): two filters in flight, ancestors / history / weights / log-likelihood
+    against the oracle, and the multiplied-out factored weights equal to the reference layout's to rounding."""
+    from bssm_amd.plan import FilterPlan
+    monkeypatch.setenv("BSSM_AMD_GRID_PPT", "1")
+    n, N, R, seed, s0 = 40, 65536, 2, 5, 7
+    model = negbin_m4_informative(n, seed=103)
+    arr = M.model_arrays(model)
+    got = {}
+    for factored in (False, True):
+        plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R, factored_weights=factored)
+        plan.run(seed, stream0=s0)
+        ll = plan.loglik()
+        assert FilterPlan.last_kernel() == "pf_grid_step_v2<4,4,1,false,true,true>", FilterPlan.last_kernel()
+        lay = plan.weights_layout()
+        assert lay["factored"] == factored
+        if factored:
+            assert lay["block_particles"] == 256 and lay["n_blocks"] == 256
+        got[factored] = plan.fetch(1)
+        ref, fl = _follow(oracle, got[factored]["indices"], N, lambda: oracle.bsf_filter(arr, N, seed=seed, stream=s0 + 1))
+        out = dict(indices=got[factored]["indices"].T, alpha=got[factored]["alpha"], weights=got[factored]["weights"].T, logLik=ll[1])
+        _compare_full_size(out, ref, fl, n, max_ties=2)
+        plan.close()
+    assert np.array_equal(got[False]["indices"], got[True]["indices"])
+    assert np.allclose(got[False]["weights"], got[True]["weights"], rtol=1e-14, atol=0)
+
+
 def test_c3_full_size_against_oracle(oracle):
     """configs[2] at full size: svm on the exchange data (T = 945), psi-APF N = 32 768 + filter-smoother back-trace"""
     y = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "exchange.txt"))
@@ -376,11 +404,12 @@ def test_step_kernel_variants_match_oracle(oracle, monkeypatch, name, N, ppt, ps
     assert k.endswith(",true>") == exact, (k, model.m)
 
 
-@pytest.mark.parametrize("N,ppt", [(2048, "2"), (4096, "4"), (1500, "2")])
+@pytest.mark.parametrize("N,ppt", [(2048, "2"), (4096, "4"), (1500, "2"), (40000, "1"), (60000, "1")])
 def test_degenerate_filter_outputs_match_oracle(oracle, monkeypatch, N, ppt):
     """The degenerate stop (src/model_ssm_ung.cpp:678-682) in the round-2 step kernel with the weights exchange on: the
     weights of the last healthy time point still leave in the global scale, every later slot of weights / particles /
-    ancestors is zero like the reference's, the log-likelihood is -Inf"""
+    ancestors is zero like the reference's, the log-likelihood is -Inf.  (40 000 / 60 000 particles at one per lane: 157 / 235
+    particle blocks -- the blocks above 128 of the combine live in LDS, round 5)"""
     y = np.array([1.0, 2.0, 3.0, 2.0, 3.0, 1.0, 2.0])
     D = np.array([0.0, 0.0, 0.0, 800.0, 0.0, 0.0, 0.0])  # exp(signal) overflows at t = 3: every log-weight is -Inf there
     model = M.ssm_ung(y, Z=1.0, T=1.0, R=0.3, a1=0.0, P1=1.0, distribution="poisson", D=D)
