@@ -182,10 +182,13 @@ def test_step_kernel_random_shapes_match_oracle(oracle, monkeypatch, case):
     assert np.max(np.abs(out["weights"] - ref["weights"])) <= 1e-9
 
 
-@pytest.mark.parametrize("N,ppt", [(20000, "1"), (40000, "2"), (100000, "4"), (98304, "4"), (65536, "2")])
+@pytest.mark.parametrize("N,ppt", [(20000, "1"), (40000, "2"), (100000, "4"), (98304, "4"), (65536, "2"),
+                                   (33000, "1"), (49153, "1"), (65535, "1"), (65536, "1"), (100000, "2")])
 def test_step_kernel_more_than_64_blocks_matches_oracle(oracle, monkeypatch, N, ppt):
     """Filters of 65 ... 128 particle blocks in the round-2 step kernel (two block prefixes per lane in the wave-local
-    combine, ballots over both halves): ancestors, weights and log-likelihood against the oracle"""
+    combine, ballots over both halves) and of 129 ... 256 blocks (round 5: the upper half of the combine in LDS; 129, 193 -- the first
+    block of the fourth chunk --, 256 with a ragged last block, 256 complete, 196 at two per lane): ancestors, weights and
+    log-likelihood against the oracle"""
     from bssm_amd.plan import FilterPlan
     rng = np.random.default_rng(77)
     n = 8

@@ -1138,6 +1138,44 @@ def _twelve_case(seed=21, n=24):
     return dict(y=y, m=m, k=k, th=th, kn=kn, Rm=Rm, Z=Z, H=H, T=T, R=R, a1=a1, P1=P1, n=n)
 
 
+USER_SIXTEEN = r"""
+#define BSSM_USER_NLG 1
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  for (int j = 0; j < 16; j++) out[j] = (0.4 + 0.03 * j) * a[j] + 0.1 * sin(a[(j + 5) & 15]) + th[0] * 0.01 * j;
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) {
+  double z = 0.0;
+  for (int j = 0; j < 16; j++) z += (j & 1 ? -0.2 : 0.3) * a[j];
+  return z;
+}
+"""
+
+
+@pytest.mark.parametrize("path,N", [("wg", 400), ("row", 1000), ("grid", 18000)])
+def test_user_model_sixteen_states_full_noise_matrix(oracle, monkeypatch, path, N):
+    """SIXTEEN states, a dense 16 x 16 noise matrix, a dense P1: the padded dimension IS the state dimension (no padding rows to hide an
+    indexing slip); bootstrap filter against orc_nlg_general_bsf_filter on the three kernel shapes"""
+    rng = np.random.default_rng(33)
+    m, k, n = 16, 16, 14
+    th = np.array([0.7]); kn = np.zeros(0)
+    Rm = 0.05 * rng.normal(size=(m, k)) + 0.15 * np.eye(m)
+    Z = lambda t, a, th_, kn_: float(sum((-0.2 if j & 1 else 0.3) * a[j] for j in range(16)))
+    H = lambda t, a, th_, kn_: 0.7
+    T = lambda t, a, th_, kn_: np.array([(0.4 + 0.03 * j) * a[j] + 0.1 * np.sin(a[(j + 5) & 15]) + th_[0] * 0.01 * j for j in range(16)])
+    R = lambda t, a, th_, kn_: Rm
+    y = rng.normal(size=n); y[3] = np.nan
+    a1 = 0.1 * rng.normal(size=m)
+    Lp = 0.2 * rng.normal(size=(m, m)); P1 = Lp @ Lp.T + 0.05 * np.eye(m)
+    u = M.ssm_nlg_user(y, USER_SIXTEEN, theta=th, known_params=kn, a1=a1, P1=P1, H=0.7, n_states=m, R=Rm)
+    if path != "grid": monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    out = F.bootstrap_filter(u, N, seed=5, return_indices=True)
+    ref = oracle.nlg_general_bsf_filter(y, m, k, th, kn, a1, P1, Z, H, T, R, N, seed=5)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+
+
 @pytest.mark.parametrize("path,N", [("wg", 300), ("row", 2000), ("grid", 20000)])
 def test_user_model_twelve_states_bootstrap_against_the_general_oracle(oracle, monkeypatch, path, N):
     """A user model with TWELVE states and a constant 12 x 5 matrix R (round 5: the MP = 16 functor kernels; the reference's
