@@ -2,8 +2,9 @@
 //
 // Three kinds:
 //   configuration   BSSM_AMD_CACHE_GB, BSSM_AMD_COPY_THREADS, BSSM_AMD_USER_CACHE, BSSM_AMD_IS_CHUNK, BSSM_AMD_GATHER,
-//                   BSSM_AMD_TRACE, BSSM_AMD_TAIL_SPLIT (opt-in: a sparsely filled last round of a post-correction chunk through
-//                   the step kernels -- faster, but a draw's result then depends on the shard layout; default off)
+//                   BSSM_AMD_TRACE, BSSM_AMD_TAIL_SPLIT (=0: off; default ON since round 5 -- a sparsely filled last round of a
+//                   post-correction chunk through the row family, bit-identical to the workgroup kernel), BSSM_AMD_TAIL_CONCURRENT (=0:
+//                   that tail behind the last full round instead of beside it), BSSM_AMD_TAIL_MAX_EIGHTHS, BSSM_AMD_USER_BUILD_JOBS
 //   test / tuning   kernel-shape and set-up choices the parity tests and the tuning scripts flip between calls:
 //                   BSSM_AMD_FORCE_PATH, BSSM_AMD_GRID_PPT, BSSM_AMD_GRID_V2_WX, BSSM_AMD_GRID_V2_EXACT,
 //                   BSSM_AMD_GRID_STREAMS, BSSM_AMD_XCD_REMAP, BSSM_AMD_WG_WIDE, BSSM_AMD_DEVICE_SETUP, BSSM_AMD_GENERIC_SETUP,
