@@ -847,7 +847,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       std::memcpy(h + nf + ne + nm, models[0].y, (size_t)n * sizeof(double));
       HIP_TRY(ct->fpar.alloc(nf * sizeof(double))); HIP_TRY(ct->ext.alloc(ne * sizeof(double)));
       HIP_TRY(ct->modes.alloc(nm * sizeof(double))); HIP_TRY(ct->y.alloc((size_t)n * sizeof(double)));
-      HIP_TRY(ct->scratch.alloc(bssm::fn_setup_scratch_doubles(n, m) * F * sizeof(double)));
+      HIP_TRY(ct->scratch.alloc(bssm::fn_setup_scratch_doubles(n, m) * (((size_t)F + 63) / 64 * 64) * sizeof(double)));  // (blocks of 64 draws: FnWork)
       HIP_TRY(ct->mats.alloc(ct->ms * F * sizeof(double))); HIP_TRY(ct->obs.alloc(ct->os * F * sizeof(double)));
       HIP_TRY(ct->init.alloc(ct->is * F * sizeof(double))); HIP_TRY(ct->amats.alloc(ct->as * F * sizeof(double)));
       HIP_TRY(ct->ok.alloc((size_t)F * sizeof(int)));

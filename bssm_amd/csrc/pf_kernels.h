@@ -182,7 +182,7 @@ struct FnSetupDev {
   const double* ext;    // [F][m + m*m]: a1, P1 of the draw
   const double* modes;  // [F][m*n], m x n column-major per draw
   const double* y;      // [n], shared by the draws
-  double* scratch;      // draw-interleaved work arrays, fn_setup_scratch_doubles(n, m) * F doubles
+  double* scratch;      // work arrays in blocks of 64 draws (FnWork), fn_setup_scratch_doubles(n, m) * ceil64(F) doubles
   double *mats, *obs, *init, *amats;  // per-draw contiguous outputs: [F][n][2 m^2 + m], [F][n][ROW_HDR + SER_HDR + m], [F][m + m^2], [F][n][m^2 + m]
   int* ok;              // [F]: 0 = the smoother failed (tables are then neutral and the caller reports -Inf)
 };

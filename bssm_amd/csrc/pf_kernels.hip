@@ -319,14 +319,23 @@ size_t fn_setup_scratch_doubles(int n, int m) {
 // As one kernel whose waves shared the draws, a chunk took 1.5 ms on the C5 shape with five busy CUs (292 draws): the tables alone
 // 0.5 ms, because each of their store instructions touches 64 cache lines (per-draw contiguous output) and only those CUs issued
 // them; spread over the chip by time point the three parallel phases cost a few launches (profiles/r03_setup_phases.txt).
+// Work arrays in BLOCKS of 64 draws (round 5, late): element k of draw d at block_base(d / 64)[k * 64 + d % 64] -- the stride between the
+// elements of a draw is the compile-time constant 64 instead of the number of draws of the chunk, so every `k * stride` folds into an
+// immediate or a shift and the per-lane address is a block base plus the lane's 8 bytes: 1 261 -> 853 instructions in the sequential phase
+// (scalar address arithmetic 578 -> 271).  The phase itself only went 665 -> 641 us per 300 time points: with one wave per SIMD it is bound by
+// the DEPENDENT fp64 chain of the Kalman recursion (Joseph form, three divisions per time point: ~2 500 cycles), not by issue slots or
+// memory latency (a four-step operand prefetch changed nothing either) -- docs/design_round_5.md.
+constexpr size_t FN_ES = 64;
 template <int M>
 struct FnWork {
   double *sZ, *sT, *sRR, *sD, *sC, *sy, *sH, *sa1, *sP1, *at, *Pt, *cc, *K, *v, *Fs, *Vf, *Cf;
   __device__ FnWork(const FnSetupDev& b, int d) {
     constexpr int MM = M * M;
-    const size_t F = (size_t)b.F;
+    constexpr size_t F = FN_ES;
     const int n = b.n;
-    double* w = b.scratch + d;
+    const size_t mm = MM, n1 = (size_t)n + 1;
+    const size_t total = (size_t)n * M + n * mm + mm + n + (size_t)n * M + n + 1 + M + mm + n1 * M + n1 * mm + n1 * mm + (size_t)n * M + n + n + n1 * mm + n1 * mm;  // fn_setup_scratch_doubles
+    double* w = b.scratch + (size_t)(d >> 6) * total * FN_ES + (size_t)(d & 63);
     sZ = w;                 w += (size_t)n * M * F;
     sT = w;                 w += (size_t)n * MM * F;
     sRR = w;                w += (size_t)MM * F;
@@ -349,7 +358,7 @@ struct FnWork {
 template <int M, int PHASE>
 __global__ void __launch_bounds__(64) fn_setup_kernel(const FnSetupDev b) {
   constexpr int MM = M * M;
-  const size_t F = (size_t)b.F;
+  constexpr size_t F = FN_ES;  // (stride between the elements of a draw in the work arrays: FnWork)
   const int n = b.n;
   if constexpr (PHASE == 0) {
     // ---- linearisation at the stored mode: Z_t = Z'(mode_t), D_t = Z(mode_t) - Z_t mode_t, T_t = T'(mode_t),
