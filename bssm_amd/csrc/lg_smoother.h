@@ -211,6 +211,7 @@ struct LgSmoother {
   LG_HD LG_INL static bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es = 1,
                         bool with_factors = true) {
     const int n = g.n;
+    int bad = 0;
     double a[M], P[MM], a1n[M], P1n[MM];
     double tmp[MM], tmp2[MM], inner[MM], IKZ[MM];
     ldv(g.a1, es, M, a); ldv(g.P1, es, MM, P);
@@ -293,8 +294,10 @@ struct LgSmoother {
         symmatu(P1n);
       }
       stv(K + (size_t)t * M * es, es, M, Kt);
-      for (int i = 0; i < M; i++) if (!lg_finite(a1n[i])) return false;
-      for (int q = 0; q < MM; q++) if (!lg_finite(P1n[q])) return false;
+      // (a non-finite value is carried to the end of the pass and reported there: NaN / Inf only propagate, and twelve early-exit branches
+      // per time point sat on the dependent chain of a kernel that is nothing but that chain)
+      for (int i = 0; i < M; i++) bad |= !lg_finite(a1n[i]);
+      for (int q = 0; q < MM; q++) bad |= !lg_finite(P1n[q]);
       stv(at + (size_t)(t + 1) * M * es, es, M, a1n);
       stv(Pt + (size_t)(t + 1) * MM * es, es, MM, P1n);
       stv(cc + (size_t)t * MM * es, es, MM, P1n);
@@ -302,6 +305,7 @@ struct LgSmoother {
       for (int q = 0; q < MM; q++) P[q] = P1n[q];
       if (kAhead) fin = fnx;
     }
+    if (bad) return false;
     LG_STAMP(2);
     // ---- backward pass (smoother_ccov)
     double rt[M], Nt[MM], L[MM], N2[MM];
@@ -378,22 +382,23 @@ struct LgSmoother {
       for (int q = 0; q < MM; q++) Nt[q] = N2[q];
       symmatu(Nt);
       for (int i = 0; i < M; i++) { double s = 0.0; for (int q = 0; q < M; q++) s += P[i + M * q] * rt[q]; a[i] = a[i] + s; }
-      for (int i = 0; i < M; i++) if (!lg_finite(a[i])) return false;
+      for (int i = 0; i < M; i++) bad |= !lg_finite(a[i]);
       stv(at + (size_t)t * M * es, es, M, a);
       if (need_cc) {
-        for (int q = 0; q < MM; q++) if (!lg_finite(ct[q])) return false;
+        for (int q = 0; q < MM; q++) bad |= !lg_finite(ct[q]);
         stv(cc + (size_t)t * MM * es, es, MM, ct);
       }
       if (need_P) {
         mul(P, Nt, tmp); mul(tmp, P, tmp2);
         symmatu(tmp2);
         for (int q = 0; q < MM; q++) P[q] = P[q] - tmp2[q];
-        for (int q = 0; q < MM; q++) if (!lg_finite(P[q])) return false;
+        for (int q = 0; q < MM; q++) bad |= !lg_finite(P[q]);
         stv(Pt + (size_t)t * MM * es, es, MM, P);
       }
       if (kAhead) bin = bnx;
     }
     for (int q = 0; q < MM; q++) cc[((size_t)n * MM + q) * es] = 0.0;
+    if (bad) return false;
     LG_STAMP(3);
     if (!with_factors) return true;
     // ---- conditional_cov: Vt <- U sqrt(s) of Var(alpha_t | alpha_{t-1}, y), Ct <- Cov' pinv(V_{t-1}); in place, so from the

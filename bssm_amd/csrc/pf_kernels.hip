@@ -322,9 +322,9 @@ size_t fn_setup_scratch_doubles(int n, int m) {
 // Work arrays in BLOCKS of 64 draws (round 5, late): element k of draw d at block_base(d / 64)[k * 64 + d % 64] -- the stride between the
 // elements of a draw is the compile-time constant 64 instead of the number of draws of the chunk, so every `k * stride` folds into an
 // immediate or a shift and the per-lane address is a block base plus the lane's 8 bytes: 1 261 -> 853 instructions in the sequential phase
-// (scalar address arithmetic 578 -> 271).  The phase itself only went 665 -> 641 us per 300 time points: with one wave per SIMD it is bound by
-// the DEPENDENT fp64 chain of the Kalman recursion (Joseph form, three divisions per time point: ~2 500 cycles), not by issue slots or
-// memory latency (a four-step operand prefetch changed nothing either) -- docs/design_round_5.md.
+// (scalar address arithmetic 578 -> 271).  The phase itself only went 665 -> 641 us per 300 time points: one wave per SIMD issues in order,
+// and ~450 fp64 VALU instructions at four cycles each per time point are what it costs (not memory latency: a four-step operand prefetch
+// changed nothing) -- docs/design_round_5.md.
 constexpr size_t FN_ES = 64;
 template <int M>
 struct FnWork {
