@@ -141,11 +141,61 @@ def _share_torch_hip_runtime():
     if spec is None or not spec.submodule_search_locations:
         return
     path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(path):
-        try:
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass  # (a CPU-only torch build, a broken install: the system runtime is used as before)
+    trace = os.environ.get("BSSM_AMD_TRACE", "0") not in ("", "0")
+    if not os.path.exists(path):
+        return
+    # the preload only helps if torch's copy answers to the SONAME this library asks for (libamdhip64.so.<major>): with another
+    # major version libbssm_amd.so would still bind to the system copy and TWO runtimes would share the process -- skip it then
+    want = [nm for nm in _elf_dynamic(LIB_PATH)[1] if nm.startswith("libamdhip64.so")]
+    have = _elf_dynamic(path)[0]
+    if want and have and have not in want:
+        if trace:
+            print(f"[bssm_amd] torch ships {have}, the library needs {want[0]}: torch's HIP runtime NOT preloaded "
+                  "(import torch first, or set BSSM_AMD_SYSTEM_HIP=1)", file=sys.stderr)
+        return
+    try:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        if trace:
+            print(f"[bssm_amd] preloaded torch's HIP runtime {path} (SONAME {have or 'unknown'})", file=sys.stderr)
+    except OSError as e:
+        if trace:
+            print(f"[bssm_amd] torch's HIP runtime could not be preloaded ({e}): the system runtime is used", file=sys.stderr)
+
+
+def _elf_dynamic(path):
+    """(DT_SONAME or None, [DT_NEEDED ...]) of a 64-bit little-endian ELF shared object; (None, []) when it cannot be read"""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+            return None, []
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+        dyn = strtab_idx = None
+        secs = []
+        for i in range(shnum):
+            name, typ, flags, addr, off, size, link, info, align, entsize = struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize)
+            secs.append((typ, off, size, link))
+            if typ == 6:  # SHT_DYNAMIC
+                dyn, strtab_idx = (off, size), link
+        if dyn is None:
+            return None, []
+        _, soff, ssize, _ = secs[strtab_idx]
+        strtab = data[soff:soff + ssize]
+        cstr = lambda o: strtab[o:strtab.index(b"\0", o)].decode()
+        soname, needed = None, []
+        for o in range(dyn[0], dyn[0] + dyn[1], 16):
+            tag, val = struct.unpack_from("<qQ", data, o)
+            if tag == 0:
+                break
+            if tag == 1:
+                needed.append(cstr(val))
+            elif tag == 14:
+                soname = cstr(val)
+        return soname, needed
+    except Exception:  # noqa: BLE001
+        return None, []
 
 
 def lib():

@@ -473,3 +473,25 @@ def test_shim_runs_up_to_the_device_and_reports_r_errors():
         R.call("_bssm_bsf", {**r_model_list(mng), "phi": np.ones(2)}, 10, 1, False, M.model_type(mng))
     assert R.L.mockr_poisoned_touches() == 0 and R.L.mockr_protect_depth() == 0
     R.reset()
+
+
+def test_hip_runtime_preload_checks_the_soname(monkeypatch, capsys):
+    """One HIP runtime per process (bssm_amd/_lib.py: _share_torch_hip_runtime): torch's libamdhip64 is preloaded only if it answers to the
+    SONAME libbssm_amd.so asks for -- with another major version the library would bind to the system copy anyway and two runtimes would
+    share the process; what was decided is logged under BSSM_AMD_TRACE (round-4 advisor finding)."""
+    import sys
+    soname, needed = _lib._elf_dynamic(_lib.LIB_PATH)
+    want = [nm for nm in needed if nm.startswith("libamdhip64.so")]
+    assert len(want) == 1 and "libhiprtc" in " ".join(needed)
+    assert _lib._elf_dynamic(__file__) == (None, [])           # not an ELF file: no opinion
+    loaded = []
+    monkeypatch.setattr(_lib.C, "CDLL", lambda path, mode=0: loaded.append(path))
+    monkeypatch.setenv("BSSM_AMD_TRACE", "1")
+    monkeypatch.delitem(sys.modules, "torch", raising=False)
+    real = _lib._elf_dynamic
+    monkeypatch.setattr(_lib, "_elf_dynamic", lambda p: real(p) if p == _lib.LIB_PATH else ("libamdhip64.so.5", []))
+    _lib._share_torch_hip_runtime()
+    assert loaded == [] and "NOT preloaded" in capsys.readouterr().err
+    monkeypatch.setattr(_lib, "_elf_dynamic", lambda p: real(p) if p == _lib.LIB_PATH else (want[0], []))
+    _lib._share_torch_hip_runtime()
+    assert len(loaded) == 1 and loaded[0].endswith("libamdhip64.so") and "preloaded torch's HIP runtime" in capsys.readouterr().err
