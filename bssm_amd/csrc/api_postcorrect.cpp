@@ -299,7 +299,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           // A particle system that takes more than half a CU's LDS runs one workgroup per CU, so the filters go through the chip in
           // rounds of `cus` workgroups that all take the same time; a sparsely filled LAST round (C5: 2 340 = 9 x 256 + 36; one rank's
           // shard of it at 8 ranks: 293 = 256 + 37) costs a full round.  Those filters go through the ROW family instead (pf_row_step.h:
-          // one wave per row of 64 particles, one launch per time step, the whole chip), behind the full rounds.
+          // one wave per row of 64 particles, one launch per time step, the whole chip), beside the last full round (below).
           // ON by default since round 5: both families evaluate pf_canon.h, so a draw's result is the same bits whichever ran it
           // (tests/test_gpu_postcorrect.py, tests/test_gpu_fullsize.py assert split == whole bit for bit) -- which draws land in the
           // tail depends on the draws per chunk, the shard layout and the CU count, and the output does not.  (Rounds 3-4 sent the
