@@ -306,13 +306,21 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           // tail through the step kernels, whose reduction shape differs: opt-in, results depended on the device list.)
           // Not when a path is forced, and only for the shapes the row family carries (row_filter_supported).  BSSM_AMD_TAIL_SPLIT=0 turns it off.
           int tail = 0, cus_round = 0;
+          bool lean_all = false;   // every full round in the 96-register form, the tail beside all of them (below)
           if (all_rows) tail = sub.F;
           else if ((size_t)(sub.MP + 1) * (size_t)N * sizeof(double) > 80 * 1024 && bssm::opt().force_path == 0 && bssm::opt().tail_split &&
               bssm::row_filter_supported(sub)) {
             int dev = 0; hipDeviceProp_t prop;
             const int cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            const int r = sub.F % cus;
+            const int r = sub.F % cus, rounds = sub.F / cus;
             if (r > 0 && r <= cus * bssm::opt().tail_max_eighths / 8) { tail = r; cus_round = cus; }
+            // Late round 5: a LARGER remainder (up to three quarters of a round) of a chunk of three or four full rounds also goes through the
+            // row family -- beside ALL the rounds, which then run the 96-register form: its launch sequence has several rounds to finish in, and
+            // the remainder's own round is saved.  C5 shape: 914 = 3 x 256 + 146 draws 16.6 -> 15.7 ms, 1 170 = 4 x 256 + 146: 21.7 -> 20.3,
+            // 1 216: 22.3 -> 21.3; with five rounds and more nothing is left of it (1 450: 25.3 -> 25.5; the lean form costs every round ~2.6 %).
+            // These calls then sit within 1-3 % of draws / 256 x one round: the chip is packed as well as the kernels' efficiency allows.
+            else if (r > 0 && r <= cus * 6 / 8 && rounds >= 3 && rounds <= 4 && bssm::opt().tail_concurrent && bssm::opt().tail_max_eighths > 0 &&
+                     bssm::wg_lean_form_exists(sub)) { tail = r; cus_round = cus; lean_all = true; }
           }
           bssm::FilterBatch head = sub;
           head.F = sub.F - tail;
@@ -363,7 +371,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           if (conc) {
             // the full rounds before the last one keep the 128-register kernel (the 96-register form spills more: 2 340 draws as ONE lean
             // launch took 41.8 ms against 40.7); the tail is released when they are done and runs beside the last round
-            const int last = cus_round > 0 && head.F > cus_round ? cus_round : head.F;
+            const int last = lean_all ? head.F : (cus_round > 0 && head.F > cus_round ? cus_round : head.F);
             if (int rc2 = launch_wg_part(0, head.F - last, false)) return rc2;
             HIP_TRY(hipEventRecord(ev_fork, nullptr));
             HIP_TRY(hipStreamWaitEvent(tstream, ev_fork, 0));

@@ -95,6 +95,9 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws);
 // weights output; functor models, and linear-state models of at most four states).  The workspace is a GridWorkspace with
 // chunk = 64; launch_grid_filter runs it.
 bool row_filter_supported(const FilterBatch& b);
+// whether launch_wg_filter has a 96-register form (pf_wg_kernel_lean, FilterBatch::lean) for this batch: one- and two-dimensional states at four
+// particles per lane of a 1024-thread workgroup (2048 < N <= 4096); not for user models compiled in process
+bool wg_lean_form_exists(const FilterBatch& b);
 // States of more than 16 dimensions (pf_big.h): both shapes give the same bits, so the choice is throughput alone -- a batch that fills
 // the chip with rows runs faster in the row shape (two to four waves per SIMD) than workgroup-resident (one 131 KB workgroup per CU)
 bool prefer_step_shape(const FilterBatch& b, bool use_grid);

@@ -142,6 +142,11 @@ bool row_filter_supported(const FilterBatch& b) {
   if (opt().force_path == 3 && b.MP == 8 && b.KP % 4 == 0) return true;  // EXPERIMENT hook only (pf_filter_impl.h launch_grid_mk): not bit-identical to pf_wg_kernel
   return b.MP <= 4 || b.MP >= 32;  // (eight- and sixteen-dimensional states: pf_wg_kernel's matrix-core transitions sum in another order)
 }
+bool wg_lean_form_exists(const FilterBatch& b) {
+  if (b.MP > 2 || b.N <= 2048 || b.N > 4096 || user_slot_rows_only(b.user_slot)) return false;
+  if (opt().wg_wide == 0) return false;           // (tuning switch: the 512-thread kernels have no lean form)
+  return b.fpar ? b.MP == b.KP : true;
+}
 bool prefer_step_shape(const FilterBatch& b, bool use_grid) {
   if (use_grid || b.MP < 32 || b.fpar) return use_grid;
   const long long rows = (long long)b.F * ((b.N + CANON_ROW - 1) / CANON_ROW);

@@ -81,6 +81,42 @@ def test_c3_svm_exchange_psi_smoother_full_size():
     assert np.max(np.abs(out["alphahat"] - bsf["alphahat"])) < 0.25  # smoothed log-volatility, sd ~ 0.5
 
 
+def test_c5_large_remainder_beside_all_rounds_is_invisible_in_the_output(monkeypatch):
+    """C5 shape, 3 x 256 + 150 draws: the remainder is more than half a round, and the chunk has three full rounds -- it goes through the row
+    family BESIDE all three (which run the 96-register form of the workgroup kernel; api_postcorrect.cpp, late round 5).  Same bits as with
+    every draw workgroup-resident (BSSM_AMD_TAIL_SPLIT=0) and as with the remainder in a round of its own (BSSM_AMD_TAIL_CONCURRENT=0)."""
+    import torch
+    from bssm_amd.plan import FilterPlan
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = np.random.default_rng(107)
+    n, K, dT = 60, 500.0, 0.1
+    r = np.zeros(n); pp = np.zeros(n); pp[0] = 50.0
+    for t in range(1, n):
+        r[t] = r[t - 1] + rng.normal(0, 0.05)
+        rr = np.exp(r[t - 1]) / (1 + np.exp(r[t - 1]))
+        pp[t] = K * pp[t - 1] * np.exp(rr * dT) / (K + pp[t - 1] * (np.exp(rr * dT) - 1)) + rng.normal(0, 1)
+    y = pp + rng.normal(0, 1, n)
+    th0 = np.array([0.0, np.log(0.05), 0.0])
+    model = M.ssm_nlg(y, "nlg_growth", theta=th0, known_params=[dT, K, 0.0, 50.0, 1.0, 100.0])
+    ns = 3 * cus + (cus * 5) // 8
+    theta = th0 + rng.normal(0, 0.05, (ns, 3))
+    counts = np.ones(ns, dtype=np.uint32)
+    mode = F.psi_setup(model)["mode"].reshape(-1, order="F")
+    modes = np.tile(mode[:, None], (1, ns))
+    c0 = FilterPlan.family_launches()
+    beside = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4)
+    c1 = FilterPlan.family_launches()
+    assert c1["row"] == c0["row"] + 1 and c1["wg"] == c0["wg"] + 1, (c0, c1)   # one lean launch of three rounds + the row family
+    monkeypatch.setenv("BSSM_AMD_TAIL_CONCURRENT", "0")
+    own_round = PC._run_local_block_nlg(model, theta, modes, counts, 0, ns, 4096, 9, 2, 3, 4)
+    c2 = FilterPlan.family_launches()
+    assert c2["row"] == c1["row"] and c2["wg"] == c1["wg"] + 1, (c1, c2)       # (more than half a round: no split without the concurrency)
+    monkeypatch.delenv("BSSM_AMD_TAIL_CONCURRENT")
+    for k in ("loglik", "weights"):
+        assert np.array_equal(beside[k], own_round[k]), k
+    assert np.all(np.isfinite(beside["loglik"]))
+
+
 def test_c4_mng_two_matrix_core_transitions_agree(monkeypatch):
     """configs[3]: ssm_mng m=8 p=4 T=2000 N=16384: the step kernel's fp64-MFMA state transition through LDS tiles (one and two
     particles per lane) and the row family's fragment-native transition (pf_big.h, one 16-row block) are independent
