@@ -14,12 +14,14 @@ chains) together -- SURVEY.md 8d's regime B on the metric's own configuration; t
 ("replicas only"), one process per GPU, and reports the aggregate.
 
 Extra objects in the JSON line:
-  roofline      dominant kernel (pf_grid_step): algorithmic bytes per launch = N * (16 m + 24) B
+  roofline      dominant kernel (pf_grid_step_v2): algorithmic bytes per launch = N * (16 m + 24) B
                  / its average launch duration measured with HIP events on the launch stream
   cpu_baseline  the CPU oracle (single-threaded per filter, like the reference) timed on a bounded sample
   single_filter one filter call alone (latency regime)
   regime_b      512 independent N=2048 filters, one workgroup each, state resident in LDS (the shape IS
                 post-correction uses)
+  mng_c4, post_correct (+ post_correct_scaling.projected: one rank's share at 1 / 2 / 4 / 8 ranks, measured on this GPU),
+  big_states (17 ... 64 state dimensions), dropin (the C ABI with host buffers), accuracy (same seeds against the CPU oracle)
 """
 import argparse
 import json
