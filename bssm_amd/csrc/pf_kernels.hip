@@ -15,6 +15,7 @@ __device__ unsigned long long g_setup_stamps[8];
 #endif
 #include "lg_smoother.h"
 #include "lg_smoother_rows.h"
+#include "lg_factors_rows.h"
 #include "pf_filter_impl.h"
 #include "tls_stream.h"
 
@@ -658,6 +659,18 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     }
   }
 }
+// conditional factors of sixteen-dimensional (padded) states: M lanes per (draw, time point), matrices in LDS (lg_factors_rows.h)
+template <int M>
+__global__ void __launch_bounds__(64) ung_factors_rows_kernel(const UngSetupDev b) {
+  constexpr int G = 64 / M;
+  __shared__ double lds[LgFactorRows<M>::kLdsDoubles];
+  const int d = min((int)(blockIdx.x * G + threadIdx.x / M), b.F - 1);  // (surplus groups redo the last draw: every lane takes part in the barriers)
+  const UngWork<M> W(b, d);
+  LgFactorRows<M> rows(lds);
+  rows.skip = b.ok[d] == 0;
+  const bool fine = rows.cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, (size_t)b.F, 0);
+  if (!fine && !rows.skip && rows.r == 0) b.ok[d] = 0;  // (every writer stores 0)
+}
 template <int M>
 static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64);
@@ -670,7 +683,8 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
     if ((M == 8 || M == 4) && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<MR, 1, true>), dim3((unsigned)((b.F + 64 / MR - 1) / (64 / MR))), dim3(64), 0, stream, b);
     else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
   }
-  hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
+  if constexpr (M == 16) hipLaunchKernelGGL((ung_factors_rows_kernel<16>), dim3((unsigned)((b.F + 3) / 4), (unsigned)b.n + 1), dim3(64), 0, stream, b);
+  else hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   hipLaunchKernelGGL((ung_setup_kernel<M, 3, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   return hipGetLastError();
 }
