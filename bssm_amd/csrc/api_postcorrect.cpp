@@ -629,8 +629,9 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   // 0.109 s with 32 host threads; until the factors left the sequential kernel it was 0.26 s and only the default below 8 threads).
   // (n < 65535: the set-up's parallel kernels carry the time point in gridDim.y; longer series take the host set-up)
   // (univariate observations: 9 ... 16 states go padded to 16 -- ung_pack, round 5)
-  const int m_dev = (p0 == 1 && m > 8) ? 16 : m;   // the state dimension the set-up kernels are instantiated for
-  bool dev_full = psi && have_device() && (p0 == 1 ? m <= 16 : m <= 8) && n < 65535 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
+  // (17 ... 64 states go padded to 32 / 64: the smoother with its matrices in LDS, lg_smoother_wave.h)
+  const int m_dev = (p0 == 1 && m > 8) ? (m <= 16 ? 16 : (m <= 32 ? 32 : 64)) : m;   // the state dimension the set-up kernels are instantiated for
+  bool dev_full = psi && have_device() && (p0 == 1 ? m <= 64 : m <= 8) && n < 65535 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
   if (bssm::opt().device_setup >= 0) dev_full = dev_full && bssm::opt().device_setup == 2;
   if (bssm::opt().generic_setup) dev_full = false;
   if (dev_full) {

@@ -796,8 +796,9 @@ bool ung_pack(const HostModel& h, const double* is_mode, LgPacked* lg) {
   // states of 9 ... 16 dimensions (a monthly seasonal: m = 13) are packed PADDED to 16 (round 5): zero rows / columns of Z, T, R R', C, a1,
   // P1 -- the padded components stay exactly zero through the filter and the smoother, the products only gain exact zero terms, and the
   // Jacobi rotations of the factors skip zero off-diagonals -- so that ONE device instantiation (ung_setup_kernel<16>) carries them
-  if (!is_mode || h.gaussian() || h.p != 1 || h.m < 1 || h.m > 16 || bssm::opt().generic_setup) return false;
-  const int n = h.n, mr = h.m, m = mr <= 8 ? mr : 16, k = h.k;
+  // (17 ... 64 states: padded to 32 / 64 for the LDS-resident smoother, lg_smoother_wave.h -- late round 5)
+  if (!is_mode || h.gaussian() || h.p != 1 || h.m < 1 || h.m > 64 || bssm::opt().generic_setup) return false;
+  const int n = h.n, mr = h.m, m = mr <= 8 ? mr : (mr <= 16 ? 16 : (mr <= 32 ? 32 : 64)), k = h.k;
   lg->n = n; lg->m = m;
   lg->Zs = h.Ztv ? m : 0; lg->Ts = h.Ttv ? m * m : 0; lg->Rs = h.Rtv ? m * m : 0; lg->Ds = h.Dtv ? 1 : 0; lg->Cs = h.Ctv ? m : 0; lg->Hs = 1;
   const int nR = h.Rtv ? n : 1, nZt = h.Ztv ? n : 1, nTt = h.Ttv ? n : 1, nCt = h.Ctv ? n : 1;

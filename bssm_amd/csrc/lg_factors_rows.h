@@ -39,7 +39,7 @@ struct LgFactorRows {
 
   // |eigenvalues| (descending) in s[], eigenvectors U (sign: the largest component of every vector positive) left in A, of the symmetric part
   // of the matrix whose row r this lane passes in.  Uses A, W and the four vectors; C is untouched.
-  __device__ void sym_singular(const double (&row)[M], double (&s)[M]) {
+  __device__ LG_INL void sym_singular(const double (&row)[M], double (&s)[M]) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < M; j++) { A[r * LD + j] = row[j]; W[r * LD + j] = (j == r) ? 1.0 : 0.0; }
@@ -119,7 +119,7 @@ struct LgFactorRows {
   }
 
   // conditional_cov at time point t of draw d (arrays draw-interleaved, element k at ptr[k * es + d]); returns whether everything written is finite
-  __device__ bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d) {
+  __device__ LG_INL bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d) {
     int bad = 0;
     double row[M], s[M];
     if (t == 0) {
@@ -187,7 +187,7 @@ struct LgFactorRows {
   }
 
   // any lane of the group bad -> false in every lane of the group
-  __device__ bool reduce_bad(int bad) {
+  __device__ LG_INL bool reduce_bad(int bad) {
     __syncthreads();
     vc[r] = bad ? 1.0 : 0.0;
     __syncthreads();

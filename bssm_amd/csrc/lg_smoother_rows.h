@@ -36,15 +36,15 @@ struct LgRows {
     sh = lds_wave + (size_t)(lane / M) * GS;
   }
   // rows of a matrix into LDS buffer `b` (0 / 1); the barriers fence the previous readers and the new ones (one wave per workgroup)
-  __device__ void put(int b, const double (&row)[M]) {
+  __device__ LG_INL void put(int b, const double (&row)[M]) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < M; j++) sh[b * MM + r * M + j] = row[j];
     __syncthreads();
   }
-  __device__ double get(int b, int i, int j) const { return sh[b * MM + i * M + j]; }
+  __device__ LG_INL double get(int b, int i, int j) const { return sh[b * MM + i * M + j]; }
   // one value per lane -> the vector in every lane
-  __device__ void gather(double x, double (&out)[M]) {
+  __device__ LG_INL void gather(double x, double (&out)[M]) {
     __syncthreads();
     sh[2 * MM + r] = x;
     __syncthreads();
@@ -52,7 +52,7 @@ struct LgRows {
     for (int q = 0; q < M; q++) out[q] = sh[2 * MM + q];
   }
   // symmatu: the lower triangle takes the upper one's values (row r, column j < r  <-  row j, column r)
-  __device__ void symmatu(double (&row)[M]) {
+  __device__ LG_INL void symmatu(double (&row)[M]) {
     put(0, row);
 #pragma unroll
     for (int j = 0; j < M; j++) if (j < r) row[j] = get(0, j, r);
@@ -60,7 +60,7 @@ struct LgRows {
 
   // at [(n+1)][M], Pt [(n+1)][MM], cc [(n+1)][MM], K [n][M], v [n], Fs [n]: element k at ptr[k * es] (draw-interleaved), as LgSmoother::run
   // leaves them with with_factors = false.  Returns the draw's verdict (the same in the M lanes of a group).
-  __device__ bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es) {
+  __device__ LG_INL bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es) {
     const int n = g.n, sub = g.sub;
     int bad = 0;
     double a[M], P[M], Z[M], T[M], RR[M], Cv[M], Kt[M];

@@ -16,6 +16,7 @@ __device__ unsigned long long g_setup_stamps[8];
 #include "lg_smoother.h"
 #include "lg_smoother_rows.h"
 #include "lg_factors_rows.h"
+#include "lg_smoother_wave.h"
 #include "pf_filter_impl.h"
 #include "tls_stream.h"
 
@@ -535,8 +536,9 @@ struct UngWork {
 };
 template <int M, int PHASE, bool ROWS>
 __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
-  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16)));
+  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : (M <= 16 ? 16 : (M <= 32 ? 32 : 64)))));
   constexpr int DPW = (PHASE == 1 && ROWS) ? 64 / M : 64;  // draws per workgroup
+  constexpr int kU = M >= 32 ? 1 : M;                      // (the copy loops of the tables stay loops for the padded big states)
   const int d0 = blockIdx.x * DPW + ((PHASE == 1 && ROWS) ? (int)threadIdx.x / M : (int)threadIdx.x);
   if (!(PHASE == 1 && ROWS) && d0 >= b.F) return;
   const int d = min(d0, b.F - 1);  // (rows: surplus groups redo the last draw -- every lane takes part in the LDS exchanges)
@@ -580,7 +582,11 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
     g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
     bool ok;
-    if constexpr (ROWS) {
+    if constexpr (ROWS && M >= 32) {  // 17 ... 64 states (padded): the matrices of the recursion in LDS (lg_smoother_wave.h)
+      __shared__ double lds[LgWave<M>::kLdsDoubles];
+      LgWave<M> wave(lds);
+      ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F);
+    } else if constexpr (ROWS) {
       __shared__ double lds[LgRows<M>::kLdsDoubles];
       LgRows<M> rows(lds);
       ok = rows.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F);
@@ -589,8 +595,10 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     }
     b.ok[d] = ok ? 1 : 0;
   } else if constexpr (PHASE == 2) {
-    if (!b.ok[d]) return;
-    if (!LgSmoother<M>::cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, F)) b.ok[d] = 0;  // (every writer stores 0)
+    if constexpr (M < 16) {  // (16 and more states: ung_factors_rows_kernel)
+      if (!b.ok[d]) return;
+      if (!LgSmoother<M>::cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, F)) b.ok[d] = 0;  // (every writer stores 0)
+    }
   } else {
     // ---- tables: psi proposal operands (src/model_ssm_ung.cpp:585-586), observation rows, initial state (:543)
     const int t = blockIdx.y;
@@ -602,7 +610,18 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
     double* mt = mats + (size_t)t * MS;
     for (int q = 0; q < MS; q++) mt[q] = 0.0;
-    if (ok) {
+    if constexpr (M >= 32) {  // (no work arrays of a lane: a 32 x 32 matrix is 8 KB of scratch memory; MP == M here)
+      if (ok) {
+        const double* c1 = cc + (size_t)(t + 1) * MM * F;
+        const double* p1 = Pt + (size_t)(t + 1) * MM * F;
+        for (int q = 0; q < MM; q++) { mt[q] = c1[(size_t)q * F]; mt[MM + q] = p1[(size_t)q * F]; }
+        for (int j = 0; j < M; j++) {
+          double s = 0.0;
+          for (int c = 0; c < M; c++) s += c1[(size_t)(j + M * c) * F] * at[((size_t)t * M + c) * F];
+          mt[2 * MM + j] = at[((size_t)(t + 1) * M + j) * F] - s;
+        }
+      }
+    } else if (ok) {
       double ah0[M], ah1[M], Ct1[MM];
 #pragma unroll
       for (int j = 0; j < M; j++) { ah0[j] = at[((size_t)t * M + j) * F]; ah1[j] = at[((size_t)(t + 1) * M + j) * F]; }
@@ -637,7 +656,7 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
         ob[OB_AUX] = (y / phi) * (y / phi);
       } else {
         ob[OB_D] = in[(b.oD + (size_t)t * b.Ds) * F] + in[(b.ox + t) * F];
-#pragma unroll
+#pragma unroll kU
         for (int c = 0; c < M; c++) ob[SER_HDR + c] = in[(b.oZ + (size_t)t * b.Zs + c) * F];
         ob[OB_AUX] = dist == DIST_NEGBIN ? y + phi : (dist == DIST_GAMMA ? y / u : 0.0);
       }
@@ -649,17 +668,17 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     if (t == 0) {
       for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
       if (ok) {
-#pragma unroll
+#pragma unroll kU
         for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
-#pragma unroll
+#pragma unroll kU
         for (int c = 0; c < M; c++)
-#pragma unroll
+#pragma unroll kU
           for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
       }
     }
   }
 }
-// conditional factors of sixteen-dimensional (padded) states: M lanes per (draw, time point), matrices in LDS (lg_factors_rows.h)
+// conditional factors of states of sixteen and more (padded) dimensions: M lanes per (draw, time point), matrices in LDS (lg_factors_rows.h)
 template <int M>
 __global__ void __launch_bounds__(64) ung_factors_rows_kernel(const UngSetupDev b) {
   constexpr int G = 64 / M;
@@ -675,17 +694,21 @@ template <int M>
 static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64);
   hipLaunchKernelGGL((ung_setup_kernel<M, 0, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 0, hipGetErrorString(de)); }
   const bool lane_form = opt().mng_lane_per_draw;  // (comparison switch, shared with the ssm_mng set-up)
-  constexpr int MR = (M == 16 || M == 8 || M == 4) ? M : 1;  // (as the ssm_mng set-up: rows for 16, 8 and 4 states)
-  if constexpr (M == 16) {  // (no one-lane-per-draw form: five 16 x 16 matrices do not fit a lane)
-    hipLaunchKernelGGL((ung_setup_kernel<16, 1, true>), dim3((unsigned)((b.F + 3) / 4)), dim3(64), 0, stream, b);
+  constexpr int MR = (M == 8 || M == 4) ? M : 1;  // (as the ssm_mng set-up: rows for 8 and 4 states; 16 and 32: rows only, above)
+  if constexpr (M >= 16) {  // (no one-lane-per-draw form: five 16 x 16 matrices do not fit a lane)
+    hipLaunchKernelGGL((ung_setup_kernel<M, 1, true>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M))), dim3(64), 0, stream, b);
   } else {
     if ((M == 8 || M == 4) && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<MR, 1, true>), dim3((unsigned)((b.F + 64 / MR - 1) / (64 / MR))), dim3(64), 0, stream, b);
     else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
   }
-  if constexpr (M == 16) hipLaunchKernelGGL((ung_factors_rows_kernel<16>), dim3((unsigned)((b.F + 3) / 4), (unsigned)b.n + 1), dim3(64), 0, stream, b);
+  if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 1, hipGetErrorString(de)); }
+  if constexpr (M >= 16) hipLaunchKernelGGL((ung_factors_rows_kernel<M>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M)), (unsigned)b.n + 1), dim3(64), 0, stream, b);
   else hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
+  if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 2, hipGetErrorString(de)); }
   hipLaunchKernelGGL((ung_setup_kernel<M, 3, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 3, hipGetErrorString(de)); }
   return hipGetLastError();
 }
 hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream) {
@@ -700,6 +723,8 @@ hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream) {
     case 7: return launch_ung_setup_m<7>(b, stream);
     case 8: return launch_ung_setup_m<8>(b, stream);
     case 16: return launch_ung_setup_m<16>(b, stream);  // (9 ... 16 states arrive padded to 16: ung_pack)
+    case 32: return launch_ung_setup_m<32>(b, stream);  // (17 ... 32: padded to 32)
+    case 64: return launch_ung_setup_m<64>(b, stream);  // (33 ... 64: padded to 64)
     default: return hipErrorInvalidValue;
   }
 }

@@ -120,7 +120,7 @@ def test_few_noise_terms_keep_the_wide_stream(oracle, monkeypatch):
         assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
 
 
-def test_post_correction_of_a_seasonal_model(oracle):
+def test_post_correction_of_a_seasonal_model(oracle, monkeypatch):
     """IS2 post-correction of bsm_ng(period = 24) draws (psi-APF N = 64 per draw, smoothing summaries) against the oracle's
     restatement of approx_mcmc::is_correction_psi (src/approx_mcmc.cpp:353-427); the job cut over two logical shards gives the same bits"""
     rng = np.random.default_rng(9)
@@ -139,12 +139,21 @@ def test_post_correction_of_a_seasonal_model(oracle):
     one = PC.post_correct(model, mo, 64, threads=4, is_type="is2", seed=5)
     ref = oracle.is_correction(arrs, 64, 5, method=1, counts=counts, modes=modes, is_type=2, output_type=2, n_threads=2)
     assert np.allclose(one["loglik"], ref["loglik"], rtol=0, atol=1e-8 * n)
-    assert np.allclose(one["weights"], ref["weights"], rtol=1e-7)
-    assert np.allclose(one["alphahat"], ref["alphahat"].T, rtol=1e-7, atol=1e-9)
-    assert np.allclose(one["Vt"], ref["Vt"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(one["weights"], ref["weights"], rtol=1e-6)
+    # (the psi set-up of these draws runs on the device since late round 5 -- states padded to 32, lg_smoother_wave.h + lg_factors_rows.h: the
+    # seasonal model's smoothing covariances are singular, and their factors amplify the device's FMA contraction to ~1e-7 of the state scale,
+    # as for the monthly seasonal of tests/test_gpu_postcorrect.py; the host set-up keeps the tight bounds below)
+    assert np.allclose(one["alphahat"], ref["alphahat"].T, rtol=1e-6, atol=2e-7)
+    assert np.allclose(one["Vt"], ref["Vt"], rtol=1e-6, atol=2e-7)
     two = PC.post_correct(model, mo, 64, threads=4, is_type="is2", seed=5, devices=[0, 0])
     for key in ("weights", "alphahat", "Vt"):
         assert np.array_equal(one[key], two[key]), key
+    monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", "0")
+    host = PC.post_correct(model, mo, 64, threads=4, is_type="is2", seed=5)
+    assert np.allclose(host["loglik"], ref["loglik"], rtol=0, atol=1e-8 * n)
+    assert np.allclose(host["weights"], ref["weights"], rtol=1e-7)
+    assert np.allclose(host["alphahat"], ref["alphahat"].T, rtol=1e-7, atol=1e-9)
+    assert np.allclose(host["Vt"], ref["Vt"], rtol=1e-6, atol=1e-9)
 
 
 @pytest.mark.parametrize("m,p,path,N", [(20, 12, "wg", 256), (20, 12, "row", 600), (4, 12, "wg", 512), (4, 12, "grid", 4096), (33, 16, "wg", 200)])
