@@ -1,16 +1,21 @@
 // lg_factors_rows.h -- the conditional factors of the psi set-up (LgSmoother<M>::cond_step: conditional_cov with use_svd = true,
 // src/conditional_dist.cpp:4-31) for states of 16 and more dimensions, ROW-DISTRIBUTED: M lanes share one (draw, time point), lane r owns
-// row r, and every M x M matrix of the step lives in LDS (rows padded to M + 1 doubles: a column read is as conflict-free as a row read).
+// row r, and the M x M matrices of the step live in LDS (rows padded to M + 1 doubles: a column read is as conflict-free as a row read).
 //
 // Why: with one lane per (draw, time point) the work matrices of a 16 x 16 step are 18 KB of scratch memory per LANE (74 KB at 32 x 32),
 // every element access a dependent round trip -- 172 ms per 2 048 monthly-seasonal draws, 83 % of that set-up -- and 32 x 32 does not run at
-// all.  Here a cyclic Jacobi rotation (p, q) is three LDS phases that are parallel over the M lanes: lane r rotates the column pair of ITS row
-// (A[r][p], A[r][q] and the eigenvector rows W[r][p], W[r][q]), then lane c rotates the row pair in ITS column (A[p][c], A[q][c]).
+// all.  Here a cyclic Jacobi rotation (p, q) is ONE LDS round trip that is parallel over the M lanes: every lane reads the column pair of ITS
+// row (A[r][p], A[r][q], the eigenvector rows W[r][p], W[r][q]) and the row pair in ITS column (A[p][r], A[q][r]) together -- the column
+// update leaves the row pair of a lane outside {p, q} untouched, and the lanes p and q form the 2 x 2 block's intermediate values from the four
+// block elements themselves -- and then writes its results of both updates.  Two matrix slots per group: X (the Jacobi matrix, then U, then the
+// own-row operands of the products) and Y (the eigenvector accumulator, then the pseudo-inverse, then the cross-covariance): 68 KB at M = 64,
+// two workgroups per CU.
 //
 // The arithmetic follows LgSmoother<M>::sym_singular / cond_step term by term: the same rotations in the same cyclic order from the same
-// formulas, products summed over the inner index in ascending order, the same sign and ordering conventions.  Two differences that do not
-// change a needed result: the off-diagonal / diagonal masses of the stopping test are summed row by row (they only decide when to stop, and
-// a further sweep is a no-op in double precision), and a non-finite value is carried to the end and reported there.
+// formulas, products summed over the inner index in ascending order, the same sign and ordering conventions (the stable descending sort is
+// evaluated as ranks: #{larger} + #{equal, earlier}).  Two differences that do not change a needed result: the off-diagonal / diagonal masses of
+// the stopping test are summed row by row (they only decide when to stop, and a further sweep is a no-op in double precision), and a
+// non-finite value is carried to the end and reported there.
 // Device only; one wave per workgroup (blockDim.x = 64); every lane of the wave must call it.
 #pragma once
 #include "lg_smoother.h"
@@ -21,35 +26,38 @@ template <int M>
 struct LgFactorRows {
   static_assert(64 % M == 0 && M >= 16, "M lanes per matrix must tile the wave");
   static constexpr int MM = M * M, G = 64 / M, LD = M + 1, MAT = M * LD;
-  static constexpr int GS = 3 * MAT + 4 * M + 2;   // per group: three matrices, four vectors (+ 2: groups start in different banks)
+  static constexpr int GS = 2 * MAT + 4 * M + 2;   // per group: two matrices, four vectors (+ 2: groups start in different banks)
   static constexpr size_t kLdsDoubles = (size_t)G * GS;
   static constexpr double kEps = DBL_EPSILON;
 
-  double *A, *W, *C;        // this group's matrices: A (Jacobi work matrix -> U), W (eigenvector accumulator -> pseudo-inverse), C (cross-covariance)
+  double *A, *W;              // this group's matrix slots: X (Jacobi work matrix -> U -> own-row operands), Y (eigenvector accumulator -> pseudo-inverse -> cross-covariance)
   double *va, *vb, *vc, *vd;  // this group's vectors
-  int r;                    // the row (and, in the row phase of a rotation, the column) this lane owns
-  bool skip = false;        // this group's draw has already failed: its decompositions take no rotations (the result is discarded)
+  int r;                      // the row (and, in a rotation, also the column) this lane owns
+  bool skip = false;          // this group's draw has already failed: its decompositions take no rotations (the result is discarded)
+  int mr = M;                 // rows / columns from mr on are exact zeros (states padded to M): no rotation touches them
   __device__ LgFactorRows(double* lds_wave) {
     const int lane = threadIdx.x & 63;
     r = lane % M;
     double* base = lds_wave + (size_t)(lane / M) * GS;
-    A = base; W = base + MAT; C = base + 2 * MAT;
-    va = base + 3 * MAT; vb = va + M; vc = vb + M; vd = vc + M;
+    A = base; W = base + MAT;
+    va = base + 2 * MAT; vb = va + M; vc = vb + M; vd = vc + M;
   }
 
-  // |eigenvalues| (descending) in s[], eigenvectors U (sign: the largest component of every vector positive) left in A, of the symmetric part
-  // of the matrix whose row r this lane passes in.  Uses A, W and the four vectors; C is untouched.
-  __device__ LG_INL void sym_singular(const double (&row)[M], double (&s)[M]) {
+  // |eigenvalues| (descending) left in vd[], eigenvectors U (sign: the largest component of every vector positive) left in A, of the symmetric
+  // part of the matrix whose row r this lane passes in.  Uses A, W and the four vectors.
+  __device__ LG_INL void sym_singular(const double (&row)[M]) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < M; j++) { A[r * LD + j] = row[j]; W[r * LD + j] = (j == r) ? 1.0 : 0.0; }
     __syncthreads();
-    double sym[M];
+    {
+      double sym[M];
 #pragma unroll
-    for (int j = 0; j < M; j++) sym[j] = 0.5 * (row[j] + A[j * LD + r]);
-    __syncthreads();
+      for (int j = 0; j < M; j++) sym[j] = 0.5 * (row[j] + A[j * LD + r]);
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < M; j++) A[r * LD + j] = sym[j];
+      for (int j = 0; j < M; j++) A[r * LD + j] = sym[j];
+    }
     __syncthreads();
     bool done = skip;
     for (int sweep = 0; sweep < 60; sweep++) {
@@ -64,122 +72,139 @@ struct LgFactorRows {
       for (int j = 0; j < M; j++) { off += va[j]; dg += vb[j]; }
       done = done || off < 1e-300 || off < 1e-60 * dg;
       if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // (every group of the wave has converged)
-      for (int p = 0; p < M - 1; p++)
-        for (int q = p + 1; q < M; q++) {
-          const double apq = A[p * LD + q], app = A[p * LD + p], aqq = A[q * LD + q];
-          const bool act = !done && apq != 0.0;
-          const double tau = (aqq - app) / (2.0 * (act ? apq : 1.0));
-          const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
-          // column pair of this lane's row, of A and of the eigenvector accumulator
+      // (a pair with a padded index has apq == 0 exactly and is no rotation in LgSmoother::sym_singular either: the loops stop at mr)
+      for (int p = 0; p < mr - 1; p++)
+        for (int q = p + 1; q < mr; q++) {
+          const double apq = A[p * LD + q], app = A[p * LD + p], aqq = A[q * LD + q], aqp = A[q * LD + p];
+          // this lane's column pair (of A and of the eigenvector accumulator) and the row pair in its column, all as they are BEFORE the rotation
           const double x = A[r * LD + p], y = A[r * LD + q], wx = W[r * LD + p], wy = W[r * LD + q];
+          double x2 = A[p * LD + r], y2 = A[q * LD + r];
+          const bool act = !done && apq != 0.0;
+          double t, cs;
+          if constexpr (M >= 32) {
+            // the same tangent and cosine from three long operations instead of five (a rotation is one dependent chain, and 2 016 of them
+            // make a sweep at M = 64): with h = aqq - app, g = 2 apq:  t = sign(h g) |g| / (|h| + sqrt(h^2 + g^2)),  cs = rsqrt(1 + t^2)
+            const double h = aqq - app, g = 2.0 * (act ? apq : 1.0);
+            const double sgn = (h == 0.0 || (h > 0) == (g > 0)) ? 1.0 : -1.0;
+            t = sgn * fabs(g) / (fabs(h) + sqrt(h * h + g * g));
+            cs = rsqrt(1.0 + t * t);
+          } else {
+            const double tau = (aqq - app) / (2.0 * (act ? apq : 1.0));
+            t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            cs = 1.0 / sqrt(1.0 + t * t);
+          }
+          const double sn = t * cs;
+          // the column update A[., p], A[., q] <- (cs x - sn y, sn x + cs y) leaves A[p][r], A[q][r] of a lane r outside {p, q} as read above;
+          // in the columns p and q the row update reads what the column update made of the 2 x 2 block
+          if (r == p) { x2 = cs * app - sn * apq; y2 = cs * aqp - sn * aqq; }
+          if (r == q) { x2 = sn * app + cs * apq; y2 = sn * aqp + cs * aqq; }
           __syncthreads();
           if (act) {
-            A[r * LD + p] = cs * x - sn * y; A[r * LD + q] = sn * x + cs * y;
+            if (r != p && r != q) { A[r * LD + p] = cs * x - sn * y; A[r * LD + q] = sn * x + cs * y; }
+            A[p * LD + r] = cs * x2 - sn * y2; A[q * LD + r] = sn * x2 + cs * y2;
             W[r * LD + p] = cs * wx - sn * wy; W[r * LD + q] = sn * wx + cs * wy;
           }
           __syncthreads();
-          // row pair in this lane's column
-          const double x2 = A[p * LD + r], y2 = A[q * LD + r];
-          __syncthreads();
-          if (act) { A[p * LD + r] = cs * x2 - sn * y2; A[q * LD + r] = sn * x2 + cs * y2; }
-          __syncthreads();
         }
     }
-    // singular values, stable insertion sort descending (every lane the same sort on the same values), sign convention
-    double sv[M];
-    int ord[M];
-#pragma unroll
-    for (int j = 0; j < M; j++) { sv[j] = fabs(A[j * LD + j]); ord[j] = j; }
-    for (int a = 1; a < M; a++) {
-      const int o = ord[a];
-      const double so = sv[o];
-      int b = a - 1;
-      while (b >= 0 && sv[ord[b]] < so) { ord[b + 1] = ord[b]; b--; }
-      ord[b + 1] = o;
-    }
-    // (ord[] and sv[] are indexed dynamically: they live in scratch memory, M entries each -- the sort is M^2 / 4 steps once per call)
+    // singular values in stable descending order, as ranks: lane r's value goes to place #{larger} + #{equal and earlier}
+    const double svr = fabs(A[r * LD + r]);
+    __syncthreads();
+    va[r] = svr;
+    __syncthreads();
+    int rank = 0;
+    for (int i = 0; i < M; i++) { const double o = va[i]; rank += (o > svr || (o == svr && i < r)) ? 1 : 0; }
+    __syncthreads();
+    vd[rank] = svr; vb[rank] = (double)r;   // (a NaN on the diagonal leaves places unfilled: the result is non-finite and reported anyway)
+    __syncthreads();
     // lane j owns output column j: its source column, its sign
-    int src = 0;
-    for (int j = 0; j < M; j++) { s[j] = sv[ord[j]]; if (j == r) src = ord[j]; }
+    const int src = min(max((int)vb[r], 0), M - 1);
     int big = 0;
     for (int i = 1; i < M; i++) if (fabs(W[i * LD + src]) > fabs(W[big * LD + src])) big = i;
     const double sg = W[big * LD + src] < 0 ? -1.0 : 1.0;
     __syncthreads();
-    va[r] = sg; vb[r] = (double)src;
+    va[r] = sg; vc[r] = (double)src;
     __syncthreads();
-    // U[r][j] = sg_j W[r][ord_j]: into A (the Jacobi matrix is spent)
-    double urow[M];
+    // U[r][j] = sg_j W[r][src_j]: into A (the Jacobi matrix is spent)
+#pragma unroll 4
+    for (int j = 0; j < M; j++) A[r * LD + j] = va[j] * W[r * LD + (int)vc[j]];
+    __syncthreads();
+  }
+
+  // c[j] = sum over q (ascending, from 0.0) of A[r][q] * W[q][j]: this lane's own operand row in slot X, the broadcast operand in slot Y
+  __device__ LG_INL void prod_xy(double (&c)[M]) {
 #pragma unroll
-    for (int j = 0; j < M; j++) urow[j] = va[j] * W[r * LD + (int)vb[j]];
-    __syncthreads();
+    for (int j = 0; j < M; j++) c[j] = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < M; q++) {
+      const double a = A[r * LD + q];
 #pragma unroll
-    for (int j = 0; j < M; j++) A[r * LD + j] = urow[j];
-    __syncthreads();
+      for (int j = 0; j < M; j++) c[j] += a * W[q * LD + j];
+    }
   }
 
   // conditional_cov at time point t of draw d (arrays draw-interleaved, element k at ptr[k * es + d]); returns whether everything written is finite
   __device__ LG_INL bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d) {
     int bad = 0;
-    double row[M], s[M];
+    double row[M];
     if (t == 0) {
 #pragma unroll
       for (int j = 0; j < M; j++) row[j] = Pt[(size_t)(r + M * j) * es + d];
-      sym_singular(row, s);
+      sym_singular(row);
 #pragma unroll
       for (int j = 0; j < M; j++) {
-        const double v = A[r * LD + j] * sqrt(s[j]);
+        const double v = A[r * LD + j] * sqrt(vd[j]);
         Vout[(size_t)(r + M * j) * es + d] = v;
         bad |= !lg_finite(v);
       }
       return reduce_bad(bad);
     }
-    double vc_row[M];
 #pragma unroll
-    for (int j = 0; j < M; j++) {
-      row[j] = Pt[((size_t)(t - 1) * MM + r + M * j) * es + d];
-      vc_row[j] = Pt[((size_t)t * MM + r + M * j) * es + d];
-      C[r * LD + j] = cc[((size_t)(t - 1) * MM + r + M * j) * es + d];
-    }
-    sym_singular(row, s);   // U in A
-    // pseudo-inverse W2 = sum over the kept components c of U[:, c] U[:, c]' / s_c, ascending c (into W)
-    double acc[M];
+    for (int j = 0; j < M; j++) row[j] = Pt[((size_t)(t - 1) * MM + r + M * j) * es + d];
+    sym_singular(row);   // U in X, |eigenvalues| in vd
+    // pseudo-inverse W2 = sum over the kept components c of U[:, c] U[:, c]' / s_c, ascending c
+    const double s0 = vd[0];
 #pragma unroll
-    for (int j = 0; j < M; j++) acc[j] = 0.0;
+    for (int j = 0; j < M; j++) row[j] = 0.0;
+#pragma unroll 1
     for (int c = 0; c < M; c++) {
-      if (!(s[c] > kEps * M * s[0])) continue;
-      const double urc = A[r * LD + c], sc = s[c];
+      const double sc = vd[c];
+      if (!(sc > kEps * M * s0)) continue;
+      const double urc = A[r * LD + c];
 #pragma unroll
-      for (int j = 0; j < M; j++) acc[j] += urc * A[j * LD + c] / sc;
+      for (int j = 0; j < M; j++) row[j] += urc * A[j * LD + c] / sc;
     }
+    __syncthreads();   // every lane is through with U (and long through with the eigenvector accumulator)
+#pragma unroll
+    for (int j = 0; j < M; j++) W[r * LD + j] = row[j];
+    // tmp = Cp' W2 (row r: sum over q of Cp[q][r] W2[q][j]): column r of the cross-covariance is this lane's operand row
+#pragma unroll
+    for (int q = 0; q < M; q++) row[q] = cc[((size_t)(t - 1) * MM + q + M * r) * es + d];
+#pragma unroll
+    for (int q = 0; q < M; q++) A[r * LD + q] = row[q];
     __syncthreads();
+    prod_xy(row);
 #pragma unroll
-    for (int j = 0; j < M; j++) W[r * LD + j] = acc[j];
+    for (int j = 0; j < M; j++) {
+      Cout[((size_t)t * MM + r + M * j) * es + d] = row[j];
+      bad |= !lg_finite(row[j]);
+    }
+    // Vc - tmp Cp: tmp's rows into X, the cross-covariance's rows into Y
+    __syncthreads();   // every lane is through with W2
+#pragma unroll
+    for (int j = 0; j < M; j++) A[r * LD + j] = row[j];
+#pragma unroll
+    for (int j = 0; j < M; j++) row[j] = cc[((size_t)(t - 1) * MM + r + M * j) * es + d];
+#pragma unroll
+    for (int j = 0; j < M; j++) W[r * LD + j] = row[j];
     __syncthreads();
-    // tmp = Cp' W2 (row r: sum over q of Cp[q][r] W2[q][j]), tmp2 = tmp Cp
-    double tmp[M];
+    prod_xy(row);
+#pragma unroll
+    for (int j = 0; j < M; j++) row[j] = Pt[((size_t)t * MM + r + M * j) * es + d] - row[j];
+    sym_singular(row);
 #pragma unroll
     for (int j = 0; j < M; j++) {
-      double sacc = 0.0;
-      for (int q = 0; q < M; q++) sacc += C[q * LD + r] * W[q * LD + j];
-      tmp[j] = sacc;
-    }
-#pragma unroll
-    for (int j = 0; j < M; j++) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int q = 0; q < M; q++) sacc += tmp[q] * C[q * LD + j];
-      vc_row[j] -= sacc;
-    }
-#pragma unroll
-    for (int j = 0; j < M; j++) {
-      Cout[((size_t)t * MM + r + M * j) * es + d] = tmp[j];
-      bad |= !lg_finite(tmp[j]);
-    }
-    sym_singular(vc_row, s);
-#pragma unroll
-    for (int j = 0; j < M; j++) {
-      const double v = A[r * LD + j] * sqrt(s[j]);
+      const double v = A[r * LD + j] * sqrt(vd[j]);
       Vout[((size_t)t * MM + r + M * j) * es + d] = v;
       bad |= !lg_finite(v);
     }

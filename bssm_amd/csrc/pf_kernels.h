@@ -198,6 +198,7 @@ hipError_t launch_fn_setup(const FnSetupDev& b, hipStream_t stream);
 struct UngSetupDev {
   int F, n, m;
   int p = 1;                 // series per time point (ssm_mng: mng_setup_kernel, mng_pack element order; obs rows ROW_HDR + p (SER_HDR + MP))
+  int mr = 0;                // the states the draws really have where m is a padded dimension (16 / 32 / 64; 0: m) -- the rest is exact zeros
   int Zs, Ts, Rs, Ds, Cs;
   size_t oZ, oT, oR, oD, oC, oy, oa, oP, ou, ox, om, oh;
   const double* in;

@@ -687,6 +687,7 @@ __global__ void __launch_bounds__(64) ung_factors_rows_kernel(const UngSetupDev 
   const UngWork<M> W(b, d);
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
+  rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
   const bool fine = rows.cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, (size_t)b.F, 0);
   if (!fine && !rows.skip && rows.r == 0) b.ok[d] = 0;  // (every writer stores 0)
 }

@@ -14,7 +14,7 @@
 using namespace bssm;
 
 struct Dev {
-  int F, n;
+  int F, n, mr;
   const double *Z, *T, *RR, *D, *C, *y, *H, *a1, *P1;
   double *at, *Pt, *cc, *K, *v, *Fs, *Vf, *Cf;
   int* ok;
@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(64) factors_kernel(const Dev b) {
   const int d = min((int)(blockIdx.x * G + threadIdx.x / M), b.F - 1);
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
+  rows.mr = b.mr;
   const bool fine = rows.cond_step((int)blockIdx.y, b.Pt + d, b.cc + d, b.Vf + d, b.Cf + d, (size_t)b.F, 0);
   if (!fine && !rows.skip && rows.r == 0) b.ok[d] = 0;
 }
@@ -99,7 +100,7 @@ int check(int mr, int n, int F, unsigned seed) {
   auto up = [&](const std::vector<double>& hsrc) { double* p; CK(hipMalloc(&p, hsrc.size() * 8)); CK(hipMemcpy(p, hsrc.data(), hsrc.size() * 8, hipMemcpyHostToDevice)); return p; };
   auto dalloc = [&](size_t cnt) { double* p; CK(hipMalloc(&p, cnt * 8)); CK(hipMemset(p, 0, cnt * 8)); return p; };
   Dev b{};
-  b.F = F; b.n = n;
+  b.F = F; b.n = n; b.mr = mr;
   b.Z = up(inter(Z, M)); b.T = up(inter(T, MM)); b.RR = up(inter(RR, MM)); b.D = up(D); b.C = up(inter(C, M)); b.y = up(inter(y, n)); b.H = up(inter(H, n));
   b.a1 = up(inter(a1, M)); b.P1 = up(inter(P1, MM));
   b.at = dalloc((size_t)F * n1 * M); b.Pt = dalloc((size_t)F * n1 * MM); b.cc = dalloc((size_t)F * n1 * MM); b.K = dalloc((size_t)F * n * M); b.v = dalloc((size_t)F * n); b.Fs = dalloc((size_t)F * n);
