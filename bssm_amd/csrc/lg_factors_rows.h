@@ -22,6 +22,10 @@
 
 namespace bssm {
 
+#ifdef LGF_STATS
+__device__ unsigned long long lgf_stats[8];   // analysis builds (scripts/lgwave_check.hip): calls, sweeps, clocks of the Jacobi loops / of cond_step
+#endif
+
 template <int M>
 struct LgFactorRows {
   static_assert(64 % M == 0 && M >= 16, "M lanes per matrix must tile the wave");
@@ -60,7 +64,14 @@ struct LgFactorRows {
     }
     __syncthreads();
     bool done = skip;
+#ifdef LGF_STATS
+    const unsigned long long lgf_c0 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) atomicAdd(&lgf_stats[0], 1ull);
+#endif
     for (int sweep = 0; sweep < 60; sweep++) {
+#ifdef LGF_STATS
+      if (threadIdx.x == 0) atomicAdd(&lgf_stats[1], 1ull);
+#endif
       // stopping test of the sweep (LgSmoother::sym_singular): off-diagonal mass below 1e-60 of the diagonal's
       double po = 0.0;
       for (int j = r + 1; j < M; j++) { const double x = A[r * LD + j]; po += x * x; }
@@ -72,6 +83,76 @@ struct LgFactorRows {
       for (int j = 0; j < M; j++) { off += va[j]; dg += vb[j]; }
       done = done || off < 1e-300 || off < 1e-60 * dg;
       if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // (every group of the wave has converged)
+      if constexpr (M >= 32) {
+        // ROUND-ROBIN ordering (the tournament schedule): a step is mr / 2 rotations on disjoint index pairs -- they commute, so the step is
+        // A <- J' A J with J their product: the parameters of pair i by lane i from the matrix as the step finds it, then every lane rotates
+        // the column pairs of its row (of A and of the eigenvector accumulator), then the row pairs in its column.  A sweep is mr - 1 steps
+        // instead of mr (mr - 1) / 2 dependent rotations; the same rotations as the cyclic order up to the order of roundings (the host takes
+        // the cyclic order: the decompositions agree to the last places, and differ as any two exact methods do where eigenvalues repeat).
+        const int ne = (mr + 1) & ~1, half = ne / 2, ring = ne - 1;
+        auto pair_of = [&](int k, int i, int& p, int& q) {   // (k and i are the same in every lane: scalar arithmetic)
+          int a = k + i, b = k - i;
+          a = a >= ring ? a - ring : a; b = b < 0 ? b + ring : b;
+          if (i == 0) { a = ring; b = k; }
+          p = a < b ? a : b; q = a < b ? b : a;
+        };
+        constexpr int B = 8;   // pairs per batch: their operands are requested together (a rotation is otherwise one LDS round trip after the other)
+        for (int k = 0; k < ring; k++) {
+          __syncthreads();
+          if (r < half) {
+            int p, q;
+            pair_of(k, r, p, q);
+            double cs = 1.0, sn = 0.0;
+            if (q < mr && !done) {
+              const double apq = A[p * LD + q];
+              if (apq != 0.0) {
+                const double h = A[q * LD + q] - A[p * LD + p], g = 2.0 * apq;
+                const double sgn = (h == 0.0 || (h > 0) == (g > 0)) ? 1.0 : -1.0;
+                const double t = sgn * fabs(g) / (fabs(h) + sqrt(h * h + g * g));
+                cs = rsqrt(1.0 + t * t);
+                sn = t * cs;
+              }
+            }
+            va[r] = cs; vb[r] = sn;
+          }
+          __syncthreads();
+          for (int i0 = 0; i0 < half; i0 += B) {
+            double cs[B], sn[B], x[B], y[B], wx[B], wy[B];
+            int pp[B], qq[B];
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+              const int i = i0 + u < half ? i0 + u : half - 1;
+              pair_of(k, i, pp[u], qq[u]);
+              cs[u] = va[i]; sn[u] = vb[i];
+              x[u] = A[r * LD + pp[u]]; y[u] = A[r * LD + qq[u]]; wx[u] = W[r * LD + pp[u]]; wy[u] = W[r * LD + qq[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+              if (i0 + u < half && sn[u] != 0.0) {
+                A[r * LD + pp[u]] = cs[u] * x[u] - sn[u] * y[u]; A[r * LD + qq[u]] = sn[u] * x[u] + cs[u] * y[u];
+                W[r * LD + pp[u]] = cs[u] * wx[u] - sn[u] * wy[u]; W[r * LD + qq[u]] = sn[u] * wx[u] + cs[u] * wy[u];
+              }
+            }
+          }
+          __syncthreads();
+          for (int i0 = 0; i0 < half; i0 += B) {
+            double cs[B], sn[B], x[B], y[B];
+            int pp[B], qq[B];
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+              const int i = i0 + u < half ? i0 + u : half - 1;
+              pair_of(k, i, pp[u], qq[u]);
+              cs[u] = va[i]; sn[u] = vb[i];
+              x[u] = A[pp[u] * LD + r]; y[u] = A[qq[u] * LD + r];
+            }
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+              if (i0 + u < half && sn[u] != 0.0) { A[pp[u] * LD + r] = cs[u] * x[u] - sn[u] * y[u]; A[qq[u] * LD + r] = sn[u] * x[u] + cs[u] * y[u]; }
+            }
+          }
+        }
+        __syncthreads();
+      } else {
       // (a pair with a padded index has apq == 0 exactly and is no rotation in LgSmoother::sym_singular either: the loops stop at mr)
       for (int p = 0; p < mr - 1; p++)
         for (int q = p + 1; q < mr; q++) {
@@ -80,20 +161,9 @@ struct LgFactorRows {
           const double x = A[r * LD + p], y = A[r * LD + q], wx = W[r * LD + p], wy = W[r * LD + q];
           double x2 = A[p * LD + r], y2 = A[q * LD + r];
           const bool act = !done && apq != 0.0;
-          double t, cs;
-          if constexpr (M >= 32) {
-            // the same tangent and cosine from three long operations instead of five (a rotation is one dependent chain, and 2 016 of them
-            // make a sweep at M = 64): with h = aqq - app, g = 2 apq:  t = sign(h g) |g| / (|h| + sqrt(h^2 + g^2)),  cs = rsqrt(1 + t^2)
-            const double h = aqq - app, g = 2.0 * (act ? apq : 1.0);
-            const double sgn = (h == 0.0 || (h > 0) == (g > 0)) ? 1.0 : -1.0;
-            t = sgn * fabs(g) / (fabs(h) + sqrt(h * h + g * g));
-            cs = rsqrt(1.0 + t * t);
-          } else {
-            const double tau = (aqq - app) / (2.0 * (act ? apq : 1.0));
-            t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-            cs = 1.0 / sqrt(1.0 + t * t);
-          }
-          const double sn = t * cs;
+          const double tau = (aqq - app) / (2.0 * (act ? apq : 1.0));
+          const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
           // the column update A[., p], A[., q] <- (cs x - sn y, sn x + cs y) leaves A[p][r], A[q][r] of a lane r outside {p, q} as read above;
           // in the columns p and q the row update reads what the column update made of the 2 x 2 block
           if (r == p) { x2 = cs * app - sn * apq; y2 = cs * aqp - sn * aqq; }
@@ -106,7 +176,11 @@ struct LgFactorRows {
           }
           __syncthreads();
         }
+      }
     }
+#ifdef LGF_STATS
+    if (threadIdx.x == 0) atomicAdd(&lgf_stats[2], (unsigned long long)(__builtin_readcyclecounter() - lgf_c0));
+#endif
     // singular values in stable descending order, as ranks: lane r's value goes to place #{larger} + #{equal and earlier}
     const double svr = fabs(A[r * LD + r]);
     __syncthreads();
@@ -147,6 +221,9 @@ struct LgFactorRows {
   __device__ LG_INL bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d) {
     int bad = 0;
     double row[M];
+#ifdef LGF_STATS
+    const unsigned long long lgf_t0 = __builtin_readcyclecounter();
+#endif
     if (t == 0) {
 #pragma unroll
       for (int j = 0; j < M; j++) row[j] = Pt[(size_t)(r + M * j) * es + d];
@@ -208,6 +285,9 @@ struct LgFactorRows {
       Vout[((size_t)t * MM + r + M * j) * es + d] = v;
       bad |= !lg_finite(v);
     }
+#ifdef LGF_STATS
+    if (threadIdx.x == 0) { atomicAdd(&lgf_stats[3], (unsigned long long)(__builtin_readcyclecounter() - lgf_t0)); atomicAdd(&lgf_stats[4], 1ull); }
+#endif
     return reduce_bad(bad);
   }
 

@@ -582,10 +582,8 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
     g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
     bool ok;
-    if constexpr (ROWS && M >= 32) {  // 17 ... 64 states (padded): the matrices of the recursion in LDS (lg_smoother_wave.h)
-      __shared__ double lds[LgWave<M>::kLdsDoubles];
-      LgWave<M> wave(lds);
-      ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F);
+    if constexpr (ROWS && M >= 32) {  // (17 ... 64 states, padded: ung_smooth_wave_kernel)
+      ok = false;
     } else if constexpr (ROWS) {
       __shared__ double lds[LgRows<M>::kLdsDoubles];
       LgRows<M> rows(lds);
@@ -678,6 +676,24 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     }
   }
 }
+// Kalman filter + covariance smoother of 17 ... 64 states (padded to 32 / 64): one workgroup of M / 16 waves per 64 / M draws, the matrices of the
+// recursion in LDS (lg_smoother_wave.h) -- phase 1 of the set-up for these dimensions
+template <int M>
+__global__ void __launch_bounds__(LgWave<M>::kThreads) ung_smooth_wave_kernel(const UngSetupDev b) {
+  __shared__ double lds[LgWave<M>::kLdsDoubles];
+  const int d = min((int)(blockIdx.x * (64 / M) + (threadIdx.x & 63) / M), b.F - 1);  // (surplus groups redo the last draw: every lane takes part in the barriers)
+  const size_t F = (size_t)b.F;
+  const UngWork<M> W(b, d);
+  const double* in = W.in;
+  LgModel g;
+  g.n = b.n;
+  g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
+  g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
+  g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
+  LgWave<M> wave(lds);
+  const bool ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F);
+  if (wave.r == 0 && wave.w == 0) b.ok[d] = ok ? 1 : 0;
+}
 // conditional factors of states of sixteen and more (padded) dimensions: M lanes per (draw, time point), matrices in LDS (lg_factors_rows.h)
 template <int M>
 __global__ void __launch_bounds__(64) ung_factors_rows_kernel(const UngSetupDev b) {
@@ -698,7 +714,9 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 0, hipGetErrorString(de)); }
   const bool lane_form = opt().mng_lane_per_draw;  // (comparison switch, shared with the ssm_mng set-up)
   constexpr int MR = (M == 8 || M == 4) ? M : 1;  // (as the ssm_mng set-up: rows for 8 and 4 states; 16 and 32: rows only, above)
-  if constexpr (M >= 16) {  // (no one-lane-per-draw form: five 16 x 16 matrices do not fit a lane)
+  if constexpr (M >= 32) {
+    hipLaunchKernelGGL((ung_smooth_wave_kernel<M>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M))), dim3(LgWave<M>::kThreads), 0, stream, b);
+  } else if constexpr (M >= 16) {  // (no one-lane-per-draw form: five 16 x 16 matrices do not fit a lane)
     hipLaunchKernelGGL((ung_setup_kernel<M, 1, true>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M))), dim3(64), 0, stream, b);
   } else {
     if ((M == 8 || M == 4) && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<MR, 1, true>), dim3((unsigned)((b.F + 64 / MR - 1) / (64 / MR))), dim3(64), 0, stream, b);

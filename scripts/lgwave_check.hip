@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
+#define LGF_STATS 1
 #include "lg_smoother.h"
 #include "lg_smoother_wave.h"
 #include "lg_factors_rows.h"
@@ -21,10 +22,10 @@ struct Dev {
 };
 
 template <int M>
-__global__ void __launch_bounds__(64) smooth_kernel(const Dev b) {
+__global__ void __launch_bounds__(LgWave<M>::kThreads) smooth_kernel(const Dev b) {
   constexpr int G = 64 / M;
   __shared__ double lds[LgWave<M>::kLdsDoubles];
-  const int d = min((int)(blockIdx.x * G + threadIdx.x / M), b.F - 1);
+  const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);
   LgModel g;
   g.n = b.n;
   g.Z = b.Z + d; g.Zs = 0; g.T = b.T + d; g.Ts = 0; g.RR = b.RR + d; g.Rs = 0; g.D = b.D + d; g.Ds = 0; g.C = b.C + d; g.Cs = 0;
@@ -110,7 +111,7 @@ int check(int mr, int n, int F, unsigned seed) {
   hipEvent_t e0, e1, e2;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL((smooth_kernel<M>), dim3((F + G - 1) / G), dim3(64), 0, 0, b);
+  hipLaunchKernelGGL((smooth_kernel<M>), dim3((F + G - 1) / G), dim3(LgWave<M>::kThreads), 0, 0, b);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   std::vector<double> g_at((size_t)F * n1 * M), g_Pt((size_t)F * n1 * MM), g_cc((size_t)F * n1 * MM), g_Vf((size_t)F * n1 * MM), g_Cf((size_t)F * n1 * MM);
@@ -123,13 +124,20 @@ int check(int mr, int n, int F, unsigned seed) {
   CK(hipDeviceSynchronize());
   float ms_f = 0;
   CK(hipEventElapsedTime(&ms_f, e1, e2));
+  {
+    unsigned long long st[8] = {0}, zero[8] = {0};
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(bssm::lgf_stats), sizeof(st)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(bssm::lgf_stats), zero, sizeof(zero)));
+    std::printf("   factors: %llu decompositions, %.2f sweeps each, %.0f clocks (100 MHz) per decomposition; %llu steps behind t = 0 at %.0f clocks each\n", st[0], (double)st[1] / (double)st[0],
+                (double)st[2] / (double)st[0], st[4], (double)st[3] / (double)(st[4] ? st[4] : 1));
+  }
   CK(hipMemcpy(g_Vf.data(), b.Vf, g_Vf.size() * 8, hipMemcpyDeviceToHost));
   CK(hipMemcpy(g_Cf.data(), b.Cf, g_Cf.size() * 8, hipMemcpyDeviceToHost));
   std::vector<int> g_ok(F);
   CK(hipMemcpy(g_ok.data(), b.ok, F * sizeof(int), hipMemcpyDeviceToHost));
   // timing of the smoother alone
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL((smooth_kernel<M>), dim3((F + G - 1) / G), dim3(64), 0, 0, b);
+  hipLaunchKernelGGL((smooth_kernel<M>), dim3((F + G - 1) / G), dim3(LgWave<M>::kThreads), 0, 0, b);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms_s = 0;
