@@ -9,7 +9,8 @@
 // update leaves the row pair of a lane outside {p, q} untouched, and the lanes p and q form the 2 x 2 block's intermediate values from the four
 // block elements themselves -- and then writes its results of both updates.  Two matrix slots per group: X (the Jacobi matrix, then U, then the
 // own-row operands of the products) and Y (the eigenvector accumulator, then the pseudo-inverse, then the cross-covariance): 68 KB at M = 64,
-// two workgroups per CU.
+// two workgroups per CU.  At 64 (padded) states a workgroup is NW = 4 waves: lane r of every wave works on row r, wave w owns the columns
+// [w M / NW, (w + 1) M / NW) of it in the products and every NW-th rotation of a round-robin step.
 //
 // The arithmetic follows LgSmoother<M>::sym_singular / cond_step term by term: the same rotations in the same cyclic order from the same
 // formulas, products summed over the inner index in ascending order, the same sign and ordering conventions (the stable descending sort is
@@ -26,41 +27,48 @@ namespace bssm {
 __device__ unsigned long long lgf_stats[8];   // analysis builds (scripts/lgwave_check.hip): calls, sweeps, clocks of the Jacobi loops / of cond_step
 #endif
 
-template <int M>
+// (NW: four waves at 64 states -- 256 draws of 53 states 328 -> 244 ms; at 32 states two waves per workgroup were SLOWER in a full batch, 38 -> 47 ms
+// per 512 draws: the rotations are bound by the CU's LDS instruction rate there, and every wave repeats the per-step parameters)
+template <int M, int NW = (M >= 64 ? M / 16 : 1)>
 struct LgFactorRows {
   static_assert(64 % M == 0 && M >= 16, "M lanes per matrix must tile the wave");
-  static constexpr int MM = M * M, G = 64 / M, LD = M + 1, MAT = M * LD;
+  static_assert(M % NW == 0, "the waves split the columns evenly");
+  static constexpr int MM = M * M, G = 64 / M, LD = M + 1, MAT = M * LD, JW = M / NW;
   static constexpr int GS = 2 * MAT + 4 * M + 2;   // per group: two matrices, four vectors (+ 2: groups start in different banks)
   static constexpr size_t kLdsDoubles = (size_t)G * GS;
+  static constexpr int kThreads = 64 * NW;
   static constexpr double kEps = DBL_EPSILON;
 
   double *A, *W;              // this group's matrix slots: X (Jacobi work matrix -> U -> own-row operands), Y (eigenvector accumulator -> pseudo-inverse -> cross-covariance)
   double *va, *vb, *vc, *vd;  // this group's vectors
-  int r;                      // the row (and, in a rotation, also the column) this lane owns
+  int r;                      // the row (and, in a rotation, also the column) this lane works on
+  int w, j0;                  // its wave, the first of the JW columns the wave owns
   bool skip = false;          // this group's draw has already failed: its decompositions take no rotations (the result is discarded)
   int mr = M;                 // rows / columns from mr on are exact zeros (states padded to M): no rotation touches them
-  __device__ LgFactorRows(double* lds_wave) {
+  __device__ LgFactorRows(double* lds_wg) {
     const int lane = threadIdx.x & 63;
     r = lane % M;
-    double* base = lds_wave + (size_t)(lane / M) * GS;
+    w = (int)threadIdx.x >> 6;
+    j0 = w * JW;
+    double* base = lds_wg + (size_t)(lane / M) * GS;
     A = base; W = base + MAT;
     va = base + 2 * MAT; vb = va + M; vc = vb + M; vd = vc + M;
   }
 
   // |eigenvalues| (descending) left in vd[], eigenvectors U (sign: the largest component of every vector positive) left in A, of the symmetric
-  // part of the matrix whose row r this lane passes in.  Uses A, W and the four vectors.
-  __device__ LG_INL void sym_singular(const double (&row)[M]) {
+  // part of the matrix whose row r (this lane's columns of it) is passed in.  Uses A, W and the four vectors.
+  __device__ LG_INL void sym_singular(const double (&row)[JW]) {
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < M; j++) { A[r * LD + j] = row[j]; W[r * LD + j] = (j == r) ? 1.0 : 0.0; }
+    for (int jj = 0; jj < JW; jj++) { A[r * LD + j0 + jj] = row[jj]; W[r * LD + j0 + jj] = (j0 + jj == r) ? 1.0 : 0.0; }
     __syncthreads();
     {
-      double sym[M];
+      double sym[JW];
 #pragma unroll
-      for (int j = 0; j < M; j++) sym[j] = 0.5 * (row[j] + A[j * LD + r]);
+      for (int jj = 0; jj < JW; jj++) sym[jj] = 0.5 * (row[jj] + A[(j0 + jj) * LD + r]);
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < M; j++) A[r * LD + j] = sym[j];
+      for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = sym[jj];
     }
     __syncthreads();
     bool done = skip;
@@ -77,18 +85,19 @@ struct LgFactorRows {
       for (int j = r + 1; j < M; j++) { const double x = A[r * LD + j]; po += x * x; }
       const double dr = A[r * LD + r];
       __syncthreads();
-      va[r] = po; vb[r] = dr * dr;
+      va[r] = po; vb[r] = dr * dr;   // (every wave of the workgroup stores the same values)
       __syncthreads();
       double off = 0.0, dg = 0.0;
       for (int j = 0; j < M; j++) { off += va[j]; dg += vb[j]; }
       done = done || off < 1e-300 || off < 1e-60 * dg;
-      if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // (every group of the wave has converged)
+      if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // (every group has converged: the same verdict in every wave)
       if constexpr (M >= 32) {
         // ROUND-ROBIN ordering (the tournament schedule): a step is mr / 2 rotations on disjoint index pairs -- they commute, so the step is
-        // A <- J' A J with J their product: the parameters of pair i by lane i from the matrix as the step finds it, then every lane rotates
-        // the column pairs of its row (of A and of the eigenvector accumulator), then the row pairs in its column.  A sweep is mr - 1 steps
-        // instead of mr (mr - 1) / 2 dependent rotations; the same rotations as the cyclic order up to the order of roundings (the host takes
-        // the cyclic order: the decompositions agree to the last places, and differ as any two exact methods do where eigenvalues repeat).
+        // A <- J' A J with J their product: the parameters of pair i by lane i from the matrix as the step finds it, then the column pairs of
+        // every row are rotated (of A and of the eigenvector accumulator), then the row pairs in every column; wave w takes the pairs w, w + NW, ...
+        // A sweep is mr - 1 steps instead of mr (mr - 1) / 2 dependent rotations; the same rotations as the cyclic order up to the order of
+        // roundings (the host takes the cyclic order: the decompositions agree to the last places, and differ as any two exact methods do
+        // where eigenvalues repeat).
         const int ne = (mr + 1) & ~1, half = ne / 2, ring = ne - 1;
         auto pair_of = [&](int k, int i, int& p, int& q) {   // (k and i are the same in every lane: scalar arithmetic)
           int a = k + i, b = k - i;
@@ -97,15 +106,17 @@ struct LgFactorRows {
           p = a < b ? a : b; q = a < b ? b : a;
         };
         constexpr int B = 8;   // pairs per batch: their operands are requested together (a rotation is otherwise one LDS round trip after the other)
+        const int mine = (half - w + NW - 1) / NW;   // pairs of this wave: w, w + NW, ...
         for (int k = 0; k < ring; k++) {
           __syncthreads();
-          if (r < half) {
+          if (r < half) {   // (every wave computes all parameters: the same values into the same places)
             int p, q;
             pair_of(k, r, p, q);
             double cs = 1.0, sn = 0.0;
             if (q < mr && !done) {
               const double apq = A[p * LD + q];
               if (apq != 0.0) {
+                // tangent and cosine from three long operations: with h = aqq - app, g = 2 apq:  t = sign(h g) |g| / (|h| + sqrt(h^2 + g^2)),  cs = rsqrt(1 + t^2)
                 const double h = A[q * LD + q] - A[p * LD + p], g = 2.0 * apq;
                 const double sgn = (h == 0.0 || (h > 0) == (g > 0)) ? 1.0 : -1.0;
                 const double t = sgn * fabs(g) / (fabs(h) + sqrt(h * h + g * g));
@@ -116,38 +127,38 @@ struct LgFactorRows {
             va[r] = cs; vb[r] = sn;
           }
           __syncthreads();
-          for (int i0 = 0; i0 < half; i0 += B) {
+          for (int i0 = 0; i0 < mine; i0 += B) {
             double cs[B], sn[B], x[B], y[B], wx[B], wy[B];
             int pp[B], qq[B];
 #pragma unroll
             for (int u = 0; u < B; u++) {
-              const int i = i0 + u < half ? i0 + u : half - 1;
+              const int i = w + NW * (i0 + u < mine ? i0 + u : mine - 1);
               pair_of(k, i, pp[u], qq[u]);
               cs[u] = va[i]; sn[u] = vb[i];
               x[u] = A[r * LD + pp[u]]; y[u] = A[r * LD + qq[u]]; wx[u] = W[r * LD + pp[u]]; wy[u] = W[r * LD + qq[u]];
             }
 #pragma unroll
             for (int u = 0; u < B; u++) {
-              if (i0 + u < half && sn[u] != 0.0) {
+              if (i0 + u < mine && sn[u] != 0.0) {
                 A[r * LD + pp[u]] = cs[u] * x[u] - sn[u] * y[u]; A[r * LD + qq[u]] = sn[u] * x[u] + cs[u] * y[u];
                 W[r * LD + pp[u]] = cs[u] * wx[u] - sn[u] * wy[u]; W[r * LD + qq[u]] = sn[u] * wx[u] + cs[u] * wy[u];
               }
             }
           }
           __syncthreads();
-          for (int i0 = 0; i0 < half; i0 += B) {
+          for (int i0 = 0; i0 < mine; i0 += B) {
             double cs[B], sn[B], x[B], y[B];
             int pp[B], qq[B];
 #pragma unroll
             for (int u = 0; u < B; u++) {
-              const int i = i0 + u < half ? i0 + u : half - 1;
+              const int i = w + NW * (i0 + u < mine ? i0 + u : mine - 1);
               pair_of(k, i, pp[u], qq[u]);
               cs[u] = va[i]; sn[u] = vb[i];
               x[u] = A[pp[u] * LD + r]; y[u] = A[qq[u] * LD + r];
             }
 #pragma unroll
             for (int u = 0; u < B; u++) {
-              if (i0 + u < half && sn[u] != 0.0) { A[pp[u] * LD + r] = cs[u] * x[u] - sn[u] * y[u]; A[qq[u] * LD + r] = sn[u] * x[u] + cs[u] * y[u]; }
+              if (i0 + u < mine && sn[u] != 0.0) { A[pp[u] * LD + r] = cs[u] * x[u] - sn[u] * y[u]; A[qq[u] * LD + r] = sn[u] * x[u] + cs[u] * y[u]; }
             }
           }
         }
@@ -201,88 +212,88 @@ struct LgFactorRows {
     __syncthreads();
     // U[r][j] = sg_j W[r][src_j]: into A (the Jacobi matrix is spent)
 #pragma unroll 4
-    for (int j = 0; j < M; j++) A[r * LD + j] = va[j] * W[r * LD + (int)vc[j]];
+    for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = va[j0 + jj] * W[r * LD + (int)vc[j0 + jj]];
     __syncthreads();
   }
 
-  // c[j] = sum over q (ascending, from 0.0) of A[r][q] * W[q][j]: this lane's own operand row in slot X, the broadcast operand in slot Y
-  __device__ LG_INL void prod_xy(double (&c)[M]) {
+  // c[jj] = sum over q (ascending, from 0.0) of A[r][q] * W[q][j0 + jj]: the row's own operand in slot X, the broadcast operand in slot Y
+  __device__ LG_INL void prod_xy(double (&c)[JW]) {
 #pragma unroll
-    for (int j = 0; j < M; j++) c[j] = 0.0;
-#pragma unroll 1
+    for (int jj = 0; jj < JW; jj++) c[jj] = 0.0;
+#pragma unroll 2
     for (int q = 0; q < M; q++) {
       const double a = A[r * LD + q];
 #pragma unroll
-      for (int j = 0; j < M; j++) c[j] += a * W[q * LD + j];
+      for (int jj = 0; jj < JW; jj++) c[jj] += a * W[q * LD + j0 + jj];
     }
   }
 
   // conditional_cov at time point t of draw d (arrays draw-interleaved, element k at ptr[k * es + d]); returns whether everything written is finite
   __device__ LG_INL bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d) {
     int bad = 0;
-    double row[M];
+    double row[JW];
 #ifdef LGF_STATS
     const unsigned long long lgf_t0 = __builtin_readcyclecounter();
 #endif
     if (t == 0) {
 #pragma unroll
-      for (int j = 0; j < M; j++) row[j] = Pt[(size_t)(r + M * j) * es + d];
+      for (int jj = 0; jj < JW; jj++) row[jj] = Pt[(size_t)(r + M * (j0 + jj)) * es + d];
       sym_singular(row);
 #pragma unroll
-      for (int j = 0; j < M; j++) {
-        const double v = A[r * LD + j] * sqrt(vd[j]);
-        Vout[(size_t)(r + M * j) * es + d] = v;
+      for (int jj = 0; jj < JW; jj++) {
+        const double v = A[r * LD + j0 + jj] * sqrt(vd[j0 + jj]);
+        Vout[(size_t)(r + M * (j0 + jj)) * es + d] = v;
         bad |= !lg_finite(v);
       }
       return reduce_bad(bad);
     }
 #pragma unroll
-    for (int j = 0; j < M; j++) row[j] = Pt[((size_t)(t - 1) * MM + r + M * j) * es + d];
+    for (int jj = 0; jj < JW; jj++) row[jj] = Pt[((size_t)(t - 1) * MM + r + M * (j0 + jj)) * es + d];
     sym_singular(row);   // U in X, |eigenvalues| in vd
     // pseudo-inverse W2 = sum over the kept components c of U[:, c] U[:, c]' / s_c, ascending c
     const double s0 = vd[0];
 #pragma unroll
-    for (int j = 0; j < M; j++) row[j] = 0.0;
+    for (int jj = 0; jj < JW; jj++) row[jj] = 0.0;
 #pragma unroll 1
     for (int c = 0; c < M; c++) {
       const double sc = vd[c];
       if (!(sc > kEps * M * s0)) continue;
       const double urc = A[r * LD + c];
 #pragma unroll
-      for (int j = 0; j < M; j++) row[j] += urc * A[j * LD + c] / sc;
+      for (int jj = 0; jj < JW; jj++) row[jj] += urc * A[(j0 + jj) * LD + c] / sc;
     }
     __syncthreads();   // every lane is through with U (and long through with the eigenvector accumulator)
 #pragma unroll
-    for (int j = 0; j < M; j++) W[r * LD + j] = row[j];
-    // tmp = Cp' W2 (row r: sum over q of Cp[q][r] W2[q][j]): column r of the cross-covariance is this lane's operand row
+    for (int jj = 0; jj < JW; jj++) W[r * LD + j0 + jj] = row[jj];
+    // tmp = Cp' W2 (row r: sum over q of Cp[q][r] W2[q][j]): column r of the cross-covariance is the row's operand
 #pragma unroll
-    for (int q = 0; q < M; q++) row[q] = cc[((size_t)(t - 1) * MM + q + M * r) * es + d];
+    for (int jj = 0; jj < JW; jj++) row[jj] = cc[((size_t)(t - 1) * MM + (j0 + jj) + M * r) * es + d];
 #pragma unroll
-    for (int q = 0; q < M; q++) A[r * LD + q] = row[q];
+    for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = row[jj];
     __syncthreads();
     prod_xy(row);
 #pragma unroll
-    for (int j = 0; j < M; j++) {
-      Cout[((size_t)t * MM + r + M * j) * es + d] = row[j];
-      bad |= !lg_finite(row[j]);
+    for (int jj = 0; jj < JW; jj++) {
+      Cout[((size_t)t * MM + r + M * (j0 + jj)) * es + d] = row[jj];
+      bad |= !lg_finite(row[jj]);
     }
     // Vc - tmp Cp: tmp's rows into X, the cross-covariance's rows into Y
-    __syncthreads();   // every lane is through with W2
+    __syncthreads();   // every lane is through with W2 and with the operand rows
 #pragma unroll
-    for (int j = 0; j < M; j++) A[r * LD + j] = row[j];
+    for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = row[jj];
 #pragma unroll
-    for (int j = 0; j < M; j++) row[j] = cc[((size_t)(t - 1) * MM + r + M * j) * es + d];
+    for (int jj = 0; jj < JW; jj++) row[jj] = cc[((size_t)(t - 1) * MM + r + M * (j0 + jj)) * es + d];
 #pragma unroll
-    for (int j = 0; j < M; j++) W[r * LD + j] = row[j];
+    for (int jj = 0; jj < JW; jj++) W[r * LD + j0 + jj] = row[jj];
     __syncthreads();
     prod_xy(row);
 #pragma unroll
-    for (int j = 0; j < M; j++) row[j] = Pt[((size_t)t * MM + r + M * j) * es + d] - row[j];
+    for (int jj = 0; jj < JW; jj++) row[jj] = Pt[((size_t)t * MM + r + M * (j0 + jj)) * es + d] - row[jj];
     sym_singular(row);
 #pragma unroll
-    for (int j = 0; j < M; j++) {
-      const double v = A[r * LD + j] * sqrt(vd[j]);
-      Vout[((size_t)t * MM + r + M * j) * es + d] = v;
+    for (int jj = 0; jj < JW; jj++) {
+      const double v = A[r * LD + j0 + jj] * sqrt(vd[j0 + jj]);
+      Vout[((size_t)t * MM + r + M * (j0 + jj)) * es + d] = v;
       bad |= !lg_finite(v);
     }
 #ifdef LGF_STATS
@@ -294,7 +305,9 @@ struct LgFactorRows {
   // any lane of the group bad -> false in every lane of the group
   __device__ LG_INL bool reduce_bad(int bad) {
     __syncthreads();
-    vc[r] = bad ? 1.0 : 0.0;
+    vc[r] = 0.0;
+    __syncthreads();
+    if (bad) vc[r] = 1.0;
     __syncthreads();
     double any = 0.0;
     for (int j = 0; j < M; j++) any += vc[j];

@@ -696,16 +696,16 @@ __global__ void __launch_bounds__(LgWave<M>::kThreads) ung_smooth_wave_kernel(co
 }
 // conditional factors of states of sixteen and more (padded) dimensions: M lanes per (draw, time point), matrices in LDS (lg_factors_rows.h)
 template <int M>
-__global__ void __launch_bounds__(64) ung_factors_rows_kernel(const UngSetupDev b) {
+__global__ void __launch_bounds__(LgFactorRows<M>::kThreads) ung_factors_rows_kernel(const UngSetupDev b) {
   constexpr int G = 64 / M;
   __shared__ double lds[LgFactorRows<M>::kLdsDoubles];
-  const int d = min((int)(blockIdx.x * G + threadIdx.x / M), b.F - 1);  // (surplus groups redo the last draw: every lane takes part in the barriers)
+  const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);  // (surplus groups redo the last draw: every lane takes part in the barriers)
   const UngWork<M> W(b, d);
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
   rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
   const bool fine = rows.cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, (size_t)b.F, 0);
-  if (!fine && !rows.skip && rows.r == 0) b.ok[d] = 0;  // (every writer stores 0)
+  if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;  // (every writer stores 0)
 }
 template <int M>
 static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
@@ -723,7 +723,7 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
     else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
   }
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 1, hipGetErrorString(de)); }
-  if constexpr (M >= 16) hipLaunchKernelGGL((ung_factors_rows_kernel<M>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M)), (unsigned)b.n + 1), dim3(64), 0, stream, b);
+  if constexpr (M >= 16) hipLaunchKernelGGL((ung_factors_rows_kernel<M>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M)), (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
   else hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 2, hipGetErrorString(de)); }
   hipLaunchKernelGGL((ung_setup_kernel<M, 3, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);

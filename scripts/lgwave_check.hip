@@ -35,15 +35,15 @@ __global__ void __launch_bounds__(LgWave<M>::kThreads) smooth_kernel(const Dev b
   b.ok[d] = ok ? 1 : 0;
 }
 template <int M>
-__global__ void __launch_bounds__(64) factors_kernel(const Dev b) {
+__global__ void __launch_bounds__(LgFactorRows<M>::kThreads) factors_kernel(const Dev b) {
   constexpr int G = 64 / M;
   __shared__ double lds[LgFactorRows<M>::kLdsDoubles];
-  const int d = min((int)(blockIdx.x * G + threadIdx.x / M), b.F - 1);
+  const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
   rows.mr = b.mr;
   const bool fine = rows.cond_step((int)blockIdx.y, b.Pt + d, b.cc + d, b.Vf + d, b.Cf + d, (size_t)b.F, 0);
-  if (!fine && !rows.skip && rows.r == 0) b.ok[d] = 0;
+  if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); std::exit(1); } } while (0)
@@ -119,7 +119,7 @@ int check(int mr, int n, int F, unsigned seed) {
   CK(hipMemcpy(g_Pt.data(), b.Pt, g_Pt.size() * 8, hipMemcpyDeviceToHost));
   CK(hipMemcpy(g_cc.data(), b.cc, g_cc.size() * 8, hipMemcpyDeviceToHost));
   CK(hipEventRecord(e1));
-  hipLaunchKernelGGL((factors_kernel<M>), dim3((F + G - 1) / G, n + 1), dim3(64), 0, 0, b);
+  hipLaunchKernelGGL((factors_kernel<M>), dim3((F + G - 1) / G, n + 1), dim3(LgFactorRows<M>::kThreads), 0, 0, b);
   CK(hipEventRecord(e2));
   CK(hipDeviceSynchronize());
   float ms_f = 0;
