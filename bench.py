@@ -450,6 +450,52 @@ def mng_post_correct_leg(ns=512, n=200, nsim=256, threads=8):
             "round_history_s": {"round 2 (one kernel, one lane per draw)": 0.26, "host set-up, 32 threads": 0.10}}
 
 
+def seasonal_post_correct_leg(period, ns=256, nsim=64, threads=8):
+    """One psi post-correction call over `ns` theta-draws of bsm_ng(period = 24 / 52) -- 25 / 53 states: the set-up (Gaussian approximation,
+    smoother, conditional factors, tables) on the device with the states padded to 32 / 64 (lg_smoother_wave.h, lg_factors_rows.h); the host
+    set-up timed beside it on 8 draws"""
+    import numpy as np
+    from bssm_amd import filters as F, models as M, post_correct as PC
+    rng = np.random.default_rng(5)
+    n, m = 3 * period if period == 24 else 2 * period, period + 1
+    y = rng.poisson(np.exp(1.6 + 0.4 * np.sin(2 * np.pi * np.arange(n) / period))).astype(float)
+    y[7] = np.nan
+    model = M.bsm_ng(y, sd_level=M.halfnormal(0.1, 1), sd_slope=M.halfnormal(0.02, 1), sd_seasonal=M.halfnormal(0.05, 1), period=period,
+                     distribution="poisson", P1=np.diag([1.0, 0.1] + [0.5] * (period - 1)), a1=np.array([1.6] + [0.0] * period))
+    mode = np.asarray(F.psi_setup(model)["mode"]).reshape(-1, 1)
+
+    def job(k):
+        theta = np.column_stack([rng.uniform(0.05, 0.2, k), rng.uniform(0.01, 0.03, k), rng.uniform(0.02, 0.08, k)])
+        return dict(theta=theta, counts=np.ones(k, dtype=np.uint32), modes=np.repeat(mode, k, axis=1) + rng.normal(0, 0.03, (n, k)), output_type=3)
+
+    def timed(mo, reps):
+        best, r = 1e9, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = PC.post_correct(model, mo, nsim, threads=threads, is_type="is2", seed=6)
+            best = min(best, time.perf_counter() - t0)
+        return best, r
+    sec, r = timed(job(ns), 2)
+    assert np.all(np.isfinite(r["loglik"]))
+    small = job(8)
+    dev8, r8 = timed(small, 2)
+    prev = os.environ.get("BSSM_AMD_DEVICE_SETUP")
+    os.environ["BSSM_AMD_DEVICE_SETUP"] = "0"
+    try:
+        host8, h8 = timed(small, 1)
+    finally:
+        if prev is None:
+            del os.environ["BSSM_AMD_DEVICE_SETUP"]
+        else:
+            os.environ["BSSM_AMD_DEVICE_SETUP"] = prev
+    return {"workload": "bsm_ng(period = %d): m = %d, T = %d, %d theta-draws, psi-APF N = %d, is2, output theta; one bssm_is_correction call, %d host threads"
+                        % (period, m, n, ns, nsim, threads),
+            "seconds": sec, "draws_per_s": ns / sec,
+            "setup": "device: ung_setup_kernel<%d> (Laplace step, tables), ung_smooth_wave_kernel<%d>, ung_factors_rows_kernel<%d>" % ((32 if m <= 32 else 64,) * 3),
+            "eight_draws_device_s": dev8, "eight_draws_host_setup_s": host8,
+            "max_abs_dloglik_device_vs_host_setup": float(np.max(np.abs(r8["loglik"] - h8["loglik"])))}
+
+
 def accuracy_leg(model, N, T, R, m, fw, stream, max_pairs=64):
     """The metric's second half: log-likelihood RMSE (and weighted state means, states, weights, ancestors) against the
     reference-equivalent CPU path on identical seeds, on the very variant that was timed: the same plan shape (N, T, R
@@ -900,9 +946,15 @@ def main():
                     big["period_%d" % period]["roofline_hbm"] = {"bound": "hbm", "achieved": hb / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hb / 8e12,
                                                                  "bytes_per_particle_step": 16.0 * mb + 16.0}
                 pbg.close()
+                try:
+                    big["period_%d" % period]["post_correct"] = seasonal_post_correct_leg(period)
+                except Exception as e:  # noqa: BLE001
+                    big["period_%d" % period]["post_correct"] = {"error": repr(e)[:200]}
             out["big_states"] = big
         except Exception as e:  # noqa: BLE001
             out["big_states"] = {"error": repr(e)[:200]}
+        from bssm_amd import _lib as _Lb
+        _Lb.lib().bssm_amd_trim_cache()   # (the set-up of 256 draws of 53 states leaves 3.5 GB of work arrays cached: the legs below start from a clean arena)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only: the other ranks would idle behind it
         # ---- CPU baseline: the oracle (reference loop structure, one thread per filter) on a bounded sample

@@ -198,3 +198,47 @@ def test_degenerate_and_unobserved_series_on_a_big_state(oracle, monkeypatch):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             assert F.bootstrap_filter(bad, N, seed=1)["logLik"] == -np.inf
+
+
+@pytest.mark.parametrize("m", [20, 40])
+def test_device_set_up_of_big_states_time_varying_and_a_failing_draw(oracle, monkeypatch, m):
+    """psi set-up on the device for 17 ... 64 states (padded to 32 / 64: lg_smoother_wave.h, lg_factors_rows.h) with time-varying Z, T and D, C
+    (the smoother reloads its T slot every step), against the oracle and the host set-up; a draw whose covariances overflow shares its
+    workgroup with a good one (two draws per wave at 32) and must come back with weight 0 / logLik -Inf while the others are unaffected"""
+    rng = np.random.default_rng(100 + m)
+    k, n, ns = 3, 18, 5
+    T = np.stack([0.85 * np.linalg.qr(rng.normal(size=(m, m)))[0] for _ in range(n)], axis=2)
+    R0 = 0.2 * rng.normal(size=(m, k))
+    Z = rng.normal(0, 0.25, (m, n))
+    y = rng.poisson(3.0, n).astype(float)
+    y[5] = np.nan
+    C = 0.02 * rng.normal(size=(m, n))
+    D = 0.1 * rng.normal(size=n)
+    # (distinct prior variances: no repeated eigenvalue whose eigenvectors two programs may choose differently)
+    model = M.ssm_ung(y, Z=Z, T=T, R=R0, a1=np.zeros(m), P1=np.diag(0.05 + 0.002 * np.arange(m)), distribution="poisson", u=np.ones(n), D=D, C=C,
+                      init_theta=np.zeros(1), update_fn=lambda th: dict(R=R0 * np.exp(th[0])))
+    theta = rng.normal(0, 0.2, (ns, 1))
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    arrs = PC.expand_models(model, theta)
+    assert arrs[0]["T"].shape == (m, m, n)
+    modes = np.stack([oracle.psi_setup(a)["mode"] for a in arrs], axis=1) + rng.normal(0, 0.03, (n, ns))
+    mo = dict(theta=theta, counts=counts, modes=modes, output_type=2)
+    ref = oracle.is_correction(arrs, 48, 4, method=1, counts=counts, modes=modes, is_type=2, output_type=2, n_threads=2)
+    res = {}
+    for dev in ("2", "0"):
+        monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+        res[dev] = PC.post_correct(model, mo, 48, threads=2, is_type="is2", seed=4)
+        assert np.allclose(res[dev]["loglik"], ref["loglik"], rtol=0, atol=1e-8 * n)
+        assert np.allclose(res[dev]["weights"], ref["weights"], rtol=1e-6)
+        assert np.allclose(res[dev]["alphahat"], ref["alphahat"].T, rtol=1e-6, atol=1e-6)
+    # a draw that fails: R scaled by exp(400) -> R R' overflows in the smoother
+    theta_bad = theta.copy()
+    theta_bad[1, 0] = 400.0
+    mo_bad = dict(theta=theta_bad, counts=counts, modes=modes, output_type=3)
+    mo_ok = dict(theta=theta, counts=counts, modes=modes, output_type=3)
+    for dev in ("2", "0"):
+        monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+        bad = PC.post_correct(model, mo_bad, 48, threads=2, is_type="is2", seed=4)
+        good = PC.post_correct(model, mo_ok, 48, threads=2, is_type="is2", seed=4)
+        assert bad["weights"][1] == 0.0 and np.isneginf(bad["loglik"][1])
+        assert np.array_equal(np.delete(bad["loglik"], 1), np.delete(good["loglik"], 1))
