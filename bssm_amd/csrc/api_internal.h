@@ -61,6 +61,7 @@ inline int fail(int code, const std::string& msg) { g_err = msg; return code; }
 inline bool have_device() {
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess) return false;
+  if (cnt > 0) bssm::prewarm_streams();
   return cnt > 0;
 }
 inline int no_device() {

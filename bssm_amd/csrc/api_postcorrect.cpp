@@ -333,7 +333,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           bool conc = bssm::opt().tail_concurrent && head.F > 0 && tail > 0;
           if (conc) {
             static thread_local bssm::TlsStream tail_stream;   // (at the highest stream priority: measured, no difference)
-            tstream = tail_stream.get();
+            tstream = tail_stream.get(false, true);   // (the stream reserved for it at the first entry-point call: options.cpp, prewarm_streams)
             conc = tstream != nullptr && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess;
           }
           // filters [f_begin, f_begin + count) of the sub-batch
@@ -634,6 +634,13 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   bool dev_full = psi && have_device() && (p0 == 1 ? m <= 64 : m <= 8) && n < 65535 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
   if (bssm::opt().device_setup >= 0) dev_full = dev_full && bssm::opt().device_setup == 2;
   if (bssm::opt().generic_setup) dev_full = false;
+  if (dev_full && m_dev >= 32) {
+    // the work arrays of a padded big state are 4 (n + 1) M^2 doubles per draw (13 MB at M = 64, T = 100) and a chunk is at least 64 draws: a series so
+    // long that 64 draws do not fit a quarter of what the device has free (up to three chunks are alive at once) takes the host set-up instead of failing with hipErrorOutOfMemory
+    size_t free_b = 0, total_b = 0;
+    const double per_draw = (double)bssm::ung_setup_scratch_doubles(n, m_dev) * sizeof(double);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_draw * 64.0 > 0.25 * ((double)free_b + (double)arena().cached)) dev_full = false;
+  }
   if (dev_full) {
     std::vector<bssm::LgPacked> packs(cnt);
     auto prepare_full = [&](int i) -> std::string {

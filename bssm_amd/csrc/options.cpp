@@ -17,22 +17,52 @@ namespace bssm {
 // process-wide pool of idle HIP streams (tls_stream.h): a stream a thread no longer needs waits here for the next thread
 namespace {
 std::mutex g_stream_pool_mu;
-std::map<std::pair<int, bool>, std::vector<hipStream_t>>& stream_pool() {
-  static auto* pool = new std::map<std::pair<int, bool>, std::vector<hipStream_t>>();  // (never destroyed: threads may exit after main)
+std::map<std::pair<int, int>, std::vector<hipStream_t>>& stream_pool() {
+  static auto* pool = new std::map<std::pair<int, int>, std::vector<hipStream_t>>();  // (never destroyed: threads may exit after main)
   return *pool;
 }
 }  // namespace
-hipStream_t stream_pool_take(int dev, bool highest_priority) {
+hipStream_t stream_pool_take(int dev, int kind) {
   std::lock_guard<std::mutex> lk(g_stream_pool_mu);
-  auto& v = stream_pool()[{dev, highest_priority}];
+  auto& v = stream_pool()[{dev, kind}];
   if (v.empty()) return nullptr;
   hipStream_t s = v.back();
   v.pop_back();
   return s;
 }
-void stream_pool_give(int dev, bool highest_priority, hipStream_t s) {
+void stream_pool_give(int dev, int kind, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_stream_pool_mu);
-  stream_pool()[{dev, highest_priority}].push_back(s);
+  stream_pool()[{dev, kind}].push_back(s);
+}
+
+// The runtime gives a stream its hardware queue at the stream's first use, and which queues of a process run side by side turned out to depend
+// on the order in which they came to be.  A post-correction call that was the process's FIRST GPU work overlapped the tail of a chunk with its
+// last round (293 draws of C5: 5.8 ms); the same call behind a full-output filter batch -- whose streams came first -- did not (13 ms: slower
+// than the tail BEHIND the round, 7.2 ms), whatever the number of hardware queues allowed, and a stream with a queue of its own (CU-masked)
+// was worse still (profiles/r05_tail_queue.txt).  So the library brings its streams into being in the order of the first case, once, at the
+// first entry-point call: the set-up stream (highest priority), the null stream, the tail's stream -- one tiny operation each.
+void prewarm_streams() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (!opt().prewarm_streams) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) { (void)hipGetLastError(); return; }
+    TlsStream a, b;
+    hipStream_t hs = a.get(true);
+    if (hs) (void)hipMemsetAsync(p, 0, 64, hs);
+    (void)hipMemsetAsync((char*)p + 64, 0, 64, nullptr);
+    hipStream_t ts = b.get(false, true);
+    if (ts) (void)hipMemsetAsync((char*)p + 128, 0, 64, ts);
+    if (hs) (void)hipStreamSynchronize(hs);
+    if (ts) (void)hipStreamSynchronize(ts);
+    (void)hipStreamSynchronize(nullptr);
+    a.drop();
+    b.drop();
+    (void)hipFree(p);
+    (void)hipGetLastError();
+  });
 }
 
 namespace {
@@ -58,6 +88,7 @@ Options read_env() {
   { const char* e = std::getenv("BSSM_AMD_TAIL_SPLIT"); o.tail_split = !(e && e[0] == '0'); }  // on unless BSSM_AMD_TAIL_SPLIT=0
   if (const char* e = std::getenv("BSSM_AMD_TAIL_MAX_EIGHTHS")) o.tail_max_eighths = std::max(0, std::min(8, std::atoi(e)));
   if (const char* e = std::getenv("BSSM_AMD_TAIL_CONCURRENT")) o.tail_concurrent = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BSSM_AMD_PREWARM_STREAMS")) o.prewarm_streams = std::atoi(e) != 0;
   if (const char* e = std::getenv("BSSM_AMD_FORCE_PATH")) o.force_path = !std::strcmp(e, "wg") ? 1 : (!std::strcmp(e, "grid") ? 2 : (!std::strcmp(e, "row") ? 3 : 0));
   o.grid_ppt = env_int("BSSM_AMD_GRID_PPT", 0);
   o.grid_v2_wx = env_tri("BSSM_AMD_GRID_V2_WX");

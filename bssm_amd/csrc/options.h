@@ -31,6 +31,7 @@ struct Options {
   bool tail_split = true;       // a sparsely filled last round of a post-correction chunk through the row family (bit-identical: pf_canon.h)
   // test / tuning
   int tail_max_eighths = 4;     // the last round goes through the row family when it fills at most this many eighths of the CUs (BSSM_AMD_TAIL_MAX_EIGHTHS)
+  bool prewarm_streams = true;  // the library's streams are brought into being in a fixed order at the first entry-point call (options.cpp: prewarm_streams; BSSM_AMD_PREWARM_STREAMS=0: on demand)
   bool tail_concurrent = true;  // that tail BESIDE the last full round instead of behind it (BSSM_AMD_TAIL_CONCURRENT=0: behind)
   int force_path = 0;           // 0 none, 1 "wg", 2 "grid", 3 "row" (the row family where the batch has such kernels; test hook)
   int grid_ppt = 0;             // 0: automatic

@@ -13,21 +13,24 @@
 namespace bssm {
 
 #ifndef BSSM_USER_MODEL
-hipStream_t stream_pool_take(int dev, bool highest_priority);  // nullptr when the pool has none
-void stream_pool_give(int dev, bool highest_priority, hipStream_t s);
+hipStream_t stream_pool_take(int dev, int kind);  // nullptr when the pool has none; kind: 0 plain, 1 highest priority, 2 plain, reserved (created early)
+void stream_pool_give(int dev, int kind, hipStream_t s);
+void prewarm_streams();  // once per process, at the first entry-point call (options.cpp)
 #endif
 
 struct TlsStream {
   hipStream_t s = nullptr;
   int dev = -1;
-  bool hi = false;
+  int hi = 0;   // kind: 0 plain, 1 highest priority, 2 plain, reserved (created early)
   // highest_priority: for small latency-critical kernels that compete with grids filling every CU
-  hipStream_t get(bool highest_priority = false) {
+  // reserved: a stream of the kind the library creates once, early, for work that must run BESIDE the null stream's (the tail of a
+  // post-correction chunk beside its last round; prewarm_streams() in options.cpp says why) -- a plain stream from a pool of its own
+  hipStream_t get(bool highest_priority = false, bool reserved = false) {
     int cur = 0;
     if (hipGetDevice(&cur) != hipSuccess) return nullptr;
     if (s && cur == dev) return s;
     drop();
-    hi = highest_priority;
+    hi = highest_priority ? 1 : (reserved ? 2 : 0);
 #ifndef BSSM_USER_MODEL
     if ((s = stream_pool_take(cur, hi)) != nullptr) { dev = cur; return s; }
 #endif
