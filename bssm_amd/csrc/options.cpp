@@ -39,8 +39,11 @@ void stream_pool_give(int dev, int kind, hipStream_t s) {
 // on the order in which they came to be.  A post-correction call that was the process's FIRST GPU work overlapped the tail of a chunk with its
 // last round (293 draws of C5: 5.8 ms); the same call behind a full-output filter batch -- whose streams came first -- did not (13 ms: slower
 // than the tail BEHIND the round, 7.2 ms), whatever the number of hardware queues allowed, and a stream with a queue of its own (CU-masked)
-// was worse still (profiles/r05_tail_queue.txt).  So the library brings its streams into being in the order of the first case, once, at the
-// first entry-point call: the set-up stream (highest priority), the null stream, the tail's stream -- one tiny operation each.
+// was worse still (profiles/r05_tail_queue.txt).  So the library brings its streams into being in ONE order, once, at the first entry-point
+// call: the null stream, two plain streams (the side launch sequence and the output copies of the filter entry points take them from the pool),
+// the tail's stream, the set-up stream (highest priority) -- one tiny operation each.  The order is the one of five tried that keeps BOTH overlaps:
+// with the set-up stream or the tail's in front of the plain ones the drop-in filter call (2.6 GB of outputs streaming out beside the steps) went
+// 55 -> 63-65 ms and the psi smoother call 14.8 -> 18.2 ms.
 void prewarm_streams() {
   static std::once_flag once;
   std::call_once(once, [] {
@@ -49,17 +52,24 @@ void prewarm_streams() {
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
     void* p = nullptr;
     if (hipMalloc(&p, 256) != hipSuccess) { (void)hipGetLastError(); return; }
-    TlsStream a, b;
-    hipStream_t hs = a.get(true);
-    if (hs) (void)hipMemsetAsync(p, 0, 64, hs);
-    (void)hipMemsetAsync((char*)p + 64, 0, 64, nullptr);
-    hipStream_t ts = b.get(false, true);
-    if (ts) (void)hipMemsetAsync((char*)p + 128, 0, 64, ts);
-    if (hs) (void)hipStreamSynchronize(hs);
-    if (ts) (void)hipStreamSynchronize(ts);
-    (void)hipStreamSynchronize(nullptr);
-    a.drop();
-    b.drop();
+    // the order: h = set-up stream (highest priority), n = the null stream, t = the tail's stream, p = a plain stream for the pool
+    // (side launch sequence / output copies of the filter entry points); BSSM_AMD_PREWARM_ORDER overrides it (measurements only)
+    const char* order = std::getenv("BSSM_AMD_PREWARM_ORDER");
+    if (!order || !*order) order = "n,p,p,t,h";
+    std::vector<TlsStream> made(16);
+    int used = 0;
+    for (const char* c = order; *c && used < 16; c++) {
+      hipStream_t st = nullptr;
+      bool null_stream = false;
+      if (*c == 'h') st = made[used++].get(true);
+      else if (*c == 't') st = made[used++].get(false, true);
+      else if (*c == 'p') st = made[used++].get(false, false);
+      else if (*c == 'n') null_stream = true;
+      else continue;
+      if (st || null_stream) (void)hipMemsetAsync((char*)p + 64 * (used % 4), 0, 8, st);
+    }
+    (void)hipDeviceSynchronize();
+    for (int q = used - 1; q >= 0; q--) made[q].drop();   // (the pool hands out the last one given first: the first plain stream made is the first taken)
     (void)hipFree(p);
     (void)hipGetLastError();
   });
