@@ -91,3 +91,16 @@ def test_bench_accuracy_object_checks_every_pair_with_the_following_oracle():
     assert acc["loglik_rmse_vs_cpu_same_seeds"] <= 1e-9 * 40 and acc["weighted_state_means_max_rel_diff"] <= 1e-9
     assert acc["pairs_without_a_tie"] + acc["pairs_with_ties"] == 8 and acc["loglik_sd_of_the_estimator_across_streams"] > 0
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] == 1
+
+
+def test_seasonal_post_correction_leg_of_the_big_states_object():
+    """big_states.period_24.post_correct of the bench line (the psi set-up of 25 states on the device, the host set-up beside it), at a size that takes a second"""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.seasonal_post_correct_leg(24, ns=24, nsim=32, threads=2)
+    assert r["seconds"] > 0 and r["draws_per_s"] > 0
+    assert "ung_smooth_wave_kernel<32>" in r["setup"] and "ung_factors_rows_kernel<32>" in r["setup"]
+    assert r["eight_draws_device_s"] > 0 and r["eight_draws_host_setup_s"] > 0
+    # (singular smoothing covariances: the factors amplify last-place differences to ~1e-7 of a log-likelihood, tests/test_gpu_postcorrect.py)
+    assert r["max_abs_dloglik_device_vs_host_setup"] < 5e-6
+    assert os.environ.get("BSSM_AMD_DEVICE_SETUP") is None
