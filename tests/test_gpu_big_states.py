@@ -242,3 +242,29 @@ def test_device_set_up_of_big_states_time_varying_and_a_failing_draw(oracle, mon
         good = PC.post_correct(model, mo_ok, 48, threads=2, is_type="is2", seed=4)
         assert bad["weights"][1] == 0.0 and np.isneginf(bad["loglik"][1])
         assert np.array_equal(np.delete(bad["loglik"], 1), np.delete(good["loglik"], 1))
+
+
+@pytest.mark.parametrize("m,n", [(17, 6), (32, 5), (33, 4), (64, 3), (25, 1)])
+def test_device_set_up_dimension_edges(oracle, monkeypatch, m, n):
+    """the padded dimensions at their edges: 17 (odd, the first beyond the 16-state kernels), 32 and 64 (no padding), 33 (the first at 64), and a
+    series of ONE time point -- device set-up against the oracle and the host set-up"""
+    rng = np.random.default_rng(7 * m + n)
+    k, ns = 2, 3
+    T = 0.8 * np.linalg.qr(rng.normal(size=(m, m)))[0]
+    R0 = 0.25 * rng.normal(size=(m, k))
+    Z = rng.normal(0, 0.3, m)
+    y = rng.poisson(2.0, n).astype(float)
+    model = M.ssm_ung(y, Z=Z, T=T, R=R0, a1=np.zeros(m), P1=np.diag(0.1 + 0.003 * np.arange(m)), distribution="poisson", u=np.ones(n),
+                      init_theta=np.zeros(1), update_fn=lambda th: dict(R=R0 * np.exp(th[0])))
+    theta = rng.normal(0, 0.2, (ns, 1))
+    counts = np.ones(ns, dtype=np.uint32)
+    arrs = PC.expand_models(model, theta)
+    modes = np.stack([oracle.psi_setup(a)["mode"] for a in arrs], axis=1).reshape(n, ns)
+    mo = dict(theta=theta, counts=counts, modes=modes, output_type=2)
+    ref = oracle.is_correction(arrs, 40, 3, method=1, counts=counts, modes=modes, is_type=2, output_type=2, n_threads=2)
+    for dev in ("2", "0"):
+        monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
+        res = PC.post_correct(model, mo, 40, threads=2, is_type="is2", seed=3)
+        assert np.all(np.isfinite(res["loglik"]))
+        assert np.allclose(res["loglik"], ref["loglik"], rtol=0, atol=1e-8 * max(n, 4))
+        assert np.allclose(res["alphahat"], ref["alphahat"].T, rtol=1e-6, atol=1e-6)
