@@ -19,7 +19,10 @@
 
 namespace bssm {
 
-template <int M, int NW = M / 16>
+#ifndef LGW_NW32
+#define LGW_NW32 4   // waves per workgroup at 32 (padded) states: four (eight columns each, 222 registers: two workgroups = two waves per SIMD; 512 draws 10.2 -> 5.2 ms against two)
+#endif
+template <int M, int NW = (M == 32 ? LGW_NW32 : M / 16)>
 struct LgWave {
   static_assert(M == 32 || M == 64, "M lanes per draw must tile the wave");
   static_assert(M % NW == 0, "the waves split the columns evenly");

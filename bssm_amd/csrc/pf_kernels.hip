@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
 // Kalman filter + covariance smoother of 17 ... 64 states (padded to 32 / 64): one workgroup of M / 16 waves per 64 / M draws, the matrices of the
 // recursion in LDS (lg_smoother_wave.h) -- phase 1 of the set-up for these dimensions
 template <int M>
-__global__ void __launch_bounds__(LgWave<M>::kThreads) ung_smooth_wave_kernel(const UngSetupDev b) {
+__global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) ung_smooth_wave_kernel(const UngSetupDev b) {
   __shared__ double lds[LgWave<M>::kLdsDoubles];
   const int d = min((int)(blockIdx.x * (64 / M) + (threadIdx.x & 63) / M), b.F - 1);  // (surplus groups redo the last draw: every lane takes part in the barriers)
   const size_t F = (size_t)b.F;

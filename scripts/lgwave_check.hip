@@ -22,7 +22,7 @@ struct Dev {
 };
 
 template <int M>
-__global__ void __launch_bounds__(LgWave<M>::kThreads) smooth_kernel(const Dev b) {
+__global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) smooth_kernel(const Dev b) {
   constexpr int G = 64 / M;
   __shared__ double lds[LgWave<M>::kLdsDoubles];
   const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);
