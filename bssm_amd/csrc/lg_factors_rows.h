@@ -27,9 +27,13 @@ namespace bssm {
 __device__ unsigned long long lgf_stats[8];   // analysis builds (scripts/lgwave_check.hip): calls, sweeps, clocks of the Jacobi loops / of cond_step
 #endif
 
-// (NW: four waves at 64 states -- 256 draws of 53 states 328 -> 244 ms; at 32 states two waves per workgroup were SLOWER in a full batch, 38 -> 47 ms
-// per 512 draws: the rotations are bound by the CU's LDS instruction rate there, and every wave repeats the per-step parameters)
-template <int M, int NW = (M >= 64 ? M / 16 : 1)>
+// (NW: four waves at 64 states -- 256 draws of 53 states 328 -> 244 ms, and 148 ms once the kernel was held to 256 registers so that two workgroups
+// share a CU; two waves at 32 states: at 347 registers they were SLOWER in a full batch than one, 38 -> 47 ms per 512 draws -- half the workgroups
+// per CU, every wave repeating the per-step parameters -- and at 256 registers (nine spilt) faster, 39.6 -> 29.5 ms)
+#ifndef LGF_NW32
+#define LGF_NW32 2   // waves per workgroup at 32 (padded) states
+#endif
+template <int M, int NW = (M >= 64 ? M / 16 : (M == 32 ? LGF_NW32 : 1))>
 struct LgFactorRows {
   static_assert(64 % M == 0 && M >= 16, "M lanes per matrix must tile the wave");
   static_assert(M % NW == 0, "the waves split the columns evenly");

@@ -696,9 +696,9 @@ __global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) ung_sm
 }
 // conditional factors of states of sixteen and more (padded) dimensions: M lanes per (draw, time point), matrices in LDS (lg_factors_rows.h)
 template <int M>
-// (64 states: two waves per SIMD -- 256 registers, three of them spilt, instead of 262: the CU's LDS holds two workgroups, the registers of the
-// first build only one; 256 draws of 53 states 244 -> 148 ms)
-__global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 64 ? 2 : 1)) ung_factors_rows_kernel(const UngSetupDev b) {
+// (32 and 64 states: two waves per SIMD -- 256 registers, a few of them spilt: the CU's LDS holds two (64) / four (32) workgroups, the registers of
+// the first build only half of that; 256 draws of 53 states 244 -> 148 ms, 512 draws of 25 states 39.6 -> 29.5 ms)
+__global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) ung_factors_rows_kernel(const UngSetupDev b) {
   constexpr int G = 64 / M;
   __shared__ double lds[LgFactorRows<M>::kLdsDoubles];
   const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);  // (surplus groups redo the last draw: every lane takes part in the barriers)

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) smooth
   b.ok[d] = ok ? 1 : 0;
 }
 template <int M>
-__global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 64 ? 2 : 1)) factors_kernel(const Dev b) {
+__global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) factors_kernel(const Dev b) {
   constexpr int G = 64 / M;
   __shared__ double lds[LgFactorRows<M>::kLdsDoubles];
   const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);
