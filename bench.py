@@ -139,8 +139,8 @@ def live_pmc_traffic(args, kernel, layout_factored, timeout=150):
     base = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--replicas", str(args.replicas), "--particles",
             str(args.particles), "--T", str(args.T), "--series", args.series, "--no-cpu-baseline", "--no-single", "--no-regime-b",
             "--no-post-correct", "--no-dropin", "--no-accuracy", "--no-side-runs", "--no-clock", "--no-mng", "--no-live-pmc"]
-    if not layout_factored:
-        base.append("--reference-weights-layout")
+    if layout_factored:
+        base.append("--factored-weights-layout")
     env = dict(os.environ, BSSM_BENCH_CALIB="1", TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -641,8 +641,10 @@ def main():
     ap.add_argument("--series", choices=["informative", "model"], default="informative",
                     help="the observed series of the metric model: counts that stay informative (default), or simulated from the "
                          "model itself (rounds 1-3: its integrated-random-walk level drifts off, 98 %% zeros, weights ~ 1)")
-    ap.add_argument("--reference-weights-layout", action="store_true",
-                    help="keep the weights output as exp(w - max_t) (what the drop-in entry points return) instead of the factored layout")
+    ap.add_argument("--factored-weights-layout", action="store_true",
+                    help="quote `value` on the library's factored weights layout (opt-in for device-resident plans) instead of the reference's "
+                         "exp(w - max_t), which is what the drop-in entry points return and what `value` is quoted on since round 6")
+    ap.add_argument("--reference-weights-layout", action="store_true", help="(the default since round 6; kept so that older command lines still run)")
     ap.add_argument("--no-mng", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed profile instead of two rocprofv3 --pmc passes of this run")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the reference-layout / other-series runs of the same batch")
@@ -712,10 +714,11 @@ def main():
     make_model = negbin_m4_informative if args.series == "informative" else negbin_m4
     model = make_model(T, seed=103)
     R = args.replicas
-    # weights kept in the library's factored layout (opt-in for device-resident callers, include/bssm_amd.h
-    # BSSM_PLAN_FACTORED_WEIGHTS: block-scaled weight x one factor per (time point, particle block); bssm_plan_fetch multiplies
-    # it out); --reference-weights-layout times the reference's exp(w - max_t) layout instead
-    fw = not args.reference_weights_layout
+    # Round 6: `value` is quoted on the weights layout the reference interface returns, exp(w - max_t) (what bssm_bsf hands back).  The
+    # library's factored layout (opt-in for device-resident callers, include/bssm_amd.h BSSM_PLAN_FACTORED_WEIGHTS: block-scaled
+    # weight x one factor per (time point, particle block); bssm_plan_fetch multiplies it out) is timed beside it as
+    # roofline_factored_layout; --factored-weights-layout swaps the two.
+    fw = args.factored_weights_layout and not args.reference_weights_layout
     plan = FilterPlan(model, N, method="bsf", keep_history=True, force="grid", n_rep=R, factored_weights=fw)
     info = plan.info()
     stream = torch.cuda.current_stream().cuda_stream
@@ -758,7 +761,8 @@ def main():
                                "informative counts (ESS ~0.76 N, every step resamples for real)" if args.series == "informative"
                                else "simulated from the model (98 % zeros, weights ~ 1, resampling ~ identity)",
                                "factored (library layout, opt-in for device-resident plans); the reference's exp(w - max_t) layout "
-                               "is timed beside it as roofline_reference_layout" if fw else "reference: exp(w - max_t)"),
+                               "is timed beside it as roofline_reference_layout" if fw else "reference: exp(w - max_t), what the drop-in entry points "
+                               "return (the library's factored layout is timed beside it as roofline_factored_layout)"),
                    "series": args.series, "filters_in_flight": R, "weights_layout": ("factored: exp(w - max_block) written once + exp(max_block - max_t) per (t, block of %d)"
                                                                % layout["block_particles"]) if layout["factored"] else "reference: exp(w - max_t)",
                    "kernel_shape": info["path"], "blocks_per_launch": info["blocks"],
@@ -774,25 +778,32 @@ def main():
         seqs = max(1, plan.launch_sequences())
         bytes_per_launch = float(R) / seqs * N * info["bytes_per_particle_step"]
         ppt = max(1, -(-N // (info["blocks"] // info["n_filters"] * info["threads"])))  # particles per thread of the step kernel
-        achieved = seqs * bytes_per_launch / (k_ms * 1e-3) / 1e9
+        achieved_events = seqs * bytes_per_launch / (k_ms * 1e-3) / 1e9
+        # Round 6 (review of round 5, item 5): `achieved` / `frac` are the WALL-CLOCK figures of the timed region -- algorithmic bytes of
+        # all its launches over its elapsed time, i.e. bytes per launch over the wall time one launch accounts for (wall_per_launch_us);
+        # the HIP-event launch duration gives achieved_by_hip_events / frac_by_hip_events beside them (the two launch sequences overlap
+        # by slightly less than 2.0, so the event figure is ~1 % higher)
+        achieved = (value / world) * info["bytes_per_particle_step"] / 1e9
         committed = pmc_traffic(R // seqs, N, ppt, plan.last_kernel(), layout["factored"])
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": committed,
+                           "frac": achieved / HBM_PEAK_GBS, "frac_source": "wall clock of the timed region",
+                           "achieved_by_hip_events": achieved_events, "frac_by_hip_events": achieved_events / HBM_PEAK_GBS, "traffic": committed,
                            "traffic_source": "profiles/r05_pmc_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script at this kernel)" % ("" if layout["factored"] else "_reference_layout"),
                            "traffic_committed_profile": committed,
                            "kernel": plan.last_kernel(), "avg_launch_us": k_ms * 1e3, "sampled_launches": k_n,
                            "concurrent_launches": seqs, "filters_per_launch": R // seqs,
                            "wall_per_launch_us": ms_per_step * 1e3 / (T + 1) / seqs,
                            "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "achieved_note": "concurrent_launches x algorithmic_bytes_per_launch / avg_launch_us: the launches "
-                                            "of the two sequences overlap in time, each lasting avg_launch_us",
+                           "achieved_note": "achieved = algorithmic bytes of the timed region / its wall time; achieved_by_hip_events = "
+                                            "concurrent_launches x algorithmic_bytes_per_launch / avg_launch_us (the launches of the two sequences "
+                                            "overlap in time, each lasting avg_launch_us)",
                            "frac_of_measured_copy_6290GBs": achieved / 6290.0}
         if world == 1 and not args.no_clock:
             ck = clock_power_while(lambda k: (plan.run(5000 + k, stream0=0, hip_stream=stream), torch.cuda.synchronize()))
             torch.cuda.synchronize()
             out["roofline"]["clock_power_under_load"] = ck
             out["roofline"]["valu"] = valu_roofline(HEAD_VALU_PER_PSTEP, seqs * (R // seqs) * float(N) / (k_ms * 1e-3),
-                                                    "pf_grid_step_v2<4,4,4,false,true,true>", ck, key="head") if ppt == 4 and m == 4 and layout["factored"] else None
+                                                    "pf_grid_step_v2<4,4,4,false,true,true>", ck, key="head") if ppt == 4 and m == 4 and (layout["factored"] or (LIVE_VALU or {}).get("head")) else None
     head_kernel, head_factored = (FilterPlan.last_kernel(), layout["factored"]) if rank == 0 else ("", True)
     plan.close()
     if rank == 0 and world == 1 and not args.no_live_pmc and "roofline" in out:
@@ -827,6 +838,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_side_runs:
         if fw:   # the layout the drop-in entry points return, next to the factored one `value` is quoted on
             out["roofline_reference_layout"] = side_run(model, False)
+        else:    # the library's factored layout (opt-in for device-resident plans), next to the reference one `value` is quoted on
+            out["roofline_factored_layout"] = side_run(model, True)
         other = negbin_m4 if args.series == "informative" else negbin_m4_informative
         out["other_series"] = {"series": "model" if args.series == "informative" else "informative", **side_run(other(T, seed=103), fw),
                                "note": "the same model matrices and plan on the other observed series (see config.workload); rounds 1-3 "
@@ -834,10 +847,13 @@ def main():
         # the same batch under the CONTRACT's choices, in `config` so that the record is self-contained (round-4 review 6a): the
         # reference's weights layout (what the drop-in entry points return) and the SURVEY 8d series simulated from the model
         if "roofline_reference_layout" in out:
-            out["config"]["reference_layout_frac"] = out["roofline_reference_layout"]["frac"]
-        out["config"]["contract_series_frac" if args.series == "informative" else "informative_series_frac"] = out["other_series"]["frac"]
-        out["config"]["fracs_note"] = ("roofline.frac of the same 32-filter batch: reference_layout_frac = weights as exp(w - max_t) (reference layout), "
-                                       "contract_series_frac = y simulated from the model (SURVEY.md 8d seed 103: 98 % zeros); HIP-event launch durations, 88 B per particle-step")
+            out["config"]["reference_layout_frac"] = out["roofline_reference_layout"]["frac_by_wall_clock"]
+        if "roofline_factored_layout" in out:
+            out["config"]["factored_layout_frac"] = out["roofline_factored_layout"]["frac_by_wall_clock"]
+        out["config"]["contract_series_frac" if args.series == "informative" else "informative_series_frac"] = out["other_series"]["frac_by_wall_clock"]
+        out["config"]["fracs_note"] = ("wall-clock roofline fraction of the same 32-filter batch (5 timed passes each): factored_layout_frac = the library's factored weights "
+                                       "layout (opt-in, device-resident plans), contract_series_frac = y simulated from the model (SURVEY.md 8d seed 103: 98 % zeros); "
+                                       "88 B per particle-step; the HIP-event figures are in the side objects")
 
     if rank == 0 and world == 1 and R != 1 and not args.no_single:
         # ---- regime A: ONE filter, latency-bound (1000 dependent launches, one wave per SIMD)

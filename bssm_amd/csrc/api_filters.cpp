@@ -167,6 +167,14 @@ const char* bssm_amd_last_error(void) { return g_err.c_str(); }
 // (stream format 2 = PACKED normals for draws of more than two, round 4; normalisation 2 = pf_canon.h rows for N <= 8192, round 5:
 // results for a given seed are not bit-reproducible across these numbers -- the parity bar against the reference is unaffected)
 const char* bssm_amd_version(void) { return "bssm_amd 0.5 (gfx950; random-stream format 2, normalisation 2)"; }
+// 0: not calibrated, 1: the current device's tail stream was measured to run beside its null stream, 2: measured, none of the candidates did
+int bssm_amd_tail_overlap_state(int32_t* candidates_tried) {
+  (void)have_device();
+  int tried = 0;
+  const int st = bssm::tail_overlap_state(&tried);
+  if (candidates_tried) *candidates_tried = tried;
+  return st;
+}
 void bssm_amd_trim_cache(void) { arena().trim(); stage_arena().trim(); }
 void bssm_amd_last_is_timing(double out[2]) { out[0] = g_is_timing[0]; out[1] = g_is_timing[1]; }
 void bssm_amd_last_is_timing4(double out[4]) { for (int q = 0; q < 4; q++) out[q] = g_is_timing4[q]; }
@@ -204,6 +212,8 @@ int bssm_psi_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
 // ---------------------------------------------------------------- built-in non-linear / SDE models
 }  // extern "C"
 namespace bssm_api {   // (functor_tables, to_fn_model, functor_psi_tables are called from api_postcorrect.cpp too)
+// length of the interval one Milstein call covers: 1 in every filter (src/model_ssm_sde.cpp:27,61); bssm_milstein sets its caller's t
+static thread_local double g_milstein_tend = 1.0;
 // known_tv_params of user models (BSSM_USER_TV) in device memory: uploaded once per (device, content) and kept -- the
 // parameter blocks of every filter (and of device-resident plans) carry the device address, and a matrix is a few KB.  Entries
 // are found by a hash and CONFIRMED by comparing dimensions and content; the cache is bounded (256 MiB per process), beyond
@@ -245,7 +255,8 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   if (n < 1) return fail(BSSM_ERR_INVALID, "n must be positive");
   const int need_theta[] = {0, 3, 4, 2, 1, 3, 3, 0, 0}, need_known[] = {0, 6, 0, 0, 0, 0, 0, 0, 0};
   if (mod->n_theta < need_theta[id] || mod->n_known < need_known[id]) return fail(BSSM_ERR_INVALID, "theta / known_params too short for this model");
-  if (mod->n_theta > 8 || mod->n_known > 8) return fail(BSSM_ERR_INVALID, "at most 8 theta / known_params");
+  if (mod->n_theta > bssm::FP_LONG_MAX || mod->n_known > bssm::FP_LONG_MAX) return fail(BSSM_ERR_INVALID, "at most 64 theta / known_params");
+  if (!user && (mod->n_theta > 8 || mod->n_known > 8)) return fail(BSSM_ERR_INVALID, "the shipped models take at most 8 theta / known_params");
   if (user && mod->user_slot < 1) return fail(BSSM_ERR_INVALID, "user-defined model without a loaded library (bssm_user_model_load)");
   if (id == bssm::FN_USER_NLG && (mod->n_states < 1 || mod->n_states > 16)) return fail(BSSM_ERR_UNSUPPORTED, "user-defined ssm_nlg models: n_states must be 1 ... 16");
   if (id == bssm::FN_USER_NLG && mod->n_states > 2 && !mod->use_ext) return fail(BSSM_ERR_INVALID, "user-defined ssm_nlg model with more than 2 states: fill R_ext / a1_ext / P1_ext and set use_ext");
@@ -259,8 +270,16 @@ int functor_tables(const bssm_fn_model* mod, bssm::FilterTables* ft, std::vector
   fpar->assign(bssm::FP_SIZE, 0.0);
   double* fp = fpar->data();
   fp[bssm::FP_ID] = id; fp[bssm::FP_L] = mod->L; fp[bssm::FP_POS] = mod->positive ? 1.0 : 0.0; fp[bssm::FP_X0] = mod->x0;
-  for (int q = 0; q < mod->n_theta; q++) fp[bssm::FP_THETA + q] = th[q];
-  for (int q = 0; q < mod->n_known; q++) fp[bssm::FP_KNOWN + q] = kp[q];
+  fp[bssm::FP_TEND] = g_milstein_tend;
+  {  // theta / known_params: in the header up to 8 entries each, else in the tail behind the two matrices (pf_functors.h)
+    int tail = bssm::fp_size(MP);
+    const int thoff = mod->n_theta > 8 ? tail : bssm::FP_THETA;
+    if (mod->n_theta > 8) tail += mod->n_theta;
+    const int knoff = mod->n_known > 8 ? tail : bssm::FP_KNOWN;
+    fp[bssm::FP_THOFF] = thoff; fp[bssm::FP_KNOFF] = knoff;
+    for (int q = 0; q < mod->n_theta; q++) fp[thoff + q] = th[q];
+    for (int q = 0; q < mod->n_known; q++) fp[knoff + q] = kp[q];
+  }
   double a1[2] = {0, 0}, P1[4] = {0, 0, 0, 0}, H = 1.0;
   switch (id) {  // R/cpp_example_models.R: a1_fn, P1_fn, H_fn, R_fn of each snippet
     case bssm::FN_NLG_GROWTH: a1[0] = kp[2]; a1[1] = kp[3]; P1[0] = kp[4]; P1[3] = kp[5]; H = std::exp(th[0]);
@@ -407,7 +426,7 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
   const bool user = mod->model_id == bssm::FN_USER_NLG;
   if (!user && (mod->model_id < bssm::FN_NLG_GROWTH || mod->model_id > bssm::FN_NLG_LINEAR_GAUSSIAN))
     return fail(BSSM_ERR_UNSUPPORTED, "the psi-APF and the EKF particle filter are for ssm_nlg models");
-  if (mod->n_theta > 8 || mod->n_known > 8) return fail(BSSM_ERR_INVALID, "at most 8 theta / known_params");
+  if (mod->n_theta > bssm::FP_LONG_MAX || mod->n_known > bssm::FP_LONG_MAX) return fail(BSSM_ERR_INVALID, "at most 64 theta / known_params");
   f->id = mod->model_id; f->n = mod->n; f->m = mod->model_id == bssm::FN_NLG_GROWTH ? 2 : (user ? mod->n_states : 1);
   if (user) {
     if (mod->user_slot < 1 || mod->user_slot > 63) return fail(BSSM_ERR_INVALID, "user-defined model without a loaded library");
@@ -541,6 +560,28 @@ int bssm_bsf_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t se
 int bssm_bsf_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
   if (model && !bssm::fn_is_sde(model->model_id)) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");
   return run_functor(model, nsim, seed, false, out);
+}
+// R_milstein (src/R_milstein.cpp:4-22 -> milstein(), src/milstein.cpp:18-34): the terminal value of ONE Milstein path from model->x0
+// over [0, t_end] in 2^L steps.  It is the prior draw of particle 0 of a bootstrap filter with that seed (src/model_ssm_sde.cpp:25-28
+// calls the same function with t = 1), so it runs through the filter kernels themselves -- built-in and user-defined models alike.
+int bssm_milstein(const bssm_fn_model* model, double t_end, uint32_t seed, double* x_out) {
+  if (!model || !x_out) return fail(BSSM_ERR_INVALID, "NULL argument");
+  if (!bssm::fn_is_sde(model->model_id)) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");
+  if (!(t_end > 0) || !std::isfinite(t_end)) return fail(BSSM_ERR_INVALID, "t must be positive");
+  bssm_fn_model one = *model;
+  const double missing = std::nan("");
+  one.n = 1; one.y = &missing;
+  constexpr int N = 64;
+  std::vector<double> alpha((size_t)2 * N), w((size_t)2 * N);
+  bssm_filter_out out;
+  std::memset(&out, 0, sizeof out);
+  out.alpha = alpha.data(); out.weights = w.data();
+  struct Restore { ~Restore() { g_milstein_tend = 1.0; } } restore;
+  g_milstein_tend = t_end;
+  const int rc = run_functor(&one, N, seed, false, &out);
+  if (rc < 0) return rc;
+  *x_out = alpha[0];
+  return BSSM_OK;
 }
 int bssm_bsf_smoother_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out) {
   if (model && !bssm::fn_is_sde(model->model_id)) return fail(BSSM_ERR_INVALID, "not an ssm_sde model id");

@@ -319,7 +319,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
             // the remainder's own round is saved.  C5 shape: 914 = 3 x 256 + 146 draws 16.6 -> 15.7 ms, 1 170 = 4 x 256 + 146: 21.7 -> 20.3,
             // 1 216: 22.3 -> 21.3; with five rounds and more nothing is left of it (1 450: 25.3 -> 25.5; the lean form costs every round ~2.6 %).
             // These calls then sit within 1-3 % of draws / 256 x one round: the chip is packed as well as the kernels' efficiency allows.
-            else if (r > 0 && r <= cus * 6 / 8 && rounds >= 3 && rounds <= 4 && bssm::opt().tail_concurrent && bssm::opt().tail_max_eighths > 0 &&
+            else if (r > 0 && r <= cus * 6 / 8 && rounds >= 3 && rounds <= 4 && bssm::opt().tail_concurrent && bssm::tail_overlap_available() && bssm::opt().tail_max_eighths > 0 &&
                      bssm::wg_lean_form_exists(sub)) { tail = r; cus_round = cus; lean_all = true; }
           }
           bssm::FilterBatch head = sub;
@@ -330,7 +330,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           // to the chunk's stream.  BSSM_AMD_TAIL_CONCURRENT=0: the tail behind the round, as before.
           hipStream_t tstream = nullptr;
           hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-          bool conc = bssm::opt().tail_concurrent && head.F > 0 && tail > 0;
+          bool conc = bssm::opt().tail_concurrent && head.F > 0 && tail > 0 && bssm::tail_overlap_available();
           if (conc) {
             static thread_local bssm::TlsStream tail_stream;   // (at the highest stream priority: measured, no difference)
             tstream = tail_stream.get(false, true);   // (the stream reserved for it at the first entry-point call: options.cpp, prewarm_streams)
@@ -821,7 +821,9 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   J.tabs.resize(count);
   J.bad.assign(count, 0);
   J.const_add.assign(count, 0.0); J.sub.assign(count, 0.0);
-  J.fps = (size_t)bssm::fp_size(bssm::pad_dim(m));
+  J.fps = (size_t)bssm::fp_size(bssm::pad_dim(m)) + bssm::fp_tail(models[0].n_theta, models[0].n_known);
+  for (int i = 1; i < count; i++)
+    if (models[i].n_theta != models[0].n_theta || models[i].n_known != models[0].n_known) return fail(BSSM_ERR_INVALID, "every draw must carry the same number of theta / known_params");
   J.fpar.assign((size_t)count * J.fps, 0.0);
   // ---- SURVEY.md 8f rank 1, all of it on the device (built-in models, uniform particle count): per draw the host packs
   // theta and (a1, P1); linearisation at the stored mode, smoother, conditional factors and the filter's tables are ONE
@@ -1148,6 +1150,7 @@ int run_multi_device(int cnt, const uint32_t* counts, int is_type, const int32_t
       const int lo = bounds[r], hi = bounds[r + 1];
       info[r] = ShardInfo{devices[r], lo, hi - lo, 0.0, 0.0, 0.0};
       if (hipSetDevice(devices[r]) != hipSuccess) { errs[r] = "hipSetDevice failed"; rcs[r] = BSSM_ERR_HIP; return; }
+      bssm::prewarm_streams();  // this shard's device: its streams in the library's order (once per device, options.cpp)
       const double t0 = now_ms();
       std::vector<double>& buf = host_blocks[r];
       if (hi > lo) {
@@ -1219,6 +1222,7 @@ int suggest_n_multi(const uint32_t* candidates, int32_t n_candidates, uint32_t r
       const int lo = bounds[r], hi = bounds[r + 1];
       if (hi <= lo) return;
       if (hipSetDevice(devices[r]) != hipSuccess) { errs[r] = "hipSetDevice failed"; rcs[r] = BSSM_ERR_HIP; return; }
+      bssm::prewarm_streams();
       for (int i = 0; i < n_candidates; i++) {
         const int rc = batch(candidates[i], (uint32_t)i * replications + (uint32_t)lo, (uint32_t)(hi - lo), host_blocks[r].data() + (size_t)i * block);
         if (rc < 0) { errs[r] = g_err; rcs[r] = rc; return; }

@@ -130,7 +130,7 @@ struct FnModel {
   int id = 0, n = 0, m = 1;
   int k = 1;  // noise terms (columns of R); read for user models with an R_fn only
   std::vector<double> y;
-  double theta[8] = {0}, known[8] = {0};
+  double theta[64] = {0}, known[64] = {0};  // (FP_LONG_MAX entries, pf_functors.h)
   double x0 = 0;
   int positive = 0, L = 0;
   // user-defined ssm_nlg (id 7): host functions and the state-independent numbers the caller supplied

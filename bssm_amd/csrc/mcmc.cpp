@@ -298,7 +298,7 @@ int run_chain(Target& tg, const double* theta0, const bssm_mcmc_job* job, bssm_m
   const ChainRng rng{job->seed};
   const size_t sz_a = (size_t)(n + 1) * m, sz_v = (size_t)m * m * (n + 1);
   std::vector<double> sampled(otype == 1 ? sz_a : 0), ah_i(otype == 2 ? sz_a : 0), vt_i(otype == 2 ? sz_v : 0),
-      valpha(otype == 2 ? sz_v : 0, 0.0), mode, mode_prop;
+      valpha(otype == 2 ? sz_v : 0, 0.0), mode, mode_prop, diff(m), after(m);  // sized by m: states go to 64
 
   double ll[2] = {0, 0}, ll_prop[2] = {0, 0};
   int rc;
@@ -368,7 +368,6 @@ int run_chain(Target& tg, const double* theta0, const bssm_mcmc_job* job, bssm_m
     if (i > job->burnin && otype == 2) {  // running mean of the summaries, thinning does not affect this
       const double cnt = (double)(i - job->burnin);
       for (int t = 0; t <= n; t++) {
-        double diff[16], after[16];
         for (int r = 0; r < m; r++) {
           double& a = out->alphahat[r + (size_t)m * t];
           diff[r] = ah_i[r + (size_t)m * t] - a;

@@ -50,9 +50,14 @@ enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, 
        FP_M = 25,
        // user models with BSSM_USER_TV: the known_tv_params matrix (device pointer as a bit pattern; rows, columns)
        FP_TVPTR = 26, FP_TVROWS = 27, FP_TVCOLS = 28,
+       FP_TEND = 29,   // ssm_sde: length of the interval one Milstein call covers (1 in every filter; bssm_milstein: the caller's t)
+       // user models: where theta / known_params start in the block -- FP_THETA / FP_KNOWN for up to 8 entries each (every shipped
+       // model), else the tail behind the two matrices (round 6: the reference has no cap on either, src/model_ssm_nlg.h:23-31)
+       FP_THOFF = 30, FP_KNOFF = 31,
        // full R (MP x MP, column-major, zero-padded; user models: up to 16 x 16 since round 5) and the inverse lower factor of
        // R R' for the psi-APF's transition-density ratio with any constant R (MP x MP, column-major)
-       FP_RMAT = 30, FP_SIZE = 30 + 512 };  // (FP_SIZE: the largest block -- 16 x 16, user models of up to 16 states for the bootstrap filter)
+       FP_RMAT = 32, FP_LONG_MAX = 64 /* most theta / known_params entries of a user model */,
+       FP_SIZE = 32 + 512 + 2 * FP_LONG_MAX };  // (FP_SIZE: the largest block -- 16 x 16 matrices, user models of up to 16 states, both tails)
 // The two matrices sit back to back in the padded dimension of the model, so that a block is as short as its model needs: the growth
 // model's (MP = 2) is 38 doubles, and a post-correction job packs, uploads and reads fp_size(MP) per draw -- with fixed 16 x 16 slots a
 // 2 340-draw job moved 10 MB of zeros and its call went from 40 to 47 ms.
@@ -64,7 +69,11 @@ enum { FP_ID = 0, FP_L = 1, FP_POS = 2, FP_X0 = 3, FP_THETA = 4, FP_KNOWN = 12, 
 #define BSSM_FP_HD
 #endif
 BSSM_FP_HD constexpr int fp_rlinv(int mp) { return FP_RMAT + mp * mp; }   // offset of the inverse lower factor of R R'
-BSSM_FP_HD constexpr int fp_size(int mp) { return FP_RMAT + 2 * mp * mp; }  // doubles of one block
+BSSM_FP_HD constexpr int fp_size(int mp) { return FP_RMAT + 2 * mp * mp; }  // doubles of one block without the tails
+BSSM_FP_HD constexpr int fp_tail(int n_theta, int n_known) { return (n_theta > 8 ? n_theta : 0) + (n_known > 8 ? n_known : 0); }
+// theta / known_params as a user snippet sees them (wave-uniform offsets read from the block itself)
+#define BSSM_FP_UTH(fp_) ((const double*)((fp_) + (int)(fp_)[FP_THOFF]))
+#define BSSM_FP_UKN(fp_) ((const double*)((fp_) + (int)(fp_)[FP_KNOFF]))
 
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_TV)
 template <class PF>
@@ -109,7 +118,7 @@ __device__ __forceinline__ void nlg_T_fn(int id, PF fp, const double (&a)[MP], d
     case FN_USER_NLG:
 #pragma unroll
       for (int j = 0; j < MP; j++) x[j] = 0.0;  // (the snippet writes its own states: the padding components must not stay undefined)
-      bssm_user_T(BSSM_UTV(fp, t) &a[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN), &x[0]);
+      bssm_user_T(BSSM_UTV(fp, t) &a[0], BSSM_FP_UTH(fp), BSSM_FP_UKN(fp), &x[0]);
       break;
 #endif
     default: x[0] = a[0]; break;                                                                             // linear_gaussian
@@ -119,7 +128,7 @@ template <int MP, class PF>
 __device__ __forceinline__ double nlg_Z_fn(int id, PF fp, const double (&x)[MP], int t = 0) {
   switch (id) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG)
-    case FN_USER_NLG: return bssm_user_Z(BSSM_UTV(fp, t) &x[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN));
+    case FN_USER_NLG: return bssm_user_Z(BSSM_UTV(fp, t) &x[0], BSSM_FP_UTH(fp), BSSM_FP_UKN(fp));
 #endif
     case FN_NLG_GROWTH: return MP > 1 ? x[MP > 1 ? 1 : 0] : x[0];  // second state (:393-400)
     case FN_NLG_AR_EXP:
@@ -155,19 +164,19 @@ __device__ __forceinline__ void nlg_T_gn(int id, const double* __restrict__ fp, 
 // ---- ssm_sde: Milstein scheme with 2^L sub-steps per unit time (src/milstein.cpp:18-48)
 __device__ __forceinline__ double sde_drift(int id, const double* __restrict__ fp, double x) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
-  if (id == FN_USER_SDE) return bssm_user_drift(x, fp + FP_THETA);
+  if (id == FN_USER_SDE) return bssm_user_drift(x, BSSM_FP_UTH(fp));
 #endif
   return id == FN_SDE_GBM ? fp[FP_THETA + 0] * x : tl_exp(fp[FP_THETA + 0]) * (fp[FP_THETA + 1] - x);
 }
 __device__ __forceinline__ double sde_diffusion(int id, const double* __restrict__ fp, double x) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
-  if (id == FN_USER_SDE) return bssm_user_diffusion(x, fp + FP_THETA);
+  if (id == FN_USER_SDE) return bssm_user_diffusion(x, BSSM_FP_UTH(fp));
 #endif
   return id == FN_SDE_GBM ? fmax(0.0, fp[FP_THETA + 1] * x) : fp[FP_R];  // poisson_ou: exp(theta2), precomputed
 }
 __device__ __forceinline__ double sde_ddiffusion(int id, const double* __restrict__ fp, double x) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
-  if (id == FN_USER_SDE) return bssm_user_ddiffusion(x, fp + FP_THETA);
+  if (id == FN_USER_SDE) return bssm_user_ddiffusion(x, BSSM_FP_UTH(fp));
 #endif
   return id == FN_SDE_GBM ? (x > 0.0 ? fp[FP_THETA + 1] : 0.0) : 0.0;
 }
@@ -175,7 +184,7 @@ __device__ __forceinline__ double milstein(int id, const double* __restrict__ fp
                                            uint32_t i, double x) {
   const int L = (int)fp[FP_L];
   const int nsub = 1 << L;
-  const double dt = 1.0 / (double)nsub, sdt = sqrt(dt);
+  const double dt = fp[FP_TEND] / (double)nsub, sdt = sqrt(dt);  // (FP_TEND = 1 in the filters: the same bits as 1 / nsub)
   const bool positive = fp[FP_POS] != 0.0;
   for (int k = 0; k < nsub; k += 2) {
     double z0, z1;
@@ -229,7 +238,7 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
     if (id == FN_USER_NLG) {  // alpha' = T(a) + R(a) eta with any m x k matrix R (src/model_ssm_nlg.cpp:1118-1126)
 #pragma unroll
       for (int j = 0; j < MP; j++) x[j] = 0.0;
-      bssm_user_T(BSSM_UTV(fp, (int)t) &a[0], fp + FP_THETA, fp + FP_KNOWN, &x[0]);
+      bssm_user_T(BSSM_UTV(fp, (int)t) &a[0], BSSM_FP_UTH(fp), BSSM_FP_UKN(fp), &x[0]);
 #ifdef BSSM_USER_RFN
       double Rm[MP * MP];
       {
@@ -237,7 +246,7 @@ __device__ __forceinline__ void functor_propagate(const double* __restrict__ fp,
         double Ru[MP * MP];
 #pragma unroll
         for (int q = 0; q < MP * MP; q++) Ru[q] = 0.0;
-        bssm_user_R(BSSM_UTV(fp, (int)t) &a[0], fp + FP_THETA, fp + FP_KNOWN, &Ru[0]);  // m x k, column-major with leading dimension m
+        bssm_user_R(BSSM_UTV(fp, (int)t) &a[0], BSSM_FP_UTH(fp), BSSM_FP_UKN(fp), &Ru[0]);  // m x k, column-major with leading dimension m
 #pragma unroll
         for (int c = 0; c < MP; c++)
 #pragma unroll
@@ -270,7 +279,7 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
   const int id = FID > 0 ? FID : (int)fp[FP_ID];
   const double y = ob[OB_Y];
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_SDE)
-  if (id == FN_USER_SDE) return bssm_user_log_obs(y, x[0], fp + FP_THETA);
+  if (id == FN_USER_SDE) return bssm_user_log_obs(y, x[0], BSSM_FP_UTH(fp));
 #endif
   if (id == FN_SDE_POISSON_OU) {  // R::dpois(y, exp(x), log): y x - e^x - lgamma(y + 1) (host puts lgamma in OB_AUX)
     return y * x[0] - tl_exp(x[0]) - ob[OB_AUX];
@@ -278,8 +287,8 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
   // normalised Gaussian log-density (dmvnorm(..., lwr = true, logd = true), src/dmvnorm.cpp:10-13)
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_HFN)
   if (id == FN_USER_NLG) {  // H_fn at the particle (src/model_ssm_nlg.cpp:950-953)
-    const double h = bssm_user_H(BSSM_UTV(fp, t) &x[0], fp + FP_THETA, fp + FP_KNOWN);
-    const double q = (y - bssm_user_Z(BSSM_UTV(fp, t) &x[0], fp + FP_THETA, fp + FP_KNOWN)) / h;
+    const double h = bssm_user_H(BSSM_UTV(fp, t) &x[0], BSSM_FP_UTH(fp), BSSM_FP_UKN(fp));
+    const double q = (y - bssm_user_Z(BSSM_UTV(fp, t) &x[0], BSSM_FP_UTH(fp), BSSM_FP_UKN(fp))) / h;
     return -0.9189385332046727 - tl_log(h) - 0.5 * q * q;  // -0.5 log(2 pi) - log h - q^2 / 2
   }
 #endif
@@ -293,7 +302,7 @@ __device__ __forceinline__ double functor_log_weight(const double* __restrict__ 
 template <int MP, class PF>
 __device__ __forceinline__ double nlg_H_at(int id, PF fp, const double (&x)[MP], int t) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_HFN)
-  if (id == FN_USER_NLG) return bssm_user_H(BSSM_UTV(fp, t) &x[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN));
+  if (id == FN_USER_NLG) return bssm_user_H(BSSM_UTV(fp, t) &x[0], BSSM_FP_UTH(fp), BSSM_FP_UKN(fp));
 #endif
   return fp[FP_H];
 }
@@ -307,7 +316,7 @@ __device__ __forceinline__ void user_RR_at(PF fp, const double (&a)[MP], int t, 
   double Ru[MP * MP];
 #pragma unroll
   for (int q = 0; q < MP * MP; q++) Ru[q] = 0.0;
-  bssm_user_R(BSSM_UTV(fp, t) &a[0], (const double*)(fp + FP_THETA), (const double*)(fp + FP_KNOWN), &Ru[0]);  // m x k, leading dimension m; columns >= k stay zero
+  bssm_user_R(BSSM_UTV(fp, t) &a[0], BSSM_FP_UTH(fp), BSSM_FP_UKN(fp), &Ru[0]);  // m x k, leading dimension m; columns >= k stay zero
 #pragma unroll
   for (int j = 0; j < MP; j++)
 #pragma unroll
@@ -448,7 +457,7 @@ __device__ __forceinline__ void nlg_Z_gn(int id, const double* __restrict__ fp, 
   for (int c = 0; c < MP; c++) Zg[c] = 0.0;
   switch (id) {
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_NLG) && defined(BSSM_USER_JACOBIANS)
-    case FN_USER_NLG: bssm_user_Zg(BSSM_UTV(fp, t) &x[0], fp + FP_THETA, fp + FP_KNOWN, &Zg[0]); break;
+    case FN_USER_NLG: bssm_user_Zg(BSSM_UTV(fp, t) &x[0], BSSM_FP_UTH(fp), BSSM_FP_UKN(fp), &Zg[0]); break;
 #endif
     case FN_NLG_GROWTH: if constexpr (MP > 1) Zg[1] = 1.0; break;
     case FN_NLG_AR_EXP:

@@ -15,7 +15,9 @@ namespace bssm {
 #ifndef BSSM_USER_MODEL
 hipStream_t stream_pool_take(int dev, int kind);  // nullptr when the pool has none; kind: 0 plain, 1 highest priority, 2 plain, reserved (created early)
 void stream_pool_give(int dev, int kind, hipStream_t s);
-void prewarm_streams();  // once per process, at the first entry-point call (options.cpp)
+bool tail_overlap_available();          // false when no stream of the current device was MEASURED to run beside its null stream (options.cpp)
+int tail_overlap_state(int* candidates_tried);  // 0 not calibrated, 1 measured yes, 2 measured no
+void prewarm_streams();  // once per DEVICE: at the first entry-point call with that device current, and in every shard thread (options.cpp)
 #endif
 
 struct TlsStream {

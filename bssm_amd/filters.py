@@ -97,6 +97,20 @@ def _functor_filter(model: BssmModel, particles: int, seed: int, smoother: bool,
     return res
 
 
+def milstein(model: BssmModel, L: int, t: float = 1.0, seed: int = 1) -> float:
+    """R_milstein (R/RcppExports.R:104-106, src/R_milstein.cpp:4-22): terminal value of one Milstein path of an ssm_sde model from
+    x0 over [0, t] in 2^L steps, on the device (bssm_milstein)."""
+    if not model.inherits("ssm_sde"):
+        raise TypeError("milstein() is for ssm_sde models")
+    L = check_intmax(L, "L", positive=False, max=20)   # (2^0 = one step is a valid discretisation, src/milstein.cpp:22)
+    smod, keep = _lib.pack_fn_model(model, L)
+    x = C.c_double(0.0)
+    fn = _lib.lib().bssm_milstein
+    fn.argtypes = [C.POINTER(_lib.FnModel), C.c_double, C.c_uint32, C.POINTER(C.c_double)]
+    _lib.check(fn(C.byref(smod), C.c_double(float(t)), C.c_uint32(seed), C.byref(x)))
+    return x.value
+
+
 def bootstrap_filter(model: BssmModel, particles: int, seed: int | None = None, return_indices: bool = False, L=None):
     """R/bootstrap_filter.R:48-120 (lineargaussian :48-79, nongaussian :85-120).
 

@@ -114,6 +114,9 @@ const char* bssm_amd_last_error(void);
 const char* bssm_amd_version(void);
 /* The library keeps freed device buffers in an arena (default cap 96 GiB, env BSSM_AMD_CACHE_GB) because
  * hipMalloc/hipFree of multi-GB scratch dominate repeated calls; this returns all cached blocks to the driver. */
+/* diagnostic (round 6): whether the stream that steps the tail of a post-correction chunk was MEASURED to run beside the current
+ * device's null stream (csrc/options.cpp: prewarm_streams).  0 not calibrated, 1 yes, 2 no (tails then go behind their rounds) */
+int bssm_amd_tail_overlap_state(int32_t* candidates_tried);
 void bssm_amd_trim_cache(void);
 /* The library reads its BSSM_AMD_* environment switches once, when it is loaded (bssm_amd/csrc/options.h lists them); a process
  * that changes one afterwards calls this to have them read again.  Calls already in flight keep the snapshot they started with. */
@@ -237,6 +240,9 @@ int bssm_bsf_smoother_nlg(const bssm_fn_model* model, uint32_t nsim, uint32_t se
 /* replaces _bssm_bsf_sde / _bssm_bsf_smoother_sde (12 args, src/R_sde.cpp:35-130) */
 int bssm_bsf_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);
 int bssm_bsf_smoother_sde(const bssm_fn_model* model, uint32_t nsim, uint32_t seed, bssm_filter_out* out);
+/* replaces _bssm_R_milstein (9 args, src/R_milstein.cpp:4-22; src/RcppExports.cpp:1313): terminal value of one Milstein path from
+ * model->x0 over [0, t_end] in 2^(model->L) steps -- the prior draw of particle 0 of a bootstrap filter with `seed` (t_end = 1 there) */
+int bssm_milstein(const bssm_fn_model* model, double t_end, uint32_t seed, double* x_out);
 /* replaces _bssm_nonlinear_loglik (method = 2, bsf) and _bssm_loglik_sde (src/R_loglik.cpp:91-124, src/R_sde.cpp:11-31),
  * batched over n_rep Philox streams */
 int bssm_fn_loglik_batch(const bssm_fn_model* model, uint32_t nsim, uint32_t sampling_method, uint32_t seed, uint32_t stream0,

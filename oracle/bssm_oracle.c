@@ -1490,9 +1490,9 @@ static double sde_drift(const orc_fn_model *mod, double x) { return mod->id == 5
 static double sde_diff(const orc_fn_model *mod, double x) { return mod->id == 5 ? fmax(0.0, mod->theta[1] * x) : exp(mod->theta[2]); }
 static double sde_ddiff(const orc_fn_model *mod, double x) { return mod->id == 5 ? mod->theta[1] * (x > 0.0) : 0.0; }
 /* milstein.cpp:18-48; increments N(0, sqrt(dt)) from Box-Muller pairs d = 0.. of (purpose, t, particle) */
-static double fn_milstein(const orc_fn_model *mod, const orc_rng *rng, uint32_t purpose, uint32_t t, uint32_t i, double x) {
+static double fn_milstein_t(const orc_fn_model *mod, const orc_rng *rng, uint32_t purpose, uint32_t t, uint32_t i, double x, double t_end) {
   unsigned nsub = 1u << mod->L;
-  double dt = 1.0 / nsub, sdt = sqrt(dt);
+  double dt = t_end / nsub, sdt = sqrt(dt);
   for (unsigned k = 0; k < nsub; k++) {
     double z0, z1;
     orc_rng_normal_pair(rng, purpose, t, i, k / 2, &z0, &z1);
@@ -1502,6 +1502,11 @@ static double fn_milstein(const orc_fn_model *mod, const orc_rng *rng, uint32_t 
   }
   return x;
 }
+static double fn_milstein(const orc_fn_model *mod, const orc_rng *rng, uint32_t purpose, uint32_t t, uint32_t i, double x) {
+  return fn_milstein_t(mod, rng, purpose, t, i, x, 1.0); /* the filters step one unit of time, model_ssm_sde.cpp:27,61 */
+}
+/* R_milstein (R_milstein.cpp:4-22): one path from x0 over [0, t_end]; stream = the prior draw of particle 0 */
+double orc_milstein(const orc_fn_model *mod, double t_end, const orc_rng *rng) { return fn_milstein_t(mod, rng, 0, 0, 0, mod->x0, t_end); }
 static double fn_log_obs(const orc_fn_model *mod, int t, const double *x) {
   double y = mod->y[t];
   if (mod->id == 6) return y * x[0] - exp(x[0]) - lgamma(y + 1.0); /* R::dpois(y, exp(x), log) */

@@ -448,6 +448,18 @@ def fn_bsf_filter(model: dict, nsim: int, seed=1, stream=0):
     return dict(logLik=ll, alpha=alpha, weights=weights, indices=indices)
 
 
+def milstein(model: dict, t_end: float, seed=1) -> float:
+    """R_milstein (src/R_milstein.cpp:4-22): the terminal value of one Milstein path from x0 over [0, t_end]"""
+    L = lib()
+    L.orc_milstein.restype = C.c_double
+    s = OrcFn()
+    s.id = int(model["model_id"])
+    for i, v in enumerate(np.asarray(model["theta"], dtype=float)): s.theta[i] = v
+    s.x0, s.positive, s.L = float(model.get("x0", 0.0)), int(bool(model.get("positive", False))), int(model.get("L", 0))
+    rng, _ = make_rng(seed, 0)
+    return float(L.orc_milstein(C.byref(s), C.c_double(t_end), C.byref(rng)))
+
+
 _NLG_FN = C.CFUNCTYPE(None, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p)
 
 

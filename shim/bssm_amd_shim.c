@@ -481,7 +481,6 @@ static SEXP counts_sexp(const uint32_t* c, int ns) {
   UNPROTECT(1);
   return v;
 }
-static SEXP real_vec(const double* x, int ns) __attribute__((unused));
 static SEXP real_vec(const double* x, int ns) {
   SEXP v = PROTECT(Rf_allocVector(REALSXP, ns));
   if (ns) memcpy(REAL(v), x, (size_t)ns * sizeof(double));
@@ -590,6 +589,101 @@ SEXP _bssm_nongaussian_is_mcmc(SEXP model_, SEXP output_type, SEXP nsim, SEXP it
   SEXP res = mcmc_result(ot, alpha, alphahat, Vt, tht, weights, cnt, out.acceptance_rate, cs.S, post, modes);
   UNPROTECT(np);
   return res;
+}
+
+
+/* ------------------------------------------------------------------ pseudo-marginal / delayed-acceptance chains
+ * run_mcmc(model, mcmc_type = "pm" | "da") (R/run_mcmc.R:497-522): one device filter pass per iteration through a
+ * device-resident plan (bssm_run_mcmc, csrc/mcmc.cpp).  The lists carry no weights / modes (src/R_mcmc.cpp:207-232). */
+static SEXP chain_result(int output_type, SEXP alpha, SEXP alphahat, SEXP Vt, SEXP theta, SEXP counts, double acc, SEXP S, SEXP posterior) {
+  const char* n1[] = {"alpha", "theta", "counts", "acceptance_rate", "S", "posterior", ""};
+  const char* n2[] = {"alphahat", "Vt", "theta", "counts", "acceptance_rate", "S", "posterior", ""};
+  const char* n3[] = {"theta", "counts", "acceptance_rate", "S", "posterior", ""};
+  SEXP res = PROTECT(Rf_mkNamed(VECSXP, output_type == 1 ? n1 : (output_type == 2 ? n2 : n3)));
+  int k = 0;
+  if (output_type == 1) SET_VECTOR_ELT(res, k++, alpha);
+  if (output_type == 2) { SET_VECTOR_ELT(res, k++, alphahat); SET_VECTOR_ELT(res, k++, Vt); }
+  SET_VECTOR_ELT(res, k++, theta); SET_VECTOR_ELT(res, k++, counts);
+  SET_VECTOR_ELT(res, k++, Rf_ScalarReal(acc)); SET_VECTOR_ELT(res, k++, S); SET_VECTOR_ELT(res, k++, posterior);
+  UNPROTECT(1);
+  return res;
+}
+/* state storage of a filtered chain: alpha (n+1) x m x capacity (trimmed to n_stored afterwards), or the running summaries */
+typedef struct { double* alpha_cap; SEXP ah_mn, Vt; } state_store;
+static void state_alloc(state_store* st, bssm_mcmc_out* out, int ot, int n, int m, int cap, int* np) {
+  st->alpha_cap = NULL; st->ah_mn = R_NilValue; st->Vt = R_NilValue;
+  if (ot == 1) { st->alpha_cap = (double*)R_alloc((size_t)(n + 1) * m * cap + 1, sizeof(double)); out->alpha = st->alpha_cap; }
+  if (ot == 2) {
+    st->ah_mn = PROTECT(Rf_allocMatrix(REALSXP, m, n + 1)); (*np)++;
+    st->Vt = PROTECT(Rf_alloc3DArray(REALSXP, m, m, n + 1)); (*np)++;
+    out->alphahat = REAL(st->ah_mn); out->Vt = REAL(st->Vt);
+  }
+}
+static SEXP finish_chain(const chain_store* cs, const bssm_mcmc_out* out, const state_store* st, int ot, int n, int m, int n_par, int* np) {
+  const int ns = out->n_stored;
+  SEXP alpha = R_NilValue, alphahat = R_NilValue;
+  if (ot == 1) {
+    alpha = PROTECT(Rf_alloc3DArray(REALSXP, n + 1, m, ns)); (*np)++;
+    memcpy(REAL(alpha), st->alpha_cap, (size_t)(n + 1) * m * ns * sizeof(double));
+  }
+  if (ot == 2) { /* mcmc_run.alphahat.t() */
+    alphahat = PROTECT(Rf_allocMatrix(REALSXP, n + 1, m)); (*np)++;
+    for (int t = 0; t <= n; t++) for (int c = 0; c < m; c++) REAL(alphahat)[t + (size_t)(n + 1) * c] = REAL(st->ah_mn)[c + (size_t)m * t];
+  }
+  SEXP tht = PROTECT(transpose_theta(cs->theta, n_par, ns)); (*np)++;
+  SEXP cnt = PROTECT(counts_sexp(cs->counts, ns)); (*np)++;
+  SEXP post = PROTECT(real_vec(cs->posterior, ns)); (*np)++;
+  return chain_result(ot, alpha, alphahat, st->Vt, tht, cnt, out->acceptance_rate, cs->S, post);
+}
+
+static SEXP nongaussian_chain(int mcmc_type, SEXP model_, SEXP output_type, SEXP nsim, SEXP iter, SEXP burnin, SEXP thin, SEXP gamma,
+                              SEXP target_acceptance, SEXP S, SEXP seed, SEXP end_ram, SEXP sampling_method, SEXP model_type) {
+  const int mt = Rf_asInteger(model_type), ot = Rf_asInteger(output_type), sm_ = Rf_asInteger(sampling_method);
+  int np = 0;
+  if (sm_ != BSSM_PSI && sm_ != BSSM_BSF) Rf_error("sampling method 'spdk' is outside the particle-filter path of this build");
+  shim_model sm;
+  unpack_model(model_, mt, 0, &sm);
+  own_theta_dependent(model_, &sm);
+  SEXP theta0 = elt(model_, "theta");
+  const int n_par = Rf_length(theta0), n = sm.mod.n, m = sm.mod.m;
+  int32_t flags[8];
+  bssm_mcmc_job job;
+  closure_ctx ctx = {model_, elt(model_, "update_fn"), elt(model_, "prior_fn")};
+  memset(&job, 0, sizeof(job));
+  job.model_type = mt; job.n_par = n_par;
+  if (builtin_flags(model_, mt, flags)) {
+    SEXP pd = PROTECT(Rf_coerceVector(elt(model_, "prior_distributions"), INTSXP)); np++;
+    job.flags = flags; job.prior_distributions = (const int32_t*)INTEGER(pd); job.prior_parameters = REAL(elt(model_, "prior_parameters"));
+  } else {
+    job.update_fn = cb_update; job.prior_fn = cb_prior; job.user = &ctx;
+  }
+  job.mcmc_type = mcmc_type; job.sampling_method = (uint32_t)sm_; job.nsim = (uint32_t)Rf_asInteger(nsim);
+  job.iter = (uint64_t)Rf_asInteger(iter); job.burnin = (uint64_t)Rf_asInteger(burnin); job.thin = (uint32_t)Rf_asInteger(thin);
+  job.gamma = Rf_asReal(gamma); job.target_acceptance = Rf_asReal(target_acceptance); job.end_ram = Rf_asLogical(end_ram);
+  job.seed = (uint32_t)Rf_asInteger(seed); job.output_type = ot;
+  chain_store cs;
+  bssm_mcmc_out out;
+  state_store st;
+  chain_alloc(&cs, &out, n_par, 1, Rf_asInteger(iter), Rf_asInteger(burnin), Rf_asInteger(thin), S, &np);
+  out.modes = NULL; out.approx_loglik = NULL; out.prior = NULL;  /* filtered chains keep theta / counts / posterior only */
+  state_alloc(&st, &out, ot, n, m, cs.cap, &np);
+  check_rc(bssm_run_mcmc(&sm.mod, REAL(theta0), &job, &out));
+  SEXP res = finish_chain(&cs, &out, &st, ot, n, m, n_par, &np);
+  UNPROTECT(np);
+  return res;
+}
+/* .Call('_bssm_nongaussian_pm_mcmc', model_, output_type, nsim, iter, burnin, thin, gamma, target_acceptance, S, seed, end_ram,
+ *       n_threads, sampling_method, model_type, verbose): src/R_mcmc.cpp:167-242 (mcmc::pm_mcmc, src/mcmc.cpp:337-491) */
+SEXP _bssm_nongaussian_pm_mcmc(SEXP model_, SEXP output_type, SEXP nsim, SEXP iter, SEXP burnin, SEXP thin, SEXP gamma, SEXP target_acceptance,
+                               SEXP S, SEXP seed, SEXP end_ram, SEXP n_threads, SEXP sampling_method, SEXP model_type, SEXP verbose) {
+  (void)n_threads; (void)verbose;
+  return nongaussian_chain(BSSM_MCMC_PM, model_, output_type, nsim, iter, burnin, thin, gamma, target_acceptance, S, seed, end_ram, sampling_method, model_type);
+}
+/* .Call('_bssm_nongaussian_da_mcmc', <the same 15>): src/R_mcmc.cpp:246-327 (mcmc::da_mcmc, src/mcmc.cpp:530-685) */
+SEXP _bssm_nongaussian_da_mcmc(SEXP model_, SEXP output_type, SEXP nsim, SEXP iter, SEXP burnin, SEXP thin, SEXP gamma, SEXP target_acceptance,
+                               SEXP S, SEXP seed, SEXP end_ram, SEXP n_threads, SEXP sampling_method, SEXP model_type, SEXP verbose) {
+  (void)n_threads; (void)verbose;
+  return nongaussian_chain(BSSM_MCMC_DA, model_, output_type, nsim, iter, burnin, thin, gamma, target_acceptance, S, seed, end_ram, sampling_method, model_type);
 }
 
 /* ================================================================== ssm_nlg / ssm_sde */
@@ -863,6 +957,55 @@ SEXP _bssm_nonlinear_is_mcmc(SEXP y, SEXP Z, SEXP H, SEXP T, SEXP R, SEXP Zg, SE
   return res;
 }
 
+
+/* pm / da chains of the functor models: bssm_run_mcmc_fn with the filter of each iteration on the device */
+static SEXP fn_chain(const bssm_fn_model* f, int mcmc_type, int sampling_method, int L_c, int L_f, SEXP theta, SEXP log_prior_pdf, SEXP nsim,
+                     SEXP iter, SEXP burnin, SEXP thin, SEXP gamma, SEXP target_acceptance, SEXP S, SEXP end_ram, SEXP seed, int max_iter,
+                     double conv_tol, int ot) {
+  const int n_par = Rf_length(theta), n = f->n, m = fn_states(f);
+  int np = 0;
+  bssm_mcmc_job job;
+  memset(&job, 0, sizeof(job));
+  job.n_par = n_par; job.prior_fn = cb_fn_prior; job.user = (void*)prior_closure(log_prior_pdf);
+  job.mcmc_type = mcmc_type; job.sampling_method = (uint32_t)sampling_method; job.nsim = (uint32_t)Rf_asInteger(nsim);
+  job.iter = (uint64_t)Rf_asInteger(iter); job.burnin = (uint64_t)Rf_asInteger(burnin); job.thin = (uint32_t)Rf_asInteger(thin);
+  job.gamma = Rf_asReal(gamma); job.target_acceptance = Rf_asReal(target_acceptance); job.end_ram = Rf_asLogical(end_ram);
+  job.seed = (uint32_t)Rf_asInteger(seed); job.output_type = ot; job.max_iter = max_iter; job.conv_tol = conv_tol;
+  job.L_c = L_c; job.L_f = L_f;
+  chain_store cs;
+  bssm_mcmc_out out;
+  state_store st;
+  chain_alloc(&cs, &out, n_par, 1, Rf_asInteger(iter), Rf_asInteger(burnin), Rf_asInteger(thin), S, &np);
+  out.modes = NULL; out.approx_loglik = NULL; out.prior = NULL;
+  state_alloc(&st, &out, ot, n, m, cs.cap, &np);
+  check_rc(bssm_run_mcmc_fn(f, REAL(theta), &job, &out));
+  SEXP res = finish_chain(&cs, &out, &st, ot, n, m, n_par, &np);
+  UNPROTECT(np);
+  return res;
+}
+/* .Call('_bssm_nonlinear_pm_mcmc', y, Z, H, T, R, Zg, Tg, a1, P1, theta, log_prior_pdf, known_params, known_tv_params, time_varying,
+ *       n_states, n_etas, seed, nsim, iter, burnin, thin, gamma, target_acceptance, S, end_ram, n_threads, max_iter, conv_tol,
+ *       sampling_method, iekf_iter, output_type, verbose): src/R_mcmc.cpp:550-608; sampling_method 1 psi / 2 bsf / 4 ekf */
+SEXP _bssm_nonlinear_pm_mcmc(SEXP y, SEXP Z, SEXP H, SEXP T, SEXP R, SEXP Zg, SEXP Tg, SEXP a1, SEXP P1, SEXP theta, SEXP log_prior_pdf,
+                             SEXP known_params, SEXP known_tv_params, SEXP time_varying, SEXP n_states, SEXP n_etas, SEXP seed, SEXP nsim,
+                             SEXP iter, SEXP burnin, SEXP thin, SEXP gamma, SEXP target_acceptance, SEXP S, SEXP end_ram, SEXP n_threads,
+                             SEXP max_iter, SEXP conv_tol, SEXP sampling_method, SEXP iekf_iter, SEXP output_type, SEXP verbose) {
+  (void)H; (void)T; (void)R; (void)Zg; (void)Tg; (void)a1; (void)P1; (void)time_varying; (void)n_etas; (void)n_threads; (void)iekf_iter; (void)verbose;
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
+  return fn_chain(&f, BSSM_MCMC_PM, Rf_asInteger(sampling_method), 0, 0, theta, log_prior_pdf, nsim, iter, burnin, thin, gamma, target_acceptance, S,
+                  end_ram, seed, Rf_asInteger(max_iter), Rf_asReal(conv_tol), Rf_asInteger(output_type));
+}
+/* .Call('_bssm_nonlinear_da_mcmc', <the same 32>): src/R_mcmc.cpp:610-668 */
+SEXP _bssm_nonlinear_da_mcmc(SEXP y, SEXP Z, SEXP H, SEXP T, SEXP R, SEXP Zg, SEXP Tg, SEXP a1, SEXP P1, SEXP theta, SEXP log_prior_pdf,
+                             SEXP known_params, SEXP known_tv_params, SEXP time_varying, SEXP n_states, SEXP n_etas, SEXP seed, SEXP nsim,
+                             SEXP iter, SEXP burnin, SEXP thin, SEXP gamma, SEXP target_acceptance, SEXP S, SEXP end_ram, SEXP n_threads,
+                             SEXP max_iter, SEXP conv_tol, SEXP sampling_method, SEXP iekf_iter, SEXP output_type, SEXP verbose) {
+  (void)H; (void)T; (void)R; (void)Zg; (void)Tg; (void)a1; (void)P1; (void)time_varying; (void)n_etas; (void)n_threads; (void)iekf_iter; (void)verbose;
+  bssm_fn_model f = nlg_model_tv(y, Z, theta, known_params, known_tv_params, n_states);
+  return fn_chain(&f, BSSM_MCMC_DA, Rf_asInteger(sampling_method), 0, 0, theta, log_prior_pdf, nsim, iter, burnin, thin, gamma, target_acceptance, S,
+                  end_ram, seed, Rf_asInteger(max_iter), Rf_asReal(conv_tol), Rf_asInteger(output_type));
+}
+
 /* ------------------------------------------------------------------ ssm_sde */
 #define SDE_ARGS SEXP y, SEXP x0, SEXP positive, SEXP drift, SEXP diffusion, SEXP ddiffusion, SEXP log_prior_pdf, SEXP log_obs_density
 #define SDE_UNUSED (void)diffusion; (void)ddiffusion; (void)log_prior_pdf; (void)log_obs_density
@@ -888,6 +1031,18 @@ SEXP _bssm_bsf_sde(SDE_ARGS, SEXP theta, SEXP nsim, SEXP L, SEXP seed) {
   SDE_UNUSED;
   bssm_fn_model f = sde_model(y, x0, positive, drift, theta, Rf_asInteger(L));
   return run_filter_like(f.n, 1, (uint32_t)Rf_asInteger(nsim), (uint32_t)Rf_asInteger(seed), 0, call_fn_filter, &f, NULL);
+}
+/* .Call('_bssm_R_milstein', x0, L, t, theta, drift_pntr, diffusion_pntr, ddiffusion_pntr, positive, seed): src/R_milstein.cpp:4-22 */
+SEXP _bssm_R_milstein(SEXP x0, SEXP L, SEXP t, SEXP theta, SEXP drift, SEXP diffusion, SEXP ddiffusion, SEXP positive, SEXP seed) {
+  (void)diffusion; (void)ddiffusion;
+  bssm_fn_model f;
+  double x = 0.0;
+  memset(&f, 0, sizeof(f));
+  f.theta = REAL(theta); f.n_theta = Rf_length(theta);
+  f.x0 = Rf_asReal(x0); f.positive = Rf_asLogical(positive); f.L = Rf_asInteger(L);
+  fn_identity(drift, 1, 1, &f);
+  check_rc(bssm_milstein(&f, Rf_asReal(t), (uint32_t)Rf_asInteger(seed), &x));
+  return Rf_ScalarReal(x);
 }
 /* .Call('_bssm_bsf_smoother_sde', ...): src/R_sde.cpp:75-130 */
 SEXP _bssm_bsf_smoother_sde(SDE_ARGS, SEXP theta, SEXP nsim, SEXP L, SEXP seed) {
@@ -963,6 +1118,26 @@ SEXP _bssm_sde_is_mcmc(SDE_ARGS, SEXP theta, SEXP nsim, SEXP L_c, SEXP L_f, SEXP
   return res;
 }
 
+
+/* .Call('_bssm_sde_pm_mcmc', y, x0, positive, drift, diffusion, ddiffusion, log_prior_pdf, log_obs_density, theta, nsim, L, seed, iter,
+ *       burnin, thin, gamma, target_acceptance, S, end_ram, type, verbose): src/R_sde.cpp:134-178 */
+SEXP _bssm_sde_pm_mcmc(SDE_ARGS, SEXP theta, SEXP nsim, SEXP L, SEXP seed, SEXP iter, SEXP burnin, SEXP thin, SEXP gamma, SEXP target_acceptance,
+                       SEXP S, SEXP end_ram, SEXP type, SEXP verbose) {
+  (void)diffusion; (void)ddiffusion; (void)log_obs_density; (void)verbose;
+  bssm_fn_model f = sde_model(y, x0, positive, drift, theta, Rf_asInteger(L));
+  return fn_chain(&f, BSSM_MCMC_PM, BSSM_BSF, 0, 0, theta, log_prior_pdf, nsim, iter, burnin, thin, gamma, target_acceptance, S, end_ram, seed, 0, 0.0,
+                  Rf_asInteger(type));
+}
+/* .Call('_bssm_sde_da_mcmc', <8>, theta, nsim, L_c, L_f, seed, iter, burnin, thin, gamma, target_acceptance, S, end_ram, type, verbose):
+ * src/R_sde.cpp:180-219; coarse bootstrap filter first, the fine one for proposals that pass (src/mcmc.cpp:836-960) */
+SEXP _bssm_sde_da_mcmc(SDE_ARGS, SEXP theta, SEXP nsim, SEXP L_c, SEXP L_f, SEXP seed, SEXP iter, SEXP burnin, SEXP thin, SEXP gamma,
+                       SEXP target_acceptance, SEXP S, SEXP end_ram, SEXP type, SEXP verbose) {
+  (void)diffusion; (void)ddiffusion; (void)log_obs_density; (void)verbose;
+  bssm_fn_model f = sde_model(y, x0, positive, drift, theta, Rf_asInteger(L_f));
+  return fn_chain(&f, BSSM_MCMC_DA, BSSM_BSF, Rf_asInteger(L_c), Rf_asInteger(L_f), theta, log_prior_pdf, nsim, iter, burnin, thin, gamma,
+                  target_acceptance, S, end_ram, seed, 0, 0.0, Rf_asInteger(type));
+}
+
 /* ================================================================== registration
  * These rows replace the same-named rows of CallEntries in src/RcppExports.cpp:1287-1346; every other row of that table
  * (Kalman filters, prediction, ...) keeps pointing at the reference's own stubs. */
@@ -977,7 +1152,11 @@ static const R_CallMethodDef bssm_amd_entries[] = {
     ENTRY(_bssm_nongaussian_loglik, 5),
     ENTRY(_bssm_nonlinear_loglik, 22),
     ENTRY(_bssm_nongaussian_is_mcmc, 17),
+    ENTRY(_bssm_nongaussian_pm_mcmc, 15),
+    ENTRY(_bssm_nongaussian_da_mcmc, 15),
     ENTRY(_bssm_nonlinear_is_mcmc, 34),
+    ENTRY(_bssm_nonlinear_pm_mcmc, 32),
+    ENTRY(_bssm_nonlinear_da_mcmc, 32),
     ENTRY(_bssm_suggest_n_nongaussian, 6),
     ENTRY(_bssm_suggest_n_nonlinear, 20),
     ENTRY(_bssm_postcorrection_nongaussian, 10),
@@ -988,7 +1167,10 @@ static const R_CallMethodDef bssm_amd_entries[] = {
     ENTRY(_bssm_loglik_sde, 12),
     ENTRY(_bssm_bsf_sde, 12),
     ENTRY(_bssm_bsf_smoother_sde, 12),
+    ENTRY(_bssm_R_milstein, 9),
     ENTRY(_bssm_sde_is_mcmc, 24),
+    ENTRY(_bssm_sde_pm_mcmc, 21),
+    ENTRY(_bssm_sde_da_mcmc, 22),
     ENTRY(_bssm_sde_state_sampler_bsf_is2, 13),
     ENTRY(_bssm_stratified_sample, 3),
     {NULL, NULL, 0}};

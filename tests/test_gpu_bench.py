@@ -50,13 +50,40 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
         assert abs(sc[job]["speedup_vs_n1"] - sc[job]["seconds_n1"] / sc[job]["seconds"]) < 1e-12
 
 
+def test_bench_eight_ranks_shard_the_post_correction_like_the_projection():
+    """Multi-GPU readiness without the hardware (round-5 review, item 9): the driver's 8-GPU run must work unattended, so the EIGHT-rank
+    control flow runs here with the ranks sharing this box's GPU (gloo): one line, the communicator's facts, every rank's shard timings,
+    and each rank's share of the C5 job equal to what the one-GPU projection of the same job says a rank gets"""
+    draws = 2340
+    out = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "1", "--replicas", "2", "--T", "32", "--pc-draws", str(draws),
+                      "--no-cpu-baseline", "--no-dropin", "--no-live-pmc", "--no-mng", "--no-regime-b", "--no-single", "--no-accuracy",
+                      "--no-side-runs", "--no-clock", "--no-live-valu"], timeout=1500)
+    assert out["n_gpus"] == 8 and out["communicator"]["ranks"] == 8 and out["communicator"]["world_size"] == 8
+    assert out["communicator"]["backend"] == "gloo" and out["rccl_ranks"] == 0 and out["communicator"]["distinct_gpus"] == 1
+    assert out["value"] > 0 and out["scaling"] == "weak" and out["config"]["parallelism"] == "replicas only x8"
+    pc = out["post_correct"]
+    assert "error" not in pc, pc
+    assert pc["n_gpus"] == 8 and pc["scaling"] == "strong" and pc["finite_weights"]
+    ranks = pc["per_rank_ms"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and sum(r["draws"] for r in ranks) == draws
+    per_rank = -(-draws // 8)            # projected.C5.draws_per_rank at 8 ranks: ceil(2340 / 8) = 293
+    assert max(r["draws"] for r in ranks) == per_rank and min(r["draws"] for r in ranks) >= per_rank - 8
+    for r in ranks:
+        assert r["filter_ms"] > 0 and r["collective_ms"] >= 0 and r["local_ms"] > 0
+    sc = out["post_correct_scaling"]
+    assert sc["scaling"] == "strong" and sc["n_gpus"] == 8 and sc["distinct_gpus"] == 1
+    assert sc["C5"]["seconds"] > 0 and sc["C5"]["speedup_vs_n1"] > 0
+
+
 def test_bench_single_rank_line_has_the_contract_fields():
     out = _run_bench(["--steps", "1", "--warmup", "1", "--replicas", "4", "--T", "64", "--pc-draws", "96", "--no-cpu-baseline",
                       "--no-dropin", "--no-mng", "--no-regime-b", "--no-single", "--no-live-valu"])
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 0 and out["communicator"]["ranks"] == 1
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out
-    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_by_hip_events"}
+    # round 6: frac is the wall-clock figure of the timed region (value x 88 B / 8 TB/s), the HIP-event one sits beside it
+    assert abs(out["roofline"]["frac"] - out["value"] * 88.0 / 8e12) < 1e-9 and out["roofline"]["frac_source"].startswith("wall clock")
     # traffic measured in the run (two rocprofv3 --pmc passes of one step of the same batch) wherever rocprofv3 exists
     import shutil
     if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
@@ -65,14 +92,16 @@ def test_bench_single_rank_line_has_the_contract_fields():
         assert 1.9 < live["read_factor_calibrated"] < 2.1 and live["read"] > 0 and live["written"] > 0
         assert 0.5 < out["roofline"]["traffic_over_algorithmic"] < 2.0
     assert out["post_correct"]["per_rank_ms"][0]["draws"] == 96
-    # what `value` was quoted on, and the same batch in the reference's weights layout / on the other observed series
-    assert out["config"]["series"] == "informative" and "weights layout of `value`" in out["config"]["workload"]
-    for key in ("roofline_reference_layout", "other_series"):
+    # what `value` was quoted on -- the reference's weights layout exp(w - max_t) since round 6 -- and the same batch in the library's
+    # factored layout / on the other observed series
+    assert out["config"]["series"] == "informative" and "weights layout of `value`: reference" in out["config"]["workload"]
+    assert out["config"]["weights_layout"].startswith("reference")
+    for key in ("roofline_factored_layout", "other_series"):
         assert out[key]["value"] > 0 and 0 < out[key]["frac"] < 1
-    assert out["roofline_reference_layout"]["weights_layout_factored"] is False and out["other_series"]["series"] == "model"
+    assert out["roofline_factored_layout"]["weights_layout_factored"] is True and out["other_series"]["series"] == "model"
     assert out["post_correct_scaling"]["n1_source"] == "this run" and out["post_correct_scaling"]["C5"]["speedup_vs_n1"] == 1.0
     # the same batch under the contract's choices, inside `config` (round-4 review 6a)
-    assert 0 < out["config"]["reference_layout_frac"] < 1 and 0 < out["config"]["contract_series_frac"] < 1
+    assert 0 < out["config"]["factored_layout_frac"] < 1 and 0 < out["config"]["contract_series_frac"] < 1
     # projected strong scaling: one rank's share of the job at 1 / 2 / 4 / 8 ranks, measured on this GPU (round-4 review 1c)
     pj = out["post_correct_scaling"]["projected"]
     assert pj["ranks"] == [1, 2, 4, 8] and "before the collective" in pj["what"]

@@ -375,3 +375,118 @@ def test_nonlinear_and_sde_is_mcmc_and_the_sde_state_sampler_through_the_shim(R)
     _after(R)
     assert list(st) == ["alpha", "weights"]
     assert np.array_equal(st["weights"], r["weights"]) and np.array_equal(st["alpha"], r["alpha"])
+
+
+# ---------------------------------------------------------------- round 6: the pseudo-marginal / delayed-acceptance chains and R_milstein
+def _chain_equal(out, ref, output_type, log_theta=False):
+    want = {1: ["alpha", "theta", "counts", "acceptance_rate", "S", "posterior"],
+            2: ["alphahat", "Vt", "theta", "counts", "acceptance_rate", "S", "posterior"],
+            3: ["theta", "counts", "acceptance_rate", "S", "posterior"]}[output_type]
+    assert list(out) == want                                                        # src/R_mcmc.cpp:207-232 (no weights / modes)
+    assert np.array_equal(np.exp(out["theta"]) if log_theta else out["theta"], ref["theta"])
+    assert np.array_equal(out["counts"], ref["counts"].astype(float)) and np.array_equal(out["posterior"], ref["posterior"])
+    assert out["acceptance_rate"][0] == ref["acceptance_rate"] and np.array_equal(np.tril(out["S"]), np.tril(ref["S"]))
+    if output_type == 1:
+        assert out["alpha"].shape == ref["alpha"].shape and np.array_equal(out["alpha"], ref["alpha"])
+    if output_type == 2:
+        assert np.array_equal(out["alphahat"], ref["alphahat"]) and np.array_equal(out["Vt"], ref["Vt"])
+
+
+@pytest.mark.parametrize("mcmc_type", ["pm", "da"])
+@pytest.mark.parametrize("output_type,method", [(1, "psi"), (2, "bsf"), (3, "psi")])
+def test_nongaussian_pm_and_da_mcmc_through_the_shim(R, mcmc_type, output_type, method):
+    """.Call('_bssm_nongaussian_pm_mcmc' / '_bssm_nongaussian_da_mcmc', model_, output_type, nsim, iter, burnin, thin, gamma,
+    target_acceptance, S, seed, end_ram, n_threads, sampling_method, model_type, verbose) as R/run_mcmc.R:497-522 calls them
+    (src/R_mcmc.cpp:167-327): the device-resident plan filters once per iteration.  Against run_mcmc() of the Python mirror -- the
+    same bssm_run_mcmc call with the same seed: theta, counts, posterior, S, acceptance rate and the state outputs bit for bit."""
+    from bssm_amd import mcmc
+    y = np.asarray(ZOO["poisson_slope_missing"]["y"])
+    mdl = M.bsm_ng(y, sd_level=M.halfnormal(0.3, 1), sd_slope=M.halfnormal(0.05, 0.5), distribution="poisson", P1=np.diag([1.0, 0.1]), a1=[1.0, 0.0])
+    it, burn, nsim, seed = 120, 60, 32, 41
+    ot = {1: "full", 2: "summary", 3: "theta"}[output_type]
+    ref = mcmc.run_mcmc(mdl, iter=it, particles=nsim, output_type=ot, mcmc_type=mcmc_type, sampling_method=method, burnin=burn, seed=seed)
+    lst = r_model_list(mdl)
+    th0 = np.log(np.maximum(0.001, np.asarray(mdl["theta"], dtype=float)))            # R/run_mcmc.R:471-489
+    lst["theta"] = th0
+    S0 = np.diag(0.1 * np.maximum(0.1, np.abs(th0)))
+    out = R.call("_bssm_nongaussian_%s_mcmc" % mcmc_type, lst, output_type, nsim, it, burn, 1, 2 / 3, 0.234, S0, seed, False, 1,
+                 1 if method == "psi" else 2, M.model_type(mdl), False)
+    _after(R)
+    _chain_equal(out, ref, output_type, log_theta=True)
+
+
+def test_ssm_ung_closures_in_the_pm_chain_through_the_shim(R):
+    """ssm_ung with update_fn / prior_fn (model_type 1, src/R_mcmc.cpp:195-199): the chain calls the R closures once per
+    iteration -- Python functions behind the mock -- through bssm_run_mcmc's callbacks"""
+    from bssm_amd import mcmc
+    base = ZOO["negbin_m4"]
+    R0, phi0 = np.array(base["R"], dtype=float).reshape(4, 4), float(base["phi"])
+    mdl = M.BssmModel(base.classes, **{**base, "update_fn": (lambda th: dict(R=(R0 * np.exp(th[0])).reshape(4, 4, 1), phi=phi0 * np.exp(th[1]))),
+                                       "prior_fn": (lambda th: -0.5 * float(th @ th)), "theta": np.array([0.1, -0.2])})
+    it, burn, nsim, seed = 60, 30, 32, 9
+    ref = mcmc.run_mcmc(mdl, iter=it, particles=nsim, output_type="theta", mcmc_type="pm", sampling_method="bsf", burnin=burn, seed=seed)
+    th0 = np.asarray(mdl["theta"], dtype=float)
+    S0 = np.diag(0.1 * np.maximum(0.1, np.abs(th0)))
+    out = R.call("_bssm_nongaussian_pm_mcmc", r_model_list(mdl), 3, nsim, it, burn, 1, 2 / 3, 0.234, S0, seed, False, 1, 2, M.model_type(mdl), False)
+    _after(R)
+    _chain_equal(out, ref, 3)
+
+
+@pytest.mark.parametrize("mcmc_type,method,output_type", [("pm", "psi", 1), ("pm", "bsf", 2), ("pm", "ekf", 3), ("da", "psi", 3), ("da", "bsf", 1)])
+def test_nonlinear_pm_and_da_mcmc_through_the_shim(R, mcmc_type, method, output_type):
+    """.Call('_bssm_nonlinear_pm_mcmc' / '_da_mcmc', y, Z, H, T, R, Zg, Tg, a1, P1, theta, log_prior_pdf, known_params,
+    known_tv_params, time_varying, n_states, n_etas, seed, nsim, iter, burnin, thin, gamma, target_acceptance, S, end_ram,
+    n_threads, max_iter, conv_tol, sampling_method, iekf_iter, output_type, verbose): src/R_mcmc.cpp:550-668"""
+    from bssm_amd import mcmc
+    g = _growth(n=30)
+    prior = M.example_log_prior("nlg_growth")
+    it, burn, nsim, seed = 80, 40, 32, 17
+    ot = {1: "full", 2: "summary", 3: "theta"}[output_type]
+    ref = mcmc.run_mcmc(g, iter=it, particles=nsim, output_type=ot, mcmc_type=mcmc_type, sampling_method=method, burnin=burn, seed=seed)
+    th0 = np.asarray(g["theta"], dtype=float)
+    S0 = np.diag(0.1 * np.maximum(0.1, np.abs(th0)))
+    a = _nlg_args(R, g, prior=lambda th: float(prior(th)))
+    out = R.call("_bssm_nonlinear_%s_mcmc" % mcmc_type, *a[:13], a[15], a[13], a[14], seed, nsim, it, burn, 1, 2 / 3, 0.234, S0, False, 1,
+                 100, 1e-8, {"psi": 1, "bsf": 2, "ekf": 4}[method], 0, output_type, False)
+    _after(R)
+    _chain_equal(out, ref, output_type)
+
+
+def test_sde_pm_da_mcmc_and_milstein_through_the_shim(R):
+    """.Call('_bssm_sde_pm_mcmc', <8>, theta, nsim, L, seed, iter, burnin, thin, gamma, target_acceptance, S, end_ram, type, verbose)
+    (src/R_sde.cpp:134-178), '_bssm_sde_da_mcmc' with (L_c, L_f) (:180-219) and '_bssm_R_milstein' (src/R_milstein.cpp:4-22)"""
+    from bssm_amd import mcmc
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    n = 20
+    y = np.exp(np.cumsum(rng.normal(0.01, 0.05, n)))
+    sde = M.ssm_sde(y, "sde_gbm", theta=np.array([0.02, 0.2, 0.6]), x0=1.0, positive=True)
+    sprior = M.example_log_prior("sde_gbm")
+    drift = R.extptr(bssm_amd_model_id=np.asarray([sde["model_id"]], dtype=np.int32))
+    lp = R.extptr(bssm_amd_prior_fn=lambda th: float(sprior(th)))
+    sargs = [y, 1.0, True, drift, R.extptr(), R.extptr(), lp, R.extptr()]
+    th0 = np.asarray(sde["theta"], dtype=float)
+    S0 = np.diag(0.1 * np.maximum(0.1, np.abs(th0)))
+    it, burn, nsim, seed = 80, 40, 32, 5
+    ref = mcmc.run_mcmc(sde, iter=it, particles=nsim, output_type="full", mcmc_type="pm", burnin=burn, seed=seed, L_f=3)
+    out = R.call("_bssm_sde_pm_mcmc", *sargs, th0, nsim, 3, seed, it, burn, 1, 2 / 3, 0.234, S0, False, 1, False)
+    _after(R)
+    _chain_equal(out, ref, 1)
+    ref = mcmc.run_mcmc(sde, iter=it, particles=nsim, output_type="summary", mcmc_type="da", burnin=burn, seed=seed, L_c=2, L_f=4)
+    out = R.call("_bssm_sde_da_mcmc", *sargs, th0, nsim, 2, 4, seed, it, burn, 1, 2 / 3, 0.234, S0, False, 2, False)
+    _after(R)
+    _chain_equal(out, ref, 2)
+    # R_milstein(x0, L, t, theta, drift, diffusion, ddiffusion, positive, seed): the device path against the oracle's restatement of
+    # milstein() (src/milstein.cpp:18-48) on the same stream, for the filters' unit interval and for another terminal time
+    for model_name, th, pos in (("sde_gbm", np.array([0.05, 0.3, 0.1]), True), ("sde_poisson_ou", np.array([-0.5, 1.0, -1.0]), False)):
+        mdl = M.ssm_sde(y, model_name, theta=th, x0=1.3, positive=pos)
+        dr = R.extptr(bssm_amd_model_id=np.asarray([mdl["model_id"]], dtype=np.int32))
+        for L_, t_end, sd in ((3, 1.0, 7), (5, 2.5, 8), (0, 0.25, 9)):
+            x = R.call("_bssm_R_milstein", 1.3, L_, t_end, th, dr, R.extptr(), R.extptr(), pos, sd)
+            _after(R)
+            assert x[0] == F.milstein(mdl, L_, t=t_end, seed=sd)
+            want = O.milstein({**mdl, "L": L_}, t_end, seed=sd)
+            assert abs(x[0] - want) <= 1e-12 * max(1.0, abs(want)), (model_name, L_, t_end, x[0], want)
+    # t = 1 is the prior draw of particle 0 of the bootstrap filter with that seed (src/model_ssm_sde.cpp:25-28)
+    bf = F.bootstrap_filter(sde, 64, seed=7, L=3)
+    assert F.milstein(sde, 3, t=1.0, seed=7) == bf["alpha"][0, 0, 0]

@@ -233,7 +233,9 @@ def test_shim_source_is_well_formed():
                 "_bssm_loglik_sde": 12, "_bssm_nongaussian_loglik": 5, "_bssm_nonlinear_loglik": 22, "_bssm_suggest_n_nongaussian": 6,
                 "_bssm_suggest_n_nonlinear": 20, "_bssm_postcorrection_nongaussian": 10, "_bssm_postcorrection_nonlinear": 24,
                 "_bssm_stratified_sample": 3, "_bssm_nongaussian_is_mcmc": 17, "_bssm_nonlinear_is_mcmc": 34, "_bssm_sde_is_mcmc": 24,
-                "_bssm_sde_state_sampler_bsf_is2": 13}
+                "_bssm_sde_state_sampler_bsf_is2": 13, "_bssm_nongaussian_pm_mcmc": 15, "_bssm_nongaussian_da_mcmc": 15,
+                "_bssm_nonlinear_pm_mcmc": 32, "_bssm_nonlinear_da_mcmc": 32, "_bssm_sde_pm_mcmc": 21, "_bssm_sde_da_mcmc": 22,
+                "_bssm_R_milstein": 9}
     for name, nargs in expected.items():
         assert re.search(r"ENTRY\(%s, %d\)" % (name, nargs), src), (name, nargs)
         # the definition takes exactly that many SEXP arguments
@@ -422,7 +424,10 @@ def test_shim_registry_matches_the_reference_call_table():
             "_bssm_nonlinear_loglik": 22, "_bssm_suggest_n_nongaussian": 6, "_bssm_suggest_n_nonlinear": 20,
             "_bssm_postcorrection_nongaussian": 10, "_bssm_postcorrection_nonlinear": 24, "_bssm_stratified_sample": 3,
             "_bssm_nongaussian_is_mcmc": 17, "_bssm_nonlinear_is_mcmc": 34, "_bssm_sde_is_mcmc": 24,
-            "_bssm_sde_state_sampler_bsf_is2": 13}
+            "_bssm_sde_state_sampler_bsf_is2": 13,
+            # round 6: the pseudo-marginal / delayed-acceptance chains (src/RcppExports.cpp:1306-1310, 1330-1331) and R_milstein (:1313)
+            "_bssm_nongaussian_pm_mcmc": 15, "_bssm_nongaussian_da_mcmc": 15, "_bssm_nonlinear_pm_mcmc": 32,
+            "_bssm_nonlinear_da_mcmc": 32, "_bssm_sde_pm_mcmc": 21, "_bssm_sde_da_mcmc": 22, "_bssm_R_milstein": 9}
     assert R.L.mockr_registered_count() == len(want)
     for name, nargs in want.items():
         fn, got = R.registered(name)
