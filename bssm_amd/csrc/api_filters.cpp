@@ -1042,6 +1042,12 @@ bool jit_private_dir(const std::string& path) {
   return (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
 
+// mkdir -p with mode 0700, by mkdir(2): nothing of the path reaches a shell
+void make_private_dirs(const std::string& path) {
+  for (size_t at = 1; at <= path.size(); at++)
+    if (at == path.size() || path[at] == '/') (void)mkdir(path.substr(0, at).c_str(), 0700);
+}
+
 // the translation unit hiprtc sees: the snippet, then the kernel templates (device view of the headers: __HIPCC_RTC__)
 std::string jit_translation_unit(const JitModel& jm) {
   return "#define BSSM_USER_MODEL 1\n#define BSSM_FN __device__ inline\n"
@@ -1079,7 +1085,10 @@ hipFunction_t jit_kernel(JitModel& jm, const std::string& name, std::string* err
   const std::string co_path = cache.empty() ? std::string() : cache + "/jit_" + hbuf + ".hsaco", ln_path = co_path + ".name";
   std::vector<char> code;
   std::string lowered;
-  if (!co_path.empty() && jit_private_dir(cache) && jit_private_file(co_path) && jit_private_file(ln_path)) {
+  bool from_cache = false;
+  for (int attempt = 0; attempt < 2; attempt++) {   // (a second pass only when a CACHED code object failed to load: it is deleted and compiled again)
+  code.clear(); lowered.clear(); from_cache = false;
+  if (attempt == 0 && !co_path.empty() && jit_private_dir(cache) && jit_private_file(co_path) && jit_private_file(ln_path)) {
     if (FILE* cf = std::fopen(co_path.c_str(), "rb")) {
       std::fseek(cf, 0, SEEK_END); const long sz = std::ftell(cf); std::fseek(cf, 0, SEEK_SET);
       code.resize(sz > 0 ? (size_t)sz : 0);
@@ -1089,6 +1098,7 @@ hipFunction_t jit_kernel(JitModel& jm, const std::string& name, std::string* err
     if (FILE* nf = std::fopen(ln_path.c_str(), "r")) { char nb[512] = {0}; if (std::fgets(nb, sizeof nb, nf)) lowered = nb; std::fclose(nf); }
     while (!lowered.empty() && (lowered.back() == '\n' || lowered.back() == ' ')) lowered.pop_back();
     if (lowered.empty()) code.clear();
+    from_cache = !code.empty();
   }
   if (code.empty()) {
     const double t0 = now_ms();
@@ -1117,14 +1127,15 @@ hipFunction_t jit_kernel(JitModel& jm, const std::string& name, std::string* err
     (void)hiprtcDestroyProgram(&prog);
     if (bssm::opt().trace) std::fprintf(stderr, "[bssm_amd] hiprtc: %s in %.0f ms (%zu bytes)\n", name.c_str(), now_ms() - t0, cs);
     if (!co_path.empty()) {  // best effort: a cache that cannot be written only costs the next process a recompile
-      (void)std::system(("mkdir -p -m 0700 '" + cache + "' 2>/dev/null").c_str());
-      if (jit_private_dir(cache) && cache.find_first_of("'\"\\\n") == std::string::npos) {
-        const std::string tmp = co_path + ".tmp." + std::to_string((long)getpid());
+      make_private_dirs(cache);   // mkdir(2), no shell: the path comes from the environment (BSSM_AMD_USER_CACHE / HOME)
+      if (jit_private_dir(cache)) {
+        const std::string pid = "." + std::to_string((long)getpid());
+        const std::string tmp = co_path + ".tmp" + pid, ln_tmp = ln_path + ".tmp" + pid;   // (ranks compiling the same variant at once: a file each)
         if (FILE* cf = std::fopen(tmp.c_str(), "wb")) {
           const bool okw = std::fwrite(code.data(), 1, code.size(), cf) == code.size();
           std::fclose(cf);
           (void)chmod(tmp.c_str(), 0600);
-          if (FILE* nf = std::fopen((ln_path + ".tmp").c_str(), "w")) { std::fputs(lowered.c_str(), nf); std::fclose(nf); (void)chmod((ln_path + ".tmp").c_str(), 0600); (void)std::rename((ln_path + ".tmp").c_str(), ln_path.c_str()); }
+          if (FILE* nf = std::fopen(ln_tmp.c_str(), "w")) { std::fputs(lowered.c_str(), nf); std::fclose(nf); (void)chmod(ln_tmp.c_str(), 0600); (void)std::rename(ln_tmp.c_str(), ln_path.c_str()); }
           if (okw) (void)std::rename(tmp.c_str(), co_path.c_str()); else (void)std::remove(tmp.c_str());
         }
       }
@@ -1132,13 +1143,19 @@ hipFunction_t jit_kernel(JitModel& jm, const std::string& name, std::string* err
   }
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, lowered.c_str()) != hipSuccess) {
-    (void)hipGetLastError();
-    *err = "loading the compiled user-model kernel failed: " + name;
-    return nullptr;
+  if (hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(&fn, mod, lowered.c_str()) == hipSuccess) {
+    jm.kernels[key] = fn;
+    return fn;
   }
-  jm.kernels[key] = fn;
-  return fn;
+  (void)hipGetLastError();
+  if (mod) (void)hipModuleUnload(mod);
+  if (!from_cache) break;
+  // a stale or corrupt cache entry must not fail every later process: drop it and take the compile path
+  (void)std::remove(co_path.c_str());
+  (void)std::remove(ln_path.c_str());
+  }
+  *err = "loading the compiled user-model kernel failed: " + name;
+  return nullptr;
 }
 
 JitModel* jit_of(int slot) { return slot >= 1 && slot <= 63 ? g_jit[slot] : nullptr; }
@@ -1240,6 +1257,10 @@ int bssm_user_model_jit(const char* source, int32_t n_states) {
   const std::string src(source);
   const bool sde = src.find("BSSM_USER_SDE") != std::string::npos, nlg = src.find("BSSM_USER_NLG") != std::string::npos;
   if (sde == nlg) return fail(BSSM_ERR_INVALID, "the snippet must define exactly one of BSSM_USER_NLG and BSSM_USER_SDE");
+  {  // the same snippet again (the R shim asks on every filter call): the slot it already has, as bssm_user_model_load does by path
+    std::lock_guard<std::mutex> lk(g_user_mu);
+    for (int q = 1; q < 64; q++) if (g_jit[q] && g_jit[q]->n_states == n_states && g_jit[q]->source == src) return q;
+  }
   auto* jm = new JitModel();
   jm->source = src; jm->n_states = n_states; jm->MP = bssm::pad_dim(n_states); jm->fn_id = sde ? bssm::FN_USER_SDE : bssm::FN_USER_NLG;
   // the smallest workgroup-resident variant now: a snippet that does not compile fails HERE, with the compiler's log, and a first
@@ -1249,6 +1270,7 @@ int bssm_user_model_jit(const char* source, int32_t n_states) {
   std::string err;
   if (!jit_kernel(*jm, name, &err)) { delete jm; return fail(BSSM_ERR_INVALID, err); }
   std::lock_guard<std::mutex> lk(g_user_mu);
+  for (int q = 1; q < 64; q++) if (g_jit[q] && g_jit[q]->n_states == n_states && g_jit[q]->source == src) { delete jm; return q; }  // (a concurrent first call won)
   const int slot = bssm::register_user_launchers(jit_launch_wg, jit_launch_grid);
   if (slot < 1) { delete jm; return fail(BSSM_ERR_UNSUPPORTED, "too many user models loaded"); }
   g_jit[slot] = jm;

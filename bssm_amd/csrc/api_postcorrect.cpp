@@ -93,7 +93,8 @@ struct ChunkTables {
   hipEvent_t ready = nullptr;
   StageBuf stage, okst;   // pinned input staging (alive until the copies have run) and the kernel's per-draw ok flags
   DevBuf in_a, in_b;      // ung / mng: packed draws and their transpose
-  ~ChunkTables() { if (ready) (void)hipEventDestroy(ready); }
+  // (an early error return may drop the last reference while the set-up kernels still run: nothing goes back to the arena under them)
+  ~ChunkTables() { if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); } }
   // device thread: wait for the set-up kernel, mark failed draws, give the work arrays back
   // device thread, in front of the chunk's filters: the filter stream waits for the set-up kernel ON THE DEVICE -- the host goes
   // on to enqueue the filter launches under it (round 5: a host-side wait here cost the 293-draw shard ~0.1 ms of idle device
@@ -329,7 +330,11 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
           // for the tail's row-family workgroups on every CU.  The tail's launch sequence goes on a stream of its own, forked from and joined
           // to the chunk's stream.  BSSM_AMD_TAIL_CONCURRENT=0: the tail behind the round, as before.
           hipStream_t tstream = nullptr;
-          hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+          struct EventGuard {   // destroyed on every path out of this block, early error returns included
+            hipEvent_t e = nullptr;
+            ~EventGuard() { if (e) (void)hipEventDestroy(e); }
+          } g_fork, g_join;
+          hipEvent_t &ev_fork = g_fork.e, &ev_join = g_join.e;
           bool conc = bssm::opt().tail_concurrent && head.F > 0 && tail > 0 && bssm::tail_overlap_available();
           if (conc) {
             static thread_local bssm::TlsStream tail_stream;   // (at the highest stream priority: measured, no difference)
@@ -381,10 +386,7 @@ int run_is_core(IsCore& J, int lo, int hi, double* weights, double* loglik, doub
             HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(ev_join, tstream));
             HIP_TRY(hipStreamWaitEvent(nullptr, ev_join, 0));
-            (void)hipEventDestroy(ev_join);
-            (void)hipEventDestroy(ev_fork);
           } else {
-            if (ev_fork) (void)hipEventDestroy(ev_fork);
             if (int rc2 = launch_wg_part(0, head.F, false)) return rc2;
             if (int rc2 = launch_tail(nullptr)) return rc2;
           }

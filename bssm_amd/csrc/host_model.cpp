@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -22,18 +23,44 @@ constexpr double kEps = std::numeric_limits<double>::epsilon();
 constexpr double kPi = 3.14159265358979323846;
 
 // ------------------------------------------------------------------ tiny dense matrix
-// Inline storage (no heap): the psi set-up builds thousands of these per draw, and with a std::vector behind each
-// one the allocator was most of the set-up time.  64 x 64 covers the largest state dimension the kernels support;
-// copies move only the r * c entries in use.
+// Small matrices live inline (no heap): the psi set-up builds thousands of these per draw, and with a std::vector behind each one
+// the allocator was most of the set-up time.  Round 6: 16 x 16 inline (every model of up to 16 states -- 2 KB per Mat instead of the
+// 32 KB a 64 x 64 inline array cost EVERY model: ~1 MB of stack per set-up thread, a page touched per m x 1 vector); larger ones
+// (seasonal components of period 24 / 52, R/models.R:995-997) spill to the heap.  Copies move only the r * c entries in use.
 struct Mat {
-  static constexpr int kMaxElems = 64 * 64;  // (round 5: states of up to 64 dimensions -- seasonal components of period 24 / 52, R/models.R:995-997; nothing beyond r * c is initialised or copied)
+  static constexpr int kInline = 16 * 16;
   int r = 0, c = 0;
-  double a[kMaxElems];
+  double* a = inl;
+  double inl[kInline];
+  std::unique_ptr<double[]> heap;
+  void room(int n) {   // storage for n entries; the old contents are not kept
+    if (n > kInline) { heap.reset(new double[(size_t)n]); a = heap.get(); }
+    else { heap.reset(); a = inl; }
+  }
   Mat() {}
-  Mat(int r_, int c_) : r(r_), c(c_) { for (int i = 0; i < r * c; i++) a[i] = 0.0; }
-  Mat(int r_, int c_, const double* src) : r(r_), c(c_) { std::memcpy(a, src, sizeof(double) * (size_t)(r * c)); }
-  Mat(const Mat& o) : r(o.r), c(o.c) { std::memcpy(a, o.a, sizeof(double) * (size_t)(r * c)); }
-  Mat& operator=(const Mat& o) { r = o.r; c = o.c; std::memcpy(a, o.a, sizeof(double) * (size_t)(r * c)); return *this; }
+  Mat(int r_, int c_) : r(r_), c(c_) { room(r * c); for (int i = 0; i < r * c; i++) a[i] = 0.0; }
+  Mat(int r_, int c_, const double* src) : r(r_), c(c_) { room(r * c); std::memcpy(a, src, sizeof(double) * (size_t)(r * c)); }
+  Mat(const Mat& o) : r(o.r), c(o.c) { room(r * c); std::memcpy(a, o.a, sizeof(double) * (size_t)(r * c)); }
+  Mat(Mat&& o) noexcept : r(o.r), c(o.c) {
+    if (o.heap) { heap = std::move(o.heap); a = heap.get(); }
+    else std::memcpy(inl, o.inl, sizeof(double) * (size_t)(r * c));
+    o.r = o.c = 0; o.a = o.inl;
+  }
+  Mat& operator=(const Mat& o) {
+    if (this == &o) return *this;
+    if (o.size() != size() || o.size() <= kInline) room(o.size());
+    r = o.r; c = o.c;
+    std::memcpy(a, o.a, sizeof(double) * (size_t)(r * c));
+    return *this;
+  }
+  Mat& operator=(Mat&& o) noexcept {
+    if (this == &o) return *this;
+    r = o.r; c = o.c;
+    if (o.heap) { heap = std::move(o.heap); a = heap.get(); }
+    else { heap.reset(); a = inl; std::memcpy(inl, o.inl, sizeof(double) * (size_t)(r * c)); }
+    o.r = o.c = 0; o.a = o.inl;
+    return *this;
+  }
   int size() const { return r * c; }
   double& operator()(int i, int j) { return a[i + r * j]; }
   double operator()(int i, int j) const { return a[i + r * j]; }
@@ -321,7 +348,20 @@ bool smoother_ccov(const Sys& S, const Approx& ap, std::vector<Mat>* at, std::ve
   return true;
 }
 
-// src/conditional_dist.cpp:4-31 (use_svd = true)
+// src/conditional_dist.cpp:4-31 (use_svd = true).  Round 6: factor columns whose singular value is at the rounding level of the
+// subtraction that formed the matrix -- s_c <= eps m trace(Vt[t] before the subtraction) -- are ZERO (the rule and its reason: the header
+// of orc_conditional_cov in oracle/bssm_oracle.c; LgSmoother<M>::cond_step and the factor kernels apply the same cut)
+namespace {
+void factor_with_cut(const Mat& U, const std::vector<double>& s, double tr, Mat* out) {
+  const int m = U.r;
+  const double thr = kEps * m * tr;
+  for (int c = 0; c < m; c++) {
+    const double f = s[c] > thr ? std::sqrt(s[c]) : 0.0;
+    for (int i = 0; i < m; i++) (*out)(i, c) = f == 0.0 ? 0.0 : U(i, c) * f;
+  }
+}
+double mat_trace(const Mat& A) { double t = 0.0; for (int i = 0; i < A.r; i++) t += A(i, i); return t; }
+}  // namespace
 void conditional_cov(std::vector<Mat>* Vt, std::vector<Mat>* Ct) {
   const int n1 = (int)Vt->size(), m = (*Vt)[0].r;
   Mat U;
@@ -334,13 +374,15 @@ void conditional_cov(std::vector<Mat>* Vt, std::vector<Mat>* Ct) {
       for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) W(i, j) += U(i, c) * U(j, c) / s[c];
     }
     const Mat tmp = tr((*Ct)[t - 1]) * W;
+    const double trc = mat_trace((*Vt)[t]);
     (*Vt)[t] = (*Vt)[t] - tmp * (*Ct)[t - 1];
     (*Ct)[t] = tmp;
     sym_singular((*Vt)[t], &U, &s);
-    for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) (*Vt)[t](i, c) = U(i, c) * std::sqrt(s[c]);
+    factor_with_cut(U, s, trc, &(*Vt)[t]);
   }
+  const double tr0 = mat_trace((*Vt)[0]);
   sym_singular((*Vt)[0], &U, &s);
-  for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) (*Vt)[0](i, c) = U(i, c) * std::sqrt(s[c]);
+  factor_with_cut(U, s, tr0, &(*Vt)[0]);
 }
 
 // Fixed-size fast paths of smoother_ccov + conditional_cov and of fast_smoother for univariate observations and

@@ -232,6 +232,251 @@ struct LgFactorRows {
     }
   }
 
+
+  // ================================================================================================================================
+  // Round 6: the THIN path of a time point t >= 1.  The two decompositions of conditional_cov are what the set-up of 17 ... 64 states
+  // spends its time in (2.9 ms per (draw, time point) at 53 states: 72 % of a seasonal post-correction), and neither needs a full Jacobi:
+  //   * pinv(V_{t-1}) only ever multiplies the cross-covariance.  V_{t-1} is a smoothed covariance, positive definite unless a state is
+  //     deterministic: a diagonal-pivoted Cholesky factor (rank-revealing: a pivot below eps m x the first one ends it) and two triangular
+  //     solves per column of the cross-covariance give pinv(V_{t-1}) C_{t-1} in ~3 m^2 LDS operations per lane instead of ~10 sweeps
+  //     of m - 1 rotation steps;  a rank-deficient V_{t-1} takes the full path below, decomposition and all (same numbers as before);
+  //   * Var(alpha_t | alpha_{t-1}, y) has the rank of the noise of one step (3 of 53 for bsm_ng(period = 52)): a pivoted Cholesky factor
+  //     L (m x r, r <= RT = 4; more: the full path) and the eigen-decomposition of the r x r Gram matrix L'L = Q diag(lambda) Q' give
+  //     U sqrt(s) = L Q directly -- the same columns the full decomposition finds for the non-zero part, and EXACT zeros where it returns
+  //     rounding noise (the cut every implementation applies since round 6: oracle/bssm_oracle.c, orc_conditional_cov).
+  // Wave 0 does the sequential parts (the other waves keep the barriers); the products use every wave's columns.
+  static constexpr int RT = 4;
+  __device__ LG_INL static bool thin_enabled() {
+#ifdef LGF_NO_THIN
+    return false;
+#else
+    return M >= 16;
+#endif
+  }
+  // sum of va-published diagonal entries (ascending): every lane passes the diagonal element it holds (or anything where it holds none)
+  __device__ LG_INL double trace_of(const double mine) {
+    __syncthreads();
+    if (r >= j0 && r < j0 + JW) va[r] = (r < mr) ? mine : 0.0;
+    __syncthreads();
+    double tr = 0.0;
+    for (int i = 0; i < M; i++) tr += va[i];
+    __syncthreads();
+    return tr;
+  }
+  // symmetric part of the matrix whose row r (this wave's columns of it) is passed in, into slot X
+  __device__ LG_INL void store_sym(const double (&row)[JW]) {
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = row[jj];
+    __syncthreads();
+    double sym[JW];
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) sym[jj] = 0.5 * (row[jj] + A[(j0 + jj) * LD + r]);
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = sym[jj];
+    __syncthreads();
+  }
+  // Diagonal-pivoted Cholesky of the symmetric matrix in slot X: `steps` columns of the factor into slot Y (W[i][j]: rows in their own
+  // order, column j belongs to pivot j; columns behind the rank are zero), the pivot rows into vc[0 ... rank).  A pivot that is not
+  // above the threshold (relative to the first pivot, or absolute) ends the factor; the loop keeps its trip count.  Returns the rank.
+  __device__ LG_INL int pivoted_cholesky(const int steps, const double thr, const bool relative) {
+    double dg = (r < mr) ? A[r * LD + r] : -1.0;
+    bool picked = r >= mr, open = true;
+    int rank = 0;
+    double thr_abs = thr;
+    for (int j = 0; j < steps; j++) {
+      double* buf = (j & 1) ? vb : va;   // (two buffers: a wave may still scan the previous step's while wave 0 publishes this one's)
+      if (w == 0) buf[r] = picked ? -1.0 : dg;
+      __syncthreads();
+      int best = 0;
+      double dmax = buf[0];
+      for (int i = 1; i < M; i++) { const double v = buf[i]; if (v > dmax) { dmax = v; best = i; } }
+      if (j == 0 && relative) thr_abs = thr * dmax;
+      open = open && dmax > thr_abs;
+      rank += open ? 1 : 0;
+      if (w == 0) {
+        double l = 0.0;
+        if (open) {
+          double c = A[r * LD + best];
+          for (int k = 0; k < j; k++) c -= W[r * LD + k] * W[best * LD + k];
+          l = picked ? 0.0 : c / sqrt(dmax);
+          if (r == best) { l = sqrt(dmax); picked = true; }
+          vc[j] = (double)best;
+        }
+        W[r * LD + j] = l;
+        dg -= l * l;
+      }
+    }
+    __syncthreads();
+    return rank;
+  }
+  // Returns whether THIS GROUP's matrices need the full path (a singular V_{t-1}, or more than RT noise directions): a property of the
+  // draw alone -- which draws share a workgroup must not show in anybody's bits (the result of a post-correction call is the same for
+  // every device list).  Every group runs all of it (the barriers are the workgroup's); a group that needs the full path writes nothing
+  // here, the others write their results and their `bad` flag.
+  __device__ LG_INL bool thin_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d, int* bad_out) {
+    int bad = 0;
+    double row[JW], cout[JW];
+    // ---- pinv(V_{t-1}) C_{t-1} by a pivoted Cholesky factor
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) row[jj] = Pt[((size_t)(t - 1) * MM + r + M * (j0 + jj)) * es + d];
+    store_sym(row);
+    const int rank1 = pivoted_cholesky(mr, kEps * mr, true);
+    bool need_full = rank1 < mr;   // a singular V_{t-1}: what follows is computed (on a factor with zero columns: not finite) and discarded
+    const int pr = (r < mr) ? min(max((int)vc[r], 0), M - 1) : r;   // the row of the matrix that is pivot r (clamped: places behind the rank of a singular matrix hold stale values)
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) row[jj] = (r < mr) ? W[pr * LD + j0 + jj] : 0.0;
+    __syncthreads();   // every lane has read its pivot row of the factor (and vc)
+    if (w == 0 && r < mr) vd[pr] = (double)r;      // inverse permutation: the place of row pr
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = row[jj];    // slot X: the factor with its rows in pivot order (lower triangular)
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) W[r * LD + j0 + jj] = (r < mr) ? cc[((size_t)(t - 1) * MM + pr + M * (j0 + jj)) * es + d] : 0.0;  // slot Y: C_{t-1}, rows in pivot order
+    __syncthreads();
+    if (w == 0 && r < mr) {   // lane c solves column c: forward, then backward substitution, in place
+      const int c = r;
+      for (int a = 0; a < mr; a++) {
+        double acc = W[a * LD + c];
+        for (int k = 0; k < a; k++) acc -= A[a * LD + k] * W[k * LD + c];
+        W[a * LD + c] = acc / A[a * LD + a];
+      }
+      for (int a = mr - 1; a >= 0; a--) {
+        double acc = W[a * LD + c];
+        for (int k = a + 1; k < mr; k++) acc -= A[k * LD + a] * W[k * LD + c];
+        W[a * LD + c] = acc / A[a * LD + a];
+      }
+    }
+    __syncthreads();
+    // C_t = (pinv(V_{t-1}) C_{t-1})': element [r][j] is the solution's [place of j][r]
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) {
+      const int j = j0 + jj;
+      const int pl = min(max((int)vd[j], 0), M - 1);
+      cout[jj] = (r < mr && j < mr) ? W[pl * LD + r] : 0.0;
+    }
+    // ---- Var(alpha_t | alpha_{t-1}, y) = V_t - C_t C_{t-1}: the cross-covariance again (rows in pivot order) into slot X
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = (r < mr) ? cc[((size_t)(t - 1) * MM + pr + M * (j0 + jj)) * es + d] : 0.0;
+    __syncthreads();
+    {
+      double acc[JW];
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) acc[jj] = 0.0;
+#pragma unroll 2
+      for (int a = 0; a < mr; a++) {
+        const double y = W[a * LD + r];
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++) acc[jj] += y * A[a * LD + j0 + jj];
+      }
+      double dgc = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) {
+        const double pt = Pt[((size_t)t * MM + r + M * (j0 + jj)) * es + d];
+        if (j0 + jj == r) dgc = pt;
+        row[jj] = (r < mr) ? pt - acc[jj] : 0.0;
+      }
+      const double trc = trace_of(dgc);
+      const double thr = kEps * mr * trc;
+      store_sym(row);
+      const int rank2 = pivoted_cholesky(RT + 1, thr, false);
+      need_full = need_full || rank2 > RT;   // more noise directions than the thin form takes
+      // ---- Gram matrix of the factor's RT columns (every lane the same sums), its eigen-decomposition by cyclic Jacobi in registers
+      double g[RT][RT], q[RT][RT];
+#pragma unroll
+      for (int a = 0; a < RT; a++)
+#pragma unroll
+        for (int b = 0; b < RT; b++) { g[a][b] = 0.0; q[a][b] = a == b ? 1.0 : 0.0; }
+      for (int i = 0; i < mr; i++) {
+        double l[RT];
+#pragma unroll
+        for (int a = 0; a < RT; a++) l[a] = W[i * LD + a];
+#pragma unroll
+        for (int a = 0; a < RT; a++)
+#pragma unroll
+          for (int b = a; b < RT; b++) g[a][b] += l[a] * l[b];
+      }
+#pragma unroll
+      for (int a = 0; a < RT; a++)
+#pragma unroll
+        for (int b = 0; b < a; b++) g[a][b] = g[b][a];
+      for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0, dgs = 0.0;
+#pragma unroll
+        for (int b = 0; b < RT; b++) {
+#pragma unroll
+          for (int a = 0; a < b; a++) off += g[a][b] * g[a][b];
+          dgs += g[b][b] * g[b][b];
+        }
+        if (off < 1e-300 || off < 1e-60 * dgs) break;
+#pragma unroll
+        for (int p = 0; p < RT - 1; p++)
+#pragma unroll
+          for (int qq = p + 1; qq < RT; qq++) {
+            const double apq = g[p][qq];
+            if (apq == 0.0) continue;
+            const double tau = (g[qq][qq] - g[p][p]) / (2.0 * apq);
+            const double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = tt * cs;
+#pragma unroll
+            for (int i = 0; i < RT; i++) { const double x = g[i][p], y = g[i][qq]; g[i][p] = cs * x - sn * y; g[i][qq] = sn * x + cs * y; }
+#pragma unroll
+            for (int i = 0; i < RT; i++) { const double x = g[p][i], y = g[qq][i]; g[p][i] = cs * x - sn * y; g[qq][i] = sn * x + cs * y; }
+#pragma unroll
+            for (int i = 0; i < RT; i++) { const double x = q[i][p], y = q[i][qq]; q[i][p] = cs * x - sn * y; q[i][qq] = sn * x + cs * y; }
+          }
+      }
+      // eigenvalues in stable descending order (ranks), this row of L Q in that order
+      double lam[RT], f[RT], lam_at[RT];
+#pragma unroll
+      for (int a = 0; a < RT; a++) lam[a] = fabs(g[a][a]);
+      double lrow[RT];
+#pragma unroll
+      for (int a = 0; a < RT; a++) lrow[a] = (r < mr) ? W[r * LD + a] : 0.0;
+#pragma unroll
+      for (int c = 0; c < RT; c++) { f[c] = 0.0; lam_at[c] = 0.0; }
+#pragma unroll
+      for (int a = 0; a < RT; a++) {
+        int rk = 0;
+#pragma unroll
+        for (int b = 0; b < RT; b++) rk += (lam[b] > lam[a] || (lam[b] == lam[a] && b < a)) ? 1 : 0;
+        double fa = 0.0;
+#pragma unroll
+        for (int b = 0; b < RT; b++) fa += lrow[b] * q[b][a];
+#pragma unroll
+        for (int c = 0; c < RT; c++) if (rk == c) { f[c] = fa; lam_at[c] = lam[a]; }
+      }
+      // sign of every column: its largest component positive (the first of equals)
+      __syncthreads();   // every lane is through with the factor's columns in slot Y and with the Jacobi matrix in slot X
+      if (w == 0) {
+#pragma unroll
+        for (int c = 0; c < RT; c++) A[r * LD + c] = f[c];
+      }
+      __syncthreads();
+      double sg[RT];
+#pragma unroll
+      for (int c = 0; c < RT; c++) {
+        int big = 0;
+        for (int i = 1; i < M; i++) if (fabs(A[i * LD + c]) > fabs(A[big * LD + c])) big = i;
+        sg[c] = A[big * LD + c] < 0 ? -1.0 : 1.0;
+      }
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) {
+        const int j = j0 + jj;
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < RT; c++) if (j == c && lam_at[c] > thr) v = sg[c] * f[c];
+        if (!need_full && !skip) {
+          Vout[((size_t)t * MM + r + M * j) * es + d] = v;
+          Cout[((size_t)t * MM + r + M * j) * es + d] = cout[jj];
+          bad |= !lg_finite(v) || !lg_finite(cout[jj]);
+        }
+      }
+    }
+    *bad_out = bad;
+    return need_full && !skip;   // (a draw that has already failed is discarded whatever is computed for it)
+  }
+
   // conditional_cov at time point t of draw d (arrays draw-interleaved, element k at ptr[k * es + d]); returns whether everything written is finite
   __device__ LG_INL bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d) {
     int bad = 0;
@@ -240,16 +485,26 @@ struct LgFactorRows {
     const unsigned long long lgf_t0 = __builtin_readcyclecounter();
 #endif
     if (t == 0) {
+      double dg0 = 0.0;
 #pragma unroll
-      for (int jj = 0; jj < JW; jj++) row[jj] = Pt[(size_t)(r + M * (j0 + jj)) * es + d];
+      for (int jj = 0; jj < JW; jj++) { row[jj] = Pt[(size_t)(r + M * (j0 + jj)) * es + d]; if (j0 + jj == r) dg0 = row[jj]; }
+      const double tr0 = trace_of(dg0);
       sym_singular(row);
 #pragma unroll
       for (int jj = 0; jj < JW; jj++) {
-        const double v = A[r * LD + j0 + jj] * sqrt(vd[j0 + jj]);
+        const double sv = vd[j0 + jj];
+        const double v = sv > kEps * mr * tr0 ? A[r * LD + j0 + jj] * sqrt(sv) : 0.0;   // (the cut of orc_conditional_cov, oracle/bssm_oracle.c)
         Vout[(size_t)(r + M * (j0 + jj)) * es + d] = v;
         bad |= !lg_finite(v);
       }
       return reduce_bad(bad);
+    }
+    bool mine_full = true;   // this group's results come from the full path below
+    int bad_thin = 0;
+    if (thin_enabled()) {
+      mine_full = thin_step(t, Pt, cc, Vout, Cout, es, d, &bad_thin);
+      if (!__syncthreads_or(mine_full)) return reduce_bad(bad_thin);
+      // some group of the workgroup needs the full path: every group runs it (barriers), only those groups store its results
     }
 #pragma unroll
     for (int jj = 0; jj < JW; jj++) row[jj] = Pt[((size_t)(t - 1) * MM + r + M * (j0 + jj)) * es + d];
@@ -278,8 +533,7 @@ struct LgFactorRows {
     prod_xy(row);
 #pragma unroll
     for (int jj = 0; jj < JW; jj++) {
-      Cout[((size_t)t * MM + r + M * (j0 + jj)) * es + d] = row[jj];
-      bad |= !lg_finite(row[jj]);
+      if (mine_full) { Cout[((size_t)t * MM + r + M * (j0 + jj)) * es + d] = row[jj]; bad |= !lg_finite(row[jj]); }
     }
     // Vc - tmp Cp: tmp's rows into X, the cross-covariance's rows into Y
     __syncthreads();   // every lane is through with W2 and with the operand rows
@@ -291,19 +545,25 @@ struct LgFactorRows {
     for (int jj = 0; jj < JW; jj++) W[r * LD + j0 + jj] = row[jj];
     __syncthreads();
     prod_xy(row);
+    double dgc = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < JW; jj++) row[jj] = Pt[((size_t)t * MM + r + M * (j0 + jj)) * es + d] - row[jj];
+    for (int jj = 0; jj < JW; jj++) {
+      const double pt = Pt[((size_t)t * MM + r + M * (j0 + jj)) * es + d];
+      if (j0 + jj == r) dgc = pt;
+      row[jj] = pt - row[jj];
+    }
+    const double trc = trace_of(dgc);
     sym_singular(row);
 #pragma unroll
     for (int jj = 0; jj < JW; jj++) {
-      const double v = A[r * LD + j0 + jj] * sqrt(vd[j0 + jj]);
-      Vout[((size_t)t * MM + r + M * (j0 + jj)) * es + d] = v;
-      bad |= !lg_finite(v);
+      const double sv = vd[j0 + jj];
+      const double v = sv > kEps * mr * trc ? A[r * LD + j0 + jj] * sqrt(sv) : 0.0;
+      if (mine_full) { Vout[((size_t)t * MM + r + M * (j0 + jj)) * es + d] = v; bad |= !lg_finite(v); }
     }
 #ifdef LGF_STATS
     if (threadIdx.x == 0) { atomicAdd(&lgf_stats[3], (unsigned long long)(__builtin_readcyclecounter() - lgf_t0)); atomicAdd(&lgf_stats[4], 1ull); }
 #endif
-    return reduce_bad(bad);
+    return reduce_bad(mine_full ? bad : bad_thin);
   }
 
   // any lane of the group bad -> false in every lane of the group

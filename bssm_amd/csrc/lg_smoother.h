@@ -179,10 +179,14 @@ struct LgSmoother {
   LG_HD LG_INL static bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es) {
     double U[MM], s[M], W[MM], Vp[MM], Vc[MM], Cp[MM], tmp[MM], tmp2[MM];
     int bad = 0;
+    // (round 6: factor columns with s_c <= eps M trace(the covariance before the subtraction) are zero -- the rule of
+    // oracle/bssm_oracle.c: orc_conditional_cov, host_model.cpp: conditional_cov)
     if (t == 0) {
       ldv(Pt, es, MM, Vp);
+      double tr0 = 0.0;
+      for (int i = 0; i < M; i++) tr0 += Vp[i + M * i];
       sym_singular(Vp, U, s);
-      for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vp[i + M * c] = U[i + M * c] * sqrt(s[c]);
+      for (int c = 0; c < M; c++) { const double f = s[c] > kEps * M * tr0 ? sqrt(s[c]) : 0.0; for (int i = 0; i < M; i++) Vp[i + M * c] = f == 0.0 ? 0.0 : U[i + M * c] * f; }
       stv(Vout, es, MM, Vp);
       for (int q = 0; q < MM; q++) bad |= !lg_finite(Vp[q]);
       return bad == 0;
@@ -198,11 +202,13 @@ struct LgSmoother {
     }
     mul_at(Cp, W, tmp);       // tr(Ct[t-1]) * W
     mul(tmp, Cp, tmp2);
+    double trc = 0.0;
+    for (int i = 0; i < M; i++) trc += Vc[i + M * i];
     for (int q = 0; q < MM; q++) Vc[q] = Vc[q] - tmp2[q];
     stv(Cout + (size_t)t * MM * es, es, MM, tmp);
     for (int q = 0; q < MM; q++) bad |= !lg_finite(tmp[q]);
     sym_singular(Vc, U, s);
-    for (int c = 0; c < M; c++) for (int i = 0; i < M; i++) Vc[i + M * c] = U[i + M * c] * sqrt(s[c]);
+    for (int c = 0; c < M; c++) { const double f = s[c] > kEps * M * trc ? sqrt(s[c]) : 0.0; for (int i = 0; i < M; i++) Vc[i + M * c] = f == 0.0 ? 0.0 : U[i + M * c] * f; }
     stv(Vout + (size_t)t * MM * es, es, MM, Vc);
     for (int q = 0; q < MM; q++) bad |= !lg_finite(Vc[q]);
     return bad == 0;

@@ -653,7 +653,23 @@ static void sym_svd(const double *Ain, int m, double *U, double *s) {
   }
 }
 
-/* conditional_dist.cpp:4-31 */
+/* conditional_dist.cpp:4-31.
+ * ONE documented deviation (round 6), at the level of the reference's own rounding noise: Var(alpha_t | alpha_{t-1}, y) is formed by the
+ * subtraction Vt.slice(t) -= tmp * Ct.slice(t-1) (:18), whose rounding error is ~eps * |Vt.slice(t)|; where that covariance is singular
+ * (fewer noise terms than states: bsm_ng with a seasonal component has rank 3 of 25 / 53) the decomposition of :21-23 returns the null
+ * directions with "singular values" of that size, and U * sqrt(s) carries them as columns of norm ~1e-8 -- in arbitrary, LAPACK- and
+ * summation-order-dependent directions (measured here: 3e-8 ... 8e-8 of a factor whose real columns have norm 1e-2 ... 1e-1).  Columns with
+ * s_c <= eps * m * trace(Vt.slice(t) before the subtraction) -- the rule of :15 applied at the magnitude the subtraction can resolve --
+ * are set to ZERO here, in the product's host code (csrc/host_model.cpp) and in its kernels, so that all three agree to rounding instead
+ * of to 1e-7; the kept columns are untouched.  The same rule at t = 0 (a singular smoothed covariance of the first time point). */
+static void factor_with_cut(const double *U, const double *s, int m, double tr, double *out) {
+  const double thr = ORC_EPS * m * tr;
+  for (int c = 0; c < m; c++) {
+    const double f = s[c] > thr ? sqrt(s[c]) : 0.0;
+    for (int i = 0; i < m; i++) out[i + m * c] = f == 0.0 ? 0.0 : U[i + m * c] * f;
+  }
+}
+static double mat_trace(const double *A, int m) { double t = 0.0; for (int i = 0; i < m; i++) t += A[i + m * i]; return t; }
 void orc_conditional_cov(double *Vt, double *Ct, int m, int n1) {
   const int mm = m * m;
   double U[ORC_MAXM * ORC_MAXM], s[ORC_MAXM], W[ORC_MAXM * ORC_MAXM], tmp[ORC_MAXM * ORC_MAXM], A[ORC_MAXM * ORC_MAXM];
@@ -669,13 +685,15 @@ void orc_conditional_cov(double *Vt, double *Ct, int m, int n1) {
     }
     mat_mul_at(Cp, W, m, m, m, tmp); /* Ct(t-1)' * W */
     mat_mul(tmp, Cp, m, m, m, A);
+    const double tr = mat_trace(Vc, m);
     for (int q = 0; q < mm; q++) Vc[q] -= A[q];
     memcpy(Cc, tmp, sizeof(double) * mm);
     sym_svd(Vc, m, U, s);
-    for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) Vc[i + m * c] = U[i + m * c] * sqrt(s[c]);
+    factor_with_cut(U, s, m, tr, Vc);
   }
+  const double tr0 = mat_trace(Vt, m);
   sym_svd(Vt, m, U, s);
-  for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) Vt[i + m * c] = U[i + m * c] * sqrt(s[c]);
+  factor_with_cut(U, s, m, tr0, Vt);
 }
 
 /* ------------------------------------------------------------------ */

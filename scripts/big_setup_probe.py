@@ -1,6 +1,6 @@
 """psi set-up of bsm_ng draws with 25 (period 24) and 53 (period 52) states: the device set-up (padded to 32 / 64, lg_smoother_wave.h +
 lg_factors_rows.h) beside the host set-up -- differences of the log-likelihoods and the time of a post-correction call.
-Usage (GPU box): python scripts/big_setup_probe.py [draws ...]  -> gpurun_out/r05_big_setup.txt"""
+Usage (GPU box): python scripts/big_setup_probe.py [draws ...]  -> gpurun_out/r06_big_setup.txt"""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np  # noqa: E402
 from bssm_amd import filters as F, models as M, post_correct as PC  # noqa: E402
 
-out = open(os.path.join(root, "gpurun_out", "r05_big_setup.txt"), "w") if os.path.isdir(os.path.join(root, "gpurun_out")) else None
+out = open(os.path.join(root, "gpurun_out", "r06_big_setup.txt"), "w") if os.path.isdir(os.path.join(root, "gpurun_out")) else None
 
 
 def say(s):
