@@ -399,8 +399,9 @@ struct DeviceBatch {
   // workspace of the one-launch-per-step families: the row family when BSSM_AMD_FORCE_PATH=row asks for it and the batch has such
   // kernels (pf_row_step.h; otherwise it is reached through the tail split of a post-correction chunk only), else the step kernels
   int alloc_step_workspace() {
-    // (states of more than 16 dimensions -- pf_big.h -- have no other step shape than the row family: up to 16 384 particles)
-    if (fb.MP >= 32 && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "nsim above 16384 is not supported for states of more than 16 dimensions");
+    // (states of more than 16 dimensions -- pf_big.h -- have no other step shape than the row family: up to 102 400 particles since round 6;
+    // the reference's front-end stops at 1e5, R/check_arguments.R:407-418)
+    if (fb.MP >= 32 && !bssm::row_filter_supported(fb)) return fail(BSSM_ERR_UNSUPPORTED, "nsim above 102400 is not supported for states of more than 16 dimensions");
     // (a user model compiled in process takes the row family wherever it reaches -- one kernel variant to compile instead of one per particles-per-lane)
     if ((bssm::opt().force_path == 3 || fb.MP >= 32 || bssm::user_slot_rows_only(fb.user_slot)) && bssm::row_filter_supported(fb)) {
       HIP_TRY(ws.alloc(bssm::row_workspace_bytes(fb)));

@@ -137,12 +137,17 @@ int bssm_plan_sample_or_summarise(bssm_plan* plan, int32_t filter, uint32_t seed
     for (int t = 0; t <= n; t++) for (int c = 0; c < m; c++) alpha[t + (size_t)(n + 1) * c] = tr[(size_t)t * m + c];
   }
   if (alphahat || Vt) {
-    if (m > 8) return fail(BSSM_ERR_UNSUPPORTED, "summaries of the plan's particle system: m <= 8");
-    DevBuf d_b, d_mean, d_cov;
-    HIP_TRY(d_b.alloc((size_t)N * sizeof(uint32_t)));
+    DevBuf d_b, d_mean, d_cov, d_smooth;
     HIP_TRY(d_mean.alloc((size_t)(n + 1) * m * sizeof(double)));
     HIP_TRY(d_cov.alloc((size_t)(n + 1) * m * m * sizeof(double)));
-    HIP_TRY(bssm::launch_smooth_summary(hist, idx, d_b.as<uint32_t>(), d_mean.as<double>(), d_cov.as<double>(), 1, n, m, N, st));
+    if (m <= 8) {   // the fused back-trace + summary kernel
+      HIP_TRY(d_b.alloc((size_t)N * sizeof(uint32_t)));
+      HIP_TRY(bssm::launch_smooth_summary(hist, idx, d_b.as<uint32_t>(), d_mean.as<double>(), d_cov.as<double>(), 1, n, m, N, st));
+    } else {        // up to 64 states (round 6): filter_smoother into a work copy, then summary (src/filter_smoother.cpp:5-18, src/summary.cpp:4-17), as the smoother entry points do
+      HIP_TRY(d_smooth.alloc((size_t)(n + 1) * m * N * sizeof(double)));
+      HIP_TRY(bssm::launch_backtrace(hist, idx, d_smooth.as<double>(), 1, n, m, N, st));
+      HIP_TRY(bssm::launch_summary(d_smooth.as<double>(), d_mean.as<double>(), d_cov.as<double>(), 1, n + 1, m, N, st));
+    }
     if (alphahat) HIP_TRY(hipMemcpyAsync(alphahat, d_mean.p, d_mean.bytes, hipMemcpyDeviceToHost, st));
     if (Vt) HIP_TRY(hipMemcpyAsync(Vt, d_cov.p, d_cov.bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -291,6 +291,7 @@ struct LgFactorRows {
       __syncthreads();
       int best = 0;
       double dmax = buf[0];
+#pragma unroll 16
       for (int i = 1; i < M; i++) { const double v = buf[i]; if (v > dmax) { dmax = v; best = i; } }
       if (j == 0 && relative) thr_abs = thr * dmax;
       open = open && dmax > thr_abs;
@@ -298,8 +299,17 @@ struct LgFactorRows {
       if (w == 0) {
         double l = 0.0;
         if (open) {
-          double c = A[r * LD + best];
-          for (int k = 0; k < j; k++) c -= W[r * LD + k] * W[best * LD + k];
+          // (four partial sums: the loads of a step are independent, the subtractions of one sum are not)
+          double c0 = A[r * LD + best], c1 = 0.0, c2 = 0.0, c3 = 0.0;
+          int k = 0;
+          for (; k + 4 <= j; k += 4) {
+            c0 -= W[r * LD + k] * W[best * LD + k];
+            c1 -= W[r * LD + k + 1] * W[best * LD + k + 1];
+            c2 -= W[r * LD + k + 2] * W[best * LD + k + 2];
+            c3 -= W[r * LD + k + 3] * W[best * LD + k + 3];
+          }
+          for (; k < j; k++) c0 -= W[r * LD + k] * W[best * LD + k];
+          const double c = (c0 + c1) + (c2 + c3);
           l = picked ? 0.0 : c / sqrt(dmax);
           if (r == best) { l = sqrt(dmax); picked = true; }
           vc[j] = (double)best;
@@ -337,14 +347,28 @@ struct LgFactorRows {
     if (w == 0 && r < mr) {   // lane c solves column c: forward, then backward substitution, in place
       const int c = r;
       for (int a = 0; a < mr; a++) {
-        double acc = W[a * LD + c];
-        for (int k = 0; k < a; k++) acc -= A[a * LD + k] * W[k * LD + c];
-        W[a * LD + c] = acc / A[a * LD + a];
+        double s0 = W[a * LD + c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = 0;
+        for (; k + 4 <= a; k += 4) {
+          s0 -= A[a * LD + k] * W[k * LD + c];
+          s1 -= A[a * LD + k + 1] * W[(k + 1) * LD + c];
+          s2 -= A[a * LD + k + 2] * W[(k + 2) * LD + c];
+          s3 -= A[a * LD + k + 3] * W[(k + 3) * LD + c];
+        }
+        for (; k < a; k++) s0 -= A[a * LD + k] * W[k * LD + c];
+        W[a * LD + c] = ((s0 + s1) + (s2 + s3)) / A[a * LD + a];
       }
       for (int a = mr - 1; a >= 0; a--) {
-        double acc = W[a * LD + c];
-        for (int k = a + 1; k < mr; k++) acc -= A[k * LD + a] * W[k * LD + c];
-        W[a * LD + c] = acc / A[a * LD + a];
+        double s0 = W[a * LD + c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = a + 1;
+        for (; k + 4 <= mr; k += 4) {
+          s0 -= A[k * LD + a] * W[k * LD + c];
+          s1 -= A[(k + 1) * LD + a] * W[(k + 1) * LD + c];
+          s2 -= A[(k + 2) * LD + a] * W[(k + 2) * LD + c];
+          s3 -= A[(k + 3) * LD + a] * W[(k + 3) * LD + c];
+        }
+        for (; k < mr; k++) s0 -= A[k * LD + a] * W[k * LD + c];
+        W[a * LD + c] = ((s0 + s1) + (s2 + s3)) / A[a * LD + a];
       }
     }
     __syncthreads();

@@ -20,7 +20,8 @@
 // Everything that involves more than one particle is pf_canon.h, so the two shapes below give the same bits for a filter:
 //   pf_big_wg        one workgroup per filter, particle system in LDS, one wave per row of 64 particles (N <= 512 at MP = 32,
 //                    <= 256 at MP = 64), the whole time loop in one launch, 3 workgroup barriers per step;
-//   pf_big_row_step  one wave per row, particle system in HBM, one launch per time step (N <= 16 384), the exchange of pf_row_step.h.
+//   pf_big_row_step  one wave per row, particle system in HBM, one launch per time step, the exchange of pf_row_step.h (N <= 16 384 with the row
+//                    prefixes in registers; up to 102 400 -- the reference's front-end stops at 1e5 -- with the prefixes in LDS: round 6).
 // fp64 MFMA and fp64 VALU have the same peak on MI355X (78.6 TFLOP/s): the matrix cores buy the operand delivery (no m^2 scalar
 // operands per particle) and the registers (64 accumulators per lane at MP = 64 instead of three arrays of 64), not flops.
 #pragma once
@@ -322,11 +323,48 @@ __global__ void __launch_bounds__(ROW_NT) pf_big_row_init(const FilterBatch b, c
   row_publish(b, ws, f, g, j, j < N, 0, w, lane);
 }
 
-template <int MB, int LD = 16 * MB>
+// Round 6: filters of more than 16 384 particles (the reference's front-end takes up to 1e5 for any model, R/check_arguments.R:407-418;
+// src/model_ssm_ung.cpp:611 has no limit).  The canonical arithmetic (pf_canon.h) is defined for any number of rows; what ends at 256 rows is
+// the REGISTER form of the row prefixes (ROW_NP slots per lane).  The WIDE form keeps them in LDS -- Q (inclusive scaled prefix), I (1 / scale)
+// and the scale of every row, up to BIG_WIDE_ROWS rows = 102 400 particles -- built by wave 0 slot by slot exactly as canon_combine does (one
+// wave scan per 64 rows on top of the running total), and every lane finds its source row by a bisection over Q instead of ballots.
+constexpr int BIG_WIDE_ROWS = 1600;
+// (M, S) of the time-t weights and the three per-row tables from the (M_row, S_row) partials; wave 0 calls it, every lane of it
+__device__ __forceinline__ void big_wide_combine(const double* __restrict__ part, const int B, double* sQ, double* sI, double* sSC, double* sMS, const int lane) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  double mx = -INFINITY;
+  for (int k0 = 0; k0 < B; k0 += 64) { const int g = k0 + lane; if (g < B) mx = fmax(mx, part[2 * g]); }
+  const double M = wave_max_key(mx);
+  double run = 0.0;
+  for (int k0 = 0; k0 < B; k0 += 64) {
+    const int g = k0 + lane;
+    double pm = -INFINITY, ps = 0.0;
+    if (g < B) { const d2 pp = *(const d2*)(part + 2 * g); pm = pp.x; ps = pp.y; }
+    const double sc = fast_exp(pm - M);   // rows beyond B: 0; a poisoned (NaN) partial makes S NaN
+    const double Qk = wave_scan_incl(canon_opaque(ps * sc));
+    const double Q = k0 == 0 ? Qk : run + Qk;
+    if (g < B) { sQ[g] = Q; sI[g] = 1.0 / sc; sSC[g] = sc; }
+    run = lane_broadcast(Q, 63);
+  }
+  if (lane == 0) { sMS[0] = M; sMS[1] = run; }
+}
+// source row of target v: #{g : Q_g < v}, clamped; the target in that row's own scale (canon_source_row's result for one lane)
+__device__ __forceinline__ void big_wide_source(const double v, const int B, const double* sQ, const double* sI, int& e, double& vp) {
+  int lo = 0, len = B;   // first index with Q >= v
+  while (len > 0) {
+    const int half = len >> 1;
+    if (sQ[lo + half] < v) { lo += half + 1; len -= half + 1; } else len = half;
+  }
+  e = min(lo, B - 1);
+  const double Pm1 = e > 0 ? sQ[e - 1] : 0.0;
+  vp = canon_opaque(v - Pm1) * sI[e];
+}
+
+template <int MB, int LD = 16 * MB, bool WIDE = false>
 __global__ void __launch_bounds__(ROW_NT, big_row_occupancy(MB)) pf_big_row_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   constexpr int MP = LD;
   __shared__ double s_win[4 * ROW_WIN];
-  __shared__ double s_comb[3 * ROW_NP * 64 + 2];  // the combine of wave 0 (pf_canon.h: canon_publish)
+  __shared__ double s_comb[WIDE ? 3 * BIG_WIDE_ROWS + 2 : 3 * ROW_NP * 64 + 2];  // the combine of wave 0 (pf_canon.h: canon_publish; WIDE: Q | I | scale | M, S)
   __shared__ double s_tiles[4 * 256];
   __shared__ int s_ancs[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i16 = lane & 15;
@@ -337,16 +375,22 @@ __global__ void __launch_bounds__(ROW_NT, big_row_occupancy(MB)) pf_big_row_step
   const bool has_row = g < B, act = has_row && j < N;
   const int ncnt_step = b.psi ? m : b.k;
   const double* __restrict__ lcdf = ws.lcdf + ((size_t)(t & 1) * b.F + f) * N;
-  if (wave == 0) row_combine_publish(ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2, B, s_comb, lane);
+  double* const wQ = s_comb, * const wI = s_comb + (WIDE ? BIG_WIDE_ROWS : 0), * const wSC = s_comb + (WIDE ? 2 * BIG_WIDE_ROWS : 0), * const wMS = s_comb + (WIDE ? 3 * BIG_WIDE_ROWS : 0);
+  if (wave == 0) {
+    if constexpr (WIDE) big_wide_combine(ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2, B, wQ, wI, wSC, wMS, lane);
+    else row_combine_publish(ws.partials + ((size_t)(t & 1) * b.F + f) * B * 2, B, s_comb, lane);
+  }
   const u32x4 blk = rng_step_block(key, (uint32_t)t, (uint32_t)j);
   const uint32_t uword = rng_resample_word_rt(ncnt_step, key, (uint32_t)t, (uint32_t)j, blk);
   math_tab_load_end256(mtab);
   lds_barrier();  // (1) the only workgroup barrier of the step
-  const CanonPrefix<ROW_NP> px = canon_prefix_load<ROW_NP>(s_comb, lane, B);
-  const double M = canon_published_M<ROW_NP>(s_comb), S = canon_published_S<ROW_NP>(s_comb);
+  CanonPrefix<ROW_NP> px;
+  double M, S, wscale_g;
+  if constexpr (WIDE) { M = wMS[0]; S = wMS[1]; wscale_g = has_row ? wSC[g] : 0.0; px.B = B; }
+  else { px = canon_prefix_load<ROW_NP>(s_comb, lane, B); M = canon_published_M<ROW_NP>(s_comb); S = canon_published_S<ROW_NP>(s_comb); wscale_g = canon_published_scale<ROW_NP>(s_comb, g); }
   if (b.weights && act) {  // the stored weights of time t are exp(w - M_row): to the scale of the whole time point (also on a degenerate step, :676-682)
     double* __restrict__ wt = b.weights + ((size_t)f * (n + 1) + t) * N;
-    wt[j] = wt[j] * canon_published_scale<ROW_NP>(s_comb, g);
+    wt[j] = wt[j] * wscale_g;
   }
   if (!(S > 0.0)) {
     if (has_row && lane == 0) {
@@ -361,7 +405,21 @@ __global__ void __launch_bounds__(ROW_NT, big_row_occupancy(MB)) pf_big_row_step
   const double c_scale = canon_stratum(S, N);
   if (g == B - 1 && lane == 63) ws.llinc[(size_t)f * (n + 1) + t] = canon_llinc(M, c_scale);
 
-  const CanonSource src = canon_source_row(canon_target(uword, j, c_scale), act, px, lane);
+  CanonSource src;
+  if constexpr (WIDE) {
+    // the 64 slots of a wave are consecutive, so their targets (and source rows) increase along the lanes: the first and the last active
+    // lane bound the rows the wave draws from
+    const double v = canon_target(uword, j, c_scale);
+    src = CanonSource{0, 0.0, 0, -1};
+    const unsigned long long amask = __builtin_amdgcn_ballot_w64(act);
+    if (amask != 0ull) {
+      big_wide_source(v, B, wQ, wI, src.e, src.vp);
+      src.c_lo = __builtin_amdgcn_readlane(src.e, __builtin_ctzll(amask));
+      src.c_hi = __builtin_amdgcn_readlane(src.e, 63 - __builtin_clzll(amask));
+    }
+  } else {
+    src = canon_source_row(canon_target(uword, j, c_scale), act, px, lane);
+  }
   double* sw = s_win + wave * ROW_WIN;
   int anc = 0;
   for (int r0 = src.c_lo; r0 <= src.c_hi; r0 += 4) {  // wave-uniform bounds
@@ -408,6 +466,13 @@ template <int MB, int LD = 16 * MB>
 hipError_t launch_big_row(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing) {
   constexpr int MP = LD;
   if (b.MP != MP || b.fpar || b.KP % 4 != 0 || b.KP < 4 || b.KP > MP) return hipErrorInvalidValue;
+  if constexpr (LD == 16 * MB) {
+    if (ws.B > ROW_MAX_ROWS) {   // more than 16 384 particles: the row prefixes in LDS (round 6)
+      if (ws.B > BIG_WIDE_ROWS) return hipErrorInvalidValue;
+      { char nm[96]; std::snprintf(nm, sizeof nm, "pf_big_row_step<%d,wide>", MB); note_filter_kernel(nm); }
+      return launch_row_loop(b, ws, stream, timing, pf_big_row_step<MB, LD, true>, pf_big_row_init<MB, LD>, BIG_WIDE_ROWS);
+    }
+  }
   { char nm[96]; if (LD == 16 * MB) std::snprintf(nm, sizeof nm, "pf_big_row_step<%d>", MB); else std::snprintf(nm, sizeof nm, "pf_big_row_step<%d,%d>", MB, LD); note_filter_kernel(nm); }
   return launch_row_loop(b, ws, stream, timing, pf_big_row_step<MB, LD>, pf_big_row_init<MB, LD>);
 }

@@ -139,7 +139,9 @@ void grid_workspace_carve(const FilterBatch& b, void* base, GridWorkspace* ws) {
 }
 
 bool row_filter_supported(const FilterBatch& b) {
-  if (b.N > CANON_ROW * ROW_MAX_ROWS || b.N < 1) return false;
+  if (b.N < 1) return false;
+  if (b.MP >= 32 && !b.fpar && b.N <= CANON_ROW * BIG_WIDE_ROWS) return true;   // (pf_big.h: up to 102 400 particles with the row prefixes in LDS, round 6)
+  if (b.N > CANON_ROW * ROW_MAX_ROWS) return false;
   if (b.fpar) return b.MP == b.KP && (b.user_slot > 0 ? b.MP <= 16 : b.MP <= 2);
   if (opt().force_path == 3 && b.MP == 8 && b.KP % 4 == 0) return true;  // EXPERIMENT hook only (pf_filter_impl.h launch_grid_mk): not bit-identical to pf_wg_kernel
   return b.MP <= 4 || b.MP >= 32;  // (eight- and sixteen-dimensional states: pf_wg_kernel's matrix-core transitions sum in another order)

@@ -242,8 +242,9 @@ auto row_fn_kernels(int psi, void (**init)(const FilterBatch, const GridWorkspac
 
 // the time loop of the row family: one launch per step
 inline hipError_t launch_row_loop(const FilterBatch& b, const GridWorkspace& ws, hipStream_t stream, StepTiming* timing,
-                                  void (*kern)(const FilterBatch, const GridWorkspace, const int), void (*kern_init)(const FilterBatch, const GridWorkspace)) {
-  if (b.N > CANON_ROW * ROW_MAX_ROWS || ws.chunk != CANON_ROW || ws.B != (b.N + CANON_ROW - 1) / CANON_ROW) return hipErrorInvalidValue;
+                                  void (*kern)(const FilterBatch, const GridWorkspace, const int), void (*kern_init)(const FilterBatch, const GridWorkspace),
+                                  const int max_rows = ROW_MAX_ROWS) {
+  if (b.N > CANON_ROW * max_rows || ws.chunk != CANON_ROW || ws.B != (b.N + CANON_ROW - 1) / CANON_ROW) return hipErrorInvalidValue;
   hipError_t e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.llinc, 0, sizeof(double) * b.F * (b.n + 1), stream)) != hipSuccess) return e;

@@ -69,9 +69,9 @@ def test_psi_apf_and_smoother_of_a_seasonal_model_against_the_oracle(oracle, mon
         monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
         out = F.particle_smoother(model, N, method="psi", seed=5, return_indices=True)
         assert np.array_equal(out["indices"], ref["indices"]), path
-        assert abs(out["logLik"] - ref["logLik"]) <= 1e-8 * n, (path, out["logLik"], ref["logLik"])
-        assert _rel(out["alphahat"], mean.T[:n]) <= 1e-7, path
-        assert _rel(out["Vt"], cov[:, :, :n]) <= 1e-6, path
+        assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n, (path, out["logLik"], ref["logLik"])
+        assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8, path
+        assert _rel(out["Vt"], cov[:, :, :n]) <= 1e-7, path
 
 
 @pytest.mark.parametrize("period", [24, 52])
@@ -138,19 +138,23 @@ def test_post_correction_of_a_seasonal_model(oracle, monkeypatch):
     mo = dict(theta=theta, counts=counts, modes=modes, posterior=np.full(ns, -3.0), output_type=2)
     one = PC.post_correct(model, mo, 64, threads=4, is_type="is2", seed=5)
     ref = oracle.is_correction(arrs, 64, 5, method=1, counts=counts, modes=modes, is_type=2, output_type=2, n_threads=2)
-    assert np.allclose(one["loglik"], ref["loglik"], rtol=0, atol=1e-8 * n)
-    assert np.allclose(one["weights"], ref["weights"], rtol=1e-6)
-    # (the psi set-up of these draws runs on the device since late round 5 -- states padded to 32, lg_smoother_wave.h + lg_factors_rows.h: the
-    # seasonal model's smoothing covariances are singular, and their factors amplify the device's FMA contraction to ~1e-7 of the state scale,
-    # as for the monthly seasonal of tests/test_gpu_postcorrect.py; the host set-up keeps the tight bounds below)
-    assert np.allclose(one["alphahat"], ref["alphahat"].T, rtol=1e-6, atol=2e-7)
-    assert np.allclose(one["Vt"], ref["Vt"], rtol=1e-6, atol=2e-7)
+    # (the psi set-up of these draws runs on the device -- states padded to 32, lg_smoother_wave.h + lg_factors_rows.h.  Round 5 held it to
+    # 1e-8 n / 2e-7: the seasonal model's conditional covariances are singular, and every implementation returned their null directions as
+    # factor columns of rounding noise, each its own.  Since round 6 those columns are zero everywhere (oracle/bssm_oracle.c:
+    # orc_conditional_cov) and the device meets the contract's bar, 1e-9 n, like the host set-up below)
+    assert np.allclose(one["loglik"], ref["loglik"], rtol=0, atol=1e-9 * n)
+    assert np.allclose(one["weights"], ref["weights"], rtol=1e-7)
+    # (means and covariances: 1e-8 absolute on states of size ~2 -- the device takes pinv(V_{t-1}) C_{t-1} from a pivoted Cholesky factor, the
+    # oracle from the decomposition: two backward-stable routes that differ by cond(V_{t-1}) eps, 1e-9 here; the host set-up below follows
+    # the oracle's route and keeps 1e-9)
+    assert np.allclose(one["alphahat"], ref["alphahat"].T, rtol=1e-7, atol=1e-8)
+    assert np.allclose(one["Vt"], ref["Vt"], rtol=1e-6, atol=1e-8)
     two = PC.post_correct(model, mo, 64, threads=4, is_type="is2", seed=5, devices=[0, 0])
     for key in ("weights", "alphahat", "Vt"):
         assert np.array_equal(one[key], two[key]), key
     monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", "0")
     host = PC.post_correct(model, mo, 64, threads=4, is_type="is2", seed=5)
-    assert np.allclose(host["loglik"], ref["loglik"], rtol=0, atol=1e-8 * n)
+    assert np.allclose(host["loglik"], ref["loglik"], rtol=0, atol=1e-9 * n)
     assert np.allclose(host["weights"], ref["weights"], rtol=1e-7)
     assert np.allclose(host["alphahat"], ref["alphahat"].T, rtol=1e-7, atol=1e-9)
     assert np.allclose(host["Vt"], ref["Vt"], rtol=1e-6, atol=1e-9)
@@ -228,9 +232,9 @@ def test_device_set_up_of_big_states_time_varying_and_a_failing_draw(oracle, mon
     for dev in ("2", "0"):
         monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
         res[dev] = PC.post_correct(model, mo, 48, threads=2, is_type="is2", seed=4)
-        assert np.allclose(res[dev]["loglik"], ref["loglik"], rtol=0, atol=1e-8 * n)
-        assert np.allclose(res[dev]["weights"], ref["weights"], rtol=1e-6)
-        assert np.allclose(res[dev]["alphahat"], ref["alphahat"].T, rtol=1e-6, atol=1e-6)
+        assert np.allclose(res[dev]["loglik"], ref["loglik"], rtol=0, atol=1e-9 * n)
+        assert np.allclose(res[dev]["weights"], ref["weights"], rtol=1e-7)
+        assert np.allclose(res[dev]["alphahat"], ref["alphahat"].T, rtol=1e-7, atol=1e-8 if dev == "2" else 1e-9)
     # a draw that fails: R scaled by exp(400) -> R R' overflows in the smoother
     theta_bad = theta.copy()
     theta_bad[1, 0] = 400.0
@@ -266,5 +270,61 @@ def test_device_set_up_dimension_edges(oracle, monkeypatch, m, n):
         monkeypatch.setenv("BSSM_AMD_DEVICE_SETUP", dev)
         res = PC.post_correct(model, mo, 40, threads=2, is_type="is2", seed=3)
         assert np.all(np.isfinite(res["loglik"]))
-        assert np.allclose(res["loglik"], ref["loglik"], rtol=0, atol=1e-8 * max(n, 4))
-        assert np.allclose(res["alphahat"], ref["alphahat"].T, rtol=1e-6, atol=1e-6)
+        assert np.allclose(res["loglik"], ref["loglik"], rtol=0, atol=1e-9 * max(n, 4))
+        assert np.allclose(res["alphahat"], ref["alphahat"].T, rtol=1e-7, atol=1e-8 if dev == "2" else 1e-9)
+
+
+@pytest.mark.parametrize("period,N,n", [(24, 50000, 8), (52, 100000, 6), (24, 16385, 6), (52, 20000, 5)])
+def test_more_than_16384_particles_of_a_big_state(oracle, period, N, n):
+    """Round 6 (round-5 review, "What's missing" 2): the reference takes any particles <= 1e5 for any model (R/check_arguments.R:407-418;
+    src/model_ssm_ung.cpp:611 has no limit), and is1 post-correction multiplies nsim by the counts (src/approx_mcmc.cpp:376-378).  pf_big_row_step
+    with the row prefixes in LDS (up to 102 400 particles) against the oracle: ancestors identical, the usual bounds.  16 385 is the first count
+    beyond the register form (257 rows)."""
+    model = seasonal(period, n=n)
+    out = F.bootstrap_filter(model, N, seed=3, return_indices=True)
+    assert FilterPlan.last_kernel().startswith("pf_big_row_step") and "wide" in FilterPlan.last_kernel(), FilterPlan.last_kernel()
+    ref = oracle.bsf_filter(M.model_arrays(model), N, seed=3)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"]) <= 1e-9
+    assert np.allclose(out["weights"], ref["weights"], rtol=1e-8, atol=1e-13)
+    at, att, Pt, Ptt = oracle.filter_summary(ref["alpha"], ref["weights"])
+    assert _rel(out["att"], att.T[:n]) <= 1e-8 and _rel(out["Pt"], Pt) <= 1e-7
+
+
+def test_psi_smoother_and_the_cap_beyond_16384_particles(oracle):
+    """psi-APF + back-trace of a 25-state model at 30 000 particles (the m-dimensional proposal noise on the matrix cores, prefixes in LDS);
+    102 401 particles are refused with a message, as the reference refuses more than 1e5 (R/check_arguments.R:407-418)"""
+    from bssm_amd._lib import BssmAmdError
+    model = seasonal(24, n=6, distribution="negative binomial")
+    n, N = model.n, 30000
+    ref = oracle.psi_filter(M.model_arrays(model), N, seed=5)
+    sm = oracle.filter_smoother(ref["alpha"], ref["indices"])
+    mean, cov = oracle.summary(sm)
+    out = F.particle_smoother(model, N, method="psi", seed=5, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8 and _rel(out["Vt"], cov[:, :, :n]) <= 1e-7
+    import ctypes as C
+    from bssm_amd import _lib
+    from bssm_amd.filters import _prep, _alloc
+    arr, smod, keep = _prep(model, False)
+    fo = _lib.FilterOut()
+    rc = _lib.lib().bssm_bsf(C.byref(smod), C.c_uint32(102401), C.c_uint32(1), 0, M.model_type(model), C.byref(fo))
+    assert rc < 0 and b"102400" in _lib.lib().bssm_amd_last_error()
+
+
+def test_run_mcmc_summary_output_of_a_seasonal_model():
+    """run_mcmc(bsm_ng(period = 24), output_type = "summary", mcmc_type = "pm"): 25 states through the chain's running summaries (round-5
+    advisory: the chain kept them in 16-element stack arrays) -- alphahat / Vt finite, symmetric, and equal to a second run bit for bit"""
+    from bssm_amd import mcmc
+    rng = np.random.default_rng(2)
+    n, period = 24, 24
+    y = rng.poisson(np.exp(1.5 + 0.4 * np.sin(2 * np.pi * np.arange(n) / period))).astype(float)
+    model = M.bsm_ng(y, sd_level=M.halfnormal(0.1, 1), sd_seasonal=M.halfnormal(0.05, 1), period=period, distribution="poisson",
+                     a1=np.r_[1.5, np.zeros(period - 1)], P1=np.diag(np.r_[1.0, np.full(period - 1, 0.05)]))
+    runs = [mcmc.run_mcmc(model, iter=60, particles=64, output_type="summary", mcmc_type="pm", sampling_method="bsf", burnin=20, seed=11) for _ in range(2)]
+    a, v = runs[0]["alphahat"], runs[0]["Vt"]
+    assert a.shape == (n + 1, 24) and v.shape == (24, 24, n + 1) and np.all(np.isfinite(a)) and np.all(np.isfinite(v))
+    assert np.allclose(v, np.transpose(v, (1, 0, 2)), rtol=1e-12, atol=1e-15) and np.all(np.einsum("iit->it", v) >= 0)
+    assert np.array_equal(a, runs[1]["alphahat"]) and np.array_equal(v, runs[1]["Vt"]) and np.array_equal(runs[0]["theta"], runs[1]["theta"])
