@@ -313,10 +313,81 @@ inline void parallel_for(int count, int threads, F fn) {
   for (auto& th : pool) th.join();
 }
 
+
+// Round 6: the descriptor of a structured transition (pf_big.h: sparse_apply; FilterBatch::sp) for a batch of bootstrap filters with
+// 17 ... 64 states, or an empty vector when the batch does not qualify: time-invariant T shared by every filter of the batch, all of its
+// entries +-1 with at most two per column (the companion matrices bsm_ng / bsm_lg build for trend + seasonal, R/models.R:995-1060), at
+// most eight rows that are not a plain copy, one observation series, at most eight noise terms.  BSSM_AMD_NO_SPARSE=1 keeps the dense
+// matrix-core transition (comparison switch).
+inline std::vector<int> sparse_descriptor(const std::vector<const bssm::FilterTables*>& tabs, int n, int m, int k, int p, int psi, int* cnz_out) {
+  std::vector<int> none;
+  const int MP = tabs[0]->MP, KP = tabs[0]->KP;
+  if (psi != 0 || p != 1 || MP < 32 || MP > 64 || tabs[0]->mats_tstride != 0 || k > 8 || m > 64) return none;
+  if (const char* e = std::getenv("BSSM_AMD_NO_SPARSE")) { if (e[0] != '0') return none; }
+  const double* T0 = tabs[0]->mats.data();
+  int row_cnt[64] = {0}, noise[64] = {0}, zflag[64] = {0};
+  size_t nnz = 0;
+  for (int c = 0; c < m; c++)
+    for (int r = 0; r < m; r++) {
+      const double v = T0[r + (size_t)MP * c];
+      if (v == 0.0) continue;
+      if (v != 1.0 && v != -1.0) return none;
+      row_cnt[r]++; nnz++;
+    }
+  if (nnz > (size_t)4 * m) return none;   // (not a structured matrix: the matrix cores do better)
+  int cnz = 0;
+  const size_t ostride = (size_t)bssm::ROW_HDR + bssm::SER_HDR + MP;
+  for (const bssm::FilterTables* ft : tabs) {
+    if (std::memcmp(ft->mats.data(), T0, sizeof(double) * (size_t)MP * MP) != 0) return none;   // (bsm_ng: T does not depend on theta)
+    const double* R = ft->mats.data() + (size_t)MP * MP;
+    const double* Cv = R + (size_t)MP * KP;
+    for (int r = 0; r < m; r++) {
+      for (int kk = 0; kk < KP; kk++) if (R[r + (size_t)MP * kk] != 0.0) noise[r] = 1;
+      if (Cv[r] != 0.0) cnz = 1;
+    }
+    for (int t = 0; t < n; t++) {
+      const double* zr = ft->obs.data() + ostride * t + bssm::ROW_HDR + bssm::SER_HDR;
+      for (int r = 0; r < m; r++) if (zr[r] != 0.0) zflag[r] = 1;
+    }
+  }
+  // rows that are a plain copy of the component in front of them: x'[r] = x[r - 1]; the longest run of them is the shift block
+  bool shift[64] = {false};
+  for (int r = 1; r < m; r++) shift[r] = row_cnt[r] == 1 && !noise[r] && T0[r + (size_t)MP * (r - 1)] == 1.0;
+  int best_lo = 1, best_hi = 0;
+  for (int r = 1; r < m;) {
+    if (!shift[r]) { r++; continue; }
+    int e = r;
+    while (e + 1 < m && shift[e + 1]) e++;
+    if (e - r > best_hi - best_lo) { best_lo = r; best_hi = e; }
+    r = e + 1;
+  }
+  std::vector<int> d((size_t)bssm::SP_WORDS, 0);
+  d[0] = best_lo; d[1] = best_hi;
+  unsigned long long zmask = 0;
+  int n_slots = 0;
+  for (int r = 0; r < m; r++) {
+    if (r >= best_lo && r <= best_hi) { if (zflag[r]) zmask |= 1ull << r; continue; }
+    if (n_slots == bssm::SP_SLOTS) return none;
+    unsigned long long P = 0, Nn = 0;
+    for (int c = 0; c < m; c++) {
+      const double v = T0[r + (size_t)MP * c];
+      if (v == 1.0) P |= 1ull << c; else if (v == -1.0) Nn |= 1ull << c;
+    }
+    int* w = d.data() + bssm::SP_HDR + bssm::SP_SLOT_WORDS * n_slots;
+    w[0] = r | 0x100 | (zflag[r] ? 0x200 : 0) | (noise[r] ? 0x400 : 0);
+    w[1] = (int)(unsigned)(P & 0xffffffffull); w[2] = (int)(unsigned)(P >> 32);
+    w[3] = (int)(unsigned)(Nn & 0xffffffffull); w[4] = (int)(unsigned)(Nn >> 32);
+    n_slots++;
+  }
+  d[2] = (int)(unsigned)(zmask & 0xffffffffull); d[3] = (int)(unsigned)(zmask >> 32);
+  *cnz_out = cnz;
+  return d;
+}
+
 // ------------------------------------------------------------------ a batch of filters on the device
 struct DeviceBatch {
   bssm::FilterBatch fb{};
-  DevBuf mats, obs, init, hist, indices, weights, loglik, dead, ws, fparbuf, amatbuf;
+  DevBuf mats, obs, init, hist, indices, weights, loglik, dead, ws, fparbuf, amatbuf, spbuf;
   bssm::GridWorkspace gws{};
   bool use_grid = false;
   bool want_factored = false;     // BSSM_PLAN_FACTORED_WEIGHTS: ask the step kernels for the factored weights output
@@ -358,6 +429,16 @@ struct DeviceBatch {
     fb.mats = mats.as<double>(); fb.mats_fstride = ms; fb.mats_tstride = tabs[0]->mats_tstride;
     fb.obs = obs.as<double>(); fb.obs_fstride = os;
     fb.init = init.as<double>(); fb.init_fstride = is;
+    fb.sp = nullptr; fb.sp_cnz = 0;
+    {  // a structured transition (bsm_ng with a seasonal component: pf_big.h, sparse_apply)?
+      int cnz = 0;
+      const std::vector<int> sp = sparse_descriptor(tabs, n, m, k, p, psi, &cnz);
+      if (!sp.empty()) {
+        HIP_TRY(spbuf.alloc(sp.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(spbuf.p, sp.data(), sp.size() * sizeof(int), hipMemcpyHostToDevice));
+        fb.sp = spbuf.as<int>(); fb.sp_cnz = cnz;
+      }
+    }
     return configure(keep_hist, path_flags, keep_weights);
   }
   // tables that are already in device memory (built there by fn_setup_kernel): F filters starting at the given pointers
@@ -367,6 +448,7 @@ struct DeviceBatch {
     fb.mats = d_mats; fb.mats_fstride = ms; fb.mats_tstride = tstride;
     fb.obs = d_obs; fb.obs_fstride = os;
     fb.init = d_init; fb.init_fstride = is;
+    fb.sp = nullptr; fb.sp_cnz = 0;
     return configure(false, 0, false);
   }
   int configure(bool keep_hist, unsigned path_flags, bool keep_weights) {

@@ -180,12 +180,109 @@ __device__ __forceinline__ void big_store(const BigAcc<MB>& acc, double* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 6: STRUCTURED transitions.  The models the limit of 16 states was lifted for are bsm_ng / bsm_lg with a seasonal component
+// (R/models.R:995-1060 builds their T): level' = level + slope, slope' = slope, gamma_1' = -(gamma_1 + ... + gamma_{s-1}),
+// gamma_i' = gamma_{i-1} -- a companion matrix of +-1 with ~2 m non-zeros of 64 x 56 padded entries, and three or four noise terms.
+// The dense matrix-core transition spends 2 MP (m + k) flops per particle on it and reaches 0.26-0.49 of the matrix peak; what the step
+// really is: gather the ancestor's m components, write m components, a handful of additions.  The host recognises such a T (every entry
+// +-1, at most two per column, at most eight rows that are not a plain copy: api_internal.h, sparse_descriptor) and the kernels below
+// take this path for the bootstrap filter's steps (the initial draw a1 + L u stays on the matrix cores: L is dense):
+//   rows with ONE entry and no noise ("direct"):  x'[r] = C[r] +- x[c]
+//   the other rows ("slots", <= 8):               x'[r] = C[r] + sum of +-x[c] in ascending c + sum_k R[r][k] eta_k
+//   signal Z x' accumulated over the rows with a non-zero Z in the order they are produced (direct rows by source column, then the slots)
+// xval(c) hands over component c of this lane's ancestor; store(r, v) takes component r of the new state.  The column loop is unrolled
+// (c is static: xval may be a register array; the row family's loads all issue up front), everything read from `sp` / the tables is
+// wave-uniform.  Both shapes call it with the same operands: the same bits.
+// (SP_SLOTS, SP_HDR, SP_SLOT_WORDS, SP_WORDS: pf_kernels.h -- the host builds the descriptor)
+// Descriptor (ints, wave-uniform): [0] r_lo, [1] r_hi: the SHIFT BLOCK, rows r_lo ... r_hi with x'[r] = C[r] + x[r - 1] (the seasonal lags);
+// [2], [3]: bit r set = Z is non-zero at row r of the block; then per slot s (a row that is not such a copy: level, slope, the first seasonal
+// state, a noise state ...): [row | 0x100 valid | 0x200 Z non-zero | 0x400 has noise], the columns with +1 (two words), the columns with -1.
+template <int MP, class XVal, class Store>
+__device__ __forceinline__ double sparse_apply(const int* __restrict__ sp, const int cnz, const double* __restrict__ mt, const int KP, const int m,
+                                               const int k, const double (&z)[8], const double* __restrict__ zrow /* Z of the row to weigh, or null */,
+                                               XVal&& xval, Store&& store) {
+  const double* __restrict__ Rm = mt + MP * MP;
+  const double* __restrict__ Cv = mt + MP * MP + MP * KP;
+  const int r_lo = __builtin_amdgcn_readfirstlane(sp[0]), r_hi = __builtin_amdgcn_readfirstlane(sp[1]);
+  const unsigned long long zmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(sp[2]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(sp[3]) << 32);
+  double zsum = 0.0;
+  // ---- the slots first into registers (they read the OLD components, and a slot's row may be a source of the shift block)
+  double sv[SP_SLOTS];
+  int srow[SP_SLOTS];
+#pragma unroll
+  for (int s = 0; s < SP_SLOTS; s++) {
+    const int* __restrict__ w = sp + SP_HDR + SP_SLOT_WORDS * s;
+    srow[s] = __builtin_amdgcn_readfirstlane(w[0]);
+    sv[s] = 0.0;
+    if (!(srow[s] & 0x100)) continue;
+    const unsigned long long P = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(w[1]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(w[2]) << 32);
+    const unsigned long long Nn = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(w[3]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(w[4]) << 32);
+    const int row = srow[s] & 63;
+    double acc = Cv[row];
+#pragma unroll
+    for (int c = 0; c < MP; c++) {
+      const double v = xval(c);
+      acc += ((P >> c) & 1ull) ? v : (((Nn >> c) & 1ull) ? -v : 0.0);   // (ascending c; an absent column adds an exact zero)
+    }
+    if (srow[s] & 0x400) {
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) if (kk < k) acc = __builtin_fma(Rm[row + MP * kk], z[kk], acc);
+    }
+    sv[s] = acc;
+  }
+  // ---- the shift block
+#pragma unroll
+  for (int r = 1; r < MP; r++) {
+    if (r < r_lo || r > r_hi) continue;
+    const double v = cnz ? Cv[r] + xval(r - 1) : xval(r - 1);
+    store(r, v);
+    if (zrow && ((zmask >> r) & 1ull)) zsum = __builtin_fma(zrow[r], v, zsum);
+  }
+#pragma unroll
+  for (int s = 0; s < SP_SLOTS; s++) {
+    if (!(srow[s] & 0x100)) continue;
+    const int row = srow[s] & 63;
+    store(row, sv[s]);
+    if (zrow && (srow[s] & 0x200)) zsum = __builtin_fma(zrow[row], sv[s], zsum);
+  }
+  (void)m;
+  return zsum;
+}
+#ifndef __HIPCC_RTC__
+// BSSM_AMD_SPARSE: 0 never, all = wherever a descriptor exists (experiments), default = where it measured faster
+inline int sparse_mode() {
+  static const int mode = [] { const char* e = std::getenv("BSSM_AMD_SPARSE"); return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1)); }();
+  return mode;
+}
+#endif
+// bootstrap log-weight of one particle from its signal (one observation series): big_log_weight for p = 1, the signal given
+__device__ __forceinline__ double sparse_log_weight(const double* __restrict__ row, const double zsum) {
+  if (row[RH_FLAG] == 0.0) return 0.0;
+  const double* __restrict__ ob = row + ROW_HDR;
+  if (ob[OB_FLAG] == 0.0) return 0.0;
+  return log_obs_density((int)ob[OB_DIST], ob, ob[OB_PHI], ob[OB_D] + zsum);
+}
+// the k <= 8 normals of a step draw (two PACKED blocks at most; the stream format of big_normals4)
+__device__ __forceinline__ void sparse_normals(const RngKey key, const uint32_t t, const uint32_t particle, const int k, const u32x4& blk, double (&z)[8]) {
+  double z4[4];
+  big_normals4(key, RNG_TRANSITION, t, particle, k, 0, blk, z4);
+#pragma unroll
+  for (int q = 0; q < 4; q++) { z[q] = z4[q]; z[4 + q] = 0.0; }
+  if (k > 4) {
+    big_normals4(key, RNG_TRANSITION, t, particle, k, 1, blk, z4);
+#pragma unroll
+    for (int q = 0; q < 4; q++) z[4 + q] = z4[q];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // one workgroup per filter, one wave per row of 64 particles, particle system in LDS
 // ------------------------------------------------------------------------------------------------------------------
 // (MB = 4 runs 256 threads = one wave per SIMD; budgeted for 512 anyway: with the 470 registers a 256-thread bound allows it measured
 // 16.8 ms against 12.8 ms per 1024 bootstrap filters of 256 particles at 256 registers and 67 spilt, profiles/r05_big_states.txt)
-template <int MB>
+template <int MB, bool SPARSE = false>
 __global__ void __launch_bounds__(BIG_NT_MAX, 1) pf_big_wg(const FilterBatch b) {
   constexpr int MP = 16 * MB;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -252,11 +349,28 @@ __global__ void __launch_bounds__(BIG_NT_MAX, 1) pf_big_wg(const FilterBatch b) 
       anc = src.e * CANON_ROW + min(canon_count_below(s_cdf + src.e * CANON_ROW, slen, src.vp), slen - 1);
       if (b.indices) __builtin_nontemporal_store((uint32_t)anc, &b.indices[((size_t)f * n + t) * N + j]);
     }
+    const double* __restrict__ mt = mats + (size_t)t * b.mats_tstride;
+    if constexpr (SPARSE) {
+      // ---- structured transition (sparse_apply): this lane's particle -- its ancestor's components into registers, the barrier, then the
+      // new components straight into the particle system
+      double x[MP], z[8];
+#pragma unroll
+      for (int c = 0; c < MP; c++) x[c] = c < m ? s_state[c * Ncap + anc] : 0.0;
+      sparse_normals(key, (uint32_t)t, (uint32_t)j, ncnt_step, blk, z);
+      lds_barrier();  // (2) every gather has read the old particle system (and every search the scans)
+      double* __restrict__ hist_new = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + (t + 1)) * m * N : nullptr;
+      const double* __restrict__ orow = obs + (size_t)(t + 1 < n ? t + 1 : 0) * obs_stride;
+      const double zsum = sparse_apply<MP>(b.sp, b.sp_cnz, mt, KP, m, ncnt_step, z, t + 1 < n ? orow + ROW_HDR + SER_HDR : nullptr,
+                                           [&](int c) { return x[c]; },
+                                           [&](int r, double v) { s_state[r * Ncap + j] = v; if (hist_new && j < N) __builtin_nontemporal_store(v, &hist_new[(size_t)r * N + j]); });
+      w = t + 1 < n ? sparse_log_weight(orow, zsum) : 0.0;
+      if (j >= N) w = -INFINITY;
+      continue;
+    }
     s_anc[j] = anc;
     lds_barrier();  // (2) every search has read the scans; the ancestor table is visible
 
     // ---- transition on the matrix cores: B fragments gathered from the component-major particle system
-    const double* __restrict__ mt = mats + (size_t)t * b.mats_tstride;
     int ancs[4];
 #pragma unroll
     for (int pb = 0; pb < 4; pb++) ancs[pb] = s_anc[row0 + 16 * pb + i16];
@@ -287,11 +401,17 @@ hipError_t launch_big_wg(const FilterBatch& b, hipStream_t stream) {
   if (b.MP != MP || b.fpar || b.KP % 4 != 0 || b.KP < 4 || b.KP > MP || b.N > big_wg_capacity(MP)) return hipErrorInvalidValue;
   const int nt = (b.N + 63) / 64 * 64;
   const size_t lds = ((size_t)(MP + 1) * nt + 16 + (size_t)(nt / 64) * 256) * sizeof(double) + (size_t)nt * sizeof(int);
-  { char nm[96]; std::snprintf(nm, sizeof nm, "pf_big_wg<%d>", MB); note_filter_kernel(nm); }
-  hipError_t e = hipFuncSetAttribute((const void*)pf_big_wg<MB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // (measured, profiles/r06_big_states.txt: the structured transition does NOT pay in the workgroup-resident shape -- 256 particles x 1024 filters of
+  // 25 / 53 states 7.9 / 15.1 ms against 5.9 / 12.7 ms on the matrix cores: one wave per SIMD holds 32 / 64 components per lane, 165-268 scalar
+  // registers spilt; BSSM_AMD_SPARSE=all selects it for experiments)
+  const bool sparse = b.sp != nullptr && b.psi == 0 && b.p == 1 && b.mats_tstride == 0 && b.k <= 8 && sparse_mode() == 2;
+  { char nm[96]; std::snprintf(nm, sizeof nm, sparse ? "pf_big_wg<%d,sparse>" : "pf_big_wg<%d>", MB); note_filter_kernel(nm); }
+  const void* kern = sparse ? (const void*)pf_big_wg<MB, true> : (const void*)pf_big_wg<MB, false>;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   if ((e = hipMemsetAsync(b.dead_at, 0, sizeof(int) * b.F, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(pf_big_wg<MB>, dim3(b.F), dim3(nt), lds, stream, b);
+  if (sparse) hipLaunchKernelGGL((pf_big_wg<MB, true>), dim3(b.F), dim3(nt), lds, stream, b);
+  else hipLaunchKernelGGL((pf_big_wg<MB, false>), dim3(b.F), dim3(nt), lds, stream, b);
   return hipGetLastError();
 }
 
@@ -360,7 +480,7 @@ __device__ __forceinline__ void big_wide_source(const double v, const int B, con
   vp = canon_opaque(v - Pm1) * sI[e];
 }
 
-template <int MB, int LD = 16 * MB, bool WIDE = false>
+template <int MB, int LD = 16 * MB, bool WIDE = false, bool SPARSE = false>
 __global__ void __launch_bounds__(ROW_NT, big_row_occupancy(MB)) pf_big_row_step(const FilterBatch b, const GridWorkspace ws, const int t) {
   constexpr int MP = LD;
   __shared__ double s_win[4 * ROW_WIN];
@@ -440,6 +560,26 @@ __global__ void __launch_bounds__(ROW_NT, big_row_occupancy(MB)) pf_big_row_step
     }
   }
   if (b.indices && act) __builtin_nontemporal_store((uint32_t)anc, &b.indices[((size_t)f * n + t) * N + j]);
+  const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N;
+  double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N;
+  const double* __restrict__ mt = b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride;
+  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
+  const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
+  if constexpr (SPARSE) {
+    // ---- structured transition (sparse_apply): one particle per lane, its ancestor's components straight from the old particle system
+    double z[8];
+    sparse_normals(key, (uint32_t)t, (uint32_t)j, ncnt_step, blk, z);
+    const double* __restrict__ orow = obs + (size_t)(tn < n ? tn : 0) * obs_stride;
+    double x[MP];   // the ancestor's components: every load in flight before the first use
+#pragma unroll
+    for (int c = 0; c < MP; c++) x[c] = c < m ? st_old[(size_t)c * N + anc] : 0.0;
+    const double zsum = sparse_apply<MP>(b.sp, b.sp_cnz, mt, KP, m, ncnt_step, z, tn < n ? orow + ROW_HDR + SER_HDR : nullptr,
+                                         [&](int c) { return x[c]; },
+                                         [&](int r, double v) { if (act) st_new[(size_t)r * N + j] = v; });
+    const double ws_ = tn < n ? sparse_log_weight(orow, zsum) : 0.0;
+    row_publish(b, ws, f, g, j, act, tn, ws_, lane);
+    return;
+  }
   int* sa = s_ancs + wave * 64;
   sa[lane] = anc;
   lds_wave_sync();
@@ -447,11 +587,6 @@ __global__ void __launch_bounds__(ROW_NT, big_row_occupancy(MB)) pf_big_row_step
 #pragma unroll
   for (int pb = 0; pb < 4; pb++) ancs[pb] = sa[16 * pb + i16];
 
-  const double* __restrict__ st_old = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + t) * m * N : ws.state[t & 1] + (size_t)f * m * N;
-  double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + ((size_t)f * (n + 1) + tn) * m * N : ws.state[tn & 1] + (size_t)f * m * N;
-  const double* __restrict__ mt = b.mats + (size_t)f * b.mats_fstride + (size_t)t * b.mats_tstride;
-  const double* __restrict__ obs = b.obs + (size_t)f * b.obs_fstride;
-  const int obs_stride = ROW_HDR + b.p * (SER_HDR + MP);
   BigAcc<MB> acc;
   big_affine<MB, LD>(acc, mt + MP * MP + MP * KP, mt, m, mt + MP * MP, ncnt_step,
                  [&](int c, int pb) { return st_old[(size_t)c * N + ancs[pb]]; },
@@ -467,10 +602,18 @@ hipError_t launch_big_row(const FilterBatch& b, const GridWorkspace& ws, hipStre
   constexpr int MP = LD;
   if (b.MP != MP || b.fpar || b.KP % 4 != 0 || b.KP < 4 || b.KP > MP) return hipErrorInvalidValue;
   if constexpr (LD == 16 * MB) {
+    // (measured: the row shape gains 10-12 % at 33 ... 64 states -- 53 states 10.6-11.1 -> 9.6-9.9 ms per 262 144 particles x 200 steps = 0.59 of the
+    // HBM roof on 16 m + 16 bytes -- and loses 5 % at 17 ... 32, where the dense tiles are small: on for MB = 4 only; BSSM_AMD_SPARSE=all / 0)
+    const bool sparse = b.sp != nullptr && b.psi == 0 && b.p == 1 && b.mats_tstride == 0 && b.k <= 8 && (sparse_mode() == 2 || (sparse_mode() == 1 && MB == 4));
     if (ws.B > ROW_MAX_ROWS) {   // more than 16 384 particles: the row prefixes in LDS (round 6)
       if (ws.B > BIG_WIDE_ROWS) return hipErrorInvalidValue;
-      { char nm[96]; std::snprintf(nm, sizeof nm, "pf_big_row_step<%d,wide>", MB); note_filter_kernel(nm); }
+      { char nm[96]; std::snprintf(nm, sizeof nm, sparse ? "pf_big_row_step<%d,wide,sparse>" : "pf_big_row_step<%d,wide>", MB); note_filter_kernel(nm); }
+      if (sparse) return launch_row_loop(b, ws, stream, timing, pf_big_row_step<MB, LD, true, true>, pf_big_row_init<MB, LD>, BIG_WIDE_ROWS);
       return launch_row_loop(b, ws, stream, timing, pf_big_row_step<MB, LD, true>, pf_big_row_init<MB, LD>, BIG_WIDE_ROWS);
+    }
+    if (sparse) {
+      { char nm[96]; std::snprintf(nm, sizeof nm, "pf_big_row_step<%d,sparse>", MB); note_filter_kernel(nm); }
+      return launch_row_loop(b, ws, stream, timing, pf_big_row_step<MB, LD, false, true>, pf_big_row_init<MB, LD>);
     }
   }
   { char nm[96]; if (LD == 16 * MB) std::snprintf(nm, sizeof nm, "pf_big_row_step<%d>", MB); else std::snprintf(nm, sizeof nm, "pf_big_row_step<%d,%d>", MB, LD); note_filter_kernel(nm); }

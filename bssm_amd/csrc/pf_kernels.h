@@ -8,6 +8,9 @@
 
 namespace bssm {
 
+// layout of FilterBatch::sp, the descriptor of a structured transition (pf_big.h: sparse_apply; api_internal.h: sparse_descriptor)
+enum { SP_SLOTS = 8, SP_HDR = 4, SP_SLOT_WORDS = 6, SP_WORDS = SP_HDR + SP_SLOTS * SP_SLOT_WORDS };
+
 // Device-resident description of a batch of F independent filters that share
 // (n, m, k, N, distribution) but may differ in every matrix / observation row
 // (one per retained theta-draw in post-correction, src/approx_mcmc.cpp:370-417).
@@ -41,6 +44,12 @@ struct FilterBatch {
   int user_slot;        // 0, or the registry slot of a run-time compiled user model whose library holds the kernels
   int fn_id;            // functor models: the model id of the parameter blocks (all filters of a batch share it)
   int lean;             // host only: the workgroup-resident kernel in its 96-register form where one exists (a last round with a tail beside it)
+  // Round 6: structured transition of the bootstrap filter with 17 ... 64 states (pf_big.h: sparse_apply).  Null = the dense matrix-core
+  // transition.  Otherwise a descriptor of T's pattern (all entries +-1), shared by the filters of the batch: the block of rows that copy
+  // the component in front of them, and <= 8 other rows as column masks (pf_big.h: SP_WORDS ints).  The VALUES of R, C, Z still come
+  // from every filter's own tables.
+  const int* sp;
+  int sp_cnz;           // some C_t entry is non-zero (direct rows then add theirs)
 };
 
 // Largest N the workgroup-resident kernel can hold for a given padded state size
