@@ -434,7 +434,8 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
     const int ms = mod->n_states;
     if (ms < 1 || ms > max_states)
       return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: at most 8 states");
-    if (h.jit) return fail(BSSM_ERR_UNSUPPORTED, "this user model was compiled in process (bssm_user_model_jit): bootstrap filter only -- the psi-APF and the EKF particle filter run the snippet on the host, build it with bssm_user_model_build");
+    // (a model compiled in process -- bssm_user_model_jit -- has no host code: its T / Z / Jacobians reach the host set-up through a one-thread
+    // evaluation kernel of the same snippet, round 6)
     if (!h.T || !h.Z || !h.Tg || !h.Zg)
       return fail(BSSM_ERR_UNSUPPORTED, "this user model was compiled without BSSM_USER_JACOBIANS (bssm_user_Tg, bssm_user_Zg): the psi-APF and the EKF particle filter need them");
     // the state-independent numbers: R_diag / a1 / P1 (up to 2 states) or the R_ext / a1_ext / P1_ext blocks
@@ -1010,6 +1011,7 @@ int bssm_user_model_load(const char* lib_path) {
 // gives the same bits whether it was built by hipcc or compiled here.
 }  // extern "C"
 #include <hip/hiprtc.h>
+#include <utility>
 #include "pf_canon.h"
 namespace {
 constexpr int kJitWgThreads = 512;  // = WG_NT_MAX of pf_filter_impl.h: the 512-thread form of the workgroup-resident kernel
@@ -1048,12 +1050,46 @@ void make_private_dirs(const std::string& path) {
     if (at == path.size() || path[at] == '/') (void)mkdir(path.substr(0, at).c_str(), 0700);
 }
 
+// Round 6: the host side of the psi-APF / EKF particle filter (mode search, linearisation: host_model.cpp fn_psi_setup, fn_ekpf_init) calls the
+// model's T / Z / T' / Z' (/ H / R) at one state at a time.  A model compiled in process has no host code, so those calls run THIS kernel --
+// one thread, the snippet's own __device__ functions, operands and results in a pinned block both sides see -- ~15 us per call
+// (a psi set-up of 100 time points: a few thousand calls; models on a hot path build with hipcc, whose library carries host entry points).
+const char* const kJitEvalKernel = R"JIT(
+struct bssm_jit_eval_block { double alpha[16], theta[64], known[64], out[256]; };
+extern "C" __global__ void bssm_user_eval(int what, int t, const double* ktv, int rows, int cols, bssm_jit_eval_block* blk) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  (void)what; (void)t; (void)ktv; (void)rows; (void)cols;
+#ifdef BSSM_USER_NLG
+#ifdef BSSM_USER_TV
+#define BSSM_JTV bssm_user_tv{t, ktv, rows, cols},
+#else
+#define BSSM_JTV
+#endif
+  switch (what) {
+    case 0: bssm_user_T(BSSM_JTV blk->alpha, blk->theta, blk->known, blk->out); break;
+    case 1: blk->out[0] = bssm_user_Z(BSSM_JTV blk->alpha, blk->theta, blk->known); break;
+#ifdef BSSM_USER_JACOBIANS
+    case 2: bssm_user_Tg(BSSM_JTV blk->alpha, blk->theta, blk->known, blk->out); break;
+    case 3: bssm_user_Zg(BSSM_JTV blk->alpha, blk->theta, blk->known, blk->out); break;
+#endif
+#ifdef BSSM_USER_HFN
+    case 4: blk->out[0] = bssm_user_H(BSSM_JTV blk->alpha, blk->theta, blk->known); break;
+#endif
+#ifdef BSSM_USER_RFN
+    case 5: bssm_user_R(BSSM_JTV blk->alpha, blk->theta, blk->known, blk->out); break;
+#endif
+    default: break;
+  }
+#endif
+}
+)JIT";
+
 // the translation unit hiprtc sees: the snippet, then the kernel templates (device view of the headers: __HIPCC_RTC__)
 std::string jit_translation_unit(const JitModel& jm) {
   return "#define BSSM_USER_MODEL 1\n#define BSSM_FN __device__ inline\n"
          "struct bssm_user_tv { int t; const double* known_tv; int rows, cols; };\n" + jm.source +
          "\n#define BSSM_USER_M " + std::to_string(jm.MP) + "\n#define BSSM_USER_NSTATES " + std::to_string(jm.n_states) +
-         "\n#define BSSM_FN_PSI_MASK 1\n#include \"pf_filter_impl.h\"\n";
+         "\n#define BSSM_FN_PSI_MASK 7\n#include \"pf_filter_impl.h\"\n" + kJitEvalKernel;
 }
 
 // compile (or load from the disk cache) ONE kernel variant for the current device; nullptr + *err on failure
@@ -1104,7 +1140,8 @@ hipFunction_t jit_kernel(JitModel& jm, const std::string& name, std::string* err
     const double t0 = now_ms();
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, tu.c_str(), "bssm_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *err = "hiprtcCreateProgram failed"; return nullptr; }
-    (void)hiprtcAddNameExpression(prog, name.c_str());
+    const bool plain_name = name.find('<') == std::string::npos && name.find("::") == std::string::npos;   // an extern "C" kernel: its own name
+    if (!plain_name) (void)hiprtcAddNameExpression(prog, name.c_str());
     const std::string o_arch = "--offload-arch=" + arch, o_inc = "-I" + dir + "/csrc";
     const char* opts[] = {o_arch.c_str(), "-O3", "-std=c++17", o_inc.c_str()};
     const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
@@ -1122,7 +1159,8 @@ hipFunction_t jit_kernel(JitModel& jm, const std::string& name, std::string* err
     code.resize(cs);
     (void)hiprtcGetCode(prog, code.data());
     const char* ln = nullptr;
-    if (hiprtcGetLoweredName(prog, name.c_str(), &ln) != HIPRTC_SUCCESS || !ln) { (void)hiprtcDestroyProgram(&prog); *err = "no lowered name for " + name; return nullptr; }
+    if (plain_name) ln = name.c_str();
+    else if (hiprtcGetLoweredName(prog, name.c_str(), &ln) != HIPRTC_SUCCESS || !ln) { (void)hiprtcDestroyProgram(&prog); *err = "no lowered name for " + name; return nullptr; }
     lowered = ln;
     (void)hiprtcDestroyProgram(&prog);
     if (bssm::opt().trace) std::fprintf(stderr, "[bssm_amd] hiprtc: %s in %.0f ms (%zu bytes)\n", name.c_str(), now_ms() - t0, cs);
@@ -1160,10 +1198,66 @@ hipFunction_t jit_kernel(JitModel& jm, const std::string& name, std::string* err
 
 JitModel* jit_of(int slot) { return slot >= 1 && slot <= 63 ? g_jit[slot] : nullptr; }
 
+
+// ---- host entry points of a model compiled in process: one evaluation-kernel launch per call (see kJitEvalKernel)
+struct JitEvalBlock { double alpha[16], theta[64], known[64], out[256]; };
+int jit_eval(int slot, int what, int t, const double* ktv, int rows, int cols, const double* a, const double* th, const double* kn, double* out, int out_cnt) {
+  JitModel* jm = jit_of(slot);
+  if (!jm) return -1;
+  std::string err;
+  hipFunction_t fn = jit_kernel(*jm, "bssm_user_eval", &err);
+  if (!fn) { fail(BSSM_ERR_INVALID, err); return -1; }
+  static thread_local JitEvalBlock* blk = nullptr;   // pinned, visible to the device: no copies around the launch
+  static thread_local int blk_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!blk || blk_dev != dev) {
+    if (blk) (void)hipHostFree(blk);
+    if (hipHostMalloc((void**)&blk, sizeof(JitEvalBlock), hipHostMallocMapped) != hipSuccess) { blk = nullptr; (void)hipGetLastError(); return -1; }
+    blk_dev = dev;
+  }
+  const int ms = jm->n_states;
+  for (int q = 0; q < ms && q < 16; q++) blk->alpha[q] = a[q];
+  std::memcpy(blk->theta, th, sizeof blk->theta);   // (the caller's arrays are FnModel::theta / known: 64 entries each)
+  std::memcpy(blk->known, kn, sizeof blk->known);
+  double* dtv = nullptr;
+  if (ktv && rows > 0 && cols > 0 && device_known_tv(ktv, rows, cols, &dtv) != BSSM_OK) return -1;
+  void* dblk = nullptr;
+  if (hipHostGetDevicePointer(&dblk, blk, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  static thread_local bssm::TlsStream st_tls;
+  hipStream_t st = st_tls.get();
+  int what_ = what, t_ = t, rows_ = rows, cols_ = cols;
+  const double* dtv_c = dtv;
+  void* args[] = {&what_, &t_, &dtv_c, &rows_, &cols_, &dblk};
+  if (hipModuleLaunchKernel(fn, 1, 1, 1, 64, 1, 1, 0, st, args, nullptr) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  for (int q = 0; q < out_cnt; q++) out[q] = blk->out[q];
+  return 0;
+}
+template <int SLOT> struct JitTramp {
+  static int ms() { JitModel* jm = jit_of(SLOT); return jm ? jm->n_states : 1; }
+  static void T(int t, const double* ktv, int r, int c, const double* a, const double* th, const double* kn, double* out) { if (jit_eval(SLOT, 0, t, ktv, r, c, a, th, kn, out, ms())) for (int q = 0; q < ms(); q++) out[q] = std::nan(""); }
+  static double Z(int t, const double* ktv, int r, int c, const double* a, const double* th, const double* kn) { double v = std::nan(""); (void)jit_eval(SLOT, 1, t, ktv, r, c, a, th, kn, &v, 1); return v; }
+  static void Tg(int t, const double* ktv, int r, int c, const double* a, const double* th, const double* kn, double* out) { if (jit_eval(SLOT, 2, t, ktv, r, c, a, th, kn, out, ms() * ms())) for (int q = 0; q < ms() * ms(); q++) out[q] = std::nan(""); }
+  static void Zg(int t, const double* ktv, int r, int c, const double* a, const double* th, const double* kn, double* out) { if (jit_eval(SLOT, 3, t, ktv, r, c, a, th, kn, out, ms())) for (int q = 0; q < ms(); q++) out[q] = std::nan(""); }
+  static double H(int t, const double* ktv, int r, int c, const double* a, const double* th, const double* kn) { double v = std::nan(""); (void)jit_eval(SLOT, 4, t, ktv, r, c, a, th, kn, &v, 1); return v; }
+  static void R(int t, const double* ktv, int r, int c, const double* a, const double* th, const double* kn, double* out) { if (jit_eval(SLOT, 5, t, ktv, r, c, a, th, kn, out, ms() * ms())) for (int q = 0; q < ms() * ms(); q++) out[q] = std::nan(""); }
+};
+template <int SLOT> void jit_bind_one(int slot, bssm::UserHostFns* h, bool jac, bool hfn, bool rfn) {
+  if (slot != SLOT) return;
+  h->T = JitTramp<SLOT>::T; h->Z = JitTramp<SLOT>::Z;
+  if (jac) { h->Tg = JitTramp<SLOT>::Tg; h->Zg = JitTramp<SLOT>::Zg; }
+  if (hfn) h->H = JitTramp<SLOT>::H;
+  if (rfn) h->R = JitTramp<SLOT>::R;
+}
+template <int... S> void jit_bind_all(int slot, bssm::UserHostFns* h, bool jac, bool hfn, bool rfn, std::integer_sequence<int, S...>) {
+  (jit_bind_one<S + 1>(slot, h, jac, hfn, rfn), ...);
+}
+void jit_bind(int slot, bssm::UserHostFns* h, bool jac, bool hfn, bool rfn) { jit_bind_all(slot, h, jac, hfn, rfn, std::make_integer_sequence<int, 63>{}); }
+
 // workgroup-resident shape: the 512-thread form of launch_wg_mk (pf_filter_impl.h), bootstrap sampler
 hipError_t jit_launch_wg(const bssm::FilterBatch* bp, hipStream_t stream) {
   JitModel* jm = jit_of(bp->user_slot);
-  if (!jm || bp->psi != 0 || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process runs the bootstrap filter only (psi-APF / EKF particle filter: bssm_user_model_build)"); return hipErrorInvalidValue; }
+  if (!jm || bp->psi < 0 || bp->psi > 2 || (bp->psi != 0 && jm->MP > 8) || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process: psi-APF / EKF particle filter up to 8 states"); return hipErrorInvalidValue; }
   bssm::FilterBatch b = *bp;
   b.user_slot = 0;
   const int MP = jm->MP, N = b.N;
@@ -1174,7 +1268,7 @@ hipError_t jit_launch_wg(const bssm::FilterBatch* bp, hipStream_t stream) {
   const size_t lds = ((size_t)(MP + 1) * nt * ppt + 2 * bssm::CANON_MAX_ROWS + (size_t)(2 * MP * MP + MP)) * sizeof(double);
   if (N > nt * ppt || lds > 160 * 1024) return hipErrorInvalidValue;
   char name[160];
-  std::snprintf(name, sizeof name, "bssm::pf_wg_kernel<%d,%d,%d,%d,%d,0,false>", MP, MP, ppt, jm->fn_id, kJitWgThreads);
+  std::snprintf(name, sizeof name, "bssm::pf_wg_kernel<%d,%d,%d,%d,%d,%d,false>", MP, MP, ppt, jm->fn_id, kJitWgThreads, b.psi);
   std::string err;
   hipFunction_t fn = jit_kernel(*jm, name, &err);
   if (!fn) { fail(BSSM_ERR_INVALID, err); return hipErrorInvalidValue; }
@@ -1189,7 +1283,7 @@ hipError_t jit_launch_wg(const bssm::FilterBatch* bp, hipStream_t stream) {
 // (pf_grid_v2.h, the time loop of launch_grid_mk) beyond -- with module launches
 hipError_t jit_launch_grid(const bssm::FilterBatch* bp, const bssm::GridWorkspace* wsp_in, hipStream_t stream, bssm::StepTiming* timing) {
   JitModel* jm = jit_of(bp->user_slot);
-  if (!jm || bp->psi != 0 || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process runs the bootstrap filter only (psi-APF / EKF particle filter: bssm_user_model_build)"); return hipErrorInvalidValue; }
+  if (!jm || bp->psi < 0 || bp->psi > 2 || (bp->psi != 0 && jm->MP > 8) || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process: psi-APF / EKF particle filter up to 8 states"); return hipErrorInvalidValue; }
   const bssm::GridWorkspace& ws = *wsp_in;
   constexpr int kGridNT = 256, kMaxBlocks = 256;  // GRID_NT (pf_filter_impl.h), V2_MAX_BLOCKS (pf_grid_v2.h)
   const bool rows = ws.chunk == bssm::CANON_ROW;
@@ -1202,11 +1296,11 @@ hipError_t jit_launch_grid(const bssm::FilterBatch* bp, const bssm::GridWorkspac
   const bool wx = !rows && b.weights != nullptr && bssm::opt().grid_v2_wx != 0;  // weights exchange, as launch_grid_mk
   char n_step[160], n_init[160];
   if (rows) {
-    std::snprintf(n_step, sizeof n_step, "bssm::pf_row_step<%d,%d,%d,0>", MP, MP, jm->fn_id);
-    std::snprintf(n_init, sizeof n_init, "bssm::pf_row_init<%d,%d,%d,0>", MP, MP, jm->fn_id);
+    std::snprintf(n_step, sizeof n_step, "bssm::pf_row_step<%d,%d,%d,%d>", MP, MP, jm->fn_id, bp->psi);
+    std::snprintf(n_init, sizeof n_init, "bssm::pf_row_init<%d,%d,%d,%d>", MP, MP, jm->fn_id, bp->psi);
   } else {
-    std::snprintf(n_step, sizeof n_step, "bssm::pf_grid_step_v2_fn<%d,%d,%s,%d,0>", MP, ppt, wx ? "true" : "false", jm->fn_id);
-    std::snprintf(n_init, sizeof n_init, "bssm::pf_grid_init_v2<%d,%d,false,%d,0>", MP, ppt, jm->fn_id);
+    std::snprintf(n_step, sizeof n_step, "bssm::pf_grid_step_v2_fn<%d,%d,%s,%d,%d>", MP, ppt, wx ? "true" : "false", jm->fn_id, bp->psi);
+    std::snprintf(n_init, sizeof n_init, "bssm::pf_grid_init_v2<%d,%d,false,%d,%d>", MP, ppt, jm->fn_id, bp->psi);
   }
   std::string err;
   hipFunction_t f_step = jit_kernel(*jm, n_step, &err), f_init = f_step ? jit_kernel(*jm, n_init, &err) : nullptr;
@@ -1277,6 +1371,9 @@ int bssm_user_model_jit(const char* source, int32_t n_states) {
   g_user_host[slot] = bssm::UserHostFns();
   g_user_host[slot].has_tv = src.find("BSSM_USER_TV") != std::string::npos ? 1 : 0;
   g_user_host[slot].jit = 1;
+  if (nlg)   // host entry points for the psi-APF / EKF set-up: the evaluation kernel behind function pointers (round 6)
+    jit_bind(slot, &g_user_host[slot], src.find("BSSM_USER_JACOBIANS") != std::string::npos, src.find("BSSM_USER_HFN") != std::string::npos,
+             src.find("BSSM_USER_RFN") != std::string::npos);
   bssm::mark_user_slot_rows_only(slot);
   return slot;
 }

@@ -78,7 +78,7 @@ BSSM_FP_HD constexpr int fp_tail(int n_theta, int n_known) { return (n_theta > 8
 #if defined(BSSM_USER_MODEL) && defined(BSSM_USER_TV)
 template <class PF>
 __device__ __forceinline__ bssm_user_tv fn_user_tv(PF fp, int t) {
-  return bssm_user_tv{t, (const double*)(uintptr_t)__double_as_longlong(fp[FP_TVPTR]), (int)fp[FP_TVROWS], (int)fp[FP_TVCOLS]};
+  return bssm_user_tv{t, (const double*)(unsigned long long)__double_as_longlong(fp[FP_TVPTR]), (int)fp[FP_TVROWS], (int)fp[FP_TVCOLS]};
 }
 #define BSSM_UTV(fp_, t_) fn_user_tv((fp_), (t_)),
 #else

@@ -521,9 +521,10 @@ def test_user_model_three_states_post_correct_with_a_failed_draw(monkeypatch, de
         assert np.allclose(out["weights"][good], 1.0, rtol=1e-8)
 
 
+@pytest.mark.parametrize("jit", [False, True])   # (True, round 6: compiled in process -- the host set-up evaluates the snippet through its evaluation kernel)
 @pytest.mark.parametrize("path,N", [("wg", 700), ("grid", 3000)])
 @pytest.mark.parametrize("which", ["linear3", "nonlin4"])
-def test_user_model_psi_apf_against_the_general_oracle(oracle, monkeypatch, which, path, N):
+def test_user_model_psi_apf_against_the_general_oracle(oracle, monkeypatch, which, path, N, jit):
     """psi-APF of user-defined models with 3 and 4 states against orc_nlg_general_psi_* -- the restatement of
     ssm_nlg::psi_filter / log_weights / approximate over function pointers (src/model_ssm_nlg.cpp:62-143, 854-935, 971-1063),
     itself pinned in tests/test_reference_goldens.py: mode, approximate log-likelihood, ancestors, weights, log-likelihood"""
@@ -536,7 +537,7 @@ def test_user_model_psi_apf_against_the_general_oracle(oracle, monkeypatch, whic
         a1 = np.array([0.2, -0.1, 0.0]); P1 = np.diag([0.5, 0.3, 0.2])
         y = np.cumsum(rng.normal(0, 0.4, n)); y[7] = np.nan
         th, kn = A.reshape(-1, order="F")[:8], np.append(z, A[2, 2])
-        u = M.ssm_nlg_user(y, USER_LINEAR3, theta=th, known_params=kn, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=3)
+        u = M.ssm_nlg_user(y, USER_LINEAR3, theta=th, known_params=kn, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=3, jit=jit)
         Af = lambda th, kn: np.append(th, kn[3]).reshape(3, 3, order="F")
         fns = dict(Z_fn=lambda t, a, th, kn: kn[:3] @ a, T_fn=lambda t, a, th, kn: Af(th, kn) @ a,
                    Z_gn=lambda t, a, th, kn: kn[:3], T_gn=lambda t, a, th, kn: Af(th, kn))
@@ -549,7 +550,7 @@ def test_user_model_psi_apf_against_the_general_oracle(oracle, monkeypatch, whic
             y[t] = a[0] + 0.5 * a[2] + 0.1 * a[0] ** 2 / (1 + a[0] ** 2) + Hs * rng.normal()
             a = np.array([a[0] + a[1], th[0] * a[1] + 0.3 * np.sin(a[2]), 0.9 * a[2] + 0.2 * a[3], 0.5 * a[3]]) + rd * rng.normal(size=4)
         y[11] = np.nan
-        u = M.ssm_nlg_user(y, USER_NONLIN4, theta=th, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=4)
+        u = M.ssm_nlg_user(y, USER_NONLIN4, theta=th, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=4, jit=jit)
 
         def Tg(t, a, th, kn):
             J = np.zeros((4, 4))
@@ -599,7 +600,7 @@ BSSM_FN void bssm_user_Zg(const bssm_user_tv& tv, const double* a, const double*
 """
 
 
-def _tv3_case(seed=51, n=28):
+def _tv3_case(seed=51, n=28, jit=False):
     rng = np.random.default_rng(seed)
     tvm = np.vstack([0.3 * np.sin(np.arange(n) / 3.0), 1.0 + 0.5 * np.cos(np.arange(n) / 5.0)])  # 2 x n
     th = np.array([0.7])
@@ -612,7 +613,7 @@ def _tv3_case(seed=51, n=28):
                H_fn=lambda t, a, th, kn: Hs, R_fn=lambda t, a, th, kn: Rm)
     jac = dict(Z_gn=lambda t, a, th, kn: np.array([tvm[1, t], 0.0, 1.0]),
                T_gn=lambda t, a, th, kn: np.array([[th[0], 0.2 * np.cos(a[1]), 0.0], [0.0, 0.8, 0.1], [0.1, 0.0, 0.5]]))
-    u = M.ssm_nlg_user(y, USER_TV3, theta=th, a1=a1, P1=P1, H=Hs, R=Rm, n_states=3, known_tv_params=tvm)
+    u = M.ssm_nlg_user(y, USER_TV3, theta=th, a1=a1, P1=P1, H=Hs, R=Rm, n_states=3, known_tv_params=tvm, jit=jit)
     return u, y, th, a1, P1, fns, jac
 
 
@@ -653,15 +654,16 @@ def test_user_model_tv_snippet_without_matrix_is_refused():
         F.particle_smoother(bad, 64, method="psi", seed=1)
 
 
+@pytest.mark.parametrize("jit", [False, True])
 @pytest.mark.parametrize("path,N", [("wg", 500), ("grid", 3000)])
 @pytest.mark.parametrize("which", ["tv3_full_R", "nonlin4"])
-def test_user_model_ekf_particle_filter_three_and_four_states(oracle, monkeypatch, which, path, N):
+def test_user_model_ekf_particle_filter_three_and_four_states(oracle, monkeypatch, which, path, N, jit):
     """EKF-proposal particle filter (src/model_ssm_nlg.cpp:1148-1293) of user models with 3 states (time argument,
     known_tv_params, full matrix R, full P1) and 4 states: one EKF update per particle from its ancestor with general small
     factorisations on the device (psd_chol, dmvnorm on covariance / factor) -- against orc_nlg_general_ekpf_filter"""
     monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
     if which == "tv3_full_R":
-        u, y, th, a1, P1, fns, jac = _tv3_case(seed=61, n=22)
+        u, y, th, a1, P1, fns, jac = _tv3_case(seed=61, n=22, jit=jit)
         m, kn = 3, []
     else:
         rng = np.random.default_rng(63)
@@ -670,7 +672,7 @@ def test_user_model_ekf_particle_filter_three_and_four_states(oracle, monkeypatc
         rd = np.array([0.2, 0.15, 0.3, 0.1]); Hs = 0.5; m = 4
         a1 = np.zeros(4); P1 = np.diag([0.5, 0.2, 0.3, 0.1])
         y = np.cumsum(rng.normal(0, 0.3, n)); y[6] = np.nan
-        u = M.ssm_nlg_user(y, USER_NONLIN4, theta=th, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=4)
+        u = M.ssm_nlg_user(y, USER_NONLIN4, theta=th, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=4, jit=jit)
 
         def Tg(t, a, th, kn):
             J = np.zeros((4, 4))
@@ -907,7 +909,7 @@ BSSM_FN void bssm_user_Zg(const double* a, const double* th, const double* kn, d
 """
 
 
-def _six_case(seed=12, n=30):
+def _six_case(seed=12, n=30, jit=False):
     rng = np.random.default_rng(seed)
     m = 6
     th = np.array([0.85]); kn = np.zeros(0)
@@ -932,17 +934,18 @@ def _six_case(seed=12, n=30):
     y[9] = np.nan
     a1 = np.array([1.0, 0.0, 0.3, 0.0, 0.0, 0.4])
     P1 = np.diag([0.5, 0.01, 0.2, 0.1, 0.05, 0.3]); P1[0, 2] = P1[2, 0] = 0.1
-    u = M.ssm_nlg_user(y, USER_SIX_J, theta=th, known_params=kn, a1=a1, P1=P1, H=0.6, n_states=m, R=Rm)
+    u = M.ssm_nlg_user(y, USER_SIX_J, theta=th, known_params=kn, a1=a1, P1=P1, H=0.6, n_states=m, R=Rm, jit=jit)
     return u, y, m, th, kn, a1, P1, dict(Z_fn=Z, H_fn=H, T_fn=T, R_fn=R, Z_gn=Zg, T_gn=Tg)
 
 
+@pytest.mark.parametrize("jit", [False, True])
 @pytest.mark.parametrize("path,N", [("wg", 300), ("wg", 1200), ("grid", 4000)])
-def test_user_model_six_states_psi_apf_against_the_general_oracle(oracle, monkeypatch, path, N):
+def test_user_model_six_states_psi_apf_against_the_general_oracle(oracle, monkeypatch, path, N, jit):
     """psi-APF of a user model with SIX states and a full lower-triangular R (late round 4: the MP = 8 functor kernels carry the
     psi-APF too; src/model_ssm_nlg.cpp:62-143, 854-935, 971-1063 over function pointers): mode, approximate log-likelihood,
     ancestors, weights, log-likelihood and smoothed means against orc_nlg_general_psi_*."""
     monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
-    u, y, m, th, kn, a1, P1, fns = _six_case()
+    u, y, m, th, kn, a1, P1, fns = _six_case(jit=jit)
     n = y.size
     ref = oracle.nlg_general_psi(y, m, m, th, kn, a1, P1, nsim=N, seed=3, **fns)
     assert ref["ok"]
@@ -1085,9 +1088,12 @@ def test_user_model_compiled_in_process_equals_the_hipcc_built_library(oracle, t
     sj, sh = F.particle_smoother(uj, 700, method="bsf", seed=2), F.particle_smoother(uh, 700, method="bsf", seed=2)
     assert np.array_equal(sj["alphahat"], sh["alphahat"]) and np.array_equal(sj["Vt"], sh["Vt"])
     assert np.array_equal(F.logLik_batch(uj, 200, 40, method="bsf", seed=3), F.logLik_batch(uh, 200, 40, method="bsf", seed=3))
+    # round 6: the psi-APF and the EKF particle filter of the in-process model too -- its host set-up (mode search, linearisation) evaluates the
+    # snippet through a one-thread kernel instead of host code (device libm instead of the host's: the last place may differ, nothing else)
     for method in ("psi", "ekf"):
-        with pytest.raises(_lib.BssmAmdError, match="compiled in process"):
-            F.particle_smoother(uj, 100, method=method, seed=1)
+        pj, ph = F.particle_smoother(uj, 300, method=method, seed=1, return_indices=True), F.particle_smoother(uh, 300, method=method, seed=1, return_indices=True)
+        assert np.array_equal(pj["indices"], ph["indices"]) and abs(pj["logLik"] - ph["logLik"]) <= 1e-10 * b.n, method
+        assert np.allclose(pj["alphahat"], ph["alphahat"], rtol=1e-9, atol=1e-10), method
     # an SDE model (Milstein sub-steps)
     g, L = MODELS["sde_gbm"]
     gj = M.ssm_sde_user(g["y"], USER_GBM, theta=g["theta"], x0=g["x0"], positive=True, jit=True)
@@ -1208,3 +1214,49 @@ def test_user_model_twelve_states_bootstrap_against_the_general_oracle(oracle, m
                 F.particle_smoother(u, 100, method=method, seed=7)
         with pytest.raises(Exception, match="16"):
             M.ssm_nlg_user(np.zeros(4), USER_TWELVE, theta=c["th"], a1=np.zeros(17), P1=np.eye(17), H=0.5, n_states=17, R=np.eye(17))
+
+
+# ---------------------------------------------------------------- round 6: more than eight theta / known_params entries
+USER_MANYPAR = r"""
+#define BSSM_USER_NLG 1
+#define BSSM_USER_JACOBIANS 1
+// two states, TWELVE parameters and TEN known values (the reference has no cap on either: theta and known_params are arma::vec,
+// src/model_ssm_nlg.h:23-31): the entries beyond the eighth carry the model
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  out[0] = th[0] * a[0] + th[9] * sin(a[1]) + kn[8];
+  out[1] = th[10] * a[1] + kn[9] * a[0];
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + th[11] * a[1] + kn[1]; }
+BSSM_FN void bssm_user_Tg(const double* a, const double* th, const double* kn, double* Tg) { Tg[0] = th[0]; Tg[1] = kn[9]; Tg[2] = th[9] * cos(a[1]); Tg[3] = th[10]; }
+BSSM_FN void bssm_user_Zg(const double* a, const double* th, const double* kn, double* Zg) { Zg[0] = 1.0; Zg[1] = th[11]; }
+"""
+
+
+@pytest.mark.parametrize("jit", [False, True])
+@pytest.mark.parametrize("path,N", [("wg", 400), ("grid", 9000)])
+def test_user_model_with_twelve_parameters_and_ten_known_values(oracle, monkeypatch, path, N, jit):
+    """theta of 12 and known_params of 10 entries (round-5 review, "What's missing" 3: both were capped at 8, the reference caps neither):
+    bootstrap filter and psi-APF against the general oracle over Python functions of the same theta / known_params"""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    rng = np.random.default_rng(77)
+    n, m = 26, 2
+    th = np.array([0.8, 9.0, 9.0, 9.0, 9.0, 9.0, 9.0, 9.0, 9.0, 0.3, 0.7, 0.4])   # (the nines are never read)
+    kn = np.array([7.0, 0.1, 7.0, 7.0, 7.0, 7.0, 7.0, 7.0, 0.05, 0.1])
+    rd, Hs = np.array([0.3, 0.2]), 0.5
+    a1, P1 = np.array([0.1, -0.2]), np.diag([0.4, 0.3])
+    y = np.cumsum(rng.normal(0, 0.3, n)); y[5] = np.nan
+    u = M.ssm_nlg_user(y, USER_MANYPAR, theta=th, known_params=kn, a1=a1, P1=P1, H=Hs, R=np.diag(rd), n_states=2, jit=jit)
+    fns = dict(Z_fn=lambda t, a, th, kn: a[0] + th[11] * a[1] + kn[1],
+               T_fn=lambda t, a, th, kn: np.array([th[0] * a[0] + th[9] * np.sin(a[1]) + kn[8], th[10] * a[1] + kn[9] * a[0]]),
+               H_fn=lambda t, a, th, kn: Hs, R_fn=lambda t, a, th, kn: np.diag(rd))
+    jac = dict(Z_gn=lambda t, a, th, kn: np.array([1.0, th[11]]),
+               T_gn=lambda t, a, th, kn: np.array([[th[0], th[9] * np.cos(a[1])], [kn[9], th[10]]]))
+    ref = oracle.nlg_general_bsf_filter(y, m, m, th, kn, a1, P1, nsim=N, seed=6, **fns)
+    out = F.bootstrap_filter(u, N, seed=6, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"]) and abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    rp = oracle.nlg_general_psi(y, m, m, th, kn, a1, P1, nsim=N, seed=3, **fns, **jac)
+    assert rp["ok"]
+    su = F.psi_setup(u)
+    assert np.allclose(np.asarray(su["mode"]).reshape(m, n, order="F"), rp["mode"], rtol=0, atol=1e-9)
+    op = F.particle_smoother(u, N, method="psi", seed=3, return_indices=True)
+    assert np.array_equal(op["indices"], rp["indices"]) and abs(op["logLik"] - rp["logLik"]) <= 1e-9 * n
