@@ -433,7 +433,7 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
     const bssm::UserHostFns& h = g_user_host[mod->user_slot];
     const int ms = mod->n_states;
     if (ms < 1 || ms > max_states)
-      return fail(BSSM_ERR_UNSUPPORTED, "psi-APF / EKF particle filter of a user model: at most 8 states");
+      return fail(BSSM_ERR_UNSUPPORTED, max_states > 8 ? "psi-APF of a user model: at most 16 states" : "EKF particle filter of a user model (and the psi-APF of one with a state-dependent R_fn): at most 8 states");
     // (a model compiled in process -- bssm_user_model_jit -- has no host code: its T / Z / Jacobians reach the host set-up through a one-thread
     // evaluation kernel of the same snippet, round 6)
     if (!h.T || !h.Z || !h.Tg || !h.Zg)
@@ -454,7 +454,7 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
     f->user = &h;
     f->k = ks;
     f->uH = mod->H;
-    for (int q = 0; q < 64; q++) f->uRm[q] = 0.0;
+    for (int q = 0; q < 256; q++) f->uRm[q] = 0.0;
     if (Rsrc) { for (int c = 0; c < ks; c++) for (int j = 0; j < ms; j++) f->uRm[j + ms * c] = Rsrc[j + ms * c]; }  // m x k, zero columns behind
     else for (int j = 0; j < ms; j++) f->uRm[j + ms * j] = mod->R_diag[j];
     for (int j = 0; j < ms; j++) { f->uR[j] = f->uRm[j + ms * j]; f->ua1[j] = asrc[j]; }
@@ -473,7 +473,7 @@ int to_fn_model(const bssm_fn_model* mod, bssm::FnModel* f, int max_states) {
 int functor_psi_tables(const bssm_fn_model* mod, const double* is_mode, int max_iter, double conv_tol, bssm::FilterTables* ft,
                        std::vector<double>* fpar, std::vector<double>* amats, double* approx_loglik, bool* ok, int* m_out) {
   bssm::FnModel f;
-  int rc = to_fn_model(mod, &f);
+  int rc = to_fn_model(mod, &f, 16);   // (psi-APF: up to 16 states since round 6; a snippet with a state-dependent R_fn has no psi kernels beyond 8)
   if (rc) return rc;
   bssm::FilterTables dummy;
   int m = 1, k = 1;
@@ -606,7 +606,7 @@ int bssm_fn_psi_setup(const bssm_fn_model* model, const double* is_mode, int32_t
                       double* scales, double* approx_loglik, double* alphahat, double* Vt, double* Ct, double* Zt, double* Tt,
                       double* Dt, double* Cc) {
   bssm::FnModel f;
-  const int rc = to_fn_model(model, &f);
+  const int rc = to_fn_model(model, &f, 16);
   if (rc) return rc;
   bssm::FnSetup su;
   const bool loglik_only = !alphahat && !Vt && !Ct;  // (what the approximate MCMC chain asks for every iteration)
@@ -944,13 +944,19 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
     if (hw > 0) jobs = std::max(1, std::min(6, (int)hw / ranks));
     if (const char* ej = std::getenv("BSSM_AMD_USER_BUILD_JOBS")) jobs = std::max(1, std::min(6, std::atoi(ej)));
   }
-  // (more than 8 states: the bootstrap sampler only -- parts 0 and 3; the psi-APF / EKF particle filter of a user model end at 8 states)
-  const bool bsf_only = n_states > 8;
+  // More than 8 states: no EKF particle filter (its per-particle covariance is a register array) -- parts 2 and 5 are left out; the psi-APF
+  // (parts 1 and 4, round 6) for snippets with Jacobians and a CONSTANT R (a state-dependent R_fn needs two general m x m densities per particle:
+  // 8 states at most); everything else at 9 ... 16 states is the bootstrap sampler alone (parts 0 and 3)
+  const std::string src_s(source);
+  const bool wide = n_states > 8;
+  const bool wide_psi = wide && src_s.find("BSSM_USER_JACOBIANS") != std::string::npos && src_s.find("BSSM_USER_RFN") == std::string::npos && src_s.find("BSSM_USER_NLG") != std::string::npos;
+  const bool bsf_only = wide && !wide_psi;
   std::string cmd = "( ", objs, logs;
   for (int part = 0; part < 6; part++) {
     if (bsf_only && part % 3 != 0) continue;
+    if (wide_psi && part % 3 == 2) continue;
     const std::string obj = tmp + ".p" + std::to_string(part) + ".o", plog = log_tmp + ".p" + std::to_string(part);
-    cmd += common + (bsf_only ? "-DBSSM_USER_BSF_ONLY=1 " : "") + "-DBSSM_USER_PART=" + std::to_string(part) + " -c '" + dir + "/csrc/user_model_tu.hip' -o '" + obj + "' > '" + plog + "' 2>&1 & ";
+    cmd += common + (bsf_only ? "-DBSSM_USER_BSF_ONLY=1 " : (wide_psi ? "-DBSSM_USER_NO_EKF=1 " : "")) + "-DBSSM_USER_PART=" + std::to_string(part) + " -c '" + dir + "/csrc/user_model_tu.hip' -o '" + obj + "' > '" + plog + "' 2>&1 & ";
     if ((part + 1) % jobs == 0 && part + 1 < 6) cmd += "wait ; ";
     objs += " '" + obj + "'";
     logs += " '" + plog + "'";
@@ -1257,7 +1263,7 @@ void jit_bind(int slot, bssm::UserHostFns* h, bool jac, bool hfn, bool rfn) { ji
 // workgroup-resident shape: the 512-thread form of launch_wg_mk (pf_filter_impl.h), bootstrap sampler
 hipError_t jit_launch_wg(const bssm::FilterBatch* bp, hipStream_t stream) {
   JitModel* jm = jit_of(bp->user_slot);
-  if (!jm || bp->psi < 0 || bp->psi > 2 || (bp->psi != 0 && jm->MP > 8) || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process: psi-APF / EKF particle filter up to 8 states"); return hipErrorInvalidValue; }
+  if (!jm || bp->psi < 0 || bp->psi > 2 || (bp->psi == 2 && jm->MP > 8) || (bp->psi == 1 && jm->MP > 8 && jm->source.find("BSSM_USER_RFN") != std::string::npos) || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process: EKF particle filter (and the psi-APF with a state-dependent R_fn) up to 8 states"); return hipErrorInvalidValue; }
   bssm::FilterBatch b = *bp;
   b.user_slot = 0;
   const int MP = jm->MP, N = b.N;
@@ -1283,7 +1289,7 @@ hipError_t jit_launch_wg(const bssm::FilterBatch* bp, hipStream_t stream) {
 // (pf_grid_v2.h, the time loop of launch_grid_mk) beyond -- with module launches
 hipError_t jit_launch_grid(const bssm::FilterBatch* bp, const bssm::GridWorkspace* wsp_in, hipStream_t stream, bssm::StepTiming* timing) {
   JitModel* jm = jit_of(bp->user_slot);
-  if (!jm || bp->psi < 0 || bp->psi > 2 || (bp->psi != 0 && jm->MP > 8) || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process: psi-APF / EKF particle filter up to 8 states"); return hipErrorInvalidValue; }
+  if (!jm || bp->psi < 0 || bp->psi > 2 || (bp->psi == 2 && jm->MP > 8) || (bp->psi == 1 && jm->MP > 8 && jm->source.find("BSSM_USER_RFN") != std::string::npos) || bp->MP != jm->MP || bp->KP != jm->MP) { fail(BSSM_ERR_UNSUPPORTED, "a user model compiled in process: EKF particle filter (and the psi-APF with a state-dependent R_fn) up to 8 states"); return hipErrorInvalidValue; }
   const bssm::GridWorkspace& ws = *wsp_in;
   constexpr int kGridNT = 256, kMaxBlocks = 256;  // GRID_NT (pf_filter_impl.h), V2_MAX_BLOCKS (pf_grid_v2.h)
   const bool rows = ws.chunk == bssm::CANON_ROW;

@@ -903,7 +903,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
   const bool user_rfn = models[0].model_id == bssm::FN_USER_NLG && models[0].user_slot >= 1 && models[0].user_slot <= 63 && g_user_host[models[0].user_slot].R;
   const size_t am_stride = (size_t)n * (size_t)bssm::fn_amats_row(bssm::pad_dim(m), user_rfn);  // per-draw slot of J.amats
   if (psi) { J.amats.assign((size_t)count * am_stride, 0.0); J.count_draws = count; }
-  const bool dev_setup = psi && device_setup_enabled(n_threads) && have_device();
+  const bool dev_setup = psi && device_setup_enabled(n_threads) && have_device() && m <= 8;   // (lg_setup_kernel: up to 8 states; 9 ... 16: the host set-up)
   std::vector<bssm::FnModel> fms(dev_setup ? count : 0);
   std::vector<bssm::FnSetup> fsus(dev_setup ? count : 0);
   std::vector<bssm::LgPacked> lgs(dev_setup ? count : 0);
@@ -933,7 +933,7 @@ int bssm_is_correction_nlg(const bssm_fn_model* models, int32_t first, int32_t c
       // approximate_for_is(mode_i): scales 0, approx_loglik 0 (src/approx_mcmc.cpp:372-373)
       if (dev_setup) {
         bssm::FilterTables dummy;
-        if (to_fn_model(&models[i], &fms[i])) return g_err;
+        if (to_fn_model(&models[i], &fms[i], 16)) return g_err;
         if (functor_tables(&models[i], &dummy, &fp, &mm_, &kk_)) return g_err;
         std::memcpy(J.fpar.data() + (size_t)i * J.fps, fp.data(), J.fps * sizeof(double));
         if (bssm::fn_psi_setup_begin(fms[i], modes + (size_t)m * n * i, &fsus[i], &lgs[i])) { pending[i] = 1; return ""; }

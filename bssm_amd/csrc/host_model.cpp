@@ -1162,9 +1162,11 @@ void build_psi_tables(const HostModel& h, const PsiSetup& su, int MP, FilterTabl
 
 // ------------------------------------------------------------------ built-in ssm_nlg functors (host side)
 namespace {
+// user models: up to 16 states in the psi-APF set-up since round 6 (8 before; the EKF particle filter keeps 8: its per-particle covariance is a register array)
+constexpr int kFnM = 16, kFnMM = kFnM * kFnM;
 double fnH(const FnModel& f) { if (f.id == 7) return f.uH; return f.id == 1 ? std::exp(f.theta[0]) : (f.id == 2 ? std::exp(f.theta[3]) : std::exp(f.theta[0])); }
 void fnRdiag(const FnModel& f, double* r) {
-  for (int j = 0; j < 8; j++) r[j] = 0;  // (callers hold 8 entries: a user model may have up to 8 states)
+  for (int j = 0; j < kFnM; j++) r[j] = 0;  // (callers hold kFnM entries)
   if (f.id == 7) { for (int j = 0; j < f.m; j++) r[j] = f.uR[j]; return; }
   switch (f.id) { case 1: r[0] = std::exp(f.theta[1]); r[1] = std::exp(f.theta[2]); break; case 2: r[0] = std::exp(f.theta[2]); break;
                   case 3: r[0] = std::exp(f.theta[1]); break; default: r[0] = 1.0; }
@@ -1214,19 +1216,19 @@ double dnorm_sd(double y, double mean, double sd) { return -0.5 * (std::log(2.0 
 // dmvnorm(x, mean, S, lwr = false, logd = true) for any covariance, d <= 8 (src/dmvnorm.cpp:4-58): the components with a
 // zero diagonal are dropped, the rest goes through the Cholesky factor
 double dmvnorm_cov4(const double* x, const double* mean, const double* S, int d) {
-  int idx[8], cnt = 0;
+  int idx[kFnM], cnt = 0;
   for (int j = 0; j < d; j++) if (S[j + d * j] > kEps) idx[cnt++] = j;
-  double L[64] = {0}, z2[8], out = -0.5 * cnt * std::log(2.0 * kPi);
+  double L[kFnMM] = {0}, z2[kFnM], out = -0.5 * cnt * std::log(2.0 * kPi);
   for (int a = 0; a < cnt; a++) {
     for (int b = 0; b <= a; b++) {
       double v = S[idx[a] + d * idx[b]];
-      for (int q = 0; q < b; q++) v -= L[a + 8 * q] * L[b + 8 * q];
-      L[a + 8 * b] = a == b ? std::sqrt(v) : v / L[b + 8 * b];
+      for (int q = 0; q < b; q++) v -= L[a + kFnM * q] * L[b + kFnM * q];
+      L[a + kFnM * b] = a == b ? std::sqrt(v) : v / L[b + kFnM * b];
     }
     double sacc = x[idx[a]] - mean[idx[a]];
-    for (int b = 0; b < a; b++) sacc -= L[a + 8 * b] * z2[b];
-    z2[a] = sacc / L[a + 8 * a];
-    out += -std::log(L[a + 8 * a]) - 0.5 * z2[a] * z2[a];
+    for (int b = 0; b < a; b++) sacc -= L[a + kFnM * b] * z2[b];
+    z2[a] = sacc / L[a + kFnM * a];
+    out += -std::log(L[a + kFnM * a]) - 0.5 * z2[a] * z2[a];
   }
   return out;
 }
@@ -1235,12 +1237,12 @@ void fnRmat(const FnModel& f, double* Rm) {
   const int m = f.m;
   for (int q = 0; q < m * m; q++) Rm[q] = 0.0;
   if (f.id == 7) { for (int q = 0; q < m * m; q++) Rm[q] = f.uRm[q]; return; }
-  double rd[8]; fnRdiag(f, rd);
+  double rd[kFnM]; fnRdiag(f, rd);
   for (int j = 0; j < m; j++) Rm[j + m * j] = rd[j];
 }
 void fnRR(const FnModel& f, double* RR) {
   const int m = f.m;
-  double Rm[64]; fnRmat(f, Rm);
+  double Rm[kFnMM]; fnRmat(f, Rm);
   for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double sacc = 0; for (int q = 0; q < m; q++) sacc += Rm[i + m * q] * Rm[j + m * q]; RR[i + m * j] = sacc; }
 }
 // a user model whose R or P1 has off-diagonal entries: the densities below go through the general routine (the shipped
@@ -1260,7 +1262,7 @@ double fnH_at(const FnModel& f, const double* x, int t) {
 void fnRmat_at(const FnModel& f, const double* x, int t, double* Rm) {  // m x m, zero columns behind k
   if (f.id == 7 && f.user && f.user->R) {
     const int m = f.m;
-    double Ru[64] = {0};
+    double Ru[kFnMM] = {0};
     f.user->R(t, f.known_tv, f.tv_rows, f.tv_cols, x, f.theta, f.known, Ru);  // m x k, leading dimension m
     for (int q = 0; q < m * m; q++) Rm[q] = 0.0;
     for (int c = 0; c < f.k && c < m; c++) for (int j = 0; j < m; j++) Rm[j + m * c] = Ru[j + m * c];
@@ -1271,7 +1273,7 @@ void fnRmat_at(const FnModel& f, const double* x, int t, double* Rm) {  // m x m
 void small_rrt(int m, const double* Rm, double* RR) {
   for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double sacc = 0; for (int q = 0; q < m; q++) sacc += Rm[i + m * q] * Rm[j + m * q]; RR[i + m * j] = sacc; }
 }
-void fnRR_at(const FnModel& f, const double* x, int t, double* RR) { double Rm[64]; fnRmat_at(f, x, t, Rm); small_rrt(f.m, Rm, RR); }
+void fnRR_at(const FnModel& f, const double* x, int t, double* RR) { double Rm[kFnMM]; fnRmat_at(f, x, t, Rm); small_rrt(f.m, Rm, RR); }
 // the approximating model's observation sd per time point
 void fn_approx_H(const FnModel& f, const FnSetup& su, std::vector<double>* H) {
   if (f.state_noise()) *H = su.Ht; else H->assign(f.n, su.H);
@@ -1281,7 +1283,7 @@ void fn_linearise(const FnModel& f, const double* zpts, const double* tpts, FnSe
   const int n = f.n, m = f.m;
   for (int t = 0; t < n; t++) {
     const double* zp = zpts + (size_t)m * t; const double* tp = tpts + (size_t)m * t;
-    double* Zt = su->Z.data() + (size_t)m * t; double* Tt = su->T.data() + (size_t)m * m * t; double Tf[8];
+    double* Zt = su->Z.data() + (size_t)m * t; double* Tt = su->T.data() + (size_t)m * m * t; double Tf[kFnM];
     fnZg(f, zp, Zt, t); fnTg(f, tp, Tt, t);
     double za = 0; for (int j = 0; j < m; j++) za += Zt[j] * zp[j];
     su->D[t] = fnZ(f, zp, t) - za;
@@ -1313,7 +1315,7 @@ void fn_gaussian_model(const FnModel& f, const FnSetup& su, HostModel* g) {
 }
 double fn_log_signal_pdf(const FnModel& f, const double* al) {  // src/model_ssm_nlg.cpp:1295-1319
   const int n = f.n, m = f.m;
-  double a1[8], P1[64], rd[8], pv[8], rv[8], RR[64];
+  double a1[kFnM], P1[kFnMM], rd[kFnM], pv[kFnM], rv[kFnM], RR[kFnMM];
   fn_a1P1(f, a1, P1); fnRdiag(f, rd);
   const bool full = fn_full_cov(f);
   if (full) fnRR(f, RR);
@@ -1322,7 +1324,7 @@ double fn_log_signal_pdf(const FnModel& f, const double* al) {  // src/model_ssm
   double ll = (full || sn) ? dmvnorm_cov4(al, a1, P1, m) : dmvnorm_diag(al, a1, pv, m);
   if (std::isfinite(f.y[0])) ll += dnorm_sd(f.y[0], fnZ(f, al, 0), fnH_at(f, al, 0));
   for (int t = 0; t < n - 1; t++) {
-    double mean[8];
+    double mean[kFnM];
     fnT(f, al + (size_t)m * t, mean, t);
     if (sn) { fnRR_at(f, al + (size_t)m * t, t, RR); ll += dmvnorm_cov4(al + (size_t)m * (t + 1), mean, RR, m); }
     else ll += full ? dmvnorm_cov4(al + (size_t)m * (t + 1), mean, RR, m) : dmvnorm_diag(al + (size_t)m * (t + 1), mean, rv, m);
@@ -1333,7 +1335,7 @@ double fn_log_signal_pdf(const FnModel& f, const double* al) {  // src/model_ssm
 // out = A B A' for m x m column-major operands, m <= 8: the products are formed in the order the generic Mat operators
 // use ((A B) first, every entry summed over the inner index from zero), without their temporaries
 static inline void small_abat(int m, const double* A, const double* B, double* out) {
-  double X[64];
+  double X[kFnMM];
   for (int j = 0; j < m; j++)
     for (int i = 0; i < m; i++) { double c = 0.0; for (int q = 0; q < m; q++) c += A[i + m * q] * B[q + m * j]; X[i + m * j] = c; }
   for (int j = 0; j < m; j++)
@@ -1343,7 +1345,7 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
   const int n = f.n, m = f.m, mm = m * m;
   std::vector<double> Pt((size_t)mm * (n + 1), 0.0), Ptt((size_t)mm * n, 0.0);
   at->assign((size_t)m * (n + 1), 0.0); att->assign((size_t)m * n, 0.0);
-  double RRf[64]; double H = fnH(f);
+  double RRf[kFnMM]; double H = fnH(f);
   const bool sn = f.state_noise();
   fnRR(f, RRf);  // (diagonal R: exactly diag(r_i * r_i))
   fn_a1P1(f, at->data(), Pt.data());
@@ -1352,7 +1354,7 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
     double* af = att->data() + (size_t)m * t; double* Pf = Ptt.data() + (size_t)mm * t;
     if (std::isfinite(f.y[t])) {
       if (sn) H = fnH_at(f, a, t);  // H_fn at the predicted state (:311)
-      double Zg[8], PZ[8] = {0}, K[8], F = H * H;
+      double Zg[kFnM], PZ[kFnM] = {0}, K[kFnM], F = H * H;
       fnZg(f, a, Zg, t);
       for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) PZ[i] += P[i + m * j] * Zg[j];
       for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
@@ -1360,15 +1362,15 @@ bool fn_ekf(const FnModel& f, std::vector<double>* at, std::vector<double>* att)
       const double cF = std::sqrt(F), v = f.y[t] - fnZ(f, a, t);
       for (int i = 0; i < m; i++) K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF);
       for (int i = 0; i < m; i++) af[i] = a[i] + K[i] * v;
-      double IKZ[64], J[64];
+      double IKZ[kFnMM], J[kFnMM];
       for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
       small_abat(m, IKZ, P, J);
       for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pf[i + m * j] = J[i + m * j] + K[i] * H * H * K[j];
     } else { std::memcpy(af, a, sizeof(double) * m); std::memcpy(Pf, P, sizeof(double) * mm); }
-    double Tg[64];
+    double Tg[kFnMM];
     fnT(f, af, at->data() + (size_t)m * (t + 1), t);
     fnTg(f, af, Tg, t);
-    double Pn[64];
+    double Pn[kFnMM];
     if (sn) fnRR_at(f, af, t, RRf);  // R_fn at the filtered state (:366-370)
     small_abat(m, Tg, Pf, Pn);
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) Pt[i + m * j + (size_t)mm * (t + 1)] = Pn[i + m * j] + RRf[i + m * j];
@@ -1394,10 +1396,10 @@ void fn_a1P1(const FnModel& f, double* a1, double* P1) {
 void fn_ekpf_init(const FnModel& f, double* a1, double* P1, double* att1, double* L1) {
   const int m = f.m;
   fn_a1P1(f, a1, P1);
-  double Ptt[64] = {0};
+  double Ptt[kFnMM] = {0};
   const double y = f.y[0];
   if (std::isfinite(y)) {  // ekf_update_step (:1264-1293)
-    double Zg[8] = {0}, PZ[8] = {0}, K[8];
+    double Zg[kFnM] = {0}, PZ[kFnM] = {0}, K[kFnM];
     fnZg(f, a1, Zg, 0);
     const double H = fnH_at(f, a1, 0);
     double F = H * H;
@@ -1405,7 +1407,7 @@ void fn_ekpf_init(const FnModel& f, double* a1, double* P1, double* att1, double
     for (int j = 0; j < m; j++) F += Zg[j] * PZ[j];
     const double cF = std::sqrt(F), v = y - fnZ(f, a1, 0);
     for (int i = 0; i < m; i++) { K[i] = PZ[i] * (1.0 / cF) * (1.0 / cF); att1[i] = a1[i] + K[i] * v; }
-    double IKZ[64], tmp[64];
+    double IKZ[kFnMM], tmp[kFnMM];
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) IKZ[i + m * j] = (i == j ? 1.0 : 0.0) - K[i] * Zg[j];
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double acc = 0; for (int q = 0; q < m; q++) acc += IKZ[i + m * q] * P1[q + m * j]; tmp[i + m * j] = acc; }
     for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) { double acc = 0; for (int q = 0; q < m; q++) acc += tmp[i + m * q] * IKZ[j + m * q]; Ptt[i + m * j] = acc + K[i] * H * H * K[j]; }
@@ -1484,7 +1486,7 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
       gll = gaussian_loglik(S, ap);
     }
     // update_scales (:854-879)
-    double rd[8], rv[8], RRs[64];
+    double rd[kFnM], rv[kFnM], RRs[kFnMM];
     fnRdiag(f, rd);
     const bool full = fn_full_cov(f);
     if (full) fnRR(f, RRs);
@@ -1501,11 +1503,11 @@ bool fn_psi_setup(const FnModel& f, const double* is_mode, int max_iter, double 
     }
     for (int t = 1; t < n; t++) {
       const double* mp = su->mode.data() + (size_t)m * (t - 1); const double* md = su->mode.data() + (size_t)m * t;
-      double mean[8], amean[8];
+      double mean[kFnM], amean[kFnM];
       fnT(f, mp, mean, t - 1);
       for (int i = 0; i < m; i++) { double sacc = 0; for (int j = 0; j < m; j++) sacc += su->T[i + m * j + (size_t)mm * (t - 1)] * mp[j]; amean[i] = su->C[i + (size_t)m * (t - 1)] + sacc; }
       if (sn) {  // the model's R at the previous mode point against the approximating R_{t-1} (:869-876)
-        double RRm[64], RRa[64];
+        double RRm[kFnMM], RRa[kFnMM];
         fnRR_at(f, mp, t - 1, RRm);
         small_rrt(m, su->Rt.data() + (size_t)mm * (t - 1), RRa);
         su->scales[t] += dmvnorm_cov4(md, mean, RRm, m) - dmvnorm_cov4(md, amean, RRa, m);
@@ -1586,7 +1588,7 @@ void build_fn_psi_tables(const FnModel& f, const FnSetup& su, FilterTables* ft, 
     for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) am[j + MP * c] = su.T[j + m * c + (size_t)mm * t];
     for (int j = 0; j < m; j++) am[MP * MP + j] = su.C[j + (size_t)m * t];
     if (rfn) {
-      double RRa[64];
+      double RRa[kFnMM];
       small_rrt(m, su.Rt.data() + (size_t)mm * t, RRa);
       for (int c = 0; c < m; c++) for (int j = 0; j < m; j++) am[MP * MP + MP + j + MP * c] = RRa[j + m * c];
     }

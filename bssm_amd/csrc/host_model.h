@@ -135,8 +135,8 @@ struct FnModel {
   int positive = 0, L = 0;
   // user-defined ssm_nlg (id 7): host functions and the state-independent numbers the caller supplied
   const UserHostFns* user = nullptr;
-  double uH = 1, uR[8] = {0}, ua1[8] = {0}, uP1[64] = {0};  // (user models: up to 8 states)
-  double uRm[64] = {0};  // the full constant R (m x m, column-major, unpadded) of a user model; uR is its diagonal
+  double uH = 1, uR[16] = {0}, ua1[16] = {0}, uP1[256] = {0};  // (user models: up to 16 states in the psi-APF, round 6)
+  double uRm[256] = {0};  // the full constant R (m x m, column-major, unpadded) of a user model; uR is its diagonal
   const double* known_tv = nullptr;  // known_tv_params (host), tv_rows x tv_cols column-major: passed to BSSM_USER_TV snippets with t
   int tv_rows = 0, tv_cols = 0;
   // H or R depends on the state: the approximating model then has H_t = H_fn(mode_t), R_t = R_fn(mode_t) per time point
@@ -144,7 +144,7 @@ struct FnModel {
 };
 struct FnSetup {
   std::vector<double> Z, T, D, C;   // m x n, m x m x n, n, m x n : the mode-linearised model
-  double H = 1, R[64] = {0};
+  double H = 1, R[256] = {0};
   std::vector<double> Ht, Rt;       // models with state-dependent noise: H_t (n) and R_t (m x m x n, zero columns behind k); else empty
   std::vector<double> mode, scales;
   double approx_loglik = 0;

@@ -101,6 +101,14 @@ extern "C" hipError_t bssm_user_launch_grid(const bssm::FilterBatch* b, const bs
                                             bssm::StepTiming* timing) {
   return b->psi == 0 ? bssm_user_launch_grid_p0(b, ws, stream, timing) : hipErrorInvalidValue;
 }
+#elif defined(BSSM_USER_NO_EKF)   // 9 ... 16 states with Jacobians and a constant R: bootstrap and psi-APF (parts 0, 1, 3, 4)
+extern "C" hipError_t bssm_user_launch_wg(const bssm::FilterBatch* b, hipStream_t stream) {
+  return b->psi == 0 ? bssm_user_launch_wg_p0(b, stream) : (b->psi == 1 ? bssm_user_launch_wg_p1(b, stream) : hipErrorInvalidValue);
+}
+extern "C" hipError_t bssm_user_launch_grid(const bssm::FilterBatch* b, const bssm::GridWorkspace* ws, hipStream_t stream,
+                                            bssm::StepTiming* timing) {
+  return b->psi == 0 ? bssm_user_launch_grid_p0(b, ws, stream, timing) : (b->psi == 1 ? bssm_user_launch_grid_p1(b, ws, stream, timing) : hipErrorInvalidValue);
+}
 #else
 extern "C" hipError_t bssm_user_launch_wg(const bssm::FilterBatch* b, hipStream_t stream) {
   return b->psi == 0 ? bssm_user_launch_wg_p0(b, stream) : (b->psi == 1 ? bssm_user_launch_wg_p1(b, stream) : bssm_user_launch_wg_p2(b, stream));

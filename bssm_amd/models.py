@@ -581,7 +581,7 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
     ``known_tv_params``: the reference's matrix of known time-varying values (R/models.R:1507); a snippet that defines
     ``BSSM_USER_TV`` receives it, with the time index, as the leading ``const bssm_user_tv& tv`` argument of every function
     (``tv.t``, ``tv.known_tv`` column-major ``tv.rows x tv.cols``).
-    The bootstrap filter / smoother / bootstrap IS correction take up to 16 states (round 5; the psi-APF and the EKF particle filter: 8), with any ``R`` (n_states x n_etas matrix, or a function of theta) and the
+    The bootstrap filter / smoother / bootstrap IS correction and (round 6, snippets with Jacobians and a constant R) the psi-APF take up to 16 states; the EKF particle filter: 8, with any ``R`` (n_states x n_etas matrix, or a function of theta) and the
     reference's state-dependent ``H_fn`` / ``R_fn`` as snippet functions (``BSSM_USER_HFN`` + ``bssm_user_H``,
     ``BSSM_USER_RFN`` + ``bssm_user_R``; src/model_ssm_nlg.h:12-13), which then replace ``H`` / ``R`` (``R`` still fixes
     n_etas; for the psi-APF R(a) R(a)' must be positive definite on its non-zero diagonal).
@@ -591,7 +591,7 @@ def ssm_nlg_user(y, device_code: str, theta, a1, P1, H=1.0, R_diag=None, known_p
     theta = np.asarray(theta, dtype=float)
     m = int(n_states or np.asarray(a1(theta) if callable(a1) else a1, dtype=float).size)
     if not 1 <= m <= 16:
-        raise ValueError("user-defined ssm_nlg models: n_states must be 1 ... 16 (psi-APF / EKF particle filter: 8)")
+        raise ValueError("user-defined ssm_nlg models: n_states must be 1 ... 16 (EKF particle filter: 8)")
     if R is None and R_diag is None:
         if "BSSM_USER_RFN" not in device_code:
             raise ValueError("give R_diag, R, or a snippet with BSSM_USER_RFN / bssm_user_R")

@@ -1260,3 +1260,74 @@ def test_user_model_with_twelve_parameters_and_ten_known_values(oracle, monkeypa
     assert np.allclose(np.asarray(su["mode"]).reshape(m, n, order="F"), rp["mode"], rtol=0, atol=1e-9)
     op = F.particle_smoother(u, N, method="psi", seed=3, return_indices=True)
     assert np.array_equal(op["indices"], rp["indices"]) and abs(op["logLik"] - rp["logLik"]) <= 1e-9 * n
+
+
+# ---------------------------------------------------------------- round 6: the psi-APF of user models with 9 ... 16 states
+USER_TWELVE_J = r"""
+#define BSSM_USER_NLG 1
+#define BSSM_USER_JACOBIANS 1
+// twelve states with Jacobians (the psi-APF needs them, as in the reference: src/model_ssm_nlg.cpp:62-143)
+BSSM_FN void bssm_user_T(const double* a, const double* th, const double* kn, double* out) {
+  for (int j = 0; j < 11; j++) out[j] = (0.5 + 0.03 * j) * a[j] + 0.1 * sin(a[j + 1]);
+  out[11] = th[0] * a[11] + 0.05 * tanh(a[0]);
+}
+BSSM_FN double bssm_user_Z(const double* a, const double* th, const double* kn) { return a[0] + a[3] + a[6] + a[9] + 0.1 * a[7] * a[7]; }
+BSSM_FN void bssm_user_Tg(const double* a, const double* th, const double* kn, double* Tg) {
+  for (int q = 0; q < 144; q++) Tg[q] = 0.0;
+  for (int j = 0; j < 11; j++) { Tg[j + 12 * j] = 0.5 + 0.03 * j; Tg[j + 12 * (j + 1)] = 0.1 * cos(a[j + 1]); }
+  const double th0 = tanh(a[0]);
+  Tg[11 + 12 * 11] = th[0]; Tg[11 + 12 * 0] = 0.05 * (1.0 - th0 * th0);
+}
+BSSM_FN void bssm_user_Zg(const double* a, const double* th, const double* kn, double* Zg) {
+  for (int j = 0; j < 12; j++) Zg[j] = 0.0;
+  Zg[0] = 1.0; Zg[3] = 1.0; Zg[6] = 1.0; Zg[9] = 1.0; Zg[7] = 0.2 * a[7];
+}
+"""
+
+
+@pytest.mark.parametrize("jit", [False, True])
+@pytest.mark.parametrize("path,N", [("wg", 300), ("grid", 9000)])
+def test_user_model_twelve_states_psi_apf_against_the_general_oracle(oracle, monkeypatch, path, N, jit):
+    """psi-APF of a user model with TWELVE states (round-5 review, "What's missing" 3: it ended at 8; the reference takes any n_states,
+    src/model_ssm_nlg.cpp:971-1063): mode search and linearisation on the host (generic matrices), the MP = 16 functor kernels with the
+    transition-density ratio through the inverse factor of R R' -- mode, approximate log-likelihood, ancestors, weights, log-likelihood and
+    smoothed means against orc_nlg_general_psi_*; the EKF particle filter of it is refused (8 states)."""
+    monkeypatch.setenv("BSSM_AMD_FORCE_PATH", path)
+    rng = np.random.default_rng(23)
+    m, n = 12, 20
+    th, kn = np.array([0.8]), np.zeros(0)
+    Rm = np.diag(0.1 + 0.02 * np.arange(m)); Rm[3, 1] = -0.05; Rm[10, 4] = 0.07; Rm[6, 5] = 0.03
+    Z = lambda t, a, th_, kn_: a[0] + a[3] + a[6] + a[9] + 0.1 * a[7] ** 2
+    T = lambda t, a, th_, kn_: np.array([(0.5 + 0.03 * j) * a[j] + 0.1 * np.sin(a[j + 1]) for j in range(11)] + [th_[0] * a[11] + 0.05 * np.tanh(a[0])])
+
+    def Tg(t, a, th_, kn_):
+        J = np.zeros((12, 12))
+        for j in range(11):
+            J[j, j] = 0.5 + 0.03 * j; J[j, j + 1] = 0.1 * np.cos(a[j + 1])
+        J[11, 11] = th_[0]; J[11, 0] = 0.05 * (1.0 - np.tanh(a[0]) ** 2)
+        return J
+    Zg = lambda t, a, th_, kn_: np.array([1.0, 0, 0, 1.0, 0, 0, 1.0, 0.2 * a[7], 0, 1.0, 0, 0])
+    a = 0.3 * rng.normal(size=m); y = np.zeros(n)
+    for t in range(n):
+        y[t] = Z(t, a, th, kn) + 0.5 * rng.normal()
+        a = T(t, a, th, kn) + Rm @ rng.normal(size=m)
+    y[5] = np.nan
+    a1 = 0.1 * np.arange(m) - 0.5
+    P1 = np.diag(0.05 + 0.02 * np.arange(m)); P1[0, 4] = P1[4, 0] = 0.03
+    u = M.ssm_nlg_user(y, USER_TWELVE_J, theta=th, known_params=kn, a1=a1, P1=P1, H=0.5, n_states=m, R=Rm, jit=jit)
+    fns = dict(Z_fn=Z, H_fn=lambda t, a, th_, kn_: 0.5, T_fn=T, R_fn=lambda t, a, th_, kn_: Rm, Z_gn=Zg, T_gn=Tg)
+    ref = oracle.nlg_general_psi(y, m, m, th, kn, a1, P1, nsim=N, seed=3, **fns)
+    assert ref["ok"]
+    su = F.psi_setup(u)
+    assert np.allclose(np.asarray(su["mode"]).reshape(m, n, order="F"), ref["mode"], rtol=0, atol=1e-9)
+    assert abs(su["approx_loglik"] - ref["approx_loglik"]) <= 1e-9 * n
+    out = F.particle_smoother(u, N, method="psi", seed=3, return_indices=True)
+    assert np.array_equal(out["indices"], ref["indices"])
+    assert abs(out["logLik"] - ref["logLik"]) <= 1e-9 * n
+    assert _rel(out["weights"], ref["weights"]) <= 1e-8
+    mean, cov = oracle.summary(oracle.filter_smoother(ref["alpha"], ref["indices"]))
+    assert _rel(out["alphahat"], mean.T[:n]) <= 1e-8
+    if path == "wg":
+        from bssm_amd import _lib
+        with pytest.raises(_lib.BssmAmdError, match="8 states"):
+            F.particle_smoother(u, 100, method="ekf", seed=1)
