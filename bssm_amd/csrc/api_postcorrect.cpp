@@ -632,15 +632,16 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
   // (n < 65535: the set-up's parallel kernels carry the time point in gridDim.y; longer series take the host set-up)
   // (univariate observations: 9 ... 16 states go padded to 16 -- ung_pack, round 5)
   // (17 ... 64 states go padded to 32 / 64: the smoother with its matrices in LDS, lg_smoother_wave.h)
-  const int m_dev = (p0 == 1 && m > 8) ? (m <= 16 ? 16 : (m <= 32 ? 32 : 64)) : m;   // the state dimension the set-up kernels are instantiated for
-  bool dev_full = psi && have_device() && (p0 == 1 ? m <= 64 : m <= 8) && n < 65535 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
+  // (ssm_mng draws of 9 ... 64 states too since round 6: mng_pack pads them the same way)
+  const int m_dev = m > 8 ? (m <= 16 ? 16 : (m <= 32 ? 32 : 64)) : m;   // the state dimension the set-up kernels are instantiated for
+  bool dev_full = psi && have_device() && m <= 64 && n < 65535 && job->is_type != 1 && (p0 == 1 ? job->models[0].distribution != BSSM_GAUSSIAN : true);
   if (bssm::opt().device_setup >= 0) dev_full = dev_full && bssm::opt().device_setup == 2;
   if (bssm::opt().generic_setup) dev_full = false;
   if (dev_full && m_dev >= 32) {
     // the work arrays of a padded big state are 4 (n + 1) M^2 doubles per draw (13 MB at M = 64, T = 100) and a chunk is at least 64 draws: a series so
     // long that 64 draws do not fit a quarter of what the device has free (up to three chunks are alive at once) takes the host set-up instead of failing with hipErrorOutOfMemory
     size_t free_b = 0, total_b = 0;
-    const double per_draw = (double)bssm::ung_setup_scratch_doubles(n, m_dev) * sizeof(double);
+    const double per_draw = (double)(p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m_dev, p0) : bssm::ung_setup_scratch_doubles(n, m_dev)) * sizeof(double);
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_draw * 64.0 > 0.25 * ((double)free_b + (double)arena().cached)) dev_full = false;
   }
   if (dev_full) {
@@ -686,7 +687,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       DevBuf& din = ct->in_a; DevBuf& din_t = ct->in_b;
       HIP_TRY(din.alloc(E * F * sizeof(double)));
       HIP_TRY(din_t.alloc(E * F * sizeof(double)));
-      HIP_TRY(ct->scratch.alloc((p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m, p0) : bssm::ung_setup_scratch_doubles(n, m_dev)) * F * sizeof(double)));
+      HIP_TRY(ct->scratch.alloc((p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m_dev, p0) : bssm::ung_setup_scratch_doubles(n, m_dev)) * F * sizeof(double)));
       HIP_TRY(ct->mats.alloc(ct->ms * F * sizeof(double))); HIP_TRY(ct->obs.alloc(ct->os * F * sizeof(double)));
       HIP_TRY(ct->init.alloc(ct->is * F * sizeof(double)));
       HIP_TRY(ct->ok.alloc((size_t)F * sizeof(int)));
@@ -717,7 +718,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
     // 21.4 ms in four chunks, 12.5 ms in one; 2 048 draws 46.9 -> 38.3 ms; two-state draws unchanged)
     int hint = 0;
     {
-      const double per_draw = (double)(p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m, p0) : bssm::ung_setup_scratch_doubles(n, m_dev)) * sizeof(double);
+      const double per_draw = (double)(p0 > 1 ? bssm::mng_setup_scratch_doubles(n, m_dev, p0) : bssm::ung_setup_scratch_doubles(n, m_dev)) * sizeof(double);
       // the budget of a chunk's work arrays: 16 GB, and never more than a twelfth of what the device has free right now plus
       // what this library's arena could hand back (up to three chunks alive at once, beside their staging blocks, tables and
       // the filters' history pools of up to 24 GiB) -- a smaller or shared GPU gets smaller chunks instead of hipErrorOutOfMemory

@@ -879,36 +879,38 @@ bool ung_pack(const HostModel& h, const double* is_mode, LgPacked* lg) {
 // ssm_mng draw for mng_setup_kernel: [Z rows per (time point, series) | T | R R' | D | C | y (raw, p per time point) |
 // a1 | P1 | u | mode | distributions (p), phis (p)]; lg->n = time points, lg->sub = p
 bool mng_pack(const HostModel& h, const double* is_mode, LgPacked* lg) {
-  if (!is_mode || h.p <= 1 || h.m < 1 || h.m > 8 || h.gaussian()) return false;
-  const int n = h.n, m = h.m, k = h.k, p = h.p;
+  // (round 6: 9 ... 64 states go PADDED to 16 / 32 / 64 as ung_pack does -- zero rows / columns of Z, T, R R', C, a1, P1; the padded
+  // components stay exactly zero through the filter and the smoother)
+  if (!is_mode || h.p <= 1 || h.m < 1 || h.m > 64 || h.gaussian() || bssm::opt().generic_setup) return false;
+  const int n = h.n, mr = h.m, m = mr <= 8 ? mr : (mr <= 16 ? 16 : (mr <= 32 ? 32 : 64)), k = h.k, p = h.p;
   lg->n = n; lg->m = m; lg->sub = p;
   lg->Zs = h.Ztv ? p * m : 0; lg->Ts = h.Ttv ? m * m : 0; lg->Rs = h.Rtv ? m * m : 0; lg->Ds = h.Dtv ? p : 0; lg->Cs = h.Ctv ? m : 0; lg->Hs = 1;
-  const int nZt = h.Ztv ? n : 1, nR = h.Rtv ? n : 1;
-  const size_t nZ = (size_t)nZt * p * m, nT = (size_t)(h.Ttv ? n : 1) * m * m, nRR = (size_t)nR * m * m;
-  const size_t nD = (size_t)(h.Dtv ? n : 1) * p, nC = (size_t)(h.Ctv ? n : 1) * m, nv = (size_t)n * p;
+  const int nZt = h.Ztv ? n : 1, nR = h.Rtv ? n : 1, nTt = h.Ttv ? n : 1, nCt = h.Ctv ? n : 1;
+  const size_t nZ = (size_t)nZt * p * m, nT = (size_t)nTt * m * m, nRR = (size_t)nR * m * m;
+  const size_t nD = (size_t)(h.Dtv ? n : 1) * p, nC = (size_t)nCt * m, nv = (size_t)n * p;
   size_t o = 0;
   lg->oZ = o; o += nZ; lg->oT = o; o += nT; lg->oR = o; o += nRR; lg->oD = o; o += nD; lg->oC = o; o += nC;
   lg->oy = o; o += nv; lg->oH = lg->oy; lg->oa = o; o += m; lg->oP = o; o += (size_t)m * m;
   lg->ou = o; o += nv; lg->ox = 0; lg->om = o; o += nv; lg->oh = o; o += 2 * (size_t)p;
-  lg->buf.resize(o);
+  lg->buf.assign(o, 0.0);
   double* b = lg->buf.data();
-  for (int t = 0; t < nZt; t++)  // h.Z is p x m column-major per time point: one contiguous row per series here
-    for (int j = 0; j < p; j++) for (int c = 0; c < m; c++) b[lg->oZ + ((size_t)t * p + j) * m + c] = h.Z[j + (size_t)p * c + (size_t)p * m * t];
-  std::memcpy(b + lg->oT, h.T.data(), nT * sizeof(double));
+  for (int t = 0; t < nZt; t++)  // h.Z is p x m column-major per time point: one contiguous (padded) row per series here
+    for (int j = 0; j < p; j++) for (int c = 0; c < mr; c++) b[lg->oZ + ((size_t)t * p + j) * m + c] = h.Z[j + (size_t)p * c + (size_t)p * mr * t];
+  for (int t = 0; t < nTt; t++) for (int j = 0; j < mr; j++) for (int i = 0; i < mr; i++) b[lg->oT + (size_t)t * m * m + i + m * j] = h.T[(size_t)t * mr * mr + i + mr * j];
   for (int t = 0; t < nR; t++) {  // R R' in lg_pack_mv's operation order
-    const double* R = h.R.data() + (size_t)m * k * t;
+    const double* R = h.R.data() + (size_t)mr * k * t;
     double* RR = b + lg->oR + (size_t)m * m * t;
-    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) {
+    for (int j = 0; j < mr; j++) for (int i = 0; i < mr; i++) {
       double sacc = 0.0;
-      for (int q = 0; q < k; q++) sacc += R[i + m * q] * R[j + m * q];
+      for (int q = 0; q < k; q++) sacc += R[i + mr * q] * R[j + mr * q];
       RR[i + m * j] = sacc;
     }
   }
   std::memcpy(b + lg->oD, h.D.data(), nD * sizeof(double));
-  std::memcpy(b + lg->oC, h.C.data(), nC * sizeof(double));
+  for (int t = 0; t < nCt; t++) for (int c = 0; c < mr; c++) b[lg->oC + (size_t)t * m + c] = h.C[(size_t)t * mr + c];
   std::memcpy(b + lg->oy, h.y.data(), nv * sizeof(double));
-  std::memcpy(b + lg->oa, h.a1.data(), (size_t)m * sizeof(double));
-  std::memcpy(b + lg->oP, h.P1.data(), (size_t)m * m * sizeof(double));
+  for (int c = 0; c < mr; c++) b[lg->oa + c] = h.a1[c];
+  for (int j = 0; j < mr; j++) for (int i = 0; i < mr; i++) b[lg->oP + i + m * j] = h.P1[i + mr * j];
   std::memcpy(b + lg->ou, h.u.data(), nv * sizeof(double));
   std::memcpy(b + lg->om, is_mode, nv * sizeof(double));
   for (int j = 0; j < p; j++) { b[lg->oh + j] = (double)h.dist[j]; b[lg->oh + p + j] = h.phis[j]; }

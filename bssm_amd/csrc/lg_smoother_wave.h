@@ -12,8 +12,10 @@
 //
 // The arithmetic follows LgSmoother<M>::run term by term -- the same products in the same association, every sum over the inner index in
 // ascending order from zero -- with the two differences lg_smoother_rows.h has as well: a step without an update runs the update formulas
-// with K = 0 (products with exact zeros and ones), and a non-finite value is carried to the end and reported there.  Univariate observations
-// only (LgModel::sub == 1).  Device only; blockDim.x = 64 NW; every lane of the workgroup must call it.
+// with K = 0 (products with exact zeros and ones), and a non-finite value is carried to the end and reported there.
+// Series at a time (LgModel::sub = p > 1, round 6: ssm_mng draws of 17 ... 64 states): the n p virtual steps run through the SAME formulas, a step
+// inside a time point with T = I, R R' = 0, C = 0 in place of the model's (products with exact ones and zeros: the values LgSmoother's
+// special-cased branch has).  Device only; blockDim.x = 64 NW; every lane of the workgroup must call it.
 #pragma once
 #include "lg_smoother.h"
 
@@ -77,7 +79,7 @@ struct LgWave {
   // at [(n+1)][M], Pt [(n+1)][MM], cc [(n+1)][MM], K [n][M], v [n], Fs [n]: element k at ptr[k * es] (draw-interleaved), as LgSmoother::run
   // leaves them with with_factors = false.  Returns the draw's verdict (the same in every lane of a group).
   __device__ LG_INL bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es) {
-    const int n = g.n;
+    const int n = g.n, sub = g.sub;
     int bad = 0;
     double c[JW];
     const double a1r = g.a1[(size_t)r * es];
@@ -90,11 +92,19 @@ struct LgWave {
     // ---- forward pass (kf_predict, univariate branch, Joseph form): SA = P, SD = T
     bool have_T = false;
     for (int t = 0; t < n; t++) {
-      const double zr = g.Z[((size_t)t * g.Zs + r) * es];
-      const double yt = g.y[(size_t)t * es], sd = g.H[(size_t)t * g.Hs * es], Dt = g.D[(size_t)t * g.Ds * es];
-      const double Cr = g.C[((size_t)t * g.Cs + r) * es];
-      const bool load_T = !have_T || g.Ts != 0;
-      if (load_T) load_row(g.T + (size_t)t * g.Ts * es, es, c);
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      const bool moves = sub == 1 || js == sub - 1;   // (a step inside a time point: identity transition, no noise)
+      const double zr = g.Z[((size_t)tr * g.Zs + (size_t)js * M + r) * es];
+      const double yt = g.y[(size_t)t * es], sd = g.H[(size_t)t * g.Hs * es], Dt = g.D[((size_t)tr * g.Ds + js) * es];
+      const double Cr = moves ? g.C[((size_t)tr * g.Cs + r) * es] : 0.0;
+      const bool load_T = !have_T || g.Ts != 0 || sub != 1;
+      if (load_T) {
+        if (moves) load_row(g.T + (size_t)tr * g.Ts * es, es, c);
+        else {
+#pragma unroll
+          for (int jj = 0; jj < JW; jj++) c[jj] = (r == j0 + jj) ? 1.0 : 0.0;
+        }
+      }
       sync();
       vZ[r] = zr;
       if (load_T) { put_row(SD, c); have_T = true; }
@@ -148,7 +158,7 @@ struct LgWave {
       sync();
       prod([&](int q) { return SC[r * LD + q]; }, [&](int q, int j) { return SD[j * LD + q]; }, c);
 #pragma unroll
-      for (int jj = 0; jj < JW; jj++) c[jj] = c[jj] + g.RR[((size_t)t * g.Rs + r + M * (j0 + jj)) * es];
+      for (int jj = 0; jj < JW; jj++) c[jj] = c[jj] + (moves ? g.RR[((size_t)tr * g.Rs + r + M * (j0 + jj)) * es] : 0.0);
       put_row(SA, c);   // (every lane was through with inner before the barrier above)
       sync();
       // symmatu: the lower triangle takes the upper one's values
@@ -174,11 +184,17 @@ struct LgWave {
     for (int t = n - 1; t >= 0; t--) {
       const double F = Fs[(size_t)t * es], vt = v[(size_t)t * es];
       const bool upd = F > 0.0;
-      const double zr = g.Z[((size_t)t * g.Zs + r) * es];
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      const bool moves = sub == 1 || js == sub - 1;
+      const double zr = g.Z[((size_t)tr * g.Zs + (size_t)js * M + r) * es];
       const double Kr = upd ? K[((size_t)t * M + r) * es] : 0.0;
       const double ar = at[((size_t)t * M + r) * es];
       // L = T (I - K Z'): T row into SD, I - K Z' into SB, L into SC
-      load_row(g.T + (size_t)t * g.Ts * es, es, c);
+      if (moves) load_row(g.T + (size_t)tr * g.Ts * es, es, c);
+      else {
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++) c[jj] = (r == j0 + jj) ? 1.0 : 0.0;
+      }
       sync();
       vZ[r] = zr;
       vK[r] = Kr;

@@ -871,7 +871,8 @@ template <int M>
 __global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
   const int d = blockIdx.x * 64 + threadIdx.x;
   if (d >= b.F) return;
-  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+  constexpr int MM = M * M, MP = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : M)));   // (16 / 32 / 64: the padded dimension itself, round 6)
+  constexpr int kU = M >= 16 ? 1 : M;   // (the copy loops stay loops for the padded big states)
   const size_t F = (size_t)b.F;
   const int n = b.n, p = b.p, t = blockIdx.y;
   const MngWork<M> W(b, d);
@@ -883,7 +884,21 @@ __global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
   double* __restrict__ mats = b.mats + (size_t)d * n * MS;
   double* __restrict__ obs = b.obs + (size_t)d * n * OS;
   double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
-  {
+  if constexpr (M >= 16) {   // (no work arrays of a lane: a 16 x 16 matrix is 2 KB of scratch memory; MP == M here)
+    double* mt = mats + (size_t)t * MS;
+    for (int q = 0; q < MS; q++) mt[q] = 0.0;
+    const size_t i0 = (size_t)t * p, i1 = (size_t)(t + 1) * p;
+    if (ok) {
+      const double* c1 = cc + i1 * MM * F;
+      const double* p1 = Pt + i1 * MM * F;
+      for (int q = 0; q < MM; q++) { mt[q] = c1[(size_t)q * F]; mt[MM + q] = p1[(size_t)q * F]; }
+      for (int j = 0; j < M; j++) {
+        double sm = 0.0;
+        for (int c = 0; c < M; c++) sm += c1[(size_t)(j + M * c) * F] * at[(i0 * M + c) * F];
+        mt[2 * MM + j] = at[(i1 * M + j) * F] - sm;
+      }
+    }
+  } else {
     double* mt = mats + (size_t)t * MS;
     for (int q = 0; q < MS; q++) mt[q] = 0.0;
     const size_t i0 = (size_t)t * p, i1 = (size_t)(t + 1) * p;
@@ -908,6 +923,8 @@ __global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
         mt[2 * MP * MP + j] = ah1[j] - s;
       }
     }
+  }
+  {
     double* row = obs + (size_t)t * OS;
     for (int q = 0; q < OS; q++) row[q] = 0.0;
     bool any = false;
@@ -924,7 +941,7 @@ __global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
       any = true;
       ob[OB_FLAG] = 1.0; ob[OB_Y] = y; ob[OB_U] = u;
       ob[OB_D] = in[(b.oD + (size_t)t * b.Ds + j) * F];
-#pragma unroll
+#pragma unroll kU
       for (int c = 0; c < M; c++) ob[SER_HDR + c] = in[(b.oZ + (size_t)t * b.Zs + (size_t)j * M + c) * F];
       ob[OB_AUX] = dist == DIST_NEGBIN ? y + phi : (dist == DIST_GAMMA ? y / u : (dist == DIST_GAUSSIAN ? 1.0 / (phi * phi) : 0.0));
       ob[OB_PSIY] = ay[q * F];
@@ -936,14 +953,55 @@ __global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
   if (t == 0) {
     for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
     if (ok) {
-#pragma unroll
+#pragma unroll kU
       for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
-#pragma unroll
+#pragma unroll kU
       for (int c = 0; c < M; c++)
-#pragma unroll
+#pragma unroll kU
         for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
     }
   }
+}
+// ---- round 6: ssm_mng draws of 9 ... 64 states (padded to 16 / 32 / 64 by mng_pack), the kernels of the big univariate states over the
+// n p virtual steps: the smoother with its matrices in LDS (lg_smoother_wave.h, series at a time), the conditional factors M lanes per
+// (draw, time point) at the time points' virtual steps (lg_factors_rows.h; src/model_ssm_mlg.cpp:310-396, src/conditional_dist.cpp:4-31)
+template <int M>
+__global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) mng_smooth_wave_kernel(const UngSetupDev b) {
+  __shared__ double lds[LgWave<M>::kLdsDoubles];
+  const int d = min((int)(blockIdx.x * (64 / M) + (threadIdx.x & 63) / M), b.F - 1);  // (surplus groups redo the last draw: every lane takes part in the barriers)
+  const size_t F = (size_t)b.F;
+  const MngWork<M> W(b, d);
+  const double* in = W.in;
+  LgModel g;
+  g.n = b.n * b.p; g.sub = b.p;
+  g.Z = in + b.oZ * F; g.Zs = b.Zs; g.T = in + b.oT * F; g.Ts = b.Ts; g.RR = in + b.oR * F; g.Rs = b.Rs;
+  g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
+  g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
+  LgWave<M> wave(lds);
+  const bool ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F);
+  if (wave.r == 0 && wave.w == 0) b.ok[d] = ok ? 1 : 0;
+}
+template <int M>
+__global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) mng_factors_rows_kernel(const UngSetupDev b) {
+  constexpr int G = 64 / M;
+  __shared__ double lds[LgFactorRows<M>::kLdsDoubles];
+  const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);
+  const MngWork<M> W(b, d);
+  LgFactorRows<M> rows(lds);
+  rows.skip = b.ok[d] == 0;
+  rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
+  const bool fine = rows.cond_step((int)blockIdx.y * b.p, W.Pt, W.cc, W.Vf, W.Cf, (size_t)b.F, 0);
+  if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;  // (every writer stores 0)
+}
+template <int M>
+static hipError_t launch_mng_setup_big(const UngSetupDev& b, hipStream_t stream) {
+  const unsigned gx = (unsigned)((b.F + 63) / 64), gg = (unsigned)((b.F + 64 / M - 1) / (64 / M));
+  hipLaunchKernelGGL(mng_laplace_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  if constexpr (M >= 32) hipLaunchKernelGGL((mng_smooth_wave_kernel<M>), dim3(gg), dim3(LgWave<M>::kThreads), 0, stream, b);
+  else hipLaunchKernelGGL((mng_setup_kernel<M, true>), dim3(gg), dim3(64), 0, stream, b);
+  hipLaunchKernelGGL((mng_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+  hipLaunchKernelGGL(mng_tables_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  return hipGetLastError();
 }
 template <int M>
 static hipError_t launch_mng_setup_m(const UngSetupDev& b, hipStream_t stream) {
@@ -971,6 +1029,9 @@ hipError_t launch_mng_setup(const UngSetupDev& b, hipStream_t stream) {
     case 6: return launch_mng_setup_m<6>(b, stream);
     case 7: return launch_mng_setup_m<7>(b, stream);
     case 8: return launch_mng_setup_m<8>(b, stream);
+    case 16: return launch_mng_setup_big<16>(b, stream);  // (9 ... 16 states arrive padded to 16: mng_pack, round 6)
+    case 32: return launch_mng_setup_big<32>(b, stream);  // (17 ... 32)
+    case 64: return launch_mng_setup_big<64>(b, stream);  // (33 ... 64)
     default: return hipErrorInvalidValue;
   }
 }
