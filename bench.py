@@ -123,6 +123,20 @@ def pmc_traffic(R, N, ppt, kernel, factored):
     return None
 
 
+def committed_traffic(kernel):
+    """HBM bytes per launch of a kernel from the round's committed counter passes (profiles/r06_pmc_traffic_big_c4.json: separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs, FETCH factor calibrated on calib_copy_kernel); None when the profile has no such kernel"""
+    try:
+        p = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic_big_c4.json")))
+        e = p.get(kernel.replace(" ", ""))
+        if e:
+            return {"traffic": e["hbm_bytes_per_launch"], "traffic_over_algorithmic": e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_launch"],
+                    "traffic_particles_per_launch": e["particles_per_launch"], "traffic_source": p["source"]}
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def live_pmc_traffic(args, kernel, layout_factored, timeout=150):
     """HBM bytes per launch of the dominant kernel, MEASURED during this run: two short `rocprofv3 --pmc` passes of this very
     script (FETCH_SIZE, then WRITE_SIZE -- separate passes, as MI355X_MICROARCH.md prescribes; one timed step of the same batch, nothing
@@ -493,6 +507,55 @@ def seasonal_post_correct_leg(period, ns=256, nsim=64, threads=8):
             "seconds": sec, "draws_per_s": ns / sec,
             "setup": "device: ung_setup_kernel<%d> (Laplace step, tables), ung_smooth_wave_kernel<%d>, ung_factors_rows_kernel<%d>" % ((32 if m <= 32 else 64,) * 3),
             "eight_draws_device_s": dev8, "eight_draws_host_setup_s": host8,
+            "max_abs_dloglik_device_vs_host_setup": float(np.max(np.abs(r8["loglik"] - h8["loglik"])))}
+
+
+def mng_big_post_correct_leg(m=20, p=4, n=100, ns=512, nsim=64, threads=8):
+    """Round 6: one psi post-correction call over `ns` theta-draws of an ssm_mng model with m = 20 states (padded to 32) and p = 4 series: the
+    set-up on the device (mng_laplace_kernel, mng_smooth_wave_kernel<32> over the n p virtual steps, mng_factors_rows_kernel<32>, mng_tables_kernel<32>;
+    src/model_ssm_mlg.cpp:90-137, 310-396), the host set-up timed beside it on 8 draws"""
+    import numpy as np
+    from bssm_amd import models as M, post_correct as PC
+    from bssm_amd.filters import psi_setup
+    rng = np.random.default_rng(120)
+    k = 3
+    Q = np.linalg.qr(rng.normal(size=(m, m)))[0]
+    Z = rng.normal(0, 0.4, (p, m))
+    dists = ["poisson", "negative binomial", "gaussian", "poisson"][:p]
+    phis = [1.0, 5.0, 0.6, 1.0][:p]
+    y = np.column_stack([rng.poisson(3, n) if d == "poisson" else (rng.negative_binomial(5, 0.6, n) if d == "negative binomial" else rng.normal(0, 0.8, n))
+                         for d in dists]).astype(float)
+    R0 = 0.15 * rng.normal(size=(m, k))
+    base = M.ssm_mng(y, Z, 0.9 * Q, R0, a1=np.zeros(m), P1=np.diag(0.05 + 0.002 * np.arange(m)), distribution=dists, phi=phis)
+    model = M.BssmModel(base.classes, **{**base, "update_fn": (lambda th: dict(R=R0 * np.exp(th[0]))), "theta": np.zeros(1)})
+    mode = np.asarray(psi_setup(model)["mode"]).reshape(-1, 1, order="F")
+
+    def job(q):
+        return dict(theta=rng.normal(0, 0.1, (q, 1)), counts=np.ones(q, dtype=np.uint32), modes=np.repeat(mode, q, axis=1) + rng.normal(0, 0.03, (n * p, q)), output_type=3)
+
+    def timed(mo, reps):
+        best, r = 1e9, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = PC.post_correct(model, mo, nsim, threads=threads, is_type="is2", seed=6)
+            best = min(best, time.perf_counter() - t0)
+        return best, r
+    sec, r = timed(job(ns), 2)
+    assert np.all(np.isfinite(r["loglik"]))
+    small = job(8)
+    dev8, r8 = timed(small, 2)
+    prev = os.environ.get("BSSM_AMD_DEVICE_SETUP")
+    os.environ["BSSM_AMD_DEVICE_SETUP"] = "0"
+    try:
+        host8, h8 = timed(small, 1)
+    finally:
+        if prev is None:
+            del os.environ["BSSM_AMD_DEVICE_SETUP"]
+        else:
+            os.environ["BSSM_AMD_DEVICE_SETUP"] = prev
+    return {"workload": "ssm_mng: m = %d, p = %d, k = %d, T = %d, %d theta-draws, psi-APF N = %d, is2, output theta; one bssm_is_correction call, %d host threads"
+                        % (m, p, k, n, ns, nsim, threads),
+            "seconds": sec, "draws_per_s": ns / sec, "eight_draws_device_s": dev8, "eight_draws_host_setup_s": host8,
             "max_abs_dloglik_device_vs_host_setup": float(np.max(np.abs(r8["loglik"] - h8["loglik"])))}
 
 
@@ -918,6 +981,9 @@ def main():
                          "weights_layout_factored": pm.weights_layout()["factored"], "launch_sequences": pm.launch_sequences(),
                          "algorithmic_GBs": psm * 152 / em / 1e9, "frac_of_8TBs": psm * 152 / em / 8e12,
                          "roofline_valu": valu_roofline(C4_VALU_PER_PSTEP, psm / em, "pf_grid_step_v2<8,8,2,true,true,true>", key="c4")}
+        ctm = committed_traffic(pm.last_kernel())
+        if ctm:   # (round 6: the C4 kernel's HBM bytes by counters, a committed profile of this kernel at this launch shape when the batch is the default one)
+            out["mng_c4"]["roofline"] = {"bound": "hbm", "achieved": psm * 152 / em / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": psm * 152 / em / 8e12, **ctm}
         if not args.no_clock:
             ckm = clock_power_while(lambda k: (pm.run(5000 + k, hip_stream=stream), torch.cuda.synchronize()), samples=2)
             torch.cuda.synchronize()
@@ -960,12 +1026,16 @@ def main():
                     # (ancestor gather + new state, weights exchange) -- at these dimensions that roof is the nearer one
                     hb = psb * (16.0 * mb + 16.0)
                     big["period_%d" % period]["roofline_hbm"] = {"bound": "hbm", "achieved": hb / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hb / 8e12,
-                                                                 "bytes_per_particle_step": 16.0 * mb + 16.0}
+                                                                 "bytes_per_particle_step": 16.0 * mb + 16.0, **(committed_traffic(pbg.last_kernel()) or {"traffic": None})}
                 pbg.close()
                 try:
                     big["period_%d" % period]["post_correct"] = seasonal_post_correct_leg(period)
                 except Exception as e:  # noqa: BLE001
                     big["period_%d" % period]["post_correct"] = {"error": repr(e)[:200]}
+            try:
+                big["mng_m20_post_correct"] = mng_big_post_correct_leg()
+            except Exception as e:  # noqa: BLE001
+                big["mng_m20_post_correct"] = {"error": repr(e)[:200]}
             out["big_states"] = big
         except Exception as e:  # noqa: BLE001
             out["big_states"] = {"error": repr(e)[:200]}

@@ -133,3 +133,12 @@ def test_seasonal_post_correction_leg_of_the_big_states_object():
     # (round 6: the null directions of the singular conditional covariances are zero in every implementation; 3.5e-7 at m = 53 before)
     assert r["max_abs_dloglik_device_vs_host_setup"] < 1e-9 * 72
     assert os.environ.get("BSSM_AMD_DEVICE_SETUP") is None
+
+
+def test_mng_twenty_states_post_correction_leg_of_the_big_states_object():
+    """big_states.mng_m20_post_correct of the bench line (round 6: the psi set-up of ssm_mng draws beyond 8 states on the device), at a size that takes a second"""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.mng_big_post_correct_leg(m=20, p=4, n=20, ns=24, nsim=32, threads=2)
+    assert r["seconds"] > 0 and r["draws_per_s"] > 0 and r["eight_draws_device_s"] > 0 and r["eight_draws_host_setup_s"] > 0
+    assert r["max_abs_dloglik_device_vs_host_setup"] < 1e-9 * 20
