@@ -502,6 +502,8 @@ def seasonal_post_correct_leg(period, ns=256, nsim=64, threads=8):
             del os.environ["BSSM_AMD_DEVICE_SETUP"]
         else:
             os.environ["BSSM_AMD_DEVICE_SETUP"] = prev
+    dll = float(np.max(np.abs(r8["loglik"] - h8["loglik"])))
+    assert dll <= 1e-9 * n, "device and host psi set-up differ by %.3g in a log-likelihood (bar: 1e-9 T, BASELINE.md section 3)" % dll
     return {"workload": "bsm_ng(period = %d): m = %d, T = %d, %d theta-draws, psi-APF N = %d, is2, output theta; one bssm_is_correction call, %d host threads"
                         % (period, m, n, ns, nsim, threads),
             "seconds": sec, "draws_per_s": ns / sec,
@@ -553,6 +555,8 @@ def mng_big_post_correct_leg(m=20, p=4, n=100, ns=512, nsim=64, threads=8):
             del os.environ["BSSM_AMD_DEVICE_SETUP"]
         else:
             os.environ["BSSM_AMD_DEVICE_SETUP"] = prev
+    dll = float(np.max(np.abs(r8["loglik"] - h8["loglik"])))
+    assert dll <= 1e-9 * n, "device and host psi set-up differ by %.3g in a log-likelihood (bar: 1e-9 T, BASELINE.md section 3)" % dll
     return {"workload": "ssm_mng: m = %d, p = %d, k = %d, T = %d, %d theta-draws, psi-APF N = %d, is2, output theta; one bssm_is_correction call, %d host threads"
                         % (m, p, k, n, ns, nsim, threads),
             "seconds": sec, "draws_per_s": ns / sec, "eight_draws_device_s": dev8, "eight_draws_host_setup_s": host8,
