@@ -25,8 +25,10 @@
  *    ("Any number of GPUs" is verified on logical shards of ONE physical GPU and with two gloo ranks: no multi-GPU
  *    node has been available to this build.)  Results for a given seed are not reproducible ACROSS library versions
  *    whose bssm_amd_version() names another random-stream format or normalisation.
- *  - Limits: state dimension m <= 64, observation series p <= 16, user-defined models <= 16 states (psi-APF / EKF: 8); particles up to
- *    262 144 for m <= 16 and up to 16 384 for 17 <= m <= 64.  Beyond them the entry points refuse with a message.
+ *  - Limits (round 6): state dimension m <= 64, observation series p <= 16; particles up to 262 144 for m <= 16 and up to 102 400 for
+ *    17 <= m <= 64 (the reference's front-end stops at 1e5, R/check_arguments.R:407-418); user-defined models <= 16 states (bootstrap
+ *    paths; psi-APF with Jacobians and a constant R), <= 8 (EKF particle filter; psi-APF with a state-dependent R_fn), <= 64 theta and
+ *    <= 64 known_params entries.  Beyond them the entry points refuse with a message.
  */
 #ifndef BSSM_AMD_H
 #define BSSM_AMD_H
@@ -188,7 +190,7 @@ typedef struct bssm_fn_model {
   int32_t L;                  /* ssm_sde: 2^L Milstein sub-steps per unit time */
   /* ---- user-defined models only (model_id BSSM_FN_USER_NLG / BSSM_FN_USER_SDE); ignored for the built-in ids */
   int32_t user_slot;          /* from bssm_user_model_load */
-  int32_t n_states;           /* ssm_nlg: 1 ... 16 for the bootstrap filter / smoother / bootstrap IS correction (round 5), 1 ... 8 for the psi-APF and the EKF particle filter */
+  int32_t n_states;           /* ssm_nlg: 1 ... 16 for the bootstrap filter / smoother / bootstrap IS correction and (round 6: Jacobians, constant R) the psi-APF, 1 ... 8 for the EKF particle filter */
   double H;                   /* ssm_nlg: observation sd (the value H_fn returns; unused when the snippet defines BSSM_USER_HFN) */
   double R_diag[2];           /* ssm_nlg: diagonal of R_fn's value (n_states <= 2, diagonal R) */
   double a1[2], P1[4];        /* ssm_nlg: a1_fn, P1_fn values (P1 column-major, n_states x n_states), n_states <= 2 */
@@ -210,11 +212,11 @@ typedef struct bssm_fn_model {
  * calls it through function pointers (src/model_ssm_nlg.h:10-21, src/model_ssm_sde.h:8-11); device code cannot call host
  * pointers, so the user's __device__ functions (contract: bssm_amd/csrc/pf_functors.h) are compiled by hipcc INTO the
  * filter kernels, one shared library per snippet, cached by content hash next to libbssm_amd.so (or in
- * $BSSM_AMD_USER_CACHE).  bssm_user_model_build compiles `source` for `n_states` (1 ... 8) and writes the library path;
+ * $BSSM_AMD_USER_CACHE).  bssm_user_model_build compiles `source` for `n_states` (1 ... 16) and writes the library path;
  * bssm_user_model_load maps it and returns a slot >= 1 for bssm_fn_model.user_slot (negative = error).
  * Built for user models: every single-model entry point of the built-in models -- bootstrap, psi-APF (bssm_psi_smoother_nlg,
  * bssm_fn_psi_setup) and EKF particle filter (bssm_ekpf_*) with their smoothers and bssm_fn_loglik_batch; the psi-APF and
- * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS).  The psi-APF and the EKF particle filter take up to 8 states (late round 4), any constant
+ * the EKF filter need the Jacobians in the snippet (BSSM_USER_JACOBIANS).  The psi-APF takes up to 16 states (round 6; 8 with a state-dependent R_fn), the EKF particle filter up to 8, any constant
  * n_states x n_etas matrix R whose R R' is positive definite on its non-zero diagonal, and any positive semi-definite P1
  * (round 3); so does the EKF particle filter (1- and 2-state models: constant diagonal R).  Snippets that define
  * BSSM_USER_TV receive the time index and known_tv_params in every function.  The bootstrap filter / smoother / bootstrap IS correction take up to 16 states (round 5), any n_states x n_etas matrix
@@ -227,10 +229,11 @@ int bssm_user_model_build(const char* source, int32_t n_states, char* lib_path, 
 /* The same snippet compiled IN PROCESS by hiprtc (the compiler as a library: no hipcc on the machine, no process, no shared library) --
  * what Rcpp::sourceCpp is to the reference's session (R/cpp_example_models.R:762).  Returns the registry slot (>= 1) directly.  Only the
  * kernel variant a call needs is compiled, the first time it is needed (1-2 s; the smallest workgroup-resident variant at once, so a
- * snippet with an error fails here with the compiler's log); code objects are cached on disk by content hash.  Such a slot runs the
- * BOOTSTRAP filter / smoother / bootstrap IS correction (any particle count the hipcc-built library takes); the psi-APF and the EKF particle filter evaluate the
- * snippet on the host during their set-up and refuse a JIT slot with a message -- use bssm_user_model_build + _load for those.  Results
- * are bit-identical to the hipcc-built library of the same snippet (same kernel templates, same arithmetic). */
+ * snippet with an error fails here with the compiler's log); code objects are cached on disk by content hash.  Such a slot runs EVERY
+ * sampler since round 6: the bootstrap paths bit-identical to the hipcc-built library of the same snippet (same kernel templates, same
+ * arithmetic); the psi-APF and the EKF particle filter evaluate the snippet during their host set-up through a one-thread evaluation kernel
+ * compiled from it (~15 us per call: the device's libm instead of the host's, so the last place of the mode may differ from the hipcc route).
+ * The same (source, n_states) registers once: a repeated call returns the slot it already has. */
 int bssm_user_model_jit(const char* source, int32_t n_states);
 int bssm_user_model_load(const char* lib_path);
 /* replaces _bssm_bsf_nlg (18 args, src/R_bootstrap_filter.cpp:461-504) / _bssm_bsf_smoother_nlg (:508-551):
