@@ -323,7 +323,7 @@ inline std::vector<int> sparse_descriptor(const std::vector<const bssm::FilterTa
   std::vector<int> none;
   const int MP = tabs[0]->MP, KP = tabs[0]->KP;
   if (psi != 0 || p != 1 || MP < 32 || MP > 64 || tabs[0]->mats_tstride != 0 || k > 8 || m > 64) return none;
-  if (const char* e = std::getenv("BSSM_AMD_NO_SPARSE")) { if (e[0] != '0') return none; }
+  if (bssm::opt().sparse == 0) return none;
   const double* T0 = tabs[0]->mats.data();
   int row_cnt[64] = {0}, noise[64] = {0}, zflag[64] = {0};
   size_t nnz = 0;

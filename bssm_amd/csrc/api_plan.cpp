@@ -281,6 +281,13 @@ int bssm_plan_time(bssm_plan* plan, uint32_t seed, int32_t reps, void* hip_strea
 }
 
 // test hook: the device elementary functions (0 exp, 1 log, 2 sincos(2 pi x) -> 2n outputs, 3 Box-Muller pairs)
+// diagnostic: workgroups of the conditional-factor kernels (time points >= 1) that took the full Jacobi path / all of them, since the last call
+int bssm_debug_thin_counts(uint64_t out[2]) {
+  unsigned long long c[2] = {0, 0};
+  HIP_TRY(bssm::debug_thin_counts(c));
+  out[0] = c[0]; out[1] = c[1];
+  return BSSM_OK;
+}
 int bssm_debug_stream_copy(uint64_t n_doubles) {
   if (!have_device()) return no_device();
   DevBuf a, b;

@@ -87,7 +87,7 @@ bool device_setup_enabled(int n_threads) {
 struct ChunkTables {
   int lo = 0, F = 0;
   size_t ms = 0, os = 0, is = 0, as = 0;
-  DevBuf fpar, ext, modes, y, scratch, mats, obs, init, amats, ok;
+  DevBuf fpar, ext, modes, y, scratch, mats, obs, init, amats, ok, flags;
   // the set-up kernel runs asynchronously: the host thread that prepared the chunk records `ready` behind it and goes on
   // to the next chunk; the device thread waits for the event before the chunk's filters (finish() below)
   hipEvent_t ready = nullptr;
@@ -108,7 +108,7 @@ struct ChunkTables {
     if (hipEventSynchronize(ready) != hipSuccess) return -1;
     const int* okv = (const int*)okst.p;
     for (int q = 0; q < F; q++) if (!okv[q]) (*bad)[lo + q] = 1;  // non-finite Vt / Ct: the filter returns -Inf (src/model_ssm_nlg.cpp:988-990)
-    scratch.release(); modes.release(); ext.release(); ok.release(); in_a.release(); in_b.release();
+    scratch.release(); modes.release(); ext.release(); ok.release(); flags.release(); in_a.release(); in_b.release();
     (void)hipEventDestroy(ready); ready = nullptr;
     return 0;
   }
@@ -691,16 +691,19 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       HIP_TRY(ct->mats.alloc(ct->ms * F * sizeof(double))); HIP_TRY(ct->obs.alloc(ct->os * F * sizeof(double)));
       HIP_TRY(ct->init.alloc(ct->is * F * sizeof(double)));
       HIP_TRY(ct->ok.alloc((size_t)F * sizeof(int)));
+      if (m_dev >= 16) HIP_TRY(ct->flags.alloc((size_t)F * (n + 1) * sizeof(int)));   // (16 and more padded states: thin factor kernel -> full factor kernel)
       const double t0 = now_ms();
       HIP_TRY(hipMemcpyAsync(din.p, h, E * F * sizeof(double), hipMemcpyHostToDevice, st));
       HIP_TRY(bssm::launch_transpose(din.as<double>(), din_t.as<double>(), F, (int)E, st));  // [F][E] -> [E][F]
       bssm::UngSetupDev b{};
       b.F = F; b.n = n; b.m = m_dev; b.p = p0; b.mr = m;
+      b.dm = (m_dev >= 32 && !bssm::opt().setup_interleaved) ? 1 : 0;   // draw-major matrix work arrays for the LDS-resident set-up kernels (round 6; the switch: A/B)
       b.Zs = L0.Zs; b.Ts = L0.Ts; b.Rs = L0.Rs; b.Ds = L0.Ds; b.Cs = L0.Cs;
       b.oZ = L0.oZ; b.oT = L0.oT; b.oR = L0.oR; b.oD = L0.oD; b.oC = L0.oC; b.oy = L0.oy; b.oa = L0.oa; b.oP = L0.oP;
       b.ou = L0.ou; b.ox = L0.ox; b.om = L0.om; b.oh = L0.oh;
       b.in = din_t.as<double>(); b.scratch = ct->scratch.as<double>();
       b.mats = ct->mats.as<double>(); b.obs = ct->obs.as<double>(); b.init = ct->init.as<double>(); b.ok = ct->ok.as<int>();
+      b.flags = (m_dev >= 16 && !bssm::opt().factors_one_kernel) ? ct->flags.as<int>() : nullptr;
       HIP_TRY(p0 > 1 ? bssm::launch_mng_setup(b, st) : bssm::launch_ung_setup(b, st));
       HIP_TRY(hipMemcpyAsync(ct->okst.p, ct->ok.p, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventCreateWithFlags(&ct->ready, hipEventDisableTiming));

@@ -23,6 +23,8 @@
 
 namespace bssm {
 
+// time points >= 1 whose workgroup took the full (Jacobi) path, and all of them: a diagnostic of the thin path's coverage (bssm_debug_thin_counts)
+__device__ unsigned long long lgf_thin_counts[2];
 #ifdef LGF_STATS
 __device__ unsigned long long lgf_stats[8];   // analysis builds (scripts/lgwave_check.hip): calls, sweeps, clocks of the Jacobi loops / of cond_step
 #endif
@@ -502,7 +504,18 @@ struct LgFactorRows {
   }
 
   // conditional_cov at time point t of draw d (arrays draw-interleaved, element k at ptr[k * es + d]); returns whether everything written is finite
-  __device__ LG_INL bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d) {
+  // Round 6, second half: the thin path and the full path are TWO kernels (the set-up launches the thin one over the time points >= 1, then the
+  // full one over everything): in one kernel the register allocation was the union of both (659 registers spilt at M = 64, 2.2 KB of scratch
+  // per lane, 320 us per thin time point instead of ~80).  `flag` (one int per (draw, time point), written by cond_step_thin) says which groups
+  // the full kernel still has to do; flag == nullptr: the one-kernel form (decide here).
+  __device__ LG_INL bool cond_step_thin(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d, int* flag) {
+    int bad_thin = 0;
+    const bool mine_full = thin_step(t, Pt, cc, Vout, Cout, es, d, &bad_thin);
+    if (r == 0 && w == 0) *flag = mine_full ? 1 : 0;
+    if (threadIdx.x == 0) atomicAdd(&lgf_thin_counts[1], 1ull);
+    return reduce_bad(mine_full ? 0 : bad_thin);
+  }
+  __device__ LG_INL bool cond_step(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d, const int* flag = nullptr) {
     int bad = 0;
     double row[JW];
 #ifdef LGF_STATS
@@ -525,10 +538,11 @@ struct LgFactorRows {
     }
     bool mine_full = true;   // this group's results come from the full path below
     int bad_thin = 0;
-    if (thin_enabled()) {
-      mine_full = thin_step(t, Pt, cc, Vout, Cout, es, d, &bad_thin);
-      if (!__syncthreads_or(mine_full)) return reduce_bad(bad_thin);
-      // some group of the workgroup needs the full path: every group runs it (barriers), only those groups store its results
+    if (flag) {   // the thin kernel ran before: only the groups it flagged are done here (every group of the workgroup runs the code: barriers)
+      mine_full = *flag != 0;
+      const bool any_full = __syncthreads_or(mine_full) != 0;
+      if (threadIdx.x == 0 && any_full) atomicAdd(&lgf_thin_counts[0], 1ull);
+      if (!any_full) return true;
     }
 #pragma unroll
     for (int jj = 0; jj < JW; jj++) row[jj] = Pt[((size_t)(t - 1) * MM + r + M * (j0 + jj)) * es + d];

@@ -78,7 +78,10 @@ struct LgWave {
 
   // at [(n+1)][M], Pt [(n+1)][MM], cc [(n+1)][MM], K [n][M], v [n], Fs [n]: element k at ptr[k * es] (draw-interleaved), as LgSmoother::run
   // leaves them with with_factors = false.  Returns the draw's verdict (the same in every lane of a group).
-  __device__ LG_INL bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es) {
+  // (round 6) `em`: the element stride of the MATRIX work arrays at / Pt / cc / K -- es (draw-interleaved, as the model inputs and v / Fs always are), or
+  // 1 for a draw-major layout: a 64-dimensional draw's row-distributed stores are then 512-byte segments instead of 8 bytes per 2 KB stride
+  __device__ LG_INL bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es, size_t em = 0) {
+    if (em == 0) em = es;
     const int n = g.n, sub = g.sub;
     int bad = 0;
     double c[JW];
@@ -87,8 +90,8 @@ struct LgWave {
     sync();
     va[r] = a1r;
     put_row(SA, c);
-    if (w == 0) at[(size_t)r * es] = a1r;
-    store_row(Pt, es, c);
+    if (w == 0) at[(size_t)r * em] = a1r;
+    store_row(Pt, em, c);
     // ---- forward pass (kf_predict, univariate branch, Joseph form): SA = P, SD = T
     bool have_T = false;
     for (int t = 0; t < n; t++) {
@@ -131,7 +134,7 @@ struct LgWave {
       if (r == 0 && w == 0) { Fs[(size_t)t * es] = upd ? F : 0.0; v[(size_t)t * es] = vt; }
       const double Kr = upd ? pz / F : 0.0;
       const double aur = upd ? va[r] + Kr * vt : va[r];
-      if (w == 0) K[((size_t)t * M + r) * es] = Kr;
+      if (w == 0) K[((size_t)t * M + r) * em] = Kr;
       vK[r] = Kr;
       vy[r] = aur;
       // I - K Z' into SB
@@ -169,9 +172,9 @@ struct LgWave {
       bad |= !lg_finite(a1n);
 #pragma unroll
       for (int jj = 0; jj < JW; jj++) bad |= !lg_finite(c[jj]);
-      if (w == 0) at[((size_t)(t + 1) * M + r) * es] = a1n;
-      store_row(Pt + (size_t)(t + 1) * MM * es, es, c);
-      store_row(cc + (size_t)t * MM * es, es, c);
+      if (w == 0) at[((size_t)(t + 1) * M + r) * em] = a1n;
+      store_row(Pt + (size_t)(t + 1) * MM * em, em, c);
+      store_row(cc + (size_t)t * MM * em, em, c);
       va[r] = a1n;
     }
     // ---- backward pass (smoother_ccov): SA = N, vr = r_t; T, P and the cross-covariance are staged from memory row by row
@@ -187,8 +190,8 @@ struct LgWave {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
       const bool moves = sub == 1 || js == sub - 1;
       const double zr = g.Z[((size_t)tr * g.Zs + (size_t)js * M + r) * es];
-      const double Kr = upd ? K[((size_t)t * M + r) * es] : 0.0;
-      const double ar = at[((size_t)t * M + r) * es];
+      const double Kr = upd ? K[((size_t)t * M + r) * em] : 0.0;
+      const double ar = at[((size_t)t * M + r) * em];
       // L = T (I - K Z'): T row into SD, I - K Z' into SB, L into SC
       if (moves) load_row(g.T + (size_t)tr * g.Ts * es, es, c);
       else {
@@ -206,7 +209,7 @@ struct LgWave {
       prod([&](int q) { return SD[r * LD + q]; }, [&](int q, int j) { return SB[q * LD + j]; }, c);
       put_row(SC, c);
       // cc[t] = Pt[t] L' (I - N cc[t]): cc[t] into SB, then I - N cc[t] into SB; Pt[t] row into SD, then (Pt[t] L') row into SD
-      load_row(cc + (size_t)t * MM * es, es, c);
+      load_row(cc + (size_t)t * MM * em, em, c);
       sync();           // every lane is through with I - K Z' and the T row; L is complete
       put_row(SB, c);
       sync();
@@ -215,7 +218,7 @@ struct LgWave {
       for (int jj = 0; jj < JW; jj++) c[jj] = ((r == j0 + jj) ? 1.0 : 0.0) - c[jj];
       sync();
       put_row(SB, c);
-      load_row(Pt + (size_t)t * MM * es, es, c);
+      load_row(Pt + (size_t)t * MM * em, em, c);
       put_row(SD, c);
       sync();
       prod([&](int q) { return SD[r * LD + q]; }, [&](int q, int j) { return SC[j * LD + q]; }, c);
@@ -225,7 +228,7 @@ struct LgWave {
       prod([&](int q) { return SD[r * LD + q]; }, [&](int q, int j) { return SB[q * LD + j]; }, c);
 #pragma unroll
       for (int jj = 0; jj < JW; jj++) bad |= !lg_finite(c[jj]);
-      store_row(cc + (size_t)t * MM * es, es, c);
+      store_row(cc + (size_t)t * MM * em, em, c);
       // r_{t-1} = L' r_t, N_{t-1} = L' N L (column r of L is the row's operand)
       double rn = 0.0;
 #pragma unroll 4
@@ -244,7 +247,7 @@ struct LgWave {
       vr[r] = rn;
       put_row(SA, c);
       // Pt[t] row into SB (it is a broadcast operand below)
-      load_row(Pt + (size_t)t * MM * es, es, c);
+      load_row(Pt + (size_t)t * MM * em, em, c);
       put_row(SB, c);
       sync();
       // symmatu(N)
@@ -256,7 +259,7 @@ struct LgWave {
       for (int q = 0; q < M; q++) pr += SB[r * LD + q] * vr[q];
       const double as = ar + pr;
       bad |= !lg_finite(as);
-      if (w == 0) at[((size_t)t * M + r) * es] = as;
+      if (w == 0) at[((size_t)t * M + r) * em] = as;
       // Pt[t] - symmatu(Pt[t] N Pt[t])
       prod([&](int q) { return SB[r * LD + q]; }, [&](int q, int j) { return SA[q * LD + j]; }, c);
       put_row(SD, c);   // (every lane was through with the (L' N) row before the barriers above)
@@ -270,11 +273,11 @@ struct LgWave {
         const double x = (j < r) ? SC[j * LD + r] : c[jj];
         const double pn = SB[r * LD + j] - x;
         bad |= !lg_finite(pn);
-        Pt[((size_t)t * MM + r + M * j) * es] = pn;
+        Pt[((size_t)t * MM + r + M * j) * em] = pn;
       }
     }
 #pragma unroll
-    for (int jj = 0; jj < JW; jj++) cc[((size_t)n * MM + r + M * (j0 + jj)) * es] = 0.0;
+    for (int jj = 0; jj < JW; jj++) cc[((size_t)n * MM + r + M * (j0 + jj)) * em] = 0.0;
     // any lane of the group bad -> false in every lane of the group
     sync();
     vx[r] = 0.0;

@@ -194,6 +194,10 @@ Options read_env() {
   o.mv_sequential = env_set("BSSM_AMD_MV_SEQUENTIAL");
   o.mng_lane_per_draw = env_set("BSSM_AMD_MNG_LANE_PER_DRAW");
   o.defer_summary = env_set("BSSM_AMD_DEFER_SUMMARY");
+  if (const char* e = std::getenv("BSSM_AMD_SPARSE")) o.sparse = e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1);
+  if (const char* e = std::getenv("BSSM_AMD_NO_SPARSE")) { if (e[0] != '0') o.sparse = 0; }
+  o.setup_interleaved = env_set("BSSM_AMD_SETUP_INTERLEAVED");
+  o.factors_one_kernel = env_set("BSSM_AMD_FACTORS_ONE_KERNEL");
   o.xcd_persist = env_tri("BSSM_AMD_XCD_PERSIST");   // (acts in -DBSSM_XCD_PERSIST builds only)
 #ifdef BSSM_PROBES
   o.probe_no_weights = env_set("BSSM_AMD_PROBE_NO_WEIGHTS");

@@ -252,10 +252,7 @@ __device__ __forceinline__ double sparse_apply(const int* __restrict__ sp, const
 }
 #ifndef __HIPCC_RTC__
 // BSSM_AMD_SPARSE: 0 never, all = wherever a descriptor exists (experiments), default = where it measured faster
-inline int sparse_mode() {
-  static const int mode = [] { const char* e = std::getenv("BSSM_AMD_SPARSE"); return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1)); }();
-  return mode;
-}
+inline int sparse_mode() { return opt().sparse; }
 #endif
 // bootstrap log-weight of one particle from its signal (one observation series): big_log_weight for p = 1, the signal given
 __device__ __forceinline__ double sparse_log_weight(const double* __restrict__ row, const double zsum) {

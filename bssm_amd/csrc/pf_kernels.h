@@ -208,15 +208,18 @@ struct UngSetupDev {
   int F, n, m;
   int p = 1;                 // series per time point (ssm_mng: mng_setup_kernel, mng_pack element order; obs rows ROW_HDR + p (SER_HDR + MP))
   int mr = 0;                // the states the draws really have where m is a padded dimension (16 / 32 / 64; 0: m) -- the rest is exact zeros
+  int dm = 0;                // round 6, m = 32 / 64: the MATRIX work arrays (at, Pt, cc, K, Vf, Cf) are draw-major (a draw's slice contiguous) instead of draw-interleaved
   int Zs, Ts, Rs, Ds, Cs;
   size_t oZ, oT, oR, oD, oC, oy, oa, oP, ou, ox, om, oh;
   const double* in;
   double* scratch;           // draw-interleaved work arrays, ung_setup_scratch_doubles(n, m) * F doubles
   double *mats, *obs, *init; // per-draw contiguous outputs, padded to MP = pad(m): [F][n][2 MP^2 + MP], [F][n][ROW_HDR + SER_HDR + MP], [F][MP + MP^2]
   int* ok;
+  int* flags;                // round 6, 16 and more padded states: [F][n + 1] which (draw, time point) the full factor kernel has to do (written by the thin one)
 };
 size_t ung_setup_scratch_doubles(int n, int m);
 hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream);
+hipError_t debug_thin_counts(unsigned long long out[2]);
 size_t mng_setup_scratch_doubles(int n, int m, int p);
 hipError_t launch_mng_setup(const UngSetupDev& b, hipStream_t stream);
 hipError_t launch_transpose(const double* in, double* out, int rows, int cols, hipStream_t stream);

@@ -516,24 +516,28 @@ template <int M>
 struct UngWork {
   const double* in;
   double *ay, *aH, *ayr, *scl, *at, *Pt, *cc, *K, *v, *Fs, *Vf, *Cf;
+  size_t em;   // element stride of the matrix work arrays: F (draw-interleaved) or 1 (draw-major, UngSetupDev::dm)
   __device__ UngWork(const UngSetupDev& b, int d) {
     constexpr int MM = M * M;
     const size_t F = (size_t)b.F;
     const int n = b.n;
+    const bool dm = b.dm != 0;
+    em = dm ? 1 : F;
     in = b.in + d;
-    double* w = b.scratch + d;
-    ay = w;     w += (size_t)n * F;   // approximating y minus x'beta: what the smoother sees
-    aH = w;     w += (size_t)n * F;
-    ayr = w;    w += (size_t)n * F;   // approximating y
-    scl = w;    w += (size_t)n * F;
-    at = w;     w += (size_t)(n + 1) * M * F;
-    Pt = w;     w += (size_t)(n + 1) * MM * F;
-    cc = w;     w += (size_t)(n + 1) * MM * F;
-    K = w;      w += (size_t)n * M * F;
-    v = w;      w += (size_t)n * F;
-    Fs = w;     w += (size_t)n * F;
-    Vf = w;     w += (size_t)(n + 1) * MM * F;
-    Cf = w;
+    double* w = b.scratch;   // region bases; the vectors are always draw-interleaved (+ d), a matrix array's draw slice sits at d x its per-draw size when draw-major
+    auto mat = [&](size_t per_draw) { double* p = dm ? w + (size_t)d * per_draw : w + d; w += per_draw * F; return p; };
+    ay = w + d;     w += (size_t)n * F;   // approximating y minus x'beta: what the smoother sees
+    aH = w + d;     w += (size_t)n * F;
+    ayr = w + d;    w += (size_t)n * F;   // approximating y
+    scl = w + d;    w += (size_t)n * F;
+    at = mat((size_t)(n + 1) * M);
+    Pt = mat((size_t)(n + 1) * MM);
+    cc = mat((size_t)(n + 1) * MM);
+    K = mat((size_t)n * M);
+    v = w + d;      w += (size_t)n * F;
+    Fs = w + d;     w += (size_t)n * F;
+    Vf = mat((size_t)(n + 1) * MM);
+    Cf = mat((size_t)(n + 1) * MM);
   }
 };
 template <int M, int PHASE, bool ROWS>
@@ -609,9 +613,10 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     double* __restrict__ obs = b.obs + (size_t)d * n * OS;
     double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
     double* mt = mats + (size_t)t * MS;
-    for (int q = 0; q < MS; q++) mt[q] = 0.0;
+    if (!(M >= 32 && b.dm)) { for (int q = 0; q < MS; q++) mt[q] = 0.0; }
     if constexpr (M >= 32) {  // (no work arrays of a lane: a 32 x 32 matrix is 8 KB of scratch memory; MP == M here)
-      if (ok) {
+      // (draw-major work arrays, UngSetupDev::dm: setup_tables_big_kernel copies the matrices, a workgroup per (draw, time point), coalesced)
+      if (ok && !b.dm) {
         const double* c1 = cc + (size_t)(t + 1) * MM * F;
         const double* p1 = Pt + (size_t)(t + 1) * MM * F;
         for (int q = 0; q < MM; q++) { mt[q] = c1[(size_t)q * F]; mt[MM + q] = p1[(size_t)q * F]; }
@@ -668,14 +673,39 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     if (t == 0) {
       for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
       if (ok) {
+        const size_t em = W.em;
 #pragma unroll kU
-        for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
+        for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * em];
 #pragma unroll kU
         for (int c = 0; c < M; c++)
 #pragma unroll kU
-          for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
+          for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * em];
       }
     }
+  }
+}
+// Round 6, draw-major work arrays (UngSetupDev::dm, 32 / 64 padded states): the proposal operands of time point blockIdx.y of draw blockIdx.x --
+// C_{t+1}, V_{t+1}^(1/2) and alphahat_{t+1} - C_{t+1} alphahat_t (build_psi_tables; src/model_ssm_ung.cpp:585-586) -- copied by a workgroup, coalesced on
+// both sides (one lane per draw copying 2 x 64 x 64 strided doubles per time point took 8.6 ms per 256 draws of 53 states).  `sub` = virtual steps per
+// time point (1, or p for ssm_mng draws).
+template <int M>
+__global__ void __launch_bounds__(256) setup_tables_big_kernel(const double* __restrict__ at_all, const double* __restrict__ Vf_all, const double* __restrict__ Cf_all,
+                                                               const size_t at_draw, const size_t mat_draw, const int sub, double* __restrict__ mats, const int n,
+                                                               const int* __restrict__ okv) {
+  constexpr int MM = M * M, MS = 2 * MM + M;
+  const int d = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+  double* __restrict__ mt = mats + ((size_t)d * n + t) * MS;
+  if (!okv[d]) { for (int q = tid; q < MS; q += 256) mt[q] = 0.0; return; }
+  const size_t i0 = (size_t)t * sub, i1 = (size_t)(t + 1) * sub;
+  const double* __restrict__ c1 = Cf_all + (size_t)d * mat_draw + i1 * MM;
+  const double* __restrict__ p1 = Vf_all + (size_t)d * mat_draw + i1 * MM;
+  const double* __restrict__ a0 = at_all + (size_t)d * at_draw + i0 * M;
+  const double* __restrict__ a1 = at_all + (size_t)d * at_draw + i1 * M;
+  for (int q = tid; q < MM; q += 256) { mt[q] = c1[q]; mt[MM + q] = p1[q]; }
+  if (tid < M) {
+    double sm = 0.0;
+    for (int c = 0; c < M; c++) sm += c1[tid + M * c] * a0[c];
+    mt[2 * MM + tid] = a1[tid] - sm;
   }
 }
 // Kalman filter + covariance smoother of 17 ... 64 states (padded to 32 / 64): one workgroup of M / 16 waves per 64 / M draws, the matrices of the
@@ -693,7 +723,7 @@ __global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) ung_sm
   g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
   g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
   LgWave<M> wave(lds);
-  const bool ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F);
+  const bool ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F, W.em);
   if (wave.r == 0 && wave.w == 0) b.ok[d] = ok ? 1 : 0;
 }
 // conditional factors of states of sixteen and more (padded) dimensions: M lanes per (draw, time point), matrices in LDS (lg_factors_rows.h)
@@ -708,8 +738,22 @@ __global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) 
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
   rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
-  const bool fine = rows.cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, (size_t)b.F, 0);
+  const bool fine = rows.cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, (b.flags && blockIdx.y > 0) ? b.flags + (size_t)d * (b.n + 1) + blockIdx.y : nullptr);
   if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;  // (every writer stores 0)
+}
+// the thin path of time point blockIdx.y + 1 (lg_factors_rows.h: cond_step_thin): a kernel of its own, so that its registers are its own
+template <int M>
+__global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) ung_factors_thin_kernel(const UngSetupDev b) {
+  constexpr int G = 64 / M;
+  __shared__ double lds[LgFactorRows<M>::kLdsDoubles];
+  const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);
+  const int t = (int)blockIdx.y + 1;
+  const UngWork<M> W(b, d);
+  LgFactorRows<M> rows(lds);
+  rows.skip = b.ok[d] == 0;
+  rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
+  const bool fine = rows.cond_step_thin(t, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, b.flags + (size_t)d * (b.n + 1) + t);
+  if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;
 }
 template <int M>
 static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
@@ -727,12 +771,33 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
     else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
   }
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 1, hipGetErrorString(de)); }
-  if constexpr (M >= 16) hipLaunchKernelGGL((ung_factors_rows_kernel<M>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M)), (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+  if constexpr (M >= 16) {
+    const unsigned gg = (unsigned)((b.F + 64 / M - 1) / (64 / M));
+    if (b.flags) hipLaunchKernelGGL((ung_factors_thin_kernel<M>), dim3(gg, (unsigned)b.n), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+    hipLaunchKernelGGL((ung_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+  }
   else hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 2, hipGetErrorString(de)); }
   hipLaunchKernelGGL((ung_setup_kernel<M, 3, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  if constexpr (M >= 32) {
+    if (b.dm) {   // the matrices of the tables from the draw-major work arrays (the region offsets of UngWork)
+      const size_t F = (size_t)b.F, n = (size_t)b.n, n1 = n + 1, MMs = (size_t)M * M;
+      double* w = b.scratch + 4 * n * F;
+      const double* at_all = w; w += n1 * M * F + 2 * n1 * MMs * F + n * M * F + 2 * n * F;   // at | Pt, cc | K | v, Fs
+      const double* Vf_all = w; w += n1 * MMs * F;
+      const double* Cf_all = w;
+      hipLaunchKernelGGL((setup_tables_big_kernel<M>), dim3((unsigned)b.F, (unsigned)b.n), dim3(256), 0, stream, at_all, Vf_all, Cf_all, n1 * M, n1 * MMs, 1, b.mats, b.n, b.ok);
+    }
+  }
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 3, hipGetErrorString(de)); }
   return hipGetLastError();
+}
+// diagnostic: (workgroups of the factor kernels that took the full path, all of them) since the last call; resets the counters
+hipError_t debug_thin_counts(unsigned long long out[2]) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(lgf_thin_counts), 2 * sizeof(unsigned long long));
+  if (e != hipSuccess) return e;
+  const unsigned long long z[2] = {0ull, 0ull};
+  return hipMemcpyToSymbol(HIP_SYMBOL(lgf_thin_counts), z, sizeof z);
 }
 hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream) {
   if (b.n < 1 || b.n >= 65535) return hipErrorInvalidValue;  // (time points ride in gridDim.y)
@@ -770,23 +835,27 @@ template <int M>
 struct MngWork {
   const double* in;
   double *ay, *aH, *scl, *at, *Pt, *cc, *K, *v, *Fs, *Vf, *Cf;
+  size_t em;   // element stride of the matrix work arrays: F (draw-interleaved) or 1 (draw-major, UngSetupDev::dm)
   __device__ MngWork(const UngSetupDev& b, int d) {
     constexpr int MM = M * M;
     const size_t F = (size_t)b.F;
     const int n = b.n, nv = n * b.p;
+    const bool dm = b.dm != 0;
+    em = dm ? 1 : F;
     in = b.in + d;
-    double* w = b.scratch + d;
-    ay = w;     w += (size_t)nv * F;   // approximating y
-    aH = w;     w += (size_t)nv * F;
-    scl = w;    w += (size_t)n * F;
-    at = w;     w += (size_t)(nv + 1) * M * F;
-    Pt = w;     w += (size_t)(nv + 1) * MM * F;
-    cc = w;     w += (size_t)(nv + 1) * MM * F;
-    K = w;      w += (size_t)nv * M * F;
-    v = w;      w += (size_t)nv * F;
-    Fs = w;     w += (size_t)nv * F;
-    Vf = w;     w += (size_t)(nv + 1) * MM * F;  // V_t^(1/2) and C_t at the time points (virtual steps s p)
-    Cf = w;
+    double* w = b.scratch;
+    auto mat = [&](size_t per_draw) { double* p = dm ? w + (size_t)d * per_draw : w + d; w += per_draw * F; return p; };
+    ay = w + d;     w += (size_t)nv * F;   // approximating y
+    aH = w + d;     w += (size_t)nv * F;
+    scl = w + d;    w += (size_t)n * F;
+    at = mat((size_t)(nv + 1) * M);
+    Pt = mat((size_t)(nv + 1) * MM);
+    cc = mat((size_t)(nv + 1) * MM);
+    K = mat((size_t)nv * M);
+    v = w + d;      w += (size_t)nv * F;
+    Fs = w + d;     w += (size_t)nv * F;
+    Vf = mat((size_t)(nv + 1) * MM);  // V_t^(1/2) and C_t at the time points (virtual steps s p)
+    Cf = mat((size_t)(nv + 1) * MM);
   }
 };
 // (L) Laplace step at the stored mode for time point blockIdx.y: approximating y / H of its p series and the scale (src/model_ssm_mng.cpp:117-133, 218-255, 269-315)
@@ -886,9 +955,9 @@ __global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
   double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
   if constexpr (M >= 16) {   // (no work arrays of a lane: a 16 x 16 matrix is 2 KB of scratch memory; MP == M here)
     double* mt = mats + (size_t)t * MS;
-    for (int q = 0; q < MS; q++) mt[q] = 0.0;
+    if (!b.dm) { for (int q = 0; q < MS; q++) mt[q] = 0.0; }
     const size_t i0 = (size_t)t * p, i1 = (size_t)(t + 1) * p;
-    if (ok) {
+    if (ok && !b.dm) {   // (draw-major work arrays: setup_tables_big_kernel)
       const double* c1 = cc + i1 * MM * F;
       const double* p1 = Pt + i1 * MM * F;
       for (int q = 0; q < MM; q++) { mt[q] = c1[(size_t)q * F]; mt[MM + q] = p1[(size_t)q * F]; }
@@ -953,12 +1022,13 @@ __global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
   if (t == 0) {
     for (int q = 0; q < MP + MP * MP; q++) ini[q] = 0.0;
     if (ok) {
+      const size_t em = W.em;
 #pragma unroll kU
-      for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * F];
+      for (int j = 0; j < M; j++) ini[j] = at[(size_t)j * em];
 #pragma unroll kU
       for (int c = 0; c < M; c++)
 #pragma unroll kU
-        for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * F];
+        for (int j = 0; j < M; j++) ini[MP + j + MP * c] = Pt[(size_t)(j + M * c) * em];
     }
   }
 }
@@ -978,7 +1048,7 @@ __global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) mng_sm
   g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
   g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
   LgWave<M> wave(lds);
-  const bool ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F);
+  const bool ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F, W.em);
   if (wave.r == 0 && wave.w == 0) b.ok[d] = ok ? 1 : 0;
 }
 template <int M>
@@ -990,8 +1060,21 @@ __global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) 
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
   rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
-  const bool fine = rows.cond_step((int)blockIdx.y * b.p, W.Pt, W.cc, W.Vf, W.Cf, (size_t)b.F, 0);
+  const bool fine = rows.cond_step((int)blockIdx.y * b.p, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, (b.flags && blockIdx.y > 0) ? b.flags + (size_t)d * (b.n + 1) + blockIdx.y : nullptr);
   if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;  // (every writer stores 0)
+}
+template <int M>
+__global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) mng_factors_thin_kernel(const UngSetupDev b) {
+  constexpr int G = 64 / M;
+  __shared__ double lds[LgFactorRows<M>::kLdsDoubles];
+  const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);
+  const int t = (int)blockIdx.y + 1;
+  const MngWork<M> W(b, d);
+  LgFactorRows<M> rows(lds);
+  rows.skip = b.ok[d] == 0;
+  rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
+  const bool fine = rows.cond_step_thin(t * b.p, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, b.flags + (size_t)d * (b.n + 1) + t);
+  if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;
 }
 template <int M>
 static hipError_t launch_mng_setup_big(const UngSetupDev& b, hipStream_t stream) {
@@ -999,8 +1082,19 @@ static hipError_t launch_mng_setup_big(const UngSetupDev& b, hipStream_t stream)
   hipLaunchKernelGGL(mng_laplace_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   if constexpr (M >= 32) hipLaunchKernelGGL((mng_smooth_wave_kernel<M>), dim3(gg), dim3(LgWave<M>::kThreads), 0, stream, b);
   else hipLaunchKernelGGL((mng_setup_kernel<M, true>), dim3(gg), dim3(64), 0, stream, b);
+  if (b.flags) hipLaunchKernelGGL((mng_factors_thin_kernel<M>), dim3(gg, (unsigned)b.n), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
   hipLaunchKernelGGL((mng_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
   hipLaunchKernelGGL(mng_tables_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  if constexpr (M >= 32) {
+    if (b.dm) {   // (the region offsets of MngWork)
+      const size_t F = (size_t)b.F, n = (size_t)b.n, nv = n * b.p, n1 = nv + 1, MMs = (size_t)M * M;
+      double* w = b.scratch + (2 * nv + n) * F;
+      const double* at_all = w; w += n1 * M * F + 2 * n1 * MMs * F + nv * M * F + 2 * nv * F;
+      const double* Vf_all = w; w += n1 * MMs * F;
+      const double* Cf_all = w;
+      hipLaunchKernelGGL((setup_tables_big_kernel<M>), dim3((unsigned)b.F, (unsigned)b.n), dim3(256), 0, stream, at_all, Vf_all, Cf_all, n1 * M, n1 * MMs, b.p, b.mats, b.n, b.ok);
+    }
+  }
   return hipGetLastError();
 }
 template <int M>

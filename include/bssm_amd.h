@@ -471,6 +471,9 @@ int bssm_amd_family_launches(uint64_t* wg, uint64_t* step, uint64_t* row);
 /* runs one kernel that reads n_doubles and writes n_doubles (8 B per lane, coalesced): a known byte count for
  * calibrating the profiler's FETCH_SIZE / WRITE_SIZE counters on this library's access pattern */
 int bssm_debug_stream_copy(uint64_t n_doubles);
+/* diagnostic: workgroups of the conditional-factor kernels (time points >= 1, 16 and more padded states) that took the full decomposition / all of
+ * them, since the last call (csrc/lg_factors_rows.h: the thin path) */
+int bssm_debug_thin_counts(uint64_t out[2]);
 int bssm_plan_debug_timeline(bssm_plan* plan, uint32_t seed, double* avg_delta_cycles);
 
 /* approximate log-likelihood of each of the plan's filters (psi plans: the Gaussian-approximation term ll(1) of

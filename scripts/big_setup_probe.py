@@ -47,6 +47,12 @@ for period, n in ((24, 72), (52, 104)):
             r = PC.post_correct(model, mo, 64, threads=host_threads, is_type="is2", seed=6)
             t2 = time.perf_counter() - t0
             res[dev] = r
+            if dev == "2":
+                import ctypes
+                from bssm_amd import _lib
+                cnt = (ctypes.c_uint64 * 2)()
+                _lib.lib().bssm_debug_thin_counts(cnt)
+                say("   conditional factors: %d of %d (draw, time point >= 1) workgroups took the full decomposition" % (cnt[0], cnt[1]))
             say("m = %d, T = %d, %d draws, %s set-up (%d host threads): first call %.1f ms, second %.1f ms; finite: %s" % (
                 m, n, ns, "device" if dev == "2" else "host", host_threads, t1 * 1e3, t2 * 1e3, bool(np.all(np.isfinite(r["loglik"])))))
         if "0" in res:

@@ -1187,8 +1187,8 @@ def test_user_model_twelve_states_bootstrap_against_the_general_oracle(oracle, m
     """A user model with TWELVE states and a constant 12 x 5 matrix R (round 5: the MP = 16 functor kernels; the reference's
     function-pointer interface has no state limit, src/model_ssm_nlg.h:10-21): bootstrap filter and smoother against
     orc_nlg_general_bsf_filter on the workgroup-resident shape, the row family and the round-1 step kernel (above 16 384 particles)
-    -- ancestors identical, log-likelihood to 1e-9 n; the hiprtc-compiled model gives the bits of the hipcc-built one; the psi-APF
-    and the EKF particle filter of user models end at eight states and say so."""
+    -- ancestors identical, log-likelihood to 1e-9 n; the hiprtc-compiled model gives the bits of the hipcc-built one; the EKF particle
+    filter of user models ends at eight states and says so, the psi-APF asks for the Jacobians."""
     c = _twelve_case()
     mk = lambda jit: M.ssm_nlg_user(c["y"], USER_TWELVE, theta=c["th"], known_params=c["kn"], a1=c["a1"], P1=c["P1"], H=0.5,
                                      n_states=c["m"], R=c["Rm"], jit=jit)
@@ -1209,9 +1209,12 @@ def test_user_model_twelve_states_bootstrap_against_the_general_oracle(oracle, m
         assert np.array_equal(oj[key], out[key]), key
     assert oj["logLik"] == out["logLik"]
     if path == "wg":
-        for method in ("psi", "ekf"):
-            with pytest.raises(Exception, match="at most 8 states"):
-                F.particle_smoother(u, 100, method=method, seed=7)
+        # (round 6: the psi-APF goes to 16 states for snippets WITH Jacobians -- USER_TWELVE_J below; this one has none and says so;
+        # the EKF particle filter ends at eight states)
+        with pytest.raises(Exception, match="BSSM_USER_JACOBIANS"):
+            F.particle_smoother(u, 100, method="psi", seed=7)
+        with pytest.raises(Exception, match="at most 8 states"):
+            F.particle_smoother(u, 100, method="ekf", seed=7)
         with pytest.raises(Exception, match="16"):
             M.ssm_nlg_user(np.zeros(4), USER_TWELVE, theta=c["th"], a1=np.zeros(17), P1=np.eye(17), H=0.5, n_states=17, R=np.eye(17))
 
