@@ -20,6 +20,7 @@
 // Device only; one wave per workgroup (blockDim.x = 64); every lane of the wave must call it.
 #pragma once
 #include "lg_smoother.h"
+#include "pf_device.h"   // lane_broadcast, wave_max_key
 
 namespace bssm {
 
@@ -323,6 +324,87 @@ struct LgFactorRows {
     __syncthreads();
     return rank;
   }
+  // ---- Round 6, late: the sequential parts of the thin path in REGISTERS, on every wave (G == 1: one matrix per workgroup, M = 64).
+  // Wave 0 alone ran the left-looking factorisation and the substitutions out of LDS while three waves kept the barriers: ~300 us per (draw,
+  // time point).  Here every wave holds its JW columns of row r: the factorisation is right-looking (the Schur complement in registers: a pivot
+  // step is one maximum over the wave, one column through LDS, one rank-1 update whose row operand comes by v_readlane), and the substitutions
+  // are column-oriented -- a wave solves ITS columns of the right-hand side, no barrier at all.  Same pivots and the same factor up to the
+  // order of the roundings (sums of the same products, subtracted one pivot at a time instead of in four partial sums).
+  // 1 / sqrt(d) for d > 0 (v_rsq_f64 + three Newton steps: the last place or two), d * that = sqrt(d)
+  __device__ LG_INL static double rsqrt_nr(const double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+      const double e = __builtin_fma(-(h * y), y, 0.5);
+      y = __builtin_fma(y, e, y);
+    }
+    return y;
+  }
+  __device__ LG_INL int pivoted_cholesky_regs(const int steps, const double thr, const bool relative) {
+    static_assert(G == 1, "one matrix per workgroup: the pivot is wave-uniform");
+    const int j0s = __builtin_amdgcn_readfirstlane(j0);
+    double S[JW];
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) S[jj] = A[r * LD + j0 + jj];
+    double dg = (r < mr) ? A[r * LD + r] : -1.0;
+    bool picked = r >= mr, open = true;
+    int rank = 0;
+    double thr_abs = thr;
+    for (int j = 0; j < steps; j++) {
+      double* buf = (j & 1) ? vb : va;
+      const double key = picked ? -1.0 : dg;
+      const double dmax = wave_max_key(key);
+      const unsigned long long at = __builtin_amdgcn_ballot_w64(key == dmax);
+      const int best = at ? __builtin_ctzll(at) : 0;   // (the first of equals, as the scan of pivoted_cholesky; no lane: a NaN, carried to the end)
+      if (j == 0 && relative) thr_abs = thr * dmax;
+      open = open && dmax > thr_abs;
+      rank += open ? 1 : 0;
+      if ((best / JW) == w) {   // this wave owns column `best` of the Schur complement (wave-uniform)
+        double x = S[0];
+#pragma unroll
+        for (int jj = 1; jj < JW; jj++) x = ((best % JW) == jj) ? S[jj] : x;
+        buf[r] = x;
+      }
+      __syncthreads();
+      double l = 0.0;
+      if (open) {
+        const double rs = rsqrt_nr(dmax);
+        l = picked ? 0.0 : buf[r] * rs;
+        if (r == best) { l = dmax * rs; picked = true; }
+      }
+      if (w == 0) {
+        W[r * LD + j] = l;
+        if (r == 0 && open) vc[j] = (double)best;
+      }
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) S[jj] -= l * lane_broadcast(l, j0s + jj);
+      dg -= l * l;
+    }
+    __syncthreads();
+    return rank;
+  }
+  // X <- (L L')^{-1} X for this wave's JW columns: L (lower triangular, rows in pivot order) in slot X of LDS, the right-hand side's row r in
+  // registers; forward, then backward substitution, column-oriented: a row is kept DIVIDED by its diagonal element, so that the component a
+  // step finishes is simply lane a's row -- broadcast by v_readlane and eliminated from the other rows with the factor's entry divided the same
+  // way (one multiplication per step; the entries on the other side of the diagonal are exact zeros, the row's own entry is masked).
+  __device__ LG_INL void chol_solve_regs(double (&X)[JW]) {
+    const double dinv = (r < mr) ? 1.0 / A[r * LD + r] : 0.0;
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) X[jj] *= dinv;
+    for (int a = 0; a < mr; a++) {
+      const double la = (r == a) ? 0.0 : A[r * LD + a] * dinv;
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) X[jj] -= la * lane_broadcast(X[jj], a);
+    }
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) X[jj] *= dinv;
+    for (int a = mr - 1; a >= 0; a--) {
+      const double ua = (r == a) ? 0.0 : A[a * LD + r] * dinv;
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) X[jj] -= ua * lane_broadcast(X[jj], a);
+    }
+  }
   // Returns whether THIS GROUP's matrices need the full path (a singular V_{t-1}, or more than RT noise directions): a property of the
   // draw alone -- which draws share a workgroup must not show in anybody's bits (the result of a post-correction call is the same for
   // every device list).  Every group runs all of it (the barriers are the workgroup's); a group that needs the full path writes nothing
@@ -334,7 +416,9 @@ struct LgFactorRows {
 #pragma unroll
     for (int jj = 0; jj < JW; jj++) row[jj] = Pt[((size_t)(t - 1) * MM + r + M * (j0 + jj)) * es + d];
     store_sym(row);
-    const int rank1 = pivoted_cholesky(mr, kEps * mr, true);
+    int rank1;
+    if constexpr (G == 1) rank1 = pivoted_cholesky_regs(mr, kEps * mr, true);
+    else rank1 = pivoted_cholesky(mr, kEps * mr, true);
     bool need_full = rank1 < mr;   // a singular V_{t-1}: what follows is computed (on a factor with zero columns: not finite) and discarded
     const int pr = (r < mr) ? min(max((int)vc[r], 0), M - 1) : r;   // the row of the matrix that is pivot r (clamped: places behind the rank of a singular matrix hold stale values)
 #pragma unroll
@@ -343,8 +427,20 @@ struct LgFactorRows {
     if (w == 0 && r < mr) vd[pr] = (double)r;      // inverse permutation: the place of row pr
 #pragma unroll
     for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = row[jj];    // slot X: the factor with its rows in pivot order (lower triangular)
+    double c0[JW];   // C_{t-1}, rows in pivot order
 #pragma unroll
-    for (int jj = 0; jj < JW; jj++) W[r * LD + j0 + jj] = (r < mr) ? cc[((size_t)(t - 1) * MM + pr + M * (j0 + jj)) * es + d] : 0.0;  // slot Y: C_{t-1}, rows in pivot order
+    for (int jj = 0; jj < JW; jj++) c0[jj] = (r < mr) ? cc[((size_t)(t - 1) * MM + pr + M * (j0 + jj)) * es + d] : 0.0;
+    if constexpr (G == 1) {
+      __syncthreads();   // the factor is in slot X
+      double xs[JW];
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) xs[jj] = c0[jj];
+      chol_solve_regs(xs);
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) W[r * LD + j0 + jj] = xs[jj];   // slot Y: the solution (the factor's columns there are spent: every lane read its pivot row above)
+    } else {
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) W[r * LD + j0 + jj] = c0[jj];  // slot Y: C_{t-1}, rows in pivot order
     __syncthreads();
     if (w == 0 && r < mr) {   // lane c solves column c: forward, then backward substitution, in place
       const int c = r;
@@ -373,6 +469,7 @@ struct LgFactorRows {
         W[a * LD + c] = ((s0 + s1) + (s2 + s3)) / A[a * LD + a];
       }
     }
+    }
     __syncthreads();
     // C_t = (pinv(V_{t-1}) C_{t-1})': element [r][j] is the solution's [place of j][r]
 #pragma unroll
@@ -382,8 +479,9 @@ struct LgFactorRows {
       cout[jj] = (r < mr && j < mr) ? W[pl * LD + r] : 0.0;
     }
     // ---- Var(alpha_t | alpha_{t-1}, y) = V_t - C_t C_{t-1}: the cross-covariance again (rows in pivot order) into slot X
+    // (every wave is through with the factor in slot X: the barrier behind the substitutions)
 #pragma unroll
-    for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = (r < mr) ? cc[((size_t)(t - 1) * MM + pr + M * (j0 + jj)) * es + d] : 0.0;
+    for (int jj = 0; jj < JW; jj++) A[r * LD + j0 + jj] = c0[jj];
     __syncthreads();
     {
       double acc[JW];
@@ -473,18 +571,30 @@ struct LgFactorRows {
         for (int c = 0; c < RT; c++) if (rk == c) { f[c] = fa; lam_at[c] = lam[a]; }
       }
       // sign of every column: its largest component positive (the first of equals)
+      double sg[RT];
+      if constexpr (G == 1) {   // (one matrix per wave row set: the column's largest |component| is a maximum over the wave, lane r holding row r's)
+#pragma unroll
+        for (int c = 0; c < RT; c++) {
+          const double k = fabs(f[c]);
+          const double mx = wave_max_key(k);
+          const unsigned long long at = __builtin_amdgcn_ballot_w64(k == mx);
+          const int big = at ? __builtin_ctzll(at) : 0;
+          sg[c] = lane_broadcast(f[c], big) < 0 ? -1.0 : 1.0;
+        }
+      } else {
       __syncthreads();   // every lane is through with the factor's columns in slot Y and with the Jacobi matrix in slot X
       if (w == 0) {
 #pragma unroll
         for (int c = 0; c < RT; c++) A[r * LD + c] = f[c];
       }
       __syncthreads();
-      double sg[RT];
 #pragma unroll
       for (int c = 0; c < RT; c++) {
         int big = 0;
+#pragma unroll 4
         for (int i = 1; i < M; i++) if (fabs(A[i * LD + c]) > fabs(A[big * LD + c])) big = i;
         sg[c] = A[big * LD + c] < 0 ? -1.0 : 1.0;
+      }
       }
 #pragma unroll
       for (int jj = 0; jj < JW; jj++) {

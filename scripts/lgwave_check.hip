@@ -19,6 +19,7 @@ struct Dev {
   const double *Z, *T, *RR, *D, *C, *y, *H, *a1, *P1;
   double *at, *Pt, *cc, *K, *v, *Fs, *Vf, *Cf;
   int* ok;
+  int* flags;   // [F][n + 1]: which (draw, time point) the full factor kernel still has to do (written by the thin one)
 };
 
 template <int M>
@@ -42,7 +43,20 @@ __global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) 
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
   rows.mr = b.mr;
-  const bool fine = rows.cond_step((int)blockIdx.y, b.Pt + d, b.cc + d, b.Vf + d, b.Cf + d, (size_t)b.F, 0);
+  const bool fine = rows.cond_step((int)blockIdx.y, b.Pt + d, b.cc + d, b.Vf + d, b.Cf + d, (size_t)b.F, 0, blockIdx.y > 0 ? b.flags + (size_t)d * (b.n + 1) + blockIdx.y : nullptr);
+  if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;
+}
+// the thin path of time point blockIdx.y + 1 (as ung_factors_thin_kernel of pf_kernels.hip)
+template <int M>
+__global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) factors_thin_kernel(const Dev b) {
+  constexpr int G = 64 / M;
+  __shared__ double lds[LgFactorRows<M>::kLdsDoubles];
+  const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);
+  const int t = (int)blockIdx.y + 1;
+  LgFactorRows<M> rows(lds);
+  rows.skip = b.ok[d] == 0;
+  rows.mr = b.mr;
+  const bool fine = rows.cond_step_thin(t, b.Pt + d, b.cc + d, b.Vf + d, b.Cf + d, (size_t)b.F, 0, b.flags + (size_t)d * (b.n + 1) + t);
   if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;
 }
 
@@ -107,6 +121,8 @@ int check(int mr, int n, int F, unsigned seed) {
   b.at = dalloc((size_t)F * n1 * M); b.Pt = dalloc((size_t)F * n1 * MM); b.cc = dalloc((size_t)F * n1 * MM); b.K = dalloc((size_t)F * n * M); b.v = dalloc((size_t)F * n); b.Fs = dalloc((size_t)F * n);
   b.Vf = dalloc((size_t)F * n1 * MM); b.Cf = dalloc((size_t)F * n1 * MM);
   CK(hipMalloc(&b.ok, F * sizeof(int)));
+  CK(hipMalloc(&b.flags, (size_t)F * n1 * sizeof(int)));
+  CK(hipMemset(b.flags, 0, (size_t)F * n1 * sizeof(int)));
   constexpr int G = 64 / M;
   hipEvent_t e0, e1, e2;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
@@ -118,12 +134,24 @@ int check(int mr, int n, int F, unsigned seed) {
   CK(hipMemcpy(g_at.data(), b.at, g_at.size() * 8, hipMemcpyDeviceToHost));
   CK(hipMemcpy(g_Pt.data(), b.Pt, g_Pt.size() * 8, hipMemcpyDeviceToHost));
   CK(hipMemcpy(g_cc.data(), b.cc, g_cc.size() * 8, hipMemcpyDeviceToHost));
+  hipEvent_t e3;
+  CK(hipEventCreate(&e3));
   CK(hipEventRecord(e1));
+  hipLaunchKernelGGL((factors_thin_kernel<M>), dim3((F + G - 1) / G, n), dim3(LgFactorRows<M>::kThreads), 0, 0, b);
+  CK(hipEventRecord(e3));
   hipLaunchKernelGGL((factors_kernel<M>), dim3((F + G - 1) / G, n + 1), dim3(LgFactorRows<M>::kThreads), 0, 0, b);
   CK(hipEventRecord(e2));
   CK(hipDeviceSynchronize());
-  float ms_f = 0;
+  float ms_f = 0, ms_thin = 0;
   CK(hipEventElapsedTime(&ms_f, e1, e2));
+  CK(hipEventElapsedTime(&ms_thin, e1, e3));
+  {
+    std::vector<int> fl((size_t)F * n1);
+    CK(hipMemcpy(fl.data(), b.flags, fl.size() * sizeof(int), hipMemcpyDeviceToHost));
+    size_t full = 0;
+    for (int q : fl) full += q != 0;
+    std::printf("   thin kernel %.3f ms; %zu of %zu (draw, time point >= 1) left to the full kernel\n", ms_thin, full, (size_t)F * n);
+  }
   {
     unsigned long long st[8] = {0}, zero[8] = {0};
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(bssm::lgf_stats), sizeof(st)));
@@ -167,6 +195,7 @@ int check(int mr, int n, int F, unsigned seed) {
   for (const double* p : {b.Z, b.T, b.RR, b.D, b.C, b.y, b.H, b.a1, b.P1}) CK(hipFree((void*)p));
   for (double* p : {b.at, b.Pt, b.cc, b.K, b.v, b.Fs, b.Vf, b.Cf}) CK(hipFree(p));
   CK(hipFree(b.ok));
+  CK(hipFree(b.flags));
   return (w < 1e-8 && okdiff == 0) ? 0 : 1;
 }
 
