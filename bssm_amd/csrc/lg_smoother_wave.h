@@ -39,6 +39,7 @@ struct LgWave {
   int r;                              // the row this lane works on
   int j0;                             // the first of the JW columns this lane owns
   int w;                              // its wave
+  int mr = M;                         // the states the draws really have (the rest of the padded dimension is exact zeros): the inner loops stop there
   __device__ LgWave(double* lds_wg) {
     const int lane = threadIdx.x & 63;
     w = (int)threadIdx.x >> 6;
@@ -82,6 +83,9 @@ struct LgWave {
   // 1 for a draw-major layout: a 64-dimensional draw's row-distributed stores are then 512-byte segments instead of 8 bytes per 2 KB stride
   __device__ LG_INL bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es, size_t em = 0) {
     if (em == 0) em = es;
+#ifndef LGW_NO_MFMA
+    if constexpr (M == 64 && NW == 4) return run_mfma(g, at, Pt, cc, K, v, Fs, es, em);
+#endif
     const int n = g.n, sub = g.sub;
     int bad = 0;
     double c[JW];
@@ -279,6 +283,248 @@ struct LgWave {
 #pragma unroll
     for (int jj = 0; jj < JW; jj++) cc[((size_t)n * MM + r + M * (j0 + jj)) * em] = 0.0;
     // any lane of the group bad -> false in every lane of the group
+    sync();
+    vx[r] = 0.0;
+    sync();
+    if (bad) vx[r] = 1.0;
+    sync();
+    double any = 0.0;
+#pragma unroll 4
+    for (int j = 0; j < M; j++) any += vx[j];
+    return any == 0.0;
+  }
+  // =================================================================================================================================
+  // Round 6, late: the 64-dimensional step with its matrix products on the MATRIX CORES (one draw per workgroup, four waves).
+  // The row form above is bound by LDS reads: a product asks for 17 LDS reads per 16 multiply-adds and lane, 4 x 64 x 17 reads of the one LDS
+  // per product against 64 x 16 multiply-adds per SIMD.  v_mfma_f64_16x16x4_f64 takes ONE A and ONE B element per lane for 64 x 16 x 4
+  // multiply-adds; wave w computes the 64 x 16 column strip [16 w, 16 w + 16) of a product in four accumulators (the B fragment of a k-chunk
+  // serves the four row blocks): 5 LDS reads per 4 matrix instructions.  Two more changes of FORM, none of value:
+  //   * (I - K Z') P (I - K Z')' + K HH K' with K = P Z / F is P - (P Z)(P Z)' / F: a rank-one update of the rows in place (two products less);
+  //   * L = T (I - K Z') = T - (T K) Z': a matrix-vector product and a rank-one update (one product less).
+  // 9 products on the matrix cores per time point instead of 12 row products.  The elementwise steps keep the row form (lane r: row r, wave w:
+  // columns 16 w ...), the products hand their results over through the LDS slots.  Sums run in the matrix cores' order (k-chunks of four), so
+  // the results differ from LgSmoother<M>::run in the last places (the set-up tests hold the kernels to the oracle at 1e-9 n).
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  // acc = op(X) op(Y) for this wave's 16 columns and the four row blocks; XT: X(i, k) = Xs[k][i], YT: Y(k, j) = Ys[j][k]
+  template <bool XT, bool YT>
+  __device__ LG_INL void mm_acc(const double* Xs, const double* Ys, d4 (&acc)[4]) const {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int jc = 16 * w + li;
+#pragma unroll
+    for (int ib = 0; ib < 4; ib++) acc[ib] = d4{0.0, 0.0, 0.0, 0.0};
+    const int kcn = (mr + 3) >> 2;   // (the k-chunks of the real states: the padding is exact zeros)
+#pragma unroll 2
+    for (int kc = 0; kc < kcn; kc++) {
+      const int k = 4 * kc + lk;
+      const double bv = YT ? Ys[jc * LD + k] : Ys[k * LD + jc];
+      double av[4];
+#pragma unroll
+      for (int ib = 0; ib < 4; ib++) av[ib] = XT ? Xs[k * LD + 16 * ib + li] : Xs[(16 * ib + li) * LD + k];
+#pragma unroll
+      for (int ib = 0; ib < 4; ib++) acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ib], bv, acc[ib], 0, 0, 0);
+    }
+  }
+  // D fragment: element q of row block ib is row 16 ib + (lane >> 4) + 4 q, column 16 w + (lane & 15)
+  __device__ LG_INL void mm_store(double* Dst, const d4 (&acc)[4]) const {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) Dst[(16 * ib + lk + 4 * q) * LD + 16 * w + li] = acc[ib][q];
+  }
+  __device__ LG_INL void get_row(const double* S, double (&c)[JW]) const {
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) c[jj] = S[r * LD + j0 + jj];
+  }
+  __device__ LG_INL bool run_mfma(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es, size_t em) {
+    const int n = g.n, sub = g.sub;
+    int bad = 0;
+    double c[JW];
+    d4 acc[4];
+    const double a1r = g.a1[(size_t)r * es];
+    load_row(g.P1, es, c);
+    sync();
+    va[r] = a1r;
+    put_row(SA, c);
+    if (w == 0) at[(size_t)r * em] = a1r;
+    store_row(Pt, em, c);
+    // ---- forward pass: SA = P, SD = T
+    bool have_T = false;
+    for (int t = 0; t < n; t++) {
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      const bool moves = sub == 1 || js == sub - 1;   // (a step inside a time point: identity transition, no noise)
+      const double zr = g.Z[((size_t)tr * g.Zs + (size_t)js * M + r) * es];
+      const double yt = g.y[(size_t)t * es], sd = g.H[(size_t)t * g.Hs * es], Dt = g.D[((size_t)tr * g.Ds + js) * es];
+      const double Cr = moves ? g.C[((size_t)tr * g.Cs + r) * es] : 0.0;
+      const bool load_T = moves && (!have_T || g.Ts != 0 || sub != 1);
+      if (load_T) load_row(g.T + (size_t)tr * g.Ts * es, es, c);
+      double rrv[JW];   // R R' of the step: element (min, max) of the pair (the lower triangle takes the upper one's values below)
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) {
+        const int j = j0 + jj, lo = j < r ? j : r, hi = j < r ? r : j;
+        rrv[jj] = moves ? g.RR[((size_t)tr * g.Rs + lo + M * hi) * es] : 0.0;
+      }
+      sync();
+      vZ[r] = zr;
+      if (load_T) { put_row(SD, c); have_T = true; }
+      sync();
+      const bool na = !lg_finite(yt);
+      const double HH = na ? 1.0 : sd * sd;
+      double pz = 0.0;
+#pragma unroll 4
+      for (int q = 0; q < mr; q++) pz += vZ[q] * SA[r * LD + q];
+      vx[r] = pz;
+      sync();
+      double F = 0.0;
+      if (!na) {
+#pragma unroll 4
+        for (int q = 0; q < mr; q++) F += vx[q] * vZ[q];
+      }
+      F += HH;
+      const bool upd = !na && F > kZeroTol;
+      double za = 0.0;
+#pragma unroll 4
+      for (int q = 0; q < mr; q++) za += vZ[q] * va[q];
+      const double vt = upd ? yt - Dt - za : 0.0;
+      if (r == 0 && w == 0) { Fs[(size_t)t * es] = upd ? F : 0.0; v[(size_t)t * es] = vt; }
+      const double Kr = upd ? pz / F : 0.0;
+      const double aur = upd ? va[r] + Kr * vt : va[r];
+      if (w == 0) K[((size_t)t * M + r) * em] = Kr;
+      vy[r] = aur;
+      // inner = P - K (P Z)'  (this lane's elements of its row)
+      if (upd) {
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++) SA[r * LD + j0 + jj] -= Kr * vx[j0 + jj];
+      }
+      sync();
+      double a1n = aur + Cr;
+      if (moves) {
+        double s = 0.0;
+#pragma unroll 4
+        for (int q = 0; q < mr; q++) s += SD[r * LD + q] * vy[q];
+        a1n = Cr + s;
+        mm_acc<false, false>(SD, SA, acc);   // T inner
+        mm_store(SC, acc);
+        sync();
+        mm_acc<false, true>(SC, SD, acc);    // (T inner) T'
+        mm_store(SB, acc);
+        sync();
+        // + R R', symmatu: the lower triangle takes the upper one's values
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++) { const int j = j0 + jj; c[jj] = (j < r ? SB[j * LD + r] : SB[r * LD + j]) + rrv[jj]; }
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++) { const int j = j0 + jj; c[jj] = j < r ? SA[j * LD + r] : SA[r * LD + j]; }
+        sync();   // every lane has read the upper triangle
+      }
+      put_row(SA, c);
+      bad |= !lg_finite(a1n);
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) bad |= !lg_finite(c[jj]);
+      if (w == 0) at[((size_t)(t + 1) * M + r) * em] = a1n;
+      store_row(Pt + (size_t)(t + 1) * MM * em, em, c);
+      store_row(cc + (size_t)t * MM * em, em, c);
+      va[r] = a1n;
+    }
+    // ---- backward pass (smoother_ccov): SA = N, vr = r_t
+    sync();
+    vr[r] = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) SA[r * LD + j0 + jj] = 0.0;
+    __threadfence_block();
+    sync();   // (also: the K, F and v stores of the forward pass are visible to the other waves of the workgroup)
+    for (int t = n - 1; t >= 0; t--) {
+      const double F = Fs[(size_t)t * es], vt = v[(size_t)t * es];
+      const bool upd = F > 0.0;
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      const bool moves = sub == 1 || js == sub - 1;
+      const double zr = g.Z[((size_t)tr * g.Zs + (size_t)js * M + r) * es];
+      const double Kr = upd ? K[((size_t)t * M + r) * em] : 0.0;
+      const double ar = at[((size_t)t * M + r) * em];
+      double ptrow[JW], ccrow[JW];
+      if (moves) load_row(g.T + (size_t)tr * g.Ts * es, es, c);
+      else {
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++) c[jj] = (r == j0 + jj) ? 1.0 : 0.0;
+      }
+      load_row(cc + (size_t)t * MM * em, em, ccrow);
+      load_row(Pt + (size_t)t * MM * em, em, ptrow);
+      sync();           // the step before is through with every slot
+      vZ[r] = zr;
+      vK[r] = Kr;
+      put_row(SD, c);       // T
+      put_row(SB, ccrow);   // cc[t] (the predicted covariance of t + 1)
+      sync();
+      // L = T (I - K Z') = T - (T K) Z' into SC
+      double tk = 0.0;
+#pragma unroll 4
+      for (int q = 0; q < mr; q++) tk += SD[r * LD + q] * vK[q];
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) SC[r * LD + j0 + jj] = SD[r * LD + j0 + jj] - tk * vZ[j0 + jj];
+      mm_acc<false, false>(SA, SB, acc);   // N cc[t]
+      sync();           // every lane is through with T; L is complete
+      mm_store(SD, acc);
+      sync();
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) SD[r * LD + j0 + jj] = ((r == j0 + jj) ? 1.0 : 0.0) - SD[r * LD + j0 + jj];   // I - N cc[t]
+      put_row(SB, ptrow);   // Pt[t]
+      sync();
+      mm_acc<false, true>(SB, SC, acc);    // Pt[t] L'
+      sync();           // every lane is through with Pt[t]
+      mm_store(SB, acc);
+      sync();
+      mm_acc<false, false>(SB, SD, acc);   // cc[t] = Pt[t] L' (I - N cc[t])
+      sync();           // every lane is through with I - N cc[t]
+      mm_store(SD, acc);
+      mm_acc<true, false>(SC, SA, acc);    // L' N
+      double rn = 0.0;  // r_{t-1} = L' r_t
+#pragma unroll 4
+      for (int q = 0; q < mr; q++) rn += SC[q * LD + r] * vr[q];
+      mm_store(SB, acc);
+      sync();
+      get_row(SD, c);
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) bad |= !lg_finite(c[jj]);
+      store_row(cc + (size_t)t * MM * em, em, c);
+      mm_acc<false, false>(SB, SC, acc);   // N_{t-1} = L' N L (+ Z Z' / F)
+      mm_store(SA, acc);
+      sync();
+      if (upd) {
+        rn = zr / F * vt + rn;
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++) if (j0 + jj >= r) SA[r * LD + j0 + jj] = zr * vZ[j0 + jj] / F + SA[r * LD + j0 + jj];
+      }
+      vr[r] = rn;
+      put_row(SB, ptrow);   // Pt[t] again (a broadcast operand below)
+      sync();
+      // symmatu(N)
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) if (j0 + jj < r) SA[r * LD + j0 + jj] = SA[(j0 + jj) * LD + r];
+      double pr = 0.0;
+#pragma unroll 4
+      for (int q = 0; q < mr; q++) pr += SB[r * LD + q] * vr[q];
+      const double as = ar + pr;
+      bad |= !lg_finite(as);
+      if (w == 0) at[((size_t)t * M + r) * em] = as;
+      sync();
+      // Pt[t] - symmatu(Pt[t] N Pt[t])
+      mm_acc<false, false>(SB, SA, acc);
+      mm_store(SD, acc);
+      sync();
+      mm_acc<false, false>(SD, SB, acc);
+      mm_store(SC, acc);
+      sync();
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) {
+        const int j = j0 + jj;
+        const double x = (j < r) ? SC[j * LD + r] : SC[r * LD + j];
+        const double pn = ptrow[jj] - x;
+        bad |= !lg_finite(pn);
+        Pt[((size_t)t * MM + r + M * j) * em] = pn;
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < JW; jj++) cc[((size_t)n * MM + r + M * (j0 + jj)) * em] = 0.0;
     sync();
     vx[r] = 0.0;
     sync();

@@ -723,6 +723,7 @@ __global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) ung_sm
   g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
   g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
   LgWave<M> wave(lds);
+  wave.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
   const bool ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F, W.em);
   if (wave.r == 0 && wave.w == 0) b.ok[d] = ok ? 1 : 0;
 }
@@ -1048,6 +1049,7 @@ __global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) mng_sm
   g.D = in + b.oD * F; g.Ds = b.Ds; g.C = in + b.oC * F; g.Cs = b.Cs; g.y = W.ay; g.H = W.aH; g.Hs = 1;
   g.a1 = in + b.oa * F; g.P1 = in + b.oP * F;
   LgWave<M> wave(lds);
+  wave.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
   const bool ok = wave.run(g, W.at, W.Pt, W.cc, W.K, W.v, W.Fs, F, W.em);
   if (wave.r == 0 && wave.w == 0) b.ok[d] = ok ? 1 : 0;
 }

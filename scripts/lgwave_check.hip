@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) smooth
   g.Z = b.Z + d; g.Zs = 0; g.T = b.T + d; g.Ts = 0; g.RR = b.RR + d; g.Rs = 0; g.D = b.D + d; g.Ds = 0; g.C = b.C + d; g.Cs = 0;
   g.y = b.y + d; g.H = b.H + d; g.Hs = 1; g.a1 = b.a1 + d; g.P1 = b.P1 + d;
   LgWave<M> w(lds);
+  w.mr = b.mr;
   const bool ok = w.run(g, b.at + d, b.Pt + d, b.cc + d, b.K + d, b.v + d, b.Fs + d, (size_t)b.F);
   b.ok[d] = ok ? 1 : 0;
 }
