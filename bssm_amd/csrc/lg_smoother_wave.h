@@ -18,8 +18,17 @@
 // special-cased branch has).  Device only; blockDim.x = 64 NW; every lane of the workgroup must call it.
 #pragma once
 #include "lg_smoother.h"
+#include "pf_device.h"   // wave_sum (run_mfma)
 
 namespace bssm {
+
+// analysis builds (-DLGW_STAMPS, scripts/lgwave_check.hip): clocks (s_memtime, 100 MHz) thread 0 of workgroup 0 spends between the marks of run_mfma
+#ifdef LGW_STAMPS
+__device__ unsigned long long lgw_stamps[32];
+#define LGW_T(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); lgw_acc[k] += t1_ - lgw_t0; lgw_t0 = t1_; } } while (0)
+#else
+#define LGW_T(k)
+#endif
 
 #ifndef LGW_NW32
 #define LGW_NW32 4   // waves per workgroup at 32 (padded) states: four (eight columns each, 222 registers: two workgroups = two waves per SIMD; 512 draws 10.2 -> 5.2 ms against two)
@@ -50,6 +59,9 @@ struct LgWave {
     vZ = base + 4 * MAT; va = vZ + M; vK = va + M; vx = vK + M; vy = vx + M; vr = vy + M;
   }
   __device__ LG_INL static void sync() { __syncthreads(); }
+  // a barrier that orders the workgroup's LDS traffic only: loads from / stores to memory stay in flight across it (run_mfma: the operands of the
+  // next step are requested a step ahead; nothing a wave of the workgroup stores to memory inside a pass is read by another wave inside that pass)
+  __device__ LG_INL static void sync_lds() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
   // c[jj] = sum over q (ascending, from 0.0) of own(q) * bop(q, j0 + jj)
   template <class Own, class Bop>
@@ -309,19 +321,29 @@ struct LgWave {
   template <bool XT, bool YT>
   __device__ LG_INL void mm_acc(const double* Xs, const double* Ys, d4 (&acc)[4]) const {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    const int jc = 16 * w + li;
+    // this lane's operand addresses of k-chunk 0; a chunk further is 4 columns (rows when transposed) on
+    const double* xp = XT ? Xs + lk * LD + li : Xs + li * LD + lk;
+    const double* yp = YT ? Ys + (16 * w + li) * LD + lk : Ys + lk * LD + 16 * w + li;
+    constexpr int XB = XT ? 16 : 16 * LD, XK = XT ? 4 * LD : 4, YK = YT ? 4 : 4 * LD;   // row-block and k-chunk strides
 #pragma unroll
     for (int ib = 0; ib < 4; ib++) acc[ib] = d4{0.0, 0.0, 0.0, 0.0};
     const int kcn = (mr + 3) >> 2;   // (the k-chunks of the real states: the padding is exact zeros)
-#pragma unroll 2
-    for (int kc = 0; kc < kcn; kc++) {
-      const int k = 4 * kc + lk;
-      const double bv = YT ? Ys[jc * LD + k] : Ys[k * LD + jc];
-      double av[4];
+    // the operands of chunk kc + 1 are requested BEFORE the matrix instructions of chunk kc are issued: one wave per SIMD, nothing else hides
+    // an LDS round trip (8.7 -> ... thousand clocks per product)
+    double bv = yp[0], av[4];
 #pragma unroll
-      for (int ib = 0; ib < 4; ib++) av[ib] = XT ? Xs[k * LD + 16 * ib + li] : Xs[(16 * ib + li) * LD + k];
+    for (int ib = 0; ib < 4; ib++) av[ib] = xp[ib * XB];
+    for (int kc = 0; kc < kcn; kc++) {
+      const int kn = kc + 1 < kcn ? kc + 1 : kc;   // (the last chunk asks for itself again: no branch around the loads)
+      const double bn = yp[kn * YK];
+      double an[4];
+#pragma unroll
+      for (int ib = 0; ib < 4; ib++) an[ib] = xp[kn * XK + ib * XB];
 #pragma unroll
       for (int ib = 0; ib < 4; ib++) acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ib], bv, acc[ib], 0, 0, 0);
+      bv = bn;
+#pragma unroll
+      for (int ib = 0; ib < 4; ib++) av[ib] = an[ib];
     }
   }
   // D fragment: element q of row block ib is row 16 ib + (lane >> 4) + 4 q, column 16 w + (lane & 15)
@@ -341,15 +363,37 @@ struct LgWave {
     int bad = 0;
     double c[JW];
     d4 acc[4];
+#ifdef LGW_STAMPS
+    unsigned long long lgw_acc[32] = {0}, lgw_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const double a1r = g.a1[(size_t)r * es];
     load_row(g.P1, es, c);
     sync();
-    va[r] = a1r;
+    double a_reg = a1r;   // a_t of this lane's row
     put_row(SA, c);
     if (w == 0) at[(size_t)r * em] = a1r;
     store_row(Pt, em, c);
     // ---- forward pass: SA = P, SD = T
     bool have_T = false;
+    // R R' of the step: element (min, max) of the pair (the lower triangle takes the upper one's values below); a time-invariant one is read
+    // ONCE (the model arrays are draw-interleaved: a row-distributed read of a matrix is 4 096 scattered 8-byte loads)
+    const bool rr_const = g.Rs == 0 && sub == 1;
+    double rrv[JW];
+    // a step's results (a_{t+1}, P_{t+1}) go to memory from the NEXT step, behind its operand loads: a store issued at the end of a step is still
+    // in flight when the next step waits for its operands, and the counter that tracks both cannot tell them apart (~1 us per step)
+    double pend[JW];
+    auto flush_fwd = [&](const int t) {   // the stores of step t: a_reg and pend hold a_{t+1}, P_{t+1}
+      if (w == 0) at[((size_t)(t + 1) * M + r) * em] = a_reg;
+      store_row(Pt + (size_t)(t + 1) * MM * em, em, pend);
+      store_row(cc + (size_t)t * MM * em, em, pend);
+    };
+    if (rr_const) {
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) {
+        const int j = j0 + jj, lo = j < r ? j : r, hi = j < r ? r : j;
+        rrv[jj] = g.RR[(size_t)(lo + M * hi) * es];
+      }
+    }
     for (int t = 0; t < n; t++) {
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
       const bool moves = sub == 1 || js == sub - 1;   // (a step inside a time point: identity transition, no noise)
@@ -358,37 +402,36 @@ struct LgWave {
       const double Cr = moves ? g.C[((size_t)tr * g.Cs + r) * es] : 0.0;
       const bool load_T = moves && (!have_T || g.Ts != 0 || sub != 1);
       if (load_T) load_row(g.T + (size_t)tr * g.Ts * es, es, c);
-      double rrv[JW];   // R R' of the step: element (min, max) of the pair (the lower triangle takes the upper one's values below)
+      if (!rr_const) {
 #pragma unroll
-      for (int jj = 0; jj < JW; jj++) {
-        const int j = j0 + jj, lo = j < r ? j : r, hi = j < r ? r : j;
-        rrv[jj] = moves ? g.RR[((size_t)tr * g.Rs + lo + M * hi) * es] : 0.0;
+        for (int jj = 0; jj < JW; jj++) {
+          const int j = j0 + jj, lo = j < r ? j : r, hi = j < r ? r : j;
+          rrv[jj] = moves ? g.RR[((size_t)tr * g.Rs + lo + M * hi) * es] : 0.0;
+        }
       }
-      sync();
+      sync_lds();
+      LGW_T(0);
       vZ[r] = zr;
       if (load_T) { put_row(SD, c); have_T = true; }
-      sync();
+      sync_lds();
       const bool na = !lg_finite(yt);
       const double HH = na ? 1.0 : sd * sd;
+      if (t > 0) flush_fwd(t - 1);   // (this step's operands have arrived: the stores of the step before go out behind them)
       double pz = 0.0;
 #pragma unroll 4
       for (int q = 0; q < mr; q++) pz += vZ[q] * SA[r * LD + q];
       vx[r] = pz;
-      sync();
-      double F = 0.0;
-      if (!na) {
-#pragma unroll 4
-        for (int q = 0; q < mr; q++) F += vx[q] * vZ[q];
-      }
+      // Z' P Z and Z' a: lane r holds its term of both (one draw per wave: fixed-shape sums over the lanes instead of two loops over LDS)
+      double F = na ? 0.0 : wave_sum(pz * zr);
+      const double za = wave_sum(zr * a_reg);
+      sync_lds();
+      LGW_T(1);
       F += HH;
       const bool upd = !na && F > kZeroTol;
-      double za = 0.0;
-#pragma unroll 4
-      for (int q = 0; q < mr; q++) za += vZ[q] * va[q];
       const double vt = upd ? yt - Dt - za : 0.0;
       if (r == 0 && w == 0) { Fs[(size_t)t * es] = upd ? F : 0.0; v[(size_t)t * es] = vt; }
       const double Kr = upd ? pz / F : 0.0;
-      const double aur = upd ? va[r] + Kr * vt : va[r];
+      const double aur = upd ? a_reg + Kr * vt : a_reg;
       if (w == 0) K[((size_t)t * M + r) * em] = Kr;
       vy[r] = aur;
       // inner = P - K (P Z)'  (this lane's elements of its row)
@@ -396,7 +439,8 @@ struct LgWave {
 #pragma unroll
         for (int jj = 0; jj < JW; jj++) SA[r * LD + j0 + jj] -= Kr * vx[j0 + jj];
       }
-      sync();
+      sync_lds();
+      LGW_T(2);
       double a1n = aur + Cr;
       if (moves) {
         double s = 0.0;
@@ -405,27 +449,28 @@ struct LgWave {
         a1n = Cr + s;
         mm_acc<false, false>(SD, SA, acc);   // T inner
         mm_store(SC, acc);
-        sync();
+        sync_lds();
+        LGW_T(3);
         mm_acc<false, true>(SC, SD, acc);    // (T inner) T'
         mm_store(SB, acc);
-        sync();
+        sync_lds();
+        LGW_T(4);
         // + R R', symmatu: the lower triangle takes the upper one's values
 #pragma unroll
         for (int jj = 0; jj < JW; jj++) { const int j = j0 + jj; c[jj] = (j < r ? SB[j * LD + r] : SB[r * LD + j]) + rrv[jj]; }
       } else {
 #pragma unroll
         for (int jj = 0; jj < JW; jj++) { const int j = j0 + jj; c[jj] = j < r ? SA[j * LD + r] : SA[r * LD + j]; }
-        sync();   // every lane has read the upper triangle
+        sync_lds();   // every lane has read the upper triangle
       }
       put_row(SA, c);
       bad |= !lg_finite(a1n);
 #pragma unroll
-      for (int jj = 0; jj < JW; jj++) bad |= !lg_finite(c[jj]);
-      if (w == 0) at[((size_t)(t + 1) * M + r) * em] = a1n;
-      store_row(Pt + (size_t)(t + 1) * MM * em, em, c);
-      store_row(cc + (size_t)t * MM * em, em, c);
-      va[r] = a1n;
+      for (int jj = 0; jj < JW; jj++) { bad |= !lg_finite(c[jj]); pend[jj] = c[jj]; }
+      a_reg = a1n;
+      LGW_T(5);
     }
+    if (n > 0) flush_fwd(n - 1);
     // ---- backward pass (smoother_ccov): SA = N, vr = r_t
     sync();
     vr[r] = 0.0;
@@ -433,28 +478,53 @@ struct LgWave {
     for (int jj = 0; jj < JW; jj++) SA[r * LD + j0 + jj] = 0.0;
     __threadfence_block();
     sync();   // (also: the K, F and v stores of the forward pass are visible to the other waves of the workgroup)
+    const bool t_const = g.Ts == 0;   // (a time-invariant T: its row is read once)
+    double trow[JW];
+    if (t_const) load_row(g.T, es, trow);
+    // the operands a step reads from memory (written by the forward pass, never by a later backward step) are requested ONE STEP AHEAD -- in the
+    // middle of the step before, behind its last use of the registers they arrive in: a round trip to memory (~2 us) is otherwise paid at the top of
+    // every step by the one wave a SIMD has
+    double nF = 0.0, nvt = 0.0, nzr = 0.0, nKr = 0.0, nar = 0.0, ntrow[JW], nccrow[JW], nptrow[JW];
+    auto request = [&](const int t) {
+      const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
+      const bool moves = sub == 1 || js == sub - 1;
+      nF = Fs[(size_t)t * es]; nvt = v[(size_t)t * es];
+      nzr = g.Z[((size_t)tr * g.Zs + (size_t)js * M + r) * es];
+      nKr = K[((size_t)t * M + r) * em];
+      nar = at[((size_t)t * M + r) * em];
+      if (moves && !t_const) load_row(g.T + (size_t)tr * g.Ts * es, es, ntrow);
+      load_row(cc + (size_t)t * MM * em, em, nccrow);
+      load_row(Pt + (size_t)t * MM * em, em, nptrow);
+    };
+    if (n > 0) request(n - 1);
     for (int t = n - 1; t >= 0; t--) {
-      const double F = Fs[(size_t)t * es], vt = v[(size_t)t * es];
+      const double F = nF, vt = nvt;
       const bool upd = F > 0.0;
       const int tr = sub == 1 ? t : t / sub, js = sub == 1 ? 0 : t - tr * sub;
       const bool moves = sub == 1 || js == sub - 1;
-      const double zr = g.Z[((size_t)tr * g.Zs + (size_t)js * M + r) * es];
-      const double Kr = upd ? K[((size_t)t * M + r) * em] : 0.0;
-      const double ar = at[((size_t)t * M + r) * em];
+      const double zr = nzr;
+      const double Kr = upd ? nKr : 0.0;
+      const double ar = nar;
       double ptrow[JW], ccrow[JW];
-      if (moves) load_row(g.T + (size_t)tr * g.Ts * es, es, c);
-      else {
+#pragma unroll
+      for (int jj = 0; jj < JW; jj++) { ptrow[jj] = nptrow[jj]; ccrow[jj] = nccrow[jj]; }
+      if (moves) {
+#pragma unroll
+        for (int jj = 0; jj < JW; jj++) c[jj] = t_const ? trow[jj] : ntrow[jj];
+      } else {
 #pragma unroll
         for (int jj = 0; jj < JW; jj++) c[jj] = (r == j0 + jj) ? 1.0 : 0.0;
       }
-      load_row(cc + (size_t)t * MM * em, em, ccrow);
-      load_row(Pt + (size_t)t * MM * em, em, ptrow);
-      sync();           // the step before is through with every slot
+      if (t < n - 1) store_row(Pt + (size_t)(t + 1) * MM * em, em, pend);   // the smoothed covariance of the step before (see flush_fwd)
+      if (t > 0) request(t - 1);
+      sync_lds();           // the step before is through with every slot
+      LGW_T(6);
       vZ[r] = zr;
       vK[r] = Kr;
       put_row(SD, c);       // T
       put_row(SB, ccrow);   // cc[t] (the predicted covariance of t + 1)
-      sync();
+      sync_lds();
+      LGW_T(7);
       // L = T (I - K Z') = T - (T K) Z' into SC
       double tk = 0.0;
 #pragma unroll 4
@@ -462,41 +532,51 @@ struct LgWave {
 #pragma unroll
       for (int jj = 0; jj < JW; jj++) SC[r * LD + j0 + jj] = SD[r * LD + j0 + jj] - tk * vZ[j0 + jj];
       mm_acc<false, false>(SA, SB, acc);   // N cc[t]
-      sync();           // every lane is through with T; L is complete
+      sync_lds();           // every lane is through with T; L is complete
+      LGW_T(8);
       mm_store(SD, acc);
-      sync();
+      sync_lds();
+      LGW_T(9);
 #pragma unroll
       for (int jj = 0; jj < JW; jj++) SD[r * LD + j0 + jj] = ((r == j0 + jj) ? 1.0 : 0.0) - SD[r * LD + j0 + jj];   // I - N cc[t]
       put_row(SB, ptrow);   // Pt[t]
-      sync();
+      sync_lds();
+      LGW_T(10);
       mm_acc<false, true>(SB, SC, acc);    // Pt[t] L'
-      sync();           // every lane is through with Pt[t]
+      sync_lds();           // every lane is through with Pt[t]
+      LGW_T(11);
       mm_store(SB, acc);
-      sync();
+      sync_lds();
+      LGW_T(12);
       mm_acc<false, false>(SB, SD, acc);   // cc[t] = Pt[t] L' (I - N cc[t])
-      sync();           // every lane is through with I - N cc[t]
+      sync_lds();           // every lane is through with I - N cc[t]
+      LGW_T(13);
       mm_store(SD, acc);
       mm_acc<true, false>(SC, SA, acc);    // L' N
       double rn = 0.0;  // r_{t-1} = L' r_t
 #pragma unroll 4
       for (int q = 0; q < mr; q++) rn += SC[q * LD + r] * vr[q];
       mm_store(SB, acc);
-      sync();
+      sync_lds();
+      LGW_T(14);
       get_row(SD, c);
 #pragma unroll
       for (int jj = 0; jj < JW; jj++) bad |= !lg_finite(c[jj]);
       store_row(cc + (size_t)t * MM * em, em, c);
       mm_acc<false, false>(SB, SC, acc);   // N_{t-1} = L' N L (+ Z Z' / F)
       mm_store(SA, acc);
-      sync();
+      sync_lds();
+      LGW_T(15);
       if (upd) {
-        rn = zr / F * vt + rn;
+        const double zf = zr / F;   // (one division for the row: Z Z' / F in the last place, as everything behind the matrix cores)
+        rn = zf * vt + rn;
 #pragma unroll
-        for (int jj = 0; jj < JW; jj++) if (j0 + jj >= r) SA[r * LD + j0 + jj] = zr * vZ[j0 + jj] / F + SA[r * LD + j0 + jj];
+        for (int jj = 0; jj < JW; jj++) if (j0 + jj >= r) SA[r * LD + j0 + jj] = zf * vZ[j0 + jj] + SA[r * LD + j0 + jj];
       }
       vr[r] = rn;
       put_row(SB, ptrow);   // Pt[t] again (a broadcast operand below)
-      sync();
+      sync_lds();
+      LGW_T(16);
       // symmatu(N)
 #pragma unroll
       for (int jj = 0; jj < JW; jj++) if (j0 + jj < r) SA[r * LD + j0 + jj] = SA[(j0 + jj) * LD + r];
@@ -506,23 +586,31 @@ struct LgWave {
       const double as = ar + pr;
       bad |= !lg_finite(as);
       if (w == 0) at[((size_t)t * M + r) * em] = as;
-      sync();
+      sync_lds();
+      LGW_T(17);
       // Pt[t] - symmatu(Pt[t] N Pt[t])
       mm_acc<false, false>(SB, SA, acc);
       mm_store(SD, acc);
-      sync();
+      sync_lds();
+      LGW_T(18);
       mm_acc<false, false>(SD, SB, acc);
       mm_store(SC, acc);
-      sync();
+      sync_lds();
+      LGW_T(19);
 #pragma unroll
       for (int jj = 0; jj < JW; jj++) {
         const int j = j0 + jj;
         const double x = (j < r) ? SC[j * LD + r] : SC[r * LD + j];
         const double pn = ptrow[jj] - x;
         bad |= !lg_finite(pn);
-        Pt[((size_t)t * MM + r + M * j) * em] = pn;
+        pend[jj] = pn;
       }
+      LGW_T(20);
     }
+    if (n > 0) store_row(Pt, em, pend);
+#ifdef LGW_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) for (int k = 0; k < 32; k++) atomicAdd(&lgw_stamps[k], lgw_acc[k]);
+#endif
 #pragma unroll
     for (int jj = 0; jj < JW; jj++) cc[((size_t)n * MM + r + M * (j0 + jj)) * em] = 0.0;
     sync();

@@ -1,5 +1,5 @@
 // Standalone check of lg_smoother_wave.h (LgWave<M>) and lg_factors_rows.h (LgFactorRows<M>) at M = 32 / 64 against the host routines of
-// lg_smoother.h on random padded models.  Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I bssm_amd/csrc scripts/lgwave_check.hip -o /tmp/lgwave_check
+// lg_smoother.h on random padded models.  Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -I bssm_amd/csrc scripts/lgwave_check.hip -o /tmp/lgwave_check   (-DLGW_STAMPS: phase clocks of the 64-state smoother)
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
@@ -182,6 +182,16 @@ int check(int mr, int n, int F, unsigned seed) {
     std::printf("   %-4s max |host - device| %.3e (largest |host| %.3e)\n", name, worst, scale);
     return worst;
   };
+#ifdef LGW_STAMPS
+  {
+    unsigned long long st[32] = {0}, zero[32] = {0};
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(bssm::lgw_stamps), sizeof(st)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(bssm::lgw_stamps), zero, sizeof(zero)));
+    std::printf("   smoother phases (100 MHz clocks per time point, two runs of thread 0 / workgroup 0):");
+    for (int k = 0; k < 21; k++) std::printf(" %d:%.0f", k, (double)st[k] / (2.0 * n));
+    std::printf("\n");
+  }
+#endif
   std::printf("M = %d (m = %d), n = %d, F = %d: host %.1f ms; device smoother %.3f ms, factors %.3f ms; ok host/device:", M, mr, n, F, host_ms, ms_s, ms_f);
   int okdiff = 0;
   for (int d = 0; d < F && d < 8; d++) std::printf(" %d/%d", h_ok[d], g_ok[d]);
