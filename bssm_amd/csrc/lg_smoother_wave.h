@@ -96,7 +96,7 @@ struct LgWave {
   __device__ LG_INL bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es, size_t em = 0) {
     if (em == 0) em = es;
 #ifndef LGW_NO_MFMA
-    if constexpr (M == 64 && NW == 4) return run_mfma(g, at, Pt, cc, K, v, Fs, es, em);
+    if constexpr ((M == 64 || M == 32) && NW == 4) return run_mfma(g, at, Pt, cc, K, v, Fs, es, em);
 #endif
     const int n = g.n, sub = g.sub;
     int bad = 0;
@@ -318,41 +318,59 @@ struct LgWave {
   // the results differ from LgSmoother<M>::run in the last places (the set-up tests hold the kernels to the oracle at 1e-9 n).
   typedef double d4 __attribute__((ext_vector_type(4)));
   // acc = op(X) op(Y) for this wave's 16 columns and the four row blocks; XT: X(i, k) = Xs[k][i], YT: Y(k, j) = Ys[j][k]
+  static constexpr int IB = M / 16;          // row blocks of a product (= column blocks = waves per draw)
+  static_assert(NW % G == 0 && (NW / G == IB || !(M == 64 || M == 32)), "a draw's column blocks are its waves");
+  // the draw whose product this WAVE works on and its column block there (M = 64: the workgroup's one draw, block w; M = 32: two draws per
+  // workgroup, waves 0-1 the first one's two blocks, waves 2-3 the second one's) -- for half of the lanes not the draw whose row they hold in the
+  // elementwise steps: `goff` leads from a lane's own slots to the wave's
+  __device__ LG_INL int mm_draw() const { return G == 1 ? 0 : w / (NW / G); }
+  __device__ LG_INL int mm_block() const { return G == 1 ? w : w % (NW / G); }
+  __device__ LG_INL int mm_goff() const { return (mm_draw() - (int)((threadIdx.x & 63) / M)) * GS; }
   template <bool XT, bool YT>
-  __device__ LG_INL void mm_acc(const double* Xs, const double* Ys, d4 (&acc)[4]) const {
+  __device__ LG_INL void mm_acc(const double* Xs, const double* Ys, d4 (&acc)[IB]) const {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int goff = mm_goff(), cb = mm_block();
     // this lane's operand addresses of k-chunk 0; a chunk further is 4 columns (rows when transposed) on
-    const double* xp = XT ? Xs + lk * LD + li : Xs + li * LD + lk;
-    const double* yp = YT ? Ys + (16 * w + li) * LD + lk : Ys + lk * LD + 16 * w + li;
+    const double* xp = Xs + goff + (XT ? lk * LD + li : li * LD + lk);
+    const double* yp = Ys + goff + (YT ? (16 * cb + li) * LD + lk : lk * LD + 16 * cb + li);
     constexpr int XB = XT ? 16 : 16 * LD, XK = XT ? 4 * LD : 4, YK = YT ? 4 : 4 * LD;   // row-block and k-chunk strides
 #pragma unroll
-    for (int ib = 0; ib < 4; ib++) acc[ib] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int ib = 0; ib < IB; ib++) acc[ib] = d4{0.0, 0.0, 0.0, 0.0};
     const int kcn = (mr + 3) >> 2;   // (the k-chunks of the real states: the padding is exact zeros)
-    // the operands of chunk kc + 1 are requested BEFORE the matrix instructions of chunk kc are issued: one wave per SIMD, nothing else hides
-    // an LDS round trip (8.7 -> ... thousand clocks per product)
-    double bv = yp[0], av[4];
+    // the operands of chunk kc + 1 are requested before the matrix instructions of chunk kc are issued
+    double bv = yp[0], av[IB];
 #pragma unroll
-    for (int ib = 0; ib < 4; ib++) av[ib] = xp[ib * XB];
+    for (int ib = 0; ib < IB; ib++) av[ib] = xp[ib * XB];
     for (int kc = 0; kc < kcn; kc++) {
       const int kn = kc + 1 < kcn ? kc + 1 : kc;   // (the last chunk asks for itself again: no branch around the loads)
       const double bn = yp[kn * YK];
-      double an[4];
+      double an[IB];
 #pragma unroll
-      for (int ib = 0; ib < 4; ib++) an[ib] = xp[kn * XK + ib * XB];
+      for (int ib = 0; ib < IB; ib++) an[ib] = xp[kn * XK + ib * XB];
 #pragma unroll
-      for (int ib = 0; ib < 4; ib++) acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ib], bv, acc[ib], 0, 0, 0);
+      for (int ib = 0; ib < IB; ib++) acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ib], bv, acc[ib], 0, 0, 0);
       bv = bn;
 #pragma unroll
-      for (int ib = 0; ib < 4; ib++) av[ib] = an[ib];
+      for (int ib = 0; ib < IB; ib++) av[ib] = an[ib];
     }
   }
-  // D fragment: element q of row block ib is row 16 ib + (lane >> 4) + 4 q, column 16 w + (lane & 15)
-  __device__ LG_INL void mm_store(double* Dst, const d4 (&acc)[4]) const {
+  // D fragment: element q of row block ib is row 16 ib + (lane >> 4) + 4 q, column 16 (column block) + (lane & 15)
+  __device__ LG_INL void mm_store(double* Dst, const d4 (&acc)[IB]) const {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    double* dp = Dst + mm_goff() + lk * LD + 16 * mm_block() + li;
 #pragma unroll
-    for (int ib = 0; ib < 4; ib++)
+    for (int ib = 0; ib < IB; ib++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) Dst[(16 * ib + lk + 4 * q) * LD + 16 * w + li] = acc[ib][q];
+      for (int q = 0; q < 4; q++) dp[(16 * ib + 4 * q) * LD] = acc[ib][q];
+  }
+  // sum over the M lanes that hold a draw's rows, in every one of them (fixed shape)
+  __device__ LG_INL static double draw_sum(double x) {
+    if constexpr (G == 1) return wave_sum(x);
+    else {
+#pragma unroll
+      for (int o = 1; o < M; o <<= 1) x += __shfl_xor(x, o, 64);
+      return x;
+    }
   }
   __device__ LG_INL void get_row(const double* S, double (&c)[JW]) const {
 #pragma unroll
@@ -362,7 +380,7 @@ struct LgWave {
     const int n = g.n, sub = g.sub;
     int bad = 0;
     double c[JW];
-    d4 acc[4];
+    d4 acc[IB];
 #ifdef LGW_STAMPS
     unsigned long long lgw_acc[32] = {0}, lgw_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -422,8 +440,8 @@ struct LgWave {
       for (int q = 0; q < mr; q++) pz += vZ[q] * SA[r * LD + q];
       vx[r] = pz;
       // Z' P Z and Z' a: lane r holds its term of both (one draw per wave: fixed-shape sums over the lanes instead of two loops over LDS)
-      double F = na ? 0.0 : wave_sum(pz * zr);
-      const double za = wave_sum(zr * a_reg);
+      double F = na ? 0.0 : draw_sum(pz * zr);
+      const double za = draw_sum(zr * a_reg);
       sync_lds();
       LGW_T(1);
       F += HH;
