@@ -204,15 +204,18 @@ def test_degenerate_and_unobserved_series_on_a_big_state(oracle, monkeypatch):
             assert F.bootstrap_filter(bad, N, seed=1)["logLik"] == -np.inf
 
 
-@pytest.mark.parametrize("m", [20, 40])
-def test_device_set_up_of_big_states_time_varying_and_a_failing_draw(oracle, monkeypatch, m):
+@pytest.mark.parametrize("m,tv_r", [(20, False), (40, False), (20, True), (40, True)])
+def test_device_set_up_of_big_states_time_varying_and_a_failing_draw(oracle, monkeypatch, m, tv_r):
     """psi set-up on the device for 17 ... 64 states (padded to 32 / 64: lg_smoother_wave.h, lg_factors_rows.h) with time-varying Z, T and D, C
-    (the smoother reloads its T slot every step), against the oracle and the host set-up; a draw whose covariances overflow shares its
-    workgroup with a good one (two draws per wave at 32) and must come back with weight 0 / logLik -Inf while the others are unaffected"""
+    (the smoother reloads its T slot every step; tv_r: a time-varying R as well -- the matrix-core form of the smoother keeps a time-invariant
+    T / R R' row in registers and reads a varying one step by step), against the oracle and the host set-up; a draw whose covariances overflow
+    shares its workgroup with a good one (two draws per wave at 32) and must come back with weight 0 / logLik -Inf while the others are unaffected"""
     rng = np.random.default_rng(100 + m)
     k, n, ns = 3, 18, 5
     T = np.stack([0.85 * np.linalg.qr(rng.normal(size=(m, m)))[0] for _ in range(n)], axis=2)
     R0 = 0.2 * rng.normal(size=(m, k))
+    if tv_r:
+        R0 = np.stack([R0 * (1.0 + 0.3 * np.sin(0.7 * t + np.arange(k))) for t in range(n)], axis=2)
     Z = rng.normal(0, 0.25, (m, n))
     y = rng.poisson(3.0, n).astype(float)
     y[5] = np.nan
