@@ -70,10 +70,15 @@ __device__ __forceinline__ void big_chunk(BigAcc<MB>& acc, const double (&afr)[M
 // matrix instructions of chunk kk are issued: the loops have run-time bounds (real m, real k), so nothing else would overlap a
 // chunk's load round trip with the previous chunk's 8 ... 16 MFMAs (round 5, workgroup shape: psi-APF m = 53 54 -> 28 ms per 1024 filters,
 // m = 25 15.6 -> 11.0 ms; bootstrap m = 53 15.1 -> 12.8 ms; profiles/r05_big_states.txt).
+// zexit (round 6, psi-APF): A2 is a factor U sqrt(s) with its columns in DESCENDING order of s (conditional_cov; the thin factors and the cut leave the
+// columns behind the rank exact zeros): the first k-chunk of A2 whose fragments are all zero ends the noise loop -- the chunks behind it are zero as
+// well, and adding their exact-zero products changes nothing.  bsm_ng(period = 52): 1 chunk of 14 (3 noise directions of 53), i.e. 1 instead of 14
+// Philox blocks, 2 instead of 27 Box-Muller pairs and 15 instead of 28 chunks of matrix instructions per particle-step.  The stream FORMAT still
+// follows the full count (`ncnt`), so the normals that are drawn are the oracle's.
 template <int MB, int LD, class StateAt, class Noise4>
 __device__ __forceinline__ void big_affine(BigAcc<MB>& acc, const double* __restrict__ c0, const double* __restrict__ A1, const int ms,
                                            const double* __restrict__ A2, const int ncnt, StateAt&& state_at, Noise4&& noise4,
-                                           double* tile, const int lane) {
+                                           double* tile, const int lane, const bool zexit = false) {
   constexpr int MP = LD;
   const int i = lane & 15, kq = lane >> 4;
   auto c_at = [&](int r) { return (LD == 16 * MB || r < LD) ? c0[LD == 16 * MB ? r : min(r, LD - 1)] : 0.0; };
@@ -103,6 +108,12 @@ __device__ __forceinline__ void big_affine(BigAcc<MB>& acc, const double* __rest
   }
   if (nks == 0 && nkn > 0) big_afrag<MB, LD>(A2, afr, lane);
   for (int kk = 0; kk < nkn; kk++) {
+    if (zexit) {
+      bool nz = false;
+#pragma unroll
+      for (int rb = 0; rb < MB; rb++) nz = nz || afr[rb] != 0.0;
+      if (__builtin_amdgcn_ballot_w64(nz) == 0ull) break;
+    }
     double z[4];
     noise4(kk, z);
     if (kk + 1 < nkn) big_afrag<MB, LD>(A2 + (size_t)MP * 4 * (kk + 1), afn, lane);
@@ -310,7 +321,7 @@ __global__ void __launch_bounds__(BIG_NT_MAX, 1) pf_big_wg(const FilterBatch b) 
   {
     const u32x4 blk0 = philox4x32_10((uint32_t)j, 0u, 0u, RNG_INIT, key.seed, key.stream);
     big_affine<MB, MP>(acc, ini, ini, 0, ini + MP, m, [](int, int) { return 0.0; },
-                   [&](int kk, double (&z)[4]) { big_normals4(key, RNG_INIT, 0u, (uint32_t)j, m, kk, blk0, z); }, s_tile, lane);
+                   [&](int kk, double (&z)[4]) { big_normals4(key, RNG_INIT, 0u, (uint32_t)j, m, kk, blk0, z); }, s_tile, lane, b.psi != 0);
     big_store<MB, false>(acc, s_state, (size_t)Ncap, MP, row0, CANON_ROW, lane);
     if (b.alpha_hist) big_store<MB, true>(acc, b.alpha_hist + (size_t)f * (n + 1) * m * N, (size_t)N, m, row0, cnt_row, lane);
     w = n > 0 ? big_log_weight<MB, MP>(b, obs, acc, lane) : 0.0;
@@ -373,7 +384,7 @@ __global__ void __launch_bounds__(BIG_NT_MAX, 1) pf_big_wg(const FilterBatch b) 
     for (int pb = 0; pb < 4; pb++) ancs[pb] = s_anc[row0 + 16 * pb + i16];
     big_affine<MB, MP>(acc, mt + MP * MP + MP * KP, mt, m, mt + MP * MP, ncnt_step,
                    [&](int c, int pb) { return s_state[c * Ncap + ancs[pb]]; },
-                   [&](int kk, double (&z)[4]) { big_normals4(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, ncnt_step, kk, blk, z); }, s_tile, lane);
+                   [&](int kk, double (&z)[4]) { big_normals4(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, ncnt_step, kk, blk, z); }, s_tile, lane, b.psi != 0);
     lds_barrier();  // (3) every gather has read the old particle system
     big_store<MB, false>(acc, s_state, (size_t)Ncap, MP, row0, CANON_ROW, lane);
     if (b.alpha_hist) big_store<MB, true>(acc, b.alpha_hist + ((size_t)f * (n + 1) + (t + 1)) * m * N, (size_t)N, m, row0, cnt_row, lane);
@@ -433,7 +444,7 @@ __global__ void __launch_bounds__(ROW_NT) pf_big_row_init(const FilterBatch b, c
   BigAcc<MB> acc;
   const u32x4 blk0 = philox4x32_10((uint32_t)j, 0u, 0u, RNG_INIT, key.seed, key.stream);
   big_affine<MB, LD>(acc, ini, ini, 0, ini + MP, m, [](int, int) { return 0.0; },
-                 [&](int kk, double (&z)[4]) { big_normals4(key, RNG_INIT, 0u, (uint32_t)j, m, kk, blk0, z); }, s_tiles + wave * 256, lane);
+                 [&](int kk, double (&z)[4]) { big_normals4(key, RNG_INIT, 0u, (uint32_t)j, m, kk, blk0, z); }, s_tiles + wave * 256, lane, b.psi != 0);
   double* __restrict__ st_new = b.alpha_hist ? b.alpha_hist + (size_t)f * (n + 1) * m * N : ws.state[0] + (size_t)f * m * N;
   big_store<MB, false>(acc, st_new, (size_t)N, m, g * CANON_ROW, cnt_row, lane);
   const double w = n > 0 ? big_log_weight<MB, LD>(b, obs, acc, lane) : 0.0;
@@ -588,7 +599,7 @@ __global__ void __launch_bounds__(ROW_NT, big_row_occupancy(MB)) pf_big_row_step
   big_affine<MB, LD>(acc, mt + MP * MP + MP * KP, mt, m, mt + MP * MP, ncnt_step,
                  [&](int c, int pb) { return st_old[(size_t)c * N + ancs[pb]]; },
                  [&](int kk, double (&z)[4]) { big_normals4(key, RNG_TRANSITION, (uint32_t)t, (uint32_t)j, ncnt_step, kk, blk, z); },
-                 s_tiles + wave * 256, lane);
+                 s_tiles + wave * 256, lane, b.psi != 0);
   big_store<MB, false>(acc, st_new, (size_t)N, m, g * CANON_ROW, min(CANON_ROW, N - g * CANON_ROW), lane);
   const double w = tn < n ? big_log_weight<MB, LD>(b, obs + (size_t)tn * obs_stride, acc, lane) : 0.0;
   row_publish(b, ws, f, g, j, act, tn, w, lane);
