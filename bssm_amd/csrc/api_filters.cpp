@@ -189,7 +189,9 @@ int bssm_bsf(const bssm_ung_model* model, uint32_t nsim, uint32_t seed, int gaus
   if (gaussian && model_type == 0)
     return fail(BSSM_ERR_UNSUPPORTED, "Bootstrap particle filtering for multivariate gaussian model is not yet supported. ");
   if (!is_gaussian_type_ok(gaussian, model_type)) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
-  if (model && (gaussian != 0) != (model->distribution == BSSM_GAUSSIAN))
+  // (a multivariate model's `distribution` is ignored in favour of its per-series codes -- include/bssm_amd.h -- and a Gaussian series there is no
+  // Gaussian MODEL: src/model_ssm_mng.cpp:407-442)
+  if (model && model->p <= 1 && (gaussian != 0) != (model->distribution == BSSM_GAUSSIAN))
     return fail(BSSM_ERR_INVALID, "gaussian flag and model->distribution disagree");
   return run_single_filter(model, nsim, seed, false, false, out);
 }
@@ -199,7 +201,9 @@ int bssm_bsf_smoother(const bssm_ung_model* model, uint32_t nsim, uint32_t seed,
   if (gaussian && model_type == 0)
     return fail(BSSM_ERR_UNSUPPORTED, "Bootstrap particle smoothing for multivariate gaussian model is not yet supported. ");
   if (!is_gaussian_type_ok(gaussian, model_type)) return fail(BSSM_ERR_UNSUPPORTED, "model_type not handled by this entry point");
-  if (model && (gaussian != 0) != (model->distribution == BSSM_GAUSSIAN))
+  // (a multivariate model's `distribution` is ignored in favour of its per-series codes -- include/bssm_amd.h -- and a Gaussian series there is no
+  // Gaussian MODEL: src/model_ssm_mng.cpp:407-442)
+  if (model && model->p <= 1 && (gaussian != 0) != (model->distribution == BSSM_GAUSSIAN))
     return fail(BSSM_ERR_INVALID, "gaussian flag and model->distribution disagree");
   return run_single_filter(model, nsim, seed, false, true, out);
 }

@@ -1256,6 +1256,15 @@ double orc_mlg_loglik(const orc_mng_model *mod, const double *gy, const double *
   const int n = mod->n, m = mod->m, p = mod->p;
   double at[ORC_MAXM], Pt[ORC_MAXM * ORC_MAXM], at1[ORC_MAXM], Pt1[ORC_MAXM * ORC_MAXM];
   double v[ORC_MAXP], ZF[ORC_MAXM * ORC_MAXP], K[ORC_MAXM * ORC_MAXP], Zz[ORC_MAXP * ORC_MAXM];
+  /* :93 `if(arma::accu(H) + arma::accu(R) < zero_tol) logLik = -inf` -- the SUMS of the entries (of the approximating model's H cube: the standard
+   * deviations on its diagonals; of R, signs and all): a model whose R sums below -accu(H) has log-likelihood -inf in the reference.  Missing from this
+   * restatement until round 6 (found by scripts/fuzz_parity.py: the product's host code had the line, the oracle did not). */
+  {
+    double accH = 0, accR = 0;
+    for (size_t q = 0; q < (size_t)p * n; q++) accH += gH[q];
+    for (size_t q = 0; q < (size_t)m * mod->k * (mod->Rtv ? n : 1); q++) accR += mod->R[q];
+    if (accH + accR < ORC_ZERO_TOL) return -INFINITY;
+  }
   memcpy(at, mod->a1, sizeof(double) * m); memcpy(Pt, mod->P1, sizeof(double) * m * m);
   const double LOG2PI = log(2.0 * ORC_PI);
   double ll = 0.0;

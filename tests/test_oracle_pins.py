@@ -479,3 +479,17 @@ def test_tie_following_adopts_only_explained_ties(oracle):
     assert taken["logLik"] != base["logLik"]
     # outside the with-block nothing is followed
     assert oracle.bsf_filter(arr, N, seed=3)["logLik"] == base["logLik"]
+
+
+def test_mlg_loglik_zero_tolerance_line(oracle):
+    """src/model_ssm_mlg.cpp:93 (and model_ssm_ulg.cpp:109): `if(arma::accu(H) + arma::accu(R) < zero_tol) logLik = -inf` -- the sums of the ENTRIES.
+    The multivariate restatement lacked the line until round 6; R = -6 I sums to -18 against standard deviations of ~0.6 per series and time point (12 of them)."""
+    rng = np.random.default_rng(78)
+    n, m = 6, 3
+    y = np.column_stack([rng.poisson(3, n), rng.negative_binomial(5, 0.5, n)]).astype(float)
+    mk = lambda R: M.model_arrays(M.ssm_mng(y, rng.normal(0, 0.4, (2, m)), 0.9 * np.eye(m), R, a1=np.zeros(m), P1=0.2 * np.eye(m),
+                                            distribution=["poisson", "negative binomial"], phi=[1.0, 1.5], u=np.full((n, 2), 1.2)))
+    neg, pos = oracle.mng_psi_setup(mk(-6.0 * np.eye(m))), oracle.mng_psi_setup(mk(0.9 * np.eye(m)))
+    assert np.isneginf(neg["approx_loglik"]) and np.isfinite(pos["approx_loglik"])
+    assert 0.0 < np.sum(neg["approx_H"][np.isfinite(neg["approx_H"])]) < 18.0   # (the line did decide: sum H + sum R < 0 only because of R)
+
