@@ -1,7 +1,7 @@
 """Random-configuration parity sweep: bootstrap filter and psi-APF of randomly drawn ssm_ung / ssm_mng models (state dimension 1 ... 64, noise terms,
 series, distributions, missing values, time-varying matrices, particle counts around the block sizes, a forced kernel family) through the C ABI
 against the CPU oracle -- ancestors identical, |dlogLik| <= 1e-9 n, states and weights 1e-8 relative.  Not part of the test suite: a search for cases the
-suite does not hold.  Usage (GPU box): python scripts/fuzz_parity.py [cases] [seed]  -> gpurun_out/fuzz_parity.txt (one line per case; FAIL lines first
+suite does not hold.  Usage (GPU box): python scripts/fuzz_parity.py [cases] [seed] [filter|pc]  -> gpurun_out/fuzz_parity.txt (one line per case; FAIL lines first
 in the summary)."""
 import os
 import sys
@@ -18,6 +18,7 @@ from oracle import oracle as O  # noqa: E402  (the checker)
 O.build()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+MODE = sys.argv[3] if len(sys.argv) > 3 else "filter"   # "filter": single filters; "pc": post-correction jobs (device and host psi set-up)
 DISTS = ["poisson", "binomial", "negative binomial", "gamma", "gaussian"]
 
 
@@ -112,18 +113,88 @@ def run_case(c, seed):
     return good, "idx %s dll %.2e states %.1e weights %.1e" % ("same" if same_idx else "DIFFER", dll, ok_states, dw)
 
 
+def draw_pc_case(rng):
+    """a post-correction job: theta-draws of a random ssm_ung whose update_fn scales R (and shifts D), psi (device and host set-up) or bootstrap"""
+    m = int(rng.choice([1, 2, 3, 4, 6, 8, 9, 13, 16, 17, 25, 32, 33, 40, 53, 64]))
+    k = int(rng.integers(1, min(m, 5) + 1))
+    n = int(rng.choice([1, 2, 5, 9, 14, 20]))
+    ns = int(rng.choice([1, 2, 3, 5, 8, 13]))
+    nsim = int(rng.choice([4, 16, 48, 64, 100, 300]))
+    tvT, tvZ = rng.random() < 0.25, rng.random() < 0.3
+    Q = lambda: (0.88 + 0.1 * rng.random()) * np.linalg.qr(rng.normal(size=(m, m)))[0]
+    T = np.stack([Q() for _ in range(n)], axis=2) if tvT else Q()
+    R0 = (0.1 + 0.2 * rng.random()) * rng.normal(size=(m, k))
+    dist = str(rng.choice(DISTS[:4]))
+    Z = rng.normal(0, 0.6 / np.sqrt(m), (m, n)) if tvZ else rng.normal(0, 0.6 / np.sqrt(m), m)
+    y = {"poisson": rng.poisson(3, n), "binomial": rng.binomial(6, 0.4, n), "negative binomial": rng.negative_binomial(5, 0.5, n),
+         "gamma": rng.gamma(2.0, 1.0, n)}[dist].astype(float)
+    y[rng.random(n) < 0.12] = np.nan
+    u = np.full(n, 6.0) if dist == "binomial" else np.abs(rng.normal(1, 0.1, n)) + 0.5
+    D0 = 0.1 * rng.normal(size=n)
+    model = M.ssm_ung(y, Z=Z, T=T, R=R0, a1=0.1 * rng.normal(size=m), P1=np.diag(0.05 + 0.01 * np.arange(m)), distribution=dist,
+                      phi=float(rng.uniform(0.8, 4)), u=u, D=D0, init_theta=np.zeros(2),
+                      update_fn=lambda th: dict(R=R0 * np.exp(th[0]), D=D0 + th[1]))
+    theta = np.column_stack([rng.normal(0, 0.2, ns), rng.normal(0, 0.1, ns)])
+    counts = rng.integers(1, 4, ns).astype(np.uint32)
+    is_type = int(rng.integers(1, 4))
+    output_type = int(rng.integers(1, 4))
+    psi = True   # (post_correct() is the psi-APF correction, R/post_correction.R:266-273; the bootstrap one belongs to run_mcmc)
+    return dict(model=model, m=m, n=n, ns=ns, nsim=nsim, theta=theta, counts=counts, is_type=is_type, output_type=output_type, psi=bool(psi),
+                desc="pc ung %s m=%d k=%d n=%d draws=%d N=%d tv(T%d Z%d) is%d out%d %s" % (dist[:5], m, k, n, ns, nsim, tvT, tvZ, is_type, output_type,
+                                                                                       "psi" if psi else "bsf"))
+
+
+def run_pc_case(c, seed):
+    from bssm_amd import post_correct as PC
+    os.environ.pop("BSSM_AMD_FORCE_PATH", None)
+    model, n, ns = c["model"], c["n"], c["ns"]
+    arrs = PC.expand_models(model, c["theta"])
+    rng = np.random.default_rng(seed)
+    if c["psi"]:
+        modes = np.stack([O.psi_setup(a)["mode"] for a in arrs], axis=1) + rng.normal(0, 0.02, (n, ns))
+        mo = dict(theta=c["theta"], counts=c["counts"], modes=modes, output_type=c["output_type"])
+        o_arrs, o_counts, o_modes = arrs, c["counts"], modes
+        if c["is_type"] == 3:   # expand(): src/approx_mcmc.cpp:49-88 -- every draw as often as it was counted, counts of one
+            rep = c["counts"].astype(np.int64)
+            o_arrs = [a for a, r_ in zip(arrs, rep) for _ in range(int(r_))]
+            o_modes, o_counts = np.repeat(modes, rep, axis=1), np.ones(int(rep.sum()), dtype=np.uint32)
+        ref = O.is_correction(o_arrs, c["nsim"], seed, method=1, counts=o_counts, modes=o_modes, is_type=c["is_type"], output_type=c["output_type"], n_threads=2)
+    else:
+        al = np.array([O.psi_setup(a)["approx_loglik"] for a in arrs])
+        mo = dict(theta=c["theta"], counts=c["counts"], modes=np.zeros((n, ns)), approx_loglik=al, output_type=c["output_type"])
+        ref = O.is_correction(arrs, c["nsim"], seed, method=2, counts=c["counts"], approx_loglik=al, is_type=c["is_type"], output_type=c["output_type"], n_threads=2)
+    msgs, good = [], True
+    for dev in (("2", "0") if c["psi"] else ("2",)):
+        os.environ["BSSM_AMD_DEVICE_SETUP"] = dev
+        r = PC.post_correct(model, mo, c["nsim"], threads=2, is_type="is%d" % c["is_type"], seed=seed)
+        fin = np.isfinite(ref["loglik"])
+        dll = float(np.max(np.abs(r["loglik"][fin] - ref["loglik"][fin]))) if fin.any() else 0.0
+        same_inf = bool(np.array_equal(np.isneginf(r["loglik"]), np.isneginf(ref["loglik"])))
+        dw = rel(r["weights"], ref["weights"])
+        ok = same_inf and dll <= 1e-9 * max(n, 1) and dw <= 1e-7
+        extra = ""
+        if c["output_type"] == 2:
+            da = rel(r["alphahat"], ref["alphahat"].T)
+            ok = ok and da <= 1e-6
+            extra = " alphahat %.1e" % da
+        good = good and ok
+        msgs.append("setup=%s dll %.2e w %.1e%s%s" % ("dev" if dev == "2" else "host", dll, dw, extra, "" if same_inf else " INF-MISMATCH"))
+    os.environ.pop("BSSM_AMD_DEVICE_SETUP", None)
+    return good, "; ".join(msgs)
+
+
 def main():
     lines, fails = [], 0
     t_start = time.time()
     for i in range(cases):
         rng = np.random.default_rng(seed0 * 100000 + i)
         try:
-            c = draw_case(rng)
+            c = draw_pc_case(rng) if MODE == "pc" else draw_case(rng)
         except Exception as e:  # a model the front-end refuses: not a parity case
             lines.append("skip %4d (constructor: %s)" % (i, repr(e)[:120]))
             continue
         try:
-            good, msg = run_case(c, seed=3 + i)
+            good, msg = run_pc_case(c, seed=3 + i) if MODE == "pc" else run_case(c, seed=3 + i)
             tag = "ok  " if good else "FAIL"
         except Exception as e:
             good, msg, tag = False, "exception: " + repr(e)[:300], "FAIL"
@@ -137,7 +208,7 @@ def main():
     summary = "%d cases, %d failures, %.0f s" % (cases, fails, time.time() - t_start)
     print(summary)
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(root, "gpurun_out", "fuzz_parity.txt"), "w") as fh:
+    with open(os.path.join(root, "gpurun_out", "fuzz_parity%s.txt" % ("_pc" if MODE == "pc" else "")), "w") as fh:
         fh.write(summary + "\n")
         for ln in sorted(lines, key=lambda s: (not s.startswith("FAIL"), s[5:9])):
             fh.write(ln + "\n")
