@@ -1,7 +1,7 @@
 """Random-configuration parity sweep: bootstrap filter and psi-APF of randomly drawn ssm_ung / ssm_mng models (state dimension 1 ... 64, noise terms,
 series, distributions, missing values, time-varying matrices, particle counts around the block sizes, a forced kernel family) through the C ABI
 against the CPU oracle -- ancestors identical, |dlogLik| <= 1e-9 n, states and weights 1e-8 relative.  Not part of the test suite: a search for cases the
-suite does not hold.  Usage (GPU box): python scripts/fuzz_parity.py [cases] [seed] [filter|pc]  -> gpurun_out/fuzz_parity.txt (one line per case; FAIL lines first
+suite does not hold.  Usage (GPU box): python scripts/fuzz_parity.py [cases] [seed] [filter|pc|pcmng]  -> gpurun_out/fuzz_parity.txt (one line per case; FAIL lines first
 in the summary)."""
 import os
 import sys
@@ -183,18 +183,66 @@ def run_pc_case(c, seed):
     return good, "; ".join(msgs)
 
 
+def draw_pcmng_case(rng):
+    """a post-correction job over theta-draws of a random ssm_mng (update_fn scales R): is2, psi, device and host set-up"""
+    m = int(rng.choice([1, 2, 3, 4, 6, 8, 9, 12, 16, 17, 20, 32, 33, 40, 64]))
+    k = int(rng.integers(1, min(m, 4) + 1))
+    p = int(rng.choice([2, 3, 4]))
+    n = int(rng.choice([1, 2, 5, 9, 14]))
+    ns = int(rng.choice([1, 2, 3, 5, 8]))
+    nsim = int(rng.choice([4, 16, 48, 64, 100]))
+    tvZ = rng.random() < 0.3
+    T = (0.88 + 0.1 * rng.random()) * np.linalg.qr(rng.normal(size=(m, m)))[0]
+    R0 = (0.1 + 0.2 * rng.random()) * np.abs(rng.normal(size=(m, k)))   # (entries that sum above zero: src/model_ssm_mlg.cpp:93)
+    dist = [str(rng.choice(DISTS)) for _ in range(p)]
+    Z = rng.normal(0, 0.5 / np.sqrt(m), (p, m, n)) if tvZ else rng.normal(0, 0.5 / np.sqrt(m), (p, m))
+    gen = {"poisson": lambda: rng.poisson(3, n), "binomial": lambda: rng.binomial(6, 0.4, n), "negative binomial": lambda: rng.negative_binomial(5, 0.5, n),
+           "gamma": lambda: rng.gamma(2.0, 1.0, n), "gaussian": lambda: rng.normal(0, 1, n)}
+    y = np.column_stack([gen[d]() for d in dist]).astype(float)
+    y[rng.random((n, p)) < 0.1] = np.nan
+    u = np.column_stack([np.full(n, 6.0) if d == "binomial" else np.abs(rng.normal(1, 0.1, n)) + 0.5 for d in dist])
+    model = M.ssm_mng(y, Z, T, R0, a1=0.1 * rng.normal(size=m), P1=np.diag(0.05 + 0.01 * np.arange(m)), distribution=dist,
+                      phi=[float(rng.uniform(0.8, 4)) for _ in dist], u=u, init_theta=np.zeros(1), update_fn=lambda th: dict(R=R0 * np.exp(th[0])))
+    theta = rng.normal(0, 0.2, (ns, 1))
+    return dict(model=model, m=m, n=n, p=p, ns=ns, nsim=nsim, theta=theta, counts=rng.integers(1, 4, ns).astype(np.uint32),
+                desc="pc mng p=%d %s m=%d k=%d n=%d draws=%d N=%d tvZ%d is2 psi" % (p, ",".join(d[:3] for d in dist), m, k, n, ns, nsim, tvZ))
+
+
+def run_pcmng_case(c, seed):
+    from bssm_amd import post_correct as PC
+    os.environ.pop("BSSM_AMD_FORCE_PATH", None)
+    model, n, ns, p = c["model"], c["n"], c["ns"], c["p"]
+    arrs = PC.expand_models(model, c["theta"])
+    rng = np.random.default_rng(seed)
+    modes = np.stack([O.mng_psi_setup(a)["mode"].reshape(-1, order="F") for a in arrs], axis=1)
+    modes = modes + rng.normal(0, 0.02, modes.shape)
+    mo = dict(theta=c["theta"], counts=c["counts"], modes=modes, posterior=np.zeros(ns), output_type=3)
+    refs = np.array([O.mng_psi_filter(arrs[i], c["nsim"], seed=seed, stream=i, is_mode=modes[:, i].reshape(p, n, order="F"))["logLik"] for i in range(ns)])
+    msgs, good = [], True
+    for dev in ("2", "0"):
+        os.environ["BSSM_AMD_DEVICE_SETUP"] = dev
+        r = PC.post_correct(model, mo, c["nsim"], threads=2, is_type="is2", seed=seed)
+        fin = np.isfinite(refs)
+        dll = float(np.max(np.abs(r["loglik"][fin] - refs[fin]))) if fin.any() else 0.0
+        same_inf = bool(np.array_equal(np.isneginf(r["loglik"]), np.isneginf(refs)))
+        good = good and same_inf and dll <= 1e-9 * max(n, 1)
+        msgs.append("setup=%s dll %.2e%s" % ("dev" if dev == "2" else "host", dll, "" if same_inf else " INF-MISMATCH"))
+    os.environ.pop("BSSM_AMD_DEVICE_SETUP", None)
+    return good, "; ".join(msgs)
+
+
 def main():
     lines, fails = [], 0
     t_start = time.time()
     for i in range(cases):
         rng = np.random.default_rng(seed0 * 100000 + i)
         try:
-            c = draw_pc_case(rng) if MODE == "pc" else draw_case(rng)
+            c = draw_pc_case(rng) if MODE == "pc" else (draw_pcmng_case(rng) if MODE == "pcmng" else draw_case(rng))
         except Exception as e:  # a model the front-end refuses: not a parity case
             lines.append("skip %4d (constructor: %s)" % (i, repr(e)[:120]))
             continue
         try:
-            good, msg = run_pc_case(c, seed=3 + i) if MODE == "pc" else run_case(c, seed=3 + i)
+            good, msg = run_pc_case(c, seed=3 + i) if MODE == "pc" else (run_pcmng_case(c, seed=3 + i) if MODE == "pcmng" else run_case(c, seed=3 + i))
             tag = "ok  " if good else "FAIL"
         except Exception as e:
             good, msg, tag = False, "exception: " + repr(e)[:300], "FAIL"
@@ -208,7 +256,7 @@ def main():
     summary = "%d cases, %d failures, %.0f s" % (cases, fails, time.time() - t_start)
     print(summary)
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(root, "gpurun_out", "fuzz_parity%s.txt" % ("_pc" if MODE == "pc" else "")), "w") as fh:
+    with open(os.path.join(root, "gpurun_out", "fuzz_parity%s.txt" % ("" if MODE == "filter" else "_" + MODE)), "w") as fh:
         fh.write(summary + "\n")
         for ln in sorted(lines, key=lambda s: (not s.startswith("FAIL"), s[5:9])):
             fh.write(ln + "\n")
