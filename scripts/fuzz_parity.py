@@ -1,7 +1,7 @@
 """Random-configuration parity sweep: bootstrap filter and psi-APF of randomly drawn ssm_ung / ssm_mng models (state dimension 1 ... 64, noise terms,
 series, distributions, missing values, time-varying matrices, particle counts around the block sizes, a forced kernel family) through the C ABI
 against the CPU oracle -- ancestors identical, |dlogLik| <= 1e-9 n, states and weights 1e-8 relative.  Not part of the test suite: a search for cases the
-suite does not hold.  Usage (GPU box): python scripts/fuzz_parity.py [cases] [seed] [filter|pc|pcmng]  -> gpurun_out/fuzz_parity.txt (one line per case; FAIL lines first
+suite does not hold.  Usage (GPU box): python scripts/fuzz_parity.py [cases] [seed] [filter|pc|pcmng|fn]  -> gpurun_out/fuzz_parity.txt (one line per case; FAIL lines first
 in the summary)."""
 import os
 import sys
@@ -231,18 +231,76 @@ def run_pcmng_case(c, seed):
     return good, "; ".join(msgs)
 
 
+def draw_fn_case(rng):
+    """a built-in ssm_nlg / ssm_sde model (R/cpp_example_models.R) with random parameters, length, particles, sampler and kernel family"""
+    name = str(rng.choice(["nlg_growth", "nlg_ar_exp", "nlg_sin_exp", "nlg_linear_gaussian", "sde_gbm", "sde_poisson_ou"]))
+    n = int(rng.choice([1, 2, 3, 8, 15, 30]))
+    N = int(rng.choice([1, 2, 10, 63, 64, 65, 100, 257, 700, 1024, 2049, 4096, 8192, 9000, 20000]))
+    L = None
+    if name == "nlg_growth":
+        dT, K = 0.1, 100.0
+        y = 20 + np.cumsum(rng.normal(0.3, 1, n)) + rng.normal(0, 1, n)
+        model = M.ssm_nlg(y, name, theta=[rng.normal(0, 0.3), np.log(0.05) + rng.normal(0, 0.2), rng.normal(0, 0.3)], known_params=[dT, K, 0.0, 50.0 * rng.uniform(0.5, 1.5), 1.0, 100.0])
+    elif name == "nlg_ar_exp":
+        y = np.exp(0.3 * rng.normal(size=n)) + rng.normal(0, 0.4, n)
+        model = M.ssm_nlg(y, name, theta=[rng.normal(0.2, 0.1), rng.uniform(0.5, 0.95), np.log(rng.uniform(0.2, 0.5)), np.log(rng.uniform(0.3, 0.6))])
+    elif name == "nlg_sin_exp":
+        model = M.ssm_nlg(rng.normal(1.0, 0.5, n), name, theta=[np.log(rng.uniform(0.4, 0.8)), np.log(rng.uniform(0.3, 0.6))])
+    elif name == "nlg_linear_gaussian":
+        model = M.ssm_nlg(np.cumsum(rng.normal(0, 1, n)) + rng.normal(0, 0.5, n), name, theta=[np.log(rng.uniform(0.3, 0.8))])
+    elif name == "sde_gbm":
+        x = np.exp(np.cumsum(rng.normal(0.01, 0.1, n)))
+        model, L = M.ssm_sde(np.log(x) + rng.normal(0, 0.5, n), name, theta=[rng.uniform(0.01, 0.1), rng.uniform(0.2, 0.4), rng.uniform(0.5, 1.5)], x0=1.0, positive=True), int(rng.integers(1, 5))
+    else:
+        model, L = M.ssm_sde(rng.poisson(np.exp(0.7), n).astype(float), name, theta=[np.log(rng.uniform(0.3, 0.7)), rng.uniform(0.4, 1.0), np.log(rng.uniform(0.3, 0.5))], x0=0.5, positive=False), int(rng.integers(1, 5))
+    yy = np.asarray(model["y"], dtype=float).copy()
+    miss = rng.random(n) < 0.1
+    if miss.any() and n > 1:
+        yy[miss] = np.nan
+        model = M.BssmModel(model.classes, **{**model, "y": yy})
+    method = "bsf" if name.startswith("sde") else str(rng.choice(["bsf", "psi", "ekf"]))
+    path = str(rng.choice(["", "", "wg", "grid", "row"]))
+    return dict(model=model, name=name, n=n, N=N, L=L, method=method, path=path,
+                desc="fn %s n=%d N=%d L=%s %s path=%s" % (name, n, N, L, method, path or "auto"))
+
+
+def run_fn_case(c, seed):
+    model, n, N, L = c["model"], c["n"], c["N"], c["L"]
+    if c["path"]:
+        os.environ["BSSM_AMD_FORCE_PATH"] = c["path"]
+    else:
+        os.environ.pop("BSSM_AMD_FORCE_PATH", None)
+    if c["method"] == "bsf":
+        out = F.bootstrap_filter(model, N, seed=seed, return_indices=True, L=L)
+        ref = O.fn_bsf_filter({**model, "L": L or 0}, N, seed=seed)
+        st = rel(np.transpose(out["alpha"], (1, 0, 2)), ref["alpha"])
+    else:
+        out = F.particle_smoother(model, N, method=c["method"], seed=seed, return_indices=True)
+        ref = (O.fn_psi_filter if c["method"] == "psi" else O.fn_ekpf_filter)(model, N, seed=seed)
+        sm = O.filter_smoother(ref["alpha"], ref["indices"])
+        st = rel(np.transpose(out["alpha"], (1, 0, 2)), sm[:, :n, :])
+    same_idx = np.array_equal(out["indices"], ref["indices"])
+    if np.isneginf(ref["logLik"]) or np.isneginf(out["logLik"]):
+        dll = 0.0 if out["logLik"] == ref["logLik"] else np.inf
+    else:
+        dll = abs(out["logLik"] - ref["logLik"])
+    dw = rel(out["weights"], ref["weights"])
+    good = same_idx and dll <= 1e-9 * max(n, 1) and st <= 1e-7 and dw <= 1e-7
+    return good, "idx %s dll %.2e states %.1e weights %.1e" % ("same" if same_idx else "DIFFER", dll, st, dw)
+
+
 def main():
     lines, fails = [], 0
     t_start = time.time()
     for i in range(cases):
         rng = np.random.default_rng(seed0 * 100000 + i)
         try:
-            c = draw_pc_case(rng) if MODE == "pc" else (draw_pcmng_case(rng) if MODE == "pcmng" else draw_case(rng))
+            c = draw_pc_case(rng) if MODE == "pc" else (draw_pcmng_case(rng) if MODE == "pcmng" else (draw_fn_case(rng) if MODE == "fn" else draw_case(rng)))
         except Exception as e:  # a model the front-end refuses: not a parity case
             lines.append("skip %4d (constructor: %s)" % (i, repr(e)[:120]))
             continue
         try:
-            good, msg = run_pc_case(c, seed=3 + i) if MODE == "pc" else (run_pcmng_case(c, seed=3 + i) if MODE == "pcmng" else run_case(c, seed=3 + i))
+            good, msg = run_pc_case(c, seed=3 + i) if MODE == "pc" else (run_pcmng_case(c, seed=3 + i) if MODE == "pcmng" else (run_fn_case(c, seed=3 + i) if MODE == "fn" else run_case(c, seed=3 + i)))
             tag = "ok  " if good else "FAIL"
         except Exception as e:
             good, msg, tag = False, "exception: " + repr(e)[:300], "FAIL"
