@@ -703,7 +703,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       b.ou = L0.ou; b.ox = L0.ox; b.om = L0.om; b.oh = L0.oh;
       b.in = din_t.as<double>(); b.scratch = ct->scratch.as<double>();
       b.mats = ct->mats.as<double>(); b.obs = ct->obs.as<double>(); b.init = ct->init.as<double>(); b.ok = ct->ok.as<int>();
-      b.flags = (m_dev >= 16 && !bssm::opt().factors_one_kernel) ? ct->flags.as<int>() : nullptr;
+      b.flags = (m_dev >= 16 && !bssm::opt().factors_full) ? ct->flags.as<int>() : nullptr;
       HIP_TRY(p0 > 1 ? bssm::launch_mng_setup(b, st) : bssm::launch_ung_setup(b, st));
       HIP_TRY(hipMemcpyAsync(ct->okst.p, ct->ok.p, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventCreateWithFlags(&ct->ready, hipEventDisableTiming));

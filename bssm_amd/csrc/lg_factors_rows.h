@@ -249,13 +249,6 @@ struct LgFactorRows {
   //     rounding noise (the cut every implementation applies since round 6: oracle/bssm_oracle.c, orc_conditional_cov).
   // Wave 0 does the sequential parts (the other waves keep the barriers); the products use every wave's columns.
   static constexpr int RT = 4;
-  __device__ LG_INL static bool thin_enabled() {
-#ifdef LGF_NO_THIN
-    return false;
-#else
-    return M >= 16;
-#endif
-  }
   // sum of va-published diagonal entries (ascending): every lane passes the diagonal element it holds (or anything where it holds none)
   __device__ LG_INL double trace_of(const double mine) {
     __syncthreads();
@@ -617,7 +610,7 @@ struct LgFactorRows {
   // Round 6, second half: the thin path and the full path are TWO kernels (the set-up launches the thin one over the time points >= 1, then the
   // full one over everything): in one kernel the register allocation was the union of both (659 registers spilt at M = 64, 2.2 KB of scratch
   // per lane, 320 us per thin time point instead of ~80).  `flag` (one int per (draw, time point), written by cond_step_thin) says which groups
-  // the full kernel still has to do; flag == nullptr: the one-kernel form (decide here).
+  // the full kernel still has to do; flag == nullptr: the full path at this time point whatever the matrices are (BSSM_AMD_FACTORS_FULL, and t = 0).
   __device__ LG_INL bool cond_step_thin(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d, int* flag) {
     int bad_thin = 0;
     const bool mine_full = thin_step(t, Pt, cc, Vout, Cout, es, d, &bad_thin);

@@ -197,7 +197,7 @@ Options read_env() {
   if (const char* e = std::getenv("BSSM_AMD_SPARSE")) o.sparse = e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1);
   if (const char* e = std::getenv("BSSM_AMD_NO_SPARSE")) { if (e[0] != '0') o.sparse = 0; }
   o.setup_interleaved = env_set("BSSM_AMD_SETUP_INTERLEAVED");
-  o.factors_one_kernel = env_set("BSSM_AMD_FACTORS_ONE_KERNEL");
+  o.factors_full = env_set("BSSM_AMD_FACTORS_FULL");
   o.xcd_persist = env_tri("BSSM_AMD_XCD_PERSIST");   // (acts in -DBSSM_XCD_PERSIST builds only)
 #ifdef BSSM_PROBES
   o.probe_no_weights = env_set("BSSM_AMD_PROBE_NO_WEIGHTS");

@@ -20,8 +20,8 @@ model, n, N = c["model"], c["n"], c["N"]
 arr = M.model_arrays(model)
 seed = 3 + idx
 ref = (O.mng_psi_filter if c["multi"] else O.psi_filter)(arr, N, seed=seed) if c["psi"] else (O.mng_bsf_filter if c["multi"] else O.bsf_filter)(arr, N, seed=seed)
-for label, env in (("device set-up", {}), ("host set-up", {"BSSM_AMD_DEVICE_SETUP": "0"}), ("device, full factors", {"BSSM_AMD_FACTORS_ONE_KERNEL": "1"})):
-    for k in ("BSSM_AMD_DEVICE_SETUP", "BSSM_AMD_FACTORS_ONE_KERNEL"):
+for label, env in (("device set-up", {}), ("host set-up", {"BSSM_AMD_DEVICE_SETUP": "0"}), ("device, full factors", {"BSSM_AMD_FACTORS_FULL": "1"})):
+    for k in ("BSSM_AMD_DEVICE_SETUP", "BSSM_AMD_FACTORS_FULL"):
         os.environ.pop(k, None)
     os.environ.update(env)
     if c["path"]:

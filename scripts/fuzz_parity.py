@@ -36,6 +36,9 @@ def draw_case(rng):
     N = int(rng.choice([1, 2, 10, 63, 64, 65, 100, 255, 256, 257, 700, 1024, 1500, 2049, 4096, 9000]))
     if m > 16:
         N = min(N, int(rng.choice([64, 100, 257, 1024, 2049])))
+    if os.environ.get("FUZZ_BIGN"):   # the step kernels' large particle counts (few time points: the oracle is serial)
+        n = int(rng.choice([1, 2, 3]))
+        N = int(rng.choice([8192, 8193, 16384, 16385, 20000, 32768, 50000, 65536, 65537, 99999, 100000]))   # (the front-end stops at 1e5: R/check_arguments.R:407-418)
     tvT, tvZ, tvR = rng.random() < 0.25, rng.random() < 0.3, rng.random() < 0.15
     # (a transition that contracts slowly: with fewer noise terms than states the covariance of the noise-free directions decays like |T|^(2 t), and once its
     # eigenvalues reach eps x the largest one the pseudo-inverse's cut -- src/conditional_dist.cpp:15 -- is decided by rounding, in the reference as here:
