@@ -216,6 +216,7 @@ struct UngSetupDev {
   double *mats, *obs, *init; // per-draw contiguous outputs, padded to MP = pad(m): [F][n][2 MP^2 + MP], [F][n][ROW_HDR + SER_HDR + MP], [F][MP + MP^2]
   int* ok;
   int* flags;                // round 6, 16 and more padded states: [F][n + 1] which (draw, time point) the full factor kernel has to do (written by the thin one)
+  int t_off = 0;             // the full factor kernels: time point of grid row 0 (the t = 0 decomposition runs as a launch of its own beside the thin kernel)
 };
 size_t ung_setup_scratch_doubles(int n, int m);
 hipError_t launch_ung_setup(const UngSetupDev& b, hipStream_t stream);

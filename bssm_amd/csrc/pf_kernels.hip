@@ -44,6 +44,35 @@ static hipStream_t library_side_stream() {
   return side.get(side_hi);
 }
 
+// Round 6: a launch BESIDE the sequence of `stream` -- on this thread's side stream, behind what `stream` holds now; `stream` goes on and joins it
+// later (side_join).  The events are the thread's own (created once).  Used by the set-up of 16 and more padded states: the t = 0 decomposition of
+// every draw (one Jacobi per draw, a 1.3 ms latency chain that fills half a CU's workgroup slots) runs beside the thin factors of the other time points.
+namespace {
+struct SideFork {
+  hipEvent_t fork = nullptr, join = nullptr;
+  ~SideFork() { if (fork) (void)hipEventDestroy(fork); if (join) (void)hipEventDestroy(join); }
+  hipError_t init() {
+    if (fork) return hipSuccess;
+    hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    return hipEventCreateWithFlags(&join, hipEventDisableTiming);
+  }
+};
+SideFork& side_fork() { static thread_local SideFork f; return f; }
+// side stream waits for `stream`; returns the side stream (nullptr: no side stream -- the caller launches on `stream` itself)
+hipStream_t side_begin(hipStream_t stream) {
+  hipStream_t side = library_side_stream();
+  if (!side || side == stream || side_fork().init() != hipSuccess) return nullptr;
+  if (hipEventRecord(side_fork().fork, stream) != hipSuccess || hipStreamWaitEvent(side, side_fork().fork, 0) != hipSuccess) return nullptr;
+  return side;
+}
+hipError_t side_join(hipStream_t side, hipStream_t stream) {
+  hipError_t e = hipEventRecord(side_fork().join, side);
+  if (e != hipSuccess) return e;
+  return hipStreamWaitEvent(stream, side_fork().join, 0);
+}
+}  // namespace
+
 size_t grid_workspace_bytes(const FilterBatch& b, int* B_out, int* chunk_out) {
   // One particle per thread keeps a single filter's dependent chain shortest and is best until the batch oversubscribes
   // the chip about three times (workgroups of 256 at one particle per thread: w1 = F * ceil(N / 256); the chip holds 1024).
@@ -739,7 +768,8 @@ __global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) 
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
   rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
-  const bool fine = rows.cond_step((int)blockIdx.y, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, (b.flags && blockIdx.y > 0) ? b.flags + (size_t)d * (b.n + 1) + blockIdx.y : nullptr);
+  const int t = (int)blockIdx.y + b.t_off;
+  const bool fine = rows.cond_step(t, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, (b.flags && t > 0) ? b.flags + (size_t)d * (b.n + 1) + t : nullptr);
   if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;  // (every writer stores 0)
 }
 // the thin path of time point blockIdx.y + 1 (lg_factors_rows.h: cond_step_thin): a kernel of its own, so that its registers are its own
@@ -774,8 +804,18 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 1, hipGetErrorString(de)); }
   if constexpr (M >= 16) {
     const unsigned gg = (unsigned)((b.F + 64 / M - 1) / (64 / M));
-    if (b.flags) hipLaunchKernelGGL((ung_factors_thin_kernel<M>), dim3(gg, (unsigned)b.n), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
-    hipLaunchKernelGGL((ung_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+    if (b.flags) {
+      // t = 0 (always the full decomposition) beside the thin kernel; what the thin kernel flagged behind it
+      hipStream_t side = opt().trace >= 3 ? nullptr : side_begin(stream);
+      hipLaunchKernelGGL((ung_factors_rows_kernel<M>), dim3(gg, 1u), dim3(LgFactorRows<M>::kThreads), 0, side ? side : stream, b);
+      hipLaunchKernelGGL((ung_factors_thin_kernel<M>), dim3(gg, (unsigned)b.n), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+      UngSetupDev b1 = b;
+      b1.t_off = 1;
+      hipLaunchKernelGGL((ung_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n), dim3(LgFactorRows<M>::kThreads), 0, stream, b1);
+      if (side) { const hipError_t je = side_join(side, stream); if (je != hipSuccess) return je; }
+    } else {
+      hipLaunchKernelGGL((ung_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+    }
   }
   else hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 2, hipGetErrorString(de)); }
@@ -1062,7 +1102,8 @@ __global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) 
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
   rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
-  const bool fine = rows.cond_step((int)blockIdx.y * b.p, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, (b.flags && blockIdx.y > 0) ? b.flags + (size_t)d * (b.n + 1) + blockIdx.y : nullptr);
+  const int t = (int)blockIdx.y + b.t_off;
+  const bool fine = rows.cond_step(t * b.p, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, (b.flags && t > 0) ? b.flags + (size_t)d * (b.n + 1) + t : nullptr);
   if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;  // (every writer stores 0)
 }
 template <int M>
@@ -1084,8 +1125,17 @@ static hipError_t launch_mng_setup_big(const UngSetupDev& b, hipStream_t stream)
   hipLaunchKernelGGL(mng_laplace_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   if constexpr (M >= 32) hipLaunchKernelGGL((mng_smooth_wave_kernel<M>), dim3(gg), dim3(LgWave<M>::kThreads), 0, stream, b);
   else hipLaunchKernelGGL((mng_setup_kernel<M, true>), dim3(gg), dim3(64), 0, stream, b);
-  if (b.flags) hipLaunchKernelGGL((mng_factors_thin_kernel<M>), dim3(gg, (unsigned)b.n), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
-  hipLaunchKernelGGL((mng_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+  if (b.flags) {   // (as launch_ung_setup_m: t = 0 beside the thin kernel)
+    hipStream_t side = side_begin(stream);
+    hipLaunchKernelGGL((mng_factors_rows_kernel<M>), dim3(gg, 1u), dim3(LgFactorRows<M>::kThreads), 0, side ? side : stream, b);
+    hipLaunchKernelGGL((mng_factors_thin_kernel<M>), dim3(gg, (unsigned)b.n), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+    UngSetupDev b1 = b;
+    b1.t_off = 1;
+    hipLaunchKernelGGL((mng_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n), dim3(LgFactorRows<M>::kThreads), 0, stream, b1);
+    if (side) { const hipError_t je = side_join(side, stream); if (je != hipSuccess) return je; }
+  } else {
+    hipLaunchKernelGGL((mng_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
+  }
   hipLaunchKernelGGL(mng_tables_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   if constexpr (M >= 32) {
     if (b.dm) {   // (the region offsets of MngWork)
