@@ -50,20 +50,30 @@ static hipStream_t library_side_stream() {
 namespace {
 struct SideFork {
   hipEvent_t fork = nullptr, join = nullptr;
-  ~SideFork() { if (fork) (void)hipEventDestroy(fork); if (join) (void)hipEventDestroy(join); }
+  int dev = -1;   // the device the events belong to (a pool thread may serve another device later: the events are made again there)
+  void drop() { if (fork) (void)hipEventDestroy(fork); if (join) (void)hipEventDestroy(join); fork = join = nullptr; dev = -1; }
+  ~SideFork() { drop(); }
   hipError_t init() {
-    if (fork) return hipSuccess;
-    hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+    int cur = 0;
+    hipError_t e = hipGetDevice(&cur);
     if (e != hipSuccess) return e;
-    return hipEventCreateWithFlags(&join, hipEventDisableTiming);
+    if (fork && dev == cur) return hipSuccess;
+    drop();
+    if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&join, hipEventDisableTiming)) != hipSuccess) { drop(); return e; }
+    dev = cur;
+    return hipSuccess;
   }
 };
 SideFork& side_fork() { static thread_local SideFork f; return f; }
 // side stream waits for `stream`; returns the side stream (nullptr: no side stream -- the caller launches on `stream` itself)
 hipStream_t side_begin(hipStream_t stream) {
   hipStream_t side = library_side_stream();
-  if (!side || side == stream || side_fork().init() != hipSuccess) return nullptr;
-  if (hipEventRecord(side_fork().fork, stream) != hipSuccess || hipStreamWaitEvent(side, side_fork().fork, 0) != hipSuccess) return nullptr;
+  if (!side || side == stream || side_fork().init() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipEventRecord(side_fork().fork, stream) != hipSuccess || hipStreamWaitEvent(side, side_fork().fork, 0) != hipSuccess) {
+    (void)hipGetLastError();   // (no fork: the caller launches on `stream`; the failure must not surface as the launch sequence's error)
+    return nullptr;
+  }
   return side;
 }
 hipError_t side_join(hipStream_t side, hipStream_t stream) {
