@@ -2,6 +2,9 @@
 // The filter kernels themselves are templates in pf_filter_impl.h, instantiated per padded
 // state dimension in pf_inst_mp*.hip.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -48,20 +51,37 @@ static hipStream_t library_side_stream() {
 // later (side_join).  The events are the thread's own (created once).  Used by the set-up of 16 and more padded states: the t = 0 decomposition of
 // every draw (one Jacobi per draw, a 1.3 ms latency chain that fills half a CU's workgroup slots) runs beside the thin factors of the other time points.
 namespace {
+// (the event pairs live in a process-wide pool keyed by device and are never destroyed: a thread gives its pair back when it ends -- the per-call
+// threads of a post-correction come and go -- and nothing calls into the HIP runtime from a thread_local destructor at process exit; as the streams of
+// tls_stream.h)
+struct SideEvents { hipEvent_t fork = nullptr, join = nullptr; };
+std::mutex& side_pool_mu() { static auto* m = new std::mutex; return *m; }
+std::map<int, std::vector<SideEvents>>& side_pool() { static auto* p = new std::map<int, std::vector<SideEvents>>(); return *p; }
 struct SideFork {
   hipEvent_t fork = nullptr, join = nullptr;
-  int dev = -1;   // the device the events belong to (a pool thread may serve another device later: the events are made again there)
-  void drop() { if (fork) (void)hipEventDestroy(fork); if (join) (void)hipEventDestroy(join); fork = join = nullptr; dev = -1; }
-  ~SideFork() { drop(); }
+  int dev = -1;   // the device the events belong to (a pool thread may serve another device later: it takes a pair of that device)
+  void give_back() {
+    if (!fork) return;
+    std::lock_guard<std::mutex> lk(side_pool_mu());
+    side_pool()[dev].push_back(SideEvents{fork, join});
+    fork = join = nullptr; dev = -1;
+  }
+  ~SideFork() { give_back(); }
   hipError_t init() {
     int cur = 0;
     hipError_t e = hipGetDevice(&cur);
     if (e != hipSuccess) return e;
     if (fork && dev == cur) return hipSuccess;
-    drop();
-    if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&join, hipEventDisableTiming)) != hipSuccess) { drop(); return e; }
-    dev = cur;
+    give_back();
+    {
+      std::lock_guard<std::mutex> lk(side_pool_mu());
+      auto& v = side_pool()[cur];
+      if (!v.empty()) { fork = v.back().fork; join = v.back().join; v.pop_back(); dev = cur; return hipSuccess; }
+    }
+    hipEvent_t f = nullptr, j = nullptr;
+    if ((e = hipEventCreateWithFlags(&f, hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&j, hipEventDisableTiming)) != hipSuccess) { (void)hipEventDestroy(f); return e; }
+    fork = f; join = j; dev = cur;
     return hipSuccess;
   }
 };
