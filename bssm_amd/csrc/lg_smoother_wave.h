@@ -33,9 +33,11 @@ __device__ unsigned long long lgw_stamps[32];
 #ifndef LGW_NW32
 #define LGW_NW32 4   // waves per workgroup at 32 (padded) states: four (eight columns each, 222 registers: two workgroups = two waves per SIMD; 512 draws 10.2 -> 5.2 ms against two)
 #endif
-template <int M, int NW = (M == 32 ? LGW_NW32 : M / 16)>
+// (M = 16, late round 6: states of 9 ... 16 dimensions -- monthly seasonals -- four draws per workgroup, a wave = one draw's 16 x 16 products, four matrix
+// instructions each: the rows-in-registers form of lg_smoother_rows.h took 127 us per time point, every multiply-add behind a cross-lane fetch)
+template <int M, int NW = (M == 64 ? 4 : LGW_NW32)>
 struct LgWave {
-  static_assert(M == 32 || M == 64, "M lanes per draw must tile the wave");
+  static_assert(M == 16 || M == 32 || M == 64, "M lanes per draw must tile the wave");
   static_assert(M % NW == 0, "the waves split the columns evenly");
   static constexpr int MM = M * M, G = 64 / M, LD = M + 1, MAT = M * LD, JW = M / NW;
   static constexpr int GS = 4 * MAT + 6 * M + 2;  // per group: four matrices, six vectors (+ 2: groups start in different banks)
@@ -96,7 +98,7 @@ struct LgWave {
   __device__ LG_INL bool run(const LgModel& g, double* at, double* Pt, double* cc, double* K, double* v, double* Fs, size_t es, size_t em = 0) {
     if (em == 0) em = es;
 #ifndef LGW_NO_MFMA
-    if constexpr ((M == 64 || M == 32) && NW == 4) return run_mfma(g, at, Pt, cc, K, v, Fs, es, em);
+    if constexpr ((M == 64 || M == 32 || M == 16) && NW == 4) return run_mfma(g, at, Pt, cc, K, v, Fs, es, em);
 #endif
     const int n = g.n, sub = g.sub;
     int bad = 0;

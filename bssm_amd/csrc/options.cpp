@@ -198,6 +198,7 @@ Options read_env() {
   if (const char* e = std::getenv("BSSM_AMD_NO_SPARSE")) { if (e[0] != '0') o.sparse = 0; }
   o.setup_interleaved = env_set("BSSM_AMD_SETUP_INTERLEAVED");
   o.factors_full = env_set("BSSM_AMD_FACTORS_FULL");
+  o.setup_rows16 = env_set("BSSM_AMD_SETUP_ROWS16");
   o.xcd_persist = env_tri("BSSM_AMD_XCD_PERSIST");   // (acts in -DBSSM_XCD_PERSIST builds only)
 #ifdef BSSM_PROBES
   o.probe_no_weights = env_set("BSSM_AMD_PROBE_NO_WEIGHTS");

@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(256) setup_tables_big_kernel(const double* __r
 // Kalman filter + covariance smoother of 17 ... 64 states (padded to 32 / 64): one workgroup of M / 16 waves per 64 / M draws, the matrices of the
 // recursion in LDS (lg_smoother_wave.h) -- phase 1 of the set-up for these dimensions
 template <int M>
-__global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) ung_smooth_wave_kernel(const UngSetupDev b) {
+__global__ void __launch_bounds__(LgWave<M>::kThreads, (M <= 32 ? 2 : 1)) ung_smooth_wave_kernel(const UngSetupDev b) {
   __shared__ double lds[LgWave<M>::kLdsDoubles];
   const int d = min((int)(blockIdx.x * (64 / M) + (threadIdx.x & 63) / M), b.F - 1);  // (surplus groups redo the last draw: every lane takes part in the barriers)
   const size_t F = (size_t)b.F;
@@ -826,7 +826,9 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   if constexpr (M >= 32) {
     hipLaunchKernelGGL((ung_smooth_wave_kernel<M>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M))), dim3(LgWave<M>::kThreads), 0, stream, b);
   } else if constexpr (M >= 16) {  // (no one-lane-per-draw form: five 16 x 16 matrices do not fit a lane)
-    hipLaunchKernelGGL((ung_setup_kernel<M, 1, true>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M))), dim3(64), 0, stream, b);
+    // late round 6: the matrix-core smoother for 16 padded states as well (2 048 draws of 13 states: 9.2 -> ... ms); BSSM_AMD_SETUP_ROWS16: the rows form
+    if (!opt().setup_rows16) hipLaunchKernelGGL((ung_smooth_wave_kernel<M>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M))), dim3(LgWave<M>::kThreads), 0, stream, b);
+    else hipLaunchKernelGGL((ung_setup_kernel<M, 1, true>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M))), dim3(64), 0, stream, b);
   } else {
     if ((M == 8 || M == 4) && !lane_form) hipLaunchKernelGGL((ung_setup_kernel<MR, 1, true>), dim3((unsigned)((b.F + 64 / MR - 1) / (64 / MR))), dim3(64), 0, stream, b);
     else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
@@ -1107,7 +1109,7 @@ __global__ void __launch_bounds__(64) mng_tables_kernel(const UngSetupDev b) {
 // n p virtual steps: the smoother with its matrices in LDS (lg_smoother_wave.h, series at a time), the conditional factors M lanes per
 // (draw, time point) at the time points' virtual steps (lg_factors_rows.h; src/model_ssm_mlg.cpp:310-396, src/conditional_dist.cpp:4-31)
 template <int M>
-__global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) mng_smooth_wave_kernel(const UngSetupDev b) {
+__global__ void __launch_bounds__(LgWave<M>::kThreads, (M <= 32 ? 2 : 1)) mng_smooth_wave_kernel(const UngSetupDev b) {
   __shared__ double lds[LgWave<M>::kLdsDoubles];
   const int d = min((int)(blockIdx.x * (64 / M) + (threadIdx.x & 63) / M), b.F - 1);  // (surplus groups redo the last draw: every lane takes part in the barriers)
   const size_t F = (size_t)b.F;
@@ -1153,7 +1155,7 @@ template <int M>
 static hipError_t launch_mng_setup_big(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64), gg = (unsigned)((b.F + 64 / M - 1) / (64 / M));
   hipLaunchKernelGGL(mng_laplace_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
-  if constexpr (M >= 32) hipLaunchKernelGGL((mng_smooth_wave_kernel<M>), dim3(gg), dim3(LgWave<M>::kThreads), 0, stream, b);
+  if (M >= 32 || !opt().setup_rows16) hipLaunchKernelGGL((mng_smooth_wave_kernel<M>), dim3(gg), dim3(LgWave<M>::kThreads), 0, stream, b);
   else hipLaunchKernelGGL((mng_setup_kernel<M, true>), dim3(gg), dim3(64), 0, stream, b);
   if (b.flags) {   // (as launch_ung_setup_m: t = 0 beside the thin kernel)
     hipStream_t side = side_begin(stream);

@@ -23,7 +23,7 @@ struct Dev {
 };
 
 template <int M>
-__global__ void __launch_bounds__(LgWave<M>::kThreads, (M == 32 ? 2 : 1)) smooth_kernel(const Dev b) {
+__global__ void __launch_bounds__(LgWave<M>::kThreads, (M <= 32 ? 2 : 1)) smooth_kernel(const Dev b) {
   constexpr int G = 64 / M;
   __shared__ double lds[LgWave<M>::kLdsDoubles];
   const int d = min((int)(blockIdx.x * G + (threadIdx.x & 63) / M), b.F - 1);
@@ -212,10 +212,13 @@ int check(int mr, int n, int F, unsigned seed) {
 
 int main(int argc, char** argv) {
   int rc = 0;
+  rc |= check<16>(13, 30, 7, 9);
+  rc |= check<16>(16, 12, 4, 10);
   rc |= check<32>(25, 40, 5, 11);
   rc |= check<32>(32, 20, 4, 12);
   rc |= check<64>(53, 30, 3, 13);
   if (argc > 1) {  // timing at a batch size
+    rc |= check<16>(13, 72, 2048, 16);
     rc |= check<32>(25, 100, 512, 14);
     rc |= check<64>(53, 100, 256, 15);
   }

@@ -1,5 +1,5 @@
 """post-correction of bsm_ng draws over seasonal periods 4 ... 52 (5 ... 53 states): ms per call and per draw, device set-up.
-Usage (GPU box): python scripts/seasonal_probe.py [draws]  -> gpurun_out/r06_seasonal_probe.txt"""
+Usage (GPU box): python scripts/seasonal_probe.py [draws [periods ...]]  -> gpurun_out/r06_seasonal_probe.txt"""
 import os
 import sys
 import time
@@ -10,8 +10,9 @@ import numpy as np  # noqa: E402
 from bssm_amd import filters as F, models as M, post_correct as PC  # noqa: E402
 
 ns = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+periods = [int(a) for a in sys.argv[2:]] or [4, 7, 12, 24, 52]
 out = open(os.path.join(root, "gpurun_out", "r06_seasonal_probe.txt"), "w")
-for period in (4, 7, 12, 24, 52):
+for period in periods:
     n = 2 * period + 48
     rng = np.random.default_rng(5)
     tt = np.arange(n)
