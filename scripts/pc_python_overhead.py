@@ -12,8 +12,8 @@ import numpy as np  # noqa: E402
 from bssm_amd import filters as F, models as M, post_correct as PC  # noqa: E402
 
 period = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-ns = 256
-n = 3 * period if period == 24 else 2 * period
+ns = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+n = 3 * period if period == 24 else (2 * period if period > 12 else 2 * period + 48)
 rng = np.random.default_rng(5)
 y = rng.poisson(np.exp(1.6 + 0.4 * np.sin(2 * np.pi * np.arange(n) / period))).astype(float)
 model = M.bsm_ng(y, sd_level=M.halfnormal(0.1, 1), sd_slope=M.halfnormal(0.02, 1), sd_seasonal=M.halfnormal(0.05, 1), period=period,
