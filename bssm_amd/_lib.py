@@ -248,6 +248,30 @@ def dptr(a):
 _PTR_FIELDS = ("y", "Z", "T", "R", "a1", "P1", "D", "C", "xreg", "beta", "u", "H", "initial_mode")
 
 
+class DrawList(list):
+    """per-draw model dicts (post_correct.expand_models) that may carry the batch arrays they are views of: ``batch[k]`` is a C-contiguous (count x size)
+    array whose row i is draw i's component k, ``phi`` the draws' dispersion parameters.  Replacing, adding or removing an entry drops the batch (the
+    list is then packed draw by draw); the dicts themselves are views of the batch and are not to be given other arrays in place -- copy and replace."""
+    batch = None
+    phi = None
+
+    def _drop(self):
+        self.batch = None
+        self.phi = None
+
+
+def _dropping(name):
+    def method(self, *a, **kw):
+        self._drop()
+        return getattr(list, name)(self, *a, **kw)
+    method.__name__ = name
+    return method
+
+
+for _name in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove", "sort", "reverse", "clear"):
+    setattr(DrawList, _name, _dropping(_name))
+
+
 def pack_models(arrs):
     """One UngModel per dict of ``arrs`` (models.model_arrays / post_correct.expand_models) as a ctypes array: the first draw is
     packed field by field, the others are byte copies of it whose pointer fields are patched only where the draw holds a DIFFERENT
@@ -265,6 +289,17 @@ def pack_models(arrs):
     scal = ints + ("conv_tol", "p")
     base_scal = tuple(map(base.get, scal))
     base_ptrs = tuple(map(base.get, _PTR_FIELDS))
+    batch = getattr(arrs, "batch", None)
+    if batch is not None and all(v.flags["C_CONTIGUOUS"] and v.dtype == np.float64 and v.shape[0] == cnt for v in batch.values()):
+        # built-in models expanded in one library call: every draw shares the scalars and the untouched arrays of draw 0, and its own components are
+        # rows of the batch arrays -- the pointer fields of all draws are patched at once (2 048 draws: 18 ms of per-draw Python -> well under 1 ms)
+        for f, v in batch.items():
+            off = getattr(UngModel, f).offset
+            raw[:, off:off + 8].view(np.uint64)[:, 0] = v.ctypes.data + np.arange(cnt, dtype=np.uint64) * np.uint64(v.strides[0])
+            keep.append(v)
+        off = UngModel.phi.offset
+        raw[:, off:off + 8].view(np.float64)[:, 0] = np.asarray(arrs.phi, dtype=np.float64)
+        return models, keep
     for i in range(1, cnt):
         a = arrs[i]
         if tuple(map(a.get, scal)) != base_scal or a.get("distribution_p") is not base.get("distribution_p") or a.get("phi_p") is not base.get("phi_p"):

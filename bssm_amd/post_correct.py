@@ -75,6 +75,10 @@ def expand_models(model: BssmModel, theta: np.ndarray):
             if has_x:
                 arr["xbeta"] = arr["xreg"] @ arr["beta"]
             out.append(arr)
+        # (the batch arrays ride along: _lib.pack_models patches the pointer fields of all draws at once -- row i of big[k] IS draw i's array)
+        out = _lib.DrawList(out)
+        out.batch = {k: big[k] for k in keys if bf[k].size}
+        out.phi = phi
         return out
     for i in range(theta.shape[0]):
         arr = dict(base)
