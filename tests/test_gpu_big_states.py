@@ -251,10 +251,11 @@ def test_device_set_up_of_big_states_time_varying_and_a_failing_draw(oracle, mon
         assert np.array_equal(np.delete(bad["loglik"], 1), np.delete(good["loglik"], 1))
 
 
-@pytest.mark.parametrize("m,n", [(17, 6), (32, 5), (33, 4), (64, 3), (25, 1)])
+@pytest.mark.parametrize("m,n", [(17, 6), (32, 5), (33, 4), (64, 3), (25, 1), (9, 5), (13, 1), (16, 4)])
 def test_device_set_up_dimension_edges(oracle, monkeypatch, m, n):
     """the padded dimensions at their edges: 17 (odd, the first beyond the 16-state kernels), 32 and 64 (no padding), 33 (the first at 64), and a
-    series of ONE time point -- device set-up against the oracle and the host set-up"""
+    series of ONE time point -- device set-up against the oracle and the host set-up; 9, 13 and 16 states: the matrix-core smoother of 16 padded
+    states (late round 6: LgWave<16>, four draws per workgroup -- three draws leave a group of lanes redoing the last one)"""
     rng = np.random.default_rng(7 * m + n)
     k, ns = 2, 3
     T = 0.8 * np.linalg.qr(rng.normal(size=(m, m)))[0]
