@@ -697,7 +697,7 @@ int bssm_is_correction(const bssm_is_job* job, double* weights, double* loglik, 
       HIP_TRY(bssm::launch_transpose(din.as<double>(), din_t.as<double>(), F, (int)E, st));  // [F][E] -> [E][F]
       bssm::UngSetupDev b{};
       b.F = F; b.n = n; b.m = m_dev; b.p = p0; b.mr = m;
-      b.dm = (m_dev >= 32 && !bssm::opt().setup_interleaved) ? 1 : 0;   // draw-major matrix work arrays for the LDS-resident set-up kernels (round 6; the switch: A/B)
+      b.dm = ((m_dev >= 32 || (m_dev == 16 && !bssm::opt().setup_rows16)) && !bssm::opt().setup_interleaved) ? 1 : 0;   // draw-major matrix work arrays for the LDS-resident set-up kernels (round 6; the switch: A/B)
       b.Zs = L0.Zs; b.Ts = L0.Ts; b.Rs = L0.Rs; b.Ds = L0.Ds; b.Cs = L0.Cs;
       b.oZ = L0.oZ; b.oT = L0.oT; b.oR = L0.oR; b.oD = L0.oD; b.oC = L0.oC; b.oy = L0.oy; b.oa = L0.oa; b.oP = L0.oP;
       b.ou = L0.ou; b.ox = L0.ox; b.om = L0.om; b.oh = L0.oh;

@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
     double* __restrict__ obs = b.obs + (size_t)d * n * OS;
     double* __restrict__ ini = b.init + (size_t)d * (MP + MP * MP);
     double* mt = mats + (size_t)t * MS;
-    if (!(M >= 32 && b.dm)) { for (int q = 0; q < MS; q++) mt[q] = 0.0; }
+    if (!(M >= 16 && b.dm)) { for (int q = 0; q < MS; q++) mt[q] = 0.0; }
     if constexpr (M >= 32) {  // (no work arrays of a lane: a 32 x 32 matrix is 8 KB of scratch memory; MP == M here)
       // (draw-major work arrays, UngSetupDev::dm: setup_tables_big_kernel copies the matrices, a workgroup per (draw, time point), coalesced)
       if (ok && !b.dm) {
@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(64) ung_setup_kernel(const UngSetupDev b) {
           mt[2 * MM + j] = at[((size_t)(t + 1) * M + j) * F] - s;
         }
       }
-    } else if (ok) {
+    } else if (ok && !(M == 16 && b.dm)) {   // (16 padded states with draw-major work arrays, late round 6: setup_tables_big_kernel as well)
       double ah0[M], ah1[M], Ct1[MM];
 #pragma unroll
       for (int j = 0; j < M; j++) { ah0[j] = at[((size_t)t * M + j) * F]; ah1[j] = at[((size_t)(t + 1) * M + j) * F]; }
@@ -852,7 +852,7 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   else hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 2, hipGetErrorString(de)); }
   hipLaunchKernelGGL((ung_setup_kernel<M, 3, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
-  if constexpr (M >= 32) {
+  if constexpr (M >= 16) {
     if (b.dm) {   // the matrices of the tables from the draw-major work arrays (the region offsets of UngWork)
       const size_t F = (size_t)b.F, n = (size_t)b.n, n1 = n + 1, MMs = (size_t)M * M;
       double* w = b.scratch + 4 * n * F;
@@ -1169,7 +1169,7 @@ static hipError_t launch_mng_setup_big(const UngSetupDev& b, hipStream_t stream)
     hipLaunchKernelGGL((mng_factors_rows_kernel<M>), dim3(gg, (unsigned)b.n + 1), dim3(LgFactorRows<M>::kThreads), 0, stream, b);
   }
   hipLaunchKernelGGL(mng_tables_kernel<M>, dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
-  if constexpr (M >= 32) {
+  if constexpr (M >= 16) {
     if (b.dm) {   // (the region offsets of MngWork)
       const size_t F = (size_t)b.F, n = (size_t)b.n, nv = n * b.p, n1 = nv + 1, MMs = (size_t)M * M;
       double* w = b.scratch + (2 * nv + n) * F;
