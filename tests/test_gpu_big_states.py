@@ -204,7 +204,7 @@ def test_degenerate_and_unobserved_series_on_a_big_state(oracle, monkeypatch):
             assert F.bootstrap_filter(bad, N, seed=1)["logLik"] == -np.inf
 
 
-@pytest.mark.parametrize("m,tv_r", [(20, False), (40, False), (20, True), (40, True)])
+@pytest.mark.parametrize("m,tv_r", [(20, False), (40, False), (20, True), (40, True), (13, False), (13, True)])
 def test_device_set_up_of_big_states_time_varying_and_a_failing_draw(oracle, monkeypatch, m, tv_r):
     """psi set-up on the device for 17 ... 64 states (padded to 32 / 64: lg_smoother_wave.h, lg_factors_rows.h) with time-varying Z, T and D, C
     (the smoother reloads its T slot every step; tv_r: a time-varying R as well -- the matrix-core form of the smoother keeps a time-invariant
