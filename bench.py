@@ -507,6 +507,7 @@ def seasonal_post_correct_leg(period, ns=256, nsim=64, threads=8):
     return {"workload": "bsm_ng(period = %d): m = %d, T = %d, %d theta-draws, psi-APF N = %d, is2, output theta; one bssm_is_correction call, %d host threads"
                         % (period, m, n, ns, nsim, threads),
             "seconds": sec, "draws_per_s": ns / sec,
+            "library_split_ms": {k: round(float(v), 3) for k, v in (r.get("timing_ms") or {}).items()},   # (of the last timed call: the C ABI call's own wall and its parts; the rest of `seconds` is the Python mirror)
             "setup": "device: ung_setup_kernel<%d> (Laplace step, tables), ung_smooth_wave_kernel<%d> (products on the matrix cores), ung_factors_thin_kernel<%d> (time points >= 1) + ung_factors_rows_kernel<%d> (t = 0), setup_tables_big_kernel<%d>" % ((32 if m <= 32 else 64,) * 5),
             "eight_draws_device_s": dev8, "eight_draws_host_setup_s": host8,
             "max_abs_dloglik_device_vs_host_setup": float(np.max(np.abs(r8["loglik"] - h8["loglik"])))}
