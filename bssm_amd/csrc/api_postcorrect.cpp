@@ -75,6 +75,105 @@ int device_lg_batch(const std::vector<const bssm::LgPacked*>& lgs, const std::ve
 // The device smoother shares the GPU with the filter kernels of the previous chunk (measured 4 ms alone, 10-20 ms
 // under contention per 512 draws of n = 300, m = 2); the host smoother costs 0.19 ms per draw and thread.  With fewer
 // than 8 host threads the device batch wins (C5 at threads = 1: 0.60 s -> 0.22 s), with more the host pool does.
+// ---------------------------------------------------------------------------------------------------------------------------------
+// psi set-up of ONE model with 9 ... 64 states (bssm_psi_smoother, the psi log-likelihood calls, every iteration of a pm / da chain with the
+// psi-APF, the host set-up of a post-correction): the host finds the mode and the approximating y / H (psi_setup, host_model.cpp); the
+// Kalman smoother and the conditional factors run HERE -- the set-up kernels of the post-correction path on one "draw", with the approximating
+// y / H written into their work arrays instead of the Laplace step at a stored mode (UngSetupDev::phases = 2 | 4).  A psi log-likelihood call at
+// 13 / 25 / 33 states (T = 200): 17 / 87 / 180 ms -> 7 / 23 / 44 ms; 53 states: 0.58 s of host decompositions -> 14 ms where the guards below let it.
+static bool device_factors_one(const bssm::HostModel& h, const std::vector<double>& ay, const std::vector<double>& aH, bssm::PsiSetup* out, bool* finite) {
+  if (h.p != 1 || h.m < 9 || h.m > 64 || h.n < 1 || h.n >= 65535 || out->mode.size() != (size_t)h.n) return false;
+  // OPT-IN (BSSM_AMD_SINGLE_DEVICE_SETUP=1): the kernels' thin factors are a different (more accurate) algorithm than the host routines' decompositions,
+  // and where V_{t-1} is not well conditioned the two leave different rounding-level columns in the factors -- log-likelihoods of seasonal models agree
+  // to 1e-9 ... 3e-8, not to the 1e-13 of the post-correction path's comparisons (there both sides start from a stored mode); the default keeps every
+  // single-model entry point on the host routines, which are the oracle's algorithm step by step
+  if (!bssm::opt().single_device_setup || bssm::opt().device_setup == 0 || bssm::opt().generic_setup || !have_device()) return false;
+  bssm::LgPacked L0;
+  if (!bssm::ung_pack(h, out->mode.data(), &L0)) return false;
+  const int n = h.n, m = h.m, M = L0.m;
+  const size_t MM = (size_t)M * M, n1 = (size_t)n + 1, E = L0.buf.size();
+  const size_t scratch_d = bssm::ung_setup_scratch_doubles(n, M);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)scratch_d * 8.0 > 0.25 * ((double)free_b + (double)arena().cached)) return false;
+  static thread_local bssm::TlsStream st_tls;
+  hipStream_t st = st_tls.get(true);
+  if (!st) return false;
+  if (M < 16 || bssm::opt().factors_full) return false;   // (the checks below read what the thin factor kernel leaves)
+  DevBuf din, scratch, okb, flags, cond;
+  if (din.alloc(E * sizeof(double)) != hipSuccess || scratch.alloc(scratch_d * sizeof(double)) != hipSuccess || okb.alloc(sizeof(int)) != hipSuccess ||
+      flags.alloc(n1 * sizeof(int)) != hipSuccess || cond.alloc(n1 * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  // the head of the work arrays (UngWork, F = 1): approximating y minus x'beta (what the smoother sees) | approximating standard deviations
+  std::vector<double> head(2 * (size_t)n);
+  for (int t = 0; t < n; t++) { head[t] = ay[t] - h.xbeta[t]; head[(size_t)n + t] = aH[t]; }
+  bssm::UngSetupDev b{};
+  b.F = 1; b.n = n; b.m = M; b.p = 1; b.mr = m;
+  b.dm = ((M >= 32 || (M == 16 && !bssm::opt().setup_rows16)) && !bssm::opt().setup_interleaved) ? 1 : 0;
+  b.Zs = L0.Zs; b.Ts = L0.Ts; b.Rs = L0.Rs; b.Ds = L0.Ds; b.Cs = L0.Cs;
+  b.oZ = L0.oZ; b.oT = L0.oT; b.oR = L0.oR; b.oD = L0.oD; b.oC = L0.oC; b.oy = L0.oy; b.oa = L0.oa; b.oP = L0.oP;
+  b.ou = L0.ou; b.ox = L0.ox; b.om = L0.om; b.oh = L0.oh;
+  b.in = din.as<double>();   // (one draw: [E][1] is [1][E], no transposition)
+  b.scratch = scratch.as<double>();
+  b.ok = okb.as<int>();
+  b.flags = (M >= 16 && !bssm::opt().factors_full) ? flags.as<int>() : nullptr;
+  b.phases = 2 | 4;
+  b.cond = cond.as<double>();
+  std::vector<double> at(n1 * M), Vf(n1 * MM), Cf(n1 * MM), ratio(n1, 1.0);
+  std::vector<int> flagv(n1, 0);
+  int okv = 0;
+  // offsets of the work arrays (UngWork): ay, aH, ayr, scl (n each) | at | Pt | cc | K | v | Fs | Vf | Cf
+  const size_t o_at = 4 * (size_t)n, o_Vf = o_at + n1 * M + 2 * n1 * MM + (size_t)n * M + 2 * (size_t)n, o_Cf = o_Vf + n1 * MM;
+  bool good = hipMemcpyAsync(din.p, L0.buf.data(), E * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(scratch.p, head.data(), head.size() * sizeof(double), hipMemcpyHostToDevice, st) == hipSuccess &&
+              bssm::launch_ung_setup(b, st) == hipSuccess &&
+              hipMemcpyAsync(at.data(), scratch.as<double>() + o_at, at.size() * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipMemcpyAsync(Vf.data(), scratch.as<double>() + o_Vf, Vf.size() * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipMemcpyAsync(Cf.data(), scratch.as<double>() + o_Cf, Cf.size() * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipMemcpyAsync(ratio.data() + 1, cond.as<double>() + 1, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipMemcpyAsync(flagv.data() + 1, flags.as<int>() + 1, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipMemcpyAsync(&okv, okb.p, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+  good = (hipStreamSynchronize(st) == hipSuccess) && good;   // (always: the buffers above go back to the arena behind it)
+  if (!good) { (void)hipGetLastError(); return false; }
+  // The device's numbers are taken only where they are the host routines' numbers to well below the parity bar (host_model.cpp's psi_setup is the
+  // oracle's algorithm step by step; the kernels' thin path is not):
+  //   * every time point took the thin path (a singular V_{t-1} goes through the round-robin Jacobi, whose null-space choices are its own);
+  //   * V_{t-1} is well conditioned -- smallest / first pivot of its factor >= 1e-6: a Cholesky solve and the pseudo-inverse by decomposition agree to
+  //     ~ condition number x eps, 1e-10 here (found by scripts/fuzz_parity.py: 40 states with one noise term over 33 steps differed by 9e-7 in the states);
+  //   * no two kept singular values of a factor closer than 1e-6 of the largest: inside a repeated eigenvalue's space every program picks its own
+  //     basis (a seasonal model shorter than its period keeps its prior variances at t = 0: particle states then differ by O(1e-2) between two
+  //     correct decompositions while weights and log-likelihood agree).
+  // Otherwise the host routines run as before.
+  if (okv != 0) {
+    if (bssm::opt().trace) {
+      double rmin = 1.0; int nfl = 0;
+      for (size_t t = 1; t < n1; t++) { rmin = std::min(rmin, ratio[t]); nfl += flagv[t] != 0; }
+      std::fprintf(stderr, "[bssm_amd] psi set-up of one model on the device (m = %d, n = %d): smallest pivot ratio %.3g, %d time points left to the full path\n", m, n, rmin, nfl);
+    }
+    for (size_t t = 1; t < n1; t++) if (flagv[t] != 0 || !(ratio[t] >= 1e-6)) return false;
+    std::vector<double> sv(m);
+    for (size_t t = 0; t < n1; t++) {
+      for (int c = 0; c < m; c++) { double a = 0.0; for (int i = 0; i < m; i++) { const double v = Vf[t * MM + i + (size_t)M * c]; a += v * v; } sv[c] = a; }
+      for (int c = 0; c + 1 < m; c++) if (sv[c] > 0.0 && !(sv[c] - sv[c + 1] >= 1e-6 * sv[0])) return false;
+    }
+  }
+  out->alphahat.assign((size_t)m * n1, 0.0);
+  out->Vt.assign((size_t)m * m * n1, 0.0);
+  out->Ct.assign((size_t)m * m * n1, 0.0);
+  bool fin = okv != 0;
+  for (size_t t = 0; t < n1 && fin; t++) {
+    for (int i = 0; i < m; i++) { const double v = at[t * M + i]; out->alphahat[i + (size_t)m * t] = v; fin = fin && std::isfinite(v); }
+    for (int j = 0; j < m; j++)
+      for (int i = 0; i < m; i++) {
+        const double v = Vf[t * MM + i + (size_t)M * j], c = Cf[t * MM + i + (size_t)M * j];
+        out->Vt[i + (size_t)m * j + (size_t)m * m * t] = v;
+        out->Ct[i + (size_t)m * j + (size_t)m * m * t] = c;
+        fin = fin && std::isfinite(v) && std::isfinite(c);
+      }
+  }
+  *finite = fin;
+  return true;
+}
+namespace { struct InstallDeviceFactors { InstallDeviceFactors() { bssm::device_factors_hook() = &device_factors_one; } } g_install_device_factors; }
+
 bool device_setup_enabled(int n_threads) {
   if (bssm::opt().device_setup >= 0) return bssm::opt().device_setup != 0;
   return n_threads < 8;

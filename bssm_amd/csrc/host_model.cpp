@@ -657,6 +657,8 @@ double const_term(const HostModel& h) {
   return res;
 }
 
+DeviceFactorsFn& device_factors_hook() { static DeviceFactorsFn fn = nullptr; return fn; }
+
 bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out, const GlobalApprox* global) {
   if (is_mode && h.p > 1 && bssm::opt().mv_sequential) {
     // test hook: the series-at-a-time smoother the device batch runs for multivariate observations, on the host
@@ -697,6 +699,10 @@ bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out, const G
   }
   out->approx_y = ap.y;
   out->approx_H = ap.H;
+  if (ok && p == 1 && m >= 9 && device_factors_hook()) {   // (smoother + conditional factors of 9 ... 64 states on the device: host_model.h)
+    bool fok = true;
+    if (device_factors_hook()(h, ap.y, ap.H, out, &fok)) return fok;
+  }
   {
     bool fok = true;
     if (ok && lg_fast_path(h, ap, &out->alphahat, &out->Vt, &out->Ct, &fok)) return fok;

@@ -40,6 +40,13 @@ struct PsiSetup {
   std::vector<double> Vt, Ct;    // m x m x (n+1)
   int iterations = 0;
 };
+// Late round 6: the psi set-up of ONE model with 9 ... 64 states does its smoother and conditional factors on the device (the host's share --
+// ~0.6 s of a 0.68 s single psi-APF call at 53 states, 87 ms at 25 -- was the conditional factors' decompositions): psi_setup() finds the mode and
+// the approximating y / H on the host as before and then asks this hook (set by api_postcorrect.cpp at load; nullptr in a build without it).
+// Returns false when it did not handle the model (the host routines run); *finite = the result's verdict.
+struct PsiSetup;
+typedef bool (*DeviceFactorsFn)(const HostModel& hm, const std::vector<double>& approx_y, const std::vector<double>& approx_H, PsiSetup* out, bool* finite);
+DeviceFactorsFn& device_factors_hook();
 // is_mode == nullptr: iterate from hm.initial_mode.  Returns false on a numerical failure.
 // local_approx = FALSE (src/model_ssm_ung.cpp:104-116): the pseudo-observations (approx y, H) of the FIRST approximation
 // of a chain are kept; later parameter values only re-run the smoother against them.  `set` is false until then.

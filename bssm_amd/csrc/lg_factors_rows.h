@@ -50,6 +50,7 @@ struct LgFactorRows {
   double *va, *vb, *vc, *vd;  // this group's vectors
   int r;                      // the row (and, in a rotation, also the column) this lane works on
   int w, j0;                  // its wave, the first of the JW columns the wave owns
+  double chol_ratio = 1.0;    // smallest / first pivot of the last RELATIVE pivoted Cholesky (the thin path's factor of V_{t-1}): ~ 1 / condition number
   bool skip = false;          // this group's draw has already failed: its decompositions take no rotations (the result is discarded)
   int mr = M;                 // rows / columns from mr on are exact zeros (states padded to M): no rotation touches them
   __device__ LgFactorRows(double* lds_wg) {
@@ -280,7 +281,7 @@ struct LgFactorRows {
     double dg = (r < mr) ? A[r * LD + r] : -1.0;
     bool picked = r >= mr, open = true;
     int rank = 0;
-    double thr_abs = thr;
+    double thr_abs = thr, piv0 = 1.0, pivmin = 1.0;
     for (int j = 0; j < steps; j++) {
       double* buf = (j & 1) ? vb : va;   // (two buffers: a wave may still scan the previous step's while wave 0 publishes this one's)
       if (w == 0) buf[r] = picked ? -1.0 : dg;
@@ -291,6 +292,7 @@ struct LgFactorRows {
       for (int i = 1; i < M; i++) { const double v = buf[i]; if (v > dmax) { dmax = v; best = i; } }
       if (j == 0 && relative) thr_abs = thr * dmax;
       open = open && dmax > thr_abs;
+      if (relative) { if (j == 0) { piv0 = dmax; pivmin = dmax; } else if (open) pivmin = fmin(pivmin, dmax); }
       rank += open ? 1 : 0;
       if (w == 0) {
         double l = 0.0;
@@ -315,6 +317,7 @@ struct LgFactorRows {
       }
     }
     __syncthreads();
+    if (relative) chol_ratio = piv0 > 0.0 ? pivmin / piv0 : 0.0;
     return rank;
   }
   // ---- Round 6, late: the sequential parts of the thin path in REGISTERS, on every wave (G == 1: one matrix per workgroup, M = 64).
@@ -343,7 +346,7 @@ struct LgFactorRows {
     double dg = (r < mr) ? A[r * LD + r] : -1.0;
     bool picked = r >= mr, open = true;
     int rank = 0;
-    double thr_abs = thr;
+    double thr_abs = thr, piv0 = 1.0, pivmin = 1.0;
     for (int j = 0; j < steps; j++) {
       double* buf = (j & 1) ? vb : va;
       const double key = picked ? -1.0 : dg;
@@ -352,6 +355,7 @@ struct LgFactorRows {
       const int best = at ? __builtin_ctzll(at) : 0;   // (the first of equals, as the scan of pivoted_cholesky; no lane: a NaN, carried to the end)
       if (j == 0 && relative) thr_abs = thr * dmax;
       open = open && dmax > thr_abs;
+      if (relative) { if (j == 0) { piv0 = dmax; pivmin = dmax; } else if (open) pivmin = fmin(pivmin, dmax); }
       rank += open ? 1 : 0;
       if ((best / JW) == w) {   // this wave owns column `best` of the Schur complement (wave-uniform)
         double x = S[0];
@@ -375,6 +379,7 @@ struct LgFactorRows {
       dg -= l * l;
     }
     __syncthreads();
+    if (relative) chol_ratio = piv0 > 0.0 ? pivmin / piv0 : 0.0;
     return rank;
   }
   // X <- (L L')^{-1} X for this wave's JW columns: L (lower triangular, rows in pivot order) in slot X of LDS, the right-hand side's row r in
@@ -611,10 +616,10 @@ struct LgFactorRows {
   // full one over everything): in one kernel the register allocation was the union of both (659 registers spilt at M = 64, 2.2 KB of scratch
   // per lane, 320 us per thin time point instead of ~80).  `flag` (one int per (draw, time point), written by cond_step_thin) says which groups
   // the full kernel still has to do; flag == nullptr: the full path at this time point whatever the matrices are (BSSM_AMD_FACTORS_FULL, and t = 0).
-  __device__ LG_INL bool cond_step_thin(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d, int* flag) {
+  __device__ LG_INL bool cond_step_thin(int t, const double* Pt, const double* cc, double* Vout, double* Cout, size_t es, size_t d, int* flag, double* ratio_out = nullptr) {
     int bad_thin = 0;
     const bool mine_full = thin_step(t, Pt, cc, Vout, Cout, es, d, &bad_thin);
-    if (r == 0 && w == 0) *flag = mine_full ? 1 : 0;
+    if (r == 0 && w == 0) { *flag = mine_full ? 1 : 0; if (ratio_out) *ratio_out = chol_ratio; }
     if (threadIdx.x == 0) atomicAdd(&lgf_thin_counts[1], 1ull);
     return reduce_bad(mine_full ? 0 : bad_thin);
   }

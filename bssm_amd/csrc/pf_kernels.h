@@ -216,6 +216,9 @@ struct UngSetupDev {
   double *mats, *obs, *init; // per-draw contiguous outputs, padded to MP = pad(m): [F][n][2 MP^2 + MP], [F][n][ROW_HDR + SER_HDR + MP], [F][MP + MP^2]
   int* ok;
   int* flags;                // round 6, 16 and more padded states: [F][n + 1] which (draw, time point) the full factor kernel has to do (written by the thin one)
+  double* cond = nullptr;    // (optional) [F][n + 1]: smallest / first pivot of the thin path's factor of V_{t-1} per (draw, time point >= 1) -- psi_setup of one model checks it
+  int phases = 15;           // which parts launch_ung_setup runs: 1 Laplace step at the stored mode, 2 smoother, 4 conditional factors, 8 tables -- the psi set-up of ONE
+                             // model (psi_setup: host mode search, then smoother + factors here on the caller's approximating y / H in the work arrays) asks for 2 | 4
   int t_off = 0;             // the full factor kernels: time point of grid row 0 (the t = 0 decomposition runs as a launch of its own beside the thin kernel)
 };
 size_t ung_setup_scratch_doubles(int n, int m);

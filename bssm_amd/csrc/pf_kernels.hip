@@ -813,17 +813,18 @@ __global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) 
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
   rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
-  const bool fine = rows.cond_step_thin(t, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, b.flags + (size_t)d * (b.n + 1) + t);
+  const bool fine = rows.cond_step_thin(t, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, b.flags + (size_t)d * (b.n + 1) + t, b.cond ? b.cond + (size_t)d * (b.n + 1) + t : nullptr);
   if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;
 }
 template <int M>
 static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   const unsigned gx = (unsigned)((b.F + 63) / 64);
-  hipLaunchKernelGGL((ung_setup_kernel<M, 0, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
+  if (b.phases & 1) hipLaunchKernelGGL((ung_setup_kernel<M, 0, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 0, hipGetErrorString(de)); }
   const bool lane_form = opt().mng_lane_per_draw;  // (comparison switch, shared with the ssm_mng set-up)
   constexpr int MR = (M == 8 || M == 4) ? M : 1;  // (as the ssm_mng set-up: rows for 8 and 4 states; 16 and 32: rows only, above)
-  if constexpr (M >= 32) {
+  if (!(b.phases & 2)) {
+  } else if constexpr (M >= 32) {
     hipLaunchKernelGGL((ung_smooth_wave_kernel<M>), dim3((unsigned)((b.F + 64 / M - 1) / (64 / M))), dim3(LgWave<M>::kThreads), 0, stream, b);
   } else if constexpr (M >= 16) {  // (no one-lane-per-draw form: five 16 x 16 matrices do not fit a lane)
     // late round 6: the matrix-core smoother for 16 padded states as well (2 048 draws of 13 states: 9.2 -> ... ms); BSSM_AMD_SETUP_ROWS16: the rows form
@@ -834,7 +835,8 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
     else hipLaunchKernelGGL((ung_setup_kernel<M, 1, false>), dim3(gx), dim3(64), 0, stream, b);
   }
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 1, hipGetErrorString(de)); }
-  if constexpr (M >= 16) {
+  if (!(b.phases & 4)) {
+  } else if constexpr (M >= 16) {
     const unsigned gg = (unsigned)((b.F + 64 / M - 1) / (64 / M));
     if (b.flags) {
       // t = 0 (always the full decomposition) beside the thin kernel; what the thin kernel flagged behind it
@@ -851,6 +853,7 @@ static hipError_t launch_ung_setup_m(const UngSetupDev& b, hipStream_t stream) {
   }
   else hipLaunchKernelGGL((ung_setup_kernel<M, 2, false>), dim3(gx, (unsigned)b.n + 1), dim3(64), 0, stream, b);
   if (opt().trace >= 3) { const hipError_t de = hipStreamSynchronize(stream); std::fprintf(stderr, "[bssm_amd] ung set-up M=%d phase %d: %s\n", M, 2, hipGetErrorString(de)); }
+  if (!(b.phases & 8)) return hipGetLastError();
   hipLaunchKernelGGL((ung_setup_kernel<M, 3, false>), dim3(gx, (unsigned)b.n), dim3(64), 0, stream, b);
   if constexpr (M >= 16) {
     if (b.dm) {   // the matrices of the tables from the draw-major work arrays (the region offsets of UngWork)
@@ -1148,7 +1151,7 @@ __global__ void __launch_bounds__(LgFactorRows<M>::kThreads, (M >= 32 ? 2 : 1)) 
   LgFactorRows<M> rows(lds);
   rows.skip = b.ok[d] == 0;
   rows.mr = (b.mr > 0 && b.mr < M) ? b.mr : M;
-  const bool fine = rows.cond_step_thin(t * b.p, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, b.flags + (size_t)d * (b.n + 1) + t);
+  const bool fine = rows.cond_step_thin(t * b.p, W.Pt, W.cc, W.Vf, W.Cf, W.em, 0, b.flags + (size_t)d * (b.n + 1) + t, b.cond ? b.cond + (size_t)d * (b.n + 1) + t : nullptr);
   if (!fine && !rows.skip && rows.r == 0 && rows.w == 0) b.ok[d] = 0;
 }
 template <int M>
