@@ -385,14 +385,14 @@ static void conditional_cov_step(const Mat& Vprev, const Mat& Cprev, const Mat& 
 }
 // (late round 6) The time points are independent given the smoother's moments -- the serial loop runs downwards only so that it can work in place -- and a
 // model with many states spends its whole single psi call here (53 states, T = 200: 0.58 s of a 0.68 s call, two 53 x 53 Jacobi decompositions per time
-// point).  With 16 and more states and nobody else inside, the time points go to host threads on a copy of the moments: the same arithmetic per time point,
+// point).  With 9 and more states and nobody else inside, the time points go to host threads on a copy of the moments: the same arithmetic per time point,
 // the same bits.
 static std::atomic<int> g_condcov_active{0};
 void conditional_cov(std::vector<Mat>* Vt, std::vector<Mat>* Ct) {
   const int n1 = (int)Vt->size(), m = (*Vt)[0].r;
   const int before = g_condcov_active.fetch_add(1);
   const unsigned hw = std::thread::hardware_concurrency();
-  const int nthr = (before == 0 && m >= 16 && n1 > 8) ? (int)std::min<unsigned>(std::min<unsigned>(hw ? hw : 1u, 32u), (unsigned)(n1 - 1)) : 1;
+  const int nthr = (before == 0 && m >= 9 && n1 > 8) ? (int)std::min<unsigned>(std::min<unsigned>(hw ? hw : 1u, m >= 16 ? 32u : 16u), (unsigned)(n1 - 1)) : 1;
   if (nthr > 1) {
     const std::vector<Mat> V0 = *Vt, C0 = *Ct;
     std::atomic<int> next{1};
