@@ -398,7 +398,10 @@ void conditional_cov(std::vector<Mat>* Vt, std::vector<Mat>* Ct) {
     std::atomic<int> next{1};
     auto work = [&]() { for (int t = next++; t < n1; t = next++) conditional_cov_step(V0[t - 1], C0[t - 1], V0[t], &(*Vt)[t], &(*Ct)[t]); };
     std::vector<std::thread> pool;
-    for (int q = 1; q < nthr; q++) pool.emplace_back(work);
+    try {
+      for (int q = 1; q < nthr; q++) pool.emplace_back(work);
+    } catch (...) {   // (no more threads to be had: the ones that started and this one share the time points)
+    }
     work();
     for (auto& th : pool) th.join();
   } else {
