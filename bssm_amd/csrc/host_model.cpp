@@ -392,7 +392,9 @@ void conditional_cov(std::vector<Mat>* Vt, std::vector<Mat>* Ct) {
   const int n1 = (int)Vt->size(), m = (*Vt)[0].r;
   const int before = g_condcov_active.fetch_add(1);
   const unsigned hw = std::thread::hardware_concurrency();
-  const int nthr = (before == 0 && m >= 9 && n1 > 8) ? (int)std::min<unsigned>(std::min<unsigned>(hw ? hw : 1u, m >= 16 ? 32u : 16u), (unsigned)(n1 - 1)) : 1;
+  const int forced = bssm::opt().host_factor_threads;   // (0: automatic; 1: the serial loop -- the comparison the tests make)
+  const int nthr = forced > 0 ? std::min(forced, std::max(1, n1 - 1))
+                              : ((before == 0 && m >= 9 && n1 > 8) ? (int)std::min<unsigned>(std::min<unsigned>(hw ? hw : 1u, m >= 16 ? 32u : 16u), (unsigned)(n1 - 1)) : 1);
   if (nthr > 1) {
     const std::vector<Mat> V0 = *Vt, C0 = *Ct;
     std::atomic<int> next{1};

@@ -200,6 +200,7 @@ Options read_env() {
   o.factors_full = env_set("BSSM_AMD_FACTORS_FULL");
   o.setup_rows16 = env_set("BSSM_AMD_SETUP_ROWS16");
   o.single_device_setup = env_int("BSSM_AMD_SINGLE_DEVICE_SETUP", 0) != 0;
+  o.host_factor_threads = std::max(0, env_int("BSSM_AMD_HOST_FACTOR_THREADS", 0));
   o.xcd_persist = env_tri("BSSM_AMD_XCD_PERSIST");   // (acts in -DBSSM_XCD_PERSIST builds only)
 #ifdef BSSM_PROBES
   o.probe_no_weights = env_set("BSSM_AMD_PROBE_NO_WEIGHTS");

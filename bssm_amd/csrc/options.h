@@ -10,7 +10,7 @@
 //                   BSSM_AMD_GRID_STREAMS, BSSM_AMD_XCD_REMAP, BSSM_AMD_WG_WIDE, BSSM_AMD_DEVICE_SETUP, BSSM_AMD_GENERIC_SETUP,
 //                   BSSM_AMD_MV_SEQUENTIAL, BSSM_AMD_MNG_LANE_PER_DRAW, BSSM_AMD_DEFER_SUMMARY, BSSM_AMD_SPARSE (0 | all), BSSM_AMD_NO_SPARSE,
 //                   BSSM_AMD_SETUP_INTERLEAVED, BSSM_AMD_FACTORS_FULL, BSSM_AMD_SETUP_ROWS16 (round 6: comparison switches of the big-state set-up),
-//                   BSSM_AMD_SINGLE_DEVICE_SETUP (=1: the psi set-up of ONE model with 9 ... 64 states does its smoother and conditional factors on the device)
+//                   BSSM_AMD_HOST_FACTOR_THREADS, BSSM_AMD_SINGLE_DEVICE_SETUP (=1: the psi set-up of ONE model with 9 ... 64 states does its smoother and conditional factors on the device)
 //   probes          measurement-only switches that change what a production entry point does (skip an output, bypass the output
 //                   pipe, ...): compiled in only with -DBSSM_PROBES (`make probes` -> ../ab_probes.so):
 //                   BSSM_AMD_PROBE_NO_WEIGHTS, BSSM_AMD_NO_OUTPIPE, BSSM_AMD_IS_BIG_CHUNK, BSSM_AMD_SIDE_PRIO, BSSM_AMD_SS_GLOBAL,
@@ -45,6 +45,7 @@ struct Options {
   bool generic_setup = false, mv_sequential = false, mng_lane_per_draw = false, defer_summary = false;
   int sparse = 1;               // structured transitions (pf_big.h): 0 never, 1 where they measured faster, 2 wherever a descriptor exists (BSSM_AMD_SPARSE=0|all; BSSM_AMD_NO_SPARSE=1 = 0)
   bool setup_interleaved = false;   // set-up of 32 / 64 padded states: draw-interleaved matrix work arrays (the layout before round 6) instead of draw-major
+  int host_factor_threads = 0;      // host threads of the conditional factors' time points (host_model.cpp: conditional_cov): 0 automatic (up to 32), 1 the serial loop (BSSM_AMD_HOST_FACTOR_THREADS)
   bool single_device_setup = false; // psi set-up of one model (single psi calls, pm / da chains): smoother + factors of 9 ... 64 states on the device (opt-in: api_postcorrect.cpp: device_factors_one)
   bool setup_rows16 = false;        // set-up of 9 ... 16 states: the smoother with its rows in registers (lg_smoother_rows.h, before late round 6) instead of the matrix-core form
   bool factors_full = false;        // conditional factors of 16 and more padded states: the full (Jacobi) decomposition at EVERY time point -- the thin kernel is not launched (comparison)

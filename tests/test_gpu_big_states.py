@@ -361,3 +361,18 @@ def test_single_model_psi_set_up_on_the_device_is_opt_in_and_agrees_with_the_hos
     assert np.allclose(su_d["alphahat"], su_h["alphahat"], rtol=0, atol=1e-9)
     assert abs(su_d["approx_loglik"] - su_h["approx_loglik"]) <= 1e-12 * n   # (the mode search and the approximating log-likelihood stay on the host)
 
+
+def test_host_conditional_factors_over_threads_give_the_serial_loops_bits(monkeypatch):
+    """Late round 6: the time points of the host's conditional_cov (src/conditional_dist.cpp:4-31) are independent given the smoother's moments and go to
+    host threads from 9 states on (host_model.cpp) -- the same arithmetic per time point: the set-up of a 25-state model is bit for bit the serial loop's,
+    with 7 threads as with the automatic count"""
+    model = seasonal(24, n=40)
+    monkeypatch.setenv("BSSM_AMD_HOST_FACTOR_THREADS", "1")
+    ref = F.psi_setup(model)
+    for thr in ("7", "0"):
+        monkeypatch.setenv("BSSM_AMD_HOST_FACTOR_THREADS", thr)
+        su = F.psi_setup(model)
+        for k in ("alphahat", "Vt", "Ct", "scales", "mode"):
+            assert np.array_equal(np.asarray(su[k]), np.asarray(ref[k])), (thr, k)
+        assert su["approx_loglik"] == ref["approx_loglik"]
+
