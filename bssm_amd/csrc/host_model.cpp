@@ -5,6 +5,8 @@
 #include "options.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <chrono>
 #include <thread>
 #include <atomic>
 #include <cmath>
@@ -725,9 +727,14 @@ bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out, const G
       if (ok) signal_from_states(h, S, sm, &out->mode); else out->mode = h.initial_mode;
       out->iterations = 0;
     } else {
+      const auto tl0 = std::chrono::steady_clock::now();
       out->iterations = run_laplace(h, S, &ap, &out->mode, &ok);
+      if (bssm::opt().trace) std::fprintf(stderr, "[bssm_amd] psi set-up of one model (m = %d, n = %d): mode search %d iterations %.1f ms\n", m, n, out->iterations,
+                                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
     }
+    const auto tg0 = std::chrono::steady_clock::now();
     const double gll = gaussian_loglik(S, ap);
+    if (bssm::opt().trace) std::fprintf(stderr, "[bssm_amd]   approximating log-likelihood %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count());
     update_scales(h, ap, out->mode, &out->scales);
     double ssc = 0;
     for (double v : out->scales) ssc += v;
@@ -744,12 +751,16 @@ bool psi_setup(const HostModel& h, const double* is_mode, PsiSetup* out, const G
     if (ok && lg_fast_path(h, ap, &out->alphahat, &out->Vt, &out->Ct, &fok)) return fok;
   }
   std::vector<Mat> at, Vt, Ct;
+  const auto ts0 = std::chrono::steady_clock::now();
   ok = ok && smoother_ccov(S, ap, &at, &Vt, &Ct);  // :533
+  const auto ts1 = std::chrono::steady_clock::now();
   out->alphahat.assign((size_t)m * (n + 1), 0.0);
   out->Vt.assign((size_t)m * m * (n + 1), 0.0);
   out->Ct.assign((size_t)m * m * (n + 1), 0.0);
   if (!ok) return false;
   conditional_cov(&Vt, &Ct);                       // :534
+  if (bssm::opt().trace) std::fprintf(stderr, "[bssm_amd]   smoother %.1f ms, conditional factors %.1f ms\n", std::chrono::duration<double, std::milli>(ts1 - ts0).count(),
+                                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts1).count());
   for (int t = 0; t <= n; t++) {
     for (int i = 0; i < m; i++) { out->alphahat[i + (size_t)m * t] = at[t](i, 0); ok &= std::isfinite(at[t](i, 0)); }
     for (int q = 0; q < m * m; q++) {
